@@ -1,0 +1,118 @@
+/* TEST INFRASTRUCTURE — C API of the CPU oracle (a restatement of the reference's
+ * algorithms for the hot path).  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this library; the product (libvdo_hip.so)
+ * never links or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests/golden vectors and cannot be built
+ * in this environment (OpenCV 3.4 / Eigen3 / CSparse absent), so this
+ * oracle is pinned only by self-consistency KATs (tests/test_oracle_*.py): numeric
+ * Jacobians, SE(3) identities, scipy cross-checks of the normal equations.
+ *
+ * Struct layouts below deliberately equal the ones in include/vdo_slam_hip.h so the
+ * Python tests can hand the same ctypes structures to both libraries.
+ */
+#ifndef VDO_ORACLE_H_
+#define VDO_ORACLE_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Batch dynamic-SLAM factor graph in SoA form (the graph that
+ * Optimizer::FullBatchOptimization / PartialBatchOptimization build,
+ * src/Optimizer.cc:1232-1768 / :42-637).  Poses are g2o::VertexSE3 estimates
+ * (Isometry3) stored as 12 doubles: R row-major (9) then t (3). */
+typedef struct vdo_ba_graph {
+  int32_t n_pose, n_point, n_eb, n_et, n_ep, n_prior;
+  const double* pose;      /* [n_pose][12]  cameras (T_wc) and object motions (H) */
+  const double* point;     /* [n_point][3]  VertexPointXYZ (world)               */
+  /* EdgeSE3PointXYZ (edge_se3_pointxyz.cpp:99-140): z = point in camera frame, info = w*I */
+  const int32_t* eb_pose;  /* [n_eb] */
+  const int32_t* eb_point; /* [n_eb] */
+  const double* eb_z;      /* [3][n_eb] SoA */
+  const double* eb_w;      /* [n_eb] */
+  /* LandmarkMotionTernaryEdge (types_dyn_slam3d.cpp:53-85): e = p1 - H^-1 p2 - z, info = w*I */
+  const int32_t* et_p1;    /* [n_et] */
+  const int32_t* et_p2;    /* [n_et] */
+  const int32_t* et_pose;  /* [n_et] */
+  const double* et_z;      /* [3][n_et] SoA */
+  const double* et_w;      /* [n_et] */
+  /* EdgeSE3 (edge_se3.cpp:77-104): measurement Z (12 doubles), info 6x6 row-major */
+  const int32_t* ep_i;     /* [n_ep] */
+  const int32_t* ep_j;     /* [n_ep] */
+  const double* ep_z;      /* [n_ep][12] */
+  const double* ep_info;   /* [n_ep][36] */
+  /* EdgeSE3Prior (edge_se3_prior.cpp:89-102), offset parameter = identity */
+  const int32_t* pr_pose;  /* [n_prior] */
+  const double* pr_z;      /* [n_prior][12] */
+  const double* pr_info;   /* [n_prior][36] */
+  /* Huber deltas per edge class; <= 0 means no robust kernel.  The prior never has one
+   * (src/Optimizer.cc:1364-1373). */
+  double huber_eb, huber_et, huber_ep;
+} vdo_ba_graph;
+
+/* One linearisation (BlockSolver::buildSystem, block_solver.hpp:502-560) in
+ * block form.  All arrays caller-allocated; any pointer may be NULL to skip. */
+typedef struct vdo_ba_system {
+  double* Hpp;     /* [n_pose][36]  diagonal 6x6 blocks, row-major              */
+  double* bp;      /* [n_pose][6]                                              */
+  double* Hll;     /* [n_point][9]  diagonal 3x3 blocks                         */
+  double* bl;      /* [n_point][3]                                             */
+  double* Hpl_eb;  /* [18][n_eb] SoA: 6x3 block pose x point of each binary edge (row-major index r*3+c) */
+  double* Hll_et;  /* [9][n_et]  SoA: 3x3 block p1 x p2                          */
+  double* Hlp1_et; /* [18][n_et] SoA: 3x6 block p1 x pose                        */
+  double* Hlp2_et; /* [18][n_et] SoA: 3x6 block p2 x pose                        */
+  double* Hpp_ep;  /* [n_ep][36] 6x6 block pose_i x pose_j                       */
+  double chi2;        /* sum of e^T Omega e (activeChi2)                         */
+  double robust_chi2; /* sum of rho(e) (activeRobustChi2, sparse_optimizer.cpp:102-114) */
+} vdo_ba_system;
+
+typedef struct vdo_lm_options {
+  int32_t max_iterations;     /* optimize(n): 300 full batch, 100 partial            */
+  double gain_threshold;      /* SparseOptimizerTerminateAction; <0 = not installed  */
+  int32_t verbose;
+  int32_t solver;             /* product only: 0 auto, 1 dense Cholesky, 2 PCG       */
+  double pcg_tolerance;       /* product only                                        */
+  int32_t pcg_max_iterations; /* product only                                        */
+} vdo_lm_options;
+
+#define VDO_LM_MAX_TRACE 512
+typedef struct vdo_lm_stats {
+  int32_t iterations;          /* outer iterations executed (optimize() return)      */
+  int32_t total_trials;        /* sum of levenberg trials                            */
+  int32_t stop_reason;         /* 0 max_iter,1 LM terminate,2 chi2 increase,3 gain action,4 fail */
+  double initial_chi2, final_chi2, final_lambda;
+  double chi2_trace[VDO_LM_MAX_TRACE];   /* robust chi2 after each outer iteration   */
+  int32_t trials_trace[VDO_LM_MAX_TRACE];
+  double ms_total, ms_linearize, ms_solve;
+} vdo_lm_stats;
+
+int vdo_oracle_ba_linearize(const vdo_ba_graph* g, vdo_ba_system* out);
+/* pose_out [n_pose][12], point_out [n_point][3] */
+int vdo_oracle_ba_optimize(const vdo_ba_graph* g, const vdo_lm_options* opt,
+                           double* pose_out, double* point_out, vdo_lm_stats* stats);
+/* Assemble the full normal equations as COO (upper triangle incl. diagonal) for the
+ * scipy cross-check.  Order of unknowns: points (3 each) first, then poses (6 each).
+ * Returns nnz written (or needed when rows==NULL). */
+int64_t vdo_oracle_ba_normal_equations(const vdo_ba_graph* g, int32_t* rows, int32_t* cols,
+                                       double* vals, int64_t cap, double* rhs);
+/* Solve the normal equations (H + lambda I) x = b with the oracle's sparse Cholesky. */
+int vdo_oracle_ba_solve(const vdo_ba_graph* g, double lambda, double* x);
+
+/* ---- SE(3) helpers exposed for KATs --------------------------------------------*/
+void vdo_oracle_se3_exp(const double u[6], double T16[16]);            /* SE3Quat::exp */
+void vdo_oracle_iso_oplus(const double T12[12], const double d[6], double out12[12]); /* VertexSE3::oplusImpl */
+void vdo_oracle_iso_to_mqt(const double T12[12], double e[6]);         /* toVectorMQT   */
+void vdo_oracle_edge_se3_jac(const double Z12[12], const double Xi12[12], const double Xj12[12],
+                             double e[6], double Ji[36], double Jj[36]);
+void vdo_oracle_edge_prior_jac(const double Z12[12], const double X12[12], double e[6], double J[36]);
+void vdo_oracle_edge_eb_jac(const double X12[12], const double p[3], const double z[3],
+                            double e[3], double Jpose[18], double Jpoint[9]);
+void vdo_oracle_edge_et_jac(const double H12[12], const double p1[3], const double p2[3], const double z[3],
+                            double e[3], double Jp1[9], double Jp2[9], double Jh[18]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
