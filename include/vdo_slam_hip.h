@@ -1,0 +1,149 @@
+/* vdo_slam_hip.h — C-ABI of libvdo_hip.so: the MI355X (gfx950) hot path of VDO-SLAM.
+ *
+ * The reference (halajun/VDO_SLAM) has no FFI/plugin boundary: its hot path sits behind
+ * C++ class signatures in libObjSLAM.so.  This header is the one boundary
+ * the new build introduces: host C++ that keeps the reference's class API
+ * (vdo_slam_amd/host/: ORBextractor, Frame, Tracking, Optimizer, System) calls these
+ * entry points; nothing else does.  Conventions:
+ *   - every function returns int: 0 = ok, <0 = vdo_status error; never throws, never aborts
+ *     (vdo_last_error() gives a thread-local message);
+ *   - plain pointers + explicit sizes, no C++/torch types;
+ *   - all device work is stream-ordered on the context's hipStream_t (which may be an
+ *     externally owned stream, e.g. torch's current stream), so callers can bracket calls
+ *     with their own events;
+ *   - fp64 for everything the reference computes in g2o (number_t = double,
+ *     dependencies/g2o/config.h:14-29), fp32/u8/i32 for image-side data (cv::Mat types).
+ * There is no CPU fallback: without a HIP device every compute entry point returns
+ * VDO_ERR_NO_DEVICE.
+ */
+#ifndef VDO_SLAM_HIP_H_
+#define VDO_SLAM_HIP_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum vdo_status {
+  VDO_OK = 0,
+  VDO_ERR_INVALID = -1,     /* bad argument / malformed graph                         */
+  VDO_ERR_NO_DEVICE = -2,   /* no HIP device / HIP runtime failure                    */
+  VDO_ERR_OOM = -3,
+  VDO_ERR_UNSUPPORTED = -4, /* structurally valid input outside the supported envelope */
+  VDO_ERR_INTERNAL = -5
+} vdo_status;
+
+int vdo_version(void);               /* 100*major + minor */
+const char* vdo_last_error(void);    /* thread-local, never NULL */
+
+/* ---- context ---------------------------------------------------------------------------*/
+typedef struct vdo_ctx vdo_ctx;
+/* stream == NULL: the context creates (and owns) a non-blocking stream on `device`. */
+int vdo_ctx_create(int device, void* hip_stream, vdo_ctx** out);
+int vdo_ctx_destroy(vdo_ctx* ctx);
+int vdo_ctx_synchronize(vdo_ctx* ctx);
+
+/* ---- batch dynamic bundle adjustment ------------------------------------------------------
+ * Replaces the g2o calls inside Optimizer::FullBatchOptimization (reference
+ * src/Optimizer.cc:1232-2175: graph at :1355-1766, optimize(300) at :1935) and
+ * Optimizer::PartialBatchOptimization (:42-1230, optimize(100) at :807): i.e.
+ * SparseOptimizer::initializeOptimization/optimize (g2o/core/sparse_optimizer.cpp:205-267,
+ * 354-443), OptimizationAlgorithmLevenberg::solve (g2o/core/optimization_algorithm_levenberg.cpp:61-164),
+ * BlockSolver::buildSystem (g2o/core/block_solver.hpp:502-560) and the linear solve
+ * (g2o/solvers/linear_solver_csparse.h:108-144).
+ *
+ * Graph in SoA form.  Poses = g2o::VertexSE3 estimates (Isometry3) as 12 doubles:
+ * R row-major (9) then t (3).  For bandwidth the binary edges should be sorted by eb_pose
+ * and the ternary edges by et_pose (the reference inserts them frame by frame, which already
+ * is camera-major); correctness does not depend on the order.
+ * Structural requirement (checked): a point is p1 of at most one and p2 of at most one
+ * ternary edge (dynamic tracks are chains, src/Optimizer.cc:1704-1741). */
+typedef struct vdo_ba_graph {
+  int32_t n_pose, n_point, n_eb, n_et, n_ep, n_prior;
+  const double* pose;      /* [n_pose][12]  cameras (T_wc) and object motions (H)        */
+  const double* point;     /* [n_point][3]  VertexPointXYZ (world)                       */
+  /* EdgeSE3PointXYZ (g2o/types/edge_se3_pointxyz.cpp:99-140), information = w * I3 */
+  const int32_t* eb_pose;  /* [n_eb] */
+  const int32_t* eb_point; /* [n_eb] */
+  const double* eb_z;      /* [3][n_eb] SoA: measured point in the camera frame           */
+  const double* eb_w;      /* [n_eb] */
+  /* LandmarkMotionTernaryEdge (g2o/types/types_dyn_slam3d.cpp:53-85), information = w * I3 */
+  const int32_t* et_p1;    /* [n_et] point at frame k-1 */
+  const int32_t* et_p2;    /* [n_et] point at frame k   */
+  const int32_t* et_pose;  /* [n_et] motion vertex H    */
+  const double* et_z;      /* [3][n_et] SoA measurement (zero in the reference)           */
+  const double* et_w;      /* [n_et] */
+  /* EdgeSE3 (g2o/types/edge_se3.cpp:77-104): odometry + motion smoothness */
+  const int32_t* ep_i;     /* [n_ep] */
+  const int32_t* ep_j;     /* [n_ep] */
+  const double* ep_z;      /* [n_ep][12] measurement */
+  const double* ep_info;   /* [n_ep][36] information, row-major */
+  /* EdgeSE3Prior (g2o/types/edge_se3_prior.cpp:89-102), ParameterSE3Offset = identity */
+  const int32_t* pr_pose;  /* [n_prior] */
+  const double* pr_z;      /* [n_prior][12] */
+  const double* pr_info;   /* [n_prior][36] */
+  /* RobustKernelHuber delta per edge class (<=0: none); the prior has no kernel
+   * (src/Optimizer.cc:1364-1373).  NB the reference keeps delta^2 in a float
+   * (g2o/core/robust_kernel_impl.h:84); reproduced. */
+  double huber_eb, huber_et, huber_ep;
+} vdo_ba_graph;
+
+/* One linearisation in block form (what BlockSolver::buildSystem leaves in Hpp/Hpl/Hll/b).
+ * Host arrays, caller-allocated; NULL pointers are skipped. */
+typedef struct vdo_ba_system {
+  double* Hpp;     /* [n_pose][36]  diagonal blocks, row-major                           */
+  double* bp;      /* [n_pose][6]                                                       */
+  double* Hll;     /* [n_point][9]                                                      */
+  double* bl;      /* [n_point][3]                                                      */
+  double* Hpl_eb;  /* [18][n_eb] SoA 6x3 block (pose x point) of each binary edge (index r*3+c) */
+  double* Hll_et;  /* [9][n_et]  SoA 3x3 block p1 x p2                                    */
+  double* Hlp1_et; /* [18][n_et] SoA 3x6 block p1 x pose                                  */
+  double* Hlp2_et; /* [18][n_et] SoA 3x6 block p2 x pose                                  */
+  double* Hpp_ep;  /* [n_ep][36] 6x6 block pose_i x pose_j                                */
+  double chi2;        /* activeChi2 */
+  double robust_chi2; /* activeRobustChi2 (g2o/core/sparse_optimizer.cpp:102-114) */
+} vdo_ba_system;
+
+typedef struct vdo_lm_options {
+  int32_t max_iterations;     /* SparseOptimizer::optimize(n): 300 full batch, 100 partial */
+  double gain_threshold;      /* SparseOptimizerTerminateAction::setGainThreshold; <0 = not installed */
+  int32_t verbose;
+  int32_t solver;             /* 0 auto, 2 Schur + block-Jacobi PCG                        */
+  double pcg_tolerance;       /* relative residual ||r||_M / ||b||_M; <=0 -> 1e-10          */
+  int32_t pcg_max_iterations; /* <=0 -> 4 * (6 n_pose) capped at 20000                     */
+} vdo_lm_options;
+
+#define VDO_LM_MAX_TRACE 512
+typedef struct vdo_lm_stats {
+  int32_t iterations;          /* outer iterations executed (return value of optimize())   */
+  int32_t total_trials;        /* levenberg trials summed over iterations                  */
+  int32_t stop_reason;         /* 0 max_iter, 1 LM terminate, 2 chi2 increase, 3 gain action, 4 fail */
+  double initial_chi2, final_chi2, final_lambda;
+  double chi2_trace[VDO_LM_MAX_TRACE];
+  int32_t trials_trace[VDO_LM_MAX_TRACE];
+  double ms_total, ms_linearize, ms_solve;
+} vdo_lm_stats;
+
+typedef struct vdo_ba vdo_ba;
+/* Uploads the graph to HBM (SoA, resident until destroy) and builds the chain structure. */
+int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out);
+int vdo_ba_destroy(vdo_ba* ba);
+/* K18: `repeat` back-to-back linearisation sweeps (errors + Jacobians + Huber + block
+ * accumulation) at the current estimate.  If ms_sweep != NULL it receives the mean
+ * duration of ONE binary-edge sweep kernel measured with hipEvents on the ctx stream. */
+int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep);
+int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out);
+/* Full Levenberg–Marquardt (control flow identical to the modified g2o). */
+int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_stats* stats);
+int vdo_ba_get_estimates(vdo_ba* ba, double* pose_out /*[n_pose][12]*/, double* point_out /*[n_point][3]*/);
+int vdo_ba_set_estimates(vdo_ba* ba, const double* pose, const double* point);
+/* Multi-GPU (edge/landmark shards): every rank owns a shard of the points with
+ * all their edges and a replica of the poses; `fn` must sum `count` doubles at device pointer
+ * `buf` across ranks (e.g. torch.distributed.all_reduce over RCCL) on the ctx stream. */
+typedef int (*vdo_allreduce_fn)(void* user, void* device_buf, int64_t count);
+int vdo_ba_set_allreduce(vdo_ba* ba, vdo_allreduce_fn fn, void* user);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VDO_SLAM_HIP_H_ */

@@ -1,0 +1,80 @@
+"""Host-side handle for the batch bundle-adjustment path (thin ctypes mirror of the C-ABI).
+
+Mirrors the role of ``Optimizer::FullBatchOptimization`` / ``PartialBatchOptimization``
+(reference src/Optimizer.cc:1232-2175, 42-1230): a graph goes in, refined camera poses /
+object motions / points come out.  All compute happens in libvdo_hip.so on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+
+
+class Context:
+    def __init__(self, device: int = 0, stream: int | None = None):
+        self._h = C.c_void_p()
+        K.check(K.lib().vdo_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        self.device = device
+
+    def synchronize(self):
+        K.check(K.lib().vdo_ctx_synchronize(self._h))
+
+    def close(self):
+        if self._h:
+            K.lib().vdo_ctx_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BatchBA:
+    def __init__(self, ctx: Context, graph):
+        self.ctx = ctx
+        self.graph = graph
+        self._gc, self._keep = K.graph_to_c(graph)
+        self._h = C.c_void_p()
+        K.check(K.lib().vdo_ba_create(ctx._h, C.byref(self._gc), C.byref(self._h)))
+
+    def linearize(self, repeat: int = 1, timed: bool = False):
+        """Run the linearisation sweep; with ``timed`` returns the mean ms of the K18 kernel."""
+        ms = C.c_float(0.0)
+        K.check(K.lib().vdo_ba_linearize(self._h, repeat, C.byref(ms) if timed else None))
+        return ms.value if timed else None
+
+    def system(self) -> K.BASystem:
+        S = K.BASystem(self.graph)
+        K.check(K.lib().vdo_ba_download_system(self._h, C.byref(S.c)))
+        return S
+
+    def optimize(self, max_iterations=300, gain_threshold=1e-4, verbose=0, pcg_tolerance=0.0, pcg_max_iterations=0):
+        opt = K.LMOptionsC(max_iterations, gain_threshold, verbose, 0, pcg_tolerance, pcg_max_iterations)
+        st = K.LMStatsC()
+        K.check(K.lib().vdo_ba_optimize(self._h, C.byref(opt), C.byref(st)))
+        return st
+
+    def estimates(self):
+        pose = np.zeros((self.graph.n_pose, 12)); point = np.zeros((self.graph.n_point, 3))
+        K.check(K.lib().vdo_ba_get_estimates(self._h, K._dp(pose), K._dp(point)))
+        return pose, point
+
+    def set_estimates(self, pose, point):
+        pose = np.ascontiguousarray(pose, dtype=np.float64); point = np.ascontiguousarray(point, dtype=np.float64)
+        K.check(K.lib().vdo_ba_set_estimates(self._h, K._dp(pose), K._dp(point)))
+
+    def close(self):
+        if self._h:
+            K.lib().vdo_ba_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

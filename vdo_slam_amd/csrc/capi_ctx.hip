@@ -1,0 +1,64 @@
+// Context management and error reporting of the C-ABI (include/vdo_slam_hip.h).
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/vdo_slam_hip.h"
+#include "ctx.hpp"
+
+namespace {
+thread_local char g_err[512] = "";
+}
+
+namespace vdo {
+int set_error(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  std::vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+int ctx_bind(vdo_ctx* ctx) {
+  if (!ctx) return set_error(VDO_ERR_INVALID, "null context");
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "hipSetDevice(%d): %s", ctx->device, hipGetErrorString(e));
+  return VDO_OK;
+}
+}  // namespace vdo
+
+extern "C" int vdo_version(void) { return 1; }
+extern "C" const char* vdo_last_error(void) { return g_err; }
+
+extern "C" int vdo_ctx_create(int device, void* hip_stream, vdo_ctx** out) {
+  if (!out) return vdo::set_error(VDO_ERR_INVALID, "vdo_ctx_create: null out");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return vdo::set_error(VDO_ERR_NO_DEVICE, "no HIP device available (%s); libvdo_hip has no CPU fallback",
+                          e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return vdo::set_error(VDO_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+  vdo_ctx* c = new vdo_ctx();
+  c->device = device;
+  if (hipSetDevice(device) != hipSuccess) { delete c; return vdo::set_error(VDO_ERR_NO_DEVICE, "hipSetDevice failed"); }
+  if (hip_stream) { c->stream = (hipStream_t)hip_stream; c->owns_stream = false; }
+  else {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return vdo::set_error(VDO_ERR_NO_DEVICE, "hipStreamCreate failed"); }
+    c->owns_stream = true;
+  }
+  *out = c;
+  return VDO_OK;
+}
+
+extern "C" int vdo_ctx_destroy(vdo_ctx* ctx) {
+  if (!ctx) return VDO_OK;
+  if (ctx->owns_stream && ctx->stream) { hipSetDevice(ctx->device); hipStreamDestroy(ctx->stream); }
+  delete ctx;
+  return VDO_OK;
+}
+
+extern "C" int vdo_ctx_synchronize(vdo_ctx* ctx) {
+  int rc = vdo::ctx_bind(ctx);
+  if (rc != VDO_OK) return rc;
+  hipError_t e = hipStreamSynchronize(ctx->stream);
+  if (e != hipSuccess) return vdo::set_error(VDO_ERR_NO_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(e));
+  return VDO_OK;
+}

@@ -1,0 +1,16 @@
+// Context + error plumbing shared by the C-ABI translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+struct vdo_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool owns_stream = false;
+};
+
+namespace vdo {
+// Stores a thread-local message for vdo_last_error() and returns `code`.
+int set_error(int code, const char* fmt, ...) __attribute__((format(printf, 2, 3)));
+// hipSetDevice(ctx->device); returns VDO_ERR_NO_DEVICE on failure.
+int ctx_bind(vdo_ctx* ctx);
+}  // namespace vdo

@@ -1,0 +1,151 @@
+// Device-side SE(3) / small-matrix algebra for the gfx950 kernels (fp64, all in VGPRs).
+// Semantics follow the reference's g2o + Eigen code paths; each function cites what it mirrors.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define VDO_HD __host__ __device__ __forceinline__
+
+namespace vdo {
+
+struct D3 { double x, y, z; };
+VDO_HD D3 operator+(D3 a, D3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+VDO_HD D3 operator-(D3 a, D3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+VDO_HD D3 operator*(double s, D3 a) { return {s * a.x, s * a.y, s * a.z}; }
+
+// Isometry3 as R (row-major) | t.
+struct IsoD {
+  double r[9];
+  D3 t;
+};
+
+VDO_HD IsoD iso_load(const double* __restrict__ p) {
+  IsoD a;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) a.r[i] = p[i];
+  a.t = {p[9], p[10], p[11]};
+  return a;
+}
+VDO_HD void iso_store(double* p, const IsoD& a) {
+#pragma unroll
+  for (int i = 0; i < 9; ++i) p[i] = a.r[i];
+  p[9] = a.t.x; p[10] = a.t.y; p[11] = a.t.z;
+}
+VDO_HD D3 rot(const double* r, D3 v) {
+  return {r[0] * v.x + r[1] * v.y + r[2] * v.z, r[3] * v.x + r[4] * v.y + r[5] * v.z, r[6] * v.x + r[7] * v.y + r[8] * v.z};
+}
+VDO_HD D3 rotT(const double* r, D3 v) {
+  return {r[0] * v.x + r[3] * v.y + r[6] * v.z, r[1] * v.x + r[4] * v.y + r[7] * v.z, r[2] * v.x + r[5] * v.y + r[8] * v.z};
+}
+// Transform::inverse(Isometry): R^T, -(R^T t)
+VDO_HD IsoD iso_inv(const IsoD& a) {
+  IsoD o;
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o.r[3 * i + j] = a.r[3 * j + i];
+  D3 v = rot(o.r, a.t);
+  o.t = {-v.x, -v.y, -v.z};
+  return o;
+}
+VDO_HD void mat3_mul(const double* a, const double* b, double* o) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) o[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+VDO_HD IsoD iso_mul(const IsoD& a, const IsoD& b) {
+  IsoD o;
+  mat3_mul(a.r, b.r, o.r);
+  o.t = rot(a.r, b.t) + a.t;
+  return o;
+}
+VDO_HD D3 iso_apply(const IsoD& a, D3 p) { return rot(a.r, p) + a.t; }
+
+// Eigen Quaterniond(Matrix3d) followed by normalisation and sign fix (w >= 0):
+// internal::toCompactQuaternion (g2o/types/isometry3d_mappings.cpp:75-80).
+VDO_HD D3 compact_quat(const double* m) {
+  double qx, qy, qz, qw;
+  double t = m[0] + m[4] + m[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0);
+    qw = 0.5 * t;
+    t = 0.5 / t;
+    qx = (m[7] - m[5]) * t; qy = (m[2] - m[6]) * t; qz = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[4 * i]) i = 2;
+    int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+    double c[3];
+    c[i] = 0.5 * t;
+    t = 0.5 / t;
+    qw = (m[3 * k + j] - m[3 * j + k]) * t;
+    c[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+    c[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    qx = c[0]; qy = c[1]; qz = c[2];
+  }
+  double n = sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
+  qx /= n; qy /= n; qz /= n; qw /= n;
+  if (qw < 0) { qx = -qx; qy = -qy; qz = -qz; }
+  return {qx, qy, qz};
+}
+
+// Eigen Quaterniond::toRotationMatrix
+VDO_HD void quat_to_mat(double x, double y, double z, double w, double* r) {
+  const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
+  const double twx = tx * w, twy = ty * w, twz = tz * w;
+  const double txx = tx * x, txy = ty * x, txz = tz * x;
+  const double tyy = ty * y, tyz = tz * y, tzz = tz * z;
+  r[0] = 1 - (tyy + tzz); r[1] = txy - twz; r[2] = txz + twy;
+  r[3] = txy + twz; r[4] = 1 - (txx + tzz); r[5] = tyz - twx;
+  r[6] = txz - twy; r[7] = tyz + twx; r[8] = 1 - (txx + tyy);
+}
+
+// VertexSE3::oplusImpl (g2o/types/vertex_se3.h:105-114): X <- X * fromVectorMQT(d);
+// fromCompactQuaternion (isometry3d_mappings.cpp:82-89) returns identity when |q|>1.
+// `ortho`: apply approximateNearestOrthogonalMatrix (every 1001st call).
+VDO_HD IsoD iso_oplus(const IsoD& X, const double* d, bool ortho) {
+  IsoD inc;
+  double w = 1 - (d[3] * d[3] + d[4] * d[4] + d[5] * d[5]);
+  if (w < 0) {
+    inc.r[0] = 1; inc.r[1] = 0; inc.r[2] = 0; inc.r[3] = 0; inc.r[4] = 1; inc.r[5] = 0; inc.r[6] = 0; inc.r[7] = 0; inc.r[8] = 1;
+  } else {
+    quat_to_mat(d[3], d[4], d[5], sqrt(w), inc.r);
+  }
+  inc.t = {d[0], d[1], d[2]};
+  IsoD o = iso_mul(X, inc);
+  if (ortho) {  // R -= 0.5 R (R^T R - I)   (isometry3d_mappings.h approximateNearestOrthogonalMatrix)
+    double E[9], RE[9];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) E[3 * i + j] = o.r[i] * o.r[j] + o.r[3 + i] * o.r[3 + j] + o.r[6 + i] * o.r[6 + j] - (i == j ? 1.0 : 0.0);
+    mat3_mul(o.r, E, RE);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o.r[i] -= 0.5 * RE[i];
+  }
+  return o;
+}
+
+// RobustKernelHuber::robustify (g2o/core/robust_kernel_impl.cpp:78-91); dsqr already rounded
+// through float on the host (robust_kernel_impl.h:84).  delta <= 0 -> no kernel.
+VDO_HD void huber(double e, double delta, double dsqr, double& rho0, double& rho1) {
+  if (delta <= 0 || e <= dsqr) { rho0 = e; rho1 = 1.0; }
+  else { double s = sqrt(e); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
+}
+
+// 3x3 symmetric positive definite inverse via cofactors (Eigen fixed-size inverse); returns det
+VDO_HD double sym3_inv(const double* a, double* o) {
+  double c00 = a[4] * a[8] - a[5] * a[7];
+  double c01 = a[5] * a[6] - a[3] * a[8];
+  double c02 = a[3] * a[7] - a[4] * a[6];
+  double det = a[0] * c00 + a[1] * c01 + a[2] * c02;
+  double id = 1.0 / det;
+  o[0] = c00 * id; o[1] = (a[2] * a[7] - a[1] * a[8]) * id; o[2] = (a[1] * a[5] - a[2] * a[4]) * id;
+  o[3] = c01 * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+  o[6] = c02 * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+  return det;
+}
+
+}  // namespace vdo
