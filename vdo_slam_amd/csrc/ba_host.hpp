@@ -1,0 +1,34 @@
+// Host-side handle of one batch-BA problem (shared by capi_ba.hip and ba_lm.hip).
+#pragma once
+#include <vector>
+
+#include "../../include/vdo_slam_hip.h"
+#include "ba_dev.hpp"
+#include "ctx.hpp"
+
+struct vdo_ba {
+  vdo_ctx* ctx = nullptr;
+  vdo::BADev d;
+  std::vector<void*> allocs;
+  vdo_allreduce_fn allreduce = nullptr;
+  void* allreduce_user = nullptr;
+  int oplus_calls = 0;            // VertexSE3::_numOplusCalls (same value on every vertex)
+  double* h_scal = nullptr;       // pinned
+  int32_t* h_flags = nullptr;     // pinned
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  // permutations between the caller's numbering and the tile-major device numbering
+  std::vector<int32_t> pt_old_of_new, pt_new_of_old;
+  std::vector<int32_t> eb_old_of_new, et_old_of_new;
+  std::vector<int32_t> inc_of_eb, inc1_of_et, inc2_of_et;   // by NEW edge index
+  std::vector<double> h_tmp;
+};
+
+namespace vdo {
+inline int sync_check(vdo_ba* ba, const char* what) {
+  hipError_t e = hipStreamSynchronize(ba->ctx->stream);
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
+  e = hipGetLastError();
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
+  return VDO_OK;
+}
+}  // namespace vdo

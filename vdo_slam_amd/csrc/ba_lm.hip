@@ -1,0 +1,165 @@
+// Host-side Levenberg–Marquardt driver of the batch-BA path (C-ABI: vdo_ba_optimize).
+// The control flow restates the *modified* g2o of the reference:
+//   SparseOptimizer::optimize            g2o/core/sparse_optimizer.cpp:354-443 (incl. :393-396 chi2 abort)
+//   OptimizationAlgorithmLevenberg::solve g2o/core/optimization_algorithm_levenberg.cpp:61-164 (incl. _nBad rule :154-161)
+//   SparseOptimizerTerminateAction        g2o/core/sparse_optimizer_terminate_action.cpp:49-85
+// All heavy work is HIP kernels (ba_sweep.hip, ba_solve.hip); the host only sequences
+// launches and reads back a handful of scalars per Levenberg trial.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <limits>
+
+#include "ba_host.hpp"
+
+using namespace vdo;
+
+namespace {
+double now_ms() {
+  using namespace std::chrono;
+  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
+}
+}  // namespace
+
+namespace {
+
+// read back device scalars + flags (one sync)
+int fetch(vdo_ba* ba) {
+  hipStream_t s = ba->ctx->stream;
+  hipMemcpyAsync(ba->h_scal, ba->d.scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s);
+  hipMemcpyAsync(ba->h_flags, ba->d.flags, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, s);
+  return sync_check(ba, "LM scalar readback");
+}
+
+// computeActiveErrors + activeRobustChi2 at estimate[which]
+int robust_chi2(vdo_ba* ba, int which, double* out) {
+  launch_errors(ba->d, which, ba->ctx->stream);
+  int rc = fetch(ba);
+  if (rc != VDO_OK) return rc;
+  *out = ba->h_scal[S_RCHI2];
+  return VDO_OK;
+}
+
+// (H + lambda I) x = b  ->  xp/xl on device.  ok=false mirrors a failed Cholesky.
+int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, int* pcg_iters) {
+  const BADev& d = ba->d;
+  hipStream_t s = ba->ctx->stream;
+  launch_factor(d, lambda, s);
+  launch_reduced_rhs(d, s);
+  launch_pcg_init(d, s);
+  double tol = opt->pcg_tolerance > 0 ? opt->pcg_tolerance : 1e-10;
+  int maxit = opt->pcg_max_iterations > 0 ? opt->pcg_max_iterations : std::min(20000, 24 * d.P + 200);
+  const double tol2 = tol * tol;
+  int it = 0;
+  *ok = true;
+  while (it < maxit) {
+    const int batch = std::min(16, maxit - it);
+    for (int k = 0; k < batch; ++k) launch_pcg_iter(d, lambda, tol2, s);
+    it += batch;
+    int rc = fetch(ba);
+    if (rc != VDO_OK) return rc;
+    if (ba->h_flags[0]) { *ok = false; break; }
+    if (ba->h_flags[1] == 1) break;
+    if (ba->h_flags[1] == 2) { *ok = false; break; }
+  }
+  *pcg_iters = ba->h_flags[2];
+  return VDO_OK;
+}
+
+}  // namespace
+
+extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_stats* st) {
+  if (!ba || !opt) return set_error(VDO_ERR_INVALID, "null argument");
+  int rc = ctx_bind(ba->ctx);
+  if (rc != VDO_OK) return rc;
+  vdo_lm_stats local;
+  if (!st) st = &local;
+  std::memset(st, 0, sizeof(*st));
+  BADev& d = ba->d;
+  hipStream_t s = ba->ctx->stream;
+  const double t_begin = now_ms();
+  double lambda = -1, ni = 2;
+  int nBad = 0;
+  const double tau = 1e-5, upper = 2. / 3., lower = 1. / 3.;
+  const int maxTrials = 10;
+  bool forceStop = false, ok = true;
+  double action_lastChi = 0, chi2_check = 0, last_err_chi = 0;
+#define CK(x) do { rc = (x); if (rc != VDO_OK) return rc; } while (0)
+  CK(robust_chi2(ba, 0, &last_err_chi));
+  st->initial_chi2 = last_err_chi;
+  int it = 0;
+  for (; it < opt->max_iterations && !forceStop && ok; ++it) {
+    double t0 = now_ms();
+    launch_linearize(d, s);                 // errors + buildSystem in one sweep (same estimate)
+    if (it == 0) launch_max_diag(d, s);
+    CK(fetch(ba));
+    st->ms_linearize += now_ms() - t0;
+    last_err_chi = ba->h_scal[S_RCHI2];
+    double currentChi = last_err_chi, tempChi = currentChi;
+    const double iniChi = currentChi;
+    if (it == 0) { lambda = tau * ba->h_scal[S_MAXDIAG]; ni = 2; nBad = 0; }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      t0 = now_ms();
+      bool ok2 = true;
+      int pcg_it = 0;
+      CK(solve_trial(ba, lambda, opt, &ok2, &pcg_it));
+      const bool ortho = (++ba->oplus_calls > 1000);
+      if (ortho) ba->oplus_calls = 0;
+      launch_backsub_update(d, lambda, ortho, s);      // update() into the trial buffers (push/pop = keep [0])
+      launch_errors(d, 1, s);
+      CK(fetch(ba));
+      st->ms_solve += now_ms() - t0;
+      last_err_chi = tempChi = ba->h_scal[S_RCHI2];
+      if (!ok2) tempChi = std::numeric_limits<double>::max();
+      rho = currentChi - tempChi;
+      double scale = ba->h_scal[S_SCALE] + 1e-3;
+      rho /= scale;
+      if (opt->verbose > 1)
+        std::fprintf(stderr, "  trial %d lambda=%.4g pcg=%d chi2 %.9g -> %.9g rho=%.4g\n", qmax, lambda, pcg_it, currentChi, tempChi, rho);
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, upper);
+        const double sf = std::max(lower, alpha);
+        lambda *= sf; ni = 2; currentChi = tempChi;
+        std::swap(d.pose[0], d.pose[1]);               // discardTop(): accept the trial
+        std::swap(d.point[0], d.point[1]);
+      } else {
+        lambda *= ni; ni *= 2;                          // pop(): estimate[0] untouched
+      }
+      ++qmax;
+      ++st->total_trials;
+    } while (rho < 0 && qmax < maxTrials && !forceStop);
+    int result;
+    if (qmax == maxTrials || rho == 0) result = 1;
+    else {
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+      result = nBad >= 3 ? 1 : 0;
+    }
+    ok = (result == 0);
+    if (!ok && st->stop_reason == 0) st->stop_reason = 1;
+    if (chi2_check < last_err_chi && it > 0) { ok = false; st->stop_reason = 2; }
+    chi2_check = last_err_chi;
+    if (opt->verbose || opt->gain_threshold >= 0) CK(robust_chi2(ba, 0, &last_err_chi));
+    if (opt->verbose)
+      std::fprintf(stderr, "iteration= %d\t chi2= %.6f\t lambda= %.6g\t levenbergIter= %d\n", it, last_err_chi, lambda, qmax);
+    if (it < VDO_LM_MAX_TRACE) { st->chi2_trace[it] = last_err_chi; st->trials_trace[it] = qmax; }
+    if (opt->gain_threshold >= 0) {
+      if (it == 0) action_lastChi = last_err_chi;
+      else {
+        const double gain = (action_lastChi - last_err_chi) / last_err_chi;
+        action_lastChi = last_err_chi;
+        if (gain >= 0 && gain < opt->gain_threshold) { forceStop = true; if (ok) st->stop_reason = 3; }
+      }
+    }
+  }
+  st->iterations = it;
+  st->final_lambda = lambda;
+  CK(robust_chi2(ba, 0, &st->final_chi2));
+  st->ms_total = now_ms() - t_begin;
+#undef CK
+  return VDO_OK;
+}

@@ -4,95 +4,58 @@
 // part is eliminated first — block-diagonal for static points, block-tridiagonal along each
 // dynamic track (the ternary edge couples consecutive observations, src/Optimizer.cc:1704-1741)
 // — and the reduced pose/motion system S = Hpp - Hpl Hll^-1 Hlp is solved matrix-free with
-// block-Jacobi preconditioned conjugate gradients.  x is identical to the direct solve up to
-// the PCG tolerance.
+// conjugate gradients preconditioned by the exact 6x6 diagonal blocks of S.  x equals the
+// direct solve up to the PCG tolerance.
+//
+// One workgroup per TILE for everything that touches landmarks (ba_dev.hpp): each thread keeps
+// its <=3 incidence blocks (6x3) in registers, B^T v accumulates per point in LDS, the chain
+// solves run in LDS, and B w is segment-reduced per pose slot -> the 6x3 blocks are read from
+// HBM exactly once per CG iteration and there are no global atomics.
 #include "ba_dev.hpp"
+#include "ba_tile.hpp"
 #include "se3_dev.hpp"
 
 namespace vdo {
-
-__device__ __forceinline__ double wave_sum2(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-  return v;
-}
-// block-wide sum for up to 1024 threads; result broadcast to all threads
-__device__ double block_sum1(double v, double* lds /*[17]*/) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  v = wave_sum2(v);
-  __syncthreads();
-  if (lane == 0) lds[wv] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0;
-    for (int w = 0; w < nw; ++w) s += lds[w];
-    lds[16] = s;
-  }
-  __syncthreads();
-  return lds[16];
-}
-__device__ double block_max1(double v, double* lds) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_down(v, off, 64));
-  __syncthreads();
-  if (lane == 0) lds[wv] = v;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double s = 0;
-    for (int w = 0; w < nw; ++w) s = fmax(s, lds[w]);
-    lds[16] = s;
-  }
-  __syncthreads();
-  return lds[16];
-}
 
 // computeLambdaInit (g2o/core/optimization_algorithm_levenberg.cpp:166-180): max |H(j,j)|
 __global__ __launch_bounds__(1024) void k_max_diag(BADev d) {
   __shared__ double lds[17];
   double m = 0;
-  for (int64_t i = threadIdx.x; i < 6 * (int64_t)d.P; i += blockDim.x) {
-    const int64_t p = i / 6, j = i % 6;
-    m = fmax(m, fabs(d.Hpp[36 * p + 7 * j]));
-  }
-  for (int64_t i = threadIdx.x; i < 3 * (int64_t)d.L; i += blockDim.x) {
-    const int64_t l = i / 3, j = i % 3;
-    m = fmax(m, fabs(d.Hll[9 * l + 4 * j]));
-  }
+  for (int64_t i = threadIdx.x; i < 6 * (int64_t)d.P; i += blockDim.x) m = fmax(m, fabs(d.Hpp[36 * (i / 6) + 7 * (i % 6)]));
+  for (int64_t i = threadIdx.x; i < 3 * (int64_t)d.L; i += blockDim.x) m = fmax(m, fabs(d.Hll[9 * (i / 3) + 4 * (i % 3)]));
   m = block_max1(m, lds);
   if (threadIdx.x == 0) d.scal[S_MAXDIAG] = m;
 }
 
-// 3x3 SPD inverse with positive-definiteness test (leading minors).
 __device__ __forceinline__ bool spd3_inv(const double* a, double* o) {
   const double det = sym3_inv(a, o);
   const double m2 = a[0] * a[4] - a[1] * a[3];
   return (a[0] > 0) && (m2 > 0) && (det > 0);
 }
 
-// Block LDL^T along every landmark chain: Delta_k = D_k + lambda I - O^T Delta_{k-1}^-1 O.
+// Per landmark chain: block LDL^T (Delta_k = D_k + lambda I - O^T Delta_{k-1}^-1 O) and the
+// diagonal / first off-diagonal blocks of Hll^-1 needed by the exact block-Jacobi preconditioner:
+//   G_kk = Delta_k^-1 + Gl_{k+1} G_{k+1,k+1} Gl_{k+1}^T ,  G_{k,k+1} = -Gl_{k+1} G_{k+1,k+1}
 __global__ void k_factor_chains(BADev d, double lambda) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.n_chains) return;
-  const int off = d.chain_off[c], m = d.chain_off[c + 1] - off;
+  const int64_t p0 = d.chain_off[c], p1 = d.chain_off[c + 1];
   double prev[9];
   bool ok = true;
   const int64_t Et = d.Et;
-  for (int k = 0; k < m; ++k) {
-    const int64_t l = d.chain_pt[off + k];
+  for (int64_t l = p0; l < p1; ++l) {
     double D[9];
 #pragma unroll
     for (int i = 0; i < 9; ++i) D[i] = d.Hll[9 * l + i];
     D[0] += lambda; D[4] += lambda; D[8] += lambda;
-    if (k > 0) {
-      const int64_t e = d.chain_edge[off + k - 1];
+    if (l > p0) {
+      const int64_t e = d.pt_prev_edge[l];
       double O[9], G[9];
 #pragma unroll
       for (int i = 0; i < 9; ++i) O[i] = d.Oll[i * Et + e];
       mat3_mul(prev, O, G);
 #pragma unroll
       for (int i = 0; i < 9; ++i) d.Gl[9 * l + i] = G[i];
-      // D -= O^T G
 #pragma unroll
       for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -102,36 +65,25 @@ __global__ void k_factor_chains(BADev d, double lambda) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) d.Dinv[9 * l + i] = prev[i];
   }
+  // backward: inverse blocks
+  double Gn[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { Gn[i] = prev[i]; d.Gdiag[9 * (p1 - 1) + i] = prev[i]; }
+  for (int64_t l = p1 - 2; l >= p0; --l) {
+    double G[9], T1[9], Di[9];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { G[i] = d.Gl[9 * (l + 1) + i]; Di[i] = d.Dinv[9 * l + i]; }
+    mat3_mul(G, Gn, T1);                       // Gl_{k+1} G_{k+1,k+1}
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d.Goff[9 * (l + 1) + i] = -T1[i];
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) Gn[3 * i + j] = Di[3 * i + j] + T1[3 * i] * G[3 * j] + T1[3 * i + 1] * G[3 * j + 1] + T1[3 * i + 2] * G[3 * j + 2];
+#pragma unroll
+    for (int i = 0; i < 9; ++i) d.Gdiag[9 * l + i] = Gn[i];
+  }
   if (!ok) atomicOr(d.flags, 1);
-}
-
-// w = Hll(lambda)^-1 u along every chain.  sign/addb: u_eff = addb ? (bl - u) : u ; u is zeroed after use.
-__global__ void k_chain_solve(BADev d, const double* bl_or_null, double* u, double* w) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d.n_chains) return;
-  const int off = d.chain_off[c], m = d.chain_off[c + 1] - off;
-  D3 yprev{0, 0, 0};
-  for (int k = 0; k < m; ++k) {
-    const int64_t l = d.chain_pt[off + k];
-    D3 y{u[3 * l], u[3 * l + 1], u[3 * l + 2]};
-    u[3 * l] = 0; u[3 * l + 1] = 0; u[3 * l + 2] = 0;
-    if (bl_or_null) y = D3{bl_or_null[3 * l], bl_or_null[3 * l + 1], bl_or_null[3 * l + 2]} - y;
-    if (k > 0) y = y - rotT(d.Gl + 9 * l, yprev);   // y_k = u_k - G_k^T y_{k-1}
-    yprev = y;
-    const D3 z = rot(d.Dinv + 9 * l, y);
-    w[3 * l] = z.x; w[3 * l + 1] = z.y; w[3 * l + 2] = z.z;
-  }
-  D3 wnext{0, 0, 0};
-  int64_t lnext = -1;
-  for (int k = m - 1; k >= 0; --k) {
-    const int64_t l = d.chain_pt[off + k];
-    D3 z{w[3 * l], w[3 * l + 1], w[3 * l + 2]};
-    if (lnext >= 0) {                               // w_k = z_k - G_{k+1} w_{k+1}
-      z = z - rot(d.Gl + 9 * lnext, wnext);
-      w[3 * l] = z.x; w[3 * l + 1] = z.y; w[3 * l + 2] = z.z;
-    }
-    wnext = z; lnext = l;
-  }
 }
 
 // 6x6 SPD inverse via Cholesky; returns false if a pivot is not positive.
@@ -151,7 +103,6 @@ __device__ bool spd6_inv(const double* A, double* Ainv) {
       Lm[i * 6 + j] = t / dj;
     }
   }
-  // invert L (lower) in place -> Li, then Ainv = Li^T Li
   double Li[36];
   for (int i = 0; i < 36; ++i) Li[i] = 0;
   for (int c = 0; c < 6; ++c) {
@@ -171,115 +122,253 @@ __device__ bool spd6_inv(const double* A, double* Ainv) {
   return ok;
 }
 
-// Block-Jacobi preconditioner: M_i = (Hpp_ii + lambda I)^-1
-__global__ void k_precond(BADev d, double lambda) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void load_block(const double* Binc, int64_t idx, int64_t N, double (&B)[18]) {
+#pragma unroll
+  for (int i = 0; i < 18; ++i) B[i] = Binc[i * N + idx];
+}
+
+// out(6x6 upper, 21 values) += B1 G B2^T (+ transpose if sym2) ; helper computing full 6x6 product
+__device__ __forceinline__ void bgbt(const double (&B1)[18], const double* G, const double (&B2)[18], double (&out)[36]) {
+  double T1[18];   // B1 G (6x3)
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 3; ++c) T1[3 * r + c] = B1[3 * r] * G[c] + B1[3 * r + 1] * G[3 + c] + B1[3 * r + 2] * G[6 + c];
+#pragma unroll
+  for (int r = 0; r < 6; ++r)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) out[6 * r + c] = T1[3 * r] * B2[3 * c] + T1[3 * r + 1] * B2[3 * c + 1] + T1[3 * r + 2] * B2[3 * c + 2];
+}
+
+// Exact diagonal blocks of the Schur correction, per (tile,slot):  sum B G B^T  (21 upper entries)
+__global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const Tile T = d.tiles[blockIdx.x];
+  const int nslot = T.slot_end - T.slot_begin;
+  const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
+  double* accm = smem;   // [21 * nslot]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 21 * nslot; i += VDO_TILE_THREADS) accm[i] = 0.0;
+  __syncthreads();
+  const int64_t N = d.Ninc;
+  for (int base = 0; base < nb; base += VDO_TILE_THREADS) {
+    const int j = base + tid;
+    int slot = -1;
+    double up[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) up[i] = 0.0;
+    if (j < nb) {
+      const int64_t idx = T.inc_begin + j;
+      const int key = d.inc_key[idx];
+      slot = key >> 16;
+      const int64_t l = T.pt_begin + (key & 0xffff);
+      double B[18], M[36];
+      load_block(d.Binc, idx, N, B);
+      bgbt(B, d.Gdiag + 9 * l, B, M);
+      int k = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) up[k++] = M[6 * r + c];
+    }
+    seg_reduce_to_lds<21>(up, slot, accm, 21);
+  }
+  for (int base = 0; base < nt; base += VDO_TILE_THREADS) {
+    const int j = base + tid;
+    int slot = -1;
+    double up[21];
+#pragma unroll
+    for (int i = 0; i < 21; ++i) up[i] = 0.0;
+    if (j < nt) {
+      const int64_t i1 = T.inc_begin + nb + j, i2 = T.inc_begin + nb + nt + j;
+      const int k1 = d.inc_key[i1], k2 = d.inc_key[i2];
+      slot = k1 >> 16;
+      const int64_t l1 = T.pt_begin + (k1 & 0xffff), l2 = T.pt_begin + (k2 & 0xffff);
+      double B1[18], B2[18], M11[36], M12[36], M22[36];
+      load_block(d.Binc, i1, N, B1);
+      load_block(d.Binc, i2, N, B2);
+      bgbt(B1, d.Gdiag + 9 * l1, B1, M11);
+      bgbt(B1, d.Goff + 9 * l2, B2, M12);     // [Hll^-1]_{l1,l2}, l2 = l1 + 1 in chain order
+      bgbt(B2, d.Gdiag + 9 * l2, B2, M22);
+      int k = 0;
+#pragma unroll
+      for (int r = 0; r < 6; ++r)
+#pragma unroll
+        for (int c = r; c < 6; ++c) up[k++] = M11[6 * r + c] + M22[6 * r + c] + M12[6 * r + c] + M12[6 * c + r];
+    }
+    seg_reduce_to_lds<21>(up, slot, accm, 21);
+  }
+  __syncthreads();
+  const int64_t NPS = d.NPS;
+  for (int i = tid; i < 21 * nslot; i += VDO_TILE_THREADS) {
+    const int sidx = i / 21, k = i % 21;
+    d.part_m[k * NPS + T.slot_begin + sidx] = accm[21 * sidx + k];
+  }
+}
+
+// M_i = (Hpp_ii + lambda I - sum partials)^-1
+__global__ __launch_bounds__(256) void k_precond_finalize(BADev d, double lambda) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per pose
   if (p >= d.P) return;
+  double up[21];
+  wave_gather<21>(d.part_m, d.NPS, d.ps_off, d.ps_idx, p, up);
+  if ((threadIdx.x & 63) != 0) return;
   double A[36], Ai[36];
   for (int i = 0; i < 36; ++i) A[i] = d.Hpp[36 * (int64_t)p + i];
   for (int i = 0; i < 6; ++i) A[7 * i] += lambda;
+  int k = 0;
+  for (int r = 0; r < 6; ++r)
+    for (int c = r; c < 6; ++c) { A[6 * r + c] -= up[k]; if (c != r) A[6 * c + r] -= up[k]; ++k; }
   if (!spd6_inv(A, Ai)) atomicOr(d.flags, 1);
   for (int i = 0; i < 36; ++i) d.Minv[36 * (int64_t)p + i] = Ai[i];
 }
 
-// pass A: u_l += B_inc^T v_pose  (one workgroup per incidence chunk; pose vector is uniform)
-__global__ __launch_bounds__(VDO_SWEEP_THREADS) void k_pass_a(BADev d, const double* v, double* u) {
-  const Chunk c = d.chunks_inc[blockIdx.x];
-  double pv[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) pv[i] = v[6 * (int64_t)c.pose + i];
+// Tile operator.  MODE 0: part_q = B Hll^-1 B^T v     (Schur mat-vec)
+//                 MODE 1: part_q = B Hll^-1 bl        (reduced rhs)
+//                 MODE 2: xl     = Hll^-1 (bl - B^T v) (back-substitution)
+template <int MODE>
+__global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const double* __restrict__ v) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const Tile T = d.tiles[blockIdx.x];
+  const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
+  const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, ninc = nb + 2 * nt;
+  double* u = smem;                        // [3*TP]
+  double* dinv = u + 3 * VDO_TILE_PTS;     // [9*TP]  forward pivots^-1 of the tile's points
+  double* gl = dinv + 9 * VDO_TILE_PTS;    // [9*TP]  G_k
+  double* vs = gl + 9 * VDO_TILE_PTS;      // [6*S]
+  double* qs = vs + 6 * d.max_slots;       // [6*S]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) u[i] = 0.0;
+  {   // coalesced staging of the chain factors (read once per tile, used by the serial chain solves)
+    const double* gd = d.Dinv + 9 * (int64_t)T.pt_begin;
+    const double* gg = d.Gl + 9 * (int64_t)T.pt_begin;
+    for (int i = tid; i < 9 * npts; i += VDO_TILE_THREADS) { dinv[i] = gd[i]; gl[i] = gg[i]; }
+  }
+  if (MODE != 1)
+    for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) vs[i] = v[6 * (int64_t)d.tile_pose[T.slot_begin + i / 6] + i % 6];
+  if (MODE != 2)
+    for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) qs[i] = 0.0;
+  // incidence blocks in registers
+  double B[3][18];
+  int key[3];
   const int64_t N = d.Ninc;
-  for (int e = c.begin + (int)threadIdx.x; e < c.end; e += VDO_SWEEP_THREADS) {
-    const int64_t pt = d.inc_point[e];
-    const double* B = d.Binc + e;
-    double t0 = 0, t1 = 0, t2 = 0;
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
-      t0 += B[(3 * r + 0) * N] * pv[r];
-      t1 += B[(3 * r + 1) * N] * pv[r];
-      t2 += B[(3 * r + 2) * N] * pv[r];
+  for (int j = 0; j < 3; ++j) {
+    const int li = tid + VDO_TILE_THREADS * j;
+    key[j] = -1;
+    if (li < ninc) {
+      key[j] = d.inc_key[T.inc_begin + li];
+      load_block(d.Binc, T.inc_begin + li, N, B[j]);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 18; ++i) B[j][i] = 0.0;
     }
-    atomicAdd(u + 3 * pt, t0); atomicAdd(u + 3 * pt + 1, t1); atomicAdd(u + 3 * pt + 2, t2);
-  }
-}
-
-// pass C: chunk_q[.,chunk] = sum_inc B_inc w_point
-__global__ __launch_bounds__(VDO_SWEEP_THREADS) void k_pass_c(BADev d, const double* w) {
-  __shared__ double lds[4 * 6];
-  const Chunk c = d.chunks_inc[blockIdx.x];
-  double acc[6] = {0, 0, 0, 0, 0, 0};
-  const int64_t N = d.Ninc;
-  for (int e = c.begin + (int)threadIdx.x; e < c.end; e += VDO_SWEEP_THREADS) {
-    const int64_t pt = d.inc_point[e];
-    const double w0 = w[3 * pt], w1 = w[3 * pt + 1], w2 = w[3 * pt + 2];
-    const double* B = d.Binc + e;
-#pragma unroll
-    for (int r = 0; r < 6; ++r) acc[r] += B[(3 * r) * N] * w0 + B[(3 * r + 1) * N] * w1 + B[(3 * r + 2) * N] * w2;
-  }
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const double s = wave_sum2(acc[i]);
-    if (lane == 0) lds[wv * 6 + i] = s;
   }
   __syncthreads();
-  if (threadIdx.x < 6)
-    d.chunk_q[threadIdx.x * (int64_t)d.n_chunks_inc + blockIdx.x] =
-        lds[threadIdx.x] + lds[6 + threadIdx.x] + lds[12 + threadIdx.x] + lds[18 + threadIdx.x];
-}
-
-// qs[pose] = sum over the pose's chunks of chunk_q  (fixed order)
-__global__ void k_gather_q(BADev d, double* qs) {
-  const int p = blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= d.P) return;
-  double s[6] = {0, 0, 0, 0, 0, 0};
-  const int64_t nc = d.n_chunks_inc;
-  for (int k = d.pc_off[p]; k < d.pc_off[p + 1]; ++k) {
-    const int c = d.pc_idx[k];
-    if (c < d.n_chunks_b) {
+  if (MODE != 1) {   // pass A: u_l += B^T v_slot
 #pragma unroll
-      for (int i = 0; i < 6; ++i) s[i] += d.chunk_q[i * nc + c];
-    } else {
-      const int c1 = c, c2 = c + d.n_chunks_t;
+    for (int j = 0; j < 3; ++j) {
+      if (key[j] >= 0) {
+        const double* pv = vs + 6 * (key[j] >> 16);
+        double t0 = 0, t1 = 0, t2 = 0;
 #pragma unroll
-      for (int i = 0; i < 6; ++i) s[i] += d.chunk_q[i * nc + c1] + d.chunk_q[i * nc + c2];
+        for (int r = 0; r < 6; ++r) { t0 += B[j][3 * r] * pv[r]; t1 += B[j][3 * r + 1] * pv[r]; t2 += B[j][3 * r + 2] * pv[r]; }
+        double* ul = u + 3 * (key[j] & 0xffff);
+        atomicAdd(ul, t0); atomicAdd(ul + 1, t1); atomicAdd(ul + 2, t2);
+      }
+    }
+    __syncthreads();
+  }
+  // chain solves in LDS: w = Hll^-1 y,  y = u (MODE 0) | bl (MODE 1) | bl - u (MODE 2)
+  for (int c = T.chain_begin + tid; c < T.chain_end; c += VDO_TILE_THREADS) {
+    const int64_t p0 = d.chain_off[c], p1 = d.chain_off[c + 1];
+    D3 yprev{0, 0, 0};
+    for (int64_t l = p0; l < p1; ++l) {
+      double* ul = u + 3 * (l - T.pt_begin);
+      D3 y{ul[0], ul[1], ul[2]};
+      if (MODE == 1) y = D3{d.bl[3 * l], d.bl[3 * l + 1], d.bl[3 * l + 2]};
+      if (MODE == 2) y = D3{d.bl[3 * l], d.bl[3 * l + 1], d.bl[3 * l + 2]} - y;
+      if (l > p0) y = y - rotT(gl + 9 * (l - T.pt_begin), yprev);     // y_k = u_k - G_k^T y_{k-1}
+      yprev = y;
+      const D3 z = rot(dinv + 9 * (l - T.pt_begin), y);
+      ul[0] = z.x; ul[1] = z.y; ul[2] = z.z;
+    }
+    D3 wnext{0, 0, 0};
+    for (int64_t l = p1 - 2; l >= p0; --l) {             // w_k = z_k - G_{k+1} w_{k+1}
+      const double* un = u + 3 * (l + 1 - T.pt_begin);
+      wnext = D3{un[0], un[1], un[2]};
+      double* ul = u + 3 * (l - T.pt_begin);
+      const D3 z = D3{ul[0], ul[1], ul[2]} - rot(gl + 9 * (l + 1 - T.pt_begin), wnext);
+      ul[0] = z.x; ul[1] = z.y; ul[2] = z.z;
     }
   }
+  __syncthreads();
+  if (MODE == 2) {
+    double* xo = d.xl + 3 * (int64_t)T.pt_begin;
+    for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) xo[i] = u[i];
+    return;
+  }
+  // pass C: q_slot += B w_l  (segmented wave reduction; incidences are slot-sorted per part)
 #pragma unroll
-  for (int i = 0; i < 6; ++i) qs[6 * (int64_t)p + i] = s[i];
+  for (int j = 0; j < 3; ++j) {
+    double q[6];
+    const double* wl = u + 3 * (key[j] >= 0 ? (key[j] & 0xffff) : 0);
+    const double w0 = wl[0], w1 = wl[1], w2 = wl[2];
+#pragma unroll
+    for (int r = 0; r < 6; ++r) q[r] = B[j][3 * r] * w0 + B[j][3 * r + 1] * w1 + B[j][3 * r + 2] * w2;
+    seg_reduce_to_lds<6>(q, key[j] >= 0 ? (key[j] >> 16) : -1, qs, 6);
+  }
+  __syncthreads();
+  const int64_t NPS = d.NPS;
+  for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) {
+    const int sidx = i / 6, k = i % 6;
+    d.part_q[k * NPS + T.slot_begin + sidx] = qs[6 * sidx + k];
+  }
 }
 
-// L2-coherent load: the value may have been updated by atomics (performed at L2) after this
-// CU cached the line in its vector L1.
-__device__ __forceinline__ double ld_l2(const double* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// qs[pose] = sum over the pose's (tile,slot) partials, fixed order
+__global__ __launch_bounds__(256) void k_gather_q(BADev d, double* out) {
+  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per pose
+  if (p >= d.P) return;
+  double s[6];
+  wave_gather<6>(d.part_q, d.NPS, d.ps_off, d.ps_idx, p, s);
+  const int lane = threadIdx.x & 63;
+  if (lane < 6) out[6 * (int64_t)p + lane] = s[lane];
 }
 
-// out += Hpp_offdiag * v for the EdgeSE3 blocks (single workgroup)
-__device__ void offdiag_mv(const BADev& d, const double* v, double* out) {
-  for (int k = threadIdx.x; k < d.Ep; k += blockDim.x) {
-    const int64_t vi = d.ep_i[k], vj = d.ep_j[k];
-    const double* Hm = d.Hpp_ep + 36 * (int64_t)k;
-    for (int a = 0; a < 6; ++a) {
-      double si = 0, sj = 0;
-      for (int b = 0; b < 6; ++b) { si += Hm[a * 6 + b] * v[6 * vj + b]; sj += Hm[b * 6 + a] * v[6 * vi + b]; }
-      atomicAdd(out + 6 * vi + a, si);
-      atomicAdd(out + 6 * vj + a, sj);
+// (Hpp v)_p including lambda and the EdgeSE3 off-diagonal blocks (CSR per pose, no atomics)
+__device__ __forceinline__ void hpp_mv(const BADev& d, int p, const double* v, double lambda, double* out) {
+  const double* Hm = d.Hpp + 36 * (int64_t)p;
+  const double* pv = v + 6 * (int64_t)p;
+  for (int i = 0; i < 6; ++i) {
+    double s = lambda * pv[i];
+    for (int j = 0; j < 6; ++j) s += Hm[i * 6 + j] * pv[j];
+    out[i] = s;
+  }
+  for (int k = d.pe_off[p]; k < d.pe_off[p + 1]; ++k) {
+    const int ent = d.pe_idx[k];
+    const int e = ent >> 1, side = ent & 1;
+    const double* He = d.Hpp_ep + 36 * (int64_t)e;       // block (i,j)
+    if (side == 0) {
+      const double* vj = v + 6 * (int64_t)d.ep_j[e];
+      for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) out[a] += He[a * 6 + b] * vj[b];
+    } else {
+      const double* vi = v + 6 * (int64_t)d.ep_i[e];
+      for (int a = 0; a < 6; ++a) for (int b = 0; b < 6; ++b) out[a] += He[b * 6 + a] * vi[b];
     }
   }
 }
 
 // bs = bp - qs ; x = 0 ; r = bs ; z = Minv r ; p = z ; rz = rz0 = r.z       (single workgroup)
-__global__ __launch_bounds__(1024) void k_pcg_init(BADev d, const double* qs) {
+__global__ __launch_bounds__(1024) void k_pcg_init(BADev d) {
   __shared__ double lds[17];
   double acc = 0;
   for (int p = threadIdx.x; p < d.P; p += blockDim.x) {
     double r[6];
     for (int i = 0; i < 6; ++i) {
-      r[i] = d.bp[6 * (int64_t)p + i] - qs[6 * (int64_t)p + i];
-      d.bs[6 * (int64_t)p + i] = r[i];
-      d.rp[6 * (int64_t)p + i] = r[i];
-      d.xp[6 * (int64_t)p + i] = 0;
+      const int64_t idx = 6 * (int64_t)p + i;
+      r[i] = d.bp[idx] - d.qs[idx];
+      d.bs[idx] = r[i]; d.rp[idx] = r[i]; d.xp[idx] = 0;
     }
     const double* Mi = d.Minv + 36 * (int64_t)p;
     for (int i = 0; i < 6; ++i) {
@@ -291,55 +380,69 @@ __global__ __launch_bounds__(1024) void k_pcg_init(BADev d, const double* qs) {
     }
   }
   acc = block_sum1(acc, lds);
-  if (threadIdx.x == 0) { d.scal[S_RZ] = acc; d.scal[S_RZ0] = acc; d.scal[S_RZNEW] = acc; d.flags[1] = (acc <= 0) ? 1 : 0; }
+  if (threadIdx.x == 0) { d.scal[S_RZ] = acc; d.scal[S_RZ0] = acc; d.scal[S_RZNEW] = acc; d.flags[1] = (acc > 0) ? 0 : 1; d.flags[2] = 0; }
 }
 
-// One CG update given qs = Hpl Hll^-1 Hlp p (Schur part).                     (single workgroup)
-__global__ __launch_bounds__(1024) void k_pcg_vec(BADev d, const double* qs, double lambda, double tol2) {
-  __shared__ double lds[17];
-  if (d.flags[1]) return;                       // converged earlier: no-op
-  // q = (Hpp_diag + lambda I) p - qs
-  for (int p = threadIdx.x; p < d.P; p += blockDim.x) {
-    const double* Hm = d.Hpp + 36 * (int64_t)p;
-    const double* pv = d.pp + 6 * (int64_t)p;
-    for (int i = 0; i < 6; ++i) {
-      double s = lambda * pv[i] - qs[6 * (int64_t)p + i];
-      for (int j = 0; j < 6; ++j) s += Hm[i * 6 + j] * pv[j];
-      d.qp[6 * (int64_t)p + i] = s;
+// One CG update given qs = Hpl Hll^-1 Hlp p.  Single workgroup, one thread per vector element
+// (6P elements) so that every phase is a short, fully parallel strip between barriers.
+__device__ __forceinline__ double hpp_row(const BADev& d, int64_t p, int row, const double* v, double lambda) {
+  const double* Hm = d.Hpp + 36 * p + 6 * row;
+  const double* pv = v + 6 * p;
+  double s = lambda * pv[row];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) s += Hm[j] * pv[j];
+  for (int k = d.pe_off[p]; k < d.pe_off[p + 1]; ++k) {
+    const int ent = d.pe_idx[k];
+    const int e = ent >> 1, side = ent & 1;
+    const double* He = d.Hpp_ep + 36 * (int64_t)e;       // block (i,j)
+    if (side == 0) {
+      const double* vj = v + 6 * (int64_t)d.ep_j[e];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) s += He[row * 6 + b] * vj[b];
+    } else {
+      const double* vi = v + 6 * (int64_t)d.ep_i[e];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) s += He[b * 6 + row] * vi[b];
     }
   }
-  __syncthreads();
-  offdiag_mv(d, d.pp, d.qp);
-  __syncthreads();
+  return s;
+}
+
+__global__ __launch_bounds__(1024) void k_pcg_vec(BADev d, double lambda, double tol2) {
+  __shared__ double lds[17];
+  if (d.flags[1]) return;                       // converged earlier: no-op
+  const int64_t n = 6 * (int64_t)d.P;
   double acc = 0;
-  for (int64_t i = threadIdx.x; i < 6 * (int64_t)d.P; i += blockDim.x) acc += d.pp[i] * ld_l2(d.qp + i);
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double q = hpp_row(d, i / 6, (int)(i % 6), d.pp, lambda) - d.qs[i];
+    d.qp[i] = q;
+    acc += d.pp[i] * q;
+  }
   const double pq = block_sum1(acc, lds);
   const double rz = d.scal[S_RZ];
   const double alpha = rz / pq;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    d.xp[i] += alpha * d.pp[i];
+    d.rp[i] -= alpha * d.qp[i];
+  }
+  __syncthreads();
   acc = 0;
-  for (int p = threadIdx.x; p < d.P; p += blockDim.x) {
-    double r[6];
-    for (int i = 0; i < 6; ++i) {
-      const int64_t idx = 6 * (int64_t)p + i;
-      d.xp[idx] += alpha * d.pp[idx];
-      r[i] = d.rp[idx] - alpha * ld_l2(d.qp + idx);
-      d.rp[idx] = r[i];
-    }
-    const double* Mi = d.Minv + 36 * (int64_t)p;
-    for (int i = 0; i < 6; ++i) {
-      double z = 0;
-      for (int j = 0; j < 6; ++j) z += Mi[i * 6 + j] * r[j];
-      d.zp[6 * (int64_t)p + i] = z;
-      acc += r[i] * z;
-    }
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const int64_t p = i / 6;
+    const int row = (int)(i % 6);
+    const double* Mi = d.Minv + 36 * p + 6 * row;
+    const double* r = d.rp + 6 * p;
+    double z = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) z += Mi[j] * r[j];
+    d.zp[i] = z;
+    acc += r[row] * z;
   }
   const double rznew = block_sum1(acc, lds);
   const double beta = rznew / rz;
-  for (int64_t i = threadIdx.x; i < 6 * (int64_t)d.P; i += blockDim.x) d.pp[i] = d.zp[i] + beta * d.pp[i];
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) d.pp[i] = d.zp[i] + beta * d.pp[i];
   if (threadIdx.x == 0) {
-    d.scal[S_RZ] = rznew;
-    d.scal[S_RZNEW] = rznew;
-    d.scal[S_PQ] = pq;
+    d.scal[S_RZ] = rznew; d.scal[S_RZNEW] = rznew; d.scal[S_PQ] = pq;
     int f = 0;
     if (!(pq > 0) || !(rznew == rznew)) f = 2;          // breakdown
     else if (rznew <= tol2 * d.scal[S_RZ0]) f = 1;      // converged
@@ -368,39 +471,32 @@ __global__ __launch_bounds__(1024) void k_update(BADev d, double lambda, int ort
 }
 
 // ------------------------------------------------------------------------------ launchers
+static size_t schur_lds(const BADev& d) { return (21 * VDO_TILE_PTS + 12 * (size_t)d.max_slots) * sizeof(double); }
+
 void launch_max_diag(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(1024), 0, s, d); }
 
 void launch_factor(const BADev& d, double lambda, hipStream_t s) {
   hipMemsetAsync(d.flags, 0, 4 * sizeof(int32_t), s);
   if (d.n_chains) hipLaunchKernelGGL(k_factor_chains, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, lambda);
-  hipLaunchKernelGGL(k_precond, dim3((d.P + 63) / 64), dim3(64), 0, s, d, lambda);
+  if (d.n_tiles) hipLaunchKernelGGL(k_precond_tile, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), 21 * (size_t)d.max_slots * sizeof(double), s, d);
+  hipLaunchKernelGGL(k_precond_finalize, dim3((d.P + 3) / 4), dim3(256), 0, s, d, lambda);
 }
 
-// qs (in d.zp as scratch? no: dedicated) — we reuse d.qp as the "qs" buffer before PCG starts.
 void launch_reduced_rhs(const BADev& d, hipStream_t s) {
-  // w = Hll^-1 bl ; qs = Hpl w
-  hipMemsetAsync(d.ul, 0, sizeof(double) * 3 * (size_t)d.L, s);
-  if (d.n_chains) hipLaunchKernelGGL(k_chain_solve, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, (const double*)d.bl, d.ul, d.wl);
-  if (d.n_chunks_inc) hipLaunchKernelGGL(k_pass_c, dim3(d.n_chunks_inc), dim3(VDO_SWEEP_THREADS), 0, s, d, (const double*)d.wl);
-  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 127) / 128), dim3(128), 0, s, d, d.bs);
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)nullptr);
+  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs);
 }
 
-void launch_pcg_init(const BADev& d, hipStream_t s) {
-  hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, s, d, (const double*)d.bs);
-}
+void launch_pcg_init(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, s, d); }
 
-void launch_pcg_iter_tol(const BADev& d, double lambda, double tol2, double* qs, hipStream_t s) {
-  if (d.n_chunks_inc) hipLaunchKernelGGL(k_pass_a, dim3(d.n_chunks_inc), dim3(VDO_SWEEP_THREADS), 0, s, d, (const double*)d.pp, d.ul);
-  if (d.n_chains) hipLaunchKernelGGL(k_chain_solve, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, (const double*)nullptr, d.ul, d.wl);
-  if (d.n_chunks_inc) hipLaunchKernelGGL(k_pass_c, dim3(d.n_chunks_inc), dim3(VDO_SWEEP_THREADS), 0, s, d, (const double*)d.wl);
-  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 127) / 128), dim3(128), 0, s, d, qs);
-  hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(1024), 0, s, d, (const double*)qs, lambda, tol2);
+void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s) {
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<0>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.pp);
+  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs);
+  hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(1024), 0, s, d, lambda, tol2);
 }
 
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s) {
-  // x_l = Hll^-1 (bl - Hlp x_p)
-  if (d.n_chunks_inc) hipLaunchKernelGGL(k_pass_a, dim3(d.n_chunks_inc), dim3(VDO_SWEEP_THREADS), 0, s, d, (const double*)d.xp, d.ul);
-  if (d.n_chains) hipLaunchKernelGGL(k_chain_solve, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, (const double*)d.bl, d.ul, d.xl);
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<2>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.xp);
   hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, s, d, lambda, ortho ? 1 : 0);
 }
 

@@ -1,23 +1,13 @@
-// C-ABI entry points (include/vdo_slam_hip.h) for the batch-BA path + host-side
-// Levenberg–Marquardt driver.  The control flow restates the *modified* g2o of the reference:
-//   SparseOptimizer::optimize            g2o/core/sparse_optimizer.cpp:354-443 (incl. :393-396 chi2 abort)
-//   OptimizationAlgorithmLevenberg::solve g2o/core/optimization_algorithm_levenberg.cpp:61-164 (incl. _nBad rule :154-161)
-//   SparseOptimizerTerminateAction        g2o/core/sparse_optimizer_terminate_action.cpp:49-85
-// All heavy work is HIP kernels (ba_sweep.hip, ba_solve.hip); the host only sequences
-// launches and reads back a handful of scalars per Levenberg trial.
+// C-ABI entry points (include/vdo_slam_hip.h) of the batch-BA path: graph upload with the
+// host-side re-ordering into tiles (ba_dev.hpp), linearisation, system download, estimates.
+// The Levenberg–Marquardt driver is in ba_lm.hip.
 #include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
 #include <cstdio>
 #include <cstring>
-#include <limits>
-#include <string>
+#include <numeric>
 #include <vector>
 
-#include "../../include/vdo_slam_hip.h"
-#include "ba_dev.hpp"
-#include "ctx.hpp"
+#include "ba_host.hpp"
 
 using namespace vdo;
 
@@ -35,37 +25,10 @@ int upload(T** dst, const T* src, size_t n, hipStream_t s) {
   return VDO_OK;
 }
 
-// runs of equal pose index, split at VDO_CHUNK
-std::vector<Chunk> make_chunks(const int32_t* pose, int n) {
-  std::vector<Chunk> out;
-  int b = 0;
-  while (b < n) {
-    int e = b + 1;
-    while (e < n && pose[e] == pose[b] && e - b < VDO_CHUNK) ++e;
-    out.push_back(Chunk{pose[b], b, e, 0});
-    b = e;
-  }
-  return out;
-}
-
-double now_ms() {
-  using namespace std::chrono;
-  return duration<double, std::milli>(steady_clock::now().time_since_epoch()).count();
-}
+constexpr int kSoftSlots = 64;     // normal tiles stay below this many pose slots
+constexpr int kHardSlots = 100;    // a single long chain may use up to this many (LDS bound)
 
 }  // namespace
-
-struct vdo_ba {
-  vdo_ctx* ctx = nullptr;
-  BADev d;
-  std::vector<void*> allocs;
-  vdo_allreduce_fn allreduce = nullptr;
-  void* allreduce_user = nullptr;
-  int oplus_calls = 0;            // VertexSE3::_numOplusCalls (same value on every vertex)
-  double* h_scal = nullptr;       // pinned
-  int32_t* h_flags = nullptr;     // pinned
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-};
 
 #define UP(field, src, n)                                                          \
   do {                                                                             \
@@ -93,7 +56,8 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       return set_error(VDO_ERR_INVALID, "pose-pose edge %d: index out of range", e);
   for (int e = 0; e < Npr; ++e)
     if ((unsigned)g->pr_pose[e] >= (unsigned)P) return set_error(VDO_ERR_INVALID, "prior %d: index out of range", e);
-  // ---- chains: next/prev ternary edge per point
+
+  // ---- chains (dynamic tracks) from the ternary edges
   std::vector<int32_t> next_e(L, -1), prev_e(L, -1);
   for (int e = 0; e < Et; ++e) {
     if (next_e[g->et_p1[e]] != -1 || prev_e[g->et_p2[e]] != -1)
@@ -101,77 +65,219 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     next_e[g->et_p1[e]] = e;
     prev_e[g->et_p2[e]] = e;
   }
-  std::vector<int32_t> chain_off{0}, chain_pt, chain_edge;
-  chain_pt.reserve(L); chain_edge.reserve(L);
+  // point -> binary edges CSR
+  std::vector<int32_t> pb_off(L + 1, 0), pb_idx(Eb);
+  for (int e = 0; e < Eb; ++e) pb_off[g->eb_point[e] + 1]++;
+  for (int l = 0; l < L; ++l) pb_off[l + 1] += pb_off[l];
+  {
+    std::vector<int32_t> fill(pb_off.begin(), pb_off.end() - 1);
+    for (int e = 0; e < Eb; ++e) pb_idx[fill[g->eb_point[e]]++] = e;
+  }
+  struct ChainInfo { int32_t head; int32_t npts; int32_t ninc; int32_t key; };
+  std::vector<ChainInfo> chains;
+  chains.reserve(L);
   int visited = 0;
   for (int l = 0; l < L; ++l) {
     if (prev_e[l] != -1) continue;
-    int cur = l;
-    for (;;) {
-      chain_pt.push_back(cur); ++visited;
-      int e = next_e[cur];
-      if (e == -1) { chain_edge.push_back(-1); break; }
-      chain_edge.push_back(e);
+    ChainInfo ci{l, 0, 0, P};
+    for (int cur = l;;) {
+      ++ci.npts; ++visited;
+      ci.ninc += pb_off[cur + 1] - pb_off[cur];
+      for (int k = pb_off[cur]; k < pb_off[cur + 1]; ++k) ci.key = std::min(ci.key, g->eb_pose[pb_idx[k]]);
+      const int e = next_e[cur];
+      if (e == -1) break;
+      ci.ninc += 2;
       cur = g->et_p2[e];
     }
-    chain_off.push_back((int32_t)chain_pt.size());
+    chains.push_back(ci);
   }
   if (visited != L) return set_error(VDO_ERR_UNSUPPORTED, "ternary edges form a cycle");
-  // ---- chunks
-  std::vector<Chunk> cb = make_chunks(g->eb_pose, Eb), ct = make_chunks(g->et_pose, Et);
-  const int ncb = (int)cb.size(), nct = (int)ct.size();
-  std::vector<Chunk> cinc(cb);
-  for (int rep = 0; rep < 2; ++rep)
-    for (const Chunk& c : ct) cinc.push_back(Chunk{c.pose, Eb + rep * Et + c.begin, Eb + rep * Et + c.end, 0});
-  std::vector<int32_t> pc_off(P + 1, 0), pc_idx(ncb + nct);
-  for (int i = 0; i < ncb; ++i) pc_off[cb[i].pose + 1]++;
-  for (int i = 0; i < nct; ++i) pc_off[ct[i].pose + 1]++;
-  for (int p = 0; p < P; ++p) pc_off[p + 1] += pc_off[p];
-  {
-    std::vector<int32_t> fill(pc_off.begin(), pc_off.end() - 1);
-    for (int i = 0; i < ncb; ++i) pc_idx[fill[cb[i].pose]++] = i;
-    for (int i = 0; i < nct; ++i) pc_idx[fill[ct[i].pose]++] = ncb + i;
-  }
-  std::vector<int32_t> inc_pose((size_t)Eb + 2 * (size_t)Et), inc_point((size_t)Eb + 2 * (size_t)Et);
-  for (int e = 0; e < Eb; ++e) { inc_pose[e] = g->eb_pose[e]; inc_point[e] = g->eb_point[e]; }
-  for (int e = 0; e < Et; ++e) {
-    inc_pose[Eb + e] = g->et_pose[e]; inc_point[Eb + e] = g->et_p1[e];
-    inc_pose[Eb + Et + e] = g->et_pose[e]; inc_point[Eb + Et + e] = g->et_p2[e];
-  }
+  std::stable_sort(chains.begin(), chains.end(), [](const ChainInfo& a, const ChainInfo& b) { return a.key < b.key; });
 
+  // ---- greedy tiling
   vdo_ba* ba = new vdo_ba();
   ba->ctx = ctx;
+  std::vector<Tile> tiles;
+  std::vector<int32_t> tile_pose;                  // per slot: global pose id
+  std::vector<int32_t> chain_off{0};
+  std::vector<int32_t> pt_old_of_new; pt_old_of_new.reserve(L);
+  std::vector<int32_t> pt_new_of_old(L, -1);
+  std::vector<int32_t> pose_stamp(P, -1);
+  std::vector<int32_t> cur_poses;
+  std::vector<int32_t> eb_old_of_new; eb_old_of_new.reserve(Eb);
+  std::vector<int32_t> et_old_of_new; et_old_of_new.reserve(Et);
+  std::vector<int32_t> eb_key(Eb), et_key(Et), et_slot(Et), inc_key((size_t)Eb + 2 * (size_t)Et);
+  std::vector<int32_t> pt_prev_edge_new; pt_prev_edge_new.reserve(L);
+  std::vector<int32_t> et_new_of_old(Et, -1);
+  std::vector<int32_t> tile_eb, tile_et;           // original ids of the open tile
+  int max_slots = 1;
+  Tile cur{};
+  int cur_tile_id = 0, cur_npts = 0, cur_ninc = 0;
+  auto chain_poses = [&](const ChainInfo& ci, std::vector<int32_t>& outp) {
+    outp.clear();
+    for (int c = ci.head;;) {
+      for (int k = pb_off[c]; k < pb_off[c + 1]; ++k) outp.push_back(g->eb_pose[pb_idx[k]]);
+      const int e = next_e[c];
+      if (e == -1) break;
+      outp.push_back(g->et_pose[e]);
+      c = g->et_p2[e];
+    }
+  };
+  int inc_total = 0;
+  auto close_tile = [&]() {
+    if (cur_npts == 0) return;
+    // slots: sorted distinct poses
+    std::sort(cur_poses.begin(), cur_poses.end());
+    cur.slot_begin = (int32_t)tile_pose.size();
+    for (int32_t p : cur_poses) tile_pose.push_back(p);
+    cur.slot_end = (int32_t)tile_pose.size();
+    max_slots = std::max(max_slots, cur.slot_end - cur.slot_begin);
+    auto slot_of = [&](int32_t p) { return (int32_t)(std::lower_bound(cur_poses.begin(), cur_poses.end(), p) - cur_poses.begin()); };
+    std::stable_sort(tile_eb.begin(), tile_eb.end(), [&](int a, int b) { return g->eb_pose[a] < g->eb_pose[b]; });
+    std::stable_sort(tile_et.begin(), tile_et.end(), [&](int a, int b) { return g->et_pose[a] < g->et_pose[b]; });
+    cur.eb_begin = (int32_t)eb_old_of_new.size();
+    cur.et_begin = (int32_t)et_old_of_new.size();
+    cur.inc_begin = inc_total;
+    const int nb = (int)tile_eb.size(), nt = (int)tile_et.size();
+    for (int j = 0; j < nb; ++j) {
+      const int e = tile_eb[j];
+      const int en = (int)eb_old_of_new.size();
+      eb_old_of_new.push_back(e);
+      const int32_t key = (slot_of(g->eb_pose[e]) << 16) | (pt_new_of_old[g->eb_point[e]] - cur.pt_begin);
+      eb_key[en] = key;
+      inc_key[inc_total + j] = key;
+    }
+    for (int j = 0; j < nt; ++j) {
+      const int e = tile_et[j];
+      const int en = (int)et_old_of_new.size();
+      et_old_of_new.push_back(e);
+      et_new_of_old[e] = en;
+      const int32_t sl = slot_of(g->et_pose[e]);
+      const int32_t l1 = pt_new_of_old[g->et_p1[e]] - cur.pt_begin, l2 = pt_new_of_old[g->et_p2[e]] - cur.pt_begin;
+      et_key[en] = l1 | (l2 << 16);
+      et_slot[en] = sl;
+      inc_key[inc_total + nb + j] = (sl << 16) | l1;
+      inc_key[inc_total + nb + nt + j] = (sl << 16) | l2;
+    }
+    inc_total += nb + 2 * nt;
+    cur.eb_end = (int32_t)eb_old_of_new.size();
+    cur.et_end = (int32_t)et_old_of_new.size();
+    cur.pt_end = (int32_t)pt_old_of_new.size();
+    cur.chain_end = (int32_t)chain_off.size() - 1;
+    tiles.push_back(cur);
+    ++cur_tile_id;
+    cur_npts = 0; cur_ninc = 0;
+    cur_poses.clear(); tile_eb.clear(); tile_et.clear();
+  };
+  std::vector<int32_t> cposes;
+  for (const ChainInfo& ci : chains) {
+    if (ci.npts > VDO_TILE_PTS || ci.ninc > VDO_TILE_INC) {
+      delete ba;
+      return set_error(VDO_ERR_UNSUPPORTED, "landmark track with %d points / %d incidences exceeds the tile capacity (%d / %d)",
+                       ci.npts, ci.ninc, VDO_TILE_PTS, VDO_TILE_INC);
+    }
+    chain_poses(ci, cposes);
+    int newp = 0;
+    for (int32_t p : cposes) if (pose_stamp[p] != cur_tile_id) ++newp;   // upper bound (duplicates inside the chain counted once below)
+    if (cur_npts > 0 && (cur_npts + ci.npts > VDO_TILE_PTS || cur_ninc + ci.ninc > VDO_TILE_INC ||
+                         (int)cur_poses.size() + newp > kSoftSlots))
+      close_tile();
+    if (cur_npts == 0) {
+      cur = Tile{};
+      cur.pt_begin = (int32_t)pt_old_of_new.size();
+      cur.chain_begin = (int32_t)chain_off.size() - 1;
+    }
+    for (int32_t p : cposes)
+      if (pose_stamp[p] != cur_tile_id) { pose_stamp[p] = cur_tile_id; cur_poses.push_back(p); }
+    if ((int)cur_poses.size() > kHardSlots) {
+      delete ba;
+      return set_error(VDO_ERR_UNSUPPORTED, "landmark track touches %zu pose vertices (limit %d)", cur_poses.size(), kHardSlots);
+    }
+    for (int c = ci.head;;) {
+      pt_new_of_old[c] = (int32_t)pt_old_of_new.size();
+      pt_old_of_new.push_back(c);
+      pt_prev_edge_new.push_back(prev_e[c]);    // original ternary id for now; remapped below
+      for (int k = pb_off[c]; k < pb_off[c + 1]; ++k) tile_eb.push_back(pb_idx[k]);
+      const int e = next_e[c];
+      if (e == -1) break;
+      tile_et.push_back(e);
+      c = g->et_p2[e];
+    }
+    chain_off.push_back((int32_t)pt_old_of_new.size());
+    cur_npts += ci.npts; cur_ninc += ci.ninc;
+  }
+  close_tile();
+  for (auto& pe : pt_prev_edge_new) if (pe >= 0) pe = et_new_of_old[pe];
+  const int n_tiles = (int)tiles.size(), NPS = (int)tile_pose.size(), n_chains = (int)chain_off.size() - 1;
+
+  // ---- permuted edge / vertex data
+  std::vector<double> point_new(3 * (size_t)L), eb_z(3 * (size_t)Eb), eb_w(Eb), et_z(3 * (size_t)Et), et_w(Et);
+  for (int l = 0; l < L; ++l) for (int k = 0; k < 3; ++k) point_new[3 * (size_t)l + k] = g->point[3 * (size_t)pt_old_of_new[l] + k];
+  for (int e = 0; e < Eb; ++e) {
+    const int o = eb_old_of_new[e];
+    for (int k = 0; k < 3; ++k) eb_z[(size_t)k * Eb + e] = g->eb_z[(size_t)k * Eb + o];
+    eb_w[e] = g->eb_w[o];
+  }
+  for (int e = 0; e < Et; ++e) {
+    const int o = et_old_of_new[e];
+    for (int k = 0; k < 3; ++k) et_z[(size_t)k * Et + e] = g->et_z[(size_t)k * Et + o];
+    et_w[e] = g->et_w[o];
+  }
+  // pose -> slots CSR ; pose -> pose-pose edges CSR
+  std::vector<int32_t> ps_off(P + 1, 0), ps_idx(NPS);
+  for (int k = 0; k < NPS; ++k) ps_off[tile_pose[k] + 1]++;
+  for (int p = 0; p < P; ++p) ps_off[p + 1] += ps_off[p];
+  {
+    std::vector<int32_t> fill(ps_off.begin(), ps_off.end() - 1);
+    for (int k = 0; k < NPS; ++k) ps_idx[fill[tile_pose[k]]++] = k;
+  }
+  std::vector<int32_t> pe_off(P + 1, 0), pe_idx(2 * (size_t)Ep);
+  for (int e = 0; e < Ep; ++e) { pe_off[g->ep_i[e] + 1]++; pe_off[g->ep_j[e] + 1]++; }
+  for (int p = 0; p < P; ++p) pe_off[p + 1] += pe_off[p];
+  {
+    std::vector<int32_t> fill(pe_off.begin(), pe_off.end() - 1);
+    for (int e = 0; e < Ep; ++e) { pe_idx[fill[g->ep_i[e]]++] = (e << 1); pe_idx[fill[g->ep_j[e]]++] = (e << 1) | 1; }
+  }
+  // incidence index of every (new) edge, for the un-permuting download
+  ba->inc_of_eb.resize(Eb); ba->inc1_of_et.resize(Et); ba->inc2_of_et.resize(Et);
+  for (const Tile& T : tiles) {
+    const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
+    for (int j = 0; j < nb; ++j) ba->inc_of_eb[T.eb_begin + j] = T.inc_begin + j;
+    for (int j = 0; j < nt; ++j) { ba->inc1_of_et[T.et_begin + j] = T.inc_begin + nb + j; ba->inc2_of_et[T.et_begin + j] = T.inc_begin + nb + nt + j; }
+  }
+  ba->pt_old_of_new = pt_old_of_new; ba->pt_new_of_old = pt_new_of_old;
+  ba->eb_old_of_new = eb_old_of_new; ba->et_old_of_new = et_old_of_new;
+
   hipStream_t s = ctx->stream;
   BADev& d = ba->d;
   d.P = P; d.L = L; d.Eb = Eb; d.Et = Et; d.Ep = Ep; d.Npr = Npr; d.Ninc = Eb + 2 * Et;
+  d.n_tiles = n_tiles; d.NPS = NPS; d.n_chains = n_chains; d.max_slots = max_slots;
   d.huber_eb = g->huber_eb; d.huber_et = g->huber_et; d.huber_ep = g->huber_ep;
   d.dsqr_eb = (double)(float)(g->huber_eb * g->huber_eb);   // float member, robust_kernel_impl.h:84
   d.dsqr_et = (double)(float)(g->huber_et * g->huber_et);
   d.dsqr_ep = (double)(float)(g->huber_ep * g->huber_ep);
-  d.n_chunks_b = ncb; d.n_chunks_t = nct; d.n_chunks_inc = ncb + 2 * nct;
-  d.n_chains = (int)chain_off.size() - 1;
   UP(pose[0], g->pose, 12 * (size_t)P); UP(pose[1], g->pose, 12 * (size_t)P);
-  UP(point[0], g->point, 3 * (size_t)L); UP(point[1], g->point, 3 * (size_t)L);
-  UP(eb_pose, g->eb_pose, Eb); UP(eb_point, g->eb_point, Eb); UP(eb_z, g->eb_z, 3 * (size_t)Eb); UP(eb_w, g->eb_w, Eb);
-  UP(et_p1, g->et_p1, Et); UP(et_p2, g->et_p2, Et); UP(et_pose, g->et_pose, Et); UP(et_z, g->et_z, 3 * (size_t)Et); UP(et_w, g->et_w, Et);
+  UP(point[0], point_new.data(), 3 * (size_t)L); UP(point[1], point_new.data(), 3 * (size_t)L);
+  UP(tiles, tiles.data(), n_tiles); UP(tile_pose, tile_pose.data(), NPS);
+  UP(chain_off, chain_off.data(), chain_off.size()); UP(pt_prev_edge, pt_prev_edge_new.data(), L);
+  UP(eb_key, eb_key.data(), Eb); UP(eb_z, eb_z.data(), 3 * (size_t)Eb); UP(eb_w, eb_w.data(), Eb);
+  UP(et_key, et_key.data(), Et); UP(et_slot, et_slot.data(), Et); UP(et_z, et_z.data(), 3 * (size_t)Et); UP(et_w, et_w.data(), Et);
+  UP(inc_key, inc_key.data(), inc_key.size());
   UP(ep_i, g->ep_i, Ep); UP(ep_j, g->ep_j, Ep); UP(ep_z, g->ep_z, 12 * (size_t)Ep); UP(ep_info, g->ep_info, 36 * (size_t)Ep);
   UP(pr_pose, g->pr_pose, Npr); UP(pr_z, g->pr_z, 12 * (size_t)Npr); UP(pr_info, g->pr_info, 36 * (size_t)Npr);
-  UP(chunks_b, cb.data(), ncb); UP(chunks_t, ct.data(), nct); UP(chunks_inc, cinc.data(), cinc.size());
-  UP(pc_off, pc_off.data(), P + 1); UP(pc_idx, pc_idx.data(), pc_idx.size());
-  UP(inc_pose, inc_pose.data(), inc_pose.size()); UP(inc_point, inc_point.data(), inc_point.size());
-  UP(chain_off, chain_off.data(), chain_off.size()); UP(chain_pt, chain_pt.data(), chain_pt.size());
-  UP(chain_edge, chain_edge.data(), chain_edge.size());
+  UP(ps_off, ps_off.data(), P + 1); UP(ps_idx, ps_idx.data(), NPS);
+  UP(pe_off, pe_off.data(), P + 1); UP(pe_idx, pe_idx.data(), pe_idx.size());
   const double* Z = nullptr;
   UP(Hpp, Z, 36 * (size_t)P); UP(bp, Z, 6 * (size_t)P); UP(Hll, Z, 9 * (size_t)L); UP(bl, Z, 3 * (size_t)L);
   UP(Binc, Z, 18 * (size_t)d.Ninc); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep);
-  UP(chunk_sums, Z, 18 * (size_t)(ncb + nct));
-  UP(chunk_chi, Z, 2 * (size_t)(ncb + nct + 1) + 2 * (size_t)(Ep + Npr));
-  UP(Dinv, Z, 9 * (size_t)L); UP(Gl, Z, 9 * (size_t)L);
-  UP(ul, Z, 3 * (size_t)L); UP(wl, Z, 3 * (size_t)L); UP(xl, Z, 3 * (size_t)L);
+  UP(part_sums, Z, 32 * (size_t)NPS);
+  UP(part_chi, Z, 2 * (size_t)n_tiles + 2 * (size_t)(Ep + Npr) + 2);
+  UP(Dinv, Z, 9 * (size_t)L); UP(Gl, Z, 9 * (size_t)L); UP(Gdiag, Z, 9 * (size_t)L); UP(Goff, Z, 9 * (size_t)L);
+  UP(xl, Z, 3 * (size_t)L);
   UP(Minv, Z, 36 * (size_t)P);
   UP(xp, Z, 6 * (size_t)P); UP(rp, Z, 6 * (size_t)P); UP(zp, Z, 6 * (size_t)P); UP(pp, Z, 6 * (size_t)P);
   UP(qp, Z, 6 * (size_t)P); UP(bs, Z, 6 * (size_t)P); UP(qs, Z, 6 * (size_t)P);
-  UP(chunk_q, Z, 6 * (size_t)d.n_chunks_inc);
+  UP(part_q, Z, 6 * (size_t)NPS); UP(part_m, Z, 21 * (size_t)NPS);
   UP(scal, Z, S_COUNT);
   const int32_t* ZI = nullptr;
   UP(flags, ZI, 4);
@@ -204,14 +310,6 @@ extern "C" int vdo_ba_set_allreduce(vdo_ba* ba, vdo_allreduce_fn fn, void* user)
   return VDO_OK;
 }
 
-static int sync_check(vdo_ba* ba, const char* what) {
-  hipError_t e = hipStreamSynchronize(ba->ctx->stream);
-  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
-  e = hipGetLastError();
-  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
-  return VDO_OK;
-}
-
 extern "C" int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep) {
   if (!ba) return set_error(VDO_ERR_INVALID, "null handle");
   int rc = ctx_bind(ba->ctx);
@@ -219,9 +317,9 @@ extern "C" int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep) {
   hipStream_t s = ba->ctx->stream;
   if (repeat < 1) repeat = 1;
   if (ms_sweep) {
-    launch_sweep_eb_only(ba->d, s);   // warm-up
+    launch_sweep_only(ba->d, s);   // warm-up
     hipEventRecord(ba->ev0, s);
-    for (int i = 0; i < repeat; ++i) launch_sweep_eb_only(ba->d, s);
+    for (int i = 0; i < repeat; ++i) launch_sweep_only(ba->d, s);
     hipEventRecord(ba->ev1, s);
     hipEventSynchronize(ba->ev1);
     float ms = 0;
@@ -239,29 +337,31 @@ extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
   const BADev& d = ba->d;
   hipStream_t s = ba->ctx->stream;
   auto D2H = [&](void* dst, const void* src, size_t bytes) { if (dst && bytes) hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s); };
+  std::vector<double> hll, bl, oll, binc;
   D2H(out->Hpp, d.Hpp, sizeof(double) * 36 * (size_t)d.P);
   D2H(out->bp, d.bp, sizeof(double) * 6 * (size_t)d.P);
-  D2H(out->Hll, d.Hll, sizeof(double) * 9 * (size_t)d.L);
-  D2H(out->bl, d.bl, sizeof(double) * 3 * (size_t)d.L);
-  D2H(out->Hll_et, d.Oll, sizeof(double) * 9 * (size_t)d.Et);
   D2H(out->Hpp_ep, d.Hpp_ep, sizeof(double) * 36 * (size_t)d.Ep);
-  std::vector<double> binc;
-  if (out->Hpl_eb || out->Hlp1_et || out->Hlp2_et) {
-    binc.resize(18 * (size_t)d.Ninc);
-    D2H(binc.data(), d.Binc, sizeof(double) * binc.size());
-  }
+  if (out->Hll) { hll.resize(9 * (size_t)d.L); D2H(hll.data(), d.Hll, sizeof(double) * hll.size()); }
+  if (out->bl) { bl.resize(3 * (size_t)d.L); D2H(bl.data(), d.bl, sizeof(double) * bl.size()); }
+  if (out->Hll_et) { oll.resize(9 * (size_t)d.Et); D2H(oll.data(), d.Oll, sizeof(double) * oll.size()); }
+  if (out->Hpl_eb || out->Hlp1_et || out->Hlp2_et) { binc.resize(18 * (size_t)d.Ninc); D2H(binc.data(), d.Binc, sizeof(double) * binc.size()); }
   D2H(ba->h_scal, d.scal, sizeof(double) * S_COUNT);
   rc = sync_check(ba, "vdo_ba_download_system");
   if (rc != VDO_OK) return rc;
   const size_t N = d.Ninc, Eb = d.Eb, Et = d.Et;
+  if (out->Hll) for (int l = 0; l < d.L; ++l) std::memcpy(out->Hll + 9 * (size_t)ba->pt_old_of_new[l], hll.data() + 9 * (size_t)l, 72);
+  if (out->bl) for (int l = 0; l < d.L; ++l) std::memcpy(out->bl + 3 * (size_t)ba->pt_old_of_new[l], bl.data() + 3 * (size_t)l, 24);
+  if (out->Hll_et)
+    for (size_t e = 0; e < Et; ++e) for (int i = 0; i < 9; ++i) out->Hll_et[i * Et + ba->et_old_of_new[e]] = oll[i * Et + e];
   if (out->Hpl_eb)
-    for (int i = 0; i < 18; ++i) std::memcpy(out->Hpl_eb + i * Eb, binc.data() + i * N, sizeof(double) * Eb);
+    for (size_t e = 0; e < Eb; ++e) for (int i = 0; i < 18; ++i) out->Hpl_eb[i * Eb + ba->eb_old_of_new[e]] = binc[i * N + ba->inc_of_eb[e]];
   for (int rep = 0; rep < 2; ++rep) {
     double* dst = rep == 0 ? out->Hlp1_et : out->Hlp2_et;
     if (!dst) continue;
-    for (int r = 0; r < 3; ++r)          // dst: 3x6 (point x pose) = transpose of the stored 6x3
-      for (int c = 0; c < 6; ++c)
-        std::memcpy(dst + (size_t)(r * 6 + c) * Et, binc.data() + (size_t)(c * 3 + r) * N + Eb + rep * Et, sizeof(double) * Et);
+    const std::vector<int32_t>& inc = rep == 0 ? ba->inc1_of_et : ba->inc2_of_et;
+    for (size_t e = 0; e < Et; ++e)
+      for (int r = 0; r < 3; ++r)          // dst: 3x6 (point x pose) = transpose of the stored 6x3
+        for (int c = 0; c < 6; ++c) dst[(size_t)(r * 6 + c) * Et + ba->et_old_of_new[e]] = binc[(size_t)(c * 3 + r) * N + inc[e]];
   }
   out->chi2 = ba->h_scal[S_CHI2];
   out->robust_chi2 = ba->h_scal[S_RCHI2];
@@ -274,8 +374,15 @@ extern "C" int vdo_ba_get_estimates(vdo_ba* ba, double* pose_out, double* point_
   if (rc != VDO_OK) return rc;
   hipStream_t s = ba->ctx->stream;
   if (pose_out) hipMemcpyAsync(pose_out, ba->d.pose[0], sizeof(double) * 12 * (size_t)ba->d.P, hipMemcpyDeviceToHost, s);
-  if (point_out && ba->d.L) hipMemcpyAsync(point_out, ba->d.point[0], sizeof(double) * 3 * (size_t)ba->d.L, hipMemcpyDeviceToHost, s);
-  return sync_check(ba, "vdo_ba_get_estimates");
+  if (point_out && ba->d.L) {
+    ba->h_tmp.resize(3 * (size_t)ba->d.L);
+    hipMemcpyAsync(ba->h_tmp.data(), ba->d.point[0], sizeof(double) * 3 * (size_t)ba->d.L, hipMemcpyDeviceToHost, s);
+  }
+  rc = sync_check(ba, "vdo_ba_get_estimates");
+  if (rc != VDO_OK) return rc;
+  if (point_out)
+    for (int l = 0; l < ba->d.L; ++l) std::memcpy(point_out + 3 * (size_t)ba->pt_old_of_new[l], ba->h_tmp.data() + 3 * (size_t)l, 24);
+  return VDO_OK;
 }
 
 extern "C" int vdo_ba_set_estimates(vdo_ba* ba, const double* pose, const double* point) {
@@ -284,148 +391,11 @@ extern "C" int vdo_ba_set_estimates(vdo_ba* ba, const double* pose, const double
   if (rc != VDO_OK) return rc;
   hipStream_t s = ba->ctx->stream;
   if (pose) hipMemcpyAsync(ba->d.pose[0], pose, sizeof(double) * 12 * (size_t)ba->d.P, hipMemcpyHostToDevice, s);
-  if (point && ba->d.L) hipMemcpyAsync(ba->d.point[0], point, sizeof(double) * 3 * (size_t)ba->d.L, hipMemcpyHostToDevice, s);
+  if (point && ba->d.L) {
+    ba->h_tmp.resize(3 * (size_t)ba->d.L);
+    for (int l = 0; l < ba->d.L; ++l) std::memcpy(ba->h_tmp.data() + 3 * (size_t)l, point + 3 * (size_t)ba->pt_old_of_new[l], 24);
+    hipMemcpyAsync(ba->d.point[0], ba->h_tmp.data(), sizeof(double) * 3 * (size_t)ba->d.L, hipMemcpyHostToDevice, s);
+  }
   ba->oplus_calls = 0;
   return sync_check(ba, "vdo_ba_set_estimates");
-}
-
-namespace {
-
-// read back device scalars + flags (one sync)
-int fetch(vdo_ba* ba) {
-  hipStream_t s = ba->ctx->stream;
-  hipMemcpyAsync(ba->h_scal, ba->d.scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s);
-  hipMemcpyAsync(ba->h_flags, ba->d.flags, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, s);
-  return sync_check(ba, "LM scalar readback");
-}
-
-// computeActiveErrors + activeRobustChi2 at estimate[which]
-int robust_chi2(vdo_ba* ba, int which, double* out) {
-  launch_errors(ba->d, which, ba->ctx->stream);
-  int rc = fetch(ba);
-  if (rc != VDO_OK) return rc;
-  *out = ba->h_scal[S_RCHI2];
-  return VDO_OK;
-}
-
-// (H + lambda I) x = b  ->  xp/xl on device.  ok=false mirrors a failed Cholesky.
-int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, int* pcg_iters) {
-  const BADev& d = ba->d;
-  hipStream_t s = ba->ctx->stream;
-  launch_factor(d, lambda, s);
-  launch_reduced_rhs(d, s);
-  launch_pcg_init(d, s);
-  double tol = opt->pcg_tolerance > 0 ? opt->pcg_tolerance : 1e-10;
-  int maxit = opt->pcg_max_iterations > 0 ? opt->pcg_max_iterations : std::min(20000, 24 * d.P + 200);
-  const double tol2 = tol * tol;
-  int it = 0;
-  *ok = true;
-  while (it < maxit) {
-    const int batch = std::min(16, maxit - it);
-    for (int k = 0; k < batch; ++k) launch_pcg_iter_tol(d, lambda, tol2, d.qs, s);
-    it += batch;
-    int rc = fetch(ba);
-    if (rc != VDO_OK) return rc;
-    if (ba->h_flags[0]) { *ok = false; break; }
-    if (ba->h_flags[1] == 1) break;
-    if (ba->h_flags[1] == 2) { *ok = false; break; }
-  }
-  *pcg_iters = ba->h_flags[2];
-  return VDO_OK;
-}
-
-}  // namespace
-
-extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_stats* st) {
-  if (!ba || !opt) return set_error(VDO_ERR_INVALID, "null argument");
-  int rc = ctx_bind(ba->ctx);
-  if (rc != VDO_OK) return rc;
-  vdo_lm_stats local;
-  if (!st) st = &local;
-  std::memset(st, 0, sizeof(*st));
-  BADev& d = ba->d;
-  hipStream_t s = ba->ctx->stream;
-  const double t_begin = now_ms();
-  double lambda = -1, ni = 2;
-  int nBad = 0;
-  const double tau = 1e-5, upper = 2. / 3., lower = 1. / 3.;
-  const int maxTrials = 10;
-  bool forceStop = false, ok = true;
-  double action_lastChi = 0, chi2_check = 0, last_err_chi = 0;
-#define CK(x) do { rc = (x); if (rc != VDO_OK) return rc; } while (0)
-  CK(robust_chi2(ba, 0, &last_err_chi));
-  st->initial_chi2 = last_err_chi;
-  int it = 0;
-  for (; it < opt->max_iterations && !forceStop && ok; ++it) {
-    double t0 = now_ms();
-    launch_linearize(d, s);                 // errors + buildSystem in one sweep (same estimate)
-    if (it == 0) launch_max_diag(d, s);
-    CK(fetch(ba));
-    st->ms_linearize += now_ms() - t0;
-    last_err_chi = ba->h_scal[S_RCHI2];
-    double currentChi = last_err_chi, tempChi = currentChi;
-    const double iniChi = currentChi;
-    if (it == 0) { lambda = tau * ba->h_scal[S_MAXDIAG]; ni = 2; nBad = 0; }
-    double rho = 0;
-    int qmax = 0;
-    do {
-      t0 = now_ms();
-      bool ok2 = true;
-      int pcg_it = 0;
-      CK(solve_trial(ba, lambda, opt, &ok2, &pcg_it));
-      const bool ortho = (++ba->oplus_calls > 1000);
-      if (ortho) ba->oplus_calls = 0;
-      launch_backsub_update(d, lambda, ortho, s);      // update() into the trial buffers (push/pop = keep [0])
-      launch_errors(d, 1, s);
-      CK(fetch(ba));
-      st->ms_solve += now_ms() - t0;
-      last_err_chi = tempChi = ba->h_scal[S_RCHI2];
-      if (!ok2) tempChi = std::numeric_limits<double>::max();
-      rho = currentChi - tempChi;
-      double scale = ba->h_scal[S_SCALE] + 1e-3;
-      rho /= scale;
-      if (opt->verbose > 1)
-        std::fprintf(stderr, "  trial %d lambda=%.4g pcg=%d chi2 %.9g -> %.9g rho=%.4g\n", qmax, lambda, pcg_it, currentChi, tempChi, rho);
-      if (rho > 0 && std::isfinite(tempChi)) {
-        double alpha = 1. - std::pow((2 * rho - 1), 3);
-        alpha = std::min(alpha, upper);
-        const double sf = std::max(lower, alpha);
-        lambda *= sf; ni = 2; currentChi = tempChi;
-        std::swap(d.pose[0], d.pose[1]);               // discardTop(): accept the trial
-        std::swap(d.point[0], d.point[1]);
-      } else {
-        lambda *= ni; ni *= 2;                          // pop(): estimate[0] untouched
-      }
-      ++qmax;
-      ++st->total_trials;
-    } while (rho < 0 && qmax < maxTrials && !forceStop);
-    int result;
-    if (qmax == maxTrials || rho == 0) result = 1;
-    else {
-      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
-      result = nBad >= 3 ? 1 : 0;
-    }
-    ok = (result == 0);
-    if (!ok && st->stop_reason == 0) st->stop_reason = 1;
-    if (chi2_check < last_err_chi && it > 0) { ok = false; st->stop_reason = 2; }
-    chi2_check = last_err_chi;
-    if (opt->verbose || opt->gain_threshold >= 0) CK(robust_chi2(ba, 0, &last_err_chi));
-    if (opt->verbose)
-      std::fprintf(stderr, "iteration= %d\t chi2= %.6f\t lambda= %.6g\t levenbergIter= %d\n", it, last_err_chi, lambda, qmax);
-    if (it < VDO_LM_MAX_TRACE) { st->chi2_trace[it] = last_err_chi; st->trials_trace[it] = qmax; }
-    if (opt->gain_threshold >= 0) {
-      if (it == 0) action_lastChi = last_err_chi;
-      else {
-        const double gain = (action_lastChi - last_err_chi) / last_err_chi;
-        action_lastChi = last_err_chi;
-        if (gain >= 0 && gain < opt->gain_threshold) { forceStop = true; if (ok) st->stop_reason = 3; }
-      }
-    }
-  }
-  st->iterations = it;
-  st->final_lambda = lambda;
-  CK(robust_chi2(ba, 0, &st->final_chi2));
-  st->ms_total = now_ms() - t_begin;
-#undef CK
-  return VDO_OK;
 }
