@@ -143,6 +143,50 @@ int vdo_ba_set_estimates(vdo_ba* ba, const double* pose, const double* point);
 typedef int (*vdo_allreduce_fn)(void* user, void* device_buf, int64_t count);
 int vdo_ba_set_allreduce(vdo_ba* ba, vdo_allreduce_fn fn, void* user);
 
+/* ---- per-frame joint pose + optical-flow optimisation ------------------------------------------
+ * Replaces the g2o calls inside Optimizer::PoseOptimizationFlow2Cam (reference
+ * src/Optimizer.cc:2333-2542; camera, called from Tracking::Track src/Tracking.cc:697) and
+ * Optimizer::PoseOptimizationFlow2 (:2755-2972; one call per object, src/Tracking.cc:932):
+ * graph of 1 VertexSE3Expmap + N marginalised VertexSBAFlow, N EdgeSE3ProjectFlow2 (Huber) +
+ * N EdgeFlowPrior, BlockSolver_6_3 + LinearSolverDense, optimize(100|200), chi2 gating.
+ * The whole LM loop of a problem runs in one persistent workgroup; a batch (e.g. all objects
+ * of a frame) is one kernel launch.  All pointers are HOST pointers; values are the
+ * float->double conversions the reference performs in Converter (src/Converter.cc:25-35). */
+typedef struct vdo_flow2_problem {
+  int32_t n;              /* correspondences (TemperalMatch.size() / ObjId.size())          */
+  const double* obs;      /* [n][2] last-frame pixel (kpUn.pt)                             */
+  const double* flow;     /* [n][2] measured optical flow (initial estimate and prior)     */
+  const double* depth;    /* [n]    depth of the last-frame pixel                          */
+  double K[4];            /* fx, fy, cx, cy                                                */
+  double Twl[16];         /* 4x4 row-major: last-frame camera-to-world                     */
+  double T0[16];          /* 4x4 row-major initial estimate (mTcw / mInitModel)            */
+  double info_flow;       /* 0.1  (Optimizer.cc:2405,2827)                                 */
+  double info_prior;      /* 0.3 camera (:2440) / 0.5 object (:2863)                       */
+  double huber_delta;     /* (double)sqrtf(0.04f) (:2371,2793)                             */
+  double chi2_gate;       /* 0.04f (:2335,2757)                                            */
+  int32_t max_iterations; /* 100 camera (:2455) / 200 object (:2878)                       */
+  int32_t ref_quirks;     /* 1 = reproduce the BlockSolver_6_3 / 2-DoF aliasing;
+                             0 = mathematically intended 2x2 Schur step (not parity-comparable) */
+} vdo_flow2_problem;
+
+typedef struct vdo_flow2_result {
+  double T[16];           /* refined pose, 4x4 row-major (SE3Quat::to_homogeneous_matrix)  */
+  int32_t n_inliers;      /* nInitialCorrespondences - nBad                                */
+  int32_t iterations, trials, stop_reason;
+  double initial_chi2, final_chi2, final_lambda;
+} vdo_flow2_result;
+
+typedef struct vdo_flow2_batch vdo_flow2_batch;
+/* Upload n_problems problems (inputs become HBM-resident). */
+int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_flow2_problem* probs, vdo_flow2_batch** out);
+/* One kernel launch: every problem is optimised from its initial estimate (stream-ordered, no sync). */
+int vdo_flow2_batch_run(vdo_flow2_batch* batch);
+/* results[n_problems]; flow_out[k] -> [n_k][2] refined flows; inlier_out[k] -> [n_k] (1 = inlier). Synchronises. */
+int vdo_flow2_batch_fetch(vdo_flow2_batch* batch, vdo_flow2_result* results, double** flow_out, uint8_t** inlier_out);
+int vdo_flow2_batch_destroy(vdo_flow2_batch* batch);
+/* Convenience: create + run + fetch + destroy for a single problem. */
+int vdo_flow2_optimize(vdo_ctx* ctx, const vdo_flow2_problem* p, vdo_flow2_result* result, double* flow_out, uint8_t* inlier_out);
+
 #ifdef __cplusplus
 }
 #endif

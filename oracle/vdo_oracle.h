@@ -100,6 +100,29 @@ int64_t vdo_oracle_ba_normal_equations(const vdo_ba_graph* g, int32_t* rows, int
 /* Solve the normal equations (H + lambda I) x = b with the oracle's sparse Cholesky. */
 int vdo_oracle_ba_solve(const vdo_ba_graph* g, double lambda, double* x);
 
+/* Per-frame joint pose + optical-flow problem (Optimizer::PoseOptimizationFlow2Cam /
+ * PoseOptimizationFlow2, src/Optimizer.cc:2333-2542 / 2755-2972).  Same layout as
+ * include/vdo_slam_hip.h. */
+typedef struct vdo_flow2_problem {
+  int32_t n;              /* correspondences                                             */
+  const double* obs;      /* [n][2] last-frame pixel (kpUn.pt)                           */
+  const double* flow;     /* [n][2] measured optical flow (initial estimate + prior)     */
+  const double* depth;    /* [n]    depth of the last-frame pixel                        */
+  double K[4];            /* fx, fy, cx, cy                                              */
+  double Twl[16];         /* 4x4 row-major, last-frame camera-to-world                   */
+  double T0[16];          /* 4x4 row-major initial estimate (goes through toSE3Quat)     */
+  double info_flow;       /* 0.1                                                         */
+  double info_prior;      /* 0.3 camera / 0.5 object                                     */
+  double huber_delta;     /* (double)sqrtf(0.04f)                                        */
+  double chi2_gate;       /* 0.04f                                                       */
+  int32_t max_iterations; /* 100 camera / 200 object                                     */
+  int32_t ref_quirks;     /* 1: reproduce the BlockSolver_6_3 / 2-DoF mismatch (F3)      */
+} vdo_flow2_problem;
+
+/* returns the number of inliers (>=0) ; T_out 4x4 row-major ; flow_out [n][2] ; inlier_out [n] */
+int vdo_oracle_flow2_optimize(const vdo_flow2_problem* p, double T_out[16], double* flow_out,
+                              uint8_t* inlier_out, vdo_lm_stats* stats);
+
 /* ---- SE(3) helpers exposed for KATs --------------------------------------------*/
 void vdo_oracle_se3_exp(const double u[6], double T16[16]);            /* SE3Quat::exp */
 void vdo_oracle_iso_oplus(const double T12[12], const double d[6], double out12[12]); /* VertexSE3::oplusImpl */

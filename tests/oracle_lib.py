@@ -39,5 +39,6 @@ def load():
     L.vdo_oracle_edge_prior_jac.argtypes = [dp] * 4
     L.vdo_oracle_edge_eb_jac.argtypes = [dp] * 6
     L.vdo_oracle_edge_et_jac.argtypes = [dp] * 8
+    L.vdo_oracle_flow2_optimize.argtypes = [C.POINTER(K.Flow2ProblemC), dp, dp, K.c_uint8_p, C.POINTER(K.LMStatsC)]
     _lib = L
     return L

@@ -59,6 +59,36 @@ class LMStatsC(C.Structure):
     ]
 
 
+class Flow2ProblemC(C.Structure):
+    _fields_ = [
+        ("n", C.c_int32), ("obs", c_double_p), ("flow", c_double_p), ("depth", c_double_p),
+        ("K", C.c_double * 4), ("Twl", C.c_double * 16), ("T0", C.c_double * 16),
+        ("info_flow", C.c_double), ("info_prior", C.c_double), ("huber_delta", C.c_double),
+        ("chi2_gate", C.c_double), ("max_iterations", C.c_int32), ("ref_quirks", C.c_int32),
+    ]
+
+
+class Flow2ResultC(C.Structure):
+    _fields_ = [
+        ("T", C.c_double * 16), ("n_inliers", C.c_int32), ("iterations", C.c_int32), ("trials", C.c_int32),
+        ("stop_reason", C.c_int32), ("initial_chi2", C.c_double), ("final_chi2", C.c_double), ("final_lambda", C.c_double),
+    ]
+
+
+def flow2_to_c(p):
+    """Build the C struct for a :class:`vdo_slam_amd.synth.Flow2Problem`; returns (struct, keepalive)."""
+    obs = np.ascontiguousarray(p.obs, dtype=np.float64); flow = np.ascontiguousarray(p.flow, dtype=np.float64)
+    depth = np.ascontiguousarray(p.depth, dtype=np.float64)
+    s = Flow2ProblemC()
+    s.n = p.n; s.obs = _dp(obs); s.flow = _dp(flow); s.depth = _dp(depth)
+    s.K = (C.c_double * 4)(*p.K)
+    s.Twl = (C.c_double * 16)(*np.asarray(p.Twl, dtype=np.float64).ravel())
+    s.T0 = (C.c_double * 16)(*np.asarray(p.T0, dtype=np.float64).ravel())
+    s.info_flow = p.info_flow; s.info_prior = p.info_prior; s.huber_delta = p.huber_delta
+    s.chi2_gate = p.chi2_gate; s.max_iterations = p.max_iterations; s.ref_quirks = p.ref_quirks
+    return s, [obs, flow, depth]
+
+
 def _dp(a):
     return a.ctypes.data_as(c_double_p) if a is not None else None
 
@@ -136,9 +166,17 @@ def _declare(L):
     L.vdo_ba_optimize.argtypes = [vp, C.POINTER(LMOptionsC), C.POINTER(LMStatsC)]
     L.vdo_ba_get_estimates.argtypes = [vp, c_double_p, c_double_p]
     L.vdo_ba_set_estimates.argtypes = [vp, c_double_p, c_double_p]
+    pp_d = C.POINTER(c_double_p)
+    pp_u8 = C.POINTER(c_uint8_p)
+    L.vdo_flow2_batch_create.argtypes = [vp, C.c_int, C.POINTER(Flow2ProblemC), C.POINTER(vp)]
+    L.vdo_flow2_batch_run.argtypes = [vp]
+    L.vdo_flow2_batch_fetch.argtypes = [vp, C.POINTER(Flow2ResultC), pp_d, pp_u8]
+    L.vdo_flow2_batch_destroy.argtypes = [vp]
+    L.vdo_flow2_optimize.argtypes = [vp, C.POINTER(Flow2ProblemC), C.POINTER(Flow2ResultC), c_double_p, c_uint8_p]
     for f in ("vdo_ctx_create", "vdo_ctx_destroy", "vdo_ctx_synchronize", "vdo_ba_create", "vdo_ba_destroy",
               "vdo_ba_linearize", "vdo_ba_download_system", "vdo_ba_optimize", "vdo_ba_get_estimates",
-              "vdo_ba_set_estimates"):
+              "vdo_ba_set_estimates", "vdo_flow2_batch_create", "vdo_flow2_batch_run", "vdo_flow2_batch_fetch",
+              "vdo_flow2_batch_destroy", "vdo_flow2_optimize"):
         getattr(L, f).restype = C.c_int
 
 

@@ -1,0 +1,598 @@
+// Per-frame joint pose + optical-flow Levenberg–Marquardt on gfx950 (K16/K17 in SURVEY.md):
+// Optimizer::PoseOptimizationFlow2Cam (src/Optimizer.cc:2333-2542) and
+// Optimizer::PoseOptimizationFlow2 (:2755-2972) with g2o's
+//   EdgeSE3ProjectFlow2 / EdgeFlowPrior   g2o/types/types_six_dof_expmap.cpp:772-775,805-845
+//   VertexSE3Expmap / SE3Quat             g2o/types/types_six_dof_expmap.h:67-85, se3quat.h:41-301
+//   BlockSolver_6_3 Schur + LinearSolverDense (Eigen LDLT)   g2o/core/block_solver.hpp:354-486
+//   Levenberg + modified stop rules       g2o/core/optimization_algorithm_levenberg.cpp:61-164,
+//                                         g2o/core/sparse_optimizer.cpp:354-443
+//
+// These problems are tiny (<=~1.2k correspondences, 6 unknowns after Schur) and latency-bound
+// (SURVEY.md H4), so the WHOLE LM loop runs inside ONE persistent workgroup per problem —
+// one launch for the camera problem, one launch for all objects of a frame (grid = #objects).
+// Correspondences are strided over the 256 threads, per-landmark data stays in L2-resident
+// scratch, pose-side sums use wave shuffles + one LDS stage, the 6x6 pivoted LDLT and the SE(3)
+// update run on lane 0.  ref_quirks=1 reproduces the BlockSolver_6_3 / 2-DoF aliasing (F3)
+// exactly as analysed in oracle/flow_oracle.cpp (product code does not use the oracle).
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/vdo_slam_hip.h"
+#include "ctx.hpp"
+
+namespace vdo {
+
+#define F2_THREADS 256
+
+struct Flow2Dev {        // one problem, device pointers into the batch arrays
+  int n, max_iterations, ref_quirks, pad;
+  int64_t off;           // element offset of this problem inside the per-landmark arrays
+  double K[4], Twl[16], T0[16];
+  double info_flow, info_prior, huber_delta, huber_dsqr, chi2_gate;
+};
+
+struct Flow2Arrays {
+  const double *obs, *meas, *depth;     // [2n],[2n],[n]
+  double *Xw, *fcur, *ftry, *err, *errp, *B2, *hl, *bl, *cl, *dinv, *xl;
+  double* flow_out; unsigned char* inlier_out;
+  vdo_flow2_result* results;
+};
+
+struct Q4 { double x, y, z, w; };
+struct SE3d { Q4 r; double t[3]; };
+
+__device__ __forceinline__ void q_rotate(const Q4& q, const double* v, double* o) {
+  // Eigen _transformVector: v + w*uv + qv x uv, uv = 2 qv x v
+  double ux = q.y * v[2] - q.z * v[1], uy = q.z * v[0] - q.x * v[2], uz = q.x * v[1] - q.y * v[0];
+  ux += ux; uy += uy; uz += uz;
+  o[0] = v[0] + q.w * ux + (q.y * uz - q.z * uy);
+  o[1] = v[1] + q.w * uy + (q.z * ux - q.x * uz);
+  o[2] = v[2] + q.w * uz + (q.x * uy - q.y * ux);
+}
+__device__ Q4 q_from_R(const double* m) {   // Eigen Quaterniond(Matrix3d)
+  Q4 q;
+  double t = m[0] + m[4] + m[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0); q.w = 0.5 * t; t = 0.5 / t;
+    q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+    double c[3];
+    c[i] = 0.5 * t; t = 0.5 / t;
+    q.w = (m[3 * k + j] - m[3 * j + k]) * t;
+    c[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+    c[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    q.x = c[0]; q.y = c[1]; q.z = c[2];
+  }
+  return q;
+}
+__device__ void q_normalize_pos(Q4& q) {   // SE3Quat::normalizeRotation
+  if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+  const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+}
+__device__ void m3mul(const double* a, const double* b, double* o) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+// SE3Quat::exp(update) * T      (se3quat.h:229-262, :106-112)
+__device__ SE3d se3_exp_compose(const double* u, const SE3d& T) {
+  const double ox = u[0], oy = u[1], oz = u[2];
+  const double theta = sqrt(ox * ox + oy * oy + oz * oz);
+  const double Om[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
+  double Om2[9], R[9], V[9];
+  m3mul(Om, Om, Om2);
+  if (theta < 0.00001) {
+    for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + Om[i] + Om2[i];
+    for (int i = 0; i < 9; ++i) V[i] = R[i];
+  } else {
+    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (pow(theta, 3));
+    for (int i = 0; i < 9; ++i) {
+      const double id = (i % 4 == 0) ? 1.0 : 0.0;
+      R[i] = (id + a * Om[i]) + b * Om2[i];
+      V[i] = (id + b * Om[i]) + c * Om2[i];
+    }
+  }
+  SE3d E;
+  E.r = q_from_R(R);
+  for (int i = 0; i < 3; ++i) E.t[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
+  q_normalize_pos(E.r);
+  // E * T
+  SE3d o;
+  double rt[3];
+  q_rotate(E.r, T.t, rt);
+  for (int i = 0; i < 3; ++i) o.t[i] = E.t[i] + rt[i];
+  const Q4 &a = E.r, &b = T.r;
+  o.r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  o.r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  o.r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  o.r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  q_normalize_pos(o.r);
+  return o;
+}
+
+// Eigen::LDLT<MatrixXd,Lower> (unblocked, diagonal pivoting) for n=6; solve in place.  Returns isPositive().
+__device__ bool ldlt6_solve(double* m /*36, destroyed*/, const double* b, double* x) {
+  int tr[6];
+  int sign = 0;
+  const int n = 6;
+  for (int k = 0; k < n; ++k) {
+    int big = k;
+    double bv = fabs(m[k * 6 + k]);
+    for (int i = k + 1; i < n; ++i) if (fabs(m[i * 6 + i]) > bv) { bv = fabs(m[i * 6 + i]); big = i; }
+    tr[k] = big;
+    if (k != big) {
+      const int s = n - big - 1;
+      for (int j = 0; j < k; ++j) { const double t = m[k * 6 + j]; m[k * 6 + j] = m[big * 6 + j]; m[big * 6 + j] = t; }
+      for (int i = 0; i < s; ++i) { const double t = m[(big + 1 + i) * 6 + k]; m[(big + 1 + i) * 6 + k] = m[(big + 1 + i) * 6 + big]; m[(big + 1 + i) * 6 + big] = t; }
+      { const double t = m[k * 6 + k]; m[k * 6 + k] = m[big * 6 + big]; m[big * 6 + big] = t; }
+      for (int i = k + 1; i < big; ++i) { const double t = m[i * 6 + k]; m[i * 6 + k] = m[big * 6 + i]; m[big * 6 + i] = t; }
+    }
+    const int rs = n - k - 1;
+    if (k > 0) {
+      double temp[6];
+      for (int j = 0; j < k; ++j) temp[j] = m[j * 6 + j] * m[k * 6 + j];
+      double s = 0;
+      for (int j = 0; j < k; ++j) s += m[k * 6 + j] * temp[j];
+      m[k * 6 + k] -= s;
+      for (int i = 0; i < rs; ++i) {
+        double t = 0;
+        for (int j = 0; j < k; ++j) t += m[(k + 1 + i) * 6 + j] * temp[j];
+        m[(k + 1 + i) * 6 + k] -= t;
+      }
+    }
+    const double akk = m[k * 6 + k];
+    const bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) { sign = 0; for (int j = 0; j < n; ++j) tr[j] = j; break; }
+    if (rs > 0 && valid) for (int i = 0; i < rs; ++i) m[(k + 1 + i) * 6 + k] /= akk;
+    if (sign == 1) { if (akk < 0) sign = 2; }
+    else if (sign == -1) { if (akk > 0) sign = 2; }
+    else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = -1; }
+  }
+  if (!(sign == 1 || sign == 0)) return false;
+  for (int i = 0; i < n; ++i) x[i] = b[i];
+  for (int k = 0; k < n; ++k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) x[i] -= m[i * 6 + j] * x[j];
+  for (int i = 0; i < n; ++i) { if (fabs(m[i * 6 + i]) > 2.2250738585072014e-308) x[i] /= m[i * 6 + i]; else x[i] = 0; }
+  for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) x[i] -= m[j * 6 + i] * x[j];
+  for (int k = n - 1; k >= 0; --k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+  return true;
+}
+
+__device__ __forceinline__ void inv3_dev(const double* a, double* o) {   // Eigen fixed 3x3 inverse
+  const double C00 = a[4] * a[8] - a[5] * a[7];
+  const double C10 = a[2] * a[7] - a[1] * a[8];
+  const double C20 = a[1] * a[5] - a[2] * a[4];
+  const double det = (C00 * a[0] + C10 * a[3]) + C20 * a[6];
+  const double id = 1.0 / det;
+  o[0] = C00 * id; o[1] = C10 * id; o[2] = C20 * id;
+  o[3] = (a[5] * a[6] - a[3] * a[8]) * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+  o[6] = (a[3] * a[7] - a[4] * a[6]) * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+}
+
+__device__ __forceinline__ void huber_f2(double e, double delta, double dsqr, double& r0, double& r1) {
+  if (e <= dsqr) { r0 = e; r1 = 1.0; }
+  else { const double s = sqrt(e); r0 = 2 * s * delta - dsqr; r1 = delta / s; }
+}
+
+// block reduction of K values per thread -> out[K] in LDS (valid after return for all threads)
+template <int K>
+__device__ __forceinline__ void block_reduce(double (&v)[K], double* scratch /*[4*K]*/, double* out /*[K]*/) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    double t = v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (lane == 0) scratch[wv * K + i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) out[threadIdx.x] = (scratch[threadIdx.x] + scratch[K + threadIdx.x]) + (scratch[2 * K + threadIdx.x] + scratch[3 * K + threadIdx.x]);
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restrict__ probs, Flow2Arrays A) {
+  const Flow2Dev P = probs[blockIdx.x];
+  const int N = P.n, tid = threadIdx.x;
+  const int64_t off = P.off;
+  const double* obs = A.obs + 2 * off; const double* meas = A.meas + 2 * off; const double* depth = A.depth + off;
+  double* Xw = A.Xw + 3 * off; double* fcur = A.fcur + 2 * off; double* ftry = A.ftry + 2 * off;
+  double* err = A.err + 2 * off; double* errp = A.errp + 2 * off; double* B2 = A.B2 + 12 * off;
+  double* hl = A.hl + 4 * off; double* bl = A.bl + 2 * off; double* cl = A.cl + 2 * off + blockIdx.x;
+  double* dinv = A.dinv + 9 * off; double* xl = A.xl + 2 * off + blockIdx.x;
+  vdo_flow2_result* res = A.results + blockIdx.x;
+
+  __shared__ double s_scr[4 * 28], s_red[28];
+  __shared__ SE3d s_T, s_Tb, s_Ttry;
+  __shared__ double s_Hpp[36], s_bp[6], s_xp[6];
+  __shared__ double s_lambda, s_rho, s_chi_cur;
+  __shared__ int s_ctrl[4];   // [0] continue outer, [1] continue trial loop, [2] ok2, [3] accepted
+
+  if (N < 3) {   // nInitialCorrespondences<3 -> identity, 0 inliers (Optimizer.cc:2449-2450, 2872-2873)
+    if (tid < 16) res->T[tid] = (tid % 5 == 0) ? 1.0 : 0.0;
+    if (tid == 0) { res->n_inliers = 0; res->iterations = 0; res->trials = 0; res->stop_reason = 0; res->initial_chi2 = res->final_chi2 = res->final_lambda = 0; }
+    return;
+  }
+  const double fx = P.K[0], fy = P.K[1], cx = P.K[2], cy = P.K[3];
+  // ---- setup: Xw, flows, initial pose (Converter::toSE3Quat)
+  for (int i = tid; i < N; i += F2_THREADS) {
+    const double dz = depth[i];
+    const double x = (obs[2 * i] - cx) * dz / fx, y = (obs[2 * i + 1] - cy) * dz / fy;
+    const double* W = P.Twl;
+    Xw[3 * i] = W[0] * x + W[1] * y + W[2] * dz + W[3];
+    Xw[3 * i + 1] = W[4] * x + W[5] * y + W[6] * dz + W[7];
+    Xw[3 * i + 2] = W[8] * x + W[9] * y + W[10] * dz + W[11];
+    fcur[2 * i] = meas[2 * i]; fcur[2 * i + 1] = meas[2 * i + 1];
+    xl[2 * i] = 0.0; xl[2 * i + 1] = 0.0;
+  }
+  if (tid < 6) s_xp[tid] = 0.0;
+  if (tid == 0) {
+    const double R[9] = {P.T0[0], P.T0[1], P.T0[2], P.T0[4], P.T0[5], P.T0[6], P.T0[8], P.T0[9], P.T0[10]};
+    s_T.r = q_from_R(R);
+    q_normalize_pos(s_T.r);
+    s_T.t[0] = P.T0[3]; s_T.t[1] = P.T0[7]; s_T.t[2] = P.T0[11];
+    s_ctrl[0] = 1;
+  }
+  __syncthreads();
+
+  // errors at (T, f): writes err/errp, returns robust chi2 (block-wide)
+  auto compute_errors = [&](const SE3d& T, const double* f) -> double {
+    double part[1] = {0.0};
+    for (int i = tid; i < N; i += F2_THREADS) {
+      double pc[3];
+      q_rotate(T.r, Xw + 3 * i, pc);
+      pc[0] += T.t[0]; pc[1] += T.t[1]; pc[2] += T.t[2];
+      const double u = pc[0] / pc[2] * fx + cx, v = pc[1] / pc[2] * fy + cy;
+      const double e0 = (obs[2 * i] + f[2 * i]) - u, e1 = (obs[2 * i + 1] + f[2 * i + 1]) - v;
+      err[2 * i] = e0; err[2 * i + 1] = e1;
+      const double c = e0 * (P.info_flow * e0) + e1 * (P.info_flow * e1);
+      double r0, r1;
+      huber_f2(c, P.huber_delta, P.huber_dsqr, r0, r1);
+      const double p0 = f[2 * i] - meas[2 * i], p1 = f[2 * i + 1] - meas[2 * i + 1];
+      errp[2 * i] = p0; errp[2 * i + 1] = p1;
+      part[0] += r0 + (p0 * (P.info_prior * p0) + p1 * (P.info_prior * p1));
+    }
+    block_reduce<1>(part, s_scr, s_red);
+    const double r = s_red[0];
+    __syncthreads();
+    return r;
+  };
+
+  double lambda = -1, ni = 2;
+  int nBad = 0, it = 0, total_trials = 0, stop_reason = 0;
+  const double tau = 1e-5, upper = 2. / 3., lower = 1. / 3.;
+  double chi2_check = 0;
+  double last_err_chi = compute_errors(s_T, fcur);
+  const double initial_chi2 = last_err_chi;
+  bool ok = true;
+  for (; it < P.max_iterations && ok; ++it) {
+    last_err_chi = compute_errors(s_T, fcur);
+    double currentChi = last_err_chi, tempChi = currentChi;
+    const double iniChi = currentChi;
+    // ---- buildSystem
+    {
+      double acc[28];
+#pragma unroll
+      for (int i = 0; i < 28; ++i) acc[i] = 0.0;
+      const SE3d T = s_T;
+      for (int i = tid; i < N; i += F2_THREADS) {
+        double pc[3];
+        q_rotate(T.r, Xw + 3 * i, pc);
+        const double X = pc[0] + T.t[0], Y = pc[1] + T.t[1], Z = pc[2] + T.t[2], Z2 = Z * Z;
+        double J[12];
+        J[0] = X * Y / Z2 * fx; J[1] = -(1 + (X * X / Z2)) * fx; J[2] = Y / Z * fx; J[3] = -1. / Z * fx; J[4] = 0; J[5] = X / Z2 * fx;
+        J[6] = (1 + Y * Y / Z2) * fy; J[7] = -X * Y / Z2 * fy; J[8] = -X / Z * fy; J[9] = 0; J[10] = -1. / Z * fy; J[11] = Y / Z2 * fy;
+        const double e0 = err[2 * i], e1 = err[2 * i + 1];
+        const double c = e0 * (P.info_flow * e0) + e1 * (P.info_flow * e1);
+        double r0, r1;
+        huber_f2(c, P.huber_delta, P.huber_dsqr, r0, r1);
+        const double wo = r1 * P.info_flow;
+        const double or0 = -(P.info_flow * e0) * r1, or1 = -(P.info_flow * e1) * r1;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { B2[12 * i + 2 * a] = J[a] * wo; B2[12 * i + 2 * a + 1] = J[6 + a] * wo; }
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          acc[21 + a] += J[a] * or0 + J[6 + a] * or1;
+#pragma unroll
+          for (int c2 = 0; c2 <= a; ++c2) acc[k++] += J[a] * wo * J[c2] + J[6 + a] * wo * J[6 + c2];   // lower triangle
+        }
+        const double h = wo + P.info_prior;
+        hl[4 * i] = h; hl[4 * i + 1] = 0; hl[4 * i + 2] = 0; hl[4 * i + 3] = h;
+        bl[2 * i] = or0 - P.info_prior * errp[2 * i];
+        bl[2 * i + 1] = or1 - P.info_prior * errp[2 * i + 1];
+        acc[27] = fmax(acc[27], h);
+      }
+      // max needs its own reduction: do it through the same tree with fmax on slot 27
+      double mx[1] = {acc[27]};
+      acc[27] = 0;
+      block_reduce<28>(acc, s_scr, s_red);
+      if (tid == 0) {
+        int k = 0;
+        for (int a = 0; a < 6; ++a) for (int c2 = 0; c2 <= a; ++c2) { s_Hpp[a * 6 + c2] = s_red[k]; s_Hpp[c2 * 6 + a] = s_red[k]; ++k; }
+        for (int a = 0; a < 6; ++a) s_bp[a] = s_red[21 + a];
+      }
+      __syncthreads();
+      if (it == 0) {
+        // computeLambdaInit: max |H(j,j)| over pose and flow vertices
+        double m = mx[0];
+#pragma unroll
+        for (int off2 = 32; off2 > 0; off2 >>= 1) m = fmax(m, __shfl_down(m, off2, 64));
+        if ((tid & 63) == 0) s_scr[tid >> 6] = m;
+        __syncthreads();
+        if (tid == 0) {
+          double mm = fmax(fmax(s_scr[0], s_scr[1]), fmax(s_scr[2], s_scr[3]));
+          for (int j = 0; j < 6; ++j) mm = fmax(mm, fabs(s_Hpp[7 * j]));
+          s_lambda = tau * mm;
+        }
+        __syncthreads();
+        lambda = s_lambda; ni = 2; nBad = 0;
+        __syncthreads();
+      }
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      // ---- solve (Schur with the F3 aliasing)
+      const bool Q = P.ref_quirks != 0;
+      double acc[28];
+#pragma unroll
+      for (int i = 0; i < 28; ++i) acc[i] = 0.0;
+      for (int i = tid; i < N; i += F2_THREADS) {
+        double Di[9];
+        if (Q) {
+          const double D3[9] = {hl[4 * i] + lambda, hl[4 * i + 3], 0, hl[4 * i + 1], lambda, 0, hl[4 * i + 2], 0, lambda};
+          inv3_dev(D3, Di);
+        } else {
+          const double a0 = hl[4 * i] + lambda, a1 = hl[4 * i + 2], a2 = hl[4 * i + 1], a3 = hl[4 * i + 3] + lambda;
+          const double id = 1.0 / (a0 * a3 - a1 * a2);
+          Di[0] = a3 * id; Di[1] = -a1 * id; Di[2] = 0; Di[3] = -a2 * id; Di[4] = a0 * id; Di[5] = 0; Di[6] = 0; Di[7] = 0; Di[8] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) dinv[9 * i + k] = Di[k];
+        const double b2 = (Q && i + 1 < N) ? bl[2 * i + 2] : 0.0;
+        const double db0 = (Di[0] * bl[2 * i] + Di[1] * bl[2 * i + 1]) + Di[2] * b2;
+        const double db1 = (Di[3] * bl[2 * i] + Di[4] * bl[2 * i + 1]) + Di[5] * b2;
+        const double* B = B2 + 12 * i;
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+          acc[21 + a] += B[2 * a] * db0 + B[2 * a + 1] * db1;
+          const double bd0 = B[2 * a] * Di[0] + B[2 * a + 1] * Di[3];
+          const double bd1 = B[2 * a] * Di[1] + B[2 * a + 1] * Di[4];
+#pragma unroll
+          for (int c2 = 0; c2 <= a; ++c2) acc[k++] += bd0 * B[2 * c2] + bd1 * B[2 * c2 + 1];   // lower triangle (LDLT reads only it)
+        }
+      }
+      block_reduce<28>(acc, s_scr, s_red);
+      if (tid == 0) {
+        double Hs[36], bs[6];
+        for (int i = 0; i < 36; ++i) Hs[i] = s_Hpp[i];
+        int k = 0;
+        for (int a = 0; a < 6; ++a) for (int c2 = 0; c2 <= a; ++c2) { Hs[a * 6 + c2] -= s_red[k]; ++k; }
+        for (int j = 0; j < 6; ++j) { Hs[7 * j] += lambda; bs[j] = s_bp[j] - s_red[21 + j]; }
+        double xs[6];
+        const bool ok2 = ldlt6_solve(Hs, bs, xs);
+        s_ctrl[2] = ok2 ? 1 : 0;
+        if (ok2) for (int j = 0; j < 6; ++j) s_xp[j] = xs[j];
+        // (failed LDLT leaves x untouched in the reference; the trial is rejected anyway)
+      }
+      __syncthreads();
+      const bool ok2 = s_ctrl[2] != 0;
+      double xp[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) xp[j] = s_xp[j];
+      // ---- back-substitution: cl = bl - B^T xp
+      for (int i = tid; i < N; i += F2_THREADS) {
+        const double* B = B2 + 12 * i;
+        double t0 = 0, t1 = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { t0 += B[2 * a] * (-xp[a]); t1 += B[2 * a + 1] * (-xp[a]); }
+        cl[2 * i] = bl[2 * i] + t0; cl[2 * i + 1] = bl[2 * i + 1] + t1;
+      }
+      if (tid == 0) cl[2 * N] = 0.0;
+      __syncthreads();
+      // xl[2i..2i+1] = (Dinv_i c_i)[0..1] (+ row 2 of landmark i-1), update, scale
+      double sc[1] = {0.0};
+      for (int i = tid; i < N; i += F2_THREADS) {
+        const double* Di = dinv + 9 * i;
+        const double c0 = cl[2 * i], c1 = cl[2 * i + 1], c2 = Q ? cl[2 * i + 2] : 0.0;
+        double x0 = (Di[0] * c0 + Di[1] * c1) + Di[2] * c2;
+        const double x1 = (Di[3] * c0 + Di[4] * c1) + Di[5] * c2;
+        if (Q && i > 0) {
+          const double* Dp = dinv + 9 * (i - 1);
+          const double leak = (Dp[6] * cl[2 * i - 2] + Dp[7] * cl[2 * i - 1]) + Dp[8] * c0;
+          x0 = leak + x0;            // landmark i-1 wrote first, then landmark i added its row 0
+        }
+        if (!ok2) { x0 = xl[2 * i]; }   // stale x (reference keeps the previous content)
+        const double x1e = ok2 ? x1 : xl[2 * i + 1];
+        xl[2 * i] = x0; xl[2 * i + 1] = x1e;
+        ftry[2 * i] = fcur[2 * i] + x0; ftry[2 * i + 1] = fcur[2 * i + 1] + x1e;
+        sc[0] += x0 * (lambda * x0 + bl[2 * i]) + x1e * (lambda * x1e + bl[2 * i + 1]);
+      }
+      if (tid == 0) {
+        s_Ttry = se3_exp_compose(s_xp, s_T);
+        double s = 0;
+        for (int j = 0; j < 6; ++j) s += s_xp[j] * (lambda * s_xp[j] + s_bp[j]);
+        s_rho = s;    // pose part of computeScale
+      }
+      block_reduce<1>(sc, s_scr, s_red);
+      const double scale = (s_rho + s_red[0]) + 1e-3;
+      __syncthreads();
+      last_err_chi = tempChi = compute_errors(s_Ttry, ftry);
+      if (!ok2) tempChi = 1.7976931348623157e308;
+      rho = (currentChi - tempChi) / scale;
+      if (rho > 0 && isfinite(tempChi)) {
+        double alpha = 1. - pow((2 * rho - 1), 3);
+        alpha = fmin(alpha, upper);
+        lambda *= fmax(lower, alpha); ni = 2; currentChi = tempChi;
+        for (int i = tid; i < 2 * N; i += F2_THREADS) fcur[i] = ftry[i];   // discardTop(): accept
+        if (tid == 0) s_T = s_Ttry;
+      } else {
+        lambda *= ni; ni *= 2;                                            // pop(): keep (s_T, fcur)
+      }
+      __syncthreads();
+      ++qmax; ++total_trials;
+    } while (rho < 0 && qmax < 10);
+    int result;
+    if (qmax == 10 || rho == 0) result = 1;
+    else {
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+      result = nBad >= 3 ? 1 : 0;
+    }
+    ok = (result == 0);
+    if (!ok) stop_reason = 1;
+    if (chi2_check < last_err_chi && it > 0) { ok = false; stop_reason = 2; }
+    chi2_check = last_err_chi;
+  }
+  // ---- classification on the stored errors of the last evaluated trial (Optimizer.cc:2470-2508)
+  double cnt[1] = {0.0};
+  const float gate = (float)P.chi2_gate;
+  for (int i = tid; i < N; i += F2_THREADS) {
+    const double e0 = err[2 * i], e1 = err[2 * i + 1];
+    const float chi2 = (float)(e0 * (P.info_flow * e0) + e1 * (P.info_flow * e1));
+    const bool outl = chi2 > gate;
+    A.inlier_out[off + i] = outl ? 0 : 1;
+    cnt[0] += outl ? 0.0 : 1.0;
+    A.flow_out[2 * (off + i)] = fcur[2 * i];
+    A.flow_out[2 * (off + i) + 1] = fcur[2 * i + 1];
+  }
+  block_reduce<1>(cnt, s_scr, s_red);
+  if (tid == 0) {
+    // SE3Quat::to_homogeneous_matrix
+    const Q4 q = s_T.r;
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    double* T = res->T;
+    T[0] = 1 - (tyy + tzz); T[1] = txy - twz; T[2] = txz + twy; T[3] = s_T.t[0];
+    T[4] = txy + twz; T[5] = 1 - (txx + tzz); T[6] = tyz - twx; T[7] = s_T.t[1];
+    T[8] = txz - twy; T[9] = tyz + twx; T[10] = 1 - (txx + tyy); T[11] = s_T.t[2];
+    T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+    res->n_inliers = (int)(s_red[0] + 0.5);
+    res->iterations = it; res->trials = total_trials; res->stop_reason = stop_reason;
+    res->initial_chi2 = initial_chi2; res->final_chi2 = last_err_chi; res->final_lambda = lambda;
+  }
+}
+
+}  // namespace vdo
+
+using namespace vdo;
+
+struct vdo_flow2_batch {
+  vdo_ctx* ctx = nullptr;
+  int n_problems = 0;
+  int64_t total = 0;
+  std::vector<void*> allocs;
+  Flow2Dev* d_probs = nullptr;
+  Flow2Arrays A{};
+  std::vector<int64_t> offs;
+  std::vector<int> ns;
+};
+
+extern "C" int vdo_flow2_batch_destroy(vdo_flow2_batch* b) {
+  if (!b) return VDO_OK;
+  if (b->ctx) ctx_bind(b->ctx);
+  for (void* p : b->allocs) hipFree(p);
+  delete b;
+  return VDO_OK;
+}
+
+extern "C" int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_flow2_problem* probs, vdo_flow2_batch** out) {
+  if (!ctx || !probs || !out || n_problems <= 0) return set_error(VDO_ERR_INVALID, "vdo_flow2_batch_create: bad argument");
+  int rc = ctx_bind(ctx);
+  if (rc != VDO_OK) return rc;
+  vdo_flow2_batch* b = new vdo_flow2_batch();
+  b->ctx = ctx; b->n_problems = n_problems;
+  std::vector<Flow2Dev> hp(n_problems);
+  int64_t total = 0;
+  for (int k = 0; k < n_problems; ++k) {
+    const vdo_flow2_problem& p = probs[k];
+    if (p.n < 0 || (p.n > 0 && (!p.obs || !p.flow || !p.depth))) { delete b; return set_error(VDO_ERR_INVALID, "flow2 problem %d: null input", k); }
+    Flow2Dev& d = hp[k];
+    d.n = p.n; d.max_iterations = p.max_iterations; d.ref_quirks = p.ref_quirks; d.pad = 0; d.off = total;
+    std::memcpy(d.K, p.K, sizeof(d.K)); std::memcpy(d.Twl, p.Twl, sizeof(d.Twl)); std::memcpy(d.T0, p.T0, sizeof(d.T0));
+    d.info_flow = p.info_flow; d.info_prior = p.info_prior; d.huber_delta = p.huber_delta;
+    d.huber_dsqr = (double)(float)(p.huber_delta * p.huber_delta);     // float member, robust_kernel_impl.h:84
+    d.chi2_gate = p.chi2_gate;
+    b->offs.push_back(total); b->ns.push_back(p.n);
+    total += p.n;
+  }
+  b->total = total;
+  hipStream_t s = ctx->stream;
+  auto dev = [&](size_t bytes) -> void* {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 8;
+    if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+    b->allocs.push_back(p);
+    return p;
+  };
+  const size_t T = (size_t)total, NP = (size_t)n_problems;
+  std::vector<double> obs(2 * T), meas(2 * T), dep(T);
+  for (int k = 0; k < n_problems; ++k) {
+    const vdo_flow2_problem& p = probs[k];
+    if (p.n == 0) continue;
+    std::memcpy(obs.data() + 2 * b->offs[k], p.obs, sizeof(double) * 2 * p.n);
+    std::memcpy(meas.data() + 2 * b->offs[k], p.flow, sizeof(double) * 2 * p.n);
+    std::memcpy(dep.data() + b->offs[k], p.depth, sizeof(double) * p.n);
+  }
+  double* d_obs = (double*)dev(16 * T); double* d_meas = (double*)dev(16 * T); double* d_dep = (double*)dev(8 * T);
+  b->d_probs = (Flow2Dev*)dev(sizeof(Flow2Dev) * NP);
+  Flow2Arrays& A = b->A;
+  A.obs = d_obs; A.meas = d_meas; A.depth = d_dep;
+  A.Xw = (double*)dev(24 * T); A.fcur = (double*)dev(16 * T); A.ftry = (double*)dev(16 * T);
+  A.err = (double*)dev(16 * T); A.errp = (double*)dev(16 * T); A.B2 = (double*)dev(96 * T);
+  A.hl = (double*)dev(32 * T); A.bl = (double*)dev(16 * T + 8); A.cl = (double*)dev(16 * T + 8 * NP + 8);
+  A.dinv = (double*)dev(72 * T); A.xl = (double*)dev(16 * T + 8 * NP + 8);
+  A.flow_out = (double*)dev(16 * T); A.inlier_out = (unsigned char*)dev(T);
+  A.results = (vdo_flow2_result*)dev(sizeof(vdo_flow2_result) * NP);
+  for (void* p : b->allocs) if (!p) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  if (!A.results || !d_obs) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  hipMemcpyAsync(d_obs, obs.data(), 16 * T, hipMemcpyHostToDevice, s);
+  hipMemcpyAsync(d_meas, meas.data(), 16 * T, hipMemcpyHostToDevice, s);
+  hipMemcpyAsync(d_dep, dep.data(), 8 * T, hipMemcpyHostToDevice, s);
+  hipMemcpyAsync(b->d_probs, hp.data(), sizeof(Flow2Dev) * NP, hipMemcpyHostToDevice, s);
+  hipMemsetAsync(A.xl, 0, 16 * T + 8 * NP + 8, s);
+  if (hipStreamSynchronize(s) != hipSuccess) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_NO_DEVICE, "flow2 upload failed"); }
+  *out = b;
+  return VDO_OK;
+}
+
+extern "C" int vdo_flow2_batch_run(vdo_flow2_batch* b) {
+  if (!b) return set_error(VDO_ERR_INVALID, "null handle");
+  int rc = ctx_bind(b->ctx);
+  if (rc != VDO_OK) return rc;
+  hipLaunchKernelGGL(k_flow2_lm, dim3(b->n_problems), dim3(F2_THREADS), 0, b->ctx->stream, (const Flow2Dev*)b->d_probs, b->A);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "k_flow2_lm launch: %s", hipGetErrorString(e));
+  return VDO_OK;
+}
+
+extern "C" int vdo_flow2_batch_fetch(vdo_flow2_batch* b, vdo_flow2_result* results, double** flow_out, uint8_t** inlier_out) {
+  if (!b || !results) return set_error(VDO_ERR_INVALID, "null argument");
+  int rc = ctx_bind(b->ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = b->ctx->stream;
+  hipMemcpyAsync(results, b->A.results, sizeof(vdo_flow2_result) * b->n_problems, hipMemcpyDeviceToHost, s);
+  for (int k = 0; k < b->n_problems; ++k) {
+    if (b->ns[k] == 0) continue;
+    if (flow_out && flow_out[k]) hipMemcpyAsync(flow_out[k], b->A.flow_out + 2 * b->offs[k], sizeof(double) * 2 * b->ns[k], hipMemcpyDeviceToHost, s);
+    if (inlier_out && inlier_out[k]) hipMemcpyAsync(inlier_out[k], b->A.inlier_out + b->offs[k], b->ns[k], hipMemcpyDeviceToHost, s);
+  }
+  hipError_t e = hipStreamSynchronize(s);
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "flow2 fetch: %s", hipGetErrorString(e));
+  return VDO_OK;
+}
+
+extern "C" int vdo_flow2_optimize(vdo_ctx* ctx, const vdo_flow2_problem* p, vdo_flow2_result* result, double* flow_out, uint8_t* inlier_out) {
+  vdo_flow2_batch* b = nullptr;
+  int rc = vdo_flow2_batch_create(ctx, 1, p, &b);
+  if (rc != VDO_OK) return rc;
+  rc = vdo_flow2_batch_run(b);
+  if (rc == VDO_OK) rc = vdo_flow2_batch_fetch(b, result, &flow_out, &inlier_out);
+  vdo_flow2_batch_destroy(b);
+  return rc;
+}

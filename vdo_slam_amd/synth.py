@@ -274,3 +274,75 @@ def make_ba_graph(n_frames: int = 40, n_static: int = 2000, n_objects: int = 3,
         pr_info=(I6 * PRIOR_INFO).reshape(1, 36).copy(),
         pose_gt=pose_gt, point_gt=point_gt, n_cam=P_cam)
     return g
+
+
+# ------------------------------------------------------------------------ per-frame problems
+KITTI_K = (721.5377, 721.5377, 609.5593, 172.854)   # example/kitti-0000-0013.yaml:8-16
+KITTI_W, KITTI_H = 1242, 375
+
+
+@dataclasses.dataclass
+class Flow2Problem:
+    """Inputs of Optimizer::PoseOptimizationFlow2Cam / PoseOptimizationFlow2 (SoA, fp64 holding
+    fp32-representable values, as the reference converts cv::Mat float -> double)."""
+    obs: np.ndarray        # [n,2]
+    flow: np.ndarray       # [n,2]
+    depth: np.ndarray      # [n]
+    K: tuple
+    Twl: np.ndarray        # [4,4]
+    T0: np.ndarray         # [4,4]
+    info_flow: float = 0.1
+    info_prior: float = 0.3
+    huber_delta: float = float(np.sqrt(np.float32(0.04)))     # const float deltaMono = sqrt(rp_thres)
+    chi2_gate: float = float(np.float32(0.04))
+    max_iterations: int = 100
+    ref_quirks: int = 1
+    T_true: np.ndarray | None = None
+
+    @property
+    def n(self): return self.obs.shape[0]
+
+
+def _mat4(R, t):
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = t
+    return T
+
+
+def make_flow2_problem(n: int = 1200, seed: int = 1, is_object: bool = False, outlier_frac: float = 0.1,
+                       flow_sigma: float = 0.3, init_sigma_t: float = 0.05, init_sigma_r: float = 0.004) -> Flow2Problem:
+    """KITTI-shaped correspondences between the last and the current frame."""
+    rng = np.random.default_rng(seed)
+    fx, fy, cx, cy = KITTI_K
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    # last-frame pose T_lw (camera from world) and its inverse
+    R_lw = rotvec_to_R(rng.normal(0, 0.05, 3))
+    t_lw = rng.normal(0, 2.0, 3)
+    T_lw = f32(_mat4(R_lw, t_lw))
+    Rwl = T_lw[:3, :3].T
+    Twl = _mat4(f32(Rwl), f32(-(T_lw[:3, :3].T @ T_lw[:3, 3])))     # float arithmetic as in the reference
+    if is_object:
+        u = rng.uniform(500, 700, n); v = rng.uniform(150, 260, n); z = rng.uniform(8, 20, n)
+    else:
+        u = rng.uniform(5, KITTI_W - 5, n); v = rng.uniform(5, KITTI_H - 5, n); z = rng.uniform(4, 40, n)
+    obs = f32(np.stack([u, v], 1)); depth = f32(z)
+    Xc = np.stack([(obs[:, 0] - cx) * depth / fx, (obs[:, 1] - cy) * depth / fy, depth], 1)
+    Xw = Xc @ Twl[:3, :3].T + Twl[:3, 3]
+    # true transform applied to world points in this frame: camera motion (and object motion)
+    dR = rotvec_to_R(np.array([0.0, rng.uniform(-0.01, 0.01), 0.0]))
+    dT = _mat4(dR, np.array([rng.normal(0, 0.02), rng.normal(0, 0.01), -0.8]))
+    if is_object:
+        dT = dT @ _mat4(rotvec_to_R(np.array([0, rng.uniform(-0.03, 0.03), 0])), np.array([rng.normal(0, 0.1), 0, rng.uniform(0.2, 0.8)]))
+    T_true = dT @ T_lw
+    Xn = Xw @ T_true[:3, :3].T + T_true[:3, 3]
+    proj = np.stack([Xn[:, 0] / Xn[:, 2] * fx + cx, Xn[:, 1] / Xn[:, 2] * fy + cy], 1)
+    flow = proj - obs + rng.normal(0, flow_sigma, (n, 2))
+    outl = rng.random(n) < outlier_frac
+    flow[outl] += rng.normal(0, 5.0, (int(outl.sum()), 2))
+    T0 = T_true.copy()
+    T0[:3, :3] = rotvec_to_R(rng.normal(0, init_sigma_r, 3)) @ T0[:3, :3]
+    T0[:3, 3] += rng.normal(0, init_sigma_t, 3)
+    return Flow2Problem(obs=obs, flow=f32(flow), depth=depth, K=KITTI_K, Twl=Twl, T0=f32(T0),
+                        info_prior=0.5 if is_object else 0.3, max_iterations=200 if is_object else 100,
+                        T_true=T_true)
