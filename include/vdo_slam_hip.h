@@ -187,6 +187,57 @@ int vdo_flow2_batch_destroy(vdo_flow2_batch* batch);
 /* Convenience: create + run + fetch + destroy for a single problem. */
 int vdo_flow2_optimize(vdo_ctx* ctx, const vdo_flow2_problem* p, vdo_flow2_result* result, double* flow_out, uint8_t* inlier_out);
 
+/* ---- ORB front-end ------------------------------------------------------------------------------
+ * Replaces ORBextractor::ORBextractor (reference src/ORBextractor.cc:399-459) and
+ * ORBextractor::operator() (:1035-1110): ComputePyramid (:1112-1137), ComputeKeyPointsOctTree
+ * (:754-842: per-cell cv::FAST with threshold fallback, DistributeOctTree :528-752, IC_Angle
+ * :66-93) and the per-level 7x7 GaussianBlur (:1083-1084).  Descriptors are NOT produced: the
+ * reference never computes them (call commented out at :1091). */
+typedef struct vdo_orb_params {
+  int32_t n_features;     /* ORBextractor.nFeatures  2500 */
+  float scale_factor;     /* ORBextractor.scaleFactor 1.2 */
+  int32_t n_levels;       /* ORBextractor.nLevels    8    */
+  int32_t ini_th;         /* ORBextractor.iniThFAST  20   */
+  int32_t min_th;         /* ORBextractor.minThFAST  7    */
+} vdo_orb_params;
+
+/* SoA mirror of std::vector<cv::KeyPoint>; arrays are caller-allocated with `capacity` entries. */
+typedef struct vdo_keypoints {
+  int32_t capacity, n;
+  float *x, *y, *response, *angle, *size;
+  int32_t* octave;
+} vdo_keypoints;
+
+typedef struct vdo_orb vdo_orb;
+int vdo_orb_create(vdo_ctx* ctx, const vdo_orb_params* prm, int width, int height, vdo_orb** out);
+int vdo_orb_destroy(vdo_orb* orb);
+/* gray: 8-bit single channel, row stride `stride` bytes; host pointer unless src_is_device. */
+int vdo_orb_extract(vdo_orb* orb, const uint8_t* gray, int stride, int src_is_device, vdo_keypoints* out);
+/* Inspection of the last extraction (mvImagePyramid is a public member of the reference class). */
+int vdo_orb_level_info(vdo_orb* orb, int level, int* w, int* h, int* n_features, int* n_candidates);
+int vdo_orb_get_pyramid(vdo_orb* orb, int level, uint8_t* out_bordered /* (w+38)*(h+38) */);
+int vdo_orb_get_blurred(vdo_orb* orb, int level, uint8_t* out /* w*h */);
+int vdo_orb_get_candidates(vdo_orb* orb, int level, float* x, float* y, float* response, float* angle, int cap, int* n);
+
+/* K1: Tracking::GrabImageRGBD depth preprocessing (src/Tracking.cc:180-204), in place. */
+int vdo_depth_preprocess(vdo_ctx* ctx, float* depth, int64_t n, float bf, float depth_map_factor, int is_device);
+/* K2: cv::cvtColor(RGB2GRAY / BGR2GRAY) as called at src/Tracking.cc:209-222 (host in, host out). */
+int vdo_rgb2gray(vdo_ctx* ctx, const uint8_t* rgb, int64_t n_pixels, int channels, int rgb_order, uint8_t* gray);
+
+/* ---- Frame construction (src/Frame.cc:61-260) -------------------------------------------------*/
+typedef struct vdo_frame_images vdo_frame_images;   /* HBM-resident depth (f32), flow (2 x f32), mask (i32) */
+int vdo_frame_images_create(vdo_ctx* ctx, int width, int height, vdo_frame_images** out);
+int vdo_frame_images_upload(vdo_frame_images* f, const float* depth, const float* flow, const int32_t* mask);
+int vdo_frame_images_destroy(vdo_frame_images* f);
+/* K9: static keypoint filter of Frame::Frame (:100-128) + depth gather (:178-194); outputs in input order. */
+int vdo_frame_static_filter(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth,
+                            int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y,
+                            float* depth_out, int* n_out);
+/* K10: semi-dense object sampling (:201-228), raster order.  Pass key_x == NULL to keep results on the device. */
+int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, int step, int cap,
+                            float* key_x, float* key_y, float* corr_x, float* corr_y,
+                            float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -123,6 +123,32 @@ typedef struct vdo_flow2_problem {
 int vdo_oracle_flow2_optimize(const vdo_flow2_problem* p, double T_out[16], double* flow_out,
                               uint8_t* inlier_out, vdo_lm_stats* stats);
 
+/* ---- front-end (frontend_oracle.cpp) ------------------------------------------------------*/
+typedef struct vdo_orb_params {   /* ORBextractor ctor arguments (include/ORBextractor.h:39-40) */
+  int32_t n_features;     /* 2500 */
+  float scale_factor;     /* 1.2  */
+  int32_t n_levels;       /* 8    */
+  int32_t ini_th;         /* 20   */
+  int32_t min_th;         /* 7    */
+} vdo_orb_params;
+void vdo_oracle_depth_preprocess(float* depth, int64_t n, float bf, float factor);
+void vdo_oracle_rgb2gray(const uint8_t* rgb, int64_t n_pixels, int channels, int rgb_order, uint8_t* gray);
+int vdo_oracle_orb_level_sizes(const vdo_orb_params* p, int w, int h, int32_t* ws, int32_t* hs, int32_t* nfeat);
+int vdo_oracle_orb_pyramid(const uint8_t* gray, int w, int h, const vdo_orb_params* p, uint8_t* levels_out);
+int vdo_oracle_orb_fast_level(const uint8_t* gray, int w, int h, const vdo_orb_params* p, int level,
+                              float* x, float* y, float* resp, int cap);
+int vdo_oracle_orb_extract(const uint8_t* gray, int w, int h, const vdo_orb_params* p,
+                           float* kx, float* ky, float* kresp, float* kangle, int32_t* koct, float* ksize, int cap);
+void vdo_oracle_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst);
+int vdo_oracle_frame_static_filter(int n, const float* kx, const float* ky, const int32_t* koct,
+                                   const int32_t* mask, const float* depth, const float* flow,
+                                   int w, int h, float th_depth,
+                                   int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out);
+int vdo_oracle_frame_object_sample(const int32_t* mask, const float* depth, const float* flow, int w, int h,
+                                   float th_depth_obj, int step, int cap,
+                                   float* key_x, float* key_y, float* corr_x, float* corr_y,
+                                   float* flow_x, float* flow_y, float* depth_out, int32_t* label);
+
 /* ---- SE(3) helpers exposed for KATs --------------------------------------------*/
 void vdo_oracle_se3_exp(const double u[6], double T16[16]);            /* SE3Quat::exp */
 void vdo_oracle_iso_oplus(const double T12[12], const double d[6], double out12[12]); /* VertexSE3::oplusImpl */

@@ -40,5 +40,16 @@ def load():
     L.vdo_oracle_edge_eb_jac.argtypes = [dp] * 6
     L.vdo_oracle_edge_et_jac.argtypes = [dp] * 8
     L.vdo_oracle_flow2_optimize.argtypes = [C.POINTER(K.Flow2ProblemC), dp, dp, K.c_uint8_p, C.POINTER(K.LMStatsC)]
+    from vdo_slam_amd.frontend import OrbParamsC
+    fp, i32p, u8p = K.c_float_p, K.c_int32_p, K.c_uint8_p
+    L.vdo_oracle_depth_preprocess.argtypes = [fp, C.c_int64, C.c_float, C.c_float]
+    L.vdo_oracle_rgb2gray.argtypes = [u8p, C.c_int64, C.c_int, C.c_int, u8p]
+    L.vdo_oracle_orb_level_sizes.argtypes = [C.POINTER(OrbParamsC), C.c_int, C.c_int, i32p, i32p, i32p]
+    L.vdo_oracle_orb_pyramid.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(OrbParamsC), u8p]
+    L.vdo_oracle_orb_fast_level.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(OrbParamsC), C.c_int, fp, fp, fp, C.c_int]
+    L.vdo_oracle_orb_extract.argtypes = [u8p, C.c_int, C.c_int, C.POINTER(OrbParamsC), fp, fp, fp, fp, i32p, fp, C.c_int]
+    L.vdo_oracle_gaussian_blur7.argtypes = [u8p, C.c_int, C.c_int, u8p]
+    L.vdo_oracle_frame_static_filter.argtypes = [C.c_int, fp, fp, i32p, i32p, fp, fp, C.c_int, C.c_int, C.c_float, i32p, fp, fp, fp, fp, fp]
+    L.vdo_oracle_frame_object_sample.argtypes = [i32p, fp, fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, i32p]
     _lib = L
     return L

@@ -1,0 +1,73 @@
+"""GPU parity of the front-end kernels (K1-K7, K9, K10) against the oracle: integer / index
+outputs must be bit-exact."""
+import numpy as np
+import pytest
+
+from tests import frontend_ref as R
+from vdo_slam_amd import synth_frames as SF
+from vdo_slam_amd.synth_frames import BF, DEPTH_MAP_FACTOR, TH_DEPTH_BG, TH_DEPTH_OBJ
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from vdo_slam_amd.ba import Context
+    c = Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("seed,shape", [(3, (375, 1242)), (4, (375, 1242)), (5, (480, 640))])
+def test_orb_matches_oracle_bit_exact(ctx, oracle, seed, shape):
+    from vdo_slam_amd.frontend import ORBextractor
+    h, w = shape
+    gray = SF.make_gray(seed, w, h)
+    orb = ORBextractor(ctx, w, h)
+    kp = orb(gray)
+    ref = R.extract(oracle, gray)
+    # K3: pyramid incl. border, every level
+    for l, lv in enumerate(R.pyramid(oracle, gray)):
+        assert np.array_equal(orb.pyramid(l), lv), f"pyramid level {l}"
+    # K4: FAST candidates per level, same order
+    for l in range(8):
+        x, y, r, a = orb.candidates(l)
+        rx, ry, rr = R.fast_level(oracle, gray, l)
+        assert np.array_equal(x, rx) and np.array_equal(y, ry) and np.array_equal(r, rr), f"FAST level {l}"
+    # K5+K6: final keypoints (x, y, octave, response, size bit-exact; angle fp32 bit-exact)
+    for k in ("x", "y", "octave", "response", "size", "angle"):
+        assert np.array_equal(kp[k], ref[k]), k
+    # K7: blur of every level
+    for l in (0, 3, 7):
+        inner = R.pyramid(oracle, gray)[l][19:-19, 19:-19]
+        assert np.array_equal(orb.blurred(l), R.blur7(oracle, inner)), f"blur level {l}"
+    orb.close()
+
+
+def test_depth_gray_and_frame_kernels_match_oracle(ctx, oracle):
+    from vdo_slam_amd.frontend import FrameImages, ORBextractor, depth_preprocess, rgb2gray
+    fr = SF.make_frame(seed=9)
+    d_gpu = depth_preprocess(ctx, fr["depth_raw"], BF, DEPTH_MAP_FACTOR)
+    d_ref = fr["depth_raw"].copy()
+    oracle.vdo_oracle_depth_preprocess(R._fp(d_ref), d_ref.size, BF, DEPTH_MAP_FACTOR)
+    assert np.array_equal(d_gpu, d_ref)
+    rng = np.random.default_rng(0)
+    rgb = rng.integers(0, 256, (64, 96, 3), dtype=np.uint8)
+    g_ref = np.zeros((64, 96), np.uint8)
+    oracle.vdo_oracle_rgb2gray(R._u8(rgb), 64 * 96, 3, 1, R._u8(g_ref))
+    assert np.array_equal(rgb2gray(ctx, rgb), g_ref)
+    orb = ORBextractor(ctx, 1242, 375)
+    kp = orb(fr["gray"])
+    fi = FrameImages(ctx, 1242, 375)
+    fi.upload(d_gpu, fr["flow"], fr["mask"])
+    a = fi.static_filter(kp["x"], kp["y"], TH_DEPTH_BG)
+    b = R.static_filter(oracle, kp["x"], kp["y"], kp["octave"], fr["mask"], d_ref, fr["flow"], TH_DEPTH_BG)
+    assert a["keep_idx"].size > 300
+    for k in b:
+        assert np.array_equal(a[k], b[k]), k
+    a = fi.object_sample(TH_DEPTH_OBJ)
+    b = R.object_sample(oracle, fr["mask"], d_ref, fr["flow"], TH_DEPTH_OBJ)
+    assert a["label"].size > 100
+    for k in b:
+        assert np.array_equal(a[k], b[k]), k
+    fi.close(); orb.close()

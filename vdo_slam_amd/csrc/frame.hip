@@ -1,0 +1,240 @@
+// Frame construction kernels on gfx950 — the data-parallel part of Frame::Frame
+// (reference src/Frame.cc:61-260):
+//   K9  static keypoint filter + flow correspondence + depth gather   :100-128, :178-194
+//   K10 semi-dense object sampling, stride 4, raster order            :201-228
+// Both are ordered stream compactions: the output ORDER is part of the contract (feature
+// indices are stored in the Map and in the tracklets), so flags are scanned with wave ballots /
+// workgroup scans and written in input order — never with atomics.
+#include <cstring>
+#include <vector>
+
+#include "../../include/vdo_slam_hip.h"
+#include "ctx.hpp"
+
+namespace vdo {
+
+__device__ __forceinline__ int wave_excl_scan(int v, int lane, int* total) {
+  int incl = v;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+  *total = __shfl(incl, 63, 64);
+  return incl - v;
+}
+
+// workgroup exclusive scan (<=1024 threads); returns exclusive prefix, *total = sum. lds: int[17]
+__device__ __forceinline__ int block_excl_scan(int v, int* lds, int* total) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  int wt;
+  const int ex = wave_excl_scan(v, lane, &wt);
+  __syncthreads();
+  if (lane == 0) lds[wv] = wt;
+  __syncthreads();
+  if (threadIdx.x == 0) { int a = 0; for (int q = 0; q < nw; ++q) { const int t = lds[q]; lds[q] = a; a += t; } lds[16] = a; }
+  __syncthreads();
+  *total = lds[16];
+  return ex + lds[wv];
+}
+
+// K9.  Single workgroup (n <= a few thousand keypoints), chunks of blockDim.x in input order.
+__global__ __launch_bounds__(1024) void k_static_filter(int n, const float* __restrict__ kx, const float* __restrict__ ky,
+                                                        const int32_t* __restrict__ mask, const float* __restrict__ depth,
+                                                        const float* __restrict__ flow, int w, int h, float th_depth,
+                                                        int32_t* __restrict__ keep_idx, float* __restrict__ corr_x, float* __restrict__ corr_y,
+                                                        float* __restrict__ flow_x, float* __restrict__ flow_y, float* __restrict__ depth_out,
+                                                        int* __restrict__ n_out) {
+  __shared__ int lds[17];
+  int base_out = 0;
+  for (int base = 0; base < n; base += blockDim.x) {
+    const int i = base + threadIdx.x;
+    int keep = 0;
+    float fxe = 0, fye = 0, px = 0, py = 0, dd = 0;
+    if (i < n) {
+      px = kx[i]; py = ky[i];
+      const int x = (int)px, y = (int)py;
+      const size_t o = (size_t)y * w + x;
+      if (mask[o] == 0) {
+        const float d = depth[o];
+        if (!(d > th_depth || d <= 0)) {
+          fxe = flow[2 * o]; fye = flow[2 * o + 1];
+          if (fxe != 0 && fye != 0 && px + fxe < w && py + fye < h && px < w && py < h) { keep = 1; dd = d > 0 ? d : -1.f; }
+        }
+      }
+    }
+    int total;
+    const int pos = base_out + block_excl_scan(keep, lds, &total);
+    if (keep) {
+      keep_idx[pos] = i; corr_x[pos] = px + fxe; corr_y[pos] = py + fye; flow_x[pos] = fxe; flow_y[pos] = fye; depth_out[pos] = dd;
+    }
+    base_out += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_out = base_out;
+}
+
+// K10, pass 1: flags + per-workgroup counts.  Probe index p -> (i = (p / ncol) * step, j = (p % ncol) * step)
+__global__ __launch_bounds__(256) void k_obj_count(const int32_t* __restrict__ mask, const float* __restrict__ depth, const float* __restrict__ flow,
+                                                   int w, int h, float th_obj, int step, int ncol, int nprobe, int* __restrict__ blk_cnt) {
+  __shared__ int lds[17];
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  int keep = 0;
+  if (p < nprobe) {
+    const int i = (p / ncol) * step, j = (p % ncol) * step;
+    const size_t o = (size_t)i * w + j;
+    const float d = depth[o];
+    if (mask[o] != 0 && d < th_obj && d > 0) {
+      const float fx = flow[2 * o], fy = flow[2 * o + 1];
+      if (j + fx < w && j + fx > 0 && i + fy < h && i + fy > 0) keep = 1;
+    }
+  }
+  int total;
+  block_excl_scan(keep, lds, &total);
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = total;
+}
+// pass 2: exclusive scan of the workgroup counts (single workgroup)
+__global__ __launch_bounds__(1024) void k_scan_blocks(int* __restrict__ blk_cnt, int nblk, int* __restrict__ n_out) {
+  __shared__ int lds[17];
+  int carry = 0;
+  for (int base = 0; base < nblk; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = i < nblk ? blk_cnt[i] : 0;
+    int total;
+    const int ex = block_excl_scan(v, lds, &total);
+    if (i < nblk) blk_cnt[i] = carry + ex;
+    carry += total;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *n_out = carry;
+}
+// pass 3: ordered scatter
+__global__ __launch_bounds__(256) void k_obj_scatter(const int32_t* __restrict__ mask, const float* __restrict__ depth, const float* __restrict__ flow,
+                                                     int w, int h, float th_obj, int step, int ncol, int nprobe, const int* __restrict__ blk_off, int cap,
+                                                     float* __restrict__ key_x, float* __restrict__ key_y, float* __restrict__ corr_x, float* __restrict__ corr_y,
+                                                     float* __restrict__ flow_x, float* __restrict__ flow_y, float* __restrict__ depth_out, int32_t* __restrict__ label) {
+  __shared__ int lds[17];
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  int keep = 0, i = 0, j = 0, lab = 0;
+  float fx = 0, fy = 0, d = 0;
+  if (p < nprobe) {
+    i = (p / ncol) * step; j = (p % ncol) * step;
+    const size_t o = (size_t)i * w + j;
+    d = depth[o]; lab = mask[o];
+    if (lab != 0 && d < th_obj && d > 0) {
+      fx = flow[2 * o]; fy = flow[2 * o + 1];
+      if (j + fx < w && j + fx > 0 && i + fy < h && i + fy > 0) keep = 1;
+    }
+  }
+  int total;
+  const int pos = blk_off[blockIdx.x] + block_excl_scan(keep, lds, &total);
+  if (keep && pos < cap) {
+    flow_x[pos] = fx; flow_y[pos] = fy; corr_x[pos] = j + fx; corr_y[pos] = i + fy;
+    key_x[pos] = (float)j; key_y[pos] = (float)i; depth_out[pos] = d; label[pos] = lab;
+  }
+}
+
+}  // namespace vdo
+
+using namespace vdo;
+
+struct vdo_frame_images {
+  vdo_ctx* ctx = nullptr;
+  int w = 0, h = 0;
+  int32_t* d_mask = nullptr; float *d_depth = nullptr, *d_flow = nullptr;
+  // scratch
+  float* d_f[8] = {nullptr}; int32_t* d_i[2] = {nullptr}; int* d_cnt = nullptr; int* d_blk = nullptr;
+  int cap = 0;
+  std::vector<void*> allocs;
+};
+
+extern "C" int vdo_frame_images_destroy(vdo_frame_images* f) {
+  if (!f) return VDO_OK;
+  if (f->ctx) ctx_bind(f->ctx);
+  for (void* p : f->allocs) hipFree(p);
+  delete f;
+  return VDO_OK;
+}
+
+extern "C" int vdo_frame_images_create(vdo_ctx* ctx, int w, int h, vdo_frame_images** out) {
+  if (!ctx || !out || w <= 0 || h <= 0) return set_error(VDO_ERR_INVALID, "bad argument");
+  int rc = ctx_bind(ctx);
+  if (rc != VDO_OK) return rc;
+  vdo_frame_images* f = new vdo_frame_images();
+  f->ctx = ctx; f->w = w; f->h = h;
+  f->cap = ((w + 3) / 4) * ((h + 3) / 4) + 4096;
+  auto dev = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; f->allocs.push_back(p); return p; };
+  const size_t np = (size_t)w * h;
+  f->d_mask = (int32_t*)dev(4 * np); f->d_depth = (float*)dev(4 * np); f->d_flow = (float*)dev(8 * np);
+  for (int k = 0; k < 8; ++k) f->d_f[k] = (float*)dev(4 * (size_t)f->cap);
+  for (int k = 0; k < 2; ++k) f->d_i[k] = (int32_t*)dev(4 * (size_t)f->cap);
+  f->d_cnt = (int*)dev(16); f->d_blk = (int*)dev(4 * ((size_t)f->cap / 256 + 2));
+  for (void* p : f->allocs) if (!p) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  if (!f->d_blk) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  *out = f;
+  return VDO_OK;
+}
+
+extern "C" int vdo_frame_images_upload(vdo_frame_images* f, const float* depth, const float* flow, const int32_t* mask) {
+  if (!f) return set_error(VDO_ERR_INVALID, "null handle");
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = f->ctx->stream;
+  const size_t np = (size_t)f->w * f->h;
+  if (depth) hipMemcpyAsync(f->d_depth, depth, 4 * np, hipMemcpyHostToDevice, s);
+  if (flow) hipMemcpyAsync(f->d_flow, flow, 8 * np, hipMemcpyHostToDevice, s);
+  if (mask) hipMemcpyAsync(f->d_mask, mask, 4 * np, hipMemcpyHostToDevice, s);
+  if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "frame upload failed");
+  return VDO_OK;
+}
+
+extern "C" int vdo_frame_static_filter(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth,
+                                       int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int* n_out) {
+  if (!f || !n_out || n < 0 || n > f->cap) return set_error(VDO_ERR_INVALID, "bad argument");
+  *n_out = 0;
+  if (n == 0) return VDO_OK;
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = f->ctx->stream;
+  hipMemcpyAsync(f->d_f[6], kx, 4 * (size_t)n, hipMemcpyHostToDevice, s);
+  hipMemcpyAsync(f->d_f[7], ky, 4 * (size_t)n, hipMemcpyHostToDevice, s);
+  hipLaunchKernelGGL(k_static_filter, dim3(1), dim3(1024), 0, s, n, (const float*)f->d_f[6], (const float*)f->d_f[7], (const int32_t*)f->d_mask,
+                     (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, th_depth, f->d_i[0], f->d_f[0], f->d_f[1], f->d_f[2], f->d_f[3], f->d_f[4], f->d_cnt);
+  int m = 0;
+  hipMemcpyAsync(&m, f->d_cnt, 4, hipMemcpyDeviceToHost, s);
+  if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "static filter failed: %s", hipGetErrorString(hipGetLastError()));
+  *n_out = m;
+  if (m) {
+    hipMemcpyAsync(keep_idx, f->d_i[0], 4 * (size_t)m, hipMemcpyDeviceToHost, s);
+    float* dst[5] = {corr_x, corr_y, flow_x, flow_y, depth_out};
+    for (int k = 0; k < 5; ++k) hipMemcpyAsync(dst[k], f->d_f[k], 4 * (size_t)m, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "static filter D2H failed");
+  }
+  return VDO_OK;
+}
+
+// device-only variant used by the per-frame pipeline / bench: results stay in HBM, count is returned
+extern "C" int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, int step, int cap,
+                                       float* key_x, float* key_y, float* corr_x, float* corr_y,
+                                       float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_out) {
+  if (!f || !n_out || step <= 0) return set_error(VDO_ERR_INVALID, "bad argument");
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = f->ctx->stream;
+  const int ncol = (f->w + step - 1) / step, nrow = (f->h + step - 1) / step, nprobe = ncol * nrow;
+  const int nblk = (nprobe + 255) / 256;
+  if (nprobe > f->cap) return set_error(VDO_ERR_INVALID, "sampling step too small for the scratch capacity");
+  hipLaunchKernelGGL(k_obj_count, dim3(nblk), dim3(256), 0, s, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, th_depth_obj, step, ncol, nprobe, f->d_blk);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, f->d_blk, nblk, f->d_cnt);
+  hipLaunchKernelGGL(k_obj_scatter, dim3(nblk), dim3(256), 0, s, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, th_depth_obj, step, ncol, nprobe,
+                     (const int*)f->d_blk, f->cap, f->d_f[0], f->d_f[1], f->d_f[2], f->d_f[3], f->d_f[4], f->d_f[5], f->d_f[6], f->d_i[0]);
+  int m = 0;
+  hipMemcpyAsync(&m, f->d_cnt, 4, hipMemcpyDeviceToHost, s);
+  if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "object sampling failed: %s", hipGetErrorString(hipGetLastError()));
+  *n_out = m;
+  if (key_x) {   // host outputs requested
+    if (m > cap) return set_error(VDO_ERR_INVALID, "object sampling: %d points exceed the output capacity %d", m, cap);
+    float* dst[7] = {key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out};
+    for (int k = 0; k < 7; ++k) if (dst[k] && m) hipMemcpyAsync(dst[k], f->d_f[k], 4 * (size_t)m, hipMemcpyDeviceToHost, s);
+    if (label && m) hipMemcpyAsync(label, f->d_i[0], 4 * (size_t)m, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "object sampling D2H failed");
+  }
+  return VDO_OK;
+}

@@ -1,0 +1,709 @@
+// ORB front-end on gfx950 — replaces ORBextractor::operator() (reference src/ORBextractor.cc:1035-1110):
+//   K3 ComputePyramid          :1112-1137  cv::resize(INTER_LINEAR, 8u) from the previous level + REFLECT_101 border (19 px)
+//   K4 ComputeKeyPointsOctTree :754-818    cv::FAST(cell, thr=iniTh, NMS) with fallback minTh, per 30-px cell (+6 px overlap)
+//   K5 DistributeOctTree       :470-752    quadtree, best response per node      (host C++, sequential by nature)
+//   K6 IC_Angle                :66-93      31x31 circular patch moments + cv::fastAtan2
+//   K7 GaussianBlur 7x7 s=2    :1083-1084  executed by the reference although its consumer (BRIEF) is commented out
+// Image-sized work is HBM/L2-bound integer arithmetic: tiles are staged in LDS (cell ROI 37x37,
+// blur tile + 3-px halo), one workgroup per FAST cell over ALL pyramid levels in a single launch,
+// candidates are compacted in raster order with a workgroup scan so that the reference's feature
+// order — and therefore every downstream feature index — is reproduced exactly.
+// OpenCV 3.4 fixed-point semantics are restated (parity unpinned).
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/vdo_slam_hip.h"
+#include "ctx.hpp"
+
+namespace vdo {
+
+constexpr int kEdge = 19, kHalfPatch = 15, kPatch = 31;
+constexpr int kCellCap = 160;          // max keypoints kept per FAST cell (NMS => <= ~(37/2)^2/2)
+constexpr int kMaxCellDim = 68;        // hCell = ceil(height/nRows) < 60, +6 overlap
+
+struct LevelDesc { int w, h, bw, bh; int64_t off; int64_t off_inner; };   // bordered image at img + off
+struct CellDesc { int level, x0, y0, x1, y1, addx, addy, pad; };          // ROI in level interior coords; add = j*wCell, i*hCell
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+  if (len == 1) return 0;
+  while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * (len - 1) - p; }
+  return p;
+}
+
+// ------------------------------------------------------------------------------------ K2
+__global__ void k_rgb2gray(const uint8_t* __restrict__ src, int64_t n, int ch, int rgb_order, uint8_t* __restrict__ dst) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint8_t* p = src + i * ch;
+  const int r = rgb_order ? p[0] : p[2], g = p[1], b = rgb_order ? p[2] : p[0];
+  dst[i] = (uint8_t)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14);
+}
+
+// K1: d<0 -> 0 ; else bf / (d / factor)       (src/Tracking.cc:180-204)
+__global__ void k_depth_preprocess(float* __restrict__ d, int64_t n, float bf, float factor) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float v = d[i];
+  d[i] = v < 0 ? 0.f : bf / (v / factor);
+}
+
+// ------------------------------------------------------------------------------------ K3
+// level 0: copy + border.
+__global__ void k_border_copy(const uint8_t* __restrict__ src, int sw, int sh, int sstride, uint8_t* __restrict__ dst, int bw, int bh) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y * blockDim.y + threadIdx.y;
+  if (x >= bw || y >= bh) return;
+  dst[(size_t)y * bw + x] = src[(size_t)reflect101(y - kEdge, sh) * sstride + reflect101(x - kEdge, sw)];
+}
+// level l>0: bilinear (11-bit fixed point) from the previous level's interior, border by reflection.
+__global__ void k_resize_border(const uint8_t* __restrict__ src /*interior of level l-1*/, int sw, int sh, int sstride,
+                                uint8_t* __restrict__ dst, int dw, int dh, double scale_x, double scale_y) {
+  const int bx = blockIdx.x * blockDim.x + threadIdx.x, by = blockIdx.y * blockDim.y + threadIdx.y;
+  const int bw = dw + 2 * kEdge, bh = dh + 2 * kEdge;
+  if (bx >= bw || by >= bh) return;
+  const int dx = reflect101(bx - kEdge, dw), dy = reflect101(by - kEdge, dh);
+  float fx = (float)((dx + 0.5) * scale_x - 0.5);
+  int sx = (int)floorf(fx);
+  fx -= sx;
+  bool xedge = false;
+  if (sx < 0) { fx = 0; sx = 0; }
+  if (sx + 1 >= sw) { xedge = true; fx = 0; sx = sw - 1; }
+  const int a0 = max(-32768, min(32767, (int)rintf((1.f - fx) * 2048))), a1 = max(-32768, min(32767, (int)rintf(fx * 2048)));
+  float fy = (float)((dy + 0.5) * scale_y - 0.5);
+  int sy = (int)floorf(fy);
+  fy -= sy;
+  const int b0 = max(-32768, min(32767, (int)rintf((1.f - fy) * 2048))), b1 = max(-32768, min(32767, (int)rintf(fy * 2048)));
+  const int sy0 = min(max(sy, 0), sh - 1), sy1 = min(max(sy + 1, 0), sh - 1);
+  const uint8_t* S0 = src + (size_t)sy0 * sstride;
+  const uint8_t* S1 = src + (size_t)sy1 * sstride;
+  int r0, r1;
+  if (!xedge) { r0 = S0[sx] * a0 + S0[sx + 1] * a1; r1 = S1[sx] * a0 + S1[sx + 1] * a1; }
+  else { r0 = S0[sx] * 2048; r1 = S1[sx] * 2048; }
+  dst[(size_t)by * bw + bx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// ------------------------------------------------------------------------------------ K4
+__device__ __forceinline__ int fast_score_lds(const uint8_t* roi, int stride, int x, int y, int t) {
+  const uint8_t* c = roi + y * stride + x;
+  const int v = c[0];
+  int r[16];
+  r[0] = c[3 * stride]; r[1] = c[3 * stride + 1]; r[2] = c[2 * stride + 2]; r[3] = c[stride + 3];
+  r[4] = c[3]; r[5] = c[-stride + 3]; r[6] = c[-2 * stride + 2]; r[7] = c[-3 * stride + 1];
+  r[8] = c[-3 * stride]; r[9] = c[-3 * stride - 1]; r[10] = c[-2 * stride - 2]; r[11] = c[-stride - 3];
+  r[12] = c[-3]; r[13] = c[stride - 3]; r[14] = c[2 * stride - 2]; r[15] = c[3 * stride - 1];
+  // cheap necessary condition (opposite pairs): a 9-arc contains one pixel of every opposite pair
+  int best = -1000;
+#pragma unroll
+  for (int s = 0; s < 16; ++s) {
+    int mb = 1000, md = 1000;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) { const int q = r[(s + k) & 15]; mb = min(mb, q - v); md = min(md, v - q); }
+    best = max(best, max(mb, md));
+  }
+  return best > t ? best - 1 : 0;
+}
+
+// One workgroup per cell.  out_cnt[cell], out_pack[cell*kCellCap + k] = x | y<<12 | score<<24 (level coords rel. (16,16))
+__global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ pyr, const LevelDesc* __restrict__ levels,
+                                                    const CellDesc* __restrict__ cells, int ini_th, int min_th,
+                                                    int* __restrict__ out_cnt, uint32_t* __restrict__ out_pack) {
+  __shared__ uint8_t roi[kMaxCellDim * kMaxCellDim];
+  __shared__ uint8_t sc[kMaxCellDim * kMaxCellDim];
+  __shared__ int s_wave[4], s_total;
+  const CellDesc C = cells[blockIdx.x];
+  const LevelDesc L = levels[C.level];
+  const int w = C.x1 - C.x0, h = C.y1 - C.y0, tid = threadIdx.x;
+  const uint8_t* img = pyr + L.off_inner;     // interior origin, row stride L.bw
+  for (int i = tid; i < w * h; i += 256) { const int y = i / w, x = i - y * w; roi[y * kMaxCellDim + x] = img[(size_t)(C.y0 + y) * L.bw + (C.x0 + x)]; }
+  __syncthreads();
+  const int npix = w * h;
+  const int per = (npix + 255) / 256;          // contiguous raster chunk per thread -> ordered compaction
+  int t = ini_th;
+  for (int pass = 0; pass < 2; ++pass) {
+    for (int i = tid; i < npix; i += 256) {
+      const int y = i / w, x = i - y * w;
+      int s = 0;
+      if (x >= 3 && x < w - 3 && y >= 3 && y < h - 3 && w >= 7 && h >= 7) s = fast_score_lds(roi, kMaxCellDim, x, y, t);
+      sc[y * kMaxCellDim + x] = (uint8_t)s;
+    }
+    __syncthreads();
+    // NMS (strict > against the 8 neighbours) + count in this thread's raster chunk
+    unsigned keep = 0;
+    int cnt = 0;
+    for (int k = 0; k < per; ++k) {
+      const int i = tid * per + k;
+      if (i >= npix) break;
+      const int y = i / w, x = i - y * w;
+      const int s = sc[y * kMaxCellDim + x];
+      if (s == 0) continue;
+      const uint8_t* p = sc + y * kMaxCellDim + x;
+      if (s > p[-1] && s > p[1] && s > p[-kMaxCellDim - 1] && s > p[-kMaxCellDim] && s > p[-kMaxCellDim + 1] &&
+          s > p[kMaxCellDim - 1] && s > p[kMaxCellDim] && s > p[kMaxCellDim + 1]) { keep |= 1u << k; ++cnt; }
+    }
+    // workgroup exclusive scan of cnt
+    const int lane = tid & 63, wv = tid >> 6;
+    int incl = cnt;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    if (tid == 0) { int a = 0; for (int q = 0; q < 4; ++q) { const int v = s_wave[q]; s_wave[q] = a; a += v; } s_total = a; }
+    __syncthreads();
+    const int total = s_total;
+    if (total > 0 || pass == 1) {
+      int pos = s_wave[wv] + incl - cnt;
+      for (int k = 0; k < per; ++k) {
+        if (!(keep & (1u << k))) continue;
+        const int i = tid * per + k;
+        const int y = i / w, x = i - y * w;
+        if (pos < kCellCap)
+          out_pack[(size_t)blockIdx.x * kCellCap + pos] = (uint32_t)(x + C.addx) | ((uint32_t)(y + C.addy) << 12) | ((uint32_t)sc[y * kMaxCellDim + x] << 24);
+        ++pos;
+      }
+      if (tid == 0) out_cnt[blockIdx.x] = total;
+      return;
+    }
+    t = min_th;          // vKeysCell.empty() -> retry the whole cell with minThFAST
+    __syncthreads();
+  }
+}
+
+// exclusive scan of the per-cell counts (single workgroup) -> dense offsets, per-level totals
+__global__ __launch_bounds__(1024) void k_scan_cells(const int* __restrict__ cnt, int ncells, const int* __restrict__ cell_level,
+                                                     int nlevels, int* __restrict__ offs, int* __restrict__ level_cnt) {
+  __shared__ int s_w[16], s_carry;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  if (tid == 0) s_carry = 0;
+  if (tid < nlevels) level_cnt[tid] = 0;
+  __syncthreads();
+  for (int base = 0; base < ncells; base += 1024) {
+    const int i = base + tid;
+    const int c = i < ncells ? min(cnt[i], kCellCap) : 0;
+    int incl = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
+    if (lane == 63) s_w[wv] = incl;
+    __syncthreads();
+    if (tid == 0) { int a = s_carry; for (int q = 0; q < 16; ++q) { const int v = s_w[q]; s_w[q] = a; a += v; } s_carry = a; }
+    __syncthreads();
+    if (i < ncells) { offs[i] = s_w[wv] + incl - c; if (c) atomicAdd(&level_cnt[cell_level[i]], c); }
+    __syncthreads();
+  }
+  if (tid == 0) offs[ncells] = s_carry;
+}
+
+// umax of the circular patch (ORBextractor.cc:443-458), filled on the host
+struct UMax { int v[kHalfPatch + 2]; };
+
+// cv::fastAtan2, degrees
+__device__ __forceinline__ float fast_atan2_dev(float y, float x) {
+  const float p1 = 0.9997878412794807f * (float)(180 / M_PI), p3 = -0.3258083974640975f * (float)(180 / M_PI);
+  const float p5 = 0.1555786518463281f * (float)(180 / M_PI), p7 = -0.04432655554792128f * (float)(180 / M_PI);
+  const float ax = fabsf(x), ay = fabsf(y);
+  float a, c, c2;
+  if (ax >= ay) { c = ay / (ax + (float)2.2204460492503131e-16); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+  else { c = ax / (ay + (float)2.2204460492503131e-16); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+  if (x < 0) a = 180.f - a;
+  if (y < 0) a = 360.f - a;
+  return a;
+}
+
+// Compaction to dense arrays + K6 angle for every candidate: one wave per candidate (31 rows over the lanes).
+// dense: x,y (float, relative to (16,16)), resp, angle, level
+__global__ __launch_bounds__(256) void k_compact_angle(const uint8_t* __restrict__ pyr, const LevelDesc* __restrict__ levels,
+                                                       const CellDesc* __restrict__ cells, const int* __restrict__ cnt, const int* __restrict__ offs,
+                                                       const uint32_t* __restrict__ pack, int ncells, UMax um,
+                                                       float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oresp,
+                                                       float* __restrict__ oang, int* __restrict__ olevel) {
+  const int cell = blockIdx.x;
+  const int n = min(cnt[cell], kCellCap);
+  const int lvl = cells[cell].level;
+  const LevelDesc L = levels[lvl];
+  const uint8_t* img = pyr + L.off_inner;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int k = wv; k < n; k += 4) {
+    const uint32_t pk = pack[(size_t)cell * kCellCap + k];
+    const int x = (int)(pk & 0xfff), y = (int)((pk >> 12) & 0xfff), s = (int)(pk >> 24);
+    const int cx = x + (kEdge - 3), cy = y + (kEdge - 3);       // cvRound of integer-valued coordinates
+    // rows v = -15..15 -> lanes 0..30
+    int m10 = 0, m01 = 0;
+    if (lane < 31) {
+      const int v = lane - kHalfPatch;
+      const int d = um.v[v < 0 ? -v : v];
+      const uint8_t* row = img + (size_t)(cy + v) * L.bw + cx;
+      int rs = 0;
+      for (int u = -d; u <= d; ++u) { const int p = row[u]; m10 += u * p; rs += p; }
+      m01 = v * rs;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { m10 += __shfl_down(m10, off, 64); m01 += __shfl_down(m01, off, 64); }
+    if (lane == 0) {
+      const int o = offs[cell] + k;
+      ox[o] = (float)x; oy[o] = (float)y; oresp[o] = (float)s; olevel[o] = lvl;
+      oang[o] = fast_atan2_dev((float)m01, (float)m10);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ K7
+// 7x7 Gaussian, sigma 2, 8-bit fixed-point separable (OpenCV 3.4.0 path), REFLECT_101 at the interior edge.
+struct Blur7 { int k[7]; };
+__global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, int w, int h, int sstride, Blur7 K, uint8_t* __restrict__ dst) {
+  __shared__ uint8_t tile[38][40];
+  __shared__ int hbuf[38][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8 threads, tile 32x32
+  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
+  for (int i = threadIdx.x; i < 38 * 38; i += 256) {
+    const int yy = i / 38, xx = i - yy * 38;
+    tile[yy][xx] = src[(size_t)reflect101(y0 + yy - 3, h) * sstride + reflect101(x0 + xx - 3, w)];
+  }
+  __syncthreads();
+  for (int yy = ty; yy < 38; yy += 8) {
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s += K.k[i] * tile[yy][tx + i];
+    hbuf[yy][tx] = s;
+  }
+  __syncthreads();
+  for (int yy = ty; yy < 32; yy += 8) {
+    const int x = x0 + tx, y = y0 + yy;
+    if (x >= w || y >= h) continue;
+    int s = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) s += K.k[i] * hbuf[yy + i][tx];
+    const int v = (s + (1 << 15)) >> 16;
+    dst[(size_t)y * w + x] = (uint8_t)min(255, max(0, v));
+  }
+}
+
+// --------------------------------------------------------------------------- host: quadtree (K5)
+struct Cand { float x, y, resp, angle; };
+
+struct QNode {
+  int ULx, ULy, URx, URy, BLx, BLy, BRx, BRy;
+  std::vector<int> keys;    // indices into the candidate array
+  bool noMore = false;
+  int prev = -1, next = -1; // intrusive list (front = head)
+  bool alive = true;
+};
+
+// DistributeOctTree with an index-based intrusive list (same traversal/insert order as the
+// reference's std::list: children are pushed to the FRONT, parents erased).  Ties in the
+// "expand largest first" phase are broken by node creation order (the reference breaks them by
+// heap address).
+class QuadTree {
+ public:
+  QuadTree(const std::vector<Cand>& c) : cand(c) {}
+  void run(int minX, int maxX, int minY, int maxY, int N, std::vector<int>& out) {
+    out.clear();
+    if (cand.empty()) return;
+    const int nIni = (int)std::round((float)(maxX - minX) / (maxY - minY));
+    const float hX = (float)(maxX - minX) / nIni;
+    std::vector<int> ini(nIni);
+    for (int i = 0; i < nIni; ++i) {
+      QNode n;
+      n.ULx = (int)(hX * (float)i); n.ULy = 0; n.URx = (int)(hX * (float)(i + 1)); n.URy = 0;
+      n.BLx = n.ULx; n.BLy = maxY - minY; n.BRx = n.URx; n.BRy = maxY - minY;
+      ini[i] = push_back(n);
+    }
+    for (int k = 0; k < (int)cand.size(); ++k) nodes[ini[(int)(cand[k].x / hX)]].keys.push_back(k);
+    for (int it = head; it != -1;) {
+      const int nx = nodes[it].next;
+      if (nodes[it].keys.size() == 1) nodes[it].noMore = true;
+      else if (nodes[it].keys.empty()) erase(it);
+      it = nx;
+    }
+    bool finish = false;
+    std::vector<std::pair<int, int>> sizeAndNode;   // (size, node id); id order == creation order
+    while (!finish) {
+      int prevSize = count;
+      int nToExpand = 0;
+      sizeAndNode.clear();
+      for (int it = head; it != -1;) {
+        if (nodes[it].noMore) { it = nodes[it].next; continue; }
+        const int nx = nodes[it].next;
+        divide_and_add(it, sizeAndNode, &nToExpand);
+        erase(it);
+        it = nx;
+      }
+      if (count >= N || count == prevSize) finish = true;
+      else if (count + nToExpand * 3 > N) {
+        while (!finish) {
+          prevSize = count;
+          std::vector<std::pair<int, int>> prev = sizeAndNode;
+          sizeAndNode.clear();
+          std::sort(prev.begin(), prev.end());
+          for (int j = (int)prev.size() - 1; j >= 0; --j) {
+            divide_and_add(prev[j].second, sizeAndNode, nullptr);
+            erase(prev[j].second);
+            if (count >= N) break;
+          }
+          if (count >= N || count == prevSize) finish = true;
+        }
+      }
+    }
+    for (int it = head; it != -1; it = nodes[it].next) {
+      const std::vector<int>& ks = nodes[it].keys;
+      int best = ks[0];
+      float mr = cand[best].resp;
+      for (size_t k = 1; k < ks.size(); ++k) if (cand[ks[k]].resp > mr) { best = ks[k]; mr = cand[ks[k]].resp; }
+      out.push_back(best);
+    }
+  }
+
+ private:
+  const std::vector<Cand>& cand;
+  std::vector<QNode> nodes;
+  int head = -1, tail = -1, count = 0;
+  int push_back(const QNode& n) {
+    nodes.push_back(n);
+    const int id = (int)nodes.size() - 1;
+    nodes[id].prev = tail; nodes[id].next = -1;
+    if (tail != -1) nodes[tail].next = id; else head = id;
+    tail = id; ++count;
+    return id;
+  }
+  int push_front(const QNode& n) {
+    nodes.push_back(n);
+    const int id = (int)nodes.size() - 1;
+    nodes[id].prev = -1; nodes[id].next = head;
+    if (head != -1) nodes[head].prev = id; else tail = id;
+    head = id; ++count;
+    return id;
+  }
+  void erase(int id) {
+    QNode& n = nodes[id];
+    if (n.prev != -1) nodes[n.prev].next = n.next; else head = n.next;
+    if (n.next != -1) nodes[n.next].prev = n.prev; else tail = n.prev;
+    n.alive = false; --count;
+  }
+  void divide_and_add(int id, std::vector<std::pair<int, int>>& sizeAndNode, int* nToExpand) {
+    QNode c[4];
+    {
+      const QNode& n = nodes[id];
+      const int halfX = (int)std::ceil((float)(n.URx - n.ULx) / 2), halfY = (int)std::ceil((float)(n.BRy - n.ULy) / 2);
+      QNode &n1 = c[0], &n2 = c[1], &n3 = c[2], &n4 = c[3];
+      n1.ULx = n.ULx; n1.ULy = n.ULy; n1.URx = n.ULx + halfX; n1.URy = n.ULy; n1.BLx = n.ULx; n1.BLy = n.ULy + halfY; n1.BRx = n.ULx + halfX; n1.BRy = n.ULy + halfY;
+      n2.ULx = n1.URx; n2.ULy = n1.URy; n2.URx = n.URx; n2.URy = n.URy; n2.BLx = n1.BRx; n2.BLy = n1.BRy; n2.BRx = n.URx; n2.BRy = n.ULy + halfY;
+      n3.ULx = n1.BLx; n3.ULy = n1.BLy; n3.URx = n1.BRx; n3.URy = n1.BRy; n3.BLx = n.BLx; n3.BLy = n.BLy; n3.BRx = n1.BRx; n3.BRy = n.BLy;
+      n4.ULx = n3.URx; n4.ULy = n3.URy; n4.URx = n2.BRx; n4.URy = n2.BRy; n4.BLx = n3.BRx; n4.BLy = n3.BRy; n4.BRx = n.BRx; n4.BRy = n.BRy;
+      for (int k : n.keys) {
+        const Cand& kp = cand[k];
+        if (kp.x < n1.URx) { if (kp.y < n1.BRy) n1.keys.push_back(k); else n3.keys.push_back(k); }
+        else if (kp.y < n1.BRy) n2.keys.push_back(k);
+        else n4.keys.push_back(k);
+      }
+      for (int q = 0; q < 4; ++q) if (c[q].keys.size() == 1) c[q].noMore = true;
+    }
+    for (int q = 0; q < 4; ++q) {
+      if (c[q].keys.empty()) continue;
+      const int nid = push_front(c[q]);
+      if (nodes[nid].keys.size() > 1) {
+        if (nToExpand) ++*nToExpand;
+        sizeAndNode.push_back(std::make_pair((int)nodes[nid].keys.size(), nid));
+      }
+    }
+  }
+};
+
+}  // namespace vdo
+
+using namespace vdo;
+
+struct vdo_orb {
+  vdo_ctx* ctx = nullptr;
+  vdo_orb_params prm{};
+  int w = 0, h = 0, ncells = 0;
+  std::vector<LevelDesc> levels;
+  std::vector<CellDesc> cells;
+  std::vector<int> cell_level, nfeat;
+  std::vector<float> scale;
+  UMax um{};
+  Blur7 blur{};
+  // device
+  std::vector<void*> allocs;
+  uint8_t *d_src = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
+  LevelDesc* d_levels = nullptr; CellDesc* d_cells = nullptr; int* d_cell_level = nullptr;
+  int *d_cnt = nullptr, *d_offs = nullptr, *d_level_cnt = nullptr; uint32_t* d_pack = nullptr;
+  float *d_x = nullptr, *d_y = nullptr, *d_resp = nullptr, *d_ang = nullptr; int* d_lvl = nullptr;
+  int64_t pyr_bytes = 0, blur_bytes = 0;
+  int dense_cap = 0;
+  // host mirrors of the last extraction
+  std::vector<float> hx, hy, hresp, hang; std::vector<int> hlvl, hoffs, hlevel_cnt;
+  int n_cand = 0;
+};
+
+extern "C" int vdo_orb_destroy(vdo_orb* o) {
+  if (!o) return VDO_OK;
+  if (o->ctx) ctx_bind(o->ctx);
+  for (void* p : o->allocs) hipFree(p);
+  delete o;
+  return VDO_OK;
+}
+
+extern "C" int vdo_orb_create(vdo_ctx* ctx, const vdo_orb_params* prm, int w, int h, vdo_orb** out) {
+  if (!ctx || !prm || !out || w < 64 || h < 64 || prm->n_levels < 1 || prm->n_levels > 16 || !(prm->scale_factor > 1.f))
+    return set_error(VDO_ERR_INVALID, "vdo_orb_create: bad argument");
+  int rc = ctx_bind(ctx);
+  if (rc != VDO_OK) return rc;
+  vdo_orb* o = new vdo_orb();
+  o->ctx = ctx; o->prm = *prm; o->w = w; o->h = h;
+  const int NL = prm->n_levels;
+  // scale tables, level sizes (ORBextractor ctor :403-419, ComputePyramid :1116-1117)
+  o->scale.resize(NL);
+  o->scale[0] = 1.0f;
+  for (int i = 1; i < NL; ++i) o->scale[i] = o->scale[i - 1] * prm->scale_factor;
+  o->levels.resize(NL);
+  int64_t off = 0, boff = 0;
+  for (int l = 0; l < NL; ++l) {
+    const float inv = 1.0f / o->scale[l];
+    LevelDesc& L = o->levels[l];
+    L.w = (int)lrintf((float)w * inv); L.h = (int)lrintf((float)h * inv);
+    L.bw = L.w + 2 * kEdge; L.bh = L.h + 2 * kEdge;
+    L.off = off; L.off_inner = off + (int64_t)kEdge * L.bw + kEdge;
+    off += (int64_t)L.bw * L.bh;
+    boff += (int64_t)L.w * L.h;
+    if (L.w < 2 * kEdge + 8 || L.h < 2 * kEdge + 8) { delete o; return set_error(VDO_ERR_UNSUPPORTED, "pyramid level %d too small (%dx%d)", l, L.w, L.h); }
+  }
+  o->pyr_bytes = off; o->blur_bytes = boff;
+  // features per level (:424-435)
+  o->nfeat.resize(NL);
+  {
+    float factor = 1.0f / prm->scale_factor;
+    float nd = prm->n_features * (1 - factor) / (1 - (float)std::pow((double)factor, (double)NL));
+    int sum = 0;
+    for (int l = 0; l < NL - 1; ++l) { o->nfeat[l] = (int)lrintf(nd); sum += o->nfeat[l]; nd *= factor; }
+    o->nfeat[NL - 1] = std::max(prm->n_features - sum, 0);
+  }
+  // FAST cells (:760-796)
+  for (int l = 0; l < NL; ++l) {
+    const LevelDesc& L = o->levels[l];
+    const float W = 30;
+    const int minBX = kEdge - 3, minBY = minBX, maxBX = L.w - kEdge + 3, maxBY = L.h - kEdge + 3;
+    const float width = (float)(maxBX - minBX), height = (float)(maxBY - minBY);
+    const int nCols = (int)(width / W), nRows = (int)(height / W);
+    if (nCols <= 0 || nRows <= 0) continue;
+    const int wCell = (int)std::ceil(width / nCols), hCell = (int)std::ceil(height / nRows);
+    for (int i = 0; i < nRows; ++i) {
+      const float iniY = (float)(minBY + i * hCell);
+      float maxY = iniY + hCell + 6;
+      if (iniY >= maxBY - 3) continue;
+      if (maxY > maxBY) maxY = (float)maxBY;
+      for (int j = 0; j < nCols; ++j) {
+        const float iniX = (float)(minBX + j * wCell);
+        float maxX = iniX + wCell + 6;
+        if (iniX >= maxBX - 6) continue;
+        if (maxX > maxBX) maxX = (float)maxBX;
+        CellDesc c{l, (int)iniX, (int)iniY, (int)maxX, (int)maxY, j * wCell, i * hCell, 0};
+        if (c.x1 - c.x0 > kMaxCellDim || c.y1 - c.y0 > kMaxCellDim) { delete o; return set_error(VDO_ERR_INTERNAL, "FAST cell larger than %d px", kMaxCellDim); }
+        o->cells.push_back(c);
+        o->cell_level.push_back(l);
+      }
+    }
+  }
+  o->ncells = (int)o->cells.size();
+  // umax (:443-458)
+  {
+    int* umax = o->um.v;
+    int v, v0;
+    const int vmax = (int)std::floor(kHalfPatch * std::sqrt(2.f) / 2 + 1);
+    const int vmin = (int)std::ceil(kHalfPatch * std::sqrt(2.f) / 2);
+    const double hp2 = kHalfPatch * kHalfPatch;
+    for (v = 0; v <= vmax; ++v) umax[v] = (int)lrint(std::sqrt(hp2 - v * v));
+    for (v = kHalfPatch, v0 = 0; v >= vmin; --v) { while (umax[v0] == umax[v0 + 1]) ++v0; umax[v] = v0; ++v0; }
+  }
+  // Gaussian kernel 7, sigma 2 -> 8-bit fixed point
+  {
+    double kd[7], sum = 0;
+    for (int i = 0; i < 7; ++i) { const double x = i - 3; kd[i] = std::exp(-0.5 / 4.0 * x * x); sum += kd[i]; }
+    for (int i = 0; i < 7; ++i) o->blur.k[i] = (int)lrint((double)(float)(kd[i] / sum) * 256);
+  }
+  hipStream_t s = ctx->stream;
+  auto dev = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes ? bytes : 8) != hipSuccess) return nullptr; o->allocs.push_back(p); return p; };
+  o->dense_cap = o->ncells * kCellCap;
+  o->d_src = (uint8_t*)dev((size_t)w * h * 4);
+  o->d_pyr = (uint8_t*)dev(o->pyr_bytes); o->d_blur = (uint8_t*)dev(o->blur_bytes);
+  o->d_levels = (LevelDesc*)dev(sizeof(LevelDesc) * NL); o->d_cells = (CellDesc*)dev(sizeof(CellDesc) * o->ncells);
+  o->d_cell_level = (int*)dev(4 * (size_t)o->ncells);
+  o->d_cnt = (int*)dev(4 * (size_t)o->ncells); o->d_offs = (int*)dev(4 * ((size_t)o->ncells + 1)); o->d_level_cnt = (int*)dev(4 * 16);
+  o->d_pack = (uint32_t*)dev(4 * (size_t)o->dense_cap);
+  o->d_x = (float*)dev(4 * (size_t)o->dense_cap); o->d_y = (float*)dev(4 * (size_t)o->dense_cap);
+  o->d_resp = (float*)dev(4 * (size_t)o->dense_cap); o->d_ang = (float*)dev(4 * (size_t)o->dense_cap); o->d_lvl = (int*)dev(4 * (size_t)o->dense_cap);
+  for (void* p : o->allocs) if (!p) { vdo_orb_destroy(o); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  if (!o->d_lvl) { vdo_orb_destroy(o); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  hipMemcpyAsync(o->d_levels, o->levels.data(), sizeof(LevelDesc) * NL, hipMemcpyHostToDevice, s);
+  hipMemcpyAsync(o->d_cells, o->cells.data(), sizeof(CellDesc) * o->ncells, hipMemcpyHostToDevice, s);
+  hipMemcpyAsync(o->d_cell_level, o->cell_level.data(), 4 * (size_t)o->ncells, hipMemcpyHostToDevice, s);
+  if (hipStreamSynchronize(s) != hipSuccess) { vdo_orb_destroy(o); return set_error(VDO_ERR_NO_DEVICE, "orb upload failed"); }
+  *out = o;
+  return VDO_OK;
+}
+
+// Device part of operator(): pyramid, blur, FAST cells, compaction + angles.  gray_dev: device, row stride `stride`.
+static int orb_device_stage(vdo_orb* o, const uint8_t* gray_dev, int stride) {
+  hipStream_t s = o->ctx->stream;
+  const int NL = o->prm.n_levels;
+  const dim3 tb(32, 8);
+  {
+    const LevelDesc& L = o->levels[0];
+    hipLaunchKernelGGL(k_border_copy, dim3((L.bw + 31) / 32, (L.bh + 7) / 8), tb, 0, s, gray_dev, L.w, L.h, stride, o->d_pyr + L.off, L.bw, L.bh);
+  }
+  for (int l = 1; l < NL; ++l) {
+    const LevelDesc &P = o->levels[l - 1], &L = o->levels[l];
+    const double sx = 1. / ((double)L.w / P.w), sy = 1. / ((double)L.h / P.h);
+    hipLaunchKernelGGL(k_resize_border, dim3((L.bw + 31) / 32, (L.bh + 7) / 8), tb, 0, s, (const uint8_t*)(o->d_pyr + P.off_inner), P.w, P.h, P.bw,
+                       o->d_pyr + L.off, L.w, L.h, sx, sy);
+  }
+  hipLaunchKernelGGL(k_fast_cells, dim3(o->ncells), dim3(256), 0, s, (const uint8_t*)o->d_pyr, (const LevelDesc*)o->d_levels, (const CellDesc*)o->d_cells,
+                     o->prm.ini_th, o->prm.min_th, o->d_cnt, o->d_pack);
+  hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, s, (const int*)o->d_cnt, o->ncells, (const int*)o->d_cell_level, NL, o->d_offs, o->d_level_cnt);
+  hipLaunchKernelGGL(k_compact_angle, dim3(o->ncells), dim3(256), 0, s, (const uint8_t*)o->d_pyr, (const LevelDesc*)o->d_levels, (const CellDesc*)o->d_cells,
+                     (const int*)o->d_cnt, (const int*)o->d_offs, (const uint32_t*)o->d_pack, o->ncells, o->um, o->d_x, o->d_y, o->d_resp, o->d_ang, o->d_lvl);
+  // K7: the reference blurs every non-empty level (result unused since BRIEF is commented out)
+  int64_t boff = 0;
+  for (int l = 0; l < NL; ++l) {
+    const LevelDesc& L = o->levels[l];
+    hipLaunchKernelGGL(k_blur7, dim3((L.w + 31) / 32, (L.h + 31) / 32), dim3(256), 0, s, (const uint8_t*)(o->d_pyr + L.off_inner), L.w, L.h, L.bw, o->blur, o->d_blur + boff);
+    boff += (int64_t)L.w * L.h;
+  }
+  return VDO_OK;
+}
+
+extern "C" int vdo_orb_extract(vdo_orb* o, const uint8_t* gray, int stride, int src_is_device, vdo_keypoints* out) {
+  if (!o || !gray || !out) return set_error(VDO_ERR_INVALID, "vdo_orb_extract: null argument");
+  int rc = ctx_bind(o->ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = o->ctx->stream;
+  const uint8_t* src = gray;
+  int sstride = stride;
+  if (!src_is_device) {
+    hipMemcpy2DAsync(o->d_src, o->w, gray, stride, o->w, o->h, hipMemcpyHostToDevice, s);
+    src = o->d_src; sstride = o->w;
+  }
+  orb_device_stage(o, src, sstride);
+  // candidates -> host
+  o->hoffs.resize(o->ncells + 1); o->hlevel_cnt.resize(16);
+  hipMemcpyAsync(o->hoffs.data(), o->d_offs, 4 * ((size_t)o->ncells + 1), hipMemcpyDeviceToHost, s);
+  hipMemcpyAsync(o->hlevel_cnt.data(), o->d_level_cnt, 4 * 16, hipMemcpyDeviceToHost, s);
+  if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "orb device stage failed: %s", hipGetErrorString(hipGetLastError()));
+  const int total = o->hoffs[o->ncells];
+  o->n_cand = total;
+  o->hx.resize(total); o->hy.resize(total); o->hresp.resize(total); o->hang.resize(total); o->hlvl.resize(total);
+  if (total) {
+    hipMemcpyAsync(o->hx.data(), o->d_x, 4 * (size_t)total, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(o->hy.data(), o->d_y, 4 * (size_t)total, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(o->hresp.data(), o->d_resp, 4 * (size_t)total, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(o->hang.data(), o->d_ang, 4 * (size_t)total, hipMemcpyDeviceToHost, s);
+    hipMemcpyAsync(o->hlvl.data(), o->d_lvl, 4 * (size_t)total, hipMemcpyDeviceToHost, s);
+    if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "orb D2H failed");
+  }
+  // K5 on the host, level by level (candidates of a level are contiguous: cells are level-major)
+  int n = 0, pos = 0;
+  const int NL = o->prm.n_levels;
+  for (int l = 0; l < NL; ++l) {
+    const int cnt = o->hlevel_cnt[l];
+    std::vector<Cand> c(cnt);
+    for (int k = 0; k < cnt; ++k) c[k] = Cand{o->hx[pos + k], o->hy[pos + k], o->hresp[pos + k], o->hang[pos + k]};
+    pos += cnt;
+    std::vector<int> sel;
+    const LevelDesc& L = o->levels[l];
+    const int minB = kEdge - 3;
+    QuadTree qt(c);
+    qt.run(minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, o->nfeat[l], sel);
+    const int patch = (int)(kPatch * o->scale[l]);
+    for (int id : sel) {
+      if (n >= out->capacity) return set_error(VDO_ERR_INVALID, "vdo_orb_extract: keypoint capacity %d too small", out->capacity);
+      float x = c[id].x + minB, y = c[id].y + minB;
+      if (l != 0) { x = x * o->scale[l]; y = y * o->scale[l]; }
+      out->x[n] = x; out->y[n] = y; out->response[n] = c[id].resp; out->angle[n] = c[id].angle;
+      out->octave[n] = l; out->size[n] = (float)patch;
+      ++n;
+    }
+  }
+  out->n = n;
+  return VDO_OK;
+}
+
+extern "C" int vdo_orb_level_info(vdo_orb* o, int level, int* w, int* h, int* n_features, int* n_candidates) {
+  if (!o || level < 0 || level >= o->prm.n_levels) return set_error(VDO_ERR_INVALID, "bad level");
+  if (w) *w = o->levels[level].w;
+  if (h) *h = o->levels[level].h;
+  if (n_features) *n_features = o->nfeat[level];
+  if (n_candidates) *n_candidates = o->hlevel_cnt.empty() ? 0 : o->hlevel_cnt[level];
+  return VDO_OK;
+}
+
+// mvImagePyramid[level] with its 19-px border: (w+38) x (h+38) bytes
+extern "C" int vdo_orb_get_pyramid(vdo_orb* o, int level, uint8_t* out_bordered) {
+  if (!o || !out_bordered || level < 0 || level >= o->prm.n_levels) return set_error(VDO_ERR_INVALID, "bad argument");
+  int rc = ctx_bind(o->ctx);
+  if (rc != VDO_OK) return rc;
+  const LevelDesc& L = o->levels[level];
+  if (hipMemcpy(out_bordered, o->d_pyr + L.off, (size_t)L.bw * L.bh, hipMemcpyDeviceToHost) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "D2H failed");
+  return VDO_OK;
+}
+
+extern "C" int vdo_orb_get_blurred(vdo_orb* o, int level, uint8_t* out) {
+  if (!o || !out || level < 0 || level >= o->prm.n_levels) return set_error(VDO_ERR_INVALID, "bad argument");
+  int rc = ctx_bind(o->ctx);
+  if (rc != VDO_OK) return rc;
+  int64_t boff = 0;
+  for (int l = 0; l < level; ++l) boff += (int64_t)o->levels[l].w * o->levels[l].h;
+  const LevelDesc& L = o->levels[level];
+  if (hipMemcpy(out, o->d_blur + boff, (size_t)L.w * L.h, hipMemcpyDeviceToHost) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "D2H failed");
+  return VDO_OK;
+}
+
+// FAST candidates of the last extraction for one level (reference push order; relative to (16,16))
+extern "C" int vdo_orb_get_candidates(vdo_orb* o, int level, float* x, float* y, float* resp, float* angle, int cap, int* n) {
+  if (!o || !n || level < 0 || level >= o->prm.n_levels || o->hlevel_cnt.empty()) return set_error(VDO_ERR_INVALID, "bad argument / no extraction yet");
+  int pos = 0;
+  for (int l = 0; l < level; ++l) pos += o->hlevel_cnt[l];
+  const int cnt = o->hlevel_cnt[level];
+  *n = cnt;
+  for (int k = 0; k < cnt && k < cap; ++k) {
+    if (x) x[k] = o->hx[pos + k];
+    if (y) y[k] = o->hy[pos + k];
+    if (resp) resp[k] = o->hresp[pos + k];
+    if (angle) angle[k] = o->hang[pos + k];
+  }
+  return VDO_OK;
+}
+
+extern "C" int vdo_depth_preprocess(vdo_ctx* ctx, float* depth, int64_t n, float bf, float factor, int is_device) {
+  if (!ctx || !depth || n <= 0) return set_error(VDO_ERR_INVALID, "bad argument");
+  int rc = ctx_bind(ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = ctx->stream;
+  float* d = depth;
+  if (!is_device) {
+    if (hipMalloc((void**)&d, 4 * (size_t)n) != hipSuccess) return set_error(VDO_ERR_OOM, "hipMalloc failed");
+    hipMemcpyAsync(d, depth, 4 * (size_t)n, hipMemcpyHostToDevice, s);
+  }
+  hipLaunchKernelGGL(k_depth_preprocess, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, n, bf, factor);
+  if (!is_device) {
+    hipMemcpyAsync(depth, d, 4 * (size_t)n, hipMemcpyDeviceToHost, s);
+    hipStreamSynchronize(s);
+    hipFree(d);
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "depth preprocess: %s", hipGetErrorString(e));
+  return VDO_OK;
+}
+
+extern "C" int vdo_rgb2gray(vdo_ctx* ctx, const uint8_t* rgb, int64_t n_pixels, int channels, int rgb_order, uint8_t* gray) {
+  if (!ctx || !rgb || !gray || n_pixels <= 0 || (channels != 3 && channels != 4)) return set_error(VDO_ERR_INVALID, "bad argument");
+  int rc = ctx_bind(ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = ctx->stream;
+  uint8_t *ds = nullptr, *dd = nullptr;
+  if (hipMalloc((void**)&ds, (size_t)n_pixels * channels) != hipSuccess || hipMalloc((void**)&dd, (size_t)n_pixels) != hipSuccess) { if (ds) hipFree(ds); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  hipMemcpyAsync(ds, rgb, (size_t)n_pixels * channels, hipMemcpyHostToDevice, s);
+  hipLaunchKernelGGL(k_rgb2gray, dim3((unsigned)((n_pixels + 255) / 256)), dim3(256), 0, s, (const uint8_t*)ds, n_pixels, channels, rgb_order, dd);
+  hipMemcpyAsync(gray, dd, (size_t)n_pixels, hipMemcpyDeviceToHost, s);
+  hipError_t e = hipStreamSynchronize(s);
+  hipFree(ds); hipFree(dd);
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "rgb2gray: %s", hipGetErrorString(e));
+  return VDO_OK;
+}

@@ -1,0 +1,164 @@
+"""Host-side mirrors of ``ORBextractor`` and the data-parallel part of ``Frame::Frame``
+(thin ctypes wrappers; all compute in libvdo_hip.so)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi as K
+
+
+class OrbParamsC(C.Structure):
+    _fields_ = [("n_features", C.c_int32), ("scale_factor", C.c_float), ("n_levels", C.c_int32),
+                ("ini_th", C.c_int32), ("min_th", C.c_int32)]
+
+
+class KeypointsC(C.Structure):
+    _fields_ = [("capacity", C.c_int32), ("n", C.c_int32), ("x", K.c_float_p), ("y", K.c_float_p),
+                ("response", K.c_float_p), ("angle", K.c_float_p), ("size", K.c_float_p), ("octave", K.c_int32_p)]
+
+
+def _fp(a): return a.ctypes.data_as(K.c_float_p)
+def _ip(a): return a.ctypes.data_as(K.c_int32_p)
+def _u8(a): return a.ctypes.data_as(K.c_uint8_p)
+
+
+_declared = False
+
+
+def _lib():
+    global _declared
+    L = K.lib()
+    if not _declared:
+        vp = C.c_void_p
+        ip = C.POINTER(C.c_int)
+        L.vdo_orb_create.argtypes = [vp, C.POINTER(OrbParamsC), C.c_int, C.c_int, C.POINTER(vp)]
+        L.vdo_orb_destroy.argtypes = [vp]
+        L.vdo_orb_extract.argtypes = [vp, K.c_uint8_p, C.c_int, C.c_int, C.POINTER(KeypointsC)]
+        L.vdo_orb_level_info.argtypes = [vp, C.c_int, ip, ip, ip, ip]
+        L.vdo_orb_get_pyramid.argtypes = [vp, C.c_int, K.c_uint8_p]
+        L.vdo_orb_get_blurred.argtypes = [vp, C.c_int, K.c_uint8_p]
+        L.vdo_orb_get_candidates.argtypes = [vp, C.c_int, K.c_float_p, K.c_float_p, K.c_float_p, K.c_float_p, C.c_int, ip]
+        L.vdo_depth_preprocess.argtypes = [vp, K.c_float_p, C.c_int64, C.c_float, C.c_float, C.c_int]
+        L.vdo_rgb2gray.argtypes = [vp, K.c_uint8_p, C.c_int64, C.c_int, C.c_int, K.c_uint8_p]
+        L.vdo_frame_images_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+        L.vdo_frame_images_upload.argtypes = [vp, K.c_float_p, K.c_float_p, K.c_int32_p]
+        L.vdo_frame_images_destroy.argtypes = [vp]
+        L.vdo_frame_static_filter.argtypes = [vp, C.c_int, K.c_float_p, K.c_float_p, C.c_float, K.c_int32_p] + [K.c_float_p] * 5 + [ip]
+        L.vdo_frame_object_sample.argtypes = [vp, C.c_float, C.c_int, C.c_int] + [K.c_float_p] * 7 + [K.c_int32_p, ip]
+        _declared = True
+    return L
+
+
+class ORBextractor:
+    """``ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST)`` (include/ORBextractor.h:39-40)."""
+
+    def __init__(self, ctx, width, height, nfeatures=2500, scale_factor=1.2, nlevels=8, ini_th=20, min_th=7):
+        self.ctx = ctx
+        self.params = OrbParamsC(nfeatures, scale_factor, nlevels, ini_th, min_th)
+        self.w, self.h, self.nlevels = width, height, nlevels
+        self._h = C.c_void_p()
+        K.check(_lib().vdo_orb_create(ctx._h, C.byref(self.params), width, height, C.byref(self._h)))
+
+    def __call__(self, gray: np.ndarray, capacity=None):
+        gray = np.ascontiguousarray(gray, dtype=np.uint8)
+        cap = capacity or (self.params.n_features + 256)
+        a = {k: np.zeros(cap, np.float32) for k in ("x", "y", "response", "angle", "size")}
+        octave = np.zeros(cap, np.int32)
+        kp = KeypointsC(cap, 0, _fp(a["x"]), _fp(a["y"]), _fp(a["response"]), _fp(a["angle"]), _fp(a["size"]), _ip(octave))
+        K.check(_lib().vdo_orb_extract(self._h, _u8(gray), gray.shape[1], 0, C.byref(kp)))
+        n = kp.n
+        out = {k: v[:n].copy() for k, v in a.items()}
+        out["octave"] = octave[:n].copy()
+        return out
+
+    def level_info(self, level):
+        w, h, nf, nc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
+        K.check(_lib().vdo_orb_level_info(self._h, level, C.byref(w), C.byref(h), C.byref(nf), C.byref(nc)))
+        return w.value, h.value, nf.value, nc.value
+
+    def pyramid(self, level):
+        w, h, _, _ = self.level_info(level)
+        out = np.zeros((h + 38, w + 38), np.uint8)
+        K.check(_lib().vdo_orb_get_pyramid(self._h, level, _u8(out)))
+        return out
+
+    def blurred(self, level):
+        w, h, _, _ = self.level_info(level)
+        out = np.zeros((h, w), np.uint8)
+        K.check(_lib().vdo_orb_get_blurred(self._h, level, _u8(out)))
+        return out
+
+    def candidates(self, level):
+        _, _, _, nc = self.level_info(level)
+        cap = max(nc, 1)
+        x, y, r, a = (np.zeros(cap, np.float32) for _ in range(4))
+        n = C.c_int()
+        K.check(_lib().vdo_orb_get_candidates(self._h, level, _fp(x), _fp(y), _fp(r), _fp(a), cap, C.byref(n)))
+        return x[:n.value], y[:n.value], r[:n.value], a[:n.value]
+
+    def close(self):
+        if self._h:
+            _lib().vdo_orb_destroy(self._h); self._h = C.c_void_p()
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
+
+
+def depth_preprocess(ctx, depth: np.ndarray, bf: float, factor: float) -> np.ndarray:
+    d = np.ascontiguousarray(depth, dtype=np.float32).copy()
+    K.check(_lib().vdo_depth_preprocess(ctx._h, _fp(d), d.size, bf, factor, 0))
+    return d
+
+
+def rgb2gray(ctx, rgb: np.ndarray, rgb_order=True) -> np.ndarray:
+    rgb = np.ascontiguousarray(rgb, dtype=np.uint8)
+    out = np.zeros(rgb.shape[:2], np.uint8)
+    K.check(_lib().vdo_rgb2gray(ctx._h, _u8(rgb), out.size, rgb.shape[2], 1 if rgb_order else 0, _u8(out)))
+    return out
+
+
+class FrameImages:
+    """Depth / flow / mask of one frame resident in HBM + the Frame::Frame kernels over them."""
+
+    def __init__(self, ctx, width, height):
+        self.ctx, self.w, self.h = ctx, width, height
+        self._h = C.c_void_p()
+        K.check(_lib().vdo_frame_images_create(ctx._h, width, height, C.byref(self._h)))
+
+    def upload(self, depth, flow, mask):
+        depth = np.ascontiguousarray(depth, dtype=np.float32); flow = np.ascontiguousarray(flow, dtype=np.float32)
+        mask = np.ascontiguousarray(mask, dtype=np.int32)
+        K.check(_lib().vdo_frame_images_upload(self._h, _fp(depth), _fp(flow), _ip(mask)))
+
+    def static_filter(self, kx, ky, th_depth):
+        kx = np.ascontiguousarray(kx, dtype=np.float32); ky = np.ascontiguousarray(ky, dtype=np.float32)
+        n = kx.size
+        idx = np.zeros(n, np.int32)
+        f = [np.zeros(n, np.float32) for _ in range(5)]
+        m = C.c_int()
+        K.check(_lib().vdo_frame_static_filter(self._h, n, _fp(kx), _fp(ky), th_depth, _ip(idx), *[_fp(a) for a in f], C.byref(m)))
+        m = m.value
+        return dict(keep_idx=idx[:m], corr_x=f[0][:m], corr_y=f[1][:m], flow_x=f[2][:m], flow_y=f[3][:m], depth=f[4][:m])
+
+    def object_sample(self, th_depth_obj, step=4):
+        cap = ((self.w + step - 1) // step) * ((self.h + step - 1) // step)
+        f = [np.zeros(cap, np.float32) for _ in range(7)]
+        lab = np.zeros(cap, np.int32)
+        m = C.c_int()
+        K.check(_lib().vdo_frame_object_sample(self._h, th_depth_obj, step, cap, *[_fp(a) for a in f], _ip(lab), C.byref(m)))
+        m = m.value
+        names = ("key_x", "key_y", "corr_x", "corr_y", "flow_x", "flow_y", "depth")
+        out = {k: a[:m] for k, a in zip(names, f)}
+        out["label"] = lab[:m]
+        return out
+
+    def close(self):
+        if self._h:
+            _lib().vdo_frame_images_destroy(self._h); self._h = C.c_void_p()
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
