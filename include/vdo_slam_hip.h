@@ -228,6 +228,8 @@ int vdo_rgb2gray(vdo_ctx* ctx, const uint8_t* rgb, int64_t n_pixels, int channel
 typedef struct vdo_frame_images vdo_frame_images;   /* HBM-resident depth (f32), flow (2 x f32), mask (i32) */
 int vdo_frame_images_create(vdo_ctx* ctx, int width, int height, vdo_frame_images** out);
 int vdo_frame_images_upload(vdo_frame_images* f, const float* depth, const float* flow, const int32_t* mask);
+int vdo_frame_images_upload_device(vdo_frame_images* f, const float* depth_dev, const float* flow_dev, const int32_t* mask_dev);
+int vdo_frame_images_depth_preprocess(vdo_frame_images* f, float bf, float depth_map_factor);   /* K1 in place, resident image */
 int vdo_frame_images_destroy(vdo_frame_images* f);
 /* K9: static keypoint filter of Frame::Frame (:100-128) + depth gather (:178-194); outputs in input order. */
 int vdo_frame_static_filter(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth,

@@ -11,7 +11,10 @@
 //   pose    [P][12]      AoS (R row-major | t); few, L2-resident
 //   point   [L][3]       AoS, tile-major: read once per tile, coalesced
 //   edges   SoA, tile-major: key int32 (pose-slot<<16 | local point), z [3][E], w [E]
-//   Binc    [18][Ninc]   SoA 6x3 pose-x-point block per incidence, written once per sweep
+//   Finc    [4][Eb+Et]   SoA FACTORED pose-x-point blocks, written once per sweep.  Every 6x3 block of
+//           Hpl is  s*we*[ I ; k[c]x ] * (R^T or I)  with c = the point in the pose's frame (zc resp.
+//           v = H^-1 p2) and R the pose rotation, so (we, c) + the L2-resident pose reproduce it
+//           exactly: 32 B/edge instead of 144 B, both for the sweep's write and for every PCG mat-vec.
 //   part_*  [k][NPS]     per-(tile,pose-slot) partial sums (NPS = total slots)
 #pragma once
 #include <hip/hip_runtime.h>
@@ -56,7 +59,8 @@ struct BADev {
   // linear system
   double *Hpp = nullptr, *bp = nullptr;              // [P][36], [P][6]
   double *Hll = nullptr, *bl = nullptr;              // [L][9],  [L][3]
-  double* Binc = nullptr;                            // [18][Ninc]
+  double* Finc = nullptr;                            // [4][Eb+Et] factored pose-landmark blocks: (we, c.x, c.y, c.z)
+  double* Binc = nullptr;                            // [18][Ninc] explicit 6x3 blocks — only materialised for vdo_ba_download_system
   double* Oll = nullptr;                             // [9][Et]  p1 x p2 blocks
   double* Hpp_ep = nullptr;                          // [Ep][36]
   double* part_sums = nullptr;                       // [32][NPS] sweep partials (16 binary + 16 ternary)
@@ -86,5 +90,6 @@ void launch_reduced_rhs(const BADev& d, hipStream_t s);
 void launch_pcg_init(const BADev& d, hipStream_t s);
 void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s);
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s);
+void launch_expand_binc(const BADev& d, hipStream_t s);            // Finc -> explicit Binc (download/debug only)
 
 }  // namespace vdo

@@ -122,9 +122,48 @@ __device__ bool spd6_inv(const double* A, double* Ainv) {
   return ok;
 }
 
-__device__ __forceinline__ void load_block(const double* Binc, int64_t idx, int64_t N, double (&B)[18]) {
+// Factored pose-landmark block (ba_dev.hpp): F = (we, c).  kind 0: EdgeSE3PointXYZ, 1: ternary (H,p1), 2: ternary (H,p2).
+//   kind 0:  B = -we [ I ; 2[c]x ] Rt        kind 1:  B = we [ I ; [c]x ]        kind 2:  B = -we [ I ; [c]x ] Rt
+// (Rt = R^T of the pose vertex, row-major).
+struct FInc { double we, cx, cy, cz; };
+__device__ __forceinline__ FInc load_f(const double* __restrict__ Finc, int64_t idx, int64_t NF) {
+  return FInc{Finc[idx], Finc[NF + idx], Finc[2 * NF + idx], Finc[3 * NF + idx]};
+}
+// explicit 6x3 block (row-major 18) — used by the preconditioner and the debug expansion
+__device__ __forceinline__ void expand_block(int kind, const FInc& f, const double* Rt, double (&B)[18]) {
+  if (kind == 1) {
+    B[0] = f.we; B[1] = 0; B[2] = 0; B[3] = 0; B[4] = f.we; B[5] = 0; B[6] = 0; B[7] = 0; B[8] = f.we;
+    B[9] = 0; B[10] = -f.we * f.cz; B[11] = f.we * f.cy;
+    B[12] = f.we * f.cz; B[13] = 0; B[14] = -f.we * f.cx;
+    B[15] = -f.we * f.cy; B[16] = f.we * f.cx; B[17] = 0;
+    return;
+  }
+  const double s2 = (kind == 0 ? -2.0 : -1.0) * f.we;
 #pragma unroll
-  for (int i = 0; i < 18; ++i) B[i] = Binc[i * N + idx];
+  for (int j = 0; j < 3; ++j) {
+    const double a = Rt[j], b = Rt[3 + j], cc = Rt[6 + j];   // column j of Rt
+    B[0 * 3 + j] = -f.we * a;
+    B[1 * 3 + j] = -f.we * b;
+    B[2 * 3 + j] = -f.we * cc;
+    B[3 * 3 + j] = s2 * (f.cy * cc - f.cz * b);
+    B[4 * 3 + j] = s2 * (f.cz * a - f.cx * cc);
+    B[5 * 3 + j] = s2 * (f.cx * b - f.cy * a);
+  }
+}
+// incidence li of a tile -> (kind, index into Finc)
+__device__ __forceinline__ void inc_locate(const Tile& T, int li, int64_t Eb, int& kind, int64_t& fidx) {
+  const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
+  if (li < nb) { kind = 0; fidx = T.eb_begin + li; }
+  else if (li < nb + nt) { kind = 1; fidx = Eb + T.et_begin + (li - nb); }
+  else { kind = 2; fidx = Eb + T.et_begin + (li - nb - nt); }
+}
+// stage R^T of every pose slot of the tile into LDS (9 doubles per slot)
+__device__ __forceinline__ void stage_slot_rt(const BADev& d, const Tile& T, double* slotR) {
+  const int nslot = T.slot_end - T.slot_begin;
+  for (int i = threadIdx.x; i < 9 * nslot; i += blockDim.x) {
+    const int sidx = i / 9, k = i - 9 * sidx;
+    slotR[i] = d.pose[0][12 * (int64_t)d.tile_pose[T.slot_begin + sidx] + 3 * (k % 3) + (k / 3)];   // transpose
+  }
 }
 
 // out(6x6 upper, 21 values) += B1 G B2^T (+ transpose if sym2) ; helper computing full 6x6 product
@@ -146,11 +185,13 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   const Tile T = d.tiles[blockIdx.x];
   const int nslot = T.slot_end - T.slot_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
-  double* accm = smem;   // [21 * nslot]
+  double* accm = smem;                       // [21 * S]
+  double* slotR = accm + 21 * d.max_slots;   // [9 * S]
   const int tid = threadIdx.x;
   for (int i = tid; i < 21 * nslot; i += VDO_TILE_THREADS) accm[i] = 0.0;
+  stage_slot_rt(d, T, slotR);
   __syncthreads();
-  const int64_t N = d.Ninc;
+  const int64_t NF = (int64_t)d.Eb + d.Et;
   for (int base = 0; base < nb; base += VDO_TILE_THREADS) {
     const int j = base + tid;
     int slot = -1;
@@ -163,7 +204,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
       slot = key >> 16;
       const int64_t l = T.pt_begin + (key & 0xffff);
       double B[18], M[36];
-      load_block(d.Binc, idx, N, B);
+      expand_block(0, load_f(d.Finc, T.eb_begin + j, NF), slotR + 9 * slot, B);
       bgbt(B, d.Gdiag + 9 * l, B, M);
       int k = 0;
 #pragma unroll
@@ -171,7 +212,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
 #pragma unroll
         for (int c = r; c < 6; ++c) up[k++] = M[6 * r + c];
     }
-    seg_reduce_to_lds<21>(up, slot, accm, 21);
+    seg_apply16<21>(up, seg_ctl16(slot), accm + 21 * (slot >= 0 ? slot : 0));
   }
   for (int base = 0; base < nt; base += VDO_TILE_THREADS) {
     const int j = base + tid;
@@ -185,8 +226,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
       slot = k1 >> 16;
       const int64_t l1 = T.pt_begin + (k1 & 0xffff), l2 = T.pt_begin + (k2 & 0xffff);
       double B1[18], B2[18], M11[36], M12[36], M22[36];
-      load_block(d.Binc, i1, N, B1);
-      load_block(d.Binc, i2, N, B2);
+      const FInc f = load_f(d.Finc, (int64_t)d.Eb + T.et_begin + j, NF);
+      expand_block(1, f, slotR + 9 * slot, B1);
+      expand_block(2, f, slotR + 9 * slot, B2);
       bgbt(B1, d.Gdiag + 9 * l1, B1, M11);
       bgbt(B1, d.Goff + 9 * l2, B2, M12);     // [Hll^-1]_{l1,l2}, l2 = l1 + 1 in chain order
       bgbt(B2, d.Gdiag + 9 * l2, B2, M22);
@@ -196,7 +238,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
 #pragma unroll
         for (int c = r; c < 6; ++c) up[k++] = M11[6 * r + c] + M22[6 * r + c] + M12[6 * r + c] + M12[6 * c + r];
     }
-    seg_reduce_to_lds<21>(up, slot, accm, 21);
+    seg_apply16<21>(up, seg_ctl16(slot), accm + 21 * (slot >= 0 ? slot : 0));
   }
   __syncthreads();
   const int64_t NPS = d.NPS;
@@ -237,8 +279,10 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
   double* gl = dinv + 9 * VDO_TILE_PTS;    // [9*TP]  G_k
   double* vs = gl + 9 * VDO_TILE_PTS;      // [6*S]
   double* qs = vs + 6 * d.max_slots;       // [6*S]
+  double* slotR = qs + 6 * d.max_slots;    // [9*S]  R^T of the pose slots
   const int tid = threadIdx.x;
   for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) u[i] = 0.0;
+  stage_slot_rt(d, T, slotR);
   {   // coalesced staging of the chain factors (read once per tile, used by the serial chain solves)
     const double* gd = d.Dinv + 9 * (int64_t)T.pt_begin;
     const double* gg = d.Gl + 9 * (int64_t)T.pt_begin;
@@ -248,33 +292,37 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) vs[i] = v[6 * (int64_t)d.tile_pose[T.slot_begin + i / 6] + i % 6];
   if (MODE != 2)
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) qs[i] = 0.0;
-  // incidence blocks in registers
-  double B[3][18];
-  int key[3];
-  const int64_t N = d.Ninc;
+  // factored incidence blocks in registers (4 doubles each)
+  FInc F[3];
+  int key[3], kind[3];
+  const int64_t NF = (int64_t)d.Eb + d.Et;
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int li = tid + VDO_TILE_THREADS * j;
-    key[j] = -1;
+    key[j] = -1; kind[j] = 1;
+    F[j] = FInc{0, 0, 0, 0};
     if (li < ninc) {
       key[j] = d.inc_key[T.inc_begin + li];
-      load_block(d.Binc, T.inc_begin + li, N, B[j]);
-    } else {
-#pragma unroll
-      for (int i = 0; i < 18; ++i) B[j][i] = 0.0;
+      int64_t fidx;
+      inc_locate(T, li, d.Eb, kind[j], fidx);
+      F[j] = load_f(d.Finc, fidx, NF);
     }
   }
   __syncthreads();
-  if (MODE != 1) {   // pass A: u_l += B^T v_slot
+  if (MODE != 1) {   // pass A: u_l += B^T v_slot = sgn*we * (I or R) (vt - s c x vr)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       if (key[j] >= 0) {
-        const double* pv = vs + 6 * (key[j] >> 16);
-        double t0 = 0, t1 = 0, t2 = 0;
-#pragma unroll
-        for (int r = 0; r < 6; ++r) { t0 += B[j][3 * r] * pv[r]; t1 += B[j][3 * r + 1] * pv[r]; t2 += B[j][3 * r + 2] * pv[r]; }
+        const int sl = key[j] >> 16;
+        const double* pv = vs + 6 * sl;
+        const double s = kind[j] == 0 ? 2.0 : 1.0;
+        const FInc f = F[j];
+        const D3 t{pv[0] - s * (f.cy * pv[5] - f.cz * pv[4]), pv[1] - s * (f.cz * pv[3] - f.cx * pv[5]), pv[2] - s * (f.cx * pv[4] - f.cy * pv[3])};
+        D3 o;
+        if (kind[j] == 1) o = f.we * t;
+        else o = (-f.we) * rotT(slotR + 9 * sl, t);        // R t  (slotR holds R^T)
         double* ul = u + 3 * (key[j] & 0xffff);
-        atomicAdd(ul, t0); atomicAdd(ul + 1, t1); atomicAdd(ul + 2, t2);
+        atomicAdd(ul, o.x); atomicAdd(ul + 1, o.y); atomicAdd(ul + 2, o.z);
       }
     }
     __syncthreads();
@@ -313,10 +361,17 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
   for (int j = 0; j < 3; ++j) {
     double q[6];
     const double* wl = u + 3 * (key[j] >= 0 ? (key[j] & 0xffff) : 0);
-    const double w0 = wl[0], w1 = wl[1], w2 = wl[2];
-#pragma unroll
-    for (int r = 0; r < 6; ++r) q[r] = B[j][3 * r] * w0 + B[j][3 * r + 1] * w1 + B[j][3 * r + 2] * w2;
-    seg_reduce_to_lds<6>(q, key[j] >= 0 ? (key[j] >> 16) : -1, qs, 6);
+    const int sl = key[j] >= 0 ? (key[j] >> 16) : 0;
+    const FInc f = F[j];
+    D3 y{wl[0], wl[1], wl[2]};
+    if (kind[j] != 1) y = rot(slotR + 9 * sl, y);          // R^T w
+    const double sg = kind[j] == 1 ? f.we : -f.we, s = kind[j] == 0 ? 2.0 : 1.0;
+    q[0] = sg * y.x; q[1] = sg * y.y; q[2] = sg * y.z;
+    q[3] = sg * s * (f.cy * y.z - f.cz * y.y);
+    q[4] = sg * s * (f.cz * y.x - f.cx * y.z);
+    q[5] = sg * s * (f.cx * y.y - f.cy * y.x);
+    const int skey = key[j] >= 0 ? (key[j] >> 16) : -1;
+    seg_apply16<6>(q, seg_ctl16(skey), qs + 6 * (skey >= 0 ? skey : 0));
   }
   __syncthreads();
   const int64_t NPS = d.NPS;
@@ -470,15 +525,39 @@ __global__ __launch_bounds__(1024) void k_update(BADev d, double lambda, int ort
   if (threadIdx.x == 0) d.scal[S_SCALE] = acc;
 }
 
+// Finc -> explicit 6x3 blocks Binc[18][Ninc] (download / debugging only; never on the solve path)
+__global__ __launch_bounds__(VDO_TILE_THREADS) void k_expand_binc(BADev d) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const Tile T = d.tiles[blockIdx.x];
+  const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, ninc = nb + 2 * nt;
+  double* slotR = smem;
+  stage_slot_rt(d, T, slotR);
+  __syncthreads();
+  const int64_t NF = (int64_t)d.Eb + d.Et, N = d.Ninc;
+  for (int li = threadIdx.x; li < ninc; li += VDO_TILE_THREADS) {
+    int kind; int64_t fidx;
+    inc_locate(T, li, d.Eb, kind, fidx);
+    const int sl = d.inc_key[T.inc_begin + li] >> 16;
+    double B[18];
+    expand_block(kind, load_f(d.Finc, fidx, NF), slotR + 9 * sl, B);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) d.Binc[i * N + T.inc_begin + li] = B[i];
+  }
+}
+
 // ------------------------------------------------------------------------------ launchers
-static size_t schur_lds(const BADev& d) { return (21 * VDO_TILE_PTS + 12 * (size_t)d.max_slots) * sizeof(double); }
+static size_t schur_lds(const BADev& d) { return (21 * VDO_TILE_PTS + 21 * (size_t)d.max_slots) * sizeof(double); }
+
+void launch_expand_binc(const BADev& d, hipStream_t s) {
+  if (d.n_tiles) hipLaunchKernelGGL(k_expand_binc, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), 9 * (size_t)d.max_slots * sizeof(double), s, d);
+}
 
 void launch_max_diag(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(1024), 0, s, d); }
 
 void launch_factor(const BADev& d, double lambda, hipStream_t s) {
   hipMemsetAsync(d.flags, 0, 4 * sizeof(int32_t), s);
   if (d.n_chains) hipLaunchKernelGGL(k_factor_chains, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, lambda);
-  if (d.n_tiles) hipLaunchKernelGGL(k_precond_tile, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), 21 * (size_t)d.max_slots * sizeof(double), s, d);
+  if (d.n_tiles) hipLaunchKernelGGL(k_precond_tile, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), 30 * (size_t)d.max_slots * sizeof(double), s, d);
   hipLaunchKernelGGL(k_precond_finalize, dim3((d.P + 3) / 4), dim3(256), 0, s, d, lambda);
 }
 

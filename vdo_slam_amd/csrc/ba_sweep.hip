@@ -32,6 +32,17 @@ __host__ __device__ inline size_t sweep_lds_doubles(int max_slots, bool build) {
   return 3 * VDO_TILE_PTS + (build ? 9 * VDO_TILE_PTS : 0) + 18 * (size_t)max_slots + (build ? 32 * (size_t)max_slots : 0) + 24;
 }
 
+// The 16 running sums of one edge (we, we*c, we*c c^T, we*e, we*c x e), segment-reduced over the
+// wave 4 at a time (values are produced just-in-time to keep the register footprint small).
+__device__ __forceinline__ void pose_sums(double we, D3 c, D3 er, int slot, double* accpose_base) {
+  const SegCtl16 sc = seg_ctl16(slot);
+  double* dst = accpose_base + 32 * (slot >= 0 ? slot : 0);
+  { double g[4] = {we, we * c.x, we * c.y, we * c.z}; seg_apply16<4>(g, sc, dst); }
+  { double g[4] = {we * c.x * c.x, we * c.x * c.y, we * c.x * c.z, we * c.y * c.y}; seg_apply16<4>(g, sc, dst + 4); }
+  { double g[4] = {we * c.y * c.z, we * c.z * c.z, we * er.x, we * er.y}; seg_apply16<4>(g, sc, dst + 8); }
+  { double g[4] = {we * er.z, we * (c.y * er.z - c.z * er.y), we * (c.z * er.x - c.x * er.z), we * (c.x * er.y - c.y * er.x)}; seg_apply16<4>(g, sc, dst + 12); }
+}
+
 template <bool BUILD>
 __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int which) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
@@ -68,15 +79,14 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   }
   __syncthreads();
   double chi = 0.0, rchi = 0.0;
-  const int64_t Eb = d.Eb, Et = d.Et, N = d.Ninc;
+  const int64_t Eb = d.Eb, Et = d.Et, NF = d.Eb + d.Et;
   // ------------------------------------------------------------------ EdgeSE3PointXYZ
   for (int base = T.eb_begin; base < T.eb_end; base += VDO_TILE_THREADS) {
     const int e = base + tid;
     const bool valid = e < T.eb_end;
     int slot = -1;
-    double acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    double we = 0.0;
+    D3 zc{0, 0, 0}, er{0, 0, 0};
     if (valid) {
       const int key = d.eb_key[e];
       slot = key >> 16;
@@ -85,53 +95,34 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
       const D3 z{d.eb_z[e], d.eb_z[Eb + e], d.eb_z[2 * Eb + e]};
       const double* Wp = slotW + 18 * slot;   // W.r = R^T = Jl (row-major), W.t
       const D3 p{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
-      const D3 zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
-      const D3 er = zc - z;
+      zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
+      er = zc - z;
       const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
       double rho0, rho1;
       huber(c2, d.huber_eb, d.dsqr_eb, rho0, rho1);
       chi += c2; rchi += rho0;
       if (BUILD) {
-        const double we = w * rho1;
-        // 6x3 block: rows 0..2 = -we*Jl ; rows 3..5 = -we * 2[zc]x * Jl
-        double* B = d.Binc + (T.inc_begin + (e - T.eb_begin));
-        const double s2 = -2.0 * we;
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const double a = Wp[j], b = Wp[3 + j], cc = Wp[6 + j];   // column j of Jl
-          B[(0 * 3 + j) * N] = -we * a;
-          B[(1 * 3 + j) * N] = -we * b;
-          B[(2 * 3 + j) * N] = -we * cc;
-          B[(3 * 3 + j) * N] = s2 * (zc.y * cc - zc.z * b);
-          B[(4 * 3 + j) * N] = s2 * (zc.z * a - zc.x * cc);
-          B[(5 * 3 + j) * N] = s2 * (zc.x * b - zc.y * a);
-        }
+        we = w * rho1;
+        // 6x3 block Hpl = -we * [ I ; 2[zc]x ] * Jl  -> stored factored as (we, zc); 32 B instead of 144 B
+        double* F = d.Finc + e;
+        F[0] = we; F[NF] = zc.x; F[2 * NF] = zc.y; F[3 * NF] = zc.z;
         // landmark side: Hll += we * R R^T ; bl += -we * R e   (R e = Jl^T e)
         double* A = accpt + 9 * lp;
         atomicAdd(A + 0, we * Wp[12]); atomicAdd(A + 1, we * Wp[13]); atomicAdd(A + 2, we * Wp[14]);
         atomicAdd(A + 3, we * Wp[15]); atomicAdd(A + 4, we * Wp[16]); atomicAdd(A + 5, we * Wp[17]);
         const D3 Re = rotT(Wp, er);
         atomicAdd(A + 6, -we * Re.x); atomicAdd(A + 7, -we * Re.y); atomicAdd(A + 8, -we * Re.z);
-        acc[0] = we;
-        acc[1] = we * zc.x; acc[2] = we * zc.y; acc[3] = we * zc.z;
-        acc[4] = we * zc.x * zc.x; acc[5] = we * zc.x * zc.y; acc[6] = we * zc.x * zc.z;
-        acc[7] = we * zc.y * zc.y; acc[8] = we * zc.y * zc.z; acc[9] = we * zc.z * zc.z;
-        acc[10] = we * er.x; acc[11] = we * er.y; acc[12] = we * er.z;
-        acc[13] = we * (zc.y * er.z - zc.z * er.y);
-        acc[14] = we * (zc.z * er.x - zc.x * er.z);
-        acc[15] = we * (zc.x * er.y - zc.y * er.x);
       }
     }
-    if (BUILD) seg_reduce_to_lds<16>(acc, slot, accpose, 32);
+    if (BUILD) pose_sums(we, zc, er, slot, accpose);
   }
   // ------------------------------------------------------------ LandmarkMotionTernaryEdge
   for (int base = T.et_begin; base < T.et_end; base += VDO_TILE_THREADS) {
     const int e = base + tid;
     const bool valid = e < T.et_end;
     int slot = -1;
-    double acc[16];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    double we = 0.0;
+    D3 v{0, 0, 0}, er{0, 0, 0};
     if (valid) {
       const int key = d.et_key[e];
       slot = d.et_slot[e];
@@ -141,36 +132,20 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
       const double* Hi = slotW + 18 * slot;   // Hi.r = R_H^T, Hi.t ; J2 = -Hi.r
       const D3 p1{pts[3 * l1], pts[3 * l1 + 1], pts[3 * l1 + 2]};
       const D3 p2{pts[3 * l2], pts[3 * l2 + 1], pts[3 * l2 + 2]};
-      const D3 v = rot(Hi, p2) + D3{Hi[9], Hi[10], Hi[11]};
-      const D3 er = p1 - v - z;
+      v = rot(Hi, p2) + D3{Hi[9], Hi[10], Hi[11]};
+      er = p1 - v - z;
       const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
       double rho0, rho1;
       huber(c2, d.huber_et, d.dsqr_et, rho0, rho1);
       chi += c2; rchi += rho0;
       if (BUILD) {
-        const double we = w * rho1;
-        const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, j0 = e - T.et_begin;
+        we = w * rho1;
         double* O = d.Oll + e;               // O = we * J1^T J2 = -we * Hi.r (p1 x p2)
 #pragma unroll
         for (int i = 0; i < 9; ++i) O[i * Et] = -we * Hi[i];
-        double* B1 = d.Binc + (T.inc_begin + nb + j0);        // (H,p1): we * Jh^T
-        B1[0 * N] = we;  B1[1 * N] = 0;   B1[2 * N] = 0;
-        B1[3 * N] = 0;   B1[4 * N] = we;  B1[5 * N] = 0;
-        B1[6 * N] = 0;   B1[7 * N] = 0;   B1[8 * N] = we;
-        B1[9 * N] = 0;            B1[10 * N] = -we * v.z;  B1[11 * N] = we * v.y;
-        B1[12 * N] = we * v.z;    B1[13 * N] = 0;          B1[14 * N] = -we * v.x;
-        B1[15 * N] = -we * v.y;   B1[16 * N] = we * v.x;   B1[17 * N] = 0;
-        double* B2 = d.Binc + (T.inc_begin + nb + nt + j0);   // (H,p2): -we * Jh^T Hi.r
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const double a = Hi[j], b = Hi[3 + j], cc = Hi[6 + j];
-          B2[(0 * 3 + j) * N] = -we * a;
-          B2[(1 * 3 + j) * N] = -we * b;
-          B2[(2 * 3 + j) * N] = -we * cc;
-          B2[(3 * 3 + j) * N] = -we * (v.y * cc - v.z * b);
-          B2[(4 * 3 + j) * N] = -we * (v.z * a - v.x * cc);
-          B2[(5 * 3 + j) * N] = -we * (v.x * b - v.y * a);
-        }
+        // (H,p1): we * [I ; [v]x]   and   (H,p2): -we * [I ; [v]x] * Hi.r   -> both from (we, v)
+        double* F = d.Finc + Eb + e;
+        F[0] = we; F[NF] = v.x; F[2 * NF] = v.y; F[3 * NF] = v.z;
         // p1: Hll += we*I, b += -we*e ; p2: Hll += we*R_H R_H^T, b += we * R_H e
         double* A1 = accpt + 9 * l1;
         atomicAdd(A1 + 0, we); atomicAdd(A1 + 3, we); atomicAdd(A1 + 5, we);
@@ -180,17 +155,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
         atomicAdd(A2 + 3, we * Hi[15]); atomicAdd(A2 + 4, we * Hi[16]); atomicAdd(A2 + 5, we * Hi[17]);
         const D3 Re = rotT(Hi, er);
         atomicAdd(A2 + 6, we * Re.x); atomicAdd(A2 + 7, we * Re.y); atomicAdd(A2 + 8, we * Re.z);
-        acc[0] = we;
-        acc[1] = we * v.x; acc[2] = we * v.y; acc[3] = we * v.z;
-        acc[4] = we * v.x * v.x; acc[5] = we * v.x * v.y; acc[6] = we * v.x * v.z;
-        acc[7] = we * v.y * v.y; acc[8] = we * v.y * v.z; acc[9] = we * v.z * v.z;
-        acc[10] = we * er.x; acc[11] = we * er.y; acc[12] = we * er.z;
-        acc[13] = we * (v.y * er.z - v.z * er.y);
-        acc[14] = we * (v.z * er.x - v.x * er.z);
-        acc[15] = we * (v.x * er.y - v.y * er.x);
       }
     }
-    if (BUILD) seg_reduce_to_lds<16>(acc, slot, accpose + 16, 32);
+    if (BUILD) pose_sums(we, v, er, slot, accpose + 16);
   }
   // ---- write back
   const double c_tot = block_sum1(chi, red);

@@ -39,6 +39,84 @@ __device__ __forceinline__ void seg_reduce_to_lds(double (&v)[N], int key, doubl
   }
 }
 
+// Same reduction split into a control word (computed once per wave-iteration from the keys)
+// and small value groups, so that callers can produce the values just-in-time and keep the
+// register footprint low (16 running sums scanned 4 at a time instead of 16 at once).
+struct SegCtl { unsigned take; int key; bool tail; };
+__device__ __forceinline__ SegCtl seg_ctl(int key) {
+  const int lane = threadIdx.x & 63;
+  const int kprev1 = __shfl_up(key, 1, 64);
+  const int head = (lane == 0 || kprev1 != key) ? 1 : 0;
+  int f = head;
+  unsigned take = 0;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int off = 1 << k;
+    const int ft = __shfl_up(f, off, 64);
+    if ((lane >= off) && !f) { take |= 1u << k; f |= ft; }
+  }
+  const int hnext = __shfl_down(head, 1, 64);
+  return SegCtl{take, key, (key >= 0) && (lane == 63 || hnext != 0)};
+}
+template <int N>
+__device__ __forceinline__ void seg_apply(double (&v)[N], const SegCtl& c, double* lds_acc_slot /* &acc[key*stride + first] */) {
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    const int off = 1 << k;
+    const bool take = (c.take >> k) & 1u;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+      const double t = __shfl_up(v[i], off, 64);
+      if (take) v[i] += t;
+    }
+  }
+  if (c.tail) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) atomicAdd(lds_acc_slot + i, v[i]);
+  }
+  asm volatile("" ::: "memory");   // keep the groups sequential: bounds live registers
+}
+
+// ---- DPP variant: segments are additionally cut at 16-lane row boundaries so every step is a
+// VALU `row_shr` DPP move (no ds_bpermute round trip through the LDS crossbar).  A segment that
+// spans several rows simply issues one LDS atomic per row (<=4 lanes on the same address).
+template <int CTRL>
+__device__ __forceinline__ int dpp_i32(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = dpp_i32<CTRL>(__double2loint(v), 0), hi = dpp_i32<CTRL>(__double2hiint(v), 0);
+  return __hiloint2double(hi, lo);
+}
+struct SegCtl16 { unsigned take; bool tail; };
+__device__ __forceinline__ SegCtl16 seg_ctl16(int key) {
+  const int lr = threadIdx.x & 15;
+  const int kprev = dpp_i32<0x111>(key, -2);          // row_shr:1
+  const int head = (lr == 0 || kprev != key) ? 1 : 0;
+  int f = head;
+  unsigned take = 0;
+  { const int ft = dpp_i32<0x111>(f, 1); if (lr >= 1 && !f) { take |= 1u; f |= ft; } }
+  { const int ft = dpp_i32<0x112>(f, 1); if (lr >= 2 && !f) { take |= 2u; f |= ft; } }
+  { const int ft = dpp_i32<0x114>(f, 1); if (lr >= 4 && !f) { take |= 4u; f |= ft; } }
+  { const int ft = dpp_i32<0x118>(f, 1); if (lr >= 8 && !f) { take |= 8u; f |= ft; } }
+  const int hnext = dpp_i32<0x101>(head, 1);          // row_shl:1 (lane 15 of a row keeps `old` = 1)
+  return SegCtl16{take, (key >= 0) && (lr == 15 || hnext != 0)};
+}
+template <int N>
+__device__ __forceinline__ void seg_apply16(double (&v)[N], const SegCtl16& c, double* lds_acc_slot) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) { const double t = dpp_f64<0x111>(v[i]); if (c.take & 1u) v[i] += t; }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { const double t = dpp_f64<0x112>(v[i]); if (c.take & 2u) v[i] += t; }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { const double t = dpp_f64<0x114>(v[i]); if (c.take & 4u) v[i] += t; }
+#pragma unroll
+  for (int i = 0; i < N; ++i) { const double t = dpp_f64<0x118>(v[i]); if (c.take & 8u) v[i] += t; }
+  if (c.tail) {
+#pragma unroll
+    for (int i = 0; i < N; ++i) atomicAdd(lds_acc_slot + i, v[i]);
+  }
+}
+
 // One wave sums, for pose p, the K-vectors of all its (tile,slot) partials (part: [K][NPS] SoA).
 // Lanes stride over the slot list, then a fixed shuffle tree -> deterministic.  Result in all lanes.
 template <int K>

@@ -269,7 +269,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(pe_off, pe_off.data(), P + 1); UP(pe_idx, pe_idx.data(), pe_idx.size());
   const double* Z = nullptr;
   UP(Hpp, Z, 36 * (size_t)P); UP(bp, Z, 6 * (size_t)P); UP(Hll, Z, 9 * (size_t)L); UP(bl, Z, 3 * (size_t)L);
-  UP(Binc, Z, 18 * (size_t)d.Ninc); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep);
+  UP(Finc, Z, 4 * ((size_t)Eb + (size_t)Et)); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep);
   UP(part_sums, Z, 32 * (size_t)NPS);
   UP(part_chi, Z, 2 * (size_t)n_tiles + 2 * (size_t)(Ep + Npr) + 2);
   UP(Dinv, Z, 9 * (size_t)L); UP(Gl, Z, 9 * (size_t)L); UP(Gdiag, Z, 9 * (size_t)L); UP(Goff, Z, 9 * (size_t)L);
@@ -344,7 +344,16 @@ extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
   if (out->Hll) { hll.resize(9 * (size_t)d.L); D2H(hll.data(), d.Hll, sizeof(double) * hll.size()); }
   if (out->bl) { bl.resize(3 * (size_t)d.L); D2H(bl.data(), d.bl, sizeof(double) * bl.size()); }
   if (out->Hll_et) { oll.resize(9 * (size_t)d.Et); D2H(oll.data(), d.Oll, sizeof(double) * oll.size()); }
-  if (out->Hpl_eb || out->Hlp1_et || out->Hlp2_et) { binc.resize(18 * (size_t)d.Ninc); D2H(binc.data(), d.Binc, sizeof(double) * binc.size()); }
+  if (out->Hpl_eb || out->Hlp1_et || out->Hlp2_et) {
+    // the solve path keeps the blocks factored (Finc); materialise the explicit 6x3 blocks on demand
+    if (!ba->d.Binc && d.Ninc) {
+      if (hipMalloc((void**)&ba->d.Binc, sizeof(double) * 18 * (size_t)d.Ninc) != hipSuccess) return set_error(VDO_ERR_OOM, "hipMalloc(Binc) failed");
+      ba->allocs.push_back((void*)ba->d.Binc);
+    }
+    launch_expand_binc(ba->d, s);
+    binc.resize(18 * (size_t)d.Ninc);
+    D2H(binc.data(), ba->d.Binc, sizeof(double) * binc.size());
+  }
   D2H(ba->h_scal, d.scal, sizeof(double) * S_COUNT);
   rc = sync_check(ba, "vdo_ba_download_system");
   if (rc != VDO_OK) return rc;

@@ -185,6 +185,25 @@ extern "C" int vdo_frame_images_upload(vdo_frame_images* f, const float* depth, 
   return VDO_OK;
 }
 
+// Same as upload, but the sources are DEVICE pointers (e.g. torch tensors): device-to-device, stream-ordered, no sync.
+extern "C" int vdo_frame_images_upload_device(vdo_frame_images* f, const float* depth, const float* flow, const int32_t* mask) {
+  if (!f) return set_error(VDO_ERR_INVALID, "null handle");
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = f->ctx->stream;
+  const size_t np = (size_t)f->w * f->h;
+  if (depth) hipMemcpyAsync(f->d_depth, depth, 4 * np, hipMemcpyDeviceToDevice, s);
+  if (flow) hipMemcpyAsync(f->d_flow, flow, 8 * np, hipMemcpyDeviceToDevice, s);
+  if (mask) hipMemcpyAsync(f->d_mask, mask, 4 * np, hipMemcpyDeviceToDevice, s);
+  return VDO_OK;
+}
+
+// K1 on the resident depth image (in place)
+extern "C" int vdo_frame_images_depth_preprocess(vdo_frame_images* f, float bf, float depth_map_factor) {
+  if (!f) return set_error(VDO_ERR_INVALID, "null handle");
+  return vdo_depth_preprocess(f->ctx, f->d_depth, (int64_t)f->w * f->h, bf, depth_map_factor, 1);
+}
+
 extern "C" int vdo_frame_static_filter(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth,
                                        int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int* n_out) {
   if (!f || !n_out || n < 0 || n > f->cap) return set_error(VDO_ERR_INVALID, "bad argument");

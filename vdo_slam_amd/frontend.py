@@ -73,6 +73,18 @@ class ORBextractor:
         out["octave"] = octave[:n].copy()
         return out
 
+    def extract_device(self, gray_ptr: int, stride: int, capacity=None):
+        """Like ``__call__`` but the gray image is already resident in HBM (raw device pointer)."""
+        cap = capacity or (self.params.n_features + 256)
+        a = {k: np.zeros(cap, np.float32) for k in ("x", "y", "response", "angle", "size")}
+        octave = np.zeros(cap, np.int32)
+        kp = KeypointsC(cap, 0, _fp(a["x"]), _fp(a["y"]), _fp(a["response"]), _fp(a["angle"]), _fp(a["size"]), _ip(octave))
+        K.check(_lib().vdo_orb_extract(self._h, C.cast(C.c_void_p(gray_ptr), K.c_uint8_p), stride, 1, C.byref(kp)))
+        n = kp.n
+        out = {k: v[:n] for k, v in a.items()}
+        out["octave"] = octave[:n]
+        return out
+
     def level_info(self, level):
         w, h, nf, nc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         K.check(_lib().vdo_orb_level_info(self._h, level, C.byref(w), C.byref(h), C.byref(nf), C.byref(nc)))
@@ -132,6 +144,17 @@ class FrameImages:
         depth = np.ascontiguousarray(depth, dtype=np.float32); flow = np.ascontiguousarray(flow, dtype=np.float32)
         mask = np.ascontiguousarray(mask, dtype=np.int32)
         K.check(_lib().vdo_frame_images_upload(self._h, _fp(depth), _fp(flow), _ip(mask)))
+
+    def upload_device(self, depth_ptr: int, flow_ptr: int, mask_ptr: int):
+        """Bind device-resident inputs (raw pointers, e.g. ``tensor.data_ptr()``): D2D, stream-ordered."""
+        L = _lib()
+        L.vdo_frame_images_upload_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        K.check(L.vdo_frame_images_upload_device(self._h, C.c_void_p(depth_ptr), C.c_void_p(flow_ptr), C.c_void_p(mask_ptr)))
+
+    def depth_preprocess(self, bf, factor):
+        L = _lib()
+        L.vdo_frame_images_depth_preprocess.argtypes = [C.c_void_p, C.c_float, C.c_float]
+        K.check(L.vdo_frame_images_depth_preprocess(self._h, bf, factor))
 
     def static_filter(self, kx, ky, th_depth):
         kx = np.ascontiguousarray(kx, dtype=np.float32); ky = np.ascontiguousarray(ky, dtype=np.float32)
