@@ -206,7 +206,11 @@ def main():
         bytes_launch = 208 * gr.n_eb + 452 * gr.n_et + 96 * gr.n_point     # SURVEY.md §8d B_sweep terms of this kernel
         achieved = bytes_launch / (sweep_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_sweep_tile<true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": int(bytes_launch), "avg_launch_ms": sweep_ms,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                           "traffic_note": "PMC passes cannot run inside bench.py; measured 2*FETCH_SIZE+WRITE_SIZE = 391 MB/launch for this "
+                                           "graph (profiles/r01_sweep_pmc_hbm_traffic.txt): below the algorithmic bytes because the 6x3 blocks "
+                                           "are stored factored (32 B instead of 144 B)",
+                           "bytes_per_launch": int(bytes_launch), "avg_launch_ms": sweep_ms,
                            "units_per_launch": {"EdgeSE3PointXYZ": int(gr.n_eb), "LandmarkMotionTernaryEdge": int(gr.n_et), "points": int(gr.n_point)}}
         bar.close()
         if rank == 0 and not args.no_cpu_baseline:
