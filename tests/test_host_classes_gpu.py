@@ -1,0 +1,144 @@
+"""The C++ host classes (vdo_slam_amd/host: ORBextractor, Frame, Optimizer with the reference's
+signatures) driven through libvdo_host.so and compared with the oracle."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from tests import frontend_ref as R
+from vdo_slam_amd import _capi as K
+from vdo_slam_amd import synth, synth_frames as SF, synth_map as SM
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class HostMapFlat(C.Structure):
+    _fields_ = [("n_frames", C.c_int), ("K", K.c_float_p), ("cam_pose", K.c_float_p),
+                ("sta_cnt", K.c_int32_p), ("sta_uv", K.c_float_p), ("sta_d", K.c_float_p), ("sta_xw", K.c_float_p),
+                ("n_tr_sta", C.c_int), ("tr_sta_len", K.c_int32_p), ("tr_sta_pairs", K.c_int32_p),
+                ("dyn_cnt", K.c_int32_p), ("dyn_uv", K.c_float_p), ("dyn_d", K.c_float_p), ("dyn_xw", K.c_float_p),
+                ("n_tr_dyn", C.c_int), ("tr_dyn_len", K.c_int32_p), ("tr_dyn_pairs", K.c_int32_p), ("obj_of_dyn", K.c_int32_p),
+                ("rm_cnt", K.c_int32_p), ("rm", K.c_float_p), ("rm_label", K.c_int32_p)]
+
+
+@pytest.fixture(scope="module")
+def host():
+    path = os.path.join(ROOT, "vdo_slam_amd", "libvdo_host.so")
+    assert os.path.exists(path), "libvdo_host.so missing: run __graft_entry__.build()"
+    L = C.CDLL(path)
+    L.host_batch_optimization.argtypes = [C.POINTER(HostMapFlat), C.c_int, K.c_float_p, K.c_float_p, K.c_float_p, K.c_float_p, C.POINTER(K.LMStatsC)]
+    return L
+
+
+def _f(a): return np.ascontiguousarray(a, dtype=np.float32)
+def _i(a): return np.ascontiguousarray(a, dtype=np.int32)
+
+
+def _flatten(m):
+    keep = []
+    def fp(a): a = _f(a); keep.append(a); return a.ctypes.data_as(K.c_float_p)
+    def ip(a): a = _i(a); keep.append(a); return a.ctypes.data_as(K.c_int32_p)
+    fe = m["feats"]
+    cat = lambda key, w: np.concatenate([np.asarray(f[key], np.float32).reshape(-1, w) for f in fe]) if sum(len(f[key]) for f in fe) else np.zeros((0, w), np.float32)
+    s = HostMapFlat()
+    s.n_frames = m["n_frames"]; s.K = fp(m["K"]); s.cam_pose = fp(m["cam_pose"])
+    s.sta_cnt = ip([len(f["sta_uv"]) for f in fe]); s.sta_uv = fp(cat("sta_uv", 2)); s.sta_d = fp(cat("sta_d", 1)); s.sta_xw = fp(cat("sta_xw", 3))
+    s.n_tr_sta = len(m["tr_sta"]); s.tr_sta_len = ip([len(t) for t in m["tr_sta"]]); s.tr_sta_pairs = ip([p for t in m["tr_sta"] for p in t])
+    s.dyn_cnt = ip([len(f["dyn_uv"]) for f in fe]); s.dyn_uv = fp(cat("dyn_uv", 2)); s.dyn_d = fp(cat("dyn_d", 1)); s.dyn_xw = fp(cat("dyn_xw", 3))
+    s.n_tr_dyn = len(m["tr_dyn"]); s.tr_dyn_len = ip([len(t) for t in m["tr_dyn"]]); s.tr_dyn_pairs = ip([p for t in m["tr_dyn"] for p in t])
+    s.obj_of_dyn = ip(m["obj_of_dyn"])
+    s.rm_cnt = ip([len(r) for r in m["rigid_motion"]]); s.rm = fp(np.concatenate(m["rigid_motion"])); s.rm_label = ip(np.concatenate(m["rm_label"]))
+    return s, keep
+
+
+@pytest.mark.parametrize("window", [0, 8])
+def test_optimizer_batch_matches_oracle_on_the_reference_built_graph(host, oracle, window):
+    """Optimizer::FullBatchOptimization / PartialBatchOptimization (C++ host class, GPU solve) vs the
+    oracle LM on the graph built by the Python restatement of the reference builder."""
+    m = SM.make_map(n_frames=8 if window else 12, n_static=400, n_objects=2, dyn_tracks_per_object=40, seed=5)
+    s, keep = _flatten(m)
+    F = m["n_frames"]
+    n_sta = sum(len(f["sta_uv"]) for f in m["feats"]); n_dyn = sum(len(f["dyn_uv"]) for f in m["feats"])
+    n_rm = sum(len(r) for r in m["rigid_motion"])
+    cam_out = np.zeros((F, 4, 4), np.float32); rm_out = np.zeros((n_rm, 4, 4), np.float32)
+    sta_out = np.zeros((n_sta, 3), np.float32); dyn_out = np.zeros((max(n_dyn, 1), 3), np.float32)
+    st = K.LMStatsC()
+    assert host.host_batch_optimization(C.byref(s), window, _p(cam_out), _p(rm_out), _p(sta_out), _p(dyn_out), C.byref(st)) == 0
+    # oracle on the same graph
+    g, info = SM.map_to_graph(m, partial_window=window or None)
+    gc, keep2 = K.graph_to_c(g)
+    opt = K.LMOptionsC(100 if window else 300, 1e-3 if window else 1e-4, 0, 0, 0.0, 0)
+    st_o = K.LMStatsC()
+    pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(pose_o), K._dp(point_o), C.byref(st_o)) == 0
+    assert st.iterations == st_o.iterations and st.total_trials == st_o.total_trials
+    assert abs(st.final_chi2 - st_o.final_chi2) <= 1e-6 * st_o.final_chi2
+    # refined camera poses (float32 in the Map): frame `start` is the gauge, the others must match
+    start = info["start"]
+    for i in range(start + (0 if window else 1), F):
+        ref = pose_o[info["cam_idx"][i - start]]
+        np.testing.assert_allclose(cam_out[i][:3, :3].ravel(), ref[:9], atol=2e-6)
+        np.testing.assert_allclose(cam_out[i][:3, 3], ref[9:], rtol=1e-4, atol=1e-5)
+    # refined static points
+    off = np.cumsum([0] + [len(f["sta_uv"]) for f in m["feats"]])
+    checked = 0
+    for i in range(start, F):
+        for j, mk in enumerate(info["mkS"][i]):
+            if mk >= 0:
+                np.testing.assert_allclose(sta_out[off[i] + j], point_o[mk], rtol=1e-4, atol=1e-4)
+                checked += 1
+    assert checked > 100
+
+
+def _p(a):
+    return a.ctypes.data_as(K.c_float_p)
+
+
+def test_frame_constructor_matches_oracle(host, oracle):
+    host.host_frame.argtypes = [K.c_uint8_p, K.c_float_p, K.c_float_p, K.c_int32_p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_float,
+                                K.c_float_p, K.c_float_p, K.c_int32_p, C.c_int, C.POINTER(C.c_int), K.c_float_p, K.c_float_p,
+                                C.POINTER(C.c_int), K.c_float_p, K.c_int32_p, C.c_int]
+    fr = SF.make_frame(seed=12)
+    depth = fr["depth_raw"].copy()
+    cap, capo = 4096, 40000
+    kx = np.zeros(cap, np.float32); ky = np.zeros(cap, np.float32); ko = np.zeros(cap, np.int32)
+    sc = np.zeros((cap, 2), np.float32); sd = np.zeros(cap, np.float32); ok = np.zeros((capo, 2), np.float32); ol = np.zeros(capo, np.int32)
+    ns, no = C.c_int(), C.c_int()
+    n = host.host_frame(R._u8(fr["gray"]), _p(depth), _p(fr["flow"]), R._ip(fr["mask"]), 1242, 375, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ,
+                        _p(kx), _p(ky), R._ip(ko), cap, C.byref(ns), _p(sc), _p(sd), C.byref(no), _p(ok), R._ip(ol), capo)
+    d_ref = fr["depth_raw"].copy()
+    oracle.vdo_oracle_depth_preprocess(R._fp(d_ref), d_ref.size, SF.BF, SF.DEPTH_MAP_FACTOR)
+    assert np.array_equal(depth, d_ref)                      # GrabImageRGBD mutates the depth in place
+    ref = R.extract(oracle, fr["gray"])
+    assert n == ref["x"].size
+    assert np.array_equal(kx[:n], ref["x"]) and np.array_equal(ky[:n], ref["y"]) and np.array_equal(ko[:n], ref["octave"])
+    sf = R.static_filter(oracle, ref["x"], ref["y"], ref["octave"], fr["mask"], d_ref, fr["flow"], SF.TH_DEPTH_BG)
+    assert ns.value == sf["keep_idx"].size
+    assert np.array_equal(sc[:ns.value, 0], sf["corr_x"]) and np.array_equal(sc[:ns.value, 1], sf["corr_y"]) and np.array_equal(sd[:ns.value], sf["depth"])
+    ob = R.object_sample(oracle, fr["mask"], d_ref, fr["flow"], SF.TH_DEPTH_OBJ)
+    assert no.value == ob["label"].size
+    assert np.array_equal(ok[:no.value, 0], ob["key_x"]) and np.array_equal(ol[:no.value], ob["label"])
+
+
+def test_pose_optimization_flow2cam_class_matches_oracle(host, oracle):
+    from tests.test_oracle_flow2 import run_oracle
+    host.host_pose_optimization_flow2cam.argtypes = [C.c_int, K.c_float_p, K.c_float_p, K.c_float_p, K.c_float_p, K.c_float_p, K.c_float_p, K.c_int32_p, K.c_float_p]
+    prob = synth.make_flow2_problem(900, seed=31)
+    # the class receives the LAST frame pose T_lw (float) and derives Twl itself (Optimizer.cc:2414-2420)
+    Twl = prob.Twl
+    Tlw = np.linalg.inv(Twl).astype(np.float32)
+    inv = np.eye(4, dtype=np.float32)
+    inv[:3, :3] = Tlw[:3, :3].T
+    inv[:3, 3] = -(Tlw[:3, :3].T @ Tlw[:3, 3]).astype(np.float32)      # Converter::toInvMatrix in fp32
+    prob.Twl = inv.astype(np.float64)
+    T, flow, inl, ninl, st = run_oracle(oracle, prob)
+    n = prob.n
+    Tout = np.zeros((4, 4), np.float32); match = np.zeros(n, np.int32); cur = np.zeros((n, 2), np.float32)
+    got = host.host_pose_optimization_flow2cam(n, _p(_f(prob.obs)), _p(_f(prob.flow)), _p(_f(prob.depth)), _p(Tlw), _p(_f(prob.T0)), _p(Tout), R._ip(match), _p(cur))
+    assert got == ninl
+    assert np.array_equal(match >= 0, inl.astype(bool))
+    np.testing.assert_allclose(Tout, T.astype(np.float32), rtol=1e-4, atol=1e-5)
+    exp = (prob.obs + flow).astype(np.float32)
+    np.testing.assert_allclose(cur[inl.astype(bool)], exp[inl.astype(bool)], atol=1e-4)
