@@ -240,6 +240,40 @@ int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, int step, i
                             float* key_x, float* key_y, float* corr_x, float* corr_y,
                             float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_out);
 
+/* ---- Tracking-side gathers over the resident images ------------
+ * All coordinate arrays are host pointers (the reference keeps them in std::vector<cv::KeyPoint>). */
+
+/* Tracking::GrabImageRGBD, static correspondences: depth at ((int)kx,(int)ky) if inside the
+ * 1-px-inset image and > 0, else -1.  Replaces src/Tracking.cc:259-275. */
+int vdo_propagate_static(vdo_frame_images* f, int n, const float* kx, const float* ky, float* depth_out);
+/* Object correspondences: (depth,label) if inside and 0 < depth < th_depth_obj, else (0.1, 0).
+ * Replaces src/Tracking.cc:278-305. */
+int vdo_propagate_object(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth_obj,
+                         float* depth_out, int32_t* label_out);
+/* Optimizer::Get3DinWorld over a vector of keypoints: Twc[:3,:3]*x3Dc + Twc[:3,3] with cv::gemm
+ * rounding (double accumulate, one rounding).  Replaces src/Optimizer.cc:2974-2995 (called per point
+ * from Tracking.cc:1086,1094 and Optimizer builders).  K4 = fx,fy,cx,cy ; Twc row-major 4x4. */
+int vdo_get3d_world(vdo_ctx* ctx, int n, const float* kx, const float* ky, const float* depth,
+                    const float K4[4], const float Twc[16], float* xyz_out);
+/* Tracking::GetSceneFlowObj: flow3d = X_cur - X_last with both points back-projected through
+ * Frame::UnprojectStereoObject / UnprojectStereoObjectLast (src/Frame.cc:517-555); entries whose
+ * semantic label is <= 0 in either frame get obj_label = -1 and zero flow.  Replaces src/Tracking.cc:1278-1364 (per-point part). */
+int vdo_scene_flow(vdo_ctx* ctx, int n, const float* cur_x, const float* cur_y, const float* cur_d, const int32_t* cur_label, const float Tcw_cur[16],
+                   const float* last_x, const float* last_y, const float* last_d, const int32_t* last_label, const float Tcw_last[16],
+                   const float K4[4], float* flow3d_out, int32_t* obj_label_inout);
+/* Tracking::RenewFrameInfo, static part (src/Tracking.cc:2666-2790): carry the inliers TM_sta, top
+ * up from the ORB keypoints (stride-20 interleave, skipping keypoints within 1 px of a carried one),
+ * then depth.  Outputs need capacity max_num_sta + 1 ; *n_out = count. */
+int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm_sta, const float* stat_x, const float* stat_y,
+                     int n_orb, const float* orb_x, const float* orb_y, int max_num_sta,
+                     float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y,
+                     int32_t* inlier_id, float* depth_out, int* n_out);
+/* Tracking::UpdateMask (src/Tracking.cc:3015-3065): labels of this frame's mask at n positions
+ * (-1 outside), and the warp of label `label` from `last`'s mask into `cur`'s mask by `last`'s flow. */
+int vdo_mask_at(vdo_frame_images* f, int n, const float* cx, const float* cy, int32_t* label_out);
+int vdo_mask_warp(vdo_frame_images* cur, vdo_frame_images* last, int32_t label);
+int vdo_frame_images_download_mask(vdo_frame_images* f, int32_t* mask_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -149,6 +149,22 @@ int vdo_oracle_frame_object_sample(const int32_t* mask, const float* depth, cons
                                    float* key_x, float* key_y, float* corr_x, float* corr_y,
                                    float* flow_x, float* flow_y, float* depth_out, int32_t* label);
 
+/* ---- tracking-side stages (tracking_oracle.cpp) ------------------------------------------*/
+void vdo_oracle_propagate_static(int n, const float* kx, const float* ky, const float* depth, int w, int h, float* depth_out);
+void vdo_oracle_propagate_object(int n, const float* kx, const float* ky, const float* depth, const int32_t* mask, int w, int h,
+                                 float th_obj, float* depth_out, int32_t* label_out);
+void vdo_oracle_scene_flow(int n, const float* cur_x, const float* cur_y, const float* cur_d, const int32_t* cur_lab, const float* Tcw_cur,
+                           const float* last_x, const float* last_y, const float* last_d, const int32_t* last_lab, const float* Tcw_last,
+                           const float* K4, float* flow3d, int32_t* obj_label_inout);
+void vdo_oracle_get3d_world(int n, const float* kx, const float* ky, const float* d, const float* K4, const float* Twc, float* xyz);
+int vdo_oracle_renew_static(int n_tm, const int32_t* tm_sta, const float* stat_x, const float* stat_y,
+                            int n_orb, const float* orb_x, const float* orb_y,
+                            const int32_t* mask, const float* depth, const float* flow, int w, int h, int max_num_sta,
+                            float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y,
+                            int32_t* inlier_id, float* depth_out);
+void vdo_oracle_mask_at(int n, const float* cx, const float* cy, const int32_t* mask, int w, int h, int32_t* out);
+void vdo_oracle_mask_warp(const int32_t* mask_last, const float* flow_last, int w, int h, int32_t lab, int32_t* mask_cur);
+
 /* ---- SE(3) helpers exposed for KATs --------------------------------------------*/
 void vdo_oracle_se3_exp(const double u[6], double T16[16]);            /* SE3Quat::exp */
 void vdo_oracle_iso_oplus(const double T12[12], const double d[6], double out12[12]); /* VertexSE3::oplusImpl */

@@ -51,5 +51,13 @@ def load():
     L.vdo_oracle_gaussian_blur7.argtypes = [u8p, C.c_int, C.c_int, u8p]
     L.vdo_oracle_frame_static_filter.argtypes = [C.c_int, fp, fp, i32p, i32p, fp, fp, C.c_int, C.c_int, C.c_float, i32p, fp, fp, fp, fp, fp]
     L.vdo_oracle_frame_object_sample.argtypes = [i32p, fp, fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, i32p]
+    L.vdo_oracle_propagate_static.argtypes = [C.c_int, fp, fp, fp, C.c_int, C.c_int, fp]
+    L.vdo_oracle_propagate_object.argtypes = [C.c_int, fp, fp, fp, i32p, C.c_int, C.c_int, C.c_float, fp, i32p]
+    L.vdo_oracle_scene_flow.argtypes = [C.c_int, fp, fp, fp, i32p, fp, fp, fp, fp, i32p, fp, fp, fp, i32p]
+    L.vdo_oracle_get3d_world.argtypes = [C.c_int, fp, fp, fp, fp, fp, fp]
+    L.vdo_oracle_renew_static.argtypes = [C.c_int, i32p, fp, fp, C.c_int, fp, fp, i32p, fp, fp, C.c_int, C.c_int, C.c_int,
+                                          fp, fp, fp, fp, fp, fp, i32p, fp]
+    L.vdo_oracle_mask_at.argtypes = [C.c_int, fp, fp, i32p, C.c_int, C.c_int, i32p]
+    L.vdo_oracle_mask_warp.argtypes = [i32p, fp, C.c_int, C.c_int, C.c_int32, i32p]
     _lib = L
     return L

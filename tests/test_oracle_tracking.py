@@ -1,0 +1,153 @@
+"""Known-answer tests pinning oracle/tracking_oracle.cpp (K11-K15) against independent numpy
+statements of the same reference loops (src/Tracking.cc:259-305, 1278-1364, 2666-2790, 3015-3065)."""
+import numpy as np
+
+from tests import tracking_ref as T
+from vdo_slam_amd import synth_frames as SF
+from vdo_slam_amd.synth import KITTI_K
+
+
+def _frame(seed):
+    fr = SF.make_frame(seed=seed)
+    depth = (SF.BF / np.maximum(fr["depth_raw"] / SF.DEPTH_MAP_FACTOR, 1e-9)).astype(np.float32)
+    depth[fr["depth_raw"] <= 0] = 0 if seed % 2 else -1
+    return fr, np.ascontiguousarray(depth)
+
+
+def _points(rng, n, w, h, pad=8):
+    return rng.uniform(-pad, w + pad, n).astype(np.float32), rng.uniform(-pad, h + pad, n).astype(np.float32)
+
+
+def test_propagate_gathers_match_numpy(oracle):
+    fr, depth = _frame(3)
+    h, w = depth.shape
+    rng = np.random.default_rng(0)
+    kx, ky = _points(rng, 5000, w, h)
+    u, v = kx.astype(np.int32), ky.astype(np.int32)        # C cast truncates toward zero, like astype
+    inside = (u < w - 1) & (u > 0) & (v < h - 1) & (v > 0)
+    dd = np.where(inside, depth[np.clip(v, 0, h - 1), np.clip(u, 0, w - 1)], np.float32(-1))
+    exp = np.where(inside & (dd > 0), dd, np.float32(-1))
+    assert np.array_equal(T.propagate_static(oracle, kx, ky, depth), exp)
+    ok = inside & (dd > 0) & (dd < SF.TH_DEPTH_OBJ)
+    d, lab = T.propagate_object(oracle, kx, ky, depth, fr["mask"], SF.TH_DEPTH_OBJ)
+    assert np.array_equal(d, np.where(ok, dd, np.float32(0.1)))
+    assert np.array_equal(lab, np.where(ok, fr["mask"][np.clip(v, 0, h - 1), np.clip(u, 0, w - 1)], 0))
+    assert inside.sum() > 4000 and (~inside).sum() > 50
+    m = T.mask_at(oracle, kx, ky, fr["mask"])
+    in2 = (u < w) & (u > 0) & (v < h) & (v > 0)
+    assert np.array_equal(m, np.where(in2, fr["mask"][np.clip(v, 0, h - 1), np.clip(u, 0, w - 1)], -1))
+
+
+def _rand_pose(rng, scale=1.0):
+    from scipy.spatial.transform import Rotation
+    Tm = np.eye(4)
+    Tm[:3, :3] = Rotation.from_rotvec(rng.normal(0, 0.1, 3)).as_matrix()
+    Tm[:3, 3] = rng.normal(0, scale, 3)
+    return Tm
+
+
+def test_backprojection_roundtrip_and_scene_flow_of_static_points(oracle):
+    rng = np.random.default_rng(1)
+    K4 = np.array(KITTI_K, np.float32)
+    n = 3000
+    Xw = np.c_[rng.uniform(-20, 20, n), rng.uniform(-2, 2, n), rng.uniform(8, 40, n)]
+    Tcw0, Tcw1 = _rand_pose(rng), _rand_pose(rng)
+
+    def proj(Tcw):
+        Xc = Xw @ Tcw[:3, :3].T + Tcw[:3, 3]
+        return (K4[0] * Xc[:, 0] / Xc[:, 2] + K4[2]).astype(np.float32), (K4[1] * Xc[:, 1] / Xc[:, 2] + K4[3]).astype(np.float32), Xc[:, 2].astype(np.float32)
+
+    u0, v0, z0 = proj(Tcw0)
+    u1, v1, z1 = proj(Tcw1)
+    # Get3DinWorld with Twc = inv(Tcw) returns the world point
+    X = T.get3d_world(oracle, u0, v0, z0, K4, np.linalg.inv(Tcw0))
+    np.testing.assert_allclose(X, Xw, atol=2e-3)
+    # static points seen from two poses have zero scene flow; labels <= 0 are flagged -1
+    lab = np.ones(n, np.int32); lab[::7] = 0
+    lab_last = np.ones(n, np.int32); lab_last[::11] = -3
+    fl, ol = T.scene_flow(oracle, (u1, v1, z1, lab), Tcw1, (u0, v0, z0, lab_last), Tcw0, K4, np.full(n, 5, np.int32))
+    bad = (lab <= 0) | (lab_last <= 0)
+    assert np.array_equal(ol, np.where(bad, -1, 5))
+    assert np.all(fl[bad] == 0)
+    assert np.abs(fl[~bad]).max() < 5e-3
+    # moving points: flow equals the displacement
+    disp = rng.normal(0, 0.5, (n, 3))
+    Xw2 = Xw + disp
+    Xc = Xw2 @ Tcw1[:3, :3].T + Tcw1[:3, 3]
+    u2 = (K4[0] * Xc[:, 0] / Xc[:, 2] + K4[2]).astype(np.float32); v2 = (K4[1] * Xc[:, 1] / Xc[:, 2] + K4[3]).astype(np.float32)
+    fl2, _ = T.scene_flow(oracle, (u2, v2, Xc[:, 2], np.ones(n, np.int32)), Tcw1, (u0, v0, z0, np.ones(n, np.int32)), Tcw0, K4, np.zeros(n, np.int32))
+    np.testing.assert_allclose(fl2, disp, atol=5e-3)
+
+
+def _renew_python(tm, sx, sy, ox, oy, mask, depth, flow, max_num):
+    """Straight sequential statement of RenewFrameInfo's static part (Tracking.cc:2666-2790)."""
+    h, w = mask.shape
+    keys, ids = [], []
+
+    def accept(px, py):
+        x, y = int(px), int(py)
+        if x >= w or y >= h or x <= 0 or y <= 0: return None
+        if mask[y, x] != 0 or depth[y, x] > 40 or depth[y, x] <= 0: return None
+        fx, fy = flow[y, x]
+        if fx != 0 and fy != 0 and np.float32(px + fx) < w and np.float32(py + fy) < h and np.float32(px + fx) > 0 and np.float32(py + fy) > 0:
+            return (px, py, np.float32(px + fx), np.float32(py + fy), fx, fy, depth[y, x])
+        return None
+
+    for t in tm:
+        if t == -1: continue
+        a = accept(sx[t], sy[t])
+        if a is not None: keys.append(a); ids.append(int(t))
+        if len(keys) > max_num: break
+    carried = np.array([[k[0], k[1]] for k in keys], np.float32).reshape(-1, 2)
+    tot, start = len(keys), 0
+    while tot < max_num:
+        if start == 20: break
+        for i in range(start, ox.size, 20):
+            if carried.shape[0]:
+                dx = carried[:, 0] - ox[i]; dy = carried[:, 1] - oy[i]
+                if np.sqrt(dx * dx + dy * dy).min() < 1.0: continue
+            a = accept(ox[i], oy[i])
+            if a is not None: keys.append(a); ids.append(-1); tot += 1
+            if tot >= max_num: break
+        start += 1
+    return np.array(keys, np.float32).reshape(-1, 7), np.array(ids, np.int32)
+
+
+def _renew_inputs(seed, n_stat, n_orb, inlier_frac):
+    fr, depth = _frame(seed)
+    h, w = depth.shape
+    rng = np.random.default_rng(seed)
+    sx, sy = _points(rng, n_stat, w, h, pad=3)
+    tm = np.where(rng.random(n_stat) < inlier_frac, np.arange(n_stat), -1).astype(np.int32)
+    ox, oy = _points(rng, n_orb, w, h, pad=3)
+    # some ORB keypoints coincide (within 1 px) with carried static keys
+    k = min(n_orb // 4, n_stat)
+    ox[:k] = sx[:k] + rng.uniform(-0.6, 0.6, k).astype(np.float32); oy[:k] = sy[:k] + rng.uniform(-0.6, 0.6, k).astype(np.float32)
+    return fr, depth, tm, sx, sy, ox, oy
+
+
+def test_renew_static_matches_sequential_python(oracle):
+    for seed, n_stat, n_orb, frac, max_num in [(5, 300, 500, 0.7, 400), (6, 700, 300, 0.9, 200), (7, 50, 3000, 0.5, 600), (8, 0, 100, 0.5, 50)]:
+        fr, depth, tm, sx, sy, ox, oy = _renew_inputs(seed, n_stat, n_orb, frac)
+        got = T.renew_static(oracle, tm, sx, sy, ox, oy, fr["mask"], depth, fr["flow"], max_num)
+        exp, ids = _renew_python(tm, sx, sy, ox, oy, fr["mask"], depth, fr["flow"], max_num)
+        assert got["key_x"].size == exp.shape[0]
+        for j, name in enumerate(("key_x", "key_y", "corr_x", "corr_y", "flow_x", "flow_y", "depth")):
+            assert np.array_equal(got[name], exp[:, j]), (seed, name)
+        assert np.array_equal(got["inlier_id"], ids)
+        assert got["key_x"].size <= max_num + 1
+
+
+def test_mask_warp_matches_numpy(oracle):
+    fr, _ = _frame(9)
+    cur = SF.make_frame(seed=10)["mask"]
+    h, w = cur.shape
+    for lab in (1, 3):
+        got = T.mask_warp(oracle, fr["mask"], fr["flow"], lab, cur)
+        jj, kk = np.nonzero(fr["mask"] == lab)
+        fx = fr["flow"][jj, kk, 0].astype(np.int32); fy = fr["flow"][jj, kk, 1].astype(np.int32)
+        ok = (kk + fx < w) & (kk + fx > 0) & (jj + fy < h) & (jj + fy > 0)
+        exp = cur.copy()
+        exp[(jj + fy)[ok], (kk + fx)[ok]] = lab
+        assert np.array_equal(got, exp)
+        assert (got != cur).sum() > 100

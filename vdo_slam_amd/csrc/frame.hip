@@ -10,6 +10,7 @@
 
 #include "../../include/vdo_slam_hip.h"
 #include "ctx.hpp"
+#include "frame_images.hpp"
 
 namespace vdo {
 
@@ -134,16 +135,6 @@ __global__ __launch_bounds__(256) void k_obj_scatter(const int32_t* __restrict__
 }  // namespace vdo
 
 using namespace vdo;
-
-struct vdo_frame_images {
-  vdo_ctx* ctx = nullptr;
-  int w = 0, h = 0;
-  int32_t* d_mask = nullptr; float *d_depth = nullptr, *d_flow = nullptr;
-  // scratch
-  float* d_f[8] = {nullptr}; int32_t* d_i[2] = {nullptr}; int* d_cnt = nullptr; int* d_blk = nullptr;
-  int cap = 0;
-  std::vector<void*> allocs;
-};
 
 extern "C" int vdo_frame_images_destroy(vdo_frame_images* f) {
   if (!f) return VDO_OK;

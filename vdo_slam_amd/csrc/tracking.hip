@@ -1,0 +1,326 @@
+// Tracking-side kernels on gfx950 — the data-parallel loops of Tracking::GrabImageRGBD / Track
+// (reference src/Tracking.cc) over the HBM-resident depth / flow / mask images:
+//   K11 propagate last-frame correspondences: depth + label gather            :259-305
+//   K12 back-projection  Frame::UnprojectStereoObject, Optimizer::Get3DinWorld  src/Frame.cc:517-555, src/Optimizer.cc:2974-2995
+//   K13 scene flow per object point (GetSceneFlowObj)                          :1278-1364
+//   K14 RenewFrameInfo, static part: inlier carry-over, O(n*m) "already used"
+//       distance test, validity predicate; the ORDER-dependent selection
+//       (first-come truncation, stride-20 interleave) is applied on the host
+//       from the flags, reproducing the sequential reference exactly             :2666-2778
+//   K15 UpdateMask: label gather at flowed positions + mask warp                 :3015-3065
+// All gathers are 4-byte random reads of L2-resident images: latency-bound, a few µs each.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "../../include/vdo_slam_hip.h"
+#include "ctx.hpp"
+#include "frame_images.hpp"
+
+namespace vdo {
+
+// mode 0: K11 static (depth>0 else -1; bounds u<w-1,u>0,v<h-1,v>0)
+// mode 1: K11 object (depth<th && depth>0 -> depth,label else 0.1,0)
+// mode 2: K15 mask at (u<w,u>0,v<h,v>0) else -1
+__global__ void k_gather(int mode, int n, const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ depth,
+                         const int32_t* __restrict__ mask, int w, int h, float th, float* __restrict__ dout, int32_t* __restrict__ lout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int u = (int)kx[i], v = (int)ky[i];
+  if (mode == 0) {
+    float o = -1.f;
+    if (u < (w - 1) && u > 0 && v < (h - 1) && v > 0) { const float d = depth[(size_t)v * w + u]; if (d > 0) o = d; }
+    dout[i] = o;
+  } else if (mode == 1) {
+    float o = 0.1f; int l = 0;
+    if (u < (w - 1) && u > 0 && v < (h - 1) && v > 0) {
+      const float d = depth[(size_t)v * w + u];
+      if (d < th && d > 0) { o = d; l = mask[(size_t)v * w + u]; }
+    }
+    dout[i] = o; lout[i] = l;
+  } else {
+    lout[i] = (u < w && u > 0 && v < h && v > 0) ? mask[(size_t)v * w + u] : -1;
+  }
+}
+
+struct Cam { float invfx, invfy, cx, cy; float R[9]; float t[3]; };   // R|t applied to the camera-frame point
+
+// cv::gemm semantics for small float matrices: accumulate in double, round once
+__device__ __forceinline__ void gemm3_dev(const float* A, const float* v, float* o) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = (float)((double)A[3 * i] * v[0] + (double)A[3 * i + 1] * v[1] + (double)A[3 * i + 2] * v[2]);
+}
+__device__ __forceinline__ void backproject(const Cam& c, float u, float v, float z, float* out) {
+  const float xc[3] = {(u - c.cx) * z * c.invfx, (v - c.cy) * z * c.invfy, z};
+  float r[3];
+  gemm3_dev(c.R, xc, r);
+  out[0] = r[0] + c.t[0]; out[1] = r[1] + c.t[1]; out[2] = r[2] + c.t[2];
+}
+
+__global__ void k_get3d_world(int n, const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ d, Cam c, float* __restrict__ xyz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float o[3];
+  backproject(c, kx[i], ky[i], d[i], o);
+  xyz[3 * i] = o[0]; xyz[3 * i + 1] = o[1]; xyz[3 * i + 2] = o[2];
+}
+
+__global__ void k_scene_flow(int n, const float* __restrict__ cx_, const float* __restrict__ cy_, const float* __restrict__ cd, const int32_t* __restrict__ cl, Cam cc,
+                             const float* __restrict__ lx, const float* __restrict__ ly, const float* __restrict__ ld, const int32_t* __restrict__ ll, Cam lc,
+                             float* __restrict__ flow3d, int32_t* __restrict__ objlab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  if (cl[i] <= 0 || ll[i] <= 0) { objlab[i] = -1; flow3d[3 * i] = 0; flow3d[3 * i + 1] = 0; flow3d[3 * i + 2] = 0; return; }
+  float p[3], c[3];
+  backproject(lc, lx[i], ly[i], ld[i], p);
+  backproject(cc, cx_[i], cy_[i], cd[i], c);
+  flow3d[3 * i] = c[0] - p[0]; flow3d[3 * i + 1] = c[1] - p[1]; flow3d[3 * i + 2] = c[2] - p[2];
+}
+
+// K14 validity predicate of RenewFrameInfo (static): writes flag, flow and depth for every candidate
+__global__ void k_renew_pred(int n, const float* __restrict__ px, const float* __restrict__ py, const int32_t* __restrict__ mask,
+                             const float* __restrict__ depth, const float* __restrict__ flow, int w, int h,
+                             int32_t* __restrict__ ok, float* __restrict__ fx, float* __restrict__ fy, float* __restrict__ dout) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float x_ = px[i], y_ = py[i];
+  const int x = (int)x_, y = (int)y_;
+  int good = 0;
+  float fxe = 0, fye = 0, d = -1.f;
+  if (!(x >= w || y >= h || x <= 0 || y <= 0)) {
+    const size_t o = (size_t)y * w + x;
+    const float dd = depth[o];
+    if (mask[o] == 0 && !(dd > 40 || dd <= 0)) {
+      fxe = flow[2 * o]; fye = flow[2 * o + 1];
+      if (fxe != 0 && fye != 0 && x_ + fxe < w && y_ + fye < h && x_ + fxe > 0 && y_ + fye > 0) { good = 1; d = dd > 0 ? dd : -1.f; }
+    }
+  }
+  ok[i] = good; fx[i] = fxe; fy[i] = fye; dout[i] = d;
+}
+
+// used[i] = exists j: sqrt((rx[j]-qx[i])^2 + (ry[j]-qy[i])^2) < 1     (float arithmetic as in the reference)
+__global__ __launch_bounds__(256) void k_near_flags(int nq, const float* __restrict__ qx, const float* __restrict__ qy,
+                                                    int nr, const float* __restrict__ rx, const float* __restrict__ ry, int32_t* __restrict__ used) {
+  __shared__ float sx[256], sy[256];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const float x = i < nq ? qx[i] : 0.f, y = i < nq ? qy[i] : 0.f;
+  int u = 0;
+  for (int base = 0; base < nr; base += 256) {
+    const int j = base + threadIdx.x;
+    sx[threadIdx.x] = j < nr ? rx[j] : 1e30f;
+    sy[threadIdx.x] = j < nr ? ry[j] : 1e30f;
+    __syncthreads();
+    const int m = min(256, nr - base);
+    for (int k = 0; k < m; ++k) {
+      const float dx = sx[k] - x, dy = sy[k] - y;
+      if (sqrtf(dx * dx + dy * dy) < 1.0f) u = 1;
+    }
+    __syncthreads();
+  }
+  if (i < nq) used[i] = u;
+}
+
+// K15b: every pixel of the previous mask with label `lab` writes `lab` at its flowed position
+// (all writers store the same value, so the raster-order "last writer wins" of the reference is immaterial)
+__global__ void k_mask_warp(const int32_t* __restrict__ mask_last, const float* __restrict__ flow_last, int w, int h, int32_t lab, int32_t* __restrict__ mask_cur) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (k >= w) return;
+  const size_t o = (size_t)j * w + k;
+  if (mask_last[o] != lab) return;
+  const int fx = (int)flow_last[2 * o], fy = (int)flow_last[2 * o + 1];
+  if (k + fx < w && k + fx > 0 && j + fy < h && j + fy > 0) mask_cur[(size_t)(j + fy) * w + (k + fx)] = lab;
+}
+
+static Cam make_cam_Twc(const float* K4, const float* Twc) {   // Get3DinWorld: R = Twc[:3,:3], t = Twc[:3,3]
+  Cam c;
+  c.invfx = 1.0f / K4[0]; c.invfy = 1.0f / K4[1]; c.cx = K4[2]; c.cy = K4[3];
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) c.R[3 * i + j] = Twc[4 * i + j]; c.t[i] = Twc[4 * i + 3]; }
+  return c;
+}
+static Cam make_cam_Tcw(const float* K4, const float* Tcw) {   // UnprojectStereo*: Rwl = Rlw^T, twl = -Rlw^T tlw (cv::gemm rounding)
+  Cam c;
+  c.invfx = 1.0f / K4[0]; c.invfy = 1.0f / K4[1]; c.cx = K4[2]; c.cy = K4[3];
+  float nR[9];
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { c.R[3 * i + j] = Tcw[4 * j + i]; nR[3 * i + j] = -Tcw[4 * j + i]; }
+  for (int i = 0; i < 3; ++i) c.t[i] = (float)((double)nR[3 * i] * Tcw[3] + (double)nR[3 * i + 1] * Tcw[7] + (double)nR[3 * i + 2] * Tcw[11]);
+  return c;
+}
+
+}  // namespace vdo
+
+using namespace vdo;
+
+namespace {
+struct Scratch {   // small device scratch owned per call (n is a few thousand)
+  std::vector<void*> p;
+  hipStream_t s;
+  template <class T> T* up(const T* host, size_t n) {
+    T* d = nullptr;
+    if (hipMalloc((void**)&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    p.push_back(d);
+    if (host && n) hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, s);
+    return d;
+  }
+  template <class T> void down(T* host, const T* dev, size_t n) { if (host && n) hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, s); }
+  ~Scratch() { for (void* q : p) hipFree(q); }
+};
+int finish(hipStream_t s, const char* what) {
+  hipError_t e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
+  return VDO_OK;
+}
+}  // namespace
+
+extern "C" int vdo_propagate_static(vdo_frame_images* f, int n, const float* kx, const float* ky, float* depth_out) {
+  if (!f || n < 0) return set_error(VDO_ERR_INVALID, "bad argument");
+  if (n == 0) return VDO_OK;
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  Scratch S; S.s = f->ctx->stream;
+  float *dx = S.up(kx, n), *dy = S.up(ky, n), *dd = S.up<float>(nullptr, n);
+  if (!dd) return set_error(VDO_ERR_OOM, "hipMalloc failed");
+  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.s, 0, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, 0.f, dd, (int32_t*)nullptr);
+  S.down(depth_out, dd, n);
+  return finish(S.s, "vdo_propagate_static");
+}
+
+extern "C" int vdo_propagate_object(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth_obj, float* depth_out, int32_t* label_out) {
+  if (!f || n < 0) return set_error(VDO_ERR_INVALID, "bad argument");
+  if (n == 0) return VDO_OK;
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  Scratch S; S.s = f->ctx->stream;
+  float *dx = S.up(kx, n), *dy = S.up(ky, n), *dd = S.up<float>(nullptr, n);
+  int32_t* dl = S.up<int32_t>(nullptr, n);
+  if (!dl) return set_error(VDO_ERR_OOM, "hipMalloc failed");
+  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.s, 1, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, th_depth_obj, dd, dl);
+  S.down(depth_out, dd, n); S.down(label_out, dl, n);
+  return finish(S.s, "vdo_propagate_object");
+}
+
+extern "C" int vdo_mask_at(vdo_frame_images* f, int n, const float* cx, const float* cy, int32_t* label_out) {
+  if (!f || n < 0) return set_error(VDO_ERR_INVALID, "bad argument");
+  if (n == 0) return VDO_OK;
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  Scratch S; S.s = f->ctx->stream;
+  float *dx = S.up(cx, n), *dy = S.up(cy, n);
+  int32_t* dl = S.up<int32_t>(nullptr, n);
+  if (!dl) return set_error(VDO_ERR_OOM, "hipMalloc failed");
+  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.s, 2, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, 0.f, (float*)nullptr, dl);
+  S.down(label_out, dl, n);
+  return finish(S.s, "vdo_mask_at");
+}
+
+extern "C" int vdo_mask_warp(vdo_frame_images* cur, vdo_frame_images* last, int32_t label) {
+  if (!cur || !last || cur->w != last->w || cur->h != last->h) return set_error(VDO_ERR_INVALID, "bad argument");
+  int rc = ctx_bind(cur->ctx);
+  if (rc != VDO_OK) return rc;
+  hipLaunchKernelGGL(k_mask_warp, dim3((cur->w + 255) / 256, cur->h), dim3(256), 0, cur->ctx->stream, (const int32_t*)last->d_mask, (const float*)last->d_flow, cur->w, cur->h, label, cur->d_mask);
+  return VDO_OK;
+}
+
+extern "C" int vdo_frame_images_download_mask(vdo_frame_images* f, int32_t* mask_out) {
+  if (!f || !mask_out) return set_error(VDO_ERR_INVALID, "bad argument");
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  hipMemcpyAsync(mask_out, f->d_mask, 4 * (size_t)f->w * f->h, hipMemcpyDeviceToHost, f->ctx->stream);
+  return finish(f->ctx->stream, "vdo_frame_images_download_mask");
+}
+
+extern "C" int vdo_get3d_world(vdo_ctx* ctx, int n, const float* kx, const float* ky, const float* depth, const float K4[4], const float Twc[16], float* xyz_out) {
+  if (!ctx || n < 0) return set_error(VDO_ERR_INVALID, "bad argument");
+  if (n == 0) return VDO_OK;
+  int rc = ctx_bind(ctx);
+  if (rc != VDO_OK) return rc;
+  Scratch S; S.s = ctx->stream;
+  float *dx = S.up(kx, n), *dy = S.up(ky, n), *dd = S.up(depth, n), *dxyz = S.up<float>(nullptr, 3 * (size_t)n);
+  if (!dxyz) return set_error(VDO_ERR_OOM, "hipMalloc failed");
+  hipLaunchKernelGGL(k_get3d_world, dim3((n + 255) / 256), dim3(256), 0, S.s, n, (const float*)dx, (const float*)dy, (const float*)dd, make_cam_Twc(K4, Twc), dxyz);
+  S.down(xyz_out, dxyz, 3 * (size_t)n);
+  return finish(S.s, "vdo_get3d_world");
+}
+
+extern "C" int vdo_scene_flow(vdo_ctx* ctx, int n, const float* cur_x, const float* cur_y, const float* cur_d, const int32_t* cur_label, const float Tcw_cur[16],
+                              const float* last_x, const float* last_y, const float* last_d, const int32_t* last_label, const float Tcw_last[16],
+                              const float K4[4], float* flow3d_out, int32_t* obj_label_inout) {
+  if (!ctx || n < 0) return set_error(VDO_ERR_INVALID, "bad argument");
+  if (n == 0) return VDO_OK;
+  int rc = ctx_bind(ctx);
+  if (rc != VDO_OK) return rc;
+  Scratch S; S.s = ctx->stream;
+  float *a = S.up(cur_x, n), *b = S.up(cur_y, n), *c = S.up(cur_d, n), *d = S.up(last_x, n), *e = S.up(last_y, n), *g = S.up(last_d, n);
+  int32_t *cl = S.up(cur_label, n), *ll = S.up(last_label, n), *ol = S.up(obj_label_inout, n);
+  float* fl = S.up<float>(nullptr, 3 * (size_t)n);
+  if (!fl) return set_error(VDO_ERR_OOM, "hipMalloc failed");
+  hipLaunchKernelGGL(k_scene_flow, dim3((n + 255) / 256), dim3(256), 0, S.s, n, (const float*)a, (const float*)b, (const float*)c, (const int32_t*)cl, make_cam_Tcw(K4, Tcw_cur),
+                     (const float*)d, (const float*)e, (const float*)g, (const int32_t*)ll, make_cam_Tcw(K4, Tcw_last), fl, ol);
+  S.down(flow3d_out, fl, 3 * (size_t)n); S.down(obj_label_inout, ol, n);
+  return finish(S.s, "vdo_scene_flow");
+}
+
+// K14, static part.  Same contract as Tracking::RenewFrameInfo :2666-2790 (see the oracle for the
+// sequential statement).  GPU: predicates + O(n*m) distance flags; host: order-dependent selection.
+extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm_sta, const float* stat_x, const float* stat_y,
+                                int n_orb, const float* orb_x, const float* orb_y, int max_num_sta,
+                                float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y,
+                                int32_t* inlier_id, float* depth_out, int* n_out) {
+  if (!f || !n_out || n_tm < 0 || n_orb < 0) return set_error(VDO_ERR_INVALID, "bad argument");
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  Scratch S; S.s = f->ctx->stream;
+  // phase 1 candidates: the inlier static keys, in TM_sta order
+  std::vector<float> cx1, cy1; std::vector<int32_t> id1;
+  for (int i = 0; i < n_tm; ++i) if (tm_sta[i] != -1) { cx1.push_back(stat_x[tm_sta[i]]); cy1.push_back(stat_y[tm_sta[i]]); id1.push_back(tm_sta[i]); }
+  const int n1 = (int)cx1.size();
+  std::vector<int32_t> ok1(n1), ok2(n_orb), used2(n_orb);
+  std::vector<float> fx1(n1), fy1(n1), d1(n1), fx2(n_orb), fy2(n_orb), d2(n_orb);
+  float *dx1 = S.up(cx1.data(), n1), *dy1 = S.up(cy1.data(), n1);
+  int32_t* dok1 = S.up<int32_t>(nullptr, n1);
+  float *dfx1 = S.up<float>(nullptr, n1), *dfy1 = S.up<float>(nullptr, n1), *dd1 = S.up<float>(nullptr, n1);
+  if (n1) hipLaunchKernelGGL(k_renew_pred, dim3((n1 + 255) / 256), dim3(256), 0, S.s, n1, (const float*)dx1, (const float*)dy1, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok1, dfx1, dfy1, dd1);
+  float *dx2 = S.up(orb_x, n_orb), *dy2 = S.up(orb_y, n_orb);
+  int32_t *dok2 = S.up<int32_t>(nullptr, n_orb), *dused = S.up<int32_t>(nullptr, n_orb);
+  float *dfx2 = S.up<float>(nullptr, n_orb), *dfy2 = S.up<float>(nullptr, n_orb), *dd2 = S.up<float>(nullptr, n_orb);
+  if (!dd2 || !dd1) return set_error(VDO_ERR_OOM, "hipMalloc failed");
+  if (n_orb) hipLaunchKernelGGL(k_renew_pred, dim3((n_orb + 255) / 256), dim3(256), 0, S.s, n_orb, (const float*)dx2, (const float*)dy2, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok2, dfx2, dfy2, dd2);
+  S.down(ok1.data(), dok1, n1); S.down(fx1.data(), dfx1, n1); S.down(fy1.data(), dfy1, n1); S.down(d1.data(), dd1, n1);
+  rc = finish(S.s, "vdo_renew_static (carry)");
+  if (rc != VDO_OK) return rc;
+  // carry-over: first-come, stop once size > max (the reference checks after every element, :2703-2709)
+  int m = 0;
+  for (int i = 0; i < n1; ++i) {
+    if (ok1[i]) {
+      key_x[m] = cx1[i]; key_y[m] = cy1[i]; corr_x[m] = cx1[i] + fx1[i]; corr_y[m] = cy1[i] + fy1[i];
+      flow_x[m] = fx1[i]; flow_y[m] = fy1[i]; inlier_id[m] = id1[i]; depth_out[m] = d1[i];
+      ++m;
+    }
+    if (m > max_num_sta) break;
+  }
+  const int n_check = m;
+  if (m < max_num_sta && n_orb) {
+    float *dcx = S.up(key_x, n_check), *dcy = S.up(key_y, n_check);
+    hipLaunchKernelGGL(k_near_flags, dim3((n_orb + 255) / 256), dim3(256), 0, S.s, n_orb, (const float*)dx2, (const float*)dy2, n_check, (const float*)dcx, (const float*)dcy, dused);
+    S.down(used2.data(), dused, n_orb); S.down(ok2.data(), dok2, n_orb); S.down(fx2.data(), dfx2, n_orb); S.down(fy2.data(), dfy2, n_orb); S.down(d2.data(), dd2, n_orb);
+    rc = finish(S.s, "vdo_renew_static (top-up)");
+    if (rc != VDO_OK) return rc;
+    int tot = m, start_id = 0;
+    const int step = 20;
+    while (tot < max_num_sta) {                       // stride-20 interleave (:2722-2778)
+      if (start_id == step) break;
+      for (int i = start_id; i < n_orb; i += step) {
+        if (used2[i]) continue;
+        if (ok2[i]) {
+          key_x[m] = orb_x[i]; key_y[m] = orb_y[i]; corr_x[m] = orb_x[i] + fx2[i]; corr_y[m] = orb_y[i] + fy2[i];
+          flow_x[m] = fx2[i]; flow_y[m] = fy2[i]; inlier_id[m] = -1; depth_out[m] = d2[i];
+          ++m; ++tot;
+        }
+        if (tot >= max_num_sta) break;
+      }
+      ++start_id;
+    }
+  }
+  *n_out = m;
+  return VDO_OK;
+}
