@@ -42,6 +42,7 @@ typedef struct vdo_ctx vdo_ctx;
 int vdo_ctx_create(int device, void* hip_stream, vdo_ctx** out);
 int vdo_ctx_destroy(vdo_ctx* ctx);
 int vdo_ctx_synchronize(vdo_ctx* ctx);
+int vdo_ctx_stream(vdo_ctx* ctx, void** hip_stream_out);   /* the hipStream_t all calls are ordered on */
 
 /* ---- batch dynamic bundle adjustment ------------------------------------------------------
  * Replaces the g2o calls inside Optimizer::FullBatchOptimization (reference
@@ -137,11 +138,20 @@ int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out);
 int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_stats* stats);
 int vdo_ba_get_estimates(vdo_ba* ba, double* pose_out /*[n_pose][12]*/, double* point_out /*[n_point][3]*/);
 int vdo_ba_set_estimates(vdo_ba* ba, const double* pose, const double* point);
-/* Multi-GPU (edge/landmark shards): every rank owns a shard of the points with
- * all their edges and a replica of the poses; `fn` must sum `count` doubles at device pointer
- * `buf` across ranks (e.g. torch.distributed.all_reduce over RCCL) on the ctx stream. */
-typedef int (*vdo_allreduce_fn)(void* user, void* device_buf, int64_t count);
-int vdo_ba_set_allreduce(vdo_ba* ba, vdo_allreduce_fn fn, void* user);
+/* Multi-GPU (landmark-track shards).  One process per GPU; every rank creates its
+ * vdo_ba from a SHARD graph: all pose vertices, all pose-pose edges and priors (replicated), and
+ * the points it owns with every binary/ternary edge incident to them (vdo_ba_partition assigns
+ * whole tracks to ranks).  `fn` must reduce `count` doubles in place at the DEVICE pointer `buf`
+ * across ranks, stream-ordered on the ctx stream (op 0 = sum, 1 = max; e.g. torch.distributed
+ * all_reduce over RCCL).  Exchanges: Hpp|bp|chi2 (42P+2 doubles) once per linearisation, the
+ * block-Jacobi diagonal (21P+1) once per Levenberg trial, 6P doubles per PCG iteration, 3 scalars per
+ * trial.  Every rank returns the same poses; points come back for the owned shard only. */
+typedef int (*vdo_allreduce_fn)(void* user, void* device_buf, int64_t count, int op);
+int vdo_ba_set_allreduce(vdo_ba* ba, vdo_allreduce_fn fn, void* user, int shard_rank);
+/* Host-only (no GPU needed): owner rank of every point so that tracks (points linked by ternary
+ * edges) stay together, shards are contiguous in first-observing-frame order and balanced by
+ * incidence count. */
+int vdo_ba_partition(const vdo_ba_graph* g, int world, int32_t* owner_of_point /*[n_point]*/);
 
 /* ---- per-frame joint pose + optical-flow optimisation ------------------------------------------
  * Replaces the g2o calls inside Optimizer::PoseOptimizationFlow2Cam (reference

@@ -19,6 +19,15 @@ class Context:
         K.check(K.lib().vdo_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = device
 
+    @property
+    def stream_ptr(self) -> int:
+        """The hipStream_t every call of this context is ordered on (for ExternalStream wrappers)."""
+        out = C.c_void_p()
+        L = K.lib()
+        L.vdo_ctx_stream.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        K.check(L.vdo_ctx_stream(self._h, C.byref(out)))
+        return out.value or 0
+
     def synchronize(self):
         K.check(K.lib().vdo_ctx_synchronize(self._h))
 

@@ -75,20 +75,33 @@ struct BADev {
   double* part_m = nullptr;                          // [21][NPS] preconditioner partials
   double* scal = nullptr;
   int32_t* flags = nullptr;                          // [0] factor failure [1] pcg state [2] pcg iterations
+  // multi-GPU shards: poses replicated, points + their edges owned by one rank.
+  // Hpp | bp | red_chi are ONE allocation so that a linearisation needs a single all-reduce.
+  int sharded = 0, shard_rank = 0;
+  double* red_chi = nullptr;                         // [4] chi2, robust chi2, scale partials (follows bp)
+  double* msum = nullptr;                            // [P][21] block-Jacobi partials awaiting the all-reduce
+};
+
+// Cross-rank reduction hook (vdo_ba_set_allreduce); a sticky error is picked up at the next readback.
+struct Reducer {
+  int (*fn)(void*, void*, int64_t, int) = nullptr;
+  void* user = nullptr;
+  mutable int err = 0;
+  void operator()(void* buf, int64_t n, int op = 0) const { if (fn && !err) err = fn(user, buf, n, op); }
 };
 
 enum Scal { S_CHI2 = 0, S_RCHI2, S_MAXDIAG, S_RZ, S_PQ, S_RZ0, S_SCALE, S_RZNEW, S_COUNT = 16 };
 
 // ---- ba_sweep.hip
-void launch_errors(const BADev& d, int which, hipStream_t s);      // chi2 of estimate[which] -> scal
-void launch_linearize(const BADev& d, hipStream_t s);              // build system at estimate[0] (+chi2)
+void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R);      // chi2 of estimate[which] -> scal
+void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R);              // build system at estimate[0] (+chi2)
 void launch_sweep_only(const BADev& d, hipStream_t s);             // just the K18 tile sweep kernel (bench)
 // ---- ba_solve.hip
-void launch_max_diag(const BADev& d, hipStream_t s);
-void launch_factor(const BADev& d, double lambda, hipStream_t s);  // chain LDL^T + inverse blocks + block-Jacobi
-void launch_reduced_rhs(const BADev& d, hipStream_t s);
+void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R);
+void launch_factor(const BADev& d, double lambda, hipStream_t s, const Reducer& R);  // chain LDL^T + inverse blocks + block-Jacobi
+void launch_reduced_rhs(const BADev& d, hipStream_t s, const Reducer& R);
 void launch_pcg_init(const BADev& d, hipStream_t s);
-void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s);
+void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s, const Reducer& R);
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s);
 void launch_expand_binc(const BADev& d, hipStream_t s);            // Finc -> explicit Binc (download/debug only)
 

@@ -10,8 +10,7 @@ struct vdo_ba {
   vdo_ctx* ctx = nullptr;
   vdo::BADev d;
   std::vector<void*> allocs;
-  vdo_allreduce_fn allreduce = nullptr;
-  void* allreduce_user = nullptr;
+  vdo::Reducer red;               // cross-rank sum/max hook (vdo_ba_set_allreduce); unset = single GPU
   int oplus_calls = 0;            // VertexSE3::_numOplusCalls (same value on every vertex)
   double* h_scal = nullptr;       // pinned
   int32_t* h_flags = nullptr;     // pinned
@@ -29,6 +28,7 @@ inline int sync_check(vdo_ba* ba, const char* what) {
   if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
   e = hipGetLastError();
   if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
+  if (ba->red.err) return set_error(VDO_ERR_INVALID, "%s: all-reduce hook failed (%d)", what, ba->red.err);
   return VDO_OK;
 }
 }  // namespace vdo

@@ -35,7 +35,7 @@ int fetch(vdo_ba* ba) {
 
 // computeActiveErrors + activeRobustChi2 at estimate[which]
 int robust_chi2(vdo_ba* ba, int which, double* out) {
-  launch_errors(ba->d, which, ba->ctx->stream);
+  launch_errors(ba->d, which, ba->ctx->stream, ba->red);
   int rc = fetch(ba);
   if (rc != VDO_OK) return rc;
   *out = ba->h_scal[S_RCHI2];
@@ -46,8 +46,8 @@ int robust_chi2(vdo_ba* ba, int which, double* out) {
 int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, int* pcg_iters) {
   const BADev& d = ba->d;
   hipStream_t s = ba->ctx->stream;
-  launch_factor(d, lambda, s);
-  launch_reduced_rhs(d, s);
+  launch_factor(d, lambda, s, ba->red);
+  launch_reduced_rhs(d, s, ba->red);
   launch_pcg_init(d, s);
   double tol = opt->pcg_tolerance > 0 ? opt->pcg_tolerance : 1e-10;
   int maxit = opt->pcg_max_iterations > 0 ? opt->pcg_max_iterations : std::min(20000, 24 * d.P + 200);
@@ -56,7 +56,7 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
   *ok = true;
   while (it < maxit) {
     const int batch = std::min(16, maxit - it);
-    for (int k = 0; k < batch; ++k) launch_pcg_iter(d, lambda, tol2, s);
+    for (int k = 0; k < batch; ++k) launch_pcg_iter(d, lambda, tol2, s, ba->red);
     it += batch;
     int rc = fetch(ba);
     if (rc != VDO_OK) return rc;
@@ -92,8 +92,8 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
   int it = 0;
   for (; it < opt->max_iterations && !forceStop && ok; ++it) {
     double t0 = now_ms();
-    launch_linearize(d, s);                 // errors + buildSystem in one sweep (same estimate)
-    if (it == 0) launch_max_diag(d, s);
+    launch_linearize(d, s, ba->red);                 // errors + buildSystem in one sweep (same estimate)
+    if (it == 0) launch_max_diag(d, s, ba->red);
     CK(fetch(ba));
     st->ms_linearize += now_ms() - t0;
     last_err_chi = ba->h_scal[S_RCHI2];
@@ -110,7 +110,7 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
       const bool ortho = (++ba->oplus_calls > 1000);
       if (ortho) ba->oplus_calls = 0;
       launch_backsub_update(d, lambda, ortho, s);      // update() into the trial buffers (push/pop = keep [0])
-      launch_errors(d, 1, s);
+      launch_errors(d, 1, s, ba->red);
       CK(fetch(ba));
       st->ms_solve += now_ms() - t0;
       last_err_chi = tempChi = ba->h_scal[S_RCHI2];

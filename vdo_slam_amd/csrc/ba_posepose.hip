@@ -148,7 +148,7 @@ __device__ void jtwj6(const double* Ja, const double* Om, double w, const double
 
 // one thread per EdgeSE3 (k < Ep) or prior (k >= Ep).  ep_chi: [2][Ep+Npr] (chi2, robust chi2)
 template <bool BUILD>
-__global__ void k_posepose(BADev d, int which, double* ep_chi) {
+__global__ void k_posepose(BADev d, int which, double* ep_chi, int acc) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   const int n = d.Ep + d.Npr;
   if (k >= n) return;
@@ -168,16 +168,15 @@ __global__ void k_posepose(BADev d, int which, double* ep_chi) {
       double r[6];
       for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 6; ++j) s += info[i * 6 + j] * e[j]; r[i] = -s * rho1; }
       jtwj6(Ji, info, rho1, Ji, Hm);
-      for (int i = 0; i < 36; ++i) atomicAdd(d.Hpp + 36 * (int64_t)vi + i, Hm[i]);
+      if (acc) for (int i = 0; i < 36; ++i) atomicAdd(d.Hpp + 36 * (int64_t)vi + i, Hm[i]);
       jtwj6(Jj, info, rho1, Jj, Hm);
-      for (int i = 0; i < 36; ++i) atomicAdd(d.Hpp + 36 * (int64_t)vj + i, Hm[i]);
+      if (acc) for (int i = 0; i < 36; ++i) atomicAdd(d.Hpp + 36 * (int64_t)vj + i, Hm[i]);
       jtwj6(Ji, info, rho1, Jj, Hm);
       for (int i = 0; i < 36; ++i) d.Hpp_ep[36 * (int64_t)k + i] = Hm[i];
       for (int a = 0; a < 6; ++a) {
         double si = 0, sj = 0;
         for (int i = 0; i < 6; ++i) { si += Ji[i * 6 + a] * r[i]; sj += Jj[i * 6 + a] * r[i]; }
-        atomicAdd(d.bp + 6 * (int64_t)vi + a, si);
-        atomicAdd(d.bp + 6 * (int64_t)vj + a, sj);
+        if (acc) { atomicAdd(d.bp + 6 * (int64_t)vi + a, si); atomicAdd(d.bp + 6 * (int64_t)vj + a, sj); }
       }
     }
   } else {
@@ -193,11 +192,11 @@ __global__ void k_posepose(BADev d, int which, double* ep_chi) {
       double r[6];
       for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 6; ++j) s += info[i * 6 + j] * e[j]; r[i] = -s; }
       jtwj6(Ji, info, 1.0, Ji, Hm);
-      for (int i = 0; i < 36; ++i) atomicAdd(d.Hpp + 36 * (int64_t)v + i, Hm[i]);
+      if (acc) for (int i = 0; i < 36; ++i) atomicAdd(d.Hpp + 36 * (int64_t)v + i, Hm[i]);
       for (int a = 0; a < 6; ++a) {
         double si = 0;
         for (int i = 0; i < 6; ++i) si += Ji[i * 6 + a] * r[i];
-        atomicAdd(d.bp + 6 * (int64_t)v + a, si);
+        if (acc) atomicAdd(d.bp + 6 * (int64_t)v + a, si);
       }
     }
   }
@@ -207,8 +206,11 @@ __global__ void k_posepose(BADev d, int which, double* ep_chi) {
 void launch_posepose(const BADev& d, int which, bool build, double* ep_chi, hipStream_t s) {
   const int n2 = d.Ep + d.Npr;
   if (!n2) return;
-  if (build) hipLaunchKernelGGL(k_posepose<true>, dim3((n2 + 63) / 64), dim3(64), 0, s, d, which, ep_chi);
-  else hipLaunchKernelGGL(k_posepose<false>, dim3((n2 + 63) / 64), dim3(64), 0, s, d, which, ep_chi);
+  // Shards: the fp64 atomics below commit in a run-dependent order, so only rank 0 accumulates the
+  // (replicated) pose-pose terms and the all-reduce hands every rank the same bits.
+  const int acc = (!d.sharded || d.shard_rank == 0) ? 1 : 0;
+  if (build) hipLaunchKernelGGL(k_posepose<true>, dim3((n2 + 63) / 64), dim3(64), 0, s, d, which, ep_chi, acc);
+  else hipLaunchKernelGGL(k_posepose<false>, dim3((n2 + 63) / 64), dim3(64), 0, s, d, which, ep_chi, acc);
 }
 
 }  // namespace vdo

@@ -249,12 +249,26 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
 }
 
 // M_i = (Hpp_ii + lambda I - sum partials)^-1
+// SRC 0: gather this GPU's partials and invert.  Shards: SRC 1 gathers into msum (all-reduced by the
+// hook), SRC 2 inverts from the reduced msum.
+template <int SRC>
 __global__ __launch_bounds__(256) void k_precond_finalize(BADev d, double lambda) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per pose
   if (p >= d.P) return;
   double up[21];
-  wave_gather<21>(d.part_m, d.NPS, d.ps_off, d.ps_idx, p, up);
+  if (SRC != 2) wave_gather<21>(d.part_m, d.NPS, d.ps_off, d.ps_idx, p, up);
   if ((threadIdx.x & 63) != 0) return;
+  if (SRC == 1) {
+#pragma unroll
+    for (int i = 0; i < 21; ++i) d.msum[21 * (int64_t)p + i] = up[i];
+    if (p == 0) d.msum[21 * (int64_t)d.P] = (double)d.flags[0];     // a failed chain factor on ANY rank must stop every rank
+    return;
+  }
+  if (SRC == 2) {
+#pragma unroll
+    for (int i = 0; i < 21; ++i) up[i] = d.msum[21 * (int64_t)p + i];
+    if (p == 0 && d.msum[21 * (int64_t)d.P] > 0) atomicOr(d.flags, 1);
+  }
   double A[36], Ai[36];
   for (int i = 0; i < 36; ++i) A[i] = d.Hpp[36 * (int64_t)p + i];
   for (int i = 0; i < 6; ++i) A[7 * i] += lambda;
@@ -510,9 +524,11 @@ __global__ __launch_bounds__(1024) void k_pcg_vec(BADev d, double lambda, double
 __global__ __launch_bounds__(1024) void k_update(BADev d, double lambda, int ortho) {
   __shared__ double lds[17];
   double acc = 0;
+  const bool own_poses = !d.sharded || d.shard_rank == 0;     // replicated vertices count once in computeScale
   for (int p = threadIdx.x; p < d.P; p += blockDim.x) {
     const double* x = d.xp + 6 * (int64_t)p;
-    for (int i = 0; i < 6; ++i) acc += x[i] * (lambda * x[i] + d.bp[6 * (int64_t)p + i]);
+    if (own_poses)
+      for (int i = 0; i < 6; ++i) acc += x[i] * (lambda * x[i] + d.bp[6 * (int64_t)p + i]);
     const IsoD X = iso_load(d.pose[0] + 12 * (int64_t)p);
     iso_store(d.pose[1] + 12 * (int64_t)p, iso_oplus(X, x, ortho != 0));
   }
@@ -522,7 +538,7 @@ __global__ __launch_bounds__(1024) void k_update(BADev d, double lambda, int ort
     d.point[1][i] = d.point[0][i] + x;
   }
   acc = block_sum1(acc, lds);
-  if (threadIdx.x == 0) d.scal[S_SCALE] = acc;
+  if (threadIdx.x == 0) { if (d.sharded) d.red_chi[2] = acc; else d.scal[S_SCALE] = acc; }
 }
 
 // Finc -> explicit 6x3 blocks Binc[18][Ninc] (download / debugging only; never on the solve path)
@@ -552,25 +568,34 @@ void launch_expand_binc(const BADev& d, hipStream_t s) {
   if (d.n_tiles) hipLaunchKernelGGL(k_expand_binc, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), 9 * (size_t)d.max_slots * sizeof(double), s, d);
 }
 
-void launch_max_diag(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(1024), 0, s, d); }
+void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R) {
+  hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(1024), 0, s, d);
+  if (d.sharded) R(d.scal + S_MAXDIAG, 1, 1);
+}
 
-void launch_factor(const BADev& d, double lambda, hipStream_t s) {
+void launch_factor(const BADev& d, double lambda, hipStream_t s, const Reducer& R) {
   hipMemsetAsync(d.flags, 0, 4 * sizeof(int32_t), s);
   if (d.n_chains) hipLaunchKernelGGL(k_factor_chains, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, lambda);
   if (d.n_tiles) hipLaunchKernelGGL(k_precond_tile, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), 30 * (size_t)d.max_slots * sizeof(double), s, d);
-  hipLaunchKernelGGL(k_precond_finalize, dim3((d.P + 3) / 4), dim3(256), 0, s, d, lambda);
+  const dim3 g((d.P + 3) / 4), b(256);
+  if (!d.sharded) { hipLaunchKernelGGL(k_precond_finalize<0>, g, b, 0, s, d, lambda); return; }
+  hipLaunchKernelGGL(k_precond_finalize<1>, g, b, 0, s, d, lambda);
+  R(d.msum, 21 * (int64_t)d.P + 1);
+  hipLaunchKernelGGL(k_precond_finalize<2>, g, b, 0, s, d, lambda);
 }
 
-void launch_reduced_rhs(const BADev& d, hipStream_t s) {
+void launch_reduced_rhs(const BADev& d, hipStream_t s, const Reducer& R) {
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)nullptr);
   hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs);
+  if (d.sharded) R(d.qs, 6 * (int64_t)d.P);
 }
 
 void launch_pcg_init(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, s, d); }
 
-void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s) {
+void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s, const Reducer& R) {
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<0>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.pp);
   hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs);
+  if (d.sharded) R(d.qs, 6 * (int64_t)d.P);      // the one exchange per CG iteration: 6P doubles
   hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(1024), 0, s, d, lambda, tol2);
 }
 

@@ -226,26 +226,41 @@ __global__ __launch_bounds__(256) void k_finalize_pose(BADev d) {
 }
 
 // Fixed-order final reduction of the chi2 partials: tiles, then pose-pose edges.
-__global__ __launch_bounds__(256) void k_reduce_chi(BADev d) {
+// mode 0: single GPU, everything -> scal.   Shards: mode 1 = this rank's tiles -> red_chi (summed
+// across ranks by the hook), mode 2/3 = red_chi + the replicated pose-pose edges -> scal
+// (3 also publishes the all-reduced computeScale() partial that k_update left in red_chi[2]).
+__global__ __launch_bounds__(256) void k_reduce_chi(BADev d, int mode) {
   __shared__ double lds[24];
   const int nt = d.n_tiles, n2 = d.Ep + d.Npr;
   const double* ep_chi = d.part_chi + 2 * (int64_t)nt;
   double a0 = 0, a1 = 0;
-  for (int i = threadIdx.x; i < nt; i += blockDim.x) { a0 += d.part_chi[i]; a1 += d.part_chi[nt + i]; }
-  for (int i = threadIdx.x; i < n2; i += blockDim.x) { a0 += ep_chi[i]; a1 += ep_chi[n2 + i]; }
+  if (mode <= 1)
+    for (int i = threadIdx.x; i < nt; i += blockDim.x) { a0 += d.part_chi[i]; a1 += d.part_chi[nt + i]; }
+  if (mode != 1)
+    for (int i = threadIdx.x; i < n2; i += blockDim.x) { a0 += ep_chi[i]; a1 += ep_chi[n2 + i]; }
   a0 = block_sum1(a0, lds);
   a1 = block_sum1(a1, lds);
-  if (threadIdx.x == 0) { d.scal[S_CHI2] = a0; d.scal[S_RCHI2] = a1; }
+  if (threadIdx.x == 0) {
+    if (mode == 1) { d.red_chi[0] = a0; d.red_chi[1] = a1; }
+    else {
+      if (mode >= 2) { a0 += d.red_chi[0]; a1 += d.red_chi[1]; }
+      d.scal[S_CHI2] = a0; d.scal[S_RCHI2] = a1;
+      if (mode == 3) d.scal[S_SCALE] = d.red_chi[2];
+    }
+  }
 }
 
 // ---------------------------------------------------------------------------- launchers
 static double* ep_chi_buf(const BADev& d) { return d.part_chi + 2 * (int64_t)d.n_tiles; }
 
-void launch_errors(const BADev& d, int which, hipStream_t s) {
+void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R) {
   const size_t lds = sweep_lds_doubles(d.max_slots, false) * sizeof(double);
   if (d.n_tiles) hipLaunchKernelGGL(k_sweep_tile<false>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, which);
   launch_posepose(d, which, false, ep_chi_buf(d), s);
-  hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d);
+  if (!d.sharded) { hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 0); return; }
+  hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 1);
+  R(d.red_chi, 3);
+  hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, which == 1 ? 3 : 2);
 }
 
 void launch_sweep_only(const BADev& d, hipStream_t s) {
@@ -253,11 +268,15 @@ void launch_sweep_only(const BADev& d, hipStream_t s) {
   if (d.n_tiles) hipLaunchKernelGGL(k_sweep_tile<true>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, 0);
 }
 
-void launch_linearize(const BADev& d, hipStream_t s) {
+void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R) {
   launch_sweep_only(d, s);
   hipLaunchKernelGGL(k_finalize_pose, dim3((d.P + 3) / 4), dim3(256), 0, s, d);
-  launch_posepose(d, 0, true, ep_chi_buf(d), s);
-  hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d);
+  launch_posepose(d, 0, true, ep_chi_buf(d), s);           // shards: accumulated by rank 0 only (see launch_posepose)
+  if (d.sharded) {           // landmark-side partial sums of every rank -> full Hpp / bp / chi2, one exchange
+    hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 1);
+    R(d.Hpp, 42 * (int64_t)d.P + 2);
+  }
+  hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, d.sharded ? 2 : 0);
 }
 
 }  // namespace vdo

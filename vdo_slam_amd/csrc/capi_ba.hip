@@ -268,7 +268,10 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(ps_off, ps_off.data(), P + 1); UP(ps_idx, ps_idx.data(), NPS);
   UP(pe_off, pe_off.data(), P + 1); UP(pe_idx, pe_idx.data(), pe_idx.size());
   const double* Z = nullptr;
-  UP(Hpp, Z, 36 * (size_t)P); UP(bp, Z, 6 * (size_t)P); UP(Hll, Z, 9 * (size_t)L); UP(bl, Z, 3 * (size_t)L);
+  UP(Hpp, Z, 42 * (size_t)P + 4);                      // Hpp | bp | red_chi contiguous: one all-reduce per linearisation when sharded
+  ba->d.bp = ba->d.Hpp + 36 * (size_t)P; ba->d.red_chi = ba->d.bp + 6 * (size_t)P;
+  UP(msum, Z, 21 * (size_t)P + 1);
+  UP(Hll, Z, 9 * (size_t)L); UP(bl, Z, 3 * (size_t)L);
   UP(Finc, Z, 4 * ((size_t)Eb + (size_t)Et)); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep);
   UP(part_sums, Z, 32 * (size_t)NPS);
   UP(part_chi, Z, 2 * (size_t)n_tiles + 2 * (size_t)(Ep + Npr) + 2);
@@ -304,9 +307,11 @@ extern "C" int vdo_ba_destroy(vdo_ba* ba) {
   return VDO_OK;
 }
 
-extern "C" int vdo_ba_set_allreduce(vdo_ba* ba, vdo_allreduce_fn fn, void* user) {
-  if (!ba) return set_error(VDO_ERR_INVALID, "null handle");
-  ba->allreduce = fn; ba->allreduce_user = user;
+extern "C" int vdo_ba_set_allreduce(vdo_ba* ba, vdo_allreduce_fn fn, void* user, int shard_rank) {
+  if (!ba || shard_rank < 0) return set_error(VDO_ERR_INVALID, "vdo_ba_set_allreduce: bad argument");
+  ba->red.fn = fn; ba->red.user = user; ba->red.err = 0;
+  ba->d.sharded = fn ? 1 : 0;
+  ba->d.shard_rank = fn ? shard_rank : 0;
   return VDO_OK;
 }
 
@@ -326,7 +331,7 @@ extern "C" int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep) {
     hipEventElapsedTime(&ms, ba->ev0, ba->ev1);
     *ms_sweep = ms / repeat;
   }
-  for (int i = 0; i < (ms_sweep ? 1 : repeat); ++i) launch_linearize(ba->d, s);
+  for (int i = 0; i < (ms_sweep ? 1 : repeat); ++i) launch_linearize(ba->d, s, ba->red);
   return sync_check(ba, "vdo_ba_linearize");
 }
 

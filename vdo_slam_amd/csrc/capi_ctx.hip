@@ -62,3 +62,9 @@ extern "C" int vdo_ctx_synchronize(vdo_ctx* ctx) {
   if (e != hipSuccess) return vdo::set_error(VDO_ERR_NO_DEVICE, "hipStreamSynchronize: %s", hipGetErrorString(e));
   return VDO_OK;
 }
+
+extern "C" int vdo_ctx_stream(vdo_ctx* ctx, void** hip_stream_out) {
+  if (!ctx || !hip_stream_out) return vdo::set_error(VDO_ERR_INVALID, "vdo_ctx_stream: null argument");
+  *hip_stream_out = (void*)ctx->stream;
+  return VDO_OK;
+}

@@ -1,0 +1,139 @@
+"""Multi-GPU batch BA: landmark-track shards, one process per GPU.
+
+Every rank holds all pose vertices and pose-pose edges (replicated) and the points it owns with
+their binary/ternary edges.  The C-ABI solver (vdo_ba_optimize) calls back into
+:class:`AllReduceHook` for the few exchanges it needs (see include/vdo_slam_hip.h,
+vdo_ba_set_allreduce); here that is ``torch.distributed.all_reduce`` — RCCL over xGMI with the
+"nccl" backend, gloo for CPU tests.  Nothing in this file computes: it only cuts the graph and
+moves bytes.
+"""
+import ctypes as C
+import dataclasses
+import os
+import sys
+
+import numpy as np
+
+from . import _capi as K
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_int)
+
+
+def partition(graph, world: int) -> np.ndarray:
+    """Owner rank of every point (host-only C-ABI call: works without a GPU)."""
+    gc, keep = K.graph_to_c(graph)
+    owner = np.zeros(graph.n_point, np.int32)
+    L = K.lib()
+    L.vdo_ba_partition.argtypes = [C.POINTER(K.BAGraphC), C.c_int, K.c_int32_p]
+    K.check(L.vdo_ba_partition(C.byref(gc), world, owner.ctypes.data_as(K.c_int32_p)))
+    return owner
+
+
+def shard_graph(graph, owner: np.ndarray, rank: int):
+    """Shard of ``graph`` for ``rank``: (BAGraph, ids of its points in the full graph)."""
+    mine = np.nonzero(owner == rank)[0].astype(np.int32)
+    new_of_old = np.full(graph.n_point, -1, np.int32)
+    new_of_old[mine] = np.arange(mine.size, dtype=np.int32)
+    eb = np.nonzero(owner[graph.eb_point] == rank)[0] if graph.n_eb else np.zeros(0, np.int64)
+    et = np.nonzero(owner[graph.et_p1] == rank)[0] if graph.n_et else np.zeros(0, np.int64)
+    if graph.n_et:
+        assert np.all(owner[graph.et_p2[et]] == rank), "a track was split across ranks"
+    g = dataclasses.replace(
+        graph,
+        point=np.ascontiguousarray(graph.point[mine]),
+        eb_pose=graph.eb_pose[eb], eb_point=new_of_old[graph.eb_point[eb]],
+        eb_z=np.ascontiguousarray(graph.eb_z[:, eb]), eb_w=graph.eb_w[eb],
+        et_p1=new_of_old[graph.et_p1[et]], et_p2=new_of_old[graph.et_p2[et]], et_pose=graph.et_pose[et],
+        et_z=np.ascontiguousarray(graph.et_z[:, et]), et_w=graph.et_w[et],
+        point_gt=None if graph.point_gt is None else graph.point_gt[mine])
+    return g, mine
+
+
+class _DevView:
+    """Zero-copy view of ``count`` doubles at a raw device pointer for ``torch.as_tensor``."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False), "version": 3, "strides": None}
+
+
+class AllReduceHook:
+    """ctypes callback handed to ``vdo_ba_set_allreduce``: in-place sum / max over the process group."""
+
+    def __init__(self, group=None, stream_ptr: int = 0, on_device: bool = True):
+        import torch
+        import torch.distributed as dist
+        self.calls = 0
+        self.doubles = 0
+        self.error = None
+        trace = bool(os.environ.get("VDO_DIST_TRACE"))
+
+        def fn(_user, buf, count, op):
+            try:
+                rop = dist.ReduceOp.MAX if op == 1 else dist.ReduceOp.SUM
+                if trace:
+                    print(f"[allreduce rank {dist.get_rank(group)}] #{self.calls} count={count} op={op}", file=sys.stderr, flush=True)
+                if on_device:
+                    ext = torch.cuda.ExternalStream(stream_ptr) if stream_ptr else torch.cuda.current_stream()
+                    with torch.cuda.stream(ext):
+                        t = torch.as_tensor(_DevView(buf, count), device="cuda")
+                        if dist.get_backend(group) == "gloo":       # single-box tests: stage through the host
+                            h = t.cpu()
+                            dist.all_reduce(h, op=rop, group=group)
+                            t.copy_(h)
+                        else:
+                            dist.all_reduce(t, op=rop, group=group)
+                else:
+                    arr = np.ctypeslib.as_array(C.cast(buf, C.POINTER(C.c_double)), shape=(int(count),))
+                    dist.all_reduce(torch.from_numpy(arr), op=rop, group=group)
+                self.calls += 1
+                self.doubles += int(count)
+                return 0
+            except Exception as e:                     # never unwind through the C frames
+                self.error = e
+                return -1
+
+        self.cfunc = ALLREDUCE_FN(fn)
+
+
+class ShardedBatchBA:
+    """Batch BA over ``dist.get_world_size()`` GPUs.  ``optimize`` returns the same LM statistics on
+    every rank; ``estimates`` returns the full pose array and the full point array (shards gathered)."""
+
+    def __init__(self, ctx, graph, group=None, owner=None):
+        import torch.distributed as dist
+        from .ba import BatchBA
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.group = group
+        self.full = graph
+        self.owner = partition(graph, self.world) if owner is None else owner
+        self.shard, self.mine = shard_graph(graph, self.owner, self.rank)
+        self.ba = BatchBA(ctx, self.shard)
+        self.hook = AllReduceHook(group, stream_ptr=ctx.stream_ptr)
+        L = K.lib()
+        L.vdo_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int]
+        K.check(L.vdo_ba_set_allreduce(self.ba._h, self.hook.cfunc, None, self.rank))
+
+    def optimize(self, **kw):
+        try:
+            st = self.ba.optimize(**kw)
+        except K.VdoError as e:
+            if self.hook.error is not None:
+                raise RuntimeError(f"all-reduce hook failed: {self.hook.error!r}") from e
+            raise
+        return st
+
+    def estimates(self):
+        import torch
+        import torch.distributed as dist
+        pose, pt = self.ba.estimates()
+        full = np.zeros((self.full.n_point, 3))
+        full[self.mine] = pt
+        t = torch.from_numpy(full)
+        if dist.get_backend(self.group) == "nccl":
+            tg = t.cuda(); dist.all_reduce(tg, group=self.group); full = tg.cpu().numpy()
+        else:
+            dist.all_reduce(t, group=self.group)
+        return pose, full
+
+    def close(self):
+        self.ba.close()
