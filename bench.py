@@ -115,8 +115,12 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (libvdo_hip has no CPU fallback)")
     torch.cuda.set_device(local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    use_dist = world > 1 or bool(os.environ.get("VDO_BENCH_FORCE_DIST"))     # FORCE: exercise the RCCL legs on a 1-GPU box
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
+        os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
+        import datetime
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=300))
     stream = torch.cuda.Stream()          # non-default stream shared by torch events and libvdo_hip
     torch.cuda.set_stream(stream)
 
@@ -154,7 +158,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -167,7 +171,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if world > 1:
+    if use_dist:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     fps = world * args.steps / dt
@@ -198,6 +202,25 @@ def main():
         out["ms_per_lm_iter"] = ms_iter
         out["config"]["batch_graph"] = f"{g.n_cam} frames, {g.n_pose} pose/motion vertices, {g.n_point} points, {g.n_eb} EdgeSE3PointXYZ, {g.n_et} ternary"
         ba.close()
+        if use_dist and not os.environ.get("VDO_BENCH_NO_SHARDED"):
+            # ---- the same batch graph SHARDED over the ranks (landmark tracks; all-reduce over RCCL/xGMI)
+            try:
+                from vdo_slam_amd.dist import ShardedBatchBA
+                gs = synth.make_ba_graph(60, 30000, 5, 800, seed=1)
+                sh = ShardedBatchBA(ctx, gs)
+                sh.optimize(max_iterations=1, gain_threshold=-1.0)
+                sh.ba.set_estimates(sh.shard.pose, sh.shard.point)
+                calls0 = sh.hook.calls
+                barrier()
+                t0 = time.perf_counter()
+                st = sh.optimize(max_iterations=5, gain_threshold=-1.0)
+                barrier()
+                out["ms_per_lm_iter_sharded"] = (time.perf_counter() - t0) * 1e3 / max(1, st.iterations)
+                out["config"]["batch_sharding"] = (f"landmark tracks over {world} ranks: {sh.mine.size}/{gs.n_point} points on rank 0, "
+                                                   f"{sh.hook.calls - calls0} all-reduces in {st.iterations} LM iterations, final chi2 {st.final_chi2:.6g}")
+                sh.close()
+            except Exception as e:                       # the replica numbers above stay valid
+                out["batch_sharded_error"] = repr(e)[:300]
         # ---- roofline of the dominant kernel (K18 sweep) on an HBM-sized graph
         gr = synth.make_ba_graph(200, args.roofline_static, 10, 1500, seed=7 + rank)
         bar = BatchBA(ctx, gr)
@@ -223,7 +246,7 @@ def main():
                                "ms_per_stage": cstage}
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -90,6 +90,17 @@ def test_shard_systems_sum_to_the_full_system_gloo_world2(tmp_path, oracle):
 
 
 @pytest.mark.gpu
+def test_sharded_lm_over_rccl_world1(tmp_path):
+    """The hook on the "nccl" (= RCCL) backend: raw-device-pointer tensors, external stream, SUM and MAX.
+    One rank is all a 1-GPU box allows; the multi-rank protocol is covered by the gloo test below."""
+    res = _run_world("gpu_lm", 1, tmp_path, backend="nccl", timeout=240)
+    for c in res[0]["cases"]:
+        assert c["it"][0] == c["it"][1] and c["trials"][0] == c["trials"][1], c
+        assert abs(c["chi"][0] - c["chi"][1]) <= 1e-6 * c["chi"][1], c
+        assert c["pose_err"] < 1e-6 and c["point_err"] < 1e-5 and c["hook_calls"] > 10
+
+
+@pytest.mark.gpu
 def test_sharded_lm_matches_single_gpu_world2(tmp_path):
     """Two ranks sharing cuda:0 (gloo between them; the data path is the same hook RCCL serves)."""
     res = _run_world("gpu_lm", 2, tmp_path, timeout=240)
