@@ -197,6 +197,34 @@ int vdo_flow2_batch_destroy(vdo_flow2_batch* batch);
 /* Convenience: create + run + fetch + destroy for a single problem. */
 int vdo_flow2_optimize(vdo_ctx* ctx, const vdo_flow2_problem* p, vdo_flow2_result* result, double* flow_out, uint8_t* inlier_out);
 
+/* ---- non-joint per-frame pose refinement (bJoint == false) -----------------------------------------
+ * Replaces the g2o calls inside Optimizer::PoseOptimizationNew (reference src/Optimizer.cc:2177-2331;
+ * camera, called from src/Tracking.cc:699) and Optimizer::PoseOptimizationObjMot (:2544-2753; per
+ * object, src/Tracking.cc:936): 1 VertexSE3Expmap + n unary reprojection edges with information I2
+ * (EdgeSE3ProjectXYZOnlyPose with Huber sqrt(0.01) / EdgeSE3ProjectXYZOnlyObjMotion without kernel),
+ * BlockSolver_6_3 + LinearSolverDense, optimize(100 / 200), one classification round at chi2 > 0.01f.
+ * Results use vdo_flow2_result. */
+typedef struct vdo_pose_problem {
+  int32_t n;              /* correspondences                                               */
+  int32_t kind;           /* 0 EdgeSE3ProjectXYZOnlyPose (K) ; 1 EdgeSE3ProjectXYZOnlyObjMotion (P) */
+  const double* obs;      /* [n][2] current-frame pixel (kpUn.pt)                          */
+  const double* Xw;       /* [n][3] back-projected last-frame point (float -> double)      */
+  double K[4];            /* fx, fy, cx, cy (kind 0)                                       */
+  double P[12];           /* 3x4 row-major K*Tcw (kind 1, Optimizer.cc:2604-2606)          */
+  double T0[16];          /* initial estimate: mTcw (kind 0) / Tcw^-1 * mInitModel (kind 1) */
+  double huber_delta;     /* (double)sqrtf(0.01f) kind 0 (:2213) ; <= 0: no kernel (kind 1) */
+  double chi2_gate;       /* 0.01f (:2181, :2546)                                          */
+  int32_t max_iterations; /* 100 (:2269) / 200 (:2664)                                     */
+  int32_t pad;
+} vdo_pose_problem;
+
+typedef struct vdo_pose_batch vdo_pose_batch;
+int vdo_pose_batch_create(vdo_ctx* ctx, int n_problems, const vdo_pose_problem* probs, vdo_pose_batch** out);
+int vdo_pose_batch_run(vdo_pose_batch* batch);       /* one kernel launch, stream-ordered, no sync */
+int vdo_pose_batch_fetch(vdo_pose_batch* batch, vdo_flow2_result* results, uint8_t** inlier_out);
+int vdo_pose_batch_destroy(vdo_pose_batch* batch);
+int vdo_pose_optimize(vdo_ctx* ctx, const vdo_pose_problem* p, vdo_flow2_result* result, uint8_t* inlier_out);
+
 /* ---- ORB front-end ------------------------------------------------------------------------------
  * Replaces ORBextractor::ORBextractor (reference src/ORBextractor.cc:399-459) and
  * ORBextractor::operator() (:1035-1110): ComputePyramid (:1112-1137), ComputeKeyPointsOctTree

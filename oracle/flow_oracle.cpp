@@ -352,3 +352,200 @@ extern "C" int vdo_oracle_flow2_optimize(const vdo_flow2_problem* p, double T_ou
   S.T.toMatrix4(T_out);
   return N - nbad;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Non-joint pose refinement: Optimizer::PoseOptimizationNew (src/Optimizer.cc:2177-2331) and
+// Optimizer::PoseOptimizationObjMot (:2544-2753).  One VertexSE3Expmap and n unary edges
+//   EdgeSE3ProjectXYZOnlyPose       g2o/types/types_six_dof_expmap.h:151-179, .cpp:266-296
+//   EdgeSE3ProjectXYZOnlyObjMotion  .h:214-245, .cpp:394-443
+// No marginalised vertex, so BlockSolver::solve takes the non-Schur branch
+// (g2o/core/block_solver.hpp:357-366): (Hpp + lambda I) x = b by the dense LDLT.
+namespace {
+struct PoseOnly {
+  const vdo_pose_problem* P;
+  int N;
+  SE3Quat T;
+  Huber hub;
+  bool robust;
+  double Hpp[36], bp[6], x[6];
+  std::vector<double> err;
+
+  explicit PoseOnly(const vdo_pose_problem* p) : P(p), N(p->n), robust(p->huber_delta > 0) {
+    M3 R;
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) = p->T0[4 * i + j];
+    T = SE3Quat::fromRt(R, v3(p->T0[3], p->T0[7], p->T0[11]));
+    if (robust) hub.setDelta(p->huber_delta);
+    err.resize(2 * (size_t)N);
+    for (int i = 0; i < 6; ++i) x[i] = 0;
+  }
+  void project(const V3& pc, double& u, double& v) const {
+    if (P->kind == 0) { u = pc.x / pc.z * P->K[0] + P->K[2]; v = pc.y / pc.z * P->K[1] + P->K[3]; }
+    else {
+      const double* M = P->P;
+      const double m1 = M[0] * pc.x + M[1] * pc.y + M[2] * pc.z + M[3];
+      const double m2 = M[4] * pc.x + M[5] * pc.y + M[6] * pc.z + M[7];
+      const double m3 = M[8] * pc.x + M[9] * pc.y + M[10] * pc.z + M[11];
+      const double inv = 1.0 / m3;
+      u = m1 * inv; v = m2 * inv;
+    }
+  }
+  double compute_errors() {
+    double rchi = 0;
+    for (int i = 0; i < N; ++i) {
+      const V3 pc = T.map(v3(P->Xw[3 * i], P->Xw[3 * i + 1], P->Xw[3 * i + 2]));
+      double u, v;
+      project(pc, u, v);
+      const double e0 = P->obs[2 * i] - u, e1 = P->obs[2 * i + 1] - v;
+      err[2 * i] = e0; err[2 * i + 1] = e1;
+      const double c = e0 * e0 + e1 * e1;
+      double r0 = c, r1 = 1;
+      if (robust) hub.robustify(c, r0, r1);
+      rchi += r0;
+    }
+    return rchi;
+  }
+  void jacobian(const V3& pc, double* J) const {
+    const double x_ = pc.x, y_ = pc.y, z_ = pc.z;
+    if (P->kind == 0) {
+      const double fx = P->K[0], fy = P->K[1];
+      const double invz = 1.0 / z_, invz_2 = invz * invz;
+      J[0] = x_ * y_ * invz_2 * fx; J[1] = -(1 + (x_ * x_ * invz_2)) * fx; J[2] = y_ * invz * fx; J[3] = -invz * fx; J[4] = 0; J[5] = x_ * invz_2 * fx;
+      J[6] = (1 + y_ * y_ * invz_2) * fy; J[7] = -x_ * y_ * invz_2 * fy; J[8] = -x_ * invz * fy; J[9] = 0; J[10] = -invz * fy; J[11] = y_ * invz_2 * fy;
+    } else {
+      const double* M = P->P;
+      const double m1 = M[0] * x_ + M[1] * y_ + M[2] * z_ + M[3];
+      const double m2 = M[4] * x_ + M[5] * y_ + M[6] * z_ + M[7];
+      const double m3 = M[8] * x_ + M[9] * y_ + M[10] * z_ + M[11];
+      const double invm3 = 1.0 / m3, invm3_2 = invm3 * invm3;
+      double t[6];
+      t[0] = invm3_2 * (M[0] * m3 - M[8] * m1); t[1] = invm3_2 * (M[1] * m3 - M[9] * m1); t[2] = invm3_2 * (M[2] * m3 - M[10] * m1);
+      t[3] = invm3_2 * (M[4] * m3 - M[8] * m2); t[4] = invm3_2 * (M[5] * m3 - M[9] * m2); t[5] = invm3_2 * (M[6] * m3 - M[10] * m2);
+      for (int r = 0; r < 2; ++r) {
+        const double* tr = t + 3 * r;
+        J[6 * r + 0] = -1.0 * (y_ * tr[2] - z_ * tr[1]);
+        J[6 * r + 1] = -1.0 * (z_ * tr[0] - x_ * tr[2]);
+        J[6 * r + 2] = -1.0 * (x_ * tr[1] - y_ * tr[0]);
+        J[6 * r + 3] = -1.0 * tr[0]; J[6 * r + 4] = -1.0 * tr[1]; J[6 * r + 5] = -1.0 * tr[2];
+      }
+    }
+  }
+  void build_system() {
+    for (int i = 0; i < 36; ++i) Hpp[i] = 0;
+    for (int i = 0; i < 6; ++i) bp[i] = 0;
+    for (int i = 0; i < N; ++i) {
+      const V3 pc = T.map(v3(P->Xw[3 * i], P->Xw[3 * i + 1], P->Xw[3 * i + 2]));
+      double J[12];
+      jacobian(pc, J);
+      const double e0 = err[2 * i], e1 = err[2 * i + 1];
+      double r0, r1 = 1;
+      if (robust) hub.robustify(e0 * e0 + e1 * e1, r0, r1);
+      // base_unary_edge.hpp:55-66:  b -= ((rho1 * A^T) * Omega) * e ;  A += (A^T * (rho1 Omega)) * A   (Omega = I2)
+      for (int a = 0; a < 6; ++a) {
+        bp[a] -= (r1 * J[a]) * e0 + (r1 * J[6 + a]) * e1;
+        for (int c = 0; c < 6; ++c) Hpp[a * 6 + c] += (J[a] * r1) * J[c] + (J[6 + a] * r1) * J[6 + c];
+      }
+    }
+  }
+  bool solve(double lambda) {
+    double Hs[36];
+    for (int i = 0; i < 36; ++i) Hs[i] = Hpp[i];
+    for (int j = 0; j < 6; ++j) Hs[7 * j] += lambda;
+    LDLT6 ch;
+    ch.compute(Hs);
+    if (!ch.isPositive()) return false;
+    ch.solve(bp, x);
+    return true;
+  }
+};
+}  // namespace
+
+extern "C" int vdo_oracle_edge_unary_jac(const vdo_pose_problem* p, const double* T16, const double* Xw, const double* obs, double* err2, double* J12) {
+  // KAT helper: error and analytic Jacobian of one unary edge at pose T16 (4x4 row-major)
+  vdo_pose_problem q = *p;
+  q.n = 1; q.obs = obs; q.Xw = Xw;
+  for (int i = 0; i < 16; ++i) q.T0[i] = T16[i];
+  PoseOnly S(&q);
+  S.compute_errors();
+  err2[0] = S.err[0]; err2[1] = S.err[1];
+  S.jacobian(S.T.map(v3(Xw[0], Xw[1], Xw[2])), J12);
+  return 0;
+}
+
+extern "C" int vdo_oracle_pose_optimize(const vdo_pose_problem* p, double T_out[16], uint8_t* inlier_out, vdo_lm_stats* st) {
+  vdo_lm_stats local;
+  if (!st) st = &local;
+  std::memset(st, 0, sizeof(*st));
+  const int N = p->n;
+  if (N < 3) {   // nInitialCorrespondences<3 (Optimizer.cc:2264-2265 returns 0; :2659-2660 returns eye)
+    for (int i = 0; i < 16; ++i) T_out[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    return 0;
+  }
+  PoseOnly S(p);
+  double lambda = -1, ni = 2;
+  int nBad = 0;
+  const double tau = 1e-5, upper = 2. / 3., lower = 1. / 3.;
+  const int maxTrials = 10;
+  bool ok = true;
+  double chi2_check = 0, last_err_chi = S.compute_errors();
+  st->initial_chi2 = last_err_chi;
+  int it = 0;
+  for (; it < p->max_iterations && ok; ++it) {
+    last_err_chi = S.compute_errors();
+    double currentChi = last_err_chi, tempChi = currentChi;
+    const double iniChi = currentChi;
+    S.build_system();
+    if (it == 0) {
+      double m = 0;
+      for (int j = 0; j < 6; ++j) m = std::max(std::fabs(S.Hpp[7 * j]), m);
+      lambda = tau * m; ni = 2; nBad = 0;
+    }
+    double rho = 0;
+    int qmax = 0;
+    do {
+      const SE3Quat Tb = S.T;
+      const bool ok2 = S.solve(lambda);
+      S.T = SE3Quat::exp(S.x).compose(S.T);
+      last_err_chi = tempChi = S.compute_errors();
+      if (!ok2) tempChi = std::numeric_limits<double>::max();
+      rho = currentChi - tempChi;
+      double scale = 0;
+      for (int j = 0; j < 6; ++j) scale += S.x[j] * (lambda * S.x[j] + S.bp[j]);
+      scale += 1e-3;
+      rho /= scale;
+      if (rho > 0 && std::isfinite(tempChi)) {
+        double alpha = 1. - std::pow((2 * rho - 1), 3);
+        alpha = std::min(alpha, upper);
+        lambda *= std::max(lower, alpha); ni = 2; currentChi = tempChi;
+      } else {
+        lambda *= ni; ni *= 2;
+        S.T = Tb;
+      }
+      ++qmax; ++st->total_trials;
+    } while (rho < 0 && qmax < maxTrials);
+    int result;
+    if (qmax == maxTrials || rho == 0) result = 1;
+    else {
+      if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+      result = nBad >= 3 ? 1 : 0;
+    }
+    ok = (result == 0);
+    if (!ok) st->stop_reason = 1;
+    if (chi2_check < last_err_chi && it > 0) { ok = false; st->stop_reason = 2; }
+    chi2_check = last_err_chi;
+    if (it < VDO_LM_MAX_TRACE) { st->chi2_trace[it] = last_err_chi; st->trials_trace[it] = qmax; }
+  }
+  st->iterations = it;
+  st->final_lambda = lambda;
+  st->final_chi2 = last_err_chi;
+  // classification on the stored errors of the last evaluated trial (Optimizer.cc:2284-2299, 2679-2694)
+  int nbad = 0;
+  const float gate = (float)p->chi2_gate;
+  for (int i = 0; i < N; ++i) {
+    const float chi2 = (float)(S.err[2 * i] * S.err[2 * i] + S.err[2 * i + 1] * S.err[2 * i + 1]);
+    const bool out = chi2 > gate;
+    if (inlier_out) inlier_out[i] = out ? 0 : 1;
+    nbad += out;
+  }
+  S.T.toMatrix4(T_out);
+  return N - nbad;
+}

@@ -123,6 +123,24 @@ typedef struct vdo_flow2_problem {
 int vdo_oracle_flow2_optimize(const vdo_flow2_problem* p, double T_out[16], double* flow_out,
                               uint8_t* inlier_out, vdo_lm_stats* stats);
 
+/* Non-joint per-frame pose refinement (Optimizer::PoseOptimizationNew src/Optimizer.cc:2177-2331,
+ * Optimizer::PoseOptimizationObjMot :2544-2753): one VertexSE3Expmap, n unary reprojection edges,
+ * information I2.  Same layout as include/vdo_slam_hip.h. */
+typedef struct vdo_pose_problem {
+  int32_t n;
+  int32_t kind;           /* 0 EdgeSE3ProjectXYZOnlyPose (K) ; 1 EdgeSE3ProjectXYZOnlyObjMotion (P) */
+  const double* obs;      /* [n][2] current-frame pixel                                  */
+  const double* Xw;       /* [n][3] 3-D point                                            */
+  double K[4];            /* fx, fy, cx, cy (kind 0)                                     */
+  double P[12];           /* 3x4 row-major K*Tcw (kind 1)                                */
+  double T0[16];          /* initial estimate                                            */
+  double huber_delta;     /* (double)sqrtf(0.01f) kind 0 ; <= 0: no kernel (kind 1)      */
+  double chi2_gate;       /* 0.01f                                                       */
+  int32_t max_iterations; /* 100 / 200                                                   */
+  int32_t pad;
+} vdo_pose_problem;
+int vdo_oracle_pose_optimize(const vdo_pose_problem* p, double T_out[16], uint8_t* inlier_out, vdo_lm_stats* stats);
+
 /* ---- front-end (frontend_oracle.cpp) ------------------------------------------------------*/
 typedef struct vdo_orb_params {   /* ORBextractor ctor arguments (include/ORBextractor.h:39-40) */
   int32_t n_features;     /* 2500 */

@@ -51,6 +51,9 @@ def load():
     L.vdo_oracle_gaussian_blur7.argtypes = [u8p, C.c_int, C.c_int, u8p]
     L.vdo_oracle_frame_static_filter.argtypes = [C.c_int, fp, fp, i32p, i32p, fp, fp, C.c_int, C.c_int, C.c_float, i32p, fp, fp, fp, fp, fp]
     L.vdo_oracle_frame_object_sample.argtypes = [i32p, fp, fp, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, i32p]
+    from vdo_slam_amd.pose_only import PoseProblemC
+    L.vdo_oracle_pose_optimize.argtypes = [C.POINTER(PoseProblemC), dp, K.c_uint8_p, C.POINTER(K.LMStatsC)]
+    L.vdo_oracle_edge_unary_jac.argtypes = [C.POINTER(PoseProblemC), dp, dp, dp, dp, dp]
     L.vdo_oracle_propagate_static.argtypes = [C.c_int, fp, fp, fp, C.c_int, C.c_int, fp]
     L.vdo_oracle_propagate_object.argtypes = [C.c_int, fp, fp, fp, i32p, C.c_int, C.c_int, C.c_float, fp, i32p]
     L.vdo_oracle_scene_flow.argtypes = [C.c_int, fp, fp, fp, i32p, fp, fp, fp, fp, i32p, fp, fp, fp, i32p]

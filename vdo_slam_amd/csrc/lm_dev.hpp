@@ -1,0 +1,180 @@
+// Device helpers shared by the per-frame Levenberg-Marquardt kernels (flow2.hip, pose_only.hip):
+// SE3Quat / Eigen quaternion arithmetic in the reference's operation order
+// (g2o/types/se3quat.h:41-301), the pivoted 6x6 LDLT of Eigen as LinearSolverDense uses it
+// (g2o/solvers/linear_solver_dense.h:65-113), RobustKernelHuber (robust_kernel_impl.cpp:78-91)
+// and the fixed-order block reduction.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define F2_THREADS 256
+
+namespace vdo {
+
+struct Q4 { double x, y, z, w; };
+struct SE3d { Q4 r; double t[3]; };
+
+__device__ __forceinline__ void q_rotate(const Q4& q, const double* v, double* o) {
+  // Eigen _transformVector: v + w*uv + qv x uv, uv = 2 qv x v
+  double ux = q.y * v[2] - q.z * v[1], uy = q.z * v[0] - q.x * v[2], uz = q.x * v[1] - q.y * v[0];
+  ux += ux; uy += uy; uz += uz;
+  o[0] = v[0] + q.w * ux + (q.y * uz - q.z * uy);
+  o[1] = v[1] + q.w * uy + (q.z * ux - q.x * uz);
+  o[2] = v[2] + q.w * uz + (q.x * uy - q.y * ux);
+}
+__device__ inline Q4 q_from_R(const double* m) {   // Eigen Quaterniond(Matrix3d)
+  Q4 q;
+  double t = m[0] + m[4] + m[8];
+  if (t > 0.0) {
+    t = sqrt(t + 1.0); q.w = 0.5 * t; t = 0.5 / t;
+    q.x = (m[7] - m[5]) * t; q.y = (m[2] - m[6]) * t; q.z = (m[3] - m[1]) * t;
+  } else {
+    int i = 0;
+    if (m[4] > m[0]) i = 1;
+    if (m[8] > m[4 * i]) i = 2;
+    const int j = (i + 1) % 3, k = (j + 1) % 3;
+    t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+    double c[3];
+    c[i] = 0.5 * t; t = 0.5 / t;
+    q.w = (m[3 * k + j] - m[3 * j + k]) * t;
+    c[j] = (m[3 * j + i] + m[3 * i + j]) * t;
+    c[k] = (m[3 * k + i] + m[3 * i + k]) * t;
+    q.x = c[0]; q.y = c[1]; q.z = c[2];
+  }
+  return q;
+}
+__device__ inline void q_normalize_pos(Q4& q) {   // SE3Quat::normalizeRotation
+  if (q.w < 0) { q.x = -q.x; q.y = -q.y; q.z = -q.z; q.w = -q.w; }
+  const double n = sqrt(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+  q.x /= n; q.y /= n; q.z /= n; q.w /= n;
+}
+__device__ inline void m3mul(const double* a, const double* b, double* o) {
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+// SE3Quat::exp(update) * T      (se3quat.h:229-262, :106-112)
+__device__ inline SE3d se3_exp_compose(const double* u, const SE3d& T) {
+  const double ox = u[0], oy = u[1], oz = u[2];
+  const double theta = sqrt(ox * ox + oy * oy + oz * oz);
+  const double Om[9] = {0, -oz, oy, oz, 0, -ox, -oy, ox, 0};
+  double Om2[9], R[9], V[9];
+  m3mul(Om, Om, Om2);
+  if (theta < 0.00001) {
+    for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + Om[i] + Om2[i];
+    for (int i = 0; i < 9; ++i) V[i] = R[i];
+  } else {
+    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (pow(theta, 3));
+    for (int i = 0; i < 9; ++i) {
+      const double id = (i % 4 == 0) ? 1.0 : 0.0;
+      R[i] = (id + a * Om[i]) + b * Om2[i];
+      V[i] = (id + b * Om[i]) + c * Om2[i];
+    }
+  }
+  SE3d E;
+  E.r = q_from_R(R);
+  for (int i = 0; i < 3; ++i) E.t[i] = V[3 * i] * u[3] + V[3 * i + 1] * u[4] + V[3 * i + 2] * u[5];
+  q_normalize_pos(E.r);
+  // E * T
+  SE3d o;
+  double rt[3];
+  q_rotate(E.r, T.t, rt);
+  for (int i = 0; i < 3; ++i) o.t[i] = E.t[i] + rt[i];
+  const Q4 &a = E.r, &b = T.r;
+  o.r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  o.r.y = a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z;
+  o.r.z = a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x;
+  o.r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  q_normalize_pos(o.r);
+  return o;
+}
+
+// Eigen::LDLT<MatrixXd,Lower> (unblocked, diagonal pivoting) for n=6; solve in place.  Returns isPositive().
+__device__ inline bool ldlt6_solve(double* m /*36, destroyed*/, const double* b, double* x) {
+  int tr[6];
+  int sign = 0;
+  const int n = 6;
+  for (int k = 0; k < n; ++k) {
+    int big = k;
+    double bv = fabs(m[k * 6 + k]);
+    for (int i = k + 1; i < n; ++i) if (fabs(m[i * 6 + i]) > bv) { bv = fabs(m[i * 6 + i]); big = i; }
+    tr[k] = big;
+    if (k != big) {
+      const int s = n - big - 1;
+      for (int j = 0; j < k; ++j) { const double t = m[k * 6 + j]; m[k * 6 + j] = m[big * 6 + j]; m[big * 6 + j] = t; }
+      for (int i = 0; i < s; ++i) { const double t = m[(big + 1 + i) * 6 + k]; m[(big + 1 + i) * 6 + k] = m[(big + 1 + i) * 6 + big]; m[(big + 1 + i) * 6 + big] = t; }
+      { const double t = m[k * 6 + k]; m[k * 6 + k] = m[big * 6 + big]; m[big * 6 + big] = t; }
+      for (int i = k + 1; i < big; ++i) { const double t = m[i * 6 + k]; m[i * 6 + k] = m[big * 6 + i]; m[big * 6 + i] = t; }
+    }
+    const int rs = n - k - 1;
+    if (k > 0) {
+      double temp[6];
+      for (int j = 0; j < k; ++j) temp[j] = m[j * 6 + j] * m[k * 6 + j];
+      double s = 0;
+      for (int j = 0; j < k; ++j) s += m[k * 6 + j] * temp[j];
+      m[k * 6 + k] -= s;
+      for (int i = 0; i < rs; ++i) {
+        double t = 0;
+        for (int j = 0; j < k; ++j) t += m[(k + 1 + i) * 6 + j] * temp[j];
+        m[(k + 1 + i) * 6 + k] -= t;
+      }
+    }
+    const double akk = m[k * 6 + k];
+    const bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) { sign = 0; for (int j = 0; j < n; ++j) tr[j] = j; break; }
+    if (rs > 0 && valid) for (int i = 0; i < rs; ++i) m[(k + 1 + i) * 6 + k] /= akk;
+    if (sign == 1) { if (akk < 0) sign = 2; }
+    else if (sign == -1) { if (akk > 0) sign = 2; }
+    else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = -1; }
+  }
+  if (!(sign == 1 || sign == 0)) return false;
+  for (int i = 0; i < n; ++i) x[i] = b[i];
+  for (int k = 0; k < n; ++k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+  for (int i = 0; i < n; ++i) for (int j = 0; j < i; ++j) x[i] -= m[i * 6 + j] * x[j];
+  for (int i = 0; i < n; ++i) { if (fabs(m[i * 6 + i]) > 2.2250738585072014e-308) x[i] /= m[i * 6 + i]; else x[i] = 0; }
+  for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) x[i] -= m[j * 6 + i] * x[j];
+  for (int k = n - 1; k >= 0; --k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+  return true;
+}
+
+__device__ __forceinline__ void inv3_dev(const double* a, double* o) {   // Eigen fixed 3x3 inverse
+  const double C00 = a[4] * a[8] - a[5] * a[7];
+  const double C10 = a[2] * a[7] - a[1] * a[8];
+  const double C20 = a[1] * a[5] - a[2] * a[4];
+  const double det = (C00 * a[0] + C10 * a[3]) + C20 * a[6];
+  const double id = 1.0 / det;
+  o[0] = C00 * id; o[1] = C10 * id; o[2] = C20 * id;
+  o[3] = (a[5] * a[6] - a[3] * a[8]) * id; o[4] = (a[0] * a[8] - a[2] * a[6]) * id; o[5] = (a[2] * a[3] - a[0] * a[5]) * id;
+  o[6] = (a[3] * a[7] - a[4] * a[6]) * id; o[7] = (a[1] * a[6] - a[0] * a[7]) * id; o[8] = (a[0] * a[4] - a[1] * a[3]) * id;
+}
+
+__device__ __forceinline__ void huber_f2(double e, double delta, double dsqr, double& r0, double& r1) {
+  if (e <= dsqr) { r0 = e; r1 = 1.0; }
+  else { const double s = sqrt(e); r0 = 2 * s * delta - dsqr; r1 = delta / s; }
+}
+
+// block reduction of K values per thread -> out[K] in LDS (valid after return for all threads)
+template <int K>
+__device__ __forceinline__ void block_reduce(double (&v)[K], double* scratch /*[4*K]*/, double* out /*[K]*/) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < K; ++i) {
+    double t = v[i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_down(t, off, 64);
+    if (lane == 0) scratch[wv * K + i] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < K) out[threadIdx.x] = (scratch[threadIdx.x] + scratch[K + threadIdx.x]) + (scratch[2 * K + threadIdx.x] + scratch[3 * K + threadIdx.x]);
+  __syncthreads();
+}
+
+// SE3Quat::to_homogeneous_matrix, row-major 4x4
+__device__ inline void se3_to_matrix(const SE3d& S, double* T) {
+  const Q4 q = S.r;
+  const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+  const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+  T[0] = 1 - (tyy + tzz); T[1] = txy - twz; T[2] = txz + twy; T[3] = S.t[0];
+  T[4] = txy + twz; T[5] = 1 - (txx + tzz); T[6] = tyz - twx; T[7] = S.t[1];
+  T[8] = txz - twy; T[9] = tyz + twx; T[10] = 1 - (txx + tyy); T[11] = S.t[2];
+  T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+}
+
+}  // namespace vdo
