@@ -256,6 +256,8 @@ int vdo_orb_level_info(vdo_orb* orb, int level, int* w, int* h, int* n_features,
 int vdo_orb_get_pyramid(vdo_orb* orb, int level, uint8_t* out_bordered /* (w+38)*(h+38) */);
 int vdo_orb_get_blurred(vdo_orb* orb, int level, uint8_t* out /* w*h */);
 int vdo_orb_get_candidates(vdo_orb* orb, int level, float* x, float* y, float* response, float* angle, int cap, int* n);
+/* Wall time of the last vdo_orb_extract: ms[0] device stage launch .. candidates on the host, ms[1] host quadtree. */
+int vdo_orb_last_timing(vdo_orb* orb, double ms[2]);
 
 /* K1: Tracking::GrabImageRGBD depth preprocessing (src/Tracking.cc:180-204), in place. */
 int vdo_depth_preprocess(vdo_ctx* ctx, float* depth, int64_t n, float bf, float depth_map_factor, int is_device);

@@ -38,25 +38,37 @@ struct Flow2Arrays {
   vdo_flow2_result* results;
 };
 
+#ifdef F2_PROFILE
+#define F2_TICK(slot) do { if (tid == 0) { const long long t_ = clock64(); s_prof[slot] += t_ - s_tprev; s_tprev = t_; } } while (0)
+#else
+#define F2_TICK(slot) do { } while (0)
+#endif
+
 __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restrict__ probs, Flow2Arrays A) {
   const Flow2Dev P = probs[blockIdx.x];
   const int N = P.n, tid = threadIdx.x;
   const int64_t off = P.off;
-  const double* obs = A.obs + 2 * off; const double* meas = A.meas + 2 * off; const double* depth = A.depth + off;
-  double* Xw = A.Xw + 3 * off; double* fcur = A.fcur + 2 * off; double* ftry = A.ftry + 2 * off;
-  double* err = A.err + 2 * off; double* errp = A.errp + 2 * off; double* B2 = A.B2 + 12 * off;
-  double* hl = A.hl + 4 * off; double* bl = A.bl + 2 * off; double* cl = A.cl + 2 * off + blockIdx.x;
-  double* dinv = A.dinv + 9 * off; double* xl = A.xl + 2 * off + blockIdx.x;
+  const double* __restrict__ obs = A.obs + 2 * off; const double* __restrict__ meas = A.meas + 2 * off; const double* __restrict__ depth = A.depth + off;
+  double* __restrict__ Xw = A.Xw + 3 * off; double* fcur = A.fcur + 2 * off; double* ftry = A.ftry + 2 * off;
+  double* __restrict__ err = A.err + 2 * off; double* __restrict__ errp = A.errp + 2 * off; double* __restrict__ B2 = A.B2 + 12 * off;
+  double* __restrict__ hl = A.hl + off; double* __restrict__ bl = A.bl + 2 * off; double* __restrict__ cl = A.cl + 2 * off + blockIdx.x;
+  double* __restrict__ dinv = A.dinv + 9 * off; double* __restrict__ xl = A.xl + 2 * off + blockIdx.x;
   vdo_flow2_result* res = A.results + blockIdx.x;
 
-  __shared__ double s_scr[4 * 28], s_red[28];
-  __shared__ SE3d s_T, s_Tb, s_Ttry;
-  __shared__ double s_Hpp[36], s_bp[6], s_xp[6];
-  __shared__ double s_lambda, s_rho, s_chi_cur;
+  __shared__ double s_scr[F2_WAVES * 28], s_red[28];
+  __shared__ double s_wide[28 * (F2_THREADS + 1)];
+  __shared__ SE3d s_T, s_Ttry;
+  __shared__ double s_Hpp[36], s_bp[6], s_xp[6], s_Hs[36], s_bs[6], s_xs[6];
+  __shared__ double s_lambda, s_rho;
   __shared__ int s_ctrl[4];   // [0] continue outer, [1] continue trial loop, [2] ok2, [3] accepted
+#ifdef F2_PROFILE
+  __shared__ long long s_prof[16], s_tprev;
+  if (tid == 0) { for (int i = 0; i < 16; ++i) s_prof[i] = 0; s_tprev = clock64(); }
+#endif
 
   if (N < 3) {   // nInitialCorrespondences<3 -> identity, 0 inliers (Optimizer.cc:2449-2450, 2872-2873)
     if (tid < 16) res->T[tid] = (tid % 5 == 0) ? 1.0 : 0.0;
+    if (tid < N) { A.inlier_out[off + tid] = 0; A.flow_out[2 * (off + tid)] = meas[tid]; A.flow_out[2 * (off + tid) + 1] = meas[N + tid]; }   // nothing optimised: flows stay as measured
     if (tid == 0) { res->n_inliers = 0; res->iterations = 0; res->trials = 0; res->stop_reason = 0; res->initial_chi2 = res->final_chi2 = res->final_lambda = 0; }
     return;
   }
@@ -64,13 +76,13 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   // ---- setup: Xw, flows, initial pose (Converter::toSE3Quat)
   for (int i = tid; i < N; i += F2_THREADS) {
     const double dz = depth[i];
-    const double x = (obs[2 * i] - cx) * dz / fx, y = (obs[2 * i + 1] - cy) * dz / fy;
+    const double x = (obs[i] - cx) * dz / fx, y = (obs[N + i] - cy) * dz / fy;
     const double* W = P.Twl;
-    Xw[3 * i] = W[0] * x + W[1] * y + W[2] * dz + W[3];
-    Xw[3 * i + 1] = W[4] * x + W[5] * y + W[6] * dz + W[7];
-    Xw[3 * i + 2] = W[8] * x + W[9] * y + W[10] * dz + W[11];
-    fcur[2 * i] = meas[2 * i]; fcur[2 * i + 1] = meas[2 * i + 1];
-    xl[2 * i] = 0.0; xl[2 * i + 1] = 0.0;
+    Xw[i] = W[0] * x + W[1] * y + W[2] * dz + W[3];
+    Xw[N + i] = W[4] * x + W[5] * y + W[6] * dz + W[7];
+    Xw[2 * N + i] = W[8] * x + W[9] * y + W[10] * dz + W[11];
+    fcur[i] = meas[i]; fcur[N + i] = meas[N + i];
+    xl[i] = 0.0; xl[N + 1 + i] = 0.0;
   }
   if (tid < 6) s_xp[tid] = 0.0;
   if (tid == 0) {
@@ -87,16 +99,17 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     double part[1] = {0.0};
     for (int i = tid; i < N; i += F2_THREADS) {
       double pc[3];
-      q_rotate(T.r, Xw + 3 * i, pc);
+      const double xw[3] = {Xw[i], Xw[N + i], Xw[2 * N + i]};
+      q_rotate(T.r, xw, pc);
       pc[0] += T.t[0]; pc[1] += T.t[1]; pc[2] += T.t[2];
       const double u = pc[0] / pc[2] * fx + cx, v = pc[1] / pc[2] * fy + cy;
-      const double e0 = (obs[2 * i] + f[2 * i]) - u, e1 = (obs[2 * i + 1] + f[2 * i + 1]) - v;
-      err[2 * i] = e0; err[2 * i + 1] = e1;
+      const double e0 = (obs[i] + f[i]) - u, e1 = (obs[N + i] + f[N + i]) - v;
+      err[i] = e0; err[N + i] = e1;
       const double c = e0 * (P.info_flow * e0) + e1 * (P.info_flow * e1);
       double r0, r1;
       huber_f2(c, P.huber_delta, P.huber_dsqr, r0, r1);
-      const double p0 = f[2 * i] - meas[2 * i], p1 = f[2 * i + 1] - meas[2 * i + 1];
-      errp[2 * i] = p0; errp[2 * i + 1] = p1;
+      const double p0 = f[i] - meas[i], p1 = f[N + i] - meas[N + i];
+      errp[i] = p0; errp[N + i] = p1;
       part[0] += r0 + (p0 * (P.info_prior * p0) + p1 * (P.info_prior * p1));
     }
     block_reduce<1>(part, s_scr, s_red);
@@ -113,7 +126,9 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   const double initial_chi2 = last_err_chi;
   bool ok = true;
   for (; it < P.max_iterations && ok; ++it) {
+    F2_TICK(7);
     last_err_chi = compute_errors(s_T, fcur);
+    F2_TICK(0);
     double currentChi = last_err_chi, tempChi = currentChi;
     const double iniChi = currentChi;
     // ---- buildSystem
@@ -124,19 +139,20 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       const SE3d T = s_T;
       for (int i = tid; i < N; i += F2_THREADS) {
         double pc[3];
-        q_rotate(T.r, Xw + 3 * i, pc);
+        const double xw[3] = {Xw[i], Xw[N + i], Xw[2 * N + i]};
+        q_rotate(T.r, xw, pc);
         const double X = pc[0] + T.t[0], Y = pc[1] + T.t[1], Z = pc[2] + T.t[2], Z2 = Z * Z;
         double J[12];
         J[0] = X * Y / Z2 * fx; J[1] = -(1 + (X * X / Z2)) * fx; J[2] = Y / Z * fx; J[3] = -1. / Z * fx; J[4] = 0; J[5] = X / Z2 * fx;
         J[6] = (1 + Y * Y / Z2) * fy; J[7] = -X * Y / Z2 * fy; J[8] = -X / Z * fy; J[9] = 0; J[10] = -1. / Z * fy; J[11] = Y / Z2 * fy;
-        const double e0 = err[2 * i], e1 = err[2 * i + 1];
+        const double e0 = err[i], e1 = err[N + i];
         const double c = e0 * (P.info_flow * e0) + e1 * (P.info_flow * e1);
         double r0, r1;
         huber_f2(c, P.huber_delta, P.huber_dsqr, r0, r1);
         const double wo = r1 * P.info_flow;
         const double or0 = -(P.info_flow * e0) * r1, or1 = -(P.info_flow * e1) * r1;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) { B2[12 * i + 2 * a] = J[a] * wo; B2[12 * i + 2 * a + 1] = J[6 + a] * wo; }
+        for (int a = 0; a < 6; ++a) { B2[(2 * a) * N + i] = J[a] * wo; B2[(2 * a + 1) * N + i] = J[6 + a] * wo; }
         int k = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
@@ -145,15 +161,15 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
           for (int c2 = 0; c2 <= a; ++c2) acc[k++] += J[a] * wo * J[c2] + J[6 + a] * wo * J[6 + c2];   // lower triangle
         }
         const double h = wo + P.info_prior;
-        hl[4 * i] = h; hl[4 * i + 1] = 0; hl[4 * i + 2] = 0; hl[4 * i + 3] = h;
-        bl[2 * i] = or0 - P.info_prior * errp[2 * i];
-        bl[2 * i + 1] = or1 - P.info_prior * errp[2 * i + 1];
+        hl[i] = h;            // Hll block = h * I2 (off-diagonals are exact zeros)
+        bl[i] = or0 - P.info_prior * errp[i];
+        bl[N + i] = or1 - P.info_prior * errp[N + i];
         acc[27] = fmax(acc[27], h);
       }
       // max needs its own reduction: do it through the same tree with fmax on slot 27
       double mx[1] = {acc[27]};
       acc[27] = 0;
-      block_reduce<28>(acc, s_scr, s_red);
+      block_reduce_wide<28>(acc, s_wide, s_red);
       if (tid == 0) {
         int k = 0;
         for (int a = 0; a < 6; ++a) for (int c2 = 0; c2 <= a; ++c2) { s_Hpp[a * 6 + c2] = s_red[k]; s_Hpp[c2 * 6 + a] = s_red[k]; ++k; }
@@ -168,7 +184,8 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
         if ((tid & 63) == 0) s_scr[tid >> 6] = m;
         __syncthreads();
         if (tid == 0) {
-          double mm = fmax(fmax(s_scr[0], s_scr[1]), fmax(s_scr[2], s_scr[3]));
+          double mm = s_scr[0];
+          for (int w = 1; w < F2_WAVES; ++w) mm = fmax(mm, s_scr[w]);
           for (int j = 0; j < 6; ++j) mm = fmax(mm, fabs(s_Hpp[7 * j]));
           s_lambda = tau * mm;
         }
@@ -177,6 +194,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
         __syncthreads();
       }
     }
+    F2_TICK(1);
     double rho = 0;
     int qmax = 0;
     do {
@@ -188,74 +206,77 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       for (int i = tid; i < N; i += F2_THREADS) {
         double Di[9];
         if (Q) {
-          const double D3[9] = {hl[4 * i] + lambda, hl[4 * i + 3], 0, hl[4 * i + 1], lambda, 0, hl[4 * i + 2], 0, lambda};
+          const double hh = hl[i];
+          const double D3[9] = {hh + lambda, hh, 0, 0.0, lambda, 0, 0.0, 0, lambda};
           inv3_dev(D3, Di);
         } else {
-          const double a0 = hl[4 * i] + lambda, a1 = hl[4 * i + 2], a2 = hl[4 * i + 1], a3 = hl[4 * i + 3] + lambda;
+          const double a0 = hl[i] + lambda, a1 = 0.0, a2 = 0.0, a3 = hl[i] + lambda;
           const double id = 1.0 / (a0 * a3 - a1 * a2);
           Di[0] = a3 * id; Di[1] = -a1 * id; Di[2] = 0; Di[3] = -a2 * id; Di[4] = a0 * id; Di[5] = 0; Di[6] = 0; Di[7] = 0; Di[8] = 0;
         }
 #pragma unroll
-        for (int k = 0; k < 9; ++k) dinv[9 * i + k] = Di[k];
-        const double b2 = (Q && i + 1 < N) ? bl[2 * i + 2] : 0.0;
-        const double db0 = (Di[0] * bl[2 * i] + Di[1] * bl[2 * i + 1]) + Di[2] * b2;
-        const double db1 = (Di[3] * bl[2 * i] + Di[4] * bl[2 * i + 1]) + Di[5] * b2;
-        const double* B = B2 + 12 * i;
+        for (int k = 0; k < 9; ++k) dinv[k * N + i] = Di[k];
+        const double b2 = (Q && i + 1 < N) ? bl[i + 1] : 0.0;
+        const double db0 = (Di[0] * bl[i] + Di[1] * bl[N + i]) + Di[2] * b2;
+        const double db1 = (Di[3] * bl[i] + Di[4] * bl[N + i]) + Di[5] * b2;
+        const double* B = B2 + i;
         int k = 0;
 #pragma unroll
         for (int a = 0; a < 6; ++a) {
-          acc[21 + a] += B[2 * a] * db0 + B[2 * a + 1] * db1;
-          const double bd0 = B[2 * a] * Di[0] + B[2 * a + 1] * Di[3];
-          const double bd1 = B[2 * a] * Di[1] + B[2 * a + 1] * Di[4];
+          acc[21 + a] += B[(2 * a) * N] * db0 + B[(2 * a + 1) * N] * db1;
+          const double bd0 = B[(2 * a) * N] * Di[0] + B[(2 * a + 1) * N] * Di[3];
+          const double bd1 = B[(2 * a) * N] * Di[1] + B[(2 * a + 1) * N] * Di[4];
 #pragma unroll
-          for (int c2 = 0; c2 <= a; ++c2) acc[k++] += bd0 * B[2 * c2] + bd1 * B[2 * c2 + 1];   // lower triangle (LDLT reads only it)
+          for (int c2 = 0; c2 <= a; ++c2) acc[k++] += bd0 * B[(2 * c2) * N] + bd1 * B[(2 * c2 + 1) * N];   // lower triangle (LDLT reads only it)
         }
       }
-      block_reduce<28>(acc, s_scr, s_red);
+      block_reduce_wide<28>(acc, s_wide, s_red);
+      F2_TICK(2);
       if (tid == 0) {
-        double Hs[36], bs[6];
+        double* Hs = s_Hs; double* bs = s_bs; double* xs = s_xs;      // LDS, not scratch: the pivoted LDLT indexes dynamically
         for (int i = 0; i < 36; ++i) Hs[i] = s_Hpp[i];
         int k = 0;
         for (int a = 0; a < 6; ++a) for (int c2 = 0; c2 <= a; ++c2) { Hs[a * 6 + c2] -= s_red[k]; ++k; }
         for (int j = 0; j < 6; ++j) { Hs[7 * j] += lambda; bs[j] = s_bp[j] - s_red[21 + j]; }
-        double xs[6];
         const bool ok2 = ldlt6_solve(Hs, bs, xs);
         s_ctrl[2] = ok2 ? 1 : 0;
         if (ok2) for (int j = 0; j < 6; ++j) s_xp[j] = xs[j];
         // (failed LDLT leaves x untouched in the reference; the trial is rejected anyway)
       }
       __syncthreads();
+      F2_TICK(3);
       const bool ok2 = s_ctrl[2] != 0;
       double xp[6];
 #pragma unroll
       for (int j = 0; j < 6; ++j) xp[j] = s_xp[j];
       // ---- back-substitution: cl = bl - B^T xp
       for (int i = tid; i < N; i += F2_THREADS) {
-        const double* B = B2 + 12 * i;
+        const double* B = B2 + i;
         double t0 = 0, t1 = 0;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) { t0 += B[2 * a] * (-xp[a]); t1 += B[2 * a + 1] * (-xp[a]); }
-        cl[2 * i] = bl[2 * i] + t0; cl[2 * i + 1] = bl[2 * i + 1] + t1;
+        for (int a = 0; a < 6; ++a) { t0 += B[(2 * a) * N] * (-xp[a]); t1 += B[(2 * a + 1) * N] * (-xp[a]); }
+        cl[i] = bl[i] + t0; cl[N + 1 + i] = bl[N + i] + t1;
       }
-      if (tid == 0) cl[2 * N] = 0.0;
+      if (tid == 0) cl[N] = 0.0;
       __syncthreads();
+      F2_TICK(4);
       // xl[2i..2i+1] = (Dinv_i c_i)[0..1] (+ row 2 of landmark i-1), update, scale
       double sc[1] = {0.0};
       for (int i = tid; i < N; i += F2_THREADS) {
-        const double* Di = dinv + 9 * i;
-        const double c0 = cl[2 * i], c1 = cl[2 * i + 1], c2 = Q ? cl[2 * i + 2] : 0.0;
-        double x0 = (Di[0] * c0 + Di[1] * c1) + Di[2] * c2;
-        const double x1 = (Di[3] * c0 + Di[4] * c1) + Di[5] * c2;
+        const double* Di = dinv + i;
+        const double c0 = cl[i], c1 = cl[N + 1 + i], c2 = Q ? cl[i + 1] : 0.0;
+        double x0 = (Di[0] * c0 + Di[N] * c1) + Di[2 * N] * c2;
+        const double x1 = (Di[3 * N] * c0 + Di[4 * N] * c1) + Di[5 * N] * c2;
         if (Q && i > 0) {
-          const double* Dp = dinv + 9 * (i - 1);
-          const double leak = (Dp[6] * cl[2 * i - 2] + Dp[7] * cl[2 * i - 1]) + Dp[8] * c0;
+          const double* Dp = dinv + (i - 1);
+          const double leak = (Dp[6 * N] * cl[i - 1] + Dp[7 * N] * cl[N + i]) + Dp[8 * N] * c0;
           x0 = leak + x0;            // landmark i-1 wrote first, then landmark i added its row 0
         }
-        if (!ok2) { x0 = xl[2 * i]; }   // stale x (reference keeps the previous content)
-        const double x1e = ok2 ? x1 : xl[2 * i + 1];
-        xl[2 * i] = x0; xl[2 * i + 1] = x1e;
-        ftry[2 * i] = fcur[2 * i] + x0; ftry[2 * i + 1] = fcur[2 * i + 1] + x1e;
-        sc[0] += x0 * (lambda * x0 + bl[2 * i]) + x1e * (lambda * x1e + bl[2 * i + 1]);
+        if (!ok2) { x0 = xl[i]; }   // stale x (reference keeps the previous content)
+        const double x1e = ok2 ? x1 : xl[N + 1 + i];
+        xl[i] = x0; xl[N + 1 + i] = x1e;
+        ftry[i] = fcur[i] + x0; ftry[N + i] = fcur[N + i] + x1e;
+        sc[0] += x0 * (lambda * x0 + bl[i]) + x1e * (lambda * x1e + bl[N + i]);
       }
       if (tid == 0) {
         s_Ttry = se3_exp_compose(s_xp, s_T);
@@ -266,14 +287,16 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       block_reduce<1>(sc, s_scr, s_red);
       const double scale = (s_rho + s_red[0]) + 1e-3;
       __syncthreads();
+      F2_TICK(5);
       last_err_chi = tempChi = compute_errors(s_Ttry, ftry);
+      F2_TICK(6);
       if (!ok2) tempChi = 1.7976931348623157e308;
       rho = (currentChi - tempChi) / scale;
       if (rho > 0 && isfinite(tempChi)) {
         double alpha = 1. - pow((2 * rho - 1), 3);
         alpha = fmin(alpha, upper);
         lambda *= fmax(lower, alpha); ni = 2; currentChi = tempChi;
-        for (int i = tid; i < 2 * N; i += F2_THREADS) fcur[i] = ftry[i];   // discardTop(): accept
+        { double* t_ = fcur; fcur = ftry; ftry = t_; }                       // discardTop(): accept (uniform pointer swap)
         if (tid == 0) s_T = s_Ttry;
       } else {
         lambda *= ni; ni *= 2;                                            // pop(): keep (s_T, fcur)
@@ -296,13 +319,13 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   double cnt[1] = {0.0};
   const float gate = (float)P.chi2_gate;
   for (int i = tid; i < N; i += F2_THREADS) {
-    const double e0 = err[2 * i], e1 = err[2 * i + 1];
+    const double e0 = err[i], e1 = err[N + i];
     const float chi2 = (float)(e0 * (P.info_flow * e0) + e1 * (P.info_flow * e1));
     const bool outl = chi2 > gate;
     A.inlier_out[off + i] = outl ? 0 : 1;
     cnt[0] += outl ? 0.0 : 1.0;
-    A.flow_out[2 * (off + i)] = fcur[2 * i];
-    A.flow_out[2 * (off + i) + 1] = fcur[2 * i + 1];
+    A.flow_out[2 * (off + i)] = fcur[i];
+    A.flow_out[2 * (off + i) + 1] = fcur[N + i];
   }
   block_reduce<1>(cnt, s_scr, s_red);
   if (tid == 0) {
@@ -318,6 +341,9 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     res->n_inliers = (int)(s_red[0] + 0.5);
     res->iterations = it; res->trials = total_trials; res->stop_reason = stop_reason;
     res->initial_chi2 = initial_chi2; res->final_chi2 = last_err_chi; res->final_lambda = lambda;
+#ifdef F2_PROFILE
+    for (int i = 0; i < 8; ++i) res->T[i] = (double)s_prof[i];     // cycles per phase instead of the pose (debug build only)
+#endif
   }
 }
 
@@ -378,8 +404,9 @@ extern "C" int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_fl
   for (int k = 0; k < n_problems; ++k) {
     const vdo_flow2_problem& p = probs[k];
     if (p.n == 0) continue;
-    std::memcpy(obs.data() + 2 * b->offs[k], p.obs, sizeof(double) * 2 * p.n);
-    std::memcpy(meas.data() + 2 * b->offs[k], p.flow, sizeof(double) * 2 * p.n);
+    // per-problem SoA planes [2][n]: consecutive lanes read consecutive doubles (512 B per wave load)
+    double* po = obs.data() + 2 * b->offs[k]; double* pm = meas.data() + 2 * b->offs[k];
+    for (int i = 0; i < p.n; ++i) { po[i] = p.obs[2 * i]; po[p.n + i] = p.obs[2 * i + 1]; pm[i] = p.flow[2 * i]; pm[p.n + i] = p.flow[2 * i + 1]; }
     std::memcpy(dep.data() + b->offs[k], p.depth, sizeof(double) * p.n);
   }
   double* d_obs = (double*)dev(16 * T); double* d_meas = (double*)dev(16 * T); double* d_dep = (double*)dev(8 * T);
@@ -388,7 +415,7 @@ extern "C" int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_fl
   A.obs = d_obs; A.meas = d_meas; A.depth = d_dep;
   A.Xw = (double*)dev(24 * T); A.fcur = (double*)dev(16 * T); A.ftry = (double*)dev(16 * T);
   A.err = (double*)dev(16 * T); A.errp = (double*)dev(16 * T); A.B2 = (double*)dev(96 * T);
-  A.hl = (double*)dev(32 * T); A.bl = (double*)dev(16 * T + 8); A.cl = (double*)dev(16 * T + 8 * NP + 8);
+  A.hl = (double*)dev(8 * T); A.bl = (double*)dev(16 * T + 8); A.cl = (double*)dev(16 * T + 8 * NP + 8);
   A.dinv = (double*)dev(72 * T); A.xl = (double*)dev(16 * T + 8 * NP + 8);
   A.flow_out = (double*)dev(16 * T); A.inlier_out = (unsigned char*)dev(T);
   A.results = (vdo_flow2_result*)dev(sizeof(vdo_flow2_result) * NP);

@@ -5,6 +5,7 @@
 // Both are ordered stream compactions: the output ORDER is part of the contract (feature
 // indices are stored in the Map and in the tracklets), so flags are scanned with wave ballots /
 // workgroup scans and written in input order — never with atomics.
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -140,6 +141,7 @@ extern "C" int vdo_frame_images_destroy(vdo_frame_images* f) {
   if (!f) return VDO_OK;
   if (f->ctx) ctx_bind(f->ctx);
   for (void* p : f->allocs) hipFree(p);
+  if (f->h_pin) hipHostFree(f->h_pin);
   delete f;
   return VDO_OK;
 }
@@ -154,11 +156,17 @@ extern "C" int vdo_frame_images_create(vdo_ctx* ctx, int w, int h, vdo_frame_ima
   auto dev = [&](size_t bytes) -> void* { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; f->allocs.push_back(p); return p; };
   const size_t np = (size_t)w * h;
   f->d_mask = (int32_t*)dev(4 * np); f->d_depth = (float*)dev(4 * np); f->d_flow = (float*)dev(8 * np);
-  for (int k = 0; k < 8; ++k) f->d_f[k] = (float*)dev(4 * (size_t)f->cap);
-  for (int k = 0; k < 2; ++k) f->d_i[k] = (int32_t*)dev(4 * (size_t)f->cap);
+  f->d_rows = (float*)dev(4 * (size_t)f->cap * 10);
+  if (f->d_rows) {
+    for (int k = 0; k < 7; ++k) f->d_f[k] = f->d_rows + (size_t)k * f->cap;
+    f->d_i[0] = (int32_t*)(f->d_rows + (size_t)7 * f->cap);
+    f->d_f[7] = f->d_rows + (size_t)8 * f->cap;
+    f->d_i[1] = (int32_t*)(f->d_rows + (size_t)9 * f->cap);
+  }
+  if (hipHostMalloc((void**)&f->h_pin, 4 * ((size_t)f->cap * 8 + 16)) != hipSuccess) f->h_pin = nullptr;
   f->d_cnt = (int*)dev(16); f->d_blk = (int*)dev(4 * ((size_t)f->cap / 256 + 2));
   for (void* p : f->allocs) if (!p) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
-  if (!f->d_blk) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  if (!f->d_blk || !f->h_pin) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
   *out = f;
   return VDO_OK;
 }
@@ -197,25 +205,30 @@ extern "C" int vdo_frame_images_depth_preprocess(vdo_frame_images* f, float bf, 
 
 extern "C" int vdo_frame_static_filter(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth,
                                        int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int* n_out) {
-  if (!f || !n_out || n < 0 || n > f->cap) return set_error(VDO_ERR_INVALID, "bad argument");
+  if (!f || !n_out || n < 0 || 10 * (size_t)n > 8 * (size_t)f->cap) return set_error(VDO_ERR_INVALID, "bad argument / too many keypoints for the staging buffer");
   *n_out = 0;
   if (n == 0) return VDO_OK;
   int rc = ctx_bind(f->ctx);
   if (rc != VDO_OK) return rc;
   hipStream_t s = f->ctx->stream;
-  hipMemcpyAsync(f->d_f[6], kx, 4 * (size_t)n, hipMemcpyHostToDevice, s);
-  hipMemcpyAsync(f->d_f[7], ky, 4 * (size_t)n, hipMemcpyHostToDevice, s);
-  hipLaunchKernelGGL(k_static_filter, dim3(1), dim3(1024), 0, s, n, (const float*)f->d_f[6], (const float*)f->d_f[7], (const int32_t*)f->d_mask,
+  // inputs: kx|ky -> pinned -> rows 8,9 in one strided H2D; outputs: rows 0..7 (5 float rows, 2 unused, idx) x n in one
+  // strided D2H next to the count (m <= n is only known after the kernel): 1 sync, no pageable copies.
+  float* pin = f->h_pin;
+  std::memcpy(pin, kx, 4 * (size_t)n); std::memcpy(pin + n, ky, 4 * (size_t)n);
+  hipMemcpy2DAsync(f->d_f[7], 4 * (size_t)f->cap, pin, 4 * (size_t)n, 4 * (size_t)n, 2, hipMemcpyHostToDevice, s);
+  hipLaunchKernelGGL(k_static_filter, dim3(1), dim3(1024), 0, s, n, (const float*)f->d_f[7], (const float*)f->d_i[1], (const int32_t*)f->d_mask,
                      (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, th_depth, f->d_i[0], f->d_f[0], f->d_f[1], f->d_f[2], f->d_f[3], f->d_f[4], f->d_cnt);
-  int m = 0;
-  hipMemcpyAsync(&m, f->d_cnt, 4, hipMemcpyDeviceToHost, s);
+  int* pcnt = (int*)(pin + (size_t)8 * f->cap);
+  float* stage = pin + 2 * (size_t)n;          // behind the inputs (the H2D above is stream-ordered before the D2H)
+  hipMemcpyAsync(pcnt, f->d_cnt, 4, hipMemcpyDeviceToHost, s);
+  hipMemcpy2DAsync(stage, 4 * (size_t)n, f->d_rows, 4 * (size_t)f->cap, 4 * (size_t)n, 8, hipMemcpyDeviceToHost, s);
   if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "static filter failed: %s", hipGetErrorString(hipGetLastError()));
+  const int m = *pcnt;
   *n_out = m;
   if (m) {
-    hipMemcpyAsync(keep_idx, f->d_i[0], 4 * (size_t)m, hipMemcpyDeviceToHost, s);
     float* dst[5] = {corr_x, corr_y, flow_x, flow_y, depth_out};
-    for (int k = 0; k < 5; ++k) hipMemcpyAsync(dst[k], f->d_f[k], 4 * (size_t)m, hipMemcpyDeviceToHost, s);
-    if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "static filter D2H failed");
+    for (int k = 0; k < 5; ++k) std::memcpy(dst[k], stage + (size_t)k * n, 4 * (size_t)m);
+    std::memcpy(keep_idx, stage + (size_t)7 * n, 4 * (size_t)m);
   }
   return VDO_OK;
 }
@@ -235,16 +248,29 @@ extern "C" int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, 
   hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, f->d_blk, nblk, f->d_cnt);
   hipLaunchKernelGGL(k_obj_scatter, dim3(nblk), dim3(256), 0, s, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, th_depth_obj, step, ncol, nprobe,
                      (const int*)f->d_blk, f->cap, f->d_f[0], f->d_f[1], f->d_f[2], f->d_f[3], f->d_f[4], f->d_f[5], f->d_f[6], f->d_i[0]);
-  int m = 0;
-  hipMemcpyAsync(&m, f->d_cnt, 4, hipMemcpyDeviceToHost, s);
+  // count + the first kSpec columns of the 8 result rows in one go (pinned); a second strided copy only if m > kSpec
+  constexpr int kSpec = 8192;
+  float* pin = f->h_pin;
+  int* pcnt = (int*)(pin + (size_t)8 * f->cap);
+  const int spec = key_x ? std::min(kSpec, f->cap) : 0;
+  hipMemcpyAsync(pcnt, f->d_cnt, 4, hipMemcpyDeviceToHost, s);
+  if (spec) hipMemcpy2DAsync(pin, 4 * (size_t)spec, f->d_rows, 4 * (size_t)f->cap, 4 * (size_t)spec, 8, hipMemcpyDeviceToHost, s);
   if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "object sampling failed: %s", hipGetErrorString(hipGetLastError()));
+  const int m = *pcnt;
   *n_out = m;
   if (key_x) {   // host outputs requested
     if (m > cap) return set_error(VDO_ERR_INVALID, "object sampling: %d points exceed the output capacity %d", m, cap);
     float* dst[7] = {key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out};
-    for (int k = 0; k < 7; ++k) if (dst[k] && m) hipMemcpyAsync(dst[k], f->d_f[k], 4 * (size_t)m, hipMemcpyDeviceToHost, s);
-    if (label && m) hipMemcpyAsync(label, f->d_i[0], 4 * (size_t)m, hipMemcpyDeviceToHost, s);
-    if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "object sampling D2H failed");
+    const int m0 = std::min(m, spec);
+    for (int k = 0; k < 7; ++k) if (dst[k] && m0) std::memcpy(dst[k], pin + (size_t)k * spec, 4 * (size_t)m0);
+    if (label && m0) std::memcpy(label, pin + (size_t)7 * spec, 4 * (size_t)m0);
+    if (m > spec) {
+      const int r = m - spec;
+      hipMemcpy2DAsync(pin, 4 * (size_t)r, f->d_rows + spec, 4 * (size_t)f->cap, 4 * (size_t)r, 8, hipMemcpyDeviceToHost, s);
+      if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "object sampling D2H failed");
+      for (int k = 0; k < 7; ++k) if (dst[k]) std::memcpy(dst[k] + spec, pin + (size_t)k * r, 4 * (size_t)r);
+      if (label) std::memcpy(label + spec, pin + (size_t)7 * r, 4 * (size_t)r);
+    }
   }
   return VDO_OK;
 }

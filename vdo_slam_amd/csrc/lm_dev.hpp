@@ -6,7 +6,10 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#ifndef F2_THREADS
 #define F2_THREADS 256
+#endif
+#define F2_WAVES (F2_THREADS / 64)
 
 namespace vdo {
 
@@ -151,8 +154,10 @@ __device__ __forceinline__ void huber_f2(double e, double delta, double dsqr, do
 }
 
 // block reduction of K values per thread -> out[K] in LDS (valid after return for all threads)
+// Sum of K per-thread values over the workgroup (F2_THREADS threads): shuffle tree inside each wave,
+// one LDS stage across the waves, fixed order.  scratch: [F2_WAVES*K], out: [K].
 template <int K>
-__device__ __forceinline__ void block_reduce(double (&v)[K], double* scratch /*[4*K]*/, double* out /*[K]*/) {
+__device__ __forceinline__ void block_reduce(double (&v)[K], double* scratch, double* out) {
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < K; ++i) {
@@ -162,7 +167,40 @@ __device__ __forceinline__ void block_reduce(double (&v)[K], double* scratch /*[
     if (lane == 0) scratch[wv * K + i] = t;
   }
   __syncthreads();
-  if (threadIdx.x < K) out[threadIdx.x] = (scratch[threadIdx.x] + scratch[K + threadIdx.x]) + (scratch[2 * K + threadIdx.x] + scratch[3 * K + threadIdx.x]);
+  if (threadIdx.x < K) {
+    double a = 0.0;
+#pragma unroll
+    for (int w = 0; w < F2_WAVES; w += 4)
+      a += (scratch[w * K + threadIdx.x] + scratch[(w + 1) * K + threadIdx.x]) + (scratch[(w + 2) * K + threadIdx.x] + scratch[(w + 3) * K + threadIdx.x]);
+    out[threadIdx.x] = a;
+  }
+  __syncthreads();
+}
+
+// Wide variant for the 27/28 running sums of a linearisation: K shuffle trees cost ~20k cycles (each
+// 64-bit __shfl_down is two ds_bpermute with ~100-cycle dependent latency, 6 levels deep, 28 chains);
+// going through LDS is an order of magnitude cheaper: every thread stores its K values (conflict-free,
+// column per quantity), 8 threads per quantity each add 32 of the 256 entries (stride-8 interleave, also
+// conflict-free), and an 8-lane shuffle finishes.  wide: [K][F2_THREADS + 1] doubles of LDS.
+template <int K>
+__device__ __forceinline__ void block_reduce_wide(const double (&v)[K], double* wide, double* out) {
+  static_assert(K * 8 <= F2_THREADS, "one 8-lane group per quantity");
+  constexpr int LD = F2_THREADS + 1;
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < K; ++i) wide[i * LD + tid] = v[i];
+  __syncthreads();
+  const int q = tid >> 3, part = tid & 7;
+  double a = 0.0;
+  if (q < K) {
+    const double* col = wide + q * LD + part;
+#pragma unroll 8
+    for (int j = 0; j < F2_THREADS / 8; ++j) a += col[8 * j];
+  }
+  a += __shfl_down(a, 4, 8);
+  a += __shfl_down(a, 2, 8);
+  a += __shfl_down(a, 1, 8);
+  if (q < K && part == 0) out[q] = a;
   __syncthreads();
 }
 

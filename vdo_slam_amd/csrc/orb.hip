@@ -10,6 +10,7 @@
 // order — and therefore every downstream feature index — is reproduced exactly.
 // OpenCV 3.4 fixed-point semantics are restated (parity unpinned).
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -20,6 +21,7 @@
 namespace vdo {
 
 constexpr int kEdge = 19, kHalfPatch = 15, kPatch = 31;
+constexpr int kSpecCand = 24576;       // candidates fetched speculatively together with the header (typ. 10-15 k per KITTI frame)
 constexpr int kCellCap = 160;          // max keypoints kept per FAST cell (NMS => <= ~(37/2)^2/2)
 constexpr int kMaxCellDim = 68;        // hCell = ceil(height/nRows) < 60, +6 overlap
 
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(1024) void k_scan_cells(const int* __restrict__ cnt
     if (i < ncells) { offs[i] = s_w[wv] + incl - c; if (c) atomicAdd(&level_cnt[cell_level[i]], c); }
     __syncthreads();
   }
-  if (tid == 0) offs[ncells] = s_carry;
+  if (tid == 0) { offs[ncells] = s_carry; level_cnt[16] = s_carry; }     // header: per-level counts + total, fetched in one copy
 }
 
 // umax of the circular patch (ORBextractor.cc:443-458), filled on the host
@@ -278,44 +280,52 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, 
 }
 
 // --------------------------------------------------------------------------- host: quadtree (K5)
-struct Cand { float x, y, resp, angle; };
-
 struct QNode {
   int ULx, ULy, URx, URy, BLx, BLy, BRx, BRy;
-  std::vector<int> keys;    // indices into the candidate array
-  bool noMore = false;
+  int b = 0, e = 0;         // keys = idx[b, e): every node owns a contiguous run of the shared index array
   int prev = -1, next = -1; // intrusive list (front = head)
-  bool alive = true;
+  bool noMore = false;
 };
 
-// DistributeOctTree with an index-based intrusive list (same traversal/insert order as the
-// reference's std::list: children are pushed to the FRONT, parents erased).  Ties in the
-// "expand largest first" phase are broken by node creation order (the reference breaks them by
-// heap address).
+// DistributeOctTree (reference src/ORBextractor.cc:528-752, DivideNode :470-526) with an index-based
+// intrusive list (same traversal/insert order as the reference's std::list: children are pushed to the
+// FRONT, parents erased).  Ties in the "expand largest first" phase are broken by node creation order
+// (the reference breaks them by heap address).  Allocation-free in steady state: the keys
+// of a node are a run of one index array, DivideNode is a stable 4-way partition of that run
+// (children keep the parent's key order, like the reference's push_back loops), buffers are reused
+// across levels and frames.
 class QuadTree {
  public:
-  QuadTree(const std::vector<Cand>& c) : cand(c) {}
-  void run(int minX, int maxX, int minY, int maxY, int N, std::vector<int>& out) {
+  // candidates as SoA (x, y relative to the level's (minX, minY); resp)
+  void run(const float* cx, const float* cy, const float* cresp, int ncand, int minX, int maxX, int minY, int maxY, int N, std::vector<int>& out) {
     out.clear();
-    if (cand.empty()) return;
+    if (ncand <= 0) return;
+    x = cx; y = cy; resp = cresp;
+    nodes.clear(); head = tail = -1; count = 0;
+    idx.resize(ncand); tmp.resize(ncand); cls.resize(ncand);
     const int nIni = (int)std::round((float)(maxX - minX) / (maxY - minY));
     const float hX = (float)(maxX - minX) / nIni;
-    std::vector<int> ini(nIni);
+    // initial nodes: stable bucket sort of the candidates by column strip
+    ini_cnt.assign(nIni + 1, 0);
+    for (int k = 0; k < ncand; ++k) { const int q = (int)(x[k] / hX); cls[k] = (uint8_t)q; ini_cnt[q + 1]++; }
+    for (int i = 0; i < nIni; ++i) ini_cnt[i + 1] += ini_cnt[i];
+    ini_fill.assign(ini_cnt.begin(), ini_cnt.end() - 1);
+    for (int k = 0; k < ncand; ++k) idx[ini_fill[cls[k]]++] = k;
     for (int i = 0; i < nIni; ++i) {
       QNode n;
       n.ULx = (int)(hX * (float)i); n.ULy = 0; n.URx = (int)(hX * (float)(i + 1)); n.URy = 0;
       n.BLx = n.ULx; n.BLy = maxY - minY; n.BRx = n.URx; n.BRy = maxY - minY;
-      ini[i] = push_back(n);
+      n.b = ini_cnt[i]; n.e = ini_cnt[i + 1];
+      push_back(n);
     }
-    for (int k = 0; k < (int)cand.size(); ++k) nodes[ini[(int)(cand[k].x / hX)]].keys.push_back(k);
     for (int it = head; it != -1;) {
       const int nx = nodes[it].next;
-      if (nodes[it].keys.size() == 1) nodes[it].noMore = true;
-      else if (nodes[it].keys.empty()) erase(it);
+      const int sz = nodes[it].e - nodes[it].b;
+      if (sz == 1) nodes[it].noMore = true;
+      else if (sz == 0) erase(it);
       it = nx;
     }
     bool finish = false;
-    std::vector<std::pair<int, int>> sizeAndNode;   // (size, node id); id order == creation order
     while (!finish) {
       int prevSize = count;
       int nToExpand = 0;
@@ -323,7 +333,7 @@ class QuadTree {
       for (int it = head; it != -1;) {
         if (nodes[it].noMore) { it = nodes[it].next; continue; }
         const int nx = nodes[it].next;
-        divide_and_add(it, sizeAndNode, &nToExpand);
+        divide_and_add(it, &nToExpand);
         erase(it);
         it = nx;
       }
@@ -331,12 +341,12 @@ class QuadTree {
       else if (count + nToExpand * 3 > N) {
         while (!finish) {
           prevSize = count;
-          std::vector<std::pair<int, int>> prev = sizeAndNode;
+          prevSN.swap(sizeAndNode);
           sizeAndNode.clear();
-          std::sort(prev.begin(), prev.end());
-          for (int j = (int)prev.size() - 1; j >= 0; --j) {
-            divide_and_add(prev[j].second, sizeAndNode, nullptr);
-            erase(prev[j].second);
+          std::sort(prevSN.begin(), prevSN.end());
+          for (int j = (int)prevSN.size() - 1; j >= 0; --j) {
+            divide_and_add(prevSN[j].second, nullptr);
+            erase(prevSN[j].second);
             if (count >= N) break;
           }
           if (count >= N || count == prevSize) finish = true;
@@ -344,17 +354,20 @@ class QuadTree {
       }
     }
     for (int it = head; it != -1; it = nodes[it].next) {
-      const std::vector<int>& ks = nodes[it].keys;
-      int best = ks[0];
-      float mr = cand[best].resp;
-      for (size_t k = 1; k < ks.size(); ++k) if (cand[ks[k]].resp > mr) { best = ks[k]; mr = cand[ks[k]].resp; }
+      const QNode& n = nodes[it];
+      int best = idx[n.b];
+      float mr = resp[best];
+      for (int k = n.b + 1; k < n.e; ++k) if (resp[idx[k]] > mr) { best = idx[k]; mr = resp[best]; }
       out.push_back(best);
     }
   }
 
  private:
-  const std::vector<Cand>& cand;
+  const float *x = nullptr, *y = nullptr, *resp = nullptr;
+  std::vector<int> idx, tmp, ini_cnt, ini_fill;
+  std::vector<uint8_t> cls;
   std::vector<QNode> nodes;
+  std::vector<std::pair<int, int>> sizeAndNode, prevSN;   // (size, node id); id order == creation order
   int head = -1, tail = -1, count = 0;
   int push_back(const QNode& n) {
     nodes.push_back(n);
@@ -373,35 +386,38 @@ class QuadTree {
     return id;
   }
   void erase(int id) {
-    QNode& n = nodes[id];
+    const QNode n = nodes[id];
     if (n.prev != -1) nodes[n.prev].next = n.next; else head = n.next;
     if (n.next != -1) nodes[n.next].prev = n.prev; else tail = n.prev;
-    n.alive = false; --count;
+    --count;
   }
-  void divide_and_add(int id, std::vector<std::pair<int, int>>& sizeAndNode, int* nToExpand) {
+  void divide_and_add(int id, int* nToExpand) {
     QNode c[4];
-    {
-      const QNode& n = nodes[id];
-      const int halfX = (int)std::ceil((float)(n.URx - n.ULx) / 2), halfY = (int)std::ceil((float)(n.BRy - n.ULy) / 2);
-      QNode &n1 = c[0], &n2 = c[1], &n3 = c[2], &n4 = c[3];
-      n1.ULx = n.ULx; n1.ULy = n.ULy; n1.URx = n.ULx + halfX; n1.URy = n.ULy; n1.BLx = n.ULx; n1.BLy = n.ULy + halfY; n1.BRx = n.ULx + halfX; n1.BRy = n.ULy + halfY;
-      n2.ULx = n1.URx; n2.ULy = n1.URy; n2.URx = n.URx; n2.URy = n.URy; n2.BLx = n1.BRx; n2.BLy = n1.BRy; n2.BRx = n.URx; n2.BRy = n.ULy + halfY;
-      n3.ULx = n1.BLx; n3.ULy = n1.BLy; n3.URx = n1.BRx; n3.URy = n1.BRy; n3.BLx = n.BLx; n3.BLy = n.BLy; n3.BRx = n1.BRx; n3.BRy = n.BLy;
-      n4.ULx = n3.URx; n4.ULy = n3.URy; n4.URx = n2.BRx; n4.URy = n2.BRy; n4.BLx = n3.BRx; n4.BLy = n3.BRy; n4.BRx = n.BRx; n4.BRy = n.BRy;
-      for (int k : n.keys) {
-        const Cand& kp = cand[k];
-        if (kp.x < n1.URx) { if (kp.y < n1.BRy) n1.keys.push_back(k); else n3.keys.push_back(k); }
-        else if (kp.y < n1.BRy) n2.keys.push_back(k);
-        else n4.keys.push_back(k);
-      }
-      for (int q = 0; q < 4; ++q) if (c[q].keys.size() == 1) c[q].noMore = true;
+    const QNode n = nodes[id];
+    const int halfX = (int)std::ceil((float)(n.URx - n.ULx) / 2), halfY = (int)std::ceil((float)(n.BRy - n.ULy) / 2);
+    QNode &n1 = c[0], &n2 = c[1], &n3 = c[2], &n4 = c[3];
+    n1.ULx = n.ULx; n1.ULy = n.ULy; n1.URx = n.ULx + halfX; n1.URy = n.ULy; n1.BLx = n.ULx; n1.BLy = n.ULy + halfY; n1.BRx = n.ULx + halfX; n1.BRy = n.ULy + halfY;
+    n2.ULx = n1.URx; n2.ULy = n1.URy; n2.URx = n.URx; n2.URy = n.URy; n2.BLx = n1.BRx; n2.BLy = n1.BRy; n2.BRx = n.URx; n2.BRy = n.ULy + halfY;
+    n3.ULx = n1.BLx; n3.ULy = n1.BLy; n3.URx = n1.BRx; n3.URy = n1.BRy; n3.BLx = n.BLx; n3.BLy = n.BLy; n3.BRx = n1.BRx; n3.BRy = n.BLy;
+    n4.ULx = n3.URx; n4.ULy = n3.URy; n4.URx = n2.BRx; n4.URy = n2.BRy; n4.BLx = n3.BRx; n4.BLy = n3.BRy; n4.BRx = n.BRx; n4.BRy = n.BRy;
+    int cnt[4] = {0, 0, 0, 0};
+    const float sx = (float)n1.URx, sy = (float)n1.BRy;      // kp.pt.x < n1.UR.x compares float with int -> float
+    for (int k = n.b; k < n.e; ++k) {
+      const int ki = idx[k];
+      const int q = (x[ki] < sx) ? ((y[ki] < sy) ? 0 : 2) : ((y[ki] < sy) ? 1 : 3);
+      cls[k] = (uint8_t)q; ++cnt[q];
     }
+    int cur[4];
+    cur[0] = n.b; cur[1] = cur[0] + cnt[0]; cur[2] = cur[1] + cnt[1]; cur[3] = cur[2] + cnt[2];
+    for (int q = 0; q < 4; ++q) { c[q].b = cur[q]; c[q].e = cur[q] + cnt[q]; c[q].noMore = cnt[q] == 1; }
+    for (int k = n.b; k < n.e; ++k) tmp[cur[cls[k]]++] = idx[k];
+    std::memcpy(idx.data() + n.b, tmp.data() + n.b, sizeof(int) * (size_t)(n.e - n.b));
     for (int q = 0; q < 4; ++q) {
-      if (c[q].keys.empty()) continue;
+      if (cnt[q] == 0) continue;
       const int nid = push_front(c[q]);
-      if (nodes[nid].keys.size() > 1) {
+      if (cnt[q] > 1) {
         if (nToExpand) ++*nToExpand;
-        sizeAndNode.push_back(std::make_pair((int)nodes[nid].keys.size(), nid));
+        sizeAndNode.push_back(std::make_pair(cnt[q], nid));
       }
     }
   }
@@ -429,15 +445,23 @@ struct vdo_orb {
   float *d_x = nullptr, *d_y = nullptr, *d_resp = nullptr, *d_ang = nullptr; int* d_lvl = nullptr;
   int64_t pyr_bytes = 0, blur_bytes = 0;
   int dense_cap = 0;
-  // host mirrors of the last extraction
-  std::vector<float> hx, hy, hresp, hang; std::vector<int> hlvl, hoffs, hlevel_cnt;
+  // pinned staging: [32 ints: level counts, total][5][kSpecCand] — header and candidates arrive with ONE sync
+  float* h_pin = nullptr;
+  float* h_over = nullptr; size_t h_over_n = 0;      // overflow staging when a frame has more than kSpecCand candidates
+  // host view of the last extraction (pointers into the pinned staging)
+  const float *hx = nullptr, *hy = nullptr, *hresp = nullptr, *hang = nullptr; std::vector<int> hlevel_cnt;
   int n_cand = 0;
+  QuadTree qt;                                        // buffers reused across levels and frames
+  std::vector<int> sel;
+  double ms_device = 0, ms_tree = 0;                  // last extraction: launch..sync, host quadtree
 };
 
 extern "C" int vdo_orb_destroy(vdo_orb* o) {
   if (!o) return VDO_OK;
   if (o->ctx) ctx_bind(o->ctx);
   for (void* p : o->allocs) hipFree(p);
+  if (o->h_pin) hipHostFree(o->h_pin);
+  if (o->h_over) hipHostFree(o->h_over);
   delete o;
   return VDO_OK;
 }
@@ -526,12 +550,16 @@ extern "C" int vdo_orb_create(vdo_ctx* ctx, const vdo_orb_params* prm, int w, in
   o->d_pyr = (uint8_t*)dev(o->pyr_bytes); o->d_blur = (uint8_t*)dev(o->blur_bytes);
   o->d_levels = (LevelDesc*)dev(sizeof(LevelDesc) * NL); o->d_cells = (CellDesc*)dev(sizeof(CellDesc) * o->ncells);
   o->d_cell_level = (int*)dev(4 * (size_t)o->ncells);
-  o->d_cnt = (int*)dev(4 * (size_t)o->ncells); o->d_offs = (int*)dev(4 * ((size_t)o->ncells + 1)); o->d_level_cnt = (int*)dev(4 * 16);
+  o->d_cnt = (int*)dev(4 * (size_t)o->ncells); o->d_offs = (int*)dev(4 * ((size_t)o->ncells + 1)); o->d_level_cnt = (int*)dev(4 * 32);
   o->d_pack = (uint32_t*)dev(4 * (size_t)o->dense_cap);
-  o->d_x = (float*)dev(4 * (size_t)o->dense_cap); o->d_y = (float*)dev(4 * (size_t)o->dense_cap);
-  o->d_resp = (float*)dev(4 * (size_t)o->dense_cap); o->d_ang = (float*)dev(4 * (size_t)o->dense_cap); o->d_lvl = (int*)dev(4 * (size_t)o->dense_cap);
+  o->d_x = (float*)dev(4 * (size_t)o->dense_cap * 5);       // x | y | resp | angle | level: rows of one allocation (single strided D2H)
+  if (o->d_x) {
+    o->d_y = o->d_x + (size_t)o->dense_cap; o->d_resp = o->d_x + 2 * (size_t)o->dense_cap; o->d_ang = o->d_x + 3 * (size_t)o->dense_cap;
+    o->d_lvl = (int*)(o->d_x + 4 * (size_t)o->dense_cap);
+  }
+  if (hipHostMalloc((void**)&o->h_pin, 4 * (32 + 5 * (size_t)kSpecCand)) != hipSuccess) o->h_pin = nullptr;
   for (void* p : o->allocs) if (!p) { vdo_orb_destroy(o); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
-  if (!o->d_lvl) { vdo_orb_destroy(o); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  if (!o->d_lvl || !o->h_pin) { vdo_orb_destroy(o); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
   hipMemcpyAsync(o->d_levels, o->levels.data(), sizeof(LevelDesc) * NL, hipMemcpyHostToDevice, s);
   hipMemcpyAsync(o->d_cells, o->cells.data(), sizeof(CellDesc) * o->ncells, hipMemcpyHostToDevice, s);
   hipMemcpyAsync(o->d_cell_level, o->cell_level.data(), 4 * (size_t)o->ncells, hipMemcpyHostToDevice, s);
@@ -581,47 +609,64 @@ extern "C" int vdo_orb_extract(vdo_orb* o, const uint8_t* gray, int stride, int 
     hipMemcpy2DAsync(o->d_src, o->w, gray, stride, o->w, o->h, hipMemcpyHostToDevice, s);
     src = o->d_src; sstride = o->w;
   }
+  const auto t_begin = std::chrono::steady_clock::now();
   orb_device_stage(o, src, sstride);
-  // candidates -> host
-  o->hoffs.resize(o->ncells + 1); o->hlevel_cnt.resize(16);
-  hipMemcpyAsync(o->hoffs.data(), o->d_offs, 4 * ((size_t)o->ncells + 1), hipMemcpyDeviceToHost, s);
-  hipMemcpyAsync(o->hlevel_cnt.data(), o->d_level_cnt, 4 * 16, hipMemcpyDeviceToHost, s);
+  // candidates -> host: header (level counts + total) and the first kSpecCand columns of the 5 candidate rows, one sync
+  int* hdr = (int*)o->h_pin;
+  float* rows = o->h_pin + 32;
+  const int spec = std::min(kSpecCand, o->dense_cap);
+  hipMemcpyAsync(hdr, o->d_level_cnt, 4 * 32, hipMemcpyDeviceToHost, s);
+  hipMemcpy2DAsync(rows, 4 * (size_t)spec, o->d_x, 4 * (size_t)o->dense_cap, 4 * (size_t)spec, 5, hipMemcpyDeviceToHost, s);
   if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "orb device stage failed: %s", hipGetErrorString(hipGetLastError()));
-  const int total = o->hoffs[o->ncells];
+  const int total = hdr[16];
   o->n_cand = total;
-  o->hx.resize(total); o->hy.resize(total); o->hresp.resize(total); o->hang.resize(total); o->hlvl.resize(total);
-  if (total) {
-    hipMemcpyAsync(o->hx.data(), o->d_x, 4 * (size_t)total, hipMemcpyDeviceToHost, s);
-    hipMemcpyAsync(o->hy.data(), o->d_y, 4 * (size_t)total, hipMemcpyDeviceToHost, s);
-    hipMemcpyAsync(o->hresp.data(), o->d_resp, 4 * (size_t)total, hipMemcpyDeviceToHost, s);
-    hipMemcpyAsync(o->hang.data(), o->d_ang, 4 * (size_t)total, hipMemcpyDeviceToHost, s);
-    hipMemcpyAsync(o->hlvl.data(), o->d_lvl, 4 * (size_t)total, hipMemcpyDeviceToHost, s);
+  o->hlevel_cnt.assign(hdr, hdr + 16);
+  size_t pitch = (size_t)spec;
+  if (total > spec) {           // rare: fetch everything into a (grown on demand) pinned overflow buffer
+    if (o->h_over_n < (size_t)total) {
+      if (o->h_over) hipHostFree(o->h_over);
+      o->h_over = nullptr; o->h_over_n = 0;
+      if (hipHostMalloc((void**)&o->h_over, 4 * 5 * (size_t)total) != hipSuccess) return set_error(VDO_ERR_OOM, "hipHostMalloc failed");
+      o->h_over_n = (size_t)total;
+    }
+    hipMemcpy2DAsync(o->h_over, 4 * (size_t)total, o->d_x, 4 * (size_t)o->dense_cap, 4 * (size_t)total, 5, hipMemcpyDeviceToHost, s);
     if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "orb D2H failed");
+    rows = o->h_over; pitch = (size_t)total;
   }
+  o->hx = rows; o->hy = rows + pitch; o->hresp = rows + 2 * pitch; o->hang = rows + 3 * pitch;
+  const auto t_dev = std::chrono::steady_clock::now();
   // K5 on the host, level by level (candidates of a level are contiguous: cells are level-major)
   int n = 0, pos = 0;
   const int NL = o->prm.n_levels;
   for (int l = 0; l < NL; ++l) {
     const int cnt = o->hlevel_cnt[l];
-    std::vector<Cand> c(cnt);
-    for (int k = 0; k < cnt; ++k) c[k] = Cand{o->hx[pos + k], o->hy[pos + k], o->hresp[pos + k], o->hang[pos + k]};
+    const float *cx = o->hx + pos, *cy = o->hy + pos, *cr = o->hresp + pos, *ca = o->hang + pos;
     pos += cnt;
     std::vector<int> sel;
     const LevelDesc& L = o->levels[l];
     const int minB = kEdge - 3;
-    QuadTree qt(c);
-    qt.run(minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, o->nfeat[l], sel);
+    o->qt.run(cx, cy, cr, cnt, minB, L.w - kEdge + 3, minB, L.h - kEdge + 3, o->nfeat[l], sel);
     const int patch = (int)(kPatch * o->scale[l]);
     for (int id : sel) {
       if (n >= out->capacity) return set_error(VDO_ERR_INVALID, "vdo_orb_extract: keypoint capacity %d too small", out->capacity);
-      float x = c[id].x + minB, y = c[id].y + minB;
+      float x = cx[id] + minB, y = cy[id] + minB;
       if (l != 0) { x = x * o->scale[l]; y = y * o->scale[l]; }
-      out->x[n] = x; out->y[n] = y; out->response[n] = c[id].resp; out->angle[n] = c[id].angle;
+      out->x[n] = x; out->y[n] = y; out->response[n] = cr[id]; out->angle[n] = ca[id];
       out->octave[n] = l; out->size[n] = (float)patch;
       ++n;
     }
   }
   out->n = n;
+  const auto t_end = std::chrono::steady_clock::now();
+  o->ms_device = std::chrono::duration<double, std::milli>(t_dev - t_begin).count();
+  o->ms_tree = std::chrono::duration<double, std::milli>(t_end - t_dev).count();
+  return VDO_OK;
+}
+
+// Wall time of the last vdo_orb_extract: [0] launch of the device stage .. candidates on the host, [1] host quadtree (K5)
+extern "C" int vdo_orb_last_timing(vdo_orb* o, double ms[2]) {
+  if (!o || !ms) return set_error(VDO_ERR_INVALID, "null argument");
+  ms[0] = o->ms_device; ms[1] = o->ms_tree;
   return VDO_OK;
 }
 

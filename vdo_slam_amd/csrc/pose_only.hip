@@ -77,7 +77,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_pose_lm(const PoseDev* __restric
   double* err = A.err + 2 * P.off;
   vdo_flow2_result* res = A.results + blockIdx.x;
 
-  __shared__ double s_scr[4 * 27], s_red[27];
+  __shared__ double s_scr[F2_WAVES * 27], s_red[27];
   __shared__ SE3d s_T, s_Ttry;
   __shared__ double s_Hpp[36], s_bp[6], s_xp[6];
   __shared__ double s_lambda, s_scale;
@@ -85,6 +85,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_pose_lm(const PoseDev* __restric
 
   if (N < 3) {   // nInitialCorrespondences<3 (Optimizer.cc:2264-2265, 2659-2660)
     if (tid < 16) res->T[tid] = (tid % 5 == 0) ? 1.0 : 0.0;
+    if (tid < N) A.inlier_out[P.off + tid] = 0;
     if (tid == 0) { res->n_inliers = 0; res->iterations = 0; res->trials = 0; res->stop_reason = 0; res->initial_chi2 = res->final_chi2 = res->final_lambda = 0; }
     return;
   }

@@ -74,16 +74,29 @@ class ORBextractor:
         return out
 
     def extract_device(self, gray_ptr: int, stride: int, capacity=None):
-        """Like ``__call__`` but the gray image is already resident in HBM (raw device pointer)."""
+        """Like ``__call__`` but the gray image is already resident in HBM (raw device pointer).
+        The returned arrays are views of buffers owned by this extractor: valid until the next call."""
         cap = capacity or (self.params.n_features + 256)
-        a = {k: np.zeros(cap, np.float32) for k in ("x", "y", "response", "angle", "size")}
-        octave = np.zeros(cap, np.int32)
-        kp = KeypointsC(cap, 0, _fp(a["x"]), _fp(a["y"]), _fp(a["response"]), _fp(a["angle"]), _fp(a["size"]), _ip(octave))
-        K.check(_lib().vdo_orb_extract(self._h, C.cast(C.c_void_p(gray_ptr), K.c_uint8_p), stride, 1, C.byref(kp)))
+        st = getattr(self, "_dev_out", None)
+        if st is None or st[0] != cap:
+            a = {k: np.zeros(cap, np.float32) for k in ("x", "y", "response", "angle", "size")}
+            octave = np.zeros(cap, np.int32)
+            kp = KeypointsC(cap, 0, _fp(a["x"]), _fp(a["y"]), _fp(a["response"]), _fp(a["angle"]), _fp(a["size"]), _ip(octave))
+            st = self._dev_out = (cap, a, octave, kp, C.byref(kp), _lib().vdo_orb_extract)
+        _, a, octave, kp, kp_ref, fn = st
+        K.check(fn(self._h, C.cast(C.c_void_p(gray_ptr), K.c_uint8_p), stride, 1, kp_ref))
         n = kp.n
         out = {k: v[:n] for k, v in a.items()}
         out["octave"] = octave[:n]
         return out
+
+    def last_timing(self):
+        """(ms device stage incl. D2H of the candidates, ms host quadtree) of the last extraction."""
+        ms = (C.c_double * 2)()
+        L = _lib()
+        L.vdo_orb_last_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        K.check(L.vdo_orb_last_timing(self._h, ms))
+        return ms[0], ms[1]
 
     def level_info(self, level):
         w, h, nf, nc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
@@ -157,21 +170,31 @@ class FrameImages:
         K.check(L.vdo_frame_images_depth_preprocess(self._h, bf, factor))
 
     def static_filter(self, kx, ky, th_depth):
+        """Outputs are views of buffers owned by this object: valid until the next call."""
         kx = np.ascontiguousarray(kx, dtype=np.float32); ky = np.ascontiguousarray(ky, dtype=np.float32)
         n = kx.size
-        idx = np.zeros(n, np.int32)
-        f = [np.zeros(n, np.float32) for _ in range(5)]
-        m = C.c_int()
-        K.check(_lib().vdo_frame_static_filter(self._h, n, _fp(kx), _fp(ky), th_depth, _ip(idx), *[_fp(a) for a in f], C.byref(m)))
+        st = getattr(self, "_sf", None)
+        if st is None or st[0] < n:
+            cap = max(n, 4096)
+            idx = np.zeros(cap, np.int32); f = [np.zeros(cap, np.float32) for _ in range(5)]
+            m = C.c_int()
+            st = self._sf = (cap, idx, f, m, [_ip(idx)] + [_fp(a) for a in f] + [C.byref(m)], _lib().vdo_frame_static_filter)
+        _, idx, f, m, args, fn = st
+        K.check(fn(self._h, n, _fp(kx), _fp(ky), th_depth, *args))
         m = m.value
         return dict(keep_idx=idx[:m], corr_x=f[0][:m], corr_y=f[1][:m], flow_x=f[2][:m], flow_y=f[3][:m], depth=f[4][:m])
 
     def object_sample(self, th_depth_obj, step=4):
+        """Outputs are views of buffers owned by this object: valid until the next call."""
         cap = ((self.w + step - 1) // step) * ((self.h + step - 1) // step)
-        f = [np.zeros(cap, np.float32) for _ in range(7)]
-        lab = np.zeros(cap, np.int32)
-        m = C.c_int()
-        K.check(_lib().vdo_frame_object_sample(self._h, th_depth_obj, step, cap, *[_fp(a) for a in f], _ip(lab), C.byref(m)))
+        st = getattr(self, "_os", None)
+        if st is None or st[0] != cap:
+            f = [np.zeros(cap, np.float32) for _ in range(7)]
+            lab = np.zeros(cap, np.int32)
+            m = C.c_int()
+            st = self._os = (cap, f, lab, m, [_fp(a) for a in f] + [_ip(lab), C.byref(m)], _lib().vdo_frame_object_sample)
+        _, f, lab, m, args, fn = st
+        K.check(fn(self._h, th_depth_obj, step, cap, *args))
         m = m.value
         names = ("key_x", "key_y", "corr_x", "corr_y", "flow_x", "flow_y", "depth")
         out = {k: a[:m] for k, a in zip(names, f)}
