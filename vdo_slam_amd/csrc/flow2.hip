@@ -124,10 +124,14 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   double chi2_check = 0;
   double last_err_chi = compute_errors(s_T, fcur);
   const double initial_chi2 = last_err_chi;
+  bool err_valid = true;
   bool ok = true;
   for (; it < P.max_iterations && ok; ++it) {
     F2_TICK(7);
-    last_err_chi = compute_errors(s_T, fcur);
+    // computeActiveErrors at the current estimate: err/errp and the chi2 are already those of this estimate
+    // when the previous trial was accepted (or right after the initial evaluation) - same inputs, same code,
+    // same bits - so the pass is only repeated after a rejected trial.
+    if (!err_valid) last_err_chi = compute_errors(s_T, fcur);
     F2_TICK(0);
     double currentChi = last_err_chi, tempChi = currentChi;
     const double iniChi = currentChi;
@@ -295,11 +299,11 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       if (rho > 0 && isfinite(tempChi)) {
         double alpha = 1. - pow((2 * rho - 1), 3);
         alpha = fmin(alpha, upper);
-        lambda *= fmax(lower, alpha); ni = 2; currentChi = tempChi;
+        lambda *= fmax(lower, alpha); ni = 2; currentChi = tempChi; err_valid = true;
         { double* t_ = fcur; fcur = ftry; ftry = t_; }                       // discardTop(): accept (uniform pointer swap)
         if (tid == 0) s_T = s_Ttry;
       } else {
-        lambda *= ni; ni *= 2;                                            // pop(): keep (s_T, fcur)
+        lambda *= ni; ni *= 2; err_valid = false;                         // pop(): keep (s_T, fcur)
       }
       __syncthreads();
       ++qmax; ++total_trials;

@@ -125,9 +125,9 @@ __global__ __launch_bounds__(F2_THREADS) void k_pose_lm(const PoseDev* __restric
   double chi2_check = 0;
   double last_err_chi = compute_errors(s_T);
   const double initial_chi2 = last_err_chi;
-  bool ok = true;
+  bool ok = true, err_valid = true;
   for (; it < P.max_iterations && ok; ++it) {
-    last_err_chi = compute_errors(s_T);
+    if (!err_valid) last_err_chi = compute_errors(s_T);     // stored errors already belong to this estimate after an accepted trial
     double currentChi = last_err_chi, tempChi = currentChi;
     const double iniChi = currentChi;
     {   // ---- buildSystem
@@ -186,10 +186,10 @@ __global__ __launch_bounds__(F2_THREADS) void k_pose_lm(const PoseDev* __restric
       if (rho > 0 && isfinite(tempChi)) {
         double alpha = 1. - pow((2 * rho - 1), 3);
         alpha = fmin(alpha, upper);
-        lambda *= fmax(lower, alpha); ni = 2; currentChi = tempChi;
+        lambda *= fmax(lower, alpha); ni = 2; currentChi = tempChi; err_valid = true;
         if (tid == 0) s_T = s_Ttry;
       } else {
-        lambda *= ni; ni *= 2;
+        lambda *= ni; ni *= 2; err_valid = false;
       }
       __syncthreads();
       ++qmax; ++total_trials;
