@@ -314,6 +314,61 @@ int vdo_mask_at(vdo_frame_images* f, int n, const float* cx, const float* cy, in
 int vdo_mask_warp(vdo_frame_images* cur, vdo_frame_images* last, int32_t label);
 int vdo_frame_images_download_mask(vdo_frame_images* f, int32_t* mask_out);
 
+/* ---- Tracking bookkeeping around the gathers ------------------------------------ */
+
+/* Tracking::DynObjTracking (src/Tracking.cc:1366-1612): groups the object points of the current frame
+ * by semantic label; drops labels with > 50 % of their points in the image border (obj label -1),
+ * labels whose share of slow points (||flow3d_xz|| < sf_mg_thres) exceeds sf_ds_thres become static
+ * (obj label 0), labels with mean depth > th_depth_obj or < 150 points are dropped (-1); the survivors
+ * get the motion label of the last-frame object whose semantic label wins the vote of their points'
+ * last-frame labels (else a fresh id from *max_id_inout).  flow3d comes from vdo_scene_flow.
+ * Outputs: obj_label_inout updated; accepted objects as CSR obj_off[n_obj+1] / obj_idx (capacity n),
+ * obj_sem / obj_mod (capacity: number of distinct labels). */
+typedef struct vdo_dyn_obj_params {
+  int32_t img_w, img_h;
+  int32_t shrink_row, shrink_col; /* 25 / 50 on KITTI, 0 / 0 otherwise (:1412-1416)               */
+  float sf_mg_thres, sf_ds_thres; /* Tracking::fSFMgThres / fSFDsThres (yaml SFMgThres, SFDsThres) */
+  float th_depth_obj;             /* mThDepthObj                                                   */
+  int32_t f_id;                   /* frame id: 1 resets the id counter (:1536-1537)                 */
+} vdo_dyn_obj_params;
+int vdo_dyn_obj_tracking(const vdo_dyn_obj_params* prm, int n, const int32_t* sem_label, int32_t* obj_label_inout,
+                         const float* key_x, const float* key_y, const float* depth, const float* flow3d, const int32_t* last_sem_label,
+                         int n_last_obj, const int32_t* last_sem_pos, const int32_t* last_mod_label, const uint8_t* last_obj_stat,
+                         int32_t* max_id_inout, int32_t* obj_off, int32_t* obj_idx, int32_t* obj_sem, int32_t* obj_mod, int* n_obj_out);
+
+/* Tracking::RenewFrameInfo, object part (src/Tracking.cc:2806-2995).  `f` holds the NEW frame's images.
+ * Carries the inliers of every tracked object (int-truncated position must lie on a mask != 0 with
+ * 0 < depth < 25 and flow inside the image), tops every tracked object up to max_num_obj from the
+ * semi-dense sampling tmp_* of the new image (stride-15 interleave, skipping samples within 1 px of a
+ * carried point), then appends all samples of labels that are not tracked yet (object label -2).
+ * Outputs (capacity `cap` each): key, depth, semantic label, flow, correspondence, inlier id (-1 for
+ * added points), object label. */
+int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* inl_off, const int32_t* inl_idx, const uint8_t* obj_stat,
+                     const int32_t* sem_pos, const int32_t* mod_label,
+                     const float* cur_x, const float* cur_y, const int32_t* cur_obj_label,
+                     int n_tmp, const float* tmp_x, const float* tmp_y, const float* tmp_depth, const int32_t* tmp_label,
+                     const float* tmp_flow_x, const float* tmp_flow_y, const float* tmp_corr_x, const float* tmp_corr_y,
+                     int max_num_obj, int cap,
+                     float* key_x, float* key_y, float* depth_out, int32_t* sem_out, float* flow_x, float* flow_y,
+                     float* corr_x, float* corr_y, int32_t* dyn_inlier_id, int32_t* obj_label_out, int* n_out);
+
+/* Tracking::UpdateMask (src/Tracking.cc:2997-3068) in one stream-ordered sequence without host round
+ * trips: per last-frame semantic label (ascending) the labels of `cur`'s mask at the flowed positions
+ * vote; with >= 100 votes and background winning, that label's pixels of `last`'s mask are warped by
+ * `last`'s flow into `cur`'s mask (visible to the next label's vote, as in the reference). */
+int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, int n, const int32_t* last_sem_label,
+                    const float* last_corr_x, const float* last_corr_y, int* n_recovered);
+
+/* Tracklets: Tracking::GetStaticTrack / GetDynamicTrackNew (src/Tracking.cc:2201-2421) rebuild every
+ * tracklet from frame 0 on every frame; this builder is incremental (one association vector per call)
+ * and yields the same tracklets in the same order.  Host only. */
+typedef struct vdo_tracks vdo_tracks;
+int vdo_tracks_create(int with_object_label, vdo_tracks** out);
+int vdo_tracks_destroy(vdo_tracks* t);
+int vdo_tracks_add_frame(vdo_tracks* t, int n, const int32_t* asso /* index in the previous frame or -1 */, const int32_t* feat_label);
+int vdo_tracks_size(vdo_tracks* t, int* n_tracks, int64_t* n_pairs);
+int vdo_tracks_get(vdo_tracks* t, int32_t* track_off, int32_t* pair_frame, int32_t* pair_feat, int32_t* obj_id);
+
 #ifdef __cplusplus
 }
 #endif

@@ -141,6 +141,26 @@ typedef struct vdo_pose_problem {
 } vdo_pose_problem;
 int vdo_oracle_pose_optimize(const vdo_pose_problem* p, double T_out[16], uint8_t* inlier_out, vdo_lm_stats* stats);
 
+/* ---- Tracking bookkeeping (tracking_logic_oracle.cpp) --------------------------------------*/
+int vdo_oracle_dyn_obj_tracking(int n, const int32_t* sem_label, int32_t* obj_label_inout, const float* kx, const float* ky,
+                                const float* depth, const float* flow3d, const int32_t* last_sem_label,
+                                int n_last_obj, const int32_t* last_sem_pos, const int32_t* last_mod_label, const uint8_t* last_obj_stat,
+                                int img_w, int img_h, int shrink_row, int shrink_col, float sf_mg_thres, float sf_ds_thres, float th_depth_obj,
+                                int f_id, int32_t* max_id_inout,
+                                int32_t* obj_off, int32_t* obj_idx, int32_t* obj_sem, int32_t* obj_mod);
+int vdo_oracle_renew_object(int n_obj, const int32_t* inl_off, const int32_t* inl_idx, const uint8_t* obj_stat,
+                            const int32_t* sem_pos, const int32_t* mod_label,
+                            const float* cur_x, const float* cur_y, const int32_t* cur_obj_label,
+                            int n_tmp, const float* tmp_x, const float* tmp_y, const float* tmp_depth, const int32_t* tmp_label,
+                            const float* tmp_flow_x, const float* tmp_flow_y, const float* tmp_corr_x, const float* tmp_corr_y,
+                            const int32_t* mask, const float* depth, const float* flow, int w, int h, int max_num_obj, int cap,
+                            float* key_x, float* key_y, float* depth_out, int32_t* sem_out, float* flow_x, float* flow_y,
+                            float* corr_x, float* corr_y, int32_t* dyn_inlier_id, int32_t* obj_label_out);
+int vdo_oracle_update_mask(int n, const int32_t* last_sem_label, const float* last_corr_x, const float* last_corr_y,
+                           const int32_t* mask_last, const float* flow_last, int w, int h, int32_t* mask_cur);
+int vdo_oracle_build_tracks(int n_frames, const int32_t* asso_off, const int32_t* asso, const int32_t* feat_label,
+                            int cap_tracks, int cap_pairs, int32_t* track_off, int32_t* pair_frame, int32_t* pair_feat, int32_t* obj_id);
+
 /* ---- front-end (frontend_oracle.cpp) ------------------------------------------------------*/
 typedef struct vdo_orb_params {   /* ORBextractor ctor arguments (include/ORBextractor.h:39-40) */
   int32_t n_features;     /* 2500 */

@@ -62,5 +62,12 @@ def load():
                                           fp, fp, fp, fp, fp, fp, i32p, fp]
     L.vdo_oracle_mask_at.argtypes = [C.c_int, fp, fp, i32p, C.c_int, C.c_int, i32p]
     L.vdo_oracle_mask_warp.argtypes = [i32p, fp, C.c_int, C.c_int, C.c_int32, i32p]
+    u8 = K.c_uint8_p
+    L.vdo_oracle_dyn_obj_tracking.argtypes = [C.c_int, i32p, i32p, fp, fp, fp, fp, i32p, C.c_int, i32p, i32p, u8, C.c_int, C.c_int, C.c_int, C.c_int,
+                                              C.c_float, C.c_float, C.c_float, C.c_int, i32p, i32p, i32p, i32p, i32p]
+    L.vdo_oracle_renew_object.argtypes = [C.c_int, i32p, i32p, u8, i32p, i32p, fp, fp, i32p, C.c_int, fp, fp, fp, i32p, fp, fp, fp, fp,
+                                          i32p, fp, fp, C.c_int, C.c_int, C.c_int, C.c_int, fp, fp, fp, i32p, fp, fp, fp, fp, i32p, i32p]
+    L.vdo_oracle_update_mask.argtypes = [C.c_int, i32p, fp, fp, i32p, fp, C.c_int, C.c_int, i32p]
+    L.vdo_oracle_build_tracks.argtypes = [C.c_int, i32p, i32p, i32p, C.c_int, C.c_int, i32p, i32p, i32p, i32p]
     _lib = L
     return L

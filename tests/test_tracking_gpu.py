@@ -72,6 +72,77 @@ def test_renew_static(ctx, oracle, case):
         assert np.array_equal(got[k], exp[k]), k
 
 
+def _object_case(oracle, seed):
+    from tests import frontend_ref as R
+    fr, depth = _frame(seed)
+    rng = np.random.default_rng(seed)
+    ob = R.object_sample(oracle, fr["mask"], depth, fr["flow"], SF.TH_DEPTH_OBJ)          # K10 sampling of the new image
+    tmp = dict(x=ob["key_x"], y=ob["key_y"], depth=ob["depth"], label=ob["label"], flow_x=ob["flow_x"], flow_y=ob["flow_y"],
+               corr_x=ob["corr_x"], corr_y=ob["corr_y"])
+    # current object points: pixels on the masks (plus strays), sub-pixel positions as they come out of the flow propagation
+    ys, xs = np.nonzero(fr["mask"])
+    pick = rng.permutation(ys.size)[:3000]
+    cx = (xs[pick] + rng.uniform(-0.4, 1.4, pick.size)).astype(np.float32)
+    cy = (ys[pick] + rng.uniform(-0.4, 1.4, pick.size)).astype(np.float32)
+    cx[:40] = rng.uniform(-5, 1250, 40).astype(np.float32); cy[:40] = rng.uniform(-5, 380, 40).astype(np.float32)
+    lab_at = fr["mask"][np.clip(cy.astype(int), 0, 374), np.clip(cx.astype(int), 0, 1241)]
+    col = rng.integers(1, 9, cx.size).astype(np.int32)
+    labels = [l for l in np.unique(ob["label"]) if l > 0]
+    tracked = labels[:3] if len(labels) >= 3 else labels
+    inl = [np.nonzero((lab_at == l) & (rng.random(cx.size) < 0.8))[0].astype(np.int32) for l in tracked]
+    stat = np.ones(len(tracked), np.uint8)
+    if len(tracked) > 1:
+        stat[1] = 0
+    return fr, depth, tmp, cx, cy, col, inl, stat, np.array(tracked, np.int32), np.arange(11, 11 + len(tracked)).astype(np.int32)
+
+
+@pytest.mark.parametrize("seed,max_num", [(21, 800), (22, 60), (23, 100000)])
+def test_renew_object(ctx, oracle, seed, max_num):
+    fr, depth, tmp, cx, cy, col, inl, stat, sem_pos, mod = _object_case(oracle, seed)
+    im = _images(ctx, depth, fr["flow"], fr["mask"])
+    got = TR.renew_object(im, inl, stat, sem_pos, mod, cx, cy, col, tmp, max_num)
+    exp = T.renew_object(oracle, inl, stat, sem_pos, mod, cx, cy, col, tmp, fr["mask"], depth, fr["flow"], max_num)
+    assert exp["key_x"].size > 200
+    for k in exp:
+        assert np.array_equal(got[k], exp[k]), k
+    assert (exp["obj_label"] == -2).sum() > 0 and (exp["inlier_id"] >= 0).sum() > 0
+    if max_num >= 800:                       # with the small cap the carried points already fill the objects: no top-up
+        assert ((exp["inlier_id"] == -1) & (exp["obj_label"] > 0)).sum() > 0
+
+
+def test_update_mask_recovers_a_dropped_mask(ctx, oracle):
+    """The current mask misses one object (Mask-RCNN dropout): its last-frame points land on background,
+    the vote says 0, the previous mask is warped in; labels that are still there are left alone."""
+    from tests import frontend_ref as R
+    fr, depth = _frame(31)
+    rng = np.random.default_rng(31)
+    ob = R.object_sample(oracle, fr["mask"], depth, fr["flow"], SF.TH_DEPTH_OBJ)
+    labels = np.unique(ob["label"])
+    assert labels.size >= 3
+    cur_mask = fr["mask"].copy()
+    # "current" segmentation: every object shifted by its mean flow, one of them missing, one too small to vote
+    cur_mask[:] = 0
+    for l in labels:
+        ys, xs = np.nonzero(fr["mask"] == l)
+        if l == labels[0]:
+            continue                                                        # dropped mask
+        fx = int(np.median(fr["flow"][ys, xs, 0])); fy = int(np.median(fr["flow"][ys, xs, 1]))
+        ok = (xs + fx > 0) & (xs + fx < 1242) & (ys + fy > 0) & (ys + fy < 375)
+        cur_mask[(ys + fy)[ok], (xs + fx)[ok]] = l
+    keep = np.ones(ob["label"].size, bool)
+    small = np.nonzero(ob["label"] == labels[1])[0]
+    keep[small[60:]] = False                                                # fewer than 100 votes: skipped whatever they say
+    sl, cx, cy = ob["label"][keep], ob["corr_x"][keep], ob["corr_y"][keep]
+    last_im = _images(ctx, depth, fr["flow"], fr["mask"])
+    cur_im = _images(ctx, depth, fr["flow"], cur_mask)
+    rec = TR.update_mask(cur_im, last_im, sl, cx, cy)
+    exp, rec_o = T.update_mask(oracle, sl, cx, cy, fr["mask"], fr["flow"], cur_mask)
+    assert rec == rec_o and rec >= 1
+    got = TR.download_mask(cur_im)
+    assert np.array_equal(got, exp)
+    assert (got == labels[0]).sum() > 500 and (cur_mask == labels[0]).sum() == 0
+
+
 def test_mask_warp(ctx, oracle):
     fr, depth = _frame(9)
     cur = SF.make_frame(seed=10)

@@ -16,6 +16,7 @@
 #include "../../include/vdo_slam_hip.h"
 #include "ctx.hpp"
 #include "frame_images.hpp"
+#include "near_flags.hpp"
 
 namespace vdo {
 
@@ -96,28 +97,6 @@ __global__ void k_renew_pred(int n, const float* __restrict__ px, const float* _
     }
   }
   ok[i] = good; fx[i] = fxe; fy[i] = fye; dout[i] = d;
-}
-
-// used[i] = exists j: sqrt((rx[j]-qx[i])^2 + (ry[j]-qy[i])^2) < 1     (float arithmetic as in the reference)
-__global__ __launch_bounds__(256) void k_near_flags(int nq, const float* __restrict__ qx, const float* __restrict__ qy,
-                                                    int nr, const float* __restrict__ rx, const float* __restrict__ ry, int32_t* __restrict__ used) {
-  __shared__ float sx[256], sy[256];
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  const float x = i < nq ? qx[i] : 0.f, y = i < nq ? qy[i] : 0.f;
-  int u = 0;
-  for (int base = 0; base < nr; base += 256) {
-    const int j = base + threadIdx.x;
-    sx[threadIdx.x] = j < nr ? rx[j] : 1e30f;
-    sy[threadIdx.x] = j < nr ? ry[j] : 1e30f;
-    __syncthreads();
-    const int m = min(256, nr - base);
-    for (int k = 0; k < m; ++k) {
-      const float dx = sx[k] - x, dy = sy[k] - y;
-      if (sqrtf(dx * dx + dy * dy) < 1.0f) u = 1;
-    }
-    __syncthreads();
-  }
-  if (i < nq) used[i] = u;
 }
 
 // K15b: every pixel of the previous mask with label `lab` writes `lab` at its flowed position

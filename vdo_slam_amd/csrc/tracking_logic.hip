@@ -1,0 +1,401 @@
+// Tracking-side bookkeeping around the K11-K15 gathers (tracking.hip), as the C-ABI serves it:
+//   vdo_dyn_obj_tracking   Tracking::DynObjTracking            reference src/Tracking.cc:1366-1612
+//   vdo_renew_object       Tracking::RenewFrameInfo, objects    :2806-2995
+//   vdo_update_mask        Tracking::UpdateMask                 :2997-3068
+//   vdo_tracks_*           GetStaticTrack / GetDynamicTrackNew  :2201-2421 (incremental instead of from frame 0)
+// Split of work: everything that touches an image or is O(n*m) runs on the GPU (gathers at the
+// carried / flowed positions, the "is there a carried point within 1 px" test, the per-label vote
+// and the conditional mask warp — the latter two without any host round trip); the order-dependent
+// selections (first-come truncation, stride-15 interleave, id hand-out) stay on the host and consume
+// flags.  Grouping by label uses one pass over label-slot tables instead of the reference's nested
+// searches; float accumulations keep the reference's per-label index order.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/vdo_slam_hip.h"
+#include "ctx.hpp"
+#include "frame_images.hpp"
+#include "near_flags.hpp"
+
+namespace vdo {
+
+// object-carry predicate at INT-truncated coordinates (:2832-2856): ok, sem label, depth, flow
+__global__ void k_renew_obj_pred(int n, const float* __restrict__ px, const float* __restrict__ py, const int32_t* __restrict__ mask,
+                                 const float* __restrict__ depth, const float* __restrict__ flow, int w, int h,
+                                 int32_t* __restrict__ ok, int32_t* __restrict__ sem, float* __restrict__ dout, float* __restrict__ fx, float* __restrict__ fy) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int x = (int)px[i], y = (int)py[i];
+  int good = 0, sl = 0;
+  float d = 0, fxe = 0, fye = 0;
+  if (!(x >= w || y >= h || x <= 0 || y <= 0)) {
+    const size_t o = (size_t)y * w + x;
+    sl = mask[o]; d = depth[o];
+    if (sl != 0 && d < 25 && d > 0) {
+      fxe = flow[2 * o]; fye = flow[2 * o + 1];
+      if (x + fxe < w && y + fye < h && x + fxe > 0 && y + fye > 0) good = 1;
+    }
+  }
+  ok[i] = good; sem[i] = sl; dout[i] = d; fx[i] = fxe; fy[i] = fye;
+}
+
+constexpr int kVoteBins = 1024;    // instance labels of a mask are small non-negative integers
+
+// One workgroup per call: vote of the current mask at the flowed positions of one last-frame label.
+// flag[0] = 1 when >= 100 positions are inside the image and the most frequent label (smallest label on
+// ties) is the background 0; flag[1] = 1 if a label fell outside the histogram (host reports an error).
+__global__ __launch_bounds__(256) void k_label_vote(int n, const float* __restrict__ cx, const float* __restrict__ cy,
+                                                    const int32_t* __restrict__ mask, int w, int h, int32_t* __restrict__ flag) {
+  __shared__ int hist[kVoteBins];
+  __shared__ int s_valid, s_bad;
+  for (int i = threadIdx.x; i < kVoteBins; i += 256) hist[i] = 0;
+  if (threadIdx.x == 0) { s_valid = 0; s_bad = 0; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int u = (int)cx[i], v = (int)cy[i];
+    if (u < w && u > 0 && v < h && v > 0) {
+      const int l = mask[(size_t)v * w + u];
+      if (l < 0 || l >= kVoteBins) atomicOr(&s_bad, 1);
+      else { atomicAdd(&hist[l], 1); atomicAdd(&s_valid, 1); }
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int best = 0, cnt = -1;
+    for (int l = 0; l < kVoteBins; ++l) if (hist[l] > cnt) { cnt = hist[l]; best = l; }
+    flag[0] = (s_valid >= 100 && best == 0 && !s_bad) ? 1 : 0;
+    flag[1] = s_bad;
+  }
+}
+
+// mask warp of one label, executed only if the vote said so (flag on the device: no host round trip)
+__global__ void k_mask_warp_if(const int32_t* __restrict__ flag, const int32_t* __restrict__ mask_last, const float* __restrict__ flow_last,
+                               int w, int h, int32_t lab, int32_t* __restrict__ mask_cur) {
+  if (!flag[0]) return;
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (k >= w) return;
+  const size_t o = (size_t)j * w + k;
+  if (mask_last[o] != lab) return;
+  const int fx = (int)flow_last[2 * o], fy = (int)flow_last[2 * o + 1];
+  if (k + fx < w && k + fx > 0 && j + fy < h && j + fy > 0) mask_cur[(size_t)(j + fy) * w + (k + fx)] = lab;
+}
+
+struct DevScratch {
+  std::vector<void*> p;
+  hipStream_t s;
+  template <class T> T* up(const T* host, size_t n) {
+    T* d = nullptr;
+    if (hipMalloc((void**)&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
+    p.push_back(d);
+    if (host && n) hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, s);
+    return d;
+  }
+  template <class T> void down(T* host, const T* dev, size_t n) { if (host && n) hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, s); }
+  ~DevScratch() { for (void* q : p) hipFree(q); }
+};
+
+static int finish(hipStream_t s, const char* what) {
+  hipError_t e = hipStreamSynchronize(s);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
+  return VDO_OK;
+}
+
+// sorted distinct labels + slot of every element
+static void label_slots(int n, const int32_t* lab, std::vector<int32_t>& uni, std::vector<int32_t>& slot) {
+  uni.assign(lab, lab + n);
+  std::sort(uni.begin(), uni.end());
+  uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
+  slot.resize(n);
+  for (int i = 0; i < n; ++i) slot[i] = (int32_t)(std::lower_bound(uni.begin(), uni.end(), lab[i]) - uni.begin());
+}
+
+// most frequent value, smallest on ties (std::sort of <16 map entries is a stable insertion sort)
+static int majority(std::vector<int32_t>& v) {
+  std::sort(v.begin(), v.end());
+  int best = 0, cnt = -1;
+  for (size_t a = 0; a < v.size();) {
+    size_t b = a;
+    while (b < v.size() && v[b] == v[a]) ++b;
+    if ((int)(b - a) > cnt) { cnt = (int)(b - a); best = v[a]; }
+    a = b;
+  }
+  return best;
+}
+
+}  // namespace vdo
+
+using namespace vdo;
+
+extern "C" int vdo_dyn_obj_tracking(const vdo_dyn_obj_params* prm, int n, const int32_t* sem_label, int32_t* obj_label_inout,
+                                    const float* key_x, const float* key_y, const float* depth, const float* flow3d, const int32_t* last_sem_label,
+                                    int n_last_obj, const int32_t* last_sem_pos, const int32_t* last_mod_label, const uint8_t* last_obj_stat,
+                                    int32_t* max_id_inout, int32_t* obj_off, int32_t* obj_idx, int32_t* obj_sem, int32_t* obj_mod, int* n_obj_out) {
+  if (!prm || !n_obj_out || !max_id_inout || n < 0 || (n > 0 && (!sem_label || !obj_label_inout || !key_x || !key_y || !depth || !flow3d || !last_sem_label)))
+    return set_error(VDO_ERR_INVALID, "vdo_dyn_obj_tracking: bad argument");
+  std::vector<int32_t> uni, slot;
+  label_slots(n, sem_label, uni, slot);
+  const int L = (int)uni.size();
+  // one pass: members per label (index order), border votes
+  std::vector<int> cnt(L, 0);
+  std::vector<float> border(L, 0.f);
+  for (int i = 0; i < n; ++i) {
+    if (obj_label_inout[i] == -1) continue;
+    const int s = slot[i];
+    ++cnt[s];
+    const float u = key_x[i], v = key_y[i];
+    if (v < prm->shrink_row || v > (prm->img_h - prm->shrink_row) || u < prm->shrink_col || u > (prm->img_w - prm->shrink_col)) border[s] += 1.f;
+  }
+  // state per label: 0 candidate, 1 border-dropped
+  std::vector<int> state(L, 0);
+  for (int s = 0; s < L; ++s) if (border[s] / (float)cnt[s] > 0.5f) state[s] = 1;     // 0/0 -> NaN -> kept, as in the reference
+  // second pass: depth sum / slow-flow votes of the surviving labels (float, index order)
+  std::vector<float> dsum(L, 0.f), slow(L, 0.f);
+  for (int i = 0; i < n; ++i) {
+    if (obj_label_inout[i] == -1) continue;
+    const int s = slot[i];
+    if (state[s] == 1) { obj_label_inout[i] = -1; continue; }
+    dsum[s] = dsum[s] + depth[i];
+    const float fx = flow3d[3 * i], fz = flow3d[3 * i + 2];
+    if (std::sqrt(fx * fx + fz * fz) < prm->sf_mg_thres) slow[s] = slow[s] + 1.f;
+  }
+  for (int s = 0; s < L; ++s) {
+    if (state[s]) continue;
+    if (slow[s] / (float)cnt[s] > prm->sf_ds_thres) state[s] = 2;                                    // static object -> label 0
+    else if (dsum[s] / (float)cnt[s] > prm->th_depth_obj || cnt[s] < 150) state[s] = 3;              // too far / too small -> -1
+  }
+  // members of the accepted labels, CSR in label order
+  std::vector<int> acc_of(L, -1);
+  int n_acc = 0;
+  obj_off[0] = 0;
+  for (int s = 0; s < L; ++s) if (state[s] == 0) { acc_of[s] = n_acc; obj_off[n_acc + 1] = obj_off[n_acc] + cnt[s]; obj_sem[n_acc] = uni[s]; ++n_acc; }
+  std::vector<int> cur(n_acc + 1);
+  for (int a = 0; a <= n_acc; ++a) cur[a] = obj_off[a];
+  for (int i = 0; i < n; ++i) {
+    if (obj_label_inout[i] == -1) continue;       // includes the border-dropped ones set above
+    const int s = slot[i];
+    if (state[s] == 2) obj_label_inout[i] = 0;
+    else if (state[s] == 3) obj_label_inout[i] = -1;
+    else if (state[s] == 0) obj_idx[cur[acc_of[s]]++] = i;
+  }
+  // association with the last frame's objects
+  int max_id = *max_id_inout;
+  if (prm->f_id == 1) max_id = 1;
+  std::vector<int32_t> votes;
+  for (int a = 0; a < n_acc; ++a) {
+    votes.clear();
+    for (int q = obj_off[a]; q < obj_off[a + 1]; ++q) votes.push_back(last_sem_label[obj_idx[q]]);
+    const int new_lab = majority(votes);
+    int lab = -1;
+    if (max_id != 1)
+      for (int k = 0; k < n_last_obj; ++k)
+        if (last_sem_pos[k] == new_lab && last_obj_stat[k]) { lab = last_mod_label[k]; break; }
+    if (lab == -1) { lab = max_id; max_id = max_id + 1; }
+    // NB a found label can legitimately be any value the previous frame handed out (>= 1), never -1
+    for (int q = obj_off[a]; q < obj_off[a + 1]; ++q) obj_label_inout[obj_idx[q]] = lab;
+    obj_mod[a] = lab;
+  }
+  *max_id_inout = max_id;
+  *n_obj_out = n_acc;
+  return VDO_OK;
+}
+
+extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* inl_off, const int32_t* inl_idx, const uint8_t* obj_stat,
+                                const int32_t* sem_pos, const int32_t* mod_label,
+                                const float* cur_x, const float* cur_y, const int32_t* cur_obj_label,
+                                int n_tmp, const float* tmp_x, const float* tmp_y, const float* tmp_depth, const int32_t* tmp_label,
+                                const float* tmp_flow_x, const float* tmp_flow_y, const float* tmp_corr_x, const float* tmp_corr_y,
+                                int max_num_obj, int cap,
+                                float* key_x, float* key_y, float* depth_out, int32_t* sem_out, float* flow_x, float* flow_y,
+                                float* corr_x, float* corr_y, int32_t* dyn_inlier_id, int32_t* obj_label_out, int* n_out) {
+  if (!f || !n_out || n_obj < 0 || n_tmp < 0 || cap < 0) return set_error(VDO_ERR_INVALID, "vdo_renew_object: bad argument");
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  DevScratch S; S.s = f->ctx->stream;
+  // ---- carried candidates: inliers of the tracked objects, object-major (the reference's visiting order)
+  std::vector<float> cx, cy; std::vector<int32_t> cid, cobj;
+  for (int i = 0; i < n_obj; ++i) {
+    if (!obj_stat[i]) continue;
+    for (int q = inl_off[i]; q < inl_off[i + 1]; ++q) { const int id = inl_idx[q]; cx.push_back(cur_x[id]); cy.push_back(cur_y[id]); cid.push_back(id); cobj.push_back(i); }
+  }
+  const int nc = (int)cx.size();
+  std::vector<int32_t> ok(nc), sem(nc); std::vector<float> dd(nc), fx(nc), fy(nc);
+  if (nc) {
+    float *dx = S.up(cx.data(), nc), *dy = S.up(cy.data(), nc);
+    int32_t *dok = S.up<int32_t>(nullptr, nc), *dsem = S.up<int32_t>(nullptr, nc);
+    float *ddd = S.up<float>(nullptr, nc), *dfx = S.up<float>(nullptr, nc), *dfy = S.up<float>(nullptr, nc);
+    if (!dfy) return set_error(VDO_ERR_OOM, "hipMalloc failed");
+    hipLaunchKernelGGL(k_renew_obj_pred, dim3((nc + 255) / 256), dim3(256), 0, S.s, nc, (const float*)dx, (const float*)dy, (const int32_t*)f->d_mask,
+                       (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok, dsem, ddd, dfx, dfy);
+    S.down(ok.data(), dok, nc); S.down(sem.data(), dsem, nc); S.down(dd.data(), ddd, nc); S.down(fx.data(), dfx, nc); S.down(fy.data(), dfy, nc);
+    rc = finish(S.s, "vdo_renew_object (carry)");
+    if (rc != VDO_OK) return rc;
+  }
+  int m = 0;
+  auto push = [&](float x, float y, float d, int sl, float flx, float fly, float crx, float cry, int inl, int ol) -> bool {
+    if (m >= cap) return false;
+    key_x[m] = x; key_y[m] = y; depth_out[m] = d; sem_out[m] = sl; flow_x[m] = flx; flow_y[m] = fly; corr_x[m] = crx; corr_y[m] = cry;
+    dyn_inlier_id[m] = inl; obj_label_out[m] = ol; ++m;
+    return true;
+  };
+  std::vector<int> fea_count(n_obj, -1);
+  for (int i = 0; i < n_obj; ++i) if (obj_stat[i]) fea_count[i] = 0;
+  for (int k = 0; k < nc; ++k) {
+    if (!ok[k]) continue;
+    const int x = (int)cx[k], y = (int)cy[k];
+    if (!push((float)x, (float)y, dd[k], sem[k], fx[k], fy[k], x + fx[k], y + fy[k], cid[k], cur_obj_label[cid[k]])) return set_error(VDO_ERR_INVALID, "vdo_renew_object: output capacity %d too small", cap);
+    ++fea_count[cobj[k]];
+  }
+  const int n_check = m;
+  // ---- top-up from the semi-dense sampling of the new image: GPU answers "is a carried point within 1 px"
+  std::vector<int32_t> used(n_tmp, 0);
+  if (n_tmp && n_check) {
+    float *dqx = S.up(tmp_x, n_tmp), *dqy = S.up(tmp_y, n_tmp), *drx = S.up(key_x, n_check), *dry = S.up(key_y, n_check);
+    int32_t* dused = S.up<int32_t>(nullptr, n_tmp);
+    if (!dused) return set_error(VDO_ERR_OOM, "hipMalloc failed");
+    hipLaunchKernelGGL(k_near_flags, dim3((n_tmp + 255) / 256), dim3(256), 0, S.s, n_tmp, (const float*)dqx, (const float*)dqy, n_check, (const float*)drx, (const float*)dry, dused);
+    S.down(used.data(), dused, n_tmp);
+    rc = finish(S.s, "vdo_renew_object (top-up)");
+    if (rc != VDO_OK) return rc;
+  }
+  for (int i = 0; i < n_obj; ++i) {
+    if (!obj_stat[i]) continue;
+    int tot = fea_count[i];
+    for (int start = 0; start < 15 && tot < max_num_obj; ++start) {
+      for (int j = start; j < n_tmp; j += 15) {
+        if (tmp_label[j] != sem_pos[i] || used[j]) continue;
+        if (!push(tmp_x[j], tmp_y[j], tmp_depth[j], tmp_label[j], tmp_flow_x[j], tmp_flow_y[j], tmp_corr_x[j], tmp_corr_y[j], -1, mod_label[i]))
+          return set_error(VDO_ERR_INVALID, "vdo_renew_object: output capacity %d too small", cap);
+        if (++tot >= max_num_obj) break;
+      }
+    }
+  }
+  // ---- labels the tracker does not follow yet: all their sampled points, object label -2
+  std::vector<int32_t> uni, slot;
+  label_slots(n_tmp, tmp_label, uni, slot);
+  std::vector<char> known(uni.size(), 0);
+  for (int i = 0; i < n_obj; ++i) {
+    if (!obj_stat[i]) continue;
+    auto it = std::lower_bound(uni.begin(), uni.end(), sem_pos[i]);
+    if (it != uni.end() && *it == sem_pos[i]) known[it - uni.begin()] = 1;
+  }
+  for (size_t s = 0; s < uni.size(); ++s) {
+    if (known[s]) continue;
+    for (int j = 0; j < n_tmp; ++j)
+      if (slot[j] == (int)s && !push(tmp_x[j], tmp_y[j], tmp_depth[j], tmp_label[j], tmp_flow_x[j], tmp_flow_y[j], tmp_corr_x[j], tmp_corr_y[j], -1, -2))
+        return set_error(VDO_ERR_INVALID, "vdo_renew_object: output capacity %d too small", cap);
+  }
+  *n_out = m;
+  return VDO_OK;
+}
+
+extern "C" int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, int n, const int32_t* last_sem_label,
+                               const float* last_corr_x, const float* last_corr_y, int* n_recovered) {
+  if (!cur || !last || cur->w != last->w || cur->h != last->h || n < 0) return set_error(VDO_ERR_INVALID, "vdo_update_mask: bad argument");
+  if (n_recovered) *n_recovered = 0;
+  if (n == 0) return VDO_OK;
+  int rc = ctx_bind(cur->ctx);
+  if (rc != VDO_OK) return rc;
+  DevScratch S; S.s = cur->ctx->stream;
+  // group the flowed positions by last-frame label (ascending labels, index order inside a label)
+  std::vector<int32_t> uni, slot;
+  label_slots(n, last_sem_label, uni, slot);
+  const int L = (int)uni.size();
+  std::vector<int> off(L + 1, 0);
+  for (int i = 0; i < n; ++i) off[slot[i] + 1]++;
+  for (int s = 0; s < L; ++s) off[s + 1] += off[s];
+  std::vector<float> gx(n), gy(n);
+  {
+    std::vector<int> c(off.begin(), off.end() - 1);
+    for (int i = 0; i < n; ++i) { const int p = c[slot[i]]++; gx[p] = last_corr_x[i]; gy[p] = last_corr_y[i]; }
+  }
+  float *dx = S.up(gx.data(), n), *dy = S.up(gy.data(), n);
+  int32_t* dflag = S.up<int32_t>(nullptr, 2 * (size_t)L);
+  if (!dflag) return set_error(VDO_ERR_OOM, "hipMalloc failed");
+  // label after label, stream-ordered (a recovered mask is visible to the next label's vote, as in the reference); no host sync inside
+  for (int s = 0; s < L; ++s) {
+    const int ns = off[s + 1] - off[s];
+    hipLaunchKernelGGL(k_label_vote, dim3(1), dim3(256), 0, S.s, ns, (const float*)(dx + off[s]), (const float*)(dy + off[s]), (const int32_t*)cur->d_mask, cur->w, cur->h, dflag + 2 * s);
+    hipLaunchKernelGGL(k_mask_warp_if, dim3((cur->w + 255) / 256, cur->h), dim3(256), 0, S.s, (const int32_t*)(dflag + 2 * s), (const int32_t*)last->d_mask,
+                       (const float*)last->d_flow, cur->w, cur->h, uni[s], cur->d_mask);
+  }
+  std::vector<int32_t> flag(2 * (size_t)L);
+  S.down(flag.data(), dflag, flag.size());
+  rc = finish(S.s, "vdo_update_mask");
+  if (rc != VDO_OK) return rc;
+  int rec = 0;
+  for (int s = 0; s < L; ++s) {
+    if (flag[2 * s + 1]) return set_error(VDO_ERR_UNSUPPORTED, "vdo_update_mask: mask label outside [0,%d)", kVoteBins);
+    rec += flag[2 * s];
+  }
+  if (n_recovered) *n_recovered = rec;
+  return VDO_OK;
+}
+
+// ---- tracklets, incrementally: each frame only looks at its own association vector --------------------
+struct vdo_tracks {
+  bool with_label = false;
+  int n_frames = 0;
+  std::vector<int32_t> pre;                       // track id of every feature of the last added frame
+  std::vector<std::vector<int32_t>> frames, feats; // per track: (frame, feature) pairs
+  std::vector<int32_t> obj_id;
+  int64_t n_pairs = 0;
+};
+
+extern "C" int vdo_tracks_create(int with_object_label, vdo_tracks** out) {
+  if (!out) return set_error(VDO_ERR_INVALID, "null out");
+  vdo_tracks* t = new vdo_tracks();
+  t->with_label = with_object_label != 0;
+  *out = t;
+  return VDO_OK;
+}
+extern "C" int vdo_tracks_destroy(vdo_tracks* t) { delete t; return VDO_OK; }
+
+// asso[j] = index, in the previous frame's feature list, of the feature matched to feature j (-1: none).
+extern "C" int vdo_tracks_add_frame(vdo_tracks* t, int n, const int32_t* asso, const int32_t* feat_label) {
+  if (!t || n < 0 || (n > 0 && !asso) || (t->with_label && n > 0 && !feat_label)) return set_error(VDO_ERR_INVALID, "vdo_tracks_add_frame: bad argument");
+  const int i = t->n_frames;
+  std::vector<int32_t> cur(n, -1);
+  for (int j = 0; j < n; ++j) {
+    const int a = asso[j];
+    if (a == -1) continue;
+    if (i > 0 && (a < 0 || a >= (int)t->pre.size())) return set_error(VDO_ERR_INVALID, "frame %d feature %d: association %d out of range", i, j, a);
+    if (i > 0 && t->pre[a] != -1) {
+      const int id = t->pre[a];
+      t->frames[id].push_back(i + 1); t->feats[id].push_back(j);
+      cur[j] = id; t->n_pairs += 1;
+    } else {
+      const int id = (int)t->frames.size();
+      t->frames.push_back({i, i + 1}); t->feats.push_back({a, j});
+      if (t->with_label) t->obj_id.push_back(feat_label[j]);
+      cur[j] = id; t->n_pairs += 2;
+    }
+  }
+  t->pre.swap(cur);
+  t->n_frames = i + 1;
+  return VDO_OK;
+}
+
+extern "C" int vdo_tracks_size(vdo_tracks* t, int* n_tracks, int64_t* n_pairs) {
+  if (!t) return set_error(VDO_ERR_INVALID, "null handle");
+  if (n_tracks) *n_tracks = (int)t->frames.size();
+  if (n_pairs) *n_pairs = t->n_pairs;
+  return VDO_OK;
+}
+
+extern "C" int vdo_tracks_get(vdo_tracks* t, int32_t* track_off, int32_t* pair_frame, int32_t* pair_feat, int32_t* obj_id) {
+  if (!t || !track_off || !pair_frame || !pair_feat) return set_error(VDO_ERR_INVALID, "null argument");
+  int off = 0;
+  track_off[0] = 0;
+  for (size_t k = 0; k < t->frames.size(); ++k) {
+    const size_t len = t->frames[k].size();
+    std::memcpy(pair_frame + off, t->frames[k].data(), 4 * len);
+    std::memcpy(pair_feat + off, t->feats[k].data(), 4 * len);
+    off += (int)len;
+    track_off[k + 1] = off;
+    if (obj_id && t->with_label) obj_id[k] = t->obj_id[k];
+  }
+  return VDO_OK;
+}
