@@ -56,6 +56,10 @@ struct BADev {
   // pose -> slots CSR, pose -> pose-pose edges CSR
   int32_t *ps_off = nullptr, *ps_idx = nullptr;
   int32_t *pe_off = nullptr, *pe_idx = nullptr;   // entry = edge<<1 | side (0: pose is i, 1: pose is j)
+  // pose chains (paths of the EdgeSE3 graph) for the block-tridiagonal preconditioner, in path order
+  int n_pchains = 0;
+  int32_t *pc_off = nullptr, *pc_pose = nullptr;  // [n_pchains+1], [P]
+  int32_t* pc_edge = nullptr;                     // [P] edge<<1|side linking position k-1 -> k (side 0: previous pose is the edge's i), -1 at a chain head
   // linear system
   double *Hpp = nullptr, *bp = nullptr;              // [P][36], [P][6]
   double *Hll = nullptr, *bl = nullptr;              // [L][9],  [L][3]
@@ -69,7 +73,9 @@ struct BADev {
   double *Dinv = nullptr, *Gl = nullptr;             // [L][9]: forward pivots^-1, G_k = Delta_{k-1}^-1 O_{k-1}
   double *Gdiag = nullptr, *Goff = nullptr;          // [L][9]: [Hll^-1]_{kk}, [Hll^-1]_{k-1,k}
   double* xl = nullptr;                              // [L][3]
-  double* Minv = nullptr;                            // [P][36]
+  double* Minv = nullptr;                            // [P][36] chain position k: Delta_k^-1 of the block LDL^T (chains of length 1: plain block-Jacobi)
+  double* Adg = nullptr;                             // [P][36] S_pp + lambda I by pose id (input of the chain factorisation)
+  double* Lc = nullptr;                              // [P][36] chain position k: L_k = E_{k-1,k}^T Delta_{k-1}^-1
   double *xp = nullptr, *rp = nullptr, *zp = nullptr, *pp = nullptr, *qp = nullptr, *bs = nullptr, *qs = nullptr;  // [6P]
   double* part_q = nullptr;                          // [6][NPS]
   double* part_m = nullptr;                          // [21][NPS] preconditioner partials

@@ -269,14 +269,101 @@ __global__ __launch_bounds__(256) void k_precond_finalize(BADev d, double lambda
     for (int i = 0; i < 21; ++i) up[i] = d.msum[21 * (int64_t)p + i];
     if (p == 0 && d.msum[21 * (int64_t)d.P] > 0) atomicOr(d.flags, 1);
   }
-  double A[36], Ai[36];
+  double A[36];
   for (int i = 0; i < 36; ++i) A[i] = d.Hpp[36 * (int64_t)p + i];
   for (int i = 0; i < 6; ++i) A[7 * i] += lambda;
   int k = 0;
   for (int r = 0; r < 6; ++r)
     for (int c = r; c < 6; ++c) { A[6 * r + c] -= up[k]; if (c != r) A[6 * c + r] -= up[k]; ++k; }
-  if (!spd6_inv(A, Ai)) atomicOr(d.flags, 1);
-  for (int i = 0; i < 36; ++i) d.Minv[36 * (int64_t)p + i] = Ai[i];
+  for (int i = 0; i < 36; ++i) d.Adg[36 * (int64_t)p + i] = A[i];      // inverted / factored per pose chain by k_pchain_factor
+}
+
+// Block LDL^T of the block-tridiagonal preconditioner  M = blockdiag(S_pp) + (EdgeSE3 off-diagonal blocks)
+// along every pose chain:  Delta_0 = A_0,  L_k = E_{k-1,k}^T Delta_{k-1}^-1,  Delta_k = A_k - L_k E_{k-1,k}.
+// M is SPD: blockdiag(S) minus the EdgeSE3 diagonal terms is the (PSD) Schur complement of the landmark
+// system, the EdgeSE3 terms themselves are J^T W J.  One thread per chain (a handful of chains, once per
+// Levenberg trial); Minv / Lc are indexed by chain position.
+__global__ void k_pchain_factor(BADev d) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= d.n_pchains) return;
+  const int b = d.pc_off[c], e = d.pc_off[c + 1];
+  double Dp[36], A[36], E[36], Lk[36];
+  for (int k = b; k < e; ++k) {
+    const int64_t p = d.pc_pose[k];
+    for (int i = 0; i < 36; ++i) A[i] = d.Adg[36 * p + i];
+    if (k > b) {
+      const int ent = d.pc_edge[k];
+      const double* He = d.Hpp_ep + 36 * (int64_t)(ent >> 1);
+      if (ent & 1) { for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) E[r * 6 + q] = He[q * 6 + r]; }
+      else { for (int i = 0; i < 36; ++i) E[i] = He[i]; }
+      for (int r = 0; r < 6; ++r)
+        for (int q = 0; q < 6; ++q) {
+          double t = 0;
+          for (int m = 0; m < 6; ++m) t += E[m * 6 + r] * Dp[m * 6 + q];
+          Lk[r * 6 + q] = t;
+        }
+      for (int r = 0; r < 6; ++r)
+        for (int q = 0; q < 6; ++q) {
+          double t = 0;
+          for (int m = 0; m < 6; ++m) t += Lk[r * 6 + m] * E[m * 6 + q];
+          A[r * 6 + q] -= t;
+        }
+      for (int i = 0; i < 36; ++i) d.Lc[36 * (int64_t)k + i] = Lk[i];
+    }
+    if (!spd6_inv(A, Dp)) atomicOr(d.flags, 1);
+    for (int i = 0; i < 36; ++i) d.Minv[36 * (int64_t)k + i] = Dp[i];
+  }
+}
+
+// z = M^-1 r along the pose chains (forward / diagonal / backward block substitution).  Called by all
+// 1024 threads of the single PCG workgroup: one wave per chain (round-robin), lane (row, col) of a 6x6
+// block = (lane >> 3, lane & 7); each step is one block mat-vec: multiply, 3 xor-shuffles over the columns,
+// one broadcast of the new 6-vector.  The next step's block elements are fetched before the current
+// step's arithmetic (they depend only on k), so the dependent chain per step is ALU + shuffles.
+__device__ __forceinline__ double row_sum6(double t) {     // sum over the 8-lane group (columns 6,7 carry zeros)
+  t += __shfl_xor(t, 1, 64);
+  t += __shfl_xor(t, 2, 64);
+  t += __shfl_xor(t, 4, 64);
+  return t;
+}
+__device__ void pchain_apply(const BADev& d, const double* __restrict__ r, double* __restrict__ z) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int row = lane >> 3, col = lane & 7;
+  const bool act = row < 6 && col < 6;
+  const int el = act ? row * 6 + col : 0, elT = act ? col * 6 + row : 0;
+  for (int c = wave; c < d.n_pchains; c += nwave) {
+    const int b = d.pc_off[c], e = d.pc_off[c + 1];
+    // ---- forward: y_b = r_b ; y_k = r_k - L_k y_{k-1}      (y kept in z)
+    int64_t p = d.pc_pose[b];
+    double ycol = act ? r[6 * p + col] : 0.0;
+    if (act && col == 0) z[6 * p + row] = r[6 * p + row];
+    double lnext = (b + 1 < e && act) ? d.Lc[36 * (int64_t)(b + 1) + el] : 0.0;
+    for (int k = b + 1; k < e; ++k) {
+      const double lk = lnext;
+      if (k + 1 < e && act) lnext = d.Lc[36 * (int64_t)(k + 1) + el];
+      p = d.pc_pose[k];
+      const double rk = act ? r[6 * p + row] : 0.0;
+      const double ynew = rk - row_sum6(act ? lk * ycol : 0.0);
+      if (act && col == 0) z[6 * p + row] = ynew;
+      ycol = __shfl(ynew, (col < 6 ? col : 0) * 8, 64);
+    }
+    __threadfence_block();      // the y parked in z by other lanes of this wave must be visible to the loads below
+    // ---- backward: z_last = Dinv y ; z_k = Dinv_k y_k - L_{k+1}^T z_{k+1}
+    //      after the forward loop ycol holds y_{e-1}[col]
+    double zcol = 0.0;
+    double dnext = act ? d.Minv[36 * (int64_t)(e - 1) + el] : 0.0;
+    double ltnext = 0.0;
+    for (int k = e - 1; k >= b; --k) {
+      const double dk = dnext, ltk = ltnext;       // ltk = L_{k+1}^T element (0 at the chain end)
+      if (k - 1 >= b && act) { dnext = d.Minv[36 * (int64_t)(k - 1) + el]; ltnext = d.Lc[36 * (int64_t)k + elT]; }
+      p = d.pc_pose[k];
+      if (k < e - 1) ycol = act ? z[6 * p + col] : 0.0;       // y_k was parked in z by the forward pass
+      const double zk = row_sum6(act ? (dk * ycol - ltk * zcol) : 0.0);
+      __builtin_amdgcn_wave_barrier();
+      if (act && col == 0) z[6 * p + row] = zk;
+      zcol = __shfl(zk, (col < 6 ? col : 0) * 8, 64);
+    }
+  }
 }
 
 // Tile operator.  MODE 0: part_q = B Hll^-1 B^T v     (Schur mat-vec)
@@ -431,23 +518,16 @@ __device__ __forceinline__ void hpp_mv(const BADev& d, int p, const double* v, d
 // bs = bp - qs ; x = 0 ; r = bs ; z = Minv r ; p = z ; rz = rz0 = r.z       (single workgroup)
 __global__ __launch_bounds__(1024) void k_pcg_init(BADev d) {
   __shared__ double lds[17];
-  double acc = 0;
-  for (int p = threadIdx.x; p < d.P; p += blockDim.x) {
-    double r[6];
-    for (int i = 0; i < 6; ++i) {
-      const int64_t idx = 6 * (int64_t)p + i;
-      r[i] = d.bp[idx] - d.qs[idx];
-      d.bs[idx] = r[i]; d.rp[idx] = r[i]; d.xp[idx] = 0;
-    }
-    const double* Mi = d.Minv + 36 * (int64_t)p;
-    for (int i = 0; i < 6; ++i) {
-      double z = 0;
-      for (int j = 0; j < 6; ++j) z += Mi[i * 6 + j] * r[j];
-      d.zp[6 * (int64_t)p + i] = z;
-      d.pp[6 * (int64_t)p + i] = z;
-      acc += r[i] * z;
-    }
+  const int64_t n = 6 * (int64_t)d.P;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
+    const double r = d.bp[i] - d.qs[i];
+    d.bs[i] = r; d.rp[i] = r; d.xp[i] = 0;
   }
+  __syncthreads();
+  pchain_apply(d, d.rp, d.zp);
+  __syncthreads();
+  double acc = 0;
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const double z = d.zp[i]; d.pp[i] = z; acc += d.rp[i] * z; }
   acc = block_sum1(acc, lds);
   if (threadIdx.x == 0) { d.scal[S_RZ] = acc; d.scal[S_RZ0] = acc; d.scal[S_RZNEW] = acc; d.flags[1] = (acc > 0) ? 0 : 1; d.flags[2] = 0; }
 }
@@ -495,18 +575,10 @@ __global__ __launch_bounds__(1024) void k_pcg_vec(BADev d, double lambda, double
     d.rp[i] -= alpha * d.qp[i];
   }
   __syncthreads();
+  pchain_apply(d, d.rp, d.zp);                  // z = M^-1 r  (block-tridiagonal along the pose chains)
+  __syncthreads();
   acc = 0;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const int64_t p = i / 6;
-    const int row = (int)(i % 6);
-    const double* Mi = d.Minv + 36 * p + 6 * row;
-    const double* r = d.rp + 6 * p;
-    double z = 0;
-#pragma unroll
-    for (int j = 0; j < 6; ++j) z += Mi[j] * r[j];
-    d.zp[i] = z;
-    acc += r[row] * z;
-  }
+  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += d.rp[i] * d.zp[i];
   const double rznew = block_sum1(acc, lds);
   const double beta = rznew / rz;
   for (int64_t i = threadIdx.x; i < n; i += blockDim.x) d.pp[i] = d.zp[i] + beta * d.pp[i];
@@ -578,10 +650,13 @@ void launch_factor(const BADev& d, double lambda, hipStream_t s, const Reducer& 
   if (d.n_chains) hipLaunchKernelGGL(k_factor_chains, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, lambda);
   if (d.n_tiles) hipLaunchKernelGGL(k_precond_tile, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), 30 * (size_t)d.max_slots * sizeof(double), s, d);
   const dim3 g((d.P + 3) / 4), b(256);
-  if (!d.sharded) { hipLaunchKernelGGL(k_precond_finalize<0>, g, b, 0, s, d, lambda); return; }
-  hipLaunchKernelGGL(k_precond_finalize<1>, g, b, 0, s, d, lambda);
-  R(d.msum, 21 * (int64_t)d.P + 1);
-  hipLaunchKernelGGL(k_precond_finalize<2>, g, b, 0, s, d, lambda);
+  if (!d.sharded) hipLaunchKernelGGL(k_precond_finalize<0>, g, b, 0, s, d, lambda);
+  else {
+    hipLaunchKernelGGL(k_precond_finalize<1>, g, b, 0, s, d, lambda);
+    R(d.msum, 21 * (int64_t)d.P + 1);
+    hipLaunchKernelGGL(k_precond_finalize<2>, g, b, 0, s, d, lambda);
+  }
+  hipLaunchKernelGGL(k_pchain_factor, dim3((d.n_pchains + 63) / 64), dim3(64), 0, s, d);
 }
 
 void launch_reduced_rhs(const BADev& d, hipStream_t s, const Reducer& R) {

@@ -238,6 +238,57 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     std::vector<int32_t> fill(pe_off.begin(), pe_off.end() - 1);
     for (int e = 0; e < Ep; ++e) { pe_idx[fill[g->ep_i[e]]++] = (e << 1); pe_idx[fill[g->ep_j[e]]++] = (e << 1) | 1; }
   }
+  // ---- pose chains for the block-tridiagonal preconditioner: connected components of the pose-pose
+  // (EdgeSE3) graph that are simple paths - the odometry chain of the cameras, the smoothness chain of
+  // every object's motions (src/Optimizer.cc:1590-1612, 1743-1766) - in path order; every other pose
+  // (isolated, or part of a branching / cyclic component) is a chain of length 1 (plain block-Jacobi).
+  std::vector<int32_t> pc_off{0}, pc_pose, pc_edge;
+  {
+    std::vector<int> deg(P, 0);
+    for (int e = 0; e < Ep; ++e) { deg[g->ep_i[e]]++; deg[g->ep_j[e]]++; }
+    std::vector<int> comp(P, -1);
+    std::vector<char> comp_ok;
+    std::vector<int> stack;
+    int ncomp = 0;
+    for (int p0 = 0; p0 < P; ++p0) {
+      if (comp[p0] != -1) continue;
+      int nodes = 0, degsum = 0; bool ok = true;
+      stack.assign(1, p0); comp[p0] = ncomp;
+      while (!stack.empty()) {
+        const int p = stack.back(); stack.pop_back();
+        ++nodes; degsum += deg[p];
+        if (deg[p] > 2) ok = false;
+        for (int k = pe_off[p]; k < pe_off[p + 1]; ++k) {
+          const int e = pe_idx[k] >> 1;
+          const int q = (pe_idx[k] & 1) ? g->ep_i[e] : g->ep_j[e];
+          if (comp[q] == -1) { comp[q] = ncomp; stack.push_back(q); }
+        }
+      }
+      if (degsum / 2 != nodes - 1) ok = false;        // a tree with max degree 2 is a path; anything else has a cycle or a double edge
+      comp_ok.push_back(ok ? 1 : 0);
+      ++ncomp;
+    }
+    std::vector<char> done(P, 0);
+    for (int p0 = 0; p0 < P; ++p0) {
+      if (done[p0]) continue;
+      if (!comp_ok[comp[p0]] || deg[p0] == 0) { done[p0] = 1; pc_pose.push_back(p0); pc_edge.push_back(-1); pc_off.push_back((int32_t)pc_pose.size()); continue; }
+      if (deg[p0] != 1) continue;                       // start paths at their lower-numbered end point
+      int prev = -1, cur = p0, via = -1;
+      while (cur != -1) {
+        done[cur] = 1; pc_pose.push_back(cur); pc_edge.push_back(via);
+        int nxt = -1, nvia = -1;
+        for (int k = pe_off[cur]; k < pe_off[cur + 1]; ++k) {
+          const int e = pe_idx[k] >> 1, side = pe_idx[k] & 1;
+          const int q = side ? g->ep_i[e] : g->ep_j[e];
+          if (q != prev && !done[q]) { nxt = q; nvia = (e << 1) | side; }     // side 0: cur is i of the edge -> E(cur,next) = block(i,j); 1: transposed
+        }
+        prev = cur; cur = nxt; via = nvia;
+      }
+      pc_off.push_back((int32_t)pc_pose.size());
+    }
+    for (int p = 0; p < P; ++p) if (!done[p]) { pc_pose.push_back(p); pc_edge.push_back(-1); pc_off.push_back((int32_t)pc_pose.size()); }   // unreachable, defensive
+  }
+  const int n_pchains = (int)pc_off.size() - 1;
   // incidence index of every (new) edge, for the un-permuting download
   ba->inc_of_eb.resize(Eb); ba->inc1_of_et.resize(Et); ba->inc2_of_et.resize(Et);
   for (const Tile& T : tiles) {
@@ -267,6 +318,8 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(pr_pose, g->pr_pose, Npr); UP(pr_z, g->pr_z, 12 * (size_t)Npr); UP(pr_info, g->pr_info, 36 * (size_t)Npr);
   UP(ps_off, ps_off.data(), P + 1); UP(ps_idx, ps_idx.data(), NPS);
   UP(pe_off, pe_off.data(), P + 1); UP(pe_idx, pe_idx.data(), pe_idx.size());
+  d.n_pchains = n_pchains;
+  UP(pc_off, pc_off.data(), pc_off.size()); UP(pc_pose, pc_pose.data(), P); UP(pc_edge, pc_edge.data(), P);
   const double* Z = nullptr;
   UP(Hpp, Z, 42 * (size_t)P + 4);                      // Hpp | bp | red_chi contiguous: one all-reduce per linearisation when sharded
   ba->d.bp = ba->d.Hpp + 36 * (size_t)P; ba->d.red_chi = ba->d.bp + 6 * (size_t)P;
@@ -277,7 +330,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(part_chi, Z, 2 * (size_t)n_tiles + 2 * (size_t)(Ep + Npr) + 2);
   UP(Dinv, Z, 9 * (size_t)L); UP(Gl, Z, 9 * (size_t)L); UP(Gdiag, Z, 9 * (size_t)L); UP(Goff, Z, 9 * (size_t)L);
   UP(xl, Z, 3 * (size_t)L);
-  UP(Minv, Z, 36 * (size_t)P);
+  UP(Minv, Z, 36 * (size_t)P); UP(Lc, Z, 36 * (size_t)P); UP(Adg, Z, 36 * (size_t)P);
   UP(xp, Z, 6 * (size_t)P); UP(rp, Z, 6 * (size_t)P); UP(zp, Z, 6 * (size_t)P); UP(pp, Z, 6 * (size_t)P);
   UP(qp, Z, 6 * (size_t)P); UP(bs, Z, 6 * (size_t)P); UP(qs, Z, 6 * (size_t)P);
   UP(part_q, Z, 6 * (size_t)NPS); UP(part_m, Z, 21 * (size_t)NPS);
