@@ -68,6 +68,7 @@ struct BADev {
   double* Oll = nullptr;                             // [9][Et]  p1 x p2 blocks
   double* Hpp_ep = nullptr;                          // [Ep][36]
   double* part_sums = nullptr;                       // [32][NPS] sweep partials (16 binary + 16 ternary)
+  double* part_red = nullptr;                        // [256] per-block partials of k_update / k_max_diag
   double* part_chi = nullptr;                        // [2][n_tiles] + [2][Ep+Npr]
   // solver workspaces
   double *Dinv = nullptr, *Gl = nullptr;             // [L][9]: forward pivots^-1, G_k = Delta_{k-1}^-1 O_{k-1}

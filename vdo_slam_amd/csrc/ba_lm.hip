@@ -55,7 +55,7 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
   int it = 0;
   *ok = true;
   while (it < maxit) {
-    const int batch = std::min(16, maxit - it);
+    const int batch = std::min(it == 0 ? 6 : 12, maxit - it);      // the chain preconditioner converges in a handful of iterations: first look after 6
     for (int k = 0; k < batch; ++k) launch_pcg_iter(d, lambda, tol2, s, ba->red);
     it += batch;
     int rc = fetch(ba);

@@ -21,10 +21,11 @@ namespace vdo {
 __global__ __launch_bounds__(1024) void k_max_diag(BADev d) {
   __shared__ double lds[17];
   double m = 0;
-  for (int64_t i = threadIdx.x; i < 6 * (int64_t)d.P; i += blockDim.x) m = fmax(m, fabs(d.Hpp[36 * (i / 6) + 7 * (i % 6)]));
-  for (int64_t i = threadIdx.x; i < 3 * (int64_t)d.L; i += blockDim.x) m = fmax(m, fabs(d.Hll[9 * (i / 3) + 4 * (i % 3)]));
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = gtid; i < 6 * (int64_t)d.P; i += gsz) m = fmax(m, fabs(d.Hpp[36 * (i / 6) + 7 * (i % 6)]));
+  for (int64_t i = gtid; i < 3 * (int64_t)d.L; i += gsz) m = fmax(m, fabs(d.Hll[9 * (i / 3) + 4 * (i % 3)]));
   m = block_max1(m, lds);
-  if (threadIdx.x == 0) d.scal[S_MAXDIAG] = m;
+  if (threadIdx.x == 0) d.part_red[blockIdx.x] = m;
 }
 
 __device__ __forceinline__ bool spd3_inv(const double* a, double* o) {
@@ -283,36 +284,52 @@ __global__ __launch_bounds__(256) void k_precond_finalize(BADev d, double lambda
 // M is SPD: blockdiag(S) minus the EdgeSE3 diagonal terms is the (PSD) Schur complement of the landmark
 // system, the EdgeSE3 terms themselves are J^T W J.  One thread per chain (a handful of chains, once per
 // Levenberg trial); Minv / Lc are indexed by chain position.
-__global__ void k_pchain_factor(BADev d) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d.n_pchains) return;
+__global__ __launch_bounds__(64) void k_pchain_factor(BADev d) {
+  // one wave per chain; lane = 6*row + col of a 6x6 block (36 active lanes), blocks exchanged through LDS
+  __shared__ double sE[36], sD[36], sL[36], sA[36];
+  const int c = blockIdx.x, lane = threadIdx.x;
+  const bool act = lane < 36;
+  const int r = act ? lane / 6 : 0, q = act ? lane % 6 : 0;
   const int b = d.pc_off[c], e = d.pc_off[c + 1];
-  double Dp[36], A[36], E[36], Lk[36];
+  bool bad = false;
   for (int k = b; k < e; ++k) {
     const int64_t p = d.pc_pose[k];
-    for (int i = 0; i < 36; ++i) A[i] = d.Adg[36 * p + i];
+    double a = act ? d.Adg[36 * p + lane] : 0.0;
     if (k > b) {
       const int ent = d.pc_edge[k];
       const double* He = d.Hpp_ep + 36 * (int64_t)(ent >> 1);
-      if (ent & 1) { for (int r = 0; r < 6; ++r) for (int q = 0; q < 6; ++q) E[r * 6 + q] = He[q * 6 + r]; }
-      else { for (int i = 0; i < 36; ++i) E[i] = He[i]; }
-      for (int r = 0; r < 6; ++r)
-        for (int q = 0; q < 6; ++q) {
-          double t = 0;
-          for (int m = 0; m < 6; ++m) t += E[m * 6 + r] * Dp[m * 6 + q];
-          Lk[r * 6 + q] = t;
-        }
-      for (int r = 0; r < 6; ++r)
-        for (int q = 0; q < 6; ++q) {
-          double t = 0;
-          for (int m = 0; m < 6; ++m) t += Lk[r * 6 + m] * E[m * 6 + q];
-          A[r * 6 + q] -= t;
-        }
-      for (int i = 0; i < 36; ++i) d.Lc[36 * (int64_t)k + i] = Lk[i];
+      if (act) sE[lane] = (ent & 1) ? He[q * 6 + r] : He[lane];        // E = block (previous pose, this pose)
+      __syncthreads();
+      double t = 0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) t += sE[m * 6 + r] * sD[m * 6 + q];   // L = E^T Delta_prev^-1
+      if (act) { sL[lane] = t; d.Lc[36 * (int64_t)k + lane] = t; }
+      __syncthreads();
+      t = 0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) t += sL[r * 6 + m] * sE[m * 6 + q];   // Delta = A - L E
+      a -= t;
     }
-    if (!spd6_inv(A, Dp)) atomicOr(d.flags, 1);
-    for (int i = 0; i < 36; ++i) d.Minv[36 * (int64_t)k + i] = Dp[i];
+    if (act) sA[lane] = a;
+    __syncthreads();
+    // in-place Gauss-Jordan inverse (SPD: no pivoting); a non-positive pivot flags the factorisation as failed
+#pragma unroll 1
+    for (int kk = 0; kk < 6; ++kk) {
+      const double pv = sA[kk * 7], aik = sA[r * 6 + kk], akj = sA[kk * 6 + q], own = sA[act ? lane : 0];
+      if (!(pv > 0)) bad = true;
+      __syncthreads();
+      double nv;
+      if (r == kk && q == kk) nv = 1.0 / pv;
+      else if (r == kk) nv = akj / pv;
+      else if (q == kk) nv = -aik / pv;
+      else nv = own - aik * akj / pv;
+      if (act) sA[lane] = nv;
+      __syncthreads();
+    }
+    if (act) { const double v = sA[lane]; sD[lane] = v; d.Minv[36 * (int64_t)k + lane] = v; }
+    __syncthreads();
   }
+  if (bad && lane == 0) atomicOr(d.flags, 1);
 }
 
 // z = M^-1 r along the pose chains (forward / diagonal / backward block substitution).  Called by all
@@ -372,6 +389,7 @@ __device__ void pchain_apply(const BADev& d, const double* __restrict__ r, doubl
 template <int MODE>
 __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const double* __restrict__ v) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  if (MODE == 0 && d.flags[1]) return;     // PCG already converged: the launches queued behind it are no-ops
   const Tile T = d.tiles[blockIdx.x];
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, ninc = nb + 2 * nt;
@@ -483,9 +501,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
 }
 
 // qs[pose] = sum over the pose's (tile,slot) partials, fixed order
-__global__ __launch_bounds__(256) void k_gather_q(BADev d, double* out) {
+__global__ __launch_bounds__(256) void k_gather_q(BADev d, double* out, int pcg) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per pose
-  if (p >= d.P) return;
+  if (p >= d.P || (pcg && d.flags[1])) return;
   double s[6];
   wave_gather<6>(d.part_q, d.NPS, d.ps_off, d.ps_idx, p, s);
   const int lane = threadIdx.x & 63;
@@ -593,24 +611,39 @@ __global__ __launch_bounds__(1024) void k_pcg_vec(BADev d, double lambda, double
 }
 
 // trial estimate = current (+) x ; scale = sum x (lambda x + b)   (computeScale, levenberg.cpp:182-189)
+// Grid-wide (the points are the bulk): every block leaves one partial, k_reduce_part sums them in block order.
 __global__ __launch_bounds__(1024) void k_update(BADev d, double lambda, int ortho) {
   __shared__ double lds[17];
   double acc = 0;
   const bool own_poses = !d.sharded || d.shard_rank == 0;     // replicated vertices count once in computeScale
-  for (int p = threadIdx.x; p < d.P; p += blockDim.x) {
-    const double* x = d.xp + 6 * (int64_t)p;
+  const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t p = gtid; p < d.P; p += gsz) {
+    const double* x = d.xp + 6 * p;
     if (own_poses)
-      for (int i = 0; i < 6; ++i) acc += x[i] * (lambda * x[i] + d.bp[6 * (int64_t)p + i]);
-    const IsoD X = iso_load(d.pose[0] + 12 * (int64_t)p);
-    iso_store(d.pose[1] + 12 * (int64_t)p, iso_oplus(X, x, ortho != 0));
+      for (int i = 0; i < 6; ++i) acc += x[i] * (lambda * x[i] + d.bp[6 * p + i]);
+    const IsoD X = iso_load(d.pose[0] + 12 * p);
+    iso_store(d.pose[1] + 12 * p, iso_oplus(X, x, ortho != 0));
   }
-  for (int64_t i = threadIdx.x; i < 3 * (int64_t)d.L; i += blockDim.x) {
+  for (int64_t i = gtid; i < 3 * (int64_t)d.L; i += gsz) {
     const double x = d.xl[i];
     acc += x * (lambda * x + d.bl[i]);
     d.point[1][i] = d.point[0][i] + x;
   }
   acc = block_sum1(acc, lds);
-  if (threadIdx.x == 0) { if (d.sharded) d.red_chi[2] = acc; else d.scal[S_SCALE] = acc; }
+  if (threadIdx.x == 0) d.part_red[blockIdx.x] = acc;
+}
+
+// fixed-order sum (op 0) / max (op 1) of the per-block partials of k_update / k_max_diag
+__global__ __launch_bounds__(256) void k_reduce_part(BADev d, int n, int op) {
+  __shared__ double lds[24];
+  double a = 0;
+  for (int i = threadIdx.x; i < n; i += blockDim.x) a = op ? fmax(a, d.part_red[i]) : a + d.part_red[i];
+  a = op ? block_max1(a, lds) : block_sum1(a, lds);
+  if (threadIdx.x == 0) {
+    if (op) d.scal[S_MAXDIAG] = a;
+    else if (d.sharded) d.red_chi[2] = a;
+    else d.scal[S_SCALE] = a;
+  }
 }
 
 // Finc -> explicit 6x3 blocks Binc[18][Ninc] (download / debugging only; never on the solve path)
@@ -640,8 +673,12 @@ void launch_expand_binc(const BADev& d, hipStream_t s) {
   if (d.n_tiles) hipLaunchKernelGGL(k_expand_binc, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), 9 * (size_t)d.max_slots * sizeof(double), s, d);
 }
 
+static int red_blocks(const BADev& d) { return (int)std::min<int64_t>(256, std::max<int64_t>(1, (3 * (int64_t)d.L + 6 * (int64_t)d.P + 4095) / 4096)); }
+
 void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R) {
-  hipLaunchKernelGGL(k_max_diag, dim3(1), dim3(1024), 0, s, d);
+  const int nb = red_blocks(d);
+  hipLaunchKernelGGL(k_max_diag, dim3(nb), dim3(1024), 0, s, d);
+  hipLaunchKernelGGL(k_reduce_part, dim3(1), dim3(256), 0, s, d, nb, 1);
   if (d.sharded) R(d.scal + S_MAXDIAG, 1, 1);
 }
 
@@ -656,12 +693,12 @@ void launch_factor(const BADev& d, double lambda, hipStream_t s, const Reducer& 
     R(d.msum, 21 * (int64_t)d.P + 1);
     hipLaunchKernelGGL(k_precond_finalize<2>, g, b, 0, s, d, lambda);
   }
-  hipLaunchKernelGGL(k_pchain_factor, dim3((d.n_pchains + 63) / 64), dim3(64), 0, s, d);
+  hipLaunchKernelGGL(k_pchain_factor, dim3(d.n_pchains), dim3(64), 0, s, d);
 }
 
 void launch_reduced_rhs(const BADev& d, hipStream_t s, const Reducer& R) {
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)nullptr);
-  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs);
+  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs, 0);
   if (d.sharded) R(d.qs, 6 * (int64_t)d.P);
 }
 
@@ -669,14 +706,16 @@ void launch_pcg_init(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_pcg_i
 
 void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s, const Reducer& R) {
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<0>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.pp);
-  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs);
+  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs, 1);
   if (d.sharded) R(d.qs, 6 * (int64_t)d.P);      // the one exchange per CG iteration: 6P doubles
   hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(1024), 0, s, d, lambda, tol2);
 }
 
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s) {
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<2>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.xp);
-  hipLaunchKernelGGL(k_update, dim3(1), dim3(1024), 0, s, d, lambda, ortho ? 1 : 0);
+  const int nb = red_blocks(d);
+  hipLaunchKernelGGL(k_update, dim3(nb), dim3(1024), 0, s, d, lambda, ortho ? 1 : 0);
+  hipLaunchKernelGGL(k_reduce_part, dim3(1), dim3(256), 0, s, d, nb, 0);
 }
 
 }  // namespace vdo

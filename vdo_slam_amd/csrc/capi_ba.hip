@@ -328,6 +328,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(Finc, Z, 4 * ((size_t)Eb + (size_t)Et)); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep);
   UP(part_sums, Z, 32 * (size_t)NPS);
   UP(part_chi, Z, 2 * (size_t)n_tiles + 2 * (size_t)(Ep + Npr) + 2);
+  UP(part_red, Z, 256);
   UP(Dinv, Z, 9 * (size_t)L); UP(Gl, Z, 9 * (size_t)L); UP(Gdiag, Z, 9 * (size_t)L); UP(Goff, Z, 9 * (size_t)L);
   UP(xl, Z, 3 * (size_t)L);
   UP(Minv, Z, 36 * (size_t)P); UP(Lc, Z, 36 * (size_t)P); UP(Adg, Z, 36 * (size_t)P);
