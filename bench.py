@@ -36,6 +36,21 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~
 N_DISTINCT_FRAMES = 4   # synthetic frames cycled through the timed loop
 
 
+def _pmc_traffic_bytes(graph):
+    """HBM bytes per k_sweep_tile launch from the committed PMC summary, if it was taken on this very graph (else None)."""
+    import re
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_sweep_pmc_hbm_traffic.txt")
+    try:
+        txt = open(path).read()
+        m = re.search(r"n_eb (\d+) n_et (\d+) n_point (\d+)", txt)
+        t = re.search(r"= ([0-9.]+) MB\s*$", txt, re.M)
+        if m and t and (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (graph.n_eb, graph.n_et, graph.n_point):
+            return float(t.group(1)) * 1e6
+    except OSError:
+        pass
+    return None
+
+
 def _dist_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -229,10 +244,10 @@ def main():
         bytes_launch = 208 * gr.n_eb + 452 * gr.n_et + 96 * gr.n_point     # SURVEY.md §8d B_sweep terms of this kernel
         achieved = bytes_launch / (sweep_ms * 1e-3) / 1e9
         out["roofline"] = {"bound": "hbm", "kernel": "k_sweep_tile<true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                           "traffic_note": "PMC passes cannot run inside bench.py; measured 2*FETCH_SIZE+WRITE_SIZE = 391 MB/launch for this "
-                                           "graph (profiles/r01_sweep_pmc_hbm_traffic.txt): below the algorithmic bytes because the 6x3 blocks "
-                                           "are stored factored (32 B instead of 144 B)",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": _pmc_traffic_bytes(gr),
+                           "traffic_note": "HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes over this same "
+                                           "kernel and graph (profiles/r01_sweep_pmc_hbm_traffic.txt; not re-collected inside bench.py): below the "
+                                           "algorithmic bytes because the 6x3 blocks are stored factored (32 B instead of 144 B)",
                            "bytes_per_launch": int(bytes_launch), "avg_launch_ms": sweep_ms,
                            "units_per_launch": {"EdgeSE3PointXYZ": int(gr.n_eb), "LandmarkMotionTernaryEdge": int(gr.n_et), "points": int(gr.n_point)}}
         bar.close()
