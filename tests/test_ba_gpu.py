@@ -97,3 +97,81 @@ def test_invalid_graph_is_rejected(ctx):
     g.eb_point[0] = g.n_point + 5
     with pytest.raises(K.VdoError):
         BatchBA(ctx, g)
+
+
+def _with_extra_pose_edges(g, pairs):
+    """Copy of ``g`` with additional EdgeSE3 edges (i, j): measurement = relative pose of the initial
+    estimates (Z = Xi^-1 Xj, so the edge is consistent), information of the first existing edge."""
+    import dataclasses
+    def T(p):
+        M = np.eye(4); M[:3, :3] = p[:9].reshape(3, 3); M[:3, 3] = p[9:]; return M
+    zs, infos = [], []
+    for i, j in pairs:
+        Z = np.linalg.inv(T(g.pose[i])) @ T(g.pose[j])
+        zs.append(np.concatenate([Z[:3, :3].ravel(), Z[:3, 3]]))
+        infos.append(g.ep_info[0])
+    return dataclasses.replace(
+        g, ep_i=np.concatenate([g.ep_i, np.array([p[0] for p in pairs], np.int32)]),
+        ep_j=np.concatenate([g.ep_j, np.array([p[1] for p in pairs], np.int32)]),
+        ep_z=np.concatenate([g.ep_z, np.array(zs)]), ep_info=np.concatenate([g.ep_info, np.array(infos)]))
+
+
+@pytest.mark.parametrize("variant", ["loop_closure", "branch", "double_edge", "reversed_edges"])
+def test_lm_with_non_path_pose_graphs(ctx, oracle, variant):
+    """The block-tridiagonal preconditioner follows the simple paths of the EdgeSE3 graph; components with a
+    cycle, a branch or a doubled edge fall back to block-Jacobi, edges stored (j,i) are followed transposed.
+    The LM trajectory must not notice (it only changes how fast PCG converges)."""
+    import dataclasses
+    from vdo_slam_amd.ba import BatchBA
+    g = synth.make_ba_graph(14, 400, 2, 40, seed=9)
+    F = g.n_cam
+    if variant == "loop_closure":
+        g = _with_extra_pose_edges(g, [(0, F - 1)])
+    elif variant == "branch":
+        g = _with_extra_pose_edges(g, [(3, 7)])
+    elif variant == "double_edge":
+        g = _with_extra_pose_edges(g, [(4, 5)])
+    else:   # same graph, every second odometry edge stored as (j, i) with the inverse measurement
+        def inv12(z):
+            R = z[:9].reshape(3, 3); t = z[9:]
+            return np.concatenate([R.T.ravel(), -R.T @ t])
+        ei, ej, ez = g.ep_i.copy(), g.ep_j.copy(), g.ep_z.copy()
+        for e in range(0, g.n_ep, 2):
+            ei[e], ej[e] = g.ep_j[e], g.ep_i[e]
+            ez[e] = inv12(g.ep_z[e])
+        g = dataclasses.replace(g, ep_i=ei, ep_j=ej, ep_z=ez)
+    gc, keep = K.graph_to_c(g)
+    opt = K.LMOptionsC(40, 1e-4, 0, 0, 0.0, 0)
+    st_o = K.LMStatsC()
+    pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(pose_o), K._dp(point_o), C.byref(st_o)) == 0
+    ba = BatchBA(ctx, g)
+    st = ba.optimize(max_iterations=40, gain_threshold=1e-4)
+    pose, point = ba.estimates()
+    assert st.iterations == st_o.iterations and st.total_trials == st_o.total_trials
+    assert abs(st.final_chi2 - st_o.final_chi2) <= 1e-6 * st_o.final_chi2
+    assert np.abs(pose[:, :9] - pose_o[:, :9]).max() <= 1e-4
+    assert np.abs(pose[:, 9:] - pose_o[:, 9:]).max() <= 1e-4 * np.abs(pose_o[:, 9:]).max()
+    ba.close()
+
+
+def test_static_only_graph_without_pose_pose_edges(ctx, oracle):
+    """PartialBatchOptimization-shaped corner: static points only, no EdgeSE3 at all (every pose is a chain of
+    length 1), gauge held by the prior."""
+    import dataclasses
+    from vdo_slam_amd.ba import BatchBA
+    g = synth.make_ba_graph(8, 300, 0, 0, seed=2)
+    z = np.zeros(0, np.int32)
+    g = dataclasses.replace(g, ep_i=z, ep_j=z, ep_z=np.zeros((0, 12)), ep_info=np.zeros((0, 36)))
+    gc, keep = K.graph_to_c(g)
+    opt = K.LMOptionsC(15, -1.0, 0, 0, 0.0, 0)
+    st_o = K.LMStatsC()
+    pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(pose_o), K._dp(point_o), C.byref(st_o)) == 0
+    ba = BatchBA(ctx, g)
+    st = ba.optimize(max_iterations=15, gain_threshold=-1.0)
+    pose, point = ba.estimates()
+    assert st.iterations == st_o.iterations and st.total_trials == st_o.total_trials
+    assert abs(st.final_chi2 - st_o.final_chi2) <= 1e-6 * st_o.final_chi2
+    assert np.abs(pose - pose_o).max() <= 1e-4 * max(1.0, np.abs(pose_o).max())
+    ba.close()
