@@ -145,6 +145,7 @@ def main():
     from vdo_slam_amd.frontend import FrameImages, ORBextractor
 
     ctx = Context(local, stream.cuda_stream)
+    ctx_lm = Context(local)               # second HIP stream: the per-frame LM kernels overlap the ORB front-end of the same frame
     frames, cam, obj = make_frame_inputs(seed0=1000 * (rank + 1))
     W, H = synth.KITTI_W, synth.KITTI_H
     # ---- inputs resident in HBM
@@ -152,23 +153,29 @@ def main():
                 flow=torch.from_numpy(f["flow"]).cuda(), mask=torch.from_numpy(f["mask"]).cuda()) for f in frames]
     orb = ORBextractor(ctx, W, H)
     fimg = FrameImages(ctx, W, H)
-    cam_b = [Flow2Batch(ctx, [p]) for p in cam]
-    obj_b = [Flow2Batch(ctx, ps) for ps in obj]
+    cam_b = [Flow2Batch(ctx_lm, [p]) for p in cam]
+    obj_b = [Flow2Batch(ctx_lm, ps) for ps in obj]
     torch.cuda.synchronize()
 
     n_kp = n_stat = n_obj = 0
 
     def step(i):
+        # Within a frame the LM chain (camera, then objects: they consume last frame's correspondences + this frame's
+        # flow) and the ORB front-end (whose keypoints are only needed by RenewFrameInfo at the END of the frame,
+        # src/Tracking.cc:1168) are independent: the LM kernels go to their own stream first, the front-end (device
+        # stages + host quadtree) runs meanwhile, and the frame joins both before the next one starts.
         nonlocal n_kp, n_stat, n_obj
         k = i % N_DISTINCT_FRAMES
         d = dev[k]
         fimg.upload_device(d["depth"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())   # raw inputs -> working images (D2D)
         fimg.depth_preprocess(SF.BF, SF.DEPTH_MAP_FACTOR)                                       # K1
+        ctx.synchronize()                                                                        # the LM's inputs (K11 gathers) need the metric depth
+        cam_b[k].run()                                                                           # K16 (stream 2)
+        obj_b[k].run()                                                                           # K17 (5 objects, one launch, stream 2)
         kp = orb.extract_device(d["gray"].data_ptr(), W)                                         # K3-K7 (+ host quadtree)
         st = fimg.static_filter(kp["x"], kp["y"], SF.TH_DEPTH_BG)                                # K9
         ob = fimg.object_sample(SF.TH_DEPTH_OBJ)                                                 # K10
-        cam_b[k].run()                                                                           # K16
-        obj_b[k].run()                                                                           # K17 (5 objects, one launch)
+        ctx_lm.synchronize()                                                                     # join: RenewFrameInfo needs both
         n_kp, n_stat, n_obj = kp["x"].size, st["keep_idx"].size, ob["label"].size
 
     def barrier():
@@ -199,7 +206,7 @@ def main():
         "dtype": "f64 (LM) / u8,i32,f32 (front-end)", "data": "synthetic",
         "config": {"workload": "KITTI-0000-shaped per-frame hot path: K1 depth, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), "
                                "K9 static filter, K10 object sampling, joint pose+flow LM camera (1200) + 5 objects (800..200), ref_quirks=1",
-                   "parallelism": f"replicas x{world}", "orb_keypoints": int(n_kp), "static_matches": int(n_stat), "object_points": int(n_obj),
+                   "parallelism": f"replicas x{world}; inside a frame the LM chain (stream 2) overlaps the ORB front-end (stream 1)", "orb_keypoints": int(n_kp), "static_matches": int(n_stat), "object_points": int(n_obj),
                    "camera_lm_iterations": int(lm["iterations"])},
     }
 

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_pose_lm(const PoseDev* __restric
   vdo_flow2_result* res = A.results + blockIdx.x;
 
   __shared__ double s_scr[F2_WAVES * 27], s_red[27];
+  __shared__ double s_wide[27 * (F2_THREADS + 1)];
   __shared__ SE3d s_T, s_Ttry;
   __shared__ double s_Hpp[36], s_bp[6], s_xp[6];
   __shared__ double s_lambda, s_scale;
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_pose_lm(const PoseDev* __restric
           for (int c2 = 0; c2 <= a; ++c2) acc[k++] += (J[a] * r1) * J[c2] + (J[6 + a] * r1) * J[6 + c2];
         }
       }
-      block_reduce<27>(acc, s_scr, s_red);
+      block_reduce_wide<27>(acc, s_wide, s_red);
       if (tid == 0) {
         int k = 0;
         double mm = 0;
