@@ -64,15 +64,20 @@ def make_frame_inputs(seed0):
     return frames, cam, obj
 
 
-def cpu_baseline_frames(frames, cam, obj, budget_s=12.0):
-    """Oracle (1 thread) on the same frames: same stages as the GPU step."""
-    from tests import oracle_lib, frontend_ref as R
+def cpu_baseline_frames(frames, cam, obj, budget_s=14.0):
+    """Oracle (1 thread) on the same frames: the same stages, chained frame to frame like FramePipeline does."""
+    from tests import oracle_lib, frontend_ref as R, tracking_ref as T
     from tests.test_oracle_flow2 import run_oracle
-    from vdo_slam_amd import synth_frames as SF
+    from vdo_slam_amd import synth, synth_frames as SF
+    from vdo_slam_amd.tracking import DynObjParamsC
     o = oracle_lib.load()
     n = 0
     t0 = time.perf_counter()
-    stage = {"depth": 0.0, "orb": 0.0, "frame": 0.0, "lm_cam": 0.0, "lm_obj": 0.0}
+    stage = {"depth": 0.0, "orb": 0.0, "frame": 0.0, "lm_cam": 0.0, "lm_obj": 0.0, "tracking_k11_k15": 0.0}
+    K4 = np.array(synth.KITTI_K, np.float32)
+    last = None
+    Tl = np.eye(4, dtype=np.float32)
+    max_id = 1
     while True:
         k = n % len(frames)
         fr = frames[k]
@@ -80,16 +85,51 @@ def cpu_baseline_frames(frames, cam, obj, budget_s=12.0):
         d = fr["depth_raw"].copy()
         o.vdo_oracle_depth_preprocess(R._fp(d), d.size, SF.BF, SF.DEPTH_MAP_FACTOR)
         stage["depth"] += time.perf_counter() - t; t = time.perf_counter()
+        mask = fr["mask"]
+        if last is not None:                                                            # K15, K11
+            mask, _ = T.update_mask(o, last["ob"]["label"], last["ob"]["corr_x"], last["ob"]["corr_y"], last["mask"], last["flow"], mask)
+            sd = T.propagate_static(o, last["st"]["corr_x"], last["st"]["corr_y"], d)
+            od, osem = T.propagate_object(o, last["ob"]["corr_x"], last["ob"]["corr_y"], d, mask, SF.TH_DEPTH_OBJ)
+        stage["tracking_k11_k15"] += time.perf_counter() - t; t = time.perf_counter()
         kp = R.extract(o, fr["gray"])
         stage["orb"] += time.perf_counter() - t; t = time.perf_counter()
-        R.static_filter(o, kp["x"], kp["y"], kp["octave"], fr["mask"], d, fr["flow"], SF.TH_DEPTH_BG)
-        R.object_sample(o, fr["mask"], d, fr["flow"], SF.TH_DEPTH_OBJ)
+        st = R.static_filter(o, kp["x"], kp["y"], kp["octave"], mask, d, fr["flow"], SF.TH_DEPTH_BG)
+        ob = R.object_sample(o, mask, d, fr["flow"], SF.TH_DEPTH_OBJ)
         stage["frame"] += time.perf_counter() - t; t = time.perf_counter()
-        run_oracle(o, cam[k])
+        Tc, _, inl, _, _ = run_oracle(o, cam[k])
+        Tc = Tc.astype(np.float32)
         stage["lm_cam"] += time.perf_counter() - t; t = time.perf_counter()
+        if last is not None:                                                            # K13 + DynObjTracking
+            lo = last["ob"]
+            fl, olab = T.scene_flow(o, (lo["corr_x"], lo["corr_y"], od, osem), Tc, (lo["key_x"], lo["key_y"], lo["depth"], lo["label"]), Tl, K4,
+                                    np.full(od.size, -2, np.int32))
+            prm = DynObjParamsC(fr["mask"].shape[1], fr["mask"].shape[0], 25, 50, 0.12, 0.3, SF.TH_DEPTH_OBJ, n)
+            dyn = T.dyn_obj_tracking(o, prm, osem, olab, lo["corr_x"], lo["corr_y"], od, fl, lo["label"], last["sem_pos"], last["mod"], np.ones(len(last["mod"]), np.uint8), max_id)
+            max_id = dyn["max_id"]
+        stage["tracking_k11_k15"] += time.perf_counter() - t; t = time.perf_counter()
         for p in obj[k]:
             run_oracle(o, p)
-        stage["lm_obj"] += time.perf_counter() - t
+        stage["lm_obj"] += time.perf_counter() - t; t = time.perf_counter()
+        if last is not None:                                                            # K14 + K12 + tracklets
+            ns = last["st"]["corr_x"].size
+            tm = np.where(inl[np.arange(ns) % inl.size] != 0, np.arange(ns), -1).astype(np.int32)
+            rs = T.renew_static(o, tm, last["st"]["corr_x"], last["st"]["corr_y"], kp["x"], kp["y"], mask, d, fr["flow"], 1200)
+            Twc = np.linalg.inv(Tc.astype(np.float64)).astype(np.float32)
+            T.get3d_world(o, rs["key_x"], rs["key_y"], rs["depth"], K4, Twc)
+            tmp = dict(x=ob["key_x"], y=ob["key_y"], depth=ob["depth"], label=ob["label"], flow_x=ob["flow_x"], flow_y=ob["flow_y"], corr_x=ob["corr_x"], corr_y=ob["corr_y"])
+            ro = T.renew_object(o, dyn["objects"], np.ones(len(dyn["objects"]), np.uint8), dyn["sem"], dyn["mod"], lo["corr_x"], lo["corr_y"], dyn["obj_label"], tmp, mask, d, fr["flow"], 800)
+            T.get3d_world(o, ro["key_x"], ro["key_y"], ro["depth"], K4, Twc)
+            assos_s.append(rs["inlier_id"]); assos_d.append(ro["inlier_id"]); labs_d.append(ro["obj_label"])
+            T.build_tracks(o, assos_s); T.build_tracks(o, assos_d, labs_d)              # the reference rebuilds every tracklet from frame 0
+            st = dict(corr_x=rs["corr_x"], corr_y=rs["corr_y"])
+            ob = dict(key_x=ro["key_x"], key_y=ro["key_y"], corr_x=ro["corr_x"], corr_y=ro["corr_y"], depth=ro["depth"], label=ro["sem"])
+            sem_pos, mod = dyn["sem"], dyn["mod"]
+        else:
+            assos_s, assos_d, labs_d = [], [], []
+            sem_pos, mod = np.zeros(0, np.int32), np.zeros(0, np.int32)
+        stage["tracking_k11_k15"] += time.perf_counter() - t
+        last = dict(st=st, ob=ob, mask=mask, flow=fr["flow"], sem_pos=sem_pos, mod=mod)
+        Tl = Tc
         n += 1
         if time.perf_counter() - t0 > budget_s or n >= 40:
             break
@@ -151,32 +191,46 @@ def main():
     # ---- inputs resident in HBM
     dev = [dict(gray=torch.from_numpy(f["gray"]).cuda(), depth=torch.from_numpy(f["depth_raw"]).cuda(),
                 flow=torch.from_numpy(f["flow"]).cuda(), mask=torch.from_numpy(f["mask"]).cuda()) for f in frames]
-    orb = ORBextractor(ctx, W, H)
-    fimg = FrameImages(ctx, W, H)
     cam_b = [Flow2Batch(ctx_lm, [p]) for p in cam]
     obj_b = [Flow2Batch(ctx_lm, ps) for ps in obj]
-    torch.cuda.synchronize()
+    # The per-frame sequence runs in the C++ host class FramePipeline (vdo_slam_amd/host/FramePipeline.cc: the hot
+    # part of Tracking::GrabImageRGBD + Track over the C-ABI, state chained frame to frame); one ctypes call per frame.
+    host = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "vdo_slam_amd", "libvdo_host.so"))
 
-    n_kp = n_stat = n_obj = 0
+    class PipelineParams(C.Structure):
+        _fields_ = [("width", C.c_int), ("height", C.c_int), ("K4", C.c_float * 4), ("bf", C.c_float), ("depth_map_factor", C.c_float),
+                    ("th_depth_bg", C.c_float), ("th_depth_obj", C.c_float), ("max_track_bg", C.c_int), ("max_track_obj", C.c_int),
+                    ("sf_mg_thres", C.c_float), ("sf_ds_thres", C.c_float), ("n_features", C.c_int), ("n_levels", C.c_int), ("ini_th", C.c_int),
+                    ("min_th", C.c_int), ("scale_factor", C.c_float)]
+
+    class FrameCounts(C.Structure):
+        _fields_ = [(k_, C.c_int) for k_ in ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects",
+                                             "n_recovered_masks", "n_static_tracks", "n_dynamic_tracks")]
+
+    prm = PipelineParams(W, H, (C.c_float * 4)(*synth.KITTI_K), SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, 1200, 800,
+                         0.12, 0.3, 2500, 8, 20, 7, 1.2)          # example/kitti-0000-0013.yaml
+    host.host_pipeline_create.restype = C.c_void_p
+    host.host_pipeline_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PipelineParams)]
+    host.host_pipeline_step.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.POINTER(FrameCounts)]
+    host.host_pipeline_destroy.argtypes = [C.c_void_p]
+    pipe = host.host_pipeline_create(ctx._h, ctx_lm._h, C.byref(prm))
+    if not pipe:
+        raise SystemExit("FramePipeline could not be created")
+    torch.cuda.synchronize()
+    counts = FrameCounts()
+    n_cam = cam[0].n
 
     def step(i):
-        # Within a frame the LM chain (camera, then objects: they consume last frame's correspondences + this frame's
-        # flow) and the ORB front-end (whose keypoints are only needed by RenewFrameInfo at the END of the frame,
-        # src/Tracking.cc:1168) are independent: the LM kernels go to their own stream first, the front-end (device
-        # stages + host quadtree) runs meanwhile, and the frame joins both before the next one starts.
-        nonlocal n_kp, n_stat, n_obj
+        # UpdateMask (K15) -> K1 -> propagation (K11) -> camera LM (K16, stream 2) || ORB (K3-K7) + K9 + K10 ->
+        # scene flow (K13) + DynObjTracking -> object LMs (K17, stream 2) || RenewFrameInfo static (K14, K12) ->
+        # RenewFrameInfo objects (K14, K12) -> tracklets.  The LM problems of a frame are pre-built KITTI-shaped
+        # problems (the RANSAC initialisers that would seed them are SURVEY §8f-2); everything else is chained data.
         k = i % N_DISTINCT_FRAMES
         d = dev[k]
-        fimg.upload_device(d["depth"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())   # raw inputs -> working images (D2D)
-        fimg.depth_preprocess(SF.BF, SF.DEPTH_MAP_FACTOR)                                       # K1
-        ctx.synchronize()                                                                        # the LM's inputs (K11 gathers) need the metric depth
-        cam_b[k].run()                                                                           # K16 (stream 2)
-        obj_b[k].run()                                                                           # K17 (5 objects, one launch, stream 2)
-        kp = orb.extract_device(d["gray"].data_ptr(), W)                                         # K3-K7 (+ host quadtree)
-        st = fimg.static_filter(kp["x"], kp["y"], SF.TH_DEPTH_BG)                                # K9
-        ob = fimg.object_sample(SF.TH_DEPTH_OBJ)                                                 # K10
-        ctx_lm.synchronize()                                                                     # join: RenewFrameInfo needs both
-        n_kp, n_stat, n_obj = kp["x"].size, st["keep_idx"].size, ob["label"].size
+        rc = host.host_pipeline_step(pipe, d["gray"].data_ptr(), d["depth"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr(),
+                                     cam_b[k]._h, obj_b[k]._h, n_cam, len(obj[k]), C.byref(counts))
+        if rc != 0:
+            raise SystemExit("FramePipeline.Step failed (see stderr)")
 
     def barrier():
         torch.cuda.synchronize()
@@ -198,16 +252,26 @@ def main():
     dt = float(tt.item())
     fps = world * args.steps / dt
     lm = cam_b[0].fetch()[0]
+    sect = (C.c_double * 9)()
+    host.host_pipeline_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+    host.host_pipeline_timing(pipe, sect)
+    n_all = args.steps + args.warmup
+    sect_names = ("k1_k15_k11", "orb", "k9_k10", "wait_cam_lm", "k13_dynobj", "renew_static", "wait_obj_lm", "renew_object", "tracklets")
 
     out = {
         "metric": "frames/sec (per-frame hot path, KITTI-0000-shaped 1242x375) + ms/LM-iter (batch factor graph)",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64 (LM) / u8,i32,f32 (front-end)", "data": "synthetic",
-        "config": {"workload": "KITTI-0000-shaped per-frame hot path: K1 depth, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), "
-                               "K9 static filter, K10 object sampling, joint pose+flow LM camera (1200) + 5 objects (800..200), ref_quirks=1",
-                   "parallelism": f"replicas x{world}; inside a frame the LM chain (stream 2) overlaps the ORB front-end (stream 1)", "orb_keypoints": int(n_kp), "static_matches": int(n_stat), "object_points": int(n_obj),
-                   "camera_lm_iterations": int(lm["iterations"])},
+        "config": {"workload": "KITTI-0000-shaped per-frame hot path (C++ FramePipeline over the C-ABI): K15 UpdateMask, K1 depth, K11 propagation, ORB 2500 feats/8 levels "
+                               "(pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, joint pose+flow LM camera (1200) + 5 objects (800..200) with "
+                               "ref_quirks=1, K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets",
+                   "parallelism": f"replicas x{world}; inside a frame the LM chain (stream 2) overlaps the ORB front-end / RenewFrameInfo (stream 1)",
+                   "orb_keypoints": counts.n_orb, "new_static_candidates": counts.n_static_new, "object_samples": counts.n_object_samples,
+                   "static_tracked": counts.n_static_tracked, "object_points_tracked": counts.n_object_tracked, "objects": counts.n_objects,
+                   "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
+                   "camera_lm_iterations": int(lm["iterations"]),
+                   "host_ms_per_section": {k_: round(sect[j] / n_all, 4) for j, k_ in enumerate(sect_names)}},
     }
 
     if not args.no_batch:

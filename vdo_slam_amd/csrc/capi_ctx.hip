@@ -50,7 +50,10 @@ extern "C" int vdo_ctx_create(int device, void* hip_stream, vdo_ctx** out) {
 
 extern "C" int vdo_ctx_destroy(vdo_ctx* ctx) {
   if (!ctx) return VDO_OK;
-  if (ctx->owns_stream && ctx->stream) { hipSetDevice(ctx->device); hipStreamDestroy(ctx->stream); }
+  hipSetDevice(ctx->device);
+  if (ctx->d_arena) hipFree(ctx->d_arena);
+  if (ctx->h_arena) hipHostFree(ctx->h_arena);
+  if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return VDO_OK;
 }

@@ -2,10 +2,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
+
 struct vdo_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
   bool owns_stream = false;
+  // grow-only scratch of the small per-call entry points (arena.hpp): device block + pinned host block
+  char* d_arena = nullptr; size_t d_cap = 0;
+  char* h_arena = nullptr; size_t h_cap = 0;
 };
 
 namespace vdo {

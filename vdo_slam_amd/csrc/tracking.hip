@@ -17,6 +17,7 @@
 #include "ctx.hpp"
 #include "frame_images.hpp"
 #include "near_flags.hpp"
+#include "arena.hpp"
 
 namespace vdo {
 
@@ -129,39 +130,18 @@ static Cam make_cam_Tcw(const float* K4, const float* Tcw) {   // UnprojectStere
 
 using namespace vdo;
 
-namespace {
-struct Scratch {   // small device scratch owned per call (n is a few thousand)
-  std::vector<void*> p;
-  hipStream_t s;
-  template <class T> T* up(const T* host, size_t n) {
-    T* d = nullptr;
-    if (hipMalloc((void**)&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
-    p.push_back(d);
-    if (host && n) hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, s);
-    return d;
-  }
-  template <class T> void down(T* host, const T* dev, size_t n) { if (host && n) hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, s); }
-  ~Scratch() { for (void* q : p) hipFree(q); }
-};
-int finish(hipStream_t s, const char* what) {
-  hipError_t e = hipStreamSynchronize(s);
-  if (e == hipSuccess) e = hipGetLastError();
-  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
-  return VDO_OK;
-}
-}  // namespace
-
 extern "C" int vdo_propagate_static(vdo_frame_images* f, int n, const float* kx, const float* ky, float* depth_out) {
   if (!f || n < 0) return set_error(VDO_ERR_INVALID, "bad argument");
   if (n == 0) return VDO_OK;
   int rc = ctx_bind(f->ctx);
   if (rc != VDO_OK) return rc;
-  Scratch S; S.s = f->ctx->stream;
+  Arena S(f->ctx);
+  if (!S.reserve(Arena::bytes_for(3 * (size_t)n))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   float *dx = S.up(kx, n), *dy = S.up(ky, n), *dd = S.up<float>(nullptr, n);
   if (!dd) return set_error(VDO_ERR_OOM, "hipMalloc failed");
   hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.s, 0, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, 0.f, dd, (int32_t*)nullptr);
   S.down(depth_out, dd, n);
-  return finish(S.s, "vdo_propagate_static");
+  return S.finish("vdo_propagate_static");
 }
 
 extern "C" int vdo_propagate_object(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth_obj, float* depth_out, int32_t* label_out) {
@@ -169,13 +149,14 @@ extern "C" int vdo_propagate_object(vdo_frame_images* f, int n, const float* kx,
   if (n == 0) return VDO_OK;
   int rc = ctx_bind(f->ctx);
   if (rc != VDO_OK) return rc;
-  Scratch S; S.s = f->ctx->stream;
+  Arena S(f->ctx);
+  if (!S.reserve(Arena::bytes_for(4 * (size_t)n))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   float *dx = S.up(kx, n), *dy = S.up(ky, n), *dd = S.up<float>(nullptr, n);
   int32_t* dl = S.up<int32_t>(nullptr, n);
   if (!dl) return set_error(VDO_ERR_OOM, "hipMalloc failed");
   hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.s, 1, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, th_depth_obj, dd, dl);
   S.down(depth_out, dd, n); S.down(label_out, dl, n);
-  return finish(S.s, "vdo_propagate_object");
+  return S.finish("vdo_propagate_object");
 }
 
 extern "C" int vdo_mask_at(vdo_frame_images* f, int n, const float* cx, const float* cy, int32_t* label_out) {
@@ -183,13 +164,14 @@ extern "C" int vdo_mask_at(vdo_frame_images* f, int n, const float* cx, const fl
   if (n == 0) return VDO_OK;
   int rc = ctx_bind(f->ctx);
   if (rc != VDO_OK) return rc;
-  Scratch S; S.s = f->ctx->stream;
+  Arena S(f->ctx);
+  if (!S.reserve(Arena::bytes_for(3 * (size_t)n))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   float *dx = S.up(cx, n), *dy = S.up(cy, n);
   int32_t* dl = S.up<int32_t>(nullptr, n);
   if (!dl) return set_error(VDO_ERR_OOM, "hipMalloc failed");
   hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.s, 2, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, 0.f, (float*)nullptr, dl);
   S.down(label_out, dl, n);
-  return finish(S.s, "vdo_mask_at");
+  return S.finish("vdo_mask_at");
 }
 
 extern "C" int vdo_mask_warp(vdo_frame_images* cur, vdo_frame_images* last, int32_t label) {
@@ -205,7 +187,10 @@ extern "C" int vdo_frame_images_download_mask(vdo_frame_images* f, int32_t* mask
   int rc = ctx_bind(f->ctx);
   if (rc != VDO_OK) return rc;
   hipMemcpyAsync(mask_out, f->d_mask, 4 * (size_t)f->w * f->h, hipMemcpyDeviceToHost, f->ctx->stream);
-  return finish(f->ctx->stream, "vdo_frame_images_download_mask");
+  hipError_t e = hipStreamSynchronize(f->ctx->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "vdo_frame_images_download_mask: %s", hipGetErrorString(e));
+  return VDO_OK;
 }
 
 extern "C" int vdo_get3d_world(vdo_ctx* ctx, int n, const float* kx, const float* ky, const float* depth, const float K4[4], const float Twc[16], float* xyz_out) {
@@ -213,12 +198,13 @@ extern "C" int vdo_get3d_world(vdo_ctx* ctx, int n, const float* kx, const float
   if (n == 0) return VDO_OK;
   int rc = ctx_bind(ctx);
   if (rc != VDO_OK) return rc;
-  Scratch S; S.s = ctx->stream;
+  Arena S(ctx);
+  if (!S.reserve(Arena::bytes_for(6 * (size_t)n))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   float *dx = S.up(kx, n), *dy = S.up(ky, n), *dd = S.up(depth, n), *dxyz = S.up<float>(nullptr, 3 * (size_t)n);
   if (!dxyz) return set_error(VDO_ERR_OOM, "hipMalloc failed");
   hipLaunchKernelGGL(k_get3d_world, dim3((n + 255) / 256), dim3(256), 0, S.s, n, (const float*)dx, (const float*)dy, (const float*)dd, make_cam_Twc(K4, Twc), dxyz);
   S.down(xyz_out, dxyz, 3 * (size_t)n);
-  return finish(S.s, "vdo_get3d_world");
+  return S.finish("vdo_get3d_world");
 }
 
 extern "C" int vdo_scene_flow(vdo_ctx* ctx, int n, const float* cur_x, const float* cur_y, const float* cur_d, const int32_t* cur_label, const float Tcw_cur[16],
@@ -228,7 +214,8 @@ extern "C" int vdo_scene_flow(vdo_ctx* ctx, int n, const float* cur_x, const flo
   if (n == 0) return VDO_OK;
   int rc = ctx_bind(ctx);
   if (rc != VDO_OK) return rc;
-  Scratch S; S.s = ctx->stream;
+  Arena S(ctx);
+  if (!S.reserve(Arena::bytes_for(12 * (size_t)n))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   float *a = S.up(cur_x, n), *b = S.up(cur_y, n), *c = S.up(cur_d, n), *d = S.up(last_x, n), *e = S.up(last_y, n), *g = S.up(last_d, n);
   int32_t *cl = S.up(cur_label, n), *ll = S.up(last_label, n), *ol = S.up(obj_label_inout, n);
   float* fl = S.up<float>(nullptr, 3 * (size_t)n);
@@ -236,7 +223,7 @@ extern "C" int vdo_scene_flow(vdo_ctx* ctx, int n, const float* cur_x, const flo
   hipLaunchKernelGGL(k_scene_flow, dim3((n + 255) / 256), dim3(256), 0, S.s, n, (const float*)a, (const float*)b, (const float*)c, (const int32_t*)cl, make_cam_Tcw(K4, Tcw_cur),
                      (const float*)d, (const float*)e, (const float*)g, (const int32_t*)ll, make_cam_Tcw(K4, Tcw_last), fl, ol);
   S.down(flow3d_out, fl, 3 * (size_t)n); S.down(obj_label_inout, ol, n);
-  return finish(S.s, "vdo_scene_flow");
+  return S.finish("vdo_scene_flow");
 }
 
 // K14, static part.  Same contract as Tracking::RenewFrameInfo :2666-2790 (see the oracle for the
@@ -248,7 +235,8 @@ extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm
   if (!f || !n_out || n_tm < 0 || n_orb < 0) return set_error(VDO_ERR_INVALID, "bad argument");
   int rc = ctx_bind(f->ctx);
   if (rc != VDO_OK) return rc;
-  Scratch S; S.s = f->ctx->stream;
+  Arena S(f->ctx);
+  if (!S.reserve(Arena::bytes_for(16 * ((size_t)n_tm + (size_t)n_orb) + 4 * (size_t)max_num_sta))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   // phase 1 candidates: the inlier static keys, in TM_sta order
   std::vector<float> cx1, cy1; std::vector<int32_t> id1;
   for (int i = 0; i < n_tm; ++i) if (tm_sta[i] != -1) { cx1.push_back(stat_x[tm_sta[i]]); cy1.push_back(stat_y[tm_sta[i]]); id1.push_back(tm_sta[i]); }
@@ -265,7 +253,7 @@ extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm
   if (!dd2 || !dd1) return set_error(VDO_ERR_OOM, "hipMalloc failed");
   if (n_orb) hipLaunchKernelGGL(k_renew_pred, dim3((n_orb + 255) / 256), dim3(256), 0, S.s, n_orb, (const float*)dx2, (const float*)dy2, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok2, dfx2, dfy2, dd2);
   S.down(ok1.data(), dok1, n1); S.down(fx1.data(), dfx1, n1); S.down(fy1.data(), dfy1, n1); S.down(d1.data(), dd1, n1);
-  rc = finish(S.s, "vdo_renew_static (carry)");
+  rc = S.finish("vdo_renew_static (carry)");
   if (rc != VDO_OK) return rc;
   // carry-over: first-come, stop once size > max (the reference checks after every element, :2703-2709)
   int m = 0;
@@ -282,7 +270,7 @@ extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm
     float *dcx = S.up(key_x, n_check), *dcy = S.up(key_y, n_check);
     hipLaunchKernelGGL(k_near_flags, dim3((n_orb + 255) / 256), dim3(256), 0, S.s, n_orb, (const float*)dx2, (const float*)dy2, n_check, (const float*)dcx, (const float*)dcy, dused);
     S.down(used2.data(), dused, n_orb); S.down(ok2.data(), dok2, n_orb); S.down(fx2.data(), dfx2, n_orb); S.down(fy2.data(), dfy2, n_orb); S.down(d2.data(), dd2, n_orb);
-    rc = finish(S.s, "vdo_renew_static (top-up)");
+    rc = S.finish("vdo_renew_static (top-up)");
     if (rc != VDO_OK) return rc;
     int tot = m, start_id = 0;
     const int step = 20;

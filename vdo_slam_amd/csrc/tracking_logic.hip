@@ -18,6 +18,7 @@
 #include "ctx.hpp"
 #include "frame_images.hpp"
 #include "near_flags.hpp"
+#include "arena.hpp"
 
 namespace vdo {
 
@@ -82,38 +83,44 @@ __global__ void k_mask_warp_if(const int32_t* __restrict__ flag, const int32_t* 
   if (k + fx < w && k + fx > 0 && j + fy < h && j + fy > 0) mask_cur[(size_t)(j + fy) * w + (k + fx)] = lab;
 }
 
-struct DevScratch {
-  std::vector<void*> p;
-  hipStream_t s;
-  template <class T> T* up(const T* host, size_t n) {
-    T* d = nullptr;
-    if (hipMalloc((void**)&d, std::max<size_t>(n, 1) * sizeof(T)) != hipSuccess) return nullptr;
-    p.push_back(d);
-    if (host && n) hipMemcpyAsync(d, host, n * sizeof(T), hipMemcpyHostToDevice, s);
-    return d;
-  }
-  template <class T> void down(T* host, const T* dev, size_t n) { if (host && n) hipMemcpyAsync(host, dev, n * sizeof(T), hipMemcpyDeviceToHost, s); }
-  ~DevScratch() { for (void* q : p) hipFree(q); }
-};
-
-static int finish(hipStream_t s, const char* what) {
-  hipError_t e = hipStreamSynchronize(s);
-  if (e == hipSuccess) e = hipGetLastError();
-  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
-  return VDO_OK;
-}
-
-// sorted distinct labels + slot of every element
+// sorted distinct labels + slot of every element.  Mask labels are small integers: a presence table over
+// [min, max] gives both in O(n) (a sort + binary searches of ~5k labels cost ~0.1 ms per call); wide label
+// ranges fall back to sort + lower_bound.
 static void label_slots(int n, const int32_t* lab, std::vector<int32_t>& uni, std::vector<int32_t>& slot) {
+  uni.clear();
+  slot.resize(n);
+  if (n == 0) return;
+  int32_t lo = lab[0], hi = lab[0];
+  for (int i = 1; i < n; ++i) { lo = std::min(lo, lab[i]); hi = std::max(hi, lab[i]); }
+  const int64_t range = (int64_t)hi - lo + 1;
+  if (range <= 65536) {
+    static thread_local std::vector<int32_t> table;
+    table.assign((size_t)range, -1);
+    for (int i = 0; i < n; ++i) table[lab[i] - lo] = 0;
+    for (int64_t v = 0; v < range; ++v) if (table[v] == 0) { table[v] = (int32_t)uni.size(); uni.push_back((int32_t)(lo + v)); }
+    for (int i = 0; i < n; ++i) slot[i] = table[lab[i] - lo];
+    return;
+  }
   uni.assign(lab, lab + n);
   std::sort(uni.begin(), uni.end());
   uni.erase(std::unique(uni.begin(), uni.end()), uni.end());
-  slot.resize(n);
   for (int i = 0; i < n; ++i) slot[i] = (int32_t)(std::lower_bound(uni.begin(), uni.end(), lab[i]) - uni.begin());
 }
 
 // most frequent value, smallest on ties (std::sort of <16 map entries is a stable insertion sort)
 static int majority(std::vector<int32_t>& v) {
+  if (v.empty()) return 0;
+  int32_t lo = v[0], hi = v[0];
+  for (int32_t x : v) { lo = std::min(lo, x); hi = std::max(hi, x); }
+  const int64_t range = (int64_t)hi - lo + 1;
+  if (range <= 65536) {
+    static thread_local std::vector<int32_t> cntv;
+    cntv.assign((size_t)range, 0);
+    for (int32_t x : v) ++cntv[x - lo];
+    int best = lo, cnt = -1;
+    for (int64_t k = 0; k < range; ++k) if (cntv[k] > cnt) { cnt = cntv[k]; best = (int)(lo + k); }
+    return best;
+  }
   std::sort(v.begin(), v.end());
   int best = 0, cnt = -1;
   for (size_t a = 0; a < v.size();) {
@@ -213,7 +220,8 @@ extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* i
   if (!f || !n_out || n_obj < 0 || n_tmp < 0 || cap < 0) return set_error(VDO_ERR_INVALID, "vdo_renew_object: bad argument");
   int rc = ctx_bind(f->ctx);
   if (rc != VDO_OK) return rc;
-  DevScratch S; S.s = f->ctx->stream;
+  Arena S(f->ctx);
+  if (!S.reserve(Arena::bytes_for(16 * ((size_t)(n_obj ? inl_off[n_obj] : 0) + (size_t)n_tmp + 64)))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   // ---- carried candidates: inliers of the tracked objects, object-major (the reference's visiting order)
   std::vector<float> cx, cy; std::vector<int32_t> cid, cobj;
   for (int i = 0; i < n_obj; ++i) {
@@ -230,7 +238,7 @@ extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* i
     hipLaunchKernelGGL(k_renew_obj_pred, dim3((nc + 255) / 256), dim3(256), 0, S.s, nc, (const float*)dx, (const float*)dy, (const int32_t*)f->d_mask,
                        (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok, dsem, ddd, dfx, dfy);
     S.down(ok.data(), dok, nc); S.down(sem.data(), dsem, nc); S.down(dd.data(), ddd, nc); S.down(fx.data(), dfx, nc); S.down(fy.data(), dfy, nc);
-    rc = finish(S.s, "vdo_renew_object (carry)");
+    rc = S.finish("vdo_renew_object (carry)");
     if (rc != VDO_OK) return rc;
   }
   int m = 0;
@@ -257,7 +265,7 @@ extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* i
     if (!dused) return set_error(VDO_ERR_OOM, "hipMalloc failed");
     hipLaunchKernelGGL(k_near_flags, dim3((n_tmp + 255) / 256), dim3(256), 0, S.s, n_tmp, (const float*)dqx, (const float*)dqy, n_check, (const float*)drx, (const float*)dry, dused);
     S.down(used.data(), dused, n_tmp);
-    rc = finish(S.s, "vdo_renew_object (top-up)");
+    rc = S.finish("vdo_renew_object (top-up)");
     if (rc != VDO_OK) return rc;
   }
   for (int i = 0; i < n_obj; ++i) {
@@ -298,7 +306,8 @@ extern "C" int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, in
   if (n == 0) return VDO_OK;
   int rc = ctx_bind(cur->ctx);
   if (rc != VDO_OK) return rc;
-  DevScratch S; S.s = cur->ctx->stream;
+  Arena S(cur->ctx);
+  if (!S.reserve(Arena::bytes_for(4 * (size_t)n + 64))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   // group the flowed positions by last-frame label (ascending labels, index order inside a label)
   std::vector<int32_t> uni, slot;
   label_slots(n, last_sem_label, uni, slot);
@@ -323,7 +332,7 @@ extern "C" int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, in
   }
   std::vector<int32_t> flag(2 * (size_t)L);
   S.down(flag.data(), dflag, flag.size());
-  rc = finish(S.s, "vdo_update_mask");
+  rc = S.finish("vdo_update_mask");
   if (rc != VDO_OK) return rc;
   int rec = 0;
   for (int s = 0; s < L; ++s) {

@@ -1,0 +1,212 @@
+#include "FramePipeline.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+
+namespace VDO_SLAM {
+
+namespace {
+void inv_rigid(const float* T, float* o) {                 // Converter::toInvMatrix
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) o[4 * i + j] = T[4 * j + i];
+    o[4 * i + 3] = -(T[0 * 4 + i] * T[3] + T[1 * 4 + i] * T[7] + T[2 * 4 + i] * T[11]);
+  }
+  o[12] = o[13] = o[14] = 0; o[15] = 1;
+}
+}  // namespace
+
+#define VDO_TRY(call) do { if ((call) != VDO_OK) { std::fprintf(stderr, "FramePipeline: %s\n", vdo_last_error()); return -1; } } while (0)
+
+FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p) : ctx_(ctx), ctx_lm_(ctx_lm), p_(p) {
+  vdo_orb_params op{p.n_features, p.scale_factor, p.n_levels, p.ini_th, p.min_th};
+  if (vdo_orb_create(ctx, &op, p.width, p.height, &orb_) != VDO_OK) return;
+  for (int k = 0; k < 2; ++k) if (vdo_frame_images_create(ctx, p.width, p.height, &img_[k]) != VDO_OK) return;
+  if (vdo_tracks_create(0, &tr_sta_) != VDO_OK || vdo_tracks_create(1, &tr_dyn_) != VDO_OK) return;
+  const int capk = p.n_features + 256;
+  kx_.resize(capk); ky_.resize(capk); kr_.resize(capk); ka_.resize(capk); ks_.resize(capk); ko_.resize(capk);
+  for (int i = 0; i < 16; ++i) Tcw_last_[i] = (i % 5 == 0) ? 1.f : 0.f;
+  ok_ = true;
+}
+
+FramePipeline::~FramePipeline() {
+  if (orb_) vdo_orb_destroy(orb_);
+  for (int k = 0; k < 2; ++k) if (img_[k]) vdo_frame_images_destroy(img_[k]);
+  if (tr_sta_) vdo_tracks_destroy(tr_sta_);
+  if (tr_dyn_) vdo_tracks_destroy(tr_dyn_);
+}
+
+int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
+                        vdo_flow2_batch* cam, vdo_flow2_batch* obj, int n_cam_pts, int n_obj_problems, FrameCounts* out) {
+  if (!ok_) return -1;
+  FrameCounts fc{};
+  auto t_prev = std::chrono::steady_clock::now();
+  auto tick = [&](int slot) { const auto t = std::chrono::steady_clock::now(); ms_[slot] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
+  vdo_frame_images *cur = img_[cur_], *last = img_[cur_ ^ 1];
+  const int W = p_.width, H = p_.height;
+  // ---- GrabImageRGBD: images, K1, UpdateMask (K15), propagation (K11)            Tracking.cc:180-305
+  VDO_TRY(vdo_frame_images_upload_device(cur, d_depth_raw, d_flow, d_mask));
+  VDO_TRY(vdo_frame_images_depth_preprocess(cur, p_.bf, p_.depth_map_factor));
+  const int n_s = have_last_ ? (int)sta_.cx.size() : 0, n_o = have_last_ ? (int)obj_.cx.size() : 0;
+  std::vector<float>& stat_depth = f_[0]; std::vector<float>& obj_depth = f_[1]; std::vector<int32_t>& obj_sem = i_[0];
+  stat_depth.assign(n_s, -1.f); obj_depth.assign(n_o, 0.f); obj_sem.assign(n_o, 0);
+  if (have_last_) {
+    int rec = 0;
+    VDO_TRY(vdo_update_mask(cur, last, n_o, obj_.sem.data(), obj_.cx.data(), obj_.cy.data(), &rec));
+    fc.n_recovered_masks = rec;
+    VDO_TRY(vdo_propagate_static(cur, n_s, sta_.cx.data(), sta_.cy.data(), stat_depth.data()));
+    VDO_TRY(vdo_propagate_object(cur, n_o, obj_.cx.data(), obj_.cy.data(), p_.th_depth_obj, obj_depth.data(), obj_sem.data()));
+  } else {
+    VDO_TRY(vdo_ctx_synchronize(ctx_));
+  }
+  tick(0);
+  // ---- camera pose (K16) on the LM stream, front-end of this frame meanwhile      Tracking.cc:690-700 || Frame.cc:61-260
+  if (cam) VDO_TRY(vdo_flow2_batch_run(cam));
+  vdo_keypoints kp{(int32_t)kx_.size(), 0, kx_.data(), ky_.data(), kr_.data(), ka_.data(), ks_.data(), ko_.data()};
+  VDO_TRY(vdo_orb_extract(orb_, d_gray, W, 1, &kp));
+  fc.n_orb = kp.n;
+  tick(1);
+  // K9 + K10 of the new image: only RenewFrameInfo needs them, so they run while the object LMs are in flight
+  int n_new_s = 0, n_tmp = 0;
+  std::vector<int32_t>& keep = i_[1];
+  ObjSet& tmp = tmp_;                                   // K10: semi-dense sampling of this image (mvTmpObj*)
+  auto frame_filters = [&]() -> int {
+    keep.resize(std::max(kp.n, 1));
+    for (int k = 2; k < 7; ++k) f_[k].resize(std::max(kp.n, 1));
+    VDO_TRY(vdo_frame_static_filter(cur, kp.n, kx_.data(), ky_.data(), p_.th_depth_bg, keep.data(), f_[2].data(), f_[3].data(), f_[4].data(), f_[5].data(), f_[6].data(), &n_new_s));
+    fc.n_static_new = n_new_s;
+    const int cap_s = ((W + 3) / 4) * ((H + 3) / 4);
+    tmp.x.resize(cap_s); tmp.y.resize(cap_s); tmp.cx.resize(cap_s); tmp.cy.resize(cap_s); tmp.fx.resize(cap_s); tmp.fy.resize(cap_s); tmp.d.resize(cap_s); tmp.sem.resize(cap_s);
+    VDO_TRY(vdo_frame_object_sample(cur, p_.th_depth_obj, 4, cap_s, tmp.x.data(), tmp.y.data(), tmp.cx.data(), tmp.cy.data(), tmp.fx.data(), tmp.fy.data(), tmp.d.data(), tmp.sem.data(), &n_tmp));
+    fc.n_object_samples = n_tmp;
+    return 0;
+  };
+  tick(2);
+  // ---- consume the camera result
+  float Tcw[16];
+  for (int i = 0; i < 16; ++i) Tcw[i] = Tcw_last_[i];
+  inl_out_.assign(std::max(n_cam_pts, 1), 1);
+  if (cam) {
+    VDO_TRY(vdo_ctx_synchronize(ctx_lm_));
+    vdo_flow2_result r;
+    flow_out_.resize(2 * (size_t)std::max(n_cam_pts, 1));
+    double* fo = flow_out_.data(); uint8_t* io = inl_out_.data();
+    VDO_TRY(vdo_flow2_batch_fetch(cam, &r, &fo, &io));
+    for (int i = 0; i < 16; ++i) Tcw[i] = (float)r.T[i];
+  }
+  tick(3);
+  StaSet nsta; ObjSet nobj;
+  std::vector<int32_t> sta_asso, dyn_asso;
+  if (!have_last_) {
+    // ---- Initialization(): the new features ARE the tracked set                   Tracking.cc:1215-1276
+    if (obj) VDO_TRY(vdo_flow2_batch_run(obj));
+    if (frame_filters() != 0) return -1;
+    nsta.x.resize(n_new_s); nsta.y.resize(n_new_s);
+    for (int i = 0; i < n_new_s; ++i) { nsta.x[i] = kx_[keep[i]]; nsta.y[i] = ky_[keep[i]]; }
+    nsta.cx.assign(f_[2].begin(), f_[2].begin() + n_new_s); nsta.cy.assign(f_[3].begin(), f_[3].begin() + n_new_s);
+    nsta.fx.assign(f_[4].begin(), f_[4].begin() + n_new_s); nsta.fy.assign(f_[5].begin(), f_[5].begin() + n_new_s);
+    nsta.d.assign(f_[6].begin(), f_[6].begin() + n_new_s);
+    nobj = tmp;                                         // (copy: tmp_ keeps its capacity for the next frame)
+    for (auto* v : {&nobj.x, &nobj.y, &nobj.cx, &nobj.cy, &nobj.fx, &nobj.fy, &nobj.d}) v->resize(n_tmp);
+    nobj.sem.resize(n_tmp); nobj.label.assign(n_tmp, -2);
+    if (obj) VDO_TRY(vdo_ctx_synchronize(ctx_lm_));
+  } else {
+    // ---- GetSceneFlowObj (K13) + DynObjTracking                                   Tracking.cc:1278-1612
+    std::vector<float>& flow3d = f_[7];
+    flow3d.resize(3 * (size_t)std::max(n_o, 1));
+    std::vector<int32_t>& olab = i_[2];
+    olab.assign(n_o, -2);
+    VDO_TRY(vdo_scene_flow(ctx_, n_o, obj_.cx.data(), obj_.cy.data(), obj_depth.data(), obj_sem.data(), Tcw,
+                           obj_.x.data(), obj_.y.data(), obj_.d.data(), obj_.sem.data(), Tcw_last_, p_.K4, flow3d.data(), olab.data()));
+    vdo_dyn_obj_params dp{W, H, 25, 50, p_.sf_mg_thres, p_.sf_ds_thres, p_.th_depth_obj, f_id_};
+    std::vector<int32_t>&off = i_[3], &idx = i_[4], &osem = i_[5], &omod = i_[6];
+    off.assign(n_o + 2, 0); idx.resize(std::max(n_o, 1)); osem.resize(n_o + 1); omod.resize(n_o + 1);
+    int n_objects = 0;
+    VDO_TRY(vdo_dyn_obj_tracking(&dp, n_o, obj_sem.data(), olab.data(), obj_.cx.data(), obj_.cy.data(), obj_depth.data(), flow3d.data(), obj_.sem.data(),
+                                 (int)last_sem_pos_.size(), last_sem_pos_.data(), last_mod_label_.data(), last_obj_stat_.data(), &max_id_,
+                                 off.data(), idx.data(), osem.data(), omod.data(), &n_objects));
+    fc.n_objects = n_objects;
+    tick(4);
+    // ---- object motions (K17) on the LM stream, RenewFrameInfo (static) meanwhile  Tracking.cc:932 || :2666-2805
+    if (obj) VDO_TRY(vdo_flow2_batch_run(obj));
+    if (frame_filters() != 0) return -1;
+    std::vector<int32_t>& tm = i_[7];
+    tm.resize(n_s);
+    for (int i = 0; i < n_s; ++i) tm[i] = inl_out_[n_cam_pts > 0 ? i % n_cam_pts : 0] ? i : -1;
+    const int cs = p_.max_track_bg + 2;
+    nsta.x.resize(cs); nsta.y.resize(cs); nsta.cx.resize(cs); nsta.cy.resize(cs); nsta.fx.resize(cs); nsta.fy.resize(cs); nsta.d.resize(cs);
+    sta_asso.resize(cs);
+    int m = 0;
+    VDO_TRY(vdo_renew_static(cur, n_s, tm.data(), sta_.cx.data(), sta_.cy.data(), kp.n, kx_.data(), ky_.data(), p_.max_track_bg,
+                             nsta.x.data(), nsta.y.data(), nsta.cx.data(), nsta.cy.data(), nsta.fx.data(), nsta.fy.data(), sta_asso.data(), nsta.d.data(), &m));
+    for (auto* v : {&nsta.x, &nsta.y, &nsta.cx, &nsta.cy, &nsta.fx, &nsta.fy, &nsta.d}) v->resize(m);
+    sta_asso.resize(m);
+    float Twc[16];
+    inv_rigid(Tcw, Twc);
+    std::vector<float>& xyz = f_[8];
+    xyz.resize(3 * (size_t)std::max(m, 1));
+    VDO_TRY(vdo_get3d_world(ctx_, m, nsta.x.data(), nsta.y.data(), nsta.d.data(), p_.K4, Twc, xyz.data()));          // mvStat3DPointTmp
+    tick(5);
+    // ---- consume the object results, RenewFrameInfo (objects)                      Tracking.cc:2806-2995
+    if (obj) {
+      VDO_TRY(vdo_ctx_synchronize(ctx_lm_));
+      std::vector<vdo_flow2_result> rs(std::max(n_obj_problems, 1));
+      VDO_TRY(vdo_flow2_batch_fetch(obj, rs.data(), nullptr, nullptr));
+    }
+    tick(6);
+    std::vector<uint8_t> stat(std::max(n_objects, 1), 1);
+    const int cap_o = off[n_objects] + n_tmp + 8;
+    nobj.x.resize(cap_o); nobj.y.resize(cap_o); nobj.cx.resize(cap_o); nobj.cy.resize(cap_o); nobj.fx.resize(cap_o); nobj.fy.resize(cap_o); nobj.d.resize(cap_o);
+    nobj.sem.resize(cap_o); nobj.label.resize(cap_o); dyn_asso.resize(cap_o);
+    int mo = 0;
+    VDO_TRY(vdo_renew_object(cur, n_objects, off.data(), idx.data(), stat.data(), osem.data(), omod.data(), obj_.cx.data(), obj_.cy.data(), olab.data(),
+                             n_tmp, tmp.x.data(), tmp.y.data(), tmp.d.data(), tmp.sem.data(), tmp.fx.data(), tmp.fy.data(), tmp.cx.data(), tmp.cy.data(),
+                             p_.max_track_obj, cap_o, nobj.x.data(), nobj.y.data(), nobj.d.data(), nobj.sem.data(), nobj.fx.data(), nobj.fy.data(),
+                             nobj.cx.data(), nobj.cy.data(), dyn_asso.data(), nobj.label.data(), &mo));
+    for (auto* v : {&nobj.x, &nobj.y, &nobj.cx, &nobj.cy, &nobj.fx, &nobj.fy, &nobj.d}) v->resize(mo);
+    nobj.sem.resize(mo); nobj.label.resize(mo); dyn_asso.resize(mo);
+    xyz.resize(3 * (size_t)std::max(mo, 1));
+    VDO_TRY(vdo_get3d_world(ctx_, mo, nobj.x.data(), nobj.y.data(), nobj.d.data(), p_.K4, Twc, xyz.data()));          // mvObj3DPoint
+    tick(7);
+    // ---- tracklets (incremental GetStaticTrack / GetDynamicTrackNew)               Tracking.cc:2201-2421
+    VDO_TRY(vdo_tracks_add_frame(tr_sta_, m, sta_asso.data(), nullptr));
+    VDO_TRY(vdo_tracks_add_frame(tr_dyn_, mo, dyn_asso.data(), nobj.label.data()));
+    last_sem_pos_.assign(osem.begin(), osem.begin() + n_objects);
+    last_mod_label_.assign(omod.begin(), omod.begin() + n_objects);
+    last_obj_stat_.assign(n_objects, 1);
+  }
+  tick(8);
+  fc.n_static_tracked = (int)nsta.x.size(); fc.n_object_tracked = (int)nobj.x.size();
+  int64_t np = 0;
+  vdo_tracks_size(tr_sta_, &fc.n_static_tracks, &np);
+  vdo_tracks_size(tr_dyn_, &fc.n_dynamic_tracks, &np);
+  sta_ = std::move(nsta); obj_ = std::move(nobj);
+  std::memcpy(Tcw_last_, Tcw, sizeof Tcw);
+  cur_ ^= 1; have_last_ = true; ++f_id_;
+  if (out) *out = fc;
+  return 0;
+}
+
+}  // namespace VDO_SLAM
+
+// ---- flat hooks for the Python bench / tests ------------------------------------------------------
+using VDO_SLAM::FramePipeline;
+using VDO_SLAM::FrameCounts;
+using VDO_SLAM::PipelineParams;
+
+extern "C" {
+FramePipeline* host_pipeline_create(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams* p) {
+  FramePipeline* fp = new FramePipeline(ctx, ctx_lm, *p);
+  if (!fp->ok()) { delete fp; return nullptr; }
+  return fp;
+}
+void host_pipeline_destroy(FramePipeline* fp) { delete fp; }
+// accumulated wall ms per section since creation: [0] K1+K15+K11, [1] ORB, [2] K9+K10, [3] wait camera LM + fetch,
+// [4] K13 + DynObjTracking, [5] RenewFrameInfo static + K12, [6] wait object LMs + fetch, [7] RenewFrameInfo objects + K12, [8] tracklets
+void host_pipeline_timing(FramePipeline* fp, double* ms9) { for (int i = 0; i < 9; ++i) ms9[i] = fp->ms_[i]; }
+int host_pipeline_step(FramePipeline* fp, const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
+                       vdo_flow2_batch* cam, vdo_flow2_batch* obj, int n_cam_pts, int n_obj_problems, FrameCounts* out) {
+  return fp->Step(d_gray, d_depth_raw, d_flow, d_mask, cam, obj, n_cam_pts, n_obj_problems, out);
+}
+}

@@ -1,0 +1,66 @@
+// FramePipeline — the per-frame sequence of Tracking::GrabImageRGBD + Tracking::Track (reference
+// src/Tracking.cc:164-314, 646-1276) over the C-ABI, with frame-to-frame state, minus what is not on the
+// hot path (ground-truth bookkeeping, metrics, drawing) and minus the P3P/AP3P RANSAC initialisers
+// (GetInitModelCam/Obj, SURVEY.md §8f-2: the pose problems of a frame are handed in by the caller).
+//
+//   UpdateMask (K15) -> depth preprocess (K1) -> propagation (K11) -> camera LM (K16, own stream)
+//        || ORB (K3-K7) + Frame filters (K9, K10)
+//   -> scene flow (K13) + DynObjTracking -> object LMs (K17, own stream) || RenewFrameInfo static (K14, K12)
+//   -> RenewFrameInfo objects (K14, K12) -> tracklets
+//
+// The LM kernels run on a second context/stream so that they overlap the front-end of the same frame
+// (the ORB keypoints are first needed by RenewFrameInfo at the end of the frame, src/Tracking.cc:1168).
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/vdo_slam_hip.h"
+
+namespace VDO_SLAM {
+
+struct PipelineParams {
+  int width, height;
+  float K4[4];                       // fx, fy, cx, cy
+  float bf, depth_map_factor;        // Camera.bf, DepthMapFactor
+  float th_depth_bg, th_depth_obj;   // ThDepthBG, ThDepthOBJ
+  int max_track_bg, max_track_obj;   // MaxTrackPointBG, MaxTrackPointOBJ
+  float sf_mg_thres, sf_ds_thres;    // SFMgThres, SFDsThres
+  int n_features, n_levels, ini_th, min_th; float scale_factor;   // ORBextractor.*
+};
+
+struct FrameCounts { int n_orb, n_static_new, n_object_samples, n_static_tracked, n_object_tracked, n_objects, n_recovered_masks, n_static_tracks, n_dynamic_tracks; };
+
+class FramePipeline {
+ public:
+  FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p);
+  ~FramePipeline();
+  // One frame.  d_* are DEVICE pointers of the raw inputs (gray u8, disparity*factor f32, flow 2xf32, mask i32).
+  // cam / obj: the frame's pose problems (already resident); their results are fetched like Track() consumes them.
+  int Step(const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
+           vdo_flow2_batch* cam, vdo_flow2_batch* obj, int n_cam_pts, int n_obj_problems, FrameCounts* out);
+  bool ok() const { return ok_; }
+  double ms_[12] = {0};              // accumulated wall time per section (see host_pipeline_timing)
+
+ private:
+  struct ObjSet { std::vector<float> x, y, cx, cy, fx, fy, d; std::vector<int32_t> sem, label; };
+  struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d; };
+  vdo_ctx *ctx_, *ctx_lm_;
+  PipelineParams p_;
+  vdo_orb* orb_ = nullptr;
+  vdo_frame_images* img_[2] = {nullptr, nullptr};
+  vdo_tracks *tr_sta_ = nullptr, *tr_dyn_ = nullptr;
+  int cur_ = 0, f_id_ = 0;
+  bool ok_ = false, have_last_ = false;
+  int32_t max_id_ = 1;
+  StaSet sta_;                        // last frame: static keys + their correspondences in the next image
+  ObjSet tmp_;                        // K10 output of the current frame (capacity kept across frames)
+  ObjSet obj_;                        // last frame: object keys, correspondences, depth, semantic + motion labels
+  std::vector<int32_t> last_sem_pos_, last_mod_label_; std::vector<uint8_t> last_obj_stat_;
+  float Tcw_last_[16];
+  // scratch reused across frames
+  std::vector<float> kx_, ky_, kr_, ka_, ks_; std::vector<int32_t> ko_;
+  std::vector<float> f_[16]; std::vector<int32_t> i_[8];
+  std::vector<double> flow_out_; std::vector<uint8_t> inl_out_;
+};
+
+}  // namespace VDO_SLAM
