@@ -65,75 +65,31 @@ def make_frame_inputs(seed0):
 
 
 def cpu_baseline_frames(frames, cam, obj, budget_s=14.0):
-    """Oracle (1 thread) on the same frames: the same stages, chained frame to frame like FramePipeline does."""
-    from tests import oracle_lib, frontend_ref as R, tracking_ref as T
+    """Oracle (1 thread) on the same frames: the same stages, chained frame to frame like FramePipeline does
+    (tests/pipeline_ref.py composes the oracle's functions; the LM oracle supplies pose and inliers)."""
+    from tests import oracle_lib
+    from tests.pipeline_ref import OraclePipeline
     from tests.test_oracle_flow2 import run_oracle
-    from vdo_slam_amd import synth, synth_frames as SF
-    from vdo_slam_amd.tracking import DynObjParamsC
     o = oracle_lib.load()
+    pipe = OraclePipeline(o)
     n = 0
+    t_lm_cam = t_lm_obj = 0.0
     t0 = time.perf_counter()
-    stage = {"depth": 0.0, "orb": 0.0, "frame": 0.0, "lm_cam": 0.0, "lm_obj": 0.0, "tracking_k11_k15": 0.0}
-    K4 = np.array(synth.KITTI_K, np.float32)
-    last = None
-    Tl = np.eye(4, dtype=np.float32)
-    max_id = 1
     while True:
         k = n % len(frames)
-        fr = frames[k]
         t = time.perf_counter()
-        d = fr["depth_raw"].copy()
-        o.vdo_oracle_depth_preprocess(R._fp(d), d.size, SF.BF, SF.DEPTH_MAP_FACTOR)
-        stage["depth"] += time.perf_counter() - t; t = time.perf_counter()
-        mask = fr["mask"]
-        if last is not None:                                                            # K15, K11
-            mask, _ = T.update_mask(o, last["ob"]["label"], last["ob"]["corr_x"], last["ob"]["corr_y"], last["mask"], last["flow"], mask)
-            sd = T.propagate_static(o, last["st"]["corr_x"], last["st"]["corr_y"], d)
-            od, osem = T.propagate_object(o, last["ob"]["corr_x"], last["ob"]["corr_y"], d, mask, SF.TH_DEPTH_OBJ)
-        stage["tracking_k11_k15"] += time.perf_counter() - t; t = time.perf_counter()
-        kp = R.extract(o, fr["gray"])
-        stage["orb"] += time.perf_counter() - t; t = time.perf_counter()
-        st = R.static_filter(o, kp["x"], kp["y"], kp["octave"], mask, d, fr["flow"], SF.TH_DEPTH_BG)
-        ob = R.object_sample(o, mask, d, fr["flow"], SF.TH_DEPTH_OBJ)
-        stage["frame"] += time.perf_counter() - t; t = time.perf_counter()
         Tc, _, inl, _, _ = run_oracle(o, cam[k])
-        Tc = Tc.astype(np.float32)
-        stage["lm_cam"] += time.perf_counter() - t; t = time.perf_counter()
-        if last is not None:                                                            # K13 + DynObjTracking
-            lo = last["ob"]
-            fl, olab = T.scene_flow(o, (lo["corr_x"], lo["corr_y"], od, osem), Tc, (lo["key_x"], lo["key_y"], lo["depth"], lo["label"]), Tl, K4,
-                                    np.full(od.size, -2, np.int32))
-            prm = DynObjParamsC(fr["mask"].shape[1], fr["mask"].shape[0], 25, 50, 0.12, 0.3, SF.TH_DEPTH_OBJ, n)
-            dyn = T.dyn_obj_tracking(o, prm, osem, olab, lo["corr_x"], lo["corr_y"], od, fl, lo["label"], last["sem_pos"], last["mod"], np.ones(len(last["mod"]), np.uint8), max_id)
-            max_id = dyn["max_id"]
-        stage["tracking_k11_k15"] += time.perf_counter() - t; t = time.perf_counter()
+        t_lm_cam += time.perf_counter() - t
+        pipe.step(frames[k], Tc.astype(np.float32), inl)
+        t = time.perf_counter()
         for p in obj[k]:
             run_oracle(o, p)
-        stage["lm_obj"] += time.perf_counter() - t; t = time.perf_counter()
-        if last is not None:                                                            # K14 + K12 + tracklets
-            ns = last["st"]["corr_x"].size
-            tm = np.where(inl[np.arange(ns) % inl.size] != 0, np.arange(ns), -1).astype(np.int32)
-            rs = T.renew_static(o, tm, last["st"]["corr_x"], last["st"]["corr_y"], kp["x"], kp["y"], mask, d, fr["flow"], 1200)
-            Twc = np.linalg.inv(Tc.astype(np.float64)).astype(np.float32)
-            T.get3d_world(o, rs["key_x"], rs["key_y"], rs["depth"], K4, Twc)
-            tmp = dict(x=ob["key_x"], y=ob["key_y"], depth=ob["depth"], label=ob["label"], flow_x=ob["flow_x"], flow_y=ob["flow_y"], corr_x=ob["corr_x"], corr_y=ob["corr_y"])
-            ro = T.renew_object(o, dyn["objects"], np.ones(len(dyn["objects"]), np.uint8), dyn["sem"], dyn["mod"], lo["corr_x"], lo["corr_y"], dyn["obj_label"], tmp, mask, d, fr["flow"], 800)
-            T.get3d_world(o, ro["key_x"], ro["key_y"], ro["depth"], K4, Twc)
-            assos_s.append(rs["inlier_id"]); assos_d.append(ro["inlier_id"]); labs_d.append(ro["obj_label"])
-            T.build_tracks(o, assos_s); T.build_tracks(o, assos_d, labs_d)              # the reference rebuilds every tracklet from frame 0
-            st = dict(corr_x=rs["corr_x"], corr_y=rs["corr_y"])
-            ob = dict(key_x=ro["key_x"], key_y=ro["key_y"], corr_x=ro["corr_x"], corr_y=ro["corr_y"], depth=ro["depth"], label=ro["sem"])
-            sem_pos, mod = dyn["sem"], dyn["mod"]
-        else:
-            assos_s, assos_d, labs_d = [], [], []
-            sem_pos, mod = np.zeros(0, np.int32), np.zeros(0, np.int32)
-        stage["tracking_k11_k15"] += time.perf_counter() - t
-        last = dict(st=st, ob=ob, mask=mask, flow=fr["flow"], sem_pos=sem_pos, mod=mod)
-        Tl = Tc
+        t_lm_obj += time.perf_counter() - t
         n += 1
         if time.perf_counter() - t0 > budget_s or n >= 40:
             break
     dt = time.perf_counter() - t0
+    stage = dict(pipe.stage_s, lm_cam=t_lm_cam, lm_obj=t_lm_obj)
     return n / dt, n, {k2: v / n * 1e3 for k2, v in stage.items()}
 
 
@@ -184,8 +140,15 @@ def main():
     from vdo_slam_amd.flow2 import Flow2Batch
     from vdo_slam_amd.frontend import FrameImages, ORBextractor
 
-    ctx = Context(local, stream.cuda_stream)
-    ctx_lm = Context(local)               # second HIP stream: the per-frame LM kernels overlap the ORB front-end of the same frame
+    n_lm_cu = int(os.environ.get("VDO_BENCH_LM_CUS", "0"))      # measured: no gain from CU partitioning (the LM kernel is not slowed by its neighbours)
+    if n_lm_cu > 0:
+        # the LM chain gets CUs of its own (one latency-bound workgroup per problem); everything else runs on the other CUs
+        ctx = Context(local, cu_mask=(0, n_lm_cu, True))
+        ctx_lm = Context(local, cu_mask=(0, n_lm_cu, False))
+        ctx_ba = Context(local, stream.cuda_stream)          # batch / roofline legs: whole chip, torch's stream
+    else:
+        ctx = ctx_ba = Context(local, stream.cuda_stream)
+        ctx_lm = Context(local)           # second HIP stream: the per-frame LM kernels overlap the ORB front-end of the same frame
     frames, cam, obj = make_frame_inputs(seed0=1000 * (rank + 1))
     W, H = synth.KITTI_W, synth.KITTI_H
     # ---- inputs resident in HBM
@@ -195,29 +158,10 @@ def main():
     obj_b = [Flow2Batch(ctx_lm, ps) for ps in obj]
     # The per-frame sequence runs in the C++ host class FramePipeline (vdo_slam_amd/host/FramePipeline.cc: the hot
     # part of Tracking::GrabImageRGBD + Track over the C-ABI, state chained frame to frame); one ctypes call per frame.
-    host = C.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "vdo_slam_amd", "libvdo_host.so"))
-
-    class PipelineParams(C.Structure):
-        _fields_ = [("width", C.c_int), ("height", C.c_int), ("K4", C.c_float * 4), ("bf", C.c_float), ("depth_map_factor", C.c_float),
-                    ("th_depth_bg", C.c_float), ("th_depth_obj", C.c_float), ("max_track_bg", C.c_int), ("max_track_obj", C.c_int),
-                    ("sf_mg_thres", C.c_float), ("sf_ds_thres", C.c_float), ("n_features", C.c_int), ("n_levels", C.c_int), ("ini_th", C.c_int),
-                    ("min_th", C.c_int), ("scale_factor", C.c_float)]
-
-    class FrameCounts(C.Structure):
-        _fields_ = [(k_, C.c_int) for k_ in ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects",
-                                             "n_recovered_masks", "n_static_tracks", "n_dynamic_tracks")]
-
-    prm = PipelineParams(W, H, (C.c_float * 4)(*synth.KITTI_K), SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, 1200, 800,
-                         0.12, 0.3, 2500, 8, 20, 7, 1.2)          # example/kitti-0000-0013.yaml
-    host.host_pipeline_create.restype = C.c_void_p
-    host.host_pipeline_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PipelineParams)]
-    host.host_pipeline_step.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.POINTER(FrameCounts)]
-    host.host_pipeline_destroy.argtypes = [C.c_void_p]
-    pipe = host.host_pipeline_create(ctx._h, ctx_lm._h, C.byref(prm))
-    if not pipe:
-        raise SystemExit("FramePipeline could not be created")
+    from vdo_slam_amd.pipeline import FramePipeline, kitti_params
+    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ))
     torch.cuda.synchronize()
-    counts = FrameCounts()
+    counts = pipe.counts
     n_cam = cam[0].n
 
     def step(i):
@@ -227,10 +171,7 @@ def main():
         # problems (the RANSAC initialisers that would seed them are SURVEY §8f-2); everything else is chained data.
         k = i % N_DISTINCT_FRAMES
         d = dev[k]
-        rc = host.host_pipeline_step(pipe, d["gray"].data_ptr(), d["depth"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr(),
-                                     cam_b[k]._h, obj_b[k]._h, n_cam, len(obj[k]), C.byref(counts))
-        if rc != 0:
-            raise SystemExit("FramePipeline.Step failed (see stderr)")
+        pipe.step(d["gray"].data_ptr(), d["depth"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr(), cam_b[k], obj_b[k], n_cam, len(obj[k]))
 
     def barrier():
         torch.cuda.synchronize()
@@ -252,11 +193,8 @@ def main():
     dt = float(tt.item())
     fps = world * args.steps / dt
     lm = cam_b[0].fetch()[0]
-    sect = (C.c_double * 9)()
-    host.host_pipeline_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-    host.host_pipeline_timing(pipe, sect)
     n_all = args.steps + args.warmup
-    sect_names = ("k1_k15_k11", "orb", "k9_k10", "wait_cam_lm", "k13_dynobj", "renew_static", "wait_obj_lm", "renew_object", "tracklets")
+    sect = pipe.section_ms()
 
     out = {
         "metric": "frames/sec (per-frame hot path, KITTI-0000-shaped 1242x375) + ms/LM-iter (batch factor graph)",
@@ -271,13 +209,13 @@ def main():
                    "static_tracked": counts.n_static_tracked, "object_points_tracked": counts.n_object_tracked, "objects": counts.n_objects,
                    "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
                    "camera_lm_iterations": int(lm["iterations"]),
-                   "host_ms_per_section": {k_: round(sect[j] / n_all, 4) for j, k_ in enumerate(sect_names)}},
+                   "host_ms_per_section": {k_: round(v_ / n_all, 4) for k_, v_ in sect.items()}},
     }
 
     if not args.no_batch:
         # ---- batch leg: LM outer iterations on the KITTI-shaped full-batch graph (configs[2] shape)
         g = synth.make_ba_graph(60, 30000, 5, 800, seed=1 + rank)
-        ba = BatchBA(ctx, g)
+        ba = BatchBA(ctx_ba, g)
         ba.optimize(max_iterations=1, gain_threshold=-1.0)
         ba.set_estimates(g.pose, g.point)
         barrier()
@@ -293,7 +231,7 @@ def main():
             try:
                 from vdo_slam_amd.dist import ShardedBatchBA
                 gs = synth.make_ba_graph(60, 30000, 5, 800, seed=1)
-                sh = ShardedBatchBA(ctx, gs)
+                sh = ShardedBatchBA(ctx_ba, gs)
                 sh.optimize(max_iterations=1, gain_threshold=-1.0)
                 sh.ba.set_estimates(sh.shard.pose, sh.shard.point)
                 calls0 = sh.hook.calls
@@ -309,7 +247,7 @@ def main():
                 out["batch_sharded_error"] = repr(e)[:300]
         # ---- roofline of the dominant kernel (K18 sweep) on an HBM-sized graph
         gr = synth.make_ba_graph(200, args.roofline_static, 10, 1500, seed=7 + rank)
-        bar = BatchBA(ctx, gr)
+        bar = BatchBA(ctx_ba, gr)
         bar.linearize()
         sweep_ms = bar.linearize(repeat=30, timed=True)
         bytes_launch = 208 * gr.n_eb + 452 * gr.n_et + 96 * gr.n_point     # SURVEY.md §8d B_sweep terms of this kernel

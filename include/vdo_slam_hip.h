@@ -43,6 +43,10 @@ int vdo_ctx_create(int device, void* hip_stream, vdo_ctx** out);
 int vdo_ctx_destroy(vdo_ctx* ctx);
 int vdo_ctx_synchronize(vdo_ctx* ctx);
 int vdo_ctx_stream(vdo_ctx* ctx, void** hip_stream_out);   /* the hipStream_t all calls are ordered on */
+/* Context with an owned stream restricted to the compute units [cu_first, cu_first+cu_count) (invert != 0:
+ * to every CU except those).  The per-frame LM kernels are one latency-bound workgroup per problem: giving
+ * them CUs of their own keeps the image kernels of the same frame (which run concurrently) off their SIMDs. */
+int vdo_ctx_create_cu_mask(int device, int cu_first, int cu_count, int invert, vdo_ctx** out);
 
 /* ---- batch dynamic bundle adjustment ------------------------------------------------------
  * Replaces the g2o calls inside Optimizer::FullBatchOptimization (reference

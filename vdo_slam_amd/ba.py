@@ -14,9 +14,15 @@ from . import _capi as K
 
 
 class Context:
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, cu_mask: tuple | None = None):
+        """``cu_mask=(first, count, invert)``: own stream restricted to (or excluding) a range of compute units."""
         self._h = C.c_void_p()
-        K.check(K.lib().vdo_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
+        if cu_mask is not None:
+            L = K.lib()
+            L.vdo_ctx_create_cu_mask.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+            K.check(L.vdo_ctx_create_cu_mask(device, cu_mask[0], cu_mask[1], int(cu_mask[2]), C.byref(self._h)))
+        else:
+            K.check(K.lib().vdo_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(self._h)))
         self.device = device
 
     @property

@@ -71,3 +71,32 @@ extern "C" int vdo_ctx_stream(vdo_ctx* ctx, void** hip_stream_out) {
   *hip_stream_out = (void*)ctx->stream;
   return VDO_OK;
 }
+
+// A context whose (owned) stream may only use the compute units [cu_first, cu_first + cu_count) - or, with
+// `invert`, every CU except those.  Used to give the latency-bound per-frame LM kernels (one workgroup per
+// problem) CUs of their own while the image kernels of the same frame run on the rest of the chip.
+extern "C" int vdo_ctx_create_cu_mask(int device, int cu_first, int cu_count, int invert, vdo_ctx** out) {
+  if (!out || cu_first < 0 || cu_count <= 0) return vdo::set_error(VDO_ERR_INVALID, "vdo_ctx_create_cu_mask: bad argument");
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0)
+    return vdo::set_error(VDO_ERR_NO_DEVICE, "no HIP device available (%s); libvdo_hip has no CPU fallback", e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+  if (device < 0 || device >= n) return vdo::set_error(VDO_ERR_INVALID, "device %d out of range [0,%d)", device, n);
+  if (hipSetDevice(device) != hipSuccess) return vdo::set_error(VDO_ERR_NO_DEVICE, "hipSetDevice failed");
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return vdo::set_error(VDO_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+  const int ncu = prop.multiProcessorCount;
+  if (cu_first + cu_count > ncu) return vdo::set_error(VDO_ERR_INVALID, "CU range [%d,%d) exceeds the %d CUs of the device", cu_first, cu_first + cu_count, ncu);
+  const int words = (ncu + 31) / 32;
+  uint32_t mask[32] = {0};
+  for (int c = 0; c < ncu; ++c) {
+    const bool in = c >= cu_first && c < cu_first + cu_count;
+    if (in != (invert != 0)) mask[c / 32] |= 1u << (c % 32);
+  }
+  vdo_ctx* c = new vdo_ctx();
+  c->device = device;
+  if (hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)words, mask) != hipSuccess) { delete c; return vdo::set_error(VDO_ERR_NO_DEVICE, "hipExtStreamCreateWithCUMask failed"); }
+  c->owns_stream = true;
+  *out = c;
+  return VDO_OK;
+}

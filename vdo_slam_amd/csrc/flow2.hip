@@ -364,12 +364,14 @@ struct vdo_flow2_batch {
   Flow2Arrays A{};
   std::vector<int64_t> offs;
   std::vector<int> ns;
+  char* h_pin = nullptr;          // pinned staging of the results: [results NP][flow_out 2T doubles][inlier_out T bytes]
 };
 
 extern "C" int vdo_flow2_batch_destroy(vdo_flow2_batch* b) {
   if (!b) return VDO_OK;
   if (b->ctx) ctx_bind(b->ctx);
   for (void* p : b->allocs) hipFree(p);
+  if (b->h_pin) hipHostFree(b->h_pin);
   delete b;
   return VDO_OK;
 }
@@ -430,6 +432,7 @@ extern "C" int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_fl
   hipMemcpyAsync(d_dep, dep.data(), 8 * T, hipMemcpyHostToDevice, s);
   hipMemcpyAsync(b->d_probs, hp.data(), sizeof(Flow2Dev) * NP, hipMemcpyHostToDevice, s);
   hipMemsetAsync(A.xl, 0, 16 * T + 8 * NP + 8, s);
+  if (hipHostMalloc((void**)&b->h_pin, sizeof(vdo_flow2_result) * NP + 16 * T + T + 64) != hipSuccess) { b->h_pin = nullptr; vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipHostMalloc failed"); }
   if (hipStreamSynchronize(s) != hipSuccess) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_NO_DEVICE, "flow2 upload failed"); }
   *out = b;
   return VDO_OK;
@@ -450,14 +453,22 @@ extern "C" int vdo_flow2_batch_fetch(vdo_flow2_batch* b, vdo_flow2_result* resul
   int rc = ctx_bind(b->ctx);
   if (rc != VDO_OK) return rc;
   hipStream_t s = b->ctx->stream;
-  hipMemcpyAsync(results, b->A.results, sizeof(vdo_flow2_result) * b->n_problems, hipMemcpyDeviceToHost, s);
-  for (int k = 0; k < b->n_problems; ++k) {
-    if (b->ns[k] == 0) continue;
-    if (flow_out && flow_out[k]) hipMemcpyAsync(flow_out[k], b->A.flow_out + 2 * b->offs[k], sizeof(double) * 2 * b->ns[k], hipMemcpyDeviceToHost, s);
-    if (inlier_out && inlier_out[k]) hipMemcpyAsync(inlier_out[k], b->A.inlier_out + b->offs[k], b->ns[k], hipMemcpyDeviceToHost, s);
-  }
+  // everything through the pinned block (pageable D2H copies cost ~50-100 us each): 1-3 copies, one sync, then memcpy
+  const size_t NP = (size_t)b->n_problems, T = (size_t)b->total;
+  vdo_flow2_result* pr = (vdo_flow2_result*)b->h_pin;
+  double* pf = (double*)(b->h_pin + sizeof(vdo_flow2_result) * NP);
+  uint8_t* pi = (uint8_t*)(pf + 2 * T);
+  hipMemcpyAsync(pr, b->A.results, sizeof(vdo_flow2_result) * NP, hipMemcpyDeviceToHost, s);
+  if (flow_out && T) hipMemcpyAsync(pf, b->A.flow_out, 16 * T, hipMemcpyDeviceToHost, s);
+  if (inlier_out && T) hipMemcpyAsync(pi, b->A.inlier_out, T, hipMemcpyDeviceToHost, s);
   hipError_t e = hipStreamSynchronize(s);
   if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "flow2 fetch: %s", hipGetErrorString(e));
+  std::memcpy(results, pr, sizeof(vdo_flow2_result) * NP);
+  for (int k = 0; k < b->n_problems; ++k) {
+    if (b->ns[k] == 0) continue;
+    if (flow_out && flow_out[k]) std::memcpy(flow_out[k], pf + 2 * b->offs[k], sizeof(double) * 2 * b->ns[k]);
+    if (inlier_out && inlier_out[k]) std::memcpy(inlier_out[k], pi + b->offs[k], (size_t)b->ns[k]);
+  }
   return VDO_OK;
 }
 

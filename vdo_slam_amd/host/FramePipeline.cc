@@ -87,8 +87,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   float Tcw[16];
   for (int i = 0; i < 16; ++i) Tcw[i] = Tcw_last_[i];
   inl_out_.assign(std::max(n_cam_pts, 1), 1);
-  if (cam) {
-    VDO_TRY(vdo_ctx_synchronize(ctx_lm_));
+  if (cam) {                                             // (the fetch is stream-ordered behind the kernel and synchronises once)
     vdo_flow2_result r;
     flow_out_.resize(2 * (size_t)std::max(n_cam_pts, 1));
     double* fo = flow_out_.data(); uint8_t* io = inl_out_.data();
@@ -150,7 +149,6 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     tick(5);
     // ---- consume the object results, RenewFrameInfo (objects)                      Tracking.cc:2806-2995
     if (obj) {
-      VDO_TRY(vdo_ctx_synchronize(ctx_lm_));
       std::vector<vdo_flow2_result> rs(std::max(n_obj_problems, 1));
       VDO_TRY(vdo_flow2_batch_fetch(obj, rs.data(), nullptr, nullptr));
     }

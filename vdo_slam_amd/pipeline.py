@@ -1,0 +1,69 @@
+"""ctypes handle on the C++ ``FramePipeline`` (vdo_slam_amd/host/FramePipeline.{h,cc}): the per-frame
+sequence of Tracking::GrabImageRGBD + Track over the C-ABI.  Used by bench.py and the tests."""
+import ctypes as C
+import os
+
+from . import _capi as K
+
+HOST_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libvdo_host.so")
+
+
+class PipelineParams(C.Structure):
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("K4", C.c_float * 4), ("bf", C.c_float), ("depth_map_factor", C.c_float),
+                ("th_depth_bg", C.c_float), ("th_depth_obj", C.c_float), ("max_track_bg", C.c_int), ("max_track_obj", C.c_int),
+                ("sf_mg_thres", C.c_float), ("sf_ds_thres", C.c_float), ("n_features", C.c_int), ("n_levels", C.c_int), ("ini_th", C.c_int),
+                ("min_th", C.c_int), ("scale_factor", C.c_float)]
+
+
+class FrameCounts(C.Structure):
+    _fields_ = [(k, C.c_int) for k in ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects",
+                                       "n_recovered_masks", "n_static_tracks", "n_dynamic_tracks")]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+SECTIONS = ("k1_k15_k11", "orb", "k9_k10", "wait_cam_lm", "k13_dynobj", "renew_static", "wait_obj_lm", "renew_object", "tracklets")
+
+
+def kitti_params(width, height, K4, bf, depth_map_factor, th_bg, th_obj):
+    """example/kitti-0000-0013.yaml: MaxTrackPointBG 1200, MaxTrackPointOBJ 800, SFMgThres 0.12, SFDsThres 0.3, ORB 2500/1.2/8/20/7."""
+    return PipelineParams(width, height, (C.c_float * 4)(*K4), bf, depth_map_factor, th_bg, th_obj, 1200, 800, 0.12, 0.3, 2500, 8, 20, 7, 1.2)
+
+
+class FramePipeline:
+    def __init__(self, ctx, ctx_lm, params: PipelineParams):
+        if not os.path.exists(HOST_LIB):
+            raise K.VdoError(f"{HOST_LIB} missing: run __graft_entry__.build()")
+        L = self._L = C.CDLL(HOST_LIB)
+        L.host_pipeline_create.restype = C.c_void_p
+        L.host_pipeline_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PipelineParams)]
+        L.host_pipeline_step.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.POINTER(FrameCounts)]
+        L.host_pipeline_destroy.argtypes = [C.c_void_p]
+        L.host_pipeline_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
+        self._keep = (ctx, ctx_lm)
+        self._h = L.host_pipeline_create(ctx._h, ctx_lm._h, C.byref(params))
+        if not self._h:
+            raise K.VdoError("FramePipeline could not be created")
+        self.counts = FrameCounts()
+
+    def step(self, d_gray: int, d_depth_raw: int, d_flow: int, d_mask: int, cam_batch=None, obj_batch=None, n_cam_pts=0, n_obj_problems=0):
+        """Device pointers of the raw inputs + the frame's (resident) pose problems.  Returns the counts of the frame."""
+        rc = self._L.host_pipeline_step(self._h, d_gray, d_depth_raw, d_flow, d_mask, cam_batch._h if cam_batch else None,
+                                        obj_batch._h if obj_batch else None, n_cam_pts, n_obj_problems, C.byref(self.counts))
+        if rc != 0:
+            raise K.VdoError("FramePipeline.Step failed: " + (K.lib().vdo_last_error() or b"").decode())
+        return self.counts.as_dict()
+
+    def section_ms(self):
+        ms = (C.c_double * 9)()
+        self._L.host_pipeline_timing(self._h, ms)
+        return dict(zip(SECTIONS, ms))
+
+    def close(self):
+        if self._h:
+            self._L.host_pipeline_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try: self.close()
+        except Exception: pass
