@@ -16,7 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def lib():
     if not os.path.exists(K.LIB_PATH):
         subprocess.run(["make", "-C", os.path.join(ROOT, "vdo_slam_amd", "csrc"), "-j8"], check=True)
-    return C.CDLL(K.LIB_PATH)
+    return K.lib()
 
 
 def _declared_symbols():

@@ -25,9 +25,7 @@ class HostMapFlat(C.Structure):
 
 @pytest.fixture(scope="module")
 def host():
-    path = os.path.join(ROOT, "vdo_slam_amd", "libvdo_host.so")
-    assert os.path.exists(path), "libvdo_host.so missing: run __graft_entry__.build()"
-    L = C.CDLL(path)
+    L = K.load_host_lib()
     L.host_batch_optimization.argtypes = [C.POINTER(HostMapFlat), C.c_int, K.c_float_p, K.c_float_p, K.c_float_p, K.c_float_p, C.POINTER(K.LMStatsC)]
     return L
 

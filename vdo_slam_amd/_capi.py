@@ -147,9 +147,42 @@ def lib() -> C.CDLL:
             raise RuntimeError(
                 f"{LIB_PATH} is missing: the HIP extension has not been built "
                 "(run `python -c 'import __graft_entry__ as g; g.build()'`). There is no CPU fallback.")
+        _share_hip_runtime_with_torch()
         _lib = C.CDLL(LIB_PATH)
         _declare(_lib)
     return _lib
+
+
+def load_host_lib() -> C.CDLL:
+    """libvdo_host.so (C++ classes with the reference's signatures, links libvdo_hip.so)."""
+    path = os.path.join(_HERE, "libvdo_host.so")
+    if not os.path.exists(path):
+        raise RuntimeError(f"{path} is missing: run __graft_entry__.build()")
+    lib()                                          # same HIP runtime, libvdo_hip resolved first
+    return C.CDLL(path)
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so; if libvdo_hip pulled in
+    /opt/rocm's copy first, a later ``import torch`` would load a SECOND runtime that finds no device ("No HIP
+    GPUs are available").  Loading torch's copy first (without importing torch) makes the dynamic linker resolve
+    libvdo_hip's DT_NEEDED libamdhip64.so.N to it by SONAME, whichever of the two the process imports first."""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                                     # torch already brought its runtime in
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
 
 
 def _declare(L):

@@ -33,9 +33,7 @@ def kitti_params(width, height, K4, bf, depth_map_factor, th_bg, th_obj):
 
 class FramePipeline:
     def __init__(self, ctx, ctx_lm, params: PipelineParams):
-        if not os.path.exists(HOST_LIB):
-            raise K.VdoError(f"{HOST_LIB} missing: run __graft_entry__.build()")
-        L = self._L = C.CDLL(HOST_LIB)
+        L = self._L = K.load_host_lib()
         L.host_pipeline_create.restype = C.c_void_p
         L.host_pipeline_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PipelineParams)]
         L.host_pipeline_step.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.POINTER(FrameCounts)]
