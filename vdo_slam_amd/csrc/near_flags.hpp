@@ -1,32 +1,39 @@
 // "Is there a reference point within 1 px" for every query point — the O(n*m) test of
-// Tracking::RenewFrameInfo (reference src/Tracking.cc:2727-2745 static, :2893-2907 objects), tiled
-// through LDS.  Float arithmetic as in the reference: sqrt((rx-qx)^2 + (ry-qy)^2) < 1.
+// Tracking::RenewFrameInfo (reference src/Tracking.cc:2727-2745 static, :2893-2907 objects).
+// Float arithmetic as in the reference: sqrt((rx-qx)^2 + (ry-qy)^2) < 1.
+// 2-D grid: block (bx, by) tests 256 queries against 256 references staged in LDS and ORs its verdict
+// into used[] (callers zero it first): a few hundred workgroups instead of ~20 that each walk the whole
+// reference set (83 -> ~6 us for 5.5 k x 3.9 k points).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace vdo {
 
-// used[i] = exists j: sqrt((rx[j]-qx[i])^2 + (ry[j]-qy[i])^2) < 1
 static __global__ __launch_bounds__(256) void k_near_flags(int nq, const float* __restrict__ qx, const float* __restrict__ qy,
                                                            int nr, const float* __restrict__ rx, const float* __restrict__ ry, int32_t* __restrict__ used) {
   __shared__ float sx[256], sy[256];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  const float x = i < nq ? qx[i] : 0.f, y = i < nq ? qy[i] : 0.f;
+  const int base = blockIdx.y * 256;
+  const int j = base + threadIdx.x;
+  sx[threadIdx.x] = j < nr ? rx[j] : 1e30f;
+  sy[threadIdx.x] = j < nr ? ry[j] : 1e30f;
+  __syncthreads();
+  if (i >= nq) return;
+  const float x = qx[i], y = qy[i];
+  const int m = min(256, nr - base);
   int u = 0;
-  for (int base = 0; base < nr; base += 256) {
-    const int j = base + threadIdx.x;
-    sx[threadIdx.x] = j < nr ? rx[j] : 1e30f;
-    sy[threadIdx.x] = j < nr ? ry[j] : 1e30f;
-    __syncthreads();
-    const int m = min(256, nr - base);
-    for (int k = 0; k < m; ++k) {
-      const float dx = sx[k] - x, dy = sy[k] - y;
-      if (sqrtf(dx * dx + dy * dy) < 1.0f) u = 1;
-    }
-    __syncthreads();
+  for (int k = 0; k < m; ++k) {
+    const float dx = sx[k] - x, dy = sy[k] - y;
+    if (sqrtf(dx * dx + dy * dy) < 1.0f) u = 1;
   }
-  if (i < nq) used[i] = u;
+  if (u) atomicOr(&used[i], 1);
+}
+
+// used[0..nq) = 0, then the 2-D launch
+static inline void launch_near_flags(hipStream_t s, int nq, const float* qx, const float* qy, int nr, const float* rx, const float* ry, int32_t* used) {
+  hipMemsetAsync(used, 0, sizeof(int32_t) * (size_t)nq, s);
+  if (nq > 0 && nr > 0) hipLaunchKernelGGL(k_near_flags, dim3((nq + 255) / 256, (nr + 255) / 256), dim3(256), 0, s, nq, qx, qy, nr, rx, ry, used);
 }
 
 }  // namespace vdo

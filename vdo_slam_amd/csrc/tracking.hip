@@ -268,7 +268,7 @@ extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm
   const int n_check = m;
   if (m < max_num_sta && n_orb) {
     float *dcx = S.up(key_x, n_check), *dcy = S.up(key_y, n_check);
-    hipLaunchKernelGGL(k_near_flags, dim3((n_orb + 255) / 256), dim3(256), 0, S.s, n_orb, (const float*)dx2, (const float*)dy2, n_check, (const float*)dcx, (const float*)dcy, dused);
+    launch_near_flags(S.s, n_orb, dx2, dy2, n_check, dcx, dcy, dused);
     S.down(used2.data(), dused, n_orb); S.down(ok2.data(), dok2, n_orb); S.down(fx2.data(), dfx2, n_orb); S.down(fy2.data(), dfy2, n_orb); S.down(d2.data(), dd2, n_orb);
     rc = S.finish("vdo_renew_static (top-up)");
     if (rc != VDO_OK) return rc;

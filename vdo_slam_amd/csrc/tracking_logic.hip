@@ -63,10 +63,23 @@ __global__ __launch_bounds__(256) void k_label_vote(int n, const float* __restri
     }
   }
   __syncthreads();
+  // most frequent label, smallest on ties: every thread scans 4 bins, then a (count desc, label asc) reduction
+  __shared__ int s_cnt[256], s_lab[256];
+  {
+    int best = threadIdx.x * 4, cnt = hist[best];
+    for (int l = best + 1; l < threadIdx.x * 4 + 4; ++l) if (hist[l] > cnt) { cnt = hist[l]; best = l; }
+    s_cnt[threadIdx.x] = cnt; s_lab[threadIdx.x] = best;
+  }
+  __syncthreads();
+  for (int step = 128; step > 0; step >>= 1) {
+    if (threadIdx.x < step) {
+      const int c2 = s_cnt[threadIdx.x + step], l2 = s_lab[threadIdx.x + step];
+      if (c2 > s_cnt[threadIdx.x] || (c2 == s_cnt[threadIdx.x] && l2 < s_lab[threadIdx.x])) { s_cnt[threadIdx.x] = c2; s_lab[threadIdx.x] = l2; }
+    }
+    __syncthreads();
+  }
   if (threadIdx.x == 0) {
-    int best = 0, cnt = -1;
-    for (int l = 0; l < kVoteBins; ++l) if (hist[l] > cnt) { cnt = hist[l]; best = l; }
-    flag[0] = (s_valid >= 100 && best == 0 && !s_bad) ? 1 : 0;
+    flag[0] = (s_valid >= 100 && s_lab[0] == 0 && !s_bad) ? 1 : 0;
     flag[1] = s_bad;
   }
 }
@@ -263,7 +276,7 @@ extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* i
     float *dqx = S.up(tmp_x, n_tmp), *dqy = S.up(tmp_y, n_tmp), *drx = S.up(key_x, n_check), *dry = S.up(key_y, n_check);
     int32_t* dused = S.up<int32_t>(nullptr, n_tmp);
     if (!dused) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-    hipLaunchKernelGGL(k_near_flags, dim3((n_tmp + 255) / 256), dim3(256), 0, S.s, n_tmp, (const float*)dqx, (const float*)dqy, n_check, (const float*)drx, (const float*)dry, dused);
+    launch_near_flags(S.s, n_tmp, dqx, dqy, n_check, drx, dry, dused);
     S.down(used.data(), dused, n_tmp);
     rc = S.finish("vdo_renew_object (top-up)");
     if (rc != VDO_OK) return rc;
