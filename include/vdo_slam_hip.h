@@ -229,6 +229,33 @@ int vdo_pose_batch_fetch(vdo_pose_batch* batch, vdo_flow2_result* results, uint8
 int vdo_pose_batch_destroy(vdo_pose_batch* batch);
 int vdo_pose_optimize(vdo_ctx* ctx, const vdo_pose_problem* p, vdo_flow2_result* result, uint8_t* inlier_out);
 
+/* ---- RANSAC initialiser of the per-frame pose problems -------------------------------
+ * What Tracking::GetInitModelCam / GetInitModelObj (reference src/Tracking.cc:1614-1715, 1717-1849) get from
+ * cv::solvePnPRansac(pre_3d, cur_2d, K, distCoeffs = 0, rvec, tvec, false, 500, 0.4, 0.98, inliers,
+ * SOLVEPNP_AP3P): the sequential RANSAC of OpenCV 3.4 (cv::RNG subsets of 4 points, minimal P3P solve on 3 with
+ * the 4th as tie-breaker, inliers = squared reprojection error <= thr^2, iteration budget shrunk by
+ * RANSACUpdateNumIters) with every hypothesis solved and voted on the GPU at once and the loop replayed on the
+ * host over the votes.  OpenCV's final EPnP refit on the inliers is NOT applied (the LM refinement that follows in
+ * the reference starts from this pose).  T = [R|t] camera-from-world (what Rodrigues(rvec), tvec give). */
+typedef struct vdo_pnp_problem {
+  int32_t n;
+  const double* X;          /* [n][3] 3-D points (pre_3d)                         */
+  const double* uv;         /* [n][2] pixels (cur_2d)                             */
+  double K[4];              /* fx, fy, cx, cy                                     */
+  int32_t max_iterations;   /* 500                                                */
+  double reproj_threshold;  /* 0.4 px                                             */
+  double confidence;        /* 0.98                                               */
+} vdo_pnp_problem;
+typedef struct vdo_pnp_result {
+  double T[16];             /* 4x4 row-major; identity when no model was found    */
+  int32_t n_inliers;        /* inliers.rows                                       */
+  int32_t iterations_run;   /* hypotheses the sequential loop would have examined */
+  int32_t best_iteration;   /* index of the winning hypothesis (-1: none)         */
+} vdo_pnp_result;
+/* All problems of a frame (camera + every object) in one call: two launches, one synchronisation. */
+int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_problem* probs, vdo_pnp_result* results, uint8_t** inlier_out);
+int vdo_pnp_ransac(vdo_ctx* ctx, const vdo_pnp_problem* p, vdo_pnp_result* result, uint8_t* inlier_out);
+
 /* ---- ORB front-end ------------------------------------------------------------------------------
  * Replaces ORBextractor::ORBextractor (reference src/ORBextractor.cc:399-459) and
  * ORBextractor::operator() (:1035-1110): ComputePyramid (:1112-1137), ComputeKeyPointsOctTree

@@ -161,6 +161,13 @@ int vdo_oracle_update_mask(int n, const int32_t* last_sem_label, const float* la
 int vdo_oracle_build_tracks(int n_frames, const int32_t* asso_off, const int32_t* asso, const int32_t* feat_label,
                             int cap_tracks, int cap_pairs, int32_t* track_off, int32_t* pair_frame, int32_t* pair_feat, int32_t* obj_id);
 
+/* ---- RANSAC initialiser (p3p_oracle.cpp): cv::solvePnPRansac(AP3P) restated up to the final refit --------*/
+int vdo_oracle_quartic(double a4, double a3, double a2, double a1, double a0, double* roots);
+int vdo_oracle_p3p(const double* f9, const double* P9, double* R_out, double* t_out);
+void vdo_oracle_ransac_subsets(int n, int max_iters, int32_t* idx);
+int vdo_oracle_p3p_ransac(int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence,
+                          double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter);
+
 /* ---- front-end (frontend_oracle.cpp) ------------------------------------------------------*/
 typedef struct vdo_orb_params {   /* ORBextractor ctor arguments (include/ORBextractor.h:39-40) */
   int32_t n_features;     /* 2500 */

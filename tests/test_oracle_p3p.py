@@ -1,0 +1,110 @@
+"""KATs for the RANSAC initialiser oracle (oracle/p3p_oracle.cpp): quartic roots vs numpy, the P3P quartic
+coefficients vs the geometry they were derived from, pose recovery on exact data, RANSAC on contaminated data."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from vdo_slam_amd import _capi as K
+from vdo_slam_amd.synth import KITTI_K, rotvec_to_R
+
+dp = K.c_double_p
+
+
+def _bind(o):
+    o.vdo_oracle_quartic.argtypes = [C.c_double] * 5 + [dp]
+    o.vdo_oracle_p3p.argtypes = [dp, dp, dp, dp]
+    o.vdo_oracle_ransac_subsets.argtypes = [C.c_int, C.c_int, K.c_int32_p]
+    o.vdo_oracle_p3p_ransac.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_double, C.c_double, dp, K.c_uint8_p, K.c_int32_p, K.c_int32_p]
+    return o
+
+
+def test_quartic_roots_match_numpy(oracle):
+    o = _bind(oracle)
+    rng = np.random.default_rng(0)
+    for trial in range(300):
+        if trial % 3 == 0:                       # 4 real roots
+            r = rng.uniform(-3, 3, 4); co = np.poly(r)
+        elif trial % 3 == 1:                     # 2 real + complex pair
+            z = complex(rng.uniform(-2, 2), rng.uniform(0.2, 2)); co = np.real(np.poly([rng.uniform(-3, 3), rng.uniform(-3, 3), z, z.conjugate()]))
+        else:
+            co = rng.normal(0, 1, 5); co[0] = rng.uniform(0.5, 2)
+        co = co * rng.uniform(0.1, 10)
+        out = np.zeros(4)
+        n = o.vdo_oracle_quartic(*[float(c) for c in co], K._dp(out))
+        ref = np.roots(co)
+        ref = np.sort(ref[np.abs(ref.imag) < 1e-9].real)
+        got = np.sort(out[:n])
+        assert n == ref.size, (trial, co, got, ref)
+        np.testing.assert_allclose(got, ref, rtol=1e-7, atol=1e-8)
+
+
+def _scene(rng, n, outlier_frac=0.0, pix_sigma=0.0):
+    fx, fy, cx, cy = KITTI_K
+    R = rotvec_to_R(rng.normal(0, 0.2, 3)); t = rng.normal(0, 1.0, 3)
+    Xc = np.c_[rng.uniform(-15, 15, n), rng.uniform(-3, 3, n), rng.uniform(4, 40, n)]
+    Xw = (Xc - t) @ R                                     # Xc = R Xw + t
+    uv = np.c_[fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy] + rng.normal(0, pix_sigma, (n, 2)) if pix_sigma else np.c_[fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy]
+    out = rng.random(n) < outlier_frac
+    uv[out] += rng.uniform(-60, 60, (int(out.sum()), 2))
+    return np.ascontiguousarray(Xw), np.ascontiguousarray(uv), R, t, out
+
+
+def test_p3p_contains_the_true_pose(oracle):
+    o = _bind(oracle)
+    rng = np.random.default_rng(1)
+    fx, fy, cx, cy = KITTI_K
+    hits = 0
+    for trial in range(200):
+        Xw, uv, R, t, _ = _scene(rng, 3)
+        f = np.c_[(uv[:, 0] - cx) / fx, (uv[:, 1] - cy) / fy, np.ones(3)]
+        f /= np.linalg.norm(f, axis=1, keepdims=True)
+        Ro = np.zeros((4, 9)); to = np.zeros((4, 3))
+        n = o.vdo_oracle_p3p(K._dp(np.ascontiguousarray(f)), K._dp(Xw), K._dp(Ro), K._dp(to))
+        assert 1 <= n <= 4
+        errs = [max(np.abs(Ro[s].reshape(3, 3) - R).max(), np.abs(to[s] - t).max()) for s in range(n)]
+        for s in range(n):                                # every returned pose is a rotation that maps the 3 points onto their rays
+            Rs = Ro[s].reshape(3, 3)
+            np.testing.assert_allclose(Rs @ Rs.T, np.eye(3), atol=1e-9)
+            assert np.linalg.det(Rs) > 0
+            Xc = Xw @ Rs.T + to[s]
+            np.testing.assert_allclose(Xc / np.linalg.norm(Xc, axis=1, keepdims=True), f, atol=2e-5)   # ill-conditioned triangles lose digits in the quartic
+        hits += min(errs) < 1e-6
+    assert hits >= 198                                    # (near-degenerate triangles may lose the root to rounding)
+
+
+def test_subsets_are_distinct_and_deterministic(oracle):
+    o = _bind(oracle)
+    a = np.zeros((500, 4), np.int32); b = np.zeros((500, 4), np.int32)
+    o.vdo_oracle_ransac_subsets(1200, 500, a.ctypes.data_as(K.c_int32_p)); o.vdo_oracle_ransac_subsets(1200, 500, b.ctypes.data_as(K.c_int32_p))
+    assert np.array_equal(a, b) and a.min() >= 0 and a.max() < 1200
+    assert all(len(set(r)) == 4 for r in a.tolist())
+    c = np.zeros((50, 4), np.int32)
+    o.vdo_oracle_ransac_subsets(5, 50, c.ctypes.data_as(K.c_int32_p))
+    assert all(len(set(r)) == 4 for r in c.tolist())
+
+
+@pytest.mark.parametrize("n,outl", [(1200, 0.3), (300, 0.5), (60, 0.1), (4, 0.0)])
+def test_ransac_finds_the_pose_among_outliers(oracle, n, outl):
+    o = _bind(oracle)
+    rng = np.random.default_rng(n)
+    Xw, uv, R, t, is_out = _scene(rng, n, outl, pix_sigma=0.1)
+    T = np.zeros(16); inl = np.zeros(n, np.uint8); its = C.c_int32(); bi = C.c_int32()
+    K4 = np.array(KITTI_K, np.float64)
+    good = o.vdo_oracle_p3p_ransac(n, K._dp(Xw), K._dp(uv), K._dp(K4), 500, 0.4, 0.98, K._dp(T), inl.ctypes.data_as(K.c_uint8_p), C.byref(its), C.byref(bi))
+    T = T.reshape(4, 4)
+    assert good == inl.sum() and good >= 4
+    assert its.value <= 500 and 0 <= bi.value < its.value
+    if n >= 60:
+        assert good > 0.5 * (~is_out).sum()
+        assert not inl[is_out].any() or inl[is_out].sum() <= 2
+        assert np.abs(T[:3, :3] - R).max() < 5e-3 and np.abs(T[:3, 3] - t).max() < 0.1
+        assert its.value < 500                             # the confidence rule stopped early
+
+
+def test_ransac_with_too_few_points(oracle):
+    o = _bind(oracle)
+    T = np.zeros(16)
+    X = np.zeros((3, 3)); uv = np.zeros((3, 2)); K4 = np.array(KITTI_K, np.float64)
+    assert o.vdo_oracle_p3p_ransac(3, K._dp(X), K._dp(uv), K._dp(K4), 500, 0.4, 0.98, K._dp(T), None, None, None) == 0
+    assert np.array_equal(T.reshape(4, 4), np.eye(4))

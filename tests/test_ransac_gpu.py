@@ -1,0 +1,62 @@
+"""GPU RANSAC initialiser (vdo_slam_amd/csrc/ransac.hip) against the oracle's sequential run: same winning
+hypothesis, same number of iterations examined, same inlier set; pose to 1e-9."""
+import ctypes as C
+import time
+
+import numpy as np
+import pytest
+
+from tests.test_oracle_p3p import _bind, _scene
+from vdo_slam_amd import _capi as K
+from vdo_slam_amd.ba import Context
+from vdo_slam_amd.ransac import pnp_ransac_batch
+from vdo_slam_amd.synth import KITTI_K
+
+pytestmark = pytest.mark.gpu
+
+
+def _oracle(o, Xw, uv):
+    n = Xw.shape[0]
+    T = np.zeros(16); inl = np.zeros(max(n, 1), np.uint8); its = C.c_int32(); bi = C.c_int32()
+    K4 = np.array(KITTI_K, np.float64)
+    good = o.vdo_oracle_p3p_ransac(n, K._dp(Xw), K._dp(uv), K._dp(K4), 500, 0.4, 0.98, K._dp(T), inl.ctypes.data_as(K.c_uint8_p), C.byref(its), C.byref(bi))
+    return dict(T=T.reshape(4, 4), n_inliers=good, iterations_run=its.value, best_iteration=bi.value, inliers=inl[:n])
+
+
+def test_batch_matches_the_sequential_oracle(oracle):
+    o = _bind(oracle)
+    ctx = Context(0)
+    rng = np.random.default_rng(5)
+    cases = [(1200, 0.3), (800, 0.5), (400, 0.2), (150, 0.7), (60, 0.0), (4, 0.0), (3, 0.0), (0, 0.0)]
+    probs = []
+    for n, outl in cases:
+        if n:
+            Xw, uv, R, t, _ = _scene(rng, n, outl, pix_sigma=0.1)
+        else:
+            Xw, uv = np.zeros((0, 3)), np.zeros((0, 2))
+        probs.append((Xw, uv))
+    got = pnp_ransac_batch(ctx, probs, KITTI_K)
+    for (n, outl), g, (Xw, uv) in zip(cases, got, probs):
+        e = _oracle(o, Xw, uv)
+        assert g["n_inliers"] == e["n_inliers"] and g["iterations_run"] == e["iterations_run"] and g["best_iteration"] == e["best_iteration"], (n, g, e)
+        assert np.array_equal(g["inliers"], e["inliers"])
+        assert np.abs(g["T"] - e["T"]).max() < 1e-9
+    assert got[0]["n_inliers"] > 700 and got[0]["iterations_run"] < 500
+    assert got[6]["n_inliers"] == 0 and np.array_equal(got[6]["T"], np.eye(4))
+
+
+def test_pure_outliers_run_the_full_budget(oracle):
+    """No consistent pose (what the bench's chained random frames produce): all 500 hypotheses are examined."""
+    o = _bind(oracle)
+    ctx = Context(0)
+    rng = np.random.default_rng(9)
+    Xw = np.c_[rng.uniform(-15, 15, 1200), rng.uniform(-3, 3, 1200), rng.uniform(4, 40, 1200)]
+    uv = np.c_[rng.uniform(0, 1242, 1200), rng.uniform(0, 375, 1200)]
+    g = pnp_ransac_batch(ctx, [(Xw, uv)], KITTI_K)[0]
+    e = _oracle(o, Xw, uv)
+    assert g["iterations_run"] == e["iterations_run"] == 500
+    assert g["n_inliers"] == e["n_inliers"] and g["best_iteration"] == e["best_iteration"] and np.array_equal(g["inliers"], e["inliers"])
+    t0 = time.perf_counter()
+    for _ in range(20):
+        pnp_ransac_batch(ctx, [(Xw, uv)], KITTI_K)
+    print("ransac 1200 pts x 500 hyp: %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3))

@@ -1,0 +1,323 @@
+// RANSAC initialiser of the per-frame pose problems on gfx950: what
+// Tracking::GetInitModelCam / GetInitModelObj obtain from cv::solvePnPRansac(pre_3d, cur_2d, K, 0, ..., 500 iterations,
+// 0.4 px, confidence 0.98, SOLVEPNP_AP3P) (reference src/Tracking.cc:1652-1655, 1755-1758), up to OpenCV's final
+// EPnP refit (the LM refinement that follows starts from this pose; see oracle/p3p_oracle.cpp for the scheme restated).
+//
+// The sequential algorithm is kept — same subsets (cv::RNG stream, drawn on the host: 2 000 integers), same
+// acceptance and budget rule — but its two data-parallel parts run at once for ALL hypotheses:
+//   k_p3p_hyp      one thread per hypothesis: minimal solver on 3 points (quartic in d3/d1 + absolute orientation),
+//                  4th point picks among the <= 4 solutions
+//   k_ransac_vote  one workgroup per hypothesis: squared reprojection error of every correspondence, inlier count
+//                  and inlier bit-mask
+// and the host then replays the loop over the 500 counts (a better model shrinks the iteration budget), which
+// yields exactly the model, inlier set and iteration count the sequential run would have produced.
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/vdo_slam_hip.h"
+#include "arena.hpp"
+#include "ctx.hpp"
+
+namespace vdo {
+
+struct PnpDev {          // one problem inside the batch arrays
+  int n, n_hyp, pt_off, hyp_off, mask_off, mask_words, pad0, pad1;
+  double K[4];
+  double thr2;
+};
+
+__device__ __forceinline__ double d3dot(const double* a, const double* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+__device__ __forceinline__ void d3cross(const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
+__device__ __forceinline__ bool d3unit(double* a) { const double n = sqrt(d3dot(a, a)); if (!(n > 1e-300)) return false; a[0] /= n; a[1] /= n; a[2] /= n; return true; }
+
+// real roots of x^4 + b x^3 + c x^2 + d x + e: depressed quartic, positive root of the resolvent cubic, two quadratics; Newton polish
+__device__ int quartic_real_roots(double b, double c, double d, double e, double* roots) {
+  const double p = c - 3 * b * b / 8, q = d - b * c / 2 + b * b * b / 8, r = e - b * d / 4 + b * b * c / 16 - 3 * b * b * b * b / 256;
+  double y[4];
+  int n = 0;
+  const double scale = fabs(p) + fabs(r) + 1e-300;
+  if (fabs(q) < 1e-14 * scale) {
+    const double disc = p * p - 4 * r;
+    if (disc >= 0) {
+      const double s = sqrt(disc);
+      const double w0 = (-p + s) / 2, w1 = (-p - s) / 2;
+      if (w0 >= 0) { y[n++] = sqrt(w0); y[n++] = -sqrt(w0); }
+      if (w1 >= 0) { y[n++] = sqrt(w1); y[n++] = -sqrt(w1); }
+    }
+  } else {
+    const double A = 2 * p, B = p * p - 4 * r, C = -q * q;
+    const double P = B - A * A / 3, Q = 2 * A * A * A / 27 - A * B / 3 + C;
+    const double disc = Q * Q / 4 + P * P * P / 27;
+    double t;
+    if (disc >= 0) {
+      const double s = sqrt(disc);
+      t = cbrt(-Q / 2 + s) + cbrt(-Q / 2 - s);
+    } else {
+      const double m = 2 * sqrt(-P / 3);
+      double arg = 3 * Q / (P * m);
+      arg = fmin(1.0, fmax(-1.0, arg));
+      t = m * cos(acos(arg) / 3);
+    }
+    double z = t - A / 3;
+#pragma unroll
+    for (int it = 0; it < 3; ++it) {
+      const double f = ((z + A) * z + B) * z + C, fp = (3 * z + 2 * A) * z + B;
+      if (fp != 0) z -= f / fp;
+    }
+    if (z > 0) {
+      const double s = sqrt(z);
+      const double h1 = (p + z - q / s) / 2, h2 = (p + z + q / s) / 2;
+      const double d1 = s * s - 4 * h1, d2 = s * s - 4 * h2;
+      if (d1 >= 0) { const double w = sqrt(d1); y[n++] = (-s + w) / 2; y[n++] = (-s - w) / 2; }
+      if (d2 >= 0) { const double w = sqrt(d2); y[n++] = (s + w) / 2; y[n++] = (s - w) / 2; }
+    }
+  }
+  for (int i = 0; i < n; ++i) {
+    double x = y[i] - b / 4;
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+      const double f = (((x + b) * x + c) * x + d) * x + e, fp = ((4 * x + 3 * b) * x + 2 * c) * x + d;
+      if (fp != 0) x -= f / fp;
+    }
+    roots[i] = x;
+  }
+  return n;
+}
+
+// orthonormal frame (columns e1 e2 e3) of a triangle: e1 along P2-P1, e3 its normal
+__device__ bool tri_frame(const double* P1, const double* P2, const double* P3, double* B) {
+  double e1[3] = {P2[0] - P1[0], P2[1] - P1[1], P2[2] - P1[2]}, w[3] = {P3[0] - P1[0], P3[1] - P1[1], P3[2] - P1[2]}, e3[3], e2[3];
+  if (!d3unit(e1)) return false;
+  d3cross(e1, w, e3);
+  if (!d3unit(e3)) return false;
+  d3cross(e3, e1, e2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { B[3 * i] = e1[i]; B[3 * i + 1] = e2[i]; B[3 * i + 2] = e3[i]; }
+  return true;
+}
+
+__device__ __forceinline__ double reproj_err2(const double* R, const double* t, const double* K4, const double* X, double u, double v) {
+  const double x = R[0] * X[0] + R[1] * X[1] + R[2] * X[2] + t[0], y = R[3] * X[0] + R[4] * X[1] + R[5] * X[2] + t[1],
+               z = R[6] * X[0] + R[7] * X[1] + R[8] * X[2] + t[2];
+  const double du = K4[0] * x / z + K4[2] - u, dv = K4[1] * y / z + K4[3] - v;
+  return du * du + dv * dv;
+}
+
+// hyp_pose [n_hyp_total][12] (R row-major | t), hyp_ok [n_hyp_total]
+__global__ __launch_bounds__(64) void k_p3p_hyp(const PnpDev* __restrict__ probs, const double* __restrict__ X, const double* __restrict__ uv,
+                                                const int32_t* __restrict__ subsets, double* __restrict__ hyp_pose, int32_t* __restrict__ hyp_ok) {
+  const PnpDev P = probs[blockIdx.y];
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= P.n_hyp) return;
+  const int32_t* idx = subsets + 4 * (size_t)(P.hyp_off + h);
+  const double* Xp = X + 3 * (size_t)P.pt_off;
+  const double* up = uv + 2 * (size_t)P.pt_off;
+  double f[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    f[k][0] = (up[2 * idx[k]] - P.K[2]) / P.K[0]; f[k][1] = (up[2 * idx[k] + 1] - P.K[3]) / P.K[1]; f[k][2] = 1.0;
+    d3unit(f[k]);
+  }
+  const double *P1 = Xp + 3 * idx[0], *P2 = Xp + 3 * idx[1], *P3 = Xp + 3 * idx[2], *P4 = Xp + 3 * idx[3];
+  const double u4 = up[2 * idx[3]], v4 = up[2 * idx[3] + 1];
+  double* out = hyp_pose + 12 * (size_t)(P.hyp_off + h);
+  int ok = 0;
+  double d23[3] = {P2[0] - P3[0], P2[1] - P3[1], P2[2] - P3[2]}, d13[3] = {P1[0] - P3[0], P1[1] - P3[1], P1[2] - P3[2]}, d12[3] = {P1[0] - P2[0], P1[1] - P2[1], P1[2] - P2[2]};
+  const double a2 = d3dot(d23, d23), b2 = d3dot(d13, d13), c2 = d3dot(d12, d12);
+  const double ca = d3dot(f[1], f[2]), cb = d3dot(f[0], f[2]), cg = d3dot(f[0], f[1]);
+  double Bw[9];
+  if (a2 > 0 && b2 > 0 && c2 > 0 && tri_frame(P1, P2, P3, Bw)) {
+    // Grunert's quartic in v = d3/d1 (coefficients: resultant of the three cosine-law equations, see tests/test_oracle_p3p.py)
+    const double A4 = a2 * a2 - 2 * a2 * b2 - 2 * a2 * c2 + b2 * b2 - 4 * b2 * c2 * ca * ca + 2 * b2 * c2 + c2 * c2;
+    const double A3 = -4 * (a2 * a2 * cb - a2 * b2 * ca * cg - a2 * b2 * cb - 2 * a2 * c2 * cb + b2 * b2 * ca * cg - 2 * b2 * c2 * ca * ca * cb - b2 * c2 * ca * cg + b2 * c2 * cb + c2 * c2 * cb);
+    const double A2 = 2 * (2 * a2 * a2 * cb * cb + a2 * a2 - 4 * a2 * b2 * ca * cb * cg - 2 * a2 * b2 * cg * cg - 4 * a2 * c2 * cb * cb - 2 * a2 * c2 + 2 * b2 * b2 * ca * ca +
+                           2 * b2 * b2 * cg * cg - b2 * b2 - 2 * b2 * c2 * ca * ca - 4 * b2 * c2 * ca * cb * cg + 2 * c2 * c2 * cb * cb + c2 * c2);
+    const double A1 = -4 * (a2 * a2 * cb - a2 * b2 * ca * cg - 2 * a2 * b2 * cb * cg * cg + a2 * b2 * cb - 2 * a2 * c2 * cb + b2 * b2 * ca * cg - b2 * c2 * ca * cg - b2 * c2 * cb + c2 * c2 * cb);
+    const double A0 = a2 * a2 - 4 * a2 * b2 * cg * cg + 2 * a2 * b2 - 2 * a2 * c2 + b2 * b2 - 2 * b2 * c2 + c2 * c2;
+    if (fabs(A4) > 1e-300) {
+      double vr[4];
+      const int nr = quartic_real_roots(A3 / A4, A2 / A4, A1 / A4, A0 / A4, vr);
+      double best = DBL_MAX;
+      for (int k = 0; k < nr; ++k) {
+        const double v = vr[k];
+        if (!(v > 0)) continue;
+        const double den = 2 * b2 * (ca * v - cg);
+        if (!(fabs(den) > 1e-300)) continue;
+        const double u = -(-2 * a2 * cb * v + a2 * v * v + a2 - b2 * v * v + b2 + 2 * c2 * cb * v - c2 * v * v - c2) / den;
+        if (!(u > 0)) continue;
+        const double w = 1 + v * v - 2 * v * cb;
+        if (!(w > 0)) continue;
+        const double d1 = sqrt(b2 / w), d2 = u * d1, d3 = v * d1;
+        const double X1[3] = {d1 * f[0][0], d1 * f[0][1], d1 * f[0][2]}, X2[3] = {d2 * f[1][0], d2 * f[1][1], d2 * f[1][2]}, X3[3] = {d3 * f[2][0], d3 * f[2][1], d3 * f[2][2]};
+        double Bc[9], R[9], t[3];
+        if (!tri_frame(X1, X2, X3, Bc)) continue;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int j = 0; j < 3; ++j) R[3 * i + j] = Bc[3 * i] * Bw[3 * j] + Bc[3 * i + 1] * Bw[3 * j + 1] + Bc[3 * i + 2] * Bw[3 * j + 2];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) t[i] = X1[i] - (R[3 * i] * P1[0] + R[3 * i + 1] * P1[1] + R[3 * i + 2] * P1[2]);
+        const double e4 = reproj_err2(R, t, P.K, P4, u4, v4);
+        if (e4 < best) {        // first smallest wins, like the sequential scan over the solutions
+          best = e4; ok = 1;
+#pragma unroll
+          for (int i = 0; i < 9; ++i) out[i] = R[i];
+          out[9] = t[0]; out[10] = t[1]; out[11] = t[2];
+        }
+      }
+    }
+  }
+  hyp_ok[P.hyp_off + h] = ok;
+}
+
+// one workgroup per (hypothesis, problem): inlier count + bit-mask of squared reprojection error <= thr^2
+__global__ __launch_bounds__(256) void k_ransac_vote(const PnpDev* __restrict__ probs, const double* __restrict__ X, const double* __restrict__ uv,
+                                                     const double* __restrict__ hyp_pose, const int32_t* __restrict__ hyp_ok,
+                                                     int32_t* __restrict__ count, uint32_t* __restrict__ mask) {
+  const PnpDev P = probs[blockIdx.y];
+  const int h = blockIdx.x;
+  if (h >= P.n_hyp) return;
+  __shared__ int s_cnt[4];
+  const int gh = P.hyp_off + h;
+  uint32_t* mrow = mask + (size_t)P.mask_off + (size_t)h * P.mask_words;
+  if (!hyp_ok[gh]) {
+    for (int w = threadIdx.x; w < P.mask_words; w += 256) mrow[w] = 0;
+    if (threadIdx.x == 0) count[gh] = 0;
+    return;
+  }
+  double R[9], t[3];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) R[i] = hyp_pose[12 * (size_t)gh + i];
+  t[0] = hyp_pose[12 * (size_t)gh + 9]; t[1] = hyp_pose[12 * (size_t)gh + 10]; t[2] = hyp_pose[12 * (size_t)gh + 11];
+  const double* Xp = X + 3 * (size_t)P.pt_off;
+  const double* up = uv + 2 * (size_t)P.pt_off;
+  int c = 0;
+  const int n_pad = (P.n + 63) & ~63;
+  for (int i = threadIdx.x; i < n_pad; i += 256) {
+    bool in = false;
+    if (i < P.n) in = reproj_err2(R, t, P.K, Xp + 3 * i, up[2 * i], up[2 * i + 1]) <= P.thr2;
+    const unsigned long long b = __ballot(in);
+    c += in;
+    if ((threadIdx.x & 63) == 0) { mrow[i >> 5] = (uint32_t)b; if ((i >> 5) + 1 < P.mask_words) mrow[(i >> 5) + 1] = (uint32_t)(b >> 32); }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off, 64);
+  if ((threadIdx.x & 63) == 0) s_cnt[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) count[gh] = s_cnt[0] + s_cnt[1] + s_cnt[2] + s_cnt[3];
+}
+
+// cv::RNG
+struct CvRng {
+  uint64_t state;
+  explicit CvRng(uint64_t s) : state(s ? s : 0xffffffffULL) {}
+  unsigned next() { state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32); return (unsigned)state; }
+  int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+};
+
+static int ransac_update_iters(double p, double ep, int model_points, int max_iters) {     // RANSACUpdateNumIters
+  p = std::min(1.0, std::max(0.0, p)); ep = std::min(1.0, std::max(0.0, ep));
+  double num = std::max(1.0 - p, DBL_MIN);
+  double denom = 1.0 - std::pow(1.0 - ep, model_points);
+  if (denom < DBL_MIN) return 0;
+  num = std::log(num); denom = std::log(denom);
+  return denom >= 0 || -num >= max_iters * (-denom) ? max_iters : (int)std::lrint(num / denom);
+}
+
+}  // namespace vdo
+
+using namespace vdo;
+
+extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_problem* probs, vdo_pnp_result* results, uint8_t** inlier_out) {
+  if (!ctx || !probs || !results || n_problems <= 0) return set_error(VDO_ERR_INVALID, "vdo_pnp_ransac_batch: bad argument");
+  int rc = ctx_bind(ctx);
+  if (rc != VDO_OK) return rc;
+  std::vector<PnpDev> hp(n_problems);
+  size_t tot_pts = 0, tot_hyp = 0, tot_words = 0;
+  int max_hyp = 0;
+  for (int k = 0; k < n_problems; ++k) {
+    const vdo_pnp_problem& p = probs[k];
+    if (p.n < 0 || p.max_iterations < 0 || (p.n > 0 && (!p.X || !p.uv))) return set_error(VDO_ERR_INVALID, "pnp problem %d: bad fields", k);
+    PnpDev& d = hp[k];
+    d.n = p.n; d.n_hyp = p.n >= 4 ? p.max_iterations : 0;
+    d.pt_off = (int)tot_pts; d.hyp_off = (int)tot_hyp; d.mask_off = (int)tot_words; d.mask_words = (p.n + 63) / 64 * 2;
+    std::memcpy(d.K, p.K, sizeof d.K);
+    d.thr2 = p.reproj_threshold * p.reproj_threshold;
+    tot_pts += p.n; tot_hyp += d.n_hyp; tot_words += (size_t)d.n_hyp * d.mask_words;
+    max_hyp = std::max(max_hyp, d.n_hyp);
+  }
+  for (int k = 0; k < n_problems; ++k) {
+    vdo_pnp_result& r = results[k];
+    for (int i = 0; i < 16; ++i) r.T[i] = (i % 5 == 0) ? 1.0 : 0.0;
+    r.n_inliers = 0; r.iterations_run = 0; r.best_iteration = -1;
+    if (inlier_out && inlier_out[k] && probs[k].n) std::memset(inlier_out[k], 0, (size_t)probs[k].n);
+  }
+  if (tot_hyp == 0) return VDO_OK;
+  // the subsets the sequential loop would draw (getSubset: 4 distinct indices by rejection, RNG seeded with (uint64)-1 per call)
+  std::vector<int32_t> subsets(4 * tot_hyp);
+  std::vector<double> X(3 * tot_pts), uv(2 * tot_pts);
+  for (int k = 0; k < n_problems; ++k) {
+    const PnpDev& d = hp[k];
+    if (d.n) { std::memcpy(X.data() + 3 * (size_t)d.pt_off, probs[k].X, sizeof(double) * 3 * d.n); std::memcpy(uv.data() + 2 * (size_t)d.pt_off, probs[k].uv, sizeof(double) * 2 * d.n); }
+    CvRng rng((uint64_t)-1);
+    for (int it = 0; it < d.n_hyp; ++it) {
+      int32_t* s = subsets.data() + 4 * ((size_t)d.hyp_off + it);
+      for (int i = 0; i < 4; ++i)
+        for (;;) {
+          const int c = rng.uniform(0, d.n);
+          bool dup = false;
+          for (int j = 0; j < i; ++j) dup |= (s[j] == c);
+          if (!dup) { s[i] = c; break; }
+        }
+    }
+  }
+  Arena S(ctx);
+  if (!S.reserve(40 * tot_pts + 128 * tot_hyp + 4 * tot_words + sizeof(PnpDev) * (size_t)n_problems + 16 * 256 + 8192))
+    return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
+  PnpDev* dprob = S.up(hp.data(), (size_t)n_problems);
+  double *dX = S.up(X.data(), X.size()), *duv = S.up(uv.data(), uv.size());
+  int32_t* dsub = S.up(subsets.data(), subsets.size());
+  double* dpose = S.up<double>(nullptr, 12 * tot_hyp);
+  int32_t *dok = S.up<int32_t>(nullptr, tot_hyp), *dcnt = S.up<int32_t>(nullptr, tot_hyp);
+  uint32_t* dmask = S.up<uint32_t>(nullptr, tot_words);
+  if (!dprob || !dX || !duv || !dsub || !dpose || !dok || !dcnt || !dmask) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
+  hipLaunchKernelGGL(k_p3p_hyp, dim3((max_hyp + 63) / 64, n_problems), dim3(64), 0, S.s, (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const int32_t*)dsub, dpose, dok);
+  hipLaunchKernelGGL(k_ransac_vote, dim3(max_hyp, n_problems), dim3(256), 0, S.s, (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const double*)dpose, (const int32_t*)dok, dcnt, dmask);
+  std::vector<int32_t> cnt(tot_hyp), okv(tot_hyp);
+  std::vector<double> pose(12 * tot_hyp);
+  std::vector<uint32_t> mask(tot_words);
+  S.down(cnt.data(), dcnt, tot_hyp); S.down(okv.data(), dok, tot_hyp); S.down(pose.data(), dpose, 12 * tot_hyp); S.down(mask.data(), dmask, tot_words);
+  rc = S.finish("vdo_pnp_ransac_batch");
+  if (rc != VDO_OK) return rc;
+  // replay of RANSACPointSetRegistrator::run over the precomputed votes
+  for (int k = 0; k < n_problems; ++k) {
+    const PnpDev& d = hp[k];
+    if (!d.n_hyp) continue;
+    int niters = d.n_hyp, max_good = 0, it = 0, bi = -1;
+    for (; it < niters; ++it) {
+      const int g = d.hyp_off + it;
+      if (!okv[g]) continue;
+      if (cnt[g] > std::max(max_good, 3)) {
+        max_good = cnt[g]; bi = it;
+        niters = ransac_update_iters(probs[k].confidence, (double)(d.n - cnt[g]) / d.n, 4, niters);
+      }
+    }
+    vdo_pnp_result& r = results[k];
+    r.iterations_run = it; r.best_iteration = bi; r.n_inliers = max_good;
+    if (bi < 0) continue;
+    const double* Pz = pose.data() + 12 * ((size_t)d.hyp_off + bi);
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) r.T[4 * i + j] = Pz[3 * i + j]; r.T[4 * i + 3] = Pz[9 + i]; }
+    if (inlier_out && inlier_out[k]) {
+      const uint32_t* row = mask.data() + (size_t)d.mask_off + (size_t)bi * d.mask_words;
+      for (int i = 0; i < d.n; ++i) inlier_out[k][i] = (row[i >> 5] >> (i & 31)) & 1u;
+    }
+  }
+  return VDO_OK;
+}
+
+extern "C" int vdo_pnp_ransac(vdo_ctx* ctx, const vdo_pnp_problem* p, vdo_pnp_result* result, uint8_t* inlier_out) {
+  return vdo_pnp_ransac_batch(ctx, 1, p, result, &inlier_out);
+}
