@@ -167,8 +167,10 @@ def main():
     def step(i):
         # UpdateMask (K15) -> K1 -> propagation (K11) -> camera LM (K16, stream 2) || ORB (K3-K7) + K9 + K10 ->
         # scene flow (K13) + DynObjTracking -> object LMs (K17, stream 2) || RenewFrameInfo static (K14, K12) ->
-        # RenewFrameInfo objects (K14, K12) -> tracklets.  The LM problems of a frame are pre-built KITTI-shaped
-        # problems (the RANSAC initialisers that would seed them are SURVEY §8f-2); everything else is chained data.
+        # RenewFrameInfo objects (K14, K12) -> tracklets, with the RANSAC-P3P initialisers (GetInitModelCam/Obj) in
+        # front of both LM stages.  The LM problems of a frame are pre-built KITTI-shaped problems (the chained random
+        # frames are not geometrically consistent: RANSAC finds no consensus and runs its full 500-hypothesis budget,
+        # the LM on such data would not be representative); everything else is chained data.
         k = i % N_DISTINCT_FRAMES
         d = dev[k]
         pipe.step(d["gray"].data_ptr(), d["depth"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr(), cam_b[k], obj_b[k], n_cam, len(obj[k]))

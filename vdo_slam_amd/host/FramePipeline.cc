@@ -2,6 +2,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -26,7 +27,7 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
   if (vdo_tracks_create(0, &tr_sta_) != VDO_OK || vdo_tracks_create(1, &tr_dyn_) != VDO_OK) return;
   const int capk = p.n_features + 256;
   kx_.resize(capk); ky_.resize(capk); kr_.resize(capk); ka_.resize(capk); ks_.resize(capk); ko_.resize(capk);
-  for (int i = 0; i < 16; ++i) Tcw_last_[i] = (i % 5 == 0) ? 1.f : 0.f;
+  for (int i = 0; i < 16; ++i) Tcw_last_[i] = vel_[i] = (i % 5 == 0) ? 1.f : 0.f;
   ok_ = true;
 }
 
@@ -59,6 +60,30 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     VDO_TRY(vdo_propagate_object(cur, n_o, obj_.cx.data(), obj_.cy.data(), p_.th_depth_obj, obj_depth.data(), obj_sem.data()));
   } else {
     VDO_TRY(vdo_ctx_synchronize(ctx_));
+  }
+  // ---- GetInitModelCam: RANSAC (P3P) on last frame's 3-D points vs this frame's keys, against the motion model   Tracking.cc:1614-1715
+  if (have_last_ && n_s >= 4) {
+    std::vector<double>& X = d_[0]; std::vector<double>& uvd = d_[1];
+    X.resize(3 * (size_t)n_s); uvd.resize(2 * (size_t)n_s);
+    for (int i = 0; i < n_s; ++i) {
+      X[3 * i] = sta_.xyz[3 * i]; X[3 * i + 1] = sta_.xyz[3 * i + 1]; X[3 * i + 2] = sta_.xyz[3 * i + 2];
+      uvd[2 * i] = sta_.cx[i]; uvd[2 * i + 1] = sta_.cy[i];
+    }
+    vdo_pnp_problem pp{n_s, X.data(), uvd.data(), {p_.K4[0], p_.K4[1], p_.K4[2], p_.K4[3]}, 500, 0.4, 0.98};
+    vdo_pnp_result pr;
+    inl_ransac_.assign(n_s, 0);
+    VDO_TRY(vdo_pnp_ransac(ctx_, &pp, &pr, inl_ransac_.data()));
+    // motion-model inliers (mVelocity * last pose), same 0.4 px gate; the larger set seeds the optimisation
+    float MM[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float a = 0; for (int k = 0; k < 4; ++k) a += vel_[4 * i + k] * Tcw_last_[4 * k + j]; MM[4 * i + j] = a; }
+    int mm = 0;
+    for (int i = 0; i < n_s; ++i) {
+      const float x = sta_.xyz[3 * i], y = sta_.xyz[3 * i + 1], z = sta_.xyz[3 * i + 2];
+      const float xc = MM[0] * x + MM[1] * y + MM[2] * z + MM[3], yc = MM[4] * x + MM[5] * y + MM[6] * z + MM[7], invz = 1.0f / (MM[8] * x + MM[9] * y + MM[10] * z + MM[11]);
+      const float u_ = sta_.cx[i] - (p_.K4[0] * xc * invz + p_.K4[2]), v_ = sta_.cy[i] - (p_.K4[1] * yc * invz + p_.K4[3]);
+      mm += std::sqrt(u_ * u_ + v_ * v_) < 0.4f;
+    }
+    fc.n_ransac_cam = pr.n_inliers; fc.n_motion_model_cam = mm;
   }
   tick(0);
   // ---- camera pose (K16) on the LM stream, front-end of this frame meanwhile      Tracking.cc:690-700 || Frame.cc:61-260
@@ -110,6 +135,12 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     for (auto* v : {&nobj.x, &nobj.y, &nobj.cx, &nobj.cy, &nobj.fx, &nobj.fy, &nobj.d}) v->resize(n_tmp);
     nobj.sem.resize(n_tmp); nobj.label.assign(n_tmp, -2);
     if (obj) VDO_TRY(vdo_ctx_synchronize(ctx_lm_));
+    {
+      const float I4[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
+      nsta.xyz.resize(3 * (size_t)std::max(n_new_s, 1)); nobj.xyz.resize(3 * (size_t)std::max(n_tmp, 1));
+      VDO_TRY(vdo_get3d_world(ctx_, n_new_s, nsta.x.data(), nsta.y.data(), nsta.d.data(), p_.K4, I4, nsta.xyz.data()));   // Get3DinCamera
+      VDO_TRY(vdo_get3d_world(ctx_, n_tmp, nobj.x.data(), nobj.y.data(), nobj.d.data(), p_.K4, I4, nobj.xyz.data()));
+    }
   } else {
     // ---- GetSceneFlowObj (K13) + DynObjTracking                                   Tracking.cc:1278-1612
     std::vector<float>& flow3d = f_[7];
@@ -127,6 +158,24 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
                                  off.data(), idx.data(), osem.data(), omod.data(), &n_objects));
     fc.n_objects = n_objects;
     tick(4);
+    // ---- GetInitModelObj for every accepted object: one batched RANSAC call                   Tracking.cc:1717-1849
+    if (n_objects > 0) {
+      std::vector<double>& X = d_[0]; std::vector<double>& uvd = d_[1];
+      X.resize(3 * (size_t)off[n_objects] + 3); uvd.resize(2 * (size_t)off[n_objects] + 2);
+      std::vector<vdo_pnp_problem> pp(n_objects);
+      std::vector<vdo_pnp_result> pr(n_objects);
+      for (int a = 0; a < n_objects; ++a) {
+        for (int q = off[a]; q < off[a + 1]; ++q) {
+          const int id = idx[q];
+          X[3 * q] = obj_.xyz[3 * id]; X[3 * q + 1] = obj_.xyz[3 * id + 1]; X[3 * q + 2] = obj_.xyz[3 * id + 2];
+          uvd[2 * q] = obj_.cx[id]; uvd[2 * q + 1] = obj_.cy[id];
+        }
+        pp[a] = vdo_pnp_problem{off[a + 1] - off[a], X.data() + 3 * (size_t)off[a], uvd.data() + 2 * (size_t)off[a], {p_.K4[0], p_.K4[1], p_.K4[2], p_.K4[3]}, 500, 0.4, 0.98};
+      }
+      VDO_TRY(vdo_pnp_ransac_batch(ctx_, n_objects, pp.data(), pr.data(), nullptr));
+      for (int a = 0; a < n_objects; ++a) fc.n_ransac_obj += pr[a].n_inliers;
+    }
+    tick(9);
     // ---- object motions (K17) on the LM stream, RenewFrameInfo (static) meanwhile  Tracking.cc:932 || :2666-2805
     if (obj) VDO_TRY(vdo_flow2_batch_run(obj));
     if (frame_filters() != 0) return -1;
@@ -143,9 +192,8 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     sta_asso.resize(m);
     float Twc[16];
     inv_rigid(Tcw, Twc);
-    std::vector<float>& xyz = f_[8];
-    xyz.resize(3 * (size_t)std::max(m, 1));
-    VDO_TRY(vdo_get3d_world(ctx_, m, nsta.x.data(), nsta.y.data(), nsta.d.data(), p_.K4, Twc, xyz.data()));          // mvStat3DPointTmp
+    nsta.xyz.resize(3 * (size_t)std::max(m, 1));
+    VDO_TRY(vdo_get3d_world(ctx_, m, nsta.x.data(), nsta.y.data(), nsta.d.data(), p_.K4, Twc, nsta.xyz.data()));     // mvStat3DPointTmp
     tick(5);
     // ---- consume the object results, RenewFrameInfo (objects)                      Tracking.cc:2806-2995
     if (obj) {
@@ -164,8 +212,8 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
                              nobj.cx.data(), nobj.cy.data(), dyn_asso.data(), nobj.label.data(), &mo));
     for (auto* v : {&nobj.x, &nobj.y, &nobj.cx, &nobj.cy, &nobj.fx, &nobj.fy, &nobj.d}) v->resize(mo);
     nobj.sem.resize(mo); nobj.label.resize(mo); dyn_asso.resize(mo);
-    xyz.resize(3 * (size_t)std::max(mo, 1));
-    VDO_TRY(vdo_get3d_world(ctx_, mo, nobj.x.data(), nobj.y.data(), nobj.d.data(), p_.K4, Twc, xyz.data()));          // mvObj3DPoint
+    nobj.xyz.resize(3 * (size_t)std::max(mo, 1));
+    VDO_TRY(vdo_get3d_world(ctx_, mo, nobj.x.data(), nobj.y.data(), nobj.d.data(), p_.K4, Twc, nobj.xyz.data()));     // mvObj3DPoint
     tick(7);
     // ---- tracklets (incremental GetStaticTrack / GetDynamicTrackNew)               Tracking.cc:2201-2421
     VDO_TRY(vdo_tracks_add_frame(tr_sta_, m, sta_asso.data(), nullptr));
@@ -180,6 +228,11 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   vdo_tracks_size(tr_sta_, &fc.n_static_tracks, &np);
   vdo_tracks_size(tr_dyn_, &fc.n_dynamic_tracks, &np);
   sta_ = std::move(nsta); obj_ = std::move(nobj);
+  {                                                      // mVelocity = mCurrentFrame.mTcw * LastTwc   (Tracking.cc:703-709)
+    float Twl[16];
+    inv_rigid(Tcw_last_, Twl);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float a = 0; for (int k = 0; k < 4; ++k) a += Tcw[4 * i + k] * Twl[4 * k + j]; vel_[4 * i + j] = a; }
+  }
   std::memcpy(Tcw_last_, Tcw, sizeof Tcw);
   cur_ ^= 1; have_last_ = true; ++f_id_;
   if (out) *out = fc;
@@ -201,8 +254,9 @@ FramePipeline* host_pipeline_create(vdo_ctx* ctx, vdo_ctx* ctx_lm, const Pipelin
 }
 void host_pipeline_destroy(FramePipeline* fp) { delete fp; }
 // accumulated wall ms per section since creation: [0] K1+K15+K11, [1] ORB, [2] K9+K10, [3] wait camera LM + fetch,
-// [4] K13 + DynObjTracking, [5] RenewFrameInfo static + K12, [6] wait object LMs + fetch, [7] RenewFrameInfo objects + K12, [8] tracklets
-void host_pipeline_timing(FramePipeline* fp, double* ms9) { for (int i = 0; i < 9; ++i) ms9[i] = fp->ms_[i]; }
+// [4] K13 + DynObjTracking, [5] RenewFrameInfo static + K12, [6] wait object LMs + fetch, [7] RenewFrameInfo objects + K12, [8] tracklets,
+// [9] object RANSAC initialisers ([0] includes the camera one)
+void host_pipeline_timing(FramePipeline* fp, double* ms10) { for (int i = 0; i < 10; ++i) ms10[i] = fp->ms_[i]; }
 int host_pipeline_step(FramePipeline* fp, const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
                        vdo_flow2_batch* cam, vdo_flow2_batch* obj, int n_cam_pts, int n_obj_problems, FrameCounts* out) {
   return fp->Step(d_gray, d_depth_raw, d_flow, d_mask, cam, obj, n_cam_pts, n_obj_problems, out);

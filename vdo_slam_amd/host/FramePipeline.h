@@ -28,7 +28,8 @@ struct PipelineParams {
   int n_features, n_levels, ini_th, min_th; float scale_factor;   // ORBextractor.*
 };
 
-struct FrameCounts { int n_orb, n_static_new, n_object_samples, n_static_tracked, n_object_tracked, n_objects, n_recovered_masks, n_static_tracks, n_dynamic_tracks; };
+struct FrameCounts { int n_orb, n_static_new, n_object_samples, n_static_tracked, n_object_tracked, n_objects, n_recovered_masks, n_static_tracks, n_dynamic_tracks,
+                         n_ransac_cam, n_motion_model_cam, n_ransac_obj; };
 
 class FramePipeline {
  public:
@@ -42,8 +43,8 @@ class FramePipeline {
   double ms_[12] = {0};              // accumulated wall time per section (see host_pipeline_timing)
 
  private:
-  struct ObjSet { std::vector<float> x, y, cx, cy, fx, fy, d; std::vector<int32_t> sem, label; };
-  struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d; };
+  struct ObjSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; std::vector<int32_t> sem, label; };
+  struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; };
   vdo_ctx *ctx_, *ctx_lm_;
   PipelineParams p_;
   vdo_orb* orb_ = nullptr;
@@ -56,11 +57,12 @@ class FramePipeline {
   ObjSet tmp_;                        // K10 output of the current frame (capacity kept across frames)
   ObjSet obj_;                        // last frame: object keys, correspondences, depth, semantic + motion labels
   std::vector<int32_t> last_sem_pos_, last_mod_label_; std::vector<uint8_t> last_obj_stat_;
-  float Tcw_last_[16];
+  float Tcw_last_[16], vel_[16];      // last pose, mVelocity
   // scratch reused across frames
   std::vector<float> kx_, ky_, kr_, ka_, ks_; std::vector<int32_t> ko_;
   std::vector<float> f_[16]; std::vector<int32_t> i_[8];
-  std::vector<double> flow_out_; std::vector<uint8_t> inl_out_;
+  std::vector<double> flow_out_; std::vector<uint8_t> inl_out_, inl_ransac_;
+  std::vector<double> d_[2];
 };
 
 }  // namespace VDO_SLAM

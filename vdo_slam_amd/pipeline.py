@@ -17,13 +17,13 @@ class PipelineParams(C.Structure):
 
 class FrameCounts(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects",
-                                       "n_recovered_masks", "n_static_tracks", "n_dynamic_tracks")]
+                                       "n_recovered_masks", "n_static_tracks", "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
 
 
-SECTIONS = ("k1_k15_k11", "orb", "k9_k10", "wait_cam_lm", "k13_dynobj", "renew_static", "wait_obj_lm", "renew_object", "tracklets")
+SECTIONS = ("k1_k15_k11_ransac_cam", "orb", "k9_k10", "wait_cam_lm", "k13_dynobj", "renew_static", "wait_obj_lm", "renew_object", "tracklets", "ransac_obj")
 
 
 def kitti_params(width, height, K4, bf, depth_map_factor, th_bg, th_obj):
@@ -54,7 +54,7 @@ class FramePipeline:
         return self.counts.as_dict()
 
     def section_ms(self):
-        ms = (C.c_double * 9)()
+        ms = (C.c_double * 10)()
         self._L.host_pipeline_timing(self._h, ms)
         return dict(zip(SECTIONS, ms))
 
