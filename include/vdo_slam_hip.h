@@ -193,6 +193,11 @@ typedef struct vdo_flow2_result {
 typedef struct vdo_flow2_batch vdo_flow2_batch;
 /* Upload n_problems problems (inputs become HBM-resident). */
 int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_flow2_problem* probs, vdo_flow2_batch** out);
+/* Per-frame use: slots of fixed capacity that are (re)defined every frame without re-allocating —
+ * vdo_flow2_batch_reserve once, then per frame vdo_flow2_batch_set (inputs staged through pinned memory,
+ * stream-ordered, no sync; problem == NULL empties a slot) -> run -> fetch. */
+int vdo_flow2_batch_reserve(vdo_ctx* ctx, int n_problems, const int32_t* capacity, vdo_flow2_batch** out);
+int vdo_flow2_batch_set(vdo_flow2_batch* batch, int k, const vdo_flow2_problem* problem);
 /* One kernel launch: every problem is optimised from its initial estimate (stream-ordered, no sync). */
 int vdo_flow2_batch_run(vdo_flow2_batch* batch);
 /* results[n_problems]; flow_out[k] -> [n_k][2] refined flows; inlier_out[k] -> [n_k] (1 = inlier). Synchronises. */

@@ -1,0 +1,47 @@
+"""End-to-end: the full Track() sequence of FramePipeline (build_lm mode: RANSAC initialisers, joint pose+flow LM
+for the camera and every object built from the chained correspondences, RenewFrameInfo, UpdateMask, tracklets) on a
+geometrically consistent synthetic sequence (vdo_slam_amd/synth_seq.py) must recover the camera trajectory and the
+object motions."""
+import numpy as np
+import pytest
+
+from vdo_slam_amd import synth, synth_frames as SF, synth_seq as SQ
+from vdo_slam_amd.ba import Context
+from vdo_slam_amd.pipeline import FramePipeline, kitti_params
+
+pytestmark = pytest.mark.gpu
+W, H = synth.KITTI_W, synth.KITTI_H
+
+
+def test_trajectory_and_object_motions_are_recovered():
+    import torch
+    n_frames = 8
+    Ts = SQ.camera_poses(n_frames)
+    objs = SQ.default_objects()
+    ctx, ctx_lm = Context(0), Context(0)
+    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1))
+    t_err, r_err, tracked = [], [], []
+    for k in range(n_frames):
+        fr = SQ.render_frame(k, Ts, objs)
+        d = {q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")}
+        torch.cuda.synchronize()
+        c = pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
+        Tcw = pipe.pose().astype(np.float64)
+        gt = fr["Tcw"]
+        t_err.append(np.abs(Tcw[:3, 3] - gt[:3, 3]).max()); r_err.append(np.abs(Tcw[:3, :3] - gt[:3, :3]).max())
+        if k >= 1:
+            assert c["n_ransac_cam"] > 0.8 * max(c["n_static_tracked"], 1) or c["n_motion_model_cam"] > 500, (k, c)
+            assert c["n_cam_inliers"] > 400, (k, c)
+        if k >= 2:
+            ms = pipe.motions()
+            tracked.append(len(ms))
+            for m in ms:
+                ob = objs[m["sem_label"] - 1]
+                assert np.abs(m["H"][:3, 3] - ob["v"]).max() < 0.06, (k, m, ob["v"])
+                assert np.abs(m["H"][:3, :3] - np.eye(3)).max() < 0.02
+                assert m["n_inliers"] >= 50
+    # forward motion 0.8 m/frame over 7 steps: drift stays at the centimetre level
+    assert max(t_err) < 0.08 and max(r_err) < 5e-3, (t_err, r_err)
+    assert t_err[1] < 0.02
+    assert max(tracked) >= 1 and c["n_static_tracks"] > 500 and c["n_dynamic_tracks"] > 100
+    pipe.close()

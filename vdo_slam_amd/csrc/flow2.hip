@@ -14,6 +14,7 @@
 // scratch, pose-side sums use wave shuffles + one LDS stage, the 6x6 pivoted LDLT and the SE(3)
 // update run on lane 0.  ref_quirks=1 reproduces the BlockSolver_6_3 / 2-DoF aliasing (F3)
 // exactly as analysed in oracle/flow_oracle.cpp (product code does not use the oracle).
+#include <algorithm>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -365,6 +366,9 @@ struct vdo_flow2_batch {
   std::vector<int64_t> offs;
   std::vector<int> ns;
   char* h_pin = nullptr;          // pinned staging of the results: [results NP][flow_out 2T doubles][inlier_out T bytes]
+  double* h_up = nullptr;         // pinned staging of in-place problem updates: 5 doubles per point of capacity
+  std::vector<Flow2Dev> hp;       // host mirror of d_probs
+  std::vector<int> caps;          // capacity (points) of every problem slot
 };
 
 extern "C" int vdo_flow2_batch_destroy(vdo_flow2_batch* b) {
@@ -372,6 +376,7 @@ extern "C" int vdo_flow2_batch_destroy(vdo_flow2_batch* b) {
   if (b->ctx) ctx_bind(b->ctx);
   for (void* p : b->allocs) hipFree(p);
   if (b->h_pin) hipHostFree(b->h_pin);
+  if (b->h_up) hipHostFree(b->h_up);
   delete b;
   return VDO_OK;
 }
@@ -434,7 +439,61 @@ extern "C" int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_fl
   hipMemsetAsync(A.xl, 0, 16 * T + 8 * NP + 8, s);
   if (hipHostMalloc((void**)&b->h_pin, sizeof(vdo_flow2_result) * NP + 16 * T + T + 64) != hipSuccess) { b->h_pin = nullptr; vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipHostMalloc failed"); }
   if (hipStreamSynchronize(s) != hipSuccess) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_NO_DEVICE, "flow2 upload failed"); }
+  b->hp = hp; b->caps = b->ns;
   *out = b;
+  return VDO_OK;
+}
+
+// Slots for problems that are (re)defined every frame: capacity[k] points each, initially empty.
+extern "C" int vdo_flow2_batch_reserve(vdo_ctx* ctx, int n_problems, const int32_t* capacity, vdo_flow2_batch** out) {
+  if (!ctx || !capacity || !out || n_problems <= 0) return set_error(VDO_ERR_INVALID, "vdo_flow2_batch_reserve: bad argument");
+  int64_t tot = 0;
+  for (int k = 0; k < n_problems; ++k) { if (capacity[k] < 0) return set_error(VDO_ERR_INVALID, "negative capacity"); tot += capacity[k]; }
+  std::vector<double> zeros(2 * (size_t)std::max<int64_t>(1, *std::max_element(capacity, capacity + n_problems)), 0.0);
+  std::vector<vdo_flow2_problem> dummy(n_problems);
+  for (int k = 0; k < n_problems; ++k) {
+    std::memset(&dummy[k], 0, sizeof(vdo_flow2_problem));
+    dummy[k].n = capacity[k]; dummy[k].obs = zeros.data(); dummy[k].flow = zeros.data(); dummy[k].depth = zeros.data();
+  }
+  int rc = vdo_flow2_batch_create(ctx, n_problems, dummy.data(), out);
+  if (rc != VDO_OK) return rc;
+  vdo_flow2_batch* b = *out;
+  if (hipHostMalloc((void**)&b->h_up, sizeof(double) * 5 * (size_t)std::max<int64_t>(tot, 1) + sizeof(Flow2Dev) * (size_t)n_problems) != hipSuccess) { b->h_up = nullptr; vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipHostMalloc failed"); }
+  for (int k = 0; k < n_problems; ++k) { b->hp[k].n = 0; b->ns[k] = 0; }
+  hipMemcpyAsync(b->d_probs, b->hp.data(), sizeof(Flow2Dev) * (size_t)n_problems, hipMemcpyHostToDevice, ctx->stream);
+  if (hipStreamSynchronize(ctx->stream) != hipSuccess) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_NO_DEVICE, "flow2 reserve failed"); }
+  return VDO_OK;
+}
+
+// (Re)define problem k of a reserved batch: inputs go through pinned staging into the slot's HBM arrays,
+// stream-ordered, no synchronisation (the staging of slot k is reused by the next vdo_flow2_batch_set of slot k:
+// run + fetch in between, as a frame does).  p == NULL empties the slot.
+extern "C" int vdo_flow2_batch_set(vdo_flow2_batch* b, int k, const vdo_flow2_problem* p) {
+  if (!b || k < 0 || k >= b->n_problems || !b->h_up) return set_error(VDO_ERR_INVALID, "vdo_flow2_batch_set: bad argument / batch not created by vdo_flow2_batch_reserve");
+  int rc = ctx_bind(b->ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = b->ctx->stream;
+  Flow2Dev& d = b->hp[k];
+  const int n = p ? p->n : 0;
+  if (n < 0 || n > b->caps[k] || (n > 0 && (!p->obs || !p->flow || !p->depth))) return set_error(VDO_ERR_INVALID, "vdo_flow2_batch_set: %d points do not fit slot %d (capacity %d)", n, k, b->caps[k]);
+  if (n) {
+    const int64_t off = b->offs[k];
+    double* st = b->h_up + 5 * off;
+    double *po = st, *pm = st + 2 * (size_t)n, *pd = st + 4 * (size_t)n;
+    for (int i = 0; i < n; ++i) { po[i] = p->obs[2 * i]; po[n + i] = p->obs[2 * i + 1]; pm[i] = p->flow[2 * i]; pm[n + i] = p->flow[2 * i + 1]; pd[i] = p->depth[i]; }
+    hipMemcpyAsync((double*)b->A.obs + 2 * off, po, 16 * (size_t)n, hipMemcpyHostToDevice, s);
+    hipMemcpyAsync((double*)b->A.meas + 2 * off, pm, 16 * (size_t)n, hipMemcpyHostToDevice, s);
+    hipMemcpyAsync((double*)b->A.depth + off, pd, 8 * (size_t)n, hipMemcpyHostToDevice, s);
+    d.max_iterations = p->max_iterations; d.ref_quirks = p->ref_quirks;
+    std::memcpy(d.K, p->K, sizeof(d.K)); std::memcpy(d.Twl, p->Twl, sizeof(d.Twl)); std::memcpy(d.T0, p->T0, sizeof(d.T0));
+    d.info_flow = p->info_flow; d.info_prior = p->info_prior; d.huber_delta = p->huber_delta;
+    d.huber_dsqr = (double)(float)(p->huber_delta * p->huber_delta);
+    d.chi2_gate = p->chi2_gate;
+  }
+  d.n = n; b->ns[k] = n;
+  Flow2Dev* pst = (Flow2Dev*)(b->h_up + 5 * (size_t)std::max<int64_t>(b->total, 1)) + k;       // pinned copy of the descriptor
+  *pst = d;
+  hipMemcpyAsync(b->d_probs + k, pst, sizeof(Flow2Dev), hipMemcpyHostToDevice, s);
   return VDO_OK;
 }
 

@@ -18,6 +18,18 @@ void inv_rigid(const float* T, float* o) {                 // Converter::toInvMa
 }
 }  // namespace
 
+static void fill_flow2(vdo_flow2_problem& p, int n, const double* obs, const double* flow, const double* depth, const float* K4, const float* Tcw_last,
+                       const double* T0, double info_prior, int max_it) {
+  std::memset(&p, 0, sizeof p);
+  p.n = n; p.obs = obs; p.flow = flow; p.depth = depth;
+  for (int i = 0; i < 4; ++i) p.K[i] = K4[i];
+  float Twl[16];
+  inv_rigid(Tcw_last, Twl);                              // Converter::toInvMatrix(pLastFrame->mTcw)  (Optimizer.cc:2414-2420)
+  for (int i = 0; i < 16; ++i) { p.Twl[i] = Twl[i]; p.T0[i] = T0[i]; }
+  p.info_flow = 0.1; p.info_prior = info_prior; p.huber_delta = (double)std::sqrt(0.04f); p.chi2_gate = (double)0.04f;
+  p.max_iterations = max_it; p.ref_quirks = 1;
+}
+
 #define VDO_TRY(call) do { if ((call) != VDO_OK) { std::fprintf(stderr, "FramePipeline: %s\n", vdo_last_error()); return -1; } } while (0)
 
 FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p) : ctx_(ctx), ctx_lm_(ctx_lm), p_(p) {
@@ -28,6 +40,13 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
   const int capk = p.n_features + 256;
   kx_.resize(capk); ky_.resize(capk); kr_.resize(capk); ka_.resize(capk); ks_.resize(capk); ko_.resize(capk);
   for (int i = 0; i < 16; ++i) Tcw_last_[i] = vel_[i] = (i % 5 == 0) ? 1.f : 0.f;
+  if (p.build_lm) {
+    const int32_t ccap = std::max(p.max_track_bg + 8, p.n_features + 256);      // frame 1 tracks every filtered ORB keypoint of frame 0 (Initialization)
+    if (vdo_flow2_batch_reserve(ctx_lm, 1, &ccap, &lm_cam_) != VDO_OK) return;
+    int32_t ocap[kMaxObjects];
+    for (int k = 0; k < kMaxObjects; ++k) ocap[k] = kObjCap;
+    if (vdo_flow2_batch_reserve(ctx_lm, kMaxObjects, ocap, &lm_obj_) != VDO_OK) return;
+  }
   ok_ = true;
 }
 
@@ -36,6 +55,8 @@ FramePipeline::~FramePipeline() {
   for (int k = 0; k < 2; ++k) if (img_[k]) vdo_frame_images_destroy(img_[k]);
   if (tr_sta_) vdo_tracks_destroy(tr_sta_);
   if (tr_dyn_) vdo_tracks_destroy(tr_dyn_);
+  if (lm_cam_) vdo_flow2_batch_destroy(lm_cam_);
+  if (lm_obj_) vdo_flow2_batch_destroy(lm_obj_);
 }
 
 int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
@@ -77,13 +98,38 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     float MM[16];
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float a = 0; for (int k = 0; k < 4; ++k) a += vel_[4 * i + k] * Tcw_last_[4 * k + j]; MM[4 * i + j] = a; }
     int mm = 0;
+    inl_mm_.assign(n_s, 0);
     for (int i = 0; i < n_s; ++i) {
       const float x = sta_.xyz[3 * i], y = sta_.xyz[3 * i + 1], z = sta_.xyz[3 * i + 2];
       const float xc = MM[0] * x + MM[1] * y + MM[2] * z + MM[3], yc = MM[4] * x + MM[5] * y + MM[6] * z + MM[7], invz = 1.0f / (MM[8] * x + MM[9] * y + MM[10] * z + MM[11]);
       const float u_ = sta_.cx[i] - (p_.K4[0] * xc * invz + p_.K4[2]), v_ = sta_.cy[i] - (p_.K4[1] * yc * invz + p_.K4[3]);
-      mm += std::sqrt(u_ * u_ + v_ * v_) < 0.4f;
+      if (std::sqrt(u_ * u_ + v_ * v_) < 0.4f) { inl_mm_[i] = 1; ++mm; }
     }
     fc.n_ransac_cam = pr.n_inliers; fc.n_motion_model_cam = mm;
+    if (lm_cam_) {
+      // TemperalMatch_subset + initial pose: RANSAC model if it has more inliers than the motion model (Tracking.cc:1690-1712)
+      const bool use_ransac = pr.n_inliers > mm;
+      const std::vector<uint8_t>& flag = use_ransac ? inl_ransac_ : inl_mm_;
+      double T0[16];
+      for (int i = 0; i < 16; ++i) T0[i] = use_ransac ? (double)(float)pr.T[i] : (double)MM[i];     // iniTcw is a CV_32F Mat
+      cam_subset_.clear();
+      std::vector<double>&ob = d_[2], &fl = d_[3], &dp = d_[4];
+      ob.clear(); fl.clear(); dp.clear();
+      for (int i = 0; i < n_s; ++i) {
+        if (!flag[i]) continue;
+        cam_subset_.push_back(i);
+        ob.push_back(sta_.x[i]); ob.push_back(sta_.y[i]); fl.push_back(sta_.fx[i]); fl.push_back(sta_.fy[i]); dp.push_back(sta_.d[i]);
+      }
+      vdo_flow2_problem fp;
+      fill_flow2(fp, (int)cam_subset_.size(), ob.data(), fl.data(), dp.data(), p_.K4, Tcw_last_, T0, 0.3, 100);
+      VDO_TRY(vdo_flow2_batch_set(lm_cam_, 0, &fp));
+      cam = lm_cam_; n_cam_pts = fp.n;
+      for (int i = 0; i < 16; ++i) Tcw_init_[i] = (float)T0[i];
+    }
+  } else if (lm_cam_) {
+    for (int i = 0; i < 16; ++i) Tcw_init_[i] = Tcw_last_[i];
+    VDO_TRY(vdo_flow2_batch_set(lm_cam_, 0, nullptr));
+    if (have_last_) { cam = lm_cam_; n_cam_pts = 0; }
   }
   tick(0);
   // ---- camera pose (K16) on the LM stream, front-end of this frame meanwhile      Tracking.cc:690-700 || Frame.cc:61-260
@@ -117,7 +163,26 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     flow_out_.resize(2 * (size_t)std::max(n_cam_pts, 1));
     double* fo = flow_out_.data(); uint8_t* io = inl_out_.data();
     VDO_TRY(vdo_flow2_batch_fetch(cam, &r, &fo, &io));
-    for (int i = 0; i < 16; ++i) Tcw[i] = (float)r.T[i];
+    if (!(cam == lm_cam_ && n_cam_pts < 3)) for (int i = 0; i < 16; ++i) Tcw[i] = (float)r.T[i];
+    else if (cam == lm_cam_ && have_last_) for (int i = 0; i < 16; ++i) Tcw[i] = Tcw_init_[i];      // < 3 matches: the pose stays at its initial value
+    fc.n_cam_inliers = r.n_inliers; fc.cam_lm_iterations = r.iterations;
+  }
+  // current static keys: the propagated correspondences, moved to (last key + refined flow) for the LM inliers (Optimizer.cc:2527-2532)
+  std::vector<float>&cur_sx = f_[9], &cur_sy = f_[10];
+  std::vector<int32_t>& tm = i_[7];
+  if (have_last_) {
+    cur_sx = sta_.cx; cur_sy = sta_.cy;
+    tm.assign(n_s, -1);
+    if (cam && cam == lm_cam_) {
+      for (size_t j = 0; j < cam_subset_.size(); ++j) {
+        if (!inl_out_[j]) continue;
+        const int i = cam_subset_[j];
+        tm[i] = i;
+        cur_sx[i] = sta_.x[i] + (float)flow_out_[2 * j]; cur_sy[i] = sta_.y[i] + (float)flow_out_[2 * j + 1];
+      }
+    } else {
+      for (int i = 0; i < n_s; ++i) tm[i] = inl_out_[n_cam_pts > 0 ? i % n_cam_pts : 0] ? i : -1;
+    }
   }
   tick(3);
   StaSet nsta; ObjSet nobj;
@@ -172,21 +237,46 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
         }
         pp[a] = vdo_pnp_problem{off[a + 1] - off[a], X.data() + 3 * (size_t)off[a], uvd.data() + 2 * (size_t)off[a], {p_.K4[0], p_.K4[1], p_.K4[2], p_.K4[3]}, 500, 0.4, 0.98};
       }
-      VDO_TRY(vdo_pnp_ransac_batch(ctx_, n_objects, pp.data(), pr.data(), nullptr));
+      std::vector<uint8_t>& rin = inl_ransac_;
+      rin.assign((size_t)off[n_objects] + 1, 0);
+      std::vector<uint8_t*> rip(n_objects);
+      for (int a = 0; a < n_objects; ++a) rip[a] = rin.data() + off[a];
+      VDO_TRY(vdo_pnp_ransac_batch(ctx_, n_objects, pp.data(), pr.data(), rip.data()));
       for (int a = 0; a < n_objects; ++a) fc.n_ransac_obj += pr[a].n_inliers;
+      if (lm_obj_) {
+        // per object: ObjIdTest_in = RANSAC inliers; fewer than 50 -> the object is not tracked this frame (Tracking.cc:879)
+        obj_subsets_.assign(n_objects, {});
+        obj_stat_.assign(n_objects, 1);
+        obj_buf_.resize(std::min(n_objects, (int)kMaxObjects));
+        for (int a = 0; a < n_objects; ++a) {
+          std::vector<int32_t>& sub = obj_subsets_[a];
+          for (int q = off[a]; q < off[a + 1]; ++q) if (rin[q]) sub.push_back(idx[q]);
+          if ((int)sub.size() < 50 || a >= kMaxObjects || (int)sub.size() > kObjCap) { obj_stat_[a] = 0; if (a < kMaxObjects) VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr)); continue; }
+          ObjBuf& B = obj_buf_[a];
+          B.ob.clear(); B.fl.clear(); B.dp.clear();
+          for (int id : sub) { B.ob.push_back(obj_.x[id]); B.ob.push_back(obj_.y[id]); B.fl.push_back(obj_.fx[id]); B.fl.push_back(obj_.fy[id]); B.dp.push_back(obj_.d[id]); }
+          double T0[16];
+          for (int i = 0; i < 16; ++i) T0[i] = (double)(float)pr[a].T[i];                 // mInitModel (CV_32F)
+          vdo_flow2_problem fp;
+          fill_flow2(fp, (int)sub.size(), B.ob.data(), B.fl.data(), B.dp.data(), p_.K4, Tcw_last_, T0, 0.5, 200);
+          VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, &fp));
+        }
+        for (int a = n_objects; a < kMaxObjects; ++a) VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr));
+        obj = lm_obj_; n_obj_problems = kMaxObjects;
+      }
+    } else if (lm_obj_) {
+      for (int a = 0; a < kMaxObjects; ++a) VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr));
+      obj = nullptr;
     }
     tick(9);
     // ---- object motions (K17) on the LM stream, RenewFrameInfo (static) meanwhile  Tracking.cc:932 || :2666-2805
     if (obj) VDO_TRY(vdo_flow2_batch_run(obj));
     if (frame_filters() != 0) return -1;
-    std::vector<int32_t>& tm = i_[7];
-    tm.resize(n_s);
-    for (int i = 0; i < n_s; ++i) tm[i] = inl_out_[n_cam_pts > 0 ? i % n_cam_pts : 0] ? i : -1;
     const int cs = p_.max_track_bg + 2;
     nsta.x.resize(cs); nsta.y.resize(cs); nsta.cx.resize(cs); nsta.cy.resize(cs); nsta.fx.resize(cs); nsta.fy.resize(cs); nsta.d.resize(cs);
     sta_asso.resize(cs);
     int m = 0;
-    VDO_TRY(vdo_renew_static(cur, n_s, tm.data(), sta_.cx.data(), sta_.cy.data(), kp.n, kx_.data(), ky_.data(), p_.max_track_bg,
+    VDO_TRY(vdo_renew_static(cur, n_s, tm.data(), cur_sx.data(), cur_sy.data(), kp.n, kx_.data(), ky_.data(), p_.max_track_bg,
                              nsta.x.data(), nsta.y.data(), nsta.cx.data(), nsta.cy.data(), nsta.fx.data(), nsta.fy.data(), sta_asso.data(), nsta.d.data(), &m));
     for (auto* v : {&nsta.x, &nsta.y, &nsta.cx, &nsta.cy, &nsta.fx, &nsta.fy, &nsta.d}) v->resize(m);
     sta_asso.resize(m);
@@ -196,17 +286,54 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     VDO_TRY(vdo_get3d_world(ctx_, m, nsta.x.data(), nsta.y.data(), nsta.d.data(), p_.K4, Twc, nsta.xyz.data()));     // mvStat3DPointTmp
     tick(5);
     // ---- consume the object results, RenewFrameInfo (objects)                      Tracking.cc:2806-2995
-    if (obj) {
+    std::vector<float>&cur_ox = f_[11], &cur_oy = f_[12];
+    cur_ox = obj_.cx; cur_oy = obj_.cy;
+    std::vector<uint8_t> stat(std::max(n_objects, 1), 1);
+    std::vector<int32_t>*p_off = &off, *p_idx = &idx;
+    if (obj && obj == lm_obj_) {
+      // vnObjInlierID = LM inliers; current keys of the inliers move to (last key + refined flow); H = Tcw^-1 * (Tcw H)  (Tracking.cc:932-933)
+      std::vector<vdo_flow2_result> rs(kMaxObjects);
+      std::vector<std::vector<double>> fo(kMaxObjects); std::vector<std::vector<uint8_t>> io(kMaxObjects);
+      double* fop[kMaxObjects]; uint8_t* iop[kMaxObjects];
+      for (int a = 0; a < kMaxObjects; ++a) {
+        const size_t na = (a < n_objects && obj_stat_[a]) ? obj_subsets_[a].size() : 0;
+        fo[a].resize(2 * na + 2); io[a].resize(na + 1);
+        fop[a] = fo[a].data(); iop[a] = io[a].data();
+      }
+      VDO_TRY(vdo_flow2_batch_fetch(obj, rs.data(), fop, iop));
+      inl_off_.assign(1, 0); inl_idx_.clear();
+      motions_.clear();
+      float Twc_c[16];
+      inv_rigid(Tcw, Twc_c);
+      for (int a = 0; a < n_objects; ++a) {
+        stat[a] = (a < kMaxObjects) ? obj_stat_[a] : 0;
+        if (stat[a]) {
+          const std::vector<int32_t>& sub = obj_subsets_[a];
+          for (size_t j = 0; j < sub.size(); ++j) {
+            if (!io[a][j]) { olab[sub[j]] = -1; continue; }                     // outliers of the object optimisation (Optimizer.cc:2960-2966)
+            inl_idx_.push_back(sub[j]);
+            cur_ox[sub[j]] = obj_.x[sub[j]] + (float)fo[a][2 * j]; cur_oy[sub[j]] = obj_.y[sub[j]] + (float)fo[a][2 * j + 1];
+          }
+          ObjectMotion om; om.mod_label = omod[a]; om.sem_label = osem[a]; om.n_inliers = rs[a].n_inliers;
+          for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float acc = 0; for (int k = 0; k < 4; ++k) acc += Twc_c[4 * i + k] * (float)rs[a].T[4 * k + j]; om.H[4 * i + j] = acc; }
+          motions_.push_back(om);
+        } else {
+          for (int q = off[a]; q < off[a + 1]; ++q) inl_idx_.push_back(idx[q]);   // untracked object: vnObjInlierID = its point set (Tracking.cc:872-886)
+        }
+        inl_off_.push_back((int32_t)inl_idx_.size());
+      }
+      if (inl_idx_.empty()) inl_idx_.push_back(0);
+      p_off = &inl_off_; p_idx = &inl_idx_;
+    } else if (obj) {
       std::vector<vdo_flow2_result> rs(std::max(n_obj_problems, 1));
       VDO_TRY(vdo_flow2_batch_fetch(obj, rs.data(), nullptr, nullptr));
     }
     tick(6);
-    std::vector<uint8_t> stat(std::max(n_objects, 1), 1);
-    const int cap_o = off[n_objects] + n_tmp + 8;
+    const int cap_o = (*p_off)[n_objects] + n_tmp + 8;
     nobj.x.resize(cap_o); nobj.y.resize(cap_o); nobj.cx.resize(cap_o); nobj.cy.resize(cap_o); nobj.fx.resize(cap_o); nobj.fy.resize(cap_o); nobj.d.resize(cap_o);
     nobj.sem.resize(cap_o); nobj.label.resize(cap_o); dyn_asso.resize(cap_o);
     int mo = 0;
-    VDO_TRY(vdo_renew_object(cur, n_objects, off.data(), idx.data(), stat.data(), osem.data(), omod.data(), obj_.cx.data(), obj_.cy.data(), olab.data(),
+    VDO_TRY(vdo_renew_object(cur, n_objects, p_off->data(), p_idx->data(), stat.data(), osem.data(), omod.data(), cur_ox.data(), cur_oy.data(), olab.data(),
                              n_tmp, tmp.x.data(), tmp.y.data(), tmp.d.data(), tmp.sem.data(), tmp.fx.data(), tmp.fy.data(), tmp.cx.data(), tmp.cy.data(),
                              p_.max_track_obj, cap_o, nobj.x.data(), nobj.y.data(), nobj.d.data(), nobj.sem.data(), nobj.fx.data(), nobj.fy.data(),
                              nobj.cx.data(), nobj.cy.data(), dyn_asso.data(), nobj.label.data(), &mo));
@@ -220,7 +347,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     VDO_TRY(vdo_tracks_add_frame(tr_dyn_, mo, dyn_asso.data(), nobj.label.data()));
     last_sem_pos_.assign(osem.begin(), osem.begin() + n_objects);
     last_mod_label_.assign(omod.begin(), omod.begin() + n_objects);
-    last_obj_stat_.assign(n_objects, 1);
+    last_obj_stat_.assign(stat.begin(), stat.begin() + n_objects);
   }
   tick(8);
   fc.n_static_tracked = (int)nsta.x.size(); fc.n_object_tracked = (int)nobj.x.size();
@@ -234,6 +361,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float a = 0; for (int k = 0; k < 4; ++k) a += Tcw[4 * i + k] * Twl[4 * k + j]; vel_[4 * i + j] = a; }
   }
   std::memcpy(Tcw_last_, Tcw, sizeof Tcw);
+  std::memcpy(Tcw_out_, Tcw, sizeof Tcw);
   cur_ ^= 1; have_last_ = true; ++f_id_;
   if (out) *out = fc;
   return 0;
@@ -257,6 +385,12 @@ void host_pipeline_destroy(FramePipeline* fp) { delete fp; }
 // [4] K13 + DynObjTracking, [5] RenewFrameInfo static + K12, [6] wait object LMs + fetch, [7] RenewFrameInfo objects + K12, [8] tracklets,
 // [9] object RANSAC initialisers ([0] includes the camera one)
 void host_pipeline_timing(FramePipeline* fp, double* ms10) { for (int i = 0; i < 10; ++i) ms10[i] = fp->ms_[i]; }
+void host_pipeline_pose(FramePipeline* fp, float* Tcw16) { std::memcpy(Tcw16, fp->Tcw_out_, 64); }
+int host_pipeline_motions(FramePipeline* fp, int cap, int* mod_label, int* sem_label, int* n_inliers, float* H16) {
+  const int n = std::min(cap, (int)fp->motions_.size());
+  for (int a = 0; a < n; ++a) { mod_label[a] = fp->motions_[a].mod_label; sem_label[a] = fp->motions_[a].sem_label; n_inliers[a] = fp->motions_[a].n_inliers; std::memcpy(H16 + 16 * a, fp->motions_[a].H, 64); }
+  return (int)fp->motions_.size();
+}
 int host_pipeline_step(FramePipeline* fp, const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
                        vdo_flow2_batch* cam, vdo_flow2_batch* obj, int n_cam_pts, int n_obj_problems, FrameCounts* out) {
   return fp->Step(d_gray, d_depth_raw, d_flow, d_mask, cam, obj, n_cam_pts, n_obj_problems, out);

@@ -26,10 +26,11 @@ struct PipelineParams {
   int max_track_bg, max_track_obj;   // MaxTrackPointBG, MaxTrackPointOBJ
   float sf_mg_thres, sf_ds_thres;    // SFMgThres, SFDsThres
   int n_features, n_levels, ini_th, min_th; float scale_factor;   // ORBextractor.*
+  int build_lm;                      // 1: build the frame's pose problems from the chained correspondences (full Track()); 0: caller supplies them
 };
 
 struct FrameCounts { int n_orb, n_static_new, n_object_samples, n_static_tracked, n_object_tracked, n_objects, n_recovered_masks, n_static_tracks, n_dynamic_tracks,
-                         n_ransac_cam, n_motion_model_cam, n_ransac_obj; };
+                         n_ransac_cam, n_motion_model_cam, n_ransac_obj, n_cam_inliers, cam_lm_iterations; };
 
 class FramePipeline {
  public:
@@ -40,6 +41,9 @@ class FramePipeline {
   int Step(const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
            vdo_flow2_batch* cam, vdo_flow2_batch* obj, int n_cam_pts, int n_obj_problems, FrameCounts* out);
   bool ok() const { return ok_; }
+  struct ObjectMotion { int mod_label, sem_label, n_inliers; float H[16]; };   // H: world-frame motion of the object from the last to this frame
+  std::vector<ObjectMotion> motions_;   // objects tracked in the last Step (build_lm mode)
+  float Tcw_out_[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   double ms_[12] = {0};              // accumulated wall time per section (see host_pipeline_timing)
 
  private:
@@ -62,7 +66,16 @@ class FramePipeline {
   std::vector<float> kx_, ky_, kr_, ka_, ks_; std::vector<int32_t> ko_;
   std::vector<float> f_[16]; std::vector<int32_t> i_[8];
   std::vector<double> flow_out_; std::vector<uint8_t> inl_out_, inl_ransac_;
-  std::vector<double> d_[2];
+  std::vector<double> d_[5];
+  // build_lm mode
+  static constexpr int kMaxObjects = 8, kObjCap = 6000;
+  struct ObjBuf { std::vector<double> ob, fl, dp; };
+  vdo_flow2_batch *lm_cam_ = nullptr, *lm_obj_ = nullptr;
+  std::vector<int32_t> cam_subset_, inl_off_, inl_idx_;
+  std::vector<std::vector<int32_t>> obj_subsets_;
+  std::vector<uint8_t> inl_mm_, obj_stat_;
+  std::vector<ObjBuf> obj_buf_;
+  float Tcw_init_[16];
 };
 
 }  // namespace VDO_SLAM

@@ -12,12 +12,12 @@ class PipelineParams(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("K4", C.c_float * 4), ("bf", C.c_float), ("depth_map_factor", C.c_float),
                 ("th_depth_bg", C.c_float), ("th_depth_obj", C.c_float), ("max_track_bg", C.c_int), ("max_track_obj", C.c_int),
                 ("sf_mg_thres", C.c_float), ("sf_ds_thres", C.c_float), ("n_features", C.c_int), ("n_levels", C.c_int), ("ini_th", C.c_int),
-                ("min_th", C.c_int), ("scale_factor", C.c_float)]
+                ("min_th", C.c_int), ("scale_factor", C.c_float), ("build_lm", C.c_int)]
 
 
 class FrameCounts(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects",
-                                       "n_recovered_masks", "n_static_tracks", "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj")]
+                                       "n_recovered_masks", "n_static_tracks", "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -26,9 +26,9 @@ class FrameCounts(C.Structure):
 SECTIONS = ("k1_k15_k11_ransac_cam", "orb", "k9_k10", "wait_cam_lm", "k13_dynobj", "renew_static", "wait_obj_lm", "renew_object", "tracklets", "ransac_obj")
 
 
-def kitti_params(width, height, K4, bf, depth_map_factor, th_bg, th_obj):
+def kitti_params(width, height, K4, bf, depth_map_factor, th_bg, th_obj, build_lm=0):
     """example/kitti-0000-0013.yaml: MaxTrackPointBG 1200, MaxTrackPointOBJ 800, SFMgThres 0.12, SFDsThres 0.3, ORB 2500/1.2/8/20/7."""
-    return PipelineParams(width, height, (C.c_float * 4)(*K4), bf, depth_map_factor, th_bg, th_obj, 1200, 800, 0.12, 0.3, 2500, 8, 20, 7, 1.2)
+    return PipelineParams(width, height, (C.c_float * 4)(*K4), bf, depth_map_factor, th_bg, th_obj, 1200, 800, 0.12, 0.3, 2500, 8, 20, 7, 1.2, int(build_lm))
 
 
 class FramePipeline:
@@ -52,6 +52,22 @@ class FramePipeline:
         if rc != 0:
             raise K.VdoError("FramePipeline.Step failed: " + (K.lib().vdo_last_error() or b"").decode())
         return self.counts.as_dict()
+
+    def pose(self):
+        """Tcw (4x4 float32) of the last frame."""
+        import numpy as np
+        T = np.zeros(16, np.float32)
+        self._L.host_pipeline_pose.argtypes = [C.c_void_p, K.c_float_p]
+        self._L.host_pipeline_pose(self._h, T.ctypes.data_as(K.c_float_p))
+        return T.reshape(4, 4)
+
+    def motions(self, cap=16):
+        """Tracked objects of the last frame (build_lm mode): list of dict(mod_label, sem_label, n_inliers, H 4x4)."""
+        import numpy as np
+        ml = np.zeros(cap, np.int32); sl = np.zeros(cap, np.int32); ni = np.zeros(cap, np.int32); H = np.zeros((cap, 16), np.float32)
+        self._L.host_pipeline_motions.argtypes = [C.c_void_p, C.c_int, K.c_int32_p, K.c_int32_p, K.c_int32_p, K.c_float_p]
+        n = self._L.host_pipeline_motions(self._h, cap, ml.ctypes.data_as(K.c_int32_p), sl.ctypes.data_as(K.c_int32_p), ni.ctypes.data_as(K.c_int32_p), H.ctypes.data_as(K.c_float_p))
+        return [dict(mod_label=int(ml[a]), sem_label=int(sl[a]), n_inliers=int(ni[a]), H=H[a].reshape(4, 4).copy()) for a in range(min(n, cap))]
 
     def section_ms(self):
         ms = (C.c_double * 10)()

@@ -1,0 +1,85 @@
+"""Geometrically consistent synthetic RGB-D / flow / mask sequence (SURVEY.md §8d "Synthetic inputs"):
+a static scene (ground plane, two side walls, a distant back wall) seen by a camera that drives forward with
+a small yaw oscillation, plus K rigid objects (upright fronto-parallel panels) that translate on the ground.
+Depth, exact dense optical flow (frame t -> t+1) and instance masks are rendered analytically per pixel,
+in the on-disk conventions of the reference (depth = disparity * DepthMapFactor, example/vdo_slam.cc:105-139).
+The gray image is texture only (ORB needs corners; correspondences come from the flow)."""
+import numpy as np
+
+from .synth import KITTI_H, KITTI_K, KITTI_W, rotvec_to_R
+from .synth_frames import BF, DEPTH_MAP_FACTOR, make_gray
+
+
+def camera_poses(n_frames, step=0.8, yaw_amp=0.004):
+    """T_wc of every frame (camera-to-world, y down, z forward); frame 0 is the identity."""
+    Ts = [np.eye(4)]
+    yaw = 0.0
+    for k in range(1, n_frames + 1):
+        yaw += yaw_amp * np.sin(0.3 * k)
+        T = np.eye(4)
+        T[:3, :3] = rotvec_to_R(np.array([0.0, yaw, 0.0]))
+        T[:3, 3] = Ts[-1][:3, 3] + Ts[-1][:3, :3] @ np.array([0.0, 0.0, step])
+        Ts.append(T)
+    return Ts
+
+
+def default_objects():
+    """(centre xyz at frame 0 [m], half width, half height, velocity per frame [m])."""
+    return [dict(c=np.array([-3.0, 0.9, 14.0]), hw=1.1, hh=0.75, v=np.array([0.0, 0.0, 1.1])),
+            dict(c=np.array([2.5, 0.85, 10.0]), hw=1.0, hh=0.8, v=np.array([0.02, 0.0, 0.55])),
+            dict(c=np.array([5.0, 0.9, 19.0]), hw=1.2, hh=0.75, v=np.array([-0.03, 0.0, 0.9]))]
+
+
+def render_frame(k, Ts, objects, w=KITTI_W, h=KITTI_H, K4=KITTI_K, flow_sigma=0.0, seed=0):
+    """Frame k: dict(gray u8, depth_raw f32 (disparity*256), flow f32 [h,w,2] (k -> k+1), mask i32, Tcw 4x4, Tcw_next)."""
+    fx, fy, cx, cy = K4
+    T_wc, T_wc1 = Ts[k], Ts[k + 1]
+    vv, uu = np.mgrid[0:h, 0:w].astype(np.float64)
+    rays = np.stack([(uu - cx) / fx, (vv - cy) / fy, np.ones_like(uu)], -1)            # camera frame, z = 1  ->  parameter = depth
+    d = rays @ T_wc[:3, :3].T
+    o = T_wc[:3, 3]
+    s = np.full((h, w), np.inf)
+    label = np.zeros((h, w), np.int32)
+
+    def hit(cond, sv):
+        nonlocal s
+        upd = cond & (sv > 0.5) & (sv < s)
+        s = np.where(upd, sv, s)
+        return upd
+
+    with np.errstate(divide="ignore", invalid="ignore"):
+        hit(d[..., 1] > 1e-9, (1.65 - o[1]) / d[..., 1])                               # ground y = 1.65 (camera height)
+        for xw in (-9.0, 9.0):                                                         # side walls
+            sv = (xw - o[0]) / d[..., 0]
+            yy = o[1] + sv * d[..., 1]
+            hit((np.abs(d[..., 0]) > 1e-9) & (yy > -6.0) & (yy < 1.65), sv)
+        hit(d[..., 2] > 1e-9, (400.0 - o[2]) / d[..., 2])                              # back wall far beyond ThDepthBG
+        for j, ob in enumerate(objects):                                               # panels z = const, facing the camera
+            c = ob["c"] + k * ob["v"]
+            sv = (c[2] - o[2]) / d[..., 2]
+            px = o[0] + sv * d[..., 0]; py = o[1] + sv * d[..., 1]
+            upd = hit((d[..., 2] > 1e-9) & (np.abs(px - c[0]) < ob["hw"]) & (np.abs(py - c[1]) < ob["hh"]), sv)
+            label = np.where(upd, j + 1, label)
+    depth = s                                                                          # z-depth in the camera frame (ray z = 1)
+    Xw = o + depth[..., None] * d
+    Xn = Xw.copy()
+    for j, ob in enumerate(objects):
+        Xn[label == j + 1] += ob["v"]
+    T_c1w = np.linalg.inv(T_wc1)
+    Xc1 = Xn @ T_c1w[:3, :3].T + T_c1w[:3, 3]
+    with np.errstate(divide="ignore", invalid="ignore"):
+        un = fx * Xc1[..., 0] / Xc1[..., 2] + cx; vn = fy * Xc1[..., 1] / Xc1[..., 2] + cy
+    flow = np.stack([un - uu, vn - vv], -1)
+    if flow_sigma:
+        flow = flow + np.random.default_rng(seed + 77 * k).normal(0, flow_sigma, flow.shape)
+    flow = np.nan_to_num(flow, nan=0.0, posinf=0.0, neginf=0.0).astype(np.float32)
+    valid = np.isfinite(depth) & (depth < 300)
+    disp = np.where(valid, np.rint(DEPTH_MAP_FACTOR * BF / np.where(valid, depth, 1.0)), 0.0)
+    return dict(gray=make_gray(seed + 1000 + k, w, h), depth_raw=np.ascontiguousarray(disp.astype(np.float32)), flow=np.ascontiguousarray(flow),
+                mask=np.ascontiguousarray(label), Tcw=np.linalg.inv(T_wc), Tcw_next=np.linalg.inv(T_wc1), depth_true=depth)
+
+
+def object_motion(ob):
+    """World-frame rigid motion H of an object per frame (pure translation)."""
+    H = np.eye(4); H[:3, 3] = ob["v"]
+    return H
