@@ -1,43 +1,88 @@
 """The per-frame sequence of Tracking::GrabImageRGBD + Track composed from the ORACLE's functions
 (sequential CPU restatements), chained frame to frame exactly like the product's C++ FramePipeline
-(vdo_slam_amd/host/FramePipeline.cc).  Used as the checker of the pipeline test and as bench.py's CPU baseline."""
+(vdo_slam_amd/host/FramePipeline.cc).  Used as the checker of the pipeline tests and as bench.py's CPU baseline.
+
+build_lm=False: the camera pose / inliers of a frame are handed in (bench: pre-built pose problems).
+build_lm=True : the full Track(): RANSAC / motion-model initial models, joint pose+flow LM for the camera and for every
+                object built from the chained correspondences, refined keys and inlier sets fed to RenewFrameInfo."""
+import ctypes as C
+import time
+
 import numpy as np
 
 from tests import frontend_ref as R
 from tests import tracking_ref as T
+from vdo_slam_amd import _capi as K
 from vdo_slam_amd import synth, synth_frames as SF
 from vdo_slam_amd.tracking import DynObjParamsC
-from vdo_slam_amd import _capi as K
+
+f32 = np.float32
+
+
+def inv_rigid_f32(Tm):
+    """Converter::toInvMatrix in float, operation order of FramePipeline.cc:inv_rigid."""
+    Tm = np.asarray(Tm, f32)
+    o = np.zeros((4, 4), f32)
+    for i in range(3):
+        for j in range(3):
+            o[i, j] = Tm[j, i]
+        o[i, 3] = -f32(f32(f32(Tm[0, i] * Tm[0, 3]) + f32(Tm[1, i] * Tm[1, 3])) + f32(Tm[2, i] * Tm[2, 3]))
+    o[3, 3] = 1
+    return o
+
+
+def matmul4_f32(A, B):
+    """4x4 float product with the sequential accumulation of the C++ loops (a = 0; a += A[i][k] * B[k][j])."""
+    A = np.asarray(A, f32); B = np.asarray(B, f32)
+    o = np.zeros((4, 4), f32)
+    for i in range(4):
+        for j in range(4):
+            a = f32(0)
+            for k in range(4):
+                a = f32(a + f32(A[i, k] * B[k, j]))
+            o[i, j] = a
+    return o
 
 
 class OraclePipeline:
-    def __init__(self, oracle, max_bg=1200, max_obj=800, sf_mg=0.12, sf_ds=0.3):
+    MAX_OBJECTS, OBJ_CAP = 8, 6000
+
+    def __init__(self, oracle, max_bg=1200, max_obj=800, sf_mg=0.12, sf_ds=0.3, build_lm=False):
         self.o = oracle
-        self.K4 = np.array(synth.KITTI_K, np.float32)
-        self.max_bg, self.max_obj, self.sf_mg, self.sf_ds = max_bg, max_obj, sf_mg, sf_ds
+        self.K4 = np.array(synth.KITTI_K, f32)
+        self.max_bg, self.max_obj, self.sf_mg, self.sf_ds, self.build_lm = max_bg, max_obj, sf_mg, sf_ds, build_lm
         self.last = None
-        self.Tl = np.eye(4, dtype=np.float32)
+        self.Tl = np.eye(4, dtype=f32)
+        self.vel = np.eye(4, dtype=f32)
         self.max_id = 1
         self.f_id = 0
         self.assos_s, self.assos_d, self.labs_d = [], [], []
-        self.stage_s = {"depth": 0.0, "orb": 0.0, "frame": 0.0, "tracking_k11_k15": 0.0, "ransac_init": 0.0}
-        self.vel = np.eye(4, dtype=np.float32)
-        import ctypes as C
+        self.motions = []
+        self.stage_s = {"depth": 0.0, "orb": 0.0, "frame": 0.0, "tracking_k11_k15": 0.0, "ransac_init": 0.0, "lm_cam": 0.0, "lm_obj": 0.0}
         dp = K.c_double_p
         oracle.vdo_oracle_p3p_ransac.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_double, C.c_double, dp, K.c_uint8_p, K.c_int32_p, K.c_int32_p]
 
+    # ---- helpers
     def _ransac(self, X, uv):
         n = X.shape[0]
+        Tm = np.eye(4).ravel().copy(); inl = np.zeros(max(n, 1), np.uint8)
         if n < 4:
-            return 0
+            return 0, Tm.reshape(4, 4), inl[:n]
         X = np.ascontiguousarray(X, np.float64); uv = np.ascontiguousarray(uv, np.float64)
-        T = np.zeros(16)
-        return self.o.vdo_oracle_p3p_ransac(n, K._dp(X), K._dp(uv), K._dp(self.K4.astype(np.float64)), 500, 0.4, 0.98, K._dp(T), None, None, None)
+        good = self.o.vdo_oracle_p3p_ransac(n, K._dp(X), K._dp(uv), K._dp(self.K4.astype(np.float64)), 500, 0.4, 0.98, K._dp(Tm), inl.ctypes.data_as(K.c_uint8_p), None, None)
+        return good, Tm.reshape(4, 4), inl[:n]
 
-    def step(self, fr, Tc=None, inl=None, timer=None):
-        """fr: dict(gray, depth_raw, flow, mask).  Tc: camera pose of this frame (float32 4x4, default: previous);
-        inl: inlier flags of the camera optimisation (cycled over the static set, default all)."""
-        import time
+    def _lm(self, kx, ky, fx, fy, d, T0, info_prior, max_it):
+        from tests.test_oracle_flow2 import run_oracle
+        Twl = inv_rigid_f32(self.Tl).astype(np.float64)
+        prob = synth.Flow2Problem(obs=np.c_[kx, ky].astype(np.float64), flow=np.c_[fx, fy].astype(np.float64), depth=np.asarray(d, np.float64), K=synth.KITTI_K,
+                                  Twl=Twl, T0=np.asarray(T0, np.float64), info_prior=info_prior, max_iterations=max_it)
+        prob.huber_delta = float(np.sqrt(f32(0.04))); prob.chi2_gate = float(f32(0.04)); prob.info_flow = 0.1; prob.ref_quirks = 1
+        return run_oracle(self.o, prob)
+
+    def step(self, fr, Tc=None, inl=None):
+        """fr: dict(gray, depth_raw, flow, mask).  build_lm=False: Tc = camera pose of this frame (float32 4x4, default: previous),
+        inl = inlier flags of the camera optimisation (cycled over the static set, default all)."""
         o = self.o
         tick = time.perf_counter
         t = tick()
@@ -52,71 +97,118 @@ class OraclePipeline:
             T.propagate_static(o, last["st"]["corr_x"], last["st"]["corr_y"], d)
             od, osem = T.propagate_object(o, last["ob"]["corr_x"], last["ob"]["corr_y"], d, mask, SF.TH_DEPTH_OBJ)
         self.stage_s["tracking_k11_k15"] += tick() - t; t = tick()
-        n_rc = n_mm = n_ro = 0
+        n_rc = n_mm = n_ro = n_cam_inl = cam_its = 0
+        cam_lm = None
         if last is not None and last["st"]["corr_x"].size >= 4:                        # GetInitModelCam
             ls = last["st"]
-            n_rc = self._ransac(ls["xyz"], np.c_[ls["corr_x"], ls["corr_y"]])
-            MM = (self.vel.astype(np.float32) @ self.Tl.astype(np.float32)).astype(np.float32)
-            Xc = ls["xyz"].astype(np.float32) @ MM[:3, :3].T + MM[:3, 3]
-            u = self.K4[0] * Xc[:, 0] / Xc[:, 2] + self.K4[2]; v = self.K4[1] * Xc[:, 1] / Xc[:, 2] + self.K4[3]
-            n_mm = int((np.sqrt((ls["corr_x"] - u) ** 2 + (ls["corr_y"] - v) ** 2) < 0.4).sum())
+            ns = ls["corr_x"].size
+            n_rc, T_r, inl_r = self._ransac(ls["xyz"], np.c_[ls["corr_x"], ls["corr_y"]])
+            MM = matmul4_f32(self.vel, self.Tl)
+            X = ls["xyz"].astype(f32)
+            xc = MM[0, 0] * X[:, 0] + MM[0, 1] * X[:, 1] + MM[0, 2] * X[:, 2] + MM[0, 3]
+            yc = MM[1, 0] * X[:, 0] + MM[1, 1] * X[:, 1] + MM[1, 2] * X[:, 2] + MM[1, 3]
+            invz = f32(1.0) / (MM[2, 0] * X[:, 0] + MM[2, 1] * X[:, 1] + MM[2, 2] * X[:, 2] + MM[2, 3])
+            u_ = ls["corr_x"] - (self.K4[0] * xc * invz + self.K4[2]); v_ = ls["corr_y"] - (self.K4[1] * yc * invz + self.K4[3])
+            inl_m = np.sqrt(u_ * u_ + v_ * v_) < f32(0.4)
+            n_mm = int(inl_m.sum())
+            self.stage_s["ransac_init"] += tick() - t; t = tick()
+            if self.build_lm:
+                use_r = n_rc > n_mm
+                flag = inl_r.astype(bool) if use_r else inl_m
+                T0 = (T_r.astype(f32) if use_r else MM).astype(np.float64)
+                sub = np.nonzero(flag)[0]
+                Tn, fl_new, inl_lm, ninl, st_lm = self._lm(ls["key_x"][sub], ls["key_y"][sub], ls["flow_x"][sub], ls["flow_y"][sub], ls["depth"][sub], T0, 0.3, 100)
+                cam_lm = dict(sub=sub, T=(Tn if sub.size >= 3 else T0), flow=fl_new, inl=inl_lm.astype(bool))
+                n_cam_inl, cam_its = int(ninl), int(st_lm.iterations)
+                self.stage_s["lm_cam"] += tick() - t; t = tick()
+        elif last is not None and self.build_lm:
+            cam_lm = dict(sub=np.zeros(0, np.int64), T=self.Tl.astype(np.float64), flow=np.zeros((0, 2)), inl=np.zeros(0, bool))
         self.stage_s["ransac_init"] += tick() - t; t = tick()
         kp = R.extract(o, fr["gray"])
         self.stage_s["orb"] += tick() - t; t = tick()
         st = R.static_filter(o, kp["x"], kp["y"], kp["octave"], mask, d, fr["flow"], SF.TH_DEPTH_BG)
         ob = R.object_sample(o, mask, d, fr["flow"], SF.TH_DEPTH_OBJ)
         self.stage_s["frame"] += tick() - t; t = tick()
-        Tc = self.Tl if Tc is None else np.asarray(Tc, np.float32)
+        if cam_lm is not None:
+            Tc = np.asarray(cam_lm["T"], np.float64).astype(f32)
+        else:
+            Tc = self.Tl if Tc is None else np.asarray(Tc, f32)
         counts = dict(n_orb=int(kp["x"].size), n_static_new=int(st["keep_idx"].size), n_object_samples=int(ob["label"].size), n_recovered_masks=int(rec), n_objects=0)
+        self.motions = []
         if last is not None:
-            lo = last["ob"]
+            ls, lo = last["st"], last["ob"]
+            ns = ls["corr_x"].size
+            cur_sx, cur_sy = ls["corr_x"].copy(), ls["corr_y"].copy()
+            if cam_lm is not None:
+                tm = np.full(ns, -1, np.int32)
+                good = cam_lm["sub"][cam_lm["inl"]]
+                tm[good] = good
+                cur_sx[good] = ls["key_x"][good] + cam_lm["flow"][cam_lm["inl"], 0].astype(f32)
+                cur_sy[good] = ls["key_y"][good] + cam_lm["flow"][cam_lm["inl"], 1].astype(f32)
+            elif inl is None or inl.size == 0:
+                tm = np.arange(ns, dtype=np.int32)
+            else:
+                tm = np.where(inl[np.arange(ns) % inl.size] != 0, np.arange(ns), -1).astype(np.int32)
             fl, olab = T.scene_flow(o, (lo["corr_x"], lo["corr_y"], od, osem), Tc, (lo["key_x"], lo["key_y"], lo["depth"], lo["label"]), self.Tl, self.K4,
                                     np.full(od.size, -2, np.int32))
             h, w = fr["mask"].shape
             prm = DynObjParamsC(w, h, 25, 50, self.sf_mg, self.sf_ds, SF.TH_DEPTH_OBJ, self.f_id)
-            dyn = T.dyn_obj_tracking(o, prm, osem, olab, lo["corr_x"], lo["corr_y"], od, fl, lo["label"], last["sem_pos"], last["mod"],
-                                     np.ones(len(last["mod"]), np.uint8), self.max_id)
+            dyn = T.dyn_obj_tracking(o, prm, osem, olab, lo["corr_x"], lo["corr_y"], od, fl, lo["label"], last["sem_pos"], last["mod"], last["stat"], self.max_id)
             self.max_id = dyn["max_id"]
-            counts["n_objects"] = len(dyn["objects"])
+            n_obj = len(dyn["objects"])
+            counts["n_objects"] = n_obj
             self.stage_s["tracking_k11_k15"] += tick() - t; t = tick()
-            for ids in dyn["objects"]:                                                  # GetInitModelObj
-                n_ro += self._ransac(lo["xyz"][ids], np.c_[lo["corr_x"][ids], lo["corr_y"][ids]])
+            olab = dyn["obj_label"].copy()
+            cur_ox, cur_oy = lo["corr_x"].copy(), lo["corr_y"].copy()
+            stat = np.ones(n_obj, np.uint8)
+            inl_sets = [ids.copy() for ids in dyn["objects"]]
+            Twc_c = inv_rigid_f32(Tc)
+            for a, ids in enumerate(dyn["objects"]):                                    # GetInitModelObj (+ object LM)
+                n_r, T_r, inl_r = self._ransac(lo["xyz"][ids], np.c_[lo["corr_x"][ids], lo["corr_y"][ids]])
+                n_ro += n_r
+                if not self.build_lm:
+                    continue
+                self.stage_s["ransac_init"] += tick() - t; t = tick()
+                sub = ids[inl_r.astype(bool)]
+                if sub.size < 50 or a >= self.MAX_OBJECTS or sub.size > self.OBJ_CAP:
+                    stat[a] = 0
+                    continue
+                Tn, fl_new, inl_lm, ninl, _ = self._lm(lo["key_x"][sub], lo["key_y"][sub], lo["flow_x"][sub], lo["flow_y"][sub], lo["depth"][sub], T_r.astype(f32).astype(np.float64), 0.5, 200)
+                il = inl_lm.astype(bool)
+                olab[sub[~il]] = -1
+                good = sub[il]
+                cur_ox[good] = lo["key_x"][good] + fl_new[il, 0].astype(f32); cur_oy[good] = lo["key_y"][good] + fl_new[il, 1].astype(f32)
+                inl_sets[a] = good
+                self.motions.append(dict(mod_label=int(dyn["mod"][a]), sem_label=int(dyn["sem"][a]), n_inliers=int(ninl), H=matmul4_f32(Twc_c, Tn.astype(f32))))
+                self.stage_s["lm_obj"] += tick() - t; t = tick()
             self.stage_s["ransac_init"] += tick() - t; t = tick()
-            ns = last["st"]["corr_x"].size
-            if inl is None or inl.size == 0:
-                tm = np.arange(ns, dtype=np.int32)
-            else:
-                tm = np.where(inl[np.arange(ns) % inl.size] != 0, np.arange(ns), -1).astype(np.int32)
-            rs = T.renew_static(o, tm, last["st"]["corr_x"], last["st"]["corr_y"], kp["x"], kp["y"], mask, d, fr["flow"], self.max_bg)
-            Twc = np.eye(4, dtype=np.float32)
-            Twc[:3, :3] = Tc[:3, :3].T
-            Twc[:3, 3] = -(Tc[:3, :3].T @ Tc[:3, 3])
-            xyz_s = T.get3d_world(o, rs["key_x"], rs["key_y"], rs["depth"], self.K4, Twc)
+            rs = T.renew_static(o, tm, cur_sx, cur_sy, kp["x"], kp["y"], mask, d, fr["flow"], self.max_bg)
+            xyz_s = T.get3d_world(o, rs["key_x"], rs["key_y"], rs["depth"], self.K4, Twc_c)
             tmp = dict(x=ob["key_x"], y=ob["key_y"], depth=ob["depth"], label=ob["label"], flow_x=ob["flow_x"], flow_y=ob["flow_y"], corr_x=ob["corr_x"], corr_y=ob["corr_y"])
-            ro = T.renew_object(o, dyn["objects"], np.ones(len(dyn["objects"]), np.uint8), dyn["sem"], dyn["mod"], lo["corr_x"], lo["corr_y"], dyn["obj_label"], tmp,
-                                mask, d, fr["flow"], self.max_obj)
-            xyz_o = T.get3d_world(o, ro["key_x"], ro["key_y"], ro["depth"], self.K4, Twc)
+            ro = T.renew_object(o, inl_sets, stat, dyn["sem"], dyn["mod"], cur_ox, cur_oy, olab, tmp, mask, d, fr["flow"], self.max_obj)
+            xyz_o = T.get3d_world(o, ro["key_x"], ro["key_y"], ro["depth"], self.K4, Twc_c)
             self.assos_s.append(rs["inlier_id"]); self.assos_d.append(ro["inlier_id"]); self.labs_d.append(ro["obj_label"])
             ts = T.build_tracks(o, self.assos_s); td = T.build_tracks(o, self.assos_d, self.labs_d)   # the reference rebuilds from frame 0
             counts["n_static_tracks"], counts["n_dynamic_tracks"] = ts[0].size - 1, td[0].size - 1
-            st_n = dict(corr_x=rs["corr_x"], corr_y=rs["corr_y"], xyz=xyz_s)
-            ob_n = dict(key_x=ro["key_x"], key_y=ro["key_y"], corr_x=ro["corr_x"], corr_y=ro["corr_y"], depth=ro["depth"], label=ro["sem"], xyz=xyz_o)
-            sem_pos, mod = dyn["sem"], dyn["mod"]
+            st_n = dict(key_x=rs["key_x"], key_y=rs["key_y"], corr_x=rs["corr_x"], corr_y=rs["corr_y"], flow_x=rs["flow_x"], flow_y=rs["flow_y"], depth=rs["depth"], xyz=xyz_s)
+            ob_n = dict(key_x=ro["key_x"], key_y=ro["key_y"], corr_x=ro["corr_x"], corr_y=ro["corr_y"], flow_x=ro["flow_x"], flow_y=ro["flow_y"], depth=ro["depth"], label=ro["sem"], xyz=xyz_o)
+            sem_pos, mod, stat_n = dyn["sem"], dyn["mod"], stat
             self.result = dict(static=rs, objects=ro)
         else:
-            I4 = np.eye(4, dtype=np.float32)                                           # Initialization(): Get3DinCamera
+            I4 = np.eye(4, dtype=f32)                                                  # Initialization(): Get3DinCamera
             sx, sy = kp["x"][st["keep_idx"]], kp["y"][st["keep_idx"]]
-            st_n = dict(corr_x=st["corr_x"], corr_y=st["corr_y"], xyz=T.get3d_world(o, sx, sy, st["depth"], self.K4, I4))
-            ob_n = dict(key_x=ob["key_x"], key_y=ob["key_y"], corr_x=ob["corr_x"], corr_y=ob["corr_y"], depth=ob["depth"], label=ob["label"],
-                        xyz=T.get3d_world(o, ob["key_x"], ob["key_y"], ob["depth"], self.K4, I4))
-            sem_pos, mod = np.zeros(0, np.int32), np.zeros(0, np.int32)
+            st_n = dict(key_x=sx, key_y=sy, corr_x=st["corr_x"], corr_y=st["corr_y"], flow_x=st["flow_x"], flow_y=st["flow_y"], depth=st["depth"],
+                        xyz=T.get3d_world(o, sx, sy, st["depth"], self.K4, I4))
+            ob_n = dict(key_x=ob["key_x"], key_y=ob["key_y"], corr_x=ob["corr_x"], corr_y=ob["corr_y"], flow_x=ob["flow_x"], flow_y=ob["flow_y"], depth=ob["depth"],
+                        label=ob["label"], xyz=T.get3d_world(o, ob["key_x"], ob["key_y"], ob["depth"], self.K4, I4))
+            sem_pos, mod, stat_n = np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.uint8)
             counts["n_static_tracks"] = counts["n_dynamic_tracks"] = 0
         counts["n_static_tracked"], counts["n_object_tracked"] = int(st_n["corr_x"].size), int(ob_n["corr_x"].size)
         counts["n_ransac_cam"], counts["n_motion_model_cam"], counts["n_ransac_obj"] = int(n_rc), int(n_mm), int(n_ro)
-        Twl = np.eye(4, dtype=np.float32); Twl[:3, :3] = self.Tl[:3, :3].T; Twl[:3, 3] = -(self.Tl[:3, :3].T @ self.Tl[:3, 3])
-        self.vel = (Tc @ Twl).astype(np.float32)                                       # mVelocity
+        counts["n_cam_inliers"], counts["cam_lm_iterations"] = n_cam_inl, cam_its
+        self.vel = matmul4_f32(Tc, inv_rigid_f32(self.Tl))                             # mVelocity
         self.stage_s["tracking_k11_k15"] += tick() - t
-        self.last = dict(st=st_n, ob=ob_n, mask=mask, flow=fr["flow"], sem_pos=sem_pos, mod=mod)
+        self.last = dict(st=st_n, ob=ob_n, mask=mask, flow=fr["flow"], sem_pos=sem_pos, mod=mod, stat=stat_n)
         self.Tl = Tc
         self.f_id += 1
         return counts

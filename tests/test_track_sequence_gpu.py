@@ -45,3 +45,32 @@ def test_trajectory_and_object_motions_are_recovered():
     assert t_err[1] < 0.02
     assert max(tracked) >= 1 and c["n_static_tracks"] > 500 and c["n_dynamic_tracks"] > 100
     pipe.close()
+
+
+def test_full_track_sequence_matches_the_oracle_sequence(oracle):
+    """Same sequence through the oracle-composed Track() (tests/pipeline_ref.py, build_lm=True: oracle RANSAC, oracle LM,
+    oracle RenewFrameInfo ...): every per-frame count agrees and the poses agree to float precision."""
+    import torch
+    from tests.pipeline_ref import OraclePipeline
+    n_frames = 5
+    Ts = SQ.camera_poses(n_frames)
+    objs = SQ.default_objects()
+    ctx, ctx_lm = Context(0), Context(0)
+    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1))
+    ref = OraclePipeline(oracle, build_lm=True)
+    keys = ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects", "n_recovered_masks", "n_static_tracks",
+            "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations")
+    for k in range(n_frames):
+        fr = SQ.render_frame(k, Ts, objs)
+        d = {q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")}
+        torch.cuda.synchronize()
+        got = pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
+        exp = ref.step(fr)
+        assert {q: got[q] for q in keys} == {q: exp[q] for q in keys}, (k, got, exp)
+        np.testing.assert_allclose(pipe.pose(), ref.Tl, rtol=0, atol=2e-6)
+        ms, mo = pipe.motions(), ref.motions
+        assert len(ms) == len(mo)
+        for a, b in zip(ms, mo):
+            assert (a["mod_label"], a["sem_label"], a["n_inliers"]) == (b["mod_label"], b["sem_label"], b["n_inliers"])
+            np.testing.assert_allclose(a["H"], b["H"], rtol=0, atol=5e-6)
+    pipe.close()
