@@ -1,15 +1,18 @@
 #!/usr/bin/env python
 """bench.py — headline measurement of the hot path on MI355X (driver contract in the task brief).
 
-A *step* is one KITTI-0000-shaped frame (1242x375) through the per-frame hot path with every
-input already resident in HBM when the timed region starts:
-    K1 depth preprocess -> ORB (pyramid, FAST cells, quadtree, IC angle, blur) -> K9 static filter
-    -> K10 object sampling -> per-frame joint pose+flow LM for the camera (1200 matches)
-    -> the same LM for the 5 objects of the frame (one launch).
-This is BASELINE.json configs[1] ("KITTI seq 0000 on 1xMI355X: ORB+flow front-end and per-frame
-PoseOptimization on GPU").  Stages of TrackRGBD not yet on the GPU path (P3P RANSAC initialiser,
-RenewFrameInfo, UpdateMask, tracklets — SURVEY.md §8 "next") are outside the step on BOTH sides
-(GPU and CPU baseline).  The same JSON line also carries
+A *step* is one KITTI-0000-shaped frame (1242x375) through the whole per-frame hot path of TrackRGBD — the hot part
+of Tracking::GrabImageRGBD + Track(), run by the C++ FramePipeline over the C-ABI — with every input (gray, raw
+depth, dense flow, instance mask) already resident in HBM when the timed region starts:
+    UpdateMask -> depth preprocess -> correspondence propagation -> RANSAC-P3P / motion-model initial camera model
+    -> joint pose+flow LM (camera) || ORB (pyramid, FAST cells, quadtree, IC angle, blur) + static filter + object sampling
+    -> scene flow + DynObjTracking -> RANSAC per object -> joint pose+flow LM of every object (one launch)
+    || RenewFrameInfo (static, objects) -> tracklets.
+The frames come from a geometrically consistent synthetic sequence (vdo_slam_amd/synth_seq.py), so RANSAC, the LM and
+the object tracker do the work they do on KITTI (consensus found, 1200 static matches, 2-3 tracked objects).
+This is BASELINE.json configs[1] ("KITTI seq 0000 on 1xMI355X: ORB+flow front-end and per-frame PoseOptimization on
+GPU").  The CPU baseline runs the same full Track() composed from the oracle on the first frames of the same sequence.
+The same JSON line also carries
   * ms_per_lm_iter of the full-batch dynamic BA (configs[2] shape), and
   * `roofline` for the dominant kernel of that leg, the per-edge Jacobian sweep (K18), measured
     live with HIP events on the stream the kernel is launched on, on a graph large enough to be
@@ -33,7 +36,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
-N_DISTINCT_FRAMES = 4   # synthetic frames cycled through the timed loop
+N_DISTINCT_FRAMES = 4   # make_frame_inputs(): independent random frames (tools/frame_probe.py)
+MAX_SEQ_FRAMES = 160    # length of the consistent synthetic sequence (the objects stay in view that long)
 
 
 def _pmc_traffic_bytes(graph):
@@ -64,33 +68,21 @@ def make_frame_inputs(seed0):
     return frames, cam, obj
 
 
-def cpu_baseline_frames(frames, cam, obj, budget_s=14.0):
-    """Oracle (1 thread) on the same frames: the same stages, chained frame to frame like FramePipeline does
-    (tests/pipeline_ref.py composes the oracle's functions; the LM oracle supplies pose and inliers)."""
+def cpu_baseline_frames(frames, budget_s=14.0):
+    """Oracle (1 thread) on the first frames of the same sequence: the full Track() composed from the oracle's
+    functions (tests/pipeline_ref.py, build_lm=True: oracle ORB, RANSAC, LM, RenewFrameInfo, UpdateMask, tracklets)."""
     from tests import oracle_lib
     from tests.pipeline_ref import OraclePipeline
-    from tests.test_oracle_flow2 import run_oracle
-    o = oracle_lib.load()
-    pipe = OraclePipeline(o)
+    pipe = OraclePipeline(oracle_lib.load(), build_lm=True)
     n = 0
-    t_lm_cam = t_lm_obj = 0.0
     t0 = time.perf_counter()
-    while True:
-        k = n % len(frames)
-        t = time.perf_counter()
-        Tc, _, inl, _, _ = run_oracle(o, cam[k])
-        t_lm_cam += time.perf_counter() - t
-        pipe.step(frames[k], Tc.astype(np.float32), inl)
-        t = time.perf_counter()
-        for p in obj[k]:
-            run_oracle(o, p)
-        t_lm_obj += time.perf_counter() - t
+    while n < len(frames):
+        pipe.step(frames[n])
         n += 1
-        if time.perf_counter() - t0 > budget_s or n >= 40:
+        if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    stage = dict(pipe.stage_s, lm_cam=t_lm_cam, lm_obj=t_lm_obj)
-    return n / dt, n, {k2: v / n * 1e3 for k2, v in stage.items()}
+    return n / dt, n, {k2: v / n * 1e3 for k2, v in pipe.stage_s.items()}, pipe.Tl.astype(np.float64)
 
 
 def cpu_baseline_batch(graph, its=2):
@@ -135,10 +127,8 @@ def main():
     stream = torch.cuda.Stream()          # non-default stream shared by torch events and libvdo_hip
     torch.cuda.set_stream(stream)
 
-    from vdo_slam_amd import synth, synth_frames as SF
+    from vdo_slam_amd import synth, synth_frames as SF, synth_seq as SQ
     from vdo_slam_amd.ba import BatchBA, Context
-    from vdo_slam_amd.flow2 import Flow2Batch
-    from vdo_slam_amd.frontend import FrameImages, ORBextractor
 
     n_lm_cu = int(os.environ.get("VDO_BENCH_LM_CUS", "0"))      # measured: no gain from CU partitioning (the LM kernel is not slowed by its neighbours)
     if n_lm_cu > 0:
@@ -149,31 +139,32 @@ def main():
     else:
         ctx = ctx_ba = Context(local, stream.cuda_stream)
         ctx_lm = Context(local)           # second HIP stream: the per-frame LM kernels overlap the ORB front-end of the same frame
-    frames, cam, obj = make_frame_inputs(seed0=1000 * (rank + 1))
+    # ---- the sequence: geometrically consistent synthetic KITTI-shaped RGB-D + flow + masks (vdo_slam_amd/synth_seq.py),
+    # one distinct frame per step, resident in HBM before the timed region
     W, H = synth.KITTI_W, synth.KITTI_H
-    # ---- inputs resident in HBM
-    dev = [dict(gray=torch.from_numpy(f["gray"]).cuda(), depth=torch.from_numpy(f["depth_raw"]).cuda(),
-                flow=torch.from_numpy(f["flow"]).cuda(), mask=torch.from_numpy(f["mask"]).cuda()) for f in frames]
-    cam_b = [Flow2Batch(ctx_lm, [p]) for p in cam]
-    obj_b = [Flow2Batch(ctx_lm, ps) for ps in obj]
+    n_seq = min(args.steps + args.warmup, MAX_SEQ_FRAMES)
+    Ts = SQ.camera_poses(n_seq)
+    objs = SQ.default_objects()
+    frames = [SQ.render_frame(k, Ts, objs, seed=17 * rank) for k in range(n_seq)]
+    dev = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames]
     # The per-frame sequence runs in the C++ host class FramePipeline (vdo_slam_amd/host/FramePipeline.cc: the hot
     # part of Tracking::GrabImageRGBD + Track over the C-ABI, state chained frame to frame); one ctypes call per frame.
     from vdo_slam_amd.pipeline import FramePipeline, kitti_params
-    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ))
+    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1))
     torch.cuda.synchronize()
     counts = pipe.counts
-    n_cam = cam[0].n
+    agg = {"cam_lm_iterations": 0, "n_static_tracked": 0, "n_object_tracked": 0, "n_objects": 0, "n_ransac_cam": 0, "n_cam_inliers": 0}
 
     def step(i):
-        # UpdateMask (K15) -> K1 -> propagation (K11) -> camera LM (K16, stream 2) || ORB (K3-K7) + K9 + K10 ->
-        # scene flow (K13) + DynObjTracking -> object LMs (K17, stream 2) || RenewFrameInfo static (K14, K12) ->
-        # RenewFrameInfo objects (K14, K12) -> tracklets, with the RANSAC-P3P initialisers (GetInitModelCam/Obj) in
-        # front of both LM stages.  The LM problems of a frame are pre-built KITTI-shaped problems (the chained random
-        # frames are not geometrically consistent: RANSAC finds no consensus and runs its full 500-hypothesis budget,
-        # the LM on such data would not be representative); everything else is chained data.
-        k = i % N_DISTINCT_FRAMES
-        d = dev[k]
-        pipe.step(d["gray"].data_ptr(), d["depth"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr(), cam_b[k], obj_b[k], n_cam, len(obj[k]))
+        # Full Track() of one frame: UpdateMask (K15) -> K1 -> propagation (K11) -> GetInitModelCam (RANSAC-P3P, motion model)
+        # -> camera pose+flow LM (K16, stream 2) || ORB (K3-K7) + K9 + K10 -> scene flow (K13) + DynObjTracking ->
+        # GetInitModelObj (RANSAC per object) -> object LMs (K17, one launch, stream 2) || RenewFrameInfo static (K14, K12)
+        # -> RenewFrameInfo objects (K14, K12) -> tracklets.  The LM problems are built from the frame's own chained
+        # correspondences (build_lm mode).  A sequence longer than MAX_SEQ_FRAMES wraps to frame 0 (a scene cut).
+        d = dev[i % n_seq]
+        c = pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
+        for q in agg:
+            agg[q] += c[q]
 
     def barrier():
         torch.cuda.synchronize()
@@ -186,7 +177,7 @@ def main():
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(args.warmup + i)                 # the sequence continues where the warm-up left it
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -194,23 +185,28 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt = float(tt.item())
     fps = world * args.steps / dt
-    lm = cam_b[0].fetch()[0]
     n_all = args.steps + args.warmup
     sect = pipe.section_ms()
+    k_last = (n_all - 1) % n_seq
+    Tcw = pipe.pose().astype(np.float64)
+    drift = float(np.abs(Tcw[:3, 3] - frames[k_last]["Tcw"][:3, 3]).max()) if n_all <= n_seq else None
+    motions = pipe.motions()
 
     out = {
         "metric": "frames/sec (per-frame hot path, KITTI-0000-shaped 1242x375) + ms/LM-iter (batch factor graph)",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f64 (LM) / u8,i32,f32 (front-end)", "data": "synthetic",
-        "config": {"workload": "KITTI-0000-shaped per-frame hot path (C++ FramePipeline over the C-ABI): K15 UpdateMask, K1 depth, K11 propagation, ORB 2500 feats/8 levels "
-                               "(pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, joint pose+flow LM camera (1200) + 5 objects (800..200) with "
-                               "ref_quirks=1, K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets",
+        "dtype": "f64 (LM, RANSAC) / u8,i32,f32 (front-end, tracking)", "data": "synthetic",
+        "config": {"workload": "KITTI-0000-shaped TrackRGBD per frame (C++ FramePipeline over the C-ABI, full Track()): K15 UpdateMask, K1 depth, K11 propagation, "
+                               "RANSAC-P3P + motion-model initialisers, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, "
+                               "joint pose+flow LM for the camera (<=1200 matches) and every tracked object (ref_quirks=1) built from the frame's own correspondences, "
+                               "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets; "
+                               f"geometrically consistent synthetic sequence of {n_seq} frames, 3 moving objects",
                    "parallelism": f"replicas x{world}; inside a frame the LM chain (stream 2) overlaps the ORB front-end / RenewFrameInfo (stream 1)",
                    "orb_keypoints": counts.n_orb, "new_static_candidates": counts.n_static_new, "object_samples": counts.n_object_samples,
-                   "static_tracked": counts.n_static_tracked, "object_points_tracked": counts.n_object_tracked, "objects": counts.n_objects,
                    "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
-                   "camera_lm_iterations": int(lm["iterations"]),
+                   "per_frame_mean": {q: round(v / n_all, 2) for q, v in agg.items()},
+                   "trajectory_drift_m": drift, "object_translations_last_frame": [np.round(m["H"][:3, 3], 4).tolist() for m in motions],
                    "host_ms_per_section": {k_: round(v_ / n_all, 4) for k_, v_ in sect.items()}},
     }
 
@@ -266,9 +262,9 @@ def main():
             cb_ms, cb_sweep, cb_its = cpu_baseline_batch(g)
             out["cpu_baseline_batch"] = {"ms_per_lm_iter": cb_ms, "sweep_ms": cb_sweep, "iterations": cb_its, "cores": 1, "kind": "port"}
     if rank == 0 and not args.no_cpu_baseline:
-        cfps, cn, cstage = cpu_baseline_frames(frames, cam, obj)
+        cfps, cn, cstage, _ = cpu_baseline_frames(frames)
         out["cpu_baseline"] = {"value": cfps, "unit": "frames/s", "cores": 1, "kind": "port",
-                               "sample": f"{cn} frames of the same synthetic sequence through the same stages (oracle, 1 thread)",
+                               "sample": f"the first {cn} frames of the same sequence through the same full Track() (oracle, 1 thread)",
                                "ms_per_stage": cstage}
     if rank == 0:
         print(json.dumps(out))

@@ -6,8 +6,8 @@ from vdo_slam_amd import synth
 from vdo_slam_amd.ba import Context
 from vdo_slam_amd.flow2 import Flow2Batch
 ctx = Context(0)
-names = ["errors(iter)", "build", "solve-acc", "ldlt", "backsub", "xl+exp", "errors(trial)", "accept/ctl"]
-for label, probs in (("camera 1200", [synth.make_flow2_problem(1200, seed=4)]), ("object 300", [synth.make_flow2_problem(300, seed=33, is_object=True)])):
+names = ["schur sums", "serial ldlt+exp", "sweep (solve+err+build)", "accept/ctl", "init", "-", "-", "-"]
+for label, probs in (("camera 1200", [synth.make_flow2_problem(1200, seed=4)]), ("object 1000", [synth.make_flow2_problem(1000, seed=33, is_object=True)])):
     b = Flow2Batch(ctx, probs)
     b.run(); b.run()
     r = b.fetch()[0]

@@ -17,6 +17,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/vdo_slam_hip.h"
@@ -33,8 +34,8 @@ struct Flow2Dev {        // one problem, device pointers into the batch arrays
 };
 
 struct Flow2Arrays {
-  const double *obs, *meas, *depth;     // [2n],[2n],[n]
-  double *Xw, *fcur, *ftry, *err, *errp, *B2, *hl, *bl, *cl, *dinv, *xl;
+  const double* in;      // per problem at 5*off: key points [2][n], measured flow [2][n], depth [n]   (SoA planes)
+  double *Xw, *f0, *f1, *err, *B2a, *B2b, *hla, *hlb, *bla, *blb, *xl;
   double* flow_out; unsigned char* inlier_out;
   vdo_flow2_result* results;
 };
@@ -45,23 +46,29 @@ struct Flow2Arrays {
 #define F2_TICK(slot) do { } while (0)
 #endif
 
+// Work per LM trial: two sweeps over the correspondences and one serial section -
+//   (1) Schur sums  sum_i B_i D_i^-1 B_i^T, sum_i B_i D_i^-1 b_i  for this lambda        -> 27 block sums
+//   (2) lane 0: 6x6 pivoted LDLT, SE3 exp, pose part of computeScale
+//   (3) per correspondence: back-substitution, flow update, edge errors AT THE TRIAL POINT and - speculatively -
+//       the linearisation there (Jacobians, B blocks, 27 pose sums) into the alternate buffers   -> 29 block sums
+// An accepted trial makes the alternate buffers the current ones (g2o: the next iteration's computeActiveErrors +
+// buildSystem see exactly this estimate: same inputs, same code, same bits); a rejected one leaves them untouched.
 __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restrict__ probs, Flow2Arrays A) {
   const Flow2Dev P = probs[blockIdx.x];
   const int N = P.n, tid = threadIdx.x;
   const int64_t off = P.off;
-  const double* __restrict__ obs = A.obs + 2 * off; const double* __restrict__ meas = A.meas + 2 * off; const double* __restrict__ depth = A.depth + off;
-  double* __restrict__ Xw = A.Xw + 3 * off; double* fcur = A.fcur + 2 * off; double* ftry = A.ftry + 2 * off;
-  double* __restrict__ err = A.err + 2 * off; double* __restrict__ errp = A.errp + 2 * off; double* __restrict__ B2 = A.B2 + 12 * off;
-  double* __restrict__ hl = A.hl + off; double* __restrict__ bl = A.bl + 2 * off; double* __restrict__ cl = A.cl + 2 * off + blockIdx.x;
-  double* __restrict__ dinv = A.dinv + 9 * off; double* __restrict__ xl = A.xl + 2 * off + blockIdx.x;
+  const double* __restrict__ obs = A.in + 5 * off; const double* __restrict__ meas = obs + 2 * (size_t)N; const double* __restrict__ depth = obs + 4 * (size_t)N;
+  double* __restrict__ Xw = A.Xw + 3 * off; double* fcur = A.f0 + 2 * off; double* ftry = A.f1 + 2 * off;
+  double* __restrict__ err = A.err + 2 * off; double* __restrict__ xl = A.xl + 2 * off;
+  double *Bc = A.B2a + 12 * off, *Bt = A.B2b + 12 * off, *hc = A.hla + off, *ht = A.hlb + off, *bc = A.bla + 2 * off, *bt = A.blb + 2 * off;   // current / trial linearisation
   vdo_flow2_result* res = A.results + blockIdx.x;
 
-  __shared__ double s_scr[F2_WAVES * 28], s_red[28];
-  __shared__ double s_wide[28 * (F2_THREADS + 1)];
+  __shared__ double s_scr[F2_WAVES * 4], s_red[32];
+  __shared__ double s_wide[29 * (F2_THREADS + 1)];
   __shared__ SE3d s_T, s_Ttry;
-  __shared__ double s_Hpp[36], s_bp[6], s_xp[6], s_Hs[36], s_bs[6], s_xs[6];
+  __shared__ double s_Hc[27], s_xp[6];   // s_Hc: Hpp (lower triangle, packed) + bp of the current linearisation
   __shared__ double s_lambda, s_rho;
-  __shared__ int s_ctrl[4];   // [0] continue outer, [1] continue trial loop, [2] ok2, [3] accepted
+  __shared__ int s_ctrl[4];   // [2] ok2
 #ifdef F2_PROFILE
   __shared__ long long s_prof[16], s_tprev;
   if (tid == 0) { for (int i = 0; i < 16; ++i) s_prof[i] = 0; s_tprev = clock64(); }
@@ -74,6 +81,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     return;
   }
   const double fx = P.K[0], fy = P.K[1], cx = P.K[2], cy = P.K[3];
+  const bool Q = P.ref_quirks != 0;
   // ---- setup: Xw, flows, initial pose (Converter::toSE3Quat)
   for (int i = tid; i < N; i += F2_THREADS) {
     const double dz = depth[i];
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     Xw[N + i] = W[4] * x + W[5] * y + W[6] * dz + W[7];
     Xw[2 * N + i] = W[8] * x + W[9] * y + W[10] * dz + W[11];
     fcur[i] = meas[i]; fcur[N + i] = meas[N + i];
-    xl[i] = 0.0; xl[N + 1 + i] = 0.0;
+    xl[i] = 0.0; xl[N + i] = 0.0;
   }
   if (tid < 6) s_xp[tid] = 0.0;
   if (tid == 0) {
@@ -91,222 +99,249 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     s_T.r = q_from_R(R);
     q_normalize_pos(s_T.r);
     s_T.t[0] = P.T0[3]; s_T.t[1] = P.T0[7]; s_T.t[2] = P.T0[11];
-    s_ctrl[0] = 1;
   }
   __syncthreads();
 
-  // errors at (T, f): writes err/errp, returns robust chi2 (block-wide)
-  auto compute_errors = [&](const SE3d& T, const double* f) -> double {
-    double part[1] = {0.0};
+  // D_i^-1 of landmark i for this lambda.  ref_quirks (F3): BlockSolver_6_3 treats the 2-DoF flow vertex as 3-DoF, so the
+  // block is D3 = [h+l, h, 0; 0, l, 0; 0, 0, l] (h = Hll diagonal, exact zeros elsewhere) and Eigen's cofactor inverse of it is
+  //   [ l*l, -(h*l), 0;  0, (h+l)*l, 0;  0, 0, (h+l)*l ] * (1 / ((l*l)*(h+l)))
+  // - every other cofactor is a difference of products with a literal zero, i.e. exactly +-0 (oracle/flow_oracle.cpp runs the
+  // general 3x3 formula on the same block and gets the same bits).  d0 = Dinv(0,0), d1 = Dinv(0,1), d2 = Dinv(1,1) = Dinv(2,2).
+  auto dinv_q = [&](const double hh, const double lam, double& d0, double& d1, double& d2) {
+    const double a0 = hh + lam;
+    const double C00 = lam * lam, hl_ = hh * lam, al = a0 * lam;
+    const double id = 1.0 / (C00 * a0);
+    d0 = C00 * id; d1 = (-hl_) * id; d2 = al * id;
+  };
+  auto dinv_of = [&](const double hh, const double lam, double* Di) {      // ref_quirks == 0: the proper 2x2 block
+    const double a0 = hh + lam, a1 = 0.0, a2 = 0.0, a3 = hh + lam;
+    const double id = 1.0 / (a0 * a3 - a1 * a2);
+    Di[0] = a3 * id; Di[1] = -a1 * id; Di[2] = 0; Di[3] = -a2 * id; Di[4] = a0 * id; Di[5] = 0; Di[6] = 0; Di[7] = 0; Di[8] = 0;
+  };
+
+  // Sweep (3): TRIAL -> finish the solve for every correspondence (reads the current linearisation Br/hr/br and x_p),
+  // then evaluate + linearise the edges at (T, f) into Bw/hw/bw.  Block sums -> s_red[0..26] (Hpp lower, bp), [27] robust chi2,
+  // [28] landmark part of computeScale; returns the per-thread max of the Hll diagonal (computeLambdaInit).
+  auto sweep = [&](auto trial_c, const double lam, const bool ok2, const double* __restrict__ Br, const double* __restrict__ hr, const double* __restrict__ br,
+                   double* __restrict__ Bw, double* __restrict__ hw, double* __restrict__ bw, const double* fin, double* fout) -> double {
+    constexpr bool TRIAL = decltype(trial_c)::value;
+    const SE3d T = TRIAL ? s_Ttry : s_T;
+    double xp[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) xp[j] = s_xp[j];
+    double acc[29];
+#pragma unroll
+    for (int i = 0; i < 29; ++i) acc[i] = 0.0;
+    double hmax = 0.0;
     for (int i = tid; i < N; i += F2_THREADS) {
+      double f0v, f1v;
+      if (TRIAL) {
+        // back-substitution c = b_l - B^T x_p for this landmark
+        const double* B = Br + i;
+        double t0 = 0, t1 = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a) { t0 += B[(2 * a) * N] * (-xp[a]); t1 += B[(2 * a + 1) * N] * (-xp[a]); }
+        const double b0 = br[i], b1 = br[N + i];
+        const double c0 = b0 + t0, c1 = b1 + t1;
+        double x0, x1;
+        if (Q) {
+          // x[2i..2i+2] = D_i^-1 c_i with the aliased 3x3 block (dinv_q): rows 0/1 give this landmark's flow update, row 2 of
+          // landmark i-1 (= its d2 * c0 of THIS landmark: the aliased third component) was written into slot 2i first
+          double d0, d1, d2;
+          dinv_q(hr[i], lam, d0, d1, d2);
+          x0 = d0 * c0 + d1 * c1;
+          x1 = d2 * c1;
+          if (i > 0) {
+            double p0_, p1_, p2_;
+            dinv_q(hr[i - 1], lam, p0_, p1_, p2_);
+            x0 = p2_ * c0 + x0;
+          }
+        } else {
+          double Di[9];
+          dinv_of(hr[i], lam, Di);
+          x0 = (Di[0] * c0 + Di[1] * c1) + Di[2] * 0.0;
+          x1 = (Di[3] * c0 + Di[4] * c1) + Di[5] * 0.0;
+        }
+        if (!ok2) x0 = xl[i];         // failed LDLT: stale x (the reference keeps the previous content); the trial is rejected anyway
+        const double x1e = ok2 ? x1 : xl[N + i];
+        xl[i] = x0; xl[N + i] = x1e;
+        f0v = fin[i] + x0; f1v = fin[N + i] + x1e;
+        fout[i] = f0v; fout[N + i] = f1v;
+        acc[28] += x0 * (lam * x0 + b0) + x1e * (lam * x1e + b1);
+      } else {
+        f0v = fin[i]; f1v = fin[N + i];
+      }
+      // computeActiveErrors at (T, f)
       double pc[3];
       const double xw[3] = {Xw[i], Xw[N + i], Xw[2 * N + i]};
       q_rotate(T.r, xw, pc);
-      pc[0] += T.t[0]; pc[1] += T.t[1]; pc[2] += T.t[2];
-      const double u = pc[0] / pc[2] * fx + cx, v = pc[1] / pc[2] * fy + cy;
-      const double e0 = (obs[i] + f[i]) - u, e1 = (obs[N + i] + f[N + i]) - v;
+      const double X = pc[0] + T.t[0], Y = pc[1] + T.t[1], Z = pc[2] + T.t[2], Z2 = Z * Z;
+      const double u = X / Z * fx + cx, v = Y / Z * fy + cy;
+      const double e0 = (obs[i] + f0v) - u, e1 = (obs[N + i] + f1v) - v;
       err[i] = e0; err[N + i] = e1;
       const double c = e0 * (P.info_flow * e0) + e1 * (P.info_flow * e1);
       double r0, r1;
       huber_f2(c, P.huber_delta, P.huber_dsqr, r0, r1);
-      const double p0 = f[i] - meas[i], p1 = f[N + i] - meas[N + i];
-      errp[i] = p0; errp[N + i] = p1;
-      part[0] += r0 + (p0 * (P.info_prior * p0) + p1 * (P.info_prior * p1));
+      const double p0 = f0v - meas[i], p1 = f1v - meas[N + i];
+      acc[27] += r0 + (p0 * (P.info_prior * p0) + p1 * (P.info_prior * p1));
+      // buildSystem at the same point
+      double J[12];
+      J[0] = X * Y / Z2 * fx; J[1] = -(1 + (X * X / Z2)) * fx; J[2] = Y / Z * fx; J[3] = -1. / Z * fx; J[4] = 0; J[5] = X / Z2 * fx;
+      J[6] = (1 + Y * Y / Z2) * fy; J[7] = -X * Y / Z2 * fy; J[8] = -X / Z * fy; J[9] = 0; J[10] = -1. / Z * fy; J[11] = Y / Z2 * fy;
+      const double wo = r1 * P.info_flow;
+      const double or0 = -(P.info_flow * e0) * r1, or1 = -(P.info_flow * e1) * r1;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) { Bw[(2 * a) * N + i] = J[a] * wo; Bw[(2 * a + 1) * N + i] = J[6 + a] * wo; }
+      int k = 0;
+#pragma unroll
+      for (int a = 0; a < 6; ++a) {
+        acc[21 + a] += J[a] * or0 + J[6 + a] * or1;
+#pragma unroll
+        for (int c2 = 0; c2 <= a; ++c2) acc[k++] += J[a] * wo * J[c2] + J[6 + a] * wo * J[6 + c2];   // lower triangle
+      }
+      const double h = wo + P.info_prior;
+      hw[i] = h;                // Hll block = h * I2 (off-diagonals are exact zeros)
+      bw[i] = or0 - P.info_prior * p0;
+      bw[N + i] = or1 - P.info_prior * p1;
+      hmax = fmax(hmax, h);
     }
-    block_reduce<1>(part, s_scr, s_red);
-    const double r = s_red[0];
-    __syncthreads();
-    return r;
+    block_reduce_wide<29>(acc, s_wide, s_red);
+    return hmax;
   };
 
   double lambda = -1, ni = 2;
   int nBad = 0, it = 0, total_trials = 0, stop_reason = 0;
   const double tau = 1e-5, upper = 2. / 3., lower = 1. / 3.;
   double chi2_check = 0;
-  double last_err_chi = compute_errors(s_T, fcur);
+  // initial computeActiveErrors + buildSystem
+  double hmax = sweep(std::false_type{}, 0.0, true, nullptr, nullptr, nullptr, Bc, hc, bc, fcur, nullptr);
+  double last_err_chi = s_red[27];
   const double initial_chi2 = last_err_chi;
-  bool err_valid = true;
+  if (tid < 27) s_Hc[tid] = s_red[tid];
+  {
+    // computeLambdaInit: max |H(j,j)| over pose and flow vertices
+#pragma unroll
+    for (int off2 = 32; off2 > 0; off2 >>= 1) hmax = fmax(hmax, __shfl_down(hmax, off2, 64));
+    if ((tid & 63) == 0) s_scr[tid >> 6] = hmax;
+    __syncthreads();
+    if (tid == 0) {
+      double mm = s_scr[0];
+      for (int w = 1; w < F2_WAVES; ++w) mm = fmax(mm, s_scr[w]);
+      for (int j = 0; j < 6; ++j) mm = fmax(mm, fabs(s_Hc[j * (j + 3) / 2]));
+      s_lambda = tau * mm;
+    }
+    __syncthreads();
+    lambda = s_lambda; ni = 2; nBad = 0;
+  }
+  F2_TICK(4);
+  bool built = true;
   bool ok = true;
   for (; it < P.max_iterations && ok; ++it) {
-    F2_TICK(7);
-    // computeActiveErrors at the current estimate: err/errp and the chi2 are already those of this estimate
-    // when the previous trial was accepted (or right after the initial evaluation) - same inputs, same code,
-    // same bits - so the pass is only repeated after a rejected trial.
-    if (!err_valid) last_err_chi = compute_errors(s_T, fcur);
-    F2_TICK(0);
+    // computeActiveErrors + buildSystem at the current estimate: already there after an accepted trial; repeated
+    // only when the previous trial was rejected without ending the iteration loop (non-finite chi2)
+    if (!built) {
+      sweep(std::false_type{}, 0.0, true, nullptr, nullptr, nullptr, Bc, hc, bc, fcur, nullptr);
+      last_err_chi = s_red[27];
+      if (tid < 27) s_Hc[tid] = s_red[tid];
+      __syncthreads();
+      built = true;
+    }
     double currentChi = last_err_chi, tempChi = currentChi;
     const double iniChi = currentChi;
-    // ---- buildSystem
-    {
-      double acc[28];
-#pragma unroll
-      for (int i = 0; i < 28; ++i) acc[i] = 0.0;
-      const SE3d T = s_T;
-      for (int i = tid; i < N; i += F2_THREADS) {
-        double pc[3];
-        const double xw[3] = {Xw[i], Xw[N + i], Xw[2 * N + i]};
-        q_rotate(T.r, xw, pc);
-        const double X = pc[0] + T.t[0], Y = pc[1] + T.t[1], Z = pc[2] + T.t[2], Z2 = Z * Z;
-        double J[12];
-        J[0] = X * Y / Z2 * fx; J[1] = -(1 + (X * X / Z2)) * fx; J[2] = Y / Z * fx; J[3] = -1. / Z * fx; J[4] = 0; J[5] = X / Z2 * fx;
-        J[6] = (1 + Y * Y / Z2) * fy; J[7] = -X * Y / Z2 * fy; J[8] = -X / Z * fy; J[9] = 0; J[10] = -1. / Z * fy; J[11] = Y / Z2 * fy;
-        const double e0 = err[i], e1 = err[N + i];
-        const double c = e0 * (P.info_flow * e0) + e1 * (P.info_flow * e1);
-        double r0, r1;
-        huber_f2(c, P.huber_delta, P.huber_dsqr, r0, r1);
-        const double wo = r1 * P.info_flow;
-        const double or0 = -(P.info_flow * e0) * r1, or1 = -(P.info_flow * e1) * r1;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) { B2[(2 * a) * N + i] = J[a] * wo; B2[(2 * a + 1) * N + i] = J[6 + a] * wo; }
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          acc[21 + a] += J[a] * or0 + J[6 + a] * or1;
-#pragma unroll
-          for (int c2 = 0; c2 <= a; ++c2) acc[k++] += J[a] * wo * J[c2] + J[6 + a] * wo * J[6 + c2];   // lower triangle
-        }
-        const double h = wo + P.info_prior;
-        hl[i] = h;            // Hll block = h * I2 (off-diagonals are exact zeros)
-        bl[i] = or0 - P.info_prior * errp[i];
-        bl[N + i] = or1 - P.info_prior * errp[N + i];
-        acc[27] = fmax(acc[27], h);
-      }
-      // max needs its own reduction: do it through the same tree with fmax on slot 27
-      double mx[1] = {acc[27]};
-      acc[27] = 0;
-      block_reduce_wide<28>(acc, s_wide, s_red);
-      if (tid == 0) {
-        int k = 0;
-        for (int a = 0; a < 6; ++a) for (int c2 = 0; c2 <= a; ++c2) { s_Hpp[a * 6 + c2] = s_red[k]; s_Hpp[c2 * 6 + a] = s_red[k]; ++k; }
-        for (int a = 0; a < 6; ++a) s_bp[a] = s_red[21 + a];
-      }
-      __syncthreads();
-      if (it == 0) {
-        // computeLambdaInit: max |H(j,j)| over pose and flow vertices
-        double m = mx[0];
-#pragma unroll
-        for (int off2 = 32; off2 > 0; off2 >>= 1) m = fmax(m, __shfl_down(m, off2, 64));
-        if ((tid & 63) == 0) s_scr[tid >> 6] = m;
-        __syncthreads();
-        if (tid == 0) {
-          double mm = s_scr[0];
-          for (int w = 1; w < F2_WAVES; ++w) mm = fmax(mm, s_scr[w]);
-          for (int j = 0; j < 6; ++j) mm = fmax(mm, fabs(s_Hpp[7 * j]));
-          s_lambda = tau * mm;
-        }
-        __syncthreads();
-        lambda = s_lambda; ni = 2; nBad = 0;
-        __syncthreads();
-      }
-    }
-    F2_TICK(1);
     double rho = 0;
     int qmax = 0;
     do {
-      // ---- solve (Schur with the F3 aliasing)
-      const bool Q = P.ref_quirks != 0;
-      double acc[28];
+      // ---- (1) Schur sums for this lambda (with the F3 aliasing)
+      {
+        double acc[27];
 #pragma unroll
-      for (int i = 0; i < 28; ++i) acc[i] = 0.0;
-      for (int i = tid; i < N; i += F2_THREADS) {
-        double Di[9];
-        if (Q) {
-          const double hh = hl[i];
-          const double D3[9] = {hh + lambda, hh, 0, 0.0, lambda, 0, 0.0, 0, lambda};
-          inv3_dev(D3, Di);
-        } else {
-          const double a0 = hl[i] + lambda, a1 = 0.0, a2 = 0.0, a3 = hl[i] + lambda;
-          const double id = 1.0 / (a0 * a3 - a1 * a2);
-          Di[0] = a3 * id; Di[1] = -a1 * id; Di[2] = 0; Di[3] = -a2 * id; Di[4] = a0 * id; Di[5] = 0; Di[6] = 0; Di[7] = 0; Di[8] = 0;
+        for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+        const double* __restrict__ Br = Bc; const double* __restrict__ hr = hc; const double* __restrict__ br = bc;
+        for (int i = tid; i < N; i += F2_THREADS) {
+          const double bl0 = br[i], bl1 = br[N + i];
+          const double* B = Br + i;
+          double Bv[12];
+#pragma unroll
+          for (int a = 0; a < 12; ++a) Bv[a] = B[a * N];
+          if (Q) {
+            double d0, d1, d2;
+            dinv_q(hr[i], lambda, d0, d1, d2);
+            const double db0 = d0 * bl0 + d1 * bl1, db1 = d2 * bl1;      // (the aliased third row/column only ever meets exact zeros)
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+              acc[21 + a] += Bv[2 * a] * db0 + Bv[2 * a + 1] * db1;
+              const double bd0 = Bv[2 * a] * d0;
+              const double bd1 = Bv[2 * a] * d1 + Bv[2 * a + 1] * d2;
+#pragma unroll
+              for (int c2 = 0; c2 <= a; ++c2) acc[k++] += bd0 * Bv[2 * c2] + bd1 * Bv[2 * c2 + 1];   // lower triangle (LDLT reads only it)
+            }
+          } else {
+            double Di[9];
+            dinv_of(hr[i], lambda, Di);
+            const double db0 = Di[0] * bl0 + Di[1] * bl1, db1 = Di[3] * bl0 + Di[4] * bl1;
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+              acc[21 + a] += Bv[2 * a] * db0 + Bv[2 * a + 1] * db1;
+              const double bd0 = Bv[2 * a] * Di[0] + Bv[2 * a + 1] * Di[3];
+              const double bd1 = Bv[2 * a] * Di[1] + Bv[2 * a + 1] * Di[4];
+#pragma unroll
+              for (int c2 = 0; c2 <= a; ++c2) acc[k++] += bd0 * Bv[2 * c2] + bd1 * Bv[2 * c2 + 1];
+            }
+          }
         }
-#pragma unroll
-        for (int k = 0; k < 9; ++k) dinv[k * N + i] = Di[k];
-        const double b2 = (Q && i + 1 < N) ? bl[i + 1] : 0.0;
-        const double db0 = (Di[0] * bl[i] + Di[1] * bl[N + i]) + Di[2] * b2;
-        const double db1 = (Di[3] * bl[i] + Di[4] * bl[N + i]) + Di[5] * b2;
-        const double* B = B2 + i;
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) {
-          acc[21 + a] += B[(2 * a) * N] * db0 + B[(2 * a + 1) * N] * db1;
-          const double bd0 = B[(2 * a) * N] * Di[0] + B[(2 * a + 1) * N] * Di[3];
-          const double bd1 = B[(2 * a) * N] * Di[1] + B[(2 * a + 1) * N] * Di[4];
-#pragma unroll
-          for (int c2 = 0; c2 <= a; ++c2) acc[k++] += bd0 * B[(2 * c2) * N] + bd1 * B[(2 * c2 + 1) * N];   // lower triangle (LDLT reads only it)
-        }
+        block_reduce_wide<27>(acc, s_wide, s_red);
       }
-      block_reduce_wide<28>(acc, s_wide, s_red);
-      F2_TICK(2);
+      F2_TICK(0);
+      // ---- (2) reduced 6x6 system, SE3 update, pose part of computeScale
       if (tid == 0) {
-        double* Hs = s_Hs; double* bs = s_bs; double* xs = s_xs;      // LDS, not scratch: the pivoted LDLT indexes dynamically
-        for (int i = 0; i < 36; ++i) Hs[i] = s_Hpp[i];
-        int k = 0;
-        for (int a = 0; a < 6; ++a) for (int c2 = 0; c2 <= a; ++c2) { Hs[a * 6 + c2] -= s_red[k]; ++k; }
-        for (int j = 0; j < 6; ++j) { Hs[7 * j] += lambda; bs[j] = s_bp[j] - s_red[21 + j]; }
-        const bool ok2 = ldlt6_solve(Hs, bs, xs);
+        double Hs[36], bs[6], xs[6];                                   // registers: every index below is a constant after unrolling
+        {
+          int k = 0;
+#pragma unroll
+          for (int a = 0; a < 6; ++a) {
+#pragma unroll
+            for (int c2 = 0; c2 <= a; ++c2) { Hs[c2 * 6 + a] = s_Hc[k]; Hs[a * 6 + c2] = s_Hc[k] - s_red[k]; ++k; }
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) { Hs[7 * j] += lambda; bs[j] = s_Hc[21 + j] - s_red[21 + j]; }
+        const bool ok2 = ldlt6_solve_reg(Hs, bs, xs);
         s_ctrl[2] = ok2 ? 1 : 0;
-        if (ok2) for (int j = 0; j < 6; ++j) s_xp[j] = xs[j];
-        // (failed LDLT leaves x untouched in the reference; the trial is rejected anyway)
-      }
-      __syncthreads();
-      F2_TICK(3);
-      const bool ok2 = s_ctrl[2] != 0;
-      double xp[6];
+        if (ok2) {
 #pragma unroll
-      for (int j = 0; j < 6; ++j) xp[j] = s_xp[j];
-      // ---- back-substitution: cl = bl - B^T xp
-      for (int i = tid; i < N; i += F2_THREADS) {
-        const double* B = B2 + i;
-        double t0 = 0, t1 = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a) { t0 += B[(2 * a) * N] * (-xp[a]); t1 += B[(2 * a + 1) * N] * (-xp[a]); }
-        cl[i] = bl[i] + t0; cl[N + 1 + i] = bl[N + i] + t1;
-      }
-      if (tid == 0) cl[N] = 0.0;
-      __syncthreads();
-      F2_TICK(4);
-      // xl[2i..2i+1] = (Dinv_i c_i)[0..1] (+ row 2 of landmark i-1), update, scale
-      double sc[1] = {0.0};
-      for (int i = tid; i < N; i += F2_THREADS) {
-        const double* Di = dinv + i;
-        const double c0 = cl[i], c1 = cl[N + 1 + i], c2 = Q ? cl[i + 1] : 0.0;
-        double x0 = (Di[0] * c0 + Di[N] * c1) + Di[2 * N] * c2;
-        const double x1 = (Di[3 * N] * c0 + Di[4 * N] * c1) + Di[5 * N] * c2;
-        if (Q && i > 0) {
-          const double* Dp = dinv + (i - 1);
-          const double leak = (Dp[6 * N] * cl[i - 1] + Dp[7 * N] * cl[N + i]) + Dp[8 * N] * c0;
-          x0 = leak + x0;            // landmark i-1 wrote first, then landmark i added its row 0
+          for (int j = 0; j < 6; ++j) s_xp[j] = xs[j];
         }
-        if (!ok2) { x0 = xl[i]; }   // stale x (reference keeps the previous content)
-        const double x1e = ok2 ? x1 : xl[N + 1 + i];
-        xl[i] = x0; xl[N + 1 + i] = x1e;
-        ftry[i] = fcur[i] + x0; ftry[N + i] = fcur[N + i] + x1e;
-        sc[0] += x0 * (lambda * x0 + bl[i]) + x1e * (lambda * x1e + bl[N + i]);
-      }
-      if (tid == 0) {
+        // (failed LDLT leaves x untouched in the reference; the trial is rejected anyway)
         s_Ttry = se3_exp_compose(s_xp, s_T);
         double s = 0;
-        for (int j = 0; j < 6; ++j) s += s_xp[j] * (lambda * s_xp[j] + s_bp[j]);
+        for (int j = 0; j < 6; ++j) s += s_xp[j] * (lambda * s_xp[j] + s_Hc[21 + j]);
         s_rho = s;    // pose part of computeScale
       }
-      block_reduce<1>(sc, s_scr, s_red);
-      const double scale = (s_rho + s_red[0]) + 1e-3;
       __syncthreads();
-      F2_TICK(5);
-      last_err_chi = tempChi = compute_errors(s_Ttry, ftry);
-      F2_TICK(6);
+      F2_TICK(1);
+      const bool ok2 = s_ctrl[2] != 0;
+      // ---- (3) finish the solve per correspondence, errors + speculative linearisation at the trial point
+      sweep(std::true_type{}, lambda, ok2, Bc, hc, bc, Bt, ht, bt, fcur, ftry);
+      last_err_chi = tempChi = s_red[27];
+      const double scale = (s_rho + s_red[28]) + 1e-3;
+      F2_TICK(2);
       if (!ok2) tempChi = 1.7976931348623157e308;
       rho = (currentChi - tempChi) / scale;
       if (rho > 0 && isfinite(tempChi)) {
         double alpha = 1. - pow((2 * rho - 1), 3);
         alpha = fmin(alpha, upper);
-        lambda *= fmax(lower, alpha); ni = 2; currentChi = tempChi; err_valid = true;
-        { double* t_ = fcur; fcur = ftry; ftry = t_; }                       // discardTop(): accept (uniform pointer swap)
-        if (tid == 0) s_T = s_Ttry;
+        lambda *= fmax(lower, alpha); ni = 2; currentChi = tempChi; built = true;
+        { double* t_ = fcur; fcur = ftry; ftry = t_; }                       // discardTop(): accept (uniform pointer swaps)
+        { double* t_ = Bc; Bc = Bt; Bt = t_; t_ = hc; hc = ht; ht = t_; t_ = bc; bc = bt; bt = t_; }
+        if (tid < 27) s_Hc[tid] = s_red[tid];
+        if (tid == 32) s_T = s_Ttry;
       } else {
-        lambda *= ni; ni *= 2; err_valid = false;                         // pop(): keep (s_T, fcur)
+        lambda *= ni; ni *= 2; built = false;                               // pop(): keep (s_T, fcur) and their linearisation
       }
       __syncthreads();
+      F2_TICK(3);
       ++qmax; ++total_trials;
     } while (rho < 0 && qmax < 10);
     int result;
@@ -334,15 +369,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   }
   block_reduce<1>(cnt, s_scr, s_red);
   if (tid == 0) {
-    // SE3Quat::to_homogeneous_matrix
-    const Q4 q = s_T.r;
-    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
-    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
-    double* T = res->T;
-    T[0] = 1 - (tyy + tzz); T[1] = txy - twz; T[2] = txz + twy; T[3] = s_T.t[0];
-    T[4] = txy + twz; T[5] = 1 - (txx + tzz); T[6] = tyz - twx; T[7] = s_T.t[1];
-    T[8] = txz - twy; T[9] = tyz + twx; T[10] = 1 - (txx + tyy); T[11] = s_T.t[2];
-    T[12] = 0; T[13] = 0; T[14] = 0; T[15] = 1;
+    se3_to_matrix(s_T, res->T);
     res->n_inliers = (int)(s_red[0] + 0.5);
     res->iterations = it; res->trials = total_trials; res->stop_reason = stop_reason;
     res->initial_chi2 = initial_chi2; res->final_chi2 = last_err_chi; res->final_lambda = lambda;
@@ -369,6 +396,7 @@ struct vdo_flow2_batch {
   double* h_up = nullptr;         // pinned staging of in-place problem updates: 5 doubles per point of capacity
   std::vector<Flow2Dev> hp;       // host mirror of d_probs
   std::vector<int> caps;          // capacity (points) of every problem slot
+  bool probs_dirty = false;       // host mirror changed since the last upload of d_probs
 };
 
 extern "C" int vdo_flow2_batch_destroy(vdo_flow2_batch* b) {
@@ -411,32 +439,29 @@ extern "C" int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_fl
     return p;
   };
   const size_t T = (size_t)total, NP = (size_t)n_problems;
-  std::vector<double> obs(2 * T), meas(2 * T), dep(T);
+  std::vector<double> in(5 * T);
   for (int k = 0; k < n_problems; ++k) {
     const vdo_flow2_problem& p = probs[k];
     if (p.n == 0) continue;
-    // per-problem SoA planes [2][n]: consecutive lanes read consecutive doubles (512 B per wave load)
-    double* po = obs.data() + 2 * b->offs[k]; double* pm = meas.data() + 2 * b->offs[k];
+    // per-problem SoA planes: key points [2][n], measured flow [2][n], depth [n]: consecutive lanes read consecutive doubles
+    double* po = in.data() + 5 * b->offs[k]; double* pm = po + 2 * (size_t)p.n;
     for (int i = 0; i < p.n; ++i) { po[i] = p.obs[2 * i]; po[p.n + i] = p.obs[2 * i + 1]; pm[i] = p.flow[2 * i]; pm[p.n + i] = p.flow[2 * i + 1]; }
-    std::memcpy(dep.data() + b->offs[k], p.depth, sizeof(double) * p.n);
+    std::memcpy(po + 4 * (size_t)p.n, p.depth, sizeof(double) * p.n);
   }
-  double* d_obs = (double*)dev(16 * T); double* d_meas = (double*)dev(16 * T); double* d_dep = (double*)dev(8 * T);
+  double* d_in = (double*)dev(40 * T);
   b->d_probs = (Flow2Dev*)dev(sizeof(Flow2Dev) * NP);
   Flow2Arrays& A = b->A;
-  A.obs = d_obs; A.meas = d_meas; A.depth = d_dep;
-  A.Xw = (double*)dev(24 * T); A.fcur = (double*)dev(16 * T); A.ftry = (double*)dev(16 * T);
-  A.err = (double*)dev(16 * T); A.errp = (double*)dev(16 * T); A.B2 = (double*)dev(96 * T);
-  A.hl = (double*)dev(8 * T); A.bl = (double*)dev(16 * T + 8); A.cl = (double*)dev(16 * T + 8 * NP + 8);
-  A.dinv = (double*)dev(72 * T); A.xl = (double*)dev(16 * T + 8 * NP + 8);
+  A.in = d_in;
+  A.Xw = (double*)dev(24 * T); A.f0 = (double*)dev(16 * T); A.f1 = (double*)dev(16 * T);
+  A.err = (double*)dev(16 * T); A.B2a = (double*)dev(96 * T); A.B2b = (double*)dev(96 * T);
+  A.hla = (double*)dev(8 * T); A.hlb = (double*)dev(8 * T); A.bla = (double*)dev(16 * T); A.blb = (double*)dev(16 * T);
+  A.xl = (double*)dev(16 * T);
   A.flow_out = (double*)dev(16 * T); A.inlier_out = (unsigned char*)dev(T);
   A.results = (vdo_flow2_result*)dev(sizeof(vdo_flow2_result) * NP);
   for (void* p : b->allocs) if (!p) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
-  if (!A.results || !d_obs) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
-  hipMemcpyAsync(d_obs, obs.data(), 16 * T, hipMemcpyHostToDevice, s);
-  hipMemcpyAsync(d_meas, meas.data(), 16 * T, hipMemcpyHostToDevice, s);
-  hipMemcpyAsync(d_dep, dep.data(), 8 * T, hipMemcpyHostToDevice, s);
+  if (!A.results || !d_in) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  hipMemcpyAsync(d_in, in.data(), 40 * T, hipMemcpyHostToDevice, s);
   hipMemcpyAsync(b->d_probs, hp.data(), sizeof(Flow2Dev) * NP, hipMemcpyHostToDevice, s);
-  hipMemsetAsync(A.xl, 0, 16 * T + 8 * NP + 8, s);
   if (hipHostMalloc((void**)&b->h_pin, sizeof(vdo_flow2_result) * NP + 16 * T + T + 64) != hipSuccess) { b->h_pin = nullptr; vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipHostMalloc failed"); }
   if (hipStreamSynchronize(s) != hipSuccess) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_NO_DEVICE, "flow2 upload failed"); }
   b->hp = hp; b->caps = b->ns;
@@ -481,9 +506,7 @@ extern "C" int vdo_flow2_batch_set(vdo_flow2_batch* b, int k, const vdo_flow2_pr
     double* st = b->h_up + 5 * off;
     double *po = st, *pm = st + 2 * (size_t)n, *pd = st + 4 * (size_t)n;
     for (int i = 0; i < n; ++i) { po[i] = p->obs[2 * i]; po[n + i] = p->obs[2 * i + 1]; pm[i] = p->flow[2 * i]; pm[n + i] = p->flow[2 * i + 1]; pd[i] = p->depth[i]; }
-    hipMemcpyAsync((double*)b->A.obs + 2 * off, po, 16 * (size_t)n, hipMemcpyHostToDevice, s);
-    hipMemcpyAsync((double*)b->A.meas + 2 * off, pm, 16 * (size_t)n, hipMemcpyHostToDevice, s);
-    hipMemcpyAsync((double*)b->A.depth + off, pd, 8 * (size_t)n, hipMemcpyHostToDevice, s);
+    hipMemcpyAsync((double*)b->A.in + 5 * off, st, 40 * (size_t)n, hipMemcpyHostToDevice, s);      // one copy: the slot has the staging's layout
     d.max_iterations = p->max_iterations; d.ref_quirks = p->ref_quirks;
     std::memcpy(d.K, p->K, sizeof(d.K)); std::memcpy(d.Twl, p->Twl, sizeof(d.Twl)); std::memcpy(d.T0, p->T0, sizeof(d.T0));
     d.info_flow = p->info_flow; d.info_prior = p->info_prior; d.huber_delta = p->huber_delta;
@@ -491,9 +514,7 @@ extern "C" int vdo_flow2_batch_set(vdo_flow2_batch* b, int k, const vdo_flow2_pr
     d.chi2_gate = p->chi2_gate;
   }
   d.n = n; b->ns[k] = n;
-  Flow2Dev* pst = (Flow2Dev*)(b->h_up + 5 * (size_t)std::max<int64_t>(b->total, 1)) + k;       // pinned copy of the descriptor
-  *pst = d;
-  hipMemcpyAsync(b->d_probs + k, pst, sizeof(Flow2Dev), hipMemcpyHostToDevice, s);
+  b->probs_dirty = true;                 // the descriptors go up in one copy at the next run
   return VDO_OK;
 }
 
@@ -501,6 +522,12 @@ extern "C" int vdo_flow2_batch_run(vdo_flow2_batch* b) {
   if (!b) return set_error(VDO_ERR_INVALID, "null handle");
   int rc = ctx_bind(b->ctx);
   if (rc != VDO_OK) return rc;
+  if (b->probs_dirty) {
+    Flow2Dev* pst = (Flow2Dev*)(b->h_up + 5 * (size_t)std::max<int64_t>(b->total, 1));           // pinned copy of the descriptors
+    std::memcpy(pst, b->hp.data(), sizeof(Flow2Dev) * (size_t)b->n_problems);
+    hipMemcpyAsync(b->d_probs, pst, sizeof(Flow2Dev) * (size_t)b->n_problems, hipMemcpyHostToDevice, b->ctx->stream);
+    b->probs_dirty = false;
+  }
   hipLaunchKernelGGL(k_flow2_lm, dim3(b->n_problems), dim3(F2_THREADS), 0, b->ctx->stream, (const Flow2Dev*)b->d_probs, b->A);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "k_flow2_lm launch: %s", hipGetErrorString(e));

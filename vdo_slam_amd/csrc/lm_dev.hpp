@@ -24,7 +24,20 @@ __device__ __forceinline__ void q_rotate(const Q4& q, const double* v, double* o
   o[1] = v[1] + q.w * uy + (q.z * ux - q.x * uz);
   o[2] = v[2] + q.w * uz + (q.x * uy - q.y * ux);
 }
-__device__ inline Q4 q_from_R(const double* m) {   // Eigen Quaterniond(Matrix3d)
+template <int I>
+__device__ __forceinline__ Q4 q_from_R_neg_trace(const double* m) {   // constant indices: R stays in registers
+  constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+  double t = sqrt(m[4 * I] - m[4 * J] - m[4 * K] + 1.0);
+  double c[3];
+  c[I] = 0.5 * t; t = 0.5 / t;
+  Q4 q;
+  q.w = (m[3 * K + J] - m[3 * J + K]) * t;
+  c[J] = (m[3 * J + I] + m[3 * I + J]) * t;
+  c[K] = (m[3 * K + I] + m[3 * I + K]) * t;
+  q.x = c[0]; q.y = c[1]; q.z = c[2];
+  return q;
+}
+__device__ __forceinline__ Q4 q_from_R(const double* m) {   // Eigen Quaterniond(Matrix3d)
   Q4 q;
   double t = m[0] + m[4] + m[8];
   if (t > 0.0) {
@@ -33,15 +46,8 @@ __device__ inline Q4 q_from_R(const double* m) {   // Eigen Quaterniond(Matrix3d
   } else {
     int i = 0;
     if (m[4] > m[0]) i = 1;
-    if (m[8] > m[4 * i]) i = 2;
-    const int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
-    double c[3];
-    c[i] = 0.5 * t; t = 0.5 / t;
-    q.w = (m[3 * k + j] - m[3 * j + k]) * t;
-    c[j] = (m[3 * j + i] + m[3 * i + j]) * t;
-    c[k] = (m[3 * k + i] + m[3 * i + k]) * t;
-    q.x = c[0]; q.y = c[1]; q.z = c[2];
+    if (m[8] > (i == 1 ? m[4] : m[0])) i = 2;
+    q = i == 0 ? q_from_R_neg_trace<0>(m) : (i == 1 ? q_from_R_neg_trace<1>(m) : q_from_R_neg_trace<2>(m));
   }
   return q;
 }
@@ -134,6 +140,87 @@ __device__ inline bool ldlt6_solve(double* m /*36, destroyed*/, const double* b,
   for (int i = 0; i < n; ++i) { if (fabs(m[i * 6 + i]) > 2.2250738585072014e-308) x[i] /= m[i * 6 + i]; else x[i] = 0; }
   for (int i = n - 1; i >= 0; --i) for (int j = i + 1; j < n; ++j) x[i] -= m[j * 6 + i] * x[j];
   for (int k = n - 1; k >= 0; --k) { const double t = x[k]; x[k] = x[tr[k]]; x[tr[k]] = t; }
+  return true;
+}
+
+// The same factorisation with every index a compile-time constant (full unrolling; the run-time pivot is dispatched through
+// a chain of uniform branches), so the 6x6 block lives in registers: the LDS version above pays ~100 cycles of dependent
+// latency per element access, ~10k cycles per solve on the one active lane.  Same operations in the same order.
+__device__ __forceinline__ bool ldlt6_solve_reg(double (&m)[36], const double (&b)[6], double (&x)[6]) {
+  int tr[6] = {0, 1, 2, 3, 4, 5};
+  int sign = 0;
+  bool stop = false;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (stop) continue;
+    int big = k;
+    double bv = fabs(m[k * 6 + k]);
+#pragma unroll
+    for (int i = k + 1; i < 6; ++i) if (fabs(m[i * 6 + i]) > bv) { bv = fabs(m[i * 6 + i]); big = i; }
+    tr[k] = big;
+#pragma unroll
+    for (int bb = k + 1; bb < 6; ++bb) {
+      if (big != bb) continue;
+#pragma unroll
+      for (int j = 0; j < k; ++j) { const double t = m[k * 6 + j]; m[k * 6 + j] = m[bb * 6 + j]; m[bb * 6 + j] = t; }
+#pragma unroll
+      for (int i = bb + 1; i < 6; ++i) { const double t = m[i * 6 + k]; m[i * 6 + k] = m[i * 6 + bb]; m[i * 6 + bb] = t; }
+      { const double t = m[k * 6 + k]; m[k * 6 + k] = m[bb * 6 + bb]; m[bb * 6 + bb] = t; }
+#pragma unroll
+      for (int i = k + 1; i < bb; ++i) { const double t = m[i * 6 + k]; m[i * 6 + k] = m[bb * 6 + i]; m[bb * 6 + i] = t; }
+    }
+    if (k > 0) {
+      double temp[6];
+#pragma unroll
+      for (int j = 0; j < k; ++j) temp[j] = m[j * 6 + j] * m[k * 6 + j];
+      double s = 0;
+#pragma unroll
+      for (int j = 0; j < k; ++j) s += m[k * 6 + j] * temp[j];
+      m[k * 6 + k] -= s;
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) {
+        double t = 0;
+#pragma unroll
+        for (int j = 0; j < k; ++j) t += m[i * 6 + j] * temp[j];
+        m[i * 6 + k] -= t;
+      }
+    }
+    const double akk = m[k * 6 + k];
+    const bool valid = fabs(akk) > 0.0;
+    if (k == 0 && !valid) { sign = 0; stop = true; continue; }      // (tr stays the identity: tr[0] = 0 when every diagonal entry is 0)
+    if (valid) {
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) m[i * 6 + k] /= akk;
+    }
+    if (sign == 1) { if (akk < 0) sign = 2; }
+    else if (sign == -1) { if (akk > 0) sign = 2; }
+    else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = -1; }
+  }
+  if (!(sign == 1 || sign == 0)) return false;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) x[i] = b[i];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+#pragma unroll
+    for (int bb = k + 1; bb < 6; ++bb) if (tr[k] == bb) { const double t = x[k]; x[k] = x[bb]; x[bb] = t; }
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j < i; ++j) x[i] -= m[i * 6 + j] * x[j];
+  }
+#pragma unroll
+  for (int i = 0; i < 6; ++i) { if (fabs(m[i * 6 + i]) > 2.2250738585072014e-308) x[i] /= m[i * 6 + i]; else x[i] = 0; }
+#pragma unroll
+  for (int i = 5; i >= 0; --i) {
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) x[i] -= m[j * 6 + i] * x[j];
+  }
+#pragma unroll
+  for (int k = 5; k >= 0; --k) {
+#pragma unroll
+    for (int bb = k + 1; bb < 6; ++bb) if (tr[k] == bb) { const double t = x[k]; x[k] = x[bb]; x[bb] = t; }
+  }
   return true;
 }
 

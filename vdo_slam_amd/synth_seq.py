@@ -25,9 +25,10 @@ def camera_poses(n_frames, step=0.8, yaw_amp=0.004):
 
 def default_objects():
     """(centre xyz at frame 0 [m], half width, half height, velocity per frame [m])."""
-    return [dict(c=np.array([-3.0, 0.9, 14.0]), hw=1.1, hh=0.75, v=np.array([0.0, 0.0, 1.1])),
-            dict(c=np.array([2.5, 0.85, 10.0]), hw=1.0, hh=0.8, v=np.array([0.02, 0.0, 0.55])),
-            dict(c=np.array([5.0, 0.9, 19.0]), hw=1.2, hh=0.75, v=np.array([-0.03, 0.0, 0.9]))]
+    # velocities close to the camera's 0.8 m/frame: the objects stay inside ThDepthObj for ~100 frames
+    return [dict(c=np.array([-3.0, 0.9, 14.0]), hw=1.1, hh=0.75, v=np.array([0.0, 0.0, 0.9])),
+            dict(c=np.array([2.5, 0.85, 10.0]), hw=1.0, hh=0.8, v=np.array([0.01, 0.0, 0.76])),
+            dict(c=np.array([5.0, 0.9, 19.0]), hw=1.2, hh=0.75, v=np.array([-0.02, 0.0, 0.85]))]
 
 
 def render_frame(k, Ts, objects, w=KITTI_W, h=KITTI_H, K4=KITTI_K, flow_sigma=0.0, seed=0):
