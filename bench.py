@@ -37,6 +37,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 N_DISTINCT_FRAMES = 4   # make_frame_inputs(): independent random frames (tools/frame_probe.py)
+FLOW_SIGMA = 0.05       # px, noise of the dense flow input (a noise-free flow lets the object LMs chase 1e-15 residuals for 100+ iterations)
 MAX_SEQ_FRAMES = 160    # length of the consistent synthetic sequence (the objects stay in view that long)
 
 
@@ -138,19 +139,21 @@ def main():
         ctx_ba = Context(local, stream.cuda_stream)          # batch / roofline legs: whole chip, torch's stream
     else:
         ctx = ctx_ba = Context(local, stream.cuda_stream)
-        ctx_lm = Context(local)           # second HIP stream: the per-frame LM kernels overlap the ORB front-end of the same frame
+        ctx_lm = Context(local)           # second HIP stream: the camera LM overlaps the ORB front-end of the same frame
+    ctx_obj = Context(local)              # third HIP stream: the object LMs overlap RenewFrameInfo and the next frame's camera stage
     # ---- the sequence: geometrically consistent synthetic KITTI-shaped RGB-D + flow + masks (vdo_slam_amd/synth_seq.py),
     # one distinct frame per step, resident in HBM before the timed region
     W, H = synth.KITTI_W, synth.KITTI_H
     n_seq = min(args.steps + args.warmup, MAX_SEQ_FRAMES)
     Ts = SQ.camera_poses(n_seq)
     objs = SQ.default_objects()
-    frames = [SQ.render_frame(k, Ts, objs, seed=17 * rank) for k in range(n_seq)]
+    frames = [SQ.render_frame(k, Ts, objs, flow_sigma=FLOW_SIGMA, seed=17 * rank) for k in range(n_seq)]
     dev = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames]
     # The per-frame sequence runs in the C++ host class FramePipeline (vdo_slam_amd/host/FramePipeline.cc: the hot
     # part of Tracking::GrabImageRGBD + Track over the C-ABI, state chained frame to frame); one ctypes call per frame.
     from vdo_slam_amd.pipeline import FramePipeline, kitti_params
-    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1))
+    defer = 0 if os.environ.get("VDO_BENCH_SYNC_OBJECTS") else 1
+    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj)
     torch.cuda.synchronize()
     counts = pipe.counts
     agg = {"cam_lm_iterations": 0, "n_static_tracked": 0, "n_object_tracked": 0, "n_objects": 0, "n_ransac_cam": 0, "n_cam_inliers": 0}
@@ -174,10 +177,12 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    pipe.flush()
     barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
         step(args.warmup + i)                 # the sequence continues where the warm-up left it
+    pipe.flush()                              # deferred mode: the object stage of the last frame ends inside the timed region
     barrier()
     dt = time.perf_counter() - t0
     tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
@@ -201,8 +206,9 @@ def main():
                                "RANSAC-P3P + motion-model initialisers, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, "
                                "joint pose+flow LM for the camera (<=1200 matches) and every tracked object (ref_quirks=1) built from the frame's own correspondences, "
                                "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets; "
-                               f"geometrically consistent synthetic sequence of {n_seq} frames, 3 moving objects",
-                   "parallelism": f"replicas x{world}; inside a frame the LM chain (stream 2) overlaps the ORB front-end / RenewFrameInfo (stream 1)",
+                               f"geometrically consistent synthetic sequence of {n_seq} frames, 3 moving objects, flow noise sigma {FLOW_SIGMA} px",
+                   "parallelism": f"replicas x{world}; 3 HIP streams per replica: camera LM (2) || ORB front-end (1); object LMs (3) || RenewFrameInfo (1) and - "
+                                  f"defer_objects={defer} - the next frame's camera stage; every LM problem runs on a cluster of up to 8 workgroups",
                    "orb_keypoints": counts.n_orb, "new_static_candidates": counts.n_static_new, "object_samples": counts.n_object_samples,
                    "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
                    "per_frame_mean": {q: round(v / n_all, 2) for q, v in agg.items()},

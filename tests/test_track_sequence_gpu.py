@@ -74,3 +74,47 @@ def test_full_track_sequence_matches_the_oracle_sequence(oracle):
             assert (a["mod_label"], a["sem_label"], a["n_inliers"]) == (b["mod_label"], b["sem_label"], b["n_inliers"])
             np.testing.assert_allclose(a["H"], b["H"], rtol=0, atol=5e-6)
     pipe.close()
+
+
+def test_deferred_object_stage_gives_the_same_sequence():
+    """defer_objects=1 (object LMs of frame k consumed inside Step(k+1), three streams) reorders work across the
+    frame boundary without changing any data dependency: poses, per-frame counts (object counts one Step later),
+    object motions and tracklets are identical to the synchronous mode."""
+    import torch
+    n_frames = 7
+    Ts = SQ.camera_poses(n_frames)
+    objs = SQ.default_objects()
+    frames = [SQ.render_frame(k, Ts, objs, flow_sigma=0.05) for k in range(n_frames)]
+    dev = [{q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for fr in frames]
+    torch.cuda.synchronize()
+
+    def run(defer):
+        ctx, ctx_lm, ctx_obj = Context(0), Context(0), Context(0)
+        pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj)
+        poses, counts, motions = [], [], []
+        for k, d in enumerate(dev):
+            c = pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
+            if defer and k > 0:      # the object stage of frame k-1 ended inside this Step
+                counts[-1]["n_object_tracked"], counts[-1]["n_dynamic_tracks"] = c["n_object_tracked"], c["n_dynamic_tracks"]
+                motions.append(pipe.motions())
+            poses.append(pipe.pose().copy()); counts.append(dict(c))
+            if not defer:
+                motions.append(pipe.motions())
+        if defer:
+            c = pipe.flush()
+            counts[-1]["n_object_tracked"], counts[-1]["n_dynamic_tracks"] = c["n_object_tracked"], c["n_dynamic_tracks"]
+            motions.append(pipe.motions())
+        pipe.close()
+        return poses, counts, motions
+
+    p0, c0, m0 = run(0)
+    p1, c1, m1 = run(1)
+    assert c0[1:] == c1[1:], [(a, b) for a, b in zip(c0, c1) if a != b][:2]
+    for a, b in zip(p0, p1):
+        assert np.array_equal(a, b)
+    # synchronous mode reports the motions of frame k after Step(k); deferred mode after Step(k+1) / flush
+    assert len(m0) == len(m1) == n_frames
+    for a, b in zip(m0, m1):
+        assert [(x["mod_label"], x["sem_label"], x["n_inliers"]) for x in a] == [(x["mod_label"], x["sem_label"], x["n_inliers"]) for x in b]
+        for x, y in zip(a, b):
+            assert np.array_equal(x["H"], y["H"])

@@ -6,12 +6,12 @@ from vdo_slam_amd import synth
 from vdo_slam_amd.ba import Context
 from vdo_slam_amd.flow2 import Flow2Batch
 ctx = Context(0)
-names = ["schur sums", "serial ldlt+exp", "sweep (solve+err+build)", "accept/ctl", "init", "-", "-", "-"]
-for label, probs in (("camera 1200", [synth.make_flow2_problem(1200, seed=4)]), ("object 1000", [synth.make_flow2_problem(1000, seed=33, is_object=True)])):
+names = ["schur sums", "serial tail", "sweep (solve+err+build)", "accept/ctl", "init", "serial: Hs", "serial: ldlt", "serial: exp+scale"]
+sizes = [int(a) for a in sys.argv[1:]] or [1200, 1000]
+for label, probs in [("n=%d" % n, [synth.make_flow2_problem(n, seed=4)]) for n in sizes]:
     b = Flow2Batch(ctx, probs)
     b.run(); b.run()
     r = b.fetch()[0]
     cyc = np.array(r["T"]).ravel()[:8]
     print(label, "its", r["iterations"], "trials", r["trials"], "total cycles %.0f" % cyc.sum())
-    for n, c in zip(names, cyc):
-        print("   %-14s %9.0f cycles  %5.1f %%" % (n, c, 100 * c / cyc.sum()))
+    print("   per trial: " + ", ".join("%s %.0f" % (n, c / max(1, r["trials"])) for n, c in zip(names, cyc) if n != "init"))

@@ -29,6 +29,7 @@ namespace vdo {
 struct Flow2Dev {        // one problem, device pointers into the batch arrays
   int n, max_iterations, ref_quirks, pad;
   int64_t off;           // element offset of this problem inside the per-landmark arrays
+  int64_t out_off, out_total;   // outputs are packed by the ACTUAL sizes (one D2H copy of exactly what was computed): offset of this problem, sum over the batch
   double K[4], Twl[16], T0[16];
   double info_flow, info_prior, huber_delta, huber_dsqr, chi2_gate;
 };
@@ -36,9 +37,26 @@ struct Flow2Dev {        // one problem, device pointers into the batch arrays
 struct Flow2Arrays {
   const double* in;      // per problem at 5*off: key points [2][n], measured flow [2][n], depth [n]   (SoA planes)
   double *Xw, *f0, *f1, *err, *B2a, *B2b, *hla, *hlb, *bla, *blb, *xl;
-  double* flow_out; unsigned char* inlier_out;
-  vdo_flow2_result* results;
+  char* out;             // [results n_problems][refined flows 2*out_total doubles, (x, y) per point][inlier flags out_total bytes]
+  int n_problems;
+  struct Flow2Comm* comm;   // [n_problems]: exchange area of the workgroup cluster of every problem
 };
+
+// One problem is spread over a CLUSTER of up to F2_CLUSTER workgroups (one CU each; a single wave needs ~8k cycles per
+// correspondence and trial, so one workgroup with 5 correspondences per thread is 4x slower than five with one each).
+// The workgroups exchange their block sums through this area (double-buffered by phase parity) and meet at a counter
+// barrier; every workgroup then adds the partial sums in the same order, runs the same 6x6 solve and takes the same
+// decisions - same bits everywhere, so the control flow (and the number of barriers) is identical across the cluster.
+constexpr int F2_CLUSTER = 8;
+static_assert(F2_THREADS == 32 * F2_CLUSTER, "cluster exchange: one thread per (workgroup, value)");
+// Exchange slot: one double as two {32-bit half, 32-bit phase tag} words.  8-byte stores are single-copy atomic, so a reader
+// that finds both tags equal to the phase it waits for has the value of that phase - no fence, no separate flag, one round
+// trip through L2 (the LL idea of RCCL's low-latency protocol).
+struct Flow2Slot { unsigned int lo, tag_lo, hi, tag_hi; };
+struct Flow2Comm {
+  Flow2Slot slot[2][F2_CLUSTER][32];    // [phase & 1][workgroup][0..28 sums, 29 max, 30 Hll diagonal of the chunk's last landmark]
+};
+typedef unsigned int f2_u32x4 __attribute__((ext_vector_type(4)));
 
 #ifdef F2_PROFILE
 #define F2_TICK(slot) do { if (tid == 0) { const long long t_ = clock64(); s_prof[slot] += t_ - s_tprev; s_tprev = t_; } } while (0)
@@ -54,21 +72,32 @@ struct Flow2Arrays {
 // An accepted trial makes the alternate buffers the current ones (g2o: the next iteration's computeActiveErrors +
 // buildSystem see exactly this estimate: same inputs, same code, same bits); a rejected one leaves them untouched.
 __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restrict__ probs, Flow2Arrays A) {
-  const Flow2Dev P = probs[blockIdx.x];
+  const int prob = blockIdx.x / F2_CLUSTER, wg = blockIdx.x % F2_CLUSTER;
+  const Flow2Dev P = probs[prob];
   const int N = P.n, tid = threadIdx.x;
+  const int Gp = min(F2_CLUSTER, max(1, (N + F2_THREADS - 1) / F2_THREADS));      // workgroups that share this problem
+  if (wg >= Gp) return;
+  __builtin_amdgcn_s_setprio(3);        // latency-bound persistent workgroups: issue ahead of the throughput kernels sharing the CU
+  const int chunk = (N + Gp - 1) / Gp, c_lo = wg * chunk, c_hi = min(N, c_lo + chunk);   // this workgroup's correspondences [c_lo, c_hi): nothing but
+  const int first = c_lo + tid, stride = F2_THREADS;                                      // the block sums (and one Hll entry) crosses workgroups
+  Flow2Comm* comm = A.comm + prob;
   const int64_t off = P.off;
   const double* __restrict__ obs = A.in + 5 * off; const double* __restrict__ meas = obs + 2 * (size_t)N; const double* __restrict__ depth = obs + 4 * (size_t)N;
   double* __restrict__ Xw = A.Xw + 3 * off; double* fcur = A.f0 + 2 * off; double* ftry = A.f1 + 2 * off;
   double* __restrict__ err = A.err + 2 * off; double* __restrict__ xl = A.xl + 2 * off;
   double *Bc = A.B2a + 12 * off, *Bt = A.B2b + 12 * off, *hc = A.hla + off, *ht = A.hlb + off, *bc = A.bla + 2 * off, *bt = A.blb + 2 * off;   // current / trial linearisation
-  vdo_flow2_result* res = A.results + blockIdx.x;
+  vdo_flow2_result* res = (vdo_flow2_result*)A.out + prob;
+  double* __restrict__ flow_out = (double*)(A.out + sizeof(vdo_flow2_result) * (size_t)A.n_problems) + 2 * P.out_off;
+  unsigned char* __restrict__ inlier_out = (unsigned char*)((double*)(A.out + sizeof(vdo_flow2_result) * (size_t)A.n_problems) + 2 * P.out_total) + P.out_off;
 
   __shared__ double s_scr[F2_WAVES * 4], s_red[32];
   __shared__ double s_wide[29 * (F2_THREADS + 1)];
   __shared__ SE3d s_T, s_Ttry;
   __shared__ double s_Hc[27], s_xp[6];   // s_Hc: Hpp (lower triangle, packed) + bp of the current linearisation
-  __shared__ double s_lambda, s_rho;
-  __shared__ int s_ctrl[4];   // [2] ok2
+  __shared__ double s_rho;
+  __shared__ int s_ctrl[4];   // [2] ok2, [3] cluster exchange timed out
+  __shared__ double s_hlast;  // Hll diagonal of the last landmark of this workgroup's chunk (last sweep)
+  if (tid == 0) s_ctrl[3] = 0;
 #ifdef F2_PROFILE
   __shared__ long long s_prof[16], s_tprev;
   if (tid == 0) { for (int i = 0; i < 16; ++i) s_prof[i] = 0; s_tprev = clock64(); }
@@ -76,14 +105,14 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
 
   if (N < 3) {   // nInitialCorrespondences<3 -> identity, 0 inliers (Optimizer.cc:2449-2450, 2872-2873)
     if (tid < 16) res->T[tid] = (tid % 5 == 0) ? 1.0 : 0.0;
-    if (tid < N) { A.inlier_out[off + tid] = 0; A.flow_out[2 * (off + tid)] = meas[tid]; A.flow_out[2 * (off + tid) + 1] = meas[N + tid]; }   // nothing optimised: flows stay as measured
+    if (tid < N) { inlier_out[tid] = 0; flow_out[2 * tid] = meas[tid]; flow_out[2 * tid + 1] = meas[N + tid]; }   // nothing optimised: flows stay as measured
     if (tid == 0) { res->n_inliers = 0; res->iterations = 0; res->trials = 0; res->stop_reason = 0; res->initial_chi2 = res->final_chi2 = res->final_lambda = 0; }
     return;
   }
   const double fx = P.K[0], fy = P.K[1], cx = P.K[2], cy = P.K[3];
   const bool Q = P.ref_quirks != 0;
   // ---- setup: Xw, flows, initial pose (Converter::toSE3Quat)
-  for (int i = tid; i < N; i += F2_THREADS) {
+  for (int i = first; i < c_hi; i += stride) {
     const double dz = depth[i];
     const double x = (obs[i] - cx) * dz / fx, y = (obs[N + i] - cy) * dz / fy;
     const double* W = P.Twl;
@@ -101,6 +130,58 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     s_T.t[0] = P.T0[3]; s_T.t[1] = P.T0[7]; s_T.t[2] = P.T0[11];
   }
   __syncthreads();
+
+  // Cluster-wide sums: s_red[0..K) holds this workgroup's block sums on entry, the sums over the cluster on return (added in
+  // workgroup order by everybody); mx: block maximum in, cluster maximum out; hb: Hll diagonal of this chunk's last landmark
+  // in, of the PREVIOUS chunk's last landmark out (the F3 aliasing couples neighbours).  One exchange = one barrier.
+  int phase = 0;
+  __shared__ double s_part[F2_CLUSTER][32];
+  auto cluster_sum = [&](const int K, double& mx, double& hb) -> bool {
+    if (Gp == 1) return true;
+    const unsigned tag = (unsigned)phase + 1u;
+    if (tid < 31) {
+      const double v = tid < K ? s_red[tid] : (tid == 29 ? mx : (tid == 30 ? hb : 0.0));
+      const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+      const f2_u32x4 w = {(unsigned)u, tag, (unsigned)(u >> 32), tag};
+      *(volatile f2_u32x4*)&comm->slot[phase & 1][wg][tid] = w;
+    }
+    {
+      const int g2 = tid >> 5, q = tid & 31;                // F2_THREADS = 8 * 32: one thread per (workgroup, value)
+      double v = 0.0;
+      int bad = 0;
+      if (g2 < Gp && q < 31) {
+        const volatile f2_u32x4* src = (const volatile f2_u32x4*)&comm->slot[phase & 1][g2][q];
+        f2_u32x4 w = *src;
+        int spins = 0;
+        while (w.y != tag || w.w != tag) {
+          __builtin_amdgcn_s_sleep(1);
+          if (++spins > (1 << 20)) { bad = 1; break; }      // never hang the GPU: the launch fails instead (vdo_flow2_batch_fetch reports it)
+          w = *src;
+        }
+        v = __longlong_as_double((long long)(((unsigned long long)w.z << 32) | (unsigned long long)w.x));
+      }
+      s_part[g2][q] = v;
+      if (bad) s_ctrl[3] = 1;
+    }
+    __syncthreads();
+    if (s_ctrl[3]) return false;
+    if (tid < K) {
+      double a = 0.0;
+      for (int g2 = 0; g2 < Gp; ++g2) a += s_part[g2][tid];
+      s_red[tid] = a;
+    }
+    if (tid == 32) {
+      double m = 0.0;
+      for (int g2 = 0; g2 < Gp; ++g2) m = fmax(m, s_part[g2][29]);
+      s_red[31] = m;
+      s_red[30] = wg > 0 ? s_part[wg - 1][30] : 0.0;
+    }
+    __syncthreads();
+    mx = s_red[31]; hb = s_red[30];
+    ++phase;
+    return true;
+  };
+#define F2_CLUSTER_SUM(K, mx, hb) do { if (!cluster_sum(K, mx, hb)) { if (wg == 0 && tid == 0) { res->stop_reason = -1; res->iterations = -1; } return; } } while (0)
 
   // D_i^-1 of landmark i for this lambda.  ref_quirks (F3): BlockSolver_6_3 treats the 2-DoF flow vertex as 3-DoF, so the
   // block is D3 = [h+l, h, 0; 0, l, 0; 0, 0, l] (h = Hll diagonal, exact zeros elsewhere) and Eigen's cofactor inverse of it is
@@ -123,7 +204,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   // then evaluate + linearise the edges at (T, f) into Bw/hw/bw.  Block sums -> s_red[0..26] (Hpp lower, bp), [27] robust chi2,
   // [28] landmark part of computeScale; returns the per-thread max of the Hll diagonal (computeLambdaInit).
   auto sweep = [&](auto trial_c, const double lam, const bool ok2, const double* __restrict__ Br, const double* __restrict__ hr, const double* __restrict__ br,
-                   double* __restrict__ Bw, double* __restrict__ hw, double* __restrict__ bw, const double* fin, double* fout) -> double {
+                   double* __restrict__ Bw, double* __restrict__ hw, double* __restrict__ bw, const double* fin, double* fout, const double hb_prev) -> double {
     constexpr bool TRIAL = decltype(trial_c)::value;
     const SE3d T = TRIAL ? s_Ttry : s_T;
     double xp[6];
@@ -133,7 +214,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
 #pragma unroll
     for (int i = 0; i < 29; ++i) acc[i] = 0.0;
     double hmax = 0.0;
-    for (int i = tid; i < N; i += F2_THREADS) {
+    for (int i = first; i < c_hi; i += stride) {
       double f0v, f1v;
       if (TRIAL) {
         // back-substitution c = b_l - B^T x_p for this landmark
@@ -153,7 +234,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
           x1 = d2 * c1;
           if (i > 0) {
             double p0_, p1_, p2_;
-            dinv_q(hr[i - 1], lam, p0_, p1_, p2_);
+            dinv_q(i > c_lo ? hr[i - 1] : hb_prev, lam, p0_, p1_, p2_);      // (the previous chunk's last landmark belongs to another workgroup)
             x0 = p2_ * c0 + x0;
           }
         } else {
@@ -204,6 +285,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       bw[i] = or0 - P.info_prior * p0;
       bw[N + i] = or1 - P.info_prior * p1;
       hmax = fmax(hmax, h);
+      if (i == c_hi - 1) s_hlast = h;
     }
     block_reduce_wide<29>(acc, s_wide, s_red);
     return hmax;
@@ -214,24 +296,24 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   const double tau = 1e-5, upper = 2. / 3., lower = 1. / 3.;
   double chi2_check = 0;
   // initial computeActiveErrors + buildSystem
-  double hmax = sweep(std::false_type{}, 0.0, true, nullptr, nullptr, nullptr, Bc, hc, bc, fcur, nullptr);
+  double hmax = sweep(std::false_type{}, 0.0, true, nullptr, nullptr, nullptr, Bc, hc, bc, fcur, nullptr, 0.0);
+#pragma unroll
+  for (int off2 = 32; off2 > 0; off2 >>= 1) hmax = fmax(hmax, __shfl_down(hmax, off2, 64));
+  if ((tid & 63) == 0) s_scr[tid >> 6] = hmax;
+  __syncthreads();
+  double hmx = s_scr[0];
+  for (int w = 1; w < F2_WAVES; ++w) hmx = fmax(hmx, s_scr[w]);
+  double hb_cur = s_hlast, hb_try = 0.0;     // -> Hll diagonal of the landmark just before this chunk (current / trial linearisation)
+  F2_CLUSTER_SUM(29, hmx, hb_cur);
   double last_err_chi = s_red[27];
   const double initial_chi2 = last_err_chi;
   if (tid < 27) s_Hc[tid] = s_red[tid];
+  __syncthreads();
   {
     // computeLambdaInit: max |H(j,j)| over pose and flow vertices
-#pragma unroll
-    for (int off2 = 32; off2 > 0; off2 >>= 1) hmax = fmax(hmax, __shfl_down(hmax, off2, 64));
-    if ((tid & 63) == 0) s_scr[tid >> 6] = hmax;
-    __syncthreads();
-    if (tid == 0) {
-      double mm = s_scr[0];
-      for (int w = 1; w < F2_WAVES; ++w) mm = fmax(mm, s_scr[w]);
-      for (int j = 0; j < 6; ++j) mm = fmax(mm, fabs(s_Hc[j * (j + 3) / 2]));
-      s_lambda = tau * mm;
-    }
-    __syncthreads();
-    lambda = s_lambda; ni = 2; nBad = 0;
+    double mm = hmx;
+    for (int j = 0; j < 6; ++j) mm = fmax(mm, fabs(s_Hc[j * (j + 3) / 2]));
+    lambda = tau * mm; ni = 2; nBad = 0;
   }
   F2_TICK(4);
   bool built = true;
@@ -240,7 +322,8 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     // computeActiveErrors + buildSystem at the current estimate: already there after an accepted trial; repeated
     // only when the previous trial was rejected without ending the iteration loop (non-finite chi2)
     if (!built) {
-      sweep(std::false_type{}, 0.0, true, nullptr, nullptr, nullptr, Bc, hc, bc, fcur, nullptr);
+      sweep(std::false_type{}, 0.0, true, nullptr, nullptr, nullptr, Bc, hc, bc, fcur, nullptr, 0.0);
+      { double d_ = 0; hb_cur = s_hlast; F2_CLUSTER_SUM(29, d_, hb_cur); }
       last_err_chi = s_red[27];
       if (tid < 27) s_Hc[tid] = s_red[tid];
       __syncthreads();
@@ -257,7 +340,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
 #pragma unroll
         for (int i = 0; i < 27; ++i) acc[i] = 0.0;
         const double* __restrict__ Br = Bc; const double* __restrict__ hr = hc; const double* __restrict__ br = bc;
-        for (int i = tid; i < N; i += F2_THREADS) {
+        for (int i = first; i < c_hi; i += stride) {
           const double bl0 = br[i], bl1 = br[N + i];
           const double* B = Br + i;
           double Bv[12];
@@ -292,6 +375,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
           }
         }
         block_reduce_wide<27>(acc, s_wide, s_red);
+        { double d_ = 0, e_ = 0; F2_CLUSTER_SUM(27, d_, e_); }
       }
       F2_TICK(0);
       // ---- (2) reduced 6x6 system, SE3 update, pose part of computeScale
@@ -307,7 +391,9 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
         }
 #pragma unroll
         for (int j = 0; j < 6; ++j) { Hs[7 * j] += lambda; bs[j] = s_Hc[21 + j] - s_red[21 + j]; }
+        F2_TICK(5);
         const bool ok2 = ldlt6_solve_reg(Hs, bs, xs);
+        F2_TICK(6);
         s_ctrl[2] = ok2 ? 1 : 0;
         if (ok2) {
 #pragma unroll
@@ -318,12 +404,14 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
         double s = 0;
         for (int j = 0; j < 6; ++j) s += s_xp[j] * (lambda * s_xp[j] + s_Hc[21 + j]);
         s_rho = s;    // pose part of computeScale
+        F2_TICK(7);
       }
       __syncthreads();
       F2_TICK(1);
       const bool ok2 = s_ctrl[2] != 0;
       // ---- (3) finish the solve per correspondence, errors + speculative linearisation at the trial point
-      sweep(std::true_type{}, lambda, ok2, Bc, hc, bc, Bt, ht, bt, fcur, ftry);
+      sweep(std::true_type{}, lambda, ok2, Bc, hc, bc, Bt, ht, bt, fcur, ftry, hb_cur);
+      { double d_ = 0; hb_try = s_hlast; F2_CLUSTER_SUM(29, d_, hb_try); }
       last_err_chi = tempChi = s_red[27];
       const double scale = (s_rho + s_red[28]) + 1e-3;
       F2_TICK(2);
@@ -334,7 +422,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
         alpha = fmin(alpha, upper);
         lambda *= fmax(lower, alpha); ni = 2; currentChi = tempChi; built = true;
         { double* t_ = fcur; fcur = ftry; ftry = t_; }                       // discardTop(): accept (uniform pointer swaps)
-        { double* t_ = Bc; Bc = Bt; Bt = t_; t_ = hc; hc = ht; ht = t_; t_ = bc; bc = bt; bt = t_; }
+        { double* t_ = Bc; Bc = Bt; Bt = t_; t_ = hc; hc = ht; ht = t_; t_ = bc; bc = bt; bt = t_; hb_cur = hb_try; }
         if (tid < 27) s_Hc[tid] = s_red[tid];
         if (tid == 32) s_T = s_Ttry;
       } else {
@@ -358,17 +446,18 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   // ---- classification on the stored errors of the last evaluated trial (Optimizer.cc:2470-2508)
   double cnt[1] = {0.0};
   const float gate = (float)P.chi2_gate;
-  for (int i = tid; i < N; i += F2_THREADS) {
+  for (int i = first; i < c_hi; i += stride) {
     const double e0 = err[i], e1 = err[N + i];
     const float chi2 = (float)(e0 * (P.info_flow * e0) + e1 * (P.info_flow * e1));
     const bool outl = chi2 > gate;
-    A.inlier_out[off + i] = outl ? 0 : 1;
+    inlier_out[i] = outl ? 0 : 1;
     cnt[0] += outl ? 0.0 : 1.0;
-    A.flow_out[2 * (off + i)] = fcur[i];
-    A.flow_out[2 * (off + i) + 1] = fcur[N + i];
+    flow_out[2 * i] = fcur[i];
+    flow_out[2 * i + 1] = fcur[N + i];
   }
   block_reduce<1>(cnt, s_scr, s_red);
-  if (tid == 0) {
+  { double d_ = 0, e_ = 0; F2_CLUSTER_SUM(1, d_, e_); }
+  if (tid == 0 && wg == 0) {
     se3_to_matrix(s_T, res->T);
     res->n_inliers = (int)(s_red[0] + 0.5);
     res->iterations = it; res->trials = total_trials; res->stop_reason = stop_reason;
@@ -426,9 +515,11 @@ extern "C" int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_fl
     d.info_flow = p.info_flow; d.info_prior = p.info_prior; d.huber_delta = p.huber_delta;
     d.huber_dsqr = (double)(float)(p.huber_delta * p.huber_delta);     // float member, robust_kernel_impl.h:84
     d.chi2_gate = p.chi2_gate;
+    d.out_off = total;
     b->offs.push_back(total); b->ns.push_back(p.n);
     total += p.n;
   }
+  for (Flow2Dev& d : hp) d.out_total = total;
   b->total = total;
   hipStream_t s = ctx->stream;
   auto dev = [&](size_t bytes) -> void* {
@@ -456,10 +547,11 @@ extern "C" int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_fl
   A.err = (double*)dev(16 * T); A.B2a = (double*)dev(96 * T); A.B2b = (double*)dev(96 * T);
   A.hla = (double*)dev(8 * T); A.hlb = (double*)dev(8 * T); A.bla = (double*)dev(16 * T); A.blb = (double*)dev(16 * T);
   A.xl = (double*)dev(16 * T);
-  A.flow_out = (double*)dev(16 * T); A.inlier_out = (unsigned char*)dev(T);
-  A.results = (vdo_flow2_result*)dev(sizeof(vdo_flow2_result) * NP);
+  A.out = (char*)dev(sizeof(vdo_flow2_result) * NP + 17 * T + 64);
+  A.n_problems = n_problems;
+  A.comm = (Flow2Comm*)dev(sizeof(Flow2Comm) * NP);
   for (void* p : b->allocs) if (!p) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
-  if (!A.results || !d_in) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  if (!A.out || !d_in) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
   hipMemcpyAsync(d_in, in.data(), 40 * T, hipMemcpyHostToDevice, s);
   hipMemcpyAsync(b->d_probs, hp.data(), sizeof(Flow2Dev) * NP, hipMemcpyHostToDevice, s);
   if (hipHostMalloc((void**)&b->h_pin, sizeof(vdo_flow2_result) * NP + 16 * T + T + 64) != hipSuccess) { b->h_pin = nullptr; vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipHostMalloc failed"); }
@@ -523,12 +615,16 @@ extern "C" int vdo_flow2_batch_run(vdo_flow2_batch* b) {
   int rc = ctx_bind(b->ctx);
   if (rc != VDO_OK) return rc;
   if (b->probs_dirty) {
+    int64_t used = 0;
+    for (int k = 0; k < b->n_problems; ++k) { b->hp[k].out_off = used; used += b->hp[k].n; }
+    for (int k = 0; k < b->n_problems; ++k) b->hp[k].out_total = used;
     Flow2Dev* pst = (Flow2Dev*)(b->h_up + 5 * (size_t)std::max<int64_t>(b->total, 1));           // pinned copy of the descriptors
     std::memcpy(pst, b->hp.data(), sizeof(Flow2Dev) * (size_t)b->n_problems);
     hipMemcpyAsync(b->d_probs, pst, sizeof(Flow2Dev) * (size_t)b->n_problems, hipMemcpyHostToDevice, b->ctx->stream);
     b->probs_dirty = false;
   }
-  hipLaunchKernelGGL(k_flow2_lm, dim3(b->n_problems), dim3(F2_THREADS), 0, b->ctx->stream, (const Flow2Dev*)b->d_probs, b->A);
+  hipMemsetAsync(b->A.comm, 0, sizeof(Flow2Comm) * (size_t)b->n_problems, b->ctx->stream);      // barrier counters of the clusters
+  hipLaunchKernelGGL(k_flow2_lm, dim3(b->n_problems * F2_CLUSTER), dim3(F2_THREADS), 0, b->ctx->stream, (const Flow2Dev*)b->d_probs, b->A);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "k_flow2_lm launch: %s", hipGetErrorString(e));
   return VDO_OK;
@@ -539,21 +635,27 @@ extern "C" int vdo_flow2_batch_fetch(vdo_flow2_batch* b, vdo_flow2_result* resul
   int rc = ctx_bind(b->ctx);
   if (rc != VDO_OK) return rc;
   hipStream_t s = b->ctx->stream;
-  // everything through the pinned block (pageable D2H copies cost ~50-100 us each): 1-3 copies, one sync, then memcpy
-  const size_t NP = (size_t)b->n_problems, T = (size_t)b->total;
-  vdo_flow2_result* pr = (vdo_flow2_result*)b->h_pin;
-  double* pf = (double*)(b->h_pin + sizeof(vdo_flow2_result) * NP);
-  uint8_t* pi = (uint8_t*)(pf + 2 * T);
-  hipMemcpyAsync(pr, b->A.results, sizeof(vdo_flow2_result) * NP, hipMemcpyDeviceToHost, s);
-  if (flow_out && T) hipMemcpyAsync(pf, b->A.flow_out, 16 * T, hipMemcpyDeviceToHost, s);
-  if (inlier_out && T) hipMemcpyAsync(pi, b->A.inlier_out, T, hipMemcpyDeviceToHost, s);
+  // one D2H copy of exactly what the launch produced - results, refined flows and inlier flags are packed by the actual
+  // problem sizes - into the pinned block (pageable D2H copies cost ~50-100 us each), one sync, then memcpy
+  const size_t NP = (size_t)b->n_problems;
+  size_t used = 0;
+  for (int k = 0; k < b->n_problems; ++k) used += (size_t)b->ns[k];
+  const bool want_pts = (flow_out || inlier_out) && used;
+  const size_t bytes = sizeof(vdo_flow2_result) * NP + (want_pts ? 17 * used : 0);
+  hipMemcpyAsync(b->h_pin, b->A.out, bytes, hipMemcpyDeviceToHost, s);
   hipError_t e = hipStreamSynchronize(s);
   if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "flow2 fetch: %s", hipGetErrorString(e));
+  const vdo_flow2_result* pr = (const vdo_flow2_result*)b->h_pin;
+  const double* pf = (const double*)(b->h_pin + sizeof(vdo_flow2_result) * NP);
+  const uint8_t* pi = (const uint8_t*)(pf + 2 * used);
   std::memcpy(results, pr, sizeof(vdo_flow2_result) * NP);
+  for (size_t k = 0; k < NP; ++k) if (pr[k].iterations < 0) return set_error(VDO_ERR_NO_DEVICE, "k_flow2_lm: the workgroup cluster of problem %d lost its barrier", (int)k);
+  size_t o = 0;
   for (int k = 0; k < b->n_problems; ++k) {
-    if (b->ns[k] == 0) continue;
-    if (flow_out && flow_out[k]) std::memcpy(flow_out[k], pf + 2 * b->offs[k], sizeof(double) * 2 * b->ns[k]);
-    if (inlier_out && inlier_out[k]) std::memcpy(inlier_out[k], pi + b->offs[k], (size_t)b->ns[k]);
+    const size_t n = (size_t)b->ns[k];
+    if (n && flow_out && flow_out[k]) std::memcpy(flow_out[k], pf + 2 * o, sizeof(double) * 2 * n);
+    if (n && inlier_out && inlier_out[k]) std::memcpy(inlier_out[k], pi + o, n);
+    o += n;
   }
   return VDO_OK;
 }

@@ -32,7 +32,7 @@ static void fill_flow2(vdo_flow2_problem& p, int n, const double* obs, const dou
 
 #define VDO_TRY(call) do { if ((call) != VDO_OK) { std::fprintf(stderr, "FramePipeline: %s\n", vdo_last_error()); return -1; } } while (0)
 
-FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p) : ctx_(ctx), ctx_lm_(ctx_lm), p_(p) {
+FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p, vdo_ctx* ctx_obj) : ctx_(ctx), ctx_lm_(ctx_lm), ctx_obj_(ctx_obj ? ctx_obj : ctx_lm), p_(p) {
   vdo_orb_params op{p.n_features, p.scale_factor, p.n_levels, p.ini_th, p.min_th};
   if (vdo_orb_create(ctx, &op, p.width, p.height, &orb_) != VDO_OK) return;
   for (int k = 0; k < 2; ++k) if (vdo_frame_images_create(ctx, p.width, p.height, &img_[k]) != VDO_OK) return;
@@ -45,7 +45,7 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
     if (vdo_flow2_batch_reserve(ctx_lm, 1, &ccap, &lm_cam_) != VDO_OK) return;
     int32_t ocap[kMaxObjects];
     for (int k = 0; k < kMaxObjects; ++k) ocap[k] = kObjCap;
-    if (vdo_flow2_batch_reserve(ctx_lm, kMaxObjects, ocap, &lm_obj_) != VDO_OK) return;
+    if (vdo_flow2_batch_reserve(ctx_obj_, kMaxObjects, ocap, &lm_obj_) != VDO_OK) return;
   }
   ok_ = true;
 }
@@ -70,15 +70,11 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   // ---- GrabImageRGBD: images, K1, UpdateMask (K15), propagation (K11)            Tracking.cc:180-305
   VDO_TRY(vdo_frame_images_upload_device(cur, d_depth_raw, d_flow, d_mask));
   VDO_TRY(vdo_frame_images_depth_preprocess(cur, p_.bf, p_.depth_map_factor));
-  const int n_s = have_last_ ? (int)sta_.cx.size() : 0, n_o = have_last_ ? (int)obj_.cx.size() : 0;
+  const int n_s = have_last_ ? (int)sta_.cx.size() : 0;
   std::vector<float>& stat_depth = f_[0]; std::vector<float>& obj_depth = f_[1]; std::vector<int32_t>& obj_sem = i_[0];
-  stat_depth.assign(n_s, -1.f); obj_depth.assign(n_o, 0.f); obj_sem.assign(n_o, 0);
+  stat_depth.assign(n_s, -1.f);
   if (have_last_) {
-    int rec = 0;
-    VDO_TRY(vdo_update_mask(cur, last, n_o, obj_.sem.data(), obj_.cx.data(), obj_.cy.data(), &rec));
-    fc.n_recovered_masks = rec;
     VDO_TRY(vdo_propagate_static(cur, n_s, sta_.cx.data(), sta_.cy.data(), stat_depth.data()));
-    VDO_TRY(vdo_propagate_object(cur, n_o, obj_.cx.data(), obj_.cy.data(), p_.th_depth_obj, obj_depth.data(), obj_sem.data()));
   } else {
     VDO_TRY(vdo_ctx_synchronize(ctx_));
   }
@@ -138,6 +134,19 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   VDO_TRY(vdo_orb_extract(orb_, d_gray, W, 1, &kp));
   fc.n_orb = kp.n;
   tick(1);
+  // ---- deferred mode: the object stage of the PREVIOUS frame ends here - its LMs had the camera stage and the ORB
+  // front-end of this frame to finish (nothing above depends on the object set)
+  if (pending_) { if (FinishObjects(&fc) != 0) return -1; t_prev = std::chrono::steady_clock::now(); }
+  // ---- UpdateMask (K15) + object part of the propagation (K11): they need the object set of the last frame
+  const int n_o = have_last_ ? (int)obj_.cx.size() : 0;
+  obj_depth.assign(n_o, 0.f); obj_sem.assign(n_o, 0);
+  if (have_last_) {
+    int rec = 0;
+    VDO_TRY(vdo_update_mask(cur, last, n_o, obj_.sem.data(), obj_.cx.data(), obj_.cy.data(), &rec));
+    fc.n_recovered_masks = rec;
+    VDO_TRY(vdo_propagate_object(cur, n_o, obj_.cx.data(), obj_.cy.data(), p_.th_depth_obj, obj_depth.data(), obj_sem.data()));
+  }
+  tick(10);
   // K9 + K10 of the new image: only RenewFrameInfo needs them, so they run while the object LMs are in flight
   int n_new_s = 0, n_tmp = 0;
   std::vector<int32_t>& keep = i_[1];
@@ -285,6 +294,53 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     nsta.xyz.resize(3 * (size_t)std::max(m, 1));
     VDO_TRY(vdo_get3d_world(ctx_, m, nsta.x.data(), nsta.y.data(), nsta.d.data(), p_.K4, Twc, nsta.xyz.data()));     // mvStat3DPointTmp
     tick(5);
+    // ---- static tracklets (incremental GetStaticTrack)                             Tracking.cc:2201-2300
+    VDO_TRY(vdo_tracks_add_frame(tr_sta_, m, sta_asso.data(), nullptr));
+    // the object stage (results of the LMs, RenewFrameInfo of the objects, dynamic tracklets) ends in FinishObjects():
+    // right below, or - deferred mode - inside the next Step, after that frame's camera stage and ORB front-end
+    n_objects_ = n_objects; obj_run_ = obj; n_obj_problems_ = n_obj_problems; n_tmp_ = n_tmp; img_obj_ = cur;
+    std::memcpy(Tcw_obj_, Tcw, sizeof Tcw);
+    pending_ = true;
+  }
+  tick(8);
+  fc.n_static_tracked = (int)nsta.x.size();
+  int64_t np = 0;
+  vdo_tracks_size(tr_sta_, &fc.n_static_tracks, &np);
+  sta_ = std::move(nsta);
+  if (!have_last_) { fc.n_object_tracked = (int)nobj.x.size(); obj_ = std::move(nobj); vdo_tracks_size(tr_dyn_, &fc.n_dynamic_tracks, &np); }
+  {                                                      // mVelocity = mCurrentFrame.mTcw * LastTwc   (Tracking.cc:703-709)
+    float Twl[16];
+    inv_rigid(Tcw_last_, Twl);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float a = 0; for (int k = 0; k < 4; ++k) a += Tcw[4 * i + k] * Twl[4 * k + j]; vel_[4 * i + j] = a; }
+  }
+  std::memcpy(Tcw_last_, Tcw, sizeof Tcw);
+  std::memcpy(Tcw_out_, Tcw, sizeof Tcw);
+  cur_ ^= 1; have_last_ = true; ++f_id_;
+  if (pending_ && !p_.defer_objects) { if (FinishObjects(&fc) != 0) return -1; }
+  if (out) *out = fc;
+  return 0;
+}
+
+
+// The object stage of a frame: consume the object LMs (K17), RenewFrameInfo of the objects (K14, K12), dynamic tracklets.
+// fc: the object-related counts of THAT frame (n_object_tracked, n_dynamic_tracks) are written into it.
+int FramePipeline::FinishObjects(FrameCounts* fcp) {
+  if (!pending_) return 0;
+  FrameCounts dummy{};
+  FrameCounts& fc = fcp ? *fcp : dummy;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto tick = [&](int slot) { const auto t = std::chrono::steady_clock::now(); ms_[slot] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
+  const int n_objects = n_objects_, n_tmp = n_tmp_, n_obj_problems = n_obj_problems_;
+  vdo_flow2_batch* obj = obj_run_;
+  vdo_frame_images* cur = img_obj_;
+  const float* Tcw = Tcw_obj_;
+  std::vector<int32_t>&olab = i_[2], &off = i_[3], &idx = i_[4], &osem = i_[5], &omod = i_[6];
+  ObjSet& tmp = tmp_;
+  ObjSet nobj;
+  std::vector<int32_t> dyn_asso;
+  float Twc[16];
+  inv_rigid(Tcw, Twc);
+  {
     // ---- consume the object results, RenewFrameInfo (objects)                      Tracking.cc:2806-2995
     std::vector<float>&cur_ox = f_[11], &cur_oy = f_[12];
     cur_ox = obj_.cx; cur_oy = obj_.cy;
@@ -343,27 +399,17 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     VDO_TRY(vdo_get3d_world(ctx_, mo, nobj.x.data(), nobj.y.data(), nobj.d.data(), p_.K4, Twc, nobj.xyz.data()));     // mvObj3DPoint
     tick(7);
     // ---- tracklets (incremental GetStaticTrack / GetDynamicTrackNew)               Tracking.cc:2201-2421
-    VDO_TRY(vdo_tracks_add_frame(tr_sta_, m, sta_asso.data(), nullptr));
     VDO_TRY(vdo_tracks_add_frame(tr_dyn_, mo, dyn_asso.data(), nobj.label.data()));
     last_sem_pos_.assign(osem.begin(), osem.begin() + n_objects);
     last_mod_label_.assign(omod.begin(), omod.begin() + n_objects);
     last_obj_stat_.assign(stat.begin(), stat.begin() + n_objects);
   }
   tick(8);
-  fc.n_static_tracked = (int)nsta.x.size(); fc.n_object_tracked = (int)nobj.x.size();
+  fc.n_object_tracked = (int)nobj.x.size();
   int64_t np = 0;
-  vdo_tracks_size(tr_sta_, &fc.n_static_tracks, &np);
   vdo_tracks_size(tr_dyn_, &fc.n_dynamic_tracks, &np);
-  sta_ = std::move(nsta); obj_ = std::move(nobj);
-  {                                                      // mVelocity = mCurrentFrame.mTcw * LastTwc   (Tracking.cc:703-709)
-    float Twl[16];
-    inv_rigid(Tcw_last_, Twl);
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float a = 0; for (int k = 0; k < 4; ++k) a += Tcw[4 * i + k] * Twl[4 * k + j]; vel_[4 * i + j] = a; }
-  }
-  std::memcpy(Tcw_last_, Tcw, sizeof Tcw);
-  std::memcpy(Tcw_out_, Tcw, sizeof Tcw);
-  cur_ ^= 1; have_last_ = true; ++f_id_;
-  if (out) *out = fc;
+  obj_ = std::move(nobj);
+  pending_ = false;
   return 0;
 }
 
@@ -375,8 +421,8 @@ using VDO_SLAM::FrameCounts;
 using VDO_SLAM::PipelineParams;
 
 extern "C" {
-FramePipeline* host_pipeline_create(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams* p) {
-  FramePipeline* fp = new FramePipeline(ctx, ctx_lm, *p);
+FramePipeline* host_pipeline_create(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams* p, vdo_ctx* ctx_obj) {
+  FramePipeline* fp = new FramePipeline(ctx, ctx_lm, *p, ctx_obj);
   if (!fp->ok()) { delete fp; return nullptr; }
   return fp;
 }
@@ -384,7 +430,9 @@ void host_pipeline_destroy(FramePipeline* fp) { delete fp; }
 // accumulated wall ms per section since creation: [0] K1+K15+K11, [1] ORB, [2] K9+K10, [3] wait camera LM + fetch,
 // [4] K13 + DynObjTracking, [5] RenewFrameInfo static + K12, [6] wait object LMs + fetch, [7] RenewFrameInfo objects + K12, [8] tracklets,
 // [9] object RANSAC initialisers ([0] includes the camera one)
-void host_pipeline_timing(FramePipeline* fp, double* ms10) { for (int i = 0; i < 10; ++i) ms10[i] = fp->ms_[i]; }
+// [10] K15 + K11 (objects)
+void host_pipeline_timing(FramePipeline* fp, double* ms11) { for (int i = 0; i < 11; ++i) ms11[i] = fp->ms_[i]; }
+int host_pipeline_flush(FramePipeline* fp, FrameCounts* out) { return fp->Flush(out); }
 void host_pipeline_pose(FramePipeline* fp, float* Tcw16) { std::memcpy(Tcw16, fp->Tcw_out_, 64); }
 int host_pipeline_motions(FramePipeline* fp, int cap, int* mod_label, int* sem_label, int* n_inliers, float* H16) {
   const int n = std::min(cap, (int)fp->motions_.size());

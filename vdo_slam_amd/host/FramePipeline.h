@@ -1,15 +1,17 @@
 // FramePipeline — the per-frame sequence of Tracking::GrabImageRGBD + Tracking::Track (reference
 // src/Tracking.cc:164-314, 646-1276) over the C-ABI, with frame-to-frame state, minus what is not on the
-// hot path (ground-truth bookkeeping, metrics, drawing) and minus the P3P/AP3P RANSAC initialisers
-// (GetInitModelCam/Obj, SURVEY.md §8f-2: the pose problems of a frame are handed in by the caller).
+// hot path (ground-truth bookkeeping, metrics, drawing).
 //
-//   UpdateMask (K15) -> depth preprocess (K1) -> propagation (K11) -> camera LM (K16, own stream)
-//        || ORB (K3-K7) + Frame filters (K9, K10)
-//   -> scene flow (K13) + DynObjTracking -> object LMs (K17, own stream) || RenewFrameInfo static (K14, K12)
-//   -> RenewFrameInfo objects (K14, K12) -> tracklets
+//   depth preprocess (K1) -> static propagation (K11) -> GetInitModelCam (RANSAC-P3P | motion model) -> camera LM (K16, stream 2)
+//        || ORB (K3-K7)
+//   [deferred mode: the object stage of the previous frame ends here]
+//   -> UpdateMask (K15) + object propagation (K11) -> scene flow (K13) + DynObjTracking -> GetInitModelObj (RANSAC per object)
+//   -> object LMs (K17, one launch, stream 3) || Frame filters (K9, K10) + RenewFrameInfo static (K14, K12) + static tracklets
+//   -> object stage: RenewFrameInfo objects (K14, K12) -> dynamic tracklets      (FinishObjects)
 //
-// The LM kernels run on a second context/stream so that they overlap the front-end of the same frame
-// (the ORB keypoints are first needed by RenewFrameInfo at the end of the frame, src/Tracking.cc:1168).
+// The LM kernels run on their own contexts/streams so that they overlap the front-end work that does not depend on them
+// (the ORB keypoints are first needed by RenewFrameInfo at the end of the frame, src/Tracking.cc:1168; nothing of the next
+// frame's camera stage needs this frame's object results).
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -27,6 +29,9 @@ struct PipelineParams {
   float sf_mg_thres, sf_ds_thres;    // SFMgThres, SFDsThres
   int n_features, n_levels, ini_th, min_th; float scale_factor;   // ORBextractor.*
   int build_lm;                      // 1: build the frame's pose problems from the chained correspondences (full Track()); 0: caller supplies them
+  int defer_objects;                 // 1: Step() returns with the object LMs of the frame in flight; their results (object motions, renewed object
+                                     //    set, dynamic tracklets) are consumed inside the next Step() - after that frame's camera stage and ORB
+                                     //    front-end, which do not depend on them - or by Flush().  Same results, one frame of latency for the objects.
 };
 
 struct FrameCounts { int n_orb, n_static_new, n_object_samples, n_static_tracked, n_object_tracked, n_objects, n_recovered_masks, n_static_tracks, n_dynamic_tracks,
@@ -34,12 +39,15 @@ struct FrameCounts { int n_orb, n_static_new, n_object_samples, n_static_tracked
 
 class FramePipeline {
  public:
-  FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p);
+  // ctx: front-end / tracking kernels; ctx_lm: camera pose problems; ctx_obj: object pose problems (NULL: ctx_lm) - three HIP streams
+  FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p, vdo_ctx* ctx_obj = nullptr);
   ~FramePipeline();
   // One frame.  d_* are DEVICE pointers of the raw inputs (gray u8, disparity*factor f32, flow 2xf32, mask i32).
   // cam / obj: the frame's pose problems (already resident); their results are fetched like Track() consumes them.
   int Step(const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
            vdo_flow2_batch* cam, vdo_flow2_batch* obj, int n_cam_pts, int n_obj_problems, FrameCounts* out);
+  // Ends a pending object stage (deferred mode); fc (optional) receives its n_object_tracked / n_dynamic_tracks.
+  int Flush(FrameCounts* fc = nullptr) { return FinishObjects(fc); }
   bool ok() const { return ok_; }
   struct ObjectMotion { int mod_label, sem_label, n_inliers; float H[16]; };   // H: world-frame motion of the object from the last to this frame
   std::vector<ObjectMotion> motions_;   // objects tracked in the last Step (build_lm mode)
@@ -49,7 +57,14 @@ class FramePipeline {
  private:
   struct ObjSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; std::vector<int32_t> sem, label; };
   struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; };
-  vdo_ctx *ctx_, *ctx_lm_;
+  int FinishObjects(FrameCounts* fc);
+  vdo_ctx *ctx_, *ctx_lm_, *ctx_obj_;
+  // object stage handed from Step() to FinishObjects()
+  bool pending_ = false;
+  int n_objects_ = 0, n_obj_problems_ = 0, n_tmp_ = 0;
+  vdo_flow2_batch* obj_run_ = nullptr;
+  vdo_frame_images* img_obj_ = nullptr;
+  float Tcw_obj_[16];
   PipelineParams p_;
   vdo_orb* orb_ = nullptr;
   vdo_frame_images* img_[2] = {nullptr, nullptr};
