@@ -153,7 +153,8 @@ def main():
     # part of Tracking::GrabImageRGBD + Track over the C-ABI, state chained frame to frame); one ctypes call per frame.
     from vdo_slam_amd.pipeline import FramePipeline, kitti_params
     defer = 0 if os.environ.get("VDO_BENCH_SYNC_OBJECTS") else 1
-    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj)
+    ctx_w = None if os.environ.get("VDO_BENCH_NO_WORKER") else Context(local)      # helper host thread of FramePipeline, own stream + arena
+    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj, ctx_w)
     torch.cuda.synchronize()
     counts = pipe.counts
     agg = {"cam_lm_iterations": 0, "n_static_tracked": 0, "n_object_tracked": 0, "n_objects": 0, "n_ransac_cam": 0, "n_cam_inliers": 0}
@@ -179,9 +180,12 @@ def main():
         step(i)
     pipe.flush()
     barrier()
+    step_ms = []
     t0 = time.perf_counter()
     for i in range(args.steps):
+        ts = time.perf_counter()
         step(args.warmup + i)                 # the sequence continues where the warm-up left it
+        step_ms.append((time.perf_counter() - ts) * 1e3)
     pipe.flush()                              # deferred mode: the object stage of the last frame ends inside the timed region
     barrier()
     dt = time.perf_counter() - t0
@@ -208,10 +212,12 @@ def main():
                                "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets; "
                                f"geometrically consistent synthetic sequence of {n_seq} frames, 3 moving objects, flow noise sigma {FLOW_SIGMA} px",
                    "parallelism": f"replicas x{world}; 3 HIP streams per replica: camera LM (2) || ORB front-end (1); object LMs (3) || RenewFrameInfo (1) and - "
-                                  f"defer_objects={defer} - the next frame's camera stage; every LM problem runs on a cluster of up to 8 workgroups",
+                                  f"defer_objects={defer} - the next frame's camera stage; every LM problem runs on a cluster of up to 8 workgroups; "
+                                  f"host threads per replica: 1 + {0 if ctx_w is None else 1} helper (object stage of the previous frame || camera stage + ORB; K9/K10/RenewFrameInfo static || object chain) + 3 ORB quadtree helpers",
                    "orb_keypoints": counts.n_orb, "new_static_candidates": counts.n_static_new, "object_samples": counts.n_object_samples,
                    "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
                    "per_frame_mean": {q: round(v / n_all, 2) for q, v in agg.items()},
+                   "step_ms_p50_p90_max": [round(float(np.percentile(step_ms, 50)), 3), round(float(np.percentile(step_ms, 90)), 3), round(max(step_ms), 3)],
                    "trajectory_drift_m": drift, "object_translations_last_frame": [np.round(m["H"][:3, 3], 4).tolist() for m in motions],
                    "host_ms_per_section": {k_: round(v_ / n_all, 4) for k_, v_ in sect.items()}},
     }

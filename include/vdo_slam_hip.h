@@ -307,6 +307,10 @@ int vdo_frame_images_upload(vdo_frame_images* f, const float* depth, const float
 int vdo_frame_images_upload_device(vdo_frame_images* f, const float* depth_dev, const float* flow_dev, const int32_t* mask_dev);
 int vdo_frame_images_depth_preprocess(vdo_frame_images* f, float bf, float depth_map_factor);   /* K1 in place, resident image */
 int vdo_frame_images_destroy(vdo_frame_images* f);
+/* Later calls on these images run on `ctx` (its stream and scratch arena) instead of the context they were created with.
+ * Every call on vdo_frame_images is host-synchronous, so the switch needs no device-side ordering; it exists so that a
+ * host worker thread can work on the images of one frame while the main thread works on another context (FramePipeline). */
+int vdo_frame_images_set_ctx(vdo_frame_images* f, vdo_ctx* ctx);
 /* K9: static keypoint filter of Frame::Frame (:100-128) + depth gather (:178-194); outputs in input order. */
 int vdo_frame_static_filter(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth,
                             int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y,

@@ -88,9 +88,10 @@ def test_deferred_object_stage_gives_the_same_sequence():
     dev = [{q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for fr in frames]
     torch.cuda.synchronize()
 
-    def run(defer):
+    def run(defer, worker=False):
         ctx, ctx_lm, ctx_obj = Context(0), Context(0), Context(0)
-        pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj)
+        ctx_w = Context(0) if worker else None          # + a helper host thread with its own context (FramePipeline.h)
+        pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj, ctx_w)
         poses, counts, motions = [], [], []
         for k, d in enumerate(dev):
             c = pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
@@ -108,13 +109,14 @@ def test_deferred_object_stage_gives_the_same_sequence():
         return poses, counts, motions
 
     p0, c0, m0 = run(0)
-    p1, c1, m1 = run(1)
-    assert c0[1:] == c1[1:], [(a, b) for a, b in zip(c0, c1) if a != b][:2]
-    for a, b in zip(p0, p1):
-        assert np.array_equal(a, b)
-    # synchronous mode reports the motions of frame k after Step(k); deferred mode after Step(k+1) / flush
-    assert len(m0) == len(m1) == n_frames
-    for a, b in zip(m0, m1):
-        assert [(x["mod_label"], x["sem_label"], x["n_inliers"]) for x in a] == [(x["mod_label"], x["sem_label"], x["n_inliers"]) for x in b]
-        for x, y in zip(a, b):
-            assert np.array_equal(x["H"], y["H"])
+    for defer, worker in ((1, False), (1, True), (0, True)):
+        p1, c1, m1 = run(defer, worker)
+        assert c0[1:] == c1[1:], (defer, worker, [(a, b) for a, b in zip(c0, c1) if a != b][:2])
+        for a, b in zip(p0, p1):
+            assert np.array_equal(a, b)
+        # synchronous mode reports the motions of frame k after Step(k); deferred mode after Step(k+1) / flush
+        assert len(m0) == len(m1) == n_frames
+        for a, b in zip(m0, m1):
+            assert [(x["mod_label"], x["sem_label"], x["n_inliers"]) for x in a] == [(x["mod_label"], x["sem_label"], x["n_inliers"]) for x in b]
+            for x, y in zip(a, b):
+                assert np.array_equal(x["H"], y["H"])

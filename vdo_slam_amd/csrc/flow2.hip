@@ -547,14 +547,21 @@ extern "C" int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_fl
   A.err = (double*)dev(16 * T); A.B2a = (double*)dev(96 * T); A.B2b = (double*)dev(96 * T);
   A.hla = (double*)dev(8 * T); A.hlb = (double*)dev(8 * T); A.bla = (double*)dev(16 * T); A.blb = (double*)dev(16 * T);
   A.xl = (double*)dev(16 * T);
-  A.out = (char*)dev(sizeof(vdo_flow2_result) * NP + 17 * T + 64);
   A.n_problems = n_problems;
   A.comm = (Flow2Comm*)dev(sizeof(Flow2Comm) * NP);
   for (void* p : b->allocs) if (!p) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
-  if (!A.out || !d_in) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  if (!d_in) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
   hipMemcpyAsync(d_in, in.data(), 40 * T, hipMemcpyHostToDevice, s);
   hipMemcpyAsync(b->d_probs, hp.data(), sizeof(Flow2Dev) * NP, hipMemcpyHostToDevice, s);
-  if (hipHostMalloc((void**)&b->h_pin, sizeof(vdo_flow2_result) * NP + 16 * T + T + 64) != hipSuccess) { b->h_pin = nullptr; vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipHostMalloc failed"); }
+  // The outputs (results, refined flows, inlier flags: ~17 B per correspondence) are written by the kernel straight into
+  // pinned, device-mapped host memory: fetching them is a stream synchronisation, not a copy - a D2H copy queued behind a
+  // running LM kernel would also hold up the copies of the other streams on the same SDMA queue for the kernel's duration.
+  if (hipHostMalloc((void**)&b->h_pin, sizeof(vdo_flow2_result) * NP + 16 * T + T + 64, hipHostMallocMapped) != hipSuccess) { b->h_pin = nullptr; vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipHostMalloc failed"); }
+  {
+    void* dp = nullptr;
+    if (hipHostGetDevicePointer(&dp, b->h_pin, 0) != hipSuccess || !dp) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_NO_DEVICE, "hipHostGetDevicePointer failed"); }
+    A.out = (char*)dp;
+  }
   if (hipStreamSynchronize(s) != hipSuccess) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_NO_DEVICE, "flow2 upload failed"); }
   b->hp = hp; b->caps = b->ns;
   *out = b;
@@ -635,14 +642,13 @@ extern "C" int vdo_flow2_batch_fetch(vdo_flow2_batch* b, vdo_flow2_result* resul
   int rc = ctx_bind(b->ctx);
   if (rc != VDO_OK) return rc;
   hipStream_t s = b->ctx->stream;
-  // one D2H copy of exactly what the launch produced - results, refined flows and inlier flags are packed by the actual
-  // problem sizes - into the pinned block (pageable D2H copies cost ~50-100 us each), one sync, then memcpy
+  // results, refined flows and inlier flags are packed by the actual problem sizes in the pinned block the kernel wrote
   const size_t NP = (size_t)b->n_problems;
   size_t used = 0;
   for (int k = 0; k < b->n_problems; ++k) used += (size_t)b->ns[k];
   const bool want_pts = (flow_out || inlier_out) && used;
   const size_t bytes = sizeof(vdo_flow2_result) * NP + (want_pts ? 17 * used : 0);
-  hipMemcpyAsync(b->h_pin, b->A.out, bytes, hipMemcpyDeviceToHost, s);
+  (void)bytes;                                             // (already in host memory: the kernel wrote through the mapping)
   hipError_t e = hipStreamSynchronize(s);
   if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "flow2 fetch: %s", hipGetErrorString(e));
   const vdo_flow2_result* pr = (const vdo_flow2_result*)b->h_pin;

@@ -146,6 +146,12 @@ extern "C" int vdo_frame_images_destroy(vdo_frame_images* f) {
   return VDO_OK;
 }
 
+extern "C" int vdo_frame_images_set_ctx(vdo_frame_images* f, vdo_ctx* ctx) {
+  if (!f || !ctx) return set_error(VDO_ERR_INVALID, "vdo_frame_images_set_ctx: null argument");
+  f->ctx = ctx;
+  return VDO_OK;
+}
+
 extern "C" int vdo_frame_images_create(vdo_ctx* ctx, int w, int h, vdo_frame_images** out) {
   if (!ctx || !out || w <= 0 || h <= 0) return set_error(VDO_ERR_INVALID, "bad argument");
   int rc = ctx_bind(ctx);

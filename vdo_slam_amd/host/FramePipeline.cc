@@ -4,7 +4,9 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <atomic>
 #include <cstring>
+#include <thread>
 
 namespace VDO_SLAM {
 
@@ -17,6 +19,39 @@ void inv_rigid(const float* T, float* o) {                 // Converter::toInvMa
   o[12] = o[13] = o[14] = 0; o[15] = 1;
 }
 }  // namespace
+
+// One persistent helper thread: run() hands it a job, wait() returns the job's result.  It polls (a job arrives every few
+// hundred microseconds while a sequence is running; a condition variable's wake-up latency would eat the overlap) and backs
+// off to yield/sleep when idle.
+class FramePipeline::Worker {
+ public:
+  Worker() : th_([this] { loop(); }) {}
+  ~Worker() { state_.store(3, std::memory_order_release); th_.join(); }
+  void run(std::function<int()> job) { job_ = std::move(job); state_.store(1, std::memory_order_release); }
+  int wait() {
+    if (!busy()) return 0;
+    while (state_.load(std::memory_order_acquire) != 2) std::this_thread::yield();
+    state_.store(0, std::memory_order_relaxed);
+    return rc_;
+  }
+  bool busy() const { const int s = state_.load(std::memory_order_acquire); return s == 1 || s == 2; }
+
+ private:
+  void loop() {
+    unsigned idle = 0;
+    for (;;) {
+      const int s = state_.load(std::memory_order_acquire);
+      if (s == 3) return;
+      if (s == 1) { rc_ = job_(); state_.store(2, std::memory_order_release); idle = 0; continue; }
+      if (++idle < 200000u) continue;                            // ~0.1 ms of polling, then be polite
+      if (idle < 400000u) std::this_thread::yield(); else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
+  }
+  std::function<int()> job_;
+  int rc_ = 0;
+  std::atomic<int> state_{0};     // 0 idle, 1 job posted, 2 job done, 3 quit
+  std::thread th_;                // (last: started after the other members exist)
+};
 
 static void fill_flow2(vdo_flow2_problem& p, int n, const double* obs, const double* flow, const double* depth, const float* K4, const float* Tcw_last,
                        const double* T0, double info_prior, int max_it) {
@@ -32,7 +67,8 @@ static void fill_flow2(vdo_flow2_problem& p, int n, const double* obs, const dou
 
 #define VDO_TRY(call) do { if ((call) != VDO_OK) { std::fprintf(stderr, "FramePipeline: %s\n", vdo_last_error()); return -1; } } while (0)
 
-FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p, vdo_ctx* ctx_obj) : ctx_(ctx), ctx_lm_(ctx_lm), ctx_obj_(ctx_obj ? ctx_obj : ctx_lm), p_(p) {
+FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p, vdo_ctx* ctx_obj, vdo_ctx* ctx_worker)
+    : ctx_(ctx), ctx_lm_(ctx_lm), ctx_obj_(ctx_obj ? ctx_obj : ctx_lm), ctx_w_(ctx_worker ? ctx_worker : ctx), p_(p) {
   vdo_orb_params op{p.n_features, p.scale_factor, p.n_levels, p.ini_th, p.min_th};
   if (vdo_orb_create(ctx, &op, p.width, p.height, &orb_) != VDO_OK) return;
   for (int k = 0; k < 2; ++k) if (vdo_frame_images_create(ctx, p.width, p.height, &img_[k]) != VDO_OK) return;
@@ -47,10 +83,12 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
     for (int k = 0; k < kMaxObjects; ++k) ocap[k] = kObjCap;
     if (vdo_flow2_batch_reserve(ctx_obj_, kMaxObjects, ocap, &lm_obj_) != VDO_OK) return;
   }
+  if (ctx_worker) worker_.reset(new Worker());
   ok_ = true;
 }
 
 FramePipeline::~FramePipeline() {
+  if (worker_) { worker_->wait(); worker_.reset(); }
   if (orb_) vdo_orb_destroy(orb_);
   for (int k = 0; k < 2; ++k) if (img_[k]) vdo_frame_images_destroy(img_[k]);
   if (tr_sta_) vdo_tracks_destroy(tr_sta_);
@@ -67,6 +105,15 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   auto tick = [&](int slot) { const auto t = std::chrono::steady_clock::now(); ms_[slot] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
   vdo_frame_images *cur = img_[cur_], *last = img_[cur_ ^ 1];
   const int W = p_.width, H = p_.height;
+  struct Join { Worker* w; ~Join() { if (w) w->wait(); } } join_guard{worker_.get()};      // never leave Step with the helper thread on its locals
+  // ---- deferred mode: the object stage of the PREVIOUS frame ends during this frame's camera stage + ORB front-end (nothing
+  // there depends on the object set) - on the helper thread if there is one, else right after ORB on this thread
+  bool fin_async = false;
+  if (pending_ && worker_) {
+    vdo_frame_images_set_ctx(img_obj_, ctx_w_);
+    worker_->run([this, &fc] { return FinishObjects(&fc); });
+    fin_async = true;
+  }
   // ---- GrabImageRGBD: images, K1, UpdateMask (K15), propagation (K11)            Tracking.cc:180-305
   VDO_TRY(vdo_frame_images_upload_device(cur, d_depth_raw, d_flow, d_mask));
   VDO_TRY(vdo_frame_images_depth_preprocess(cur, p_.bf, p_.depth_map_factor));
@@ -134,9 +181,14 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   VDO_TRY(vdo_orb_extract(orb_, d_gray, W, 1, &kp));
   fc.n_orb = kp.n;
   tick(1);
-  // ---- deferred mode: the object stage of the PREVIOUS frame ends here - its LMs had the camera stage and the ORB
-  // front-end of this frame to finish (nothing above depends on the object set)
-  if (pending_) { if (FinishObjects(&fc) != 0) return -1; t_prev = std::chrono::steady_clock::now(); }
+  if (fin_async) {
+    const int rc = worker_->wait();
+    vdo_frame_images_set_ctx(last, ctx_);
+    if (rc != 0) return -1;
+  } else if (pending_) {
+    if (FinishObjects(&fc) != 0) return -1;
+  }
+  t_prev = std::chrono::steady_clock::now();
   // ---- UpdateMask (K15) + object part of the propagation (K11): they need the object set of the last frame
   const int n_o = have_last_ ? (int)obj_.cx.size() : 0;
   obj_depth.assign(n_o, 0.f); obj_sem.assign(n_o, 0);
@@ -196,6 +248,37 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   tick(3);
   StaSet nsta; ObjSet nobj;
   std::vector<int32_t> sta_asso, dyn_asso;
+  // ---- K9 + K10 of the new image, RenewFrameInfo (static) (K14, K12), static tracklets: independent of the object chain
+  // below (scene flow -> DynObjTracking -> object RANSAC -> object LMs) - on the helper thread if there is one
+  vdo_ctx* ctx_f = worker_ ? ctx_w_ : ctx_;
+  auto stage_static = [&]() -> int {
+    auto tp = std::chrono::steady_clock::now();
+    auto tk = [&](int slot) { const auto t = std::chrono::steady_clock::now(); ms_[slot] += std::chrono::duration<double, std::milli>(t - tp).count(); tp = t; };
+    if (frame_filters() != 0) return -1;
+    tk(2);
+    const int cs = p_.max_track_bg + 2;
+    nsta.x.resize(cs); nsta.y.resize(cs); nsta.cx.resize(cs); nsta.cy.resize(cs); nsta.fx.resize(cs); nsta.fy.resize(cs); nsta.d.resize(cs);
+    sta_asso.resize(cs);
+    int m = 0;
+    VDO_TRY(vdo_renew_static(cur, n_s, tm.data(), cur_sx.data(), cur_sy.data(), kp.n, kx_.data(), ky_.data(), p_.max_track_bg,
+                             nsta.x.data(), nsta.y.data(), nsta.cx.data(), nsta.cy.data(), nsta.fx.data(), nsta.fy.data(), sta_asso.data(), nsta.d.data(), &m));
+    for (auto* v : {&nsta.x, &nsta.y, &nsta.cx, &nsta.cy, &nsta.fx, &nsta.fy, &nsta.d}) v->resize(m);
+    sta_asso.resize(m);
+    float Twc[16];
+    inv_rigid(Tcw, Twc);
+    nsta.xyz.resize(3 * (size_t)std::max(m, 1));
+    VDO_TRY(vdo_get3d_world(ctx_f, m, nsta.x.data(), nsta.y.data(), nsta.d.data(), p_.K4, Twc, nsta.xyz.data()));     // mvStat3DPointTmp
+    // ---- static tracklets (incremental GetStaticTrack)                             Tracking.cc:2201-2300
+    VDO_TRY(vdo_tracks_add_frame(tr_sta_, m, sta_asso.data(), nullptr));
+    tk(5);
+    return 0;
+  };
+  bool static_async = false;
+  if (have_last_ && worker_) {
+    vdo_frame_images_set_ctx(cur, ctx_w_);
+    worker_->run(stage_static);
+    static_async = true;
+  }
   if (!have_last_) {
     // ---- Initialization(): the new features ARE the tracked set                   Tracking.cc:1215-1276
     if (obj) VDO_TRY(vdo_flow2_batch_run(obj));
@@ -280,22 +363,13 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     tick(9);
     // ---- object motions (K17) on the LM stream, RenewFrameInfo (static) meanwhile  Tracking.cc:932 || :2666-2805
     if (obj) VDO_TRY(vdo_flow2_batch_run(obj));
-    if (frame_filters() != 0) return -1;
-    const int cs = p_.max_track_bg + 2;
-    nsta.x.resize(cs); nsta.y.resize(cs); nsta.cx.resize(cs); nsta.cy.resize(cs); nsta.fx.resize(cs); nsta.fy.resize(cs); nsta.d.resize(cs);
-    sta_asso.resize(cs);
-    int m = 0;
-    VDO_TRY(vdo_renew_static(cur, n_s, tm.data(), cur_sx.data(), cur_sy.data(), kp.n, kx_.data(), ky_.data(), p_.max_track_bg,
-                             nsta.x.data(), nsta.y.data(), nsta.cx.data(), nsta.cy.data(), nsta.fx.data(), nsta.fy.data(), sta_asso.data(), nsta.d.data(), &m));
-    for (auto* v : {&nsta.x, &nsta.y, &nsta.cx, &nsta.cy, &nsta.fx, &nsta.fy, &nsta.d}) v->resize(m);
-    sta_asso.resize(m);
-    float Twc[16];
-    inv_rigid(Tcw, Twc);
-    nsta.xyz.resize(3 * (size_t)std::max(m, 1));
-    VDO_TRY(vdo_get3d_world(ctx_, m, nsta.x.data(), nsta.y.data(), nsta.d.data(), p_.K4, Twc, nsta.xyz.data()));     // mvStat3DPointTmp
-    tick(5);
-    // ---- static tracklets (incremental GetStaticTrack)                             Tracking.cc:2201-2300
-    VDO_TRY(vdo_tracks_add_frame(tr_sta_, m, sta_asso.data(), nullptr));
+    // ---- RenewFrameInfo (static) meanwhile                                         Tracking.cc:2666-2805
+    if (static_async) {
+      const int rc = worker_->wait();
+      vdo_frame_images_set_ctx(cur, ctx_);
+      if (rc != 0) return -1;
+    } else if (stage_static() != 0) return -1;
+    t_prev = std::chrono::steady_clock::now();
     // the object stage (results of the LMs, RenewFrameInfo of the objects, dynamic tracklets) ends in FinishObjects():
     // right below, or - deferred mode - inside the next Step, after that frame's camera stage and ORB front-end
     n_objects_ = n_objects; obj_run_ = obj; n_obj_problems_ = n_obj_problems; n_tmp_ = n_tmp; img_obj_ = cur;
@@ -396,7 +470,7 @@ int FramePipeline::FinishObjects(FrameCounts* fcp) {
     for (auto* v : {&nobj.x, &nobj.y, &nobj.cx, &nobj.cy, &nobj.fx, &nobj.fy, &nobj.d}) v->resize(mo);
     nobj.sem.resize(mo); nobj.label.resize(mo); dyn_asso.resize(mo);
     nobj.xyz.resize(3 * (size_t)std::max(mo, 1));
-    VDO_TRY(vdo_get3d_world(ctx_, mo, nobj.x.data(), nobj.y.data(), nobj.d.data(), p_.K4, Twc, nobj.xyz.data()));     // mvObj3DPoint
+    VDO_TRY(vdo_get3d_world(ctx_w_, mo, nobj.x.data(), nobj.y.data(), nobj.d.data(), p_.K4, Twc, nobj.xyz.data()));     // mvObj3DPoint
     tick(7);
     // ---- tracklets (incremental GetStaticTrack / GetDynamicTrackNew)               Tracking.cc:2201-2421
     VDO_TRY(vdo_tracks_add_frame(tr_dyn_, mo, dyn_asso.data(), nobj.label.data()));
@@ -421,8 +495,8 @@ using VDO_SLAM::FrameCounts;
 using VDO_SLAM::PipelineParams;
 
 extern "C" {
-FramePipeline* host_pipeline_create(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams* p, vdo_ctx* ctx_obj) {
-  FramePipeline* fp = new FramePipeline(ctx, ctx_lm, *p, ctx_obj);
+FramePipeline* host_pipeline_create(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams* p, vdo_ctx* ctx_obj, vdo_ctx* ctx_worker) {
+  FramePipeline* fp = new FramePipeline(ctx, ctx_lm, *p, ctx_obj, ctx_worker);
   if (!fp->ok()) { delete fp; return nullptr; }
   return fp;
 }

@@ -14,6 +14,8 @@
 // frame's camera stage needs this frame's object results).
 #pragma once
 #include <cstdint>
+#include <functional>
+#include <memory>
 #include <vector>
 
 #include "../../include/vdo_slam_hip.h"
@@ -39,8 +41,11 @@ struct FrameCounts { int n_orb, n_static_new, n_object_samples, n_static_tracked
 
 class FramePipeline {
  public:
-  // ctx: front-end / tracking kernels; ctx_lm: camera pose problems; ctx_obj: object pose problems (NULL: ctx_lm) - three HIP streams
-  FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p, vdo_ctx* ctx_obj = nullptr);
+  // ctx: front-end / tracking kernels; ctx_lm: camera pose problems; ctx_obj: object pose problems (NULL: ctx_lm) - three HIP streams.
+  // ctx_worker (optional): a second HOST thread runs the stages that are independent of what the main thread is doing - the object
+  // stage of the previous frame (deferred mode) next to this frame's camera stage + ORB, and K9/K10 + RenewFrameInfo (static) next
+  // to the scene-flow / object-tracking / object-RANSAC chain - with this context (its own stream and scratch arena).
+  FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p, vdo_ctx* ctx_obj = nullptr, vdo_ctx* ctx_worker = nullptr);
   ~FramePipeline();
   // One frame.  d_* are DEVICE pointers of the raw inputs (gray u8, disparity*factor f32, flow 2xf32, mask i32).
   // cam / obj: the frame's pose problems (already resident); their results are fetched like Track() consumes them.
@@ -58,7 +63,9 @@ class FramePipeline {
   struct ObjSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; std::vector<int32_t> sem, label; };
   struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; };
   int FinishObjects(FrameCounts* fc);
-  vdo_ctx *ctx_, *ctx_lm_, *ctx_obj_;
+  class Worker;
+  std::unique_ptr<Worker> worker_;
+  vdo_ctx *ctx_, *ctx_lm_, *ctx_obj_, *ctx_w_;
   // object stage handed from Step() to FinishObjects()
   bool pending_ = false;
   int n_objects_ = 0, n_obj_problems_ = 0, n_tmp_ = 0;
