@@ -6,6 +6,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstring>
 #include <vector>
 
@@ -16,15 +17,17 @@ namespace vdo {
 
 class Arena {
  public:
-  explicit Arena(vdo_ctx* c) : c_(c), s(c->stream) {}
-  hipStream_t s;
+  explicit Arena(vdo_ctx* c) : c_(c), s_(c->stream) {}
+  // The stream to launch on.  Asking for it sends the inputs staged so far (one merged H2D copy), so a kernel launched
+  // on it sees them.
+  hipStream_t stream() { flush(); return s_; }
 
   // Make room for `bytes` of device scratch and as much pinned staging (called once, before any up/alloc:
   // growing re-allocates the blocks).
   bool reserve(size_t bytes) {
     bytes = (bytes + 4095) & ~size_t(4095);
     if (bytes > c_->d_cap) {
-      hipStreamSynchronize(s);
+      hipStreamSynchronize(s_);
       if (c_->d_arena) hipFree(c_->d_arena);
       c_->d_arena = nullptr; c_->d_cap = 0;
       const size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes * 2;
@@ -32,63 +35,74 @@ class Arena {
       c_->d_cap = want;
     }
     if (bytes > c_->h_cap) {
-      hipStreamSynchronize(s);
+      hipStreamSynchronize(s_);
       if (c_->h_arena) hipHostFree(c_->h_arena);
       c_->h_arena = nullptr; c_->h_cap = 0;
       const size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes * 2;
       if (hipHostMalloc((void**)&c_->h_arena, want) != hipSuccess) return false;
       c_->h_cap = want;
     }
-    d_off_ = h_off_ = 0;
+    off_ = 0; in_lo_ = in_hi_ = 0;
     return true;
   }
   static size_t bytes_for(size_t n_elems_total) { return n_elems_total * 8 + 64 * 256 + 4096; }   // 8 B per element + alignment slack
 
-  // device buffer of n elements; with `host` != null its content is staged and copied in (stream-ordered)
+  // Device buffer of n elements; with `host` != null its content is staged for the next merged H2D copy.  The device block
+  // and the pinned block share their layout (a buffer has the same offset in both), so adjacent staged inputs travel in ONE
+  // copy and all outputs of a call come back in ONE copy (a copy costs ~5-7 us of stream time whatever its size here).
   template <class T>
   T* up(const T* host, size_t n) {
-    T* d = (T*)take(d_off_, c_->d_arena, c_->d_cap, n * sizeof(T));
-    if (!d) return nullptr;
+    const size_t a = (off_ + 255) & ~size_t(255), bytes = n * sizeof(T);
+    if (!c_->d_arena || !c_->h_arena || a + bytes > c_->d_cap || a + bytes > c_->h_cap) return nullptr;
+    off_ = a + bytes;
     if (host && n) {
-      T* h = (T*)take(h_off_, c_->h_arena, c_->h_cap, n * sizeof(T));
-      if (!h) return nullptr;
-      std::memcpy(h, host, n * sizeof(T));
-      hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, s);
+      std::memcpy(c_->h_arena + a, host, bytes);
+      if (in_hi_ == in_lo_) { in_lo_ = a; in_hi_ = a + bytes; }
+      else if (a - in_hi_ <= 4096) in_hi_ = a + bytes;            // adjacent (up to alignment / a small output buffer nothing wrote yet)
+      else { flush(); in_lo_ = a; in_hi_ = a + bytes; }
+    } else if (in_hi_ != in_lo_ && bytes > 4096) {
+      flush();                                                    // a large device-only buffer ends the run of adjacent inputs
     }
-    return d;
+    return (T*)(c_->d_arena + a);
   }
   // queue device -> caller copy (through the pinned block; delivered by finish())
   template <class T>
   void down(T* user, const T* dev, size_t n) {
     if (!user || !n) return;
-    T* h = (T*)take(h_off_, c_->h_arena, c_->h_cap, n * sizeof(T));
-    if (!h) { failed_ = true; return; }
-    hipMemcpyAsync(h, dev, n * sizeof(T), hipMemcpyDeviceToHost, s);
-    pend_.push_back({user, h, n * sizeof(T)});
+    const size_t o = (size_t)((const char*)dev - c_->d_arena);
+    if ((const char*)dev < c_->d_arena || o + n * sizeof(T) > c_->d_cap) { failed_ = true; return; }
+    pend_.push_back({user, o, n * sizeof(T)});
   }
-  // one synchronisation, then the queued outputs reach the caller's arrays
+  // the outputs come back (one copy of their span, or one per buffer when the span is mostly something else), one
+  // synchronisation, then they reach the caller's arrays
   int finish(const char* what) {
-    hipError_t e = hipStreamSynchronize(s);
+    flush();
+    if (!pend_.empty()) {
+      size_t lo = ~size_t(0), hi = 0, sum = 0;
+      for (const Pend& p : pend_) { lo = std::min(lo, p.off); hi = std::max(hi, p.off + p.bytes); sum += p.bytes; }
+      if (hi - lo <= 4 * sum + (size_t(64) << 10)) hipMemcpyAsync(c_->h_arena + lo, c_->d_arena + lo, hi - lo, hipMemcpyDeviceToHost, s_);
+      else for (const Pend& p : pend_) hipMemcpyAsync(c_->h_arena + p.off, c_->d_arena + p.off, p.bytes, hipMemcpyDeviceToHost, s_);
+    }
+    hipError_t e = hipStreamSynchronize(s_);
     if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));
-    if (failed_) return set_error(VDO_ERR_OOM, "%s: scratch arena exhausted", what);
-    for (const Pend& p : pend_) std::memcpy(p.user, p.pinned, p.bytes);
+    if (e != hipSuccess) { pend_.clear(); return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e)); }
+    if (failed_) { pend_.clear(); return set_error(VDO_ERR_OOM, "%s: scratch arena exhausted", what); }
+    for (const Pend& p : pend_) std::memcpy(p.user, c_->h_arena + p.off, p.bytes);
     pend_.clear();
     return VDO_OK;
   }
 
  private:
-  struct Pend { void* user; const void* pinned; size_t bytes; };
+  void flush() {
+    if (in_hi_ != in_lo_) hipMemcpyAsync(c_->d_arena + in_lo_, c_->h_arena + in_lo_, in_hi_ - in_lo_, hipMemcpyHostToDevice, s_);
+    in_lo_ = in_hi_ = 0;
+  }
+  struct Pend { void* user; size_t off, bytes; };
   vdo_ctx* c_;
-  size_t d_off_ = 0, h_off_ = 0;
+  hipStream_t s_;
+  size_t off_ = 0, in_lo_ = 0, in_hi_ = 0;
   bool failed_ = false;
   std::vector<Pend> pend_;
-  static void* take(size_t& off, char* base, size_t cap, size_t bytes) {
-    const size_t a = (off + 255) & ~size_t(255);
-    if (!base || a + bytes > cap) return nullptr;
-    off = a + bytes;
-    return base + a;
-  }
 };
 
 }  // namespace vdo

@@ -284,8 +284,8 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   int32_t *dok = S.up<int32_t>(nullptr, tot_hyp), *dcnt = S.up<int32_t>(nullptr, tot_hyp);
   uint32_t* dmask = S.up<uint32_t>(nullptr, tot_words);
   if (!dprob || !dX || !duv || !dsub || !dpose || !dok || !dcnt || !dmask) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
-  hipLaunchKernelGGL(k_p3p_hyp, dim3((max_hyp + 63) / 64, n_problems), dim3(64), 0, S.s, (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const int32_t*)dsub, dpose, dok);
-  hipLaunchKernelGGL(k_ransac_vote, dim3(max_hyp, n_problems), dim3(256), 0, S.s, (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const double*)dpose, (const int32_t*)dok, dcnt, dmask);
+  hipLaunchKernelGGL(k_p3p_hyp, dim3((max_hyp + 63) / 64, n_problems), dim3(64), 0, S.stream(), (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const int32_t*)dsub, dpose, dok);
+  hipLaunchKernelGGL(k_ransac_vote, dim3(max_hyp, n_problems), dim3(256), 0, S.stream(), (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const double*)dpose, (const int32_t*)dok, dcnt, dmask);
   std::vector<int32_t> cnt(tot_hyp), okv(tot_hyp);
   std::vector<double> pose(12 * tot_hyp);
   std::vector<uint32_t> mask(tot_words);

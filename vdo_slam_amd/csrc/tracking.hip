@@ -139,7 +139,7 @@ extern "C" int vdo_propagate_static(vdo_frame_images* f, int n, const float* kx,
   if (!S.reserve(Arena::bytes_for(3 * (size_t)n))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   float *dx = S.up(kx, n), *dy = S.up(ky, n), *dd = S.up<float>(nullptr, n);
   if (!dd) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.s, 0, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, 0.f, dd, (int32_t*)nullptr);
+  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.stream(), 0, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, 0.f, dd, (int32_t*)nullptr);
   S.down(depth_out, dd, n);
   return S.finish("vdo_propagate_static");
 }
@@ -154,7 +154,7 @@ extern "C" int vdo_propagate_object(vdo_frame_images* f, int n, const float* kx,
   float *dx = S.up(kx, n), *dy = S.up(ky, n), *dd = S.up<float>(nullptr, n);
   int32_t* dl = S.up<int32_t>(nullptr, n);
   if (!dl) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.s, 1, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, th_depth_obj, dd, dl);
+  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.stream(), 1, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, th_depth_obj, dd, dl);
   S.down(depth_out, dd, n); S.down(label_out, dl, n);
   return S.finish("vdo_propagate_object");
 }
@@ -169,7 +169,7 @@ extern "C" int vdo_mask_at(vdo_frame_images* f, int n, const float* cx, const fl
   float *dx = S.up(cx, n), *dy = S.up(cy, n);
   int32_t* dl = S.up<int32_t>(nullptr, n);
   if (!dl) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.s, 2, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, 0.f, (float*)nullptr, dl);
+  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.stream(), 2, n, (const float*)dx, (const float*)dy, (const float*)f->d_depth, (const int32_t*)f->d_mask, f->w, f->h, 0.f, (float*)nullptr, dl);
   S.down(label_out, dl, n);
   return S.finish("vdo_mask_at");
 }
@@ -202,7 +202,7 @@ extern "C" int vdo_get3d_world(vdo_ctx* ctx, int n, const float* kx, const float
   if (!S.reserve(Arena::bytes_for(6 * (size_t)n))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   float *dx = S.up(kx, n), *dy = S.up(ky, n), *dd = S.up(depth, n), *dxyz = S.up<float>(nullptr, 3 * (size_t)n);
   if (!dxyz) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-  hipLaunchKernelGGL(k_get3d_world, dim3((n + 255) / 256), dim3(256), 0, S.s, n, (const float*)dx, (const float*)dy, (const float*)dd, make_cam_Twc(K4, Twc), dxyz);
+  hipLaunchKernelGGL(k_get3d_world, dim3((n + 255) / 256), dim3(256), 0, S.stream(), n, (const float*)dx, (const float*)dy, (const float*)dd, make_cam_Twc(K4, Twc), dxyz);
   S.down(xyz_out, dxyz, 3 * (size_t)n);
   return S.finish("vdo_get3d_world");
 }
@@ -220,7 +220,7 @@ extern "C" int vdo_scene_flow(vdo_ctx* ctx, int n, const float* cur_x, const flo
   int32_t *cl = S.up(cur_label, n), *ll = S.up(last_label, n), *ol = S.up(obj_label_inout, n);
   float* fl = S.up<float>(nullptr, 3 * (size_t)n);
   if (!fl) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-  hipLaunchKernelGGL(k_scene_flow, dim3((n + 255) / 256), dim3(256), 0, S.s, n, (const float*)a, (const float*)b, (const float*)c, (const int32_t*)cl, make_cam_Tcw(K4, Tcw_cur),
+  hipLaunchKernelGGL(k_scene_flow, dim3((n + 255) / 256), dim3(256), 0, S.stream(), n, (const float*)a, (const float*)b, (const float*)c, (const int32_t*)cl, make_cam_Tcw(K4, Tcw_cur),
                      (const float*)d, (const float*)e, (const float*)g, (const int32_t*)ll, make_cam_Tcw(K4, Tcw_last), fl, ol);
   S.down(flow3d_out, fl, 3 * (size_t)n); S.down(obj_label_inout, ol, n);
   return S.finish("vdo_scene_flow");
@@ -246,12 +246,12 @@ extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm
   float *dx1 = S.up(cx1.data(), n1), *dy1 = S.up(cy1.data(), n1);
   int32_t* dok1 = S.up<int32_t>(nullptr, n1);
   float *dfx1 = S.up<float>(nullptr, n1), *dfy1 = S.up<float>(nullptr, n1), *dd1 = S.up<float>(nullptr, n1);
-  if (n1) hipLaunchKernelGGL(k_renew_pred, dim3((n1 + 255) / 256), dim3(256), 0, S.s, n1, (const float*)dx1, (const float*)dy1, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok1, dfx1, dfy1, dd1);
+  if (n1) hipLaunchKernelGGL(k_renew_pred, dim3((n1 + 255) / 256), dim3(256), 0, S.stream(), n1, (const float*)dx1, (const float*)dy1, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok1, dfx1, dfy1, dd1);
   float *dx2 = S.up(orb_x, n_orb), *dy2 = S.up(orb_y, n_orb);
   int32_t *dok2 = S.up<int32_t>(nullptr, n_orb), *dused = S.up<int32_t>(nullptr, n_orb);
   float *dfx2 = S.up<float>(nullptr, n_orb), *dfy2 = S.up<float>(nullptr, n_orb), *dd2 = S.up<float>(nullptr, n_orb);
   if (!dd2 || !dd1) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-  if (n_orb) hipLaunchKernelGGL(k_renew_pred, dim3((n_orb + 255) / 256), dim3(256), 0, S.s, n_orb, (const float*)dx2, (const float*)dy2, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok2, dfx2, dfy2, dd2);
+  if (n_orb) hipLaunchKernelGGL(k_renew_pred, dim3((n_orb + 255) / 256), dim3(256), 0, S.stream(), n_orb, (const float*)dx2, (const float*)dy2, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok2, dfx2, dfy2, dd2);
   S.down(ok1.data(), dok1, n1); S.down(fx1.data(), dfx1, n1); S.down(fy1.data(), dfy1, n1); S.down(d1.data(), dd1, n1);
   rc = S.finish("vdo_renew_static (carry)");
   if (rc != VDO_OK) return rc;
@@ -268,7 +268,7 @@ extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm
   const int n_check = m;
   if (m < max_num_sta && n_orb) {
     float *dcx = S.up(key_x, n_check), *dcy = S.up(key_y, n_check);
-    launch_near_flags(S.s, n_orb, dx2, dy2, n_check, dcx, dcy, dused);
+    launch_near_flags(S.stream(), n_orb, dx2, dy2, n_check, dcx, dcy, dused);
     S.down(used2.data(), dused, n_orb); S.down(ok2.data(), dok2, n_orb); S.down(fx2.data(), dfx2, n_orb); S.down(fy2.data(), dfy2, n_orb); S.down(d2.data(), dd2, n_orb);
     rc = S.finish("vdo_renew_static (top-up)");
     if (rc != VDO_OK) return rc;

@@ -248,7 +248,7 @@ extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* i
     int32_t *dok = S.up<int32_t>(nullptr, nc), *dsem = S.up<int32_t>(nullptr, nc);
     float *ddd = S.up<float>(nullptr, nc), *dfx = S.up<float>(nullptr, nc), *dfy = S.up<float>(nullptr, nc);
     if (!dfy) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-    hipLaunchKernelGGL(k_renew_obj_pred, dim3((nc + 255) / 256), dim3(256), 0, S.s, nc, (const float*)dx, (const float*)dy, (const int32_t*)f->d_mask,
+    hipLaunchKernelGGL(k_renew_obj_pred, dim3((nc + 255) / 256), dim3(256), 0, S.stream(), nc, (const float*)dx, (const float*)dy, (const int32_t*)f->d_mask,
                        (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok, dsem, ddd, dfx, dfy);
     S.down(ok.data(), dok, nc); S.down(sem.data(), dsem, nc); S.down(dd.data(), ddd, nc); S.down(fx.data(), dfx, nc); S.down(fy.data(), dfy, nc);
     rc = S.finish("vdo_renew_object (carry)");
@@ -276,7 +276,7 @@ extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* i
     float *dqx = S.up(tmp_x, n_tmp), *dqy = S.up(tmp_y, n_tmp), *drx = S.up(key_x, n_check), *dry = S.up(key_y, n_check);
     int32_t* dused = S.up<int32_t>(nullptr, n_tmp);
     if (!dused) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-    launch_near_flags(S.s, n_tmp, dqx, dqy, n_check, drx, dry, dused);
+    launch_near_flags(S.stream(), n_tmp, dqx, dqy, n_check, drx, dry, dused);
     S.down(used.data(), dused, n_tmp);
     rc = S.finish("vdo_renew_object (top-up)");
     if (rc != VDO_OK) return rc;
@@ -339,8 +339,8 @@ extern "C" int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, in
   // label after label, stream-ordered (a recovered mask is visible to the next label's vote, as in the reference); no host sync inside
   for (int s = 0; s < L; ++s) {
     const int ns = off[s + 1] - off[s];
-    hipLaunchKernelGGL(k_label_vote, dim3(1), dim3(256), 0, S.s, ns, (const float*)(dx + off[s]), (const float*)(dy + off[s]), (const int32_t*)cur->d_mask, cur->w, cur->h, dflag + 2 * s);
-    hipLaunchKernelGGL(k_mask_warp_if, dim3((cur->w + 255) / 256, cur->h), dim3(256), 0, S.s, (const int32_t*)(dflag + 2 * s), (const int32_t*)last->d_mask,
+    hipLaunchKernelGGL(k_label_vote, dim3(1), dim3(256), 0, S.stream(), ns, (const float*)(dx + off[s]), (const float*)(dy + off[s]), (const int32_t*)cur->d_mask, cur->w, cur->h, dflag + 2 * s);
+    hipLaunchKernelGGL(k_mask_warp_if, dim3((cur->w + 255) / 256, cur->h), dim3(256), 0, S.stream(), (const int32_t*)(dflag + 2 * s), (const int32_t*)last->d_mask,
                        (const float*)last->d_flow, cur->w, cur->h, uni[s], cur->d_mask);
   }
   std::vector<int32_t> flag(2 * (size_t)L);
