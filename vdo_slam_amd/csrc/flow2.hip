@@ -35,11 +35,14 @@ struct Flow2Dev {        // one problem, device pointers into the batch arrays
 };
 
 struct Flow2Arrays {
-  const double* in;      // per problem at 5*off: key points [2][n], measured flow [2][n], depth [n]   (SoA planes)
+  const double* in;      // per problem at 5*off: key points [2][n], measured flow [2][n], depth [n]   (SoA planes); HBM, or - batches
+                         // made by vdo_flow2_batch_reserve - the mapped pinned block vdo_flow2_batch_set writes (read once, in the setup)
+  double* om;            // per problem at 4*off: HBM copy of key points + measured flow (what the sweeps read)
   double *Xw, *f0, *f1, *err, *B2a, *B2b, *hla, *hlb, *bla, *blb, *xl;
   char* out;             // [results n_problems][refined flows 2*out_total doubles, (x, y) per point][inlier flags out_total bytes]
   int n_problems;
   struct Flow2Comm* comm;   // [n_problems]: exchange area of the workgroup cluster of every problem
+  unsigned int tag_base;    // launch number << 16: exchange tags of earlier launches never match, the area needs no clearing
 };
 
 // One problem is spread over a CLUSTER of up to F2_CLUSTER workgroups (one CU each; a single wave needs ~8k cycles per
@@ -82,7 +85,8 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   const int first = c_lo + tid, stride = F2_THREADS;                                      // the block sums (and one Hll entry) crosses workgroups
   Flow2Comm* comm = A.comm + prob;
   const int64_t off = P.off;
-  const double* __restrict__ obs = A.in + 5 * off; const double* __restrict__ meas = obs + 2 * (size_t)N; const double* __restrict__ depth = obs + 4 * (size_t)N;
+  const double* __restrict__ in_obs = A.in + 5 * off; const double* __restrict__ in_meas = in_obs + 2 * (size_t)N; const double* __restrict__ depth = in_obs + 4 * (size_t)N;
+  double* __restrict__ obs = A.om + 4 * off; double* __restrict__ meas = obs + 2 * (size_t)N;
   double* __restrict__ Xw = A.Xw + 3 * off; double* fcur = A.f0 + 2 * off; double* ftry = A.f1 + 2 * off;
   double* __restrict__ err = A.err + 2 * off; double* __restrict__ xl = A.xl + 2 * off;
   double *Bc = A.B2a + 12 * off, *Bt = A.B2b + 12 * off, *hc = A.hla + off, *ht = A.hlb + off, *bc = A.bla + 2 * off, *bt = A.blb + 2 * off;   // current / trial linearisation
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
 
   if (N < 3) {   // nInitialCorrespondences<3 -> identity, 0 inliers (Optimizer.cc:2449-2450, 2872-2873)
     if (tid < 16) res->T[tid] = (tid % 5 == 0) ? 1.0 : 0.0;
-    if (tid < N) { inlier_out[tid] = 0; flow_out[2 * tid] = meas[tid]; flow_out[2 * tid + 1] = meas[N + tid]; }   // nothing optimised: flows stay as measured
+    if (tid < N) { inlier_out[tid] = 0; flow_out[2 * tid] = in_meas[tid]; flow_out[2 * tid + 1] = in_meas[N + tid]; }   // nothing optimised: flows stay as measured
     if (tid == 0) { res->n_inliers = 0; res->iterations = 0; res->trials = 0; res->stop_reason = 0; res->initial_chi2 = res->final_chi2 = res->final_lambda = 0; }
     return;
   }
@@ -114,12 +118,14 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   // ---- setup: Xw, flows, initial pose (Converter::toSE3Quat)
   for (int i = first; i < c_hi; i += stride) {
     const double dz = depth[i];
-    const double x = (obs[i] - cx) * dz / fx, y = (obs[N + i] - cy) * dz / fy;
+    const double o0 = in_obs[i], o1 = in_obs[N + i], m0 = in_meas[i], m1 = in_meas[N + i];
+    obs[i] = o0; obs[N + i] = o1; meas[i] = m0; meas[N + i] = m1;
+    const double x = (o0 - cx) * dz / fx, y = (o1 - cy) * dz / fy;
     const double* W = P.Twl;
     Xw[i] = W[0] * x + W[1] * y + W[2] * dz + W[3];
     Xw[N + i] = W[4] * x + W[5] * y + W[6] * dz + W[7];
     Xw[2 * N + i] = W[8] * x + W[9] * y + W[10] * dz + W[11];
-    fcur[i] = meas[i]; fcur[N + i] = meas[N + i];
+    fcur[i] = m0; fcur[N + i] = m1;
     xl[i] = 0.0; xl[N + i] = 0.0;
   }
   if (tid < 6) s_xp[tid] = 0.0;
@@ -138,7 +144,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   __shared__ double s_part[F2_CLUSTER][32];
   auto cluster_sum = [&](const int K, double& mx, double& hb) -> bool {
     if (Gp == 1) return true;
-    const unsigned tag = (unsigned)phase + 1u;
+    const unsigned tag = A.tag_base + (unsigned)phase + 1u;
     if (tid < 31) {
       const double v = tid < K ? s_red[tid] : (tid == 29 ? mx : (tid == 30 ? hb : 0.0));
       const unsigned long long u = (unsigned long long)__double_as_longlong(v);
@@ -486,6 +492,8 @@ struct vdo_flow2_batch {
   std::vector<Flow2Dev> hp;       // host mirror of d_probs
   std::vector<int> caps;          // capacity (points) of every problem slot
   bool probs_dirty = false;       // host mirror changed since the last upload of d_probs
+  unsigned run_seq = 0;           // launches so far (tags of the cluster exchange)
+  const Flow2Dev* d_probs_run = nullptr;   // descriptors the kernel reads: d_probs, or the mapped pinned copy (reserved batches)
 };
 
 extern "C" int vdo_flow2_batch_destroy(vdo_flow2_batch* b) {
@@ -543,12 +551,14 @@ extern "C" int vdo_flow2_batch_create(vdo_ctx* ctx, int n_problems, const vdo_fl
   b->d_probs = (Flow2Dev*)dev(sizeof(Flow2Dev) * NP);
   Flow2Arrays& A = b->A;
   A.in = d_in;
+  A.om = (double*)dev(32 * T);
   A.Xw = (double*)dev(24 * T); A.f0 = (double*)dev(16 * T); A.f1 = (double*)dev(16 * T);
   A.err = (double*)dev(16 * T); A.B2a = (double*)dev(96 * T); A.B2b = (double*)dev(96 * T);
   A.hla = (double*)dev(8 * T); A.hlb = (double*)dev(8 * T); A.bla = (double*)dev(16 * T); A.blb = (double*)dev(16 * T);
   A.xl = (double*)dev(16 * T);
   A.n_problems = n_problems;
   A.comm = (Flow2Comm*)dev(sizeof(Flow2Comm) * NP);
+  if (A.comm) hipMemsetAsync(A.comm, 0, sizeof(Flow2Comm) * NP, s);
   for (void* p : b->allocs) if (!p) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
   if (!d_in) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
   hipMemcpyAsync(d_in, in.data(), 40 * T, hipMemcpyHostToDevice, s);
@@ -582,9 +592,15 @@ extern "C" int vdo_flow2_batch_reserve(vdo_ctx* ctx, int n_problems, const int32
   int rc = vdo_flow2_batch_create(ctx, n_problems, dummy.data(), out);
   if (rc != VDO_OK) return rc;
   vdo_flow2_batch* b = *out;
-  if (hipHostMalloc((void**)&b->h_up, sizeof(double) * 5 * (size_t)std::max<int64_t>(tot, 1) + sizeof(Flow2Dev) * (size_t)n_problems) != hipSuccess) { b->h_up = nullptr; vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipHostMalloc failed"); }
+  // Inputs and descriptors of a reserved batch live in MAPPED pinned memory: vdo_flow2_batch_set writes them, the kernel reads
+  // them through the mapping (once, in its setup: 40 B per correspondence) - defining the problems of a frame costs no copy.
+  if (hipHostMalloc((void**)&b->h_up, sizeof(double) * 5 * (size_t)std::max<int64_t>(tot, 1) + sizeof(Flow2Dev) * (size_t)n_problems, hipHostMallocMapped) != hipSuccess) { b->h_up = nullptr; vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_OOM, "hipHostMalloc failed"); }
+  void* dp = nullptr;
+  if (hipHostGetDevicePointer(&dp, b->h_up, 0) != hipSuccess || !dp) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_NO_DEVICE, "hipHostGetDevicePointer failed"); }
+  b->A.in = (const double*)dp;
+  b->d_probs_run = (const Flow2Dev*)((const double*)dp + 5 * (size_t)std::max<int64_t>(tot, 1));
   for (int k = 0; k < n_problems; ++k) { b->hp[k].n = 0; b->ns[k] = 0; }
-  hipMemcpyAsync(b->d_probs, b->hp.data(), sizeof(Flow2Dev) * (size_t)n_problems, hipMemcpyHostToDevice, ctx->stream);
+  std::memcpy(b->h_up + 5 * (size_t)std::max<int64_t>(tot, 1), b->hp.data(), sizeof(Flow2Dev) * (size_t)n_problems);
   if (hipStreamSynchronize(ctx->stream) != hipSuccess) { vdo_flow2_batch_destroy(b); return set_error(VDO_ERR_NO_DEVICE, "flow2 reserve failed"); }
   return VDO_OK;
 }
@@ -605,7 +621,7 @@ extern "C" int vdo_flow2_batch_set(vdo_flow2_batch* b, int k, const vdo_flow2_pr
     double* st = b->h_up + 5 * off;
     double *po = st, *pm = st + 2 * (size_t)n, *pd = st + 4 * (size_t)n;
     for (int i = 0; i < n; ++i) { po[i] = p->obs[2 * i]; po[n + i] = p->obs[2 * i + 1]; pm[i] = p->flow[2 * i]; pm[n + i] = p->flow[2 * i + 1]; pd[i] = p->depth[i]; }
-    hipMemcpyAsync((double*)b->A.in + 5 * off, st, 40 * (size_t)n, hipMemcpyHostToDevice, s);      // one copy: the slot has the staging's layout
+    (void)s;                               // (the kernel reads the slot through the mapping)
     d.max_iterations = p->max_iterations; d.ref_quirks = p->ref_quirks;
     std::memcpy(d.K, p->K, sizeof(d.K)); std::memcpy(d.Twl, p->Twl, sizeof(d.Twl)); std::memcpy(d.T0, p->T0, sizeof(d.T0));
     d.info_flow = p->info_flow; d.info_prior = p->info_prior; d.huber_delta = p->huber_delta;
@@ -625,13 +641,11 @@ extern "C" int vdo_flow2_batch_run(vdo_flow2_batch* b) {
     int64_t used = 0;
     for (int k = 0; k < b->n_problems; ++k) { b->hp[k].out_off = used; used += b->hp[k].n; }
     for (int k = 0; k < b->n_problems; ++k) b->hp[k].out_total = used;
-    Flow2Dev* pst = (Flow2Dev*)(b->h_up + 5 * (size_t)std::max<int64_t>(b->total, 1));           // pinned copy of the descriptors
-    std::memcpy(pst, b->hp.data(), sizeof(Flow2Dev) * (size_t)b->n_problems);
-    hipMemcpyAsync(b->d_probs, pst, sizeof(Flow2Dev) * (size_t)b->n_problems, hipMemcpyHostToDevice, b->ctx->stream);
+    std::memcpy(b->h_up + 5 * (size_t)std::max<int64_t>(b->total, 1), b->hp.data(), sizeof(Flow2Dev) * (size_t)b->n_problems);   // mapped: no copy
     b->probs_dirty = false;
   }
-  hipMemsetAsync(b->A.comm, 0, sizeof(Flow2Comm) * (size_t)b->n_problems, b->ctx->stream);      // barrier counters of the clusters
-  hipLaunchKernelGGL(k_flow2_lm, dim3(b->n_problems * F2_CLUSTER), dim3(F2_THREADS), 0, b->ctx->stream, (const Flow2Dev*)b->d_probs, b->A);
+  b->A.tag_base = (++b->run_seq) << 16;
+  hipLaunchKernelGGL(k_flow2_lm, dim3(b->n_problems * F2_CLUSTER), dim3(F2_THREADS), 0, b->ctx->stream, b->d_probs_run ? b->d_probs_run : (const Flow2Dev*)b->d_probs, b->A);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "k_flow2_lm launch: %s", hipGetErrorString(e));
   return VDO_OK;
