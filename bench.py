@@ -56,6 +56,18 @@ def _pmc_traffic_bytes(graph):
     return None
 
 
+def _cpu_budget():
+    """CPUs this job may use: the cgroup quota if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def _dist_env():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("LOCAL_RANK", "0"))
 
@@ -153,7 +165,13 @@ def main():
     # part of Tracking::GrabImageRGBD + Track over the C-ABI, state chained frame to frame); one ctypes call per frame.
     from vdo_slam_amd.pipeline import FramePipeline, kitti_params
     defer = 0 if os.environ.get("VDO_BENCH_SYNC_OBJECTS") else 1
-    ctx_w = None if os.environ.get("VDO_BENCH_NO_WORKER") else Context(local)      # helper host thread of FramePipeline, own stream + arena
+    # host threads per replica: main + 1 helper of FramePipeline (polls) + 3 quadtree helpers of ORB (sleep when idle); with fewer
+    # than ~5 CPUs per rank the helpers would only steal time from each other
+    cpus_per_rank = _cpu_budget() / max(1, world)
+    if cpus_per_rank < 3 and "VDO_ORB_THREADS" not in os.environ:
+        os.environ["VDO_ORB_THREADS"] = "0"
+    use_worker = not os.environ.get("VDO_BENCH_NO_WORKER") and cpus_per_rank >= 5
+    ctx_w = Context(local) if use_worker else None      # helper host thread of FramePipeline, own stream + arena
     pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj, ctx_w)
     torch.cuda.synchronize()
     counts = pipe.counts
@@ -213,7 +231,7 @@ def main():
                                f"geometrically consistent synthetic sequence of {n_seq} frames, 3 moving objects, flow noise sigma {FLOW_SIGMA} px",
                    "parallelism": f"replicas x{world}; 3 HIP streams per replica: camera LM (2) || ORB front-end (1); object LMs (3) || RenewFrameInfo (1) and - "
                                   f"defer_objects={defer} - the next frame's camera stage; every LM problem runs on a cluster of up to 8 workgroups; "
-                                  f"host threads per replica: 1 + {0 if ctx_w is None else 1} helper (object stage of the previous frame || camera stage + ORB; K9/K10/RenewFrameInfo static || object chain) + 3 ORB quadtree helpers",
+                                  f"{cpus_per_rank:.1f} CPUs per replica, host threads per replica: 1 + {0 if ctx_w is None else 1} helper (object stage of the previous frame || camera stage + ORB; K9/K10/RenewFrameInfo static || object chain) + 3 ORB quadtree helpers",
                    "orb_keypoints": counts.n_orb, "new_static_candidates": counts.n_static_new, "object_samples": counts.n_object_samples,
                    "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
                    "per_frame_mean": {q: round(v / n_all, 2) for q, v in agg.items()},
