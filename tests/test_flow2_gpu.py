@@ -63,3 +63,24 @@ def test_flow2_batch_of_objects_one_launch(ctx, oracle):
         _check(a, T, flow, inl, ninl, st)
         assert np.array_equal(a["T"], c["T"]) and np.array_equal(a["inliers"], c["inliers"])
     b.close()
+
+
+@pytest.mark.parametrize("quirks", [1, 0])
+def test_flow2_cluster_sizes_match_the_oracle(ctx, oracle, quirks):
+    """Problem sizes around the workgroup-cluster boundaries (1..8 workgroups per problem, ragged last chunk, more than one
+    correspondence per thread beyond 2048): one launch, every problem against the sequential oracle - the F3 leak between
+    neighbouring landmarks crosses the chunk boundaries."""
+    from vdo_slam_amd.flow2 import Flow2Batch
+    sizes = [255, 256, 257, 511, 513, 1025, 1792, 2048, 2049, 3001]
+    probs = []
+    for k, n in enumerate(sizes):
+        p = synth.make_flow2_problem(n, seed=100 + k, is_object=bool(k & 1))
+        p.ref_quirks = quirks
+        probs.append(p)
+    b = Flow2Batch(ctx, probs)
+    b.run()
+    res = b.fetch()
+    for p, r in zip(probs, res):
+        T, flow, inl, ninl, st = run_oracle(oracle, p)
+        _check(r, T, flow, inl, ninl, st)
+    b.close()
