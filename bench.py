@@ -124,6 +124,11 @@ def main():
     ap.add_argument("--no-batch", action="store_true", help="skip the batch-BA / roofline legs")
     ap.add_argument("--roofline-static", type=int, default=600000, help="static landmarks of the roofline graph")
     args = ap.parse_args()
+    # stdout carries exactly ONE line (the JSON result): libraries that print banners to fd 1 (RCCL's version block on
+    # communicator teardown) are sent to stderr
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     import torch
     import torch.distributed as dist
@@ -296,10 +301,10 @@ def main():
         out["cpu_baseline"] = {"value": cfps, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": f"the first {cn} frames of the same sequence through the same full Track() (oracle, 1 thread)",
                                "ms_per_stage": cstage}
-    if rank == 0:
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":
