@@ -37,7 +37,9 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 N_DISTINCT_FRAMES = 4   # make_frame_inputs(): independent random frames (tools/frame_probe.py)
-FLOW_SIGMA = 0.05       # px, noise of the dense flow input (a noise-free flow lets the object LMs chase 1e-15 residuals for 100+ iterations)
+# SURVEY.md 8d "synthetic inputs": flow noise N(0, 0.3^2) px, 2 % invalid depth, 1 % exactly-zero flow, 5 moving objects, one
+# instance mask missing for two frames (exercises UpdateMask)
+FLOW_SIGMA, INVALID_DEPTH, ZERO_FLOW, N_OBJECTS, DROP_MASKS = 0.3, 0.02, 0.01, 5, {30: {2}, 31: {2}}
 MAX_SEQ_FRAMES = 160    # length of the consistent synthetic sequence (the objects stay in view that long)
 
 
@@ -163,8 +165,9 @@ def main():
     W, H = synth.KITTI_W, synth.KITTI_H
     n_seq = min(args.steps + args.warmup, MAX_SEQ_FRAMES)
     Ts = SQ.camera_poses(n_seq)
-    objs = SQ.default_objects()
-    frames = [SQ.render_frame(k, Ts, objs, flow_sigma=FLOW_SIGMA, seed=17 * rank) for k in range(n_seq)]
+    objs = SQ.default_objects(N_OBJECTS)
+    frames = [SQ.render_frame(k, Ts, objs, flow_sigma=FLOW_SIGMA, seed=17 * rank, invalid_depth=INVALID_DEPTH, zero_flow=ZERO_FLOW, drop_masks=DROP_MASKS)
+              for k in range(n_seq)]
     dev = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames]
     # The per-frame sequence runs in the C++ host class FramePipeline (vdo_slam_amd/host/FramePipeline.cc: the hot
     # part of Tracking::GrabImageRGBD + Track over the C-ABI, state chained frame to frame); one ctypes call per frame.
@@ -180,7 +183,7 @@ def main():
     pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj, ctx_w)
     torch.cuda.synchronize()
     counts = pipe.counts
-    agg = {"cam_lm_iterations": 0, "n_static_tracked": 0, "n_object_tracked": 0, "n_objects": 0, "n_ransac_cam": 0, "n_cam_inliers": 0}
+    agg = {"cam_lm_iterations": 0, "n_static_tracked": 0, "n_object_tracked": 0, "n_objects": 0, "n_ransac_cam": 0, "n_cam_inliers": 0, "n_ransac_obj": 0, "n_recovered_masks": 0}
 
     def step(i):
         # Full Track() of one frame: UpdateMask (K15) -> K1 -> propagation (K11) -> GetInitModelCam (RANSAC-P3P, motion model)
@@ -233,7 +236,8 @@ def main():
                                "RANSAC-P3P + motion-model initialisers, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, "
                                "joint pose+flow LM for the camera (<=1200 matches) and every tracked object (ref_quirks=1) built from the frame's own correspondences, "
                                "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets; "
-                               f"geometrically consistent synthetic sequence of {n_seq} frames, 3 moving objects, flow noise sigma {FLOW_SIGMA} px",
+                               f"geometrically consistent synthetic sequence of {n_seq} frames: {N_OBJECTS} moving objects, flow noise sigma {FLOW_SIGMA} px, "
+                               f"{INVALID_DEPTH:.0%} invalid depth, {ZERO_FLOW:.0%} zero flow, one instance mask missing in frames {sorted(DROP_MASKS)}",
                    "parallelism": f"replicas x{world}; 3 HIP streams per replica: camera LM (2) || ORB front-end (1); object LMs (3) || RenewFrameInfo (1) and - "
                                   f"defer_objects={defer} - the next frame's camera stage; every LM problem runs on a cluster of up to 8 workgroups; "
                                   f"{cpus_per_rank:.1f} CPUs per replica, host threads per replica: 1 + {0 if ctx_w is None else 1} helper (object stage of the previous frame || camera stage + ORB; K9/K10/RenewFrameInfo static || object chain) + 3 ORB quadtree helpers",

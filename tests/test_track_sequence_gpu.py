@@ -120,3 +120,73 @@ def test_deferred_object_stage_gives_the_same_sequence():
             assert [(x["mod_label"], x["sem_label"], x["n_inliers"]) for x in a] == [(x["mod_label"], x["sem_label"], x["n_inliers"]) for x in b]
             for x, y in zip(a, b):
                 assert np.array_equal(x["H"], y["H"])
+
+
+def test_noisy_sequence_with_invalid_pixels_and_a_dropped_mask_matches_the_oracle(oracle):
+    """SURVEY.md 8d's input features: 5 objects, N(0, 0.3^2) px flow noise, 2 % invalid depth, 1 % exactly-zero flow, the
+    instance mask of one object missing for two frames (UpdateMask recovers it).  GPU Track() == oracle Track()."""
+    import torch
+    from tests.pipeline_ref import OraclePipeline
+    n_frames = 9
+    Ts = SQ.camera_poses(n_frames)
+    objs = SQ.default_objects(5)
+    drop = {5: {2}, 6: {2}}
+    ctx, ctx_lm, ctx_obj, ctx_w = Context(0), Context(0), Context(0), Context(0)
+    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1), ctx_obj, ctx_w)
+    ref = OraclePipeline(oracle, build_lm=True)
+    keys = ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects", "n_recovered_masks", "n_static_tracks",
+            "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations")
+    recovered = 0
+    for k in range(n_frames):
+        fr = SQ.render_frame(k, Ts, objs, flow_sigma=0.3, invalid_depth=0.02, zero_flow=0.01, drop_masks=drop)
+        d = {q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")}
+        torch.cuda.synchronize()
+        got = pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
+        exp = ref.step(fr)
+        assert {q: got[q] for q in keys} == {q: exp[q] for q in keys}, (k, got, exp)
+        np.testing.assert_allclose(pipe.pose(), ref.Tl, rtol=0, atol=5e-6)
+        ms, mo = pipe.motions(), ref.motions
+        assert [(a["mod_label"], a["sem_label"], a["n_inliers"]) for a in ms] == [(b["mod_label"], b["sem_label"], b["n_inliers"]) for b in mo]
+        # Object motions: the LM of a distant, noisy object stops (reference stop rules) before it has converged, so its result
+        # depends on the seed at the 1e-2 level, and the seed is the float32 cast of the RANSAC-P3P pose (GPU and oracle agree on
+        # that pose to ~1e-10, i.e. not always on its float32 rounding).  The LM kernel itself is exact on these very problems:
+        # test_every_lm_problem_of_the_noisy_sequence below.
+        for a, b in zip(ms, mo):
+            np.testing.assert_allclose(a["H"], b["H"], rtol=0, atol=2e-2 * max(1.0, float(np.abs(b["H"][:3, 3]).max())))
+        recovered += got["n_recovered_masks"]
+    assert recovered >= 1 and got["n_objects"] >= 3
+    pipe.close()
+
+
+def test_every_lm_problem_of_the_noisy_sequence(oracle):
+    """All pose problems (camera and objects) the oracle-composed Track() builds on the noisy 5-object sequence, solved by the
+    GPU kernel: same iterations, trials, inlier masks, poses to 1e-9 - also for the small, weakly constrained object problems."""
+    import tests.test_oracle_flow2 as TF
+    from tests.pipeline_ref import OraclePipeline
+    from vdo_slam_amd.flow2 import Flow2Batch
+    n_frames = 5
+    Ts = SQ.camera_poses(n_frames)
+    objs = SQ.default_objects(5)
+    ref = OraclePipeline(oracle, build_lm=True)
+    probs = []
+    orig = TF.run_oracle
+
+    def rec(o, prob):
+        r = orig(o, prob)
+        probs.append((prob, r))
+        return r
+    TF.run_oracle = rec
+    try:
+        for k in range(n_frames):
+            ref.step(SQ.render_frame(k, Ts, objs, flow_sigma=0.3, invalid_depth=0.02, zero_flow=0.01))
+    finally:
+        TF.run_oracle = orig
+    assert len(probs) >= 12
+    ctx = Context(0)
+    b = Flow2Batch(ctx, [p for p, _ in probs])
+    b.run()
+    for (p, (T, flow, inl, ninl, st)), r in zip(probs, b.fetch()):
+        assert (r["iterations"], r["trials"], r["n_inliers"]) == (st.iterations, st.total_trials, ninl), p.n
+        assert np.array_equal(r["inliers"], inl)
+        assert np.abs(r["T"] - T).max() <= 1e-9 * max(1.0, np.abs(T[:3, 3]).max())
+    b.close()

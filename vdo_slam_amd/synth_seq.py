@@ -23,16 +23,20 @@ def camera_poses(n_frames, step=0.8, yaw_amp=0.004):
     return Ts
 
 
-def default_objects():
-    """(centre xyz at frame 0 [m], half width, half height, velocity per frame [m])."""
+def default_objects(n=3):
+    """(centre xyz at frame 0 [m], half width, half height, velocity per frame [m]); n = 3 or 5 objects."""
     # velocities close to the camera's 0.8 m/frame: the objects stay inside ThDepthObj for ~100 frames
     return [dict(c=np.array([-3.0, 0.9, 14.0]), hw=1.1, hh=0.75, v=np.array([0.0, 0.0, 0.9])),
             dict(c=np.array([2.5, 0.85, 10.0]), hw=1.0, hh=0.8, v=np.array([0.01, 0.0, 0.76])),
-            dict(c=np.array([5.0, 0.9, 19.0]), hw=1.2, hh=0.75, v=np.array([-0.02, 0.0, 0.85]))]
+            dict(c=np.array([5.0, 0.9, 19.0]), hw=1.2, hh=0.75, v=np.array([-0.02, 0.0, 0.85]))] + ([] if n <= 3 else [
+            dict(c=np.array([-6.0, 0.8, 9.0]), hw=0.9, hh=0.85, v=np.array([0.0, 0.0, 0.82])),
+            dict(c=np.array([0.3, 0.95, 21.0]), hw=1.3, hh=0.7, v=np.array([0.015, 0.0, 0.7]))])
 
 
-def render_frame(k, Ts, objects, w=KITTI_W, h=KITTI_H, K4=KITTI_K, flow_sigma=0.0, seed=0):
-    """Frame k: dict(gray u8, depth_raw f32 (disparity*256), flow f32 [h,w,2] (k -> k+1), mask i32, Tcw 4x4, Tcw_next)."""
+def render_frame(k, Ts, objects, w=KITTI_W, h=KITTI_H, K4=KITTI_K, flow_sigma=0.0, seed=0, invalid_depth=0.0, zero_flow=0.0, drop_masks=None):
+    """Frame k: dict(gray u8, depth_raw f32 (disparity*256), flow f32 [h,w,2] (k -> k+1), mask i32, Tcw 4x4, Tcw_next).
+    SURVEY.md 8d extras: flow_sigma px of Gaussian flow noise, a fraction invalid_depth of pixels with disparity 0, a fraction
+    zero_flow of pixels with exactly-zero flow, drop_masks = {frame: labels whose instance mask is missing in that frame}."""
     fx, fy, cx, cy = K4
     T_wc, T_wc1 = Ts[k], Ts[k + 1]
     vv, uu = np.mgrid[0:h, 0:w].astype(np.float64)
@@ -76,6 +80,14 @@ def render_frame(k, Ts, objects, w=KITTI_W, h=KITTI_H, K4=KITTI_K, flow_sigma=0.
     flow = np.nan_to_num(flow, nan=0.0, posinf=0.0, neginf=0.0).astype(np.float32)
     valid = np.isfinite(depth) & (depth < 300)
     disp = np.where(valid, np.rint(DEPTH_MAP_FACTOR * BF / np.where(valid, depth, 1.0)), 0.0)
+    if invalid_depth or zero_flow:
+        r = np.random.default_rng(seed + 31 * k + 5).random((2, h, w))
+        if invalid_depth:
+            disp = np.where(r[0] < invalid_depth, 0.0, disp)
+        if zero_flow:
+            flow[r[1] < zero_flow] = 0.0
+    if drop_masks and k in drop_masks:
+        label = np.where(np.isin(label, list(drop_masks[k])), 0, label).astype(np.int32)
     return dict(gray=make_gray(seed + 1000 + k, w, h), depth_raw=np.ascontiguousarray(disp.astype(np.float32)), flow=np.ascontiguousarray(flow),
                 mask=np.ascontiguousarray(label), Tcw=np.linalg.inv(T_wc), Tcw_next=np.linalg.inv(T_wc1), depth_true=depth)
 
