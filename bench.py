@@ -297,10 +297,10 @@ def main():
                            "bytes_per_launch": int(bytes_launch), "avg_launch_ms": sweep_ms,
                            "units_per_launch": {"EdgeSE3PointXYZ": int(gr.n_eb), "LandmarkMotionTernaryEdge": int(gr.n_et), "points": int(gr.n_point)}}
         bar.close()
-        if rank == 0 and not args.no_cpu_baseline:
+        if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cb_ms, cb_sweep, cb_its = cpu_baseline_batch(g)
             out["cpu_baseline_batch"] = {"ms_per_lm_iter": cb_ms, "sweep_ms": cb_sweep, "iterations": cb_its, "cores": 1, "kind": "port"}
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is reported at N=1 only
         cfps, cn, cstage, _ = cpu_baseline_frames(frames)
         out["cpu_baseline"] = {"value": cfps, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": f"the first {cn} frames of the same sequence through the same full Track() (oracle, 1 thread)",
