@@ -1,5 +1,7 @@
 #include "FramePipeline.h"
 
+#include "Optimizer.h"
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
@@ -52,6 +54,23 @@ class FramePipeline::Worker {
   std::atomic<int> state_{0};     // 0 idle, 1 job posted, 2 job done, 3 quit
   std::thread th_;                // (last: started after the other members exist)
 };
+
+namespace {
+cv::Mat mat44f(const float* p) { cv::Mat m(4, 4, cv::CV_32F); std::memcpy(m.data, p, 64); return m; }
+// one frame's features in the Map's format: cv::KeyPoint / float depth / 3x1 cv::Mat world point per feature
+void push_features(std::vector<std::vector<cv::KeyPoint> >& F, std::vector<std::vector<float> >& D, std::vector<std::vector<cv::Mat> >& P,
+                   const std::vector<float>& x, const std::vector<float>& y, const std::vector<float>& d, const std::vector<float>& xyz) {
+  const size_t n = x.size();
+  std::vector<cv::KeyPoint> f(n); std::vector<float> dd(d.begin(), d.begin() + n); std::vector<cv::Mat> p(n);
+  for (size_t i = 0; i < n; ++i) {
+    f[i] = cv::KeyPoint(x[i], y[i], 0);
+    cv::Mat m(3, 1, cv::CV_32F);
+    std::memcpy(m.data, xyz.data() + 3 * i, 12);
+    p[i] = m;
+  }
+  F.push_back(std::move(f)); D.push_back(std::move(dd)); P.push_back(std::move(p));
+}
+}  // namespace
 
 static void fill_flow2(vdo_flow2_problem& p, int n, const double* obs, const double* flow, const double* depth, const float* K4, const float* Tcw_last,
                        const double* T0, double info_prior, int max_it) {
@@ -380,6 +399,13 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   fc.n_static_tracked = (int)nsta.x.size();
   int64_t np = 0;
   vdo_tracks_size(tr_sta_, &fc.n_static_tracks, &np);
+  if (map_) {                                            // "Save Graph Structure" (1), (5): static features and the camera pose of this frame
+    push_features(map_->vpFeatSta, map_->vfDepSta, map_->vp3DPointSta, nsta.x, nsta.y, nsta.d, nsta.xyz);
+    float Twc_m[16];
+    inv_rigid(Tcw, Twc_m);
+    map_->vmCameraPose.push_back(mat44f(Twc_m)); map_->vmCameraPose_RF.push_back(mat44f(Twc_m));
+    if (!have_last_) push_features(map_->vpFeatDyn, map_->vfDepDyn, map_->vp3DPointDyn, nobj.x, nobj.y, nobj.d, nobj.xyz);
+  }
   sta_ = std::move(nsta);
   if (!have_last_) { fc.n_object_tracked = (int)nobj.x.size(); obj_ = std::move(nobj); vdo_tracks_size(tr_dyn_, &fc.n_dynamic_tracks, &np); }
   {                                                      // mVelocity = mCurrentFrame.mTcw * LastTwc   (Tracking.cc:703-709)
@@ -387,6 +413,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     inv_rigid(Tcw_last_, Twl);
     for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float a = 0; for (int k = 0; k < 4; ++k) a += Tcw[4 * i + k] * Twl[4 * k + j]; vel_[4 * i + j] = a; }
   }
+  inv_rigid(vel_, cam_motion_);                          // (6.1) CameraMotionTmp = toInvMatrix(mVelocity)
   std::memcpy(Tcw_last_, Tcw, sizeof Tcw);
   std::memcpy(Tcw_out_, Tcw, sizeof Tcw);
   cur_ ^= 1; have_last_ = true; ++f_id_;
@@ -482,8 +509,34 @@ int FramePipeline::FinishObjects(FrameCounts* fcp) {
   fc.n_object_tracked = (int)nobj.x.size();
   int64_t np = 0;
   vdo_tracks_size(tr_dyn_, &fc.n_dynamic_tracks, &np);
+  if (map_) {                                            // "Save Graph Structure" (2), (6): object features, rigid motions + labels
+    push_features(map_->vpFeatDyn, map_->vfDepDyn, map_->vp3DPointDyn, nobj.x, nobj.y, nobj.d, nobj.xyz);
+    std::vector<cv::Mat> mots; std::vector<int> labs;
+    mots.push_back(mat44f(cam_motion_)); labs.push_back(0);
+    if (obj && obj == lm_obj_)
+      for (const ObjectMotion& om : motions_) { mots.push_back(mat44f(om.H)); labs.push_back(om.mod_label); }
+    map_->vmRigidMotion.push_back(mots); map_->vmRigidMotion_RF.push_back(mots); map_->vnRMLabel.push_back(labs);
+  }
   obj_ = std::move(nobj);
   pending_ = false;
+  return 0;
+}
+
+int FramePipeline::FinalizeMap() {
+  if (!map_) return -1;
+  if (pending_ && FinishObjects(nullptr) != 0) return -1;
+  for (int which = 0; which < 2; ++which) {
+    vdo_tracks* t = which ? tr_dyn_ : tr_sta_;
+    int nt = 0; int64_t np = 0;
+    VDO_TRY(vdo_tracks_size(t, &nt, &np));
+    std::vector<int32_t> off(nt + 1, 0), fr((size_t)std::max<int64_t>(np, 1)), ft((size_t)std::max<int64_t>(np, 1)), oid(std::max(nt, 1));
+    VDO_TRY(vdo_tracks_get(t, off.data(), fr.data(), ft.data(), which ? oid.data() : nullptr));
+    std::vector<std::vector<std::pair<int, int> > >& T = which ? map_->TrackletDyn : map_->TrackletSta;
+    T.assign(nt, {});
+    for (int a = 0; a < nt; ++a)
+      for (int q = off[a]; q < off[a + 1]; ++q) T[a].push_back(std::make_pair((int)fr[q], (int)ft[q]));
+    if (which) map_->nObjID.assign(oid.begin(), oid.begin() + nt);
+  }
   return 0;
 }
 
@@ -507,6 +560,62 @@ void host_pipeline_destroy(FramePipeline* fp) { delete fp; }
 // [10] K15 + K11 (objects)
 void host_pipeline_timing(FramePipeline* fp, double* ms11) { for (int i = 0; i < 11; ++i) ms11[i] = fp->ms_[i]; }
 int host_pipeline_flush(FramePipeline* fp, FrameCounts* out) { return fp->Flush(out); }
+
+// ---- Map: Track() -> Map -> Optimizer::FullBatchOptimization (tests / demos)
+VDO_SLAM::Map* host_pipeline_attach_map(FramePipeline* fp) { VDO_SLAM::Map* m = new VDO_SLAM::Map(); fp->AttachMap(m); return m; }
+void host_map_destroy(VDO_SLAM::Map* m) { delete m; }
+int host_pipeline_finalize_map(FramePipeline* fp) { return fp->FinalizeMap(); }
+// dims: [0] frames, [1] static features, [2] dynamic features, [3] static tracklets, [4] their pairs, [5] dynamic tracklets, [6] their pairs, [7] rigid motions
+void host_map_dims(const VDO_SLAM::Map* m, int* dims) {
+  for (int i = 0; i < 8; ++i) dims[i] = 0;
+  dims[0] = (int)m->vpFeatSta.size();
+  for (const auto& f : m->vpFeatSta) dims[1] += (int)f.size();
+  for (const auto& f : m->vpFeatDyn) dims[2] += (int)f.size();
+  dims[3] = (int)m->TrackletSta.size(); for (const auto& t : m->TrackletSta) dims[4] += (int)t.size();
+  dims[5] = (int)m->TrackletDyn.size(); for (const auto& t : m->TrackletDyn) dims[6] += (int)t.size();
+  for (const auto& r : m->vmRigidMotion) dims[7] += (int)r.size();
+}
+// flat copy of the Map (arrays sized by host_map_dims); refined != 0: the *_RF poses / motions
+void host_map_export(const VDO_SLAM::Map* m, int refined, float* cam_pose, int* sta_cnt, float* sta_uv, float* sta_d, float* sta_xw, int* tr_sta_len, int* tr_sta_pairs,
+                     int* dyn_cnt, float* dyn_uv, float* dyn_d, float* dyn_xw, int* tr_dyn_len, int* tr_dyn_pairs, int* obj_of_dyn, int* rm_cnt, float* rm, int* rm_label) {
+  const int F = (int)m->vpFeatSta.size();
+  size_t so = 0, dof = 0, ro = 0, po = 0;
+  for (int i = 0; i < F; ++i) {
+    std::memcpy(cam_pose + 16 * i, (refined ? m->vmCameraPose_RF : m->vmCameraPose)[i].data, 64);
+    sta_cnt[i] = (int)m->vpFeatSta[i].size();
+    for (size_t j = 0; j < m->vpFeatSta[i].size(); ++j, ++so) {
+      sta_uv[2 * so] = m->vpFeatSta[i][j].pt.x; sta_uv[2 * so + 1] = m->vpFeatSta[i][j].pt.y; sta_d[so] = m->vfDepSta[i][j];
+      std::memcpy(sta_xw + 3 * so, m->vp3DPointSta[i][j].data, 12);
+    }
+    dyn_cnt[i] = (int)m->vpFeatDyn[i].size();
+    for (size_t j = 0; j < m->vpFeatDyn[i].size(); ++j, ++dof) {
+      dyn_uv[2 * dof] = m->vpFeatDyn[i][j].pt.x; dyn_uv[2 * dof + 1] = m->vpFeatDyn[i][j].pt.y; dyn_d[dof] = m->vfDepDyn[i][j];
+      std::memcpy(dyn_xw + 3 * dof, m->vp3DPointDyn[i][j].data, 12);
+    }
+    if (i < (int)m->vmRigidMotion.size()) {
+      const auto& R = refined ? m->vmRigidMotion_RF[i] : m->vmRigidMotion[i];
+      rm_cnt[i] = (int)R.size();
+      for (size_t j = 0; j < R.size(); ++j, ++ro) { std::memcpy(rm + 16 * ro, R[j].data, 64); rm_label[ro] = m->vnRMLabel[i][j]; }
+    }
+  }
+  for (size_t t = 0; t < m->TrackletSta.size(); ++t) {
+    tr_sta_len[t] = (int)m->TrackletSta[t].size();
+    for (const auto& pr : m->TrackletSta[t]) { tr_sta_pairs[2 * po] = pr.first; tr_sta_pairs[2 * po + 1] = pr.second; ++po; }
+  }
+  po = 0;
+  for (size_t t = 0; t < m->TrackletDyn.size(); ++t) {
+    tr_dyn_len[t] = (int)m->TrackletDyn[t].size(); obj_of_dyn[t] = m->nObjID[t];
+    for (const auto& pr : m->TrackletDyn[t]) { tr_dyn_pairs[2 * po] = pr.first; tr_dyn_pairs[2 * po + 1] = pr.second; ++po; }
+  }
+}
+// Optimizer::FullBatchOptimization on the Map (GPU solve): refined poses / motions land in vmCameraPose_RF / vmRigidMotion_RF
+int host_map_full_batch(VDO_SLAM::Map* m, const float* K9, vdo_lm_stats* st) {
+  cv::Mat K(3, 3, cv::CV_32F);
+  std::memcpy(K.data, K9, 36);
+  VDO_SLAM::Optimizer::FullBatchOptimization(m, K);
+  if (st) *st = VDO_SLAM::Optimizer::last_batch_stats;
+  return 0;
+}
 void host_pipeline_pose(FramePipeline* fp, float* Tcw16) { std::memcpy(Tcw16, fp->Tcw_out_, 64); }
 int host_pipeline_motions(FramePipeline* fp, int cap, int* mod_label, int* sem_label, int* n_inliers, float* H16) {
   const int n = std::min(cap, (int)fp->motions_.size());

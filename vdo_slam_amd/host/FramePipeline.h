@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/vdo_slam_hip.h"
+#include "Map.h"
 
 namespace VDO_SLAM {
 
@@ -51,6 +52,13 @@ class FramePipeline {
   // cam / obj: the frame's pose problems (already resident); their results are fetched like Track() consumes them.
   int Step(const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
            vdo_flow2_batch* cam, vdo_flow2_batch* obj, int n_cam_pts, int n_obj_problems, FrameCounts* out);
+  // "Save Graph Structure" of Track() (src/Tracking.cc:1046-1110, Initialization :1238-1246): with a Map attached every frame
+  // appends its static / dynamic features, depths, 3-D points, camera pose and rigid motions (+ labels) to it - the input
+  // format of Optimizer::Full/PartialBatchOptimization.  FinalizeMap() writes the tracklets (GetStaticTrack /
+  // GetDynamicTrackNew, kept incrementally here) after the last frame (call Flush() first in deferred mode).
+  // The Map format costs one heap allocation per 3-D point (cv::Mat 3x1, as in the reference): off the benchmarked path.
+  void AttachMap(Map* m) { map_ = m; }
+  int FinalizeMap();
   // Ends a pending object stage (deferred mode); fc (optional) receives its n_object_tracked / n_dynamic_tracks.
   int Flush(FrameCounts* fc = nullptr) { return FinishObjects(fc); }
   bool ok() const { return ok_; }
@@ -63,6 +71,8 @@ class FramePipeline {
   struct ObjSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; std::vector<int32_t> sem, label; };
   struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; };
   int FinishObjects(FrameCounts* fc);
+  Map* map_ = nullptr;
+  float cam_motion_[16];              // Converter::toInvMatrix(mVelocity) of the frame whose object stage is pending
   class Worker;
   std::unique_ptr<Worker> worker_;
   vdo_ctx *ctx_, *ctx_lm_, *ctx_obj_, *ctx_w_;

@@ -61,6 +61,59 @@ class FramePipeline:
             raise K.VdoError("FramePipeline.Flush failed: " + (K.lib().vdo_last_error() or b"").decode())
         return self.counts.as_dict()
 
+    # ---- Map: Track() -> Map -> Optimizer::FullBatchOptimization
+    def attach_map(self):
+        """From now on every frame appends its features / poses / motions to a VDO_SLAM::Map ("Save Graph Structure")."""
+        self._L.host_pipeline_attach_map.restype = C.c_void_p
+        self._L.host_pipeline_attach_map.argtypes = [C.c_void_p]
+        self._map = self._L.host_pipeline_attach_map(self._h)
+
+    def finalize_map(self):
+        self._L.host_pipeline_finalize_map.argtypes = [C.c_void_p]
+        if self._L.host_pipeline_finalize_map(self._h) != 0:
+            raise K.VdoError("FramePipeline.FinalizeMap failed")
+
+    def export_map(self, K4, refined=False):
+        """The Map as the dict vdo_slam_amd/synth_map.py uses (cam_pose, feats, tr_sta, tr_dyn, obj_of_dyn, rigid_motion, rm_label)."""
+        import numpy as np
+        L = self._L
+        dims = (C.c_int * 8)()
+        L.host_map_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
+        L.host_map_dims(self._map, dims)
+        F, ns, nd, ts, tsp, td, tdp, nrm = list(dims)
+        f32 = lambda *sh: np.zeros(sh if all(sh) else tuple(max(1, q) for q in sh), np.float32)
+        i32 = lambda n: np.zeros(max(1, n), np.int32)
+        cam = f32(F, 4, 4); sta_cnt = i32(F); sta_uv = f32(ns, 2); sta_d = f32(ns); sta_xw = f32(ns, 3); tsl = i32(ts); tspairs = i32(2 * tsp)
+        dyn_cnt = i32(F); dyn_uv = f32(nd, 2); dyn_d = f32(nd); dyn_xw = f32(nd, 3); tdl = i32(td); tdpairs = i32(2 * tdp); oid = i32(td)
+        rm_cnt = i32(F); rm = f32(nrm, 4, 4); rml = i32(nrm)
+        fp = lambda a: a.ctypes.data_as(K.c_float_p)
+        ip = lambda a: a.ctypes.data_as(K.c_int32_p)
+        L.host_map_export.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 17
+        L.host_map_export(self._map, int(refined), fp(cam), ip(sta_cnt), fp(sta_uv), fp(sta_d), fp(sta_xw), ip(tsl), ip(tspairs),
+                          ip(dyn_cnt), fp(dyn_uv), fp(dyn_d), fp(dyn_xw), ip(tdl), ip(tdpairs), ip(oid), ip(rm_cnt), fp(rm), ip(rml))
+        so = np.concatenate([[0], np.cumsum(sta_cnt[:F])]); do = np.concatenate([[0], np.cumsum(dyn_cnt[:F])])
+        feats = [dict(sta_uv=sta_uv[so[i]:so[i + 1]], sta_d=sta_d[so[i]:so[i + 1]], sta_xw=sta_xw[so[i]:so[i + 1]],
+                      dyn_uv=dyn_uv[do[i]:do[i + 1]], dyn_d=dyn_d[do[i]:do[i + 1]], dyn_xw=dyn_xw[do[i]:do[i + 1]]) for i in range(F)]
+        def tracks(lens, pairs, n):
+            out, o = [], 0
+            for t in range(n):
+                out.append([(int(pairs[2 * (o + k)]), int(pairs[2 * (o + k) + 1])) for k in range(lens[t])]); o += lens[t]
+            return out
+        ro = np.concatenate([[0], np.cumsum(rm_cnt[:max(F - 1, 0)])])
+        Km = np.array([[K4[0], 0, K4[2]], [0, K4[1], K4[3]], [0, 0, 1]], np.float32)
+        return dict(n_frames=F, K=Km, cam_pose=cam[:F], feats=feats, tr_sta=tracks(tsl, tspairs, ts), tr_dyn=tracks(tdl, tdpairs, td),
+                    obj_of_dyn=oid[:td].copy(), rigid_motion=[rm[ro[i]:ro[i + 1]] for i in range(F - 1)], rm_label=[rml[ro[i]:ro[i + 1]] for i in range(F - 1)])
+
+    def full_batch(self, K4):
+        """Optimizer::FullBatchOptimization (C++ graph builder, GPU solve) on the attached Map; returns the LM statistics."""
+        import numpy as np
+        Km = np.array([K4[0], 0, K4[2], 0, K4[1], K4[3], 0, 0, 1], np.float32)
+        st = K.LMStatsC()
+        self._L.host_map_full_batch.argtypes = [C.c_void_p, K.c_float_p, C.POINTER(K.LMStatsC)]
+        if self._L.host_map_full_batch(self._map, Km.ctypes.data_as(K.c_float_p), C.byref(st)) != 0:
+            raise K.VdoError("FullBatchOptimization failed")
+        return st
+
     def pose(self):
         """Tcw (4x4 float32) of the last frame."""
         import numpy as np
@@ -85,6 +138,9 @@ class FramePipeline:
     def close(self):
         if self._h:
             self._L.host_pipeline_destroy(self._h); self._h = None
+            if getattr(self, "_map", None):
+                self._L.host_map_destroy.argtypes = [C.c_void_p]
+                self._L.host_map_destroy(self._map); self._map = None
 
     def __del__(self):
         try: self.close()
