@@ -63,3 +63,41 @@ def test_track_then_full_batch_matches_the_oracle(oracle, defer, worker):
     err_after = max(np.abs(m_rf["cam_pose"][i][:3, 3] - gt[i][:3, 3]).max() for i in range(n_frames))
     assert err_before < 0.05 and err_after < 0.05
     pipe.close()
+
+
+def test_partial_batch_optimization_runs_on_the_reference_schedule():
+    """WINDOW_SIZE 8 / OVERLAP_SIZE 2: the windowed optimisation fires at f_id 7 and 13 (src/Tracking.cc:1169), refines the
+    Map's window in place and leaves the tracker's own state alone."""
+    import torch
+    n_frames = 14
+    Ts = SQ.camera_poses(n_frames)
+    objs = SQ.default_objects()
+
+    def run(window):
+        ctx, ctx_lm, ctx_obj = Context(0), Context(0), Context(0)
+        pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1,
+                                                       window_size=window, overlap_size=2 if window else 0), ctx_obj)
+        pipe.attach_map()
+        fired, poses = [], []
+        for k in range(n_frames):
+            fr = SQ.render_frame(k, Ts, objs, flow_sigma=0.1)
+            d = {q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")}
+            torch.cuda.synchronize()
+            pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
+            fired.append(pipe.partial_batches()); poses.append(pipe.pose().copy())
+        pipe.finalize_map()
+        m = pipe.export_map(synth.KITTI_K)
+        pipe.close()
+        return fired, poses, m
+
+    fired, poses, m = run(8)
+    fired0, poses0, m0 = run(0)
+    assert [b - a for a, b in zip([0] + fired[:-1], fired)] == [1 if k in (7, 13) else 0 for k in range(n_frames)]
+    assert fired0[-1] == 0
+    for a, b in zip(poses, poses0):
+        assert np.array_equal(a, b)                       # Track() itself does not read the refined Map
+    moved = max(np.abs(m["cam_pose"][i] - m0["cam_pose"][i]).max() for i in range(n_frames))
+    assert 0 < moved < 0.05                              # the window's poses were refined (a little)
+    err = max(np.abs(m["cam_pose"][i][:3, 3] - Ts[i][:3, 3]).max() for i in range(n_frames))
+    assert err < 0.06
+    assert len(m["tr_sta"]) == len(m0["tr_sta"]) and len(m["tr_dyn"]) == len(m0["tr_dyn"])

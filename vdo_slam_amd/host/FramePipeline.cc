@@ -391,7 +391,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     t_prev = std::chrono::steady_clock::now();
     // the object stage (results of the LMs, RenewFrameInfo of the objects, dynamic tracklets) ends in FinishObjects():
     // right below, or - deferred mode - inside the next Step, after that frame's camera stage and ORB front-end
-    n_objects_ = n_objects; obj_run_ = obj; n_obj_problems_ = n_obj_problems; n_tmp_ = n_tmp; img_obj_ = cur;
+    n_objects_ = n_objects; obj_run_ = obj; n_obj_problems_ = n_obj_problems; n_tmp_ = n_tmp; img_obj_ = cur; f_id_obj_ = f_id_;
     std::memcpy(Tcw_obj_, Tcw, sizeof Tcw);
     pending_ = true;
   }
@@ -516,6 +516,15 @@ int FramePipeline::FinishObjects(FrameCounts* fcp) {
     if (obj && obj == lm_obj_)
       for (const ObjectMotion& om : motions_) { mots.push_back(mat44f(om.H)); labs.push_back(om.mod_label); }
     map_->vmRigidMotion.push_back(mots); map_->vmRigidMotion_RF.push_back(mots); map_->vnRMLabel.push_back(labs);
+    // ---- partial batch optimisation on the last window (local optimisation)      Tracking.cc:1165-1183
+    const int Wn = p_.window_size, Ov = p_.overlap_size;
+    if (Wn > 0 && Wn > Ov && (f_id_obj_ - Ov + 1) % (Wn - Ov) == 0 && f_id_obj_ >= Wn - 1 && (int)map_->vpFeatSta.size() == f_id_obj_ + 1) {
+      if (TrackletsToMap() != 0) return -1;
+      cv::Mat Kc = cv::Mat::zeros(3, 3, cv::CV_32F);
+      Kc.at<float>(0, 0) = p_.K4[0]; Kc.at<float>(1, 1) = p_.K4[1]; Kc.at<float>(0, 2) = p_.K4[2]; Kc.at<float>(1, 2) = p_.K4[3]; Kc.at<float>(2, 2) = 1.f;
+      Optimizer::PartialBatchOptimization(map_, Kc, Wn);
+      ++n_partial_batches_;
+    }
   }
   obj_ = std::move(nobj);
   pending_ = false;
@@ -525,6 +534,11 @@ int FramePipeline::FinishObjects(FrameCounts* fcp) {
 int FramePipeline::FinalizeMap() {
   if (!map_) return -1;
   if (pending_ && FinishObjects(nullptr) != 0) return -1;
+  return TrackletsToMap();
+}
+
+// mpMap->TrackletSta = GetStaticTrack(); mpMap->TrackletDyn = GetDynamicTrackNew();   (Tracking.cc:1065-1071)
+int FramePipeline::TrackletsToMap() {
   for (int which = 0; which < 2; ++which) {
     vdo_tracks* t = which ? tr_dyn_ : tr_sta_;
     int nt = 0; int64_t np = 0;
@@ -565,6 +579,7 @@ int host_pipeline_flush(FramePipeline* fp, FrameCounts* out) { return fp->Flush(
 VDO_SLAM::Map* host_pipeline_attach_map(FramePipeline* fp) { VDO_SLAM::Map* m = new VDO_SLAM::Map(); fp->AttachMap(m); return m; }
 void host_map_destroy(VDO_SLAM::Map* m) { delete m; }
 int host_pipeline_finalize_map(FramePipeline* fp) { return fp->FinalizeMap(); }
+int host_pipeline_partial_batches(FramePipeline* fp) { return fp->n_partial_batches_; }
 // dims: [0] frames, [1] static features, [2] dynamic features, [3] static tracklets, [4] their pairs, [5] dynamic tracklets, [6] their pairs, [7] rigid motions
 void host_map_dims(const VDO_SLAM::Map* m, int* dims) {
   for (int i = 0; i < 8; ++i) dims[i] = 0;

@@ -35,6 +35,9 @@ struct PipelineParams {
   int defer_objects;                 // 1: Step() returns with the object LMs of the frame in flight; their results (object motions, renewed object
                                      //    set, dynamic tracklets) are consumed inside the next Step() - after that frame's camera stage and ORB
                                      //    front-end, which do not depend on them - or by Flush().  Same results, one frame of latency for the objects.
+  int window_size, overlap_size;     // WINDOW_SIZE / OVERLAP_SIZE: with a Map attached, Optimizer::PartialBatchOptimization runs on the last
+                                     //    window_size frames whenever (f_id-overlap+1) % (window-overlap) == 0 && f_id >= window-1
+                                     //    (src/Tracking.cc:1169-1183); 0 = never
 };
 
 struct FrameCounts { int n_orb, n_static_new, n_object_samples, n_static_tracked, n_object_tracked, n_objects, n_recovered_masks, n_static_tracks, n_dynamic_tracks,
@@ -59,6 +62,7 @@ class FramePipeline {
   // The Map format costs one heap allocation per 3-D point (cv::Mat 3x1, as in the reference): off the benchmarked path.
   void AttachMap(Map* m) { map_ = m; }
   int FinalizeMap();
+  int n_partial_batches_ = 0;          // PartialBatchOptimization runs so far
   // Ends a pending object stage (deferred mode); fc (optional) receives its n_object_tracked / n_dynamic_tracks.
   int Flush(FrameCounts* fc = nullptr) { return FinishObjects(fc); }
   bool ok() const { return ok_; }
@@ -71,7 +75,9 @@ class FramePipeline {
   struct ObjSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; std::vector<int32_t> sem, label; };
   struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; };
   int FinishObjects(FrameCounts* fc);
+  int TrackletsToMap();
   Map* map_ = nullptr;
+  int f_id_obj_ = 0;                  // frame id of the pending object stage
   float cam_motion_[16];              // Converter::toInvMatrix(mVelocity) of the frame whose object stage is pending
   class Worker;
   std::unique_ptr<Worker> worker_;
