@@ -1,0 +1,118 @@
+"""System::TrackRGBD (vdo_slam_amd/host/System.{h,cc}: the reference's entry API as a shell around FramePipeline) on host
+images: settings file, colour conversion, in-place depth conversion, ground-truth gate of the object tracker, Map, the final
+FullBatchOptimization."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from vdo_slam_amd import _capi as K
+from vdo_slam_amd import synth, synth_frames as SF, synth_seq as SQ
+from vdo_slam_amd.ba import Context
+from vdo_slam_amd.pipeline import FramePipeline, kitti_params
+
+pytestmark = pytest.mark.gpu
+W, H = synth.KITTI_W, synth.KITTI_H
+
+YAML = """%YAML:1.0
+Camera.fx: {fx}
+Camera.fy: {fy}
+Camera.cx: {cx}
+Camera.cy: {cy}
+Camera.k1: 0.0
+Camera.width: {w}
+Camera.height: {h}
+Camera.fps: 10.0
+Camera.bf: {bf}
+Camera.RGB: 1
+ChooseData: 2
+DepthMapFactor: {dmf}
+ThDepthBG: {thbg}
+ThDepthOBJ: {thobj}
+MaxTrackPointBG: 1200 # 1200 1500 2000
+MaxTrackPointOBJ: 800
+SFMgThres: 0.12 # 0.05
+SFDsThres: 0.3
+WINDOW_SIZE: 20
+OVERLAP_SIZE: 4
+UseSampleFeature: 0
+ORBextractor.nFeatures: 2500
+ORBextractor.scaleFactor: 1.2
+ORBextractor.nLevels: 8
+ORBextractor.iniThFAST: 20
+ORBextractor.minThFAST: 7
+"""
+
+
+@pytest.fixture(scope="module")
+def host():
+    L = K.load_host_lib()
+    L.host_system_create.restype = C.c_void_p
+    L.host_system_create.argtypes = [C.c_char_p]
+    L.host_system_destroy.argtypes = [C.c_void_p]
+    L.host_system_track.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.host_system_motions.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+    L.host_system_refined_poses.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    L.host_system_save.argtypes = [C.c_void_p, C.c_char_p]
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_system_trackrgbd_on_host_images(host, oracle, tmp_path):
+    import torch
+    from tests import frontend_ref as R
+    n_frames = 7
+    fx, fy, cx, cy = synth.KITTI_K
+    cfg = tmp_path / "kitti.yaml"
+    cfg.write_text(YAML.format(fx=fx, fy=fy, cx=cx, cy=cy, w=W, h=H, bf=SF.BF, dmf=SF.DEPTH_MAP_FACTOR, thbg=SF.TH_DEPTH_BG, thobj=SF.TH_DEPTH_OBJ))
+    Ts = SQ.camera_poses(n_frames)
+    objs = SQ.default_objects()
+    frames = [SQ.render_frame(k, Ts, objs, flow_sigma=0.1) for k in range(n_frames)]
+
+    def run_system(gt_labels):
+        sys_ = host.host_system_create(str(cfg).encode())
+        assert sys_
+        poses, motions = [], []
+        for k, fr in enumerate(frames):
+            rgb = np.ascontiguousarray(np.repeat(fr["gray"][:, :, None], 3, axis=2))          # 3 equal channels: cvtColor returns the channel
+            depth = fr["depth_raw"].copy(); mask = fr["mask"].copy()
+            rows = np.array([[k, lab, 0, 0, 0, 0, 0, 0, 0, 0] for lab in gt_labels], np.float32).reshape(-1, 10)
+            T = np.zeros(16, np.float32)
+            assert host.host_system_track(sys_, _ptr(rgb), 3, _ptr(depth), _ptr(fr["flow"]), _ptr(mask), W, H, _ptr(rows) if len(rows) else None, len(rows), 10, n_frames, _ptr(T)) == 0
+            if k == 0:                                                                          # the caller's depth map is converted in place (K1)
+                ref = fr["depth_raw"].copy()
+                oracle.vdo_oracle_depth_preprocess(R._fp(ref), ref.size, SF.BF, SF.DEPTH_MAP_FACTOR)
+                assert np.array_equal(depth, ref)
+            sl = np.zeros(16, np.int32); Hm = np.zeros((16, 16), np.float32)
+            nm = host.host_system_motions(sys_, 16, _ptr(sl), _ptr(Hm))
+            poses.append(T.reshape(4, 4).copy()); motions.append(sorted(int(x) for x in sl[:nm]))
+        rf = np.zeros((n_frames, 16), np.float32)
+        assert host.host_system_refined_poses(sys_, n_frames, _ptr(rf)) == n_frames             # FullBatchOptimization ran at the last frame
+        out = tmp_path / "traj.txt"
+        host.host_system_save(sys_, str(out).encode())
+        assert len(out.read_text().splitlines()) == 2 * (n_frames + 1)
+        host.host_system_destroy(sys_)
+        return poses, motions, rf.reshape(-1, 4, 4)
+
+    poses, motions, rf = run_system([1, 2, 3])
+    # the same sequence through FramePipeline with device inputs
+    ctx, ctx_lm, ctx_obj = Context(0), Context(0), Context(0)
+    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1), ctx_obj)
+    for k, fr in enumerate(frames):
+        d = {q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")}
+        torch.cuda.synchronize()
+        pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
+        assert np.array_equal(pipe.pose(), poses[k]), k
+        assert sorted(m["sem_label"] for m in pipe.motions()) == motions[k] or k == 0
+    pipe.close()
+    assert motions[-1] and set(motions[-1]) <= {1, 2, 3}
+    gt_last = np.linalg.inv(frames[-1]["Tcw"])
+    assert np.abs(rf[-1][:3, 3] - gt_last[:3, 3]).max() < 0.05
+    # no ground-truth row for object 2: it is not tracked (src/Tracking.cc:791-841), the others are
+    poses2, motions2, _ = run_system([1, 3])
+    assert all(2 not in m for m in motions2) and any(m for m in motions2)
+    assert all(np.array_equal(a, b) for a, b in zip(poses, poses2))        # the camera pose does not depend on the object gate

@@ -134,8 +134,9 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     fin_async = true;
   }
   // ---- GrabImageRGBD: images, K1, UpdateMask (K15), propagation (K11)            Tracking.cc:180-305
-  VDO_TRY(vdo_frame_images_upload_device(cur, d_depth_raw, d_flow, d_mask));
-  VDO_TRY(vdo_frame_images_depth_preprocess(cur, p_.bf, p_.depth_map_factor));
+  if (host_inputs_) VDO_TRY(vdo_frame_images_upload(cur, d_depth_raw, d_flow, d_mask));
+  else VDO_TRY(vdo_frame_images_upload_device(cur, d_depth_raw, d_flow, d_mask));
+  if (!depth_metric_) VDO_TRY(vdo_frame_images_depth_preprocess(cur, p_.bf, p_.depth_map_factor));
   const int n_s = have_last_ ? (int)sta_.cx.size() : 0;
   std::vector<float>& stat_depth = f_[0]; std::vector<float>& obj_depth = f_[1]; std::vector<int32_t>& obj_sem = i_[0];
   stat_depth.assign(n_s, -1.f);
@@ -197,7 +198,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   // ---- camera pose (K16) on the LM stream, front-end of this frame meanwhile      Tracking.cc:690-700 || Frame.cc:61-260
   if (cam) VDO_TRY(vdo_flow2_batch_run(cam));
   vdo_keypoints kp{(int32_t)kx_.size(), 0, kx_.data(), ky_.data(), kr_.data(), ka_.data(), ks_.data(), ko_.data()};
-  VDO_TRY(vdo_orb_extract(orb_, d_gray, W, 1, &kp));
+  VDO_TRY(vdo_orb_extract(orb_, d_gray, W, host_inputs_ ? 0 : 1, &kp));
   fc.n_orb = kp.n;
   tick(1);
   if (fin_async) {
@@ -362,7 +363,12 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
         for (int a = 0; a < n_objects; ++a) {
           std::vector<int32_t>& sub = obj_subsets_[a];
           for (int q = off[a]; q < off[a + 1]; ++q) if (rin[q]) sub.push_back(idx[q]);
-          if ((int)sub.size() < 50 || a >= kMaxObjects || (int)sub.size() > kObjCap) { obj_stat_[a] = 0; if (a < kMaxObjects) VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr)); continue; }
+          bool gated = true;                                                            // ground truth in both frames (Tracking.cc:791-841)
+          if (gate_on_) {
+            gated = std::find(gate_cur_.begin(), gate_cur_.end(), osem[a]) != gate_cur_.end() && std::find(gate_last_.begin(), gate_last_.end(), osem[a]) != gate_last_.end();
+            if (!gated) { sub.clear(); for (int q = off[a]; q < off[a + 1]; ++q) sub.push_back(idx[q]); }   // vnObjInlierID = ObjIdNew
+          }
+          if (!gated || (int)sub.size() < 50 || a >= kMaxObjects || (int)sub.size() > kObjCap) { obj_stat_[a] = 0; if (a < kMaxObjects) VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr)); continue; }
           ObjBuf& B = obj_buf_[a];
           B.ob.clear(); B.fl.clear(); B.dp.clear();
           for (int id : sub) { B.ob.push_back(obj_.x[id]); B.ob.push_back(obj_.y[id]); B.fl.push_back(obj_.fx[id]); B.fl.push_back(obj_.fy[id]); B.dp.push_back(obj_.d[id]); }
@@ -417,6 +423,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   std::memcpy(Tcw_last_, Tcw, sizeof Tcw);
   std::memcpy(Tcw_out_, Tcw, sizeof Tcw);
   cur_ ^= 1; have_last_ = true; ++f_id_;
+  gate_last_ = gate_cur_;
   if (pending_ && !p_.defer_objects) { if (FinishObjects(&fc) != 0) return -1; }
   if (out) *out = fc;
   return 0;
@@ -528,6 +535,18 @@ int FramePipeline::FinishObjects(FrameCounts* fcp) {
   }
   obj_ = std::move(nobj);
   pending_ = false;
+  return 0;
+}
+
+int FramePipeline::StepHost(const uint8_t* gray, const float* depth, const float* flow, const int32_t* mask, bool depth_is_metric, FrameCounts* out) {
+  host_inputs_ = true; depth_metric_ = depth_is_metric;
+  const int rc = Step(gray, depth, flow, mask, nullptr, nullptr, 0, 0, out);
+  host_inputs_ = false; depth_metric_ = false;
+  return rc;
+}
+
+int FramePipeline::DownloadMask(int32_t* mask_out) {
+  VDO_TRY(vdo_frame_images_download_mask(img_[cur_ ^ 1], mask_out));      // (cur_ was flipped at the end of Step)
   return 0;
 }
 

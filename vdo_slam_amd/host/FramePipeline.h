@@ -55,6 +55,14 @@ class FramePipeline {
   // cam / obj: the frame's pose problems (already resident); their results are fetched like Track() consumes them.
   int Step(const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
            vdo_flow2_batch* cam, vdo_flow2_batch* obj, int n_cam_pts, int n_obj_problems, FrameCounts* out);
+  // The same with HOST pointers (the System::TrackRGBD shell): images are uploaded first; depth_is_metric: K1 was already applied.
+  int StepHost(const uint8_t* gray, const float* depth, const float* flow, const int32_t* mask, bool depth_is_metric, FrameCounts* out);
+  // Objects the caller has ground truth for in the frame about to be given to Step (label = mask id).  The reference only
+  // tracks an object whose label has a ground-truth row in BOTH the last and the current frame (src/Tracking.cc:791-841:
+  // otherwise bObjStat = false and the object keeps its point set untouched).  Without a call every label is allowed.
+  void SetObjectGate(const int* labels, int n) { gate_on_ = true; gate_cur_.assign(labels, labels + n); }
+  // copy of the (possibly UpdateMask-modified) instance mask of the last frame given to Step
+  int DownloadMask(int32_t* mask_out);
   // "Save Graph Structure" of Track() (src/Tracking.cc:1046-1110, Initialization :1238-1246): with a Map attached every frame
   // appends its static / dynamic features, depths, 3-D points, camera pose and rigid motions (+ labels) to it - the input
   // format of Optimizer::Full/PartialBatchOptimization.  FinalizeMap() writes the tracklets (GetStaticTrack /
@@ -76,6 +84,8 @@ class FramePipeline {
   struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; };
   int FinishObjects(FrameCounts* fc);
   int TrackletsToMap();
+  bool host_inputs_ = false, depth_metric_ = false, gate_on_ = false;
+  std::vector<int> gate_cur_, gate_last_;
   Map* map_ = nullptr;
   int f_id_obj_ = 0;                  // frame id of the pending object stage
   float cam_motion_[16];              // Converter::toInvMatrix(mVelocity) of the frame whose object stage is pending

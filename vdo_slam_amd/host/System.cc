@@ -1,0 +1,166 @@
+#include "System.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <sstream>
+
+#include "Optimizer.h"
+
+namespace VDO_SLAM {
+
+namespace {
+// The settings files of the reference are flat "key: value" YAML 1.0 (example/kitti-0000-0013.yaml): that subset is read here
+// (cv::FileStorage is not available on this side).  Returns false when the file cannot be opened.
+bool read_settings(const std::string& path, std::map<std::string, double>& out) {
+  std::ifstream f(path.c_str());
+  if (!f.is_open()) return false;
+  std::string line;
+  while (std::getline(f, line)) {
+    const size_t h = line.find('#');
+    if (h != std::string::npos) line = line.substr(0, h);
+    if (line.empty() || line[0] == '%') continue;
+    const size_t c = line.find(':');
+    if (c == std::string::npos) continue;
+    std::string key = line.substr(0, c), val = line.substr(c + 1);
+    while (!key.empty() && (key.back() == ' ' || key.back() == '\t')) key.pop_back();
+    char* end = nullptr;
+    const double v = std::strtod(val.c_str(), &end);
+    if (end != val.c_str()) out[key] = v;
+  }
+  return true;
+}
+double get(const std::map<std::string, double>& m, const char* k, double dflt = 0) { auto it = m.find(k); return it == m.end() ? dflt : it->second; }
+}  // namespace
+
+Tracking::Tracking(System*, Map* pMap, const std::string& strSettingPath, const int) : mpMap(pMap) {
+  if (!read_settings(strSettingPath, cfg_)) { std::cerr << "Failed to open settings file at: " << strSettingPath << std::endl; std::exit(-1); }
+  mK = cv::Mat::eye(3, 3, cv::CV_32F);
+  mK.at<float>(0, 0) = (float)get(cfg_, "Camera.fx"); mK.at<float>(1, 1) = (float)get(cfg_, "Camera.fy");
+  mK.at<float>(0, 2) = (float)get(cfg_, "Camera.cx"); mK.at<float>(1, 2) = (float)get(cfg_, "Camera.cy");
+  mbf = (float)get(cfg_, "Camera.bf");
+  mbRGB = get(cfg_, "Camera.RGB", 1) != 0;
+  mDepthMapFactor = (float)get(cfg_, "DepthMapFactor", 1);
+  PipelineParams p{};
+  p.width = (int)get(cfg_, "Camera.width"); p.height = (int)get(cfg_, "Camera.height");
+  p.K4[0] = mK.at<float>(0, 0); p.K4[1] = mK.at<float>(1, 1); p.K4[2] = mK.at<float>(0, 2); p.K4[3] = mK.at<float>(1, 2);
+  p.bf = mbf; p.depth_map_factor = mDepthMapFactor;
+  p.th_depth_bg = (float)get(cfg_, "ThDepthBG"); p.th_depth_obj = (float)get(cfg_, "ThDepthOBJ");
+  p.max_track_bg = (int)get(cfg_, "MaxTrackPointBG"); p.max_track_obj = (int)get(cfg_, "MaxTrackPointOBJ");
+  p.sf_mg_thres = (float)get(cfg_, "SFMgThres"); p.sf_ds_thres = (float)get(cfg_, "SFDsThres");
+  p.n_features = (int)get(cfg_, "ORBextractor.nFeatures"); p.n_levels = (int)get(cfg_, "ORBextractor.nLevels");
+  p.ini_th = (int)get(cfg_, "ORBextractor.iniThFAST"); p.min_th = (int)get(cfg_, "ORBextractor.minThFAST");
+  p.scale_factor = (float)get(cfg_, "ORBextractor.scaleFactor");
+  p.build_lm = 1; p.defer_objects = 0;               // TrackRGBD returns with the frame complete, like the reference
+  p.window_size = (int)get(cfg_, "WINDOW_SIZE"); p.overlap_size = (int)get(cfg_, "OVERLAP_SIZE");
+  if (p.width <= 0 || p.height <= 0) { std::cerr << "settings: Camera.width / Camera.height missing" << std::endl; std::exit(-1); }
+  const char* dev = std::getenv("VDO_DEVICE");
+  for (int k = 0; k < 4; ++k)
+    if (vdo_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx_[k]) != VDO_OK) { std::cerr << "no HIP device: " << vdo_last_error() << std::endl; std::exit(-1); }
+  pipe_.reset(new FramePipeline(ctx_[0], ctx_[1], p, ctx_[2], ctx_[3]));
+  if (!pipe_->ok()) { std::cerr << "FramePipeline: " << vdo_last_error() << std::endl; std::exit(-1); }
+  pipe_->AttachMap(mpMap);
+}
+
+Tracking::~Tracking() {
+  pipe_.reset();
+  for (int k = 0; k < 4; ++k) if (ctx_[k]) vdo_ctx_destroy(ctx_[k]);
+}
+
+cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Mat& imFlow, const cv::Mat& maskSEM, const cv::Mat&,
+                                const std::vector<std::vector<float> >& vObjPose_gt, const double&, cv::Mat&, const int& nImage) {
+  StopFrame = nImage - 1;
+  if (!have_frame_) f_id = 0;
+  const int64_t n = (int64_t)imRGB.rows * imRGB.cols;
+  // colour -> grey (cvtColor CV_RGB2GRAY / CV_BGR2GRAY, Tracking.cc:209-222); the caller's image is not touched
+  const uint8_t* gray = imRGB.data;
+  if (imRGB.channels() >= 3) {
+    gray_.resize((size_t)n);
+    if (vdo_rgb2gray(ctx_[0], imRGB.data, n, imRGB.channels(), mbRGB ? 1 : 0, gray_.data()) != VDO_OK) { std::cerr << vdo_last_error() << std::endl; return cv::Mat(); }
+    gray = gray_.data();
+  }
+  // K1 in place on the caller's depth map (Tracking.cc:180-204)
+  if (vdo_depth_preprocess(ctx_[0], (float*)imD.data, n, mbf, mDepthMapFactor, 0) != VDO_OK) { std::cerr << vdo_last_error() << std::endl; return cv::Mat(); }
+  // ground-truth rows gate the object tracker (label = row[1], Tracking.cc:332-336, 791-841)
+  std::vector<int> labels;
+  for (const auto& row : vObjPose_gt) if (row.size() > 1) labels.push_back((int)row[1]);
+  pipe_->SetObjectGate(labels.data(), (int)labels.size());
+  FrameCounts fc{};
+  if (pipe_->StepHost(gray, (const float*)imD.data, (const float*)imFlow.data, (const int32_t*)maskSEM.data, true, &fc) != 0) return cv::Mat();
+  if (fc.n_recovered_masks > 0) pipe_->DownloadMask((int32_t*)maskSEM.data);      // UpdateMask writes through the shared header (Tracking.cc:3049-3068)
+  have_frame_ = true;
+  // full batch optimisation after the last frame (Tracking.cc:1189-1210)
+  if (f_id == StopFrame && f_id > 1) {
+    pipe_->FinalizeMap();
+    Optimizer::FullBatchOptimization(mpMap, mK);
+  }
+  ++f_id;
+  cv::Mat Tcw(4, 4, cv::CV_32F);
+  std::memcpy(Tcw.data, pipe_->Tcw_out_, 64);
+  return Tcw;
+}
+
+System::System(const std::string& strSettingsFile, const eSensor sensor) : mSensor(sensor) {
+  std::ifstream f(strSettingsFile.c_str());
+  if (!f.is_open()) { std::cerr << "Failed to open settings file at: " << strSettingsFile << std::endl; std::exit(-1); }
+  mpMap = new Map();
+  mpTracker = new Tracking(this, mpMap, strSettingsFile, mSensor);
+}
+
+System::~System() { delete mpTracker; delete mpMap; }
+
+cv::Mat System::TrackRGBD(const cv::Mat& im, cv::Mat& depthmap, const cv::Mat& flowmap, const cv::Mat& masksem, const cv::Mat& mTcw_gt,
+                          const std::vector<std::vector<float> >& vObjPose_gt, const double& timestamp, cv::Mat& imTraj, const int& nImage) {
+  if (mSensor != RGBD) { std::cerr << "ERROR: you called TrackRGBD but input sensor was not set to RGBD." << std::endl; std::exit(-1); }
+  return mpTracker->GrabImageRGBD(im, depthmap, flowmap, masksem, mTcw_gt, vObjPose_gt, timestamp, imTraj, nImage);
+}
+
+void System::SaveResults(const std::string& filename) {
+  std::ofstream o(filename.c_str());
+  o.precision(9);
+  for (int rf = 0; rf < 2; ++rf) {
+    const std::vector<cv::Mat>& P = rf ? mpMap->vmCameraPose_RF : mpMap->vmCameraPose;
+    o << (rf ? "# camera poses T_wc after the batch optimisation" : "# camera poses T_wc") << "\n";
+    for (size_t i = 0; i < P.size(); ++i) {
+      o << i;
+      for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) o << ' ' << P[i].at<float>(r, c);
+      o << "\n";
+    }
+  }
+}
+
+}  // namespace VDO_SLAM
+
+// ---- flat hooks (tests / Python) ----------------------------------------------------------------------------------------
+extern "C" {
+VDO_SLAM::System* host_system_create(const char* settings) { return new VDO_SLAM::System(settings, VDO_SLAM::System::RGBD); }
+void host_system_destroy(VDO_SLAM::System* s) { delete s; }
+// one TrackRGBD call on host images: im (h x w x channels u8), depth (in/out f32), flow (f32 x2), mask (in/out i32), ground-truth
+// object rows [n_rows][row_len]; Tcw_out 16 floats.  Returns 0, or -1 when the tracker returned an empty pose.
+int host_system_track(VDO_SLAM::System* s, const unsigned char* im, int channels, float* depth, const float* flow, int* mask, int w, int h,
+                      const float* obj_rows, int n_rows, int row_len, int n_images, float* Tcw_out) {
+  cv::Mat I(h, w, VDO_CV_MAKETYPE(cv::CV_8U, channels), (void*)im), D(h, w, cv::CV_32FC1, depth), Fl(h, w, cv::CV_32FC2, (void*)flow), M(h, w, cv::CV_32SC1, mask);
+  cv::Mat gt = cv::Mat::eye(4, 4, cv::CV_32F), traj;
+  std::vector<std::vector<float> > rows(n_rows);
+  for (int i = 0; i < n_rows; ++i) rows[i].assign(obj_rows + (size_t)i * row_len, obj_rows + (size_t)(i + 1) * row_len);
+  cv::Mat T = s->TrackRGBD(I, D, Fl, M, gt, rows, 0.0, traj, n_images);
+  if (T.empty()) return -1;
+  std::memcpy(Tcw_out, T.data, 64);
+  return 0;
+}
+int host_system_motions(VDO_SLAM::System* s, int cap, int* sem_label, float* H16) {
+  const auto& m = s->tracker()->pipeline()->motions_;
+  const int n = std::min(cap, (int)m.size());
+  for (int a = 0; a < n; ++a) { sem_label[a] = m[a].sem_label; std::memcpy(H16 + 16 * a, m[a].H, 64); }
+  return (int)m.size();
+}
+int host_system_refined_poses(VDO_SLAM::System* s, int cap, float* Twc16) {
+  const auto& P = s->map()->vmCameraPose_RF;
+  const int n = std::min(cap, (int)P.size());
+  for (int i = 0; i < n; ++i) std::memcpy(Twc16 + 16 * i, P[i].data, 64);
+  return (int)P.size();
+}
+void host_system_save(VDO_SLAM::System* s, const char* path) { s->SaveResults(path); }
+}
