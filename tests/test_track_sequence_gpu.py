@@ -88,10 +88,11 @@ def test_deferred_object_stage_gives_the_same_sequence():
     dev = [{q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for fr in frames]
     torch.cuda.synchronize()
 
-    def run(defer, worker=False):
+    def run(defer, worker=False, orb_thread=False):
         ctx, ctx_lm, ctx_obj = Context(0), Context(0), Context(0)
         ctx_w = Context(0) if worker else None          # + a helper host thread with its own context (FramePipeline.h)
-        pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj, ctx_w)
+        ctx_o = Context(0) if orb_thread else None      # + ORB on a thread and stream of its own
+        pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj, ctx_w, ctx_o)
         poses, counts, motions = [], [], []
         for k, d in enumerate(dev):
             c = pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
@@ -109,9 +110,9 @@ def test_deferred_object_stage_gives_the_same_sequence():
         return poses, counts, motions
 
     p0, c0, m0 = run(0)
-    for defer, worker in ((1, False), (1, True), (0, True)):
-        p1, c1, m1 = run(defer, worker)
-        assert c0[1:] == c1[1:], (defer, worker, [(a, b) for a, b in zip(c0, c1) if a != b][:2])
+    for defer, worker, orb_thread in ((1, False, False), (1, True, False), (0, True, False), (1, True, True), (0, False, True)):
+        p1, c1, m1 = run(defer, worker, orb_thread)
+        assert c0[1:] == c1[1:], (defer, worker, orb_thread, [(a, b) for a, b in zip(c0, c1) if a != b][:2])
         for a, b in zip(p0, p1):
             assert np.array_equal(a, b)
         # synchronous mode reports the motions of frame k after Step(k); deferred mode after Step(k+1) / flush

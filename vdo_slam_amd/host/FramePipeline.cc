@@ -86,10 +86,10 @@ static void fill_flow2(vdo_flow2_problem& p, int n, const double* obs, const dou
 
 #define VDO_TRY(call) do { if ((call) != VDO_OK) { std::fprintf(stderr, "FramePipeline: %s\n", vdo_last_error()); return -1; } } while (0)
 
-FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p, vdo_ctx* ctx_obj, vdo_ctx* ctx_worker)
+FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p, vdo_ctx* ctx_obj, vdo_ctx* ctx_worker, vdo_ctx* ctx_orb)
     : ctx_(ctx), ctx_lm_(ctx_lm), ctx_obj_(ctx_obj ? ctx_obj : ctx_lm), ctx_w_(ctx_worker ? ctx_worker : ctx), p_(p) {
   vdo_orb_params op{p.n_features, p.scale_factor, p.n_levels, p.ini_th, p.min_th};
-  if (vdo_orb_create(ctx, &op, p.width, p.height, &orb_) != VDO_OK) return;
+  if (vdo_orb_create(ctx_orb ? ctx_orb : ctx, &op, p.width, p.height, &orb_) != VDO_OK) return;
   for (int k = 0; k < 2; ++k) if (vdo_frame_images_create(ctx, p.width, p.height, &img_[k]) != VDO_OK) return;
   if (vdo_tracks_create(0, &tr_sta_) != VDO_OK || vdo_tracks_create(1, &tr_dyn_) != VDO_OK) return;
   const int capk = p.n_features + 256;
@@ -103,11 +103,13 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
     if (vdo_flow2_batch_reserve(ctx_obj_, kMaxObjects, ocap, &lm_obj_) != VDO_OK) return;
   }
   if (ctx_worker) worker_.reset(new Worker());
+  if (ctx_orb) orb_worker_.reset(new Worker());
   ok_ = true;
 }
 
 FramePipeline::~FramePipeline() {
   if (worker_) { worker_->wait(); worker_.reset(); }
+  if (orb_worker_) { orb_worker_->wait(); orb_worker_.reset(); }
   if (orb_) vdo_orb_destroy(orb_);
   for (int k = 0; k < 2; ++k) if (img_[k]) vdo_frame_images_destroy(img_[k]);
   if (tr_sta_) vdo_tracks_destroy(tr_sta_);
@@ -124,7 +126,18 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   auto tick = [&](int slot) { const auto t = std::chrono::steady_clock::now(); ms_[slot] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
   vdo_frame_images *cur = img_[cur_], *last = img_[cur_ ^ 1];
   const int W = p_.width, H = p_.height;
-  struct Join { Worker* w; ~Join() { if (w) w->wait(); } } join_guard{worker_.get()};      // never leave Step with the helper thread on its locals
+  struct Join { Worker* w; ~Join() { if (w) w->wait(); } } join_guard{worker_.get()}, join_guard_orb{orb_worker_.get()};   // never leave Step with a helper thread on its locals
+  // ---- ORB (K3-K7) needs only the grey image: on its own thread + stream from the start, if there is one
+  vdo_keypoints kp{(int32_t)kx_.size(), 0, kx_.data(), ky_.data(), kr_.data(), ka_.data(), ks_.data(), ko_.data()};
+  const bool gray_on_host = host_inputs_;
+  auto stage_orb = [&]() -> int {
+    const auto t0 = std::chrono::steady_clock::now();
+    VDO_TRY(vdo_orb_extract(orb_, d_gray, W, gray_on_host ? 0 : 1, &kp));
+    ms_[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
+  };
+  const bool orb_async = (bool)orb_worker_;
+  if (orb_async) orb_worker_->run(stage_orb);
   // ---- deferred mode: the object stage of the PREVIOUS frame ends during this frame's camera stage + ORB front-end (nothing
   // there depends on the object set) - on the helper thread if there is one, else right after ORB on this thread
   bool fin_async = false;
@@ -197,10 +210,8 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   tick(0);
   // ---- camera pose (K16) on the LM stream, front-end of this frame meanwhile      Tracking.cc:690-700 || Frame.cc:61-260
   if (cam) VDO_TRY(vdo_flow2_batch_run(cam));
-  vdo_keypoints kp{(int32_t)kx_.size(), 0, kx_.data(), ky_.data(), kr_.data(), ka_.data(), ks_.data(), ko_.data()};
-  VDO_TRY(vdo_orb_extract(orb_, d_gray, W, host_inputs_ ? 0 : 1, &kp));
-  fc.n_orb = kp.n;
-  tick(1);
+  if (!orb_async) { if (stage_orb() != 0) return -1; fc.n_orb = kp.n; }
+  t_prev = std::chrono::steady_clock::now();
   if (fin_async) {
     const int rc = worker_->wait();
     vdo_frame_images_set_ctx(last, ctx_);
@@ -293,6 +304,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     tk(5);
     return 0;
   };
+  if (orb_async) { if (orb_worker_->wait() != 0) return -1; fc.n_orb = kp.n; t_prev = std::chrono::steady_clock::now(); }
   bool static_async = false;
   if (have_last_ && worker_) {
     vdo_frame_images_set_ctx(cur, ctx_w_);
@@ -581,8 +593,8 @@ using VDO_SLAM::FrameCounts;
 using VDO_SLAM::PipelineParams;
 
 extern "C" {
-FramePipeline* host_pipeline_create(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams* p, vdo_ctx* ctx_obj, vdo_ctx* ctx_worker) {
-  FramePipeline* fp = new FramePipeline(ctx, ctx_lm, *p, ctx_obj, ctx_worker);
+FramePipeline* host_pipeline_create(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams* p, vdo_ctx* ctx_obj, vdo_ctx* ctx_worker, vdo_ctx* ctx_orb) {
+  FramePipeline* fp = new FramePipeline(ctx, ctx_lm, *p, ctx_obj, ctx_worker, ctx_orb);
   if (!fp->ok()) { delete fp; return nullptr; }
   return fp;
 }

@@ -32,17 +32,17 @@ def kitti_params(width, height, K4, bf, depth_map_factor, th_bg, th_obj, build_l
 
 
 class FramePipeline:
-    def __init__(self, ctx, ctx_lm, params: PipelineParams, ctx_obj=None, ctx_worker=None):
+    def __init__(self, ctx, ctx_lm, params: PipelineParams, ctx_obj=None, ctx_worker=None, ctx_orb=None):
         L = self._L = K.load_host_lib()
         L.host_pipeline_create.restype = C.c_void_p
-        L.host_pipeline_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PipelineParams), C.c_void_p, C.c_void_p]
+        L.host_pipeline_create.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(PipelineParams), C.c_void_p, C.c_void_p, C.c_void_p]
         L.host_pipeline_flush.argtypes = [C.c_void_p, C.POINTER(FrameCounts)]
         L.host_pipeline_step.argtypes = [C.c_void_p] * 7 + [C.c_int, C.c_int, C.POINTER(FrameCounts)]
         L.host_pipeline_destroy.argtypes = [C.c_void_p]
         L.host_pipeline_timing.argtypes = [C.c_void_p, C.POINTER(C.c_double)]
-        self._keep = (ctx, ctx_lm, ctx_obj, ctx_worker)
+        self._keep = (ctx, ctx_lm, ctx_obj, ctx_worker, ctx_orb)
         self._h = L.host_pipeline_create(ctx._h, ctx_lm._h, C.byref(params), ctx_obj._h if ctx_obj is not None else None,
-                                         ctx_worker._h if ctx_worker is not None else None)
+                                         ctx_worker._h if ctx_worker is not None else None, ctx_orb._h if ctx_orb is not None else None)
         if not self._h:
             raise K.VdoError("FramePipeline could not be created")
         self.counts = FrameCounts()
