@@ -84,3 +84,18 @@ def test_flow2_cluster_sizes_match_the_oracle(ctx, oracle, quirks):
         T, flow, inl, ninl, st = run_oracle(oracle, p)
         _check(r, T, flow, inl, ninl, st)
     b.close()
+
+
+def test_flow2_large_batch_never_oversubscribes_the_clusters(ctx, oracle):
+    """160 problems x 3 workgroups would be 480 cluster workgroups - more than can be guaranteed resident at once, and cluster
+    members wait for each other: the launch lowers the cluster size instead.  Results are those of the oracle either way."""
+    from vdo_slam_amd.flow2 import Flow2Batch
+    probs = [synth.make_flow2_problem(600 + (k % 7) * 20, seed=300 + k, is_object=bool(k & 1)) for k in range(160)]
+    b = Flow2Batch(ctx, probs)
+    b.run()
+    res = b.fetch()
+    for k in (0, 1, 79, 158, 159):
+        T, flow, inl, ninl, st = run_oracle(oracle, probs[k])
+        _check(res[k], T, flow, inl, ninl, st)
+    assert all(r["iterations"] >= 1 for r in res)
+    b.close()
