@@ -143,7 +143,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   bool fin_async = false;
   if (pending_ && worker_) {
     vdo_frame_images_set_ctx(img_obj_, ctx_w_);
-    worker_->run([this, &fc] { return FinishObjects(&fc); });
+    worker_->run([this, &fc] { return FinishObjects(&fc, true); });
     fin_async = true;
   }
   // ---- GrabImageRGBD: images, K1, UpdateMask (K15), propagation (K11)            Tracking.cc:180-305
@@ -212,24 +212,6 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   if (cam) VDO_TRY(vdo_flow2_batch_run(cam));
   if (!orb_async) { if (stage_orb() != 0) return -1; fc.n_orb = kp.n; }
   t_prev = std::chrono::steady_clock::now();
-  if (fin_async) {
-    const int rc = worker_->wait();
-    vdo_frame_images_set_ctx(last, ctx_);
-    if (rc != 0) return -1;
-  } else if (pending_) {
-    if (FinishObjects(&fc) != 0) return -1;
-  }
-  t_prev = std::chrono::steady_clock::now();
-  // ---- UpdateMask (K15) + object part of the propagation (K11): they need the object set of the last frame
-  const int n_o = have_last_ ? (int)obj_.cx.size() : 0;
-  obj_depth.assign(n_o, 0.f); obj_sem.assign(n_o, 0);
-  if (have_last_) {
-    int rec = 0;
-    VDO_TRY(vdo_update_mask(cur, last, n_o, obj_.sem.data(), obj_.cx.data(), obj_.cy.data(), &rec));
-    fc.n_recovered_masks = rec;
-    VDO_TRY(vdo_propagate_object(cur, n_o, obj_.cx.data(), obj_.cy.data(), p_.th_depth_obj, obj_depth.data(), obj_sem.data()));
-  }
-  tick(10);
   // K9 + K10 of the new image: only RenewFrameInfo needs them, so they run while the object LMs are in flight
   int n_new_s = 0, n_tmp = 0;
   std::vector<int32_t>& keep = i_[1];
@@ -277,6 +259,27 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     }
   }
   tick(3);
+  // ---- the object set of the last frame: wait for its object stage (its tail - tracklets, Map - goes on behind)
+  bool tail_async = false;
+  if (fin_async) {
+    const int rc = worker_->wait();
+    vdo_frame_images_set_ctx(last, ctx_);
+    if (rc != 0) return -1;
+    if (tail_pending_) { worker_->run([this, &fc] { return FinishObjectsTail(&fc); }); tail_async = true; }
+  } else if (pending_) {
+    if (FinishObjects(&fc) != 0) return -1;
+  }
+  t_prev = std::chrono::steady_clock::now();
+  // ---- UpdateMask (K15) + object part of the propagation (K11): they need the object set of the last frame
+  const int n_o = have_last_ ? (int)obj_.cx.size() : 0;
+  obj_depth.assign(n_o, 0.f); obj_sem.assign(n_o, 0);
+  if (have_last_) {
+    int rec = 0;
+    VDO_TRY(vdo_update_mask(cur, last, n_o, obj_.sem.data(), obj_.cx.data(), obj_.cy.data(), &rec));
+    fc.n_recovered_masks = rec;
+    VDO_TRY(vdo_propagate_object(cur, n_o, obj_.cx.data(), obj_.cy.data(), p_.th_depth_obj, obj_depth.data(), obj_sem.data()));
+  }
+  tick(10);
   StaSet nsta; ObjSet nobj;
   std::vector<int32_t> sta_asso, dyn_asso;
   // ---- K9 + K10 of the new image, RenewFrameInfo (static) (K14, K12), static tracklets: independent of the object chain
@@ -305,6 +308,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     return 0;
   };
   if (orb_async) { if (orb_worker_->wait() != 0) return -1; fc.n_orb = kp.n; t_prev = std::chrono::steady_clock::now(); }
+  if (tail_async && worker_->wait() != 0) return -1;
   bool static_async = false;
   if (have_last_ && worker_) {
     vdo_frame_images_set_ctx(cur, ctx_w_);
@@ -444,7 +448,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
 
 // The object stage of a frame: consume the object LMs (K17), RenewFrameInfo of the objects (K14, K12), dynamic tracklets.
 // fc: the object-related counts of THAT frame (n_object_tracked, n_dynamic_tracks) are written into it.
-int FramePipeline::FinishObjects(FrameCounts* fcp) {
+int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
   if (!pending_) return 0;
   FrameCounts dummy{};
   FrameCounts& fc = fcp ? *fcp : dummy;
@@ -518,21 +522,35 @@ int FramePipeline::FinishObjects(FrameCounts* fcp) {
     nobj.xyz.resize(3 * (size_t)std::max(mo, 1));
     VDO_TRY(vdo_get3d_world(ctx_w_, mo, nobj.x.data(), nobj.y.data(), nobj.d.data(), p_.K4, Twc, nobj.xyz.data()));     // mvObj3DPoint
     tick(7);
-    // ---- tracklets (incremental GetStaticTrack / GetDynamicTrackNew)               Tracking.cc:2201-2421
-    VDO_TRY(vdo_tracks_add_frame(tr_dyn_, mo, dyn_asso.data(), nobj.label.data()));
     last_sem_pos_.assign(osem.begin(), osem.begin() + n_objects);
     last_mod_label_.assign(omod.begin(), omod.begin() + n_objects);
     last_obj_stat_.assign(stat.begin(), stat.begin() + n_objects);
   }
-  tick(8);
   fc.n_object_tracked = (int)nobj.x.size();
+  obj_ = std::move(nobj);                                // from here on the next frame's object chain (K15, K11, K13 ...) can start
+  dyn_asso_tail_ = std::move(dyn_asso);
+  tail_has_lm_ = obj && obj == lm_obj_;
+  pending_ = false; tail_pending_ = true;
+  return defer_tail ? 0 : FinishObjectsTail(&fc);
+}
+
+int FramePipeline::FinishObjectsTail(FrameCounts* fcp) {
+  if (!tail_pending_) return 0;
+  FrameCounts dummy{};
+  FrameCounts& fc = fcp ? *fcp : dummy;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto tick = [&](int slot) { const auto t = std::chrono::steady_clock::now(); ms_[slot] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
+  const ObjSet& nobj = obj_;
+  // ---- tracklets (incremental GetDynamicTrackNew)                                  Tracking.cc:2309-2421
+  VDO_TRY(vdo_tracks_add_frame(tr_dyn_, (int)nobj.x.size(), dyn_asso_tail_.data(), nobj.label.data()));
+  tick(8);
   int64_t np = 0;
   vdo_tracks_size(tr_dyn_, &fc.n_dynamic_tracks, &np);
   if (map_) {                                            // "Save Graph Structure" (2), (6): object features, rigid motions + labels
     push_features(map_->vpFeatDyn, map_->vfDepDyn, map_->vp3DPointDyn, nobj.x, nobj.y, nobj.d, nobj.xyz);
     std::vector<cv::Mat> mots; std::vector<int> labs;
     mots.push_back(mat44f(cam_motion_)); labs.push_back(0);
-    if (obj && obj == lm_obj_)
+    if (tail_has_lm_)
       for (const ObjectMotion& om : motions_) { mots.push_back(mat44f(om.H)); labs.push_back(om.mod_label); }
     map_->vmRigidMotion.push_back(mots); map_->vmRigidMotion_RF.push_back(mots); map_->vnRMLabel.push_back(labs);
     // ---- partial batch optimisation on the last window (local optimisation)      Tracking.cc:1165-1183
@@ -545,8 +563,7 @@ int FramePipeline::FinishObjects(FrameCounts* fcp) {
       ++n_partial_batches_;
     }
   }
-  obj_ = std::move(nobj);
-  pending_ = false;
+  tail_pending_ = false;
   return 0;
 }
 

@@ -84,7 +84,10 @@ class FramePipeline {
  private:
   struct ObjSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; std::vector<int32_t> sem, label; };
   struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; };
-  int FinishObjects(FrameCounts* fc);
+  int FinishObjects(FrameCounts* fc, bool defer_tail = false);
+  int FinishObjectsTail(FrameCounts* fc);   // dynamic tracklets, Map, windowed optimisation: nothing the next frame's object chain waits for
+  bool tail_pending_ = false, tail_has_lm_ = false;
+  std::vector<int32_t> dyn_asso_tail_;
   int TrackletsToMap();
   bool host_inputs_ = false, depth_metric_ = false, gate_on_ = false;
   std::vector<int> gate_cur_, gate_last_;
