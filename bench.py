@@ -180,9 +180,10 @@ def main():
         os.environ["VDO_ORB_THREADS"] = "0"
     use_worker = not os.environ.get("VDO_BENCH_NO_WORKER") and cpus_per_rank >= 5
     ctx_w = Context(local) if use_worker else None      # helper host thread of FramePipeline, own stream + arena
-    # ORB on a thread + stream of its own (FramePipeline supports it, results identical): measured 764 vs 792 frames/s - the ORB call
-    # itself gets slower (0.44 -> 0.64 ms) next to two other host threads driving the same device; off unless asked for
-    ctx_orb = Context(local) if (use_worker and os.environ.get("VDO_BENCH_ORB_THREAD")) else None
+    # ORB on a stream of its own (device stage queued at the start of the frame, under the camera stage): supported, results identical,
+    # but measured neutral (843 vs 824 frames/s, inside the run-to-run spread): the camera stage's small kernels then share the GPU
+    # with ORB's - off unless asked for
+    ctx_orb = Context(local) if os.environ.get("VDO_BENCH_ORB_STREAM") else None
     pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj, ctx_w, ctx_orb)
     torch.cuda.synchronize()
     counts = pipe.counts
@@ -241,9 +242,9 @@ def main():
                                "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets; "
                                f"geometrically consistent synthetic sequence of {n_seq} frames: {N_OBJECTS} moving objects, flow noise sigma {FLOW_SIGMA} px, "
                                f"{INVALID_DEPTH:.0%} invalid depth, {ZERO_FLOW:.0%} zero flow, one instance mask missing in frames {sorted(DROP_MASKS)}",
-                   "parallelism": f"replicas x{world}; 3 HIP streams per replica: camera LM (2) || ORB front-end (1); object LMs (3) || RenewFrameInfo (1) and - "
+                   "parallelism": f"replicas x{world}; {4 + (ctx_orb is not None)} HIP streams per replica: camera LM (2) || ORB front-end ({5 if ctx_orb is not None else 1}); object LMs (3) || RenewFrameInfo (1) and - "
                                   f"defer_objects={defer} - the next frame's camera stage; every LM problem runs on a cluster of up to 8 workgroups; "
-                                  f"{cpus_per_rank:.1f} CPUs per replica, host threads per replica: 1 + {(ctx_w is not None) + (ctx_orb is not None)} helpers (ORB on its own thread: {ctx_orb is not None}; object stage of the previous frame || camera stage + ORB; K9/K10/RenewFrameInfo static || object chain) + 3 ORB quadtree helpers",
+                                  f"{cpus_per_rank:.1f} CPUs per replica, host threads per replica: 1 + {int(ctx_w is not None)} helper (object stage of the previous frame || camera stage + ORB; K9/K10/RenewFrameInfo static || object chain) + 3 ORB quadtree helpers",
                    "orb_keypoints": counts.n_orb, "new_static_candidates": counts.n_static_new, "object_samples": counts.n_object_samples,
                    "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
                    "per_frame_mean": {q: round(v / n_all, 2) for q, v in agg.items()},

@@ -287,6 +287,10 @@ int vdo_orb_create(vdo_ctx* ctx, const vdo_orb_params* prm, int width, int heigh
 int vdo_orb_destroy(vdo_orb* orb);
 /* gray: 8-bit single channel, row stride `stride` bytes; host pointer unless src_is_device. */
 int vdo_orb_extract(vdo_orb* orb, const uint8_t* gray, int stride, int src_is_device, vdo_keypoints* out);
+/* The same in two halves: _begin queues the device stage (K3, K4, K6, K7 + the copy of the candidates) on the extractor's stream
+ * and returns at once, _end waits for it and runs the quadtrees (K5) - a caller overlaps other work with the device stage. */
+int vdo_orb_extract_begin(vdo_orb* orb, const uint8_t* gray, int stride, int src_is_device);
+int vdo_orb_extract_end(vdo_orb* orb, vdo_keypoints* out);
 /* Inspection of the last extraction (mvImagePyramid is a public member of the reference class). */
 int vdo_orb_level_info(vdo_orb* orb, int level, int* w, int* h, int* n_features, int* n_candidates);
 int vdo_orb_get_pyramid(vdo_orb* orb, int level, uint8_t* out_bordered /* (w+38)*(h+38) */);

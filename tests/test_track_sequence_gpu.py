@@ -91,7 +91,7 @@ def test_deferred_object_stage_gives_the_same_sequence():
     def run(defer, worker=False, orb_thread=False):
         ctx, ctx_lm, ctx_obj = Context(0), Context(0), Context(0)
         ctx_w = Context(0) if worker else None          # + a helper host thread with its own context (FramePipeline.h)
-        ctx_o = Context(0) if orb_thread else None      # + ORB on a thread and stream of its own
+        ctx_o = Context(0) if orb_thread else None      # + ORB on a stream of its own (device stage queued at the start of the frame)
         pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj, ctx_w, ctx_o)
         poses, counts, motions = [], [], []
         for k, d in enumerate(dev):

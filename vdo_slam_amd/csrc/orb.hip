@@ -516,6 +516,8 @@ struct vdo_orb {
   std::vector<int> sel[16];
   std::unique_ptr<LevelPool> pool;                    // helpers for the per-level quadtrees (VDO_ORB_THREADS, default 3)
   double ms_device = 0, ms_tree = 0;                  // last extraction: launch..sync, host quadtree
+  bool begun = false;                                 // between vdo_orb_extract_begin and _end
+  std::chrono::steady_clock::time_point t_begin;
 };
 
 extern "C" int vdo_orb_destroy(vdo_orb* o) {
@@ -665,8 +667,10 @@ static int orb_device_stage(vdo_orb* o, const uint8_t* gray_dev, int stride) {
   return VDO_OK;
 }
 
-extern "C" int vdo_orb_extract(vdo_orb* o, const uint8_t* gray, int stride, int src_is_device, vdo_keypoints* out) {
-  if (!o || !gray || !out) return set_error(VDO_ERR_INVALID, "vdo_orb_extract: null argument");
+// operator() in two halves: _begin queues the device stage (pyramid, FAST cells, compaction + angles, blur) and the copy of the
+// candidates on the extractor's stream and returns; _end waits for them and runs the quadtrees (K5).  vdo_orb_extract = both.
+extern "C" int vdo_orb_extract_begin(vdo_orb* o, const uint8_t* gray, int stride, int src_is_device) {
+  if (!o || !gray) return set_error(VDO_ERR_INVALID, "vdo_orb_extract_begin: null argument");
   int rc = ctx_bind(o->ctx);
   if (rc != VDO_OK) return rc;
   hipStream_t s = o->ctx->stream;
@@ -676,14 +680,34 @@ extern "C" int vdo_orb_extract(vdo_orb* o, const uint8_t* gray, int stride, int 
     hipMemcpy2DAsync(o->d_src, o->w, gray, stride, o->w, o->h, hipMemcpyHostToDevice, s);
     src = o->d_src; sstride = o->w;
   }
-  const auto t_begin = std::chrono::steady_clock::now();
+  o->t_begin = std::chrono::steady_clock::now();
   orb_device_stage(o, src, sstride);
-  // candidates -> host: header (level counts + total) and the first kSpecCand columns of the 5 candidate rows, one sync
+  // candidates -> host: header (level counts + total) and the first kSpecCand columns of the 5 candidate rows
   int* hdr = (int*)o->h_pin;
   float* rows = o->h_pin + 32;
   const int spec = std::min(kSpecCand, o->dense_cap);
   hipMemcpyAsync(hdr, o->d_level_cnt, 4 * 32, hipMemcpyDeviceToHost, s);
   hipMemcpy2DAsync(rows, 4 * (size_t)spec, o->d_x, 4 * (size_t)o->dense_cap, 4 * (size_t)spec, 5, hipMemcpyDeviceToHost, s);
+  o->begun = true;
+  return VDO_OK;
+}
+
+extern "C" int vdo_orb_extract(vdo_orb* o, const uint8_t* gray, int stride, int src_is_device, vdo_keypoints* out) {
+  int rc = vdo_orb_extract_begin(o, gray, stride, src_is_device);
+  return rc != VDO_OK ? rc : vdo_orb_extract_end(o, out);
+}
+
+extern "C" int vdo_orb_extract_end(vdo_orb* o, vdo_keypoints* out) {
+  if (!o || !out) return set_error(VDO_ERR_INVALID, "vdo_orb_extract_end: null argument");
+  if (!o->begun) return set_error(VDO_ERR_INVALID, "vdo_orb_extract_end without vdo_orb_extract_begin");
+  o->begun = false;
+  int rc = ctx_bind(o->ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = o->ctx->stream;
+  const auto t_begin = o->t_begin;
+  int* hdr = (int*)o->h_pin;
+  float* rows = o->h_pin + 32;
+  const int spec = std::min(kSpecCand, o->dense_cap);
   if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "orb device stage failed: %s", hipGetErrorString(hipGetLastError()));
   const int total = hdr[16];
   o->n_cand = total;

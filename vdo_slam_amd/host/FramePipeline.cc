@@ -103,13 +103,12 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
     if (vdo_flow2_batch_reserve(ctx_obj_, kMaxObjects, ocap, &lm_obj_) != VDO_OK) return;
   }
   if (ctx_worker) worker_.reset(new Worker());
-  if (ctx_orb) orb_worker_.reset(new Worker());
+  orb_split_ = ctx_orb != nullptr;
   ok_ = true;
 }
 
 FramePipeline::~FramePipeline() {
   if (worker_) { worker_->wait(); worker_.reset(); }
-  if (orb_worker_) { orb_worker_->wait(); orb_worker_.reset(); }
   if (orb_) vdo_orb_destroy(orb_);
   for (int k = 0; k < 2; ++k) if (img_[k]) vdo_frame_images_destroy(img_[k]);
   if (tr_sta_) vdo_tracks_destroy(tr_sta_);
@@ -126,18 +125,10 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   auto tick = [&](int slot) { const auto t = std::chrono::steady_clock::now(); ms_[slot] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
   vdo_frame_images *cur = img_[cur_], *last = img_[cur_ ^ 1];
   const int W = p_.width, H = p_.height;
-  struct Join { Worker* w; ~Join() { if (w) w->wait(); } } join_guard{worker_.get()}, join_guard_orb{orb_worker_.get()};   // never leave Step with a helper thread on its locals
-  // ---- ORB (K3-K7) needs only the grey image: on its own thread + stream from the start, if there is one
+  struct Join { Worker* w; ~Join() { if (w) w->wait(); } } join_guard{worker_.get()};      // never leave Step with the helper thread on its locals
+  // ---- ORB (K3-K7) needs only the grey image: with a stream of its own its device stage starts now, under the camera stage
   vdo_keypoints kp{(int32_t)kx_.size(), 0, kx_.data(), ky_.data(), kr_.data(), ka_.data(), ks_.data(), ko_.data()};
-  const bool gray_on_host = host_inputs_;
-  auto stage_orb = [&]() -> int {
-    const auto t0 = std::chrono::steady_clock::now();
-    VDO_TRY(vdo_orb_extract(orb_, d_gray, W, gray_on_host ? 0 : 1, &kp));
-    ms_[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    return 0;
-  };
-  const bool orb_async = (bool)orb_worker_;
-  if (orb_async) orb_worker_->run(stage_orb);
+  if (orb_split_) VDO_TRY(vdo_orb_extract_begin(orb_, d_gray, W, host_inputs_ ? 0 : 1));
   // ---- deferred mode: the object stage of the PREVIOUS frame ends during this frame's camera stage + ORB front-end (nothing
   // there depends on the object set) - on the helper thread if there is one, else right after ORB on this thread
   bool fin_async = false;
@@ -210,8 +201,10 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   tick(0);
   // ---- camera pose (K16) on the LM stream, front-end of this frame meanwhile      Tracking.cc:690-700 || Frame.cc:61-260
   if (cam) VDO_TRY(vdo_flow2_batch_run(cam));
-  if (!orb_async) { if (stage_orb() != 0) return -1; fc.n_orb = kp.n; }
-  t_prev = std::chrono::steady_clock::now();
+  if (orb_split_) VDO_TRY(vdo_orb_extract_end(orb_, &kp));
+  else VDO_TRY(vdo_orb_extract(orb_, d_gray, W, host_inputs_ ? 0 : 1, &kp));
+  fc.n_orb = kp.n;
+  tick(1);
   // K9 + K10 of the new image: only RenewFrameInfo needs them, so they run while the object LMs are in flight
   int n_new_s = 0, n_tmp = 0;
   std::vector<int32_t>& keep = i_[1];
@@ -307,7 +300,6 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     tk(5);
     return 0;
   };
-  if (orb_async) { if (orb_worker_->wait() != 0) return -1; fc.n_orb = kp.n; t_prev = std::chrono::steady_clock::now(); }
   if (tail_async && worker_->wait() != 0) return -1;
   bool static_async = false;
   if (have_last_ && worker_) {

@@ -49,8 +49,8 @@ class FramePipeline {
   // ctx_worker (optional): a second HOST thread runs the stages that are independent of what the main thread is doing - the object
   // stage of the previous frame (deferred mode) next to this frame's camera stage + ORB, and K9/K10 + RenewFrameInfo (static) next
   // to the scene-flow / object-tracking / object-RANSAC chain - with this context (its own stream and scratch arena).
-  // ctx_orb (optional): ORB (device part + quadtrees) runs on a third host thread with this context from the start of Step() - it
-  // needs nothing but the grey image, and its keypoints are first consumed by K9 / RenewFrameInfo (static).
+  // ctx_orb (optional): the ORB extractor gets this context (a stream of its own): its device stage is queued at the very start
+  // of Step() (vdo_orb_extract_begin) and runs under the camera stage; the quadtrees follow where ORB used to be (vdo_orb_extract_end).
   FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p, vdo_ctx* ctx_obj = nullptr, vdo_ctx* ctx_worker = nullptr, vdo_ctx* ctx_orb = nullptr);
   ~FramePipeline();
   // One frame.  d_* are DEVICE pointers of the raw inputs (gray u8, disparity*factor f32, flow 2xf32, mask i32).
@@ -95,7 +95,8 @@ class FramePipeline {
   int f_id_obj_ = 0;                  // frame id of the pending object stage
   float cam_motion_[16];              // Converter::toInvMatrix(mVelocity) of the frame whose object stage is pending
   class Worker;
-  std::unique_ptr<Worker> worker_, orb_worker_;
+  std::unique_ptr<Worker> worker_;
+  bool orb_split_ = false;
   vdo_ctx *ctx_, *ctx_lm_, *ctx_obj_, *ctx_w_;
   // object stage handed from Step() to FinishObjects()
   bool pending_ = false;
