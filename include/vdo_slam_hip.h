@@ -402,6 +402,12 @@ int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* inl_off, con
  * `last`'s flow into `cur`'s mask (visible to the next label's vote, as in the reference). */
 int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, int n, const int32_t* last_sem_label,
                     const float* last_corr_x, const float* last_corr_y, int* n_recovered);
+/* UpdateMask (K15) -> object part of the propagation (K11) -> GetSceneFlowObj (K13) in one call (src/Tracking.cc:2997-3068,
+ * :283-305, :1278-1364): what vdo_update_mask + vdo_propagate_object + vdo_scene_flow do in that order, with one upload, one
+ * download and one synchronisation.  obj_label_out starts at -2 like vObjLabel (Tracking.cc:1289). */
+int vdo_object_chain(vdo_frame_images* cur, vdo_frame_images* last, int n, const int32_t* last_sem_label, const float* last_corr_x, const float* last_corr_y,
+                     float th_depth_obj, const float Tcw_cur[16], const float* last_x, const float* last_y, const float* last_d, const float Tcw_last[16],
+                     const float K4[4], int* n_recovered, float* depth_out, int32_t* sem_out, float* flow3d_out, int32_t* obj_label_out);
 
 /* Tracklets: Tracking::GetStaticTrack / GetDynamicTrackNew (src/Tracking.cc:2201-2421) rebuild every
  * tracklet from frame 0 on every frame; this builder is incremental (one association vector per call)

@@ -153,3 +153,37 @@ def test_mask_warp(ctx, oracle):
         TR.mask_warp(cur_im, last_im, lab)
         exp = T.mask_warp(oracle, fr["mask"], fr["flow"], lab, exp)
     assert np.array_equal(TR.download_mask(cur_im), exp)
+
+
+def test_object_chain_equals_the_three_separate_calls(ctx, oracle):
+    """vdo_object_chain = vdo_update_mask + vdo_propagate_object + vdo_scene_flow (one upload / download / sync): same mask in
+    HBM, same depths, labels, scene flow and object labels, bit for bit - on the dropped-mask scenario."""
+    from tests import frontend_ref as R
+    fr, depth = _frame(31)
+    ob = R.object_sample(oracle, fr["mask"], depth, fr["flow"], SF.TH_DEPTH_OBJ)
+    labels = np.unique(ob["label"])
+    cur_mask = fr["mask"].copy()
+    cur_mask[:] = 0
+    for l in labels[1:]:                                                    # labels[0]: dropped mask
+        ys, xs = np.nonzero(fr["mask"] == l)
+        fx = int(np.median(fr["flow"][ys, xs, 0])); fy = int(np.median(fr["flow"][ys, xs, 1]))
+        ok = (xs + fx > 0) & (xs + fx < 1242) & (ys + fy > 0) & (ys + fy < 375)
+        cur_mask[(ys + fy)[ok], (xs + fx)[ok]] = l
+    sl, cx, cy = ob["label"], ob["corr_x"], ob["corr_y"]
+    rng = np.random.default_rng(5)
+    Tl = np.eye(4, dtype=np.float32)
+    Tc = np.eye(4, dtype=np.float32); Tc[:3, 3] = [0.02, -0.01, -0.8]
+    K4 = np.array(KITTI_K, np.float32)
+    # separate calls
+    last_im = _images(ctx, depth, fr["flow"], fr["mask"])
+    cur_a = _images(ctx, depth, fr["flow"], cur_mask)
+    rec_a = TR.update_mask(cur_a, last_im, sl, cx, cy)
+    d_a, sem_a = TR.propagate_object(cur_a, cx, cy, SF.TH_DEPTH_OBJ)
+    fl_a, ol_a = TR.scene_flow(ctx, (cx, cy, d_a, sem_a), Tc, (ob["key_x"], ob["key_y"], ob["depth"], sl), Tl, K4, np.full(sl.size, -2, np.int32))
+    # one call
+    cur_b = _images(ctx, depth, fr["flow"], cur_mask)
+    rec_b, d_b, sem_b, fl_b, ol_b = TR.object_chain(cur_b, last_im, sl, cx, cy, SF.TH_DEPTH_OBJ, Tc, ob["key_x"], ob["key_y"], ob["depth"], Tl, K4)
+    assert rec_a == rec_b >= 1
+    assert np.array_equal(TR.download_mask(cur_a), TR.download_mask(cur_b))
+    assert np.array_equal(d_a, d_b) and np.array_equal(sem_a, sem_b) and np.array_equal(fl_a, fl_b) and np.array_equal(ol_a, ol_b)
+    assert (ol_b == -1).sum() > 0 and (sem_b == labels[0]).sum() > 100

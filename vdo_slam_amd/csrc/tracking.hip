@@ -18,6 +18,7 @@
 #include "frame_images.hpp"
 #include "near_flags.hpp"
 #include "arena.hpp"
+#include "tracking_shared.hpp"
 
 namespace vdo {
 
@@ -45,7 +46,6 @@ __global__ void k_gather(int mode, int n, const float* __restrict__ kx, const fl
   }
 }
 
-struct Cam { float invfx, invfy, cx, cy; float R[9]; float t[3]; };   // R|t applied to the camera-frame point
 
 // cv::gemm semantics for small float matrices: accumulate in double, round once
 __device__ __forceinline__ void gemm3_dev(const float* A, const float* v, float* o) {
@@ -109,21 +109,6 @@ __global__ void k_mask_warp(const int32_t* __restrict__ mask_last, const float* 
   if (mask_last[o] != lab) return;
   const int fx = (int)flow_last[2 * o], fy = (int)flow_last[2 * o + 1];
   if (k + fx < w && k + fx > 0 && j + fy < h && j + fy > 0) mask_cur[(size_t)(j + fy) * w + (k + fx)] = lab;
-}
-
-static Cam make_cam_Twc(const float* K4, const float* Twc) {   // Get3DinWorld: R = Twc[:3,:3], t = Twc[:3,3]
-  Cam c;
-  c.invfx = 1.0f / K4[0]; c.invfy = 1.0f / K4[1]; c.cx = K4[2]; c.cy = K4[3];
-  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) c.R[3 * i + j] = Twc[4 * i + j]; c.t[i] = Twc[4 * i + 3]; }
-  return c;
-}
-static Cam make_cam_Tcw(const float* K4, const float* Tcw) {   // UnprojectStereo*: Rwl = Rlw^T, twl = -Rlw^T tlw (cv::gemm rounding)
-  Cam c;
-  c.invfx = 1.0f / K4[0]; c.invfy = 1.0f / K4[1]; c.cx = K4[2]; c.cy = K4[3];
-  float nR[9];
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { c.R[3 * i + j] = Tcw[4 * j + i]; nR[3 * i + j] = -Tcw[4 * j + i]; }
-  for (int i = 0; i < 3; ++i) c.t[i] = (float)((double)nR[3 * i] * Tcw[3] + (double)nR[3 * i + 1] * Tcw[7] + (double)nR[3 * i + 2] * Tcw[11]);
-  return c;
 }
 
 }  // namespace vdo

@@ -19,6 +19,7 @@
 #include "frame_images.hpp"
 #include "near_flags.hpp"
 #include "arena.hpp"
+#include "tracking_shared.hpp"
 
 namespace vdo {
 
@@ -350,6 +351,67 @@ extern "C" int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, in
   int rec = 0;
   for (int s = 0; s < L; ++s) {
     if (flag[2 * s + 1]) return set_error(VDO_ERR_UNSUPPORTED, "vdo_update_mask: mask label outside [0,%d)", kVoteBins);
+    rec += flag[2 * s];
+  }
+  if (n_recovered) *n_recovered = rec;
+  return VDO_OK;
+}
+
+// UpdateMask (K15) -> object propagation (K11) -> GetSceneFlowObj (K13) as ONE call: the three steps of the object chain between
+// the renewed object set of the last frame and DynObjTracking.  Same kernels, same order on the stream as vdo_update_mask +
+// vdo_propagate_object + vdo_scene_flow (which remain), but one staged upload, one download, one synchronisation instead of three.
+extern "C" int vdo_object_chain(vdo_frame_images* cur, vdo_frame_images* last, int n, const int32_t* last_sem_label, const float* last_corr_x, const float* last_corr_y,
+                                float th_depth_obj, const float Tcw_cur[16], const float* last_x, const float* last_y, const float* last_d, const float Tcw_last[16],
+                                const float K4[4], int* n_recovered, float* depth_out, int32_t* sem_out, float* flow3d_out, int32_t* obj_label_out) {
+  if (!cur || !last || cur->w != last->w || cur->h != last->h || n < 0) return set_error(VDO_ERR_INVALID, "vdo_object_chain: bad argument");
+  if (n_recovered) *n_recovered = 0;
+  if (n == 0) return VDO_OK;
+  int rc = ctx_bind(cur->ctx);
+  if (rc != VDO_OK) return rc;
+  Arena S(cur->ctx);
+  if (!S.reserve(Arena::bytes_for(16 * (size_t)n + 64))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
+  // K15: the flowed positions grouped by last-frame label (ascending labels, index order inside a label)
+  std::vector<int32_t> uni, slot;
+  label_slots(n, last_sem_label, uni, slot);
+  const int L = (int)uni.size();
+  std::vector<int> off(L + 1, 0);
+  for (int i = 0; i < n; ++i) off[slot[i] + 1]++;
+  for (int s = 0; s < L; ++s) off[s + 1] += off[s];
+  std::vector<float> gx(n), gy(n);
+  {
+    std::vector<int> c(off.begin(), off.end() - 1);
+    for (int i = 0; i < n; ++i) { const int p = c[slot[i]]++; gx[p] = last_corr_x[i]; gy[p] = last_corr_y[i]; }
+  }
+  std::vector<int32_t> olab0(n, -2);
+  // every input of the three steps in one run of staged buffers -> one H2D copy
+  float *dgx = S.up(gx.data(), n), *dgy = S.up(gy.data(), n);
+  float *dcx = S.up(last_corr_x, n), *dcy = S.up(last_corr_y, n);
+  float *dlx = S.up(last_x, n), *dly = S.up(last_y, n), *dld = S.up(last_d, n);
+  int32_t *dll = S.up(last_sem_label, n), *dol = S.up(olab0.data(), n);
+  // outputs, contiguous -> one D2H copy
+  int32_t* dflag = S.up<int32_t>(nullptr, 2 * (size_t)L);
+  float* ddep = S.up<float>(nullptr, n);
+  int32_t* dsem = S.up<int32_t>(nullptr, n);
+  float* dfl = S.up<float>(nullptr, 3 * (size_t)n);
+  if (!dgx || !dgy || !dcx || !dcy || !dlx || !dly || !dld || !dll || !dol || !dflag || !ddep || !dsem || !dfl) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
+  for (int s = 0; s < L; ++s) {      // label after label (a recovered mask is visible to the next label's vote, as in the reference)
+    const int ns = off[s + 1] - off[s];
+    hipLaunchKernelGGL(k_label_vote, dim3(1), dim3(256), 0, S.stream(), ns, (const float*)(dgx + off[s]), (const float*)(dgy + off[s]), (const int32_t*)cur->d_mask, cur->w, cur->h, dflag + 2 * s);
+    hipLaunchKernelGGL(k_mask_warp_if, dim3((cur->w + 255) / 256, cur->h), dim3(256), 0, S.stream(), (const int32_t*)(dflag + 2 * s), (const int32_t*)last->d_mask,
+                       (const float*)last->d_flow, cur->w, cur->h, uni[s], cur->d_mask);
+  }
+  // K11 (objects) on the updated mask, K13 on its outputs
+  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.stream(), 1, n, (const float*)dcx, (const float*)dcy, (const float*)cur->d_depth, (const int32_t*)cur->d_mask,
+                     cur->w, cur->h, th_depth_obj, ddep, dsem);
+  hipLaunchKernelGGL(k_scene_flow, dim3((n + 255) / 256), dim3(256), 0, S.stream(), n, (const float*)dcx, (const float*)dcy, (const float*)ddep, (const int32_t*)dsem, make_cam_Tcw(K4, Tcw_cur),
+                     (const float*)dlx, (const float*)dly, (const float*)dld, (const int32_t*)dll, make_cam_Tcw(K4, Tcw_last), dfl, dol);
+  std::vector<int32_t> flag(2 * (size_t)L);
+  S.down(flag.data(), dflag, flag.size()); S.down(depth_out, ddep, n); S.down(sem_out, dsem, n); S.down(flow3d_out, dfl, 3 * (size_t)n); S.down(obj_label_out, dol, n);
+  rc = S.finish("vdo_object_chain");
+  if (rc != VDO_OK) return rc;
+  int rec = 0;
+  for (int s = 0; s < L; ++s) {
+    if (flag[2 * s + 1]) return set_error(VDO_ERR_UNSUPPORTED, "vdo_object_chain: mask label outside [0,%d)", kVoteBins);
     rec += flag[2 * s];
   }
   if (n_recovered) *n_recovered = rec;

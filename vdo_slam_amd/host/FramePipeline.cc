@@ -266,11 +266,16 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   // ---- UpdateMask (K15) + object part of the propagation (K11): they need the object set of the last frame
   const int n_o = have_last_ ? (int)obj_.cx.size() : 0;
   obj_depth.assign(n_o, 0.f); obj_sem.assign(n_o, 0);
+  std::vector<float>& flow3d = f_[7];
+  std::vector<int32_t>& olab = i_[2];
   if (have_last_) {
+    // UpdateMask (K15) -> K11 (objects) -> GetSceneFlowObj (K13): one call, one synchronisation   Tracking.cc:2997-3068, 283-305, 1278-1364
     int rec = 0;
-    VDO_TRY(vdo_update_mask(cur, last, n_o, obj_.sem.data(), obj_.cx.data(), obj_.cy.data(), &rec));
+    flow3d.resize(3 * (size_t)std::max(n_o, 1));
+    olab.assign(n_o, -2);
+    VDO_TRY(vdo_object_chain(cur, last, n_o, obj_.sem.data(), obj_.cx.data(), obj_.cy.data(), p_.th_depth_obj, Tcw, obj_.x.data(), obj_.y.data(), obj_.d.data(),
+                             Tcw_last_, p_.K4, &rec, obj_depth.data(), obj_sem.data(), flow3d.data(), olab.data()));
     fc.n_recovered_masks = rec;
-    VDO_TRY(vdo_propagate_object(cur, n_o, obj_.cx.data(), obj_.cy.data(), p_.th_depth_obj, obj_depth.data(), obj_sem.data()));
   }
   tick(10);
   StaSet nsta; ObjSet nobj;
@@ -328,12 +333,6 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     }
   } else {
     // ---- GetSceneFlowObj (K13) + DynObjTracking                                   Tracking.cc:1278-1612
-    std::vector<float>& flow3d = f_[7];
-    flow3d.resize(3 * (size_t)std::max(n_o, 1));
-    std::vector<int32_t>& olab = i_[2];
-    olab.assign(n_o, -2);
-    VDO_TRY(vdo_scene_flow(ctx_, n_o, obj_.cx.data(), obj_.cy.data(), obj_depth.data(), obj_sem.data(), Tcw,
-                           obj_.x.data(), obj_.y.data(), obj_.d.data(), obj_.sem.data(), Tcw_last_, p_.K4, flow3d.data(), olab.data()));
     vdo_dyn_obj_params dp{W, H, 25, 50, p_.sf_mg_thres, p_.sf_ds_thres, p_.th_depth_obj, f_id_};
     std::vector<int32_t>&off = i_[3], &idx = i_[4], &osem = i_[5], &omod = i_[6];
     off.assign(n_o + 2, 0); idx.resize(std::max(n_o, 1)); osem.resize(n_o + 1); omod.resize(n_o + 1);

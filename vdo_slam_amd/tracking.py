@@ -159,6 +159,23 @@ def update_mask(cur_images, last_images, last_sem_label, last_corr_x, last_corr_
     return n.value
 
 
+def object_chain(cur_images, last_images, last_sem_label, last_corr_x, last_corr_y, th_depth_obj, Tcw_cur, last_x, last_y, last_d, Tcw_last, K4):
+    """UpdateMask -> object propagation -> scene flow in one call (vdo_object_chain).
+    Returns (n_recovered, depth, sem_label, flow3d [n,3], obj_label)."""
+    sl, cx, cy = _i(last_sem_label), _f(last_corr_x), _f(last_corr_y)
+    lx, ly, ld = _f(last_x), _f(last_y), _f(last_d)
+    Tc, Tl, K4 = _f(Tcw_cur), _f(Tcw_last), _f(K4)
+    n = sl.size
+    rec = C.c_int()
+    d = np.zeros(n, np.float32); sem = np.zeros(n, np.int32); fl = np.zeros((n, 3), np.float32); ol = np.zeros(n, np.int32)
+    L = K.lib()
+    L.vdo_object_chain.argtypes = [C.c_void_p, C.c_void_p, C.c_int, K.c_int32_p, K.c_float_p, K.c_float_p, C.c_float, K.c_float_p, K.c_float_p, K.c_float_p, K.c_float_p,
+                                   K.c_float_p, K.c_float_p, C.POINTER(C.c_int), K.c_float_p, K.c_int32_p, K.c_float_p, K.c_int32_p]
+    K.check(L.vdo_object_chain(cur_images._h, last_images._h, n, _ip(sl), _fp(cx), _fp(cy), th_depth_obj, _fp(Tc), _fp(lx), _fp(ly), _fp(ld), _fp(Tl), _fp(K4),
+                               C.byref(rec), _fp(d), _ip(sem), _fp(fl), _ip(ol)))
+    return rec.value, d, sem, fl, ol
+
+
 class TrackBuilder:
     """Incremental GetStaticTrack / GetDynamicTrackNew (host only: usable without a GPU)."""
 
