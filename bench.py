@@ -176,8 +176,8 @@ def main():
     # host threads per replica: main + 1 helper of FramePipeline (polls) + 3 quadtree helpers of ORB (sleep when idle); with fewer
     # than ~5 CPUs per rank the helpers would only steal time from each other
     cpus_per_rank = _cpu_budget() / max(1, world)
-    if cpus_per_rank < 3 and "VDO_ORB_THREADS" not in os.environ:
-        os.environ["VDO_ORB_THREADS"] = "0"
+    if "VDO_ORB_THREADS" not in os.environ:             # quadtree helpers of ORB (library default 3): measured 888 / 916 / 921 frames/s with 3 / 5 / 7
+        os.environ["VDO_ORB_THREADS"] = "0" if cpus_per_rank < 3 else ("5" if cpus_per_rank >= 10 else "3")
     use_worker = not os.environ.get("VDO_BENCH_NO_WORKER") and cpus_per_rank >= 5
     ctx_w = Context(local) if use_worker else None      # helper host thread of FramePipeline, own stream + arena
     # ORB on a stream of its own (device stage queued at the start of the frame, under the camera stage): supported, results identical,
@@ -244,7 +244,7 @@ def main():
                                f"{INVALID_DEPTH:.0%} invalid depth, {ZERO_FLOW:.0%} zero flow, one instance mask missing in frames {sorted(DROP_MASKS)}",
                    "parallelism": f"replicas x{world}; {4 + (ctx_orb is not None)} HIP streams per replica: camera LM (2) || ORB front-end ({5 if ctx_orb is not None else 1}); object LMs (3) || RenewFrameInfo (1) and - "
                                   f"defer_objects={defer} - the next frame's camera stage; every LM problem runs on a cluster of up to 8 workgroups; "
-                                  f"{cpus_per_rank:.1f} CPUs per replica, host threads per replica: 1 + {int(ctx_w is not None)} helper (object stage of the previous frame || camera stage + ORB; K9/K10/RenewFrameInfo static || object chain) + 3 ORB quadtree helpers",
+                                  f"{cpus_per_rank:.1f} CPUs per replica, host threads per replica: 1 + {int(ctx_w is not None)} helper (object stage of the previous frame || camera stage + ORB; K9/K10/RenewFrameInfo static || object chain) + {os.environ['VDO_ORB_THREADS']} ORB quadtree helpers",
                    "orb_keypoints": counts.n_orb, "new_static_candidates": counts.n_static_new, "object_samples": counts.n_object_samples,
                    "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
                    "per_frame_mean": {q: round(v / n_all, 2) for q, v in agg.items()},
