@@ -97,7 +97,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   __shared__ double s_scr[F2_WAVES * 4], s_red[32];
   __shared__ double s_wide[29 * (F2_THREADS + 1)];
   __shared__ SE3d s_T, s_Ttry;
-  __shared__ double s_Hc[27], s_xp[6];   // s_Hc: Hpp (lower triangle, packed) + bp of the current linearisation
+  __shared__ double s_Hc[27], s_xp[6], s_Hs[36], s_bs[6], s_xs[6];   // s_Hc: Hpp (lower triangle, packed) + bp of the current linearisation
   __shared__ double s_rho;
   __shared__ int s_ctrl[4];   // [2] ok2, [3] cluster exchange timed out
   __shared__ double s_hlast;  // Hll diagonal of the last landmark of this workgroup's chunk (last sweep)
@@ -386,24 +386,23 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       F2_TICK(0);
       // ---- (2) reduced 6x6 system, SE3 update, pose part of computeScale
       if (tid == 0) {
-        double Hs[36], bs[6], xs[6];                                   // registers: every index below is a constant after unrolling
         {
           int k = 0;
 #pragma unroll
           for (int a = 0; a < 6; ++a) {
 #pragma unroll
-            for (int c2 = 0; c2 <= a; ++c2) { Hs[c2 * 6 + a] = s_Hc[k]; Hs[a * 6 + c2] = s_Hc[k] - s_red[k]; ++k; }
+            for (int c2 = 0; c2 <= a; ++c2) { s_Hs[c2 * 6 + a] = s_Hc[k]; s_Hs[a * 6 + c2] = s_Hc[k] - s_red[k]; ++k; }
           }
         }
 #pragma unroll
-        for (int j = 0; j < 6; ++j) { Hs[7 * j] += lambda; bs[j] = s_Hc[21 + j] - s_red[21 + j]; }
+        for (int j = 0; j < 6; ++j) { s_Hs[7 * j] += lambda; s_bs[j] = s_Hc[21 + j] - s_red[21 + j]; }
         F2_TICK(5);
-        const bool ok2 = ldlt6_solve_reg(Hs, bs, xs);
+        const bool ok2 = ldlt6_solve_perm(s_Hs, s_bs, s_xs);
         F2_TICK(6);
         s_ctrl[2] = ok2 ? 1 : 0;
         if (ok2) {
 #pragma unroll
-          for (int j = 0; j < 6; ++j) s_xp[j] = xs[j];
+          for (int j = 0; j < 6; ++j) s_xp[j] = s_xs[j];
         }
         // (failed LDLT leaves x untouched in the reference; the trial is rejected anyway)
         s_Ttry = se3_exp_compose(s_xp, s_T);

@@ -143,84 +143,91 @@ __device__ inline bool ldlt6_solve(double* m /*36, destroyed*/, const double* b,
   return true;
 }
 
-// The same factorisation with every index a compile-time constant (full unrolling; the run-time pivot is dispatched through
-// a chain of uniform branches), so the 6x6 block lives in registers: the LDS version above pays ~100 cycles of dependent
-// latency per element access, ~10k cycles per solve on the one active lane.  Same operations in the same order.
-__device__ __forceinline__ bool ldlt6_solve_reg(double (&m)[36], const double (&b)[6], double (&x)[6]) {
-  int tr[6] = {0, 1, 2, 3, 4, 5};
+// The same factorisation without its branches.  Eigen's unblocked LDLT is left-looking: when step k looks for its pivot, the trailing
+// diagonal entries have not been touched yet - the pivot ORDER is a function of the original diagonal alone (selection with
+// Eigen's swap semantics: first maximum wins, the displaced entry takes the pivot's old place).  So: find the order first,
+// gather the symmetrically permuted matrix (dynamic indices: from LDS), and run an LDLT WITHOUT pivoting on it with constant
+// indices in registers - the same products and sums in the same order as the pivoted version, minus its branches and swaps.
+// A: full symmetric 6x6 in LDS (lower part is read), b: LDS, x: LDS (written in the original ordering).  Returns isPositive().
+__device__ __forceinline__ bool ldlt6_solve_perm(const double* A, const double* b, double* x) {
+  int ord[6] = {0, 1, 2, 3, 4, 5};
+  {
+    double d[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) d[i] = fabs(A[7 * i]);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      int big = k;
+      double bv = d[k];
+#pragma unroll
+      for (int i = k + 1; i < 6; ++i) if (d[i] > bv) { bv = d[i]; big = i; }
+      // swap positions k and big (values and indices travel together)
+#pragma unroll
+      for (int bb = k + 1; bb < 6; ++bb)
+        if (big == bb) { const double t = d[k]; d[k] = d[bb]; d[bb] = t; const int u = ord[k]; ord[k] = ord[bb]; ord[bb] = u; }
+    }
+  }
+  double m[21];                      // lower triangle of P A P^T, row-major packed: (i, j) at i*(i+1)/2 + j
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+#pragma unroll
+    for (int j = 0; j <= i; ++j) {
+      const int r = ord[i], c = ord[j];
+      m[i * (i + 1) / 2 + j] = r >= c ? A[r * 6 + c] : A[c * 6 + r];
+    }
+  }
+#define VDO_M(i, j) m[(i) * ((i) + 1) / 2 + (j)]
   int sign = 0;
-  bool stop = false;
+  bool zero = false;
 #pragma unroll
   for (int k = 0; k < 6; ++k) {
-    if (stop) continue;
-    int big = k;
-    double bv = fabs(m[k * 6 + k]);
-#pragma unroll
-    for (int i = k + 1; i < 6; ++i) if (fabs(m[i * 6 + i]) > bv) { bv = fabs(m[i * 6 + i]); big = i; }
-    tr[k] = big;
-#pragma unroll
-    for (int bb = k + 1; bb < 6; ++bb) {
-      if (big != bb) continue;
-#pragma unroll
-      for (int j = 0; j < k; ++j) { const double t = m[k * 6 + j]; m[k * 6 + j] = m[bb * 6 + j]; m[bb * 6 + j] = t; }
-#pragma unroll
-      for (int i = bb + 1; i < 6; ++i) { const double t = m[i * 6 + k]; m[i * 6 + k] = m[i * 6 + bb]; m[i * 6 + bb] = t; }
-      { const double t = m[k * 6 + k]; m[k * 6 + k] = m[bb * 6 + bb]; m[bb * 6 + bb] = t; }
-#pragma unroll
-      for (int i = k + 1; i < bb; ++i) { const double t = m[i * 6 + k]; m[i * 6 + k] = m[bb * 6 + i]; m[bb * 6 + i] = t; }
-    }
+    if (zero) continue;
     if (k > 0) {
       double temp[6];
 #pragma unroll
-      for (int j = 0; j < k; ++j) temp[j] = m[j * 6 + j] * m[k * 6 + j];
+      for (int j = 0; j < k; ++j) temp[j] = VDO_M(j, j) * VDO_M(k, j);
       double s = 0;
 #pragma unroll
-      for (int j = 0; j < k; ++j) s += m[k * 6 + j] * temp[j];
-      m[k * 6 + k] -= s;
+      for (int j = 0; j < k; ++j) s += VDO_M(k, j) * temp[j];
+      VDO_M(k, k) -= s;
 #pragma unroll
       for (int i = k + 1; i < 6; ++i) {
         double t = 0;
 #pragma unroll
-        for (int j = 0; j < k; ++j) t += m[i * 6 + j] * temp[j];
-        m[i * 6 + k] -= t;
+        for (int j = 0; j < k; ++j) t += VDO_M(i, j) * temp[j];
+        VDO_M(i, k) -= t;
       }
     }
-    const double akk = m[k * 6 + k];
+    const double akk = VDO_M(k, k);
     const bool valid = fabs(akk) > 0.0;
-    if (k == 0 && !valid) { sign = 0; stop = true; continue; }      // (tr stays the identity: tr[0] = 0 when every diagonal entry is 0)
+    if (k == 0 && !valid) { sign = 0; zero = true; continue; }      // the largest diagonal entry is 0: Eigen stops, the solve below yields x = 0
     if (valid) {
 #pragma unroll
-      for (int i = k + 1; i < 6; ++i) m[i * 6 + k] /= akk;
+      for (int i = k + 1; i < 6; ++i) VDO_M(i, k) /= akk;
     }
     if (sign == 1) { if (akk < 0) sign = 2; }
     else if (sign == -1) { if (akk > 0) sign = 2; }
     else if (sign == 0) { if (akk > 0) sign = 1; else if (akk < 0) sign = -1; }
   }
   if (!(sign == 1 || sign == 0)) return false;
+  double y[6];
 #pragma unroll
-  for (int i = 0; i < 6; ++i) x[i] = b[i];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) {
-#pragma unroll
-    for (int bb = k + 1; bb < 6; ++bb) if (tr[k] == bb) { const double t = x[k]; x[k] = x[bb]; x[bb] = t; }
-  }
+  for (int k = 0; k < 6; ++k) y[k] = b[ord[k]];
 #pragma unroll
   for (int i = 0; i < 6; ++i) {
 #pragma unroll
-    for (int j = 0; j < i; ++j) x[i] -= m[i * 6 + j] * x[j];
+    for (int j = 0; j < i; ++j) y[i] -= VDO_M(i, j) * y[j];
   }
 #pragma unroll
-  for (int i = 0; i < 6; ++i) { if (fabs(m[i * 6 + i]) > 2.2250738585072014e-308) x[i] /= m[i * 6 + i]; else x[i] = 0; }
+  for (int i = 0; i < 6; ++i) { if (fabs(VDO_M(i, i)) > 2.2250738585072014e-308) y[i] /= VDO_M(i, i); else y[i] = 0; }
 #pragma unroll
   for (int i = 5; i >= 0; --i) {
 #pragma unroll
-    for (int j = i + 1; j < 6; ++j) x[i] -= m[j * 6 + i] * x[j];
+    for (int j = i + 1; j < 6; ++j) y[i] -= VDO_M(j, i) * y[j];
   }
+#undef VDO_M
 #pragma unroll
-  for (int k = 5; k >= 0; --k) {
-#pragma unroll
-    for (int bb = k + 1; bb < 6; ++bb) if (tr[k] == bb) { const double t = x[k]; x[k] = x[bb]; x[bb] = t; }
-  }
+  for (int k = 0; k < 6; ++k) x[ord[k]] = y[k];
   return true;
 }
 
