@@ -177,30 +177,6 @@ __global__ __launch_bounds__(256) void k_fast_cells(const uint8_t* __restrict__ 
   }
 }
 
-// exclusive scan of the per-cell counts (single workgroup) -> dense offsets, per-level totals
-__global__ __launch_bounds__(1024) void k_scan_cells(const int* __restrict__ cnt, int ncells, const int* __restrict__ cell_level,
-                                                     int nlevels, int* __restrict__ offs, int* __restrict__ level_cnt) {
-  __shared__ int s_w[16], s_carry;
-  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-  if (tid == 0) s_carry = 0;
-  if (tid < nlevels) level_cnt[tid] = 0;
-  __syncthreads();
-  for (int base = 0; base < ncells; base += 1024) {
-    const int i = base + tid;
-    const int c = i < ncells ? min(cnt[i], kCellCap) : 0;
-    int incl = c;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const int v = __shfl_up(incl, off, 64); if (lane >= off) incl += v; }
-    if (lane == 63) s_w[wv] = incl;
-    __syncthreads();
-    if (tid == 0) { int a = s_carry; for (int q = 0; q < 16; ++q) { const int v = s_w[q]; s_w[q] = a; a += v; } s_carry = a; }
-    __syncthreads();
-    if (i < ncells) { offs[i] = s_w[wv] + incl - c; if (c) atomicAdd(&level_cnt[cell_level[i]], c); }
-    __syncthreads();
-  }
-  if (tid == 0) { offs[ncells] = s_carry; level_cnt[16] = s_carry; }     // header: per-level counts + total, fetched in one copy
-}
-
 // umax of the circular patch (ORBextractor.cc:443-458), filled on the host
 struct UMax { int v[kHalfPatch + 2]; };
 
@@ -220,8 +196,8 @@ __device__ __forceinline__ float fast_atan2_dev(float y, float x) {
 // Compaction to dense arrays + K6 angle for every candidate: one wave per candidate (31 rows over the lanes).
 // dense: x,y (float, relative to (16,16)), resp, angle, level
 __global__ __launch_bounds__(256) void k_compact_angle(const uint8_t* __restrict__ pyr, const LevelDesc* __restrict__ levels,
-                                                       const CellDesc* __restrict__ cells, const int* __restrict__ cnt, const int* __restrict__ offs,
-                                                       const uint32_t* __restrict__ pack, int ncells, UMax um,
+                                                       const CellDesc* __restrict__ cells, const int* __restrict__ cnt, const int* __restrict__ cell_level,
+                                                       int* __restrict__ level_cnt, const uint32_t* __restrict__ pack, int ncells, UMax um,
                                                        float* __restrict__ ox, float* __restrict__ oy, float* __restrict__ oresp,
                                                        float* __restrict__ oang, int* __restrict__ olevel) {
   const int cell = blockIdx.x;
@@ -230,6 +206,27 @@ __global__ __launch_bounds__(256) void k_compact_angle(const uint8_t* __restrict
   const LevelDesc L = levels[lvl];
   const uint8_t* img = pyr + L.off_inner;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  // dense offset of this cell = number of candidates in the cells before it (every workgroup sums its own prefix: ~1100 counts,
+  // L2-resident - cheaper than a separate single-workgroup scan kernel in front of this one); workgroup 0 also writes the header
+  // (per-level counts + total) the host fetches next to the candidates
+  __shared__ int s_part[4], s_lvl[16];
+  int base;
+  {
+    int a = 0;
+    for (int c = threadIdx.x; c < cell; c += 256) a += min(cnt[c], kCellCap);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_down(a, off, 64);
+    if (lane == 0) s_part[wv] = a;
+    if (cell == 0 && threadIdx.x < 16) s_lvl[threadIdx.x] = 0;
+    __syncthreads();
+    base = s_part[0] + s_part[1] + s_part[2] + s_part[3];
+    if (cell == 0) {
+      for (int c = threadIdx.x; c < ncells; c += 256) { const int v = min(cnt[c], kCellCap); if (v) atomicAdd(&s_lvl[cell_level[c]], v); }
+      __syncthreads();
+      if (threadIdx.x < 16) level_cnt[threadIdx.x] = s_lvl[threadIdx.x];
+      if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < 16; ++q) t += s_lvl[q]; level_cnt[16] = t; }
+    }
+  }
   for (int k = wv; k < n; k += 4) {
     const uint32_t pk = pack[(size_t)cell * kCellCap + k];
     const int x = (int)(pk & 0xfff), y = (int)((pk >> 12) & 0xfff), s = (int)(pk >> 24);
@@ -247,7 +244,7 @@ __global__ __launch_bounds__(256) void k_compact_angle(const uint8_t* __restrict
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) { m10 += __shfl_down(m10, off, 64); m01 += __shfl_down(m01, off, 64); }
     if (lane == 0) {
-      const int o = offs[cell] + k;
+      const int o = base + k;
       ox[o] = (float)x; oy[o] = (float)y; oresp[o] = (float)s; olevel[o] = lvl;
       oang[o] = fast_atan2_dev((float)m01, (float)m10);
     }
@@ -657,9 +654,8 @@ static int orb_device_stage(vdo_orb* o, const uint8_t* gray_dev, int stride) {
   }
   hipLaunchKernelGGL(k_fast_cells, dim3(o->ncells), dim3(256), 0, s, (const uint8_t*)o->d_pyr, (const LevelDesc*)o->d_levels, (const CellDesc*)o->d_cells,
                      o->prm.ini_th, o->prm.min_th, o->d_cnt, o->d_pack);
-  hipLaunchKernelGGL(k_scan_cells, dim3(1), dim3(1024), 0, s, (const int*)o->d_cnt, o->ncells, (const int*)o->d_cell_level, NL, o->d_offs, o->d_level_cnt);
   hipLaunchKernelGGL(k_compact_angle, dim3(o->ncells), dim3(256), 0, s, (const uint8_t*)o->d_pyr, (const LevelDesc*)o->d_levels, (const CellDesc*)o->d_cells,
-                     (const int*)o->d_cnt, (const int*)o->d_offs, (const uint32_t*)o->d_pack, o->ncells, o->um, o->d_x, o->d_y, o->d_resp, o->d_ang, o->d_lvl);
+                     (const int*)o->d_cnt, (const int*)o->d_cell_level, o->d_level_cnt, (const uint32_t*)o->d_pack, o->ncells, o->um, o->d_x, o->d_y, o->d_resp, o->d_ang, o->d_lvl);
   return VDO_OK;
 }
 
