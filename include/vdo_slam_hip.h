@@ -319,6 +319,12 @@ int vdo_frame_images_set_ctx(vdo_frame_images* f, vdo_ctx* ctx);
 int vdo_frame_static_filter(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth,
                             int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y,
                             float* depth_out, int* n_out);
+/* The same for UseSampleFeature = 1 (src/Frame.cc:132-166: the destination is tested on all four sides), and the sampler that
+ * replaces ORB there: Frame::SampleKeyPoints (:672-737), 3000 random grid positions from cv::RNG(seed); host only. */
+int vdo_frame_static_filter_sampled(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth,
+                                    int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y,
+                                    float* depth_out, int* n_out);
+int vdo_sample_keypoints(int rows, int cols, uint64_t seed, int capacity, float* x_out, float* y_out, int* n_out);
 /* K10: semi-dense object sampling (:201-228), raster order.  Pass key_x == NULL to keep results on the device. */
 int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, int step, int cap,
                             float* key_x, float* key_y, float* corr_x, float* corr_y,

@@ -452,6 +452,58 @@ extern "C" int vdo_oracle_frame_static_filter(int n, const float* kx, const floa
   return m;
 }
 
+// Frame::Frame static filter, UseSampleFea == 1 branch (src/Frame.cc:132-166)
+extern "C" int vdo_oracle_frame_static_filter_sampled(int n, const float* kx, const float* ky, const int32_t* mask, const float* depth, const float* flow,
+                                                      int w, int h, float th_depth,
+                                                      int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out) {
+  int m = 0;
+  for (int i = 0; i < n; ++i) {
+    const int x = (int)kx[i], y = (int)ky[i];
+    if (mask[(size_t)y * w + x] != 0) continue;
+    if (depth[(size_t)y * w + x] > th_depth || depth[(size_t)y * w + x] <= 0) continue;
+    const float fxe = flow[2 * ((size_t)y * w + x)], fye = flow[2 * ((size_t)y * w + x) + 1];
+    if (fxe != 0 && fye != 0) {
+      if (kx[i] + fxe < w && ky[i] + fye < h && kx[i] + fxe > 0 && ky[i] + fye > 0) {
+        keep_idx[m] = i; corr_x[m] = kx[i] + fxe; corr_y[m] = ky[i] + fye; flow_x[m] = fxe; flow_y[m] = fye;
+        const float dd = depth[(size_t)((int)ky[i]) * w + (int)kx[i]];      // depth gather (:178-194)
+        depth_out[m] = dd > 0 ? dd : -1.f;
+        ++m;
+      }
+    }
+  }
+  return m;
+}
+
+// Frame::SampleKeyPoints (src/Frame.cc:672-737) with cv::RNG(seed)
+extern "C" int vdo_oracle_sample_keypoints(int rows, int cols, unsigned long long seed, float* x_out, float* y_out) {
+  struct Rng {
+    unsigned long long state;
+    unsigned next() { state = (unsigned long long)(unsigned)state * 4164903690U + (unsigned)(state >> 32); return (unsigned)state; }
+    int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
+  } rng{seed ? seed : 0xffffffffULL};
+  const int N = 3000, n_div = 20;
+  std::vector<std::vector<std::pair<float, float> > > grid(n_div * n_div);
+  const int x_step = cols / n_div, y_step = rows / n_div;
+  int key_num = 0;
+  while (key_num < N) {
+    for (int i = 0; i < n_div; ++i) {
+      for (int j = 0; j < n_div; ++j) {
+        const float x = rng.uniform(i * x_step, (i + 1) * x_step);
+        const float y = rng.uniform(j * y_step, (j + 1) * y_step);
+        if (x >= cols || y >= rows || x <= 0 || y <= 0) continue;
+        grid[i * n_div + j].push_back(std::make_pair(x, y));
+        key_num = key_num + 1;
+        if (key_num >= N) break;
+      }
+      if (key_num >= N) break;
+    }
+  }
+  int n = 0;
+  for (size_t c = 0; c < grid.size(); ++c)
+    for (size_t k = 0; k < grid[c].size(); ++k) { x_out[n] = grid[c][k].first; y_out[n] = grid[c][k].second; ++n; }
+  return n;
+}
+
 // Frame::Frame semi-dense object sampling (stride 4, raster order)
 extern "C" int vdo_oracle_frame_object_sample(const int32_t* mask, const float* depth, const float* flow, int w, int h,
                                               float th_depth_obj, int step, int cap,

@@ -185,6 +185,10 @@ int vdo_oracle_orb_fast_level(const uint8_t* gray, int w, int h, const vdo_orb_p
 int vdo_oracle_orb_extract(const uint8_t* gray, int w, int h, const vdo_orb_params* p,
                            float* kx, float* ky, float* kresp, float* kangle, int32_t* koct, float* ksize, int cap);
 void vdo_oracle_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst);
+int vdo_oracle_frame_static_filter_sampled(int n, const float* kx, const float* ky, const int32_t* mask, const float* depth, const float* flow,
+                                           int w, int h, float th_depth,
+                                           int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out);
+int vdo_oracle_sample_keypoints(int rows, int cols, unsigned long long seed, float* x_out, float* y_out);   /* capacity 3000 */
 int vdo_oracle_frame_static_filter(int n, const float* kx, const float* ky, const int32_t* koct,
                                    const int32_t* mask, const float* depth, const float* flow,
                                    int w, int h, float th_depth,

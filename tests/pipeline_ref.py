@@ -47,9 +47,10 @@ def matmul4_f32(A, B):
 class OraclePipeline:
     MAX_OBJECTS, OBJ_CAP = 8, 6000
 
-    def __init__(self, oracle, max_bg=1200, max_obj=800, sf_mg=0.12, sf_ds=0.3, build_lm=False):
+    def __init__(self, oracle, max_bg=1200, max_obj=800, sf_mg=0.12, sf_ds=0.3, build_lm=False, K4=None, use_sample=False, sample_seed=1):
         self.o = oracle
-        self.K4 = np.array(synth.KITTI_K, f32)
+        self.K4 = np.array(synth.KITTI_K if K4 is None else K4, f32)
+        self.use_sample, self.sample_seed = use_sample, sample_seed      # UseSampleFeature = 1 (omd.yaml): SampleKeyPoints instead of ORB
         self.max_bg, self.max_obj, self.sf_mg, self.sf_ds, self.build_lm = max_bg, max_obj, sf_mg, sf_ds, build_lm
         self.last = None
         self.Tl = np.eye(4, dtype=f32)
@@ -75,7 +76,7 @@ class OraclePipeline:
     def _lm(self, kx, ky, fx, fy, d, T0, info_prior, max_it):
         from tests.test_oracle_flow2 import run_oracle
         Twl = inv_rigid_f32(self.Tl).astype(np.float64)
-        prob = synth.Flow2Problem(obs=np.c_[kx, ky].astype(np.float64), flow=np.c_[fx, fy].astype(np.float64), depth=np.asarray(d, np.float64), K=synth.KITTI_K,
+        prob = synth.Flow2Problem(obs=np.c_[kx, ky].astype(np.float64), flow=np.c_[fx, fy].astype(np.float64), depth=np.asarray(d, np.float64), K=tuple(float(v) for v in self.K4),
                                   Twl=Twl, T0=np.asarray(T0, np.float64), info_prior=info_prior, max_iterations=max_it)
         prob.huber_delta = float(np.sqrt(f32(0.04))); prob.chi2_gate = float(f32(0.04)); prob.info_flow = 0.1; prob.ref_quirks = 1
         return run_oracle(self.o, prob)
@@ -124,9 +125,24 @@ class OraclePipeline:
         elif last is not None and self.build_lm:
             cam_lm = dict(sub=np.zeros(0, np.int64), T=self.Tl.astype(np.float64), flow=np.zeros((0, 2)), inl=np.zeros(0, bool))
         self.stage_s["ransac_init"] += tick() - t; t = tick()
-        kp = R.extract(o, fr["gray"])
+        if self.use_sample:
+            h_, w_ = fr["mask"].shape
+            sx = np.zeros(3000, f32); sy = np.zeros(3000, f32)
+            o.vdo_oracle_sample_keypoints.argtypes = [C.c_int, C.c_int, C.c_ulonglong, K.c_float_p, K.c_float_p]
+            ns = o.vdo_oracle_sample_keypoints(h_, w_, self.sample_seed + self.f_id, R._fp(sx), R._fp(sy))
+            kp = dict(x=sx[:ns].copy(), y=sy[:ns].copy(), octave=np.zeros(ns, np.int32))
+        else:
+            kp = R.extract(o, fr["gray"])
         self.stage_s["orb"] += tick() - t; t = tick()
-        st = R.static_filter(o, kp["x"], kp["y"], kp["octave"], mask, d, fr["flow"], SF.TH_DEPTH_BG)
+        if self.use_sample:
+            n_ = kp["x"].size
+            idx_ = np.zeros(n_, np.int32); ff_ = [np.zeros(n_, f32) for _ in range(5)]
+            o.vdo_oracle_frame_static_filter_sampled.argtypes = [C.c_int, K.c_float_p, K.c_float_p, K.c_int32_p, K.c_float_p, K.c_float_p, C.c_int, C.c_int, C.c_float, K.c_int32_p] + [K.c_float_p] * 5
+            m_ = o.vdo_oracle_frame_static_filter_sampled(n_, R._fp(kp["x"]), R._fp(kp["y"]), R._ip(np.ascontiguousarray(mask)), R._fp(d), R._fp(fr["flow"]), mask.shape[1], mask.shape[0],
+                                                          SF.TH_DEPTH_BG, R._ip(idx_), *[R._fp(a) for a in ff_])
+            st = dict(keep_idx=idx_[:m_], corr_x=ff_[0][:m_], corr_y=ff_[1][:m_], flow_x=ff_[2][:m_], flow_y=ff_[3][:m_], depth=ff_[4][:m_])
+        else:
+            st = R.static_filter(o, kp["x"], kp["y"], kp["octave"], mask, d, fr["flow"], SF.TH_DEPTH_BG)
         ob = R.object_sample(o, mask, d, fr["flow"], SF.TH_DEPTH_OBJ)
         self.stage_s["frame"] += tick() - t; t = tick()
         if cam_lm is not None:
@@ -182,7 +198,9 @@ class OraclePipeline:
                 self.motions.append(dict(mod_label=int(dyn["mod"][a]), sem_label=int(dyn["sem"][a]), n_inliers=int(ninl), H=matmul4_f32(Twc_c, Tn.astype(f32))))
                 self.stage_s["lm_obj"] += tick() - t; t = tick()
             self.stage_s["ransac_init"] += tick() - t; t = tick()
-            rs = T.renew_static(o, tm, cur_sx, cur_sy, kp["x"], kp["y"], mask, d, fr["flow"], self.max_bg)
+            # top-up source: all ORB keypoints, or - UseSampleFeature - the filtered samples mvStatKeysTmp (Tracking.cc:2718-2721)
+            src_x, src_y = (kp["x"][st["keep_idx"]], kp["y"][st["keep_idx"]]) if self.use_sample else (kp["x"], kp["y"])
+            rs = T.renew_static(o, tm, cur_sx, cur_sy, src_x, src_y, mask, d, fr["flow"], self.max_bg)
             xyz_s = T.get3d_world(o, rs["key_x"], rs["key_y"], rs["depth"], self.K4, Twc_c)
             tmp = dict(x=ob["key_x"], y=ob["key_y"], depth=ob["depth"], label=ob["label"], flow_x=ob["flow_x"], flow_y=ob["flow_y"], corr_x=ob["corr_x"], corr_y=ob["corr_y"])
             ro = T.renew_object(o, inl_sets, stat, dyn["sem"], dyn["mod"], cur_ox, cur_oy, olab, tmp, mask, d, fr["flow"], self.max_obj)

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(1024) void k_static_filter(int n, const float* __re
                                                         const float* __restrict__ flow, int w, int h, float th_depth,
                                                         int32_t* __restrict__ keep_idx, float* __restrict__ corr_x, float* __restrict__ corr_y,
                                                         float* __restrict__ flow_x, float* __restrict__ flow_y, float* __restrict__ depth_out,
-                                                        int* __restrict__ n_out) {
+                                                        int* __restrict__ n_out, int sampled) {
   __shared__ int lds[17];
   int base_out = 0;
   for (int base = 0; base < n; base += blockDim.x) {
@@ -58,7 +58,9 @@ __global__ __launch_bounds__(1024) void k_static_filter(int n, const float* __re
         const float d = depth[o];
         if (!(d > th_depth || d <= 0)) {
           fxe = flow[2 * o]; fye = flow[2 * o + 1];
-          if (fxe != 0 && fye != 0 && px + fxe < w && py + fye < h && px < w && py < h) { keep = 1; dd = d > 0 ? d : -1.f; }
+          // ORB branch (Frame.cc:116-124): destination right/bottom bounds only; sampled branch (:156-160): all four sides
+          const bool inb = sampled ? (px + fxe < w && py + fye < h && px + fxe > 0 && py + fye > 0) : (px + fxe < w && py + fye < h && px < w && py < h);
+          if (fxe != 0 && fye != 0 && inb) { keep = 1; dd = d > 0 ? d : -1.f; }
         }
       }
     }
@@ -209,8 +211,51 @@ extern "C" int vdo_frame_images_depth_preprocess(vdo_frame_images* f, float bf, 
   return vdo_depth_preprocess(f->ctx, f->d_depth, (int64_t)f->w * f->h, bf, depth_map_factor, 1);
 }
 
+static int static_filter_impl(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth, int sampled,
+                              int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int* n_out);
+
 extern "C" int vdo_frame_static_filter(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth,
                                        int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int* n_out) {
+  return static_filter_impl(f, n, kx, ky, th_depth, 0, keep_idx, corr_x, corr_y, flow_x, flow_y, depth_out, n_out);
+}
+extern "C" int vdo_frame_static_filter_sampled(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth,
+                                               int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int* n_out) {
+  return static_filter_impl(f, n, kx, ky, th_depth, 1, keep_idx, corr_x, corr_y, flow_x, flow_y, depth_out, n_out);
+}
+
+// Frame::SampleKeyPoints (src/Frame.cc:672-737): N = 3000 random integer positions over a 20 x 20 grid, cv::RNG(seed) (the reference
+// seeds with time(NULL): any seed is "the reference"), output in grid-cell order.  Host only.
+extern "C" int vdo_sample_keypoints(int rows, int cols, uint64_t seed, int capacity, float* x_out, float* y_out, int* n_out) {
+  if (rows <= 0 || cols <= 0 || !x_out || !y_out || !n_out) return set_error(VDO_ERR_INVALID, "vdo_sample_keypoints: bad argument");
+  const int N = 3000, n_div = 20;
+  if (capacity < N) return set_error(VDO_ERR_INVALID, "vdo_sample_keypoints: capacity %d < %d", capacity, N);
+  if (cols < n_div || rows < n_div) return set_error(VDO_ERR_INVALID, "vdo_sample_keypoints: image smaller than the grid");
+  uint64_t state = seed ? seed : 0xffffffffULL;                                    // cv::RNG (MWC, operations.hpp)
+  auto next = [&]() -> unsigned { state = (uint64_t)(unsigned)state * 4164903690U + (unsigned)(state >> 32); return (unsigned)state; };
+  auto uniform = [&](int a, int b) -> int { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); };
+  std::vector<std::vector<float> > gx(n_div * n_div), gy(n_div * n_div);
+  const int x_step = cols / n_div, y_step = rows / n_div;
+  int key_num = 0;
+  while (key_num < N) {
+    bool done = false;
+    for (int i = 0; i < n_div && !done; ++i)
+      for (int j = 0; j < n_div; ++j) {
+        const float x = (float)uniform(i * x_step, (i + 1) * x_step);
+        const float y = (float)uniform(j * y_step, (j + 1) * y_step);
+        if (x >= cols || y >= rows || x <= 0 || y <= 0) continue;
+        gx[i * n_div + j].push_back(x); gy[i * n_div + j].push_back(y);
+        if (++key_num >= N) { done = true; break; }
+      }
+  }
+  int n = 0;
+  for (int c = 0; c < n_div * n_div; ++c)
+    for (size_t k = 0; k < gx[c].size(); ++k) { x_out[n] = gx[c][k]; y_out[n] = gy[c][k]; ++n; }
+  *n_out = n;
+  return VDO_OK;
+}
+
+static int static_filter_impl(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth, int sampled,
+                              int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int* n_out) {
   if (!f || !n_out || n < 0 || 10 * (size_t)n > 8 * (size_t)f->cap) return set_error(VDO_ERR_INVALID, "bad argument / too many keypoints for the staging buffer");
   *n_out = 0;
   if (n == 0) return VDO_OK;
@@ -223,7 +268,7 @@ extern "C" int vdo_frame_static_filter(vdo_frame_images* f, int n, const float* 
   std::memcpy(pin, kx, 4 * (size_t)n); std::memcpy(pin + n, ky, 4 * (size_t)n);
   hipMemcpy2DAsync(f->d_f[7], 4 * (size_t)f->cap, pin, 4 * (size_t)n, 4 * (size_t)n, 2, hipMemcpyHostToDevice, s);
   hipLaunchKernelGGL(k_static_filter, dim3(1), dim3(1024), 0, s, n, (const float*)f->d_f[7], (const float*)f->d_i[1], (const int32_t*)f->d_mask,
-                     (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, th_depth, f->d_i[0], f->d_f[0], f->d_f[1], f->d_f[2], f->d_f[3], f->d_f[4], f->d_cnt);
+                     (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, th_depth, f->d_i[0], f->d_f[0], f->d_f[1], f->d_f[2], f->d_f[3], f->d_f[4], f->d_cnt, sampled);
   int* pcnt = (int*)(pin + (size_t)8 * f->cap);
   float* stage = pin + 2 * (size_t)n;          // behind the inputs (the H2D above is stream-ordered before the D2H)
   hipMemcpyAsync(pcnt, f->d_cnt, 4, hipMemcpyDeviceToHost, s);

@@ -92,7 +92,7 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
   if (vdo_orb_create(ctx_orb ? ctx_orb : ctx, &op, p.width, p.height, &orb_) != VDO_OK) return;
   for (int k = 0; k < 2; ++k) if (vdo_frame_images_create(ctx, p.width, p.height, &img_[k]) != VDO_OK) return;
   if (vdo_tracks_create(0, &tr_sta_) != VDO_OK || vdo_tracks_create(1, &tr_dyn_) != VDO_OK) return;
-  const int capk = p.n_features + 256;
+  const int capk = std::max(p.n_features + 256, 3008);           // (SampleKeyPoints yields 3000)
   kx_.resize(capk); ky_.resize(capk); kr_.resize(capk); ka_.resize(capk); ks_.resize(capk); ko_.resize(capk);
   for (int i = 0; i < 16; ++i) Tcw_last_[i] = vel_[i] = (i % 5 == 0) ? 1.f : 0.f;
   if (p.build_lm) {
@@ -128,7 +128,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   struct Join { Worker* w; ~Join() { if (w) w->wait(); } } join_guard{worker_.get()};      // never leave Step with the helper thread on its locals
   // ---- ORB (K3-K7) needs only the grey image: with a stream of its own its device stage starts now, under the camera stage
   vdo_keypoints kp{(int32_t)kx_.size(), 0, kx_.data(), ky_.data(), kr_.data(), ka_.data(), ks_.data(), ko_.data()};
-  if (orb_split_) VDO_TRY(vdo_orb_extract_begin(orb_, d_gray, W, host_inputs_ ? 0 : 1));
+  if (orb_split_ && !p_.use_sample_feature) VDO_TRY(vdo_orb_extract_begin(orb_, d_gray, W, host_inputs_ ? 0 : 1));
   // ---- deferred mode: the object stage of the PREVIOUS frame ends during this frame's camera stage + ORB front-end (nothing
   // there depends on the object set) - on the helper thread if there is one, else right after ORB on this thread
   bool fin_async = false;
@@ -201,7 +201,11 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   tick(0);
   // ---- camera pose (K16) on the LM stream, front-end of this frame meanwhile      Tracking.cc:690-700 || Frame.cc:61-260
   if (cam) VDO_TRY(vdo_flow2_batch_run(cam));
-  if (orb_split_) VDO_TRY(vdo_orb_extract_end(orb_, &kp));
+  if (p_.use_sample_feature) {                           // Option II of Frame::Frame (src/Frame.cc:132-166): random samples instead of ORB
+    int ns = 0;
+    VDO_TRY(vdo_sample_keypoints(H, W, (uint64_t)(p_.sample_seed + f_id_), kp.capacity, kx_.data(), ky_.data(), &ns));
+    kp.n = ns;
+  } else if (orb_split_) VDO_TRY(vdo_orb_extract_end(orb_, &kp));
   else VDO_TRY(vdo_orb_extract(orb_, d_gray, W, host_inputs_ ? 0 : 1, &kp));
   fc.n_orb = kp.n;
   tick(1);
@@ -212,7 +216,8 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   auto frame_filters = [&]() -> int {
     keep.resize(std::max(kp.n, 1));
     for (int k = 2; k < 7; ++k) f_[k].resize(std::max(kp.n, 1));
-    VDO_TRY(vdo_frame_static_filter(cur, kp.n, kx_.data(), ky_.data(), p_.th_depth_bg, keep.data(), f_[2].data(), f_[3].data(), f_[4].data(), f_[5].data(), f_[6].data(), &n_new_s));
+    VDO_TRY((p_.use_sample_feature ? vdo_frame_static_filter_sampled : vdo_frame_static_filter)(cur, kp.n, kx_.data(), ky_.data(), p_.th_depth_bg, keep.data(), f_[2].data(), f_[3].data(),
+                                                                                                  f_[4].data(), f_[5].data(), f_[6].data(), &n_new_s));
     fc.n_static_new = n_new_s;
     const int cap_s = ((W + 3) / 4) * ((H + 3) / 4);
     tmp.x.resize(cap_s); tmp.y.resize(cap_s); tmp.cx.resize(cap_s); tmp.cy.resize(cap_s); tmp.fx.resize(cap_s); tmp.fy.resize(cap_s); tmp.d.resize(cap_s); tmp.sem.resize(cap_s);
@@ -292,7 +297,15 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     nsta.x.resize(cs); nsta.y.resize(cs); nsta.cx.resize(cs); nsta.cy.resize(cs); nsta.fx.resize(cs); nsta.fy.resize(cs); nsta.d.resize(cs);
     sta_asso.resize(cs);
     int m = 0;
-    VDO_TRY(vdo_renew_static(cur, n_s, tm.data(), cur_sx.data(), cur_sy.data(), kp.n, kx_.data(), ky_.data(), p_.max_track_bg,
+    // top-up source: every ORB keypoint, or - UseSampleFeature - the filtered samples mvStatKeysTmp (Tracking.cc:2718-2721)
+    int n_src = kp.n;
+    const float *src_x = kx_.data(), *src_y = ky_.data();
+    if (p_.use_sample_feature) {
+      f_[13].resize(std::max(n_new_s, 1)); f_[14].resize(std::max(n_new_s, 1));
+      for (int i = 0; i < n_new_s; ++i) { f_[13][i] = kx_[keep[i]]; f_[14][i] = ky_[keep[i]]; }
+      n_src = n_new_s; src_x = f_[13].data(); src_y = f_[14].data();
+    }
+    VDO_TRY(vdo_renew_static(cur, n_s, tm.data(), cur_sx.data(), cur_sy.data(), n_src, src_x, src_y, p_.max_track_bg,
                              nsta.x.data(), nsta.y.data(), nsta.cx.data(), nsta.cy.data(), nsta.fx.data(), nsta.fy.data(), sta_asso.data(), nsta.d.data(), &m));
     for (auto* v : {&nsta.x, &nsta.y, &nsta.cx, &nsta.cy, &nsta.fx, &nsta.fy, &nsta.d}) v->resize(m);
     sta_asso.resize(m);

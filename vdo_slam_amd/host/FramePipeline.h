@@ -35,6 +35,9 @@ struct PipelineParams {
   int defer_objects;                 // 1: Step() returns with the object LMs of the frame in flight; their results (object motions, renewed object
                                      //    set, dynamic tracklets) are consumed inside the next Step() - after that frame's camera stage and ORB
                                      //    front-end, which do not depend on them - or by Flush().  Same results, one frame of latency for the objects.
+  int use_sample_feature;            // UseSampleFeature (omd.yaml): Frame::SampleKeyPoints (3000 random grid positions) instead of ORB, the static
+  int sample_seed;                   //    filter's sampled branch, top-up from the filtered samples; cv::RNG seed of frame f = sample_seed + f
+                                     //    (the reference seeds with time(NULL))
   int window_size, overlap_size;     // WINDOW_SIZE / OVERLAP_SIZE: with a Map attached, Optimizer::PartialBatchOptimization runs on the last
                                      //    window_size frames whenever (f_id-overlap+1) % (window-overlap) == 0 && f_id >= window-1
                                      //    (src/Tracking.cc:1169-1183); 0 = never
