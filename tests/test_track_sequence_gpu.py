@@ -191,3 +191,44 @@ def test_every_lm_problem_of_the_noisy_sequence(oracle):
         assert np.array_equal(r["inliers"], inl)
         assert np.abs(r["T"] - T).max() <= 1e-9 * max(1.0, np.abs(T[:3, 3]).max())
     b.close()
+
+
+@pytest.mark.parametrize("scenario", ["no_objects", "ten_objects", "blind_frame"])
+def test_track_sequence_edge_cases_match_the_oracle(oracle, scenario):
+    """No object in the scene; more objects than object-LM slots (8); a frame whose depth map is entirely invalid (no static
+    feature survives, tracking restarts from nothing on the next frame).  GPU Track() == oracle Track(), no failure."""
+    import torch
+    from tests.pipeline_ref import OraclePipeline
+    n_frames = 5
+    Ts = SQ.camera_poses(n_frames)
+    if scenario == "ten_objects":
+        objs = [dict(c=np.array([-6.6 + 1.2 * j, 0.9, 9.0 + 1.5 * (j % 3)]), hw=0.45, hh=0.6, v=np.array([0.0, 0.0, 0.7 + 0.015 * j])) for j in range(12)]
+    elif scenario == "no_objects":
+        objs = []
+    else:
+        objs = SQ.default_objects()
+    ctx, ctx_lm, ctx_obj, ctx_w = Context(0), Context(0), Context(0), Context(0)
+    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1), ctx_obj, ctx_w)
+    ref = OraclePipeline(oracle, build_lm=True)
+    keys = ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects", "n_static_tracks", "n_dynamic_tracks",
+            "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations")
+    seen_objects = 0
+    for k in range(n_frames):
+        fr = SQ.render_frame(k, Ts, objs, flow_sigma=0.05)
+        if scenario == "blind_frame" and k == 2:
+            fr["depth_raw"][:] = 0.0
+        d = {q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")}
+        torch.cuda.synchronize()
+        got = pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
+        exp = ref.step(fr)
+        assert {q: got[q] for q in keys} == {q: exp[q] for q in keys}, (scenario, k, got, exp)
+        np.testing.assert_allclose(pipe.pose(), ref.Tl, rtol=0, atol=5e-6)
+        assert len(pipe.motions()) == len(ref.motions) or k == 0
+        seen_objects = max(seen_objects, got["n_objects"])
+        if scenario == "blind_frame" and k == 2:
+            assert got["n_static_new"] == 0 and got["n_object_samples"] == 0
+    if scenario == "no_objects":
+        assert seen_objects == 0 and got["n_object_tracked"] == 0
+    if scenario == "ten_objects":
+        assert seen_objects >= 9 and len(pipe.motions()) <= 8         # 9-10 accepted objects, 8 object-LM slots: the rest keep their point sets untracked
+    pipe.close()

@@ -468,6 +468,7 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
   std::vector<int32_t> dyn_asso;
   float Twc[16];
   inv_rigid(Tcw, Twc);
+  motions_.clear();                                      // (a frame without tracked objects reports none)
   {
     // ---- consume the object results, RenewFrameInfo (objects)                      Tracking.cc:2806-2995
     std::vector<float>&cur_ox = f_[11], &cur_oy = f_[12];
@@ -486,7 +487,6 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
       }
       VDO_TRY(vdo_flow2_batch_fetch(obj, rs.data(), fop, iop));
       inl_off_.assign(1, 0); inl_idx_.clear();
-      motions_.clear();
       float Twc_c[16];
       inv_rigid(Tcw, Twc_c);
       for (int a = 0; a < n_objects; ++a) {
