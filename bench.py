@@ -39,7 +39,7 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~
 N_DISTINCT_FRAMES = 4   # make_frame_inputs(): independent random frames (tools/frame_probe.py)
 # SURVEY.md 8d "synthetic inputs": flow noise N(0, 0.3^2) px, 2 % invalid depth, 1 % exactly-zero flow, 5 moving objects, one
 # instance mask missing for two frames (exercises UpdateMask)
-FLOW_SIGMA, INVALID_DEPTH, ZERO_FLOW, N_OBJECTS, DROP_MASKS = 0.3, 0.02, 0.01, 5, {30: {2}, 31: {2}}
+FLOW_SIGMA, INVALID_DEPTH, ZERO_FLOW, N_OBJECTS, DROP_MASKS, BOX_DEPTH = 0.3, 0.02, 0.01, 5, {30: {2}, 31: {2}}, 0.9
 MAX_SEQ_FRAMES = 160    # length of the consistent synthetic sequence (the objects stay in view that long)
 
 
@@ -165,7 +165,7 @@ def main():
     W, H = synth.KITTI_W, synth.KITTI_H
     n_seq = min(args.steps + args.warmup, MAX_SEQ_FRAMES)
     Ts = SQ.camera_poses(n_seq)
-    objs = SQ.default_objects(N_OBJECTS)
+    objs = SQ.default_objects(N_OBJECTS, box_depth=BOX_DEPTH)         # axis-aligned boxes (2 x 0.9 m deep), not planar panels
     frames = [SQ.render_frame(k, Ts, objs, flow_sigma=FLOW_SIGMA, seed=17 * rank, invalid_depth=INVALID_DEPTH, zero_flow=ZERO_FLOW, drop_masks=DROP_MASKS)
               for k in range(n_seq)]
     dev = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames]
@@ -240,7 +240,7 @@ def main():
                                "RANSAC-P3P + motion-model initialisers, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, "
                                "joint pose+flow LM for the camera (<=1200 matches) and every tracked object (ref_quirks=1) built from the frame's own correspondences, "
                                "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets; "
-                               f"geometrically consistent synthetic sequence of {n_seq} frames: {N_OBJECTS} moving objects, flow noise sigma {FLOW_SIGMA} px, "
+                               f"geometrically consistent synthetic sequence of {n_seq} frames: {N_OBJECTS} moving boxes, flow noise sigma {FLOW_SIGMA} px, "
                                f"{INVALID_DEPTH:.0%} invalid depth, {ZERO_FLOW:.0%} zero flow, one instance mask missing in frames {sorted(DROP_MASKS)}",
                    "parallelism": f"replicas x{world}; {4 + (ctx_orb is not None)} HIP streams per replica: camera LM (2) || ORB front-end ({5 if ctx_orb is not None else 1}); object LMs (3) || RenewFrameInfo (1) and - "
                                   f"defer_objects={defer} - the next frame's camera stage; every LM problem runs on a cluster of up to 8 workgroups; "

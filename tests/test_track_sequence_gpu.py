@@ -130,7 +130,7 @@ def test_noisy_sequence_with_invalid_pixels_and_a_dropped_mask_matches_the_oracl
     from tests.pipeline_ref import OraclePipeline
     n_frames = 9
     Ts = SQ.camera_poses(n_frames)
-    objs = SQ.default_objects(5)
+    objs = SQ.default_objects(5, box_depth=0.9)          # boxes: the objects have depth structure
     drop = {5: {2}, 6: {2}}
     ctx, ctx_lm, ctx_obj, ctx_w = Context(0), Context(0), Context(0), Context(0)
     pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1), ctx_obj, ctx_w)

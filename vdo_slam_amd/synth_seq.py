@@ -23,14 +23,18 @@ def camera_poses(n_frames, step=0.8, yaw_amp=0.004):
     return Ts
 
 
-def default_objects(n=3):
-    """(centre xyz at frame 0 [m], half width, half height, velocity per frame [m]); n = 3 or 5 objects."""
+def default_objects(n=3, box_depth=0.0):
+    """(centre xyz at frame 0 [m], half width, half height, velocity per frame [m]); n = 3 or 5 objects.
+    box_depth > 0: axis-aligned boxes of that half depth ("hd") instead of fronto-parallel panels."""
     # velocities close to the camera's 0.8 m/frame: the objects stay inside ThDepthObj for ~100 frames
-    return [dict(c=np.array([-3.0, 0.9, 14.0]), hw=1.1, hh=0.75, v=np.array([0.0, 0.0, 0.9])),
+    objs = [dict(c=np.array([-3.0, 0.9, 14.0]), hw=1.1, hh=0.75, v=np.array([0.0, 0.0, 0.9])),
             dict(c=np.array([2.5, 0.85, 10.0]), hw=1.0, hh=0.8, v=np.array([0.01, 0.0, 0.76])),
             dict(c=np.array([5.0, 0.9, 19.0]), hw=1.2, hh=0.75, v=np.array([-0.02, 0.0, 0.85]))] + ([] if n <= 3 else [
             dict(c=np.array([-6.0, 0.8, 9.0]), hw=0.9, hh=0.85, v=np.array([0.0, 0.0, 0.82])),
             dict(c=np.array([0.3, 0.95, 21.0]), hw=1.3, hh=0.7, v=np.array([0.015, 0.0, 0.7]))])
+    if box_depth > 0:
+        objs = [dict(ob, hd=box_depth) for ob in objs]
+    return objs
 
 
 def render_frame(k, Ts, objects, w=KITTI_W, h=KITTI_H, K4=KITTI_K, flow_sigma=0.0, seed=0, invalid_depth=0.0, zero_flow=0.0, drop_masks=None):
@@ -59,11 +63,18 @@ def render_frame(k, Ts, objects, w=KITTI_W, h=KITTI_H, K4=KITTI_K, flow_sigma=0.
             yy = o[1] + sv * d[..., 1]
             hit((np.abs(d[..., 0]) > 1e-9) & (yy > -6.0) & (yy < 1.65), sv)
         hit(d[..., 2] > 1e-9, (400.0 - o[2]) / d[..., 2])                              # back wall far beyond ThDepthBG
-        for j, ob in enumerate(objects):                                               # panels z = const, facing the camera
+        for j, ob in enumerate(objects):
             c = ob["c"] + k * ob["v"]
-            sv = (c[2] - o[2]) / d[..., 2]
-            px = o[0] + sv * d[..., 0]; py = o[1] + sv * d[..., 1]
-            upd = hit((d[..., 2] > 1e-9) & (np.abs(px - c[0]) < ob["hw"]) & (np.abs(py - c[1]) < ob["hh"]), sv)
+            hd = ob.get("hd", 0.0)
+            if hd <= 0:                                                                # panel z = const, facing the camera
+                sv = (c[2] - o[2]) / d[..., 2]
+                px = o[0] + sv * d[..., 0]; py = o[1] + sv * d[..., 1]
+                upd = hit((d[..., 2] > 1e-9) & (np.abs(px - c[0]) < ob["hw"]) & (np.abs(py - c[1]) < ob["hh"]), sv)
+            else:                                                                      # axis-aligned box (slab method): front, sides and top are seen
+                lo = c - np.array([ob["hw"], ob["hh"], hd]); hi = c + np.array([ob["hw"], ob["hh"], hd])
+                t1 = (lo - o) / d; t2 = (hi - o) / d
+                tn = np.nanmax(np.minimum(t1, t2), axis=-1); tf = np.nanmin(np.maximum(t1, t2), axis=-1)
+                upd = hit((tn <= tf) & (tf > 0), tn)
             label = np.where(upd, j + 1, label)
     depth = s                                                                          # z-depth in the camera frame (ray z = 1)
     Xw = o + depth[..., None] * d
