@@ -30,6 +30,44 @@ struct RNG {
   int uniform(int a, int b) { return a == b ? a : (int)(next() % (unsigned)(b - a) + a); }
 };
 
+inline double from_bits(uint64_t b) { double d; std::memcpy(&d, &b, 8); return d; }
+inline uint64_t to_bits(double d) { uint64_t b; std::memcpy(&b, &d, 8); return b; }
+
+// Cube root and the largest root of a three-real-root depressed cubic written with +, -, *, / and sqrt only (IEEE, correctly
+// rounded everywhere) and integer arithmetic on the exponent field - deliberately NOT std::cbrt / std::cos / std::acos: the
+// GPU build (vdo_slam_amd/csrc/ransac.hip) runs the same sequence of operations, and libm and the device maths library do not
+// round their transcendentals alike.  With this the RANSAC pose is the same bit pattern on both sides.
+double cbrt_exact(double x) {
+  if (x == 0 || x != x) return x;
+  uint64_t bits = to_bits(x);
+  const uint64_t sign = bits & 0x8000000000000000ULL;
+  bits &= 0x7fffffffffffffffULL;
+  int bexp = (int)(bits >> 52), adj = 0;
+  if (bexp == 0x7ff) return x;
+  if (bexp == 0) { bits = to_bits(from_bits(bits) * 18014398509481984.0 /* 2^54 */); bexp = (int)(bits >> 52); adj = -18; }
+  const int e = bexp - 1023;
+  const int k = (e >= 0 ? e : e - 2) / 3, r = e - 3 * k;
+  const uint64_t frac = bits & 0x000fffffffffffffULL;
+  const double f = from_bits(frac | (1023ULL << 52));
+  const double m = from_bits(frac | ((uint64_t)(1023 + r) << 52));
+  double y = (1.0 + (f - 1.0) * 0.26) * (r == 0 ? 1.0 : r == 1 ? 1.2599210498948732 : 1.5874010519681994);
+  for (int it = 0; it < 6; ++it) y = y - (y * y * y - m) / (3.0 * (y * y));
+  const double s = from_bits((uint64_t)(1023 + k + adj) << 52);
+  return from_bits(to_bits(y * s) | sign);
+}
+
+double cubic3_largest_root(double P, double Q) {
+  double t = 2 * std::sqrt(-P / 3);
+  for (int it = 0; it < 64; ++it) {
+    const double f = (t * t + P) * t + Q, fp = 3 * (t * t) + P;
+    if (!(fp > 0)) break;
+    const double tn = t - f / fp;
+    if (!(tn < t)) break;
+    t = tn;
+  }
+  return t;
+}
+
 // real roots of x^4 + b x^3 + c x^2 + d x + e (Ferrari via the resolvent cubic), polished by Newton
 int solve_quartic_monic(double b, double c, double d, double e, double* roots) {
   const double p = c - 3 * b * b / 8, q = d - b * c / 2 + b * b * b / 8, r = e - b * d / 4 + b * b * c / 16 - 3 * b * b * b * b / 256;
@@ -51,12 +89,9 @@ int solve_quartic_monic(double b, double c, double d, double e, double* roots) {
     double t;
     if (disc >= 0) {
       const double s = std::sqrt(disc);
-      t = std::cbrt(-Q / 2 + s) + std::cbrt(-Q / 2 - s);
+      t = cbrt_exact(-Q / 2 + s) + cbrt_exact(-Q / 2 - s);
     } else {
-      const double m = 2 * std::sqrt(-P / 3);
-      double arg = 3 * Q / (P * m);
-      arg = std::min(1.0, std::max(-1.0, arg));
-      t = m * std::cos(std::acos(arg) / 3);          // largest root
+      t = cubic3_largest_root(P, Q);                 // largest root
     }
     double z = t - A / 3;
     for (int it = 0; it < 3; ++it) {                  // Newton on the cubic
@@ -178,6 +213,8 @@ int update_num_iters(double p, double ep, int model_points, int max_iters) {
 }  // namespace
 
 // KAT helpers
+extern "C" double vdo_oracle_cbrt_exact(double x) { return cbrt_exact(x); }
+extern "C" double vdo_oracle_cubic3_largest_root(double P, double Q) { return cubic3_largest_root(P, Q); }
 extern "C" int vdo_oracle_quartic(double a4, double a3, double a2, double a1, double a0, double* roots) {
   return solve_quartic_monic(a3 / a4, a2 / a4, a1 / a4, a0 / a4, roots);
 }

@@ -14,9 +14,38 @@ dp = K.c_double_p
 def _bind(o):
     o.vdo_oracle_quartic.argtypes = [C.c_double] * 5 + [dp]
     o.vdo_oracle_p3p.argtypes = [dp, dp, dp, dp]
+    o.vdo_oracle_cbrt_exact.argtypes = [C.c_double]; o.vdo_oracle_cbrt_exact.restype = C.c_double
+    o.vdo_oracle_cubic3_largest_root.argtypes = [C.c_double, C.c_double]; o.vdo_oracle_cubic3_largest_root.restype = C.c_double
     o.vdo_oracle_ransac_subsets.argtypes = [C.c_int, C.c_int, K.c_int32_p]
     o.vdo_oracle_p3p_ransac.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_double, C.c_double, dp, K.c_uint8_p, K.c_int32_p, K.c_int32_p]
     return o
+
+
+def test_libm_free_cube_root_and_cubic(oracle):
+    """The +,-,*,/,sqrt-only routines the oracle and the GPU share (bit-identical RANSAC poses): within 2 ulp of cbrt over
+    the whole exponent range incl. subnormals, signs and specials; the Newton-from-the-right root equals the trigonometric
+    largest root of a three-real-root cubic."""
+    o = _bind(oracle)
+    rng = np.random.default_rng(1)
+    xs = np.concatenate([rng.uniform(-10, 10, 2000), 10.0 ** rng.uniform(-320, 300, 2000) * rng.choice([-1, 1], 2000),
+                         [1.0, 8.0, 27.0, -64.0, 1e-310, -4e-320, 2.0 ** -1074, 1.7e308]])
+    for x in xs:
+        got, ref = o.vdo_oracle_cbrt_exact(float(x)), np.cbrt(x)
+        assert abs(got - ref) <= 2 * np.spacing(abs(ref)), (x, got, ref)
+    assert o.vdo_oracle_cbrt_exact(0.0) == 0.0 and np.isinf(o.vdo_oracle_cbrt_exact(np.inf)) and np.isnan(o.vdo_oracle_cbrt_exact(np.nan))
+    assert o.vdo_oracle_cbrt_exact(27.0) == 3.0 and o.vdo_oracle_cbrt_exact(-8.0) == -2.0
+    for _ in range(2000):
+        r = np.sort(rng.uniform(-5, 5, 2) * 10.0 ** rng.uniform(-3, 3))
+        r3 = -(r[0] + r[1])                                  # depressed: the roots sum to zero
+        roots = np.array([r[0], r[1], r3])
+        P = roots[0] * roots[1] + roots[0] * roots[2] + roots[1] * roots[2]
+        Q = -roots.prod()
+        if not (Q * Q / 4 + P * P * P / 27 < 0):
+            continue
+        t = o.vdo_oracle_cubic3_largest_root(float(P), float(Q))
+        big = roots.max()
+        gap = big - np.sort(roots)[1]
+        assert abs(t - big) <= 1e-9 * abs(big) * max(1.0, abs(big) / max(gap, 1e-300) * 1e-3), (roots, t)
 
 
 def test_quartic_roots_match_numpy(oracle):

@@ -1,5 +1,6 @@
 """GPU RANSAC initialiser (vdo_slam_amd/csrc/ransac.hip) against the oracle's sequential run: same winning
-hypothesis, same number of iterations examined, same inlier set; pose to 1e-9."""
+hypothesis, same number of iterations examined, same inlier set, and the SAME BITS in the pose (the cubic/cube-root of the
+minimal solver is written with IEEE-exact operations only on both sides)."""
 import ctypes as C
 import time
 
@@ -40,7 +41,7 @@ def test_batch_matches_the_sequential_oracle(oracle):
         e = _oracle(o, Xw, uv)
         assert g["n_inliers"] == e["n_inliers"] and g["iterations_run"] == e["iterations_run"] and g["best_iteration"] == e["best_iteration"], (n, g, e)
         assert np.array_equal(g["inliers"], e["inliers"])
-        assert np.abs(g["T"] - e["T"]).max() < 1e-9
+        assert np.array_equal(g["T"], e["T"]), (n, np.abs(g["T"] - e["T"]).max())
     assert got[0]["n_inliers"] > 700 and got[0]["iterations_run"] < 500
     assert got[6]["n_inliers"] == 0 and np.array_equal(got[6]["T"], np.eye(4))
 
@@ -56,6 +57,7 @@ def test_pure_outliers_run_the_full_budget(oracle):
     e = _oracle(o, Xw, uv)
     assert g["iterations_run"] == e["iterations_run"] == 500
     assert g["n_inliers"] == e["n_inliers"] and g["best_iteration"] == e["best_iteration"] and np.array_equal(g["inliers"], e["inliers"])
+    assert np.array_equal(g["T"], e["T"])
     t0 = time.perf_counter()
     for _ in range(20):
         pnp_ransac_batch(ctx, [(Xw, uv)], KITTI_K)

@@ -148,12 +148,10 @@ def test_noisy_sequence_with_invalid_pixels_and_a_dropped_mask_matches_the_oracl
         np.testing.assert_allclose(pipe.pose(), ref.Tl, rtol=0, atol=5e-6)
         ms, mo = pipe.motions(), ref.motions
         assert [(a["mod_label"], a["sem_label"], a["n_inliers"]) for a in ms] == [(b["mod_label"], b["sem_label"], b["n_inliers"]) for b in mo]
-        # Object motions: the LM of a distant, noisy object stops (reference stop rules) before it has converged, so its result
-        # depends on the seed at the 1e-2 level, and the seed is the float32 cast of the RANSAC-P3P pose (GPU and oracle agree on
-        # that pose to ~1e-10, i.e. not always on its float32 rounding).  The LM kernel itself is exact on these very problems:
-        # test_every_lm_problem_of_the_noisy_sequence below.
+        # Object motions: the north star's bar (1e-4 relative on SE(3) object motions).  The seeds agree bit for bit (RANSAC-P3P
+        # is IEEE-exact on both sides), so also the weakly constrained LMs of distant, noisy objects take the same path.
         for a, b in zip(ms, mo):
-            np.testing.assert_allclose(a["H"], b["H"], rtol=0, atol=2e-2 * max(1.0, float(np.abs(b["H"][:3, 3]).max())))
+            np.testing.assert_allclose(a["H"], b["H"], rtol=0, atol=1e-4 * max(1.0, float(np.abs(b["H"][:3, 3]).max())))
         recovered += got["n_recovered_masks"]
     assert recovered >= 1 and got["n_objects"] >= 3
     pipe.close()

@@ -33,6 +33,48 @@ __device__ __forceinline__ double d3dot(const double* a, const double* b) { retu
 __device__ __forceinline__ void d3cross(const double* a, const double* b, double* o) { o[0] = a[1] * b[2] - a[2] * b[1]; o[1] = a[2] * b[0] - a[0] * b[2]; o[2] = a[0] * b[1] - a[1] * b[0]; }
 __device__ __forceinline__ bool d3unit(double* a) { const double n = sqrt(d3dot(a, a)); if (!(n > 1e-300)) return false; a[0] /= n; a[1] /= n; a[2] /= n; return true; }
 
+// Cube root and the largest root of a depressed cubic from +, -, *, / and sqrt only (all correctly rounded on gfx950 and on
+// the host) plus exponent-field integer arithmetic: no libm/ocml transcendental, so that the CPU oracle
+// (oracle/p3p_oracle.cpp, same sequence of operations) gets the SAME BITS.  cbrt: a = m * 8^k with m in [1, 8), linear
+// seed, 6 Newton steps (the first brings the relative error below 1e-3, then it squares), exact scaling by 2^k.
+__device__ __forceinline__ double cbrt_exact(double x) {
+  if (x == 0 || x != x) return x;
+  unsigned long long bits = (unsigned long long)__double_as_longlong(x);
+  const unsigned long long sign = bits & 0x8000000000000000ULL;
+  bits &= 0x7fffffffffffffffULL;
+  int bexp = (int)(bits >> 52), adj = 0;
+  if (bexp == 0x7ff) return x;
+  if (bexp == 0) {                       // subnormal: scale by 2^54 (exact), take 2^-18 off the result
+    bits = (unsigned long long)__double_as_longlong(__longlong_as_double((long long)bits) * 18014398509481984.0);
+    bexp = (int)(bits >> 52); adj = -18;
+  }
+  const int e = bexp - 1023;
+  const int k = (e >= 0 ? e : e - 2) / 3, r = e - 3 * k;          // floor division: r in {0, 1, 2}
+  const unsigned long long frac = bits & 0x000fffffffffffffULL;
+  const double f = __longlong_as_double((long long)(frac | (1023ULL << 52)));            // [1, 2)
+  const double m = __longlong_as_double((long long)(frac | ((unsigned long long)(1023 + r) << 52)));   // [1, 8)
+  double y = (1.0 + (f - 1.0) * 0.26) * (r == 0 ? 1.0 : r == 1 ? 1.2599210498948732 : 1.5874010519681994);
+#pragma unroll
+  for (int it = 0; it < 6; ++it) y = y - (y * y * y - m) / (3.0 * (y * y));
+  const double s = __longlong_as_double((long long)((unsigned long long)(1023 + k + adj) << 52));
+  return __longlong_as_double((long long)((unsigned long long)__double_as_longlong(y * s) | sign));
+}
+
+// largest root of t^3 + P t + Q when it has three real roots (P < 0, Q^2/4 + P^3/27 < 0): it lies in [m/2, m], m = 2 sqrt(-P/3);
+// f is positive and convex on (root, m], so Newton from m decreases monotonically onto it; stop at the first step that does
+// not decrease (rounding noise) - a deterministic rule, the same on both sides.
+__device__ __forceinline__ double cubic3_largest_root(double P, double Q) {
+  double t = 2 * sqrt(-P / 3);
+  for (int it = 0; it < 64; ++it) {
+    const double f = (t * t + P) * t + Q, fp = 3 * (t * t) + P;
+    if (!(fp > 0)) break;
+    const double tn = t - f / fp;
+    if (!(tn < t)) break;
+    t = tn;
+  }
+  return t;
+}
+
 // real roots of x^4 + b x^3 + c x^2 + d x + e: depressed quartic, positive root of the resolvent cubic, two quadratics; Newton polish
 __device__ int quartic_real_roots(double b, double c, double d, double e, double* roots) {
   const double p = c - 3 * b * b / 8, q = d - b * c / 2 + b * b * b / 8, r = e - b * d / 4 + b * b * c / 16 - 3 * b * b * b * b / 256;
@@ -54,12 +96,9 @@ __device__ int quartic_real_roots(double b, double c, double d, double e, double
     double t;
     if (disc >= 0) {
       const double s = sqrt(disc);
-      t = cbrt(-Q / 2 + s) + cbrt(-Q / 2 - s);
+      t = cbrt_exact(-Q / 2 + s) + cbrt_exact(-Q / 2 - s);
     } else {
-      const double m = 2 * sqrt(-P / 3);
-      double arg = 3 * Q / (P * m);
-      arg = fmin(1.0, fmax(-1.0, arg));
-      t = m * cos(acos(arg) / 3);
+      t = cubic3_largest_root(P, Q);
     }
     double z = t - A / 3;
 #pragma unroll
