@@ -291,6 +291,12 @@ int vdo_orb_extract(vdo_orb* orb, const uint8_t* gray, int stride, int src_is_de
  * and returns at once, _end waits for it and runs the quadtrees (K5) - a caller overlaps other work with the device stage. */
 int vdo_orb_extract_begin(vdo_orb* orb, const uint8_t* gray, int stride, int src_is_device);
 int vdo_orb_extract_end(vdo_orb* orb, vdo_keypoints* out);
+/* K8 - rotated BRIEF, the `_descriptors` output of ORBextractor::operator() (computeOrbDescriptor src/ORBextractor.cc:97-136,
+ * pattern :139-397; the reference allocates the 32-byte rows but has the call commented out, :1083-1091).  vdo_orb_descriptors:
+ * descriptors of the keypoints the last vdo_orb_extract / _end returned, same order, host buffer [capacity_rows][32];
+ * vdo_orb_extract_desc = operator() with both outputs (desc32 nullable, [out->capacity][32]). */
+int vdo_orb_descriptors(vdo_orb* orb, uint8_t* desc32, int capacity_rows);
+int vdo_orb_extract_desc(vdo_orb* orb, const uint8_t* gray, int stride, int src_is_device, vdo_keypoints* out, uint8_t* desc32);
 /* Inspection of the last extraction (mvImagePyramid is a public member of the reference class). */
 int vdo_orb_level_info(vdo_orb* orb, int level, int* w, int* h, int* n_features, int* n_candidates);
 int vdo_orb_get_pyramid(vdo_orb* orb, int level, uint8_t* out_bordered /* (w+38)*(h+38) */);

@@ -323,6 +323,54 @@ float ic_angle(const Img& im, float px, float py, const int* umax) {
   return fast_atan2((float)m01, (float)m10);
 }
 
+void gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst);
+
+#include "orb_pattern.inc"
+
+// sin and cos of a float angle in [0, 2 pi] (what computeOrbDescriptor takes from cosf/sinf, src/ORBextractor.cc:101-102),
+// evaluated in double from +,-,* only - Cody-Waite reduction by pi/2 and Taylor polynomials on |r| <= pi/4 (truncation
+// < 1e-17) - and rounded to float: the correctly rounded float result except for double-rounding ties (~1e-9 of the
+// arguments), and the SAME BITS as the GPU build, which runs the same operations (device and glibc cosf differ).
+void sincos_exact(float angle, float* s_out, float* c_out) {
+  const double x = (double)angle;
+  const int k = (int)(x * 0.63661977236758138 + 0.5);
+  const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+  const double z = r * r;
+  const double sp = r * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880 + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0 +
+                    z * (-1.0 / 1307674368000.0 + z * (1.0 / 355687428096000.0)))))))));
+  const double cp = 1.0 + z * (-1.0 / 2 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800 + z * (1.0 / 479001600 +
+                    z * (-1.0 / 87178291200.0 + z * (1.0 / 20922789888000.0))))))));
+  double sn, cs;
+  switch (k & 3) {
+    case 0: sn = sp; cs = cp; break;
+    case 1: sn = cp; cs = -sp; break;
+    case 2: sn = -sp; cs = -cp; break;
+    default: sn = -cp; cs = sp; break;
+  }
+  *s_out = (float)sn; *c_out = (float)cs;
+}
+
+// computeOrbDescriptor (src/ORBextractor.cc:97-136): 256 rotated pair tests on the blurred level image.
+// `img` = the blurred clone of mvImagePyramid[level] (contiguous, step = w); (px, py) level coordinates; angle in degrees.
+void orb_descriptor(const uint8_t* img, int w, float px, float py, float angle_deg, uint8_t* desc) {
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  const float angle = angle_deg * factorPI;
+  float a, b;
+  sincos_exact(angle, &b, &a);                      // a = cos, b = sin
+  const uint8_t* center = img + (size_t)cv_round_f(py) * w + cv_round_f(px);
+  const signed char* pat = kRefBitPattern31;
+  for (int i = 0; i < 32; ++i, pat += 32) {
+    int val = 0;
+    for (int k = 0; k < 8; ++k) {
+      const float x0 = (float)pat[4 * k], y0 = (float)pat[4 * k + 1], x1 = (float)pat[4 * k + 2], y1 = (float)pat[4 * k + 3];
+      const int t0 = center[cv_round_f(x0 * b + y0 * a) * w + cv_round_f(x0 * a - y0 * b)];
+      const int t1 = center[cv_round_f(x1 * b + y1 * a) * w + cv_round_f(x1 * a - y1 * b)];
+      val |= (t0 < t1) << k;
+    }
+    desc[i] = (uint8_t)val;
+  }
+}
+
 }  // namespace
 
 extern "C" void vdo_oracle_depth_preprocess(float* depth, int64_t n, float bf, float factor) {
@@ -375,9 +423,10 @@ extern "C" int vdo_oracle_orb_fast_level(const uint8_t* gray, int w, int h, cons
   return (int)c.size();
 }
 
-// ORBextractor::operator(): keypoints of all levels (level-0 coordinates), returns count
-extern "C" int vdo_oracle_orb_extract(const uint8_t* gray, int w, int h, const vdo_orb_params* p,
-                                      float* kx, float* ky, float* kresp, float* kangle, int32_t* koct, float* ksize, int cap) {
+// ORBextractor::operator(): keypoints of all levels (level-0 coordinates), returns count.  desc (nullable): [cap][32] rotated
+// BRIEF of every keypoint on the blurred level image - the call the reference has commented out (src/ORBextractor.cc:1083-1091)
+extern "C" int vdo_oracle_orb_extract_desc(const uint8_t* gray, int w, int h, const vdo_orb_params* p,
+                                           float* kx, float* ky, float* kresp, float* kangle, int32_t* koct, float* ksize, int cap, uint8_t* desc) {
   std::vector<Img> lv;
   build_pyramid(gray, w, h, *p, lv);
   std::vector<int> ws, hs, nf; std::vector<float> sc;
@@ -392,10 +441,13 @@ extern "C" int vdo_oracle_orb_extract(const uint8_t* gray, int w, int h, const v
     const int minB = EDGE_THRESHOLD - 3;
     distribute(c, minB, lv[l].w - EDGE_THRESHOLD + 3, minB, lv[l].h - EDGE_THRESHOLD + 3, nf[l], sel);
     const int patch = (int)(PATCH_SIZE * sc[l]);
+    std::vector<uint8_t> working;
+    if (desc && !sel.empty()) { working.resize((size_t)lv[l].w * lv[l].h); gaussian_blur7(lv[l].d.data(), lv[l].w, lv[l].h, working.data()); }
     for (const Cand& k : sel) {
       if (n >= cap) return -1;
       const float x = k.x + minB, y = k.y + minB;
       const float ang = ic_angle(lv[l], x, y, umax);
+      if (desc) orb_descriptor(working.data(), lv[l].w, x, y, ang, desc + 32 * (size_t)n);
       float ox = x, oy = y;
       if (l != 0) { ox = x * sc[l]; oy = y * sc[l]; }
       kx[n] = ox; ky[n] = oy; kresp[n] = k.resp; kangle[n] = ang; koct[n] = l; ksize[n] = (float)patch;
@@ -405,9 +457,23 @@ extern "C" int vdo_oracle_orb_extract(const uint8_t* gray, int w, int h, const v
   return n;
 }
 
+extern "C" int vdo_oracle_orb_extract(const uint8_t* gray, int w, int h, const vdo_orb_params* p,
+                                      float* kx, float* ky, float* kresp, float* kangle, int32_t* koct, float* ksize, int cap) {
+  return vdo_oracle_orb_extract_desc(gray, w, h, p, kx, ky, kresp, kangle, koct, ksize, cap, nullptr);
+}
+
+// KAT hooks for the descriptor stage
+extern "C" void vdo_oracle_sincos_exact(float angle, float* s, float* c) { sincos_exact(angle, s, c); }
+extern "C" void vdo_oracle_orb_descriptor(const uint8_t* blurred, int w, float px, float py, float angle_deg, uint8_t* desc32) {
+  orb_descriptor(blurred, w, px, py, angle_deg, desc32);
+}
+extern "C" const signed char* vdo_oracle_orb_pattern(void) { return kRefBitPattern31; }
+
 // cv::GaussianBlur(src, dst, Size(7,7), 2, 2, BORDER_REFLECT_101) for CV_8UC1 (OpenCV 3.4.0 path:
 // separable filter with 8-bit fixed-point kernels, (sum + 2^15) >> 16)
-extern "C" void vdo_oracle_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst) {
+extern "C" void vdo_oracle_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst) { gaussian_blur7(src, w, h, dst); }
+namespace {
+void gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst) {
   double kd[7], sum = 0;
   for (int i = 0; i < 7; ++i) { const double x = i - 3; kd[i] = std::exp(-0.5 / (2.0 * 2.0) * x * x); sum += kd[i]; }
   int k[7];
@@ -427,6 +493,7 @@ extern "C" void vdo_oracle_gaussian_blur7(const uint8_t* src, int w, int h, uint
       dst[(size_t)y * w + x] = (uint8_t)std::min(255, std::max(0, v));
     }
 }
+}  // namespace
 
 // Frame::Frame static filter (UseSampleFea == 0 branch): returns count; outputs indexed by kept order
 extern "C" int vdo_oracle_frame_static_filter(int n, const float* kx, const float* ky, const int32_t* koct,

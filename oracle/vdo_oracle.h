@@ -184,6 +184,12 @@ int vdo_oracle_orb_fast_level(const uint8_t* gray, int w, int h, const vdo_orb_p
                               float* x, float* y, float* resp, int cap);
 int vdo_oracle_orb_extract(const uint8_t* gray, int w, int h, const vdo_orb_params* p,
                            float* kx, float* ky, float* kresp, float* kangle, int32_t* koct, float* ksize, int cap);
+/* the same + rotated BRIEF (computeOrbDescriptor, src/ORBextractor.cc:97-136; commented-out call site :1083-1091): desc [cap][32], nullable */
+int vdo_oracle_orb_extract_desc(const uint8_t* gray, int w, int h, const vdo_orb_params* p,
+                                float* kx, float* ky, float* kresp, float* kangle, int32_t* koct, float* ksize, int cap, uint8_t* desc);
+void vdo_oracle_sincos_exact(float angle, float* s, float* c);
+void vdo_oracle_orb_descriptor(const uint8_t* blurred, int w, float px, float py, float angle_deg, uint8_t* desc32);
+const signed char* vdo_oracle_orb_pattern(void);
 void vdo_oracle_gaussian_blur7(const uint8_t* src, int w, int h, uint8_t* dst);
 int vdo_oracle_frame_static_filter_sampled(int n, const float* kx, const float* ky, const int32_t* mask, const float* depth, const float* flow,
                                            int w, int h, float th_depth,

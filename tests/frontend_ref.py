@@ -50,6 +50,18 @@ def extract(o, gray, prm=PARAMS, cap=8192):
     return dict(x=a[0][:n], y=a[1][:n], response=a[2][:n], angle=a[3][:n], octave=octv[:n], size=a[4][:n])
 
 
+def extract_desc(o, gray, prm=PARAMS, cap=8192):
+    """extract() + the 32-byte rotated-BRIEF rows (oracle of K8)."""
+    h, w = gray.shape
+    a = [np.zeros(cap, np.float32) for _ in range(5)]
+    octv = np.zeros(cap, np.int32)
+    desc = np.zeros((cap, 32), np.uint8)
+    o.vdo_oracle_orb_extract_desc.argtypes = [K.c_uint8_p, C.c_int, C.c_int, C.POINTER(OrbParamsC)] + [K.c_float_p] * 4 + [K.c_int32_p, K.c_float_p, C.c_int, K.c_uint8_p]
+    n = o.vdo_oracle_orb_extract_desc(_u8(gray), w, h, C.byref(prm), _fp(a[0]), _fp(a[1]), _fp(a[2]), _fp(a[3]), _ip(octv), _fp(a[4]), cap, _u8(desc))
+    assert n >= 0
+    return dict(x=a[0][:n], y=a[1][:n], response=a[2][:n], angle=a[3][:n], octave=octv[:n], size=a[4][:n], desc=desc[:n])
+
+
 def blur7(o, img):
     img = np.ascontiguousarray(img)
     out = np.zeros_like(img)

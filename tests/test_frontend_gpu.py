@@ -44,6 +44,29 @@ def test_orb_matches_oracle_bit_exact(ctx, oracle, seed, shape):
     orb.close()
 
 
+@pytest.mark.parametrize("seed,shape", [(3, (375, 1242)), (4, (375, 1242)), (5, (480, 640))])
+def test_rotated_brief_descriptor_bits_match_oracle(ctx, oracle, seed, shape):
+    """K8: the 256 descriptor bits of every keypoint == oracle, through vdo_orb_extract_desc and through the
+    separate vdo_orb_descriptors call; keypoints unchanged by asking for descriptors."""
+    from vdo_slam_amd.frontend import ORBextractor
+    h, w = shape
+    gray = SF.make_gray(seed, w, h)
+    orb = ORBextractor(ctx, w, h)
+    kp = orb(gray, descriptors=True)
+    ref = R.extract_desc(oracle, gray)
+    n = ref["x"].size
+    assert n > 1500 and kp["desc"].shape == (n, 32)
+    for k in ("x", "y", "octave", "angle"):
+        assert np.array_equal(kp[k], ref[k]), k
+    assert np.array_equal(kp["desc"], ref["desc"]), int((kp["desc"] != ref["desc"]).any(axis=1).sum())
+    # not degenerate: bits are balanced and rows differ
+    bits = np.unpackbits(kp["desc"], axis=1)
+    assert 0.35 < bits.mean() < 0.65 and np.unique(kp["desc"], axis=0).shape[0] > 0.95 * n
+    kp2 = orb(gray)
+    assert np.array_equal(orb.descriptors(kp2["x"].size), ref["desc"])
+    orb.close()
+
+
 def test_depth_gray_and_frame_kernels_match_oracle(ctx, oracle):
     from vdo_slam_amd.frontend import FrameImages, ORBextractor, depth_preprocess, rgb2gray
     fr = SF.make_frame(seed=9)

@@ -102,3 +102,78 @@ def test_frame_filters_against_numpy(oracle, frame):
     ob = R.object_sample(oracle, frame["mask"], depth, frame["flow"], TH_DEPTH_OBJ)
     assert ob["label"].size > 100 and np.all(ob["label"] > 0)
     assert np.all(np.diff(ob["key_y"] * 4096 + ob["key_x"]) > 0)    # raster order
+
+
+def test_sincos_exact_is_the_correctly_rounded_float(oracle):
+    """The +,-,*-only sin/cos the descriptor stage uses on both sides: equal to the double-precision value rounded to float
+    (what a correctly rounded cosf/sinf returns) on all but double-rounding ties."""
+    import ctypes as C
+    oracle.vdo_oracle_sincos_exact.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    rng = np.random.default_rng(0)
+    ang = np.concatenate([rng.uniform(0, 2 * np.pi, 20000), np.arange(0, 361, 1) * np.float32(np.pi / 180), [0.0, np.float32(2 * np.pi)]]).astype(np.float32)
+    bad = 0
+    for a in ang:
+        s, c = C.c_float(), C.c_float()
+        oracle.vdo_oracle_sincos_exact(float(a), C.byref(s), C.byref(c))
+        es, ec = np.float32(np.sin(np.float64(a))), np.float32(np.cos(np.float64(a)))
+        assert abs(s.value - float(es)) <= np.spacing(abs(es)) and abs(c.value - float(ec)) <= np.spacing(abs(ec)), a
+        bad += (s.value != float(es)) + (c.value != float(ec))
+    assert bad <= 2, bad
+
+
+def test_brief_descriptor_against_a_brute_force_scalar_implementation(oracle):
+    """computeOrbDescriptor (src/ORBextractor.cc:97-136) restated with numpy float32 scalars: same 32 bytes; the pattern
+    table has the reference's shape (256 pairs inside the 31-px patch); rotation by 90 degrees moves the sample points as
+    a rotation of the image does."""
+    import ctypes as C
+    oracle.vdo_oracle_orb_descriptor.argtypes = [R._u8(np.zeros(1, np.uint8)).__class__, C.c_int, C.c_float, C.c_float, C.c_float, R._u8(np.zeros(1, np.uint8)).__class__]
+    oracle.vdo_oracle_orb_pattern.restype = C.POINTER(C.c_byte)
+    pat = np.ctypeslib.as_array(oracle.vdo_oracle_orb_pattern(), (1024,)).astype(np.int32).reshape(256, 4)
+    assert np.abs(pat).max() == 13 and (pat[:, 0] ** 2 + pat[:, 1] ** 2).max() <= 338 and np.unique(pat, axis=0).shape[0] == 256
+    assert tuple(pat[0]) == (8, -3, 9, 5) and tuple(pat[255]) == (-1, -6, 0, -11)          # first / last entry of bit_pattern_31_
+    rng = np.random.default_rng(3)
+    w, h = 96, 80
+    img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+    f32 = np.float32
+    factor = f32(np.pi / f32(180.0))
+    for _ in range(40):
+        px, py = f32(rng.integers(19, w - 19)), f32(rng.integers(19, h - 19))
+        ang = f32(rng.uniform(0, 360))
+        got = np.zeros(32, np.uint8)
+        oracle.vdo_oracle_orb_descriptor(R._u8(img), w, px, py, ang, R._u8(got))
+        rad = f32(ang * factor)
+        a, b = f32(np.cos(np.float64(rad))), f32(np.sin(np.float64(rad)))
+        exp = np.zeros(32, np.uint8)
+        for i in range(256):
+            x0, y0, x1, y1 = (f32(v) for v in pat[i])
+            def val(x, y):
+                r = int(np.rint(f32(f32(x * b) + f32(y * a)))); c = int(np.rint(f32(f32(x * a) - f32(y * b))))
+                return int(img[int(py) + r, int(px) + c])
+            exp[i // 8] |= (val(x0, y0) < val(x1, y1)) << (i % 8)
+        assert np.array_equal(got, exp), (px, py, ang)
+    # angle 0: unrotated pattern
+    got = np.zeros(32, np.uint8)
+    oracle.vdo_oracle_orb_descriptor(R._u8(img), w, 40.0, 40.0, 0.0, R._u8(got))
+    exp = np.packbits([img[40 + p[1], 40 + p[0]] < img[40 + p[3], 40 + p[2]] for p in pat], bitorder="little")
+    assert np.array_equal(got, exp)
+    # angle 90 on the image == angle 0 on the image rotated by -90 degrees about the keypoint
+    got90 = np.zeros(32, np.uint8)
+    oracle.vdo_oracle_orb_descriptor(R._u8(img), w, 40.0, 40.0, 90.0, R._u8(got90))
+    exp90 = np.packbits([img[40 + p[0], 40 - p[1]] < img[40 + p[2], 40 - p[3]] for p in pat], bitorder="little")
+    assert np.array_equal(got90, exp90)
+
+
+def test_extract_desc_keeps_the_keypoints_and_describes_on_the_blurred_level(oracle):
+    gray = SF.make_gray(2, 400, 240)
+    a, b = R.extract(oracle, gray), R.extract_desc(oracle, gray)
+    for k in a:
+        assert np.array_equal(a[k], b[k])
+    import ctypes as C
+    # first level-0 keypoint, recomputed by hand from the blurred level 0
+    inner = R.pyramid(oracle, gray)[0][19:-19, 19:-19]
+    blurred = R.blur7(oracle, inner)
+    i = int(np.flatnonzero(b["octave"] == 0)[0])
+    one = np.zeros(32, np.uint8)
+    oracle.vdo_oracle_orb_descriptor.argtypes = [R._u8(one).__class__, C.c_int, C.c_float, C.c_float, C.c_float, R._u8(one).__class__]
+    oracle.vdo_oracle_orb_descriptor(R._u8(blurred), blurred.shape[1], float(b["x"][i]), float(b["y"][i]), float(b["angle"][i]), R._u8(one))
+    assert np.array_equal(one, b["desc"][i])

@@ -4,6 +4,8 @@
 //   K5 DistributeOctTree       :470-752    quadtree, best response per node      (host C++, sequential by nature)
 //   K6 IC_Angle                :66-93      31x31 circular patch moments + cv::fastAtan2
 //   K7 GaussianBlur 7x7 s=2    :1083-1084  executed by the reference although its consumer (BRIEF) is commented out
+//   K8 computeOrbDescriptor    :97-136     256 rotated pair tests on the blurred level (call site commented out :1083-1091;
+//                                          here on request: vdo_orb_descriptors / vdo_orb_extract_desc)
 // Image-sized work is HBM/L2-bound integer arithmetic: tiles are staged in LDS (cell ROI 37x37,
 // blur tile + 3-px halo), one workgroup per FAST cell over ALL pyramid levels in a single launch,
 // candidates are compacted in raster order with a workgroup scan so that the reference's feature
@@ -23,6 +25,7 @@
 
 #include "../../include/vdo_slam_hip.h"
 #include "ctx.hpp"
+#include "orb_pattern.hpp"
 
 namespace vdo {
 
@@ -31,7 +34,7 @@ constexpr int kSpecCand = 24576;       // candidates fetched speculatively toget
 constexpr int kCellCap = 160;          // max keypoints kept per FAST cell (NMS => <= ~(37/2)^2/2)
 constexpr int kMaxCellDim = 68;        // hCell = ceil(height/nRows) < 60, +6 overlap
 
-struct LevelDesc { int w, h, bw, bh; int64_t off; int64_t off_inner; };   // bordered image at img + off
+struct LevelDesc { int w, h, bw, bh; int64_t off; int64_t off_inner; int64_t off_blur; };   // bordered image at img + off; blurred interior (w x h, contiguous) at blur + off_blur
 struct CellDesc { int level, x0, y0, x1, y1, addx, addy, pad; };          // ROI in level interior coords; add = j*wCell, i*hCell
 
 __device__ __forceinline__ int reflect101(int p, int len) {
@@ -282,6 +285,63 @@ __global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, 
   }
 }
 
+
+// ------------------------------------------------------------------------------------ K8
+// computeOrbDescriptor (reference src/ORBextractor.cc:97-136): for each of the 256 learned point pairs, rotated by the
+// keypoint angle, compare two pixels of the blurred level image: bit = I(p0) < I(p1); pixel index =
+// cvRound(x*b + y*a)*step + cvRound(x*a - y*b) around cvRound(kp) with a = cos, b = sin (fp32 products and sums, no
+// contraction).  One wave per keypoint: lane i evaluates tests 4i..4i+3 (one 16-byte load of its slice of the pattern),
+// neighbouring lanes merge their nibbles into a byte, even lanes write the 32 bytes.
+// cos/sin: evaluated in double from +,-,* only and rounded to float (= correctly rounded cosf/sinf up to double-rounding
+// ties); the oracle runs the same operations, so the descriptor BITS agree although ocml and glibc sinf/cosf do not.
+struct OrbPattern { int4 q[64]; };
+
+__device__ __forceinline__ void sincos_exact_dev(float angle, float* s_out, float* c_out) {
+  const double x = (double)angle;
+  const int k = (int)(x * 0.63661977236758138 + 0.5);
+  const double r = (x - k * 1.57079632673412561417e+00) - k * 6.07710050650619224932e-11;
+  const double z = r * r;
+  const double sp = r * (1.0 + z * (-1.0 / 6 + z * (1.0 / 120 + z * (-1.0 / 5040 + z * (1.0 / 362880 + z * (-1.0 / 39916800 + z * (1.0 / 6227020800.0 +
+                    z * (-1.0 / 1307674368000.0 + z * (1.0 / 355687428096000.0)))))))));
+  const double cp = 1.0 + z * (-1.0 / 2 + z * (1.0 / 24 + z * (-1.0 / 720 + z * (1.0 / 40320 + z * (-1.0 / 3628800 + z * (1.0 / 479001600 +
+                    z * (-1.0 / 87178291200.0 + z * (1.0 / 20922789888000.0))))))));
+  double sn, cs;
+  switch (k & 3) {
+    case 0: sn = sp; cs = cp; break;
+    case 1: sn = cp; cs = -sp; break;
+    case 2: sn = -sp; cs = -cp; break;
+    default: sn = -cp; cs = sp; break;
+  }
+  *s_out = (float)sn; *c_out = (float)cs;
+}
+
+__global__ __launch_bounds__(256) void k_orb_desc(const uint8_t* __restrict__ blur, const LevelDesc* __restrict__ levels, const int* __restrict__ sel, int n,
+                                                  const float* __restrict__ dx, const float* __restrict__ dy, const float* __restrict__ dang,
+                                                  const int* __restrict__ dlvl, const OrbPattern* __restrict__ pat, uint8_t* __restrict__ desc) {
+  const int kp = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (kp >= n) return;
+  const int id = sel[kp];
+  const LevelDesc L = levels[dlvl[id]];
+  const int cx = (int)dx[id] + (kEdge - 3), cy = (int)dy[id] + (kEdge - 3);       // cvRound of integer-valued level coordinates
+  const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+  float a, b;
+  sincos_exact_dev(dang[id] * factorPI, &b, &a);
+  const uint8_t* center = blur + L.off_blur + (size_t)cy * L.w + cx;
+  const int4 q = pat->q[lane];                      // 16 signed bytes: (x0,y0,x1,y1) of 4 tests
+  const int words[4] = {q.x, q.y, q.z, q.w};
+  int nib = 0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const float x0 = (float)(signed char)(words[t] & 0xff), y0 = (float)(signed char)((words[t] >> 8) & 0xff);
+    const float x1 = (float)(signed char)((words[t] >> 16) & 0xff), y1 = (float)(signed char)((words[t] >> 24) & 0xff);
+    const int t0 = center[__float2int_rn(x0 * b + y0 * a) * L.w + __float2int_rn(x0 * a - y0 * b)];
+    const int t1 = center[__float2int_rn(x1 * b + y1 * a) * L.w + __float2int_rn(x1 * a - y1 * b)];
+    nib |= (t0 < t1) << t;
+  }
+  const int hi = __shfl_down(nib, 1, 64);
+  if ((lane & 1) == 0) desc[(size_t)kp * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+}
+
 // --------------------------------------------------------------------------- host: quadtree (K5)
 struct QNode {
   int ULx, ULy, URx, URy, BLx, BLy, BRx, BRy;
@@ -503,6 +563,9 @@ struct vdo_orb {
   float *d_x = nullptr, *d_y = nullptr, *d_resp = nullptr, *d_ang = nullptr; int* d_lvl = nullptr;
   int64_t pyr_bytes = 0, blur_bytes = 0;
   int dense_cap = 0;
+  // K8 (on request): dense ids of the keypoints of the last extraction, device pattern / selection / descriptor rows
+  std::vector<int> sel_dense;
+  OrbPattern* d_pat = nullptr; int* d_sel = nullptr; uint8_t* d_desc = nullptr; int desc_cap = 0;
   // pinned staging: [32 ints: level counts, total][5][kSpecCand] — header and candidates arrive with ONE sync
   float* h_pin = nullptr;
   float* h_over = nullptr; size_t h_over_n = 0;      // overflow staging when a frame has more than kSpecCand candidates
@@ -548,7 +611,7 @@ extern "C" int vdo_orb_create(vdo_ctx* ctx, const vdo_orb_params* prm, int w, in
     LevelDesc& L = o->levels[l];
     L.w = (int)lrintf((float)w * inv); L.h = (int)lrintf((float)h * inv);
     L.bw = L.w + 2 * kEdge; L.bh = L.h + 2 * kEdge;
-    L.off = off; L.off_inner = off + (int64_t)kEdge * L.bw + kEdge;
+    L.off = off; L.off_inner = off + (int64_t)kEdge * L.bw + kEdge; L.off_blur = boff;
     off += (int64_t)L.bw * L.bh;
     boff += (int64_t)L.w * L.h;
     if (L.w < 2 * kEdge + 8 || L.h < 2 * kEdge + 8) { delete o; return set_error(VDO_ERR_UNSUPPORTED, "pyramid level %d too small (%dx%d)", l, L.w, L.h); }
@@ -613,6 +676,7 @@ extern "C" int vdo_orb_create(vdo_ctx* ctx, const vdo_orb_params* prm, int w, in
   o->d_pyr = (uint8_t*)dev(o->pyr_bytes); o->d_blur = (uint8_t*)dev(o->blur_bytes);
   o->d_levels = (LevelDesc*)dev(sizeof(LevelDesc) * NL); o->d_cells = (CellDesc*)dev(sizeof(CellDesc) * o->ncells);
   o->d_cell_level = (int*)dev(4 * (size_t)o->ncells);
+  o->d_pat = (OrbPattern*)dev(sizeof(OrbPattern));
   o->d_cnt = (int*)dev(4 * (size_t)o->ncells); o->d_offs = (int*)dev(4 * ((size_t)o->ncells + 1)); o->d_level_cnt = (int*)dev(4 * 32);
   o->d_pack = (uint32_t*)dev(4 * (size_t)o->dense_cap);
   o->d_x = (float*)dev(4 * (size_t)o->dense_cap * 5);       // x | y | resp | angle | level: rows of one allocation (single strided D2H)
@@ -626,6 +690,8 @@ extern "C" int vdo_orb_create(vdo_ctx* ctx, const vdo_orb_params* prm, int w, in
   hipMemcpyAsync(o->d_levels, o->levels.data(), sizeof(LevelDesc) * NL, hipMemcpyHostToDevice, s);
   hipMemcpyAsync(o->d_cells, o->cells.data(), sizeof(CellDesc) * o->ncells, hipMemcpyHostToDevice, s);
   hipMemcpyAsync(o->d_cell_level, o->cell_level.data(), 4 * (size_t)o->ncells, hipMemcpyHostToDevice, s);
+  static_assert(sizeof(kOrbPattern31) == sizeof(OrbPattern), "256 tests x 4 signed bytes");
+  hipMemcpyAsync(o->d_pat, kOrbPattern31, sizeof(OrbPattern), hipMemcpyHostToDevice, s);
   if (hipStreamSynchronize(s) != hipSuccess) { vdo_orb_destroy(o); return set_error(VDO_ERR_NO_DEVICE, "orb upload failed"); }
   if (hipEventCreateWithFlags(&o->ev_cand, hipEventDisableTiming) != hipSuccess) { vdo_orb_destroy(o); return set_error(VDO_ERR_NO_DEVICE, "hipEventCreate failed"); }
   {
@@ -746,11 +812,13 @@ extern "C" int vdo_orb_extract_end(vdo_orb* o, vdo_keypoints* out) {
   if (o->pool) o->pool->run(NL, level_task);
   else for (int l = 0; l < NL; ++l) level_task(l);
   int n = 0;
+  o->sel_dense.clear();
   for (int l = 0; l < NL; ++l) {
     const int pos = lvl_pos[l];
     const float *cx = o->hx + pos, *cy = o->hy + pos, *cr = o->hresp + pos, *ca = o->hang + pos;
     const int patch = (int)(kPatch * o->scale[l]);
     for (int id : o->sel[l]) {
+      o->sel_dense.push_back(pos + id);
       if (n >= out->capacity) return set_error(VDO_ERR_INVALID, "vdo_orb_extract: keypoint capacity %d too small", out->capacity);
       float x = cx[id] + minB, y = cy[id] + minB;
       if (l != 0) { x = x * o->scale[l]; y = y * o->scale[l]; }
@@ -764,6 +832,41 @@ extern "C" int vdo_orb_extract_end(vdo_orb* o, vdo_keypoints* out) {
   o->ms_device = std::chrono::duration<double, std::milli>(t_dev - t_begin).count();
   o->ms_tree = std::chrono::duration<double, std::milli>(t_end - t_dev).count();
   return VDO_OK;
+}
+
+// K8: descriptors of the keypoints of the last extraction, in their output order.  desc32: host, [n][32].
+extern "C" int vdo_orb_descriptors(vdo_orb* o, uint8_t* desc32, int capacity_rows) {
+  if (!o || !desc32) return set_error(VDO_ERR_INVALID, "vdo_orb_descriptors: null argument");
+  const int n = (int)o->sel_dense.size();
+  if (n > capacity_rows) return set_error(VDO_ERR_INVALID, "vdo_orb_descriptors: %d keypoints, room for %d", n, capacity_rows);
+  if (n == 0) return VDO_OK;
+  int rc = ctx_bind(o->ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = o->ctx->stream;
+  if (n > o->desc_cap) {
+    const int cap = std::max(n, 4096);
+    int* ns = nullptr; uint8_t* nd = nullptr;
+    if (hipMalloc((void**)&ns, 4 * (size_t)cap) != hipSuccess || hipMalloc((void**)&nd, 32 * (size_t)cap) != hipSuccess) { if (ns) hipFree(ns); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+    hipStreamSynchronize(s);
+    auto drop = [&](void* p) { if (!p) return; hipFree(p); o->allocs.erase(std::remove(o->allocs.begin(), o->allocs.end(), p), o->allocs.end()); };
+    drop(o->d_sel); drop(o->d_desc);
+    o->d_sel = ns; o->d_desc = nd; o->desc_cap = cap;
+    o->allocs.push_back(ns); o->allocs.push_back(nd);
+  }
+  // the blurred levels of this extraction are queued on the same stream (orb_blur_stage), the dense candidate arrays are still resident
+  hipMemcpyAsync(o->d_sel, o->sel_dense.data(), 4 * (size_t)n, hipMemcpyHostToDevice, s);
+  hipLaunchKernelGGL(k_orb_desc, dim3((n + 3) / 4), dim3(256), 0, s, (const uint8_t*)o->d_blur, (const LevelDesc*)o->d_levels, (const int*)o->d_sel, n,
+                     (const float*)o->d_x, (const float*)o->d_y, (const float*)o->d_ang, (const int*)o->d_lvl, (const OrbPattern*)o->d_pat, o->d_desc);
+  hipMemcpyAsync(desc32, o->d_desc, 32 * (size_t)n, hipMemcpyDeviceToHost, s);
+  if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "orb descriptors: %s", hipGetErrorString(hipGetLastError()));
+  return VDO_OK;
+}
+
+// operator() with both of its outputs: keypoints and (desc32 != NULL) the 32-byte descriptors, [out->capacity][32]
+extern "C" int vdo_orb_extract_desc(vdo_orb* o, const uint8_t* gray, int stride, int src_is_device, vdo_keypoints* out, uint8_t* desc32) {
+  int rc = vdo_orb_extract(o, gray, stride, src_is_device, out);
+  if (rc != VDO_OK || !desc32) return rc;
+  return vdo_orb_descriptors(o, desc32, out->capacity);
 }
 
 // Wall time of the last vdo_orb_extract: [0] launch of the device stage .. candidates on the host, [1] host quadtree (K5)

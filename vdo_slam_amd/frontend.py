@@ -36,6 +36,8 @@ def _lib():
         L.vdo_orb_create.argtypes = [vp, C.POINTER(OrbParamsC), C.c_int, C.c_int, C.POINTER(vp)]
         L.vdo_orb_destroy.argtypes = [vp]
         L.vdo_orb_extract.argtypes = [vp, K.c_uint8_p, C.c_int, C.c_int, C.POINTER(KeypointsC)]
+        L.vdo_orb_extract_desc.argtypes = [vp, K.c_uint8_p, C.c_int, C.c_int, C.POINTER(KeypointsC), K.c_uint8_p]
+        L.vdo_orb_descriptors.argtypes = [vp, K.c_uint8_p, C.c_int]
         L.vdo_orb_level_info.argtypes = [vp, C.c_int, ip, ip, ip, ip]
         L.vdo_orb_get_pyramid.argtypes = [vp, C.c_int, K.c_uint8_p]
         L.vdo_orb_get_blurred.argtypes = [vp, C.c_int, K.c_uint8_p]
@@ -61,17 +63,30 @@ class ORBextractor:
         self._h = C.c_void_p()
         K.check(_lib().vdo_orb_create(ctx._h, C.byref(self.params), width, height, C.byref(self._h)))
 
-    def __call__(self, gray: np.ndarray, capacity=None):
+    def __call__(self, gray: np.ndarray, capacity=None, descriptors=False):
+        """Keypoints; with ``descriptors=True`` also ``desc`` [n, 32] uint8 (rotated BRIEF, K8)."""
         gray = np.ascontiguousarray(gray, dtype=np.uint8)
         cap = capacity or (self.params.n_features + 256)
         a = {k: np.zeros(cap, np.float32) for k in ("x", "y", "response", "angle", "size")}
         octave = np.zeros(cap, np.int32)
         kp = KeypointsC(cap, 0, _fp(a["x"]), _fp(a["y"]), _fp(a["response"]), _fp(a["angle"]), _fp(a["size"]), _ip(octave))
-        K.check(_lib().vdo_orb_extract(self._h, _u8(gray), gray.shape[1], 0, C.byref(kp)))
+        if descriptors:
+            desc = np.zeros((cap, 32), np.uint8)
+            K.check(_lib().vdo_orb_extract_desc(self._h, _u8(gray), gray.shape[1], 0, C.byref(kp), _u8(desc)))
+        else:
+            K.check(_lib().vdo_orb_extract(self._h, _u8(gray), gray.shape[1], 0, C.byref(kp)))
         n = kp.n
         out = {k: v[:n].copy() for k, v in a.items()}
         out["octave"] = octave[:n].copy()
+        if descriptors:
+            out["desc"] = desc[:n].copy()
         return out
+
+    def descriptors(self, n):
+        """Descriptors of the ``n`` keypoints the last extraction returned (separate call, vdo_orb_descriptors)."""
+        desc = np.zeros((max(n, 1), 32), np.uint8)
+        K.check(_lib().vdo_orb_descriptors(self._h, _u8(desc), max(n, 1)))
+        return desc[:n]
 
     def extract_device(self, gray_ptr: int, stride: int, capacity=None):
         """Like ``__call__`` but the gray image is already resident in HBM (raw device pointer).

@@ -46,8 +46,10 @@ void ORBextractor::operator()(cv::InputArray image, cv::InputArray /*mask*/, std
   keypoints.clear();
   keypoints.reserve(out.n);
   for (int i = 0; i < out.n; ++i) keypoints.push_back(cv::KeyPoint(x[i], y[i], s[i], a[i], r[i], o[i]));
-  // descriptors: allocated, never written (the reference's computeDescriptors call is commented out, :1091)
+  // descriptors: allocated; written only when mbComputeDescriptors is set (the reference's computeDescriptors call is
+  // commented out, :1091, so its rows stay uninitialised - the default here too)
   if (out.n) descriptors.create(out.n, 32, cv::CV_8UC1); else descriptors = cv::Mat();
+  if (out.n && mbComputeDescriptors && vdo_orb_descriptors(mOrb, descriptors.data, out.n) != VDO_OK) die("vdo_orb_descriptors");
   // mvImagePyramid: public member of the reference class; level interiors as views into the bordered images
   mBordered.resize(nlevels);
   for (int l = 0; l < nlevels; ++l) {

@@ -23,6 +23,9 @@ class ORBextractor {
   std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
   std::vector<float> inline GetInverseScaleSigmaSquares() { return mvInvLevelSigma2; }
   std::vector<cv::Mat> mvImagePyramid;   // level interiors (row stride = width + 38, as ROIs of the bordered images)
+  // rotated BRIEF (computeOrbDescriptor, src/ORBextractor.cc:97-136): off = the reference as shipped (call commented out,
+  // rows uninitialised); on = `descriptors` holds the 32-byte rows the commented-out call would have produced
+  bool mbComputeDescriptors = false;
 
  protected:
   int nfeatures;
