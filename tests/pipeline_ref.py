@@ -45,8 +45,6 @@ def matmul4_f32(A, B):
 
 
 class OraclePipeline:
-    MAX_OBJECTS, OBJ_CAP = 8, 6000
-
     def __init__(self, oracle, max_bg=1200, max_obj=800, sf_mg=0.12, sf_ds=0.3, build_lm=False, K4=None, use_sample=False, sample_seed=1):
         self.o = oracle
         self.K4 = np.array(synth.KITTI_K if K4 is None else K4, f32)
@@ -186,7 +184,7 @@ class OraclePipeline:
                     continue
                 self.stage_s["ransac_init"] += tick() - t; t = tick()
                 sub = ids[inl_r.astype(bool)]
-                if sub.size < 50 or a >= self.MAX_OBJECTS or sub.size > self.OBJ_CAP:
+                if sub.size < 50:
                     stat[a] = 0
                     continue
                 Tn, fl_new, inl_lm, ninl, _ = self._lm(lo["key_x"][sub], lo["key_y"][sub], lo["flow_x"][sub], lo["flow_y"][sub], lo["depth"][sub], T_r.astype(f32).astype(np.float64), 0.5, 200)

@@ -22,6 +22,8 @@
 
 #include "../../include/vdo_slam_hip.h"
 #include "ctx.hpp"
+#include <cstdlib>
+
 #include "lm_dev.hpp"
 
 namespace vdo {
@@ -43,6 +45,7 @@ struct Flow2Arrays {
   int n_problems;
   struct Flow2Comm* comm;   // [n_problems]: exchange area of the workgroup cluster of every problem
   unsigned int tag_base;    // launch number << 16: exchange tags of earlier launches never match, the area needs no clearing
+  int max_cluster;          // workgroups per problem in this launch (<= F2_CLUSTER): lowered by the launch for very large batches
 };
 
 // One problem is spread over a CLUSTER of up to F2_CLUSTER workgroups (one CU each; a single wave needs ~8k cycles per
@@ -78,7 +81,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   const int prob = blockIdx.x / F2_CLUSTER, wg = blockIdx.x % F2_CLUSTER;
   const Flow2Dev P = probs[prob];
   const int N = P.n, tid = threadIdx.x;
-  const int Gp = min(F2_CLUSTER, max(1, (N + F2_THREADS - 1) / F2_THREADS));      // workgroups that share this problem
+  const int Gp = min(A.max_cluster, max(1, (N + F2_THREADS - 1) / F2_THREADS));      // workgroups that share this problem
   if (wg >= Gp) return;
   __builtin_amdgcn_s_setprio(3);        // latency-bound persistent workgroups: issue ahead of the throughput kernels sharing the CU
   const int chunk = (N + Gp - 1) / Gp, c_lo = wg * chunk, c_hi = min(N, c_lo + chunk);   // this workgroup's correspondences [c_lo, c_hi): nothing but
@@ -644,6 +647,20 @@ extern "C" int vdo_flow2_batch_run(vdo_flow2_batch* b) {
     b->probs_dirty = false;
   }
   b->A.tag_base = (++b->run_seq) << 16;
+  // The workgroups of a cluster wait for each other, so all of them must be resident at once: keep their number below what
+  // the device can hold (2 workgroups per CU by LDS; half of that is left to whatever else is running) by lowering the
+  // cluster size for very large batches - a single-workgroup "cluster" waits for nobody.
+  {
+    int budget = 256;
+    if (const char* e = std::getenv("VDO_LM_CLUSTER_BUDGET")) budget = std::max(1, std::atoi(e));
+    int mc = F2_CLUSTER;
+    for (; mc > 1; mc >>= 1) {
+      int64_t wgs = 0;
+      for (int k = 0; k < b->n_problems; ++k) if (b->ns[k] >= 3) wgs += std::min(mc, std::max(1, (b->ns[k] + F2_THREADS - 1) / F2_THREADS));
+      if (wgs <= budget) break;
+    }
+    b->A.max_cluster = mc;
+  }
   hipLaunchKernelGGL(k_flow2_lm, dim3(b->n_problems * F2_CLUSTER), dim3(F2_THREADS), 0, b->ctx->stream, b->d_probs_run ? b->d_probs_run : (const Flow2Dev*)b->d_probs, b->A);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "k_flow2_lm launch: %s", hipGetErrorString(e));

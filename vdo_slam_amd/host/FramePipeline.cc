@@ -98,9 +98,8 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
   if (p.build_lm) {
     const int32_t ccap = std::max(p.max_track_bg + 8, p.n_features + 256);      // frame 1 tracks every filtered ORB keypoint of frame 0 (Initialization)
     if (vdo_flow2_batch_reserve(ctx_lm, 1, &ccap, &lm_cam_) != VDO_OK) return;
-    int32_t ocap[kMaxObjects];
-    for (int k = 0; k < kMaxObjects; ++k) ocap[k] = kObjCap;
-    if (vdo_flow2_batch_reserve(ctx_obj_, kMaxObjects, ocap, &lm_obj_) != VDO_OK) return;
+    std::vector<int32_t> ocap(obj_slots_, obj_cap_);
+    if (vdo_flow2_batch_reserve(ctx_obj_, obj_slots_, ocap.data(), &lm_obj_) != VDO_OK) return;
   }
   if (ctx_worker) worker_.reset(new Worker());
   orb_split_ = ctx_orb != nullptr;
@@ -115,6 +114,19 @@ FramePipeline::~FramePipeline() {
   if (tr_dyn_) vdo_tracks_destroy(tr_dyn_);
   if (lm_cam_) vdo_flow2_batch_destroy(lm_cam_);
   if (lm_obj_) vdo_flow2_batch_destroy(lm_obj_);
+}
+
+// More accepted objects than slots, or an object with more correspondences than a slot holds: a larger batch replaces the
+// current one (no launch of it is in flight here: the previous frame's object stage has been consumed).
+int FramePipeline::ReserveObjectSlots(int n_objects, int max_points) {
+  if (n_objects <= obj_slots_ && max_points <= obj_cap_) return 0;
+  const int slots = std::max(obj_slots_, (n_objects + 3) / 4 * 4), cap = std::max(obj_cap_, (max_points + 2047) / 2048 * 2048);
+  std::vector<int32_t> ocap(slots, cap);
+  vdo_flow2_batch* nb = nullptr;
+  VDO_TRY(vdo_flow2_batch_reserve(ctx_obj_, slots, ocap.data(), &nb));
+  if (lm_obj_) vdo_flow2_batch_destroy(lm_obj_);
+  lm_obj_ = nb; obj_slots_ = slots; obj_cap_ = cap;
+  return 0;
 }
 
 int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
@@ -318,6 +330,8 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     tk(5);
     return 0;
   };
+  // (declared after every local stage_static touches: on an early return this wait runs BEFORE those locals are destroyed)
+  Join join_static{worker_.get()};
   if (tail_async && worker_->wait() != 0) return -1;
   bool static_async = false;
   if (have_last_ && worker_) {
@@ -379,7 +393,8 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
         // per object: ObjIdTest_in = RANSAC inliers; fewer than 50 -> the object is not tracked this frame (Tracking.cc:879)
         obj_subsets_.assign(n_objects, {});
         obj_stat_.assign(n_objects, 1);
-        obj_buf_.resize(std::min(n_objects, (int)kMaxObjects));
+        obj_buf_.resize(n_objects);
+        int need_pts = 0;
         for (int a = 0; a < n_objects; ++a) {
           std::vector<int32_t>& sub = obj_subsets_[a];
           for (int q = off[a]; q < off[a + 1]; ++q) if (rin[q]) sub.push_back(idx[q]);
@@ -388,7 +403,13 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
             gated = std::find(gate_cur_.begin(), gate_cur_.end(), osem[a]) != gate_cur_.end() && std::find(gate_last_.begin(), gate_last_.end(), osem[a]) != gate_last_.end();
             if (!gated) { sub.clear(); for (int q = off[a]; q < off[a + 1]; ++q) sub.push_back(idx[q]); }   // vnObjInlierID = ObjIdNew
           }
-          if (!gated || (int)sub.size() < 50 || a >= kMaxObjects || (int)sub.size() > kObjCap) { obj_stat_[a] = 0; if (a < kMaxObjects) VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr)); continue; }
+          if (!gated || (int)sub.size() < 50) obj_stat_[a] = 0;
+          else need_pts = std::max(need_pts, (int)sub.size());
+        }
+        if (ReserveObjectSlots(n_objects, need_pts) != 0) return -1;                    // every object gets a slot, whatever its size
+        for (int a = 0; a < n_objects; ++a) {
+          const std::vector<int32_t>& sub = obj_subsets_[a];
+          if (!obj_stat_[a]) { VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr)); continue; }
           ObjBuf& B = obj_buf_[a];
           B.ob.clear(); B.fl.clear(); B.dp.clear();
           for (int id : sub) { B.ob.push_back(obj_.x[id]); B.ob.push_back(obj_.y[id]); B.fl.push_back(obj_.fx[id]); B.fl.push_back(obj_.fy[id]); B.dp.push_back(obj_.d[id]); }
@@ -398,11 +419,11 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
           fill_flow2(fp, (int)sub.size(), B.ob.data(), B.fl.data(), B.dp.data(), p_.K4, Tcw_last_, T0, 0.5, 200);
           VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, &fp));
         }
-        for (int a = n_objects; a < kMaxObjects; ++a) VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr));
-        obj = lm_obj_; n_obj_problems = kMaxObjects;
+        for (int a = n_objects; a < obj_slots_; ++a) VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr));
+        obj = lm_obj_; n_obj_problems = obj_slots_;
       }
     } else if (lm_obj_) {
-      for (int a = 0; a < kMaxObjects; ++a) VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr));
+      for (int a = 0; a < obj_slots_; ++a) VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr));
       obj = nullptr;
     }
     tick(9);
@@ -477,20 +498,21 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
     std::vector<int32_t>*p_off = &off, *p_idx = &idx;
     if (obj && obj == lm_obj_) {
       // vnObjInlierID = LM inliers; current keys of the inliers move to (last key + refined flow); H = Tcw^-1 * (Tcw H)  (Tracking.cc:932-933)
-      std::vector<vdo_flow2_result> rs(kMaxObjects);
-      std::vector<std::vector<double>> fo(kMaxObjects); std::vector<std::vector<uint8_t>> io(kMaxObjects);
-      double* fop[kMaxObjects]; uint8_t* iop[kMaxObjects];
-      for (int a = 0; a < kMaxObjects; ++a) {
+      const int NS = n_obj_problems;                       // slots of the batch when it was launched
+      std::vector<vdo_flow2_result> rs(NS);
+      std::vector<std::vector<double>> fo(NS); std::vector<std::vector<uint8_t>> io(NS);
+      std::vector<double*> fop(NS); std::vector<uint8_t*> iop(NS);
+      for (int a = 0; a < NS; ++a) {
         const size_t na = (a < n_objects && obj_stat_[a]) ? obj_subsets_[a].size() : 0;
         fo[a].resize(2 * na + 2); io[a].resize(na + 1);
         fop[a] = fo[a].data(); iop[a] = io[a].data();
       }
-      VDO_TRY(vdo_flow2_batch_fetch(obj, rs.data(), fop, iop));
+      VDO_TRY(vdo_flow2_batch_fetch(obj, rs.data(), fop.data(), iop.data()));
       inl_off_.assign(1, 0); inl_idx_.clear();
       float Twc_c[16];
       inv_rigid(Tcw, Twc_c);
       for (int a = 0; a < n_objects; ++a) {
-        stat[a] = (a < kMaxObjects) ? obj_stat_[a] : 0;
+        stat[a] = obj_stat_[a];
         if (stat[a]) {
           const std::vector<int32_t>& sub = obj_subsets_[a];
           for (size_t j = 0; j < sub.size(); ++j) {

@@ -125,7 +125,11 @@ class FramePipeline {
   std::vector<double> flow_out_; std::vector<uint8_t> inl_out_, inl_ransac_;
   std::vector<double> d_[5];
   // build_lm mode
-  static constexpr int kMaxObjects = 8, kObjCap = 6000;
+  // object-LM slots: one per accepted object of a frame, each with room for obj_cap_ correspondences.  The reference has no
+  // limit on either (src/Tracking.cc:785-1001 loops over all objects, an untracked label carries all its step-4 samples), so
+  // the batch is re-reserved (grown, never shrunk) when a frame needs more - rare, costs one allocation.
+  int obj_slots_ = 8, obj_cap_ = 6000;
+  int ReserveObjectSlots(int n_objects, int max_points);
   struct ObjBuf { std::vector<double> ob, fl, dp; };
   vdo_flow2_batch *lm_cam_ = nullptr, *lm_obj_ = nullptr;
   std::vector<int32_t> cam_subset_, inl_off_, inl_idx_;

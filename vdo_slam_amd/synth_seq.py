@@ -1,6 +1,8 @@
 """Geometrically consistent synthetic RGB-D / flow / mask sequence (SURVEY.md §8d "Synthetic inputs"):
 a static scene (ground plane, two side walls, a distant back wall) seen by a camera that drives forward with
-a small yaw oscillation, plus K rigid objects (upright fronto-parallel panels) that translate on the ground.
+a small yaw oscillation, plus K rigid objects (upright fronto-parallel panels, or boxes) that move on the ground: their
+centres translate with constant velocity, boxes may also turn about their vertical axis with a constant yaw rate (<= 0.05
+rad/frame), and an object may exist only for a range of frames [t0, t1) (one leaves, one enters: SURVEY 8d).
 Depth, exact dense optical flow (frame t -> t+1) and instance masks are rendered analytically per pixel,
 in the on-disk conventions of the reference (depth = disparity * DepthMapFactor, example/vdo_slam.cc:105-139).
 The gray image is texture only (ORB needs corners; correspondences come from the flow)."""
@@ -37,6 +39,32 @@ def default_objects(n=3, box_depth=0.0):
     return objs
 
 
+def survey_objects(leave_at=60, enter_at=80, box_depth=0.9):
+    """SURVEY.md 8d's object set: 5 boxes with labels 1..5 moving with constant twists - all but one also turn (yaw rate
+    <= 0.05 rad/frame) - where object 2 exists only before frame `leave_at` and object 5 only from frame `enter_at` on."""
+    objs = default_objects(5, box_depth=box_depth)
+    for ob, (yaw0, rate) in zip(objs, [(0.10, 0.012), (-0.20, -0.02), (0.0, 0.0), (0.30, 0.035), (-0.10, 0.05)]):
+        ob["yaw0"], ob["yaw_rate"] = yaw0, rate
+    objs[1]["t1"] = leave_at
+    objs[4]["t0"] = enter_at
+    # object 5 starts so that it is in range when it appears (the camera has advanced 0.8 m/frame by then)
+    objs[4]["c"] = objs[4]["c"] + np.array([0.0, 0.0, 0.1 * enter_at])
+    return objs
+
+
+def object_exists(ob, k):
+    return ob.get("t0", 0) <= k < ob.get("t1", 1 << 30)
+
+
+def _yaw_R(a):
+    return rotvec_to_R(np.array([0.0, a, 0.0]))
+
+
+def object_pose(ob, k):
+    """(R, c): orientation and centre of the object at frame k (world frame)."""
+    return _yaw_R(ob.get("yaw0", 0.0) + k * ob.get("yaw_rate", 0.0)), ob["c"] + k * ob["v"]
+
+
 def render_frame(k, Ts, objects, w=KITTI_W, h=KITTI_H, K4=KITTI_K, flow_sigma=0.0, seed=0, invalid_depth=0.0, zero_flow=0.0, drop_masks=None):
     """Frame k: dict(gray u8, depth_raw f32 (disparity*256), flow f32 [h,w,2] (k -> k+1), mask i32, Tcw 4x4, Tcw_next).
     SURVEY.md 8d extras: flow_sigma px of Gaussian flow noise, a fraction invalid_depth of pixels with disparity 0, a fraction
@@ -64,15 +92,19 @@ def render_frame(k, Ts, objects, w=KITTI_W, h=KITTI_H, K4=KITTI_K, flow_sigma=0.
             hit((np.abs(d[..., 0]) > 1e-9) & (yy > -6.0) & (yy < 1.65), sv)
         hit(d[..., 2] > 1e-9, (400.0 - o[2]) / d[..., 2])                              # back wall far beyond ThDepthBG
         for j, ob in enumerate(objects):
-            c = ob["c"] + k * ob["v"]
+            if not object_exists(ob, k):
+                continue
+            Ro, c = object_pose(ob, k)
             hd = ob.get("hd", 0.0)
             if hd <= 0:                                                                # panel z = const, facing the camera
+                assert not ob.get("yaw_rate") and not ob.get("yaw0"), "only boxes turn"
                 sv = (c[2] - o[2]) / d[..., 2]
                 px = o[0] + sv * d[..., 0]; py = o[1] + sv * d[..., 1]
                 upd = hit((d[..., 2] > 1e-9) & (np.abs(px - c[0]) < ob["hw"]) & (np.abs(py - c[1]) < ob["hh"]), sv)
-            else:                                                                      # axis-aligned box (slab method): front, sides and top are seen
-                lo = c - np.array([ob["hw"], ob["hh"], hd]); hi = c + np.array([ob["hw"], ob["hh"], hd])
-                t1 = (lo - o) / d; t2 = (hi - o) / d
+            else:                                                                      # oriented box (slab method in the box frame): front, sides and top are seen
+                ol = (o - c) @ Ro; dl = d @ Ro                                         # (the ray parameter = camera depth is frame independent)
+                half = np.array([ob["hw"], ob["hh"], hd])
+                t1 = (-half - ol) / dl; t2 = (half - ol) / dl
                 tn = np.nanmax(np.minimum(t1, t2), axis=-1); tf = np.nanmin(np.maximum(t1, t2), axis=-1)
                 upd = hit((tn <= tf) & (tf > 0), tn)
             label = np.where(upd, j + 1, label)
@@ -80,7 +112,10 @@ def render_frame(k, Ts, objects, w=KITTI_W, h=KITTI_H, K4=KITTI_K, flow_sigma=0.
     Xw = o + depth[..., None] * d
     Xn = Xw.copy()
     for j, ob in enumerate(objects):
-        Xn[label == j + 1] += ob["v"]
+        sel = label == j + 1
+        if sel.any():
+            H = object_motion(ob, k)
+            Xn[sel] = Xw[sel] @ H[:3, :3].T + H[:3, 3]
     T_c1w = np.linalg.inv(T_wc1)
     Xc1 = Xn @ T_c1w[:3, :3].T + T_c1w[:3, 3]
     with np.errstate(divide="ignore", invalid="ignore"):
@@ -103,7 +138,16 @@ def render_frame(k, Ts, objects, w=KITTI_W, h=KITTI_H, K4=KITTI_K, flow_sigma=0.
                 mask=np.ascontiguousarray(label), Tcw=np.linalg.inv(T_wc), Tcw_next=np.linalg.inv(T_wc1), depth_true=depth)
 
 
-def object_motion(ob):
-    """World-frame rigid motion H of an object per frame (pure translation)."""
-    H = np.eye(4); H[:3, 3] = ob["v"]
+def object_motion(ob, k=0):
+    """World-frame rigid motion H of an object from frame k to k+1: X' = R_d (X - c_k) + c_{k+1}, R_d = yaw by the yaw rate
+    (a pure translation by v when the object does not turn)."""
+    H = np.eye(4)
+    rate = ob.get("yaw_rate", 0.0)
+    if rate:
+        _, c0 = object_pose(ob, k)
+        Rd = _yaw_R(rate)
+        H[:3, :3] = Rd
+        H[:3, 3] = (c0 + ob["v"]) - Rd @ c0
+    else:
+        H[:3, 3] = ob["v"]
     return H
