@@ -39,8 +39,17 @@ HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~
 N_DISTINCT_FRAMES = 4   # make_frame_inputs(): independent random frames (tools/frame_probe.py)
 # SURVEY.md 8d "synthetic inputs": flow noise N(0, 0.3^2) px, 2 % invalid depth, 1 % exactly-zero flow, 5 moving objects, one
 # instance mask missing for two frames (exercises UpdateMask)
-FLOW_SIGMA, INVALID_DEPTH, ZERO_FLOW, N_OBJECTS, DROP_MASKS, BOX_DEPTH = 0.3, 0.02, 0.01, 5, {30: {2}, 31: {2}}, 0.9
+FLOW_SIGMA, INVALID_DEPTH, ZERO_FLOW, N_OBJECTS, BOX_DEPTH = 0.3, 0.02, 0.01, 5, 0.9
 MAX_SEQ_FRAMES = 160    # length of the consistent synthetic sequence (the objects stay in view that long)
+
+
+def sequence_events(warmup, steps):
+    """Where the 8d events fall: SURVEY's frames (mask dropped for two frames, object 2 leaves at 60, object 5 enters at 80)
+    for a KITTI-0000-length run, pulled inside the timed window [warmup, warmup+steps) whatever --steps is."""
+    drop_at = min(30, warmup + 3)
+    leave_at = min(60, warmup + max(2, (2 * steps) // 5))
+    enter_at = min(80, warmup + max(4, (3 * steps) // 5))
+    return {drop_at: {1}, drop_at + 1: {1}}, leave_at, enter_at
 
 
 def _pmc_traffic_bytes(graph):
@@ -117,6 +126,25 @@ def cpu_baseline_batch(graph, its=2):
     return (time.perf_counter() - t0) * 1e3 / max(1, st.iterations), sweep_ms, int(st.iterations)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` outside torchrun: start N ranks of this script (one process per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment, exactly what torchrun would set); rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -124,8 +152,13 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the batch-BA / roofline legs")
+    ap.add_argument("--no-host-inputs", action="store_true", help="skip the System::TrackRGBD (host buffers in) leg")
+    ap.add_argument("--replicas-per-gpu", type=int, default=1, help="R independent sequences (FramePipelines) on every GPU; value = all of them")
+    ap.add_argument("--replica-sweep", type=str, default="", help="e.g. 1,2,4,8: also report frames/s for these numbers of sequences per GPU")
     ap.add_argument("--roofline-static", type=int, default=600000, help="static landmarks of the roofline graph")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(spawn_ranks(args.gpus))
     # stdout carries exactly ONE line (the JSON result): libraries that print banners to fd 1 (RCCL's version block on
     # communicator teardown) are sent to stderr
     sys.stdout.flush()
@@ -137,68 +170,83 @@ def main():
     rank, world, local = _dist_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (libvdo_hip has no CPU fallback)")
+    n_dev = torch.cuda.device_count()
+    shared_gpu = world > n_dev            # more ranks than devices (a 1-GPU box asked for --gpus 2): ranks share devices, collectives over gloo
+    local = local % n_dev
     torch.cuda.set_device(local)
     use_dist = world > 1 or bool(os.environ.get("VDO_BENCH_FORCE_DIST"))     # FORCE: exercise the RCCL legs on a 1-GPU box
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29531")
         os.environ.setdefault("RANK", "0"); os.environ.setdefault("WORLD_SIZE", "1")
         import datetime
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=300))
+        if shared_gpu:
+            dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=300))
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local), timeout=datetime.timedelta(seconds=300))
     stream = torch.cuda.Stream()          # non-default stream shared by torch events and libvdo_hip
     torch.cuda.set_stream(stream)
 
     from vdo_slam_amd import synth, synth_frames as SF, synth_seq as SQ
     from vdo_slam_amd.ba import BatchBA, Context
 
-    n_lm_cu = int(os.environ.get("VDO_BENCH_LM_CUS", "0"))      # measured: no gain from CU partitioning (the LM kernel is not slowed by its neighbours)
-    if n_lm_cu > 0:
-        # the LM chain gets CUs of its own (one latency-bound workgroup per problem); everything else runs on the other CUs
-        ctx = Context(local, cu_mask=(0, n_lm_cu, True))
-        ctx_lm = Context(local, cu_mask=(0, n_lm_cu, False))
-        ctx_ba = Context(local, stream.cuda_stream)          # batch / roofline legs: whole chip, torch's stream
-    else:
-        ctx = ctx_ba = Context(local, stream.cuda_stream)
-        ctx_lm = Context(local)           # second HIP stream: the camera LM overlaps the ORB front-end of the same frame
-    ctx_obj = Context(local)              # third HIP stream: the object LMs overlap RenewFrameInfo and the next frame's camera stage
+    ctx_ba = Context(local, stream.cuda_stream)            # batch / roofline legs: torch's stream
     # ---- the sequence: geometrically consistent synthetic KITTI-shaped RGB-D + flow + masks (vdo_slam_amd/synth_seq.py),
-    # one distinct frame per step, resident in HBM before the timed region
+    # one distinct frame per step, resident in HBM before the timed region.  SURVEY 8d's events (a mask missing for two frames,
+    # an object leaving, an object entering; turning boxes) fall inside the timed window whatever --steps is.
     W, H = synth.KITTI_W, synth.KITTI_H
     n_seq = min(args.steps + args.warmup, MAX_SEQ_FRAMES)
     Ts = SQ.camera_poses(n_seq)
-    objs = SQ.default_objects(N_OBJECTS, box_depth=BOX_DEPTH)         # axis-aligned boxes (2 x 0.9 m deep), not planar panels
-    frames = [SQ.render_frame(k, Ts, objs, flow_sigma=FLOW_SIGMA, seed=17 * rank, invalid_depth=INVALID_DEPTH, zero_flow=ZERO_FLOW, drop_masks=DROP_MASKS)
+    drop_masks, leave_at, enter_at = sequence_events(args.warmup, args.steps)
+    objs = SQ.survey_objects(leave_at=leave_at, enter_at=enter_at, box_depth=BOX_DEPTH)     # 5 boxes (2 x 0.9 m deep), 4 of them turning
+    frames = [SQ.render_frame(k, Ts, objs, flow_sigma=FLOW_SIGMA, seed=17 * rank, invalid_depth=INVALID_DEPTH, zero_flow=ZERO_FLOW, drop_masks=drop_masks)
               for k in range(n_seq)]
     dev = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames]
     # The per-frame sequence runs in the C++ host class FramePipeline (vdo_slam_amd/host/FramePipeline.cc: the hot
     # part of Tracking::GrabImageRGBD + Track over the C-ABI, state chained frame to frame); one ctypes call per frame.
     from vdo_slam_amd.pipeline import FramePipeline, kitti_params
+    import threading
     defer = 0 if os.environ.get("VDO_BENCH_SYNC_OBJECTS") else 1
-    # host threads per replica: main + 1 helper of FramePipeline (polls) + 3 quadtree helpers of ORB (sleep when idle); with fewer
-    # than ~5 CPUs per rank the helpers would only steal time from each other
-    cpus_per_rank = _cpu_budget() / max(1, world)
-    if "VDO_ORB_THREADS" not in os.environ:             # quadtree helpers of ORB (library default 3): measured 888 / 916 / 921 frames/s with 3 / 5 / 7
-        os.environ["VDO_ORB_THREADS"] = "0" if cpus_per_rank < 3 else ("5" if cpus_per_rank >= 10 else "3")
-    use_worker = not os.environ.get("VDO_BENCH_NO_WORKER") and cpus_per_rank >= 5
-    ctx_w = Context(local) if use_worker else None      # helper host thread of FramePipeline, own stream + arena
-    # ORB on a stream of its own (device stage queued at the start of the frame, under the camera stage): supported, results identical,
-    # but measured neutral (843 vs 824 frames/s, inside the run-to-run spread): the camera stage's small kernels then share the GPU
-    # with ORB's - off unless asked for
-    ctx_orb = Context(local) if os.environ.get("VDO_BENCH_ORB_STREAM") else None
-    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctx_obj, ctx_w, ctx_orb)
-    torch.cuda.synchronize()
-    counts = pipe.counts
-    agg = {"cam_lm_iterations": 0, "n_static_tracked": 0, "n_object_tracked": 0, "n_objects": 0, "n_ransac_cam": 0, "n_cam_inliers": 0, "n_ransac_obj": 0, "n_recovered_masks": 0}
+    cpus = _cpu_budget() / max(1, world)
+    AGG = ("cam_lm_iterations", "n_static_tracked", "n_object_tracked", "n_objects", "n_ransac_cam", "n_cam_inliers", "n_ransac_obj", "n_recovered_masks")
 
-    def step(i):
-        # Full Track() of one frame: UpdateMask (K15) -> K1 -> propagation (K11) -> GetInitModelCam (RANSAC-P3P, motion model)
-        # -> camera pose+flow LM (K16, stream 2) || ORB (K3-K7) + K9 + K10 -> scene flow (K13) + DynObjTracking ->
-        # GetInitModelObj (RANSAC per object) -> object LMs (K17, one launch, stream 2) || RenewFrameInfo static (K14, K12)
-        # -> RenewFrameInfo objects (K14, K12) -> tracklets.  The LM problems are built from the frame's own chained
-        # correspondences (build_lm mode).  A sequence longer than MAX_SEQ_FRAMES wraps to frame 0 (a scene cut).
-        d = dev[i % n_seq]
-        c = pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
-        for q in agg:
-            agg[q] += c[q]
+    class Replica:
+        """One sequence on this GPU: a FramePipeline with its own HIP streams (4 contexts), host helper thread and Map."""
+        def __init__(self, cpus_here, first=False):
+            # host threads per replica: main + 1 helper of FramePipeline (polls) + the quadtree helpers of ORB (sleep when idle);
+            # with fewer than ~5 CPUs per replica the helpers would only steal time from each other
+            orb_threads = os.environ.get("VDO_ORB_THREADS_FORCE") or ("0" if cpus_here < 3 else ("5" if cpus_here >= 10 else "3"))
+            os.environ["VDO_ORB_THREADS"] = orb_threads           # read by vdo_orb_create
+            self.orb_threads = orb_threads
+            self.ctx = Context(local, stream.cuda_stream) if first else Context(local)
+            self.ctx_lm, self.ctx_obj = Context(local), Context(local)       # camera LM || ORB front-end; object LMs || RenewFrameInfo + next camera stage
+            self.ctx_w = Context(local) if (not os.environ.get("VDO_BENCH_NO_WORKER") and cpus_here >= 5) else None
+            self.pipe = FramePipeline(self.ctx, self.ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ,
+                                                                         build_lm=1, defer_objects=defer), self.ctx_obj, self.ctx_w, None)
+            self.pipe.attach_map()                                # "Save Graph Structure": every frame is pushed into the Map (Tracking.cc:1031-1159)
+            self.agg = {q: 0 for q in AGG}
+            self.step_ms = []
+            self.err = None
+
+        def run(self, i0, n, timed):
+            # Full Track() of one frame per step: UpdateMask (K15) -> K1 -> propagation (K11) -> GetInitModelCam (RANSAC-P3P, motion model)
+            # -> camera pose+flow LM (K16) || ORB (K3-K7) + K9 + K10 -> scene flow (K13) + DynObjTracking -> GetInitModelObj (RANSAC per
+            # object) -> object LMs (K17, one launch) || RenewFrameInfo static (K14, K12) -> RenewFrameInfo objects -> tracklets -> Map.
+            # The LM problems are built from the frame's own chained correspondences.  A sequence longer than MAX_SEQ_FRAMES wraps (a scene cut).
+            try:
+                for i in range(i0, i0 + n):
+                    d = dev[i % n_seq]
+                    ts = time.perf_counter()
+                    c = self.pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
+                    if timed:
+                        self.step_ms.append((time.perf_counter() - ts) * 1e3)
+                    for q in AGG:
+                        self.agg[q] += c[q]
+                self.pipe.flush()                     # deferred mode: the object stage of the last frame ends inside the timed region
+            except Exception as e:                    # noqa: BLE001 - reported by the main thread
+                self.err = e
+
+        def close(self):
+            self.pipe.close()
 
     def barrier():
         torch.cuda.synchronize()
@@ -206,52 +254,107 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        step(i)
-    pipe.flush()
-    barrier()
-    step_ms = []
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        ts = time.perf_counter()
-        step(args.warmup + i)                 # the sequence continues where the warm-up left it
-        step_ms.append((time.perf_counter() - ts) * 1e3)
-    pipe.flush()                              # deferred mode: the object stage of the last frame ends inside the timed region
-    barrier()
-    dt = time.perf_counter() - t0
-    tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
-    if use_dist:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt = float(tt.item())
-    fps = world * args.steps / dt
+    def run_sequences(R):
+        """R independent sequences on this GPU (own pipelines, streams, host threads), each through warm-up + the timed steps;
+        returns (seconds for the timed steps - max over ranks, replicas)."""
+        reps = [Replica(cpus / R, first=(k == 0)) for k in range(R)]
+        torch.cuda.synchronize()
+
+        def all_run(i0, n, timed):
+            if R == 1:
+                reps[0].run(i0, n, timed)
+            else:
+                th = [threading.Thread(target=r.run, args=(i0, n, timed)) for r in reps]
+                for t in th: t.start()
+                for t in th: t.join()
+            for r in reps:
+                if r.err is not None:
+                    raise r.err
+        all_run(0, args.warmup, False)
+        barrier()
+        t0 = time.perf_counter()
+        all_run(args.warmup, args.steps, True)        # the sequence continues where the warm-up left it
+        barrier()
+        dt = time.perf_counter() - t0
+        tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
+        if use_dist:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item()), reps
+
+    R = max(1, args.replicas_per_gpu)
+    dt, reps = run_sequences(R)
+    fps = world * R * args.steps / dt
     n_all = args.steps + args.warmup
+    pipe = reps[0].pipe
+    counts, agg, step_ms = pipe.counts, reps[0].agg, reps[0].step_ms
     sect = pipe.section_ms()
     k_last = (n_all - 1) % n_seq
     Tcw = pipe.pose().astype(np.float64)
     drift = float(np.abs(Tcw[:3, 3] - frames[k_last]["Tcw"][:3, 3]).max()) if n_all <= n_seq else None
     motions = pipe.motions()
+    identical = all(np.array_equal(r.pipe.pose(), pipe.pose()) and [m["H"].tolist() for m in r.pipe.motions()] == [m["H"].tolist() for m in motions] for r in reps[1:])
+    rep0 = reps[0]
 
     out = {
         "metric": "frames/sec (per-frame hot path, KITTI-0000-shaped 1242x375) + ms/LM-iter (batch factor graph)",
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64 (LM, RANSAC) / u8,i32,f32 (front-end, tracking)", "data": "synthetic",
-        "config": {"workload": "KITTI-0000-shaped TrackRGBD per frame (C++ FramePipeline over the C-ABI, full Track()): K15 UpdateMask, K1 depth, K11 propagation, "
+        "config": {"workload": "KITTI-0000-shaped TrackRGBD per frame (C++ FramePipeline over the C-ABI, full Track() incl. the per-frame push into the Map): K15 UpdateMask, K1 depth, K11 propagation, "
                                "RANSAC-P3P + motion-model initialisers, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, "
                                "joint pose+flow LM for the camera (<=1200 matches) and every tracked object (ref_quirks=1) built from the frame's own correspondences, "
-                               "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets; "
-                               f"geometrically consistent synthetic sequence of {n_seq} frames: {N_OBJECTS} moving boxes, flow noise sigma {FLOW_SIGMA} px, "
-                               f"{INVALID_DEPTH:.0%} invalid depth, {ZERO_FLOW:.0%} zero flow, one instance mask missing in frames {sorted(DROP_MASKS)}",
-                   "parallelism": f"replicas x{world}; {4 + (ctx_orb is not None)} HIP streams per replica: camera LM (2) || ORB front-end ({5 if ctx_orb is not None else 1}); object LMs (3) || RenewFrameInfo (1) and - "
+                               "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets, Map; "
+                               f"geometrically consistent synthetic sequence of {n_seq} frames: {N_OBJECTS} moving boxes (4 turning, yaw rate <= 0.05 rad/frame), flow noise sigma {FLOW_SIGMA} px, "
+                               f"{INVALID_DEPTH:.0%} invalid depth, {ZERO_FLOW:.0%} zero flow, the instance mask of object 1 missing in frames {sorted(drop_masks)}, "
+                               f"object 2 leaves at frame {leave_at}, object 5 enters at frame {enter_at}",
+                   "sequences_per_gpu": R, "sequences_identical": bool(identical),
+                   "parallelism": f"replicas x{world}" + (f" (ranks share {n_dev} device(s), collectives over gloo)" if shared_gpu else "") + f", {R} sequence(s) per GPU; 4 HIP streams per sequence: camera LM (2) || ORB front-end (1); object LMs (3) || RenewFrameInfo (1) and - "
                                   f"defer_objects={defer} - the next frame's camera stage; every LM problem runs on a cluster of up to 8 workgroups; "
-                                  f"{cpus_per_rank:.1f} CPUs per replica, host threads per replica: 1 + {int(ctx_w is not None)} helper (object stage of the previous frame || camera stage + ORB; K9/K10/RenewFrameInfo static || object chain) + {os.environ['VDO_ORB_THREADS']} ORB quadtree helpers",
+                                  f"{cpus:.1f} CPUs per rank, host threads per sequence: 1 + {int(rep0.ctx_w is not None)} helper (object stage of the previous frame || camera stage + ORB; K9/K10/RenewFrameInfo static || object chain) + {rep0.orb_threads} ORB quadtree helpers",
                    "orb_keypoints": counts.n_orb, "new_static_candidates": counts.n_static_new, "object_samples": counts.n_object_samples,
                    "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
                    "per_frame_mean": {q: round(v / n_all, 2) for q, v in agg.items()},
+                   "n_recovered_masks_total": int(agg["n_recovered_masks"]),
                    "step_ms_p50_p90_max": [round(float(np.percentile(step_ms, 50)), 3), round(float(np.percentile(step_ms, 90)), 3), round(max(step_ms), 3)],
                    "trajectory_drift_m": drift, "object_translations_last_frame": [np.round(m["H"][:3, 3], 4).tolist() for m in motions],
                    "host_ms_per_section": {k_: round(v_ / n_all, 4) for k_, v_ in sect.items()}},
     }
+    if R > 1:
+        out["config"]["single_sequence_latency_ms_p50"] = round(float(np.percentile(step_ms, 50)), 3)
+    for r in reps:
+        r.close()
+    del reps, pipe, rep0
+    # ---- R-sweep: aggregate frames/s for several numbers of independent sequences per GPU (the per-frame path keeps <= ~10 of the
+    # 256 CUs busy: one sequence per GPU leaves the chip idle, SURVEY 8e "replicas only")
+    if args.replica_sweep:
+        sweep = {}
+        for Rs in [int(x) for x in args.replica_sweep.split(",") if x]:
+            dts, rs = run_sequences(Rs)
+            same = all(np.array_equal(r.pipe.pose(), rs[0].pipe.pose()) for r in rs[1:]) and np.array_equal(rs[0].pipe.pose().astype(np.float64), Tcw)
+            sweep[str(Rs)] = {"frames_per_s": world * Rs * args.steps / dts, "step_ms_p50": round(float(np.percentile(rs[0].step_ms, 50)), 3), "identical_to_single": bool(same)}
+            for r in rs:
+                r.close()
+        out["sequences_per_gpu_sweep"] = sweep
+    # ---- the same sequence through System::TrackRGBD with HOST buffers (include/System.h:45-51: the reference's real entry;
+    # 7.9 MB of H2D per frame, the caller's depth converted in place, synchronous - the frame is complete when the call returns)
+    if rank == 0 and world == 1 and not args.no_host_inputs:
+        import tempfile
+        from vdo_slam_amd.system import System, write_settings
+        with tempfile.TemporaryDirectory() as td:
+            sysm = System(write_settings(os.path.join(td, "kitti.yaml"), W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, window=0, overlap=0))
+            host_in = [(f["gray"], f["depth_raw"].copy(), f["flow"], f["mask"].copy()) for f in frames[:n_all]]
+            for k in range(args.warmup):
+                sysm.track_rgbd(*host_in[k])
+            t0 = time.perf_counter()
+            Th = None
+            for k in range(args.warmup, n_all):
+                Th = sysm.track_rgbd(*host_in[k % len(host_in)])
+            dth = time.perf_counter() - t0
+            out["value_host_inputs"] = args.steps / dth
+            out["config"]["host_inputs"] = ("System::TrackRGBD on pageable host buffers (gray u8, raw depth f32 converted in place, flow 2xf32, mask i32 = 7.9 MB/frame H2D + 1.9 MB D2H), "
+                                            "synchronous object stage (defer_objects=0), Map attached, no windowed optimisation; same camera pose as the device-input run: "
+                                            + str(bool(Th is not None and np.array_equal(Th.astype(np.float64), Tcw))))
+            sysm.close()
 
     if not args.no_batch:
         # ---- batch leg: LM outer iterations on the KITTI-shaped full-batch graph (configs[2] shape)

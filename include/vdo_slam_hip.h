@@ -369,6 +369,9 @@ int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm_sta, const
 int vdo_mask_at(vdo_frame_images* f, int n, const float* cx, const float* cy, int32_t* label_out);
 int vdo_mask_warp(vdo_frame_images* cur, vdo_frame_images* last, int32_t label);
 int vdo_frame_images_download_mask(vdo_frame_images* f, int32_t* mask_out);
+/* The resident depth image after K1 (metres): GrabImageRGBD converts the caller's imD in place (src/Tracking.cc:180-204); a host
+ * caller that uploaded the raw map gets the converted one back with this. */
+int vdo_frame_images_download_depth(vdo_frame_images* f, float* depth_out);
 
 /* ---- Tracking bookkeeping around the gathers ------------------------------------ */
 

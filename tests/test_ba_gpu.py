@@ -90,6 +90,38 @@ def test_lm_matches_oracle(ctx, oracle, shape):
     ba.close()
 
 
+@pytest.mark.parametrize("shape,seed", [((60, 30000, 5, 800), 1), ((60, 10000, 5, 400), 2)])
+def test_bench_scale_graphs_match_the_oracle(ctx, oracle, shape, seed):
+    """The graph bench.py times (60 frames, 54 k points, 224 k edges: `make_ba_graph(60, 30000, 5, 800, seed=1)`) and a
+    BASELINE configs[2]-sized one (~10 k landmarks, 5 objects): every block of the linearisation <= 1e-12 of the oracle
+    (tiles are full here: > 256 points per tile, the 64-slot limit and the 768-incidence limit are all reached), and 5
+    Levenberg iterations take the same trials to the same chi2 and estimates."""
+    from vdo_slam_amd.ba import BatchBA
+    g = synth.make_ba_graph(*shape, seed=seed)
+    ba = BatchBA(ctx, g)
+    ba.linearize()
+    S = ba.system()
+    R = _oracle_system(oracle, g)
+    for name in BLOCKS:
+        a, b = getattr(S, name), getattr(R, name)
+        if b.size:
+            assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max() + 1e-300, name
+    assert abs(S.robust_chi2 - R.robust_chi2) <= 1e-12 * abs(R.robust_chi2)
+    gc, keep = K.graph_to_c(g)
+    opt = K.LMOptionsC(5, 1e-4, 0, 0, 0.0, 0)
+    st_o = K.LMStatsC()
+    pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(pose_o), K._dp(point_o), C.byref(st_o)) == 0
+    st = ba.optimize(max_iterations=5, gain_threshold=1e-4)
+    pose, point = ba.estimates()
+    assert (st.iterations, st.total_trials) == (st_o.iterations, st_o.total_trials) and st.iterations == 5
+    assert abs(st.final_chi2 - st_o.final_chi2) <= 1e-6 * st_o.final_chi2
+    assert np.abs(pose[:, :9] - pose_o[:, :9]).max() <= 1e-4
+    assert np.abs(pose[:, 9:] - pose_o[:, 9:]).max() <= 1e-4 * np.abs(pose_o[:, 9:]).max()
+    assert np.abs(point - point_o).max() <= 1e-4 * np.abs(point_o).max()
+    ba.close()
+
+
 def test_invalid_graph_is_rejected(ctx):
     from vdo_slam_amd.ba import BatchBA
     g = synth.make_ba_graph(6, 50, 1, 5, seed=1)

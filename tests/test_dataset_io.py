@@ -117,3 +117,28 @@ def test_read_png_colour_is_bgr(host, tmp_path):
     assert host.host_io_read_png(str(p).encode(), 0, dims, out.ctypes.data_as(C.c_void_p)) == 0 and list(dims) == [17, 23, 3]
     assert np.array_equal(out, rgb[:, :, ::-1])
     assert host.host_io_read_png(str(tmp_path / "nope.png").encode(), 0, dims, None) != 0
+
+
+def test_untrusted_headers_are_rejected_without_allocating(host, tmp_path):
+    """A PNG whose IHDR claims 2^31 x 2^31 pixels, one whose claimed size cannot come out of its few compressed bytes, a .flo
+    with absurd dimensions and a mask line with a 40-digit number: an error code, no allocation failure, no overflow."""
+    import struct, zlib
+    good = tmp_path / "g.png"
+    _png(good, np.arange(12, dtype=np.uint8).reshape(3, 4), 8, filters=[0])
+    raw = bytearray(good.read_bytes())
+    dims = (C.c_int * 3)()
+    for w, h in ((1 << 31, 1 << 31), (30000, 30000)):
+        b = bytearray(raw)
+        b[16:24] = struct.pack(">II", w & 0xffffffff, h & 0xffffffff)
+        b[29:33] = struct.pack(">I", zlib.crc32(bytes(b[12:29])) & 0xffffffff)
+        p = tmp_path / f"bad_{h}.png"
+        p.write_bytes(bytes(b))
+        assert host.host_io_read_png(str(p).encode(), 0, dims, None) != 0
+    flo = tmp_path / "bad.flo"
+    flo.write_bytes(struct.pack("<fii", 202021.25, 1 << 30, 1 << 30) + b"\0" * 64)
+    assert host.host_io_read_flo(str(flo).encode(), dims, None) != 0
+    m = tmp_path / "m.txt"
+    m.write_text("1 " + "9" * 40 + " 3\n")
+    out = np.zeros((1, 3), np.int32)
+    assert host.host_io_load_mask(str(m).encode(), 1, 3, out.ctypes.data_as(C.c_void_p)) == 0
+    assert out[0, 0] == 1 and out[0, 2] == 3 and out[0, 1] > 0

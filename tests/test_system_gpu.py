@@ -116,3 +116,29 @@ def test_system_trackrgbd_on_host_images(host, oracle, tmp_path):
     poses2, motions2, _ = run_system([1, 3])
     assert all(2 not in m for m in motions2) and any(m for m in motions2)
     assert all(np.array_equal(a, b) for a, b in zip(poses, poses2))        # the camera pose does not depend on the object gate
+
+
+def test_system_rejects_frames_that_do_not_match_the_settings(tmp_path):
+    """Camera.width/height size the device images; a frame of another size, element type or with padded rows is refused
+    (empty pose, message) instead of being read out of bounds; OMD settings (ChooseData 1) run no global batch at the end."""
+    from vdo_slam_amd.system import System, write_settings
+    cfg = write_settings(tmp_path / "k.yaml", W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, choose_data=1)
+    n_frames = 4
+    Ts = SQ.camera_poses(n_frames)
+    frames = [SQ.render_frame(k, Ts, SQ.default_objects(), flow_sigma=0.1) for k in range(n_frames)]
+    s = System(cfg)
+    fr = frames[0]
+    small = {q: np.ascontiguousarray(fr[q][:300, :1000]) for q in ("gray", "depth_raw", "flow", "mask")}
+    assert s.track_rgbd(small["gray"], small["depth_raw"].copy(), small["flow"], small["mask"].copy()) is None
+    for k, f in enumerate(frames):
+        d = f["depth_raw"].copy()
+        T = s.track_rgbd(f["gray"], d, f["flow"], f["mask"].copy(), n_images=n_frames)
+        assert T is not None and np.isfinite(T).all()
+        assert d.max() < 1e4 and not np.array_equal(d, f["depth_raw"])         # converted in place (metres)
+    assert np.abs(T[:3, 3] - frames[-1]["Tcw"][:3, 3]).max() < 0.05
+    rf = s.refined_poses(n_frames)
+    # OMD: FullBatchOptimization does not run (src/Tracking.cc:1198) - the refined poses are the unrefined ones
+    assert rf.shape[0] == n_frames
+    s.close()
+    with pytest.raises(K.VdoError):
+        System(tmp_path / "missing.yaml")

@@ -178,6 +178,18 @@ extern "C" int vdo_frame_images_download_mask(vdo_frame_images* f, int32_t* mask
   return VDO_OK;
 }
 
+// the resident depth image (metres once K1 ran): what Tracking::GrabImageRGBD leaves in the caller's imD (src/Tracking.cc:180-204)
+extern "C" int vdo_frame_images_download_depth(vdo_frame_images* f, float* depth_out) {
+  if (!f || !depth_out) return set_error(VDO_ERR_INVALID, "bad argument");
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  hipMemcpyAsync(depth_out, f->d_depth, 4 * (size_t)f->w * f->h, hipMemcpyDeviceToHost, f->ctx->stream);
+  hipError_t e = hipStreamSynchronize(f->ctx->stream);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "vdo_frame_images_download_depth: %s", hipGetErrorString(e));
+  return VDO_OK;
+}
+
 extern "C" int vdo_get3d_world(vdo_ctx* ctx, int n, const float* kx, const float* ky, const float* depth, const float K4[4], const float Twc[16], float* xyz_out) {
   if (!ctx || n < 0) return set_error(VDO_ERR_INVALID, "bad argument");
   if (n == 0) return VDO_OK;

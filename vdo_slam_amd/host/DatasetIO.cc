@@ -22,6 +22,7 @@ bool read_file(const std::string& path, std::vector<unsigned char>& buf) {
   std::fclose(f);
   return got == (size_t)n;
 }
+constexpr int kMaxImageDim = 1 << 15;       // header fields are untrusted: sizes beyond this are rejected before any allocation
 unsigned be32(const unsigned char* p) { return ((unsigned)p[0] << 24) | ((unsigned)p[1] << 16) | ((unsigned)p[2] << 8) | p[3]; }
 }  // namespace
 
@@ -30,7 +31,7 @@ bool ReadOpticalFlow(const std::string& path, cv::Mat& flow) {
   if (!read_file(path, b) || b.size() < 12) return false;
   float magic; int w, h;
   std::memcpy(&magic, b.data(), 4); std::memcpy(&w, b.data() + 4, 4); std::memcpy(&h, b.data() + 8, 4);
-  if (magic != 202021.25f || w <= 0 || h <= 0 || b.size() < 12 + (size_t)w * h * 8) return false;      // "PIEH"
+  if (magic != 202021.25f || w <= 0 || h <= 0 || w > kMaxImageDim || h > kMaxImageDim || b.size() < 12 + (size_t)w * h * 8) return false;      // "PIEH"
   flow.create(h, w, cv::CV_32FC2);
   std::memcpy(flow.data, b.data() + 12, (size_t)w * h * 8);
   return true;
@@ -56,7 +57,7 @@ bool LoadMask(const std::string& path, cv::Mat& mask) {
       if (*q == '-') { neg = true; ++q; }
       if (q >= eol || *q < '0' || *q > '9') { ++q; continue; }
       int v = 0;
-      while (q < eol && *q >= '0' && *q <= '9') { v = v * 10 + (*q - '0'); ++q; }
+      while (q < eol && *q >= '0' && *q <= '9') { if (v < 100000000) v = v * 10 + (*q - '0'); ++q; }      // (clamped: no signed overflow on a long digit run)
       any = true;
       if (col < mask.cols) mask.at<int32_t>(row, col) = neg ? -v : v;
       ++col;
@@ -90,9 +91,10 @@ bool ReadPNG(const std::string& path, cv::Mat& img, bool as_float) {
     pos += 12 + (size_t)len;
   }
   const int ch = ctype == 0 ? 1 : ctype == 2 ? 3 : ctype == 6 ? 4 : ctype == 4 ? 2 : 0;
-  if (!w || !h || !ch || interlace || (depth != 8 && depth != 16) || ctype == 4) return false;
+  if (!w || !h || w > (unsigned)kMaxImageDim || h > (unsigned)kMaxImageDim || !ch || interlace || (depth != 8 && depth != 16) || ctype == 4) return false;
   if (depth == 16 && ch != 1 && !as_float) return false;
   const size_t bpp = (size_t)ch * depth / 8, stride = (size_t)w * bpp;
+  if (z.empty() || (stride + 1) * h > 1032 * z.size() + 64) return false;      // deflate expands at most ~1032x: the header lies about the size
   std::vector<unsigned char> raw((stride + 1) * h);
   uLongf out_len = (uLongf)raw.size();
   if (uncompress(raw.data(), &out_len, z.data(), (uLong)z.size()) != Z_OK || out_len != raw.size()) return false;
@@ -143,22 +145,22 @@ bool ReadPNG(const std::string& path, cv::Mat& img, bool as_float) {
 
 extern "C" {
 // flat hooks for the tests: sizes are returned through dims[0..2] = rows, cols, channels; data is copied into `out` when it is not NULL
-int host_io_read_flo(const char* path, int* dims, float* out) {
+int host_io_read_flo(const char* path, int* dims, float* out) try {
   cv::Mat m;
   if (!VDO_SLAM::ReadOpticalFlow(path, m)) return -1;
   dims[0] = m.rows; dims[1] = m.cols; dims[2] = 2;
   if (out) std::memcpy(out, m.data, (size_t)m.rows * m.cols * 8);
   return 0;
-}
-int host_io_load_mask(const char* path, int rows, int cols, int* out) {
+} catch (...) { return -2; }
+int host_io_load_mask(const char* path, int rows, int cols, int* out) try {
   cv::Mat m(rows, cols, cv::CV_32SC1, out);
   return VDO_SLAM::LoadMask(path, m) ? 0 : -1;
-}
-int host_io_read_png(const char* path, int as_float, int* dims, void* out) {
+} catch (...) { return -2; }
+int host_io_read_png(const char* path, int as_float, int* dims, void* out) try {
   cv::Mat m;
   if (!VDO_SLAM::ReadPNG(path, m, as_float != 0)) return -1;
   dims[0] = m.rows; dims[1] = m.cols; dims[2] = m.channels();
   if (out) std::memcpy(out, m.data, m.step * (size_t)m.rows);
   return 0;
-}
+} catch (...) { return -2; }
 }

@@ -9,6 +9,7 @@
 #include <atomic>
 #include <cstring>
 #include <thread>
+#include <stdexcept>
 
 namespace VDO_SLAM {
 
@@ -605,6 +606,11 @@ int FramePipeline::DownloadMask(int32_t* mask_out) {
   return 0;
 }
 
+int FramePipeline::DownloadDepth(float* depth_out) {
+  VDO_TRY(vdo_frame_images_download_depth(img_[cur_ ^ 1], depth_out));
+  return 0;
+}
+
 int FramePipeline::FinalizeMap() {
   if (!map_) return -1;
   if (pending_ && FinishObjects(nullptr) != 0) return -1;
@@ -701,7 +707,8 @@ void host_map_export(const VDO_SLAM::Map* m, int refined, float* cam_pose, int* 
 int host_map_full_batch(VDO_SLAM::Map* m, const float* K9, vdo_lm_stats* st) {
   cv::Mat K(3, 3, cv::CV_32F);
   std::memcpy(K.data, K9, 36);
-  VDO_SLAM::Optimizer::FullBatchOptimization(m, K);
+  try { VDO_SLAM::Optimizer::FullBatchOptimization(m, K); }
+  catch (const std::exception& e) { std::fprintf(stderr, "host_map_full_batch: %s\n", e.what()); return -1; }
   if (st) *st = VDO_SLAM::Optimizer::last_batch_stats;
   return 0;
 }

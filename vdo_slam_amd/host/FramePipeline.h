@@ -68,6 +68,8 @@ class FramePipeline {
   void SetObjectGate(const int* labels, int n) { gate_on_ = true; gate_cur_.assign(labels, labels + n); }
   // copy of the (possibly UpdateMask-modified) instance mask of the last frame given to Step
   int DownloadMask(int32_t* mask_out);
+  // the depth map of the last frame given to Step after K1 (metres): what GrabImageRGBD leaves in the caller's imD
+  int DownloadDepth(float* depth_out);
   // "Save Graph Structure" of Track() (src/Tracking.cc:1046-1110, Initialization :1238-1246): with a Map attached every frame
   // appends its static / dynamic features, depths, 3-D points, camera pose and rigid motions (+ labels) to it - the input
   // format of Optimizer::Full/PartialBatchOptimization.  FinalizeMap() writes the tracklets (GetStaticTrack /
@@ -79,6 +81,7 @@ class FramePipeline {
   // Ends a pending object stage (deferred mode); fc (optional) receives its n_object_tracked / n_dynamic_tracks.
   int Flush(FrameCounts* fc = nullptr) { return FinishObjects(fc); }
   bool ok() const { return ok_; }
+  const PipelineParams& params() const { return p_; }
   struct ObjectMotion { int mod_label, sem_label, n_inliers; float H[16]; };   // H: world-frame motion of the object from the last to this frame
   std::vector<ObjectMotion> motions_;   // objects tracked in the last Step (build_lm mode)
   float Tcw_out_[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};

@@ -4,12 +4,13 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
+#include <string>
 
 namespace VDO_SLAM {
 
-static void die(const char* what) {
-  std::fprintf(stderr, "VDO_SLAM::ORBextractor: %s: %s\n", what, vdo_last_error());
-  std::exit(-1);
+static void die(const char* what) {   // the reference has no error channel (it exits); a GPU failure surfaces as an exception the flat hooks turn into a return code
+  throw std::runtime_error(std::string("VDO_SLAM::ORBextractor: ") + what + ": " + vdo_last_error());
 }
 
 ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int _iniThFAST, int _minThFAST)

@@ -7,6 +7,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
+#include <string>
 #include <iostream>
 
 #include "Converter.h"
@@ -17,9 +19,8 @@ vdo_lm_stats Optimizer::last_batch_stats;
 
 namespace {
 
-void die(const char* what) {
-  std::fprintf(stderr, "VDO_SLAM::Optimizer: %s: %s\n", what, vdo_last_error());
-  std::exit(-1);
+void die(const char* what) {   // the reference has no error channel (it exits); a GPU failure surfaces as an exception the flat hooks turn into a return code
+  throw std::runtime_error(std::string("VDO_SLAM::Optimizer: ") + what + ": " + vdo_last_error());
 }
 
 // Eigen::Quaterniond(Matrix3d) + normalisation (+ sign fix when `positive_w`), then back to a

@@ -43,6 +43,7 @@ Tracking::Tracking(System*, Map* pMap, const std::string& strSettingPath, const 
   mbf = (float)get(cfg_, "Camera.bf");
   mbRGB = get(cfg_, "Camera.RGB", 1) != 0;
   mDepthMapFactor = (float)get(cfg_, "DepthMapFactor", 1);
+  mTestData = (int)get(cfg_, "ChooseData", 2);       // 1 OMD, 2 KITTI, 3 VirtualKITTI (include/Tracking.h:129-133, src/Tracking.cc:115-128)
   PipelineParams p{};
   p.width = (int)get(cfg_, "Camera.width"); p.height = (int)get(cfg_, "Camera.height");
   p.K4[0] = mK.at<float>(0, 0); p.K4[1] = mK.at<float>(1, 1); p.K4[2] = mK.at<float>(0, 2); p.K4[3] = mK.at<float>(1, 2);
@@ -74,6 +75,22 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
                                 const std::vector<std::vector<float> >& vObjPose_gt, const double&, cv::Mat&, const int& nImage) {
   StopFrame = nImage - 1;
   if (!have_frame_) f_id = 0;
+  // The device images were sized from Camera.width / Camera.height of the settings file: every input must have exactly that
+  // size, the reference's element types (src/System.h:45-51) and contiguous rows - anything else would be read out of bounds.
+  // The reference has no error channel: an empty Mat + a message on stderr.
+  {
+    const int W = pipe_->params().width, H = pipe_->params().height;
+    auto bad = [&](const cv::Mat& m, const char* name, int depth, int ch_lo, int ch_hi) {
+      const bool ok = !m.empty() && m.rows == H && m.cols == W && m.depth() == depth && m.channels() >= ch_lo && m.channels() <= ch_hi &&
+                      m.step == (size_t)m.cols * m.elemSize();
+      if (!ok) std::cerr << "VDO_SLAM::Tracking::GrabImageRGBD: " << name << " is " << m.cols << "x" << m.rows << " (type " << m.type() << ", step " << m.step
+                         << "), expected a continuous " << W << "x" << H << " image of the settings file's Camera.width/height" << std::endl;
+      return !ok;
+    };
+    if (bad(imRGB, "imRGB", cv::CV_8U, 1, 4) || imRGB.channels() == 2 || bad(imD, "imD", cv::CV_32F, 1, 1) || bad(imFlow, "imFlow", cv::CV_32F, 2, 2) ||
+        bad(maskSEM, "maskSEM", cv::CV_32S, 1, 1))
+      return cv::Mat();
+  }
   const int64_t n = (int64_t)imRGB.rows * imRGB.cols;
   // colour -> grey (cvtColor CV_RGB2GRAY / CV_BGR2GRAY, Tracking.cc:209-222); the caller's image is not touched
   const uint8_t* gray = imRGB.data;
@@ -82,18 +99,25 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
     if (vdo_rgb2gray(ctx_[0], imRGB.data, n, imRGB.channels(), mbRGB ? 1 : 0, gray_.data()) != VDO_OK) { std::cerr << vdo_last_error() << std::endl; return cv::Mat(); }
     gray = gray_.data();
   }
-  // K1 in place on the caller's depth map (Tracking.cc:180-204)
-  if (vdo_depth_preprocess(ctx_[0], (float*)imD.data, n, mbf, mDepthMapFactor, 0) != VDO_OK) { std::cerr << vdo_last_error() << std::endl; return cv::Mat(); }
   // ground-truth rows gate the object tracker (label = row[1], Tracking.cc:332-336, 791-841)
   std::vector<int> labels;
   for (const auto& row : vObjPose_gt) if (row.size() > 1) labels.push_back((int)row[1]);
   pipe_->SetObjectGate(labels.data(), (int)labels.size());
+  // K1 (Tracking.cc:180-204): OMD and KITTI convert disparity*factor to metres - on the device, on the uploaded map; the caller's
+  // imD, which the reference converts in place, receives the converted map back.  VirtualKITTI only clamps negative values.
+  bool metric = false;
+  if (mTestData != 1 && mTestData != 2) {
+    float* d = (float*)imD.data;
+    for (int64_t i = 0; i < n; ++i) if (d[i] < 0) d[i] = 0;
+    metric = true;
+  }
   FrameCounts fc{};
-  if (pipe_->StepHost(gray, (const float*)imD.data, (const float*)imFlow.data, (const int32_t*)maskSEM.data, true, &fc) != 0) return cv::Mat();
+  if (pipe_->StepHost(gray, (const float*)imD.data, (const float*)imFlow.data, (const int32_t*)maskSEM.data, metric, &fc) != 0) return cv::Mat();
+  if (!metric && pipe_->DownloadDepth((float*)imD.data) != 0) return cv::Mat();
   if (fc.n_recovered_masks > 0) pipe_->DownloadMask((int32_t*)maskSEM.data);      // UpdateMask writes through the shared header (Tracking.cc:3049-3068)
   have_frame_ = true;
-  // full batch optimisation after the last frame (Tracking.cc:1189-1210)
-  if (f_id == StopFrame && f_id > 1) {
+  // full batch optimisation after the last frame, KITTI only (Tracking.cc:1189-1210: `bGlobalBatch && mTestData==KITTI`)
+  if (f_id == StopFrame && f_id > 1 && mTestData == 2) {
     pipe_->FinalizeMap();
     Optimizer::FullBatchOptimization(mpMap, mK);
   }
@@ -136,19 +160,36 @@ void System::SaveResults(const std::string& filename) {
 
 // ---- flat hooks (tests / Python) ----------------------------------------------------------------------------------------
 extern "C" {
-VDO_SLAM::System* host_system_create(const char* settings) { return new VDO_SLAM::System(settings, VDO_SLAM::System::RGBD); }
+// (the C++ classes keep the reference's behaviour - exit(-1) on an unreadable settings file, no error channel; these hooks are
+// reached through ctypes, so they check first and turn failures into return codes instead of ending the host process)
+VDO_SLAM::System* host_system_create(const char* settings) {
+  {
+    std::ifstream f(settings);
+    if (!f.is_open()) { std::fprintf(stderr, "host_system_create: cannot open %s\n", settings); return nullptr; }
+  }
+  {
+    const char* dev = std::getenv("VDO_DEVICE");
+    vdo_ctx* probe = nullptr;
+    if (vdo_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &probe) != VDO_OK) { std::fprintf(stderr, "host_system_create: %s\n", vdo_last_error()); return nullptr; }
+    vdo_ctx_destroy(probe);
+  }
+  try { return new VDO_SLAM::System(settings, VDO_SLAM::System::RGBD); }
+  catch (const std::exception& e) { std::fprintf(stderr, "host_system_create: %s\n", e.what()); return nullptr; }
+}
 void host_system_destroy(VDO_SLAM::System* s) { delete s; }
 // one TrackRGBD call on host images: im (h x w x channels u8), depth (in/out f32), flow (f32 x2), mask (in/out i32), ground-truth
-// object rows [n_rows][row_len]; Tcw_out 16 floats.  Returns 0, or -1 when the tracker returned an empty pose.
+// object rows [n_rows][row_len]; Tcw_out 16 floats.  Returns 0, -1 when the tracker returned an empty pose, -2 on a GPU failure.
 int host_system_track(VDO_SLAM::System* s, const unsigned char* im, int channels, float* depth, const float* flow, int* mask, int w, int h,
                       const float* obj_rows, int n_rows, int row_len, int n_images, float* Tcw_out) {
   cv::Mat I(h, w, VDO_CV_MAKETYPE(cv::CV_8U, channels), (void*)im), D(h, w, cv::CV_32FC1, depth), Fl(h, w, cv::CV_32FC2, (void*)flow), M(h, w, cv::CV_32SC1, mask);
   cv::Mat gt = cv::Mat::eye(4, 4, cv::CV_32F), traj;
   std::vector<std::vector<float> > rows(n_rows);
   for (int i = 0; i < n_rows; ++i) rows[i].assign(obj_rows + (size_t)i * row_len, obj_rows + (size_t)(i + 1) * row_len);
-  cv::Mat T = s->TrackRGBD(I, D, Fl, M, gt, rows, 0.0, traj, n_images);
-  if (T.empty()) return -1;
-  std::memcpy(Tcw_out, T.data, 64);
+  try {
+    cv::Mat T = s->TrackRGBD(I, D, Fl, M, gt, rows, 0.0, traj, n_images);
+    if (T.empty()) return -1;
+    std::memcpy(Tcw_out, T.data, 64);
+  } catch (const std::exception& e) { std::fprintf(stderr, "host_system_track: %s\n", e.what()); return -2; }
   return 0;
 }
 int host_system_motions(VDO_SLAM::System* s, int cap, int* sem_label, float* H16) {

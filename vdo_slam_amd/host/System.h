@@ -32,6 +32,7 @@ class Tracking {
   Map* mpMap;
   std::map<std::string, double> cfg_;
   bool mbRGB = true;
+  int mTestData = 2;                  // ChooseData: 1 OMD, 2 KITTI, 3 VirtualKITTI
   float mbf = 0, mDepthMapFactor = 1;
   vdo_ctx* ctx_[4] = {nullptr, nullptr, nullptr, nullptr};
   std::unique_ptr<FramePipeline> pipe_;

@@ -1,7 +1,9 @@
 // extern "C" hooks that let the Python test-suite drive the C++ host classes of this directory
 // (ORBextractor / Frame / Optimizer with the reference's signatures).  Not part of the product
 // ABI (that is include/vdo_slam_hip.h); they only marshal flat arrays into Map / Frame objects.
+#include <cstdio>
 #include <cstring>
+#include <stdexcept>
 #include <vector>
 
 #include "Converter.h"
@@ -69,8 +71,10 @@ int host_batch_optimization(const host_map_flat* f, int partial_window, float* c
     map.TrackletDyn.push_back(tr);
     map.nObjID.push_back(f->obj_of_dyn[t]);
   }
-  if (partial_window > 0) Optimizer::PartialBatchOptimization(&map, K, partial_window);
-  else Optimizer::FullBatchOptimization(&map, K);
+  try {
+    if (partial_window > 0) Optimizer::PartialBatchOptimization(&map, K, partial_window);
+    else Optimizer::FullBatchOptimization(&map, K);
+  } catch (const std::exception& e) { std::fprintf(stderr, "host_batch_optimization: %s\n", e.what()); return -1; }
   if (st) *st = Optimizer::last_batch_stats;
   so = dof = ro = 0;
   for (int i = 0; i < F; ++i) {
