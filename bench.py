@@ -198,6 +198,8 @@ def main():
     Ts = SQ.camera_poses(n_seq)
     drop_masks, leave_at, enter_at = sequence_events(args.warmup, args.steps)
     objs = SQ.survey_objects(leave_at=leave_at, enter_at=enter_at, box_depth=BOX_DEPTH)     # 5 boxes (2 x 0.9 m deep), 4 of them turning
+    if os.environ.get("VDO_BENCH_R01_OBJECTS"):              # round 1's sequence: translating boxes, no events but the dropped mask
+        objs = SQ.default_objects(N_OBJECTS, box_depth=BOX_DEPTH)
     frames = [SQ.render_frame(k, Ts, objs, flow_sigma=FLOW_SIGMA, seed=17 * rank, invalid_depth=INVALID_DEPTH, zero_flow=ZERO_FLOW, drop_masks=drop_masks)
               for k in range(n_seq)]
     dev = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames]
@@ -222,7 +224,8 @@ def main():
             self.ctx_w = Context(local) if (not os.environ.get("VDO_BENCH_NO_WORKER") and cpus_here >= 5) else None
             self.pipe = FramePipeline(self.ctx, self.ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ,
                                                                          build_lm=1, defer_objects=defer), self.ctx_obj, self.ctx_w, None)
-            self.pipe.attach_map()                                # "Save Graph Structure": every frame is pushed into the Map (Tracking.cc:1031-1159)
+            if not os.environ.get("VDO_BENCH_NO_MAP"):
+                self.pipe.keep_graph()                            # "Save Graph Structure" (Tracking.cc:1031-1159): every frame is appended to the flat GraphStore the batch optimisers read
             self.agg = {q: 0 for q in AGG}
             self.step_ms = []
             self.err = None
@@ -300,10 +303,10 @@ def main():
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64 (LM, RANSAC) / u8,i32,f32 (front-end, tracking)", "data": "synthetic",
-        "config": {"workload": "KITTI-0000-shaped TrackRGBD per frame (C++ FramePipeline over the C-ABI, full Track() incl. the per-frame push into the Map): K15 UpdateMask, K1 depth, K11 propagation, "
+        "config": {"workload": "KITTI-0000-shaped TrackRGBD per frame (C++ FramePipeline over the C-ABI, full Track() incl. \"Save Graph Structure\": every frame appended to the GraphStore of the batch optimisers): K15 UpdateMask, K1 depth, K11 propagation, "
                                "RANSAC-P3P + motion-model initialisers, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, "
                                "joint pose+flow LM for the camera (<=1200 matches) and every tracked object (ref_quirks=1) built from the frame's own correspondences, "
-                               "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets, Map; "
+                               "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets, graph store; "
                                f"geometrically consistent synthetic sequence of {n_seq} frames: {N_OBJECTS} moving boxes (4 turning, yaw rate <= 0.05 rad/frame), flow noise sigma {FLOW_SIGMA} px, "
                                f"{INVALID_DEPTH:.0%} invalid depth, {ZERO_FLOW:.0%} zero flow, the instance mask of object 1 missing in frames {sorted(drop_masks)}, "
                                f"object 2 leaves at frame {leave_at}, object 5 enters at frame {enter_at}",

@@ -134,7 +134,7 @@ def test_system_rejects_frames_that_do_not_match_the_settings(tmp_path):
         d = f["depth_raw"].copy()
         T = s.track_rgbd(f["gray"], d, f["flow"], f["mask"].copy(), n_images=n_frames)
         assert T is not None and np.isfinite(T).all()
-        assert d.max() < 1e4 and not np.array_equal(d, f["depth_raw"])         # converted in place (metres)
+        assert np.isfinite(d).mean() > 0.9 and d[np.isfinite(d)].max() < 1e4 and not np.array_equal(d, f["depth_raw"])         # converted in place (metres; bf/0 = inf where the disparity is 0)
     assert np.abs(T[:3, 3] - frames[-1]["Tcw"][:3, 3]).max() < 0.05
     rf = s.refined_poses(n_frames)
     # OMD: FullBatchOptimization does not run (src/Tracking.cc:1198) - the refined poses are the unrefined ones

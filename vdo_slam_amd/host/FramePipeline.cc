@@ -56,22 +56,6 @@ class FramePipeline::Worker {
   std::thread th_;                // (last: started after the other members exist)
 };
 
-namespace {
-cv::Mat mat44f(const float* p) { cv::Mat m(4, 4, cv::CV_32F); std::memcpy(m.data, p, 64); return m; }
-// one frame's features in the Map's format: cv::KeyPoint / float depth / 3x1 cv::Mat world point per feature
-void push_features(std::vector<std::vector<cv::KeyPoint> >& F, std::vector<std::vector<float> >& D, std::vector<std::vector<cv::Mat> >& P,
-                   const std::vector<float>& x, const std::vector<float>& y, const std::vector<float>& d, const std::vector<float>& xyz) {
-  const size_t n = x.size();
-  std::vector<cv::KeyPoint> f(n); std::vector<float> dd(d.begin(), d.begin() + n); std::vector<cv::Mat> p(n);
-  for (size_t i = 0; i < n; ++i) {
-    f[i] = cv::KeyPoint(x[i], y[i], 0);
-    cv::Mat m(3, 1, cv::CV_32F);
-    std::memcpy(m.data, xyz.data() + 3 * i, 12);
-    p[i] = m;
-  }
-  F.push_back(std::move(f)); D.push_back(std::move(dd)); P.push_back(std::move(p));
-}
-}  // namespace
 
 static void fill_flow2(vdo_flow2_problem& p, int n, const double* obs, const double* flow, const double* depth, const float* K4, const float* Tcw_last,
                        const double* T0, double info_prior, int max_it) {
@@ -447,12 +431,12 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   fc.n_static_tracked = (int)nsta.x.size();
   int64_t np = 0;
   vdo_tracks_size(tr_sta_, &fc.n_static_tracks, &np);
-  if (map_) {                                            // "Save Graph Structure" (1), (5): static features and the camera pose of this frame
-    push_features(map_->vpFeatSta, map_->vfDepSta, map_->vp3DPointSta, nsta.x, nsta.y, nsta.d, nsta.xyz);
+  if (keep_graph_) {                                     // "Save Graph Structure" (1), (5): static features and the camera pose of this frame
+    store_.sta.append(nsta.x.size(), nsta.x.data(), nsta.y.data(), nsta.d.data(), nsta.xyz.data());
     float Twc_m[16];
     inv_rigid(Tcw, Twc_m);
-    map_->vmCameraPose.push_back(mat44f(Twc_m)); map_->vmCameraPose_RF.push_back(mat44f(Twc_m));
-    if (!have_last_) push_features(map_->vpFeatDyn, map_->vfDepDyn, map_->vp3DPointDyn, nobj.x, nobj.y, nobj.d, nobj.xyz);
+    store_.add_camera(Twc_m);
+    if (!have_last_) store_.dyn.append(nobj.x.size(), nobj.x.data(), nobj.y.data(), nobj.d.data(), nobj.xyz.data());
   }
   sta_ = std::move(nsta);
   if (!have_last_) { fc.n_object_tracked = (int)nobj.x.size(); obj_ = std::move(nobj); vdo_tracks_size(tr_dyn_, &fc.n_dynamic_tracks, &np); }
@@ -573,20 +557,18 @@ int FramePipeline::FinishObjectsTail(FrameCounts* fcp) {
   tick(8);
   int64_t np = 0;
   vdo_tracks_size(tr_dyn_, &fc.n_dynamic_tracks, &np);
-  if (map_) {                                            // "Save Graph Structure" (2), (6): object features, rigid motions + labels
-    push_features(map_->vpFeatDyn, map_->vfDepDyn, map_->vp3DPointDyn, nobj.x, nobj.y, nobj.d, nobj.xyz);
-    std::vector<cv::Mat> mots; std::vector<int> labs;
-    mots.push_back(mat44f(cam_motion_)); labs.push_back(0);
+  if (keep_graph_) {                                     // "Save Graph Structure" (2), (6): object features, rigid motions + labels
+    store_.dyn.append(nobj.x.size(), nobj.x.data(), nobj.y.data(), nobj.d.data(), nobj.xyz.data());
+    std::vector<float> mots(cam_motion_, cam_motion_ + 16); std::vector<int32_t> labs(1, 0);
     if (tail_has_lm_)
-      for (const ObjectMotion& om : motions_) { mots.push_back(mat44f(om.H)); labs.push_back(om.mod_label); }
-    map_->vmRigidMotion.push_back(mots); map_->vmRigidMotion_RF.push_back(mots); map_->vnRMLabel.push_back(labs);
+      for (const ObjectMotion& om : motions_) { mots.insert(mots.end(), om.H, om.H + 16); labs.push_back(om.mod_label); }
+    store_.add_motions((int)labs.size(), mots.data(), labs.data());
     // ---- partial batch optimisation on the last window (local optimisation)      Tracking.cc:1165-1183
     const int Wn = p_.window_size, Ov = p_.overlap_size;
-    if (Wn > 0 && Wn > Ov && (f_id_obj_ - Ov + 1) % (Wn - Ov) == 0 && f_id_obj_ >= Wn - 1 && (int)map_->vpFeatSta.size() == f_id_obj_ + 1) {
-      if (TrackletsToMap() != 0) return -1;
-      cv::Mat Kc = cv::Mat::zeros(3, 3, cv::CV_32F);
-      Kc.at<float>(0, 0) = p_.K4[0]; Kc.at<float>(1, 1) = p_.K4[1]; Kc.at<float>(0, 2) = p_.K4[2]; Kc.at<float>(1, 2) = p_.K4[3]; Kc.at<float>(2, 2) = 1.f;
-      Optimizer::PartialBatchOptimization(map_, Kc, Wn);
+    if (Wn > 0 && Wn > Ov && (f_id_obj_ - Ov + 1) % (Wn - Ov) == 0 && f_id_obj_ >= Wn - 1 && store_.sta.frames() == f_id_obj_ + 1) {
+      if (GetTracks(&tl_sta_, nullptr) != 0) return -1;
+      try { Optimizer::PartialBatchOptimization(store_, tl_sta_, p_.K4, Wn); }
+      catch (const std::exception& e) { std::fprintf(stderr, "FramePipeline: %s\n", e.what()); return -1; }
       ++n_partial_batches_;
     }
   }
@@ -614,22 +596,37 @@ int FramePipeline::DownloadDepth(float* depth_out) {
 int FramePipeline::FinalizeMap() {
   if (!map_) return -1;
   if (pending_ && FinishObjects(nullptr) != 0) return -1;
-  return TrackletsToMap();
+  return SyncMap();
 }
 
-// mpMap->TrackletSta = GetStaticTrack(); mpMap->TrackletDyn = GetDynamicTrackNew();   (Tracking.cc:1065-1071)
-int FramePipeline::TrackletsToMap() {
+// the reference-format Map (vector<vector<cv::Mat>> ...) rebuilt from the store + mpMap->TrackletSta = GetStaticTrack();
+// mpMap->TrackletDyn = GetDynamicTrackNew()   (Tracking.cc:1065-1071)
+int FramePipeline::SyncMap() {
+  if (!map_) return -1;
+  if (GetTracks(&tl_sta_, &tl_dyn_) != 0) return -1;
+  StoreToMap(store_, tl_sta_, tl_dyn_, *map_);
+  return 0;
+}
+
+int FramePipeline::FullBatchOptimization() {
+  if (pending_ && FinishObjects(nullptr) != 0) return -1;
+  if (GetTracks(&tl_sta_, &tl_dyn_) != 0) return -1;
+  try { Optimizer::FullBatchOptimization(store_, tl_sta_, tl_dyn_, p_.K4); }
+  catch (const std::exception& e) { std::fprintf(stderr, "FramePipeline: %s\n", e.what()); return -1; }
+  return 0;
+}
+
+// the tracklets kept incrementally (vdo_tracks_*) as flat lists
+int FramePipeline::GetTracks(TrackList* sta, TrackList* dyn) {
   for (int which = 0; which < 2; ++which) {
+    TrackList* L = which ? dyn : sta;
+    if (!L) continue;
     vdo_tracks* t = which ? tr_dyn_ : tr_sta_;
     int nt = 0; int64_t np = 0;
     VDO_TRY(vdo_tracks_size(t, &nt, &np));
-    std::vector<int32_t> off(nt + 1, 0), fr((size_t)std::max<int64_t>(np, 1)), ft((size_t)std::max<int64_t>(np, 1)), oid(std::max(nt, 1));
-    VDO_TRY(vdo_tracks_get(t, off.data(), fr.data(), ft.data(), which ? oid.data() : nullptr));
-    std::vector<std::vector<std::pair<int, int> > >& T = which ? map_->TrackletDyn : map_->TrackletSta;
-    T.assign(nt, {});
-    for (int a = 0; a < nt; ++a)
-      for (int q = off[a]; q < off[a + 1]; ++q) T[a].push_back(std::make_pair((int)fr[q], (int)ft[q]));
-    if (which) map_->nObjID.assign(oid.begin(), oid.begin() + nt);
+    L->off.assign((size_t)nt + 1, 0); L->frame.resize((size_t)std::max<int64_t>(np, 1)); L->feat.resize((size_t)std::max<int64_t>(np, 1)); L->obj.assign((size_t)std::max(nt, 1), 0);
+    VDO_TRY(vdo_tracks_get(t, L->off.data(), L->frame.data(), L->feat.data(), which ? L->obj.data() : nullptr));
+    L->frame.resize((size_t)np); L->feat.resize((size_t)np); L->obj.resize((size_t)nt);
   }
   return 0;
 }
@@ -659,6 +656,23 @@ int host_pipeline_flush(FramePipeline* fp, FrameCounts* out) { return fp->Flush(
 VDO_SLAM::Map* host_pipeline_attach_map(FramePipeline* fp) { VDO_SLAM::Map* m = new VDO_SLAM::Map(); fp->AttachMap(m); return m; }
 void host_map_destroy(VDO_SLAM::Map* m) { delete m; }
 int host_pipeline_finalize_map(FramePipeline* fp) { return fp->FinalizeMap(); }
+void host_pipeline_keep_graph(FramePipeline* fp) { fp->KeepGraph(); }
+// Optimizer::FullBatchOptimization straight from the store (no Map); the attached Map, if any, is brought up to date afterwards
+int host_pipeline_full_batch(FramePipeline* fp, vdo_lm_stats* st) {
+  if (fp->FullBatchOptimization() != 0) return -1;
+  if (st) *st = VDO_SLAM::Optimizer::last_batch_stats;
+  return 0;
+}
+// dims: [0] frames, [1] static features, [2] dynamic features, [3] transitions, [4] motions
+void host_pipeline_store_dims(const FramePipeline* fp, int64_t* dims) {
+  const VDO_SLAM::GraphStore& S = fp->store();
+  dims[0] = S.frames(); dims[1] = S.sta.off.back(); dims[2] = S.dyn.off.back(); dims[3] = S.transitions(); dims[4] = S.rm_off.back();
+}
+// refined (refined != 0) or unrefined camera poses T_wc [frames][16] of the store
+void host_pipeline_store_poses(const FramePipeline* fp, int refined, float* out) {
+  const VDO_SLAM::GraphStore& S = fp->store();
+  std::memcpy(out, (refined ? S.cam_rf : S.cam).data(), sizeof(float) * S.cam.size());
+}
 int host_pipeline_partial_batches(FramePipeline* fp) { return fp->n_partial_batches_; }
 // dims: [0] frames, [1] static features, [2] dynamic features, [3] static tracklets, [4] their pairs, [5] dynamic tracklets, [6] their pairs, [7] rigid motions
 void host_map_dims(const VDO_SLAM::Map* m, int* dims) {

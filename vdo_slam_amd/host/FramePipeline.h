@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "../../include/vdo_slam_hip.h"
+#include "GraphStore.h"
 #include "Map.h"
 
 namespace VDO_SLAM {
@@ -70,13 +71,17 @@ class FramePipeline {
   int DownloadMask(int32_t* mask_out);
   // the depth map of the last frame given to Step after K1 (metres): what GrabImageRGBD leaves in the caller's imD
   int DownloadDepth(float* depth_out);
-  // "Save Graph Structure" of Track() (src/Tracking.cc:1046-1110, Initialization :1238-1246): with a Map attached every frame
-  // appends its static / dynamic features, depths, 3-D points, camera pose and rigid motions (+ labels) to it - the input
-  // format of Optimizer::Full/PartialBatchOptimization.  FinalizeMap() writes the tracklets (GetStaticTrack /
-  // GetDynamicTrackNew, kept incrementally here) after the last frame (call Flush() first in deferred mode).
-  // The Map format costs one heap allocation per 3-D point (cv::Mat 3x1, as in the reference): off the benchmarked path.
-  void AttachMap(Map* m) { map_ = m; }
+  // "Save Graph Structure" of Track() (src/Tracking.cc:1031-1159, Initialization :1238-1246): once KeepGraph() / AttachMap()
+  // was called every frame appends its static / dynamic features, depths, 3-D points, camera pose and rigid motions (+ labels)
+  // to a flat GraphStore (plain array appends: a few microseconds per frame) - what Optimizer::Full/PartialBatchOptimization
+  // build their graph from directly.  A Map in the reference's format (one cv::Mat per 3-D point) is materialised from the
+  // store on request only: SyncMap(), which FinalizeMap() calls after the last frame (Flush() first in deferred mode).
+  void KeepGraph() { keep_graph_ = true; }
+  void AttachMap(Map* m) { map_ = m; keep_graph_ = true; }
+  int SyncMap();                       // store + tracklets -> the attached Map (complete rebuild)
   int FinalizeMap();
+  int FullBatchOptimization();         // Optimizer::FullBatchOptimization on the store (tracklets read from the incremental builders)
+  const GraphStore& store() const { return store_; }
   int n_partial_batches_ = 0;          // PartialBatchOptimization runs so far
   // Ends a pending object stage (deferred mode); fc (optional) receives its n_object_tracked / n_dynamic_tracks.
   int Flush(FrameCounts* fc = nullptr) { return FinishObjects(fc); }
@@ -94,7 +99,10 @@ class FramePipeline {
   int FinishObjectsTail(FrameCounts* fc);   // dynamic tracklets, Map, windowed optimisation: nothing the next frame's object chain waits for
   bool tail_pending_ = false, tail_has_lm_ = false;
   std::vector<int32_t> dyn_asso_tail_;
-  int TrackletsToMap();
+  int GetTracks(TrackList* sta, TrackList* dyn);
+  GraphStore store_;
+  TrackList tl_sta_, tl_dyn_;
+  bool keep_graph_ = false;
   bool host_inputs_ = false, depth_metric_ = false, gate_on_ = false;
   std::vector<int> gate_cur_, gate_last_;
   Map* map_ = nullptr;

@@ -11,6 +11,8 @@
 #include <string>
 #include <iostream>
 
+#include <cstring>
+
 #include "Converter.h"
 
 namespace VDO_SLAM {
@@ -54,28 +56,33 @@ void quat_roundtrip(const double R[9], bool positive_w, double Ro[9]) {
   Ro[6] = txz - twy; Ro[7] = tyz + twx; Ro[8] = 1 - (txx + tyy);
 }
 
-// cv::Mat (4x4 float) -> VertexSE3 estimate / EdgeSE3 measurement (12 doubles) via toSE3Quat
-void to_iso12(const cv::Mat& T, double out[12]) {
+// 4x4 float (row-major) -> VertexSE3 estimate / EdgeSE3 measurement (12 doubles) via toSE3Quat
+void to_iso12(const float* T, double out[12]) {
   double R[9];
-  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = T.at<float>(i, j);
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R[3 * i + j] = T[4 * i + j];
   quat_roundtrip(R, true, out);
-  out[9] = T.at<float>(0, 3); out[10] = T.at<float>(1, 3); out[11] = T.at<float>(2, 3);
+  out[9] = T[3]; out[10] = T[7]; out[11] = T[11];
 }
 // VertexSE3::getEstimateData (toVectorQT) -> q.matrix() -> Converter::toCvSE3 (write-back, :2094-2122)
-cv::Mat iso12_to_cv(const double p[12]) {
+void iso12_to_f16(const double p[12], float* T) {
   double Ro[9];
   quat_roundtrip(p, false, Ro);
-  return Converter::toCvSE3(Ro, p + 9);
+  const cv::Mat M = Converter::toCvSE3(Ro, p + 9);
+  std::memcpy(T, M.data, 64);
 }
+const float kIdent16[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
 
 struct GraphBuilder {
   std::vector<double> pose, point, eb_z[3], eb_w, et_z[3], et_w, ep_z, ep_info, pr_z, pr_info;
   std::vector<int32_t> eb_pose, eb_point, et_p1, et_p2, et_pose, ep_i, ep_j, pr_pose;
-  int add_pose(const cv::Mat& T) { double p[12]; to_iso12(T, p); pose.insert(pose.end(), p, p + 12); return (int)(pose.size() / 12) - 1; }
-  int add_point(const cv::Mat& Xw) { for (int k = 0; k < 3; ++k) point.push_back((double)Xw.at<float>(k)); return (int)(point.size() / 3) - 1; }
-  void add_eb(int cam, int pt, const cv::Mat& Xc, double w) {
+  int add_pose(const float* T) { double p[12]; to_iso12(T, p); pose.insert(pose.end(), p, p + 12); return (int)(pose.size() / 12) - 1; }
+  int add_point(const float* Xw) { for (int k = 0; k < 3; ++k) point.push_back((double)Xw[k]); return (int)(point.size() / 3) - 1; }
+  // measurement = Optimizer::Get3DinCamera(feature, depth, K) (:2997-3013, fp32 arithmetic)
+  void add_eb(int cam, int pt, float u, float v, float z, const float* K4, double w) {
     eb_pose.push_back(cam); eb_point.push_back(pt);
-    for (int k = 0; k < 3; ++k) eb_z[k].push_back((double)Xc.at<float>(k));
+    const float invfx = 1.0f / K4[0], invfy = 1.0f / K4[1];
+    const float x = (u - K4[2]) * z * invfx, y = (v - K4[3]) * z * invfy;
+    eb_z[0].push_back((double)x); eb_z[1].push_back((double)y); eb_z[2].push_back((double)z);
     eb_w.push_back(w);
   }
   void add_et(int p1, int p2, int h, double w) {
@@ -84,12 +91,12 @@ struct GraphBuilder {
     et_w.push_back(w);
   }
   static void push_info(std::vector<double>& v, double s) { for (int i = 0; i < 36; ++i) v.push_back(i % 7 == 0 ? s : 0.0); }
-  void add_ep(int i, int j, const cv::Mat& Z, double s) {
+  void add_ep(int i, int j, const float* Z, double s) {
     ep_i.push_back(i); ep_j.push_back(j);
     double z[12]; to_iso12(Z, z); ep_z.insert(ep_z.end(), z, z + 12);
     push_info(ep_info, s);
   }
-  void add_prior(int v, const cv::Mat& Z, double s) {
+  void add_prior(int v, const float* Z, double s) {
     pr_pose.push_back(v);
     double z[12]; to_iso12(Z, z); pr_z.insert(pr_z.end(), z, z + 12);
     push_info(pr_info, s);
@@ -118,17 +125,16 @@ struct GraphBuilder {
   }
 };
 
-cv::Mat point_to_cv(const double* p) {   // Converter::toCvMat(Matrix<double,3,1>)
-  cv::Mat m(3, 1, cv::CV_32F);
-  for (int k = 0; k < 3; ++k) m.at<float>(k) = (float)p[k];
-  return m;
-}
-
-// position of every feature inside its tracklet (the reference searches linearly, :1456-1463)
-void label_tracks(const std::vector<std::vector<std::pair<int, int> > >& tracks, std::vector<std::vector<int> >& lab, std::vector<std::vector<int> >& pos) {
-  for (int t = 0; t < (int)tracks.size(); ++t) {
-    if (tracks[t].size() < 3) continue;     // track length >= 3 (:1275-1296)
-    for (int k = 0; k < (int)tracks[t].size(); ++k) { lab[tracks[t][k].first][tracks[t][k].second] = t; pos[tracks[t][k].first][tracks[t][k].second] = k; }
+// tracklet and position inside it of every feature (global feature index = off[frame] + feature); tracks shorter than 3 are
+// not used (:1275-1296).  One pass over the pairs - the reference searches every observation linearly (:1456-1463).
+void label_tracks(const TrackList& T, const FeatureBlock& F, std::vector<int32_t>& lab, std::vector<int32_t>& pos) {
+  lab.assign((size_t)F.off.back(), -1); pos.assign((size_t)F.off.back(), -1);
+  for (int t = 0; t < T.size(); ++t) {
+    if (T.off[t + 1] - T.off[t] < 3) continue;
+    for (int q = T.off[t]; q < T.off[t + 1]; ++q) {
+      const int64_t g = F.off[T.frame[q]] + T.feat[q];
+      lab[(size_t)g] = t; pos[(size_t)g] = q - T.off[t];
+    }
   }
 }
 
@@ -204,107 +210,104 @@ cv::Mat Optimizer::PoseOptimizationFlow2(Frame* pCurFrame, Frame* pLastFrame, co
 }
 
 // ------------------------------------------------------------------------------- batch
-void Optimizer::FullBatchOptimization(Map* pMap, const cv::Mat Calib_K) {
-  const int N = (int)pMap->vpFeatSta.size();
-  const auto& StaTracks = pMap->TrackletSta;
-  const auto& DynTracks = pMap->TrackletDyn;
-  std::vector<std::vector<int> > labS(N), posS(N), mkS(N), labD(N), posD(N), mkD(N);
-  for (int i = 0; i < N; ++i) {
-    labS[i].assign(pMap->vpFeatSta[i].size(), -1); posS[i] = labS[i]; mkS[i] = labS[i];
-    labD[i].assign(pMap->vpFeatDyn[i].size(), -1); posD[i] = labD[i]; mkD[i] = labD[i];
-  }
-  label_tracks(StaTracks, labS, posS);
-  label_tracks(DynTracks, labD, posD);
-  std::vector<std::vector<int> > VertexID(N > 0 ? N - 1 : 0);
-  for (int i = 0; i < N - 1; ++i) VertexID[i].assign(pMap->vnRMLabel[i].size(), -1);
+// The graph builders of the reference (src/Optimizer.cc:1259-1766 full, :44-637 partial) over the flat GraphStore: one pass
+// over the frames, every observation finds its landmark through the per-feature (tracklet, position) labels, vertices and
+// edges go straight into the SoA arrays vdo_ba_create takes.
+void Optimizer::FullBatchOptimization(GraphStore& S, const TrackList& StaTracks, const TrackList& DynTracks, const float K4[4]) {
+  const int N = S.frames();
+  if (N <= 0) return;
+  std::vector<int32_t> labS, posS, labD, posD;
+  label_tracks(StaTracks, S.sta, labS, posS);
+  label_tracks(DynTracks, S.dyn, labD, posD);
+  std::vector<int32_t> mkS(labS.size(), -1), mkD(labD.size(), -1);
+  std::vector<int32_t> VertexID((size_t)S.rm_off.back(), -1);            // vertex of every (transition, motion)
 
   // information (float sigma^2 as in :1330-1335) and Huber delta (:1352)
   const float sigma2_cam = 0.001f, sigma2_3d_sta = 80, sigma2_obj_smo = 0.001f, sigma2_obj = 100, sigma2_3d_dyn = 80;
   const float deltaHuber = 0.0001f;
-  const cv::Mat IDENT = cv::Mat::eye(4, 4, cv::CV_32F);
   GraphBuilder G;
   int PreFrame = -1;
   for (int i = 0; i < N; ++i) {
-    const int cam = G.add_pose(pMap->vmCameraPose[i]);
-    if (i == 0) G.add_prior(cam, pMap->vmCameraPose[i], 100000.0);                                  // :1364-1373
-    else {
-      VertexID[i - 1][0] = cam;
-      G.add_ep(PreFrame, cam, pMap->vmRigidMotion[i - 1][0], 1.0 / sigma2_cam);                      // :1383-1399
+    const int cam = G.add_pose(&S.cam[16 * (size_t)i]);
+    if (i == 0) G.add_prior(cam, &S.cam[0], 100000.0);                                              // :1364-1373
+    else if (i - 1 < S.transitions() && S.n_motions(i - 1) > 0) {
+      VertexID[(size_t)S.rm_off[i - 1]] = cam;
+      G.add_ep(PreFrame, cam, &S.rm[16 * (size_t)S.rm_off[i - 1]], 1.0 / sigma2_cam);              // :1383-1399
     }
     // static features (:1404-1524)
-    for (int j = 0; j < (int)labS[i].size(); ++j) {
-      if (labS[i][j] == -1) continue;
-      const int tr = labS[i][j], ps = posS[i][j];
+    for (int64_t g = S.sta.off[i]; g < S.sta.off[i + 1]; ++g) {
+      if (labS[(size_t)g] == -1) continue;
+      const int tr = labS[(size_t)g], ps = posS[(size_t)g];
       int pt;
-      if (ps == 0) pt = G.add_point(pMap->vp3DPointSta[i][j]);
-      else pt = mkS[StaTracks[tr][ps - 1].first][StaTracks[tr][ps - 1].second];
+      if (ps == 0) pt = G.add_point(&S.sta.xyz[3 * (size_t)g]);
+      else { const int q = StaTracks.off[tr] + ps - 1; pt = mkS[(size_t)(S.sta.off[StaTracks.frame[q]] + StaTracks.feat[q])]; }
       if (pt < 0) continue;
-      G.add_eb(cam, pt, Get3DinCamera(pMap->vpFeatSta[i][j], pMap->vfDepSta[i][j], Calib_K), 1.0 / sigma2_3d_sta);
-      mkS[i][j] = pt;
+      G.add_eb(cam, pt, S.sta.u[(size_t)g], S.sta.v[(size_t)g], S.sta.d[(size_t)g], K4, 1.0 / sigma2_3d_sta);
+      mkS[(size_t)g] = pt;
     }
     // dynamic features + object motions (:1530-1747)
     if (i == 0) {
-      for (int j = 0; j < (int)labD[i].size(); ++j) {
-        if (labD[i][j] == -1) continue;
-        const int pt = G.add_point(pMap->vp3DPointDyn[i][j]);
-        G.add_eb(cam, pt, Get3DinCamera(pMap->vpFeatDyn[i][j], pMap->vfDepDyn[i][j], Calib_K), 1.0 / sigma2_3d_dyn);
-        mkD[i][j] = pt;
+      for (int64_t g = S.dyn.off[0]; g < S.dyn.off[1]; ++g) {
+        if (labD[(size_t)g] == -1) continue;
+        const int pt = G.add_point(&S.dyn.xyz[3 * (size_t)g]);
+        G.add_eb(cam, pt, S.dyn.u[(size_t)g], S.dyn.v[(size_t)g], S.dyn.d[(size_t)g], K4, 1.0 / sigma2_3d_dyn);
+        mkD[(size_t)g] = pt;
       }
-    } else {
-      const int nmot = (int)pMap->vmRigidMotion[i - 1].size();
-      std::vector<int> ObjUniqueID(nmot > 0 ? nmot - 1 : 0, -1);
+    } else if (i - 1 < S.transitions()) {
+      const int64_t r0 = S.rm_off[i - 1];
+      const int nmot = S.n_motions(i - 1);
       for (int j = 1; j < nmot; ++j) {
-        const int mv = G.add_pose(IDENT);                                                           // motions start at identity (:1581)
+        const int mv = G.add_pose(kIdent16);                                                        // motions start at identity (:1581)
         if (i > 2) {                                                                                // smoothness (:1593-1622)
+          const int64_t p0 = S.rm_off[i - 2];
           int TraceID = -1;
-          for (int k = 0; k < (int)pMap->vnRMLabel[i - 2].size(); ++k)
-            if (pMap->vnRMLabel[i - 2][k] == pMap->vnRMLabel[i - 1][j]) { TraceID = k; break; }
-          if (TraceID != -1 && VertexID[i - 2][TraceID] >= 0) G.add_ep(VertexID[i - 2][TraceID], mv, IDENT, 1.0 / sigma2_obj_smo);
+          for (int k = 0; k < S.n_motions(i - 2); ++k)
+            if (S.rm_label[(size_t)(p0 + k)] == S.rm_label[(size_t)(r0 + j)]) { TraceID = k; break; }
+          if (TraceID != -1 && VertexID[(size_t)(p0 + TraceID)] >= 0) G.add_ep(VertexID[(size_t)(p0 + TraceID)], mv, kIdent16, 1.0 / sigma2_obj_smo);
         }
-        ObjUniqueID[j - 1] = mv;
-        VertexID[i - 1][j] = mv;
+        VertexID[(size_t)(r0 + j)] = mv;
       }
-      for (int j = 0; j < (int)labD[i].size(); ++j) {
-        if (labD[i][j] == -1) continue;
-        const int tr = labD[i][j], ps = posD[i][j];
+      for (int64_t g = S.dyn.off[i]; g < S.dyn.off[i + 1]; ++g) {
+        if (labD[(size_t)g] == -1) continue;
+        const int tr = labD[(size_t)g], ps = posD[(size_t)g];
         int ObjPositionID = -1;
-        for (int k = 1; k < (int)pMap->vnRMLabel[i - 1].size(); ++k)
-          if (pMap->vnRMLabel[i - 1][k] == pMap->nObjID[tr]) { ObjPositionID = ObjUniqueID[k - 1]; break; }
+        for (int k = 1; k < nmot; ++k)
+          if (S.rm_label[(size_t)(r0 + k)] == DynTracks.obj[tr]) { ObjPositionID = VertexID[(size_t)(r0 + k)]; break; }
         if (ObjPositionID == -1 && ps != 0) continue;
-        const int pt = G.add_point(pMap->vp3DPointDyn[i][j]);
-        G.add_eb(cam, pt, Get3DinCamera(pMap->vpFeatDyn[i][j], pMap->vfDepDyn[i][j], Calib_K), 1.0 / sigma2_3d_dyn);
+        const int pt = G.add_point(&S.dyn.xyz[3 * (size_t)g]);
+        G.add_eb(cam, pt, S.dyn.u[(size_t)g], S.dyn.v[(size_t)g], S.dyn.d[(size_t)g], K4, 1.0 / sigma2_3d_dyn);
         if (ps != 0) {
-          const int prev = mkD[DynTracks[tr][ps - 1].first][DynTracks[tr][ps - 1].second];
+          const int q = DynTracks.off[tr] + ps - 1;
+          const int prev = mkD[(size_t)(S.dyn.off[DynTracks.frame[q]] + DynTracks.feat[q])];
           if (prev >= 0) G.add_et(prev, pt, ObjPositionID, 1.0 / sigma2_obj);      // (the reference would dereference a null vertex here)
         }
-        mkD[i][j] = pt;
+        mkD[(size_t)g] = pt;
       }
     }
     PreFrame = cam;
   }
   std::vector<double> pose, point;
   G.optimize((double)deltaHuber, 300, 1e-4, pose, point, &last_batch_stats);                        // optimize(300), gain 1e-4
-  // write back (:2094-2172)
-  if ((int)pMap->vmCameraPose_RF.size() < N) pMap->vmCameraPose_RF = pMap->vmCameraPose;
-  if ((int)pMap->vmRigidMotion_RF.size() < N - 1) pMap->vmRigidMotion_RF = pMap->vmRigidMotion;
-  for (int i = 0; i < N - 1; ++i)
-    for (int j = 0; j < (int)VertexID[i].size(); ++j) {
-      if (VertexID[i][j] < 0) continue;
-      const cv::Mat T = iso12_to_cv(&pose[12 * (size_t)VertexID[i][j]]);
-      if (j == 0) pMap->vmCameraPose_RF[i + 1] = T; else pMap->vmRigidMotion_RF[i][j] = T;
+  // write back (:2094-2172): refined camera poses / motions into the *_RF copies, refined points in place
+  if (S.cam_rf.size() != S.cam.size()) S.cam_rf = S.cam;
+  if (S.rm_rf.size() != S.rm.size()) S.rm_rf = S.rm;
+  for (int i = 0; i + 1 < N && i < S.transitions(); ++i)
+    for (int j = 0; j < S.n_motions(i); ++j) {
+      const int v = VertexID[(size_t)(S.rm_off[i] + j)];
+      if (v < 0) continue;
+      if (j == 0) iso12_to_f16(&pose[12 * (size_t)v], &S.cam_rf[16 * (size_t)(i + 1)]);
+      else iso12_to_f16(&pose[12 * (size_t)v], &S.rm_rf[16 * (size_t)(S.rm_off[i] + j)]);
     }
-  for (int i = 0; i < N; ++i) {
-    for (int j = 0; j < (int)mkS[i].size(); ++j) if (mkS[i][j] != -1) pMap->vp3DPointSta[i][j] = point_to_cv(&point[3 * (size_t)mkS[i][j]]);
-    for (int j = 0; j < (int)mkD[i].size(); ++j) if (mkD[i][j] != -1) pMap->vp3DPointDyn[i][j] = point_to_cv(&point[3 * (size_t)mkD[i][j]]);
-  }
+  for (size_t g = 0; g < mkS.size(); ++g) if (mkS[g] != -1) for (int k = 0; k < 3; ++k) S.sta.xyz[3 * g + k] = (float)point[3 * (size_t)mkS[g] + k];
+  for (size_t g = 0; g < mkD.size(); ++g) if (mkD[g] != -1) for (int k = 0; k < 3; ++k) S.dyn.xyz[3 * g + k] = (float)point[3 * (size_t)mkD[g] + k];
 }
 
-void Optimizer::PartialBatchOptimization(Map* pMap, const cv::Mat Calib_K, const int WINDOW_SIZE) {
-  const int N = (int)pMap->vpFeatSta.size();
-  const auto& StaTracks = pMap->TrackletSta;
-  std::vector<std::vector<int> > labS(N), posS(N), mkS(N);
-  for (int i = 0; i < N; ++i) { labS[i].assign(pMap->vpFeatSta[i].size(), -1); posS[i] = labS[i]; mkS[i] = labS[i]; }
-  label_tracks(StaTracks, labS, posS);
+void Optimizer::PartialBatchOptimization(GraphStore& S, const TrackList& StaTracks, const float K4[4], const int WINDOW_SIZE) {
+  const int N = S.frames();
+  if (N < WINDOW_SIZE || WINDOW_SIZE <= 0) return;
+  std::vector<int32_t> labS, posS;
+  label_tracks(StaTracks, S.sta, labS, posS);
+  std::vector<int32_t> mkS(labS.size(), -1);
   const float sigma2_cam = 0.0001f, sigma2_3d_sta = 16;          // :190-195 (STATIC_ONLY = true, :211)
   const float deltaHuber = 0.0001f;
   const int Start = N - WINDOW_SIZE;
@@ -312,33 +315,136 @@ void Optimizer::PartialBatchOptimization(Map* pMap, const cv::Mat Calib_K, const
   GraphBuilder G;
   int PreFrame = -1;
   for (int i = Start; i < N; ++i) {
-    const int cam = G.add_pose(pMap->vmCameraPose[i]);
-    if (i == Start && N == WINDOW_SIZE) G.add_prior(cam, pMap->vmCameraPose[i], 1.0 / 0.0000001);  // :227-236
+    const int cam = G.add_pose(&S.cam[16 * (size_t)i]);
+    if (i == Start && N == WINDOW_SIZE) G.add_prior(cam, &S.cam[16 * (size_t)i], 1.0 / 0.0000001);  // :227-236
     camID[i] = cam;
-    if (i != Start) G.add_ep(PreFrame, cam, pMap->vmRigidMotion[i - 1][0], 1.0 / sigma2_cam);
-    for (int j = 0; j < (int)labS[i].size(); ++j) {
-      if (labS[i][j] == -1) continue;
-      const int tr = labS[i][j], ps = posS[i][j];
+    if (i != Start) G.add_ep(PreFrame, cam, &S.rm[16 * (size_t)S.rm_off[i - 1]], 1.0 / sigma2_cam);
+    for (int64_t g = S.sta.off[i]; g < S.sta.off[i + 1]; ++g) {
+      if (labS[(size_t)g] == -1) continue;
+      const int tr = labS[(size_t)g], ps = posS[(size_t)g];
       int pt;
-      if (ps == 0) pt = G.add_point(pMap->vp3DPointSta[i][j]);
+      if (ps == 0) pt = G.add_point(&S.sta.xyz[3 * (size_t)g]);
       else {
-        const int pf = StaTracks[tr][ps - 1].first;
-        pt = pf >= Start ? mkS[pf][StaTracks[tr][ps - 1].second] : -1;   // tracks that started before the window are skipped (:341-344)
+        const int q = StaTracks.off[tr] + ps - 1;
+        const int pf = StaTracks.frame[q];
+        pt = pf >= Start ? mkS[(size_t)(S.sta.off[pf] + StaTracks.feat[q])] : -1;   // tracks that started before the window are skipped (:341-344)
       }
       if (pt < 0) continue;
-      G.add_eb(cam, pt, Get3DinCamera(pMap->vpFeatSta[i][j], pMap->vfDepSta[i][j], Calib_K), 1.0 / sigma2_3d_sta);
-      mkS[i][j] = pt;
+      G.add_eb(cam, pt, S.sta.u[(size_t)g], S.sta.v[(size_t)g], S.sta.d[(size_t)g], K4, 1.0 / sigma2_3d_sta);
+      mkS[(size_t)g] = pt;
     }
     PreFrame = cam;
   }
   std::vector<double> pose, point;
   G.optimize((double)deltaHuber, 100, 1e-3, pose, point, &last_batch_stats);                        // optimize(100), gain 1e-3 (:182,:807)
   for (int i = Start; i < N; ++i) {                                                                 // :1055-1068
-    pMap->vmCameraPose[i] = iso12_to_cv(&pose[12 * (size_t)camID[i]]);
-    if (i > Start) pMap->vmRigidMotion[i - 1][0] = Converter::toInvMatrix(pMap->vmCameraPose[i - 1]) * pMap->vmCameraPose[i];
+    iso12_to_f16(&pose[12 * (size_t)camID[i]], &S.cam[16 * (size_t)i]);
+    if (i > Start) {                                                                                // vmRigidMotion[i-1][0] = toInvMatrix(pose[i-1]) * pose[i]  (fp32)
+      const cv::Mat A(4, 4, cv::CV_32F, &S.cam[16 * (size_t)(i - 1)]), B(4, 4, cv::CV_32F, &S.cam[16 * (size_t)i]);
+      const cv::Mat M = Converter::toInvMatrix(A) * B;
+      std::memcpy(&S.rm[16 * (size_t)S.rm_off[i - 1]], M.data, 64);
+    }
   }
-  for (int i = Start; i < N; ++i)
-    for (int j = 0; j < (int)mkS[i].size(); ++j) if (mkS[i][j] != -1) pMap->vp3DPointSta[i][j] = point_to_cv(&point[3 * (size_t)mkS[i][j]]);
+  for (size_t g = 0; g < mkS.size(); ++g) if (mkS[g] != -1) for (int k = 0; k < 3; ++k) S.sta.xyz[3 * g + k] = (float)point[3 * (size_t)mkS[g] + k];
+}
+
+// ---- the reference's signatures: the Map is read into a store, optimised, and receives the results (same builder)
+void StoreFromMap(const Map& m, GraphStore& S, TrackList& sta, TrackList& dyn) {
+  S.clear();
+  const int N = (int)m.vpFeatSta.size();
+  auto fill = [](FeatureBlock& F, const std::vector<cv::KeyPoint>& kp, const std::vector<float>& dep, const std::vector<cv::Mat>& pts) {
+    const size_t n = kp.size();
+    for (size_t j = 0; j < n; ++j) {
+      F.u.push_back(kp[j].pt.x); F.v.push_back(kp[j].pt.y); F.d.push_back(dep[j]);
+      for (int k = 0; k < 3; ++k) F.xyz.push_back(pts[j].at<float>(k));
+    }
+    F.off.push_back(F.off.back() + (int64_t)n);
+  };
+  for (int i = 0; i < N; ++i) {
+    fill(S.sta, m.vpFeatSta[i], m.vfDepSta[i], m.vp3DPointSta[i]);
+    fill(S.dyn, m.vpFeatDyn[i], m.vfDepDyn[i], m.vp3DPointDyn[i]);
+    S.cam.insert(S.cam.end(), (const float*)m.vmCameraPose[i].data, (const float*)m.vmCameraPose[i].data + 16);
+    const cv::Mat& rf = i < (int)m.vmCameraPose_RF.size() ? m.vmCameraPose_RF[i] : m.vmCameraPose[i];
+    S.cam_rf.insert(S.cam_rf.end(), (const float*)rf.data, (const float*)rf.data + 16);
+    if (i < (int)m.vmRigidMotion.size()) {
+      for (size_t j = 0; j < m.vmRigidMotion[i].size(); ++j) {
+        S.rm.insert(S.rm.end(), (const float*)m.vmRigidMotion[i][j].data, (const float*)m.vmRigidMotion[i][j].data + 16);
+        const cv::Mat& r2 = (i < (int)m.vmRigidMotion_RF.size() && j < m.vmRigidMotion_RF[i].size()) ? m.vmRigidMotion_RF[i][j] : m.vmRigidMotion[i][j];
+        S.rm_rf.insert(S.rm_rf.end(), (const float*)r2.data, (const float*)r2.data + 16);
+        S.rm_label.push_back(m.vnRMLabel[i][j]);
+      }
+      S.rm_off.push_back(S.rm_off.back() + (int64_t)m.vmRigidMotion[i].size());
+    }
+  }
+  auto tracks = [](const std::vector<std::vector<std::pair<int, int> > >& T, TrackList& L) {
+    L.off.assign(1, 0); L.frame.clear(); L.feat.clear(); L.obj.clear();
+    for (const auto& t : T) {
+      for (const auto& pr : t) { L.frame.push_back(pr.first); L.feat.push_back(pr.second); }
+      L.off.push_back((int32_t)L.frame.size());
+    }
+  };
+  tracks(m.TrackletSta, sta); tracks(m.TrackletDyn, dyn);
+  dyn.obj.assign(m.nObjID.begin(), m.nObjID.end());
+}
+
+void StoreToMap(const GraphStore& S, const TrackList& sta, const TrackList& dyn, Map& m) {
+  const int N = S.frames();
+  auto m44 = [](const float* p) { cv::Mat M(4, 4, cv::CV_32F); std::memcpy(M.data, p, 64); return M; };
+  auto feats = [](const FeatureBlock& F, int i, std::vector<cv::KeyPoint>& kp, std::vector<float>& dep, std::vector<cv::Mat>& pts) {
+    const int64_t a = F.off[i], n = F.off[i + 1] - a;
+    kp.resize((size_t)n); dep.assign(F.d.begin() + a, F.d.begin() + a + n); pts.resize((size_t)n);
+    for (int64_t j = 0; j < n; ++j) {
+      kp[(size_t)j] = cv::KeyPoint(F.u[(size_t)(a + j)], F.v[(size_t)(a + j)], 0);
+      cv::Mat p(3, 1, cv::CV_32F);
+      std::memcpy(p.data, &F.xyz[3 * (size_t)(a + j)], 12);
+      pts[(size_t)j] = p;
+    }
+  };
+  m.vpFeatSta.resize(N); m.vfDepSta.resize(N); m.vp3DPointSta.resize(N);
+  m.vpFeatDyn.resize(N); m.vfDepDyn.resize(N); m.vp3DPointDyn.resize(N);
+  m.vmCameraPose.resize(N); m.vmCameraPose_RF.resize(N);
+  for (int i = 0; i < N; ++i) {
+    feats(S.sta, i, m.vpFeatSta[i], m.vfDepSta[i], m.vp3DPointSta[i]);
+    if (i < S.dyn.frames()) feats(S.dyn, i, m.vpFeatDyn[i], m.vfDepDyn[i], m.vp3DPointDyn[i]);
+    m.vmCameraPose[i] = m44(&S.cam[16 * (size_t)i]); m.vmCameraPose_RF[i] = m44(&S.cam_rf[16 * (size_t)i]);
+  }
+  const int Tn = S.transitions();
+  m.vmRigidMotion.resize(Tn); m.vmRigidMotion_RF.resize(Tn); m.vnRMLabel.resize(Tn);
+  for (int i = 0; i < Tn; ++i) {
+    const int n = S.n_motions(i);
+    m.vmRigidMotion[i].resize(n); m.vmRigidMotion_RF[i].resize(n); m.vnRMLabel[i].resize(n);
+    for (int j = 0; j < n; ++j) {
+      m.vmRigidMotion[i][j] = m44(&S.rm[16 * (size_t)(S.rm_off[i] + j)]); m.vmRigidMotion_RF[i][j] = m44(&S.rm_rf[16 * (size_t)(S.rm_off[i] + j)]);
+      m.vnRMLabel[i][j] = S.rm_label[(size_t)(S.rm_off[i] + j)];
+    }
+  }
+  auto tracks = [](const TrackList& L, std::vector<std::vector<std::pair<int, int> > >& T) {
+    T.assign(L.size(), {});
+    for (int t = 0; t < L.size(); ++t)
+      for (int q = L.off[t]; q < L.off[t + 1]; ++q) T[t].push_back(std::make_pair((int)L.frame[q], (int)L.feat[q]));
+  };
+  tracks(sta, m.TrackletSta); tracks(dyn, m.TrackletDyn);
+  m.nObjID.assign(dyn.obj.begin(), dyn.obj.end());
+}
+
+namespace {
+void K4_of(const cv::Mat& K, float K4[4]) { K4[0] = K.at<float>(0, 0); K4[1] = K.at<float>(1, 1); K4[2] = K.at<float>(0, 2); K4[3] = K.at<float>(1, 2); }
+}  // namespace
+
+void Optimizer::FullBatchOptimization(Map* pMap, const cv::Mat Calib_K) {
+  GraphStore S; TrackList sta, dyn;
+  StoreFromMap(*pMap, S, sta, dyn);
+  float K4[4]; K4_of(Calib_K, K4);
+  FullBatchOptimization(S, sta, dyn, K4);
+  StoreToMap(S, sta, dyn, *pMap);
+}
+
+void Optimizer::PartialBatchOptimization(Map* pMap, const cv::Mat Calib_K, const int WINDOW_SIZE) {
+  GraphStore S; TrackList sta, dyn;
+  StoreFromMap(*pMap, S, sta, dyn);
+  float K4[4]; K4_of(Calib_K, K4);
+  PartialBatchOptimization(S, sta, K4, WINDOW_SIZE);
+  StoreToMap(S, sta, dyn, *pMap);
 }
 
 // :2974-3013 (fp32 arithmetic)

@@ -118,8 +118,7 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
   have_frame_ = true;
   // full batch optimisation after the last frame, KITTI only (Tracking.cc:1189-1210: `bGlobalBatch && mTestData==KITTI`)
   if (f_id == StopFrame && f_id > 1 && mTestData == 2) {
-    pipe_->FinalizeMap();
-    Optimizer::FullBatchOptimization(mpMap, mK);
+    if (pipe_->FullBatchOptimization() != 0) return cv::Mat();     // graph built straight from the pipeline's GraphStore
   }
   ++f_id;
   cv::Mat Tcw(4, 4, cv::CV_32F);
@@ -142,7 +141,11 @@ cv::Mat System::TrackRGBD(const cv::Mat& im, cv::Mat& depthmap, const cv::Mat& f
   return mpTracker->GrabImageRGBD(im, depthmap, flowmap, masksem, mTcw_gt, vObjPose_gt, timestamp, imTraj, nImage);
 }
 
+// The Map (reference format) is materialised from the pipeline's flat store when somebody looks at it.
+Map* System::map() { mpTracker->pipeline()->SyncMap(); return mpMap; }
+
 void System::SaveResults(const std::string& filename) {
+  map();
   std::ofstream o(filename.c_str());
   o.precision(9);
   for (int rf = 0; rf < 2; ++rf) {

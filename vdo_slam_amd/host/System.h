@@ -48,7 +48,7 @@ class System {
   cv::Mat TrackRGBD(const cv::Mat& im, cv::Mat& depthmap, const cv::Mat& flowmap, const cv::Mat& masksem, const cv::Mat& mTcw_gt,
                     const std::vector<std::vector<float> >& vObjPose_gt, const double& timestamp, cv::Mat& imTraj, const int& nImage);
   void SaveResults(const std::string& filename);   // camera trajectory (T_wc rows), before and after the batch optimisation
-  Map* map() { return mpMap; }
+  Map* map();                          // brought up to date from the pipeline's GraphStore on access
   Tracking* tracker() { return mpTracker; }
 
  private:

@@ -70,6 +70,30 @@ class FramePipeline:
         self._L.host_pipeline_attach_map.argtypes = [C.c_void_p]
         self._map = self._L.host_pipeline_attach_map(self._h)
 
+    def keep_graph(self):
+        """Like attach_map() but without a Map: the frames are appended to the pipeline's flat GraphStore only."""
+        self._L.host_pipeline_keep_graph.argtypes = [C.c_void_p]
+        self._L.host_pipeline_keep_graph(self._h)
+
+    def full_batch_store(self):
+        """Optimizer::FullBatchOptimization built straight from the GraphStore (no Map); returns the LM statistics."""
+        st = K.LMStatsC()
+        self._L.host_pipeline_full_batch.argtypes = [C.c_void_p, C.POINTER(K.LMStatsC)]
+        if self._L.host_pipeline_full_batch(self._h, C.byref(st)) != 0:
+            raise K.VdoError("FullBatchOptimization (store) failed")
+        return st
+
+    def store_poses(self, refined=False):
+        """Camera poses T_wc [frames, 4, 4] of the GraphStore (refined: after the full batch)."""
+        import numpy as np
+        dims = (C.c_int64 * 5)()
+        self._L.host_pipeline_store_dims.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
+        self._L.host_pipeline_store_dims(self._h, dims)
+        out = np.zeros((max(1, dims[0]), 4, 4), np.float32)
+        self._L.host_pipeline_store_poses.argtypes = [C.c_void_p, C.c_int, K.c_float_p]
+        self._L.host_pipeline_store_poses(self._h, int(refined), out.ctypes.data_as(K.c_float_p))
+        return out[:dims[0]]
+
     def partial_batches(self):
         """PartialBatchOptimization runs so far (window_size / overlap_size of the parameters)."""
         self._L.host_pipeline_partial_batches.argtypes = [C.c_void_p]
