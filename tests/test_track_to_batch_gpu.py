@@ -44,10 +44,12 @@ def test_track_then_full_batch_matches_the_oracle(oracle, defer, worker):
     # GPU: C++ builder + solver
     st = pipe.full_batch(synth.KITTI_K)
     m_rf = pipe.export_map(synth.KITTI_K, refined=True)
-    # the same optimisation built straight from the pipeline's flat GraphStore (no Map, no per-point cv::Mat): same graph, same bits
+    # the same optimisation built straight from the pipeline's flat GraphStore (no Map, no per-point cv::Mat): the same graph
+    # (two solves of one graph agree to the rounding of the pose-pose atomics, not bit for bit)
     st2 = pipe.full_batch_store()
-    assert (st2.iterations, st2.total_trials, st2.final_chi2) == (st.iterations, st.total_trials, st.final_chi2)
-    assert np.array_equal(pipe.store_poses(refined=True), m_rf["cam_pose"]) and np.array_equal(pipe.store_poses(), m["cam_pose"])
+    assert (st2.iterations, st2.total_trials) == (st.iterations, st.total_trials) and abs(st2.final_chi2 - st.final_chi2) <= 1e-9 * st.final_chi2
+    np.testing.assert_allclose(pipe.store_poses(refined=True), m_rf["cam_pose"], rtol=0, atol=1e-6)
+    assert np.array_equal(pipe.store_poses(), m["cam_pose"])
     # oracle: Python restatement of the builder + the oracle's LM on the same Map
     g, info = SM.map_to_graph(m)
     gc, keep = K.graph_to_c(g)
