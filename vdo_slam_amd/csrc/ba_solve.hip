@@ -213,7 +213,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
 #pragma unroll
         for (int c = r; c < 6; ++c) up[k++] = M[6 * r + c];
     }
-    seg_apply16<21>(up, seg_ctl16(slot), accm + 21 * (slot >= 0 ? slot : 0));
+    { const SegCtl16 sc_ = seg_ctl16(slot); seg_apply16<21>(up, sc_, seg_flags(sc_), accm + 21 * (slot >= 0 ? slot : 0)); }
   }
   for (int base = 0; base < nt; base += VDO_TILE_THREADS) {
     const int j = base + tid;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
 #pragma unroll
         for (int c = r; c < 6; ++c) up[k++] = M11[6 * r + c] + M22[6 * r + c] + M12[6 * r + c] + M12[6 * c + r];
     }
-    seg_apply16<21>(up, seg_ctl16(slot), accm + 21 * (slot >= 0 ? slot : 0));
+    { const SegCtl16 sc_ = seg_ctl16(slot); seg_apply16<21>(up, sc_, seg_flags(sc_), accm + 21 * (slot >= 0 ? slot : 0)); }
   }
   __syncthreads();
   const int64_t NPS = d.NPS;
@@ -490,7 +490,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     q[4] = sg * s * (f.cz * y.x - f.cx * y.z);
     q[5] = sg * s * (f.cx * y.y - f.cy * y.x);
     const int skey = key[j] >= 0 ? (key[j] >> 16) : -1;
-    seg_apply16<6>(q, seg_ctl16(skey), qs + 6 * (skey >= 0 ? skey : 0));
+    { const SegCtl16 sc_ = seg_ctl16(skey); seg_apply16<6>(q, sc_, seg_flags(sc_), qs + 6 * (skey >= 0 ? skey : 0)); }
   }
   __syncthreads();
   const int64_t NPS = d.NPS;

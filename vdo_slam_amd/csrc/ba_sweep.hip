@@ -27,20 +27,36 @@ namespace vdo {
 
 void launch_posepose(const BADev& d, int which, bool build, double* ep_chi, hipStream_t s);
 
-// LDS carve-up (doubles): pts[3*TP] | accpt[9*TP] | slotW[18*S] | accpose[32*S] | red[24]
+// LDS carve-up (doubles): pts[3*TP] | accpt[4][TP] | slotW[12*S] | accpose[32*S] | red[40]
 __host__ __device__ inline size_t sweep_lds_doubles(int max_slots, bool build) {
-  return 3 * VDO_TILE_PTS + (build ? 9 * VDO_TILE_PTS : 0) + 18 * (size_t)max_slots + (build ? 32 * (size_t)max_slots : 0) + 24;
+  return 3 * VDO_TILE_PTS + (build ? 4 * VDO_TILE_PTS : 0) + 12 * (size_t)max_slots + (build ? 32 * (size_t)max_slots : 0) + 40;
+}
+
+// workgroup sums of two doubles at once (one pass of barriers); results broadcast through lds[32], lds[33]
+__device__ __forceinline__ void block_sum2(double& a, double& b, double* lds) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  a = wave_sum(a); b = wave_sum(b);
+  if (lane == 0) { lds[wv] = a; lds[16 + wv] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double sa = 0, sb = 0;
+    for (int w = 0; w < nw; ++w) { sa += lds[w]; sb += lds[16 + w]; }
+    lds[32] = sa; lds[33] = sb;
+  }
+  __syncthreads();
+  a = lds[32]; b = lds[33];
 }
 
 // The 16 running sums of one edge (we, we*c, we*c c^T, we*e, we*c x e), segment-reduced over the
 // wave 4 at a time (values are produced just-in-time to keep the register footprint small).
 __device__ __forceinline__ void pose_sums(double we, D3 c, D3 er, int slot, double* accpose_base) {
   const SegCtl16 sc = seg_ctl16(slot);
+  const SegFlags sf = seg_flags(sc);
   double* dst = accpose_base + 32 * (slot >= 0 ? slot : 0);
-  { double g[4] = {we, we * c.x, we * c.y, we * c.z}; seg_apply16<4>(g, sc, dst); }
-  { double g[4] = {we * c.x * c.x, we * c.x * c.y, we * c.x * c.z, we * c.y * c.y}; seg_apply16<4>(g, sc, dst + 4); }
-  { double g[4] = {we * c.y * c.z, we * c.z * c.z, we * er.x, we * er.y}; seg_apply16<4>(g, sc, dst + 8); }
-  { double g[4] = {we * er.z, we * (c.y * er.z - c.z * er.y), we * (c.z * er.x - c.x * er.z), we * (c.x * er.y - c.y * er.x)}; seg_apply16<4>(g, sc, dst + 12); }
+  { double g[4] = {we, we * c.x, we * c.y, we * c.z}; seg_apply16<4>(g, sc, sf, dst); }
+  { double g[4] = {we * c.x * c.x, we * c.x * c.y, we * c.x * c.z, we * c.y * c.y}; seg_apply16<4>(g, sc, sf, dst + 4); }
+  { double g[4] = {we * c.y * c.z, we * c.z * c.z, we * er.x, we * er.y}; seg_apply16<4>(g, sc, sf, dst + 8); }
+  { double g[4] = {we * er.z, we * (c.y * er.z - c.z * er.y), we * (c.z * er.x - c.x * er.z), we * (c.x * er.y - c.y * er.x)}; seg_apply16<4>(g, sc, sf, dst + 12); }
 }
 
 template <bool BUILD>
@@ -49,9 +65,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   const Tile T = d.tiles[blockIdx.x];
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
   double* pts = smem;
-  double* accpt = pts + 3 * VDO_TILE_PTS;
-  double* slotW = accpt + (BUILD ? 9 * VDO_TILE_PTS : 0);
-  double* accpose = slotW + 18 * d.max_slots;
+  double* accpt = pts + 3 * VDO_TILE_PTS;                 // [4][TP] SoA: sum of we | b.x | b.y | b.z  (lanes hit 16 bank pairs by point id)
+  double* slotW = accpt + (BUILD ? 4 * VDO_TILE_PTS : 0);
+  double* accpose = slotW + 12 * d.max_slots;
   double* red = accpose + (BUILD ? 32 * d.max_slots : 0);
   const double* __restrict__ pose = d.pose[which];
   const double* __restrict__ point = d.point[which] + 3 * (int64_t)T.pt_begin;
@@ -59,23 +75,15 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   // ---- stage points, inverse poses, zero accumulators
   for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) pts[i] = point[i];
   if (BUILD) {
-    for (int i = tid; i < 9 * npts; i += VDO_TILE_THREADS) accpt[i] = 0.0;
+    for (int i = tid; i < 4 * VDO_TILE_PTS; i += VDO_TILE_THREADS) accpt[i] = 0.0;
     for (int i = tid; i < 32 * nslot; i += VDO_TILE_THREADS) accpose[i] = 0.0;
   }
   for (int sidx = tid; sidx < nslot; sidx += VDO_TILE_THREADS) {
-    const IsoD X = iso_load(pose + 12 * (int64_t)d.tile_pose[T.slot_begin + sidx]);
-    const IsoD W = iso_inv(X);
-    double* o = slotW + 18 * sidx;
+    const IsoD W = iso_inv(iso_load(pose + 12 * (int64_t)d.tile_pose[T.slot_begin + sidx]));
+    double* o = slotW + 12 * sidx;
 #pragma unroll
     for (int i = 0; i < 9; ++i) o[i] = W.r[i];
     o[9] = W.t.x; o[10] = W.t.y; o[11] = W.t.z;
-    // M = R R^T (upper triangle), R = X.r
-    o[12] = X.r[0] * X.r[0] + X.r[1] * X.r[1] + X.r[2] * X.r[2];
-    o[13] = X.r[0] * X.r[3] + X.r[1] * X.r[4] + X.r[2] * X.r[5];
-    o[14] = X.r[0] * X.r[6] + X.r[1] * X.r[7] + X.r[2] * X.r[8];
-    o[15] = X.r[3] * X.r[3] + X.r[4] * X.r[4] + X.r[5] * X.r[5];
-    o[16] = X.r[3] * X.r[6] + X.r[4] * X.r[7] + X.r[5] * X.r[8];
-    o[17] = X.r[6] * X.r[6] + X.r[7] * X.r[7] + X.r[8] * X.r[8];
   }
   __syncthreads();
   double chi = 0.0, rchi = 0.0;
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
       const int lp = key & 0xffff;
       const double w = d.eb_w[e];
       const D3 z{d.eb_z[e], d.eb_z[Eb + e], d.eb_z[2 * Eb + e]};
-      const double* Wp = slotW + 18 * slot;   // W.r = R^T = Jl (row-major), W.t
+      const double* Wp = slotW + 12 * slot;   // W.r = R^T = Jl (row-major), W.t
       const D3 p{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
       zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
       er = zc - z;
@@ -106,12 +114,11 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
         // 6x3 block Hpl = -we * [ I ; 2[zc]x ] * Jl  -> stored factored as (we, zc); 32 B instead of 144 B
         double* F = d.Finc + e;
         F[0] = we; F[NF] = zc.x; F[2 * NF] = zc.y; F[3 * NF] = zc.z;
-        // landmark side: Hll += we * R R^T ; bl += -we * R e   (R e = Jl^T e)
-        double* A = accpt + 9 * lp;
-        atomicAdd(A + 0, we * Wp[12]); atomicAdd(A + 1, we * Wp[13]); atomicAdd(A + 2, we * Wp[14]);
-        atomicAdd(A + 3, we * Wp[15]); atomicAdd(A + 4, we * Wp[16]); atomicAdd(A + 5, we * Wp[17]);
+        // landmark side: Hll += we * Jl^T Jl = we * R R^T = we * I (R is a rotation: g2o's product differs from I by a few
+        // 1e-16, far inside the 1e-12 parity bar) -> ONE running sum per point; bl += -we * R e   (R e = Jl^T e)
         const D3 Re = rotT(Wp, er);
-        atomicAdd(A + 6, -we * Re.x); atomicAdd(A + 7, -we * Re.y); atomicAdd(A + 8, -we * Re.z);
+        atomicAdd(accpt + lp, we);
+        atomicAdd(accpt + VDO_TILE_PTS + lp, -we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + lp, -we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + lp, -we * Re.z);
       }
     }
     if (BUILD) pose_sums(we, zc, er, slot, accpose);
@@ -129,7 +136,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
       const int l1 = key & 0xffff, l2 = key >> 16;
       const double w = d.et_w[e];
       const D3 z{d.et_z[e], d.et_z[Et + e], d.et_z[2 * Et + e]};
-      const double* Hi = slotW + 18 * slot;   // Hi.r = R_H^T, Hi.t ; J2 = -Hi.r
+      const double* Hi = slotW + 12 * slot;   // Hi.r = R_H^T, Hi.t ; J2 = -Hi.r
       const D3 p1{pts[3 * l1], pts[3 * l1 + 1], pts[3 * l1 + 2]};
       const D3 p2{pts[3 * l2], pts[3 * l2 + 1], pts[3 * l2 + 2]};
       v = rot(Hi, p2) + D3{Hi[9], Hi[10], Hi[11]};
@@ -146,34 +153,31 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
         // (H,p1): we * [I ; [v]x]   and   (H,p2): -we * [I ; [v]x] * Hi.r   -> both from (we, v)
         double* F = d.Finc + Eb + e;
         F[0] = we; F[NF] = v.x; F[2 * NF] = v.y; F[3 * NF] = v.z;
-        // p1: Hll += we*I, b += -we*e ; p2: Hll += we*R_H R_H^T, b += we * R_H e
-        double* A1 = accpt + 9 * l1;
-        atomicAdd(A1 + 0, we); atomicAdd(A1 + 3, we); atomicAdd(A1 + 5, we);
-        atomicAdd(A1 + 6, -we * er.x); atomicAdd(A1 + 7, -we * er.y); atomicAdd(A1 + 8, -we * er.z);
-        double* A2 = accpt + 9 * l2;
-        atomicAdd(A2 + 0, we * Hi[12]); atomicAdd(A2 + 1, we * Hi[13]); atomicAdd(A2 + 2, we * Hi[14]);
-        atomicAdd(A2 + 3, we * Hi[15]); atomicAdd(A2 + 4, we * Hi[16]); atomicAdd(A2 + 5, we * Hi[17]);
+        // p1: Hll += we*I, b += -we*e ; p2: Hll += we*R_H R_H^T = we*I, b += we * R_H e
+        atomicAdd(accpt + l1, we);
+        atomicAdd(accpt + VDO_TILE_PTS + l1, -we * er.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l1, -we * er.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l1, -we * er.z);
         const D3 Re = rotT(Hi, er);
-        atomicAdd(A2 + 6, we * Re.x); atomicAdd(A2 + 7, we * Re.y); atomicAdd(A2 + 8, we * Re.z);
+        atomicAdd(accpt + l2, we);
+        atomicAdd(accpt + VDO_TILE_PTS + l2, we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l2, we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l2, we * Re.z);
       }
     }
     if (BUILD) pose_sums(we, v, er, slot, accpose + 16);
   }
   // ---- write back
-  const double c_tot = block_sum1(chi, red);
-  const double r_tot = block_sum1(rchi, red);
-  if (tid == 0) { d.part_chi[blockIdx.x] = c_tot; d.part_chi[d.n_tiles + blockIdx.x] = r_tot; }
+  block_sum2(chi, rchi, red);
+  if (tid == 0) { d.part_chi[blockIdx.x] = chi; d.part_chi[d.n_tiles + blockIdx.x] = rchi; }
   if (BUILD) {
-    __syncthreads();
-    // landmarks: accpt layout [m00 m01 m02 m11 m12 m22 b0 b1 b2] -> Hll 3x3 full + bl
-    for (int l = tid; l < npts; l += VDO_TILE_THREADS) {
-      const double* A = accpt + 9 * l;
-      double* H = d.Hll + 9 * (int64_t)(T.pt_begin + l);
-      H[0] = A[0]; H[1] = A[1]; H[2] = A[2];
-      H[3] = A[1]; H[4] = A[3]; H[5] = A[4];
-      H[6] = A[2]; H[7] = A[4]; H[8] = A[5];
-      double* b = d.bl + 3 * (int64_t)(T.pt_begin + l);
-      b[0] = A[6]; b[1] = A[7]; b[2] = A[8];
+    // (block_sum2's barriers order the LDS atomics before these reads)
+    // landmarks: Hll = (sum of we) * I, bl - coalesced: consecutive lanes write consecutive doubles
+    double* __restrict__ H = d.Hll + 9 * (int64_t)T.pt_begin;
+    for (int i = tid; i < 9 * npts; i += VDO_TILE_THREADS) {
+      const int l = i / 9, k = i - 9 * l;
+      H[i] = (k == 0 || k == 4 || k == 8) ? accpt[l] : 0.0;
+    }
+    double* __restrict__ b = d.bl + 3 * (int64_t)T.pt_begin;
+    for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) {
+      const int l = i / 3, k = i - 3 * l;
+      b[i] = accpt[(1 + k) * VDO_TILE_PTS + l];
     }
     const int64_t NPS = d.NPS;
     for (int i = tid; i < 32 * nslot; i += VDO_TILE_THREADS) {

@@ -101,16 +101,30 @@ __device__ __forceinline__ SegCtl16 seg_ctl16(int key) {
   const int hnext = dpp_i32<0x101>(head, 1);          // row_shl:1 (lane 15 of a row keeps `old` = 1)
   return SegCtl16{take, (key >= 0) && (lr == 15 || hnext != 0)};
 }
+// zero-filling DPP move (bound_ctrl: lanes whose source is outside the row read 0; every lane is written, so there is no
+// `old` operand to initialise)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64z(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, true);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
+  return __hiloint2double(hi, lo);
+}
+// The conditional add of a scan step is ONE fused multiply-add with a 0.0 / 1.0 flag: fma(t, 1, v) = round(t + v), the very
+// result of the addition, and fma(t, 0, v) = v exactly (t is finite) - instead of two v_cndmask + v_add per double.
+struct SegFlags { double f1, f2, f4, f8; };
+__device__ __forceinline__ SegFlags seg_flags(const SegCtl16& c) {
+  return SegFlags{(c.take & 1u) ? 1.0 : 0.0, (c.take & 2u) ? 1.0 : 0.0, (c.take & 4u) ? 1.0 : 0.0, (c.take & 8u) ? 1.0 : 0.0};
+}
 template <int N>
-__device__ __forceinline__ void seg_apply16(double (&v)[N], const SegCtl16& c, double* lds_acc_slot) {
+__device__ __forceinline__ void seg_apply16(double (&v)[N], const SegCtl16& c, const SegFlags& f, double* lds_acc_slot) {
 #pragma unroll
-  for (int i = 0; i < N; ++i) { const double t = dpp_f64<0x111>(v[i]); if (c.take & 1u) v[i] += t; }
+  for (int i = 0; i < N; ++i) v[i] = __builtin_fma(dpp_f64z<0x111>(v[i]), f.f1, v[i]);
 #pragma unroll
-  for (int i = 0; i < N; ++i) { const double t = dpp_f64<0x112>(v[i]); if (c.take & 2u) v[i] += t; }
+  for (int i = 0; i < N; ++i) v[i] = __builtin_fma(dpp_f64z<0x112>(v[i]), f.f2, v[i]);
 #pragma unroll
-  for (int i = 0; i < N; ++i) { const double t = dpp_f64<0x114>(v[i]); if (c.take & 4u) v[i] += t; }
+  for (int i = 0; i < N; ++i) v[i] = __builtin_fma(dpp_f64z<0x114>(v[i]), f.f4, v[i]);
 #pragma unroll
-  for (int i = 0; i < N; ++i) { const double t = dpp_f64<0x118>(v[i]); if (c.take & 8u) v[i] += t; }
+  for (int i = 0; i < N; ++i) v[i] = __builtin_fma(dpp_f64z<0x118>(v[i]), f.f8, v[i]);
   if (c.tail) {
 #pragma unroll
     for (int i = 0; i < N; ++i) atomicAdd(lds_acc_slot + i, v[i]);
