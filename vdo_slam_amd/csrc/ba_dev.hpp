@@ -50,6 +50,14 @@ struct BADev {
   // edges (tile-major)
   int32_t* eb_key = nullptr; double *eb_z = nullptr, *eb_w = nullptr;         // key = slot<<16 | local point
   int32_t *et_key = nullptr, *et_slot = nullptr; double *et_z = nullptr, *et_w = nullptr;  // key = lp1 | lp2<<16
+  // compact edge inputs, chosen at vdo_ba_create when they lose nothing:
+  //   eb_w == nullptr : every EdgeSE3PointXYZ carries the same information scalar (eb_w_uni) - true for every graph the reference
+  //                     builds (one sigma per edge class, src/Optimizer.cc:1330-1335)
+  //   eb_zf != nullptr: every measurement component is exactly a float (the reference's are: Get3DinCamera returns CV_32F) -
+  //                     stored as fp32 planes [3][Eb], widened exactly in the kernel; eb_z is then not allocated
+  //   et_w == nullptr / et_z == nullptr: uniform weight / all-zero measurements of the ternary edges (always, in the reference)
+  double eb_w_uni = 0, et_w_uni = 0;
+  float* eb_zf = nullptr;
   int32_t* inc_key = nullptr;            // [Ninc] slot<<16 | local point
   int32_t *ep_i = nullptr, *ep_j = nullptr; double *ep_z = nullptr, *ep_info = nullptr;
   int32_t* pr_pose = nullptr; double *pr_z = nullptr, *pr_info = nullptr;
@@ -62,7 +70,7 @@ struct BADev {
   int32_t* pc_edge = nullptr;                     // [P] edge<<1|side linking position k-1 -> k (side 0: previous pose is the edge's i), -1 at a chain head
   // linear system
   double *Hpp = nullptr, *bp = nullptr;              // [P][36], [P][6]
-  double *Hll = nullptr, *bl = nullptr;              // [L][9],  [L][3]
+  double *Hll = nullptr, *bl = nullptr;              // [L] (the landmark diagonal block is Hll[l] * I3, see ba_sweep.hip),  [L][3]
   double* Finc = nullptr;                            // [4][Eb+Et] factored pose-landmark blocks: (we, c.x, c.y, c.z)
   double* Binc = nullptr;                            // [18][Ninc] explicit 6x3 blocks — only materialised for vdo_ba_download_system
   double* Oll = nullptr;                             // [9][Et]  p1 x p2 blocks

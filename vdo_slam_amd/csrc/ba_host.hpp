@@ -20,6 +20,7 @@ struct vdo_ba {
   std::vector<int32_t> eb_old_of_new, et_old_of_new;
   std::vector<int32_t> inc_of_eb, inc1_of_et, inc2_of_et;   // by NEW edge index
   std::vector<double> h_tmp;
+  int compact_edges = 0;          // bit 0: uniform eb_w, 1: fp32 eb_z, 2: uniform et_w, 3: et_z all zero (ba_dev.hpp)
 };
 
 namespace vdo {

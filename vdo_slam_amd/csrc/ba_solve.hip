@@ -23,7 +23,7 @@ __global__ __launch_bounds__(1024) void k_max_diag(BADev d) {
   double m = 0;
   const int64_t gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = gtid; i < 6 * (int64_t)d.P; i += gsz) m = fmax(m, fabs(d.Hpp[36 * (i / 6) + 7 * (i % 6)]));
-  for (int64_t i = gtid; i < 3 * (int64_t)d.L; i += gsz) m = fmax(m, fabs(d.Hll[9 * (i / 3) + 4 * (i % 3)]));
+  for (int64_t i = gtid; i < (int64_t)d.L; i += gsz) m = fmax(m, fabs(d.Hll[i]));        // (the landmark block is Hll[l] * I3)
   m = block_max1(m, lds);
   if (threadIdx.x == 0) d.part_red[blockIdx.x] = m;
 }
@@ -45,10 +45,8 @@ __global__ void k_factor_chains(BADev d, double lambda) {
   bool ok = true;
   const int64_t Et = d.Et;
   for (int64_t l = p0; l < p1; ++l) {
-    double D[9];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) D[i] = d.Hll[9 * l + i];
-    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    const double hd = d.Hll[l] + lambda;
+    double D[9] = {hd, 0.0, 0.0, 0.0, hd, 0.0, 0.0, 0.0, hd};
     if (l > p0) {
       const int64_t e = d.pt_prev_edge[l];
       double O[9], G[9];

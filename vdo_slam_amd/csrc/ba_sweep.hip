@@ -11,8 +11,8 @@
 //      staged in LDS;
 //   2. edges stream in fully coalesced (key 4 B + z 24 B + w 8 B per edge); the 6x3
 //      pose-landmark block is written once, coalesced SoA (144 B);
-//   3. landmark 3x3+3 sums accumulate in LDS with ds_add_f64 (all edges of a point are in the
-//      tile) and are written once per point (96 B);
+//   3. landmark sums accumulate in LDS with ds_add_f64 (all edges of a point are in the tile): the 3x3 block is
+//      (sum of we) * I - J_point^T J_point = R R^T = I for both edge classes - so 1 + 3 sums per point, written once (32 B);
 //   4. the pose 6x6+6 contribution of an edge depends on 16 running sums only
 //      (J_pose = [-I | 2[zc]x]  resp. [I | -[v]x]): Σw, Σw·zc, Σw·zc zcᵀ, Σw·e, Σw·zc×e.
 //      They are reduced with a wave-level segmented scan (edges are pose-sorted inside the
@@ -99,8 +99,8 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
       const int key = d.eb_key[e];
       slot = key >> 16;
       const int lp = key & 0xffff;
-      const double w = d.eb_w[e];
-      const D3 z{d.eb_z[e], d.eb_z[Eb + e], d.eb_z[2 * Eb + e]};
+      const double w = d.eb_w ? d.eb_w[e] : d.eb_w_uni;                       // (wave-uniform choices: 16 B per edge instead of 36 B)
+      const D3 z = d.eb_zf ? D3{(double)d.eb_zf[e], (double)d.eb_zf[Eb + e], (double)d.eb_zf[2 * Eb + e]} : D3{d.eb_z[e], d.eb_z[Eb + e], d.eb_z[2 * Eb + e]};
       const double* Wp = slotW + 12 * slot;   // W.r = R^T = Jl (row-major), W.t
       const D3 p{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
       zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
@@ -134,8 +134,8 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
       const int key = d.et_key[e];
       slot = d.et_slot[e];
       const int l1 = key & 0xffff, l2 = key >> 16;
-      const double w = d.et_w[e];
-      const D3 z{d.et_z[e], d.et_z[Et + e], d.et_z[2 * Et + e]};
+      const double w = d.et_w ? d.et_w[e] : d.et_w_uni;
+      const D3 z = d.et_z ? D3{d.et_z[e], d.et_z[Et + e], d.et_z[2 * Et + e]} : D3{0.0, 0.0, 0.0};
       const double* Hi = slotW + 12 * slot;   // Hi.r = R_H^T, Hi.t ; J2 = -Hi.r
       const D3 p1{pts[3 * l1], pts[3 * l1 + 1], pts[3 * l1 + 2]};
       const D3 p2{pts[3 * l2], pts[3 * l2 + 1], pts[3 * l2 + 2]};
@@ -168,12 +168,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   if (tid == 0) { d.part_chi[blockIdx.x] = chi; d.part_chi[d.n_tiles + blockIdx.x] = rchi; }
   if (BUILD) {
     // (block_sum2's barriers order the LDS atomics before these reads)
-    // landmarks: Hll = (sum of we) * I, bl - coalesced: consecutive lanes write consecutive doubles
-    double* __restrict__ H = d.Hll + 9 * (int64_t)T.pt_begin;
-    for (int i = tid; i < 9 * npts; i += VDO_TILE_THREADS) {
-      const int l = i / 9, k = i - 9 * l;
-      H[i] = (k == 0 || k == 4 || k == 8) ? accpt[l] : 0.0;
-    }
+    // landmarks: Hll = (sum of we) * I -> one double per point; bl - coalesced: consecutive lanes write consecutive doubles
+    double* __restrict__ H = d.Hll + (int64_t)T.pt_begin;
+    for (int i = tid; i < npts; i += VDO_TILE_THREADS) H[i] = accpt[i];
     double* __restrict__ b = d.bl + 3 * (int64_t)T.pt_begin;
     for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) {
       const int l = i / 3, k = i - 3 * l;

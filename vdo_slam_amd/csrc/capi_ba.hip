@@ -2,6 +2,7 @@
 // host-side re-ordering into tiles (ba_dev.hpp), linearisation, system download, estimates.
 // The Levenberg–Marquardt driver is in ba_lm.hip.
 #include <algorithm>
+#include <cstdlib>
 #include <cstdio>
 #include <cstring>
 #include <numeric>
@@ -212,6 +213,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
 
   // ---- permuted edge / vertex data
   std::vector<double> point_new(3 * (size_t)L), eb_z(3 * (size_t)Eb), eb_w(Eb), et_z(3 * (size_t)Et), et_w(Et);
+  std::vector<float> eb_zf_host;                   // (function scope: alive until the uploads have been synchronised)
   for (int l = 0; l < L; ++l) for (int k = 0; k < 3; ++k) point_new[3 * (size_t)l + k] = g->point[3 * (size_t)pt_old_of_new[l] + k];
   for (int e = 0; e < Eb; ++e) {
     const int o = eb_old_of_new[e];
@@ -311,8 +313,23 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(point[0], point_new.data(), 3 * (size_t)L); UP(point[1], point_new.data(), 3 * (size_t)L);
   UP(tiles, tiles.data(), n_tiles); UP(tile_pose, tile_pose.data(), NPS);
   UP(chain_off, chain_off.data(), chain_off.size()); UP(pt_prev_edge, pt_prev_edge_new.data(), L);
-  UP(eb_key, eb_key.data(), Eb); UP(eb_z, eb_z.data(), 3 * (size_t)Eb); UP(eb_w, eb_w.data(), Eb);
-  UP(et_key, et_key.data(), Et); UP(et_slot, et_slot.data(), Et); UP(et_z, et_z.data(), 3 * (size_t)Et); UP(et_w, et_w.data(), Et);
+  UP(eb_key, eb_key.data(), Eb);
+  UP(et_key, et_key.data(), Et); UP(et_slot, et_slot.data(), Et);
+  {
+    // compact edge inputs where they are lossless (ba_dev.hpp): one information scalar per edge class, fp32 measurements
+    const bool force_general = std::getenv("VDO_BA_GENERAL_EDGES") != nullptr;
+    bool wb_uni = Eb > 0 && !force_general, wt_uni = Et > 0 && !force_general, zb_f32 = Eb > 0 && !force_general, zt_zero = Et > 0 && !force_general;
+    for (int e = 1; e < Eb && wb_uni; ++e) wb_uni = eb_w[e] == eb_w[0];
+    for (int e = 1; e < Et && wt_uni; ++e) wt_uni = et_w[e] == et_w[0];
+    for (size_t i = 0; i < 3 * (size_t)Eb && zb_f32; ++i) zb_f32 = eb_z[i] == (double)(float)eb_z[i];
+    for (size_t i = 0; i < 3 * (size_t)Et && zt_zero; ++i) zt_zero = et_z[i] == 0.0;
+    if (wb_uni) d.eb_w_uni = eb_w[0]; else UP(eb_w, eb_w.data(), Eb);
+    if (wt_uni) d.et_w_uni = et_w[0]; else UP(et_w, et_w.data(), Et);
+    if (zb_f32) { eb_zf_host.assign(eb_z.begin(), eb_z.end()); UP(eb_zf, eb_zf_host.data(), eb_zf_host.size()); }
+    else UP(eb_z, eb_z.data(), 3 * (size_t)Eb);
+    if (!zt_zero) UP(et_z, et_z.data(), 3 * (size_t)Et);
+    ba->compact_edges = (wb_uni ? 1 : 0) | (zb_f32 ? 2 : 0) | (wt_uni ? 4 : 0) | (zt_zero ? 8 : 0);
+  }
   UP(inc_key, inc_key.data(), inc_key.size());
   UP(ep_i, g->ep_i, Ep); UP(ep_j, g->ep_j, Ep); UP(ep_z, g->ep_z, 12 * (size_t)Ep); UP(ep_info, g->ep_info, 36 * (size_t)Ep);
   UP(pr_pose, g->pr_pose, Npr); UP(pr_z, g->pr_z, 12 * (size_t)Npr); UP(pr_info, g->pr_info, 36 * (size_t)Npr);
@@ -324,7 +341,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(Hpp, Z, 42 * (size_t)P + 4);                      // Hpp | bp | red_chi contiguous: one all-reduce per linearisation when sharded
   ba->d.bp = ba->d.Hpp + 36 * (size_t)P; ba->d.red_chi = ba->d.bp + 6 * (size_t)P;
   UP(msum, Z, 21 * (size_t)P + 1);
-  UP(Hll, Z, 9 * (size_t)L); UP(bl, Z, 3 * (size_t)L);
+  UP(Hll, Z, (size_t)L); UP(bl, Z, 3 * (size_t)L);
   UP(Finc, Z, 4 * ((size_t)Eb + (size_t)Et)); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep);
   UP(part_sums, Z, 32 * (size_t)NPS);
   UP(part_chi, Z, 2 * (size_t)n_tiles + 2 * (size_t)(Ep + Npr) + 2);
@@ -400,7 +417,7 @@ extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
   D2H(out->Hpp, d.Hpp, sizeof(double) * 36 * (size_t)d.P);
   D2H(out->bp, d.bp, sizeof(double) * 6 * (size_t)d.P);
   D2H(out->Hpp_ep, d.Hpp_ep, sizeof(double) * 36 * (size_t)d.Ep);
-  if (out->Hll) { hll.resize(9 * (size_t)d.L); D2H(hll.data(), d.Hll, sizeof(double) * hll.size()); }
+  if (out->Hll) { hll.resize((size_t)d.L); D2H(hll.data(), d.Hll, sizeof(double) * hll.size()); }      // device: one scalar per point (block = s * I3)
   if (out->bl) { bl.resize(3 * (size_t)d.L); D2H(bl.data(), d.bl, sizeof(double) * bl.size()); }
   if (out->Hll_et) { oll.resize(9 * (size_t)d.Et); D2H(oll.data(), d.Oll, sizeof(double) * oll.size()); }
   if (out->Hpl_eb || out->Hlp1_et || out->Hlp2_et) {
@@ -417,7 +434,7 @@ extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
   rc = sync_check(ba, "vdo_ba_download_system");
   if (rc != VDO_OK) return rc;
   const size_t N = d.Ninc, Eb = d.Eb, Et = d.Et;
-  if (out->Hll) for (int l = 0; l < d.L; ++l) std::memcpy(out->Hll + 9 * (size_t)ba->pt_old_of_new[l], hll.data() + 9 * (size_t)l, 72);
+  if (out->Hll) for (int l = 0; l < d.L; ++l) { double* o = out->Hll + 9 * (size_t)ba->pt_old_of_new[l]; for (int i = 0; i < 9; ++i) o[i] = (i % 4 == 0) ? hll[(size_t)l] : 0.0; }
   if (out->bl) for (int l = 0; l < d.L; ++l) std::memcpy(out->bl + 3 * (size_t)ba->pt_old_of_new[l], bl.data() + 3 * (size_t)l, 24);
   if (out->Hll_et)
     for (size_t e = 0; e < Et; ++e) for (int i = 0; i < 9; ++i) out->Hll_et[i * Et + ba->et_old_of_new[e]] = oll[i * Et + e];
