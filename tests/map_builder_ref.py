@@ -1,4 +1,4 @@
-"""Synthetic ``Map`` (reference include/Map.h:35-84) in flat-array form: per-frame static /
+"""TEST INFRASTRUCTURE (not part of the product package).  Synthetic ``Map`` (reference include/Map.h:35-84) in flat-array form: per-frame static /
 dynamic features with depths and world points, tracklets, camera poses and rigid motions — the
 INPUT of ``Optimizer::FullBatchOptimization`` / ``PartialBatchOptimization``.  Used to test the
 C++ host classes (vdo_slam_amd/host) end to end."""
@@ -6,8 +6,8 @@ from __future__ import annotations
 
 import numpy as np
 
-from . import synth
-from .synth import KITTI_K, iso, iso_apply, iso_inv, iso_mul, rotvec_to_R
+from vdo_slam_amd import synth
+from vdo_slam_amd.synth import KITTI_K, iso, iso_apply, iso_inv, iso_mul, rotvec_to_R
 
 
 def _T44(T12):

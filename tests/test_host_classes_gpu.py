@@ -8,7 +8,8 @@ import pytest
 
 from tests import frontend_ref as R
 from vdo_slam_amd import _capi as K
-from vdo_slam_amd import synth, synth_frames as SF, synth_map as SM
+from tests import map_builder_ref as SM
+from vdo_slam_amd import synth, synth_frames as SF
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -140,3 +141,67 @@ def test_pose_optimization_flow2cam_class_matches_oracle(host, oracle):
     np.testing.assert_allclose(Tout, T.astype(np.float32), rtol=1e-4, atol=1e-5)
     exp = (prob.obs + flow).astype(np.float32)
     np.testing.assert_allclose(cur[inl.astype(bool)], exp[inl.astype(bool)], atol=1e-4)
+
+
+def test_non_joint_statics_of_the_optimizer_class_match_the_oracle(host, oracle):
+    """Optimizer::PoseOptimizationNew / PoseOptimizationObjMot (include/Optimizer.h:25,27): the host statics marshal Frame members
+    (UnprojectStereoStat / Object, P = K * Tcw, Init = Tcw^-1 * mInitModel) into vdo_pose_optimize; result == the oracle's
+    unary-edge LM on the same marshalled problem."""
+    from tests.test_oracle_pose_only import run_oracle
+    from vdo_slam_amd import pose_only as PO
+    fx, fy, cx, cy = synth.KITTI_K
+    f32 = np.float32
+    rng = np.random.default_rng(8)
+
+    def inv32(T):                                        # Converter::toInvMatrix in fp32
+        o = np.eye(4, dtype=f32)
+        o[:3, :3] = T[:3, :3].T
+        o[:3, 3] = -(T[:3, :3].T.astype(np.float64) @ T[:3, 3].astype(np.float64)).astype(f32)
+        return o
+
+    def unproject(xy, d, Tcw):                           # Frame::UnprojectStereo*: fp32 with cv::gemm's double accumulation
+        x3 = np.stack([(xy[:, 0] - f32(cx)) * d * (f32(1) / f32(fx)), (xy[:, 1] - f32(cy)) * d * (f32(1) / f32(fy)), d], 1).astype(f32)
+        R = Tcw[:3, :3].astype(np.float64); t = Tcw[:3, 3].astype(np.float64)
+        return (x3.astype(np.float64) @ R).astype(f32) + (-(t @ R).astype(f32))
+
+    n = 700
+    Tl = synth._mat4(synth.rotvec_to_R(rng.normal(0, 0.02, 3)), rng.normal(0, 1.0, 3)).astype(f32)
+    last_xy = np.c_[rng.uniform(50, 1190, n), rng.uniform(30, 340, n)].astype(f32)
+    depth = rng.uniform(5, 35, n).astype(f32)
+    Xw = unproject(last_xy, depth, Tl)
+    # ---- camera: true current pose = small motion on top of the last pose
+    dT = synth._mat4(synth.rotvec_to_R(np.array([0.0, 0.006, 0.0])), np.array([0.02, -0.01, -0.8]))
+    Tc_true = dT @ Tl.astype(np.float64)
+    Xc = Xw.astype(np.float64) @ Tc_true[:3, :3].T + Tc_true[:3, 3]
+    cur_xy = np.c_[fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy] + rng.normal(0, 0.05, (n, 2))
+    cur_xy[rng.random(n) < 0.1] += rng.normal(0, 4.0, 2)
+    cur_xy = cur_xy.astype(f32)
+    Tinit = (synth._mat4(synth.rotvec_to_R(rng.normal(0, 0.003, 3)), rng.normal(0, 0.03, 3)) @ Tc_true).astype(f32)
+    host.host_pose_optimization_new.argtypes = [C.c_int] + [K.c_float_p] * 6 + [K.c_int32_p]
+    Tout = np.zeros((4, 4), f32); match = np.zeros(n, np.int32)
+    got = host.host_pose_optimization_new(n, _p(last_xy), _p(depth), _p(cur_xy), _p(Tl), _p(Tinit), _p(Tout), R._ip(match))
+    prob = PO.PoseProblem(kind=0, obs=cur_xy.astype(np.float64), Xw=Xw.astype(np.float64), K=tuple(float(f32(v)) for v in synth.KITTI_K), P=np.zeros((3, 4)),
+                          T0=Tinit.astype(np.float64), huber_delta=float(np.sqrt(f32(0.01))), max_iterations=100)
+    T, inl, ninl, st = run_oracle(oracle, prob)
+    assert got == ninl and 0.6 * n < ninl < n
+    assert np.array_equal(match >= 0, inl.astype(bool))
+    np.testing.assert_allclose(Tout, T.astype(f32), rtol=1e-4, atol=1e-5)
+    # ---- object: points moved by a world-frame motion H, seen from the current camera
+    Hm = synth._mat4(synth.rotvec_to_R(np.array([0.0, 0.02, 0.0])), np.array([0.1, 0.0, 0.6]))
+    Tcur = Tc_true.astype(f32)
+    Xn = Xw.astype(np.float64) @ Hm[:3, :3].T + Hm[:3, 3]
+    Xc = Xn @ Tcur[:3, :3].astype(np.float64).T + Tcur[:3, 3].astype(np.float64)
+    obj_xy = (np.c_[fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy] + rng.normal(0, 0.03, (n, 2))).astype(f32)
+    init_model = (Tcur.astype(np.float64) @ synth._mat4(np.eye(3), np.array([0.05, 0.0, 0.5]))).astype(f32)      # mInitModel = Tcw * H0
+    host.host_pose_optimization_objmot.argtypes = [C.c_int] + [K.c_float_p] * 7 + [K.c_int32_p, K.c_int32_p]
+    Hout = np.zeros((4, 4), f32); flag = np.zeros(n, np.int32); lab = np.zeros(n, np.int32)
+    got = host.host_pose_optimization_objmot(n, _p(last_xy), _p(depth), _p(obj_xy), _p(Tl), _p(Tcur), _p(init_model), _p(Hout), R._ip(flag), R._ip(lab))
+    KK = np.array([[f32(fx), 0, f32(cx), 0], [0, f32(fy), f32(cy), 0], [0, 0, 1, 0]], np.float64)
+    Init = (inv32(Tcur).astype(np.float64) @ init_model.astype(np.float64)).astype(f32)                 # cv::Mat product: fp32 result
+    probo = PO.PoseProblem(kind=1, obs=obj_xy.astype(np.float64), Xw=Xw.astype(np.float64), K=tuple(float(f32(v)) for v in synth.KITTI_K),
+                           P=KK @ Tcur.astype(np.float64), T0=Init.astype(np.float64), huber_delta=0.0, max_iterations=200)
+    T, inl, ninl, st = run_oracle(oracle, probo)
+    assert got == ninl and ninl > 0.8 * n
+    assert np.array_equal(flag.astype(bool), inl.astype(bool)) and np.array_equal(lab == -1, ~inl.astype(bool))
+    np.testing.assert_allclose(Hout, T.astype(f32), rtol=1e-4, atol=2e-5)
+    np.testing.assert_allclose(Hout[:3, 3], Hm[:3, 3], atol=0.02)

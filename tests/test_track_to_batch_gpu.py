@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 from vdo_slam_amd import _capi as K
-from vdo_slam_amd import synth, synth_frames as SF, synth_map as SM, synth_seq as SQ
+from tests import map_builder_ref as SM
+from vdo_slam_amd import synth, synth_frames as SF, synth_seq as SQ
 from vdo_slam_amd.ba import Context
 from vdo_slam_amd.pipeline import FramePipeline, kitti_params
 

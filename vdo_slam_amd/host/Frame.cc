@@ -85,6 +85,33 @@ Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlo
   }
 }
 
+namespace {
+// Rwl * x3Dc + twl with Rwl = Rlw^T, twl = -Rlw^T tlw: cv::Mat products of CV_32F accumulate in double (cv::gemm) and round once
+cv::Mat unproject_world(float u, float v, float z, const cv::Mat& Tcw) {
+  const float x3[3] = {(u - Frame::cx) * z * Frame::invfx, (v - Frame::cy) * z * Frame::invfy, z};
+  cv::Mat o(3, 1, cv::CV_32F);
+  for (int i = 0; i < 3; ++i) {
+    double r = 0, t = 0;
+    for (int k = 0; k < 3; ++k) { r += (double)Tcw.at<float>(k, i) * (double)x3[k]; t += (double)Tcw.at<float>(k, i) * (double)Tcw.at<float>(k, 3); }
+    o.at<float>(i) = (float)r + (-(float)t);
+  }
+  return o;
+}
+}  // namespace
+
+cv::Mat Frame::UnprojectStereoStat(const int& i, const bool&) {
+  const float z = mvStatDepth[i];
+  if (z > 0) return unproject_world(mvStatKeys[i].pt.x, mvStatKeys[i].pt.y, z, mTcw);
+  std::cout << "found a depth value < 0 ..." << std::endl;
+  return cv::Mat();
+}
+cv::Mat Frame::UnprojectStereoObject(const int& i, const bool&) {
+  const float z = mvObjDepth[i];
+  if (z > 0) return unproject_world(mvObjKeys[i].pt.x, mvObjKeys[i].pt.y, z, mTcw);
+  std::cout << "found a depth value < 0 ..." << std::endl;
+  return cv::Mat();
+}
+
 // Frame.cc:617-670 (addnoise is never set on the bJoint path)
 cv::Mat Frame::ObtainFlowDepthObject(const int& i, const bool&) {
   const float z = mvObjDepth[i];

@@ -16,6 +16,11 @@ class Frame {
         const int& UseSampleFea);
   void ExtractORB(int flag, const cv::Mat& im);
   void SetPose(cv::Mat Tcw) { mTcw = Tcw.clone(); }
+  // Frame.cc:484-555: back-projection of a tracked feature into the world frame (Rwl * x3Dc + twl, fp32 with cv::gemm's
+  // double accumulation).  `addnoise`: the reference perturbs the depth with cv::RNG(time(NULL)) Gaussian noise on this path
+  // (irreproducible by construction, and only reached with bJoint == false); the mirror uses the measured depth.
+  cv::Mat UnprojectStereoStat(const int& i, const bool& addnoise);
+  cv::Mat UnprojectStereoObject(const int& i, const bool& addnoise);
   cv::Mat ObtainFlowDepthObject(const int& i, const bool& addnoise);
   cv::Mat ObtainFlowDepthCamera(const int& i, const bool& addnoise);
 
@@ -36,7 +41,7 @@ class Frame {
   std::vector<cv::KeyPoint> mvObjKeys, mvObjCorres;
   std::vector<float> mvObjDepth;
   std::vector<cv::Point2f> mvObjFlowNext;
-  std::vector<int> vSemObjLabel;
+  std::vector<int> vSemObjLabel, vObjLabel;
   cv::Mat mInitModel;
   cv::Mat mTcw;
   static long unsigned int nNextId;

@@ -209,6 +209,73 @@ cv::Mat Optimizer::PoseOptimizationFlow2(Frame* pCurFrame, Frame* pLastFrame, co
   return Converter::toCvMat(r.T);
 }
 
+// ---- the non-joint variants (bJoint == false): unary reprojection edges, g2o replaced by vdo_pose_optimize
+// Optimizer::PoseOptimizationNew (src/Optimizer.cc:2177-2331): camera pose from the current static keys vs the last frame's
+// back-projected points (EdgeSE3ProjectXYZOnlyPose, information I2, Huber sqrt(0.01), 100 iterations, chi2 gate 0.01)
+int Optimizer::PoseOptimizationNew(Frame* pCurFrame, Frame* pLastFrame, vector<int>& TemperalMatch) {
+  const int N = (int)TemperalMatch.size();
+  std::vector<double> obs(2 * (size_t)N), Xw(3 * (size_t)N);
+  for (int i = 0; i < N; ++i) {
+    const cv::KeyPoint& kpUn = pCurFrame->mvStatKeys[TemperalMatch[i]];
+    obs[2 * i] = kpUn.pt.x; obs[2 * i + 1] = kpUn.pt.y;
+    const cv::Mat X = pLastFrame->UnprojectStereoStat(TemperalMatch[i], 1);
+    for (int k = 0; k < 3; ++k) Xw[3 * i + k] = X.empty() ? 0.0 : (double)X.at<float>(k);
+  }
+  if (N < 3) return 0;                                                // nInitialCorrespondences<3 (:2258-2259)
+  const float rp_thres = 0.01f;
+  vdo_pose_problem p{};
+  p.n = N; p.kind = 0; p.obs = obs.data(); p.Xw = Xw.data();
+  p.K[0] = pCurFrame->fx; p.K[1] = pCurFrame->fy; p.K[2] = pCurFrame->cx; p.K[3] = pCurFrame->cy;
+  Converter::toDouble16(pCurFrame->mTcw, p.T0);
+  p.huber_delta = (double)std::sqrt(rp_thres); p.chi2_gate = (double)rp_thres; p.max_iterations = 100;
+  vdo_flow2_result r;
+  std::vector<uint8_t> inl(N);
+  if (vdo_pose_optimize(HostContext(), &p, &r, inl.data()) != VDO_OK) die("vdo_pose_optimize");
+  int nBad = 0;
+  for (int i = 0; i < N; ++i) if (!inl[i]) { TemperalMatch[i] = -1; ++nBad; }                       // :2287-2293
+  pCurFrame->SetPose(Converter::toCvMat(r.T));
+  std::cout << "(Camera) inliers number/total numbers: " << N - nBad << "/" << N << std::endl;
+  return N - nBad;
+}
+
+// Optimizer::PoseOptimizationObjMot (:2544-2753): world-frame object motion H from the current object keys vs the last frame's
+// back-projected object points through P = K * Tcw (EdgeSE3ProjectXYZOnlyObjMotion, no robust kernel, 200 iterations)
+cv::Mat Optimizer::PoseOptimizationObjMot(Frame* pCurFrame, Frame* pLastFrame, const vector<int>& ObjId, std::vector<int>& InlierID) {
+  const int N = (int)ObjId.size();
+  if (N < 3) return cv::Mat::eye(4, 4, cv::CV_32F);                    // :2665-2666
+  std::vector<double> obs(2 * (size_t)N), Xw(3 * (size_t)N);
+  for (int i = 0; i < N; ++i) {
+    const cv::KeyPoint& kpUn = pCurFrame->mvObjKeys[ObjId[i]];
+    obs[2 * i] = kpUn.pt.x; obs[2 * i + 1] = kpUn.pt.y;
+    const cv::Mat X = pLastFrame->UnprojectStereoObject(ObjId[i], 0);
+    for (int k = 0; k < 3; ++k) Xw[3 * i + k] = X.empty() ? 0.0 : (double)X.at<float>(k);
+  }
+  const float rp_thres = 0.01f;
+  vdo_pose_problem p{};
+  p.n = N; p.kind = 1; p.obs = obs.data(); p.Xw = Xw.data();
+  // PP = KK * toMatrix4d(mTcw) in double (:2604-2606)
+  double T[16];
+  Converter::toDouble16(pCurFrame->mTcw, T);
+  const double KK[12] = {pCurFrame->fx, 0, pCurFrame->cx, 0, 0, pCurFrame->fy, pCurFrame->cy, 0, 0, 0, 1, 0};
+  for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < 4; ++j) { double a = 0; for (int k = 0; k < 4; ++k) a += KK[4 * i + k] * T[4 * k + j]; p.P[4 * i + j] = a; }
+  const cv::Mat Init = Converter::toInvMatrix(pCurFrame->mTcw) * pCurFrame->mInitModel;             // :2590
+  Converter::toDouble16(Init, p.T0);
+  p.huber_delta = 0.0; p.chi2_gate = (double)rp_thres; p.max_iterations = 200;
+  vdo_flow2_result r;
+  std::vector<uint8_t> inl(N);
+  if (vdo_pose_optimize(HostContext(), &p, &r, inl.data()) != VDO_OK) die("vdo_pose_optimize");
+  InlierID.clear();
+  int nBad = 0;
+  if (pCurFrame->vObjLabel.size() < pCurFrame->mvObjKeys.size()) pCurFrame->vObjLabel.resize(pCurFrame->mvObjKeys.size(), 0);
+  for (int i = 0; i < N; ++i) {                                        // :2735-2742
+    if (inl[i]) InlierID.push_back(ObjId[i]);
+    else { pCurFrame->vObjLabel[ObjId[i]] = -1; ++nBad; }
+  }
+  std::cout << "(OBJ)inliers number/total numbers: " << N - nBad << "/" << N << std::endl;
+  return Converter::toCvMat(r.T);
+}
+
 // ------------------------------------------------------------------------------- batch
 // The graph builders of the reference (src/Optimizer.cc:1259-1766 full, :44-637 partial) over the flat GraphStore: one pass
 // over the frames, every observation finds its landmark through the per-feature (tracklet, position) labels, vertices and

@@ -14,7 +14,9 @@ using std::vector;
 
 class Optimizer {
  public:
+  int static PoseOptimizationNew(Frame* pCurFrame, Frame* pLastFrame, vector<int>& TemperalMatch);
   int static PoseOptimizationFlow2Cam(Frame* pCurFrame, Frame* pLastFrame, vector<int>& TemperalMatch);
+  cv::Mat static PoseOptimizationObjMot(Frame* pCurFrame, Frame* pLastFrame, const vector<int>& ObjId, std::vector<int>& InlierID);
   cv::Mat static PoseOptimizationFlow2(Frame* pCurFrame, Frame* pLastFrame, const vector<int>& ObjId, std::vector<int>& InlierID);
   void static FullBatchOptimization(Map* pMap, const cv::Mat Calib_K);
   void static PartialBatchOptimization(Map* pMap, const cv::Mat Calib_K, const int WINDOW_SIZE);

@@ -131,4 +131,47 @@ int host_pose_optimization_flow2cam(int n, const float* last_xy, const float* fl
   return inl;
 }
 
+// Optimizer::PoseOptimizationNew through the host classes: the last frame's static keys + depths are back-projected with its
+// pose (UnprojectStereoStat), the current frame's keys are the observations.  Returns the inlier count.
+int host_pose_optimization_new(int n, const float* last_xy, const float* depth, const float* cur_xy, const float* Tcw_last, const float* Tcw_init,
+                               float* Tcw_out, int* match_out) {
+  Frame last, cur;
+  Frame::fx = 721.5377f; Frame::fy = 721.5377f; Frame::cx = 609.5593f; Frame::cy = 172.854f; Frame::invfx = 1.0f / Frame::fx; Frame::invfy = 1.0f / Frame::fy;
+  last.mTcw = mat44(Tcw_last); cur.mTcw = mat44(Tcw_init);
+  std::vector<int> match(n);
+  for (int i = 0; i < n; ++i) {
+    last.mvStatKeys.push_back(cv::KeyPoint(last_xy[2 * i], last_xy[2 * i + 1], 0));
+    last.mvStatDepth.push_back(depth[i]);
+    cur.mvStatKeys.push_back(cv::KeyPoint(cur_xy[2 * i], cur_xy[2 * i + 1], 0));
+    match[i] = i;
+  }
+  int inl = -1;
+  try { inl = Optimizer::PoseOptimizationNew(&cur, &last, match); } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return -1; }
+  std::memcpy(Tcw_out, cur.mTcw.data, 64);
+  for (int i = 0; i < n; ++i) match_out[i] = match[i];
+  return inl;
+}
+
+// Optimizer::PoseOptimizationObjMot through the host classes.  Returns the number of inliers; H_out = the returned motion.
+int host_pose_optimization_objmot(int n, const float* last_xy, const float* depth, const float* cur_xy, const float* Tcw_last, const float* Tcw_cur,
+                                  const float* init_model, float* H_out, int* inlier_flag, int* obj_label_out) {
+  Frame last, cur;
+  Frame::fx = 721.5377f; Frame::fy = 721.5377f; Frame::cx = 609.5593f; Frame::cy = 172.854f; Frame::invfx = 1.0f / Frame::fx; Frame::invfy = 1.0f / Frame::fy;
+  last.mTcw = mat44(Tcw_last); cur.mTcw = mat44(Tcw_cur); cur.mInitModel = mat44(init_model);
+  std::vector<int> ids(n), inliers;
+  for (int i = 0; i < n; ++i) {
+    last.mvObjKeys.push_back(cv::KeyPoint(last_xy[2 * i], last_xy[2 * i + 1], 0));
+    last.mvObjDepth.push_back(depth[i]);
+    cur.mvObjKeys.push_back(cv::KeyPoint(cur_xy[2 * i], cur_xy[2 * i + 1], 0));
+    cur.vObjLabel.push_back(7);
+    ids[i] = i;
+  }
+  cv::Mat H;
+  try { H = Optimizer::PoseOptimizationObjMot(&cur, &last, ids, inliers); } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return -1; }
+  std::memcpy(H_out, H.data, 64);
+  for (int i = 0; i < n; ++i) { inlier_flag[i] = 0; obj_label_out[i] = cur.vObjLabel[i]; }
+  for (int id : inliers) inlier_flag[id] = 1;
+  return (int)inliers.size();
+}
+
 }  // extern "C"

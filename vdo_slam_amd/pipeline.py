@@ -105,7 +105,7 @@ class FramePipeline:
             raise K.VdoError("FramePipeline.FinalizeMap failed")
 
     def export_map(self, K4, refined=False):
-        """The Map as the dict vdo_slam_amd/synth_map.py uses (cam_pose, feats, tr_sta, tr_dyn, obj_of_dyn, rigid_motion, rm_label)."""
+        """The Map as a dict of flat arrays (the layout tests/map_builder_ref.py uses: cam_pose, feats, tr_sta, tr_dyn, obj_of_dyn, rigid_motion, rm_label)."""
         import numpy as np
         L = self._L
         dims = (C.c_int * 8)()
