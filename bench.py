@@ -381,14 +381,16 @@ def main():
                 sh = ShardedBatchBA(ctx_ba, gs)
                 sh.optimize(max_iterations=1, gain_threshold=-1.0)
                 sh.ba.set_estimates(sh.shard.pose, sh.shard.point)
-                calls0 = sh.hook.calls
+                calls0, dbl0 = sh.hook.calls, sh.hook.doubles
                 barrier()
                 t0 = time.perf_counter()
                 st = sh.optimize(max_iterations=5, gain_threshold=-1.0)
                 barrier()
                 out["ms_per_lm_iter_sharded"] = (time.perf_counter() - t0) * 1e3 / max(1, st.iterations)
-                out["config"]["batch_sharding"] = (f"landmark tracks over {world} ranks: {sh.mine.size}/{gs.n_point} points on rank 0, "
-                                                   f"{sh.hook.calls - calls0} all-reduces in {st.iterations} LM iterations, final chi2 {st.final_chi2:.6g}")
+                out["config"]["batch_sharding"] = (f"landmark tracks over {world} ranks: {sh.mine.size}/{gs.n_point} points on rank 0, transport {sh.transport} "
+                                                   f"({'ncclAllReduce issued by the C-ABI on its stream' if sh.transport == 'rccl' else 'torch.distributed through the host callback'}), "
+                                                   f"{sh.hook.calls - calls0} all-reduces / {8 * (sh.hook.doubles - dbl0)} bytes in {st.iterations} LM iterations "
+                                                   f"({st.total_trials} trials), final chi2 {st.final_chi2:.6g}")
                 sh.close()
             except Exception as e:                       # the replica numbers above stay valid
                 out["batch_sharded_error"] = repr(e)[:300]

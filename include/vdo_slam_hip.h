@@ -152,6 +152,17 @@ int vdo_ba_set_estimates(vdo_ba* ba, const double* pose, const double* point);
  * trial.  Every rank returns the same poses; points come back for the owned shard only. */
 typedef int (*vdo_allreduce_fn)(void* user, void* device_buf, int64_t count, int op);
 int vdo_ba_set_allreduce(vdo_ba* ba, vdo_allreduce_fn fn, void* user, int shard_rank);
+/* The same exchanges issued by the library itself over RCCL (xGMI inside a node): ncclAllReduce in place on the solver's
+ * device buffers, on the context's stream - no host callback in the loop.  Rank 0 draws a 128-byte id
+ * (ncclGetUniqueId) which the host hands to every rank over any side channel; every rank then creates its communicator on the
+ * context its vdo_ba uses and attaches it.  vdo_rccl_comm_stats: all-reduces issued so far and their payload bytes. */
+typedef struct vdo_rccl_comm vdo_rccl_comm;
+int vdo_rccl_unique_id(char id_out[128]);
+int vdo_rccl_comm_create(vdo_ctx* ctx, const char id[128], int n_ranks, int rank, vdo_rccl_comm** out);
+int vdo_rccl_comm_destroy(vdo_rccl_comm* comm);
+int vdo_rccl_comm_stats(const vdo_rccl_comm* comm, int64_t* calls, int64_t* bytes);
+int vdo_rccl_allreduce(vdo_rccl_comm* comm, double* device_buf, int64_t count, int op /* 0 sum, 1 max */);
+int vdo_ba_set_rccl(vdo_ba* ba, vdo_rccl_comm* comm /* NULL: back to single GPU */);
 /* Host-only (no GPU needed): owner rank of every point so that tracks (points linked by ternary
  * edges) stay together, shards are contiguous in first-observing-frame order and balanced by
  * incidence count. */

@@ -1,10 +1,11 @@
 """Worker of the world_size>1 tests (one process per rank, rendezvous on 127.0.0.1).
 
-mode "oracle_sum" (CPU, gloo): every rank linearises ITS shard with the oracle, the landmark-side
-    partial sums go through the product's AllReduceHook exactly as vdo_ba_optimize would call it,
-    and rank 0 checks the result against the oracle linearisation of the full graph.
-mode "gpu_lm" (GPU; gloo between processes that share cuda:0 on a 1-GPU box, nccl otherwise):
-    ShardedBatchBA.optimize vs single-GPU BatchBA.optimize on the full graph.
+mode "oracle_sum" (CPU, gloo) - PROTOCOL ONLY: the product has no CPU path, so the shard systems are linearised
+    by the oracle; what is exercised of the product is the partition, the shard construction and the AllReduceHook
+    (called exactly as vdo_ba_optimize calls it) over a real 2-rank process group.  It does NOT run the sharded HIP path.
+mode "gpu_lm" (GPU): ShardedBatchBA.optimize (the sharded HIP solver) vs single-GPU BatchBA.optimize on the full graph;
+    backend "nccl": one GPU per rank, exchanges issued by the library itself over RCCL (transport "rccl") and - for
+    comparison - through the host callback; backend "gloo": ranks share cuda:0 on a 1-GPU box (callback transport).
 """
 import ctypes as C
 import dataclasses
@@ -74,21 +75,23 @@ def gpu_lm(rank, world, out_path, backend):
     torch.cuda.set_device(dev)
     ctx = Context(dev)
     res = dict(rank=rank, cases=[])
-    for kw in (dict(n_frames=14, n_static=500, n_objects=2, dyn_tracks_per_object=40, seed=3),
-               dict(n_frames=30, n_static=3000, n_objects=3, dyn_tracks_per_object=100, seed=4)):
-        g = synth.make_ba_graph(**kw)
-        sh = D.ShardedBatchBA(ctx, g)
-        st = sh.optimize(max_iterations=6, gain_threshold=-1.0)
-        pose, point = sh.estimates()
-        one = BatchBA(ctx, g)
-        st1 = one.optimize(max_iterations=6, gain_threshold=-1.0)
-        pose1, point1 = one.estimates()
-        res["cases"].append(dict(
-            it=(st.iterations, st1.iterations), trials=(st.total_trials, st1.total_trials),
-            chi=(st.final_chi2, st1.final_chi2), chi0=(st.initial_chi2, st1.initial_chi2),
-            pose_err=float(np.abs(pose - pose1).max()), point_err=float(np.abs(point - point1).max()),
-            hook_calls=sh.hook.calls, hook_doubles=sh.hook.doubles, n_mine=int(sh.mine.size), n_point=int(g.n_point)))
-        sh.close(); one.close()
+    transports = ("rccl", "callback") if backend == "nccl" else ("callback",)
+    for transport in transports:
+        for kw in (dict(n_frames=14, n_static=500, n_objects=2, dyn_tracks_per_object=40, seed=3),
+                   dict(n_frames=30, n_static=3000, n_objects=3, dyn_tracks_per_object=100, seed=4)):
+            g = synth.make_ba_graph(**kw)
+            sh = D.ShardedBatchBA(ctx, g, transport=transport)
+            st = sh.optimize(max_iterations=6, gain_threshold=-1.0)
+            pose, point = sh.estimates()
+            one = BatchBA(ctx, g)
+            st1 = one.optimize(max_iterations=6, gain_threshold=-1.0)
+            pose1, point1 = one.estimates()
+            res["cases"].append(dict(
+                transport=sh.transport, it=(st.iterations, st1.iterations), trials=(st.total_trials, st1.total_trials),
+                chi=(st.final_chi2, st1.final_chi2), chi0=(st.initial_chi2, st1.initial_chi2),
+                pose_err=float(np.abs(pose - pose1).max()), point_err=float(np.abs(point - point1).max()),
+                hook_calls=sh.hook.calls, hook_doubles=sh.hook.doubles, n_mine=int(sh.mine.size), n_point=int(g.n_point)))
+            sh.close(); one.close()
     json.dump(res, open(f"{out_path}.{rank}", "w"))
     dist.barrier()
 

@@ -81,7 +81,10 @@ def test_partition_rejects_bad_input():
         D.partition(g, 0)
 
 
-def test_shard_systems_sum_to_the_full_system_gloo_world2(tmp_path, oracle):
+def test_protocol_only_shard_systems_sum_to_the_full_system_gloo_world2(tmp_path, oracle):
+    """PROTOCOL ONLY (no GPU here, and the product has no CPU path): partition + shard construction + the all-reduce hook over
+    a real 2-rank gloo group, with the ORACLE linearising each shard.  The sharded HIP solver itself is tested by the gpu tests
+    below (2 ranks sharing one GPU over gloo; RCCL transport at world 1, and at world 2 where two GPUs are visible)."""
     res = _run_world("oracle_sum", 2, tmp_path)
     assert sum(r["n_mine"] for r in res) > 0 and all(r["n_mine"] > 0 for r in res)
     for r in res:
@@ -91,13 +94,41 @@ def test_shard_systems_sum_to_the_full_system_gloo_world2(tmp_path, oracle):
 
 @pytest.mark.gpu
 def test_sharded_lm_over_rccl_world1(tmp_path):
-    """The hook on the "nccl" (= RCCL) backend: raw-device-pointer tensors, external stream, SUM and MAX.
-    One rank is all a 1-GPU box allows; the multi-rank protocol is covered by the gloo test below."""
+    """backend "nccl" (= RCCL): the exchanges issued by the library itself (vdo_rccl_comm_*, ncclAllReduce in place on the
+    context's stream: SUM and MAX) and, for comparison, through the host callback.  One rank is all a 1-GPU box allows."""
     res = _run_world("gpu_lm", 1, tmp_path, backend="nccl", timeout=240)
+    assert {c["transport"] for c in res[0]["cases"]} == {"rccl", "callback"}
     for c in res[0]["cases"]:
         assert c["it"][0] == c["it"][1] and c["trials"][0] == c["trials"][1], c
         assert abs(c["chi"][0] - c["chi"][1]) <= 1e-6 * c["chi"][1], c
         assert c["pose_err"] < 1e-6 and c["point_err"] < 1e-5 and c["hook_calls"] > 10
+    by = {}
+    for c in res[0]["cases"]:
+        by.setdefault(c["n_point"], {})[c["transport"]] = c
+    for pair in by.values():                              # the same exchanges whichever way they travel
+        assert pair["rccl"]["hook_calls"] == pair["callback"]["hook_calls"] and pair["rccl"]["hook_doubles"] == pair["callback"]["hook_doubles"]
+
+
+def _n_gpus():
+    try:
+        import torch
+        return torch.cuda.device_count()
+    except Exception:
+        return 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(_n_gpus() < 2, reason="needs two GPUs (one per rank) for RCCL at world 2")
+def test_sharded_lm_over_rccl_world2(tmp_path):
+    """Two ranks, one GPU each, all-reduces over RCCL/xGMI issued from the C-ABI: sharded LM == single-GPU LM on every rank."""
+    res = _run_world("gpu_lm", 2, tmp_path, backend="nccl", timeout=300)
+    for r in res:
+        for c in r["cases"]:
+            assert c["it"][0] == c["it"][1] and c["trials"][0] == c["trials"][1], c
+            assert abs(c["chi"][0] - c["chi"][1]) <= 1e-6 * c["chi"][1], c
+            assert c["pose_err"] < 1e-6 and c["point_err"] < 1e-5 and 0 < c["n_mine"] < c["n_point"], c
+    for ca, cb in zip(res[0]["cases"], res[1]["cases"]):
+        assert ca["chi"][0] == cb["chi"][0] and ca["it"] == cb["it"]
 
 
 @pytest.mark.gpu

@@ -1,11 +1,13 @@
 """Multi-GPU batch BA: landmark-track shards, one process per GPU.
 
 Every rank holds all pose vertices and pose-pose edges (replicated) and the points it owns with
-their binary/ternary edges.  The C-ABI solver (vdo_ba_optimize) calls back into
-:class:`AllReduceHook` for the few exchanges it needs (see include/vdo_slam_hip.h,
-vdo_ba_set_allreduce); here that is ``torch.distributed.all_reduce`` — RCCL over xGMI with the
-"nccl" backend, gloo for CPU tests.  Nothing in this file computes: it only cuts the graph and
-moves bytes.
+their binary/ternary edges.  The exchanges the C-ABI solver (vdo_ba_optimize) needs go one of two ways:
+  * transport "rccl" (the default when the process group is "nccl" with one GPU per rank): the library owns an RCCL
+    communicator (vdo_rccl_comm_*, vdo_ba_set_rccl) and issues ncclAllReduce itself, in place, on its stream - the host is
+    not in the loop; torch.distributed only carries the 128-byte communicator id at start-up;
+  * transport "callback": the solver calls back into :class:`AllReduceHook` (vdo_ba_set_allreduce), which runs
+    ``torch.distributed.all_reduce`` - for gloo groups (CPU tests, several ranks sharing one GPU).
+Nothing in this file computes: it only cuts the graph and moves bytes.
 """
 import ctypes as C
 import dataclasses
@@ -95,11 +97,56 @@ class AllReduceHook:
         self.cfunc = ALLREDUCE_FN(fn)
 
 
+class RcclComm:
+    """RCCL communicator owned by libvdo_hip (one per context); the id travels through the torch process group."""
+
+    def __init__(self, ctx, group=None):
+        import torch.distributed as dist
+        L = K.lib()
+        L.vdo_rccl_unique_id.argtypes = [C.c_char_p]
+        L.vdo_rccl_comm_create.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        L.vdo_rccl_comm_destroy.argtypes = [C.c_void_p]
+        L.vdo_rccl_comm_stats.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+        L.vdo_rccl_allreduce.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int]
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        buf = C.create_string_buffer(128)
+        if rank == 0:
+            K.check(L.vdo_rccl_unique_id(buf))
+        box = [buf.raw]
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        self._h = C.c_void_p()
+        K.check(L.vdo_rccl_comm_create(ctx._h, box[0], world, rank, C.byref(self._h)))
+        self.rank, self.world, self._keep = rank, world, ctx
+
+    def stats(self):
+        calls, nbytes = C.c_int64(), C.c_int64()
+        K.check(K.lib().vdo_rccl_comm_stats(self._h, C.byref(calls), C.byref(nbytes)))
+        return calls.value, nbytes.value
+
+    def allreduce(self, device_ptr: int, count: int, op: int = 0):
+        K.check(K.lib().vdo_rccl_allreduce(self._h, C.c_void_p(device_ptr), count, op))
+
+    def close(self):
+        if self._h:
+            K.lib().vdo_rccl_comm_destroy(self._h); self._h = C.c_void_p()
+
+
+class _Counter:
+    def __init__(self, comm): self.comm = comm
+    @property
+    def calls(self): return self.comm.stats()[0]
+    @property
+    def doubles(self): return self.comm.stats()[1] // 8
+    error = None
+
+
 class ShardedBatchBA:
     """Batch BA over ``dist.get_world_size()`` GPUs.  ``optimize`` returns the same LM statistics on
-    every rank; ``estimates`` returns the full pose array and the full point array (shards gathered)."""
+    every rank; ``estimates`` returns the full pose array and the full point array (shards gathered).
+    transport: "rccl" (ncclAllReduce issued by the library), "callback" (torch.distributed through a host callback), or
+    None = rccl for an "nccl" process group, callback otherwise."""
 
-    def __init__(self, ctx, graph, group=None, owner=None):
+    def __init__(self, ctx, graph, group=None, owner=None, transport=None):
         import torch.distributed as dist
         from .ba import BatchBA
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
@@ -108,10 +155,20 @@ class ShardedBatchBA:
         self.owner = partition(graph, self.world) if owner is None else owner
         self.shard, self.mine = shard_graph(graph, self.owner, self.rank)
         self.ba = BatchBA(ctx, self.shard)
-        self.hook = AllReduceHook(group, stream_ptr=ctx.stream_ptr)
+        if transport is None:
+            transport = "rccl" if dist.get_backend(group) == "nccl" else "callback"
+        self.transport = transport
         L = K.lib()
-        L.vdo_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int]
-        K.check(L.vdo_ba_set_allreduce(self.ba._h, self.hook.cfunc, None, self.rank))
+        self.comm = None
+        if transport == "rccl":
+            self.comm = RcclComm(ctx, group)
+            L.vdo_ba_set_rccl.argtypes = [C.c_void_p, C.c_void_p]
+            K.check(L.vdo_ba_set_rccl(self.ba._h, self.comm._h))
+            self.hook = _Counter(self.comm)
+        else:
+            self.hook = AllReduceHook(group, stream_ptr=ctx.stream_ptr)
+            L.vdo_ba_set_allreduce.argtypes = [C.c_void_p, ALLREDUCE_FN, C.c_void_p, C.c_int]
+            K.check(L.vdo_ba_set_allreduce(self.ba._h, self.hook.cfunc, None, self.rank))
 
     def optimize(self, **kw):
         try:
@@ -137,3 +194,5 @@ class ShardedBatchBA:
 
     def close(self):
         self.ba.close()
+        if self.comm is not None:
+            self.comm.close()
