@@ -173,6 +173,8 @@ extern "C" int vdo_frame_images_create(vdo_ctx* ctx, int w, int h, vdo_frame_ima
   }
   if (hipHostMalloc((void**)&f->h_pin, 4 * ((size_t)f->cap * 8 + 16)) != hipSuccess) f->h_pin = nullptr;
   f->d_cnt = (int*)dev(16); f->d_blk = (int*)dev(4 * ((size_t)f->cap / 256 + 2));
+  f->d_cand = (unsigned long long*)dev(8 * np);
+  if (f->d_cand) hipMemsetAsync(f->d_cand, 0, 8 * np, ctx->stream);
   for (void* p : f->allocs) if (!p) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
   if (!f->d_blk || !f->h_pin) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
   *out = f;

@@ -16,6 +16,7 @@ struct vdo_frame_images {
   float* d_rows = nullptr;
   float* d_f[8] = {nullptr}; int32_t* d_i[2] = {nullptr}; int* d_cnt = nullptr; int* d_blk = nullptr;
   int cap = 0;
+  unsigned long long* d_cand = nullptr;   // [h][w] UpdateMask: labels whose warp lands on a pixel (bit = label slot); all zero between calls
   float* h_pin = nullptr;          // pinned staging, 8 rows x cap + 16 (count lives at h_pin[8*cap])
   std::vector<void*> allocs;
 };

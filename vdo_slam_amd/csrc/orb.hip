@@ -257,35 +257,6 @@ __global__ __launch_bounds__(256) void k_compact_angle(const uint8_t* __restrict
 // ------------------------------------------------------------------------------------ K7
 // 7x7 Gaussian, sigma 2, 8-bit fixed-point separable (OpenCV 3.4.0 path), REFLECT_101 at the interior edge.
 struct Blur7 { int k[7]; };
-__global__ __launch_bounds__(256) void k_blur7(const uint8_t* __restrict__ src, int w, int h, int sstride, Blur7 K, uint8_t* __restrict__ dst) {
-  __shared__ uint8_t tile[38][40];
-  __shared__ int hbuf[38][32];
-  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8 threads, tile 32x32
-  const int x0 = blockIdx.x * 32, y0 = blockIdx.y * 32;
-  for (int i = threadIdx.x; i < 38 * 38; i += 256) {
-    const int yy = i / 38, xx = i - yy * 38;
-    tile[yy][xx] = src[(size_t)reflect101(y0 + yy - 3, h) * sstride + reflect101(x0 + xx - 3, w)];
-  }
-  __syncthreads();
-  for (int yy = ty; yy < 38; yy += 8) {
-    int s = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) s += K.k[i] * tile[yy][tx + i];
-    hbuf[yy][tx] = s;
-  }
-  __syncthreads();
-  for (int yy = ty; yy < 32; yy += 8) {
-    const int x = x0 + tx, y = y0 + yy;
-    if (x >= w || y >= h) continue;
-    int s = 0;
-#pragma unroll
-    for (int i = 0; i < 7; ++i) s += K.k[i] * hbuf[yy + i][tx];
-    const int v = (s + (1 << 15)) >> 16;
-    dst[(size_t)y * w + x] = (uint8_t)min(255, max(0, v));
-  }
-}
-
-
 // ------------------------------------------------------------------------------------ K8
 // computeOrbDescriptor (reference src/ORBextractor.cc:97-136): for each of the 256 learned point pairs, rotated by the
 // keypoint angle, compare two pixels of the blurred level image: bit = I(p0) < I(p1); pixel index =
@@ -340,6 +311,44 @@ __global__ __launch_bounds__(256) void k_orb_desc(const uint8_t* __restrict__ bl
   }
   const int hi = __shfl_down(nib, 1, 64);
   if ((lane & 1) == 0) desc[(size_t)kp * 32 + (lane >> 1)] = (uint8_t)(nib | (hi << 4));
+}
+
+// all pyramid levels in ONE launch: blockIdx.x -> (level, tile) through the per-level tile offsets
+struct BlurTiles { int off[17]; int tiles_x[16]; };
+__global__ __launch_bounds__(256) void k_blur7_all(const uint8_t* __restrict__ pyr, const LevelDesc* __restrict__ levels, int n_levels, BlurTiles bt, Blur7 K,
+                                                   uint8_t* __restrict__ blur) {
+  int lvl = 0;
+  while (lvl + 1 < n_levels && (int)blockIdx.x >= bt.off[lvl + 1]) ++lvl;
+  const LevelDesc L = levels[lvl];
+  const int t = blockIdx.x - bt.off[lvl], by = t / bt.tiles_x[lvl], bx = t - by * bt.tiles_x[lvl];
+  const uint8_t* __restrict__ src = pyr + L.off_inner;
+  uint8_t* __restrict__ dst = blur + L.off_blur;
+  const int w = L.w, h = L.h, sstride = L.bw;
+  __shared__ uint8_t tile[38][40];
+  __shared__ int hbuf[38][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;       // 32 x 8 threads, tile 32x32
+  const int x0 = bx * 32, y0 = by * 32;
+  for (int i = threadIdx.x; i < 38 * 38; i += 256) {
+    const int yy = i / 38, xx = i - yy * 38;
+    tile[yy][xx] = src[(size_t)reflect101(y0 + yy - 3, h) * sstride + reflect101(x0 + xx - 3, w)];
+  }
+  __syncthreads();
+  for (int yy = ty; yy < 38; yy += 8) {
+    int a = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) a += K.k[i] * tile[yy][tx + i];
+    hbuf[yy][tx] = a;
+  }
+  __syncthreads();
+  for (int yy = ty; yy < 32; yy += 8) {
+    const int x = x0 + tx, y = y0 + yy;
+    if (x >= w || y >= h) continue;
+    int a = 0;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) a += K.k[i] * hbuf[yy + i][tx];
+    const int v = (a + (1 << 15)) >> 16;
+    dst[(size_t)y * w + x] = (uint8_t)min(255, max(0, v));
+  }
 }
 
 // --------------------------------------------------------------------------- host: quadtree (K5)
@@ -729,12 +738,15 @@ static int orb_device_stage(vdo_orb* o, const uint8_t* gray_dev, int stride) {
 // waits for it, so it is queued BEHIND the copy of the candidates: the host starts the quadtrees ~45 us earlier.
 static void orb_blur_stage(vdo_orb* o) {
   hipStream_t s = o->ctx->stream;
-  int64_t boff = 0;
+  BlurTiles bt{};
+  int tot = 0;
   for (int l = 0; l < o->prm.n_levels; ++l) {
     const LevelDesc& L = o->levels[l];
-    hipLaunchKernelGGL(k_blur7, dim3((L.w + 31) / 32, (L.h + 31) / 32), dim3(256), 0, s, (const uint8_t*)(o->d_pyr + L.off_inner), L.w, L.h, L.bw, o->blur, o->d_blur + boff);
-    boff += (int64_t)L.w * L.h;
+    bt.off[l] = tot; bt.tiles_x[l] = (L.w + 31) / 32;
+    tot += bt.tiles_x[l] * ((L.h + 31) / 32);
   }
+  bt.off[o->prm.n_levels] = tot;
+  hipLaunchKernelGGL(k_blur7_all, dim3(tot), dim3(256), 0, s, (const uint8_t*)o->d_pyr, (const LevelDesc*)o->d_levels, o->prm.n_levels, bt, o->blur, o->d_blur);
 }
 
 // operator() in two halves: _begin queues the device stage (pyramid, FAST cells, compaction + angles, blur) and the copy of the

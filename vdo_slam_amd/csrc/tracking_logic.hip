@@ -97,6 +97,113 @@ __global__ void k_mask_warp_if(const int32_t* __restrict__ flag, const int32_t* 
   if (k + fx < w && k + fx > 0 && j + fy < h && j + fy > 0) mask_cur[(size_t)(j + fy) * w + (k + fx)] = lab;
 }
 
+// ---- UpdateMask in three launches, whatever the number of labels (the label-after-label form above costs two launches per
+// label).  The reference walks the labels in ascending order; a label is "recovered" when >= 100 of its flowed samples are
+// inside the image and the most frequent CURRENT label under them is the background, and then its whole last-frame mask is
+// warped into the current mask - visible to the votes of the labels after it.  Equivalent without the sequential image
+// passes:
+//   1. k_warp_candidates: ONE pass over the last frame: cand[q] gets bit s for every label slot s whose warp lands on q;
+//   2. k_votes_seq (one workgroup): label after label; the label seen under a sample q is the recovered label of the highest
+//      earlier slot with its bit in cand[q] (a later warp overwrites an earlier one), else the untouched current mask;
+//   3. k_apply_warps: every pixel with candidate bits takes the highest recovered slot's label; cand is cleared on the way.
+// Up to 64 labels per frame (one bit each); more fall back to the label-after-label launches.
+struct LabelSlots { int n; int32_t lab[64]; };
+
+__global__ __launch_bounds__(256) void k_warp_candidates(const int32_t* __restrict__ mask_last, const float* __restrict__ flow_last, int w, int h, LabelSlots T,
+                                                         unsigned long long* __restrict__ cand) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x, j = blockIdx.y;
+  if (k >= w) return;
+  const size_t o = (size_t)j * w + k;
+  const int32_t lab = mask_last[o];
+  int slot = -1;
+  for (int s = 0; s < T.n; ++s) if (T.lab[s] == lab) slot = s;
+  if (slot < 0) return;
+  const int fx = (int)flow_last[2 * o], fy = (int)flow_last[2 * o + 1];
+  if (k + fx < w && k + fx > 0 && j + fy < h && j + fy > 0) atomicOr(&cand[(size_t)(j + fy) * w + (k + fx)], 1ull << slot);
+}
+
+// off[s] .. off[s+1]: samples (flowed positions) of label slot s.  flag[2s] = recovered, flag[2s+1] = a label fell outside the
+// histogram; rec_out = bit mask of the recovered slots.
+__global__ __launch_bounds__(256) void k_votes_seq(LabelSlots T, const int32_t* __restrict__ off, const float* __restrict__ cx, const float* __restrict__ cy,
+                                                   const int32_t* __restrict__ mask, const unsigned long long* __restrict__ cand, int w, int h,
+                                                   int32_t* __restrict__ flag, unsigned long long* __restrict__ rec_out) {
+  __shared__ int hist[kVoteBins];
+  __shared__ int s_valid, s_bad;
+  __shared__ int s_cnt[256], s_lab[256];
+  __shared__ unsigned long long s_rec;
+  if (threadIdx.x == 0) s_rec = 0ull;
+  for (int s = 0; s < T.n; ++s) {
+    for (int i = threadIdx.x; i < kVoteBins; i += 256) hist[i] = 0;
+    if (threadIdx.x == 0) { s_valid = 0; s_bad = 0; }
+    __syncthreads();
+    const unsigned long long rec = s_rec;
+    for (int i = off[s] + threadIdx.x; i < off[s + 1]; i += 256) {
+      const int u = (int)cx[i], v = (int)cy[i];
+      if (u < w && u > 0 && v < h && v > 0) {
+        const size_t q = (size_t)v * w + u;
+        const unsigned long long m = cand[q] & rec;
+        const int l = m ? T.lab[63 - __clzll((long long)m)] : mask[q];
+        if (l < 0 || l >= kVoteBins) atomicOr(&s_bad, 1);
+        else { atomicAdd(&hist[l], 1); atomicAdd(&s_valid, 1); }
+      }
+    }
+    __syncthreads();
+    {
+      int best = threadIdx.x * 4, cnt = hist[best];
+      for (int l = best + 1; l < threadIdx.x * 4 + 4; ++l) if (hist[l] > cnt) { cnt = hist[l]; best = l; }
+      s_cnt[threadIdx.x] = cnt; s_lab[threadIdx.x] = best;
+    }
+    __syncthreads();
+    for (int step = 128; step > 0; step >>= 1) {
+      if (threadIdx.x < step) {
+        const int c2 = s_cnt[threadIdx.x + step], l2 = s_lab[threadIdx.x + step];
+        if (c2 > s_cnt[threadIdx.x] || (c2 == s_cnt[threadIdx.x] && l2 < s_lab[threadIdx.x])) { s_cnt[threadIdx.x] = c2; s_lab[threadIdx.x] = l2; }
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const int r = (s_valid >= 100 && s_lab[0] == 0 && !s_bad) ? 1 : 0;
+      flag[2 * s] = r; flag[2 * s + 1] = s_bad;
+      if (r) s_rec = rec | (1ull << s);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *rec_out = s_rec;
+}
+
+__global__ void k_apply_warps(unsigned long long* __restrict__ cand, const unsigned long long* __restrict__ rec, LabelSlots T, int64_t n, int32_t* __restrict__ mask_cur) {
+  const int64_t q = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (q >= n) return;
+  const unsigned long long c = cand[q];
+  if (!c) return;
+  const unsigned long long m = c & *rec;
+  if (m) mask_cur[q] = T.lab[63 - __clzll((long long)m)];
+  cand[q] = 0ull;
+}
+
+// the UpdateMask launches for the label slots uni[0..L) with samples dx/dy grouped by slot (off on the host); doff / dflag /
+// drec: device scratch of the caller's arena (L+1 ints, 2L ints, one 64-bit word)
+static void launch_update_mask(vdo_frame_images* cur, vdo_frame_images* last, const std::vector<int32_t>& uni, const std::vector<int>& off, const float* dx, const float* dy,
+                               const int32_t* doff, int32_t* dflag, unsigned long long* drec, hipStream_t st) {
+  const int L = (int)uni.size();
+  if (L <= 64 && cur->d_cand) {
+    LabelSlots T{};
+    T.n = L;
+    for (int s = 0; s < L; ++s) T.lab[s] = uni[s];
+    hipLaunchKernelGGL(k_warp_candidates, dim3((cur->w + 255) / 256, cur->h), dim3(256), 0, st, (const int32_t*)last->d_mask, (const float*)last->d_flow, cur->w, cur->h, T, cur->d_cand);
+    hipLaunchKernelGGL(k_votes_seq, dim3(1), dim3(256), 0, st, T, doff, dx, dy, (const int32_t*)cur->d_mask, (const unsigned long long*)cur->d_cand, cur->w, cur->h, dflag, drec);
+    const int64_t np = (int64_t)cur->w * cur->h;
+    hipLaunchKernelGGL(k_apply_warps, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, cur->d_cand, (const unsigned long long*)drec, T, np, cur->d_mask);
+    return;
+  }
+  for (int s = 0; s < L; ++s) {      // label after label (a recovered mask is visible to the next label's vote, as in the reference)
+    const int ns = off[s + 1] - off[s];
+    hipLaunchKernelGGL(k_label_vote, dim3(1), dim3(256), 0, st, ns, dx + off[s], dy + off[s], (const int32_t*)cur->d_mask, cur->w, cur->h, dflag + 2 * s);
+    hipLaunchKernelGGL(k_mask_warp_if, dim3((cur->w + 255) / 256, cur->h), dim3(256), 0, st, (const int32_t*)(dflag + 2 * s), (const int32_t*)last->d_mask,
+                       (const float*)last->d_flow, cur->w, cur->h, uni[s], cur->d_mask);
+  }
+}
+
 // sorted distinct labels + slot of every element.  Mask labels are small integers: a presence table over
 // [min, max] gives both in O(n) (a sort + binary searches of ~5k labels cost ~0.1 ms per call); wide label
 // ranges fall back to sort + lower_bound.
@@ -321,7 +428,7 @@ extern "C" int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, in
   int rc = ctx_bind(cur->ctx);
   if (rc != VDO_OK) return rc;
   Arena S(cur->ctx);
-  if (!S.reserve(Arena::bytes_for(4 * (size_t)n + 64))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
+  if (!S.reserve(Arena::bytes_for(4 * (size_t)n + 512))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   // group the flowed positions by last-frame label (ascending labels, index order inside a label)
   std::vector<int32_t> uni, slot;
   label_slots(n, last_sem_label, uni, slot);
@@ -335,15 +442,12 @@ extern "C" int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, in
     for (int i = 0; i < n; ++i) { const int p = c[slot[i]]++; gx[p] = last_corr_x[i]; gy[p] = last_corr_y[i]; }
   }
   float *dx = S.up(gx.data(), n), *dy = S.up(gy.data(), n);
+  std::vector<int32_t> off32(off.begin(), off.end());
+  int32_t* doff = S.up(off32.data(), off32.size());
   int32_t* dflag = S.up<int32_t>(nullptr, 2 * (size_t)L);
-  if (!dflag) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-  // label after label, stream-ordered (a recovered mask is visible to the next label's vote, as in the reference); no host sync inside
-  for (int s = 0; s < L; ++s) {
-    const int ns = off[s + 1] - off[s];
-    hipLaunchKernelGGL(k_label_vote, dim3(1), dim3(256), 0, S.stream(), ns, (const float*)(dx + off[s]), (const float*)(dy + off[s]), (const int32_t*)cur->d_mask, cur->w, cur->h, dflag + 2 * s);
-    hipLaunchKernelGGL(k_mask_warp_if, dim3((cur->w + 255) / 256, cur->h), dim3(256), 0, S.stream(), (const int32_t*)(dflag + 2 * s), (const int32_t*)last->d_mask,
-                       (const float*)last->d_flow, cur->w, cur->h, uni[s], cur->d_mask);
-  }
+  unsigned long long* drec = S.up<unsigned long long>(nullptr, 1);
+  if (!dflag || !doff || !drec) return set_error(VDO_ERR_OOM, "hipMalloc failed");
+  launch_update_mask(cur, last, uni, off, dx, dy, doff, dflag, drec, S.stream());          // stream-ordered, no host sync inside
   std::vector<int32_t> flag(2 * (size_t)L);
   S.down(flag.data(), dflag, flag.size());
   rc = S.finish("vdo_update_mask");
@@ -369,7 +473,7 @@ extern "C" int vdo_object_chain(vdo_frame_images* cur, vdo_frame_images* last, i
   int rc = ctx_bind(cur->ctx);
   if (rc != VDO_OK) return rc;
   Arena S(cur->ctx);
-  if (!S.reserve(Arena::bytes_for(16 * (size_t)n + 64))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
+  if (!S.reserve(Arena::bytes_for(16 * (size_t)n + 512))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   // K15: the flowed positions grouped by last-frame label (ascending labels, index order inside a label)
   std::vector<int32_t> uni, slot;
   label_slots(n, last_sem_label, uni, slot);
@@ -388,18 +492,16 @@ extern "C" int vdo_object_chain(vdo_frame_images* cur, vdo_frame_images* last, i
   float *dcx = S.up(last_corr_x, n), *dcy = S.up(last_corr_y, n);
   float *dlx = S.up(last_x, n), *dly = S.up(last_y, n), *dld = S.up(last_d, n);
   int32_t *dll = S.up(last_sem_label, n), *dol = S.up(olab0.data(), n);
+  std::vector<int32_t> off32(off.begin(), off.end());
+  int32_t* doff = S.up(off32.data(), off32.size());
+  unsigned long long* drec = S.up<unsigned long long>(nullptr, 1);
   // outputs, contiguous -> one D2H copy
   int32_t* dflag = S.up<int32_t>(nullptr, 2 * (size_t)L);
   float* ddep = S.up<float>(nullptr, n);
   int32_t* dsem = S.up<int32_t>(nullptr, n);
   float* dfl = S.up<float>(nullptr, 3 * (size_t)n);
-  if (!dgx || !dgy || !dcx || !dcy || !dlx || !dly || !dld || !dll || !dol || !dflag || !ddep || !dsem || !dfl) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
-  for (int s = 0; s < L; ++s) {      // label after label (a recovered mask is visible to the next label's vote, as in the reference)
-    const int ns = off[s + 1] - off[s];
-    hipLaunchKernelGGL(k_label_vote, dim3(1), dim3(256), 0, S.stream(), ns, (const float*)(dgx + off[s]), (const float*)(dgy + off[s]), (const int32_t*)cur->d_mask, cur->w, cur->h, dflag + 2 * s);
-    hipLaunchKernelGGL(k_mask_warp_if, dim3((cur->w + 255) / 256, cur->h), dim3(256), 0, S.stream(), (const int32_t*)(dflag + 2 * s), (const int32_t*)last->d_mask,
-                       (const float*)last->d_flow, cur->w, cur->h, uni[s], cur->d_mask);
-  }
+  if (!dgx || !dgy || !dcx || !dcy || !dlx || !dly || !dld || !dll || !dol || !doff || !drec || !dflag || !ddep || !dsem || !dfl) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
+  launch_update_mask(cur, last, uni, off, dgx, dgy, doff, dflag, drec, S.stream());
   // K11 (objects) on the updated mask, K13 on its outputs
   hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.stream(), 1, n, (const float*)dcx, (const float*)dcy, (const float*)cur->d_depth, (const int32_t*)cur->d_mask,
                      cur->w, cur->h, th_depth_obj, ddep, dsem);
