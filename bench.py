@@ -371,6 +371,17 @@ def main():
         barrier()
         ms_iter = (time.perf_counter() - t0) * 1e3 / max(1, st.iterations)
         out["ms_per_lm_iter"] = ms_iter
+        # the same iterations with the reduced-camera matrix assembled densely and factorised on the fp64 MFMA units (solver 3: the
+        # fallback for pose graphs that are not sets of paths; vdo_lm_options.solver)
+        ba.optimize(max_iterations=1, gain_threshold=-1.0, solver=3)
+        ba.set_estimates(g.pose, g.point)
+        barrier()
+        t0 = time.perf_counter()
+        st3 = ba.optimize(max_iterations=5, gain_threshold=-1.0, solver=3)
+        barrier()
+        out["ms_per_lm_iter_dense_mfma"] = (time.perf_counter() - t0) * 1e3 / max(1, st3.iterations)
+        out["config"]["batch_solvers"] = (f"PCG (pose-chain preconditioner): {st.iterations} iterations / {st.total_trials} trials, chi2 {st.final_chi2:.9g}; "
+                                          f"dense MFMA Cholesky of the {6 * g.n_pose} x {6 * g.n_pose} reduced-camera matrix: {st3.iterations} / {st3.total_trials}, chi2 {st3.final_chi2:.9g}")
         out["config"]["batch_graph"] = f"{g.n_cam} frames, {g.n_pose} pose/motion vertices, {g.n_point} points, {g.n_eb} EdgeSE3PointXYZ, {g.n_et} ternary"
         ba.close()
         if use_dist and not os.environ.get("VDO_BENCH_NO_SHARDED"):

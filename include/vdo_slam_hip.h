@@ -113,7 +113,11 @@ typedef struct vdo_lm_options {
   int32_t max_iterations;     /* SparseOptimizer::optimize(n): 300 full batch, 100 partial */
   double gain_threshold;      /* SparseOptimizerTerminateAction::setGainThreshold; <0 = not installed */
   int32_t verbose;
-  int32_t solver;             /* 0 auto, 2 Schur + block-Jacobi PCG                        */
+  int32_t solver;             /* 2: Schur complement solved matrix-free by PCG with the pose-chain preconditioner;
+                               * 3: Schur complement assembled densely and factorised by a blocked Cholesky on the fp64 MFMA
+                               *    units (6 n_pose <= 8192) - what g2o's LinearSolverDense / CSparse do on the reduced system;
+                               * 0: auto = 3 when the EdgeSE3 graph is not a set of simple paths (loop closures, branches) or a
+                               *    PCG solve needed more than 60 iterations, else 2                                      */
   double pcg_tolerance;       /* relative residual ||r||_M / ||b||_M; <=0 -> 1e-10          */
   int32_t pcg_max_iterations; /* <=0 -> 4 * (6 n_pose) capped at 20000                     */
 } vdo_lm_options;

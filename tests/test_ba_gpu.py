@@ -172,11 +172,13 @@ def _with_extra_pose_edges(g, pairs):
         ep_z=np.concatenate([g.ep_z, np.array(zs)]), ep_info=np.concatenate([g.ep_info, np.array(infos)]))
 
 
+@pytest.mark.parametrize("solver", [2, 3, 0])
 @pytest.mark.parametrize("variant", ["loop_closure", "branch", "double_edge", "reversed_edges"])
-def test_lm_with_non_path_pose_graphs(ctx, oracle, variant):
+def test_lm_with_non_path_pose_graphs(ctx, oracle, variant, solver):
     """The block-tridiagonal preconditioner follows the simple paths of the EdgeSE3 graph; components with a
     cycle, a branch or a doubled edge fall back to block-Jacobi, edges stored (j,i) are followed transposed.
-    The LM trajectory must not notice (it only changes how fast PCG converges)."""
+    The LM trajectory must not notice (it only changes how fast PCG converges).  solver 2 = PCG, 3 = dense MFMA Cholesky of the
+    explicit reduced-camera matrix, 0 = auto (dense for the three non-path variants): identical LM trajectories."""
     import dataclasses
     from vdo_slam_amd.ba import BatchBA
     g = synth.make_ba_graph(14, 400, 2, 40, seed=9)
@@ -202,12 +204,36 @@ def test_lm_with_non_path_pose_graphs(ctx, oracle, variant):
     pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
     assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(pose_o), K._dp(point_o), C.byref(st_o)) == 0
     ba = BatchBA(ctx, g)
-    st = ba.optimize(max_iterations=40, gain_threshold=1e-4)
+    st = ba.optimize(max_iterations=40, gain_threshold=1e-4, solver=solver)
     pose, point = ba.estimates()
     assert st.iterations == st_o.iterations and st.total_trials == st_o.total_trials
     assert abs(st.final_chi2 - st_o.final_chi2) <= 1e-6 * st_o.final_chi2
     assert np.abs(pose[:, :9] - pose_o[:, :9]).max() <= 1e-4
     assert np.abs(pose[:, 9:] - pose_o[:, 9:]).max() <= 1e-4 * np.abs(pose_o[:, 9:]).max()
+    assert np.abs(point - point_o).max() <= 1e-4 * np.abs(point_o).max()
+    ba.close()
+
+
+@pytest.mark.parametrize("shape,seed", [((12, 300, 2, 40), 3), ((40, 2000, 3, 150), 3), ((25, 3000, 0, 0), 5)])
+def test_dense_mfma_solver_matches_oracle(ctx, oracle, shape, seed):
+    """solver = 3 on ordinary (path) graphs, incl. dynamic tracks (block-tridiagonal landmark chains) and a size whose 6P is not a
+    multiple of the 64-wide Cholesky blocks: same iterations / trials / chi2 / estimates as the direct-solve oracle."""
+    from vdo_slam_amd.ba import BatchBA
+    g = synth.make_ba_graph(*shape, seed=seed)
+    gc, keep = K.graph_to_c(g)
+    opt = K.LMOptionsC(30, 1e-4, 0, 0, 0.0, 0)
+    st_o = K.LMStatsC()
+    pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(pose_o), K._dp(point_o), C.byref(st_o)) == 0
+    ba = BatchBA(ctx, g)
+    st = ba.optimize(max_iterations=30, gain_threshold=1e-4, solver=3)
+    pose, point = ba.estimates()
+    assert (6 * g.n_pose) % 64 != 0 or shape[0] == 25
+    assert (st.iterations, st.total_trials) == (st_o.iterations, st_o.total_trials)
+    assert abs(st.final_chi2 - st_o.final_chi2) <= 1e-6 * st_o.final_chi2
+    assert np.abs(pose[:, :9] - pose_o[:, :9]).max() <= 1e-4
+    assert np.abs(pose[:, 9:] - pose_o[:, 9:]).max() <= 1e-4 * np.abs(pose_o[:, 9:]).max()
+    assert np.abs(point - point_o).max() <= 1e-4 * np.abs(point_o).max()
     ba.close()
 
 

@@ -68,8 +68,9 @@ class BatchBA:
         K.check(K.lib().vdo_ba_download_system(self._h, C.byref(S.c)))
         return S
 
-    def optimize(self, max_iterations=300, gain_threshold=1e-4, verbose=0, pcg_tolerance=0.0, pcg_max_iterations=0):
-        opt = K.LMOptionsC(max_iterations, gain_threshold, verbose, 0, pcg_tolerance, pcg_max_iterations)
+    def optimize(self, max_iterations=300, gain_threshold=1e-4, verbose=0, pcg_tolerance=0.0, pcg_max_iterations=0, solver=0):
+        """solver: 0 auto, 2 Schur + chain-preconditioned PCG, 3 Schur + dense MFMA Cholesky of the reduced-camera matrix."""
+        opt = K.LMOptionsC(max_iterations, gain_threshold, verbose, solver, pcg_tolerance, pcg_max_iterations)
         st = K.LMStatsC()
         K.check(K.lib().vdo_ba_optimize(self._h, C.byref(opt), C.byref(st)))
         return st

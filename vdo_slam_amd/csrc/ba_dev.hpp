@@ -119,5 +119,9 @@ void launch_pcg_init(const BADev& d, hipStream_t s);
 void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s, const Reducer& R);
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s);
 void launch_expand_binc(const BADev& d, hipStream_t s);            // Finc -> explicit Binc (download/debug only)
+void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R);   // explicit reduced-camera matrix
+void launch_dense_rhs(const BADev& d, double* rhs, int64_t ld, hipStream_t s);
+// ---- ba_dense.hip
+void launch_dense_solve(const BADev& d, double* S, int64_t ld, double* Winv, double* rhs, hipStream_t s);    // MFMA Cholesky + substitutions -> xp
 
 }  // namespace vdo

@@ -20,6 +20,11 @@ struct vdo_ba {
   std::vector<int32_t> eb_old_of_new, et_old_of_new;
   std::vector<int32_t> inc_of_eb, inc1_of_et, inc2_of_et;   // by NEW edge index
   std::vector<double> h_tmp;
+  // dense reduced-camera solver (ba_dense.hip), allocated on first use: S [ld][ld], W [ld/64][64][64], rhs [ld]
+  double *dense_S = nullptr, *dense_W = nullptr, *dense_rhs = nullptr;
+  int64_t dense_ld = 0;
+  bool pose_graph_is_paths = true;   // every EdgeSE3 lies on a simple path (the chain preconditioner covers them all)
+  int last_solver = 0;            // 2 PCG, 3 dense: what the last trial used
   int compact_edges = 0;          // bit 0: uniform eb_w, 1: fp32 eb_z, 2: uniform et_w, 3: et_z all zero (ba_dev.hpp)
 };
 

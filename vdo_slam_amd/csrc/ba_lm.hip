@@ -42,12 +42,50 @@ int robust_chi2(vdo_ba* ba, int which, double* out) {
   return VDO_OK;
 }
 
+constexpr int kPcgSlow = 60;                     // PCG iterations per solve above which auto mode switches to the dense solver
+constexpr int64_t kDenseMaxUnknowns = 8192;     // 6P above this: S no longer "small" (512 MB at 8192) - PCG only
+
+int dense_prepare(vdo_ba* ba) {
+  if (ba->dense_S) return VDO_OK;
+  const int64_t ld = (6 * (int64_t)ba->d.P + 63) / 64 * 64;
+  void *pS = nullptr, *pW = nullptr, *pr = nullptr;
+  if (hipMalloc(&pS, sizeof(double) * (size_t)ld * (size_t)ld) != hipSuccess || hipMalloc(&pW, sizeof(double) * (size_t)ld * 64) != hipSuccess ||
+      hipMalloc(&pr, sizeof(double) * (size_t)ld) != hipSuccess) {
+    if (pS) hipFree(pS);
+    if (pW) hipFree(pW);
+    return set_error(VDO_ERR_OOM, "dense reduced-camera solver: hipMalloc(%lld x %lld doubles) failed", (long long)ld, (long long)ld);
+  }
+  ba->dense_S = (double*)pS; ba->dense_W = (double*)pW; ba->dense_rhs = (double*)pr; ba->dense_ld = ld;
+  ba->allocs.push_back(pS); ba->allocs.push_back(pW); ba->allocs.push_back(pr);
+  return VDO_OK;
+}
+
 // (H + lambda I) x = b  ->  xp/xl on device.  ok=false mirrors a failed Cholesky.
+// solver: 2 = Schur + chain-preconditioned PCG; 3 = Schur + dense MFMA Cholesky of the reduced-camera matrix; 0 = auto: dense when
+// the pose graph is not a set of paths (loop closures, branches: the chain preconditioner then misses edges) or once a PCG solve
+// needed more than kPcgSlow iterations, as long as 6P <= kDenseMaxUnknowns.
 int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, int* pcg_iters) {
   const BADev& d = ba->d;
   hipStream_t s = ba->ctx->stream;
   launch_factor(d, lambda, s, ba->red);
   launch_reduced_rhs(d, s, ba->red);
+  const bool small = 6 * (int64_t)d.P <= kDenseMaxUnknowns;
+  bool dense = opt->solver == 3 || (opt->solver == 0 && small && (!ba->pose_graph_is_paths || ba->last_solver == 3));
+  if (dense && !small && opt->solver == 3) return set_error(VDO_ERR_UNSUPPORTED, "dense solver: %lld unknowns exceed %lld", 6LL * d.P, (long long)kDenseMaxUnknowns);
+  if (dense) {
+    int rc = dense_prepare(ba);
+    if (rc != VDO_OK) return rc;
+    launch_dense_assemble(d, ba->dense_S, ba->dense_ld, lambda, s, ba->red);
+    launch_dense_rhs(d, ba->dense_rhs, ba->dense_ld, s);
+    launch_dense_solve(d, ba->dense_S, ba->dense_ld, ba->dense_W, ba->dense_rhs, s);
+    rc = fetch(ba);
+    if (rc != VDO_OK) return rc;
+    *ok = ba->h_flags[0] == 0;
+    *pcg_iters = 0;
+    ba->last_solver = 3;
+    return VDO_OK;
+  }
+  ba->last_solver = 2;
   launch_pcg_init(d, s);
   double tol = opt->pcg_tolerance > 0 ? opt->pcg_tolerance : 1e-10;
   int maxit = opt->pcg_max_iterations > 0 ? opt->pcg_max_iterations : std::min(20000, 24 * d.P + 200);
@@ -65,6 +103,7 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
     if (ba->h_flags[1] == 2) { *ok = false; break; }
   }
   *pcg_iters = ba->h_flags[2];
+  if (opt->solver == 0 && small && *ok && *pcg_iters > kPcgSlow) ba->last_solver = 3;      // the next trials go to the dense solver
   return VDO_OK;
 }
 

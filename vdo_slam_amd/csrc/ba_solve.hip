@@ -664,6 +664,173 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_expand_binc(BADev d) {
   }
 }
 
+// ---- explicit reduced-camera matrix for the dense solver (ba_dense.hip) ---------------------------------------------
+// S (row-major, leading dimension ld >= 6P, padded rows/columns = identity) = blockdiag(Hpp + lambda I) + EdgeSE3 off-diagonal
+// blocks - sum over tiles of B Hll^-1 B^T.
+__global__ __launch_bounds__(256) void k_dense_init(BADev d, double* __restrict__ S, int64_t ld, double lambda) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t N = 6 * (int64_t)d.P;
+  if (i < 36 * (int64_t)d.P) {
+    const int64_t p = i / 36; const int a = (int)(i % 36) / 6, b = (int)(i % 6);
+    atomicAdd(S + (6 * p + a) * ld + 6 * p + b, d.Hpp[i] + (a == b ? lambda : 0.0));
+  } else if (i < 36 * (int64_t)(d.P + d.Ep)) {
+    const int64_t e = (i - 36 * (int64_t)d.P) / 36; const int a = (int)(i % 36) / 6, b = (int)(i % 6);
+    const double v = d.Hpp_ep[36 * e + 6 * a + b];                     // block (ep_i, ep_j)
+    const int64_t pi = d.ep_i[e], pj = d.ep_j[e];
+    atomicAdd(S + (6 * pi + a) * ld + 6 * pj + b, v);
+    atomicAdd(S + (6 * pj + b) * ld + 6 * pi + a, v);
+  } else {
+    const int64_t k = i - 36 * (int64_t)(d.P + d.Ep);
+    if (N + k < ld) S[(N + k) * ld + N + k] = 1.0;
+  }
+}
+
+// One workgroup per tile; for every pose slot s of the tile the six unit vectors e_(s,b) go through B^T, the landmark chain
+// solves and B at once (6 right-hand sides); the resulting 6x6 blocks against every slot r that shares a point (or a
+// dynamic track) with s are subtracted from S with fp64 atomics.  Only the points reached from slot s are touched.
+__global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, double* __restrict__ S, int64_t ld) {
+  extern __shared__ __attribute__((aligned(16))) double smem[];
+  const Tile T = d.tiles[blockIdx.x];
+  const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
+  const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, ninc = nb + 2 * nt;
+  double* u6 = smem;                          // [6][3*TP]
+  double* dinv = u6 + 18 * VDO_TILE_PTS;      // [9*TP]
+  double* gl = dinv + 9 * VDO_TILE_PTS;       // [9*TP]
+  double* q36 = gl + 9 * VDO_TILE_PTS;        // [36*S]  block (r, s): [b][a]
+  double* slotR = q36 + 36 * d.max_slots;     // [9*S]
+  int* touched = (int*)(slotR + 9 * d.max_slots);   // [TP]
+  const int tid = threadIdx.x;
+  stage_slot_rt(d, T, slotR);
+  {
+    const double* gd = d.Dinv + 9 * (int64_t)T.pt_begin;
+    const double* gg = d.Gl + 9 * (int64_t)T.pt_begin;
+    for (int i = tid; i < 9 * npts; i += VDO_TILE_THREADS) { dinv[i] = gd[i]; gl[i] = gg[i]; }
+  }
+  int key[3], kind[3];
+  FInc F[3];
+  const int64_t NF = (int64_t)d.Eb + d.Et;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int li = tid + VDO_TILE_THREADS * j;
+    key[j] = -1; kind[j] = 1; F[j] = FInc{0, 0, 0, 0};
+    if (li < ninc) {
+      key[j] = d.inc_key[T.inc_begin + li];
+      int64_t fidx;
+      inc_locate(T, li, d.Eb, kind[j], fidx);
+      F[j] = load_f(d.Finc, fidx, NF);
+    }
+  }
+  for (int s = 0; s < nslot; ++s) {
+    __syncthreads();
+    for (int i = tid; i < 18 * VDO_TILE_PTS; i += VDO_TILE_THREADS) u6[i] = 0.0;
+    for (int i = tid; i < 36 * nslot; i += VDO_TILE_THREADS) q36[i] = 0.0;
+    for (int i = tid; i < npts; i += VDO_TILE_THREADS) touched[i] = 0;
+    __syncthreads();
+    // pass A: u_b[l] += row b of the explicit 6x3 block of every incidence (s, l)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      if (key[j] >= 0 && (key[j] >> 16) == s) {
+        double B[18];
+        expand_block(kind[j], F[j], slotR + 9 * s, B);
+        const int lp = key[j] & 0xffff;
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          double* ul = u6 + b * 3 * VDO_TILE_PTS + 3 * lp;
+          atomicAdd(ul, B[3 * b]); atomicAdd(ul + 1, B[3 * b + 1]); atomicAdd(ul + 2, B[3 * b + 2]);
+        }
+        touched[lp] = 1;
+      }
+    }
+    __syncthreads();
+    // chain solves w = Hll^-1 u for the chains slot s reaches, one (chain, right-hand side) per thread-iteration; a reached
+    // chain becomes "touched" as a whole (its points all carry w)
+    const int nch = T.chain_end - T.chain_begin;
+    for (int c = tid; c < nch; c += VDO_TILE_THREADS) {
+      const int64_t p0 = d.chain_off[T.chain_begin + c], p1 = d.chain_off[T.chain_begin + c + 1];
+      if (p1 - p0 < 2) continue;
+      int any = 0;
+      for (int64_t l = p0; l < p1; ++l) any |= touched[l - T.pt_begin];
+      if (any) for (int64_t l = p0; l < p1; ++l) touched[l - T.pt_begin] = 2;
+    }
+    __syncthreads();
+    for (int task = tid; task < 6 * nch; task += VDO_TILE_THREADS) {
+      const int c = task / 6, b = task - 6 * c;
+      const int64_t p0 = d.chain_off[T.chain_begin + c], p1 = d.chain_off[T.chain_begin + c + 1];
+      if (!touched[p0 - T.pt_begin]) continue;
+      double* u = u6 + b * 3 * VDO_TILE_PTS;
+      D3 yprev{0, 0, 0};
+      for (int64_t l = p0; l < p1; ++l) {
+        double* ul = u + 3 * (l - T.pt_begin);
+        D3 y{ul[0], ul[1], ul[2]};
+        if (l > p0) y = y - rotT(gl + 9 * (l - T.pt_begin), yprev);
+        yprev = y;
+        const D3 z = rot(dinv + 9 * (l - T.pt_begin), y);
+        ul[0] = z.x; ul[1] = z.y; ul[2] = z.z;
+      }
+      for (int64_t l = p1 - 2; l >= p0; --l) {
+        const double* un = u + 3 * (l + 1 - T.pt_begin);
+        const D3 wnext{un[0], un[1], un[2]};
+        double* ul = u + 3 * (l - T.pt_begin);
+        const D3 z = D3{ul[0], ul[1], ul[2]} - rot(gl + 9 * (l + 1 - T.pt_begin), wnext);
+        ul[0] = z.x; ul[1] = z.y; ul[2] = z.z;
+      }
+    }
+    __syncthreads();
+    // pass C: block (r, s) += B_r w_b for every incidence (r, l) on a touched point; incidences are slot-sorted inside each
+    // part, so the 36 values go through the segmented DPP reduction (many lanes share a slot: plain LDS atomics would serialise)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const bool on = key[j] >= 0 && touched[key[j] & 0xffff];
+      const int r = on ? (key[j] >> 16) : -1, lp = on ? (key[j] & 0xffff) : 0;
+      if (!__any(on)) continue;                                  // (wave-uniform: nothing of this wave's incidences is reached from slot s)
+      double B[18];
+      expand_block(kind[j], F[j], slotR + 9 * (r >= 0 ? r : 0), B);
+      const SegCtl16 sc = seg_ctl16(r);
+      const SegFlags sf = seg_flags(sc);
+      double* q = q36 + 36 * (r >= 0 ? r : 0);
+#pragma unroll
+      for (int b = 0; b < 6; ++b) {
+        const double* w = u6 + b * 3 * VDO_TILE_PTS + 3 * lp;
+        const double w0 = on ? w[0] : 0.0, w1 = on ? w[1] : 0.0, w2 = on ? w[2] : 0.0;
+        double g[6];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) g[a] = B[3 * a] * w0 + B[3 * a + 1] * w1 + B[3 * a + 2] * w2;
+        seg_apply16<6>(g, sc, sf, q + 6 * b);                    // q layout [b][a]
+      }
+    }
+    __syncthreads();
+    const int64_t gs = d.tile_pose[T.slot_begin + s];
+    for (int i = tid; i < 36 * nslot; i += VDO_TILE_THREADS) {
+      const double v = q36[i];
+      if (v == 0.0) continue;
+      const int r = i / 36, b = (i % 36) / 6, a = i % 6;         // q36[r][b][a]
+      const int64_t gr = d.tile_pose[T.slot_begin + r];
+      atomicAdd(S + (6 * gr + a) * ld + 6 * gs + b, -v);
+    }
+  }
+}
+
+size_t dense_tile_lds(const BADev& d) { return (36 * VDO_TILE_PTS + 45 * (size_t)d.max_slots) * sizeof(double) + VDO_TILE_PTS * sizeof(int); }
+
+// S <- reduced-camera matrix at this lambda (launch_factor must have run: it leaves the landmark chain factors of Hll + lambda I)
+void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R) {
+  hipMemsetAsync(S, 0, sizeof(double) * (size_t)ld * (size_t)ld, s);
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_dense_tile, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), dense_tile_lds(d), s, d, S, ld);
+  if (d.sharded) R(S, ld * ld);                     // landmark-side contributions of every rank (all-reduce of S)
+  const int64_t n = 36 * (int64_t)(d.P + d.Ep) + (ld - 6 * (int64_t)d.P);
+  hipLaunchKernelGGL(k_dense_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, S, ld, lambda);
+}
+
+// rhs of the reduced system: bs = bp - B Hll^-1 bl (qs from launch_reduced_rhs), zero-padded to ld
+__global__ void k_dense_rhs(BADev d, double* __restrict__ rhs, int64_t ld) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= ld) return;
+  rhs[i] = i < 6 * (int64_t)d.P ? d.bp[i] - d.qs[i] : 0.0;
+}
+void launch_dense_rhs(const BADev& d, double* rhs, int64_t ld, hipStream_t s) {
+  hipLaunchKernelGGL(k_dense_rhs, dim3((unsigned)((ld + 255) / 256)), dim3(256), 0, s, d, rhs, ld);
+}
+
 // ------------------------------------------------------------------------------ launchers
 static size_t schur_lds(const BADev& d) { return (21 * VDO_TILE_PTS + 21 * (size_t)d.max_slots) * sizeof(double); }
 

@@ -245,6 +245,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   // every object's motions (src/Optimizer.cc:1590-1612, 1743-1766) - in path order; every other pose
   // (isolated, or part of a branching / cyclic component) is a chain of length 1 (plain block-Jacobi).
   std::vector<int32_t> pc_off{0}, pc_pose, pc_edge;
+  std::vector<char> comp_ok_all;
   {
     std::vector<int> deg(P, 0);
     for (int e = 0; e < Ep; ++e) { deg[g->ep_i[e]]++; deg[g->ep_j[e]]++; }
@@ -268,6 +269,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       }
       if (degsum / 2 != nodes - 1) ok = false;        // a tree with max degree 2 is a path; anything else has a cycle or a double edge
       comp_ok.push_back(ok ? 1 : 0);
+      comp_ok_all.push_back(ok ? 1 : 0);
       ++ncomp;
     }
     std::vector<char> done(P, 0);
@@ -291,6 +293,11 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     for (int p = 0; p < P; ++p) if (!done[p]) { pc_pose.push_back(p); pc_edge.push_back(-1); pc_off.push_back((int32_t)pc_pose.size()); }   // unreachable, defensive
   }
   const int n_pchains = (int)pc_off.size() - 1;
+  {   // every EdgeSE3 on a simple path? (else the auto solver choice goes to the dense Cholesky, ba_lm.hip)
+    bool paths = true;
+    for (size_t c = 0; c < comp_ok_all.size(); ++c) paths = paths && comp_ok_all[c];
+    ba->pose_graph_is_paths = paths;
+  }
   // incidence index of every (new) edge, for the un-permuting download
   ba->inc_of_eb.resize(Eb); ba->inc1_of_et.resize(Et); ba->inc2_of_et.resize(Et);
   for (const Tile& T : tiles) {
