@@ -265,6 +265,8 @@ typedef struct vdo_pnp_problem {
   int32_t max_iterations;   /* 500                                                */
   double reproj_threshold;  /* 0.4 px                                             */
   double confidence;        /* 0.98                                               */
+  int32_t refit;            /* 1: the winning model is re-estimated on its inliers by EPnP, as cv::solvePnPRansac does for the P3P
+                             *    / AP3P kernels since OpenCV 3.3 (the inlier set stays the RANSAC one); 0: the P3P hypothesis     */
 } vdo_pnp_problem;
 typedef struct vdo_pnp_result {
   double T[16];             /* 4x4 row-major; identity when no model was found    */

@@ -19,6 +19,7 @@
 #include <cstring>
 #include <vector>
 
+#include "epnp_oracle.hpp"
 #include "vdo_oracle.h"
 
 namespace {
@@ -268,4 +269,29 @@ extern "C" int vdo_oracle_p3p_ransac(int n, const double* X, const double* uv, c
   if (inlier_out)
     for (int i = 0; i < n; ++i) inlier_out[i] = reproj2(best, K4, X + 3 * i, uv + 2 * i) <= t2;
   return max_good;
+}
+
+// KAT hook: EPnP on all given points
+extern "C" double vdo_oracle_epnp(int n, const double* X, const double* uv, const double* K4, double* T_out) {
+  const ref_epnp::Result r = ref_epnp::solve(n, X, uv, K4);
+  for (int i = 0; i < 16; ++i) T_out[i] = (i % 5 == 0) ? 1.0 : 0.0;
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T_out[4 * i + j] = r.R[3 * i + j]; T_out[4 * i + 3] = r.t[i]; }
+  return r.err;
+}
+
+// solvePnPRansac as a whole: the RANSAC above, then - refit != 0 - the winning model re-estimated on its inliers by EPnP (the pose
+// OpenCV 3.4 returns; the inlier set stays the RANSAC one)
+extern "C" int vdo_oracle_pnp_ransac_refit(int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence, int refit,
+                                           double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter) {
+  std::vector<uint8_t> inl((size_t)std::max(n, 1), 0);
+  const int good = vdo_oracle_p3p_ransac(n, X, uv, K4, max_iters, thr, confidence, T_out, inl.data(), iters_run, best_iter);
+  if (inlier_out && n > 0) std::memcpy(inlier_out, inl.data(), (size_t)n);
+  if (good >= 4 && refit) {
+    std::vector<double> Xi, ui;
+    for (int i = 0; i < n; ++i) if (inl[i]) { Xi.insert(Xi.end(), X + 3 * i, X + 3 * i + 3); ui.insert(ui.end(), uv + 2 * i, uv + 2 * i + 2); }
+    const ref_epnp::Result r = ref_epnp::solve((int)(ui.size() / 2), Xi.data(), ui.data(), K4);
+    if (r.err >= 0.0)                                  // (degenerate - coplanar - inliers: the RANSAC hypothesis stays)
+      for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T_out[4 * i + j] = r.R[3 * i + j]; T_out[4 * i + 3] = r.t[i]; }
+  }
+  return good;
 }

@@ -167,6 +167,11 @@ int vdo_oracle_p3p(const double* f9, const double* P9, double* R_out, double* t_
 void vdo_oracle_ransac_subsets(int n, int max_iters, int32_t* idx);
 int vdo_oracle_p3p_ransac(int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence,
                           double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter);
+/* EPnP (4 control points) on all given points: T_out 4x4 camera-from-world, returns the mean reprojection error [px] */
+double vdo_oracle_epnp(int n, const double* X, const double* uv, const double* K4, double* T_out);
+/* the RANSAC above + (refit != 0) OpenCV 3.4's final EPnP re-estimation of the winning model on its inliers */
+int vdo_oracle_pnp_ransac_refit(int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence, int refit,
+                                double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter);
 
 /* ---- front-end (frontend_oracle.cpp) ------------------------------------------------------*/
 typedef struct vdo_orb_params {   /* ORBextractor ctor arguments (include/ORBextractor.h:39-40) */

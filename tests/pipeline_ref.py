@@ -45,7 +45,8 @@ def matmul4_f32(A, B):
 
 
 class OraclePipeline:
-    def __init__(self, oracle, max_bg=1200, max_obj=800, sf_mg=0.12, sf_ds=0.3, build_lm=False, K4=None, use_sample=False, sample_seed=1):
+    def __init__(self, oracle, max_bg=1200, max_obj=800, sf_mg=0.12, sf_ds=0.3, build_lm=False, K4=None, use_sample=False, sample_seed=1, pnp_refit=True):
+        self.pnp_refit = pnp_refit                      # cv::solvePnPRansac's final EPnP re-estimation on the inliers (OpenCV >= 3.3)
         self.o = oracle
         self.K4 = np.array(synth.KITTI_K if K4 is None else K4, f32)
         self.use_sample, self.sample_seed = use_sample, sample_seed      # UseSampleFeature = 1 (omd.yaml): SampleKeyPoints instead of ORB
@@ -60,6 +61,7 @@ class OraclePipeline:
         self.stage_s = {"depth": 0.0, "orb": 0.0, "frame": 0.0, "tracking_k11_k15": 0.0, "ransac_init": 0.0, "lm_cam": 0.0, "lm_obj": 0.0}
         dp = K.c_double_p
         oracle.vdo_oracle_p3p_ransac.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_double, C.c_double, dp, K.c_uint8_p, K.c_int32_p, K.c_int32_p]
+        oracle.vdo_oracle_pnp_ransac_refit.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_double, C.c_double, C.c_int, dp, K.c_uint8_p, K.c_int32_p, K.c_int32_p]
 
     # ---- helpers
     def _ransac(self, X, uv):
@@ -68,7 +70,7 @@ class OraclePipeline:
         if n < 4:
             return 0, Tm.reshape(4, 4), inl[:n]
         X = np.ascontiguousarray(X, np.float64); uv = np.ascontiguousarray(uv, np.float64)
-        good = self.o.vdo_oracle_p3p_ransac(n, K._dp(X), K._dp(uv), K._dp(self.K4.astype(np.float64)), 500, 0.4, 0.98, K._dp(Tm), inl.ctypes.data_as(K.c_uint8_p), None, None)
+        good = self.o.vdo_oracle_pnp_ransac_refit(n, K._dp(X), K._dp(uv), K._dp(self.K4.astype(np.float64)), 500, 0.4, 0.98, int(self.pnp_refit), K._dp(Tm), inl.ctypes.data_as(K.c_uint8_p), None, None)
         return good, Tm.reshape(4, 4), inl[:n]
 
     def _lm(self, kx, ky, fx, fy, d, T0, info_prior, max_it):

@@ -18,6 +18,9 @@ def _bind(o):
     o.vdo_oracle_cubic3_largest_root.argtypes = [C.c_double, C.c_double]; o.vdo_oracle_cubic3_largest_root.restype = C.c_double
     o.vdo_oracle_ransac_subsets.argtypes = [C.c_int, C.c_int, K.c_int32_p]
     o.vdo_oracle_p3p_ransac.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_double, C.c_double, dp, K.c_uint8_p, K.c_int32_p, K.c_int32_p]
+    o.vdo_oracle_epnp.restype = C.c_double
+    o.vdo_oracle_epnp.argtypes = [C.c_int, dp, dp, dp, dp]
+    o.vdo_oracle_pnp_ransac_refit.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_double, C.c_double, C.c_int, dp, K.c_uint8_p, K.c_int32_p, K.c_int32_p]
     return o
 
 
@@ -137,3 +140,36 @@ def test_ransac_with_too_few_points(oracle):
     X = np.zeros((3, 3)); uv = np.zeros((3, 2)); K4 = np.array(KITTI_K, np.float64)
     assert o.vdo_oracle_p3p_ransac(3, K._dp(X), K._dp(uv), K._dp(K4), 500, 0.4, 0.98, K._dp(T), None, None, None) == 0
     assert np.array_equal(T.reshape(4, 4), np.eye(4))
+
+
+def test_epnp_recovers_the_pose_and_refines_the_ransac_model(oracle):
+    """EPnP (4 control points, oracle/epnp_oracle.hpp): exact data -> the exact pose (any n >= 6); noisy data -> the least-squares
+    pose, closer to the truth than a single P3P hypothesis; and inside the RANSAC wrapper the refit replaces the winning
+    hypothesis while the inlier set stays the RANSAC one.  Coplanar points are left to the hypothesis (documented guard)."""
+    o = _bind(oracle)
+    rng = np.random.default_rng(11)
+    K4 = np.array(KITTI_K, np.float64)
+    for n in (6, 40, 700):
+        Xw, uv, R, t, _ = _scene(rng, n)
+        T = np.zeros(16)
+        err = o.vdo_oracle_epnp(n, K._dp(Xw), K._dp(uv), K._dp(K4), K._dp(T))
+        T = T.reshape(4, 4)
+        assert err < 1e-8 and np.abs(T[:3, :3] - R).max() < 1e-10 and np.abs(T[:3, 3] - t).max() < 1e-9, (n, err)
+        assert abs(np.linalg.det(T[:3, :3]) - 1) < 1e-12
+    # noisy + outliers: RANSAC hypothesis vs refit
+    Xw, uv, R, t, outl = _scene(rng, 900, 0.3, pix_sigma=0.15)
+    res = {}
+    for refit in (0, 1):
+        T = np.zeros(16); inl = np.zeros(900, np.uint8); its = C.c_int32(); bi = C.c_int32()
+        good = o.vdo_oracle_pnp_ransac_refit(900, K._dp(Xw), K._dp(uv), K._dp(K4), 500, 0.4, 0.98, refit, K._dp(T), inl.ctypes.data_as(K.c_uint8_p), C.byref(its), C.byref(bi))
+        res[refit] = (good, T.reshape(4, 4).copy(), inl.copy(), its.value, bi.value)
+    assert res[0][0] == res[1][0] and np.array_equal(res[0][2], res[1][2]) and res[0][3:] == res[1][3:]       # same consensus
+    e0 = np.abs(res[0][1][:3, 3] - t).max(); e1 = np.abs(res[1][1][:3, 3] - t).max()
+    assert e1 < e0 and e1 < 0.01, (e0, e1)                 # the refit uses all ~600 inliers instead of 3 points
+    assert not np.array_equal(res[0][1], res[1][1])
+    # coplanar points: no refit (the 4-control-point formulation is undefined there)
+    Xp = Xw.copy(); Xp[:, 2] = 12.0
+    Xc = Xp @ R.T + t
+    uvp = np.c_[KITTI_K[0] * Xc[:, 0] / Xc[:, 2] + KITTI_K[2], KITTI_K[1] * Xc[:, 1] / Xc[:, 2] + KITTI_K[3]]
+    T = np.zeros(16)
+    assert o.vdo_oracle_epnp(900, K._dp(np.ascontiguousarray(Xp)), K._dp(np.ascontiguousarray(uvp)), K._dp(K4), K._dp(T)) < 0

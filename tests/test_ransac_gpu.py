@@ -16,15 +16,18 @@ from vdo_slam_amd.synth import KITTI_K
 pytestmark = pytest.mark.gpu
 
 
-def _oracle(o, Xw, uv):
+def _oracle(o, Xw, uv, refit=0):
     n = Xw.shape[0]
     T = np.zeros(16); inl = np.zeros(max(n, 1), np.uint8); its = C.c_int32(); bi = C.c_int32()
     K4 = np.array(KITTI_K, np.float64)
-    good = o.vdo_oracle_p3p_ransac(n, K._dp(Xw), K._dp(uv), K._dp(K4), 500, 0.4, 0.98, K._dp(T), inl.ctypes.data_as(K.c_uint8_p), C.byref(its), C.byref(bi))
+    good = o.vdo_oracle_pnp_ransac_refit(n, K._dp(Xw), K._dp(uv), K._dp(K4), 500, 0.4, 0.98, refit, K._dp(T), inl.ctypes.data_as(K.c_uint8_p), C.byref(its), C.byref(bi))
     return dict(T=T.reshape(4, 4), n_inliers=good, iterations_run=its.value, best_iteration=bi.value, inliers=inl[:n])
 
 
-def test_batch_matches_the_sequential_oracle(oracle):
+@pytest.mark.parametrize("refit", [0, 1])
+def test_batch_matches_the_sequential_oracle(oracle, refit):
+    """refit = 1: + OpenCV's final EPnP re-estimation on the inliers (host code of the C-ABI vs oracle/epnp_oracle.hpp): the pose
+    is still the same bit pattern."""
     o = _bind(oracle)
     ctx = Context(0)
     rng = np.random.default_rng(5)
@@ -36,9 +39,9 @@ def test_batch_matches_the_sequential_oracle(oracle):
         else:
             Xw, uv = np.zeros((0, 3)), np.zeros((0, 2))
         probs.append((Xw, uv))
-    got = pnp_ransac_batch(ctx, probs, KITTI_K)
+    got = pnp_ransac_batch(ctx, probs, KITTI_K, refit=refit)
     for (n, outl), g, (Xw, uv) in zip(cases, got, probs):
-        e = _oracle(o, Xw, uv)
+        e = _oracle(o, Xw, uv, refit)
         assert g["n_inliers"] == e["n_inliers"] and g["iterations_run"] == e["iterations_run"] and g["best_iteration"] == e["best_iteration"], (n, g, e)
         assert np.array_equal(g["inliers"], e["inliers"])
         assert np.array_equal(g["T"], e["T"]), (n, np.abs(g["T"] - e["T"]).max())

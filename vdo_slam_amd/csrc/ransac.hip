@@ -1,7 +1,7 @@
 // RANSAC initialiser of the per-frame pose problems on gfx950: what
 // Tracking::GetInitModelCam / GetInitModelObj obtain from cv::solvePnPRansac(pre_3d, cur_2d, K, 0, ..., 500 iterations,
 // 0.4 px, confidence 0.98, SOLVEPNP_AP3P) (reference src/Tracking.cc:1652-1655, 1755-1758), up to OpenCV's final
-// EPnP refit (the LM refinement that follows starts from this pose; see oracle/p3p_oracle.cpp for the scheme restated).
+// EPnP refit, which is host code (epnp_refit.hpp) applied to the winner's inliers when vdo_pnp_problem.refit is set.
 //
 // The sequential algorithm is kept — same subsets (cv::RNG stream, drawn on the host: 2 000 integers), same
 // acceptance and budget rule — but its two data-parallel parts run at once for ALL hypotheses:
@@ -14,12 +14,16 @@
 #include <algorithm>
 #include <cfloat>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <vector>
 
 #include "../../include/vdo_slam_hip.h"
 #include "arena.hpp"
 #include "ctx.hpp"
+#include "epnp_refit.hpp"
+#include "host_pool.hpp"
 
 namespace vdo {
 
@@ -352,6 +356,40 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
     if (inlier_out && inlier_out[k]) {
       const uint32_t* row = mask.data() + (size_t)d.mask_off + (size_t)bi * d.mask_words;
       for (int i = 0; i < d.n; ++i) inlier_out[k][i] = (row[i >> 5] >> (i & 31)) & 1u;
+    }
+  }
+  // OpenCV's last step: the winning model re-estimated on its inliers by EPnP (solvePnP(inliers, SOLVEPNP_EPNP)); problems are
+  // independent: one per pool task (the objects of a frame in parallel)
+  std::vector<int> todo;
+  for (int k = 0; k < n_problems; ++k) if (probs[k].refit && results[k].n_inliers >= 4 && results[k].best_iteration >= 0) todo.push_back(k);
+  if (!todo.empty()) {
+    auto refit_one = [&](int q) {
+      const int k = todo[q];
+      const PnpDev& d = hp[k];
+      const uint32_t* row = mask.data() + (size_t)d.mask_off + (size_t)results[k].best_iteration * d.mask_words;
+      thread_local std::vector<double> Xi, ui;
+      thread_local epnp::Scratch scr;
+      Xi.clear(); ui.clear();
+      for (int i = 0; i < d.n; ++i)
+        if ((row[i >> 5] >> (i & 31)) & 1u) {
+          Xi.insert(Xi.end(), probs[k].X + 3 * (size_t)i, probs[k].X + 3 * (size_t)i + 3);
+          ui.insert(ui.end(), probs[k].uv + 2 * (size_t)i, probs[k].uv + 2 * (size_t)i + 2);
+        }
+      const epnp::Result r = epnp::solve((int)(ui.size() / 2), Xi.data(), ui.data(), probs[k].K, scr);
+      if (r.err >= 0.0)                              // (degenerate - coplanar - inliers: the RANSAC hypothesis stays)
+        for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) results[k].T[4 * i + j] = r.R[3 * i + j]; results[k].T[4 * i + 3] = r.t[i]; }
+    };
+    static LevelPool* pool = [] {
+      const char* e = std::getenv("VDO_PNP_THREADS");
+      const int nw = e ? std::atoi(e) : 3;
+      return nw > 0 ? new LevelPool(std::min(nw, 15)) : nullptr;
+    }();
+    static std::mutex pool_mu;                       // (one batch at a time through the shared helpers; a second caller refits inline)
+    if (todo.size() > 1 && pool && pool_mu.try_lock()) {
+      pool->run((int)todo.size(), refit_one);
+      pool_mu.unlock();
+    } else {
+      for (int q = 0; q < (int)todo.size(); ++q) refit_one(q);
     }
   }
   return VDO_OK;

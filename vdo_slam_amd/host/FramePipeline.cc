@@ -154,7 +154,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
       X[3 * i] = sta_.xyz[3 * i]; X[3 * i + 1] = sta_.xyz[3 * i + 1]; X[3 * i + 2] = sta_.xyz[3 * i + 2];
       uvd[2 * i] = sta_.cx[i]; uvd[2 * i + 1] = sta_.cy[i];
     }
-    vdo_pnp_problem pp{n_s, X.data(), uvd.data(), {p_.K4[0], p_.K4[1], p_.K4[2], p_.K4[3]}, 500, 0.4, 0.98};
+    vdo_pnp_problem pp{n_s, X.data(), uvd.data(), {p_.K4[0], p_.K4[1], p_.K4[2], p_.K4[3]}, 500, 0.4, 0.98, p_.pnp_refit};
     vdo_pnp_result pr;
     inl_ransac_.assign(n_s, 0);
     VDO_TRY(vdo_pnp_ransac(ctx_, &pp, &pr, inl_ransac_.data()));
@@ -366,7 +366,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
           X[3 * q] = obj_.xyz[3 * id]; X[3 * q + 1] = obj_.xyz[3 * id + 1]; X[3 * q + 2] = obj_.xyz[3 * id + 2];
           uvd[2 * q] = obj_.cx[id]; uvd[2 * q + 1] = obj_.cy[id];
         }
-        pp[a] = vdo_pnp_problem{off[a + 1] - off[a], X.data() + 3 * (size_t)off[a], uvd.data() + 2 * (size_t)off[a], {p_.K4[0], p_.K4[1], p_.K4[2], p_.K4[3]}, 500, 0.4, 0.98};
+        pp[a] = vdo_pnp_problem{off[a + 1] - off[a], X.data() + 3 * (size_t)off[a], uvd.data() + 2 * (size_t)off[a], {p_.K4[0], p_.K4[1], p_.K4[2], p_.K4[3]}, 500, 0.4, 0.98, p_.pnp_refit};
       }
       std::vector<uint8_t>& rin = inl_ransac_;
       rin.assign((size_t)off[n_objects] + 1, 0);

@@ -39,6 +39,8 @@ struct PipelineParams {
   int use_sample_feature;            // UseSampleFeature (omd.yaml): Frame::SampleKeyPoints (3000 random grid positions) instead of ORB, the static
   int sample_seed;                   //    filter's sampled branch, top-up from the filtered samples; cv::RNG seed of frame f = sample_seed + f
                                      //    (the reference seeds with time(NULL))
+  int pnp_refit;                     // 1: GetInitModelCam/Obj receive what cv::solvePnPRansac returns since OpenCV 3.3 - the winning P3P model re-estimated on
+                                     //    its inliers by EPnP (vdo_pnp_problem.refit); 0: the raw P3P hypothesis
   int window_size, overlap_size;     // WINDOW_SIZE / OVERLAP_SIZE: with a Map attached, Optimizer::PartialBatchOptimization runs on the last
                                      //    window_size frames whenever (f_id-overlap+1) % (window-overlap) == 0 && f_id >= window-1
                                      //    (src/Tracking.cc:1169-1183); 0 = never

@@ -56,6 +56,7 @@ Tracking::Tracking(System*, Map* pMap, const std::string& strSettingPath, const 
   p.scale_factor = (float)get(cfg_, "ORBextractor.scaleFactor");
   p.build_lm = 1; p.defer_objects = 0;               // TrackRGBD returns with the frame complete, like the reference
   p.use_sample_feature = (int)get(cfg_, "UseSampleFeature"); p.sample_seed = 1;
+  p.pnp_refit = 1;                                   // solvePnPRansac's EPnP re-estimation (OpenCV 3.4)
   p.window_size = (int)get(cfg_, "WINDOW_SIZE"); p.overlap_size = (int)get(cfg_, "OVERLAP_SIZE");
   if (p.width <= 0 || p.height <= 0) { std::cerr << "settings: Camera.width / Camera.height missing" << std::endl; std::exit(-1); }
   const char* dev = std::getenv("VDO_DEVICE");

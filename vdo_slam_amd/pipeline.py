@@ -12,7 +12,7 @@ class PipelineParams(C.Structure):
     _fields_ = [("width", C.c_int), ("height", C.c_int), ("K4", C.c_float * 4), ("bf", C.c_float), ("depth_map_factor", C.c_float),
                 ("th_depth_bg", C.c_float), ("th_depth_obj", C.c_float), ("max_track_bg", C.c_int), ("max_track_obj", C.c_int),
                 ("sf_mg_thres", C.c_float), ("sf_ds_thres", C.c_float), ("n_features", C.c_int), ("n_levels", C.c_int), ("ini_th", C.c_int),
-                ("min_th", C.c_int), ("scale_factor", C.c_float), ("build_lm", C.c_int), ("defer_objects", C.c_int), ("use_sample_feature", C.c_int), ("sample_seed", C.c_int), ("window_size", C.c_int), ("overlap_size", C.c_int)]
+                ("min_th", C.c_int), ("scale_factor", C.c_float), ("build_lm", C.c_int), ("defer_objects", C.c_int), ("use_sample_feature", C.c_int), ("sample_seed", C.c_int), ("pnp_refit", C.c_int), ("window_size", C.c_int), ("overlap_size", C.c_int)]
 
 
 class FrameCounts(C.Structure):
@@ -27,10 +27,10 @@ SECTIONS = ("k1_k11_ransac_cam", "orb", "k9_k10", "wait_cam_lm", "k13_dynobj", "
 
 
 def kitti_params(width, height, K4, bf, depth_map_factor, th_bg, th_obj, build_lm=0, defer_objects=0, window_size=0, overlap_size=0, use_sample_feature=0, sample_seed=1,
-                 sf_mg_thres=0.12, sf_ds_thres=0.3, n_features=2500):
+                 sf_mg_thres=0.12, sf_ds_thres=0.3, n_features=2500, pnp_refit=1):
     """example/kitti-0000-0013.yaml: MaxTrackPointBG 1200, MaxTrackPointOBJ 800, SFMgThres 0.12, SFDsThres 0.3, ORB 2500/1.2/8/20/7."""
     return PipelineParams(width, height, (C.c_float * 4)(*K4), bf, depth_map_factor, th_bg, th_obj, 1200, 800, sf_mg_thres, sf_ds_thres, n_features, 8, 20, 7, 1.2, int(build_lm), int(defer_objects),
-                          int(use_sample_feature), int(sample_seed), int(window_size), int(overlap_size))
+                          int(use_sample_feature), int(sample_seed), int(pnp_refit), int(window_size), int(overlap_size))
 
 
 class FramePipeline:
