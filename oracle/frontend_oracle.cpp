@@ -120,6 +120,20 @@ const int RING[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2
 
 int fast_score(const Img& im, int x, int y, int t) {   // 0 = not a corner, else cornerScore (>= t)
   const int v = im.at(y, x);
+  // cv::FAST's high-speed rejection (a necessary condition, the result is unchanged): an arc of 9 contiguous ring pixels contains
+  // one pixel of every opposite pair (k, k + 8), so a corner needs every pair to have a pixel brighter than v + t, or every pair
+  // to have one darker than v - t.  Pairs are visited in OpenCV's order 0/8, 4/12, 2/10, 6/14, then the odd ones; ~90 % of the
+  // pixels leave after two pairs.
+  {
+    static const int order[8] = {0, 4, 2, 6, 1, 3, 5, 7};
+    int d = 3;                                           // bit 0: still possibly "brighter" corner, bit 1: "darker"
+    for (int q = 0; q < 8 && d; ++q) {
+      const int k = order[q];
+      const int a = im.at(y + RING[k][1], x + RING[k][0]), b = im.at(y + RING[k + 8][1], x + RING[k + 8][0]);
+      d &= ((a > v + t || b > v + t) ? 1 : 0) | ((a < v - t || b < v - t) ? 2 : 0);
+    }
+    if (!d) return 0;
+  }
   int r[16];
   for (int k = 0; k < 16; ++k) r[k] = im.at(y + RING[k][1], x + RING[k][0]);
   int best = -1000;
