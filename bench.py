@@ -344,20 +344,31 @@ def main():
         import tempfile
         from vdo_slam_amd.system import System, write_settings
         with tempfile.TemporaryDirectory() as td:
-            sysm = System(write_settings(os.path.join(td, "kitti.yaml"), W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, window=0, overlap=0))
-            host_in = [(f["gray"], f["depth_raw"].copy(), f["flow"], f["mask"].copy()) for f in frames[:n_all]]
-            for k in range(args.warmup):
-                sysm.track_rgbd(*host_in[k])
-            t0 = time.perf_counter()
-            Th = None
-            for k in range(args.warmup, n_all):
-                Th = sysm.track_rgbd(*host_in[k % len(host_in)])
-            dth = time.perf_counter() - t0
-            out["value_host_inputs"] = args.steps / dth
-            out["config"]["host_inputs"] = ("System::TrackRGBD on pageable host buffers (gray u8, raw depth f32 converted in place, flow 2xf32, mask i32 = 7.9 MB/frame H2D + 1.9 MB D2H), "
-                                            "synchronous object stage (defer_objects=0), Map attached, no windowed optimisation; same camera pose as the device-input run: "
-                                            + str(bool(Th is not None and np.array_equal(Th.astype(np.float64), Tcw))))
-            sysm.close()
+            host_in = [(f["gray"], f["depth_raw"], f["flow"], f["mask"]) for f in frames[:n_all]]
+            for mode in ("deferred", "sync"):
+                sysm = System(write_settings(os.path.join(td, "kitti.yaml"), W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, window=0, overlap=0))
+                sysm.set_defer(mode == "deferred")
+                # depth and mask are mutated in place by TrackRGBD; ground-truth object rows (frame, label, ...) for every object of the
+                # sequence, as the reference's object_pose.txt carries them: the tracker only follows objects that have one (Tracking.cc:791-841)
+                bufs = [(g_, d_.copy(), fl_, m_.copy(), np.array([[k_, lab + 1] + [0.0] * 8 for lab in range(len(objs))], np.float32))
+                        for k_, (g_, d_, fl_, m_) in enumerate(host_in)]
+                for k in range(args.warmup):
+                    sysm.track_rgbd(*bufs[k])
+                t0 = time.perf_counter()
+                Th = None
+                for k in range(args.warmup, n_all):
+                    Th = sysm.track_rgbd(*bufs[k % len(bufs)])
+                sysm.flush()
+                dth = time.perf_counter() - t0
+                out["value_host_inputs" if mode == "deferred" else "value_host_inputs_sync"] = args.steps / dth
+                same = bool(Th is not None and np.array_equal(Th.astype(np.float64), Tcw))
+                sysm.close()
+                if mode == "sync":
+                    continue
+                out["config"]["host_inputs"] = ("System::TrackRGBD on pageable host buffers (gray u8, raw depth f32 converted in place, flow 2xf32, mask i32 = 7.9 MB/frame H2D "
+                                                "+ 1.9 MB D2H of the converted depth), graph store attached, no windowed optimisation; "
+                                                "value_host_inputs: object stage deferred into the next call (as `value`), value_host_inputs_sync: everything done when TrackRGBD returns "
+                                                "(the reference's semantics); same camera pose as the device-input run: " + str(same))
 
     if not args.no_batch:
         # ---- batch leg: LM outer iterations on the KITTI-shaped full-batch graph (configs[2] shape)

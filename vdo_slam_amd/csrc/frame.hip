@@ -181,6 +181,8 @@ extern "C" int vdo_frame_images_create(vdo_ctx* ctx, int w, int h, vdo_frame_ima
   return VDO_OK;
 }
 
+// Host images -> HBM.  The caller's buffers are pageable (cv::Mat data); plain stream copies move them at ~35 GB/s on this stack
+// (measured: tools/host_input_probe.py; a pinned staging block filled by pool threads was tried and was no faster).
 extern "C" int vdo_frame_images_upload(vdo_frame_images* f, const float* depth, const float* flow, const int32_t* mask) {
   if (!f) return set_error(VDO_ERR_INVALID, "null handle");
   int rc = ctx_bind(f->ctx);

@@ -603,6 +603,7 @@ int FramePipeline::FinalizeMap() {
 // mpMap->TrackletDyn = GetDynamicTrackNew()   (Tracking.cc:1065-1071)
 int FramePipeline::SyncMap() {
   if (!map_) return -1;
+  if (pending_ && FinishObjects(nullptr) != 0) return -1;
   if (GetTracks(&tl_sta_, &tl_dyn_) != 0) return -1;
   StoreToMap(store_, tl_sta_, tl_dyn_, *map_);
   return 0;

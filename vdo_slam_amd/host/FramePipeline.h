@@ -88,6 +88,8 @@ class FramePipeline {
   // Ends a pending object stage (deferred mode); fc (optional) receives its n_object_tracked / n_dynamic_tracks.
   int Flush(FrameCounts* fc = nullptr) { return FinishObjects(fc); }
   bool ok() const { return ok_; }
+  // deferred object stage on / off between frames (a pending stage is consumed by the next Step or by Flush either way)
+  void SetDeferObjects(bool on) { p_.defer_objects = on ? 1 : 0; }
   const PipelineParams& params() const { return p_; }
   struct ObjectMotion { int mod_label, sem_label, n_inliers; float H[16]; };   // H: world-frame motion of the object from the last to this frame
   std::vector<ObjectMotion> motions_;   // objects tracked in the last Step (build_lm mode)

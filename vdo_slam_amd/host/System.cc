@@ -196,6 +196,12 @@ int host_system_track(VDO_SLAM::System* s, const unsigned char* im, int channels
   } catch (const std::exception& e) { std::fprintf(stderr, "host_system_track: %s\n", e.what()); return -2; }
   return 0;
 }
+// throughput mode of the shell: the object stage of a frame ends inside the next TrackRGBD call (same results, the object motions of
+// frame k become visible with frame k+1; the final batch optimisation / SaveResults / map() flush it).  Off by default: the
+// reference has everything done when TrackRGBD returns.
+void host_system_set_defer(VDO_SLAM::System* s, int on) { s->tracker()->pipeline()->SetDeferObjects(on != 0); }
+void host_system_timing(VDO_SLAM::System* s, double* ms11) { for (int i = 0; i < 11; ++i) ms11[i] = s->tracker()->pipeline()->ms_[i]; }
+int host_system_flush(VDO_SLAM::System* s) { return s->tracker()->pipeline()->Flush(nullptr); }
 int host_system_motions(VDO_SLAM::System* s, int cap, int* sem_label, float* H16) {
   const auto& m = s->tracker()->pipeline()->motions_;
   const int n = std::min(cap, (int)m.size());

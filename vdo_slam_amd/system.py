@@ -75,6 +75,16 @@ class System:
                                        0 if rows is None else rows.shape[1], int(n_images), _ptr(self._T))
         return None if rc != 0 else self._T.reshape(4, 4).copy()
 
+    def set_defer(self, on=True):
+        """Throughput mode: the object stage of a frame ends inside the next track_rgbd call (same results one frame later)."""
+        self._L.host_system_set_defer.argtypes = [C.c_void_p, C.c_int]
+        self._L.host_system_set_defer(self._h, int(bool(on)))
+
+    def flush(self):
+        self._L.host_system_flush.argtypes = [C.c_void_p]
+        if self._L.host_system_flush(self._h) != 0:
+            raise K.VdoError("System flush failed")
+
     def motions(self, cap=32):
         sl = np.zeros(cap, np.int32); Hm = np.zeros((cap, 16), np.float32)
         n = self._L.host_system_motions(self._h, cap, _ptr(sl), _ptr(Hm))
