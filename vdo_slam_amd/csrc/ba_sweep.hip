@@ -15,8 +15,8 @@
 //      (sum of we) * I - J_point^T J_point = R R^T = I for both edge classes - so 1 + 3 sums per point, written once (32 B);
 //   4. the pose 6x6+6 contribution of an edge depends on 16 running sums only
 //      (J_pose = [-I | 2[zc]x]  resp. [I | -[v]x]): Σw, Σw·zc, Σw·zc zcᵀ, Σw·e, Σw·zc×e.
-//      They are reduced with a wave-level segmented scan (edges are pose-sorted inside the
-//      tile), accumulated per pose slot in LDS and written as per-(tile,slot) partials;
+//      Every thread sums them in registers over its few consecutive edges (edges are pose-sorted inside the tile), the
+//      threads' totals go through a segmented DPP scan into per-slot LDS accumulators and are written as per-(tile,slot) partials;
 //      k_finalize_pose expands them to the 6x6 block + rhs in fixed order.
 // No global atomics; HBM traffic = the algorithmic bytes of SURVEY.md §8d (+ the partials).
 #include "ba_dev.hpp"
@@ -47,16 +47,34 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* lds) {
   a = lds[32]; b = lds[33];
 }
 
-// The 16 running sums of one edge (we, we*c, we*c c^T, we*e, we*c x e), segment-reduced over the
-// wave 4 at a time (values are produced just-in-time to keep the register footprint small).
-__device__ __forceinline__ void pose_sums(double we, D3 c, D3 er, int slot, double* accpose_base) {
-  const SegCtl16 sc = seg_ctl16(slot);
+// Per-thread running sums: a thread owns a few CONSECUTIVE edges of the pose-sorted list, so they mostly share a pose slot and
+// their 16 sums add up in registers; a change of slot inside the chunk (rare: at most nslot - 1 times per tile) is flushed to the
+// slot's LDS accumulators at once, and only the final (slot, sums) of every thread goes through the segmented DPP scan - one
+// scan per thread instead of one per edge.
+__device__ __forceinline__ void acc_edge(double (&acc)[16], int& cur, int slot, double we, D3 c, D3 er, double* accpose_base) {
+  if (slot != cur) {
+    if (cur >= 0) {
+      double* dst = accpose_base + 32 * cur;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) atomicAdd(dst + i, acc[i]);
+    }
+    cur = slot;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+  }
+  acc[0] += we; acc[1] += we * c.x; acc[2] += we * c.y; acc[3] += we * c.z;
+  acc[4] += we * c.x * c.x; acc[5] += we * c.x * c.y; acc[6] += we * c.x * c.z; acc[7] += we * c.y * c.y;
+  acc[8] += we * c.y * c.z; acc[9] += we * c.z * c.z; acc[10] += we * er.x; acc[11] += we * er.y;
+  acc[12] += we * er.z; acc[13] += we * (c.y * er.z - c.z * er.y); acc[14] += we * (c.z * er.x - c.x * er.z); acc[15] += we * (c.x * er.y - c.y * er.x);
+}
+__device__ __forceinline__ void acc_finish(double (&acc)[16], int cur, double* accpose_base) {
+  const SegCtl16 sc = seg_ctl16(cur);
   const SegFlags sf = seg_flags(sc);
-  double* dst = accpose_base + 32 * (slot >= 0 ? slot : 0);
-  { double g[4] = {we, we * c.x, we * c.y, we * c.z}; seg_apply16<4>(g, sc, sf, dst); }
-  { double g[4] = {we * c.x * c.x, we * c.x * c.y, we * c.x * c.z, we * c.y * c.y}; seg_apply16<4>(g, sc, sf, dst + 4); }
-  { double g[4] = {we * c.y * c.z, we * c.z * c.z, we * er.x, we * er.y}; seg_apply16<4>(g, sc, sf, dst + 8); }
-  { double g[4] = {we * er.z, we * (c.y * er.z - c.z * er.y), we * (c.z * er.x - c.x * er.z), we * (c.x * er.y - c.y * er.x)}; seg_apply16<4>(g, sc, sf, dst + 12); }
+  double* dst = accpose_base + 32 * (cur >= 0 ? cur : 0);
+  { double g[4] = {acc[0], acc[1], acc[2], acc[3]}; seg_apply16<4>(g, sc, sf, dst); }
+  { double g[4] = {acc[4], acc[5], acc[6], acc[7]}; seg_apply16<4>(g, sc, sf, dst + 4); }
+  { double g[4] = {acc[8], acc[9], acc[10], acc[11]}; seg_apply16<4>(g, sc, sf, dst + 8); }
+  { double g[4] = {acc[12], acc[13], acc[14], acc[15]}; seg_apply16<4>(g, sc, sf, dst + 12); }
 }
 
 template <bool BUILD>
@@ -72,6 +90,23 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   const double* __restrict__ pose = d.pose[which];
   const double* __restrict__ point = d.point[which] + 3 * (int64_t)T.pt_begin;
   const int tid = threadIdx.x;
+  const int64_t Eb = d.Eb, Et = d.Et, NF = d.Eb + d.Et;
+  // ---- this thread's EdgeSE3PointXYZ inputs (<= 3 consecutive edges) are requested first: their HBM latency runs under the staging
+  const int nbe = T.eb_end - T.eb_begin;
+  const int per_b = (nbe + VDO_TILE_THREADS - 1) / VDO_TILE_THREADS;          // consecutive edges per thread (<= 3)
+  int ekey[3];
+  double ew[3];
+  D3 ez[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int e = T.eb_begin + tid * per_b + j;
+    ekey[j] = -1; ew[j] = 0.0; ez[j] = D3{0.0, 0.0, 0.0};
+    if (j < per_b && e < T.eb_end) {
+      ekey[j] = d.eb_key[e];
+      ew[j] = d.eb_w ? d.eb_w[e] : d.eb_w_uni;                                  // (wave-uniform choices: 16 B per edge instead of 36 B)
+      ez[j] = d.eb_zf ? D3{(double)d.eb_zf[e], (double)d.eb_zf[Eb + e], (double)d.eb_zf[2 * Eb + e]} : D3{d.eb_z[e], d.eb_z[Eb + e], d.eb_z[2 * Eb + e]};
+    }
+  }
   // ---- stage points, inverse poses, zero accumulators
   for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) pts[i] = point[i];
   if (BUILD) {
@@ -87,81 +122,85 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   }
   __syncthreads();
   double chi = 0.0, rchi = 0.0;
-  const int64_t Eb = d.Eb, Et = d.Et, NF = d.Eb + d.Et;
   // ------------------------------------------------------------------ EdgeSE3PointXYZ
-  for (int base = T.eb_begin; base < T.eb_end; base += VDO_TILE_THREADS) {
-    const int e = base + tid;
-    const bool valid = e < T.eb_end;
-    int slot = -1;
-    double we = 0.0;
-    D3 zc{0, 0, 0}, er{0, 0, 0};
-    if (valid) {
-      const int key = d.eb_key[e];
-      slot = key >> 16;
-      const int lp = key & 0xffff;
-      const double w = d.eb_w ? d.eb_w[e] : d.eb_w_uni;                       // (wave-uniform choices: 16 B per edge instead of 36 B)
-      const D3 z = d.eb_zf ? D3{(double)d.eb_zf[e], (double)d.eb_zf[Eb + e], (double)d.eb_zf[2 * Eb + e]} : D3{d.eb_z[e], d.eb_z[Eb + e], d.eb_z[2 * Eb + e]};
-      const double* Wp = slotW + 12 * slot;   // W.r = R^T = Jl (row-major), W.t
-      const D3 p{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
-      zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
-      er = zc - z;
-      const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
-      double rho0, rho1;
-      huber(c2, d.huber_eb, d.dsqr_eb, rho0, rho1);
-      chi += c2; rchi += rho0;
-      if (BUILD) {
-        we = w * rho1;
-        // 6x3 block Hpl = -we * [ I ; 2[zc]x ] * Jl  -> stored factored as (we, zc); 32 B instead of 144 B
-        double* F = d.Finc + e;
-        F[0] = we; F[NF] = zc.x; F[2 * NF] = zc.y; F[3 * NF] = zc.z;
-        // landmark side: Hll += we * Jl^T Jl = we * R R^T = we * I (R is a rotation: g2o's product differs from I by a few
-        // 1e-16, far inside the 1e-12 parity bar) -> ONE running sum per point; bl += -we * R e   (R e = Jl^T e)
-        const D3 Re = rotT(Wp, er);
-        atomicAdd(accpt + lp, we);
-        atomicAdd(accpt + VDO_TILE_PTS + lp, -we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + lp, -we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + lp, -we * Re.z);
+  {
+    double acc[16];
+    int cur = -1;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int e = T.eb_begin + tid * per_b + j;
+      if (ekey[j] >= 0) {
+        const int key = ekey[j];
+        const int slot = key >> 16;
+        const int lp = key & 0xffff;
+        const double w = ew[j];
+        const D3 z = ez[j];
+        const double* Wp = slotW + 12 * slot;   // W.r = R^T = Jl (row-major), W.t
+        const D3 p{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
+        const D3 zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
+        const D3 er = zc - z;
+        const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
+        double rho0, rho1;
+        huber(c2, d.huber_eb, d.dsqr_eb, rho0, rho1);
+        chi += c2; rchi += rho0;
+        if (BUILD) {
+          const double we = w * rho1;
+          // 6x3 block Hpl = -we * [ I ; 2[zc]x ] * Jl  -> stored factored as (we, zc); 32 B instead of 144 B
+          double* F = d.Finc + e;
+          F[0] = we; F[NF] = zc.x; F[2 * NF] = zc.y; F[3 * NF] = zc.z;
+          // landmark side: Hll += we * Jl^T Jl = we * R R^T = we * I (R is a rotation: g2o's product differs from I by a few
+          // 1e-16, far inside the 1e-12 parity bar) -> ONE running sum per point; bl += -we * R e   (R e = Jl^T e)
+          const D3 Re = rotT(Wp, er);
+          atomicAdd(accpt + lp, we);
+          atomicAdd(accpt + VDO_TILE_PTS + lp, -we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + lp, -we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + lp, -we * Re.z);
+          acc_edge(acc, cur, slot, we, zc, er, accpose);
+        }
       }
     }
-    if (BUILD) pose_sums(we, zc, er, slot, accpose);
+    if (BUILD) acc_finish(acc, cur, accpose);
   }
   // ------------------------------------------------------------ LandmarkMotionTernaryEdge
-  for (int base = T.et_begin; base < T.et_end; base += VDO_TILE_THREADS) {
-    const int e = base + tid;
-    const bool valid = e < T.et_end;
-    int slot = -1;
-    double we = 0.0;
-    D3 v{0, 0, 0}, er{0, 0, 0};
-    if (valid) {
-      const int key = d.et_key[e];
-      slot = d.et_slot[e];
-      const int l1 = key & 0xffff, l2 = key >> 16;
-      const double w = d.et_w ? d.et_w[e] : d.et_w_uni;
-      const D3 z = d.et_z ? D3{d.et_z[e], d.et_z[Et + e], d.et_z[2 * Et + e]} : D3{0.0, 0.0, 0.0};
-      const double* Hi = slotW + 12 * slot;   // Hi.r = R_H^T, Hi.t ; J2 = -Hi.r
-      const D3 p1{pts[3 * l1], pts[3 * l1 + 1], pts[3 * l1 + 2]};
-      const D3 p2{pts[3 * l2], pts[3 * l2 + 1], pts[3 * l2 + 2]};
-      v = rot(Hi, p2) + D3{Hi[9], Hi[10], Hi[11]};
-      er = p1 - v - z;
-      const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
-      double rho0, rho1;
-      huber(c2, d.huber_et, d.dsqr_et, rho0, rho1);
-      chi += c2; rchi += rho0;
-      if (BUILD) {
-        we = w * rho1;
-        double* O = d.Oll + e;               // O = we * J1^T J2 = -we * Hi.r (p1 x p2)
+  {
+    const int nte = T.et_end - T.et_begin;
+    const int per = (nte + VDO_TILE_THREADS - 1) / VDO_TILE_THREADS;
+    double acc[16];
+    int cur = -1;
+    for (int j = 0; j < per; ++j) {
+      const int e = T.et_begin + tid * per + j;
+      if (e < T.et_end) {
+        const int key = d.et_key[e];
+        const int slot = d.et_slot[e];
+        const int l1 = key & 0xffff, l2 = key >> 16;
+        const double w = d.et_w ? d.et_w[e] : d.et_w_uni;
+        const D3 z = d.et_z ? D3{d.et_z[e], d.et_z[Et + e], d.et_z[2 * Et + e]} : D3{0.0, 0.0, 0.0};
+        const double* Hi = slotW + 12 * slot;   // Hi.r = R_H^T, Hi.t ; J2 = -Hi.r
+        const D3 p1{pts[3 * l1], pts[3 * l1 + 1], pts[3 * l1 + 2]};
+        const D3 p2{pts[3 * l2], pts[3 * l2 + 1], pts[3 * l2 + 2]};
+        const D3 v = rot(Hi, p2) + D3{Hi[9], Hi[10], Hi[11]};
+        const D3 er = p1 - v - z;
+        const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
+        double rho0, rho1;
+        huber(c2, d.huber_et, d.dsqr_et, rho0, rho1);
+        chi += c2; rchi += rho0;
+        if (BUILD) {
+          const double we = w * rho1;
+          double* O = d.Oll + e;               // O = we * J1^T J2 = -we * Hi.r (p1 x p2)
 #pragma unroll
-        for (int i = 0; i < 9; ++i) O[i * Et] = -we * Hi[i];
-        // (H,p1): we * [I ; [v]x]   and   (H,p2): -we * [I ; [v]x] * Hi.r   -> both from (we, v)
-        double* F = d.Finc + Eb + e;
-        F[0] = we; F[NF] = v.x; F[2 * NF] = v.y; F[3 * NF] = v.z;
-        // p1: Hll += we*I, b += -we*e ; p2: Hll += we*R_H R_H^T = we*I, b += we * R_H e
-        atomicAdd(accpt + l1, we);
-        atomicAdd(accpt + VDO_TILE_PTS + l1, -we * er.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l1, -we * er.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l1, -we * er.z);
-        const D3 Re = rotT(Hi, er);
-        atomicAdd(accpt + l2, we);
-        atomicAdd(accpt + VDO_TILE_PTS + l2, we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l2, we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l2, we * Re.z);
+          for (int i = 0; i < 9; ++i) O[i * Et] = -we * Hi[i];
+          // (H,p1): we * [I ; [v]x]   and   (H,p2): -we * [I ; [v]x] * Hi.r   -> both from (we, v)
+          double* F = d.Finc + Eb + e;
+          F[0] = we; F[NF] = v.x; F[2 * NF] = v.y; F[3 * NF] = v.z;
+          // p1: Hll += we*I, b += -we*e ; p2: Hll += we*R_H R_H^T = we*I, b += we * R_H e
+          atomicAdd(accpt + l1, we);
+          atomicAdd(accpt + VDO_TILE_PTS + l1, -we * er.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l1, -we * er.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l1, -we * er.z);
+          const D3 Re = rotT(Hi, er);
+          atomicAdd(accpt + l2, we);
+          atomicAdd(accpt + VDO_TILE_PTS + l2, we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l2, we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l2, we * Re.z);
+          acc_edge(acc, cur, slot, we, v, er, accpose + 16);
+        }
       }
     }
-    if (BUILD) pose_sums(we, v, er, slot, accpose + 16);
+    if (BUILD) acc_finish(acc, cur, accpose + 16);
   }
   // ---- write back
   block_sum2(chi, rchi, red);
