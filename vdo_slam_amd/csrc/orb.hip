@@ -95,6 +95,109 @@ __global__ void k_resize_border(const uint8_t* __restrict__ src /*interior of le
   dst[(size_t)by * bw + bx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
 }
 
+// The whole pyramid in ONE launch.  A level is resized from the level below, so eight dependent launches used to build it (~60 us of
+// stream time, 8 launch overheads on the host).  Here every workgroup owns one 32x32 tile of one level and recomputes, in LDS, the
+// regions of the levels below that feed it, cascading up from the source image: level 0 region -> level 1 region -> ... -> the
+// tile.  Every pixel of every level is computed with the same fixed-point formula from the same exact inputs as in the
+// level-by-level version (k_resize_border), so the result is bit-identical; the recomputation (a level-7 tile needs a ~130x130
+// source window) costs a few microseconds of an otherwise idle GPU.  The 19-px REFLECT_101 border is written by the owner of
+// the mirrored interior pixel.
+struct PyrDesc {
+  int n_levels;
+  int w[8], h[8];
+  double sx[8], sy[8];          // scale of level l relative to level l-1 (inv of cv::resize's inv_scale), [0] unused
+  int tile_off[9];              // first workgroup of every level
+  int tiles_x[8];
+};
+constexpr int kPyrRegion = 144;   // max edge of a cascaded region (checked on the host at create time)
+
+__device__ __forceinline__ void resize_src(int d, double scale, int slen, int& s0, int& s1, int& c0, int& c1) {
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int si = (int)floorf(f);
+  f -= si;
+  bool edge = false;
+  if (si < 0) { f = 0; si = 0; }
+  if (si + 1 >= slen) { edge = true; f = 0; si = slen - 1; }
+  c0 = max(-32768, min(32767, (int)rintf((1.f - f) * 2048))); c1 = max(-32768, min(32767, (int)rintf(f * 2048)));
+  s0 = si; s1 = edge ? si : si + 1;
+  if (edge) { c0 = 2048; c1 = 0; }
+}
+// vertical taps of cv::resize are NOT collapsed at the border: both rows are clamped (k_resize_border does the same)
+__device__ __forceinline__ void resize_src_y(int d, double scale, int slen, int& s0, int& s1, int& c0, int& c1) {
+  float f = (float)((d + 0.5) * scale - 0.5);
+  int si = (int)floorf(f);
+  f -= si;
+  c0 = max(-32768, min(32767, (int)rintf((1.f - f) * 2048))); c1 = max(-32768, min(32767, (int)rintf(f * 2048)));
+  s0 = min(max(si, 0), slen - 1); s1 = min(max(si + 1, 0), slen - 1);
+}
+
+__global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__ src, int sstride, PyrDesc P, const LevelDesc* __restrict__ levels, uint8_t* __restrict__ pyr) {
+  __shared__ uint8_t bufA[kPyrRegion * kPyrRegion];
+  __shared__ uint8_t bufB[kPyrRegion * kPyrRegion];
+  __shared__ int rx0[8], rx1[8], ry0[8], ry1[8];
+  int lvl = 0;
+  while (lvl + 1 < P.n_levels && (int)blockIdx.x >= P.tile_off[lvl + 1]) ++lvl;
+  const int t = blockIdx.x - P.tile_off[lvl], ty = t / P.tiles_x[lvl], tx = t - ty * P.tiles_x[lvl];
+  if (threadIdx.x == 0) {
+    // inclusive pixel ranges needed at every level, from the tile down to the source
+    int x0 = tx * 32, x1 = min(x0 + 31, P.w[lvl] - 1), y0 = ty * 32, y1 = min(y0 + 31, P.h[lvl] - 1);
+    rx0[lvl] = x0; rx1[lvl] = x1; ry0[lvl] = y0; ry1[lvl] = y1;
+    for (int k = lvl; k > 0; --k) {
+      int a0, a1, c0, c1, b0, b1;
+      resize_src(x0, P.sx[k], P.w[k - 1], a0, a1, c0, c1);
+      resize_src(x1, P.sx[k], P.w[k - 1], b0, b1, c0, c1);
+      x0 = a0; x1 = b1;
+      resize_src_y(y0, P.sy[k], P.h[k - 1], a0, a1, c0, c1);
+      resize_src_y(y1, P.sy[k], P.h[k - 1], b0, b1, c0, c1);
+      y0 = a0; y1 = b1;
+      rx0[k - 1] = x0; rx1[k - 1] = x1; ry0[k - 1] = y0; ry1[k - 1] = y1;
+    }
+  }
+  __syncthreads();
+  // level 0 region from the source image
+  uint8_t* cur = bufA;
+  uint8_t* nxt = bufB;
+  {
+    const int w0 = rx1[0] - rx0[0] + 1, h0 = ry1[0] - ry0[0] + 1;
+    for (int i = threadIdx.x; i < w0 * h0; i += 256) { const int yy = i / w0, xx = i - yy * w0; cur[yy * kPyrRegion + xx] = src[(size_t)(ry0[0] + yy) * sstride + rx0[0] + xx]; }
+  }
+  __syncthreads();
+  for (int k = 1; k <= lvl; ++k) {
+    const int wk = rx1[k] - rx0[k] + 1, hk = ry1[k] - ry0[k] + 1;
+    const int ox = rx0[k - 1], oy = ry0[k - 1];
+    for (int i = threadIdx.x; i < wk * hk; i += 256) {
+      const int yy = i / wk, xx = i - yy * wk;
+      int sx0, sx1, a0, a1, sy0, sy1, b0, b1;
+      resize_src(rx0[k] + xx, P.sx[k], P.w[k - 1], sx0, sx1, a0, a1);
+      resize_src_y(ry0[k] + yy, P.sy[k], P.h[k - 1], sy0, sy1, b0, b1);
+      const uint8_t* S0 = cur + (sy0 - oy) * kPyrRegion - ox;
+      const uint8_t* S1 = cur + (sy1 - oy) * kPyrRegion - ox;
+      const int r0 = S0[sx0] * a0 + S0[sx1] * a1, r1 = S1[sx0] * a0 + S1[sx1] * a1;
+      nxt[yy * kPyrRegion + xx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+    }
+    __syncthreads();
+    uint8_t* tmp = cur; cur = nxt; nxt = tmp;
+  }
+  // the tile (interior) + the border pixels that mirror its pixels (REFLECT_101: p <-> -p and p <-> 2(len-1) - p, 19 px wide)
+  const LevelDesc L = levels[lvl];
+  uint8_t* dst = pyr + L.off;
+  const int wt = rx1[lvl] - rx0[lvl] + 1, ht = ry1[lvl] - ry0[lvl] + 1;
+  for (int i = threadIdx.x; i < wt * ht; i += 256) {
+    const int yy = i / wt, xx = i - yy * wt;
+    const int x = rx0[lvl] + xx, y = ry0[lvl] + yy;
+    const uint8_t v = cur[yy * kPyrRegion + xx];
+    int xs[2] = {x, 0}, ys[2] = {y, 0};
+    bool mx = false, my = false;
+    if (x >= 1 && x <= kEdge) { xs[1] = -x; mx = true; } else if (x <= L.w - 2 && x >= L.w - 1 - kEdge) { xs[1] = 2 * (L.w - 1) - x; mx = true; }
+    if (y >= 1 && y <= kEdge) { ys[1] = -y; my = true; } else if (y <= L.h - 2 && y >= L.h - 1 - kEdge) { ys[1] = 2 * (L.h - 1) - y; my = true; }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+        if ((a == 0 || my) && (b == 0 || mx)) dst[(size_t)(ys[a] + kEdge) * L.bw + xs[b] + kEdge] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------ K4
 __device__ __forceinline__ int fast_score_lds(const uint8_t* roi, int stride, int x, int y, int t) {
   const uint8_t* c = roi + y * stride + x;
@@ -511,6 +614,7 @@ struct vdo_orb {
   std::vector<float> scale;
   UMax um{};
   Blur7 blur{};
+  PyrDesc pyr{};                 // fused pyramid launch (k_pyramid_all); n_levels == 0: level-by-level launches
   // device
   std::vector<void*> allocs;
   uint8_t *d_src = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
@@ -609,6 +713,24 @@ extern "C" int vdo_orb_create(vdo_ctx* ctx, const vdo_orb_params* prm, int w, in
     }
   }
   o->ncells = (int)o->cells.size();
+  // fused pyramid: possible when there are at most 8 levels and every cascaded region fits the LDS buffers
+  if (NL <= 8 && !std::getenv("VDO_ORB_PYRAMID_LAUNCHES")) {
+    PyrDesc& P = o->pyr;
+    P.n_levels = NL;
+    int tot = 0;
+    for (int l = 0; l < NL; ++l) {
+      P.w[l] = o->levels[l].w; P.h[l] = o->levels[l].h;
+      P.sx[l] = l ? 1. / ((double)o->levels[l].w / o->levels[l - 1].w) : 1.0;
+      P.sy[l] = l ? 1. / ((double)o->levels[l].h / o->levels[l - 1].h) : 1.0;
+      P.tile_off[l] = tot; P.tiles_x[l] = (P.w[l] + 31) / 32;
+      tot += P.tiles_x[l] * ((P.h[l] + 31) / 32);
+    }
+    P.tile_off[NL] = tot;
+    // widest region any tile needs at any level below it: grow a 32-px span down the cascade (+2 px per step covers the taps and the float rounding)
+    double span_x = 32, span_y = 32, worst = 32;
+    for (int l = NL - 1; l > 0; --l) { span_x = span_x * P.sx[l] + 3; span_y = span_y * P.sy[l] + 3; worst = std::max(worst, std::max(span_x, span_y)); }
+    if (worst > kPyrRegion - 2) P.n_levels = 0;
+  }
   // umax (:443-458)
   {
     int* umax = o->um.v;
@@ -664,15 +786,19 @@ static int orb_device_stage(vdo_orb* o, const uint8_t* gray_dev, int stride) {
   hipStream_t s = o->ctx->stream;
   const int NL = o->prm.n_levels;
   const dim3 tb(32, 8);
-  {
-    const LevelDesc& L = o->levels[0];
-    hipLaunchKernelGGL(k_border_copy, dim3((L.bw + 31) / 32, (L.bh + 7) / 8), tb, 0, s, gray_dev, L.w, L.h, stride, o->d_pyr + L.off, L.bw, L.bh);
-  }
-  for (int l = 1; l < NL; ++l) {
-    const LevelDesc &P = o->levels[l - 1], &L = o->levels[l];
-    const double sx = 1. / ((double)L.w / P.w), sy = 1. / ((double)L.h / P.h);
-    hipLaunchKernelGGL(k_resize_border, dim3((L.bw + 31) / 32, (L.bh + 7) / 8), tb, 0, s, (const uint8_t*)(o->d_pyr + P.off_inner), P.w, P.h, P.bw,
-                       o->d_pyr + L.off, L.w, L.h, sx, sy);
+  if (o->pyr.n_levels) {
+    hipLaunchKernelGGL(k_pyramid_all, dim3(o->pyr.tile_off[o->pyr.n_levels]), dim3(256), 0, s, gray_dev, stride, o->pyr, (const LevelDesc*)o->d_levels, o->d_pyr);
+  } else {
+    {
+      const LevelDesc& L = o->levels[0];
+      hipLaunchKernelGGL(k_border_copy, dim3((L.bw + 31) / 32, (L.bh + 7) / 8), tb, 0, s, gray_dev, L.w, L.h, stride, o->d_pyr + L.off, L.bw, L.bh);
+    }
+    for (int l = 1; l < NL; ++l) {
+      const LevelDesc &P = o->levels[l - 1], &L = o->levels[l];
+      const double sx = 1. / ((double)L.w / P.w), sy = 1. / ((double)L.h / P.h);
+      hipLaunchKernelGGL(k_resize_border, dim3((L.bw + 31) / 32, (L.bh + 7) / 8), tb, 0, s, (const uint8_t*)(o->d_pyr + P.off_inner), P.w, P.h, P.bw,
+                         o->d_pyr + L.off, L.w, L.h, sx, sy);
+    }
   }
   hipLaunchKernelGGL(k_fast_cells, dim3(o->ncells), dim3(256), 0, s, (const uint8_t*)o->d_pyr, (const LevelDesc*)o->d_levels, (const CellDesc*)o->d_cells,
                      o->prm.ini_th, o->prm.min_th, o->d_cnt, o->d_pack);
