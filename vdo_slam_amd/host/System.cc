@@ -1,5 +1,6 @@
 #include "System.h"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -43,7 +44,7 @@ Tracking::Tracking(System*, Map* pMap, const std::string& strSettingPath, const 
   mbf = (float)get(cfg_, "Camera.bf");
   mbRGB = get(cfg_, "Camera.RGB", 1) != 0;
   mDepthMapFactor = (float)get(cfg_, "DepthMapFactor", 1);
-  mTestData = (int)get(cfg_, "ChooseData", 2);       // 1 OMD, 2 KITTI, 3 VirtualKITTI (include/Tracking.h:129-133, src/Tracking.cc:115-128)
+  { const int dc = (int)get(cfg_, "ChooseData", 2); mTestData = dc == 1 ? OMD : dc == 3 ? VirtualKITTI : KITTI; }   // include/Tracking.h:129-133, src/Tracking.cc:115-128
   PipelineParams p{};
   p.width = (int)get(cfg_, "Camera.width"); p.height = (int)get(cfg_, "Camera.height");
   p.K4[0] = mK.at<float>(0, 0); p.K4[1] = mK.at<float>(1, 1); p.K4[2] = mK.at<float>(0, 2); p.K4[3] = mK.at<float>(1, 2);
@@ -58,6 +59,11 @@ Tracking::Tracking(System*, Map* pMap, const std::string& strSettingPath, const 
   p.use_sample_feature = (int)get(cfg_, "UseSampleFeature"); p.sample_seed = 1;
   p.pnp_refit = 1;                                   // solvePnPRansac's EPnP re-estimation (OpenCV 3.4)
   p.window_size = (int)get(cfg_, "WINDOW_SIZE"); p.overlap_size = (int)get(cfg_, "OVERLAP_SIZE");
+  mDistCoef = cv::Mat::zeros(4, 1, cv::CV_32F);
+  mThDepth = p.th_depth_bg; mThDepthObj = p.th_depth_obj;
+  nWINDOW_SIZE = p.window_size; nOVERLAP_SIZE = p.overlap_size; nMaxTrackPointBG = p.max_track_bg; nMaxTrackPointOBJ = p.max_track_obj;
+  nUseSampleFea = p.use_sample_feature; fSFMgThres = p.sf_mg_thres; fSFDsThres = p.sf_ds_thres;
+  mState = NO_IMAGES_YET;
   if (p.width <= 0 || p.height <= 0) { std::cerr << "settings: Camera.width / Camera.height missing" << std::endl; std::exit(-1); }
   const char* dev = std::getenv("VDO_DEVICE");
   for (int k = 0; k < 4; ++k)
@@ -76,6 +82,9 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
                                 const std::vector<std::vector<float> >& vObjPose_gt, const double&, cv::Mat&, const int& nImage) {
   StopFrame = nImage - 1;
   if (!have_frame_) f_id = 0;
+  const auto t_call = std::chrono::steady_clock::now();
+  mLastProcessedState = mState;
+  if (mState == NO_IMAGES_YET) mState = NOT_INITIALIZED;
   // The device images were sized from Camera.width / Camera.height of the settings file: every input must have exactly that
   // size, the reference's element types (src/System.h:45-51) and contiguous rows - anything else would be read out of bounds.
   // The reference has no error channel: an empty Mat + a message on stderr.
@@ -107,7 +116,7 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
   // K1 (Tracking.cc:180-204): OMD and KITTI convert disparity*factor to metres - on the device, on the uploaded map; the caller's
   // imD, which the reference converts in place, receives the converted map back.  VirtualKITTI only clamps negative values.
   bool metric = false;
-  if (mTestData != 1 && mTestData != 2) {
+  if (mTestData != OMD && mTestData != KITTI) {
     float* d = (float*)imD.data;
     for (int64_t i = 0; i < n; ++i) if (d[i] < 0) d[i] = 0;
     metric = true;
@@ -118,10 +127,12 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
   if (fc.n_recovered_masks > 0) pipe_->DownloadMask((int32_t*)maskSEM.data);      // UpdateMask writes through the shared header (Tracking.cc:3049-3068)
   have_frame_ = true;
   // full batch optimisation after the last frame, KITTI only (Tracking.cc:1189-1210: `bGlobalBatch && mTestData==KITTI`)
-  if (f_id == StopFrame && f_id > 1 && mTestData == 2) {
+  if (f_id == StopFrame && f_id > 1 && bGlobalBatch && mTestData == KITTI) {
     if (pipe_->FullBatchOptimization() != 0) return cv::Mat();     // graph built straight from the pipeline's GraphStore
   }
   ++f_id;
+  mState = OK; bFirstFrame = false; bFrame2Frame = true;
+  all_timing.push_back(std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - t_call).count());
   cv::Mat Tcw(4, 4, cv::CV_32F);
   std::memcpy(Tcw.data, pipe_->Tcw_out_, 64);
   return Tcw;

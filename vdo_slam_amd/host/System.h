@@ -25,15 +25,27 @@ class Tracking {
   cv::Mat GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Mat& imFlow, const cv::Mat& maskSEM, const cv::Mat& mTcw_gt,
                         const std::vector<std::vector<float> >& vObjPose_gt, const double& timestamp, cv::Mat& imTraj, const int& nImage);
   FramePipeline* pipeline() { return pipe_.get(); }
+
+  // ---- public state of the reference class (include/Tracking.h:116-198) that is scalar configuration / progress.  The per-frame
+  // containers of the reference (mCurrentFrame, mImGray, mSegMap, TemperalMatch, mvTmpObj* ...) live in HBM / inside FramePipeline
+  // here and are not mirrored as host members; FramePipeline's accessors (Tcw_out_, motions_, store(), DownloadMask/Depth) serve them.
+  enum eTrackingState { NO_IMAGES_YET = 0, NOT_INITIALIZED = 1, OK = 2 };
+  eTrackingState mState = NO_IMAGES_YET, mLastProcessedState = NO_IMAGES_YET;
+  enum eDataState { OMD = 1, KITTI = 2, VirtualKITTI = 3 };
+  eDataState mTestData = KITTI;        // ChooseData
+  int mSensor = 2;                     // System::RGBD
   int f_id = 0, StopFrame = 0;
-  cv::Mat mK;
+  bool bLocalBatch = true, bGlobalBatch = true, bJoint = true, bFrame2Frame = false, bFirstFrame = true;
+  int nWINDOW_SIZE = 0, nOVERLAP_SIZE = 0, nMaxTrackPointBG = 0, nMaxTrackPointOBJ = 0, nUseSampleFea = 0;
+  float fSFMgThres = 0, fSFDsThres = 0;
+  std::vector<float> all_timing;       // per frame: ms of this TrackRGBD call (the reference keeps five clock() buckets per frame)
+  cv::Mat mK, mDistCoef;
+  float mbf = 0, mThDepth = 0, mThDepthObj = 0, mDepthMapFactor = 1;
 
  private:
   Map* mpMap;
   std::map<std::string, double> cfg_;
   bool mbRGB = true;
-  int mTestData = 2;                  // ChooseData: 1 OMD, 2 KITTI, 3 VirtualKITTI
-  float mbf = 0, mDepthMapFactor = 1;
   vdo_ctx* ctx_[4] = {nullptr, nullptr, nullptr, nullptr};
   std::unique_ptr<FramePipeline> pipe_;
   std::vector<uint8_t> gray_;
