@@ -41,7 +41,19 @@ def test_orb_matches_oracle_bit_exact(ctx, oracle, seed, shape):
     for l in (0, 3, 7):
         inner = R.pyramid(oracle, gray)[l][19:-19, 19:-19]
         assert np.array_equal(orb.blurred(l), R.blur7(oracle, inner)), f"blur level {l}"
-    orb.close()
+    # the pyramid above came from the one-launch kernel; the level-by-level launches give the same bytes
+    assert orb.pyramid_launches() == 1
+    import os
+    os.environ["VDO_ORB_PYRAMID_LAUNCHES"] = "1"
+    try:
+        orb2 = ORBextractor(ctx, w, h)
+    finally:
+        del os.environ["VDO_ORB_PYRAMID_LAUNCHES"]
+    assert orb2.pyramid_launches() == 8
+    orb2(gray)
+    for l in range(8):
+        assert np.array_equal(orb.pyramid(l), orb2.pyramid(l)), f"pyramid level {l}: fused vs level-by-level"
+    orb.close(); orb2.close()
 
 
 @pytest.mark.parametrize("seed,shape", [(3, (375, 1242)), (4, (375, 1242)), (5, (480, 640))])

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvdo_hip.so")
+LIB_PATH = os.environ.get("VDO_HIP_LIB") or os.path.join(_HERE, "libvdo_hip.so")     # (override: the phase-profiler build of tools/build_profiled_flow2.sh)
 
 c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)

@@ -54,7 +54,7 @@ struct Flow2Arrays {
 // barrier; every workgroup then adds the partial sums in the same order, runs the same 6x6 solve and takes the same
 // decisions - same bits everywhere, so the control flow (and the number of barriers) is identical across the cluster.
 constexpr int F2_CLUSTER = 8;
-static_assert(F2_THREADS == 32 * F2_CLUSTER, "cluster exchange: one thread per (workgroup, value)");
+static_assert(F2_THREADS >= 32 * F2_CLUSTER, "cluster exchange: one thread per (workgroup, value)");
 // Exchange slot: one double as two {32-bit half, 32-bit phase tag} words.  8-byte stores are single-copy atomic, so a reader
 // that finds both tags equal to the phase it waits for has the value of that phase - no fence, no separate flag, one round
 // trip through L2 (the LL idea of RCCL's low-latency protocol).
@@ -63,6 +63,28 @@ struct Flow2Comm {
   Flow2Slot slot[2][F2_CLUSTER][32];    // [phase & 1][workgroup][0..28 sums, 29 max, 30 Hll diagonal of the chunk's last landmark]
 };
 typedef unsigned int f2_u32x4 __attribute__((ext_vector_type(4)));
+// 16-byte slot accesses of the exchange.  F2_XSCOPE: 3 = system scope (sc0 sc1: past every cache), 2 = agent scope (sc1: coherent
+// across the XCDs' L2s), 1 = workgroup scope bits (sc0: misses the CU's L1, served by the XCD's L2 - valid only between
+// workgroups of ONE XCD).
+#ifndef F2_XSCOPE
+#define F2_XSCOPE 2
+#endif
+#if F2_XSCOPE == 3
+#define F2_SC "sc0 sc1"
+#elif F2_XSCOPE == 2
+#define F2_SC "sc1"
+#else
+#define F2_SC "sc0"
+#endif
+__device__ __forceinline__ void f2_slot_store(Flow2Slot* p, const f2_u32x4 w) { asm volatile("global_store_dwordx4 %0, %1, off " F2_SC :: "v"(p), "v"(w) : "memory"); }
+__device__ __forceinline__ f2_u32x4 f2_slot_load(const Flow2Slot* p) {
+  f2_u32x4 w;
+  asm volatile("global_load_dwordx4 %0, %1, off " F2_SC "\n\ts_waitcnt vmcnt(0)" : "=v"(w) : "v"(p) : "memory");
+  return w;
+}
+
+// what the Schur sums of a trial leave in registers for the solve sweep of the same trial (first correspondence of a thread)
+struct F2Pre { double B[12], b0, b1, d0, d1, d2, p2; int i; };
 
 #ifdef F2_PROFILE
 #define F2_TICK(slot) do { if (tid == 0) { const long long t_ = clock64(); s_prof[slot] += t_ - s_tprev; s_tprev = t_; } } while (0)
@@ -78,7 +100,15 @@ typedef unsigned int f2_u32x4 __attribute__((ext_vector_type(4)));
 // An accepted trial makes the alternate buffers the current ones (g2o: the next iteration's computeActiveErrors +
 // buildSystem see exactly this estimate: same inputs, same code, same bits); a rejected one leaves them untouched.
 __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restrict__ probs, Flow2Arrays A) {
+  // Workgroups go to the 8 XCDs round-robin by their linear id, and each XCD has its own L2: the workgroups of a cluster take
+  // ids that are equal mod 8, so that the block sums they exchange stay inside one L2.
+#ifdef F2_LINEAR_MAP
   const int prob = blockIdx.x / F2_CLUSTER, wg = blockIdx.x % F2_CLUSTER;
+#else
+  const int xcd = blockIdx.x & 7, rest = blockIdx.x >> 3;
+  const int wg = rest % F2_CLUSTER, prob = (rest / F2_CLUSTER) * 8 + xcd;
+#endif
+  if (prob >= A.n_problems) return;
   const Flow2Dev P = probs[prob];
   const int N = P.n, tid = threadIdx.x;
   const int Gp = min(A.max_cluster, max(1, (N + F2_THREADS - 1) / F2_THREADS));      // workgroups that share this problem
@@ -98,7 +128,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   unsigned char* __restrict__ inlier_out = (unsigned char*)((double*)(A.out + sizeof(vdo_flow2_result) * (size_t)A.n_problems) + 2 * P.out_total) + P.out_off;
 
   __shared__ double s_scr[F2_WAVES * 4], s_red[32];
-  __shared__ double s_wide[29 * (F2_THREADS + 1)];
+  __shared__ double s_wpart[F2_WAVES * 32];   // wave totals of the block sums (block_reduce_bfly)
   __shared__ SE3d s_T, s_Ttry;
   __shared__ double s_Hc[27], s_xp[6], s_Hs[36], s_bs[6], s_xs[6];   // s_Hc: Hpp (lower triangle, packed) + bp of the current linearisation
   __shared__ double s_rho;
@@ -152,24 +182,24 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       const double v = tid < K ? s_red[tid] : (tid == 29 ? mx : (tid == 30 ? hb : 0.0));
       const unsigned long long u = (unsigned long long)__double_as_longlong(v);
       const f2_u32x4 w = {(unsigned)u, tag, (unsigned)(u >> 32), tag};
-      *(volatile f2_u32x4*)&comm->slot[phase & 1][wg][tid] = w;
+      f2_slot_store(&comm->slot[phase & 1][wg][tid], w);
     }
     {
-      const int g2 = tid >> 5, q = tid & 31;                // F2_THREADS = 8 * 32: one thread per (workgroup, value)
+      const int g2 = tid >> 5, q = tid & 31;                // one thread per (workgroup, value)
       double v = 0.0;
       int bad = 0;
       if (g2 < Gp && q < 31) {
-        const volatile f2_u32x4* src = (const volatile f2_u32x4*)&comm->slot[phase & 1][g2][q];
-        f2_u32x4 w = *src;
+        const Flow2Slot* src = &comm->slot[phase & 1][g2][q];
+        f2_u32x4 w = f2_slot_load(src);
         int spins = 0;
         while (w.y != tag || w.w != tag) {
           __builtin_amdgcn_s_sleep(1);
           if (++spins > (1 << 20)) { bad = 1; break; }      // never hang the GPU: the launch fails instead (vdo_flow2_batch_fetch reports it)
-          w = *src;
+          w = f2_slot_load(src);
         }
         v = __longlong_as_double((long long)(((unsigned long long)w.z << 32) | (unsigned long long)w.x));
       }
-      s_part[g2][q] = v;
+      if (g2 < F2_CLUSTER) s_part[g2][q] = v;
       if (bad) s_ctrl[3] = 1;
     }
     __syncthreads();
@@ -213,7 +243,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   // then evaluate + linearise the edges at (T, f) into Bw/hw/bw.  Block sums -> s_red[0..26] (Hpp lower, bp), [27] robust chi2,
   // [28] landmark part of computeScale; returns the per-thread max of the Hll diagonal (computeLambdaInit).
   auto sweep = [&](auto trial_c, const double lam, const bool ok2, const double* __restrict__ Br, const double* __restrict__ hr, const double* __restrict__ br,
-                   double* __restrict__ Bw, double* __restrict__ hw, double* __restrict__ bw, const double* fin, double* fout, const double hb_prev) -> double {
+                   double* __restrict__ Bw, double* __restrict__ hw, double* __restrict__ bw, const double* fin, double* fout, const double hb_prev, const F2Pre& pre) -> double {
     constexpr bool TRIAL = decltype(trial_c)::value;
     const SE3d T = TRIAL ? s_Ttry : s_T;
     double xp[6];
@@ -226,32 +256,44 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     for (int i = first; i < c_hi; i += stride) {
       double f0v, f1v;
       if (TRIAL) {
-        // back-substitution c = b_l - B^T x_p for this landmark
-        const double* B = Br + i;
+        // back-substitution c = b_l - B^T x_p for this landmark (first correspondence of the thread: B, b_l and D^-1 are
+        // still in registers from the Schur sums of this trial - same loads, same lambda, same divisions)
+        const bool hp = Q && i == pre.i;
+        double Bl[12], b0, b1;
+        if (hp) {
+#pragma unroll
+          for (int a = 0; a < 12; ++a) Bl[a] = pre.B[a];
+          b0 = pre.b0; b1 = pre.b1;
+        } else {
+          const double* B = Br + i;
+#pragma unroll
+          for (int a = 0; a < 12; ++a) Bl[a] = B[a * N];
+          b0 = br[i]; b1 = br[N + i];
+        }
         double t0 = 0, t1 = 0;
 #pragma unroll
-        for (int a = 0; a < 6; ++a) { t0 += B[(2 * a) * N] * (-xp[a]); t1 += B[(2 * a + 1) * N] * (-xp[a]); }
-        const double b0 = br[i], b1 = br[N + i];
+        for (int a = 0; a < 6; ++a) { t0 += Bl[2 * a] * (-xp[a]); t1 += Bl[2 * a + 1] * (-xp[a]); }
         const double c0 = b0 + t0, c1 = b1 + t1;
         double x0, x1;
         if (Q) {
           // x[2i..2i+2] = D_i^-1 c_i with the aliased 3x3 block (dinv_q): rows 0/1 give this landmark's flow update, row 2 of
           // landmark i-1 (= its d2 * c0 of THIS landmark: the aliased third component) was written into slot 2i first
-          double d0, d1, d2;
-          dinv_q(hr[i], lam, d0, d1, d2);
+          double d0, d1, d2, p2_ = 0;
+          if (hp) { d0 = pre.d0; d1 = pre.d1; d2 = pre.d2; p2_ = pre.p2; }
+          else {
+            dinv_q(hr[i], lam, d0, d1, d2);
+            if (i > 0) { double p0_, p1_; dinv_q(i > c_lo ? hr[i - 1] : hb_prev, lam, p0_, p1_, p2_); }      // (the previous chunk's last landmark belongs to another workgroup)
+          }
           x0 = d0 * c0 + d1 * c1;
           x1 = d2 * c1;
-          if (i > 0) {
-            double p0_, p1_, p2_;
-            dinv_q(i > c_lo ? hr[i - 1] : hb_prev, lam, p0_, p1_, p2_);      // (the previous chunk's last landmark belongs to another workgroup)
-            x0 = p2_ * c0 + x0;
-          }
+          if (i > 0) x0 = p2_ * c0 + x0;
         } else {
           double Di[9];
           dinv_of(hr[i], lam, Di);
           x0 = (Di[0] * c0 + Di[1] * c1) + Di[2] * 0.0;
           x1 = (Di[3] * c0 + Di[4] * c1) + Di[5] * 0.0;
         }
+        F2_TICK(8);
         if (!ok2) x0 = xl[i];         // failed LDLT: stale x (the reference keeps the previous content); the trial is rejected anyway
         const double x1e = ok2 ? x1 : xl[N + i];
         xl[i] = x0; xl[N + i] = x1e;
@@ -269,6 +311,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       const double u = X / Z * fx + cx, v = Y / Z * fy + cy;
       const double e0 = (obs[i] + f0v) - u, e1 = (obs[N + i] + f1v) - v;
       err[i] = e0; err[N + i] = e1;
+      if (TRIAL) F2_TICK(9);
       const double c = e0 * (P.info_flow * e0) + e1 * (P.info_flow * e1);
       double r0, r1;
       huber_f2(c, P.huber_delta, P.huber_dsqr, r0, r1);
@@ -295,8 +338,10 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       bw[N + i] = or1 - P.info_prior * p1;
       hmax = fmax(hmax, h);
       if (i == c_hi - 1) s_hlast = h;
+      if (TRIAL) F2_TICK(10);
     }
-    block_reduce_wide<29>(acc, s_wide, s_red);
+    block_reduce_bfly<29>(acc, s_wpart, s_red);
+    if (TRIAL) F2_TICK(11);
     return hmax;
   };
 
@@ -305,7 +350,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   const double tau = 1e-5, upper = 2. / 3., lower = 1. / 3.;
   double chi2_check = 0;
   // initial computeActiveErrors + buildSystem
-  double hmax = sweep(std::false_type{}, 0.0, true, nullptr, nullptr, nullptr, Bc, hc, bc, fcur, nullptr, 0.0);
+  double hmax = sweep(std::false_type{}, 0.0, true, nullptr, nullptr, nullptr, Bc, hc, bc, fcur, nullptr, 0.0, F2Pre{});
 #pragma unroll
   for (int off2 = 32; off2 > 0; off2 >>= 1) hmax = fmax(hmax, __shfl_down(hmax, off2, 64));
   if ((tid & 63) == 0) s_scr[tid >> 6] = hmax;
@@ -331,7 +376,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     // computeActiveErrors + buildSystem at the current estimate: already there after an accepted trial; repeated
     // only when the previous trial was rejected without ending the iteration loop (non-finite chi2)
     if (!built) {
-      sweep(std::false_type{}, 0.0, true, nullptr, nullptr, nullptr, Bc, hc, bc, fcur, nullptr, 0.0);
+      sweep(std::false_type{}, 0.0, true, nullptr, nullptr, nullptr, Bc, hc, bc, fcur, nullptr, 0.0, F2Pre{});
       { double d_ = 0; hb_cur = s_hlast; F2_CLUSTER_SUM(29, d_, hb_cur); }
       last_err_chi = s_red[27];
       if (tid < 27) s_Hc[tid] = s_red[tid];
@@ -344,6 +389,8 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     int qmax = 0;
     do {
       // ---- (1) Schur sums for this lambda (with the F3 aliasing)
+      F2Pre pre;
+      pre.i = -1;
       {
         double acc[27];
 #pragma unroll
@@ -359,6 +406,12 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
             double d0, d1, d2;
             dinv_q(hr[i], lambda, d0, d1, d2);
             const double db0 = d0 * bl0 + d1 * bl1, db1 = d2 * bl1;      // (the aliased third row/column only ever meets exact zeros)
+            if (i == first) {
+#pragma unroll
+              for (int a = 0; a < 12; ++a) pre.B[a] = Bv[a];
+              pre.b0 = bl0; pre.b1 = bl1; pre.d0 = d0; pre.d1 = d1; pre.d2 = d2; pre.p2 = 0.0; pre.i = i;
+              if (i > 0) { double p0_, p1_; dinv_q(i > c_lo ? hr[i - 1] : hb_cur, lambda, p0_, p1_, pre.p2); }
+            }
             int k = 0;
 #pragma unroll
             for (int a = 0; a < 6; ++a) {
@@ -383,24 +436,34 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
             }
           }
         }
-        block_reduce_wide<27>(acc, s_wide, s_red);
+        F2_TICK(12);
+        block_reduce_bfly<27>(acc, s_wpart, s_red);
+        F2_TICK(13);
         { double d_ = 0, e_ = 0; F2_CLUSTER_SUM(27, d_, e_); }
       }
       F2_TICK(0);
       // ---- (2) reduced 6x6 system, SE3 update, pose part of computeScale
-      if (tid == 0) {
-        {
-          int k = 0;
-#pragma unroll
-          for (int a = 0; a < 6; ++a) {
-#pragma unroll
-            for (int c2 = 0; c2 <= a; ++c2) { s_Hs[c2 * 6 + a] = s_Hc[k]; s_Hs[a * 6 + c2] = s_Hc[k] - s_red[k]; ++k; }
-          }
+      // reduced system: lower triangle Hpp - (Schur sums) + lambda I, rhs bp - (Schur sums); one thread per entry
+      if (tid < 36) {
+        const int a = tid / 6, c2 = tid - 6 * a;
+        if (c2 <= a) {
+          const int k = a * (a + 1) / 2 + c2;
+          double v = s_Hc[k] - s_red[k];
+          if (c2 == a) v += lambda;
+          s_Hs[tid] = v;
+        } else {
+          s_Hs[tid] = s_Hc[c2 * (c2 + 1) / 2 + a];
         }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) { s_Hs[7 * j] += lambda; s_bs[j] = s_Hc[21 + j] - s_red[21 + j]; }
-        F2_TICK(5);
-        const bool ok2 = ldlt6_solve_perm(s_Hs, s_bs, s_xs);
+      } else if (tid < 42) {
+        const int j = tid - 36;
+        s_bs[j] = s_Hc[21 + j] - s_red[21 + j];
+      }
+      __syncthreads();
+      F2_TICK(5);
+      bool ok2w = false;
+      if (tid < 64) ok2w = ldlt6_solve_lanes(s_Hs, s_bs, s_xs);      // wave 0: one row of the 6x6 system per lane
+      if (tid == 0) {
+        const bool ok2 = ok2w;
         F2_TICK(6);
         s_ctrl[2] = ok2 ? 1 : 0;
         if (ok2) {
@@ -418,7 +481,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       F2_TICK(1);
       const bool ok2 = s_ctrl[2] != 0;
       // ---- (3) finish the solve per correspondence, errors + speculative linearisation at the trial point
-      sweep(std::true_type{}, lambda, ok2, Bc, hc, bc, Bt, ht, bt, fcur, ftry, hb_cur);
+      sweep(std::true_type{}, lambda, ok2, Bc, hc, bc, Bt, ht, bt, fcur, ftry, hb_cur, pre);
       { double d_ = 0; hb_try = s_hlast; F2_CLUSTER_SUM(29, d_, hb_try); }
       last_err_chi = tempChi = s_red[27];
       const double scale = (s_rho + s_red[28]) + 1e-3;
@@ -426,7 +489,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       if (!ok2) tempChi = 1.7976931348623157e308;
       rho = (currentChi - tempChi) / scale;
       if (rho > 0 && isfinite(tempChi)) {
-        double alpha = 1. - pow((2 * rho - 1), 3);
+        double alpha = 1. - cube_rn(2 * rho - 1);
         alpha = fmin(alpha, upper);
         lambda *= fmax(lower, alpha); ni = 2; currentChi = tempChi; built = true;
         { double* t_ = fcur; fcur = ftry; ftry = t_; }                       // discardTop(): accept (uniform pointer swaps)
@@ -471,7 +534,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     res->iterations = it; res->trials = total_trials; res->stop_reason = stop_reason;
     res->initial_chi2 = initial_chi2; res->final_chi2 = last_err_chi; res->final_lambda = lambda;
 #ifdef F2_PROFILE
-    for (int i = 0; i < 8; ++i) res->T[i] = (double)s_prof[i];     // cycles per phase instead of the pose (debug build only)
+    for (int i = 0; i < 16; ++i) res->T[i] = (double)s_prof[i];     // cycles per phase instead of the pose (debug build only)
 #endif
   }
 }
@@ -661,7 +724,7 @@ extern "C" int vdo_flow2_batch_run(vdo_flow2_batch* b) {
     }
     b->A.max_cluster = mc;
   }
-  hipLaunchKernelGGL(k_flow2_lm, dim3(b->n_problems * F2_CLUSTER), dim3(F2_THREADS), 0, b->ctx->stream, b->d_probs_run ? b->d_probs_run : (const Flow2Dev*)b->d_probs, b->A);
+  hipLaunchKernelGGL(k_flow2_lm, dim3(((b->n_problems + 7) / 8) * 8 * F2_CLUSTER), dim3(F2_THREADS), 0, b->ctx->stream, b->d_probs_run ? b->d_probs_run : (const Flow2Dev*)b->d_probs, b->A);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "k_flow2_lm launch: %s", hipGetErrorString(e));
   return VDO_OK;

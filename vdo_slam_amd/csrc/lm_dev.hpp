@@ -59,6 +59,24 @@ __device__ inline void q_normalize_pos(Q4& q) {   // SE3Quat::normalizeRotation
 __device__ inline void m3mul(const double* a, const double* b, double* o) {
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) o[3 * i + j] = a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
 }
+// x^3 with ONE rounding (x^2 and x^2*x carried as exact two-term sums): what a correctly rounded pow(x, 3) returns - the
+// library pow costs several hundred cycles of a latency-bound section for the same bits.
+__device__ __forceinline__ double cube_rn(double x) {
+  const double p = x * x, pe = __builtin_fma(x, x, -p);
+  const double h = p * x, he = __builtin_fma(p, x, -h);
+  if (!(fabs(h) < 1.7976931348623157e308)) return h;      // overflow / NaN: as the plain product
+  return h + (he + pe * x);
+}
+// sin and cos of a small angle (|x| < 0.3: every LM update): the kernel polynomials of fdlibm (k_sin.c / k_cos.c coefficients),
+// no range reduction, the two Horner chains interleave; < 1 ulp like the library calls they replace.
+__device__ __forceinline__ void sincos_small(double x, double& sn, double& cs) {
+  const double z = x * x;
+  const double rs = 8.33333333332248946124e-03 + z * (-1.98412698298579493134e-04 + z * (2.75573137070700676789e-06 + z * (-2.50507602534068634195e-08 + z * 1.58969099521155010221e-10)));
+  const double rc = z * (4.16666666666666019037e-02 + z * (-1.38888888888741095749e-03 + z * (2.48015872894767294178e-05 + z * (-2.75573143513906633035e-07 + z * (2.08757232129817482790e-09 + z * -1.13596475577881948265e-11)))));
+  sn = x + (z * x) * (-1.66666666666666324348e-01 + z * rs);
+  cs = 1.0 - (0.5 * z - z * rc);
+}
+
 // SE3Quat::exp(update) * T      (se3quat.h:229-262, :106-112)
 __device__ inline SE3d se3_exp_compose(const double* u, const SE3d& T) {
   const double ox = u[0], oy = u[1], oz = u[2];
@@ -70,7 +88,9 @@ __device__ inline SE3d se3_exp_compose(const double* u, const SE3d& T) {
     for (int i = 0; i < 9; ++i) R[i] = ((i % 4 == 0) ? 1.0 : 0.0) + Om[i] + Om2[i];
     for (int i = 0; i < 9; ++i) V[i] = R[i];
   } else {
-    const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (pow(theta, 3));
+    double sn, cs;
+    if (theta < 0.3) sincos_small(theta, sn, cs); else { sn = sin(theta); cs = cos(theta); }
+    const double a = sn / theta, b = (1 - cs) / (theta * theta), c = (theta - sn) / cube_rn(theta);
     for (int i = 0; i < 9; ++i) {
       const double id = (i % 4 == 0) ? 1.0 : 0.0;
       R[i] = (id + a * Om[i]) + b * Om2[i];
@@ -231,6 +251,110 @@ __device__ __forceinline__ bool ldlt6_solve_perm(const double* A, const double* 
   return true;
 }
 
+// The same solve spread over the lanes of ONE FULL WAVE (every lane of the wave must call it): lane i < 6 owns row i of
+// P A P^T, the uniform quantities (pivot order, row k, the pivots) travel through v_readlane.  Every entry goes through the
+// same products, sums and quotients in the same order as in ldlt6_solve_perm - identical bits (tools/lm_dev_check.hip compares
+// them) - but a step costs one dot product, one division and one update instead of 5 - k of each: ~40 % fewer instructions
+// on the serial path of an LM trial.  A, b, x: LDS as above.  Returns isPositive() (uniform).
+__device__ __forceinline__ double readlane_f64(double v, const int lane) {
+  const unsigned long long u = (unsigned long long)__double_as_longlong(v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)u, lane), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(u >> 32), lane);
+  return __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+}
+__device__ __forceinline__ bool ldlt6_solve_lanes(const double* A, const double* b, double* x) {
+  const int lane = threadIdx.x & 63;
+  const int li = lane < 6 ? lane : 5;
+  // ---- pivot order.  Without ties among the |diagonal| entries Eigen's selection (first maximum wins, the displaced entry takes
+  // the pivot's old place) is the descending order: lane i counts the entries above its own, a ballot per rank turns the
+  // ranks into the order.  Ties (or NaNs: ranks that are no permutation) take the step-by-step selection of ldlt6_solve_perm.
+  int ord[6];
+  {
+    double dd[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) dd[i] = fabs(A[7 * i]);
+    const double dm = fabs(A[7 * li]);
+    int rank = 0, ties = 0;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) { rank += dd[j] > dm ? 1 : 0; ties += (dd[j] == dm && j != li) ? 1 : 0; }
+    bool simple = __ballot(lane < 6 && ties != 0) == 0ull;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+      const unsigned long long mk = __ballot(lane < 6 && rank == q);
+      simple = simple && mk != 0ull;
+      ord[q] = (int)__builtin_ctzll(mk | (1ull << 63));
+    }
+    if (!simple) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) ord[i] = i;
+#pragma unroll
+      for (int k = 0; k < 5; ++k) {
+        int big = k;
+        double bv = dd[k];
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) if (dd[i] > bv) { bv = dd[i]; big = i; }
+#pragma unroll
+        for (int bb = k + 1; bb < 6; ++bb)
+          if (big == bb) { const double t = dd[k]; dd[k] = dd[bb]; dd[bb] = t; const int u = ord[k]; ord[k] = ord[bb]; ord[bb] = u; }
+      }
+    }
+  }
+  int r = ord[0];
+#pragma unroll
+  for (int i = 1; i < 6; ++i) r = li == i ? ord[i] : r;
+  double m[6];                       // row li of P A P^T (columns <= li are meaningful)
+#pragma unroll
+  for (int j = 0; j < 6; ++j) { const int c = ord[j]; m[j] = r >= c ? A[r * 6 + c] : A[c * 6 + r]; }
+  double y = b[r];
+  // ---- the largest |diagonal| entry is 0 (or NaN): Eigen stops at once and solves with the untouched matrix - the rare path
+  // goes to the one-lane routine
+  const double a00 = readlane_f64(m[0], 0);
+  if (!(fabs(a00) > 0.0)) {
+    bool ok = false;
+    if (lane == 0) ok = ldlt6_solve_perm(A, b, x);
+    return __builtin_amdgcn_readfirstlane((int)ok) != 0;
+  }
+  double D[6];                       // pivots (uniform)
+  double dself = 0.0;                // this lane's pivot
+  bool neg = false;                  // isPositive(): no negative pivot (the sign bookkeeping of Eigen reduces to this)
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    if (k > 0) {
+      double temp[6];
+#pragma unroll
+      for (int j = 0; j < k; ++j) temp[j] = D[j] * readlane_f64(m[j], k);
+      double t = 0;
+#pragma unroll
+      for (int j = 0; j < k; ++j) t += m[j] * temp[j];
+      m[k] -= t;                     // row k: the pivot; rows below: column k
+    }
+    const double akk = readlane_f64(m[k], k);
+    D[k] = akk;
+    dself = lane == k ? akk : dself;
+    const bool valid = fabs(akk) > 0.0;
+    const double q = m[k] / akk;
+    m[k] = (valid && lane > k) ? q : m[k];
+    neg = neg || akk < 0;
+  }
+  if (neg) return false;
+#pragma unroll
+  for (int j = 0; j < 5; ++j) { const double yj = readlane_f64(y, j); const double u = y - m[j] * yj; y = lane > j ? u : y; }
+  y = fabs(dself) > 2.2250738585072014e-308 ? y / dself : 0.0;
+  double yf[6];
+  yf[5] = readlane_f64(y, 5);
+#pragma unroll
+  for (int i = 4; i >= 0; --i) {
+    double yi = readlane_f64(y, i);
+#pragma unroll
+    for (int j = i + 1; j < 6; ++j) yi -= readlane_f64(m[i], j) * yf[j];
+    yf[i] = yi;
+  }
+  double mine = yf[0];
+#pragma unroll
+  for (int i = 1; i < 6; ++i) mine = li == i ? yf[i] : mine;
+  if (lane < 6) x[r] = mine;
+  return true;
+}
+
 __device__ __forceinline__ void inv3_dev(const double* a, double* o) {   // Eigen fixed 3x3 inverse
   const double C00 = a[4] * a[8] - a[5] * a[7];
   const double C10 = a[2] * a[7] - a[1] * a[8];
@@ -295,6 +419,74 @@ __device__ __forceinline__ void block_reduce_wide(const double (&v)[K], double* 
   a += __shfl_down(a, 2, 8);
   a += __shfl_down(a, 1, 8);
   if (q < K && part == 0) out[q] = a;
+  __syncthreads();
+}
+
+// Butterfly variant (gfx950): the K (<= 32) running sums never leave the registers inside a wave.  A halving step pairs lanes
+// and registers: each lane of a pair keeps half of the quantities and receives the partner's partial sums of those - after
+// the six steps every lane holds the wave total of ONE quantity.  The two widest steps are single instructions on gfx950
+// (v_permlane32_swap / v_permlane16_swap exchange 32- / 16-lane rows between two registers: swap + add, no selects); the
+// steps inside a 16-lane row use DPP (row_ror:8, row_half_mirror, quad_perm).  ~130 VALU instructions for 32 quantities
+// against 32 LDS stores + 32 dependent LDS loads per thread in block_reduce_wide; then one small LDS stage across the waves
+// (added in wave order by everybody: fixed order, same bits in every workgroup of a cluster).  part: [F2_WAVES][32], out: [K].
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const long long u = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_update_dpp(0, (int)(unsigned)u, CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, (int)(unsigned)((unsigned long long)u >> 32), CTRL, 0xF, 0xF, false);
+  return __longlong_as_double((long long)(((unsigned long long)(unsigned)hi << 32) | (unsigned long long)(unsigned)lo));
+}
+template <bool ROW32>
+__device__ __forceinline__ void rows_swap_f64(double& a, double& b) {
+  const unsigned long long ua = (unsigned long long)__double_as_longlong(a), ub = (unsigned long long)__double_as_longlong(b);
+  const auto lo = ROW32 ? __builtin_amdgcn_permlane32_swap((unsigned)ua, (unsigned)ub, false, false) : __builtin_amdgcn_permlane16_swap((unsigned)ua, (unsigned)ub, false, false);
+  const auto hi = ROW32 ? __builtin_amdgcn_permlane32_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false)
+                        : __builtin_amdgcn_permlane16_swap((unsigned)(ua >> 32), (unsigned)(ub >> 32), false, false);
+  a = __longlong_as_double((long long)(((unsigned long long)hi[0] << 32) | lo[0]));
+  b = __longlong_as_double((long long)(((unsigned long long)hi[1] << 32) | lo[1]));
+}
+// quantity whose wave total lane `lane` holds after wave_reduce32
+__device__ __forceinline__ int bfly_quantity(int lane) { return ((lane >> 5) << 4) | (((lane >> 4) & 1) << 3) | (((lane >> 3) & 1) << 2) | (((lane >> 2) & 1) << 1) | ((lane >> 1) & 1); }
+template <int K>
+__device__ __forceinline__ double wave_reduce32(const double (&acc)[K]) {
+  static_assert(K <= 32, "at most 32 quantities");
+  const int lane = threadIdx.x & 63;
+  double v[32];
+#pragma unroll
+  for (int i = 0; i < 32; ++i) v[i] = i < K ? acc[i] : 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { rows_swap_f64<true>(v[j], v[j + 16]); v[j] = v[j] + v[j + 16]; }    // lanes >= 32 now carry quantities 16..31
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { rows_swap_f64<false>(v[j], v[j + 8]); v[j] = v[j] + v[j + 8]; }       // odd rows: +8
+  {
+    const bool up = (lane & 8) != 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const double keep = up ? v[j + 4] : v[j], send = up ? v[j] : v[j + 4]; v[j] = keep + dpp_f64<0x128>(send); }      // row_ror:8
+  }
+  {
+    const bool up = (lane & 4) != 0;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) { const double keep = up ? v[j + 2] : v[j], send = up ? v[j] : v[j + 2]; v[j] = keep + dpp_f64<0x141>(send); }      // row_half_mirror: i <-> 7 - i
+  }
+  {
+    const bool up = (lane & 2) != 0;
+    const double keep = up ? v[1] : v[0], send = up ? v[0] : v[1];
+    v[0] = keep + dpp_f64<0x4E>(send);                                                                                                       // quad_perm [2,3,0,1]
+  }
+  return v[0] + dpp_f64<0xB1>(v[0]);                                                                                                          // quad_perm [1,0,3,2]
+}
+template <int K>
+__device__ __forceinline__ void block_reduce_bfly(const double (&acc)[K], double* part, double* out) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const double t = wave_reduce32<K>(acc);
+  if ((lane & 1) == 0) part[wv * 32 + bfly_quantity(lane)] = t;
+  __syncthreads();
+  if (threadIdx.x < K) {
+    double a = part[threadIdx.x];
+#pragma unroll
+    for (int w = 1; w < F2_WAVES; ++w) a += part[w * 32 + threadIdx.x];
+    out[threadIdx.x] = a;
+  }
   __syncthreads();
 }
 

@@ -109,7 +109,7 @@ struct PyrDesc {
   int tile_off[9];              // first workgroup of every level
   int tiles_x[8];
 };
-constexpr int kPyrRegion = 144;   // max edge of a cascaded region (checked on the host at create time)
+constexpr int kPyrRegion = 160;   // max edge of a cascaded region (checked on the host at create time)
 
 __device__ __forceinline__ void resize_src(int d, double scale, int slen, int& s0, int& s1, int& c0, int& c1) {
   float f = (float)((d + 0.5) * scale - 0.5);
@@ -641,6 +641,11 @@ struct vdo_orb {
   std::chrono::steady_clock::time_point t_begin;
 };
 
+extern "C" int vdo_orb_pyramid_launches(const vdo_orb* o) {
+  if (!o) return set_error(VDO_ERR_INVALID, "null handle");
+  return o->pyr.n_levels ? 1 : (int)o->levels.size();
+}
+
 extern "C" int vdo_orb_destroy(vdo_orb* o) {
   if (!o) return VDO_OK;
   if (o->ctx) ctx_bind(o->ctx);
@@ -726,10 +731,35 @@ extern "C" int vdo_orb_create(vdo_ctx* ctx, const vdo_orb_params* prm, int w, in
       tot += P.tiles_x[l] * ((P.h[l] + 31) / 32);
     }
     P.tile_off[NL] = tot;
-    // widest region any tile needs at any level below it: grow a 32-px span down the cascade (+2 px per step covers the taps and the float rounding)
-    double span_x = 32, span_y = 32, worst = 32;
-    for (int l = NL - 1; l > 0; --l) { span_x = span_x * P.sx[l] + 3; span_y = span_y * P.sy[l] + 3; worst = std::max(worst, std::max(span_x, span_y)); }
-    if (worst > kPyrRegion - 2) P.n_levels = 0;
+    // widest region any tile needs at any level below it: the kernel's own cascade (same arithmetic) over every tile column / row
+    auto src_range = [](int d0, int d1, double scale, int slen, bool clamp_both, int& s0, int& s1) {
+      auto tap = [&](int d, int& lo, int& hi) {
+        float f = (float)((d + 0.5) * scale - 0.5);
+        int si = (int)std::floor(f);
+        if (clamp_both) { lo = std::min(std::max(si, 0), slen - 1); hi = std::min(std::max(si + 1, 0), slen - 1); return; }
+        if (si < 0) si = 0;
+        if (si + 1 >= slen) { lo = hi = slen - 1; return; }
+        lo = si; hi = si + 1;
+      };
+      int a, b;
+      tap(d0, s0, a); tap(d1, b, s1);
+    };
+    int worst = 32;
+    for (int l = 1; l < NL; ++l) {
+      for (int axis = 0; axis < 2; ++axis) {
+        const int len = axis ? P.h[l] : P.w[l];
+        for (int t0 = 0; t0 < len; t0 += 32) {
+          int d0 = t0, d1 = std::min(t0 + 31, len - 1);
+          for (int k = l; k > 0; --k) {
+            int s0, s1;
+            src_range(d0, d1, axis ? P.sy[k] : P.sx[k], axis ? P.h[k - 1] : P.w[k - 1], axis == 1, s0, s1);
+            d0 = s0; d1 = s1;
+            worst = std::max(worst, d1 - d0 + 1);
+          }
+        }
+      }
+    }
+    if (worst > kPyrRegion) P.n_levels = 0;
   }
   // umax (:443-458)
   {

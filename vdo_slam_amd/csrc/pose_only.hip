@@ -78,7 +78,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_pose_lm(const PoseDev* __restric
   vdo_flow2_result* res = A.results + blockIdx.x;
 
   __shared__ double s_scr[F2_WAVES * 27], s_red[27];
-  __shared__ double s_wide[27 * (F2_THREADS + 1)];
+  __shared__ double s_wpart[F2_WAVES * 32];
   __shared__ SE3d s_T, s_Ttry;
   __shared__ double s_Hpp[36], s_bp[6], s_xp[6];
   __shared__ double s_lambda, s_scale;
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_pose_lm(const PoseDev* __restric
           for (int c2 = 0; c2 <= a; ++c2) acc[k++] += (J[a] * r1) * J[c2] + (J[6 + a] * r1) * J[6 + c2];
         }
       }
-      block_reduce_wide<27>(acc, s_wide, s_red);
+      block_reduce_bfly<27>(acc, s_wpart, s_red);
       if (tid == 0) {
         int k = 0;
         double mm = 0;
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_pose_lm(const PoseDev* __restric
       if (!ok2) tempChi = 1.7976931348623157e308;
       rho = (currentChi - tempChi) / scale;
       if (rho > 0 && isfinite(tempChi)) {
-        double alpha = 1. - pow((2 * rho - 1), 3);
+        double alpha = 1. - cube_rn(2 * rho - 1);
         alpha = fmin(alpha, upper);
         lambda *= fmax(lower, alpha); ni = 2; currentChi = tempChi; err_valid = true;
         if (tid == 0) s_T = s_Ttry;

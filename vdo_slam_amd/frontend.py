@@ -113,6 +113,12 @@ class ORBextractor:
         K.check(L.vdo_orb_last_timing(self._h, ms))
         return ms[0], ms[1]
 
+    def pyramid_launches(self):
+        """Kernel launches per pyramid: 1 (fused) or the number of levels."""
+        L = _lib()
+        L.vdo_orb_pyramid_launches.argtypes = [C.c_void_p]
+        return int(L.vdo_orb_pyramid_launches(self._h))
+
     def level_info(self, level):
         w, h, nf, nc = C.c_int(), C.c_int(), C.c_int(), C.c_int()
         K.check(_lib().vdo_orb_level_info(self._h, level, C.byref(w), C.byref(h), C.byref(nf), C.byref(nc)))
