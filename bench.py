@@ -222,8 +222,10 @@ def main():
             self.ctx = Context(local, stream.cuda_stream) if first else Context(local)
             self.ctx_lm, self.ctx_obj = Context(local), Context(local)       # camera LM || ORB front-end; object LMs || RenewFrameInfo + next camera stage
             self.ctx_w = Context(local) if (not os.environ.get("VDO_BENCH_NO_WORKER") and cpus_here >= 5) else None
+            # + ORB of the frame on a third host thread (its own context / stream) when there are CPUs for it
+            self.ctx_orb = Context(local) if (self.ctx_w is not None and not os.environ.get("VDO_BENCH_NO_ORB_THREAD") and cpus_here >= 6) else None
             self.pipe = FramePipeline(self.ctx, self.ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ,
-                                                                         build_lm=1, defer_objects=defer), self.ctx_obj, self.ctx_w, None)
+                                                                         build_lm=1, defer_objects=defer), self.ctx_obj, self.ctx_w, self.ctx_orb)
             if not os.environ.get("VDO_BENCH_NO_MAP"):
                 self.pipe.keep_graph()                            # "Save Graph Structure" (Tracking.cc:1031-1159): every frame is appended to the flat GraphStore the batch optimisers read
             self.agg = {q: 0 for q in AGG}
@@ -313,7 +315,7 @@ def main():
                    "sequences_per_gpu": R, "sequences_identical": bool(identical),
                    "parallelism": f"replicas x{world}" + (f" (ranks share {n_dev} device(s), collectives over gloo)" if shared_gpu else "") + f", {R} sequence(s) per GPU; 4 HIP streams per sequence: camera LM (2) || ORB front-end (1); object LMs (3) || RenewFrameInfo (1) and - "
                                   f"defer_objects={defer} - the next frame's camera stage; every LM problem runs on a cluster of up to 8 workgroups; "
-                                  f"{cpus:.1f} CPUs per rank, host threads per sequence: 1 + {int(rep0.ctx_w is not None)} helper (object stage of the previous frame || camera stage + ORB; K9/K10/RenewFrameInfo static || object chain) + {rep0.orb_threads} ORB quadtree helpers",
+                                  f"{cpus:.1f} CPUs per rank, host threads per sequence: 1 + {int(rep0.ctx_w is not None)} helper (object stage of the previous frame || camera stage; K9/K10/RenewFrameInfo static || object chain) + {int(rep0.ctx_orb is not None)} ORB thread (K3-K7 of the frame, from the start of the frame to the static stage) + {rep0.orb_threads} ORB quadtree helpers",
                    "orb_keypoints": counts.n_orb, "new_static_candidates": counts.n_static_new, "object_samples": counts.n_object_samples,
                    "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
                    "per_frame_mean": {q: round(v / n_all, 2) for q, v in agg.items()},

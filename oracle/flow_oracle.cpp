@@ -23,6 +23,8 @@
 // ref_quirks = 0 is the mathematically intended 2x2 Schur step (NOT parity-comparable).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
+#include <cstdio>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -287,6 +289,7 @@ extern "C" int vdo_oracle_flow2_optimize(const vdo_flow2_problem* p, double T_ou
   const double tau = 1e-5, upper = 2. / 3., lower = 1. / 3.;
   const int maxTrials = 10;
   bool ok = true;
+  const bool trace_rho = std::getenv("VDO_ORACLE_LM_TRACE") != nullptr;      // (debug: gain ratio of every trial on stderr)
   double chi2_check = 0, last_err_chi = S.compute_errors();
   st->initial_chi2 = last_err_chi;
   int it = 0;
@@ -312,6 +315,7 @@ extern "C" int vdo_oracle_flow2_optimize(const vdo_flow2_problem* p, double T_ou
       for (int j = 0; j < 2 * N; ++j) scale += S.x[6 + j] * (lambda * S.x[6 + j] + S.bl[j]);
       scale += 1e-3;
       rho /= scale;
+      if (trace_rho) std::fprintf(stderr, "[lm n=%d it=%d q=%d] rho %.6g lambda %.4g chi %.9g -> %.9g\n", N, it, qmax, rho, lambda, currentChi, tempChi);
       if (rho > 0 && std::isfinite(tempChi)) {
         double alpha = 1. - std::pow((2 * rho - 1), 3);
         alpha = std::min(alpha, upper);

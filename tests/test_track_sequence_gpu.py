@@ -110,7 +110,7 @@ def test_deferred_object_stage_gives_the_same_sequence():
         return poses, counts, motions
 
     p0, c0, m0 = run(0)
-    for defer, worker, orb_thread in ((1, False, False), (1, True, False), (0, True, False), (1, True, True), (0, False, True)):
+    for defer, worker, orb_thread in ((1, False, False), (1, True, False), (0, True, False), (1, True, True), (0, True, True), (0, False, True)):
         p1, c1, m1 = run(defer, worker, orb_thread)
         assert c0[1:] == c1[1:], (defer, worker, orb_thread, [(a, b) for a, b in zip(c0, c1) if a != b][:2])
         for a, b in zip(p0, p1):

@@ -132,7 +132,7 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
   __shared__ SE3d s_T, s_Ttry;
   __shared__ double s_Hc[27], s_xp[6], s_Hs[36], s_bs[6], s_xs[6];   // s_Hc: Hpp (lower triangle, packed) + bp of the current linearisation
   __shared__ double s_rho;
-  __shared__ int s_ctrl[4];   // [2] ok2, [3] cluster exchange timed out
+  __shared__ int s_ctrl[4];   // [1] failed solve: trial skipped, [2] ok2, [3] cluster exchange timed out
   __shared__ double s_hlast;  // Hll diagonal of the last landmark of this workgroup's chunk (last sweep)
   if (tid == 0) s_ctrl[3] = 0;
 #ifdef F2_PROFILE
@@ -392,12 +392,13 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
       F2Pre pre;
       pre.i = -1;
       {
-        double acc[27];
+        double acc[28];      // 27 Schur sums + [27] the landmark part of computeScale for the STALE x (what a failed solve leaves behind)
 #pragma unroll
-        for (int i = 0; i < 27; ++i) acc[i] = 0.0;
+        for (int i = 0; i < 28; ++i) acc[i] = 0.0;
         const double* __restrict__ Br = Bc; const double* __restrict__ hr = hc; const double* __restrict__ br = bc;
         for (int i = first; i < c_hi; i += stride) {
           const double bl0 = br[i], bl1 = br[N + i];
+          { const double xs0 = xl[i], xs1 = xl[N + i]; acc[27] += xs0 * (lambda * xs0 + bl0) + xs1 * (lambda * xs1 + bl1); }
           const double* B = Br + i;
           double Bv[12];
 #pragma unroll
@@ -437,9 +438,9 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
           }
         }
         F2_TICK(12);
-        block_reduce_bfly<27>(acc, s_wpart, s_red);
+        block_reduce_bfly<28>(acc, s_wpart, s_red);
         F2_TICK(13);
-        { double d_ = 0, e_ = 0; F2_CLUSTER_SUM(27, d_, e_); }
+        { double d_ = 0, e_ = 0; F2_CLUSTER_SUM(28, d_, e_); }
       }
       F2_TICK(0);
       // ---- (2) reduced 6x6 system, SE3 update, pose part of computeScale
@@ -471,15 +472,28 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
           for (int j = 0; j < 6; ++j) s_xp[j] = s_xs[j];
         }
         // (failed LDLT leaves x untouched in the reference; the trial is rejected anyway)
-        s_Ttry = se3_exp_compose(s_xp, s_T);
         double s = 0;
         for (int j = 0; j < 6; ++j) s += s_xp[j] * (lambda * s_xp[j] + s_Hc[21 + j]);
         s_rho = s;    // pose part of computeScale
+        // A failed solve rejects the trial whatever its errors are (tempChi = DBL_MAX) as long as computeScale - known here: the
+        // stale x against the current gradient - is positive, and everything the evaluation would leave behind (errors, chi2,
+        // the trial linearisation) is overwritten by the trial that follows: skip the SE3 update and the sweep.  Not for the
+        // last trial of an iteration (its errors are the ones classified).
+        bool skip = false;
+        if (!ok2 && qmax + 1 < 10) skip = (currentChi - 1.7976931348623157e308) / ((s + s_red[27]) + 1e-3) < 0;
+        s_ctrl[1] = skip ? 1 : 0;
+        if (!skip) s_Ttry = se3_exp_compose(s_xp, s_T);
         F2_TICK(7);
       }
       __syncthreads();
       F2_TICK(1);
       const bool ok2 = s_ctrl[2] != 0;
+      if (s_ctrl[1]) {
+        rho = (currentChi - 1.7976931348623157e308) / ((s_rho + s_red[27]) + 1e-3);
+        lambda *= ni; ni *= 2; built = false;
+        ++qmax; ++total_trials;
+        continue;
+      }
       // ---- (3) finish the solve per correspondence, errors + speculative linearisation at the trial point
       sweep(std::true_type{}, lambda, ok2, Bc, hc, bc, Bt, ht, bt, fcur, ftry, hb_cur, pre);
       { double d_ = 0; hb_try = s_hlast; F2_CLUSTER_SUM(29, d_, hb_try); }

@@ -524,10 +524,20 @@ extern "C" int vdo_object_chain(vdo_frame_images* cur, vdo_frame_images* last, i
 struct vdo_tracks {
   bool with_label = false;
   int n_frames = 0;
-  std::vector<int32_t> pre;                       // track id of every feature of the last added frame
-  std::vector<std::vector<int32_t>> frames, feats; // per track: (frame, feature) pairs
+  std::vector<int32_t> pre, cur;                  // track id of every feature of the last added frame (+ the buffer the next frame fills)
+  // (frame, feature) pairs of every track as singly linked chains in flat append-only pools: a frame adds a few thousand pairs,
+  // one small heap vector per track made that a few thousand allocations per frame
+  std::vector<int32_t> p_frame, p_feat, p_next;   // pools
+  std::vector<int32_t> first, last, len;          // per track
   std::vector<int32_t> obj_id;
   int64_t n_pairs = 0;
+  int add_pair(int id, int frame, int feat) {
+    const int k = (int)p_frame.size();
+    p_frame.push_back(frame); p_feat.push_back(feat); p_next.push_back(-1);
+    if (last[id] >= 0) p_next[last[id]] = k; else first[id] = k;
+    last[id] = k; len[id] += 1;
+    return k;
+  }
 };
 
 extern "C" int vdo_tracks_create(int with_object_label, vdo_tracks** out) {
@@ -543,18 +553,20 @@ extern "C" int vdo_tracks_destroy(vdo_tracks* t) { delete t; return VDO_OK; }
 extern "C" int vdo_tracks_add_frame(vdo_tracks* t, int n, const int32_t* asso, const int32_t* feat_label) {
   if (!t || n < 0 || (n > 0 && !asso) || (t->with_label && n > 0 && !feat_label)) return set_error(VDO_ERR_INVALID, "vdo_tracks_add_frame: bad argument");
   const int i = t->n_frames;
-  std::vector<int32_t> cur(n, -1);
+  std::vector<int32_t>& cur = t->cur;
+  cur.assign(n, -1);
   for (int j = 0; j < n; ++j) {
     const int a = asso[j];
     if (a == -1) continue;
     if (i > 0 && (a < 0 || a >= (int)t->pre.size())) return set_error(VDO_ERR_INVALID, "frame %d feature %d: association %d out of range", i, j, a);
     if (i > 0 && t->pre[a] != -1) {
       const int id = t->pre[a];
-      t->frames[id].push_back(i + 1); t->feats[id].push_back(j);
+      t->add_pair(id, i + 1, j);
       cur[j] = id; t->n_pairs += 1;
     } else {
-      const int id = (int)t->frames.size();
-      t->frames.push_back({i, i + 1}); t->feats.push_back({a, j});
+      const int id = (int)t->first.size();
+      t->first.push_back(-1); t->last.push_back(-1); t->len.push_back(0);
+      t->add_pair(id, i, a); t->add_pair(id, i + 1, j);
       if (t->with_label) t->obj_id.push_back(feat_label[j]);
       cur[j] = id; t->n_pairs += 2;
     }
@@ -566,7 +578,7 @@ extern "C" int vdo_tracks_add_frame(vdo_tracks* t, int n, const int32_t* asso, c
 
 extern "C" int vdo_tracks_size(vdo_tracks* t, int* n_tracks, int64_t* n_pairs) {
   if (!t) return set_error(VDO_ERR_INVALID, "null handle");
-  if (n_tracks) *n_tracks = (int)t->frames.size();
+  if (n_tracks) *n_tracks = (int)t->first.size();
   if (n_pairs) *n_pairs = t->n_pairs;
   return VDO_OK;
 }
@@ -575,11 +587,8 @@ extern "C" int vdo_tracks_get(vdo_tracks* t, int32_t* track_off, int32_t* pair_f
   if (!t || !track_off || !pair_frame || !pair_feat) return set_error(VDO_ERR_INVALID, "null argument");
   int off = 0;
   track_off[0] = 0;
-  for (size_t k = 0; k < t->frames.size(); ++k) {
-    const size_t len = t->frames[k].size();
-    std::memcpy(pair_frame + off, t->frames[k].data(), 4 * len);
-    std::memcpy(pair_feat + off, t->feats[k].data(), 4 * len);
-    off += (int)len;
+  for (size_t k = 0; k < t->first.size(); ++k) {
+    for (int q = t->first[k]; q >= 0; q = t->p_next[q]) { pair_frame[off] = t->p_frame[q]; pair_feat[off] = t->p_feat[q]; ++off; }
     track_off[k + 1] = off;
     if (obj_id && t->with_label) obj_id[k] = t->obj_id[k];
   }

@@ -87,12 +87,14 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
     if (vdo_flow2_batch_reserve(ctx_obj_, obj_slots_, ocap.data(), &lm_obj_) != VDO_OK) return;
   }
   if (ctx_worker) worker_.reset(new Worker());
+  if (ctx_worker && ctx_orb) worker_orb_.reset(new Worker());
   orb_split_ = ctx_orb != nullptr;
   ok_ = true;
 }
 
 FramePipeline::~FramePipeline() {
   if (worker_) { worker_->wait(); worker_.reset(); }
+  if (worker_orb_) { worker_orb_->wait(); worker_orb_.reset(); }
   if (orb_) vdo_orb_destroy(orb_);
   for (int k = 0; k < 2; ++k) if (img_[k]) vdo_frame_images_destroy(img_[k]);
   if (tr_sta_) vdo_tracks_destroy(tr_sta_);
@@ -125,7 +127,29 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   struct Join { Worker* w; ~Join() { if (w) w->wait(); } } join_guard{worker_.get()};      // never leave Step with the helper thread on its locals
   // ---- ORB (K3-K7) needs only the grey image: with a stream of its own its device stage starts now, under the camera stage
   vdo_keypoints kp{(int32_t)kx_.size(), 0, kx_.data(), ky_.data(), kr_.data(), ka_.data(), ks_.data(), ko_.data()};
-  if (orb_split_ && !p_.use_sample_feature) VDO_TRY(vdo_orb_extract_begin(orb_, d_gray, W, host_inputs_ ? 0 : 1));
+  // (with a thread of its own the whole extraction - device stage, quadtrees, angles - leaves the main thread: nothing before the
+  // static stage reads a keypoint)
+  Join join_orb{nullptr};                                // declared after kp: joined before kp goes away on every path out of Step
+  bool orb_pending = false;
+  if (worker_orb_ && !p_.use_sample_feature) {
+    worker_orb_->run([this, &kp, d_gray, W]() -> int {
+      const auto t0 = std::chrono::steady_clock::now();
+      const int rc = vdo_orb_extract(orb_, d_gray, W, host_inputs_ ? 0 : 1, &kp);
+      ms_[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+      if (rc != VDO_OK) { std::fprintf(stderr, "FramePipeline: %s\n", vdo_last_error()); return -1; }
+      return 0;
+    });
+    join_orb.w = worker_orb_.get();
+    orb_pending = true;
+  } else if (orb_split_ && !p_.use_sample_feature) VDO_TRY(vdo_orb_extract_begin(orb_, d_gray, W, host_inputs_ ? 0 : 1));
+  // the keypoints of this frame are ready (called by whoever reads them first: the static stage)
+  auto orb_join = [&]() -> int {
+    if (!orb_pending) return 0;
+    orb_pending = false;
+    const int rc = worker_orb_->wait();
+    fc.n_orb = kp.n;
+    return rc;
+  };
   // ---- deferred mode: the object stage of the PREVIOUS frame ends during this frame's camera stage + ORB front-end (nothing
   // there depends on the object set) - on the helper thread if there is one, else right after ORB on this thread
   bool fin_async = false;
@@ -202,15 +226,22 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     int ns = 0;
     VDO_TRY(vdo_sample_keypoints(H, W, (uint64_t)(p_.sample_seed + f_id_), kp.capacity, kx_.data(), ky_.data(), &ns));
     kp.n = ns;
-  } else if (orb_split_) VDO_TRY(vdo_orb_extract_end(orb_, &kp));
-  else VDO_TRY(vdo_orb_extract(orb_, d_gray, W, host_inputs_ ? 0 : 1, &kp));
-  fc.n_orb = kp.n;
-  tick(1);
+    fc.n_orb = kp.n;
+    tick(1);
+  } else if (orb_pending) {
+    // (on its own thread)
+  } else {
+    if (orb_split_) VDO_TRY(vdo_orb_extract_end(orb_, &kp));
+    else VDO_TRY(vdo_orb_extract(orb_, d_gray, W, host_inputs_ ? 0 : 1, &kp));
+    fc.n_orb = kp.n;
+    tick(1);
+  }
   // K9 + K10 of the new image: only RenewFrameInfo needs them, so they run while the object LMs are in flight
   int n_new_s = 0, n_tmp = 0;
   std::vector<int32_t>& keep = i_[1];
   ObjSet& tmp = tmp_;                                   // K10: semi-dense sampling of this image (mvTmpObj*)
   auto frame_filters = [&]() -> int {
+    if (orb_join() != 0) return -1;
     keep.resize(std::max(kp.n, 1));
     for (int k = 2; k < 7; ++k) f_[k].resize(std::max(kp.n, 1));
     VDO_TRY((p_.use_sample_feature ? vdo_frame_static_filter_sampled : vdo_frame_static_filter)(cur, kp.n, kx_.data(), ky_.data(), p_.th_depth_bg, keep.data(), f_[2].data(), f_[3].data(),
@@ -255,12 +286,19 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   }
   tick(3);
   // ---- the object set of the last frame: wait for its object stage (its tail - tracklets, Map - goes on behind)
-  bool tail_async = false;
+  bool tail_async = false, tail_on_orb = false;
   if (fin_async) {
     const int rc = worker_->wait();
     vdo_frame_images_set_ctx(last, ctx_);
     if (rc != 0) return -1;
-    if (tail_pending_) { worker_->run([this, &fc] { return FinishObjectsTail(&fc); }); tail_async = true; }
+    if (tail_pending_ && worker_orb_) {
+      // the ORB thread is free by now (the camera stage it ran under is over): it takes the tail, the helper thread goes straight to the static stage
+      if (orb_join() != 0) return -1;
+      tail_done_.store(false, std::memory_order_relaxed);
+      worker_orb_->run([this, &fc] { const int rc = FinishObjectsTail(&fc); tail_done_.store(true, std::memory_order_release); return rc; });
+      join_orb.w = worker_orb_.get();
+      tail_async = true; tail_on_orb = true;
+    } else if (tail_pending_) { worker_->run([this, &fc] { return FinishObjectsTail(&fc); }); tail_async = true; }
   } else if (pending_) {
     if (FinishObjects(&fc) != 0) return -1;
   }
@@ -311,13 +349,14 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     nsta.xyz.resize(3 * (size_t)std::max(m, 1));
     VDO_TRY(vdo_get3d_world(ctx_f, m, nsta.x.data(), nsta.y.data(), nsta.d.data(), p_.K4, Twc, nsta.xyz.data()));     // mvStat3DPointTmp
     // ---- static tracklets (incremental GetStaticTrack)                             Tracking.cc:2201-2300
+    while (!tail_done_.load(std::memory_order_acquire)) std::this_thread::yield();      // (the tail of the last frame may be reading the static tracklets: windowed batch optimisation)
     VDO_TRY(vdo_tracks_add_frame(tr_sta_, m, sta_asso.data(), nullptr));
     tk(5);
     return 0;
   };
   // (declared after every local stage_static touches: on an early return this wait runs BEFORE those locals are destroyed)
   Join join_static{worker_.get()};
-  if (tail_async && worker_->wait() != 0) return -1;
+  if (tail_async && !tail_on_orb && worker_->wait() != 0) return -1;
   bool static_async = false;
   if (have_last_ && worker_) {
     vdo_frame_images_set_ctx(cur, ctx_w_);
@@ -420,6 +459,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
       vdo_frame_images_set_ctx(cur, ctx_);
       if (rc != 0) return -1;
     } else if (stage_static() != 0) return -1;
+    if (tail_on_orb && worker_orb_->wait() != 0) return -1;
     t_prev = std::chrono::steady_clock::now();
     // the object stage (results of the LMs, RenewFrameInfo of the objects, dynamic tracklets) ends in FinishObjects():
     // right below, or - deferred mode - inside the next Step, after that frame's camera stage and ORB front-end

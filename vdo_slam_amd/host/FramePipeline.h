@@ -16,6 +16,7 @@
 #include <cstdint>
 #include <functional>
 #include <memory>
+#include <atomic>
 #include <vector>
 
 #include "../../include/vdo_slam_hip.h"
@@ -55,8 +56,10 @@ class FramePipeline {
   // ctx_worker (optional): a second HOST thread runs the stages that are independent of what the main thread is doing - the object
   // stage of the previous frame (deferred mode) next to this frame's camera stage + ORB, and K9/K10 + RenewFrameInfo (static) next
   // to the scene-flow / object-tracking / object-RANSAC chain - with this context (its own stream and scratch arena).
-  // ctx_orb (optional): the ORB extractor gets this context (a stream of its own): its device stage is queued at the very start
-  // of Step() (vdo_orb_extract_begin) and runs under the camera stage; the quadtrees follow where ORB used to be (vdo_orb_extract_end).
+  // ctx_orb (optional): the ORB extractor gets this context (a stream of its own).  With ctx_worker as well, ORB (K3-K7: only the
+  // grey image goes in, only RenewFrameInfo / the static filter read what comes out) runs on a THIRD host thread from the start of
+  // Step() to the static stage; without ctx_worker its device stage is queued at the very start of Step()
+  // (vdo_orb_extract_begin) and the quadtrees follow where ORB used to be (vdo_orb_extract_end).
   FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams& p, vdo_ctx* ctx_obj = nullptr, vdo_ctx* ctx_worker = nullptr, vdo_ctx* ctx_orb = nullptr);
   ~FramePipeline();
   // One frame.  d_* are DEVICE pointers of the raw inputs (gray u8, disparity*factor f32, flow 2xf32, mask i32).
@@ -114,6 +117,8 @@ class FramePipeline {
   float cam_motion_[16];              // Converter::toInvMatrix(mVelocity) of the frame whose object stage is pending
   class Worker;
   std::unique_ptr<Worker> worker_;
+  std::unique_ptr<Worker> worker_orb_;    // ORB of the current frame, then the tail of the last frame's object stage (ctx_orb + ctx_worker)
+  std::atomic<bool> tail_done_{true};
   bool orb_split_ = false;
   vdo_ctx *ctx_, *ctx_lm_, *ctx_obj_, *ctx_w_;
   // object stage handed from Step() to FinishObjects()

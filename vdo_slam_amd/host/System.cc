@@ -66,16 +66,16 @@ Tracking::Tracking(System*, Map* pMap, const std::string& strSettingPath, const 
   mState = NO_IMAGES_YET;
   if (p.width <= 0 || p.height <= 0) { std::cerr << "settings: Camera.width / Camera.height missing" << std::endl; std::exit(-1); }
   const char* dev = std::getenv("VDO_DEVICE");
-  for (int k = 0; k < 4; ++k)
+  for (int k = 0; k < 5; ++k)
     if (vdo_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx_[k]) != VDO_OK) { std::cerr << "no HIP device: " << vdo_last_error() << std::endl; std::exit(-1); }
-  pipe_.reset(new FramePipeline(ctx_[0], ctx_[1], p, ctx_[2], ctx_[3]));
+  pipe_.reset(new FramePipeline(ctx_[0], ctx_[1], p, ctx_[2], ctx_[3], ctx_[4]));
   if (!pipe_->ok()) { std::cerr << "FramePipeline: " << vdo_last_error() << std::endl; std::exit(-1); }
   pipe_->AttachMap(mpMap);
 }
 
 Tracking::~Tracking() {
   pipe_.reset();
-  for (int k = 0; k < 4; ++k) if (ctx_[k]) vdo_ctx_destroy(ctx_[k]);
+  for (int k = 0; k < 5; ++k) if (ctx_[k]) vdo_ctx_destroy(ctx_[k]);
 }
 
 cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Mat& imFlow, const cv::Mat& maskSEM, const cv::Mat&,

@@ -46,7 +46,7 @@ class Tracking {
   Map* mpMap;
   std::map<std::string, double> cfg_;
   bool mbRGB = true;
-  vdo_ctx* ctx_[4] = {nullptr, nullptr, nullptr, nullptr};
+  vdo_ctx* ctx_[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // front-end / camera LM / object LMs / helper thread / ORB thread
   std::unique_ptr<FramePipeline> pipe_;
   std::vector<uint8_t> gray_;
   bool have_frame_ = false;
