@@ -384,6 +384,12 @@ int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm_sta, const
                      int n_orb, const float* orb_x, const float* orb_y, int max_num_sta,
                      float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y,
                      int32_t* inlier_id, float* depth_out, int* n_out);
+/* The same + Optimizer::Get3DinWorld of the new set (mvStat3DPointTmp, src/Tracking.cc:2784-2790) in one pass over the device
+ * (one synchronisation): xyz_out [3 * (max_num_sta + 1)], nullable (K4 / Twc unused then). */
+int vdo_renew_static_world(vdo_frame_images* f, int n_tm, const int32_t* tm_sta, const float* stat_x, const float* stat_y,
+                           int n_orb, const float* orb_x, const float* orb_y, int max_num_sta, const float K4[4], const float Twc[16],
+                           float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y,
+                           int32_t* inlier_id, float* depth_out, float* xyz_out, int* n_out);
 /* Tracking::UpdateMask (src/Tracking.cc:3015-3065): labels of this frame's mask at n positions
  * (-1 outside), and the warp of label `label` from `last`'s mask into `cur`'s mask by `last`'s flow. */
 int vdo_mask_at(vdo_frame_images* f, int n, const float* cx, const float* cy, int32_t* label_out);
@@ -430,6 +436,16 @@ int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* inl_off, con
                      int max_num_obj, int cap,
                      float* key_x, float* key_y, float* depth_out, int32_t* sem_out, float* flow_x, float* flow_y,
                      float* corr_x, float* corr_y, int32_t* dyn_inlier_id, int32_t* obj_label_out, int* n_out);
+/* The same + the 3-D points of the new set (mvObj3DPoint, src/Tracking.cc:2981-2990) in one pass over the device (one
+ * synchronisation): xyz_out [3 * cap], nullable (K4 / Twc unused then). */
+int vdo_renew_object_world(vdo_frame_images* f, int n_obj, const int32_t* inl_off, const int32_t* inl_idx, const uint8_t* obj_stat,
+                           const int32_t* sem_pos, const int32_t* mod_label,
+                           const float* cur_x, const float* cur_y, const int32_t* cur_obj_label,
+                           int n_tmp, const float* tmp_x, const float* tmp_y, const float* tmp_depth, const int32_t* tmp_label,
+                           const float* tmp_flow_x, const float* tmp_flow_y, const float* tmp_corr_x, const float* tmp_corr_y,
+                           int max_num_obj, int cap, const float K4[4], const float Twc[16],
+                           float* key_x, float* key_y, float* depth_out, int32_t* sem_out, float* flow_x, float* flow_y,
+                           float* corr_x, float* corr_y, int32_t* dyn_inlier_id, int32_t* obj_label_out, float* xyz_out, int* n_out);
 
 /* Tracking::UpdateMask (src/Tracking.cc:2997-3068) in one stream-ordered sequence without host round
  * trips: per last-frame semantic label (ascending) the labels of `cur`'s mask at the flowed positions

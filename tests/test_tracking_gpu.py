@@ -70,6 +70,13 @@ def test_renew_static(ctx, oracle, case):
     exp = T.renew_static(oracle, tm, sx, sy, ox, oy, fr["mask"], depth, fr["flow"], max_num)
     for k in exp:
         assert np.array_equal(got[k], exp[k]), k
+    # the one-pass form with the 3-D points: same set, xyz = K12 of its keys (bit for bit)
+    K4 = np.array(KITTI_K, np.float32)
+    Twc = np.eye(4, dtype=np.float32); Twc[:3, 3] = (0.3, -0.1, 2.0); Twc[0, 1], Twc[1, 0] = -0.02, 0.02
+    got3 = TR.renew_static(im, tm, sx, sy, ox, oy, max_num, world=(K4, Twc))
+    for k in exp:
+        assert np.array_equal(got3[k], exp[k]), k
+    assert np.array_equal(got3["xyz"], TR.get3d_world(ctx, got3["key_x"], got3["key_y"], got3["depth"], K4, Twc))
 
 
 def _object_case(oracle, seed):
@@ -108,6 +115,12 @@ def test_renew_object(ctx, oracle, seed, max_num):
     assert (exp["obj_label"] == -2).sum() > 0 and (exp["inlier_id"] >= 0).sum() > 0
     if max_num >= 800:                       # with the small cap the carried points already fill the objects: no top-up
         assert ((exp["inlier_id"] == -1) & (exp["obj_label"] > 0)).sum() > 0
+    K4 = np.array(KITTI_K, np.float32)
+    Twc = np.eye(4, dtype=np.float32); Twc[:3, 3] = (0.3, -0.1, 2.0); Twc[0, 1], Twc[1, 0] = -0.02, 0.02
+    got3 = TR.renew_object(im, inl, stat, sem_pos, mod, cx, cy, col, tmp, max_num, world=(K4, Twc))
+    for k in exp:
+        assert np.array_equal(got3[k], exp[k]), k
+    assert np.array_equal(got3["xyz"], TR.get3d_world(ctx, got3["key_x"], got3["key_y"], got3["depth"], K4, Twc))
 
 
 def test_update_mask_recovers_a_dropped_mask(ctx, oracle):

@@ -47,18 +47,6 @@ __global__ void k_gather(int mode, int n, const float* __restrict__ kx, const fl
 }
 
 
-// cv::gemm semantics for small float matrices: accumulate in double, round once
-__device__ __forceinline__ void gemm3_dev(const float* A, const float* v, float* o) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i) o[i] = (float)((double)A[3 * i] * v[0] + (double)A[3 * i + 1] * v[1] + (double)A[3 * i + 2] * v[2]);
-}
-__device__ __forceinline__ void backproject(const Cam& c, float u, float v, float z, float* out) {
-  const float xc[3] = {(u - c.cx) * z * c.invfx, (v - c.cy) * z * c.invfy, z};
-  float r[3];
-  gemm3_dev(c.R, xc, r);
-  out[0] = r[0] + c.t[0]; out[1] = r[1] + c.t[1]; out[2] = r[2] + c.t[2];
-}
-
 __global__ void k_get3d_world(int n, const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ d, Cam c, float* __restrict__ xyz) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -98,6 +86,30 @@ __global__ void k_renew_pred(int n, const float* __restrict__ px, const float* _
     }
   }
   ok[i] = good; fx[i] = fxe; fy[i] = fye; dout[i] = d;
+}
+
+// carried[i] = ok[i] && (number of ok before i) <= max_keep: the first-come truncation of the carry-over loop ("stop once the
+// size exceeds the limit", Tracking.cc:2703-2709) as a selection mask.  Single workgroup, chunks in input order.
+__global__ __launch_bounds__(1024) void k_carry_select(int n, const int32_t* __restrict__ ok, int max_keep, int32_t* __restrict__ sel) {
+  __shared__ int lds[17];
+  int carry = 0;
+  for (int base = 0; base < n; base += 1024) {
+    const int i = base + threadIdx.x;
+    const int v = (i < n && ok[i]) ? 1 : 0;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int incl = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const int t = __shfl_up(incl, off, 64); if (lane >= off) incl += t; }
+    __syncthreads();
+    if (lane == 63) lds[wv] = incl;
+    __syncthreads();
+    if (threadIdx.x == 0) { int a = 0; for (int q = 0; q < 16; ++q) { const int t = lds[q]; lds[q] = a; a += t; } lds[16] = a; }
+    __syncthreads();
+    const int rank = carry + lds[wv] + incl - v;
+    if (i < n) sel[i] = (v && rank <= max_keep) ? 1 : 0;
+    carry += lds[16];
+    __syncthreads();
+  }
 }
 
 // K15b: every pixel of the previous mask with label `lab` writes `lab` at its flowed position
@@ -225,32 +237,48 @@ extern "C" int vdo_scene_flow(vdo_ctx* ctx, int n, const float* cur_x, const flo
 
 // K14, static part.  Same contract as Tracking::RenewFrameInfo :2666-2790 (see the oracle for the
 // sequential statement).  GPU: predicates + O(n*m) distance flags; host: order-dependent selection.
-extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm_sta, const float* stat_x, const float* stat_y,
-                                int n_orb, const float* orb_x, const float* orb_y, int max_num_sta,
-                                float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y,
-                                int32_t* inlier_id, float* depth_out, int* n_out) {
-  if (!f || !n_out || n_tm < 0 || n_orb < 0) return set_error(VDO_ERR_INVALID, "bad argument");
+// RenewFrameInfo (static) + Get3DinWorld of the new set in ONE pass over the device: both candidate lists (carried inliers,
+// top-up keypoints) are judged, the carry-over truncation is a device-side selection, the "within 1 px of a carried key"
+// test runs against that selection, every candidate is back-projected - one copy back, one synchronisation; the
+// ORDER-dependent part (first-come, stride-20 interleave) stays on the host.  xyz_out may be NULL (K4 / Twc unused then).
+extern "C" int vdo_renew_static_world(vdo_frame_images* f, int n_tm, const int32_t* tm_sta, const float* stat_x, const float* stat_y,
+                                      int n_orb, const float* orb_x, const float* orb_y, int max_num_sta, const float K4[4], const float Twc[16],
+                                      float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y,
+                                      int32_t* inlier_id, float* depth_out, float* xyz_out, int* n_out) {
+  if (!f || !n_out || n_tm < 0 || n_orb < 0 || (xyz_out && (!K4 || !Twc))) return set_error(VDO_ERR_INVALID, "bad argument");
   int rc = ctx_bind(f->ctx);
   if (rc != VDO_OK) return rc;
   Arena S(f->ctx);
-  if (!S.reserve(Arena::bytes_for(16 * ((size_t)n_tm + (size_t)n_orb) + 4 * (size_t)max_num_sta))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
+  if (!S.reserve(Arena::bytes_for(24 * ((size_t)n_tm + (size_t)n_orb) + 4 * (size_t)max_num_sta))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   // phase 1 candidates: the inlier static keys, in TM_sta order
   std::vector<float> cx1, cy1; std::vector<int32_t> id1;
   for (int i = 0; i < n_tm; ++i) if (tm_sta[i] != -1) { cx1.push_back(stat_x[tm_sta[i]]); cy1.push_back(stat_y[tm_sta[i]]); id1.push_back(tm_sta[i]); }
   const int n1 = (int)cx1.size();
-  std::vector<int32_t> ok1(n1), ok2(n_orb), used2(n_orb);
-  std::vector<float> fx1(n1), fy1(n1), d1(n1), fx2(n_orb), fy2(n_orb), d2(n_orb);
+  std::vector<int32_t> ok1(n1), ok2(n_orb), used2(n_orb, 0);
+  std::vector<float> fx1(n1), fy1(n1), d1(n1), fx2(n_orb), fy2(n_orb), d2(n_orb), xyz1(xyz_out ? 3 * (size_t)n1 : 0), xyz2(xyz_out ? 3 * (size_t)n_orb : 0);
   float *dx1 = S.up(cx1.data(), n1), *dy1 = S.up(cy1.data(), n1);
-  int32_t* dok1 = S.up<int32_t>(nullptr, n1);
-  float *dfx1 = S.up<float>(nullptr, n1), *dfy1 = S.up<float>(nullptr, n1), *dd1 = S.up<float>(nullptr, n1);
-  if (n1) hipLaunchKernelGGL(k_renew_pred, dim3((n1 + 255) / 256), dim3(256), 0, S.stream(), n1, (const float*)dx1, (const float*)dy1, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok1, dfx1, dfy1, dd1);
   float *dx2 = S.up(orb_x, n_orb), *dy2 = S.up(orb_y, n_orb);
+  int32_t *dok1 = S.up<int32_t>(nullptr, n1), *dsel1 = S.up<int32_t>(nullptr, n1);
+  float *dfx1 = S.up<float>(nullptr, n1), *dfy1 = S.up<float>(nullptr, n1), *dd1 = S.up<float>(nullptr, n1), *dxyz1 = S.up<float>(nullptr, xyz_out ? 3 * (size_t)n1 : 0);
   int32_t *dok2 = S.up<int32_t>(nullptr, n_orb), *dused = S.up<int32_t>(nullptr, n_orb);
-  float *dfx2 = S.up<float>(nullptr, n_orb), *dfy2 = S.up<float>(nullptr, n_orb), *dd2 = S.up<float>(nullptr, n_orb);
-  if (!dd2 || !dd1) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-  if (n_orb) hipLaunchKernelGGL(k_renew_pred, dim3((n_orb + 255) / 256), dim3(256), 0, S.stream(), n_orb, (const float*)dx2, (const float*)dy2, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok2, dfx2, dfy2, dd2);
+  float *dfx2 = S.up<float>(nullptr, n_orb), *dfy2 = S.up<float>(nullptr, n_orb), *dd2 = S.up<float>(nullptr, n_orb), *dxyz2 = S.up<float>(nullptr, xyz_out ? 3 * (size_t)n_orb : 0);
+  if (!dxyz2 || !dxyz1 || !dd2 || !dd1) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
+  hipStream_t s = S.stream();
+  const Cam cam = xyz_out ? make_cam_Twc(K4, Twc) : Cam{};
+  if (n1) {
+    hipLaunchKernelGGL(k_renew_pred, dim3((n1 + 255) / 256), dim3(256), 0, s, n1, (const float*)dx1, (const float*)dy1, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok1, dfx1, dfy1, dd1);
+    hipLaunchKernelGGL(k_carry_select, dim3(1), dim3(1024), 0, s, n1, (const int32_t*)dok1, max_num_sta, dsel1);
+    if (xyz_out) hipLaunchKernelGGL(k_backproject_pts, dim3((n1 + 255) / 256), dim3(256), 0, s, n1, (const float*)dx1, (const float*)dy1, (const float*)dd1, cam, 0, dxyz1);
+  }
+  if (n_orb) {
+    hipLaunchKernelGGL(k_renew_pred, dim3((n_orb + 255) / 256), dim3(256), 0, s, n_orb, (const float*)dx2, (const float*)dy2, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok2, dfx2, dfy2, dd2);
+    launch_near_flags_sel(s, n_orb, dx2, dy2, n1, dx1, dy1, dsel1, 0, dused);
+    if (xyz_out) hipLaunchKernelGGL(k_backproject_pts, dim3((n_orb + 255) / 256), dim3(256), 0, s, n_orb, (const float*)dx2, (const float*)dy2, (const float*)dd2, cam, 0, dxyz2);
+  }
   S.down(ok1.data(), dok1, n1); S.down(fx1.data(), dfx1, n1); S.down(fy1.data(), dfy1, n1); S.down(d1.data(), dd1, n1);
-  rc = S.finish("vdo_renew_static (carry)");
+  S.down(used2.data(), dused, n_orb); S.down(ok2.data(), dok2, n_orb); S.down(fx2.data(), dfx2, n_orb); S.down(fy2.data(), dfy2, n_orb); S.down(d2.data(), dd2, n_orb);
+  if (xyz_out) { S.down(xyz1.data(), dxyz1, 3 * (size_t)n1); S.down(xyz2.data(), dxyz2, 3 * (size_t)n_orb); }
+  rc = S.finish("vdo_renew_static");
   if (rc != VDO_OK) return rc;
   // carry-over: first-come, stop once size > max (the reference checks after every element, :2703-2709)
   int m = 0;
@@ -258,17 +286,12 @@ extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm
     if (ok1[i]) {
       key_x[m] = cx1[i]; key_y[m] = cy1[i]; corr_x[m] = cx1[i] + fx1[i]; corr_y[m] = cy1[i] + fy1[i];
       flow_x[m] = fx1[i]; flow_y[m] = fy1[i]; inlier_id[m] = id1[i]; depth_out[m] = d1[i];
+      if (xyz_out) { xyz_out[3 * m] = xyz1[3 * i]; xyz_out[3 * m + 1] = xyz1[3 * i + 1]; xyz_out[3 * m + 2] = xyz1[3 * i + 2]; }
       ++m;
     }
     if (m > max_num_sta) break;
   }
-  const int n_check = m;
   if (m < max_num_sta && n_orb) {
-    float *dcx = S.up(key_x, n_check), *dcy = S.up(key_y, n_check);
-    launch_near_flags(S.stream(), n_orb, dx2, dy2, n_check, dcx, dcy, dused);
-    S.down(used2.data(), dused, n_orb); S.down(ok2.data(), dok2, n_orb); S.down(fx2.data(), dfx2, n_orb); S.down(fy2.data(), dfy2, n_orb); S.down(d2.data(), dd2, n_orb);
-    rc = S.finish("vdo_renew_static (top-up)");
-    if (rc != VDO_OK) return rc;
     int tot = m, start_id = 0;
     const int step = 20;
     while (tot < max_num_sta) {                       // stride-20 interleave (:2722-2778)
@@ -278,6 +301,7 @@ extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm
         if (ok2[i]) {
           key_x[m] = orb_x[i]; key_y[m] = orb_y[i]; corr_x[m] = orb_x[i] + fx2[i]; corr_y[m] = orb_y[i] + fy2[i];
           flow_x[m] = fx2[i]; flow_y[m] = fy2[i]; inlier_id[m] = -1; depth_out[m] = d2[i];
+          if (xyz_out) { xyz_out[3 * m] = xyz2[3 * i]; xyz_out[3 * m + 1] = xyz2[3 * i + 1]; xyz_out[3 * m + 2] = xyz2[3 * i + 2]; }
           ++m; ++tot;
         }
         if (tot >= max_num_sta) break;
@@ -287,4 +311,12 @@ extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm
   }
   *n_out = m;
   return VDO_OK;
+}
+
+extern "C" int vdo_renew_static(vdo_frame_images* f, int n_tm, const int32_t* tm_sta, const float* stat_x, const float* stat_y,
+                                int n_orb, const float* orb_x, const float* orb_y, int max_num_sta,
+                                float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y,
+                                int32_t* inlier_id, float* depth_out, int* n_out) {
+  return vdo_renew_static_world(f, n_tm, tm_sta, stat_x, stat_y, n_orb, orb_x, orb_y, max_num_sta, nullptr, nullptr,
+                                key_x, key_y, corr_x, corr_y, flow_x, flow_y, inlier_id, depth_out, nullptr, n_out);
 }

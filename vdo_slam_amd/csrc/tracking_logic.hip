@@ -330,19 +330,22 @@ extern "C" int vdo_dyn_obj_tracking(const vdo_dyn_obj_params* prm, int n, const 
   return VDO_OK;
 }
 
-extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* inl_off, const int32_t* inl_idx, const uint8_t* obj_stat,
-                                const int32_t* sem_pos, const int32_t* mod_label,
-                                const float* cur_x, const float* cur_y, const int32_t* cur_obj_label,
-                                int n_tmp, const float* tmp_x, const float* tmp_y, const float* tmp_depth, const int32_t* tmp_label,
-                                const float* tmp_flow_x, const float* tmp_flow_y, const float* tmp_corr_x, const float* tmp_corr_y,
-                                int max_num_obj, int cap,
-                                float* key_x, float* key_y, float* depth_out, int32_t* sem_out, float* flow_x, float* flow_y,
-                                float* corr_x, float* corr_y, int32_t* dyn_inlier_id, int32_t* obj_label_out, int* n_out) {
-  if (!f || !n_out || n_obj < 0 || n_tmp < 0 || cap < 0) return set_error(VDO_ERR_INVALID, "vdo_renew_object: bad argument");
+// RenewFrameInfo (objects) + the 3-D points of the new set (mvObj3DPoint) in ONE pass over the device: the carried candidates
+// are judged, the "within 1 px of a carried key" test of the sampled points runs against the device-side verdicts, carried
+// and sampled points are all back-projected - one copy back, one synchronisation.  xyz_out may be NULL (K4 / Twc unused then).
+extern "C" int vdo_renew_object_world(vdo_frame_images* f, int n_obj, const int32_t* inl_off, const int32_t* inl_idx, const uint8_t* obj_stat,
+                                      const int32_t* sem_pos, const int32_t* mod_label,
+                                      const float* cur_x, const float* cur_y, const int32_t* cur_obj_label,
+                                      int n_tmp, const float* tmp_x, const float* tmp_y, const float* tmp_depth, const int32_t* tmp_label,
+                                      const float* tmp_flow_x, const float* tmp_flow_y, const float* tmp_corr_x, const float* tmp_corr_y,
+                                      int max_num_obj, int cap, const float K4[4], const float Twc[16],
+                                      float* key_x, float* key_y, float* depth_out, int32_t* sem_out, float* flow_x, float* flow_y,
+                                      float* corr_x, float* corr_y, int32_t* dyn_inlier_id, int32_t* obj_label_out, float* xyz_out, int* n_out) {
+  if (!f || !n_out || n_obj < 0 || n_tmp < 0 || cap < 0 || (xyz_out && (!K4 || !Twc))) return set_error(VDO_ERR_INVALID, "vdo_renew_object: bad argument");
   int rc = ctx_bind(f->ctx);
   if (rc != VDO_OK) return rc;
   Arena S(f->ctx);
-  if (!S.reserve(Arena::bytes_for(16 * ((size_t)(n_obj ? inl_off[n_obj] : 0) + (size_t)n_tmp + 64)))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
+  if (!S.reserve(Arena::bytes_for(24 * ((size_t)(n_obj ? inl_off[n_obj] : 0) + (size_t)n_tmp + 64)))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   // ---- carried candidates: inliers of the tracked objects, object-major (the reference's visiting order)
   std::vector<float> cx, cy; std::vector<int32_t> cid, cobj;
   for (int i = 0; i < n_obj; ++i) {
@@ -351,22 +354,39 @@ extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* i
   }
   const int nc = (int)cx.size();
   std::vector<int32_t> ok(nc), sem(nc); std::vector<float> dd(nc), fx(nc), fy(nc);
-  if (nc) {
+  std::vector<int32_t> used(n_tmp, 0);
+  std::vector<float> xyz_c(xyz_out ? 3 * (size_t)nc : 0), xyz_t(xyz_out ? 3 * (size_t)n_tmp : 0);
+  if (nc || (n_tmp && xyz_out)) {
     float *dx = S.up(cx.data(), nc), *dy = S.up(cy.data(), nc);
+    float *dqx = S.up(tmp_x, n_tmp), *dqy = S.up(tmp_y, n_tmp), *dqd = S.up(xyz_out ? tmp_depth : nullptr, xyz_out ? n_tmp : 0);
     int32_t *dok = S.up<int32_t>(nullptr, nc), *dsem = S.up<int32_t>(nullptr, nc);
     float *ddd = S.up<float>(nullptr, nc), *dfx = S.up<float>(nullptr, nc), *dfy = S.up<float>(nullptr, nc);
-    if (!dfy) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-    hipLaunchKernelGGL(k_renew_obj_pred, dim3((nc + 255) / 256), dim3(256), 0, S.stream(), nc, (const float*)dx, (const float*)dy, (const int32_t*)f->d_mask,
-                       (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok, dsem, ddd, dfx, dfy);
+    int32_t* dused = S.up<int32_t>(nullptr, n_tmp);
+    float *dxc = S.up<float>(nullptr, xyz_out ? 3 * (size_t)nc : 0), *dxt = S.up<float>(nullptr, xyz_out ? 3 * (size_t)n_tmp : 0);
+    if (!dxt || !dxc || !dused || !dfy) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
+    hipStream_t st = S.stream();
+    const Cam cam = xyz_out ? make_cam_Twc(K4, Twc) : Cam{};
+    if (nc) {
+      hipLaunchKernelGGL(k_renew_obj_pred, dim3((nc + 255) / 256), dim3(256), 0, st, nc, (const float*)dx, (const float*)dy, (const int32_t*)f->d_mask,
+                         (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok, dsem, ddd, dfx, dfy);
+      // top-up from the semi-dense sampling of the new image: "is a carried point within 1 px" against the verdicts above
+      if (n_tmp) launch_near_flags_sel(st, n_tmp, dqx, dqy, nc, dx, dy, dok, 1, dused);
+      if (xyz_out) hipLaunchKernelGGL(k_backproject_pts, dim3((nc + 255) / 256), dim3(256), 0, st, nc, (const float*)dx, (const float*)dy, (const float*)ddd, cam, 1, dxc);
+    }
+    if (n_tmp && xyz_out) hipLaunchKernelGGL(k_backproject_pts, dim3((n_tmp + 255) / 256), dim3(256), 0, st, n_tmp, (const float*)dqx, (const float*)dqy, (const float*)dqd, cam, 0, dxt);
     S.down(ok.data(), dok, nc); S.down(sem.data(), dsem, nc); S.down(dd.data(), ddd, nc); S.down(fx.data(), dfx, nc); S.down(fy.data(), dfy, nc);
-    rc = S.finish("vdo_renew_object (carry)");
+    if (nc && n_tmp) S.down(used.data(), dused, n_tmp);
+    if (xyz_out) { S.down(xyz_c.data(), dxc, 3 * (size_t)nc); S.down(xyz_t.data(), dxt, 3 * (size_t)n_tmp); }
+    rc = S.finish("vdo_renew_object");
     if (rc != VDO_OK) return rc;
   }
   int m = 0;
-  auto push = [&](float x, float y, float d, int sl, float flx, float fly, float crx, float cry, int inl, int ol) -> bool {
+  auto push = [&](float x, float y, float d, int sl, float flx, float fly, float crx, float cry, int inl, int ol, const float* p3) -> bool {
     if (m >= cap) return false;
     key_x[m] = x; key_y[m] = y; depth_out[m] = d; sem_out[m] = sl; flow_x[m] = flx; flow_y[m] = fly; corr_x[m] = crx; corr_y[m] = cry;
-    dyn_inlier_id[m] = inl; obj_label_out[m] = ol; ++m;
+    dyn_inlier_id[m] = inl; obj_label_out[m] = ol;
+    if (xyz_out) { xyz_out[3 * m] = p3[0]; xyz_out[3 * m + 1] = p3[1]; xyz_out[3 * m + 2] = p3[2]; }
+    ++m;
     return true;
   };
   std::vector<int> fea_count(n_obj, -1);
@@ -374,28 +394,17 @@ extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* i
   for (int k = 0; k < nc; ++k) {
     if (!ok[k]) continue;
     const int x = (int)cx[k], y = (int)cy[k];
-    if (!push((float)x, (float)y, dd[k], sem[k], fx[k], fy[k], x + fx[k], y + fy[k], cid[k], cur_obj_label[cid[k]])) return set_error(VDO_ERR_INVALID, "vdo_renew_object: output capacity %d too small", cap);
+    if (!push((float)x, (float)y, dd[k], sem[k], fx[k], fy[k], x + fx[k], y + fy[k], cid[k], cur_obj_label[cid[k]], xyz_c.data() + 3 * (size_t)k)) return set_error(VDO_ERR_INVALID, "vdo_renew_object: output capacity %d too small", cap);
     ++fea_count[cobj[k]];
   }
-  const int n_check = m;
-  // ---- top-up from the semi-dense sampling of the new image: GPU answers "is a carried point within 1 px"
-  std::vector<int32_t> used(n_tmp, 0);
-  if (n_tmp && n_check) {
-    float *dqx = S.up(tmp_x, n_tmp), *dqy = S.up(tmp_y, n_tmp), *drx = S.up(key_x, n_check), *dry = S.up(key_y, n_check);
-    int32_t* dused = S.up<int32_t>(nullptr, n_tmp);
-    if (!dused) return set_error(VDO_ERR_OOM, "hipMalloc failed");
-    launch_near_flags(S.stream(), n_tmp, dqx, dqy, n_check, drx, dry, dused);
-    S.down(used.data(), dused, n_tmp);
-    rc = S.finish("vdo_renew_object (top-up)");
-    if (rc != VDO_OK) return rc;
-  }
+  // ---- top-up from the semi-dense sampling of the new image (used[]: a carried point within 1 px)
   for (int i = 0; i < n_obj; ++i) {
     if (!obj_stat[i]) continue;
     int tot = fea_count[i];
     for (int start = 0; start < 15 && tot < max_num_obj; ++start) {
       for (int j = start; j < n_tmp; j += 15) {
         if (tmp_label[j] != sem_pos[i] || used[j]) continue;
-        if (!push(tmp_x[j], tmp_y[j], tmp_depth[j], tmp_label[j], tmp_flow_x[j], tmp_flow_y[j], tmp_corr_x[j], tmp_corr_y[j], -1, mod_label[i]))
+        if (!push(tmp_x[j], tmp_y[j], tmp_depth[j], tmp_label[j], tmp_flow_x[j], tmp_flow_y[j], tmp_corr_x[j], tmp_corr_y[j], -1, mod_label[i], xyz_t.data() + 3 * (size_t)j))
           return set_error(VDO_ERR_INVALID, "vdo_renew_object: output capacity %d too small", cap);
         if (++tot >= max_num_obj) break;
       }
@@ -413,11 +422,24 @@ extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* i
   for (size_t s = 0; s < uni.size(); ++s) {
     if (known[s]) continue;
     for (int j = 0; j < n_tmp; ++j)
-      if (slot[j] == (int)s && !push(tmp_x[j], tmp_y[j], tmp_depth[j], tmp_label[j], tmp_flow_x[j], tmp_flow_y[j], tmp_corr_x[j], tmp_corr_y[j], -1, -2))
+      if (slot[j] == (int)s && !push(tmp_x[j], tmp_y[j], tmp_depth[j], tmp_label[j], tmp_flow_x[j], tmp_flow_y[j], tmp_corr_x[j], tmp_corr_y[j], -1, -2, xyz_t.data() + 3 * (size_t)j))
         return set_error(VDO_ERR_INVALID, "vdo_renew_object: output capacity %d too small", cap);
   }
   *n_out = m;
   return VDO_OK;
+}
+
+extern "C" int vdo_renew_object(vdo_frame_images* f, int n_obj, const int32_t* inl_off, const int32_t* inl_idx, const uint8_t* obj_stat,
+                                const int32_t* sem_pos, const int32_t* mod_label,
+                                const float* cur_x, const float* cur_y, const int32_t* cur_obj_label,
+                                int n_tmp, const float* tmp_x, const float* tmp_y, const float* tmp_depth, const int32_t* tmp_label,
+                                const float* tmp_flow_x, const float* tmp_flow_y, const float* tmp_corr_x, const float* tmp_corr_y,
+                                int max_num_obj, int cap,
+                                float* key_x, float* key_y, float* depth_out, int32_t* sem_out, float* flow_x, float* flow_y,
+                                float* corr_x, float* corr_y, int32_t* dyn_inlier_id, int32_t* obj_label_out, int* n_out) {
+  return vdo_renew_object_world(f, n_obj, inl_off, inl_idx, obj_stat, sem_pos, mod_label, cur_x, cur_y, cur_obj_label, n_tmp, tmp_x, tmp_y, tmp_depth, tmp_label,
+                                tmp_flow_x, tmp_flow_y, tmp_corr_x, tmp_corr_y, max_num_obj, cap, nullptr, nullptr,
+                                key_x, key_y, depth_out, sem_out, flow_x, flow_y, corr_x, corr_y, dyn_inlier_id, obj_label_out, nullptr, n_out);
 }
 
 extern "C" int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, int n, const int32_t* last_sem_label,

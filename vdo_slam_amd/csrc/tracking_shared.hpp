@@ -22,6 +22,29 @@ inline Cam make_cam_Tcw(const float* K4, const float* Tcw) {   // UnprojectStere
   return c;
 }
 
+// cv::gemm semantics for small float matrices: accumulate in double, round once
+__device__ __forceinline__ void gemm3_dev(const float* A, const float* v, float* o) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i) o[i] = (float)((double)A[3 * i] * v[0] + (double)A[3 * i + 1] * v[1] + (double)A[3 * i + 2] * v[2]);
+}
+__device__ __forceinline__ void backproject(const Cam& c, float u, float v, float z, float* out) {
+  const float xc[3] = {(u - c.cx) * z * c.invfx, (v - c.cy) * z * c.invfy, z};
+  float r[3];
+  gemm3_dev(c.R, xc, r);
+  out[0] = r[0] + c.t[0]; out[1] = r[1] + c.t[1]; out[2] = r[2] + c.t[2];
+}
+// K12 over a candidate list (one-pass RenewFrameInfo: the 3-D point of every candidate, the host keeps the selected ones);
+// as_int: the key is the truncated position (objects, Tracking.cc:2846-2851)
+static __global__ void k_backproject_pts(int n, const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ d, Cam c, int as_int,
+                                         float* __restrict__ xyz) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float x = kx[i], y = ky[i];
+  if (as_int) { x = (float)(int)x; y = (float)(int)y; }
+  float o[3];
+  backproject(c, x, y, d[i], o);
+  xyz[3 * i] = o[0]; xyz[3 * i + 1] = o[1]; xyz[3 * i + 2] = o[2];
+}
 
 // defined in tracking.hip
 __global__ void k_gather(int mode, int n, const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ depth,

@@ -340,14 +340,15 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
       for (int i = 0; i < n_new_s; ++i) { f_[13][i] = kx_[keep[i]]; f_[14][i] = ky_[keep[i]]; }
       n_src = n_new_s; src_x = f_[13].data(); src_y = f_[14].data();
     }
-    VDO_TRY(vdo_renew_static(cur, n_s, tm.data(), cur_sx.data(), cur_sy.data(), n_src, src_x, src_y, p_.max_track_bg,
-                             nsta.x.data(), nsta.y.data(), nsta.cx.data(), nsta.cy.data(), nsta.fx.data(), nsta.fy.data(), sta_asso.data(), nsta.d.data(), &m));
-    for (auto* v : {&nsta.x, &nsta.y, &nsta.cx, &nsta.cy, &nsta.fx, &nsta.fy, &nsta.d}) v->resize(m);
-    sta_asso.resize(m);
     float Twc[16];
     inv_rigid(Tcw, Twc);
+    nsta.xyz.resize(3 * (size_t)cs);
+    // RenewFrameInfo (static) + Get3DinWorld (mvStat3DPointTmp) in one pass, one synchronisation
+    VDO_TRY(vdo_renew_static_world(cur, n_s, tm.data(), cur_sx.data(), cur_sy.data(), n_src, src_x, src_y, p_.max_track_bg, p_.K4, Twc,
+                                   nsta.x.data(), nsta.y.data(), nsta.cx.data(), nsta.cy.data(), nsta.fx.data(), nsta.fy.data(), sta_asso.data(), nsta.d.data(), nsta.xyz.data(), &m));
+    for (auto* v : {&nsta.x, &nsta.y, &nsta.cx, &nsta.cy, &nsta.fx, &nsta.fy, &nsta.d}) v->resize(m);
+    sta_asso.resize(m);
     nsta.xyz.resize(3 * (size_t)std::max(m, 1));
-    VDO_TRY(vdo_get3d_world(ctx_f, m, nsta.x.data(), nsta.y.data(), nsta.d.data(), p_.K4, Twc, nsta.xyz.data()));     // mvStat3DPointTmp
     // ---- static tracklets (incremental GetStaticTrack)                             Tracking.cc:2201-2300
     while (!tail_done_.load(std::memory_order_acquire)) std::this_thread::yield();      // (the tail of the last frame may be reading the static tracklets: windowed batch optimisation)
     VDO_TRY(vdo_tracks_add_frame(tr_sta_, m, sta_asso.data(), nullptr));
@@ -564,14 +565,15 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
     nobj.x.resize(cap_o); nobj.y.resize(cap_o); nobj.cx.resize(cap_o); nobj.cy.resize(cap_o); nobj.fx.resize(cap_o); nobj.fy.resize(cap_o); nobj.d.resize(cap_o);
     nobj.sem.resize(cap_o); nobj.label.resize(cap_o); dyn_asso.resize(cap_o);
     int mo = 0;
-    VDO_TRY(vdo_renew_object(cur, n_objects, p_off->data(), p_idx->data(), stat.data(), osem.data(), omod.data(), cur_ox.data(), cur_oy.data(), olab.data(),
-                             n_tmp, tmp.x.data(), tmp.y.data(), tmp.d.data(), tmp.sem.data(), tmp.fx.data(), tmp.fy.data(), tmp.cx.data(), tmp.cy.data(),
-                             p_.max_track_obj, cap_o, nobj.x.data(), nobj.y.data(), nobj.d.data(), nobj.sem.data(), nobj.fx.data(), nobj.fy.data(),
-                             nobj.cx.data(), nobj.cy.data(), dyn_asso.data(), nobj.label.data(), &mo));
+    nobj.xyz.resize(3 * (size_t)std::max(cap_o, 1));
+    // RenewFrameInfo (objects) + mvObj3DPoint in one pass, one synchronisation
+    VDO_TRY(vdo_renew_object_world(cur, n_objects, p_off->data(), p_idx->data(), stat.data(), osem.data(), omod.data(), cur_ox.data(), cur_oy.data(), olab.data(),
+                                   n_tmp, tmp.x.data(), tmp.y.data(), tmp.d.data(), tmp.sem.data(), tmp.fx.data(), tmp.fy.data(), tmp.cx.data(), tmp.cy.data(),
+                                   p_.max_track_obj, cap_o, p_.K4, Twc, nobj.x.data(), nobj.y.data(), nobj.d.data(), nobj.sem.data(), nobj.fx.data(), nobj.fy.data(),
+                                   nobj.cx.data(), nobj.cy.data(), dyn_asso.data(), nobj.label.data(), nobj.xyz.data(), &mo));
     for (auto* v : {&nobj.x, &nobj.y, &nobj.cx, &nobj.cy, &nobj.fx, &nobj.fy, &nobj.d}) v->resize(mo);
     nobj.sem.resize(mo); nobj.label.resize(mo); dyn_asso.resize(mo);
     nobj.xyz.resize(3 * (size_t)std::max(mo, 1));
-    VDO_TRY(vdo_get3d_world(ctx_w_, mo, nobj.x.data(), nobj.y.data(), nobj.d.data(), p_.K4, Twc, nobj.xyz.data()));     // mvObj3DPoint
     tick(7);
     last_sem_pos_.assign(osem.begin(), osem.begin() + n_objects);
     last_mod_label_.assign(omod.begin(), omod.begin() + n_objects);

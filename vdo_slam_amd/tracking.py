@@ -66,18 +66,30 @@ def scene_flow(ctx, cur, Tcw_cur, last, Tcw_last, K4, obj_label):
     return out, ol
 
 
-def renew_static(images, tm_sta, stat_x, stat_y, orb_x, orb_y, max_num_sta):
+def renew_static(images, tm_sta, stat_x, stat_y, orb_x, orb_y, max_num_sta, world=None):
+    """RenewFrameInfo (static).  ``world`` = (K4, Twc): the same call also returns the 3-D points ``xyz`` of the new set."""
     tm, sx, sy, ox, oy = _i(tm_sta), _f(stat_x), _f(stat_y), _f(orb_x), _f(orb_y)
     cap = max_num_sta + 2
     f = [np.zeros(cap, np.float32) for _ in range(6)]
     ids = np.zeros(cap, np.int32); d = np.zeros(cap, np.float32)
     n = C.c_int()
-    K.check(_lib().vdo_renew_static(images._h, tm.size, _ip(tm), _fp(sx), _fp(sy), ox.size, _fp(ox), _fp(oy), max_num_sta,
-                                    *[_fp(a) for a in f], _ip(ids), _fp(d), C.byref(n)))
+    if world is None:
+        K.check(_lib().vdo_renew_static(images._h, tm.size, _ip(tm), _fp(sx), _fp(sy), ox.size, _fp(ox), _fp(oy), max_num_sta,
+                                        *[_fp(a) for a in f], _ip(ids), _fp(d), C.byref(n)))
+    else:
+        K4, Twc = _f(world[0]), _f(world[1])
+        xyz = np.zeros((cap, 3), np.float32)
+        L = K.lib()
+        fp, ip = K.c_float_p, K.c_int32_p
+        L.vdo_renew_static_world.argtypes = [C.c_void_p, C.c_int, ip, fp, fp, C.c_int, fp, fp, C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, ip, fp, fp, C.POINTER(C.c_int)]
+        K.check(L.vdo_renew_static_world(images._h, tm.size, _ip(tm), _fp(sx), _fp(sy), ox.size, _fp(ox), _fp(oy), max_num_sta, _fp(K4), _fp(Twc),
+                                         *[_fp(a) for a in f], _ip(ids), _fp(d), _fp(xyz), C.byref(n)))
     n = n.value
     names = ("key_x", "key_y", "corr_x", "corr_y", "flow_x", "flow_y")
     out = {k: a[:n] for k, a in zip(names, f)}
     out["inlier_id"] = ids[:n]; out["depth"] = d[:n]
+    if world is not None:
+        out["xyz"] = xyz[:n]
     return out
 
 
@@ -121,8 +133,9 @@ def dyn_obj_tracking(prm: DynObjParamsC, sem_label, obj_label, key_x, key_y, dep
     return dict(obj_label=ol, objects=[idx[off[a]:off[a + 1]].copy() for a in range(k)], sem=osem[:k].copy(), mod=omod[:k].copy(), max_id=mid.value)
 
 
-def renew_object(images, inl_sets, obj_stat, sem_pos, mod_label, cur_x, cur_y, cur_obj_label, tmp, max_num_obj, cap=None):
-    """RenewFrameInfo (objects).  ``inl_sets``: list of index arrays; ``tmp``: dict(x,y,depth,label,flow_x,flow_y,corr_x,corr_y)."""
+def renew_object(images, inl_sets, obj_stat, sem_pos, mod_label, cur_x, cur_y, cur_obj_label, tmp, max_num_obj, cap=None, world=None):
+    """RenewFrameInfo (objects).  ``inl_sets``: list of index arrays; ``tmp``: dict(x,y,depth,label,flow_x,flow_y,corr_x,corr_y);
+    ``world`` = (K4, Twc): the same call also returns the 3-D points ``xyz`` of the new set."""
     off = np.zeros(len(inl_sets) + 1, np.int32)
     off[1:] = np.cumsum([len(s) for s in inl_sets])
     idx = _i(np.concatenate([np.asarray(s, np.int32) for s in inl_sets])) if len(inl_sets) and off[-1] else np.zeros(1, np.int32)
@@ -139,13 +152,25 @@ def renew_object(images, inl_sets, obj_stat, sem_pos, mod_label, cur_x, cur_y, c
     fp, ip = K.c_float_p, K.c_int32_p
     L.vdo_renew_object.argtypes = [C.c_void_p, C.c_int, ip, ip, K.c_uint8_p, ip, ip, fp, fp, ip, C.c_int, fp, fp, fp, ip, fp, fp, fp, fp, C.c_int, C.c_int,
                                    fp, fp, fp, ip, fp, fp, fp, fp, ip, ip, C.POINTER(C.c_int)]
-    K.check(L.vdo_renew_object(images._h, len(inl_sets), _ip(off), _ip(idx), _u8p(st), _ip(sp), _ip(ml), _fp(cx), _fp(cy), _ip(col),
-                               n_tmp, _fp(t["x"]), _fp(t["y"]), _fp(t["depth"]), _ip(t["label"]), _fp(t["flow_x"]), _fp(t["flow_y"]), _fp(t["corr_x"]), _fp(t["corr_y"]),
-                               max_num_obj, cap, _fp(f[0]), _fp(f[1]), _fp(f[2]), _ip(sem), _fp(f[3]), _fp(f[4]), _fp(f[5]), _fp(f[6]), _ip(inl), _ip(ol), C.byref(n)))
+    if world is None:
+        K.check(L.vdo_renew_object(images._h, len(inl_sets), _ip(off), _ip(idx), _u8p(st), _ip(sp), _ip(ml), _fp(cx), _fp(cy), _ip(col),
+                                   n_tmp, _fp(t["x"]), _fp(t["y"]), _fp(t["depth"]), _ip(t["label"]), _fp(t["flow_x"]), _fp(t["flow_y"]), _fp(t["corr_x"]), _fp(t["corr_y"]),
+                                   max_num_obj, cap, _fp(f[0]), _fp(f[1]), _fp(f[2]), _ip(sem), _fp(f[3]), _fp(f[4]), _fp(f[5]), _fp(f[6]), _ip(inl), _ip(ol), C.byref(n)))
+    else:
+        K4, Twc = _f(world[0]), _f(world[1])
+        xyz = np.zeros((cap, 3), np.float32)
+        L.vdo_renew_object_world.argtypes = [C.c_void_p, C.c_int, ip, ip, K.c_uint8_p, ip, ip, fp, fp, ip, C.c_int, fp, fp, fp, ip, fp, fp, fp, fp, C.c_int, C.c_int, fp, fp,
+                                             fp, fp, fp, ip, fp, fp, fp, fp, ip, ip, fp, C.POINTER(C.c_int)]
+        K.check(L.vdo_renew_object_world(images._h, len(inl_sets), _ip(off), _ip(idx), _u8p(st), _ip(sp), _ip(ml), _fp(cx), _fp(cy), _ip(col),
+                                         n_tmp, _fp(t["x"]), _fp(t["y"]), _fp(t["depth"]), _ip(t["label"]), _fp(t["flow_x"]), _fp(t["flow_y"]), _fp(t["corr_x"]), _fp(t["corr_y"]),
+                                         max_num_obj, cap, _fp(K4), _fp(Twc), _fp(f[0]), _fp(f[1]), _fp(f[2]), _ip(sem), _fp(f[3]), _fp(f[4]), _fp(f[5]), _fp(f[6]), _ip(inl), _ip(ol),
+                                         _fp(xyz), C.byref(n)))
     m = n.value
     names = ("key_x", "key_y", "depth", "flow_x", "flow_y", "corr_x", "corr_y")
     out = {k: a[:m] for k, a in zip(names, f)}
     out.update(sem=sem[:m], inlier_id=inl[:m], obj_label=ol[:m])
+    if world is not None:
+        out["xyz"] = xyz[:m]
     return out
 
 
