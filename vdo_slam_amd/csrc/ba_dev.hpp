@@ -66,6 +66,7 @@ struct BADev {
   int32_t *pe_off = nullptr, *pe_idx = nullptr;   // entry = edge<<1 | side (0: pose is i, 1: pose is j)
   // pose chains (paths of the EdgeSE3 graph) for the block-tridiagonal preconditioner, in path order
   int n_pchains = 0;
+  int pc_maxlen = 0, pc_waves = 0;                // longest chain; waves of the PCG workgroup that hold a chain strip in LDS (0: the strips do not fit - global-memory path)
   int32_t *pc_off = nullptr, *pc_pose = nullptr;  // [n_pchains+1], [P]
   int32_t* pc_edge = nullptr;                     // [P] edge<<1|side linking position k-1 -> k (side 0: previous pose is the edge's i), -1 at a chain head
   // linear system

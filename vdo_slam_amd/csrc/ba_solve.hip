@@ -284,19 +284,34 @@ __global__ __launch_bounds__(256) void k_precond_finalize(BADev d, double lambda
 // Levenberg trial); Minv / Lc are indexed by chain position.
 __global__ __launch_bounds__(64) void k_pchain_factor(BADev d) {
   // one wave per chain; lane = 6*row + col of a 6x6 block (36 active lanes), blocks exchanged through LDS
-  __shared__ double sE[36], sD[36], sL[36], sA[36];
+  __shared__ double sE[36], sD[36], sL[36];
   const int c = blockIdx.x, lane = threadIdx.x;
   const bool act = lane < 36;
   const int r = act ? lane / 6 : 0, q = act ? lane % 6 : 0;
   const int b = d.pc_off[c], e = d.pc_off[c + 1];
   bool bad = false;
+  // the inputs of a step (A_k, E_{k-1,k}) do not depend on the recursion: the next step's are requested while this one computes
+  // (pc_pose / pc_edge -> Adg / Hpp_ep is a two-level pointer chase through HBM, ~2 us per step when it sits on the critical path)
+  // (indices three steps ahead, values two: neither load waits for the other inside a step)
+  auto idx_p = [&](int k) -> int { return k < e ? d.pc_pose[k] : 0; };
+  auto idx_e = [&](int k) -> int { return (k < e && k > b) ? d.pc_edge[k] : -1; };
+  auto fetch_a = [&](int k, int p) -> double { return (k < e && act) ? d.Adg[36 * (int64_t)p + lane] : 0.0; };
+  auto fetch_e = [&](int ent) -> double {
+    if (ent < 0 || !act) return 0.0;
+    const double* He = d.Hpp_ep + 36 * (int64_t)(ent >> 1);
+    return (ent & 1) ? He[q * 6 + r] : He[lane];                     // E = block (previous pose, this pose)
+  };
+  int p_n2 = idx_p(b + 2), t_n2 = idx_e(b + 2);
+  double a_nx, e_nx, a_n2, e_n2;
+  { const int p0 = idx_p(b), p1 = idx_p(b + 1), t1 = idx_e(b + 1); a_nx = fetch_a(b, p0); e_nx = 0.0; a_n2 = fetch_a(b + 1, p1); e_n2 = fetch_e(t1); }
   for (int k = b; k < e; ++k) {
-    const int64_t p = d.pc_pose[k];
-    double a = act ? d.Adg[36 * p + lane] : 0.0;
+    double a = a_nx;
+    const double ev = e_nx;
+    a_nx = a_n2; e_nx = e_n2;
+    a_n2 = fetch_a(k + 2, p_n2); e_n2 = fetch_e(t_n2);
+    p_n2 = idx_p(k + 3); t_n2 = idx_e(k + 3);
     if (k > b) {
-      const int ent = d.pc_edge[k];
-      const double* He = d.Hpp_ep + 36 * (int64_t)(ent >> 1);
-      if (act) sE[lane] = (ent & 1) ? He[q * 6 + r] : He[lane];        // E = block (previous pose, this pose)
+      if (act) sE[lane] = ev;
       __syncthreads();
       double t = 0;
 #pragma unroll
@@ -308,23 +323,26 @@ __global__ __launch_bounds__(64) void k_pchain_factor(BADev d) {
       for (int m = 0; m < 6; ++m) t += sL[r * 6 + m] * sE[m * 6 + q];   // Delta = A - L E
       a -= t;
     }
-    if (act) sA[lane] = a;
-    __syncthreads();
-    // in-place Gauss-Jordan inverse (SPD: no pivoting); a non-positive pivot flags the factorisation as failed
-#pragma unroll 1
+    // in-place Gauss-Jordan inverse (SPD: no pivoting) IN REGISTERS: the pivot is a v_readlane, its row and column come
+    // through ds_bpermute (no LDS round trip, no barrier), the reciprocal is v_rcp_f64 + two Newton steps running under the
+    // permutes - this is the preconditioner, not the solve: its rounding only has to be deterministic.
+    // A non-positive pivot flags the factorisation as failed.
+#pragma unroll
     for (int kk = 0; kk < 6; ++kk) {
-      const double pv = sA[kk * 7], aik = sA[r * 6 + kk], akj = sA[kk * 6 + q], own = sA[act ? lane : 0];
+      const double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), kk * 7), __builtin_amdgcn_readlane(__double2loint(a), kk * 7));
+      const double aik = __shfl(a, r * 6 + kk, 64), akj = __shfl(a, kk * 6 + q, 64);
       if (!(pv > 0)) bad = true;
-      __syncthreads();
+      double rp = __builtin_amdgcn_rcp(pv);
+      rp = __builtin_fma(__builtin_fma(-pv, rp, 1.0), rp, rp);
+      rp = __builtin_fma(__builtin_fma(-pv, rp, 1.0), rp, rp);
       double nv;
-      if (r == kk && q == kk) nv = 1.0 / pv;
-      else if (r == kk) nv = akj / pv;
-      else if (q == kk) nv = -aik / pv;
-      else nv = own - aik * akj / pv;
-      if (act) sA[lane] = nv;
-      __syncthreads();
+      if (r == kk && q == kk) nv = rp;
+      else if (r == kk) nv = akj * rp;
+      else if (q == kk) nv = -aik * rp;
+      else nv = a - aik * (akj * rp);
+      a = nv;
     }
-    if (act) { const double v = sA[lane]; sD[lane] = v; d.Minv[36 * (int64_t)k + lane] = v; }
+    if (act) { sD[lane] = a; d.Minv[36 * (int64_t)k + lane] = a; }
     __syncthreads();
   }
   if (bad && lane == 0) atomicOr(d.flags, 1);
@@ -378,6 +396,117 @@ __device__ void pchain_apply(const BADev& d, const double* __restrict__ r, doubl
       if (act && col == 0) z[6 * p + row] = zk;
       zcol = __shfl(zk, (col < 6 ? col : 0) * 8, 64);
     }
+  }
+}
+
+// The same operator with the chain in LDS and no transposes.  A wave owns a chain; r of the chain is staged into the wave's
+// LDS strip [len][6] (coalesced 48-byte rows), the substitutions overwrite it in place (r -> y -> Dinv y -> z), z goes back
+// in one pass: the recursion never waits for global memory (the version above chases pc_pose -> r / z through HBM twice per
+// step).  lane = (a, b) = (lane >> 3, lane & 7) holds one entry of the 6x6 block; a block mat-vec is one multiply and one
+// 8-lane all-reduce - over the octet (sum over b) or over the lanes of equal b (sum over a).  The two kinds ALTERNATE: a
+// vector that comes out indexed by a (replicated along the octet) is consumed by a step that holds its block transposed
+// and reduces over a, whose result is indexed by b (replicated across the octets) - no lane permutation between steps.
+// The blocks (Lc, Minv) do not depend on the recursion: they are fetched eight steps ahead.
+__device__ void pchain_apply_lds(const BADev& d, const double* __restrict__ r, double* __restrict__ z, double* lds_strips) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int a = lane >> 3, b = lane & 7;
+  const bool act = a < 6 && b < 6;
+  const int el = act ? a * 6 + b : 0, elT = act ? b * 6 + a : 0;
+  const int ia = a < 6 ? a : 0, ib = b < 6 ? b : 0;
+  if (wave >= d.pc_waves) return;
+  double* yb = lds_strips + (size_t)wave * 6 * d.pc_maxlen;
+  for (int c = wave; c < d.n_pchains; c += d.pc_waves) {
+    const int bgn = d.pc_off[c], len = d.pc_off[c + 1] - bgn;
+    for (int k = lane; k < len; k += 64) {
+      const double* src = r + 6 * (int64_t)d.pc_pose[bgn + k];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) yb[6 * k + i] = src[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- forward: y_0 = r_0 ; y_k = r_k - L_k y_{k-1}.  Step s = k - 1: even s holds L natural (vector indexed by b in, by a out),
+    //      odd s holds it transposed (a in, b out)
+    double v = b < 6 ? yb[ib] : 0.0;                       // y_0[b]
+    const int nst = len - 1;
+    double Lp[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Lp[j] = (j < nst && act) ? d.Lc[36 * (int64_t)(bgn + 1 + j) + ((j & 1) ? elT : el)] : 0.0;
+    for (int s0 = 0; s0 < nst; s0 += 8) {
+      double Ln[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Ln[j] = (s0 + 8 + j < nst && act) ? d.Lc[36 * (int64_t)(bgn + 1 + s0 + 8 + j) + ((j & 1) ? elT : el)] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = s0 + j + 1;
+        if (k < len) {
+          if ((j & 1) == 0) {
+            const double sum = octet_allsum(Lp[j] * v);
+            v = yb[6 * k + ia] - sum;
+            if (b == 0 && a < 6) yb[6 * k + a] = v;
+          } else {
+            const double sum = stride8_allsum(Lp[j] * v);
+            v = yb[6 * k + ib] - sum;
+            if (a == 0 && b < 6) yb[6 * k + b] = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Lp[j] = Ln[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- diagonal: w_k = Dinv_k y_k for every k (independent steps)
+    for (int k0 = 0; k0 < len; k0 += 8) {
+      double Dv[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Dv[j] = (k0 + j < len && act) ? d.Minv[36 * (int64_t)(bgn + k0 + j) + el] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = k0 + j;
+        if (k < len) {
+          const double w = octet_allsum(Dv[j] * (b < 6 ? yb[6 * k + ib] : 0.0));
+          __builtin_amdgcn_wave_barrier();                 // (every lane has read y_k before it is overwritten)
+          if (b == 0 && a < 6) yb[6 * k + a] = w;
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- backward: z_last = w_last ; z_k = w_k - L_{k+1}^T z_{k+1}.  Step t = len - 2 - k: even t holds L transposed (b in, a out),
+    //      odd t natural (a in, b out)
+    v = b < 6 ? yb[6 * (len - 1) + ib] : 0.0;              // z_last[b]
+#pragma unroll
+    for (int j = 0; j < 8; ++j) Lp[j] = (j < nst && act) ? d.Lc[36 * (int64_t)(bgn + len - 1 - j) + ((j & 1) ? el : elT)] : 0.0;
+    for (int t0 = 0; t0 < nst; t0 += 8) {
+      double Ln[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Ln[j] = (t0 + 8 + j < nst && act) ? d.Lc[36 * (int64_t)(bgn + len - 1 - (t0 + 8 + j)) + ((j & 1) ? el : elT)] : 0.0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int k = len - 2 - (t0 + j);
+        if (k >= 0) {
+          if ((j & 1) == 0) {
+            const double sum = octet_allsum(Lp[j] * v);
+            v = yb[6 * k + ia] - sum;
+            if (b == 0 && a < 6) yb[6 * k + a] = v;
+          } else {
+            const double sum = stride8_allsum(Lp[j] * v);
+            v = yb[6 * k + ib] - sum;
+            if (a == 0 && b < 6) yb[6 * k + b] = v;
+          }
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) Lp[j] = Ln[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int k = lane; k < len; k += 64) {
+      double* dst = z + 6 * (int64_t)d.pc_pose[bgn + k];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) dst[i] = yb[6 * k + i];
+    }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
@@ -533,6 +662,7 @@ __device__ __forceinline__ void hpp_mv(const BADev& d, int p, const double* v, d
 
 // bs = bp - qs ; x = 0 ; r = bs ; z = Minv r ; p = z ; rz = rz0 = r.z       (single workgroup)
 __global__ __launch_bounds__(1024) void k_pcg_init(BADev d) {
+  extern __shared__ __attribute__((aligned(16))) double pc_strips[];
   __shared__ double lds[17];
   const int64_t n = 6 * (int64_t)d.P;
   for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
@@ -540,7 +670,7 @@ __global__ __launch_bounds__(1024) void k_pcg_init(BADev d) {
     d.bs[i] = r; d.rp[i] = r; d.xp[i] = 0;
   }
   __syncthreads();
-  pchain_apply(d, d.rp, d.zp);
+  if (d.pc_waves) pchain_apply_lds(d, d.rp, d.zp, pc_strips); else pchain_apply(d, d.rp, d.zp);
   __syncthreads();
   double acc = 0;
   for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const double z = d.zp[i]; d.pp[i] = z; acc += d.rp[i] * z; }
@@ -574,6 +704,7 @@ __device__ __forceinline__ double hpp_row(const BADev& d, int64_t p, int row, co
 }
 
 __global__ __launch_bounds__(1024) void k_pcg_vec(BADev d, double lambda, double tol2) {
+  extern __shared__ __attribute__((aligned(16))) double pc_strips[];
   __shared__ double lds[17];
   if (d.flags[1]) return;                       // converged earlier: no-op
   const int64_t n = 6 * (int64_t)d.P;
@@ -591,7 +722,7 @@ __global__ __launch_bounds__(1024) void k_pcg_vec(BADev d, double lambda, double
     d.rp[i] -= alpha * d.qp[i];
   }
   __syncthreads();
-  pchain_apply(d, d.rp, d.zp);                  // z = M^-1 r  (block-tridiagonal along the pose chains)
+  if (d.pc_waves) pchain_apply_lds(d, d.rp, d.zp, pc_strips); else pchain_apply(d, d.rp, d.zp);     // z = M^-1 r  (block-tridiagonal along the pose chains)
   __syncthreads();
   acc = 0;
   for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += d.rp[i] * d.zp[i];
@@ -867,13 +998,14 @@ void launch_reduced_rhs(const BADev& d, hipStream_t s, const Reducer& R) {
   if (d.sharded) R(d.qs, 6 * (int64_t)d.P);
 }
 
-void launch_pcg_init(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), 0, s, d); }
+static size_t pc_strip_bytes(const BADev& d) { return (size_t)d.pc_waves * 6 * (size_t)d.pc_maxlen * sizeof(double); }
+void launch_pcg_init(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), pc_strip_bytes(d), s, d); }
 
 void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s, const Reducer& R) {
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<0>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.pp);
   hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs, 1);
   if (d.sharded) R(d.qs, 6 * (int64_t)d.P);      // the one exchange per CG iteration: 6P doubles
-  hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(1024), 0, s, d, lambda, tol2);
+  hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(1024), pc_strip_bytes(d), s, d, lambda, tol2);
 }
 
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s) {

@@ -109,6 +109,36 @@ __device__ __forceinline__ double dpp_f64z(double v) {
   const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, true);
   return __hiloint2double(hi, lo);
 }
+// plain DPP move of a double (every lane has a source for the controls used with it)
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64p(double v) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+// Sum over the 8 lanes of a lane octet (lane & ~7), result in all of them: xor 1, xor 2, mirror inside the octet.
+__device__ __forceinline__ double octet_allsum(double v) {
+  v += dpp_f64p<0xB1>(v);      // quad_perm [1,0,3,2]
+  v += dpp_f64p<0x4E>(v);      // quad_perm [2,3,0,1]
+  v += dpp_f64p<0x141>(v);     // row_half_mirror: the two quads of an octet are uniform by now
+  return v;
+}
+// Sum over the 8 lanes with the same (lane & 7), result in all of them: xor 8 (row_ror:8), xor 16 and xor 32 with the gfx950
+// row-swap instructions (v_permlane16_swap / v_permlane32_swap of a register with its copy: both halves of a pair end up side by side).
+__device__ __forceinline__ double stride8_allsum(double v) {
+  v += dpp_f64p<0x128>(v);
+  {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  }
+  {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);
+  }
+  return v;
+}
 // The conditional add of a scan step is ONE fused multiply-add with a 0.0 / 1.0 flag: fma(t, 1, v) = round(t + v), the very
 // result of the addition, and fma(t, 0, v) = v exactly (t is finite) - instead of two v_cndmask + v_add per double.
 struct SegFlags { double f1, f2, f4, f8; };

@@ -63,6 +63,18 @@ VDO_HD D3 iso_apply(const IsoD& a, D3 p) { return rot(a.r, p) + a.t; }
 
 // Eigen Quaterniond(Matrix3d) followed by normalisation and sign fix (w >= 0):
 // internal::toCompactQuaternion (g2o/types/isometry3d_mappings.cpp:75-80).
+template <int I>
+VDO_HD void compact_quat_neg_trace(const double* m, double& qx, double& qy, double& qz, double& qw) {   // constant indices: m stays in registers
+  constexpr int J = (I + 1) % 3, K = (J + 1) % 3;
+  double t = sqrt(m[4 * I] - m[4 * J] - m[4 * K] + 1.0);
+  double c[3];
+  c[I] = 0.5 * t;
+  t = 0.5 / t;
+  qw = (m[3 * K + J] - m[3 * J + K]) * t;
+  c[J] = (m[3 * J + I] + m[3 * I + J]) * t;
+  c[K] = (m[3 * K + I] + m[3 * I + K]) * t;
+  qx = c[0]; qy = c[1]; qz = c[2];
+}
 VDO_HD D3 compact_quat(const double* m) {
   double qx, qy, qz, qw;
   double t = m[0] + m[4] + m[8];
@@ -74,16 +86,10 @@ VDO_HD D3 compact_quat(const double* m) {
   } else {
     int i = 0;
     if (m[4] > m[0]) i = 1;
-    if (m[8] > m[4 * i]) i = 2;
-    int j = (i + 1) % 3, k = (j + 1) % 3;
-    t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
-    double c[3];
-    c[i] = 0.5 * t;
-    t = 0.5 / t;
-    qw = (m[3 * k + j] - m[3 * j + k]) * t;
-    c[j] = (m[3 * j + i] + m[3 * i + j]) * t;
-    c[k] = (m[3 * k + i] + m[3 * i + k]) * t;
-    qx = c[0]; qy = c[1]; qz = c[2];
+    if (m[8] > (i == 1 ? m[4] : m[0])) i = 2;
+    if (i == 0) compact_quat_neg_trace<0>(m, qx, qy, qz, qw);
+    else if (i == 1) compact_quat_neg_trace<1>(m, qx, qy, qz, qw);
+    else compact_quat_neg_trace<2>(m, qx, qy, qz, qw);
   }
   double n = sqrt(qx * qx + qy * qy + qz * qz + qw * qw);
   qx /= n; qy /= n; qz /= n; qw /= n;
