@@ -44,14 +44,24 @@ __global__ void k_factor_chains(BADev d, double lambda) {
   double prev[9];
   bool ok = true;
   const int64_t Et = d.Et;
+  // (the inputs of a step do not depend on the recursion: the O block of the next step and the edge index of the one after are
+  // requested while this step computes - a step no longer waits for the pt_prev_edge -> Oll pointer chase)
+  double hl_n = d.Hll[p0];
+  int64_t e_next = p0 + 1 < p1 ? d.pt_prev_edge[p0 + 1] : 0;
+  double O[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
   for (int64_t l = p0; l < p1; ++l) {
-    const double hd = d.Hll[l] + lambda;
+    const double hd = hl_n + lambda;
+    double On[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t e_nn = 0;
+    if (l + 1 < p1) {
+      hl_n = d.Hll[l + 1];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) On[i] = d.Oll[i * Et + e_next];
+      if (l + 2 < p1) e_nn = d.pt_prev_edge[l + 2];
+    }
     double D[9] = {hd, 0.0, 0.0, 0.0, hd, 0.0, 0.0, 0.0, hd};
     if (l > p0) {
-      const int64_t e = d.pt_prev_edge[l];
-      double O[9], G[9];
-#pragma unroll
-      for (int i = 0; i < 9; ++i) O[i] = d.Oll[i * Et + e];
+      double G[9];
       mat3_mul(prev, O, G);
 #pragma unroll
       for (int i = 0; i < 9; ++i) d.Gl[9 * l + i] = G[i];
@@ -62,16 +72,24 @@ __global__ void k_factor_chains(BADev d, double lambda) {
     }
     ok &= spd3_inv(D, prev);
 #pragma unroll
-    for (int i = 0; i < 9; ++i) d.Dinv[9 * l + i] = prev[i];
+    for (int i = 0; i < 9; ++i) { d.Dinv[9 * l + i] = prev[i]; O[i] = On[i]; }
+    e_next = e_nn;
   }
   // backward: inverse blocks
   double Gn[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) { Gn[i] = prev[i]; d.Gdiag[9 * (p1 - 1) + i] = prev[i]; }
+  double Gx[9], Dx[9];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) { Gx[i] = p1 - 2 >= p0 ? d.Gl[9 * (p1 - 1) + i] : 0.0; Dx[i] = p1 - 2 >= p0 ? d.Dinv[9 * (p1 - 2) + i] : 0.0; }
   for (int64_t l = p1 - 2; l >= p0; --l) {
     double G[9], T1[9], Di[9];
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { G[i] = d.Gl[9 * (l + 1) + i]; Di[i] = d.Dinv[9 * l + i]; }
+    for (int i = 0; i < 9; ++i) { G[i] = Gx[i]; Di[i] = Dx[i]; }
+    if (l - 1 >= p0) {
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { Gx[i] = d.Gl[9 * l + i]; Dx[i] = d.Dinv[9 * (l - 1) + i]; }
+    }
     mat3_mul(G, Gn, T1);                       // Gl_{k+1} G_{k+1,k+1}
 #pragma unroll
     for (int i = 0; i < 9; ++i) d.Goff[9 * (l + 1) + i] = -T1[i];
