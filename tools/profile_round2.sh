@@ -17,9 +17,10 @@ timeout 150 rocprofv3 --kernel-trace --stats -d $O/prof_dense -- python $R/tools
 cd $R
 for n in bench sweep ba_bench ba_large dense; do DB=$(find $O/prof_$n -name "*.db" | head -1); python tools/rocprof_summary.py $DB 40 > $O/${n}_kernel_stats.txt 2>&1; done
 python tools/pmc_summary.py k_sweep_tile $(find $O/pmc_fetch -name "*.db" | head -1) $(find $O/pmc_write -name "*.db" | head -1) > $O/sweep_pmc_hbm_traffic.txt 2>&1
-tail -1 $O/sweep.log >> $O/sweep_pmc_hbm_traffic.txt
+grep "^n_eb" $O/sweep.log | tail -1 >> $O/sweep_pmc_hbm_traffic.txt
 python tools/pmc_counters.py k_sweep_tile $(find $O/pmc_sq1 -name "*.db" | head -1) $(find $O/pmc_sq2 -name "*.db" | head -1) > $O/sweep_sq_counters.txt 2>&1
 DB=$(find $O/prof_bench -name "*.db" | head -1); python tools/rocprof_timeline.py $DB 40 2400 > $O/frame_timeline.txt 2>&1
+cp $O/sweep_pmc_hbm_traffic.txt profiles/r02_sweep_pmc_hbm_traffic.txt      # (bench.py quotes the counter-based traffic of this very run)
 timeout 280 python bench.py --replica-sweep 1,2,4,8 > $O/bench.json 2> $O/bench.err
 find $O -name "*.db" -size +20M -delete
 tail -c 400 $O/bench.json
