@@ -321,8 +321,9 @@ int vdo_orb_get_blurred(vdo_orb* orb, int level, uint8_t* out /* w*h */);
 int vdo_orb_get_candidates(vdo_orb* orb, int level, float* x, float* y, float* response, float* angle, int cap, int* n);
 /* Wall time of the last vdo_orb_extract: ms[0] device stage launch .. candidates on the host, ms[1] host quadtree. */
 int vdo_orb_last_timing(vdo_orb* orb, double ms[2]);
-/* Kernel launches that build the pyramid of one image: 1 (every level in one launch - possible with <= 8 levels whose cascaded
- * source windows fit the LDS buffers) or n_levels (level by level; also forced by the environment variable VDO_ORB_PYRAMID_LAUNCHES). */
+/* Kernel launches that build the pyramid of one image: 2 (levels 0-4 cascaded in LDS from the image, the rest from level 4;
+ * 1 with <= 5 levels) - possible with <= 8 levels whose cascaded source windows fit the LDS buffers - or n_levels (level by
+ * level; also forced by the environment variable VDO_ORB_PYRAMID_LAUNCHES). */
 int vdo_orb_pyramid_launches(const vdo_orb* orb);
 
 /* K1: Tracking::GrabImageRGBD depth preprocessing (src/Tracking.cc:180-204), in place. */

@@ -41,8 +41,8 @@ def test_orb_matches_oracle_bit_exact(ctx, oracle, seed, shape):
     for l in (0, 3, 7):
         inner = R.pyramid(oracle, gray)[l][19:-19, 19:-19]
         assert np.array_equal(orb.blurred(l), R.blur7(oracle, inner)), f"blur level {l}"
-    # the pyramid above came from the one-launch kernel; the level-by-level launches give the same bytes
-    assert orb.pyramid_launches() == 1
+    # the pyramid above came from the cascaded kernel; the level-by-level launches give the same bytes
+    assert orb.pyramid_launches() == 2            # levels 0-4 cascade from the image, 5-7 from level 4
     import os
     os.environ["VDO_ORB_PYRAMID_LAUNCHES"] = "1"
     try:

@@ -103,13 +103,14 @@ __global__ void k_resize_border(const uint8_t* __restrict__ src /*interior of le
 // source window) costs a few microseconds of an otherwise idle GPU.  The 19-px REFLECT_101 border is written by the owner of
 // the mirrored interior pixel.
 struct PyrDesc {
-  int n_levels;
+  int n_levels;                 // levels of the pyramid (0: this launch form is not used)
+  int base, lv0, lv1;           // this launch builds levels [lv0, lv1) from the image of level `base` (0: the source image)
   int w[8], h[8];
   double sx[8], sy[8];          // scale of level l relative to level l-1 (inv of cv::resize's inv_scale), [0] unused
   int tile_off[9];              // first workgroup of every level
   int tiles_x[8];
 };
-constexpr int kPyrRegion = 160;   // max edge of a cascaded region (checked on the host at create time)
+constexpr int kPyrRegion = 96;    // max edge of a cascaded region (checked on the host at create time)
 
 __device__ __forceinline__ void resize_src(int d, double scale, int slen, int& s0, int& s1, int& c0, int& c1) {
   float f = (float)((d + 0.5) * scale - 0.5);
@@ -135,14 +136,14 @@ __global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__
   __shared__ uint8_t bufA[kPyrRegion * kPyrRegion];
   __shared__ uint8_t bufB[kPyrRegion * kPyrRegion];
   __shared__ int rx0[8], rx1[8], ry0[8], ry1[8];
-  int lvl = 0;
-  while (lvl + 1 < P.n_levels && (int)blockIdx.x >= P.tile_off[lvl + 1]) ++lvl;
+  int lvl = P.lv0;
+  while (lvl + 1 < P.lv1 && (int)blockIdx.x >= P.tile_off[lvl + 1]) ++lvl;
   const int t = blockIdx.x - P.tile_off[lvl], ty = t / P.tiles_x[lvl], tx = t - ty * P.tiles_x[lvl];
   if (threadIdx.x == 0) {
     // inclusive pixel ranges needed at every level, from the tile down to the source
     int x0 = tx * 32, x1 = min(x0 + 31, P.w[lvl] - 1), y0 = ty * 32, y1 = min(y0 + 31, P.h[lvl] - 1);
     rx0[lvl] = x0; rx1[lvl] = x1; ry0[lvl] = y0; ry1[lvl] = y1;
-    for (int k = lvl; k > 0; --k) {
+    for (int k = lvl; k > P.base; --k) {
       int a0, a1, c0, c1, b0, b1;
       resize_src(x0, P.sx[k], P.w[k - 1], a0, a1, c0, c1);
       resize_src(x1, P.sx[k], P.w[k - 1], b0, b1, c0, c1);
@@ -154,15 +155,16 @@ __global__ __launch_bounds__(256) void k_pyramid_all(const uint8_t* __restrict__
     }
   }
   __syncthreads();
-  // level 0 region from the source image
+  // region of the base level from its image (the source, or a level an earlier launch wrote)
   uint8_t* cur = bufA;
   uint8_t* nxt = bufB;
   {
-    const int w0 = rx1[0] - rx0[0] + 1, h0 = ry1[0] - ry0[0] + 1;
-    for (int i = threadIdx.x; i < w0 * h0; i += 256) { const int yy = i / w0, xx = i - yy * w0; cur[yy * kPyrRegion + xx] = src[(size_t)(ry0[0] + yy) * sstride + rx0[0] + xx]; }
+    const int bs = P.base;
+    const int w0 = rx1[bs] - rx0[bs] + 1, h0 = ry1[bs] - ry0[bs] + 1;
+    for (int i = threadIdx.x; i < w0 * h0; i += 256) { const int yy = i / w0, xx = i - yy * w0; cur[yy * kPyrRegion + xx] = src[(size_t)(ry0[bs] + yy) * sstride + rx0[bs] + xx]; }
   }
   __syncthreads();
-  for (int k = 1; k <= lvl; ++k) {
+  for (int k = P.base + 1; k <= lvl; ++k) {
     const int wk = rx1[k] - rx0[k] + 1, hk = ry1[k] - ry0[k] + 1;
     const int ox = rx0[k - 1], oy = ry0[k - 1];
     for (int i = threadIdx.x; i < wk * hk; i += 256) {
@@ -614,7 +616,8 @@ struct vdo_orb {
   std::vector<float> scale;
   UMax um{};
   Blur7 blur{};
-  PyrDesc pyr{};                 // fused pyramid launch (k_pyramid_all); n_levels == 0: level-by-level launches
+  PyrDesc pyr{};                 // cascaded pyramid launches (k_pyramid_all); n_levels == 0: level-by-level launches
+  PyrDesc pyr2{};                // second cascade (upper levels from the top level of the first); lv1 == lv0: not used
   // device
   std::vector<void*> allocs;
   uint8_t *d_src = nullptr, *d_pyr = nullptr, *d_blur = nullptr;
@@ -643,7 +646,7 @@ struct vdo_orb {
 
 extern "C" int vdo_orb_pyramid_launches(const vdo_orb* o) {
   if (!o) return set_error(VDO_ERR_INVALID, "null handle");
-  return o->pyr.n_levels ? 1 : (int)o->levels.size();
+  return o->pyr.n_levels ? (o->pyr2.lv1 > o->pyr2.lv0 ? 2 : 1) : (int)o->levels.size();
 }
 
 extern "C" int vdo_orb_destroy(vdo_orb* o) {
@@ -720,17 +723,27 @@ extern "C" int vdo_orb_create(vdo_ctx* ctx, const vdo_orb_params* prm, int w, in
   o->ncells = (int)o->cells.size();
   // fused pyramid: possible when there are at most 8 levels and every cascaded region fits the LDS buffers
   if (NL <= 8 && !std::getenv("VDO_ORB_PYRAMID_LAUNCHES")) {
+    // Two cascades: levels [0, split] from the source image, levels (split, NL) from level `split` - a tile of the top level
+    // would otherwise recompute a ~140 x 140 source window through seven levels (58 us for the one-launch form, 8 launches x
+    // ~6 us level by level; two launches: the deepest cascade is four levels)
+    const int split = NL > 5 ? 4 : NL - 1;
     PyrDesc& P = o->pyr;
-    P.n_levels = NL;
-    int tot = 0;
+    P.n_levels = NL; P.base = 0; P.lv0 = 0; P.lv1 = split + 1;
     for (int l = 0; l < NL; ++l) {
       P.w[l] = o->levels[l].w; P.h[l] = o->levels[l].h;
       P.sx[l] = l ? 1. / ((double)o->levels[l].w / o->levels[l - 1].w) : 1.0;
       P.sy[l] = l ? 1. / ((double)o->levels[l].h / o->levels[l - 1].h) : 1.0;
-      P.tile_off[l] = tot; P.tiles_x[l] = (P.w[l] + 31) / 32;
-      tot += P.tiles_x[l] * ((P.h[l] + 31) / 32);
+      P.tiles_x[l] = (P.w[l] + 31) / 32;
     }
-    P.tile_off[NL] = tot;
+    PyrDesc& Q = o->pyr2;
+    Q = P;
+    Q.base = split; Q.lv0 = split + 1; Q.lv1 = NL;
+    for (PyrDesc* D : {&P, &Q}) {
+      int tot = 0;
+      for (int l = 0; l <= NL; ++l) D->tile_off[l] = 0;
+      for (int l = D->lv0; l < D->lv1; ++l) { D->tile_off[l] = tot; tot += D->tiles_x[l] * ((D->h[l] + 31) / 32); }
+      for (int l = D->lv1; l <= NL; ++l) D->tile_off[l] = tot;
+    }
     // widest region any tile needs at any level below it: the kernel's own cascade (same arithmetic) over every tile column / row
     auto src_range = [](int d0, int d1, double scale, int slen, bool clamp_both, int& s0, int& s1) {
       auto tap = [&](int d, int& lo, int& hi) {
@@ -745,16 +758,18 @@ extern "C" int vdo_orb_create(vdo_ctx* ctx, const vdo_orb_params* prm, int w, in
       tap(d0, s0, a); tap(d1, b, s1);
     };
     int worst = 32;
-    for (int l = 1; l < NL; ++l) {
-      for (int axis = 0; axis < 2; ++axis) {
-        const int len = axis ? P.h[l] : P.w[l];
-        for (int t0 = 0; t0 < len; t0 += 32) {
-          int d0 = t0, d1 = std::min(t0 + 31, len - 1);
-          for (int k = l; k > 0; --k) {
-            int s0, s1;
-            src_range(d0, d1, axis ? P.sy[k] : P.sx[k], axis ? P.h[k - 1] : P.w[k - 1], axis == 1, s0, s1);
-            d0 = s0; d1 = s1;
-            worst = std::max(worst, d1 - d0 + 1);
+    for (const PyrDesc* D : {&P, &Q}) {
+      for (int l = std::max(D->lv0, D->base + 1); l < D->lv1; ++l) {
+        for (int axis = 0; axis < 2; ++axis) {
+          const int len = axis ? D->h[l] : D->w[l];
+          for (int t0 = 0; t0 < len; t0 += 32) {
+            int d0 = t0, d1 = std::min(t0 + 31, len - 1);
+            for (int k = l; k > D->base; --k) {
+              int s0, s1;
+              src_range(d0, d1, axis ? D->sy[k] : D->sx[k], axis ? D->h[k - 1] : D->w[k - 1], axis == 1, s0, s1);
+              d0 = s0; d1 = s1;
+              worst = std::max(worst, d1 - d0 + 1);
+            }
           }
         }
       }
@@ -818,6 +833,10 @@ static int orb_device_stage(vdo_orb* o, const uint8_t* gray_dev, int stride) {
   const dim3 tb(32, 8);
   if (o->pyr.n_levels) {
     hipLaunchKernelGGL(k_pyramid_all, dim3(o->pyr.tile_off[o->pyr.n_levels]), dim3(256), 0, s, gray_dev, stride, o->pyr, (const LevelDesc*)o->d_levels, o->d_pyr);
+    if (o->pyr2.lv1 > o->pyr2.lv0) {
+      const LevelDesc& B = o->levels[o->pyr2.base];
+      hipLaunchKernelGGL(k_pyramid_all, dim3(o->pyr2.tile_off[o->pyr2.n_levels]), dim3(256), 0, s, (const uint8_t*)(o->d_pyr + B.off_inner), B.bw, o->pyr2, (const LevelDesc*)o->d_levels, o->d_pyr);
+    }
   } else {
     {
       const LevelDesc& L = o->levels[0];

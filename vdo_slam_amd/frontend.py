@@ -114,7 +114,7 @@ class ORBextractor:
         return ms[0], ms[1]
 
     def pyramid_launches(self):
-        """Kernel launches per pyramid: 1 (fused) or the number of levels."""
+        """Kernel launches per pyramid: 2 / 1 (cascaded in LDS) or the number of levels."""
         L = _lib()
         L.vdo_orb_pyramid_launches.argtypes = [C.c_void_p]
         return int(L.vdo_orb_pyramid_launches(self._h))
