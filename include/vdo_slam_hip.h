@@ -356,6 +356,13 @@ int vdo_sample_keypoints(int rows, int cols, uint64_t seed, int capacity, float*
 int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, int step, int cap,
                             float* key_x, float* key_y, float* corr_x, float* corr_y,
                             float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_out);
+/* K9 + K10 of one image in one call and ONE synchronisation (Frame::Frame runs them back to back: src/Frame.cc:104-131 / 132-166,
+ * 168-199): the arguments of vdo_frame_static_filter[_sampled] (sampled != 0: the UseSampleFeature branch) followed by those of
+ * vdo_frame_object_sample (host outputs required). */
+int vdo_frame_filters(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth, int sampled,
+                      int32_t* keep_idx, float* s_corr_x, float* s_corr_y, float* s_flow_x, float* s_flow_y, float* s_depth, int* n_static,
+                      float th_depth_obj, int step, int cap,
+                      float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_obj);
 
 /* ---- Tracking-side gathers over the resident images ------------
  * All coordinate arrays are host pointers (the reference keeps them in std::vector<cv::KeyPoint>). */

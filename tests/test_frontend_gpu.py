@@ -105,4 +105,11 @@ def test_depth_gray_and_frame_kernels_match_oracle(ctx, oracle):
     assert a["label"].size > 100
     for k in b:
         assert np.array_equal(a[k], b[k]), k
+    # K9 + K10 in one call (one synchronisation, separate scratch sets): the same results
+    st, ob = fi.filters(kp["x"], kp["y"], TH_DEPTH_BG, TH_DEPTH_OBJ)
+    sref = R.static_filter(oracle, kp["x"], kp["y"], kp["octave"], fr["mask"], d_ref, fr["flow"], TH_DEPTH_BG)
+    for k in sref:
+        assert np.array_equal(st[k], sref[k]), k
+    for k in b:
+        assert np.array_equal(ob[k], b[k]), k
     fi.close(); orb.close()

@@ -144,6 +144,7 @@ extern "C" int vdo_frame_images_destroy(vdo_frame_images* f) {
   if (f->ctx) ctx_bind(f->ctx);
   for (void* p : f->allocs) hipFree(p);
   if (f->h_pin) hipHostFree(f->h_pin);
+  if (f->h_pin2) hipHostFree(f->h_pin2);
   delete f;
   return VDO_OK;
 }
@@ -172,11 +173,13 @@ extern "C" int vdo_frame_images_create(vdo_ctx* ctx, int w, int h, vdo_frame_ima
     f->d_i[1] = (int32_t*)(f->d_rows + (size_t)9 * f->cap);
   }
   if (hipHostMalloc((void**)&f->h_pin, 4 * ((size_t)f->cap * 8 + 16)) != hipSuccess) f->h_pin = nullptr;
+  if (hipHostMalloc((void**)&f->h_pin2, 4 * ((size_t)f->cap * 8 + 16)) != hipSuccess) f->h_pin2 = nullptr;
+  f->d_rows2 = (float*)dev(4 * (size_t)f->cap * 8); f->d_cnt2 = (int*)dev(16);
   f->d_cnt = (int*)dev(16); f->d_blk = (int*)dev(4 * ((size_t)f->cap / 256 + 2));
   f->d_cand = (unsigned long long*)dev(8 * np);
   if (f->d_cand) hipMemsetAsync(f->d_cand, 0, 8 * np, ctx->stream);
   for (void* p : f->allocs) if (!p) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
-  if (!f->d_blk || !f->h_pin) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
+  if (!f->d_blk || !f->h_pin || !f->h_pin2) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
   *out = f;
   return VDO_OK;
 }
@@ -258,13 +261,7 @@ extern "C" int vdo_sample_keypoints(int rows, int cols, uint64_t seed, int capac
   return VDO_OK;
 }
 
-static int static_filter_impl(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth, int sampled,
-                              int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int* n_out) {
-  if (!f || !n_out || n < 0 || 10 * (size_t)n > 8 * (size_t)f->cap) return set_error(VDO_ERR_INVALID, "bad argument / too many keypoints for the staging buffer");
-  *n_out = 0;
-  if (n == 0) return VDO_OK;
-  int rc = ctx_bind(f->ctx);
-  if (rc != VDO_OK) return rc;
+static int static_filter_enqueue(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth, int sampled) {
   hipStream_t s = f->ctx->stream;
   // inputs: kx|ky -> pinned -> rows 8,9 in one strided H2D; outputs: rows 0..7 (5 float rows, 2 unused, idx) x n in one
   // strided D2H next to the count (m <= n is only known after the kernel): 1 sync, no pageable copies.
@@ -277,43 +274,58 @@ static int static_filter_impl(vdo_frame_images* f, int n, const float* kx, const
   float* stage = pin + 2 * (size_t)n;          // behind the inputs (the H2D above is stream-ordered before the D2H)
   hipMemcpyAsync(pcnt, f->d_cnt, 4, hipMemcpyDeviceToHost, s);
   hipMemcpy2DAsync(stage, 4 * (size_t)n, f->d_rows, 4 * (size_t)f->cap, 4 * (size_t)n, 8, hipMemcpyDeviceToHost, s);
-  if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "static filter failed: %s", hipGetErrorString(hipGetLastError()));
-  const int m = *pcnt;
+  return VDO_OK;
+}
+static void static_filter_collect(vdo_frame_images* f, int n, int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int* n_out) {
+  float* pin = f->h_pin;
+  const int m = *(int*)(pin + (size_t)8 * f->cap);
+  float* stage = pin + 2 * (size_t)n;
   *n_out = m;
   if (m) {
     float* dst[5] = {corr_x, corr_y, flow_x, flow_y, depth_out};
     for (int k = 0; k < 5; ++k) std::memcpy(dst[k], stage + (size_t)k * n, 4 * (size_t)m);
     std::memcpy(keep_idx, stage + (size_t)7 * n, 4 * (size_t)m);
   }
+}
+static int static_filter_impl(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth, int sampled,
+                              int32_t* keep_idx, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int* n_out) {
+  if (!f || !n_out || n < 0 || 10 * (size_t)n > 8 * (size_t)f->cap) return set_error(VDO_ERR_INVALID, "bad argument / too many keypoints for the staging buffer");
+  *n_out = 0;
+  if (n == 0) return VDO_OK;
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  static_filter_enqueue(f, n, kx, ky, th_depth, sampled);
+  if (hipStreamSynchronize(f->ctx->stream) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "static filter failed: %s", hipGetErrorString(hipGetLastError()));
+  static_filter_collect(f, n, keep_idx, corr_x, corr_y, flow_x, flow_y, depth_out, n_out);
   return VDO_OK;
 }
 
 // device-only variant used by the per-frame pipeline / bench: results stay in HBM, count is returned
-extern "C" int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, int step, int cap,
-                                       float* key_x, float* key_y, float* corr_x, float* corr_y,
-                                       float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_out) {
-  if (!f || !n_out || step <= 0) return set_error(VDO_ERR_INVALID, "bad argument");
-  int rc = ctx_bind(f->ctx);
-  if (rc != VDO_OK) return rc;
+constexpr int kObjSpec = 8192;     // columns of the 8 result rows that come back with the count (a second copy only if more were kept)
+static int object_sample_enqueue(vdo_frame_images* f, float th_depth_obj, int step, bool want_host, float* rows, int* cnt, float* pin) {
   hipStream_t s = f->ctx->stream;
   const int ncol = (f->w + step - 1) / step, nrow = (f->h + step - 1) / step, nprobe = ncol * nrow;
   const int nblk = (nprobe + 255) / 256;
   if (nprobe > f->cap) return set_error(VDO_ERR_INVALID, "sampling step too small for the scratch capacity");
+  const size_t C = (size_t)f->cap;
   hipLaunchKernelGGL(k_obj_count, dim3(nblk), dim3(256), 0, s, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, th_depth_obj, step, ncol, nprobe, f->d_blk);
-  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, f->d_blk, nblk, f->d_cnt);
+  hipLaunchKernelGGL(k_scan_blocks, dim3(1), dim3(1024), 0, s, f->d_blk, nblk, cnt);
   hipLaunchKernelGGL(k_obj_scatter, dim3(nblk), dim3(256), 0, s, (const int32_t*)f->d_mask, (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, th_depth_obj, step, ncol, nprobe,
-                     (const int*)f->d_blk, f->cap, f->d_f[0], f->d_f[1], f->d_f[2], f->d_f[3], f->d_f[4], f->d_f[5], f->d_f[6], f->d_i[0]);
-  // count + the first kSpec columns of the 8 result rows in one go (pinned); a second strided copy only if m > kSpec
-  constexpr int kSpec = 8192;
-  float* pin = f->h_pin;
+                     (const int*)f->d_blk, f->cap, rows, rows + C, rows + 2 * C, rows + 3 * C, rows + 4 * C, rows + 5 * C, rows + 6 * C, (int32_t*)(rows + 7 * C));
+  // count + the first kObjSpec columns of the 8 result rows in one go (pinned); a second strided copy only if m > kObjSpec
   int* pcnt = (int*)(pin + (size_t)8 * f->cap);
-  const int spec = key_x ? std::min(kSpec, f->cap) : 0;
-  hipMemcpyAsync(pcnt, f->d_cnt, 4, hipMemcpyDeviceToHost, s);
-  if (spec) hipMemcpy2DAsync(pin, 4 * (size_t)spec, f->d_rows, 4 * (size_t)f->cap, 4 * (size_t)spec, 8, hipMemcpyDeviceToHost, s);
-  if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "object sampling failed: %s", hipGetErrorString(hipGetLastError()));
-  const int m = *pcnt;
+  const int spec = want_host ? std::min(kObjSpec, f->cap) : 0;
+  hipMemcpyAsync(pcnt, cnt, 4, hipMemcpyDeviceToHost, s);
+  if (spec) hipMemcpy2DAsync(pin, 4 * (size_t)spec, rows, 4 * C, 4 * (size_t)spec, 8, hipMemcpyDeviceToHost, s);
+  return VDO_OK;
+}
+static int object_sample_collect(vdo_frame_images* f, int cap, float* rows, float* pin, float* key_x, float* key_y, float* corr_x, float* corr_y,
+                                 float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_out) {
+  hipStream_t s = f->ctx->stream;
+  const int m = *(int*)(pin + (size_t)8 * f->cap);
   *n_out = m;
   if (key_x) {   // host outputs requested
+    const int spec = std::min(kObjSpec, f->cap);
     if (m > cap) return set_error(VDO_ERR_INVALID, "object sampling: %d points exceed the output capacity %d", m, cap);
     float* dst[7] = {key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out};
     const int m0 = std::min(m, spec);
@@ -321,11 +333,40 @@ extern "C" int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, 
     if (label && m0) std::memcpy(label, pin + (size_t)7 * spec, 4 * (size_t)m0);
     if (m > spec) {
       const int r = m - spec;
-      hipMemcpy2DAsync(pin, 4 * (size_t)r, f->d_rows + spec, 4 * (size_t)f->cap, 4 * (size_t)r, 8, hipMemcpyDeviceToHost, s);
+      hipMemcpy2DAsync(pin, 4 * (size_t)r, rows + spec, 4 * (size_t)f->cap, 4 * (size_t)r, 8, hipMemcpyDeviceToHost, s);
       if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "object sampling D2H failed");
       for (int k = 0; k < 7; ++k) if (dst[k]) std::memcpy(dst[k] + spec, pin + (size_t)k * r, 4 * (size_t)r);
       if (label) std::memcpy(label + spec, pin + (size_t)7 * r, 4 * (size_t)r);
     }
   }
   return VDO_OK;
+}
+extern "C" int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, int step, int cap,
+                                       float* key_x, float* key_y, float* corr_x, float* corr_y,
+                                       float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_out) {
+  if (!f || !n_out || step <= 0) return set_error(VDO_ERR_INVALID, "bad argument");
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  rc = object_sample_enqueue(f, th_depth_obj, step, key_x != nullptr, f->d_rows, f->d_cnt, f->h_pin);
+  if (rc != VDO_OK) return rc;
+  if (hipStreamSynchronize(f->ctx->stream) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "object sampling failed: %s", hipGetErrorString(hipGetLastError()));
+  return object_sample_collect(f, cap, f->d_rows, f->h_pin, key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out, label, n_out);
+}
+
+// K9 + K10 of one image with ONE synchronisation: the two results use separate scratch sets, so both pipelines are queued
+// back to back (Frame::Frame runs them back to back too: src/Frame.cc:104-131, 168-199).
+extern "C" int vdo_frame_filters(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth, int sampled,
+                                 int32_t* keep_idx, float* s_corr_x, float* s_corr_y, float* s_flow_x, float* s_flow_y, float* s_depth, int* n_static,
+                                 float th_depth_obj, int step, int cap,
+                                 float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_obj) {
+  if (!f || !n_static || !n_obj || n < 0 || step <= 0 || !key_x || 10 * (size_t)n > 8 * (size_t)f->cap) return set_error(VDO_ERR_INVALID, "vdo_frame_filters: bad argument");
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  *n_static = 0;
+  if (n) static_filter_enqueue(f, n, kx, ky, th_depth, sampled);
+  rc = object_sample_enqueue(f, th_depth_obj, step, true, f->d_rows2, f->d_cnt2, f->h_pin2);
+  if (rc != VDO_OK) return rc;
+  if (hipStreamSynchronize(f->ctx->stream) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "frame filters failed: %s", hipGetErrorString(hipGetLastError()));
+  if (n) static_filter_collect(f, n, keep_idx, s_corr_x, s_corr_y, s_flow_x, s_flow_y, s_depth, n_static);
+  return object_sample_collect(f, cap, f->d_rows2, f->h_pin2, key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out, label, n_obj);
 }

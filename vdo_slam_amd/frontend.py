@@ -222,6 +222,29 @@ class FrameImages:
         out["label"] = lab[:m]
         return out
 
+    def filters(self, kx, ky, th_depth, th_depth_obj, step=4, sampled=False):
+        """K9 + K10 in one call / one synchronisation: (static_filter dict, object_sample dict)."""
+        kx = np.ascontiguousarray(kx, dtype=np.float32); ky = np.ascontiguousarray(ky, dtype=np.float32)
+        n = kx.size
+        idx = np.zeros(max(n, 1), np.int32); sf = [np.zeros(max(n, 1), np.float32) for _ in range(5)]
+        cap = ((self.w + step - 1) // step) * ((self.h + step - 1) // step)
+        f = [np.zeros(cap, np.float32) for _ in range(7)]
+        lab = np.zeros(cap, np.int32)
+        ms, mo = C.c_int(), C.c_int()
+        L = _lib()
+        fp, ip = K.c_float_p, K.c_int32_p
+        L.vdo_frame_filters.argtypes = [C.c_void_p, C.c_int, fp, fp, C.c_float, C.c_int, ip, fp, fp, fp, fp, fp, C.POINTER(C.c_int),
+                                        C.c_float, C.c_int, C.c_int, fp, fp, fp, fp, fp, fp, fp, ip, C.POINTER(C.c_int)]
+        K.check(L.vdo_frame_filters(self._h, n, _fp(kx), _fp(ky), th_depth, int(bool(sampled)), _ip(idx), *[_fp(a) for a in sf], C.byref(ms),
+                                    th_depth_obj, step, cap, *[_fp(a) for a in f], _ip(lab), C.byref(mo)))
+        m = ms.value
+        st = dict(keep_idx=idx[:m], corr_x=sf[0][:m], corr_y=sf[1][:m], flow_x=sf[2][:m], flow_y=sf[3][:m], depth=sf[4][:m])
+        m = mo.value
+        names = ("key_x", "key_y", "corr_x", "corr_y", "flow_x", "flow_y", "depth")
+        ob = {k: a[:m] for k, a in zip(names, f)}
+        ob["label"] = lab[:m]
+        return st, ob
+
     def close(self):
         if self._h:
             _lib().vdo_frame_images_destroy(self._h); self._h = C.c_void_p()

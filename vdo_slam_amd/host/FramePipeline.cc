@@ -244,12 +244,13 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     if (orb_join() != 0) return -1;
     keep.resize(std::max(kp.n, 1));
     for (int k = 2; k < 7; ++k) f_[k].resize(std::max(kp.n, 1));
-    VDO_TRY((p_.use_sample_feature ? vdo_frame_static_filter_sampled : vdo_frame_static_filter)(cur, kp.n, kx_.data(), ky_.data(), p_.th_depth_bg, keep.data(), f_[2].data(), f_[3].data(),
-                                                                                                  f_[4].data(), f_[5].data(), f_[6].data(), &n_new_s));
-    fc.n_static_new = n_new_s;
     const int cap_s = ((W + 3) / 4) * ((H + 3) / 4);
     tmp.x.resize(cap_s); tmp.y.resize(cap_s); tmp.cx.resize(cap_s); tmp.cy.resize(cap_s); tmp.fx.resize(cap_s); tmp.fy.resize(cap_s); tmp.d.resize(cap_s); tmp.sem.resize(cap_s);
-    VDO_TRY(vdo_frame_object_sample(cur, p_.th_depth_obj, 4, cap_s, tmp.x.data(), tmp.y.data(), tmp.cx.data(), tmp.cy.data(), tmp.fx.data(), tmp.fy.data(), tmp.d.data(), tmp.sem.data(), &n_tmp));
+    // K9 + K10 of the new image: one call, one synchronisation
+    VDO_TRY(vdo_frame_filters(cur, kp.n, kx_.data(), ky_.data(), p_.th_depth_bg, p_.use_sample_feature ? 1 : 0, keep.data(), f_[2].data(), f_[3].data(),
+                              f_[4].data(), f_[5].data(), f_[6].data(), &n_new_s,
+                              p_.th_depth_obj, 4, cap_s, tmp.x.data(), tmp.y.data(), tmp.cx.data(), tmp.cy.data(), tmp.fx.data(), tmp.fy.data(), tmp.d.data(), tmp.sem.data(), &n_tmp));
+    fc.n_static_new = n_new_s;
     fc.n_object_samples = n_tmp;
     return 0;
   };
