@@ -31,6 +31,11 @@ import time
 
 import numpy as np
 
+# polling waits instead of interrupt-driven ones (read by the HSA runtime when torch brings HIP up, so it has to be set here):
+# a wait that falls asleep is woken 4-9 ms late now and then on the virtualised GPU hosts - one frame in ~100 took 8 ms
+# (vdo_slam_amd/csrc/capi_ctx.hip has the same default for hosts where libvdo_hip is what starts HIP)
+os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
@@ -277,10 +282,20 @@ def main():
                     raise r.err
         all_run(0, args.warmup, False)
         barrier()
+
+        def _throttled():
+            try:
+                return {k: int(v) for k, v in (l.split() for l in open("/sys/fs/cgroup/cpu.stat")) if k in ("nr_throttled", "throttled_usec", "usage_usec")}
+            except (OSError, ValueError):
+                return {}
+        thr0 = _throttled() if os.environ.get("VDO_BENCH_DUMP_STEPS") else None
         t0 = time.perf_counter()
         all_run(args.warmup, args.steps, True)        # the sequence continues where the warm-up left it
         barrier()
         dt = time.perf_counter() - t0
+        if thr0 is not None:                          # (debug: CPU-quota throttling and CPU seconds inside the timed region)
+            thr1 = _throttled()
+            print("cgroup cpu.stat delta over the timed region:", {k: thr1.get(k, 0) - thr0.get(k, 0) for k in thr1}, "wall_us", int(dt * 1e6), file=sys.stderr)
         tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared_gpu else "cuda")
         if use_dist:
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -292,6 +307,8 @@ def main():
     n_all = args.steps + args.warmup
     pipe = reps[0].pipe
     counts, agg, step_ms = pipe.counts, reps[0].agg, reps[0].step_ms
+    if os.environ.get("VDO_BENCH_DUMP_STEPS"):              # (debug: where the slow steps of a run are)
+        print("step_ms:", " ".join(f"{v:.2f}" for v in step_ms), file=sys.stderr)
     sect = pipe.section_ms()
     k_last = (n_all - 1) % n_seq
     Tcw = pipe.pose().astype(np.float64)

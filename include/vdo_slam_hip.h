@@ -363,6 +363,12 @@ int vdo_frame_filters(vdo_frame_images* f, int n, const float* kx, const float* 
                       int32_t* keep_idx, float* s_corr_x, float* s_corr_y, float* s_flow_x, float* s_flow_y, float* s_depth, int* n_static,
                       float th_depth_obj, int step, int cap,
                       float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_obj);
+/* The same on the stream of `on_ctx` instead of the image set's own context (NULL: the latter): for a caller that runs K9 / K10 on a
+ * second host thread while the owning thread keeps using the image set (the scratch of this call is used by nothing else). */
+int vdo_frame_filters_on(vdo_ctx* on_ctx, vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth, int sampled,
+                         int32_t* keep_idx, float* s_corr_x, float* s_corr_y, float* s_flow_x, float* s_flow_y, float* s_depth, int* n_static,
+                         float th_depth_obj, int step, int cap,
+                         float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_obj);
 
 /* ---- Tracking-side gathers over the resident images ------------
  * All coordinate arrays are host pointers (the reference keeps them in std::vector<cv::KeyPoint>). */

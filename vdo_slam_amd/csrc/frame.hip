@@ -261,8 +261,7 @@ extern "C" int vdo_sample_keypoints(int rows, int cols, uint64_t seed, int capac
   return VDO_OK;
 }
 
-static int static_filter_enqueue(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth, int sampled) {
-  hipStream_t s = f->ctx->stream;
+static int static_filter_enqueue(vdo_frame_images* f, hipStream_t s, int n, const float* kx, const float* ky, float th_depth, int sampled) {
   // inputs: kx|ky -> pinned -> rows 8,9 in one strided H2D; outputs: rows 0..7 (5 float rows, 2 unused, idx) x n in one
   // strided D2H next to the count (m <= n is only known after the kernel): 1 sync, no pageable copies.
   float* pin = f->h_pin;
@@ -294,7 +293,7 @@ static int static_filter_impl(vdo_frame_images* f, int n, const float* kx, const
   if (n == 0) return VDO_OK;
   int rc = ctx_bind(f->ctx);
   if (rc != VDO_OK) return rc;
-  static_filter_enqueue(f, n, kx, ky, th_depth, sampled);
+  static_filter_enqueue(f, f->ctx->stream, n, kx, ky, th_depth, sampled);
   if (hipStreamSynchronize(f->ctx->stream) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "static filter failed: %s", hipGetErrorString(hipGetLastError()));
   static_filter_collect(f, n, keep_idx, corr_x, corr_y, flow_x, flow_y, depth_out, n_out);
   return VDO_OK;
@@ -302,8 +301,7 @@ static int static_filter_impl(vdo_frame_images* f, int n, const float* kx, const
 
 // device-only variant used by the per-frame pipeline / bench: results stay in HBM, count is returned
 constexpr int kObjSpec = 8192;     // columns of the 8 result rows that come back with the count (a second copy only if more were kept)
-static int object_sample_enqueue(vdo_frame_images* f, float th_depth_obj, int step, bool want_host, float* rows, int* cnt, float* pin) {
-  hipStream_t s = f->ctx->stream;
+static int object_sample_enqueue(vdo_frame_images* f, hipStream_t s, float th_depth_obj, int step, bool want_host, float* rows, int* cnt, float* pin) {
   const int ncol = (f->w + step - 1) / step, nrow = (f->h + step - 1) / step, nprobe = ncol * nrow;
   const int nblk = (nprobe + 255) / 256;
   if (nprobe > f->cap) return set_error(VDO_ERR_INVALID, "sampling step too small for the scratch capacity");
@@ -319,9 +317,8 @@ static int object_sample_enqueue(vdo_frame_images* f, float th_depth_obj, int st
   if (spec) hipMemcpy2DAsync(pin, 4 * (size_t)spec, rows, 4 * C, 4 * (size_t)spec, 8, hipMemcpyDeviceToHost, s);
   return VDO_OK;
 }
-static int object_sample_collect(vdo_frame_images* f, int cap, float* rows, float* pin, float* key_x, float* key_y, float* corr_x, float* corr_y,
+static int object_sample_collect(vdo_frame_images* f, hipStream_t s, int cap, float* rows, float* pin, float* key_x, float* key_y, float* corr_x, float* corr_y,
                                  float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_out) {
-  hipStream_t s = f->ctx->stream;
   const int m = *(int*)(pin + (size_t)8 * f->cap);
   *n_out = m;
   if (key_x) {   // host outputs requested
@@ -347,26 +344,37 @@ extern "C" int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, 
   if (!f || !n_out || step <= 0) return set_error(VDO_ERR_INVALID, "bad argument");
   int rc = ctx_bind(f->ctx);
   if (rc != VDO_OK) return rc;
-  rc = object_sample_enqueue(f, th_depth_obj, step, key_x != nullptr, f->d_rows, f->d_cnt, f->h_pin);
+  rc = object_sample_enqueue(f, f->ctx->stream, th_depth_obj, step, key_x != nullptr, f->d_rows, f->d_cnt, f->h_pin);
   if (rc != VDO_OK) return rc;
   if (hipStreamSynchronize(f->ctx->stream) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "object sampling failed: %s", hipGetErrorString(hipGetLastError()));
-  return object_sample_collect(f, cap, f->d_rows, f->h_pin, key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out, label, n_out);
+  return object_sample_collect(f, f->ctx->stream, cap, f->d_rows, f->h_pin, key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out, label, n_out);
 }
 
 // K9 + K10 of one image with ONE synchronisation: the two results use separate scratch sets, so both pipelines are queued
 // back to back (Frame::Frame runs them back to back too: src/Frame.cc:104-131, 168-199).
+// (on_ctx: the stream / device binding to use instead of the image set's own context - a caller that runs this on a second host
+// thread while the owning thread keeps using the image set; the two scratch sets used here are not touched by anything else)
+extern "C" int vdo_frame_filters_on(vdo_ctx* on_ctx, vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth, int sampled,
+                                    int32_t* keep_idx, float* s_corr_x, float* s_corr_y, float* s_flow_x, float* s_flow_y, float* s_depth, int* n_static,
+                                    float th_depth_obj, int step, int cap,
+                                    float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_obj) {
+  if (!f || !n_static || !n_obj || n < 0 || step <= 0 || !key_x || 10 * (size_t)n > 8 * (size_t)f->cap) return set_error(VDO_ERR_INVALID, "vdo_frame_filters: bad argument");
+  vdo_ctx* c = on_ctx ? on_ctx : f->ctx;
+  int rc = ctx_bind(c);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = c->stream;
+  *n_static = 0;
+  if (n) static_filter_enqueue(f, s, n, kx, ky, th_depth, sampled);
+  rc = object_sample_enqueue(f, s, th_depth_obj, step, true, f->d_rows2, f->d_cnt2, f->h_pin2);
+  if (rc != VDO_OK) return rc;
+  if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "frame filters failed: %s", hipGetErrorString(hipGetLastError()));
+  if (n) static_filter_collect(f, n, keep_idx, s_corr_x, s_corr_y, s_flow_x, s_flow_y, s_depth, n_static);
+  return object_sample_collect(f, s, cap, f->d_rows2, f->h_pin2, key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out, label, n_obj);
+}
 extern "C" int vdo_frame_filters(vdo_frame_images* f, int n, const float* kx, const float* ky, float th_depth, int sampled,
                                  int32_t* keep_idx, float* s_corr_x, float* s_corr_y, float* s_flow_x, float* s_flow_y, float* s_depth, int* n_static,
                                  float th_depth_obj, int step, int cap,
                                  float* key_x, float* key_y, float* corr_x, float* corr_y, float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_obj) {
-  if (!f || !n_static || !n_obj || n < 0 || step <= 0 || !key_x || 10 * (size_t)n > 8 * (size_t)f->cap) return set_error(VDO_ERR_INVALID, "vdo_frame_filters: bad argument");
-  int rc = ctx_bind(f->ctx);
-  if (rc != VDO_OK) return rc;
-  *n_static = 0;
-  if (n) static_filter_enqueue(f, n, kx, ky, th_depth, sampled);
-  rc = object_sample_enqueue(f, th_depth_obj, step, true, f->d_rows2, f->d_cnt2, f->h_pin2);
-  if (rc != VDO_OK) return rc;
-  if (hipStreamSynchronize(f->ctx->stream) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "frame filters failed: %s", hipGetErrorString(hipGetLastError()));
-  if (n) static_filter_collect(f, n, keep_idx, s_corr_x, s_corr_y, s_flow_x, s_flow_y, s_depth, n_static);
-  return object_sample_collect(f, cap, f->d_rows2, f->h_pin2, key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out, label, n_obj);
+  return vdo_frame_filters_on(nullptr, f, n, kx, ky, th_depth, sampled, keep_idx, s_corr_x, s_corr_y, s_flow_x, s_flow_y, s_depth, n_static,
+                              th_depth_obj, step, cap, key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out, label, n_obj);
 }

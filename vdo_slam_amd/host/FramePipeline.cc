@@ -7,6 +7,7 @@
 #include <cmath>
 #include <cstdio>
 #include <atomic>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <stdexcept>
@@ -88,6 +89,8 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
   }
   if (ctx_worker) worker_.reset(new Worker());
   if (ctx_worker && ctx_orb) worker_orb_.reset(new Worker());
+  ctx_orb_ = ctx_orb;
+  spec_enabled_ = std::getenv("VDO_PIPE_SPEC_FILTERS") != nullptr;      // (measured: no gain over running them behind UpdateMask - opt-in)
   orb_split_ = ctx_orb != nullptr;
   ok_ = true;
 }
@@ -121,34 +124,81 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   if (!ok_) return -1;
   FrameCounts fc{};
   auto t_prev = std::chrono::steady_clock::now();
+  const auto t_step0 = t_prev;
+  double ms0[12];
+  for (int i = 0; i < 12; ++i) ms0[i] = ms_[i];
+  static const bool trace_slow = std::getenv("VDO_PIPE_TRACE_SLOW") != nullptr;    // (debug: the sections of a step that took > 2.5 ms)
   auto tick = [&](int slot) { const auto t = std::chrono::steady_clock::now(); ms_[slot] += std::chrono::duration<double, std::milli>(t - t_prev).count(); t_prev = t; };
   vdo_frame_images *cur = img_[cur_], *last = img_[cur_ ^ 1];
   const int W = p_.width, H = p_.height;
   struct Join { Worker* w; ~Join() { if (w) w->wait(); } } join_guard{worker_.get()};      // never leave Step with the helper thread on its locals
   // ---- ORB (K3-K7) needs only the grey image: with a stream of its own its device stage starts now, under the camera stage
   vdo_keypoints kp{(int32_t)kx_.size(), 0, kx_.data(), ky_.data(), kr_.data(), ka_.data(), ks_.data(), ko_.data()};
+  // K9 + K10 of the new image: only RenewFrameInfo needs them
+  int n_new_s = 0, n_tmp = 0;
+  std::vector<int32_t>& keep = i_[1];
+  ObjSet& tmp = tmpb_[cur_];                            // K10: semi-dense sampling of this image (mvTmpObj*)
+  bool spec_done = false;                               // K9 / K10 ran ahead of UpdateMask (ORB thread)
+  auto run_filters = [&](vdo_ctx* on) -> int {
+    keep.resize(std::max(kp.n, 1));
+    for (int k = 2; k < 7; ++k) f_[k].resize(std::max(kp.n, 1));
+    const int cap_s = ((W + 3) / 4) * ((H + 3) / 4);
+    tmp.x.resize(cap_s); tmp.y.resize(cap_s); tmp.cx.resize(cap_s); tmp.cy.resize(cap_s); tmp.fx.resize(cap_s); tmp.fy.resize(cap_s); tmp.d.resize(cap_s); tmp.sem.resize(cap_s);
+    // one call, one synchronisation
+    VDO_TRY(vdo_frame_filters_on(on, cur, kp.n, kx_.data(), ky_.data(), p_.th_depth_bg, p_.use_sample_feature ? 1 : 0, keep.data(), f_[2].data(), f_[3].data(),
+                                 f_[4].data(), f_[5].data(), f_[6].data(), &n_new_s,
+                                 p_.th_depth_obj, 4, cap_s, tmp.x.data(), tmp.y.data(), tmp.cx.data(), tmp.cy.data(), tmp.fx.data(), tmp.fy.data(), tmp.d.data(), tmp.sem.data(), &n_tmp));
+    return 0;
+  };
+  auto spec_filters = [&]() -> int {
+    const auto t0 = std::chrono::steady_clock::now();
+    const int rc = run_filters(ctx_orb_);
+    ms_[2] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    spec_done = rc == 0;
+    return rc;
+  };
   // (with a thread of its own the whole extraction - device stage, quadtrees, angles - leaves the main thread: nothing before the
   // static stage reads a keypoint)
   Join join_orb{nullptr};                                // declared after kp: joined before kp goes away on every path out of Step
-  bool orb_pending = false;
-  if (worker_orb_ && !p_.use_sample_feature) {
-    worker_orb_->run([this, &kp, d_gray, W]() -> int {
+  const int tag = f_id_ + 1;
+  // (destroyed BEFORE join_orb: whatever way Step is left, the ORB thread's waits below end)
+  struct Release {
+    std::atomic<int>*img, *obj; int tag;
+    ~Release() { if (img->load() != tag) img->store(tag); const int v = obj->load(); if (v != tag && v != -tag) obj->store(-tag); }
+  } release{&images_ready_, &objects_done_, tag};
+  const bool orb_pending = worker_orb_ && !p_.use_sample_feature;
+  const bool tail_via_orb = orb_pending && pending_ && worker_;     // its job ends with the tail of the last frame's object stage
+  if (orb_pending) {
+    worker_orb_->run([this, &kp, &spec_filters, &fc, d_gray, W, tag, tail_via_orb]() -> int {
       const auto t0 = std::chrono::steady_clock::now();
-      const int rc = vdo_orb_extract(orb_, d_gray, W, host_inputs_ ? 0 : 1, &kp);
+      int rc = vdo_orb_extract(orb_, d_gray, W, host_inputs_ ? 0 : 1, &kp) == VDO_OK ? 0 : -1;
       ms_[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-      if (rc != VDO_OK) { std::fprintf(stderr, "FramePipeline: %s\n", vdo_last_error()); return -1; }
-      return 0;
+      if (rc != 0) std::fprintf(stderr, "FramePipeline: %s\n", vdo_last_error());
+      // (opt-in, VDO_PIPE_SPEC_FILTERS) K9 + K10 read the mask UpdateMask may still repair - it rarely does (a mask missing from the
+      // segmentation), so they can run here, ahead of it, and be redone behind it only when a mask was recovered
+      while (images_ready_.load(std::memory_order_acquire) != tag) std::this_thread::yield();
+      if (rc == 0 && spec_enabled_) rc = spec_filters();
+      orb_ready_.store(rc == 0 ? tag : -tag, std::memory_order_release);
+      if (tail_via_orb) {                                // then the tail of the last frame's object stage, as soon as that stage is over
+        int v;
+        while ((v = objects_done_.load(std::memory_order_acquire)) != tag && v != -tag) std::this_thread::yield();
+        if (v == tag) {
+          const int rc2 = FinishObjectsTail(&fc);
+          tail_done_.store(true, std::memory_order_release);
+          if (rc2 != 0) rc = rc2;
+        }
+      }
+      return rc;
     });
     join_orb.w = worker_orb_.get();
-    orb_pending = true;
   } else if (orb_split_ && !p_.use_sample_feature) VDO_TRY(vdo_orb_extract_begin(orb_, d_gray, W, host_inputs_ ? 0 : 1));
-  // the keypoints of this frame are ready (called by whoever reads them first: the static stage)
+  // the keypoints (and the speculative K9 / K10) of this frame are ready - called by whoever reads them first: the static stage
   auto orb_join = [&]() -> int {
     if (!orb_pending) return 0;
-    orb_pending = false;
-    const int rc = worker_orb_->wait();
+    int v;
+    while ((v = orb_ready_.load(std::memory_order_acquire)) != tag && v != -tag) std::this_thread::yield();
     fc.n_orb = kp.n;
-    return rc;
+    return v == tag ? 0 : -1;
   };
   // ---- deferred mode: the object stage of the PREVIOUS frame ends during this frame's camera stage + ORB front-end (nothing
   // there depends on the object set) - on the helper thread if there is one, else right after ORB on this thread
@@ -170,6 +220,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   } else {
     VDO_TRY(vdo_ctx_synchronize(ctx_));
   }
+  images_ready_.store(f_id_ + 1, std::memory_order_release);      // (both branches synchronised the stream the upload and K1 went through)
   // ---- GetInitModelCam: RANSAC (P3P) on last frame's 3-D points vs this frame's keys, against the motion model   Tracking.cc:1614-1715
   if (have_last_ && n_s >= 4) {
     std::vector<double>& X = d_[0]; std::vector<double>& uvd = d_[1];
@@ -236,20 +287,10 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     fc.n_orb = kp.n;
     tick(1);
   }
-  // K9 + K10 of the new image: only RenewFrameInfo needs them, so they run while the object LMs are in flight
-  int n_new_s = 0, n_tmp = 0;
-  std::vector<int32_t>& keep = i_[1];
-  ObjSet& tmp = tmp_;                                   // K10: semi-dense sampling of this image (mvTmpObj*)
+  // K9 + K10 behind UpdateMask: the speculative results stand unless a mask was recovered
   auto frame_filters = [&]() -> int {
     if (orb_join() != 0) return -1;
-    keep.resize(std::max(kp.n, 1));
-    for (int k = 2; k < 7; ++k) f_[k].resize(std::max(kp.n, 1));
-    const int cap_s = ((W + 3) / 4) * ((H + 3) / 4);
-    tmp.x.resize(cap_s); tmp.y.resize(cap_s); tmp.cx.resize(cap_s); tmp.cy.resize(cap_s); tmp.fx.resize(cap_s); tmp.fy.resize(cap_s); tmp.d.resize(cap_s); tmp.sem.resize(cap_s);
-    // K9 + K10 of the new image: one call, one synchronisation
-    VDO_TRY(vdo_frame_filters(cur, kp.n, kx_.data(), ky_.data(), p_.th_depth_bg, p_.use_sample_feature ? 1 : 0, keep.data(), f_[2].data(), f_[3].data(),
-                              f_[4].data(), f_[5].data(), f_[6].data(), &n_new_s,
-                              p_.th_depth_obj, 4, cap_s, tmp.x.data(), tmp.y.data(), tmp.cx.data(), tmp.cy.data(), tmp.fx.data(), tmp.fy.data(), tmp.d.data(), tmp.sem.data(), &n_tmp));
+    if (!(spec_done && fc.n_recovered_masks == 0) && run_filters(nullptr) != 0) return -1;
     fc.n_static_new = n_new_s;
     fc.n_object_samples = n_tmp;
     return 0;
@@ -292,12 +333,10 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     const int rc = worker_->wait();
     vdo_frame_images_set_ctx(last, ctx_);
     if (rc != 0) return -1;
-    if (tail_pending_ && worker_orb_) {
-      // the ORB thread is free by now (the camera stage it ran under is over): it takes the tail, the helper thread goes straight to the static stage
-      if (orb_join() != 0) return -1;
+    if (tail_pending_ && tail_via_orb) {
+      // the ORB thread takes the tail (it is told that the object stage is over), the helper thread goes straight to the static stage
       tail_done_.store(false, std::memory_order_relaxed);
-      worker_orb_->run([this, &fc] { const int rc = FinishObjectsTail(&fc); tail_done_.store(true, std::memory_order_release); return rc; });
-      join_orb.w = worker_orb_.get();
+      objects_done_.store(tag, std::memory_order_release);
       tail_async = true; tail_on_orb = true;
     } else if (tail_pending_) { worker_->run([this, &fc] { return FinishObjectsTail(&fc); }); tail_async = true; }
   } else if (pending_) {
@@ -374,7 +413,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     nsta.cx.assign(f_[2].begin(), f_[2].begin() + n_new_s); nsta.cy.assign(f_[3].begin(), f_[3].begin() + n_new_s);
     nsta.fx.assign(f_[4].begin(), f_[4].begin() + n_new_s); nsta.fy.assign(f_[5].begin(), f_[5].begin() + n_new_s);
     nsta.d.assign(f_[6].begin(), f_[6].begin() + n_new_s);
-    nobj = tmp;                                         // (copy: tmp_ keeps its capacity for the next frame)
+    nobj = tmp;                                         // (copy: the buffer keeps its capacity for later frames)
     for (auto* v : {&nobj.x, &nobj.y, &nobj.cx, &nobj.cy, &nobj.fx, &nobj.fy, &nobj.d}) v->resize(n_tmp);
     nobj.sem.resize(n_tmp); nobj.label.assign(n_tmp, -2);
     if (obj) VDO_TRY(vdo_ctx_synchronize(ctx_lm_));
@@ -465,7 +504,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     t_prev = std::chrono::steady_clock::now();
     // the object stage (results of the LMs, RenewFrameInfo of the objects, dynamic tracklets) ends in FinishObjects():
     // right below, or - deferred mode - inside the next Step, after that frame's camera stage and ORB front-end
-    n_objects_ = n_objects; obj_run_ = obj; n_obj_problems_ = n_obj_problems; n_tmp_ = n_tmp; img_obj_ = cur; f_id_obj_ = f_id_;
+    n_objects_ = n_objects; obj_run_ = obj; n_obj_problems_ = n_obj_problems; n_tmp_ = n_tmp; img_obj_ = cur; f_id_obj_ = f_id_; tmp_idx_obj_ = cur_;
     std::memcpy(Tcw_obj_, Tcw, sizeof Tcw);
     pending_ = true;
   }
@@ -493,6 +532,14 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   cur_ ^= 1; have_last_ = true; ++f_id_;
   gate_last_ = gate_cur_;
   if (pending_ && !p_.defer_objects) { if (FinishObjects(&fc) != 0) return -1; }
+  if (trace_slow) {
+    const double tot = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_step0).count();
+    if (tot > 2.5) {
+      std::fprintf(stderr, "[slow step f=%d] %.2f ms:", f_id_ - 1, tot);
+      for (int i = 0; i < 12; ++i) std::fprintf(stderr, " [%d] %.2f", i, ms_[i] - ms0[i]);
+      std::fprintf(stderr, "\n");
+    }
+  }
   if (out) *out = fc;
   return 0;
 }
@@ -511,7 +558,7 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
   vdo_frame_images* cur = img_obj_;
   const float* Tcw = Tcw_obj_;
   std::vector<int32_t>&olab = i_[2], &off = i_[3], &idx = i_[4], &osem = i_[5], &omod = i_[6];
-  ObjSet& tmp = tmp_;
+  ObjSet& tmp = tmpb_[tmp_idx_obj_];
   ObjSet nobj;
   std::vector<int32_t> dyn_asso;
   float Twc[16];
