@@ -1016,7 +1016,16 @@ void launch_reduced_rhs(const BADev& d, hipStream_t s, const Reducer& R) {
   if (d.sharded) R(d.qs, 6 * (int64_t)d.P);
 }
 
-static size_t pc_strip_bytes(const BADev& d) { return (size_t)d.pc_waves * 6 * (size_t)d.pc_maxlen * sizeof(double); }
+static size_t pc_strip_bytes(const BADev& d) {
+  const size_t bytes = (size_t)d.pc_waves * 6 * (size_t)d.pc_maxlen * sizeof(double);
+  static size_t raised = 0;                 // more than the default 64 KB of dynamic LDS: tell the runtime once (per size)
+  if (bytes > (size_t)(48 * 1024) && bytes > raised) {
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_vec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    raised = bytes;
+  }
+  return bytes;
+}
 void launch_pcg_init(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), pc_strip_bytes(d), s, d); }
 
 void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s, const Reducer& R) {

@@ -343,11 +343,11 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(ps_off, ps_off.data(), P + 1); UP(ps_idx, ps_idx.data(), NPS);
   UP(pe_off, pe_off.data(), P + 1); UP(pe_idx, pe_idx.data(), pe_idx.size());
   d.n_pchains = n_pchains;
-  {   // LDS strips of the chain preconditioner (ba_solve.hip pchain_apply_lds): [len][6] doubles per resident chain, <= 60 KB in all
+  {   // LDS strips of the chain preconditioner (ba_solve.hip pchain_apply_lds): [len][6] doubles per resident chain, <= 144 KB in all
     int maxlen = 1;
     for (int c = 0; c < n_pchains; ++c) maxlen = std::max(maxlen, (int)(pc_off[c + 1] - pc_off[c]));
     d.pc_maxlen = maxlen;
-    d.pc_waves = (int)std::min<size_t>(std::min(n_pchains, 16), (size_t)(60 * 1024) / (48 * (size_t)maxlen));
+    d.pc_waves = (int)std::min<size_t>(std::min(n_pchains, 16), (size_t)(144 * 1024) / (48 * (size_t)maxlen));     // (up to 144 of the 160 KB of a CU: launch_pcg_* raise the kernels' dynamic-LDS limit)
     if (std::getenv("VDO_BA_CHAIN_GLOBAL")) d.pc_waves = 0;
   }
   UP(pc_off, pc_off.data(), pc_off.size()); UP(pc_pose, pc_pose.data(), P); UP(pc_edge, pc_edge.data(), P);
