@@ -31,10 +31,6 @@ import time
 
 import numpy as np
 
-# polling waits instead of interrupt-driven ones (read by the HSA runtime when torch brings HIP up, so it has to be set here):
-# a wait that falls asleep is woken 4-9 ms late now and then on the virtualised GPU hosts - one frame in ~100 took 8 ms
-# (vdo_slam_amd/csrc/capi_ctx.hip has the same default for hosts where libvdo_hip is what starts HIP)
-os.environ.setdefault("HSA_ENABLE_INTERRUPT", "0")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:

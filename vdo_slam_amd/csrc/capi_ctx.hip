@@ -29,19 +29,8 @@ int ctx_bind(vdo_ctx* ctx) {
 extern "C" int vdo_version(void) { return 1; }
 extern "C" const char* vdo_last_error(void) { return g_err; }
 
-// The per-frame path is a string of ~5 us kernels with a host wait after every few of them, from up to three host threads at once.
-// With interrupt-driven waits (the ROCr default) a wait that falls asleep is woken 4-9 ms late now and then on the virtualised
-// hosts this runs on (one frame in ~100 took 8 ms instead of 0.75 ms: tools / bench.py VDO_PIPE_TRACE_SLOW); polling waits do not.
-// The variable is read by the HSA runtime when it starts, i.e. at the first HIP call of the process: it takes effect when this
-// library is what brings HIP up (the C++ host path), and a host that starts HIP itself sets it itself (bench.py does).
-static void prefer_polling_waits() {
-  static const int once = (setenv("HSA_ENABLE_INTERRUPT", "0", 0 /* never override the user's choice */), 0);
-  (void)once;
-}
-
 extern "C" int vdo_ctx_create(int device, void* hip_stream, vdo_ctx** out) {
   if (!out) return vdo::set_error(VDO_ERR_INVALID, "vdo_ctx_create: null out");
-  prefer_polling_waits();
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
   if (e != hipSuccess || n <= 0)
