@@ -62,10 +62,14 @@ __device__ __forceinline__ void acc_edge(double (&acc)[16], int& cur, int slot, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0;
   }
-  acc[0] += we; acc[1] += we * c.x; acc[2] += we * c.y; acc[3] += we * c.z;
-  acc[4] += we * c.x * c.x; acc[5] += we * c.x * c.y; acc[6] += we * c.x * c.z; acc[7] += we * c.y * c.y;
-  acc[8] += we * c.y * c.z; acc[9] += we * c.z * c.z; acc[10] += we * er.x; acc[11] += we * er.y;
-  acc[12] += we * er.z; acc[13] += we * (c.y * er.z - c.z * er.y); acc[14] += we * (c.z * er.x - c.x * er.z); acc[15] += we * (c.x * er.y - c.y * er.x);
+  // (the running sums take their terms by fused multiply-add: the kernel is bound by VALU issue, and the order of these sums - hence
+  // their last bits - already differs from the oracle's sequential order; the residual and the cross products stay unfused)
+  const double wx = we * c.x, wy = we * c.y, wz = we * c.z;
+  acc[0] += we; acc[1] += wx; acc[2] += wy; acc[3] += wz;
+  acc[4] = __builtin_fma(wx, c.x, acc[4]); acc[5] = __builtin_fma(wx, c.y, acc[5]); acc[6] = __builtin_fma(wx, c.z, acc[6]); acc[7] = __builtin_fma(wy, c.y, acc[7]);
+  acc[8] = __builtin_fma(wy, c.z, acc[8]); acc[9] = __builtin_fma(wz, c.z, acc[9]);
+  acc[10] = __builtin_fma(we, er.x, acc[10]); acc[11] = __builtin_fma(we, er.y, acc[11]); acc[12] = __builtin_fma(we, er.z, acc[12]);
+  acc[13] = __builtin_fma(we, c.y * er.z - c.z * er.y, acc[13]); acc[14] = __builtin_fma(we, c.z * er.x - c.x * er.z, acc[14]); acc[15] = __builtin_fma(we, c.x * er.y - c.y * er.x, acc[15]);
 }
 __device__ __forceinline__ void acc_finish(double (&acc)[16], int cur, double* accpose_base) {
   const SegCtl16 sc = seg_ctl16(cur);
@@ -200,7 +204,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
         }
       }
     }
-    if (BUILD) acc_finish(acc, cur, accpose + 16);
+    if (BUILD && nte > 0) acc_finish(acc, cur, accpose + 16);      // (uniform: tiles of static points have no ternary edges - 256 scan instructions less)
   }
   // ---- write back
   block_sum2(chi, rchi, red);
