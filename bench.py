@@ -326,9 +326,9 @@ def main():
                                f"{INVALID_DEPTH:.0%} invalid depth, {ZERO_FLOW:.0%} zero flow, the instance mask of object 1 missing in frames {sorted(drop_masks)}, "
                                f"object 2 leaves at frame {leave_at}, object 5 enters at frame {enter_at}",
                    "sequences_per_gpu": R, "sequences_identical": bool(identical),
-                   "parallelism": f"replicas x{world}" + (f" (ranks share {n_dev} device(s), collectives over gloo)" if shared_gpu else "") + f", {R} sequence(s) per GPU; 4 HIP streams per sequence: camera LM (2) || ORB front-end (1); object LMs (3) || RenewFrameInfo (1) and - "
-                                  f"defer_objects={defer} - the next frame's camera stage; every LM problem runs on a cluster of up to 8 workgroups; "
-                                  f"{cpus:.1f} CPUs per rank, host threads per sequence: 1 + {int(rep0.ctx_w is not None)} helper (object stage of the previous frame || camera stage; K9/K10/RenewFrameInfo static || object chain) + {int(rep0.ctx_orb is not None)} ORB thread (K3-K7 of the frame, from the start of the frame to the static stage) + {rep0.orb_threads} ORB quadtree helpers",
+                   "parallelism": f"replicas x{world}" + (f" (ranks share {n_dev} device(s), collectives over gloo)" if shared_gpu else "") + f", {R} sequence(s) per GPU; {4 + int(rep0.ctx_orb is not None)} HIP streams per sequence: camera LM (2) || ORB front-end ({5 if rep0.ctx_orb is not None else 1}) || object LMs of the last frame (3) -> RenewFrameInfo (4), then UpdateMask and the static stage (4) || the object chain (1); "
+                                  f"defer_objects={defer}; every LM problem runs on a cluster of up to 8 workgroups; "
+                                  f"{cpus:.1f} CPUs per rank, host threads per sequence: 1 + {int(rep0.ctx_w is not None)} helper (object stage of the previous frame || camera stage; K9/K10/RenewFrameInfo static || object chain) + {int(rep0.ctx_orb is not None)} ORB thread (K3-K7 of the frame from its start, then the tail of the last frame's object stage) + {rep0.orb_threads} ORB quadtree helpers",
                    "orb_keypoints": counts.n_orb, "new_static_candidates": counts.n_static_new, "object_samples": counts.n_object_samples,
                    "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
                    "per_frame_mean": {q: round(v / n_all, 2) for q, v in agg.items()},
