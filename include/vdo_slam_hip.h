@@ -356,6 +356,11 @@ int vdo_sample_keypoints(int rows, int cols, uint64_t seed, int capacity, float*
 int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, int step, int cap,
                             float* key_x, float* key_y, float* corr_x, float* corr_y,
                             float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_out);
+/* K10 on the stream of `on_ctx` (NULL: the image set's own) with a scratch set of its own: for a caller that samples the objects on
+ * a second host thread while the owning thread runs K9 / RenewFrameInfo on the same image set.  Host outputs required. */
+int vdo_frame_object_sample_on(vdo_ctx* on_ctx, vdo_frame_images* f, float th_depth_obj, int step, int cap,
+                               float* key_x, float* key_y, float* corr_x, float* corr_y,
+                               float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_out);
 /* K9 + K10 of one image in one call and ONE synchronisation (Frame::Frame runs them back to back: src/Frame.cc:104-131 / 132-166,
  * 168-199): the arguments of vdo_frame_static_filter[_sampled] (sampled != 0: the UseSampleFeature branch) followed by those of
  * vdo_frame_object_sample (host outputs required). */

@@ -121,16 +121,6 @@ def test_deferred_object_stage_gives_the_same_sequence():
             assert [(x["mod_label"], x["sem_label"], x["n_inliers"]) for x in a] == [(x["mod_label"], x["sem_label"], x["n_inliers"]) for x in b]
             for x, y in zip(a, b):
                 assert np.array_equal(x["H"], y["H"])
-    # + K9 / K10 speculatively ahead of UpdateMask on the ORB thread (opt-in; redone when a mask was recovered)
-    import os
-    os.environ["VDO_PIPE_SPEC_FILTERS"] = "1"
-    try:
-        p1, c1, m1 = run(1, True, True)
-    finally:
-        del os.environ["VDO_PIPE_SPEC_FILTERS"]
-    assert c0[1:] == c1[1:]
-    for a, b in zip(p0, p1):
-        assert np.array_equal(a, b)
 
 
 def test_noisy_sequence_with_invalid_pixels_and_a_dropped_mask_matches_the_oracle(oracle):

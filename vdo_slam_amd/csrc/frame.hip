@@ -350,6 +350,21 @@ extern "C" int vdo_frame_object_sample(vdo_frame_images* f, float th_depth_obj, 
   return object_sample_collect(f, f->ctx->stream, cap, f->d_rows, f->h_pin, key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out, label, n_out);
 }
 
+// K10 on the stream of `on_ctx` and the second scratch set: for a caller that samples the objects on another host thread while the
+// owning thread runs K9 / RenewFrameInfo on the same image set.
+extern "C" int vdo_frame_object_sample_on(vdo_ctx* on_ctx, vdo_frame_images* f, float th_depth_obj, int step, int cap,
+                                          float* key_x, float* key_y, float* corr_x, float* corr_y,
+                                          float* flow_x, float* flow_y, float* depth_out, int32_t* label, int* n_out) {
+  if (!f || !n_out || step <= 0 || !key_x) return set_error(VDO_ERR_INVALID, "vdo_frame_object_sample_on: bad argument");
+  vdo_ctx* c = on_ctx ? on_ctx : f->ctx;
+  int rc = ctx_bind(c);
+  if (rc != VDO_OK) return rc;
+  rc = object_sample_enqueue(f, c->stream, th_depth_obj, step, true, f->d_rows2, f->d_cnt2, f->h_pin2);
+  if (rc != VDO_OK) return rc;
+  if (hipStreamSynchronize(c->stream) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "object sampling failed: %s", hipGetErrorString(hipGetLastError()));
+  return object_sample_collect(f, c->stream, cap, f->d_rows2, f->h_pin2, key_x, key_y, corr_x, corr_y, flow_x, flow_y, depth_out, label, n_out);
+}
+
 // K9 + K10 of one image with ONE synchronisation: the two results use separate scratch sets, so both pipelines are queued
 // back to back (Frame::Frame runs them back to back too: src/Frame.cc:104-131, 168-199).
 // (on_ctx: the stream / device binding to use instead of the image set's own context - a caller that runs this on a second host

@@ -90,7 +90,6 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
   if (ctx_worker) worker_.reset(new Worker());
   if (ctx_worker && ctx_orb) worker_orb_.reset(new Worker());
   ctx_orb_ = ctx_orb;
-  spec_enabled_ = std::getenv("VDO_PIPE_SPEC_FILTERS") != nullptr;      // (measured: no gain over running them behind UpdateMask - opt-in)
   orb_split_ = ctx_orb != nullptr;
   ok_ = true;
 }
@@ -138,24 +137,23 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   int n_new_s = 0, n_tmp = 0;
   std::vector<int32_t>& keep = i_[1];
   ObjSet& tmp = tmpb_[cur_];                            // K10: semi-dense sampling of this image (mvTmpObj*)
-  bool spec_done = false;                               // K9 / K10 ran ahead of UpdateMask (ORB thread)
-  auto run_filters = [&](vdo_ctx* on) -> int {
+  const int cap_s = ((W + 3) / 4) * ((H + 3) / 4);
+  auto size_filter_outputs = [&]() {
     keep.resize(std::max(kp.n, 1));
     for (int k = 2; k < 7; ++k) f_[k].resize(std::max(kp.n, 1));
-    const int cap_s = ((W + 3) / 4) * ((H + 3) / 4);
-    tmp.x.resize(cap_s); tmp.y.resize(cap_s); tmp.cx.resize(cap_s); tmp.cy.resize(cap_s); tmp.fx.resize(cap_s); tmp.fy.resize(cap_s); tmp.d.resize(cap_s); tmp.sem.resize(cap_s);
-    // one call, one synchronisation
-    VDO_TRY(vdo_frame_filters_on(on, cur, kp.n, kx_.data(), ky_.data(), p_.th_depth_bg, p_.use_sample_feature ? 1 : 0, keep.data(), f_[2].data(), f_[3].data(),
-                                 f_[4].data(), f_[5].data(), f_[6].data(), &n_new_s,
-                                 p_.th_depth_obj, 4, cap_s, tmp.x.data(), tmp.y.data(), tmp.cx.data(), tmp.cy.data(), tmp.fx.data(), tmp.fy.data(), tmp.d.data(), tmp.sem.data(), &n_tmp));
-    return 0;
   };
-  auto spec_filters = [&]() -> int {
+  auto size_sample_outputs = [&]() {
+    tmp.x.resize(cap_s); tmp.y.resize(cap_s); tmp.cx.resize(cap_s); tmp.cy.resize(cap_s); tmp.fx.resize(cap_s); tmp.fy.resize(cap_s); tmp.d.resize(cap_s); tmp.sem.resize(cap_s);
+  };
+  // K10 alone, on the ORB thread's stream (second scratch set of the image set): nothing in this Step reads the samples - the object
+  // stage of this frame does, in the next Step - so they leave the static stage and run behind UpdateMask on the thread that is free
+  auto run_k10_on_orb = [&]() -> int {
     const auto t0 = std::chrono::steady_clock::now();
-    const int rc = run_filters(ctx_orb_);
-    ms_[2] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-    spec_done = rc == 0;
-    return rc;
+    size_sample_outputs();
+    VDO_TRY(vdo_frame_object_sample_on(ctx_orb_, cur, p_.th_depth_obj, 4, cap_s, tmp.x.data(), tmp.y.data(), tmp.cx.data(), tmp.cy.data(), tmp.fx.data(), tmp.fy.data(), tmp.d.data(),
+                                       tmp.sem.data(), &n_tmp));
+    ms_[11] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return 0;
   };
   // (with a thread of its own the whole extraction - device stage, quadtrees, angles - leaves the main thread: nothing before the
   // static stage reads a keypoint)
@@ -163,23 +161,20 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   const int tag = f_id_ + 1;
   // (destroyed BEFORE join_orb: whatever way Step is left, the ORB thread's waits below end)
   struct Release {
-    std::atomic<int>*img, *obj; int tag;
-    ~Release() { if (img->load() != tag) img->store(tag); const int v = obj->load(); if (v != tag && v != -tag) obj->store(-tag); }
-  } release{&images_ready_, &objects_done_, tag};
+    std::atomic<int>*obj, *msk; int tag;
+    ~Release() { for (std::atomic<int>* a : {obj, msk}) { const int v = a->load(); if (v != tag && v != -tag) a->store(-tag); } }
+  } release{&objects_done_, &mask_final_, tag};
   const bool orb_pending = worker_orb_ && !p_.use_sample_feature;
-  const bool tail_via_orb = orb_pending && pending_ && worker_;     // its job ends with the tail of the last frame's object stage
+  const bool tail_via_orb = orb_pending && pending_ && worker_;     // its job goes on with the tail of the last frame's object stage
+  const bool k10_via_orb = orb_pending && have_last_ && worker_;    // ... and ends with K10 of this frame, behind UpdateMask
   if (orb_pending) {
-    worker_orb_->run([this, &kp, &spec_filters, &fc, d_gray, W, tag, tail_via_orb]() -> int {
+    worker_orb_->run([this, &kp, &run_k10_on_orb, &fc, d_gray, W, tag, tail_via_orb, k10_via_orb]() -> int {
       const auto t0 = std::chrono::steady_clock::now();
       int rc = vdo_orb_extract(orb_, d_gray, W, host_inputs_ ? 0 : 1, &kp) == VDO_OK ? 0 : -1;
       ms_[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (rc != 0) std::fprintf(stderr, "FramePipeline: %s\n", vdo_last_error());
-      // (opt-in, VDO_PIPE_SPEC_FILTERS) K9 + K10 read the mask UpdateMask may still repair - it rarely does (a mask missing from the
-      // segmentation), so they can run here, ahead of it, and be redone behind it only when a mask was recovered
-      while (images_ready_.load(std::memory_order_acquire) != tag) std::this_thread::yield();
-      if (rc == 0 && spec_enabled_) rc = spec_filters();
       orb_ready_.store(rc == 0 ? tag : -tag, std::memory_order_release);
-      if (tail_via_orb) {                                // then the tail of the last frame's object stage, as soon as that stage is over
+      if (tail_via_orb) {                                // the tail of the last frame's object stage, as soon as that stage is over
         int v;
         while ((v = objects_done_.load(std::memory_order_acquire)) != tag && v != -tag) std::this_thread::yield();
         if (v == tag) {
@@ -187,6 +182,11 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
           tail_done_.store(true, std::memory_order_release);
           if (rc2 != 0) rc = rc2;
         }
+      }
+      if (k10_via_orb) {                                 // K10 reads the mask UpdateMask may repair: behind it
+        int v;
+        while ((v = mask_final_.load(std::memory_order_acquire)) != tag && v != -tag) std::this_thread::yield();
+        if (v == tag && run_k10_on_orb() != 0) rc = -1;
       }
       return rc;
     });
@@ -220,7 +220,6 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   } else {
     VDO_TRY(vdo_ctx_synchronize(ctx_));
   }
-  images_ready_.store(f_id_ + 1, std::memory_order_release);      // (both branches synchronised the stream the upload and K1 went through)
   // ---- GetInitModelCam: RANSAC (P3P) on last frame's 3-D points vs this frame's keys, against the motion model   Tracking.cc:1614-1715
   if (have_last_ && n_s >= 4) {
     std::vector<double>& X = d_[0]; std::vector<double>& uvd = d_[1];
@@ -287,12 +286,21 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     fc.n_orb = kp.n;
     tick(1);
   }
-  // K9 + K10 behind UpdateMask: the speculative results stand unless a mask was recovered
+  // K9 (+ K10 unless the ORB thread samples the objects) of the new image: one call, one synchronisation
   auto frame_filters = [&]() -> int {
     if (orb_join() != 0) return -1;
-    if (!(spec_done && fc.n_recovered_masks == 0) && run_filters(nullptr) != 0) return -1;
+    size_filter_outputs();
+    if (k10_via_orb) {
+      VDO_TRY((p_.use_sample_feature ? vdo_frame_static_filter_sampled : vdo_frame_static_filter)(cur, kp.n, kx_.data(), ky_.data(), p_.th_depth_bg, keep.data(), f_[2].data(), f_[3].data(),
+                                                                                                    f_[4].data(), f_[5].data(), f_[6].data(), &n_new_s));
+    } else {
+      size_sample_outputs();
+      VDO_TRY(vdo_frame_filters(cur, kp.n, kx_.data(), ky_.data(), p_.th_depth_bg, p_.use_sample_feature ? 1 : 0, keep.data(), f_[2].data(), f_[3].data(),
+                                f_[4].data(), f_[5].data(), f_[6].data(), &n_new_s,
+                                p_.th_depth_obj, 4, cap_s, tmp.x.data(), tmp.y.data(), tmp.cx.data(), tmp.cy.data(), tmp.fx.data(), tmp.fy.data(), tmp.d.data(), tmp.sem.data(), &n_tmp));
+      fc.n_object_samples = n_tmp;
+    }
     fc.n_static_new = n_new_s;
-    fc.n_object_samples = n_tmp;
     return 0;
   };
   tick(2);
@@ -357,6 +365,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
                              Tcw_last_, p_.K4, &rec, obj_depth.data(), obj_sem.data(), flow3d.data(), olab.data()));
     fc.n_recovered_masks = rec;
   }
+  mask_final_.store(tag, std::memory_order_release);      // (UpdateMask is through: K10 may sample the mask)
   tick(10);
   StaSet nsta; ObjSet nobj;
   std::vector<int32_t> sta_asso, dyn_asso;
@@ -500,7 +509,8 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
       vdo_frame_images_set_ctx(cur, ctx_);
       if (rc != 0) return -1;
     } else if (stage_static() != 0) return -1;
-    if (tail_on_orb && worker_orb_->wait() != 0) return -1;
+    if ((tail_on_orb || k10_via_orb) && worker_orb_->wait() != 0) return -1;
+    if (k10_via_orb) fc.n_object_samples = n_tmp;
     t_prev = std::chrono::steady_clock::now();
     // the object stage (results of the LMs, RenewFrameInfo of the objects, dynamic tracklets) ends in FinishObjects():
     // right below, or - deferred mode - inside the next Step, after that frame's camera stage and ORB front-end

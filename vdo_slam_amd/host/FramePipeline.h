@@ -136,11 +136,10 @@ class FramePipeline {
   int32_t max_id_ = 1;
   StaSet sta_;                        // last frame: static keys + their correspondences in the next image
   ObjSet tmpb_[2];                    // K10 output of a frame, by image-set index (the object stage of frame k-1 reads [k-1] while frame k fills [k])
-  bool spec_enabled_ = false;         // K9 / K10 ahead of UpdateMask on the ORB thread (VDO_PIPE_SPEC_FILTERS turns it on: no measured gain)
   int tmp_idx_obj_ = 0;               // which of the two the pending object stage reads
   std::atomic<int> orb_ready_{0};     // +-(frame id + 1): keypoints and speculative K9 / K10 of that frame are there (negative: failed)
   std::atomic<int> objects_done_{0};  // +-(frame id + 1): the object stage the ORB thread's tail waits for is over (negative: no tail)
-  std::atomic<int> images_ready_{0};  // frame id + 1 whose images (upload, K1) are complete on the device: the ORB thread's speculative K9 / K10 wait for it
+  std::atomic<int> mask_final_{0};    // +-(frame id + 1): UpdateMask of that frame is through (K10 on the ORB thread waits for it; negative: skip)
   ObjSet obj_;                        // last frame: object keys, correspondences, depth, semantic + motion labels
   std::vector<int32_t> last_sem_pos_, last_mod_label_; std::vector<uint8_t> last_obj_stat_;
   float Tcw_last_[16], vel_[16];      // last pose, mVelocity
