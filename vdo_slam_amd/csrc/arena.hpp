@@ -73,6 +73,15 @@ class Arena {
     if ((const char*)dev < c_->d_arena || o + n * sizeof(T) > c_->d_cap) { failed_ = true; return; }
     pend_.push_back({user, o, n * sizeof(T)});
   }
+  // queue a device -> pinned copy WITHOUT a hand-over to a caller array: returns where the data will be in the pinned block once
+  // finish() has returned (valid until the context's arena is used again) - large outputs of which the caller reads a few rows
+  template <class T>
+  const T* down_view(const T* dev, size_t n) {
+    const size_t o = (size_t)((const char*)dev - c_->d_arena);
+    if ((const char*)dev < c_->d_arena || o + n * sizeof(T) > c_->d_cap) { failed_ = true; return nullptr; }
+    if (n) pend_.push_back({nullptr, o, n * sizeof(T)});
+    return (const T*)(c_->h_arena + o);
+  }
   // the outputs come back (one copy of their span, or one per buffer when the span is mostly something else), one
   // synchronisation, then they reach the caller's arrays
   int finish(const char* what) {
@@ -87,7 +96,7 @@ class Arena {
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { pend_.clear(); return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e)); }
     if (failed_) { pend_.clear(); return set_error(VDO_ERR_OOM, "%s: scratch arena exhausted", what); }
-    for (const Pend& p : pend_) std::memcpy(p.user, c_->h_arena + p.off, p.bytes);
+    for (const Pend& p : pend_) if (p.user) std::memcpy(p.user, c_->h_arena + p.off, p.bytes);
     pend_.clear();
     return VDO_OK;
   }

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/vdo_slam_hip.h"
@@ -299,22 +300,38 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
     if (inlier_out && inlier_out[k] && probs[k].n) std::memset(inlier_out[k], 0, (size_t)probs[k].n);
   }
   if (tot_hyp == 0) return VDO_OK;
-  // the subsets the sequential loop would draw (getSubset: 4 distinct indices by rejection, RNG seeded with (uint64)-1 per call)
+  // the subsets the sequential loop would draw (getSubset: 4 distinct indices by rejection, RNG seeded with (uint64)-1 per call):
+  // a function of (point count, hypotheses) alone - the draws of a frame's problems cost ~30 us of the object chain, and the same
+  // counts come back every few frames, so the tables are kept (8 KB per distinct count)
   std::vector<int32_t> subsets(4 * tot_hyp);
   std::vector<double> X(3 * tot_pts), uv(2 * tot_pts);
-  for (int k = 0; k < n_problems; ++k) {
-    const PnpDev& d = hp[k];
-    if (d.n) { std::memcpy(X.data() + 3 * (size_t)d.pt_off, probs[k].X, sizeof(double) * 3 * d.n); std::memcpy(uv.data() + 2 * (size_t)d.pt_off, probs[k].uv, sizeof(double) * 2 * d.n); }
-    CvRng rng((uint64_t)-1);
-    for (int it = 0; it < d.n_hyp; ++it) {
-      int32_t* s = subsets.data() + 4 * ((size_t)d.hyp_off + it);
-      for (int i = 0; i < 4; ++i)
-        for (;;) {
-          const int c = rng.uniform(0, d.n);
-          bool dup = false;
-          for (int j = 0; j < i; ++j) dup |= (s[j] == c);
-          if (!dup) { s[i] = c; break; }
-        }
+  {
+    static std::mutex cache_mu;
+    static std::unordered_map<uint64_t, std::vector<int32_t>> cache;
+    for (int k = 0; k < n_problems; ++k) {
+      const PnpDev& d = hp[k];
+      if (d.n) { std::memcpy(X.data() + 3 * (size_t)d.pt_off, probs[k].X, sizeof(double) * 3 * d.n); std::memcpy(uv.data() + 2 * (size_t)d.pt_off, probs[k].uv, sizeof(double) * 2 * d.n); }
+      if (!d.n_hyp) continue;
+      int32_t* dst = subsets.data() + 4 * (size_t)d.hyp_off;
+      const uint64_t key = ((uint64_t)(uint32_t)d.n << 32) | (uint32_t)d.n_hyp;
+      {
+        std::lock_guard<std::mutex> g(cache_mu);
+        auto it = cache.find(key);
+        if (it != cache.end()) { std::memcpy(dst, it->second.data(), sizeof(int32_t) * 4 * (size_t)d.n_hyp); continue; }
+      }
+      CvRng rng((uint64_t)-1);
+      for (int it = 0; it < d.n_hyp; ++it) {
+        int32_t* s = dst + 4 * (size_t)it;
+        for (int i = 0; i < 4; ++i)
+          for (;;) {
+            const int c = rng.uniform(0, d.n);
+            bool dup = false;
+            for (int j = 0; j < i; ++j) dup |= (s[j] == c);
+            if (!dup) { s[i] = c; break; }
+          }
+      }
+      std::lock_guard<std::mutex> g(cache_mu);
+      if (cache.size() < 4096) cache.emplace(key, std::vector<int32_t>(dst, dst + 4 * (size_t)d.n_hyp));
     }
   }
   Arena S(ctx);
@@ -329,12 +346,13 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   if (!dprob || !dX || !duv || !dsub || !dpose || !dok || !dcnt || !dmask) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
   hipLaunchKernelGGL(k_p3p_hyp, dim3((max_hyp + 63) / 64, n_problems), dim3(64), 0, S.stream(), (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const int32_t*)dsub, dpose, dok);
   hipLaunchKernelGGL(k_ransac_vote, dim3(max_hyp, n_problems), dim3(256), 0, S.stream(), (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const double*)dpose, (const int32_t*)dok, dcnt, dmask);
-  std::vector<int32_t> cnt(tot_hyp), okv(tot_hyp);
-  std::vector<double> pose(12 * tot_hyp);
-  std::vector<uint32_t> mask(tot_words);
-  S.down(cnt.data(), dcnt, tot_hyp); S.down(okv.data(), dok, tot_hyp); S.down(pose.data(), dpose, 12 * tot_hyp); S.down(mask.data(), dmask, tot_words);
+  // (votes, poses and inlier masks of all hypotheses are read where they land in the pinned block: the replay touches a few rows)
+  const int32_t *cnt = S.down_view(dcnt, tot_hyp), *okv = S.down_view(dok, tot_hyp);
+  const double* pose = S.down_view(dpose, 12 * tot_hyp);
+  const uint32_t* mask = S.down_view(dmask, tot_words);
   rc = S.finish("vdo_pnp_ransac_batch");
   if (rc != VDO_OK) return rc;
+  if (!cnt || !okv || !pose || !mask) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
   // replay of RANSACPointSetRegistrator::run over the precomputed votes
   for (int k = 0; k < n_problems; ++k) {
     const PnpDev& d = hp[k];
@@ -351,10 +369,10 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
     vdo_pnp_result& r = results[k];
     r.iterations_run = it; r.best_iteration = bi; r.n_inliers = max_good;
     if (bi < 0) continue;
-    const double* Pz = pose.data() + 12 * ((size_t)d.hyp_off + bi);
+    const double* Pz = pose + 12 * ((size_t)d.hyp_off + bi);
     for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) r.T[4 * i + j] = Pz[3 * i + j]; r.T[4 * i + 3] = Pz[9 + i]; }
     if (inlier_out && inlier_out[k]) {
-      const uint32_t* row = mask.data() + (size_t)d.mask_off + (size_t)bi * d.mask_words;
+      const uint32_t* row = mask + (size_t)d.mask_off + (size_t)bi * d.mask_words;
       for (int i = 0; i < d.n; ++i) inlier_out[k][i] = (row[i >> 5] >> (i & 31)) & 1u;
     }
   }
@@ -366,7 +384,7 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
     auto refit_one = [&](int q) {
       const int k = todo[q];
       const PnpDev& d = hp[k];
-      const uint32_t* row = mask.data() + (size_t)d.mask_off + (size_t)results[k].best_iteration * d.mask_words;
+      const uint32_t* row = mask + (size_t)d.mask_off + (size_t)results[k].best_iteration * d.mask_words;
       thread_local std::vector<double> Xi, ui;
       thread_local epnp::Scratch scr;
       Xi.clear(); ui.clear();
