@@ -548,9 +548,13 @@ __global__ __launch_bounds__(F2_THREADS) void k_flow2_lm(const Flow2Dev* __restr
     res->iterations = it; res->trials = total_trials; res->stop_reason = stop_reason;
     res->initial_chi2 = initial_chi2; res->final_chi2 = last_err_chi; res->final_lambda = lambda;
 #ifdef F2_PROFILE
-    for (int i = 0; i < 16; ++i) res->T[i] = (double)s_prof[i];     // cycles per phase instead of the pose (debug build only)
+    for (int i = 0; i < 14; ++i) res->T[i] = (double)s_prof[i];     // cycles per phase instead of the pose (debug build only)
 #endif
   }
+#ifdef F2_PROFILE
+  __syncthreads();
+  if (tid == 0 && wg < 2) res->T[14 + wg] = (double)(__builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20) & 0xf) + 100.0 * blockIdx.x;   // XCC_ID of workgroups 0 / 1 (+ 100 x block id)
+#endif
 }
 
 }  // namespace vdo
