@@ -159,6 +159,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   // static stage reads a keypoint)
   Join join_orb{nullptr};                                // declared after kp: joined before kp goes away on every path out of Step
   const int tag = f_id_ + 1;
+  orb_ready_.store(0, std::memory_order_relaxed); objects_done_.store(0, std::memory_order_relaxed); mask_final_.store(0, std::memory_order_relaxed);   // (a Step that failed may have left this tag behind)
   // (destroyed BEFORE join_orb: whatever way Step is left, the ORB thread's waits below end)
   struct Release {
     std::atomic<int>*obj, *msk; int tag;
