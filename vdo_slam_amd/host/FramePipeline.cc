@@ -193,7 +193,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     });
     join_orb.w = worker_orb_.get();
   } else if (orb_split_ && !p_.use_sample_feature) VDO_TRY(vdo_orb_extract_begin(orb_, d_gray, W, host_inputs_ ? 0 : 1));
-  // the keypoints (and the speculative K9 / K10) of this frame are ready - called by whoever reads them first: the static stage
+  // the keypoints of this frame are ready - called by whoever reads them first: the static stage
   auto orb_join = [&]() -> int {
     if (!orb_pending) return 0;
     int v;
