@@ -11,6 +11,8 @@
 // its <=3 incidence blocks (6x3) in registers, B^T v accumulates per point in LDS, the chain
 // solves run in LDS, and B w is segment-reduced per pose slot -> the 6x3 blocks are read from
 // HBM exactly once per CG iteration and there are no global atomics.
+#include <atomic>
+
 #include "ba_dev.hpp"
 #include "ba_tile.hpp"
 #include "se3_dev.hpp"
@@ -1018,11 +1020,11 @@ void launch_reduced_rhs(const BADev& d, hipStream_t s, const Reducer& R) {
 
 static size_t pc_strip_bytes(const BADev& d) {
   const size_t bytes = (size_t)d.pc_waves * 6 * (size_t)d.pc_maxlen * sizeof(double);
-  static size_t raised = 0;                 // more than the default 64 KB of dynamic LDS: tell the runtime once (per size)
-  if (bytes > (size_t)(48 * 1024) && bytes > raised) {
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_vec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    raised = bytes;
+  static std::atomic<size_t> raised{0};     // more than the default 64 KB of dynamic LDS: tell the runtime (once per size; the calls are idempotent)
+  if (bytes > (size_t)(48 * 1024) && bytes > raised.load(std::memory_order_relaxed)) {
+    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_vec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e1 == hipSuccess && e2 == hipSuccess) raised.store(bytes, std::memory_order_relaxed);
   }
   return bytes;
 }
