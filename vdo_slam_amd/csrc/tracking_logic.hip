@@ -547,18 +547,20 @@ struct vdo_tracks {
   bool with_label = false;
   int n_frames = 0;
   std::vector<int32_t> pre, cur;                  // track id of every feature of the last added frame (+ the buffer the next frame fills)
-  // (frame, feature) pairs of every track as singly linked chains in flat append-only pools: a frame adds a few thousand pairs,
-  // one small heap vector per track made that a few thousand allocations per frame
-  std::vector<int32_t> p_frame, p_feat, p_next;   // pools
-  std::vector<int32_t> first, last, len;          // per track
+  // (frame, feature) pairs of every track as singly linked chains in ONE flat append-only pool: a frame adds a few thousand pairs
+  // (one small heap vector per track made that a few thousand allocations per frame; three parallel pools three cache lines per pair)
+  struct Pair { int32_t frame, feat, next; };
+  struct Track { int32_t first, last, len; };
+  std::vector<Pair> pool;
+  std::vector<Track> trk;
   std::vector<int32_t> obj_id;
   int64_t n_pairs = 0;
-  int add_pair(int id, int frame, int feat) {
-    const int k = (int)p_frame.size();
-    p_frame.push_back(frame); p_feat.push_back(feat); p_next.push_back(-1);
-    if (last[id] >= 0) p_next[last[id]] = k; else first[id] = k;
-    last[id] = k; len[id] += 1;
-    return k;
+  void add_pair(int id, int frame, int feat) {
+    const int k = (int)pool.size();
+    pool.push_back(Pair{frame, feat, -1});
+    Track& t = trk[id];
+    if (t.last >= 0) pool[t.last].next = k; else t.first = k;
+    t.last = k; t.len += 1;
   }
 };
 
@@ -566,6 +568,10 @@ extern "C" int vdo_tracks_create(int with_object_label, vdo_tracks** out) {
   if (!out) return set_error(VDO_ERR_INVALID, "null out");
   vdo_tracks* t = new vdo_tracks();
   t->with_label = with_object_label != 0;
+  // address space up front (pages are touched as the pools fill): a doubling std::vector re-allocates and copies several MB now
+  // and then - a multi-millisecond frame in the middle of a sequence
+  t->pool.reserve((size_t)1 << 22); t->trk.reserve((size_t)1 << 20);
+  if (t->with_label) t->obj_id.reserve((size_t)1 << 20);
   *out = t;
   return VDO_OK;
 }
@@ -586,8 +592,8 @@ extern "C" int vdo_tracks_add_frame(vdo_tracks* t, int n, const int32_t* asso, c
       t->add_pair(id, i + 1, j);
       cur[j] = id; t->n_pairs += 1;
     } else {
-      const int id = (int)t->first.size();
-      t->first.push_back(-1); t->last.push_back(-1); t->len.push_back(0);
+      const int id = (int)t->trk.size();
+      t->trk.push_back(vdo_tracks::Track{-1, -1, 0});
       t->add_pair(id, i, a); t->add_pair(id, i + 1, j);
       if (t->with_label) t->obj_id.push_back(feat_label[j]);
       cur[j] = id; t->n_pairs += 2;
@@ -600,7 +606,7 @@ extern "C" int vdo_tracks_add_frame(vdo_tracks* t, int n, const int32_t* asso, c
 
 extern "C" int vdo_tracks_size(vdo_tracks* t, int* n_tracks, int64_t* n_pairs) {
   if (!t) return set_error(VDO_ERR_INVALID, "null handle");
-  if (n_tracks) *n_tracks = (int)t->first.size();
+  if (n_tracks) *n_tracks = (int)t->trk.size();
   if (n_pairs) *n_pairs = t->n_pairs;
   return VDO_OK;
 }
@@ -609,8 +615,8 @@ extern "C" int vdo_tracks_get(vdo_tracks* t, int32_t* track_off, int32_t* pair_f
   if (!t || !track_off || !pair_frame || !pair_feat) return set_error(VDO_ERR_INVALID, "null argument");
   int off = 0;
   track_off[0] = 0;
-  for (size_t k = 0; k < t->first.size(); ++k) {
-    for (int q = t->first[k]; q >= 0; q = t->p_next[q]) { pair_frame[off] = t->p_frame[q]; pair_feat[off] = t->p_feat[q]; ++off; }
+  for (size_t k = 0; k < t->trk.size(); ++k) {
+    for (int q = t->trk[k].first; q >= 0; q = t->pool[q].next) { pair_frame[off] = t->pool[q].frame; pair_feat[off] = t->pool[q].feat; ++off; }
     track_off[k + 1] = off;
     if (obj_id && t->with_label) obj_id[k] = t->obj_id[k];
   }

@@ -87,6 +87,7 @@ FramePipeline::FramePipeline(vdo_ctx* ctx, vdo_ctx* ctx_lm, const PipelineParams
     std::vector<int32_t> ocap(obj_slots_, obj_cap_);
     if (vdo_flow2_batch_reserve(ctx_obj_, obj_slots_, ocap.data(), &lm_obj_) != VDO_OK) return;
   }
+  store_.sta.reserve((size_t)1 << 20); store_.dyn.reserve((size_t)1 << 22);      // ~800 frames of 1 200 static / 5 000 object features before a re-allocation
   if (ctx_worker) worker_.reset(new Worker());
   if (ctx_worker && ctx_orb) worker_orb_.reset(new Worker());
   ctx_orb_ = ctx_orb;

@@ -25,6 +25,9 @@ struct FeatureBlock {                         // features of all frames, frame i
     off.push_back(off.back() + (int64_t)n);
   }
   void clear() { off.assign(1, 0); u.clear(); v.clear(); d.clear(); xyz.clear(); }
+  // Address space for `n_features` up front (pages are only touched as the arrays fill): without it a doubling std::vector
+  // re-allocates and copies several MB now and then - a multi-millisecond frame in the middle of a sequence.
+  void reserve(size_t n_features) { u.reserve(n_features); v.reserve(n_features); d.reserve(n_features); xyz.reserve(3 * n_features); off.reserve(4096); }
 };
 
 struct TrackList {                            // tracklets, flat: track t = pairs [off[t], off[t+1]) of (frame, feature)
