@@ -73,6 +73,15 @@ class OraclePipeline:
         good = self.o.vdo_oracle_pnp_ransac_refit(n, K._dp(X), K._dp(uv), K._dp(self.K4.astype(np.float64)), 500, 0.4, 0.98, int(self.pnp_refit), K._dp(Tm), inl.ctypes.data_as(K.c_uint8_p), None, None)
         return good, Tm.reshape(4, 4), inl[:n]
 
+    def _mm_inliers(self, MM, X, u, v):
+        """Points whose projection by the 4x4 fp32 model MM lies within 0.4 px of (u, v): the float formula of Tracking.cc:1674-1688 / :1786-1800
+        (cv::Mat product of the 3x3 block and the point accumulated left to right, + the translation column)."""
+        xc = MM[0, 0] * X[:, 0] + MM[0, 1] * X[:, 1] + MM[0, 2] * X[:, 2] + MM[0, 3]
+        yc = MM[1, 0] * X[:, 0] + MM[1, 1] * X[:, 1] + MM[1, 2] * X[:, 2] + MM[1, 3]
+        invz = f32(1.0) / (MM[2, 0] * X[:, 0] + MM[2, 1] * X[:, 1] + MM[2, 2] * X[:, 2] + MM[2, 3])
+        u_ = u - (self.K4[0] * xc * invz + self.K4[2]); v_ = v - (self.K4[1] * yc * invz + self.K4[3])
+        return np.sqrt(u_ * u_ + v_ * v_) < f32(0.4)
+
     def _lm(self, kx, ky, fx, fy, d, T0, info_prior, max_it):
         from tests.test_oracle_flow2 import run_oracle
         Twl = inv_rigid_f32(self.Tl).astype(np.float64)
@@ -179,24 +188,40 @@ class OraclePipeline:
             stat = np.ones(n_obj, np.uint8)
             inl_sets = [ids.copy() for ids in dyn["objects"]]
             Twc_c = inv_rigid_f32(Tc)
+            n_mm_obj = n_mm_won = 0
+            H_all = [np.eye(4, dtype=f32) for _ in range(n_obj)]                        # mCurrentFrame.vObjMod (identity where the object is not tracked)
             for a, ids in enumerate(dyn["objects"]):                                    # GetInitModelObj (+ object LM)
                 n_r, T_r, inl_r = self._ransac(lo["xyz"][ids], np.c_[lo["corr_x"][ids], lo["corr_y"][ids]])
                 n_ro += n_r
+                # Tracking.cc:1767-1825: an object that carries a label of the last frame also gets the motion model
+                # mCurrentFrame.mTcw * mLastFrame.vObjMod[PreObjID]; its 0.4 px inliers (fp32, :1784-1797) against RANSAC's:
+                # RANSAC wins only with MORE inliers (:1803)
+                seed, chosen = T_r.astype(f32), inl_r.astype(bool)
+                prev = np.nonzero(np.asarray(last["mod"]) == dyn["mod"][a])[0]
+                if prev.size:
+                    MMo = matmul4_f32(Tc, last["H"][int(prev[0])])
+                    inl_mo = self._mm_inliers(MMo, lo["xyz"][ids].astype(f32), lo["corr_x"][ids], lo["corr_y"][ids])
+                    n_mm_obj += int(inl_mo.sum())
+                    if not (n_r > int(inl_mo.sum())):
+                        seed, chosen = MMo, inl_mo
+                        n_mm_won += 1
                 if not self.build_lm:
                     continue
                 self.stage_s["ransac_init"] += tick() - t; t = tick()
-                sub = ids[inl_r.astype(bool)]
+                sub = ids[chosen]
                 if sub.size < 50:
                     stat[a] = 0
                     continue
-                Tn, fl_new, inl_lm, ninl, _ = self._lm(lo["key_x"][sub], lo["key_y"][sub], lo["flow_x"][sub], lo["flow_y"][sub], lo["depth"][sub], T_r.astype(f32).astype(np.float64), 0.5, 200)
+                Tn, fl_new, inl_lm, ninl, _ = self._lm(lo["key_x"][sub], lo["key_y"][sub], lo["flow_x"][sub], lo["flow_y"][sub], lo["depth"][sub], seed.astype(np.float64), 0.5, 200)
                 il = inl_lm.astype(bool)
                 olab[sub[~il]] = -1
                 good = sub[il]
                 cur_ox[good] = lo["key_x"][good] + fl_new[il, 0].astype(f32); cur_oy[good] = lo["key_y"][good] + fl_new[il, 1].astype(f32)
                 inl_sets[a] = good
-                self.motions.append(dict(mod_label=int(dyn["mod"][a]), sem_label=int(dyn["sem"][a]), n_inliers=int(ninl), H=matmul4_f32(Twc_c, Tn.astype(f32))))
+                H_all[a] = matmul4_f32(Twc_c, Tn.astype(f32))
+                self.motions.append(dict(mod_label=int(dyn["mod"][a]), sem_label=int(dyn["sem"][a]), n_inliers=int(ninl), H=H_all[a]))
                 self.stage_s["lm_obj"] += tick() - t; t = tick()
+            counts["n_mm_inliers_obj"], counts["n_motion_model_obj"] = n_mm_obj, n_mm_won
             self.stage_s["ransac_init"] += tick() - t; t = tick()
             # top-up source: all ORB keypoints, or - UseSampleFeature - the filtered samples mvStatKeysTmp (Tracking.cc:2718-2721)
             src_x, src_y = (kp["x"][st["keep_idx"]], kp["y"][st["keep_idx"]]) if self.use_sample else (kp["x"], kp["y"])
@@ -211,6 +236,7 @@ class OraclePipeline:
             st_n = dict(key_x=rs["key_x"], key_y=rs["key_y"], corr_x=rs["corr_x"], corr_y=rs["corr_y"], flow_x=rs["flow_x"], flow_y=rs["flow_y"], depth=rs["depth"], xyz=xyz_s)
             ob_n = dict(key_x=ro["key_x"], key_y=ro["key_y"], corr_x=ro["corr_x"], corr_y=ro["corr_y"], flow_x=ro["flow_x"], flow_y=ro["flow_y"], depth=ro["depth"], label=ro["sem"], xyz=xyz_o)
             sem_pos, mod, stat_n = dyn["sem"], dyn["mod"], stat
+            H_last = H_all
             self.result = dict(static=rs, objects=ro)
         else:
             I4 = np.eye(4, dtype=f32)                                                  # Initialization(): Get3DinCamera
@@ -220,13 +246,15 @@ class OraclePipeline:
             ob_n = dict(key_x=ob["key_x"], key_y=ob["key_y"], corr_x=ob["corr_x"], corr_y=ob["corr_y"], flow_x=ob["flow_x"], flow_y=ob["flow_y"], depth=ob["depth"],
                         label=ob["label"], xyz=T.get3d_world(o, ob["key_x"], ob["key_y"], ob["depth"], self.K4, I4))
             sem_pos, mod, stat_n = np.zeros(0, np.int32), np.zeros(0, np.int32), np.zeros(0, np.uint8)
+            H_last = []
             counts["n_static_tracks"] = counts["n_dynamic_tracks"] = 0
+            counts["n_mm_inliers_obj"] = counts["n_motion_model_obj"] = 0
         counts["n_static_tracked"], counts["n_object_tracked"] = int(st_n["corr_x"].size), int(ob_n["corr_x"].size)
         counts["n_ransac_cam"], counts["n_motion_model_cam"], counts["n_ransac_obj"] = int(n_rc), int(n_mm), int(n_ro)
         counts["n_cam_inliers"], counts["cam_lm_iterations"] = n_cam_inl, cam_its
         self.vel = matmul4_f32(Tc, inv_rigid_f32(self.Tl))                             # mVelocity
         self.stage_s["tracking_k11_k15"] += tick() - t
-        self.last = dict(st=st_n, ob=ob_n, mask=mask, flow=fr["flow"], sem_pos=sem_pos, mod=mod, stat=stat_n)
+        self.last = dict(st=st_n, ob=ob_n, mask=mask, flow=fr["flow"], sem_pos=sem_pos, mod=mod, stat=stat_n, H=H_last)
         self.Tl = Tc
         self.f_id += 1
         return counts

@@ -151,3 +151,22 @@ def test_mask_warp_matches_numpy(oracle):
         exp[(jj + fy)[ok], (kk + fx)[ok]] = lab
         assert np.array_equal(got, exp)
         assert (got != cur).sum() > 100
+
+
+def test_get_init_model_obj_prefers_the_motion_model_on_ties(oracle):
+    """The checker's own GetInitModelObj (tests/pipeline_ref.py): exact flow + constant object velocity -> RANSAC and the motion
+    model Tcw * vObjMod_prev both explain every point; the reference keeps RANSAC only when it has MORE inliers
+    (src/Tracking.cc:1803), so the motion model seeds every object from its second tracked frame on, and never in its first."""
+    from tests.pipeline_ref import OraclePipeline
+    from vdo_slam_amd import synth_seq as SQ
+    n = 5
+    Ts = SQ.camera_poses(n); objs = SQ.default_objects()
+    ref = OraclePipeline(oracle, build_lm=True)
+    rows = [ref.step(SQ.render_frame(k, Ts, objs)) for k in range(n)]
+    assert rows[1]["n_objects"] >= 2 and rows[1]["n_motion_model_obj"] == 0 and rows[1]["n_mm_inliers_obj"] == 0
+    for c in rows[2:]:
+        assert c["n_motion_model_obj"] == c["n_objects"] >= 2
+        assert c["n_mm_inliers_obj"] >= c["n_ransac_obj"]
+    # the motions recovered from motion-model seeds are the true ones
+    for m in ref.motions:
+        assert abs(m["H"][:3, 3] - objs[m["sem_label"] - 1]["v"]).max() < 0.02

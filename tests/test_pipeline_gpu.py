@@ -14,7 +14,7 @@ from vdo_slam_amd.pipeline import FramePipeline, kitti_params
 pytestmark = pytest.mark.gpu
 W, H = synth.KITTI_W, synth.KITTI_H
 KEYS = ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects", "n_recovered_masks",
-        "n_static_tracks", "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj")
+        "n_static_tracks", "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_mm_inliers_obj", "n_motion_model_obj")
 
 
 def _dev(fr):

@@ -77,7 +77,7 @@ def test_omd_shaped_track_with_sampled_features_matches_the_oracle(oracle):
     pipe = FramePipeline(ctx, ctx_lm, prm, ctx_obj, ctx_w)
     ref = OraclePipeline(oracle, build_lm=True, K4=OMD_K, use_sample=True, sample_seed=11, sf_mg=0.02)
     keys = ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects", "n_static_tracks", "n_dynamic_tracks",
-            "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations")
+            "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations", "n_mm_inliers_obj", "n_motion_model_obj")
     for k in range(n_frames):
         fr = SQ.render_frame(k, Ts, objs, w=OMD_W, h=OMD_H, K4=OMD_K, flow_sigma=0.05)
         d = {q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")}

@@ -59,7 +59,7 @@ def test_full_track_sequence_matches_the_oracle_sequence(oracle):
     pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1))
     ref = OraclePipeline(oracle, build_lm=True)
     keys = ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects", "n_recovered_masks", "n_static_tracks",
-            "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations")
+            "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations", "n_mm_inliers_obj", "n_motion_model_obj")
     for k in range(n_frames):
         fr = SQ.render_frame(k, Ts, objs)
         d = {q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")}
@@ -136,7 +136,7 @@ def test_noisy_sequence_with_invalid_pixels_and_a_dropped_mask_matches_the_oracl
     pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1), ctx_obj, ctx_w)
     ref = OraclePipeline(oracle, build_lm=True)
     keys = ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects", "n_recovered_masks", "n_static_tracks",
-            "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations")
+            "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations", "n_mm_inliers_obj", "n_motion_model_obj")
     recovered = 0
     for k in range(n_frames):
         fr = SQ.render_frame(k, Ts, objs, flow_sigma=0.3, invalid_depth=0.02, zero_flow=0.01, drop_masks=drop)
@@ -219,7 +219,7 @@ def test_track_sequence_edge_cases_match_the_oracle(oracle, scenario):
     pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1), ctx_obj, ctx_w)
     ref = OraclePipeline(oracle, build_lm=True)
     keys = ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects", "n_static_tracks", "n_dynamic_tracks",
-            "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations")
+            "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations", "n_mm_inliers_obj", "n_motion_model_obj")
     seen_objects = most_motions = 0
     for k in range(n_frames):
         fr = SQ.render_frame(k, Ts, objs, flow_sigma=0.05)
@@ -262,7 +262,7 @@ def test_turning_objects_that_leave_and_enter_match_the_oracle(oracle):
     pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1), ctx_obj, ctx_w)
     ref = OraclePipeline(oracle, build_lm=True)
     keys = ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects", "n_recovered_masks", "n_static_tracks",
-            "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations")
+            "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations", "n_mm_inliers_obj", "n_motion_model_obj")
     labels_seen, recovered, turning_checked = set(), 0, 0
     for k in range(n_frames):
         fr = SQ.render_frame(k, Ts, objs, flow_sigma=0.3, invalid_depth=0.02, zero_flow=0.01, drop_masks=drop)
@@ -288,4 +288,46 @@ def test_turning_objects_that_leave_and_enter_match_the_oracle(oracle):
                 turning_checked += abs(ob.get("yaw_rate", 0.0)) > 0.01
     assert 2 in labels_seen and 5 in labels_seen            # the leaving and the entering object were both tracked while present
     assert turning_checked >= 3 and recovered >= 1
+    pipe.close()
+
+
+@pytest.mark.parametrize("flow_sigma, mm_wins", [(0.1, True), (0.5, False)])
+def test_object_motion_model_branch_of_get_init_model_obj(oracle, flow_sigma, mm_wins):
+    """GetInitModelObj (src/Tracking.cc:1767-1825): an object that was tracked in the last frame also gets the motion model
+    mCurrentFrame.mTcw * mLastFrame.vObjMod[PreObjID]; RANSAC seeds the LM (and defines ObjId_sub) only when it has MORE 0.4 px
+    inliers.  Low flow noise: the constant-velocity motion model explains at least as many points as the RANSAC model -> it seeds
+    every re-tracked object.  Heavy flow noise: the last frame's motion is too inaccurate, RANSAC wins although the motion model
+    exists.  Either way GPU Track() == oracle Track(): choice, subset sizes, LM inliers, motions."""
+    import torch
+    from tests.pipeline_ref import OraclePipeline
+    n_frames = 7
+    Ts = SQ.camera_poses(n_frames)
+    objs = SQ.default_objects()
+    ctx, ctx_lm, ctx_obj, ctx_w = Context(0), Context(0), Context(0), Context(0)
+    pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=1), ctx_obj, ctx_w)
+    ref = OraclePipeline(oracle, build_lm=True)
+    keys = ("n_objects", "n_ransac_obj", "n_mm_inliers_obj", "n_motion_model_obj", "n_ransac_cam", "n_motion_model_cam", "n_cam_inliers", "n_static_tracked")
+    won = had_model = 0
+    exp_motions = []
+    got_motions = []
+    for k in range(n_frames):
+        fr = SQ.render_frame(k, Ts, objs, flow_sigma=flow_sigma)
+        d = {q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")}
+        torch.cuda.synchronize()
+        got = pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
+        if k > 0:
+            got_motions.append(pipe.motions())              # (deferred object stage: the motions of frame k-1, consumed inside this Step)
+        exp = ref.step(fr)
+        exp_motions.append(ref.motions)
+        assert {q: got[q] for q in keys} == {q: exp[q] for q in keys}, (k, got, exp)
+        np.testing.assert_allclose(pipe.pose(), ref.Tl, rtol=0, atol=5e-6)
+        won += got["n_motion_model_obj"]; had_model += got["n_mm_inliers_obj"] > 0
+        if k == 1:
+            assert got["n_mm_inliers_obj"] == 0 and got["n_motion_model_obj"] == 0     # first frame of every object: no motion model (:1829-1838)
+    pipe.flush()
+    got_motions.append(pipe.motions())
+    for ms, mo in zip(got_motions, exp_motions):
+        _motions_match(ms, mo)
+    assert had_model >= 4
+    assert (won >= 6) if mm_wins else (won == 0), won
     pipe.close()

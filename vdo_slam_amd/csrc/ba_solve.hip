@@ -1020,11 +1020,17 @@ void launch_reduced_rhs(const BADev& d, hipStream_t s, const Reducer& R) {
 
 static size_t pc_strip_bytes(const BADev& d) {
   const size_t bytes = (size_t)d.pc_waves * 6 * (size_t)d.pc_maxlen * sizeof(double);
-  static std::atomic<size_t> raised{0};     // more than the default 64 KB of dynamic LDS: tell the runtime (once per size; the calls are idempotent)
-  if (bytes > (size_t)(48 * 1024) && bytes > raised.load(std::memory_order_relaxed)) {
-    const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_vec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-    if (e1 == hipSuccess && e2 == hipSuccess) raised.store(bytes, std::memory_order_relaxed);
+  // more than the default 64 KB of dynamic LDS: tell the runtime.  The attribute is per DEVICE (a process may hold BA contexts on
+  // several GPUs): the size already granted is remembered per device id; the calls are idempotent.
+  static std::atomic<size_t> raised[64];
+  if (bytes > (size_t)(48 * 1024)) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (bytes > raised[dev].load(std::memory_order_relaxed)) {
+      const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_vec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e1 == hipSuccess && e2 == hipSuccess) raised[dev].store(bytes, std::memory_order_relaxed);
+    }
   }
   return bytes;
 }

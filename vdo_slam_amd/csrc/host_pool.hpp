@@ -24,43 +24,61 @@ class LevelPool {
     cv_.notify_all();
     for (auto& t : th_) t.join();
   }
+  // Runs fn(0) .. fn(n_tasks-1) on the workers and the calling thread; returns when all are done AND no worker still holds the
+  // batch.  A batch is a descriptor on the caller's stack, published under mu_ with a generation count: a worker that wakes late
+  // finds either the batch it was woken for, a later one, or none - never a half-reset one.  Calls from several threads (the static
+  // pool of the RANSAC refits is shared by every pipeline of a process) are serialised.
   template <class F>
   void run(int n_tasks, F&& fn) {
-    fn_ = [&fn](int i) { fn(i); };
-    n_ = n_tasks; next_.store(0, std::memory_order_relaxed); done_.store(0, std::memory_order_relaxed);
-    { std::lock_guard<std::mutex> g(mu_); ++gen_; }
+    if (n_tasks <= 0) return;
+    std::lock_guard<std::mutex> serial(run_mu_);
+    Batch b;
+    b.fn = [&fn](int i) { fn(i); };
+    b.n = n_tasks;
+    { std::lock_guard<std::mutex> g(mu_); cur_ = &b; ++gen_; }
     cv_.notify_all();
-    drain();
-    while (done_.load(std::memory_order_acquire) < n_) std::this_thread::yield();
+    drain(b);
+    while (b.done.load(std::memory_order_acquire) < b.n) std::this_thread::yield();
+    { std::lock_guard<std::mutex> g(mu_); cur_ = nullptr; }                       // from here on no worker can pick the batch up ...
+    while (b.active.load(std::memory_order_acquire) != 0) std::this_thread::yield();   // ... and those that did have left it
   }
 
  private:
-  void drain() {
+  struct Batch {
+    std::function<void(int)> fn;
+    int n = 0;
+    std::atomic<int> next{0}, done{0};
+    std::atomic<int> active{0};       // workers inside drain(); incremented under mu_ while the batch is published
+  };
+  static void drain(Batch& b) {
     for (;;) {
-      const int i = next_.fetch_add(1, std::memory_order_relaxed);
-      if (i >= n_) break;
-      fn_(i);
-      done_.fetch_add(1, std::memory_order_release);
+      const int i = b.next.fetch_add(1, std::memory_order_relaxed);
+      if (i >= b.n) break;
+      b.fn(i);
+      b.done.fetch_add(1, std::memory_order_release);
     }
   }
   void worker() {
     uint64_t seen = 0;
     for (;;) {
+      Batch* b;
       {
         std::unique_lock<std::mutex> l(mu_);
         cv_.wait(l, [&] { return gen_ != seen; });
         seen = gen_;
         if (stop_) return;
+        b = cur_;
+        if (b) b->active.fetch_add(1, std::memory_order_relaxed);
       }
-      drain();
+      if (!b) continue;
+      drain(*b);
+      b->active.fetch_sub(1, std::memory_order_release);
     }
   }
   std::vector<std::thread> th_;
-  std::mutex mu_;
+  std::mutex mu_, run_mu_;
   std::condition_variable cv_;
-  std::function<void(int)> fn_;
-  std::atomic<int> next_{0}, done_{0};
-  int n_ = 0;
+  Batch* cur_ = nullptr;               // guarded by mu_
   uint64_t gen_ = 0;
   bool stop_ = false;
 };

@@ -6,8 +6,18 @@
 // librccl is opened at run time (dlopen): a process that already carries an RCCL (e.g. torch's) shares it, and the library
 // still loads on a machine without RCCL (single-GPU use never touches it).
 #include <dlfcn.h>
-#include <rccl/rccl.h>
+#include <hip/hip_runtime.h>
+// The handful of RCCL types / enum values this file passes through the dlsym'ed entry points, declared here so that the library
+// builds on a machine without the RCCL headers (the ABI of nccl.h: 128-byte unique id, opaque communicator, C enums).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+typedef enum { ncclSuccess = 0 } ncclResult_t;
+typedef enum { ncclSum = 0, ncclMax = 2 } ncclRedOp_t;
+typedef enum { ncclDouble = 8 } ncclDataType_t;
+}
 
+#include <cstdio>
 #include <cstring>
 #include <mutex>
 
@@ -25,6 +35,7 @@ struct RcclApi {
   ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
   bool ok = false;
+  char why[256] = "symbols missing";   // dlerror() of the failed dlopen, captured once (a second dlerror() call returns NULL)
 };
 
 static RcclApi& rccl_api() {
@@ -35,7 +46,7 @@ static RcclApi& rccl_api() {
       api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (api.handle) break;
     }
-    if (!api.handle) return;
+    if (!api.handle) { const char* e = dlerror(); if (e) std::snprintf(api.why, sizeof api.why, "%s", e); return; }
     api.GetUniqueId = (decltype(api.GetUniqueId))dlsym(api.handle, "ncclGetUniqueId");
     api.CommInitRank = (decltype(api.CommInitRank))dlsym(api.handle, "ncclCommInitRank");
     api.CommDestroy = (decltype(api.CommDestroy))dlsym(api.handle, "ncclCommDestroy");
@@ -64,7 +75,7 @@ static int rccl_err(const char* what, ncclResult_t r) {
 
 extern "C" int vdo_rccl_unique_id(char id_out[128]) {
   RcclApi& A = rccl_api();
-  if (!A.ok) return set_error(VDO_ERR_UNSUPPORTED, "librccl could not be loaded: %s", dlerror() ? dlerror() : "symbols missing");
+  if (!A.ok) return set_error(VDO_ERR_UNSUPPORTED, "librccl could not be loaded: %s", A.why);
   if (!id_out) return set_error(VDO_ERR_INVALID, "vdo_rccl_unique_id: null argument");
   static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
   ncclUniqueId id;
@@ -76,7 +87,7 @@ extern "C" int vdo_rccl_unique_id(char id_out[128]) {
 
 extern "C" int vdo_rccl_comm_create(vdo_ctx* ctx, const char id[128], int n_ranks, int rank, vdo_rccl_comm** out) {
   RcclApi& A = rccl_api();
-  if (!A.ok) return set_error(VDO_ERR_UNSUPPORTED, "librccl could not be loaded");
+  if (!A.ok) return set_error(VDO_ERR_UNSUPPORTED, "librccl could not be loaded: %s", A.why);
   if (!ctx || !id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks) return set_error(VDO_ERR_INVALID, "vdo_rccl_comm_create: bad argument");
   int rc = ctx_bind(ctx);
   if (rc != VDO_OK) return rc;

@@ -140,6 +140,19 @@ class _Counter:
     error = None
 
 
+def _one_gpu_per_rank(ctx, group):
+    """RCCL needs a device of its own per rank (ncclCommInitRank fails - or hangs - when two ranks of a communicator sit on the
+    same GPU).  Every rank contributes (host, device) and all take the same decision."""
+    import socket
+    import torch.distributed as dist
+    import os
+    # (a launcher that narrows the visible devices per rank makes every rank's device "0": the masks are part of the identity)
+    mine = (socket.gethostname(), int(getattr(ctx, "device", 0)), os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", ""))
+    everyone = [None] * dist.get_world_size(group)
+    dist.all_gather_object(everyone, mine, group=group)
+    return len(set(everyone)) == len(everyone)
+
+
 class ShardedBatchBA:
     """Batch BA over ``dist.get_world_size()`` GPUs.  ``optimize`` returns the same LM statistics on
     every rank; ``estimates`` returns the full pose array and the full point array (shards gathered).
@@ -156,7 +169,7 @@ class ShardedBatchBA:
         self.shard, self.mine = shard_graph(graph, self.owner, self.rank)
         self.ba = BatchBA(ctx, self.shard)
         if transport is None:
-            transport = "rccl" if dist.get_backend(group) == "nccl" else "callback"
+            transport = "rccl" if dist.get_backend(group) == "nccl" and _one_gpu_per_rank(ctx, group) else "callback"
         self.transport = transport
         L = K.lib()
         self.comm = None

@@ -465,15 +465,42 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
       for (int a = 0; a < n_objects; ++a) rip[a] = rin.data() + off[a];
       VDO_TRY(vdo_pnp_ransac_batch(ctx_, n_objects, pp.data(), pr.data(), rip.data()));
       for (int a = 0; a < n_objects; ++a) fc.n_ransac_obj += pr[a].n_inliers;
+      // ---- the motion model of an object that was there in the last frame: MotionModel = mCurrentFrame.mTcw * mLastFrame.vObjMod[PreObjID],
+      // its 0.4 px inliers; RANSAC seeds the LM only if it has MORE inliers                       Tracking.cc:1767-1825
+      std::vector<uint8_t>& min_ = inl_mm_;
+      min_.assign((size_t)off[n_objects] + 1, 0);
+      obj_use_mm_.assign(n_objects, 0);
+      obj_mm_.resize(16 * (size_t)n_objects);
+      for (int a = 0; a < n_objects; ++a) {
+        int pre = -1;
+        for (size_t i = 0; i < last_mod_label_.size(); ++i) if (last_mod_label_[i] == omod[a]) { pre = (int)i; break; }
+        if (pre < 0 || 16 * (size_t)pre + 16 > last_obj_mod_.size()) continue;
+        float* MM = obj_mm_.data() + 16 * (size_t)a;
+        const float* Hl = last_obj_mod_.data() + 16 * (size_t)pre;
+        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float s = 0; for (int k = 0; k < 4; ++k) s += Tcw[4 * i + k] * Hl[4 * k + j]; MM[4 * i + j] = s; }
+        int mm = 0;
+        for (int q = off[a]; q < off[a + 1]; ++q) {
+          const int id = idx[q];
+          const float x = obj_.xyz[3 * id], y = obj_.xyz[3 * id + 1], z = obj_.xyz[3 * id + 2];
+          const float xc = MM[0] * x + MM[1] * y + MM[2] * z + MM[3], yc = MM[4] * x + MM[5] * y + MM[6] * z + MM[7], invz = 1.0f / (MM[8] * x + MM[9] * y + MM[10] * z + MM[11]);
+          const float u_ = obj_.cx[id] - (p_.K4[0] * xc * invz + p_.K4[2]), v_ = obj_.cy[id] - (p_.K4[1] * yc * invz + p_.K4[3]);
+          if (std::sqrt(u_ * u_ + v_ * v_) < 0.4f) { min_[q] = 1; ++mm; }
+        }
+        fc.n_mm_inliers_obj += mm;
+        if (!(pr[a].n_inliers > mm)) { obj_use_mm_[a] = 1; ++fc.n_motion_model_obj; }
+      }
       if (lm_obj_) {
-        // per object: ObjIdTest_in = RANSAC inliers; fewer than 50 -> the object is not tracked this frame (Tracking.cc:879)
+        // per object: ObjIdTest_in = inliers of the chosen model; fewer than 50 -> the object is not tracked this frame (Tracking.cc:879)
         obj_subsets_.assign(n_objects, {});
         obj_stat_.assign(n_objects, 1);
         obj_buf_.resize(n_objects);
         int need_pts = 0;
         for (int a = 0; a < n_objects; ++a) {
           std::vector<int32_t>& sub = obj_subsets_[a];
-          for (int q = off[a]; q < off[a + 1]; ++q) if (rin[q]) sub.push_back(idx[q]);
+          const std::vector<uint8_t>& flag = obj_use_mm_[a] ? min_ : rin;
+          for (int q = off[a]; q < off[a + 1]; ++q) if (flag[q]) sub.push_back(idx[q]);
+          // (the reference also sets vObjLabel = -1 outside the chosen set, Tracking.cc:1841-1846: RenewFrameInfo only reads the labels of LM
+          // inliers, a subset of the chosen set, and then replaces vObjLabel, :2862,2991 - nothing observes it)
           bool gated = true;                                                            // ground truth in both frames (Tracking.cc:791-841)
           if (gate_on_) {
             gated = std::find(gate_cur_.begin(), gate_cur_.end(), osem[a]) != gate_cur_.end() && std::find(gate_last_.begin(), gate_last_.end(), osem[a]) != gate_last_.end();
@@ -490,7 +517,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
           B.ob.clear(); B.fl.clear(); B.dp.clear();
           for (int id : sub) { B.ob.push_back(obj_.x[id]); B.ob.push_back(obj_.y[id]); B.fl.push_back(obj_.fx[id]); B.fl.push_back(obj_.fy[id]); B.dp.push_back(obj_.d[id]); }
           double T0[16];
-          for (int i = 0; i < 16; ++i) T0[i] = (double)(float)pr[a].T[i];                 // mInitModel (CV_32F)
+          for (int i = 0; i < 16; ++i) T0[i] = obj_use_mm_[a] ? (double)obj_mm_[16 * (size_t)a + i] : (double)(float)pr[a].T[i];   // mInitModel (CV_32F)
           vdo_flow2_problem fp;
           fill_flow2(fp, (int)sub.size(), B.ob.data(), B.fl.data(), B.dp.data(), p_.K4, Tcw_last_, T0, 0.5, 200);
           VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, &fp));
@@ -638,6 +665,13 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
     last_sem_pos_.assign(osem.begin(), osem.begin() + n_objects);
     last_mod_label_.assign(omod.begin(), omod.begin() + n_objects);
     last_obj_stat_.assign(stat.begin(), stat.begin() + n_objects);
+    // mLastFrame.vObjMod of the next frame: the motion of every object of this frame, identity where it was not tracked (Tracking.cc:836,884,933)
+    last_obj_mod_.assign(16 * (size_t)n_objects, 0.f);
+    for (int a = 0, m = 0; a < n_objects; ++a) {
+      float* Hd = last_obj_mod_.data() + 16 * (size_t)a;
+      if (obj && obj == lm_obj_ && stat[a] && m < (int)motions_.size()) std::memcpy(Hd, motions_[m++].H, 64);
+      else Hd[0] = Hd[5] = Hd[10] = Hd[15] = 1.f;
+    }
   }
   fc.n_object_tracked = (int)nobj.x.size();
   obj_ = std::move(nobj);                                // from here on the next frame's object chain (K15, K11, K13 ...) can start

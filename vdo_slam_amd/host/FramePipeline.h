@@ -48,7 +48,9 @@ struct PipelineParams {
 };
 
 struct FrameCounts { int n_orb, n_static_new, n_object_samples, n_static_tracked, n_object_tracked, n_objects, n_recovered_masks, n_static_tracks, n_dynamic_tracks,
-                         n_ransac_cam, n_motion_model_cam, n_ransac_obj, n_cam_inliers, cam_lm_iterations; };
+                         n_ransac_cam, n_motion_model_cam, n_ransac_obj, n_cam_inliers, cam_lm_iterations,
+                         n_mm_inliers_obj,        // sum over the re-tracked objects of the frame of their motion-model inliers (Tracking.cc:1784-1797)
+                         n_motion_model_obj; };   // objects of the frame whose LM was seeded by the motion model (Tracking.cc:1803-1825: RANSAC did not have MORE inliers)
 
 class FramePipeline {
  public:
@@ -142,6 +144,7 @@ class FramePipeline {
   std::atomic<int> mask_final_{0};    // +-(frame id + 1): UpdateMask of that frame is through (K10 on the ORB thread waits for it; negative: skip)
   ObjSet obj_;                        // last frame: object keys, correspondences, depth, semantic + motion labels
   std::vector<int32_t> last_sem_pos_, last_mod_label_; std::vector<uint8_t> last_obj_stat_;
+  std::vector<float> last_obj_mod_;   // mLastFrame.vObjMod: 16 floats per object of the last frame (identity for an object that was not tracked, Tracking.cc:836,884)
   float Tcw_last_[16], vel_[16];      // last pose, mVelocity
   // scratch reused across frames
   std::vector<float> kx_, ky_, kr_, ka_, ks_; std::vector<int32_t> ko_;
@@ -158,7 +161,8 @@ class FramePipeline {
   vdo_flow2_batch *lm_cam_ = nullptr, *lm_obj_ = nullptr;
   std::vector<int32_t> cam_subset_, inl_off_, inl_idx_;
   std::vector<std::vector<int32_t>> obj_subsets_;
-  std::vector<uint8_t> inl_mm_, obj_stat_;
+  std::vector<uint8_t> inl_mm_, obj_stat_, obj_use_mm_;   // obj_use_mm_[a]: the motion model seeds object a's LM
+  std::vector<float> obj_mm_;                             // MotionModel of the frame's objects (16 floats each)
   std::vector<ObjBuf> obj_buf_;
   float Tcw_init_[16];
 };

@@ -17,7 +17,7 @@ class PipelineParams(C.Structure):
 
 class FrameCounts(C.Structure):
     _fields_ = [(k, C.c_int) for k in ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects",
-                                       "n_recovered_masks", "n_static_tracks", "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations")]
+                                       "n_recovered_masks", "n_static_tracks", "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations", "n_mm_inliers_obj", "n_motion_model_obj")]
 
     def as_dict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
