@@ -210,7 +210,7 @@ def main():
     import threading
     defer = 0 if os.environ.get("VDO_BENCH_SYNC_OBJECTS") else 1
     cpus = _cpu_budget() / max(1, world)
-    AGG = ("cam_lm_iterations", "n_static_tracked", "n_object_tracked", "n_objects", "n_ransac_cam", "n_cam_inliers", "n_ransac_obj", "n_recovered_masks")
+    AGG = ("cam_lm_iterations", "n_static_tracked", "n_object_tracked", "n_objects", "n_ransac_cam", "n_cam_inliers", "n_ransac_obj", "n_recovered_masks", "n_motion_model_obj", "n_mm_inliers_obj")
 
     class Replica:
         """One sequence on this GPU: a FramePipeline with its own HIP streams (4 contexts), host helper thread and Map."""
@@ -333,6 +333,7 @@ def main():
                    "static_tracklets": counts.n_static_tracks, "dynamic_tracklets": counts.n_dynamic_tracks,
                    "per_frame_mean": {q: round(v / n_all, 2) for q, v in agg.items()},
                    "n_recovered_masks_total": int(agg["n_recovered_masks"]),
+                   "n_motion_model_obj": int(agg["n_motion_model_obj"]),      # object-frames whose LM was seeded by the motion model (GetInitModelObj, Tracking.cc:1803-1825)
                    "step_ms_p50_p90_max": [round(float(np.percentile(step_ms, 50)), 3), round(float(np.percentile(step_ms, 90)), 3), round(max(step_ms), 3)],
                    "trajectory_drift_m": drift, "object_translations_last_frame": [np.round(m["H"][:3, 3], 4).tolist() for m in motions],
                    "host_ms_per_section": {k_: round(v_ / n_all, 4) for k_, v_ in sect.items()}},

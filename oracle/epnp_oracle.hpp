@@ -1,385 +1,253 @@
-// TEST INFRASTRUCTURE - CPU oracle.  EPnP (Lepetit, Moreno-Noguer, Fua: "EPnP: an accurate O(n) solution to the PnP problem", IJCV
-// 2009) in the 4-control-point formulation OpenCV 3.4 uses for the final refit of cv::solvePnPRansac: with SOLVEPNP_P3P / AP3P the
-// winning RANSAC model is re-estimated on its inliers by solvePnP(..., SOLVEPNP_EPNP) (modules/calib3d/src/solvepnp.cpp, not vendored
-// in the reference; call sites reference src/Tracking.cc:1652-1655, 1755-1758).  OpenCV is not available here: restated from the
-// published algorithm and OpenCV's epnp.cpp structure (choose_control_points, compute_barycentric_coordinates, fill_M, M^T M and
-// its 4 smallest eigenvectors, compute_L_6x10 / compute_rho, find_betas_approx_1/2/3, 5 Gauss-Newton steps each, compute_R_and_t,
-// smallest mean reprojection error wins) - PARITY UNPINNED.  Known liberties (all rounding-level or degenerate-case only):
-//   * eigen-decompositions by cyclic Jacobi instead of OpenCV's SVD routines (eigenvector signs are irrelevant to the result);
-//   * the small least-squares systems by pseudo-inverse through the normal equations' eigen-decomposition (cvSolve CV_SVD), the
-//     Gauss-Newton step by Householder QR (qr_solve);
-//   * the absolute orientation by Horn's quaternion method (largest eigenvector of the 4x4 N matrix) instead of SVD(ABt) + the
-//     det < 0 row flip - the same rotation whenever the optimum is a proper rotation;
-//   * pixel coordinates + the camera matrix (zero distortion: undistortPoints is the identity up to rounding); no Rodrigues round trip.
-// Only +, -, *, / and sqrt: the product (vdo_slam_amd/csrc/epnp_refit.hpp) performs the same operations in the same order, so the
-// refit pose is the same bit pattern on both sides.
+// TEST INFRASTRUCTURE - CPU oracle (see vdo_oracle.h).  EPnP: the re-estimation cv::solvePnPRansac(..., SOLVEPNP_AP3P) performs
+// on the inliers of the winning model since OpenCV 3.3 (solvePnP(inliers, SOLVEPNP_EPNP)); the reference pins OpenCV 3.4.0
+// (/root/reference/Dockerfile:40-63) and receives that pose in Tracking::GetInitModelCam / GetInitModelObj
+// (/root/reference/src/Tracking.cc:1652-1660, 1755-1763).  OpenCV is not vendored under /root/reference, so this restates the
+// published algorithm (Lepetit, Moreno-Noguer, Fua: "EPnP: an accurate O(n) solution to the PnP problem", IJCV 2009) in the
+// structure and WITH THE NUMERICAL TOOLS OF OpenCV's calib3d/epnp.cpp - parity unpinned until run against OpenCV 3.4.0
+// (tools/pin_reference/):
+//   choose_control_points            centroid + principal directions from the SVD of PW0^T PW0, scaled by sqrt(sigma / n)
+//   compute_barycentric_coordinates  inverse of the 3x3 control-point matrix THROUGH ITS SVD (cvInvert(CV_SVD))
+//   fill_M / compute_pose            the dense 2n x 12 matrix M, M^T M by full products, SVD of M^T M (svd_opencv below), the four vectors of the smallest singular values
+//   find_betas_approx_1/2/3          cvSolve(..., CV_SVD): x = V diag(1/w) U^T b, singular values under 2 eps sum(w) dropped
+//   gauss_newton                     5 iterations on the 6x4 system, solved by an orthogonal (Givens) triangularisation
+//   estimate_R_and_t                 SVD of sum (pc - pc0)(pw - pw0)^T, R = U V^T, third ROW of R negated when det R < 0
+// This file is deliberately NOT the product's routine (vdo_slam_amd/csrc/epnp_refit.hpp: running sums for M^T M, QL / cyclic
+// Jacobi eigen-solvers, normal equations for the small systems, Horn's quaternion for the orientation): the two share the
+// algorithm, not the arithmetic, and are compared to 1e-9 (tests/test_oracle_p3p.py, tests/test_ransac_gpu.py) - agreement is
+// evidence, not an identity.  One product decision is mirrored because OpenCV's behaviour there is an artefact: (near-)coplanar
+// point sets (third singular value of PW0^T PW0 below 1e-8 of the first) return err < 0 and the caller keeps the hypothesis.
 #pragma once
 #include <cmath>
 #include <cstring>
+#include <utility>
 #include <vector>
 
 namespace ref_epnp {
 
-// cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (row-major, overwritten); V: columns = eigenvectors;
-// eigenvalues in w, sorted descending (eigenvector columns permuted alike)
-inline void jacobi_eig(int n, double* A, double* V, double* w) {
-  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0, diag = 0.0;
-    for (int p = 0; p < n; ++p) { diag += A[p * n + p] * A[p * n + p]; for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q]; }
-    if (off <= 1e-32 * diag || off == 0.0) break;
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = A[p * n + q];
-        if (apq == 0.0) continue;
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < n; ++k) {                 // rows p, q:  A <- J^T A
-          const double akp = A[p * n + k], akq = A[q * n + k];
-          A[p * n + k] = c * akp - s * akq; A[q * n + k] = s * akp + c * akq;
-        }
-        for (int k = 0; k < n; ++k) {                 // columns p, q:  A <- A J
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < n; ++k) {
-          const double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
-        }
-      }
-  }
-  for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
-  for (int i = 0; i < n - 1; ++i) {                   // selection sort, descending
-    int m = i;
-    for (int j = i + 1; j < n; ++j) if (w[j] > w[m]) m = j;
-    if (m != i) {
-      const double tw = w[i]; w[i] = w[m]; w[m] = tw;
-      for (int k = 0; k < n; ++k) { const double tv = V[k * n + i]; V[k * n + i] = V[k * n + m]; V[k * n + m] = tv; }
-    }
-  }
-}
+struct Result { double R[9], t[3], err; };
 
-// Symmetric eigen-decomposition by Householder tridiagonalisation + implicit QL with Wilkinson shifts (the classical tred2 /
-// tql2 pair) - ~5x fewer operations than cyclic Jacobi at n = 12.  A (row-major n x n, n <= 12) is overwritten; on return the
-// COLUMNS of V are the eigenvectors, w the eigenvalues, sorted descending.
-inline void sym_eig_ql(int n, double* A, double* V, double* w) {
-  double d[12], e[12];
-  double* z = V;
-  for (int i = 0; i < n * n; ++i) z[i] = A[i];
-  // ---- tred2: z -> orthogonal Q with Q^T A Q tridiagonal (d diagonal, e sub-diagonal)
-  for (int i = n - 1; i > 0; --i) {
-    const int l = i - 1;
-    double h = 0.0, scale = 0.0;
-    if (l > 0) {
-      for (int k = 0; k <= l; ++k) scale += std::fabs(z[i * n + k]);
-      if (scale == 0.0) e[i] = z[i * n + l];
-      else {
-        for (int k = 0; k <= l; ++k) { z[i * n + k] /= scale; h += z[i * n + k] * z[i * n + k]; }
-        double f = z[i * n + l];
-        double g = f >= 0.0 ? -std::sqrt(h) : std::sqrt(h);
-        e[i] = scale * g;
-        h -= f * g;
-        z[i * n + l] = f - g;
-        f = 0.0;
-        for (int j = 0; j <= l; ++j) {
-          z[j * n + i] = z[i * n + j] / h;
-          g = 0.0;
-          for (int k = 0; k <= j; ++k) g += z[j * n + k] * z[i * n + k];
-          for (int k = j + 1; k <= l; ++k) g += z[k * n + j] * z[i * n + k];
-          e[j] = g / h;
-          f += e[j] * z[i * n + j];
-        }
-        const double hh = f / (h + h);
-        for (int j = 0; j <= l; ++j) {
-          f = z[i * n + j];
-          e[j] = g = e[j] - hh * f;
-          for (int k = 0; k <= j; ++k) z[j * n + k] -= f * e[k] + g * z[i * n + k];
-        }
-      }
-    } else e[i] = z[i * n + l];
-    d[i] = h;
-  }
-  d[0] = 0.0; e[0] = 0.0;
+// cv::SVD as OpenCV 3.4.0 computes it when built without LAPACK (the reference's Dockerfile installs none before building OpenCV):
+// one-sided Jacobi (Hestenes) on the ROWS of A^T (modules/core/src/lapack.cpp, JacobiSVDImpl_ - restated from the published
+// source, not vendored here).  Everything that fixes the SIGN and ORDER of the singular vectors is kept, because EPnP's control
+// points - and with noisy data its result - depend on the signs of the principal directions: V starts as the identity; pairs
+// (i, j), i < j, in row-major order; a pair is rotated unless |<a_i, a_j>| <= 10 eps sqrt(|a_i|^2 |a_j|^2); the rotation (c, s)
+// is the one below (c >= 0 when |a_i| >= |a_j|, else s >= 0); at most max(m, 30) sweeps; singular values = row norms, sorted
+// descending by selection with swaps; left vectors = rows / singular value.  (OpenCV completes the left vectors of zero singular
+// values with pseudo-random vectors; here such a row stays zero - no caller reads one.)
+// A is m x n row-major.  Outputs: w [n]; Ut n x m (ROW j = j-th left singular vector); Vt n x n (ROW j = j-th right singular vector).
+inline void svd_opencv(int m, int n, const double* A, double* w, double* Ut, double* Vt) {
+  std::vector<double> At((size_t)n * m), W(n);
+  for (int i = 0; i < n; ++i) for (int k = 0; k < m; ++k) At[(size_t)i * m + k] = A[(size_t)k * n + i];
+  const double eps = 10 * 2.220446049250313e-16;
   for (int i = 0; i < n; ++i) {
-    const int l = i - 1;
-    if (d[i] != 0.0) {
-      for (int j = 0; j <= l; ++j) {
-        double g = 0.0;
-        for (int k = 0; k <= l; ++k) g += z[i * n + k] * z[k * n + j];
-        for (int k = 0; k <= l; ++k) z[k * n + j] -= g * z[k * n + i];
-      }
-    }
-    d[i] = z[i * n + i];
-    z[i * n + i] = 1.0;
-    for (int j = 0; j <= l; ++j) z[j * n + i] = z[i * n + j] = 0.0;
+    double sd = 0; for (int k = 0; k < m; ++k) sd += At[(size_t)i * m + k] * At[(size_t)i * m + k];
+    W[i] = sd;
+    for (int k = 0; k < n; ++k) Vt[i * n + k] = i == k ? 1.0 : 0.0;
   }
-  // ---- tql2: implicit QL on (d, e), rotations accumulated into z
-  for (int i = 1; i < n; ++i) e[i - 1] = e[i];
-  e[n - 1] = 0.0;
-  for (int l = 0; l < n; ++l) {
-    int iter = 0, m;
-    do {
-      for (m = l; m < n - 1; ++m) {
-        const double dd = std::fabs(d[m]) + std::fabs(d[m + 1]);
-        if (std::fabs(e[m]) <= 2.220446049250313e-16 * dd) break;
+  const int max_iter = m > 30 ? m : 30;
+  for (int iter = 0; iter < max_iter; ++iter) {
+    bool changed = false;
+    for (int i = 0; i < n - 1; ++i)
+      for (int j = i + 1; j < n; ++j) {
+        double* Ai = &At[(size_t)i * m]; double* Aj = &At[(size_t)j * m];
+        double a = W[i], p = 0, b = W[j];
+        for (int k = 0; k < m; ++k) p += Ai[k] * Aj[k];
+        if (std::fabs(p) <= eps * std::sqrt(a * b)) continue;
+        p *= 2;
+        const double beta = a - b, gamma = std::hypot(p, beta);
+        double c, s;
+        if (beta < 0) { const double delta = (gamma - beta) * 0.5; s = std::sqrt(delta / gamma); c = p / (gamma * s * 2); }
+        else { c = std::sqrt((gamma + beta) / (gamma * 2)); s = p / (gamma * c * 2); }
+        a = b = 0;
+        for (int k = 0; k < m; ++k) { const double t0 = c * Ai[k] + s * Aj[k], t1 = -s * Ai[k] + c * Aj[k]; Ai[k] = t0; Aj[k] = t1; a += t0 * t0; b += t1 * t1; }
+        W[i] = a; W[j] = b;
+        changed = true;
+        double* Vi = Vt + i * n; double* Vj = Vt + j * n;
+        for (int k = 0; k < n; ++k) { const double t0 = c * Vi[k] + s * Vj[k], t1 = -s * Vi[k] + c * Vj[k]; Vi[k] = t0; Vj[k] = t1; }
       }
-      if (m != l) {
-        if (iter++ == 60) break;
-        double g = (d[l + 1] - d[l]) / (2.0 * e[l]);
-        double r = std::sqrt(g * g + 1.0);
-        g = d[m] - d[l] + e[l] / (g + (g >= 0.0 ? std::fabs(r) : -std::fabs(r)));
-        double s = 1.0, c = 1.0, p = 0.0;
-        int i;
-        for (i = m - 1; i >= l; --i) {
-          double f = s * e[i];
-          const double b = c * e[i];
-          e[i + 1] = r = std::sqrt(f * f + g * g);
-          if (r == 0.0) { d[i + 1] -= p; e[m] = 0.0; break; }
-          s = f / r; c = g / r;
-          g = d[i + 1] - p;
-          r = (d[i] - g) * s + 2.0 * c * b;
-          d[i + 1] = g + (p = s * r);
-          g = c * r - b;
-          for (int k = 0; k < n; ++k) {
-            f = z[k * n + i + 1];
-            z[k * n + i + 1] = s * z[k * n + i] + c * f;
-            z[k * n + i] = c * z[k * n + i] - s * f;
-          }
-        }
-        if (r == 0.0 && i >= l) continue;
-        d[l] -= p; e[l] = g; e[m] = 0.0;
-      }
-    } while (m != l);
+    if (!changed) break;
   }
-  for (int i = 0; i < n; ++i) w[i] = d[i];
-  for (int i = 0; i < n - 1; ++i) {                   // selection sort, descending
-    int m = i;
-    for (int j = i + 1; j < n; ++j) if (w[j] > w[m]) m = j;
-    if (m != i) {
-      const double tw = w[i]; w[i] = w[m]; w[m] = tw;
-      for (int k = 0; k < n; ++k) { const double tv = V[k * n + i]; V[k * n + i] = V[k * n + m]; V[k * n + m] = tv; }
+  for (int i = 0; i < n; ++i) { double sd = 0; for (int k = 0; k < m; ++k) sd += At[(size_t)i * m + k] * At[(size_t)i * m + k]; W[i] = std::sqrt(sd); }
+  for (int i = 0; i < n - 1; ++i) {
+    int j = i;
+    for (int k = i + 1; k < n; ++k) if (W[j] < W[k]) j = k;
+    if (i != j) {
+      std::swap(W[i], W[j]);
+      for (int k = 0; k < m; ++k) std::swap(At[(size_t)i * m + k], At[(size_t)j * m + k]);
+      for (int k = 0; k < n; ++k) std::swap(Vt[i * n + k], Vt[j * n + k]);
     }
+  }
+  for (int i = 0; i < n; ++i) {
+    w[i] = W[i];
+    const double sc = W[i] > 2.2250738585072014e-308 ? 1 / W[i] : 0.0;
+    for (int k = 0; k < m; ++k) Ut[(size_t)i * m + k] = At[(size_t)i * m + k] * sc;
   }
 }
 
-// minimum-norm least squares x = pinv(A) b for A (m x k, row-major, k <= 5) through the eigen-decomposition of A^T A
-inline void lstsq_pinv(int m, int k, const double* A, const double* b, double* x) {
-  double AtA[25], Atb[5], V[25], w[5];
-  for (int i = 0; i < k; ++i) {
-    for (int j = 0; j < k; ++j) { double s = 0.0; for (int r = 0; r < m; ++r) s += A[r * k + i] * A[r * k + j]; AtA[i * k + j] = s; }
-    double s = 0.0; for (int r = 0; r < m; ++r) s += A[r * k + i] * b[r]; Atb[i] = s;
-  }
-  jacobi_eig(k, AtA, V, w);
-  for (int i = 0; i < k; ++i) x[i] = 0.0;
-  for (int e = 0; e < k; ++e) {
-    if (!(w[e] > 1e-14 * w[0])) continue;             // (singular value below ~1e-7 of the largest: dropped, as a pseudo-inverse does)
-    double proj = 0.0; for (int i = 0; i < k; ++i) proj += V[i * k + e] * Atb[i];
-    proj /= w[e];
-    for (int i = 0; i < k; ++i) x[i] += V[i * k + e] * proj;
+// cvSolve(A, b, x, CV_SVD): minimum-norm least squares through the SVD; singular values not above 2 eps sum(w) do not contribute
+inline void solve_svd(int m, int n, const double* A, const double* b, double* x) {
+  std::vector<double> w(n), Ut((size_t)m * n), Vt((size_t)n * n);
+  svd_opencv(m, n, A, w.data(), Ut.data(), Vt.data());
+  double thr = 0; for (int j = 0; j < n; ++j) thr += w[j];
+  thr *= 2.0 * 2.220446049250313e-16;
+  for (int i = 0; i < n; ++i) x[i] = 0;
+  for (int j = 0; j < n; ++j) {
+    if (!(w[j] > thr)) continue;
+    double ub = 0; for (int r = 0; r < m; ++r) ub += Ut[(size_t)j * m + r] * b[r];
+    ub /= w[j];
+    for (int i = 0; i < n; ++i) x[i] += Vt[j * n + i] * ub;
   }
 }
 
-// least squares of the 6 x 4 Gauss-Newton system by Householder QR; false when A is (numerically) rank deficient
-inline bool qr_solve_6x4(double* A /*6x4 row-major, destroyed*/, double* b /*6, destroyed*/, double* x /*4*/) {
-  const int m = 6, n = 4;
-  for (int k = 0; k < n; ++k) {
-    double norm2 = 0.0; for (int i = k; i < m; ++i) norm2 += A[i * n + k] * A[i * n + k];
-    if (!(norm2 > 0.0)) return false;
-    const double alpha = (A[k * n + k] > 0.0 ? -1.0 : 1.0) * std::sqrt(norm2);
-    double v[6]; for (int i = k; i < m; ++i) v[i] = A[i * n + k];
-    v[k] -= alpha;
-    double vtv = 0.0; for (int i = k; i < m; ++i) vtv += v[i] * v[i];
-    if (!(vtv > 0.0)) return false;
-    for (int j = k; j < n; ++j) {
-      double dot = 0.0; for (int i = k; i < m; ++i) dot += v[i] * A[i * n + j];
-      const double f = 2.0 * dot / vtv;
-      for (int i = k; i < m; ++i) A[i * n + j] -= f * v[i];
+// least squares of the 6 x 4 Gauss-Newton system: A is brought to triangular form by Givens rotations (applied to b as well),
+// then back substitution; false when a diagonal entry of the triangle vanishes
+inline bool solve_givens_6x4(double A[24], double b[6], double x[4]) {
+  for (int c = 0; c < 4; ++c)
+    for (int r = 5; r > c; --r) {
+      const double lo = A[4 * r + c];
+      if (lo == 0) continue;
+      const double hi = A[4 * (r - 1) + c], h = std::hypot(hi, lo), cs = hi / h, sn = lo / h;
+      for (int k = c; k < 4; ++k) { const double u = A[4 * (r - 1) + k], v = A[4 * r + k]; A[4 * (r - 1) + k] = cs * u + sn * v; A[4 * r + k] = cs * v - sn * u; }
+      const double u = b[r - 1], v = b[r]; b[r - 1] = cs * u + sn * v; b[r] = cs * v - sn * u;
     }
-    { double dot = 0.0; for (int i = k; i < m; ++i) dot += v[i] * b[i]; const double f = 2.0 * dot / vtv; for (int i = k; i < m; ++i) b[i] -= f * v[i]; }
-  }
-  for (int k = n - 1; k >= 0; --k) {
-    double s = b[k]; for (int j = k + 1; j < n; ++j) s -= A[k * n + j] * x[j];
-    if (A[k * n + k] == 0.0) return false;
-    x[k] = s / A[k * n + k];
+  for (int c = 3; c >= 0; --c) {
+    if (!(std::fabs(A[4 * c + c]) > 0)) return false;
+    double s = b[c]; for (int k = c + 1; k < 4; ++k) s -= A[4 * c + k] * x[k];
+    x[c] = s / A[4 * c + c];
   }
   return true;
 }
 
-struct Result { double R[9], t[3], err; };
-
-// X [n][3] world points, uv [n][2] pixels, K4 = fx, fy, cx, cy.  n >= 4.
+// X [n][3] world points, uv [n][2] pixels, K4 = fx, fy, cx, cy; n >= 4
 inline Result solve(int n, const double* X, const double* uv, const double* K4) {
   const double fu = K4[0], fv = K4[1], uc = K4[2], vc = K4[3];
+  Result none{}; none.err = -1.0;
   // ---- choose_control_points
-  double cws[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
-  for (int i = 0; i < n; ++i) for (int j = 0; j < 3; ++j) cws[0][j] += X[3 * i + j];
-  for (int j = 0; j < 3; ++j) cws[0][j] /= n;
-  double C[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+  double cw[4][3] = {};
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) cw[0][k] += X[3 * i + k];
+  for (int k = 0; k < 3; ++k) cw[0][k] /= n;
+  std::vector<double> PW0(3 * (size_t)n);
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) PW0[3 * (size_t)i + k] = X[3 * i + k] - cw[0][k];
+  double PtP[9];
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s = 0; for (int i = 0; i < n; ++i) s += PW0[3 * (size_t)i + a] * PW0[3 * (size_t)i + b]; PtP[3 * a + b] = s; }
+  double dc[3], UCt[9], VCt[9];
+  svd_opencv(3, 3, PtP, dc, UCt, VCt);
+  if (!(dc[2] > 1e-8 * dc[0])) return none;             // (near-)coplanar: see the header
+  for (int i = 1; i < 4; ++i) { const double k = std::sqrt(dc[i - 1] / n); for (int j = 0; j < 3; ++j) cw[i][j] = cw[0][j] + k * UCt[3 * (i - 1) + j]; }
+  // ---- compute_barycentric_coordinates: CC^-1 = V diag(1/w) U^T
+  double CC[9], wi[3], Ui[9], Vi[9], CCi[9];
+  for (int r = 0; r < 3; ++r) for (int j = 1; j < 4; ++j) CC[3 * r + j - 1] = cw[j][r] - cw[0][r];
+  svd_opencv(3, 3, CC, wi, Ui, Vi);                     // (Ui, Vi: rows = vectors)
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s = 0; for (int k = 0; k < 3; ++k) s += Vi[3 * k + a] * Ui[3 * k + b] / wi[k]; CCi[3 * a + b] = s; }
+  std::vector<double> al(4 * (size_t)n);
   for (int i = 0; i < n; ++i) {
-    const double d0 = X[3 * i] - cws[0][0], d1 = X[3 * i + 1] - cws[0][1], d2 = X[3 * i + 2] - cws[0][2];
-    C[0] += d0 * d0; C[1] += d0 * d1; C[2] += d0 * d2; C[4] += d1 * d1; C[5] += d1 * d2; C[8] += d2 * d2;
-  }
-  C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
-  double Vc[9], dc[3];
-  jacobi_eig(3, C, Vc, dc);
-  // (near-)coplanar points: the fourth control point collapses onto the centroid and the barycentric coordinates are undefined.
-  // OpenCV's behaviour there is an artefact of its pseudo-inverse; here the caller keeps the RANSAC hypothesis (err < 0).
-  if (!(dc[2] > 1e-8 * dc[0])) { Result none{}; none.err = -1.0; return none; }
-  for (int i = 1; i < 4; ++i) {
-    const double k = std::sqrt((dc[i - 1] > 0.0 ? dc[i - 1] : 0.0) / n);
-    for (int j = 0; j < 3; ++j) cws[i][j] = cws[0][j] + k * Vc[j * 3 + (i - 1)];
-  }
-  // ---- compute_barycentric_coordinates
-  double cc[9], ci[9];
-  for (int i = 0; i < 3; ++i) for (int j = 1; j < 4; ++j) cc[3 * i + j - 1] = cws[j][i] - cws[0][i];
-  {
-    const double det = cc[0] * (cc[4] * cc[8] - cc[5] * cc[7]) - cc[1] * (cc[3] * cc[8] - cc[5] * cc[6]) + cc[2] * (cc[3] * cc[7] - cc[4] * cc[6]);
-    const double id = 1.0 / det;
-    ci[0] = (cc[4] * cc[8] - cc[5] * cc[7]) * id; ci[1] = (cc[2] * cc[7] - cc[1] * cc[8]) * id; ci[2] = (cc[1] * cc[5] - cc[2] * cc[4]) * id;
-    ci[3] = (cc[5] * cc[6] - cc[3] * cc[8]) * id; ci[4] = (cc[0] * cc[8] - cc[2] * cc[6]) * id; ci[5] = (cc[2] * cc[3] - cc[0] * cc[5]) * id;
-    ci[6] = (cc[3] * cc[7] - cc[4] * cc[6]) * id; ci[7] = (cc[1] * cc[6] - cc[0] * cc[7]) * id; ci[8] = (cc[0] * cc[4] - cc[1] * cc[3]) * id;
-  }
-  std::vector<double> alphas(4 * (size_t)n);
-  for (int i = 0; i < n; ++i) {
-    const double* pi = X + 3 * i; double* a = &alphas[4 * (size_t)i];
-    for (int j = 0; j < 3; ++j) a[1 + j] = ci[3 * j] * (pi[0] - cws[0][0]) + ci[3 * j + 1] * (pi[1] - cws[0][1]) + ci[3 * j + 2] * (pi[2] - cws[0][2]);
+    double* a = &al[4 * (size_t)i];
+    for (int j = 0; j < 3; ++j) a[1 + j] = CCi[3 * j] * PW0[3 * (size_t)i] + CCi[3 * j + 1] * PW0[3 * (size_t)i + 1] + CCi[3 * j + 2] * PW0[3 * (size_t)i + 2];
     a[0] = 1.0 - a[1] - a[2] - a[3];
   }
-  // ---- M^T M (12 x 12).  Rows of M: [a_j fu, 0, a_j (uc - u)] and [0, a_j fv, a_j (vc - v)] per control point j, so the 3 x 3
-  // block (j, k) of M^T M is  sum_i a_j a_k [fu^2, 0, fu du; 0, fv^2, fv dv; fu du, fv dv, du^2 + dv^2]  with du = uc - u, dv = vc - v:
-  // four running sums per control-point pair instead of the 78 products of the dense rows
-  double s1[16], su[16], sv[16], sq[16];
-  for (int i = 0; i < 16; ++i) s1[i] = su[i] = sv[i] = sq[i] = 0.0;
+  // ---- fill_M (dense) and M^T M
+  std::vector<double> M(24 * (size_t)n, 0.0);
   for (int i = 0; i < n; ++i) {
-    const double* a = &alphas[4 * (size_t)i];
-    const double du = uc - uv[2 * i], dv = vc - uv[2 * i + 1], dd = du * du + dv * dv;
-    for (int j = 0; j < 4; ++j)
-      for (int k = j; k < 4; ++k) {
-        const double ajk = a[j] * a[k];
-        s1[4 * j + k] += ajk; su[4 * j + k] += ajk * du; sv[4 * j + k] += ajk * dv; sq[4 * j + k] += ajk * dd;
-      }
+    double* m1 = &M[24 * (size_t)i]; double* m2 = m1 + 12;
+    const double* a = &al[4 * (size_t)i];
+    for (int j = 0; j < 4; ++j) {
+      m1[3 * j] = a[j] * fu; m1[3 * j + 1] = 0.0; m1[3 * j + 2] = a[j] * (uc - uv[2 * i]);
+      m2[3 * j] = 0.0; m2[3 * j + 1] = a[j] * fv; m2[3 * j + 2] = a[j] * (vc - uv[2 * i + 1]);
+    }
   }
   double MtM[144];
-  for (int j = 0; j < 4; ++j)
-    for (int k = 0; k < 4; ++k) {
-      const int jj = j <= k ? j : k, kk = j <= k ? k : j;
-      const double a1 = s1[4 * jj + kk], au = su[4 * jj + kk], av = sv[4 * jj + kk], aq = sq[4 * jj + kk];
-      double* Bk = MtM + (3 * j) * 12 + 3 * k;
-      Bk[0] = fu * fu * a1; Bk[1] = 0.0; Bk[2] = fu * au;
-      Bk[12] = 0.0; Bk[13] = fv * fv * a1; Bk[14] = fv * av;
-      Bk[24] = fu * au; Bk[25] = fv * av; Bk[26] = aq;
-    }
-  double V12[144], w12[12];
-  sym_eig_ql(12, MtM, V12, w12);
-  const double* vcol[4];   // v[0] = eigenvector of the smallest eigenvalue ... (ut + 12*11, 12*10, 12*9, 12*8 in OpenCV's U^T)
-  double vv[4][12];
-  for (int e = 0; e < 4; ++e) { for (int k = 0; k < 12; ++k) vv[e][k] = V12[k * 12 + (11 - e)]; vcol[e] = vv[e]; }
+  for (int a = 0; a < 12; ++a) for (int b = a; b < 12; ++b) { double s = 0; for (int r = 0; r < 2 * n; ++r) s += M[12 * (size_t)r + a] * M[12 * (size_t)r + b]; MtM[12 * a + b] = MtM[12 * b + a] = s; }
+  double w12[12], U12[144], V12[144];
+  svd_opencv(12, 12, MtM, w12, U12, V12);
+  // v[0] .. v[3]: the singular vectors of the four smallest singular values, smallest first - rows 11, 10, 9, 8 of U^T in OpenCV.
+  // Read from V^T here: for the symmetric positive semi-definite M^T M the two coincide in exact arithmetic (same signs), but a
+  // left vector is a row of A V^T divided by its norm and carries a relative error of eps sigma_max / sigma_i (1e-8 for typical
+  // noisy data, unbounded for noise-free data), a right vector does not.  DEVIATION from OpenCV at that level, on purpose.
+  double v[4][12];
+  for (int e = 0; e < 4; ++e) for (int k = 0; k < 12; ++k) v[e][k] = V12[12 * (11 - e) + k];
   // ---- compute_L_6x10, compute_rho
-  double dv[4][6][3];
-  for (int i = 0; i < 4; ++i) {
-    int a = 0, b = 1;
-    for (int j = 0; j < 6; ++j) {
-      for (int k = 0; k < 3; ++k) dv[i][j][k] = vcol[i][3 * a + k] - vcol[i][3 * b + k];
-      ++b;
-      if (b > 3) { ++a; b = a + 1; }
-    }
-  }
-  auto dot3 = [](const double* p, const double* q) { return p[0] * q[0] + p[1] * q[1] + p[2] * q[2]; };
-  double L[60], rho[6];
+  static const int PA[6] = {0, 0, 0, 1, 1, 2}, PB[6] = {1, 2, 3, 2, 3, 3};
+  double L[6][10], rho[6];
   for (int i = 0; i < 6; ++i) {
-    double* row = L + 10 * i;
-    row[0] = dot3(dv[0][i], dv[0][i]); row[1] = 2.0 * dot3(dv[0][i], dv[1][i]); row[2] = dot3(dv[1][i], dv[1][i]);
-    row[3] = 2.0 * dot3(dv[0][i], dv[2][i]); row[4] = 2.0 * dot3(dv[1][i], dv[2][i]); row[5] = dot3(dv[2][i], dv[2][i]);
-    row[6] = 2.0 * dot3(dv[0][i], dv[3][i]); row[7] = 2.0 * dot3(dv[1][i], dv[3][i]); row[8] = 2.0 * dot3(dv[2][i], dv[3][i]);
-    row[9] = dot3(dv[3][i], dv[3][i]);
+    double d[4][3];
+    for (int e = 0; e < 4; ++e) for (int k = 0; k < 3; ++k) d[e][k] = v[e][3 * PA[i] + k] - v[e][3 * PB[i] + k];
+    auto dt = [&](int a, int b) { return d[a][0] * d[b][0] + d[a][1] * d[b][1] + d[a][2] * d[b][2]; };
+    L[i][0] = dt(0, 0); L[i][1] = 2 * dt(0, 1); L[i][2] = dt(1, 1); L[i][3] = 2 * dt(0, 2); L[i][4] = 2 * dt(1, 2);
+    L[i][5] = dt(2, 2); L[i][6] = 2 * dt(0, 3); L[i][7] = 2 * dt(1, 3); L[i][8] = 2 * dt(2, 3); L[i][9] = dt(3, 3);
+    rho[i] = 0;
+    for (int k = 0; k < 3; ++k) { const double q = cw[PA[i]][k] - cw[PB[i]][k]; rho[i] += q * q; }
   }
-  auto dist2 = [](const double* p, const double* q) { return (p[0] - q[0]) * (p[0] - q[0]) + (p[1] - q[1]) * (p[1] - q[1]) + (p[2] - q[2]) * (p[2] - q[2]); };
-  rho[0] = dist2(cws[0], cws[1]); rho[1] = dist2(cws[0], cws[2]); rho[2] = dist2(cws[0], cws[3]);
-  rho[3] = dist2(cws[1], cws[2]); rho[4] = dist2(cws[1], cws[3]); rho[5] = dist2(cws[2], cws[3]);
-  // ---- the three beta initialisations + Gauss-Newton + pose; smallest reprojection error wins (N = 1, then 2, then 3)
-  Result best{}; best.err = -1.0;
+  // ---- the three initialisations of beta, Gauss-Newton, pose; the smallest mean reprojection error wins (ties: the earlier one)
+  Result best = none;
+  std::vector<double> pc(3 * (size_t)n);
   for (int N = 1; N <= 3; ++N) {
-    double betas[4] = {0, 0, 0, 0};
-    if (N == 1) {                                     // betas_approx_1 = [B11 B12 B13 B14]
-      double A[24], b4[4];
-      for (int i = 0; i < 6; ++i) { A[4 * i] = L[10 * i]; A[4 * i + 1] = L[10 * i + 1]; A[4 * i + 2] = L[10 * i + 3]; A[4 * i + 3] = L[10 * i + 6]; }
-      lstsq_pinv(6, 4, A, rho, b4);
-      if (b4[0] < 0) { betas[0] = std::sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
-      else { betas[0] = std::sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
-    } else if (N == 2) {                              // betas_approx_2 = [B11 B12 B22]
-      double A[18], b3[3];
-      for (int i = 0; i < 6; ++i) { A[3 * i] = L[10 * i]; A[3 * i + 1] = L[10 * i + 1]; A[3 * i + 2] = L[10 * i + 2]; }
-      lstsq_pinv(6, 3, A, rho, b3);
-      if (b3[0] < 0) { betas[0] = std::sqrt(-b3[0]); betas[1] = (b3[2] < 0) ? std::sqrt(-b3[2]) : 0.0; }
-      else { betas[0] = std::sqrt(b3[0]); betas[1] = (b3[2] > 0) ? std::sqrt(b3[2]) : 0.0; }
-      if (b3[1] < 0) betas[0] = -betas[0];
-      betas[2] = 0.0; betas[3] = 0.0;
-    } else {                                          // betas_approx_3 = [B11 B12 B22 B13 B23]
-      double A[30], b5[5];
-      for (int i = 0; i < 6; ++i) for (int j = 0; j < 5; ++j) A[5 * i + j] = L[10 * i + j];
-      lstsq_pinv(6, 5, A, rho, b5);
-      if (b5[0] < 0) { betas[0] = std::sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? std::sqrt(-b5[2]) : 0.0; }
-      else { betas[0] = std::sqrt(b5[0]); betas[1] = (b5[2] > 0) ? std::sqrt(b5[2]) : 0.0; }
-      if (b5[1] < 0) betas[0] = -betas[0];
-      betas[2] = b5[3] / betas[0]; betas[3] = 0.0;
+    double be[4] = {0, 0, 0, 0};
+    if (N == 1) {                                       // [B11 B12 B13 B14]: columns 0, 1, 3, 6
+      double A[24], s[4];
+      for (int i = 0; i < 6; ++i) { A[4 * i] = L[i][0]; A[4 * i + 1] = L[i][1]; A[4 * i + 2] = L[i][3]; A[4 * i + 3] = L[i][6]; }
+      solve_svd(6, 4, A, rho, s);
+      const double sg = s[0] < 0 ? -1.0 : 1.0;
+      be[0] = std::sqrt(sg * s[0]);
+      for (int k = 1; k < 4; ++k) be[k] = sg * s[k] / be[0];
+    } else if (N == 2) {                                // [B11 B12 B22]: columns 0, 1, 2
+      double A[18], s[3];
+      for (int i = 0; i < 6; ++i) for (int k = 0; k < 3; ++k) A[3 * i + k] = L[i][k];
+      solve_svd(6, 3, A, rho, s);
+      if (s[0] < 0) { be[0] = std::sqrt(-s[0]); be[1] = s[2] < 0 ? std::sqrt(-s[2]) : 0.0; }
+      else { be[0] = std::sqrt(s[0]); be[1] = s[2] > 0 ? std::sqrt(s[2]) : 0.0; }
+      if (s[1] < 0) be[0] = -be[0];
+    } else {                                            // [B11 B12 B22 B13 B23]: columns 0 .. 4
+      double A[30], s[5];
+      for (int i = 0; i < 6; ++i) for (int k = 0; k < 5; ++k) A[5 * i + k] = L[i][k];
+      solve_svd(6, 5, A, rho, s);
+      if (s[0] < 0) { be[0] = std::sqrt(-s[0]); be[1] = s[2] < 0 ? std::sqrt(-s[2]) : 0.0; }
+      else { be[0] = std::sqrt(s[0]); be[1] = s[2] > 0 ? std::sqrt(s[2]) : 0.0; }
+      if (s[1] < 0) be[0] = -be[0];
+      be[2] = s[3] / be[0];
     }
-    for (int it = 0; it < 5; ++it) {                  // gauss_newton
-      double A[24], B[6], x[4];
+    for (int it = 0; it < 5; ++it) {                    // gauss_newton on  rho_i = sum_{a <= b} L_i[ab] beta_a beta_b
+      double A[24], r[6], dx[4];
       for (int i = 0; i < 6; ++i) {
-        const double* rl = L + 10 * i; double* ra = A + 4 * i;
-        ra[0] = 2 * rl[0] * betas[0] + rl[1] * betas[1] + rl[3] * betas[2] + rl[6] * betas[3];
-        ra[1] = rl[1] * betas[0] + 2 * rl[2] * betas[1] + rl[4] * betas[2] + rl[7] * betas[3];
-        ra[2] = rl[3] * betas[0] + rl[4] * betas[1] + 2 * rl[5] * betas[2] + rl[8] * betas[3];
-        ra[3] = rl[6] * betas[0] + rl[7] * betas[1] + rl[8] * betas[2] + 2 * rl[9] * betas[3];
-        B[i] = rho[i] - (rl[0] * betas[0] * betas[0] + rl[1] * betas[0] * betas[1] + rl[2] * betas[1] * betas[1] + rl[3] * betas[0] * betas[2] +
-                         rl[4] * betas[1] * betas[2] + rl[5] * betas[2] * betas[2] + rl[6] * betas[0] * betas[3] + rl[7] * betas[1] * betas[3] +
-                         rl[8] * betas[2] * betas[3] + rl[9] * betas[3] * betas[3]);
+        const double* l = L[i];
+        A[4 * i + 0] = 2 * l[0] * be[0] + l[1] * be[1] + l[3] * be[2] + l[6] * be[3];
+        A[4 * i + 1] = l[1] * be[0] + 2 * l[2] * be[1] + l[4] * be[2] + l[7] * be[3];
+        A[4 * i + 2] = l[3] * be[0] + l[4] * be[1] + 2 * l[5] * be[2] + l[8] * be[3];
+        A[4 * i + 3] = l[6] * be[0] + l[7] * be[1] + l[8] * be[2] + 2 * l[9] * be[3];
+        r[i] = rho[i] - (l[0] * be[0] * be[0] + l[1] * be[0] * be[1] + l[2] * be[1] * be[1] + l[3] * be[0] * be[2] + l[4] * be[1] * be[2] +
+                         l[5] * be[2] * be[2] + l[6] * be[0] * be[3] + l[7] * be[1] * be[3] + l[8] * be[2] * be[3] + l[9] * be[3] * be[3]);
       }
-      if (!qr_solve_6x4(A, B, x)) break;
-      for (int i = 0; i < 4; ++i) betas[i] += x[i];
+      if (!solve_givens_6x4(A, r, dx)) break;
+      for (int k = 0; k < 4; ++k) be[k] += dx[k];
     }
-    // ---- compute_R_and_t: control points in the camera frame, points in the camera frame, sign, absolute orientation
-    double ccs[4][3];
-    for (int i = 0; i < 4; ++i) for (int k = 0; k < 3; ++k) ccs[i][k] = 0.0;
-    for (int e = 0; e < 4; ++e) for (int j = 0; j < 4; ++j) for (int k = 0; k < 3; ++k) ccs[j][k] += betas[e] * vcol[e][3 * j + k];
-    std::vector<double> pcs(3 * (size_t)n);
-    for (int i = 0; i < n; ++i) {
-      const double* a = &alphas[4 * (size_t)i];
-      for (int k = 0; k < 3; ++k) pcs[3 * (size_t)i + k] = a[0] * ccs[0][k] + a[1] * ccs[1][k] + a[2] * ccs[2][k] + a[3] * ccs[3][k];
-    }
-    if (pcs[2] < 0.0) for (size_t i = 0; i < pcs.size(); ++i) pcs[i] = -pcs[i];       // solve_for_sign
-    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
-    for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { pc0[k] += pcs[3 * (size_t)i + k]; pw0[k] += X[3 * i + k]; }
+    // ---- compute_R_and_t: control points and points in the camera frame, solve_for_sign, estimate_R_and_t, reprojection_error
+    double cc[4][3] = {};
+    for (int e = 0; e < 4; ++e) for (int j = 0; j < 4; ++j) for (int k = 0; k < 3; ++k) cc[j][k] += be[e] * v[e][3 * j + k];
+    for (int i = 0; i < n; ++i) { const double* a = &al[4 * (size_t)i]; for (int k = 0; k < 3; ++k) pc[3 * (size_t)i + k] = a[0] * cc[0][k] + a[1] * cc[1][k] + a[2] * cc[2][k] + a[3] * cc[3][k]; }
+    if (pc[2] < 0) for (double& q : pc) q = -q;
+    double pc0[3] = {}, pw0[3] = {};
+    for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { pc0[k] += pc[3 * (size_t)i + k]; pw0[k] += X[3 * i + k]; }
     for (int k = 0; k < 3; ++k) { pc0[k] /= n; pw0[k] /= n; }
-    double Sm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // S[j][k] = sum (pw - pw0)[j] (pc - pc0)[k]   (Horn: rotation world -> camera)
-    for (int i = 0; i < n; ++i)
-      for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) Sm[3 * j + k] += (X[3 * i + j] - pw0[j]) * (pcs[3 * (size_t)i + k] - pc0[k]);
-    double Nq[16] = {Sm[0] + Sm[4] + Sm[8], Sm[5] - Sm[7], Sm[6] - Sm[2], Sm[1] - Sm[3],
-                     Sm[5] - Sm[7], Sm[0] - Sm[4] - Sm[8], Sm[1] + Sm[3], Sm[6] + Sm[2],
-                     Sm[6] - Sm[2], Sm[1] + Sm[3], -Sm[0] + Sm[4] - Sm[8], Sm[5] + Sm[7],
-                     Sm[1] - Sm[3], Sm[6] + Sm[2], Sm[5] + Sm[7], -Sm[0] - Sm[4] + Sm[8]};
-    double Vq[16], wq[4];
-    jacobi_eig(4, Nq, Vq, wq);
-    double q0 = Vq[0], q1 = Vq[4], q2 = Vq[8], q3 = Vq[12];      // eigenvector of the largest eigenvalue: unit quaternion (w, x, y, z)
-    { const double nq = std::sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3); q0 /= nq; q1 /= nq; q2 /= nq; q3 /= nq; }
-    Result cur;
-    cur.R[0] = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3; cur.R[1] = 2 * (q1 * q2 - q0 * q3); cur.R[2] = 2 * (q1 * q3 + q0 * q2);
-    cur.R[3] = 2 * (q1 * q2 + q0 * q3); cur.R[4] = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3; cur.R[5] = 2 * (q2 * q3 - q0 * q1);
-    cur.R[6] = 2 * (q1 * q3 - q0 * q2); cur.R[7] = 2 * (q2 * q3 + q0 * q1); cur.R[8] = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
+    double ABt[9] = {};
+    for (int i = 0; i < n; ++i) for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) ABt[3 * a + b] += (pc[3 * (size_t)i + a] - pc0[a]) * (X[3 * i + b] - pw0[b]);
+    double wa[3], Ua[9], Va[9];
+    svd_opencv(3, 3, ABt, wa, Ua, Va);                  // (rows = vectors)
+    if (!(wa[2] > 1e-14 * wa[0])) {                     // rank 2: the third left vector completes a right-handed frame
+      Ua[6] = Ua[1] * Ua[5] - Ua[2] * Ua[4]; Ua[7] = Ua[2] * Ua[3] - Ua[0] * Ua[5]; Ua[8] = Ua[0] * Ua[4] - Ua[1] * Ua[3];
+    }
+    Result cur;                                         // R = U V^T
+    for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cur.R[3 * a + b] = Ua[a] * Va[b] + Ua[3 + a] * Va[3 + b] + Ua[6 + a] * Va[6 + b];
+    const double det = cur.R[0] * (cur.R[4] * cur.R[8] - cur.R[5] * cur.R[7]) - cur.R[1] * (cur.R[3] * cur.R[8] - cur.R[5] * cur.R[6]) + cur.R[2] * (cur.R[3] * cur.R[7] - cur.R[4] * cur.R[6]);
+    if (det < 0) { cur.R[6] = -cur.R[6]; cur.R[7] = -cur.R[7]; cur.R[8] = -cur.R[8]; }
     for (int k = 0; k < 3; ++k) cur.t[k] = pc0[k] - (cur.R[3 * k] * pw0[0] + cur.R[3 * k + 1] * pw0[1] + cur.R[3 * k + 2] * pw0[2]);
-    double sum = 0.0;                                  // reprojection_error
+    double sum = 0;
     for (int i = 0; i < n; ++i) {
-      const double* pw = X + 3 * i;
-      const double Xc = cur.R[0] * pw[0] + cur.R[1] * pw[1] + cur.R[2] * pw[2] + cur.t[0];
-      const double Yc = cur.R[3] * pw[0] + cur.R[4] * pw[1] + cur.R[5] * pw[2] + cur.t[1];
-      const double inv_Zc = 1.0 / (cur.R[6] * pw[0] + cur.R[7] * pw[1] + cur.R[8] * pw[2] + cur.t[2]);
-      const double ue = uc + fu * Xc * inv_Zc, ve = vc + fv * Yc * inv_Zc;
-      const double u = uv[2 * i], v = uv[2 * i + 1];
-      sum += std::sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+      const double* p = X + 3 * i;
+      const double xc = cur.R[0] * p[0] + cur.R[1] * p[1] + cur.R[2] * p[2] + cur.t[0], yc = cur.R[3] * p[0] + cur.R[4] * p[1] + cur.R[5] * p[2] + cur.t[1];
+      const double zi = 1.0 / (cur.R[6] * p[0] + cur.R[7] * p[1] + cur.R[8] * p[2] + cur.t[2]);
+      sum += std::hypot(uv[2 * i] - (uc + fu * xc * zi), uv[2 * i + 1] - (vc + fv * yc * zi));
     }
     cur.err = sum / n;
-    if (best.err < 0.0 || cur.err < best.err) best = cur;
+    if (best.err < 0 || cur.err < best.err) best = cur;
   }
   return best;
 }

@@ -10,8 +10,8 @@
 //     geometric solutions;
 //   * inliers: squared reprojection error <= thr^2 (findInliers); the iteration budget shrinks with
 //     RANSACUpdateNumIters(confidence, outlier ratio, 4, niters) whenever a better model is found.
-// NOT restated: the final EPnP refit on the inliers — the Levenberg-Marquardt refinement that follows in the
-// reference (PoseOptimizationFlow2Cam) starts from this pose anyway.
+//   * the final re-estimation of the winning model on its inliers by EPnP (OpenCV >= 3.3): epnp_oracle.hpp,
+//     vdo_oracle_pnp_ransac_refit below.
 #include <algorithm>
 #include <cfloat>
 #include <cmath>

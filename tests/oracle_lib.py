@@ -71,3 +71,26 @@ def load():
     L.vdo_oracle_build_tracks.argtypes = [C.c_int, i32p, i32p, i32p, C.c_int, C.c_int, i32p, i32p, i32p, i32p]
     _lib = L
     return L
+
+
+_prod_epnp = None
+
+
+def load_product_epnp():
+    """The PRODUCT's host-side EPnP refit (vdo_slam_amd/csrc/epnp_refit.hpp - plain C++, no GPU) compiled behind a C entry point
+    (tests/helpers/product_host_epnp.cpp).  Two uses: tests/test_epnp_independent.py compares it with the oracle's independent EPnP;
+    the sequence tests hand it to OraclePipeline(seed_refit="product") so that both sides start every LM from the same float seed
+    (see tests/pipeline_ref.py for why that is needed)."""
+    global _prod_epnp
+    if _prod_epnp is not None:
+        return _prod_epnp
+    here = os.path.join(ROOT, "tests", "helpers")
+    src, out = os.path.join(here, "product_host_epnp.cpp"), os.path.join(here, "libproduct_host_epnp.so")
+    hdr = os.path.join(ROOT, "vdo_slam_amd", "csrc", "epnp_refit.hpp")
+    if not os.path.exists(out) or os.path.getmtime(out) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-ffp-contract=off", "-shared", "-o", out, src], check=True)
+    L = C.CDLL(out)
+    L.product_host_epnp.restype = C.c_double
+    L.product_host_epnp.argtypes = [C.c_int] + [K.c_double_p] * 4
+    _prod_epnp = L
+    return L

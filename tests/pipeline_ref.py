@@ -45,8 +45,21 @@ def matmul4_f32(A, B):
 
 
 class OraclePipeline:
-    def __init__(self, oracle, max_bg=1200, max_obj=800, sf_mg=0.12, sf_ds=0.3, build_lm=False, K4=None, use_sample=False, sample_seed=1, pnp_refit=True):
+    def __init__(self, oracle, max_bg=1200, max_obj=800, sf_mg=0.12, sf_ds=0.3, build_lm=False, K4=None, use_sample=False, sample_seed=1, pnp_refit=True, seed_refit=None):
+        """seed_refit: None - the EPnP re-estimation of a RANSAC model is the oracle's own (oracle/epnp_oracle.hpp, independent of the
+        product: SVD-based).  "product" - it is computed by a CPU build of the product's host routine (tests/oracle_lib.load_product_epnp).
+        Why the second mode exists: the two EPnPs agree to ~1e-12 .. 1e-9 (tests/test_epnp_independent.py), but the pose then seeds the LM
+        as a CV_32F matrix, and on noisy, weakly constrained object problems the reference's LM (2-DoF flow vertices aliased onto 3x3
+        blocks) is CHAOTIC in that seed: one float ulp in one element can move an object motion by metres a few frames later
+        (measured: 6.6 m on the 5-object 0.3 px sequence).  A frame-by-frame equality test of everything else therefore needs the two
+        sides to start from the same float; the EPnP arithmetic itself is pinned separately."""
         self.pnp_refit = pnp_refit                      # cv::solvePnPRansac's final EPnP re-estimation on the inliers (OpenCV >= 3.3)
+        self.seed_lib = None
+        if seed_refit == "product":
+            from tests import oracle_lib
+            self.seed_lib = oracle_lib.load_product_epnp()
+        elif seed_refit is not None:
+            raise ValueError(seed_refit)
         self.o = oracle
         self.K4 = np.array(synth.KITTI_K if K4 is None else K4, f32)
         self.use_sample, self.sample_seed = use_sample, sample_seed      # UseSampleFeature = 1 (omd.yaml): SampleKeyPoints instead of ORB
@@ -70,7 +83,14 @@ class OraclePipeline:
         if n < 4:
             return 0, Tm.reshape(4, 4), inl[:n]
         X = np.ascontiguousarray(X, np.float64); uv = np.ascontiguousarray(uv, np.float64)
-        good = self.o.vdo_oracle_pnp_ransac_refit(n, K._dp(X), K._dp(uv), K._dp(self.K4.astype(np.float64)), 500, 0.4, 0.98, int(self.pnp_refit), K._dp(Tm), inl.ctypes.data_as(K.c_uint8_p), None, None)
+        K4d = self.K4.astype(np.float64)
+        own_refit = int(self.pnp_refit and self.seed_lib is None)
+        good = self.o.vdo_oracle_pnp_ransac_refit(n, K._dp(X), K._dp(uv), K._dp(K4d), 500, 0.4, 0.98, own_refit, K._dp(Tm), inl.ctypes.data_as(K.c_uint8_p), None, None)
+        if self.pnp_refit and self.seed_lib is not None and good >= 4:
+            sel = inl[:n] > 0
+            Xi, ui, T2 = np.ascontiguousarray(X[sel]), np.ascontiguousarray(uv[sel]), np.zeros(16)
+            if self.seed_lib.product_host_epnp(int(sel.sum()), K._dp(Xi), K._dp(ui), K._dp(K4d), K._dp(T2)) >= 0:      # (coplanar inliers: the hypothesis stays)
+                Tm = T2
         return good, Tm.reshape(4, 4), inl[:n]
 
     def _mm_inliers(self, MM, X, u, v):

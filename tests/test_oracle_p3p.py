@@ -173,3 +173,57 @@ def test_epnp_recovers_the_pose_and_refines_the_ransac_model(oracle):
     uvp = np.c_[KITTI_K[0] * Xc[:, 0] / Xc[:, 2] + KITTI_K[2], KITTI_K[1] * Xc[:, 1] / Xc[:, 2] + KITTI_K[3]]
     T = np.zeros(16)
     assert o.vdo_oracle_epnp(900, K._dp(np.ascontiguousarray(Xp)), K._dp(np.ascontiguousarray(uvp)), K._dp(K4), K._dp(T)) < 0
+
+
+def test_p3p_solution_set_is_complete_against_a_numerical_solver(oracle):
+    """Second opinion on the minimal solver that shares no algebra with it: the three law-of-cosines equations
+    d_i^2 + d_j^2 - 2 d_i d_j cos(theta_ij) = |P_i - P_j|^2 are solved for the depths by Newton from many starting points; the
+    set of positive solutions found that way must be the set of depths |R P_i + t| the oracle's P3P returns (Grunert's quartic,
+    resolvent cubic, absolute orientation) - no root lost, none invented."""
+    o = _bind(oracle)
+    rng = np.random.default_rng(21)
+    fx, fy, cx, cy = KITTI_K
+    checked = multi = 0
+    for trial in range(120):
+        Xw, uv, R, t, _ = _scene(rng, 3)
+        f = np.c_[(uv[:, 0] - cx) / fx, (uv[:, 1] - cy) / fy, np.ones(3)]
+        f /= np.linalg.norm(f, axis=1, keepdims=True)
+        cosv = np.array([f[0] @ f[1], f[0] @ f[2], f[1] @ f[2]])
+        dist2 = np.array([((Xw[0] - Xw[1]) ** 2).sum(), ((Xw[0] - Xw[2]) ** 2).sum(), ((Xw[1] - Xw[2]) ** 2).sum()])
+        pairs = ((0, 1), (0, 2), (1, 2))
+
+        def F(d):
+            return np.array([d[i] ** 2 + d[j] ** 2 - 2 * d[i] * d[j] * c - q for (i, j), c, q in zip(pairs, cosv, dist2)])
+
+        def J(d):
+            Jm = np.zeros((3, 3))
+            for r, ((i, j), c) in enumerate(zip(pairs, cosv)):
+                Jm[r, i] = 2 * d[i] - 2 * d[j] * c; Jm[r, j] = 2 * d[j] - 2 * d[i] * c
+            return Jm
+        found = []
+        scale = np.sqrt(dist2.max())
+        for _ in range(400):
+            d = rng.uniform(0.05, 60.0, 3)
+            ok = False
+            for _it in range(60):
+                try:
+                    step = np.linalg.solve(J(d), F(d))
+                except np.linalg.LinAlgError:
+                    break
+                d = d - step
+                if np.abs(step).max() < 1e-13 * max(1.0, np.abs(d).max()):
+                    ok = True
+                    break
+            if ok and d.min() > 1e-6 and np.abs(F(d)).max() < 1e-9 * scale ** 2 and not any(np.abs(d - e).max() < 1e-6 * max(1.0, np.abs(e).max()) for e in found):
+                found.append(d)
+        # ill-conditioned triangles (nearly double roots) are left out: Newton and the quartic both lose digits there
+        if any(abs(np.linalg.det(J(d))) < 1e-3 * scale ** 3 for d in found):
+            continue
+        Ro = np.zeros((4, 9)); to = np.zeros((4, 3))
+        n = o.vdo_oracle_p3p(K._dp(np.ascontiguousarray(f)), K._dp(Xw), K._dp(Ro), K._dp(to))
+        got = [np.linalg.norm(Xw @ Ro[s].reshape(3, 3).T + to[s], axis=1) for s in range(n)]
+        assert len(got) == len(found), (trial, got, found)
+        for d in found:
+            assert min(np.abs(d - g).max() for g in got) < 1e-5 * max(1.0, d.max()), (trial, d, got)
+        checked += 1; multi += len(found) > 1
+    assert checked >= 60 and multi >= 10

@@ -26,8 +26,9 @@ def _oracle(o, Xw, uv, refit=0):
 
 @pytest.mark.parametrize("refit", [0, 1])
 def test_batch_matches_the_sequential_oracle(oracle, refit):
-    """refit = 1: + OpenCV's final EPnP re-estimation on the inliers (host code of the C-ABI vs oracle/epnp_oracle.hpp): the pose
-    is still the same bit pattern."""
+    """refit = 0: the pose is the same bit pattern on both sides.  refit = 1: + OpenCV's final EPnP re-estimation on the inliers -
+    host code of the C-ABI (csrc/epnp_refit.hpp) against the oracle's INDEPENDENT restatement (oracle/epnp_oracle.hpp: SVD-based,
+    different arithmetic): consensus and inliers identical, pose to 1e-9."""
     o = _bind(oracle)
     ctx = Context(0)
     rng = np.random.default_rng(5)
@@ -44,7 +45,10 @@ def test_batch_matches_the_sequential_oracle(oracle, refit):
         e = _oracle(o, Xw, uv, refit)
         assert g["n_inliers"] == e["n_inliers"] and g["iterations_run"] == e["iterations_run"] and g["best_iteration"] == e["best_iteration"], (n, g, e)
         assert np.array_equal(g["inliers"], e["inliers"])
-        assert np.array_equal(g["T"], e["T"]), (n, np.abs(g["T"] - e["T"]).max())
+        if refit:
+            assert np.abs(g["T"] - e["T"]).max() <= 1e-9 * max(1.0, np.abs(e["T"]).max()), (n, np.abs(g["T"] - e["T"]).max())
+        else:
+            assert np.array_equal(g["T"], e["T"]), (n, np.abs(g["T"] - e["T"]).max())
     assert got[0]["n_inliers"] > 700 and got[0]["iterations_run"] < 500
     assert got[6]["n_inliers"] == 0 and np.array_equal(got[6]["T"], np.eye(4))
 

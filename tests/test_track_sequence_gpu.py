@@ -134,7 +134,7 @@ def test_noisy_sequence_with_invalid_pixels_and_a_dropped_mask_matches_the_oracl
     drop = {5: {2}, 6: {2}}
     ctx, ctx_lm, ctx_obj, ctx_w = Context(0), Context(0), Context(0), Context(0)
     pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1), ctx_obj, ctx_w)
-    ref = OraclePipeline(oracle, build_lm=True)
+    ref = OraclePipeline(oracle, build_lm=True, seed_refit="product")   # noisy objects: the LM is chaotic in the float seed (tests/pipeline_ref.py)
     keys = ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects", "n_recovered_masks", "n_static_tracks",
             "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations", "n_mm_inliers_obj", "n_motion_model_obj")
     recovered = 0
@@ -260,7 +260,7 @@ def test_turning_objects_that_leave_and_enter_match_the_oracle(oracle):
     drop = {8: {1}, 9: {1}}
     ctx, ctx_lm, ctx_obj, ctx_w = Context(0), Context(0), Context(0), Context(0)
     pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1), ctx_obj, ctx_w)
-    ref = OraclePipeline(oracle, build_lm=True)
+    ref = OraclePipeline(oracle, build_lm=True, seed_refit="product")   # noisy objects: the LM is chaotic in the float seed (tests/pipeline_ref.py)
     keys = ("n_orb", "n_static_new", "n_object_samples", "n_static_tracked", "n_object_tracked", "n_objects", "n_recovered_masks", "n_static_tracks",
             "n_dynamic_tracks", "n_ransac_cam", "n_motion_model_cam", "n_ransac_obj", "n_cam_inliers", "cam_lm_iterations", "n_mm_inliers_obj", "n_motion_model_obj")
     labels_seen, recovered, turning_checked = set(), 0, 0
@@ -305,7 +305,7 @@ def test_object_motion_model_branch_of_get_init_model_obj(oracle, flow_sigma, mm
     objs = SQ.default_objects()
     ctx, ctx_lm, ctx_obj, ctx_w = Context(0), Context(0), Context(0), Context(0)
     pipe = FramePipeline(ctx, ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=1), ctx_obj, ctx_w)
-    ref = OraclePipeline(oracle, build_lm=True)
+    ref = OraclePipeline(oracle, build_lm=True, seed_refit="product")   # noisy objects: the LM is chaotic in the float seed (tests/pipeline_ref.py)
     keys = ("n_objects", "n_ransac_obj", "n_mm_inliers_obj", "n_motion_model_obj", "n_ransac_cam", "n_motion_model_cam", "n_cam_inliers", "n_static_tracked")
     won = had_model = 0
     exp_motions = []

@@ -7,10 +7,11 @@
 // control points from the PCA of the points, barycentric coordinates, M^T M and the eigenvectors of its 4 smallest eigenvalues,
 // the L_6x10 / rho system, three beta initialisations each refined by 5 Gauss-Newton steps, absolute orientation, smallest mean
 // reprojection error wins.  OpenCV itself is not available to pin this against (parity unpinned); deliberate
-// liberties: symmetric eigen-solvers instead of OpenCV's SVD routines, Horn's quaternion method for the absolute orientation,
-// pseudo-inverse through the normal equations for the small least-squares systems.
-// Arithmetic: +, -, *, / and sqrt only, fixed summation order - the CPU oracle (oracle/epnp_oracle.hpp) performs the same
-// operations in the same order, so the refit pose is compared BIT FOR BIT in tests/test_ransac_gpu.py.
+// liberties: symmetric eigen-solvers instead of OpenCV's SVD routines (except for the principal directions of the control points,
+// whose signs matter: principal_directions), Horn's quaternion method for the absolute orientation, pseudo-inverse through the
+// normal equations for the small least-squares systems.
+// The CPU oracle (oracle/epnp_oracle.hpp) is an independent restatement with OpenCV's own numerical tools (SVD everywhere); the two
+// are compared to 1e-9 (tests/test_epnp_independent.py on the CPU, tests/test_ransac_gpu.py through the C-ABI).
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -162,6 +163,54 @@ inline void sym_eig_ql(int n, double* A, double* V, double* w) {
   }
 }
 
+// Principal directions of the 3 x 3 scatter matrix C with the SIGNS cv::SVD gives them.  EPnP's control points are
+// centroid + sqrt(sigma_i / n) * (i-th principal direction): flipping a direction moves a control point to the other side of the
+// centroid, and with noisy data the pose EPnP returns depends on that choice - so this one step follows the numerical scheme of
+// OpenCV 3.4.0's SVD (one-sided Jacobi on the rows of the matrix, modules/core/src/lapack.cpp; the reference's OpenCV is built
+// without LAPACK, /root/reference/Dockerfile:33-50): rows orthogonalised pairwise in the order (0,1), (0,2), (1,2), rotation with
+// c >= 0 if |row i| >= |row j| else s >= 0, convergence at |<row i, row j>| <= 10 eps |row i| |row j|, at most 30 sweeps, singular
+// values = row norms sorted descending (selection, swaps), directions = rows / norm.  d: the three rows (unit vectors), w: their
+// singular values.
+inline void principal_directions(const double C[9], double w[3], double d[9]) {
+  double r[3][3] = {{C[0], C[1], C[2]}, {C[3], C[4], C[5]}, {C[6], C[7], C[8]}};
+  double n2[3];
+  for (int i = 0; i < 3; ++i) n2[i] = r[i][0] * r[i][0] + r[i][1] * r[i][1] + r[i][2] * r[i][2];
+  for (int sweep = 0; sweep < 30; ++sweep) {
+    bool changed = false;
+    for (int i = 0; i < 2; ++i)
+      for (int j = i + 1; j < 3; ++j) {
+        double p = r[i][0] * r[j][0] + r[i][1] * r[j][1] + r[i][2] * r[j][2];
+        if (std::fabs(p) <= 2.220446049250313e-15 * std::sqrt(n2[i] * n2[j])) continue;
+        p *= 2.0;
+        const double beta = n2[i] - n2[j], gamma = std::hypot(p, beta);
+        double c, s;
+        if (beta < 0.0) { s = std::sqrt((gamma - beta) * 0.5 / gamma); c = p / (gamma * s * 2.0); }
+        else { c = std::sqrt((gamma + beta) / (gamma * 2.0)); s = p / (gamma * c * 2.0); }
+        double ni = 0.0, nj = 0.0;
+        for (int k = 0; k < 3; ++k) {
+          const double ri = c * r[i][k] + s * r[j][k], rj = c * r[j][k] - s * r[i][k];
+          r[i][k] = ri; r[j][k] = rj; ni += ri * ri; nj += rj * rj;
+        }
+        n2[i] = ni; n2[j] = nj;
+        changed = true;
+      }
+    if (!changed) break;
+  }
+  int ord[3] = {0, 1, 2};
+  double nr[3];
+  for (int i = 0; i < 3; ++i) nr[i] = std::sqrt(r[i][0] * r[i][0] + r[i][1] * r[i][1] + r[i][2] * r[i][2]);
+  for (int i = 0; i < 2; ++i) {
+    int m = i;
+    for (int k = i + 1; k < 3; ++k) if (nr[ord[m]] < nr[ord[k]]) m = k;
+    if (m != i) { const int t = ord[i]; ord[i] = ord[m]; ord[m] = t; }
+  }
+  for (int i = 0; i < 3; ++i) {
+    w[i] = nr[ord[i]];
+    const double inv = w[i] > 0.0 ? 1.0 / w[i] : 0.0;
+    for (int k = 0; k < 3; ++k) d[3 * i + k] = r[ord[i]][k] * inv;
+  }
+}
+
 // minimum-norm least squares x = pinv(A) b for A (m x k, row-major, k <= 5) through the eigen-decomposition of A^T A
 inline void lstsq_pinv(int m, int k, const double* A, const double* b, double* x) {
   double AtA[25], Atb[5], V[25], w[5];
@@ -221,14 +270,14 @@ inline Result solve(int n, const double* X, const double* uv, const double* K4, 
     C[0] += d0 * d0; C[1] += d0 * d1; C[2] += d0 * d2; C[4] += d1 * d1; C[5] += d1 * d2; C[8] += d2 * d2;
   }
   C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
-  double Vc[9], dc[3];
-  jacobi_eig(3, C, Vc, dc);
+  double Dc[9], dc[3];
+  principal_directions(C, dc, Dc);
   // (near-)coplanar points: the fourth control point collapses onto the centroid and the barycentric coordinates are undefined.
   // OpenCV's behaviour there is an artefact of its pseudo-inverse; here the caller keeps the RANSAC hypothesis (err < 0).
   if (!(dc[2] > 1e-8 * dc[0])) { Result none{}; none.err = -1.0; return none; }
   for (int i = 1; i < 4; ++i) {
     const double k = std::sqrt((dc[i - 1] > 0.0 ? dc[i - 1] : 0.0) / n);
-    for (int j = 0; j < 3; ++j) cws[i][j] = cws[0][j] + k * Vc[j * 3 + (i - 1)];
+    for (int j = 0; j < 3; ++j) cws[i][j] = cws[0][j] + k * Dc[3 * (i - 1) + j];
   }
   // ---- compute_barycentric_coordinates
   double cc[9], ci[9];
