@@ -437,6 +437,17 @@ extern "C" int vdo_oracle_orb_fast_level(const uint8_t* gray, int w, int h, cons
   return (int)c.size();
 }
 
+// KAT hooks for the golden vectors of tools/pin_reference: cv::FAST(img, kps, thr, true) on a whole image (x, y, score in raster
+// order) and cv::fastAtan2
+extern "C" int vdo_oracle_fast_image(const uint8_t* img, int w, int h, int thr, float* x, float* y, float* resp, int cap) {
+  Img im; im.w = w; im.h = h; im.d.assign(img, img + (size_t)w * h);
+  std::vector<Cand> c;
+  fast_roi(im, 0, 0, w, h, thr, c);
+  for (int i = 0; i < (int)c.size() && i < cap; ++i) { x[i] = c[i].x; y[i] = c[i].y; resp[i] = c[i].resp; }
+  return (int)c.size();
+}
+extern "C" float vdo_oracle_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+
 // ORBextractor::operator(): keypoints of all levels (level-0 coordinates), returns count.  desc (nullable): [cap][32] rotated
 // BRIEF of every keypoint on the blurred level image - the call the reference has commented out (src/ORBextractor.cc:1083-1091)
 extern "C" int vdo_oracle_orb_extract_desc(const uint8_t* gray, int w, int h, const vdo_orb_params* p,
