@@ -141,6 +141,15 @@ int vdo_ba_destroy(vdo_ba* ba);
  * accumulation) at the current estimate.  If ms_sweep != NULL it receives the mean
  * duration of ONE binary-edge sweep kernel measured with hipEvents on the ctx stream. */
 int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep);
+/* Measurement hook of the roofline leg (bench.py, tools/sweep_only.py; no counterpart in the reference - its g2o prints one
+ * time per outer iteration, g2o/core/sparse_optimizer.cpp:406-418): `repeat` back-to-back runs, hipEvents on the ctx stream, of
+ *   ms[0] the tile sweep kernel alone (k_sweep_tile<true>),
+ *   ms[1] a whole linearisation as BlockSolver::buildSystem means it (g2o/core/block_solver.hpp:502-560): sweep + expansion of
+ *         the pose blocks (k_finalize_pose) + pose-pose edges (k_posepose) + chi2 reduction,
+ * and the layout figures the byte model of DESIGN.md 4.1 needs:
+ *   dims[0] tiles, [1] (tile, pose-slot) pairs, [2] running sums per partial row (16 / 32), [3] max slots of a tile,
+ *   [4] bytes read per EdgeSE3PointXYZ (key + measurement [+ weight]), [5] bytes read per ternary edge. */
+int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int64_t dims[6]);
 int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out);
 /* Full Levenberg–Marquardt (control flow identical to the modified g2o). */
 int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_stats* stats);

@@ -11,11 +11,12 @@
 //   pose    [P][12]      AoS (R row-major | t); few, L2-resident
 //   point   [L][3]       AoS, tile-major: read once per tile, coalesced
 //   edges   SoA, tile-major: key int32 (pose-slot<<16 | local point), z [3][E], w [E]
-//   Finc    [4][Eb+Et]   SoA FACTORED pose-x-point blocks, written once per sweep.  Every 6x3 block of
+//   Finc    [Eb+Et]      FACTORED pose-x-point blocks, written once per sweep.  Every 6x3 block of
 //           Hpl is  s*we*[ I ; k[c]x ] * (R^T or I)  with c = the point in the pose's frame (zc resp.
-//           v = H^-1 p2) and R the pose rotation, so (we, c) + the L2-resident pose reproduce it
-//           exactly: 32 B/edge instead of 144 B, both for the sweep's write and for every PCG mat-vec.
-//   part_*  [k][NPS]     per-(tile,pose-slot) partial sums (NPS = total slots)
+//           v = H^-1 p2) and R the pose rotation; c is a function of the point and the pose, both staged in LDS
+//           by every consumer anyway, so ONLY we (the Huber-weighted information scalar) is stored:
+//           8 B/edge instead of 144 B, both for the sweep's write and for every PCG mat-vec.
+//   part_q / part_m  [k][NPS]   per-(tile,pose-slot) partial sums of the solver (NPS = total slots); part_sums: pose-major rows, see below
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -63,6 +64,13 @@ struct BADev {
   int32_t* pr_pose = nullptr; double *pr_z = nullptr, *pr_info = nullptr;
   // pose -> slots CSR, pose -> pose-pose edges CSR
   int32_t *ps_off = nullptr, *ps_idx = nullptr;
+  // sweep partials, POSE-MAJOR: the (tile,slot) partial of global slot s is row slot_dst[s] of part_sums, and the rows of pose p are
+  // [ps_off[p], ps_off[p+1]) - contiguous, so k_finalize_pose streams them.  A row holds ps_stride running sums: 16 when no pose
+  // vertex carries both EdgeSE3PointXYZ and ternary edges (never, in the reference's graphs: cameras see points, motions link them) -
+  // the row then holds whichever kind the pose has (pose_kind: 0 binary, 1 ternary) - else 32 (binary | ternary).
+  int32_t* slot_dst = nullptr;           // [NPS]
+  int32_t* pose_kind = nullptr;          // [P]
+  int ps_stride = 16;
   int32_t *pe_off = nullptr, *pe_idx = nullptr;   // entry = edge<<1 | side (0: pose is i, 1: pose is j)
   // pose chains (paths of the EdgeSE3 graph) for the block-tridiagonal preconditioner, in path order
   int n_pchains = 0;
@@ -72,11 +80,13 @@ struct BADev {
   // linear system
   double *Hpp = nullptr, *bp = nullptr;              // [P][36], [P][6]
   double *Hll = nullptr, *bl = nullptr;              // [L] (the landmark diagonal block is Hll[l] * I3, see ba_sweep.hip),  [L][3]
-  double* Finc = nullptr;                            // [4][Eb+Et] factored pose-landmark blocks: (we, c.x, c.y, c.z)
+  double* Finc = nullptr;                            // [Eb+Et] factored pose-landmark blocks: we (c is recomputed, ba_solve.hip make_f)
   double* Binc = nullptr;                            // [18][Ninc] explicit 6x3 blocks — only materialised for vdo_ba_download_system
   double* Oll = nullptr;                             // [9][Et]  p1 x p2 blocks
   double* Hpp_ep = nullptr;                          // [Ep][36]
-  double* part_sums = nullptr;                       // [32][NPS] sweep partials (16 binary + 16 ternary)
+  double* ep_blk = nullptr;                          // [Ep+Npr][84] per pose-pose edge: Hii | Hjj | bi | bj (added to the pose blocks by k_finalize_pose)
+  int32_t *pr_off = nullptr, *pr_idx = nullptr;      // pose -> priors CSR
+  double* part_sums = nullptr;                       // [NPS][ps_stride] sweep partials, pose-major rows (see slot_dst)
   double* part_red = nullptr;                        // [256] per-block partials of k_update / k_max_diag
   double* part_chi = nullptr;                        // [2][n_tiles] + [2][Ep+Npr]
   // solver workspaces

@@ -1,5 +1,5 @@
 // Pose-pose factors of the batch graph on the GPU: EdgeSE3 (odometry, motion smoothness) and
-// EdgeSE3Prior.  One thread per edge (there are only O(#frames x #objects) of them).
+// EdgeSE3Prior.  One wave per edge (there are only O(#frames x #objects) of them).
 //   EdgeSE3 / EdgeSE3Prior      g2o/types/edge_se3.cpp:77-104, edge_se3_prior.cpp:89-102
 //   computeEdgeSE3Gradient      g2o/types/isometry3d_gradients.h:191-261
 //   computeEdgeSE3PriorGradient g2o/types/isometry3d_gradients.h:264-325
@@ -160,98 +160,72 @@ __device__ __forceinline__ double chi2_6(const double* e, const double* info) {
   return s;
 }
 
-// out(6x6) = Ja^T (w * Omega) Jb
-__device__ __forceinline__ void jtwj6(const double* Ja, const double* Om, double w, const double* Jb, double* out) {
-  double WJ[36];
-  #pragma unroll
-  for (int i = 0; i < 6; ++i)
-    #pragma unroll
-    for (int j = 0; j < 6; ++j) {
-      double s = 0;
-#pragma unroll
-      for (int k = 0; k < 6; ++k) s += Om[i * 6 + k] * Jb[k * 6 + j];
-      WJ[i * 6 + j] = w * s;
-    }
-  #pragma unroll
-  for (int a = 0; a < 6; ++a)
-    #pragma unroll
-    for (int c = 0; c < 6; ++c) {
-      double s = 0;
-#pragma unroll
-      for (int i = 0; i < 6; ++i) s += Ja[i * 6 + a] * WJ[i * 6 + c];
-      out[a * 6 + c] = s;
-    }
-}
-
-// one thread per EdgeSE3 (k < Ep) or prior (k >= Ep).  ep_chi: [2][Ep+Npr] (chi2, robust chi2)
+// One WAVE per EdgeSE3 (k < Ep) or prior (k >= Ep).  ep_chi: [2][Ep+Npr] (chi2, robust chi2).
+// The residual and the two 6x6 Jacobians are a long scalar computation (dq/dR, the quaternion branches): lane 0 runs it and leaves
+// Ji, Jj, the information matrix and the weighted residual in LDS; the products J^T (rho' Omega) J - 3 x 432 multiply-adds when one
+// thread formed them - are then taken entry by entry: lane l < 36 owns entry (l / 6, l % 6) of all three blocks, lanes 36..41 the two
+// right-hand sides, each with the summation order of the one-thread routine (same bits).  Nothing is accumulated here: the blocks of
+// edge k go to ep_blk[k] = Hii (36) | Hjj (36) | bi (6) | bj (6) and Hpp_ep[k] = Hij; k_finalize_pose adds them to the pose blocks
+// in the fixed order of the pose's edge list (no atomics, run-independent bits).
 template <bool BUILD>
-__global__ __launch_bounds__(64) void k_posepose(BADev d, int which, double* ep_chi, int acc) {
-  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(64) void k_posepose(BADev d, int which, double* ep_chi) {
+  __shared__ double sJi[36], sJj[36], sOm[36], sR[6], sRho;
+  const int k = blockIdx.x, lane = threadIdx.x;
   const int n = d.Ep + d.Npr;
   if (k >= n) return;
   const double* pose = d.pose[which];
-  double e[6], Ji[36], Jj[36], Hm[36];
-  if (k < d.Ep) {
-    const int vi = d.ep_i[k], vj = d.ep_j[k];
-    const double* info = d.ep_info + 36 * (int64_t)k;
-    const IsoD Z = iso_load(d.ep_z + 12 * (int64_t)k);
-    const IsoD Xi = iso_load(pose + 12 * (int64_t)vi), Xj = iso_load(pose + 12 * (int64_t)vj);
-    edge_se3_dev(Z, Xi, Xj, e, BUILD ? Ji : nullptr, BUILD ? Jj : nullptr);
+  const bool is_edge = k < d.Ep;
+  const double* info = is_edge ? d.ep_info + 36 * (int64_t)k : d.pr_info + 36 * (int64_t)(k - d.Ep);
+  double rho1 = 1.0;
+  if (lane == 0) {
+    double e[6], Ji[36], Jj[36];
+    if (is_edge) {
+      const IsoD Z = iso_load(d.ep_z + 12 * (int64_t)k);
+      const IsoD Xi = iso_load(pose + 12 * (int64_t)d.ep_i[k]), Xj = iso_load(pose + 12 * (int64_t)d.ep_j[k]);
+      edge_se3_dev(Z, Xi, Xj, e, BUILD ? Ji : nullptr, BUILD ? Jj : nullptr);
+    } else {
+      const int q = k - d.Ep;
+      edge_prior_dev(iso_load(d.pr_z + 12 * (int64_t)q), iso_load(pose + 12 * (int64_t)d.pr_pose[q]), e, BUILD ? Ji : nullptr);
+    }
     const double chi = chi2_6(e, info);
-    double rho0, rho1;
-    huber(chi, d.huber_ep, d.dsqr_ep, rho0, rho1);
+    double rho0 = chi;
+    if (is_edge) huber(chi, d.huber_ep, d.dsqr_ep, rho0, rho1);     // (no robust kernel on the prior)
     ep_chi[k] = chi; ep_chi[n + k] = rho0;
     if (BUILD) {
-      double r[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 6; ++j) s += info[i * 6 + j] * e[j]; r[i] = -s * rho1; }
-      jtwj6(Ji, info, rho1, Ji, Hm);
-      if (acc) {
+      for (int i = 0; i < 36; ++i) { sJi[i] = Ji[i]; sJj[i] = is_edge ? Jj[i] : 0.0; }
 #pragma unroll
-        for (int i = 0; i < 36; ++i) atomicAdd(d.Hpp + 36 * (int64_t)vi + i, Hm[i]);
-      }
-      jtwj6(Jj, info, rho1, Jj, Hm);
-      if (acc) {
-#pragma unroll
-        for (int i = 0; i < 36; ++i) atomicAdd(d.Hpp + 36 * (int64_t)vj + i, Hm[i]);
-      }
-      jtwj6(Ji, info, rho1, Jj, Hm);
-#pragma unroll
-      for (int i = 0; i < 36; ++i) d.Hpp_ep[36 * (int64_t)k + i] = Hm[i];
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        double si = 0, sj = 0;
-  #pragma unroll
-        for (int i = 0; i < 6; ++i) { si += Ji[i * 6 + a] * r[i]; sj += Jj[i * 6 + a] * r[i]; }
-        if (acc) { atomicAdd(d.bp + 6 * (int64_t)vi + a, si); atomicAdd(d.bp + 6 * (int64_t)vj + a, sj); }
-      }
+      for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 6; ++j) s += info[i * 6 + j] * e[j]; sR[i] = -s * rho1; }
+      sRho = rho1;                                         // (the other lanes did not run the robust kernel)
     }
-  } else {
-    const int q = k - d.Ep;
-    const int v = d.pr_pose[q];
-    const double* info = d.pr_info + 36 * (int64_t)q;
-    const IsoD Z = iso_load(d.pr_z + 12 * (int64_t)q);
-    const IsoD X = iso_load(pose + 12 * (int64_t)v);
-    edge_prior_dev(Z, X, e, BUILD ? Ji : nullptr);
-    const double chi = chi2_6(e, info);
-    ep_chi[k] = chi; ep_chi[n + k] = chi;    // no robust kernel on the prior
-    if (BUILD) {
-      double r[6];
+  }
+  if (!BUILD) return;
+  if (lane < 36) sOm[lane] = info[lane];
+  __syncthreads();
+  rho1 = sRho;
+  double* blk = d.ep_blk + 84 * (int64_t)k;
+  if (lane < 36) {
+    const int a = lane / 6, c = lane - 6 * a;
+    double wi[6], wj[6];                                   // column c of rho1 * Omega * Ji  /  rho1 * Omega * Jj
 #pragma unroll
-      for (int i = 0; i < 6; ++i) { double s = 0; for (int j = 0; j < 6; ++j) s += info[i * 6 + j] * e[j]; r[i] = -s; }
-      jtwj6(Ji, info, 1.0, Ji, Hm);
-      if (acc) {
+    for (int i = 0; i < 6; ++i) {
+      double si = 0, sj = 0;
 #pragma unroll
-        for (int i = 0; i < 36; ++i) atomicAdd(d.Hpp + 36 * (int64_t)v + i, Hm[i]);
-      }
-#pragma unroll
-      for (int a = 0; a < 6; ++a) {
-        double si = 0;
-  #pragma unroll
-        for (int i = 0; i < 6; ++i) si += Ji[i * 6 + a] * r[i];
-        if (acc) atomicAdd(d.bp + 6 * (int64_t)v + a, si);
-      }
+      for (int q = 0; q < 6; ++q) { si += sOm[i * 6 + q] * sJi[q * 6 + c]; sj += sOm[i * 6 + q] * sJj[q * 6 + c]; }
+      wi[i] = rho1 * si; wj[i] = rho1 * sj;
     }
+    double hii = 0, hjj = 0, hij = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { hii += sJi[i * 6 + a] * wi[i]; hjj += sJj[i * 6 + a] * wj[i]; hij += sJi[i * 6 + a] * wj[i]; }
+    blk[lane] = hii;
+    blk[36 + lane] = hjj;
+    if (is_edge) d.Hpp_ep[36 * (int64_t)k + lane] = hij;
+  } else if (lane < 42) {
+    const int a = lane - 36;
+    double si = 0, sj = 0;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) { si += sJi[i * 6 + a] * sR[i]; sj += sJj[i * 6 + a] * sR[i]; }
+    blk[72 + a] = si; blk[78 + a] = sj;
   }
 }
 
@@ -259,11 +233,8 @@ __global__ __launch_bounds__(64) void k_posepose(BADev d, int which, double* ep_
 void launch_posepose(const BADev& d, int which, bool build, double* ep_chi, hipStream_t s) {
   const int n2 = d.Ep + d.Npr;
   if (!n2) return;
-  // Shards: the fp64 atomics below commit in a run-dependent order, so only rank 0 accumulates the
-  // (replicated) pose-pose terms and the all-reduce hands every rank the same bits.
-  const int acc = (!d.sharded || d.shard_rank == 0) ? 1 : 0;
-  if (build) hipLaunchKernelGGL(k_posepose<true>, dim3((n2 + 63) / 64), dim3(64), 0, s, d, which, ep_chi, acc);
-  else hipLaunchKernelGGL(k_posepose<false>, dim3((n2 + 63) / 64), dim3(64), 0, s, d, which, ep_chi, acc);
+  if (build) hipLaunchKernelGGL(k_posepose<true>, dim3(n2), dim3(64), 0, s, d, which, ep_chi);
+  else hipLaunchKernelGGL(k_posepose<false>, dim3(n2), dim3(64), 0, s, d, which, ep_chi);
 }
 
 }  // namespace vdo

@@ -144,9 +144,31 @@ __device__ bool spd6_inv(const double* A, double* Ainv) {
 // Factored pose-landmark block (ba_dev.hpp): F = (we, c).  kind 0: EdgeSE3PointXYZ, 1: ternary (H,p1), 2: ternary (H,p2).
 //   kind 0:  B = -we [ I ; 2[c]x ] Rt        kind 1:  B = we [ I ; [c]x ]        kind 2:  B = -we [ I ; [c]x ] Rt
 // (Rt = R^T of the pose vertex, row-major).
+// Only `we` lives in HBM (Finc [Eb+Et]: 8 B per edge); c is recomputed from the tile's points and inverse poses staged in LDS -
+// estimate [0], the linearisation point - with the very operations of the sweep (ba_sweep.hip: zc = W p + t_W, v = H^-1 p2), so
+// the block is bit-for-bit the one the sweep's sums were formed from.  That is 24 B per incidence less in the sweep's write and
+// in every pass of the solver over the blocks (one CG iteration reads them once).
 struct FInc { double we, cx, cy, cz; };
-__device__ __forceinline__ FInc load_f(const double* __restrict__ Finc, int64_t idx, int64_t NF) {
-  return FInc{Finc[idx], Finc[NF + idx], Finc[2 * NF + idx], Finc[3 * NF + idx]};
+// inverse pose (R^T | -R^T t, 12 doubles; the first 9 are the R^T the block expansion needs) of every pose slot + the points of the tile
+__device__ __forceinline__ void stage_slot_w_pts(const BADev& d, const Tile& T, double* slotW, double* pts) {
+  const int nslot = T.slot_end - T.slot_begin, npts = T.pt_end - T.pt_begin;
+  for (int sidx = threadIdx.x; sidx < nslot; sidx += blockDim.x) {
+    const IsoD W = iso_inv(iso_load(d.pose[0] + 12 * (int64_t)d.tile_pose[T.slot_begin + sidx]));
+    double* o = slotW + 12 * sidx;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = W.r[i];
+    o[9] = W.t.x; o[10] = W.t.y; o[11] = W.t.z;
+  }
+  const double* __restrict__ point = d.point[0] + 3 * (int64_t)T.pt_begin;
+  for (int i = threadIdx.x; i < 3 * npts; i += blockDim.x) pts[i] = point[i];
+}
+// incidence li of the tile (key = slot << 16 | local point) -> its factored block (we from HBM, c from LDS)
+__device__ __forceinline__ FInc make_f(const BADev& d, const Tile& T, int li, int kind, int key, double we, const double* slotW, const double* pts) {
+  int lp = key & 0xffff;                                   // kind 0: the observed point; kind 2: p2
+  if (kind == 1) lp = d.et_key[T.et_begin + (li - (T.eb_end - T.eb_begin))] >> 16;     // (H, p1): c = H^-1 p2 as well
+  const double* W = slotW + 12 * (key >> 16);
+  const D3 c = rot(W, D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]}) + D3{W[9], W[10], W[11]};
+  return FInc{we, c.x, c.y, c.z};
 }
 // explicit 6x3 block (row-major 18) — used by the preconditioner and the debug expansion
 __device__ __forceinline__ void expand_block(int kind, const FInc& f, const double* Rt, double (&B)[18]) {
@@ -176,15 +198,6 @@ __device__ __forceinline__ void inc_locate(const Tile& T, int li, int64_t Eb, in
   else if (li < nb + nt) { kind = 1; fidx = Eb + T.et_begin + (li - nb); }
   else { kind = 2; fidx = Eb + T.et_begin + (li - nb - nt); }
 }
-// stage R^T of every pose slot of the tile into LDS (9 doubles per slot)
-__device__ __forceinline__ void stage_slot_rt(const BADev& d, const Tile& T, double* slotR) {
-  const int nslot = T.slot_end - T.slot_begin;
-  for (int i = threadIdx.x; i < 9 * nslot; i += blockDim.x) {
-    const int sidx = i / 9, k = i - 9 * sidx;
-    slotR[i] = d.pose[0][12 * (int64_t)d.tile_pose[T.slot_begin + sidx] + 3 * (k % 3) + (k / 3)];   // transpose
-  }
-}
-
 // out(6x6 upper, 21 values) += B1 G B2^T (+ transpose if sym2) ; helper computing full 6x6 product
 __device__ __forceinline__ void bgbt(const double (&B1)[18], const double* G, const double (&B2)[18], double (&out)[36]) {
   double T1[18];   // B1 G (6x3)
@@ -205,12 +218,12 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   const int nslot = T.slot_end - T.slot_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
   double* accm = smem;                       // [21 * S]
-  double* slotR = accm + 21 * d.max_slots;   // [9 * S]
+  double* slotW = accm + 21 * d.max_slots;   // [12 * S]
+  double* pts = slotW + 12 * d.max_slots;    // [3 * TP]
   const int tid = threadIdx.x;
   for (int i = tid; i < 21 * nslot; i += VDO_TILE_THREADS) accm[i] = 0.0;
-  stage_slot_rt(d, T, slotR);
+  stage_slot_w_pts(d, T, slotW, pts);
   __syncthreads();
-  const int64_t NF = (int64_t)d.Eb + d.Et;
   for (int base = 0; base < nb; base += VDO_TILE_THREADS) {
     const int j = base + tid;
     int slot = -1;
@@ -223,7 +236,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
       slot = key >> 16;
       const int64_t l = T.pt_begin + (key & 0xffff);
       double B[18], M[36];
-      expand_block(0, load_f(d.Finc, T.eb_begin + j, NF), slotR + 9 * slot, B);
+      expand_block(0, make_f(d, T, j, 0, key, d.Finc[T.eb_begin + j], slotW, pts), slotW + 12 * slot, B);
       bgbt(B, d.Gdiag + 9 * l, B, M);
       int k = 0;
 #pragma unroll
@@ -245,9 +258,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
       slot = k1 >> 16;
       const int64_t l1 = T.pt_begin + (k1 & 0xffff), l2 = T.pt_begin + (k2 & 0xffff);
       double B1[18], B2[18], M11[36], M12[36], M22[36];
-      const FInc f = load_f(d.Finc, (int64_t)d.Eb + T.et_begin + j, NF);
-      expand_block(1, f, slotR + 9 * slot, B1);
-      expand_block(2, f, slotR + 9 * slot, B2);
+      const FInc f = make_f(d, T, nb + nt + j, 2, k2, d.Finc[(int64_t)d.Eb + T.et_begin + j], slotW, pts);
+      expand_block(1, f, slotW + 12 * slot, B1);
+      expand_block(2, f, slotW + 12 * slot, B2);
       bgbt(B1, d.Gdiag + 9 * l1, B1, M11);
       bgbt(B1, d.Goff + 9 * l2, B2, M12);     // [Hll^-1]_{l1,l2}, l2 = l1 + 1 in chain order
       bgbt(B2, d.Gdiag + 9 * l2, B2, M22);
@@ -545,10 +558,11 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
   double* gl = dinv + 9 * VDO_TILE_PTS;    // [9*TP]  G_k
   double* vs = gl + 9 * VDO_TILE_PTS;      // [6*S]
   double* qs = vs + 6 * d.max_slots;       // [6*S]
-  double* slotR = qs + 6 * d.max_slots;    // [9*S]  R^T of the pose slots
+  double* slotW = qs + 6 * d.max_slots;    // [12*S] inverse poses of the slots (R^T | -R^T t)
+  double* pts = slotW + 12 * d.max_slots;  // [3*TP]  the tile's points (linearisation point)
   const int tid = threadIdx.x;
   for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) u[i] = 0.0;
-  stage_slot_rt(d, T, slotR);
+  stage_slot_w_pts(d, T, slotW, pts);
   {   // coalesced staging of the chain factors (read once per tile, used by the serial chain solves)
     const double* gd = d.Dinv + 9 * (int64_t)T.pt_begin;
     const double* gg = d.Gl + 9 * (int64_t)T.pt_begin;
@@ -558,23 +572,24 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) vs[i] = v[6 * (int64_t)d.tile_pose[T.slot_begin + i / 6] + i % 6];
   if (MODE != 2)
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) qs[i] = 0.0;
-  // factored incidence blocks in registers (4 doubles each)
+  // factored incidence blocks in registers: we requested now, c formed behind the staging barrier
   FInc F[3];
   int key[3], kind[3];
-  const int64_t NF = (int64_t)d.Eb + d.Et;
+  double we[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int li = tid + VDO_TILE_THREADS * j;
-    key[j] = -1; kind[j] = 1;
-    F[j] = FInc{0, 0, 0, 0};
+    key[j] = -1; kind[j] = 1; we[j] = 0.0;
     if (li < ninc) {
       key[j] = d.inc_key[T.inc_begin + li];
       int64_t fidx;
       inc_locate(T, li, d.Eb, kind[j], fidx);
-      F[j] = load_f(d.Finc, fidx, NF);
+      we[j] = d.Finc[fidx];
     }
   }
   __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 3; ++j) F[j] = key[j] >= 0 ? make_f(d, T, tid + VDO_TILE_THREADS * j, kind[j], key[j], we[j], slotW, pts) : FInc{0, 0, 0, 0};
   if (MODE != 1) {   // pass A: u_l += B^T v_slot = sgn*we * (I or R) (vt - s c x vr)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -586,7 +601,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
         const D3 t{pv[0] - s * (f.cy * pv[5] - f.cz * pv[4]), pv[1] - s * (f.cz * pv[3] - f.cx * pv[5]), pv[2] - s * (f.cx * pv[4] - f.cy * pv[3])};
         D3 o;
         if (kind[j] == 1) o = f.we * t;
-        else o = (-f.we) * rotT(slotR + 9 * sl, t);        // R t  (slotR holds R^T)
+        else o = (-f.we) * rotT(slotW + 12 * sl, t);       // R t  (slotW starts with R^T)
         double* ul = u + 3 * (key[j] & 0xffff);
         atomicAdd(ul, o.x); atomicAdd(ul + 1, o.y); atomicAdd(ul + 2, o.z);
       }
@@ -630,7 +645,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     const int sl = key[j] >= 0 ? (key[j] >> 16) : 0;
     const FInc f = F[j];
     D3 y{wl[0], wl[1], wl[2]};
-    if (kind[j] != 1) y = rot(slotR + 9 * sl, y);          // R^T w
+    if (kind[j] != 1) y = rot(slotW + 12 * sl, y);         // R^T w
     const double sg = kind[j] == 1 ? f.we : -f.we, s = kind[j] == 0 ? 2.0 : 1.0;
     q[0] = sg * y.x; q[1] = sg * y.y; q[2] = sg * y.z;
     q[3] = sg * s * (f.cy * y.z - f.cz * y.y);
@@ -800,16 +815,18 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_expand_binc(BADev d) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Tile T = d.tiles[blockIdx.x];
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, ninc = nb + 2 * nt;
-  double* slotR = smem;
-  stage_slot_rt(d, T, slotR);
+  double* slotW = smem;                     // [12*S]
+  double* pts = slotW + 12 * d.max_slots;   // [3*TP]
+  stage_slot_w_pts(d, T, slotW, pts);
   __syncthreads();
-  const int64_t NF = (int64_t)d.Eb + d.Et, N = d.Ninc;
+  const int64_t N = d.Ninc;
   for (int li = threadIdx.x; li < ninc; li += VDO_TILE_THREADS) {
     int kind; int64_t fidx;
     inc_locate(T, li, d.Eb, kind, fidx);
-    const int sl = d.inc_key[T.inc_begin + li] >> 16;
+    const int key = d.inc_key[T.inc_begin + li];
+    const int sl = key >> 16;
     double B[18];
-    expand_block(kind, load_f(d.Finc, fidx, NF), slotR + 9 * sl, B);
+    expand_block(kind, make_f(d, T, li, kind, key, d.Finc[fidx], slotW, pts), slotW + 12 * sl, B);
 #pragma unroll
     for (int i = 0; i < 18; ++i) d.Binc[i * N + T.inc_begin + li] = B[i];
   }
@@ -848,10 +865,11 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   double* dinv = u6 + 18 * VDO_TILE_PTS;      // [9*TP]
   double* gl = dinv + 9 * VDO_TILE_PTS;       // [9*TP]
   double* q36 = gl + 9 * VDO_TILE_PTS;        // [36*S]  block (r, s): [b][a]
-  double* slotR = q36 + 36 * d.max_slots;     // [9*S]
-  int* touched = (int*)(slotR + 9 * d.max_slots);   // [TP]
+  double* slotW = q36 + 36 * d.max_slots;     // [12*S]
+  double* pts = slotW + 12 * d.max_slots;     // [3*TP]
+  int* touched = (int*)(pts + 3 * VDO_TILE_PTS);    // [TP]
   const int tid = threadIdx.x;
-  stage_slot_rt(d, T, slotR);
+  stage_slot_w_pts(d, T, slotW, pts);
   {
     const double* gd = d.Dinv + 9 * (int64_t)T.pt_begin;
     const double* gg = d.Gl + 9 * (int64_t)T.pt_begin;
@@ -859,18 +877,21 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   }
   int key[3], kind[3];
   FInc F[3];
-  const int64_t NF = (int64_t)d.Eb + d.Et;
+  double we[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
     const int li = tid + VDO_TILE_THREADS * j;
-    key[j] = -1; kind[j] = 1; F[j] = FInc{0, 0, 0, 0};
+    key[j] = -1; kind[j] = 1; we[j] = 0.0;
     if (li < ninc) {
       key[j] = d.inc_key[T.inc_begin + li];
       int64_t fidx;
       inc_locate(T, li, d.Eb, kind[j], fidx);
-      F[j] = load_f(d.Finc, fidx, NF);
+      we[j] = d.Finc[fidx];
     }
   }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < 3; ++j) F[j] = key[j] >= 0 ? make_f(d, T, tid + VDO_TILE_THREADS * j, kind[j], key[j], we[j], slotW, pts) : FInc{0, 0, 0, 0};
   for (int s = 0; s < nslot; ++s) {
     __syncthreads();
     for (int i = tid; i < 18 * VDO_TILE_PTS; i += VDO_TILE_THREADS) u6[i] = 0.0;
@@ -882,7 +903,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     for (int j = 0; j < 3; ++j) {
       if (key[j] >= 0 && (key[j] >> 16) == s) {
         double B[18];
-        expand_block(kind[j], F[j], slotR + 9 * s, B);
+        expand_block(kind[j], F[j], slotW + 12 * s, B);
         const int lp = key[j] & 0xffff;
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
@@ -935,7 +956,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       const int r = on ? (key[j] >> 16) : -1, lp = on ? (key[j] & 0xffff) : 0;
       if (!__any(on)) continue;                                  // (wave-uniform: nothing of this wave's incidences is reached from slot s)
       double B[18];
-      expand_block(kind[j], F[j], slotR + 9 * (r >= 0 ? r : 0), B);
+      expand_block(kind[j], F[j], slotW + 12 * (r >= 0 ? r : 0), B);
       const SegCtl16 sc = seg_ctl16(r);
       const SegFlags sf = seg_flags(sc);
       double* q = q36 + 36 * (r >= 0 ? r : 0);
@@ -961,7 +982,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   }
 }
 
-size_t dense_tile_lds(const BADev& d) { return (36 * VDO_TILE_PTS + 45 * (size_t)d.max_slots) * sizeof(double) + VDO_TILE_PTS * sizeof(int); }
+size_t dense_tile_lds(const BADev& d) { return (39 * VDO_TILE_PTS + 48 * (size_t)d.max_slots) * sizeof(double) + VDO_TILE_PTS * sizeof(int); }
 
 // S <- reduced-camera matrix at this lambda (launch_factor must have run: it leaves the landmark chain factors of Hll + lambda I)
 void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R) {
@@ -983,10 +1004,10 @@ void launch_dense_rhs(const BADev& d, double* rhs, int64_t ld, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------ launchers
-static size_t schur_lds(const BADev& d) { return (21 * VDO_TILE_PTS + 21 * (size_t)d.max_slots) * sizeof(double); }
+static size_t schur_lds(const BADev& d) { return (24 * VDO_TILE_PTS + 24 * (size_t)d.max_slots) * sizeof(double); }
 
 void launch_expand_binc(const BADev& d, hipStream_t s) {
-  if (d.n_tiles) hipLaunchKernelGGL(k_expand_binc, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), 9 * (size_t)d.max_slots * sizeof(double), s, d);
+  if (d.n_tiles) hipLaunchKernelGGL(k_expand_binc, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), (12 * (size_t)d.max_slots + 3 * VDO_TILE_PTS) * sizeof(double), s, d);
 }
 
 static int red_blocks(const BADev& d) { return (int)std::min<int64_t>(256, std::max<int64_t>(1, (3 * (int64_t)d.L + 6 * (int64_t)d.P + 4095) / 4096)); }
@@ -1001,7 +1022,7 @@ void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R) {
 void launch_factor(const BADev& d, double lambda, hipStream_t s, const Reducer& R) {
   hipMemsetAsync(d.flags, 0, 4 * sizeof(int32_t), s);
   if (d.n_chains) hipLaunchKernelGGL(k_factor_chains, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, lambda);
-  if (d.n_tiles) hipLaunchKernelGGL(k_precond_tile, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), 30 * (size_t)d.max_slots * sizeof(double), s, d);
+  if (d.n_tiles) hipLaunchKernelGGL(k_precond_tile, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), (33 * (size_t)d.max_slots + 3 * VDO_TILE_PTS) * sizeof(double), s, d);
   const dim3 g((d.P + 3) / 4), b(256);
   if (!d.sharded) hipLaunchKernelGGL(k_precond_finalize<0>, g, b, 0, s, d, lambda);
   else {

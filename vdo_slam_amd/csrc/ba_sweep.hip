@@ -18,7 +18,7 @@
 //      Every thread sums them in registers over its few consecutive edges (edges are pose-sorted inside the tile), the
 //      threads' totals go through a segmented DPP scan into per-slot LDS accumulators and are written as per-(tile,slot) partials;
 //      k_finalize_pose expands them to the 6x6 block + rhs in fixed order.
-// No global atomics; HBM traffic = the algorithmic bytes of SURVEY.md §8d (+ the partials).
+// No global atomics.
 #include "ba_dev.hpp"
 #include "ba_tile.hpp"
 #include "se3_dev.hpp"
@@ -27,9 +27,10 @@ namespace vdo {
 
 void launch_posepose(const BADev& d, int which, bool build, double* ep_chi, hipStream_t s);
 
-// LDS carve-up (doubles): pts[3*TP] | accpt[4][TP] | slotW[12*S] | accpose[32*S] | red[40]
-__host__ __device__ inline size_t sweep_lds_doubles(int max_slots, bool build) {
-  return 3 * VDO_TILE_PTS + (build ? 4 * VDO_TILE_PTS : 0) + 12 * (size_t)max_slots + (build ? 32 * (size_t)max_slots : 0) + 40;
+// LDS carve-up (doubles): pts[3*TP] | accpt[4][TP] | slotW[12*S] | accpose[ps_stride*S] | red[40]
+// (ps_stride = 16: a slot carries binary OR ternary sums, both kinds share its 16 accumulators - 29 KB per workgroup, 5 per CU)
+__host__ __device__ inline size_t sweep_lds_doubles(int max_slots, bool build, int ps_stride) {
+  return 3 * VDO_TILE_PTS + (build ? 4 * VDO_TILE_PTS : 0) + 12 * (size_t)max_slots + (build ? (size_t)ps_stride * (size_t)max_slots : 0) + 40;
 }
 
 // workgroup sums of two doubles at once (one pass of barriers); results broadcast through lds[32], lds[33]
@@ -51,10 +52,10 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* lds) {
 // their 16 sums add up in registers; a change of slot inside the chunk (rare: at most nslot - 1 times per tile) is flushed to the
 // slot's LDS accumulators at once, and only the final (slot, sums) of every thread goes through the segmented DPP scan - one
 // scan per thread instead of one per edge.
-__device__ __forceinline__ void acc_edge(double (&acc)[16], int& cur, int slot, double we, D3 c, D3 er, double* accpose_base) {
+__device__ __forceinline__ void acc_edge(double (&acc)[16], int& cur, int slot, double we, D3 c, D3 er, double* accpose_base, int arow) {
   if (slot != cur) {
     if (cur >= 0) {
-      double* dst = accpose_base + 32 * cur;
+      double* dst = accpose_base + arow * cur;
 #pragma unroll
       for (int i = 0; i < 16; ++i) atomicAdd(dst + i, acc[i]);
     }
@@ -71,10 +72,10 @@ __device__ __forceinline__ void acc_edge(double (&acc)[16], int& cur, int slot, 
   acc[10] = __builtin_fma(we, er.x, acc[10]); acc[11] = __builtin_fma(we, er.y, acc[11]); acc[12] = __builtin_fma(we, er.z, acc[12]);
   acc[13] = __builtin_fma(we, c.y * er.z - c.z * er.y, acc[13]); acc[14] = __builtin_fma(we, c.z * er.x - c.x * er.z, acc[14]); acc[15] = __builtin_fma(we, c.x * er.y - c.y * er.x, acc[15]);
 }
-__device__ __forceinline__ void acc_finish(double (&acc)[16], int cur, double* accpose_base) {
+__device__ __forceinline__ void acc_finish(double (&acc)[16], int cur, double* accpose_base, int arow) {
   const SegCtl16 sc = seg_ctl16(cur);
   const SegFlags sf = seg_flags(sc);
-  double* dst = accpose_base + 32 * (cur >= 0 ? cur : 0);
+  double* dst = accpose_base + arow * (cur >= 0 ? cur : 0);
   { double g[4] = {acc[0], acc[1], acc[2], acc[3]}; seg_apply16<4>(g, sc, sf, dst); }
   { double g[4] = {acc[4], acc[5], acc[6], acc[7]}; seg_apply16<4>(g, sc, sf, dst + 4); }
   { double g[4] = {acc[8], acc[9], acc[10], acc[11]}; seg_apply16<4>(g, sc, sf, dst + 8); }
@@ -90,11 +91,12 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   double* accpt = pts + 3 * VDO_TILE_PTS;                 // [4][TP] SoA: sum of we | b.x | b.y | b.z  (lanes hit 16 bank pairs by point id)
   double* slotW = accpt + (BUILD ? 4 * VDO_TILE_PTS : 0);
   double* accpose = slotW + 12 * d.max_slots;
-  double* red = accpose + (BUILD ? 32 * d.max_slots : 0);
+  const int arow = d.ps_stride, tofs = d.ps_stride == 32 ? 16 : 0;      // row of a slot's accumulators; where its ternary sums start
+  double* red = accpose + (BUILD ? arow * d.max_slots : 0);
   const double* __restrict__ pose = d.pose[which];
   const double* __restrict__ point = d.point[which] + 3 * (int64_t)T.pt_begin;
   const int tid = threadIdx.x;
-  const int64_t Eb = d.Eb, Et = d.Et, NF = d.Eb + d.Et;
+  const int64_t Eb = d.Eb, Et = d.Et;
   // ---- this thread's EdgeSE3PointXYZ inputs (<= 3 consecutive edges) are requested first: their HBM latency runs under the staging
   const int nbe = T.eb_end - T.eb_begin;
   const int per_b = (nbe + VDO_TILE_THREADS - 1) / VDO_TILE_THREADS;          // consecutive edges per thread (<= 3)
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) pts[i] = point[i];
   if (BUILD) {
     for (int i = tid; i < 4 * VDO_TILE_PTS; i += VDO_TILE_THREADS) accpt[i] = 0.0;
-    for (int i = tid; i < 32 * nslot; i += VDO_TILE_THREADS) accpose[i] = 0.0;
+    for (int i = tid; i < arow * nslot; i += VDO_TILE_THREADS) accpose[i] = 0.0;
   }
   for (int sidx = tid; sidx < nslot; sidx += VDO_TILE_THREADS) {
     const IsoD W = iso_inv(iso_load(pose + 12 * (int64_t)d.tile_pose[T.slot_begin + sidx]));
@@ -149,19 +151,19 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
         chi += c2; rchi += rho0;
         if (BUILD) {
           const double we = w * rho1;
-          // 6x3 block Hpl = -we * [ I ; 2[zc]x ] * Jl  -> stored factored as (we, zc); 32 B instead of 144 B
-          double* F = d.Finc + e;
-          F[0] = we; F[NF] = zc.x; F[2 * NF] = zc.y; F[3 * NF] = zc.z;
+          // 6x3 block Hpl = -we * [ I ; 2[zc]x ] * Jl  -> only we is stored (8 B instead of 144 B): the consumers recompute zc from
+          // the point and the pose exactly as above (ba_solve.hip make_f)
+          d.Finc[e] = we;
           // landmark side: Hll += we * Jl^T Jl = we * R R^T = we * I (R is a rotation: g2o's product differs from I by a few
           // 1e-16, far inside the 1e-12 parity bar) -> ONE running sum per point; bl += -we * R e   (R e = Jl^T e)
           const D3 Re = rotT(Wp, er);
           atomicAdd(accpt + lp, we);
           atomicAdd(accpt + VDO_TILE_PTS + lp, -we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + lp, -we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + lp, -we * Re.z);
-          acc_edge(acc, cur, slot, we, zc, er, accpose);
+          acc_edge(acc, cur, slot, we, zc, er, accpose, arow);
         }
       }
     }
-    if (BUILD) acc_finish(acc, cur, accpose);
+    if (BUILD) acc_finish(acc, cur, accpose, arow);
   }
   // ------------------------------------------------------------ LandmarkMotionTernaryEdge
   {
@@ -192,19 +194,18 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
 #pragma unroll
           for (int i = 0; i < 9; ++i) O[i * Et] = -we * Hi[i];
           // (H,p1): we * [I ; [v]x]   and   (H,p2): -we * [I ; [v]x] * Hi.r   -> both from (we, v)
-          double* F = d.Finc + Eb + e;
-          F[0] = we; F[NF] = v.x; F[2 * NF] = v.y; F[3 * NF] = v.z;
+          d.Finc[Eb + e] = we;
           // p1: Hll += we*I, b += -we*e ; p2: Hll += we*R_H R_H^T = we*I, b += we * R_H e
           atomicAdd(accpt + l1, we);
           atomicAdd(accpt + VDO_TILE_PTS + l1, -we * er.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l1, -we * er.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l1, -we * er.z);
           const D3 Re = rotT(Hi, er);
           atomicAdd(accpt + l2, we);
           atomicAdd(accpt + VDO_TILE_PTS + l2, we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l2, we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l2, we * Re.z);
-          acc_edge(acc, cur, slot, we, v, er, accpose + 16);
+          acc_edge(acc, cur, slot, we, v, er, accpose + tofs, arow);
         }
       }
     }
-    if (BUILD && nte > 0) acc_finish(acc, cur, accpose + 16);      // (uniform: tiles of static points have no ternary edges - 256 scan instructions less)
+    if (BUILD && nte > 0) acc_finish(acc, cur, accpose + tofs, arow);      // (uniform: tiles of static points have no ternary edges - 256 scan instructions less)
   }
   // ---- write back
   block_sum2(chi, rchi, red);
@@ -219,24 +220,53 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
       const int l = i / 3, k = i - 3 * l;
       b[i] = accpt[(1 + k) * VDO_TILE_PTS + l];
     }
-    const int64_t NPS = d.NPS;
-    for (int i = tid; i < 32 * nslot; i += VDO_TILE_THREADS) {
-      const int sidx = i >> 5, k = i & 31;
-      d.part_sums[k * NPS + T.slot_begin + sidx] = accpose[32 * sidx + k];
+    // per-(tile,slot) partials -> their pose-major rows: 128 (256) contiguous bytes per slot
+    if (d.ps_stride == 16) {
+      for (int i = tid; i < 16 * nslot; i += VDO_TILE_THREADS) {
+        const int sidx = i >> 4, k = i & 15;
+        d.part_sums[16 * (int64_t)d.slot_dst[T.slot_begin + sidx] + k] = accpose[16 * sidx + k];
+      }
+    } else {
+      for (int i = tid; i < 32 * nslot; i += VDO_TILE_THREADS) {
+        const int sidx = i >> 5, k = i & 31;
+        d.part_sums[32 * (int64_t)d.slot_dst[T.slot_begin + sidx] + k] = accpose[32 * sidx + k];
+      }
     }
   }
 }
 
 // Expand the running sums of every (tile,slot) partial of a pose into its 6x6 block and rhs.
-__global__ __launch_bounds__(256) void k_finalize_pose(BADev d) {
+// + the contributions of the pose's EdgeSE3 / prior edges (k_posepose left them in ep_blk), in the order of the pose's edge list;
+// + (chi_mode >= 0) the chi2 reduction of the whole linearisation in one extra workgroup: every partial it reads was written by an
+// earlier launch.
+__device__ void reduce_chi_body(const BADev& d, int mode, double* lds);
+__global__ __launch_bounds__(256) void k_finalize_pose(BADev d, int add_posepose, int chi_mode) {
+  if (chi_mode >= 0 && blockIdx.x == gridDim.x - 1) {
+    __shared__ double lds[24];
+    reduce_chi_body(d, chi_mode, lds);
+    return;
+  }
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per pose
   if (p >= d.P) return;
-  double sall[32];
-  wave_gather<32>(d.part_sums, d.NPS, d.ps_off, d.ps_idx, p, sall);
-  if ((threadIdx.x & 63) != 0) return;
+  // the pose's partial rows are contiguous (pose-major part_sums): the wave streams them, lane l always meets component l % stride
+  const int lane = threadIdx.x & 63, st = d.ps_stride;
+  const double* __restrict__ base = d.part_sums + (int64_t)d.ps_off[p] * st;
+  const int64_t n = (int64_t)(d.ps_off[p + 1] - d.ps_off[p]) * st;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int64_t i = lane;
+  for (; i + 192 < n; i += 256) { a0 += base[i]; a1 += base[i + 64]; a2 += base[i + 128]; a3 += base[i + 192]; }
+  for (; i < n; i += 64) a0 += base[i];
+  double a = (a0 + a1) + (a2 + a3);
+  a += __shfl_xor(a, 32, 64);
+  if (st == 16) a += __shfl_xor(a, 16, 64);
+  const int kind = d.pose_kind[p];
   double sb[16], stn[16];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { sb[i] = sall[i]; stn[i] = sall[16 + i]; }
+  for (int k = 0; k < 16; ++k) {
+    const double lo = __shfl(a, k, 64), hi = __shfl(a, 16 + k, 64);
+    sb[k] = st == 32 ? lo : (kind == 0 ? lo : 0.0);
+    stn[k] = st == 32 ? hi : (kind == 1 ? lo : 0.0);
+  }
   double Hm[36], b[6];
 #pragma unroll
   for (int i = 0; i < 36; ++i) Hm[i] = 0;
@@ -262,19 +292,32 @@ __global__ __launch_bounds__(256) void k_finalize_pose(BADev d) {
   for (int i = 0; i < 6; ++i)
 #pragma unroll
     for (int j = 0; j < i; ++j) Hm[i * 6 + j] = Hm[j * 6 + i];
-  double* Ho = d.Hpp + 36 * (int64_t)p;
+  // every lane holds the whole block: lane i < 36 stores entry i, lanes 36..41 the right-hand side (coalesced)
+  double out = 0.0;
 #pragma unroll
-  for (int i = 0; i < 36; ++i) Ho[i] = Hm[i];
+  for (int i = 0; i < 36; ++i) out = lane == i ? Hm[i] : out;
 #pragma unroll
-  for (int i = 0; i < 6; ++i) d.bp[6 * (int64_t)p + i] = b[i];
+  for (int i = 0; i < 6; ++i) out = lane == 36 + i ? b[i] : out;
+  if (add_posepose && lane < 42) {
+    for (int q = d.pe_off[p]; q < d.pe_off[p + 1]; ++q) {
+      const int ent = d.pe_idx[q];
+      const double* blk = d.ep_blk + 84 * (int64_t)(ent >> 1);
+      out += lane < 36 ? blk[36 * (ent & 1) + lane] : blk[72 + 6 * (ent & 1) + (lane - 36)];
+    }
+    for (int q = d.pr_off[p]; q < d.pr_off[p + 1]; ++q) {
+      const double* blk = d.ep_blk + 84 * (int64_t)(d.Ep + d.pr_idx[q]);
+      out += lane < 36 ? blk[lane] : blk[72 + (lane - 36)];
+    }
+  }
+  if (lane < 36) d.Hpp[36 * (int64_t)p + lane] = out;
+  else if (lane < 42) d.bp[6 * (int64_t)p + (lane - 36)] = out;
 }
 
 // Fixed-order final reduction of the chi2 partials: tiles, then pose-pose edges.
 // mode 0: single GPU, everything -> scal.   Shards: mode 1 = this rank's tiles -> red_chi (summed
 // across ranks by the hook), mode 2/3 = red_chi + the replicated pose-pose edges -> scal
 // (3 also publishes the all-reduced computeScale() partial that k_update left in red_chi[2]).
-__global__ __launch_bounds__(256) void k_reduce_chi(BADev d, int mode) {
-  __shared__ double lds[24];
+__device__ void reduce_chi_body(const BADev& d, int mode, double* lds) {
   const int nt = d.n_tiles, n2 = d.Ep + d.Npr;
   const double* ep_chi = d.part_chi + 2 * (int64_t)nt;
   double a0 = 0, a1 = 0;
@@ -293,12 +336,16 @@ __global__ __launch_bounds__(256) void k_reduce_chi(BADev d, int mode) {
     }
   }
 }
+__global__ __launch_bounds__(256) void k_reduce_chi(BADev d, int mode) {
+  __shared__ double lds[24];
+  reduce_chi_body(d, mode, lds);
+}
 
 // ---------------------------------------------------------------------------- launchers
 static double* ep_chi_buf(const BADev& d) { return d.part_chi + 2 * (int64_t)d.n_tiles; }
 
 void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R) {
-  const size_t lds = sweep_lds_doubles(d.max_slots, false) * sizeof(double);
+  const size_t lds = sweep_lds_doubles(d.max_slots, false, d.ps_stride) * sizeof(double);
   if (d.n_tiles) hipLaunchKernelGGL(k_sweep_tile<false>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, which);
   launch_posepose(d, which, false, ep_chi_buf(d), s);
   if (!d.sharded) { hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 0); return; }
@@ -308,19 +355,21 @@ void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R) {
 }
 
 void launch_sweep_only(const BADev& d, hipStream_t s) {
-  const size_t lds = sweep_lds_doubles(d.max_slots, true) * sizeof(double);
+  const size_t lds = sweep_lds_doubles(d.max_slots, true, d.ps_stride) * sizeof(double);
   if (d.n_tiles) hipLaunchKernelGGL(k_sweep_tile<true>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, 0);
 }
 
 void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R) {
+  launch_posepose(d, 0, true, ep_chi_buf(d), s);           // per-edge blocks -> ep_blk (independent of the sweep)
   launch_sweep_only(d, s);
-  hipLaunchKernelGGL(k_finalize_pose, dim3((d.P + 3) / 4), dim3(256), 0, s, d);
-  launch_posepose(d, 0, true, ep_chi_buf(d), s);           // shards: accumulated by rank 0 only (see launch_posepose)
-  if (d.sharded) {           // landmark-side partial sums of every rank -> full Hpp / bp / chi2, one exchange
-    hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 1);
-    R(d.Hpp, 42 * (int64_t)d.P + 2);
-  }
-  hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, d.sharded ? 2 : 0);
+  // pose blocks = landmark-side sums + pose-pose blocks.  Shards: the (replicated) pose-pose terms are added by rank 0 only, the
+  // all-reduce of Hpp | bp | chi2 then hands every rank the same bits.
+  const int add_pp = (!d.sharded || d.shard_rank == 0) ? 1 : 0;
+  const int nb = (d.P + 3) / 4;
+  if (!d.sharded) { hipLaunchKernelGGL(k_finalize_pose, dim3(nb + 1), dim3(256), 0, s, d, add_pp, 0); return; }   // (+ the chi2 reduction in the last workgroup)
+  hipLaunchKernelGGL(k_finalize_pose, dim3(nb + 1), dim3(256), 0, s, d, add_pp, 1);
+  R(d.Hpp, 42 * (int64_t)d.P + 2);
+  hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 2);
 }
 
 }  // namespace vdo

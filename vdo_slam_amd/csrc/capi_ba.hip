@@ -233,12 +233,30 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     std::vector<int32_t> fill(ps_off.begin(), ps_off.end() - 1);
     for (int k = 0; k < NPS; ++k) ps_idx[fill[tile_pose[k]]++] = k;
   }
+  // pose-major rows of the sweep partials (ba_dev.hpp): slot s -> row slot_dst[s]; 16 sums per row unless a pose carries both edge kinds
+  std::vector<int32_t> slot_dst(std::max(NPS, 1)), pose_kind(std::max(P, 1), 0);
+  for (int k = 0; k < NPS; ++k) slot_dst[ps_idx[k]] = k;
+  int ps_stride = 16;
+  {
+    std::vector<char> has_b(P, 0), has_t(P, 0);
+    for (int e = 0; e < Eb; ++e) has_b[g->eb_pose[e]] = 1;
+    for (int e = 0; e < Et; ++e) has_t[g->et_pose[e]] = 1;
+    for (int p = 0; p < P; ++p) { pose_kind[p] = has_t[p] ? 1 : 0; if (has_b[p] && has_t[p]) ps_stride = 32; }
+    if (std::getenv("VDO_BA_WIDE_PARTIALS")) ps_stride = 32;
+  }
   std::vector<int32_t> pe_off(P + 1, 0), pe_idx(2 * (size_t)Ep);
   for (int e = 0; e < Ep; ++e) { pe_off[g->ep_i[e] + 1]++; pe_off[g->ep_j[e] + 1]++; }
   for (int p = 0; p < P; ++p) pe_off[p + 1] += pe_off[p];
   {
     std::vector<int32_t> fill(pe_off.begin(), pe_off.end() - 1);
     for (int e = 0; e < Ep; ++e) { pe_idx[fill[g->ep_i[e]]++] = (e << 1); pe_idx[fill[g->ep_j[e]]++] = (e << 1) | 1; }
+  }
+  std::vector<int32_t> pr_off(P + 1, 0), pr_idx(std::max(Npr, 1));
+  for (int q = 0; q < Npr; ++q) pr_off[g->pr_pose[q] + 1]++;
+  for (int p = 0; p < P; ++p) pr_off[p + 1] += pr_off[p];
+  {
+    std::vector<int32_t> fill(pr_off.begin(), pr_off.end() - 1);
+    for (int q = 0; q < Npr; ++q) pr_idx[fill[g->pr_pose[q]]++] = q;
   }
   // ---- pose chains for the block-tridiagonal preconditioner: connected components of the pose-pose
   // (EdgeSE3) graph that are simple paths - the odometry chain of the cameras, the smoothness chain of
@@ -341,7 +359,10 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(ep_i, g->ep_i, Ep); UP(ep_j, g->ep_j, Ep); UP(ep_z, g->ep_z, 12 * (size_t)Ep); UP(ep_info, g->ep_info, 36 * (size_t)Ep);
   UP(pr_pose, g->pr_pose, Npr); UP(pr_z, g->pr_z, 12 * (size_t)Npr); UP(pr_info, g->pr_info, 36 * (size_t)Npr);
   UP(ps_off, ps_off.data(), P + 1); UP(ps_idx, ps_idx.data(), NPS);
+  UP(slot_dst, slot_dst.data(), std::max(NPS, 1)); UP(pose_kind, pose_kind.data(), std::max(P, 1));
+  d.ps_stride = ps_stride;
   UP(pe_off, pe_off.data(), P + 1); UP(pe_idx, pe_idx.data(), pe_idx.size());
+  UP(pr_off, pr_off.data(), P + 1); UP(pr_idx, pr_idx.data(), pr_idx.size());
   d.n_pchains = n_pchains;
   {   // LDS strips of the chain preconditioner (ba_solve.hip pchain_apply_lds): [len][6] doubles per resident chain, <= 144 KB in all
     int maxlen = 1;
@@ -356,8 +377,8 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   ba->d.bp = ba->d.Hpp + 36 * (size_t)P; ba->d.red_chi = ba->d.bp + 6 * (size_t)P;
   UP(msum, Z, 21 * (size_t)P + 1);
   UP(Hll, Z, (size_t)L); UP(bl, Z, 3 * (size_t)L);
-  UP(Finc, Z, 4 * ((size_t)Eb + (size_t)Et)); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep);
-  UP(part_sums, Z, 32 * (size_t)NPS);
+  UP(Finc, Z, (size_t)Eb + (size_t)Et + 1); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep); UP(ep_blk, Z, 84 * (size_t)std::max(Ep + Npr, 1));
+  UP(part_sums, Z, (size_t)ps_stride * (size_t)std::max(NPS, 1));
   UP(part_chi, Z, 2 * (size_t)n_tiles + 2 * (size_t)(Ep + Npr) + 2);
   UP(part_red, Z, 256);
   UP(Dinv, Z, 9 * (size_t)L); UP(Gl, Z, 9 * (size_t)L); UP(Gdiag, Z, 9 * (size_t)L); UP(Goff, Z, 9 * (size_t)L);
@@ -418,6 +439,31 @@ extern "C" int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep) {
   }
   for (int i = 0; i < (ms_sweep ? 1 : repeat); ++i) launch_linearize(ba->d, s, ba->red);
   return sync_check(ba, "vdo_ba_linearize");
+}
+
+extern "C" int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int64_t dims[6]) {
+  if (!ba || !ms) return set_error(VDO_ERR_INVALID, "vdo_ba_profile_linearize: null argument");
+  int rc = ctx_bind(ba->ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = ba->ctx->stream;
+  if (repeat < 1) repeat = 1;
+  const BADev& d = ba->d;
+  for (int which = 0; which < 2; ++which) {
+    if (which == 0) launch_sweep_only(d, s); else launch_linearize(d, s, ba->red);          // warm-up
+    hipEventRecord(ba->ev0, s);
+    for (int i = 0; i < repeat; ++i) { if (which == 0) launch_sweep_only(d, s); else launch_linearize(d, s, ba->red); }
+    hipEventRecord(ba->ev1, s);
+    hipEventSynchronize(ba->ev1);
+    float t = 0;
+    hipEventElapsedTime(&t, ba->ev0, ba->ev1);
+    ms[which] = t / repeat;
+  }
+  if (dims) {
+    dims[0] = d.n_tiles; dims[1] = d.NPS; dims[2] = d.ps_stride; dims[3] = d.max_slots;
+    dims[4] = 4 + (d.eb_zf ? 12 : 24) + (d.eb_w ? 8 : 0);
+    dims[5] = 8 + (d.et_z ? 24 : 0) + (d.et_w ? 8 : 0);
+  }
+  return sync_check(ba, "vdo_ba_profile_linearize");
 }
 
 extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
