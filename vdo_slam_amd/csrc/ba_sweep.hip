@@ -19,6 +19,7 @@
 //      threads' totals go through a segmented DPP scan into per-slot LDS accumulators and are written as per-(tile,slot) partials;
 //      k_finalize_pose expands them to the 6x6 block + rhs in fixed order.
 // No global atomics.
+#include <cstdlib>
 #include "ba_dev.hpp"
 #include "ba_tile.hpp"
 #include "se3_dev.hpp"
