@@ -9,16 +9,21 @@
 // One workgroup per TILE (see ba_dev.hpp).  Per tile:
 //   1. the tile's points (<=256 x 24 B, contiguous) and the inverse poses of its pose slots are
 //      staged in LDS;
-//   2. edges stream in fully coalesced (key 4 B + z 24 B + w 8 B per edge); the 6x3
-//      pose-landmark block is written once, coalesced SoA (144 B);
+//   2. edges stream in fully coalesced - 16 B per EdgeSE3PointXYZ in the compact form (key 4 B + fp32 measurement 12 B, one
+//      information scalar per edge class), 36 B in the general one; of the 6x3 pose-landmark block only the Huber-weighted
+//      information scalar we is written (8 B): the block is we * [I ; k[c]x] * (R^T | I) with c a function of the point and
+//      the pose, which every consumer has in LDS anyway (ba_solve.hip make_f);
 //   3. landmark sums accumulate in LDS with ds_add_f64 (all edges of a point are in the tile): the 3x3 block is
 //      (sum of we) * I - J_point^T J_point = R R^T = I for both edge classes - so 1 + 3 sums per point, written once (32 B);
 //   4. the pose 6x6+6 contribution of an edge depends on 16 running sums only
 //      (J_pose = [-I | 2[zc]x]  resp. [I | -[v]x]): Σw, Σw·zc, Σw·zc zcᵀ, Σw·e, Σw·zc×e.
 //      Every thread sums them in registers over its few consecutive edges (edges are pose-sorted inside the tile), the
-//      threads' totals go through a segmented DPP scan into per-slot LDS accumulators and are written as per-(tile,slot) partials;
-//      k_finalize_pose expands them to the 6x6 block + rhs in fixed order.
-// No global atomics.
+//      threads' totals go through a segmented DPP scan into per-slot LDS accumulators and leave as one 128-byte row per
+//      (tile, slot) of the POSE-MAJOR partial array; k_finalize_pose streams a pose's rows, expands them to the 6x6 block + rhs
+//      and adds the blocks of the pose's EdgeSE3 / prior edges (k_posepose), all in fixed order.
+// No global atomics.  HBM bytes of a linearisation with this layout: vdo_slam_amd/ba.py linearize_byte_model;
+// what bounds the kernel (measured): VALU issue (~2/3 of the SIMD cycles at 4 workgroups per CU) plus the
+// start-up latency of a tile, t = 30 us + 128 us / (workgroups per CU) on the roofline graph.
 #include <cstdlib>
 #include "ba_dev.hpp"
 #include "ba_tile.hpp"
@@ -29,7 +34,8 @@ namespace vdo {
 void launch_posepose(const BADev& d, int which, bool build, double* ep_chi, hipStream_t s);
 
 // LDS carve-up (doubles): pts[3*TP] | accpt[4][TP] | slotW[12*S] | accpose[ps_stride*S] | red[40]
-// (ps_stride = 16: a slot carries binary OR ternary sums, both kinds share its 16 accumulators - 29 KB per workgroup, 5 per CU)
+// (ps_stride = 16: a slot carries binary OR ternary sums, both kinds share its 16 accumulators; 14 KB + 224 B per pose slot of the
+// largest tile: 4 workgroups per CU at 81 slots)
 __host__ __device__ inline size_t sweep_lds_doubles(int max_slots, bool build, int ps_stride) {
   return 3 * VDO_TILE_PTS + (build ? 4 * VDO_TILE_PTS : 0) + 12 * (size_t)max_slots + (build ? (size_t)ps_stride * (size_t)max_slots : 0) + 40;
 }
@@ -64,7 +70,7 @@ __device__ __forceinline__ void acc_edge(double (&acc)[16], int& cur, int slot, 
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.0;
   }
-  // (the running sums take their terms by fused multiply-add: the kernel is bound by VALU issue, and the order of these sums - hence
+  // (the running sums take their terms by fused multiply-add: VALU issue is what the kernel has least of, and the order of these sums - hence
   // their last bits - already differs from the oracle's sequential order; the residual and the cross products stay unfused)
   const double wx = we * c.x, wy = we * c.y, wz = we * c.z;
   acc[0] += we; acc[1] += wx; acc[2] += wy; acc[3] += wz;

@@ -5,6 +5,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
+#include <stdexcept>
+#include <string>
 
 namespace VDO_SLAM {
 
@@ -13,12 +15,16 @@ bool Frame::mbInitialComputations = true;
 float Frame::cx, Frame::cy, Frame::fx, Frame::fy, Frame::invfx, Frame::invfy;
 
 namespace {
+// The reference has no error channel; it ends the process only for unreadable settings / a wrong sensor (src/System.cc:35-39, 55-59).
+// A failure of the GPU path is not one of those: it surfaces as an exception that the flat hooks (host_capi.cc, System.cc) turn into
+// a return code, so that a host that loaded this library through an FFI survives it.
+[[noreturn]] void fail(const char* what) { throw std::runtime_error(std::string("VDO_SLAM::Frame: ") + what + ": " + vdo_last_error()); }
 vdo_frame_images* g_imgs = nullptr;
 int g_w = 0, g_h = 0;
 vdo_frame_images* images_for(int w, int h) {
   if (!g_imgs || g_w != w || g_h != h) {
     if (g_imgs) vdo_frame_images_destroy(g_imgs);
-    if (vdo_frame_images_create(HostContext(), w, h, &g_imgs) != VDO_OK) { std::fprintf(stderr, "VDO_SLAM::Frame: %s\n", vdo_last_error()); std::exit(-1); }
+    if (vdo_frame_images_create(HostContext(), w, h, &g_imgs) != VDO_OK) { g_imgs = nullptr; fail("frame images"); }
     g_w = w; g_h = h;
   }
   return g_imgs;
@@ -38,22 +44,17 @@ Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlo
   N = (int)mvKeys.size();
   if (mvKeys.empty()) return;
   if (UseSampleFea != 0) {
-    std::cerr << "VDO_SLAM::Frame: UseSampleFeature=1 (random sampling, cv::RNG(time)) is not on the GPU path" << std::endl;
-    std::exit(-1);
+    throw std::runtime_error("VDO_SLAM::Frame: UseSampleFeature=1 runs through FramePipeline (PipelineParams.use_sample_feature), not through this constructor");
   }
   vdo_frame_images* imgs = images_for(imGray.cols, imGray.rows);
-  if (vdo_frame_images_upload(imgs, (const float*)imDepth.data, (const float*)imFlow.data, (const int32_t*)maskSEM.data) != VDO_OK) {
-    std::fprintf(stderr, "VDO_SLAM::Frame: %s\n", vdo_last_error()); std::exit(-1);
-  }
+  if (vdo_frame_images_upload(imgs, (const float*)imDepth.data, (const float*)imFlow.data, (const int32_t*)maskSEM.data) != VDO_OK) fail("GPU call");
   // ---- background features: Frame.cc:100-128 + :178-194
   std::vector<float> kx(N), ky(N);
   for (int i = 0; i < N; ++i) { kx[i] = mvKeys[i].pt.x; ky[i] = mvKeys[i].pt.y; }
   std::vector<int32_t> keep(N);
   std::vector<float> cxv(N), cyv(N), fxv(N), fyv(N), dv(N);
   int m = 0;
-  if (vdo_frame_static_filter(imgs, N, kx.data(), ky.data(), mThDepth, keep.data(), cxv.data(), cyv.data(), fxv.data(), fyv.data(), dv.data(), &m) != VDO_OK) {
-    std::fprintf(stderr, "VDO_SLAM::Frame: %s\n", vdo_last_error()); std::exit(-1);
-  }
+  if (vdo_frame_static_filter(imgs, N, kx.data(), ky.data(), mThDepth, keep.data(), cxv.data(), cyv.data(), fxv.data(), fyv.data(), dv.data(), &m) != VDO_OK) fail("GPU call");
   for (int i = 0; i < m; ++i) {
     const cv::KeyPoint& k = mvKeys[keep[i]];
     mvStatKeysTmp.push_back(k);
@@ -68,9 +69,7 @@ Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlo
   for (auto& v : o) v.resize(cap);
   std::vector<int32_t> lab(cap);
   int n_obj = 0;
-  if (vdo_frame_object_sample(imgs, mThDepthObj, 4, cap, o[0].data(), o[1].data(), o[2].data(), o[3].data(), o[4].data(), o[5].data(), o[6].data(), lab.data(), &n_obj) != VDO_OK) {
-    std::fprintf(stderr, "VDO_SLAM::Frame: %s\n", vdo_last_error()); std::exit(-1);
-  }
+  if (vdo_frame_object_sample(imgs, mThDepthObj, 4, cap, o[0].data(), o[1].data(), o[2].data(), o[3].data(), o[4].data(), o[5].data(), o[6].data(), lab.data(), &n_obj) != VDO_OK) fail("GPU call");
   for (int i = 0; i < n_obj; ++i) {
     mvObjFlowNext.push_back(cv::Point2f(o[4][i], o[5][i]));
     mvObjCorres.push_back(cv::KeyPoint(o[2][i], o[3][i], 0, 0, 0, -1));

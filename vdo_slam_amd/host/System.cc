@@ -1,5 +1,7 @@
 #include "System.h"
 
+#include <stdexcept>
+
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -67,9 +69,9 @@ Tracking::Tracking(System*, Map* pMap, const std::string& strSettingPath, const 
   if (p.width <= 0 || p.height <= 0) { std::cerr << "settings: Camera.width / Camera.height missing" << std::endl; std::exit(-1); }
   const char* dev = std::getenv("VDO_DEVICE");
   for (int k = 0; k < 5; ++k)
-    if (vdo_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx_[k]) != VDO_OK) { std::cerr << "no HIP device: " << vdo_last_error() << std::endl; std::exit(-1); }
+    if (vdo_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx_[k]) != VDO_OK) throw std::runtime_error(std::string("VDO_SLAM::Tracking: no HIP device: ") + vdo_last_error());   // (GPU failures throw; only settings / sensor errors exit, as in the reference)
   pipe_.reset(new FramePipeline(ctx_[0], ctx_[1], p, ctx_[2], ctx_[3], ctx_[4]));
-  if (!pipe_->ok()) { std::cerr << "FramePipeline: " << vdo_last_error() << std::endl; std::exit(-1); }
+  if (!pipe_->ok()) throw std::runtime_error(std::string("VDO_SLAM::Tracking: FramePipeline: ") + vdo_last_error());
   pipe_->AttachMap(mpMap);
 }
 

@@ -96,6 +96,7 @@ int host_frame(const unsigned char* gray, float* depth_raw_inout, const float* f
                float bf, float depth_factor, float th_bg, float th_obj,
                float* kx, float* ky, int* koct, int cap,
                int* n_stat, float* stat_corr /*[cap][2]*/, float* stat_depth, int* n_obj, float* obj_key /*[capo][2]*/, int* obj_label, int capo) {
+  try {
   static ORBextractor* orb = nullptr;
   if (!orb) orb = new ORBextractor(2500, 1.2f, 8, 20, 7);
   if (vdo_depth_preprocess(HostContext(), depth_raw_inout, (int64_t)w * h, bf, depth_factor, 0) != VDO_OK) return -1;   // Tracking.cc:180-204
@@ -109,6 +110,7 @@ int host_frame(const unsigned char* gray, float* depth_raw_inout, const float* f
   *n_obj = (int)fr.mvObjKeys.size();
   for (int i = 0; i < *n_obj && i < capo; ++i) { obj_key[2 * i] = fr.mvObjKeys[i].pt.x; obj_key[2 * i + 1] = fr.mvObjKeys[i].pt.y; obj_label[i] = fr.vSemObjLabel[i]; }
   return fr.N;
+  } catch (const std::exception& e) { std::fprintf(stderr, "host_frame: %s\n", e.what()); return -1; }
 }
 
 // Optimizer::PoseOptimizationFlow2Cam through the host classes.  Tcw_last / Tcw_init: 4x4 float row-major.
@@ -125,7 +127,8 @@ int host_pose_optimization_flow2cam(int n, const float* last_xy, const float* fl
     cur.mvStatKeys.push_back(cv::KeyPoint(last_xy[2 * i] + flow[2 * i], last_xy[2 * i + 1] + flow[2 * i + 1], 0));
     match[i] = i;
   }
-  const int inl = Optimizer::PoseOptimizationFlow2Cam(&cur, &last, match);
+  int inl;
+  try { inl = Optimizer::PoseOptimizationFlow2Cam(&cur, &last, match); } catch (const std::exception& e) { std::fprintf(stderr, "%s\n", e.what()); return -1; }
   std::memcpy(Tcw_out, cur.mTcw.data, 64);
   for (int i = 0; i < n; ++i) { match_out[i] = match[i]; cur_xy_out[2 * i] = cur.mvStatKeys[i].pt.x; cur_xy_out[2 * i + 1] = cur.mvStatKeys[i].pt.y; }
   return inl;

@@ -2,6 +2,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <stdexcept>
+#include <string>
 
 namespace VDO_SLAM {
 vdo_ctx* HostContext() {
@@ -9,8 +11,8 @@ vdo_ctx* HostContext() {
   if (!ctx) {
     const char* dev = std::getenv("VDO_DEVICE");
     if (vdo_ctx_create(dev ? std::atoi(dev) : 0, nullptr, &ctx) != VDO_OK) {
-      std::fprintf(stderr, "VDO_SLAM: cannot create the HIP context: %s\n", vdo_last_error());
-      std::exit(-1);
+      ctx = nullptr;
+      throw std::runtime_error(std::string("VDO_SLAM: cannot create the HIP context: ") + vdo_last_error());   // (not exit: see Frame.cc)
     }
   }
   return ctx;
