@@ -56,7 +56,7 @@ def sequence_events(warmup, steps):
 def _pmc_traffic_bytes(graph):
     """HBM bytes per k_sweep_tile launch from the committed PMC summary, if it was taken on this very graph (else None)."""
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_sweep_pmc_hbm_traffic.txt")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_sweep_pmc_hbm_traffic.txt")
     try:
         txt = open(path).read()
         m = re.search(r"n_eb (\d+) n_et (\d+) n_point (\d+)", txt)
@@ -110,6 +110,39 @@ def cpu_baseline_frames(frames, budget_s=14.0):
     return n / dt, n, {k2: v / n * 1e3 for k2, v in pipe.stage_s.items()}, pipe.Tl.astype(np.float64)
 
 
+def cpu_worker(path, budget_s):
+    """One of the N concurrent CPU-baseline processes: the oracle-composed Track() over the stored frames, for ~budget_s seconds."""
+    from tests import oracle_lib
+    from tests.pipeline_ref import OraclePipeline
+    z = np.load(path)
+    n_fr = int(z["n"])
+    frames = [{q: z[f"{q}_{k}"] for q in ("gray", "depth_raw", "flow", "mask")} for k in range(n_fr)]
+    pipe = OraclePipeline(oracle_lib.load(), build_lm=True)
+    n = 0
+    t0 = time.perf_counter()
+    while n < n_fr:
+        pipe.step(frames[n]); n += 1
+        if time.perf_counter() - t0 > budget_s:
+            break
+    print(json.dumps({"frames": n, "seconds": time.perf_counter() - t0}))
+
+
+def cpu_baseline_frames_multi(frames, nproc, budget_s=8.0, max_frames=40):
+    """the N-process throughput of the CPU path - nproc independent sequences (the reference is single-threaded; one
+    process per core is how a host would be filled), same frames, run concurrently; aggregate frames/s."""
+    import subprocess
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        path = os.path.join(td, "frames.npz")
+        fr = frames[:max_frames]
+        np.savez(path, n=len(fr), **{f"{q}_{k}": f[q] for k, f in enumerate(fr) for q in ("gray", "depth_raw", "flow", "mask")})
+        env = dict(os.environ, OMP_NUM_THREADS="1")
+        procs = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-worker", path, "--cpu-worker-budget", str(budget_s)], stdout=subprocess.PIPE, env=env)
+                 for _ in range(nproc)]
+        outs = [json.loads(pr.communicate()[0].decode().strip().splitlines()[-1]) for pr in procs]
+    return sum(o["frames"] / o["seconds"] for o in outs), [o["frames"] for o in outs]
+
+
 def cpu_baseline_batch(graph, its=2):
     from tests import oracle_lib
     from vdo_slam_amd import _capi as K
@@ -157,7 +190,12 @@ def main():
     ap.add_argument("--replicas-per-gpu", type=int, default=1, help="R independent sequences (FramePipelines) on every GPU; value = all of them")
     ap.add_argument("--replica-sweep", type=str, default="", help="e.g. 1,2,4,8: also report frames/s for these numbers of sequences per GPU")
     ap.add_argument("--roofline-static", type=int, default=600000, help="static landmarks of the roofline graph")
+    ap.add_argument("--cpu-worker", type=str, default="", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-worker-budget", type=float, default=8.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.cpu_worker:
+        cpu_worker(args.cpu_worker, args.cpu_worker_budget)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(spawn_ranks(args.gpus))
     # stdout carries exactly ONE line (the JSON result): libraries that print banners to fd 1 (RCCL's version block on
@@ -209,6 +247,9 @@ def main():
     from vdo_slam_amd.pipeline import FramePipeline, kitti_params
     import threading
     defer = 0 if os.environ.get("VDO_BENCH_SYNC_OBJECTS") else 1
+
+    def defer_now():
+        return defer
     cpus = _cpu_budget() / max(1, world)
     AGG = ("cam_lm_iterations", "n_static_tracked", "n_object_tracked", "n_objects", "n_ransac_cam", "n_cam_inliers", "n_ransac_obj", "n_recovered_masks", "n_motion_model_obj", "n_mm_inliers_obj")
 
@@ -226,7 +267,7 @@ def main():
             # + ORB of the frame on a third host thread (its own context / stream) when there are CPUs for it
             self.ctx_orb = Context(local) if (self.ctx_w is not None and not os.environ.get("VDO_BENCH_NO_ORB_THREAD") and cpus_here >= 6) else None
             self.pipe = FramePipeline(self.ctx, self.ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ,
-                                                                         build_lm=1, defer_objects=defer), self.ctx_obj, self.ctx_w, self.ctx_orb)
+                                                                         build_lm=1, defer_objects=defer_now()), self.ctx_obj, self.ctx_w, self.ctx_orb)
             if not os.environ.get("VDO_BENCH_NO_MAP"):
                 self.pipe.keep_graph()                            # "Save Graph Structure" (Tracking.cc:1031-1159): every frame is appended to the flat GraphStore the batch optimisers read
             self.agg = {q: 0 for q in AGG}
@@ -343,6 +384,19 @@ def main():
     for r in reps:
         r.close()
     del reps, pipe, rep0
+    # ---- the same device-resident sequence with the REFERENCE'S RETURN SEMANTICS: everything of a frame (object LMs, RenewFrameInfo of the
+    # objects, tracklets) is done when Step returns - no work deferred into the next call.  (`value` defers the object stage of frame k
+    # into Step k+1: same results, one frame of latency for the object motions.)
+    if not os.environ.get("VDO_BENCH_SYNC_OBJECTS") and R == 1:
+        defer_saved = defer
+        defer = 0
+        dts_sync, rs_sync = run_sequences(1)
+        defer = defer_saved
+        out["value_sync"] = world * args.steps / dts_sync
+        out["config"]["value_sync"] = ("device-resident inputs, every Step complete on return (the reference's TrackRGBD semantics); camera pose identical to the "
+                                       "deferred run: " + str(bool(np.array_equal(rs_sync[0].pipe.pose().astype(np.float64), Tcw))))
+        for r in rs_sync:
+            r.close()
     # ---- R-sweep: aggregate frames/s for several numbers of independent sequences per GPU (the per-frame path keeps <= ~10 of the
     # 256 CUs busy: one sequence per GPU leaves the chip idle, SURVEY 8e "replicas only")
     if args.replica_sweep:
@@ -429,29 +483,57 @@ def main():
                                                    f"({'ncclAllReduce issued by the C-ABI on its stream' if sh.transport == 'rccl' else 'torch.distributed through the host callback'}), "
                                                    f"{sh.hook.calls - calls0} all-reduces / {8 * (sh.hook.doubles - dbl0)} bytes in {st.iterations} LM iterations "
                                                    f"({st.total_trials} trials), final chi2 {st.final_chi2:.6g}")
+                out["sharded"] = {"ranks": world, "transport": sh.transport, "lm_iterations": int(st.iterations), "trials": int(st.total_trials),
+                                  "allreduces_per_lm_iter": (sh.hook.calls - calls0) / max(1, st.iterations),
+                                  "allreduce_bytes_per_lm_iter": 8 * (sh.hook.doubles - dbl0) / max(1, st.iterations),
+                                  "points_on_rank0": int(sh.mine.size), "points": int(gs.n_point)}
                 sh.close()
             except Exception as e:                       # the replica numbers above stay valid
                 out["batch_sharded_error"] = repr(e)[:300]
-        # ---- roofline of the dominant kernel (K18 sweep) on an HBM-sized graph
+        # ---- BASELINE configs[2] (KITTI 0018-0020-shaped: ~10 k landmarks, 5 objects) and a configs[4]-shaped graph (1 M landmarks,
+        # 5 k pose vertices, 20 objects) on ONE GPU: ms per LM outer iteration (PCG)
+        for key, shape, its in (("ms_per_lm_iter_config3", (60, 10000, 5, 400), 5), ("ms_per_lm_iter_large", (239, 950000, 20, 500), 3)):
+            if key == "ms_per_lm_iter_large" and (world > 1 or os.environ.get("VDO_BENCH_NO_LARGE")):
+                continue
+            gx = synth.make_ba_graph(*shape, seed=5 + rank)
+            bx = BatchBA(ctx_ba, gx)
+            bx.optimize(max_iterations=1, gain_threshold=-1.0)
+            bx.set_estimates(gx.pose, gx.point)
+            barrier()
+            t0 = time.perf_counter()
+            stx = bx.optimize(max_iterations=its, gain_threshold=-1.0)
+            barrier()
+            out[key] = (time.perf_counter() - t0) * 1e3 / max(1, stx.iterations)
+            out["config"][key] = (f"{gx.n_cam} frames, {gx.n_pose} pose/motion vertices, {gx.n_point} points, {gx.n_eb} EdgeSE3PointXYZ, {gx.n_et} ternary, {gx.n_ep} EdgeSE3: "
+                                  f"{stx.iterations} iterations / {stx.total_trials} trials, chi2 {stx.initial_chi2:.6g} -> {stx.final_chi2:.6g}")
+            bx.close()
+            del bx, gx
+        # ---- roofline of the dominant kernel (K18 sweep) and of the whole linearisation on an HBM-sized graph
         gr = synth.make_ba_graph(200, args.roofline_static, 10, 1500, seed=7 + rank)
         bar = BatchBA(ctx_ba, gr)
         bar.linearize()
-        sweep_ms = bar.linearize(repeat=30, timed=True)
-        bytes_launch = 208 * gr.n_eb + 452 * gr.n_et + 96 * gr.n_point     # SURVEY.md §8d B_sweep terms of this kernel
-        achieved = bytes_launch / (sweep_ms * 1e-3) / 1e9
-        traffic = _pmc_traffic_bytes(gr)
-        out["roofline"] = {"bound": "hbm", "kernel": "k_sweep_tile<true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                           # counter-based: the bytes the kernel really moves through HBM (PMC) over the same live-measured duration
-                           "achieved_hbm": None if traffic is None else traffic / (sweep_ms * 1e-3) / 1e9,
-                           "frac_hbm": None if traffic is None else traffic / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                           "traffic_note": "`achieved` / `frac` use the ALGORITHMIC bytes of SURVEY 8d (208 B per EdgeSE3PointXYZ, 452 B per ternary edge, 96 B per point); "
-                                           "`traffic` = HBM bytes per launch = 2*FETCH_SIZE + WRITE_SIZE from separate rocprofv3 --pmc passes over this same kernel and graph "
-                                           "(profiles/r02_sweep_pmc_hbm_traffic.txt; not re-collected inside bench.py) - a third of the algorithmic figure because the 6x3 "
-                                           "blocks are stored factored (32 B instead of 144 B), a point is read once per tile, the landmark block is one scalar, and "
-                                           "the edge inputs are 16 B (fp32 measurements, one information scalar per class); `achieved_hbm` / `frac_hbm` = that real traffic over the same time",
-                           "bytes_per_launch": int(bytes_launch), "avg_launch_ms": sweep_ms,
-                           "units_per_launch": {"EdgeSE3PointXYZ": int(gr.n_eb), "LandmarkMotionTernaryEdge": int(gr.n_et), "points": int(gr.n_point)}}
+        sweep_ms, lin_ms, dims = bar.profile_linearize(30)       # hipEvents on the stream the kernels run on (vdo_ba_profile_linearize)
+        from vdo_slam_amd.ba import linearize_byte_model
+        model = linearize_byte_model(gr, dims)
+        alg_bytes = 208 * gr.n_eb + 452 * gr.n_et + 96 * gr.n_point     # SURVEY.md §8d B_sweep terms of this kernel
+        traffic = _pmc_traffic_bytes(gr)                                 # rocprofv3 --pmc passes over this kernel and graph, if committed for this layout
+        used = traffic if traffic is not None else float(model["sweep"])
+        achieved = used / (sweep_ms * 1e-3) / 1e9
+        out["roofline"] = {
+            "bound": "hbm", "kernel": "k_sweep_tile<true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "frac_basis": "counters (2*FETCH_SIZE + WRITE_SIZE)" if traffic is not None else "model_bytes (no counter file for this layout)",
+            "model_bytes": model, "avg_launch_ms": sweep_ms, "linearize_ms": lin_ms,
+            "achieved_model": model["sweep"] / (sweep_ms * 1e-3) / 1e9, "frac_model": model["sweep"] / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "linearize_achieved_model": model["linearize"] / (lin_ms * 1e-3) / 1e9, "linearize_frac_model": model["linearize"] / (lin_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "survey_8d_bytes": int(alg_bytes), "survey_8d_rate": alg_bytes / (sweep_ms * 1e-3) / 1e9,
+            "note": "`frac` = HBM bytes the sweep kernel really moves per launch (PMC counters when profiles/ holds a pass over this very graph and layout, else the "
+                    "design's byte model = the floor for this layout: vdo_slam_amd/ba.py linearize_byte_model) / its mean duration (hipEvents, this run) / 8 TB/s - it "
+                    "cannot exceed 1.  `survey_8d_rate` divides the bytes of SURVEY 8d's formula (208 B per EdgeSE3PointXYZ, 452 B per ternary edge, 96 B per point) "
+                    "by the same time: the kernel moves a fifth of them (8 B of a 6x3 block instead of 144 B, 16 B of edge inputs instead of 64 B, one scalar for the "
+                    "landmark block), so that rate is NOT a bandwidth.  `linearize_*`: sweep + expansion of the pose blocks + pose-pose edges + chi2 (one "
+                    "BlockSolver::buildSystem).  What bounds the sweep is VALU issue and per-tile latency, not HBM (DESIGN.md 4.1).",
+            "layout": dims,
+            "units_per_launch": {"EdgeSE3PointXYZ": int(gr.n_eb), "LandmarkMotionTernaryEdge": int(gr.n_et), "points": int(gr.n_point), "poses": int(gr.n_pose)}}
         bar.close()
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cb_ms, cb_sweep, cb_its = cpu_baseline_batch(g)
@@ -461,6 +543,14 @@ def main():
         out["cpu_baseline"] = {"value": cfps, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": f"the first {cn} frames of the same sequence through the same full Track() (oracle, 1 thread)",
                                "ms_per_stage": cstage}
+        # the N-process throughput next to the 1-thread figure (N = min(8, CPUs of this job); the reference itself is single-threaded)
+        try:
+            nproc = int(max(1, min(8, _cpu_budget())))
+            mfps, mframes = cpu_baseline_frames_multi(frames, nproc)
+            out["cpu_baseline"]["multi_process"] = {"value": mfps, "unit": "frames/s", "processes": nproc, "cores_of_the_job": int(_cpu_budget()),
+                                                    "sample": f"{nproc} concurrent processes, {mframes} frames each, ~8 s"}
+        except Exception as e:                            # noqa: BLE001 - the 1-thread baseline above stays valid
+            out["cpu_baseline"]["multi_process_error"] = repr(e)[:200]
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

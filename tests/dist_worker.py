@@ -75,10 +75,14 @@ def gpu_lm(rank, world, out_path, backend):
     torch.cuda.set_device(dev)
     ctx = Context(dev)
     res = dict(rank=rank, cases=[])
+    import hashlib
     transports = ("rccl", "callback") if backend == "nccl" else ("callback",)
+    cases = (dict(n_frames=14, n_static=500, n_objects=2, dyn_tracks_per_object=40, seed=3),
+             dict(n_frames=30, n_static=3000, n_objects=3, dyn_tracks_per_object=100, seed=4))
+    if world > 2:
+        cases = cases[1:]                                  # (many ranks on one GPU: one graph with enough tracks for every rank)
     for transport in transports:
-        for kw in (dict(n_frames=14, n_static=500, n_objects=2, dyn_tracks_per_object=40, seed=3),
-                   dict(n_frames=30, n_static=3000, n_objects=3, dyn_tracks_per_object=100, seed=4)):
+        for kw in cases:
             g = synth.make_ba_graph(**kw)
             sh = D.ShardedBatchBA(ctx, g, transport=transport)
             st = sh.optimize(max_iterations=6, gain_threshold=-1.0)
@@ -90,7 +94,10 @@ def gpu_lm(rank, world, out_path, backend):
                 transport=sh.transport, it=(st.iterations, st1.iterations), trials=(st.total_trials, st1.total_trials),
                 chi=(st.final_chi2, st1.final_chi2), chi0=(st.initial_chi2, st1.initial_chi2),
                 pose_err=float(np.abs(pose - pose1).max()), point_err=float(np.abs(point - point1).max()),
-                hook_calls=sh.hook.calls, hook_doubles=sh.hook.doubles, n_mine=int(sh.mine.size), n_point=int(g.n_point)))
+                hook_calls=sh.hook.calls, hook_doubles=sh.hook.doubles, n_mine=int(sh.mine.size), n_point=int(g.n_point),
+                # replicated state must be the same BITS on every rank (poses, LM scalars): compared across ranks by the test
+                pose_sha=hashlib.sha1(np.ascontiguousarray(pose).tobytes()).hexdigest(), lam=float(st.final_lambda),
+                chi_trace_sha=hashlib.sha1(np.ascontiguousarray(np.frombuffer(bytes(st.chi2_trace), np.float64)[:st.iterations + 1]).tobytes()).hexdigest()))
             sh.close(); one.close()
     json.dump(res, open(f"{out_path}.{rank}", "w"))
     dist.barrier()
