@@ -13,6 +13,7 @@
 // yields exactly the model, inlier set and iteration count the sequential run would have produced.
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -275,8 +276,17 @@ static int ransac_update_iters(double p, double ep, int model_points, int max_it
 
 using namespace vdo;
 
+namespace {
+struct PnpTrace {
+  double t[5] = {0, 0, 0, 0, 0}; long n = 0; bool on = std::getenv("VDO_PNP_TRACE") != nullptr;
+  ~PnpTrace() { if (on && n) std::fprintf(stderr, "[pnp trace] calls %ld: setup %.1f us, gpu %.1f us, replay %.1f us, refit %.1f us (per call)\n", n, t[0] / n, t[1] / n, t[2] / n, t[3] / n); }
+} g_pnp_trace;
+inline double pnp_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+}  // namespace
+
 extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_problem* probs, vdo_pnp_result* results, uint8_t** inlier_out) {
   if (!ctx || !probs || !results || n_problems <= 0) return set_error(VDO_ERR_INVALID, "vdo_pnp_ransac_batch: bad argument");
+  const double tr0 = g_pnp_trace.on ? pnp_now_us() : 0.0;
   int rc = ctx_bind(ctx);
   if (rc != VDO_OK) return rc;
   std::vector<PnpDev> hp(n_problems);
@@ -334,6 +344,7 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
       if (cache.size() < 4096) cache.emplace(key, std::vector<int32_t>(dst, dst + 4 * (size_t)d.n_hyp));
     }
   }
+  const double tr1 = g_pnp_trace.on ? pnp_now_us() : 0.0;
   Arena S(ctx);
   if (!S.reserve(40 * tot_pts + 128 * tot_hyp + 4 * tot_words + sizeof(PnpDev) * (size_t)n_problems + 16 * 256 + 8192))
     return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
@@ -353,6 +364,7 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   rc = S.finish("vdo_pnp_ransac_batch");
   if (rc != VDO_OK) return rc;
   if (!cnt || !okv || !pose || !mask) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
+  const double tr2 = g_pnp_trace.on ? pnp_now_us() : 0.0;
   // replay of RANSACPointSetRegistrator::run over the precomputed votes
   for (int k = 0; k < n_problems; ++k) {
     const PnpDev& d = hp[k];
@@ -378,6 +390,7 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   }
   // OpenCV's last step: the winning model re-estimated on its inliers by EPnP (solvePnP(inliers, SOLVEPNP_EPNP)); problems are
   // independent: one per pool task (the objects of a frame in parallel)
+  const double tr3 = g_pnp_trace.on ? pnp_now_us() : 0.0;
   std::vector<int> todo;
   for (int k = 0; k < n_problems; ++k) if (probs[k].refit && results[k].n_inliers >= 4 && results[k].best_iteration >= 0) todo.push_back(k);
   if (!todo.empty()) {
@@ -409,6 +422,10 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
     } else {
       for (int q = 0; q < (int)todo.size(); ++q) refit_one(q);
     }
+  }
+  if (g_pnp_trace.on && n_problems > 1) {
+    const double tr4 = pnp_now_us();
+    g_pnp_trace.t[0] += tr1 - tr0; g_pnp_trace.t[1] += tr2 - tr1; g_pnp_trace.t[2] += tr3 - tr2; g_pnp_trace.t[3] += tr4 - tr3; ++g_pnp_trace.n;
   }
   return VDO_OK;
 }
