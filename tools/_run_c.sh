@@ -1,4 +1,11 @@
 cd $GRAFT_REPO_ROOT
-VDO_PNP_TRACE=1 python bench.py --no-batch --no-cpu-baseline --no-host-inputs --steps 60 2>&1 >/dev/null | grep "pnp trace"
-VDO_PNP_TRACE=1 VDO_PNP_THREADS=0 python bench.py --no-batch --no-cpu-baseline --no-host-inputs --steps 60 2> gpurun_out/t.err | python -c "
-import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('no pnp threads:', d['value'], d['config']['host_ms_per_section']['ransac_obj'])"; grep "pnp trace" gpurun_out/t.err
+python -m pytest tests/test_ba_gpu.py tests/test_host_classes_gpu.py -x -q -m gpu 2>&1 | tail -2
+for e in 0 1; do
+if [ $e = 1 ]; then export VDO_BA_TILE_ORDER_IDENTITY=1; fi
+echo "identity order: $e"
+python tools/ba_probe.py 200 600000 10 1500 3 0 2>&1 | tail -1
+python tools/ba_probe.py 60 30000 5 800 5 0 2>&1 | tail -1
+cd /tmp; export TMPDIR=/tmp; O=$GRAFT_REPO_ROOT/gpurun_out/r03c; mkdir -p $O; rm -rf $O/prof_ba_large
+timeout 150 rocprofv3 --kernel-trace --stats -d $O/prof_ba_large -- python $GRAFT_REPO_ROOT/tools/ba_probe.py 200 600000 10 1500 3 0 > $O/ba_large.log 2>&1
+cd $GRAFT_REPO_ROOT; DB=$(find $O/prof_ba_large -name "*.db" | head -1); python tools/rocprof_summary.py $DB 20 2>&1 | grep "schur\|precond_tile"; find $O -name "*.db" -size +20M -delete
+done

@@ -46,6 +46,7 @@ struct BADev {
   // tiles
   Tile* tiles = nullptr;
   int32_t* tile_pose = nullptr;          // [NPS] global pose id of each slot
+  int32_t* tile_order = nullptr;         // [n_tiles] launch order of the solver's tile kernels: tiles with the longest landmark chain first
   int32_t* chain_off = nullptr;          // [n_chains+1] point ranges (points of a chain are contiguous)
   int32_t* pt_prev_edge = nullptr;       // [L] ternary edge linking point l-1 -> l (or -1: chain head)
   // edges (tile-major)
@@ -92,6 +93,11 @@ struct BADev {
   // solver workspaces
   double *Dinv = nullptr, *Gl = nullptr;             // [L][9]: forward pivots^-1, G_k = Delta_{k-1}^-1 O_{k-1}
   double *Gdiag = nullptr, *Goff = nullptr;          // [L][9]: [Hll^-1]_{kk}, [Hll^-1]_{k-1,k}
+  // A point that is a chain of its own (every static landmark: most of the graph) has Hll + lambda I = (Hll[l] + lambda) I3: its factor,
+  // its pivot inverse and its block of Hll^-1 are ONE scalar - dscal[l] = 1 / (Hll[l] + lambda) - and none of the four [L][9] arrays is
+  // written or read for it (pt_single[l] = 1).
+  double* dscal = nullptr;                           // [L]
+  uint8_t* pt_single = nullptr;                      // [L]
   double* xl = nullptr;                              // [L][3]
   double* Minv = nullptr;                            // [P][36] chain position k: Delta_k^-1 of the block LDL^T (chains of length 1: plain block-Jacobi)
   double* Adg = nullptr;                             // [P][36] S_pp + lambda I by pose id (input of the chain factorisation)

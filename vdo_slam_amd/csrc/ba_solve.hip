@@ -43,6 +43,12 @@ __global__ void k_factor_chains(BADev d, double lambda) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.n_chains) return;
   const int64_t p0 = d.chain_off[c], p1 = d.chain_off[c + 1];
+  if (p1 - p0 == 1) {                                  // a point on its own: (Hll + lambda) I3 -> one scalar (ba_dev.hpp dscal)
+    const double hd = d.Hll[p0] + lambda;
+    d.dscal[p0] = 1.0 / hd;
+    if (!(hd > 0)) atomicOr(d.flags, 1);
+    return;
+  }
   double prev[9];
   bool ok = true;
   const int64_t Et = d.Et;
@@ -214,7 +220,7 @@ __device__ __forceinline__ void bgbt(const double (&B1)[18], const double* G, co
 // Exact diagonal blocks of the Schur correction, per (tile,slot):  sum B G B^T  (21 upper entries)
 __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const Tile T = d.tiles[blockIdx.x];
+  const Tile T = d.tiles[d.tile_order[blockIdx.x]];
   const int nslot = T.slot_end - T.slot_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
   double* accm = smem;                       // [21 * S]
@@ -237,7 +243,13 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
       const int64_t l = T.pt_begin + (key & 0xffff);
       double B[18], M[36];
       expand_block(0, make_f(d, T, j, 0, key, d.Finc[T.eb_begin + j], slotW, pts), slotW + 12 * slot, B);
-      bgbt(B, d.Gdiag + 9 * l, B, M);
+      if (d.pt_single[l]) {                            // [Hll^-1]_ll = g I3:  B G B^T = g B B^T
+        const double g = d.dscal[l];
+#pragma unroll
+        for (int r = 0; r < 6; ++r)
+#pragma unroll
+          for (int c = r; c < 6; ++c) M[6 * r + c] = g * (B[3 * r] * B[3 * c] + B[3 * r + 1] * B[3 * c + 1] + B[3 * r + 2] * B[3 * c + 2]);
+      } else bgbt(B, d.Gdiag + 9 * l, B, M);
       int k = 0;
 #pragma unroll
       for (int r = 0; r < 6; ++r)
@@ -546,28 +558,26 @@ __device__ void pchain_apply_lds(const BADev& d, const double* __restrict__ r, d
 // Tile operator.  MODE 0: part_q = B Hll^-1 B^T v     (Schur mat-vec)
 //                 MODE 1: part_q = B Hll^-1 bl        (reduced rhs)
 //                 MODE 2: xl     = Hll^-1 (bl - B^T v) (back-substitution)
+// The landmark factors are NOT staged in LDS: a point that is a chain of its own (every static landmark) needs one scalar, read where it is
+// used; the multi-point chains (dynamic tracks) stream their 3x3 factors from HBM one step ahead of the recursion.  12 KB + 192 B per pose
+// slot of LDS instead of 54 KB + 168 B.  Measured on the roofline graph (2 190 poses, 690 k points of which 87 % static), mat-vec pass:
+// staged for every point 57.6 us; this form 40.3 us; factors requested TWO steps ahead 48 us (170 VGPRs); separate launches for static tiles
+// (no chain code) and dynamic tiles (factors staged) 23 + 22 us.
 template <int MODE>
 __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const double* __restrict__ v) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (MODE == 0 && d.flags[1]) return;     // PCG already converged: the launches queued behind it are no-ops
-  const Tile T = d.tiles[blockIdx.x];
+  const Tile T = d.tiles[d.tile_order[blockIdx.x]];        // tiles with the longest landmark chains first: their serial solves would be the tail of the launch
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, ninc = nb + 2 * nt;
   double* u = smem;                        // [3*TP]
-  double* dinv = u + 3 * VDO_TILE_PTS;     // [9*TP]  forward pivots^-1 of the tile's points
-  double* gl = dinv + 9 * VDO_TILE_PTS;    // [9*TP]  G_k
-  double* vs = gl + 9 * VDO_TILE_PTS;      // [6*S]
+  double* vs = u + 3 * VDO_TILE_PTS;       // [6*S]
   double* qs = vs + 6 * d.max_slots;       // [6*S]
   double* slotW = qs + 6 * d.max_slots;    // [12*S] inverse poses of the slots (R^T | -R^T t)
   double* pts = slotW + 12 * d.max_slots;  // [3*TP]  the tile's points (linearisation point)
   const int tid = threadIdx.x;
   for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) u[i] = 0.0;
   stage_slot_w_pts(d, T, slotW, pts);
-  {   // coalesced staging of the chain factors (read once per tile, used by the serial chain solves)
-    const double* gd = d.Dinv + 9 * (int64_t)T.pt_begin;
-    const double* gg = d.Gl + 9 * (int64_t)T.pt_begin;
-    for (int i = tid; i < 9 * npts; i += VDO_TILE_THREADS) { dinv[i] = gd[i]; gl[i] = gg[i]; }
-  }
   if (MODE != 1)
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) vs[i] = v[6 * (int64_t)d.tile_pose[T.slot_begin + i / 6] + i % 6];
   if (MODE != 2)
@@ -608,26 +618,53 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     }
     __syncthreads();
   }
-  // chain solves in LDS: w = Hll^-1 y,  y = u (MODE 0) | bl (MODE 1) | bl - u (MODE 2)
+  // chain solves: w = Hll^-1 y,  y = u (MODE 0) | bl (MODE 1) | bl - u (MODE 2); w overwrites u
   for (int c = T.chain_begin + tid; c < T.chain_end; c += VDO_TILE_THREADS) {
     const int64_t p0 = d.chain_off[c], p1 = d.chain_off[c + 1];
+    if (p1 - p0 == 1) {                                    // w = y / (Hll + lambda)
+      double* ul = u + 3 * (p0 - T.pt_begin);
+      D3 y{ul[0], ul[1], ul[2]};
+      if (MODE == 1) y = D3{d.bl[3 * p0], d.bl[3 * p0 + 1], d.bl[3 * p0 + 2]};
+      if (MODE == 2) y = D3{d.bl[3 * p0], d.bl[3 * p0 + 1], d.bl[3 * p0 + 2]} - y;
+      const double g = d.dscal[p0];
+      ul[0] = g * y.x; ul[1] = g * y.y; ul[2] = g * y.z;
+      continue;
+    }
     D3 yprev{0, 0, 0};
+    double Dn[9], Gn[9];                                   // factors of the next step, requested before this step's arithmetic
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { Dn[i] = d.Dinv[9 * p0 + i]; Gn[i] = 0.0; }
     for (int64_t l = p0; l < p1; ++l) {
+      double Dc[9], Gc[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { Dc[i] = Dn[i]; Gc[i] = Gn[i]; }
+      if (l + 1 < p1) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) { Dn[i] = d.Dinv[9 * (l + 1) + i]; Gn[i] = d.Gl[9 * (l + 1) + i]; }
+      }
       double* ul = u + 3 * (l - T.pt_begin);
       D3 y{ul[0], ul[1], ul[2]};
       if (MODE == 1) y = D3{d.bl[3 * l], d.bl[3 * l + 1], d.bl[3 * l + 2]};
       if (MODE == 2) y = D3{d.bl[3 * l], d.bl[3 * l + 1], d.bl[3 * l + 2]} - y;
-      if (l > p0) y = y - rotT(gl + 9 * (l - T.pt_begin), yprev);     // y_k = u_k - G_k^T y_{k-1}
+      if (l > p0) y = y - rotT(Gc, yprev);                 // y_k = u_k - G_k^T y_{k-1}
       yprev = y;
-      const D3 z = rot(dinv + 9 * (l - T.pt_begin), y);
+      const D3 z = rot(Dc, y);
       ul[0] = z.x; ul[1] = z.y; ul[2] = z.z;
     }
-    D3 wnext{0, 0, 0};
-    for (int64_t l = p1 - 2; l >= p0; --l) {             // w_k = z_k - G_{k+1} w_{k+1}
+#pragma unroll
+    for (int i = 0; i < 9; ++i) Gn[i] = d.Gl[9 * (p1 - 1) + i];
+    for (int64_t l = p1 - 2; l >= p0; --l) {                // w_k = z_k - G_{k+1} w_{k+1}
+      double Gc[9];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) Gc[i] = Gn[i];
+      if (l - 1 >= p0) {
+#pragma unroll
+        for (int i = 0; i < 9; ++i) Gn[i] = d.Gl[9 * l + i];
+      }
       const double* un = u + 3 * (l + 1 - T.pt_begin);
-      wnext = D3{un[0], un[1], un[2]};
+      const D3 wnext{un[0], un[1], un[2]};
       double* ul = u + 3 * (l - T.pt_begin);
-      const D3 z = D3{ul[0], ul[1], ul[2]} - rot(gl + 9 * (l + 1 - T.pt_begin), wnext);
+      const D3 z = D3{ul[0], ul[1], ul[2]} - rot(Gc, wnext);
       ul[0] = z.x; ul[1] = z.y; ul[2] = z.z;
     }
   }
@@ -873,7 +910,11 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   {
     const double* gd = d.Dinv + 9 * (int64_t)T.pt_begin;
     const double* gg = d.Gl + 9 * (int64_t)T.pt_begin;
-    for (int i = tid; i < 9 * npts; i += VDO_TILE_THREADS) { dinv[i] = gd[i]; gl[i] = gg[i]; }
+    for (int i = tid; i < 9 * npts; i += VDO_TILE_THREADS) {
+      const int64_t l = T.pt_begin + i / 9;
+      if (d.pt_single[l]) { dinv[i] = (i % 9) % 4 == 0 ? d.dscal[l] : 0.0; gl[i] = 0.0; }      // (a point on its own: dscal * I3, ba_dev.hpp)
+      else { dinv[i] = gd[i]; gl[i] = gg[i]; }
+    }
   }
   int key[3], kind[3];
   FInc F[3];
@@ -1004,7 +1045,7 @@ void launch_dense_rhs(const BADev& d, double* rhs, int64_t ld, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------ launchers
-static size_t schur_lds(const BADev& d) { return (24 * VDO_TILE_PTS + 24 * (size_t)d.max_slots) * sizeof(double); }
+static size_t schur_lds(const BADev& d) { return (6 * VDO_TILE_PTS + 24 * (size_t)d.max_slots) * sizeof(double); }
 
 void launch_expand_binc(const BADev& d, hipStream_t s) {
   if (d.n_tiles) hipLaunchKernelGGL(k_expand_binc, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), (12 * (size_t)d.max_slots + 3 * VDO_TILE_PTS) * sizeof(double), s, d);

@@ -337,7 +337,18 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(pose[0], g->pose, 12 * (size_t)P); UP(pose[1], g->pose, 12 * (size_t)P);
   UP(point[0], point_new.data(), 3 * (size_t)L); UP(point[1], point_new.data(), 3 * (size_t)L);
   UP(tiles, tiles.data(), n_tiles); UP(tile_pose, tile_pose.data(), NPS);
+  {
+    std::vector<int32_t> order(std::max(n_tiles, 1), 0), longest(std::max(n_tiles, 1), 0);
+    for (int t = 0; t < n_tiles; ++t) { order[t] = t; for (int c = tiles[t].chain_begin; c < tiles[t].chain_end; ++c) longest[t] = std::max(longest[t], chain_off[c + 1] - chain_off[c]); }
+    if (!std::getenv("VDO_BA_TILE_ORDER_IDENTITY")) std::stable_sort(order.begin(), order.begin() + n_tiles, [&](int a, int b) { return longest[a] > longest[b]; });
+    UP(tile_order, order.data(), order.size());
+  }
   UP(chain_off, chain_off.data(), chain_off.size()); UP(pt_prev_edge, pt_prev_edge_new.data(), L);
+  {
+    std::vector<uint8_t> single(std::max(L, 1), 0);
+    for (int c = 0; c < n_chains; ++c) if (chain_off[c + 1] - chain_off[c] == 1) single[chain_off[c]] = 1;
+    UP(pt_single, single.data(), single.size());
+  }
   UP(eb_key, eb_key.data(), Eb);
   UP(et_key, et_key.data(), Et); UP(et_slot, et_slot.data(), Et);
   {
@@ -382,7 +393,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(part_chi, Z, 2 * (size_t)n_tiles + 2 * (size_t)(Ep + Npr) + 2);
   UP(part_red, Z, 256);
   UP(Dinv, Z, 9 * (size_t)L); UP(Gl, Z, 9 * (size_t)L); UP(Gdiag, Z, 9 * (size_t)L); UP(Goff, Z, 9 * (size_t)L);
-  UP(xl, Z, 3 * (size_t)L);
+  UP(xl, Z, 3 * (size_t)L); UP(dscal, Z, (size_t)std::max(L, 1));
   UP(Minv, Z, 36 * (size_t)P); UP(Lc, Z, 36 * (size_t)P); UP(Adg, Z, 36 * (size_t)P);
   UP(xp, Z, 6 * (size_t)P); UP(rp, Z, 6 * (size_t)P); UP(zp, Z, 6 * (size_t)P); UP(pp, Z, 6 * (size_t)P);
   UP(qp, Z, 6 * (size_t)P); UP(bs, Z, 6 * (size_t)P); UP(qs, Z, 6 * (size_t)P);
