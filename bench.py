@@ -251,6 +251,7 @@ def main():
     def defer_now():
         return defer
     cpus = _cpu_budget() / max(1, world)
+    dump_sections = bool(os.environ.get("VDO_BENCH_DUMP_SECTIONS"))
     AGG = ("cam_lm_iterations", "n_static_tracked", "n_object_tracked", "n_objects", "n_ransac_cam", "n_cam_inliers", "n_ransac_obj", "n_recovered_masks", "n_motion_model_obj", "n_mm_inliers_obj")
 
     class Replica:
@@ -272,6 +273,7 @@ def main():
                 self.pipe.keep_graph()                            # "Save Graph Structure" (Tracking.cc:1031-1159): every frame is appended to the flat GraphStore the batch optimisers read
             self.agg = {q: 0 for q in AGG}
             self.step_ms = []
+            self.sect_trace = []
             self.err = None
 
         def run(self, i0, n, timed):
@@ -286,6 +288,8 @@ def main():
                     c = self.pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
                     if timed:
                         self.step_ms.append((time.perf_counter() - ts) * 1e3)
+                        if dump_sections:                     # (debug: cumulative section times after every step + the counts of the frame)
+                            self.sect_trace.append((dict(self.pipe.section_ms()), dict(c)))
                     for q in AGG:
                         self.agg[q] += c[q]
                 self.pipe.flush()                     # deferred mode: the object stage of the last frame ends inside the timed region
@@ -346,6 +350,13 @@ def main():
     counts, agg, step_ms = pipe.counts, reps[0].agg, reps[0].step_ms
     if os.environ.get("VDO_BENCH_DUMP_STEPS"):              # (debug: where the slow steps of a run are)
         print("step_ms:", " ".join(f"{v:.2f}" for v in step_ms), file=sys.stderr)
+    if dump_sections:
+        prev = None
+        for i, (sm, cc) in enumerate(reps[0].sect_trace):
+            if prev is not None:
+                print(f"step {i:3d} {step_ms[i]:.2f} ms objs {cc['n_objects']} obj_pts {cc['n_object_tracked']} mm {cc['n_motion_model_obj']} | " +
+                      " ".join(f"{k_}={sm[k_] - prev[k_]:.3f}" for k_ in sm), file=sys.stderr)
+            prev = sm
     sect = pipe.section_ms()
     k_last = (n_all - 1) % n_seq
     Tcw = pipe.pose().astype(np.float64)

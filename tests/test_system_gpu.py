@@ -92,9 +92,16 @@ def test_system_trackrgbd_on_host_images(host, oracle, tmp_path):
             poses.append(T.reshape(4, 4).copy()); motions.append(sorted(int(x) for x in sl[:nm]))
         rf = np.zeros((n_frames, 16), np.float32)
         assert host.host_system_refined_poses(sys_, n_frames, _ptr(rf)) == n_frames             # FullBatchOptimization ran at the last frame
-        out = tmp_path / "traj.txt"
-        host.host_system_save(sys_, str(out).encode())
-        assert len(out.read_text().splitlines()) == 2 * (n_frames + 1)
+        prefix = str(tmp_path / "res_")                                                          # SaveResults takes a path PREFIX, as in the reference (src/System.cc:75-78)
+        host.host_system_save(sys_, prefix.encode())
+        ini = np.loadtxt(prefix + "initial_stereo_new.txt"); ref_ = np.loadtxt(prefix + "refined_stereo_new.txt"); gt_ = np.loadtxt(prefix + "cam_pose_gt_stereo.txt")
+        assert ini.shape == ref_.shape == gt_.shape == (n_frames, 17) and np.array_equal(ini[:, 0], np.arange(n_frames))
+        np.testing.assert_allclose(ini[-1, 1:13].reshape(3, 4), np.linalg.inv(T.reshape(4, 4).astype(np.float64))[:3], atol=2e-5)      # T_wc of the last frame, 9 digits
+        np.testing.assert_allclose(ref_[:, 1:], rf.reshape(n_frames, 16), atol=1e-6)
+        np.testing.assert_allclose(gt_[:, 1:], np.tile(np.eye(4).ravel(), (n_frames, 1)), atol=0)    # (this test hands identity ground-truth poses in)
+        mot = np.loadtxt(prefix + "obj_mot_world_new.txt").reshape(-1, 18)
+        assert mot.shape[0] >= 1 and set(mot[:, 1].astype(int)) <= {1, 2, 3, 4, 5, 6, 7, 8}
+        assert os.path.exists(prefix + "obj_mot_world_rf_new.txt")
         host.host_system_destroy(sys_)
         return poses, motions, rf.reshape(-1, 4, 4)
 

@@ -621,6 +621,13 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
         fop[a] = fo[a].data(); iop[a] = io[a].data();
       }
       VDO_TRY(vdo_flow2_batch_fetch(obj, rs.data(), fop.data(), iop.data()));
+      static const bool trace_obj = std::getenv("VDO_PIPE_TRACE_OBJ") != nullptr;
+      if (trace_obj) {
+        std::fprintf(stderr, "[obj lm f=%d]", f_id_obj_);
+        for (int a = 0; a < n_objects; ++a)
+          if (obj_stat_[a]) std::fprintf(stderr, " sem %d n %zu its %d trials %d inl %d |", osem[a], obj_subsets_[a].size(), rs[a].iterations, rs[a].trials, rs[a].n_inliers);
+        std::fprintf(stderr, "\n");
+      }
       inl_off_.assign(1, 0); inl_idx_.clear();
       float Twc_c[16];
       inv_rigid(Tcw, Twc_c);

@@ -23,6 +23,7 @@ class Map {
   std::vector<int> nObjID;
   // poses (T_wc) and rigid motions ([0] = camera motion, [1..] = objects) + refined copies
   std::vector<cv::Mat> vmCameraPose, vmCameraPose_RF;
+  std::vector<cv::Mat> vmCameraPose_GT;                    // Converter::toInvMatrix(mCurrentFrame.mTcw_gt) per frame (src/Tracking.cc:320-328, 1113-1115)
   std::vector<std::vector<cv::Mat> > vmRigidMotion, vmRigidMotion_RF;
   std::vector<std::vector<int> > vnRMLabel;
 };

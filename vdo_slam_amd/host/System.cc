@@ -7,9 +7,11 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <iomanip>
 #include <iostream>
 #include <sstream>
 
+#include "Converter.h"
 #include "Optimizer.h"
 
 namespace VDO_SLAM {
@@ -80,7 +82,7 @@ Tracking::~Tracking() {
   for (int k = 0; k < 5; ++k) if (ctx_[k]) vdo_ctx_destroy(ctx_[k]);
 }
 
-cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Mat& imFlow, const cv::Mat& maskSEM, const cv::Mat&,
+cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Mat& imFlow, const cv::Mat& maskSEM, const cv::Mat& mTcw_gt,
                                 const std::vector<std::vector<float> >& vObjPose_gt, const double&, cv::Mat&, const int& nImage) {
   StopFrame = nImage - 1;
   if (!have_frame_) f_id = 0;
@@ -127,6 +129,14 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
   if (pipe_->StepHost(gray, (const float*)imD.data, (const float*)imFlow.data, (const int32_t*)maskSEM.data, metric, &fc) != 0) return cv::Mat();
   if (!metric && pipe_->DownloadDepth((float*)imD.data) != 0) return cv::Mat();
   if (fc.n_recovered_masks > 0) pipe_->DownloadMask((int32_t*)maskSEM.data);      // UpdateMask writes through the shared header (Tracking.cc:3049-3068)
+  // ground-truth camera pose of the frame relative to the first one, as Map::vmCameraPose_GT keeps it (src/Tracking.cc:319-328, 1113-1115;
+  // Initialization() sets the first frame's to the identity, :1255-1256) - bookkeeping for SaveResults only
+  if (!mTcw_gt.empty() && mTcw_gt.rows == 4 && mTcw_gt.cols == 4 && mTcw_gt.depth() == cv::CV_32F) {
+    cv::Mat Tgt = cv::Mat::eye(4, 4, cv::CV_32F);
+    if (!have_frame_) mOriginInv = mTcw_gt.clone();
+    else Tgt = Converter::toInvMatrix(mTcw_gt) * mOriginInv;
+    mpMap->vmCameraPose_GT.push_back(Converter::toInvMatrix(Tgt));
+  }
   have_frame_ = true;
   // full batch optimisation after the last frame, KITTI only (Tracking.cc:1189-1210: `bGlobalBatch && mTestData==KITTI`)
   if (f_id == StopFrame && f_id > 1 && bGlobalBatch && mTestData == KITTI) {
@@ -160,17 +170,25 @@ Map* System::map() { mpTracker->pipeline()->SyncMap(); return mpMap; }
 
 void System::SaveResults(const std::string& filename) {
   map();
-  std::ofstream o(filename.c_str());
-  o.precision(9);
-  for (int rf = 0; rf < 2; ++rf) {
-    const std::vector<cv::Mat>& P = rf ? mpMap->vmCameraPose_RF : mpMap->vmCameraPose;
-    o << (rf ? "# camera poses T_wc after the batch optimisation" : "# camera poses T_wc") << "\n";
-    for (size_t i = 0; i < P.size(); ++i) {
-      o << i;
-      for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) o << ' ' << P[i].at<float>(r, c);
-      o << "\n";
-    }
-  }
+  auto row = [](std::ofstream& o, const cv::Mat& T) {
+    for (int r = 0; r < 3; ++r) for (int c = 0; c < 4; ++c) o << T.at<float>(r, c) << " ";
+    o << 0.0 << " " << 0.0 << " " << 0.0 << " " << 1.0 << std::endl;
+  };
+  const int start_frame = 0;
+  auto poses = [&](const char* name, const std::vector<cv::Mat>& P) {      // src/System.cc:125-178
+    std::ofstream o((filename + name).c_str(), std::ios::trunc);
+    for (size_t i = 0; i < P.size(); ++i) { o << start_frame + i << " " << std::fixed << std::setprecision(9); row(o, P[i]); }
+  };
+  poses("initial_stereo_new.txt", mpMap->vmCameraPose);
+  poses("refined_stereo_new.txt", mpMap->vmCameraPose_RF);
+  poses("cam_pose_gt_stereo.txt", mpMap->vmCameraPose_GT);
+  auto motions = [&](const char* name, const std::vector<std::vector<cv::Mat> >& M) {   // row format of src/System.cc:85-100, world frame (System.h)
+    std::ofstream o((filename + name).c_str(), std::ios::trunc);
+    for (size_t i = 0; i < M.size(); ++i)
+      for (size_t j = 1; j < M[i].size(); ++j) { o << start_frame + i + 1 << " " << mpMap->vnRMLabel[i][j] << " " << std::fixed << std::setprecision(9); row(o, M[i][j]); }
+  };
+  motions("obj_mot_world_new.txt", mpMap->vmRigidMotion);
+  motions("obj_mot_world_rf_new.txt", mpMap->vmRigidMotion_RF);
 }
 
 }  // namespace VDO_SLAM

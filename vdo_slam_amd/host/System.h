@@ -50,6 +50,7 @@ class Tracking {
   std::unique_ptr<FramePipeline> pipe_;
   std::vector<uint8_t> gray_;
   bool have_frame_ = false;
+  cv::Mat mOriginInv;                  // ground-truth pose of the first frame (src/Tracking.cc:319-323)
 };
 
 class System {
@@ -59,7 +60,12 @@ class System {
   ~System();
   cv::Mat TrackRGBD(const cv::Mat& im, cv::Mat& depthmap, const cv::Mat& flowmap, const cv::Mat& masksem, const cv::Mat& mTcw_gt,
                     const std::vector<std::vector<float> >& vObjPose_gt, const double& timestamp, cv::Mat& imTraj, const int& nImage);
-  void SaveResults(const std::string& filename);   // camera trajectory (T_wc rows), before and after the batch optimisation
+  // The reference's result files (src/System.cc:66-198), `filename` being the path PREFIX as there: initial_stereo_new.txt,
+  // refined_stereo_new.txt, cam_pose_gt_stereo.txt (frame id + the 16 entries of T_wc, fixed, 9 digits) and the object motions per
+  // transition in the same row format.  The reference writes the object motions in the BODY frame of the ground-truth object pose
+  // (obj_mot_stereo_new.txt / _rf_new.txt / obj_mot_gt.txt / obj_centre.txt: ground-truth object-pose parsing, out of scope);
+  // here they are written in the WORLD frame under names of their own: obj_mot_world_new.txt / obj_mot_world_rf_new.txt.
+  void SaveResults(const std::string& filename);
   Map* map();                          // brought up to date from the pipeline's GraphStore on access
   Tracking* tracker() { return mpTracker; }
 
