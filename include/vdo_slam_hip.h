@@ -344,6 +344,9 @@ int vdo_rgb2gray(vdo_ctx* ctx, const uint8_t* rgb, int64_t n_pixels, int channel
 typedef struct vdo_frame_images vdo_frame_images;   /* HBM-resident depth (f32), flow (2 x f32), mask (i32) */
 int vdo_frame_images_create(vdo_ctx* ctx, int width, int height, vdo_frame_images** out);
 int vdo_frame_images_upload(vdo_frame_images* f, const float* depth, const float* flow, const int32_t* mask);
+/* The same copies issued and awaited on the stream of `ctx` instead of the image set's own - for a host thread that brings the flow and the
+ * mask of a frame up while another one already works on its depth map (the reference hands TrackRGBD host cv::Mat's, include/System.h:45-51). */
+int vdo_frame_images_upload_on(vdo_ctx* ctx, vdo_frame_images* f, const float* depth, const float* flow, const int32_t* mask);
 int vdo_frame_images_upload_device(vdo_frame_images* f, const float* depth_dev, const float* flow_dev, const int32_t* mask_dev);
 int vdo_frame_images_depth_preprocess(vdo_frame_images* f, float bf, float depth_map_factor);   /* K1 in place, resident image */
 int vdo_frame_images_destroy(vdo_frame_images* f);

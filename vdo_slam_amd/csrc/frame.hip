@@ -199,6 +199,19 @@ extern "C" int vdo_frame_images_upload(vdo_frame_images* f, const float* depth, 
   return VDO_OK;
 }
 
+extern "C" int vdo_frame_images_upload_on(vdo_ctx* ctx, vdo_frame_images* f, const float* depth, const float* flow, const int32_t* mask) {
+  if (!ctx || !f) return set_error(VDO_ERR_INVALID, "null handle");
+  int rc = ctx_bind(ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = ctx->stream;
+  const size_t np = (size_t)f->w * f->h;
+  if (depth) hipMemcpyAsync(f->d_depth, depth, 4 * np, hipMemcpyHostToDevice, s);
+  if (flow) hipMemcpyAsync(f->d_flow, flow, 8 * np, hipMemcpyHostToDevice, s);
+  if (mask) hipMemcpyAsync(f->d_mask, mask, 4 * np, hipMemcpyHostToDevice, s);
+  if (hipStreamSynchronize(s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "frame upload failed");
+  return VDO_OK;
+}
+
 // Same as upload, but the sources are DEVICE pointers (e.g. torch tensors): device-to-device, stream-ordered, no sync.
 extern "C" int vdo_frame_images_upload_device(vdo_frame_images* f, const float* depth, const float* flow, const int32_t* mask) {
   if (!f) return set_error(VDO_ERR_INVALID, "null handle");

@@ -211,7 +211,15 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     fin_async = true;
   }
   // ---- GrabImageRGBD: images, K1, UpdateMask (K15), propagation (K11)            Tracking.cc:180-305
-  if (host_inputs_) VDO_TRY(vdo_frame_images_upload(cur, d_depth_raw, d_flow, d_mask));
+  // Host inputs (System::TrackRGBD): 7.5 MB of pageable copies.  Only the depth map is needed at once (K1, K11); the flow and the mask are first
+  // read behind the camera stage (UpdateMask, the static stage): they go up while the camera optimisation runs on its own stream (the
+  // copies block this thread for ~0.15 ms it would otherwise spend waiting for that launch).  The converted depth map the caller is owed
+  // (the reference converts imD in place) is read back while the object optimisations of the frame run, instead of after the frame.
+  // (Converting the caller's copy on the host instead - the same two correctly rounded divisions per pixel - takes one thread 0.4 ms: measured, dropped.)
+  const bool late_upload = host_inputs_ && !std::getenv("VDO_PIPE_SYNC_UPLOAD");
+  depth_on_host_ = false;
+  if (late_upload) VDO_TRY(vdo_frame_images_upload(cur, d_depth_raw, nullptr, nullptr));
+  else if (host_inputs_) VDO_TRY(vdo_frame_images_upload(cur, d_depth_raw, d_flow, d_mask));
   else VDO_TRY(vdo_frame_images_upload_device(cur, d_depth_raw, d_flow, d_mask));
   if (!depth_metric_) VDO_TRY(vdo_frame_images_depth_preprocess(cur, p_.bf, p_.depth_map_factor));
   const int n_s = have_last_ ? (int)sta_.cx.size() : 0;
@@ -274,6 +282,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   tick(0);
   // ---- camera pose (K16) on the LM stream, front-end of this frame meanwhile      Tracking.cc:690-700 || Frame.cc:61-260
   if (cam) VDO_TRY(vdo_flow2_batch_run(cam));
+  if (late_upload) VDO_TRY(vdo_frame_images_upload(cur, nullptr, d_flow, d_mask));
   if (p_.use_sample_feature) {                           // Option II of Frame::Frame (src/Frame.cc:132-166): random samples instead of ORB
     int ns = 0;
     VDO_TRY(vdo_sample_keypoints(H, W, (uint64_t)(p_.sample_seed + f_id_), kp.capacity, kx_.data(), ky_.data(), &ns));
@@ -570,6 +579,10 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   std::memcpy(Tcw_out_, Tcw, sizeof Tcw);
   cur_ ^= 1; have_last_ = true; ++f_id_;
   gate_last_ = gate_cur_;
+  if (host_inputs_ && depth_inout_ && !depth_metric_ && pending_ && !p_.defer_objects) {      // (the object LMs of the frame are in flight: the copy engine is free)
+    VDO_TRY(vdo_frame_images_download_depth(img_[cur_ ^ 1], depth_inout_));
+    depth_on_host_ = true;
+  }
   if (pending_ && !p_.defer_objects) { if (FinishObjects(&fc) != 0) return -1; }
   if (trace_slow) {
     const double tot = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_step0).count();
@@ -719,10 +732,10 @@ int FramePipeline::FinishObjectsTail(FrameCounts* fcp) {
   return 0;
 }
 
-int FramePipeline::StepHost(const uint8_t* gray, const float* depth, const float* flow, const int32_t* mask, bool depth_is_metric, FrameCounts* out) {
-  host_inputs_ = true; depth_metric_ = depth_is_metric;
+int FramePipeline::StepHost(const uint8_t* gray, const float* depth, const float* flow, const int32_t* mask, bool depth_is_metric, FrameCounts* out, float* depth_inout) {
+  host_inputs_ = true; depth_metric_ = depth_is_metric; depth_inout_ = depth_inout;
   const int rc = Step(gray, depth, flow, mask, nullptr, nullptr, 0, 0, out);
-  host_inputs_ = false; depth_metric_ = false;
+  host_inputs_ = false; depth_metric_ = false; depth_inout_ = nullptr;
   return rc;
 }
 

@@ -69,7 +69,11 @@ class FramePipeline {
   int Step(const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
            vdo_flow2_batch* cam, vdo_flow2_batch* obj, int n_cam_pts, int n_obj_problems, FrameCounts* out);
   // The same with HOST pointers (the System::TrackRGBD shell): images are uploaded first; depth_is_metric: K1 was already applied.
-  int StepHost(const uint8_t* gray, const float* depth, const float* flow, const int32_t* mask, bool depth_is_metric, FrameCounts* out);
+  // depth_inout (optional, the caller's raw depth map): receives the converted map (metres; the reference converts imD in place) inside the
+  // Step when that read-back can run under the frame's object optimisations - DepthConvertedOnHost() tells; otherwise the caller fetches it
+  // with DownloadDepth.
+  int StepHost(const uint8_t* gray, const float* depth, const float* flow, const int32_t* mask, bool depth_is_metric, FrameCounts* out, float* depth_inout = nullptr);
+  bool DepthConvertedOnHost() const { return depth_on_host_; }
   // Objects the caller has ground truth for in the frame about to be given to Step (label = mask id).  The reference only
   // tracks an object whose label has a ground-truth row in BOTH the last and the current frame (src/Tracking.cc:791-841:
   // otherwise bObjStat = false and the object keeps its point set untouched).  Without a call every label is allowed.
@@ -113,6 +117,8 @@ class FramePipeline {
   TrackList tl_sta_, tl_dyn_;
   bool keep_graph_ = false;
   bool host_inputs_ = false, depth_metric_ = false, gate_on_ = false;
+  float* depth_inout_ = nullptr;      // StepHost: the caller's depth map to convert in place
+  bool depth_on_host_ = false;
   std::vector<int> gate_cur_, gate_last_;
   Map* map_ = nullptr;
   int f_id_obj_ = 0;                  // frame id of the pending object stage

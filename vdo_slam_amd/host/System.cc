@@ -126,8 +126,8 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
     metric = true;
   }
   FrameCounts fc{};
-  if (pipe_->StepHost(gray, (const float*)imD.data, (const float*)imFlow.data, (const int32_t*)maskSEM.data, metric, &fc) != 0) return cv::Mat();
-  if (!metric && pipe_->DownloadDepth((float*)imD.data) != 0) return cv::Mat();
+  if (pipe_->StepHost(gray, (const float*)imD.data, (const float*)imFlow.data, (const int32_t*)maskSEM.data, metric, &fc, (float*)imD.data) != 0) return cv::Mat();
+  if (!metric && !pipe_->DepthConvertedOnHost() && pipe_->DownloadDepth((float*)imD.data) != 0) return cv::Mat();
   if (fc.n_recovered_masks > 0) pipe_->DownloadMask((int32_t*)maskSEM.data);      // UpdateMask writes through the shared header (Tracking.cc:3049-3068)
   // ground-truth camera pose of the frame relative to the first one, as Map::vmCameraPose_GT keeps it (src/Tracking.cc:319-328, 1113-1115;
   // Initialization() sets the first frame's to the identity, :1255-1256) - bookkeeping for SaveResults only
