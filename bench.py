@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes as C
+import gc
 import json
 import os
 import sys
@@ -206,6 +207,11 @@ def main():
 
     import torch
     import torch.distributed as dist
+    # the cyclic collector stays out of the timed windows, as in timeit: with torch imported a full collection walks ~10^6 objects
+    # (40-45 ms, 30 frames' worth), and where it lands depends on the allocation count of everything before it.  Reference counting
+    # still frees everything the legs drop; VDO_BENCH_GC=1 leaves the collector on.
+    if not os.environ.get("VDO_BENCH_GC"):
+        gc.collect(); gc.freeze(); gc.disable()
     rank, world, local = _dist_env()
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (libvdo_hip has no CPU fallback)")
@@ -435,12 +441,20 @@ def main():
                         for k_, (g_, d_, fl_, m_) in enumerate(host_in)]
                 for k in range(args.warmup):
                     sysm.track_rgbd(*bufs[k])
+                gc_n = [g_["collections"] for g_ in gc.get_stats()]
                 t0 = time.perf_counter()
                 Th = None
+                call_ms = []
                 for k in range(args.warmup, n_all):
+                    tc = time.perf_counter()
                     Th = sysm.track_rgbd(*bufs[k % len(bufs)])
+                    call_ms.append((time.perf_counter() - tc) * 1e3)
                 sysm.flush()
                 dth = time.perf_counter() - t0
+                out["config"]["host_inputs_call_ms_p50_p90_max_" + mode] = [round(float(np.percentile(call_ms, 50)), 3), round(float(np.percentile(call_ms, 90)), 3), round(max(call_ms), 3)]
+                if os.environ.get("VDO_BENCH_DUMP_STEPS"):
+                    print(f"host-input calls ({mode}):", " ".join(f"{v:.2f}" for v in call_ms), "| gc collections in the window:",
+                          [g_["collections"] - n0 for g_, n0 in zip(gc.get_stats(), gc_n)], file=sys.stderr)
                 out["value_host_inputs" if mode == "deferred" else "value_host_inputs_sync"] = args.steps / dth
                 same = bool(Th is not None and np.array_equal(Th.astype(np.float64), Tcw))
                 sysm.close()

@@ -126,9 +126,16 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
     metric = true;
   }
   FrameCounts fc{};
+  static const bool trace_slow = std::getenv("VDO_PIPE_TRACE_SLOW") != nullptr;      // (debug: where a call of > 5 ms went)
+  auto since = [&](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+  const double ms_pre = since(t_call);
   if (pipe_->StepHost(gray, (const float*)imD.data, (const float*)imFlow.data, (const int32_t*)maskSEM.data, metric, &fc, (float*)imD.data) != 0) return cv::Mat();
+  const double ms_step = since(t_call);
   if (!metric && !pipe_->DepthConvertedOnHost() && pipe_->DownloadDepth((float*)imD.data) != 0) return cv::Mat();
+  const double ms_depth = since(t_call);
   if (fc.n_recovered_masks > 0) pipe_->DownloadMask((int32_t*)maskSEM.data);      // UpdateMask writes through the shared header (Tracking.cc:3049-3068)
+  if (trace_slow && since(t_call) > 5.0)
+    std::fprintf(stderr, "[slow TrackRGBD f=%d] pre %.2f step %.2f depth %.2f mask(%d) %.2f ms\n", f_id, ms_pre, ms_step, ms_depth, fc.n_recovered_masks, since(t_call));
   // ground-truth camera pose of the frame relative to the first one, as Map::vmCameraPose_GT keeps it (src/Tracking.cc:319-328, 1113-1115;
   // Initialization() sets the first frame's to the identity, :1255-1256) - bookkeeping for SaveResults only
   if (!mTcw_gt.empty() && mTcw_gt.rows == 4 && mTcw_gt.cols == 4 && mTcw_gt.depth() == cv::CV_32F) {
