@@ -75,7 +75,8 @@ struct BADev {
   int32_t *pe_off = nullptr, *pe_idx = nullptr;   // entry = edge<<1 | side (0: pose is i, 1: pose is j)
   // pose chains (paths of the EdgeSE3 graph) for the block-tridiagonal preconditioner, in path order
   int n_pchains = 0;
-  int pc_maxlen = 0, pc_waves = 0;                // longest chain; waves of the PCG workgroup that hold a chain strip in LDS (0: the strips do not fit - global-memory path)
+  int pc_nwave = 1;                               // waves of a chain's workgroup = segments of the partitioned substitutions (ba_solve.hip)
+  int pc_maxlen = 0, pc_lds = 0;                  // longest chain; 1: a chain's strip [len][6] fits the LDS of its workgroup (k_pcg_chain), 0: global-memory path
   int32_t *pc_off = nullptr, *pc_pose = nullptr;  // [n_pchains+1], [P]
   int32_t* pc_edge = nullptr;                     // [P] edge<<1|side linking position k-1 -> k (side 0: previous pose is the edge's i), -1 at a chain head
   // linear system
@@ -102,11 +103,14 @@ struct BADev {
   double* Minv = nullptr;                            // [P][36] chain position k: Delta_k^-1 of the block LDL^T (chains of length 1: plain block-Jacobi)
   double* Adg = nullptr;                             // [P][36] S_pp + lambda I by pose id (input of the chain factorisation)
   double* Lc = nullptr;                              // [P][36] chain position k: L_k = E_{k-1,k}^T Delta_{k-1}^-1
+  double *Pf = nullptr, *Qb = nullptr;               // [P][36] chain position k: products of -L / -L^T from the segment's end (k_pchain_prefix)
   double *xp = nullptr, *rp = nullptr, *zp = nullptr, *pp = nullptr, *qp = nullptr, *bs = nullptr, *qs = nullptr;  // [6P]
+  double* pp2 = nullptr;                             // [6P] second search-direction buffer (the PCG iterations ping-pong between pp and pp2)
+  double *part_pq = nullptr, *part_rz = nullptr;     // [(P+3)/4] p.q per workgroup of k_pcg_q; [n_pchains] r.z per chain of k_pcg_chain
   double* part_q = nullptr;                          // [6][NPS]
   double* part_m = nullptr;                          // [21][NPS] preconditioner partials
   double* scal = nullptr;
-  int32_t* flags = nullptr;                          // [0] factor failure [1] pcg state [2] pcg iterations
+  int32_t* flags = nullptr;                          // [0] factor failure [1] pcg state [2] pcg iterations [3] arrival counter of k_pcg_chain
   // multi-GPU shards: poses replicated, points + their edges owned by one rank.
   // Hpp | bp | red_chi are ONE allocation so that a linearisation needs a single all-reduce.
   int sharded = 0, shard_rank = 0;
@@ -122,7 +126,7 @@ struct Reducer {
   void operator()(void* buf, int64_t n, int op = 0) const { if (fn && !err) err = fn(user, buf, n, op); }
 };
 
-enum Scal { S_CHI2 = 0, S_RCHI2, S_MAXDIAG, S_RZ, S_PQ, S_RZ0, S_SCALE, S_RZNEW, S_COUNT = 16 };
+enum Scal { S_CHI2 = 0, S_RCHI2, S_MAXDIAG, S_RZ, S_PQ, S_RZ0, S_SCALE, S_RZNEW, S_BETA, S_COUNT = 16 };
 
 // ---- ba_sweep.hip
 void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R);      // chi2 of estimate[which] -> scal
@@ -133,7 +137,7 @@ void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R);
 void launch_factor(const BADev& d, double lambda, hipStream_t s, const Reducer& R);  // chain LDL^T + inverse blocks + block-Jacobi
 void launch_reduced_rhs(const BADev& d, hipStream_t s, const Reducer& R);
 void launch_pcg_init(const BADev& d, hipStream_t s);
-void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s, const Reducer& R);
+void launch_pcg_iter(const BADev& d, double lambda, double tol2, int parity, hipStream_t s, const Reducer& R);   // parity: 0, 1, 0, ... from the first iteration after launch_pcg_init
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s);
 void launch_expand_binc(const BADev& d, hipStream_t s);            // Finc -> explicit Binc (download/debug only)
 void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R);   // explicit reduced-camera matrix

@@ -90,11 +90,11 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
   double tol = opt->pcg_tolerance > 0 ? opt->pcg_tolerance : 1e-10;
   int maxit = opt->pcg_max_iterations > 0 ? opt->pcg_max_iterations : std::min(20000, 24 * d.P + 200);
   const double tol2 = tol * tol;
-  int it = 0;
+  int it = 0, parity = 0;
   *ok = true;
   while (it < maxit) {
     const int batch = std::min(it == 0 ? 6 : 12, maxit - it);      // the chain preconditioner converges in a handful of iterations: first look after 6
-    for (int k = 0; k < batch; ++k) launch_pcg_iter(d, lambda, tol2, s, ba->red);
+    for (int k = 0; k < batch; ++k, parity ^= 1) launch_pcg_iter(d, lambda, tol2, parity, s, ba->red);
     it += batch;
     int rc = fetch(ba);
     if (rc != VDO_OK) return rc;

@@ -393,10 +393,10 @@ __global__ __launch_bounds__(64) void k_pchain_factor(BADev d) {
   if (bad && lane == 0) atomicOr(d.flags, 1);
 }
 
-// z = M^-1 r along the pose chains (forward / diagonal / backward block substitution).  Called by all
-// 1024 threads of the single PCG workgroup: one wave per chain (round-robin), lane (row, col) of a 6x6
-// block = (lane >> 3, lane & 7); each step is one block mat-vec: multiply, 3 xor-shuffles over the columns,
-// one broadcast of the new 6-vector.  The next step's block elements are fetched before the current
+// z = M^-1 r along ONE pose chain (forward / diagonal / backward block substitution) with r and z in global memory - the
+// path for chains whose strip does not fit the LDS (pc_lds = 0).  Called by the single wave of the chain's workgroup;
+// lane (row, col) of a 6x6 block = (lane >> 3, lane & 7); each step is one block mat-vec: multiply, 3 xor-shuffles over the
+// columns, one broadcast of the new 6-vector.  The next step's block elements are fetched before the current
 // step's arithmetic (they depend only on k), so the dependent chain per step is ALU + shuffles.
 __device__ __forceinline__ double row_sum6(double t) {     // sum over the 8-lane group (columns 6,7 carry zeros)
   t += __shfl_xor(t, 1, 64);
@@ -404,12 +404,12 @@ __device__ __forceinline__ double row_sum6(double t) {     // sum over the 8-lan
   t += __shfl_xor(t, 4, 64);
   return t;
 }
-__device__ void pchain_apply(const BADev& d, const double* __restrict__ r, double* __restrict__ z) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+__device__ void pchain_apply(const BADev& d, int c, const double* __restrict__ r, double* __restrict__ z) {
+  const int lane = threadIdx.x & 63;
   const int row = lane >> 3, col = lane & 7;
   const bool act = row < 6 && col < 6;
   const int el = act ? row * 6 + col : 0, elT = act ? col * 6 + row : 0;
-  for (int c = wave; c < d.n_pchains; c += nwave) {
+  {
     const int b = d.pc_off[c], e = d.pc_off[c + 1];
     // ---- forward: y_b = r_b ; y_k = r_k - L_k y_{k-1}      (y kept in z)
     int64_t p = d.pc_pose[b];
@@ -444,114 +444,267 @@ __device__ void pchain_apply(const BADev& d, const double* __restrict__ r, doubl
   }
 }
 
-// The same operator with the chain in LDS and no transposes.  A wave owns a chain; r of the chain is staged into the wave's
-// LDS strip [len][6] (coalesced 48-byte rows), the substitutions overwrite it in place (r -> y -> Dinv y -> z), z goes back
-// in one pass: the recursion never waits for global memory (the version above chases pc_pose -> r / z through HBM twice per
-// step).  lane = (a, b) = (lane >> 3, lane & 7) holds one entry of the 6x6 block; a block mat-vec is one multiply and one
-// 8-lane all-reduce - over the octet (sum over b) or over the lanes of equal b (sum over a).  The two kinds ALTERNATE: a
-// vector that comes out indexed by a (replicated along the octet) is consumed by a step that holds its block transposed
-// and reduces over a, whose result is indexed by b (replicated across the octets) - no lane permutation between steps.
-// The blocks (Lc, Minv) do not depend on the recursion: they are fetched eight steps ahead.
-__device__ void pchain_apply_lds(const BADev& d, const double* __restrict__ r, double* __restrict__ z, double* lds_strips) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// The same operator with the chain in LDS, partitioned over the waves of the chain's workgroup.  k_pcg_chain forms r of the chain
+// straight into the LDS strip yb [len][6]; the substitutions overwrite it in place (r -> y -> Dinv y -> z).
+//
+// A wave alone would walk the 2 (len - 1) dependent block mat-vecs of the two substitutions one after the other (~120 ns each: 49 us on the
+// 200-pose chains of the roofline graph).  The recurrences are linear, so the chain is cut into S <= 16 segments of G positions, one wave each:
+//   forward   y_k = r_k - L_k y_{k-1}:  every segment runs its recurrence from a ZERO input (yhat); the true value differs by P_k y_in, where y_in is
+//             the true y at the end of the segment before and P_k = (-L_k)(-L_{k-1})...(-L_{k0}) depends on the factorisation only (k_pchain_prefix
+//             stores it next to Lc, once per Levenberg trial).  Wave 0 carries y_in across the S - 1 boundaries, then every position is corrected
+//             independently (no recurrence: one lane per (position, row));
+//   backward  z_k = w_k - L_{k+1}^T z_{k+1}: the same with Q_k = (-L_{k+1}^T)...(-L_{e+1}^T) and the first z of the segment behind.
+// Dependent steps per substitution: G + S instead of len (200 -> 29).
+// Inside a segment: lane = (a, b) = (lane >> 3, lane & 7) holds one entry of the 6x6 block; a block mat-vec is one multiply and one 8-lane
+// all-reduce - over the octet (sum over b) or over the lanes of equal b (sum over a).  The two kinds ALTERNATE: a vector that comes out
+// indexed by a (replicated along the octet) is consumed by a step that holds its block transposed and reduces over a, whose result is indexed
+// by b (replicated across the octets) - no lane permutation between steps.  The blocks do not depend on the recurrence: fetched eight steps ahead.
+__host__ __device__ inline int pc_seg_len(int len, int nwave) { const int g = (len + nwave - 1) / nwave; return g < 8 ? 8 : g; }
+
+// y_0 = yb_0 ; y_j = yb_j - Lc[lc0 + j] y_{j-1}   (j < n), in place; one wave
+__device__ void pseg_forward(const BADev& d, int64_t lc0, int n, double* yb) {
+  const int lane = threadIdx.x & 63;
   const int a = lane >> 3, b = lane & 7;
   const bool act = a < 6 && b < 6;
   const int el = act ? a * 6 + b : 0, elT = act ? b * 6 + a : 0;
   const int ia = a < 6 ? a : 0, ib = b < 6 ? b : 0;
-  if (wave >= d.pc_waves) return;
-  double* yb = lds_strips + (size_t)wave * 6 * d.pc_maxlen;
-  for (int c = wave; c < d.n_pchains; c += d.pc_waves) {
-    const int bgn = d.pc_off[c], len = d.pc_off[c + 1] - bgn;
-    for (int k = lane; k < len; k += 64) {
-      const double* src = r + 6 * (int64_t)d.pc_pose[bgn + k];
+  // Step s = j - 1: even s holds L natural (vector indexed by b in, by a out), odd s holds it transposed (a in, b out)
+  double v = b < 6 ? yb[ib] : 0.0;                       // y_0[b]
+  const int nst = n - 1;
+  double Lp[8];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) yb[6 * k + i] = src[i];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- forward: y_0 = r_0 ; y_k = r_k - L_k y_{k-1}.  Step s = k - 1: even s holds L natural (vector indexed by b in, by a out),
-    //      odd s holds it transposed (a in, b out)
-    double v = b < 6 ? yb[ib] : 0.0;                       // y_0[b]
-    const int nst = len - 1;
-    double Lp[8];
+  for (int j = 0; j < 8; ++j) Lp[j] = (j < nst && act) ? d.Lc[36 * (lc0 + 1 + j) + ((j & 1) ? elT : el)] : 0.0;
+  for (int s0 = 0; s0 < nst; s0 += 8) {
+    double Ln[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) Lp[j] = (j < nst && act) ? d.Lc[36 * (int64_t)(bgn + 1 + j) + ((j & 1) ? elT : el)] : 0.0;
-    for (int s0 = 0; s0 < nst; s0 += 8) {
-      double Ln[8];
+    for (int j = 0; j < 8; ++j) Ln[j] = (s0 + 8 + j < nst && act) ? d.Lc[36 * (lc0 + 1 + s0 + 8 + j) + ((j & 1) ? elT : el)] : 0.0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) Ln[j] = (s0 + 8 + j < nst && act) ? d.Lc[36 * (int64_t)(bgn + 1 + s0 + 8 + j) + ((j & 1) ? elT : el)] : 0.0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = s0 + j + 1;
-        if (k < len) {
-          if ((j & 1) == 0) {
-            const double sum = octet_allsum(Lp[j] * v);
-            v = yb[6 * k + ia] - sum;
-            if (b == 0 && a < 6) yb[6 * k + a] = v;
-          } else {
-            const double sum = stride8_allsum(Lp[j] * v);
-            v = yb[6 * k + ib] - sum;
-            if (a == 0 && b < 6) yb[6 * k + b] = v;
-          }
-        }
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Lp[j] = Ln[j];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- diagonal: w_k = Dinv_k y_k for every k (independent steps)
-    for (int k0 = 0; k0 < len; k0 += 8) {
-      double Dv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Dv[j] = (k0 + j < len && act) ? d.Minv[36 * (int64_t)(bgn + k0 + j) + el] : 0.0;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = k0 + j;
-        if (k < len) {
-          const double w = octet_allsum(Dv[j] * (b < 6 ? yb[6 * k + ib] : 0.0));
-          __builtin_amdgcn_wave_barrier();                 // (every lane has read y_k before it is overwritten)
-          if (b == 0 && a < 6) yb[6 * k + a] = w;
+    for (int j = 0; j < 8; ++j) {
+      const int k = s0 + j + 1;
+      if (k < n) {
+        if ((j & 1) == 0) {
+          const double sum = octet_allsum(Lp[j] * v);
+          v = yb[6 * k + ia] - sum;
+          if (b == 0 && a < 6) yb[6 * k + a] = v;
+        } else {
+          const double sum = stride8_allsum(Lp[j] * v);
+          v = yb[6 * k + ib] - sum;
+          if (a == 0 && b < 6) yb[6 * k + b] = v;
         }
       }
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // ---- backward: z_last = w_last ; z_k = w_k - L_{k+1}^T z_{k+1}.  Step t = len - 2 - k: even t holds L transposed (b in, a out),
-    //      odd t natural (a in, b out)
-    v = b < 6 ? yb[6 * (len - 1) + ib] : 0.0;              // z_last[b]
 #pragma unroll
-    for (int j = 0; j < 8; ++j) Lp[j] = (j < nst && act) ? d.Lc[36 * (int64_t)(bgn + len - 1 - j) + ((j & 1) ? el : elT)] : 0.0;
-    for (int t0 = 0; t0 < nst; t0 += 8) {
-      double Ln[8];
+    for (int j = 0; j < 8; ++j) Lp[j] = Ln[j];
+  }
+}
+
+// z_{n-1} = yb_{n-1} ; z_j = yb_j - Lc[lc0 + j + 1]^T z_{j+1}, in place; one wave
+__device__ void pseg_backward(const BADev& d, int64_t lc0, int n, double* yb) {
+  const int lane = threadIdx.x & 63;
+  const int a = lane >> 3, b = lane & 7;
+  const bool act = a < 6 && b < 6;
+  const int el = act ? a * 6 + b : 0, elT = act ? b * 6 + a : 0;
+  const int ia = a < 6 ? a : 0, ib = b < 6 ? b : 0;
+  // Step t = n - 2 - j: even t holds L transposed (b in, a out), odd t natural (a in, b out)
+  const int nst = n - 1;
+  double v = b < 6 ? yb[6 * (n - 1) + ib] : 0.0;          // z_last[b]
+  double Lp[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) Ln[j] = (t0 + 8 + j < nst && act) ? d.Lc[36 * (int64_t)(bgn + len - 1 - (t0 + 8 + j)) + ((j & 1) ? el : elT)] : 0.0;
+  for (int j = 0; j < 8; ++j) Lp[j] = (j < nst && act) ? d.Lc[36 * (lc0 + n - 1 - j) + ((j & 1) ? el : elT)] : 0.0;
+  for (int t0 = 0; t0 < nst; t0 += 8) {
+    double Ln[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int k = len - 2 - (t0 + j);
-        if (k >= 0) {
-          if ((j & 1) == 0) {
-            const double sum = octet_allsum(Lp[j] * v);
-            v = yb[6 * k + ia] - sum;
-            if (b == 0 && a < 6) yb[6 * k + a] = v;
-          } else {
-            const double sum = stride8_allsum(Lp[j] * v);
-            v = yb[6 * k + ib] - sum;
-            if (a == 0 && b < 6) yb[6 * k + b] = v;
-          }
+    for (int j = 0; j < 8; ++j) Ln[j] = (t0 + 8 + j < nst && act) ? d.Lc[36 * (lc0 + n - 1 - (t0 + 8 + j)) + ((j & 1) ? el : elT)] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int k = n - 2 - (t0 + j);
+      if (k >= 0) {
+        if ((j & 1) == 0) {
+          const double sum = octet_allsum(Lp[j] * v);
+          v = yb[6 * k + ia] - sum;
+          if (b == 0 && a < 6) yb[6 * k + a] = v;
+        } else {
+          const double sum = stride8_allsum(Lp[j] * v);
+          v = yb[6 * k + ib] - sum;
+          if (a == 0 && b < 6) yb[6 * k + b] = v;
         }
       }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) Lp[j] = Ln[j];
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    for (int k = lane; k < len; k += 64) {
-      double* dst = z + 6 * (int64_t)d.pc_pose[bgn + k];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) dst[i] = yb[6 * k + i];
+    for (int j = 0; j < 8; ++j) Lp[j] = Ln[j];
+  }
+}
+
+__device__ __forceinline__ void wave_lds_sync() {      // LDS writes of this wave visible to its other lanes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// yb [len][6] (r of the chain, staged by ALL threads of the workgroup before the call) -> z.  Called by every thread of the workgroup
+// (blockDim = 64 * pc_nwave); bnd: [16][6] doubles of LDS for the boundary vectors.  Ends with a barrier.
+__device__ void pchain_solve_partitioned(const BADev& d, int bgn, int len, double* yb, double* bnd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int G = pc_seg_len(len, nwave), S = (len + G - 1) / G;
+  const int k0 = wave * G, n = wave < S ? (len - k0 < G ? len - k0 : G) : 0;
+  const int64_t c0 = (int64_t)bgn + k0;                          // chain position of the segment's first pose
+  const int pr_k = lane / 6, pr_a = lane - 6 * pr_k;             // lane -> (position inside a round of 10, row) for the recurrence-free passes
+  __syncthreads();
+  if (n > 0) pseg_forward(d, c0, n, yb + 6 * k0);
+  __syncthreads();
+  if (wave == 0 && S > 1) {                                      // Y_s = true y at the last position of segment s, s = 0 .. S-2 -> bnd[6 s]
+    const int a = lane < 6 ? lane : 0;
+    double Y = yb[6 * (G - 1) + a];
+    if (lane < 6) bnd[a] = Y;
+    double row[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) row[i] = S > 2 ? d.Pf[36 * ((int64_t)bgn + 2 * G - 1) + 6 * a + i] : 0.0;
+    for (int s = 1; s <= S - 2; ++s) {
+      const int e = (s + 1) * G - 1;
+      double nx[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) nx[i] = s + 1 <= S - 2 ? d.Pf[36 * ((int64_t)bgn + (s + 2) * G - 1) + 6 * a + i] : 0.0;
+      double acc = yb[6 * e + a];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc += row[i] * __shfl(Y, i, 64);
+      Y = acc;
+      if (lane < 6) bnd[6 * s + a] = Y;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) row[i] = nx[i];
     }
-    __builtin_amdgcn_wave_barrier();
+  }
+  __syncthreads();
+  if (n > 0) {
+    if (wave > 0) {                                              // y_k = yhat_k + P_k y_in
+      double yin[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) yin[i] = bnd[6 * (wave - 1) + i];
+      for (int base = 0; base < n; base += 10) {
+        const int k = base + pr_k;
+        if (lane < 60 && k < n) {
+          const double* P = d.Pf + 36 * (c0 + k) + 6 * pr_a;
+          double acc = yb[6 * (k0 + k) + pr_a];
+#pragma unroll
+          for (int i = 0; i < 6; ++i) acc += P[i] * yin[i];
+          yb[6 * (k0 + k) + pr_a] = acc;
+        }
+      }
+      wave_lds_sync();
+    }
+    for (int base = 0; base < n; base += 10) {                   // w_k = Dinv_k y_k  (a round reads its 10 positions, then writes them)
+      const int k = base + pr_k;
+      const bool on = lane < 60 && k < n;
+      double w = 0.0;
+      if (on) {
+        const double* D = d.Minv + 36 * (c0 + k) + 6 * pr_a;
+        const double* y = yb + 6 * (k0 + k);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) w += D[i] * y[i];
+      }
+      wave_lds_sync();
+      if (on) yb[6 * (k0 + k) + pr_a] = w;
+    }
+    wave_lds_sync();
+    pseg_backward(d, c0, n, yb + 6 * k0);
+  }
+  __syncthreads();
+  if (wave == 0 && S > 1) {                                      // Z_s = true z at the first position of segment s, s = S-1 .. 1 -> bnd[6 s]
+    const int a = lane < 6 ? lane : 0;
+    double Z = yb[6 * ((S - 1) * G) + a];
+    if (lane < 6) bnd[6 * (S - 1) + a] = Z;
+    double row[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) row[i] = S > 2 ? d.Qb[36 * ((int64_t)bgn + (S - 2) * G) + 6 * a + i] : 0.0;
+    for (int s = S - 2; s >= 1; --s) {
+      const int f = s * G;
+      double nx[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) nx[i] = s - 1 >= 1 ? d.Qb[36 * ((int64_t)bgn + (s - 1) * G) + 6 * a + i] : 0.0;
+      double acc = yb[6 * f + a];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc += row[i] * __shfl(Z, i, 64);
+      Z = acc;
+      if (lane < 6) bnd[6 * s + a] = Z;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) row[i] = nx[i];
+    }
+  }
+  __syncthreads();
+  if (n > 0 && wave < S - 1) {                                   // z_k = zhat_k + Q_k z_in
+    double zin[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) zin[i] = bnd[6 * (wave + 1) + i];
+    for (int base = 0; base < n; base += 10) {
+      const int k = base + pr_k;
+      if (lane < 60 && k < n) {
+        const double* Q = d.Qb + 36 * (c0 + k) + 6 * pr_a;
+        double acc = yb[6 * (k0 + k) + pr_a];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) acc += Q[i] * zin[i];
+        yb[6 * (k0 + k) + pr_a] = acc;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// P_k and Q_k of the partitioned substitutions (see above) for every chain position, from Lc: one workgroup per chain, one wave per segment,
+// G dependent 6x6 products each way.  Once per Levenberg trial, behind k_pchain_factor.
+__global__ __launch_bounds__(1024) void k_pchain_prefix(BADev d) {
+  __shared__ double scr[16][36];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int bgn = d.pc_off[c], len = d.pc_off[c + 1] - bgn;
+  const int G = pc_seg_len(len, nwave), S = (len + G - 1) / G;
+  if (wave >= S || S < 2) return;
+  const int k0 = wave * G, n = len - k0 < G ? len - k0 : G;
+  const int a = lane >> 3, b = lane & 7;
+  const bool act = a < 6 && b < 6;
+  const int ia = act ? a : 0, ib = act ? b : 0;
+  double* P = scr[wave];
+  if (wave > 0) {                       // P_{k0} = -L_{k0} ; P_k = -L_k P_{k-1}
+    double v = act ? -d.Lc[36 * ((int64_t)bgn + k0) + 6 * ia + ib] : 0.0;
+    if (act) d.Pf[36 * ((int64_t)bgn + k0) + 6 * a + b] = v;
+    double Lr[6];
+#pragma unroll
+    for (int m = 0; m < 6; ++m) Lr[m] = n > 1 ? d.Lc[36 * ((int64_t)bgn + k0 + 1) + 6 * ia + m] : 0.0;
+    for (int j = 1; j < n; ++j) {
+      double Ln[6];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) Ln[m] = j + 1 < n ? d.Lc[36 * ((int64_t)bgn + k0 + j + 1) + 6 * ia + m] : 0.0;
+      if (act) P[6 * a + b] = v;
+      wave_lds_sync();
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) t += Lr[m] * P[6 * m + ib];
+      wave_lds_sync();
+      v = -t;
+      if (act) d.Pf[36 * ((int64_t)bgn + k0 + j) + 6 * a + b] = v;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) Lr[m] = Ln[m];
+    }
+  }
+  if (wave < S - 1) {                   // Q_e = -L_{e+1}^T ; Q_k = -L_{k+1}^T Q_{k+1}     (e = last position of the segment)
+    const int e = k0 + n - 1;
+    double v = act ? -d.Lc[36 * ((int64_t)bgn + e + 1) + 6 * ib + ia] : 0.0;
+    if (act) d.Qb[36 * ((int64_t)bgn + e) + 6 * a + b] = v;
+    double Lr[6];                       // column a of L_{k+1}
+#pragma unroll
+    for (int m = 0; m < 6; ++m) Lr[m] = n > 1 ? d.Lc[36 * ((int64_t)bgn + e) + 6 * m + ia] : 0.0;
+    for (int k = e - 1; k >= k0; --k) {
+      double Ln[6];
+#pragma unroll
+      for (int m = 0; m < 6; ++m) Ln[m] = k - 1 >= k0 ? d.Lc[36 * ((int64_t)bgn + k) + 6 * m + ia] : 0.0;
+      if (act) P[6 * a + b] = v;
+      wave_lds_sync();
+      double t = 0.0;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) t += Lr[m] * P[6 * m + ib];
+      wave_lds_sync();
+      v = -t;
+      if (act) d.Qb[36 * ((int64_t)bgn + k) + 6 * a + b] = v;
+#pragma unroll
+      for (int m = 0; m < 6; ++m) Lr[m] = Ln[m];
+    }
   }
 }
 
@@ -564,7 +717,7 @@ __device__ void pchain_apply_lds(const BADev& d, const double* __restrict__ r, d
 // staged for every point 57.6 us; this form 40.3 us; factors requested TWO steps ahead 48 us (170 VGPRs); separate launches for static tiles
 // (no chain code) and dynamic tiles (factors staged) 23 + 22 us.
 template <int MODE>
-__global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const double* __restrict__ v) {
+__global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const double* __restrict__ v, const double* __restrict__ v2) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (MODE == 0 && d.flags[1]) return;     // PCG already converged: the launches queued behind it are no-ops
   const Tile T = d.tiles[d.tile_order[blockIdx.x]];        // tiles with the longest landmark chains first: their serial solves would be the tail of the launch
@@ -578,7 +731,14 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
   const int tid = threadIdx.x;
   for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) u[i] = 0.0;
   stage_slot_w_pts(d, T, slotW, pts);
-  if (MODE != 1)
+  if (MODE == 0) {                         // the search direction of this PCG iteration: p = z + beta p_old (v = z, v2 = p_old; k_pcg_q stores it)
+    const double beta = d.scal[S_BETA];
+    for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) {
+      const int64_t g = 6 * (int64_t)d.tile_pose[T.slot_begin + i / 6] + i % 6;
+      vs[i] = v[g] + beta * v2[g];
+    }
+  }
+  if (MODE == 2)
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) vs[i] = v[6 * (int64_t)d.tile_pose[T.slot_begin + i / 6] + i % 6];
   if (MODE != 2)
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) qs[i] = 0.0;
@@ -732,82 +892,138 @@ __device__ __forceinline__ void hpp_mv(const BADev& d, int p, const double* v, d
   }
 }
 
-// bs = bp - qs ; x = 0 ; r = bs ; z = Minv r ; p = z ; rz = rz0 = r.z       (single workgroup)
-__global__ __launch_bounds__(1024) void k_pcg_init(BADev d) {
-  extern __shared__ __attribute__((aligned(16))) double pc_strips[];
-  __shared__ double lds[17];
-  const int64_t n = 6 * (int64_t)d.P;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const double r = d.bp[i] - d.qs[i];
-    d.bs[i] = r; d.rp[i] = r; d.xp[i] = 0;
-  }
-  __syncthreads();
-  if (d.pc_waves) pchain_apply_lds(d, d.rp, d.zp, pc_strips); else pchain_apply(d, d.rp, d.zp);
-  __syncthreads();
-  double acc = 0;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) { const double z = d.zp[i]; d.pp[i] = z; acc += d.rp[i] * z; }
-  acc = block_sum1(acc, lds);
-  if (threadIdx.x == 0) { d.scal[S_RZ] = acc; d.scal[S_RZ0] = acc; d.scal[S_RZNEW] = acc; d.flags[1] = (acc > 0) ? 0 : 1; d.flags[2] = 0; }
-}
+// ---- The vector phases of a PCG iteration, spread over the chip.
+// Round 2 ran them in ONE workgroup (k_pcg_vec: (Hpp + lambda) p - qs, two dot products, three axpys and the chain preconditioner between
+// barriers): 127 us per iteration on the 2 190-pose graph, most of it a single CU chasing pe_off -> pe_idx -> ep_j -> p through HBM with
+// 1 024 threads.  Now an iteration is three launches, none of them serial in the number of poses:
+//   k_schur_tile<0>   part_q = B Hll^-1 B^T p         one workgroup per tile   (p = z + beta p_old formed while it is staged)
+//   k_pcg_q           q = (Hpp + lambda) p - sum part_q, p stored, p.q per workgroup     one WAVE per pose
+//   k_pcg_chain<0>    alpha = rz / p.q ; x += alpha p ; r -= alpha q ; z = M^-1 r ; r.z per chain     one workgroup (one wave) per pose chain;
+//                     the workgroup that arrives last adds the chains' r.z in chain order: beta, convergence flags.
+// p lives in two buffers (pp, pp2) that alternate: k_pcg_q reads its neighbours' p_old while other workgroups store p.  All sums have a
+// fixed order (per-workgroup partials added by index): run-independent bits, and identical bits on every rank of a sharded solve.
 
-// One CG update given qs = Hpl Hll^-1 Hlp p.  Single workgroup, one thread per vector element
-// (6P elements) so that every phase is a short, fully parallel strip between barriers.
-__device__ __forceinline__ double hpp_row(const BADev& d, int64_t p, int row, const double* v, double lambda) {
-  const double* Hm = d.Hpp + 36 * p + 6 * row;
-  const double* pv = v + 6 * p;
-  double s = lambda * pv[row];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) s += Hm[j] * pv[j];
-  for (int k = d.pe_off[p]; k < d.pe_off[p + 1]; ++k) {
-    const int ent = d.pe_idx[k];
-    const int e = ent >> 1, side = ent & 1;
-    const double* He = d.Hpp_ep + 36 * (int64_t)e;       // block (i,j)
-    if (side == 0) {
-      const double* vj = v + 6 * (int64_t)d.ep_j[e];
-#pragma unroll
-      for (int b = 0; b < 6; ++b) s += He[row * 6 + b] * vj[b];
-    } else {
-      const double* vi = v + 6 * (int64_t)d.ep_i[e];
-#pragma unroll
-      for (int b = 0; b < 6; ++b) s += He[b * 6 + row] * vi[b];
-    }
-  }
-  return s;
-}
-
-__global__ __launch_bounds__(1024) void k_pcg_vec(BADev d, double lambda, double tol2) {
-  extern __shared__ __attribute__((aligned(16))) double pc_strips[];
-  __shared__ double lds[17];
+// q = (Hpp + lambda I) p + off-diagonal EdgeSE3 blocks - qs, with p = z + beta p_old ; partial p.q of the workgroup's 4 poses
+__global__ __launch_bounds__(256) void k_pcg_q(BADev d, double lambda, int par, int gather) {
+  __shared__ double lds[4];
   if (d.flags[1]) return;                       // converged earlier: no-op
-  const int64_t n = 6 * (int64_t)d.P;
-  double acc = 0;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-    const double q = hpp_row(d, i / 6, (int)(i % 6), d.pp, lambda) - d.qs[i];
-    d.qp[i] = q;
-    acc += d.pp[i] * q;
+  const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int p = blockIdx.x * 4 + wv;
+  const double* __restrict__ pold = par ? d.pp2 : d.pp;
+  double* __restrict__ pnew = par ? d.pp : d.pp2;
+  const double beta = d.scal[S_BETA];
+  double dot = 0.0;
+  if (p < d.P) {
+    double qsum[6];
+    if (gather) wave_gather<6>(d.part_q, d.NPS, d.ps_off, d.ps_idx, p, qsum);      // (sharded: gathered and all-reduced into qs by the launches before)
+    else {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) qsum[i] = d.qs[6 * (int64_t)p + i];
+    }
+    const int l = lane < 6 ? lane : 0;
+    const double pn = d.zp[6 * (int64_t)p + l] + beta * pold[6 * (int64_t)p + l];
+    if (lane < 6) pnew[6 * (int64_t)p + lane] = pn;
+    const double* Hm = d.Hpp + 36 * (int64_t)p + 6 * l;
+    double q = lambda * pn;
+#pragma unroll
+    for (int j = 0; j < 6; ++j) q += Hm[j] * __shfl(pn, j, 64);
+    for (int k = d.pe_off[p]; k < d.pe_off[p + 1]; ++k) {
+      const int ent = d.pe_idx[k];
+      const int e = ent >> 1, side = ent & 1;
+      const double* He = d.Hpp_ep + 36 * (int64_t)e;       // block (i,j)
+      const int64_t o = side == 0 ? d.ep_j[e] : d.ep_i[e];
+      const double on = d.zp[6 * o + l] + beta * pold[6 * o + l];
+#pragma unroll
+      for (int b = 0; b < 6; ++b) q += (side == 0 ? He[l * 6 + b] : He[b * 6 + l]) * __shfl(on, b, 64);
+    }
+    double ql = qsum[0];
+#pragma unroll
+    for (int i = 1; i < 6; ++i) ql = (l == i) ? qsum[i] : ql;
+    q -= ql;
+    if (lane < 6) { d.qp[6 * (int64_t)p + lane] = q; dot = pn * q; }
   }
-  const double pq = block_sum1(acc, lds);
-  const double rz = d.scal[S_RZ];
-  const double alpha = rz / pq;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) {
-    d.xp[i] += alpha * d.pp[i];
-    d.rp[i] -= alpha * d.qp[i];
+  dot = wave_sum(dot);
+  if (lane == 0) lds[wv] = dot;
+  __syncthreads();
+  if (threadIdx.x == 0) d.part_pq[blockIdx.x] = (lds[0] + lds[1]) + (lds[2] + lds[3]);
+}
+
+// INIT:  bs = bp - qs ; x = 0 ; r = bs ; z = M^-1 r ; p = z ; rz = rz0 = r.z ; beta = 0
+// else:  one CG update given q (k_pcg_q): alpha = rz / p.q ; x += alpha p ; r -= alpha q ; z = M^-1 r ; rz_new ; beta = rz_new / rz
+// One workgroup per pose chain (64 * pc_nwave threads: the chain's segments, see pchain_solve_partitioned); the chain's r is formed straight
+// into its LDS strip.  LDS: strip [6 * pc_maxlen] | boundary vectors [96] | reduction scratch [24]
+template <int INIT>
+__global__ __launch_bounds__(1024) void k_pcg_chain(BADev d, double tol2, int par, int npart) {
+  extern __shared__ __attribute__((aligned(16))) double strip[];
+  if (!INIT && d.flags[1]) return;
+  const int c = blockIdx.x, tid = threadIdx.x, nth = blockDim.x;
+  const bool in_lds = d.pc_lds != 0;
+  double* bnd = strip + (in_lds ? 6 * (size_t)d.pc_maxlen : 0);
+  double* red = bnd + 96;
+  const int bgn = d.pc_off[c], len = d.pc_off[c + 1] - bgn;
+  double alpha = 0.0, pq = 0.0, rz = 0.0;
+  if (!INIT) {
+    double a = 0.0;
+    for (int i = tid; i < npart; i += nth) a += d.part_pq[i];
+    pq = block_sum1(a, red);
+    rz = d.scal[S_RZ];
+    alpha = rz / pq;
+  }
+  const double* __restrict__ pn = par ? d.pp : d.pp2;      // p of this iteration (k_pcg_q stored it)
+  for (int i = tid; i < 6 * len; i += nth) {
+    const int k = i / 6;
+    const int64_t g = 6 * (int64_t)d.pc_pose[bgn + k] + (i - 6 * k);
+    double r;
+    if (INIT) { r = d.bp[g] - d.qs[g]; d.bs[g] = r; d.xp[g] = 0.0; }
+    else { d.xp[g] += alpha * pn[g]; r = d.rp[g] - alpha * d.qp[g]; }
+    d.rp[g] = r;
+    if (in_lds) strip[i] = r;
+  }
+  if (in_lds) pchain_solve_partitioned(d, bgn, len, strip, bnd);
+  else {                                             // (a chain too long for the LDS: one wave, vectors in global memory)
+    __threadfence();
+    __syncthreads();
+    if (tid < 64) pchain_apply(d, c, d.rp, d.zp);
+    __threadfence();
+    __syncthreads();
+  }
+  double acc = 0.0;
+  for (int i = tid; i < 6 * len; i += nth) {
+    const int k = i / 6;
+    const int64_t g = 6 * (int64_t)d.pc_pose[bgn + k] + (i - 6 * k);
+    double z;
+    if (in_lds) { z = strip[i]; d.zp[g] = z; } else z = d.zp[g];
+    if (INIT) d.pp[g] = z;
+    acc += d.rp[g] * z;
+  }
+  acc = block_sum1(acc, red);
+  // ---- the chain that arrives last closes the iteration (its sum runs over the chains in index order, whoever it is)
+  __shared__ int s_last;
+  if (tid == 0) {
+    d.part_rz[c] = acc;
+    __threadfence();
+    s_last = atomicAdd(d.flags + 3, 1) == (int)gridDim.x - 1;
   }
   __syncthreads();
-  if (d.pc_waves) pchain_apply_lds(d, d.rp, d.zp, pc_strips); else pchain_apply(d, d.rp, d.zp);     // z = M^-1 r  (block-tridiagonal along the pose chains)
-  __syncthreads();
-  acc = 0;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) acc += d.rp[i] * d.zp[i];
-  const double rznew = block_sum1(acc, lds);
-  const double beta = rznew / rz;
-  for (int64_t i = threadIdx.x; i < n; i += blockDim.x) d.pp[i] = d.zp[i] + beta * d.pp[i];
-  if (threadIdx.x == 0) {
-    d.scal[S_RZ] = rznew; d.scal[S_RZNEW] = rznew; d.scal[S_PQ] = pq;
-    int f = 0;
-    if (!(pq > 0) || !(rznew == rznew)) f = 2;          // breakdown
-    else if (rznew <= tol2 * d.scal[S_RZ0]) f = 1;      // converged
-    d.flags[1] = f;
-    d.flags[2] += 1;
+  if (!s_last) return;
+  __threadfence();
+  double a = 0.0;
+  for (int i = tid; i < (int)gridDim.x; i += nth) a += __builtin_nontemporal_load(d.part_rz + i);
+  const double rznew = block_sum1(a, red);
+  if (tid == 0) {
+    d.flags[3] = 0;
+    if (INIT) {
+      d.scal[S_RZ] = rznew; d.scal[S_RZ0] = rznew; d.scal[S_RZNEW] = rznew; d.scal[S_BETA] = 0.0;
+      d.flags[1] = (rznew > 0) ? 0 : 1; d.flags[2] = 0;
+    } else {
+      d.scal[S_BETA] = rznew / rz;
+      d.scal[S_RZ] = rznew; d.scal[S_RZNEW] = rznew; d.scal[S_PQ] = pq;
+      int f = 0;
+      if (!(pq > 0) || !(rznew == rznew)) f = 2;          // breakdown
+      else if (rznew <= tol2 * d.scal[S_RZ0]) f = 1;      // converged
+      d.flags[1] = f;
+      d.flags[2] += 1;
+    }
   }
 }
 
@@ -1072,16 +1288,17 @@ void launch_factor(const BADev& d, double lambda, hipStream_t s, const Reducer& 
     hipLaunchKernelGGL(k_precond_finalize<2>, g, b, 0, s, d, lambda);
   }
   hipLaunchKernelGGL(k_pchain_factor, dim3(d.n_pchains), dim3(64), 0, s, d);
+  if (d.pc_lds && d.pc_nwave > 1) hipLaunchKernelGGL(k_pchain_prefix, dim3(d.n_pchains), dim3(64 * d.pc_nwave), 0, s, d);
 }
 
 void launch_reduced_rhs(const BADev& d, hipStream_t s, const Reducer& R) {
-  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)nullptr);
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)nullptr, (const double*)nullptr);
   hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs, 0);
   if (d.sharded) R(d.qs, 6 * (int64_t)d.P);
 }
 
 static size_t pc_strip_bytes(const BADev& d) {
-  const size_t bytes = (size_t)d.pc_waves * 6 * (size_t)d.pc_maxlen * sizeof(double);
+  const size_t bytes = ((d.pc_lds ? 6 * (size_t)d.pc_maxlen : 0) + 96 + 24) * sizeof(double);
   // more than the default 64 KB of dynamic LDS: tell the runtime.  The attribute is per DEVICE (a process may hold BA contexts on
   // several GPUs): the size already granted is remembered per device id; the calls are idempotent.
   static std::atomic<size_t> raised[64];
@@ -1089,24 +1306,28 @@ static size_t pc_strip_bytes(const BADev& d) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
     if (bytes > raised[dev].load(std::memory_order_relaxed)) {
-      const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_init), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
-      const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_vec), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      const hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_chain<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      const hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(k_pcg_chain<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
       if (e1 == hipSuccess && e2 == hipSuccess) raised[dev].store(bytes, std::memory_order_relaxed);
     }
   }
   return bytes;
 }
-void launch_pcg_init(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_pcg_init, dim3(1), dim3(1024), pc_strip_bytes(d), s, d); }
+void launch_pcg_init(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_pcg_chain<1>, dim3(d.n_pchains), dim3(64 * d.pc_nwave), pc_strip_bytes(d), s, d, 0.0, 0, 0); }
 
-void launch_pcg_iter(const BADev& d, double lambda, double tol2, hipStream_t s, const Reducer& R) {
-  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<0>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.pp);
-  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs, 1);
-  if (d.sharded) R(d.qs, 6 * (int64_t)d.P);      // the one exchange per CG iteration: 6P doubles
-  hipLaunchKernelGGL(k_pcg_vec, dim3(1), dim3(1024), pc_strip_bytes(d), s, d, lambda, tol2);
+void launch_pcg_iter(const BADev& d, double lambda, double tol2, int parity, hipStream_t s, const Reducer& R) {
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<0>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.zp, (const double*)(parity ? d.pp2 : d.pp));
+  const int nq = (d.P + 3) / 4;
+  if (d.sharded) {
+    hipLaunchKernelGGL(k_gather_q, dim3(nq), dim3(256), 0, s, d, d.qs, 1);
+    R(d.qs, 6 * (int64_t)d.P);                     // the one exchange per CG iteration: 6P doubles
+    hipLaunchKernelGGL(k_pcg_q, dim3(nq), dim3(256), 0, s, d, lambda, parity, 0);
+  } else hipLaunchKernelGGL(k_pcg_q, dim3(nq), dim3(256), 0, s, d, lambda, parity, 1);
+  hipLaunchKernelGGL(k_pcg_chain<0>, dim3(d.n_pchains), dim3(64 * d.pc_nwave), pc_strip_bytes(d), s, d, tol2, parity, nq);
 }
 
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s) {
-  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<2>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.xp);
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<2>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.xp, (const double*)nullptr);
   const int nb = red_blocks(d);
   hipLaunchKernelGGL(k_update, dim3(nb), dim3(1024), 0, s, d, lambda, ortho ? 1 : 0);
   hipLaunchKernelGGL(k_reduce_part, dim3(1), dim3(256), 0, s, d, nb, 0);

@@ -379,8 +379,10 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     int maxlen = 1;
     for (int c = 0; c < n_pchains; ++c) maxlen = std::max(maxlen, (int)(pc_off[c + 1] - pc_off[c]));
     d.pc_maxlen = maxlen;
-    d.pc_waves = (int)std::min<size_t>(std::min(n_pchains, 16), (size_t)(144 * 1024) / (48 * (size_t)maxlen));     // (up to 144 of the 160 KB of a CU: launch_pcg_* raise the kernels' dynamic-LDS limit)
-    if (std::getenv("VDO_BA_CHAIN_GLOBAL")) d.pc_waves = 0;
+    d.pc_lds = 48 * (size_t)maxlen <= (size_t)(144 * 1024) ? 1 : 0;     // (up to 144 of the 160 KB of a CU: launch_pcg_* raise the kernels' dynamic-LDS limit)
+    if (std::getenv("VDO_BA_CHAIN_GLOBAL")) d.pc_lds = 0;
+    d.pc_nwave = d.pc_lds ? std::min(16, std::max(1, (maxlen + 7) / 8)) : 1;      // segments of >= 8 positions, one wave each
+    if (const char* e = std::getenv("VDO_BA_CHAIN_WAVES")) d.pc_nwave = std::min(16, std::max(1, std::atoi(e)));
   }
   UP(pc_off, pc_off.data(), pc_off.size()); UP(pc_pose, pc_pose.data(), P); UP(pc_edge, pc_edge.data(), P);
   const double* Z = nullptr;
@@ -394,9 +396,10 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(part_red, Z, 256);
   UP(Dinv, Z, 9 * (size_t)L); UP(Gl, Z, 9 * (size_t)L); UP(Gdiag, Z, 9 * (size_t)L); UP(Goff, Z, 9 * (size_t)L);
   UP(xl, Z, 3 * (size_t)L); UP(dscal, Z, (size_t)std::max(L, 1));
-  UP(Minv, Z, 36 * (size_t)P); UP(Lc, Z, 36 * (size_t)P); UP(Adg, Z, 36 * (size_t)P);
-  UP(xp, Z, 6 * (size_t)P); UP(rp, Z, 6 * (size_t)P); UP(zp, Z, 6 * (size_t)P); UP(pp, Z, 6 * (size_t)P);
+  UP(Minv, Z, 36 * (size_t)P); UP(Lc, Z, 36 * (size_t)P); UP(Pf, Z, 36 * (size_t)P); UP(Qb, Z, 36 * (size_t)P); UP(Adg, Z, 36 * (size_t)P);
+  UP(xp, Z, 6 * (size_t)P); UP(rp, Z, 6 * (size_t)P); UP(zp, Z, 6 * (size_t)P); UP(pp, Z, 6 * (size_t)P); UP(pp2, Z, 6 * (size_t)P);
   UP(qp, Z, 6 * (size_t)P); UP(bs, Z, 6 * (size_t)P); UP(qs, Z, 6 * (size_t)P);
+  UP(part_pq, Z, (size_t)(P + 3) / 4 + 1); UP(part_rz, Z, (size_t)n_pchains + 1);
   UP(part_q, Z, 6 * (size_t)NPS); UP(part_m, Z, 21 * (size_t)NPS);
   UP(scal, Z, S_COUNT);
   const int32_t* ZI = nullptr;
