@@ -15,6 +15,8 @@ struct vdo_ba {
   double* h_scal = nullptr;       // pinned
   int32_t* h_flags = nullptr;     // pinned
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  hipStream_t side = nullptr;     // second stream of a solve: the reduced right-hand side beside the pose-chain factorisation (ba_solve.hip)
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // permutations between the caller's numbering and the tile-major device numbering
   std::vector<int32_t> pt_old_of_new, pt_new_of_old;
   std::vector<int32_t> eb_old_of_new, et_old_of_new;

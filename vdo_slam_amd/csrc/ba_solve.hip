@@ -327,68 +327,90 @@ __global__ __launch_bounds__(256) void k_precond_finalize(BADev d, double lambda
 // M is SPD: blockdiag(S) minus the EdgeSE3 diagonal terms is the (PSD) Schur complement of the landmark
 // system, the EdgeSE3 terms themselves are J^T W J.  One thread per chain (a handful of chains, once per
 // Levenberg trial); Minv / Lc are indexed by chain position.
+// The workgroup is ONE wave, the loop body straight-line code:
+//  * the LDS hand-overs use a wave-scope fence, not __syncthreads - whose s_waitcnt vmcnt(0) makes every step wait for the loads it has
+//    just requested for the steps ahead and for its own stores of Lc / Minv;
+//  * no lane is masked off (lanes 36..63 repeat the work of lanes 0..27 and store the same values to the same places) and the inputs of the
+//    steps past the end are loads from clamped, valid addresses: with branches around the loads the compiler loses count of the loads in
+//    flight and waits for ALL of them in every step (measured: 1.04 us per step = one trip to HBM; the recurrence itself is a tenth of it).
+__device__ __forceinline__ void chain_wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 __global__ __launch_bounds__(64) void k_pchain_factor(BADev d) {
-  // one wave per chain; lane = 6*row + col of a 6x6 block (36 active lanes), blocks exchanged through LDS
+  // lane = 6*row + col of a 6x6 block, blocks exchanged through LDS
   __shared__ double sE[36], sD[36], sL[36];
   const int c = blockIdx.x, lane = threadIdx.x;
-  const bool act = lane < 36;
-  const int r = act ? lane / 6 : 0, q = act ? lane % 6 : 0;
+  const int ln = lane < 36 ? lane : lane - 36;
+  const int r = ln / 6, q = ln % 6;
   const int b = d.pc_off[c], e = d.pc_off[c + 1];
   bool bad = false;
-  // the inputs of a step (A_k, E_{k-1,k}) do not depend on the recursion: the next step's are requested while this one computes
-  // (pc_pose / pc_edge -> Adg / Hpp_ep is a two-level pointer chase through HBM, ~2 us per step when it sits on the critical path)
-  // (indices three steps ahead, values two: neither load waits for the other inside a step)
-  auto idx_p = [&](int k) -> int { return k < e ? d.pc_pose[k] : 0; };
-  auto idx_e = [&](int k) -> int { return (k < e && k > b) ? d.pc_edge[k] : -1; };
-  auto fetch_a = [&](int k, int p) -> double { return (k < e && act) ? d.Adg[36 * (int64_t)p + lane] : 0.0; };
+  // the inputs of a step (A_k, E_{k-1,k}) do not depend on the recursion and sit behind a two-level pointer chase through HBM
+  // (pc_pose / pc_edge -> Adg / Hpp_ep): they are requested a CHUNK of 8 steps ahead, their indices two chunks ahead, into register sets
+  // that rotate at the end of a chunk (a rotation inside every step would wait for the loads of that very step)
+  constexpr int CH = 8;
+  const double* __restrict__ Hbase = d.Ep > 0 ? d.Hpp_ep : d.Adg;      // (a graph without EdgeSE3: every entry is -1, the address only has to be valid)
+  auto idx_p = [&](int k) -> int { return d.pc_pose[k < e ? k : e - 1]; };
+  auto idx_e = [&](int k) -> int { const int t = d.pc_edge[k < e ? k : e - 1]; return k > b ? t : -1; };
+  auto fetch_a = [&](int p) -> double { return d.Adg[36 * (int64_t)p + ln]; };
   auto fetch_e = [&](int ent) -> double {
-    if (ent < 0 || !act) return 0.0;
-    const double* He = d.Hpp_ep + 36 * (int64_t)(ent >> 1);
-    return (ent & 1) ? He[q * 6 + r] : He[lane];                     // E = block (previous pose, this pose)
+    const int en = ent < 0 ? 0 : ent;
+    return Hbase[36 * (int64_t)(en >> 1) + ((en & 1) ? q * 6 + r : ln)];      // E = block (previous pose, this pose); ent < 0: unused
   };
-  int p_n2 = idx_p(b + 2), t_n2 = idx_e(b + 2);
-  double a_nx, e_nx, a_n2, e_n2;
-  { const int p0 = idx_p(b), p1 = idx_p(b + 1), t1 = idx_e(b + 1); a_nx = fetch_a(b, p0); e_nx = 0.0; a_n2 = fetch_a(b + 1, p1); e_n2 = fetch_e(t1); }
-  for (int k = b; k < e; ++k) {
-    double a = a_nx;
-    const double ev = e_nx;
-    a_nx = a_n2; e_nx = e_n2;
-    a_n2 = fetch_a(k + 2, p_n2); e_n2 = fetch_e(t_n2);
-    p_n2 = idx_p(k + 3); t_n2 = idx_e(k + 3);
-    if (k > b) {
-      if (act) sE[lane] = ev;
-      __syncthreads();
-      double t = 0;
+  int pi[CH], ti[CH];
+  double A[CH], E[CH];
 #pragma unroll
-      for (int m = 0; m < 6; ++m) t += sE[m * 6 + r] * sD[m * 6 + q];   // L = E^T Delta_prev^-1
-      if (act) { sL[lane] = t; d.Lc[36 * (int64_t)k + lane] = t; }
-      __syncthreads();
-      t = 0;
+  for (int j = 0; j < CH; ++j) { pi[j] = idx_p(b + j); ti[j] = idx_e(b + j); }
 #pragma unroll
-      for (int m = 0; m < 6; ++m) t += sL[r * 6 + m] * sE[m * 6 + q];   // Delta = A - L E
-      a -= t;
+  for (int j = 0; j < CH; ++j) { A[j] = fetch_a(pi[j]); E[j] = ti[j] < 0 ? 0.0 : fetch_e(ti[j]); }
+#pragma unroll
+  for (int j = 0; j < CH; ++j) { pi[j] = idx_p(b + CH + j); ti[j] = idx_e(b + CH + j); }
+  sD[ln] = 0.0;
+  for (int k0 = b; k0 < e; k0 += CH) {
+    double An[CH], En[CH];
+    int pn[CH], tn[CH];
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { An[j] = fetch_a(pi[j]); En[j] = fetch_e(ti[j]); }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) { pn[j] = idx_p(k0 + 2 * CH + j); tn[j] = idx_e(k0 + 2 * CH + j); }
+#pragma unroll
+    for (int j = 0; j < CH; ++j) {
+      const int k = k0 + j;
+      if (k < e) {
+        double a = A[j];
+        sE[ln] = E[j];                       // (0 at the head of the chain: L = 0, Delta = A)
+        chain_wave_sync();
+        // (dot products as two fused chains of three: the step is a latency chain, 4 dependent operations instead of 12)
+        double t = __builtin_fma(sE[12 + r], sD[12 + q], __builtin_fma(sE[6 + r], sD[6 + q], sE[r] * sD[q])) +
+                   __builtin_fma(sE[30 + r], sD[30 + q], __builtin_fma(sE[24 + r], sD[24 + q], sE[18 + r] * sD[18 + q]));   // L = E^T Delta_prev^-1
+        sL[ln] = t; d.Lc[36 * (int64_t)k + ln] = t;
+        chain_wave_sync();
+        t = __builtin_fma(sL[r * 6 + 2], sE[12 + q], __builtin_fma(sL[r * 6 + 1], sE[6 + q], sL[r * 6] * sE[q])) +
+            __builtin_fma(sL[r * 6 + 5], sE[30 + q], __builtin_fma(sL[r * 6 + 4], sE[24 + q], sL[r * 6 + 3] * sE[18 + q]));      // Delta = A - L E
+        a -= t;
+        // in-place Gauss-Jordan inverse (SPD: no pivoting) IN REGISTERS: the pivot is a v_readlane, its row and column come
+        // through ds_bpermute (no LDS round trip, no barrier), the reciprocal is v_rcp_f64 + two Newton steps running under the
+        // permutes - this is the preconditioner, not the solve: its rounding only has to be deterministic.
+        // A non-positive pivot flags the factorisation as failed.
+#pragma unroll
+        for (int kk = 0; kk < 6; ++kk) {
+          const double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), kk * 7), __builtin_amdgcn_readlane(__double2loint(a), kk * 7));
+          const double aik = __shfl(a, r * 6 + kk, 64), akj = __shfl(a, kk * 6 + q, 64);
+          if (!(pv > 0)) bad = true;
+          double rp = __builtin_amdgcn_rcp(pv);
+          rp = __builtin_fma(__builtin_fma(-pv, rp, 1.0), rp, rp);
+          rp = __builtin_fma(__builtin_fma(-pv, rp, 1.0), rp, rp);      // (the second step is free: the chain waits for the permutes - measured)
+          const double rowv = akj * rp, colv = -aik * rp, gen = a - aik * rowv;      // (selects, not branches: all four are a few cycles)
+          const double on_row = q == kk ? rp : rowv, off_row = q == kk ? colv : gen;
+          a = r == kk ? on_row : off_row;
+        }
+        sD[ln] = a; d.Minv[36 * (int64_t)k + ln] = a;
+        chain_wave_sync();
+      }
     }
-    // in-place Gauss-Jordan inverse (SPD: no pivoting) IN REGISTERS: the pivot is a v_readlane, its row and column come
-    // through ds_bpermute (no LDS round trip, no barrier), the reciprocal is v_rcp_f64 + two Newton steps running under the
-    // permutes - this is the preconditioner, not the solve: its rounding only has to be deterministic.
-    // A non-positive pivot flags the factorisation as failed.
 #pragma unroll
-    for (int kk = 0; kk < 6; ++kk) {
-      const double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), kk * 7), __builtin_amdgcn_readlane(__double2loint(a), kk * 7));
-      const double aik = __shfl(a, r * 6 + kk, 64), akj = __shfl(a, kk * 6 + q, 64);
-      if (!(pv > 0)) bad = true;
-      double rp = __builtin_amdgcn_rcp(pv);
-      rp = __builtin_fma(__builtin_fma(-pv, rp, 1.0), rp, rp);
-      rp = __builtin_fma(__builtin_fma(-pv, rp, 1.0), rp, rp);
-      double nv;
-      if (r == kk && q == kk) nv = rp;
-      else if (r == kk) nv = akj * rp;
-      else if (q == kk) nv = -aik * rp;
-      else nv = a - aik * (akj * rp);
-      a = nv;
-    }
-    if (act) { sD[lane] = a; d.Minv[36 * (int64_t)k + lane] = a; }
-    __syncthreads();
+    for (int j = 0; j < CH; ++j) { A[j] = An[j]; E[j] = ti[j] < 0 ? 0.0 : En[j]; pi[j] = pn[j]; ti[j] = tn[j]; }
   }
   if (bad && lane == 0) atomicOr(d.flags, 1);
 }
@@ -1276,7 +1298,11 @@ void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R) {
   if (d.sharded) R(d.scal + S_MAXDIAG, 1, 1);
 }
 
-void launch_factor(const BADev& d, double lambda, hipStream_t s, const Reducer& R) {
+// The factorisations of a Levenberg trial and the reduced right-hand side, which only needs the landmark factors.  The pose-chain
+// factorisation is a recurrence over the chain (a few workgroups, 0.7 us per step): on one GPU the reduced right-hand side (k_schur_tile<1>,
+// k_gather_q: every CU) runs beside it on the stream `side`, forked / joined with the two events.  Sharded solves keep one stream: the
+// exchanges of the all-reduce hook are ordered on it.
+void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const Reducer& R, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
   hipMemsetAsync(d.flags, 0, 4 * sizeof(int32_t), s);
   if (d.n_chains) hipLaunchKernelGGL(k_factor_chains, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, lambda);
   if (d.n_tiles) hipLaunchKernelGGL(k_precond_tile, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), (33 * (size_t)d.max_slots + 3 * VDO_TILE_PTS) * sizeof(double), s, d);
@@ -1287,14 +1313,15 @@ void launch_factor(const BADev& d, double lambda, hipStream_t s, const Reducer& 
     R(d.msum, 21 * (int64_t)d.P + 1);
     hipLaunchKernelGGL(k_precond_finalize<2>, g, b, 0, s, d, lambda);
   }
+  const bool two = side && fork && join && !d.sharded;
+  hipStream_t sr = two ? side : s;
+  if (two) { hipEventRecord(fork, s); hipStreamWaitEvent(side, fork, 0); }
   hipLaunchKernelGGL(k_pchain_factor, dim3(d.n_pchains), dim3(64), 0, s, d);
   if (d.pc_lds && d.pc_nwave > 1) hipLaunchKernelGGL(k_pchain_prefix, dim3(d.n_pchains), dim3(64 * d.pc_nwave), 0, s, d);
-}
-
-void launch_reduced_rhs(const BADev& d, hipStream_t s, const Reducer& R) {
-  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)nullptr, (const double*)nullptr);
-  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs, 0);
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), sr, d, (const double*)nullptr, (const double*)nullptr);
+  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, sr, d, d.qs, 0);
   if (d.sharded) R(d.qs, 6 * (int64_t)d.P);
+  if (two) { hipEventRecord(join, side); hipStreamWaitEvent(s, join, 0); }
 }
 
 static size_t pc_strip_bytes(const BADev& d) {

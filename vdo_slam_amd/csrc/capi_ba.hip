@@ -410,6 +410,9 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     return set_error(VDO_ERR_OOM, "hipHostMalloc failed");
   }
   hipEventCreate(&ba->ev0); hipEventCreate(&ba->ev1);
+  if (!std::getenv("VDO_BA_ONE_STREAM") && hipStreamCreateWithFlags(&ba->side, hipStreamNonBlocking) == hipSuccess) {
+    hipEventCreateWithFlags(&ba->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&ba->ev_join, hipEventDisableTiming);
+  } else ba->side = nullptr;
   if (hipStreamSynchronize(s) != hipSuccess) { vdo_ba_destroy(ba); return set_error(VDO_ERR_NO_DEVICE, "upload failed: %s", hipGetErrorString(hipGetLastError())); }
   *out = ba;
   return VDO_OK;
@@ -423,6 +426,9 @@ extern "C" int vdo_ba_destroy(vdo_ba* ba) {
   if (ba->h_flags) hipHostFree(ba->h_flags);
   if (ba->ev0) hipEventDestroy(ba->ev0);
   if (ba->ev1) hipEventDestroy(ba->ev1);
+  if (ba->ev_fork) hipEventDestroy(ba->ev_fork);
+  if (ba->ev_join) hipEventDestroy(ba->ev_join);
+  if (ba->side) hipStreamDestroy(ba->side);
   delete ba;
   return VDO_OK;
 }
