@@ -257,3 +257,38 @@ def test_static_only_graph_without_pose_pose_edges(ctx, oracle):
     assert abs(st.final_chi2 - st_o.final_chi2) <= 1e-6 * st_o.final_chi2
     assert np.abs(pose - pose_o).max() <= 1e-4 * max(1.0, np.abs(pose_o).max())
     ba.close()
+
+
+@pytest.mark.parametrize("n_frames", [12, 20, 40, 150])
+def test_pose_chain_solver_is_the_same_operator_however_it_is_partitioned(ctx, oracle, n_frames, monkeypatch):
+    """The chain preconditioner (block LDL^T along the pose chains) is applied with the chain cut into segments, one wave each
+    (ba_solve.hip pchain_solve_partitioned: zero-input recurrences + prefix products P_k / Q_k + boundary pass).  One segment
+    (the plain recurrence), the default cut, the finest cut (8 positions per segment, last one ragged: 12 = 8 + 4, 20 = 8 + 8 + 4,
+    150 = 15 x 10) and the global-memory path for chains too long for the LDS are the same operator up to rounding: the LM takes the
+    same iterations and trials to the same chi2 and estimates - and those are the oracle's (direct solve)."""
+    from vdo_slam_amd.ba import BatchBA
+    g = synth.make_ba_graph(n_frames, 40 * n_frames, 2, 30, seed=11)
+    gc, keep = K.graph_to_c(g)
+    opt = K.LMOptionsC(6, -1.0, 0, 0, 0.0, 0)
+    st_o = K.LMStatsC()
+    pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(pose_o), K._dp(point_o), C.byref(st_o)) == 0
+    runs = {}
+    for name, env in (("one_segment", {"VDO_BA_CHAIN_WAVES": "1"}), ("default", {}), ("finest", {"VDO_BA_CHAIN_WAVES": "16"}), ("global", {"VDO_BA_CHAIN_GLOBAL": "1"})):
+        for k_ in ("VDO_BA_CHAIN_WAVES", "VDO_BA_CHAIN_GLOBAL"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)                     # (read when the graph is uploaded)
+        ba = BatchBA(ctx, g)
+        st = ba.optimize(max_iterations=6, gain_threshold=-1.0, solver=2)
+        pose, point = ba.estimates()
+        runs[name] = (st.iterations, st.total_trials, st.final_chi2, pose.copy(), point.copy())
+        ba.close()
+    ref = runs["one_segment"]
+    assert ref[0] == st_o.iterations and ref[1] == st_o.total_trials
+    assert abs(ref[2] - st_o.final_chi2) <= 1e-6 * st_o.final_chi2
+    for name, r in runs.items():
+        assert r[0] == ref[0] and r[1] == ref[1], name
+        assert abs(r[2] - ref[2]) <= 1e-9 * ref[2], name
+        assert np.abs(r[3] - ref[3]).max() <= 1e-8 and np.abs(r[4] - ref[4]).max() <= 1e-7, name
+        assert np.abs(r[3] - pose_o).max() <= 1e-4 * max(1.0, np.abs(pose_o).max()), name

@@ -76,10 +76,12 @@ def test_full_track_sequence_matches_the_oracle_sequence(oracle):
     pipe.close()
 
 
-def test_deferred_object_stage_gives_the_same_sequence():
+def test_deferred_object_stage_gives_the_same_sequence(monkeypatch):
     """defer_objects=1 (object LMs of frame k consumed inside Step(k+1), three streams) reorders work across the
     frame boundary without changing any data dependency: poses, per-frame counts (object counts one Step later),
-    object motions and tracklets are identical to the synchronous mode."""
+    object motions and tracklets are identical to the synchronous mode.  So does the camera stage running ahead
+    (FramePipeline::CameraStage: the RANSAC + camera optimisation of frame k+1 need nothing of frame k+1's images and
+    are launched at the end of Step(k), the default) against VDO_PIPE_NO_CAM_AHEAD=1 (launched at the start of Step(k+1))."""
     import torch
     n_frames = 7
     Ts = SQ.camera_poses(n_frames)
@@ -88,7 +90,11 @@ def test_deferred_object_stage_gives_the_same_sequence():
     dev = [{q: torch.from_numpy(np.ascontiguousarray(fr[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for fr in frames]
     torch.cuda.synchronize()
 
-    def run(defer, worker=False, orb_thread=False):
+    def run(defer, worker=False, orb_thread=False, cam_ahead=True):
+        if cam_ahead:
+            monkeypatch.delenv("VDO_PIPE_NO_CAM_AHEAD", raising=False)
+        else:
+            monkeypatch.setenv("VDO_PIPE_NO_CAM_AHEAD", "1")            # (read when the pipeline is built)
         ctx, ctx_lm, ctx_obj = Context(0), Context(0), Context(0)
         ctx_w = Context(0) if worker else None          # + a helper host thread with its own context (FramePipeline.h)
         ctx_o = Context(0) if orb_thread else None      # + ORB on a stream of its own (device stage queued at the start of the frame)
@@ -109,10 +115,11 @@ def test_deferred_object_stage_gives_the_same_sequence():
         pipe.close()
         return poses, counts, motions
 
-    p0, c0, m0 = run(0)
-    for defer, worker, orb_thread in ((1, False, False), (1, True, False), (0, True, False), (1, True, True), (0, True, True), (0, False, True)):
-        p1, c1, m1 = run(defer, worker, orb_thread)
-        assert c0[1:] == c1[1:], (defer, worker, orb_thread, [(a, b) for a, b in zip(c0, c1) if a != b][:2])
+    p0, c0, m0 = run(0, cam_ahead=False)
+    for defer, worker, orb_thread, ahead in ((1, False, False, True), (1, True, False, True), (0, True, False, True), (1, True, True, True), (0, True, True, True), (0, False, True, True),
+                                             (0, False, False, True), (1, True, True, False), (0, True, True, False)):
+        p1, c1, m1 = run(defer, worker, orb_thread, ahead)
+        assert c0[1:] == c1[1:], (defer, worker, orb_thread, ahead, [(a, b) for a, b in zip(c0, c1) if a != b][:2])
         for a, b in zip(p0, p1):
             assert np.array_equal(a, b)
         # synchronous mode reports the motions of frame k after Step(k); deferred mode after Step(k+1) / flush

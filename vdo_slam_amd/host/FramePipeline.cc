@@ -119,6 +119,70 @@ int FramePipeline::ReserveObjectSlots(int n_objects, int max_points) {
   return 0;
 }
 
+// The camera stage of the NEXT frame: GetInitModelCam (RANSAC-P3P + EPnP refit against the motion model, Tracking.cc:1614-1715) and the launch
+// of PoseOptimizationFlow2Cam (K16, Tracking.cc:690-700) on the LM stream.  Nothing in it reads the next frame's images: the 3-D points, key
+// points, flow and depth are the last frame's (mLastFrame.mvStatKeys / mvCorres / mvFlowNext / mvStatDepth), the "current" key points are
+// the correspondences the last frame's flow predicts, the motion model is mVelocity * last pose.  So it can start as soon as a frame's
+// static stage is over - Step() calls it at its end (cam_ahead_), while the frame's object optimisations are still running, and the next
+// Step() finds the camera pose computed or on its way; without that (first call, VDO_PIPE_NO_CAM_AHEAD) the next Step() calls it at its
+// start.  Same inputs, same arithmetic, same results either way (tests/test_track_sequence_gpu.py runs both).
+int FramePipeline::CameraStage() {
+  const auto t0 = std::chrono::steady_clock::now();
+  cam_run_ = nullptr; cam_n_pts_ = 0; cam_n_ransac_ = 0; cam_n_mm_ = 0;
+  const int n_s = have_last_ ? (int)sta_.cx.size() : 0;
+  if (have_last_ && n_s >= 4) {
+    std::vector<double>& X = dcam_[0]; std::vector<double>& uvd = dcam_[1];
+    X.resize(3 * (size_t)n_s); uvd.resize(2 * (size_t)n_s);
+    for (int i = 0; i < n_s; ++i) {
+      X[3 * i] = sta_.xyz[3 * i]; X[3 * i + 1] = sta_.xyz[3 * i + 1]; X[3 * i + 2] = sta_.xyz[3 * i + 2];
+      uvd[2 * i] = sta_.cx[i]; uvd[2 * i + 1] = sta_.cy[i];
+    }
+    vdo_pnp_problem pp{n_s, X.data(), uvd.data(), {p_.K4[0], p_.K4[1], p_.K4[2], p_.K4[3]}, 500, 0.4, 0.98, p_.pnp_refit};
+    vdo_pnp_result pr;
+    inl_ransac_cam_.assign(n_s, 0);
+    VDO_TRY(vdo_pnp_ransac(ctx_, &pp, &pr, inl_ransac_cam_.data()));
+    // motion-model inliers (mVelocity * last pose), same 0.4 px gate; the larger set seeds the optimisation
+    float MM[16];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float a = 0; for (int k = 0; k < 4; ++k) a += vel_[4 * i + k] * Tcw_last_[4 * k + j]; MM[4 * i + j] = a; }
+    int mm = 0;
+    inl_mm_cam_.assign(n_s, 0);
+    for (int i = 0; i < n_s; ++i) {
+      const float x = sta_.xyz[3 * i], y = sta_.xyz[3 * i + 1], z = sta_.xyz[3 * i + 2];
+      const float xc = MM[0] * x + MM[1] * y + MM[2] * z + MM[3], yc = MM[4] * x + MM[5] * y + MM[6] * z + MM[7], invz = 1.0f / (MM[8] * x + MM[9] * y + MM[10] * z + MM[11]);
+      const float u_ = sta_.cx[i] - (p_.K4[0] * xc * invz + p_.K4[2]), v_ = sta_.cy[i] - (p_.K4[1] * yc * invz + p_.K4[3]);
+      if (std::sqrt(u_ * u_ + v_ * v_) < 0.4f) { inl_mm_cam_[i] = 1; ++mm; }
+    }
+    cam_n_ransac_ = pr.n_inliers; cam_n_mm_ = mm;
+    if (lm_cam_) {
+      // TemperalMatch_subset + initial pose: RANSAC model if it has more inliers than the motion model (Tracking.cc:1690-1712)
+      const bool use_ransac = pr.n_inliers > mm;
+      const std::vector<uint8_t>& flag = use_ransac ? inl_ransac_cam_ : inl_mm_cam_;
+      double T0[16];
+      for (int i = 0; i < 16; ++i) T0[i] = use_ransac ? (double)(float)pr.T[i] : (double)MM[i];     // iniTcw is a CV_32F Mat
+      cam_subset_.clear();
+      std::vector<double>&ob = dcam_[2], &fl = dcam_[3], &dp = dcam_[4];
+      ob.clear(); fl.clear(); dp.clear();
+      for (int i = 0; i < n_s; ++i) {
+        if (!flag[i]) continue;
+        cam_subset_.push_back(i);
+        ob.push_back(sta_.x[i]); ob.push_back(sta_.y[i]); fl.push_back(sta_.fx[i]); fl.push_back(sta_.fy[i]); dp.push_back(sta_.d[i]);
+      }
+      vdo_flow2_problem fp;
+      fill_flow2(fp, (int)cam_subset_.size(), ob.data(), fl.data(), dp.data(), p_.K4, Tcw_last_, T0, 0.3, 100);
+      VDO_TRY(vdo_flow2_batch_set(lm_cam_, 0, &fp));        // (copied into the batch's pinned block: dcam_ is free again)
+      cam_run_ = lm_cam_; cam_n_pts_ = fp.n;
+      for (int i = 0; i < 16; ++i) Tcw_init_[i] = (float)T0[i];
+    }
+  } else if (lm_cam_) {
+    for (int i = 0; i < 16; ++i) Tcw_init_[i] = Tcw_last_[i];
+    VDO_TRY(vdo_flow2_batch_set(lm_cam_, 0, nullptr));
+    if (have_last_) { cam_run_ = lm_cam_; cam_n_pts_ = 0; }
+  }
+  if (cam_run_) VDO_TRY(vdo_flow2_batch_run(cam_run_));      // on the LM stream
+  ms_[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+  return 0;
+}
+
 int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const float* d_flow, const int32_t* d_mask,
                         vdo_flow2_batch* cam, vdo_flow2_batch* obj, int n_cam_pts, int n_obj_problems, FrameCounts* out) {
   if (!ok_) return -1;
@@ -230,58 +294,17 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   } else {
     VDO_TRY(vdo_ctx_synchronize(ctx_));
   }
-  // ---- GetInitModelCam: RANSAC (P3P) on last frame's 3-D points vs this frame's keys, against the motion model   Tracking.cc:1614-1715
-  if (have_last_ && n_s >= 4) {
-    std::vector<double>& X = d_[0]; std::vector<double>& uvd = d_[1];
-    X.resize(3 * (size_t)n_s); uvd.resize(2 * (size_t)n_s);
-    for (int i = 0; i < n_s; ++i) {
-      X[3 * i] = sta_.xyz[3 * i]; X[3 * i + 1] = sta_.xyz[3 * i + 1]; X[3 * i + 2] = sta_.xyz[3 * i + 2];
-      uvd[2 * i] = sta_.cx[i]; uvd[2 * i + 1] = sta_.cy[i];
-    }
-    vdo_pnp_problem pp{n_s, X.data(), uvd.data(), {p_.K4[0], p_.K4[1], p_.K4[2], p_.K4[3]}, 500, 0.4, 0.98, p_.pnp_refit};
-    vdo_pnp_result pr;
-    inl_ransac_.assign(n_s, 0);
-    VDO_TRY(vdo_pnp_ransac(ctx_, &pp, &pr, inl_ransac_.data()));
-    // motion-model inliers (mVelocity * last pose), same 0.4 px gate; the larger set seeds the optimisation
-    float MM[16];
-    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float a = 0; for (int k = 0; k < 4; ++k) a += vel_[4 * i + k] * Tcw_last_[4 * k + j]; MM[4 * i + j] = a; }
-    int mm = 0;
-    inl_mm_.assign(n_s, 0);
-    for (int i = 0; i < n_s; ++i) {
-      const float x = sta_.xyz[3 * i], y = sta_.xyz[3 * i + 1], z = sta_.xyz[3 * i + 2];
-      const float xc = MM[0] * x + MM[1] * y + MM[2] * z + MM[3], yc = MM[4] * x + MM[5] * y + MM[6] * z + MM[7], invz = 1.0f / (MM[8] * x + MM[9] * y + MM[10] * z + MM[11]);
-      const float u_ = sta_.cx[i] - (p_.K4[0] * xc * invz + p_.K4[2]), v_ = sta_.cy[i] - (p_.K4[1] * yc * invz + p_.K4[3]);
-      if (std::sqrt(u_ * u_ + v_ * v_) < 0.4f) { inl_mm_[i] = 1; ++mm; }
-    }
-    fc.n_ransac_cam = pr.n_inliers; fc.n_motion_model_cam = mm;
-    if (lm_cam_) {
-      // TemperalMatch_subset + initial pose: RANSAC model if it has more inliers than the motion model (Tracking.cc:1690-1712)
-      const bool use_ransac = pr.n_inliers > mm;
-      const std::vector<uint8_t>& flag = use_ransac ? inl_ransac_ : inl_mm_;
-      double T0[16];
-      for (int i = 0; i < 16; ++i) T0[i] = use_ransac ? (double)(float)pr.T[i] : (double)MM[i];     // iniTcw is a CV_32F Mat
-      cam_subset_.clear();
-      std::vector<double>&ob = d_[2], &fl = d_[3], &dp = d_[4];
-      ob.clear(); fl.clear(); dp.clear();
-      for (int i = 0; i < n_s; ++i) {
-        if (!flag[i]) continue;
-        cam_subset_.push_back(i);
-        ob.push_back(sta_.x[i]); ob.push_back(sta_.y[i]); fl.push_back(sta_.fx[i]); fl.push_back(sta_.fy[i]); dp.push_back(sta_.d[i]);
-      }
-      vdo_flow2_problem fp;
-      fill_flow2(fp, (int)cam_subset_.size(), ob.data(), fl.data(), dp.data(), p_.K4, Tcw_last_, T0, 0.3, 100);
-      VDO_TRY(vdo_flow2_batch_set(lm_cam_, 0, &fp));
-      cam = lm_cam_; n_cam_pts = fp.n;
-      for (int i = 0; i < 16; ++i) Tcw_init_[i] = (float)T0[i];
-    }
-  } else if (lm_cam_) {
-    for (int i = 0; i < 16; ++i) Tcw_init_[i] = Tcw_last_[i];
-    VDO_TRY(vdo_flow2_batch_set(lm_cam_, 0, nullptr));
-    if (have_last_) { cam = lm_cam_; n_cam_pts = 0; }
-  }
   tick(0);
-  // ---- camera pose (K16) on the LM stream, front-end of this frame meanwhile      Tracking.cc:690-700 || Frame.cc:61-260
-  if (cam) VDO_TRY(vdo_flow2_batch_run(cam));
+  // ---- GetInitModelCam + PoseOptimizationFlow2Cam (K16): launched at the end of the LAST Step if the camera stage runs ahead (CameraStage)
+  {
+    vdo_flow2_batch* cam_ext = cam;
+    if (!cam_ahead_ && CameraStage() != 0) return -1;
+    cam_ahead_ = false;
+    fc.n_ransac_cam = cam_n_ransac_; fc.n_motion_model_cam = cam_n_mm_;
+    if (cam_run_ || !cam_ext) { cam = cam_run_; n_cam_pts = cam_n_pts_; }
+    else VDO_TRY(vdo_flow2_batch_run(cam_ext));             // (a caller-supplied batch, build_lm = 0)
+  }
+  t_prev = std::chrono::steady_clock::now();               // (CameraStage books its own time)
   if (late_upload) VDO_TRY(vdo_frame_images_upload(cur, nullptr, d_flow, d_mask));
   if (p_.use_sample_feature) {                           // Option II of Frame::Frame (src/Frame.cc:132-166): random samples instead of ORB
     int ns = 0;
@@ -579,6 +602,11 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   std::memcpy(Tcw_out_, Tcw, sizeof Tcw);
   cur_ ^= 1; have_last_ = true; ++f_id_;
   gate_last_ = gate_cur_;
+  // the camera stage of the NEXT frame (needs nothing of its images): under the object optimisations of this one
+  if (cam_ahead_on_ && lm_cam_ && !cam_ahead_) {
+    if (CameraStage() != 0) return -1;
+    cam_ahead_ = true;
+  }
   if (host_inputs_ && depth_inout_ && !depth_metric_ && pending_ && !p_.defer_objects) {      // (the object LMs of the frame are in flight: the copy engine is free)
     VDO_TRY(vdo_frame_images_download_depth(img_[cur_ ^ 1], depth_inout_));
     depth_on_host_ = true;

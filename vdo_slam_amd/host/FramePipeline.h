@@ -17,6 +17,7 @@
 #include <functional>
 #include <memory>
 #include <atomic>
+#include <cstdlib>
 #include <vector>
 
 #include "../../include/vdo_slam_hip.h"
@@ -108,6 +109,7 @@ class FramePipeline {
  private:
   struct ObjSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; std::vector<int32_t> sem, label; };
   struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; };
+  int CameraStage();                        // GetInitModelCam + launch of the camera optimisation for the frame after the last one
   int FinishObjects(FrameCounts* fc, bool defer_tail = false);
   int FinishObjectsTail(FrameCounts* fc);   // dynamic tracklets, Map, windowed optimisation: nothing the next frame's object chain waits for
   bool tail_pending_ = false, tail_has_lm_ = false;
@@ -171,6 +173,13 @@ class FramePipeline {
   std::vector<float> obj_mm_;                             // MotionModel of the frame's objects (16 floats each)
   std::vector<ObjBuf> obj_buf_;
   float Tcw_init_[16];
+  // camera stage (CameraStage): launched ahead of its frame or at the start of its Step
+  bool cam_ahead_ = false;
+  bool cam_ahead_on_ = std::getenv("VDO_PIPE_NO_CAM_AHEAD") == nullptr;      // (read when the pipeline is built)
+  vdo_flow2_batch* cam_run_ = nullptr;
+  int cam_n_pts_ = 0, cam_n_ransac_ = 0, cam_n_mm_ = 0;
+  std::vector<double> dcam_[5];
+  std::vector<uint8_t> inl_ransac_cam_, inl_mm_cam_;
 };
 
 }  // namespace VDO_SLAM
