@@ -89,11 +89,8 @@ __device__ __forceinline__ void acc_finish(double (&acc)[16], int cur, double* a
   { double g[4] = {acc[12], acc[13], acc[14], acc[15]}; seg_apply16<4>(g, sc, sf, dst + 12); }
 }
 
-#ifndef VDO_SWEEP_WPE
-#define VDO_SWEEP_WPE 4
-#endif
 template <bool BUILD>
-__global__ __launch_bounds__(VDO_TILE_THREADS, VDO_SWEEP_WPE) void k_sweep_tile(BADev d, int which) {
+__global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int which) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Tile T = d.tiles[blockIdx.x];
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
@@ -151,16 +148,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, VDO_SWEEP_WPE) void k_sweep_tile(
         const int lp = key & 0xffff;
         const double w = ew[j];
         const D3 z = ez[j];
-#ifdef VDO_SWEEP_HACK_POSE_ONCE
-        double Wreg[12];
-        if (j == 0) {
-#pragma unroll
-          for (int i = 0; i < 12; ++i) Wreg[i] = slotW[12 * slot + i];
-        }
-        const double* Wp = Wreg;
-#else
         const double* Wp = slotW + 12 * slot;   // W.r = R^T = Jl (row-major), W.t
-#endif
         const D3 p{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
         const D3 zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
         const D3 er = zc - z;
