@@ -370,6 +370,27 @@ def main():
     Tcw = pipe.pose().astype(np.float64)
     drift = float(np.abs(Tcw[:3, 3] - frames[k_last]["Tcw"][:3, 3]).max()) if n_all <= n_seq else None
     motions = pipe.motions()
+    # accuracy of what the timed run computed, against the ground truth of the synthetic sequence - ASSERTED below (a fast wrong answer is not a result):
+    # camera translation / rotation error at the last frame, and for every tracked object the error of its estimated world-frame motion k-1 -> k
+    # applied to the object's centre
+    rot_err = float(np.abs(Tcw[:3, :3] - frames[k_last]["Tcw"][:3, :3]).max()) if n_all <= n_seq else None
+    motion_err = []
+    if n_all <= n_seq and k_last >= 1:
+        for m in motions:
+            ob = objs[m["sem_label"] - 1]
+            Hgt = SQ.object_motion(ob, k_last - 1)
+            _, c_ob = SQ.object_pose(ob, k_last - 1)
+            He = m["H"].astype(np.float64)
+            motion_err.append(float(np.abs((He[:3, :3] @ c_ob + He[:3, 3]) - (Hgt[:3, :3] @ c_ob + Hgt[:3, 3])).max()))
+    acc_bounds = {"trajectory_drift_m": 0.05 + 0.005 * n_all, "rotation_error": 0.01, "object_motion_error_m": 0.3}
+    if n_all <= n_seq:
+        bad = []
+        if drift > acc_bounds["trajectory_drift_m"]: bad.append(f"camera drift {drift:.3f} m after {n_all} frames")
+        if rot_err > acc_bounds["rotation_error"]: bad.append(f"camera rotation error {rot_err:.4f}")
+        bad += [f"object motion error {e:.3f} m" for e in motion_err if e > acc_bounds["object_motion_error_m"]]
+        if not motions: bad.append("no object tracked in the last frame")
+        if bad:
+            raise SystemExit("bench.py: the timed run computed a WRONG answer (" + "; ".join(bad) + f"; bounds {acc_bounds})")
     identical = all(np.array_equal(r.pipe.pose(), pipe.pose()) and [m["H"].tolist() for m in r.pipe.motions()] == [m["H"].tolist() for m in motions] for r in reps[1:])
     rep0 = reps[0]
 
@@ -395,7 +416,9 @@ def main():
                    "n_recovered_masks_total": int(agg["n_recovered_masks"]),
                    "n_motion_model_obj": int(agg["n_motion_model_obj"]),      # object-frames whose LM was seeded by the motion model (GetInitModelObj, Tracking.cc:1803-1825)
                    "step_ms_p50_p90_max": [round(float(np.percentile(step_ms, 50)), 3), round(float(np.percentile(step_ms, 90)), 3), round(max(step_ms), 3)],
-                   "trajectory_drift_m": drift, "object_translations_last_frame": [np.round(m["H"][:3, 3], 4).tolist() for m in motions],
+                   "trajectory_drift_m": drift, "rotation_error_last_frame": rot_err, "object_motion_error_m_last_frame": [round(e, 4) for e in motion_err],
+                   "accuracy_asserted": {"against": "ground truth of the synthetic sequence, last frame of the timed run", "bounds": acc_bounds},
+                   "object_translations_last_frame": [np.round(m["H"][:3, 3], 4).tolist() for m in motions],
                    "host_ms_per_section": {k_: round(v_ / n_all, 4) for k_, v_ in sect.items()}},
     }
     if R > 1:
