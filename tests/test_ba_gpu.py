@@ -292,3 +292,60 @@ def test_pose_chain_solver_is_the_same_operator_however_it_is_partitioned(ctx, o
         assert abs(r[2] - ref[2]) <= 1e-9 * ref[2], name
         assert np.abs(r[3] - ref[3]).max() <= 1e-8 and np.abs(r[4] - ref[4]).max() <= 1e-7, name
         assert np.abs(r[3] - pose_o).max() <= 1e-4 * max(1.0, np.abs(pose_o).max()), name
+
+
+def test_config4_sized_graph_properties(ctx, monkeypatch):
+    """BASELINE configs[4] shape (1 M landmarks, 5 k pose / motion vertices, 20 objects, 5.8 M edges) - too large for the oracle, so the
+    HIP path is checked through properties that do not depend on the size:
+      * two linearisations give the same chi2 bits (fixed summation order) and the same blocks up to the order of the LDS additions;
+      * renumbering the caller's points and edges at random changes nothing beyond rounding (the tile-major renumbering, the
+        slot tables and the pose-major partial rows are a function of the graph, not of how the caller listed it);
+      * three Levenberg iterations lower chi2 at every accepted step, and the pose-chain solver cut into 16 segments and into one give
+        the same trajectory."""
+    import dataclasses
+    from vdo_slam_amd.ba import BatchBA
+    g = synth.make_ba_graph(239, 950000, 20, 500, seed=3)
+    assert g.n_point > 1_000_000 and g.n_pose > 4_900 and g.n_eb > 5_000_000
+    ba = BatchBA(ctx, g)
+    ba.linearize()
+    S1 = ba.system()
+    Hpp, bp, Hll, bl, chi = S1.Hpp.copy(), S1.bp.copy(), S1.Hll.copy(), S1.bl.copy(), (float(S1.chi2), float(S1.robust_chi2))
+    ba.linearize(repeat=2)
+    S2 = ba.system()
+    assert chi == (float(S2.chi2), float(S2.robust_chi2))                        # fixed summation order
+    # (the sums of a tile meet in LDS by ds_add_f64: the order among the waves of a workgroup is not fixed - a few ulp from run to run)
+    assert np.abs(S2.Hpp - Hpp).max() <= 1e-13 * np.abs(Hpp).max() and np.abs(S2.bp - bp).max() <= 1e-13 * np.abs(bp).max()
+    print("run-to-run: Hpp", np.abs(S2.Hpp - Hpp).max() / np.abs(Hpp).max(), "bp", np.abs(S2.bp - bp).max() / np.abs(bp).max())
+    np.testing.assert_allclose(Hll, S2.Hll, rtol=1e-13, atol=1e-18)
+    del S1, S2
+    # ---- the same graph, listed in another order
+    rng = np.random.default_rng(5)
+    pp = rng.permutation(g.n_point); inv = np.empty_like(pp); inv[pp] = np.arange(g.n_point)      # new index of old point i = inv[i]
+    pe = rng.permutation(g.n_eb); pt = rng.permutation(g.n_et)
+    g2 = dataclasses.replace(g, point=g.point[pp], point_gt=None,
+                             eb_pose=g.eb_pose[pe], eb_point=inv[g.eb_point[pe]].astype(g.eb_point.dtype), eb_z=np.ascontiguousarray(g.eb_z[:, pe]), eb_w=g.eb_w[pe],
+                             et_p1=inv[g.et_p1[pt]].astype(g.et_p1.dtype), et_p2=inv[g.et_p2[pt]].astype(g.et_p2.dtype), et_pose=g.et_pose[pt],
+                             et_z=np.ascontiguousarray(g.et_z[:, pt]), et_w=g.et_w[pt])
+    bb = BatchBA(ctx, g2)
+    bb.linearize()
+    T = bb.system()
+    scale = np.abs(Hpp).max()
+    assert np.abs(T.Hpp - Hpp).max() <= 1e-11 * scale and np.abs(T.bp - bp).max() <= 1e-11 * np.abs(bp).max()
+    assert abs(float(T.chi2) - chi[0]) <= 1e-11 * chi[0] and abs(float(T.robust_chi2) - chi[1]) <= 1e-11 * chi[1]
+    np.testing.assert_allclose(T.Hll[inv], Hll, rtol=1e-12, atol=1e-15)
+    np.testing.assert_allclose(T.bl[inv], bl, rtol=0, atol=1e-11 * np.abs(bl).max())
+    bb.close(); del T
+    # ---- Levenberg at full size
+    st = ba.optimize(max_iterations=3, gain_threshold=-1.0, solver=2)
+    tr = [st.initial_chi2] + [st.chi2_trace[i] for i in range(st.iterations)]
+    assert st.iterations == 3 and all(b_ < a_ for a_, b_ in zip(tr, tr[1:])) and abs(tr[-1] - st.final_chi2) <= 1e-12 * tr[-1], tr
+    pose_a, point_a = ba.estimates()
+    ba.close()
+    monkeypatch.setenv("VDO_BA_CHAIN_WAVES", "1")
+    bc = BatchBA(ctx, g)
+    st1 = bc.optimize(max_iterations=3, gain_threshold=-1.0, solver=2)
+    pose_b, point_b = bc.estimates()
+    bc.close()
+    assert st1.iterations == st.iterations and st1.total_trials == st.total_trials
+    assert abs(st1.final_chi2 - st.final_chi2) <= 1e-9 * st.final_chi2
+    assert np.abs(pose_a - pose_b).max() <= 1e-7 and np.abs(point_a - point_b).max() <= 1e-6
