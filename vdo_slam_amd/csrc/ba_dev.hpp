@@ -16,7 +16,7 @@
 //           v = H^-1 p2) and R the pose rotation; c is a function of the point and the pose, both staged in LDS
 //           by every consumer anyway, so ONLY we (the Huber-weighted information scalar) is stored:
 //           8 B/edge instead of 144 B, both for the sweep's write and for every PCG mat-vec.
-//   part_q / part_m  [k][NPS]   per-(tile,pose-slot) partial sums of the solver (NPS = total slots); part_sums: pose-major rows, see below
+//   part_q / part_m / part_sums   per-(tile,pose-slot) partial sums of the solver and of the sweep (NPS = total slots): pose-major rows, see below
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -107,8 +107,8 @@ struct BADev {
   double *xp = nullptr, *rp = nullptr, *zp = nullptr, *pp = nullptr, *qp = nullptr, *bs = nullptr, *qs = nullptr;  // [6P]
   double* pp2 = nullptr;                             // [6P] second search-direction buffer (the PCG iterations ping-pong between pp and pp2)
   double *part_pq = nullptr, *part_rz = nullptr;     // [(P+3)/4] p.q per workgroup of k_pcg_q; [n_pchains] r.z per chain of k_pcg_chain
-  double* part_q = nullptr;                          // [6][NPS]
-  double* part_m = nullptr;                          // [21][NPS] preconditioner partials
+  double* part_q = nullptr;                          // [NPS][8] pose-major rows (row slot_dst[s] of slot s), 6 used: Schur mat-vec partials
+  double *part_m = nullptr, *part_m8 = nullptr;      // [NPS][16] + [NPS][8] pose-major rows: the 21 preconditioner partials of a slot (16 + 5)
   double* scal = nullptr;
   int32_t* flags = nullptr;                          // [0] factor failure [1] pcg state [2] pcg iterations [3] arrival counter of k_pcg_chain
   // multi-GPU shards: poses replicated, points + their edges owned by one rank.

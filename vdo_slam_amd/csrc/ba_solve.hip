@@ -285,10 +285,13 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
     { const SegCtl16 sc_ = seg_ctl16(slot); seg_apply16<21>(up, sc_, seg_flags(sc_), accm + 21 * (slot >= 0 ? slot : 0)); }
   }
   __syncthreads();
-  const int64_t NPS = d.NPS;
-  for (int i = tid; i < 21 * nslot; i += VDO_TILE_THREADS) {
-    const int sidx = i / 21, k = i % 21;
-    d.part_m[k * NPS + T.slot_begin + sidx] = accm[21 * sidx + k];
+  // one row of 16 + one of 8 doubles per (tile, slot), pose-major (k_precond_finalize streams a pose's rows)
+  for (int i = tid; i < 24 * nslot; i += VDO_TILE_THREADS) {
+    const int sidx = i / 24, k = i - 24 * sidx;
+    if (k >= 21) continue;
+    const int64_t row = d.slot_dst[T.slot_begin + sidx];
+    if (k < 16) d.part_m[16 * row + k] = accm[21 * sidx + k];
+    else d.part_m8[8 * row + (k - 16)] = accm[21 * sidx + k];
   }
 }
 
@@ -300,7 +303,13 @@ __global__ __launch_bounds__(256) void k_precond_finalize(BADev d, double lambda
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per pose
   if (p >= d.P) return;
   double up[21];
-  if (SRC != 2) wave_gather<21>(d.part_m, d.NPS, d.ps_off, d.ps_idx, p, up);
+  if (SRC != 2) {
+    const double a16 = wave_gather_rows<16>(d.part_m, d.ps_off[p], d.ps_off[p + 1]), a8 = wave_gather_rows<8>(d.part_m8, d.ps_off[p], d.ps_off[p + 1]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) up[i] = __shfl(a16, i, 64);
+#pragma unroll
+    for (int i = 0; i < 5; ++i) up[16 + i] = __shfl(a8, i, 64);
+  }
   if ((threadIdx.x & 63) != 0) return;
   if (SRC == 1) {
 #pragma unroll
@@ -874,10 +883,10 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     { const SegCtl16 sc_ = seg_ctl16(skey); seg_apply16<6>(q, sc_, seg_flags(sc_), qs + 6 * (skey >= 0 ? skey : 0)); }
   }
   __syncthreads();
-  const int64_t NPS = d.NPS;
-  for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) {
-    const int sidx = i / 6, k = i % 6;
-    d.part_q[k * NPS + T.slot_begin + sidx] = qs[6 * sidx + k];
+  // one row of 8 doubles (6 used) per (tile, slot), pose-major (k_pcg_q / k_gather_q stream a pose's rows)
+  for (int i = tid; i < 8 * nslot; i += VDO_TILE_THREADS) {
+    const int sidx = i >> 3, k = i & 7;
+    if (k < 6) d.part_q[8 * (int64_t)d.slot_dst[T.slot_begin + sidx] + k] = qs[6 * sidx + k];
   }
 }
 
@@ -885,10 +894,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
 __global__ __launch_bounds__(256) void k_gather_q(BADev d, double* out, int pcg) {
   const int p = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per pose
   if (p >= d.P || (pcg && d.flags[1])) return;
-  double s[6];
-  wave_gather<6>(d.part_q, d.NPS, d.ps_off, d.ps_idx, p, s);
+  const double s = wave_gather_rows<8>(d.part_q, d.ps_off[p], d.ps_off[p + 1]);
   const int lane = threadIdx.x & 63;
-  if (lane < 6) out[6 * (int64_t)p + lane] = s[lane];
+  if (lane < 6) out[6 * (int64_t)p + lane] = s;
 }
 
 // (Hpp v)_p including lambda and the EdgeSE3 off-diagonal blocks (CSR per pose, no atomics)
@@ -936,13 +944,9 @@ __global__ __launch_bounds__(256) void k_pcg_q(BADev d, double lambda, int par, 
   const double beta = d.scal[S_BETA];
   double dot = 0.0;
   if (p < d.P) {
-    double qsum[6];
-    if (gather) wave_gather<6>(d.part_q, d.NPS, d.ps_off, d.ps_idx, p, qsum);      // (sharded: gathered and all-reduced into qs by the launches before)
-    else {
-#pragma unroll
-      for (int i = 0; i < 6; ++i) qsum[i] = d.qs[6 * (int64_t)p + i];
-    }
     const int l = lane < 6 ? lane : 0;
+    // the Schur part of q: this pose's partial rows (sharded: gathered and all-reduced into qs by the launches before)
+    const double ql = gather ? wave_gather_rows<8>(d.part_q, d.ps_off[p], d.ps_off[p + 1]) : d.qs[6 * (int64_t)p + l];
     const double pn = d.zp[6 * (int64_t)p + l] + beta * pold[6 * (int64_t)p + l];
     if (lane < 6) pnew[6 * (int64_t)p + lane] = pn;
     const double* Hm = d.Hpp + 36 * (int64_t)p + 6 * l;
@@ -958,9 +962,6 @@ __global__ __launch_bounds__(256) void k_pcg_q(BADev d, double lambda, int par, 
 #pragma unroll
       for (int b = 0; b < 6; ++b) q += (side == 0 ? He[l * 6 + b] : He[b * 6 + l]) * __shfl(on, b, 64);
     }
-    double ql = qsum[0];
-#pragma unroll
-    for (int i = 1; i < 6; ++i) ql = (l == i) ? qsum[i] : ql;
     q -= ql;
     if (lane < 6) { d.qp[6 * (int64_t)p + lane] = q; dot = pn * q; }
   }

@@ -161,21 +161,24 @@ __device__ __forceinline__ void seg_apply16(double (&v)[N], const SegCtl16& c, c
   }
 }
 
-// One wave sums, for pose p, the K-vectors of all its (tile,slot) partials (part: [K][NPS] SoA).
-// Lanes stride over the slot list, then a fixed shuffle tree -> deterministic.  Result in all lanes.
-template <int K>
-__device__ __forceinline__ void wave_gather(const double* __restrict__ part, int64_t NPS, const int32_t* __restrict__ ps_off,
-                                            const int32_t* __restrict__ ps_idx, int p, double (&out)[K]) {
+// Sum over the pose-major rows [r0, r1) of `part` (rows of STRIDE doubles, STRIDE = 8 or 16: every (tile, pose slot) pair owns one row, the
+// rows of a pose are contiguous - slot_dst, ba_dev.hpp): the wave streams them, 64 / STRIDE rows (512 contiguous bytes) per step; lane l always
+// meets component l % STRIDE, whose total is returned in every lane with that remainder.  Fixed order.
+template <int STRIDE>
+__device__ __forceinline__ double wave_gather_rows(const double* __restrict__ part, int r0, int r1) {
+  static_assert(STRIDE == 8 || STRIDE == 16, "row of 8 or 16 doubles");
   const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int i = 0; i < K; ++i) out[i] = 0.0;
-  for (int k = ps_off[p] + lane; k < ps_off[p + 1]; k += 64) {
-    const int64_t c = ps_idx[k];
-#pragma unroll
-    for (int i = 0; i < K; ++i) out[i] += part[i * NPS + c];
-  }
-#pragma unroll
-  for (int i = 0; i < K; ++i) out[i] = __shfl(wave_sum(out[i]), 0, 64);
+  const double* __restrict__ base = part + (int64_t)r0 * STRIDE;
+  const int64_t n = (int64_t)(r1 - r0) * STRIDE;
+  double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+  int64_t i = lane;
+  for (; i + 192 < n; i += 256) { a0 += base[i]; a1 += base[i + 64]; a2 += base[i + 128]; a3 += base[i + 192]; }
+  for (; i < n; i += 64) a0 += base[i];
+  double a = (a0 + a1) + (a2 + a3);
+  a += __shfl_xor(a, 32, 64);
+  a += __shfl_xor(a, 16, 64);
+  if (STRIDE == 8) a += __shfl_xor(a, 8, 64);
+  return a;
 }
 
 // workgroup sum of one double (<= 1024 threads); result broadcast.  lds: >= 17 doubles

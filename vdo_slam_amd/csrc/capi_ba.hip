@@ -400,7 +400,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(xp, Z, 6 * (size_t)P); UP(rp, Z, 6 * (size_t)P); UP(zp, Z, 6 * (size_t)P); UP(pp, Z, 6 * (size_t)P); UP(pp2, Z, 6 * (size_t)P);
   UP(qp, Z, 6 * (size_t)P); UP(bs, Z, 6 * (size_t)P); UP(qs, Z, 6 * (size_t)P);
   UP(part_pq, Z, (size_t)(P + 3) / 4 + 1); UP(part_rz, Z, (size_t)n_pchains + 1);
-  UP(part_q, Z, 6 * (size_t)NPS); UP(part_m, Z, 21 * (size_t)NPS);
+  UP(part_q, Z, 8 * (size_t)NPS + 8); UP(part_m, Z, 16 * (size_t)NPS + 16); UP(part_m8, Z, 8 * (size_t)NPS + 8);
   UP(scal, Z, S_COUNT);
   const int32_t* ZI = nullptr;
   UP(flags, ZI, 4);
