@@ -581,7 +581,7 @@ struct vdo_flow2_batch {
 
 extern "C" int vdo_flow2_batch_destroy(vdo_flow2_batch* b) {
   if (!b) return VDO_OK;
-  if (b->ctx) ctx_bind(b->ctx);
+  if (b->ctx) { ctx_bind(b->ctx); hipStreamSynchronize(b->ctx->stream); }      // (a launch may still be in flight: the camera stage runs one frame ahead)
   for (void* p : b->allocs) hipFree(p);
   if (b->h_pin) hipHostFree(b->h_pin);
   if (b->h_up) hipHostFree(b->h_up);
