@@ -149,3 +149,68 @@ def test_system_rejects_frames_that_do_not_match_the_settings(tmp_path):
     s.close()
     with pytest.raises(K.VdoError):
         System(tmp_path / "missing.yaml")
+
+
+def test_tracking_frame_state_matches_the_oracle(host, oracle, tmp_path):
+    """Tracking's public per-frame containers (reference include/Tracking.h:116-198, include/Frame.h:126-180), materialised on request by
+    Tracking::SyncFrameState(): after every TrackRGBD call mCurrentFrame holds what the reference's Track() leaves there - the renewed
+    static and object sets of RenewFrameInfo, their 3-D points, the per-object vectors, max_id - and they are the oracle pipeline's."""
+    from tests.pipeline_ref import OraclePipeline
+    host.host_system_frame_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    n_frames = 4
+    fx, fy, cx, cy = synth.KITTI_K
+    cfg = tmp_path / "kitti.yaml"
+    cfg.write_text(YAML.format(fx=fx, fy=fy, cx=cx, cy=cy, w=W, h=H, bf=SF.BF, dmf=SF.DEPTH_MAP_FACTOR, thbg=SF.TH_DEPTH_BG, thobj=SF.TH_DEPTH_OBJ).replace("WINDOW_SIZE: 20", "WINDOW_SIZE: 0"))
+    Ts = SQ.camera_poses(n_frames)
+    objs = SQ.default_objects()
+    sys_ = host.host_system_create(str(cfg).encode())
+    assert sys_
+    ref = OraclePipeline(oracle, build_lm=True)
+
+    def state(what, rows):
+        n = host.host_system_frame_state(sys_, what, None, 0)
+        assert n >= 0
+        buf = np.zeros(max(rows * n, 1), np.float32)
+        assert host.host_system_frame_state(sys_, what, _ptr(buf), buf.size) == n
+        return n, buf[:rows * n]
+
+    for k in range(n_frames):
+        fr = SQ.render_frame(k, Ts, objs)
+        depth = fr["depth_raw"].copy(); mask = fr["mask"].copy()
+        rows = np.array([[k, lab, 0, 0, 0, 0, 0, 0, 0, 0] for lab in (1, 2, 3)], np.float32)
+        T = np.zeros(16, np.float32)
+        assert host.host_system_track(sys_, _ptr(fr["gray"]), 1, _ptr(depth), _ptr(fr["flow"]), _ptr(mask), W, H, _ptr(rows), 3, 10, 1 << 30, _ptr(T)) == 0
+        exp = ref.step(fr)
+        L = ref.last
+        n, s = state(0, 10)
+        st = s.reshape(10, n)
+        assert n == L["st"]["key_x"].size == exp["n_static_tracked"]
+        for row, q in enumerate(("key_x", "key_y", "corr_x", "corr_y", "flow_x", "flow_y", "depth")):
+            assert np.array_equal(st[row], L["st"][q]), (k, q)
+        assert np.array_equal(st[7:10].T, np.asarray(L["st"]["xyz"], np.float32).reshape(-1, 3)), k
+        n, s = state(1, 12)
+        ob = s.reshape(12, n)
+        assert n == L["ob"]["key_x"].size == exp["n_object_tracked"]
+        for row, q in enumerate(("key_x", "key_y", "corr_x", "corr_y", "flow_x", "flow_y", "depth")):
+            assert np.array_equal(ob[row], L["ob"][q]), (k, q)
+        assert np.array_equal(ob[7:10].T, np.asarray(L["ob"]["xyz"], np.float32).reshape(-1, 3)), k
+        assert np.array_equal(ob[10].astype(np.int32), L["ob"]["label"]), k                      # vSemObjLabel
+        if k > 0:
+            assert np.array_equal(ob[11].astype(np.int32), ref.result["objects"]["obj_label"]), k    # vObjLabel
+        n, s = state(2, 19)
+        po = s.reshape(n, 19)
+        assert n == len(L["sem_pos"])
+        assert np.array_equal(po[:, 0].astype(np.int32), L["sem_pos"]) and np.array_equal(po[:, 1].astype(np.int32), L["mod"]) and np.array_equal(po[:, 2].astype(np.uint8), L["stat"])
+        for a in range(n):
+            Hm = po[a, 3:].reshape(4, 4)
+            if L["stat"][a]:
+                np.testing.assert_allclose(Hm, L["H"][a], rtol=0, atol=5e-6)
+            else:
+                assert np.array_equal(Hm, np.eye(4, dtype=np.float32))
+        n, s = state(3, 8)
+        assert n == exp["n_object_samples"]
+        _, sc = state(4, 17)
+        assert int(sc[0]) == ref.max_id
+        np.testing.assert_allclose(sc[1:].reshape(4, 4), ref.Tl, rtol=0, atol=2e-6)
+        assert np.array_equal(sc[1:], T)
+    host.host_system_destroy(sys_)

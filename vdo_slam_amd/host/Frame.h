@@ -36,12 +36,18 @@ class Frame {
   int N_s = 0, N_s_tmp = 0;
   std::vector<cv::KeyPoint> mvStatKeys, mvStatKeysTmp, mvCorres;
   std::vector<float> mvStatDepth, mvStatDepthTmp;
+  std::vector<cv::Mat> mvStat3DPointTmp;         // 3x1 CV_32F, world frame
   std::vector<cv::Point2f> mvFlowNext;
   // objects
   std::vector<cv::KeyPoint> mvObjKeys, mvObjCorres;
   std::vector<float> mvObjDepth;
   std::vector<cv::Point2f> mvObjFlowNext;
   std::vector<int> vSemObjLabel, vObjLabel;
+  std::vector<cv::Mat> mvObj3DPoint;             // 3x1 CV_32F, world frame
+  // per object of the frame (include/Frame.h:150-160)
+  std::vector<bool> bObjStat;
+  std::vector<cv::Mat> vObjMod;                  // 4x4 CV_32F
+  std::vector<int> nModLabel, nSemPosition;
   cv::Mat mInitModel;
   cv::Mat mTcw;
   static long unsigned int nNextId;

@@ -457,6 +457,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     nsta.fx.assign(f_[4].begin(), f_[4].begin() + n_new_s); nsta.fy.assign(f_[5].begin(), f_[5].begin() + n_new_s);
     nsta.d.assign(f_[6].begin(), f_[6].begin() + n_new_s);
     nobj = tmp;                                         // (copy: the buffer keeps its capacity for later frames)
+    n_tmp_ = n_tmp; tmp_idx_obj_ = cur_;                // (ObjectSamples(): the samples of this frame)
     for (auto* v : {&nobj.x, &nobj.y, &nobj.cx, &nobj.cy, &nobj.fx, &nobj.fy, &nobj.d}) v->resize(n_tmp);
     nobj.sem.resize(n_tmp); nobj.label.assign(n_tmp, -2);
     if (obj) VDO_TRY(vdo_ctx_synchronize(ctx_lm_));

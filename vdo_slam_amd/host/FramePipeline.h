@@ -106,9 +106,22 @@ class FramePipeline {
   float Tcw_out_[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   double ms_[12] = {0};              // accumulated wall time per section (see host_pipeline_timing)
 
+  // ---- the per-frame state the reference keeps in Tracking::mCurrentFrame / mLastFrame after Track() (RenewFrameInfo,
+  // src/Tracking.cc:2780-2812, 2984-2991; per-object vectors :836-933), as views of the pipeline's own flat arrays.  Valid between
+  // Steps, after Flush() in deferred mode; Tracking::SyncFrameState() turns them into the reference's containers.
+  struct ObjSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; std::vector<int32_t> sem, label; };   // mvObjKeys, mvObjCorres, mvObjFlowNext, mvObjDepth, mvObj3DPoint, vSemObjLabel, vObjLabel
+  struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; };                                      // mvStatKeysTmp, mvCorres, mvFlowNext, mvStatDepthTmp, mvStat3DPointTmp
+  const StaSet& StaticSet() const { return sta_; }
+  const ObjSet& ObjectSet() const { return obj_; }
+  const ObjSet& ObjectSamples() const { return tmpb_[tmp_idx_obj_]; }        // mvTmpObjKeys / Corres / FlowNext / Depth / SemObjLabel of the last frame (first n_object_samples entries)
+  int NumObjectSamples() const { return n_tmp_; }
+  const std::vector<int32_t>& ObjSemPosition() const { return last_sem_pos_; }   // nSemPosition
+  const std::vector<int32_t>& ObjModLabel() const { return last_mod_label_; }    // nModLabel
+  const std::vector<uint8_t>& ObjStat() const { return last_obj_stat_; }          // bObjStat
+  const std::vector<float>& ObjMod() const { return last_obj_mod_; }              // vObjMod: [n][16], world-frame motion, identity where not tracked
+  int MaxId() const { return max_id_; }                                           // max_id
+
  private:
-  struct ObjSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; std::vector<int32_t> sem, label; };
-  struct StaSet { std::vector<float> x, y, cx, cy, fx, fy, d, xyz; };
   int CameraStage();                        // GetInitModelCam + launch of the camera optimisation for the frame after the last one
   int FinishObjects(FrameCounts* fc, bool defer_tail = false);
   int FinishObjectsTail(FrameCounts* fc);   // dynamic tracklets, Map, windowed optimisation: nothing the next frame's object chain waits for

@@ -157,6 +157,71 @@ cv::Mat Tracking::GrabImageRGBD(const cv::Mat& imRGB, cv::Mat& imD, const cv::Ma
   return Tcw;
 }
 
+// The reference's per-frame containers, materialised from the pipeline's flat arrays (see System.h).  Ends a pending object stage first.
+void Tracking::SyncFrameState() {
+  FramePipeline& P = *pipe_;
+  P.Flush();
+  Frame& F = mCurrentFrame;
+  F.mTcw = cv::Mat(4, 4, cv::CV_32F);
+  std::memcpy(F.mTcw.data, P.Tcw_out_, 64);
+  auto point3 = [](const float* p) { cv::Mat m(3, 1, cv::CV_32F); m.at<float>(0) = p[0]; m.at<float>(1) = p[1]; m.at<float>(2) = p[2]; return m; };
+  {   // RenewFrameInfo, static part (src/Tracking.cc:2780-2812)
+    const FramePipeline::StaSet& S = P.StaticSet();
+    const size_t n = S.x.size();
+    F.N_s_tmp = (int)n;
+    F.mvStatKeysTmp.resize(n); F.mvCorres.resize(n); F.mvFlowNext.resize(n); F.mvStatDepthTmp = S.d; F.mvStat3DPointTmp.resize(n);
+    for (size_t i = 0; i < n; ++i) {
+      F.mvStatKeysTmp[i] = cv::KeyPoint(S.x[i], S.y[i], 0, 0, 0, -1);
+      F.mvCorres[i] = cv::KeyPoint(S.cx[i], S.cy[i], 0, 0, 0, -1);
+      F.mvFlowNext[i] = cv::Point2f(S.fx[i], S.fy[i]);
+      F.mvStat3DPointTmp[i] = point3(S.xyz.data() + 3 * i);
+    }
+  }
+  {   // RenewFrameInfo, objects (:2984-2991)
+    const FramePipeline::ObjSet& O = P.ObjectSet();
+    const size_t n = O.x.size();
+    F.mvObjKeys.resize(n); F.mvObjCorres.resize(n); F.mvObjFlowNext.resize(n); F.mvObjDepth = O.d; F.mvObj3DPoint.resize(n);
+    F.vSemObjLabel.assign(O.sem.begin(), O.sem.end()); F.vObjLabel.assign(O.label.begin(), O.label.end());
+    for (size_t i = 0; i < n; ++i) {
+      F.mvObjKeys[i] = cv::KeyPoint(O.x[i], O.y[i], 0, 0, 0, -1);
+      F.mvObjCorres[i] = cv::KeyPoint(O.cx[i], O.cy[i], 0, 0, 0, -1);
+      F.mvObjFlowNext[i] = cv::Point2f(O.fx[i], O.fy[i]);
+      F.mvObj3DPoint[i] = point3(O.xyz.data() + 3 * i);
+    }
+  }
+  {   // per object of the frame (:836-933)
+    const std::vector<int32_t>&sp = P.ObjSemPosition(), &ml = P.ObjModLabel();
+    const std::vector<uint8_t>& st = P.ObjStat();
+    const std::vector<float>& Hm = P.ObjMod();
+    const size_t n = sp.size();
+    F.nSemPosition.assign(sp.begin(), sp.end()); F.nModLabel.assign(ml.begin(), ml.end());
+    F.bObjStat.resize(n); F.vObjMod.resize(n);
+    for (size_t a = 0; a < n; ++a) {
+      F.bObjStat[a] = a < st.size() && st[a] != 0;
+      F.vObjMod[a] = cv::Mat::eye(4, 4, cv::CV_32F);
+      if (16 * (a + 1) <= Hm.size()) std::memcpy(F.vObjMod[a].data, Hm.data() + 16 * a, 64);
+    }
+  }
+  {   // the semi-dense samples of the frame (Frame::Frame :201-228 -> mvTmpObj*, :2925-2983 reads them)
+    const FramePipeline::ObjSet& T = P.ObjectSamples();
+    const size_t n = std::min<size_t>((size_t)std::max(P.NumObjectSamples(), 0), T.x.size());
+    mvTmpObjKeys.resize(n); mvTmpObjCorres.resize(n); mvTmpObjFlowNext.resize(n);
+    mvTmpObjDepth.assign(T.d.begin(), T.d.begin() + n); mvTmpSemObjLabel.assign(T.sem.begin(), T.sem.begin() + n);
+    for (size_t i = 0; i < n; ++i) {
+      mvTmpObjKeys[i] = cv::KeyPoint(T.x[i], T.y[i], 0, 0, 0, -1);
+      mvTmpObjCorres[i] = cv::KeyPoint(T.cx[i], T.cy[i], 0, 0, 0, -1);
+      mvTmpObjFlowNext[i] = cv::Point2f(T.fx[i], T.fy[i]);
+    }
+  }
+  max_id = P.MaxId();
+  if (have_frame_) {                   // K1's metric depth map and the mask as UpdateMask left it
+    const int W = P.params().width, H = P.params().height;
+    mDepthMap.create(H, W, cv::CV_32F); mSegMap.create(H, W, cv::CV_32SC1);
+    P.DownloadDepth((float*)mDepthMap.data);
+    P.DownloadMask((int32_t*)mSegMap.data);
+  }
+}
+
 System::System(const std::string& strSettingsFile, const eSensor sensor) : mSensor(sensor) {
   std::ifstream f(strSettingsFile.c_str());
   if (!f.is_open()) { std::cerr << "Failed to open settings file at: " << strSettingsFile << std::endl; std::exit(-1); }
@@ -233,6 +298,61 @@ int host_system_track(VDO_SLAM::System* s, const unsigned char* im, int channels
     std::memcpy(Tcw_out, T.data, 64);
   } catch (const std::exception& e) { std::fprintf(stderr, "host_system_track: %s\n", e.what()); return -2; }
   return 0;
+}
+// Tracking::SyncFrameState() + a flat copy of what it filled (tests): what = 0 static set [10][n] (x y cx cy fx fy depth X Y Z), 1 object set
+// [12][n] (... + vSemObjLabel, vObjLabel), 2 per object [n][19] (nSemPosition, nModLabel, bObjStat, vObjMod), 3 samples [8][n]
+// (x y cx cy fx fy depth label), 4 scalars (max_id, mTcw).  Returns n (rows filled only if cap allows), -1 on a bad argument.
+int host_system_frame_state(VDO_SLAM::System* s, int what, float* out, int cap) {
+  try {
+    VDO_SLAM::Tracking* T = s->tracker();
+    T->SyncFrameState();
+    const VDO_SLAM::Frame& F = T->mCurrentFrame;
+    if (what == 0) {
+      const int n = F.N_s_tmp;
+      if (out && cap >= 10 * n)
+        for (int i = 0; i < n; ++i) {
+          const float v[10] = {F.mvStatKeysTmp[i].pt.x, F.mvStatKeysTmp[i].pt.y, F.mvCorres[i].pt.x, F.mvCorres[i].pt.y, F.mvFlowNext[i].x, F.mvFlowNext[i].y, F.mvStatDepthTmp[i],
+                               F.mvStat3DPointTmp[i].at<float>(0), F.mvStat3DPointTmp[i].at<float>(1), F.mvStat3DPointTmp[i].at<float>(2)};
+          for (int k = 0; k < 10; ++k) out[(size_t)k * n + i] = v[k];
+        }
+      return n;
+    }
+    if (what == 1) {
+      const int n = (int)F.mvObjKeys.size();
+      if (out && cap >= 12 * n)
+        for (int i = 0; i < n; ++i) {
+          const float v[12] = {F.mvObjKeys[i].pt.x, F.mvObjKeys[i].pt.y, F.mvObjCorres[i].pt.x, F.mvObjCorres[i].pt.y, F.mvObjFlowNext[i].x, F.mvObjFlowNext[i].y, F.mvObjDepth[i],
+                               F.mvObj3DPoint[i].at<float>(0), F.mvObj3DPoint[i].at<float>(1), F.mvObj3DPoint[i].at<float>(2), (float)F.vSemObjLabel[i], (float)F.vObjLabel[i]};
+          for (int k = 0; k < 12; ++k) out[(size_t)k * n + i] = v[k];
+        }
+      return n;
+    }
+    if (what == 2) {
+      const int n = (int)F.nSemPosition.size();
+      if (out && cap >= 19 * n)
+        for (int a = 0; a < n; ++a) {
+          float* o = out + 19 * (size_t)a;
+          o[0] = (float)F.nSemPosition[a]; o[1] = (float)F.nModLabel[a]; o[2] = F.bObjStat[a] ? 1.f : 0.f;
+          std::memcpy(o + 3, F.vObjMod[a].data, 64);
+        }
+      return n;
+    }
+    if (what == 3) {
+      const int n = (int)T->mvTmpObjKeys.size();
+      if (out && cap >= 8 * n)
+        for (int i = 0; i < n; ++i) {
+          const float v[8] = {T->mvTmpObjKeys[i].pt.x, T->mvTmpObjKeys[i].pt.y, T->mvTmpObjCorres[i].pt.x, T->mvTmpObjCorres[i].pt.y, T->mvTmpObjFlowNext[i].x, T->mvTmpObjFlowNext[i].y,
+                              T->mvTmpObjDepth[i], (float)T->mvTmpSemObjLabel[i]};
+          for (int k = 0; k < 8; ++k) out[(size_t)k * n + i] = v[k];
+        }
+      return n;
+    }
+    if (what == 4) {
+      if (out && cap >= 17) { out[0] = (float)T->max_id; std::memcpy(out + 1, F.mTcw.data, 64); }
+      return 1;
+    }
+  } catch (const std::exception& e) { std::fprintf(stderr, "host_system_frame_state: %s\n", e.what()); }
+  return -1;
 }
 // throughput mode of the shell: the object stage of a frame ends inside the next TrackRGBD call (same results, the object motions of
 // frame k become visible with frame k+1; the final batch optimisation / SaveResults / map() flush it).  Off by default: the

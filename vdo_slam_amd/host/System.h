@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 
+#include "Frame.h"
 #include "FramePipeline.h"
 #include "Map.h"
 #include "minicv.h"
@@ -26,9 +27,21 @@ class Tracking {
                         const std::vector<std::vector<float> >& vObjPose_gt, const double& timestamp, cv::Mat& imTraj, const int& nImage);
   FramePipeline* pipeline() { return pipe_.get(); }
 
-  // ---- public state of the reference class (include/Tracking.h:116-198) that is scalar configuration / progress.  The per-frame
-  // containers of the reference (mCurrentFrame, mImGray, mSegMap, TemperalMatch, mvTmpObj* ...) live in HBM / inside FramePipeline
-  // here and are not mirrored as host members; FramePipeline's accessors (Tcw_out_, motions_, store(), DownloadMask/Depth) serve them.
+  // ---- public state of the reference class (include/Tracking.h:116-198).  Scalar configuration / progress members are kept up to date by
+  // every call.  The per-frame containers live in HBM / in FramePipeline's flat arrays; SyncFrameState() materialises them in the reference's
+  // form on request (as System::map() does for the Map): mCurrentFrame - mTcw, the renewed static set (mvStatKeysTmp, mvStatDepthTmp,
+  // mvStat3DPointTmp, mvCorres, mvFlowNext, N_s_tmp), the renewed object set (mvObjKeys, mvObjDepth, mvObj3DPoint, mvObjCorres, mvObjFlowNext,
+  // vSemObjLabel, vObjLabel) and the per-object vectors (nSemPosition, nModLabel, bObjStat, vObjMod) as Track() leaves them
+  // (src/Tracking.cc:2780-2812, 2984-2991, 836-933) -, the semi-dense samples mvTmpObj*, max_id, and the converted depth map / repaired mask
+  // (mDepthMap, mSegMap).  mImGray / mFlowMap are the caller's own buffers; TemperalMatch* and repro_e are locals of Track() here.
+  void SyncFrameState();
+  Frame mCurrentFrame;
+  cv::Mat mDepthMap, mSegMap;
+  std::vector<cv::KeyPoint> mvTmpObjKeys, mvTmpObjCorres;
+  std::vector<float> mvTmpObjDepth;
+  std::vector<int> mvTmpSemObjLabel;
+  std::vector<cv::Point2f> mvTmpObjFlowNext;
+  int max_id = 1;
   enum eTrackingState { NO_IMAGES_YET = 0, NOT_INITIALIZED = 1, OK = 2 };
   eTrackingState mState = NO_IMAGES_YET, mLastProcessedState = NO_IMAGES_YET;
   enum eDataState { OMD = 1, KITTI = 2, VirtualKITTI = 3 };
