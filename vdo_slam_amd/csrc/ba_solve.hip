@@ -4,13 +4,16 @@
 // part is eliminated first — block-diagonal for static points, block-tridiagonal along each
 // dynamic track (the ternary edge couples consecutive observations, src/Optimizer.cc:1704-1741)
 // — and the reduced pose/motion system S = Hpp - Hpl Hll^-1 Hlp is solved matrix-free with
-// conjugate gradients preconditioned by the exact 6x6 diagonal blocks of S.  x equals the
+// conjugate gradients preconditioned by the block-tridiagonal matrix M = blockdiag(S) + EdgeSE3
+// off-diagonal blocks along every pose chain (block LDL^T, k_pchain_factor).  x equals the
 // direct solve up to the PCG tolerance.
 //
 // One workgroup per TILE for everything that touches landmarks (ba_dev.hpp): each thread keeps
-// its <=3 incidence blocks (6x3) in registers, B^T v accumulates per point in LDS, the chain
-// solves run in LDS, and B w is segment-reduced per pose slot -> the 6x3 blocks are read from
-// HBM exactly once per CG iteration and there are no global atomics.
+// its <=3 incidences in registers (the Huber-weighted information scalar from HBM, the 6x3 block
+// recomputed from the LDS-resident point and inverse pose: make_f), B^T v accumulates per point in
+// LDS, the landmark-chain solves run there, and B w is segment-reduced per pose slot into pose-major
+// partial rows -> 8 B per incidence from HBM per CG iteration, no global atomics.  One WAVE per
+// pose and one workgroup per pose chain for the vector phases of the CG (k_pcg_q, k_pcg_chain).
 #include <atomic>
 
 #include "ba_dev.hpp"

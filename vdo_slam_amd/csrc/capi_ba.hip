@@ -375,7 +375,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(pe_off, pe_off.data(), P + 1); UP(pe_idx, pe_idx.data(), pe_idx.size());
   UP(pr_off, pr_off.data(), P + 1); UP(pr_idx, pr_idx.data(), pr_idx.size());
   d.n_pchains = n_pchains;
-  {   // LDS strips of the chain preconditioner (ba_solve.hip pchain_apply_lds): [len][6] doubles per resident chain, <= 144 KB in all
+  {   // LDS strip of a pose chain's workgroup (ba_solve.hip pchain_solve_partitioned): [len][6] doubles, <= 144 KB
     int maxlen = 1;
     for (int c = 0; c < n_pchains; ++c) maxlen = std::max(maxlen, (int)(pc_off[c + 1] - pc_off[c]));
     d.pc_maxlen = maxlen;
