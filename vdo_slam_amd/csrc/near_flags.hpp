@@ -1,6 +1,8 @@
 // "Is there a reference point within 1 px" for every query point — the O(n*m) test of
 // Tracking::RenewFrameInfo (reference src/Tracking.cc:2727-2745 static, :2893-2907 objects).
-// Float arithmetic as in the reference: sqrt((rx-qx)^2 + (ry-qy)^2) < 1.
+// Float arithmetic as in the reference: sqrt((rx-qx)^2 + (ry-qy)^2) < 1 - evaluated as (rx-qx)^2 + (ry-qy)^2 < 1 on the same float sum:
+// the correctly rounded square root of a float below 1 is below 1 (the largest, 1 - 2^-24, has the root 1 - 2^-25 - ..., which rounds down) and
+// sqrt(1) = 1, so the two predicates agree for every input, and the quarter-rate v_sqrt_f32 leaves the 256-step inner loop.
 // 2-D grid: block (bx, by) tests 256 queries against 256 references staged in LDS and ORs its verdict
 // into used[] (callers zero it first): a few hundred workgroups instead of ~20 that each walk the whole
 // reference set (83 -> ~6 us for 5.5 k x 3.9 k points).
@@ -25,7 +27,7 @@ static __global__ __launch_bounds__(256) void k_near_flags(int nq, const float* 
   int u = 0;
   for (int k = 0; k < m; ++k) {
     const float dx = sx[k] - x, dy = sy[k] - y;
-    if (sqrtf(dx * dx + dy * dy) < 1.0f) u = 1;
+    if (dx * dx + dy * dy < 1.0f) u = 1;
   }
   if (u) atomicOr(&used[i], 1);
 }
@@ -49,7 +51,7 @@ static __global__ __launch_bounds__(256) void k_near_flags_sel(int nq, const flo
   int u = 0;
   for (int k = 0; k < m; ++k) {
     const float dx = sx[k] - x, dy = sy[k] - y;
-    if (sqrtf(dx * dx + dy * dy) < 1.0f) u = 1;
+    if (dx * dx + dy * dy < 1.0f) u = 1;
   }
   if (u) atomicOr(&used[i], 1);
 }
