@@ -43,9 +43,13 @@ def test_traffic_is_the_counter_figure_of_the_committed_profile():
     m = re.search(r"= ([0-9.]+) MB \+ ([0-9.]+) MB = ([0-9.]+) MB", txt)
     assert m, txt
     assert abs(float(m.group(3)) * 1e6 - d["roofline"]["traffic"]) <= 0.06e6
-    # the profile's kernel time and the live hipEvent time of the bench agree
+    # the kernel time of the rocprofv3 --kernel-trace pass and the live hipEvent time of the bench agree (the --pmc passes run the kernel a
+    # few per cent slower: looser bound)
+    kt = open(os.path.join(ROOT, "profiles", "r03_sweep_kernel_stats.txt")).read()
+    avg = float(re.search(r"k_sweep_tile<true>[^|]*\|\s*\d+\s*\|\s*[0-9.]+\s*\|\s*([0-9.]+)", kt).group(1))
+    assert abs(avg - d["roofline"]["avg_launch_ms"] * 1e3) < 0.08 * avg, (avg, d["roofline"]["avg_launch_ms"])
     us = float(re.search(r"avg_duration=([0-9.]+) us", txt).group(1))
-    assert abs(us - d["roofline"]["avg_launch_ms"] * 1e3) < 0.08 * us
+    assert abs(us - d["roofline"]["avg_launch_ms"] * 1e3) < 0.15 * us
 
 
 def test_value_is_the_reference_semantics_number():
