@@ -1,5 +1,6 @@
 #!/bin/bash
-# scratch: builds vdo_slam_amd/libvdo_hip_$1.so with ba_sweep.hip compiled with the extra flags $2
+# A/B builds: tools/build_variant.sh NAME "-DFLAG ..." [source without .hip, default ba_sweep] -> vdo_slam_amd/libvdo_hip_NAME.so = the product library with that
+# one source compiled with the extra flags (load it with VDO_HIP_LIB=...; the product library is not touched)
 set -e
 cd "$(dirname "$0")/../vdo_slam_amd/csrc"
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -ffp-contract=off -Wno-unused-value"

@@ -1,3 +1,4 @@
+# rocprofv3 kernel statistics of the LM on the roofline graph (2 190 poses) and on the bench graph -> gpurun_out/r03e/ (run through gpurun)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r03e; mkdir -p $O
 timeout 150 rocprofv3 --kernel-trace --stats -d $O/prof_ba_large -- python $R/tools/ba_probe.py 200 600000 10 1500 3 0 > $O/ba_large.log 2>&1
