@@ -79,6 +79,15 @@ __device__ __forceinline__ void acc_edge(double (&acc)[16], int& cur, int slot, 
   acc[10] = __builtin_fma(we, er.x, acc[10]); acc[11] = __builtin_fma(we, er.y, acc[11]); acc[12] = __builtin_fma(we, er.z, acc[12]);
   acc[13] = __builtin_fma(we, c.y * er.z - c.z * er.y, acc[13]); acc[14] = __builtin_fma(we, c.z * er.x - c.x * er.z, acc[14]); acc[15] = __builtin_fma(we, c.x * er.y - c.y * er.x, acc[15]);
 }
+// the 16 running sums of one edge (see acc_edge), for a thread whose edges share a pose slot
+__device__ __forceinline__ void acc_terms(double (&acc)[16], double we, D3 c, D3 er) {
+  const double wx = we * c.x, wy = we * c.y, wz = we * c.z;
+  acc[0] += we; acc[1] += wx; acc[2] += wy; acc[3] += wz;
+  acc[4] = __builtin_fma(wx, c.x, acc[4]); acc[5] = __builtin_fma(wx, c.y, acc[5]); acc[6] = __builtin_fma(wx, c.z, acc[6]); acc[7] = __builtin_fma(wy, c.y, acc[7]);
+  acc[8] = __builtin_fma(wy, c.z, acc[8]); acc[9] = __builtin_fma(wz, c.z, acc[9]);
+  acc[10] = __builtin_fma(we, er.x, acc[10]); acc[11] = __builtin_fma(we, er.y, acc[11]); acc[12] = __builtin_fma(we, er.z, acc[12]);
+  acc[13] = __builtin_fma(we, c.y * er.z - c.z * er.y, acc[13]); acc[14] = __builtin_fma(we, c.z * er.x - c.x * er.z, acc[14]); acc[15] = __builtin_fma(we, c.x * er.y - c.y * er.x, acc[15]);
+}
 __device__ __forceinline__ void acc_finish(double (&acc)[16], int cur, double* accpose_base, int arow) {
   const SegCtl16 sc = seg_ctl16(cur);
   const SegFlags sf = seg_flags(sc);
@@ -105,17 +114,19 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   const double* __restrict__ point = d.point[which] + 3 * (int64_t)T.pt_begin;
   const int tid = threadIdx.x;
   const int64_t Eb = d.Eb, Et = d.Et;
-  // ---- this thread's EdgeSE3PointXYZ inputs (<= 3 consecutive edges) are requested first: their HBM latency runs under the staging
-  const int nbe = T.eb_end - T.eb_begin;
-  const int per_b = (nbe + VDO_TILE_THREADS - 1) / VDO_TILE_THREADS;          // consecutive edges per thread (<= 3)
+  // ---- this thread's EdgeSE3PointXYZ inputs are requested first: their HBM latency runs under the staging.  <= 3 consecutive edges of ONE
+  // pose slot (thr_tab, built with the tiles): no slot bookkeeping per edge, the slot's inverse pose is read once, nothing is flushed to
+  // the slot accumulators before the thread is through
+  const unsigned tt = d.thr_tab[(int64_t)ti * VDO_TILE_THREADS + tid];
+  const int e0 = T.eb_begin + (int)(tt >> 2), ecnt = (int)(tt & 3u);
   int ekey[3];
   double ew[3];
   D3 ez[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) {
-    const int e = T.eb_begin + tid * per_b + j;
+    const int e = e0 + j;
     ekey[j] = -1; ew[j] = 0.0; ez[j] = D3{0.0, 0.0, 0.0};
-    if (j < per_b && e < T.eb_end) {
+    if (j < ecnt) {
       ekey[j] = d.eb_key[e];
       ew[j] = d.eb_w ? d.eb_w[e] : d.eb_w_uni;                                  // (wave-uniform choices: 16 B per edge instead of 36 B)
       ez[j] = d.eb_zf ? D3{(double)d.eb_zf[e], (double)d.eb_zf[Eb + e], (double)d.eb_zf[2 * Eb + e]} : D3{d.eb_z[e], d.eb_z[Eb + e], d.eb_z[2 * Eb + e]};
@@ -139,17 +150,22 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   // ------------------------------------------------------------------ EdgeSE3PointXYZ
   {
     double acc[16];
-    int cur = -1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+    const int slot = ecnt ? (ekey[0] >> 16) : -1;
+    double Wp[12];                                 // W.r = R^T = Jl (row-major), W.t of the thread's slot
+    {
+      const double* Ws = slotW + 12 * (slot >= 0 ? slot : 0);
+#pragma unroll
+      for (int i = 0; i < 12; ++i) Wp[i] = Ws[i];
+    }
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      const int e = T.eb_begin + tid * per_b + j;
-      if (ekey[j] >= 0) {
-        const int key = ekey[j];
-        const int slot = key >> 16;
-        const int lp = key & 0xffff;
+      if (j < ecnt) {
+        const int e = e0 + j;
+        const int lp = ekey[j] & 0xffff;
         const double w = ew[j];
         const D3 z = ez[j];
-        const double* Wp = slotW + 12 * slot;   // W.r = R^T = Jl (row-major), W.t
         const D3 p{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
         const D3 zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
         const D3 er = zc - z;
@@ -167,11 +183,11 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
           const D3 Re = rotT(Wp, er);
           atomicAdd(accpt + lp, we);
           atomicAdd(accpt + VDO_TILE_PTS + lp, -we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + lp, -we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + lp, -we * Re.z);
-          acc_edge(acc, cur, slot, we, zc, er, accpose, arow);
+          acc_terms(acc, we, zc, er);
         }
       }
     }
-    if (BUILD) acc_finish(acc, cur, accpose, arow);
+    if (BUILD) acc_finish(acc, slot, accpose, arow);
   }
   // ------------------------------------------------------------ LandmarkMotionTernaryEdge
   {

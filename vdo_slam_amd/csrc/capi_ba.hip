@@ -74,16 +74,17 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     std::vector<int32_t> fill(pb_off.begin(), pb_off.end() - 1);
     for (int e = 0; e < Eb; ++e) pb_idx[fill[g->eb_point[e]]++] = e;
   }
-  struct ChainInfo { int32_t head; int32_t npts; int32_t ninc; int32_t key; };
+  struct ChainInfo { int32_t head; int32_t npts; int32_t ninc; int32_t key; int32_t nb; };
   std::vector<ChainInfo> chains;
   chains.reserve(L);
   int visited = 0;
   for (int l = 0; l < L; ++l) {
     if (prev_e[l] != -1) continue;
-    ChainInfo ci{l, 0, 0, P};
+    ChainInfo ci{l, 0, 0, P, 0};
     for (int cur = l;;) {
       ++ci.npts; ++visited;
       ci.ninc += pb_off[cur + 1] - pb_off[cur];
+      ci.nb += pb_off[cur + 1] - pb_off[cur];
       for (int k = pb_off[cur]; k < pb_off[cur + 1]; ++k) ci.key = std::min(ci.key, g->eb_pose[pb_idx[k]]);
       const int e = next_e[cur];
       if (e == -1) break;
@@ -113,7 +114,11 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   std::vector<int32_t> tile_eb, tile_et;           // original ids of the open tile
   int max_slots = 1;
   Tile cur{};
-  int cur_tile_id = 0, cur_npts = 0, cur_ninc = 0;
+  int cur_tile_id = 0, cur_npts = 0, cur_ninc = 0, cur_nb = 0;
+  bool thr_overflow = false;
+  int cur_need = 0;                                // threads the open tile needs: sum over its pose slots of ceil(edges / 3)
+  std::vector<int32_t> pose_cnt(P, 0), cnt_stamp(P, -1), chain_eb_poses;
+  std::vector<uint16_t> thr_tab;                   // per (tile, thread): (first EdgeSE3PointXYZ of the thread, relative to the tile) << 2 | count (ba_dev.hpp)
   auto chain_poses = [&](const ChainInfo& ci, std::vector<int32_t>& outp) {
     outp.clear();
     for (int c = ci.head;;) {
@@ -148,6 +153,26 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       eb_key[en] = key;
       inc_key[inc_total + j] = key;
     }
+    {   // threads of the sweep: runs of equal pose slot cut into pieces of <= pb edges, pb the smallest of 1 .. 3 that fits 256 threads
+      int pb = 1;
+      for (; pb < 3; ++pb) {
+        int need = 0;
+        for (int j = 0; j < nb;) { int k = j; while (k < nb && g->eb_pose[tile_eb[k]] == g->eb_pose[tile_eb[j]]) ++k; need += (k - j + pb - 1) / pb; j = k; }
+        if (need <= VDO_TILE_THREADS) break;
+      }
+      const size_t base = thr_tab.size();
+      thr_tab.resize(base + VDO_TILE_THREADS, 0);
+      int t = 0;
+      for (int j = 0; j < nb;) {
+        int k = j;
+        while (k < nb && g->eb_pose[tile_eb[k]] == g->eb_pose[tile_eb[j]]) ++k;
+        for (int q = j; q < k; q += pb, ++t) {
+          if (t >= VDO_TILE_THREADS) { thr_overflow = true; break; }
+          thr_tab[base + t] = (uint16_t)((q << 2) | std::min(pb, k - q));
+        }
+        j = k;
+      }
+    }
     for (int j = 0; j < nt; ++j) {
       const int e = tile_et[j];
       const int en = (int)et_old_of_new.size();
@@ -167,7 +192,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     cur.chain_end = (int32_t)chain_off.size() - 1;
     tiles.push_back(cur);
     ++cur_tile_id;
-    cur_npts = 0; cur_ninc = 0;
+    cur_npts = 0; cur_ninc = 0; cur_nb = 0; cur_need = 0;
     cur_poses.clear(); tile_eb.clear(); tile_et.clear();
   };
   std::vector<int32_t> cposes;
@@ -180,8 +205,27 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     chain_poses(ci, cposes);
     int newp = 0;
     for (int32_t p : cposes) if (pose_stamp[p] != cur_tile_id) ++newp;   // upper bound (duplicates inside the chain counted once below)
+    // (+ every thread of the sweep takes <= 3 edges of ONE pose slot: the sum over the slots of ceil(edges / 3) must fit the 256 threads)
+    auto pieces_with_chain = [&](bool commit) {
+      int need = cur_need;
+      chain_eb_poses.clear();
+      for (int c = ci.head;;) {
+        for (int k = pb_off[c]; k < pb_off[c + 1]; ++k) chain_eb_poses.push_back(g->eb_pose[pb_idx[k]]);
+        const int e = next_e[c];
+        if (e == -1) break;
+        c = g->et_p2[e];
+      }
+      for (int32_t p : chain_eb_poses) {
+        if (cnt_stamp[p] != cur_tile_id) { cnt_stamp[p] = cur_tile_id; pose_cnt[p] = 0; }
+        if (pose_cnt[p] % 3 == 0) ++need;
+        ++pose_cnt[p];
+      }
+      if (commit) cur_need = need;
+      else for (int32_t p : chain_eb_poses) --pose_cnt[p];
+      return need;
+    };
     if (cur_npts > 0 && (cur_npts + ci.npts > VDO_TILE_PTS || cur_ninc + ci.ninc > VDO_TILE_INC ||
-                         (int)cur_poses.size() + newp > kSoftSlots))
+                         (int)cur_poses.size() + newp > kSoftSlots || pieces_with_chain(false) > VDO_TILE_THREADS))
       close_tile();
     if (cur_npts == 0) {
       cur = Tile{};
@@ -205,9 +249,11 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       c = g->et_p2[e];
     }
     chain_off.push_back((int32_t)pt_old_of_new.size());
-    cur_npts += ci.npts; cur_ninc += ci.ninc;
+    cur_npts += ci.npts; cur_ninc += ci.ninc; cur_nb += ci.nb;
+    pieces_with_chain(true);
   }
   close_tile();
+  if (thr_overflow) { delete ba; return set_error(VDO_ERR_UNSUPPORTED, "a tile has more pose-slot pieces than threads"); }
   for (auto& pe : pt_prev_edge_new) if (pe >= 0) pe = et_new_of_old[pe];
   const int n_tiles = (int)tiles.size(), NPS = (int)tile_pose.size(), n_chains = (int)chain_off.size() - 1;
 
@@ -337,6 +383,8 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(pose[0], g->pose, 12 * (size_t)P); UP(pose[1], g->pose, 12 * (size_t)P);
   UP(point[0], point_new.data(), 3 * (size_t)L); UP(point[1], point_new.data(), 3 * (size_t)L);
   UP(tiles, tiles.data(), n_tiles); UP(tile_pose, tile_pose.data(), NPS);
+  thr_tab.resize(std::max<size_t>(thr_tab.size(), 1));
+  UP(thr_tab, thr_tab.data(), thr_tab.size());
   {
     std::vector<int32_t> order(std::max(n_tiles, 1), 0), longest(std::max(n_tiles, 1), 0);
     for (int t = 0; t < n_tiles; ++t) { order[t] = t; for (int c = tiles[t].chain_begin; c < tiles[t].chain_end; ++c) longest[t] = std::max(longest[t], chain_off[c + 1] - chain_off[c]); }
