@@ -86,7 +86,8 @@ __device__ __forceinline__ void acc_terms(double (&acc)[16], double we, D3 c, D3
   acc[4] = __builtin_fma(wx, c.x, acc[4]); acc[5] = __builtin_fma(wx, c.y, acc[5]); acc[6] = __builtin_fma(wx, c.z, acc[6]); acc[7] = __builtin_fma(wy, c.y, acc[7]);
   acc[8] = __builtin_fma(wy, c.z, acc[8]); acc[9] = __builtin_fma(wz, c.z, acc[9]);
   acc[10] = __builtin_fma(we, er.x, acc[10]); acc[11] = __builtin_fma(we, er.y, acc[11]); acc[12] = __builtin_fma(we, er.z, acc[12]);
-  acc[13] = __builtin_fma(we, c.y * er.z - c.z * er.y, acc[13]); acc[14] = __builtin_fma(we, c.z * er.x - c.x * er.z, acc[14]); acc[15] = __builtin_fma(we, c.x * er.y - c.y * er.x, acc[15]);
+  acc[13] = __builtin_fma(we, __builtin_fma(c.y, er.z, -(c.z * er.y)), acc[13]); acc[14] = __builtin_fma(we, __builtin_fma(c.z, er.x, -(c.x * er.z)), acc[14]);
+  acc[15] = __builtin_fma(we, __builtin_fma(c.x, er.y, -(c.y * er.x)), acc[15]);
 }
 __device__ __forceinline__ void acc_finish(double (&acc)[16], int cur, double* accpose_base, int arow) {
   const SegCtl16 sc = seg_ctl16(cur);
@@ -180,7 +181,10 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
           d.Finc[e] = we;
           // landmark side: Hll += we * Jl^T Jl = we * R R^T = we * I (R is a rotation: g2o's product differs from I by a few
           // 1e-16, far inside the 1e-12 parity bar) -> ONE running sum per point; bl += -we * R e   (R e = Jl^T e)
-          const D3 Re = rotT(Wp, er);
+          // (R e and the cross product zc x e by fused multiply-adds: no cancellation follows them, the blocks move by ~1e-16 of their size -
+          // unlike zc itself, whose last bit the subtraction zc - z amplifies past the 1e-12 parity bar)
+          const D3 Re{__builtin_fma(Wp[6], er.z, __builtin_fma(Wp[3], er.y, Wp[0] * er.x)), __builtin_fma(Wp[7], er.z, __builtin_fma(Wp[4], er.y, Wp[1] * er.x)),
+                      __builtin_fma(Wp[8], er.z, __builtin_fma(Wp[5], er.y, Wp[2] * er.x))};
           atomicAdd(accpt + lp, we);
           atomicAdd(accpt + VDO_TILE_PTS + lp, -we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + lp, -we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + lp, -we * Re.z);
           acc_terms(acc, we, zc, er);
