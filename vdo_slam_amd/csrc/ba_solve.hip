@@ -223,7 +223,8 @@ __device__ __forceinline__ void bgbt(const double (&B1)[18], const double* G, co
 // Exact diagonal blocks of the Schur correction, per (tile,slot):  sum B G B^T  (21 upper entries)
 __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const Tile T = d.tiles[d.tile_order[blockIdx.x]];
+  const int ti = d.tile_order[blockIdx.x];
+  const Tile T = d.tiles[ti];
   const int nslot = T.slot_end - T.slot_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
   double* accm = smem;                       // [21 * S]
@@ -233,33 +234,51 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   for (int i = tid; i < 21 * nslot; i += VDO_TILE_THREADS) accm[i] = 0.0;
   stage_slot_w_pts(d, T, slotW, pts);
   __syncthreads();
-  for (int base = 0; base < nb; base += VDO_TILE_THREADS) {
-    const int j = base + tid;
+  {
+    // EdgeSE3PointXYZ incidences by the sweep's thread table: <= 3 consecutive edges of ONE pose slot per thread - their contributions
+    // add up in registers and go through ONE segmented scan.  A point that is a chain of its own (every static landmark) has
+    // [Hll^-1]_ll = g I3, and its block B = -we [I ; 2[c]x] R^T gives  B G B^T = g we^2 [I ; 2[c]x] [I ; 2[c]x]^T  (R drops out): a function of
+    // ten running sums  s, s c, s c c^T  (s = g we^2) - no 6x3 block, no 6x6 product.
+    const unsigned tt = d.thr_tab[(int64_t)ti * VDO_TILE_THREADS + tid];
+    const int j0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
     int slot = -1;
     double up[21];
 #pragma unroll
     for (int i = 0; i < 21; ++i) up[i] = 0.0;
-    if (j < nb) {
-      const int64_t idx = T.inc_begin + j;
-      const int key = d.inc_key[idx];
-      slot = key >> 16;
-      const int64_t l = T.pt_begin + (key & 0xffff);
-      double B[18], M[36];
-      expand_block(0, make_f(d, T, j, 0, key, d.Finc[T.eb_begin + j], slotW, pts), slotW + 12 * slot, B);
-      if (d.pt_single[l]) {                            // [Hll^-1]_ll = g I3:  B G B^T = g B B^T
-        const double g = d.dscal[l];
+    double s0 = 0.0, sx = 0.0, sy = 0.0, sz = 0.0, sxx = 0.0, sxy = 0.0, sxz = 0.0, syy = 0.0, syz = 0.0, szz = 0.0;
 #pragma unroll
-        for (int r = 0; r < 6; ++r)
+    for (int q = 0; q < 3; ++q) {
+      if (q < ecnt) {
+        const int j = j0 + q;
+        const int key = d.inc_key[T.inc_begin + j];
+        slot = key >> 16;
+        const int64_t l = T.pt_begin + (key & 0xffff);
+        const FInc f = make_f(d, T, j, 0, key, d.Finc[T.eb_begin + j], slotW, pts);
+        if (d.pt_single[l]) {
+          const double sw = d.dscal[l] * f.we * f.we;
+          const double wx = sw * f.cx, wy = sw * f.cy, wz = sw * f.cz;
+          s0 += sw; sx += wx; sy += wy; sz += wz;
+          sxx += wx * f.cx; sxy += wx * f.cy; sxz += wx * f.cz; syy += wy * f.cy; syz += wy * f.cz; szz += wz * f.cz;
+        } else {
+          double B[18], M[36];
+          expand_block(0, f, slotW + 12 * slot, B);
+          bgbt(B, d.Gdiag + 9 * l, B, M);
+          int k = 0;
 #pragma unroll
-          for (int c = r; c < 6; ++c) M[6 * r + c] = g * (B[3 * r] * B[3 * c] + B[3 * r + 1] * B[3 * c + 1] + B[3 * r + 2] * B[3 * c + 2]);
-      } else bgbt(B, d.Gdiag + 9 * l, B, M);
-      int k = 0;
+          for (int r = 0; r < 6; ++r)
 #pragma unroll
-      for (int r = 0; r < 6; ++r)
-#pragma unroll
-        for (int c = r; c < 6; ++c) up[k++] = M[6 * r + c];
+            for (int c = r; c < 6; ++c) up[k++] += M[6 * r + c];
+        }
+      }
     }
-    { const SegCtl16 sc_ = seg_ctl16(slot); seg_apply16<21>(up, sc_, seg_flags(sc_), accm + 21 * (slot >= 0 ? slot : 0)); }
+    // upper triangle (row-major, 21 entries) of  s [[I, -2[c]x], [2[c]x, 4 (|c|^2 I - c c^T)]]  summed over the thread's single points
+    up[0] += s0; up[4] += 2.0 * sz; up[5] += -2.0 * sy;
+    up[6] += s0; up[8] += -2.0 * sz; up[10] += 2.0 * sx;
+    up[11] += s0; up[12] += 2.0 * sy; up[13] += -2.0 * sx;
+    up[15] += 4.0 * (syy + szz); up[16] += -4.0 * sxy; up[17] += -4.0 * sxz;
+    up[18] += 4.0 * (sxx + szz); up[19] += -4.0 * syz;
+    up[20] += 4.0 * (sxx + syy);
+    if (nb > 0) { const SegCtl16 sc_ = seg_ctl16(slot); seg_apply16<21>(up, sc_, seg_flags(sc_), accm + 21 * (slot >= 0 ? slot : 0)); }
   }
   for (int base = 0; base < nt; base += VDO_TILE_THREADS) {
     const int j = base + tid;
