@@ -795,39 +795,65 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) vs[i] = v[6 * (int64_t)d.tile_pose[T.slot_begin + i / 6] + i % 6];
   if (MODE != 2)
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) qs[i] = 0.0;
-  // factored incidence blocks in registers: we requested now, c formed behind the staging barrier
-  FInc F[3];
-  int key[3], kind[3];
-  double we[3];
+  // EdgeSE3PointXYZ incidences by the sweep's thread table: <= 3 consecutive ones of ONE pose slot per thread (key and we requested now, c
+  // formed behind the staging barrier; the slot's inverse pose and its part of v are read once, the thread's B w add up in registers and go
+  // through ONE segmented scan).  The incidences of the ternary edges (dynamic tiles only) follow in strided loops, one scan per round.
+  const int ti_ = d.tile_order[blockIdx.x];
+  const unsigned tt = d.thr_tab[(int64_t)ti_ * VDO_TILE_THREADS + tid];
+  const int j0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
+  int keyb[3];
+  double web[3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int li = tid + VDO_TILE_THREADS * j;
-    key[j] = -1; kind[j] = 1; we[j] = 0.0;
-    if (li < ninc) {
-      key[j] = d.inc_key[T.inc_begin + li];
-      int64_t fidx;
-      inc_locate(T, li, d.Eb, kind[j], fidx);
-      we[j] = d.Finc[fidx];
-    }
+  for (int q = 0; q < 3; ++q) {
+    keyb[q] = -1; web[q] = 0.0;
+    if (q < ecnt) { keyb[q] = d.inc_key[T.inc_begin + j0 + q]; web[q] = d.Finc[T.eb_begin + j0 + q]; }
   }
   __syncthreads();
+  const int slotb = ecnt ? (keyb[0] >> 16) : -1;
+  double Wb[12];
+  {
+    const double* Ws = slotW + 12 * (slotb >= 0 ? slotb : 0);
 #pragma unroll
-  for (int j = 0; j < 3; ++j) F[j] = key[j] >= 0 ? make_f(d, T, tid + VDO_TILE_THREADS * j, kind[j], key[j], we[j], slotW, pts) : FInc{0, 0, 0, 0};
+    for (int i = 0; i < 12; ++i) Wb[i] = Ws[i];
+  }
+  D3 cb[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) {
+    const int lp = keyb[q] >= 0 ? (keyb[q] & 0xffff) : 0;
+    cb[q] = rot(Wb, D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]}) + D3{Wb[9], Wb[10], Wb[11]};
+  }
+  // one incidence of a ternary edge (li >= nb): kind 1 = (H, p1), kind 2 = (H, p2)
+  auto tern_load = [&](int li, int& key, int& kind, FInc& f) {
+    key = d.inc_key[T.inc_begin + li];
+    int64_t fidx;
+    inc_locate(T, li, d.Eb, kind, fidx);
+    f = make_f(d, T, li, kind, key, d.Finc[fidx], slotW, pts);
+  };
   if (MODE != 1) {   // pass A: u_l += B^T v_slot = sgn*we * (I or R) (vt - s c x vr)
+    double pv[6];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if (key[j] >= 0) {
-        const int sl = key[j] >> 16;
-        const double* pv = vs + 6 * sl;
-        const double s = kind[j] == 0 ? 2.0 : 1.0;
-        const FInc f = F[j];
-        const D3 t{pv[0] - s * (f.cy * pv[5] - f.cz * pv[4]), pv[1] - s * (f.cz * pv[3] - f.cx * pv[5]), pv[2] - s * (f.cx * pv[4] - f.cy * pv[3])};
-        D3 o;
-        if (kind[j] == 1) o = f.we * t;
-        else o = (-f.we) * rotT(slotW + 12 * sl, t);       // R t  (slotW starts with R^T)
-        double* ul = u + 3 * (key[j] & 0xffff);
+    for (int i = 0; i < 6; ++i) pv[i] = vs[6 * (slotb >= 0 ? slotb : 0) + i];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      if (keyb[q] >= 0) {
+        const D3 c = cb[q];
+        const D3 t{pv[0] - 2.0 * (c.y * pv[5] - c.z * pv[4]), pv[1] - 2.0 * (c.z * pv[3] - c.x * pv[5]), pv[2] - 2.0 * (c.x * pv[4] - c.y * pv[3])};
+        const D3 o = (-web[q]) * rotT(Wb, t);              // R t  (W starts with R^T)
+        double* ul = u + 3 * (keyb[q] & 0xffff);
         atomicAdd(ul, o.x); atomicAdd(ul + 1, o.y); atomicAdd(ul + 2, o.z);
       }
+    }
+    for (int li = nb + tid; li < ninc; li += VDO_TILE_THREADS) {
+      int key, kind; FInc f;
+      tern_load(li, key, kind, f);
+      const int sl = key >> 16;
+      const double* pw = vs + 6 * sl;
+      const D3 t{pw[0] - (f.cy * pw[5] - f.cz * pw[4]), pw[1] - (f.cz * pw[3] - f.cx * pw[5]), pw[2] - (f.cx * pw[4] - f.cy * pw[3])};
+      D3 o;
+      if (kind == 1) o = f.we * t;
+      else o = (-f.we) * rotT(slotW + 12 * sl, t);
+      double* ul = u + 3 * (key & 0xffff);
+      atomicAdd(ul, o.x); atomicAdd(ul + 1, o.y); atomicAdd(ul + 2, o.z);
     }
     __syncthreads();
   }
@@ -888,20 +914,41 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     return;
   }
   // pass C: q_slot += B w_l  (segmented wave reduction; incidences are slot-sorted per part)
+  {
+    double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    double q[6];
-    const double* wl = u + 3 * (key[j] >= 0 ? (key[j] & 0xffff) : 0);
-    const int sl = key[j] >= 0 ? (key[j] >> 16) : 0;
-    const FInc f = F[j];
-    D3 y{wl[0], wl[1], wl[2]};
-    if (kind[j] != 1) y = rot(slotW + 12 * sl, y);         // R^T w
-    const double sg = kind[j] == 1 ? f.we : -f.we, s = kind[j] == 0 ? 2.0 : 1.0;
-    q[0] = sg * y.x; q[1] = sg * y.y; q[2] = sg * y.z;
-    q[3] = sg * s * (f.cy * y.z - f.cz * y.y);
-    q[4] = sg * s * (f.cz * y.x - f.cx * y.z);
-    q[5] = sg * s * (f.cx * y.y - f.cy * y.x);
-    const int skey = key[j] >= 0 ? (key[j] >> 16) : -1;
+    for (int k = 0; k < 3; ++k) {
+      if (keyb[k] >= 0) {
+        const double* wl = u + 3 * (keyb[k] & 0xffff);
+        const D3 y = rot(Wb, D3{wl[0], wl[1], wl[2]});       // R^T w
+        const D3 c = cb[k];
+        const double sg = -web[k];
+        q[0] += sg * y.x; q[1] += sg * y.y; q[2] += sg * y.z;
+        q[3] += sg * 2.0 * (c.y * y.z - c.z * y.y);
+        q[4] += sg * 2.0 * (c.z * y.x - c.x * y.z);
+        q[5] += sg * 2.0 * (c.x * y.y - c.y * y.x);
+      }
+    }
+    if (nb > 0) { const SegCtl16 sc_ = seg_ctl16(slotb); seg_apply16<6>(q, sc_, seg_flags(sc_), qs + 6 * (slotb >= 0 ? slotb : 0)); }
+  }
+  for (int base = nb; base < ninc; base += VDO_TILE_THREADS) {      // (uniform trip count: every lane takes part in the scans)
+    const int li = base + tid;
+    double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    int skey = -1;
+    if (li < ninc) {
+      int key, kind; FInc f;
+      tern_load(li, key, kind, f);
+      const int sl = key >> 16;
+      const double* wl = u + 3 * (key & 0xffff);
+      D3 y{wl[0], wl[1], wl[2]};
+      if (kind != 1) y = rot(slotW + 12 * sl, y);            // R^T w
+      const double sg = kind == 1 ? f.we : -f.we;
+      q[0] = sg * y.x; q[1] = sg * y.y; q[2] = sg * y.z;
+      q[3] = sg * (f.cy * y.z - f.cz * y.y);
+      q[4] = sg * (f.cz * y.x - f.cx * y.z);
+      q[5] = sg * (f.cx * y.y - f.cy * y.x);
+      skey = sl;
+    }
     { const SegCtl16 sc_ = seg_ctl16(skey); seg_apply16<6>(q, sc_, seg_flags(sc_), qs + 6 * (skey >= 0 ? skey : 0)); }
   }
   __syncthreads();
