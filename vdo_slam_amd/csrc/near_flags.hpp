@@ -55,8 +55,10 @@ static __global__ __launch_bounds__(256) void k_near_flags_sel(int nq, const flo
   }
   if (u) atomicOr(&used[i], 1);
 }
-static inline void launch_near_flags_sel(hipStream_t s, int nq, const float* qx, const float* qy, int nr, const float* rx, const float* ry, const int32_t* rsel, int as_int, int32_t* used) {
-  hipMemsetAsync(used, 0, sizeof(int32_t) * (size_t)nq, s);
+// (zero = false: the caller's previous kernel cleared used[])
+static inline void launch_near_flags_sel(hipStream_t s, int nq, const float* qx, const float* qy, int nr, const float* rx, const float* ry, const int32_t* rsel, int as_int, int32_t* used,
+                                         bool zero = true) {
+  if (zero) hipMemsetAsync(used, 0, sizeof(int32_t) * (size_t)nq, s);
   if (nq > 0 && nr > 0) hipLaunchKernelGGL(k_near_flags_sel, dim3((nq + 255) / 256, (nr + 255) / 256), dim3(256), 0, s, nq, qx, qy, nr, rx, ry, rsel, as_int, used);
 }
 

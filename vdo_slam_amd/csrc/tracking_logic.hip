@@ -43,6 +43,41 @@ __global__ void k_renew_obj_pred(int n, const float* __restrict__ px, const floa
   ok[i] = good; sem[i] = sl; dout[i] = d; fx[i] = fxe; fy[i] = fye;
 }
 
+// RenewFrameInfo (objects) + mvObj3DPoint in ONE launch: thread i judges carried candidate i (k_renew_obj_pred) and back-projects it from its
+// truncated position with the depth it has just read; thread j back-projects sample j of the new image and clears its "within 1 px of a carried
+// point" flag for the k_near_flags_sel launch that follows (one launch instead of predicate + fill + two back-projections).
+__global__ void k_renew_obj_all(int n, const float* __restrict__ px, const float* __restrict__ py, const int32_t* __restrict__ mask,
+                                const float* __restrict__ depth, const float* __restrict__ flow, int w, int h,
+                                int32_t* __restrict__ ok, int32_t* __restrict__ sem, float* __restrict__ dout, float* __restrict__ fx, float* __restrict__ fy,
+                                Cam cam, float* __restrict__ xyz_c,
+                                int n_tmp, const float* __restrict__ qx, const float* __restrict__ qy, const float* __restrict__ qd, float* __restrict__ xyz_t,
+                                int32_t* __restrict__ used) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) {
+    const int x = (int)px[i], y = (int)py[i];
+    int good = 0, sl = 0;
+    float d = 0, fxe = 0, fye = 0;
+    if (!(x >= w || y >= h || x <= 0 || y <= 0)) {
+      const size_t o = (size_t)y * w + x;
+      sl = mask[o]; d = depth[o];
+      if (sl != 0 && d < 25 && d > 0) {
+        fxe = flow[2 * o]; fye = flow[2 * o + 1];
+        if (x + fxe < w && y + fye < h && x + fxe > 0 && y + fye > 0) good = 1;
+      }
+    }
+    ok[i] = good; sem[i] = sl; dout[i] = d; fx[i] = fxe; fy[i] = fye;
+    float o3[3];
+    backproject(cam, (float)x, (float)y, d, o3);
+    xyz_c[3 * i] = o3[0]; xyz_c[3 * i + 1] = o3[1]; xyz_c[3 * i + 2] = o3[2];
+  }
+  if (i < n_tmp) {
+    used[i] = 0;
+    float o3[3];
+    backproject(cam, qx[i], qy[i], qd[i], o3);
+    xyz_t[3 * i] = o3[0]; xyz_t[3 * i + 1] = o3[1]; xyz_t[3 * i + 2] = o3[2];
+  }
+}
+
 constexpr int kVoteBins = 1024;    // instance labels of a mask are small non-negative integers
 
 // One workgroup per call: vote of the current mask at the flowed positions of one last-frame label.
@@ -347,15 +382,17 @@ extern "C" int vdo_renew_object_world(vdo_frame_images* f, int n_obj, const int3
   Arena S(f->ctx);
   if (!S.reserve(Arena::bytes_for(24 * ((size_t)(n_obj ? inl_off[n_obj] : 0) + (size_t)n_tmp + 64)))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   // ---- carried candidates: inliers of the tracked objects, object-major (the reference's visiting order)
-  std::vector<float> cx, cy; std::vector<int32_t> cid, cobj;
+  static thread_local std::vector<float> cx, cy, dd, fx, fy, xyz_c, xyz_t;      // (per-thread scratch: no allocation in steady state)
+  static thread_local std::vector<int32_t> cid, cobj, ok, sem, used;
+  cx.clear(); cy.clear(); cid.clear(); cobj.clear();
   for (int i = 0; i < n_obj; ++i) {
     if (!obj_stat[i]) continue;
     for (int q = inl_off[i]; q < inl_off[i + 1]; ++q) { const int id = inl_idx[q]; cx.push_back(cur_x[id]); cy.push_back(cur_y[id]); cid.push_back(id); cobj.push_back(i); }
   }
   const int nc = (int)cx.size();
-  std::vector<int32_t> ok(nc), sem(nc); std::vector<float> dd(nc), fx(nc), fy(nc);
-  std::vector<int32_t> used(n_tmp, 0);
-  std::vector<float> xyz_c(xyz_out ? 3 * (size_t)nc : 0), xyz_t(xyz_out ? 3 * (size_t)n_tmp : 0);
+  ok.resize(nc); sem.resize(nc); dd.resize(nc); fx.resize(nc); fy.resize(nc);
+  used.assign(n_tmp, 0);
+  xyz_c.resize(xyz_out ? 3 * (size_t)nc : 0); xyz_t.resize(xyz_out ? 3 * (size_t)n_tmp : 0);
   if (nc || (n_tmp && xyz_out)) {
     float *dx = S.up(cx.data(), nc), *dy = S.up(cy.data(), nc);
     float *dqx = S.up(tmp_x, n_tmp), *dqy = S.up(tmp_y, n_tmp), *dqd = S.up(xyz_out ? tmp_depth : nullptr, xyz_out ? n_tmp : 0);
@@ -366,14 +403,18 @@ extern "C" int vdo_renew_object_world(vdo_frame_images* f, int n_obj, const int3
     if (!dxt || !dxc || !dused || !dfy) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
     hipStream_t st = S.stream();
     const Cam cam = xyz_out ? make_cam_Twc(K4, Twc) : Cam{};
-    if (nc) {
+    if (xyz_out) {                         // (what FramePipeline calls: one fused launch, then the 1-px test)
+      const int nmax = std::max(nc, n_tmp);
+      hipLaunchKernelGGL(k_renew_obj_all, dim3((nmax + 255) / 256), dim3(256), 0, st, nc, (const float*)dx, (const float*)dy, (const int32_t*)f->d_mask,
+                         (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok, dsem, ddd, dfx, dfy, cam, dxc,
+                         n_tmp, (const float*)dqx, (const float*)dqy, (const float*)dqd, dxt, dused);
+      // top-up from the semi-dense sampling of the new image: "is a carried point within 1 px" against the verdicts above
+      if (nc && n_tmp) launch_near_flags_sel(st, n_tmp, dqx, dqy, nc, dx, dy, dok, 1, dused, false);
+    } else if (nc) {
       hipLaunchKernelGGL(k_renew_obj_pred, dim3((nc + 255) / 256), dim3(256), 0, st, nc, (const float*)dx, (const float*)dy, (const int32_t*)f->d_mask,
                          (const float*)f->d_depth, (const float*)f->d_flow, f->w, f->h, dok, dsem, ddd, dfx, dfy);
-      // top-up from the semi-dense sampling of the new image: "is a carried point within 1 px" against the verdicts above
       if (n_tmp) launch_near_flags_sel(st, n_tmp, dqx, dqy, nc, dx, dy, dok, 1, dused);
-      if (xyz_out) hipLaunchKernelGGL(k_backproject_pts, dim3((nc + 255) / 256), dim3(256), 0, st, nc, (const float*)dx, (const float*)dy, (const float*)ddd, cam, 1, dxc);
     }
-    if (n_tmp && xyz_out) hipLaunchKernelGGL(k_backproject_pts, dim3((n_tmp + 255) / 256), dim3(256), 0, st, n_tmp, (const float*)dqx, (const float*)dqy, (const float*)dqd, cam, 0, dxt);
     S.down(ok.data(), dok, nc); S.down(sem.data(), dsem, nc); S.down(dd.data(), ddd, nc); S.down(fx.data(), dfx, nc); S.down(fy.data(), dfy, nc);
     if (nc && n_tmp) S.down(used.data(), dused, n_tmp);
     if (xyz_out) { S.down(xyz_c.data(), dxc, 3 * (size_t)nc); S.down(xyz_t.data(), dxt, 3 * (size_t)n_tmp); }
