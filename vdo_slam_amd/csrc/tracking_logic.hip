@@ -527,6 +527,29 @@ extern "C" int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, in
 // UpdateMask (K15) -> object propagation (K11) -> GetSceneFlowObj (K13) as ONE call: the three steps of the object chain between
 // the renewed object set of the last frame and DynObjTracking.  Same kernels, same order on the stream as vdo_update_mask +
 // vdo_propagate_object + vdo_scene_flow (which remain), but one staged upload, one download, one synchronisation instead of three.
+// K11 (objects) + K13 in one launch: depth / label of the updated mask under the correspondence (k_gather mode 1), then the scene flow of the
+// point from those two values (k_scene_flow) - same arithmetic, one launch and one pass over the inputs less
+static __global__ void k_gather_scene_flow(int n, const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ depth, const int32_t* __restrict__ mask,
+                                           int w, int h, float th, float* __restrict__ dout, int32_t* __restrict__ lout, Cam cc,
+                                           const float* __restrict__ lx, const float* __restrict__ ly, const float* __restrict__ ld, const int32_t* __restrict__ ll, Cam lc,
+                                           float* __restrict__ flow3d, int32_t* __restrict__ objlab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float xf = kx[i], yf = ky[i];
+  const int u = (int)xf, v = (int)yf;
+  float o = 0.1f; int l = 0;
+  if (u < (w - 1) && u > 0 && v < (h - 1) && v > 0) {
+    const float d = depth[(size_t)v * w + u];
+    if (d < th && d > 0) { o = d; l = mask[(size_t)v * w + u]; }
+  }
+  dout[i] = o; lout[i] = l;
+  if (l <= 0 || ll[i] <= 0) { objlab[i] = -1; flow3d[3 * i] = 0; flow3d[3 * i + 1] = 0; flow3d[3 * i + 2] = 0; return; }
+  float p[3], c[3];
+  backproject(lc, lx[i], ly[i], ld[i], p);
+  backproject(cc, xf, yf, o, c);
+  flow3d[3 * i] = c[0] - p[0]; flow3d[3 * i + 1] = c[1] - p[1]; flow3d[3 * i + 2] = c[2] - p[2];
+}
+
 extern "C" int vdo_object_chain(vdo_frame_images* cur, vdo_frame_images* last, int n, const int32_t* last_sem_label, const float* last_corr_x, const float* last_corr_y,
                                 float th_depth_obj, const float Tcw_cur[16], const float* last_x, const float* last_y, const float* last_d, const float Tcw_last[16],
                                 const float K4[4], int* n_recovered, float* depth_out, int32_t* sem_out, float* flow3d_out, int32_t* obj_label_out) {
@@ -538,24 +561,26 @@ extern "C" int vdo_object_chain(vdo_frame_images* cur, vdo_frame_images* last, i
   Arena S(cur->ctx);
   if (!S.reserve(Arena::bytes_for(16 * (size_t)n + 512))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
   // K15: the flowed positions grouped by last-frame label (ascending labels, index order inside a label)
-  std::vector<int32_t> uni, slot;
+  static thread_local std::vector<int32_t> uni, slot, olab0, off32, flag;       // (per-thread scratch: no allocation in steady state)
+  static thread_local std::vector<int> off, c;
+  static thread_local std::vector<float> gx, gy;
   label_slots(n, last_sem_label, uni, slot);
   const int L = (int)uni.size();
-  std::vector<int> off(L + 1, 0);
+  off.assign(L + 1, 0);
   for (int i = 0; i < n; ++i) off[slot[i] + 1]++;
   for (int s = 0; s < L; ++s) off[s + 1] += off[s];
-  std::vector<float> gx(n), gy(n);
+  gx.resize(n); gy.resize(n);
   {
-    std::vector<int> c(off.begin(), off.end() - 1);
+    c.assign(off.begin(), off.end() - 1);
     for (int i = 0; i < n; ++i) { const int p = c[slot[i]]++; gx[p] = last_corr_x[i]; gy[p] = last_corr_y[i]; }
   }
-  std::vector<int32_t> olab0(n, -2);
+  olab0.assign(n, -2);
   // every input of the three steps in one run of staged buffers -> one H2D copy
   float *dgx = S.up(gx.data(), n), *dgy = S.up(gy.data(), n);
   float *dcx = S.up(last_corr_x, n), *dcy = S.up(last_corr_y, n);
   float *dlx = S.up(last_x, n), *dly = S.up(last_y, n), *dld = S.up(last_d, n);
   int32_t *dll = S.up(last_sem_label, n), *dol = S.up(olab0.data(), n);
-  std::vector<int32_t> off32(off.begin(), off.end());
+  off32.assign(off.begin(), off.end());
   int32_t* doff = S.up(off32.data(), off32.size());
   unsigned long long* drec = S.up<unsigned long long>(nullptr, 1);
   // outputs, contiguous -> one D2H copy
@@ -566,11 +591,10 @@ extern "C" int vdo_object_chain(vdo_frame_images* cur, vdo_frame_images* last, i
   if (!dgx || !dgy || !dcx || !dcy || !dlx || !dly || !dld || !dll || !dol || !doff || !drec || !dflag || !ddep || !dsem || !dfl) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
   launch_update_mask(cur, last, uni, off, dgx, dgy, doff, dflag, drec, S.stream());
   // K11 (objects) on the updated mask, K13 on its outputs
-  hipLaunchKernelGGL(k_gather, dim3((n + 255) / 256), dim3(256), 0, S.stream(), 1, n, (const float*)dcx, (const float*)dcy, (const float*)cur->d_depth, (const int32_t*)cur->d_mask,
-                     cur->w, cur->h, th_depth_obj, ddep, dsem);
-  hipLaunchKernelGGL(k_scene_flow, dim3((n + 255) / 256), dim3(256), 0, S.stream(), n, (const float*)dcx, (const float*)dcy, (const float*)ddep, (const int32_t*)dsem, make_cam_Tcw(K4, Tcw_cur),
+  hipLaunchKernelGGL(k_gather_scene_flow, dim3((n + 255) / 256), dim3(256), 0, S.stream(), n, (const float*)dcx, (const float*)dcy, (const float*)cur->d_depth, (const int32_t*)cur->d_mask,
+                     cur->w, cur->h, th_depth_obj, ddep, dsem, make_cam_Tcw(K4, Tcw_cur),
                      (const float*)dlx, (const float*)dly, (const float*)dld, (const int32_t*)dll, make_cam_Tcw(K4, Tcw_last), dfl, dol);
-  std::vector<int32_t> flag(2 * (size_t)L);
+  flag.assign(2 * (size_t)L, 0);
   S.down(flag.data(), dflag, flag.size()); S.down(depth_out, ddep, n); S.down(sem_out, dsem, n); S.down(flow3d_out, dfl, 3 * (size_t)n); S.down(obj_label_out, dol, n);
   rc = S.finish("vdo_object_chain");
   if (rc != VDO_OK) return rc;
