@@ -289,7 +289,10 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   const double tr0 = g_pnp_trace.on ? pnp_now_us() : 0.0;
   int rc = ctx_bind(ctx);
   if (rc != VDO_OK) return rc;
-  std::vector<PnpDev> hp(n_problems);
+  static thread_local std::vector<PnpDev> hp;          // (per-thread scratch: no allocation in steady state)
+  static thread_local std::vector<int32_t> subsets;
+  static thread_local std::vector<double> X, uv;
+  hp.assign(n_problems, PnpDev{});
   size_t tot_pts = 0, tot_hyp = 0, tot_words = 0;
   int max_hyp = 0;
   for (int k = 0; k < n_problems; ++k) {
@@ -313,8 +316,8 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   // the subsets the sequential loop would draw (getSubset: 4 distinct indices by rejection, RNG seeded with (uint64)-1 per call):
   // a function of (point count, hypotheses) alone - the draws of a frame's problems cost ~30 us of the object chain, and the same
   // counts come back every few frames, so the tables are kept (8 KB per distinct count)
-  std::vector<int32_t> subsets(4 * tot_hyp);
-  std::vector<double> X(3 * tot_pts), uv(2 * tot_pts);
+  subsets.resize(4 * tot_hyp);
+  X.resize(3 * tot_pts); uv.resize(2 * tot_pts);
   {
     static std::mutex cache_mu;
     static std::unordered_map<uint64_t, std::vector<int32_t>> cache;
@@ -394,9 +397,10 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   std::vector<int> todo;
   for (int k = 0; k < n_problems; ++k) if (probs[k].refit && results[k].n_inliers >= 4 && results[k].best_iteration >= 0) todo.push_back(k);
   if (!todo.empty()) {
-    auto refit_one = [&](int q) {
+    const PnpDev* hp_main = hp.data();               // (hp is thread_local: a pool thread naming it would see ITS OWN, empty, vector)
+    auto refit_one = [&, hp_main](int q) {
       const int k = todo[q];
-      const PnpDev& d = hp[k];
+      const PnpDev& d = hp_main[k];
       const uint32_t* row = mask + (size_t)d.mask_off + (size_t)results[k].best_iteration * d.mask_words;
       thread_local std::vector<double> Xi, ui;
       thread_local epnp::Scratch scr;

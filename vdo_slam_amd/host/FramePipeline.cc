@@ -535,7 +535,8 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
       }
       if (lm_obj_) {
         // per object: ObjIdTest_in = inliers of the chosen model; fewer than 50 -> the object is not tracked this frame (Tracking.cc:879)
-        obj_subsets_.assign(n_objects, {});
+        if ((int)obj_subsets_.size() < n_objects) obj_subsets_.resize(n_objects);      // (inner vectors keep their capacity from frame to frame)
+        for (int a = 0; a < n_objects; ++a) obj_subsets_[a].clear();
         obj_stat_.assign(n_objects, 1);
         obj_buf_.resize(n_objects);
         int need_pts = 0;
@@ -665,9 +666,11 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
     if (obj && obj == lm_obj_) {
       // vnObjInlierID = LM inliers; current keys of the inliers move to (last key + refined flow); H = Tcw^-1 * (Tcw H)  (Tracking.cc:932-933)
       const int NS = n_obj_problems;                       // slots of the batch when it was launched
-      std::vector<vdo_flow2_result> rs(NS);
-      std::vector<std::vector<double>> fo(NS); std::vector<std::vector<uint8_t>> io(NS);
-      std::vector<double*> fop(NS); std::vector<uint8_t*> iop(NS);
+      std::vector<vdo_flow2_result>& rs = lm_rs_;           // (members: their buffers keep their capacity from frame to frame)
+      std::vector<std::vector<double>>& fo = lm_fo_; std::vector<std::vector<uint8_t>>& io = lm_io_;
+      std::vector<double*>& fop = lm_fop_; std::vector<uint8_t*>& iop = lm_iop_;
+      rs.resize(NS); fop.resize(NS); iop.resize(NS);
+      if ((int)fo.size() < NS) { fo.resize(NS); io.resize(NS); }
       for (int a = 0; a < NS; ++a) {
         const size_t na = (a < n_objects && obj_stat_[a]) ? obj_subsets_[a].size() : 0;
         fo[a].resize(2 * na + 2); io[a].resize(na + 1);

@@ -182,6 +182,8 @@ class FramePipeline {
   vdo_flow2_batch *lm_cam_ = nullptr, *lm_obj_ = nullptr;
   std::vector<int32_t> cam_subset_, inl_off_, inl_idx_;
   std::vector<std::vector<int32_t>> obj_subsets_;
+  std::vector<vdo_flow2_result> lm_rs_; std::vector<std::vector<double>> lm_fo_; std::vector<std::vector<uint8_t>> lm_io_;   // fetch buffers of the object LMs
+  std::vector<double*> lm_fop_; std::vector<uint8_t*> lm_iop_;
   std::vector<uint8_t> inl_mm_, obj_stat_, obj_use_mm_;   // obj_use_mm_[a]: the motion model seeds object a's LM
   std::vector<float> obj_mm_;                             // MotionModel of the frame's objects (16 floats each)
   std::vector<ObjBuf> obj_buf_;
