@@ -17,13 +17,14 @@
 //      (sum of we) * I - J_point^T J_point = R R^T = I for both edge classes - so 1 + 3 sums per point, written once (32 B);
 //   4. the pose 6x6+6 contribution of an edge depends on 16 running sums only
 //      (J_pose = [-I | 2[zc]x]  resp. [I | -[v]x]): Σw, Σw·zc, Σw·zc zcᵀ, Σw·e, Σw·zc×e.
-//      Every thread sums them in registers over its few consecutive edges (edges are pose-sorted inside the tile), the
+//      Every thread sums them in registers over its <= 3 consecutive EdgeSE3PointXYZ edges, which belong to ONE pose slot (edges are
+//      pose-sorted inside the tile; a per-tile thread table - ba_dev.hpp thr_tab - cuts every slot's run into pieces of <= 3), the
 //      threads' totals go through a segmented DPP scan into per-slot LDS accumulators and leave as one 128-byte row per
 //      (tile, slot) of the POSE-MAJOR partial array; k_finalize_pose streams a pose's rows, expands them to the 6x6 block + rhs
 //      and adds the blocks of the pose's EdgeSE3 / prior edges (k_posepose), all in fixed order.
 // No global atomics.  HBM bytes of a linearisation with this layout: vdo_slam_amd/ba.py linearize_byte_model;
-// what bounds the kernel (measured): VALU issue (~2/3 of the SIMD cycles at 4 workgroups per CU) plus the
-// start-up latency of a tile, t = 30 us + 128 us / (workgroups per CU) on the roofline graph.
+// what bounds the kernel (measured): instruction issue - ~60 % of the SIMD cycles are VALU at 4 workgroups per CU, the rest
+// is what the phases of a tile leave idle; 59 us for 3.76 M edges on the roofline graph = 0.34 of the HBM peak.
 #include <cstdlib>
 #include "ba_dev.hpp"
 #include "ba_tile.hpp"
@@ -55,10 +56,10 @@ __device__ __forceinline__ void block_sum2(double& a, double& b, double* lds) {
   a = lds[32]; b = lds[33];
 }
 
-// Per-thread running sums: a thread owns a few CONSECUTIVE edges of the pose-sorted list, so they mostly share a pose slot and
-// their 16 sums add up in registers; a change of slot inside the chunk (rare: at most nslot - 1 times per tile) is flushed to the
-// slot's LDS accumulators at once, and only the final (slot, sums) of every thread goes through the segmented DPP scan - one
-// scan per thread instead of one per edge.
+// Per-thread running sums of the TERNARY edges (the EdgeSE3PointXYZ edges of a thread share a slot by construction: acc_terms): a thread owns
+// a few CONSECUTIVE edges of the slot-sorted list, so they mostly share a slot and their 16 sums add up in registers; a change of slot inside
+// the chunk is flushed to the slot's LDS accumulators at once, and only the final (slot, sums) of every thread goes through the segmented DPP
+// scan - one scan per thread instead of one per edge.
 __device__ __forceinline__ void acc_edge(double (&acc)[16], int& cur, int slot, double we, D3 c, D3 er, double* accpose_base, int arow) {
   if (slot != cur) {
     if (cur >= 0) {
