@@ -255,7 +255,7 @@ inline bool qr_solve_6x4(double* A /*6x4 row-major, destroyed*/, double* b /*6, 
 }
 
 struct Result { double R[9], t[3], err; };
-struct Scratch { std::vector<double> alphas, pcs; };      // per-thread buffers, grown on demand (no allocation in steady state)
+struct Scratch { std::vector<double> alphas; };      // per-thread buffers, grown on demand (no allocation in steady state)
 
 // X [n][3] world points, uv [n][2] pixels, K4 = fx, fy, cx, cy.  n >= 4.
 inline Result solve(int n, const double* X, const double* uv, const double* K4, Scratch& scr) {
@@ -296,6 +296,19 @@ inline Result solve(int n, const double* X, const double* uv, const double* K4, 
     for (int j = 0; j < 3; ++j) a[1 + j] = ci[3 * j] * (pi[0] - cws[0][0]) + ci[3 * j + 1] * (pi[1] - cws[0][1]) + ci[3 * j + 2] * (pi[2] - cws[0][2]);
     a[0] = 1.0 - a[1] - a[2] - a[3];
   }
+  // ---- sums over the points that the three candidate solutions below share.  The camera-frame points are pc_i = sum_j a_ij ccs_j (ccs = the
+  // candidate's control points), so their mean is sum_j abar_j ccs_j and Horn's matrix  S = sum_i (pw_i - pw0) (pc_i - pc0)^T  equals
+  // sum_j Q_j ccs_j^T  with  Q_j = sum_i a_ij (pw_i - pw0)  (the deviations pw_i - pw0 sum to zero, pc0 drops out): abar and Q are formed ONCE,
+  // a candidate costs O(1) for its absolute orientation instead of three passes over the points.
+  double pw0[3] = {0, 0, 0}, abar[4] = {0, 0, 0, 0}, Qj[4][3] = {{0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+  for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) pw0[k] += X[3 * i + k];
+  for (int k = 0; k < 3; ++k) pw0[k] /= n;
+  for (int i = 0; i < n; ++i) {
+    const double* a = &alphas[4 * (size_t)i];
+    const double d0 = X[3 * i] - pw0[0], d1 = X[3 * i + 1] - pw0[1], d2 = X[3 * i + 2] - pw0[2];
+    for (int j = 0; j < 4; ++j) { abar[j] += a[j]; Qj[j][0] += a[j] * d0; Qj[j][1] += a[j] * d1; Qj[j][2] += a[j] * d2; }
+  }
+  for (int j = 0; j < 4; ++j) abar[j] /= n;
   // ---- M^T M (12 x 12).  Rows of M: [a_j fu, 0, a_j (uc - u)] and [0, a_j fv, a_j (vc - v)] per control point j, so the 3 x 3
   // block (j, k) of M^T M is  sum_i a_j a_k [fu^2, 0, fu du; 0, fv^2, fv dv; fu du, fv dv, du^2 + dv^2]  with du = uc - u, dv = vc - v:
   // four running sums per control-point pair instead of the 78 products of the dense rows
@@ -393,19 +406,17 @@ inline Result solve(int n, const double* X, const double* uv, const double* K4, 
     double ccs[4][3];
     for (int i = 0; i < 4; ++i) for (int k = 0; k < 3; ++k) ccs[i][k] = 0.0;
     for (int e = 0; e < 4; ++e) for (int j = 0; j < 4; ++j) for (int k = 0; k < 3; ++k) ccs[j][k] += betas[e] * vcol[e][3 * j + k];
-    std::vector<double>& pcs = scr.pcs;
-    if (pcs.size() < 3 * (size_t)n) pcs.resize(3 * (size_t)n);
-    for (int i = 0; i < n; ++i) {
-      const double* a = &alphas[4 * (size_t)i];
-      for (int k = 0; k < 3; ++k) pcs[3 * (size_t)i + k] = a[0] * ccs[0][k] + a[1] * ccs[1][k] + a[2] * ccs[2][k] + a[3] * ccs[3][k];
+    // solve_for_sign: the depth of the FIRST point in the camera frame decides the sign of the whole solution (OpenCV epnp.cpp solve_for_sign)
+    {
+      const double* a = &alphas[0];
+      const double z0 = a[0] * ccs[0][2] + a[1] * ccs[1][2] + a[2] * ccs[2][2] + a[3] * ccs[3][2];
+      if (z0 < 0.0) for (int j = 0; j < 4; ++j) for (int k = 0; k < 3; ++k) ccs[j][k] = -ccs[j][k];
     }
-    if (pcs[2] < 0.0) for (size_t i = 0; i < 3 * (size_t)n; ++i) pcs[i] = -pcs[i];       // solve_for_sign
-    double pc0[3] = {0, 0, 0}, pw0[3] = {0, 0, 0};
-    for (int i = 0; i < n; ++i) for (int k = 0; k < 3; ++k) { pc0[k] += pcs[3 * (size_t)i + k]; pw0[k] += X[3 * i + k]; }
-    for (int k = 0; k < 3; ++k) { pc0[k] /= n; pw0[k] /= n; }
-    double Sm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // S[j][k] = sum (pw - pw0)[j] (pc - pc0)[k]   (Horn: rotation world -> camera)
-    for (int i = 0; i < n; ++i)
-      for (int j = 0; j < 3; ++j) for (int k = 0; k < 3; ++k) Sm[3 * j + k] += (X[3 * i + j] - pw0[j]) * (pcs[3 * (size_t)i + k] - pc0[k]);
+    double pc0[3] = {0, 0, 0};
+    for (int j = 0; j < 4; ++j) for (int k = 0; k < 3; ++k) pc0[k] += abar[j] * ccs[j][k];
+    double Sm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // S[r][k] = sum (pw - pw0)[r] (pc - pc0)[k] = sum_j Q_j[r] ccs_j[k]   (Horn: rotation world -> camera)
+    for (int j = 0; j < 4; ++j)
+      for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) Sm[3 * r + k] += Qj[j][r] * ccs[j][k];
     double Nq[16] = {Sm[0] + Sm[4] + Sm[8], Sm[5] - Sm[7], Sm[6] - Sm[2], Sm[1] - Sm[3],
                      Sm[5] - Sm[7], Sm[0] - Sm[4] - Sm[8], Sm[1] + Sm[3], Sm[6] + Sm[2],
                      Sm[6] - Sm[2], Sm[1] + Sm[3], -Sm[0] + Sm[4] - Sm[8], Sm[5] + Sm[7],
@@ -419,17 +430,23 @@ inline Result solve(int n, const double* X, const double* uv, const double* K4, 
     cur.R[3] = 2 * (q1 * q2 + q0 * q3); cur.R[4] = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3; cur.R[5] = 2 * (q2 * q3 - q0 * q1);
     cur.R[6] = 2 * (q1 * q3 - q0 * q2); cur.R[7] = 2 * (q2 * q3 + q0 * q1); cur.R[8] = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
     for (int k = 0; k < 3; ++k) cur.t[k] = pc0[k] - (cur.R[3 * k] * pw0[0] + cur.R[3 * k + 1] * pw0[1] + cur.R[3 * k + 2] * pw0[2]);
-    double sum = 0.0;                                  // reprojection_error
-    for (int i = 0; i < n; ++i) {
+    // reprojection_error: mean pixel distance.  Four running sums (point i goes to sum i mod 4, added as (s0 + s1) + (s2 + s3)): the divisions and
+    // square roots of four points are independent of each other and of the additions, so they pipeline (and vectorise) instead of queueing
+    // behind one accumulator; the order is fixed in the source, the same bits from every compiler.
+    double sl[4] = {0.0, 0.0, 0.0, 0.0};
+    auto reproj = [&](int i) {
       const double* pw = X + 3 * i;
       const double Xc = cur.R[0] * pw[0] + cur.R[1] * pw[1] + cur.R[2] * pw[2] + cur.t[0];
       const double Yc = cur.R[3] * pw[0] + cur.R[4] * pw[1] + cur.R[5] * pw[2] + cur.t[1];
       const double inv_Zc = 1.0 / (cur.R[6] * pw[0] + cur.R[7] * pw[1] + cur.R[8] * pw[2] + cur.t[2]);
       const double ue = uc + fu * Xc * inv_Zc, ve = vc + fv * Yc * inv_Zc;
       const double u = uv[2 * i], v = uv[2 * i + 1];
-      sum += std::sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
-    }
-    cur.err = sum / n;
+      return std::sqrt((u - ue) * (u - ue) + (v - ve) * (v - ve));
+    };
+    int i4 = 0;
+    for (; i4 + 3 < n; i4 += 4) { sl[0] += reproj(i4); sl[1] += reproj(i4 + 1); sl[2] += reproj(i4 + 2); sl[3] += reproj(i4 + 3); }
+    for (int r = 0; i4 < n; ++i4, ++r) sl[r] += reproj(i4);
+    cur.err = ((sl[0] + sl[1]) + (sl[2] + sl[3])) / n;
     if (best.err < 0.0 || cur.err < best.err) best = cur;
   }
   return best;
