@@ -171,3 +171,39 @@ def test_lm_reduces_error_towards_ground_truth(oracle, small_graph):
     m0 = np.linalg.norm(g.pose[nc:, 9:] - g.pose_gt[nc:, 9:], axis=1).mean()
     m1 = np.linalg.norm(pose[nc:, 9:] - g.pose_gt[nc:, 9:], axis=1).mean()
     assert m1 < 0.5 * m0
+
+
+def test_single_point_schur_block_has_a_closed_form_in_the_weight_and_the_camera_frame_point(oracle):
+    """The identity the GPU preconditioner kernel rests on (vdo_slam_amd/csrc/ba_solve.hip k_precond_tile): for an EdgeSE3PointXYZ the
+    pose-landmark block is  B = -we [I ; 2[c]x] R^T  (c: the point in the pose's frame, we: Huber-weighted information), so for a landmark
+    with the scalar block  Hll = h I  the Schur term  B (h + lambda)^-1 B^T  does not depend on R:
+        g we^2 [[I, -2[c]x], [2[c]x, 4 (|c|^2 I - c c^T)]] .
+    Checked on the ORACLE's explicit 6x3 blocks of a random graph (we, R and c are read back from each block itself)."""
+    g = synth.make_ba_graph(6, 120, 1, 8, seed=9)
+    gc, keep = K.graph_to_c(g)
+    S = K.BASystem(g)
+    assert oracle.vdo_oracle_ba_linearize(C.byref(gc), C.byref(S.c)) == 0
+    lam = 0.37
+    worst, checked = 0.0, 0
+    for e in range(0, g.n_eb, 7):
+        B = S.Hpl_eb[:, e].reshape(6, 3)
+        we = np.linalg.norm(B[0])
+        if we < 1e-9:
+            continue
+        Rt = -B[:3] / we                                       # top block = -we R^T
+        np.testing.assert_allclose(Rt @ Rt.T, np.eye(3), atol=1e-9)
+        Cx = -(B[3:] @ Rt.T) / (2.0 * we)                     # bottom block = -2 we [c]x R^T
+        c = np.array([Cx[2, 1], Cx[0, 2], Cx[1, 0]])
+        np.testing.assert_allclose(Cx, np.array([[0, -c[2], c[1]], [c[2], 0, -c[0]], [-c[1], c[0], 0]]), atol=1e-9 * max(1.0, np.abs(c).max()))
+        l = g.eb_point[e]
+        h = S.Hll[l].reshape(3, 3)
+        if np.abs(h - h[0, 0] * np.eye(3)).max() > 1e-9 * h[0, 0]:      # a point of a dynamic track: not the scalar case
+            continue
+        gsc = 1.0 / (h[0, 0] + lam)
+        explicit = gsc * B @ B.T
+        s = gsc * we * we
+        K2 = 2.0 * Cx
+        closed = s * np.block([[np.eye(3), K2.T], [K2, 4.0 * (c @ c * np.eye(3) - np.outer(c, c))]])
+        worst = max(worst, np.abs(explicit - closed).max() / np.abs(explicit).max())
+        checked += 1
+    assert checked >= 40 and worst < 1e-12, (checked, worst)
