@@ -119,7 +119,7 @@ typedef struct vdo_lm_options {
                                * 0: auto = 3 when the EdgeSE3 graph is not a set of simple paths (loop closures, branches) or a
                                *    PCG solve needed more than 60 iterations, else 2                                      */
   double pcg_tolerance;       /* relative residual ||r||_M / ||b||_M; <=0 -> 1e-10          */
-  int32_t pcg_max_iterations; /* <=0 -> 4 * (6 n_pose) capped at 20000                     */
+  int32_t pcg_max_iterations; /* <=0 -> 24 n_pose + 200, capped at 20000                   */
 } vdo_lm_options;
 
 #define VDO_LM_MAX_TRACE 512
