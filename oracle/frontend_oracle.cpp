@@ -447,6 +447,15 @@ extern "C" int vdo_oracle_fast_image(const uint8_t* img, int w, int h, int thr, 
   return (int)c.size();
 }
 extern "C" float vdo_oracle_fast_atan2(float y, float x) { return fast_atan2(y, x); }
+// the two remaining OpenCV primitives of ORBextractor.cc as stand-alone hooks: oracle/ref/ (the reference's ORBextractor.cc compiled
+// verbatim against a mini-cv shim) forwards cv::resize / cv::copyMakeBorder here, so that build and this file differ ONLY in the
+// first-party logic
+extern "C" void vdo_oracle_resize_linear_8u(const uint8_t* src, int sw, int sh, uint8_t* dst, int dw, int dh) {
+  Img s, d; s.w = sw; s.h = sh; s.d.assign(src, src + (size_t)sw * sh); d.w = dw; d.h = dh; d.d.resize((size_t)dw * dh);
+  resize_linear_8u(s, d);
+  std::memcpy(dst, d.d.data(), d.d.size());
+}
+extern "C" int vdo_oracle_border_reflect101(int p, int len) { return reflect101(p, len); }
 
 // ORBextractor::operator(): keypoints of all levels (level-0 coordinates), returns count.  desc (nullable): [cap][32] rotated
 // BRIEF of every keypoint on the blurred level image - the call the reference has commented out (src/ORBextractor.cc:1083-1091)

@@ -86,3 +86,38 @@ def object_sample(o, mask, depth, flow, th, step=4):
     out = {k: a[:m] for k, a in zip(names, f)}
     out["label"] = lab[:m]
     return out
+
+
+# ---- oracle/_ref: the reference's own ORBextractor.cc (tests/oracle_lib.load_ref_orb) -----------------------------------------
+def ref_extract(ref, gray, prm=PARAMS, cap=8192, desc=False):
+    """ORBextractor::operator() of the reference-compiled library; desc=True runs its stages one by one + computeDescriptors."""
+    h, w = gray.shape
+    a = [np.zeros(cap, np.float32) for _ in range(5)]
+    octv = np.zeros(cap, np.int32)
+    d = np.zeros((cap, 32), np.uint8)
+    args = [_u8(gray), w, h, C.byref(prm), _fp(a[0]), _fp(a[1]), _fp(a[2]), _fp(a[3]), _ip(octv), _fp(a[4]), cap]
+    n = ref.vdo_ref_orb_extract_desc(*args, _u8(d)) if desc else ref.vdo_ref_orb_extract(*args)
+    assert n >= 0
+    out = dict(x=a[0][:n], y=a[1][:n], response=a[2][:n], angle=a[3][:n], octave=octv[:n], size=a[4][:n])
+    if desc:
+        out["desc"] = d[:n]
+    return out
+
+
+def ref_level_facts(ref, w, h, prm=PARAMS):
+    ws, hs, nf = (np.zeros(prm.n_levels, np.int32) for _ in range(3))
+    um = np.zeros(16, np.int32)
+    ref.vdo_ref_orb_level_facts(w, h, C.byref(prm), _ip(ws), _ip(hs), _ip(nf), _ip(um))
+    return ws, hs, nf, um
+
+
+def ref_pyramid(ref, gray, prm=PARAMS):
+    h, w = gray.shape
+    ws, hs, _, _ = ref_level_facts(ref, w, h, prm)
+    buf = np.zeros(int(((ws + 38) * (hs + 38)).sum()), np.uint8)
+    ref.vdo_ref_orb_pyramid(_u8(gray), w, h, C.byref(prm), _u8(buf))
+    out, off = [], 0
+    for a, b in zip(ws, hs):
+        n = (a + 38) * (b + 38)
+        out.append(buf[off:off + n].reshape(b + 38, a + 38)); off += n
+    return out

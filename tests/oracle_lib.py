@@ -94,3 +94,36 @@ def load_product_epnp():
     L.product_host_epnp.argtypes = [C.c_int] + [K.c_double_p] * 4
     _prod_epnp = L
     return L
+
+
+REF_DIR = os.path.join(ORACLE_DIR, "ref")
+REF_LIB = os.path.join(ORACLE_DIR, "_ref", "libref_orb.so")
+REFERENCE_ROOT = os.environ.get("VDO_REFERENCE_ROOT", "/root/reference")
+_ref_orb = None
+
+
+def load_ref_orb():
+    """oracle/_ref/libref_orb.so = the REFERENCE's own src/ORBextractor.cc compiled verbatim against the mini-cv shim (oracle/ref/).
+    (Re)built when the reference checkout is present (the build container); on the GPU box only the prebuilt library travels.
+    Returns None when neither exists - callers skip with "parity unpinned"."""
+    global _ref_orb
+    if _ref_orb is not None:
+        return _ref_orb
+    load()   # libvdo_oracle.so first: the shim's primitives live there
+    if os.path.exists(os.path.join(REFERENCE_ROOT, "src", "ORBextractor.cc")):
+        subprocess.run(["make", "-C", REF_DIR, "-s", f"REF={REFERENCE_ROOT}"], check=True)
+    if not os.path.exists(REF_LIB):
+        return None
+    from vdo_slam_amd.frontend import OrbParamsC
+    L = C.CDLL(REF_LIB)
+    fp, i32p, u8p = K.c_float_p, K.c_int32_p, K.c_uint8_p
+    head = [u8p, C.c_int, C.c_int, C.POINTER(OrbParamsC)]
+    L.vdo_ref_orb_extract.argtypes = head + [fp, fp, fp, fp, i32p, fp, C.c_int]
+    L.vdo_ref_orb_extract_desc.argtypes = head + [fp, fp, fp, fp, i32p, fp, C.c_int, u8p]
+    L.vdo_ref_orb_level_facts.argtypes = [C.c_int, C.c_int, C.POINTER(OrbParamsC), i32p, i32p, i32p, i32p]
+    L.vdo_ref_orb_pyramid.argtypes = head + [u8p]
+    L.vdo_ref_ic_angle.argtypes = [u8p, C.c_int, C.c_int, C.c_float, C.c_float]
+    L.vdo_ref_ic_angle.restype = C.c_float
+    L.vdo_ref_orb_descriptor.argtypes = [u8p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, u8p]
+    _ref_orb = L
+    return L

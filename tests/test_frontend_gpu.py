@@ -57,6 +57,29 @@ def test_orb_matches_oracle_bit_exact(ctx, oracle, seed, shape):
 
 
 @pytest.mark.parametrize("seed,shape", [(3, (375, 1242)), (4, (375, 1242)), (5, (480, 640))])
+def test_orb_matches_the_reference_source_bit_exact(ctx, seed, shape):
+    """HIP ORB against oracle/_ref = the reference's OWN src/ORBextractor.cc compiled verbatim (oracle/ref/, tests/test_ref_orb.py):
+    key-point list (x, y, octave, response, size, angle, order), the bordered pyramid and all descriptor bits."""
+    from tests import oracle_lib
+    from vdo_slam_amd.frontend import ORBextractor
+    ref = oracle_lib.load_ref_orb()
+    if ref is None:
+        pytest.skip("parity unpinned: oracle/_ref/libref_orb.so absent")
+    h, w = shape
+    gray = SF.make_gray(seed, w, h)
+    orb = ORBextractor(ctx, w, h)
+    kp = orb(gray, descriptors=True)
+    want = R.ref_extract(ref, gray, desc=True)
+    assert want["x"].size > 1500
+    for k in ("x", "y", "octave", "response", "size", "angle"):
+        assert np.array_equal(kp[k], want[k]), k
+    assert np.array_equal(kp["desc"], want["desc"])
+    for l, lv in enumerate(R.ref_pyramid(ref, gray)):
+        assert np.array_equal(orb.pyramid(l), lv), f"pyramid level {l}"
+    orb.close()
+
+
+@pytest.mark.parametrize("seed,shape", [(3, (375, 1242)), (4, (375, 1242)), (5, (480, 640))])
 def test_rotated_brief_descriptor_bits_match_oracle(ctx, oracle, seed, shape):
     """K8: the 256 descriptor bits of every keypoint == oracle, through vdo_orb_extract_desc and through the
     separate vdo_orb_descriptors call; keypoints unchanged by asking for descriptors."""
