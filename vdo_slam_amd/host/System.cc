@@ -38,32 +38,63 @@ bool read_settings(const std::string& path, std::map<std::string, double>& out) 
   return true;
 }
 double get(const std::map<std::string, double>& m, const char* k, double dflt = 0) { auto it = m.find(k); return it == m.end() ? dflt : it->second; }
+// Everything Tracking::Tracking reads from the settings file (src/Tracking.cc:53-161), with the reference's types: float / int
+// conversions of cv::FileNode (a missing key reads as 0, e.g. Camera.k3 in example/kitti-0018-0020.yaml; fps 0 -> 30), plus
+// Camera.width / Camera.height, which the reference's yaml files carry and this side sizes its device images from.
+struct TrackingSettings {
+  float fx, fy, cx, cy, k1, k2, p1, p2, k3, bf, fps;
+  int rgb, n_features; float scale_factor; int n_levels, ini_th, min_th, data_code;
+  float th_depth_bg, th_depth_obj, depth_map_factor;
+  int max_track_bg, max_track_obj; float sf_mg_thres, sf_ds_thres; int window_size, overlap_size, use_sample_feature, width, height;
+};
+bool read_tracking_settings(const std::string& path, TrackingSettings& t, std::map<std::string, double>* raw = nullptr) {
+  std::map<std::string, double> c;
+  if (!read_settings(path, c)) return false;
+  t.fx = (float)get(c, "Camera.fx"); t.fy = (float)get(c, "Camera.fy"); t.cx = (float)get(c, "Camera.cx"); t.cy = (float)get(c, "Camera.cy");
+  t.k1 = (float)get(c, "Camera.k1"); t.k2 = (float)get(c, "Camera.k2"); t.p1 = (float)get(c, "Camera.p1"); t.p2 = (float)get(c, "Camera.p2"); t.k3 = (float)get(c, "Camera.k3");
+  t.bf = (float)get(c, "Camera.bf");
+  t.fps = (float)get(c, "Camera.fps"); if (t.fps == 0) t.fps = 30;
+  t.rgb = (int)get(c, "Camera.RGB");
+  t.n_features = (int)get(c, "ORBextractor.nFeatures"); t.scale_factor = (float)get(c, "ORBextractor.scaleFactor"); t.n_levels = (int)get(c, "ORBextractor.nLevels");
+  t.ini_th = (int)get(c, "ORBextractor.iniThFAST"); t.min_th = (int)get(c, "ORBextractor.minThFAST");
+  t.data_code = (int)get(c, "ChooseData");
+  t.th_depth_bg = (float)get(c, "ThDepthBG"); t.th_depth_obj = (float)get(c, "ThDepthOBJ"); t.depth_map_factor = (float)get(c, "DepthMapFactor");
+  t.max_track_bg = (int)get(c, "MaxTrackPointBG"); t.max_track_obj = (int)get(c, "MaxTrackPointOBJ");
+  t.sf_mg_thres = (float)get(c, "SFMgThres"); t.sf_ds_thres = (float)get(c, "SFDsThres");
+  t.window_size = (int)get(c, "WINDOW_SIZE"); t.overlap_size = (int)get(c, "OVERLAP_SIZE"); t.use_sample_feature = (int)get(c, "UseSampleFeature");
+  t.width = (int)get(c, "Camera.width"); t.height = (int)get(c, "Camera.height");
+  if (raw) *raw = c;
+  return true;
+}
 }  // namespace
 
 Tracking::Tracking(System*, Map* pMap, const std::string& strSettingPath, const int) : mpMap(pMap) {
-  if (!read_settings(strSettingPath, cfg_)) { std::cerr << "Failed to open settings file at: " << strSettingPath << std::endl; std::exit(-1); }
+  TrackingSettings t{};
+  if (!read_tracking_settings(strSettingPath, t, &cfg_)) { std::cerr << "Failed to open settings file at: " << strSettingPath << std::endl; std::exit(-1); }
   mK = cv::Mat::eye(3, 3, cv::CV_32F);
-  mK.at<float>(0, 0) = (float)get(cfg_, "Camera.fx"); mK.at<float>(1, 1) = (float)get(cfg_, "Camera.fy");
-  mK.at<float>(0, 2) = (float)get(cfg_, "Camera.cx"); mK.at<float>(1, 2) = (float)get(cfg_, "Camera.cy");
-  mbf = (float)get(cfg_, "Camera.bf");
-  mbRGB = get(cfg_, "Camera.RGB", 1) != 0;
-  mDepthMapFactor = (float)get(cfg_, "DepthMapFactor", 1);
-  { const int dc = (int)get(cfg_, "ChooseData", 2); mTestData = dc == 1 ? OMD : dc == 3 ? VirtualKITTI : KITTI; }   // include/Tracking.h:129-133, src/Tracking.cc:115-128
+  mK.at<float>(0, 0) = t.fx; mK.at<float>(1, 1) = t.fy; mK.at<float>(0, 2) = t.cx; mK.at<float>(1, 2) = t.cy;
+  mbf = t.bf;
+  mbRGB = t.rgb != 0;
+  mDepthMapFactor = t.depth_map_factor;
+  mTestData = t.data_code == 1 ? OMD : t.data_code == 3 ? VirtualKITTI : KITTI;   // include/Tracking.h:129-133, src/Tracking.cc:115-128
+  // distortion (src/Tracking.cc:66-77): the reference's three settings files are distortion-free, and its Frame only undistorts when k1 != 0
+  // (src/Frame.cc:375-379); a calibrated distortion is outside what this path implements - refuse it instead of ignoring it
+  mDistCoef = cv::Mat::zeros(t.k3 != 0 ? 5 : 4, 1, cv::CV_32F);
+  mDistCoef.at<float>(0, 0) = t.k1; mDistCoef.at<float>(1, 0) = t.k2; mDistCoef.at<float>(2, 0) = t.p1; mDistCoef.at<float>(3, 0) = t.p2;
+  if (t.k3 != 0) mDistCoef.at<float>(4, 0) = t.k3;
+  if (t.k1 != 0 || t.k2 != 0 || t.p1 != 0 || t.p2 != 0 || t.k3 != 0) { std::cerr << "settings: lens distortion (Camera.k1..k3, p1, p2) is not supported by this build" << std::endl; std::exit(-1); }
   PipelineParams p{};
-  p.width = (int)get(cfg_, "Camera.width"); p.height = (int)get(cfg_, "Camera.height");
-  p.K4[0] = mK.at<float>(0, 0); p.K4[1] = mK.at<float>(1, 1); p.K4[2] = mK.at<float>(0, 2); p.K4[3] = mK.at<float>(1, 2);
+  p.width = t.width; p.height = t.height;
+  p.K4[0] = t.fx; p.K4[1] = t.fy; p.K4[2] = t.cx; p.K4[3] = t.cy;
   p.bf = mbf; p.depth_map_factor = mDepthMapFactor;
-  p.th_depth_bg = (float)get(cfg_, "ThDepthBG"); p.th_depth_obj = (float)get(cfg_, "ThDepthOBJ");
-  p.max_track_bg = (int)get(cfg_, "MaxTrackPointBG"); p.max_track_obj = (int)get(cfg_, "MaxTrackPointOBJ");
-  p.sf_mg_thres = (float)get(cfg_, "SFMgThres"); p.sf_ds_thres = (float)get(cfg_, "SFDsThres");
-  p.n_features = (int)get(cfg_, "ORBextractor.nFeatures"); p.n_levels = (int)get(cfg_, "ORBextractor.nLevels");
-  p.ini_th = (int)get(cfg_, "ORBextractor.iniThFAST"); p.min_th = (int)get(cfg_, "ORBextractor.minThFAST");
-  p.scale_factor = (float)get(cfg_, "ORBextractor.scaleFactor");
+  p.th_depth_bg = t.th_depth_bg; p.th_depth_obj = t.th_depth_obj;
+  p.max_track_bg = t.max_track_bg; p.max_track_obj = t.max_track_obj;
+  p.sf_mg_thres = t.sf_mg_thres; p.sf_ds_thres = t.sf_ds_thres;
+  p.n_features = t.n_features; p.n_levels = t.n_levels; p.ini_th = t.ini_th; p.min_th = t.min_th; p.scale_factor = t.scale_factor;
   p.build_lm = 1; p.defer_objects = 0;               // TrackRGBD returns with the frame complete, like the reference
-  p.use_sample_feature = (int)get(cfg_, "UseSampleFeature"); p.sample_seed = 1;
+  p.use_sample_feature = t.use_sample_feature; p.sample_seed = 1;
   p.pnp_refit = 1;                                   // solvePnPRansac's EPnP re-estimation (OpenCV 3.4)
-  p.window_size = (int)get(cfg_, "WINDOW_SIZE"); p.overlap_size = (int)get(cfg_, "OVERLAP_SIZE");
-  mDistCoef = cv::Mat::zeros(4, 1, cv::CV_32F);
+  p.window_size = t.window_size; p.overlap_size = t.overlap_size;
   mThDepth = p.th_depth_bg; mThDepthObj = p.th_depth_obj;
   nWINDOW_SIZE = p.window_size; nOVERLAP_SIZE = p.overlap_size; nMaxTrackPointBG = p.max_track_bg; nMaxTrackPointOBJ = p.max_track_obj;
   nUseSampleFea = p.use_sample_feature; fSFMgThres = p.sf_mg_thres; fSFDsThres = p.sf_ds_thres;
@@ -267,6 +298,18 @@ void System::SaveResults(const std::string& filename) {
 
 // ---- flat hooks (tests / Python) ----------------------------------------------------------------------------------------
 extern "C" {
+// The settings reader alone (no GPU): the 31 values of TrackingSettings in declaration order as doubles.  0, or -1 when the file
+// cannot be opened.  tests/test_settings_yaml.py reads the reference's three example/*.yaml through it.
+int host_settings_read(const char* path, double* out31) {
+  VDO_SLAM::TrackingSettings t{};
+  if (!VDO_SLAM::read_tracking_settings(path, t)) return -1;
+  const double v[31] = {t.fx, t.fy, t.cx, t.cy, t.k1, t.k2, t.p1, t.p2, t.k3, t.bf, t.fps, (double)t.rgb, (double)t.n_features, t.scale_factor, (double)t.n_levels,
+                        (double)t.ini_th, (double)t.min_th, (double)t.data_code, t.th_depth_bg, t.th_depth_obj, t.depth_map_factor, (double)t.max_track_bg,
+                        (double)t.max_track_obj, t.sf_mg_thres, t.sf_ds_thres, (double)t.window_size, (double)t.overlap_size, (double)t.use_sample_feature,
+                        (double)t.width, (double)t.height, 0.0};
+  for (int i = 0; i < 31; ++i) out31[i] = v[i];
+  return 0;
+}
 // (the C++ classes keep the reference's behaviour - exit(-1) on an unreadable settings file, no error channel; these hooks are
 // reached through ctypes, so they check first and turn failures into return codes instead of ending the host process)
 VDO_SLAM::System* host_system_create(const char* settings) {
