@@ -146,6 +146,56 @@ def test_bench_scale_graphs_match_the_oracle(ctx, oracle, shape, seed):
     ba.close()
 
 
+def _mixed_vertex_graph(shape, seed):
+    """A graph in which some pose vertices carry BOTH EdgeSE3PointXYZ and LandmarkMotionTernaryEdge edges (never the case in graphs the
+    reference builds, possible in a .g2o file): every 5th ternary edge takes a CAMERA vertex as its SE(3) vertex."""
+    import dataclasses
+    g = synth.make_ba_graph(*shape, seed=seed)
+    et_pose = g.et_pose.copy()
+    rng = np.random.default_rng(seed)
+    sel = np.arange(0, g.n_et, 5)
+    et_pose[sel] = rng.integers(1, g.n_cam, sel.size)
+    return dataclasses.replace(g, et_pose=et_pose.astype(g.et_pose.dtype))
+
+
+@pytest.mark.parametrize("mode", ["env", "mixed_vertex"])
+@pytest.mark.parametrize("shape", [(12, 300, 2, 40), (40, 2000, 3, 150)])
+def test_wide_partial_rows_match_oracle(ctx, oracle, shape, mode, monkeypatch):
+    """The 32-sums-per-row form of the sweep partials (`ps_stride == 32`: ba_sweep.hip's two-kind rows, k_finalize_pose's wide branch, the
+    solver's 32-wide rows), chosen when a pose vertex carries both edge kinds - forced on an ordinary graph by VDO_BA_WIDE_PARTIALS=1, and
+    reached the natural way by a mixed-vertex graph: blocks <= 1e-12 and the same LM trajectory as the oracle, PCG and dense solver."""
+    from vdo_slam_amd.ba import BatchBA
+    if mode == "env":
+        monkeypatch.setenv("VDO_BA_WIDE_PARTIALS", "1")
+        g = synth.make_ba_graph(*shape, seed=13)
+    else:
+        g = _mixed_vertex_graph(shape, 13)
+    ba = BatchBA(ctx, g)
+    assert ba.dims()["ps_stride"] == 32
+    ba.linearize()
+    S = ba.system()
+    R = _oracle_system(oracle, g)
+    for name in BLOCKS:
+        a, b = getattr(S, name), getattr(R, name)
+        if b.size:
+            assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max() + 1e-300, name
+    assert abs(S.chi2 - R.chi2) <= 1e-12 * abs(R.chi2) and abs(S.robust_chi2 - R.robust_chi2) <= 1e-12 * abs(R.robust_chi2)
+    gc, keep = K.graph_to_c(g)
+    opt = K.LMOptionsC(6, 1e-4, 0, 0, 0.0, 0)
+    st_o = K.LMStatsC()
+    pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(pose_o), K._dp(point_o), C.byref(st_o)) == 0
+    for solver in (2, 3):
+        ba.set_estimates(g.pose, g.point)
+        st = ba.optimize(max_iterations=6, gain_threshold=1e-4, solver=solver)
+        pose, point = ba.estimates()
+        assert (st.iterations, st.total_trials) == (st_o.iterations, st_o.total_trials), solver
+        assert abs(st.final_chi2 - st_o.final_chi2) <= 1e-6 * st_o.final_chi2, solver
+        assert np.abs(pose[:, :9] - pose_o[:, :9]).max() <= 1e-4 and np.abs(pose[:, 9:] - pose_o[:, 9:]).max() <= 1e-4 * np.abs(pose_o[:, 9:]).max(), solver
+        assert np.abs(point - point_o).max() <= 1e-4 * np.abs(point_o).max(), solver
+    ba.close()
+
+
 def test_invalid_graph_is_rejected(ctx):
     from vdo_slam_amd.ba import BatchBA
     g = synth.make_ba_graph(6, 50, 1, 5, seed=1)
@@ -294,9 +344,12 @@ def test_pose_chain_solver_is_the_same_operator_however_it_is_partitioned(ctx, o
         assert np.abs(r[3] - pose_o).max() <= 1e-4 * max(1.0, np.abs(pose_o).max()), name
 
 
-def test_config4_sized_graph_properties(ctx, monkeypatch):
-    """BASELINE configs[4] shape (1 M landmarks, 5 k pose / motion vertices, 20 objects, 5.8 M edges) - too large for the oracle, so the
-    HIP path is checked through properties that do not depend on the size:
+def test_config4_sized_graph_blocks_match_the_oracle_and_properties(ctx, oracle, monkeypatch):
+    """BASELINE configs[4] shape (1 M landmarks, 5 k pose / motion vertices, 20 objects, 5.8 M edges).  The oracle's whole-system Cholesky
+    is out of reach at this size, its LINEARISATION is not (20 s, 1 thread): every block of the HIP linearisation - chi2, Hpp, bp, Hll, bl,
+    all 5.76 M pose-landmark blocks, the ternary blocks - within 1e-12 of it (this is the graph with the longest dynamic tracks: 81 pose
+    slots in a tile, slot tables and thread tables at their limits).  The LM at this size is checked through properties that do not
+    depend on the size:
       * two linearisations give the same chi2 bits (fixed summation order) and the same blocks up to the order of the LDS additions;
       * renumbering the caller's points and edges at random changes nothing beyond rounding (the tile-major renumbering, the
         slot tables and the pose-major partial rows are a function of the graph, not of how the caller listed it);
@@ -309,6 +362,13 @@ def test_config4_sized_graph_properties(ctx, monkeypatch):
     ba = BatchBA(ctx, g)
     ba.linearize()
     S1 = ba.system()
+    R = _oracle_system(oracle, g)
+    for name in BLOCKS:
+        a, b = getattr(S1, name), getattr(R, name)
+        assert b.size and np.abs(a - b).max() <= 1e-12 * np.abs(b).max(), name
+    assert abs(S1.chi2 - R.chi2) <= 1e-12 * abs(R.chi2) and abs(S1.robust_chi2 - R.robust_chi2) <= 1e-12 * abs(R.robust_chi2)
+    assert ba.dims()["max_slots"] > 64              # beyond what the small graphs reach
+    del R
     Hpp, bp, Hll, bl, chi = S1.Hpp.copy(), S1.bp.copy(), S1.Hll.copy(), S1.bl.copy(), (float(S1.chi2), float(S1.robust_chi2))
     ba.linearize(repeat=2)
     S2 = ba.system()

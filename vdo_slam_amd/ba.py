@@ -71,6 +71,12 @@ class BatchBA:
         K.check(L.vdo_ba_profile_linearize(self._h, repeat, ms, dims))
         return float(ms[0]), float(ms[1]), dict(zip(("tiles", "slots", "partial_row", "max_slots", "read_bytes_eb", "read_bytes_et"), (int(v) for v in dims)))
 
+    def dims(self) -> dict:
+        """Layout facts of the tiled graph (tests): tiles, (tile, slot) pairs, ps_stride (= partial_row), max_slots, bytes read per edge."""
+        d = self.profile_linearize(1)[2]
+        d["ps_stride"] = d["partial_row"]
+        return d
+
     def system(self) -> K.BASystem:
         S = K.BASystem(self.graph)
         K.check(K.lib().vdo_ba_download_system(self._h, C.byref(S.c)))
