@@ -47,6 +47,20 @@ def test_trajectory_and_object_motions_are_recovered():
     pipe.close()
 
 
+def assert_tracklets_equal_the_oracle(oracle, pipe, ref):
+    """Tracklet CONTENTS (north star: bit-exact track indices): every (frame, feature) pair of every static and dynamic tracklet, in
+    order, and the object id of every dynamic tracklet - the product's incremental builder (vdo_tracks_*) against the oracle's
+    rebuild-from-frame-0 (GetStaticTrack / GetDynamicTrackNew, src/Tracking.cc:2201-2421) on the oracle sequence's associations."""
+    from tests import tracking_ref as T
+    ts = T.build_tracks(oracle, ref.assos_s)
+    td = T.build_tracks(oracle, ref.assos_d, ref.labs_d)
+    for got, exp, what in ((pipe.tracks(False), ts, "static"), (pipe.tracks(True), td, "dynamic")):
+        assert exp[0].size - 1 > 50, what
+        assert np.array_equal(got[0], exp[0]), what + ": track offsets"
+        assert np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2]), what + ": (frame, feature) pairs"
+    assert np.array_equal(pipe.tracks(True)[3], td[3]), "object id per dynamic tracklet"
+
+
 def test_full_track_sequence_matches_the_oracle_sequence(oracle):
     """Same sequence through the oracle-composed Track() (tests/pipeline_ref.py, build_lm=True: oracle RANSAC, oracle LM,
     oracle RenewFrameInfo ...): every per-frame count agrees and the poses agree to float precision."""
@@ -73,6 +87,7 @@ def test_full_track_sequence_matches_the_oracle_sequence(oracle):
         for a, b in zip(ms, mo):
             assert (a["mod_label"], a["sem_label"], a["n_inliers"]) == (b["mod_label"], b["sem_label"], b["n_inliers"])
             np.testing.assert_allclose(a["H"], b["H"], rtol=0, atol=5e-6)
+    assert_tracklets_equal_the_oracle(oracle, pipe, ref)
     pipe.close()
 
 
@@ -161,6 +176,7 @@ def test_noisy_sequence_with_invalid_pixels_and_a_dropped_mask_matches_the_oracl
             np.testing.assert_allclose(a["H"], b["H"], rtol=0, atol=1e-4 * max(1.0, float(np.abs(b["H"][:3, 3]).max())))
         recovered += got["n_recovered_masks"]
     assert recovered >= 1 and got["n_objects"] >= 3
+    assert_tracklets_equal_the_oracle(oracle, pipe, ref)
     pipe.close()
 
 

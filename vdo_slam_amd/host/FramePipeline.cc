@@ -851,6 +851,20 @@ void host_pipeline_destroy(FramePipeline* fp) { delete fp; }
 // [10] K15 + K11 (objects)
 void host_pipeline_timing(FramePipeline* fp, double* ms11) { for (int i = 0; i < 11; ++i) ms11[i] = fp->ms_[i]; }
 int host_pipeline_flush(FramePipeline* fp, FrameCounts* out) { return fp->Flush(out); }
+// The tracklets as Track() keeps them (GetStaticTrack / GetDynamicTrackNew, src/Tracking.cc:2201-2421), which = 0 static, 1 dynamic:
+// with off == NULL returns the sizes (n_tracks, n_pairs); else fills off [n_tracks + 1], frame / feat [n_pairs], obj [n_tracks] (dynamic only).
+int host_pipeline_tracks(FramePipeline* fp, int which, int64_t* sizes2, int32_t* off, int32_t* frame, int32_t* feat, int32_t* obj) {
+  VDO_SLAM::TrackList L;
+  if (fp->GetTracks(which ? nullptr : &L, which ? &L : nullptr) != 0) return -1;
+  if (sizes2) { sizes2[0] = L.size(); sizes2[1] = (int64_t)L.frame.size(); }
+  if (off) {
+    std::copy(L.off.begin(), L.off.end(), off);
+    std::copy(L.frame.begin(), L.frame.end(), frame);
+    std::copy(L.feat.begin(), L.feat.end(), feat);
+    if (which && obj) std::copy(L.obj.begin(), L.obj.end(), obj);
+  }
+  return 0;
+}
 
 // ---- Map: Track() -> Map -> Optimizer::FullBatchOptimization (tests / demos)
 VDO_SLAM::Map* host_pipeline_attach_map(FramePipeline* fp) { VDO_SLAM::Map* m = new VDO_SLAM::Map(); fp->AttachMap(m); return m; }

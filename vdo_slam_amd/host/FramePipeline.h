@@ -97,6 +97,8 @@ class FramePipeline {
   int n_partial_batches_ = 0;          // PartialBatchOptimization runs so far
   // Ends a pending object stage (deferred mode); fc (optional) receives its n_object_tracked / n_dynamic_tracks.
   int Flush(FrameCounts* fc = nullptr) { return FinishObjects(fc); }
+  // the tracklets kept incrementally (GetStaticTrack / GetDynamicTrackNew) as flat lists; either pointer may be NULL
+  int GetTracks(TrackList* sta, TrackList* dyn);
   bool ok() const { return ok_; }
   // deferred object stage on / off between frames (a pending stage is consumed by the next Step or by Flush either way)
   void SetDeferObjects(bool on) { p_.defer_objects = on ? 1 : 0; }
@@ -127,7 +129,6 @@ class FramePipeline {
   int FinishObjectsTail(FrameCounts* fc);   // dynamic tracklets, Map, windowed optimisation: nothing the next frame's object chain waits for
   bool tail_pending_ = false, tail_has_lm_ = false;
   std::vector<int32_t> dyn_asso_tail_;
-  int GetTracks(TrackList* sta, TrackList* dyn);
   GraphStore store_;
   TrackList tl_sta_, tl_dyn_;
   bool keep_graph_ = false;

@@ -63,6 +63,22 @@ class FramePipeline:
             raise K.VdoError("FramePipeline.Flush failed: " + (K.lib().vdo_last_error() or b"").decode())
         return self.counts.as_dict()
 
+    def tracks(self, dynamic=False):
+        """The tracklets Track() has built so far: (off, frame, feat, obj) - track t = pairs [off[t], off[t+1]) of (frame, feature index);
+        obj = object id per track (dynamic tracklets; None for static)."""
+        import numpy as np
+        L = self._L
+        L.host_pipeline_tracks.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), K.c_int32_p, K.c_int32_p, K.c_int32_p, K.c_int32_p]
+        sz = (C.c_int64 * 2)()
+        if L.host_pipeline_tracks(self._h, int(dynamic), sz, None, None, None, None) != 0:
+            raise K.VdoError("FramePipeline.GetTracks failed")
+        nt, npairs = int(sz[0]), int(sz[1])
+        off = np.zeros(nt + 1, np.int32); fr = np.zeros(max(npairs, 1), np.int32); ft = np.zeros(max(npairs, 1), np.int32); ob = np.zeros(max(nt, 1), np.int32)
+        ip = lambda a: a.ctypes.data_as(K.c_int32_p)
+        if L.host_pipeline_tracks(self._h, int(dynamic), sz, ip(off), ip(fr), ip(ft), ip(ob)) != 0:
+            raise K.VdoError("FramePipeline.GetTracks failed")
+        return off, fr[:npairs], ft[:npairs], (ob[:nt] if dynamic else None)
+
     # ---- Map: Track() -> Map -> Optimizer::FullBatchOptimization
     def attach_map(self):
         """From now on every frame appends its features / poses / motions to a VDO_SLAM::Map ("Save Graph Structure")."""
