@@ -855,6 +855,7 @@ int host_pipeline_flush(FramePipeline* fp, FrameCounts* out) { return fp->Flush(
 // with off == NULL returns the sizes (n_tracks, n_pairs); else fills off [n_tracks + 1], frame / feat [n_pairs], obj [n_tracks] (dynamic only).
 int host_pipeline_tracks(FramePipeline* fp, int which, int64_t* sizes2, int32_t* off, int32_t* frame, int32_t* feat, int32_t* obj) {
   VDO_SLAM::TrackList L;
+  if (fp->Flush(nullptr) != 0) return -1;          // a pending (deferred) object stage owns the dynamic tracklets of its frame
   if (fp->GetTracks(which ? nullptr : &L, which ? &L : nullptr) != 0) return -1;
   if (sizes2) { sizes2[0] = L.size(); sizes2[1] = (int64_t)L.frame.size(); }
   if (off) {
