@@ -55,6 +55,7 @@ class OraclePipeline:
         sides to start from the same float; the EPnP arithmetic itself is pinned separately."""
         self.pnp_refit = pnp_refit                      # cv::solvePnPRansac's final EPnP re-estimation on the inliers (OpenCV >= 3.3)
         self.seed_lib = None
+        self.epnp_log = []          # seed_refit="product": the oracle's own refit beside every borrowed one (see _ransac)
         if seed_refit == "product":
             from tests import oracle_lib
             self.seed_lib = oracle_lib.load_product_epnp()
@@ -90,6 +91,14 @@ class OraclePipeline:
             sel = inl[:n] > 0
             Xi, ui, T2 = np.ascontiguousarray(X[sel]), np.ascontiguousarray(uv[sel]), np.zeros(16)
             if self.seed_lib.product_host_epnp(int(sel.sum()), K._dp(Xi), K._dp(ui), K._dp(K4d), K._dp(T2)) >= 0:      # (coplanar inliers: the hypothesis stays)
+                # The borrowed refit does not replace the check of that stage: the oracle's OWN RANSAC + EPnP runs as well, and what it
+                # returns - inlier count, inlier mask (everything upstream of the LM) and the refit pose - is logged next to the
+                # borrowed seed; the sequence tests assert identical inliers and poses within 1e-8 (epnp_log).
+                T_own = np.eye(4).ravel().copy(); inl_own = np.zeros(max(n, 1), np.uint8)
+                good_own = self.o.vdo_oracle_pnp_ransac_refit(n, K._dp(X), K._dp(uv), K._dp(K4d), 500, 0.4, 0.98, 1, K._dp(T_own), inl_own.ctypes.data_as(K.c_uint8_p), None, None)
+                self.epnp_log.append(dict(n=int(good), same_inliers=bool(good_own == good and np.array_equal(inl_own, inl)),
+                                          dT=float(np.abs(T_own - T2).max() / max(1.0, np.abs(T2[:12]).max())),
+                                          same_float_seed=bool(np.array_equal(T_own.astype(f32), T2.astype(f32)))))
                 Tm = T2
         return good, Tm.reshape(4, 4), inl[:n]
 

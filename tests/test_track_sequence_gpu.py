@@ -47,6 +47,18 @@ def test_trajectory_and_object_motions_are_recovered():
     pipe.close()
 
 
+def assert_borrowed_seeds_are_checked(ref):
+    """OraclePipeline(seed_refit="product") takes the EPnP refit from a CPU build of the product's host routine so that both sides seed the
+    (chaotic, tests/test_oracle_flow2.py::test_f3_lm_is_chaotic_in_the_seed) object LMs with the same float.  The EPnP stage is still checked
+    inside the sequence: the oracle's own RANSAC + EPnP ran beside every borrowed refit - same inlier masks (everything upstream of the
+    LM), poses within 1e-8; the float seeds themselves mostly agree too (not asserted: one ulp is exactly what the borrowing is for)."""
+    log = ref.epnp_log
+    assert len(log) >= 5
+    assert all(c["same_inliers"] for c in log)
+    assert max(c["dT"] for c in log) <= 1e-8, max(c["dT"] for c in log)
+    print(f"EPnP inside the sequence: {len(log)} refits, oracle vs product max {max(c['dT'] for c in log):.1e}, identical float seeds {sum(c['same_float_seed'] for c in log)}/{len(log)}")
+
+
 def assert_tracklets_equal_the_oracle(oracle, pipe, ref):
     """Tracklet CONTENTS (north star: bit-exact track indices): every (frame, feature) pair of every static and dynamic tracklet, in
     order, and the object id of every dynamic tracklet - the product's incremental builder (vdo_tracks_*) against the oracle's
@@ -176,6 +188,7 @@ def test_noisy_sequence_with_invalid_pixels_and_a_dropped_mask_matches_the_oracl
             np.testing.assert_allclose(a["H"], b["H"], rtol=0, atol=1e-4 * max(1.0, float(np.abs(b["H"][:3, 3]).max())))
         recovered += got["n_recovered_masks"]
     assert recovered >= 1 and got["n_objects"] >= 3
+    assert_borrowed_seeds_are_checked(ref)
     assert_tracklets_equal_the_oracle(oracle, pipe, ref)
     pipe.close()
 
@@ -311,6 +324,8 @@ def test_turning_objects_that_leave_and_enter_match_the_oracle(oracle):
                 turning_checked += abs(ob.get("yaw_rate", 0.0)) > 0.01
     assert 2 in labels_seen and 5 in labels_seen            # the leaving and the entering object were both tracked while present
     assert turning_checked >= 3 and recovered >= 1
+    assert_borrowed_seeds_are_checked(ref)
+    assert_tracklets_equal_the_oracle(oracle, pipe, ref)
     pipe.close()
 
 
@@ -353,4 +368,5 @@ def test_object_motion_model_branch_of_get_init_model_obj(oracle, flow_sigma, mm
         _motions_match(ms, mo)
     assert had_model >= 4
     assert (won >= 6) if mm_wins else (won == 0), won
+    assert_borrowed_seeds_are_checked(ref)
     pipe.close()
