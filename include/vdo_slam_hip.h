@@ -134,7 +134,11 @@ typedef struct vdo_lm_stats {
 } vdo_lm_stats;
 
 typedef struct vdo_ba vdo_ba;
-/* Uploads the graph to HBM (SoA, resident until destroy) and builds the chain structure. */
+/* Uploads the graph to HBM (SoA, resident until destroy) and builds the chain structure.
+ * Limits (g2o has none; VDO_ERR_UNSUPPORTED names the offending track): a landmark track - one static point, or a chain of dynamic
+ * points linked by LandmarkMotionTernaryEdges - is processed by ONE workgroup and must fit its tile: <= 256 points, <= 768 edge
+ * incidences, <= 100 distinct pose vertices (cameras + motions), and sum over those poses of ceil(observations / 3) <= 256.  The graphs
+ * the reference builds are far inside (a track lives <= a few dozen frames); a static point observed from more than 100 frames is not. */
 int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out);
 int vdo_ba_destroy(vdo_ba* ba);
 /* K18: `repeat` back-to-back linearisation sweeps (errors + Jacobians + Huber + block
@@ -150,6 +154,9 @@ int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep);
  *   dims[0] tiles, [1] (tile, pose-slot) pairs, [2] running sums per partial row (16 / 32), [3] max slots of a tile,
  *   [4] bytes read per EdgeSE3PointXYZ (key + measurement [+ weight]), [5] bytes read per ternary edge. */
 int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int64_t dims[6]);
+/* One self-consistent linearisation in block form (BlockSolver::buildSystem) AT THE CURRENT ESTIMATE: the blocks of the last
+ * vdo_ba_linearize when nothing moved the estimate since, else (after vdo_ba_optimize / vdo_ba_set_estimates) a fresh linearisation is
+ * run first - collective on a sharded handle. */
 int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out);
 /* Full Levenberg–Marquardt (control flow identical to the modified g2o). */
 int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_stats* stats);

@@ -115,6 +115,7 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
   vdo_lm_stats local;
   if (!st) st = &local;
   std::memset(st, 0, sizeof(*st));
+  ba->lin_current = false;        // (the accepted steps move estimate[0] away from the last linearisation)
   BADev& d = ba->d;
   hipStream_t s = ba->ctx->stream;
   const double t_begin = now_ms();

@@ -203,6 +203,33 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
                        ci.npts, ci.ninc, VDO_TILE_PTS, VDO_TILE_INC);
     }
     chain_poses(ci, cposes);
+    {   // the track on its own must fit a tile (checked here, before anything is built, with a message that names the track):
+        // distinct pose vertices <= kHardSlots (LDS slots), and its EdgeSE3PointXYZ edges cut per pose into pieces of <= 3 must fit
+        // the 256 threads of the sweep
+      std::vector<int32_t> u(cposes);
+      std::sort(u.begin(), u.end());
+      const int distinct = (int)(std::unique(u.begin(), u.end()) - u.begin());
+      if (distinct > kHardSlots) {
+        delete ba;
+        return set_error(VDO_ERR_UNSUPPORTED, "landmark track of %d point(s) / %d incidences touches %d distinct pose vertices (limit %d per track)",
+                         ci.npts, ci.ninc, distinct, kHardSlots);
+      }
+      chain_eb_poses.clear();
+      for (int c = ci.head;;) {
+        for (int k = pb_off[c]; k < pb_off[c + 1]; ++k) chain_eb_poses.push_back(g->eb_pose[pb_idx[k]]);
+        const int e = next_e[c];
+        if (e == -1) break;
+        c = g->et_p2[e];
+      }
+      std::sort(chain_eb_poses.begin(), chain_eb_poses.end());
+      int pieces = 0;
+      for (size_t j = 0; j < chain_eb_poses.size();) { size_t k = j; while (k < chain_eb_poses.size() && chain_eb_poses[k] == chain_eb_poses[j]) ++k; pieces += (int)((k - j + 2) / 3); j = k; }
+      if (pieces > VDO_TILE_THREADS) {
+        delete ba;
+        return set_error(VDO_ERR_UNSUPPORTED, "landmark track of %d point(s) with %zu EdgeSE3PointXYZ observations needs %d per-pose pieces (limit %d per track)",
+                         ci.npts, chain_eb_poses.size(), pieces, VDO_TILE_THREADS);
+      }
+    }
     int newp = 0;
     for (int32_t p : cposes) if (pose_stamp[p] != cur_tile_id) ++newp;   // upper bound (duplicates inside the chain counted once below)
     // (+ every thread of the sweep takes <= 3 edges of ONE pose slot: the sum over the slots of ceil(edges / 3) must fit the 256 threads)
@@ -506,6 +533,7 @@ extern "C" int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep) {
     *ms_sweep = ms / repeat;
   }
   for (int i = 0; i < (ms_sweep ? 1 : repeat); ++i) launch_linearize(ba->d, s, ba->red);
+  ba->lin_current = true;
   return sync_check(ba, "vdo_ba_linearize");
 }
 
@@ -531,6 +559,7 @@ extern "C" int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int
     dims[4] = 4 + (d.eb_zf ? 12 : 24) + (d.eb_w ? 8 : 0);
     dims[5] = 8 + (d.et_z ? 24 : 0) + (d.et_w ? 8 : 0);
   }
+  ba->lin_current = true;
   return sync_check(ba, "vdo_ba_profile_linearize");
 }
 
@@ -541,6 +570,10 @@ extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
   const BADev& d = ba->d;
   hipStream_t s = ba->ctx->stream;
   auto D2H = [&](void* dst, const void* src, size_t bytes) { if (dst && bytes) hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s); };
+  // The pose-landmark blocks are kept factored (one scalar per incidence) and expanded with the CURRENT estimate; after an optimisation or
+  // vdo_ba_set_estimates the stored Hpp / bp / Hll / Finc belong to an older estimate and the expansion would mix the two: re-linearise
+  // first, so that what comes back is always one self-consistent system at the current estimate.
+  if (!ba->lin_current) { launch_linearize(ba->d, s, ba->red); ba->lin_current = true; }
   std::vector<double> hll, bl, oll, binc;
   D2H(out->Hpp, d.Hpp, sizeof(double) * 36 * (size_t)d.P);
   D2H(out->bp, d.bp, sizeof(double) * 6 * (size_t)d.P);
@@ -600,6 +633,7 @@ extern "C" int vdo_ba_get_estimates(vdo_ba* ba, double* pose_out, double* point_
 
 extern "C" int vdo_ba_set_estimates(vdo_ba* ba, const double* pose, const double* point) {
   if (!ba) return set_error(VDO_ERR_INVALID, "null handle");
+  ba->lin_current = false;
   int rc = ctx_bind(ba->ctx);
   if (rc != VDO_OK) return rc;
   hipStream_t s = ba->ctx->stream;
