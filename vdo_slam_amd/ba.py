@@ -37,7 +37,25 @@ class Context:
     def synchronize(self):
         K.check(K.lib().vdo_ctx_synchronize(self._h))
 
+    # Objects built on a context (pipelines, batches, extractors) retain it: when a garbage-collected reference cycle (e.g. the frames
+    # of a failed test) finalises the context BEFORE its users - Python gives no order inside a cycle - the destroy is postponed until
+    # the last user has let go, instead of pulling the stream and the arenas from under a live pipeline.
+    _users = 0
+    _close_pending = False
+
+    def _retain(self):
+        self._users += 1
+
+    def _release(self):
+        self._users -= 1
+        if self._users <= 0 and self._close_pending:
+            self._close_pending = False
+            self.close()
+
     def close(self):
+        if self._users > 0:
+            self._close_pending = True
+            return
         if self._h:
             K.lib().vdo_ctx_destroy(self._h)
             self._h = C.c_void_p()
@@ -56,6 +74,7 @@ class BatchBA:
         self._gc, self._keep = K.graph_to_c(graph)
         self._h = C.c_void_p()
         K.check(K.lib().vdo_ba_create(ctx._h, C.byref(self._gc), C.byref(self._h)))
+        ctx._retain()
 
     def linearize(self, repeat: int = 1, timed: bool = False):
         """Run the linearisation sweep; with ``timed`` returns the mean ms of the K18 kernel."""
@@ -102,6 +121,7 @@ class BatchBA:
         if self._h:
             K.lib().vdo_ba_destroy(self._h)
             self._h = C.c_void_p()
+            self.ctx._release()
 
     def __del__(self):
         try:

@@ -47,6 +47,9 @@ class FramePipeline:
                                          ctx_worker._h if ctx_worker is not None else None, ctx_orb._h if ctx_orb is not None else None)
         if not self._h:
             raise K.VdoError("FramePipeline could not be created")
+        for c in self._keep:
+            if c is not None:
+                c._retain()
         self.counts = FrameCounts()
 
     def step(self, d_gray: int, d_depth_raw: int, d_flow: int, d_mask: int, cam_batch=None, obj_batch=None, n_cam_pts=0, n_obj_problems=0):
@@ -188,6 +191,9 @@ class FramePipeline:
             if getattr(self, "_map", None):
                 self._L.host_map_destroy.argtypes = [C.c_void_p]
                 self._L.host_map_destroy(self._map); self._map = None
+            for c in self._keep:
+                if c is not None:
+                    c._release()
 
     def __del__(self):
         try: self.close()
