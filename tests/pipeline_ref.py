@@ -96,7 +96,8 @@ class OraclePipeline:
                 # borrowed seed; the sequence tests assert identical inliers and poses within 1e-8 (epnp_log).
                 T_own = np.eye(4).ravel().copy(); inl_own = np.zeros(max(n, 1), np.uint8)
                 good_own = self.o.vdo_oracle_pnp_ransac_refit(n, K._dp(X), K._dp(uv), K._dp(K4d), 500, 0.4, 0.98, 1, K._dp(T_own), inl_own.ctypes.data_as(K.c_uint8_p), None, None)
-                self.epnp_log.append(dict(n=int(good), same_inliers=bool(good_own == good and np.array_equal(inl_own, inl)),
+                sv = np.linalg.svd(Xi - Xi.mean(0), compute_uv=False)
+                self.epnp_log.append(dict(n=int(good), same_inliers=bool(good_own == good and np.array_equal(inl_own, inl)), flatness=float(sv[2] / sv[0]),
                                           dT=float(np.abs(T_own - T2).max() / max(1.0, np.abs(T2[:12]).max())),
                                           same_float_seed=bool(np.array_equal(T_own.astype(f32), T2.astype(f32)))))
                 Tm = T2

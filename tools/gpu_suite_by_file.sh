@@ -1,7 +1,7 @@
 # The GPU test suite file by file (one python process each: a crash in one file does not hide the others), short tracebacks.
 # usage (through gpurun, from the repo root):  bash tools/gpu_suite_by_file.sh gpurun_out/r04/suite.log [pytest args]
 OUT=$1; shift
-: > $OUT
+mkdir -p $(dirname $OUT); : > $OUT
 for f in tests/test_*.py; do
   if grep -q "mark.gpu" $f; then
     echo "=== $f" >> $OUT
