@@ -189,6 +189,8 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   FrameCounts fc{};
   auto t_prev = std::chrono::steady_clock::now();
   const auto t_step0 = t_prev;
+  static const bool ev_env = std::getenv("VDO_PIPE_EVENTS") != nullptr;
+  ev_on_ = ev_env; ev_t0_ = t_step0;
   double ms0[12];
   for (int i = 0; i < 12; ++i) ms0[i] = ms_[i];
   static const bool trace_slow = std::getenv("VDO_PIPE_TRACE_SLOW") != nullptr;    // (debug: the sections of a step that took > 2.5 ms)
@@ -239,6 +241,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
       int rc = vdo_orb_extract(orb_, d_gray, W, host_inputs_ ? 0 : 1, &kp) == VDO_OK ? 0 : -1;
       ms_[1] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
       if (rc != 0) std::fprintf(stderr, "FramePipeline: %s\n", vdo_last_error());
+      mark(kEvOrbDone);
       orb_ready_.store(rc == 0 ? tag : -tag, std::memory_order_release);
       if (tail_via_orb) {                                // the tail of the last frame's object stage, as soon as that stage is over
         int v;
@@ -304,7 +307,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   } else {
     VDO_TRY(vdo_ctx_synchronize(ctx_));
   }
-  tick(0);
+  tick(0); mark(kEvInputs);
   // ---- GetInitModelCam + PoseOptimizationFlow2Cam (K16): launched at the end of the LAST Step if the camera stage runs ahead (CameraStage)
   {
     vdo_flow2_batch* cam_ext = cam;
@@ -379,7 +382,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
       for (int i = 0; i < n_s; ++i) tm[i] = inl_out_[n_cam_pts > 0 ? i % n_cam_pts : 0] ? i : -1;
     }
   }
-  tick(3);
+  tick(3); mark(kEvCamFetched);
   // ---- the object set of the last frame: wait for its object stage (its tail - tracklets, Map - goes on behind)
   bool tail_async = false, tail_on_orb = false;
   if (fin_async) {
@@ -411,7 +414,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     fc.n_recovered_masks = rec;
   }
   mask_final_.store(tag, std::memory_order_release);      // (UpdateMask is through: K10 may sample the mask)
-  tick(10);
+  tick(10); mark(kEvObjChain);
   StaSet nsta; ObjSet nobj;
   std::vector<int32_t> sta_asso, dyn_asso;
   // ---- K9 + K10 of the new image, RenewFrameInfo (static) (K14, K12), static tracklets: independent of the object chain
@@ -421,7 +424,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     auto tp = std::chrono::steady_clock::now();
     auto tk = [&](int slot) { const auto t = std::chrono::steady_clock::now(); ms_[slot] += std::chrono::duration<double, std::milli>(t - tp).count(); tp = t; };
     if (frame_filters() != 0) return -1;
-    tk(2);
+    tk(2); mark(kEvFilters);
     const int cs = p_.max_track_bg + 2;
     nsta.x.resize(cs); nsta.y.resize(cs); nsta.cx.resize(cs); nsta.cy.resize(cs); nsta.fx.resize(cs); nsta.fy.resize(cs); nsta.d.resize(cs);
     sta_asso.resize(cs);
@@ -446,7 +449,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     // ---- static tracklets (incremental GetStaticTrack)                             Tracking.cc:2201-2300
     while (!tail_done_.load(std::memory_order_acquire)) std::this_thread::yield();      // (the tail of the last frame may be reading the static tracklets: windowed batch optimisation)
     VDO_TRY(vdo_tracks_add_frame(tr_sta_, m, sta_asso.data(), nullptr));
-    tk(5);
+    tk(5); mark(kEvStaticDone);
     return 0;
   };
   // (declared after every local stage_static touches: on an early return this wait runs BEFORE those locals are destroyed)
@@ -488,7 +491,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
                                  (int)last_sem_pos_.size(), last_sem_pos_.data(), last_mod_label_.data(), last_obj_stat_.data(), &max_id_,
                                  off.data(), idx.data(), osem.data(), omod.data(), &n_objects));
     fc.n_objects = n_objects;
-    tick(4);
+    tick(4); mark(kEvDynObj);
     // ---- GetInitModelObj for every accepted object: one batched RANSAC call                   Tracking.cc:1717-1849
     if (n_objects > 0) {
       std::vector<double>& X = d_[0]; std::vector<double>& uvd = d_[1];
@@ -574,9 +577,10 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
       for (int a = 0; a < obj_slots_; ++a) VDO_TRY(vdo_flow2_batch_set(lm_obj_, a, nullptr));
       obj = nullptr;
     }
-    tick(9);
+    tick(9); mark(kEvObjLmBuilt);
     // ---- object motions (K17) on the LM stream, RenewFrameInfo (static) meanwhile  Tracking.cc:932 || :2666-2805
     if (obj) VDO_TRY(vdo_flow2_batch_run(obj));
+    mark(kEvObjLmLaunched);
     // ---- RenewFrameInfo (static) meanwhile                                         Tracking.cc:2666-2805
     if (static_async) {
       const int rc = worker_->wait();
@@ -585,6 +589,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
     } else if (stage_static() != 0) return -1;
     if ((tail_on_orb || k10_via_orb) && worker_orb_->wait() != 0) return -1;
     if (k10_via_orb) fc.n_object_samples = n_tmp;
+    mark(kEvStaticJoined);
     t_prev = std::chrono::steady_clock::now();
     // the object stage (results of the LMs, RenewFrameInfo of the objects, dynamic tracklets) ends in FinishObjects():
     // right below, or - deferred mode - inside the next Step, after that frame's camera stage and ORB front-end
@@ -619,12 +624,14 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   if (cam_ahead_on_ && lm_cam_ && !cam_ahead_) {
     if (CameraStage() != 0) return -1;
     cam_ahead_ = true;
+    mark(kEvCamStageDone);
   }
   if (host_inputs_ && depth_inout_ && !depth_metric_ && pending_ && !p_.defer_objects) {      // (the object LMs of the frame are in flight: the copy engine is free)
     VDO_TRY(vdo_frame_images_download_depth(img_[cur_ ^ 1], depth_inout_));
     depth_on_host_ = true;
   }
-  if (pending_ && !p_.defer_objects) { if (FinishObjects(&fc) != 0) return -1; }
+  if (pending_ && !p_.defer_objects) { if (FinishObjects(&fc) != 0) return -1; mark(kEvObjDone); }
+  mark(kEvStepEnd);
   if (trace_slow) {
     const double tot = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_step0).count();
     if (tot > 2.5) {
@@ -677,6 +684,7 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
         fop[a] = fo[a].data(); iop[a] = io[a].data();
       }
       VDO_TRY(vdo_flow2_batch_fetch(obj, rs.data(), fop.data(), iop.data()));
+      mark(kEvObjLmFetched);
       static const bool trace_obj = std::getenv("VDO_PIPE_TRACE_OBJ") != nullptr;
       if (trace_obj) {
         std::fprintf(stderr, "[obj lm f=%d]", f_id_obj_);
@@ -724,7 +732,7 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
     for (auto* v : {&nobj.x, &nobj.y, &nobj.cx, &nobj.cy, &nobj.fx, &nobj.fy, &nobj.d}) v->resize(mo);
     nobj.sem.resize(mo); nobj.label.resize(mo); dyn_asso.resize(mo);
     nobj.xyz.resize(3 * (size_t)std::max(mo, 1));
-    tick(7);
+    tick(7); mark(kEvObjRenewed);
     last_sem_pos_.assign(osem.begin(), osem.begin() + n_objects);
     last_mod_label_.assign(omod.begin(), omod.begin() + n_objects);
     last_obj_stat_.assign(stat.begin(), stat.begin() + n_objects);
@@ -850,6 +858,11 @@ void host_pipeline_destroy(FramePipeline* fp) { delete fp; }
 // [9] object RANSAC initialisers ([0] includes the camera one)
 // [10] K15 + K11 (objects)
 void host_pipeline_timing(FramePipeline* fp, double* ms11) { for (int i = 0; i < 11; ++i) ms11[i] = fp->ms_[i]; }
+// VDO_PIPE_EVENTS=1: mean time after the start of its Step at which each milestone (FramePipeline::kEv*) was reached, -1 = never; reset != 0 clears
+int host_pipeline_events(FramePipeline* fp, double* ms, int reset) {
+  for (int i = 0; i < FramePipeline::kEvCount; ++i) { ms[i] = fp->ev_n_[i] ? fp->ev_ms_[i] / fp->ev_n_[i] : -1.0; if (reset) { fp->ev_ms_[i] = 0; fp->ev_n_[i] = 0; } }
+  return FramePipeline::kEvCount;
+}
 int host_pipeline_flush(FramePipeline* fp, FrameCounts* out) { return fp->Flush(out); }
 // The tracklets as Track() keeps them (GetStaticTrack / GetDynamicTrackNew, src/Tracking.cc:2201-2421), which = 0 static, 1 dynamic:
 // with off == NULL returns the sizes (n_tracks, n_pairs); else fills off [n_tracks + 1], frame / feat [n_pairs], obj [n_tracks] (dynamic only).

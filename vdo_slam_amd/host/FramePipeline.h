@@ -107,6 +107,14 @@ class FramePipeline {
   std::vector<ObjectMotion> motions_;   // objects tracked in the last Step (build_lm mode)
   float Tcw_out_[16] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1};
   double ms_[12] = {0};              // accumulated wall time per section (see host_pipeline_timing)
+  // VDO_PIPE_EVENTS=1 (debug / bench): when, relative to the start of its Step, each milestone of a frame was reached - summed over the
+  // Steps since the last reset (host_pipeline_events).  Slots: kEv* below.
+  enum { kEvInputs = 0, kEvCamFetched, kEvObjChain, kEvDynObj, kEvObjLmBuilt, kEvObjLmLaunched, kEvOrbDevice, kEvOrbDone, kEvFilters, kEvStaticDone,
+         kEvStaticJoined, kEvCamStageDone, kEvObjLmFetched, kEvObjRenewed, kEvObjDone, kEvStepEnd, kEvCount };
+  double ev_ms_[kEvCount] = {0}; long ev_n_[kEvCount] = {0};
+  bool ev_on_ = false;
+  std::chrono::steady_clock::time_point ev_t0_;
+  void mark(int k) { if (ev_on_) { ev_ms_[k] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ev_t0_).count(); ++ev_n_[k]; } }
 
   // ---- the per-frame state the reference keeps in Tracking::mCurrentFrame / mLastFrame after Track() (RenewFrameInfo,
   // src/Tracking.cc:2780-2812, 2984-2991; per-object vectors :836-933), as views of the pipeline's own flat arrays.  Valid between

@@ -185,6 +185,16 @@ class FramePipeline:
         self._L.host_pipeline_timing(self._h, ms)
         return dict(zip(SECTIONS, ms))
 
+    EVENTS = ("inputs_k1_k11", "cam_fetched", "obj_chain_k15_k11_k13", "dynobj", "obj_lm_built", "obj_lm_launched", "orb_device", "orb_done", "k9_filters",
+              "static_done", "static_joined", "cam_stage_done", "obj_lm_fetched", "obj_renewed", "obj_done", "step_end")
+
+    def events_ms(self, reset=True):
+        """VDO_PIPE_EVENTS=1: mean time (ms after the start of its Step) at which each milestone of a frame was reached; -1 = never."""
+        ms = (C.c_double * 16)()
+        self._L.host_pipeline_events.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        self._L.host_pipeline_events(self._h, ms, int(reset))
+        return dict(zip(self.EVENTS, (round(v, 4) for v in ms)))
+
     def close(self):
         if self._h:
             self._L.host_pipeline_destroy(self._h); self._h = None
