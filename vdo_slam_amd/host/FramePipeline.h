@@ -13,6 +13,7 @@
 // (the ORB keypoints are first needed by RenewFrameInfo at the end of the frame, src/Tracking.cc:1168; nothing of the next
 // frame's camera stage needs this frame's object results).
 #pragma once
+#include <chrono>
 #include <cstdint>
 #include <functional>
 #include <memory>
