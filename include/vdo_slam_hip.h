@@ -356,6 +356,10 @@ int vdo_frame_images_upload(vdo_frame_images* f, const float* depth, const float
 int vdo_frame_images_upload_on(vdo_ctx* ctx, vdo_frame_images* f, const float* depth, const float* flow, const int32_t* mask);
 int vdo_frame_images_upload_device(vdo_frame_images* f, const float* depth_dev, const float* flow_dev, const int32_t* mask_dev);
 int vdo_frame_images_depth_preprocess(vdo_frame_images* f, float bf, float depth_map_factor);   /* K1 in place, resident image */
+/* vdo_frame_images_upload_device + (convert_depth != 0) vdo_frame_images_depth_preprocess as ONE launch (GrabImageRGBD's head,
+ * src/Tracking.cc:180-204 + the cv::Mat headers it keeps): same bytes, same two divisions per depth pixel, a quarter of the stream operations. */
+int vdo_frame_images_ingest_device(vdo_frame_images* f, const float* depth_dev, const float* flow_dev, const int32_t* mask_dev, float bf, float depth_map_factor,
+                                   int convert_depth);
 int vdo_frame_images_destroy(vdo_frame_images* f);
 /* Later calls on these images run on `ctx` (its stream and scratch arena) instead of the context they were created with.
  * Every call on vdo_frame_images is host-synchronous, so the switch needs no device-side ordering; it exists so that a

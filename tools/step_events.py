@@ -20,7 +20,9 @@ frames = [SQ.render_frame(k, Ts, objs, flow_sigma=bench.FLOW_SIGMA, seed=0, inva
 dev = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames]
 torch.cuda.synchronize()
 os.environ.setdefault("VDO_ORB_THREADS", "5")
-for defer in (0, 1):
+import gc
+gc.collect(); gc.freeze(); gc.disable()
+for defer in (1, 0, 1, 0):
     ctxs = [Context(0) for _ in range(5)]
     pipe = FramePipeline(ctxs[0], ctxs[1], kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctxs[2], ctxs[3], ctxs[4])
     pipe.keep_graph()

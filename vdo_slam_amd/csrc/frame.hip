@@ -178,6 +178,8 @@ extern "C" int vdo_frame_images_create(vdo_ctx* ctx, int w, int h, vdo_frame_ima
   f->d_cnt = (int*)dev(16); f->d_blk = (int*)dev(4 * ((size_t)f->cap / 256 + 2));
   f->d_cand = (unsigned long long*)dev(8 * np);
   if (f->d_cand) hipMemsetAsync(f->d_cand, 0, 8 * np, ctx->stream);
+  f->d_ticket = (int*)dev(64);
+  if (f->d_ticket) hipMemsetAsync(f->d_ticket, 0, 64, ctx->stream);
   for (void* p : f->allocs) if (!p) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
   if (!f->d_blk || !f->h_pin || !f->h_pin2) { vdo_frame_images_destroy(f); return set_error(VDO_ERR_OOM, "hipMalloc failed"); }
   *out = f;
@@ -222,6 +224,52 @@ extern "C" int vdo_frame_images_upload_device(vdo_frame_images* f, const float* 
   if (depth) hipMemcpyAsync(f->d_depth, depth, 4 * np, hipMemcpyDeviceToDevice, s);
   if (flow) hipMemcpyAsync(f->d_flow, flow, 8 * np, hipMemcpyDeviceToDevice, s);
   if (mask) hipMemcpyAsync(f->d_mask, mask, 4 * np, hipMemcpyDeviceToDevice, s);
+  return VDO_OK;
+}
+
+// GrabImageRGBD's ingest of device-resident inputs as ONE launch: the caller's flow and mask copied into the resident image set and the
+// raw depth map converted on the way (K1: d < 0 -> 0, else bf / (d / factor) - the two correctly rounded divisions of k_depth_preprocess,
+// src/Tracking.cc:180-204), instead of three device-to-device copies and a kernel (four dependent operations at the head of every frame's
+// critical chain).  16 bytes per thread: one float4 of depth, two of flow, one int4 of mask.
+__global__ __launch_bounds__(256) void k_ingest(const float4* __restrict__ depth, const float4* __restrict__ flow, const int4* __restrict__ mask, int64_t n4, int64_t n,
+                                                float bf, float factor, int convert, float4* __restrict__ d_out, float4* __restrict__ f_out, int4* __restrict__ m_out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i < n4) {
+    float4 d = depth[i];
+    if (convert) {
+      d.x = d.x < 0 ? 0.f : bf / (d.x / factor); d.y = d.y < 0 ? 0.f : bf / (d.y / factor);
+      d.z = d.z < 0 ? 0.f : bf / (d.z / factor); d.w = d.w < 0 ? 0.f : bf / (d.w / factor);
+    }
+    d_out[i] = d;
+    f_out[2 * i] = flow[2 * i]; f_out[2 * i + 1] = flow[2 * i + 1];
+    m_out[i] = mask[i];
+  }
+  if (i == 0) {                                     // (a pixel count that is not a multiple of 4: the tail, element by element)
+    const float* ds = (const float*)depth; const float* fs = (const float*)flow; const int32_t* ms = (const int32_t*)mask;
+    float* dd = (float*)d_out; float* fd = (float*)f_out; int32_t* md = (int32_t*)m_out;
+    for (int64_t k = 4 * n4; k < n; ++k) {
+      const float v = ds[k];
+      dd[k] = convert ? (v < 0 ? 0.f : bf / (v / factor)) : v;
+      fd[2 * k] = fs[2 * k]; fd[2 * k + 1] = fs[2 * k + 1];
+      md[k] = ms[k];
+    }
+  }
+}
+
+extern "C" int vdo_frame_images_ingest_device(vdo_frame_images* f, const float* depth, const float* flow, const int32_t* mask, float bf, float depth_map_factor, int convert_depth) {
+  if (!f || !depth || !flow || !mask) return set_error(VDO_ERR_INVALID, "vdo_frame_images_ingest_device: null argument");
+  int rc = ctx_bind(f->ctx);
+  if (rc != VDO_OK) return rc;
+  const int64_t n = (int64_t)f->w * f->h;
+  if ((((uintptr_t)depth | (uintptr_t)flow | (uintptr_t)mask) & 15) != 0) {      // unaligned caller buffers: the plain copies + K1
+    rc = vdo_frame_images_upload_device(f, depth, flow, mask);
+    return rc != VDO_OK || !convert_depth ? rc : vdo_frame_images_depth_preprocess(f, bf, depth_map_factor);
+  }
+  const int64_t n4 = n / 4;
+  hipLaunchKernelGGL(k_ingest, dim3((unsigned)((std::max<int64_t>(n4, 1) + 255) / 256)), dim3(256), 0, f->ctx->stream, (const float4*)depth, (const float4*)flow, (const int4*)mask, n4, n,
+                     bf, depth_map_factor, convert_depth, (float4*)f->d_depth, (float4*)f->d_flow, (int4*)f->d_mask);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "vdo_frame_images_ingest_device: %s", hipGetErrorString(e));
   return VDO_OK;
 }
 

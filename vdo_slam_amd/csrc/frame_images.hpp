@@ -17,6 +17,7 @@ struct vdo_frame_images {
   float* d_f[8] = {nullptr}; int32_t* d_i[2] = {nullptr}; int* d_cnt = nullptr; int* d_blk = nullptr;
   int cap = 0;
   unsigned long long* d_cand = nullptr;   // [h][w] UpdateMask: labels whose warp lands on a pixel (bit = label slot); all zero between calls
+  int* d_ticket = nullptr;                // UpdateMask: arrival counter of k_votes_par, zero between launches
   float* h_pin = nullptr;          // pinned staging, 8 rows x cap + 16 (count lives at h_pin[8*cap])
   // second scratch set (rows 0-7 + count + pinned staging): K10 next to K9 in one synchronisation (vdo_frame_filters)
   float* d_rows2 = nullptr; int* d_cnt2 = nullptr; float* h_pin2 = nullptr;

@@ -138,7 +138,7 @@ __global__ void k_mask_warp_if(const int32_t* __restrict__ flag, const int32_t* 
 // warped into the current mask - visible to the votes of the labels after it.  Equivalent without the sequential image
 // passes:
 //   1. k_warp_candidates: ONE pass over the last frame: cand[q] gets bit s for every label slot s whose warp lands on q;
-//   2. k_votes_seq (one workgroup): label after label; the label seen under a sample q is the recovered label of the highest
+//   2. k_votes_par (one workgroup per label, the last one to finish re-votes sequentially what an earlier recovery can change): the label seen under a sample q is the recovered label of the highest
 //      earlier slot with its bit in cand[q] (a later warp overwrites an earlier one), else the untouched current mask;
 //   3. k_apply_warps: every pixel with candidate bits takes the highest recovered slot's label; cand is cleared on the way.
 // Up to 64 labels per frame (one bit each); more fall back to the label-after-label launches.
@@ -157,53 +157,81 @@ __global__ __launch_bounds__(256) void k_warp_candidates(const int32_t* __restri
   if (k + fx < w && k + fx > 0 && j + fy < h && j + fy > 0) atomicOr(&cand[(size_t)(j + fy) * w + (k + fx)], 1ull << slot);
 }
 
-// off[s] .. off[s+1]: samples (flowed positions) of label slot s.  flag[2s] = recovered, flag[2s+1] = a label fell outside the
-// histogram; rec_out = bit mask of the recovered slots.
-__global__ __launch_bounds__(256) void k_votes_seq(LabelSlots T, const int32_t* __restrict__ off, const float* __restrict__ cx, const float* __restrict__ cy,
-                                                   const int32_t* __restrict__ mask, const unsigned long long* __restrict__ cand, int w, int h,
-                                                   int32_t* __restrict__ flag, unsigned long long* __restrict__ rec_out) {
-  __shared__ int hist[kVoteBins];
-  __shared__ int s_valid, s_bad;
-  __shared__ int s_cnt[256], s_lab[256];
-  __shared__ unsigned long long s_rec;
-  if (threadIdx.x == 0) s_rec = 0ull;
-  for (int s = 0; s < T.n; ++s) {
-    for (int i = threadIdx.x; i < kVoteBins; i += 256) hist[i] = 0;
-    if (threadIdx.x == 0) { s_valid = 0; s_bad = 0; }
-    __syncthreads();
-    const unsigned long long rec = s_rec;
-    for (int i = off[s] + threadIdx.x; i < off[s + 1]; i += 256) {
-      const int u = (int)cx[i], v = (int)cy[i];
-      if (u < w && u > 0 && v < h && v > 0) {
-        const size_t q = (size_t)v * w + u;
-        const unsigned long long m = cand[q] & rec;
-        const int l = m ? T.lab[63 - __clzll((long long)m)] : mask[q];
-        if (l < 0 || l >= kVoteBins) atomicOr(&s_bad, 1);
-        else { atomicAdd(&hist[l], 1); atomicAdd(&s_valid, 1); }
-      }
+// The vote of ONE label slot s by one workgroup: the labels seen under its flowed samples - the recovered label of the highest slot in
+// `rec` whose warp lands on the pixel, else the untouched current mask -, their most frequent value (smallest on ties), and the verdict
+// "recovered" (>= 100 samples inside the image and the background wins).  Writes flag[2s] / flag[2s+1]; every thread returns the verdict.
+struct VoteLds { int hist[kVoteBins]; int valid, bad; int cnt[256], lab[256]; int verdict; };
+__device__ __forceinline__ int vote_label(VoteLds& L, const LabelSlots& T, int s, unsigned long long rec, const int32_t* __restrict__ off, const float* __restrict__ cx,
+                                          const float* __restrict__ cy, const int32_t* __restrict__ mask, const unsigned long long* __restrict__ cand, int w, int h,
+                                          int32_t* __restrict__ flag) {
+  for (int i = threadIdx.x; i < kVoteBins; i += 256) L.hist[i] = 0;
+  if (threadIdx.x == 0) { L.valid = 0; L.bad = 0; }
+  __syncthreads();
+  for (int i = off[s] + threadIdx.x; i < off[s + 1]; i += 256) {
+    const int u = (int)cx[i], v = (int)cy[i];
+    if (u < w && u > 0 && v < h && v > 0) {
+      const size_t q = (size_t)v * w + u;
+      const unsigned long long m = rec ? (cand[q] & rec) : 0ull;
+      const int l = m ? T.lab[63 - __clzll((long long)m)] : mask[q];
+      if (l < 0 || l >= kVoteBins) atomicOr(&L.bad, 1);
+      else { atomicAdd(&L.hist[l], 1); atomicAdd(&L.valid, 1); }
     }
-    __syncthreads();
-    {
-      int best = threadIdx.x * 4, cnt = hist[best];
-      for (int l = best + 1; l < threadIdx.x * 4 + 4; ++l) if (hist[l] > cnt) { cnt = hist[l]; best = l; }
-      s_cnt[threadIdx.x] = cnt; s_lab[threadIdx.x] = best;
-    }
-    __syncthreads();
-    for (int step = 128; step > 0; step >>= 1) {
-      if (threadIdx.x < step) {
-        const int c2 = s_cnt[threadIdx.x + step], l2 = s_lab[threadIdx.x + step];
-        if (c2 > s_cnt[threadIdx.x] || (c2 == s_cnt[threadIdx.x] && l2 < s_lab[threadIdx.x])) { s_cnt[threadIdx.x] = c2; s_lab[threadIdx.x] = l2; }
-      }
-      __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-      const int r = (s_valid >= 100 && s_lab[0] == 0 && !s_bad) ? 1 : 0;
-      flag[2 * s] = r; flag[2 * s + 1] = s_bad;
-      if (r) s_rec = rec | (1ull << s);
+  }
+  __syncthreads();
+  {
+    int best = threadIdx.x * 4, cnt = L.hist[best];
+    for (int l = best + 1; l < threadIdx.x * 4 + 4; ++l) if (L.hist[l] > cnt) { cnt = L.hist[l]; best = l; }
+    L.cnt[threadIdx.x] = cnt; L.lab[threadIdx.x] = best;
+  }
+  __syncthreads();
+  for (int step = 128; step > 0; step >>= 1) {
+    if (threadIdx.x < step) {
+      const int c2 = L.cnt[threadIdx.x + step], l2 = L.lab[threadIdx.x + step];
+      if (c2 > L.cnt[threadIdx.x] || (c2 == L.cnt[threadIdx.x] && l2 < L.lab[threadIdx.x])) { L.cnt[threadIdx.x] = c2; L.lab[threadIdx.x] = l2; }
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) *rec_out = s_rec;
+  if (threadIdx.x == 0) {
+    const int r = (L.valid >= 100 && L.lab[0] == 0 && !L.bad) ? 1 : 0;
+    flag[2 * s] = r; flag[2 * s + 1] = L.bad;
+    L.verdict = r;
+  }
+  __syncthreads();
+  return L.verdict;
+}
+
+// off[s] .. off[s+1]: samples (flowed positions) of label slot s.  flag[2s] = recovered, flag[2s+1] = a label fell outside the
+// histogram; rec_out = bit mask of the recovered slots.
+// One workgroup PER LABEL votes under the hypothesis that no earlier label was recovered (what it sees is then the untouched current mask:
+// true in almost every frame - a mask goes missing now and then).  The workgroup that finishes last (a ticket) looks at the verdicts: the
+// labels up to and including the FIRST recovered one voted under a true hypothesis; only the ones after it are voted again, label after
+// label, with the recovered set growing - the single-workgroup sequential walk this kernel used to be for every label (23-28 us per frame
+// on the object chain; ~5 us now).  ticket: one int, zero between launches (the last workgroup resets it).
+__global__ __launch_bounds__(256) void k_votes_par(LabelSlots T, const int32_t* __restrict__ off, const float* __restrict__ cx, const float* __restrict__ cy,
+                                                   const int32_t* __restrict__ mask, const unsigned long long* __restrict__ cand, int w, int h,
+                                                   int32_t* __restrict__ flag, unsigned long long* __restrict__ rec_out, int* __restrict__ ticket) {
+  __shared__ VoteLds L;
+  __shared__ int s_last, s_first;
+  vote_label(L, T, (int)blockIdx.x, 0ull, off, cx, cy, mask, cand, w, h, flag);
+  if (threadIdx.x == 0) {
+    __threadfence();                                           // the verdict is visible device-wide before the ticket is drawn
+    s_last = (atomicAdd(ticket, 1) == T.n - 1) ? 1 : 0;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  if (threadIdx.x == 0) {
+    __threadfence();
+    int first = -1;
+    for (int s = 0; s < T.n && first < 0; ++s) if (__hip_atomic_load(&flag[2 * s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) first = s;
+    s_first = first;
+    *ticket = 0;
+  }
+  __syncthreads();
+  const int first = s_first;
+  unsigned long long rec = first >= 0 ? (1ull << first) : 0ull;
+  for (int s = first + 1; first >= 0 && s < T.n; ++s)
+    if (vote_label(L, T, s, rec, off, cx, cy, mask, cand, w, h, flag)) rec |= 1ull << s;
+  if (threadIdx.x == 0) *rec_out = rec;
 }
 
 __global__ void k_apply_warps(unsigned long long* __restrict__ cand, const unsigned long long* __restrict__ rec, LabelSlots T, int64_t n, int32_t* __restrict__ mask_cur) {
@@ -221,12 +249,12 @@ __global__ void k_apply_warps(unsigned long long* __restrict__ cand, const unsig
 static void launch_update_mask(vdo_frame_images* cur, vdo_frame_images* last, const std::vector<int32_t>& uni, const std::vector<int>& off, const float* dx, const float* dy,
                                const int32_t* doff, int32_t* dflag, unsigned long long* drec, hipStream_t st) {
   const int L = (int)uni.size();
-  if (L <= 64 && cur->d_cand) {
+  if (L >= 1 && L <= 64 && cur->d_cand && cur->d_ticket) {
     LabelSlots T{};
     T.n = L;
     for (int s = 0; s < L; ++s) T.lab[s] = uni[s];
     hipLaunchKernelGGL(k_warp_candidates, dim3((cur->w + 255) / 256, cur->h), dim3(256), 0, st, (const int32_t*)last->d_mask, (const float*)last->d_flow, cur->w, cur->h, T, cur->d_cand);
-    hipLaunchKernelGGL(k_votes_seq, dim3(1), dim3(256), 0, st, T, doff, dx, dy, (const int32_t*)cur->d_mask, (const unsigned long long*)cur->d_cand, cur->w, cur->h, dflag, drec);
+    hipLaunchKernelGGL(k_votes_par, dim3(L), dim3(256), 0, st, T, doff, dx, dy, (const int32_t*)cur->d_mask, (const unsigned long long*)cur->d_cand, cur->w, cur->h, dflag, drec, cur->d_ticket);
     const int64_t np = (int64_t)cur->w * cur->h;
     hipLaunchKernelGGL(k_apply_warps, dim3((unsigned)((np + 255) / 256)), dim3(256), 0, st, cur->d_cand, (const unsigned long long*)drec, T, np, cur->d_mask);
     return;

@@ -297,16 +297,15 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   }
   if (late_upload) VDO_TRY(vdo_frame_images_upload(cur, d_depth_raw, nullptr, nullptr));
   else if (host_inputs_) VDO_TRY(vdo_frame_images_upload(cur, d_depth_raw, d_flow, d_mask));
-  else VDO_TRY(vdo_frame_images_upload_device(cur, d_depth_raw, d_flow, d_mask));
-  if (!depth_metric_) VDO_TRY(vdo_frame_images_depth_preprocess(cur, p_.bf, p_.depth_map_factor));
+  else VDO_TRY(vdo_frame_images_ingest_device(cur, d_depth_raw, d_flow, d_mask, p_.bf, p_.depth_map_factor, depth_metric_ ? 0 : 1));      // copies + K1, one launch
+  if (host_inputs_ && !depth_metric_) VDO_TRY(vdo_frame_images_depth_preprocess(cur, p_.bf, p_.depth_map_factor));
   const int n_s = have_last_ ? (int)sta_.cx.size() : 0;
   std::vector<float>& stat_depth = f_[0]; std::vector<float>& obj_depth = f_[1]; std::vector<int32_t>& obj_sem = i_[0];
   stat_depth.assign(n_s, -1.f);
-  if (have_last_) {
-    VDO_TRY(vdo_propagate_static(cur, n_s, sta_.cx.data(), sta_.cy.data(), stat_depth.data()));
-  } else {
-    VDO_TRY(vdo_ctx_synchronize(ctx_));
-  }
+  // K11 (static): the depth under the propagated static keys (mCurrentFrame.mvStatDepth, src/Tracking.cc:259-281).  Nothing of this frame's
+  // object chain reads it - RenewFrameInfo replaces it by the depth of the renewed set (:1040) - so it runs with the static stage (stage_static
+  // below, the helper thread's stream) instead of standing, with its round trip to the host, in front of UpdateMask on this thread.
+  if (!have_last_) VDO_TRY(vdo_ctx_synchronize(ctx_));
   tick(0); mark(kEvInputs);
   // ---- GetInitModelCam + PoseOptimizationFlow2Cam (K16): launched at the end of the LAST Step if the camera stage runs ahead (CameraStage)
   {
@@ -423,6 +422,7 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
   auto stage_static = [&]() -> int {
     auto tp = std::chrono::steady_clock::now();
     auto tk = [&](int slot) { const auto t = std::chrono::steady_clock::now(); ms_[slot] += std::chrono::duration<double, std::milli>(t - tp).count(); tp = t; };
+    VDO_TRY(vdo_propagate_static(cur, n_s, sta_.cx.data(), sta_.cy.data(), stat_depth.data()));      // K11 (static), see above
     if (frame_filters() != 0) return -1;
     tk(2); mark(kEvFilters);
     const int cs = p_.max_track_bg + 2;
