@@ -167,14 +167,33 @@ __device__ __forceinline__ int vote_label(VoteLds& L, const LabelSlots& T, int s
   for (int i = threadIdx.x; i < kVoteBins; i += 256) L.hist[i] = 0;
   if (threadIdx.x == 0) { L.valid = 0; L.bad = 0; }
   __syncthreads();
-  for (int i = off[s] + threadIdx.x; i < off[s + 1]; i += 256) {
-    const int u = (int)cx[i], v = (int)cy[i];
-    if (u < w && u > 0 && v < h && v > 0) {
-      const size_t q = (size_t)v * w + u;
-      const unsigned long long m = rec ? (cand[q] & rec) : 0ull;
-      const int l = m ? T.lab[63 - __clzll((long long)m)] : mask[q];
-      if (l < 0 || l >= kVoteBins) atomicOr(&L.bad, 1);
-      else { atomicAdd(&L.hist[l], 1); atomicAdd(&L.valid, 1); }
+  // (almost every sample of a label sees the same value: the lanes of a wave that agree send ONE LDS atomic with their count instead of
+  //  64 same-address ones; whole waves run the loop so that the ballots are complete)
+  const int lo = off[s], hi = off[s + 1];
+  for (int i0 = lo + (int)(threadIdx.x & ~63u); i0 < hi; i0 += 256) {
+    const int i = i0 + (int)(threadIdx.x & 63u);
+    int l = -1; bool inside = false;
+    if (i < hi) {
+      const int u = (int)cx[i], v = (int)cy[i];
+      if (u < w && u > 0 && v < h && v > 0) {
+        const size_t q = (size_t)v * w + u;
+        const unsigned long long m = rec ? (cand[q] & rec) : 0ull;
+        l = m ? T.lab[63 - __clzll((long long)m)] : mask[q];
+        inside = true;
+      }
+    }
+    const bool bad = inside && (l < 0 || l >= kVoteBins);
+    if (__ballot(bad) && (threadIdx.x & 63u) == 0) atomicOr(&L.bad, 1);
+    bool todo = inside && !bad;
+    const unsigned long long ok = __ballot(todo);
+    if (ok && (threadIdx.x & 63u) == 0) atomicAdd(&L.valid, (int)__popcll(ok));
+    for (unsigned long long act = ok; act;) {
+      const int leader = (int)__ffsll((long long)act) - 1;
+      const int l0 = __shfl(l, leader);
+      const unsigned long long same = __ballot(todo && l == l0);
+      if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&L.hist[l0], (int)__popcll(same));
+      if (l == l0) todo = false;
+      act &= ~same;
     }
   }
   __syncthreads();
@@ -219,13 +238,11 @@ __global__ __launch_bounds__(256) void k_votes_par(LabelSlots T, const int32_t* 
   }
   __syncthreads();
   if (!s_last) return;
-  if (threadIdx.x == 0) {
-    __threadfence();
-    int first = -1;
-    for (int s = 0; s < T.n && first < 0; ++s) if (__hip_atomic_load(&flag[2 * s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) first = s;
-    s_first = first;
-    *ticket = 0;
-  }
+  if (threadIdx.x == 0) { __threadfence(); s_first = 64; *ticket = 0; }
+  __syncthreads();
+  if ((int)threadIdx.x < T.n && __hip_atomic_load(&flag[2 * threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin(&s_first, (int)threadIdx.x);   // one round of loads
+  __syncthreads();
+  if (threadIdx.x == 0 && s_first == 64) s_first = -1;
   __syncthreads();
   const int first = s_first;
   unsigned long long rec = first >= 0 ? (1ull << first) : 0ull;
