@@ -59,7 +59,7 @@ def sequence_events(warmup, steps):
 def _pmc_traffic_bytes(graph):
     """HBM bytes per k_sweep_tile launch from the committed PMC summary, if it was taken on this very graph (else None)."""
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_sweep_pmc_hbm_traffic.txt")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_sweep_pmc_hbm_traffic.txt")
     try:
         txt = open(path).read()
         m = re.search(r"n_eb (\d+) n_et (\d+) n_point (\d+)", txt)
@@ -192,7 +192,7 @@ def main():
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the System::TrackRGBD (host buffers in) leg")
     ap.add_argument("--replicas-per-gpu", type=int, default=1, help="R independent sequences (FramePipelines) on every GPU; value = all of them")
     ap.add_argument("--replica-sweep", type=str, default="", help="e.g. 1,2,4,8: also report frames/s for these numbers of sequences per GPU")
-    ap.add_argument("--roofline-static", type=int, default=600000, help="static landmarks of the roofline graph")
+    ap.add_argument("--roofline-static", type=int, default=2200000, help="static landmarks of the roofline graph (default: 13.3 M edges, ~515 MB per sweep launch - twice the 256 MB Infinity Cache)")
     ap.add_argument("--cpu-worker", type=str, default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-budget", type=float, default=8.0, help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -590,6 +590,9 @@ def main():
                     "landmark block), so that rate is NOT a bandwidth.  `linearize_*`: sweep + expansion of the pose blocks + pose-pose edges + chi2 (one "
                     "BlockSolver::buildSystem).  What bounds the sweep is VALU issue and per-tile latency, not HBM (DESIGN.md 4.1).",
             "layout": dims,
+            "traffic_source": ("profiles/r04_sweep_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/sweep_only.py on this very graph "
+                               "(tools/profile_round4_sweep.sh); counters cannot be collected inside this run, the duration is live") if traffic is not None else None,
+            "graph_vs_infinity_cache": f"{model['sweep'] / 1e6:.0f} MB per sweep launch by the byte model vs 256 MB of Infinity Cache: the traffic is HBM traffic",
             "units_per_launch": {"EdgeSE3PointXYZ": int(gr.n_eb), "LandmarkMotionTernaryEdge": int(gr.n_et), "points": int(gr.n_point), "poses": int(gr.n_pose)}}
         bar.close()
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
