@@ -5,9 +5,12 @@
 //   K13 scene flow per object point                                    src/Tracking.cc:1278-1364
 //   K14 RenewFrameInfo, static part (carry inliers, top-up, depth)     src/Tracking.cc:2660-2790
 //   K15 UpdateMask: label gather + mask warp by the previous flow       src/Tracking.cc:3015-3065
-// cv::Mat products of small fp32 matrices (Rwl*x3Dc, -Rlw.t()*tlw, mRwc*x3D) go through
-// cv::gemm, which accumulates float inputs in double and rounds once (OpenCV 3.4
-// GEMMSingleMul<float,double>); restated that way — parity unpinned (OpenCV not available).
+// cv::Mat products of small fp32 matrices go through cv::gemm (OpenCV 3.4, modules/core/src/matmul.cpp), on one of two paths:
+//   * TRANSPOSED operand (-Rlw.t()*tlw): the generic GEMMSingleMul<float,double> - float inputs accumulated in double, k ascending, times
+//     alpha, one rounding to float;
+//   * no transposition and 2..4 wide (Rwl*x3Dc + twl, mRwc*x3D + mtwc): the small-matrix fast path at the head of cv::gemm, in FLOAT:
+//     t = a0*b0 + a1*b1 + a2*b2 left to right, d = (float)(t*alpha + c*beta) = t + c.
+// Restated that way - parity unpinned (OpenCV not available).
 #include <cmath>
 #include <cstdint>
 #include <vector>
@@ -15,9 +18,16 @@
 #include "vdo_oracle.h"
 
 namespace {
-// out = A(3x3 float) * v + t, products accumulated in double, rounded to float, then float add
+// generic path: A(3x3 float) * v accumulated in double, rounded to float once
 inline void gemm3(const float* A, const float* v, float* o) {
   for (int i = 0; i < 3; ++i) o[i] = (float)((double)A[3 * i] * v[0] + (double)A[3 * i + 1] * v[1] + (double)A[3 * i + 2] * v[2]);
+}
+// fast path (flags == 0, len == 3): o = A * v + c in float, left to right
+inline void gemm3_fast_add(const float* A, const float* v, const float* c, float* o) {
+  for (int i = 0; i < 3; ++i) {
+    const float t = A[3 * i] * v[0] + A[3 * i + 1] * v[1] + A[3 * i + 2] * v[2];
+    o[i] = (float)((double)t * 1.0 + (double)c[i] * 1.0);
+  }
 }
 }  // namespace
 
@@ -50,11 +60,10 @@ extern "C" void vdo_oracle_propagate_object(int n, const float* kx, const float*
 static void unproject_tcw(float u, float v, float z, const float* K4, const float* Tcw, float* out) {
   const float invfx = 1.0f / K4[0], invfy = 1.0f / K4[1], cx = K4[2], cy = K4[3];
   const float xc[3] = {(u - cx) * z * invfx, (v - cy) * z * invfy, z};
-  float Rwl[9], nRwl[9], tlw[3] = {Tcw[3], Tcw[7], Tcw[11]}, twl[3], r[3];
+  float Rwl[9], nRwl[9], tlw[3] = {Tcw[3], Tcw[7], Tcw[11]}, twl[3];
   for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) { Rwl[3 * i + j] = Tcw[4 * j + i]; nRwl[3 * i + j] = -Tcw[4 * j + i]; }
   gemm3(nRwl, tlw, twl);
-  gemm3(Rwl, xc, r);
-  for (int i = 0; i < 3; ++i) out[i] = r[i] + twl[i];
+  gemm3_fast_add(Rwl, xc, twl, out);
 }
 
 // K13: GetSceneFlowObj.  obj_label_inout[i] is set to -1 where either semantic label is <= 0.
@@ -78,9 +87,8 @@ extern "C" void vdo_oracle_get3d_world(int n, const float* kx, const float* ky, 
   for (int i = 0; i < n; ++i) {
     const float z = d[i];
     const float xc[3] = {(kx[i] - cx) * z * invfx, (ky[i] - cy) * z * invfy, z};
-    float r[3];
-    gemm3(R, xc, r);
-    for (int k = 0; k < 3; ++k) xyz[3 * i + k] = r[k] + Twc[4 * k + 3];
+    const float t[3] = {Twc[3], Twc[7], Twc[11]};
+    gemm3_fast_add(R, xc, t, xyz + 3 * i);
   }
 }
 

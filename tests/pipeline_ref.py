@@ -20,25 +20,32 @@ f32 = np.float32
 
 
 def inv_rigid_f32(Tm):
-    """Converter::toInvMatrix in float, operation order of FramePipeline.cc:inv_rigid."""
+    """Converter::toInvMatrix (src/Converter.cc:151-166) on a CV_32F matrix: R.t() is a copy; t_inv = -R.t() * t is a cv::gemm with a transposed
+    operand, i.e. OpenCV 3.4's generic GEMMSingleMul<float, double> - the dot product accumulated in double (k ascending), times alpha = -1, one
+    rounding to float.  (numpy float64 arithmetic here; products of two floats are exact in double.)"""
     Tm = np.asarray(Tm, f32)
     o = np.zeros((4, 4), f32)
     for i in range(3):
         for j in range(3):
             o[i, j] = Tm[j, i]
-        o[i, 3] = -f32(f32(f32(Tm[0, i] * Tm[0, 3]) + f32(Tm[1, i] * Tm[1, 3])) + f32(Tm[2, i] * Tm[2, 3]))
+        s = np.float64(0.0)
+        for k in range(3):
+            s = s + np.float64(Tm[k, i]) * np.float64(Tm[k, 3])
+        o[i, 3] = f32(s * -1.0)
     o[3, 3] = 1
     return o
 
 
 def matmul4_f32(A, B):
-    """4x4 float product with the sequential accumulation of the C++ loops (a = 0; a += A[i][k] * B[k][j])."""
+    """A * B for 4x4 CV_32F operands WITHOUT transposition: cv::gemm's fast path for 2..4-wide products (modules/core/src/matmul.cpp, OpenCV 3.4:
+    `flags == 0 && 2 <= len && len <= 4`) - every entry is a float expression a0*b0 + a1*b1 + a2*b2 + a3*b3 evaluated left to right in float
+    (then times alpha = 1.0 in double and back: exact).  Not the double-accumulating generic path that transposed products take (inv_rigid_f32)."""
     A = np.asarray(A, f32); B = np.asarray(B, f32)
     o = np.zeros((4, 4), f32)
     for i in range(4):
         for j in range(4):
-            a = f32(0)
-            for k in range(4):
+            a = f32(A[i, 0] * B[0, j])
+            for k in range(1, 4):
                 a = f32(a + f32(A[i, k] * B[k, j]))
             o[i, j] = a
     return o

@@ -128,9 +128,8 @@ def test_pose_optimization_flow2cam_class_matches_oracle(host, oracle):
     # the class receives the LAST frame pose T_lw (float) and derives Twl itself (Optimizer.cc:2414-2420)
     Twl = prob.Twl
     Tlw = np.linalg.inv(Twl).astype(np.float32)
-    inv = np.eye(4, dtype=np.float32)
-    inv[:3, :3] = Tlw[:3, :3].T
-    inv[:3, 3] = -(Tlw[:3, :3].T @ Tlw[:3, 3]).astype(np.float32)      # Converter::toInvMatrix in fp32
+    from tests.pipeline_ref import inv_rigid_f32
+    inv = inv_rigid_f32(Tlw)                               # Converter::toInvMatrix (cv::gemm with a transposed operand: double accumulation, one rounding)
     prob.Twl = inv.astype(np.float64)
     T, flow, inl, ninl, st = run_oracle(oracle, prob)
     n = prob.n
@@ -153,16 +152,19 @@ def test_non_joint_statics_of_the_optimizer_class_match_the_oracle(host, oracle)
     f32 = np.float32
     rng = np.random.default_rng(8)
 
-    def inv32(T):                                        # Converter::toInvMatrix in fp32
-        o = np.eye(4, dtype=f32)
-        o[:3, :3] = T[:3, :3].T
-        o[:3, 3] = -(T[:3, :3].T.astype(np.float64) @ T[:3, 3].astype(np.float64)).astype(f32)
-        return o
+    from tests.pipeline_ref import inv_rigid_f32 as inv32     # Converter::toInvMatrix
 
-    def unproject(xy, d, Tcw):                           # Frame::UnprojectStereo*: fp32 with cv::gemm's double accumulation
+    def unproject(xy, d, Tcw):                           # Frame::UnprojectStereo*: Rwl * x3Dc + twl (float fast path of cv::gemm), twl = -Rlw^T tlw (generic path)
         x3 = np.stack([(xy[:, 0] - f32(cx)) * d * (f32(1) / f32(fx)), (xy[:, 1] - f32(cy)) * d * (f32(1) / f32(fy)), d], 1).astype(f32)
-        R = Tcw[:3, :3].astype(np.float64); t = Tcw[:3, 3].astype(np.float64)
-        return (x3.astype(np.float64) @ R).astype(f32) + (-(t @ R).astype(f32))
+        twl = inv32(Tcw)[:3, 3]
+        Rwl = Tcw[:3, :3].T.astype(f32)
+        out = np.zeros((xy.shape[0], 3), f32)
+        for i in range(3):
+            t = f32(Rwl[i, 0]) * x3[:, 0]
+            t = (t + f32(Rwl[i, 1]) * x3[:, 1]).astype(f32)
+            t = (t + f32(Rwl[i, 2]) * x3[:, 2]).astype(f32)
+            out[:, i] = (t + twl[i]).astype(f32)
+        return out
 
     n = 700
     Tl = synth._mat4(synth.rotvec_to_R(rng.normal(0, 0.02, 3)), rng.normal(0, 1.0, 3)).astype(f32)
@@ -197,7 +199,8 @@ def test_non_joint_statics_of_the_optimizer_class_match_the_oracle(host, oracle)
     Hout = np.zeros((4, 4), f32); flag = np.zeros(n, np.int32); lab = np.zeros(n, np.int32)
     got = host.host_pose_optimization_objmot(n, _p(last_xy), _p(depth), _p(obj_xy), _p(Tl), _p(Tcur), _p(init_model), _p(Hout), R._ip(flag), R._ip(lab))
     KK = np.array([[f32(fx), 0, f32(cx), 0], [0, f32(fy), f32(cy), 0], [0, 0, 1, 0]], np.float64)
-    Init = (inv32(Tcur).astype(np.float64) @ init_model.astype(np.float64)).astype(f32)                 # cv::Mat product: fp32 result
+    from tests.pipeline_ref import matmul4_f32
+    Init = matmul4_f32(inv32(Tcur), init_model)                                                        # cv::Mat product (cv::gemm's float fast path)
     probo = PO.PoseProblem(kind=1, obs=obj_xy.astype(np.float64), Xw=Xw.astype(np.float64), K=tuple(float(f32(v)) for v in synth.KITTI_K),
                            P=KK @ Tcur.astype(np.float64), T0=Init.astype(np.float64), huber_delta=0.0, max_iterations=200)
     T, inl, ninl, st = run_oracle(oracle, probo)

@@ -1,6 +1,6 @@
 """GPU parity of the Tracking-side gathers (K11-K15, vdo_slam_amd/csrc/tracking.hip) through the
 C-ABI against oracle/tracking_oracle.cpp: bit-exact, including the fp32 back-projections
-(same cv::gemm double-accumulate rounding on both sides)."""
+(same cv::gemm rounding rules on both sides: float fast path for untransposed 3-wide products, double accumulation for transposed ones)."""
 import numpy as np
 import pytest
 

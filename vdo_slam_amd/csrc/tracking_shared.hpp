@@ -22,16 +22,18 @@ inline Cam make_cam_Tcw(const float* K4, const float* Tcw) {   // UnprojectStere
   return c;
 }
 
-// cv::gemm semantics for small float matrices: accumulate in double, round once
-__device__ __forceinline__ void gemm3_dev(const float* A, const float* v, float* o) {
-#pragma unroll
-  for (int i = 0; i < 3; ++i) o[i] = (float)((double)A[3 * i] * v[0] + (double)A[3 * i + 1] * v[1] + (double)A[3 * i + 2] * v[2]);
-}
+// `Rwl * x3Dc + twl` / `mRwc * x3D + mtwc` (src/Frame.cc:511,548, src/Optimizer.cc:2995): a cv::gemm of UNTRANSPOSED CV_32F operands, 3 wide. OpenCV 3.4
+// runs such products (flags == 0, 2 <= len <= 4) through the small-matrix fast path at the head of cv::gemm (modules/core/src/matmul.cpp), which
+// works in FLOAT: t = a0*b0 + a1*b1 + a2*b2 left to right, d = (float)(t * alpha + c * beta) with alpha = beta = 1.0 - a float addition.  (Round 1-3
+// accumulated these in double like the generic GEMMSingleMul<float, double> path; that path is what TRANSPOSED products take - twl = -Rlw.t() * tlw in
+// make_cam_Tcw above, Converter::toInvMatrix.  Parity unpinned either way: OpenCV is not in the image; tools/pin_reference settles it.)
 __device__ __forceinline__ void backproject(const Cam& c, float u, float v, float z, float* out) {
   const float xc[3] = {(u - c.cx) * z * c.invfx, (v - c.cy) * z * c.invfy, z};
-  float r[3];
-  gemm3_dev(c.R, xc, r);
-  out[0] = r[0] + c.t[0]; out[1] = r[1] + c.t[1]; out[2] = r[2] + c.t[2];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const float t = c.R[3 * i] * xc[0] + c.R[3 * i + 1] * xc[1] + c.R[3 * i + 2] * xc[2];      // (-ffp-contract=off: no fused multiply-add)
+    out[i] = t + c.t[i];
+  }
 }
 // K12 over a candidate list (one-pass RenewFrameInfo: the 3-D point of every candidate, the host keeps the selected ones);
 // as_int: the key is the truncated position (objects, Tracking.cc:2846-2851)

@@ -22,13 +22,15 @@ class Converter {
     for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) m.at<float>(i, j) = (float)R[3 * i + j]; m.at<float>(i, 3) = (float)t[i]; }
     return m;
   }
-  static cv::Mat toInvMatrix(const cv::Mat& T) {             // Converter::toInvMatrix (fp32 arithmetic, :151-166)
+  // Converter::toInvMatrix (:151-166).  t_inv = -R.t() * t: a cv::gemm with a transposed operand -> OpenCV 3.4's generic GEMMSingleMul<float, double>:
+  // the dot product accumulated in double (k ascending), times alpha = -1, one rounding to float
+  static cv::Mat toInvMatrix(const cv::Mat& T) {
     cv::Mat Ti = cv::Mat::eye(4, 4, cv::CV_32F);
     for (int i = 0; i < 3; ++i) {
       for (int j = 0; j < 3; ++j) Ti.at<float>(i, j) = T.at<float>(j, i);
-      float s = 0;
-      for (int k = 0; k < 3; ++k) s += -T.at<float>(k, i) * T.at<float>(k, 3);     // -R^T * t
-      Ti.at<float>(i, 3) = s;
+      double s = 0.0;
+      for (int k = 0; k < 3; ++k) s += (double)T.at<float>(k, i) * (double)T.at<float>(k, 3);
+      Ti.at<float>(i, 3) = (float)(s * -1.0);
     }
     return Ti;
   }

@@ -85,14 +85,18 @@ Frame::Frame(const cv::Mat& imGray, const cv::Mat& imDepth, const cv::Mat& imFlo
 }
 
 namespace {
-// Rwl * x3Dc + twl with Rwl = Rlw^T, twl = -Rlw^T tlw: cv::Mat products of CV_32F accumulate in double (cv::gemm) and round once
+// Rwl * x3Dc + twl with Rwl = Rlw^T (a copy), twl = -Rlw^T tlw (src/Frame.cc:506-511).  twl: cv::gemm with a transposed operand = the generic path,
+// accumulated in double, one rounding; Rwl * x3Dc + twl: untransposed and 3 wide = cv::gemm's small-matrix fast path, in float, left to right
+// (csrc/tracking_shared.hpp backproject: the same two rules on the device)
 cv::Mat unproject_world(float u, float v, float z, const cv::Mat& Tcw) {
   const float x3[3] = {(u - Frame::cx) * z * Frame::invfx, (v - Frame::cy) * z * Frame::invfy, z};
   cv::Mat o(3, 1, cv::CV_32F);
   for (int i = 0; i < 3; ++i) {
-    double r = 0, t = 0;
-    for (int k = 0; k < 3; ++k) { r += (double)Tcw.at<float>(k, i) * (double)x3[k]; t += (double)Tcw.at<float>(k, i) * (double)Tcw.at<float>(k, 3); }
-    o.at<float>(i) = (float)r + (-(float)t);
+    double t = 0;
+    for (int k = 0; k < 3; ++k) t += (double)(-Tcw.at<float>(k, i)) * (double)Tcw.at<float>(k, 3);
+    const float twl = (float)t;
+    const float r = Tcw.at<float>(0, i) * x3[0] + Tcw.at<float>(1, i) * x3[1] + Tcw.at<float>(2, i) * x3[2];
+    o.at<float>(i) = r + twl;
   }
   return o;
 }

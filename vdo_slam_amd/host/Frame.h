@@ -16,8 +16,8 @@ class Frame {
         const int& UseSampleFea);
   void ExtractORB(int flag, const cv::Mat& im);
   void SetPose(cv::Mat Tcw) { mTcw = Tcw.clone(); }
-  // Frame.cc:484-555: back-projection of a tracked feature into the world frame (Rwl * x3Dc + twl, fp32 with cv::gemm's
-  // double accumulation).  `addnoise`: the reference perturbs the depth with cv::RNG(time(NULL)) Gaussian noise on this path
+  // Frame.cc:484-555: back-projection of a tracked feature into the world frame (Rwl * x3Dc + twl in fp32 - cv::gemm's float fast path for the
+  // product, its double-accumulating generic path for twl = -Rlw^T tlw).  `addnoise`: the reference perturbs the depth with cv::RNG(time(NULL)) Gaussian noise on this path
   // (irreproducible by construction, and only reached with bJoint == false); the mirror uses the measured depth.
   cv::Mat UnprojectStereoStat(const int& i, const bool& addnoise);
   cv::Mat UnprojectStereoObject(const int& i, const bool& addnoise);

@@ -15,10 +15,16 @@
 namespace VDO_SLAM {
 
 namespace {
-void inv_rigid(const float* T, float* o) {                 // Converter::toInvMatrix
+// Converter::toInvMatrix (src/Converter.cc:151-166): t_inv = -R.t() * t is a cv::gemm with a TRANSPOSED operand (GEMM_1_T), which OpenCV 3.4 runs
+// through its generic GEMMSingleMul<float, double>: the dot product accumulated in double, k ascending, times alpha = -1, ONE rounding to float.
+// (The untransposed small products of this file - Tcw * H, R * x + t - take cv::gemm's 2..4-wide fast path instead, which works in float,
+// left to right: those loops are written in float on purpose.)
+void inv_rigid(const float* T, float* o) {
   for (int i = 0; i < 3; ++i) {
     for (int j = 0; j < 3; ++j) o[4 * i + j] = T[4 * j + i];
-    o[4 * i + 3] = -(T[0 * 4 + i] * T[3] + T[1 * 4 + i] * T[7] + T[2 * 4 + i] * T[11]);
+    double s = 0.0;
+    for (int k = 0; k < 3; ++k) s += (double)T[4 * k + i] * (double)T[4 * k + 3];
+    o[4 * i + 3] = (float)(s * -1.0);
   }
   o[12] = o[13] = o[14] = 0; o[15] = 1;
 }

@@ -65,7 +65,9 @@ class Mat {
   std::shared_ptr<std::vector<uint8_t>> buf_;
 };
 
-// float matrix product (3x3, 3x1, 4x4 ... as used by the reference on small cv::Mat)
+// float matrix product (3x3, 3x1, 4x4 ... as used by the reference on small cv::Mat): UNTRANSPOSED products 2..4 wide take cv::gemm's small-matrix
+// fast path (OpenCV 3.4 modules/core/src/matmul.cpp), which accumulates in float, k ascending - this loop.  (Products with a transposed operand
+// take the double-accumulating generic path: Converter::toInvMatrix spells that one out.)
 inline Mat operator*(const Mat& a, const Mat& b) {
   assert(a.cols == b.rows);
   Mat o = Mat::zeros(a.rows, b.cols, CV_32F);
