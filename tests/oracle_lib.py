@@ -127,3 +127,34 @@ def load_ref_orb():
     L.vdo_ref_orb_descriptor.argtypes = [u8p, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, u8p]
     _ref_orb = L
     return L
+
+
+REF_TRACK_LIB = os.path.join(ORACLE_DIR, "_ref", "libref_track.so")
+_ref_track = None
+
+
+def load_ref_track():
+    """oracle/_ref/libref_track.so = the REFERENCE's own src/System.cc + Tracking.cc + Frame.cc + Map.cc + ORBextractor.cc compiled verbatim against
+    the mini-cv shim (oracle/ref/), OpenCV primitives and the g2o behind the Optimizer statics supplied by the oracle.  (Re)built when the reference
+    checkout is present; on the GPU box only the prebuilt library travels.  None when neither exists."""
+    global _ref_track
+    if _ref_track is not None:
+        return _ref_track
+    load()
+    if os.path.exists(os.path.join(REFERENCE_ROOT, "src", "Tracking.cc")):
+        subprocess.run(["make", "-C", REF_DIR, "-s", f"REF={REFERENCE_ROOT}"], check=True)
+    if not os.path.exists(REF_TRACK_LIB):
+        return None
+    L = C.CDLL(REF_TRACK_LIB)
+    vp = C.c_void_p
+    L.vdo_ref_system_create.restype = vp
+    L.vdo_ref_system_create.argtypes = [C.c_char_p]
+    L.vdo_ref_system_destroy.argtypes = [vp]
+    L.vdo_ref_system_track.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp]
+    L.vdo_ref_system_counts.argtypes = [vp, vp]
+    L.vdo_ref_system_frame_state.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.vdo_ref_system_tracks.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    L.vdo_ref_system_timing.argtypes = [vp, vp]
+    L.vdo_ref_set_time.argtypes = [C.c_long]
+    _ref_track = L
+    return L

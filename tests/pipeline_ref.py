@@ -205,8 +205,9 @@ class OraclePipeline:
                 tm = np.full(ns, -1, np.int32)
                 good = cam_lm["sub"][cam_lm["inl"]]
                 tm[good] = good
-                cur_sx[good] = ls["key_x"][good] + cam_lm["flow"][cam_lm["inl"], 0].astype(f32)
-                cur_sy[good] = ls["key_y"][good] + cam_lm["flow"][cam_lm["inl"], 1].astype(f32)
+                # float key + DOUBLE refined flow, rounded once on the assignment (src/Optimizer.cc:2529-2530)
+                cur_sx[good] = (ls["key_x"][good].astype(np.float64) + cam_lm["flow"][cam_lm["inl"], 0]).astype(f32)
+                cur_sy[good] = (ls["key_y"][good].astype(np.float64) + cam_lm["flow"][cam_lm["inl"], 1]).astype(f32)
             elif inl is None or inl.size == 0:
                 tm = np.arange(ns, dtype=np.int32)
             else:
@@ -253,7 +254,7 @@ class OraclePipeline:
                 il = inl_lm.astype(bool)
                 olab[sub[~il]] = -1
                 good = sub[il]
-                cur_ox[good] = lo["key_x"][good] + fl_new[il, 0].astype(f32); cur_oy[good] = lo["key_y"][good] + fl_new[il, 1].astype(f32)
+                cur_ox[good] = (lo["key_x"][good].astype(np.float64) + fl_new[il, 0]).astype(f32); cur_oy[good] = (lo["key_y"][good].astype(np.float64) + fl_new[il, 1]).astype(f32)   # float + double, one rounding (Optimizer.cc:2949-2950)
                 inl_sets[a] = good
                 H_all[a] = matmul4_f32(Twc_c, Tn.astype(f32))
                 self.motions.append(dict(mod_label=int(dyn["mod"][a]), sem_label=int(dyn["sem"][a]), n_inliers=int(ninl), H=H_all[a]))

@@ -1,0 +1,85 @@
+"""Driver of oracle/_ref/libref_track.so - the reference's own System / Tracking / Frame / Map / ORBextractor sources compiled verbatim (oracle/ref/) -
+for the tests: one System::TrackRGBD call per frame and flat views of what Track() leaves behind.  TEST INFRASTRUCTURE."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from tests import oracle_lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+class Quiet:
+    """The reference prints a few hundred lines per frame to stdout: sent to /dev/null for the duration of a call."""
+    def __enter__(self):
+        import sys
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        self._null = os.open(os.devnull, os.O_WRONLY)
+        os.dup2(self._null, 1)
+        return self
+
+    def __exit__(self, *a):
+        os.dup2(self._saved, 1)
+        os.close(self._null); os.close(self._saved)
+
+
+class RefSystem:
+    COUNTS = ("n_keys", "n_static", "n_object", "n_objects", "n_cam_subset", "cam_lm_iterations", "f_id", "max_id", "n_samples", "full_batch_calls", "partial_batch_calls",
+              "n_static_tracks", "n_dynamic_tracks")
+
+    def __init__(self, settings_path):
+        self.L = oracle_lib.load_ref_track()
+        if self.L is None:
+            raise RuntimeError("oracle/_ref/libref_track.so is absent")
+        with Quiet():
+            self.h = self.L.vdo_ref_system_create(str(settings_path).encode())
+
+    def track(self, fr, k, n_images, labels=(1, 2, 3, 4, 5, 6, 7, 8), timestamp=0.0, fake_time=None, Tcw_gt=None):
+        """fr: dict(gray u8 [h, w] or [h, w, c], depth_raw f32, flow f32 [h, w, 2], mask i32).  Returns (Tcw 4x4 f32, converted depth, mask as the call left it)."""
+        gray = np.ascontiguousarray(fr["gray"])
+        ch = 1 if gray.ndim == 2 else gray.shape[2]
+        depth = np.ascontiguousarray(fr["depth_raw"], np.float32).copy(); mask = np.ascontiguousarray(fr["mask"], np.int32).copy()
+        flow = np.ascontiguousarray(fr["flow"], np.float32)
+        h, w = mask.shape
+        rows = np.array([[k, lab, 0, 0, 0, 0, 0, 0, 0, 0] for lab in labels], np.float32).reshape(-1, 10)
+        T = np.zeros(16, np.float32)
+        gt = np.eye(4, dtype=np.float32) if Tcw_gt is None else np.ascontiguousarray(Tcw_gt, np.float32)
+        self.L.vdo_ref_set_time(-1 if fake_time is None else int(fake_time))
+        with Quiet():
+            rc = self.L.vdo_ref_system_track(self.h, _p(gray), ch, _p(depth), _p(flow), _p(mask), w, h, _p(gt), _p(rows) if len(rows) else None, len(rows), 10, float(timestamp), int(n_images), _p(T))
+        if rc != 0:
+            raise RuntimeError("System::TrackRGBD returned an empty pose")
+        return T.reshape(4, 4), depth, mask
+
+    def counts(self):
+        c = np.zeros(13, np.int32)
+        self.L.vdo_ref_system_counts(self.h, _p(c))
+        return dict(zip(self.COUNTS, (int(v) for v in c)))
+
+    def state(self, what, rows):
+        n = self.L.vdo_ref_system_frame_state(self.h, what, None, 0)
+        assert n >= 0
+        buf = np.zeros(max(rows * n, 1), np.float32)
+        assert self.L.vdo_ref_system_frame_state(self.h, what, _p(buf), buf.size) == n
+        return n, buf[:rows * n]
+
+    def tracks(self, dynamic=False):
+        sz = np.zeros(2, np.int64)
+        self.L.vdo_ref_system_tracks(self.h, int(dynamic), _p(sz), None, None, None, None)
+        nt, npairs = int(sz[0]), int(sz[1])
+        off = np.zeros(nt + 1, np.int32); fr = np.zeros(max(npairs, 1), np.int32); ft = np.zeros(max(npairs, 1), np.int32); ob = np.zeros(max(nt, 1), np.int32)
+        self.L.vdo_ref_system_tracks(self.h, int(dynamic), _p(sz), _p(off), _p(fr), _p(ft), _p(ob))
+        return off, fr[:npairs], ft[:npairs], (ob[:nt] if dynamic else None)
+
+    def timing_ms(self):
+        t = np.zeros(5, np.float32)
+        self.L.vdo_ref_system_timing(self.h, _p(t))
+        return dict(zip(("mask_update", "camera_estimate", "object_tracking", "object_estimate", "map_update"), (float(v) for v in t)))
+
+    def close(self):
+        if self.h:
+            self.L.vdo_ref_system_destroy(self.h); self.h = None

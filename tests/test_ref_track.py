@@ -1,0 +1,126 @@
+"""oracle/_ref pin of the per-frame front end (SURVEY.md §8 rows a7-a14, f2 and the control flow of Track()): the oracle-composed Track()
+(tests/pipeline_ref.py - what every GPU sequence test compares the product with) against the REFERENCE'S OWN src/System.cc, Tracking.cc, Frame.cc,
+Map.cc and ORBextractor.cc, compiled verbatim from /root/reference by oracle/ref/Makefile against the mini-cv shim.
+
+Pinned by this: everything those sources do themselves - GrabImageRGBD (depth conversion, propagation of the last frame's correspondences),
+Frame::Frame (static filter, object sampling), Track()'s order and thresholds, GetInitModelCam / GetInitModelObj (motion models, inlier counts, the
+"RANSAC only with MORE inliers" rule), GetSceneFlowObj, DynObjTracking (border / scene-flow / depth / size rules, label association, the id counter),
+RenewFrameInfo (carry-over, stride-20 / stride-15 top-up, new labels), UpdateMask, GetStaticTrack / GetDynamicTrackNew, "Save Graph Structure".
+NOT pinned (the same code on both sides): the OpenCV primitives (FAST, resize, ... cv::gemm's rounding rules, solvePnPRansac) and the g2o behind the
+Optimizer statics - the oracle's restatements, forwarded by the shim / the glue in oracle/ref/ref_track_entry.cc."""
+import numpy as np
+import pytest
+
+from tests import oracle_lib
+from tests import tracking_ref as TR
+from tests.pipeline_ref import OraclePipeline
+from vdo_slam_amd import synth, synth_frames as SF, synth_seq as SQ
+from vdo_slam_amd.system import write_settings
+
+W, H = synth.KITTI_W, synth.KITTI_H
+OMD_W, OMD_H, OMD_K = 640, 480, (618.3587036132812, 618.5924072265625, 328.9866333007812, 237.7507629394531)
+
+
+@pytest.fixture(scope="module")
+def reflib():
+    if oracle_lib.load_ref_track() is None:
+        pytest.skip("parity unpinned: oracle/_ref/libref_track.so absent and no reference checkout to build it from")
+    return True
+
+
+def compare_frame(k, refsys, T_ref, ora, exp, sampled=False):
+    """everything Track() leaves in mCurrentFrame / the Tracking object, entry for entry (the layouts of host_system_frame_state)"""
+    c = refsys.counts()
+    L = ora.last
+    if not sampled:                                # (with UseSampleFeature the reference still extracts ORB - mvKeys - and then ignores it)
+        assert c["n_keys"] == exp["n_orb"], k
+    assert c["n_static"] == exp["n_static_tracked"] and c["n_object"] == exp["n_object_tracked"] and c["n_objects"] == exp["n_objects"], (k, c, exp)
+    if k > 0:
+        chosen = exp["n_ransac_cam"] if exp["n_ransac_cam"] > exp["n_motion_model_cam"] else exp["n_motion_model_cam"]      # TemperalMatch_subset (Tracking.cc:1690-1712)
+        assert c["n_cam_subset"] == chosen and c["cam_lm_iterations"] == exp["cam_lm_iterations"], (k, c, exp)
+        assert c["n_static_tracks"] == exp["n_static_tracks"] and c["n_dynamic_tracks"] == exp["n_dynamic_tracks"], (k, c, exp)
+        # (mvTmpObj* and max_id come to life in the first tracked frame: src/Tracking.cc:870-872, :1521)
+        assert c["n_samples"] == exp["n_object_samples"] and c["max_id"] == ora.max_id, (k, c, exp)
+    assert np.array_equal(T_ref, ora.Tl), (k, np.abs(T_ref - ora.Tl).max())
+    n, s = refsys.state(0, 10)
+    st = s.reshape(10, n)
+    for row, q in enumerate(("key_x", "key_y", "corr_x", "corr_y", "flow_x", "flow_y", "depth")):
+        assert np.array_equal(st[row], L["st"][q]), (k, "static", q)
+    assert np.array_equal(st[7:10].T, np.asarray(L["st"]["xyz"], np.float32).reshape(-1, 3)), (k, "static 3-D points")
+    n, s = refsys.state(1, 12)
+    ob = s.reshape(12, n)
+    for row, q in enumerate(("key_x", "key_y", "corr_x", "corr_y", "flow_x", "flow_y", "depth")):
+        assert np.array_equal(ob[row], L["ob"][q]), (k, "objects", q)
+    assert np.array_equal(ob[7:10].T, np.asarray(L["ob"]["xyz"], np.float32).reshape(-1, 3)), (k, "object 3-D points")
+    assert np.array_equal(ob[10].astype(np.int32), L["ob"]["label"]), (k, "vSemObjLabel")
+    if k > 0:
+        assert np.array_equal(ob[11].astype(np.int32), ora.result["objects"]["obj_label"]), (k, "vObjLabel")
+    n, s = refsys.state(2, 19)
+    po = s.reshape(n, 19)
+    assert n == len(L["sem_pos"])
+    assert np.array_equal(po[:, 0].astype(np.int32), L["sem_pos"]) and np.array_equal(po[:, 1].astype(np.int32), L["mod"]) and np.array_equal(po[:, 2].astype(np.uint8), L["stat"]), k
+    for a in range(n):
+        Hm = po[a, 3:].reshape(4, 4)
+        assert np.array_equal(Hm, np.asarray(L["H"][a], np.float32) if L["stat"][a] else np.eye(4, dtype=np.float32)), (k, "vObjMod", a)
+
+
+def compare_tracklets(oracle, refsys, ora):
+    ts = TR.build_tracks(oracle, ora.assos_s)
+    td = TR.build_tracks(oracle, ora.assos_d, ora.labs_d)
+    for got, exp, what in ((refsys.tracks(False), ts, "static"), (refsys.tracks(True), td, "dynamic")):
+        assert exp[0].size - 1 > 50, what
+        assert np.array_equal(got[0], exp[0]) and np.array_equal(got[1], exp[1]) and np.array_equal(got[2], exp[2]), what
+    assert np.array_equal(refsys.tracks(True)[3], td[3]), "nObjID"
+
+
+SEQUENCES = {
+    "exact": dict(n=6, objs=lambda: SQ.default_objects(), kw=dict()),
+    "noisy_dropped_mask": dict(n=8, objs=lambda: SQ.default_objects(), kw=dict(flow_sigma=0.1, drop_masks={3: {1}, 4: {1}})),
+    "five_boxes_events": dict(n=11, objs=lambda: SQ.survey_objects(leave_at=4, enter_at=6), kw=dict(flow_sigma=0.3, invalid_depth=0.02, zero_flow=0.01, drop_masks={8: {1}, 9: {1}})),
+}
+
+
+@pytest.mark.parametrize("name", sorted(SEQUENCES))
+def test_oracle_track_equals_the_reference_source(oracle, reflib, name, tmp_path):
+    from tests.ref_track import RefSystem
+    spec = SEQUENCES[name]
+    n = spec["n"]
+    cfg = write_settings(tmp_path / "kitti.yaml", W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, window=20, overlap=4)
+    Ts = SQ.camera_poses(n)
+    objs = spec["objs"]()
+    rs = RefSystem(cfg)
+    ora = OraclePipeline(oracle, build_lm=True)                  # the oracle's own RANSAC + EPnP on both sides (the shim forwards cv::solvePnPRansac to it)
+    recovered = 0
+    for k in range(n):
+        fr = SQ.render_frame(k, Ts, objs, **spec["kw"])
+        T, depth, mask = rs.track(fr, k, n_images=1 << 30)
+        exp = ora.step(fr)
+        compare_frame(k, rs, T, ora, exp)
+        assert np.array_equal(mask, ora.last["mask"]), (k, "the mask UpdateMask leaves behind")
+        recovered += exp["n_recovered_masks"]
+    compare_tracklets(oracle, rs, ora)
+    if "drop_masks" in spec["kw"]:
+        assert recovered >= 1
+    assert exp["n_objects"] >= 2
+    rs.close()
+
+
+def test_sampled_features_omd_settings(oracle, reflib, tmp_path):
+    """UseSampleFeature = 1 (example/omd.yaml): Frame::SampleKeyPoints instead of ORB, 640 x 480, SFMgThres 0.02.  The reference seeds cv::RNG with
+    time(NULL); the _ref build lets the test set that clock so that frame f draws with the seed the oracle uses (sample_seed + f)."""
+    from tests.ref_track import RefSystem
+    n = 5
+    cfg = write_settings(tmp_path / "omd.yaml", OMD_W, OMD_H, OMD_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, window=20, overlap=4, choose_data=1,
+                         use_sample_feature=1, sf_mg_thres=0.02, n_features=3000)
+    Ts = SQ.camera_poses(n, step=0.25)
+    objs = [dict(c=np.array([-1.2, 0.6, 6.0]), hw=0.7, hh=0.5, v=np.array([0.0, 0.0, 0.33])),
+            dict(c=np.array([1.5, 0.6, 8.0]), hw=0.8, hh=0.55, v=np.array([0.01, 0.0, 0.2]))]
+    rs = RefSystem(cfg)
+    ora = OraclePipeline(oracle, build_lm=True, K4=OMD_K, use_sample=True, sample_seed=11, sf_mg=0.02)
+    for k in range(n):
+        fr = SQ.render_frame(k, Ts, objs, w=OMD_W, h=OMD_H, K4=OMD_K, flow_sigma=0.05)
+        T, depth, mask = rs.track(fr, k, n_images=1 << 30, fake_time=11 + k)
+        exp = ora.step(fr)
+        compare_frame(k, rs, T, ora, exp, sampled=True)
+    assert exp["n_orb"] == 3000 and exp["n_objects"] >= 1
+    rs.close()

@@ -381,7 +381,8 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
         if (!inl_out_[j]) continue;
         const int i = cam_subset_[j];
         tm[i] = i;
-        cur_sx[i] = sta_.x[i] + (float)flow_out_[2 * j]; cur_sy[i] = sta_.y[i] + (float)flow_out_[2 * j + 1];
+        // (float key + DOUBLE refined flow, rounded once on the assignment: `pt.x = pLastFrame->mvStatKeys[..].pt.x + flow_new(0)`, src/Optimizer.cc:2529-2530)
+        cur_sx[i] = (float)((double)sta_.x[i] + flow_out_[2 * j]); cur_sy[i] = (float)((double)sta_.y[i] + flow_out_[2 * j + 1]);
       }
     } else {
       for (int i = 0; i < n_s; ++i) tm[i] = inl_out_[n_cam_pts > 0 ? i % n_cam_pts : 0] ? i : -1;
@@ -708,7 +709,7 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
           for (size_t j = 0; j < sub.size(); ++j) {
             if (!io[a][j]) { olab[sub[j]] = -1; continue; }                     // outliers of the object optimisation (Optimizer.cc:2960-2966)
             inl_idx_.push_back(sub[j]);
-            cur_ox[sub[j]] = obj_.x[sub[j]] + (float)fo[a][2 * j]; cur_oy[sub[j]] = obj_.y[sub[j]] + (float)fo[a][2 * j + 1];
+            cur_ox[sub[j]] = (float)((double)obj_.x[sub[j]] + fo[a][2 * j]); cur_oy[sub[j]] = (float)((double)obj_.y[sub[j]] + fo[a][2 * j + 1]);      // (float + double, one rounding: src/Optimizer.cc:2949-2950)
           }
           ObjectMotion om; om.mod_label = omod[a]; om.sem_label = osem[a]; om.n_inliers = rs[a].n_inliers;
           for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float acc = 0; for (int k = 0; k < 4; ++k) acc += Twc_c[4 * i + k] * (float)rs[a].T[4 * k + j]; om.H[4 * i + j] = acc; }

@@ -24,12 +24,12 @@ ThDepthBG: {thbg}
 ThDepthOBJ: {thobj}
 MaxTrackPointBG: 1200 # 1200 1500 2000
 MaxTrackPointOBJ: 800
-SFMgThres: 0.12 # 0.05
+SFMgThres: {sf_mg_thres} # 0.05
 SFDsThres: 0.3
 WINDOW_SIZE: {window}
 OVERLAP_SIZE: {overlap}
-UseSampleFeature: 0
-ORBextractor.nFeatures: 2500
+UseSampleFeature: {use_sample_feature}
+ORBextractor.nFeatures: {n_features}
 ORBextractor.scaleFactor: 1.2
 ORBextractor.nLevels: 8
 ORBextractor.iniThFAST: 20
@@ -37,11 +37,12 @@ ORBextractor.minThFAST: 7
 """
 
 
-def write_settings(path, w, h, K4, bf, dmf, thbg, thobj, window=20, overlap=4, choose_data=2):
+def write_settings(path, w, h, K4, bf, dmf, thbg, thobj, window=20, overlap=4, choose_data=2, use_sample_feature=0, sf_mg_thres=0.12, n_features=2500):
     """A settings file in the reference's flat YAML dialect (example/kitti-0000-0013.yaml)."""
     fx, fy, cx, cy = K4
     with open(path, "w") as f:
-        f.write(SETTINGS.format(fx=fx, fy=fy, cx=cx, cy=cy, w=w, h=h, bf=bf, dmf=dmf, thbg=thbg, thobj=thobj, window=window, overlap=overlap, choose_data=choose_data))
+        f.write(SETTINGS.format(fx=fx, fy=fy, cx=cx, cy=cy, w=w, h=h, bf=bf, dmf=dmf, thbg=thbg, thobj=thobj, window=window, overlap=overlap, choose_data=choose_data,
+                                use_sample_feature=use_sample_feature, sf_mg_thres=sf_mg_thres, n_features=n_features))
     return str(path)
 
 
