@@ -110,7 +110,39 @@ def cpu_baseline_frames(frames, budget_s=14.0):
         if time.perf_counter() - t0 > budget_s:
             break
     dt = time.perf_counter() - t0
-    return n / dt, n, {k2: v / n * 1e3 for k2, v in pipe.stage_s.items()}, pipe.Tl.astype(np.float64)
+    br = {k2: v / max(1, n - 1) * 1e3 for k2, v in pipe.bracket_s.items()}                    # (per tracked frame: frame 0 only initialises)
+    br["object_estimate"] = pipe.bracket_s["object_estimate"] / max(1, pipe.n_object_estimates) * 1e3     # mean per object, as the reference reports it (Tracking.cc:1003-1006)
+    return n / dt, n, {k2: v / n * 1e3 for k2, v in pipe.stage_s.items()}, pipe.Tl.astype(np.float64), br
+
+
+def cpu_reference_source_brackets(frames, W, H, n_max=12):
+    """all_timing of the reference's own src/Tracking.cc compiled verbatim (oracle/_ref/libref_track.so) over the first frames: the CPU-baseline side
+    of the five-bracket comparison.  Informational: {} when the library did not travel with the snapshot."""
+    try:
+        from tests import oracle_lib as _ol
+        if _ol.load_ref_track() is None:
+            return {}
+        import tempfile
+        from tests.ref_track import RefSystem
+        from vdo_slam_amd import synth, synth_frames as SF
+        from vdo_slam_amd.system import write_settings
+        with tempfile.TemporaryDirectory() as td:
+            rsys = RefSystem(write_settings(os.path.join(td, "k.yaml"), W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ))
+            acc = np.zeros(5); nfr = 0; t0r = time.perf_counter()
+            n_run = min(n_max, len(frames))
+            for kk in range(n_run):
+                rsys.track(frames[kk], kk, n_images=1 << 30)
+                if kk >= 1:
+                    tm = rsys.timing_ms(); acc += np.array([tm[q] for q in ("mask_update", "camera_estimate", "object_tracking", "object_estimate", "map_update")]); nfr += 1
+            dtr = time.perf_counter() - t0r
+            rsys.close()
+        return {"reference_source_build": [round(float(v) / max(nfr, 1), 4) for v in acc],
+                "reference_source_build_note": (
+                    f"all_timing of the reference's own src/Tracking.cc compiled verbatim against the mini-cv shim (oracle/ref/), {nfr} tracked frames, {n_run / dtr:.1f} frames/s as a whole: "
+                    "first-party code as the reference wrote it (one cv::Mat per 3-D point ...), but OpenCV's primitives are the oracle's scalar restatements and the shim's containers are "
+                    "unoptimised - NOT a baseline for speed; the oracle pipeline is the faster CPU path and stays `cpu_baseline`")}
+    except Exception as e:                                # noqa: BLE001 - informational leg
+        return {"reference_source_build_error": repr(e)[:200]}
 
 
 def cpu_worker(path, budget_s):
@@ -599,10 +631,23 @@ def main():
             cb_ms, cb_sweep, cb_its = cpu_baseline_batch(g)
             out["cpu_baseline_batch"] = {"ms_per_lm_iter": cb_ms, "sweep_ms": cb_sweep, "iterations": cb_its, "cores": 1, "kind": "port"}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # the CPU baseline is reported at N=1 only
-        cfps, cn, cstage, _ = cpu_baseline_frames(frames)
+        cfps, cn, cstage, _, cbr = cpu_baseline_frames(frames)
         out["cpu_baseline"] = {"value": cfps, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": f"the first {cn} frames of the same sequence through the same full Track() (oracle, 1 thread)",
                                "ms_per_stage": cstage}
+        # ---- the reference's own five clock() brackets (all_timing[0..4]: mask update, camera estimate, object tracking, object estimate per object,
+        # map update = RenewFrameInfo; src/Tracking.cc:230-243, 685-703, 1366-1603, 868-1010, 1016-1020), side by side, ms per frame
+        pf = out["config"]["host_ms_per_section"]; n_obj_mean = max(out["config"]["per_frame_mean"]["n_objects"], 1e-9)
+        out["reference_brackets_ms"] = {
+            "brackets": ["mask_update", "camera_estimate", "object_tracking", "object_estimate (mean per object)", "map_update"],
+            "cpu_oracle_1_thread": [round(cbr[q], 4) for q in ("mask_update", "camera_estimate", "object_tracking", "object_estimate", "map_update")],
+            "gpu_product_host_wall": [round(pf["k15_k11_objects"], 4), round(pf["k1_k11_ransac_cam"] + pf["wait_cam_lm"], 4), round(pf["k13_dynobj"], 4),
+                                      round((pf["ransac_obj"] + pf["wait_obj_lm"]) / n_obj_mean, 4), round(pf["renew_static"] + pf["renew_object"], 4)],
+            "note": "gpu_product_host_wall: wall time of the host sections that do the bracket's work in the throughput run (UpdateMask comes with K11 (objects) + K13 in one call; "
+                    "the camera bracket = ingest + GetInitModelCam + the wait for the camera LM launched a frame ahead; the object bracket = RANSAC / EPnP / problem set-up + "
+                    "the wait for the object LMs, divided by the mean number of objects); the brackets of the product OVERLAP (three host threads, five streams): they do not add up to the frame time"}
+        rsb = cpu_reference_source_brackets(frames, W, H)      # the reference's OWN Tracking.cc (oracle/_ref/libref_track.so, when it travelled with the snapshot)
+        out["reference_brackets_ms"].update(rsb)
         # the N-process throughput next to the 1-thread figure (N = min(8, CPUs of this job); the reference itself is single-threaded)
         try:
             nproc = int(max(1, min(8, _cpu_budget())))

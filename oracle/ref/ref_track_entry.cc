@@ -238,6 +238,9 @@ void* vdo_ref_system_create(const char* settings) {
   if (g_live_systems == 0) ref_arena::reset();
   ++g_live_systems;
   VDO_SLAM::g_full_batch_calls = VDO_SLAM::g_partial_batch_calls = 0;
+  // (the reference keeps the intrinsics in class statics set by the FIRST Frame of the process, src/Frame.cc:26-30,240-254: one calibration per
+  //  process; a test that builds a second System with other settings starts them over)
+  Frame::mbInitialComputations = true; Frame::nNextId = 0;
   return new System(settings, System::RGBD);
 }
 void vdo_ref_system_destroy(void* s) { (void)s; if (g_live_systems > 0) --g_live_systems; }      // (the reference never frees its Tracking / Map either)

@@ -80,6 +80,10 @@ class OraclePipeline:
         self.assos_s, self.assos_d, self.labs_d = [], [], []
         self.motions = []
         self.stage_s = {"depth": 0.0, "orb": 0.0, "frame": 0.0, "tracking_k11_k15": 0.0, "ransac_init": 0.0, "lm_cam": 0.0, "lm_obj": 0.0}
+        # the reference's own five clock() brackets (all_timing[0..4], src/Tracking.cc:230-243, 685-703, 1366-1603, 868-1010, 1016-1020): seconds, summed over the
+        # frames; object_estimate is the sum over the objects (the reference reports the mean per object), n_object_estimates their number
+        self.bracket_s = {"mask_update": 0.0, "camera_estimate": 0.0, "object_tracking": 0.0, "object_estimate": 0.0, "map_update": 0.0}
+        self.n_object_estimates = 0
         dp = K.c_double_p
         oracle.vdo_oracle_p3p_ransac.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_double, C.c_double, dp, K.c_uint8_p, K.c_int32_p, K.c_int32_p]
         oracle.vdo_oracle_pnp_ransac_refit.argtypes = [C.c_int, dp, dp, dp, C.c_int, C.c_double, C.c_double, C.c_int, dp, K.c_uint8_p, K.c_int32_p, K.c_int32_p]
@@ -140,12 +144,15 @@ class OraclePipeline:
         last = self.last
         rec = 0
         if last is not None:                                                            # K15, K11
+            tb = tick()
             mask, rec = T.update_mask(o, last["ob"]["label"], last["ob"]["corr_x"], last["ob"]["corr_y"], last["mask"], last["flow"], mask)
+            self.bracket_s["mask_update"] += tick() - tb
             T.propagate_static(o, last["st"]["corr_x"], last["st"]["corr_y"], d)
             od, osem = T.propagate_object(o, last["ob"]["corr_x"], last["ob"]["corr_y"], d, mask, SF.TH_DEPTH_OBJ)
         self.stage_s["tracking_k11_k15"] += tick() - t; t = tick()
         n_rc = n_mm = n_ro = n_cam_inl = cam_its = 0
         cam_lm = None
+        tb_cam = tick()
         if last is not None and last["st"]["corr_x"].size >= 4:                        # GetInitModelCam
             ls = last["st"]
             ns = ls["corr_x"].size
@@ -171,6 +178,8 @@ class OraclePipeline:
         elif last is not None and self.build_lm:
             cam_lm = dict(sub=np.zeros(0, np.int64), T=self.Tl.astype(np.float64), flow=np.zeros((0, 2)), inl=np.zeros(0, bool))
         self.stage_s["ransac_init"] += tick() - t; t = tick()
+        if last is not None:
+            self.bracket_s["camera_estimate"] += tick() - tb_cam
         if self.use_sample:
             h_, w_ = fr["mask"].shape
             sx = np.zeros(3000, f32); sy = np.zeros(3000, f32)
@@ -216,7 +225,9 @@ class OraclePipeline:
                                     np.full(od.size, -2, np.int32))
             h, w = fr["mask"].shape
             prm = DynObjParamsC(w, h, 25, 50, self.sf_mg, self.sf_ds, SF.TH_DEPTH_OBJ, self.f_id)
+            tb = tick()
             dyn = T.dyn_obj_tracking(o, prm, osem, olab, lo["corr_x"], lo["corr_y"], od, fl, lo["label"], last["sem_pos"], last["mod"], last["stat"], self.max_id)
+            self.bracket_s["object_tracking"] += tick() - tb
             self.max_id = dyn["max_id"]
             n_obj = len(dyn["objects"])
             counts["n_objects"] = n_obj
@@ -228,6 +239,7 @@ class OraclePipeline:
             Twc_c = inv_rigid_f32(Tc)
             n_mm_obj = n_mm_won = 0
             H_all = [np.eye(4, dtype=f32) for _ in range(n_obj)]                        # mCurrentFrame.vObjMod (identity where the object is not tracked)
+            tb_obj = tick()
             for a, ids in enumerate(dyn["objects"]):                                    # GetInitModelObj (+ object LM)
                 n_r, T_r, inl_r = self._ransac(lo["xyz"][ids], np.c_[lo["corr_x"][ids], lo["corr_y"][ids]])
                 n_ro += n_r
@@ -261,6 +273,8 @@ class OraclePipeline:
                 self.stage_s["lm_obj"] += tick() - t; t = tick()
             counts["n_mm_inliers_obj"], counts["n_motion_model_obj"] = n_mm_obj, n_mm_won
             self.stage_s["ransac_init"] += tick() - t; t = tick()
+            self.bracket_s["object_estimate"] += tick() - tb_obj; self.n_object_estimates += n_obj
+            tb = tick()
             # top-up source: all ORB keypoints, or - UseSampleFeature - the filtered samples mvStatKeysTmp (Tracking.cc:2718-2721)
             src_x, src_y = (kp["x"][st["keep_idx"]], kp["y"][st["keep_idx"]]) if self.use_sample else (kp["x"], kp["y"])
             rs = T.renew_static(o, tm, cur_sx, cur_sy, src_x, src_y, mask, d, fr["flow"], self.max_bg)
@@ -268,6 +282,7 @@ class OraclePipeline:
             tmp = dict(x=ob["key_x"], y=ob["key_y"], depth=ob["depth"], label=ob["label"], flow_x=ob["flow_x"], flow_y=ob["flow_y"], corr_x=ob["corr_x"], corr_y=ob["corr_y"])
             ro = T.renew_object(o, inl_sets, stat, dyn["sem"], dyn["mod"], cur_ox, cur_oy, olab, tmp, mask, d, fr["flow"], self.max_obj)
             xyz_o = T.get3d_world(o, ro["key_x"], ro["key_y"], ro["depth"], self.K4, Twc_c)
+            self.bracket_s["map_update"] += tick() - tb
             self.assos_s.append(rs["inlier_id"]); self.assos_d.append(ro["inlier_id"]); self.labs_d.append(ro["obj_label"])
             ts = T.build_tracks(o, self.assos_s); td = T.build_tracks(o, self.assos_d, self.labs_d)   # the reference rebuilds from frame 0
             counts["n_static_tracks"], counts["n_dynamic_tracks"] = ts[0].size - 1, td[0].size - 1

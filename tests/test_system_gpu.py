@@ -214,3 +214,60 @@ def test_tracking_frame_state_matches_the_oracle(host, oracle, tmp_path):
         np.testing.assert_allclose(sc[1:].reshape(4, 4), ref.Tl, rtol=0, atol=2e-6)
         assert np.array_equal(sc[1:], T)
     host.host_system_destroy(sys_)
+
+
+@pytest.mark.parametrize("noise", [0.0, 0.1])
+def test_system_trackrgbd_equals_the_reference_source(host, noise, tmp_path):
+    """The PRODUCT's System::TrackRGBD (HIP kernels under the reference's class signatures) against oracle/_ref/libref_track.so = the reference's OWN
+    System.cc / Tracking.cc / Frame.cc / Map.cc / ORBextractor.cc compiled verbatim (oracle/ref/, tests/test_ref_track.py): the pose TrackRGBD returns,
+    the renewed static and object sets with their 3-D points and labels, the per-object vectors, the recovered mask and the converted depth map, frame
+    by frame, bit for bit (object motions to 5e-6: the kernel's LM against the oracle's behind the reference's Optimizer statics)."""
+    from tests import oracle_lib
+    from tests.ref_track import RefSystem
+    if oracle_lib.load_ref_track() is None:
+        pytest.skip("parity unpinned: oracle/_ref/libref_track.so absent")
+    host.host_system_frame_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+    n_frames = 6
+    fx, fy, cx, cy = synth.KITTI_K
+    cfg = tmp_path / "kitti.yaml"
+    cfg.write_text(YAML.format(fx=fx, fy=fy, cx=cx, cy=cy, w=W, h=H, bf=SF.BF, dmf=SF.DEPTH_MAP_FACTOR, thbg=SF.TH_DEPTH_BG, thobj=SF.TH_DEPTH_OBJ))
+    Ts = SQ.camera_poses(n_frames)
+    objs = SQ.default_objects()
+    drop = {3: {1}, 4: {1}} if noise else {}
+    sys_ = host.host_system_create(str(cfg).encode())
+    assert sys_
+    rs = RefSystem(cfg)
+
+    def state(what, rows):
+        n = host.host_system_frame_state(sys_, what, None, 0)
+        assert n >= 0
+        buf = np.zeros(max(rows * n, 1), np.float32)
+        assert host.host_system_frame_state(sys_, what, _ptr(buf), buf.size) == n
+        return n, buf[:rows * n]
+
+    labels = (1, 2, 3, 4, 5, 6, 7, 8)
+    for k in range(n_frames):
+        fr = SQ.render_frame(k, Ts, objs, flow_sigma=noise, drop_masks=drop)
+        T_ref, depth_ref, mask_ref = rs.track(fr, k, n_images=1 << 30, labels=labels)
+        depth = fr["depth_raw"].copy(); mask = fr["mask"].copy()
+        rows = np.array([[k, lab, 0, 0, 0, 0, 0, 0, 0, 0] for lab in labels], np.float32)
+        T = np.zeros(16, np.float32)
+        assert host.host_system_track(sys_, _ptr(fr["gray"]), 1, _ptr(depth), _ptr(fr["flow"]), _ptr(mask), W, H, _ptr(rows), len(labels), 10, 1 << 30, _ptr(T)) == 0
+        assert np.array_equal(T.reshape(4, 4), T_ref), (k, np.abs(T.reshape(4, 4) - T_ref).max())
+        assert np.array_equal(depth, depth_ref), (k, "depth converted in place")
+        assert np.array_equal(mask, mask_ref), (k, "mask after UpdateMask")
+        for what, rows_ in ((0, 10), (1, 12), (3, 8)):
+            n, a = state(what, rows_)
+            nr, b = rs.state(what, rows_)
+            assert n == nr and (k == 0 and what == 3 or np.array_equal(a, b)), (k, what, n, nr)     # (mvTmpObj* is filled from the first tracked frame on)
+        n, a = state(2, 19)
+        nr, b = rs.state(2, 19)
+        assert n == nr
+        a, b = a.reshape(n, 19), b.reshape(n, 19)
+        assert np.array_equal(a[:, :3], b[:, :3]), (k, "nSemPosition / nModLabel / bObjStat")
+        np.testing.assert_allclose(a[:, 3:], b[:, 3:], rtol=0, atol=5e-6)
+        if k > 0:
+            _, sa = state(4, 17); _, sb = rs.state(4, 17)
+            assert sa[0] == sb[0], (k, "max_id")
+    rs.close()
+    host.host_system_destroy(sys_)
