@@ -16,7 +16,10 @@
 #include <sys/mman.h>
 namespace ref_arena {
 static char* base = nullptr; static size_t used = 0; static const size_t kSize = (size_t)8 << 30;
-inline void reset() { used = 0; }
+inline void reset() {      // start over with ZERO pages, like a fresh process (the reference reads a few never-initialised members)
+  if (base && used) madvise(base, (used + 4095) & ~(size_t)4095, MADV_DONTNEED);
+  used = 0;
+}
 inline void* take(size_t n) {
   if (!base) { base = (char*)mmap(nullptr, kSize, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0); if (base == (char*)MAP_FAILED) abort(); }
   n = (n + 15) & ~(size_t)15;

@@ -17,7 +17,10 @@
 #include <sys/mman.h>
 namespace ref_arena {
 static char* base = nullptr; static size_t used = 0; static const size_t kSize = (size_t)64 << 30;
-inline void reset() { used = 0; }
+inline void reset() {      // start over with ZERO pages, like a fresh process (the reference reads a few never-initialised members)
+  if (base && used) madvise(base, (used + 4095) & ~(size_t)4095, MADV_DONTNEED);
+  used = 0;
+}
 inline void* take(size_t n) {
   if (!base) { base = (char*)mmap(nullptr, kSize, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0); if (base == (char*)MAP_FAILED) abort(); }
   n = (n + 15) & ~(size_t)15;
@@ -232,6 +235,15 @@ extern "C" time_t time(time_t* t) {
 }
 extern "C" void vdo_ref_set_time(long t) { g_fake_time = t; }
 
+// The reference reads members it never initialises - e.g. Frame::N_s of the first frame sizes TemperalMatch (src/Tracking.cc:345; the RGB-D constructor
+// of Frame does not set it) - and works because a fresh process hands it zero pages.  The Frame temporaries live on the STACK: the part of the stack the
+// call is about to use is zeroed first, so that those reads see what they see in the reference's own process instead of the leftovers of an earlier call.
+static void __attribute__((noinline)) scrub_stack() {
+  volatile char buf[1 << 19];
+  std::memset((void*)buf, 0, sizeof buf);
+  __asm__ volatile("" ::: "memory");
+}
+
 extern "C" {
 // System::System(settings, RGBD) (src/System.cc:22-48)
 void* vdo_ref_system_create(const char* settings) {
@@ -255,6 +267,7 @@ int vdo_ref_system_track(void* sp, const unsigned char* im, int channels, float*
   if (Tcw_gt16) std::memcpy(gt.data, Tcw_gt16, 64);
   std::vector<std::vector<float> > rows(n_rows);
   for (int i = 0; i < n_rows; ++i) rows[i].assign(obj_rows + (size_t)i * row_len, obj_rows + (size_t)(i + 1) * row_len);
+  scrub_stack();
   cv::Mat T = s->TrackRGBD(I, D, Fl, M, gt, rows, timestamp, traj, n_images);
   if (T.empty()) return -1;
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Tcw_out[4 * i + j] = T.at<float>(i, j);
