@@ -257,9 +257,11 @@ def test_system_trackrgbd_equals_the_reference_source(host, noise, tmp_path):
         assert np.array_equal(depth, depth_ref), (k, "depth converted in place")
         assert np.array_equal(mask, mask_ref), (k, "mask after UpdateMask")
         for what, rows_ in ((0, 10), (1, 12), (3, 8)):
+            if k == 0 and what == 3:
+                continue                                   # (the reference fills mvTmpObj* from the first tracked frame on, src/Tracking.cc:870-872)
             n, a = state(what, rows_)
             nr, b = rs.state(what, rows_)
-            assert n == nr and (k == 0 and what == 3 or np.array_equal(a, b)), (k, what, n, nr)     # (mvTmpObj* is filled from the first tracked frame on)
+            assert n == nr and np.array_equal(a, b), (k, what, n, nr)
         n, a = state(2, 19)
         nr, b = rs.state(2, 19)
         assert n == nr
