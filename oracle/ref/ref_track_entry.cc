@@ -236,13 +236,28 @@ extern "C" time_t time(time_t* t) {
 extern "C" void vdo_ref_set_time(long t) { g_fake_time = t; }
 
 // The reference reads members it never initialises - e.g. Frame::N_s of the first frame sizes TemperalMatch (src/Tracking.cc:345; the RGB-D constructor
-// of Frame does not set it) - and works because a fresh process hands it zero pages.  The Frame temporaries live on the STACK: the part of the stack the
-// call is about to use is zeroed first, so that those reads see what they see in the reference's own process instead of the leftovers of an earlier call.
-static void __attribute__((noinline)) scrub_stack() {
-  volatile char buf[1 << 19];
-  std::memset((void*)buf, 0, sizeof buf);
-  __asm__ volatile("" ::: "memory");
+// of Frame does not set it) - and works because a fresh process hands it zero pages.  The Frame temporaries live on the STACK, whose contents depend on
+// whatever ran before (another test, a signal handler of the HIP runtime when the product shares the process): every call into the reference therefore
+// runs on a thread of its own with a freshly mapped, all-zero stack and every signal blocked - same inputs, same bytes, every time.
+#include <functional>
+#include <pthread.h>
+#include <signal.h>
+namespace {
+void* clean_stack_trampoline(void* p) { (*(std::function<void()>*)p)(); return nullptr; }
+void run_on_clean_stack(std::function<void()> fn) {
+  const size_t kStack = (size_t)256 << 20;
+  void* stk = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
+  if (stk == MAP_FAILED) { fn(); return; }
+  pthread_attr_t at; pthread_attr_init(&at); pthread_attr_setstack(&at, stk, kStack);
+  sigset_t all, old; sigfillset(&all); pthread_sigmask(SIG_BLOCK, &all, &old);      // (inherited by the new thread)
+  pthread_t th;
+  const int rc = pthread_create(&th, &at, clean_stack_trampoline, &fn);
+  pthread_sigmask(SIG_SETMASK, &old, nullptr);
+  if (rc == 0) pthread_join(th, nullptr); else fn();
+  pthread_attr_destroy(&at);
+  munmap(stk, kStack);
 }
+}  // namespace
 
 extern "C" {
 // System::System(settings, RGBD) (src/System.cc:22-48)
@@ -253,7 +268,9 @@ void* vdo_ref_system_create(const char* settings) {
   // (the reference keeps the intrinsics in class statics set by the FIRST Frame of the process, src/Frame.cc:26-30,240-254: one calibration per
   //  process; a test that builds a second System with other settings starts them over)
   Frame::mbInitialComputations = true; Frame::nNextId = 0;
-  return new System(settings, System::RGBD);
+  System* out = nullptr;
+  run_on_clean_stack([&] { out = new System(settings, System::RGBD); });
+  return out;
 }
 void vdo_ref_system_destroy(void* s) { (void)s; if (g_live_systems > 0) --g_live_systems; }      // (the reference never frees its Tracking / Map either)
 
@@ -267,8 +284,8 @@ int vdo_ref_system_track(void* sp, const unsigned char* im, int channels, float*
   if (Tcw_gt16) std::memcpy(gt.data, Tcw_gt16, 64);
   std::vector<std::vector<float> > rows(n_rows);
   for (int i = 0; i < n_rows; ++i) rows[i].assign(obj_rows + (size_t)i * row_len, obj_rows + (size_t)(i + 1) * row_len);
-  scrub_stack();
-  cv::Mat T = s->TrackRGBD(I, D, Fl, M, gt, rows, timestamp, traj, n_images);
+  cv::Mat T;
+  run_on_clean_stack([&] { T = s->TrackRGBD(I, D, Fl, M, gt, rows, timestamp, traj, n_images); });
   if (T.empty()) return -1;
   for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) Tcw_out[4 * i + j] = T.at<float>(i, j);
   return 0;
