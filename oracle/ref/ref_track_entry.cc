@@ -242,8 +242,33 @@ extern "C" void vdo_ref_set_time(long t) { g_fake_time = t; }
 #include <functional>
 #include <pthread.h>
 #include <signal.h>
+#include <execinfo.h>
+#include <unistd.h>
+#include <sys/syscall.h>
 namespace {
-void* clean_stack_trampoline(void* p) { (*(std::function<void()>*)p)(); return nullptr; }
+void segv_backtrace(int sig, siginfo_t* si, void*) {      // VDO_REF_BT=1 (debug): which thread crashed where
+  char msg[200];
+  const int m = std::snprintf(msg, sizeof msg, "ref_track: fatal signal %d at address %p in thread %ld (main pid %d), backtrace:\n", sig, si ? si->si_addr : nullptr, (long)syscall(186), (int)getpid());
+  if (write(2, msg, m) < 0) {}
+  void* bt[64];
+  const int n = backtrace(bt, 64);
+  backtrace_symbols_fd(bt, n, 2);
+  _exit(128 + sig);
+}
+void install_bt_handler() {
+  { void* warm[4]; backtrace(warm, 4); }              // (loads libgcc now, not inside the handler)
+  static char alt[1 << 16];
+  stack_t ss; ss.ss_sp = alt; ss.ss_size = sizeof alt; ss.ss_flags = 0; sigaltstack(&ss, nullptr);
+  struct sigaction sa; std::memset(&sa, 0, sizeof sa); sa.sa_sigaction = segv_backtrace; sa.sa_flags = SA_ONSTACK | SA_SIGINFO;
+  sigaction(SIGSEGV, &sa, nullptr); sigaction(SIGABRT, &sa, nullptr); sigaction(SIGBUS, &sa, nullptr);
+}
+void* clean_stack_trampoline(void* p) {
+  if (std::getenv("VDO_REF_BT")) {
+    install_bt_handler();
+    sigset_t un; sigemptyset(&un); sigaddset(&un, SIGSEGV); sigaddset(&un, SIGABRT); sigaddset(&un, SIGBUS); pthread_sigmask(SIG_UNBLOCK, &un, nullptr);
+  }
+  (*(std::function<void()>*)p)(); return nullptr;
+}
 void run_on_clean_stack(std::function<void()> fn) {
   const size_t kStack = (size_t)256 << 20;
   void* stk = mmap(nullptr, kStack, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0);
@@ -262,6 +287,7 @@ void run_on_clean_stack(std::function<void()> fn) {
 extern "C" {
 // System::System(settings, RGBD) (src/System.cc:22-48)
 void* vdo_ref_system_create(const char* settings) {
+  if (std::getenv("VDO_REF_BT")) install_bt_handler();
   if (g_live_systems == 0) ref_arena::reset();
   ++g_live_systems;
   VDO_SLAM::g_full_batch_calls = VDO_SLAM::g_partial_batch_calls = 0;

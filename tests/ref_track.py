@@ -88,3 +88,45 @@ class RefSystem:
     def close(self):
         if self.h:
             self.L.vdo_ref_system_destroy(self.h); self.h = None
+
+
+# ---- the same through a child process (GPU tests: the reference's single-threaded code with its never-initialised reads stays out of a process that
+# carries the HIP runtime and the product's helper threads) -----------------------------------------------------------------------------------
+def worker_main(settings, frames_npz, out_npz, n_images, labels):
+    z = np.load(frames_npz)
+    n = int(z["n"])
+    rs = RefSystem(settings)
+    out = {"n": n}
+    for k in range(n):
+        fr = {q: z[f"{q}_{k}"] for q in ("gray", "depth_raw", "flow", "mask")}
+        T, depth, mask = rs.track(fr, k, n_images=n_images, labels=labels)
+        out[f"T_{k}"] = T; out[f"depth_{k}"] = depth; out[f"mask_{k}"] = mask
+        for what, rows in ((0, 10), (1, 12), (2, 19), (3, 8), (4, 17)):
+            cnt, a = rs.state(what, rows)
+            out[f"s{what}_{k}"] = a.copy(); out[f"n{what}_{k}"] = cnt
+        c = rs.counts()
+        out[f"counts_{k}"] = np.array([c[q] for q in RefSystem.COUNTS], np.int32)
+    for which, name in ((0, "sta"), (1, "dyn")):
+        off, fr_, ft_, ob_ = rs.tracks(bool(which))
+        out[f"tr_{name}_off"] = off; out[f"tr_{name}_frame"] = fr_; out[f"tr_{name}_feat"] = ft_
+        if ob_ is not None:
+            out[f"tr_{name}_obj"] = ob_
+    rs.close()
+    np.savez(out_npz, **out)
+
+
+def run_sequence_in_subprocess(settings, frames, tmp_dir, n_images=1 << 30, labels=(1, 2, 3, 4, 5, 6, 7, 8)):
+    """frames: list of dict(gray, depth_raw, flow, mask).  Returns the npz the worker wrote (per frame: T_k, depth_k, mask_k, s{what}_k / n{what}_k in
+    the layouts of RefSystem.state, counts_k; tracklets at the end)."""
+    import subprocess
+    import sys
+    fin = os.path.join(str(tmp_dir), "ref_frames.npz"); fout = os.path.join(str(tmp_dir), "ref_out.npz")
+    d = {"n": len(frames)}
+    for k, fr in enumerate(frames):
+        for q in ("gray", "depth_raw", "flow", "mask"):
+            d[f"{q}_{k}"] = np.ascontiguousarray(fr[q])
+    np.savez(fin, **d)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = f"import sys; sys.path.insert(0, {root!r}); from tests.ref_track import worker_main; worker_main({str(settings)!r}, {fin!r}, {fout!r}, {int(n_images)}, {tuple(labels)!r})"
+    subprocess.run([sys.executable, "-c", code], check=True, stdout=subprocess.DEVNULL, cwd=root)
+    return np.load(fout)
