@@ -117,30 +117,34 @@ def cpu_baseline_frames(frames, budget_s=14.0):
 
 def cpu_reference_source_brackets(frames, W, H, n_max=12):
     """all_timing of the reference's own src/Tracking.cc compiled verbatim (oracle/_ref/libref_track.so) over the first frames: the CPU-baseline side
-    of the five-bracket comparison.  Informational: {} when the library did not travel with the snapshot."""
+    of the five-bracket comparison, in a CHILD process (the reference reads members it never initialises: it stays out of the process that carries the
+    HIP runtime).  Informational: {} when the library did not travel with the snapshot."""
     try:
+        import subprocess
+        import tempfile
         from tests import oracle_lib as _ol
         if _ol.load_ref_track() is None:
             return {}
-        import tempfile
-        from tests.ref_track import RefSystem
         from vdo_slam_amd import synth, synth_frames as SF
         from vdo_slam_amd.system import write_settings
+        root = os.path.dirname(os.path.abspath(__file__))
         with tempfile.TemporaryDirectory() as td:
-            rsys = RefSystem(write_settings(os.path.join(td, "k.yaml"), W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ))
-            acc = np.zeros(5); nfr = 0; t0r = time.perf_counter()
+            cfg = write_settings(os.path.join(td, "k.yaml"), W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ)
             n_run = min(n_max, len(frames))
+            d = {"n": n_run}
             for kk in range(n_run):
-                rsys.track(frames[kk], kk, n_images=1 << 30)
-                if kk >= 1:
-                    tm = rsys.timing_ms(); acc += np.array([tm[q] for q in ("mask_update", "camera_estimate", "object_tracking", "object_estimate", "map_update")]); nfr += 1
-            dtr = time.perf_counter() - t0r
-            rsys.close()
-        return {"reference_source_build": [round(float(v) / max(nfr, 1), 4) for v in acc],
+                for q in ("gray", "depth_raw", "flow", "mask"):
+                    d[f"{q}_{kk}"] = np.ascontiguousarray(frames[kk][q])
+            fin = os.path.join(td, "frames.npz")
+            np.savez(fin, **d)
+            code = f"import sys; sys.path.insert(0, {root!r}); from tests.ref_track import brackets_worker_main; brackets_worker_main({cfg!r}, {fin!r})"
+            r = subprocess.run([sys.executable, "-c", code], check=True, capture_output=True, text=True, cwd=root, timeout=120)
+        res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        return {"reference_source_build": [round(v, 4) for v in res["ms"]],
                 "reference_source_build_note": (
-                    f"all_timing of the reference's own src/Tracking.cc compiled verbatim against the mini-cv shim (oracle/ref/), {nfr} tracked frames, {n_run / dtr:.1f} frames/s as a whole: "
-                    "first-party code as the reference wrote it (one cv::Mat per 3-D point ...), but OpenCV's primitives are the oracle's scalar restatements and the shim's containers are "
-                    "unoptimised - NOT a baseline for speed; the oracle pipeline is the faster CPU path and stays `cpu_baseline`")}
+                    f"all_timing of the reference's own src/Tracking.cc compiled verbatim against the mini-cv shim (oracle/ref/), {res['tracked_frames']} tracked frames, "
+                    f"{res['frames_per_s']:.1f} frames/s as a whole: first-party code as the reference wrote it (one cv::Mat per 3-D point ...), but OpenCV's primitives are the oracle's scalar "
+                    "restatements and the shim's containers are unoptimised - NOT a baseline for speed; the oracle pipeline is the faster CPU path and stays `cpu_baseline`")}
     except Exception as e:                                # noqa: BLE001 - informational leg
         return {"reference_source_build_error": repr(e)[:200]}
 

@@ -130,3 +130,23 @@ def run_sequence_in_subprocess(settings, frames, tmp_dir, n_images=1 << 30, labe
     code = f"import sys; sys.path.insert(0, {root!r}); from tests.ref_track import worker_main; worker_main({str(settings)!r}, {fin!r}, {fout!r}, {int(n_images)}, {tuple(labels)!r})"
     subprocess.run([sys.executable, "-c", code], check=True, stdout=subprocess.DEVNULL, cwd=root)
     return np.load(fout)
+
+
+def brackets_worker_main(settings, frames_npz, n_images=1 << 30):
+    """child process of bench.py's five-bracket leg: the reference's own all_timing (src/Tracking.cc) over the stored frames, as one JSON line"""
+    import json
+    import time
+    z = np.load(frames_npz)
+    n = int(z["n"])
+    rs = RefSystem(settings)
+    acc = np.zeros(5); nfr = 0
+    t0 = time.perf_counter()
+    for k in range(n):
+        fr = {q: z[f"{q}_{k}"] for q in ("gray", "depth_raw", "flow", "mask")}
+        rs.track(fr, k, n_images=n_images)
+        if k >= 1:
+            tm = rs.timing_ms()
+            acc += np.array([tm[q] for q in ("mask_update", "camera_estimate", "object_tracking", "object_estimate", "map_update")]); nfr += 1
+    dt = time.perf_counter() - t0
+    rs.close()
+    print(json.dumps({"ms": [float(v) / max(nfr, 1) for v in acc], "tracked_frames": nfr, "frames_per_s": n / dt}))
