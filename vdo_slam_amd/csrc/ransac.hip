@@ -277,7 +277,8 @@ static int ransac_update_iters(double p, double ep, int model_points, int max_it
 using namespace vdo;
 
 namespace {
-struct PnpTrace {
+struct PnpTrace {            // (VDO_PNP_TRACE=1, debug; the pipelines of several sequences call in concurrently: updated under a mutex)
+  std::mutex mu;
   double t[5] = {0, 0, 0, 0, 0}; long n = 0; bool on = std::getenv("VDO_PNP_TRACE") != nullptr;
   ~PnpTrace() { if (on && n) std::fprintf(stderr, "[pnp trace] calls %ld: setup %.1f us, gpu %.1f us, replay %.1f us, refit %.1f us (per call)\n", n, t[0] / n, t[1] / n, t[2] / n, t[3] / n); }
 } g_pnp_trace;
@@ -429,6 +430,7 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   }
   if (g_pnp_trace.on && n_problems > 1) {
     const double tr4 = pnp_now_us();
+    std::lock_guard<std::mutex> lock(g_pnp_trace.mu);
     g_pnp_trace.t[0] += tr1 - tr0; g_pnp_trace.t[1] += tr2 - tr1; g_pnp_trace.t[2] += tr3 - tr2; g_pnp_trace.t[3] += tr4 - tr3; ++g_pnp_trace.n;
   }
   return VDO_OK;

@@ -140,17 +140,31 @@ class _Counter:
     error = None
 
 
+_probe_serial = [0]
+
+
 def _one_gpu_per_rank(ctx, group):
     """RCCL needs a device of its own per rank (ncclCommInitRank fails - or hangs - when two ranks of a communicator sit on the
-    same GPU).  Every rank contributes (host, device) and all take the same decision."""
+    same GPU).  Every rank contributes (host, device) and all take the same decision.  The exchange goes through the rendezvous
+    STORE of the process group (TCP key/value), not through a collective of the group itself: in the very situation this probe is
+    for - two ranks of an "nccl" group on one GPU - an all_gather over that group would be the first thing to fail.  Any error in the
+    exchange -> False on this rank (the host-callback transport works everywhere)."""
+    import os
     import socket
     import torch.distributed as dist
-    import os
     # (a launcher that narrows the visible devices per rank makes every rank's device "0": the masks are part of the identity)
-    mine = (socket.gethostname(), int(getattr(ctx, "device", 0)), os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", ""))
-    everyone = [None] * dist.get_world_size(group)
-    dist.all_gather_object(everyone, mine, group=group)
-    return len(set(everyone)) == len(everyone)
+    mine = repr((socket.gethostname(), int(getattr(ctx, "device", 0)), os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", "")))
+    try:
+        from torch.distributed import distributed_c10d as c10d
+        store = c10d._get_default_store()
+        ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+        _probe_serial[0] += 1                                    # (every rank constructs its sharded handles in the same order)
+        tag = f"vdo_one_gpu_per_rank/{_probe_serial[0]}/{','.join(map(str, ranks))}"
+        store.set(f"{tag}/{dist.get_rank()}", mine)
+        everyone = [store.get(f"{tag}/{r}").decode() for r in ranks]     # (get blocks until the key is there)
+        return len(set(everyone)) == len(everyone)
+    except Exception:                                            # noqa: BLE001 - no store / an old torch: fall back to the transport that cannot fail
+        return False
 
 
 class ShardedBatchBA:
