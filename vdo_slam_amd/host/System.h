@@ -1,7 +1,7 @@
 // System / Tracking — the reference's entry API (include/System.h:42-53, include/Tracking.h) as thin shells around
 // FramePipeline: settings file, colour conversion, the in-place depth conversion the caller sees, ground-truth rows as the
-// gate of the object tracker, Map bookkeeping and the batch optimisations.  Visualisation (imTraj), metric printing and
-// SaveResults' text formats are out of scope; the hot path is entirely behind FramePipeline.
+// gate of the object tracker, Map bookkeeping, the batch optimisations and SaveResults' five text files (src/System.cc:75-100).  Visualisation (imTraj)
+// and metric printing are out of scope; the hot path is entirely behind FramePipeline.
 #pragma once
 #include <map>
 #include <memory>
