@@ -44,9 +44,8 @@ struct BADev {
   double* pose[2] = {nullptr, nullptr};
   double* point[2] = {nullptr, nullptr};
   // tiles
-  Tile* tiles = nullptr;
+  Tile* tiles = nullptr;                 // [n_tiles] in LAUNCH order (capi_ba.hip): workgroup b works on tiles[b]
   int32_t* tile_pose = nullptr;          // [NPS] global pose id of each slot
-  int32_t* tile_order = nullptr;         // [n_tiles] launch order of the solver's tile kernels: tiles with the longest landmark chain first
   int32_t* chain_off = nullptr;          // [n_chains+1] point ranges (points of a chain are contiguous)
   int32_t* pt_prev_edge = nullptr;       // [L] ternary edge linking point l-1 -> l (or -1: chain head)
   // edges (tile-major)
@@ -107,7 +106,7 @@ struct BADev {
   double *xp = nullptr, *rp = nullptr, *zp = nullptr, *pp = nullptr, *qp = nullptr, *bs = nullptr, *qs = nullptr;  // [6P]
   double* pp2 = nullptr;                             // [6P] second search-direction buffer (the PCG iterations ping-pong between pp and pp2)
   double *part_pq = nullptr, *part_rz = nullptr;     // [(P+3)/4] p.q per workgroup of k_pcg_q; [n_pchains] r.z per chain of k_pcg_chain
-  uint16_t* thr_tab = nullptr;                       // [n_tiles][256]: thread t of the sweep takes (v & 3) EdgeSE3PointXYZ edges of ONE pose slot from T.eb_begin + (v >> 2)
+  uint32_t* thr_tab = nullptr;                       // [n_tiles][256], launch order like tiles: thread t of the sweep takes (v & 3) EdgeSE3PointXYZ edges of ONE pose slot from edge (v >> 2) (absolute)
   double* part_q = nullptr;                          // [NPS][8] pose-major rows (row slot_dst[s] of slot s), 6 used: Schur mat-vec partials
   double *part_m = nullptr, *part_m8 = nullptr;      // [NPS][16] + [NPS][8] pose-major rows: the 21 preconditioner partials of a slot (16 + 5)
   double* scal = nullptr;

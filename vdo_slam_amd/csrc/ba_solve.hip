@@ -223,7 +223,7 @@ __device__ __forceinline__ void bgbt(const double (&B1)[18], const double* G, co
 // Exact diagonal blocks of the Schur correction, per (tile,slot):  sum B G B^T  (21 upper entries)
 __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int ti = d.tile_order[blockIdx.x];
+  const int ti = blockIdx.x;
   const Tile T = d.tiles[ti];
   const int nslot = T.slot_end - T.slot_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
     // [Hll^-1]_ll = g I3, and its block B = -we [I ; 2[c]x] R^T gives  B G B^T = g we^2 [I ; 2[c]x] [I ; 2[c]x]^T  (R drops out): a function of
     // ten running sums  s, s c, s c c^T  (s = g we^2) - no 6x3 block, no 6x6 product.
     const unsigned tt = d.thr_tab[(int64_t)ti * VDO_TILE_THREADS + tid];
-    const int j0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
+    const int j0 = (int)(tt >> 2) - T.eb_begin, ecnt = (int)(tt & 3u);
     int slot = -1;
     double up[21];
 #pragma unroll
@@ -773,7 +773,7 @@ template <int MODE>
 __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const double* __restrict__ v, const double* __restrict__ v2) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   if (MODE == 0 && d.flags[1]) return;     // PCG already converged: the launches queued behind it are no-ops
-  const Tile T = d.tiles[d.tile_order[blockIdx.x]];        // tiles with the longest landmark chains first: their serial solves would be the tail of the launch
+  const Tile T = d.tiles[blockIdx.x];                      // (launch order: tiles with the longest landmark chains first - their serial solves would be the tail of the launch)
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, ninc = nb + 2 * nt;
   double* u = smem;                        // [3*TP]
@@ -798,15 +798,14 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
   // EdgeSE3PointXYZ incidences by the sweep's thread table: <= 3 consecutive ones of ONE pose slot per thread (key and we requested now, c
   // formed behind the staging barrier; the slot's inverse pose and its part of v are read once, the thread's B w add up in registers and go
   // through ONE segmented scan).  The incidences of the ternary edges (dynamic tiles only) follow in strided loops, one scan per round.
-  const int ti_ = d.tile_order[blockIdx.x];
-  const unsigned tt = d.thr_tab[(int64_t)ti_ * VDO_TILE_THREADS + tid];
-  const int j0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
+  const unsigned tt = d.thr_tab[(int64_t)blockIdx.x * VDO_TILE_THREADS + tid];
+  const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);    // absolute edge index; inc_key of an EdgeSE3PointXYZ incidence = eb_key of the edge
   int keyb[3];
   double web[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
     keyb[q] = -1; web[q] = 0.0;
-    if (q < ecnt) { keyb[q] = d.inc_key[T.inc_begin + j0 + q]; web[q] = d.Finc[T.eb_begin + j0 + q]; }
+    if (q < ecnt) { keyb[q] = d.eb_key[e0 + q]; web[q] = d.Finc[e0 + q]; }
   }
   __syncthreads();
   const int slotb = ecnt ? (keyb[0] >> 16) : -1;

@@ -34,26 +34,19 @@ namespace vdo {
 
 void launch_posepose(const BADev& d, int which, bool build, double* ep_chi, hipStream_t s);
 
-// LDS carve-up (doubles): pts[3*TP] | accpt[4][TP] | slotW[12*S] | accpose[ps_stride*S] | red[40]
+// -DSWEEP_PROF (tools/build_variant.sh, debug builds only): shader-clock cycles of every wave of k_sweep_tile<true> per phase
+#ifdef SWEEP_PROF
+__device__ unsigned long long g_sweep_prof[16];
+#define SW_TICK(slot) do { if ((threadIdx.x & 63) == 0) { const long long t_ = clock64(); sw_t[slot] = t_ - sw_prev; sw_prev = t_; } } while (0)
+#else
+#define SW_TICK(slot) do { } while (0)
+#endif
+
+// LDS carve-up (doubles): pts[3*TP] | accpt[4][TP] | slotW[12*S] | accpose[ps_stride*S] | red[40] | sdst[S] (int32: where the slots' rows go)
 // (ps_stride = 16: a slot carries binary OR ternary sums, both kinds share its 16 accumulators; 14 KB + 224 B per pose slot of the
 // largest tile: 4 workgroups per CU at 81 slots)
 __host__ __device__ inline size_t sweep_lds_doubles(int max_slots, bool build, int ps_stride) {
-  return 3 * VDO_TILE_PTS + (build ? 4 * VDO_TILE_PTS : 0) + 12 * (size_t)max_slots + (build ? (size_t)ps_stride * (size_t)max_slots : 0) + 40;
-}
-
-// workgroup sums of two doubles at once (one pass of barriers); results broadcast through lds[32], lds[33]
-__device__ __forceinline__ void block_sum2(double& a, double& b, double* lds) {
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
-  a = wave_sum(a); b = wave_sum(b);
-  if (lane == 0) { lds[wv] = a; lds[16 + wv] = b; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    double sa = 0, sb = 0;
-    for (int w = 0; w < nw; ++w) { sa += lds[w]; sb += lds[16 + w]; }
-    lds[32] = sa; lds[33] = sb;
-  }
-  __syncthreads();
-  a = lds[32]; b = lds[33];
+  return 3 * VDO_TILE_PTS + (build ? 4 * VDO_TILE_PTS : 0) + 12 * (size_t)max_slots + (build ? (size_t)ps_stride * (size_t)max_slots + ((size_t)max_slots + 1) / 2 : 0) + 40;
 }
 
 // Per-thread running sums of the TERNARY edges (the EdgeSE3PointXYZ edges of a thread share a slot by construction: acc_terms): a thread owns
@@ -100,10 +93,21 @@ __device__ __forceinline__ void acc_finish(double (&acc)[16], int cur, double* a
   { double g[4] = {acc[12], acc[13], acc[14], acc[15]}; seg_apply16<4>(g, sc, sf, dst + 12); }
 }
 
-template <bool BUILD>
+// COMPACT: the edge inputs are in the 16-byte form (eb_zf set, eb_w not: every graph the reference builds)
+template <bool BUILD, bool COMPACT>
 __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int which) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int ti = d.tile_order[blockIdx.x];                // tiles with dynamic tracks first (ternary edges: ~1.5x the work): not in the tail of the launch
+#ifdef SWEEP_PROF
+  long long sw_t[10], sw_prev = clock64();
+#endif
+  const int ti = blockIdx.x;                              // (descriptors are stored in launch order: tiles with dynamic tracks first - ternary edges, ~1.5x the work - not in the tail)
+  const int tid = threadIdx.x;
+  // ---- The head of a tile is a chain of dependent loads, each an HBM round trip of 2-3 k cycles (phase probe, DESIGN.md 4.1: head + staging +
+  // barrier were half of a tile's 21 k cycles).  Every request is therefore made as early as its address is known, in this order:
+  //   (1) the thread table entry (address = block id, thread id)           -> (4) this thread's edges
+  //   (2) the descriptor (scalar)  -> (3) slot pose ids, row ids, points   -> (5) the slots' poses -> inverse -> LDS
+  // so that the two chains run beside each other instead of one after the other.
+  const unsigned tt = d.thr_tab[(int64_t)ti * VDO_TILE_THREADS + tid];
   const Tile T = d.tiles[ti];
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
   double* pts = smem;
@@ -112,42 +116,75 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   double* accpose = slotW + 12 * d.max_slots;
   const int arow = d.ps_stride, tofs = d.ps_stride == 32 ? 16 : 0;      // row of a slot's accumulators; where its ternary sums start
   double* red = accpose + (BUILD ? arow * d.max_slots : 0);
+  int* sdst = reinterpret_cast<int*>(red + 40);
   const double* __restrict__ pose = d.pose[which];
   const double* __restrict__ point = d.point[which] + 3 * (int64_t)T.pt_begin;
-  const int tid = threadIdx.x;
   const int64_t Eb = d.Eb, Et = d.Et;
-  // ---- this thread's EdgeSE3PointXYZ inputs are requested first: their HBM latency runs under the staging.  <= 3 consecutive edges of ONE
-  // pose slot (thr_tab, built with the tiles): no slot bookkeeping per edge, the slot's inverse pose is read once, nothing is flushed to
-  // the slot accumulators before the thread is through
-  const unsigned tt = d.thr_tab[(int64_t)ti * VDO_TILE_THREADS + tid];
-  const int e0 = T.eb_begin + (int)(tt >> 2), ecnt = (int)(tt & 3u);
-  int ekey[3];
-  double ew[3];
-  D3 ez[3];
+  // (3) what needs the descriptor only.  Every load of the head is UNCONDITIONAL, from a clamped index: a load under a branch is waited for
+  // at the end of that branch (ISA of the round-3 form: the three edges of a thread were three round trips in a row).
+  const int my_slot = min(tid, max(nslot - 1, 0));        // (tile_pose / slot_dst carry one entry of padding)
+  const int my_pose = d.tile_pose[T.slot_begin + my_slot];
+  int my_dst = 0;
+  if (BUILD) my_dst = d.slot_dst[T.slot_begin + my_slot];
+  double pv[3];                                           // the tile's points: <= 768 doubles, three per thread
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int e = e0 + j;
-    ekey[j] = -1; ew[j] = 0.0; ez[j] = D3{0.0, 0.0, 0.0};
-    if (j < ecnt) {
+  for (int k = 0; k < 3; ++k) pv[k] = point[min(tid + k * VDO_TILE_THREADS, 3 * npts - 1)];
+  __builtin_amdgcn_sched_barrier(0);                      // (the requests above are made BEFORE the wait for the table entry that the ones below need)
+  // (4) this thread's EdgeSE3PointXYZ inputs: <= 3 consecutive edges of ONE pose slot (thr_tab, built with the tiles; absolute edge index): no
+  // slot bookkeeping per edge, the slot's inverse pose is read once, nothing is flushed to the slot accumulators before the thread is through.
+  // Values stay as loaded (fp32) until they are used behind the barrier (f32_opaque keeps the compiler from converting - i.e. waiting - here).
+  const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
+  int ekey[3] = {0, 0, 0};
+  float ezf[3][3];
+  double ezd[3][3], ew[3];
+  if (COMPACT) {                                          // 16 B per edge: one information scalar per edge class, fp32 measurements (ba_dev.hpp); Eb > 0
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int e = e0 + (j < ecnt ? j : 0);
       ekey[j] = d.eb_key[e];
-      ew[j] = d.eb_w ? d.eb_w[e] : d.eb_w_uni;                                  // (wave-uniform choices: 16 B per edge instead of 36 B)
-      ez[j] = d.eb_zf ? D3{(double)d.eb_zf[e], (double)d.eb_zf[Eb + e], (double)d.eb_zf[2 * Eb + e]} : D3{d.eb_z[e], d.eb_z[Eb + e], d.eb_z[2 * Eb + e]};
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ezf[j][k] = d.eb_zf[k * Eb + e];
+    }
+  } else if (T.eb_end > T.eb_begin) {                     // (uniform; with it e0 is a valid index whatever ecnt is)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int e = e0 + (j < ecnt ? j : 0);
+      ekey[j] = d.eb_key[e];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) ezd[j][k] = d.eb_zf ? (double)d.eb_zf[k * Eb + e] : d.eb_z[k * Eb + e];
+      ew[j] = d.eb_w ? d.eb_w[e] : d.eb_w_uni;
     }
   }
-  // ---- stage points, inverse poses, zero accumulators
-  for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) pts[i] = point[i];
-  if (BUILD) {
-    for (int i = tid; i < 4 * VDO_TILE_PTS; i += VDO_TILE_THREADS) accpt[i] = 0.0;
-    for (int i = tid; i < arow * nslot; i += VDO_TILE_THREADS) accpose[i] = 0.0;
-  }
-  for (int sidx = tid; sidx < nslot; sidx += VDO_TILE_THREADS) {
-    const IsoD W = iso_inv(iso_load(pose + 12 * (int64_t)d.tile_pose[T.slot_begin + sidx]));
+  SW_TICK(0);
+  // ---- (5) inverse poses of the slots; points -> LDS; zero accumulators
+  auto stage_slot = [&](int sidx, int pid) {
+    const IsoD W = iso_inv(iso_load(pose + 12 * (int64_t)pid));
     double* o = slotW + 12 * sidx;
 #pragma unroll
     for (int i = 0; i < 9; ++i) o[i] = W.r[i];
     o[9] = W.t.x; o[10] = W.t.y; o[11] = W.t.z;
+  };
+  if (tid < nslot) stage_slot(tid, my_pose);
+  if (BUILD) sdst[my_slot] = my_dst;                      // (by every thread - the clamped ones repeat the last slot: keeps the request out of the branch above)
+  for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) {       // (more than 256 slots in a tile: not in any graph of the bench)
+    stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
+    if (BUILD) sdst[sidx] = d.slot_dst[T.slot_begin + sidx];
   }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pv[k]; }
+  if (BUILD) {
+    for (int i = tid; i < 4 * VDO_TILE_PTS; i += VDO_TILE_THREADS) accpt[i] = 0.0;
+    for (int i = tid; i < arow * nslot; i += VDO_TILE_THREADS) accpose[i] = 0.0;
+  }
+  SW_TICK(1);
   __syncthreads();
+  SW_TICK(2);
+  if (COMPACT) {
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(ezf[j][k]));       // (f32_opaque: the widening to fp64 happens from here on)
+  }
   double chi = 0.0, rchi = 0.0;
   // ------------------------------------------------------------------ EdgeSE3PointXYZ
   {
@@ -166,8 +203,8 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
       if (j < ecnt) {
         const int e = e0 + j;
         const int lp = ekey[j] & 0xffff;
-        const double w = ew[j];
-        const D3 z = ez[j];
+        const double w = COMPACT ? d.eb_w_uni : ew[j];
+        const D3 z = COMPACT ? D3{(double)ezf[j][0], (double)ezf[j][1], (double)ezf[j][2]} : D3{ezd[j][0], ezd[j][1], ezd[j][2]};
         const D3 p{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
         const D3 zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
         const D3 er = zc - z;
@@ -192,7 +229,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
         }
       }
     }
+    SW_TICK(3);
     if (BUILD) acc_finish(acc, slot, accpose, arow);
+    SW_TICK(4);
   }
   // ------------------------------------------------------------ LandmarkMotionTernaryEdge
   {
@@ -237,10 +276,20 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
     if (BUILD && nte > 0) acc_finish(acc, cur, accpose + tofs, arow);      // (uniform: tiles of static points have no ternary edges - 256 scan instructions less)
   }
   // ---- write back
-  block_sum2(chi, rchi, red);
-  if (tid == 0) { d.part_chi[ti] = chi; d.part_chi[d.n_tiles + ti] = rchi; }
+  SW_TICK(5);
+  {   // chi2 partials of the tile: one barrier (it also orders the LDS atomics before the reads of the write-back); waves added in fixed order
+    const int lane = tid & 63, wv = tid >> 6;
+    chi = wave_sum(chi); rchi = wave_sum(rchi);
+    if (lane == 0) { red[wv] = chi; red[16 + wv] = rchi; }
+    __syncthreads();
+    if (tid == 0) {
+      double sa = 0, sb = 0;
+      for (int w = 0; w < VDO_TILE_THREADS / 64; ++w) { sa += red[w]; sb += red[16 + w]; }
+      d.part_chi[ti] = sa; d.part_chi[d.n_tiles + ti] = sb;
+    }
+  }
+  SW_TICK(6);
   if (BUILD) {
-    // (block_sum2's barriers order the LDS atomics before these reads)
     // landmarks: Hll = (sum of we) * I -> one double per point; bl - coalesced: consecutive lanes write consecutive doubles
     double* __restrict__ H = d.Hll + (int64_t)T.pt_begin;
     for (int i = tid; i < npts; i += VDO_TILE_THREADS) H[i] = accpt[i];
@@ -253,15 +302,22 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
     if (d.ps_stride == 16) {
       for (int i = tid; i < 16 * nslot; i += VDO_TILE_THREADS) {
         const int sidx = i >> 4, k = i & 15;
-        d.part_sums[16 * (int64_t)d.slot_dst[T.slot_begin + sidx] + k] = accpose[16 * sidx + k];
+        d.part_sums[16 * (int64_t)sdst[sidx] + k] = accpose[16 * sidx + k];
       }
     } else {
       for (int i = tid; i < 32 * nslot; i += VDO_TILE_THREADS) {
         const int sidx = i >> 5, k = i & 31;
-        d.part_sums[32 * (int64_t)d.slot_dst[T.slot_begin + sidx] + k] = accpose[32 * sidx + k];
+        d.part_sums[32 * (int64_t)sdst[sidx] + k] = accpose[32 * sidx + k];
       }
     }
   }
+#ifdef SWEEP_PROF
+  SW_TICK(7);
+  if (BUILD && (threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 5) {          // (a sample: the atomics of every wave would be the kernel)
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_sweep_prof[i], (unsigned long long)sw_t[i]);
+    atomicAdd(&g_sweep_prof[15], 1ull);
+  }
+#endif
 }
 
 // Expand the running sums of every (tile,slot) partial of a pose into its 6x6 block and rhs.
@@ -375,7 +431,10 @@ static double* ep_chi_buf(const BADev& d) { return d.part_chi + 2 * (int64_t)d.n
 
 void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R) {
   const size_t lds = sweep_lds_doubles(d.max_slots, false, d.ps_stride) * sizeof(double);
-  if (d.n_tiles) hipLaunchKernelGGL(k_sweep_tile<false>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, which);
+  if (d.n_tiles) {
+    if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<false, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, which);
+    else hipLaunchKernelGGL((k_sweep_tile<false, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, which);
+  }
   launch_posepose(d, which, false, ep_chi_buf(d), s);
   if (!d.sharded) { hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 0); return; }
   hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 1);
@@ -385,7 +444,10 @@ void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R) {
 
 void launch_sweep_only(const BADev& d, hipStream_t s) {
   const size_t lds = sweep_lds_doubles(d.max_slots, true, d.ps_stride) * sizeof(double);
-  if (d.n_tiles) hipLaunchKernelGGL(k_sweep_tile<true>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, 0);
+  if (d.n_tiles) {
+    if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<true, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, 0);
+    else hipLaunchKernelGGL((k_sweep_tile<true, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, 0);
+  }
 }
 
 void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R) {
@@ -402,3 +464,11 @@ void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R) {
 }
 
 }  // namespace vdo
+
+#ifdef SWEEP_PROF
+extern "C" int vdo_debug_sweep_prof(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(vdo::g_sweep_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vdo::g_sweep_prof), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif

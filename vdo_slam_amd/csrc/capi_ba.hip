@@ -118,7 +118,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   bool thr_overflow = false;
   int cur_need = 0;                                // threads the open tile needs: sum over its pose slots of ceil(edges / 3)
   std::vector<int32_t> pose_cnt(P, 0), cnt_stamp(P, -1), chain_eb_poses;
-  std::vector<uint16_t> thr_tab;                   // per (tile, thread): (first EdgeSE3PointXYZ of the thread, relative to the tile) << 2 | count (ba_dev.hpp)
+  std::vector<uint32_t> thr_tab;                   // per (tile, thread): (first EdgeSE3PointXYZ of the thread, ABSOLUTE index) << 2 | count (ba_dev.hpp)
   auto chain_poses = [&](const ChainInfo& ci, std::vector<int32_t>& outp) {
     outp.clear();
     for (int c = ci.head;;) {
@@ -168,7 +168,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
         while (k < nb && g->eb_pose[tile_eb[k]] == g->eb_pose[tile_eb[j]]) ++k;
         for (int q = j; q < k; q += pb, ++t) {
           if (t >= VDO_TILE_THREADS) { thr_overflow = true; break; }
-          thr_tab[base + t] = (uint16_t)((q << 2) | std::min(pb, k - q));
+          thr_tab[base + t] = ((uint32_t)(cur.eb_begin + q) << 2) | (uint32_t)std::min(pb, k - q);
         }
         j = k;
       }
@@ -307,7 +307,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     for (int k = 0; k < NPS; ++k) ps_idx[fill[tile_pose[k]]++] = k;
   }
   // pose-major rows of the sweep partials (ba_dev.hpp): slot s -> row slot_dst[s]; 16 sums per row unless a pose carries both edge kinds
-  std::vector<int32_t> slot_dst(std::max(NPS, 1)), pose_kind(std::max(P, 1), 0);
+  std::vector<int32_t> slot_dst((size_t)NPS + 1, 0), pose_kind(std::max(P, 1), 0);
   for (int k = 0; k < NPS; ++k) slot_dst[ps_idx[k]] = k;
   int ps_stride = 16;
   {
@@ -409,14 +409,24 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   d.dsqr_ep = (double)(float)(g->huber_ep * g->huber_ep);
   UP(pose[0], g->pose, 12 * (size_t)P); UP(pose[1], g->pose, 12 * (size_t)P);
   UP(point[0], point_new.data(), 3 * (size_t)L); UP(point[1], point_new.data(), 3 * (size_t)L);
-  UP(tiles, tiles.data(), n_tiles); UP(tile_pose, tile_pose.data(), NPS);
-  thr_tab.resize(std::max<size_t>(thr_tab.size(), 1));
-  UP(thr_tab, thr_tab.data(), thr_tab.size());
+  tile_pose.push_back(0);                          // (one entry of padding: the tile kernels read slot min(thread, slots - 1) unconditionally, also for a tile without slots)
+  UP(tile_pose, tile_pose.data(), tile_pose.size());
   {
+    // The device holds the tile descriptors and the thread tables in LAUNCH order (tiles with the longest landmark chain first: their serial
+    // solves would be the tail of a launch; they are also the ones with ternary edges, ~1.5x the work in the sweep): workgroup b reads
+    // descriptor b and table b straight from its block id - no order array in front of them, and a table entry is an absolute edge index, so
+    // the edge loads of a thread wait for ONE load, not for order -> descriptor -> table (the head of a tile was a quarter of its time).
     std::vector<int32_t> order(std::max(n_tiles, 1), 0), longest(std::max(n_tiles, 1), 0);
     for (int t = 0; t < n_tiles; ++t) { order[t] = t; for (int c = tiles[t].chain_begin; c < tiles[t].chain_end; ++c) longest[t] = std::max(longest[t], chain_off[c + 1] - chain_off[c]); }
     if (!std::getenv("VDO_BA_TILE_ORDER_IDENTITY")) std::stable_sort(order.begin(), order.begin() + n_tiles, [&](int a, int b) { return longest[a] > longest[b]; });
-    UP(tile_order, order.data(), order.size());
+    std::vector<Tile> tiles_l(std::max(n_tiles, 1));
+    std::vector<uint32_t> thr_l((size_t)std::max(n_tiles, 1) * VDO_TILE_THREADS, 0u);
+    for (int b = 0; b < n_tiles; ++b) {
+      tiles_l[b] = tiles[order[b]];
+      std::copy(thr_tab.begin() + (size_t)order[b] * VDO_TILE_THREADS, thr_tab.begin() + (size_t)(order[b] + 1) * VDO_TILE_THREADS, thr_l.begin() + (size_t)b * VDO_TILE_THREADS);
+    }
+    UP(tiles, tiles_l.data(), tiles_l.size());
+    UP(thr_tab, thr_l.data(), thr_l.size());
   }
   UP(chain_off, chain_off.data(), chain_off.size()); UP(pt_prev_edge, pt_prev_edge_new.data(), L);
   {
@@ -445,7 +455,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(ep_i, g->ep_i, Ep); UP(ep_j, g->ep_j, Ep); UP(ep_z, g->ep_z, 12 * (size_t)Ep); UP(ep_info, g->ep_info, 36 * (size_t)Ep);
   UP(pr_pose, g->pr_pose, Npr); UP(pr_z, g->pr_z, 12 * (size_t)Npr); UP(pr_info, g->pr_info, 36 * (size_t)Npr);
   UP(ps_off, ps_off.data(), P + 1); UP(ps_idx, ps_idx.data(), NPS);
-  UP(slot_dst, slot_dst.data(), std::max(NPS, 1)); UP(pose_kind, pose_kind.data(), std::max(P, 1));
+  UP(slot_dst, slot_dst.data(), slot_dst.size()); UP(pose_kind, pose_kind.data(), std::max(P, 1));
   d.ps_stride = ps_stride;
   UP(pe_off, pe_off.data(), P + 1); UP(pe_idx, pe_idx.data(), pe_idx.size());
   UP(pr_off, pr_off.data(), P + 1); UP(pr_idx, pr_idx.data(), pr_idx.size());
