@@ -13,10 +13,10 @@ out = (C.c_ulonglong * 16)()
 L.vdo_debug_sweep_prof(None, 1)
 ms_sweep, ms_lin, dims = ba.profile_linearize(10)
 L.vdo_debug_sweep_prof(out, 0)
-names = ["head: descriptor, thread table, edge loads issued", "staging: points + inverse poses -> LDS", "barrier", "EdgeSE3PointXYZ edges (incl. waiting for them)",
+names = ["head: requests of the (next) tile issued", "staging: points + inverse poses -> LDS", "barrier", "EdgeSE3PointXYZ edges (incl. waiting for them)",
          "segmented scan -> slot accumulators", "ternary edges", "chi2 block sums (2 barriers)", "write-back issued"]
-n = max(1, out[15])
+n = max(1, out[14])          # (wave, tile) pairs timed
 tot = sum(out[i] for i in range(8))
-print("tiles", dims["tiles"], "waves timed", n, "ms_sweep", ms_sweep, "cycles per wave", tot / n)
+print("tiles", dims["tiles"], "waves timed", out[15], "tiles per wave", out[14] / max(1, out[15]), "ms_sweep", ms_sweep, "cycles per wave and tile", tot / n)
 for i, nm in enumerate(names):
     print("  %-52s %8.0f  %5.1f %%" % (nm, out[i] / n, 100.0 * out[i] / tot))

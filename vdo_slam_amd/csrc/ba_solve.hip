@@ -223,24 +223,52 @@ __device__ __forceinline__ void bgbt(const double (&B1)[18], const double* G, co
 // Exact diagonal blocks of the Schur correction, per (tile,slot):  sum B G B^T  (21 upper entries)
 __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
-  const int ti = blockIdx.x;
+  // (head of a tile: every request unconditional and as early as its address is known - ba_sweep.hip)
+  const int ti = blockIdx.x, tid = threadIdx.x;
+  const unsigned tt = d.thr_tab[(int64_t)ti * VDO_TILE_THREADS + tid];
   const Tile T = d.tiles[ti];
-  const int nslot = T.slot_end - T.slot_begin;
+  const int nslot = T.slot_end - T.slot_begin, npts = T.pt_end - T.pt_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
   double* accm = smem;                       // [21 * S]
   double* slotW = accm + 21 * d.max_slots;   // [12 * S]
   double* pts = slotW + 12 * d.max_slots;    // [3 * TP]
-  const int tid = threadIdx.x;
+  const int my_slot = min(tid, max(nslot - 1, 0));
+  const int my_pose = d.tile_pose[T.slot_begin + my_slot];
+  double pvl[3];
+  {
+    const double* __restrict__ point = d.point[0] + 3 * (int64_t)T.pt_begin;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pvl[k] = point[min(tid + k * VDO_TILE_THREADS, 3 * npts - 1)];
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
+  int keyb[3];
+  double web[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { const int e = e0 + (q < ecnt ? q : 0); keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }
   for (int i = tid; i < 21 * nslot; i += VDO_TILE_THREADS) accm[i] = 0.0;
-  stage_slot_w_pts(d, T, slotW, pts);
+  auto stage_slot = [&](int sidx, int pid) {
+    const IsoD W = iso_inv(iso_load(d.pose[0] + 12 * (int64_t)pid));
+    double* o = slotW + 12 * sidx;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = W.r[i];
+    o[9] = W.t.x; o[10] = W.t.y; o[11] = W.t.z;
+  };
+  if (tid < nslot) stage_slot(tid, my_pose);
+  for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
+  // what hangs on the keys: is the point a chain of its own, and its scalar factor
+  unsigned char sgl[3];
+  double dsc[3];
+#pragma unroll
+  for (int q = 0; q < 3; ++q) { const int64_t l = T.pt_begin + (keyb[q] & 0xffff); sgl[q] = d.pt_single[l]; dsc[q] = d.dscal[l]; }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pvl[k]; }
   __syncthreads();
   {
     // EdgeSE3PointXYZ incidences by the sweep's thread table: <= 3 consecutive edges of ONE pose slot per thread - their contributions
     // add up in registers and go through ONE segmented scan.  A point that is a chain of its own (every static landmark) has
     // [Hll^-1]_ll = g I3, and its block B = -we [I ; 2[c]x] R^T gives  B G B^T = g we^2 [I ; 2[c]x] [I ; 2[c]x]^T  (R drops out): a function of
     // ten running sums  s, s c, s c c^T  (s = g we^2) - no 6x3 block, no 6x6 product.
-    const unsigned tt = d.thr_tab[(int64_t)ti * VDO_TILE_THREADS + tid];
-    const int j0 = (int)(tt >> 2) - T.eb_begin, ecnt = (int)(tt & 3u);
     int slot = -1;
     double up[21];
 #pragma unroll
@@ -249,13 +277,13 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
       if (q < ecnt) {
-        const int j = j0 + q;
-        const int key = d.inc_key[T.inc_begin + j];
+        const int j = e0 - T.eb_begin + q;
+        const int key = keyb[q];
         slot = key >> 16;
         const int64_t l = T.pt_begin + (key & 0xffff);
-        const FInc f = make_f(d, T, j, 0, key, d.Finc[T.eb_begin + j], slotW, pts);
-        if (d.pt_single[l]) {
-          const double sw = d.dscal[l] * f.we * f.we;
+        const FInc f = make_f(d, T, j, 0, key, web[q], slotW, pts);
+        if (sgl[q]) {
+          const double sw = dsc[q] * f.we * f.we;
           const double wx = sw * f.cx, wy = sw * f.cy, wz = sw * f.cz;
           s0 += sw; sx += wx; sy += wy; sz += wz;
           sxx += wx * f.cx; sxy += wx * f.cy; sxz += wx * f.cz; syy += wy * f.cy; syz += wy * f.cz; szz += wz * f.cz;
@@ -772,6 +800,11 @@ __global__ __launch_bounds__(1024) void k_pchain_prefix(BADev d) {
 template <int MODE>
 __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const double* __restrict__ v, const double* __restrict__ v2) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
+  // The head of a tile is a chain of dependent loads (ba_sweep.hip, same order here): every request is UNCONDITIONAL (clamped index: a load
+  // under a branch is waited for at the end of the branch) and made as soon as its address is known -
+  //   thread table entry -> this thread's <= 3 EdgeSE3PointXYZ incidences (key, we) ;  descriptor -> slot pose ids, points -> poses, v of the slots.
+  const int tid = threadIdx.x;
+  const unsigned tt = d.thr_tab[(int64_t)blockIdx.x * VDO_TILE_THREADS + tid];
   if (MODE == 0 && d.flags[1]) return;     // PCG already converged: the launches queued behind it are no-ops
   const Tile T = d.tiles[blockIdx.x];                      // (launch order: tiles with the longest landmark chains first - their serial solves would be the tail of the launch)
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
@@ -781,32 +814,47 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
   double* qs = vs + 6 * d.max_slots;       // [6*S]
   double* slotW = qs + 6 * d.max_slots;    // [12*S] inverse poses of the slots (R^T | -R^T t)
   double* pts = slotW + 12 * d.max_slots;  // [3*TP]  the tile's points (linearisation point)
-  const int tid = threadIdx.x;
-  for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) u[i] = 0.0;
-  stage_slot_w_pts(d, T, slotW, pts);
-  if (MODE == 0) {                         // the search direction of this PCG iteration: p = z + beta p_old (v = z, v2 = p_old; k_pcg_q stores it)
-    const double beta = d.scal[S_BETA];
-    for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) {
-      const int64_t g = 6 * (int64_t)d.tile_pose[T.slot_begin + i / 6] + i % 6;
-      vs[i] = v[g] + beta * v2[g];
-    }
+  const int my_slot = min(tid, max(nslot - 1, 0));         // (tile_pose carries one entry of padding)
+  const int my_pose = d.tile_pose[T.slot_begin + my_slot];
+  double pvl[3];
+  {
+    const double* __restrict__ point = d.point[0] + 3 * (int64_t)T.pt_begin;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pvl[k] = point[min(tid + k * VDO_TILE_THREADS, 3 * npts - 1)];
   }
-  if (MODE == 2)
-    for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) vs[i] = v[6 * (int64_t)d.tile_pose[T.slot_begin + i / 6] + i % 6];
-  if (MODE != 2)
-    for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) qs[i] = 0.0;
-  // EdgeSE3PointXYZ incidences by the sweep's thread table: <= 3 consecutive ones of ONE pose slot per thread (key and we requested now, c
-  // formed behind the staging barrier; the slot's inverse pose and its part of v are read once, the thread's B w add up in registers and go
-  // through ONE segmented scan).  The incidences of the ternary edges (dynamic tiles only) follow in strided loops, one scan per round.
-  const unsigned tt = d.thr_tab[(int64_t)blockIdx.x * VDO_TILE_THREADS + tid];
-  const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);    // absolute edge index; inc_key of an EdgeSE3PointXYZ incidence = eb_key of the edge
+  __builtin_amdgcn_sched_barrier(0);       // (the requests above are made before the wait for the table entry)
+  // EdgeSE3PointXYZ incidences by the sweep's thread table: <= 3 consecutive ones of ONE pose slot per thread (absolute edge index; the key of
+  // such an incidence is the eb_key of its edge); c is formed behind the staging barrier; the slot's inverse pose and its part of v are read
+  // once, the thread's B w add up in registers and go through ONE segmented scan.  The incidences of the ternary edges (dynamic tiles only)
+  // follow in strided loops, one scan per round.
+  const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
   int keyb[3];
   double web[3];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) {
-    keyb[q] = -1; web[q] = 0.0;
-    if (q < ecnt) { keyb[q] = d.eb_key[e0 + q]; web[q] = d.Finc[e0 + q]; }
-  }
+  for (int q = 0; q < 3; ++q) { const int e = e0 + (q < ecnt ? q : 0); keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }      // (eb_key has >= 1 entry)
+  for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) u[i] = 0.0;
+  if (MODE != 2)
+    for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) qs[i] = 0.0;
+  auto stage_slot = [&](int sidx, int pid) {
+    const IsoD W = iso_inv(iso_load(d.pose[0] + 12 * (int64_t)pid));
+    double* o = slotW + 12 * sidx;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) o[i] = W.r[i];
+    o[9] = W.t.x; o[10] = W.t.y; o[11] = W.t.z;
+    if (MODE == 0) {                       // the search direction of this PCG iteration: p = z + beta p_old (v = z, v2 = p_old; k_pcg_q stores it)
+      const double beta = d.scal[S_BETA];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) vs[6 * sidx + i] = v[6 * (int64_t)pid + i] + beta * v2[6 * (int64_t)pid + i];
+    }
+    if (MODE == 2) {
+#pragma unroll
+      for (int i = 0; i < 6; ++i) vs[6 * sidx + i] = v[6 * (int64_t)pid + i];
+    }
+  };
+  if (tid < nslot) stage_slot(tid, my_pose);
+  for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pvl[k]; }
   __syncthreads();
   const int slotb = ecnt ? (keyb[0] >> 16) : -1;
   double Wb[12];
@@ -818,7 +866,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
   D3 cb[3];
 #pragma unroll
   for (int q = 0; q < 3; ++q) {
-    const int lp = keyb[q] >= 0 ? (keyb[q] & 0xffff) : 0;
+    const int lp = q < ecnt ? (keyb[q] & 0xffff) : 0;
     cb[q] = rot(Wb, D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]}) + D3{Wb[9], Wb[10], Wb[11]};
   }
   // one incidence of a ternary edge (li >= nb): kind 1 = (H, p1), kind 2 = (H, p2)
@@ -834,7 +882,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     for (int i = 0; i < 6; ++i) pv[i] = vs[6 * (slotb >= 0 ? slotb : 0) + i];
 #pragma unroll
     for (int q = 0; q < 3; ++q) {
-      if (keyb[q] >= 0) {
+      if (q < ecnt) {
         const D3 c = cb[q];
         const D3 t{pv[0] - 2.0 * (c.y * pv[5] - c.z * pv[4]), pv[1] - 2.0 * (c.z * pv[3] - c.x * pv[5]), pv[2] - 2.0 * (c.x * pv[4] - c.y * pv[3])};
         const D3 o = (-web[q]) * rotT(Wb, t);              // R t  (W starts with R^T)
@@ -917,7 +965,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      if (keyb[k] >= 0) {
+      if (k < ecnt) {
         const double* wl = u + 3 * (keyb[k] & 0xffff);
         const D3 y = rot(Wb, D3{wl[0], wl[1], wl[2]});       // R^T w
         const D3 c = cb[k];

@@ -93,23 +93,74 @@ __device__ __forceinline__ void acc_finish(double (&acc)[16], int cur, double* a
   { double g[4] = {acc[12], acc[13], acc[14], acc[15]}; seg_apply16<4>(g, sc, sf, dst + 12); }
 }
 
-// COMPACT: the edge inputs are in the 16-byte form (eb_zf set, eb_w not: every graph the reference builds)
+// What a thread holds of a tile before the tile's staging barrier: everything the head of the tile requests from HBM (the persistent form of the
+// kernel requests the NEXT tile's while this one computes).
+template <bool COMPACT>
+struct SweepHead {
+  int my_pose, my_dst;            // pose id and partial-row id of slot min(thread, slots - 1)
+  double pv[3];                   // the tile's points: <= 768 doubles, three per thread
+  int ekey[3];                    // this thread's <= 3 EdgeSE3PointXYZ edges (one pose slot): key, measurement (+ information scalar)
+  float ezf[COMPACT ? 3 : 1][3];
+  double ezd[COMPACT ? 1 : 3][3], ew[COMPACT ? 1 : 3];
+};
+// Every load of the head is UNCONDITIONAL, from a clamped index (a load under a branch is waited for at the end of that branch: the three edges of
+// a thread were three round trips in a row in the round-3 form), and made as early as its address is known:
+//   thread table entry (address = block id, thread id) -> this thread's edges ;  descriptor (scalar) -> slot pose ids, row ids, points (-> poses)
+// Values stay as loaded (fp32) until they are used behind the staging barrier.
 template <bool BUILD, bool COMPACT>
-__global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int which) {
+__device__ __forceinline__ void sweep_request(const BADev& d, const Tile& T, unsigned tt, int which, int tid, SweepHead<COMPACT>& h) {
+  const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
+  const double* __restrict__ point = d.point[which] + 3 * (int64_t)T.pt_begin;
+  const int64_t Eb = d.Eb;
+  const int my_slot = min(tid, max(nslot - 1, 0));        // (tile_pose / slot_dst carry one entry of padding)
+  h.my_pose = d.tile_pose[T.slot_begin + my_slot];
+  h.my_dst = 0;
+  if (BUILD) h.my_dst = d.slot_dst[T.slot_begin + my_slot];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) h.pv[k] = point[min(tid + k * VDO_TILE_THREADS, 3 * npts - 1)];
+  __builtin_amdgcn_sched_barrier(0);                      // (the requests above are made BEFORE the wait for the table entry that the ones below need)
+  const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
+  if (COMPACT) {                                          // 16 B per edge: one information scalar per edge class, fp32 measurements (ba_dev.hpp); Eb > 0
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int e = e0 + (j < ecnt ? j : 0);
+      h.ekey[j] = d.eb_key[e];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) h.ezf[j][k] = d.eb_zf[k * Eb + e];
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 3; ++j) { h.ekey[j] = 0; h.ew[j] = 0.0; h.ezd[j][0] = h.ezd[j][1] = h.ezd[j][2] = 0.0; }
+    if (T.eb_end > T.eb_begin) {                          // (uniform; with it e0 is a valid index whatever ecnt is)
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const int e = e0 + (j < ecnt ? j : 0);
+        h.ekey[j] = d.eb_key[e];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) h.ezd[j][k] = d.eb_zf ? (double)d.eb_zf[k * Eb + e] : d.eb_z[k * Eb + e];
+        h.ew[j] = d.eb_w ? d.eb_w[e] : d.eb_w_uni;
+      }
+    }
+  }
+}
+
+// COMPACT: the edge inputs are in the 16-byte form (eb_zf set, eb_w not: every graph the reference builds).
+// (A persistent form - a few workgroups per CU walking tiles b, b + grid, ..., the head of the next tile requested behind the compute phase of
+// this one so that its registers are free - was built on this very body in round 4 and is SLOWER: 0.228 ms against 0.140 on the 13.3 M-edge graph.
+// The loop makes the compiler keep ~30 loop-invariant addresses and 35 scalars alive across all phases; at 128 registers it spills, and every
+// spill reload sits in the same in-order queue as the requests in flight.  DESIGN.md 4.1.)
+template <bool BUILD, bool COMPACT>
+__global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int which) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
 #ifdef SWEEP_PROF
   long long sw_t[10], sw_prev = clock64();
+#pragma unroll
+  for (int i = 0; i < 10; ++i) sw_t[i] = 0;
+#undef SW_TICK
+#define SW_TICK(slot) do { if ((threadIdx.x & 63) == 0) { const long long t_ = clock64(); sw_t[slot] += t_ - sw_prev; sw_prev = t_; } } while (0)
 #endif
-  const int ti = blockIdx.x;                              // (descriptors are stored in launch order: tiles with dynamic tracks first - ternary edges, ~1.5x the work - not in the tail)
+  const int ti = blockIdx.x;                               // (descriptors are stored in launch order: tiles with dynamic tracks first - ternary edges, ~1.5x the work - not in the tail)
   const int tid = threadIdx.x;
-  // ---- The head of a tile is a chain of dependent loads, each an HBM round trip of 2-3 k cycles (phase probe, DESIGN.md 4.1: head + staging +
-  // barrier were half of a tile's 21 k cycles).  Every request is therefore made as early as its address is known, in this order:
-  //   (1) the thread table entry (address = block id, thread id)           -> (4) this thread's edges
-  //   (2) the descriptor (scalar)  -> (3) slot pose ids, row ids, points   -> (5) the slots' poses -> inverse -> LDS
-  // so that the two chains run beside each other instead of one after the other.
-  const unsigned tt = d.thr_tab[(int64_t)ti * VDO_TILE_THREADS + tid];
-  const Tile T = d.tiles[ti];
-  const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
   double* pts = smem;
   double* accpt = pts + 3 * VDO_TILE_PTS;                 // [4][TP] SoA: sum of we | b.x | b.y | b.z  (lanes hit 16 bank pairs by point id)
   double* slotW = accpt + (BUILD ? 4 * VDO_TILE_PTS : 0);
@@ -118,204 +169,189 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_sweep_tile(BADev d, int wh
   double* red = accpose + (BUILD ? arow * d.max_slots : 0);
   int* sdst = reinterpret_cast<int*>(red + 40);
   const double* __restrict__ pose = d.pose[which];
-  const double* __restrict__ point = d.point[which] + 3 * (int64_t)T.pt_begin;
   const int64_t Eb = d.Eb, Et = d.Et;
-  // (3) what needs the descriptor only.  Every load of the head is UNCONDITIONAL, from a clamped index: a load under a branch is waited for
-  // at the end of that branch (ISA of the round-3 form: the three edges of a thread were three round trips in a row).
-  const int my_slot = min(tid, max(nslot - 1, 0));        // (tile_pose / slot_dst carry one entry of padding)
-  const int my_pose = d.tile_pose[T.slot_begin + my_slot];
-  int my_dst = 0;
-  if (BUILD) my_dst = d.slot_dst[T.slot_begin + my_slot];
-  double pv[3];                                           // the tile's points: <= 768 doubles, three per thread
-#pragma unroll
-  for (int k = 0; k < 3; ++k) pv[k] = point[min(tid + k * VDO_TILE_THREADS, 3 * npts - 1)];
-  __builtin_amdgcn_sched_barrier(0);                      // (the requests above are made BEFORE the wait for the table entry that the ones below need)
-  // (4) this thread's EdgeSE3PointXYZ inputs: <= 3 consecutive edges of ONE pose slot (thr_tab, built with the tiles; absolute edge index): no
-  // slot bookkeeping per edge, the slot's inverse pose is read once, nothing is flushed to the slot accumulators before the thread is through.
-  // Values stay as loaded (fp32) until they are used behind the barrier (f32_opaque keeps the compiler from converting - i.e. waiting - here).
-  const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
-  int ekey[3] = {0, 0, 0};
-  float ezf[3][3];
-  double ezd[3][3], ew[3];
-  if (COMPACT) {                                          // 16 B per edge: one information scalar per edge class, fp32 measurements (ba_dev.hpp); Eb > 0
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int e = e0 + (j < ecnt ? j : 0);
-      ekey[j] = d.eb_key[e];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) ezf[j][k] = d.eb_zf[k * Eb + e];
-    }
-  } else if (T.eb_end > T.eb_begin) {                     // (uniform; with it e0 is a valid index whatever ecnt is)
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int e = e0 + (j < ecnt ? j : 0);
-      ekey[j] = d.eb_key[e];
-#pragma unroll
-      for (int k = 0; k < 3; ++k) ezd[j][k] = d.eb_zf ? (double)d.eb_zf[k * Eb + e] : d.eb_z[k * Eb + e];
-      ew[j] = d.eb_w ? d.eb_w[e] : d.eb_w_uni;
-    }
-  }
-  SW_TICK(0);
-  // ---- (5) inverse poses of the slots; points -> LDS; zero accumulators
-  auto stage_slot = [&](int sidx, int pid) {
-    const IsoD W = iso_inv(iso_load(pose + 12 * (int64_t)pid));
-    double* o = slotW + 12 * sidx;
-#pragma unroll
-    for (int i = 0; i < 9; ++i) o[i] = W.r[i];
-    o[9] = W.t.x; o[10] = W.t.y; o[11] = W.t.z;
-  };
-  if (tid < nslot) stage_slot(tid, my_pose);
-  if (BUILD) sdst[my_slot] = my_dst;                      // (by every thread - the clamped ones repeat the last slot: keeps the request out of the branch above)
-  for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) {       // (more than 256 slots in a tile: not in any graph of the bench)
-    stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
-    if (BUILD) sdst[sidx] = d.slot_dst[T.slot_begin + sidx];
-  }
-#pragma unroll
-  for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pv[k]; }
-  if (BUILD) {
-    for (int i = tid; i < 4 * VDO_TILE_PTS; i += VDO_TILE_THREADS) accpt[i] = 0.0;
-    for (int i = tid; i < arow * nslot; i += VDO_TILE_THREADS) accpose[i] = 0.0;
-  }
-  SW_TICK(1);
-  __syncthreads();
-  SW_TICK(2);
-  if (COMPACT) {
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(ezf[j][k]));       // (f32_opaque: the widening to fp64 happens from here on)
-  }
-  double chi = 0.0, rchi = 0.0;
-  // ------------------------------------------------------------------ EdgeSE3PointXYZ
+  // ---- The head of a tile is a chain of dependent loads, each an HBM round trip of 2-3 k cycles (phase probe, DESIGN.md 4.1: head + staging +
+  // barrier were half of a tile's 21 k cycles in the round-3 form): sweep_request.
+  const unsigned tt = d.thr_tab[(int64_t)ti * VDO_TILE_THREADS + tid];
+  const Tile T = d.tiles[ti];
+  SweepHead<COMPACT> h;
+  sweep_request<BUILD, COMPACT>(d, T, tt, which, tid, h);
   {
-    double acc[16];
+    const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
+    const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
+    SW_TICK(0);
+    // ---- inverse poses of the slots; points -> LDS; zero accumulators
+    auto stage_slot = [&](int sidx, int pid) {
+      const IsoD W = iso_inv(iso_load(pose + 12 * (int64_t)pid));
+      double* o = slotW + 12 * sidx;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.0;
-    const int slot = ecnt ? (ekey[0] >> 16) : -1;
-    double Wp[12];                                 // W.r = R^T = Jl (row-major), W.t of the thread's slot
-    {
-      const double* Ws = slotW + 12 * (slot >= 0 ? slot : 0);
-#pragma unroll
-      for (int i = 0; i < 12; ++i) Wp[i] = Ws[i];
+      for (int i = 0; i < 9; ++i) o[i] = W.r[i];
+      o[9] = W.t.x; o[10] = W.t.y; o[11] = W.t.z;
+    };
+    if (tid < nslot) stage_slot(tid, h.my_pose);
+    if (BUILD) sdst[min(tid, max(nslot - 1, 0))] = h.my_dst;     // (by every thread - the clamped ones repeat the last slot: keeps the request out of the branch above)
+    for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) {       // (more than 256 slots in a tile: not in any graph of the bench)
+      stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
+      if (BUILD) sdst[sidx] = d.slot_dst[T.slot_begin + sidx];
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      if (j < ecnt) {
-        const int e = e0 + j;
-        const int lp = ekey[j] & 0xffff;
-        const double w = COMPACT ? d.eb_w_uni : ew[j];
-        const D3 z = COMPACT ? D3{(double)ezf[j][0], (double)ezf[j][1], (double)ezf[j][2]} : D3{ezd[j][0], ezd[j][1], ezd[j][2]};
-        const D3 p{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
-        const D3 zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
-        const D3 er = zc - z;
-        const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
-        double rho0, rho1;
-        huber(c2, d.huber_eb, d.dsqr_eb, rho0, rho1);
-        chi += c2; rchi += rho0;
-        if (BUILD) {
-          const double we = w * rho1;
-          // 6x3 block Hpl = -we * [ I ; 2[zc]x ] * Jl  -> only we is stored (8 B instead of 144 B): the consumers recompute zc from
-          // the point and the pose exactly as above (ba_solve.hip make_f)
-          d.Finc[e] = we;
-          // landmark side: Hll += we * Jl^T Jl = we * R R^T = we * I (R is a rotation: g2o's product differs from I by a few
-          // 1e-16, far inside the 1e-12 parity bar) -> ONE running sum per point; bl += -we * R e   (R e = Jl^T e)
-          // (R e and the cross product zc x e by fused multiply-adds: no cancellation follows them, the blocks move by ~1e-16 of their size -
-          // unlike zc itself, whose last bit the subtraction zc - z amplifies past the 1e-12 parity bar)
-          const D3 Re{__builtin_fma(Wp[6], er.z, __builtin_fma(Wp[3], er.y, Wp[0] * er.x)), __builtin_fma(Wp[7], er.z, __builtin_fma(Wp[4], er.y, Wp[1] * er.x)),
-                      __builtin_fma(Wp[8], er.z, __builtin_fma(Wp[5], er.y, Wp[2] * er.x))};
-          atomicAdd(accpt + lp, we);
-          atomicAdd(accpt + VDO_TILE_PTS + lp, -we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + lp, -we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + lp, -we * Re.z);
-          acc_terms(acc, we, zc, er);
-        }
-      }
+    for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = h.pv[k]; }
+    if (BUILD) {
+      for (int i = tid; i < 4 * VDO_TILE_PTS; i += VDO_TILE_THREADS) accpt[i] = 0.0;
+      for (int i = tid; i < arow * nslot; i += VDO_TILE_THREADS) accpose[i] = 0.0;
     }
-    SW_TICK(3);
-    if (BUILD) acc_finish(acc, slot, accpose, arow);
-    SW_TICK(4);
-  }
-  // ------------------------------------------------------------ LandmarkMotionTernaryEdge
-  {
-    const int nte = T.et_end - T.et_begin;
-    const int per = (nte + VDO_TILE_THREADS - 1) / VDO_TILE_THREADS;
-    double acc[16];
-    int cur = -1;
-    for (int j = 0; j < per; ++j) {
-      const int e = T.et_begin + tid * per + j;
-      if (e < T.et_end) {
-        const int key = d.et_key[e];
-        const int slot = d.et_slot[e];
-        const int l1 = key & 0xffff, l2 = key >> 16;
-        const double w = d.et_w ? d.et_w[e] : d.et_w_uni;
-        const D3 z = d.et_z ? D3{d.et_z[e], d.et_z[Et + e], d.et_z[2 * Et + e]} : D3{0.0, 0.0, 0.0};
-        const double* Hi = slotW + 12 * slot;   // Hi.r = R_H^T, Hi.t ; J2 = -Hi.r
-        const D3 p1{pts[3 * l1], pts[3 * l1 + 1], pts[3 * l1 + 2]};
-        const D3 p2{pts[3 * l2], pts[3 * l2 + 1], pts[3 * l2 + 2]};
-        const D3 v = rot(Hi, p2) + D3{Hi[9], Hi[10], Hi[11]};
-        const D3 er = p1 - v - z;
-        const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
-        double rho0, rho1;
-        huber(c2, d.huber_et, d.dsqr_et, rho0, rho1);
-        chi += c2; rchi += rho0;
-        if (BUILD) {
-          const double we = w * rho1;
-          double* O = d.Oll + e;               // O = we * J1^T J2 = -we * Hi.r (p1 x p2)
-#pragma unroll
-          for (int i = 0; i < 9; ++i) O[i * Et] = -we * Hi[i];
-          // (H,p1): we * [I ; [v]x]   and   (H,p2): -we * [I ; [v]x] * Hi.r   -> both from (we, v)
-          d.Finc[Eb + e] = we;
-          // p1: Hll += we*I, b += -we*e ; p2: Hll += we*R_H R_H^T = we*I, b += we * R_H e
-          atomicAdd(accpt + l1, we);
-          atomicAdd(accpt + VDO_TILE_PTS + l1, -we * er.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l1, -we * er.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l1, -we * er.z);
-          const D3 Re = rotT(Hi, er);
-          atomicAdd(accpt + l2, we);
-          atomicAdd(accpt + VDO_TILE_PTS + l2, we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l2, we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l2, we * Re.z);
-          acc_edge(acc, cur, slot, we, v, er, accpose + tofs, arow);
-        }
-      }
-    }
-    if (BUILD && nte > 0) acc_finish(acc, cur, accpose + tofs, arow);      // (uniform: tiles of static points have no ternary edges - 256 scan instructions less)
-  }
-  // ---- write back
-  SW_TICK(5);
-  {   // chi2 partials of the tile: one barrier (it also orders the LDS atomics before the reads of the write-back); waves added in fixed order
-    const int lane = tid & 63, wv = tid >> 6;
-    chi = wave_sum(chi); rchi = wave_sum(rchi);
-    if (lane == 0) { red[wv] = chi; red[16 + wv] = rchi; }
+    SW_TICK(1);
     __syncthreads();
-    if (tid == 0) {
-      double sa = 0, sb = 0;
-      for (int w = 0; w < VDO_TILE_THREADS / 64; ++w) { sa += red[w]; sb += red[16 + w]; }
-      d.part_chi[ti] = sa; d.part_chi[d.n_tiles + ti] = sb;
+    SW_TICK(2);
+    int ekey[3];
+    float ezf[3][3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      ekey[j] = h.ekey[j];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { ezf[j][k] = COMPACT ? h.ezf[COMPACT ? j : 0][k] : 0.f; if (COMPACT) asm volatile("" : "+v"(ezf[j][k])); }      // (opaque: the widening to fp64 happens from here on)
     }
-  }
-  SW_TICK(6);
-  if (BUILD) {
-    // landmarks: Hll = (sum of we) * I -> one double per point; bl - coalesced: consecutive lanes write consecutive doubles
-    double* __restrict__ H = d.Hll + (int64_t)T.pt_begin;
-    for (int i = tid; i < npts; i += VDO_TILE_THREADS) H[i] = accpt[i];
-    double* __restrict__ b = d.bl + 3 * (int64_t)T.pt_begin;
-    for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) {
-      const int l = i / 3, k = i - 3 * l;
-      b[i] = accpt[(1 + k) * VDO_TILE_PTS + l];
+    double ezd[3][3], ew[3];
+    if (!COMPACT) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) { ew[j] = h.ew[COMPACT ? 0 : j]; for (int k = 0; k < 3; ++k) ezd[j][k] = h.ezd[COMPACT ? 0 : j][k]; }
     }
-    // per-(tile,slot) partials -> their pose-major rows: 128 (256) contiguous bytes per slot
-    if (d.ps_stride == 16) {
-      for (int i = tid; i < 16 * nslot; i += VDO_TILE_THREADS) {
-        const int sidx = i >> 4, k = i & 15;
-        d.part_sums[16 * (int64_t)sdst[sidx] + k] = accpose[16 * sidx + k];
+    double chi = 0.0, rchi = 0.0;
+    // ------------------------------------------------------------------ EdgeSE3PointXYZ
+    {
+      double acc[16];
+  #pragma unroll
+      for (int i = 0; i < 16; ++i) acc[i] = 0.0;
+      const int slot = ecnt ? (ekey[0] >> 16) : -1;
+      double Wp[12];                                 // W.r = R^T = Jl (row-major), W.t of the thread's slot
+      {
+        const double* Ws = slotW + 12 * (slot >= 0 ? slot : 0);
+  #pragma unroll
+        for (int i = 0; i < 12; ++i) Wp[i] = Ws[i];
       }
-    } else {
-      for (int i = tid; i < 32 * nslot; i += VDO_TILE_THREADS) {
-        const int sidx = i >> 5, k = i & 31;
-        d.part_sums[32 * (int64_t)sdst[sidx] + k] = accpose[32 * sidx + k];
+  #pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        if (j < ecnt) {
+          const int e = e0 + j;
+          const int lp = ekey[j] & 0xffff;
+          const double w = COMPACT ? d.eb_w_uni : ew[j];
+          const D3 z = COMPACT ? D3{(double)ezf[j][0], (double)ezf[j][1], (double)ezf[j][2]} : D3{ezd[j][0], ezd[j][1], ezd[j][2]};
+          const D3 p{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
+          const D3 zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
+          const D3 er = zc - z;
+          const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
+          double rho0, rho1;
+          huber(c2, d.huber_eb, d.dsqr_eb, rho0, rho1);
+          chi += c2; rchi += rho0;
+          if (BUILD) {
+            const double we = w * rho1;
+            // 6x3 block Hpl = -we * [ I ; 2[zc]x ] * Jl  -> only we is stored (8 B instead of 144 B): the consumers recompute zc from
+            // the point and the pose exactly as above (ba_solve.hip make_f)
+            d.Finc[e] = we;
+            // landmark side: Hll += we * Jl^T Jl = we * R R^T = we * I (R is a rotation: g2o's product differs from I by a few
+            // 1e-16, far inside the 1e-12 parity bar) -> ONE running sum per point; bl += -we * R e   (R e = Jl^T e)
+            // (R e and the cross product zc x e by fused multiply-adds: no cancellation follows them, the blocks move by ~1e-16 of their size -
+            // unlike zc itself, whose last bit the subtraction zc - z amplifies past the 1e-12 parity bar)
+            const D3 Re{__builtin_fma(Wp[6], er.z, __builtin_fma(Wp[3], er.y, Wp[0] * er.x)), __builtin_fma(Wp[7], er.z, __builtin_fma(Wp[4], er.y, Wp[1] * er.x)),
+                        __builtin_fma(Wp[8], er.z, __builtin_fma(Wp[5], er.y, Wp[2] * er.x))};
+            atomicAdd(accpt + lp, we);
+            atomicAdd(accpt + VDO_TILE_PTS + lp, -we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + lp, -we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + lp, -we * Re.z);
+            acc_terms(acc, we, zc, er);
+          }
+        }
+      }
+      SW_TICK(3);
+      if (BUILD) acc_finish(acc, slot, accpose, arow);
+      SW_TICK(4);
+    }
+    // ------------------------------------------------------------ LandmarkMotionTernaryEdge
+    {
+      const int nte = T.et_end - T.et_begin;
+      const int per = (nte + VDO_TILE_THREADS - 1) / VDO_TILE_THREADS;
+      double acc[16];
+      int cur = -1;
+      for (int j = 0; j < per; ++j) {
+        const int e = T.et_begin + tid * per + j;
+        if (e < T.et_end) {
+          const int key = d.et_key[e];
+          const int slot = d.et_slot[e];
+          const int l1 = key & 0xffff, l2 = key >> 16;
+          const double w = d.et_w ? d.et_w[e] : d.et_w_uni;
+          const D3 z = d.et_z ? D3{d.et_z[e], d.et_z[Et + e], d.et_z[2 * Et + e]} : D3{0.0, 0.0, 0.0};
+          const double* Hi = slotW + 12 * slot;   // Hi.r = R_H^T, Hi.t ; J2 = -Hi.r
+          const D3 p1{pts[3 * l1], pts[3 * l1 + 1], pts[3 * l1 + 2]};
+          const D3 p2{pts[3 * l2], pts[3 * l2 + 1], pts[3 * l2 + 2]};
+          const D3 v = rot(Hi, p2) + D3{Hi[9], Hi[10], Hi[11]};
+          const D3 er = p1 - v - z;
+          const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
+          double rho0, rho1;
+          huber(c2, d.huber_et, d.dsqr_et, rho0, rho1);
+          chi += c2; rchi += rho0;
+          if (BUILD) {
+            const double we = w * rho1;
+            double* O = d.Oll + e;               // O = we * J1^T J2 = -we * Hi.r (p1 x p2)
+  #pragma unroll
+            for (int i = 0; i < 9; ++i) O[i * Et] = -we * Hi[i];
+            // (H,p1): we * [I ; [v]x]   and   (H,p2): -we * [I ; [v]x] * Hi.r   -> both from (we, v)
+            d.Finc[Eb + e] = we;
+            // p1: Hll += we*I, b += -we*e ; p2: Hll += we*R_H R_H^T = we*I, b += we * R_H e
+            atomicAdd(accpt + l1, we);
+            atomicAdd(accpt + VDO_TILE_PTS + l1, -we * er.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l1, -we * er.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l1, -we * er.z);
+            const D3 Re = rotT(Hi, er);
+            atomicAdd(accpt + l2, we);
+            atomicAdd(accpt + VDO_TILE_PTS + l2, we * Re.x); atomicAdd(accpt + 2 * VDO_TILE_PTS + l2, we * Re.y); atomicAdd(accpt + 3 * VDO_TILE_PTS + l2, we * Re.z);
+            acc_edge(acc, cur, slot, we, v, er, accpose + tofs, arow);
+          }
+        }
+      }
+      if (BUILD && nte > 0) acc_finish(acc, cur, accpose + tofs, arow);      // (uniform: tiles of static points have no ternary edges - 256 scan instructions less)
+    }
+    // ---- write back
+    SW_TICK(5);
+    {   // chi2 partials of the tile: one barrier (it also orders the LDS atomics before the reads of the write-back); waves added in fixed order
+      const int lane = tid & 63, wv = tid >> 6;
+      chi = wave_sum(chi); rchi = wave_sum(rchi);
+      if (lane == 0) { red[wv] = chi; red[16 + wv] = rchi; }
+      __syncthreads();
+      if (tid == 0) {
+        double sa = 0, sb = 0;
+        for (int w = 0; w < VDO_TILE_THREADS / 64; ++w) { sa += red[w]; sb += red[16 + w]; }
+        d.part_chi[ti] = sa; d.part_chi[d.n_tiles + ti] = sb;
       }
     }
+    SW_TICK(6);
+    if (BUILD) {
+      // landmarks: Hll = (sum of we) * I -> one double per point; bl - coalesced: consecutive lanes write consecutive doubles
+      double* __restrict__ H = d.Hll + (int64_t)T.pt_begin;
+      for (int i = tid; i < npts; i += VDO_TILE_THREADS) H[i] = accpt[i];
+      double* __restrict__ b = d.bl + 3 * (int64_t)T.pt_begin;
+      for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) {
+        const int l = i / 3, k = i - 3 * l;
+        b[i] = accpt[(1 + k) * VDO_TILE_PTS + l];
+      }
+      // per-(tile,slot) partials -> their pose-major rows: 128 (256) contiguous bytes per slot
+      if (d.ps_stride == 16) {
+        for (int i = tid; i < 16 * nslot; i += VDO_TILE_THREADS) {
+          const int sidx = i >> 4, k = i & 15;
+          d.part_sums[16 * (int64_t)sdst[sidx] + k] = accpose[16 * sidx + k];
+        }
+      } else {
+        for (int i = tid; i < 32 * nslot; i += VDO_TILE_THREADS) {
+          const int sidx = i >> 5, k = i & 31;
+          d.part_sums[32 * (int64_t)sdst[sidx] + k] = accpose[32 * sidx + k];
+        }
+      }
+    }
+    SW_TICK(7);
+#ifdef SWEEP_PROF
+    sw_t[9] += 1;
+#endif
   }
 #ifdef SWEEP_PROF
-  SW_TICK(7);
   if (BUILD && (threadIdx.x & 63) == 0 && (blockIdx.x & 63) == 5) {          // (a sample: the atomics of every wave would be the kernel)
     for (int i = 0; i < 8; ++i) atomicAdd(&g_sweep_prof[i], (unsigned long long)sw_t[i]);
     atomicAdd(&g_sweep_prof[15], 1ull);
+    atomicAdd(&g_sweep_prof[14], (unsigned long long)sw_t[9]);
   }
 #endif
 }
@@ -444,10 +480,9 @@ void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R) {
 
 void launch_sweep_only(const BADev& d, hipStream_t s) {
   const size_t lds = sweep_lds_doubles(d.max_slots, true, d.ps_stride) * sizeof(double);
-  if (d.n_tiles) {
-    if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<true, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, 0);
-    else hipLaunchKernelGGL((k_sweep_tile<true, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, 0);
-  }
+  if (!d.n_tiles) return;
+  if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<true, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, 0);
+  else hipLaunchKernelGGL((k_sweep_tile<true, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, 0);
 }
 
 void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R) {

@@ -2,11 +2,33 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 namespace vdo {
 
+// Sum over the wave, valid in LANE 0: the tree  v[l] += v[l + 32], += v[l + 16], ... += v[l + 1]  (the additions and their order are those of the
+// __shfl_down form this replaces - same bits), by gfx950 row swaps and DPP moves instead of ds_bpermute round trips (and without the
+// lane-address registers those need).
 __device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+  {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false), h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);        // v[l] + v[l ^ 32]
+  }
+  {
+    const unsigned lo = (unsigned)__double2loint(v), hi = (unsigned)__double2hiint(v);
+    const auto l = __builtin_amdgcn_permlane16_swap(lo, lo, false, false), h = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
+    v = __hiloint2double((int)h[0], (int)l[0]) + __hiloint2double((int)h[1], (int)l[1]);        // v[l] + v[l ^ 16]
+  }
+  auto mv = [](double x, auto ctrl) {
+    constexpr int C = decltype(ctrl)::value;
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), C, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), C, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+  };
+  v += mv(v, std::integral_constant<int, 0x128>{});    // row_ror:8  lane l < 8 reads l + 8
+  v += mv(v, std::integral_constant<int, 0x104>{});    // row_shl:4  lane l reads l + 4
+  v += mv(v, std::integral_constant<int, 0x102>{});    // row_shl:2
+  v += mv(v, std::integral_constant<int, 0x101>{});    // row_shl:1
   return v;
 }
 

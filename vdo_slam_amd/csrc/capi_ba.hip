@@ -434,7 +434,8 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     for (int c = 0; c < n_chains; ++c) if (chain_off[c + 1] - chain_off[c] == 1) single[chain_off[c]] = 1;
     UP(pt_single, single.data(), single.size());
   }
-  UP(eb_key, eb_key.data(), Eb);
+  eb_key.resize(std::max<size_t>(eb_key.size(), 1), 0);      // (>= 1 entry: the tile kernels load a thread's edges from clamped indices, unconditionally)
+  UP(eb_key, eb_key.data(), eb_key.size());
   UP(et_key, et_key.data(), Et); UP(et_slot, et_slot.data(), Et);
   {
     // compact edge inputs where they are lossless (ba_dev.hpp): one information scalar per edge class, fp32 measurements
