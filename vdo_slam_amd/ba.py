@@ -132,11 +132,11 @@ class BatchBA:
 
 def linearize_byte_model(graph, dims):
     """HBM bytes one linearisation has to move with this design - the floor the counters are compared with.
-    sweep: edge inputs + every point once + 512 B of thread table per tile (reads); we per edge, the point-point block of a ternary edge, the landmark scalar +
+    sweep: edge inputs + every point once + 1 KB of thread table and 48 B of descriptor per tile (reads); we per edge, the point-point block of a ternary edge, the landmark scalar +
     right-hand side per point, one row of running sums per (tile, pose-slot) pair (writes).  finalize: the rows again (read) + the
     6x6 block and right-hand side of every pose (write)."""
     row = 8 * dims["partial_row"]
-    sweep_r = dims["read_bytes_eb"] * graph.n_eb + dims["read_bytes_et"] * graph.n_et + 24 * graph.n_point + 2 * 256 * dims["tiles"]      # (+ the thread table of every tile)
+    sweep_r = dims["read_bytes_eb"] * graph.n_eb + dims["read_bytes_et"] * graph.n_et + 24 * graph.n_point + (4 * 256 + 48) * dims["tiles"] + 8 * dims["slots"]      # (+ thread table and descriptor of every tile, pose id and row id of every slot)
     sweep_w = 8 * (graph.n_eb + graph.n_et) + 72 * graph.n_et + 32 * graph.n_point + row * dims["slots"]
     fin = row * dims["slots"] + 336 * graph.n_pose
     return dict(sweep_read=int(sweep_r), sweep_write=int(sweep_w), sweep=int(sweep_r + sweep_w), finalize=int(fin), linearize=int(sweep_r + sweep_w + fin))

@@ -22,8 +22,11 @@
 #include <stdint.h>
 
 #define VDO_TILE_PTS 256        // max points per tile
-#define VDO_TILE_INC 768        // max incidences per tile (3 per thread at 256 threads)
 #define VDO_TILE_THREADS 256
+#ifndef VDO_TILE_EPT
+#define VDO_TILE_EPT 6          // EdgeSE3PointXYZ edges per thread of the tile kernels: what a tile costs apart from its edges (two HBM round trips at its head,
+#endif                          // barriers, write-back: ~9 k of 16 k cycles at 3 edges per thread, phase probe) is spread over this many
+#define VDO_TILE_INC (VDO_TILE_THREADS * VDO_TILE_EPT)        // max incidences per tile
 
 namespace vdo {
 
@@ -106,7 +109,7 @@ struct BADev {
   double *xp = nullptr, *rp = nullptr, *zp = nullptr, *pp = nullptr, *qp = nullptr, *bs = nullptr, *qs = nullptr;  // [6P]
   double* pp2 = nullptr;                             // [6P] second search-direction buffer (the PCG iterations ping-pong between pp and pp2)
   double *part_pq = nullptr, *part_rz = nullptr;     // [(P+3)/4] p.q per workgroup of k_pcg_q; [n_pchains] r.z per chain of k_pcg_chain
-  uint32_t* thr_tab = nullptr;                       // [n_tiles][256], launch order like tiles: thread t of the sweep takes (v & 3) EdgeSE3PointXYZ edges of ONE pose slot from edge (v >> 2) (absolute)
+  uint32_t* thr_tab = nullptr;                       // [n_tiles][256], launch order like tiles: thread t of the tile kernels takes (v & 7) <= VDO_TILE_EPT EdgeSE3PointXYZ edges of ONE pose slot from edge (v >> 3) (absolute)
   double* part_q = nullptr;                          // [NPS][8] pose-major rows (row slot_dst[s] of slot s), 6 used: Schur mat-vec partials
   double *part_m = nullptr, *part_m8 = nullptr;      // [NPS][16] + [NPS][8] pose-major rows: the 21 preconditioner partials of a slot (16 + 5)
   double* scal = nullptr;

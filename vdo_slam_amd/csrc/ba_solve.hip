@@ -241,11 +241,11 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
     for (int k = 0; k < 3; ++k) pvl[k] = point[min(tid + k * VDO_TILE_THREADS, 3 * npts - 1)];
   }
   __builtin_amdgcn_sched_barrier(0);
-  const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
-  int keyb[3];
-  double web[3];
+  const int e0 = (int)(tt >> 3), ecnt = (int)(tt & 7u);
+  int keyb[VDO_TILE_EPT];
+  double web[VDO_TILE_EPT];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) { const int e = e0 + (q < ecnt ? q : 0); keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }
+  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int e = e0 + (q < ecnt ? q : 0); keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }
   for (int i = tid; i < 21 * nslot; i += VDO_TILE_THREADS) accm[i] = 0.0;
   auto stage_slot = [&](int sidx, int pid) {
     const IsoD W = iso_inv(iso_load(d.pose[0] + 12 * (int64_t)pid));
@@ -257,15 +257,15 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   if (tid < nslot) stage_slot(tid, my_pose);
   for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
   // what hangs on the keys: is the point a chain of its own, and its scalar factor
-  unsigned char sgl[3];
-  double dsc[3];
+  unsigned char sgl[VDO_TILE_EPT];
+  double dsc[VDO_TILE_EPT];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) { const int64_t l = T.pt_begin + (keyb[q] & 0xffff); sgl[q] = d.pt_single[l]; dsc[q] = d.dscal[l]; }
+  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int64_t l = T.pt_begin + (keyb[q] & 0xffff); sgl[q] = d.pt_single[l]; dsc[q] = d.dscal[l]; }
 #pragma unroll
   for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pvl[k]; }
   __syncthreads();
   {
-    // EdgeSE3PointXYZ incidences by the sweep's thread table: <= 3 consecutive edges of ONE pose slot per thread - their contributions
+    // EdgeSE3PointXYZ incidences by the sweep's thread table: <= VDO_TILE_EPT consecutive edges of ONE pose slot per thread - their contributions
     // add up in registers and go through ONE segmented scan.  A point that is a chain of its own (every static landmark) has
     // [Hll^-1]_ll = g I3, and its block B = -we [I ; 2[c]x] R^T gives  B G B^T = g we^2 [I ; 2[c]x] [I ; 2[c]x]^T  (R drops out): a function of
     // ten running sums  s, s c, s c c^T  (s = g we^2) - no 6x3 block, no 6x6 product.
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
     for (int i = 0; i < 21; ++i) up[i] = 0.0;
     double s0 = 0.0, sx = 0.0, sy = 0.0, sz = 0.0, sxx = 0.0, sxy = 0.0, sxz = 0.0, syy = 0.0, syz = 0.0, szz = 0.0;
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < VDO_TILE_EPT; ++q) {
       if (q < ecnt) {
         const int j = e0 - T.eb_begin + q;
         const int key = keyb[q];
@@ -798,11 +798,11 @@ __global__ __launch_bounds__(1024) void k_pchain_prefix(BADev d) {
 // staged for every point 57.6 us; this form 40.3 us; factors requested TWO steps ahead 48 us (170 VGPRs); separate launches for static tiles
 // (no chain code) and dynamic tiles (factors staged) 23 + 22 us.
 template <int MODE>
-__global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const double* __restrict__ v, const double* __restrict__ v2) {
+__global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, const double* __restrict__ v, const double* __restrict__ v2) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // The head of a tile is a chain of dependent loads (ba_sweep.hip, same order here): every request is UNCONDITIONAL (clamped index: a load
   // under a branch is waited for at the end of the branch) and made as soon as its address is known -
-  //   thread table entry -> this thread's <= 3 EdgeSE3PointXYZ incidences (key, we) ;  descriptor -> slot pose ids, points -> poses, v of the slots.
+  //   thread table entry -> this thread's <= VDO_TILE_EPT EdgeSE3PointXYZ incidences (key, we) ;  descriptor -> slot pose ids, points -> poses, v of the slots.
   const int tid = threadIdx.x;
   const unsigned tt = d.thr_tab[(int64_t)blockIdx.x * VDO_TILE_THREADS + tid];
   if (MODE == 0 && d.flags[1]) return;     // PCG already converged: the launches queued behind it are no-ops
@@ -823,15 +823,15 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     for (int k = 0; k < 3; ++k) pvl[k] = point[min(tid + k * VDO_TILE_THREADS, 3 * npts - 1)];
   }
   __builtin_amdgcn_sched_barrier(0);       // (the requests above are made before the wait for the table entry)
-  // EdgeSE3PointXYZ incidences by the sweep's thread table: <= 3 consecutive ones of ONE pose slot per thread (absolute edge index; the key of
+  // EdgeSE3PointXYZ incidences by the sweep's thread table: <= VDO_TILE_EPT consecutive ones of ONE pose slot per thread (absolute edge index; the key of
   // such an incidence is the eb_key of its edge); c is formed behind the staging barrier; the slot's inverse pose and its part of v are read
   // once, the thread's B w add up in registers and go through ONE segmented scan.  The incidences of the ternary edges (dynamic tiles only)
   // follow in strided loops, one scan per round.
-  const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
-  int keyb[3];
-  double web[3];
+  const int e0 = (int)(tt >> 3), ecnt = (int)(tt & 7u);
+  int keyb[VDO_TILE_EPT];
+  double web[VDO_TILE_EPT];
 #pragma unroll
-  for (int q = 0; q < 3; ++q) { const int e = e0 + (q < ecnt ? q : 0); keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }      // (eb_key has >= 1 entry)
+  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int e = e0 + (q < ecnt ? q : 0); keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }      // (eb_key has >= 1 entry)
   for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) u[i] = 0.0;
   if (MODE != 2)
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) qs[i] = 0.0;
@@ -857,18 +857,18 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
   for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pvl[k]; }
   __syncthreads();
   const int slotb = ecnt ? (keyb[0] >> 16) : -1;
-  double Wb[12];
-  {
+  // The slot's inverse pose and c = W p + t_W of the thread's incidences are formed where they are used - in pass A and again in pass C -
+  // instead of living across the chain solves between the two: those hold the kernel's register peak (four 3x3 factors in flight), and
+  // 24 + 6 per incidence registers on top of it cost a resident wave per SIMD (150 -> 178 registers at six incidences per thread).
+  auto load_w = [&](double (&Wb)[12]) {
     const double* Ws = slotW + 12 * (slotb >= 0 ? slotb : 0);
 #pragma unroll
     for (int i = 0; i < 12; ++i) Wb[i] = Ws[i];
-  }
-  D3 cb[3];
-#pragma unroll
-  for (int q = 0; q < 3; ++q) {
+  };
+  auto make_c = [&](const double (&Wb)[12], int q) {
     const int lp = q < ecnt ? (keyb[q] & 0xffff) : 0;
-    cb[q] = rot(Wb, D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]}) + D3{Wb[9], Wb[10], Wb[11]};
-  }
+    return rot(Wb, D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]}) + D3{Wb[9], Wb[10], Wb[11]};
+  };
   // one incidence of a ternary edge (li >= nb): kind 1 = (H, p1), kind 2 = (H, p2)
   auto tern_load = [&](int li, int& key, int& kind, FInc& f) {
     key = d.inc_key[T.inc_begin + li];
@@ -877,13 +877,14 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
     f = make_f(d, T, li, kind, key, d.Finc[fidx], slotW, pts);
   };
   if (MODE != 1) {   // pass A: u_l += B^T v_slot = sgn*we * (I or R) (vt - s c x vr)
-    double pv[6];
+    double pv[6], Wb[12];
+    load_w(Wb);
 #pragma unroll
     for (int i = 0; i < 6; ++i) pv[i] = vs[6 * (slotb >= 0 ? slotb : 0) + i];
 #pragma unroll
-    for (int q = 0; q < 3; ++q) {
+    for (int q = 0; q < VDO_TILE_EPT; ++q) {
       if (q < ecnt) {
-        const D3 c = cb[q];
+        const D3 c = make_c(Wb, q);
         const D3 t{pv[0] - 2.0 * (c.y * pv[5] - c.z * pv[4]), pv[1] - 2.0 * (c.z * pv[3] - c.x * pv[5]), pv[2] - 2.0 * (c.x * pv[4] - c.y * pv[3])};
         const D3 o = (-web[q]) * rotT(Wb, t);              // R t  (W starts with R^T)
         double* ul = u + 3 * (keyb[q] & 0xffff);
@@ -962,13 +963,14 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_tile(BADev d, const 
   }
   // pass C: q_slot += B w_l  (segmented wave reduction; incidences are slot-sorted per part)
   {
-    double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double q[6] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0}, Wb[12];
+    load_w(Wb);
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
+    for (int k = 0; k < VDO_TILE_EPT; ++k) {
       if (k < ecnt) {
         const double* wl = u + 3 * (keyb[k] & 0xffff);
         const D3 y = rot(Wb, D3{wl[0], wl[1], wl[2]});       // R^T w
-        const D3 c = cb[k];
+        const D3 c = make_c(Wb, k);
         const double sg = -web[k];
         q[0] += sg * y.x; q[1] += sg * y.y; q[2] += sg * y.z;
         q[3] += sg * 2.0 * (c.y * y.z - c.z * y.y);
@@ -1271,11 +1273,11 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       else { dinv[i] = gd[i]; gl[i] = gg[i]; }
     }
   }
-  int key[3], kind[3];
-  FInc F[3];
-  double we[3];
+  int key[VDO_TILE_EPT], kind[VDO_TILE_EPT];       // (<= VDO_TILE_INC = 256 * VDO_TILE_EPT incidences per tile)
+  FInc F[VDO_TILE_EPT];
+  double we[VDO_TILE_EPT];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < VDO_TILE_EPT; ++j) {
     const int li = tid + VDO_TILE_THREADS * j;
     key[j] = -1; kind[j] = 1; we[j] = 0.0;
     if (li < ninc) {
@@ -1287,7 +1289,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   }
   __syncthreads();
 #pragma unroll
-  for (int j = 0; j < 3; ++j) F[j] = key[j] >= 0 ? make_f(d, T, tid + VDO_TILE_THREADS * j, kind[j], key[j], we[j], slotW, pts) : FInc{0, 0, 0, 0};
+  for (int j = 0; j < VDO_TILE_EPT; ++j) F[j] = key[j] >= 0 ? make_f(d, T, tid + VDO_TILE_THREADS * j, kind[j], key[j], we[j], slotW, pts) : FInc{0, 0, 0, 0};
   for (int s = 0; s < nslot; ++s) {
     __syncthreads();
     for (int i = tid; i < 18 * VDO_TILE_PTS; i += VDO_TILE_THREADS) u6[i] = 0.0;
@@ -1296,7 +1298,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     __syncthreads();
     // pass A: u_b[l] += row b of the explicit 6x3 block of every incidence (s, l)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < VDO_TILE_EPT; ++j) {
       if (key[j] >= 0 && (key[j] >> 16) == s) {
         double B[18];
         expand_block(kind[j], F[j], slotW + 12 * s, B);
@@ -1347,7 +1349,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     // pass C: block (r, s) += B_r w_b for every incidence (r, l) on a touched point; incidences are slot-sorted inside each
     // part, so the 36 values go through the segmented DPP reduction (many lanes share a slot: plain LDS atomics would serialise)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < VDO_TILE_EPT; ++j) {
       const bool on = key[j] >= 0 && touched[key[j] & 0xffff];
       const int r = on ? (key[j] >> 16) : -1, lp = on ? (key[j] & 0xffff) : 0;
       if (!__any(on)) continue;                                  // (wave-uniform: nothing of this wave's incidences is reached from slot s)

@@ -17,8 +17,8 @@
 //      (sum of we) * I - J_point^T J_point = R R^T = I for both edge classes - so 1 + 3 sums per point, written once (32 B);
 //   4. the pose 6x6+6 contribution of an edge depends on 16 running sums only
 //      (J_pose = [-I | 2[zc]x]  resp. [I | -[v]x]): Σw, Σw·zc, Σw·zc zcᵀ, Σw·e, Σw·zc×e.
-//      Every thread sums them in registers over its <= 3 consecutive EdgeSE3PointXYZ edges, which belong to ONE pose slot (edges are
-//      pose-sorted inside the tile; a per-tile thread table - ba_dev.hpp thr_tab - cuts every slot's run into pieces of <= 3), the
+//      Every thread sums them in registers over its <= VDO_TILE_EPT consecutive EdgeSE3PointXYZ edges, which belong to ONE pose slot (edges are
+//      pose-sorted inside the tile; a per-tile thread table - ba_dev.hpp thr_tab - cuts every slot's run into pieces of <= VDO_TILE_EPT), the
 //      threads' totals go through a segmented DPP scan into per-slot LDS accumulators and leave as one 128-byte row per
 //      (tile, slot) of the POSE-MAJOR partial array; k_finalize_pose streams a pose's rows, expands them to the 6x6 block + rhs
 //      and adds the blocks of the pose's EdgeSE3 / prior edges (k_posepose), all in fixed order.
@@ -99,9 +99,9 @@ template <bool COMPACT>
 struct SweepHead {
   int my_pose, my_dst;            // pose id and partial-row id of slot min(thread, slots - 1)
   double pv[3];                   // the tile's points: <= 768 doubles, three per thread
-  int ekey[3];                    // this thread's <= 3 EdgeSE3PointXYZ edges (one pose slot): key, measurement (+ information scalar)
-  float ezf[COMPACT ? 3 : 1][3];
-  double ezd[COMPACT ? 1 : 3][3], ew[COMPACT ? 1 : 3];
+  int ekey[VDO_TILE_EPT];         // this thread's <= VDO_TILE_EPT EdgeSE3PointXYZ edges (one pose slot): key, measurement (+ information scalar)
+  float ezf[COMPACT ? VDO_TILE_EPT : 1][3];
+  double ezd[COMPACT ? 1 : VDO_TILE_EPT][3], ew[COMPACT ? 1 : VDO_TILE_EPT];
 };
 // Every load of the head is UNCONDITIONAL, from a clamped index (a load under a branch is waited for at the end of that branch: the three edges of
 // a thread were three round trips in a row in the round-3 form), and made as early as its address is known:
@@ -119,10 +119,10 @@ __device__ __forceinline__ void sweep_request(const BADev& d, const Tile& T, uns
 #pragma unroll
   for (int k = 0; k < 3; ++k) h.pv[k] = point[min(tid + k * VDO_TILE_THREADS, 3 * npts - 1)];
   __builtin_amdgcn_sched_barrier(0);                      // (the requests above are made BEFORE the wait for the table entry that the ones below need)
-  const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
+  const int e0 = (int)(tt >> 3), ecnt = (int)(tt & 7u);
   if (COMPACT) {                                          // 16 B per edge: one information scalar per edge class, fp32 measurements (ba_dev.hpp); Eb > 0
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < VDO_TILE_EPT; ++j) {
       const int e = e0 + (j < ecnt ? j : 0);
       h.ekey[j] = d.eb_key[e];
 #pragma unroll
@@ -130,10 +130,10 @@ __device__ __forceinline__ void sweep_request(const BADev& d, const Tile& T, uns
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < 3; ++j) { h.ekey[j] = 0; h.ew[j] = 0.0; h.ezd[j][0] = h.ezd[j][1] = h.ezd[j][2] = 0.0; }
+    for (int j = 0; j < VDO_TILE_EPT; ++j) { h.ekey[j] = 0; h.ew[j] = 0.0; h.ezd[j][0] = h.ezd[j][1] = h.ezd[j][2] = 0.0; }
     if (T.eb_end > T.eb_begin) {                          // (uniform; with it e0 is a valid index whatever ecnt is)
 #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+      for (int j = 0; j < VDO_TILE_EPT; ++j) {
         const int e = e0 + (j < ecnt ? j : 0);
         h.ekey[j] = d.eb_key[e];
 #pragma unroll
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
   sweep_request<BUILD, COMPACT>(d, T, tt, which, tid, h);
   {
     const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
-    const int e0 = (int)(tt >> 2), ecnt = (int)(tt & 3u);
+    const int e0 = (int)(tt >> 3), ecnt = (int)(tt & 7u);
     SW_TICK(0);
     // ---- inverse poses of the slots; points -> LDS; zero accumulators
     auto stage_slot = [&](int sidx, int pid) {
@@ -203,34 +203,34 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
     SW_TICK(1);
     __syncthreads();
     SW_TICK(2);
-    int ekey[3];
-    float ezf[3][3];
+    int ekey[VDO_TILE_EPT];
+    float ezf[VDO_TILE_EPT][3];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
+    for (int j = 0; j < VDO_TILE_EPT; ++j) {
       ekey[j] = h.ekey[j];
 #pragma unroll
       for (int k = 0; k < 3; ++k) { ezf[j][k] = COMPACT ? h.ezf[COMPACT ? j : 0][k] : 0.f; if (COMPACT) asm volatile("" : "+v"(ezf[j][k])); }      // (opaque: the widening to fp64 happens from here on)
     }
-    double ezd[3][3], ew[3];
+    double ezd[VDO_TILE_EPT][3], ew[VDO_TILE_EPT];
     if (!COMPACT) {
 #pragma unroll
-      for (int j = 0; j < 3; ++j) { ew[j] = h.ew[COMPACT ? 0 : j]; for (int k = 0; k < 3; ++k) ezd[j][k] = h.ezd[COMPACT ? 0 : j][k]; }
+      for (int j = 0; j < VDO_TILE_EPT; ++j) { ew[j] = h.ew[COMPACT ? 0 : j]; for (int k = 0; k < 3; ++k) ezd[j][k] = h.ezd[COMPACT ? 0 : j][k]; }
     }
     double chi = 0.0, rchi = 0.0;
     // ------------------------------------------------------------------ EdgeSE3PointXYZ
     {
       double acc[16];
-  #pragma unroll
+#pragma unroll
       for (int i = 0; i < 16; ++i) acc[i] = 0.0;
       const int slot = ecnt ? (ekey[0] >> 16) : -1;
       double Wp[12];                                 // W.r = R^T = Jl (row-major), W.t of the thread's slot
       {
         const double* Ws = slotW + 12 * (slot >= 0 ? slot : 0);
-  #pragma unroll
+#pragma unroll
         for (int i = 0; i < 12; ++i) Wp[i] = Ws[i];
       }
-  #pragma unroll
-      for (int j = 0; j < 3; ++j) {
+#pragma unroll
+      for (int j = 0; j < VDO_TILE_EPT; ++j) {
         if (j < ecnt) {
           const int e = e0 + j;
           const int lp = ekey[j] & 0xffff;
@@ -290,7 +290,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
           if (BUILD) {
             const double we = w * rho1;
             double* O = d.Oll + e;               // O = we * J1^T J2 = -we * Hi.r (p1 x p2)
-  #pragma unroll
+#pragma unroll
             for (int i = 0; i < 9; ++i) O[i * Et] = -we * Hi[i];
             // (H,p1): we * [I ; [v]x]   and   (H,p2): -we * [I ; [v]x] * Hi.r   -> both from (we, v)
             d.Finc[Eb + e] = we;

@@ -4,6 +4,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstdio>
+#include <cmath>
 #include <cstring>
 #include <numeric>
 #include <vector>
@@ -116,9 +117,9 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   Tile cur{};
   int cur_tile_id = 0, cur_npts = 0, cur_ninc = 0, cur_nb = 0;
   bool thr_overflow = false;
-  int cur_need = 0;                                // threads the open tile needs: sum over its pose slots of ceil(edges / 3)
+  int cur_need = 0;                                // threads the open tile needs: sum over its pose slots of ceil(edges / VDO_TILE_EPT)
   std::vector<int32_t> pose_cnt(P, 0), cnt_stamp(P, -1), chain_eb_poses;
-  std::vector<uint32_t> thr_tab;                   // per (tile, thread): (first EdgeSE3PointXYZ of the thread, ABSOLUTE index) << 2 | count (ba_dev.hpp)
+  std::vector<uint32_t> thr_tab;                   // per (tile, thread): (first EdgeSE3PointXYZ of the thread, ABSOLUTE index) << 3 | count (ba_dev.hpp)
   auto chain_poses = [&](const ChainInfo& ci, std::vector<int32_t>& outp) {
     outp.clear();
     for (int c = ci.head;;) {
@@ -153,9 +154,9 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       eb_key[en] = key;
       inc_key[inc_total + j] = key;
     }
-    {   // threads of the sweep: runs of equal pose slot cut into pieces of <= pb edges, pb the smallest of 1 .. 3 that fits 256 threads
+    {   // threads of the sweep: runs of equal pose slot cut into pieces of <= pb edges, pb the smallest of 1 .. VDO_TILE_EPT that fits 256 threads
       int pb = 1;
-      for (; pb < 3; ++pb) {
+      for (; pb < VDO_TILE_EPT; ++pb) {
         int need = 0;
         for (int j = 0; j < nb;) { int k = j; while (k < nb && g->eb_pose[tile_eb[k]] == g->eb_pose[tile_eb[j]]) ++k; need += (k - j + pb - 1) / pb; j = k; }
         if (need <= VDO_TILE_THREADS) break;
@@ -168,7 +169,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
         while (k < nb && g->eb_pose[tile_eb[k]] == g->eb_pose[tile_eb[j]]) ++k;
         for (int q = j; q < k; q += pb, ++t) {
           if (t >= VDO_TILE_THREADS) { thr_overflow = true; break; }
-          thr_tab[base + t] = ((uint32_t)(cur.eb_begin + q) << 2) | (uint32_t)std::min(pb, k - q);
+          thr_tab[base + t] = ((uint32_t)(cur.eb_begin + q) << 3) | (uint32_t)std::min(pb, k - q);
         }
         j = k;
       }
@@ -195,6 +196,17 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     cur_npts = 0; cur_ninc = 0; cur_nb = 0; cur_need = 0;
     cur_poses.clear(); tile_eb.clear(); tile_et.clear();
   };
+  // Incidences a tile is CLOSED at (soft; a single track may still take up to VDO_TILE_INC): VDO_TILE_EPT per thread spreads what a tile costs
+  // apart from its edges over more edges - right for graphs of many tiles; a small graph (the 60-frame window: 0.25 M incidences) would be left
+  // with fewer tiles than the device has CUs, so it gets smaller tiles: about four tiles per CU of a 256-CU device, not fewer than 2 edges per thread.
+  int soft_inc = VDO_TILE_INC;
+  {
+    const double total_inc = (double)Eb + 2.0 * (double)Et;
+    int ept = (int)std::ceil(total_inc / (VDO_TILE_THREADS * 1024.0));
+    if (const char* e = std::getenv("VDO_BA_TILE_EPT")) ept = std::atoi(e);
+    soft_inc = VDO_TILE_THREADS * std::min(std::max(ept, 2), VDO_TILE_EPT);
+    if (std::getenv("VDO_BA_TILE_EPT")) soft_inc = VDO_TILE_THREADS * std::min(std::max(ept, 1), VDO_TILE_EPT);
+  }
   std::vector<int32_t> cposes;
   for (const ChainInfo& ci : chains) {
     if (ci.npts > VDO_TILE_PTS || ci.ninc > VDO_TILE_INC) {
@@ -204,7 +216,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     }
     chain_poses(ci, cposes);
     {   // the track on its own must fit a tile (checked here, before anything is built, with a message that names the track):
-        // distinct pose vertices <= kHardSlots (LDS slots), and its EdgeSE3PointXYZ edges cut per pose into pieces of <= 3 must fit
+        // distinct pose vertices <= kHardSlots (LDS slots), and its EdgeSE3PointXYZ edges cut per pose into pieces of <= VDO_TILE_EPT must fit
         // the 256 threads of the sweep
       std::vector<int32_t> u(cposes);
       std::sort(u.begin(), u.end());
@@ -223,7 +235,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       }
       std::sort(chain_eb_poses.begin(), chain_eb_poses.end());
       int pieces = 0;
-      for (size_t j = 0; j < chain_eb_poses.size();) { size_t k = j; while (k < chain_eb_poses.size() && chain_eb_poses[k] == chain_eb_poses[j]) ++k; pieces += (int)((k - j + 2) / 3); j = k; }
+      for (size_t j = 0; j < chain_eb_poses.size();) { size_t k = j; while (k < chain_eb_poses.size() && chain_eb_poses[k] == chain_eb_poses[j]) ++k; pieces += (int)((k - j + VDO_TILE_EPT - 1) / VDO_TILE_EPT); j = k; }
       if (pieces > VDO_TILE_THREADS) {
         delete ba;
         return set_error(VDO_ERR_UNSUPPORTED, "landmark track of %d point(s) with %zu EdgeSE3PointXYZ observations needs %d per-pose pieces (limit %d per track)",
@@ -232,7 +244,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     }
     int newp = 0;
     for (int32_t p : cposes) if (pose_stamp[p] != cur_tile_id) ++newp;   // upper bound (duplicates inside the chain counted once below)
-    // (+ every thread of the sweep takes <= 3 edges of ONE pose slot: the sum over the slots of ceil(edges / 3) must fit the 256 threads)
+    // (+ every thread of the sweep takes <= VDO_TILE_EPT edges of ONE pose slot: the sum over the slots of ceil(edges / VDO_TILE_EPT) must fit the 256 threads)
     auto pieces_with_chain = [&](bool commit) {
       int need = cur_need;
       chain_eb_poses.clear();
@@ -244,14 +256,14 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       }
       for (int32_t p : chain_eb_poses) {
         if (cnt_stamp[p] != cur_tile_id) { cnt_stamp[p] = cur_tile_id; pose_cnt[p] = 0; }
-        if (pose_cnt[p] % 3 == 0) ++need;
+        if (pose_cnt[p] % VDO_TILE_EPT == 0) ++need;
         ++pose_cnt[p];
       }
       if (commit) cur_need = need;
       else for (int32_t p : chain_eb_poses) --pose_cnt[p];
       return need;
     };
-    if (cur_npts > 0 && (cur_npts + ci.npts > VDO_TILE_PTS || cur_ninc + ci.ninc > VDO_TILE_INC ||
+    if (cur_npts > 0 && (cur_npts + ci.npts > VDO_TILE_PTS || cur_ninc + ci.ninc > soft_inc ||
                          (int)cur_poses.size() + newp > kSoftSlots || pieces_with_chain(false) > VDO_TILE_THREADS))
       close_tile();
     if (cur_npts == 0) {
