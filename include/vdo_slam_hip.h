@@ -152,8 +152,10 @@ int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep);
  *         the pose blocks (k_finalize_pose) + pose-pose edges (k_posepose) + chi2 reduction,
  * and the layout figures the byte model of DESIGN.md 4.1 needs:
  *   dims[0] tiles, [1] (tile, pose-slot) pairs, [2] running sums per partial row (16 / 32), [3] max slots of a tile,
- *   [4] bytes read per EdgeSE3PointXYZ (key + measurement [+ weight]), [5] bytes read per ternary edge. */
-int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int64_t dims[6]);
+ *   [4] bytes read per EdgeSE3PointXYZ entry (key + measurement [+ weight]), [5] bytes read per ternary edge,
+ *   [6] EdgeSE3PointXYZ ENTRIES of the tiles' edge blocks (>= the graph's edges: every tile holds its edges as a padded block of
+ *       256 x (edges per thread) entries, thread-transposed, so that every load of a tile kernel is one contiguous row), [7] reserved (0). */
+int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int64_t dims[8]);
 /* One self-consistent linearisation in block form (BlockSolver::buildSystem) AT THE CURRENT ESTIMATE: the blocks of the last
  * vdo_ba_linearize when nothing moved the estimate since, else (after vdo_ba_optimize / vdo_ba_set_estimates) a fresh linearisation is
  * run first - collective on a sharded handle. */

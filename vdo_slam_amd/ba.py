@@ -84,11 +84,11 @@ class BatchBA:
 
     def profile_linearize(self, repeat: int = 10):
         """(ms of the sweep kernel alone, ms of a whole linearisation, layout dims) - vdo_ba_profile_linearize."""
-        ms = (C.c_float * 2)(); dims = (C.c_int64 * 6)()
+        ms = (C.c_float * 2)(); dims = (C.c_int64 * 8)()
         L = K.lib()
         L.vdo_ba_profile_linearize.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         K.check(L.vdo_ba_profile_linearize(self._h, repeat, ms, dims))
-        return float(ms[0]), float(ms[1]), dict(zip(("tiles", "slots", "partial_row", "max_slots", "read_bytes_eb", "read_bytes_et"), (int(v) for v in dims)))
+        return float(ms[0]), float(ms[1]), dict(zip(("tiles", "slots", "partial_row", "max_slots", "read_bytes_eb", "read_bytes_et", "eb_entries"), (int(v) for v in dims)))
 
     def dims(self) -> dict:
         """Layout facts of the tiled graph (tests): tiles, (tile, slot) pairs, ps_stride (= partial_row), max_slots, bytes read per edge."""
@@ -132,11 +132,13 @@ class BatchBA:
 
 def linearize_byte_model(graph, dims):
     """HBM bytes one linearisation has to move with this design - the floor the counters are compared with.
-    sweep: edge inputs + every point once + 1 KB of thread table and 48 B of descriptor per tile (reads); we per edge, the point-point block of a ternary edge, the landmark scalar +
+    sweep: the edge inputs of every ENTRY of the tiles' padded edge blocks (a few percent more than the edges) + every point once + 48 B of descriptor per
+    tile + pose id and row id per (tile, pose-slot) pair (reads); we per edge, the point-point block of a ternary edge, the landmark scalar +
     right-hand side per point, one row of running sums per (tile, pose-slot) pair (writes).  finalize: the rows again (read) + the
     6x6 block and right-hand side of every pose (write)."""
     row = 8 * dims["partial_row"]
-    sweep_r = dims["read_bytes_eb"] * graph.n_eb + dims["read_bytes_et"] * graph.n_et + 24 * graph.n_point + (4 * 256 + 48) * dims["tiles"] + 8 * dims["slots"]      # (+ thread table and descriptor of every tile, pose id and row id of every slot)
+    entries = dims.get("eb_entries") or graph.n_eb
+    sweep_r = dims["read_bytes_eb"] * entries + dims["read_bytes_et"] * graph.n_et + 24 * graph.n_point + 48 * dims["tiles"] + 8 * dims["slots"]
     sweep_w = 8 * (graph.n_eb + graph.n_et) + 72 * graph.n_et + 32 * graph.n_point + row * dims["slots"]
     fin = row * dims["slots"] + 336 * graph.n_pose
     return dict(sweep_read=int(sweep_r), sweep_write=int(sweep_w), sweep=int(sweep_r + sweep_w), finalize=int(fin), linearize=int(sweep_r + sweep_w + fin))

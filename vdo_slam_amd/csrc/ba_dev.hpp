@@ -10,7 +10,8 @@
 // wave-level segmented reduction into per-(tile,pose) partials, summed later in fixed order.
 //   pose    [P][12]      AoS (R row-major | t); few, L2-resident
 //   point   [L][3]       AoS, tile-major: read once per tile, coalesced
-//   edges   SoA, tile-major: key int32 (pose-slot<<16 | local point), z [3][E], w [E]
+//   edges   SoA, tile-major: key int32 (pose-slot<<16 | local point), z [3][E], w [E]; the EdgeSE3PointXYZ edges of a tile are a padded,
+//           thread-transposed block (Tile::ept): Eb counts block entries, not edges
 //   Finc    [Eb+Et]      FACTORED pose-x-point blocks, written once per sweep.  Every 6x3 block of
 //           Hpl is  s*we*[ I ; k[c]x ] * (R^T or I)  with c = the point in the pose's frame (zc resp.
 //           v = H^-1 p2) and R the pose rotation; c is a function of the point and the pose, both staged in LDS
@@ -37,7 +38,7 @@ struct Tile {
   int32_t inc_begin;              // incidences: [inc_begin, +nb) binary, then nt (p1), then nt (p2)
   int32_t slot_begin, slot_end;   // pose slots [slot_begin, slot_end) into tile_pose / part_* arrays
   int32_t chain_begin, chain_end; // chains [chain_begin, chain_end) into chain_off
-  int32_t pad;
+  int32_t ept;                    // EdgeSE3PointXYZ entries per thread of this tile's edge block: [eb_begin, eb_end) = 256 * ept entries, entry j * 256 + t = j-th edge of thread t (key -1: none)
 };
 
 struct BADev {
@@ -109,7 +110,6 @@ struct BADev {
   double *xp = nullptr, *rp = nullptr, *zp = nullptr, *pp = nullptr, *qp = nullptr, *bs = nullptr, *qs = nullptr;  // [6P]
   double* pp2 = nullptr;                             // [6P] second search-direction buffer (the PCG iterations ping-pong between pp and pp2)
   double *part_pq = nullptr, *part_rz = nullptr;     // [(P+3)/4] p.q per workgroup of k_pcg_q; [n_pchains] r.z per chain of k_pcg_chain
-  uint32_t* thr_tab = nullptr;                       // [n_tiles][256], launch order like tiles: thread t of the tile kernels takes (v & 7) <= VDO_TILE_EPT EdgeSE3PointXYZ edges of ONE pose slot from edge (v >> 3) (absolute)
   double* part_q = nullptr;                          // [NPS][8] pose-major rows (row slot_dst[s] of slot s), 6 used: Schur mat-vec partials
   double *part_m = nullptr, *part_m8 = nullptr;      // [NPS][16] + [NPS][8] pose-major rows: the 21 preconditioner partials of a slot (16 + 5)
   double* scal = nullptr;

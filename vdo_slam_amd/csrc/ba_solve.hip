@@ -225,7 +225,6 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // (head of a tile: every request unconditional and as early as its address is known - ba_sweep.hip)
   const int ti = blockIdx.x, tid = threadIdx.x;
-  const unsigned tt = d.thr_tab[(int64_t)ti * VDO_TILE_THREADS + tid];
   const Tile T = d.tiles[ti];
   const int nslot = T.slot_end - T.slot_begin, npts = T.pt_end - T.pt_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
@@ -233,19 +232,19 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   double* slotW = accm + 21 * d.max_slots;   // [12 * S]
   double* pts = slotW + 12 * d.max_slots;    // [3 * TP]
   const int my_slot = min(tid, max(nslot - 1, 0));
-  const int my_pose = d.tile_pose[T.slot_begin + my_slot];
+  int my_pose = d.tile_pose[T.slot_begin + my_slot];
   double pvl[3];
   {
     const double* __restrict__ point = d.point[0] + 3 * (int64_t)T.pt_begin;
 #pragma unroll
     for (int k = 0; k < 3; ++k) pvl[k] = point[min(tid + k * VDO_TILE_THREADS, 3 * npts - 1)];
   }
-  __builtin_amdgcn_sched_barrier(0);
-  const int e0 = (int)(tt >> 3), ecnt = (int)(tt & 7u);
+  // this thread's EdgeSE3PointXYZ incidences: rows of its column of the tile's edge block (ba_dev.hpp Tile::ept), one contiguous row per load
+  const int ebase = (T.ept ? T.eb_begin : 0) + tid, jmax = max(T.ept - 1, 0);
   int keyb[VDO_TILE_EPT];
   double web[VDO_TILE_EPT];
 #pragma unroll
-  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int e = e0 + (q < ecnt ? q : 0); keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }
+  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int e = ebase + min(q, jmax) * VDO_TILE_THREADS; keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }
   for (int i = tid; i < 21 * nslot; i += VDO_TILE_THREADS) accm[i] = 0.0;
   auto stage_slot = [&](int sidx, int pid) {
     const IsoD W = iso_inv(iso_load(d.pose[0] + 12 * (int64_t)pid));
@@ -254,13 +253,17 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
     for (int i = 0; i < 9; ++i) o[i] = W.r[i];
     o[9] = W.t.x; o[10] = W.t.y; o[11] = W.t.z;
   };
+  asm volatile("" : "+v"(my_pose));         // (keeps the request where it was made: the compiler would sink it into the branch, behind a wait for every other request)
   if (tid < nslot) stage_slot(tid, my_pose);
   for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
   // what hangs on the keys: is the point a chain of its own, and its scalar factor
   unsigned char sgl[VDO_TILE_EPT];
   double dsc[VDO_TILE_EPT];
 #pragma unroll
-  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int64_t l = T.pt_begin + (keyb[q] & 0xffff); sgl[q] = d.pt_single[l]; dsc[q] = d.dscal[l]; }
+  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int64_t l = T.pt_begin + (keyb[q] >= 0 ? (keyb[q] & 0xffff) : 0); sgl[q] = d.pt_single[l]; dsc[q] = d.dscal[l]; }
+  int ecnt = 0;
+#pragma unroll
+  for (int q = 0; q < VDO_TILE_EPT; ++q) ecnt += (q < T.ept && keyb[q] >= 0) ? 1 : 0;
 #pragma unroll
   for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pvl[k]; }
   __syncthreads();
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
 #pragma unroll
     for (int q = 0; q < VDO_TILE_EPT; ++q) {
       if (q < ecnt) {
-        const int j = e0 - T.eb_begin + q;
+        const int j = q * VDO_TILE_THREADS + tid;
         const int key = keyb[q];
         slot = key >> 16;
         const int64_t l = T.pt_begin + (key & 0xffff);
@@ -802,9 +805,8 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // The head of a tile is a chain of dependent loads (ba_sweep.hip, same order here): every request is UNCONDITIONAL (clamped index: a load
   // under a branch is waited for at the end of the branch) and made as soon as its address is known -
-  //   thread table entry -> this thread's <= VDO_TILE_EPT EdgeSE3PointXYZ incidences (key, we) ;  descriptor -> slot pose ids, points -> poses, v of the slots.
+  //   descriptor -> this thread's <= VDO_TILE_EPT EdgeSE3PointXYZ incidences (key, we), slot pose ids, points -> poses, v of the slots.
   const int tid = threadIdx.x;
-  const unsigned tt = d.thr_tab[(int64_t)blockIdx.x * VDO_TILE_THREADS + tid];
   if (MODE == 0 && d.flags[1]) return;     // PCG already converged: the launches queued behind it are no-ops
   const Tile T = d.tiles[blockIdx.x];                      // (launch order: tiles with the longest landmark chains first - their serial solves would be the tail of the launch)
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
@@ -815,23 +817,22 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   double* slotW = qs + 6 * d.max_slots;    // [12*S] inverse poses of the slots (R^T | -R^T t)
   double* pts = slotW + 12 * d.max_slots;  // [3*TP]  the tile's points (linearisation point)
   const int my_slot = min(tid, max(nslot - 1, 0));         // (tile_pose carries one entry of padding)
-  const int my_pose = d.tile_pose[T.slot_begin + my_slot];
+  int my_pose = d.tile_pose[T.slot_begin + my_slot];
   double pvl[3];
   {
     const double* __restrict__ point = d.point[0] + 3 * (int64_t)T.pt_begin;
 #pragma unroll
     for (int k = 0; k < 3; ++k) pvl[k] = point[min(tid + k * VDO_TILE_THREADS, 3 * npts - 1)];
   }
-  __builtin_amdgcn_sched_barrier(0);       // (the requests above are made before the wait for the table entry)
-  // EdgeSE3PointXYZ incidences by the sweep's thread table: <= VDO_TILE_EPT consecutive ones of ONE pose slot per thread (absolute edge index; the key of
-  // such an incidence is the eb_key of its edge); c is formed behind the staging barrier; the slot's inverse pose and its part of v are read
-  // once, the thread's B w add up in registers and go through ONE segmented scan.  The incidences of the ternary edges (dynamic tiles only)
-  // follow in strided loops, one scan per round.
-  const int e0 = (int)(tt >> 3), ecnt = (int)(tt & 7u);
+  // EdgeSE3PointXYZ incidences: <= Tile::ept consecutive ones (pose-sorted order) of ONE pose slot per thread = the rows of its column of the
+  // tile's edge block, one contiguous row per load (the key of such an incidence is the eb_key of its edge); c is formed behind the staging
+  // barrier; the slot's inverse pose and its part of v are read once, the thread's B w add up in registers and go through ONE segmented
+  // scan.  The incidences of the ternary edges (dynamic tiles only) follow in strided loops, one scan per round.
+  const int ebase = (T.ept ? T.eb_begin : 0) + tid, jmax = max(T.ept - 1, 0);
   int keyb[VDO_TILE_EPT];
   double web[VDO_TILE_EPT];
 #pragma unroll
-  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int e = e0 + (q < ecnt ? q : 0); keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }      // (eb_key has >= 1 entry)
+  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int e = ebase + min(q, jmax) * VDO_TILE_THREADS; keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }      // (eb_key has >= 1 entry)
   for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) u[i] = 0.0;
   if (MODE != 2)
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) qs[i] = 0.0;
@@ -851,11 +852,15 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
       for (int i = 0; i < 6; ++i) vs[6 * sidx + i] = v[6 * (int64_t)pid + i];
     }
   };
+  asm volatile("" : "+v"(my_pose));         // (keeps the request where it was made: the compiler would sink it into the branch, behind a wait for every other request)
   if (tid < nslot) stage_slot(tid, my_pose);
   for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
 #pragma unroll
   for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pvl[k]; }
   __syncthreads();
+  int ecnt = 0;
+#pragma unroll
+  for (int q = 0; q < VDO_TILE_EPT; ++q) ecnt += (q < T.ept && keyb[q] >= 0) ? 1 : 0;
   const int slotb = ecnt ? (keyb[0] >> 16) : -1;
   // The slot's inverse pose and c = W p + t_W of the thread's incidences are formed where they are used - in pass A and again in pass C -
   // instead of living across the chain solves between the two: those hold the kernel's register peak (four 3x3 factors in flight), and
@@ -1218,6 +1223,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_expand_binc(BADev d) {
     int kind; int64_t fidx;
     inc_locate(T, li, d.Eb, kind, fidx);
     const int key = d.inc_key[T.inc_begin + li];
+    if (key < 0) continue;                  // (an entry of the tile's edge block without an edge)
     const int sl = key >> 16;
     double B[18];
     expand_block(kind, make_f(d, T, li, kind, key, d.Finc[fidx], slotW, pts), slotW + 12 * sl, B);

@@ -104,11 +104,12 @@ struct SweepHead {
   double ezd[COMPACT ? 1 : VDO_TILE_EPT][3], ew[COMPACT ? 1 : VDO_TILE_EPT];
 };
 // Every load of the head is UNCONDITIONAL, from a clamped index (a load under a branch is waited for at the end of that branch: the three edges of
-// a thread were three round trips in a row in the round-3 form), and made as early as its address is known:
-//   thread table entry (address = block id, thread id) -> this thread's edges ;  descriptor (scalar) -> slot pose ids, row ids, points (-> poses)
+// a thread were three round trips in a row in the round-3 form), and everything hangs on the descriptor alone (one scalar load):
+//   descriptor -> slot pose ids, row ids, points (-> poses) ;  descriptor -> this thread's edges: entry j * 256 + thread of the tile's edge block,
+//   i.e. every load is one contiguous row of 256 entries (ba_dev.hpp Tile::ept; no thread table).
 // Values stay as loaded (fp32) until they are used behind the staging barrier.
 template <bool BUILD, bool COMPACT>
-__device__ __forceinline__ void sweep_request(const BADev& d, const Tile& T, unsigned tt, int which, int tid, SweepHead<COMPACT>& h) {
+__device__ __forceinline__ void sweep_request(const BADev& d, const Tile& T, int which, int tid, SweepHead<COMPACT>& h) {
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
   const double* __restrict__ point = d.point[which] + 3 * (int64_t)T.pt_begin;
   const int64_t Eb = d.Eb;
@@ -118,23 +119,22 @@ __device__ __forceinline__ void sweep_request(const BADev& d, const Tile& T, uns
   if (BUILD) h.my_dst = d.slot_dst[T.slot_begin + my_slot];
 #pragma unroll
   for (int k = 0; k < 3; ++k) h.pv[k] = point[min(tid + k * VDO_TILE_THREADS, 3 * npts - 1)];
-  __builtin_amdgcn_sched_barrier(0);                      // (the requests above are made BEFORE the wait for the table entry that the ones below need)
-  const int e0 = (int)(tt >> 3), ecnt = (int)(tt & 7u);
+  const int ebase = (T.ept ? T.eb_begin : 0) + tid, jmax = max(T.ept - 1, 0);        // (rows past the tile's last one repeat it; a tile without edges reads entry `tid` of the first block)
   if (COMPACT) {                                          // 16 B per edge: one information scalar per edge class, fp32 measurements (ba_dev.hpp); Eb > 0
 #pragma unroll
     for (int j = 0; j < VDO_TILE_EPT; ++j) {
-      const int e = e0 + (j < ecnt ? j : 0);
+      const int e = ebase + min(j, jmax) * VDO_TILE_THREADS;
       h.ekey[j] = d.eb_key[e];
 #pragma unroll
       for (int k = 0; k < 3; ++k) h.ezf[j][k] = d.eb_zf[k * Eb + e];
     }
   } else {
 #pragma unroll
-    for (int j = 0; j < VDO_TILE_EPT; ++j) { h.ekey[j] = 0; h.ew[j] = 0.0; h.ezd[j][0] = h.ezd[j][1] = h.ezd[j][2] = 0.0; }
-    if (T.eb_end > T.eb_begin) {                          // (uniform; with it e0 is a valid index whatever ecnt is)
+    for (int j = 0; j < VDO_TILE_EPT; ++j) { h.ekey[j] = -1; h.ew[j] = 0.0; h.ezd[j][0] = h.ezd[j][1] = h.ezd[j][2] = 0.0; }
+    if (T.ept > 0) {                                      // (uniform)
 #pragma unroll
       for (int j = 0; j < VDO_TILE_EPT; ++j) {
-        const int e = e0 + (j < ecnt ? j : 0);
+        const int e = ebase + min(j, jmax) * VDO_TILE_THREADS;
         h.ekey[j] = d.eb_key[e];
 #pragma unroll
         for (int k = 0; k < 3; ++k) h.ezd[j][k] = d.eb_zf ? (double)d.eb_zf[k * Eb + e] : d.eb_z[k * Eb + e];
@@ -172,13 +172,11 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
   const int64_t Eb = d.Eb, Et = d.Et;
   // ---- The head of a tile is a chain of dependent loads, each an HBM round trip of 2-3 k cycles (phase probe, DESIGN.md 4.1: head + staging +
   // barrier were half of a tile's 21 k cycles in the round-3 form): sweep_request.
-  const unsigned tt = d.thr_tab[(int64_t)ti * VDO_TILE_THREADS + tid];
   const Tile T = d.tiles[ti];
   SweepHead<COMPACT> h;
-  sweep_request<BUILD, COMPACT>(d, T, tt, which, tid, h);
+  sweep_request<BUILD, COMPACT>(d, T, which, tid, h);
   {
     const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
-    const int e0 = (int)(tt >> 3), ecnt = (int)(tt & 7u);
     SW_TICK(0);
     // ---- inverse poses of the slots; points -> LDS; zero accumulators
     auto stage_slot = [&](int sidx, int pid) {
@@ -188,6 +186,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
       for (int i = 0; i < 9; ++i) o[i] = W.r[i];
       o[9] = W.t.x; o[10] = W.t.y; o[11] = W.t.z;
     };
+    asm volatile("" : "+v"(h.my_pose));                  // (keeps the request of the pose id where it was made - the compiler would sink it into the branch below, behind a wait for every other request)
     if (tid < nslot) stage_slot(tid, h.my_pose);
     if (BUILD) sdst[min(tid, max(nslot - 1, 0))] = h.my_dst;     // (by every thread - the clamped ones repeat the last slot: keeps the request out of the branch above)
     for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) {       // (more than 256 slots in a tile: not in any graph of the bench)
@@ -211,6 +210,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
 #pragma unroll
       for (int k = 0; k < 3; ++k) { ezf[j][k] = COMPACT ? h.ezf[COMPACT ? j : 0][k] : 0.f; if (COMPACT) asm volatile("" : "+v"(ezf[j][k])); }      // (opaque: the widening to fp64 happens from here on)
     }
+    int ecnt = 0;                                         // (a thread's edges are rows 0 .. ecnt - 1 of its column of the block)
+#pragma unroll
+    for (int j = 0; j < VDO_TILE_EPT; ++j) ecnt += (j < T.ept && ekey[j] >= 0) ? 1 : 0;
     double ezd[VDO_TILE_EPT][3], ew[VDO_TILE_EPT];
     if (!COMPACT) {
 #pragma unroll
@@ -232,7 +234,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
 #pragma unroll
       for (int j = 0; j < VDO_TILE_EPT; ++j) {
         if (j < ecnt) {
-          const int e = e0 + j;
+          const int e = T.eb_begin + j * VDO_TILE_THREADS + tid;
           const int lp = ekey[j] & 0xffff;
           const double w = COMPACT ? d.eb_w_uni : ew[j];
           const D3 z = COMPACT ? D3{(double)ezf[j][0], (double)ezf[j][1], (double)ezf[j][2]} : D3{ezd[j][0], ezd[j][1], ezd[j][2]};

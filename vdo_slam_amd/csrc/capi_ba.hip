@@ -109,7 +109,8 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   std::vector<int32_t> cur_poses;
   std::vector<int32_t> eb_old_of_new; eb_old_of_new.reserve(Eb);
   std::vector<int32_t> et_old_of_new; et_old_of_new.reserve(Et);
-  std::vector<int32_t> eb_key(Eb), et_key(Et), et_slot(Et), inc_key((size_t)Eb + 2 * (size_t)Et);
+  std::vector<int32_t> eb_key, et_key(Et), et_slot(Et), inc_key;      // (eb_key / inc_key grow with the padded edge blocks of the tiles)
+  eb_key.reserve((size_t)Eb + Eb / 8); inc_key.reserve((size_t)Eb + Eb / 8 + 2 * (size_t)Et);
   std::vector<int32_t> pt_prev_edge_new; pt_prev_edge_new.reserve(L);
   std::vector<int32_t> et_new_of_old(Et, -1);
   std::vector<int32_t> tile_eb, tile_et;           // original ids of the open tile
@@ -119,7 +120,6 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   bool thr_overflow = false;
   int cur_need = 0;                                // threads the open tile needs: sum over its pose slots of ceil(edges / VDO_TILE_EPT)
   std::vector<int32_t> pose_cnt(P, 0), cnt_stamp(P, -1), chain_eb_poses;
-  std::vector<uint32_t> thr_tab;                   // per (tile, thread): (first EdgeSE3PointXYZ of the thread, ABSOLUTE index) << 3 | count (ba_dev.hpp)
   auto chain_poses = [&](const ChainInfo& ci, std::vector<int32_t>& outp) {
     outp.clear();
     for (int c = ci.head;;) {
@@ -142,34 +142,42 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     auto slot_of = [&](int32_t p) { return (int32_t)(std::lower_bound(cur_poses.begin(), cur_poses.end(), p) - cur_poses.begin()); };
     std::stable_sort(tile_eb.begin(), tile_eb.end(), [&](int a, int b) { return g->eb_pose[a] < g->eb_pose[b]; });
     std::stable_sort(tile_et.begin(), tile_et.end(), [&](int a, int b) { return g->et_pose[a] < g->et_pose[b]; });
+    // EdgeSE3PointXYZ edges of the tile: a PADDED block of 256 x ept entries in thread-transposed order - entry j * 256 + t is the j-th edge of
+    // thread t - so that the tile kernels need no thread table and every load of theirs is one contiguous 256-lane row (with the edges in
+    // pose-sorted order and a table of first-edge indices, the six loads of a thread's edges touched the same 12 cache lines six times: the
+    // head of a tile took 7 k cycles at six edges per thread).  Every thread takes <= ept consecutive edges (pose-sorted order) of ONE pose
+    // slot: runs of equal slot are cut into pieces of <= ept, ept the smallest of 1 .. VDO_TILE_EPT that fits 256 threads; unused entries
+    // carry key -1.
     cur.eb_begin = (int32_t)eb_old_of_new.size();
     cur.et_begin = (int32_t)et_old_of_new.size();
     cur.inc_begin = inc_total;
-    const int nb = (int)tile_eb.size(), nt = (int)tile_et.size();
-    for (int j = 0; j < nb; ++j) {
-      const int e = tile_eb[j];
-      const int en = (int)eb_old_of_new.size();
-      eb_old_of_new.push_back(e);
-      const int32_t key = (slot_of(g->eb_pose[e]) << 16) | (pt_new_of_old[g->eb_point[e]] - cur.pt_begin);
-      eb_key[en] = key;
-      inc_key[inc_total + j] = key;
+    const int nb_real = (int)tile_eb.size(), nt = (int)tile_et.size();
+    int pb = 1;
+    for (; pb < VDO_TILE_EPT; ++pb) {
+      int need = 0;
+      for (int j = 0; j < nb_real;) { int k = j; while (k < nb_real && g->eb_pose[tile_eb[k]] == g->eb_pose[tile_eb[j]]) ++k; need += (k - j + pb - 1) / pb; j = k; }
+      if (need <= VDO_TILE_THREADS) break;
     }
-    {   // threads of the sweep: runs of equal pose slot cut into pieces of <= pb edges, pb the smallest of 1 .. VDO_TILE_EPT that fits 256 threads
-      int pb = 1;
-      for (; pb < VDO_TILE_EPT; ++pb) {
-        int need = 0;
-        for (int j = 0; j < nb;) { int k = j; while (k < nb && g->eb_pose[tile_eb[k]] == g->eb_pose[tile_eb[j]]) ++k; need += (k - j + pb - 1) / pb; j = k; }
-        if (need <= VDO_TILE_THREADS) break;
-      }
-      const size_t base = thr_tab.size();
-      thr_tab.resize(base + VDO_TILE_THREADS, 0);
+    const int nb = nb_real ? VDO_TILE_THREADS * pb : 0;     // entries of the block
+    cur.ept = nb_real ? pb : 0;
+    eb_old_of_new.resize((size_t)cur.eb_begin + nb, -1);
+    eb_key.resize((size_t)cur.eb_begin + nb, -1);
+    inc_key.resize((size_t)inc_total + nb + 2 * (size_t)nt, -1);
+    {
       int t = 0;
-      for (int j = 0; j < nb;) {
+      for (int j = 0; j < nb_real;) {
         int k = j;
-        while (k < nb && g->eb_pose[tile_eb[k]] == g->eb_pose[tile_eb[j]]) ++k;
+        while (k < nb_real && g->eb_pose[tile_eb[k]] == g->eb_pose[tile_eb[j]]) ++k;
         for (int q = j; q < k; q += pb, ++t) {
           if (t >= VDO_TILE_THREADS) { thr_overflow = true; break; }
-          thr_tab[base + t] = ((uint32_t)(cur.eb_begin + q) << 3) | (uint32_t)std::min(pb, k - q);
+          for (int i = 0; i < pb && q + i < k; ++i) {
+            const int e = tile_eb[q + i];
+            const int pos = i * VDO_TILE_THREADS + t;
+            const int32_t key = (slot_of(g->eb_pose[e]) << 16) | (pt_new_of_old[g->eb_point[e]] - cur.pt_begin);
+            eb_old_of_new[(size_t)cur.eb_begin + pos] = e;
+            eb_key[(size_t)cur.eb_begin + pos] = key;
+            inc_key[(size_t)inc_total + pos] = key;
+          }
         }
         j = k;
       }
@@ -297,12 +305,15 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   const int n_tiles = (int)tiles.size(), NPS = (int)tile_pose.size(), n_chains = (int)chain_off.size() - 1;
 
   // ---- permuted edge / vertex data
-  std::vector<double> point_new(3 * (size_t)L), eb_z(3 * (size_t)Eb), eb_w(Eb), et_z(3 * (size_t)Et), et_w(Et);
+  // (Ebp: entries of the padded edge blocks = the device's edge index space; entries without an edge keep zeros)
+  const int Ebp = (int)eb_old_of_new.size();
+  std::vector<double> point_new(3 * (size_t)L), eb_z(3 * (size_t)Ebp, 0.0), eb_w(Ebp, 0.0), et_z(3 * (size_t)Et), et_w(Et);
   std::vector<float> eb_zf_host;                   // (function scope: alive until the uploads have been synchronised)
   for (int l = 0; l < L; ++l) for (int k = 0; k < 3; ++k) point_new[3 * (size_t)l + k] = g->point[3 * (size_t)pt_old_of_new[l] + k];
-  for (int e = 0; e < Eb; ++e) {
+  for (int e = 0; e < Ebp; ++e) {
     const int o = eb_old_of_new[e];
-    for (int k = 0; k < 3; ++k) eb_z[(size_t)k * Eb + e] = g->eb_z[(size_t)k * Eb + o];
+    if (o < 0) continue;
+    for (int k = 0; k < 3; ++k) eb_z[(size_t)k * Ebp + e] = g->eb_z[(size_t)k * Eb + o];
     eb_w[e] = g->eb_w[o];
   }
   for (int e = 0; e < Et; ++e) {
@@ -402,7 +413,8 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     ba->pose_graph_is_paths = paths;
   }
   // incidence index of every (new) edge, for the un-permuting download
-  ba->inc_of_eb.resize(Eb); ba->inc1_of_et.resize(Et); ba->inc2_of_et.resize(Et);
+  ba->inc_of_eb.resize(Ebp); ba->inc1_of_et.resize(Et); ba->inc2_of_et.resize(Et);
+  ba->n_eb = Eb;
   for (const Tile& T : tiles) {
     const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
     for (int j = 0; j < nb; ++j) ba->inc_of_eb[T.eb_begin + j] = T.inc_begin + j;
@@ -413,7 +425,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
 
   hipStream_t s = ctx->stream;
   BADev& d = ba->d;
-  d.P = P; d.L = L; d.Eb = Eb; d.Et = Et; d.Ep = Ep; d.Npr = Npr; d.Ninc = Eb + 2 * Et;
+  d.P = P; d.L = L; d.Eb = Ebp; d.Et = Et; d.Ep = Ep; d.Npr = Npr; d.Ninc = Ebp + 2 * Et;
   d.n_tiles = n_tiles; d.NPS = NPS; d.n_chains = n_chains; d.max_slots = max_slots;
   d.huber_eb = g->huber_eb; d.huber_et = g->huber_et; d.huber_ep = g->huber_ep;
   d.dsqr_eb = (double)(float)(g->huber_eb * g->huber_eb);   // float member, robust_kernel_impl.h:84
@@ -424,21 +436,15 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   tile_pose.push_back(0);                          // (one entry of padding: the tile kernels read slot min(thread, slots - 1) unconditionally, also for a tile without slots)
   UP(tile_pose, tile_pose.data(), tile_pose.size());
   {
-    // The device holds the tile descriptors and the thread tables in LAUNCH order (tiles with the longest landmark chain first: their serial
-    // solves would be the tail of a launch; they are also the ones with ternary edges, ~1.5x the work in the sweep): workgroup b reads
-    // descriptor b and table b straight from its block id - no order array in front of them, and a table entry is an absolute edge index, so
-    // the edge loads of a thread wait for ONE load, not for order -> descriptor -> table (the head of a tile was a quarter of its time).
+    // The device holds the tile descriptors in LAUNCH order (tiles with the longest landmark chain first: their serial solves would be the
+    // tail of a launch; they are also the ones with ternary edges, ~1.5x the work in the sweep): workgroup b reads descriptor b straight from
+    // its block id - no order array in front of it (the chain of dependent loads at the head of a tile was a quarter of its time).
     std::vector<int32_t> order(std::max(n_tiles, 1), 0), longest(std::max(n_tiles, 1), 0);
     for (int t = 0; t < n_tiles; ++t) { order[t] = t; for (int c = tiles[t].chain_begin; c < tiles[t].chain_end; ++c) longest[t] = std::max(longest[t], chain_off[c + 1] - chain_off[c]); }
     if (!std::getenv("VDO_BA_TILE_ORDER_IDENTITY")) std::stable_sort(order.begin(), order.begin() + n_tiles, [&](int a, int b) { return longest[a] > longest[b]; });
     std::vector<Tile> tiles_l(std::max(n_tiles, 1));
-    std::vector<uint32_t> thr_l((size_t)std::max(n_tiles, 1) * VDO_TILE_THREADS, 0u);
-    for (int b = 0; b < n_tiles; ++b) {
-      tiles_l[b] = tiles[order[b]];
-      std::copy(thr_tab.begin() + (size_t)order[b] * VDO_TILE_THREADS, thr_tab.begin() + (size_t)(order[b] + 1) * VDO_TILE_THREADS, thr_l.begin() + (size_t)b * VDO_TILE_THREADS);
-    }
+    for (int b = 0; b < n_tiles; ++b) tiles_l[b] = tiles[order[b]];
     UP(tiles, tiles_l.data(), tiles_l.size());
-    UP(thr_tab, thr_l.data(), thr_l.size());
   }
   UP(chain_off, chain_off.data(), chain_off.size()); UP(pt_prev_edge, pt_prev_edge_new.data(), L);
   {
@@ -446,21 +452,21 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     for (int c = 0; c < n_chains; ++c) if (chain_off[c + 1] - chain_off[c] == 1) single[chain_off[c]] = 1;
     UP(pt_single, single.data(), single.size());
   }
-  eb_key.resize(std::max<size_t>(eb_key.size(), 1), 0);      // (>= 1 entry: the tile kernels load a thread's edges from clamped indices, unconditionally)
+  eb_key.resize(std::max<size_t>(eb_key.size(), 1), -1);     // (>= 1 entry: the tile kernels load a thread's edges from clamped indices, unconditionally)
   UP(eb_key, eb_key.data(), eb_key.size());
   UP(et_key, et_key.data(), Et); UP(et_slot, et_slot.data(), Et);
   {
     // compact edge inputs where they are lossless (ba_dev.hpp): one information scalar per edge class, fp32 measurements
     const bool force_general = std::getenv("VDO_BA_GENERAL_EDGES") != nullptr;
     bool wb_uni = Eb > 0 && !force_general, wt_uni = Et > 0 && !force_general, zb_f32 = Eb > 0 && !force_general, zt_zero = Et > 0 && !force_general;
-    for (int e = 1; e < Eb && wb_uni; ++e) wb_uni = eb_w[e] == eb_w[0];
+    for (int e = 1; e < Eb && wb_uni; ++e) wb_uni = g->eb_w[e] == g->eb_w[0];
     for (int e = 1; e < Et && wt_uni; ++e) wt_uni = et_w[e] == et_w[0];
-    for (size_t i = 0; i < 3 * (size_t)Eb && zb_f32; ++i) zb_f32 = eb_z[i] == (double)(float)eb_z[i];
+    for (size_t i = 0; i < 3 * (size_t)Ebp && zb_f32; ++i) zb_f32 = eb_z[i] == (double)(float)eb_z[i];
     for (size_t i = 0; i < 3 * (size_t)Et && zt_zero; ++i) zt_zero = et_z[i] == 0.0;
-    if (wb_uni) d.eb_w_uni = eb_w[0]; else UP(eb_w, eb_w.data(), Eb);
+    if (wb_uni) d.eb_w_uni = g->eb_w[0]; else UP(eb_w, eb_w.data(), Ebp);
     if (wt_uni) d.et_w_uni = et_w[0]; else UP(et_w, et_w.data(), Et);
     if (zb_f32) { eb_zf_host.assign(eb_z.begin(), eb_z.end()); UP(eb_zf, eb_zf_host.data(), eb_zf_host.size()); }
-    else UP(eb_z, eb_z.data(), 3 * (size_t)Eb);
+    else UP(eb_z, eb_z.data(), 3 * (size_t)Ebp);
     if (!zt_zero) UP(et_z, et_z.data(), 3 * (size_t)Et);
     ba->compact_edges = (wb_uni ? 1 : 0) | (zb_f32 ? 2 : 0) | (wt_uni ? 4 : 0) | (zt_zero ? 8 : 0);
   }
@@ -488,7 +494,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   ba->d.bp = ba->d.Hpp + 36 * (size_t)P; ba->d.red_chi = ba->d.bp + 6 * (size_t)P;
   UP(msum, Z, 21 * (size_t)P + 1);
   UP(Hll, Z, (size_t)L); UP(bl, Z, 3 * (size_t)L);
-  UP(Finc, Z, (size_t)Eb + (size_t)Et + 1); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep); UP(ep_blk, Z, 84 * (size_t)std::max(Ep + Npr, 1));
+  UP(Finc, Z, (size_t)Ebp + (size_t)Et + 1); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep); UP(ep_blk, Z, 84 * (size_t)std::max(Ep + Npr, 1));
   UP(part_sums, Z, (size_t)ps_stride * (size_t)std::max(NPS, 1));
   UP(part_chi, Z, 2 * (size_t)n_tiles + 2 * (size_t)(Ep + Npr) + 2);
   UP(part_red, Z, 256);
@@ -560,7 +566,7 @@ extern "C" int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep) {
   return sync_check(ba, "vdo_ba_linearize");
 }
 
-extern "C" int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int64_t dims[6]) {
+extern "C" int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int64_t dims[8]) {
   if (!ba || !ms) return set_error(VDO_ERR_INVALID, "vdo_ba_profile_linearize: null argument");
   int rc = ctx_bind(ba->ctx);
   if (rc != VDO_OK) return rc;
@@ -581,6 +587,7 @@ extern "C" int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int
     dims[0] = d.n_tiles; dims[1] = d.NPS; dims[2] = d.ps_stride; dims[3] = d.max_slots;
     dims[4] = 4 + (d.eb_zf ? 12 : 24) + (d.eb_w ? 8 : 0);
     dims[5] = 8 + (d.et_z ? 24 : 0) + (d.et_w ? 8 : 0);
+    dims[6] = d.Eb; dims[7] = 0;
   }
   ba->lin_current = true;
   return sync_check(ba, "vdo_ba_profile_linearize");
@@ -617,13 +624,13 @@ extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
   D2H(ba->h_scal, d.scal, sizeof(double) * S_COUNT);
   rc = sync_check(ba, "vdo_ba_download_system");
   if (rc != VDO_OK) return rc;
-  const size_t N = d.Ninc, Eb = d.Eb, Et = d.Et;
+  const size_t N = d.Ninc, Ebp = d.Eb, Eb = (size_t)ba->n_eb, Et = d.Et;      // (Ebp: padded edge entries of the device, Eb: edges of the graph)
   if (out->Hll) for (int l = 0; l < d.L; ++l) { double* o = out->Hll + 9 * (size_t)ba->pt_old_of_new[l]; for (int i = 0; i < 9; ++i) o[i] = (i % 4 == 0) ? hll[(size_t)l] : 0.0; }
   if (out->bl) for (int l = 0; l < d.L; ++l) std::memcpy(out->bl + 3 * (size_t)ba->pt_old_of_new[l], bl.data() + 3 * (size_t)l, 24);
   if (out->Hll_et)
     for (size_t e = 0; e < Et; ++e) for (int i = 0; i < 9; ++i) out->Hll_et[i * Et + ba->et_old_of_new[e]] = oll[i * Et + e];
   if (out->Hpl_eb)
-    for (size_t e = 0; e < Eb; ++e) for (int i = 0; i < 18; ++i) out->Hpl_eb[i * Eb + ba->eb_old_of_new[e]] = binc[i * N + ba->inc_of_eb[e]];
+    for (size_t e = 0; e < Ebp; ++e) { if (ba->eb_old_of_new[e] < 0) continue; for (int i = 0; i < 18; ++i) out->Hpl_eb[i * Eb + ba->eb_old_of_new[e]] = binc[i * N + ba->inc_of_eb[e]]; }
   for (int rep = 0; rep < 2; ++rep) {
     double* dst = rep == 0 ? out->Hlp1_et : out->Hlp2_et;
     if (!dst) continue;
