@@ -56,15 +56,15 @@ def sequence_events(warmup, steps):
     return {drop_at: {1}, drop_at + 1: {1}}, leave_at, enter_at
 
 
-def _pmc_traffic_bytes(graph):
-    """HBM bytes per k_sweep_tile launch from the committed PMC summary, if it was taken on this very graph (else None)."""
+def _pmc_traffic_bytes(graph, dims):
+    """HBM bytes per k_sweep_tile launch from the committed PMC summary, if it was taken on this very graph AND this very tile layout (else None)."""
     import re
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_sweep_pmc_hbm_traffic.txt")
     try:
         txt = open(path).read()
-        m = re.search(r"n_eb (\d+) n_et (\d+) n_point (\d+)", txt)
+        m = re.search(r"n_eb (\d+) n_et (\d+) n_point (\d+) tiles (\d+) eb_entries (\d+)", txt)
         t = re.search(r"= ([0-9.]+) MB\s*$", txt, re.M)
-        if m and t and (int(m.group(1)), int(m.group(2)), int(m.group(3))) == (graph.n_eb, graph.n_et, graph.n_point):
+        if m and t and tuple(int(v) for v in m.groups()) == (graph.n_eb, graph.n_et, graph.n_point, dims["tiles"], dims["eb_entries"]):
             return float(t.group(1)) * 1e6
     except OSError:
         pass
@@ -605,15 +605,16 @@ def main():
         gr = synth.make_ba_graph(200, args.roofline_static, 10, 1500, seed=7 + rank)
         bar = BatchBA(ctx_ba, gr)
         bar.linearize()
+        bar.profile_linearize(10)                                 # untimed warm-up (clocks, TLBs): the first launches of a process run 10-15 % slower
         sweep_ms, lin_ms, dims = bar.profile_linearize(30)       # hipEvents on the stream the kernels run on (vdo_ba_profile_linearize)
         from vdo_slam_amd.ba import linearize_byte_model
         model = linearize_byte_model(gr, dims)
         alg_bytes = 208 * gr.n_eb + 452 * gr.n_et + 96 * gr.n_point     # SURVEY.md §8d B_sweep terms of this kernel
-        traffic = _pmc_traffic_bytes(gr)                                 # rocprofv3 --pmc passes over this kernel and graph, if committed for this layout
+        traffic = _pmc_traffic_bytes(gr, dims)                               # rocprofv3 --pmc passes over this kernel and graph, if committed for this layout
         used = traffic if traffic is not None else float(model["sweep"])
         achieved = used / (sweep_ms * 1e-3) / 1e9
         out["roofline"] = {
-            "bound": "hbm", "kernel": "k_sweep_tile<true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "bound": "hbm", "kernel": "k_sweep_tile<true, true>", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "frac_basis": "counters (2*FETCH_SIZE + WRITE_SIZE)" if traffic is not None else "model_bytes (no counter file for this layout)",
             "model_bytes": model, "avg_launch_ms": sweep_ms, "linearize_ms": lin_ms,
             "achieved_model": model["sweep"] / (sweep_ms * 1e-3) / 1e9, "frac_model": model["sweep"] / (sweep_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
@@ -624,7 +625,7 @@ def main():
                     "cannot exceed 1.  `survey_8d_rate` divides the bytes of SURVEY 8d's formula (208 B per EdgeSE3PointXYZ, 452 B per ternary edge, 96 B per point) "
                     "by the same time: the kernel moves a fifth of them (8 B of a 6x3 block instead of 144 B, 16 B of edge inputs instead of 64 B, one scalar for the "
                     "landmark block), so that rate is NOT a bandwidth.  `linearize_*`: sweep + expansion of the pose blocks + pose-pose edges + chi2 (one "
-                    "BlockSolver::buildSystem).  What bounds the sweep is VALU issue and per-tile latency, not HBM (DESIGN.md 4.1).",
+                    "BlockSolver::buildSystem).  What bounds the sweep is VALU issue (DESIGN.md 4.1).",
             "layout": dims,
             "traffic_source": ("profiles/r04_sweep_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/sweep_only.py on this very graph "
                                "(tools/profile_round4_sweep.sh); counters cannot be collected inside this run, the duration is live") if traffic is not None else None,

@@ -9,6 +9,6 @@ ctx = Context(0)
 ba = BatchBA(ctx, g)
 ms_sweep, ms_lin, dims = ba.profile_linearize(10)
 m = linearize_byte_model(g, dims)
-print("n_eb", g.n_eb, "n_et", g.n_et, "n_point", g.n_point, "alg_bytes", 208 * g.n_eb + 452 * g.n_et + 96 * g.n_point, "ms", ms_sweep)
+print("n_eb", g.n_eb, "n_et", g.n_et, "n_point", g.n_point, "tiles", dims["tiles"], "eb_entries", dims["eb_entries"], "alg_bytes", 208 * g.n_eb + 452 * g.n_et + 96 * g.n_point, "ms", ms_sweep)
 print("n_pose", g.n_pose, "dims", dims, "ms_sweep", ms_sweep, "ms_linearize", ms_lin)
 print("model_bytes", m)

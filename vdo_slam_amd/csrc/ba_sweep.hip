@@ -363,18 +363,24 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
 // + (chi_mode >= 0) the chi2 reduction of the whole linearisation in one extra workgroup: every partial it reads was written by an
 // earlier launch.
 __device__ void reduce_chi_body(const BADev& d, int mode, double* lds);
-__global__ __launch_bounds__(256) void k_finalize_pose(BADev d, int add_posepose, int chi_mode) {
+#define VDO_FIN_THREADS 512
+__global__ __launch_bounds__(VDO_FIN_THREADS) void k_finalize_pose(BADev d, int add_posepose, int chi_mode) {
+  __shared__ double lds[24];
+  __shared__ double part[VDO_FIN_THREADS / 64][32];
   if (chi_mode >= 0 && blockIdx.x == gridDim.x - 1) {
-    __shared__ double lds[24];
     reduce_chi_body(d, chi_mode, lds);
     return;
   }
-  const int p = blockIdx.x * 4 + (threadIdx.x >> 6);       // one wave per pose
-  if (p >= d.P) return;
-  // the pose's partial rows are contiguous (pose-major part_sums): the wave streams them, lane l always meets component l % stride
-  const int lane = threadIdx.x & 63, st = d.ps_stride;
-  const double* __restrict__ base = d.part_sums + (int64_t)d.ps_off[p] * st;
-  const int64_t n = (int64_t)(d.ps_off[p + 1] - d.ps_off[p]) * st;
+  // One WORKGROUP per pose: the pose's partial rows are contiguous (pose-major part_sums) and its waves stream a contiguous share each - lane l
+  // always meets component l % stride (shares start at multiples of 64 doubles) - then wave 0 adds the waves' sums in wave order.  (One wave per
+  // pose, round 3, left the linearisation of a graph of few cameras and many points waiting for ~200 waves that stream 150 KB each in a
+  // dependent loop: 72 us on the 13.3 M-edge graph.)
+  const int p = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, st = d.ps_stride;
+  const int rows = d.ps_off[p + 1] - d.ps_off[p], q = 64 / st;
+  const int share = ((rows + VDO_FIN_THREADS / 64 - 1) / (VDO_FIN_THREADS / 64) + q - 1) / q * q;      // rows per wave, a multiple of 64 doubles
+  const double* __restrict__ base = d.part_sums + ((int64_t)d.ps_off[p] + (int64_t)wv * share) * st;
+  const int64_t n = (int64_t)max(0, min(share, rows - wv * share)) * st;
   double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
   int64_t i = lane;
   for (; i + 192 < n; i += 256) { a0 += base[i]; a1 += base[i + 64]; a2 += base[i + 128]; a3 += base[i + 192]; }
@@ -382,6 +388,14 @@ __global__ __launch_bounds__(256) void k_finalize_pose(BADev d, int add_posepose
   double a = (a0 + a1) + (a2 + a3);
   a += __shfl_xor(a, 32, 64);
   if (st == 16) a += __shfl_xor(a, 16, 64);
+  if (lane < 32) part[wv][lane] = a;
+  __syncthreads();
+  if (wv != 0) return;
+  a = 0.0;
+  if (lane < 32) {
+#pragma unroll
+    for (int w = 0; w < VDO_FIN_THREADS / 64; ++w) a += part[w][lane];
+  }
   const int kind = d.pose_kind[p];
   double sb[16], stn[16];
 #pragma unroll
@@ -493,9 +507,9 @@ void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R) {
   // pose blocks = landmark-side sums + pose-pose blocks.  Shards: the (replicated) pose-pose terms are added by rank 0 only, the
   // all-reduce of Hpp | bp | chi2 then hands every rank the same bits.
   const int add_pp = (!d.sharded || d.shard_rank == 0) ? 1 : 0;
-  const int nb = (d.P + 3) / 4;
-  if (!d.sharded) { hipLaunchKernelGGL(k_finalize_pose, dim3(nb + 1), dim3(256), 0, s, d, add_pp, 0); return; }   // (+ the chi2 reduction in the last workgroup)
-  hipLaunchKernelGGL(k_finalize_pose, dim3(nb + 1), dim3(256), 0, s, d, add_pp, 1);
+  const int nb = d.P;                                      // one workgroup per pose
+  if (!d.sharded) { hipLaunchKernelGGL(k_finalize_pose, dim3(nb + 1), dim3(VDO_FIN_THREADS), 0, s, d, add_pp, 0); return; }   // (+ the chi2 reduction in the last workgroup)
+  hipLaunchKernelGGL(k_finalize_pose, dim3(nb + 1), dim3(VDO_FIN_THREADS), 0, s, d, add_pp, 1);
   R(d.Hpp, 42 * (int64_t)d.P + 2);
   hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 2);
 }
