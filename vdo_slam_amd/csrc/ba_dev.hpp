@@ -129,7 +129,7 @@ struct Reducer {
   void operator()(void* buf, int64_t n, int op = 0) const { if (fn && !err) err = fn(user, buf, n, op); }
 };
 
-enum Scal { S_CHI2 = 0, S_RCHI2, S_MAXDIAG, S_RZ, S_PQ, S_RZ0, S_SCALE, S_RZNEW, S_BETA, S_COUNT = 16 };
+enum Scal { S_CHI2 = 0, S_RCHI2, S_MAXDIAG, S_RZ, S_PQ, S_RZ0, S_SCALE, S_RZNEW, S_BETA, S_LIN_CHI2, S_LIN_RCHI2, S_COUNT = 16 };   // S_LIN_*: chi2 of the last LINEARISATION (kept while the trials' error evaluations overwrite S_CHI2 / S_RCHI2)
 
 // ---- ba_sweep.hip
 void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R);      // chi2 of estimate[which] -> scal

@@ -454,7 +454,9 @@ __global__ __launch_bounds__(VDO_FIN_THREADS) void k_finalize_pose(BADev d, int 
 // mode 0: single GPU, everything -> scal.   Shards: mode 1 = this rank's tiles -> red_chi (summed
 // across ranks by the hook), mode 2/3 = red_chi + the replicated pose-pose edges -> scal
 // (3 also publishes the all-reduced computeScale() partial that k_update left in red_chi[2]).
-__device__ void reduce_chi_body(const BADev& d, int mode, double* lds) {
+// (+ 8: the reduction belongs to a linearisation - the totals are also kept in S_LIN_CHI2 / S_LIN_RCHI2.)
+__device__ void reduce_chi_body(const BADev& d, int mode_lin, double* lds) {
+  const int mode = mode_lin & 7, lin = mode_lin >> 3;
   const int nt = d.n_tiles, n2 = d.Ep + d.Npr;
   const double* ep_chi = d.part_chi + 2 * (int64_t)nt;
   double a0 = 0, a1 = 0;
@@ -469,6 +471,7 @@ __device__ void reduce_chi_body(const BADev& d, int mode, double* lds) {
     else {
       if (mode >= 2) { a0 += d.red_chi[0]; a1 += d.red_chi[1]; }
       d.scal[S_CHI2] = a0; d.scal[S_RCHI2] = a1;
+      if (lin) { d.scal[S_LIN_CHI2] = a0; d.scal[S_LIN_RCHI2] = a1; }
       if (mode == 3) d.scal[S_SCALE] = d.red_chi[2];
     }
   }
@@ -508,10 +511,10 @@ void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R) {
   // all-reduce of Hpp | bp | chi2 then hands every rank the same bits.
   const int add_pp = (!d.sharded || d.shard_rank == 0) ? 1 : 0;
   const int nb = d.P;                                      // one workgroup per pose
-  if (!d.sharded) { hipLaunchKernelGGL(k_finalize_pose, dim3(nb + 1), dim3(VDO_FIN_THREADS), 0, s, d, add_pp, 0); return; }   // (+ the chi2 reduction in the last workgroup)
+  if (!d.sharded) { hipLaunchKernelGGL(k_finalize_pose, dim3(nb + 1), dim3(VDO_FIN_THREADS), 0, s, d, add_pp, 8); return; }   // (+ the chi2 reduction in the last workgroup)
   hipLaunchKernelGGL(k_finalize_pose, dim3(nb + 1), dim3(VDO_FIN_THREADS), 0, s, d, add_pp, 1);
   R(d.Hpp, 42 * (int64_t)d.P + 2);
-  hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 2);
+  hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 2 + 8);
 }
 
 }  // namespace vdo
