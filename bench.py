@@ -605,7 +605,8 @@ def main():
         gr = synth.make_ba_graph(200, args.roofline_static, 10, 1500, seed=7 + rank)
         bar = BatchBA(ctx_ba, gr)
         bar.linearize()
-        bar.profile_linearize(10)                                 # untimed warm-up (clocks, TLBs): the first launches of a process run 10-15 % slower
+        bar.profile_linearize(100)                                # untimed warm-up, ~40 ms of the same launches: the device has idled while the host built the graph, and its clocks take tens of
+                                                                  # milliseconds of load to come back (tools/sweep_repeat_probe.py: 0.140 ms per launch in the first 40 launches, 0.110-0.115 after 150)
         sweep_ms, lin_ms, dims = bar.profile_linearize(30)       # hipEvents on the stream the kernels run on (vdo_ba_profile_linearize)
         from vdo_slam_amd.ba import linearize_byte_model
         model = linearize_byte_model(gr, dims)

@@ -136,8 +136,8 @@ typedef struct vdo_lm_stats {
 typedef struct vdo_ba vdo_ba;
 /* Uploads the graph to HBM (SoA, resident until destroy) and builds the chain structure.
  * Limits (g2o has none; VDO_ERR_UNSUPPORTED names the offending track): a landmark track - one static point, or a chain of dynamic
- * points linked by LandmarkMotionTernaryEdges - is processed by ONE workgroup and must fit its tile: <= 256 points, <= 768 edge
- * incidences, <= 100 distinct pose vertices (cameras + motions), and sum over those poses of ceil(observations / 3) <= 256.  The graphs
+ * points linked by LandmarkMotionTernaryEdges - is processed by ONE workgroup and must fit its tile: <= 256 points, <= 1536 edge
+ * incidences, <= 100 distinct pose vertices (cameras + motions), and sum over those poses of ceil(observations / 6) <= 256.  The graphs
  * the reference builds are far inside (a track lives <= a few dozen frames); a static point observed from more than 100 frames is not. */
 int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out);
 int vdo_ba_destroy(vdo_ba* ba);
@@ -147,7 +147,7 @@ int vdo_ba_destroy(vdo_ba* ba);
 int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep);
 /* Measurement hook of the roofline leg (bench.py, tools/sweep_only.py; no counterpart in the reference - its g2o prints one
  * time per outer iteration, g2o/core/sparse_optimizer.cpp:406-418): `repeat` back-to-back runs, hipEvents on the ctx stream, of
- *   ms[0] the tile sweep kernel alone (k_sweep_tile<true>),
+ *   ms[0] the tile sweep kernel alone (k_sweep_tile<true, .>),
  *   ms[1] a whole linearisation as BlockSolver::buildSystem means it (g2o/core/block_solver.hpp:502-560): sweep + expansion of
  *         the pose blocks (k_finalize_pose) + pose-pose edges (k_posepose) + chi2 reduction,
  * and the layout figures the byte model of DESIGN.md 4.1 needs:
