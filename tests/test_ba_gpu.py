@@ -196,6 +196,44 @@ def test_wide_partial_rows_match_oracle(ctx, oracle, shape, mode, monkeypatch):
     ba.close()
 
 
+@pytest.mark.parametrize("ept", [1, 2, 3, 4, 6])
+def test_every_tile_size_gives_the_oracles_blocks_and_trajectory(ctx, oracle, ept, monkeypatch):
+    """The tiles' EdgeSE3PointXYZ edges are padded, thread-transposed blocks of 256 x ept entries (ba_dev.hpp Tile::ept; capi_ba.hip picks the
+    tile size from the graph's size): every size 1 .. VDO_TILE_EPT forced with VDO_BA_TILE_EPT on one graph - the clamped loads of rows past
+    a tile's last one, the padding entries (key -1) and the per-tile ept all take part: blocks <= 1e-12 of the oracle's, the same LM
+    trajectory with the PCG and the dense solver, and the padded entry count is what the layout says."""
+    from vdo_slam_amd.ba import BatchBA
+    monkeypatch.setenv("VDO_BA_TILE_EPT", str(ept))
+    g = synth.make_ba_graph(40, 4000, 3, 150, seed=21)
+    ba = BatchBA(ctx, g)
+    dims = ba.dims()
+    assert g.n_eb <= dims["eb_entries"] <= 256 * 6 * dims["tiles"] and dims["eb_entries"] % 256 == 0
+    if ept == 1:
+        assert dims["tiles"] >= (g.n_eb + 2 * g.n_et) // 256
+    ba.linearize()
+    S = ba.system()
+    R = _oracle_system(oracle, g)
+    for name in BLOCKS:
+        a, b = getattr(S, name), getattr(R, name)
+        if b.size:
+            assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max() + 1e-300, name
+    assert abs(S.chi2 - R.chi2) <= 1e-12 * abs(R.chi2) and abs(S.robust_chi2 - R.robust_chi2) <= 1e-12 * abs(R.robust_chi2)
+    gc, keep = K.graph_to_c(g)
+    opt = K.LMOptionsC(5, 1e-4, 0, 0, 0.0, 0)
+    st_o = K.LMStatsC()
+    pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(pose_o), K._dp(point_o), C.byref(st_o)) == 0
+    for solver in (2, 3):
+        ba.set_estimates(g.pose, g.point)
+        st = ba.optimize(max_iterations=5, gain_threshold=1e-4, solver=solver)
+        pose, point = ba.estimates()
+        assert (st.iterations, st.total_trials) == (st_o.iterations, st_o.total_trials), solver
+        assert abs(st.final_chi2 - st_o.final_chi2) <= 1e-6 * st_o.final_chi2, solver
+        assert np.abs(pose[:, :9] - pose_o[:, :9]).max() <= 1e-4 and np.abs(pose[:, 9:] - pose_o[:, 9:]).max() <= 1e-4 * np.abs(pose_o[:, 9:]).max(), solver
+        assert np.abs(point - point_o).max() <= 1e-4 * np.abs(point_o).max(), solver
+    ba.close()
+
+
 def test_invalid_graph_is_rejected(ctx):
     from vdo_slam_amd.ba import BatchBA
     g = synth.make_ba_graph(6, 50, 1, 5, seed=1)

@@ -28,7 +28,7 @@ struct vdo_ba {
   int64_t dense_ld = 0;
   bool pose_graph_is_paths = true;   // every EdgeSE3 lies on a simple path (the chain preconditioner covers them all)
   int last_solver = 0;            // 2 PCG, 3 dense: what the last trial used
-  int pcg_it = 0, pcg_parity = 0, pcg_maxit = 0;      // state of the PCG solve of the trial in flight (ba_lm.hip solve_trial / solve_trial_finish)
+  int pcg_it = 0, pcg_parity = 0, pcg_maxit = 0, pcg_last = 0;      // (pcg_last: iterations the previous solve of this run needed)      // state of the PCG solve of the trial in flight (ba_lm.hip solve_trial / solve_trial_finish)
   double pcg_tol2 = 0;
   bool lin_current = false;       // the blocks on the device (Hpp, bp, Hll, bl, Finc) are the linearisation AT estimate[0]: set by vdo_ba_linearize,
                                   // cleared by vdo_ba_optimize / vdo_ba_set_estimates (vdo_ba_download_system re-linearises when it is not)

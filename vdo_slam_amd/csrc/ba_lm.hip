@@ -97,7 +97,10 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
   const double tol2 = tol * tol;
   *ok = true;
   ba->pcg_it = 0; ba->pcg_parity = 0; ba->pcg_maxit = maxit; ba->pcg_tol2 = tol2;
-  const int batch = std::min(6, maxit);                            // the chain preconditioner converges in a handful of iterations: first look after 6
+  // The chain preconditioner converges in a handful of iterations and the count drifts slowly from trial to trial (3, 3, 4, 4, 5 on the bench's
+  // graph): the first batch is what the previous solve needed + 1, at most 6 - an iteration that finds the convergence flag set still costs its
+  // three (empty) launches, ~13 us.  (6 for the first solve of a run; a batch that turns out too short takes the second-look path of the caller.)
+  const int batch = std::min(std::min(6, maxit), ba->pcg_last > 0 ? std::max(2, ba->pcg_last + 1) : 6);
   for (int k = 0; k < batch; ++k, ba->pcg_parity ^= 1) launch_pcg_iter(d, lambda, tol2, ba->pcg_parity, s, ba->red);
   ba->pcg_it = batch;
   *pending = true;
@@ -123,6 +126,7 @@ int solve_trial_finish(vdo_ba* ba, double lambda, const vdo_lm_options* opt, boo
     if (rc != VDO_OK) return rc;
   }
   *pcg_iters = ba->h_flags[2];
+  ba->pcg_last = *ok ? *pcg_iters : 0;
   const bool small = 6 * (int64_t)d.P <= kDenseMaxUnknowns;
   if (opt->solver == 0 && small && *ok && *pcg_iters > kPcgSlow) ba->last_solver = 3;      // the next trials go to the dense solver
   return VDO_OK;
@@ -138,6 +142,7 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
   if (!st) st = &local;
   std::memset(st, 0, sizeof(*st));
   ba->lin_current = false;        // (the accepted steps move estimate[0] away from the last linearisation)
+  ba->pcg_last = 0;
   BADev& d = ba->d;
   hipStream_t s = ba->ctx->stream;
   const double t_begin = now_ms();
