@@ -386,7 +386,7 @@ def test_config4_sized_graph_blocks_match_the_oracle_and_properties(ctx, oracle,
     """BASELINE configs[4] shape (1 M landmarks, 5 k pose / motion vertices, 20 objects, 5.8 M edges).  The oracle's whole-system Cholesky
     is out of reach at this size, its LINEARISATION is not (20 s, 1 thread): every block of the HIP linearisation - chi2, Hpp, bp, Hll, bl,
     all 5.76 M pose-landmark blocks, the ternary blocks - within 1e-12 of it (this is the graph with the longest dynamic tracks: 81 pose
-    slots in a tile, slot tables and thread tables at their limits).  The LM at this size is checked through properties that do not
+    slots in a tile, slot tables and edge blocks at their limits).  The LM at this size is checked through properties that do not
     depend on the size:
       * two linearisations give the same chi2 bits (fixed summation order) and the same blocks up to the order of the LDS additions;
       * renumbering the caller's points and edges at random changes nothing beyond rounding (the tile-major renumbering, the

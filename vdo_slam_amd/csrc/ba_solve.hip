@@ -268,7 +268,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pvl[k]; }
   __syncthreads();
   {
-    // EdgeSE3PointXYZ incidences by the sweep's thread table: <= VDO_TILE_EPT consecutive edges of ONE pose slot per thread - their contributions
+    // EdgeSE3PointXYZ incidences: the thread's column of the tile's edge block = <= VDO_TILE_EPT consecutive edges of ONE pose slot - their contributions
     // add up in registers and go through ONE segmented scan.  A point that is a chain of its own (every static landmark) has
     // [Hll^-1]_ll = g I3, and its block B = -we [I ; 2[c]x] R^T gives  B G B^T = g we^2 [I ; 2[c]x] [I ; 2[c]x]^T  (R drops out): a function of
     // ten running sums  s, s c, s c c^T  (s = g we^2) - no 6x3 block, no 6x6 product.

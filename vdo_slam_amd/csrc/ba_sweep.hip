@@ -9,7 +9,8 @@
 // One workgroup per TILE (see ba_dev.hpp).  Per tile:
 //   1. the tile's points (<=256 x 24 B, contiguous) and the inverse poses of its pose slots are
 //      staged in LDS;
-//   2. edges stream in fully coalesced - 16 B per EdgeSE3PointXYZ in the compact form (key 4 B + fp32 measurement 12 B, one
+//   2. edges stream in fully coalesced (the tile's EdgeSE3PointXYZ edges are a thread-transposed block: entry j * 256 + t is the j-th edge of
+//      thread t, every load one contiguous row - ba_dev.hpp Tile::ept) - 16 B per EdgeSE3PointXYZ in the compact form (key 4 B + fp32 measurement 12 B, one
 //      information scalar per edge class), 36 B in the general one; of the 6x3 pose-landmark block only the Huber-weighted
 //      information scalar we is written (8 B): the block is we * [I ; k[c]x] * (R^T | I) with c a function of the point and
 //      the pose, which every consumer has in LDS anyway (ba_solve.hip make_f);
@@ -18,13 +19,13 @@
 //   4. the pose 6x6+6 contribution of an edge depends on 16 running sums only
 //      (J_pose = [-I | 2[zc]x]  resp. [I | -[v]x]): Σw, Σw·zc, Σw·zc zcᵀ, Σw·e, Σw·zc×e.
 //      Every thread sums them in registers over its <= VDO_TILE_EPT consecutive EdgeSE3PointXYZ edges, which belong to ONE pose slot (edges are
-//      pose-sorted inside the tile; a per-tile thread table - ba_dev.hpp thr_tab - cuts every slot's run into pieces of <= VDO_TILE_EPT), the
+//      pose-sorted inside the tile; the tile builder - capi_ba.hip close_tile - cuts every slot's run into pieces of <= VDO_TILE_EPT, one per thread), the
 //      threads' totals go through a segmented DPP scan into per-slot LDS accumulators and leave as one 128-byte row per
 //      (tile, slot) of the POSE-MAJOR partial array; k_finalize_pose streams a pose's rows, expands them to the 6x6 block + rhs
 //      and adds the blocks of the pose's EdgeSE3 / prior edges (k_posepose), all in fixed order.
 // No global atomics.  HBM bytes of a linearisation with this layout: vdo_slam_amd/ba.py linearize_byte_model;
-// what bounds the kernel (measured): instruction issue - ~60 % of the SIMD cycles are VALU at 4 workgroups per CU, the rest
-// is what the phases of a tile leave idle; 59 us for 3.76 M edges on the roofline graph = 0.34 of the HBM peak.
+// what bounds the kernel (measured): VALU issue (fp64) at 4 workgroups per CU; 109-130 us for 13.3 M edges = 510 MB by counters
+// = 0.49-0.54 of the HBM peak (round 3: 210 us - the head of every tile was a chain of four dependent loads).
 #include <cstdlib>
 #include "ba_dev.hpp"
 #include "ba_tile.hpp"
