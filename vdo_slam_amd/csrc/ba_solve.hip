@@ -816,8 +816,15 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   double* qs = vs + 6 * d.max_slots;       // [6*S]
   double* slotW = qs + 6 * d.max_slots;    // [12*S] inverse poses of the slots (R^T | -R^T t)
   double* pts = slotW + 12 * d.max_slots;  // [3*TP]  the tile's points (linearisation point)
-  const int my_slot = min(tid, max(nslot - 1, 0));         // (tile_pose carries one entry of padding)
+  int* sdst = reinterpret_cast<int*>(pts + 3 * VDO_TILE_PTS);      // [S] rows of the slots' partials (requested at the head, not where they are stored to)
+  const int my_slot = min(tid, max(nslot - 1, 0));         // (tile_pose / slot_dst carry one entry of padding)
   int my_pose = d.tile_pose[T.slot_begin + my_slot];
+  int my_dst = 0;
+  if (MODE != 2) my_dst = d.slot_dst[T.slot_begin + my_slot];
+  // the landmark chain this thread solves between the two passes (a tile has <= 256 points, hence <= 256 chains: one per thread) - its range now,
+  // its scalar factor (and right-hand side) behind the staging: none of them waits for a round trip in the middle of the kernel
+  const int my_chain = min(T.chain_begin + tid, T.chain_end - 1);
+  const int64_t cp0 = d.chain_off[my_chain], cp1 = d.chain_off[my_chain + 1];
   double pvl[3];
   {
     const double* __restrict__ point = d.point[0] + 3 * (int64_t)T.pt_begin;
@@ -855,6 +862,10 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   asm volatile("" : "+v"(my_pose));         // (keeps the request where it was made: the compiler would sink it into the branch, behind a wait for every other request)
   if (tid < nslot) stage_slot(tid, my_pose);
   for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
+  if (MODE != 2) sdst[my_slot] = my_dst;
+  const double cg = d.dscal[cp0];                          // (meaningful for a chain of one point)
+  D3 cbl{0.0, 0.0, 0.0};
+  if (MODE != 0) cbl = D3{d.bl[3 * cp0], d.bl[3 * cp0 + 1], d.bl[3 * cp0 + 2]};
 #pragma unroll
   for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pvl[k]; }
   __syncthreads();
@@ -911,14 +922,16 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
     __syncthreads();
   }
   // chain solves: w = Hll^-1 y,  y = u (MODE 0) | bl (MODE 1) | bl - u (MODE 2); w overwrites u
-  for (int c = T.chain_begin + tid; c < T.chain_end; c += VDO_TILE_THREADS) {
-    const int64_t p0 = d.chain_off[c], p1 = d.chain_off[c + 1];
+  for (int c = T.chain_begin + tid; c < T.chain_end; c += VDO_TILE_THREADS) {      // (one trip: <= 256 chains per tile)
+    const bool pre = c == my_chain;
+    const int64_t p0 = pre ? cp0 : d.chain_off[c], p1 = pre ? cp1 : d.chain_off[c + 1];
     if (p1 - p0 == 1) {                                    // w = y / (Hll + lambda)
       double* ul = u + 3 * (p0 - T.pt_begin);
       D3 y{ul[0], ul[1], ul[2]};
-      if (MODE == 1) y = D3{d.bl[3 * p0], d.bl[3 * p0 + 1], d.bl[3 * p0 + 2]};
-      if (MODE == 2) y = D3{d.bl[3 * p0], d.bl[3 * p0 + 1], d.bl[3 * p0 + 2]} - y;
-      const double g = d.dscal[p0];
+      const D3 blv = (MODE == 0 || pre) ? cbl : D3{d.bl[3 * p0], d.bl[3 * p0 + 1], d.bl[3 * p0 + 2]};
+      if (MODE == 1) y = blv;
+      if (MODE == 2) y = blv - y;
+      const double g = pre ? cg : d.dscal[p0];
       ul[0] = g * y.x; ul[1] = g * y.y; ul[2] = g * y.z;
       continue;
     }
@@ -1009,7 +1022,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   // one row of 8 doubles (6 used) per (tile, slot), pose-major (k_pcg_q / k_gather_q stream a pose's rows)
   for (int i = tid; i < 8 * nslot; i += VDO_TILE_THREADS) {
     const int sidx = i >> 3, k = i & 7;
-    if (k < 6) d.part_q[8 * (int64_t)d.slot_dst[T.slot_begin + sidx] + k] = qs[6 * sidx + k];
+    if (k < 6) d.part_q[8 * (int64_t)sdst[sidx] + k] = qs[6 * sidx + k];
   }
 }
 
@@ -1408,7 +1421,7 @@ void launch_dense_rhs(const BADev& d, double* rhs, int64_t ld, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------ launchers
-static size_t schur_lds(const BADev& d) { return (6 * VDO_TILE_PTS + 24 * (size_t)d.max_slots) * sizeof(double); }
+static size_t schur_lds(const BADev& d) { return (6 * VDO_TILE_PTS + 24 * (size_t)d.max_slots + ((size_t)d.max_slots + 1) / 2) * sizeof(double); }      // (+ the slots' row ids, int32)
 
 void launch_expand_binc(const BADev& d, hipStream_t s) {
   if (d.n_tiles) hipLaunchKernelGGL(k_expand_binc, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), (12 * (size_t)d.max_slots + 3 * VDO_TILE_PTS) * sizeof(double), s, d);
