@@ -43,6 +43,7 @@ struct Tile {
 
 struct BADev {
   int P = 0, L = 0, Eb = 0, Et = 0, Ep = 0, Npr = 0, Ninc = 0, n_tiles = 0, NPS = 0, n_chains = 0, max_slots = 0;
+  int n_dyn_tiles = 0;                   // the first n_dyn_tiles tiles of the launch order hold a multi-point landmark chain (dynamic track); the others static points only
   double huber_eb = 0, huber_et = 0, huber_ep = 0, dsqr_eb = 0, dsqr_et = 0, dsqr_ep = 0;
   // estimates: [0] current, [1] trial
   double* pose[2] = {nullptr, nullptr};

@@ -221,18 +221,23 @@ __device__ __forceinline__ void bgbt(const double (&B1)[18], const double* G, co
 }
 
 // Exact diagonal blocks of the Schur correction, per (tile,slot):  sum B G B^T  (21 upper entries)
-__global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
+// DYN = false: the tile holds single-point chains only (every tile behind the first d.n_dyn_tiles of the launch order: static landmarks) - the
+// 6x3 blocks, the 6x6 products and the ternary edges are not compiled in, and the kernel fits twice as many waves (230 registers with them).
+template <bool DYN>
+__global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d, int tile0) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   // (head of a tile: every request unconditional and as early as its address is known - ba_sweep.hip)
-  const int ti = blockIdx.x, tid = threadIdx.x;
+  const int ti = tile0 + (int)blockIdx.x, tid = threadIdx.x;
   const Tile T = d.tiles[ti];
   const int nslot = T.slot_end - T.slot_begin, npts = T.pt_end - T.pt_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
   double* accm = smem;                       // [21 * S]
   double* slotW = accm + 21 * d.max_slots;   // [12 * S]
   double* pts = slotW + 12 * d.max_slots;    // [3 * TP]
+  int* sdst = reinterpret_cast<int*>(pts + 3 * VDO_TILE_PTS);      // [S] rows of the slots' partials
   const int my_slot = min(tid, max(nslot - 1, 0));
   int my_pose = d.tile_pose[T.slot_begin + my_slot];
+  const int my_dst = d.slot_dst[T.slot_begin + my_slot];
   double pvl[3];
   {
     const double* __restrict__ point = d.point[0] + 3 * (int64_t)T.pt_begin;
@@ -256,6 +261,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   asm volatile("" : "+v"(my_pose));         // (keeps the request where it was made: the compiler would sink it into the branch, behind a wait for every other request)
   if (tid < nslot) stage_slot(tid, my_pose);
   for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
+  sdst[my_slot] = my_dst;
   // what hangs on the keys: is the point a chain of its own, and its scalar factor
   unsigned char sgl[VDO_TILE_EPT];
   double dsc[VDO_TILE_EPT];
@@ -285,7 +291,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
         slot = key >> 16;
         const int64_t l = T.pt_begin + (key & 0xffff);
         const FInc f = make_f(d, T, j, 0, key, web[q], slotW, pts);
-        if (sgl[q]) {
+        if (!DYN || sgl[q]) {
           const double sw = dsc[q] * f.we * f.we;
           const double wx = sw * f.cx, wy = sw * f.cy, wz = sw * f.cz;
           s0 += sw; sx += wx; sy += wy; sz += wz;
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
     up[20] += 4.0 * (sxx + syy);
     if (nb > 0) { const SegCtl16 sc_ = seg_ctl16(slot); seg_apply16<21>(up, sc_, seg_flags(sc_), accm + 21 * (slot >= 0 ? slot : 0)); }
   }
-  for (int base = 0; base < nt; base += VDO_TILE_THREADS) {
+  for (int base = 0; DYN && base < nt; base += VDO_TILE_THREADS) {
     const int j = base + tid;
     int slot = -1;
     double up[21];
@@ -342,7 +348,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d) {
   for (int i = tid; i < 24 * nslot; i += VDO_TILE_THREADS) {
     const int sidx = i / 24, k = i - 24 * sidx;
     if (k >= 21) continue;
-    const int64_t row = d.slot_dst[T.slot_begin + sidx];
+    const int64_t row = sdst[sidx];
     if (k < 16) d.part_m[16 * row + k] = accm[21 * sidx + k];
     else d.part_m8[8 * row + (k - 16)] = accm[21 * sidx + k];
   }
@@ -1443,7 +1449,12 @@ void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R) {
 void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const Reducer& R, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
   hipMemsetAsync(d.flags, 0, 4 * sizeof(int32_t), s);
   if (d.n_chains) hipLaunchKernelGGL(k_factor_chains, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, lambda);
-  if (d.n_tiles) hipLaunchKernelGGL(k_precond_tile, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), (33 * (size_t)d.max_slots + 3 * VDO_TILE_PTS) * sizeof(double), s, d);
+  {
+    const size_t lds = (33 * (size_t)d.max_slots + 3 * VDO_TILE_PTS + ((size_t)d.max_slots + 1) / 2) * sizeof(double);
+    const int nd = d.n_tiles < 1024 ? d.n_tiles : std::min(d.n_dyn_tiles, d.n_tiles);       // tiles with dynamic tracks come first in the launch order (a graph of few tiles: one launch - a second one costs more than the registers)
+    if (nd > 0) hipLaunchKernelGGL(k_precond_tile<true>, dim3(nd), dim3(VDO_TILE_THREADS), lds, s, d, 0);
+    if (d.n_tiles > nd) hipLaunchKernelGGL(k_precond_tile<false>, dim3(d.n_tiles - nd), dim3(VDO_TILE_THREADS), lds, s, d, nd);
+  }
   const dim3 g((d.P + 3) / 4), b(256);
   if (!d.sharded) hipLaunchKernelGGL(k_precond_finalize<0>, g, b, 0, s, d, lambda);
   else {

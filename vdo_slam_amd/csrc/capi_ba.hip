@@ -442,6 +442,8 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     std::vector<int32_t> order(std::max(n_tiles, 1), 0), longest(std::max(n_tiles, 1), 0);
     for (int t = 0; t < n_tiles; ++t) { order[t] = t; for (int c = tiles[t].chain_begin; c < tiles[t].chain_end; ++c) longest[t] = std::max(longest[t], chain_off[c + 1] - chain_off[c]); }
     if (!std::getenv("VDO_BA_TILE_ORDER_IDENTITY")) std::stable_sort(order.begin(), order.begin() + n_tiles, [&](int a, int b) { return longest[a] > longest[b]; });
+    for (int t = 0; t < n_tiles; ++t) if (longest[t] > 1 || tiles[t].et_end > tiles[t].et_begin) ++ba->d.n_dyn_tiles;
+    if (std::getenv("VDO_BA_TILE_ORDER_IDENTITY")) ba->d.n_dyn_tiles = n_tiles;      // (debug order: no dynamic-first guarantee)
     std::vector<Tile> tiles_l(std::max(n_tiles, 1));
     for (int b = 0; b < n_tiles; ++b) tiles_l[b] = tiles[order[b]];
     UP(tiles, tiles_l.data(), tiles_l.size());
