@@ -71,6 +71,39 @@ def _pmc_traffic_bytes(graph, dims):
     return None
 
 
+def _pmc_traffic_live(n_static, graph, dims, timeout_s=150):
+    """HBM bytes per k_sweep_tile launch MEASURED DURING THIS BENCH RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE - each in its own run, as
+    MI355X_MICROARCH.md prescribes, no trace domains beside them) over tools/sweep_only.py on the same graph, in child processes; 2*FETCH + WRITE with
+    the guide's gfx950 correction.  None when rocprofv3 is not there, a pass fails or the child's graph / tile layout is not this one (the committed
+    counter file, then the byte model, take over)."""
+    import re, shutil, sqlite3, subprocess, tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    here = os.path.dirname(os.path.abspath(__file__))
+    tot = {}
+    tmp = tempfile.mkdtemp(prefix="vdo_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, ctr)
+            r = subprocess.run(["rocprofv3", "--pmc", ctr, "-d", out, "--", sys.executable, os.path.join(here, "tools", "sweep_only.py"), str(n_static)],
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, text=True)
+            m = re.search(r"n_eb (\d+) n_et (\d+) n_point (\d+) tiles (\d+) eb_entries (\d+)", r.stdout or "")
+            if r.returncode != 0 or not m or tuple(int(v) for v in m.groups()) != (graph.n_eb, graph.n_et, graph.n_point, dims["tiles"], dims["eb_entries"]):
+                return None
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            if not dbs:
+                return None
+            row = sqlite3.connect(dbs[0]).execute("select avg(value), count(*) from counters_collection where kernel_name like '%k_sweep_tile<true%' and counter_name = ?", (ctr,)).fetchone()
+            if not row or not row[1]:
+                return None
+            tot[ctr] = float(row[0]) * 1024.0                    # (the counters are in KB)
+        return 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]       # (gfx950 tallies 128-B read requests at 64 B: FETCH_SIZE doubled)
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def _cpu_budget():
     """CPUs this job may use: the cgroup quota if there is one, else the affinity mask."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -228,6 +261,7 @@ def main():
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the System::TrackRGBD (host buffers in) leg")
     ap.add_argument("--replicas-per-gpu", type=int, default=1, help="R independent sequences (FramePipelines) on every GPU; value = all of them")
     ap.add_argument("--replica-sweep", type=str, default="", help="e.g. 1,2,4,8: also report frames/s for these numbers of sequences per GPU")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes of the roofline leg (the committed counter file, then the byte model, take over)")
     ap.add_argument("--roofline-static", type=int, default=2200000, help="static landmarks of the roofline graph (default: 13.3 M edges, ~515 MB per sweep launch - twice the 256 MB Infinity Cache)")
     ap.add_argument("--cpu-worker", type=str, default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-budget", type=float, default=8.0, help=argparse.SUPPRESS)
@@ -611,7 +645,8 @@ def main():
         from vdo_slam_amd.ba import linearize_byte_model
         model = linearize_byte_model(gr, dims)
         alg_bytes = 208 * gr.n_eb + 452 * gr.n_et + 96 * gr.n_point     # SURVEY.md §8d B_sweep terms of this kernel
-        traffic = _pmc_traffic_bytes(gr, dims)                               # rocprofv3 --pmc passes over this kernel and graph, if committed for this layout
+        traffic_live = _pmc_traffic_live(args.roofline_static, gr, dims) if (rank == 0 and world == 1 and not args.no_live_pmc) else None
+        traffic = traffic_live if traffic_live is not None else _pmc_traffic_bytes(gr, dims)                               # rocprofv3 --pmc passes over this kernel and graph, if committed for this layout
         used = traffic if traffic is not None else float(model["sweep"])
         achieved = used / (sweep_ms * 1e-3) / 1e9
         out["roofline"] = {
@@ -628,8 +663,10 @@ def main():
                     "landmark block), so that rate is NOT a bandwidth.  `linearize_*`: sweep + expansion of the pose blocks + pose-pose edges + chi2 (one "
                     "BlockSolver::buildSystem).  What bounds the sweep is VALU issue (DESIGN.md 4.1).",
             "layout": dims,
-            "traffic_source": ("profiles/r04_sweep_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/sweep_only.py on this very graph "
-                               "(tools/profile_round4_sweep.sh); counters cannot be collected inside this run, the duration is live") if traffic is not None else None,
+            "traffic_source": ("live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/sweep_only.py on this very graph and tile layout, run by this bench in child "
+                               "processes; the duration is this process's own (hipEvents)") if traffic_live is not None else
+                              (("profiles/r04_sweep_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/sweep_only.py on this very graph and tile layout "
+                                "(tools/profile_round4_sweep.sh; the live passes of this run were not available); the duration is live") if traffic is not None else None),
             "graph_vs_infinity_cache": f"{model['sweep'] / 1e6:.0f} MB per sweep launch by the byte model vs 256 MB of Infinity Cache: the traffic is HBM traffic",
             "units_per_launch": {"EdgeSE3PointXYZ": int(gr.n_eb), "LandmarkMotionTernaryEdge": int(gr.n_et), "points": int(gr.n_point), "poses": int(gr.n_pose)}}
         bar.close()
