@@ -234,6 +234,32 @@ def test_every_tile_size_gives_the_oracles_blocks_and_trajectory(ctx, oracle, ep
     ba.close()
 
 
+def test_graph_without_binary_edges_linearises_like_the_oracle(ctx, oracle):
+    """No EdgeSE3PointXYZ at all (dynamic points linked by ternary edges only, plus the pose-pose edges): every tile's edge block is empty
+    (Tile::ept == 0) and the tile kernels' unconditional edge loads must stay inside the (one-row) arrays and count no edge: the blocks equal
+    the oracle's.  And the same graph with EVERY static point removed but the observations of the dynamic ones kept (tiles of dynamic tracks only)."""
+    import dataclasses
+    from vdo_slam_amd.ba import BatchBA
+    g0 = synth.make_ba_graph(12, 0, 2, 40, seed=5)
+    e = np.zeros(0, np.int32)
+    g = dataclasses.replace(g0, eb_pose=e.copy(), eb_point=e.copy(), eb_z=np.zeros((3, 0)), eb_w=np.zeros(0))
+    for gg in (g, g0):
+        ba = BatchBA(ctx, gg)
+        ba.linearize()
+        S = ba.system()
+        R = _oracle_system(oracle, gg)
+        for name in BLOCKS:
+            a, b = getattr(S, name), getattr(R, name)
+            if b.size:
+                assert np.abs(a - b).max() <= 1e-12 * np.abs(b).max() + 1e-300, name
+        assert abs(S.chi2 - R.chi2) <= 1e-12 * abs(R.chi2) + 1e-300
+        st = ba.optimize(max_iterations=2, gain_threshold=-1.0)      # (the solver's tile kernels on the same tiles: must run through; without observations the system is rank deficient - only that it returns is checked)
+        assert st.iterations >= 1
+        if gg is g0:
+            assert np.isfinite(st.final_chi2) and st.final_chi2 <= st.initial_chi2
+        ba.close()
+
+
 def test_invalid_graph_is_rejected(ctx):
     from vdo_slam_amd.ba import BatchBA
     g = synth.make_ba_graph(6, 50, 1, 5, seed=1)

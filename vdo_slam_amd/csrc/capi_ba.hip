@@ -454,7 +454,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     for (int c = 0; c < n_chains; ++c) if (chain_off[c + 1] - chain_off[c] == 1) single[chain_off[c]] = 1;
     UP(pt_single, single.data(), single.size());
   }
-  eb_key.resize(std::max<size_t>(eb_key.size(), 1), -1);     // (>= 1 entry: the tile kernels load a thread's edges from clamped indices, unconditionally)
+  eb_key.resize(std::max<size_t>(eb_key.size(), VDO_TILE_THREADS), -1);     // (>= one row: the tile kernels load a thread's edges unconditionally - entry `thread` of the first block for a tile without edges)
   UP(eb_key, eb_key.data(), eb_key.size());
   UP(et_key, et_key.data(), Et); UP(et_slot, et_slot.data(), Et);
   {
@@ -496,7 +496,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   ba->d.bp = ba->d.Hpp + 36 * (size_t)P; ba->d.red_chi = ba->d.bp + 6 * (size_t)P;
   UP(msum, Z, 21 * (size_t)P + 1);
   UP(Hll, Z, (size_t)L); UP(bl, Z, 3 * (size_t)L);
-  UP(Finc, Z, (size_t)Ebp + (size_t)Et + 1); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep); UP(ep_blk, Z, 84 * (size_t)std::max(Ep + Npr, 1));
+  UP(Finc, Z, std::max<size_t>((size_t)Ebp, VDO_TILE_THREADS) + (size_t)Et + 1); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep); UP(ep_blk, Z, 84 * (size_t)std::max(Ep + Npr, 1));
   UP(part_sums, Z, (size_t)ps_stride * (size_t)std::max(NPS, 1));
   UP(part_chi, Z, 2 * (size_t)n_tiles + 2 * (size_t)(Ep + Npr) + 2);
   UP(part_red, Z, 256);
