@@ -286,15 +286,18 @@ def _with_extra_pose_edges(g, pairs):
         ep_z=np.concatenate([g.ep_z, np.array(zs)]), ep_info=np.concatenate([g.ep_info, np.array(infos)]))
 
 
-@pytest.mark.parametrize("solver", [2, 3, 0])
+@pytest.mark.parametrize("solver", [2, 3, 0, 31, 32, 33, 34, 35])
 @pytest.mark.parametrize("variant", ["loop_closure", "branch", "double_edge", "reversed_edges"])
-def test_lm_with_non_path_pose_graphs(ctx, oracle, variant, solver):
+def test_lm_with_non_path_pose_graphs(ctx, oracle, variant, solver, monkeypatch):
     """The block-tridiagonal preconditioner follows the simple paths of the EdgeSE3 graph; components with a
     cycle, a branch or a doubled edge fall back to block-Jacobi, edges stored (j,i) are followed transposed.
     The LM trajectory must not notice (it only changes how fast PCG converges).  solver 2 = PCG, 3 = dense MFMA Cholesky of the
     explicit reduced-camera matrix, 0 = auto (dense for the three non-path variants): identical LM trajectories."""
     import dataclasses
     from vdo_slam_amd.ba import BatchBA
+    if solver > 30:     # the dense solver through either launch sequence of csrc/ba_dense.hip (3 and 0 take the default one)
+        monkeypatch.setenv("VDO_BA_DENSE", str(solver - 30))
+        solver = 3
     g = synth.make_ba_graph(14, 400, 2, 40, seed=9)
     F = g.n_cam
     if variant == "loop_closure":
@@ -328,11 +331,14 @@ def test_lm_with_non_path_pose_graphs(ctx, oracle, variant, solver):
     ba.close()
 
 
+@pytest.mark.parametrize("dense_version", ["1", "2", "3", "4", "5"])
 @pytest.mark.parametrize("shape,seed", [((12, 300, 2, 40), 3), ((40, 2000, 3, 150), 3), ((25, 3000, 0, 0), 5)])
-def test_dense_mfma_solver_matches_oracle(ctx, oracle, shape, seed):
+def test_dense_mfma_solver_matches_oracle(ctx, oracle, shape, seed, dense_version, monkeypatch):
     """solver = 3 on ordinary (path) graphs, incl. dynamic tracks (block-tridiagonal landmark chains) and a size whose 6P is not a
-    multiple of the 64-wide Cholesky blocks: same iterations / trials / chi2 / estimates as the direct-solve oracle."""
+    multiple of the 64-wide Cholesky blocks: same iterations / trials / chi2 / estimates as the direct-solve oracle - with both launch
+    sequences of the factorisation (VDO_BA_DENSE, csrc/ba_dense.hip: 1 = potrf + panel + syrk per step, 2 .. 5 = one fused launch per step)."""
     from vdo_slam_amd.ba import BatchBA
+    monkeypatch.setenv("VDO_BA_DENSE", dense_version)
     g = synth.make_ba_graph(*shape, seed=seed)
     gc, keep = K.graph_to_c(g)
     opt = K.LMOptionsC(30, 1e-4, 0, 0, 0.0, 0)

@@ -12,7 +12,13 @@
 // PCG needs many iterations, or on request (vdo_lm_options.solver = 3).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "ba_dev.hpp"
+
+#ifndef VDO_BA_DENSE_DEFAULT
+#define VDO_BA_DENSE_DEFAULT 1
+#endif
 
 namespace vdo {
 
@@ -237,14 +243,469 @@ __global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ S,
   if (threadIdx.x < NB) x[bi * NB + threadIdx.x] -= part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------- version 2
+// One launch per 64-column step (instead of potrf + panel + syrk), the forward substitution folded into it:
+//   k_chol_step(k)  workgroup (i, j), k < j <= i: stages the raw A_ik, A_jk and W_k = L_kk^-1, forms L_ik = A_ik W_k^T and L_jk itself
+//                   (two 64^3 products, redundant across the row - they cost less than a launch boundary and a trip through HBM), then
+//                   A_ij -= L_ik L_jk^T.  The workgroups of the first trailing column (j = k + 1) store the panel block - into the UPPER
+//                   triangle, block (k, i), which nothing of the factorisation reads: the raw A_ik stays in place for the others of the
+//                   launch - and advance the right-hand side: y_k = W_k b_k, b_i -= L_ik y_k.  Workgroup (k+1, k+1) keeps its updated
+//                   block in LDS and factorises it on the spot (potrf64_lds): L, W of step k + 1 are ready when the launch ends.
+//   potrf64_lds     the sub-panel, the trailing update and the assembly of L^-1 from the four 16x16 inverses on v_mfma_f64_16x16x4_f64
+//                   (16x16 tiles, one per wave); the 16x16 diagonal factor multiplies by 1 / sqrt(pivot) (v_rsq_f64 + two Newton steps)
+//                   instead of dividing 136 times per block.
+//   backward        x = L^-T y right-looking, one launch per block as before, reading L from the upper triangle.
+template <typename F>
+__device__ __forceinline__ void for_acc(F f) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) f((lane >> 4) + 4 * r, lane & 15, r);      // (row, column, register) of a 16x16 f64 MFMA accumulator
+}
+
+// 16x16 tile  D[i][j] = sum_{k < K} a(i, k) b(j, k),  a(i, k) = Ap[i * sai + k * sak],  b(j, k) = Bp[j * sbj + k * sbk]   (one wave; K a multiple of 4)
+__device__ __forceinline__ d4 mma16(const double* Ap, int sai, int sak, const double* Bp, int sbj, int sbk, int K) {
+  const int lane = threadIdx.x & 63, i = lane & 15, kq = lane >> 4;
+  d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+  for (int k0 = 0; k0 < K; k0 += 4) {
+    const double a = Ap[i * sai + (k0 + kq) * sak];
+    const double b = Bp[i * sbj + (k0 + kq) * sbk];
+    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  }
+  return acc;
+}
+
+// 1 / sqrt(p), p > 0: hardware estimate + two Newton steps  y <- y + y (1/2 - (p y) (y / 2))   (quadratic: ~2^-23 -> 2^-45 -> rounding)
+__device__ __forceinline__ double rsqrt_nr(double p) {
+  double y = __builtin_amdgcn_rsq(p);
+#pragma unroll
+  for (int it = 0; it < 2; ++it) {
+    const double h = 0.5 * y;
+    const double e = __builtin_fma(-(p * y), h, 0.5);
+    y = __builtin_fma(y, e, y);
+  }
+  return y;
+}
+
+// potrf16_regs with one reciprocal square root per column and multiplications everywhere else
+__device__ __forceinline__ bool potrf16_regs_v2(double (&a)[16], double (&w)[16], int r) {
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < 16; ++c) w[c] = 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    double p = bcast(a[j], j);
+    if (!(p > 0.0)) { bad = true; p = 1.0; }
+    const double inv = rsqrt_nr(p);
+    const double l = (r == j) ? p * inv : a[j] * inv;
+    a[j] = l;
+    if (r == j) {
+#pragma unroll
+      for (int c = 0; c <= j; ++c) w[c] = ((c == j ? 1.0 : 0.0) + w[c]) * inv;       // row j of L^-1 is final
+    }
+#pragma unroll
+    for (int c = j + 1; c < 16; ++c) a[c] -= l * bcast(l, c);
+#pragma unroll
+    for (int c = 0; c <= j; ++c) { const double wj = bcast(w[c], j); if (r > j) w[c] -= l * wj; }
+  }
+  return bad;
+}
+
+// A (LDS, 64 x LDS_LD, SPD in its lower triangle) -> L in its lower triangle, W = L^-1 (LDS, lower; upper zero); Tm: scratch of the same size.
+// Called by all 256 threads; *s_bad (LDS, initialised by the caller before its last barrier) is set when a pivot is not positive.
+__device__ void potrf64_lds(double* A, double* W, double* Tm, int* s_bad) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < NB * LDS_LD; i += 256) W[i] = 0.0;
+  __syncthreads();
+  for (int kb = 0; kb < 4; ++kb) {
+    const int o = 16 * kb;
+    if (wv == 0) {
+      double a[16], w[16];
+      const int r = lane & 15;
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = A[(o + r) * LDS_LD + o + c];
+      const bool bad = potrf16_regs_v2(a, w, r);
+      if (lane < 16) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) { A[(o + r) * LDS_LD + o + c] = c <= r ? a[c] : 0.0; W[(o + r) * LDS_LD + o + c] = c <= r ? w[c] : 0.0; }
+      }
+      if (__ballot(bad && lane < 16) && lane == 0) *s_bad = 1;
+    }
+    __syncthreads();
+    const int nrt = 3 - kb;                       // 16-row tiles below the diagonal sub-block
+    if (wv < nrt) {                               // sub-panel X = A_sub Wd^T, in place (a wave reads and writes only its own tile)
+      const int R0 = o + 16 + 16 * wv;
+      const d4 x = mma16(A + R0 * LDS_LD + o, LDS_LD, 1, W + o * LDS_LD + o, LDS_LD, 1, 16);
+      for_acc([&](int rr, int cc, int q) { A[(R0 + rr) * LDS_LD + o + cc] = x[q]; });
+    }
+    __syncthreads();
+    const int ntile = nrt * (nrt + 1) / 2;        // trailing update of the lower triangle, tile (ti, tj), tj <= ti:  A -= X_ti X_tj^T
+    for (int q = wv; q < ntile; q += 4) {
+      int tj = q, ti = 0;
+      while (tj > ti) { tj -= ti + 1; ++ti; }
+      const int R0 = o + 16 + 16 * ti, C0 = o + 16 + 16 * tj;
+      const d4 u = mma16(A + R0 * LDS_LD + o, LDS_LD, 1, A + C0 * LDS_LD + o, LDS_LD, 1, 16);
+      for_acc([&](int rr, int cc, int qq) { A[(R0 + rr) * LDS_LD + C0 + cc] -= u[qq]; });
+    }
+    __syncthreads();
+  }
+  // L^-1: W_ij = -W_ii * sum_{t = j}^{i - 1} L_it W_tj  for the 16x16 blocks i > j, by block distance
+  for (int dist = 1; dist < 4; ++dist) {
+    const int nbk = 4 - dist;
+    const int j = wv, i = wv + dist;
+    if (wv < nbk) {
+      const d4 t = mma16(A + 16 * i * LDS_LD + 16 * j, LDS_LD, 1, W + 16 * j * LDS_LD + 16 * j, 1, LDS_LD, 16 * dist);
+      for_acc([&](int rr, int cc, int q) { Tm[(16 * i + rr) * LDS_LD + 16 * j + cc] = t[q]; });
+    }
+    __syncthreads();
+    if (wv < nbk) {
+      const d4 v = mma16(W + 16 * i * LDS_LD + 16 * i, LDS_LD, 1, Tm + 16 * i * LDS_LD + 16 * j, 1, LDS_LD, 16);
+      for_acc([&](int rr, int cc, int q) { W[(16 * i + rr) * LDS_LD + 16 * j + cc] = -v[q]; });
+    }
+    __syncthreads();
+  }
+}
+
+// The same, with the 16-column panels factorised whole in the registers of wave 0 - lane r holds row o + r of the panel, so the sub-panel
+// X = A_sub Ld^-T falls out of the column loop that produces Ld (its broadcasts are wave-wide anyway) and no inverse is needed inside
+// the loop; the four 16x16 inverses are formed afterwards, one per wave, by forward substitution on the unit vectors (lane c: column c;
+// the entries of L are LDS broadcasts).  dinv: LDS, 64 doubles (reciprocal pivots).
+__device__ void potrf64_lds_v3(double* A, double* W, double* Tm, double* dinv, int* s_bad) {
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  for (int i = tid; i < NB * LDS_LD; i += 256) W[i] = 0.0;
+  __syncthreads();
+  for (int kb = 0; kb < 4; ++kb) {
+    const int o = 16 * kb;
+    if (wv == 0) {
+      const bool active = o + lane < NB;
+      const int row = active ? o + lane : NB - 1;
+      double a[16];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) a[c] = A[row * LDS_LD + o + c];
+      bool bad = false;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        double p = bcast(a[j], j);                  // (lane j holds row o + j)
+        if (!(p > 0.0)) { bad = true; p = 1.0; }
+        const double inv = rsqrt_nr(p);
+        const double l = (lane == j) ? p * inv : a[j] * inv;
+        a[j] = l;
+        if (lane == j) dinv[o + j] = inv;
+#pragma unroll
+        for (int c = j + 1; c < 16; ++c) a[c] -= l * bcast(l, c);
+      }
+      if (active) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) A[row * LDS_LD + o + c] = (lane < 16 && c > lane) ? 0.0 : a[c];
+      }
+      if (bad && lane == 0) *s_bad = 1;             // (p is wave-uniform)
+    }
+    __syncthreads();
+    const int nrt = 3 - kb;
+    const int ntile = nrt * (nrt + 1) / 2;          // trailing update of the lower triangle, tile (ti, tj), tj <= ti:  A -= X_ti X_tj^T
+    for (int q = wv; q < ntile; q += 4) {
+      int tj = q, ti = 0;
+      while (tj > ti) { tj -= ti + 1; ++ti; }
+      const int R0 = o + 16 + 16 * ti, C0 = o + 16 + 16 * tj;
+      const d4 u = mma16(A + R0 * LDS_LD + o, LDS_LD, 1, A + C0 * LDS_LD + o, LDS_LD, 1, 16);
+      for_acc([&](int rr, int cc, int qq) { A[(R0 + rr) * LDS_LD + C0 + cc] -= u[qq]; });
+    }
+    __syncthreads();
+  }
+  {   // Wd of block wv: column c of Ld^-1 on lane c (lanes >= 16 repeat column c & 15 and do not store)
+    const int o = 16 * wv, c = lane & 15;
+    double x[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      double sacc = (r == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < r; ++k) sacc -= A[(o + r) * LDS_LD + o + k] * x[k];
+      x[r] = sacc * dinv[o + r];
+    }
+    if (lane < 16) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) W[(o + r) * LDS_LD + o + c] = x[r];
+    }
+  }
+  __syncthreads();
+  for (int dist = 1; dist < 4; ++dist) {
+    const int nbk = 4 - dist;
+    const int j = wv, i = wv + dist;
+    if (wv < nbk) {
+      const d4 t = mma16(A + 16 * i * LDS_LD + 16 * j, LDS_LD, 1, W + 16 * j * LDS_LD + 16 * j, 1, LDS_LD, 16 * dist);
+      for_acc([&](int rr, int cc, int q) { Tm[(16 * i + rr) * LDS_LD + 16 * j + cc] = t[q]; });
+    }
+    __syncthreads();
+    if (wv < nbk) {
+      const d4 v = mma16(W + 16 * i * LDS_LD + 16 * i, LDS_LD, 1, Tm + 16 * i * LDS_LD + 16 * j, 1, LDS_LD, 16);
+      for_acc([&](int rr, int cc, int q) { W[(16 * i + rr) * LDS_LD + 16 * j + cc] = -v[q]; });
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ void store_factor(const double* A, const double* W, double* __restrict__ G, int64_t ld, double* __restrict__ Wk) {
+  for (int i = threadIdx.x; i < NB * NB; i += 256) {
+    const int rr = i >> 6, c = i & 63;
+    G[(int64_t)rr * ld + c] = c <= rr ? A[rr * LDS_LD + c] : 0.0;
+    Wk[i] = c <= rr ? W[rr * LDS_LD + c] : 0.0;
+  }
+}
+
+// diagonal block 0 (the others are factorised inside k_chol_step)
+__global__ __launch_bounds__(256) void k_potrf64_v2(double* __restrict__ S, int64_t ld, int k, double* __restrict__ Winv, int32_t* __restrict__ flags, int variant) {
+  __shared__ double A[NB * LDS_LD];
+  __shared__ double W[NB * LDS_LD];
+  __shared__ double Tm[NB * LDS_LD];
+  __shared__ double dinv[NB];
+  __shared__ int s_bad;
+  double* G = S + (int64_t)k * NB * ld + (int64_t)k * NB;
+  stage64(G, ld, A);
+  if (threadIdx.x == 0) s_bad = 0;
+  __syncthreads();
+  if (variant == 3) potrf64_lds_v3(A, W, Tm, dinv, &s_bad);
+  else potrf64_lds(A, W, Tm, &s_bad);
+  store_factor(A, W, G, ld, Winv + (int64_t)k * NB * NB);
+  if (threadIdx.x == 0 && s_bad) atomicOr(flags, 1);
+}
+
+__global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64_t ld, int k, double* __restrict__ Winv, double* __restrict__ rhs,
+                                                   double* __restrict__ yv, int32_t* __restrict__ flags, int variant) {
+  __shared__ double As[NB * LDS_LD];
+  __shared__ double Bs[NB * LDS_LD];
+  __shared__ double Ws[NB * LDS_LD];
+  __shared__ double bk[NB], yk[NB];
+  __shared__ double part[4][NB];
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, wv = tid >> 6;
+  int t = blockIdx.x, ri = 0;                       // pair index -> (bi, bj), k < bj <= bi
+  while (t > ri) { t -= ri + 1; ++ri; }
+  const int bi = k + 1 + ri, bj = k + 1 + t;
+  const bool diag = bi == bj, first = bj == k + 1;
+  stage64(S + (int64_t)bi * NB * ld + (int64_t)k * NB, ld, As);
+  if (!diag) stage64(S + (int64_t)bj * NB * ld + (int64_t)k * NB, ld, Bs);
+  stage64(Winv + (int64_t)k * NB * NB, NB, Ws);
+  if (tid == 0) s_bad = 0;
+  if (first && tid < NB) bk[tid] = rhs[k * NB + tid];
+  __syncthreads();
+  d4 li[4], lj[4];
+  gemm64_abt(As, Ws, li);                           // L_ik = A_ik W_k^T
+  if (!diag) gemm64_abt(Bs, Ws, lj);
+  __syncthreads();                                  // (every wave has read the raw blocks)
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+    for_acc([&](int rr, int cc, int q) {
+      As[(16 * wv + rr) * LDS_LD + 16 * tt + cc] = li[tt][q];
+      if (!diag) Bs[(16 * wv + rr) * LDS_LD + 16 * tt + cc] = lj[tt][q];
+    });
+  if (first) {                                      // the panel block, kept in the upper triangle: block (k, bi) = L_{bi,k}
+    double* P = S + (int64_t)k * NB * ld + (int64_t)bi * NB;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) for_acc([&](int rr, int cc, int q) { P[(int64_t)(16 * wv + rr) * ld + 16 * tt + cc] = li[tt][q]; });
+  }
+  __syncthreads();
+  d4 acc[4];
+  gemm64_abt(As, diag ? As : Bs, acc);              // L_ik L_jk^T
+  double* G = S + (int64_t)bi * NB * ld + (int64_t)bj * NB;
+  const bool next = diag && first;                  // block (k+1, k+1): factorised below
+#pragma unroll
+  for (int tt = 0; tt < 4; ++tt)
+    for_acc([&](int rr, int cc, int q) {
+      double* g = G + (int64_t)(16 * wv + rr) * ld + 16 * tt + cc;
+      if (next) Bs[(16 * wv + rr) * LDS_LD + 16 * tt + cc] = *g - acc[tt][q];       // (Bs is free in a diagonal workgroup)
+      else *g -= acc[tt][q];
+    });
+  if (first) {                                      // forward substitution: y_k = W_k b_k, b_i -= L_ik y_k
+    const int col = tid & 63, chunk = tid >> 6;
+    {
+      double a = 0.0;
+      for (int c = chunk; c < NB; c += 4) a += Ws[col * LDS_LD + c] * bk[c];
+      part[chunk][col] = a;
+    }
+    __syncthreads();
+    if (tid < NB) {
+      const double y = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+      yk[tid] = y;
+      if (diag) yv[k * NB + tid] = y;
+    }
+    __syncthreads();
+    {
+      double a = 0.0;
+      for (int c = chunk; c < NB; c += 4) a += As[col * LDS_LD + c] * yk[c];
+      part[chunk][col] = a;
+    }
+    __syncthreads();
+    if (tid < NB) rhs[bi * NB + tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+  }
+  if (next) {
+    __syncthreads();
+    if (variant == 3) potrf64_lds_v3(Bs, Ws, As, yk, &s_bad);
+    else potrf64_lds(Bs, Ws, As, &s_bad);
+    store_factor(Bs, Ws, G, ld, Winv + (int64_t)(k + 1) * NB * NB);
+    if (tid == 0 && s_bad) atomicOr(flags, 1);
+  }
+}
+
+// y of the last block (no step launch follows its factorisation)
+__global__ __launch_bounds__(256) void k_fwd_last(int kb, const double* __restrict__ Winv, const double* __restrict__ rhs, double* __restrict__ yv) {
+  __shared__ double bk[NB];
+  __shared__ double part[4][NB];
+  const int col = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+  if (threadIdx.x < NB) bk[threadIdx.x] = rhs[kb * NB + threadIdx.x];
+  __syncthreads();
+  const double* W = Winv + (int64_t)kb * NB * NB;
+  double a = 0.0;
+  for (int c = chunk; c < NB; c += 4) a += W[col * NB + c] * bk[c];
+  part[chunk][col] = a;
+  __syncthreads();
+  if (threadIdx.x < NB) yv[kb * NB + threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+// backward step kb on the version-2 layout: L_{kb,bi} (bi < kb) lives in block (bi, kb) of S.  y: the forward-substituted vector, updated in
+// place; xo: the solution (a separate vector: workgroup 0 must not overwrite what the others are still reading).
+__global__ __launch_bounds__(256) void k_trsv_back_v2(const double* __restrict__ S, int64_t ld, int kb, const double* __restrict__ Winv, double* __restrict__ y,
+                                                      double* __restrict__ xo) {
+  __shared__ double bk[NB], xk[NB];
+  __shared__ double part[4][NB];
+  const int col = threadIdx.x & 63, chunk = threadIdx.x >> 6;
+  if (threadIdx.x < NB) bk[threadIdx.x] = y[kb * NB + threadIdx.x];
+  __syncthreads();
+  {
+    const double* W = Winv + (int64_t)kb * NB * NB;
+    double acc = 0.0;
+    for (int t = chunk; t < NB; t += 4) acc += W[t * NB + col] * bk[t];         // x_kb = W_kb^T y_kb
+    part[chunk][col] = acc;
+  }
+  __syncthreads();
+  if (threadIdx.x < NB) xk[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+  __syncthreads();
+  if (blockIdx.x == 0) {
+    if (threadIdx.x < NB) xo[kb * NB + threadIdx.x] = xk[threadIdx.x];
+    return;
+  }
+  const int bi = kb - (int)blockIdx.x;
+  const double* Lb = S + (int64_t)bi * NB * ld + (int64_t)kb * NB;              // [t][col] = L_{kb,bi}[t][col]
+  double acc = 0.0;
+  for (int t = chunk; t < NB; t += 4) acc += Lb[(int64_t)t * ld + col] * xk[t];
+  __syncthreads();
+  part[chunk][col] = acc;
+  __syncthreads();
+  if (threadIdx.x < NB) y[bi * NB + threadIdx.x] -= part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+
+// G block rows per launch (kb, kb-1, .., kb-G+1, all >= 0): every workgroup solves the G x G block triangle itself - all its operands
+// (the G inverses, the G (G-1) / 2 coupling blocks, and its own G blocks of the update) are requested at the head of the kernel, so the G
+// dependent rounds cost LDS round trips, not trips to L2 - then workgroup b >= 1 updates block row kb - G + 1 - b.
+template <int G>
+__global__ __launch_bounds__(256) void k_trsv_back_multi(const double* __restrict__ S, int64_t ld, int kb, const double* __restrict__ Winv, double* __restrict__ y,
+                                                         double* __restrict__ xo) {
+  __shared__ double xs[G][NB];
+  __shared__ double vk[NB];
+  __shared__ double part[4][NB];
+  const int tid = threadIdx.x, col = tid & 63, chunk = tid >> 6;
+  const bool upd = blockIdx.x > 0;
+  const int bi = kb - G + 1 - (int)blockIdx.x;
+  double wq[G][16], lq[G * (G - 1) / 2 + 1][16], lu[G][16], yq[G];
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    const double* W = Winv + (int64_t)(kb - g) * NB * NB;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) wq[g][i] = W[(chunk + 4 * i) * NB + col];
+    yq[g] = tid < NB ? y[(kb - g) * NB + tid] : 0.0;
+  }
+  {
+    int idx = 0;
+#pragma unroll
+    for (int g = 1; g < G; ++g)
+#pragma unroll
+      for (int gp = 0; gp < g; ++gp, ++idx) {
+        const double* Lb = S + (int64_t)(kb - g) * NB * ld + (int64_t)(kb - gp) * NB;        // block (kb-g, kb-gp) holds L_{kb-gp, kb-g}
+#pragma unroll
+        for (int i = 0; i < 16; ++i) lq[idx][i] = Lb[(int64_t)(chunk + 4 * i) * ld + col];
+      }
+  }
+  if (upd) {
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const double* Lb = S + (int64_t)bi * NB * ld + (int64_t)(kb - g) * NB;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) lu[g][i] = Lb[(int64_t)(chunk + 4 * i) * ld + col];
+    }
+  }
+  {
+    int idx = 0;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      double acc = 0.0;
+#pragma unroll
+      for (int gp = 0; gp < g; ++gp, ++idx)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc += lq[idx][i] * xs[gp][chunk + 4 * i];
+      if (g > 0) {
+        part[chunk][col] = acc;
+        __syncthreads();
+      }
+      if (tid < NB) vk[tid] = g > 0 ? yq[g] - (part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid]) : yq[g];
+      __syncthreads();
+      acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc += wq[g][i] * vk[chunk + 4 * i];          // x_q = W_q^T v
+      part[chunk][col] = acc;
+      __syncthreads();
+      if (tid < NB) {
+        const double v = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+        xs[g][tid] = v;
+        if (!upd) xo[(kb - g) * NB + tid] = v;
+      }
+      __syncthreads();
+    }
+  }
+  if (upd) {
+    double acc = 0.0;
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc += lu[g][i] * xs[g][chunk + 4 * i];
+    part[chunk][col] = acc;
+    __syncthreads();
+    if (tid < NB) y[bi * NB + tid] -= part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
+  }
+}
+
 __global__ void k_copy_xp(BADev d, const double* __restrict__ x) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i < 6 * (int64_t)d.P) d.xp[i] = x[i];
 }
 
-// factor S (ld x ld, ld a multiple of 64) and solve S x = rhs -> d.xp.  d.flags[0] reports a failed factorisation.
+// VDO_BA_DENSE selects: 1 = the round-2 launch sequence (potrf + panel + syrk per step, two substitution sweeps); 2 = one launch per step
+// (above), potrf64_lds on the diagonal blocks; 3 = the same with potrf64_lds_v3; 4 = 3 + three block rows per launch of the backward
+// substitution; 5 = 2 + the same.
+static int dense_version() {
+  const char* e = std::getenv("VDO_BA_DENSE");
+  return e && e[0] >= '1' && e[0] <= '5' ? e[0] - '0' : VDO_BA_DENSE_DEFAULT;
+}
+
+// factor S (ld x ld, ld a multiple of 64) and solve S x = rhs -> d.xp.  d.flags[0] reports a failed factorisation.  rhs: [2][ld] (the second
+// half receives the forward-substituted vector of version 2).
 void launch_dense_solve(const BADev& d, double* S, int64_t ld, double* Winv, double* rhs, hipStream_t s) {
   const int nblk = (int)(ld / NB);
+  const int ver = dense_version();
+  if (ver >= 2) {
+    const int potrf = (ver == 2 || ver == 5) ? 2 : 3;            // routine of the diagonal blocks
+    const bool multi = ver >= 4;                                  // three block rows per launch of the backward substitution
+    double* yv = rhs + ld;
+    hipLaunchKernelGGL(k_potrf64_v2, dim3(1), dim3(256), 0, s, S, ld, 0, Winv, d.flags, potrf);
+    for (int k = 0; k + 1 < nblk; ++k) {
+      const int m = nblk - k - 1;
+      hipLaunchKernelGGL(k_chol_step, dim3(m * (m + 1) / 2), dim3(256), 0, s, S, ld, k, Winv, rhs, yv, d.flags, potrf);
+    }
+    hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, s, nblk - 1, (const double*)Winv, (const double*)rhs, yv);
+    int kb = nblk - 1;                                            // (b is dead by now: the solution goes where it was)
+    if (multi) for (; kb >= 2; kb -= 3) hipLaunchKernelGGL(k_trsv_back_multi<3>, dim3(kb - 1), dim3(256), 0, s, (const double*)S, ld, kb, (const double*)Winv, yv, rhs);
+    for (; kb >= 0; --kb) hipLaunchKernelGGL(k_trsv_back_v2, dim3(kb + 1), dim3(256), 0, s, (const double*)S, ld, kb, (const double*)Winv, yv, rhs);
+    hipLaunchKernelGGL(k_copy_xp, dim3((unsigned)((6 * (int64_t)d.P + 255) / 256)), dim3(256), 0, s, d, (const double*)rhs);
+    return;
+  }
   for (int k = 0; k < nblk; ++k) {
     hipLaunchKernelGGL(k_potrf64, dim3(1), dim3(256), 0, s, S, ld, k, Winv, d.flags);
     const int m = nblk - k - 1;

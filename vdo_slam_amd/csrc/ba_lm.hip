@@ -51,7 +51,7 @@ int dense_prepare(vdo_ba* ba) {
   const int64_t ld = (6 * (int64_t)ba->d.P + 63) / 64 * 64;
   void *pS = nullptr, *pW = nullptr, *pr = nullptr;
   if (hipMalloc(&pS, sizeof(double) * (size_t)ld * (size_t)ld) != hipSuccess || hipMalloc(&pW, sizeof(double) * (size_t)ld * 64) != hipSuccess ||
-      hipMalloc(&pr, sizeof(double) * (size_t)ld) != hipSuccess) {
+      hipMalloc(&pr, sizeof(double) * 2 * (size_t)ld) != hipSuccess) {
     if (pS) hipFree(pS);
     if (pW) hipFree(pW);
     return set_error(VDO_ERR_OOM, "dense reduced-camera solver: hipMalloc(%lld x %lld doubles) failed", (long long)ld, (long long)ld);

@@ -14,7 +14,9 @@
 // LDS, the landmark-chain solves run there, and B w is segment-reduced per pose slot into pose-major
 // partial rows -> 8 B per incidence from HBM per CG iteration, no global atomics.  One WAVE per
 // pose and one workgroup per pose chain for the vector phases of the CG (k_pcg_q, k_pcg_chain).
+#include <algorithm>
 #include <atomic>
+#include <cstdlib>
 
 #include "ba_dev.hpp"
 #include "ba_tile.hpp"
@@ -1279,6 +1281,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Tile T = d.tiles[blockIdx.x];
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
+  if ((int)blockIdx.y >= nslot) return;       // (the slots of a tile are dealt round-robin to the gridDim.y workgroups that share it)
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, ninc = nb + 2 * nt;
   double* u6 = smem;                          // [6][3*TP]
   double* dinv = u6 + 18 * VDO_TILE_PTS;      // [9*TP]
@@ -1287,7 +1290,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   double* slotW = q36 + 36 * d.max_slots;     // [12*S]
   double* pts = slotW + 12 * d.max_slots;     // [3*TP]
   int* touched = (int*)(pts + 3 * VDO_TILE_PTS);    // [TP]
+  int* choff = touched + VDO_TILE_PTS;              // [TP+1] the tile's chain offsets (read in every pass over the slots: not from L2 each time)
   const int tid = threadIdx.x;
+  for (int i = tid; i <= T.chain_end - T.chain_begin; i += VDO_TILE_THREADS) choff[i] = d.chain_off[T.chain_begin + i];
   stage_slot_w_pts(d, T, slotW, pts);
   {
     const double* gd = d.Dinv + 9 * (int64_t)T.pt_begin;
@@ -1315,7 +1320,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < VDO_TILE_EPT; ++j) F[j] = key[j] >= 0 ? make_f(d, T, tid + VDO_TILE_THREADS * j, kind[j], key[j], we[j], slotW, pts) : FInc{0, 0, 0, 0};
-  for (int s = 0; s < nslot; ++s) {
+  for (int s = blockIdx.y; s < nslot; s += gridDim.y) {
     __syncthreads();
     for (int i = tid; i < 18 * VDO_TILE_PTS; i += VDO_TILE_THREADS) u6[i] = 0.0;
     for (int i = tid; i < 36 * nslot; i += VDO_TILE_THREADS) q36[i] = 0.0;
@@ -1341,7 +1346,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     // chain becomes "touched" as a whole (its points all carry w)
     const int nch = T.chain_end - T.chain_begin;
     for (int c = tid; c < nch; c += VDO_TILE_THREADS) {
-      const int64_t p0 = d.chain_off[T.chain_begin + c], p1 = d.chain_off[T.chain_begin + c + 1];
+      const int64_t p0 = choff[c], p1 = choff[c + 1];
       if (p1 - p0 < 2) continue;
       int any = 0;
       for (int64_t l = p0; l < p1; ++l) any |= touched[l - T.pt_begin];
@@ -1350,7 +1355,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     __syncthreads();
     for (int task = tid; task < 6 * nch; task += VDO_TILE_THREADS) {
       const int c = task / 6, b = task - 6 * c;
-      const int64_t p0 = d.chain_off[T.chain_begin + c], p1 = d.chain_off[T.chain_begin + c + 1];
+      const int64_t p0 = choff[c], p1 = choff[c + 1];
       if (!touched[p0 - T.pt_begin]) continue;
       double* u = u6 + b * 3 * VDO_TILE_PTS;
       D3 yprev{0, 0, 0};
@@ -1405,12 +1410,17 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   }
 }
 
-size_t dense_tile_lds(const BADev& d) { return (39 * VDO_TILE_PTS + 48 * (size_t)d.max_slots) * sizeof(double) + VDO_TILE_PTS * sizeof(int); }
+size_t dense_tile_lds(const BADev& d) { return (39 * VDO_TILE_PTS + 48 * (size_t)d.max_slots) * sizeof(double) + (2 * VDO_TILE_PTS + 2) * sizeof(int); }
 
 // S <- reduced-camera matrix at this lambda (launch_factor must have run: it leaves the landmark chain factors of Hll + lambda I)
 void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R) {
   hipMemsetAsync(S, 0, sizeof(double) * (size_t)ld * (size_t)ld, s);
-  if (d.n_tiles) hipLaunchKernelGGL(k_schur_dense_tile, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), dense_tile_lds(d), s, d, S, ld);
+  // A tile's columns (one per pose slot: up to max_slots sequential passes with five barriers each, and a dynamic track's chain solves walk
+  // 60-80 points on 6 threads per chain) are independent of each other: the slots go round-robin to `split` workgroups per tile, enough of
+  // them to fill the device several times over (the graphs this solver is chosen for have a few hundred tiles at most).
+  const int split = std::getenv("VDO_BA_DENSE_SPLIT") ? std::max(1, std::atoi(std::getenv("VDO_BA_DENSE_SPLIT")))
+                                                      : (int)std::min<int64_t>(16, std::max<int64_t>(1, (2048 + d.n_tiles - 1) / std::max(1, d.n_tiles)));
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_dense_tile, dim3(d.n_tiles, split), dim3(VDO_TILE_THREADS), dense_tile_lds(d), s, d, S, ld);
   if (d.sharded) R(S, ld * ld);                     // landmark-side contributions of every rank (all-reduce of S)
   const int64_t n = 36 * (int64_t)(d.P + d.Ep) + (ld - 6 * (int64_t)d.P);
   hipLaunchKernelGGL(k_dense_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, S, ld, lambda);
