@@ -17,7 +17,7 @@
 #include "ba_dev.hpp"
 
 #ifndef VDO_BA_DENSE_DEFAULT
-#define VDO_BA_DENSE_DEFAULT 1
+#define VDO_BA_DENSE_DEFAULT 4
 #endif
 
 namespace vdo {
