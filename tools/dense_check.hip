@@ -129,6 +129,20 @@ int main(int argc, char** argv) {
       hipFree(dS); hipFree(dW); hipFree(dr); hipFree(dx); hipFree(dflags);
     }
   }
+#ifdef DENSE_PROF
+  {   // phases of the critical workgroup of k_chol_step, mean over the steps of the LAST system solved (the 34-block one), shader cycles
+    static long long h[64][16];
+    hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dense_prof), sizeof(h));
+    const char* names[15] = {"stage", "panel products", "LDS write + panel store", "update product + G", "rhs", "potrf: zero W", "potrf: panels", "potrf: trailing",
+                             "potrf: Wd", "potrf: assembly", "store", "wall ticks (100 MHz)", "cycles total", "last workgroup: cycles", "last workgroup: wall ticks"};
+    for (int i = 0; i < 15; ++i) {
+      double sum = 0; int cnt = 0;
+      for (int k = 0; k < 33; ++k) if (i < 13 || k < 32) { sum += (double)h[k][i]; ++cnt; }
+      printf("prof %-28s %10.0f\n", names[i], sum / cnt);
+    }
+    for (int k = 0; k < 33; k += 8) printf("prof step %d: total cycles %lld wall %lld | last wg cycles %lld wall %lld\n", k, h[k][12], h[k][11], h[k][13], h[k][14]);
+  }
+#endif
   printf("dense_check: %d bad\n", nbad);
   return nbad;
 }

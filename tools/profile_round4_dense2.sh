@@ -1,0 +1,11 @@
+# Round 4, dense solver, second pass: phase probe of the critical workgroup of k_chol_step (tools/dense_check_prof, -DDENSE_PROF), the dense tests on the
+# rewritten assembly kernel, ms per LM iteration against the slots-per-workgroup of the assembly, kernel statistics.  -> gpurun_out/r04e/
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r04e; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 100 $R/tools/dense_check_prof 3 4 > $O/dense_check_prof.log 2>&1; echo "dense_check_prof rc $?"; grep "prof\|2176" $O/dense_check_prof.log
+cd $R
+timeout 300 python -m pytest tests/test_ba_gpu.py -m gpu -q --tb=short -rf -k "dense or non_path or wide_partial or tile_size" 2>&1 | grep -v "^  File \"/usr" | tail -15 > $O/test_ba.log; tail -4 $O/test_ba.log
+DENSE_PROBE_VERSIONS=4 DENSE_PROBE_CHUNKS=1,2,4,8,16,99 timeout 200 python tools/dense_probe.py > $O/dense_probe.log 2>&1; tail -8 $O/dense_probe.log
+( cd /tmp && timeout 150 rocprofv3 --kernel-trace --stats -d $O/prof_probe -- env DENSE_PROBE_VERSIONS=4 python $R/tools/dense_probe.py > $O/dense_probe_prof.log 2>&1 )
+DB=$(find $O/prof_probe -name "*.db" | head -1); python tools/rocprof_summary.py $DB 40 > $O/dense_probe_kernel_stats.txt 2>&1; cut -c1-150 $O/dense_probe_kernel_stats.txt | head -12
+find $O -name "*.db" -size +20M -delete

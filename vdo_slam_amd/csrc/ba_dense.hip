@@ -25,6 +25,20 @@ namespace vdo {
 constexpr int NB = 64;
 typedef double d4 __attribute__((ext_vector_type(4)));
 
+// -DDENSE_PROF (tools/dense_check.hip, debug build only): shader-clock cycles per phase of the workgroup of k_chol_step that factorises the next
+// diagonal block - the critical path of a step
+#ifdef DENSE_PROF
+struct DProf { long long t[16]; long long prev; };
+__device__ long long g_dense_prof[64][16];
+#define DP_ARG , DProf& pr
+#define DP_PASS , pr
+#define DP_TICK(slot) do { if (threadIdx.x == 0) { const long long t_ = clock64(); pr.t[slot] += t_ - pr.prev; pr.prev = t_; } } while (0)
+#else
+#define DP_ARG
+#define DP_PASS
+#define DP_TICK(slot) do { } while (0)
+#endif
+
 // D(64x64) = A(64x64) * B(64x64)^T for one workgroup of 256 threads (4 waves).  As, Bs: LDS copies, row-major with stride LDS_LD
 // (padded: rows land on different banks).  Wave w computes rows [16w, 16w+16); acc[t] = the 16x16 tile of columns [16t, 16t+16):
 // lane l holds D[16w + (l>>4) + 4*reg][16t + (l&15)]  (f64 MFMA C/D layout).
@@ -370,10 +384,11 @@ __device__ void potrf64_lds(double* A, double* W, double* Tm, int* s_bad) {
 // X = A_sub Ld^-T falls out of the column loop that produces Ld (its broadcasts are wave-wide anyway) and no inverse is needed inside
 // the loop; the four 16x16 inverses are formed afterwards, one per wave, by forward substitution on the unit vectors (lane c: column c;
 // the entries of L are LDS broadcasts).  dinv: LDS, 64 doubles (reciprocal pivots).
-__device__ void potrf64_lds_v3(double* A, double* W, double* Tm, double* dinv, int* s_bad) {
+__device__ void potrf64_lds_v3(double* A, double* W, double* Tm, double* dinv, int* s_bad DP_ARG) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   for (int i = tid; i < NB * LDS_LD; i += 256) W[i] = 0.0;
   __syncthreads();
+  DP_TICK(5);
   for (int kb = 0; kb < 4; ++kb) {
     const int o = 16 * kb;
     if (wv == 0) {
@@ -401,6 +416,7 @@ __device__ void potrf64_lds_v3(double* A, double* W, double* Tm, double* dinv, i
       if (bad && lane == 0) *s_bad = 1;             // (p is wave-uniform)
     }
     __syncthreads();
+    DP_TICK(6);
     const int nrt = 3 - kb;
     const int ntile = nrt * (nrt + 1) / 2;          // trailing update of the lower triangle, tile (ti, tj), tj <= ti:  A -= X_ti X_tj^T
     for (int q = wv; q < ntile; q += 4) {
@@ -411,6 +427,7 @@ __device__ void potrf64_lds_v3(double* A, double* W, double* Tm, double* dinv, i
       for_acc([&](int rr, int cc, int qq) { A[(R0 + rr) * LDS_LD + C0 + cc] -= u[qq]; });
     }
     __syncthreads();
+    DP_TICK(7);
   }
   {   // Wd of block wv: column c of Ld^-1 on lane c (lanes >= 16 repeat column c & 15 and do not store)
     const int o = 16 * wv, c = lane & 15;
@@ -428,6 +445,7 @@ __device__ void potrf64_lds_v3(double* A, double* W, double* Tm, double* dinv, i
     }
   }
   __syncthreads();
+  DP_TICK(8);
   for (int dist = 1; dist < 4; ++dist) {
     const int nbk = 4 - dist;
     const int j = wv, i = wv + dist;
@@ -442,6 +460,7 @@ __device__ void potrf64_lds_v3(double* A, double* W, double* Tm, double* dinv, i
     }
     __syncthreads();
   }
+  DP_TICK(9);
 }
 
 __device__ __forceinline__ void store_factor(const double* A, const double* W, double* __restrict__ G, int64_t ld, double* __restrict__ Wk) {
@@ -463,7 +482,11 @@ __global__ __launch_bounds__(256) void k_potrf64_v2(double* __restrict__ S, int6
   stage64(G, ld, A);
   if (threadIdx.x == 0) s_bad = 0;
   __syncthreads();
-  if (variant == 3) potrf64_lds_v3(A, W, Tm, dinv, &s_bad);
+#ifdef DENSE_PROF
+  DProf pr; pr.prev = clock64();
+  for (int i = 0; i < 16; ++i) pr.t[i] = 0;
+#endif
+  if (variant == 3) potrf64_lds_v3(A, W, Tm, dinv, &s_bad DP_PASS);
   else potrf64_lds(A, W, Tm, &s_bad);
   store_factor(A, W, G, ld, Winv + (int64_t)k * NB * NB);
   if (threadIdx.x == 0 && s_bad) atomicOr(flags, 1);
@@ -482,16 +505,23 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64
   while (t > ri) { t -= ri + 1; ++ri; }
   const int bi = k + 1 + ri, bj = k + 1 + t;
   const bool diag = bi == bj, first = bj == k + 1;
+#ifdef DENSE_PROF
+  DProf pr; pr.prev = clock64();
+  for (int i = 0; i < 16; ++i) pr.t[i] = 0;
+  const long long wall0 = wall_clock64(), clk0 = pr.prev;
+#endif
   stage64(S + (int64_t)bi * NB * ld + (int64_t)k * NB, ld, As);
   if (!diag) stage64(S + (int64_t)bj * NB * ld + (int64_t)k * NB, ld, Bs);
   stage64(Winv + (int64_t)k * NB * NB, NB, Ws);
   if (tid == 0) s_bad = 0;
   if (first && tid < NB) bk[tid] = rhs[k * NB + tid];
   __syncthreads();
+  DP_TICK(0);
   d4 li[4], lj[4];
   gemm64_abt(As, Ws, li);                           // L_ik = A_ik W_k^T
   if (!diag) gemm64_abt(Bs, Ws, lj);
   __syncthreads();                                  // (every wave has read the raw blocks)
+  DP_TICK(1);
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt)
     for_acc([&](int rr, int cc, int q) {
@@ -504,6 +534,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64
     for (int tt = 0; tt < 4; ++tt) for_acc([&](int rr, int cc, int q) { P[(int64_t)(16 * wv + rr) * ld + 16 * tt + cc] = li[tt][q]; });
   }
   __syncthreads();
+  DP_TICK(2);
   d4 acc[4];
   gemm64_abt(As, diag ? As : Bs, acc);              // L_ik L_jk^T
   double* G = S + (int64_t)bi * NB * ld + (int64_t)bj * NB;
@@ -515,6 +546,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64
       if (next) Bs[(16 * wv + rr) * LDS_LD + 16 * tt + cc] = *g - acc[tt][q];       // (Bs is free in a diagonal workgroup)
       else *g -= acc[tt][q];
     });
+  DP_TICK(3);
   if (first) {                                      // forward substitution: y_k = W_k b_k, b_i -= L_ik y_k
     const int col = tid & 63, chunk = tid >> 6;
     {
@@ -539,11 +571,23 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64
   }
   if (next) {
     __syncthreads();
-    if (variant == 3) potrf64_lds_v3(Bs, Ws, As, yk, &s_bad);
+    DP_TICK(4);
+    if (variant == 3) potrf64_lds_v3(Bs, Ws, As, yk, &s_bad DP_PASS);
     else potrf64_lds(Bs, Ws, As, &s_bad);
     store_factor(Bs, Ws, G, ld, Winv + (int64_t)(k + 1) * NB * NB);
     if (tid == 0 && s_bad) atomicOr(flags, 1);
+    DP_TICK(10);
+#ifdef DENSE_PROF
+    if (tid == 0 && k < 64) {
+      for (int i = 0; i < 11; ++i) g_dense_prof[k][i] = pr.t[i];
+      g_dense_prof[k][11] = wall_clock64() - wall0;
+      g_dense_prof[k][12] = clock64() - clk0;
+    }
+#endif
   }
+#ifdef DENSE_PROF
+  if (!next && tid == 0 && k < 64 && blockIdx.x == gridDim.x - 1) { g_dense_prof[k][13] = clock64() - clk0; g_dense_prof[k][14] = wall_clock64() - wall0; }
+#endif
 }
 
 // y of the last block (no step launch follows its factorisation)

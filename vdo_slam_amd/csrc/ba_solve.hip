@@ -1253,6 +1253,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_expand_binc(BADev d) {
   }
 }
 
+#ifndef VDO_BA_DENSE_CHUNK_DEFAULT
+#define VDO_BA_DENSE_CHUNK_DEFAULT 4
+#endif
 // ---- explicit reduced-camera matrix for the dense solver (ba_dense.hip) ---------------------------------------------
 // S (row-major, leading dimension ld >= 6P, padded rows/columns = identity) = blockdiag(Hpp + lambda I) + EdgeSE3 off-diagonal
 // blocks - sum over tiles of B Hll^-1 B^T.
@@ -1277,11 +1280,12 @@ __global__ __launch_bounds__(256) void k_dense_init(BADev d, double* __restrict_
 // One workgroup per tile; for every pose slot s of the tile the six unit vectors e_(s,b) go through B^T, the landmark chain
 // solves and B at once (6 right-hand sides); the resulting 6x6 blocks against every slot r that shares a point (or a
 // dynamic track) with s are subtracted from S with fp64 atomics.  Only the points reached from slot s are touched.
-__global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, double* __restrict__ S, int64_t ld) {
+__global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, double* __restrict__ S, int64_t ld, int chunk) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Tile T = d.tiles[blockIdx.x];
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
-  if ((int)blockIdx.y >= nslot) return;       // (the slots of a tile are dealt round-robin to the gridDim.y workgroups that share it)
+  const int s_begin = (int)blockIdx.y * chunk, s_end = min(nslot, s_begin + chunk);      // (the slots of a tile go in runs of `chunk` to the workgroups (tile, y))
+  if (s_begin >= nslot) return;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, ninc = nb + 2 * nt;
   double* u6 = smem;                          // [6][3*TP]
   double* dinv = u6 + 18 * VDO_TILE_PTS;      // [9*TP]
@@ -1291,36 +1295,82 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   double* pts = slotW + 12 * d.max_slots;     // [3*TP]
   int* touched = (int*)(pts + 3 * VDO_TILE_PTS);    // [TP]
   int* choff = touched + VDO_TILE_PTS;              // [TP+1] the tile's chain offsets (read in every pass over the slots: not from L2 each time)
+  int* spose = choff + VDO_TILE_PTS + 1;            // [S] pose id of every slot
   const int tid = threadIdx.x;
-  for (int i = tid; i <= T.chain_end - T.chain_begin; i += VDO_TILE_THREADS) choff[i] = d.chain_off[T.chain_begin + i];
-  stage_slot_w_pts(d, T, slotW, pts);
+  // ---- head: what the tile needs from HBM / L2 in TWO rounds of requests, every request of a round made before the first use of any of them
+  // (the round-3 form walked the 9 * npts factor entries in a loop whose every pass waited for a flag and then for a value: ~18 round trips of
+  // ~1.5 us per workgroup, and with the slots dealt to many workgroups per tile every one of them pays for the head).
+  // round 1: pose id of slot `tid`, point `tid`'s single-point flag, the points, this thread's incidences (key + information scalar)
+  const int my_slot = min(tid, nslot - 1);
+  const int my_pose = d.tile_pose[T.slot_begin + my_slot];
+  const int my_pt = min(tid, max(npts - 1, 0));
+  const int64_t my_l = T.pt_begin + my_pt;
+  const int my_single = d.pt_single[my_l];
+  double pv[3];
   {
-    const double* gd = d.Dinv + 9 * (int64_t)T.pt_begin;
-    const double* gg = d.Gl + 9 * (int64_t)T.pt_begin;
-    for (int i = tid; i < 9 * npts; i += VDO_TILE_THREADS) {
-      const int64_t l = T.pt_begin + i / 9;
-      if (d.pt_single[l]) { dinv[i] = (i % 9) % 4 == 0 ? d.dscal[l] : 0.0; gl[i] = 0.0; }      // (a point on its own: dscal * I3, ba_dev.hpp)
-      else { dinv[i] = gd[i]; gl[i] = gg[i]; }
-    }
+    const double* __restrict__ point = d.point[0] + 3 * (int64_t)T.pt_begin;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pv[k] = point[min(tid + k * VDO_TILE_THREADS, max(3 * npts - 1, 0))];
   }
   int key[VDO_TILE_EPT], kind[VDO_TILE_EPT];       // (<= VDO_TILE_INC = 256 * VDO_TILE_EPT incidences per tile)
   FInc F[VDO_TILE_EPT];
   double we[VDO_TILE_EPT];
 #pragma unroll
-  for (int j = 0; j < VDO_TILE_EPT; ++j) {
-    const int li = tid + VDO_TILE_THREADS * j;
-    key[j] = -1; kind[j] = 1; we[j] = 0.0;
-    if (li < ninc) {
-      key[j] = d.inc_key[T.inc_begin + li];
+  for (int j = 0; j < VDO_TILE_EPT; ++j) { key[j] = -1; kind[j] = 1; we[j] = 0.0; }
+  if (ninc > 0) {                                  // (uniform)
+#pragma unroll
+    for (int j = 0; j < VDO_TILE_EPT; ++j) {
+      const int li = tid + VDO_TILE_THREADS * j, lic = min(li, ninc - 1);
       int64_t fidx;
-      inc_locate(T, li, d.Eb, kind[j], fidx);
-      we[j] = d.Finc[fidx];
+      inc_locate(T, lic, d.Eb, kind[j], fidx);
+      const int kv = d.inc_key[T.inc_begin + lic];
+      const double wv = d.Finc[fidx];
+      key[j] = li < ninc ? kv : -1;
+      we[j] = li < ninc ? wv : 0.0;
+    }
+  }
+  const int nch = T.chain_end - T.chain_begin;
+  for (int i = tid; i <= nch; i += VDO_TILE_THREADS) choff[i] = d.chain_off[T.chain_begin + i];
+  // round 2: the slot's pose, the point's factor
+  const IsoD my_iso = iso_load(d.pose[0] + 12 * (int64_t)my_pose);
+  double fd[9], fg[9];
+  {
+    const double ds = d.dscal[my_l];
+    const double* gd = d.Dinv + 9 * my_l;
+    const double* gg = d.Gl + 9 * my_l;
+    if (my_single) {                               // (a point on its own: dscal * I3, ba_dev.hpp - its rows of Dinv / Gl are never written)
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { fd[q] = q % 4 == 0 ? ds : 0.0; fg[q] = 0.0; }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { fd[q] = gd[q]; fg[q] = gg[q]; }
+    }
+  }
+  {
+    auto stage_slot = [&](int sidx, int pid, const IsoD& iso) {
+      const IsoD W = iso_inv(iso);
+      double* o = slotW + 12 * sidx;
+#pragma unroll
+      for (int i = 0; i < 9; ++i) o[i] = W.r[i];
+      o[9] = W.t.x; o[10] = W.t.y; o[11] = W.t.z;
+      spose[sidx] = pid;
+    };
+    if (tid < nslot) stage_slot(tid, my_pose, my_iso);
+    for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) {       // (more than 256 slots in a tile: not in any graph of the bench)
+      const int pid = d.tile_pose[T.slot_begin + sidx];
+      stage_slot(sidx, pid, iso_load(d.pose[0] + 12 * (int64_t)pid));
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pv[k]; }
+    if (tid < npts) {
+#pragma unroll
+      for (int q = 0; q < 9; ++q) { dinv[9 * tid + q] = fd[q]; gl[9 * tid + q] = fg[q]; }
     }
   }
   __syncthreads();
 #pragma unroll
   for (int j = 0; j < VDO_TILE_EPT; ++j) F[j] = key[j] >= 0 ? make_f(d, T, tid + VDO_TILE_THREADS * j, kind[j], key[j], we[j], slotW, pts) : FInc{0, 0, 0, 0};
-  for (int s = blockIdx.y; s < nslot; s += gridDim.y) {
+  for (int s = s_begin; s < s_end; ++s) {
     __syncthreads();
     for (int i = tid; i < 18 * VDO_TILE_PTS; i += VDO_TILE_THREADS) u6[i] = 0.0;
     for (int i = tid; i < 36 * nslot; i += VDO_TILE_THREADS) q36[i] = 0.0;
@@ -1344,7 +1394,6 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     __syncthreads();
     // chain solves w = Hll^-1 u for the chains slot s reaches, one (chain, right-hand side) per thread-iteration; a reached
     // chain becomes "touched" as a whole (its points all carry w)
-    const int nch = T.chain_end - T.chain_begin;
     for (int c = tid; c < nch; c += VDO_TILE_THREADS) {
       const int64_t p0 = choff[c], p1 = choff[c + 1];
       if (p1 - p0 < 2) continue;
@@ -1399,28 +1448,28 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       }
     }
     __syncthreads();
-    const int64_t gs = d.tile_pose[T.slot_begin + s];
+    const int64_t gs = spose[s];
     for (int i = tid; i < 36 * nslot; i += VDO_TILE_THREADS) {
       const double v = q36[i];
       if (v == 0.0) continue;
       const int r = i / 36, b = (i % 36) / 6, a = i % 6;         // q36[r][b][a]
-      const int64_t gr = d.tile_pose[T.slot_begin + r];
+      const int64_t gr = spose[r];
       atomicAdd(S + (6 * gr + a) * ld + 6 * gs + b, -v);
     }
   }
 }
 
-size_t dense_tile_lds(const BADev& d) { return (39 * VDO_TILE_PTS + 48 * (size_t)d.max_slots) * sizeof(double) + (2 * VDO_TILE_PTS + 2) * sizeof(int); }
+size_t dense_tile_lds(const BADev& d) { return (39 * VDO_TILE_PTS + 48 * (size_t)d.max_slots) * sizeof(double) + (2 * VDO_TILE_PTS + 2 + (size_t)d.max_slots) * sizeof(int); }
 
 // S <- reduced-camera matrix at this lambda (launch_factor must have run: it leaves the landmark chain factors of Hll + lambda I)
 void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R) {
   hipMemsetAsync(S, 0, sizeof(double) * (size_t)ld * (size_t)ld, s);
   // A tile's columns (one per pose slot: up to max_slots sequential passes with five barriers each, and a dynamic track's chain solves walk
-  // 60-80 points on 6 threads per chain) are independent of each other: the slots go round-robin to `split` workgroups per tile, enough of
-  // them to fill the device several times over (the graphs this solver is chosen for have a few hundred tiles at most).
-  const int split = std::getenv("VDO_BA_DENSE_SPLIT") ? std::max(1, std::atoi(std::getenv("VDO_BA_DENSE_SPLIT")))
-                                                      : (int)std::min<int64_t>(16, std::max<int64_t>(1, (2048 + d.n_tiles - 1) / std::max(1, d.n_tiles)));
-  if (d.n_tiles) hipLaunchKernelGGL(k_schur_dense_tile, dim3(d.n_tiles, split), dim3(VDO_TILE_THREADS), dense_tile_lds(d), s, d, S, ld);
+  // its points on 6 threads per chain) are independent of each other: they go in runs of `chunk` to the workgroups (tile, 0 .. max_slots / chunk) -
+  // most tiles of the bench graph carry a dozen slots, the ones with the long dynamic tracks 81: one workgroup per tile left the device waiting
+  // for those (1.82 ms).  VDO_BA_DENSE_CHUNK overrides.
+  const int chunk = std::getenv("VDO_BA_DENSE_CHUNK") ? std::max(1, std::atoi(std::getenv("VDO_BA_DENSE_CHUNK"))) : VDO_BA_DENSE_CHUNK_DEFAULT;
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_dense_tile, dim3(d.n_tiles, (d.max_slots + chunk - 1) / chunk), dim3(VDO_TILE_THREADS), dense_tile_lds(d), s, d, S, ld, chunk);
   if (d.sharded) R(S, ld * ld);                     // landmark-side contributions of every rank (all-reduce of S)
   const int64_t n = 36 * (int64_t)(d.P + d.Ep) + (ld - 6 * (int64_t)d.P);
   hipLaunchKernelGGL(k_dense_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, S, ld, lambda);
