@@ -63,6 +63,18 @@ __device__ __forceinline__ void stage64(const double* __restrict__ G, int64_t ld
   for (int i = threadIdx.x; i < NB * NB; i += blockDim.x) { const int r = i >> 6, c = i & 63; Ls[r * LDS_LD + c] = G[r * ld + c]; }
 }
 
+// The same in two halves - request (16 values per thread into registers), commit (-> LDS): the blocks a kernel needs are requested together and
+// arrive in ONE round trip; stage64's loop waits for every value before it asks for the next (16 trips of ~700 cycles each from L2: the phase
+// probe of k_chol_step showed 21 k cycles of its 101 k there).
+__device__ __forceinline__ void stage64_request(const double* __restrict__ G, int64_t ld, double (&v)[16]) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { const int i = threadIdx.x + 256 * q; v[q] = G[(int64_t)(i >> 6) * ld + (i & 63)]; }
+}
+__device__ __forceinline__ void stage64_commit(const double (&v)[16], double* Ls) {
+#pragma unroll
+  for (int q = 0; q < 16; ++q) { const int i = threadIdx.x + 256 * q; Ls[(i >> 6) * LDS_LD + (i & 63)] = v[q]; }
+}
+
 // broadcast of a double from a compile-time-known lane (two scalar v_readlane_b32: no LDS round trip)
 __device__ __forceinline__ double bcast(double v, int lane) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), lane), __builtin_amdgcn_readlane(__double2loint(v), lane));
@@ -407,7 +419,7 @@ __device__ void potrf64_lds_v3(double* A, double* W, double* Tm, double* dinv, i
         a[j] = l;
         if (lane == j) dinv[o + j] = inv;
 #pragma unroll
-        for (int c = j + 1; c < 16; ++c) a[c] -= l * bcast(l, c);
+        for (int c = j + 1; c < 16; ++c) a[c] = __builtin_fma(-l, bcast(l, c), a[c]);
       }
       if (active) {
 #pragma unroll
@@ -479,7 +491,11 @@ __global__ __launch_bounds__(256) void k_potrf64_v2(double* __restrict__ S, int6
   __shared__ double dinv[NB];
   __shared__ int s_bad;
   double* G = S + (int64_t)k * NB * ld + (int64_t)k * NB;
-  stage64(G, ld, A);
+  {
+    double v[16];
+    stage64_request(G, ld, v);
+    stage64_commit(v, A);
+  }
   if (threadIdx.x == 0) s_bad = 0;
   __syncthreads();
 #ifdef DENSE_PROF
@@ -510,11 +526,22 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64
   for (int i = 0; i < 16; ++i) pr.t[i] = 0;
   const long long wall0 = wall_clock64(), clk0 = pr.prev;
 #endif
-  stage64(S + (int64_t)bi * NB * ld + (int64_t)k * NB, ld, As);
-  if (!diag) stage64(S + (int64_t)bj * NB * ld + (int64_t)k * NB, ld, Bs);
-  stage64(Winv + (int64_t)k * NB * NB, NB, Ws);
+  double* G = S + (int64_t)bi * NB * ld + (int64_t)bj * NB;
+  d4 gv[4];                                         // this thread's 16 entries of the block it updates: requested now, used after the three products
+  {
+    double va[16], vb[16], vw[16];
+    stage64_request(S + (int64_t)bi * NB * ld + (int64_t)k * NB, ld, va);
+    stage64_request(S + (int64_t)bj * NB * ld + (int64_t)k * NB, ld, vb);           // (the same block again in a diagonal workgroup: not committed)
+    stage64_request(Winv + (int64_t)k * NB * NB, NB, vw);
+    const double bkv = (first && tid < NB) ? rhs[k * NB + tid] : 0.0;
+#pragma unroll
+    for (int tt = 0; tt < 4; ++tt) for_acc([&](int rr, int cc, int q) { gv[tt][q] = G[(int64_t)(16 * wv + rr) * ld + 16 * tt + cc]; });
+    stage64_commit(va, As);
+    if (!diag) stage64_commit(vb, Bs);
+    stage64_commit(vw, Ws);
+    if (first && tid < NB) bk[tid] = bkv;
+  }
   if (tid == 0) s_bad = 0;
-  if (first && tid < NB) bk[tid] = rhs[k * NB + tid];
   __syncthreads();
   DP_TICK(0);
   d4 li[4], lj[4];
@@ -537,14 +564,13 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64
   DP_TICK(2);
   d4 acc[4];
   gemm64_abt(As, diag ? As : Bs, acc);              // L_ik L_jk^T
-  double* G = S + (int64_t)bi * NB * ld + (int64_t)bj * NB;
   const bool next = diag && first;                  // block (k+1, k+1): factorised below
 #pragma unroll
   for (int tt = 0; tt < 4; ++tt)
     for_acc([&](int rr, int cc, int q) {
-      double* g = G + (int64_t)(16 * wv + rr) * ld + 16 * tt + cc;
-      if (next) Bs[(16 * wv + rr) * LDS_LD + 16 * tt + cc] = *g - acc[tt][q];       // (Bs is free in a diagonal workgroup)
-      else *g -= acc[tt][q];
+      const double u = gv[tt][q] - acc[tt][q];
+      if (next) Bs[(16 * wv + rr) * LDS_LD + 16 * tt + cc] = u;       // (Bs is free in a diagonal workgroup)
+      else G[(int64_t)(16 * wv + rr) * ld + 16 * tt + cc] = u;
     });
   DP_TICK(3);
   if (first) {                                      // forward substitution: y_k = W_k b_k, b_i -= L_ik y_k

@@ -139,7 +139,8 @@ void launch_sweep_only(const BADev& d, hipStream_t s);             // just the K
 // ---- ba_solve.hip
 void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R);
 // landmark-chain LDL^T + inverse blocks + block-Jacobi + pose-chain factorisation, and the reduced right-hand side qs (beside it on `side` if given)
-void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const Reducer& R, hipStream_t side, hipEvent_t fork, hipEvent_t join);
+void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const Reducer& R, hipStream_t side, hipEvent_t fork, hipEvent_t join,
+                           bool precond = true);   // precond = false: without the PCG's preconditioner (block-Jacobi sums, pose-chain factorisation) - the dense solver's trials
 void launch_pcg_init(const BADev& d, hipStream_t s);
 void launch_pcg_iter(const BADev& d, double lambda, double tol2, int parity, hipStream_t s, const Reducer& R);   // parity: 0, 1, 0, ... from the first iteration after launch_pcg_init
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s);

@@ -72,10 +72,10 @@ int dense_prepare(vdo_ba* ba) {
 int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, int* pcg_iters, bool* pending) {
   const BADev& d = ba->d;
   hipStream_t s = ba->ctx->stream;
-  launch_factor_and_rhs(d, lambda, s, ba->red, ba->side, ba->ev_fork, ba->ev_join);
   const bool small = 6 * (int64_t)d.P <= kDenseMaxUnknowns;
   bool dense = opt->solver == 3 || (opt->solver == 0 && small && (!ba->pose_graph_is_paths || ba->last_solver == 3));
   if (dense && !small && opt->solver == 3) return set_error(VDO_ERR_UNSUPPORTED, "dense solver: %lld unknowns exceed %lld", 6LL * d.P, (long long)kDenseMaxUnknowns);
+  launch_factor_and_rhs(d, lambda, s, ba->red, ba->side, ba->ev_fork, ba->ev_join, !dense);
   if (dense) {
     int rc = dense_prepare(ba);
     if (rc != VDO_OK) return rc;

@@ -1253,6 +1253,13 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_expand_binc(BADev d) {
   }
 }
 
+// -DDENSE_PROF (tools/build_variant.sh, debug builds only): shader-clock cycles per phase of k_schur_dense_tile, summed over its workgroups
+#ifdef DENSE_PROF
+__device__ unsigned long long g_asm_prof[16];
+#define AP_TICK(slot) do { if (threadIdx.x == 0) { const long long t_ = clock64(); ap_t[slot] += t_ - ap_prev; ap_prev = t_; } } while (0)
+#else
+#define AP_TICK(slot) do { } while (0)
+#endif
 #ifndef VDO_BA_DENSE_CHUNK_DEFAULT
 #define VDO_BA_DENSE_CHUNK_DEFAULT 4
 #endif
@@ -1286,6 +1293,10 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
   const int s_begin = (int)blockIdx.y * chunk, s_end = min(nslot, s_begin + chunk);      // (the slots of a tile go in runs of `chunk` to the workgroups (tile, y))
   if (s_begin >= nslot) return;
+#ifdef DENSE_PROF
+  long long ap_t[10], ap_prev = clock64();
+  for (int i = 0; i < 10; ++i) ap_t[i] = 0;
+#endif
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, ninc = nb + 2 * nt;
   double* u6 = smem;                          // [6][3*TP]
   double* dinv = u6 + 18 * VDO_TILE_PTS;      // [9*TP]
@@ -1368,14 +1379,17 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     }
   }
   __syncthreads();
+  AP_TICK(0);
 #pragma unroll
   for (int j = 0; j < VDO_TILE_EPT; ++j) F[j] = key[j] >= 0 ? make_f(d, T, tid + VDO_TILE_THREADS * j, kind[j], key[j], we[j], slotW, pts) : FInc{0, 0, 0, 0};
+  AP_TICK(1);
   for (int s = s_begin; s < s_end; ++s) {
     __syncthreads();
     for (int i = tid; i < 18 * VDO_TILE_PTS; i += VDO_TILE_THREADS) u6[i] = 0.0;
     for (int i = tid; i < 36 * nslot; i += VDO_TILE_THREADS) q36[i] = 0.0;
     for (int i = tid; i < npts; i += VDO_TILE_THREADS) touched[i] = 0;
     __syncthreads();
+    AP_TICK(2);
     // pass A: u_b[l] += row b of the explicit 6x3 block of every incidence (s, l)
 #pragma unroll
     for (int j = 0; j < VDO_TILE_EPT; ++j) {
@@ -1392,6 +1406,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       }
     }
     __syncthreads();
+    AP_TICK(3);
     // chain solves w = Hll^-1 u for the chains slot s reaches, one (chain, right-hand side) per thread-iteration; a reached
     // chain becomes "touched" as a whole (its points all carry w)
     for (int c = tid; c < nch; c += VDO_TILE_THREADS) {
@@ -1402,6 +1417,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       if (any) for (int64_t l = p0; l < p1; ++l) touched[l - T.pt_begin] = 2;
     }
     __syncthreads();
+    AP_TICK(4);
     for (int task = tid; task < 6 * nch; task += VDO_TILE_THREADS) {
       const int c = task / 6, b = task - 6 * c;
       const int64_t p0 = choff[c], p1 = choff[c + 1];
@@ -1425,6 +1441,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       }
     }
     __syncthreads();
+    AP_TICK(5);
     // pass C: block (r, s) += B_r w_b for every incidence (r, l) on a touched point; incidences are slot-sorted inside each
     // part, so the 36 values go through the segmented DPP reduction (many lanes share a slot: plain LDS atomics would serialise)
 #pragma unroll
@@ -1448,6 +1465,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       }
     }
     __syncthreads();
+    AP_TICK(6);
     const int64_t gs = spose[s];
     for (int i = tid; i < 36 * nslot; i += VDO_TILE_THREADS) {
       const double v = q36[i];
@@ -1456,7 +1474,15 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       const int64_t gr = spose[r];
       atomicAdd(S + (6 * gr + a) * ld + 6 * gs + b, -v);
     }
+      AP_TICK(7);
   }
+#ifdef DENSE_PROF
+  if (tid == 0) {
+    for (int i = 0; i < 8; ++i) atomicAdd(&g_asm_prof[i], (unsigned long long)ap_t[i]);
+    atomicAdd(&g_asm_prof[8], (unsigned long long)(s_end - s_begin));
+    atomicAdd(&g_asm_prof[9], 1ull);
+  }
+#endif
 }
 
 size_t dense_tile_lds(const BADev& d) { return (39 * VDO_TILE_PTS + 48 * (size_t)d.max_slots) * sizeof(double) + (2 * VDO_TILE_PTS + 2 + (size_t)d.max_slots) * sizeof(int); }
@@ -1505,17 +1531,19 @@ void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R) {
 // factorisation is a recurrence over the chain (a few workgroups, 0.7 us per step): on one GPU the reduced right-hand side (k_schur_tile<1>,
 // k_gather_q: every CU) runs beside it on the stream `side`, forked / joined with the two events.  Sharded solves keep one stream: the
 // exchanges of the all-reduce hook are ordered on it.
-void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const Reducer& R, hipStream_t side, hipEvent_t fork, hipEvent_t join) {
+void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const Reducer& R, hipStream_t side, hipEvent_t fork, hipEvent_t join, bool precond) {
   hipMemsetAsync(d.flags, 0, 4 * sizeof(int32_t), s);
   if (d.n_chains) hipLaunchKernelGGL(k_factor_chains, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, lambda);
-  {
+  precond = precond || d.sharded;          // (the dense solver needs the landmark factors and the reduced right-hand side only; a sharded run keeps its exchanges as they are)
+  if (precond) {
     const size_t lds = (33 * (size_t)d.max_slots + 3 * VDO_TILE_PTS + ((size_t)d.max_slots + 1) / 2) * sizeof(double);
     const int nd = d.n_tiles < 1024 ? d.n_tiles : std::min(d.n_dyn_tiles, d.n_tiles);       // tiles with dynamic tracks come first in the launch order (a graph of few tiles: one launch - a second one costs more than the registers)
     if (nd > 0) hipLaunchKernelGGL(k_precond_tile<true>, dim3(nd), dim3(VDO_TILE_THREADS), lds, s, d, 0);
     if (d.n_tiles > nd) hipLaunchKernelGGL(k_precond_tile<false>, dim3(d.n_tiles - nd), dim3(VDO_TILE_THREADS), lds, s, d, nd);
   }
   const dim3 g((d.P + 3) / 4), b(256);
-  if (!d.sharded) hipLaunchKernelGGL(k_precond_finalize<0>, g, b, 0, s, d, lambda);
+  if (!precond) { }
+  else if (!d.sharded) hipLaunchKernelGGL(k_precond_finalize<0>, g, b, 0, s, d, lambda);
   else {
     hipLaunchKernelGGL(k_precond_finalize<1>, g, b, 0, s, d, lambda);
     R(d.msum, 21 * (int64_t)d.P + 1);
@@ -1524,8 +1552,10 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
   const bool two = side && fork && join && !d.sharded;
   hipStream_t sr = two ? side : s;
   if (two) { hipEventRecord(fork, s); hipStreamWaitEvent(side, fork, 0); }
-  hipLaunchKernelGGL(k_pchain_factor, dim3(d.n_pchains), dim3(64), 0, s, d);
-  if (d.pc_lds && d.pc_nwave > 1) hipLaunchKernelGGL(k_pchain_prefix, dim3(d.n_pchains), dim3(64 * d.pc_nwave), 0, s, d);
+  if (precond) {
+    hipLaunchKernelGGL(k_pchain_factor, dim3(d.n_pchains), dim3(64), 0, s, d);
+    if (d.pc_lds && d.pc_nwave > 1) hipLaunchKernelGGL(k_pchain_prefix, dim3(d.n_pchains), dim3(64 * d.pc_nwave), 0, s, d);
+  }
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), sr, d, (const double*)nullptr, (const double*)nullptr);
   hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, sr, d, d.qs, 0);
   if (d.sharded) R(d.qs, 6 * (int64_t)d.P);
@@ -1569,3 +1599,11 @@ void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_
 }
 
 }  // namespace vdo
+
+#ifdef DENSE_PROF
+extern "C" int vdo_debug_dense_prof(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(vdo::g_asm_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vdo::g_asm_prof), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
