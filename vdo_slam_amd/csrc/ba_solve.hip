@@ -1307,6 +1307,8 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   int* touched = (int*)(pts + 3 * VDO_TILE_PTS);    // [TP]
   int* choff = touched + VDO_TILE_PTS;              // [TP+1] the tile's chain offsets (read in every pass over the slots: not from L2 each time)
   int* spose = choff + VDO_TILE_PTS + 1;            // [S] pose id of every slot
+  int* psingle = spose + d.max_slots;               // [TP] 1: the point is a chain of its own (Hll^-1 = dscal * I3, applied in pass A)
+  int* mch = psingle + VDO_TILE_PTS;                // [TP/2 + 1] the tile's chains of two or more points (the only ones the chain solves visit); last entry: their number
   const int tid = threadIdx.x;
   // ---- head: what the tile needs from HBM / L2 in TWO rounds of requests, every request of a round made before the first use of any of them
   // (the round-3 form walked the 9 * npts factor entries in a loop whose every pass waited for a flag and then for a value: ~18 round trips of
@@ -1376,9 +1378,13 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     if (tid < npts) {
 #pragma unroll
       for (int q = 0; q < 9; ++q) { dinv[9 * tid + q] = fd[q]; gl[9 * tid + q] = fg[q]; }
+      psingle[tid] = my_single;
     }
+    if (tid == 0) mch[VDO_TILE_PTS / 2] = 0;
   }
   __syncthreads();
+  for (int c = tid; c < nch; c += VDO_TILE_THREADS)
+    if (choff[c + 1] - choff[c] >= 2) mch[atomicAdd(&mch[VDO_TILE_PTS / 2], 1)] = c;       // (any order: the chains are independent of each other)
   AP_TICK(0);
 #pragma unroll
   for (int j = 0; j < VDO_TILE_EPT; ++j) F[j] = key[j] >= 0 ? make_f(d, T, tid + VDO_TILE_THREADS * j, kind[j], key[j], we[j], slotW, pts) : FInc{0, 0, 0, 0};
@@ -1397,10 +1403,11 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
         double B[18];
         expand_block(kind[j], F[j], slotW + 12 * s, B);
         const int lp = key[j] & 0xffff;
+        const double sc = psingle[lp] ? dinv[9 * lp] : 1.0;      // a point on its own: w = dscal * u, applied term by term (no chain solve visits it)
 #pragma unroll
         for (int b = 0; b < 6; ++b) {
           double* ul = u6 + b * 3 * VDO_TILE_PTS + 3 * lp;
-          atomicAdd(ul, B[3 * b]); atomicAdd(ul + 1, B[3 * b + 1]); atomicAdd(ul + 2, B[3 * b + 2]);
+          atomicAdd(ul, B[3 * b] * sc); atomicAdd(ul + 1, B[3 * b + 1] * sc); atomicAdd(ul + 2, B[3 * b + 2] * sc);
         }
         touched[lp] = 1;
       }
@@ -1409,17 +1416,18 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     AP_TICK(3);
     // chain solves w = Hll^-1 u for the chains slot s reaches, one (chain, right-hand side) per thread-iteration; a reached
     // chain becomes "touched" as a whole (its points all carry w)
-    for (int c = tid; c < nch; c += VDO_TILE_THREADS) {
+    const int n_mch = mch[VDO_TILE_PTS / 2];
+    for (int ci = tid; ci < n_mch; ci += VDO_TILE_THREADS) {
+      const int c = mch[ci];
       const int64_t p0 = choff[c], p1 = choff[c + 1];
-      if (p1 - p0 < 2) continue;
       int any = 0;
       for (int64_t l = p0; l < p1; ++l) any |= touched[l - T.pt_begin];
       if (any) for (int64_t l = p0; l < p1; ++l) touched[l - T.pt_begin] = 2;
     }
     __syncthreads();
     AP_TICK(4);
-    for (int task = tid; task < 6 * nch; task += VDO_TILE_THREADS) {
-      const int c = task / 6, b = task - 6 * c;
+    for (int task = tid; task < 6 * n_mch; task += VDO_TILE_THREADS) {
+      const int c = mch[task / 6], b = task % 6;
       const int64_t p0 = choff[c], p1 = choff[c + 1];
       if (!touched[p0 - T.pt_begin]) continue;
       double* u = u6 + b * 3 * VDO_TILE_PTS;
@@ -1442,10 +1450,48 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     }
     __syncthreads();
     AP_TICK(5);
-    // pass C: block (r, s) += B_r w_b for every incidence (r, l) on a touched point; incidences are slot-sorted inside each
-    // part, so the 36 values go through the segmented DPP reduction (many lanes share a slot: plain LDS atomics would serialise)
+    // pass C: block (r, s) += B_r w_b for every incidence (r, l) on a touched point.  The EdgeSE3PointXYZ entries of a thread (rows j < T.ept of
+    // the tile's edge block) belong to ONE pose slot (capi_ba.hip): their 36 sums add up in registers and go through ONE segmented DPP
+    // reduction per thread (threads are in slot order; many lanes share a slot: plain LDS atomics would serialise); the ternary incidences
+    // (rows behind the block, slot-sorted) one reduction each.
+    {
+      const int rt = key[0] >= 0 && T.ept > 0 ? (key[0] >> 16) : -1;       // (a thread's entries fill its column from row 0)
+      double g36[36];
+#pragma unroll
+      for (int i = 0; i < 36; ++i) g36[i] = 0.0;
+      bool mine = false;
+#pragma unroll
+      for (int j = 0; j < VDO_TILE_EPT; ++j) {
+        if (j < T.ept && key[j] >= 0 && touched[key[j] & 0xffff]) {
+          const int lp = key[j] & 0xffff;
+          mine = true;
+          double B[18];
+          expand_block(0, F[j], slotW + 12 * rt, B);
+#pragma unroll
+          for (int b = 0; b < 6; ++b) {
+            const double* w = u6 + b * 3 * VDO_TILE_PTS + 3 * lp;
+            const double w0 = w[0], w1 = w[1], w2 = w[2];
+#pragma unroll
+            for (int a = 0; a < 6; ++a) g36[6 * b + a] += B[3 * a] * w0 + B[3 * a + 1] * w1 + B[3 * a + 2] * w2;
+          }
+        }
+      }
+      if (__any(mine)) {                                           // (wave-uniform)
+        const SegCtl16 sc = seg_ctl16(rt);
+        const SegFlags sf = seg_flags(sc);
+        double* q = q36 + 36 * (rt >= 0 ? rt : 0);
+#pragma unroll
+        for (int b = 0; b < 6; ++b) {
+          double g[6];
+#pragma unroll
+          for (int a = 0; a < 6; ++a) g[a] = g36[6 * b + a];
+          seg_apply16<6>(g, sc, sf, q + 6 * b);                    // q layout [b][a]
+        }
+      }
+    }
 #pragma unroll
     for (int j = 0; j < VDO_TILE_EPT; ++j) {
+      if (j < T.ept) continue;                                     // (uniform)
       const bool on = key[j] >= 0 && touched[key[j] & 0xffff];
       const int r = on ? (key[j] >> 16) : -1, lp = on ? (key[j] & 0xffff) : 0;
       if (!__any(on)) continue;                                  // (wave-uniform: nothing of this wave's incidences is reached from slot s)
@@ -1485,7 +1531,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
 #endif
 }
 
-size_t dense_tile_lds(const BADev& d) { return (39 * VDO_TILE_PTS + 48 * (size_t)d.max_slots) * sizeof(double) + (2 * VDO_TILE_PTS + 2 + (size_t)d.max_slots) * sizeof(int); }
+size_t dense_tile_lds(const BADev& d) { return (39 * VDO_TILE_PTS + 48 * (size_t)d.max_slots) * sizeof(double) + (3 * VDO_TILE_PTS + VDO_TILE_PTS / 2 + 4 + (size_t)d.max_slots) * sizeof(int); }
 
 // S <- reduced-camera matrix at this lambda (launch_factor must have run: it leaves the landmark chain factors of Hll + lambda I)
 void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R) {
