@@ -1426,31 +1426,51 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     }
     __syncthreads();
     AP_TICK(4);
+    // (Every step's operands - the next point's right-hand side and factor blocks - are requested before the current step's result is stored:
+    // the recurrence y_l = u_l - G_l^T y_(l-1) then costs three dependent multiply-adds per point instead of an LDS round trip behind every store.)
     for (int task = tid; task < 6 * n_mch; task += VDO_TILE_THREADS) {
       const int c = mch[task / 6], b = task % 6;
-      const int64_t p0 = choff[c], p1 = choff[c + 1];
-      if (!touched[p0 - T.pt_begin]) continue;
+      const int p0 = choff[c] - T.pt_begin, p1 = choff[c + 1] - T.pt_begin;       // local point range (>= 2 points)
+      if (!touched[p0]) continue;
       double* u = u6 + b * 3 * VDO_TILE_PTS;
-      D3 yprev{0, 0, 0};
-      for (int64_t l = p0; l < p1; ++l) {
-        double* ul = u + 3 * (l - T.pt_begin);
-        D3 y{ul[0], ul[1], ul[2]};
-        if (l > p0) y = y - rotT(gl + 9 * (l - T.pt_begin), yprev);
+      auto ld3 = [](const double* p) { return D3{p[0], p[1], p[2]}; };
+      struct M9 { double m[9]; };
+      auto ld9 = [](const double* p) { M9 r; for (int i = 0; i < 9; ++i) r.m[i] = p[i]; return r; };
+      // forward: y_l = u_l - G_l^T y_(l-1), z_l = Dinv_l y_l
+      D3 uc = ld3(u + 3 * p0), yprev{0, 0, 0};
+      M9 gc = ld9(gl + 9 * p0), dc = ld9(dinv + 9 * p0);
+      for (int l = p0; l < p1; ++l) {
+        const int ln = min(l + 1, p1 - 1);
+        const D3 un = ld3(u + 3 * ln);
+        const M9 gn = ld9(gl + 9 * ln), dn = ld9(dinv + 9 * ln);
+        D3 y = uc;
+        if (l > p0) y = y - rotT(gc.m, yprev);
         yprev = y;
-        const D3 z = rot(dinv + 9 * (l - T.pt_begin), y);
+        const D3 z = rot(dc.m, y);
+        double* ul = u + 3 * l;
         ul[0] = z.x; ul[1] = z.y; ul[2] = z.z;
+        uc = un; gc = gn; dc = dn;
       }
-      for (int64_t l = p1 - 2; l >= p0; --l) {
-        const double* un = u + 3 * (l + 1 - T.pt_begin);
-        const D3 wnext{un[0], un[1], un[2]};
-        double* ul = u + 3 * (l - T.pt_begin);
-        const D3 z = D3{ul[0], ul[1], ul[2]} - rot(gl + 9 * (l + 1 - T.pt_begin), wnext);
-        ul[0] = z.x; ul[1] = z.y; ul[2] = z.z;
+      // backward: w_l = z_l - G_(l+1) w_(l+1)   (w of the last point is its z)
+      {
+        D3 wnext = ld3(u + 3 * (p1 - 1));
+        M9 gnx = ld9(gl + 9 * (p1 - 1));           // G of point l + 1
+        D3 zc = ld3(u + 3 * (p1 - 2));
+        for (int l = p1 - 2; l >= p0; --l) {
+          const int lm = max(l - 1, p0);
+          const D3 zm = ld3(u + 3 * lm);
+          const M9 gm = ld9(gl + 9 * l);           // G of point l: the next pass's G of "l + 1"
+          const D3 w = zc - rot(gnx.m, wnext);
+          double* ul = u + 3 * l;
+          ul[0] = w.x; ul[1] = w.y; ul[2] = w.z;
+          wnext = w; gnx = gm; zc = zm;
+        }
       }
     }
     __syncthreads();
     AP_TICK(5);
-    // pass C: block (r, s) += B_r w_b for every incidence (r, l) on a touched point.  The EdgeSE3PointXYZ entries of a thread (rows j < T.ept of
+    // pass C: block (r, s) += B_r w_b for every incidence (r, l) on a touched point - of the slots r >= s only: block (s, r) is the transpose
+    // (threads and ternary incidences are in slot order, so about half of the waves have nothing to do; S comes out exactly symmetric).  The EdgeSE3PointXYZ entries of a thread (rows j < T.ept of
     // the tile's edge block) belong to ONE pose slot (capi_ba.hip): their 36 sums add up in registers and go through ONE segmented DPP
     // reduction per thread (threads are in slot order; many lanes share a slot: plain LDS atomics would serialise); the ternary incidences
     // (rows behind the block, slot-sorted) one reduction each.
@@ -1462,7 +1482,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       bool mine = false;
 #pragma unroll
       for (int j = 0; j < VDO_TILE_EPT; ++j) {
-        if (j < T.ept && key[j] >= 0 && touched[key[j] & 0xffff]) {
+        if (j < T.ept && key[j] >= 0 && rt >= s && touched[key[j] & 0xffff]) {
           const int lp = key[j] & 0xffff;
           mine = true;
           double B[18];
@@ -1492,7 +1512,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
 #pragma unroll
     for (int j = 0; j < VDO_TILE_EPT; ++j) {
       if (j < T.ept) continue;                                     // (uniform)
-      const bool on = key[j] >= 0 && touched[key[j] & 0xffff];
+      const bool on = key[j] >= 0 && (key[j] >> 16) >= s && touched[key[j] & 0xffff];
       const int r = on ? (key[j] >> 16) : -1, lp = on ? (key[j] & 0xffff) : 0;
       if (!__any(on)) continue;                                  // (wave-uniform: nothing of this wave's incidences is reached from slot s)
       double B[18];
@@ -1519,6 +1539,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       const int r = i / 36, b = (i % 36) / 6, a = i % 6;         // q36[r][b][a]
       const int64_t gr = spose[r];
       atomicAdd(S + (6 * gr + a) * ld + 6 * gs + b, -v);
+      if (r != s) atomicAdd(S + (6 * gs + b) * ld + 6 * gr + a, -v);
     }
       AP_TICK(7);
   }
