@@ -509,7 +509,7 @@ __global__ __launch_bounds__(256) void k_potrf64_v2(double* __restrict__ S, int6
 }
 
 __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64_t ld, int k, double* __restrict__ Winv, double* __restrict__ rhs,
-                                                   double* __restrict__ yv, int32_t* __restrict__ flags, int variant) {
+                                                   double* __restrict__ yv, int32_t* __restrict__ flags, int variant, int npairs) {
   __shared__ double As[NB * LDS_LD];
   __shared__ double Bs[NB * LDS_LD];
   __shared__ double Ws[NB * LDS_LD];
@@ -517,10 +517,15 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64
   __shared__ double part[4][NB];
   __shared__ int s_bad;
   const int tid = threadIdx.x, wv = tid >> 6;
-  int t = blockIdx.x, ri = 0;                       // pair index -> (bi, bj), k < bj <= bi
+  // Workgroup npairs (one past the pairs) is the AUXILIARY of block row k + 1: it forms L_{k+1,k} as workgroup (k+1, k+1) does, stores it and
+  // advances the right-hand side of that row - so that the workgroup every other launch waits for goes from its products straight into the
+  // factorisation (the phase probe: 4.8 k of its 73 k cycles were this substitution).
+  const bool aux = (int)blockIdx.x == npairs;
+  int t = aux ? 0 : blockIdx.x, ri = 0;             // pair index -> (bi, bj), k < bj <= bi
   while (t > ri) { t -= ri + 1; ++ri; }
   const int bi = k + 1 + ri, bj = k + 1 + t;
-  const bool diag = bi == bj, first = bj == k + 1;
+  const bool diag = bi == bj, next = diag && bj == k + 1 && !aux;     // next: block (k+1, k+1), factorised below
+  const bool first = bj == k + 1 && !next;          // stores its panel block and substitutes its block row
 #ifdef DENSE_PROF
   DProf pr; pr.prev = clock64();
   for (int i = 0; i < 16; ++i) pr.t[i] = 0;
@@ -562,16 +567,17 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64
   }
   __syncthreads();
   DP_TICK(2);
-  d4 acc[4];
-  gemm64_abt(As, diag ? As : Bs, acc);              // L_ik L_jk^T
-  const bool next = diag && first;                  // block (k+1, k+1): factorised below
+  if (!aux) {
+    d4 acc[4];
+    gemm64_abt(As, diag ? As : Bs, acc);            // L_ik L_jk^T
 #pragma unroll
-  for (int tt = 0; tt < 4; ++tt)
-    for_acc([&](int rr, int cc, int q) {
-      const double u = gv[tt][q] - acc[tt][q];
-      if (next) Bs[(16 * wv + rr) * LDS_LD + 16 * tt + cc] = u;       // (Bs is free in a diagonal workgroup)
-      else G[(int64_t)(16 * wv + rr) * ld + 16 * tt + cc] = u;
-    });
+    for (int tt = 0; tt < 4; ++tt)
+      for_acc([&](int rr, int cc, int q) {
+        const double u = gv[tt][q] - acc[tt][q];
+        if (next) Bs[(16 * wv + rr) * LDS_LD + 16 * tt + cc] = u;       // (Bs is free in a diagonal workgroup)
+        else G[(int64_t)(16 * wv + rr) * ld + 16 * tt + cc] = u;
+      });
+  }
   DP_TICK(3);
   if (first) {                                      // forward substitution: y_k = W_k b_k, b_i -= L_ik y_k
     const int col = tid & 63, chunk = tid >> 6;
@@ -584,7 +590,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64
     if (tid < NB) {
       const double y = part[0][tid] + part[1][tid] + part[2][tid] + part[3][tid];
       yk[tid] = y;
-      if (diag) yv[k * NB + tid] = y;
+      if (aux) yv[k * NB + tid] = y;
     }
     __syncthreads();
     {
@@ -612,7 +618,7 @@ __global__ __launch_bounds__(256) void k_chol_step(double* __restrict__ S, int64
 #endif
   }
 #ifdef DENSE_PROF
-  if (!next && tid == 0 && k < 64 && blockIdx.x == gridDim.x - 1) { g_dense_prof[k][13] = clock64() - clk0; g_dense_prof[k][14] = wall_clock64() - wall0; }
+  if (!next && tid == 0 && k < 64 && blockIdx.x + 2 == gridDim.x) { g_dense_prof[k][13] = clock64() - clk0; g_dense_prof[k][14] = wall_clock64() - wall0; }
 #endif
 }
 
@@ -767,7 +773,7 @@ void launch_dense_solve(const BADev& d, double* S, int64_t ld, double* Winv, dou
     hipLaunchKernelGGL(k_potrf64_v2, dim3(1), dim3(256), 0, s, S, ld, 0, Winv, d.flags, potrf);
     for (int k = 0; k + 1 < nblk; ++k) {
       const int m = nblk - k - 1;
-      hipLaunchKernelGGL(k_chol_step, dim3(m * (m + 1) / 2), dim3(256), 0, s, S, ld, k, Winv, rhs, yv, d.flags, potrf);
+      hipLaunchKernelGGL(k_chol_step, dim3(m * (m + 1) / 2 + 1), dim3(256), 0, s, S, ld, k, Winv, rhs, yv, d.flags, potrf, m * (m + 1) / 2);
     }
     hipLaunchKernelGGL(k_fwd_last, dim3(1), dim3(256), 0, s, nblk - 1, (const double*)Winv, (const double*)rhs, yv);
     int kb = nblk - 1;                                            // (b is dead by now: the solution goes where it was)
