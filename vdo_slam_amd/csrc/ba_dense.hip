@@ -233,8 +233,10 @@ __global__ __launch_bounds__(256) void k_syrk(double* __restrict__ S, int64_t ld
 // Substitutions, one launch per 64-row block, right-looking: workgroup 0 turns the (already updated) right-hand side block into the
 // solution block x_kb = W_kb b_kb (forward) resp. W_kb^T b_kb (backward); every other workgroup recomputes x_kb for itself (4096
 // multiply-adds) and subtracts its 64x64 block's product from its own part of the right-hand side.  x is updated in place.
+// (sol: where workgroup 0 puts the solved block - NOT x itself, which the other workgroups of the launch are still reading block kb of)
 template <bool FWD>
-__global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ S, int64_t ld, int kb, const double* __restrict__ Winv, double* __restrict__ x) {
+__global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ S, int64_t ld, int kb, const double* __restrict__ Winv, double* __restrict__ x,
+                                                   double* __restrict__ sol) {
   __shared__ double bk[NB], xk[NB];
   __shared__ double part[4][NB];
   const int col = threadIdx.x & 63, chunk = threadIdx.x >> 6;
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256) void k_trsv_step(const double* __restrict__ S,
   if (threadIdx.x < NB) xk[threadIdx.x] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
   __syncthreads();
   if (blockIdx.x == 0) {
-    if (threadIdx.x < NB) x[kb * NB + threadIdx.x] = xk[threadIdx.x];
+    if (threadIdx.x < NB) sol[kb * NB + threadIdx.x] = xk[threadIdx.x];
     return;
   }
   // forward: rows of block bi = kb + blockIdx.x: b_bi -= L[bi][kb] x_kb ; backward: rows of block bi = kb - blockIdx.x: b_bi -= L[kb][bi]^T x_kb
@@ -790,8 +792,9 @@ void launch_dense_solve(const BADev& d, double* S, int64_t ld, double* Winv, dou
       hipLaunchKernelGGL(k_syrk, dim3(m * (m + 1) / 2), dim3(256), 0, s, S, ld, k, nblk);
     }
   }
-  for (int kb = 0; kb < nblk; ++kb) hipLaunchKernelGGL(k_trsv_step<true>, dim3(nblk - kb), dim3(256), 0, s, (const double*)S, ld, kb, (const double*)Winv, rhs);
-  for (int kb = nblk - 1; kb >= 0; --kb) hipLaunchKernelGGL(k_trsv_step<false>, dim3(kb + 1), dim3(256), 0, s, (const double*)S, ld, kb, (const double*)Winv, rhs);
+  double* yv = rhs + ld;      // forward: b (updated in place) -> y; backward: y (updated in place) -> x where b was
+  for (int kb = 0; kb < nblk; ++kb) hipLaunchKernelGGL(k_trsv_step<true>, dim3(nblk - kb), dim3(256), 0, s, (const double*)S, ld, kb, (const double*)Winv, rhs, yv);
+  for (int kb = nblk - 1; kb >= 0; --kb) hipLaunchKernelGGL(k_trsv_step<false>, dim3(kb + 1), dim3(256), 0, s, (const double*)S, ld, kb, (const double*)Winv, yv, rhs);
   hipLaunchKernelGGL(k_copy_xp, dim3((unsigned)((6 * (int64_t)d.P + 255) / 256)), dim3(256), 0, s, d, (const double*)rhs);
 }
 

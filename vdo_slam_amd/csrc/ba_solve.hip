@@ -1392,7 +1392,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
   for (int s = s_begin; s < s_end; ++s) {
     __syncthreads();
     for (int i = tid; i < 18 * VDO_TILE_PTS; i += VDO_TILE_THREADS) u6[i] = 0.0;
-    for (int i = tid; i < 36 * nslot; i += VDO_TILE_THREADS) q36[i] = 0.0;
+    for (int i = 36 * s + tid; i < 36 * nslot; i += VDO_TILE_THREADS) q36[i] = 0.0;      // (blocks (r, s), r >= s)
     for (int i = tid; i < npts; i += VDO_TILE_THREADS) touched[i] = 0;
     __syncthreads();
     AP_TICK(2);
@@ -1414,24 +1414,20 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     }
     __syncthreads();
     AP_TICK(3);
-    // chain solves w = Hll^-1 u for the chains slot s reaches, one (chain, right-hand side) per thread-iteration; a reached
-    // chain becomes "touched" as a whole (its points all carry w)
+    // chain solves w = Hll^-1 u for the multi-point chains slot s reaches, one (chain, right-hand side) per thread-iteration; every task looks
+    // for itself whether a point of its chain was touched (no marking pass, no barrier for it), and the task of right-hand side 0 marks the
+    // whole chain afterwards: its points all carry w (pass C, behind the barrier, sees them; the other five tasks of the chain may meet a
+    // 2 where there was a 0 - they only ask whether ANY point is touched, and one was).
     const int n_mch = mch[VDO_TILE_PTS / 2];
-    for (int ci = tid; ci < n_mch; ci += VDO_TILE_THREADS) {
-      const int c = mch[ci];
-      const int64_t p0 = choff[c], p1 = choff[c + 1];
-      int any = 0;
-      for (int64_t l = p0; l < p1; ++l) any |= touched[l - T.pt_begin];
-      if (any) for (int64_t l = p0; l < p1; ++l) touched[l - T.pt_begin] = 2;
-    }
-    __syncthreads();
     AP_TICK(4);
     // (Every step's operands - the next point's right-hand side and factor blocks - are requested before the current step's result is stored:
     // the recurrence y_l = u_l - G_l^T y_(l-1) then costs three dependent multiply-adds per point instead of an LDS round trip behind every store.)
     for (int task = tid; task < 6 * n_mch; task += VDO_TILE_THREADS) {
       const int c = mch[task / 6], b = task % 6;
       const int p0 = choff[c] - T.pt_begin, p1 = choff[c + 1] - T.pt_begin;       // local point range (>= 2 points)
-      if (!touched[p0]) continue;
+      int any = 0;
+      for (int l = p0; l < p1; ++l) any |= touched[l];
+      if (!any) continue;
       double* u = u6 + b * 3 * VDO_TILE_PTS;
       auto ld3 = [](const double* p) { return D3{p[0], p[1], p[2]}; };
       struct M9 { double m[9]; };
@@ -1466,6 +1462,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
           wnext = w; gnx = gm; zc = zm;
         }
       }
+      if (b == 0) for (int l = p0; l < p1; ++l) touched[l] = 2;
     }
     __syncthreads();
     AP_TICK(5);
@@ -1533,7 +1530,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     __syncthreads();
     AP_TICK(6);
     const int64_t gs = spose[s];
-    for (int i = tid; i < 36 * nslot; i += VDO_TILE_THREADS) {
+    for (int i = 36 * s + tid; i < 36 * nslot; i += VDO_TILE_THREADS) {
       const double v = q36[i];
       if (v == 0.0) continue;
       const int r = i / 36, b = (i % 36) / 6, a = i % 6;         // q36[r][b][a]
