@@ -175,6 +175,7 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
     st->ms_linearize += now_ms() - t0;
     double rho = 0;
     int qmax = 0;
+    bool accepted = false;          // the last trial of this iteration was accepted: estimate[0] IS that trial's estimate
     do {
       t0 = now_ms();
       bool ok2 = true, pending = false, again = false;
@@ -210,8 +211,10 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
         lambda *= sf; ni = 2; currentChi = tempChi;
         std::swap(d.pose[0], d.pose[1]);               // discardTop(): accept the trial
         std::swap(d.point[0], d.point[1]);
+        accepted = true;
       } else {
         lambda *= ni; ni *= 2;                          // pop(): estimate[0] untouched
+        accepted = false;
       }
       ++qmax;
       ++st->total_trials;
@@ -226,7 +229,12 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
     if (!ok && st->stop_reason == 0) st->stop_reason = 1;
     if (chi2_check < last_err_chi && it > 0) { ok = false; st->stop_reason = 2; }
     chi2_check = last_err_chi;
-    if (opt->verbose || opt->gain_threshold >= 0) CK(robust_chi2(ba, 0, &last_err_chi));
+    // The errors of estimate[0] for the trace and the gain rule (g2o evaluates them again after the iteration): when the iteration ended on an
+    // accepted trial they are what that trial's evaluation just produced - the same kernels on the same estimate, the same bits (last_err_chi
+    // holds them) - so the pass and its host round trip are spent only after an iteration whose last trial was rejected
+    // (VDO_BA_LM_RECHECK=1: always, as before).
+    const bool recheck = std::getenv("VDO_BA_LM_RECHECK") != nullptr;
+    if ((opt->verbose || opt->gain_threshold >= 0) && (recheck || !accepted)) CK(robust_chi2(ba, 0, &last_err_chi));
     if (opt->verbose)
       std::fprintf(stderr, "iteration= %d\t chi2= %.6f\t lambda= %.6g\t levenbergIter= %d\n", it, last_err_chi, lambda, qmax);
     if (it < VDO_LM_MAX_TRACE) { st->chi2_trace[it] = last_err_chi; st->trials_trace[it] = qmax; }
