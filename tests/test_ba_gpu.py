@@ -483,10 +483,11 @@ def test_config4_sized_graph_blocks_match_the_oracle_and_properties(ctx, oracle,
     assert np.abs(pose_a - pose_b).max() <= 1e-7 and np.abs(point_a - point_b).max() <= 1e-6
 
 
-def test_lm_reuses_the_accepted_trials_errors_bit_for_bit(ctx, monkeypatch):
+def test_lm_reuses_the_accepted_trials_errors(ctx, monkeypatch):
     """After an iteration that ended on an accepted trial the LM takes the errors of the new estimate from that trial's own evaluation instead of
-    evaluating them again (csrc/ba_lm.hip; g2o evaluates again: g2o/core/sparse_optimizer.cpp:354-443): same kernels on the same estimate, so the
-    chi2 trace, the stop decisions and the estimates must be the SAME BITS as with the second evaluation (VDO_BA_LM_RECHECK=1)."""
+    evaluating them again (csrc/ba_lm.hip; g2o evaluates again: g2o/core/sparse_optimizer.cpp:354-443) - the same kernels on the same estimate.
+    Against VDO_BA_LM_RECHECK=1 (the second evaluation): same iterations, trials and stop decision, chi2 trace and estimates to the few ulps by
+    which two runs of the LM differ anyway (the landmark sums of the linearisation are LDS atomics: their order is not fixed)."""
     from vdo_slam_amd.ba import BatchBA
     g = synth.make_ba_graph(20, 1500, 3, 80, seed=4)
     out = []
@@ -499,10 +500,11 @@ def test_lm_reuses_the_accepted_trials_errors_bit_for_bit(ctx, monkeypatch):
             ba = BatchBA(ctx, g)
             st = ba.optimize(max_iterations=12, gain_threshold=1e-6, solver=solver)
             pose, point = ba.estimates()
-            out.append((recheck, solver, st.iterations, st.total_trials, st.stop_reason, st.final_chi2, [st.chi2_trace[i] for i in range(st.iterations)], pose.copy(), point.copy()))
+            out.append((recheck, solver, st.iterations, st.total_trials, st.stop_reason, st.final_chi2, np.array([st.chi2_trace[i] for i in range(st.iterations)]), pose.copy(), point.copy()))
             ba.close()
     for a, b in ((out[0], out[2]), (out[1], out[3])):
-        assert a[1] == b[1] and a[2:6] == b[2:6], (a[:6], b[:6])
-        assert a[6] == b[6]
-        assert np.array_equal(a[7], b[7]) and np.array_equal(a[8], b[8])
+        assert a[1] == b[1] and a[2:5] == b[2:5], (a[:6], b[:6])
+        assert abs(a[5] - b[5]) <= 1e-11 * b[5]
+        assert np.abs(a[6] - b[6]).max() <= 1e-11 * b[6].max()
+        assert np.abs(a[7] - b[7]).max() <= 1e-9 and np.abs(a[8] - b[8]).max() <= 1e-9 * np.abs(b[8]).max()
     assert out[0][2] >= 3
