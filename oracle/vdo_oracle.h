@@ -173,6 +173,13 @@ double vdo_oracle_epnp(int n, const double* X, const double* uv, const double* K
 int vdo_oracle_pnp_ransac_refit(int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence, int refit,
                                 double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter);
 
+/* ---- AP3P (ap3p_oracle.cpp): Ke & Roumeliotis' solver as OpenCV 3.4's ap3p.cpp lays it out - the solver the reference's calls name.
+   The product runs Grunert (p3p_oracle.cpp restates it): these entries exist to compare the two.  coeffs5: a4 .. a0. */
+int vdo_oracle_ap3p(const double* f9, const double* P9, double* R_out, double* t_out);
+int vdo_oracle_ap3p_quartic(const double* coeffs5, double* roots4);
+int vdo_oracle_ap3p_ransac(int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence,
+                           double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter);
+
 /* ---- front-end (frontend_oracle.cpp) ------------------------------------------------------*/
 typedef struct vdo_orb_params {   /* ORBextractor ctor arguments (include/ORBextractor.h:39-40) */
   int32_t n_features;     /* 2500 */
