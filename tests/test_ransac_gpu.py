@@ -73,3 +73,34 @@ def test_pure_outliers_run_the_full_budget(oracle):
     for _ in range(20):
         pnp_ransac_batch(ctx, [(Xw, uv)], KITTI_K)
     print("ransac 1200 pts x 500 hyp: %.3f ms" % ((time.perf_counter() - t0) / 20 * 1e3))
+
+
+def test_product_ransac_against_the_independent_ap3p_oracle(oracle):
+    """The oracle above shares its minimal solver's arithmetic with the product on purpose (bit-identical poses).  This one shares NOTHING with it:
+    the reference's RANSAC around AP3P (oracle/ap3p_oracle.cpp - Ke & Roumeliotis as OpenCV 3.4 lays it out, the solver the reference's calls name;
+    other derivation, other quartic, complex arithmetic, libm).  On data whose inliers are exact the 0.4 px gate has no borderline points, so the
+    product's run (Grunert on the GPU) must end on the same winning hypothesis, the same number of hypotheses examined, the same inlier set and
+    the same pose to rounding; with 0.1 px noise the consensus may differ by the points at the gate (reported, bounded)."""
+    o = oracle
+    sig = [C.c_int, K.c_double_p, K.c_double_p, K.c_double_p, C.c_int, C.c_double, C.c_double, K.c_double_p, K.c_uint8_p, K.c_int32_p, K.c_int32_p]
+    o.vdo_oracle_ap3p_ransac.argtypes = sig
+    ctx = Context(0)
+    rng = np.random.default_rng(17)
+    K4 = np.array(KITTI_K, np.float64)
+    probs, exact = [], []
+    for n, outl, sigma in [(900, 0.3, 0.0), (500, 0.5, 0.0), (200, 0.1, 0.0), (40, 0.0, 0.0), (700, 0.3, 0.1), (300, 0.2, 0.1)]:
+        Xw, uv, R, t, _ = _scene(rng, n, outl, pix_sigma=sigma)
+        probs.append((Xw, uv)); exact.append(sigma == 0.0)
+    got = pnp_ransac_batch(ctx, probs, KITTI_K, refit=0)
+    for (Xw, uv), g, ex in zip(probs, got, exact):
+        n = Xw.shape[0]
+        T = np.zeros(16); inl = np.zeros(n, np.uint8); its = C.c_int32(); bi = C.c_int32()
+        good = o.vdo_oracle_ap3p_ransac(n, K._dp(Xw), K._dp(uv), K._dp(K4), 500, 0.4, 0.98, K._dp(T), inl.ctypes.data_as(K.c_uint8_p), C.byref(its), C.byref(bi))
+        T = T.reshape(4, 4)
+        if ex:
+            assert (g["n_inliers"], g["iterations_run"], g["best_iteration"]) == (good, its.value, bi.value), (n, g["n_inliers"], good, g["best_iteration"], bi.value)
+            assert np.array_equal(g["inliers"], inl)
+            assert np.abs(g["T"] - T).max() <= 1e-7 * max(1.0, np.abs(T).max())
+        else:
+            print("noisy: product %d inliers (hypothesis %d), AP3P oracle %d (hypothesis %d)" % (g["n_inliers"], g["best_iteration"], good, bi.value))
+            assert abs(g["n_inliers"] - good) <= 0.05 * good and np.abs(g["T"][:3, :3] - T[:3, :3]).max() < 5e-3
