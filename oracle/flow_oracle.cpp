@@ -463,6 +463,37 @@ struct PoseOnly {
 };
 }  // namespace
 
+// KAT helpers for tests/test_ref_g2o.py (the reference's own g2o, compiled verbatim, on the other side): one EdgeSE3ProjectFlow2 + its EdgeFlowPrior at
+// pose T16 and flow estimate flow_est - errors and Jacobians as compute_errors() / build_system() above form them (Jpose 2x6 row-major; the flow Jacobians are I2)
+extern "C" void vdo_oracle_edge_flow2_jac(const double K4[4], const double Twl16[16], double depth, const double obs[2], const double flow_est[2], const double flow_meas[2],
+                                          const double T16[16], double err2[2], double Jpose12[12], double errp2[2]) {
+  vdo_flow2_problem q;
+  std::memset(&q, 0, sizeof q);
+  q.n = 1; q.obs = obs; q.flow = flow_meas; q.depth = &depth;
+  for (int i = 0; i < 4; ++i) q.K[i] = K4[i];
+  for (int i = 0; i < 16; ++i) { q.Twl[i] = Twl16[i]; q.T0[i] = T16[i]; }
+  q.info_flow = 1.0; q.info_prior = 1.0; q.huber_delta = 1e30; q.chi2_gate = 1.0; q.max_iterations = 1; q.ref_quirks = 1;
+  Flow2 S(&q);
+  S.f[0] = flow_est[0]; S.f[1] = flow_est[1];
+  S.compute_errors();
+  err2[0] = S.err[0]; err2[1] = S.err[1]; errp2[0] = S.errp[0]; errp2[1] = S.errp[1];
+  const double fx = K4[0], fy = K4[1];
+  V3 pc = S.T.map(S.Xw[0]);
+  const double X = pc.x, Y = pc.y, Z = pc.z, Z2 = Z * Z;
+  double* J = Jpose12;                                     // (the expressions of build_system)
+  J[0] = X * Y / Z2 * fx; J[1] = -(1 + (X * X / Z2)) * fx; J[2] = Y / Z * fx; J[3] = -1. / Z * fx; J[4] = 0; J[5] = X / Z2 * fx;
+  J[6] = (1 + Y * Y / Z2) * fy; J[7] = -X * Y / Z2 * fy; J[8] = -X / Z * fy; J[9] = 0; J[10] = -1. / Z * fy; J[11] = Y / Z2 * fy;
+}
+extern "C" void vdo_oracle_huber(double delta, double e2, double rho2[2]) { Huber h; h.setDelta(delta); h.robustify(e2, rho2[0], rho2[1]); }
+// VertexSE3Expmap::oplusImpl: exp(update) * estimate, the estimate given as a 4x4 through Converter::toSE3Quat's SE3Quat(R, t); u == NULL: the round trip alone
+extern "C" void vdo_oracle_se3quat_oplus(const double T16[16], const double* u, double out16[16]) {
+  M3 R;
+  for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) R(i, j) = T16[4 * i + j];
+  SE3Quat T = SE3Quat::fromRt(R, v3(T16[3], T16[7], T16[11]));
+  if (u) T = SE3Quat::exp(u).compose(T);
+  T.toMatrix4(out16);
+}
+
 extern "C" int vdo_oracle_edge_unary_jac(const vdo_pose_problem* p, const double* T16, const double* Xw, const double* obs, double* err2, double* J12) {
   // KAT helper: error and analytic Jacobian of one unary edge at pose T16 (4x4 row-major)
   vdo_pose_problem q = *p;

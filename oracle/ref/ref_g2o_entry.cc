@@ -1,0 +1,504 @@
+// TEST INFRASTRUCTURE - C entry points into the reference's OWN optimiser code as oracle/_ref/libref_full.so holds it: src/Optimizer.cc, src/Converter.cc
+// and the vendored g2o (dependencies/g2o/g2o/{core,types,solvers,stuff}), compiled verbatim from /root/reference against shim/Eigen (a small dense-algebra
+// library with Eigen's interface) and shim/cs.h + minics.cpp (CSparse's interface) - oracle/ref/Makefile.  Nothing in this file is arithmetic: every function
+// builds the reference's objects (Frame / Map / g2o vertices and edges), calls the reference's methods and copies numbers out.
+//   ref_se3_exp .. ref_huber            one edge / vertex operation each: error vector and Jacobians as g2o's computeError() / linearizeOplus() leave them
+//   ref_ba_optimize / ref_ba_linearize  a flat batch graph (oracle/vdo_oracle.h vdo_ba_graph) as g2o objects, assembled the way src/Optimizer.cc:1313-1935 sets
+//                                       its optimiser up (BlockSolverX + LinearSolverCSparse + Levenberg, terminate action, ParameterSE3Offset 0, Huber kernels);
+//                                       g2o's own batch statistics give the chi2 / trials trace
+//   ref_batch_optimization              Optimizer::FullBatchOptimization / PartialBatchOptimization on a Map filled from flat arrays
+//   ref_pose_optimization_*             the four per-frame statics on Frames filled from flat arrays
+// Signatures mirror the hooks of the product's host library (vdo_slam_amd/host/host_capi.cc) and the oracle's KAT exports so that one test drives all three.
+// Not a product file; nothing of the reference is copied into this repository.
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <iostream>
+#include <list>
+#include <map>
+#include <mutex>
+#include <set>
+#include <sstream>
+#include <thread>
+#include <vector>
+#include "minicv_ref.hpp"
+#include <Eigen/Core>
+#include <Eigen/Geometry>
+#include <cvplot/cvplot.h>
+#define private public
+#define protected public
+#include "dependencies/g2o/g2o/core/block_solver.h"
+#include "dependencies/g2o/g2o/core/optimization_algorithm_levenberg.h"
+#include "dependencies/g2o/g2o/core/robust_kernel_impl.h"
+#include "dependencies/g2o/g2o/core/sparse_optimizer_terminate_action.h"
+#include "dependencies/g2o/g2o/core/batch_stats.h"
+#include "dependencies/g2o/g2o/solvers/linear_solver_csparse.h"
+#include "dependencies/g2o/g2o/solvers/linear_solver_dense.h"
+#include "dependencies/g2o/g2o/types/types_six_dof_expmap.h"
+#include "dependencies/g2o/g2o/types/types_dyn_slam3d.h"
+#include "dependencies/g2o/g2o/types/vertex_se3.h"
+#include "dependencies/g2o/g2o/types/vertex_pointxyz.h"
+#include "dependencies/g2o/g2o/types/edge_se3.h"
+#include "dependencies/g2o/g2o/types/edge_se3_pointxyz.h"
+#include "dependencies/g2o/g2o/types/edge_se3_prior.h"
+#include "dependencies/g2o/g2o/types/isometry3d_mappings.h"
+#include "System.h"
+#include "Converter.h"
+#include "Optimizer.h"
+#undef private
+#undef protected
+
+#include "../vdo_oracle.h"
+
+using VDO_SLAM::Frame;
+using VDO_SLAM::Map;
+using VDO_SLAM::Optimizer;
+using VDO_SLAM::Converter;
+
+namespace {
+g2o::Isometry3 iso12(const double* T) {
+  g2o::Isometry3 X = g2o::Isometry3::Identity();
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) X.matrix()(i, j) = T[3 * i + j]; X.matrix()(i, 3) = T[9 + i]; }
+  return X;
+}
+void to12(const g2o::Isometry3& X, double* T) { for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T[3 * i + j] = X.matrix()(i, j); T[9 + i] = X.matrix()(i, 3); } }
+g2o::SE3Quat se3_from16(const double* T) {            // what Converter::toSE3Quat does after its float -> double copy (src/Converter.cc:25-35)
+  Eigen::Matrix<double, 3, 3> R; Eigen::Matrix<double, 3, 1> t;
+  for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) R(i, j) = T[4 * i + j]; t(i) = T[4 * i + 3]; }
+  return g2o::SE3Quat(R, t);
+}
+template <typename M> void rowmajor(const M& m, double* out) { for (int i = 0; i < (int)m.rows(); ++i) for (int j = 0; j < (int)m.cols(); ++j) out[i * m.cols() + j] = m(i, j); }
+cv::Mat mat44(const float* p) { cv::Mat m(4, 4, CV_32F); std::memcpy(m.data, p, 64); return m; }
+cv::Mat mat31(const float* p) { cv::Mat m(3, 1, CV_32F); std::memcpy(m.data, p, 12); return m; }
+struct Silence {                                       // the reference's optimisers talk to std::cout
+  std::streambuf* old; std::ostringstream sink;
+  Silence() : old(std::cout.rdbuf(sink.rdbuf())) {}
+  ~Silence() { std::cout.rdbuf(old); }
+};
+}  // namespace
+
+extern "C" {
+
+// g2o::SE3Quat::exp (types/se3quat.h:212-258): update = (omega, upsilon); 4x4 row-major out
+void ref_se3_exp(const double u[6], double T16[16]) {
+  g2o::Vector6d v; for (int i = 0; i < 6; ++i) v[i] = u[i];
+  Eigen::Matrix<double, 4, 4> M = g2o::SE3Quat::exp(v).to_homogeneous_matrix();
+  rowmajor(M, T16);
+}
+// VertexSE3Expmap::oplusImpl (types/types_six_dof_expmap.h:80-84): exp(update) * estimate, the estimate given as a 4x4 (through SE3Quat(R, t) as toSE3Quat builds it)
+void ref_se3quat_oplus(const double T16[16], const double u[6], double out16[16]) {
+  g2o::VertexSE3Expmap v; v.setEstimate(se3_from16(T16));
+  v.oplusImpl(u);
+  Eigen::Matrix<double, 4, 4> M = v.estimate().to_homogeneous_matrix();
+  rowmajor(M, out16);
+}
+// SE3Quat(R, t).to_homogeneous_matrix(): the quaternion round trip every pose makes at the optimiser boundary (Converter::toSE3Quat / toCvMat)
+void ref_se3quat_roundtrip(const double T16[16], double out16[16]) { Eigen::Matrix<double, 4, 4> M = se3_from16(T16).to_homogeneous_matrix(); rowmajor(M, out16); }
+// VertexSE3::oplusImpl (types/vertex_se3.h:105-114)
+void ref_iso_oplus(const double T12[12], const double d[6], double out12[12]) {
+  g2o::VertexSE3 v; v.setEstimate(iso12(T12));
+  v.oplusImpl(d);
+  to12(v.estimate(), out12);
+}
+void ref_iso_to_mqt(const double T12[12], double e[6]) { g2o::Vector6 v = g2o::internal::toVectorMQT(iso12(T12)); for (int i = 0; i < 6; ++i) e[i] = v[i]; }
+
+// EdgeSE3 (types/edge_se3.cpp:77-104 + isometry3d_gradients.h:191-261 + dquat2mat.cpp)
+void ref_edge_se3_jac(const double Z12[12], const double Xi12[12], const double Xj12[12], double e[6], double Ji[36], double Jj[36]) {
+  g2o::VertexSE3 vi, vj; vi.setId(0); vj.setId(1); vi.setEstimate(iso12(Xi12)); vj.setEstimate(iso12(Xj12));
+  g2o::EdgeSE3 ed; ed.setVertex(0, &vi); ed.setVertex(1, &vj); ed.setMeasurement(iso12(Z12)); ed.information().setIdentity();
+  g2o::JacobianWorkspace ws; ws.updateSize(&ed); ws.allocate();
+  ed.computeError();
+  ed.BaseBinaryEdge<6, g2o::Isometry3, g2o::VertexSE3, g2o::VertexSE3>::linearizeOplus(ws);
+  for (int i = 0; i < 6; ++i) e[i] = ed.error()[i];
+  rowmajor(ed.jacobianOplusXi(), Ji); rowmajor(ed.jacobianOplusXj(), Jj);
+}
+
+// EdgeSE3Prior (types/edge_se3_prior.cpp:89-102) with the identity offset parameter of src/Optimizer.cc:1325-1327
+void ref_edge_prior_jac(const double Z12[12], const double X12[12], double e[6], double J[36]) {
+  g2o::SparseOptimizer opt;
+  g2o::ParameterSE3Offset* off = new g2o::ParameterSE3Offset; off->setId(0); opt.addParameter(off);
+  g2o::VertexSE3* v = new g2o::VertexSE3; v->setId(1); v->setEstimate(iso12(X12)); opt.addVertex(v);
+  g2o::EdgeSE3Prior* ed = new g2o::EdgeSE3Prior; ed->setVertex(0, v); ed->setMeasurement(iso12(Z12)); ed->information() = Eigen::MatrixXd::Identity(6, 6); ed->setParameterId(0, 0);
+  opt.addEdge(ed);
+  v->setEstimate(iso12(X12));                          // (updates the cache the edge resolved when it was added)
+  g2o::JacobianWorkspace ws; ws.updateSize(ed); ws.allocate();
+  ed->computeError();
+  ed->BaseUnaryEdge<6, g2o::Isometry3, g2o::VertexSE3>::linearizeOplus(ws);
+  for (int i = 0; i < 6; ++i) e[i] = ed->error()[i];
+  rowmajor(ed->_jacobianOplusXi, J);
+}
+
+// EdgeSE3PointXYZ (types/edge_se3_pointxyz.cpp:99-140) + CacheSE3Offset (types/parameter_se3_offset.cpp:77-82)
+void ref_edge_eb_jac(const double X12[12], const double p[3], const double z[3], double e[3], double Jpose[18], double Jpoint[9]) {
+  g2o::SparseOptimizer opt;
+  g2o::ParameterSE3Offset* off = new g2o::ParameterSE3Offset; off->setId(0); opt.addParameter(off);
+  g2o::VertexSE3* v = new g2o::VertexSE3; v->setId(1); v->setEstimate(iso12(X12)); opt.addVertex(v);
+  g2o::VertexPointXYZ* vp = new g2o::VertexPointXYZ; vp->setId(2); vp->setEstimate(g2o::Vector3(p[0], p[1], p[2])); opt.addVertex(vp);
+  g2o::EdgeSE3PointXYZ* ed = new g2o::EdgeSE3PointXYZ; ed->setVertex(0, v); ed->setVertex(1, vp); ed->setMeasurement(g2o::Vector3(z[0], z[1], z[2]));
+  ed->information() = Eigen::Matrix3d::Identity(); ed->setParameterId(0, 0);
+  opt.addEdge(ed);
+  v->setEstimate(iso12(X12));
+  g2o::JacobianWorkspace ws; ws.updateSize(ed); ws.allocate();
+  ed->computeError();
+  ed->BaseBinaryEdge<3, g2o::Vector3, g2o::VertexSE3, g2o::VertexPointXYZ>::linearizeOplus(ws);
+  for (int i = 0; i < 3; ++i) e[i] = ed->error()[i];
+  rowmajor(ed->jacobianOplusXi(), Jpose); rowmajor(ed->jacobianOplusXj(), Jpoint);
+}
+
+// LandmarkMotionTernaryEdge (types/types_dyn_slam3d.cpp:53-85)
+void ref_edge_et_jac(const double H12[12], const double p1[3], const double p2[3], const double z[3], double e[3], double Jp1[9], double Jp2[9], double Jh[18]) {
+  g2o::VertexPointXYZ v1, v2; g2o::VertexSE3 vh; v1.setId(0); v2.setId(1); vh.setId(2);
+  v1.setEstimate(g2o::Vector3(p1[0], p1[1], p1[2])); v2.setEstimate(g2o::Vector3(p2[0], p2[1], p2[2])); vh.setEstimate(iso12(H12));
+  g2o::LandmarkMotionTernaryEdge ed; ed.setVertex(0, &v1); ed.setVertex(1, &v2); ed.setVertex(2, &vh);
+  ed.setMeasurement(g2o::Vector3(z[0], z[1], z[2])); ed.information() = Eigen::Matrix3d::Identity();
+  g2o::JacobianWorkspace ws; ws.updateSize(&ed); ws.allocate();
+  ed.computeError();
+  ed.BaseMultiEdge<3, g2o::Vector3>::linearizeOplus(ws);
+  for (int i = 0; i < 3; ++i) e[i] = ed.error()[i];
+  rowmajor(ed._jacobianOplus[0], Jp1); rowmajor(ed._jacobianOplus[1], Jp2); rowmajor(ed._jacobianOplus[2], Jh);
+}
+
+// EdgeSE3ProjectXYZOnlyPose (kind 0, types/types_six_dof_expmap.cpp:266-296) / EdgeSE3ProjectXYZOnlyObjMotion (kind 1, :394-443)
+void ref_edge_unary_jac(int kind, const double K4[4], const double P12[12], const double T16[16], const double Xw[3], const double obs[2], double err2[2], double J12[12]) {
+  g2o::VertexSE3Expmap v; v.setId(0); v.setEstimate(se3_from16(T16));
+  g2o::JacobianWorkspace ws;
+  if (kind == 0) {
+    g2o::EdgeSE3ProjectXYZOnlyPose ed; ed.setVertex(0, &v); ed.setMeasurement(Eigen::Vector2d(obs[0], obs[1])); ed.information() = Eigen::Matrix2d::Identity();
+    ed.fx = K4[0]; ed.fy = K4[1]; ed.cx = K4[2]; ed.cy = K4[3]; ed.Xw = Eigen::Vector3d(Xw[0], Xw[1], Xw[2]);
+    ws.updateSize(&ed); ws.allocate();
+    ed.computeError();
+    ed.BaseUnaryEdge<2, Eigen::Vector2d, g2o::VertexSE3Expmap>::linearizeOplus(ws);
+    err2[0] = ed.error()[0]; err2[1] = ed.error()[1]; rowmajor(ed._jacobianOplusXi, J12);
+  } else {
+    g2o::EdgeSE3ProjectXYZOnlyObjMotion ed; ed.setVertex(0, &v); ed.setMeasurement(Eigen::Vector2d(obs[0], obs[1])); ed.information() = Eigen::Matrix2d::Identity();
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 4; ++j) ed.P(i, j) = P12[4 * i + j];
+    ed.Xw = Eigen::Vector3d(Xw[0], Xw[1], Xw[2]);
+    ws.updateSize(&ed); ws.allocate();
+    ed.computeError();
+    ed.BaseUnaryEdge<2, Eigen::Vector2d, g2o::VertexSE3Expmap>::linearizeOplus(ws);
+    err2[0] = ed.error()[0]; err2[1] = ed.error()[1]; rowmajor(ed._jacobianOplusXi, J12);
+  }
+}
+
+// EdgeSE3ProjectFlow2 (types/types_six_dof_expmap.h:436-476, .cpp:805-845) and EdgeFlowPrior (.h:414-432, .cpp:772-775)
+void ref_edge_flow2_jac(const double K4[4], const double Twl16[16], double depth, const double obs[2], const double flow_est[2], const double flow_meas[2], const double T16[16],
+                        double err2[2], double Jflow4[4], double Jpose12[12], double errp2[2], double Jp4[4]) {
+  g2o::VertexSBAFlow vf; vf.setId(0); vf.setEstimate(Eigen::Vector2d(flow_est[0], flow_est[1]));
+  g2o::VertexSE3Expmap v; v.setId(1); v.setEstimate(se3_from16(T16));
+  g2o::EdgeSE3ProjectFlow2 ed; ed.setVertex(0, &vf); ed.setVertex(1, &v); ed.setMeasurement(Eigen::Vector2d(obs[0], obs[1])); ed.information() = Eigen::Matrix2d::Identity();
+  ed.fx = K4[0]; ed.fy = K4[1]; ed.cx = K4[2]; ed.cy = K4[3]; ed.depth = depth;
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) ed.Twl(i, j) = Twl16[4 * i + j];
+  g2o::JacobianWorkspace ws; ws.updateSize(&ed); ws.allocate();
+  ed.computeError();
+  ed.BaseBinaryEdge<2, Eigen::Vector2d, g2o::VertexSBAFlow, g2o::VertexSE3Expmap>::linearizeOplus(ws);
+  err2[0] = ed.error()[0]; err2[1] = ed.error()[1];
+  rowmajor(ed.jacobianOplusXi(), Jflow4); rowmajor(ed.jacobianOplusXj(), Jpose12);
+  g2o::EdgeFlowPrior ep; ep.setVertex(0, &vf); ep.setMeasurement(Eigen::Vector2d(flow_meas[0], flow_meas[1])); ep.information() = Eigen::Matrix2d::Identity();
+  g2o::JacobianWorkspace ws2; ws2.updateSize(&ep); ws2.allocate();
+  ep.computeError();
+  ep.BaseUnaryEdge<2, Eigen::Vector2d, g2o::VertexSBAFlow>::linearizeOplus(ws2);
+  errp2[0] = ep.error()[0]; errp2[1] = ep.error()[1]; rowmajor(ep._jacobianOplusXi, Jp4);
+}
+
+// RobustKernelHuber::robustify (core/robust_kernel_impl.cpp:78-91)
+void ref_huber(double delta, double e2, double rho3[3]) {
+  g2o::RobustKernelHuber k; k.setDelta(delta);
+  Eigen::Vector3d rho; k.robustify(e2, rho);
+  rho3[0] = rho[0]; rho3[1] = rho[1]; rho3[2] = rho[2];
+}
+
+// ---- a flat batch graph as g2o objects ------------------------------------------------------------------------------------------------------
+namespace {
+struct RefGraph {
+  g2o::SparseOptimizer opt;
+  std::vector<g2o::VertexSE3*> vpose;
+  std::vector<g2o::VertexPointXYZ*> vpoint;
+  std::vector<g2o::EdgeSE3PointXYZ*> eb;
+  std::vector<g2o::LandmarkMotionTernaryEdge*> et;
+  std::vector<g2o::EdgeSE3*> ep;
+  std::vector<g2o::EdgeSE3Prior*> pr;
+  g2o::BlockSolverX* solver_ptr = nullptr;
+};
+Eigen::MatrixXd info6(const double* p) { Eigen::MatrixXd m(6, 6); for (int i = 0; i < 6; ++i) for (int j = 0; j < 6; ++j) m(i, j) = p[6 * i + j]; return m; }
+void build_graph(RefGraph& G, const vdo_ba_graph* g, double gain_threshold) {
+  // the optimiser of src/Optimizer.cc:1313-1327
+  g2o::BlockSolverX::LinearSolverType* linearSolver = new g2o::LinearSolverCSparse<g2o::BlockSolverX::PoseMatrixType>();
+  G.solver_ptr = new g2o::BlockSolverX(linearSolver);
+  g2o::OptimizationAlgorithmLevenberg* solver = new g2o::OptimizationAlgorithmLevenberg(G.solver_ptr);
+  G.opt.setAlgorithm(solver);
+  if (gain_threshold >= 0) {
+    g2o::SparseOptimizerTerminateAction* terminateAction = new g2o::SparseOptimizerTerminateAction;
+    terminateAction->setGainThreshold(gain_threshold);
+    G.opt.addPostIterationAction(terminateAction);
+  }
+  g2o::ParameterSE3Offset* cameraOffset = new g2o::ParameterSE3Offset;
+  cameraOffset->setId(0);
+  G.opt.addParameter(cameraOffset);
+  int id = 1;
+  for (int i = 0; i < g->n_pose; ++i) { g2o::VertexSE3* v = new g2o::VertexSE3; v->setId(id++); v->setEstimate(iso12(g->pose + 12 * i)); G.opt.addVertex(v); G.vpose.push_back(v); }
+  for (int i = 0; i < g->n_point; ++i) {
+    g2o::VertexPointXYZ* v = new g2o::VertexPointXYZ; v->setId(id++); v->setEstimate(g2o::Vector3(g->point[3 * i], g->point[3 * i + 1], g->point[3 * i + 2])); G.opt.addVertex(v); G.vpoint.push_back(v);
+  }
+  auto huber = [](double d) -> g2o::RobustKernel* { g2o::RobustKernelHuber* rk = new g2o::RobustKernelHuber; rk->setDelta(d); return rk; };
+  for (int k = 0; k < g->n_prior; ++k) {
+    g2o::EdgeSE3Prior* e = new g2o::EdgeSE3Prior; e->setVertex(0, G.vpose[g->pr_pose[k]]); e->setMeasurement(iso12(g->pr_z + 12 * k)); e->information() = info6(g->pr_info + 36 * k);
+    e->setParameterId(0, 0); G.opt.addEdge(e); G.pr.push_back(e);
+  }
+  for (int k = 0; k < g->n_ep; ++k) {
+    g2o::EdgeSE3* e = new g2o::EdgeSE3; e->setVertex(0, G.vpose[g->ep_i[k]]); e->setVertex(1, G.vpose[g->ep_j[k]]); e->setMeasurement(iso12(g->ep_z + 12 * k));
+    e->information() = info6(g->ep_info + 36 * k);
+    if (g->huber_ep > 0) e->setRobustKernel(huber(g->huber_ep));
+    G.opt.addEdge(e); G.ep.push_back(e);
+  }
+  for (int k = 0; k < g->n_eb; ++k) {
+    g2o::EdgeSE3PointXYZ* e = new g2o::EdgeSE3PointXYZ; e->setVertex(0, G.vpose[g->eb_pose[k]]); e->setVertex(1, G.vpoint[g->eb_point[k]]);
+    e->setMeasurement(g2o::Vector3(g->eb_z[k], g->eb_z[g->n_eb + k], g->eb_z[2 * (size_t)g->n_eb + k]));
+    e->information() = Eigen::Matrix3d::Identity() * g->eb_w[k];
+    e->setParameterId(0, 0);
+    if (g->huber_eb > 0) e->setRobustKernel(huber(g->huber_eb));
+    G.opt.addEdge(e); G.eb.push_back(e);
+  }
+  for (int k = 0; k < g->n_et; ++k) {
+    g2o::LandmarkMotionTernaryEdge* e = new g2o::LandmarkMotionTernaryEdge;
+    e->setVertex(0, G.vpoint[g->et_p1[k]]); e->setVertex(1, G.vpoint[g->et_p2[k]]); e->setVertex(2, G.vpose[g->et_pose[k]]);
+    e->setMeasurement(g2o::Vector3(g->et_z[k], g->et_z[g->n_et + k], g->et_z[2 * (size_t)g->n_et + k]));
+    e->information() = Eigen::Matrix3d::Identity() * g->et_w[k];
+    if (g->huber_et > 0) e->setRobustKernel(huber(g->huber_et));
+    G.opt.addEdge(e); G.et.push_back(e);
+  }
+  // (a vertex's cache is refreshed when its estimate is set: the edges above resolved their caches when they were added)
+  for (int i = 0; i < g->n_pose; ++i) G.vpose[i]->setEstimate(iso12(g->pose + 12 * i));
+}
+}  // namespace
+
+// optimize(max_iterations) on the graph; stats from g2o's own batch statistics (core/batch_stats.h): chi2 after every outer iteration, Levenberg trials
+int ref_ba_optimize(const vdo_ba_graph* g, const vdo_lm_options* o, double* pose_out, double* point_out, vdo_lm_stats* st) {
+  Silence quiet;
+  RefGraph G;
+  build_graph(G, g, o->gain_threshold);
+  G.opt.setComputeBatchStatistics(true);
+  if (!G.opt.initializeOptimization()) return -1;
+  G.opt.computeActiveErrors();
+  const double chi0 = G.opt.activeRobustChi2();
+  const int its = G.opt.optimize(o->max_iterations);
+  for (int i = 0; i < g->n_pose; ++i) to12(G.vpose[i]->estimate(), pose_out + 12 * i);
+  for (int i = 0; i < g->n_point; ++i) for (int c = 0; c < 3; ++c) point_out[3 * i + c] = G.vpoint[i]->estimate()[c];
+  if (st) {
+    std::memset(st, 0, sizeof *st);
+    st->iterations = its; st->initial_chi2 = chi0;
+    const g2o::BatchStatisticsContainer& B = G.opt.batchStatistics();
+    int k = 0;
+    for (size_t i = 0; i < B.size() && k < VDO_LM_MAX_TRACE; ++i) {
+      if (B[i].iteration < 0) continue;
+      st->chi2_trace[k] = B[i].chi2; st->trials_trace[k] = B[i].levenbergIterations; st->total_trials += B[i].levenbergIterations; ++k;
+    }
+    G.opt.computeActiveErrors();
+    st->final_chi2 = G.opt.activeRobustChi2();
+    st->final_lambda = static_cast<g2o::OptimizationAlgorithmLevenberg*>(G.opt._algorithm)->currentLambda();
+  }
+  return 0;
+}
+
+// one linearisation: computeActiveErrors + BlockSolver::buildSystem (core/block_solver.hpp:502-560), blocks read back out of the solver's Hpp
+// (BlockSolverX, nothing marginalised: every vertex is a "pose" of the solver) in the oracle's vdo_ba_system layout (row-major blocks)
+int ref_ba_linearize(const vdo_ba_graph* g, vdo_ba_system* out) {
+  Silence quiet;
+  RefGraph G;
+  build_graph(G, g, -1.0);
+  if (!G.opt.initializeOptimization()) return -1;
+  G.opt.computeActiveErrors();
+  out->robust_chi2 = G.opt.activeRobustChi2();
+  out->chi2 = G.opt.activeChi2();
+  if (!G.opt._algorithm->init(false)) return -4;          // (what optimize() does first: hands the optimiser to the solver, core/sparse_optimizer.cpp:378)
+  if (!G.solver_ptr->buildStructure()) return -2;
+  G.solver_ptr->buildSystem();                             // (ends in `return 0;`, core/block_solver.hpp:559: the value says nothing and Levenberg ignores it)
+  auto block = [&](g2o::OptimizableGraph::Vertex* a, g2o::OptimizableGraph::Vertex* b, int ra, int cb, double* dst) {
+    // the block (a, b) of the symmetric system: stored in the upper triangle, i.e. at (min, max) of the two Hessian indices - transposed when a comes later
+    const int ia = a->hessianIndex(), ib = b->hessianIndex();
+    const bool tr = ia > ib;
+    const Eigen::MatrixXd* m = G.solver_ptr->_Hpp->block(tr ? ib : ia, tr ? ia : ib);
+    for (int i = 0; i < ra; ++i) for (int j = 0; j < cb; ++j) dst[i * cb + j] = m ? (tr ? (*m)(j, i) : (*m)(i, j)) : 0.0;
+  };
+  for (int i = 0; i < g->n_pose; ++i) {
+    if (out->Hpp) block(G.vpose[i], G.vpose[i], 6, 6, out->Hpp + 36 * i);
+    if (out->bp) for (int c = 0; c < 6; ++c) out->bp[6 * i + c] = G.vpose[i]->b(c);
+  }
+  for (int i = 0; i < g->n_point; ++i) {
+    if (out->Hll) block(G.vpoint[i], G.vpoint[i], 3, 3, out->Hll + 9 * i);
+    if (out->bl) for (int c = 0; c < 3; ++c) out->bl[3 * i + c] = G.vpoint[i]->b(c);
+  }
+  // off-diagonal blocks are sums over all edges between the two vertices: the SoA-per-edge outputs are only meaningful for graphs with at most one
+  // edge per vertex pair (what the tests build)
+  double tmp[36];
+  for (int k = 0; k < g->n_eb; ++k) if (out->Hpl_eb) { block(G.vpose[g->eb_pose[k]], G.vpoint[g->eb_point[k]], 6, 3, tmp); for (int q = 0; q < 18; ++q) out->Hpl_eb[(size_t)q * g->n_eb + k] = tmp[q]; }
+  for (int k = 0; k < g->n_et; ++k) {
+    if (out->Hll_et) { block(G.vpoint[g->et_p1[k]], G.vpoint[g->et_p2[k]], 3, 3, tmp); for (int q = 0; q < 9; ++q) out->Hll_et[(size_t)q * g->n_et + k] = tmp[q]; }
+    if (out->Hlp1_et) { block(G.vpoint[g->et_p1[k]], G.vpose[g->et_pose[k]], 3, 6, tmp); for (int q = 0; q < 18; ++q) out->Hlp1_et[(size_t)q * g->n_et + k] = tmp[q]; }
+    if (out->Hlp2_et) { block(G.vpoint[g->et_p2[k]], G.vpose[g->et_pose[k]], 3, 6, tmp); for (int q = 0; q < 18; ++q) out->Hlp2_et[(size_t)q * g->n_et + k] = tmp[q]; }
+  }
+  for (int k = 0; k < g->n_ep; ++k) if (out->Hpp_ep) block(G.vpose[g->ep_i[k]], G.vpose[g->ep_j[k]], 6, 6, out->Hpp_ep + 36 * k);
+  return 0;
+}
+
+// ---- the Map-level batch optimisers ---------------------------------------------------------------------------------------------------------
+struct ref_map_flat {                                  // = host_map_flat of vdo_slam_amd/host/host_capi.cc
+  int n_frames;
+  const float* K;
+  const float* cam_pose;
+  const int* sta_cnt; const float *sta_uv, *sta_d, *sta_xw;
+  int n_tr_sta; const int *tr_sta_len, *tr_sta_pairs;
+  const int* dyn_cnt; const float *dyn_uv, *dyn_d, *dyn_xw;
+  int n_tr_dyn; const int *tr_dyn_len, *tr_dyn_pairs, *obj_of_dyn;
+  const int* rm_cnt; const float* rm; const int* rm_label;
+};
+
+int ref_batch_optimization(const ref_map_flat* f, int partial_window, float* cam_pose_out, float* rm_out, float* sta_xw_out, float* dyn_xw_out) {
+  Silence quiet;
+  Map map;
+  const int F = f->n_frames;
+  cv::Mat K(3, 3, CV_32F);
+  std::memcpy(K.data, f->K, 36);
+  size_t so = 0, dof = 0, ro = 0;
+  map.vpFeatSta.resize(F); map.vfDepSta.resize(F); map.vp3DPointSta.resize(F);
+  map.vpFeatDyn.resize(F); map.vfDepDyn.resize(F); map.vp3DPointDyn.resize(F);
+  for (int i = 0; i < F; ++i) {
+    map.vmCameraPose.push_back(mat44(f->cam_pose + 16 * i));
+    for (int j = 0; j < f->sta_cnt[i]; ++j, ++so) {
+      map.vpFeatSta[i].push_back(cv::KeyPoint(f->sta_uv[2 * so], f->sta_uv[2 * so + 1], 0));
+      map.vfDepSta[i].push_back(f->sta_d[so]);
+      map.vp3DPointSta[i].push_back(mat31(f->sta_xw + 3 * so));
+    }
+    for (int j = 0; j < f->dyn_cnt[i]; ++j, ++dof) {
+      map.vpFeatDyn[i].push_back(cv::KeyPoint(f->dyn_uv[2 * dof], f->dyn_uv[2 * dof + 1], 0));
+      map.vfDepDyn[i].push_back(f->dyn_d[dof]);
+      map.vp3DPointDyn[i].push_back(mat31(f->dyn_xw + 3 * dof));
+    }
+    if (i < F - 1) {
+      std::vector<cv::Mat> mots; std::vector<int> labs;
+      for (int j = 0; j < f->rm_cnt[i]; ++j, ++ro) { mots.push_back(mat44(f->rm + 16 * ro)); labs.push_back(f->rm_label[ro]); }
+      map.vmRigidMotion.push_back(mots); map.vnRMLabel.push_back(labs);
+    }
+  }
+  map.vmCameraPose_RF = map.vmCameraPose; map.vmRigidMotion_RF = map.vmRigidMotion;
+  size_t po = 0;
+  for (int t = 0; t < f->n_tr_sta; ++t) {
+    std::vector<std::pair<int, int> > tr;
+    for (int k = 0; k < f->tr_sta_len[t]; ++k, ++po) tr.push_back(std::make_pair(f->tr_sta_pairs[2 * po], f->tr_sta_pairs[2 * po + 1]));
+    map.TrackletSta.push_back(tr);
+  }
+  po = 0;
+  for (int t = 0; t < f->n_tr_dyn; ++t) {
+    std::vector<std::pair<int, int> > tr;
+    for (int k = 0; k < f->tr_dyn_len[t]; ++k, ++po) tr.push_back(std::make_pair(f->tr_dyn_pairs[2 * po], f->tr_dyn_pairs[2 * po + 1]));
+    map.TrackletDyn.push_back(tr);
+    map.nObjID.push_back(f->obj_of_dyn[t]);
+  }
+  if (partial_window > 0) Optimizer::PartialBatchOptimization(&map, K, partial_window);
+  else Optimizer::FullBatchOptimization(&map, K);
+  so = dof = ro = 0;
+  for (int i = 0; i < F; ++i) {
+    const cv::Mat& T = partial_window > 0 ? map.vmCameraPose[i] : map.vmCameraPose_RF[i];
+    std::memcpy(cam_pose_out + 16 * i, T.data, 64);
+    for (int j = 0; j < f->sta_cnt[i]; ++j, ++so) std::memcpy(sta_xw_out + 3 * so, map.vp3DPointSta[i][j].data, 12);
+    for (int j = 0; j < f->dyn_cnt[i]; ++j, ++dof) std::memcpy(dyn_xw_out + 3 * dof, map.vp3DPointDyn[i][j].data, 12);
+    if (i < F - 1)
+      for (int j = 0; j < f->rm_cnt[i]; ++j, ++ro) {
+        const cv::Mat& M = partial_window > 0 ? map.vmRigidMotion[i][j] : map.vmRigidMotion_RF[i][j];
+        std::memcpy(rm_out + 16 * ro, M.data, 64);
+      }
+  }
+  return 0;
+}
+
+// ---- the four per-frame statics ------------------------------------------------------------------------------------------------------------
+static void set_intrinsics(const float* K4) { Frame::fx = K4[0]; Frame::fy = K4[1]; Frame::cx = K4[2]; Frame::cy = K4[3]; Frame::invfx = 1.0f / Frame::fx; Frame::invfy = 1.0f / Frame::fy; }
+
+// Optimizer::PoseOptimizationFlow2Cam (src/Optimizer.cc:2333-2542).  match_out: TemperalMatch as the call leaves it (-1 = outlier); cur_xy_out: the refined keys
+int ref_pose_optimization_flow2cam(int n, const float* K4, const float* last_xy, const float* flow, const float* depth, const float* Tcw_last, const float* Tcw_init,
+                                   float* Tcw_out, int* match_out, float* cur_xy_out) {
+  Silence quiet;
+  Frame last, cur;
+  set_intrinsics(K4);
+  last.mTcw = mat44(Tcw_last); cur.mTcw = mat44(Tcw_init);
+  std::vector<int> match(n);
+  for (int i = 0; i < n; ++i) {
+    last.mvStatKeys.push_back(cv::KeyPoint(last_xy[2 * i], last_xy[2 * i + 1], 0));
+    last.mvFlowNext.push_back(cv::Point2f(flow[2 * i], flow[2 * i + 1]));
+    last.mvStatDepth.push_back(depth[i]);
+    cur.mvStatKeys.push_back(cv::KeyPoint(last_xy[2 * i] + flow[2 * i], last_xy[2 * i + 1] + flow[2 * i + 1], 0));
+    match[i] = i;
+  }
+  const int inl = Optimizer::PoseOptimizationFlow2Cam(&cur, &last, match);
+  std::memcpy(Tcw_out, cur.mTcw.data, 64);
+  for (int i = 0; i < n; ++i) { match_out[i] = match[i]; cur_xy_out[2 * i] = cur.mvStatKeys[i].pt.x; cur_xy_out[2 * i + 1] = cur.mvStatKeys[i].pt.y; }
+  return inl;
+}
+
+// Optimizer::PoseOptimizationFlow2 (src/Optimizer.cc:2755-2972): returns the number of inliers; H_out = the returned composite, obj_label_out = vObjLabel (-1 = outlier)
+int ref_pose_optimization_flow2(int n, const float* K4, const float* last_xy, const float* flow, const float* depth, const float* Tcw_last, const float* Tcw_cur,
+                                const float* init_model, float* H_out, int* inlier_flag, int* obj_label_out, float* cur_xy_out) {
+  Silence quiet;
+  Frame last, cur;
+  set_intrinsics(K4);
+  last.mTcw = mat44(Tcw_last); cur.mTcw = mat44(Tcw_cur); cur.mInitModel = mat44(init_model);
+  std::vector<int> ids(n), inliers;
+  for (int i = 0; i < n; ++i) {
+    last.mvObjKeys.push_back(cv::KeyPoint(last_xy[2 * i], last_xy[2 * i + 1], 0));
+    last.mvObjFlowNext.push_back(cv::Point2f(flow[2 * i], flow[2 * i + 1]));
+    last.mvObjDepth.push_back(depth[i]);
+    cur.mvObjKeys.push_back(cv::KeyPoint(last_xy[2 * i] + flow[2 * i], last_xy[2 * i + 1] + flow[2 * i + 1], 0));
+    cur.vObjLabel.push_back(7);
+    ids[i] = i;
+  }
+  cv::Mat H = Optimizer::PoseOptimizationFlow2(&cur, &last, ids, inliers);
+  std::memcpy(H_out, H.data, 64);
+  for (int i = 0; i < n; ++i) { inlier_flag[i] = 0; obj_label_out[i] = cur.vObjLabel[i]; cur_xy_out[2 * i] = cur.mvObjKeys[i].pt.x; cur_xy_out[2 * i + 1] = cur.mvObjKeys[i].pt.y; }
+  for (int id : inliers) inlier_flag[id] = 1;
+  return (int)inliers.size();
+}
+
+// Optimizer::PoseOptimizationNew (src/Optimizer.cc:2177-2331).  NB the reference back-projects with addnoise = 1 (UnprojectStereoStat(i, 1): cv::RNG seeded
+// with time(NULL), src/Frame.cc:484-519) - the clock of this library is vdo_ref_set_time's.
+int ref_pose_optimization_new(int n, const float* K4, const float* last_xy, const float* depth, const float* cur_xy, const float* Tcw_last, const float* Tcw_init,
+                              float* Tcw_out, int* match_out) {
+  Silence quiet;
+  Frame last, cur;
+  set_intrinsics(K4);
+  last.mTcw = mat44(Tcw_last); cur.mTcw = mat44(Tcw_init);
+  std::vector<int> match(n);
+  for (int i = 0; i < n; ++i) {
+    last.mvStatKeys.push_back(cv::KeyPoint(last_xy[2 * i], last_xy[2 * i + 1], 0));
+    last.mvStatDepth.push_back(depth[i]);
+    cur.mvStatKeys.push_back(cv::KeyPoint(cur_xy[2 * i], cur_xy[2 * i + 1], 0));
+    match[i] = i;
+  }
+  const int inl = Optimizer::PoseOptimizationNew(&cur, &last, match);
+  std::memcpy(Tcw_out, cur.mTcw.data, 64);
+  for (int i = 0; i < n; ++i) match_out[i] = match[i];
+  return inl;
+}
+
+// Optimizer::PoseOptimizationObjMot (src/Optimizer.cc:2544-2753)
+int ref_pose_optimization_objmot(int n, const float* K4, const float* last_xy, const float* depth, const float* cur_xy, const float* cur_depth, const float* Tcw_last, const float* Tcw_cur,
+                                 const float* init_model, float* H_out, int* inlier_flag, int* obj_label_out) {
+  Silence quiet;
+  Frame last, cur;
+  set_intrinsics(K4);
+  last.mTcw = mat44(Tcw_last); cur.mTcw = mat44(Tcw_cur); cur.mInitModel = mat44(init_model);
+  std::vector<int> ids(n), inliers;
+  for (int i = 0; i < n; ++i) {
+    last.mvObjKeys.push_back(cv::KeyPoint(last_xy[2 * i], last_xy[2 * i + 1], 0));
+    last.mvObjDepth.push_back(depth[i]);
+    cur.mvObjKeys.push_back(cv::KeyPoint(cur_xy[2 * i], cur_xy[2 * i + 1], 0));
+    cur.mvObjDepth.push_back(cur_depth ? cur_depth[i] : depth[i]);
+    cur.vObjLabel.push_back(7);
+    ids[i] = i;
+  }
+  cv::Mat H = Optimizer::PoseOptimizationObjMot(&cur, &last, ids, inliers);
+  std::memcpy(H_out, H.data, 64);
+  for (int i = 0; i < n; ++i) { inlier_flag[i] = 0; obj_label_out[i] = cur.vObjLabel[i]; }
+  for (int id : inliers) inlier_flag[id] = 1;
+  return (int)inliers.size();
+}
+
+}  // extern "C"

@@ -59,6 +59,7 @@ void operator delete[](void*, std::size_t) noexcept {}
 
 #include "../vdo_oracle.h"
 
+#ifndef REF_REAL_OPTIMIZER
 namespace VDO_SLAM {
 
 // src/Converter.cc:151-166, statement for statement
@@ -217,6 +218,11 @@ void Optimizer::FullBatchOptimization(Map*, const cv::Mat) { ++g_full_batch_call
 void Optimizer::PartialBatchOptimization(Map*, const cv::Mat, const int) { ++g_partial_batch_calls; }
 
 }  // namespace VDO_SLAM
+#else
+// libref_full.so: src/Converter.cc, src/Optimizer.cc and the vendored g2o are compiled verbatim beside this file (oracle/ref/Makefile) - no glue.
+// The batch optimisers really run (src/Tracking.cc:1165-1183); their call counts are not observable from outside and read -1.
+namespace VDO_SLAM { namespace { int g_full_batch_calls = -1, g_partial_batch_calls = -1, g_last_cam_iterations = -1; } }
+#endif
 
 using VDO_SLAM::System;
 using VDO_SLAM::Tracking;
@@ -290,7 +296,9 @@ void* vdo_ref_system_create(const char* settings) {
   if (std::getenv("VDO_REF_BT")) install_bt_handler();
   if (g_live_systems == 0) ref_arena::reset();
   ++g_live_systems;
+#ifndef REF_REAL_OPTIMIZER
   VDO_SLAM::g_full_batch_calls = VDO_SLAM::g_partial_batch_calls = 0;
+#endif
   // (the reference keeps the intrinsics in class statics set by the FIRST Frame of the process, src/Frame.cc:26-30,240-254: one calibration per
   //  process; a test that builds a second System with other settings starts them over)
   Frame::mbInitialComputations = true; Frame::nNextId = 0;

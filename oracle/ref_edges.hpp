@@ -114,10 +114,12 @@ inline void rot_block(const double dq[3][9], const M3& A, const M3& Sx, const M3
 // EdgeSE3: e = toVectorMQT(Z^-1 Xi^-1 Xj); Ji, Jj 6x6 row-major.
 inline void edge_se3(const Iso& Z, const Iso& Xi, const Iso& Xj, double e[6], double Ji[36], double Jj[36]) {
   Iso A = iso_inv(Z);
+  // computeError (edge_se3.cpp:77-82) multiplies left to right: (Z^-1 Xi^-1) Xj; the gradient (isometry3d_gradients.h:203-206) forms E = A (Xi^-1 Xj).
+  // Found by compiling the reference's own file (oracle/_ref, tests/test_ref_g2o.py): the two differ in the last bit.
+  toVectorMQT(iso_mul(iso_mul(A, iso_inv(Xi)), Xj), e);
+  if (!Ji) return;
   Iso B = iso_mul(iso_inv(Xi), Xj);
   Iso E = iso_mul(A, B);
-  toVectorMQT(E, e);
-  if (!Ji) return;
   for (int i = 0; i < 36; ++i) Ji[i] = Jj[i] = 0;
   double dq[3][9];
   dq_dR(E.R, dq);

@@ -244,6 +244,12 @@ void vdo_oracle_edge_eb_jac(const double X12[12], const double p[3], const doubl
 void vdo_oracle_edge_et_jac(const double H12[12], const double p1[3], const double p2[3], const double z[3],
                             double e[3], double Jp1[9], double Jp2[9], double Jh[18]);
 
+/* more KAT exports for tests/test_ref_g2o.py (flow_oracle.cpp) */
+void vdo_oracle_edge_flow2_jac(const double K4[4], const double Twl16[16], double depth, const double obs[2], const double flow_est[2], const double flow_meas[2],
+                               const double T16[16], double err2[2], double Jpose12[12], double errp2[2]);
+void vdo_oracle_huber(double delta, double e2, double rho2[2]);
+void vdo_oracle_se3quat_oplus(const double T16[16], const double* u, double out16[16]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -130,7 +130,40 @@ def load_ref_orb():
 
 
 REF_TRACK_LIB = os.path.join(ORACLE_DIR, "_ref", "libref_track.so")
+REF_FULL_LIB = os.path.join(ORACLE_DIR, "_ref", "libref_full.so")
 _ref_track = None
+_ref_full = None
+
+
+def _bind_ref_system(L):
+    vp = C.c_void_p
+    L.vdo_ref_system_create.restype = vp
+    L.vdo_ref_system_create.argtypes = [C.c_char_p]
+    L.vdo_ref_system_destroy.argtypes = [vp]
+    L.vdo_ref_system_track.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp]
+    L.vdo_ref_system_counts.argtypes = [vp, vp]
+    L.vdo_ref_system_frame_state.argtypes = [vp, C.c_int, vp, C.c_int]
+    L.vdo_ref_system_tracks.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
+    L.vdo_ref_system_timing.argtypes = [vp, vp]
+    L.vdo_ref_set_time.argtypes = [C.c_long]
+
+
+def load_ref_full():
+    """oracle/_ref/libref_full.so = the WHOLE reference library: the front-end sources of libref_track.so plus src/Optimizer.cc, src/Converter.cc and the
+    vendored g2o (dependencies/g2o/g2o: every source of its CMake target), all compiled verbatim - against the mini-cv shim, shim/Eigen (a small
+    dense-algebra library with Eigen's interface) and shim/cs.h + minics.cpp (CSparse's interface).  None when it cannot be had."""
+    global _ref_full
+    if _ref_full is not None:
+        return _ref_full
+    load()
+    if os.path.exists(os.path.join(REFERENCE_ROOT, "src", "Optimizer.cc")):
+        subprocess.run(["make", "-C", REF_DIR, "-s", "-j8", f"REF={REFERENCE_ROOT}"], check=True)
+    if not os.path.exists(REF_FULL_LIB):
+        return None
+    L = C.CDLL(REF_FULL_LIB)
+    _bind_ref_system(L)
+    _ref_full = L
+    return L
 
 
 def load_ref_track():
@@ -146,15 +179,6 @@ def load_ref_track():
     if not os.path.exists(REF_TRACK_LIB):
         return None
     L = C.CDLL(REF_TRACK_LIB)
-    vp = C.c_void_p
-    L.vdo_ref_system_create.restype = vp
-    L.vdo_ref_system_create.argtypes = [C.c_char_p]
-    L.vdo_ref_system_destroy.argtypes = [vp]
-    L.vdo_ref_system_track.argtypes = [vp, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, C.c_double, C.c_int, vp]
-    L.vdo_ref_system_counts.argtypes = [vp, vp]
-    L.vdo_ref_system_frame_state.argtypes = [vp, C.c_int, vp, C.c_int]
-    L.vdo_ref_system_tracks.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
-    L.vdo_ref_system_timing.argtypes = [vp, vp]
-    L.vdo_ref_set_time.argtypes = [C.c_long]
+    _bind_ref_system(L)
     _ref_track = L
     return L

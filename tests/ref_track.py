@@ -12,10 +12,29 @@ def _p(a):
     return a.ctypes.data_as(C.c_void_p) if a is not None else None
 
 
+_SCRATCH = None
+
+
+def scratch_dir():
+    """where the reference may drop its files: GetStaticTrack / GetDynamicTrackNew write track_distribution*.txt (src/Tracking.cc:2294-2303, :2410-2419) and the
+    batch optimisers dynamic_slam_graph_{before,after}_opt.g2o / local_ba_*.g2o (src/Optimizer.cc:806-808, :1934-1936) into the CURRENT directory"""
+    global _SCRATCH
+    if _SCRATCH is None:
+        import atexit
+        import shutil
+        import tempfile
+        _SCRATCH = tempfile.mkdtemp(prefix="vdo_ref_cwd_")
+        atexit.register(shutil.rmtree, _SCRATCH, ignore_errors=True)
+    return _SCRATCH
+
+
 class Quiet:
-    """The reference prints a few hundred lines per frame to stdout: sent to /dev/null for the duration of a call."""
+    """The reference prints a few hundred lines per frame to stdout: sent to /dev/null for the duration of a call; the call runs with a scratch directory
+    as its cwd (the reference writes its dumps there)."""
     def __enter__(self):
         import sys
+        self._cwd = os.getcwd()
+        os.chdir(scratch_dir())
         self._on = not os.environ.get("VDO_REF_VERBOSE")      # (debug: let the reference talk)
         if not self._on:
             return self
@@ -26,6 +45,7 @@ class Quiet:
         return self
 
     def __exit__(self, *a):
+        os.chdir(self._cwd)
         if not self._on:
             return
         os.dup2(self._saved, 1)
@@ -36,10 +56,11 @@ class RefSystem:
     COUNTS = ("n_keys", "n_static", "n_object", "n_objects", "n_cam_subset", "cam_lm_iterations", "f_id", "max_id", "n_samples", "full_batch_calls", "partial_batch_calls",
               "n_static_tracks", "n_dynamic_tracks")
 
-    def __init__(self, settings_path):
-        self.L = oracle_lib.load_ref_track()
+    def __init__(self, settings_path, full=False):
+        """full: libref_full.so (the reference's real Optimizer.cc + g2o behind Track()) instead of libref_track.so (the oracle's optimisers behind it)"""
+        self.L = oracle_lib.load_ref_full() if full else oracle_lib.load_ref_track()
         if self.L is None:
-            raise RuntimeError("oracle/_ref/libref_track.so is absent")
+            raise RuntimeError("oracle/_ref/libref_full.so is absent" if full else "oracle/_ref/libref_track.so is absent")
         with Quiet():
             self.h = self.L.vdo_ref_system_create(str(settings_path).encode())
 
