@@ -410,6 +410,8 @@ int ref_batch_optimization(const ref_map_flat* f, int partial_window, float* cam
   return 0;
 }
 
+void vdo_ref_set_gaussian_scale(double s) { cv::rng_gaussian_scale() = s; }
+
 // ---- the four per-frame statics ------------------------------------------------------------------------------------------------------------
 static void set_intrinsics(const float* K4) { Frame::fx = K4[0]; Frame::fy = K4[1]; Frame::cx = K4[2]; Frame::cy = K4[3]; Frame::invfx = 1.0f / Frame::fx; Frame::invfy = 1.0f / Frame::fy; }
 

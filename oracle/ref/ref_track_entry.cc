@@ -16,10 +16,15 @@
 #include <new>
 #include <sys/mman.h>
 namespace ref_arena {
-static char* base = nullptr; static size_t used = 0; static const size_t kSize = (size_t)64 << 30;
-inline void reset() {      // start over with ZERO pages, like a fresh process (the reference reads a few never-initialised members)
-  if (base && used) madvise(base, (used + 4095) & ~(size_t)4095, MADV_DONTNEED);
-  used = 0;
+static char* base = nullptr; static size_t used = 0, sys_begin = 0; static const size_t kSize = (size_t)256 << 30;
+// A System starts on never-touched (zero) pages, like a fresh process - the reference reads a few never-initialised members - and address space is never
+// reused: what g2o's type registrations and other static initialisers of this library allocated when it was loaded stays where it is (round 4 rewound the
+// arena to 0 for every first System and wiped them - harmless while the library held no g2o).  The pages of a System go back when the last one is destroyed.
+inline void mark() { sys_begin = used; }
+inline void release() {
+  const size_t a = (sys_begin + 4095) & ~(size_t)4095, b = used & ~(size_t)4095;
+  if (base && b > a) madvise(base + a, b - a, MADV_DONTNEED);
+  used = (used + 4095) & ~(size_t)4095;                  // (the next allocation starts on a page of its own: untouched)
 }
 inline void* take(size_t n) {
   if (!base) { base = (char*)mmap(nullptr, kSize, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_NORESERVE, -1, 0); if (base == (char*)MAP_FAILED) abort(); }
@@ -28,8 +33,7 @@ inline void* take(size_t n) {
   void* p = base + used; used += n; return p;
 }
 }
-// (addresses grow in allocation order and are never reused while a System lives: "by pointer" = "by creation order"; the pages are given back
-//  when the last System of the process is destroyed)
+// (addresses grow in allocation order and are never reused: "by pointer" = "by creation order")
 void* operator new(std::size_t n) { return ref_arena::take(n ? n : 1); }
 void* operator new[](std::size_t n) { return ref_arena::take(n ? n : 1); }
 void operator delete(void*) noexcept {}
@@ -294,7 +298,7 @@ extern "C" {
 // System::System(settings, RGBD) (src/System.cc:22-48)
 void* vdo_ref_system_create(const char* settings) {
   if (std::getenv("VDO_REF_BT")) install_bt_handler();
-  if (g_live_systems == 0) ref_arena::reset();
+  if (g_live_systems == 0) ref_arena::mark();
   ++g_live_systems;
 #ifndef REF_REAL_OPTIMIZER
   VDO_SLAM::g_full_batch_calls = VDO_SLAM::g_partial_batch_calls = 0;
@@ -306,7 +310,10 @@ void* vdo_ref_system_create(const char* settings) {
   run_on_clean_stack([&] { out = new System(settings, System::RGBD); });
   return out;
 }
-void vdo_ref_system_destroy(void* s) { (void)s; if (g_live_systems > 0) --g_live_systems; }      // (the reference never frees its Tracking / Map either)
+void vdo_ref_system_destroy(void* s) {      // (the reference never frees its Tracking / Map either: the pages of the arena go back instead)
+  (void)s;
+  if (g_live_systems > 0 && --g_live_systems == 0) ref_arena::release();
+}
 
 // One System::TrackRGBD call (include/System.h:45-51): im (h x w x channels u8), depth (in/out f32: raw -> metres), flow (f32 x 2), mask (in/out i32),
 // ground-truth camera pose (4x4 f32) and object rows [n_rows][row_len]; Tcw_out 16 floats.

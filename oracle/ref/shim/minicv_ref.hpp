@@ -585,6 +585,9 @@ struct KeyPointsFilter {
 };
 
 // cv::RNG (modules/core/include/opencv2/core/operations.hpp): multiply-with-carry, uniform(a, b) = next() % (b - a) + a
+// (tests silence the reference's TEST noise - UnprojectStereoStat(i, addnoise = 1) inside the non-joint optimisers, src/Frame.cc:484-519 - to compare the
+//  rest of those functions: vdo_ref_set_gaussian_scale, oracle/ref/ref_g2o_entry.cc)
+inline double& rng_gaussian_scale() { static double s = 1.0; return s; }
 class RNG {
  public:
   uint64_t state;
@@ -597,9 +600,9 @@ class RNG {
   double uniform(double a, double b) { return ((double)*this) * (b - a) + a; }
   operator float() { return next() * 2.3283064365386962890625e-10f; }
   operator double() { unsigned t = next(); return (((uint64_t)t << 32) | next()) * 5.4210108624275221700372640043497e-20; }
-  double gaussian(double sigma) {               // (never reached: every caller passes addnoise = false; a Box-Muller draw, not OpenCV's ziggurat)
+  double gaussian(double sigma) {               // (Track() never gets here: its callers pass addnoise = false; a Box-Muller draw, not OpenCV's ziggurat)
     const double u1 = std::max(1e-12, (double)uniform(0.0, 1.0)), u2 = uniform(0.0, 1.0);
-    return sigma * std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * CV_PI * u2);
+    return rng_gaussian_scale() * sigma * std::sqrt(-2.0 * std::log(u1)) * std::cos(2.0 * CV_PI * u2);
   }
 };
 

@@ -210,3 +210,202 @@ def test_batch_lm_equals_the_reference(ref, oracle, seed, kw):
     assert abs(so.final_lambda - sr.final_lambda) <= 1e-6 * sr.final_lambda
     np.testing.assert_allclose(po, pr, rtol=0, atol=1e-7 * max(1.0, np.abs(pr).max()))        # north star: 1e-4 relative on poses
     np.testing.assert_allclose(qo, qr, rtol=0, atol=1e-6 * max(1.0, np.abs(qr).max()))
+
+
+# ---- the statics of src/Optimizer.cc themselves -------------------------------------------------------------------------------------------------
+def _fp(a):
+    return a.ctypes.data_as(K.c_float_p)
+
+
+def _bind_statics(ref):
+    fp, ip = K.c_float_p, K.c_int32_p
+    ref.ref_pose_optimization_flow2cam.argtypes = [C.c_int, fp, fp, fp, fp, fp, fp, fp, ip, fp]
+    ref.ref_pose_optimization_flow2.argtypes = [C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, ip, ip, fp]
+    ref.ref_pose_optimization_new.argtypes = [C.c_int, fp, fp, fp, fp, fp, fp, fp, ip]
+    ref.ref_pose_optimization_objmot.argtypes = [C.c_int, fp, fp, fp, fp, fp, fp, fp, fp, fp, ip, ip]
+    ref.ref_batch_optimization.argtypes = [C.c_void_p, C.c_int, fp, fp, fp, fp]
+    ref.vdo_ref_set_gaussian_scale.argtypes = [C.c_double]
+
+
+def _flow2_case(seed, n, is_object, **kw):
+    """a joint problem as the reference's static sees it: float key points / flow / depth, the LAST pose as a CV_32F matrix (the static derives Twl itself,
+    src/Optimizer.cc:2414-2420), the initial estimate as a CV_32F matrix"""
+    from tests.pipeline_ref import inv_rigid_f32
+    prob = synth.make_flow2_problem(n, seed=seed, is_object=is_object, **kw)
+    Tlw = np.linalg.inv(prob.Twl).astype(np.float32)
+    prob.Twl = inv_rigid_f32(Tlw).astype(np.float64)           # Rwl = Rlw.t(), twl = -Rlw.t() * tlw through cv::Mat
+    prob.K = tuple(float(np.float32(v)) for v in prob.K)       # Frame::fx .. cy are floats
+    return prob, Tlw
+
+
+@pytest.mark.parametrize("is_object", [False, True])
+def test_joint_statics_equal_the_reference(ref, oracle, is_object):
+    """Optimizer::PoseOptimizationFlow2Cam / PoseOptimizationFlow2 - the reference's own functions on Frames filled from flat arrays - against the oracle's
+    restatement on the same numbers: pose / motion as the CV_32F matrix they return (np.array_equal), inlier sets, refined key points, outlier labels.
+    40 problems each: 6 .. 1500 correspondences, clean and heavily contaminated, near and far initial estimates (the F3 aliasing makes some of them run
+    100+ Levenberg iterations), plus the degenerate sizes the reference handles before it builds a graph."""
+    from tests.test_oracle_flow2 import run_oracle
+    _bind_statics(ref)
+    K4 = np.array(synth.KITTI_K, np.float32)
+    rng = np.random.default_rng(17)
+    exact = 0
+    for case in range(40):
+        n = int((6, 40, 300, 900, 1500)[case % 5])
+        kw = dict(outlier_frac=(0.0, 0.1, 0.35)[case % 3], flow_sigma=(0.0, 0.3, 1.0)[(case // 3) % 3], init_sigma_t=(0.05, 0.5)[(case // 9) % 2], init_sigma_r=(0.004, 0.03)[(case // 9) % 2])
+        prob, Tlw = _flow2_case(100 + case, n, is_object, **kw)
+        T, flow, inl, ninl, st = run_oracle(oracle, prob)
+        last_xy = prob.obs.astype(np.float32); fl = prob.flow.astype(np.float32); dep = prob.depth.astype(np.float32)
+        T0 = prob.T0.astype(np.float32)
+        cur = np.zeros((n, 2), np.float32); Tout = np.zeros((4, 4), np.float32)
+        if not is_object:
+            match = np.zeros(n, np.int32)
+            got = ref.ref_pose_optimization_flow2cam(n, _fp(K4), _fp(last_xy), _fp(fl), _fp(dep), _fp(Tlw), _fp(T0), _fp(Tout), match.ctypes.data_as(K.c_int32_p), _fp(cur))
+            got_inl = match >= 0
+        else:
+            flag = np.zeros(n, np.int32); lab = np.zeros(n, np.int32)
+            Tcur = np.eye(4, dtype=np.float32)                   # (only mInitModel of the current frame is read)
+            got = ref.ref_pose_optimization_flow2(n, _fp(K4), _fp(last_xy), _fp(fl), _fp(dep), _fp(Tlw), _fp(Tcur), _fp(T0), _fp(Tout), flag.ctypes.data_as(K.c_int32_p),
+                                                  lab.ctypes.data_as(K.c_int32_p), _fp(cur))
+            got_inl = flag.astype(bool)
+            assert np.array_equal(lab == -1, ~got_inl), case
+        assert got == ninl, (case, got, ninl)
+        assert np.array_equal(got_inl, inl.astype(bool)), case
+        assert np.array_equal(Tout, T.astype(np.float32)), (case, np.abs(Tout - T).max(), st.iterations)
+        exact += 1
+        exp = (last_xy.astype(np.float64) + flow).astype(np.float32)        # pt.x + flow_new(0): a float plus a double, rounded once (src/Optimizer.cc:2529-2530)
+        assert np.array_equal(cur[got_inl], exp[got_inl]), case
+    assert exact == 40
+    # fewer than three correspondences: nothing is optimised (src/Optimizer.cc:2449-2450, :2872-2873)
+    prob, Tlw = _flow2_case(5, 2, is_object)
+    last_xy = prob.obs.astype(np.float32); fl = prob.flow.astype(np.float32); dep = prob.depth.astype(np.float32); T0 = prob.T0.astype(np.float32)
+    cur = np.zeros((2, 2), np.float32); Tout = np.zeros((4, 4), np.float32); m2 = np.zeros(2, np.int32); l2 = np.zeros(2, np.int32)
+    if not is_object:
+        assert ref.ref_pose_optimization_flow2cam(2, _fp(K4), _fp(last_xy), _fp(fl), _fp(dep), _fp(Tlw), _fp(T0), _fp(Tout), m2.ctypes.data_as(K.c_int32_p), _fp(cur)) == 0
+        assert np.array_equal(Tout, T0)
+    else:
+        ref.ref_pose_optimization_flow2(2, _fp(K4), _fp(last_xy), _fp(fl), _fp(dep), _fp(Tlw), _fp(np.eye(4, dtype=np.float32)), _fp(T0), _fp(Tout), m2.ctypes.data_as(K.c_int32_p),
+                                        l2.ctypes.data_as(K.c_int32_p), _fp(cur))
+        assert np.array_equal(Tout, np.eye(4, dtype=np.float32))
+
+
+@pytest.mark.parametrize("window", [0, 8])
+def test_batch_statics_equal_the_reference(ref, oracle, window):
+    """Optimizer::FullBatchOptimization / PartialBatchOptimization - the reference's own graph builders (src/Optimizer.cc:1259-1766, :42-637), its optimiser
+    set-up and its write-back into the Map - on a Map filled from flat arrays, against the oracle's LM on the graph that the Python restatement of the
+    builder (tests/map_builder_ref.py - what the product's host classes are tested with on the GPU) makes of the same Map: refined camera poses, object
+    motions and points."""
+    from tests import map_builder_ref as SM
+    from tests.ref_track import Quiet
+    _bind_statics(ref)
+    m = SM.make_map(n_frames=8 if window else 12, n_static=400, n_objects=2, dyn_tracks_per_object=40, seed=5)
+    s, keep = SM.flatten_map(m)
+    F = m["n_frames"]
+    n_sta = sum(len(f["sta_uv"]) for f in m["feats"]); n_dyn = sum(len(f["dyn_uv"]) for f in m["feats"]); n_rm = sum(len(r) for r in m["rigid_motion"])
+    cam_out = np.zeros((F, 4, 4), np.float32); rm_out = np.zeros((n_rm, 4, 4), np.float32)
+    sta_out = np.zeros((n_sta, 3), np.float32); dyn_out = np.zeros((max(n_dyn, 1), 3), np.float32)
+    with Quiet():                                               # (the reference saves its .g2o dumps into the current directory)
+        assert ref.ref_batch_optimization(C.byref(s), window, _fp(cam_out), _fp(rm_out), _fp(sta_out), _fp(dyn_out)) == 0
+    g, info = SM.map_to_graph(m, partial_window=window or None)
+    gc, keep2 = K.graph_to_c(g)
+    opt = K.LMOptionsC(100 if window else 300, 1e-3 if window else 1e-4, 0, 0, 0.0, 0)
+    st_o = K.LMStatsC()
+    pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), _d(pose_o), _d(point_o), C.byref(st_o)) == 0
+    start = info["start"]
+    worst = 0.0
+    for i in range(start, F):
+        o = pose_o[info["cam_idx"][i - start]]
+        worst = max(worst, np.abs(cam_out[i][:3, :3].ravel() - o[:9]).max(), np.abs(cam_out[i][:3, 3] - o[9:]).max() / max(1.0, np.abs(o[9:]).max()))
+    assert worst <= 2e-6, worst                                  # (float32 storage: 6e-8 relative; north star: 1e-4)
+    off = np.cumsum([0] + [len(f["sta_uv"]) for f in m["feats"]])
+    checked = 0
+    for i in range(start, F):
+        for j, mk in enumerate(info["mkS"][i]):
+            if mk >= 0:
+                np.testing.assert_allclose(sta_out[off[i] + j], point_o[mk], rtol=2e-6, atol=2e-6)
+                checked += 1
+    assert checked > 100
+    if not window:                                               # object motions (full batch only): vmRigidMotion_RF[i][j], j >= 1
+        ro = np.cumsum([0] + [len(r) for r in m["rigid_motion"]])
+        nmot = 0
+        for i in range(F - 1):
+            for j in range(1, len(m["rigid_motion"][i])):
+                v = info["vid"][i][j]
+                if v < 0:
+                    continue
+                H = rm_out[ro[i] + j]
+                np.testing.assert_allclose(H[:3, :3].ravel(), pose_o[v][:9], rtol=0, atol=2e-6)
+                np.testing.assert_allclose(H[:3, 3], pose_o[v][9:], rtol=2e-6, atol=2e-6)
+                nmot += 1
+        assert nmot >= 10
+
+
+def test_non_joint_statics_equal_the_reference(ref, oracle):
+    """Optimizer::PoseOptimizationNew / PoseOptimizationObjMot (src/Optimizer.cc:2177-2331, :2544-2753; unreachable from Track(), which forces bJoint) - the
+    reference's own functions against the oracle's unary-edge LM on the problem marshalled the way those functions marshal it (UnprojectStereoStat / Object
+    through cv::Mat arithmetic, P = K * Tcw, Init = Tcw^-1 * mInitModel).  The reference back-projects with addnoise = 1 here - test noise from a cv::RNG
+    seeded with time(NULL): the shim's generator is silenced for the comparison (vdo_ref_set_gaussian_scale(0))."""
+    from tests.test_oracle_pose_only import run_oracle
+    from tests.pipeline_ref import inv_rigid_f32 as inv32, matmul4_f32
+    from vdo_slam_amd import pose_only as PO
+    _bind_statics(ref)
+    ref.vdo_ref_set_gaussian_scale(0.0)
+    try:
+        fx, fy, cx, cy = synth.KITTI_K
+        f32 = np.float32
+        K4 = np.array(synth.KITTI_K, f32)
+
+        def unproject(xy, d, Tcw):                           # Frame::UnprojectStereo*: Rwl * x3Dc + twl (float fast path of cv::gemm), twl = -Rlw^T tlw (generic path)
+            x3 = np.stack([(xy[:, 0] - f32(cx)) * d * (f32(1) / f32(fx)), (xy[:, 1] - f32(cy)) * d * (f32(1) / f32(fy)), d], 1).astype(f32)
+            twl = inv32(Tcw)[:3, 3]
+            Rwl = Tcw[:3, :3].T.astype(f32)
+            out = np.zeros((xy.shape[0], 3), f32)
+            for i in range(3):
+                t = f32(Rwl[i, 0]) * x3[:, 0]
+                t = (t + f32(Rwl[i, 1]) * x3[:, 1]).astype(f32)
+                t = (t + f32(Rwl[i, 2]) * x3[:, 2]).astype(f32)
+                out[:, i] = (t + twl[i]).astype(f32)
+            return out
+
+        for seed in range(8, 14):
+            rng = np.random.default_rng(seed)
+            n = int((700, 60, 250)[seed % 3])
+            Tl = synth._mat4(synth.rotvec_to_R(rng.normal(0, 0.02, 3)), rng.normal(0, 1.0, 3)).astype(f32)
+            last_xy = np.c_[rng.uniform(50, 1190, n), rng.uniform(30, 340, n)].astype(f32)
+            depth = rng.uniform(5, 35, n).astype(f32)
+            Xw = unproject(last_xy, depth, Tl)
+            dT = synth._mat4(synth.rotvec_to_R(np.array([0.0, 0.006, 0.0])), np.array([0.02, -0.01, -0.8]))
+            Tc_true = dT @ Tl.astype(np.float64)
+            Xc = Xw.astype(np.float64) @ Tc_true[:3, :3].T + Tc_true[:3, 3]
+            cur_xy = np.c_[fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy] + rng.normal(0, 0.05, (n, 2))
+            cur_xy[rng.random(n) < 0.1] += rng.normal(0, 4.0, 2)
+            cur_xy = cur_xy.astype(f32)
+            Tinit = (synth._mat4(synth.rotvec_to_R(rng.normal(0, 0.003, 3)), rng.normal(0, 0.03, 3)) @ Tc_true).astype(f32)
+            Tout = np.zeros((4, 4), f32); match = np.zeros(n, np.int32)
+            got = ref.ref_pose_optimization_new(n, _fp(K4), _fp(last_xy), _fp(depth), _fp(cur_xy), _fp(Tl), _fp(Tinit), _fp(Tout), match.ctypes.data_as(K.c_int32_p))
+            prob = PO.PoseProblem(kind=0, obs=cur_xy.astype(np.float64), Xw=Xw.astype(np.float64), K=tuple(float(f32(v)) for v in synth.KITTI_K), P=np.zeros((3, 4)),
+                                  T0=Tinit.astype(np.float64), huber_delta=float(np.sqrt(f32(0.01))), max_iterations=100)
+            T, inl, ninl, st = run_oracle(oracle, prob)
+            assert got == ninl and 0.5 * n < ninl < n, (seed, got, ninl)
+            assert np.array_equal(match >= 0, inl.astype(bool)), seed
+            assert np.array_equal(Tout, T.astype(f32)), (seed, np.abs(Tout - T).max())
+            # object: points moved by a world-frame motion H, seen from the current camera
+            Hm = synth._mat4(synth.rotvec_to_R(np.array([0.0, 0.02, 0.0])), np.array([0.1, 0.0, 0.6]))
+            Tcur = Tc_true.astype(f32)
+            Xn = Xw.astype(np.float64) @ Hm[:3, :3].T + Hm[:3, 3]
+            Xc = Xn @ Tcur[:3, :3].astype(np.float64).T + Tcur[:3, 3].astype(np.float64)
+            obj_xy = (np.c_[fx * Xc[:, 0] / Xc[:, 2] + cx, fy * Xc[:, 1] / Xc[:, 2] + cy] + rng.normal(0, 0.03, (n, 2))).astype(f32)
+            init_model = (Tcur.astype(np.float64) @ synth._mat4(np.eye(3), np.array([0.05, 0.0, 0.5]))).astype(f32)      # mInitModel = Tcw * H0
+            Hout = np.zeros((4, 4), f32); flag = np.zeros(n, np.int32); lab = np.zeros(n, np.int32)
+            got = ref.ref_pose_optimization_objmot(n, _fp(K4), _fp(last_xy), _fp(depth), _fp(obj_xy), None, _fp(Tl), _fp(Tcur), _fp(init_model), _fp(Hout),
+                                                   flag.ctypes.data_as(K.c_int32_p), lab.ctypes.data_as(K.c_int32_p))
+            KK = np.array([[f32(fx), 0, f32(cx), 0], [0, f32(fy), f32(cy), 0], [0, 0, 1, 0]], np.float64)
+            Init = matmul4_f32(inv32(Tcur), init_model)                                                        # cv::Mat product (cv::gemm's float fast path)
+            probo = PO.PoseProblem(kind=1, obs=obj_xy.astype(np.float64), Xw=Xw.astype(np.float64), K=tuple(float(f32(v)) for v in synth.KITTI_K),
+                                   P=KK @ Tcur.astype(np.float64), T0=Init.astype(np.float64), huber_delta=0.0, max_iterations=200)
+            T, inl, ninl, st = run_oracle(oracle, probo)
+            assert got == ninl and ninl > 0.8 * n, (seed, got, ninl)
+            assert np.array_equal(flag.astype(bool), inl.astype(bool)) and np.array_equal(lab == -1, ~inl.astype(bool)), seed
+            assert np.array_equal(Hout, T.astype(f32)), (seed, np.abs(Hout - T).max())
+    finally:
+        ref.vdo_ref_set_gaussian_scale(1.0)

@@ -37,7 +37,7 @@ def compare_frame(k, refsys, T_ref, ora, exp, sampled=False):
     assert c["n_static"] == exp["n_static_tracked"] and c["n_object"] == exp["n_object_tracked"] and c["n_objects"] == exp["n_objects"], (k, c, exp)
     if k > 0:
         chosen = exp["n_ransac_cam"] if exp["n_ransac_cam"] > exp["n_motion_model_cam"] else exp["n_motion_model_cam"]      # TemperalMatch_subset (Tracking.cc:1690-1712)
-        assert c["n_cam_subset"] == chosen and c["cam_lm_iterations"] == exp["cam_lm_iterations"], (k, c, exp)
+        assert c["n_cam_subset"] == chosen and c["cam_lm_iterations"] in (-1, exp["cam_lm_iterations"]), (k, c, exp)     # (-1: libref_full.so - g2o's count is not observable)
         assert c["n_static_tracks"] == exp["n_static_tracks"] and c["n_dynamic_tracks"] == exp["n_dynamic_tracks"], (k, c, exp)
         # (mvTmpObj* and max_id come to life in the first tracked frame: src/Tracking.cc:870-872, :1521)
         assert c["n_samples"] == exp["n_object_samples"] and c["max_id"] == ora.max_id, (k, c, exp)
@@ -80,15 +80,14 @@ SEQUENCES = {
 }
 
 
-@pytest.mark.parametrize("name", sorted(SEQUENCES))
-def test_oracle_track_equals_the_reference_source(oracle, reflib, name, tmp_path):
+def run_sequence_against_the_reference(oracle, name, tmp_path, full):
     from tests.ref_track import RefSystem
     spec = SEQUENCES[name]
     n = spec["n"]
     cfg = write_settings(tmp_path / "kitti.yaml", W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, window=20, overlap=4)
     Ts = SQ.camera_poses(n)
     objs = spec["objs"]()
-    rs = RefSystem(cfg)
+    rs = RefSystem(cfg, full=full)
     ora = OraclePipeline(oracle, build_lm=True)                  # the oracle's own RANSAC + EPnP on both sides (the shim forwards cv::solvePnPRansac to it)
     recovered = 0
     for k in range(n):
@@ -105,7 +104,16 @@ def test_oracle_track_equals_the_reference_source(oracle, reflib, name, tmp_path
     rs.close()
 
 
+@pytest.mark.parametrize("name", sorted(SEQUENCES))
+def test_oracle_track_equals_the_reference_source(oracle, reflib, name, tmp_path):
+    run_sequence_against_the_reference(oracle, name, tmp_path, full=False)
+
+
 def test_sampled_features_omd_settings(oracle, reflib, tmp_path):
+    run_sampled_omd(oracle, tmp_path, full=False)
+
+
+def run_sampled_omd(oracle, tmp_path, full):
     """UseSampleFeature = 1 (example/omd.yaml): Frame::SampleKeyPoints instead of ORB, 640 x 480, SFMgThres 0.02.  The reference seeds cv::RNG with
     time(NULL); the _ref build lets the test set that clock so that frame f draws with the seed the oracle uses (sample_seed + f)."""
     from tests.ref_track import RefSystem
@@ -115,7 +123,7 @@ def test_sampled_features_omd_settings(oracle, reflib, tmp_path):
     Ts = SQ.camera_poses(n, step=0.25)
     objs = [dict(c=np.array([-1.2, 0.6, 6.0]), hw=0.7, hh=0.5, v=np.array([0.0, 0.0, 0.33])),
             dict(c=np.array([1.5, 0.6, 8.0]), hw=0.8, hh=0.55, v=np.array([0.01, 0.0, 0.2]))]
-    rs = RefSystem(cfg)
+    rs = RefSystem(cfg, full=full)
     ora = OraclePipeline(oracle, build_lm=True, K4=OMD_K, use_sample=True, sample_seed=11, sf_mg=0.02)
     for k in range(n):
         fr = SQ.render_frame(k, Ts, objs, w=OMD_W, h=OMD_H, K4=OMD_K, flow_sigma=0.05)

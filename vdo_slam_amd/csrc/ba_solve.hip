@@ -178,7 +178,7 @@ __device__ __forceinline__ FInc make_f(const BADev& d, const Tile& T, int li, in
   int lp = key & 0xffff;                                   // kind 0: the observed point; kind 2: p2
   if (kind == 1) lp = d.et_key[T.et_begin + (li - (T.eb_end - T.eb_begin))] >> 16;     // (H, p1): c = H^-1 p2 as well
   const double* W = slotW + 12 * (key >> 16);
-  const D3 c = rot(W, D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]}) + D3{W[9], W[10], W[11]};
+  const D3 c = cam_point(W, D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]});
   return FInc{we, c.x, c.y, c.z};
 }
 // explicit 6x3 block (row-major 18) — used by the preconditioner and the debug expansion
@@ -891,7 +891,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   };
   auto make_c = [&](const double (&Wb)[12], int q) {
     const int lp = q < ecnt ? (keyb[q] & 0xffff) : 0;
-    return rot(Wb, D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]}) + D3{Wb[9], Wb[10], Wb[11]};
+    return cam_point(Wb, D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]});
   };
   // one incidence of a ternary edge (li >= nb): kind 1 = (H, p1), kind 2 = (H, p2)
   auto tern_load = [&](int li, int& key, int& kind, FInc& f) {

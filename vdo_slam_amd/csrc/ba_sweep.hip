@@ -43,11 +43,17 @@ __device__ unsigned long long g_sweep_prof[16];
 #define SW_TICK(slot) do { } while (0)
 #endif
 
-// LDS carve-up (doubles): pts[3*TP] | accpt[4][TP] | slotW[12*S] | accpose[ps_stride*S] | red[40] | sdst[S] (int32: where the slots' rows go)
+// LDS carve-up (doubles): pts[3][VDO_SWEEP_PLANE] (planes x | y | z) | accpt[4][TP] | slotW[12*S] | accpose[ps_stride*S] | red[40] | sdst[S] (int32: where the slots' rows go)
 // (ps_stride = 16: a slot carries binary OR ternary sums, both kinds share its 16 accumulators; 14 KB + 224 B per pose slot of the
 // largest tile: 4 workgroups per CU at 81 slots)
+// (point planes VDO_SWEEP_PLANE doubles apart: more than the 255 x 8 bytes a ds_read2_b64 spans and not a multiple of 64, so that the three coordinate reads
+//  of an edge stay three ds_read_b64 - 2 LDS cycles each, banks mod 64 - instead of being paired into a ds_read2[st64]_b64: 8 cycles, banks mod 32)
+#define VDO_SWEEP_PLANE (VDO_TILE_PTS + 2)
+// (the 16 accumulators of a slot sit ps_stride + 2 doubles apart in LDS: the tails of the segmented scan - a few lanes per 16-lane group, each adding its 16
+//  totals to ITS slot - would all meet on one bank per component with rows of 16 doubles = 128 bytes = the 32 banks of a 64-bit LDS atomic)
+#define VDO_SWEEP_APAD 2
 __host__ __device__ inline size_t sweep_lds_doubles(int max_slots, bool build, int ps_stride) {
-  return 3 * VDO_TILE_PTS + (build ? 4 * VDO_TILE_PTS : 0) + 12 * (size_t)max_slots + (build ? (size_t)ps_stride * (size_t)max_slots + ((size_t)max_slots + 1) / 2 : 0) + 40;
+  return 3 * VDO_SWEEP_PLANE + (build ? 4 * VDO_TILE_PTS : 0) + 12 * (size_t)max_slots + (build ? (size_t)(ps_stride + VDO_SWEEP_APAD) * (size_t)max_slots + ((size_t)max_slots + 1) / 2 : 0) + 40;
 }
 
 // Per-thread running sums of the TERNARY edges (the EdgeSE3PointXYZ edges of a thread share a slot by construction: acc_terms): a thread owns
@@ -163,10 +169,10 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
   const int ti = blockIdx.x;                               // (descriptors are stored in launch order: tiles with dynamic tracks first - ternary edges, ~1.5x the work - not in the tail)
   const int tid = threadIdx.x;
   double* pts = smem;
-  double* accpt = pts + 3 * VDO_TILE_PTS;                 // [4][TP] SoA: sum of we | b.x | b.y | b.z  (lanes hit 16 bank pairs by point id)
+  double* accpt = pts + 3 * VDO_SWEEP_PLANE;                 // [4][TP] SoA: sum of we | b.x | b.y | b.z  (lanes hit 16 bank pairs by point id)
   double* slotW = accpt + (BUILD ? 4 * VDO_TILE_PTS : 0);
   double* accpose = slotW + 12 * d.max_slots;
-  const int arow = d.ps_stride, tofs = d.ps_stride == 32 ? 16 : 0;      // row of a slot's accumulators; where its ternary sums start
+  const int arow = d.ps_stride + VDO_SWEEP_APAD, tofs = d.ps_stride == 32 ? 16 : 0;      // row of a slot's accumulators in LDS; where its ternary sums start
   double* red = accpose + (BUILD ? arow * d.max_slots : 0);
   int* sdst = reinterpret_cast<int*>(red + 40);
   const double* __restrict__ pose = d.pose[which];
@@ -194,8 +200,14 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
       stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
       if (BUILD) sdst[sidx] = d.slot_dst[T.slot_begin + sidx];
     }
+    // points -> LDS as three planes x | y | z of VDO_TILE_PTS: a coordinate of the 64 points of an edge row is ONE ds_read_b64 (2 LDS cycles, banks by
+    // point id mod 32 - what the tile builder's placement keeps apart, capi_ba.hip close_tile) instead of a ds_read2_b64 + ds_read_b64 over 24-byte records (10)
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = h.pv[k]; }
+    for (int k = 0; k < 3; ++k) {
+      const int i = tid + k * VDO_TILE_THREADS;             // flat index into the tile's [npts][3] block (coalesced request), < 768
+      const int q = (i * 0xAAAB) >> 17;                     // i / 3
+      if (i < 3 * npts) pts[(i - 3 * q) * VDO_SWEEP_PLANE + q] = h.pv[k];
+    }
     if (BUILD) {
       for (int i = tid; i < 4 * VDO_TILE_PTS; i += VDO_TILE_THREADS) accpt[i] = 0.0;
       for (int i = tid; i < arow * nslot; i += VDO_TILE_THREADS) accpose[i] = 0.0;
@@ -239,12 +251,12 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
           const int lp = ekey[j] & 0xffff;
           const double w = COMPACT ? d.eb_w_uni : ew[j];
           const D3 z = COMPACT ? D3{(double)ezf[j][0], (double)ezf[j][1], (double)ezf[j][2]} : D3{ezd[j][0], ezd[j][1], ezd[j][2]};
-          const D3 p{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
-          const D3 zc = rot(Wp, p) + D3{Wp[9], Wp[10], Wp[11]};
+          const D3 p{pts[lp], pts[VDO_SWEEP_PLANE + lp], pts[2 * VDO_SWEEP_PLANE + lp]};
+          const D3 zc = cam_point(Wp, p);
           const D3 er = zc - z;
-          const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
+          const double c2 = chi2_w3(w, er);
           double rho0, rho1;
-          huber(c2, d.huber_eb, d.dsqr_eb, rho0, rho1);
+          huber_dev(c2, d.huber_eb, d.dsqr_eb, rho0, rho1);
           chi += c2; rchi += rho0;
           if (BUILD) {
             const double we = w * rho1;
@@ -282,13 +294,13 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
           const double w = d.et_w ? d.et_w[e] : d.et_w_uni;
           const D3 z = d.et_z ? D3{d.et_z[e], d.et_z[Et + e], d.et_z[2 * Et + e]} : D3{0.0, 0.0, 0.0};
           const double* Hi = slotW + 12 * slot;   // Hi.r = R_H^T, Hi.t ; J2 = -Hi.r
-          const D3 p1{pts[3 * l1], pts[3 * l1 + 1], pts[3 * l1 + 2]};
-          const D3 p2{pts[3 * l2], pts[3 * l2 + 1], pts[3 * l2 + 2]};
-          const D3 v = rot(Hi, p2) + D3{Hi[9], Hi[10], Hi[11]};
+          const D3 p1{pts[l1], pts[VDO_SWEEP_PLANE + l1], pts[2 * VDO_SWEEP_PLANE + l1]};
+          const D3 p2{pts[l2], pts[VDO_SWEEP_PLANE + l2], pts[2 * VDO_SWEEP_PLANE + l2]};
+          const D3 v = cam_point(Hi, p2);
           const D3 er = p1 - v - z;
-          const double c2 = er.x * (w * er.x) + er.y * (w * er.y) + er.z * (w * er.z);
+          const double c2 = chi2_w3(w, er);
           double rho0, rho1;
-          huber(c2, d.huber_et, d.dsqr_et, rho0, rho1);
+          huber_dev(c2, d.huber_et, d.dsqr_et, rho0, rho1);
           chi += c2; rchi += rho0;
           if (BUILD) {
             const double we = w * rho1;
@@ -336,12 +348,12 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
       if (d.ps_stride == 16) {
         for (int i = tid; i < 16 * nslot; i += VDO_TILE_THREADS) {
           const int sidx = i >> 4, k = i & 15;
-          d.part_sums[16 * (int64_t)sdst[sidx] + k] = accpose[16 * sidx + k];
+          d.part_sums[16 * (int64_t)sdst[sidx] + k] = accpose[arow * sidx + k];
         }
       } else {
         for (int i = tid; i < 32 * nslot; i += VDO_TILE_THREADS) {
           const int sidx = i >> 5, k = i & 31;
-          d.part_sums[32 * (int64_t)sdst[sidx] + k] = accpose[32 * sidx + k];
+          d.part_sums[32 * (int64_t)sdst[sidx] + k] = accpose[arow * sidx + k];
         }
       }
     }

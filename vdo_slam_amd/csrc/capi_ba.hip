@@ -131,6 +131,9 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     }
   };
   int inc_total = 0;
+  // VDO_BA_PLACE=0: the edges of a slot's run in pose-sorted order (round 4) instead of the bank-aware placement below (A/B, tools/)
+  const int place_mode = std::getenv("VDO_BA_PLACE") ? std::atoi(std::getenv("VDO_BA_PLACE")) : 1;
+  long long place_ways = 0, place_groups = 0;
   auto close_tile = [&]() {
     if (cur_npts == 0) return;
     // slots: sorted distinct poses
@@ -164,22 +167,84 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     eb_key.resize((size_t)cur.eb_begin + nb, -1);
     inc_key.resize((size_t)inc_total + nb + 2 * (size_t)nt, -1);
     {
+      // Which edge of a slot's run goes to which (thread, row) is free - a thread needs <= pb edges of ONE slot in rows 0 .. count - 1, nothing else -
+      // and it decides the LDS bank conflicts of every tile kernel: row i of a wave is one LDS instruction per operand, 64 lanes at the local point
+      // ids of their edges (point reads, the four landmark ds_add_f64 of the sweep, the factor reads of the solver's kernels).  The LDS serves
+      // a wave in lane groups - 16 contiguous lanes for 64-bit stores / atomics (32 banks: point id mod 16), 32 for 64-bit reads (64 banks: id mod 32),
+      // MI355X_MICROARCH.md LDS - and every extra distinct address on a bank costs a cycle: with the edges in pose-sorted order the ids of a group
+      // are random (2.5 .. 3 addresses on the busiest bank; SQ_LDS_BANK_CONFLICT ~ SQ_ACTIVE_INST_LDS in profiles/r04_sweep_sq_counters.txt, the LDS
+      // pipe busy ~85 % of the sweep).  So: rows are filled one after the other (thread counts stay balanced: ceil or floor of run / threads), and
+      // every (thread, row) takes, of its slot's remaining edges, one whose point id collides with the fewest lanes already placed in its 16-lane
+      // group and 32-lane half of that row.
+      static thread_local std::vector<int> bucket[32];
+      int occ16[VDO_TILE_THREADS / 64][VDO_TILE_EPT][4][16], occ32[VDO_TILE_THREADS / 64][VDO_TILE_EPT][2][32];
+      std::memset(occ16, 0, sizeof occ16); std::memset(occ32, 0, sizeof occ32);
       int t = 0;
       for (int j = 0; j < nb_real;) {
         int k = j;
         while (k < nb_real && g->eb_pose[tile_eb[k]] == g->eb_pose[tile_eb[j]]) ++k;
-        for (int q = j; q < k; q += pb, ++t) {
-          if (t >= VDO_TILE_THREADS) { thr_overflow = true; break; }
-          for (int i = 0; i < pb && q + i < k; ++i) {
-            const int e = tile_eb[q + i];
-            const int pos = i * VDO_TILE_THREADS + t;
-            const int32_t key = (slot_of(g->eb_pose[e]) << 16) | (pt_new_of_old[g->eb_point[e]] - cur.pt_begin);
+        const int len = k - j, nthr = (len + pb - 1) / pb;
+        if (t + nthr > VDO_TILE_THREADS) { thr_overflow = true; break; }
+        for (int r = 0; r < 32; ++r) bucket[r].clear();
+        for (int q = k - 1; q >= j; --q) bucket[(pt_new_of_old[g->eb_point[tile_eb[q]]] - cur.pt_begin) & 31].push_back(tile_eb[q]);     // (popped from the back: pose-sorted order among equals)
+        const int32_t slot = slot_of(g->eb_pose[tile_eb[j]]);
+        int left = len;
+        for (int i = 0; i < pb && left > 0; ++i)
+          for (int tau = 0; tau < nthr && left > 0; ++tau, --left) {
+            const int T = t + tau, w = T >> 6, g16 = (T >> 4) & 3, h = (T >> 5) & 1;
+            int best = -1, best_cost = 1 << 30;
+            for (int r = 0; r < 32; ++r) {
+              if (bucket[r].empty()) continue;
+              const int cost = place_mode ? 2 * occ16[w][i][g16][r & 15] + occ32[w][i][h][r] : 0;
+              if (cost < best_cost) { best_cost = cost; best = r; }
+            }
+            const int e = bucket[best].back(); bucket[best].pop_back();
+            ++occ16[w][i][g16][best & 15]; ++occ32[w][i][h][best];
+            const int pos = i * VDO_TILE_THREADS + T;
+            const int32_t key = (slot << 16) | (pt_new_of_old[g->eb_point[e]] - cur.pt_begin);
             eb_old_of_new[(size_t)cur.eb_begin + pos] = e;
             eb_key[(size_t)cur.eb_begin + pos] = key;
             inc_key[(size_t)inc_total + pos] = key;
           }
-        }
+        t += nthr;
         j = k;
+      }
+      // refinement: the rows of ONE thread can be exchanged freely (same slot, same count) - a few passes of pairwise exchanges wherever that lowers
+      // the collisions of the two group-rows involved
+      if (place_mode && !thr_overflow) {
+        const int nthr_used = t;
+        auto lp_at = [&](int T, int i) { const int32_t key = eb_key[(size_t)cur.eb_begin + i * VDO_TILE_THREADS + T]; return key < 0 ? -1 : (key & 0xffff); };
+        for (int pass = 0; pass < 3; ++pass) {
+          int moved = 0;
+          for (int T = 0; T < nthr_used; ++T) {
+            const int w = T >> 6, g16 = (T >> 4) & 3, h = (T >> 5) & 1;
+            int cnt = 0;
+            while (cnt < pb && lp_at(T, cnt) >= 0) ++cnt;
+            for (int a = 0; a < cnt; ++a) for (int b = a + 1; b < cnt; ++b) {
+              const int la = lp_at(T, a), lb = lp_at(T, b);
+              if ((la & 31) == (lb & 31)) continue;
+              // cost of this thread's two entries where they are, and exchanged (occupancies without this thread's own entries)
+              auto c16 = [&](int i, int l) { return occ16[w][i][g16][l & 15]; };
+              auto c32 = [&](int i, int l) { return occ32[w][i][h][l & 31]; };
+              const int now = 2 * (c16(a, la) - 1) + (c32(a, la) - 1) + 2 * (c16(b, lb) - 1) + (c32(b, lb) - 1);
+              const int then = 2 * (c16(a, lb) - ((la & 15) == (lb & 15) ? 1 : 0)) + c32(a, lb) + 2 * (c16(b, la) - ((la & 15) == (lb & 15) ? 1 : 0)) + c32(b, la);
+              if (then < now) {
+                --occ16[w][a][g16][la & 15]; --occ32[w][a][h][la & 31]; --occ16[w][b][g16][lb & 15]; --occ32[w][b][h][lb & 31];
+                ++occ16[w][a][g16][lb & 15]; ++occ32[w][a][h][lb & 31]; ++occ16[w][b][g16][la & 15]; ++occ32[w][b][h][la & 31];
+                const size_t pa = (size_t)cur.eb_begin + a * VDO_TILE_THREADS + T, pbb = (size_t)cur.eb_begin + b * VDO_TILE_THREADS + T;
+                std::swap(eb_old_of_new[pa], eb_old_of_new[pbb]); std::swap(eb_key[pa], eb_key[pbb]);
+                std::swap(inc_key[(size_t)inc_total + a * VDO_TILE_THREADS + T], inc_key[(size_t)inc_total + b * VDO_TILE_THREADS + T]);
+                ++moved;
+              }
+            }
+          }
+          if (!moved) break;
+        }
+      }
+      for (int w = 0; w < VDO_TILE_THREADS / 64; ++w) for (int i = 0; i < pb; ++i) for (int g4 = 0; g4 < 4; ++g4) {      // (build statistics: the busiest bank of every 16-lane group-row)
+        int mx = 0, any = 0;
+        for (int r = 0; r < 16; ++r) { mx = std::max(mx, occ16[w][i][g4][r]); any += occ16[w][i][g4][r]; }
+        if (any) { place_ways += mx; ++place_groups; }
       }
     }
     for (int j = 0; j < nt; ++j) {
@@ -301,6 +366,9 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   }
   close_tile();
   if (thr_overflow) { delete ba; return set_error(VDO_ERR_UNSUPPORTED, "a tile has more pose-slot pieces than threads"); }
+  if (std::getenv("VDO_BA_TILE_STATS") && place_groups)
+    std::fprintf(stderr, "vdo_ba_create: %zu tiles, busiest LDS bank of a 16-lane group-row of EdgeSE3PointXYZ edges: %.3f addresses on average (placement %d)\n",
+                 tiles.size(), (double)place_ways / (double)place_groups, place_mode);
   for (auto& pe : pt_prev_edge_new) if (pe >= 0) pe = et_new_of_old[pe];
   const int n_tiles = (int)tiles.size(), NPS = (int)tile_pose.size(), n_chains = (int)chain_off.size() - 1;
 

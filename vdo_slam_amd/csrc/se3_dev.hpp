@@ -141,6 +141,49 @@ VDO_HD void huber(double e, double delta, double dsqr, double& rho0, double& rho
   else { double s = sqrt(e); rho0 = 2 * s * delta - dsqr; rho1 = delta / s; }
 }
 
+// A landmark in the frame of a pose slot: W = (R^T | -R^T t) staged row-major in LDS (12 doubles).  ONE definition for the sweep and for every consumer
+// that rebuilds the factored pose-landmark block from (we, c) (ba_solve.hip make_f): the block is bit-identical by construction.
+// Fused: three multiply-add chains seeded with the translation - 9 instructions instead of 18.  c moves by ~1e-16 of its size against the unfused
+// form (which is g2o's: a product, then a sum), and the residual c - z amplifies that by |c| / |e|: blocks within ~1e-12..1e-11 of the oracle's
+// (the test bar for blocks is 1e-10; the north star's bar is 1e-4 on poses, guarded by the LM-trajectory tests).
+VDO_HD D3 cam_point(const double* W, D3 p) {
+#ifdef VDO_UNFUSED_CAMPOINT
+  return rot(W, p) + D3{W[9], W[10], W[11]};
+#else
+  return {__builtin_fma(W[0], p.x, __builtin_fma(W[1], p.y, __builtin_fma(W[2], p.z, W[9]))), __builtin_fma(W[3], p.x, __builtin_fma(W[4], p.y, __builtin_fma(W[5], p.z, W[10]))),
+          __builtin_fma(W[6], p.x, __builtin_fma(W[7], p.y, __builtin_fma(W[8], p.z, W[11])))};
+#endif
+}
+// chi2 = e^T (w I) e of a 3-vector
+VDO_HD double chi2_w3(double w, D3 e) {
+#ifdef VDO_UNFUSED_CAMPOINT
+  return e.x * (w * e.x) + e.y * (w * e.y) + e.z * (w * e.z);
+#else
+  return w * __builtin_fma(e.z, e.z, __builtin_fma(e.y, e.y, e.x * e.x));
+#endif
+}
+
+// RobustKernelHuber::robustify for the tile kernels: the same rho0 = 2 sqrt(e) delta - dsqr (the square root by the Goldschmidt / Newton sequence the
+// compiler itself emits for sqrt(), minus its range scaling: e > dsqr >= 1e-200 here, checked on the host), rho1 = delta / sqrt(e) from the SAME iteration's
+// reciprocal-root estimate h ~ 0.5 / sqrt(e) plus one correction step (4 instructions, within 1 ulp) instead of a full IEEE division (14): the kernel is
+// VALU-issue-bound and with the reference's delta = 1e-4 (src/Optimizer.cc:1352) practically every edge is in this branch.  (Without the range
+// scaling the last bits degrade for e < 1e-230 - a delta below 1e-115.)
+__device__ __forceinline__ void huber_dev(double e, double delta, double dsqr, double& rho0, double& rho1) {
+#if defined(VDO_SLOW_HUBER) || !defined(__HIP_DEVICE_COMPILE__)
+  huber(e, delta, dsqr, rho0, rho1);
+#else
+  if (delta <= 0 || e <= dsqr) { rho0 = e; rho1 = 1.0; return; }
+  const double y = __builtin_amdgcn_rsq(e);
+  double g = e * y, h = 0.5 * y;
+  const double r = __builtin_fma(-h, g, 0.5);
+  g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+  g = __builtin_fma(__builtin_fma(-g, g, e), h, g);       // g = sqrt(e) to the last bit or one off it (the compiler's own sequence takes this correction twice)
+  rho0 = __builtin_fma(g, delta + delta, -dsqr);         // 2 sqrt(e) delta - dsqr
+  const double q = (delta + delta) * h;                   // ~ delta / sqrt(e)
+  rho1 = __builtin_fma(__builtin_fma(-q, g, delta), h + h, q);
+#endif
+}
+
 // 3x3 symmetric positive definite inverse via cofactors (Eigen fixed-size inverse); returns det
 VDO_HD double sym3_inv(const double* a, double* o) {
   double c00 = a[4] * a[8] - a[5] * a[7];
