@@ -44,6 +44,12 @@ N_DISTINCT_FRAMES = 4   # make_frame_inputs(): independent random frames (tools/
 # SURVEY.md 8d "synthetic inputs": flow noise N(0, 0.3^2) px, 2 % invalid depth, 1 % exactly-zero flow, 5 moving objects, one
 # instance mask missing for two frames (exercises UpdateMask)
 FLOW_SIGMA, INVALID_DEPTH, ZERO_FLOW, N_OBJECTS, BOX_DEPTH = 0.3, 0.02, 0.01, 5, 0.9
+# batch graphs of the N > 1 legs (and their one-GPU numbers at N = 1): BASELINE configs[3] - Oxford-Multimotion-shaped (example/omd.yaml: 3000 features per
+# frame, four swinging boxes filling a third of the view): 300 frames, 150 k static + 4 x 40 k dynamic tracks (1.9 M EdgeSE3PointXYZ, 0.8 M ternary edges,
+# 1 496 pose / motion vertices) - and configs[4]: 1 M landmarks / 5 k pose vertices / 20 objects
+OMD_SHAPE = (300, 150000, 4, 40000)
+LARGE_SHAPE = (239, 950000, 20, 500)
+SHARD_LEGS = (("control", (60, 30000, 5, 800), 5), ("omd", OMD_SHAPE, 5), ("large", LARGE_SHAPE, 3))
 MAX_SEQ_FRAMES = 160    # length of the consistent synthetic sequence (the objects stay in view that long)
 
 
@@ -593,34 +599,57 @@ def main():
         out["config"]["batch_graph"] = f"{g.n_cam} frames, {g.n_pose} pose/motion vertices, {g.n_point} points, {g.n_eb} EdgeSE3PointXYZ, {g.n_et} ternary"
         ba.close()
         if use_dist and not os.environ.get("VDO_BENCH_NO_SHARDED"):
-            # ---- the same batch graph SHARDED over the ranks (landmark tracks; all-reduce over RCCL/xGMI)
-            try:
-                from vdo_slam_amd.dist import ShardedBatchBA
-                gs = synth.make_ba_graph(60, 30000, 5, 800, seed=1)
-                sh = ShardedBatchBA(ctx_ba, gs)
-                sh.optimize(max_iterations=1, gain_threshold=-1.0)
-                sh.ba.set_estimates(sh.shard.pose, sh.shard.point)
-                calls0, dbl0 = sh.hook.calls, sh.hook.doubles
-                barrier()
-                t0 = time.perf_counter()
-                st = sh.optimize(max_iterations=5, gain_threshold=-1.0)
-                barrier()
-                out["ms_per_lm_iter_sharded"] = (time.perf_counter() - t0) * 1e3 / max(1, st.iterations)
-                out["config"]["batch_sharding"] = (f"landmark tracks over {world} ranks: {sh.mine.size}/{gs.n_point} points on rank 0, transport {sh.transport} "
-                                                   f"({'ncclAllReduce issued by the C-ABI on its stream' if sh.transport == 'rccl' else 'torch.distributed through the host callback'}), "
-                                                   f"{sh.hook.calls - calls0} all-reduces / {8 * (sh.hook.doubles - dbl0)} bytes in {st.iterations} LM iterations "
-                                                   f"({st.total_trials} trials), final chi2 {st.final_chi2:.6g}")
-                out["sharded"] = {"ranks": world, "transport": sh.transport, "lm_iterations": int(st.iterations), "trials": int(st.total_trials),
-                                  "allreduces_per_lm_iter": (sh.hook.calls - calls0) / max(1, st.iterations),
-                                  "allreduce_bytes_per_lm_iter": 8 * (sh.hook.doubles - dbl0) / max(1, st.iterations),
-                                  "points_on_rank0": int(sh.mine.size), "points": int(gs.n_point)}
-                sh.close()
-            except Exception as e:                       # the replica numbers above stay valid
-                out["batch_sharded_error"] = repr(e)[:300]
+            # ---- batch graphs SHARDED over the ranks (landmark tracks per rank, poses replicated; all-reduces of the reduced-camera quantities issued by the
+            # C-ABI over RCCL / xGMI).  north_star: "only where the graph is large enough to benefit" - so three graphs:
+            #   control  the 60-frame window graph of the N = 1 line (224 k edges, ~0.45 ms per iteration on ONE GPU): too small, expected to LOSE
+            #   omd      BASELINE configs[3]: Oxford-Multimotion-shaped multi-object graph (4 objects carrying a third of the points)
+            #   large    BASELINE configs[4]: 1 M landmarks / 5 k pose vertices / 20 objects
+            # each with the same graph on one GPU of this node beside it (every rank times its own replica: `*_1gpu` is rank 0's).
+            out["sharded"] = {}
+            for tag, shape, its in SHARD_LEGS:
+                if tag == "large" and os.environ.get("VDO_BENCH_NO_LARGE"):
+                    continue
+                try:
+                    from vdo_slam_amd.dist import ShardedBatchBA
+                    gs = synth.make_ba_graph(*shape, seed=1 if tag == "control" else 5)       # (the same graph on every rank)
+                    b1 = BatchBA(ctx_ba, gs)
+                    b1.optimize(max_iterations=1, gain_threshold=-1.0)
+                    b1.set_estimates(gs.pose, gs.point)
+                    barrier()
+                    t0 = time.perf_counter()
+                    st1 = b1.optimize(max_iterations=its, gain_threshold=-1.0)
+                    ms1 = (time.perf_counter() - t0) * 1e3 / max(1, st1.iterations)
+                    b1.close(); del b1
+                    barrier()
+                    sh = ShardedBatchBA(ctx_ba, gs)
+                    sh.optimize(max_iterations=1, gain_threshold=-1.0)
+                    sh.ba.set_estimates(sh.shard.pose, sh.shard.point)
+                    calls0, dbl0 = sh.hook.calls, sh.hook.doubles
+                    barrier()
+                    t0 = time.perf_counter()
+                    st = sh.optimize(max_iterations=its, gain_threshold=-1.0)
+                    barrier()
+                    msN = (time.perf_counter() - t0) * 1e3 / max(1, st.iterations)
+                    out["sharded"][tag] = {
+                        "graph": f"{gs.n_cam} frames, {gs.n_pose} pose/motion vertices, {gs.n_point} points, {gs.n_eb} EdgeSE3PointXYZ, {gs.n_et} ternary, {gs.n_ep} EdgeSE3",
+                        "ranks": world, "transport": sh.transport, "ms_per_lm_iter_sharded": msN, "ms_per_lm_iter_1gpu": ms1, "speedup_vs_1gpu": ms1 / msN,
+                        "lm_iterations": int(st.iterations), "trials": int(st.total_trials), "same_trajectory_as_1gpu": bool(st.iterations == st1.iterations and st.total_trials == st1.total_trials),
+                        "final_chi2": float(st.final_chi2), "final_chi2_1gpu": float(st1.final_chi2),
+                        "allreduces_per_lm_iter": (sh.hook.calls - calls0) / max(1, st.iterations),
+                        "allreduce_bytes_per_lm_iter": 8 * (sh.hook.doubles - dbl0) / max(1, st.iterations),
+                        "points_on_rank0": int(sh.mine.size), "points": int(gs.n_point)}
+                    out["ms_per_lm_iter_sharded" if tag == "control" else f"ms_per_lm_iter_{tag}_sharded"] = msN
+                    sh.close(); del sh, gs
+                except Exception as e:                       # the replica numbers above stay valid
+                    out["sharded"][tag] = {"error": repr(e)[:300]}
+            out["config"]["batch_sharding"] = ("landmark tracks cut into `ranks` runs of equal incidence count, all pose / motion vertices and pose-pose edges replicated; per LM iteration: "
+                                               "Hpp | bp | chi2 (42 P + 2 doubles) once per linearisation, the block-Jacobi diagonal (21 P + 1) once per trial, 6 P doubles per CG iteration, "
+                                               "3 scalars per trial (DESIGN 6); transport 'rccl' = ncclAllReduce issued by the C-ABI on its stream, 'callback' = torch.distributed through the "
+                                               "host callback (ranks sharing a GPU)")
         # ---- BASELINE configs[2] (KITTI 0018-0020-shaped: ~10 k landmarks, 5 objects) and a configs[4]-shaped graph (1 M landmarks,
         # 5 k pose vertices, 20 objects) on ONE GPU: ms per LM outer iteration (PCG)
-        for key, shape, its in (("ms_per_lm_iter_config3", (60, 10000, 5, 400), 5), ("ms_per_lm_iter_large", (239, 950000, 20, 500), 3)):
-            if key == "ms_per_lm_iter_large" and (world > 1 or os.environ.get("VDO_BENCH_NO_LARGE")):
+        for key, shape, its in (("ms_per_lm_iter_config3", (60, 10000, 5, 400), 5), ("ms_per_lm_iter_omd", OMD_SHAPE, 5), ("ms_per_lm_iter_large", LARGE_SHAPE, 3)):
+            if key != "ms_per_lm_iter_config3" and (world > 1 or os.environ.get("VDO_BENCH_NO_LARGE")):      # (N > 1: these two are the sharded legs above, with their 1-GPU time beside them)
                 continue
             gx = synth.make_ba_graph(*shape, seed=5 + rank)
             bx = BatchBA(ctx_ba, gx)

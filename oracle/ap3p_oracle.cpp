@@ -61,6 +61,52 @@ void solve_quartic(const double* f, double* roots) {
   roots[3] = B_4A - sqrt_2m_rh - sqrt2;
 }
 
+// The same formulas in REAL arithmetic with +, -, *, / and sqrt only - what the product's k_ap3p_hyp runs (vdo_slam_amd/csrc/ransac.hip ap3p_quartic),
+// operation for operation, so that both sides produce the same bits (libm's and the device library's pow / cbrt / complex sqrt do not round alike):
+// the complex cube root enters only through 4 Re(w^(1/3)) = twice the largest root of x^3 - 3 p3 x + 2 q3 (|w|^2 = p3^3, Re w = -q3: three real roots,
+// the monotone Newton iteration of p3p_oracle.cpp), complex square roots only through their real parts.
+extern "C" double vdo_oracle_cbrt_exact(double x);
+extern "C" double vdo_oracle_cubic3_largest_root(double P, double Q);
+inline double re_csqrt(double a, double b) {      // real part of the principal square root of a + b i
+  if (b == 0.0) return a >= 0.0 ? std::sqrt(a) : 0.0;
+  const double m = std::sqrt(a * a + b * b);
+  if (a > 0.0) return std::sqrt(2.0 * (m + a)) / 2.0;
+  return std::fabs(b) / std::sqrt(2.0 * (m - a));
+}
+void solve_quartic_lf(const double* f, double* roots) {
+  const double a4 = f[0], a3 = f[1], a2 = f[2], a1 = f[3], a0 = f[4];
+  const double a4_2 = a4 * a4, a3_2 = a3 * a3, a4_3 = a4_2 * a4, a2a4 = a2 * a4;
+  const double p4 = (8 * a2a4 - 3 * a3_2) / (8 * a4_2);
+  const double q4 = (a3_2 * a3 - 4 * a2a4 * a3 + 8 * a1 * a4_2) / (8 * a4_3);
+  const double r4 = (256 * a0 * a4_3 - 3 * (a3_2 * a3_2) - 64 * a1 * a3 * a4_2 + 16 * a2a4 * a3_2) / (256 * (a4_3 * a4));
+  const double p3 = ((p4 * p4) / 12 + r4) / 3;
+  const double q3 = (72 * r4 * p4 - 2 * p4 * p4 * p4 - 27 * q4 * q4) / 432;
+  const double D = q3 * q3 - p3 * p3 * p3;
+  double t;
+  if (D >= 0) {
+    const double sD = std::sqrt(D);
+    double w = q3 >= 0 ? -sD - q3 : sD - q3;
+    w = vdo_oracle_cbrt_exact(w);
+    t = 2.0 * (w + p3 / w);
+  } else {
+    t = 2.0 * vdo_oracle_cubic3_largest_root(-3.0 * p3, 2.0 * q3);
+  }
+  const double m2 = -2 * p4 / 3 + t;
+  const bool m2pos = m2 >= 0;
+  const double s2m = std::sqrt(m2pos ? m2 : -m2);
+  const double B_4A = -a3 / (4 * a4);
+  const double complex1 = 4 * p4 / 3 + t;
+  const double c2 = 2 * q4 / s2m;
+  const double c2re = m2pos ? c2 : 0.0, c2im = m2pos ? 0.0 : -c2;
+  const double sqrt_2m_rh = (m2pos ? s2m : 0.0) / 2;
+  const double sqrt1 = re_csqrt(-(complex1 + c2re), -c2im) / 2;
+  roots[0] = B_4A + sqrt_2m_rh + sqrt1;
+  roots[1] = B_4A + sqrt_2m_rh - sqrt1;
+  const double sqrt2 = re_csqrt(-(complex1 - c2re), c2im) / 2;
+  roots[2] = B_4A - sqrt_2m_rh + sqrt2;
+  roots[3] = B_4A - sqrt_2m_rh - sqrt2;
+}
+
 void polish_quartic_roots(const double* c, double* roots) {
   for (int it = 0; it < 2; ++it)
     for (int j = 0; j < 4; ++j) {
@@ -74,7 +120,7 @@ void polish_quartic_roots(const double* c, double* roots) {
 struct Pose { double R[9], t[3]; };
 
 // up to 4 poses (camera from world: x_cam = R x_world + t) from 3 unit bearings b and 3 world points w
-int ap3p(const double* b1, const double* b2, const double* b3, const double* w1, const double* w2, const double* w3, Pose* out) {
+int ap3p(const double* b1, const double* b2, const double* b3, const double* w1, const double* w2, const double* w3, Pose* out, bool lf = false) {
   double u0[3] = {w1[0] - w2[0], w1[1] - w2[1], w1[2] - w2[2]};
   const double nu0 = norm(u0);
   if (!(nu0 > 0)) return 0;
@@ -107,7 +153,7 @@ int ap3p(const double* b1, const double* b2, const double* b3, const double* w1,
                             2 * (g6 * g7 - g1 * g2 - g3 * g4), g7 * g7 - g2 * g2 - g4 * g4};
   if (!(std::fabs(coeffs[0]) > 0)) return 0;
   double s[4];
-  solve_quartic(coeffs, s);
+  if (lf) solve_quartic_lf(coeffs, s); else solve_quartic(coeffs, s);
   polish_quartic_roots(coeffs, s);
   double temp[3];
   cross(k1, nl, temp);
@@ -150,7 +196,7 @@ inline double reproj2(const Pose& T, const double* K4, const double* X, const do
 }
 
 // ap3p::solve on four points: pose from the first three, the fourth picks the solution (first one wins a tie)
-bool hypothesis(const double* X, const double* uv, const double* K4, const int32_t* idx, Pose* out) {
+bool hypothesis(const double* X, const double* uv, const double* K4, const int32_t* idx, Pose* out, bool lf = false) {
   double f[3][3];
   for (int k = 0; k < 3; ++k) {
     f[k][0] = (uv[2 * idx[k]] - K4[2]) / K4[0]; f[k][1] = (uv[2 * idx[k] + 1] - K4[3]) / K4[1]; f[k][2] = 1.0;
@@ -158,7 +204,7 @@ bool hypothesis(const double* X, const double* uv, const double* K4, const int32
     for (int i = 0; i < 3; ++i) f[k][i] /= nrm;
   }
   Pose sol[4];
-  const int ns = ap3p(f[0], f[1], f[2], X + 3 * idx[0], X + 3 * idx[1], X + 3 * idx[2], sol);
+  const int ns = ap3p(f[0], f[1], f[2], X + 3 * idx[0], X + 3 * idx[1], X + 3 * idx[2], sol, lf);
   if (ns == 0) return false;
   int best = 0;
   double be = 0;
@@ -196,8 +242,8 @@ extern "C" int vdo_oracle_ap3p_quartic(const double* coeffs5, double* roots4) {
 
 // RANSACPointSetRegistrator::run with the AP3P callback (same subsets - vdo_oracle_ransac_subsets -, same vote and budget rule as
 // vdo_oracle_p3p_ransac), up to the final refit
-extern "C" int vdo_oracle_ap3p_ransac(int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence,
-                                      double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter) {
+static int ap3p_ransac(bool lf, int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence,
+                       double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter) {
   for (int i = 0; i < 16; ++i) T_out[i] = (i % 5 == 0) ? 1.0 : 0.0;
   if (inlier_out) std::memset(inlier_out, 0, (size_t)(n > 0 ? n : 0));
   if (iters_run) *iters_run = 0;
@@ -210,7 +256,7 @@ extern "C" int vdo_oracle_ap3p_ransac(int n, const double* X, const double* uv, 
   Pose best{};
   for (; it < niters; ++it) {
     Pose h;
-    if (!hypothesis(X, uv, K4, idx.data() + 4 * it, &h)) continue;
+    if (!hypothesis(X, uv, K4, idx.data() + 4 * it, &h, lf)) continue;
     int good = 0;
     for (int i = 0; i < n; ++i) good += reproj2(h, K4, X + 3 * i, uv + 2 * i) <= t2;
     if (good > (max_good > 3 ? max_good : 3)) {
@@ -225,4 +271,25 @@ extern "C" int vdo_oracle_ap3p_ransac(int n, const double* X, const double* uv, 
   if (inlier_out)
     for (int i = 0; i < n; ++i) inlier_out[i] = reproj2(best, K4, X + 3 * i, uv + 2 * i) <= t2;
   return max_good;
+}
+
+extern "C" int vdo_oracle_ap3p_ransac(int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence,
+                                      double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter) {
+  return ap3p_ransac(false, n, X, uv, K4, max_iters, thr, confidence, T_out, inlier_out, iters_run, best_iter);
+}
+// the same with Ferrari's formulas in real, libm-free arithmetic: the form the product runs and is compared with bit for bit
+extern "C" int vdo_oracle_ap3p_lf_ransac(int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence,
+                                         double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter) {
+  return ap3p_ransac(true, n, X, uv, K4, max_iters, thr, confidence, T_out, inlier_out, iters_run, best_iter);
+}
+extern "C" int vdo_oracle_ap3p_lf(const double* f9, const double* P9, double* R_out /*[4][9]*/, double* t_out /*[4][3]*/) {
+  Pose sol[4];
+  const int n = ap3p(f9, f9 + 3, f9 + 6, P9, P9 + 3, P9 + 6, sol, true);
+  for (int s = 0; s < n; ++s) { std::memcpy(R_out + 9 * s, sol[s].R, 72); std::memcpy(t_out + 3 * s, sol[s].t, 24); }
+  return n;
+}
+extern "C" int vdo_oracle_ap3p_quartic_lf(const double* coeffs5, double* roots4) {
+  solve_quartic_lf(coeffs5, roots4);
+  polish_quartic_roots(coeffs5, roots4);
+  return 4;
 }

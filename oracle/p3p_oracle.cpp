@@ -281,12 +281,17 @@ extern "C" double vdo_oracle_epnp(int n, const double* X, const double* uv, cons
 
 // solvePnPRansac as a whole: the RANSAC above, then - refit != 0 - the winning model re-estimated on its inliers by EPnP (the pose
 // OpenCV 3.4 returns; the inlier set stays the RANSAC one)
+extern "C" int vdo_oracle_ap3p_lf_ransac(int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence,
+                                         double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter);
+// refit bit 0: OpenCV's final EPnP re-estimation; bit 1: Grunert's P3P as the minimal solver instead of AP3P (= vdo_pnp_problem.refit of the product).
+// The default - AP3P, what the reference's calls name (src/Tracking.cc:1652-1657) - is the libm-free form of ap3p_oracle.cpp (round 5; rounds 2-4: Grunert).
 extern "C" int vdo_oracle_pnp_ransac_refit(int n, const double* X, const double* uv, const double* K4, int max_iters, double thr, double confidence, int refit,
                                            double* T_out, uint8_t* inlier_out, int32_t* iters_run, int32_t* best_iter) {
   std::vector<uint8_t> inl((size_t)std::max(n, 1), 0);
-  const int good = vdo_oracle_p3p_ransac(n, X, uv, K4, max_iters, thr, confidence, T_out, inl.data(), iters_run, best_iter);
+  const int good = (refit & 2) ? vdo_oracle_p3p_ransac(n, X, uv, K4, max_iters, thr, confidence, T_out, inl.data(), iters_run, best_iter)
+                               : vdo_oracle_ap3p_lf_ransac(n, X, uv, K4, max_iters, thr, confidence, T_out, inl.data(), iters_run, best_iter);
   if (inlier_out && n > 0) std::memcpy(inlier_out, inl.data(), (size_t)n);
-  if (good >= 4 && refit) {
+  if (good >= 4 && (refit & 1)) {
     std::vector<double> Xi, ui;
     for (int i = 0; i < n; ++i) if (inl[i]) { Xi.insert(Xi.end(), X + 3 * i, X + 3 * i + 3); ui.insert(ui.end(), uv + 2 * i, uv + 2 * i + 2); }
     const ref_epnp::Result r = ref_epnp::solve((int)(ui.size() / 2), Xi.data(), ui.data(), K4);

@@ -251,7 +251,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d, int 
   int keyb[VDO_TILE_EPT];
   double web[VDO_TILE_EPT];
 #pragma unroll
-  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int e = ebase + min(q, jmax) * VDO_TILE_THREADS; keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }
+  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int e = ebase + min(q, jmax) * VDO_TILE_THREADS; keyb[q] = __builtin_nontemporal_load(d.eb_key + e); web[q] = __builtin_nontemporal_load(d.Finc + e);      /* streamed once per launch: past the resident lines of L2, not through them (ba_sweep.hip VDO_NT_LOAD) */ }
   for (int i = tid; i < 21 * nslot; i += VDO_TILE_THREADS) accm[i] = 0.0;
   auto stage_slot = [&](int sidx, int pid) {
     const IsoD W = iso_inv(iso_load(d.pose[0] + 12 * (int64_t)pid));
@@ -847,7 +847,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   int keyb[VDO_TILE_EPT];
   double web[VDO_TILE_EPT];
 #pragma unroll
-  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int e = ebase + min(q, jmax) * VDO_TILE_THREADS; keyb[q] = d.eb_key[e]; web[q] = d.Finc[e]; }      // (eb_key has >= 1 entry)
+  for (int q = 0; q < VDO_TILE_EPT; ++q) { const int e = ebase + min(q, jmax) * VDO_TILE_THREADS; keyb[q] = __builtin_nontemporal_load(d.eb_key + e); web[q] = __builtin_nontemporal_load(d.Finc + e);      /* streamed once per launch: past the resident lines of L2, not through them (ba_sweep.hip VDO_NT_LOAD) */ }      // (eb_key has >= 1 entry)
   for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) u[i] = 0.0;
   if (MODE != 2)
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) qs[i] = 0.0;

@@ -102,6 +102,19 @@ __device__ __forceinline__ void acc_finish(double (&acc)[16], int cur, double* a
 
 // What a thread holds of a tile before the tile's staging barrier: everything the head of the tile requests from HBM (the persistent form of the
 // kernel requests the NEXT tile's while this one computes).
+// The sweep streams ~510 MB through an L2 of 8 x 4 MB per launch: what is read or written ONCE (edge inputs, we, landmark sums, the partial rows) carries the
+// non-temporal hint, so that it does not push out what IS used again - the pose array, the descriptors and slot tables of the tiles (shared cache lines
+// between neighbouring tiles) - and streams past the resident lines instead of through them: 0.104 -> 0.093 ms on the 13.3 M-edge graph (A/B on one box,
+// profiles/r05_sweep_ab.txt).  A software prefetch of the next tile's descriptor / slot tables / points into the XCD's L2 on top of it: no gain, removed.
+// -DVDO_SWEEP_NO_NT: plain accesses (A/B).
+#ifdef VDO_SWEEP_NO_NT
+#define VDO_NT_LOAD(p) (*(p))
+#define VDO_NT_STORE(v, p) (*(p) = (v))
+#else
+#define VDO_NT_LOAD(p) __builtin_nontemporal_load(p)
+#define VDO_NT_STORE(v, p) __builtin_nontemporal_store((v), (p))
+#endif
+
 template <bool COMPACT>
 struct SweepHead {
   int my_pose, my_dst;            // pose id and partial-row id of slot min(thread, slots - 1)
@@ -131,9 +144,9 @@ __device__ __forceinline__ void sweep_request(const BADev& d, const Tile& T, int
 #pragma unroll
     for (int j = 0; j < VDO_TILE_EPT; ++j) {
       const int e = ebase + min(j, jmax) * VDO_TILE_THREADS;
-      h.ekey[j] = d.eb_key[e];
+      h.ekey[j] = VDO_NT_LOAD(d.eb_key + e);
 #pragma unroll
-      for (int k = 0; k < 3; ++k) h.ezf[j][k] = d.eb_zf[k * Eb + e];
+      for (int k = 0; k < 3; ++k) h.ezf[j][k] = VDO_NT_LOAD(d.eb_zf + k * Eb + e);
     }
   } else {
 #pragma unroll
@@ -262,7 +275,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
             const double we = w * rho1;
             // 6x3 block Hpl = -we * [ I ; 2[zc]x ] * Jl  -> only we is stored (8 B instead of 144 B): the consumers recompute zc from
             // the point and the pose exactly as above (ba_solve.hip make_f)
-            d.Finc[e] = we;
+            VDO_NT_STORE(we, d.Finc + e);
             // landmark side: Hll += we * Jl^T Jl = we * R R^T = we * I (R is a rotation: g2o's product differs from I by a few
             // 1e-16, far inside the 1e-12 parity bar) -> ONE running sum per point; bl += -we * R e   (R e = Jl^T e)
             // (R e and the cross product zc x e by fused multiply-adds: no cancellation follows them, the blocks move by ~1e-16 of their size -
@@ -338,22 +351,22 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
     if (BUILD) {
       // landmarks: Hll = (sum of we) * I -> one double per point; bl - coalesced: consecutive lanes write consecutive doubles
       double* __restrict__ H = d.Hll + (int64_t)T.pt_begin;
-      for (int i = tid; i < npts; i += VDO_TILE_THREADS) H[i] = accpt[i];
+      for (int i = tid; i < npts; i += VDO_TILE_THREADS) VDO_NT_STORE(accpt[i], H + i);
       double* __restrict__ b = d.bl + 3 * (int64_t)T.pt_begin;
       for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) {
         const int l = i / 3, k = i - 3 * l;
-        b[i] = accpt[(1 + k) * VDO_TILE_PTS + l];
+        VDO_NT_STORE(accpt[(1 + k) * VDO_TILE_PTS + l], b + i);
       }
       // per-(tile,slot) partials -> their pose-major rows: 128 (256) contiguous bytes per slot
       if (d.ps_stride == 16) {
         for (int i = tid; i < 16 * nslot; i += VDO_TILE_THREADS) {
           const int sidx = i >> 4, k = i & 15;
-          d.part_sums[16 * (int64_t)sdst[sidx] + k] = accpose[arow * sidx + k];
+          VDO_NT_STORE(accpose[arow * sidx + k], d.part_sums + 16 * (int64_t)sdst[sidx] + k);
         }
       } else {
         for (int i = tid; i < 32 * nslot; i += VDO_TILE_THREADS) {
           const int sidx = i >> 5, k = i & 31;
-          d.part_sums[32 * (int64_t)sdst[sidx] + k] = accpose[arow * sidx + k];
+          VDO_NT_STORE(accpose[arow * sidx + k], d.part_sums + 32 * (int64_t)sdst[sidx] + k);
         }
       }
     }

@@ -218,6 +218,170 @@ __global__ __launch_bounds__(64) void k_p3p_hyp(const PnpDev* __restrict__ probs
   hyp_ok[P.hyp_off + h] = ok;
 }
 
+// ---- AP3P: the minimal solver the reference's calls NAME - cv::solvePnPRansac(..., SOLVEPNP_AP3P), src/Tracking.cc:1652-1657, :1755-1760 -
+// Ke & Roumeliotis, "An Efficient Algebraic Solution to the Perspective-Three-Point Problem" (CVPR 2017) in the layout of OpenCV 3.4's
+// modules/calib3d/src/ap3p.cpp: the quartic in cos(theta1') with the coefficients g1 .. g7, its roots by Ferrari's formulas (the REAL PARTS of the four
+// roots, as solveQuartic returns them), two Newton steps per root, roots with |cos| > 1 dropped, solutions in root order, the fourth point of the sample
+// picks (first smallest reprojection error).  OpenCV evaluates Ferrari's formulas in std::complex with pow / sqrt of libm; here - and, operation for
+// operation, in oracle/ap3p_oracle.cpp ap3p_lf - they are written out in real arithmetic with +, -, *, / and sqrt only (correctly rounded on both sides:
+// same bits): the complex cube root appears only through 4 Re(w^(1/3)) = twice the largest root of x^3 - 3 p3 x + 2 q3 (three real roots: the monotone
+// Newton iteration cubic3_largest_root), square roots of complex numbers only through their real parts.  The std::complex form stays in the oracle
+// (vdo_oracle_ap3p) and the two are compared on the CPU (tests/test_oracle_ap3p.py).
+__device__ __forceinline__ double re_csqrt(double a, double b) {      // real part of the principal square root of a + b i
+  if (b == 0.0) return a >= 0.0 ? sqrt(a) : 0.0;
+  const double m = sqrt(a * a + b * b);
+  if (a > 0.0) return sqrt(2.0 * (m + a)) / 2.0;
+  return fabs(b) / sqrt(2.0 * (m - a));
+}
+__device__ void ap3p_quartic(const double* f, double* roots) {
+  const double a4 = f[0], a3 = f[1], a2 = f[2], a1 = f[3], a0 = f[4];
+  const double a4_2 = a4 * a4, a3_2 = a3 * a3, a4_3 = a4_2 * a4, a2a4 = a2 * a4;
+  const double p4 = (8 * a2a4 - 3 * a3_2) / (8 * a4_2);
+  const double q4 = (a3_2 * a3 - 4 * a2a4 * a3 + 8 * a1 * a4_2) / (8 * a4_3);
+  const double r4 = (256 * a0 * a4_3 - 3 * (a3_2 * a3_2) - 64 * a1 * a3 * a4_2 + 16 * a2a4 * a3_2) / (256 * (a4_3 * a4));
+  const double p3 = ((p4 * p4) / 12 + r4) / 3;
+  const double q3 = (72 * r4 * p4 - 2 * p4 * p4 * p4 - 27 * q4 * q4) / 432;
+  const double D = q3 * q3 - p3 * p3 * p3;
+  double t;
+  if (D >= 0) {                                  // w real
+    const double sD = sqrt(D);
+    double w = q3 >= 0 ? -sD - q3 : sD - q3;
+    w = cbrt_exact(w);
+    t = 2.0 * (w + p3 / w);
+  } else {                                       // w = -q3 -+ i sqrt(-D), |w|^2 = p3^3: 4 Re(w^(1/3)) = 2 x, x the largest root of x^3 - 3 p3 x + 2 q3
+    t = 2.0 * cubic3_largest_root(-3.0 * p3, 2.0 * q3);
+  }
+  // sqrt_2m = sqrt(complex(-2 p4 / 3 + t)): real (s, 0) or imaginary (0, s)
+  const double m2 = -2 * p4 / 3 + t;
+  const bool m2pos = m2 >= 0;
+  const double s2m = sqrt(m2pos ? m2 : -m2);
+  const double B_4A = -a3 / (4 * a4);
+  const double complex1 = 4 * p4 / 3 + t;
+  // complex2 = 2 q4 / sqrt_2m: (2 q4 / s, 0) or (0, -2 q4 / s)
+  const double c2 = 2 * q4 / s2m;
+  const double c2re = m2pos ? c2 : 0.0, c2im = m2pos ? 0.0 : -c2;
+  const double sqrt_2m_rh = (m2pos ? s2m : 0.0) / 2;
+  const double sqrt1 = re_csqrt(-(complex1 + c2re), -c2im) / 2;
+  roots[0] = B_4A + sqrt_2m_rh + sqrt1;
+  roots[1] = B_4A + sqrt_2m_rh - sqrt1;
+  const double sqrt2 = re_csqrt(-(complex1 - c2re), c2im) / 2;
+  roots[2] = B_4A - sqrt_2m_rh + sqrt2;
+  roots[3] = B_4A - sqrt_2m_rh - sqrt2;
+#pragma unroll
+  for (int it = 0; it < 2; ++it)                 // polishQuarticRoots
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const double x = roots[j];
+      const double err = (((f[0] * x + f[1]) * x + f[2]) * x + f[3]) * x + f[4];
+      const double der = ((4 * f[0] * x + 3 * f[1]) * x + 2 * f[2]) * x + f[3];
+      roots[j] -= err / der;
+    }
+}
+__device__ __forceinline__ bool d_finite(double x) { return fabs(x) <= 1.7976931348623157e308; }     // (false for NaN and infinities)
+
+// hyp_pose [n_hyp_total][12] (R row-major | t), hyp_ok [n_hyp_total]
+__global__ __launch_bounds__(64) void k_ap3p_hyp(const PnpDev* __restrict__ probs, const double* __restrict__ X, const double* __restrict__ uv,
+                                                 const int32_t* __restrict__ subsets, double* __restrict__ hyp_pose, int32_t* __restrict__ hyp_ok) {
+  const PnpDev P = probs[blockIdx.y];
+  const int h = blockIdx.x * blockDim.x + threadIdx.x;
+  if (h >= P.n_hyp) return;
+  const int32_t* idx = subsets + 4 * (size_t)(P.hyp_off + h);
+  const double* Xp = X + 3 * (size_t)P.pt_off;
+  const double* up = uv + 2 * (size_t)P.pt_off;
+  double f[3][3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    f[k][0] = (up[2 * idx[k]] - P.K[2]) / P.K[0]; f[k][1] = (up[2 * idx[k] + 1] - P.K[3]) / P.K[1]; f[k][2] = 1.0;
+    const double nrm = sqrt(d3dot(f[k], f[k]));
+    f[k][0] /= nrm; f[k][1] /= nrm; f[k][2] /= nrm;
+  }
+  const double *b1 = f[0], *b2 = f[1], *b3 = f[2];
+  const double *w1 = Xp + 3 * idx[0], *w2 = Xp + 3 * idx[1], *w3 = Xp + 3 * idx[2], *P4 = Xp + 3 * idx[3];
+  const double u4 = up[2 * idx[3]], v4 = up[2 * idx[3] + 1];
+  double* out = hyp_pose + 12 * (size_t)(P.hyp_off + h);
+  int ok = 0;
+  do {
+    const double u0[3] = {w1[0] - w2[0], w1[1] - w2[1], w1[2] - w2[2]};
+    const double nu0 = sqrt(d3dot(u0, u0));
+    if (!(nu0 > 0)) break;
+    const double k1[3] = {u0[0] / nu0, u0[1] / nu0, u0[2] / nu0};
+    double k3[3];
+    d3cross(b1, b2, k3);
+    const double nk3 = sqrt(d3dot(k3, k3));
+    if (!(nk3 > 0)) break;
+    k3[0] /= nk3; k3[1] /= nk3; k3[2] /= nk3;
+    double tz[3], v1[3], v2[3];
+    d3cross(b1, k3, tz);
+    d3cross(b1, b3, v1);
+    d3cross(b2, b3, v2);
+    const double u1[3] = {w1[0] - w3[0], w1[1] - w3[1], w1[2] - w3[2]};
+    const double u1k1 = d3dot(u1, k1), k3b3 = d3dot(k3, b3);
+    double f11 = k3b3, f13 = d3dot(k3, v1);
+    const double f15 = -u1k1 * f11;
+    double nl[3];
+    d3cross(u1, k1, nl);
+    const double delta = sqrt(d3dot(nl, nl));
+    if (!(delta > 0) || k3b3 == 0.0) break;
+    nl[0] /= delta; nl[1] /= delta; nl[2] /= delta;
+    f11 *= delta; f13 *= delta;
+    const double u2k1 = u1k1 - nu0;
+    double f21 = d3dot(tz, v2), f22 = nk3 * k3b3, f23 = d3dot(k3, v2);
+    const double f24 = u2k1 * f22, f25 = -u2k1 * f21;
+    f21 *= delta; f22 *= delta; f23 *= delta;
+    const double g1 = f13 * f22, g2 = f13 * f25 - f15 * f23, g3 = f11 * f23 - f13 * f21, g4 = -f13 * f24, g5 = f11 * f22, g6 = f11 * f25 - f15 * f21, g7 = -f15 * f24;
+    const double coeffs[5] = {g5 * g5 + g1 * g1 + g3 * g3, 2 * (g5 * g6 + g1 * g2 + g3 * g4), g6 * g6 + 2 * g5 * g7 + g2 * g2 + g4 * g4 - g1 * g1 - g3 * g3,
+                              2 * (g6 * g7 - g1 * g2 - g3 * g4), g7 * g7 - g2 * g2 - g4 * g4};
+    if (!(fabs(coeffs[0]) > 0)) break;
+    double sr[4];
+    ap3p_quartic(coeffs, sr);
+    double temp[3];
+    d3cross(k1, nl, temp);
+    const double Ck[9] = {k1[0], nl[0], temp[0], k1[1], nl[1], temp[1], k1[2], nl[2], temp[2]};          // Ck1nl, row-major
+    const double Cb[9] = {b1[0], b1[1], b1[2], k3[0], k3[1], k3[2], tz[0], tz[1], tz[2]};                  // Cb1k3tzT
+    const double sc = delta / k3b3;
+    const double b3p[3] = {sc * b3[0], sc * b3[1], sc * b3[2]};
+    double best = 0.0;
+    for (int i = 0; i < 4; ++i) {
+      const double ct1 = sr[i];
+      if (!(fabs(ct1) <= 1)) continue;
+      double st1 = sqrt(1 - ct1 * ct1);
+      st1 = (k3b3 > 0) ? st1 : -st1;
+      double ct3 = g1 * ct1 + g2, st3 = g3 * ct1 + g4;
+      const double nt3 = st1 / ((g5 * ct1 + g6) * ct1 + g7);
+      ct3 *= nt3; st3 *= nt3;
+      const double C13[9] = {ct3, 0, -st3, st1 * st3, ct1, st1 * ct3, ct1 * st3, -st1, ct1 * ct3};
+      double tm[9], Rw[9];                       // Rw: world from camera
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) tm[3 * a + b] = Ck[3 * a] * C13[b] + Ck[3 * a + 1] * C13[3 + b] + Ck[3 * a + 2] * C13[6 + b];
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = 0; b < 3; ++b) Rw[3 * a + b] = tm[3 * a] * Cb[b] + tm[3 * a + 1] * Cb[3 + b] + tm[3 * a + 2] * Cb[6 + b];
+      const double rp3[3] = {w3[0] * Rw[0] + w3[1] * Rw[3] + w3[2] * Rw[6], w3[0] * Rw[1] + w3[1] * Rw[4] + w3[2] * Rw[7], w3[0] * Rw[2] + w3[1] * Rw[5] + w3[2] * Rw[8]};   // R^T w3
+      double R[9], t[3];
+      bool fin = true;
+#pragma unroll
+      for (int a = 0; a < 3; ++a) {
+        t[a] = st1 * b3p[a] - rp3[a];
+        fin = fin && d_finite(t[a]);
+#pragma unroll
+        for (int b = 0; b < 3; ++b) { R[3 * a + b] = Rw[3 * b + a]; fin = fin && d_finite(R[3 * a + b]); }
+      }
+      if (!fin) continue;
+      const double e4 = reproj_err2(R, t, P.K, P4, u4, v4);
+      if (!ok || best > e4) {                    // the first solution, then every strictly better one (ap3p::solve on four points)
+        best = e4; ok = 1;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) out[q] = R[q];
+        out[9] = t[0]; out[10] = t[1]; out[11] = t[2];
+      }
+    }
+  } while (false);
+  hyp_ok[P.hyp_off + h] = ok;
+}
+
 // one workgroup per (hypothesis, problem): inlier count + bit-mask of squared reprojection error <= thr^2
 __global__ __launch_bounds__(256) void k_ransac_vote(const PnpDev* __restrict__ probs, const double* __restrict__ X, const double* __restrict__ uv,
                                                      const double* __restrict__ hyp_pose, const int32_t* __restrict__ hyp_ok,
@@ -359,7 +523,12 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   int32_t *dok = S.up<int32_t>(nullptr, tot_hyp), *dcnt = S.up<int32_t>(nullptr, tot_hyp);
   uint32_t* dmask = S.up<uint32_t>(nullptr, tot_words);
   if (!dprob || !dX || !duv || !dsub || !dpose || !dok || !dcnt || !dmask) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
-  hipLaunchKernelGGL(k_p3p_hyp, dim3((max_hyp + 63) / 64, n_problems), dim3(64), 0, S.stream(), (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const int32_t*)dsub, dpose, dok);
+  // minimal solver of the whole batch: AP3P (what the reference's calls name) unless every problem asks for Grunert's P3P (vdo_pnp_problem.refit bit 1)
+  bool grunert = true;
+  for (int k = 0; k < n_problems; ++k) grunert = grunert && (probs[k].refit & 2);
+  for (int k = 0; k < n_problems; ++k) if (((probs[k].refit & 2) != 0) != grunert) return set_error(VDO_ERR_INVALID, "vdo_pnp_ransac_batch: the problems of a batch must name the same minimal solver");
+  if (grunert) hipLaunchKernelGGL(k_p3p_hyp, dim3((max_hyp + 63) / 64, n_problems), dim3(64), 0, S.stream(), (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const int32_t*)dsub, dpose, dok);
+  else hipLaunchKernelGGL(k_ap3p_hyp, dim3((max_hyp + 63) / 64, n_problems), dim3(64), 0, S.stream(), (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const int32_t*)dsub, dpose, dok);
   hipLaunchKernelGGL(k_ransac_vote, dim3(max_hyp, n_problems), dim3(256), 0, S.stream(), (const PnpDev*)dprob, (const double*)dX, (const double*)duv, (const double*)dpose, (const int32_t*)dok, dcnt, dmask);
   // (votes, poses and inlier masks of all hypotheses are read where they land in the pinned block: the replay touches a few rows)
   const int32_t *cnt = S.down_view(dcnt, tot_hyp), *okv = S.down_view(dok, tot_hyp);
@@ -396,7 +565,7 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   // independent: one per pool task (the objects of a frame in parallel)
   const double tr3 = g_pnp_trace.on ? pnp_now_us() : 0.0;
   std::vector<int> todo;
-  for (int k = 0; k < n_problems; ++k) if (probs[k].refit && results[k].n_inliers >= 4 && results[k].best_iteration >= 0) todo.push_back(k);
+  for (int k = 0; k < n_problems; ++k) if ((probs[k].refit & 1) && results[k].n_inliers >= 4 && results[k].best_iteration >= 0) todo.push_back(k);
   if (!todo.empty()) {
     const PnpDev* hp_main = hp.data();               // (hp is thread_local: a pool thread naming it would see ITS OWN, empty, vector)
     auto refit_one = [&, hp_main](int q) {

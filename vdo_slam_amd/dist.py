@@ -147,24 +147,42 @@ def _one_gpu_per_rank(ctx, group):
     """RCCL needs a device of its own per rank (ncclCommInitRank fails - or hangs - when two ranks of a communicator sit on the
     same GPU).  Every rank contributes (host, device) and all take the same decision.  The exchange goes through the rendezvous
     STORE of the process group (TCP key/value), not through a collective of the group itself: in the very situation this probe is
-    for - two ranks of an "nccl" group on one GPU - an all_gather over that group would be the first thing to fail.  Any error in the
-    exchange -> False on this rank (the host-callback transport works everywhere)."""
+    for - two ranks of an "nccl" group on one GPU - an all_gather over that group would be the first thing to fail."""
     import os
     import socket
     import torch.distributed as dist
     # (a launcher that narrows the visible devices per rank makes every rank's device "0": the masks are part of the identity)
     mine = repr((socket.gethostname(), int(getattr(ctx, "device", 0)), os.environ.get("HIP_VISIBLE_DEVICES", ""), os.environ.get("ROCR_VISIBLE_DEVICES", "")))
+    from torch.distributed import distributed_c10d as c10d
+    store = c10d._get_default_store()                            # (no store / an old torch: raises on EVERY rank alike - nothing to decide)
+    ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
+    _probe_serial[0] += 1                                        # (every rank constructs its sharded handles in the same order)
+    tag = f"vdo_one_gpu_per_rank/{_probe_serial[0]}/{','.join(map(str, ranks))}"
+    me = dist.get_rank()
+    # The decision must be COLLECTIVE: ranks that pick different transports (one "rccl", one "callback") deadlock in their first all-reduce.  Two
+    # phases through the store: (1) everyone publishes its identity and reads everyone's - a rank that fails here (a get that times out) says so in
+    # (2), where everyone reads everyone's verdict; rccl only if every rank saw all identities and they are distinct.  A failure of phase 2 itself
+    # raises (the group is broken: better an exception on this rank than a hang in a collective).
     try:
-        from torch.distributed import distributed_c10d as c10d
-        store = c10d._get_default_store()
-        ranks = dist.get_process_group_ranks(group) if group is not None else list(range(dist.get_world_size()))
-        _probe_serial[0] += 1                                    # (every rank constructs its sharded handles in the same order)
-        tag = f"vdo_one_gpu_per_rank/{_probe_serial[0]}/{','.join(map(str, ranks))}"
-        store.set(f"{tag}/{dist.get_rank()}", mine)
-        everyone = [store.get(f"{tag}/{r}").decode() for r in ranks]     # (get blocks until the key is there)
-        return len(set(everyone)) == len(everyone)
-    except Exception:                                            # noqa: BLE001 - no store / an old torch: fall back to the transport that cannot fail
-        return False
+        store.set(f"{tag}/id/{me}", mine)
+        everyone = [store.get(f"{tag}/id/{r}").decode() for r in ranks]     # (get blocks until the key is there)
+        verdict = "1" if len(set(everyone)) == len(everyone) else "0"
+    except Exception:                                            # noqa: BLE001
+        verdict = "E"
+    store.set(f"{tag}/ok/{me}", verdict)
+    verdicts = [store.get(f"{tag}/ok/{r}").decode() for r in ranks]
+    if store.add(f"{tag}/done", 1) == len(ranks):                # the last reader cleans up
+        for r in ranks:
+            for kind in ("id", "ok"):
+                try:
+                    store.delete_key(f"{tag}/{kind}/{r}")
+                except Exception:                                # noqa: BLE001 - a store without delete_key: the keys stay (a few bytes)
+                    pass
+        try:
+            store.delete_key(f"{tag}/done")
+        except Exception:                                        # noqa: BLE001
+            pass
+    return all(v == "1" for v in verdicts)
 
 
 class ShardedBatchBA:
