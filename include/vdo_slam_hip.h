@@ -272,7 +272,7 @@ int vdo_pose_optimize(vdo_ctx* ctx, const vdo_pose_problem* p, vdo_flow2_result*
  * cv::solvePnPRansac(pre_3d, cur_2d, K, distCoeffs = 0, rvec, tvec, false, 500, 0.4, 0.98, inliers,
  * SOLVEPNP_AP3P): the sequential RANSAC of OpenCV 3.4 (cv::RNG subsets of 4 points, minimal P3P solve on 3 with
  * the 4th as tie-breaker, inliers = squared reprojection error <= thr^2, iteration budget shrunk by
- * RANSACUpdateNumIters) with every hypothesis solved and voted on the GPU at once and the loop replayed on the
+ * RANSACUpdateNumIters) with every hypothesis solved (AP3P) and voted on the GPU at once and the loop replayed on the
  * host over the votes.  OpenCV's final EPnP refit on the inliers is NOT applied (the LM refinement that follows in
  * the reference starts from this pose).  T = [R|t] camera-from-world (what Rodrigues(rvec), tvec give). */
 typedef struct vdo_pnp_problem {
@@ -283,8 +283,11 @@ typedef struct vdo_pnp_problem {
   int32_t max_iterations;   /* 500                                                */
   double reproj_threshold;  /* 0.4 px                                             */
   double confidence;        /* 0.98                                               */
-  int32_t refit;            /* 1: the winning model is re-estimated on its inliers by EPnP, as cv::solvePnPRansac does for the P3P
-                             *    / AP3P kernels since OpenCV 3.3 (the inlier set stays the RANSAC one); 0: the P3P hypothesis     */
+  int32_t refit;            /* bit 0: the winning model is re-estimated on its inliers by EPnP, as cv::solvePnPRansac does for the P3P
+                             *    / AP3P kernels since OpenCV 3.3 (the inlier set stays the RANSAC one); clear: the minimal hypothesis.
+                             * bit 1 (value 2): Grunert's P3P as the minimal solver (rounds 1-4) instead of AP3P - Ke & Roumeliotis in the
+                             *    layout of OpenCV 3.4's ap3p.cpp, the solver the reference's calls name (SOLVEPNP_AP3P), the default.
+                             *    All problems of a batch must name the same solver.                                                */
 } vdo_pnp_problem;
 typedef struct vdo_pnp_result {
   double T[16];             /* 4x4 row-major; identity when no model was found    */

@@ -195,6 +195,20 @@ inline double reproj2(const Pose& T, const double* K4, const double* X, const do
   return du * du + dv * dv;
 }
 
+// cv::Rodrigues on the way out of the RANSAC callback (matrix -> vector starts with R = U V^T of the SVD: the nearest orthogonal matrix) - see
+// vdo_slam_amd/csrc/ransac.hip polar_orthogonalise: Higham's iteration, the same operations in the same order
+void polar_orthogonalise(double* X) {
+  for (int it = 0; it < 8; ++it) {
+    const double c0 = X[4] * X[8] - X[5] * X[7], c1 = X[5] * X[6] - X[3] * X[8], c2 = X[3] * X[7] - X[4] * X[6];
+    const double c3 = X[2] * X[7] - X[1] * X[8], c4 = X[0] * X[8] - X[2] * X[6], c5 = X[1] * X[6] - X[0] * X[7];
+    const double c6 = X[1] * X[5] - X[2] * X[4], c7 = X[2] * X[3] - X[0] * X[5], c8 = X[0] * X[4] - X[1] * X[3];
+    const double det = X[0] * c0 + X[1] * c1 + X[2] * c2;
+    X[0] = 0.5 * (X[0] + c0 / det); X[1] = 0.5 * (X[1] + c1 / det); X[2] = 0.5 * (X[2] + c2 / det);
+    X[3] = 0.5 * (X[3] + c3 / det); X[4] = 0.5 * (X[4] + c4 / det); X[5] = 0.5 * (X[5] + c5 / det);
+    X[6] = 0.5 * (X[6] + c6 / det); X[7] = 0.5 * (X[7] + c7 / det); X[8] = 0.5 * (X[8] + c8 / det);
+  }
+}
+
 // ap3p::solve on four points: pose from the first three, the fourth picks the solution (first one wins a tie)
 bool hypothesis(const double* X, const double* uv, const double* K4, const int32_t* idx, Pose* out, bool lf = false) {
   double f[3][3];
@@ -213,6 +227,8 @@ bool hypothesis(const double* X, const double* uv, const double* K4, const int32
     if (s == 0 || be > e) { be = e; best = s; }
   }
   *out = sol[best];
+  polar_orthogonalise(out->R);
+  for (int a = 0; a < 9; ++a) if (!std::isfinite(out->R[a])) return false;
   return true;
 }
 

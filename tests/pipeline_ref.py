@@ -62,6 +62,7 @@ class OraclePipeline:
         sides to start from the same float; the EPnP arithmetic itself is pinned separately."""
         self.pnp_refit = pnp_refit                      # cv::solvePnPRansac's final EPnP re-estimation on the inliers (OpenCV >= 3.3)
         self.seed_lib = None
+        self.ransac_flags = 0       # 2: Grunert's P3P as the minimal solver of the RANSAC (rounds 1-4) instead of AP3P
         self.epnp_log = []          # seed_refit="product": the oracle's own refit beside every borrowed one (see _ransac)
         if seed_refit == "product":
             from tests import oracle_lib
@@ -96,7 +97,7 @@ class OraclePipeline:
             return 0, Tm.reshape(4, 4), inl[:n]
         X = np.ascontiguousarray(X, np.float64); uv = np.ascontiguousarray(uv, np.float64)
         K4d = self.K4.astype(np.float64)
-        own_refit = int(self.pnp_refit and self.seed_lib is None)
+        own_refit = int(self.pnp_refit and self.seed_lib is None) | self.ransac_flags      # (bit 1: Grunert's P3P instead of AP3P, as vdo_pnp_problem.refit)
         good = self.o.vdo_oracle_pnp_ransac_refit(n, K._dp(X), K._dp(uv), K._dp(K4d), 500, 0.4, 0.98, own_refit, K._dp(Tm), inl.ctypes.data_as(K.c_uint8_p), None, None)
         if self.pnp_refit and self.seed_lib is not None and good >= 4:
             sel = inl[:n] > 0
@@ -106,7 +107,7 @@ class OraclePipeline:
                 # returns - inlier count, inlier mask (everything upstream of the LM) and the refit pose - is logged next to the
                 # borrowed seed; the sequence tests assert identical inliers and poses within 1e-8 (epnp_log).
                 T_own = np.eye(4).ravel().copy(); inl_own = np.zeros(max(n, 1), np.uint8)
-                good_own = self.o.vdo_oracle_pnp_ransac_refit(n, K._dp(X), K._dp(uv), K._dp(K4d), 500, 0.4, 0.98, 1, K._dp(T_own), inl_own.ctypes.data_as(K.c_uint8_p), None, None)
+                good_own = self.o.vdo_oracle_pnp_ransac_refit(n, K._dp(X), K._dp(uv), K._dp(K4d), 500, 0.4, 0.98, 1 | self.ransac_flags, K._dp(T_own), inl_own.ctypes.data_as(K.c_uint8_p), None, None)
                 sv = np.linalg.svd(Xi - Xi.mean(0), compute_uv=False)
                 self.epnp_log.append(dict(n=int(good), same_inliers=bool(good_own == good and np.array_equal(inl_own, inl)), flatness=float(sv[2] / sv[0]),
                                           dT=float(np.abs(T_own - T2).max() / max(1.0, np.abs(T2[:12]).max())),

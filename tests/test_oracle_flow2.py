@@ -91,6 +91,8 @@ def test_f3_lm_is_chaotic_in_the_seed(oracle):
                 me.run_oracle = orig
 
     ref = Recorder(oracle, build_lm=True)
+    ref.ransac_flags = 2              # (the object problems this demonstration was recorded on: the inlier sets of the RANSAC around Grunert's P3P; with AP3P -
+                                      #  a few borderline inliers differ - the worst problem of these nine frames moves 3e-4 instead of 2e-2: the property is the LM's)
     for k in range(n_frames):
         ref.step(SQ.render_frame(k, Ts, objs, flow_sigma=0.3, invalid_depth=0.02, zero_flow=0.01))
     assert len(probs) >= 25

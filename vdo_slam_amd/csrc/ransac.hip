@@ -277,6 +277,23 @@ __device__ void ap3p_quartic(const double* f, double* roots) {
       roots[j] -= err / der;
     }
 }
+// What cv::Rodrigues does to the solver's matrix on its way out of the RANSAC callback (PnPRansacCallback::runKernel: solvePnP -> Rodrigues(R, rvec); the vote
+// then projects with Rodrigues(rvec)): matrix -> vector starts with R = U V^T of the SVD, the nearest orthogonal matrix.  For a proper solution that is the
+// identity up to rounding; for the "solutions" AP3P builds from the real part of a COMPLEX pair of roots (3.4 keeps them: only |cos| <= 1 is tested) it is
+// not - near a double root such a matrix is a few 1e-3 off a rotation and wins the vote.  The polar factor by Higham's iteration X <- (X + X^-T) / 2
+// (cofactors and one division per entry: libm-free, the same bits in oracle/ap3p_oracle.cpp); the angle-axis round trip itself is not restated.
+__device__ __forceinline__ void polar_orthogonalise(double* X) {
+#pragma unroll 1
+  for (int it = 0; it < 8; ++it) {
+    const double c0 = X[4] * X[8] - X[5] * X[7], c1 = X[5] * X[6] - X[3] * X[8], c2 = X[3] * X[7] - X[4] * X[6];
+    const double c3 = X[2] * X[7] - X[1] * X[8], c4 = X[0] * X[8] - X[2] * X[6], c5 = X[1] * X[6] - X[0] * X[7];
+    const double c6 = X[1] * X[5] - X[2] * X[4], c7 = X[2] * X[3] - X[0] * X[5], c8 = X[0] * X[4] - X[1] * X[3];
+    const double det = X[0] * c0 + X[1] * c1 + X[2] * c2;
+    X[0] = 0.5 * (X[0] + c0 / det); X[1] = 0.5 * (X[1] + c1 / det); X[2] = 0.5 * (X[2] + c2 / det);
+    X[3] = 0.5 * (X[3] + c3 / det); X[4] = 0.5 * (X[4] + c4 / det); X[5] = 0.5 * (X[5] + c5 / det);
+    X[6] = 0.5 * (X[6] + c6 / det); X[7] = 0.5 * (X[7] + c7 / det); X[8] = 0.5 * (X[8] + c8 / det);
+  }
+}
 __device__ __forceinline__ bool d_finite(double x) { return fabs(x) <= 1.7976931348623157e308; }     // (false for NaN and infinities)
 
 // hyp_pose [n_hyp_total][12] (R row-major | t), hyp_ok [n_hyp_total]
@@ -379,6 +396,14 @@ __global__ __launch_bounds__(64) void k_ap3p_hyp(const PnpDev* __restrict__ prob
       }
     }
   } while (false);
+  if (ok) {
+    double R[9];
+#pragma unroll
+    for (int q = 0; q < 9; ++q) R[q] = out[q];
+    polar_orthogonalise(R);
+#pragma unroll
+    for (int q = 0; q < 9; ++q) { out[q] = R[q]; ok = ok && d_finite(R[q]); }
+  }
   hyp_ok[P.hyp_off + h] = ok;
 }
 

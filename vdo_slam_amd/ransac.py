@@ -16,15 +16,17 @@ class PnpResultC(C.Structure):
     _fields_ = [("T", C.c_double * 16), ("n_inliers", C.c_int32), ("iterations_run", C.c_int32), ("best_iteration", C.c_int32)]
 
 
-def pnp_ransac_batch(ctx, problems, K4, max_iterations=500, thr=0.4, confidence=0.98, refit=False):
-    """problems: list of (X [n,3], uv [n,2]).  refit: OpenCV's final EPnP re-estimation of the winning model on its inliers.  Returns a list of dict(T, n_inliers, iterations_run, best_iteration, inliers)."""
+def pnp_ransac_batch(ctx, problems, K4, max_iterations=500, thr=0.4, confidence=0.98, refit=False, solver="ap3p"):
+    """problems: list of (X [n,3], uv [n,2]).  refit: OpenCV's final EPnP re-estimation of the winning model on its inliers.  solver: "ap3p" (what the
+    reference's calls name, the default) or "grunert" (rounds 1-4).  Returns a list of dict(T, n_inliers, iterations_run, best_iteration, inliers)."""
+    flags = int(bool(refit)) | (2 if solver == "grunert" else 0)
     n = len(problems)
     arr = (PnpProblemC * n)()
     keep, inl = [], []
     for i, (X, uv) in enumerate(problems):
         X = np.ascontiguousarray(X, dtype=np.float64).reshape(-1, 3); uv = np.ascontiguousarray(uv, dtype=np.float64).reshape(-1, 2)
         keep += [X, uv]
-        arr[i] = PnpProblemC(X.shape[0], K._dp(X), K._dp(uv), (C.c_double * 4)(*K4), max_iterations, thr, confidence, int(bool(refit)))
+        arr[i] = PnpProblemC(X.shape[0], K._dp(X), K._dp(uv), (C.c_double * 4)(*K4), max_iterations, thr, confidence, flags)
         inl.append(np.zeros(max(X.shape[0], 1), np.uint8))
     res = (PnpResultC * n)()
     ip = (K.c_uint8_p * n)(*[a.ctypes.data_as(K.c_uint8_p) for a in inl])
