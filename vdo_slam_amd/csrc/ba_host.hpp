@@ -26,6 +26,7 @@ struct vdo_ba {
   // dense reduced-camera solver (ba_dense.hip), allocated on first use: S [ld][ld], W [ld/64][64][64], rhs [ld]
   double *dense_S = nullptr, *dense_W = nullptr, *dense_rhs = nullptr;
   int64_t dense_ld = 0;
+  bool dense_tiles_ok = true;        // every tile's padded incidence count (256 * ept + 2 * ternary edges) fits VDO_TILE_INC: what k_schur_dense_tile holds per thread
   bool pose_graph_is_paths = true;   // every EdgeSE3 lies on a simple path (the chain preconditioner covers them all)
   int last_solver = 0;            // 2 PCG, 3 dense: what the last trial used
   int pcg_it = 0, pcg_parity = 0, pcg_maxit = 0, pcg_last = 0;      // (pcg_last: iterations the previous solve of this run needed)      // state of the PCG solve of the trial in flight (ba_lm.hip solve_trial / solve_trial_finish)

@@ -486,10 +486,15 @@ __device__ void reduce_chi_body(const BADev& d, int mode_lin, double* lds) {
   const int nt = d.n_tiles, n2 = d.Ep + d.Npr;
   const double* ep_chi = d.part_chi + 2 * (int64_t)nt;
   double a0 = 0, a1 = 0;
-  if (mode <= 1)
-    for (int i = threadIdx.x; i < nt; i += blockDim.x) { a0 += d.part_chi[i]; a1 += d.part_chi[nt + i]; }
-  if (mode != 1)
-    for (int i = threadIdx.x; i < n2; i += blockDim.x) { a0 += ep_chi[i]; a1 += ep_chi[n2 + i]; }
+  // 256 lanes with stride 256 whatever the workgroup size (k_reduce_chi: 256 threads, the last workgroup of k_finalize_pose: 512): the chi2 of a
+  // linearisation and of an error evaluation at the same estimate are the SAME BITS - ba_lm.hip skips the re-evaluation after an accepted trial on that
+  // (ADVICE r4).  The waves beyond the fourth add zeros, in wave order.
+  if (threadIdx.x < 256) {
+    if (mode <= 1)
+      for (int i = threadIdx.x; i < nt; i += 256) { a0 += d.part_chi[i]; a1 += d.part_chi[nt + i]; }
+    if (mode != 1)
+      for (int i = threadIdx.x; i < n2; i += 256) { a0 += ep_chi[i]; a1 += ep_chi[n2 + i]; }
+  }
   a0 = block_sum1(a0, lds);
   a1 = block_sum1(a1, lds);
   if (threadIdx.x == 0) {

@@ -134,6 +134,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   // VDO_BA_PLACE=0: the edges of a slot's run in pose-sorted order (round 4) instead of the bank-aware placement below (A/B, tools/)
   const int place_mode = std::getenv("VDO_BA_PLACE") ? std::atoi(std::getenv("VDO_BA_PLACE")) : 1;
   long long place_ways = 0, place_groups = 0;
+  bool dense_tiles_ok = true;
   auto close_tile = [&]() {
     if (cur_npts == 0) return;
     // slots: sorted distinct poses
@@ -260,6 +261,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       inc_key[inc_total + nb + nt + j] = (sl << 16) | l2;
     }
     inc_total += nb + 2 * nt;
+    if (nb + 2 * nt > VDO_TILE_INC) dense_tiles_ok = false;      // (the dense assembly keeps VDO_TILE_EPT incidences per thread: ba_lm.hip refuses it for this graph)
     cur.eb_end = (int32_t)eb_old_of_new.size();
     cur.et_end = (int32_t)et_old_of_new.size();
     cur.pt_end = (int32_t)pt_old_of_new.size();
@@ -479,6 +481,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     bool paths = true;
     for (size_t c = 0; c < comp_ok_all.size(); ++c) paths = paths && comp_ok_all[c];
     ba->pose_graph_is_paths = paths;
+    ba->dense_tiles_ok = dense_tiles_ok;
   }
   // incidence index of every (new) edge, for the un-permuting download
   ba->inc_of_eb.resize(Ebp); ba->inc1_of_et.resize(Et); ba->inc2_of_et.resize(Et);

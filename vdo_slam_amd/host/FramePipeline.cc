@@ -419,6 +419,10 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
                              Tcw_last_, p_.K4, &rec, obj_depth.data(), obj_sem.data(), flow3d.data(), olab.data()));
     fc.n_recovered_masks = rec;
   }
+  // vdo_object_chain returns without a synchronisation when there are no object samples (n_o == 0): the asynchronous ingest of this frame's images
+  // (vdo_frame_images_ingest_device on ctx_'s stream) must still be through before the static stage - another stream - and K10 on the ORB context read
+  // the depth map, the flow and the mask (every vdo_frame_images call is host-synchronous for its readers)
+  if (have_last_ && n_o == 0) VDO_TRY(vdo_ctx_synchronize(ctx_));
   mask_final_.store(tag, std::memory_order_release);      // (UpdateMask is through: K10 may sample the mask)
   tick(10); mark(kEvObjChain);
   StaSet nsta; ObjSet nobj;

@@ -317,6 +317,15 @@ VDO_SLAM::System* host_system_create(const char* settings) {
     std::ifstream f(settings);
     if (!f.is_open()) { std::fprintf(stderr, "host_system_create: cannot open %s\n", settings); return nullptr; }
   }
+  {   // what Tracking::Tracking would exit(-1) on - lens distortion (not supported by this build), no image size - refused here with a message instead
+    VDO_SLAM::TrackingSettings t;
+    std::map<std::string, double> raw;
+    if (!VDO_SLAM::read_tracking_settings(settings, t, &raw)) { std::fprintf(stderr, "host_system_create: cannot parse %s\n", settings); return nullptr; }
+    if (t.k1 != 0 || t.k2 != 0 || t.p1 != 0 || t.p2 != 0 || t.k3 != 0) { std::fprintf(stderr, "host_system_create: lens distortion (Camera.k1..k3, p1, p2) is not supported by this build\n"); return nullptr; }
+    if (raw.count("Camera.width") == 0 || raw.count("Camera.height") == 0 || raw["Camera.width"] <= 0 || raw["Camera.height"] <= 0) {
+      std::fprintf(stderr, "host_system_create: Camera.width / Camera.height missing in %s\n", settings); return nullptr;
+    }
+  }
   {
     const char* dev = std::getenv("VDO_DEVICE");
     vdo_ctx* probe = nullptr;
