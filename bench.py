@@ -65,7 +65,7 @@ def sequence_events(warmup, steps):
 def _pmc_traffic_bytes(graph, dims):
     """HBM bytes per k_sweep_tile launch from the committed PMC summary, if it was taken on this very graph AND this very tile layout (else None)."""
     import re
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r04_sweep_pmc_hbm_traffic.txt")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05_sweep_pmc_hbm_traffic.txt")
     try:
         txt = open(path).read()
         m = re.search(r"n_eb (\d+) n_et (\d+) n_point (\d+) tiles (\d+) eb_entries (\d+)", txt)
@@ -75,6 +75,9 @@ def _pmc_traffic_bytes(graph, dims):
     except OSError:
         pass
     return None
+
+
+_PMC_EXTRA = {}        # SQ counters of the sweep kernel per launch (the third pass of _pmc_traffic_live)
 
 
 def _pmc_traffic_live(n_static, graph, dims, timeout_s=150):
@@ -103,6 +106,21 @@ def _pmc_traffic_live(n_static, graph, dims, timeout_s=150):
             if not row or not row[1]:
                 return None
             tot[ctr] = float(row[0]) * 1024.0                    # (the counters are in KB)
+        _PMC_EXTRA.clear()
+        try:                                                     # a third pass: what the SQ saw (VALU issue, LDS pipe) - reported beside the HBM fraction, never instead of it
+            out = os.path.join(tmp, "SQ")
+            ctrs = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT"]
+            r = subprocess.run(["rocprofv3", "--pmc"] + ctrs + ["-d", out, "--", sys.executable, os.path.join(here, "tools", "sweep_only.py"), str(n_static)],
+                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, text=True)
+            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+            if r.returncode == 0 and dbs:
+                con = sqlite3.connect(dbs[0])
+                for c in ctrs:
+                    row = con.execute("select avg(value), count(*) from counters_collection where kernel_name like '%k_sweep_tile<true%' and counter_name = ?", (c,)).fetchone()
+                    if row and row[1]:
+                        _PMC_EXTRA[c] = float(row[0])
+        except Exception:                                        # noqa: BLE001
+            pass
         return 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]       # (gfx950 tallies 128-B read requests at 64 B: FETCH_SIZE doubled)
     except Exception:
         return None
@@ -260,7 +278,7 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--steps", type=int, default=148, help="timed frames; 148 + 5 warm-up = the 153 frames of KITTI-0000 (example/vdo_slam.cc:96)")
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the batch-BA / roofline legs")
@@ -668,9 +686,9 @@ def main():
         gr = synth.make_ba_graph(200, args.roofline_static, 10, 1500, seed=7 + rank)
         bar = BatchBA(ctx_ba, gr)
         bar.linearize()
-        bar.profile_linearize(100)                                # untimed warm-up, ~40 ms of the same launches: the device has idled while the host built the graph, and its clocks take tens of
-                                                                  # milliseconds of load to come back (tools/sweep_repeat_probe.py: 0.140 ms per launch in the first 40 launches, 0.110-0.115 after 150)
-        sweep_ms, lin_ms, dims = bar.profile_linearize(30)       # hipEvents on the stream the kernels run on (vdo_ba_profile_linearize)
+        bar.profile_linearize(300)                                # untimed warm-up, ~70 ms of the same launches: the device has idled while the host built the graph, and its clocks take tens of
+                                                                  # milliseconds of load to come back (tools/sweep_repeat_probe.py: the first 40 launches of a process take 1.3x the steady time)
+        sweep_ms, lin_ms, dims = bar.profile_linearize(100)      # hipEvents on the stream the kernels run on (vdo_ba_profile_linearize): 100 launches of the sweep, then 100 linearisations
         from vdo_slam_amd.ba import linearize_byte_model
         model = linearize_byte_model(gr, dims)
         alg_bytes = 208 * gr.n_eb + 452 * gr.n_et + 96 * gr.n_point     # SURVEY.md §8d B_sweep terms of this kernel
@@ -690,14 +708,25 @@ def main():
                     "cannot exceed 1.  `survey_8d_rate` divides the bytes of SURVEY 8d's formula (208 B per EdgeSE3PointXYZ, 452 B per ternary edge, 96 B per point) "
                     "by the same time: the kernel moves a fifth of them (8 B of a 6x3 block instead of 144 B, 16 B of edge inputs instead of 64 B, one scalar for the "
                     "landmark block), so that rate is NOT a bandwidth.  `linearize_*`: sweep + expansion of the pose blocks + pose-pose edges + chi2 (one "
-                    "BlockSolver::buildSystem).  What bounds the sweep is VALU issue (DESIGN.md 4.1).",
+                    "BlockSolver::buildSystem).  `valu` / `lds`: how busy the two on-chip units next in line are (DESIGN.md 4.1).",
             "layout": dims,
             "traffic_source": ("live: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/sweep_only.py on this very graph and tile layout, run by this bench in child "
                                "processes; the duration is this process's own (hipEvents)") if traffic_live is not None else
-                              (("profiles/r04_sweep_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/sweep_only.py on this very graph and tile layout "
-                                "(tools/profile_round4_sweep.sh; the live passes of this run were not available); the duration is live") if traffic is not None else None),
+                              (("profiles/r05_sweep_pmc_hbm_traffic.txt: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes over tools/sweep_only.py on this very graph and tile layout "
+                                "(tools/profile_round5_sweep.sh; the live passes of this run were not available); the duration is live") if traffic is not None else None),
             "graph_vs_infinity_cache": f"{model['sweep'] / 1e6:.0f} MB per sweep launch by the byte model vs 256 MB of Infinity Cache: the traffic is HBM traffic",
-            "units_per_launch": {"EdgeSE3PointXYZ": int(gr.n_eb), "LandmarkMotionTernaryEdge": int(gr.n_et), "points": int(gr.n_point), "poses": int(gr.n_pose)}}
+            "units_per_launch": {"EdgeSE3PointXYZ": int(gr.n_eb), "LandmarkMotionTernaryEdge": int(gr.n_et), "points": int(gr.n_point), "poses": int(gr.n_pose)},
+            "timed_launches": 100, "warmup_launches": 300}
+        if _PMC_EXTRA.get("SQ_INSTS_VALU"):
+            # what else the kernel is near: VALU issue (every VALU instruction of a wave64 occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs) and the LDS pipe
+            # (SQ_ACTIVE_INST_LDS counts quad-cycles per CU) over the kernel's duration at the device's clock - fractions of those two ceilings beside the HBM one
+            clk = torch.cuda.get_device_properties(local).clock_rate * 1e3            # Hz
+            cyc = clk * sweep_ms * 1e-3
+            out["roofline"]["valu"] = {"insts_per_launch": _PMC_EXTRA["SQ_INSTS_VALU"], "issue_frac": _PMC_EXTRA["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cyc, "clock_hz": clk,
+                                       "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x clock x kernel time)"}
+            if _PMC_EXTRA.get("SQ_ACTIVE_INST_LDS"):
+                out["roofline"]["lds"] = {"active_quad_cycles_per_launch": _PMC_EXTRA["SQ_ACTIVE_INST_LDS"], "bank_conflict_cycles_per_launch": _PMC_EXTRA.get("SQ_LDS_BANK_CONFLICT"),
+                                          "busy_frac": _PMC_EXTRA["SQ_ACTIVE_INST_LDS"] * 4.0 / 256.0 / cyc, "note": "SQ_ACTIVE_INST_LDS x 4 / (256 CUs x clock x kernel time)"}
         bar.close()
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cb_ms, cb_sweep, cb_its = cpu_baseline_batch(g)

@@ -137,8 +137,10 @@ typedef struct vdo_ba vdo_ba;
 /* Uploads the graph to HBM (SoA, resident until destroy) and builds the chain structure.
  * Limits (g2o has none; VDO_ERR_UNSUPPORTED names the offending track): a landmark track - one static point, or a chain of dynamic
  * points linked by LandmarkMotionTernaryEdges - is processed by ONE workgroup and must fit its tile: <= 256 points, <= 1536 edge
- * incidences, <= 100 distinct pose vertices (cameras + motions), and sum over those poses of ceil(observations / 6) <= 256.  The graphs
- * the reference builds are far inside (a track lives <= a few dozen frames); a static point observed from more than 100 frames is not. */
+ * incidences, <= 256 distinct pose vertices (cameras + motions), and sum over those poses of ceil(observations / 6) <= 256.  A static
+ * point may therefore be observed from up to 256 frames (every frame of the 153-frame KITTI-0000 sequence), a dynamic chain may run over
+ * up to 128 frames (its points bring a camera and a motion vertex each); a graph that holds such a track pays with fewer resident
+ * workgroups per CU (the tile kernels' LDS grows with the pose slots of the largest tile) and has no dense solver beyond ~200 slots. */
 int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out);
 int vdo_ba_destroy(vdo_ba* ba);
 /* K18: `repeat` back-to-back linearisation sweeps (errors + Jacobians + Huber + block

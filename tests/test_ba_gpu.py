@@ -527,3 +527,52 @@ def test_lm_reuses_the_accepted_trials_errors(ctx, monkeypatch):
         assert np.abs(a[6] - b[6]).max() <= 1e-11 * b[6].max()
         assert np.abs(a[7] - b[7]).max() <= 1e-9 and np.abs(a[8] - b[8]).max() <= 1e-9 * np.abs(b[8]).max()
     assert out[0][2] >= 3
+
+
+@pytest.mark.parametrize("frames", [153, 230])
+def test_static_landmarks_seen_in_every_frame_of_a_kitti_length_sequence(ctx, oracle, frames):
+    """g2o has no limit on how many poses observe a landmark; rounds 1-4 refused a track touching more than 100 pose vertices
+    (kHardSlots) - a static point seen in all 153 frames of KITTI-0000 failed vdo_ba_create.  The limit is 256 now (one thread per pose slot stages
+    its pose; the tile kernels ask for the LDS they need): a 153-frame graph - and a 230-frame one - with 25 landmarks observed from EVERY camera
+    linearises like the oracle and takes the oracle's Levenberg trajectory."""
+    import dataclasses
+    from vdo_slam_amd.ba import BatchBA
+    g0 = synth.make_ba_graph(frames, 1500, 1, 40, seed=3)
+    rng = np.random.default_rng(8)
+    cams = np.arange(g0.n_cam)
+    # 25 static points (never an end of a ternary edge): one more observation from every camera that does not see them yet
+    dyn = np.zeros(g0.n_point, bool); dyn[g0.et_p1] = True; dyn[g0.et_p2] = True
+    pick = np.nonzero(~dyn)[0][:: max(1, int((~dyn).sum() // 25))][:25]
+    seen = set(zip(g0.eb_pose.tolist(), g0.eb_point.tolist()))
+    ep, el, ez = [], [], []
+    for l in pick:
+        for c in cams:
+            if (int(c), int(l)) in seen:
+                continue
+            R = g0.pose[c, :9].reshape(3, 3); t = g0.pose[c, 9:]
+            z = R.T @ (g0.point[l] - t) + rng.normal(0, 0.05, 3)
+            ep.append(c); el.append(l); ez.append(np.float32(z).astype(np.float64))
+    g = dataclasses.replace(g0, eb_pose=np.concatenate([g0.eb_pose, np.array(ep, np.int32)]), eb_point=np.concatenate([g0.eb_point, np.array(el, np.int32)]),
+                            eb_z=np.ascontiguousarray(np.concatenate([g0.eb_z, np.array(ez).T], 1)), eb_w=np.concatenate([g0.eb_w, np.full(len(ep), g0.eb_w[0])]))
+    per_point = np.bincount(g.eb_point, minlength=g.n_point)
+    assert per_point[pick].min() >= frames
+    ba = BatchBA(ctx, g)
+    assert ba.dims()["max_slots"] >= frames
+    ba.linearize()
+    S = ba.system()
+    R_ = _oracle_system(oracle, g)
+    for name in BLOCKS:
+        a, b = getattr(S, name), getattr(R_, name)
+        if b.size:
+            assert np.abs(a - b).max() <= BLOCK_TOL * _scale(name, R_) + 1e-300, name
+    assert abs(S.chi2 - R_.chi2) <= 1e-12 * abs(R_.chi2)
+    st = ba.optimize(max_iterations=4, gain_threshold=-1.0)
+    gc, keep = K.graph_to_c(g)
+    opt = K.LMOptionsC(4, -1.0, 0, 0, 0.0, 0)
+    so = K.LMStatsC(); po = np.zeros_like(g.pose); qo = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(po), K._dp(qo), C.byref(so)) == 0
+    assert st.iterations == so.iterations and st.total_trials == so.total_trials
+    assert abs(st.final_chi2 - so.final_chi2) <= 1e-6 * so.final_chi2
+    pose, pt = ba.estimates()
+    np.testing.assert_allclose(pose, po, rtol=0, atol=1e-4 * max(1.0, np.abs(po).max()))
+    ba.close()

@@ -150,4 +150,14 @@ void launch_dense_rhs(const BADev& d, double* rhs, int64_t ld, hipStream_t s);
 // ---- ba_dense.hip
 void launch_dense_solve(const BADev& d, double* S, int64_t ld, double* Winv, double* rhs, hipStream_t s);    // MFMA Cholesky + substitutions -> xp
 
+size_t dense_tile_lds(const BADev& d);      // dynamic LDS of k_schur_dense_tile (ba_solve.hip)
+// A tile kernel's dynamic LDS grows with the pose slots of the graph's largest tile (a landmark seen from 150 frames needs 150 slots): past the runtime's
+// default limit the launch has to say so (per launch: the attribute is per device and such graphs are rare - nothing is cached).
+template <typename Kernel>
+inline size_t raise_lds(Kernel kernel, size_t bytes) {
+  if (bytes > (size_t)(48 * 1024)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  return bytes;
+}
+#define VDO_LDS_MAX_BYTES (160 * 1024)
+
 }  // namespace vdo

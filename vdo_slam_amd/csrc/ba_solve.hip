@@ -1559,7 +1559,7 @@ void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda,
   // most tiles of the bench graph carry a dozen slots, the ones with the long dynamic tracks 81: one workgroup per tile left the device waiting
   // for those (1.82 ms).  VDO_BA_DENSE_CHUNK overrides.
   const int chunk = std::getenv("VDO_BA_DENSE_CHUNK") ? std::max(1, std::atoi(std::getenv("VDO_BA_DENSE_CHUNK"))) : VDO_BA_DENSE_CHUNK_DEFAULT;
-  if (d.n_tiles) hipLaunchKernelGGL(k_schur_dense_tile, dim3(d.n_tiles, (d.max_slots + chunk - 1) / chunk), dim3(VDO_TILE_THREADS), dense_tile_lds(d), s, d, S, ld, chunk);
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_dense_tile, dim3(d.n_tiles, (d.max_slots + chunk - 1) / chunk), dim3(VDO_TILE_THREADS), raise_lds(k_schur_dense_tile, dense_tile_lds(d)), s, d, S, ld, chunk);
   if (d.sharded) R(S, ld * ld);                     // landmark-side contributions of every rank (all-reduce of S)
   const int64_t n = 36 * (int64_t)(d.P + d.Ep) + (ld - 6 * (int64_t)d.P);
   hipLaunchKernelGGL(k_dense_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, S, ld, lambda);
@@ -1579,7 +1579,7 @@ void launch_dense_rhs(const BADev& d, double* rhs, int64_t ld, hipStream_t s) {
 static size_t schur_lds(const BADev& d) { return (6 * VDO_TILE_PTS + 24 * (size_t)d.max_slots + ((size_t)d.max_slots + 1) / 2) * sizeof(double); }      // (+ the slots' row ids, int32)
 
 void launch_expand_binc(const BADev& d, hipStream_t s) {
-  if (d.n_tiles) hipLaunchKernelGGL(k_expand_binc, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), (12 * (size_t)d.max_slots + 3 * VDO_TILE_PTS) * sizeof(double), s, d);
+  if (d.n_tiles) hipLaunchKernelGGL(k_expand_binc, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_expand_binc, (12 * (size_t)d.max_slots + 3 * VDO_TILE_PTS) * sizeof(double)), s, d);
 }
 
 static int red_blocks(const BADev& d) { return (int)std::min<int64_t>(256, std::max<int64_t>(1, (3 * (int64_t)d.L + 6 * (int64_t)d.P + 4095) / 4096)); }
@@ -1602,8 +1602,8 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
   if (precond) {
     const size_t lds = (33 * (size_t)d.max_slots + 3 * VDO_TILE_PTS + ((size_t)d.max_slots + 1) / 2) * sizeof(double);
     const int nd = d.n_tiles < 1024 ? d.n_tiles : std::min(d.n_dyn_tiles, d.n_tiles);       // tiles with dynamic tracks come first in the launch order (a graph of few tiles: one launch - a second one costs more than the registers)
-    if (nd > 0) hipLaunchKernelGGL(k_precond_tile<true>, dim3(nd), dim3(VDO_TILE_THREADS), lds, s, d, 0);
-    if (d.n_tiles > nd) hipLaunchKernelGGL(k_precond_tile<false>, dim3(d.n_tiles - nd), dim3(VDO_TILE_THREADS), lds, s, d, nd);
+    if (nd > 0) hipLaunchKernelGGL(k_precond_tile<true>, dim3(nd), dim3(VDO_TILE_THREADS), raise_lds(k_precond_tile<true>, lds), s, d, 0);
+    if (d.n_tiles > nd) hipLaunchKernelGGL(k_precond_tile<false>, dim3(d.n_tiles - nd), dim3(VDO_TILE_THREADS), raise_lds(k_precond_tile<false>, lds), s, d, nd);
   }
   const dim3 g((d.P + 3) / 4), b(256);
   if (!precond) { }
@@ -1620,7 +1620,7 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
     hipLaunchKernelGGL(k_pchain_factor, dim3(d.n_pchains), dim3(64), 0, s, d);
     if (d.pc_lds && d.pc_nwave > 1) hipLaunchKernelGGL(k_pchain_prefix, dim3(d.n_pchains), dim3(64 * d.pc_nwave), 0, s, d);
   }
-  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), sr, d, (const double*)nullptr, (const double*)nullptr);
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<1>, schur_lds(d)), sr, d, (const double*)nullptr, (const double*)nullptr);
   hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, sr, d, d.qs, 0);
   if (d.sharded) R(d.qs, 6 * (int64_t)d.P);
   if (two) { hipEventRecord(join, side); hipStreamWaitEvent(s, join, 0); }
@@ -1645,7 +1645,7 @@ static size_t pc_strip_bytes(const BADev& d) {
 void launch_pcg_init(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_pcg_chain<1>, dim3(d.n_pchains), dim3(64 * d.pc_nwave), pc_strip_bytes(d), s, d, 0.0, 0, 0); }
 
 void launch_pcg_iter(const BADev& d, double lambda, double tol2, int parity, hipStream_t s, const Reducer& R) {
-  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<0>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.zp, (const double*)(parity ? d.pp2 : d.pp));
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<0>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<0>, schur_lds(d)), s, d, (const double*)d.zp, (const double*)(parity ? d.pp2 : d.pp));
   const int nq = (d.P + 3) / 4;
   if (d.sharded) {
     hipLaunchKernelGGL(k_gather_q, dim3(nq), dim3(256), 0, s, d, d.qs, 1);
@@ -1656,7 +1656,7 @@ void launch_pcg_iter(const BADev& d, double lambda, double tol2, int parity, hip
 }
 
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s) {
-  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<2>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), schur_lds(d), s, d, (const double*)d.xp, (const double*)nullptr);
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<2>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<2>, schur_lds(d)), s, d, (const double*)d.xp, (const double*)nullptr);
   const int nb = red_blocks(d);
   hipLaunchKernelGGL(k_update, dim3(nb), dim3(1024), 0, s, d, lambda, ortho ? 1 : 0);
   hipLaunchKernelGGL(k_reduce_part, dim3(1), dim3(256), 0, s, d, nb, 0);

@@ -518,8 +518,8 @@ static double* ep_chi_buf(const BADev& d) { return d.part_chi + 2 * (int64_t)d.n
 void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R) {
   const size_t lds = sweep_lds_doubles(d.max_slots, false, d.ps_stride) * sizeof(double);
   if (d.n_tiles) {
-    if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<false, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, which);
-    else hipLaunchKernelGGL((k_sweep_tile<false, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, which);
+    if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<false, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<false, true>, lds), s, d, which);
+    else hipLaunchKernelGGL((k_sweep_tile<false, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<false, false>, lds), s, d, which);
   }
   launch_posepose(d, which, false, ep_chi_buf(d), s);
   if (!d.sharded) { hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 0); return; }
@@ -531,8 +531,8 @@ void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R) {
 void launch_sweep_only(const BADev& d, hipStream_t s) {
   const size_t lds = sweep_lds_doubles(d.max_slots, true, d.ps_stride) * sizeof(double);
   if (!d.n_tiles) return;
-  if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<true, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, 0);
-  else hipLaunchKernelGGL((k_sweep_tile<true, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), lds, s, d, 0);
+  if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<true, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<true, true>, lds), s, d, 0);
+  else hipLaunchKernelGGL((k_sweep_tile<true, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<true, false>, lds), s, d, 0);
 }
 
 void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R) {

@@ -28,7 +28,8 @@ int upload(T** dst, const T* src, size_t n, hipStream_t s) {
 }
 
 constexpr int kSoftSlots = 64;     // normal tiles stay below this many pose slots
-constexpr int kHardSlots = 100;    // a single long chain may use up to this many (LDS bound)
+constexpr int kHardSlots = 256;    // a single long track may use up to this many: one thread per slot stages its pose, and 256 slots are 75 KB of the sweep's LDS (two workgroups per
+                                   // CU instead of four - paid only by graphs that hold such a track).  Rounds 1-4: 100 - a static landmark seen in all 153 frames of KITTI-0000 was refused.
 
 }  // namespace
 
@@ -498,6 +499,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   BADev& d = ba->d;
   d.P = P; d.L = L; d.Eb = Ebp; d.Et = Et; d.Ep = Ep; d.Npr = Npr; d.Ninc = Ebp + 2 * Et;
   d.n_tiles = n_tiles; d.NPS = NPS; d.n_chains = n_chains; d.max_slots = max_slots;
+  if (dense_tile_lds(d) > (size_t)VDO_LDS_MAX_BYTES) ba->dense_tiles_ok = false;      // (a tile of > ~200 pose slots: the dense assembly's workgroup no longer fits the LDS; PCG does - 76 KB at 256 slots)
   d.huber_eb = g->huber_eb; d.huber_et = g->huber_et; d.huber_ep = g->huber_ep;
   d.dsqr_eb = (double)(float)(g->huber_eb * g->huber_eb);   // float member, robust_kernel_impl.h:84
   d.dsqr_et = (double)(float)(g->huber_et * g->huber_et);
