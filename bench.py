@@ -720,7 +720,8 @@ def main():
         if _PMC_EXTRA.get("SQ_INSTS_VALU"):
             # what else the kernel is near: VALU issue (every VALU instruction of a wave64 occupies its SIMD for 4 cycles; 256 CUs x 4 SIMDs) and the LDS pipe
             # (SQ_ACTIVE_INST_LDS counts quad-cycles per CU) over the kernel's duration at the device's clock - fractions of those two ceilings beside the HBM one
-            clk = torch.cuda.get_device_properties(local).clock_rate * 1e3            # Hz
+            prop = torch.cuda.get_device_properties(local)
+            clk = float(getattr(prop, "clock_rate", 0) or 2.4e6) * 1e3                # Hz (torch builds without the field: the MI355X's 2.4 GHz)
             cyc = clk * sweep_ms * 1e-3
             out["roofline"]["valu"] = {"insts_per_launch": _PMC_EXTRA["SQ_INSTS_VALU"], "issue_frac": _PMC_EXTRA["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cyc, "clock_hz": clk,
                                        "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x clock x kernel time)"}
@@ -736,6 +737,13 @@ def main():
         out["cpu_baseline"] = {"value": cfps, "unit": "frames/s", "cores": 1, "kind": "port",
                                "sample": f"the first {cn} frames of the same sequence through the same full Track() (oracle, 1 thread)",
                                "ms_per_stage": cstage}
+        # the north star's ">= 30 x the CPU baseline", spelled out: `value` (inputs resident in HBM, the contract's headline) and the number a caller of the
+        # reference's own entry point sees - System::TrackRGBD on host buffers, everything done when the call returns (PCIe inclusive, never `value`)
+        out["speedup_vs_cpu_baseline"] = {"value": out["value"] / cfps,
+                                           "value_host_inputs_sync": (out["value_host_inputs_sync"] / cfps) if "value_host_inputs_sync" in out else None,
+                                           "target": 30.0,
+                                           "note": "the product keeps ~8 host threads busy per sequence (main + helper + ORB thread + quadtree helpers) against a 1-thread baseline; "
+                                                   "cpu_baseline.multi_process is the same CPU code on 8 processes"}
         # ---- the reference's own five clock() brackets (all_timing[0..4]: mask update, camera estimate, object tracking, object estimate per object,
         # map update = RenewFrameInfo; src/Tracking.cc:230-243, 685-703, 1366-1603, 868-1010, 1016-1020), side by side, ms per frame
         pf = out["config"]["host_ms_per_section"]; n_obj_mean = max(out["config"]["per_frame_mean"]["n_objects"], 1e-9)

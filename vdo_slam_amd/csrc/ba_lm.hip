@@ -74,9 +74,8 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
   hipStream_t s = ba->ctx->stream;
   const bool small = 6 * (int64_t)d.P <= kDenseMaxUnknowns;
   bool dense = opt->solver == 3 || (opt->solver == 0 && small && ba->dense_tiles_ok && (!ba->pose_graph_is_paths || ba->last_solver == 3));
-  // (a tile is closed on its REAL incidence count; its EdgeSE3PointXYZ block is padded to 256 * ept entries, and with many ternary edges on top
-  //  the padded count can pass the VDO_TILE_INC incidences the dense assembly keeps per workgroup - checked when the tiles are built, capi_ba.hip)
-  if (dense && !ba->dense_tiles_ok) return set_error(VDO_ERR_UNSUPPORTED, "dense solver: a tile of this graph holds more than %d padded incidences (EdgeSE3PointXYZ block + ternary edges); use the PCG solver", VDO_TILE_INC);
+  // (dense_tiles_ok: the dense assembly's workgroup fits - padded incidences per thread, LDS at the graph's largest tile; capi_ba.hip)
+  if (dense && !ba->dense_tiles_ok) return set_error(VDO_ERR_UNSUPPORTED, "dense solver: a tile of this graph does not fit the dense assembly (more than %d pose slots of LDS); use the PCG solver", 200);
   if (dense && !small && opt->solver == 3) return set_error(VDO_ERR_UNSUPPORTED, "dense solver: %lld unknowns exceed %lld", 6LL * d.P, (long long)kDenseMaxUnknowns);
   launch_factor_and_rhs(d, lambda, s, ba->red, ba->side, ba->ev_fork, ba->ev_join, !dense);
   if (dense) {

@@ -101,11 +101,17 @@ __device__ __forceinline__ void rot_block_dev(const double (*dq)[9], const doubl
 
 __device__ __forceinline__ void edge_se3_dev(const IsoD& Z, const IsoD& Xi, const IsoD& Xj, double* e, double* Ji, double* Jj) {
   const IsoD A = iso_inv(Z);
+  // computeError multiplies left to right - (Z^-1 Xi^-1) Xj, edge_se3.cpp:77-82 -, the gradient forms E = A (Xi^-1 Xj) (isometry3d_gradients.h:203-206):
+  // the two differ in the last bit, and near convergence of a pure pose graph that decides a Levenberg trial (found by compiling the reference's own file:
+  // oracle/_ref, tests/test_ref_g2o.py)
+  {
+    const IsoD Ee = iso_mul(iso_mul(A, iso_inv(Xi)), Xj);
+    const D3 q = compact_quat(Ee.r);
+    e[0] = Ee.t.x; e[1] = Ee.t.y; e[2] = Ee.t.z; e[3] = q.x; e[4] = q.y; e[5] = q.z;
+  }
+  if (!Ji) return;
   const IsoD B = iso_mul(iso_inv(Xi), Xj);
   const IsoD E = iso_mul(A, B);
-  const D3 q = compact_quat(E.r);
-  e[0] = E.t.x; e[1] = E.t.y; e[2] = E.t.z; e[3] = q.x; e[4] = q.y; e[5] = q.z;
-  if (!Ji) return;
   #pragma unroll
   for (int i = 0; i < 36; ++i) Ji[i] = Jj[i] = 0;
   double dq[3][9];

@@ -1287,6 +1287,11 @@ __global__ __launch_bounds__(256) void k_dense_init(BADev d, double* __restrict_
 // One workgroup per tile; for every pose slot s of the tile the six unit vectors e_(s,b) go through B^T, the landmark chain
 // solves and B at once (6 right-hand sides); the resulting 6x6 blocks against every slot r that shares a point (or a
 // dynamic track) with s are subtracted from S with fp64 atomics.  Only the points reached from slot s are touched.
+// Incidences a thread of the dense assembly keeps: the tile's PADDED count - its thread-transposed EdgeSE3PointXYZ block of 256 * ept <= 1536 entries,
+// then two incidences per ternary edge (<= 255 of those in a tile of 256 points) - is at most 256 * (VDO_TILE_EPT + 2).  (Rounds 3-4 kept VDO_TILE_EPT
+// and silently dropped what lay beyond 1536: the ternary incidences of a tile whose block is full - ADVICE r4.)
+#define VDO_DENSE_EPT (VDO_TILE_EPT + 2)
+
 __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, double* __restrict__ S, int64_t ld, int chunk) {
   extern __shared__ __attribute__((aligned(16))) double smem[];
   const Tile T = d.tiles[blockIdx.x];
@@ -1325,14 +1330,14 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
 #pragma unroll
     for (int k = 0; k < 3; ++k) pv[k] = point[min(tid + k * VDO_TILE_THREADS, max(3 * npts - 1, 0))];
   }
-  int key[VDO_TILE_EPT], kind[VDO_TILE_EPT];       // (<= VDO_TILE_INC = 256 * VDO_TILE_EPT incidences per tile)
-  FInc F[VDO_TILE_EPT];
-  double we[VDO_TILE_EPT];
+  int key[VDO_DENSE_EPT], kind[VDO_DENSE_EPT];       // (<= 256 * VDO_DENSE_EPT padded incidences per tile)
+  FInc F[VDO_DENSE_EPT];
+  double we[VDO_DENSE_EPT];
 #pragma unroll
-  for (int j = 0; j < VDO_TILE_EPT; ++j) { key[j] = -1; kind[j] = 1; we[j] = 0.0; }
+  for (int j = 0; j < VDO_DENSE_EPT; ++j) { key[j] = -1; kind[j] = 1; we[j] = 0.0; }
   if (ninc > 0) {                                  // (uniform)
 #pragma unroll
-    for (int j = 0; j < VDO_TILE_EPT; ++j) {
+    for (int j = 0; j < VDO_DENSE_EPT; ++j) {
       const int li = tid + VDO_TILE_THREADS * j, lic = min(li, ninc - 1);
       int64_t fidx;
       inc_locate(T, lic, d.Eb, kind[j], fidx);
@@ -1387,7 +1392,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     if (choff[c + 1] - choff[c] >= 2) mch[atomicAdd(&mch[VDO_TILE_PTS / 2], 1)] = c;       // (any order: the chains are independent of each other)
   AP_TICK(0);
 #pragma unroll
-  for (int j = 0; j < VDO_TILE_EPT; ++j) F[j] = key[j] >= 0 ? make_f(d, T, tid + VDO_TILE_THREADS * j, kind[j], key[j], we[j], slotW, pts) : FInc{0, 0, 0, 0};
+  for (int j = 0; j < VDO_DENSE_EPT; ++j) F[j] = key[j] >= 0 ? make_f(d, T, tid + VDO_TILE_THREADS * j, kind[j], key[j], we[j], slotW, pts) : FInc{0, 0, 0, 0};
   AP_TICK(1);
   for (int s = s_begin; s < s_end; ++s) {
     __syncthreads();
@@ -1398,7 +1403,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
     AP_TICK(2);
     // pass A: u_b[l] += row b of the explicit 6x3 block of every incidence (s, l)
 #pragma unroll
-    for (int j = 0; j < VDO_TILE_EPT; ++j) {
+    for (int j = 0; j < VDO_DENSE_EPT; ++j) {
       if (key[j] >= 0 && (key[j] >> 16) == s) {
         double B[18];
         expand_block(kind[j], F[j], slotW + 12 * s, B);
@@ -1478,7 +1483,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       for (int i = 0; i < 36; ++i) g36[i] = 0.0;
       bool mine = false;
 #pragma unroll
-      for (int j = 0; j < VDO_TILE_EPT; ++j) {
+      for (int j = 0; j < VDO_DENSE_EPT; ++j) {
         if (j < T.ept && key[j] >= 0 && rt >= s && touched[key[j] & 0xffff]) {
           const int lp = key[j] & 0xffff;
           mine = true;
@@ -1507,7 +1512,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
       }
     }
 #pragma unroll
-    for (int j = 0; j < VDO_TILE_EPT; ++j) {
+    for (int j = 0; j < VDO_DENSE_EPT; ++j) {
       if (j < T.ept) continue;                                     // (uniform)
       const bool on = key[j] >= 0 && (key[j] >> 16) >= s && touched[key[j] & 0xffff];
       const int r = on ? (key[j] >> 16) : -1, lp = on ? (key[j] & 0xffff) : 0;

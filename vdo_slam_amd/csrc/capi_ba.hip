@@ -262,7 +262,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       inc_key[inc_total + nb + nt + j] = (sl << 16) | l2;
     }
     inc_total += nb + 2 * nt;
-    if (nb + 2 * nt > VDO_TILE_INC) dense_tiles_ok = false;      // (the dense assembly keeps VDO_TILE_EPT incidences per thread: ba_lm.hip refuses it for this graph)
+    if (nb + 2 * nt > VDO_TILE_THREADS * (VDO_TILE_EPT + 2)) dense_tiles_ok = false;      // (the dense assembly keeps VDO_TILE_EPT + 2 incidences per thread - cannot happen: nb <= 1536, nt < 256; ba_lm.hip would refuse the solver)
     cur.eb_end = (int32_t)eb_old_of_new.size();
     cur.et_end = (int32_t)et_old_of_new.size();
     cur.pt_end = (int32_t)pt_old_of_new.size();
