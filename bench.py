@@ -494,7 +494,7 @@ def main():
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64 (LM, RANSAC) / u8,i32,f32 (front-end, tracking)", "data": "synthetic",
         "config": {"workload": "KITTI-0000-shaped TrackRGBD per frame (C++ FramePipeline over the C-ABI, full Track() incl. \"Save Graph Structure\": every frame appended to the GraphStore of the batch optimisers): K15 UpdateMask, K1 depth, K11 propagation, "
-                               "RANSAC-P3P + motion-model initialisers, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, "
+                               "RANSAC (AP3P) + EPnP + motion-model initialisers, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, "
                                "joint pose+flow LM for the camera (<=1200 matches) and every tracked object (ref_quirks=1) built from the frame's own correspondences, "
                                "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets, graph store; "
                                f"geometrically consistent synthetic sequence of {n_seq} frames: {N_OBJECTS} moving boxes (4 turning, yaw rate <= 0.05 rad/frame), flow noise sigma {FLOW_SIGMA} px, "

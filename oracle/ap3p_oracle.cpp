@@ -6,9 +6,13 @@
 // RANSAC sample picks among them by reprojection error.  OpenCV is not in this image: this is a restatement from the paper and the
 // published layout of that file - PARITY UNPINNED (order and rounding of the solutions cannot be checked against OpenCV here).
 // What IS checked (tests/test_oracle_ap3p.py): every solution is a rotation that maps the three world points onto their bearings, the
-// true pose is among them, and the solution SET equals Grunert's (oracle/p3p_oracle.cpp) - the claim the product's choice of Grunert
-// rests on (same geometric solutions, other rounding at the 0.4 px gate).  The product (csrc/ransac.hip) runs Grunert;
-// vdo_oracle_ap3p_ransac is the reference's RANSAC with this solver in it, for comparing the two on whole problems.
+// true pose is among them, and the solutions from real roots in front of the camera equal Grunert's (oracle/p3p_oracle.cpp).
+// Two forms live here.  (1) the complex-arithmetic form above (std::complex, libm pow / cbrt / sqrt): vdo_oracle_ap3p_ransac - shares
+// only the algebra with the product, the independent check.  (2) since round 5 the LIBM-FREE form (`lf`: Ferrari in real arithmetic,
+// correctly rounded operations only, the same sequence as csrc/ransac.hip k_ap3p_hyp): vdo_oracle_ap3p_lf*, what
+// vdo_oracle_pnp_ransac_refit (p3p_oracle.cpp) runs by default - the product's default minimal solver, bit for bit.  The two forms are
+// compared in tests/test_oracle_ap3p.py::test_libm_free_form_equals_the_complex_form.  Hypotheses leave through a polar
+// orthogonalisation, as cv::Rodrigues (matrix -> vector -> matrix, an SVD inside) does on the way out of solvePnPRansac.
 #include <cfloat>
 #include <cmath>
 #include <complex>

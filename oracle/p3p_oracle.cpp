@@ -5,9 +5,9 @@
 //   * cv::RNG (multiply-with-carry, coefficient 4164903690, seed (uint64)-1 in RANSACPointSetRegistrator::run),
 //     subsets of 4 distinct indices drawn by rejection (getSubset);
 //   * minimal solver on the first 3 points, the 4th picks among the <= 4 solutions by reprojection error
-//     (p3p::solve with 4 points).  The solver here is Grunert's quartic in v = d3/d1 (coefficients derived
-//     symbolically, see tests/test_oracle_p3p.py) + absolute orientation of the 3 points; AP3P returns the same
-//     geometric solutions;
+//     (p3p::solve / ap3p::solve with 4 points).  Default since round 5: AP3P (ap3p_oracle.cpp, the libm-free form).
+//     `refit & 2`: Grunert's quartic in v = d3/d1 (coefficients derived symbolically, see tests/test_oracle_p3p.py) +
+//     absolute orientation of the 3 points - rounds 1-4's solver; AP3P returns the same geometric solutions (+ mirrored ones);
 //   * inliers: squared reprojection error <= thr^2 (findInliers); the iteration budget shrinks with
 //     RANSACUpdateNumIters(confidence, outlier ratio, 4, niters) whenever a better model is found.
 //   * the final re-estimation of the winning model on its inliers by EPnP (OpenCV >= 3.3): epnp_oracle.hpp,
