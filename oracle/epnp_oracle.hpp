@@ -11,11 +11,11 @@
 //   find_betas_approx_1/2/3          cvSolve(..., CV_SVD): x = V diag(1/w) U^T b, singular values under 2 eps sum(w) dropped
 //   gauss_newton                     5 iterations on the 6x4 system, solved by an orthogonal (Givens) triangularisation
 //   estimate_R_and_t                 SVD of sum (pc - pc0)(pw - pw0)^T, R = U V^T, third ROW of R negated when det R < 0
-// This file is deliberately NOT the product's routine (vdo_slam_amd/csrc/epnp_refit.hpp: running sums for M^T M, QL / cyclic
-// Jacobi eigen-solvers, normal equations for the small systems, Horn's quaternion for the orientation): the two share the
-// algorithm, not the arithmetic, and are compared to 1e-9 (tests/test_oracle_p3p.py, tests/test_ransac_gpu.py) - agreement is
-// evidence, not an identity.  One product decision is mirrored because OpenCV's behaviour there is an artefact: (near-)coplanar
-// point sets (third singular value of PW0^T PW0 below 1e-8 of the first) return err < 0 and the caller keeps the hypothesis.
+// This file is deliberately NOT the product's routine (vdo_slam_amd/csrc/epnp_refit.hpp: running sums for M^T M, tridiagonal QL for its
+// eigenvectors, sums shared by the three candidates, Householder QR, fixed-size stack arrays): written separately, compared to 1e-9
+// (1e-6 on near-planar sets; tests/test_epnp_independent.py, tests/test_ransac_gpu.py).  Since round 5 BOTH follow OpenCV's one-sided
+// Jacobi SVD wherever its conventions decide the result (signs of the principal directions, pseudo-inverse thresholds, R = U V^T with the
+// third-row flip); (near-)coplanar point sets go through like any other (rounds 2-4 returned err < 0 for them on both sides - a liberty).
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -132,13 +132,15 @@ inline Result solve(int n, const double* X, const double* uv, const double* K4) 
   for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s = 0; for (int i = 0; i < n; ++i) s += PW0[3 * (size_t)i + a] * PW0[3 * (size_t)i + b]; PtP[3 * a + b] = s; }
   double dc[3], UCt[9], VCt[9];
   svd_opencv(3, 3, PtP, dc, UCt, VCt);
-  if (!(dc[2] > 1e-8 * dc[0])) return none;             // (near-)coplanar: see the header
   for (int i = 1; i < 4; ++i) { const double k = std::sqrt(dc[i - 1] / n); for (int j = 0; j < 3; ++j) cw[i][j] = cw[0][j] + k * UCt[3 * (i - 1) + j]; }
   // ---- compute_barycentric_coordinates: CC^-1 = V diag(1/w) U^T
   double CC[9], wi[3], Ui[9], Vi[9], CCi[9];
   for (int r = 0; r < 3; ++r) for (int j = 1; j < 4; ++j) CC[3 * r + j - 1] = cw[j][r] - cw[0][r];
   svd_opencv(3, 3, CC, wi, Ui, Vi);                     // (Ui, Vi: rows = vectors)
-  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s = 0; for (int k = 0; k < 3; ++k) s += Vi[3 * k + a] * Ui[3 * k + b] / wi[k]; CCi[3 * a + b] = s; }
+  // (cv::SVD::backSubst: singular values not above 2 eps sum(w) do not contribute - a PSEUDO-inverse: for (near-)coplanar points, whose fourth control
+  // point falls onto the centroid, every point gets a zero fourth barycentric coordinate and the algorithm goes on)
+  const double thr_cc = 2.0 * 2.220446049250313e-16 * (wi[0] + wi[1] + wi[2]);
+  for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) { double s = 0; for (int k = 0; k < 3; ++k) if (wi[k] > thr_cc) s += Vi[3 * k + a] * (1.0 / wi[k]) * Ui[3 * k + b]; CCi[3 * a + b] = s; }
   std::vector<double> al(4 * (size_t)n);
   for (int i = 0; i < n; ++i) {
     double* a = &al[4 * (size_t)i];

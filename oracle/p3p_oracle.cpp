@@ -295,7 +295,7 @@ extern "C" int vdo_oracle_pnp_ransac_refit(int n, const double* X, const double*
     std::vector<double> Xi, ui;
     for (int i = 0; i < n; ++i) if (inl[i]) { Xi.insert(Xi.end(), X + 3 * i, X + 3 * i + 3); ui.insert(ui.end(), uv + 2 * i, uv + 2 * i + 2); }
     const ref_epnp::Result r = ref_epnp::solve((int)(ui.size() / 2), Xi.data(), ui.data(), K4);
-    if (r.err >= 0.0)                                  // (degenerate - coplanar - inliers: the RANSAC hypothesis stays)
+    if (r.err >= 0.0)                                  // (always, since round 5: coplanar inliers go through EPnP like any others; only a non-finite result leaves the hypothesis)
       for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) T_out[4 * i + j] = r.R[3 * i + j]; T_out[4 * i + 3] = r.t[i]; }
   }
   return good;

@@ -102,7 +102,7 @@ class OraclePipeline:
         if self.pnp_refit and self.seed_lib is not None and good >= 4:
             sel = inl[:n] > 0
             Xi, ui, T2 = np.ascontiguousarray(X[sel]), np.ascontiguousarray(uv[sel]), np.zeros(16)
-            if self.seed_lib.product_host_epnp(int(sel.sum()), K._dp(Xi), K._dp(ui), K._dp(K4d), K._dp(T2)) >= 0:      # (coplanar inliers: the hypothesis stays)
+            if self.seed_lib.product_host_epnp(int(sel.sum()), K._dp(Xi), K._dp(ui), K._dp(K4d), K._dp(T2)) >= 0:      # (a non-finite result leaves the hypothesis)
                 # The borrowed refit does not replace the check of that stage: the oracle's OWN RANSAC + EPnP runs as well, and what it
                 # returns - inlier count, inlier mask (everything upstream of the LM) and the refit pose - is logged next to the
                 # borrowed seed; the sequence tests assert identical inliers and poses within 1e-8 (epnp_log).

@@ -68,13 +68,64 @@ def test_control_point_signs_follow_the_same_convention(oracle, product_epnp):
         assert np.abs(Ta - Tb).max() < 1e-8 * max(1.0, np.abs(Tb).max()), (trial, ea, eb)
 
 
-def test_coplanar_points_are_left_to_the_hypothesis_on_both_sides(oracle, product_epnp):
+def _planar_patch(rng, n, flat, sig):
+    """n points on a patch of relative thickness `flat` (the visible face of a box: 0 = an exact plane before the float rounding of the 3-D points), any
+    orientation, 8-25 m away, seen through a small random pose with `sig` px of pixel noise."""
+    from scipy.spatial.transform import Rotation as Rot
+    K4 = np.array(KITTI_K, np.float64)
+    ext = rng.uniform(0.5, 2.0)
+    loc = np.c_[rng.uniform(-ext, ext, n), rng.uniform(-ext / 2, ext / 2, n), rng.normal(0, flat * ext, n) if flat > 0 else np.zeros(n)]
+    Q = np.linalg.qr(rng.normal(size=(3, 3)))[0]
+    Xc = loc @ Q.T + np.array([rng.uniform(-5, 5), rng.uniform(-1, 1), rng.uniform(8, 25)])
+    R = Rot.from_rotvec(rng.normal(0, 0.05, 3)).as_matrix(); t = rng.normal(0, 0.3, 3)
+    Xw = np.ascontiguousarray(((Xc - t) @ R).astype(np.float32).astype(np.float64))          # (the reference's 3-D points are CV_32F)
+    Xc = Xw @ R.T + t
+    uv = np.c_[K4[0] * Xc[:, 0] / Xc[:, 2] + K4[2], K4[1] * Xc[:, 1] / Xc[:, 2] + K4[3]] + rng.normal(0, sig, (n, 2))
+    return Xw, np.ascontiguousarray(uv)
+
+
+def test_near_planar_and_coplanar_sets_agree(oracle, product_epnp):
+    """VERDICT r4 #6.  Rounds 2-4: on NEAR-PLANAR inlier sets (the visible face of a box) the two restatements differed by up to 1.5 in the pose, and
+    (near-)coplanar sets were left to the RANSAC hypothesis on both sides - a liberty.  Both now do what OpenCV 3.4's epnp.cpp does with its own tools (one-sided
+    Jacobi SVD: pseudo-inverse of the control-point matrix and of the beta systems with the 2 eps sum(w) threshold, R = U V^T with the third ROW negated when
+    det < 0): 1 200 patches of relative thickness 0 (exact planes) .. 0.1, 6 .. 400 points, 0 .. 0.3 px: poses within 1e-6 (measured: 6e-8), INCLUDING the
+    ones where OpenCV's row flip returns a rotation that is not the nearest one (mean reprojection error of several pixels - what the reference receives)."""
+    o = _bind(oracle)
+    rng = np.random.default_rng(11)
+    worst, n_flipped = 0.0, 0
+    for trial in range(1200):
+        n = int(rng.choice([6, 12, 30, 100, 400]))
+        flat = float(rng.choice([0.0, 1e-7, 1e-6, 1e-4, 3e-4, 1e-3, 3e-3, 1e-2, 1e-1]))
+        sig = float(rng.choice([0.0, 0.1, 0.3]))
+        Xw, uv = _planar_patch(rng, n, flat, sig)
+        ea, Ta, eb, Tb = _both(product_epnp, o, Xw, uv)
+        assert np.isfinite(Ta).all() and np.isfinite(Tb).all() and ea >= 0 and eb >= 0, (trial, n, flat, sig)
+        d = np.abs(Ta - Tb).max() / max(1.0, np.abs(Tb).max())
+        worst = max(worst, d)
+        assert d <= 1e-6, (trial, n, flat, sig, d, ea, eb)
+        assert abs(ea - eb) <= 1e-6 * max(1.0, eb)
+        n_flipped += bool(sig > 0 and eb > 10 * sig + 1.0)
+    assert n_flipped >= 20          # the row-flip artefact is in the sample (and equal on both sides)
+    print("near-planar EPnP: worst product-vs-oracle %.1e, %d of 1200 with the row-flip artefact" % (worst, n_flipped))
+
+
+def test_exactly_coplanar_points_go_through(oracle, product_epnp):
+    """Points in one world plane, exact or noisy pixels: the fourth control point falls onto the centroid, the pseudo-inverse gives every point a zero fourth
+    barycentric coordinate, M^T M gets three exactly-zero eigenvalues beside its null vector (the product switches to OpenCV's Jacobi SVD for the degenerate
+    eigenspace) - and with exact pixels the true pose comes out."""
     o = _bind(oracle)
     rng = np.random.default_rng(2)
-    Xw, uv, R, t, _ = _scene(rng, 200)
-    Xw[:, 2] = 12.0
-    ea, _, eb, _ = _both(product_epnp, o, np.ascontiguousarray(Xw), uv)
-    assert ea < 0 and eb < 0
+    for trial in range(60):
+        n = int(rng.choice([6, 40, 200])); sig = float(rng.choice([0.0, 0.3]))
+        Xw, uv, R, t, _ = _scene(rng, n, 0.0)
+        Xw[:, 2] = 12.0
+        Xc = Xw @ R.T + t
+        uv = np.ascontiguousarray(np.c_[KITTI_K[0] * Xc[:, 0] / Xc[:, 2] + KITTI_K[2], KITTI_K[1] * Xc[:, 1] / Xc[:, 2] + KITTI_K[3]] + rng.normal(0, sig, (n, 2)))
+        ea, Ta, eb, Tb = _both(product_epnp, o, np.ascontiguousarray(Xw), uv)
+        assert ea >= 0 and eb >= 0
+        assert np.abs(Ta - Tb).max() <= 1e-6 * max(1.0, np.abs(Tb).max()), (trial, n, sig, np.abs(Ta - Tb).max())
+        if sig == 0.0 and n >= 40:
+            assert eb < 1e-6 and np.abs(Tb[:3, :3] - R).max() < 1e-6 and np.abs(Tb[:3, 3] - t).max() < 1e-5, (trial, eb)
 
 
 @pytest.mark.parametrize("scenario", ["exact", "low_noise", "twelve_objects"])

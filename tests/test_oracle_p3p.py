@@ -145,7 +145,8 @@ def test_ransac_with_too_few_points(oracle):
 def test_epnp_recovers_the_pose_and_refines_the_ransac_model(oracle):
     """EPnP (4 control points, oracle/epnp_oracle.hpp): exact data -> the exact pose (any n >= 6); noisy data -> the least-squares
     pose, closer to the truth than a single P3P hypothesis; and inside the RANSAC wrapper the refit replaces the winning
-    hypothesis while the inlier set stays the RANSAC one.  Coplanar points are left to the hypothesis (documented guard)."""
+    hypothesis while the inlier set stays the RANSAC one.  Coplanar points go through like any others (round 5; a liberty of rounds 2-4 left them to
+    the hypothesis): exact pixels -> the exact pose."""
     o = _bind(oracle)
     rng = np.random.default_rng(11)
     K4 = np.array(KITTI_K, np.float64)
@@ -167,12 +168,14 @@ def test_epnp_recovers_the_pose_and_refines_the_ransac_model(oracle):
     e0 = np.abs(res[0][1][:3, 3] - t).max(); e1 = np.abs(res[1][1][:3, 3] - t).max()
     assert e1 < e0 and e1 < 0.01, (e0, e1)                 # the refit uses all ~600 inliers instead of 3 points
     assert not np.array_equal(res[0][1], res[1][1])
-    # coplanar points: no refit (the 4-control-point formulation is undefined there)
+    # coplanar points: the pseudo-inverse of the control-point matrix gives every point a zero fourth barycentric coordinate (cvInvert(CV_SVD)) and EPnP goes on
     Xp = Xw.copy(); Xp[:, 2] = 12.0
     Xc = Xp @ R.T + t
     uvp = np.c_[KITTI_K[0] * Xc[:, 0] / Xc[:, 2] + KITTI_K[2], KITTI_K[1] * Xc[:, 1] / Xc[:, 2] + KITTI_K[3]]
     T = np.zeros(16)
-    assert o.vdo_oracle_epnp(900, K._dp(np.ascontiguousarray(Xp)), K._dp(np.ascontiguousarray(uvp)), K._dp(K4), K._dp(T)) < 0
+    err = o.vdo_oracle_epnp(900, K._dp(np.ascontiguousarray(Xp)), K._dp(np.ascontiguousarray(uvp)), K._dp(K4), K._dp(T))
+    T = T.reshape(4, 4)
+    assert 0 <= err < 1e-6 and np.abs(T[:3, :3] - R).max() < 1e-6 and np.abs(T[:3, 3] - t).max() < 1e-5, err
 
 
 def test_p3p_solution_set_is_complete_against_a_numerical_solver(oracle):

@@ -49,21 +49,19 @@ def test_trajectory_and_object_motions_are_recovered():
 
 def assert_borrowed_seeds_are_checked(ref):
     """OraclePipeline(seed_refit="product") takes the EPnP refit from a CPU build of the product's host routine so that both sides seed the
-    (chaotic, tests/test_oracle_flow2.py::test_f3_lm_is_chaotic_in_the_seed) object LMs with the same float.  The EPnP stage is still checked
+    (chaotic, tests/test_oracle_flow2.py::test_f3_lm_is_chaotic_in_the_seed) object LMs with the same float.  The EPnP stage is still CHECKED
     inside the sequence: the oracle's own RANSAC + EPnP ran beside every borrowed refit - same inlier masks (everything upstream of the
-    LM) always; poses within 1e-8 wherever EPnP is well posed.  It is not on (near-)PLANAR inlier sets - the visible face of a box, a
-    fronto-parallel object: third singular value of the centred points under 1 % of the first - where the fourth control point of EPnP's
-    formulation collapses onto the plane and the result is an artefact of each implementation's pseudo-inverse (the two restatements
-    differ by up to 1.5 there; what OpenCV 3.4 returns is unpinned): those refits are counted and reported, not compared."""
+    LM) always, and every refit pose within 1e-6 of the oracle's own (rounds 2-4 only REPORTED the near-planar ones - the visible
+    face of a box -, where the two restatements differed by up to 1.5; both now follow OpenCV's SVD-based steps there, tests/test_epnp_independent.py).
+    Not compared: refits on fewer than 6 inliers (2n < 11 equations: the null space of EPnP's M is several-dimensional whatever the data)."""
     log = ref.epnp_log
     assert len(log) >= 5
     assert all(c["same_inliers"] for c in log)
-    posed = [c for c in log if c["flatness"] >= 0.01]
-    flat = [c for c in log if c["flatness"] < 0.01]
-    if posed:
-        assert max(c["dT"] for c in posed) <= 1e-8, max(c["dT"] for c in posed)
-    print(f"EPnP inside the sequence: {len(log)} refits; well posed {len(posed)}: oracle vs product max {max([c['dT'] for c in posed], default=0.0):.1e}; "
-          f"near-planar {len(flat)}: max {max([c['dT'] for c in flat], default=0.0):.1e} (reported only); identical float seeds {sum(c['same_float_seed'] for c in log)}/{len(log)}")
+    posed = [c for c in log if c["n"] >= 6]
+    assert posed and max(c["dT"] for c in posed) <= 1e-6, max(c["dT"] for c in posed)
+    flat = [c for c in posed if c["flatness"] < 0.01]
+    print(f"EPnP inside the sequence: {len(log)} refits, {len(posed)} on >= 6 inliers: oracle vs product max {max(c['dT'] for c in posed):.1e} "
+          f"({len(flat)} near-planar: max {max([c['dT'] for c in flat], default=0.0):.1e}); identical float seeds {sum(c['same_float_seed'] for c in log)}/{len(log)}")
 
 
 def assert_tracklets_equal_the_oracle(oracle, pipe, ref):

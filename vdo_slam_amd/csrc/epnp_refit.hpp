@@ -6,12 +6,17 @@
 // The 4-control-point formulation of Lepetit, Moreno-Noguer & Fua (IJCV 2009) as structured in OpenCV's epnp.cpp:
 // control points from the PCA of the points, barycentric coordinates, M^T M and the eigenvectors of its 4 smallest eigenvalues,
 // the L_6x10 / rho system, three beta initialisations each refined by 5 Gauss-Newton steps, absolute orientation, smallest mean
-// reprojection error wins.  OpenCV itself is not available to pin this against (parity unpinned); deliberate
-// liberties: symmetric eigen-solvers instead of OpenCV's SVD routines (except for the principal directions of the control points,
-// whose signs matter: principal_directions), Horn's quaternion method for the absolute orientation, pseudo-inverse through the
-// normal equations for the small least-squares systems.
-// The CPU oracle (oracle/epnp_oracle.hpp) is an independent restatement with OpenCV's own numerical tools (SVD everywhere); the two
-// are compared to 1e-9 (tests/test_epnp_independent.py on the CPU, tests/test_ransac_gpu.py through the C-ABI).
+// reprojection error wins.  OpenCV itself is not available to pin this against (parity unpinned).
+// Round 5: every step whose RESULT depends on how OpenCV computes it follows OpenCV's tool - the one-sided Jacobi SVD of
+// modules/core/src/lapack.cpp (small_svd below) for the principal directions of the control points (their signs), for the inverse of
+// the control-point matrix (cvInvert(CV_SVD): a pseudo-inverse, what makes (near-)coplanar point sets go through instead of dividing
+// by zero), for the three beta systems (cvSolve(CV_SVD): singular values under 2 eps sum(w) dropped) and for the absolute orientation
+// (R = U V^T of sum (pc - pc0)(pw - pw0)^T, THIRD ROW negated when det R < 0 - on near-planar noisy sets that is not the nearest rotation,
+// and it is what the reference receives).  Rounds 2-4 used normal equations, Horn's quaternion and "coplanar: keep the hypothesis" there and
+// differed from the oracle by up to 1.5 in the pose on near-planar inlier sets.  What stays the product's own: M^T M by
+// running sums, its eigenvectors by tridiagonalisation + QL, the sums shared by the three candidates, Householder QR for the Gauss-Newton.
+// The CPU oracle (oracle/epnp_oracle.hpp) is a separately written restatement (dense M, SVD of M^T M, Givens QR); the two
+// are compared to 1e-9 / 1e-6 on near-planar sets (tests/test_epnp_independent.py on the CPU, tests/test_ransac_gpu.py through the C-ABI).
 #pragma once
 #include <cmath>
 #include <cstring>
@@ -19,46 +24,6 @@
 
 namespace vdo {
 namespace epnp {
-
-// cyclic Jacobi eigen-decomposition of the symmetric n x n matrix A (row-major, overwritten); V: columns = eigenvectors;
-// eigenvalues in w, sorted descending (eigenvector columns permuted alike)
-inline void jacobi_eig(int n, double* A, double* V, double* w) {
-  for (int i = 0; i < n; ++i) for (int j = 0; j < n; ++j) V[i * n + j] = (i == j) ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0, diag = 0.0;
-    for (int p = 0; p < n; ++p) { diag += A[p * n + p] * A[p * n + p]; for (int q = p + 1; q < n; ++q) off += A[p * n + q] * A[p * n + q]; }
-    if (off <= 1e-32 * diag || off == 0.0) break;
-    for (int p = 0; p < n - 1; ++p)
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = A[p * n + q];
-        if (apq == 0.0) continue;
-        const double theta = (A[q * n + q] - A[p * n + p]) / (2.0 * apq);
-        const double t = (theta >= 0.0 ? 1.0 : -1.0) / (std::fabs(theta) + std::sqrt(theta * theta + 1.0));
-        const double c = 1.0 / std::sqrt(t * t + 1.0), s = t * c;
-        for (int k = 0; k < n; ++k) {                 // rows p, q:  A <- J^T A
-          const double akp = A[p * n + k], akq = A[q * n + k];
-          A[p * n + k] = c * akp - s * akq; A[q * n + k] = s * akp + c * akq;
-        }
-        for (int k = 0; k < n; ++k) {                 // columns p, q:  A <- A J
-          const double akp = A[k * n + p], akq = A[k * n + q];
-          A[k * n + p] = c * akp - s * akq; A[k * n + q] = s * akp + c * akq;
-        }
-        for (int k = 0; k < n; ++k) {
-          const double vkp = V[k * n + p], vkq = V[k * n + q];
-          V[k * n + p] = c * vkp - s * vkq; V[k * n + q] = s * vkp + c * vkq;
-        }
-      }
-  }
-  for (int i = 0; i < n; ++i) w[i] = A[i * n + i];
-  for (int i = 0; i < n - 1; ++i) {                   // selection sort, descending
-    int m = i;
-    for (int j = i + 1; j < n; ++j) if (w[j] > w[m]) m = j;
-    if (m != i) {
-      const double tw = w[i]; w[i] = w[m]; w[m] = tw;
-      for (int k = 0; k < n; ++k) { const double tv = V[k * n + i]; V[k * n + i] = V[k * n + m]; V[k * n + m] = tv; }
-    }
-  }
-}
 
 // Symmetric eigen-decomposition by Householder tridiagonalisation + implicit QL with Wilkinson shifts (the classical tred2 /
 // tql2 pair) - ~5x fewer operations than cyclic Jacobi at n = 12.  A (row-major n x n, n <= 12) is overwritten; on return the
@@ -211,20 +176,78 @@ inline void principal_directions(const double C[9], double w[3], double d[9]) {
   }
 }
 
-// minimum-norm least squares x = pinv(A) b for A (m x k, row-major, k <= 5) through the eigen-decomposition of A^T A
-inline void lstsq_pinv(int m, int k, const double* A, const double* b, double* x) {
-  double AtA[25], Atb[5], V[25], w[5];
-  for (int i = 0; i < k; ++i) {
-    for (int j = 0; j < k; ++j) { double s = 0.0; for (int r = 0; r < m; ++r) s += A[r * k + i] * A[r * k + j]; AtA[i * k + j] = s; }
-    double s = 0.0; for (int r = 0; r < m; ++r) s += A[r * k + i] * b[r]; Atb[i] = s;
+// cv::SVD of a small matrix as OpenCV 3.4.0 computes it without LAPACK (JacobiSVDImpl_, modules/core/src/lapack.cpp): Hestenes' one-sided
+// Jacobi on the COLUMNS of A.  The conventions that decide order and sign of the vectors are OpenCV's: column pairs (i, j), i < j, in row-major
+// order; a pair is left alone when |<a_i, a_j>| <= 10 eps |a_i| |a_j|; the rotation has c >= 0 when |a_i| >= |a_j|, else s >= 0; V starts as the
+// identity and takes the same rotations; at most max(m, 30) sweeps; singular values = column norms, sorted descending by selection with swaps;
+// left vectors = columns / singular value (a zero singular value leaves a zero vector: OpenCV fills in a pseudo-random one, nothing here reads it).
+// A: m x n row-major, m <= MR, n <= NC.  w [n]; U [n][MR]: ROW j = j-th left singular vector (first m entries); V [n][NC]: ROW j = j-th right one.
+template <int MR, int NC>
+inline void jacobi_svd(int m, int n, const double* A, double* w, double (*U)[MR], double (*V)[NC]) {
+  double col[NC][MR], nrm2[NC];
+  for (int j = 0; j < n; ++j) {
+    double s = 0.0;
+    for (int r = 0; r < m; ++r) { col[j][r] = A[r * n + j]; s += col[j][r] * col[j][r]; }
+    nrm2[j] = s;
+    for (int k = 0; k < n; ++k) V[j][k] = (j == k) ? 1.0 : 0.0;
   }
-  jacobi_eig(k, AtA, V, w);
+  const int sweeps = m > 30 ? m : 30;
+  for (int sweep = 0; sweep < sweeps; ++sweep) {
+    bool rotated = false;
+    for (int i = 0; i + 1 < n; ++i)
+      for (int j = i + 1; j < n; ++j) {
+        double p = 0.0;
+        for (int r = 0; r < m; ++r) p += col[i][r] * col[j][r];
+        if (std::fabs(p) <= 2.220446049250313e-15 * std::sqrt(nrm2[i] * nrm2[j])) continue;
+        p *= 2.0;
+        const double beta = nrm2[i] - nrm2[j], gamma = std::hypot(p, beta);
+        double c, s;
+        if (beta < 0.0) { s = std::sqrt((gamma - beta) * 0.5 / gamma); c = p / (gamma * s * 2.0); }
+        else { c = std::sqrt((gamma + beta) / (gamma * 2.0)); s = p / (gamma * c * 2.0); }
+        double ni = 0.0, nj = 0.0;
+        for (int r = 0; r < m; ++r) {
+          const double xi = c * col[i][r] + s * col[j][r], xj = c * col[j][r] - s * col[i][r];
+          col[i][r] = xi; col[j][r] = xj; ni += xi * xi; nj += xj * xj;
+        }
+        nrm2[i] = ni; nrm2[j] = nj;
+        for (int k = 0; k < n; ++k) { const double vi = c * V[i][k] + s * V[j][k], vj = c * V[j][k] - s * V[i][k]; V[i][k] = vi; V[j][k] = vj; }
+        rotated = true;
+      }
+    if (!rotated) break;
+  }
+  int ord[NC];
+  double nr[NC];
+  for (int j = 0; j < n; ++j) { double s = 0.0; for (int r = 0; r < m; ++r) s += col[j][r] * col[j][r]; nr[j] = std::sqrt(s); ord[j] = j; }
+  for (int i = 0; i + 1 < n; ++i) {                   // (selection with swaps: the order of equal values is OpenCV's)
+    int b = i;
+    for (int k = i + 1; k < n; ++k) if (nr[ord[b]] < nr[ord[k]]) b = k;
+    if (b != i) { const int t = ord[i]; ord[i] = ord[b]; ord[b] = t; }
+  }
+  double Vs[NC][NC];
+  for (int j = 0; j < n; ++j) for (int k = 0; k < n; ++k) Vs[j][k] = V[ord[j]][k];
+  for (int j = 0; j < n; ++j) {
+    w[j] = nr[ord[j]];
+    const double inv = w[j] > 2.2250738585072014e-308 ? 1.0 / w[j] : 0.0;
+    for (int r = 0; r < m; ++r) U[j][r] = col[ord[j]][r] * inv;
+    for (int k = 0; k < n; ++k) V[j][k] = Vs[j][k];
+  }
+}
+inline void small_svd(int m, int n, const double* A, double* w, double (*U)[6], double (*V)[5]) { jacobi_svd<6, 5>(m, n, A, w, U, V); }
+
+// cvSolve(A, b, x, CV_SVD) for the beta systems (m = 6, k <= 5): x = V diag(1/w) U^T b over the singular values above 2 eps sum(w)
+inline void lstsq_svd(int m, int k, const double* A, const double* b, double* x) {
+  double w[5], U[5][6], V[5][5];
+  small_svd(m, k, A, w, U, V);
+  double thr = 0.0;
+  for (int j = 0; j < k; ++j) thr += w[j];
+  thr *= 2.0 * 2.220446049250313e-16;
   for (int i = 0; i < k; ++i) x[i] = 0.0;
-  for (int e = 0; e < k; ++e) {
-    if (!(w[e] > 1e-14 * w[0])) continue;             // (singular value below ~1e-7 of the largest: dropped, as a pseudo-inverse does)
-    double proj = 0.0; for (int i = 0; i < k; ++i) proj += V[i * k + e] * Atb[i];
-    proj /= w[e];
-    for (int i = 0; i < k; ++i) x[i] += V[i * k + e] * proj;
+  for (int j = 0; j < k; ++j) {
+    if (!(w[j] > thr)) continue;
+    double ub = 0.0;
+    for (int r = 0; r < m; ++r) ub += U[j][r] * b[r];
+    ub /= w[j];
+    for (int i = 0; i < k; ++i) x[i] += V[j][i] * ub;
   }
 }
 
@@ -272,22 +295,25 @@ inline Result solve(int n, const double* X, const double* uv, const double* K4, 
   C[3] = C[1]; C[6] = C[2]; C[7] = C[5];
   double Dc[9], dc[3];
   principal_directions(C, dc, Dc);
-  // (near-)coplanar points: the fourth control point collapses onto the centroid and the barycentric coordinates are undefined.
-  // OpenCV's behaviour there is an artefact of its pseudo-inverse; here the caller keeps the RANSAC hypothesis (err < 0).
-  if (!(dc[2] > 1e-8 * dc[0])) { Result none{}; none.err = -1.0; return none; }
+  // ((near-)coplanar points: dc[2] -> 0, the fourth control point falls onto the centroid; OpenCV goes on - the pseudo-inverse below then gives
+  // every point a zero fourth coordinate - and so does this)
   for (int i = 1; i < 4; ++i) {
     const double k = std::sqrt((dc[i - 1] > 0.0 ? dc[i - 1] : 0.0) / n);
     for (int j = 0; j < 3; ++j) cws[i][j] = cws[0][j] + k * Dc[3 * (i - 1) + j];
   }
-  // ---- compute_barycentric_coordinates
+  // ---- compute_barycentric_coordinates: cvInvert(CC, CC_inv, CV_SVD) = V diag(1/w) U^T over the singular values above 2 eps sum(w)
   double cc[9], ci[9];
   for (int i = 0; i < 3; ++i) for (int j = 1; j < 4; ++j) cc[3 * i + j - 1] = cws[j][i] - cws[0][i];
   {
-    const double det = cc[0] * (cc[4] * cc[8] - cc[5] * cc[7]) - cc[1] * (cc[3] * cc[8] - cc[5] * cc[6]) + cc[2] * (cc[3] * cc[7] - cc[4] * cc[6]);
-    const double id = 1.0 / det;
-    ci[0] = (cc[4] * cc[8] - cc[5] * cc[7]) * id; ci[1] = (cc[2] * cc[7] - cc[1] * cc[8]) * id; ci[2] = (cc[1] * cc[5] - cc[2] * cc[4]) * id;
-    ci[3] = (cc[5] * cc[6] - cc[3] * cc[8]) * id; ci[4] = (cc[0] * cc[8] - cc[2] * cc[6]) * id; ci[5] = (cc[2] * cc[3] - cc[0] * cc[5]) * id;
-    ci[6] = (cc[3] * cc[7] - cc[4] * cc[6]) * id; ci[7] = (cc[1] * cc[6] - cc[0] * cc[7]) * id; ci[8] = (cc[0] * cc[4] - cc[1] * cc[3]) * id;
+    double wc[5], Uc[5][6], Vc[5][5];
+    small_svd(3, 3, cc, wc, Uc, Vc);
+    const double thr = 2.0 * 2.220446049250313e-16 * (wc[0] + wc[1] + wc[2]);
+    for (int a = 0; a < 3; ++a)
+      for (int b = 0; b < 3; ++b) {
+        double acc = 0.0;
+        for (int k = 0; k < 3; ++k) if (wc[k] > thr) acc += Vc[k][a] * (1.0 / wc[k]) * Uc[k][b];
+        ci[3 * a + b] = acc;
+      }
   }
   std::vector<double>& alphas = scr.alphas;
   if (alphas.size() < 4 * (size_t)n) alphas.resize(4 * (size_t)n);
@@ -333,11 +359,21 @@ inline Result solve(int n, const double* X, const double* uv, const double* K4, 
       Bk[12] = 0.0; Bk[13] = fv * fv * a1; Bk[14] = fv * av;
       Bk[24] = fu * au; Bk[25] = fv * av; Bk[26] = aq;
     }
-  double V12[144], w12[12];
+  double V12[144], w12[12], MtM_in[144];
+  std::memcpy(MtM_in, MtM, sizeof MtM);
   sym_eig_ql(12, MtM, V12, w12);
   const double* vcol[4];   // v[0] = eigenvector of the smallest eigenvalue ... (ut + 12*11, 12*10, 12*9, 12*8 in OpenCV's U^T)
   double vv[4][12];
   for (int e = 0; e < 4; ++e) { for (int k = 0; k < 12; ++k) vv[e][k] = V12[k * 12 + (11 - e)]; vcol[e] = vv[e]; }
+  // When the four smallest eigenvalues do not stand apart - fewer than 6 points (2n < 11 equations: several EXACT zeros), exactly coplanar points seen
+  // without noise - "the eigenvectors of the four smallest" are a basis of a degenerate eigenspace and which basis comes out is the solver's doing.
+  // There (only there: it costs 5x the QL) the vectors are OpenCV's: the one-sided Jacobi SVD of M^T M, right singular vectors, as the oracle reads them.
+  if (n < 6 || !(w12[8] > 1e-9 * w12[0])) {
+    static_assert(sizeof(double[12][12]) == 144 * sizeof(double), "");
+    double ws[12], Us[12][12], Vs[12][12];
+    jacobi_svd<12, 12>(12, 12, MtM_in, ws, Us, Vs);
+    for (int e = 0; e < 4; ++e) for (int k = 0; k < 12; ++k) vv[e][k] = Vs[11 - e][k];
+  }
   // ---- compute_L_6x10, compute_rho
   double dv[4][6][3];
   for (int i = 0; i < 4; ++i) {
@@ -367,13 +403,13 @@ inline Result solve(int n, const double* X, const double* uv, const double* K4, 
     if (N == 1) {                                     // betas_approx_1 = [B11 B12 B13 B14]
       double A[24], b4[4];
       for (int i = 0; i < 6; ++i) { A[4 * i] = L[10 * i]; A[4 * i + 1] = L[10 * i + 1]; A[4 * i + 2] = L[10 * i + 3]; A[4 * i + 3] = L[10 * i + 6]; }
-      lstsq_pinv(6, 4, A, rho, b4);
+      lstsq_svd(6, 4, A, rho, b4);
       if (b4[0] < 0) { betas[0] = std::sqrt(-b4[0]); betas[1] = -b4[1] / betas[0]; betas[2] = -b4[2] / betas[0]; betas[3] = -b4[3] / betas[0]; }
       else { betas[0] = std::sqrt(b4[0]); betas[1] = b4[1] / betas[0]; betas[2] = b4[2] / betas[0]; betas[3] = b4[3] / betas[0]; }
     } else if (N == 2) {                              // betas_approx_2 = [B11 B12 B22]
       double A[18], b3[3];
       for (int i = 0; i < 6; ++i) { A[3 * i] = L[10 * i]; A[3 * i + 1] = L[10 * i + 1]; A[3 * i + 2] = L[10 * i + 2]; }
-      lstsq_pinv(6, 3, A, rho, b3);
+      lstsq_svd(6, 3, A, rho, b3);
       if (b3[0] < 0) { betas[0] = std::sqrt(-b3[0]); betas[1] = (b3[2] < 0) ? std::sqrt(-b3[2]) : 0.0; }
       else { betas[0] = std::sqrt(b3[0]); betas[1] = (b3[2] > 0) ? std::sqrt(b3[2]) : 0.0; }
       if (b3[1] < 0) betas[0] = -betas[0];
@@ -381,7 +417,7 @@ inline Result solve(int n, const double* X, const double* uv, const double* K4, 
     } else {                                          // betas_approx_3 = [B11 B12 B22 B13 B23]
       double A[30], b5[5];
       for (int i = 0; i < 6; ++i) for (int j = 0; j < 5; ++j) A[5 * i + j] = L[10 * i + j];
-      lstsq_pinv(6, 5, A, rho, b5);
+      lstsq_svd(6, 5, A, rho, b5);
       if (b5[0] < 0) { betas[0] = std::sqrt(-b5[0]); betas[1] = (b5[2] < 0) ? std::sqrt(-b5[2]) : 0.0; }
       else { betas[0] = std::sqrt(b5[0]); betas[1] = (b5[2] > 0) ? std::sqrt(b5[2]) : 0.0; }
       if (b5[1] < 0) betas[0] = -betas[0];
@@ -417,18 +453,20 @@ inline Result solve(int n, const double* X, const double* uv, const double* K4, 
     double Sm[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // S[r][k] = sum (pw - pw0)[r] (pc - pc0)[k] = sum_j Q_j[r] ccs_j[k]   (Horn: rotation world -> camera)
     for (int j = 0; j < 4; ++j)
       for (int r = 0; r < 3; ++r) for (int k = 0; k < 3; ++k) Sm[3 * r + k] += Qj[j][r] * ccs[j][k];
-    double Nq[16] = {Sm[0] + Sm[4] + Sm[8], Sm[5] - Sm[7], Sm[6] - Sm[2], Sm[1] - Sm[3],
-                     Sm[5] - Sm[7], Sm[0] - Sm[4] - Sm[8], Sm[1] + Sm[3], Sm[6] + Sm[2],
-                     Sm[6] - Sm[2], Sm[1] + Sm[3], -Sm[0] + Sm[4] - Sm[8], Sm[5] + Sm[7],
-                     Sm[1] - Sm[3], Sm[6] + Sm[2], Sm[5] + Sm[7], -Sm[0] - Sm[4] + Sm[8]};
-    double Vq[16], wq[4];
-    jacobi_eig(4, Nq, Vq, wq);
-    double q0 = Vq[0], q1 = Vq[4], q2 = Vq[8], q3 = Vq[12];      // eigenvector of the largest eigenvalue: unit quaternion (w, x, y, z)
-    { const double nq = std::sqrt(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3); q0 /= nq; q1 /= nq; q2 /= nq; q3 /= nq; }
+    // estimate_R_and_t: ABt = sum (pc - pc0)(pw - pw0)^T = Sm^T;  R = U V^T;  det R < 0: the third ROW changes sign (OpenCV epnp.cpp)
     Result cur;
-    cur.R[0] = q0 * q0 + q1 * q1 - q2 * q2 - q3 * q3; cur.R[1] = 2 * (q1 * q2 - q0 * q3); cur.R[2] = 2 * (q1 * q3 + q0 * q2);
-    cur.R[3] = 2 * (q1 * q2 + q0 * q3); cur.R[4] = q0 * q0 - q1 * q1 + q2 * q2 - q3 * q3; cur.R[5] = 2 * (q2 * q3 - q0 * q1);
-    cur.R[6] = 2 * (q1 * q3 - q0 * q2); cur.R[7] = 2 * (q2 * q3 + q0 * q1); cur.R[8] = q0 * q0 - q1 * q1 - q2 * q2 + q3 * q3;
+    {
+      const double ABt[9] = {Sm[0], Sm[3], Sm[6], Sm[1], Sm[4], Sm[7], Sm[2], Sm[5], Sm[8]};
+      double wa[5], Ua[5][6], Va[5][5];
+      small_svd(3, 3, ABt, wa, Ua, Va);
+      if (!(wa[2] > 1e-14 * wa[0])) {                 // rank 2: the third left vector completes a right-handed frame (OpenCV: a pseudo-random completion)
+        Ua[2][0] = Ua[0][1] * Ua[1][2] - Ua[0][2] * Ua[1][1]; Ua[2][1] = Ua[0][2] * Ua[1][0] - Ua[0][0] * Ua[1][2]; Ua[2][2] = Ua[0][0] * Ua[1][1] - Ua[0][1] * Ua[1][0];
+      }
+      for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) cur.R[3 * a + b] = Ua[0][a] * Va[0][b] + Ua[1][a] * Va[1][b] + Ua[2][a] * Va[2][b];
+      const double det = cur.R[0] * (cur.R[4] * cur.R[8] - cur.R[5] * cur.R[7]) - cur.R[1] * (cur.R[3] * cur.R[8] - cur.R[5] * cur.R[6]) +
+                         cur.R[2] * (cur.R[3] * cur.R[7] - cur.R[4] * cur.R[6]);
+      if (det < 0.0) { cur.R[6] = -cur.R[6]; cur.R[7] = -cur.R[7]; cur.R[8] = -cur.R[8]; }
+    }
     for (int k = 0; k < 3; ++k) cur.t[k] = pc0[k] - (cur.R[3 * k] * pw0[0] + cur.R[3 * k + 1] * pw0[1] + cur.R[3 * k + 2] * pw0[2]);
     // reprojection_error: mean pixel distance.  Four running sums (point i goes to sum i mod 4, added as (s0 + s1) + (s2 + s3)): the divisions and
     // square roots of four points are independent of each other and of the additions, so they pipeline (and vectorise) instead of queueing

@@ -606,7 +606,7 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
           ui.insert(ui.end(), probs[k].uv + 2 * (size_t)i, probs[k].uv + 2 * (size_t)i + 2);
         }
       const epnp::Result r = epnp::solve((int)(ui.size() / 2), Xi.data(), ui.data(), probs[k].K, scr);
-      if (r.err >= 0.0)                              // (degenerate - coplanar - inliers: the RANSAC hypothesis stays)
+      if (r.err >= 0.0)                              // (always, since round 5: coplanar inliers go through EPnP like any others; only a non-finite result leaves the hypothesis)
         for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) results[k].T[4 * i + j] = r.R[3 * i + j]; results[k].T[4 * i + 3] = r.t[i]; }
     };
     static LevelPool* pool = [] {
