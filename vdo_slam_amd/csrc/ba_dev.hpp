@@ -83,6 +83,9 @@ struct BADev {
   int pc_maxlen = 0, pc_lds = 0;                  // longest chain; 1: a chain's strip [len][6] fits the LDS of its workgroup (k_pcg_chain), 0: global-memory path
   int32_t *pc_off = nullptr, *pc_pose = nullptr;  // [n_pchains+1], [P]
   int32_t* pc_edge = nullptr;                     // [P] edge<<1|side linking position k-1 -> k (side 0: previous pose is the edge's i), -1 at a chain head
+  // TWISTED chains (capi_ba.hip): first half of the path, second half backwards (its first position carries pc_edge = -1), the middle pose last.  The last
+  // position - the joint - has its ordinary link to the position before it and ONE far link to position pc_far_pos[c] (the end of the first half).
+  int32_t *pc_far_pos = nullptr, *pc_far_edge = nullptr;   // [n_pchains] global chain position of the far predecessor / its link (edge<<1|side); -1: not twisted
   // linear system
   double *Hpp = nullptr, *bp = nullptr;              // [P][36], [P][6]
   double *Hll = nullptr, *bl = nullptr;              // [L] (the landmark diagonal block is Hll[l] * I3, see ba_sweep.hip),  [L][3]
@@ -107,6 +110,7 @@ struct BADev {
   double* Minv = nullptr;                            // [P][36] chain position k: Delta_k^-1 of the block LDL^T (chains of length 1: plain block-Jacobi)
   double* Adg = nullptr;                             // [P][36] S_pp + lambda I by pose id (input of the chain factorisation)
   double* Lc = nullptr;                              // [P][36] chain position k: L_k = E_{k-1,k}^T Delta_{k-1}^-1
+  double* Lfar = nullptr;                            // [n_pchains][36] twisted chains: L of the joint's far link = E_{far,joint}^T Delta_far^-1
   double *Pf = nullptr, *Qb = nullptr;               // [P][36] chain position k: products of -L / -L^T from the segment's end (k_pchain_prefix)
   double *xp = nullptr, *rp = nullptr, *zp = nullptr, *pp = nullptr, *qp = nullptr, *bs = nullptr, *qs = nullptr;  // [6P]
   double* pp2 = nullptr;                             // [6P] second search-direction buffer (the PCG iterations ping-pong between pp and pp2)

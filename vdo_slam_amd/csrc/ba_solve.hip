@@ -408,26 +408,113 @@ __device__ __forceinline__ void chain_wave_sync() {
   __builtin_amdgcn_wave_barrier();
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
-__global__ __launch_bounds__(64) void k_pchain_factor(BADev d) {
-  // lane = 6*row + col of a 6x6 block, blocks exchanged through LDS
-  __shared__ double sE[36], sD[36], sL[36];
-  const int c = blockIdx.x, lane = threadIdx.x;
+// Inverse of the SPD 6x6 block held one entry per lane (lane ln = 6 r + q; lanes 36 .. 63 mirror 0 .. 27).  INV = 1 (default): the in-place Gauss-Jordan of
+// rounds 2-4 in registers - six DEPENDENT pivots (a v_readlane, two ds_bpermute, a reciprocal + two Newton steps, selects).  INV = 0 (VDO_BA_PCHAIN_CLOSED=1;
+// built in round 5 on the estimate that it would take two thirds of the time - it takes 5 % MORE, see the launch site - and kept for the record):
+// the closed form over 3x3 blocks, A = [P Q; Q^T S]:  P^-1 by cofactors, W = P^-1 Q, T = S - Q^T W, T^-1 by cofactors, and
+//   A^-1 = [P^-1 + W T^-1 W^T, -W T^-1; -(W T^-1)^T, T^-1]
+// computed REDUNDANTLY by every lane from one LDS broadcast of the block (21 doubles, conflict-free: all lanes read the same address): ~170 independent-ish
+// multiply-adds and two reciprocals instead of six pivots in a row; the 21 results go back through LDS (every lane writes the same values to the same
+// places), where the next step of the recurrence reads them anyway.  Positive definiteness = the six leading minors (the pivots of the other form).
+// sm: 36 doubles of LDS of this wave (the block as a full symmetric matrix on return); returns this lane's entry.
+template <int INV>
+__device__ __forceinline__ double chain_inv6(double a, int ln, int r, int q, double* sm, bool& bad) {
+  if (INV == 1) {
+#pragma unroll
+    for (int kk = 0; kk < 6; ++kk) {
+      const double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), kk * 7), __builtin_amdgcn_readlane(__double2loint(a), kk * 7));
+      const double aik = __shfl(a, r * 6 + kk, 64), akj = __shfl(a, kk * 6 + q, 64);
+      if (!(pv > 0)) bad = true;
+      double rp = __builtin_amdgcn_rcp(pv);
+      rp = __builtin_fma(__builtin_fma(-pv, rp, 1.0), rp, rp);
+      rp = __builtin_fma(__builtin_fma(-pv, rp, 1.0), rp, rp);      // (the second step is free: the chain waits for the permutes - measured)
+      const double rowv = akj * rp, colv = -aik * rp, gen = a - aik * rowv;      // (selects, not branches: all four are a few cycles)
+      const double on_row = q == kk ? rp : rowv, off_row = q == kk ? colv : gen;
+      a = r == kk ? on_row : off_row;
+    }
+    sm[ln] = a;
+    return a;
+  }
+  sm[ln] = a;
+  chain_wave_sync();
+  const double p00 = sm[0], p01 = sm[1], p02 = sm[2], p11 = sm[7], p12 = sm[8], p22 = sm[14];
+  const double q00 = sm[3], q01 = sm[4], q02 = sm[5], q10 = sm[9], q11 = sm[10], q12 = sm[11], q20 = sm[15], q21 = sm[16], q22 = sm[17];
+  const double s00 = sm[21], s01 = sm[22], s02 = sm[23], s11 = sm[28], s12 = sm[29], s22 = sm[35];
+  chain_wave_sync();                               // (everybody has read the block: sm may be overwritten below)
+  auto recip = [](double x) { double y = __builtin_amdgcn_rcp(x); y = __builtin_fma(__builtin_fma(-x, y, 1.0), y, y); return __builtin_fma(__builtin_fma(-x, y, 1.0), y, y); };
+  // P^-1
+  double c00 = p11 * p22 - p12 * p12, c01 = p02 * p12 - p01 * p22, c02 = p01 * p12 - p02 * p11;
+  double c11 = p00 * p22 - p02 * p02, c12 = p01 * p02 - p00 * p12, c22 = p00 * p11 - p01 * p01;
+  const double detp = __builtin_fma(p02, c02, __builtin_fma(p01, c01, p00 * c00));
+  if (!(p00 > 0) || !(c22 > 0) || !(detp > 0)) bad = true;
+  const double ip = recip(detp);
+  c00 *= ip; c01 *= ip; c02 *= ip; c11 *= ip; c12 *= ip; c22 *= ip;
+  // W = P^-1 Q
+  const double w00 = __builtin_fma(c02, q20, __builtin_fma(c01, q10, c00 * q00)), w01 = __builtin_fma(c02, q21, __builtin_fma(c01, q11, c00 * q01)), w02 = __builtin_fma(c02, q22, __builtin_fma(c01, q12, c00 * q02));
+  const double w10 = __builtin_fma(c12, q20, __builtin_fma(c11, q10, c01 * q00)), w11 = __builtin_fma(c12, q21, __builtin_fma(c11, q11, c01 * q01)), w12 = __builtin_fma(c12, q22, __builtin_fma(c11, q12, c01 * q02));
+  const double w20 = __builtin_fma(c22, q20, __builtin_fma(c12, q10, c02 * q00)), w21 = __builtin_fma(c22, q21, __builtin_fma(c12, q11, c02 * q01)), w22 = __builtin_fma(c22, q22, __builtin_fma(c12, q12, c02 * q02));
+  // T = S - Q^T W  (symmetric)
+  const double t00 = s00 - __builtin_fma(q20, w20, __builtin_fma(q10, w10, q00 * w00)), t01 = s01 - __builtin_fma(q20, w21, __builtin_fma(q10, w11, q00 * w01));
+  const double t02 = s02 - __builtin_fma(q20, w22, __builtin_fma(q10, w12, q00 * w02)), t11 = s11 - __builtin_fma(q21, w21, __builtin_fma(q11, w11, q01 * w01));
+  const double t12 = s12 - __builtin_fma(q21, w22, __builtin_fma(q11, w12, q01 * w02)), t22 = s22 - __builtin_fma(q22, w22, __builtin_fma(q12, w12, q02 * w02));
+  // T^-1
+  double d00 = t11 * t22 - t12 * t12, d01 = t02 * t12 - t01 * t22, d02 = t01 * t12 - t02 * t11;
+  double d11 = t00 * t22 - t02 * t02, d12 = t01 * t02 - t00 * t12, d22 = t00 * t11 - t01 * t01;
+  const double dett = __builtin_fma(t02, d02, __builtin_fma(t01, d01, t00 * d00));
+  if (!(t00 > 0) || !(d22 > 0) || !(dett > 0)) bad = true;
+  const double it = recip(dett);
+  d00 *= it; d01 *= it; d02 *= it; d11 *= it; d12 *= it; d22 *= it;
+  // X = -W T^-1   (the upper right block)
+  const double x00 = -__builtin_fma(w02, d02, __builtin_fma(w01, d01, w00 * d00)), x01 = -__builtin_fma(w02, d12, __builtin_fma(w01, d11, w00 * d01)), x02 = -__builtin_fma(w02, d22, __builtin_fma(w01, d12, w00 * d02));
+  const double x10 = -__builtin_fma(w12, d02, __builtin_fma(w11, d01, w10 * d00)), x11 = -__builtin_fma(w12, d12, __builtin_fma(w11, d11, w10 * d01)), x12 = -__builtin_fma(w12, d22, __builtin_fma(w11, d12, w10 * d02));
+  const double x20 = -__builtin_fma(w22, d02, __builtin_fma(w21, d01, w20 * d00)), x21 = -__builtin_fma(w22, d12, __builtin_fma(w21, d11, w20 * d01)), x22 = -__builtin_fma(w22, d22, __builtin_fma(w21, d12, w20 * d02));
+  // upper left: P^-1 - X W^T  (symmetric)
+  const double u00 = c00 - __builtin_fma(x02, w02, __builtin_fma(x01, w01, x00 * w00)), u01 = c01 - __builtin_fma(x02, w12, __builtin_fma(x01, w11, x00 * w10));
+  const double u02 = c02 - __builtin_fma(x02, w22, __builtin_fma(x01, w21, x00 * w20)), u11 = c11 - __builtin_fma(x12, w12, __builtin_fma(x11, w11, x10 * w10));
+  const double u12 = c12 - __builtin_fma(x12, w22, __builtin_fma(x11, w21, x10 * w20)), u22 = c22 - __builtin_fma(x22, w22, __builtin_fma(x21, w21, x20 * w20));
+  // back through LDS as the full symmetric matrix (same values from every lane)
+  sm[0] = u00; sm[1] = u01; sm[2] = u02; sm[3] = x00; sm[4] = x01; sm[5] = x02;
+  sm[6] = u01; sm[7] = u11; sm[8] = u12; sm[9] = x10; sm[10] = x11; sm[11] = x12;
+  sm[12] = u02; sm[13] = u12; sm[14] = u22; sm[15] = x20; sm[16] = x21; sm[17] = x22;
+  sm[18] = x00; sm[19] = x10; sm[20] = x20; sm[21] = d00; sm[22] = d01; sm[23] = d02;
+  sm[24] = x01; sm[25] = x11; sm[26] = x21; sm[27] = d01; sm[28] = d11; sm[29] = d12;
+  sm[30] = x02; sm[31] = x12; sm[32] = x22; sm[33] = d02; sm[34] = d12; sm[35] = d22;
+  chain_wave_sync();
+  return sm[ln];
+}
+
+// Two waves per chain (round 5).  An untwisted chain: wave 0 walks it, wave 1 has nothing to do.  A TWISTED chain (capi_ba.hip): wave 0 factorises the first
+// half [b, far], wave 1 the second half - stored backwards, its first position has no link - [far + 1, e - 2]; then wave 1 does the joint (position e - 1), which
+// takes Delta^-1 of BOTH halves' last positions:  Delta_joint = A - L E - L_far E_far.  Half the depth of the one recurrence that cannot be partitioned.
+template <int INV>
+__global__ __launch_bounds__(128) void k_pchain_factor(BADev d) {
+  // lane = 6*row + col of a 6x6 block, blocks exchanged through LDS (one set per wave)
+  __shared__ __attribute__((aligned(16))) double sEw[2][36], sDw[2][36], sLw[2][36];
+  const int c = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int ln = lane < 36 ? lane : lane - 36;
   const int r = ln / 6, q = ln % 6;
-  const int b = d.pc_off[c], e = d.pc_off[c + 1];
+  const int cb = d.pc_off[c], ce = d.pc_off[c + 1];
+  const int far = d.pc_far_pos[c];                                      // -1: not twisted
+  const int b = far < 0 ? cb : (wave == 0 ? cb : far + 1);              // this wave's range [b, e)
+  const int e = far < 0 ? (wave == 0 ? ce : cb) : (wave == 0 ? far + 1 : ce - 1);
+  double* sE = sEw[wave]; double* sD = sDw[wave]; double* sL = sLw[wave];
   bool bad = false;
   // the inputs of a step (A_k, E_{k-1,k}) do not depend on the recursion and sit behind a two-level pointer chase through HBM
   // (pc_pose / pc_edge -> Adg / Hpp_ep): they are requested a CHUNK of 8 steps ahead, their indices two chunks ahead, into register sets
   // that rotate at the end of a chunk (a rotation inside every step would wait for the loads of that very step)
   constexpr int CH = 8;
   const double* __restrict__ Hbase = d.Ep > 0 ? d.Hpp_ep : d.Adg;      // (a graph without EdgeSE3: every entry is -1, the address only has to be valid)
-  auto idx_p = [&](int k) -> int { return d.pc_pose[k < e ? k : e - 1]; };
-  auto idx_e = [&](int k) -> int { const int t = d.pc_edge[k < e ? k : e - 1]; return k > b ? t : -1; };
+  const int last = ce - 1;
+  auto idx_p = [&](int k) -> int { return d.pc_pose[k < e ? k : last]; };
+  auto idx_e = [&](int k) -> int { const int t = d.pc_edge[k < e ? k : last]; return k < e ? t : -1; };      // (-1: a chain head, or the head of a twisted chain's second half)
   auto fetch_a = [&](int p) -> double { return d.Adg[36 * (int64_t)p + ln]; };
   auto fetch_e = [&](int ent) -> double {
     const int en = ent < 0 ? 0 : ent;
     return Hbase[36 * (int64_t)(en >> 1) + ((en & 1) ? q * 6 + r : ln)];      // E = block (previous pose, this pose); ent < 0: unused
   };
+  // the joint's inputs (wave 1 of a twisted chain), requested up front
+  double Aj = 0.0, Ej = 0.0, Ef = 0.0;
+  if (far >= 0) { Aj = fetch_a(d.pc_pose[last]); Ej = fetch_e(d.pc_edge[last]); Ef = fetch_e(d.pc_far_edge[c]); }
   int pi[CH], ti[CH];
   double A[CH], E[CH];
 #pragma unroll
@@ -459,28 +546,39 @@ __global__ __launch_bounds__(64) void k_pchain_factor(BADev d) {
         t = __builtin_fma(sL[r * 6 + 2], sE[12 + q], __builtin_fma(sL[r * 6 + 1], sE[6 + q], sL[r * 6] * sE[q])) +
             __builtin_fma(sL[r * 6 + 5], sE[30 + q], __builtin_fma(sL[r * 6 + 4], sE[24 + q], sL[r * 6 + 3] * sE[18 + q]));      // Delta = A - L E
         a -= t;
-        // in-place Gauss-Jordan inverse (SPD: no pivoting) IN REGISTERS: the pivot is a v_readlane, its row and column come
-        // through ds_bpermute (no LDS round trip, no barrier), the reciprocal is v_rcp_f64 + two Newton steps running under the
-        // permutes - this is the preconditioner, not the solve: its rounding only has to be deterministic.
-        // A non-positive pivot flags the factorisation as failed.
-#pragma unroll
-        for (int kk = 0; kk < 6; ++kk) {
-          const double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a), kk * 7), __builtin_amdgcn_readlane(__double2loint(a), kk * 7));
-          const double aik = __shfl(a, r * 6 + kk, 64), akj = __shfl(a, kk * 6 + q, 64);
-          if (!(pv > 0)) bad = true;
-          double rp = __builtin_amdgcn_rcp(pv);
-          rp = __builtin_fma(__builtin_fma(-pv, rp, 1.0), rp, rp);
-          rp = __builtin_fma(__builtin_fma(-pv, rp, 1.0), rp, rp);      // (the second step is free: the chain waits for the permutes - measured)
-          const double rowv = akj * rp, colv = -aik * rp, gen = a - aik * rowv;      // (selects, not branches: all four are a few cycles)
-          const double on_row = q == kk ? rp : rowv, off_row = q == kk ? colv : gen;
-          a = r == kk ? on_row : off_row;
-        }
-        sD[ln] = a; d.Minv[36 * (int64_t)k + ln] = a;
+        a = chain_inv6<INV>(a, ln, r, q, sD, bad);      // (leaves the inverse in sD: the next step's Delta_prev^-1)
+        d.Minv[36 * (int64_t)k + ln] = a;
         chain_wave_sync();
       }
     }
 #pragma unroll
     for (int j = 0; j < CH; ++j) { A[j] = An[j]; E[j] = ti[j] < 0 ? 0.0 : En[j]; pi[j] = pn[j]; ti[j] = tn[j]; }
+  }
+  if (far >= 0) {                                    // (uniform over the workgroup)
+    __syncthreads();                                 // both halves done: sDw[0] = Delta_far^-1, sDw[1] = Delta^-1 of position e - 2 ... of the chain
+    if (wave == 1) {
+      const double* sD0 = sDw[0];
+      double a = Aj;
+      sE[ln] = Ej;
+      chain_wave_sync();
+      double t = __builtin_fma(sE[12 + r], sD[12 + q], __builtin_fma(sE[6 + r], sD[6 + q], sE[r] * sD[q])) +
+                 __builtin_fma(sE[30 + r], sD[30 + q], __builtin_fma(sE[24 + r], sD[24 + q], sE[18 + r] * sD[18 + q]));       // L = E^T Delta_prev^-1  (ordinary link)
+      sL[ln] = t; d.Lc[36 * (int64_t)last + ln] = t;
+      chain_wave_sync();
+      a -= __builtin_fma(sL[r * 6 + 2], sE[12 + q], __builtin_fma(sL[r * 6 + 1], sE[6 + q], sL[r * 6] * sE[q])) +
+           __builtin_fma(sL[r * 6 + 5], sE[30 + q], __builtin_fma(sL[r * 6 + 4], sE[24 + q], sL[r * 6 + 3] * sE[18 + q]));
+      chain_wave_sync();
+      sE[ln] = Ef;
+      chain_wave_sync();
+      t = __builtin_fma(sE[12 + r], sD0[12 + q], __builtin_fma(sE[6 + r], sD0[6 + q], sE[r] * sD0[q])) +
+          __builtin_fma(sE[30 + r], sD0[30 + q], __builtin_fma(sE[24 + r], sD0[24 + q], sE[18 + r] * sD0[18 + q]));           // L_far = E_far^T Delta_far^-1
+      sL[ln] = t; d.Lfar[36 * (int64_t)c + ln] = t;
+      chain_wave_sync();
+      a -= __builtin_fma(sL[r * 6 + 2], sE[12 + q], __builtin_fma(sL[r * 6 + 1], sE[6 + q], sL[r * 6] * sE[q])) +
+           __builtin_fma(sL[r * 6 + 5], sE[30 + q], __builtin_fma(sL[r * 6 + 4], sE[24 + q], sL[r * 6 + 3] * sE[18 + q]));
+      a = chain_inv6<INV>(a, ln, r, q, sD, bad);
+      d.Minv[36 * (int64_t)last + ln] = a;
+    }
   }
   if (bad && lane == 0) atomicOr(d.flags, 1);
 }
@@ -518,9 +616,21 @@ __device__ void pchain_apply(const BADev& d, int c, const double* __restrict__ r
       ycol = __shfl(ynew, (col < 6 ? col : 0) * 8, 64);
     }
     __threadfence_block();      // the y parked in z by other lanes of this wave must be visible to the loads below
+    // (twisted chain: the joint - the last position - also hangs on position far:  y_last -= L_far y_far, and on the way back z_far -= L_far^T z_last)
+    const int far = d.pc_far_pos[c];
+    const double lf = (far >= 0 && act) ? d.Lfar[36 * (int64_t)c + el] : 0.0, lfT = (far >= 0 && act) ? d.Lfar[36 * (int64_t)c + elT] : 0.0;
+    if (far >= 0) {
+      const int64_t pf = d.pc_pose[far], pl = d.pc_pose[e - 1];
+      const double yf = act ? z[6 * pf + col] : 0.0;
+      const double ynew = (act ? z[6 * pl + row] : 0.0) - row_sum6(act ? lf * yf : 0.0);
+      __builtin_amdgcn_wave_barrier();
+      if (act && col == 0) z[6 * pl + row] = ynew;
+      ycol = __shfl(ynew, (col < 6 ? col : 0) * 8, 64);
+      __threadfence_block();
+    }
     // ---- backward: z_last = Dinv y ; z_k = Dinv_k y_k - L_{k+1}^T z_{k+1}
     //      after the forward loop ycol holds y_{e-1}[col]
-    double zcol = 0.0;
+    double zcol = 0.0, zlast = 0.0;
     double dnext = act ? d.Minv[36 * (int64_t)(e - 1) + el] : 0.0;
     double ltnext = 0.0;
     for (int k = e - 1; k >= b; --k) {
@@ -528,10 +638,12 @@ __device__ void pchain_apply(const BADev& d, int c, const double* __restrict__ r
       if (k - 1 >= b && act) { dnext = d.Minv[36 * (int64_t)(k - 1) + el]; ltnext = d.Lc[36 * (int64_t)k + elT]; }
       p = d.pc_pose[k];
       if (k < e - 1) ycol = act ? z[6 * p + col] : 0.0;       // y_k was parked in z by the forward pass
-      const double zk = row_sum6(act ? (dk * ycol - ltk * zcol) : 0.0);
+      const double farterm = k == far ? lfT * zlast : 0.0;      // z_far = Dinv_far y_far - L_{far+1}^T z_{far+1} - L_far^T z_last   (L_{far+1} = 0: the second half starts there)
+      const double zk = row_sum6(act ? (dk * ycol - ltk * zcol - farterm) : 0.0);
       __builtin_amdgcn_wave_barrier();
       if (act && col == 0) z[6 * p + row] = zk;
       zcol = __shfl(zk, (col < 6 ? col : 0) * 8, 64);
+      if (k == e - 1) zlast = zcol;
     }
   }
 }
@@ -635,7 +747,7 @@ __device__ __forceinline__ void wave_lds_sync() {      // LDS writes of this wav
 
 // yb [len][6] (r of the chain, staged by ALL threads of the workgroup before the call) -> z.  Called by every thread of the workgroup
 // (blockDim = 64 * pc_nwave); bnd: [16][6] doubles of LDS for the boundary vectors.  Ends with a barrier.
-__device__ void pchain_solve_partitioned(const BADev& d, int bgn, int len, double* yb, double* bnd) {
+__device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len, double* yb, double* bnd) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   const int G = pc_seg_len(len, nwave), S = (len + G - 1) / G;
   const int k0 = wave * G, n = wave < S ? (len - k0 < G ? len - k0 : G) : 0;
@@ -666,23 +778,39 @@ __device__ void pchain_solve_partitioned(const BADev& d, int bgn, int len, doubl
     }
   }
   __syncthreads();
-  if (n > 0) {
-    if (wave > 0) {                                              // y_k = yhat_k + P_k y_in
-      double yin[6];
+  // A TWISTED chain (capi_ba.hip; uniform over the workgroup): its last position - the joint - also hangs on position far_l, the end of the first half.  The
+  // second half starts with L = 0, so the recurrences above and below run over the whole strip unchanged; what the far link adds is one block product on the
+  // way down (y_last -= L_far y_far, once y_far is final) and one on the way up (w_far -= L_far^T z_last, z_last = w_last, before the backward recurrences start).
+  const int far_l = d.pc_far_pos[c] < 0 ? -1 : d.pc_far_pos[c] - bgn;
+  const double* __restrict__ Lf = d.Lfar + 36 * (int64_t)c;
+  if (n > 0 && wave > 0) {                                       // y_k = yhat_k + P_k y_in
+    double yin[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) yin[i] = bnd[6 * (wave - 1) + i];
-      for (int base = 0; base < n; base += 10) {
-        const int k = base + pr_k;
-        if (lane < 60 && k < n) {
-          const double* P = d.Pf + 36 * (c0 + k) + 6 * pr_a;
-          double acc = yb[6 * (k0 + k) + pr_a];
+    for (int i = 0; i < 6; ++i) yin[i] = bnd[6 * (wave - 1) + i];
+    for (int base = 0; base < n; base += 10) {
+      const int k = base + pr_k;
+      if (lane < 60 && k < n) {
+        const double* P = d.Pf + 36 * (c0 + k) + 6 * pr_a;
+        double acc = yb[6 * (k0 + k) + pr_a];
 #pragma unroll
-          for (int i = 0; i < 6; ++i) acc += P[i] * yin[i];
-          yb[6 * (k0 + k) + pr_a] = acc;
-        }
+        for (int i = 0; i < 6; ++i) acc += P[i] * yin[i];
+        yb[6 * (k0 + k) + pr_a] = acc;
       }
-      wave_lds_sync();
     }
+    wave_lds_sync();
+  }
+  if (far_l >= 0) {
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      const int a = threadIdx.x;
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc += Lf[6 * a + i] * yb[6 * far_l + i];
+      yb[6 * (len - 1) + a] -= acc;
+    }
+    __syncthreads();
+  }
+  if (n > 0) {
     for (int base = 0; base < n; base += 10) {                   // w_k = Dinv_k y_k  (a round reads its 10 positions, then writes them)
       const int k = base + pr_k;
       const bool on = lane < 60 && k < n;
@@ -697,8 +825,19 @@ __device__ void pchain_solve_partitioned(const BADev& d, int bgn, int len, doubl
       if (on) yb[6 * (k0 + k) + pr_a] = w;
     }
     wave_lds_sync();
-    pseg_backward(d, c0, n, yb + 6 * k0);
   }
+  if (far_l >= 0) {
+    __syncthreads();
+    if (threadIdx.x < 6) {
+      const int a = threadIdx.x;
+      double acc = 0.0;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) acc += Lf[6 * i + a] * yb[6 * (len - 1) + i];
+      yb[6 * far_l + a] -= acc;
+    }
+    __syncthreads();
+  }
+  if (n > 0) pseg_backward(d, c0, n, yb + 6 * k0);
   __syncthreads();
   if (wave == 0 && S > 1) {                                      // Z_s = true z at the first position of segment s, s = S-1 .. 1 -> bnd[6 s]
     const int a = lane < 6 ? lane : 0;
@@ -1146,7 +1285,7 @@ __global__ __launch_bounds__(1024) void k_pcg_chain(BADev d, double tol2, int pa
     d.rp[g] = r;
     if (in_lds) strip[i] = r;
   }
-  if (in_lds) pchain_solve_partitioned(d, bgn, len, strip, bnd);
+  if (in_lds) pchain_solve_partitioned(d, c, bgn, len, strip, bnd);
   else {                                             // (a chain too long for the LDS: one wave, vectors in global memory)
     __threadfence();
     __syncthreads();
@@ -1622,7 +1761,11 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
   hipStream_t sr = two ? side : s;
   if (two) { hipEventRecord(fork, s); hipStreamWaitEvent(side, fork, 0); }
   if (precond) {
-    hipLaunchKernelGGL(k_pchain_factor, dim3(d.n_pchains), dim3(64), 0, s, d);
+    // (A/B on one box, ms per LM iteration, 60-frame | 1 M-point graph: twisted + Gauss-Jordan 0.410 | 0.906, twisted + closed form 0.416 | 0.939,
+    // untwisted + Gauss-Jordan - rounds 2-4 - 0.423 | 0.979, untwisted + closed form 0.435 | 1.030; profiles/r05_chain_ab.txt)
+    static const bool closed_form = std::getenv("VDO_BA_PCHAIN_CLOSED") != nullptr;
+    if (closed_form) hipLaunchKernelGGL(k_pchain_factor<0>, dim3(d.n_pchains), dim3(128), 0, s, d);
+    else hipLaunchKernelGGL(k_pchain_factor<1>, dim3(d.n_pchains), dim3(128), 0, s, d);
     if (d.pc_lds && d.pc_nwave > 1) hipLaunchKernelGGL(k_pchain_prefix, dim3(d.n_pchains), dim3(64 * d.pc_nwave), 0, s, d);
   }
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<1>, schur_lds(d)), sr, d, (const double*)nullptr, (const double*)nullptr);

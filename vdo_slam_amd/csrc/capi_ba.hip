@@ -429,7 +429,13 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   // (EdgeSE3) graph that are simple paths - the odometry chain of the cameras, the smoothness chain of
   // every object's motions (src/Optimizer.cc:1590-1612, 1743-1766) - in path order; every other pose
   // (isolated, or part of a branching / cyclic component) is a chain of length 1 (plain block-Jacobi).
-  std::vector<int32_t> pc_off{0}, pc_pose, pc_edge;
+  // Round 5: a path of >= kTwistMin poses is stored in TWISTED order - first half p_0 .. p_{m-1}, then the second half BACKWARDS p_{n-1} .. p_{m+1}, then p_m
+  // (the joint) - so that its block LDL^T is two independent recurrences of half the depth that meet in one step (k_pchain_factor runs them on two waves).
+  // In that order position m (p_{n-1}) has no predecessor (pc_edge = -1: L = 0, the substitutions restart there by themselves) and the joint has two: position
+  // n-2 (the ordinary link) and position m-1 - the chain's one FAR link (pc_far_pos / pc_far_edge, -1 for an untwisted chain).  No fill-in: an exact
+  // factorisation of the same block-tridiagonal matrix, reordered.
+  std::vector<int32_t> pc_off{0}, pc_pose, pc_edge, pc_far_pos, pc_far_edge;
+  const int kTwistMin = std::getenv("VDO_BA_NO_TWIST") ? (1 << 30) : 16;
   std::vector<char> comp_ok_all;
   {
     std::vector<int> deg(P, 0);
@@ -460,11 +466,15 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     std::vector<char> done(P, 0);
     for (int p0 = 0; p0 < P; ++p0) {
       if (done[p0]) continue;
-      if (!comp_ok[comp[p0]] || deg[p0] == 0) { done[p0] = 1; pc_pose.push_back(p0); pc_edge.push_back(-1); pc_off.push_back((int32_t)pc_pose.size()); continue; }
+      if (!comp_ok[comp[p0]] || deg[p0] == 0) {
+        done[p0] = 1; pc_pose.push_back(p0); pc_edge.push_back(-1); pc_off.push_back((int32_t)pc_pose.size()); pc_far_pos.push_back(-1); pc_far_edge.push_back(-1);
+        continue;
+      }
       if (deg[p0] != 1) continue;                       // start paths at their lower-numbered end point
+      std::vector<int32_t> nodes, via_of;               // the path, and for t >= 1 the link nodes[t-1] -> nodes[t] (edge << 1 | side)
       int prev = -1, cur = p0, via = -1;
       while (cur != -1) {
-        done[cur] = 1; pc_pose.push_back(cur); pc_edge.push_back(via);
+        done[cur] = 1; nodes.push_back(cur); via_of.push_back(via);
         int nxt = -1, nvia = -1;
         for (int k = pe_off[cur]; k < pe_off[cur + 1]; ++k) {
           const int e = pe_idx[k] >> 1, side = pe_idx[k] & 1;
@@ -473,9 +483,23 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
         }
         prev = cur; cur = nxt; via = nvia;
       }
+      const int n = (int)nodes.size(), base = (int)pc_pose.size();
+      if (n < kTwistMin) {
+        for (int t = 0; t < n; ++t) { pc_pose.push_back(nodes[t]); pc_edge.push_back(via_of[t]); }
+        pc_far_pos.push_back(-1); pc_far_edge.push_back(-1);
+      } else {
+        const int m = n / 2;
+        for (int t = 0; t < m; ++t) { pc_pose.push_back(nodes[t]); pc_edge.push_back(via_of[t]); }
+        // second half backwards: position m + u holds nodes[n-1-u]; its predecessor position holds nodes[n-u], the link between them is via_of[n-u] walked the other way
+        for (int u = 0; n - 1 - u > m; ++u) { pc_pose.push_back(nodes[n - 1 - u]); pc_edge.push_back(u == 0 ? -1 : (via_of[n - u] ^ 1)); }
+        pc_pose.push_back(nodes[m]); pc_edge.push_back(via_of[m + 1] ^ 1);      // the joint: ordinary link from nodes[m+1] (position n-2) ...
+        pc_far_pos.push_back(base + m - 1); pc_far_edge.push_back(via_of[m]);    // ... and the far link from nodes[m-1] (position m-1)
+      }
       pc_off.push_back((int32_t)pc_pose.size());
     }
-    for (int p = 0; p < P; ++p) if (!done[p]) { pc_pose.push_back(p); pc_edge.push_back(-1); pc_off.push_back((int32_t)pc_pose.size()); }   // unreachable, defensive
+    for (int p = 0; p < P; ++p) if (!done[p]) {      // unreachable, defensive
+      pc_pose.push_back(p); pc_edge.push_back(-1); pc_off.push_back((int32_t)pc_pose.size()); pc_far_pos.push_back(-1); pc_far_edge.push_back(-1);
+    }
   }
   const int n_pchains = (int)pc_off.size() - 1;
   {   // every EdgeSE3 on a simple path? (else the auto solver choice goes to the dense Cholesky, ba_lm.hip)
@@ -564,6 +588,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     if (const char* e = std::getenv("VDO_BA_CHAIN_WAVES")) d.pc_nwave = std::min(16, std::max(1, std::atoi(e)));
   }
   UP(pc_off, pc_off.data(), pc_off.size()); UP(pc_pose, pc_pose.data(), P); UP(pc_edge, pc_edge.data(), P);
+  UP(pc_far_pos, pc_far_pos.data(), pc_far_pos.size()); UP(pc_far_edge, pc_far_edge.data(), pc_far_edge.size());
   const double* Z = nullptr;
   UP(Hpp, Z, 42 * (size_t)P + 4);                      // Hpp | bp | red_chi contiguous: one all-reduce per linearisation when sharded
   ba->d.bp = ba->d.Hpp + 36 * (size_t)P; ba->d.red_chi = ba->d.bp + 6 * (size_t)P;
@@ -575,7 +600,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(part_red, Z, 256);
   UP(Dinv, Z, 9 * (size_t)L); UP(Gl, Z, 9 * (size_t)L); UP(Gdiag, Z, 9 * (size_t)L); UP(Goff, Z, 9 * (size_t)L);
   UP(xl, Z, 3 * (size_t)L); UP(dscal, Z, (size_t)std::max(L, 1));
-  UP(Minv, Z, 36 * (size_t)P); UP(Lc, Z, 36 * (size_t)P); UP(Pf, Z, 36 * (size_t)P); UP(Qb, Z, 36 * (size_t)P); UP(Adg, Z, 36 * (size_t)P);
+  UP(Minv, Z, 36 * (size_t)P); UP(Lc, Z, 36 * (size_t)P); UP(Lfar, Z, 36 * (size_t)std::max(n_pchains, 1)); UP(Pf, Z, 36 * (size_t)P); UP(Qb, Z, 36 * (size_t)P); UP(Adg, Z, 36 * (size_t)P);
   UP(xp, Z, 6 * (size_t)P); UP(rp, Z, 6 * (size_t)P); UP(zp, Z, 6 * (size_t)P); UP(pp, Z, 6 * (size_t)P); UP(pp2, Z, 6 * (size_t)P);
   UP(qp, Z, 6 * (size_t)P); UP(bs, Z, 6 * (size_t)P); UP(qs, Z, 6 * (size_t)P);
   UP(part_pq, Z, (size_t)(P + 3) / 4 + 1); UP(part_rz, Z, (size_t)n_pchains + 1);
