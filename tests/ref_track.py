@@ -113,10 +113,10 @@ class RefSystem:
 
 # ---- the same through a child process (GPU tests: the reference's single-threaded code with its never-initialised reads stays out of a process that
 # carries the HIP runtime and the product's helper threads) -----------------------------------------------------------------------------------
-def worker_main(settings, frames_npz, out_npz, n_images, labels):
+def worker_main(settings, frames_npz, out_npz, n_images, labels, full=False):
     z = np.load(frames_npz)
     n = int(z["n"])
-    rs = RefSystem(settings)
+    rs = RefSystem(settings, full=full)
     out = {"n": n}
     for k in range(n):
         fr = {q: z[f"{q}_{k}"] for q in ("gray", "depth_raw", "flow", "mask")}
@@ -136,8 +136,8 @@ def worker_main(settings, frames_npz, out_npz, n_images, labels):
     np.savez(out_npz, **out)
 
 
-def run_sequence_in_subprocess(settings, frames, tmp_dir, n_images=1 << 30, labels=(1, 2, 3, 4, 5, 6, 7, 8)):
-    """frames: list of dict(gray, depth_raw, flow, mask).  Returns the npz the worker wrote (per frame: T_k, depth_k, mask_k, s{what}_k / n{what}_k in
+def run_sequence_in_subprocess(settings, frames, tmp_dir, n_images=1 << 30, labels=(1, 2, 3, 4, 5, 6, 7, 8), full=False):
+    """frames: list of dict(gray, depth_raw, flow, mask); full: libref_full.so - the reference's REAL Optimizer.cc + g2o behind Track().  Returns the npz the worker wrote (per frame: T_k, depth_k, mask_k, s{what}_k / n{what}_k in
     the layouts of RefSystem.state, counts_k; tracklets at the end)."""
     import subprocess
     import sys
@@ -148,7 +148,7 @@ def run_sequence_in_subprocess(settings, frames, tmp_dir, n_images=1 << 30, labe
             d[f"{q}_{k}"] = np.ascontiguousarray(fr[q])
     np.savez(fin, **d)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = f"import sys; sys.path.insert(0, {root!r}); from tests.ref_track import worker_main; worker_main({str(settings)!r}, {fin!r}, {fout!r}, {int(n_images)}, {tuple(labels)!r})"
+    code = f"import sys; sys.path.insert(0, {root!r}); from tests.ref_track import worker_main; worker_main({str(settings)!r}, {fin!r}, {fout!r}, {int(n_images)}, {tuple(labels)!r}, {bool(full)!r})"
     subprocess.run([sys.executable, "-c", code], check=True, stdout=subprocess.DEVNULL, cwd=root)
     return np.load(fout)
 

@@ -404,7 +404,9 @@ def test_pose_chain_solver_is_the_same_operator_however_it_is_partitioned(ctx, o
     (ba_solve.hip pchain_solve_partitioned: zero-input recurrences + prefix products P_k / Q_k + boundary pass).  One segment
     (the plain recurrence), the default cut, the finest cut (8 positions per segment, last one ragged: 12 = 8 + 4, 20 = 8 + 8 + 4,
     150 = 15 x 10) and the global-memory path for chains too long for the LDS are the same operator up to rounding: the LM takes the
-    same iterations and trials to the same chi2 and estimates - and those are the oracle's (direct solve)."""
+    same iterations and trials to the same chi2 and estimates - and those are the oracle's (direct solve).  Round 5: chains of >= 16 poses are
+    stored TWISTED (first half, second half backwards, the middle pose last with a far link: capi_ba.hip) - each of the four cuts with and without
+    (VDO_BA_NO_TWIST), and the closed-form block inverse of k_pchain_factor beside the Gauss-Jordan one."""
     from vdo_slam_amd.ba import BatchBA
     g = synth.make_ba_graph(n_frames, 40 * n_frames, 2, 30, seed=11)
     gc, keep = K.graph_to_c(g)
@@ -413,8 +415,10 @@ def test_pose_chain_solver_is_the_same_operator_however_it_is_partitioned(ctx, o
     pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
     assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(pose_o), K._dp(point_o), C.byref(st_o)) == 0
     runs = {}
-    for name, env in (("one_segment", {"VDO_BA_CHAIN_WAVES": "1"}), ("default", {}), ("finest", {"VDO_BA_CHAIN_WAVES": "16"}), ("global", {"VDO_BA_CHAIN_GLOBAL": "1"})):
-        for k_ in ("VDO_BA_CHAIN_WAVES", "VDO_BA_CHAIN_GLOBAL"):
+    cuts = (("one_segment", {"VDO_BA_CHAIN_WAVES": "1"}), ("default", {}), ("finest", {"VDO_BA_CHAIN_WAVES": "16"}), ("global", {"VDO_BA_CHAIN_GLOBAL": "1"}))
+    variants = [(n_ + "_untwisted", dict(e_, VDO_BA_NO_TWIST="1")) for n_, e_ in cuts] + list(cuts) + [("closed_form_inverse", {"VDO_BA_PCHAIN_CLOSED": "1"})]
+    for name, env in variants:
+        for k_ in ("VDO_BA_CHAIN_WAVES", "VDO_BA_CHAIN_GLOBAL", "VDO_BA_NO_TWIST", "VDO_BA_PCHAIN_CLOSED"):
             monkeypatch.delenv(k_, raising=False)
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)                     # (read when the graph is uploaded)
@@ -423,7 +427,7 @@ def test_pose_chain_solver_is_the_same_operator_however_it_is_partitioned(ctx, o
         pose, point = ba.estimates()
         runs[name] = (st.iterations, st.total_trials, st.final_chi2, pose.copy(), point.copy())
         ba.close()
-    ref = runs["one_segment"]
+    ref = runs["one_segment_untwisted"]                     # (rounds 3-4's plain recurrence)
     assert ref[0] == st_o.iterations and ref[1] == st_o.total_trials
     assert abs(ref[2] - st_o.final_chi2) <= 1e-6 * st_o.final_chi2
     for name, r in runs.items():

@@ -216,17 +216,20 @@ def test_tracking_frame_state_matches_the_oracle(host, oracle, tmp_path):
     host.host_system_destroy(sys_)
 
 
+@pytest.mark.parametrize("full", [False, True])
 @pytest.mark.parametrize("noise", [0.0, 0.1])
-def test_system_trackrgbd_equals_the_reference_source(host, noise, tmp_path):
-    """The PRODUCT's System::TrackRGBD (HIP kernels under the reference's class signatures) against oracle/_ref/libref_track.so = the reference's OWN
+def test_system_trackrgbd_equals_the_reference_source(host, noise, full, tmp_path):
+    """full = True (round 5): against oracle/_ref/libref_full.so - the WHOLE reference, its real Optimizer.cc and all of g2o included, compiled verbatim
+    against a mini-Eigen (tests/test_ref_g2o.py, tests/test_ref_full.py): no oracle anywhere between the product and the reference's own source.
+    full = False: The PRODUCT's System::TrackRGBD (HIP kernels under the reference's class signatures) against oracle/_ref/libref_track.so = the reference's OWN
     System.cc / Tracking.cc / Frame.cc / Map.cc / ORBextractor.cc compiled verbatim (oracle/ref/, tests/test_ref_track.py): the pose TrackRGBD returns,
     the renewed static and object sets with their 3-D points and labels, the per-object vectors, the recovered mask and the converted depth map, frame
     by frame, bit for bit (object motions to 5e-6: the kernel's LM against the oracle's behind the reference's Optimizer statics).  The reference side
     runs in a child process (tests/ref_track.py): its code reads members it never initialises, which does not mix with the HIP runtime's threads."""
     from tests import oracle_lib
     from tests.ref_track import run_sequence_in_subprocess
-    if oracle_lib.load_ref_track() is None:
-        pytest.skip("parity unpinned: oracle/_ref/libref_track.so absent")
+    if (oracle_lib.load_ref_full() if full else oracle_lib.load_ref_track()) is None:
+        pytest.skip("parity unpinned: oracle/_ref/libref_%s.so absent" % ("full" if full else "track"))
     host.host_system_frame_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
     n_frames = 6
     fx, fy, cx, cy = synth.KITTI_K
@@ -237,7 +240,7 @@ def test_system_trackrgbd_equals_the_reference_source(host, noise, tmp_path):
     drop = {3: {1}, 4: {1}} if noise else {}
     labels = (1, 2, 3, 4, 5, 6, 7, 8)
     frames = [SQ.render_frame(k, Ts, objs, flow_sigma=noise, drop_masks=drop) for k in range(n_frames)]
-    ref = run_sequence_in_subprocess(cfg, frames, tmp_path, labels=labels)
+    ref = run_sequence_in_subprocess(cfg, frames, tmp_path, labels=labels, full=full)
     sys_ = host.host_system_create(str(cfg).encode())
     assert sys_
 

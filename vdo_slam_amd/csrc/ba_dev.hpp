@@ -80,6 +80,7 @@ struct BADev {
   // pose chains (paths of the EdgeSE3 graph) for the block-tridiagonal preconditioner, in path order
   int n_pchains = 0;
   int pc_nwave = 1;                               // waves of a chain's workgroup = segments of the partitioned substitutions (ba_solve.hip)
+  int pc_closed = 0;                              // 1 (VDO_BA_PCHAIN_CLOSED): the closed-form block inverse in k_pchain_factor (a measured dead end, ba_solve.hip)
   int pc_maxlen = 0, pc_lds = 0;                  // longest chain; 1: a chain's strip [len][6] fits the LDS of its workgroup (k_pcg_chain), 0: global-memory path
   int32_t *pc_off = nullptr, *pc_pose = nullptr;  // [n_pchains+1], [P]
   int32_t* pc_edge = nullptr;                     // [P] edge<<1|side linking position k-1 -> k (side 0: previous pose is the edge's i), -1 at a chain head

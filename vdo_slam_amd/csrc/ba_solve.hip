@@ -663,6 +663,15 @@ __device__ void pchain_apply(const BADev& d, int c, const double* __restrict__ r
 // all-reduce - over the octet (sum over b) or over the lanes of equal b (sum over a).  The two kinds ALTERNATE: a vector that comes out
 // indexed by a (replicated along the octet) is consumed by a step that holds its block transposed and reduces over a, whose result is indexed
 // by b (replicated across the octets) - no lane permutation between steps.  The blocks do not depend on the recurrence: fetched eight steps ahead.
+// -DPCG_PROF (tools/build_variant.sh pcgprof "-DPCG_PROF" ba_solve; debug builds only): shader-clock time stamps of thread 0 of workgroup 0 of k_pcg_chain<0>
+// at the phase boundaries (tools/pcg_chain_phase_probe.py)
+#ifdef PCG_PROF
+__device__ unsigned long long g_pcg_prof[20];
+__device__ __noinline__ long long* pcg_tk() { __shared__ long long tk[20]; return tk; }
+#define PCG_TICK(slot) do { if (blockIdx.x == 0 && threadIdx.x == 0) pcg_tk()[slot] = clock64(); } while (0)
+#else
+#define PCG_TICK(slot) do { } while (0)
+#endif
 __host__ __device__ inline int pc_seg_len(int len, int nwave) { const int g = (len + nwave - 1) / nwave; return g < 8 ? 8 : g; }
 
 // y_0 = yb_0 ; y_j = yb_j - Lc[lc0 + j] y_{j-1}   (j < n), in place; one wave
@@ -754,8 +763,10 @@ __device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len
   const int64_t c0 = (int64_t)bgn + k0;                          // chain position of the segment's first pose
   const int pr_k = lane / 6, pr_a = lane - 6 * pr_k;             // lane -> (position inside a round of 10, row) for the recurrence-free passes
   __syncthreads();
+  PCG_TICK(3);
   if (n > 0) pseg_forward(d, c0, n, yb + 6 * k0);
   __syncthreads();
+  PCG_TICK(4);
   if (wave == 0 && S > 1) {                                      // Y_s = true y at the last position of segment s, s = 0 .. S-2 -> bnd[6 s]
     const int a = lane < 6 ? lane : 0;
     double Y = yb[6 * (G - 1) + a];
@@ -778,6 +789,7 @@ __device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len
     }
   }
   __syncthreads();
+  PCG_TICK(5);
   // A TWISTED chain (capi_ba.hip; uniform over the workgroup): its last position - the joint - also hangs on position far_l, the end of the first half.  The
   // second half starts with L = 0, so the recurrences above and below run over the whole strip unchanged; what the far link adds is one block product on the
   // way down (y_last -= L_far y_far, once y_far is final) and one on the way up (w_far -= L_far^T z_last, z_last = w_last, before the backward recurrences start).
@@ -810,6 +822,7 @@ __device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len
     }
     __syncthreads();
   }
+  PCG_TICK(6);
   if (n > 0) {
     for (int base = 0; base < n; base += 10) {                   // w_k = Dinv_k y_k  (a round reads its 10 positions, then writes them)
       const int k = base + pr_k;
@@ -837,8 +850,10 @@ __device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len
     }
     __syncthreads();
   }
+  PCG_TICK(7);
   if (n > 0) pseg_backward(d, c0, n, yb + 6 * k0);
   __syncthreads();
+  PCG_TICK(8);
   if (wave == 0 && S > 1) {                                      // Z_s = true z at the first position of segment s, s = S-1 .. 1 -> bnd[6 s]
     const int a = lane < 6 ? lane : 0;
     double Z = yb[6 * ((S - 1) * G) + a];
@@ -861,6 +876,7 @@ __device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len
     }
   }
   __syncthreads();
+  PCG_TICK(9);
   if (n > 0 && wave < S - 1) {                                   // z_k = zhat_k + Q_k z_in
     double zin[6];
 #pragma unroll
@@ -1268,6 +1284,7 @@ __global__ __launch_bounds__(1024) void k_pcg_chain(BADev d, double tol2, int pa
   double* red = bnd + 96;
   const int bgn = d.pc_off[c], len = d.pc_off[c + 1] - bgn;
   double alpha = 0.0, pq = 0.0, rz = 0.0;
+  PCG_TICK(0);
   if (!INIT) {
     double a = 0.0;
     for (int i = tid; i < npart; i += nth) a += d.part_pq[i];
@@ -1275,6 +1292,7 @@ __global__ __launch_bounds__(1024) void k_pcg_chain(BADev d, double tol2, int pa
     rz = d.scal[S_RZ];
     alpha = rz / pq;
   }
+  PCG_TICK(1);
   const double* __restrict__ pn = par ? d.pp : d.pp2;      // p of this iteration (k_pcg_q stored it)
   for (int i = tid; i < 6 * len; i += nth) {
     const int k = i / 6;
@@ -1285,6 +1303,7 @@ __global__ __launch_bounds__(1024) void k_pcg_chain(BADev d, double tol2, int pa
     d.rp[g] = r;
     if (in_lds) strip[i] = r;
   }
+  PCG_TICK(2);
   if (in_lds) pchain_solve_partitioned(d, c, bgn, len, strip, bnd);
   else {                                             // (a chain too long for the LDS: one wave, vectors in global memory)
     __threadfence();
@@ -1293,6 +1312,7 @@ __global__ __launch_bounds__(1024) void k_pcg_chain(BADev d, double tol2, int pa
     __threadfence();
     __syncthreads();
   }
+  PCG_TICK(10);
   double acc = 0.0;
   for (int i = tid; i < 6 * len; i += nth) {
     const int k = i / 6;
@@ -1303,6 +1323,14 @@ __global__ __launch_bounds__(1024) void k_pcg_chain(BADev d, double tol2, int pa
     acc += d.rp[g] * z;
   }
   acc = block_sum1(acc, red);
+  PCG_TICK(11);
+#ifdef PCG_PROF
+  if (!INIT && blockIdx.x == 0 && threadIdx.x == 0) {
+    const long long* tk = pcg_tk();
+    for (int i = 0; i < 11; ++i) atomicAdd(&g_pcg_prof[i], (unsigned long long)(tk[i + 1] - tk[i]));
+    atomicAdd(&g_pcg_prof[19], 1ull);
+  }
+#endif
   // ---- the chain that arrives last closes the iteration (its sum runs over the chains in index order, whoever it is)
   __shared__ int s_last;
   if (tid == 0) {
@@ -1763,8 +1791,7 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
   if (precond) {
     // (A/B on one box, ms per LM iteration, 60-frame | 1 M-point graph: twisted + Gauss-Jordan 0.410 | 0.906, twisted + closed form 0.416 | 0.939,
     // untwisted + Gauss-Jordan - rounds 2-4 - 0.423 | 0.979, untwisted + closed form 0.435 | 1.030; profiles/r05_chain_ab.txt)
-    static const bool closed_form = std::getenv("VDO_BA_PCHAIN_CLOSED") != nullptr;
-    if (closed_form) hipLaunchKernelGGL(k_pchain_factor<0>, dim3(d.n_pchains), dim3(128), 0, s, d);
+    if (d.pc_closed) hipLaunchKernelGGL(k_pchain_factor<0>, dim3(d.n_pchains), dim3(128), 0, s, d);
     else hipLaunchKernelGGL(k_pchain_factor<1>, dim3(d.n_pchains), dim3(128), 0, s, d);
     if (d.pc_lds && d.pc_nwave > 1) hipLaunchKernelGGL(k_pchain_prefix, dim3(d.n_pchains), dim3(64 * d.pc_nwave), 0, s, d);
   }
@@ -1816,6 +1843,14 @@ void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_
 extern "C" int vdo_debug_dense_prof(unsigned long long* out, int reset) {
   if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(vdo::g_asm_prof), sizeof(unsigned long long) * 16) != hipSuccess) return 1;
   if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vdo::g_asm_prof), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif
+
+#ifdef PCG_PROF
+extern "C" int vdo_debug_pcg_prof(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(vdo::g_pcg_prof), sizeof(unsigned long long) * 20) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[20] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(vdo::g_pcg_prof), z, sizeof(z)) != hipSuccess) return 1; }
   return 0;
 }
 #endif

@@ -584,6 +584,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     d.pc_maxlen = maxlen;
     d.pc_lds = 48 * (size_t)maxlen <= (size_t)(144 * 1024) ? 1 : 0;     // (up to 144 of the 160 KB of a CU: launch_pcg_* raise the kernels' dynamic-LDS limit)
     if (std::getenv("VDO_BA_CHAIN_GLOBAL")) d.pc_lds = 0;
+    d.pc_closed = std::getenv("VDO_BA_PCHAIN_CLOSED") ? 1 : 0;
     d.pc_nwave = d.pc_lds ? std::min(16, std::max(1, (maxlen + 7) / 8)) : 1;      // segments of >= 8 positions, one wave each
     if (const char* e = std::getenv("VDO_BA_CHAIN_WAVES")) d.pc_nwave = std::min(16, std::max(1, std::atoi(e)));
   }
