@@ -174,11 +174,16 @@ __device__ __forceinline__ void stage_slot_w_pts(const BADev& d, const Tile& T, 
   for (int i = threadIdx.x; i < 3 * npts; i += blockDim.x) pts[i] = point[i];
 }
 // incidence li of the tile (key = slot << 16 | local point) -> its factored block (we from HBM, c from LDS)
+// PLANES: the tile's points sit in LDS as three planes x | y | z, VDO_TILE_PLANE doubles apart (k_schur_tile, as in the sweep: a coordinate of the points of 64 edges is
+// one conflict-free 8-byte read per half wave; [l][3] puts every third bank under double load); else [l][3]
+#define VDO_TILE_PLANE (VDO_TILE_PTS + 2)
+template <bool PLANES = false>
 __device__ __forceinline__ FInc make_f(const BADev& d, const Tile& T, int li, int kind, int key, double we, const double* slotW, const double* pts) {
   int lp = key & 0xffff;                                   // kind 0: the observed point; kind 2: p2
   if (kind == 1) lp = d.et_key[T.et_begin + (li - (T.eb_end - T.eb_begin))] >> 16;     // (H, p1): c = H^-1 p2 as well
   const double* W = slotW + 12 * (key >> 16);
-  const D3 c = cam_point(W, D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]});
+  const D3 p = PLANES ? D3{pts[lp], pts[VDO_TILE_PLANE + lp], pts[2 * VDO_TILE_PLANE + lp]} : D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]};
+  const D3 c = cam_point(W, p);
   return FInc{we, c.x, c.y, c.z};
 }
 // explicit 6x3 block (row-major 18) — used by the preconditioner and the debug expansion
@@ -235,8 +240,8 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d, int 
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin;
   double* accm = smem;                       // [21 * S]
   double* slotW = accm + 21 * d.max_slots;   // [12 * S]
-  double* pts = slotW + 12 * d.max_slots;    // [3 * TP]
-  int* sdst = reinterpret_cast<int*>(pts + 3 * VDO_TILE_PTS);      // [S] rows of the slots' partials
+  double* pts = slotW + 12 * d.max_slots;    // [3][VDO_TILE_PLANE]: planes x | y | z (make_f<true>)
+  int* sdst = reinterpret_cast<int*>(pts + 3 * VDO_TILE_PLANE);      // [S] rows of the slots' partials
   const int my_slot = min(tid, max(nslot - 1, 0));
   int my_pose = d.tile_pose[T.slot_begin + my_slot];
   const int my_dst = d.slot_dst[T.slot_begin + my_slot];
@@ -273,7 +278,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d, int 
 #pragma unroll
   for (int q = 0; q < VDO_TILE_EPT; ++q) ecnt += (q < T.ept && keyb[q] >= 0) ? 1 : 0;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pvl[k]; }
+  for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS, q3 = (i * 0xAAAB) >> 17; if (i < 3 * npts) pts[(i - 3 * q3) * VDO_TILE_PLANE + q3] = pvl[k]; }
   __syncthreads();
   {
     // EdgeSE3PointXYZ incidences: the thread's column of the tile's edge block = <= VDO_TILE_EPT consecutive edges of ONE pose slot - their contributions
@@ -292,7 +297,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d, int 
         const int key = keyb[q];
         slot = key >> 16;
         const int64_t l = T.pt_begin + (key & 0xffff);
-        const FInc f = make_f(d, T, j, 0, key, web[q], slotW, pts);
+        const FInc f = make_f<true>(d, T, j, 0, key, web[q], slotW, pts);
         if (!DYN || sgl[q]) {
           const double sw = dsc[q] * f.we * f.we;
           const double wx = sw * f.cx, wy = sw * f.cy, wz = sw * f.cz;
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d, int 
       slot = k1 >> 16;
       const int64_t l1 = T.pt_begin + (k1 & 0xffff), l2 = T.pt_begin + (k2 & 0xffff);
       double B1[18], B2[18], M11[36], M12[36], M22[36];
-      const FInc f = make_f(d, T, nb + nt + j, 2, k2, d.Finc[(int64_t)d.Eb + T.et_begin + j], slotW, pts);
+      const FInc f = make_f<true>(d, T, nb + nt + j, 2, k2, d.Finc[(int64_t)d.Eb + T.et_begin + j], slotW, pts);
       expand_block(1, f, slotW + 12 * slot, B1);
       expand_block(2, f, slotW + 12 * slot, B2);
       bgbt(B1, d.Gdiag + 9 * l1, B1, M11);
@@ -672,10 +677,45 @@ __device__ __noinline__ long long* pcg_tk() { __shared__ long long tk[20]; retur
 #else
 #define PCG_TICK(slot) do { } while (0)
 #endif
+// LDS block of a chain's workgroup behind its strip, boundary vectors and reduction scratch: 14 boundary matrices P | 14 boundary matrices Q | L of the far link
+#define PC_BMAT_P 0
+#define PC_BMAT_Q (14 * 36)
+#define PC_BMAT_F (28 * 36)
+#define PC_BMAT_DOUBLES (29 * 36)
 __host__ __device__ inline int pc_seg_len(int len, int nwave) { const int g = (len + nwave - 1) / nwave; return g < 8 ? 8 : g; }
 
-// y_0 = yb_0 ; y_j = yb_j - Lc[lc0 + j] y_{j-1}   (j < n), in place; one wave
-__device__ void pseg_forward(const BADev& d, int64_t lc0, int n, double* yb) {
+// What a wave's part of the partitioned solve reads FIRST in each of its phases - the first chunk of L blocks of the two recurrences, the first two rounds of
+// Delta^-1 rows - depends on the factorisation only: k_pcg_chain requests it at its head (pc_prefetch), under alpha and the vector updates, instead of paying a
+// memory latency at the head of every phase (round 5, tools/pcg_chain_phase_probe.py: 2 x 9.7 k + 3.5 k cycles of the kernel's 57 k on 240-pose chains).
+struct PcPre { double fL[8], bL[8], D[2][6]; };
+__device__ __forceinline__ void pc_prefetch(const BADev& d, int bgn, int len, PcPre& q) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
+  const int G = pc_seg_len(len, nwave), S = (len + G - 1) / G;
+  const int k0 = wave * G, n = wave < S ? (len - k0 < G ? len - k0 : G) : 0;
+  const int64_t c0 = (int64_t)bgn + (n > 0 ? k0 : 0), last = (int64_t)bgn + len - 1;
+  const int a = lane >> 3, b = lane & 7;
+  const bool act = a < 6 && b < 6;
+  const int el = act ? a * 6 + b : 0, elT = act ? b * 6 + a : 0;
+  const int nst = n - 1;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {                               // (unconditional loads from clamped positions; what lies outside the segment is zeroed where it is used)
+    const int64_t pf = c0 + 1 + j, pb = c0 + n - 1 - j;
+    q.fL[j] = d.Lc[36 * (pf <= last ? pf : last) + ((j & 1) ? elT : el)];
+    q.bL[j] = d.Lc[36 * (pb >= bgn ? (pb <= last ? pb : last) : bgn) + ((j & 1) ? el : elT)];
+    if (!(j < nst && act)) { q.fL[j] = 0.0; q.bL[j] = 0.0; }
+  }
+  const int pr_k = lane / 6, pr_a = lane - 6 * pr_k;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const int64_t pd = c0 + 10 * h + pr_k;
+    const double* D = d.Minv + 36 * (pd <= last ? pd : last) + 6 * (pr_a < 6 ? pr_a : 0);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) q.D[h][i] = D[i];
+  }
+}
+
+// y_0 = yb_0 ; y_j = yb_j - Lc[lc0 + j] y_{j-1}   (j < n), in place; one wave.  L0: the first chunk of blocks (pc_prefetch)
+__device__ void pseg_forward(const BADev& d, int64_t lc0, int n, double* yb, const double (&L0)[8]) {
   const int lane = threadIdx.x & 63;
   const int a = lane >> 3, b = lane & 7;
   const bool act = a < 6 && b < 6;
@@ -686,7 +726,7 @@ __device__ void pseg_forward(const BADev& d, int64_t lc0, int n, double* yb) {
   const int nst = n - 1;
   double Lp[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) Lp[j] = (j < nst && act) ? d.Lc[36 * (lc0 + 1 + j) + ((j & 1) ? elT : el)] : 0.0;
+  for (int j = 0; j < 8; ++j) Lp[j] = L0[j];
   for (int s0 = 0; s0 < nst; s0 += 8) {
     double Ln[8];
 #pragma unroll
@@ -711,8 +751,8 @@ __device__ void pseg_forward(const BADev& d, int64_t lc0, int n, double* yb) {
   }
 }
 
-// z_{n-1} = yb_{n-1} ; z_j = yb_j - Lc[lc0 + j + 1]^T z_{j+1}, in place; one wave
-__device__ void pseg_backward(const BADev& d, int64_t lc0, int n, double* yb) {
+// z_{n-1} = yb_{n-1} ; z_j = yb_j - Lc[lc0 + j + 1]^T z_{j+1}, in place; one wave.  L0: the first chunk of blocks (pc_prefetch)
+__device__ void pseg_backward(const BADev& d, int64_t lc0, int n, double* yb, const double (&L0)[8]) {
   const int lane = threadIdx.x & 63;
   const int a = lane >> 3, b = lane & 7;
   const bool act = a < 6 && b < 6;
@@ -723,7 +763,7 @@ __device__ void pseg_backward(const BADev& d, int64_t lc0, int n, double* yb) {
   double v = b < 6 ? yb[6 * (n - 1) + ib] : 0.0;          // z_last[b]
   double Lp[8];
 #pragma unroll
-  for (int j = 0; j < 8; ++j) Lp[j] = (j < nst && act) ? d.Lc[36 * (lc0 + n - 1 - j) + ((j & 1) ? el : elT)] : 0.0;
+  for (int j = 0; j < 8; ++j) Lp[j] = L0[j];
   for (int t0 = 0; t0 < nst; t0 += 8) {
     double Ln[8];
 #pragma unroll
@@ -748,6 +788,10 @@ __device__ void pseg_backward(const BADev& d, int64_t lc0, int n, double* yb) {
   }
 }
 
+// lane i's double to every lane (i a compile-time constant): two v_readlane_b32 - no trip through the LDS crossbar, unlike __shfl
+__device__ __forceinline__ double bcast_lane(double x, int i) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), i), __builtin_amdgcn_readlane(__double2loint(x), i));
+}
 __device__ __forceinline__ void wave_lds_sync() {      // LDS writes of this wave visible to its other lanes
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -756,7 +800,7 @@ __device__ __forceinline__ void wave_lds_sync() {      // LDS writes of this wav
 
 // yb [len][6] (r of the chain, staged by ALL threads of the workgroup before the call) -> z.  Called by every thread of the workgroup
 // (blockDim = 64 * pc_nwave); bnd: [16][6] doubles of LDS for the boundary vectors.  Ends with a barrier.
-__device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len, double* yb, double* bnd) {
+__device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len, double* yb, double* bnd, const double* bmat, const PcPre& pre) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwave = blockDim.x >> 6;
   const int G = pc_seg_len(len, nwave), S = (len + G - 1) / G;
   const int k0 = wave * G, n = wave < S ? (len - k0 < G ? len - k0 : G) : 0;
@@ -764,24 +808,27 @@ __device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len
   const int pr_k = lane / 6, pr_a = lane - 6 * pr_k;             // lane -> (position inside a round of 10, row) for the recurrence-free passes
   __syncthreads();
   PCG_TICK(3);
-  if (n > 0) pseg_forward(d, c0, n, yb + 6 * k0);
+  if (n > 0) pseg_forward(d, c0, n, yb + 6 * k0, pre.fL);
   __syncthreads();
   PCG_TICK(4);
   if (wave == 0 && S > 1) {                                      // Y_s = true y at the last position of segment s, s = 0 .. S-2 -> bnd[6 s]
     const int a = lane < 6 ? lane : 0;
     double Y = yb[6 * (G - 1) + a];
     if (lane < 6) bnd[a] = Y;
+    // (the S - 2 boundary matrices P of this carry and Q of the one on the way back sit in LDS - bmat, staged by k_pcg_chain at its head: read from HBM one step
+    //  ahead, as until round 5, every step of the carry waited a whole memory latency: 2 x 14 k of the kernel's 70 k cycles on 240-pose chains, tools/pcg_chain_phase_probe.py)
+    const double* bP = bmat + PC_BMAT_P;
     double row[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) row[i] = S > 2 ? d.Pf[36 * ((int64_t)bgn + 2 * G - 1) + 6 * a + i] : 0.0;
+    for (int i = 0; i < 6; ++i) row[i] = S > 2 ? bP[6 * a + i] : 0.0;
     for (int s = 1; s <= S - 2; ++s) {
       const int e = (s + 1) * G - 1;
       double nx[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) nx[i] = s + 1 <= S - 2 ? d.Pf[36 * ((int64_t)bgn + (s + 2) * G - 1) + 6 * a + i] : 0.0;
+      for (int i = 0; i < 6; ++i) nx[i] = s + 1 <= S - 2 ? bP[36 * s + 6 * a + i] : 0.0;
       double acc = yb[6 * e + a];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) acc += row[i] * __shfl(Y, i, 64);
+      for (int i = 0; i < 6; ++i) acc += row[i] * bcast_lane(Y, i);
       Y = acc;
       if (lane < 6) bnd[6 * s + a] = Y;
 #pragma unroll
@@ -794,7 +841,7 @@ __device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len
   // second half starts with L = 0, so the recurrences above and below run over the whole strip unchanged; what the far link adds is one block product on the
   // way down (y_last -= L_far y_far, once y_far is final) and one on the way up (w_far -= L_far^T z_last, z_last = w_last, before the backward recurrences start).
   const int far_l = d.pc_far_pos[c] < 0 ? -1 : d.pc_far_pos[c] - bgn;
-  const double* __restrict__ Lf = d.Lfar + 36 * (int64_t)c;
+  const double* Lf = bmat + PC_BMAT_F;                          // (L of the far link, staged with the boundary matrices)
   if (n > 0 && wave > 0) {                                       // y_k = yhat_k + P_k y_in
     double yin[6];
 #pragma unroll
@@ -829,10 +876,15 @@ __device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len
       const bool on = lane < 60 && k < n;
       double w = 0.0;
       if (on) {
-        const double* D = d.Minv + 36 * (c0 + k) + 6 * pr_a;
         const double* y = yb + 6 * (k0 + k);
+        if (base < 20) {                                         // (the first two rounds' rows came with pc_prefetch; uniform branch)
 #pragma unroll
-        for (int i = 0; i < 6; ++i) w += D[i] * y[i];
+          for (int i = 0; i < 6; ++i) w += (base == 0 ? pre.D[0][i] : pre.D[1][i]) * y[i];
+        } else {
+          const double* D = d.Minv + 36 * (c0 + k) + 6 * pr_a;
+#pragma unroll
+          for (int i = 0; i < 6; ++i) w += D[i] * y[i];
+        }
       }
       wave_lds_sync();
       if (on) yb[6 * (k0 + k) + pr_a] = w;
@@ -851,24 +903,25 @@ __device__ void pchain_solve_partitioned(const BADev& d, int c, int bgn, int len
     __syncthreads();
   }
   PCG_TICK(7);
-  if (n > 0) pseg_backward(d, c0, n, yb + 6 * k0);
+  if (n > 0) pseg_backward(d, c0, n, yb + 6 * k0, pre.bL);
   __syncthreads();
   PCG_TICK(8);
   if (wave == 0 && S > 1) {                                      // Z_s = true z at the first position of segment s, s = S-1 .. 1 -> bnd[6 s]
     const int a = lane < 6 ? lane : 0;
     double Z = yb[6 * ((S - 1) * G) + a];
     if (lane < 6) bnd[6 * (S - 1) + a] = Z;
+    const double* bQ = bmat + PC_BMAT_Q;                         // bQ[36 (s - 1)] = Q of position s G, s = 1 .. S-2
     double row[6];
 #pragma unroll
-    for (int i = 0; i < 6; ++i) row[i] = S > 2 ? d.Qb[36 * ((int64_t)bgn + (S - 2) * G) + 6 * a + i] : 0.0;
+    for (int i = 0; i < 6; ++i) row[i] = S > 2 ? bQ[36 * (S - 3) + 6 * a + i] : 0.0;
     for (int s = S - 2; s >= 1; --s) {
       const int f = s * G;
       double nx[6];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) nx[i] = s - 1 >= 1 ? d.Qb[36 * ((int64_t)bgn + (s - 1) * G) + 6 * a + i] : 0.0;
+      for (int i = 0; i < 6; ++i) nx[i] = s - 1 >= 1 ? bQ[36 * (s - 2) + 6 * a + i] : 0.0;
       double acc = yb[6 * f + a];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) acc += row[i] * __shfl(Z, i, 64);
+      for (int i = 0; i < 6; ++i) acc += row[i] * bcast_lane(Z, i);
       Z = acc;
       if (lane < 6) bnd[6 * s + a] = Z;
 #pragma unroll
@@ -974,12 +1027,13 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   const Tile T = d.tiles[blockIdx.x];                      // (launch order: tiles with the longest landmark chains first - their serial solves would be the tail of the launch)
   const int npts = T.pt_end - T.pt_begin, nslot = T.slot_end - T.slot_begin;
   const int nb = T.eb_end - T.eb_begin, nt = T.et_end - T.et_begin, ninc = nb + 2 * nt;
-  double* u = smem;                        // [3*TP]
-  double* vs = u + 3 * VDO_TILE_PTS;       // [6*S]
+  constexpr int PL = VDO_TILE_PLANE;       // u and pts: three planes x | y | z (round 5; [l][3] until then: bank conflicts on every read and LDS atomic, as in the sweep of round 4)
+  double* u = smem;                        // [3][PL]
+  double* vs = u + 3 * PL;                 // [6*S]
   double* qs = vs + 6 * d.max_slots;       // [6*S]
   double* slotW = qs + 6 * d.max_slots;    // [12*S] inverse poses of the slots (R^T | -R^T t)
-  double* pts = slotW + 12 * d.max_slots;  // [3*TP]  the tile's points (linearisation point)
-  int* sdst = reinterpret_cast<int*>(pts + 3 * VDO_TILE_PTS);      // [S] rows of the slots' partials (requested at the head, not where they are stored to)
+  double* pts = slotW + 12 * d.max_slots;  // [3][PL]  the tile's points (linearisation point)
+  int* sdst = reinterpret_cast<int*>(pts + 3 * PL);      // [S] rows of the slots' partials (requested at the head, not where they are stored to)
   const int my_slot = min(tid, max(nslot - 1, 0));         // (tile_pose / slot_dst carry one entry of padding)
   int my_pose = d.tile_pose[T.slot_begin + my_slot];
   int my_dst = 0;
@@ -1003,7 +1057,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   double web[VDO_TILE_EPT];
 #pragma unroll
   for (int q = 0; q < VDO_TILE_EPT; ++q) { const int e = ebase + min(q, jmax) * VDO_TILE_THREADS; keyb[q] = __builtin_nontemporal_load(d.eb_key + e); web[q] = __builtin_nontemporal_load(d.Finc + e);      /* streamed once per launch: past the resident lines of L2, not through them (ba_sweep.hip VDO_NT_LOAD) */ }      // (eb_key has >= 1 entry)
-  for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) u[i] = 0.0;
+  for (int i = tid; i < 3 * PL; i += VDO_TILE_THREADS) u[i] = 0.0;
   if (MODE != 2)
     for (int i = tid; i < 6 * nslot; i += VDO_TILE_THREADS) qs[i] = 0.0;
   auto stage_slot = [&](int sidx, int pid) {
@@ -1030,7 +1084,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   D3 cbl{0.0, 0.0, 0.0};
   if (MODE != 0) cbl = D3{d.bl[3 * cp0], d.bl[3 * cp0 + 1], d.bl[3 * cp0 + 2]};
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS; if (i < 3 * npts) pts[i] = pvl[k]; }
+  for (int k = 0; k < 3; ++k) { const int i = tid + k * VDO_TILE_THREADS, q3 = (i * 0xAAAB) >> 17; if (i < 3 * npts) pts[(i - 3 * q3) * PL + q3] = pvl[k]; }      // (q3 = i / 3 for i < 768)
   __syncthreads();
   int ecnt = 0;
 #pragma unroll
@@ -1046,14 +1100,14 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   };
   auto make_c = [&](const double (&Wb)[12], int q) {
     const int lp = q < ecnt ? (keyb[q] & 0xffff) : 0;
-    return cam_point(Wb, D3{pts[3 * lp], pts[3 * lp + 1], pts[3 * lp + 2]});
+    return cam_point(Wb, D3{pts[lp], pts[PL + lp], pts[2 * PL + lp]});
   };
   // one incidence of a ternary edge (li >= nb): kind 1 = (H, p1), kind 2 = (H, p2)
   auto tern_load = [&](int li, int& key, int& kind, FInc& f) {
     key = d.inc_key[T.inc_begin + li];
     int64_t fidx;
     inc_locate(T, li, d.Eb, kind, fidx);
-    f = make_f(d, T, li, kind, key, d.Finc[fidx], slotW, pts);
+    f = make_f<true>(d, T, li, kind, key, d.Finc[fidx], slotW, pts);
   };
   if (MODE != 1) {   // pass A: u_l += B^T v_slot = sgn*we * (I or R) (vt - s c x vr)
     double pv[6], Wb[12];
@@ -1066,8 +1120,8 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
         const D3 c = make_c(Wb, q);
         const D3 t{pv[0] - 2.0 * (c.y * pv[5] - c.z * pv[4]), pv[1] - 2.0 * (c.z * pv[3] - c.x * pv[5]), pv[2] - 2.0 * (c.x * pv[4] - c.y * pv[3])};
         const D3 o = (-web[q]) * rotT(Wb, t);              // R t  (W starts with R^T)
-        double* ul = u + 3 * (keyb[q] & 0xffff);
-        atomicAdd(ul, o.x); atomicAdd(ul + 1, o.y); atomicAdd(ul + 2, o.z);
+        double* ul = u + (keyb[q] & 0xffff);
+        atomicAdd(ul, o.x); atomicAdd(ul + PL, o.y); atomicAdd(ul + 2 * PL, o.z);
       }
     }
     for (int li = nb + tid; li < ninc; li += VDO_TILE_THREADS) {
@@ -1079,8 +1133,8 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
       D3 o;
       if (kind == 1) o = f.we * t;
       else o = (-f.we) * rotT(slotW + 12 * sl, t);
-      double* ul = u + 3 * (key & 0xffff);
-      atomicAdd(ul, o.x); atomicAdd(ul + 1, o.y); atomicAdd(ul + 2, o.z);
+      double* ul = u + (key & 0xffff);
+      atomicAdd(ul, o.x); atomicAdd(ul + PL, o.y); atomicAdd(ul + 2 * PL, o.z);
     }
     __syncthreads();
   }
@@ -1089,13 +1143,13 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
     const bool pre = c == my_chain;
     const int64_t p0 = pre ? cp0 : d.chain_off[c], p1 = pre ? cp1 : d.chain_off[c + 1];
     if (p1 - p0 == 1) {                                    // w = y / (Hll + lambda)
-      double* ul = u + 3 * (p0 - T.pt_begin);
-      D3 y{ul[0], ul[1], ul[2]};
+      double* ul = u + (p0 - T.pt_begin);
+      D3 y{ul[0], ul[PL], ul[2 * PL]};
       const D3 blv = (MODE == 0 || pre) ? cbl : D3{d.bl[3 * p0], d.bl[3 * p0 + 1], d.bl[3 * p0 + 2]};
       if (MODE == 1) y = blv;
       if (MODE == 2) y = blv - y;
       const double g = pre ? cg : d.dscal[p0];
-      ul[0] = g * y.x; ul[1] = g * y.y; ul[2] = g * y.z;
+      ul[0] = g * y.x; ul[PL] = g * y.y; ul[2 * PL] = g * y.z;
       continue;
     }
     D3 yprev{0, 0, 0};
@@ -1110,14 +1164,14 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
 #pragma unroll
         for (int i = 0; i < 9; ++i) { Dn[i] = d.Dinv[9 * (l + 1) + i]; Gn[i] = d.Gl[9 * (l + 1) + i]; }
       }
-      double* ul = u + 3 * (l - T.pt_begin);
-      D3 y{ul[0], ul[1], ul[2]};
+      double* ul = u + (l - T.pt_begin);
+      D3 y{ul[0], ul[PL], ul[2 * PL]};
       if (MODE == 1) y = D3{d.bl[3 * l], d.bl[3 * l + 1], d.bl[3 * l + 2]};
       if (MODE == 2) y = D3{d.bl[3 * l], d.bl[3 * l + 1], d.bl[3 * l + 2]} - y;
       if (l > p0) y = y - rotT(Gc, yprev);                 // y_k = u_k - G_k^T y_{k-1}
       yprev = y;
       const D3 z = rot(Dc, y);
-      ul[0] = z.x; ul[1] = z.y; ul[2] = z.z;
+      ul[0] = z.x; ul[PL] = z.y; ul[2 * PL] = z.z;
     }
 #pragma unroll
     for (int i = 0; i < 9; ++i) Gn[i] = d.Gl[9 * (p1 - 1) + i];
@@ -1129,17 +1183,17 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
 #pragma unroll
         for (int i = 0; i < 9; ++i) Gn[i] = d.Gl[9 * l + i];
       }
-      const double* un = u + 3 * (l + 1 - T.pt_begin);
-      const D3 wnext{un[0], un[1], un[2]};
-      double* ul = u + 3 * (l - T.pt_begin);
-      const D3 z = D3{ul[0], ul[1], ul[2]} - rot(Gc, wnext);
-      ul[0] = z.x; ul[1] = z.y; ul[2] = z.z;
+      const double* un = u + (l + 1 - T.pt_begin);
+      const D3 wnext{un[0], un[PL], un[2 * PL]};
+      double* ul = u + (l - T.pt_begin);
+      const D3 z = D3{ul[0], ul[PL], ul[2 * PL]} - rot(Gc, wnext);
+      ul[0] = z.x; ul[PL] = z.y; ul[2 * PL] = z.z;
     }
   }
   __syncthreads();
   if (MODE == 2) {
     double* xo = d.xl + 3 * (int64_t)T.pt_begin;
-    for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) xo[i] = u[i];
+    for (int i = tid; i < 3 * npts; i += VDO_TILE_THREADS) { const int q3 = (i * 0xAAAB) >> 17; xo[i] = u[(i - 3 * q3) * PL + q3]; }
     return;
   }
   // pass C: q_slot += B w_l  (segmented wave reduction; incidences are slot-sorted per part)
@@ -1149,8 +1203,8 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
 #pragma unroll
     for (int k = 0; k < VDO_TILE_EPT; ++k) {
       if (k < ecnt) {
-        const double* wl = u + 3 * (keyb[k] & 0xffff);
-        const D3 y = rot(Wb, D3{wl[0], wl[1], wl[2]});       // R^T w
+        const double* wl = u + (keyb[k] & 0xffff);
+        const D3 y = rot(Wb, D3{wl[0], wl[PL], wl[2 * PL]});       // R^T w
         const D3 c = make_c(Wb, k);
         const double sg = -web[k];
         q[0] += sg * y.x; q[1] += sg * y.y; q[2] += sg * y.z;
@@ -1169,8 +1223,8 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
       int key, kind; FInc f;
       tern_load(li, key, kind, f);
       const int sl = key >> 16;
-      const double* wl = u + 3 * (key & 0xffff);
-      D3 y{wl[0], wl[1], wl[2]};
+      const double* wl = u + (key & 0xffff);
+      D3 y{wl[0], wl[PL], wl[2 * PL]};
       if (kind != 1) y = rot(slotW + 12 * sl, y);            // R^T w
       const double sg = kind == 1 ? f.we : -f.we;
       q[0] = sg * y.x; q[1] = sg * y.y; q[2] = sg * y.z;
@@ -1282,7 +1336,29 @@ __global__ __launch_bounds__(1024) void k_pcg_chain(BADev d, double tol2, int pa
   const bool in_lds = d.pc_lds != 0;
   double* bnd = strip + (in_lds ? 6 * (size_t)d.pc_maxlen : 0);
   double* red = bnd + 96;
+  double* bmat = red + 24;
   const int bgn = d.pc_off[c], len = d.pc_off[c + 1] - bgn;
+  // the matrices the serial parts of the solve need - boundary products of the partitioned substitutions, the far link of a twisted chain - are requested
+  // NOW (they depend on the factorisation only) and parked in LDS below, behind alpha and the vector updates
+  double bm_val[2] = {0.0, 0.0};
+  int bm_dst[2] = {-1, -1};
+  if (in_lds) {
+    const int G = pc_seg_len(len, nth >> 6), S = (len + G - 1) / G, nbm = S > 2 ? S - 2 : 0;
+    const int total = 72 * nbm + (d.pc_far_pos[c] >= 0 ? 36 : 0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {                            // (<= 1 044 items for <= 1 024 threads; the loads are unconditional - a load under a branch is waited for at its end)
+      const int it = tid + h * nth;
+      const double* src = d.Pf + 36 * (int64_t)bgn;
+      int dst = -1;
+      if (it < 36 * nbm) { const int s = it / 36 + 1, el = it - 36 * (s - 1); dst = PC_BMAT_P + it; src = d.Pf + 36 * ((int64_t)bgn + (s + 1) * G - 1) + el; }
+      else if (it < 72 * nbm) { const int t = it - 36 * nbm, s = t / 36 + 1, el = t - 36 * (s - 1); dst = PC_BMAT_Q + t; src = d.Qb + 36 * ((int64_t)bgn + s * G) + el; }
+      else if (it < total) { const int t = it - 72 * nbm; dst = PC_BMAT_F + t; src = d.Lfar + 36 * (int64_t)c + t; }
+      bm_dst[h] = dst;
+      bm_val[h] = *src;
+    }
+  }
+  PcPre pre;
+  if (in_lds) pc_prefetch(d, bgn, len, pre);
   double alpha = 0.0, pq = 0.0, rz = 0.0;
   PCG_TICK(0);
   if (!INIT) {
@@ -1303,8 +1379,10 @@ __global__ __launch_bounds__(1024) void k_pcg_chain(BADev d, double tol2, int pa
     d.rp[g] = r;
     if (in_lds) strip[i] = r;
   }
+  if (bm_dst[0] >= 0) bmat[bm_dst[0]] = bm_val[0];
+  if (bm_dst[1] >= 0) bmat[bm_dst[1]] = bm_val[1];
   PCG_TICK(2);
-  if (in_lds) pchain_solve_partitioned(d, c, bgn, len, strip, bnd);
+  if (in_lds) pchain_solve_partitioned(d, c, bgn, len, strip, bnd, bmat, pre);
   else {                                             // (a chain too long for the LDS: one wave, vectors in global memory)
     __threadfence();
     __syncthreads();
@@ -1748,7 +1826,7 @@ void launch_dense_rhs(const BADev& d, double* rhs, int64_t ld, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------ launchers
-static size_t schur_lds(const BADev& d) { return (6 * VDO_TILE_PTS + 24 * (size_t)d.max_slots + ((size_t)d.max_slots + 1) / 2) * sizeof(double); }      // (+ the slots' row ids, int32)
+static size_t schur_lds(const BADev& d) { return (6 * VDO_TILE_PLANE + 24 * (size_t)d.max_slots + ((size_t)d.max_slots + 1) / 2) * sizeof(double); }      // (+ the slots' row ids, int32)
 
 void launch_expand_binc(const BADev& d, hipStream_t s) {
   if (d.n_tiles) hipLaunchKernelGGL(k_expand_binc, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_expand_binc, (12 * (size_t)d.max_slots + 3 * VDO_TILE_PTS) * sizeof(double)), s, d);
@@ -1772,7 +1850,7 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
   if (d.n_chains) hipLaunchKernelGGL(k_factor_chains, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, lambda);
   precond = precond || d.sharded;          // (the dense solver needs the landmark factors and the reduced right-hand side only; a sharded run keeps its exchanges as they are)
   if (precond) {
-    const size_t lds = (33 * (size_t)d.max_slots + 3 * VDO_TILE_PTS + ((size_t)d.max_slots + 1) / 2) * sizeof(double);
+    const size_t lds = (33 * (size_t)d.max_slots + 3 * VDO_TILE_PLANE + ((size_t)d.max_slots + 1) / 2) * sizeof(double);
     const int nd = d.n_tiles < 1024 ? d.n_tiles : std::min(d.n_dyn_tiles, d.n_tiles);       // tiles with dynamic tracks come first in the launch order (a graph of few tiles: one launch - a second one costs more than the registers)
     if (nd > 0) hipLaunchKernelGGL(k_precond_tile<true>, dim3(nd), dim3(VDO_TILE_THREADS), raise_lds(k_precond_tile<true>, lds), s, d, 0);
     if (d.n_tiles > nd) hipLaunchKernelGGL(k_precond_tile<false>, dim3(d.n_tiles - nd), dim3(VDO_TILE_THREADS), raise_lds(k_precond_tile<false>, lds), s, d, nd);
@@ -1802,7 +1880,7 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
 }
 
 static size_t pc_strip_bytes(const BADev& d) {
-  const size_t bytes = ((d.pc_lds ? 6 * (size_t)d.pc_maxlen : 0) + 96 + 24) * sizeof(double);
+  const size_t bytes = ((d.pc_lds ? 6 * (size_t)d.pc_maxlen : 0) + 96 + 24 + PC_BMAT_DOUBLES) * sizeof(double);
   // more than the default 64 KB of dynamic LDS: tell the runtime.  The attribute is per DEVICE (a process may hold BA contexts on
   // several GPUs): the size already granted is remembered per device id; the calls are idempotent.
   static std::atomic<size_t> raised[64];
