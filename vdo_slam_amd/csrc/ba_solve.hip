@@ -44,7 +44,7 @@ __device__ __forceinline__ bool spd3_inv(const double* a, double* o) {
 // Per landmark chain: block LDL^T (Delta_k = D_k + lambda I - O^T Delta_{k-1}^-1 O) and the
 // diagonal / first off-diagonal blocks of Hll^-1 needed by the exact block-Jacobi preconditioner:
 //   G_kk = Delta_k^-1 + Gl_{k+1} G_{k+1,k+1} Gl_{k+1}^T ,  G_{k,k+1} = -Gl_{k+1} G_{k+1,k+1}
-__global__ void k_factor_chains(BADev d, double lambda) {
+__global__ __launch_bounds__(128) void k_factor_chains(BADev d, double lambda) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.n_chains) return;
   const int64_t p0 = d.chain_off[c], p1 = d.chain_off[c + 1];
@@ -57,61 +57,102 @@ __global__ void k_factor_chains(BADev d, double lambda) {
   double prev[9];
   bool ok = true;
   const int64_t Et = d.Et;
-  // (the inputs of a step do not depend on the recursion: the O block of the next step and the edge index of the one after are
-  // requested while this step computes - a step no longer waits for the pt_prev_edge -> Oll pointer chase)
-  double hl_n = d.Hll[p0];
-  int64_t e_next = p0 + 1 < p1 ? d.pt_prev_edge[p0 + 1] : 0;
-  double O[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-  for (int64_t l = p0; l < p1; ++l) {
-    const double hd = hl_n + lambda;
-    double On[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    int64_t e_nn = 0;
-    if (l + 1 < p1) {
-      hl_n = d.Hll[l + 1];
+  // The inputs of a step (Hll of the point, the O block through the pt_prev_edge -> Oll pointer chase) do not depend on the recursion, and a step is ~500 cycles of
+  // arithmetic against ~2 500 of memory latency: with the next step's inputs requested one step ahead (rounds 2-4) the walk ran at one memory latency per step.
+  // Round 5: chunks of FC steps - the next chunk's Hll and O blocks and the edge indices of the chunk after it are requested while this chunk computes (unconditional
+  // loads from clamped positions: a load under a branch is waited for at its end).
+  constexpr int FC = 4;
+  auto cl_h = [&](int64_t l) -> int64_t { return l < p1 ? l : p1 - 1; };
+  auto cl_e = [&](int64_t l) -> int64_t { return l < p1 ? (l > p0 ? l : p0 + 1) : p1 - 1; };      // (p1 - p0 >= 2 here: positions p0 + 1 .. p1 - 1 have a previous edge)
+  double hl[FC], O[FC][9];
+  int64_t en[FC];
+  {
+    int64_t e0[FC];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) On[i] = d.Oll[i * Et + e_next];
-      if (l + 2 < p1) e_nn = d.pt_prev_edge[l + 2];
-    }
-    double D[9] = {hd, 0.0, 0.0, 0.0, hd, 0.0, 0.0, 0.0, hd};
-    if (l > p0) {
-      double G[9];
-      mat3_mul(prev, O, G);
+    for (int j = 0; j < FC; ++j) { hl[j] = d.Hll[cl_h(p0 + j)]; e0[j] = d.pt_prev_edge[cl_e(p0 + j)]; }
 #pragma unroll
-      for (int i = 0; i < 9; ++i) d.Gl[9 * l + i] = G[i];
+    for (int j = 0; j < FC; ++j) en[j] = d.pt_prev_edge[cl_e(p0 + FC + j)];
 #pragma unroll
-      for (int i = 0; i < 3; ++i)
+    for (int j = 0; j < FC; ++j)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) D[3 * i + j] -= O[i] * G[j] + O[3 + i] * G[3 + j] + O[6 + i] * G[6 + j];
-    }
-    ok &= spd3_inv(D, prev);
-#pragma unroll
-    for (int i = 0; i < 9; ++i) { d.Dinv[9 * l + i] = prev[i]; O[i] = On[i]; }
-    e_next = e_nn;
+      for (int i = 0; i < 9; ++i) O[j][i] = d.Oll[i * Et + e0[j]];
   }
-  // backward: inverse blocks
+  for (int64_t l0 = p0; l0 < p1; l0 += FC) {
+    double hln[FC], On[FC][9];
+    int64_t enn[FC];
+#pragma unroll
+    for (int j = 0; j < FC; ++j) {
+      hln[j] = d.Hll[cl_h(l0 + FC + j)];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) On[j][i] = d.Oll[i * Et + en[j]];
+    }
+#pragma unroll
+    for (int j = 0; j < FC; ++j) enn[j] = d.pt_prev_edge[cl_e(l0 + 2 * FC + j)];
+#pragma unroll
+    for (int j = 0; j < FC; ++j) {
+      const int64_t l = l0 + j;
+      if (l < p1) {
+        const double hd = hl[j] + lambda;
+        double D[9] = {hd, 0.0, 0.0, 0.0, hd, 0.0, 0.0, 0.0, hd};
+        if (l > p0) {
+          double G[9];
+          mat3_mul(prev, O[j], G);
+#pragma unroll
+          for (int i = 0; i < 9; ++i) d.Gl[9 * l + i] = G[i];
+#pragma unroll
+          for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int q = 0; q < 3; ++q) D[3 * i + q] -= O[j][i] * G[q] + O[j][3 + i] * G[3 + q] + O[j][6 + i] * G[6 + q];
+        }
+        ok &= spd3_inv(D, prev);
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d.Dinv[9 * l + i] = prev[i];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < FC; ++j) {
+      hl[j] = hln[j]; en[j] = enn[j];
+#pragma unroll
+      for (int i = 0; i < 9; ++i) O[j][i] = On[j][i];
+    }
+  }
+  // backward: inverse blocks.  Its inputs - Gl of the step, Dinv of the one below, written by the walk above - come two steps ahead (chunks of BC = 2).
   double Gn[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) { Gn[i] = prev[i]; d.Gdiag[9 * (p1 - 1) + i] = prev[i]; }
-  double Gx[9], Dx[9];
+  constexpr int BC = 2;
+  auto cl_b = [&](int64_t l) -> int64_t { return l > p0 ? l : p0; };
+  double Gx[BC][9], Dx[BC][9];                          // step l = lb - j reads Gl[l + 1], Dinv[l]
 #pragma unroll
-  for (int i = 0; i < 9; ++i) { Gx[i] = p1 - 2 >= p0 ? d.Gl[9 * (p1 - 1) + i] : 0.0; Dx[i] = p1 - 2 >= p0 ? d.Dinv[9 * (p1 - 2) + i] : 0.0; }
-  for (int64_t l = p1 - 2; l >= p0; --l) {
-    double G[9], T1[9], Di[9];
+  for (int j = 0; j < BC; ++j)
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { G[i] = Gx[i]; Di[i] = Dx[i]; }
-    if (l - 1 >= p0) {
+    for (int i = 0; i < 9; ++i) { Gx[j][i] = d.Gl[9 * cl_b(p1 - 1 - j) + i]; Dx[j][i] = d.Dinv[9 * cl_b(p1 - 2 - j) + i]; }
+  for (int64_t lb = p1 - 2; lb >= p0; lb -= BC) {
+    double Gxn[BC][9], Dxn[BC][9];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) { Gx[i] = d.Gl[9 * l + i]; Dx[i] = d.Dinv[9 * (l - 1) + i]; }
+    for (int j = 0; j < BC; ++j)
+#pragma unroll
+      for (int i = 0; i < 9; ++i) { Gxn[j][i] = d.Gl[9 * cl_b(lb - BC - j + 1) + i]; Dxn[j][i] = d.Dinv[9 * cl_b(lb - BC - j) + i]; }
+#pragma unroll
+    for (int j = 0; j < BC; ++j) {
+      const int64_t l = lb - j;
+      if (l >= p0) {
+        double T1[9];
+        mat3_mul(Gx[j], Gn, T1);                       // Gl_{k+1} G_{k+1,k+1}
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d.Goff[9 * (l + 1) + i] = -T1[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+          for (int q = 0; q < 3; ++q) Gn[3 * i + q] = Dx[j][3 * i + q] + T1[3 * i] * Gx[j][3 * q] + T1[3 * i + 1] * Gx[j][3 * q + 1] + T1[3 * i + 2] * Gx[j][3 * q + 2];
+#pragma unroll
+        for (int i = 0; i < 9; ++i) d.Gdiag[9 * l + i] = Gn[i];
+      }
     }
-    mat3_mul(G, Gn, T1);                       // Gl_{k+1} G_{k+1,k+1}
 #pragma unroll
-    for (int i = 0; i < 9; ++i) d.Goff[9 * (l + 1) + i] = -T1[i];
+    for (int j = 0; j < BC; ++j)
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-#pragma unroll
-      for (int j = 0; j < 3; ++j) Gn[3 * i + j] = Di[3 * i + j] + T1[3 * i] * G[3 * j] + T1[3 * i + 1] * G[3 * j + 1] + T1[3 * i + 2] * G[3 * j + 2];
-#pragma unroll
-    for (int i = 0; i < 9; ++i) d.Gdiag[9 * l + i] = Gn[i];
+      for (int i = 0; i < 9; ++i) { Gx[j][i] = Gxn[j][i]; Dx[j][i] = Dxn[j][i]; }
   }
   if (!ok) atomicOr(d.flags, 1);
 }
