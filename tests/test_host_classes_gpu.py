@@ -71,6 +71,46 @@ def test_optimizer_batch_matches_oracle_on_the_reference_built_graph(host, oracl
     assert checked > 100
 
 
+@pytest.mark.parametrize("window,shape", [(0, dict(n_frames=12, n_static=400, n_objects=2, dyn_tracks_per_object=40, seed=5)),
+                                          (8, dict(n_frames=8, n_static=400, n_objects=2, dyn_tracks_per_object=40, seed=5)),
+                                          (0, dict(n_frames=20, n_static=900, n_objects=3, dyn_tracks_per_object=60, seed=9))])
+def test_optimizer_batch_equals_the_reference_source(host, window, shape):
+    """Round 5, no oracle in between: the PRODUCT's Optimizer::FullBatchOptimization / PartialBatchOptimization (graph built by the C++ host class, Levenberg on
+    the GPU: tile sweep, Schur complement, chain-preconditioned PCG) against the reference's OWN src/Optimizer.cc:42-1230 / :1232-2175 with its vendored g2o
+    (BlockSolverX + LinearSolverCSparse on the whole system), compiled verbatim into oracle/_ref/libref_full.so (tests/test_ref_g2o.py) - on the same Map, filled
+    from the same flat arrays: refined camera poses, object motions, static and dynamic points as both write them back into the Map (CV_32F).  Bar: 5e-6
+    (float storage 6e-8 relative + the two solvers' 1e-6; the north star asks 1e-4)."""
+    from tests import oracle_lib
+    from tests.ref_track import Quiet
+    ref = oracle_lib.load_ref_full()
+    if ref is None:
+        pytest.skip("parity unpinned: oracle/_ref/libref_full.so absent")
+    ref.ref_batch_optimization.argtypes = [C.c_void_p, C.c_int, K.c_float_p, K.c_float_p, K.c_float_p, K.c_float_p]
+    m = SM.make_map(**shape)
+    F = m["n_frames"]
+    n_sta = sum(len(f["sta_uv"]) for f in m["feats"]); n_dyn = sum(len(f["dyn_uv"]) for f in m["feats"]); n_rm = sum(len(r) for r in m["rigid_motion"])
+    outs = {}
+    for who in ("product", "reference"):
+        s, keep = _flatten(m)
+        cam = np.zeros((F, 4, 4), np.float32); rm = np.zeros((n_rm, 4, 4), np.float32)
+        sta = np.zeros((n_sta, 3), np.float32); dyn = np.zeros((max(n_dyn, 1), 3), np.float32)
+        if who == "product":
+            st = K.LMStatsC()
+            assert host.host_batch_optimization(C.byref(s), window, _p(cam), _p(rm), _p(sta), _p(dyn), C.byref(st)) == 0
+            assert st.iterations >= 2
+        else:
+            with Quiet():                                       # (the reference saves its .g2o dumps into the current directory)
+                assert ref.ref_batch_optimization(C.byref(s), window, _p(cam), _p(rm), _p(sta), _p(dyn)) == 0
+        outs[who] = (cam, rm, sta, dyn)
+    (ca, ra, sa, da), (cb, rb, sb, db) = outs["product"], outs["reference"]
+    assert np.abs(cb).max() > 0 and np.abs(sb).max() > 0
+    scale_t = max(1.0, float(np.abs(cb[:, :3, 3]).max()))
+    assert np.abs(ca[:, :3, :3] - cb[:, :3, :3]).max() <= 5e-6 and np.abs(ca[:, :3, 3] - cb[:, :3, 3]).max() <= 5e-6 * scale_t, (np.abs(ca - cb).max(),)
+    assert np.abs(ra[:, :3, :3] - rb[:, :3, :3]).max() <= 5e-6 and np.abs(ra[:, :3, 3] - rb[:, :3, 3]).max() <= 5e-6 * max(1.0, float(np.abs(rb[:, :3, 3]).max())), (np.abs(ra - rb).max(),)
+    assert np.abs(sa - sb).max() <= 5e-6 * max(1.0, float(np.abs(sb).max())), np.abs(sa - sb).max()
+    assert np.abs(da - db).max() <= 5e-6 * max(1.0, float(np.abs(db).max())), np.abs(da - db).max()
+
+
 def _p(a):
     return a.ctypes.data_as(K.c_float_p)
 
