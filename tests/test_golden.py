@@ -1,11 +1,13 @@
-"""The CPU oracle against golden vectors produced by the REAL reference (halajun/VDO_SLAM + OpenCV 3.4.0 + Eigen3 + CSparse + its
-vendored g2o) with tools/pin_reference/run.sh on the committed inputs of tests/golden/inputs/.
+"""The CPU oracle against golden vectors of the reference on the committed inputs of tests/golden/inputs/.
 
-The reference cannot be built in the development container (none of those libraries is present, no network - SURVEY.md F7) and it
-ships no tests or fixtures of its own, so until someone runs the harness on a suitable host the outputs are absent,
-every test below SKIPS with "parity unpinned", and all parity claims of this repository read HIP == oracle, oracle == reference by
-source reading only.  test_checkers_accept_oracle_outputs keeps the readers / comparators themselves exercised meanwhile (it writes
-the oracle's own results in the harness's output layout and runs the same checks on them)."""
+Two sources of outputs (tests/golden/README.md, PINNED_BY.txt):
+  * the optimiser cases - flow2_case*.out, batch_case0/* - are COMMITTED since round 5: tools/pin_reference/make_outputs_ref_full.py wrote them from
+    oracle/_ref/libref_full.so, the reference's own src/Optimizer.cc + src/Converter.cc + vendored g2o compiled verbatim from /root/reference (against a mini-Eigen /
+    mini-CSparse).  Their tests RUN, here against the oracle and in tests/test_golden_gpu.py against the HIP path;
+  * the cases that need OpenCV 3.4.0 itself (ORB front-end, FAST, blur, cvtColor, fastAtan2, solvePnPRansac) need tools/pin_reference/run.sh on a host with the real
+    libraries; until someone runs it those outputs are absent and their tests SKIP with "parity unpinned".
+test_checkers_accept_oracle_outputs keeps the readers / comparators of the absent ones exercised meanwhile (it writes the oracle's own results in the harness's
+output layout and runs the same checks on them)."""
 import ctypes as C
 import os
 import sys
