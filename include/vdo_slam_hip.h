@@ -508,6 +508,11 @@ int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, int n, const 
 int vdo_object_chain(vdo_frame_images* cur, vdo_frame_images* last, int n, const int32_t* last_sem_label, const float* last_corr_x, const float* last_corr_y,
                      float th_depth_obj, const float Tcw_cur[16], const float* last_x, const float* last_y, const float* last_d, const float Tcw_last[16],
                      const float K4[4], int* n_recovered, float* depth_out, int32_t* sem_out, float* flow3d_out, int32_t* obj_label_out);
+/* Optional, new (no counterpart in the reference): the inputs of vdo_object_chain that belong to the LAST frame (mLastFrame's object set: vSemObjLabel, mvObjCorres,
+ * mvObjKeys, mvObjDepth - src/Tracking.cc:1040-1063 leaves them final at the end of Track()) sent to the device a frame ahead, asynchronously on `ctx`'s stream.  The
+ * next vdo_object_chain on a frame of that context uses them if - compared value by value - they are what it is called with, and otherwise stages its inputs itself. */
+int vdo_object_chain_prestage(vdo_ctx* ctx, int n, const int32_t* last_sem_label, const float* last_corr_x, const float* last_corr_y,
+                              const float* last_x, const float* last_y, const float* last_d);
 
 /* Tracklets: Tracking::GetStaticTrack / GetDynamicTrackNew (src/Tracking.cc:2201-2421) rebuild every
  * tracklet from frame 0 on every frame; this builder is incremental (one association vector per call)

@@ -249,3 +249,11 @@ def test_object_chain_equals_the_three_separate_calls(ctx, oracle):
     assert np.array_equal(TR.download_mask(cur_a), TR.download_mask(cur_b))
     assert np.array_equal(d_a, d_b) and np.array_equal(sem_a, sem_b) and np.array_equal(fl_a, fl_b) and np.array_equal(ol_a, ol_b)
     assert (ol_b == -1).sum() > 0 and (sem_b == labels[0]).sum() > 100
+    # round 5: the last frame's inputs staged a frame ahead (vdo_object_chain_prestage) - same results; and a stage that is NOT what the chain is then called
+    # with (other correspondences) is ignored, not used
+    for stale in (False, True):
+        cur_c = _images(ctx, depth, fr["flow"], cur_mask)
+        TR.object_chain_prestage(ctx, sl, (cx + 3.0) if stale else cx, cy, ob["key_x"], ob["key_y"], ob["depth"])
+        rec_c, d_c, sem_c, fl_c, ol_c = TR.object_chain(cur_c, last_im, sl, cx, cy, SF.TH_DEPTH_OBJ, Tc, ob["key_x"], ob["key_y"], ob["depth"], Tl, K4)
+        assert rec_c == rec_b and np.array_equal(TR.download_mask(cur_c), TR.download_mask(cur_b)), stale
+        assert np.array_equal(d_c, d_b) and np.array_equal(sem_c, sem_b) and np.array_equal(fl_c, fl_b) and np.array_equal(ol_c, ol_b), stale

@@ -1,7 +1,7 @@
 # Kernel + copy timeline of a few synchronous-mode frames of the bench sequence (run through gpurun from the repo root).
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/r04
+O=$R/gpurun_out/${1:-r05p}
 mkdir -p $O
 VDO_BENCH_SYNC_OBJECTS=1 timeout 250 rocprofv3 --kernel-trace --memory-copy-trace --stats -d $O/prof_sync -- python $R/bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-host-inputs --no-batch > $O/bench_sync_under_rocprof.json 2> $O/bench_sync_under_rocprof.err
 cd $R

@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -37,9 +38,11 @@ class Arena {
     if (bytes > c_->h_cap) {
       hipStreamSynchronize(s_);
       if (c_->h_arena) hipHostFree(c_->h_arena);
-      c_->h_arena = nullptr; c_->h_cap = 0;
+      c_->h_arena = nullptr; c_->h_cap = 0; c_->h_arena_dev = nullptr;
       const size_t want = bytes < (size_t(8) << 20) ? (size_t(8) << 20) : bytes * 2;
-      if (hipHostMalloc((void**)&c_->h_arena, want) != hipSuccess) return false;
+      if (hipHostMalloc((void**)&c_->h_arena, want, hipHostMallocMapped) != hipSuccess) return false;
+      void* dp = nullptr;
+      if (hipHostGetDevicePointer(&dp, c_->h_arena, 0) == hipSuccess) c_->h_arena_dev = (char*)dp;
       c_->h_cap = want;
     }
     off_ = 0; in_lo_ = in_hi_ = 0;
@@ -65,13 +68,30 @@ class Arena {
     }
     return (T*)(c_->d_arena + a);
   }
+  // An OUTPUT buffer the kernels write ONCE and nothing on the device reads again: its slot of the PINNED block as the device sees it (mapped host memory) -
+  // the stores go over PCIe while the kernel runs and no device -> host copy operation (~10 us of stream time plus its enqueue, whatever its size) stands
+  // between the last kernel and the synchronisation.  down() of such a pointer only hands the data over after finish().  Falls back to a device buffer.
+  template <class T>
+  T* out(size_t n) {
+    static const bool off = std::getenv("VDO_ARENA_NO_MAPPED_OUT") != nullptr;
+    if (off || !c_->h_arena_dev) return up<T>(nullptr, n);
+    const size_t a = (off_ + 255) & ~size_t(255), bytes = n * sizeof(T);
+    if (!c_->d_arena || !c_->h_arena || a + bytes > c_->d_cap || a + bytes > c_->h_cap) return nullptr;
+    off_ = a + bytes;
+    if (in_hi_ != in_lo_) flush();                                // (keeps a later staged input from merging its copy across this slot)
+    return (T*)(c_->h_arena_dev + a);
+  }
   // queue device -> caller copy (through the pinned block; delivered by finish())
   template <class T>
   void down(T* user, const T* dev, size_t n) {
     if (!user || !n) return;
+    if (c_->h_arena_dev && (const char*)dev >= c_->h_arena_dev && (const char*)dev + n * sizeof(T) <= c_->h_arena_dev + c_->h_cap) {      // an out() buffer: already in the pinned block
+      pend_.push_back({user, (size_t)((const char*)dev - c_->h_arena_dev), n * sizeof(T), true});
+      return;
+    }
     const size_t o = (size_t)((const char*)dev - c_->d_arena);
     if ((const char*)dev < c_->d_arena || o + n * sizeof(T) > c_->d_cap) { failed_ = true; return; }
-    pend_.push_back({user, o, n * sizeof(T)});
+    pend_.push_back({user, o, n * sizeof(T), false});
   }
   // queue a device -> pinned copy WITHOUT a hand-over to a caller array: returns where the data will be in the pinned block once
   // finish() has returned (valid until the context's arena is used again) - large outputs of which the caller reads a few rows
@@ -79,18 +99,22 @@ class Arena {
   const T* down_view(const T* dev, size_t n) {
     const size_t o = (size_t)((const char*)dev - c_->d_arena);
     if ((const char*)dev < c_->d_arena || o + n * sizeof(T) > c_->d_cap) { failed_ = true; return nullptr; }
-    if (n) pend_.push_back({nullptr, o, n * sizeof(T)});
+    if (n) pend_.push_back({nullptr, o, n * sizeof(T), false});
     return (const T*)(c_->h_arena + o);
   }
   // the outputs come back (one copy of their span, or one per buffer when the span is mostly something else), one
   // synchronisation, then they reach the caller's arrays
   int finish(const char* what) {
     flush();
-    if (!pend_.empty()) {
+    {
       size_t lo = ~size_t(0), hi = 0, sum = 0;
-      for (const Pend& p : pend_) { lo = std::min(lo, p.off); hi = std::max(hi, p.off + p.bytes); sum += p.bytes; }
-      if (hi - lo <= 4 * sum + (size_t(64) << 10)) hipMemcpyAsync(c_->h_arena + lo, c_->d_arena + lo, hi - lo, hipMemcpyDeviceToHost, s_);
-      else for (const Pend& p : pend_) hipMemcpyAsync(c_->h_arena + p.off, c_->d_arena + p.off, p.bytes, hipMemcpyDeviceToHost, s_);
+      for (const Pend& p : pend_) if (!p.mapped) { lo = std::min(lo, p.off); hi = std::max(hi, p.off + p.bytes); sum += p.bytes; }
+      if (sum) {
+        bool overlap = false;                                     // (a merged copy must not run over a mapped slot: it would bring the device block's bytes over the kernel's)
+        for (const Pend& p : pend_) if (p.mapped && p.off < hi && p.off + p.bytes > lo) overlap = true;
+        if (!overlap && hi - lo <= 4 * sum + (size_t(64) << 10)) hipMemcpyAsync(c_->h_arena + lo, c_->d_arena + lo, hi - lo, hipMemcpyDeviceToHost, s_);
+        else for (const Pend& p : pend_) if (!p.mapped) hipMemcpyAsync(c_->h_arena + p.off, c_->d_arena + p.off, p.bytes, hipMemcpyDeviceToHost, s_);
+      }
     }
     hipError_t e = hipStreamSynchronize(s_);
     if (e == hipSuccess) e = hipGetLastError();
@@ -106,7 +130,7 @@ class Arena {
     if (in_hi_ != in_lo_) hipMemcpyAsync(c_->d_arena + in_lo_, c_->h_arena + in_lo_, in_hi_ - in_lo_, hipMemcpyHostToDevice, s_);
     in_lo_ = in_hi_ = 0;
   }
-  struct Pend { void* user; size_t off, bytes; };
+  struct Pend { void* user; size_t off, bytes; bool mapped; };
   vdo_ctx* c_;
   hipStream_t s_;
   size_t off_ = 0, in_lo_ = 0, in_hi_ = 0;

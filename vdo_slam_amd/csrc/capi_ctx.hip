@@ -54,6 +54,8 @@ extern "C" int vdo_ctx_destroy(vdo_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->d_arena) hipFree(ctx->d_arena);
   if (ctx->h_arena) hipHostFree(ctx->h_arena);
+  if (ctx->d_stage) hipFree(ctx->d_stage);
+  if (ctx->h_stage) hipHostFree(ctx->h_stage);
   if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);
   delete ctx;
   return VDO_OK;

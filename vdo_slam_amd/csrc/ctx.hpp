@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstddef>
+#include <cstdint>
 
 struct vdo_ctx {
   int device = 0;
@@ -11,6 +12,12 @@ struct vdo_ctx {
   // grow-only scratch of the small per-call entry points (arena.hpp): device block + pinned host block
   char* d_arena = nullptr; size_t d_cap = 0;
   char* h_arena = nullptr; size_t h_cap = 0;
+  char* h_arena_dev = nullptr;                    // the pinned block as the DEVICE sees it (mapped): kernels write small outputs straight into it (Arena::out)
+  // inputs of the NEXT frame's object chain, staged ahead (vdo_object_chain_prestage, tracking_logic.hip): device block + pinned mirror + what the host
+  // worked out while staging (label slots); n < 0: nothing staged
+  char* d_stage = nullptr; char* h_stage = nullptr; size_t stage_cap = 0;
+  int stage_n = -1, stage_L = 0;
+  int32_t stage_uni[64]; int32_t stage_off[65];
 };
 
 namespace vdo {

@@ -10,6 +10,7 @@
 // flags.  Grouping by label uses one pass over label-slot tables instead of the reference's nested
 // searches; float accumulations keep the reference's per-label index order.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstring>
 #include <vector>
@@ -577,8 +578,10 @@ extern "C" int vdo_update_mask(vdo_frame_images* cur, vdo_frame_images* last, in
 static __global__ void k_gather_scene_flow(int n, const float* __restrict__ kx, const float* __restrict__ ky, const float* __restrict__ depth, const int32_t* __restrict__ mask,
                                            int w, int h, float th, float* __restrict__ dout, int32_t* __restrict__ lout, Cam cc,
                                            const float* __restrict__ lx, const float* __restrict__ ly, const float* __restrict__ ld, const int32_t* __restrict__ ll, Cam lc,
-                                           float* __restrict__ flow3d, int32_t* __restrict__ objlab) {
+                                           float* __restrict__ flow3d, int32_t* __restrict__ objlab, const int32_t* __restrict__ olab_init,
+                                           const int32_t* __restrict__ flag_in, int32_t* __restrict__ flag_out, int nflag) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nflag) flag_out[i] = flag_in[i];              // (the UpdateMask verdicts of the launches before this one, into the caller's - mapped - output block)
   if (i >= n) return;
   const float xf = kx[i], yf = ky[i];
   const int u = (int)xf, v = (int)yf;
@@ -593,6 +596,72 @@ static __global__ void k_gather_scene_flow(int n, const float* __restrict__ kx, 
   backproject(lc, lx[i], ly[i], ld[i], p);
   backproject(cc, xf, yf, o, c);
   flow3d[3 * i] = c[0] - p[0]; flow3d[3 * i + 1] = c[1] - p[1]; flow3d[3 * i + 2] = c[2] - p[2];
+  objlab[i] = olab_init ? olab_init[i] : -2;           // (the label DynObjTracking starts from; rounds 1-4 uploaded a buffer of -2 for the kernel to leave alone)
+}
+
+// The inputs of the object chain that belong to the LAST frame - its object set: labels, correspondences, key points, depths - are known when that frame's
+// object stage ends, a whole frame before the chain runs.  vdo_object_chain_prestage groups them by label and sends them to a block of the context that only the
+// chain reads (asynchronously, on the context's stream: the next frame's kernels are ordered behind it); vdo_object_chain finds them there - after checking, value
+// by value against the pinned mirror, that they are what it was called with - and starts with its first kernel instead of a grouping pass, a staged copy and the
+// copy's ~15 us of stream time at the head of the frame.  Optional: without it (or when anything differs) the chain stages its inputs itself, as before.
+namespace {
+struct ChainLayout { size_t gx, gy, cx, cy, lx, ly, ld, ll, off, total; };
+ChainLayout chain_layout(int n) {
+  auto al = [](size_t v) { return (v + 255) & ~size_t(255); };
+  ChainLayout q{};
+  size_t o = 0;
+  const size_t b = al(4 * (size_t)n);
+  q.gx = o; o += b; q.gy = o; o += b; q.cx = o; o += b; q.cy = o; o += b; q.lx = o; o += b; q.ly = o; o += b; q.ld = o; o += b; q.ll = o; o += b;
+  q.off = o; o += al(4 * 65);
+  q.total = o;
+  return q;
+}
+// label slots of the n samples + their (x, y) grouped by slot; returns the number of labels L (uni, off: L and L + 1 entries)
+int group_by_label(int n, const int32_t* lab, const float* px, const float* py, std::vector<int32_t>& uni, std::vector<int>& off, float* gx, float* gy) {
+  static thread_local std::vector<int32_t> slot;
+  static thread_local std::vector<int> c;
+  label_slots(n, lab, uni, slot);
+  const int L = (int)uni.size();
+  off.assign(L + 1, 0);
+  for (int i = 0; i < n; ++i) off[slot[i] + 1]++;
+  for (int s = 0; s < L; ++s) off[s + 1] += off[s];
+  c.assign(off.begin(), off.end() - 1);
+  for (int i = 0; i < n; ++i) { const int p = c[slot[i]]++; gx[p] = px[i]; gy[p] = py[i]; }
+  return L;
+}
+}  // namespace
+
+extern "C" int vdo_object_chain_prestage(vdo_ctx* ctx, int n, const int32_t* last_sem_label, const float* last_corr_x, const float* last_corr_y,
+                                         const float* last_x, const float* last_y, const float* last_d) {
+  if (!ctx || n < 0) return set_error(VDO_ERR_INVALID, "vdo_object_chain_prestage: bad argument");
+  ctx->stage_n = -1;
+  if (n == 0) return VDO_OK;
+  int rc = ctx_bind(ctx);
+  if (rc != VDO_OK) return rc;
+  const ChainLayout q = chain_layout(n);
+  if (q.total > ctx->stage_cap) {
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->d_stage) hipFree(ctx->d_stage);
+    if (ctx->h_stage) hipHostFree(ctx->h_stage);
+    ctx->d_stage = ctx->h_stage = nullptr; ctx->stage_cap = 0;
+    const size_t want = std::max<size_t>(2 * q.total, size_t(1) << 20);
+    if (hipMalloc((void**)&ctx->d_stage, want) != hipSuccess || hipHostMalloc((void**)&ctx->h_stage, want) != hipSuccess) return set_error(VDO_ERR_OOM, "vdo_object_chain_prestage: allocation failed");
+    ctx->stage_cap = want;
+  }
+  static thread_local std::vector<int32_t> uni;
+  static thread_local std::vector<int> off;
+  char* h = ctx->h_stage;
+  const int L = group_by_label(n, last_sem_label, last_corr_x, last_corr_y, uni, off, (float*)(h + q.gx), (float*)(h + q.gy));
+  if (L > 64) return VDO_OK;                              // (more labels than the one-launch form of UpdateMask takes: the chain stages for itself)
+  std::memcpy(h + q.cx, last_corr_x, 4 * (size_t)n); std::memcpy(h + q.cy, last_corr_y, 4 * (size_t)n);
+  std::memcpy(h + q.lx, last_x, 4 * (size_t)n); std::memcpy(h + q.ly, last_y, 4 * (size_t)n); std::memcpy(h + q.ld, last_d, 4 * (size_t)n);
+  std::memcpy(h + q.ll, last_sem_label, 4 * (size_t)n);
+  int32_t* ho = (int32_t*)(h + q.off);
+  for (int s = 0; s <= L; ++s) { ho[s] = off[s]; ctx->stage_off[s] = off[s]; }
+  for (int s = 0; s < L; ++s) ctx->stage_uni[s] = uni[s];
+  if (hipMemcpyAsync(ctx->d_stage, h, q.total, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "vdo_object_chain_prestage: copy failed");
+  ctx->stage_L = L; ctx->stage_n = n;
+  return VDO_OK;
 }
 
 extern "C" int vdo_object_chain(vdo_frame_images* cur, vdo_frame_images* last, int n, const int32_t* last_sem_label, const float* last_corr_x, const float* last_corr_y,
@@ -603,45 +672,71 @@ extern "C" int vdo_object_chain(vdo_frame_images* cur, vdo_frame_images* last, i
   if (n == 0) return VDO_OK;
   int rc = ctx_bind(cur->ctx);
   if (rc != VDO_OK) return rc;
-  Arena S(cur->ctx);
+  vdo_ctx* ctx = cur->ctx;
+  // VDO_CHAIN_TRACE=1 (debugging): where the wall time of this call goes, every 20 calls on stderr
+  static const bool tr_on = std::getenv("VDO_CHAIN_TRACE") != nullptr;
+  static thread_local double tr_acc[6] = {0, 0, 0, 0, 0, 0}; static thread_local int tr_n = 0;
+  auto tr_now = [] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+  const double tr0 = tr_on ? tr_now() : 0.0;
+  Arena S(ctx);
   if (!S.reserve(Arena::bytes_for(16 * (size_t)n + 512))) return set_error(VDO_ERR_OOM, "scratch arena: allocation failed");
-  // K15: the flowed positions grouped by last-frame label (ascending labels, index order inside a label)
-  static thread_local std::vector<int32_t> uni, slot, olab0, off32, flag;       // (per-thread scratch: no allocation in steady state)
-  static thread_local std::vector<int> off, c;
+  static thread_local std::vector<int32_t> uni, flag;       // (per-thread scratch: no allocation in steady state)
+  static thread_local std::vector<int> off;
   static thread_local std::vector<float> gx, gy;
-  label_slots(n, last_sem_label, uni, slot);
-  const int L = (int)uni.size();
-  off.assign(L + 1, 0);
-  for (int i = 0; i < n; ++i) off[slot[i] + 1]++;
-  for (int s = 0; s < L; ++s) off[s + 1] += off[s];
-  gx.resize(n); gy.resize(n);
-  {
-    c.assign(off.begin(), off.end() - 1);
-    for (int i = 0; i < n; ++i) { const int p = c[slot[i]]++; gx[p] = last_corr_x[i]; gy[p] = last_corr_y[i]; }
+  const float *dgx, *dgy, *dcx, *dcy, *dlx, *dly, *dld;
+  const int32_t *dll, *doff;
+  int L;
+  // ---- the last frame's half of the inputs: staged ahead (and still what the caller passes), or staged now
+  const ChainLayout q = chain_layout(n);
+  bool staged = ctx->stage_n == n && ctx->d_stage && std::getenv("VDO_PIPE_NO_CHAIN_PRESTAGE") == nullptr;
+  if (staged) {
+    const char* h = ctx->h_stage;
+    staged = std::memcmp(h + q.ll, last_sem_label, 4 * (size_t)n) == 0 && std::memcmp(h + q.cx, last_corr_x, 4 * (size_t)n) == 0 && std::memcmp(h + q.cy, last_corr_y, 4 * (size_t)n) == 0 &&
+             std::memcmp(h + q.lx, last_x, 4 * (size_t)n) == 0 && std::memcmp(h + q.ly, last_y, 4 * (size_t)n) == 0 && std::memcmp(h + q.ld, last_d, 4 * (size_t)n) == 0;
   }
-  olab0.assign(n, -2);
-  // every input of the three steps in one run of staged buffers -> one H2D copy
-  float *dgx = S.up(gx.data(), n), *dgy = S.up(gy.data(), n);
-  float *dcx = S.up(last_corr_x, n), *dcy = S.up(last_corr_y, n);
-  float *dlx = S.up(last_x, n), *dly = S.up(last_y, n), *dld = S.up(last_d, n);
-  int32_t *dll = S.up(last_sem_label, n), *dol = S.up(olab0.data(), n);
-  off32.assign(off.begin(), off.end());
-  int32_t* doff = S.up(off32.data(), off32.size());
+  ctx->stage_n = -1;                                       // (one use)
+  if (staged) {
+    const char* dv = ctx->d_stage;
+    dgx = (const float*)(dv + q.gx); dgy = (const float*)(dv + q.gy); dcx = (const float*)(dv + q.cx); dcy = (const float*)(dv + q.cy);
+    dlx = (const float*)(dv + q.lx); dly = (const float*)(dv + q.ly); dld = (const float*)(dv + q.ld); dll = (const int32_t*)(dv + q.ll); doff = (const int32_t*)(dv + q.off);
+    L = ctx->stage_L;
+    uni.assign(ctx->stage_uni, ctx->stage_uni + L); off.assign(ctx->stage_off, ctx->stage_off + L + 1);
+  } else {
+    // K15: the flowed positions grouped by last-frame label (ascending labels, index order inside a label); every input in one run of staged buffers -> one H2D copy
+    gx.resize(n); gy.resize(n);
+    L = group_by_label(n, last_sem_label, last_corr_x, last_corr_y, uni, off, gx.data(), gy.data());
+    static thread_local std::vector<int32_t> off32;
+    off32.assign(off.begin(), off.end());
+    dgx = S.up(gx.data(), n); dgy = S.up(gy.data(), n);
+    dcx = S.up(last_corr_x, n); dcy = S.up(last_corr_y, n);
+    dlx = S.up(last_x, n); dly = S.up(last_y, n); dld = S.up(last_d, n);
+    dll = S.up(last_sem_label, n);
+    doff = S.up(off32.data(), off32.size());
+    if (!dgx || !dgy || !dcx || !dcy || !dlx || !dly || !dld || !dll || !doff) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
+  }
   unsigned long long* drec = S.up<unsigned long long>(nullptr, 1);
-  // outputs, contiguous -> one D2H copy
-  int32_t* dflag = S.up<int32_t>(nullptr, 2 * (size_t)L);
-  float* ddep = S.up<float>(nullptr, n);
-  int32_t* dsem = S.up<int32_t>(nullptr, n);
-  float* dfl = S.up<float>(nullptr, 3 * (size_t)n);
-  if (!dgx || !dgy || !dcx || !dcy || !dlx || !dly || !dld || !dll || !dol || !doff || !drec || !dflag || !ddep || !dsem || !dfl) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
+  int32_t* dflag = S.up<int32_t>(nullptr, 2 * (size_t)L);  // (read by other workgroups of the votes: device memory; the last kernel copies it out)
+  // outputs: written once by the last kernel, straight into the pinned block (Arena::out) - no device -> host copy
+  int32_t* oflag = S.out<int32_t>(2 * (size_t)L);
+  float* ddep = S.out<float>(n);
+  int32_t* dsem = S.out<int32_t>(n);
+  float* dfl = S.out<float>(3 * (size_t)n);
+  int32_t* dol = S.out<int32_t>(n);
+  if (!drec || !dflag || !oflag || !ddep || !dsem || !dfl || !dol) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
+  const double tr1 = tr_on ? tr_now() : 0.0;
   launch_update_mask(cur, last, uni, off, dgx, dgy, doff, dflag, drec, S.stream());
   // K11 (objects) on the updated mask, K13 on its outputs
-  hipLaunchKernelGGL(k_gather_scene_flow, dim3((n + 255) / 256), dim3(256), 0, S.stream(), n, (const float*)dcx, (const float*)dcy, (const float*)cur->d_depth, (const int32_t*)cur->d_mask,
+  const int nth = std::max(n, 2 * L);
+  hipLaunchKernelGGL(k_gather_scene_flow, dim3((nth + 255) / 256), dim3(256), 0, S.stream(), n, dcx, dcy, (const float*)cur->d_depth, (const int32_t*)cur->d_mask,
                      cur->w, cur->h, th_depth_obj, ddep, dsem, make_cam_Tcw(K4, Tcw_cur),
-                     (const float*)dlx, (const float*)dly, (const float*)dld, (const int32_t*)dll, make_cam_Tcw(K4, Tcw_last), dfl, dol);
+                     dlx, dly, dld, dll, make_cam_Tcw(K4, Tcw_last), dfl, dol, (const int32_t*)nullptr, (const int32_t*)dflag, oflag, 2 * L);
   flag.assign(2 * (size_t)L, 0);
-  S.down(flag.data(), dflag, flag.size()); S.down(depth_out, ddep, n); S.down(sem_out, dsem, n); S.down(flow3d_out, dfl, 3 * (size_t)n); S.down(obj_label_out, dol, n);
+  double tr2 = 0.0, tr3 = 0.0;
+  if (tr_on) { tr2 = tr_now(); hipStreamSynchronize(ctx->stream); tr3 = tr_now(); }
+  S.down(flag.data(), oflag, flag.size()); S.down(depth_out, ddep, n); S.down(sem_out, dsem, n); S.down(flow3d_out, dfl, 3 * (size_t)n); S.down(obj_label_out, dol, n);
   rc = S.finish("vdo_object_chain");
+  if (tr_on) { const double tr4 = tr_now(); tr_acc[0] += tr1 - tr0; tr_acc[1] += tr2 - tr1; tr_acc[2] += tr3 - tr2; tr_acc[3] += tr4 - tr3; tr_acc[4] += staged ? 1 : 0;
+    if (++tr_n % 20 == 0) { std::fprintf(stderr, "vdo_object_chain: n %d L %d staged %.0f%% | prep %.1f us, launches enqueued %.1f, wait for the kernels %.1f, copy out %.1f\n", n, L, 100 * tr_acc[4] / 20, tr_acc[0] / 20, tr_acc[1] / 20, tr_acc[2] / 20, tr_acc[3] / 20); for (double& a : tr_acc) a = 0; } }
   if (rc != VDO_OK) return rc;
   int rec = 0;
   for (int s = 0; s < L; ++s) {

@@ -757,6 +757,10 @@ int FramePipeline::FinishObjects(FrameCounts* fcp, bool defer_tail) {
   }
   fc.n_object_tracked = (int)nobj.x.size();
   obj_ = std::move(nobj);                                // from here on the next frame's object chain (K15, K11, K13 ...) can start
+  // ... and its inputs that are THIS frame's - the object set just renewed - go to the device now, under the tail of this frame and the start of the next
+  // (vdo_object_chain_prestage: asynchronous; the chain of the next Step runs on ctx_'s stream, behind this copy)
+  if (!p_.defer_objects && !obj_.cx.empty())
+    VDO_TRY(vdo_object_chain_prestage(ctx_, (int)obj_.cx.size(), obj_.sem.data(), obj_.cx.data(), obj_.cy.data(), obj_.x.data(), obj_.y.data(), obj_.d.data()));
   dyn_asso_tail_ = std::move(dyn_asso);
   tail_has_lm_ = obj && obj == lm_obj_;
   pending_ = false; tail_pending_ = true;

@@ -201,6 +201,15 @@ def object_chain(cur_images, last_images, last_sem_label, last_corr_x, last_corr
     return rec.value, d, sem, fl, ol
 
 
+def object_chain_prestage(ctx, last_sem_label, last_corr_x, last_corr_y, last_x, last_y, last_d):
+    """vdo_object_chain_prestage: the last frame's half of object_chain's inputs sent to the device ahead (asynchronously, on the context's stream)."""
+    sl, cx, cy = _i(last_sem_label), _f(last_corr_x), _f(last_corr_y)
+    lx, ly, ld = _f(last_x), _f(last_y), _f(last_d)
+    L = K.lib()
+    L.vdo_object_chain_prestage.argtypes = [C.c_void_p, C.c_int, K.c_int32_p, K.c_float_p, K.c_float_p, K.c_float_p, K.c_float_p, K.c_float_p]
+    K.check(L.vdo_object_chain_prestage(ctx._h, sl.size, _ip(sl), _fp(cx), _fp(cy), _fp(lx), _fp(ly), _fp(ld)))
+
+
 class TrackBuilder:
     """Incremental GetStaticTrack / GetDynamicTrackNew (host only: usable without a GPU)."""
 
