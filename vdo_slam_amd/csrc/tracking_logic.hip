@@ -171,30 +171,41 @@ __device__ __forceinline__ int vote_label(VoteLds& L, const LabelSlots& T, int s
   // (almost every sample of a label sees the same value: the lanes of a wave that agree send ONE LDS atomic with their count instead of
   //  64 same-address ones; whole waves run the loop so that the ballots are complete)
   const int lo = off[s], hi = off[s + 1];
-  for (int i0 = lo + (int)(threadIdx.x & ~63u); i0 < hi; i0 += 256) {
-    const int i = i0 + (int)(threadIdx.x & 63u);
-    int l = -1; bool inside = false;
-    if (i < hi) {
-      const int u = (int)cx[i], v = (int)cy[i];
-      if (u < w && u > 0 && v < h && v > 0) {
-        const size_t q = (size_t)v * w + u;
-        const unsigned long long m = rec ? (cand[q] & rec) : 0ull;
-        l = m ? T.lab[63 - __clzll((long long)m)] : mask[q];
-        inside = true;
-      }
+  // Round 5: FOUR rounds of samples per trip, their loads hoisted - the positions of all four first, then the four mask (and candidate) words - so that a label of
+  // ~600 samples pays two dependent trips to memory instead of six (this kernel heads the frame's object chain on an otherwise idle device: ~4 us per trip).
+  for (int base = lo + (int)(threadIdx.x & ~63u); base < hi; base += 4 * 256) {
+    float px[4], py[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { const int i = min(base + k * 256 + (int)(threadIdx.x & 63u), hi - 1); px[k] = cx[i]; py[k] = cy[i]; }
+    int ml[4]; unsigned long long mc[4]; bool in[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int i = base + k * 256 + (int)(threadIdx.x & 63u);
+      const int u = (int)px[k], v = (int)py[k];
+      in[k] = i < hi && u < w && u > 0 && v < h && v > 0;
+      const size_t q = in[k] ? (size_t)v * w + u : 0;
+      ml[k] = mask[q];
+      mc[k] = rec ? cand[q] : 0ull;
     }
-    const bool bad = inside && (l < 0 || l >= kVoteBins);
-    if (__ballot(bad) && (threadIdx.x & 63u) == 0) atomicOr(&L.bad, 1);
-    bool todo = inside && !bad;
-    const unsigned long long ok = __ballot(todo);
-    if (ok && (threadIdx.x & 63u) == 0) atomicAdd(&L.valid, (int)__popcll(ok));
-    for (unsigned long long act = ok; act;) {
-      const int leader = (int)__ffsll((long long)act) - 1;
-      const int l0 = __shfl(l, leader);
-      const unsigned long long same = __ballot(todo && l == l0);
-      if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&L.hist[l0], (int)__popcll(same));
-      if (l == l0) todo = false;
-      act &= ~same;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (base + k * 256 >= hi) break;                      // (uniform over the wave: the ballots below are complete)
+      const bool inside = in[k];
+      const unsigned long long m = mc[k] & rec;
+      const int l = inside ? (m ? T.lab[63 - __clzll((long long)m)] : ml[k]) : -1;
+      const bool bad = inside && (l < 0 || l >= kVoteBins);
+      if (__ballot(bad) && (threadIdx.x & 63u) == 0) atomicOr(&L.bad, 1);
+      bool todo = inside && !bad;
+      const unsigned long long ok = __ballot(todo);
+      if (ok && (threadIdx.x & 63u) == 0) atomicAdd(&L.valid, (int)__popcll(ok));
+      for (unsigned long long act = ok; act;) {
+        const int leader = (int)__ffsll((long long)act) - 1;
+        const int l0 = __shfl(l, leader);
+        const unsigned long long same = __ballot(todo && l == l0);
+        if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&L.hist[l0], (int)__popcll(same));
+        if (l == l0) todo = false;
+        act &= ~same;
+      }
     }
   }
   __syncthreads();
