@@ -597,9 +597,12 @@ static __global__ void k_gather_scene_flow(int n, const float* __restrict__ kx, 
   const float xf = kx[i], yf = ky[i];
   const int u = (int)xf, v = (int)yf;
   float o = 0.1f; int l = 0;
-  if (u < (w - 1) && u > 0 && v < (h - 1) && v > 0) {
-    const float d = depth[(size_t)v * w + u];
-    if (d < th && d > 0) { o = d; l = mask[(size_t)v * w + u]; }
+  {
+    const bool inside = u < (w - 1) && u > 0 && v < (h - 1) && v > 0;
+    const size_t q = inside ? (size_t)v * w + u : 0;
+    const float d = depth[q];                              // (both words requested together, unconditionally: one trip to memory behind the position instead of two)
+    const int ml = mask[q];
+    if (inside && d < th && d > 0) { o = d; l = ml; }
   }
   dout[i] = o; lout[i] = l;
   if (l <= 0 || ll[i] <= 0) { objlab[i] = -1; flow3d[3 * i] = 0; flow3d[3 * i + 1] = 0; flow3d[3 * i + 2] = 0; return; }
