@@ -5,11 +5,11 @@
 // dynamic track (the ternary edge couples consecutive observations, src/Optimizer.cc:1704-1741)
 // — and the reduced pose/motion system S = Hpp - Hpl Hll^-1 Hlp is solved matrix-free with
 // conjugate gradients preconditioned by the block-tridiagonal matrix M = blockdiag(S) + EdgeSE3
-// off-diagonal blocks along every pose chain (block LDL^T, k_pchain_factor).  x equals the
-// direct solve up to the PCG tolerance.
+// off-diagonal blocks along every pose chain (block LDL^T, k_pchain_factor; round 5: long chains in TWISTED order - two half-depth
+// recurrences on two waves that meet in a joint with one far link, capi_ba.hip).  x equals the direct solve up to the PCG tolerance.
 //
 // One workgroup per TILE for everything that touches landmarks (ba_dev.hpp): each thread keeps
-// its <=3 incidences in registers (the Huber-weighted information scalar from HBM, the 6x3 block
+// its <= VDO_TILE_EPT incidences of ONE pose slot in registers (the Huber-weighted information scalar from HBM, the 6x3 block
 // recomputed from the LDS-resident point and inverse pose: make_f), B^T v accumulates per point in
 // LDS, the landmark-chain solves run there, and B w is segment-reduced per pose slot into pose-major
 // partial rows -> 8 B per incidence from HBM per CG iteration, no global atomics.  One WAVE per
@@ -441,9 +441,8 @@ __global__ __launch_bounds__(256) void k_precond_finalize(BADev d, double lambda
 // Block LDL^T of the block-tridiagonal preconditioner  M = blockdiag(S_pp) + (EdgeSE3 off-diagonal blocks)
 // along every pose chain:  Delta_0 = A_0,  L_k = E_{k-1,k}^T Delta_{k-1}^-1,  Delta_k = A_k - L_k E_{k-1,k}.
 // M is SPD: blockdiag(S) minus the EdgeSE3 diagonal terms is the (PSD) Schur complement of the landmark
-// system, the EdgeSE3 terms themselves are J^T W J.  One thread per chain (a handful of chains, once per
-// Levenberg trial); Minv / Lc are indexed by chain position.
-// The workgroup is ONE wave, the loop body straight-line code:
+// system, the EdgeSE3 terms themselves are J^T W J.  A handful of chains, once per Levenberg trial; Minv / Lc are indexed by chain position.
+// One wave per chain (two for a twisted chain, see k_pchain_factor), the loop body straight-line code:
 //  * the LDS hand-overs use a wave-scope fence, not __syncthreads - whose s_waitcnt vmcnt(0) makes every step wait for the loads it has
 //    just requested for the steps ahead and for its own stores of Lc / Minv;
 //  * no lane is masked off (lanes 36..63 repeat the work of lanes 0..27 and store the same values to the same places) and the inputs of the
