@@ -398,7 +398,7 @@ def test_static_only_graph_without_pose_pose_edges(ctx, oracle):
     ba.close()
 
 
-@pytest.mark.parametrize("n_frames", [12, 20, 40, 150])
+@pytest.mark.parametrize("n_frames", [12, 16, 17, 20, 40, 150, 239])
 def test_pose_chain_solver_is_the_same_operator_however_it_is_partitioned(ctx, oracle, n_frames, monkeypatch):
     """The chain preconditioner (block LDL^T along the pose chains) is applied with the chain cut into segments, one wave each
     (ba_solve.hip pchain_solve_partitioned: zero-input recurrences + prefix products P_k / Q_k + boundary pass).  One segment
