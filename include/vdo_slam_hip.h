@@ -299,6 +299,10 @@ typedef struct vdo_pnp_result {
 } vdo_pnp_result;
 /* All problems of a frame (camera + every object) in one call: two launches, one synchronisation. */
 int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_problem* probs, vdo_pnp_result* results, uint8_t** inlier_out);
+/* The same with a hook: host_work(host_arg) is called once, on the calling thread, while the device runs the hypotheses and the votes - for host work of the
+ * caller that does not depend on the result (GetInitModelObj's motion-model inlier count, src/Tracking.cc:1767-1800, depends on neither).  NULL: no hook. */
+int vdo_pnp_ransac_batch_overlap(vdo_ctx* ctx, int n_problems, const vdo_pnp_problem* probs, vdo_pnp_result* results, uint8_t** inlier_out,
+                                 void (*host_work)(void*), void* host_arg);
 int vdo_pnp_ransac(vdo_ctx* ctx, const vdo_pnp_problem* p, vdo_pnp_result* result, uint8_t* inlier_out);
 
 /* ---- ORB front-end ------------------------------------------------------------------------------

@@ -104,7 +104,11 @@ class Arena {
   }
   // the outputs come back (one copy of their span, or one per buffer when the span is mostly something else), one
   // synchronisation, then they reach the caller's arrays
-  int finish(const char* what) {
+  // finish() in two halves for a caller with host work of its own to do while the device runs: queue_downloads() sends the staged inputs and queues the
+  // device -> host copies (no wait); finish() then only waits and hands the data over.
+  void queue_downloads() {
+    if (queued_) return;
+    queued_ = true;
     flush();
     {
       size_t lo = ~size_t(0), hi = 0, sum = 0;
@@ -116,6 +120,10 @@ class Arena {
         else for (const Pend& p : pend_) if (!p.mapped) hipMemcpyAsync(c_->h_arena + p.off, c_->d_arena + p.off, p.bytes, hipMemcpyDeviceToHost, s_);
       }
     }
+  }
+  int finish(const char* what) {
+    queue_downloads();
+    queued_ = false;
     hipError_t e = hipStreamSynchronize(s_);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) { pend_.clear(); return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e)); }
@@ -134,7 +142,7 @@ class Arena {
   vdo_ctx* c_;
   hipStream_t s_;
   size_t off_ = 0, in_lo_ = 0, in_hi_ = 0;
-  bool failed_ = false;
+  bool failed_ = false, queued_ = false;
   std::vector<Pend> pend_;
 };
 

@@ -474,7 +474,8 @@ struct PnpTrace {            // (VDO_PNP_TRACE=1, debug; the pipelines of severa
 inline double pnp_now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 }  // namespace
 
-extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_problem* probs, vdo_pnp_result* results, uint8_t** inlier_out) {
+extern "C" int vdo_pnp_ransac_batch_overlap(vdo_ctx* ctx, int n_problems, const vdo_pnp_problem* probs, vdo_pnp_result* results, uint8_t** inlier_out,
+                                            void (*host_work)(void*), void* host_arg) {
   if (!ctx || !probs || !results || n_problems <= 0) return set_error(VDO_ERR_INVALID, "vdo_pnp_ransac_batch: bad argument");
   const double tr0 = g_pnp_trace.on ? pnp_now_us() : 0.0;
   int rc = ctx_bind(ctx);
@@ -502,7 +503,7 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
     r.n_inliers = 0; r.iterations_run = 0; r.best_iteration = -1;
     if (inlier_out && inlier_out[k] && probs[k].n) std::memset(inlier_out[k], 0, (size_t)probs[k].n);
   }
-  if (tot_hyp == 0) return VDO_OK;
+  if (tot_hyp == 0) { if (host_work) host_work(host_arg); return VDO_OK; }
   // the subsets the sequential loop would draw (getSubset: 4 distinct indices by rejection, RNG seeded with (uint64)-1 per call):
   // a function of (point count, hypotheses) alone - the draws of a frame's problems cost ~30 us of the object chain, and the same
   // counts come back every few frames, so the tables are kept (8 KB per distinct count)
@@ -559,6 +560,8 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   const int32_t *cnt = S.down_view(dcnt, tot_hyp), *okv = S.down_view(dok, tot_hyp);
   const double* pose = S.down_view(dpose, 12 * tot_hyp);
   const uint32_t* mask = S.down_view(dmask, tot_words);
+  S.queue_downloads();
+  if (host_work) host_work(host_arg);                      // (the caller's own host work, under the two kernels and the copy back)
   rc = S.finish("vdo_pnp_ransac_batch");
   if (rc != VDO_OK) return rc;
   if (!cnt || !okv || !pose || !mask) return set_error(VDO_ERR_OOM, "scratch arena exhausted");
@@ -630,6 +633,9 @@ extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_
   return VDO_OK;
 }
 
+extern "C" int vdo_pnp_ransac_batch(vdo_ctx* ctx, int n_problems, const vdo_pnp_problem* probs, vdo_pnp_result* results, uint8_t** inlier_out) {
+  return vdo_pnp_ransac_batch_overlap(ctx, n_problems, probs, results, inlier_out, nullptr, nullptr);
+}
 extern "C" int vdo_pnp_ransac(vdo_ctx* ctx, const vdo_pnp_problem* p, vdo_pnp_result* result, uint8_t* inlier_out) {
   return vdo_pnp_ransac_batch(ctx, 1, p, result, &inlier_out);
 }

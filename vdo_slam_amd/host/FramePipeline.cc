@@ -521,31 +521,45 @@ int FramePipeline::Step(const uint8_t* d_gray, const float* d_depth_raw, const f
       rin.assign((size_t)off[n_objects] + 1, 0);
       std::vector<uint8_t*> rip(n_objects);
       for (int a = 0; a < n_objects; ++a) rip[a] = rin.data() + off[a];
-      VDO_TRY(vdo_pnp_ransac_batch(ctx_, n_objects, pp.data(), pr.data(), rip.data()));
-      for (int a = 0; a < n_objects; ++a) fc.n_ransac_obj += pr[a].n_inliers;
       // ---- the motion model of an object that was there in the last frame: MotionModel = mCurrentFrame.mTcw * mLastFrame.vObjMod[PreObjID],
       // its 0.4 px inliers; RANSAC seeds the LM only if it has MORE inliers                       Tracking.cc:1767-1825
+      // The count needs nothing of the RANSAC: it runs on this thread WHILE the device works on the hypotheses and the votes (vdo_pnp_ransac_batch_overlap).
       std::vector<uint8_t>& min_ = inl_mm_;
       min_.assign((size_t)off[n_objects] + 1, 0);
       obj_use_mm_.assign(n_objects, 0);
       obj_mm_.resize(16 * (size_t)n_objects);
-      for (int a = 0; a < n_objects; ++a) {
-        int pre = -1;
-        for (size_t i = 0; i < last_mod_label_.size(); ++i) if (last_mod_label_[i] == omod[a]) { pre = (int)i; break; }
-        if (pre < 0 || 16 * (size_t)pre + 16 > last_obj_mod_.size()) continue;
-        float* MM = obj_mm_.data() + 16 * (size_t)a;
-        const float* Hl = last_obj_mod_.data() + 16 * (size_t)pre;
-        for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float s = 0; for (int k = 0; k < 4; ++k) s += Tcw[4 * i + k] * Hl[4 * k + j]; MM[4 * i + j] = s; }
-        int mm = 0;
-        for (int q = off[a]; q < off[a + 1]; ++q) {
-          const int id = idx[q];
-          const float x = obj_.xyz[3 * id], y = obj_.xyz[3 * id + 1], z = obj_.xyz[3 * id + 2];
-          const float xc = MM[0] * x + MM[1] * y + MM[2] * z + MM[3], yc = MM[4] * x + MM[5] * y + MM[6] * z + MM[7], invz = 1.0f / (MM[8] * x + MM[9] * y + MM[10] * z + MM[11]);
-          const float u_ = obj_.cx[id] - (p_.K4[0] * xc * invz + p_.K4[2]), v_ = obj_.cy[id] - (p_.K4[1] * yc * invz + p_.K4[3]);
-          if (std::sqrt(u_ * u_ + v_ * v_) < 0.4f) { min_[q] = 1; ++mm; }
+      std::vector<int> mm_cnt(n_objects, -1);                 // -1: the object has no motion of the last frame
+      struct MmCtx { FramePipeline* self; const int* off; const int32_t* idx; const int32_t* omod; const float* Tcw; int n_objects; std::vector<uint8_t>* min_; std::vector<int>* cnt; };
+      MmCtx mmc{this, off.data(), idx.data(), omod.data(), Tcw, n_objects, &min_, &mm_cnt};
+      auto mm_work = [](void* vp) {
+        MmCtx& c = *static_cast<MmCtx*>(vp);
+        FramePipeline& P = *c.self;
+        for (int a = 0; a < c.n_objects; ++a) {
+          int pre = -1;
+          for (size_t i = 0; i < P.last_mod_label_.size(); ++i) if (P.last_mod_label_[i] == c.omod[a]) { pre = (int)i; break; }
+          if (pre < 0 || 16 * (size_t)pre + 16 > P.last_obj_mod_.size()) continue;
+          float* MM = P.obj_mm_.data() + 16 * (size_t)a;
+          const float* Hl = P.last_obj_mod_.data() + 16 * (size_t)pre;
+          for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { float s = 0; for (int k = 0; k < 4; ++k) s += c.Tcw[4 * i + k] * Hl[4 * k + j]; MM[4 * i + j] = s; }
+          int mm = 0;
+          for (int q = c.off[a]; q < c.off[a + 1]; ++q) {
+            const int id = c.idx[q];
+            const float x = P.obj_.xyz[3 * id], y = P.obj_.xyz[3 * id + 1], z = P.obj_.xyz[3 * id + 2];
+            const float xc = MM[0] * x + MM[1] * y + MM[2] * z + MM[3], yc = MM[4] * x + MM[5] * y + MM[6] * z + MM[7], invz = 1.0f / (MM[8] * x + MM[9] * y + MM[10] * z + MM[11]);
+            const float u_ = P.obj_.cx[id] - (P.p_.K4[0] * xc * invz + P.p_.K4[2]), v_ = P.obj_.cy[id] - (P.p_.K4[1] * yc * invz + P.p_.K4[3]);
+            if (std::sqrt(u_ * u_ + v_ * v_) < 0.4f) { (*c.min_)[q] = 1; ++mm; }
+          }
+          (*c.cnt)[a] = mm;
         }
-        fc.n_mm_inliers_obj += mm;
-        if (!(pr[a].n_inliers > mm)) { obj_use_mm_[a] = 1; ++fc.n_motion_model_obj; }
+      };
+      static const bool mm_overlap = std::getenv("VDO_PIPE_NO_MM_OVERLAP") == nullptr;      // (A/B switch)
+      if (mm_overlap) VDO_TRY(vdo_pnp_ransac_batch_overlap(ctx_, n_objects, pp.data(), pr.data(), rip.data(), +mm_work, &mmc));
+      else { VDO_TRY(vdo_pnp_ransac_batch(ctx_, n_objects, pp.data(), pr.data(), rip.data())); mm_work(&mmc); }
+      for (int a = 0; a < n_objects; ++a) fc.n_ransac_obj += pr[a].n_inliers;
+      for (int a = 0; a < n_objects; ++a) {
+        if (mm_cnt[a] < 0) continue;
+        fc.n_mm_inliers_obj += mm_cnt[a];
+        if (!(pr[a].n_inliers > mm_cnt[a])) { obj_use_mm_[a] = 1; ++fc.n_motion_model_obj; }
       }
       if (lm_obj_) {
         // per object: ObjIdTest_in = inliers of the chosen model; fewer than 50 -> the object is not tracked this frame (Tracking.cc:879)
