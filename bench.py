@@ -42,24 +42,16 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak (MI355X_MICROARCH.md: 8 TB/s spec, ~6.3 TB/s achievable)
 N_DISTINCT_FRAMES = 4   # make_frame_inputs(): independent random frames (tools/frame_probe.py)
 # SURVEY.md 8d "synthetic inputs": flow noise N(0, 0.3^2) px, 2 % invalid depth, 1 % exactly-zero flow, 5 moving objects, one
-# instance mask missing for two frames (exercises UpdateMask)
-FLOW_SIGMA, INVALID_DEPTH, ZERO_FLOW, N_OBJECTS, BOX_DEPTH = 0.3, 0.02, 0.01, 5, 0.9
+# instance mask missing for two frames (exercises UpdateMask): ONE definition, shared with the parity tests (vdo_slam_amd/synth_seq.py)
+from vdo_slam_amd.synth_seq import (BENCH_FLOW_SIGMA as FLOW_SIGMA, BENCH_INVALID_DEPTH as INVALID_DEPTH, BENCH_ZERO_FLOW as ZERO_FLOW, BENCH_N_OBJECTS as N_OBJECTS,  # noqa: E402
+                                    BENCH_BOX_DEPTH as BOX_DEPTH, BENCH_MAX_FRAMES as MAX_SEQ_FRAMES, KITTI0000_FRAMES)
 # batch graphs of the N > 1 legs (and their one-GPU numbers at N = 1): BASELINE configs[3] - Oxford-Multimotion-shaped (example/omd.yaml: 3000 features per
 # frame, four swinging boxes filling a third of the view): 300 frames, 150 k static + 4 x 40 k dynamic tracks (1.9 M EdgeSE3PointXYZ, 0.8 M ternary edges,
 # 1 496 pose / motion vertices) - and configs[4]: 1 M landmarks / 5 k pose vertices / 20 objects
 OMD_SHAPE = (300, 150000, 4, 40000)
 LARGE_SHAPE = (239, 950000, 20, 500)
 SHARD_LEGS = (("control", (60, 30000, 5, 800), 5), ("omd", OMD_SHAPE, 5), ("large", LARGE_SHAPE, 3))
-MAX_SEQ_FRAMES = 160    # length of the consistent synthetic sequence (the objects stay in view that long)
-
-
-def sequence_events(warmup, steps):
-    """Where the 8d events fall: SURVEY's frames (mask dropped for two frames, object 2 leaves at 60, object 5 enters at 80)
-    for a KITTI-0000-length run, pulled inside the timed window [warmup, warmup+steps) whatever --steps is."""
-    drop_at = min(30, warmup + 3)
-    leave_at = min(60, warmup + max(2, (2 * steps) // 5))
-    enter_at = min(80, warmup + max(4, (3 * steps) // 5))
-    return {drop_at: {1}, drop_at + 1: {1}}, leave_at, enter_at
+FULL_WARMUP = 5          # the KITTI-0000-length run: 5 warm-up + 148 timed frames = 153 (example/vdo_slam.cc:95-96)
 
 
 def _pmc_traffic_bytes(graph, dims):
@@ -256,6 +248,44 @@ def cpu_baseline_batch(graph, its=2):
     return (time.perf_counter() - t0) * 1e3 / max(1, st.iterations), sweep_ms, int(st.iterations)
 
 
+def parity_start(seq_dir, seqs):
+    """The reference's side of the parity leg: one CPU child process per sequence runs oracle/_ref/libref_full.so (the reference's own sources compiled verbatim) over the
+    rendered frames; started before the HIP runtime is loaded, collected by parity_check.  seqs: (tag, spec, frames).  [] when the library did not travel with the snapshot."""
+    from tests import bench_parity as BP
+    cfg_par = BP.write_bench_settings(os.path.join(seq_dir, "kitti_parity.yaml"))
+    jobs = []
+    for tag, sp, fr_ in seqs:
+        out_npz = os.path.join(seq_dir, f"ref_{tag}.npz")
+        pr = BP.start_reference(cfg_par, os.path.join(seq_dir, tag), len(fr_), out_npz, BP.labels_of(sp))
+        if pr is not None:
+            jobs.append((tag, fr_, cfg_par, BP.labels_of(sp), pr, out_npz))
+    return jobs
+
+
+def parity_check(jobs):
+    """The product's side and the comparison (tests/bench_parity.py; the same as tests/test_bench_sequence_gpu.py): System::TrackRGBD on the same host buffers, synchronous,
+    its own RANSAC + EPnP + LM.  Raises SystemExit - nothing is timed - when the parity does not hold.  Returns {"parity": ..., "parity_full_sequence": ...}."""
+    out = {}
+    if not jobs:
+        return out
+    from tests import bench_parity as BP
+    from tests.ref_track import finish_sequence
+    for tag, fr_, cfg_, labels_, pr, out_npz in jobs:
+        got_ = BP.product_sequence(cfg_, fr_, labels_)
+        ref_ = finish_sequence(pr, out_npz, timeout_s=900)
+        par = BP.compare({q: ref_[q] for q in ref_.files}, got_)
+        del got_, ref_
+        # a window of the driver's size must agree in EVERYTHING; over the KITTI-0000 length one weakly constrained object may leave the reference's
+        # trajectory (the reference does the same to itself under one ulp of input: tests/test_bench_sequence_ref.py) - the number is in the record
+        bad = BP.assert_parity(par) if par["frames"] <= 60 else BP.check_long_sequence(par)
+        par["asserted"] = "everything (bit-exact parts + every object motion within 1e-4)" if par["frames"] <= 60 else \
+            "camera pose, depth, static sets, max_id of every frame bit for bit; objects equal beyond frame 60; >= 90 % of the object motions within 1e-4"
+        if bad:
+            raise SystemExit(f"bench.py: PARITY with the reference FAILED on the {par['frames']}-frame sequence, nothing timed: " + "; ".join(bad))
+        out["parity" if tag == "run" else "parity_full_sequence"] = par
+    return out
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` outside torchrun: start N ranks of this script (one process per GPU, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in the environment, exactly what torchrun would set); rank 0 prints the JSON line."""
@@ -286,6 +316,8 @@ def main():
     ap.add_argument("--replicas-per-gpu", type=int, default=1, help="R independent sequences (FramePipelines) on every GPU; value = all of them")
     ap.add_argument("--replica-sweep", type=str, default="", help="e.g. 1,2,4,8: also report frames/s for these numbers of sequences per GPU")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes of the roofline leg (the committed counter file, then the byte model, take over)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the parity leg (the timed sequences through the whole reference, oracle/_ref/libref_full.so, and through System::TrackRGBD)")
+    ap.add_argument("--no-full-sequence", action="store_true", help="do not add the KITTI-0000-length run (value_full_sequence) when --steps / --warmup ask for another window")
     ap.add_argument("--roofline-static", type=int, default=2200000, help="static landmarks of the roofline graph (default: 13.3 M edges, ~515 MB per sweep launch - twice the 256 MB Infinity Cache)")
     ap.add_argument("--cpu-worker", type=str, default="", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-worker-budget", type=float, default=8.0, help=argparse.SUPPRESS)
@@ -300,6 +332,26 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+
+    # ---- the sequences: geometrically consistent synthetic KITTI-shaped RGB-D + flow + masks (vdo_slam_amd/synth_seq.py), rendered by numpy-only child
+    # processes BEFORE the HIP runtime is loaded: (a) the one this run times - SURVEY 8d's events (a mask missing for two frames, an object leaving, an object
+    # entering; turning boxes) fall inside the timed window whatever --steps is; (b) the KITTI-0000-length one (153 frames, events at SURVEY's frames), timed
+    # as `value_full_sequence` whatever --steps the caller passes.  On rank 0 of a one-GPU run both also go through THE WHOLE REFERENCE
+    # (oracle/_ref/libref_full.so, CPU child processes started here, compared below before anything is timed).
+    import atexit, shutil, tempfile
+    from vdo_slam_amd import synth_seq as SQ
+    rank, world, _ = _dist_env()
+    seq_dir = tempfile.mkdtemp(prefix="vdo_bench_seq_", dir="/tmp")
+    atexit.register(shutil.rmtree, seq_dir, ignore_errors=True)
+    spec = SQ.bench_spec(args.warmup, args.steps, seed=17 * rank)
+    spec_full = SQ.bench_spec(FULL_WARMUP, KITTI0000_FRAMES - FULL_WARMUP, seed=17 * rank)
+    want_full = (not args.no_full_sequence) and spec_full != spec and world == 1
+    render_workers = max(1, int(_cpu_budget() / max(1, world)))
+    frames = SQ.render_bench_sequence(spec, os.path.join(seq_dir, "run"), workers=render_workers)
+    frames_full = SQ.render_bench_sequence(spec_full, os.path.join(seq_dir, "full"), workers=render_workers) if want_full else None
+    parity_jobs = []                # (tag, frames, settings, labels, reference child, its output)
+    if rank == 0 and world == 1 and not args.no_parity:
+        parity_jobs = parity_start(seq_dir, (("run", spec, frames),) + ((("full", spec_full, frames_full),) if want_full else ()))
 
     import torch
     import torch.distributed as dist
@@ -327,22 +379,19 @@ def main():
     stream = torch.cuda.Stream()          # non-default stream shared by torch events and libvdo_hip
     torch.cuda.set_stream(stream)
 
-    from vdo_slam_amd import synth, synth_frames as SF, synth_seq as SQ
+    from vdo_slam_amd import synth, synth_frames as SF
     from vdo_slam_amd.ba import BatchBA, Context
 
     ctx_ba = Context(local, stream.cuda_stream)            # batch / roofline legs: torch's stream
-    # ---- the sequence: geometrically consistent synthetic KITTI-shaped RGB-D + flow + masks (vdo_slam_amd/synth_seq.py),
-    # one distinct frame per step, resident in HBM before the timed region.  SURVEY 8d's events (a mask missing for two frames,
-    # an object leaving, an object entering; turning boxes) fall inside the timed window whatever --steps is.
     W, H = synth.KITTI_W, synth.KITTI_H
-    n_seq = min(args.steps + args.warmup, MAX_SEQ_FRAMES)
-    Ts = SQ.camera_poses(n_seq)
-    drop_masks, leave_at, enter_at = sequence_events(args.warmup, args.steps)
-    objs = SQ.survey_objects(leave_at=leave_at, enter_at=enter_at, box_depth=BOX_DEPTH)     # 5 boxes (2 x 0.9 m deep), 4 of them turning
-    if os.environ.get("VDO_BENCH_R01_OBJECTS"):              # round 1's sequence: translating boxes, no events but the dropped mask
-        objs = SQ.default_objects(N_OBJECTS, box_depth=BOX_DEPTH)
-    frames = [SQ.render_frame(k, Ts, objs, flow_sigma=FLOW_SIGMA, seed=17 * rank, invalid_depth=INVALID_DEPTH, zero_flow=ZERO_FLOW, drop_masks=drop_masks)
-              for k in range(n_seq)]
+    n_seq = spec["n_seq"]
+    drop_masks, leave_at, enter_at = {k_: set(v_) for k_, v_ in spec["drop_masks"].items()}, spec["leave_at"], spec["enter_at"]
+    objs = SQ.bench_objects(spec)                                                            # 5 boxes (2 x 0.9 m deep), 4 of them turning
+
+    # ---- PARITY FIRST ("parity asserted before any timing is reported"): the timed sequences through the product's System::TrackRGBD (host buffers,
+    # synchronous) against the whole reference's own run of them - pose, depth, mask, static / object sets, samples, labels, max_id, tracklets bit for bit, object
+    # motions to the north star's 1e-4 (tests/bench_parity.py; the same comparison as tests/test_bench_sequence_gpu.py)
+    out_parity = parity_check(parity_jobs)
     dev = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames]
     # The per-frame sequence runs in the C++ host class FramePipeline (vdo_slam_amd/host/FramePipeline.cc: the hot
     # part of Tracking::GrabImageRGBD + Track over the C-ABI, state chained frame to frame); one ctypes call per frame.
@@ -358,7 +407,8 @@ def main():
 
     class Replica:
         """One sequence on this GPU: a FramePipeline with its own HIP streams (4 contexts), host helper thread and Map."""
-        def __init__(self, cpus_here, first=False):
+        def __init__(self, cpus_here, first=False, dev_frames=None):
+            self.dev = dev if dev_frames is None else dev_frames
             # host threads per replica: main + 1 helper of FramePipeline (polls) + the quadtree helpers of ORB (sleep when idle);
             # with fewer than ~5 CPUs per replica the helpers would only steal time from each other
             orb_threads = os.environ.get("VDO_ORB_THREADS_FORCE") or ("0" if cpus_here < 3 else ("5" if cpus_here >= 10 else "3"))
@@ -385,7 +435,7 @@ def main():
             # The LM problems are built from the frame's own chained correspondences.  A sequence longer than MAX_SEQ_FRAMES wraps (a scene cut).
             try:
                 for i in range(i0, i0 + n):
-                    d = dev[i % n_seq]
+                    d = self.dev[i % len(self.dev)]
                     ts = time.perf_counter()
                     c = self.pipe.step(d["gray"].data_ptr(), d["depth_raw"].data_ptr(), d["flow"].data_ptr(), d["mask"].data_ptr())
                     if timed:
@@ -407,10 +457,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_sequences(R):
+    def run_sequences(R, dev_frames=None, warmup=None, steps=None):
         """R independent sequences on this GPU (own pipelines, streams, host threads), each through warm-up + the timed steps;
         returns (seconds for the timed steps - max over ranks, replicas)."""
-        reps = [Replica(cpus / R, first=(k == 0)) for k in range(R)]
+        warmup = args.warmup if warmup is None else warmup
+        steps = args.steps if steps is None else steps
+        reps = [Replica(cpus / R, first=(k == 0), dev_frames=dev_frames) for k in range(R)]
         torch.cuda.synchronize()
 
         def all_run(i0, n, timed):
@@ -423,7 +475,7 @@ def main():
             for r in reps:
                 if r.err is not None:
                     raise r.err
-        all_run(0, args.warmup, False)
+        all_run(0, warmup, False)
         barrier()
 
         def _throttled():
@@ -433,7 +485,7 @@ def main():
                 return {}
         thr0 = _throttled() if os.environ.get("VDO_BENCH_DUMP_STEPS") else None
         t0 = time.perf_counter()
-        all_run(args.warmup, args.steps, True)        # the sequence continues where the warm-up left it
+        all_run(warmup, steps, True)                  # the sequence continues where the warm-up left it
         barrier()
         dt = time.perf_counter() - t0
         if thr0 is not None:                          # (debug: CPU-quota throttling and CPU seconds inside the timed region)
@@ -493,7 +545,8 @@ def main():
         "value": fps, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64 (LM, RANSAC) / u8,i32,f32 (front-end, tracking)", "data": "synthetic",
-        "config": {"workload": "KITTI-0000-shaped TrackRGBD per frame (C++ FramePipeline over the C-ABI, full Track() incl. \"Save Graph Structure\": every frame appended to the GraphStore of the batch optimisers): K15 UpdateMask, K1 depth, K11 propagation, "
+        "config": {"workload": "KITTI-0000-shaped TrackRGBD per frame = the per-frame path of Track() (C++ FramePipeline over the C-ABI, incl. \"Save Graph Structure\": every frame appended to the GraphStore of the batch optimisers; "
+                               "the windowed PartialBatchOptimization Track() fires every 16 frames, src/Tracking.cc:1168-1181, is NOT inside the timed frames on either side - it is reported separately as ms_per_lm_iter*): K15 UpdateMask, K1 depth, K11 propagation, "
                                "RANSAC (AP3P) + EPnP + motion-model initialisers, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, "
                                "joint pose+flow LM for the camera (<=1200 matches) and every tracked object (ref_quirks=1) built from the frame's own correspondences, "
                                "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets, graph store; "
@@ -540,6 +593,32 @@ def main():
                                   "what rounds 1-2 reported as `value`); config.step_ms_p50_p90_max, host_ms_per_section, per_frame_mean belong to the deferred run")
         for r in rs_sync:
             r.close()
+    out.update(out_parity)
+    # ---- the KITTI-0000-length run (5 warm-up + 148 timed frames of the 153-frame sequence, SURVEY's event frames), whatever --steps the caller passed: the same
+    # Step with the reference's return semantics (everything of a frame done when its call returns); the driver's `value` window is shorter and carries no capped object LM
+    if frames_full is not None and R == 1 and not os.environ.get("VDO_BENCH_SYNC_OBJECTS"):
+        dev_full = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames_full]
+        defer_saved = defer
+        defer = 0
+        steps_full = KITTI0000_FRAMES - FULL_WARMUP
+        dt_full, rs_full = run_sequences(1, dev_full, FULL_WARMUP, steps_full)
+        defer = defer_saved
+        out["value_full_sequence"] = world * steps_full / dt_full
+        sm_full = rs_full[0].step_ms
+        Tf = rs_full[0].pipe.pose().astype(np.float64)
+        gt_full = frames_full[KITTI0000_FRAMES - 1]["Tcw"]
+        out["config"]["value_full_sequence"] = (f"{FULL_WARMUP} warm-up + {steps_full} timed frames of the {KITTI0000_FRAMES}-frame sequence (example/vdo_slam.cc:95-96; mask of object 1 missing in frames "
+                                                f"{sorted(spec_full['drop_masks'])}, object 2 leaves at {spec_full['leave_at']}, object 5 enters at {spec_full['enter_at']}), device-resident inputs, every Step complete on "
+                                                f"return; step ms p50 / p90 / max {np.percentile(sm_full, 50):.3f} / {np.percentile(sm_full, 90):.3f} / {max(sm_full):.3f}; camera drift against ground truth "
+                                                f"{float(np.abs(Tf[:3, 3] - gt_full[:3, 3]).max()):.3f} m; this is the sequence `parity_full_sequence` compares with the reference")
+        for r in rs_full:
+            r.close()
+        del dev_full, rs_full
+    elif frames_full is None and args.steps + args.warmup == KITTI0000_FRAMES and "value_sync" in out:
+        out["value_full_sequence"] = out["value"]
+        out["config"]["value_full_sequence"] = "= value: this run IS the KITTI-0000-length run"
+        if "parity" in out:
+            out["parity_full_sequence"] = out["parity"]
     # ---- R-sweep: aggregate frames/s for several numbers of independent sequences per GPU (the per-frame path keeps <= ~10 of the
     # 256 CUs busy: one sequence per GPU leaves the chip idle, SURVEY 8e "replicas only")
     if args.replica_sweep:
@@ -744,6 +823,12 @@ def main():
                                            "target": 30.0,
                                            "note": "the product keeps ~8 host threads busy per sequence (main + helper + ORB thread + quadtree helpers) against a 1-thread baseline; "
                                                    "cpu_baseline.multi_process is the same CPU code on 8 processes"}
+        if frames_full is not None and "value_full_sequence" in out:      # the same ratio over the KITTI-0000 length: both sides on the 153-frame sequence
+            cfps_f, cn_f, _, _, _ = cpu_baseline_frames(frames_full, budget_s=12.0)
+            out["cpu_baseline"]["full_sequence"] = {"value": cfps_f, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"the first {cn_f} frames of the {KITTI0000_FRAMES}-frame sequence (oracle, 1 thread)"}
+            out["speedup_vs_cpu_baseline"]["value_full_sequence"] = out["value_full_sequence"] / cfps_f
+        elif "value_full_sequence" in out:
+            out["speedup_vs_cpu_baseline"]["value_full_sequence"] = out["value_full_sequence"] / cfps
         # ---- the reference's own five clock() brackets (all_timing[0..4]: mask update, camera estimate, object tracking, object estimate per object,
         # map update = RenewFrameInfo; src/Tracking.cc:230-243, 685-703, 1366-1603, 868-1010, 1016-1020), side by side, ms per frame
         pf = out["config"]["host_ms_per_section"]; n_obj_mean = max(out["config"]["per_frame_mean"]["n_objects"], 1e-9)

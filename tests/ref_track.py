@@ -77,6 +77,9 @@ class RefSystem:
         self.L.vdo_ref_set_time(-1 if fake_time is None else int(fake_time))
         with Quiet():
             rc = self.L.vdo_ref_system_track(self.h, _p(gray), ch, _p(depth), _p(flow), _p(mask), w, h, _p(gt), _p(rows) if len(rows) else None, len(rows), 10, float(timestamp), int(n_images), _p(T))
+        # The reference keeps SHALLOW headers on the caller's images for one more frame (mImGrayLast / mDepthMapLast / mFlowMapLast / mSegMapLast,
+        # src/Tracking.cc:641-644 - UpdateMask reads them): the buffers of the last two calls stay alive here whatever the caller drops
+        self._alive = (getattr(self, "_alive", ()) + ((gray, depth, flow, mask),))[-2:]
         if rc != 0:
             raise RuntimeError("System::TrackRGBD returned an empty pose")
         return T.reshape(4, 4), depth, mask
@@ -171,3 +174,54 @@ def brackets_worker_main(settings, frames_npz, n_images=1 << 30):
     dt = time.perf_counter() - t0
     rs.close()
     print(json.dumps({"ms": [float(v) / max(nfr, 1) for v in acc], "tracked_frames": nfr, "frames_per_s": n / dt}))
+
+
+# ---- long sequences: frames read one by one from a directory of f{k}.npz files (vdo_slam_amd/synth_seq.render_bench_sequence), depth / mask kept as digests ----
+def _digest(a):
+    import hashlib
+    return np.frombuffer(hashlib.sha1(np.ascontiguousarray(a).tobytes()).digest(), np.uint8).copy()
+
+
+def dir_worker_main(settings, frames_dir, n, out_npz, n_images, labels, full=True, keep_images=False):
+    from vdo_slam_amd.synth_seq import load_bench_frame
+    rs = RefSystem(settings, full=full)
+    out = {"n": n}
+    import time
+    t0 = time.perf_counter()
+    for k in range(n):
+        fr = load_bench_frame(frames_dir, k)
+        T, depth, mask = rs.track(fr, k, n_images=n_images, labels=labels)
+        out[f"T_{k}"] = T; out[f"depth_sha_{k}"] = _digest(depth); out[f"mask_sha_{k}"] = _digest(mask)
+        if keep_images:
+            out[f"depth_{k}"] = depth; out[f"mask_{k}"] = mask
+        for what, rows in ((0, 10), (1, 12), (2, 19), (3, 8), (4, 17)):
+            cnt, a = rs.state(what, rows)
+            out[f"s{what}_{k}"] = a.copy(); out[f"n{what}_{k}"] = cnt
+        c = rs.counts()
+        out[f"counts_{k}"] = np.array([c[q] for q in RefSystem.COUNTS], np.int32)
+    out["seconds"] = time.perf_counter() - t0
+    for which, name in ((0, "sta"), (1, "dyn")):
+        off, fr_, ft_, ob_ = rs.tracks(bool(which))
+        out[f"tr_{name}_off"] = off; out[f"tr_{name}_frame"] = fr_; out[f"tr_{name}_feat"] = ft_
+        if ob_ is not None:
+            out[f"tr_{name}_obj"] = ob_
+    rs.close()
+    tmp = out_npz + ".tmp.npz"
+    np.savez(tmp, **out)
+    os.replace(tmp, out_npz)
+
+
+def start_sequence_from_dir(settings, frames_dir, n, out_npz, n_images=1 << 30, labels=(1, 2, 3, 4, 5), full=True, keep_images=False):
+    """The reference (child process, CPU) over the n frames of frames_dir; returns the Popen - the caller overlaps it with GPU work and then calls finish_sequence."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = (f"import sys; sys.path.insert(0, {root!r}); from tests.ref_track import dir_worker_main; "
+            f"dir_worker_main({str(settings)!r}, {str(frames_dir)!r}, {int(n)}, {str(out_npz)!r}, {int(n_images)}, {tuple(labels)!r}, {bool(full)!r}, {bool(keep_images)!r})")
+    return subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.DEVNULL, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"))
+
+
+def finish_sequence(proc, out_npz, timeout_s=600):
+    if proc.wait(timeout=timeout_s) != 0:
+        raise RuntimeError("the reference's TrackRGBD sequence (oracle/_ref) failed in its child process")
+    return np.load(out_npz)

@@ -86,8 +86,9 @@ def test_bench_source_keeps_the_oracle_out_of_the_product_path():
     src = open(os.path.join(ROOT, "bench.py")).read()
     uses = [m.start() for m in re.finditer(r"oracle", src)]
     assert uses, "the cpu_baseline legs load the oracle"
-    # every import of the oracle library sits inside a function whose name starts with cpu_ (the cpu_baseline legs)
+    # every import of the oracle library / the checkers under tests/ sits inside a function whose name starts with cpu_ (the cpu_baseline legs) or parity_ (the parity
+    # leg: the reference's own run of the timed sequence in child processes + the comparison - checked BEFORE anything is timed, never inside a timed region)
     for m in re.finditer(r"^(\s*)(from tests|import tests|from tests\.|.*oracle_lib|.*load_oracle).*$", src, re.M):
         head = src[:m.start()]
         fn = re.findall(r"^def (\w+)\(", head, re.M)
-        assert fn and fn[-1].startswith("cpu_"), (m.group(0).strip(), fn[-1] if fn else None)
+        assert fn and (fn[-1].startswith("cpu_") or fn[-1].startswith("parity_")), (m.group(0).strip(), fn[-1] if fn else None)

@@ -4,7 +4,6 @@ import os, sys, time
 os.environ["VDO_PIPE_EVENTS"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
-import bench
 from vdo_slam_amd import synth, synth_frames as SF, synth_seq as SQ
 from vdo_slam_amd.ba import Context
 from vdo_slam_amd.pipeline import FramePipeline, kitti_params
@@ -12,11 +11,10 @@ from vdo_slam_amd.pipeline import FramePipeline, kitti_params
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 warm = 5
 W, H = synth.KITTI_W, synth.KITTI_H
-n_seq = steps + warm
-Ts = SQ.camera_poses(n_seq)
-drop, leave_at, enter_at = bench.sequence_events(warm, steps)
-objs = SQ.survey_objects(leave_at=leave_at, enter_at=enter_at, box_depth=bench.BOX_DEPTH)
-frames = [SQ.render_frame(k, Ts, objs, flow_sigma=bench.FLOW_SIGMA, seed=0, invalid_depth=bench.INVALID_DEPTH, zero_flow=bench.ZERO_FLOW, drop_masks=drop) for k in range(n_seq)]
+import tempfile
+spec = SQ.bench_spec(warm, steps)
+n_seq = spec["n_seq"]
+frames = SQ.render_bench_sequence(spec, tempfile.mkdtemp(prefix="vdo_step_events_", dir="/tmp"))
 dev = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames]
 torch.cuda.synchronize()
 os.environ.setdefault("VDO_ORB_THREADS", "5")

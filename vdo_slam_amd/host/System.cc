@@ -425,4 +425,9 @@ int host_system_refined_poses(VDO_SLAM::System* s, int cap, float* Twc16) {
   return (int)P.size();
 }
 void host_system_save(VDO_SLAM::System* s, const char* path) { s->SaveResults(path); }
+// the tracklets Track() has built so far (GetStaticTrack / GetDynamicTrackNew, src/Tracking.cc:2201-2421): which = 0 static, 1 dynamic; off == NULL -> sizes only
+int host_pipeline_tracks(VDO_SLAM::FramePipeline* fp, int which, int64_t* sizes2, int32_t* off, int32_t* frame, int32_t* feat, int32_t* obj);
+int host_system_tracks(VDO_SLAM::System* s, int which, int64_t* sizes2, int32_t* off, int32_t* frame, int32_t* feat, int32_t* obj) {
+  return host_pipeline_tracks(s->tracker()->pipeline(), which, sizes2, off, frame, feat, obj);
+}
 }

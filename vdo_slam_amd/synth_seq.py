@@ -151,3 +151,93 @@ def object_motion(ob, k=0):
     else:
         H[:3, 3] = ob["v"]
     return H
+
+
+# ---- the sequence bench.py times, the parity leg checks and tests/test_bench_sequence_gpu.py replays (one definition) -------------------------
+# SURVEY.md 8d "synthetic inputs": flow noise N(0, 0.3^2) px, 2 % invalid depth, 1 % exactly-zero flow, 5 moving boxes (4 turning), one
+# instance mask missing for two frames (exercises UpdateMask), one object leaving and one entering
+BENCH_FLOW_SIGMA, BENCH_INVALID_DEPTH, BENCH_ZERO_FLOW, BENCH_N_OBJECTS, BENCH_BOX_DEPTH = 0.3, 0.02, 0.01, 5, 0.9
+BENCH_MAX_FRAMES = 160          # the objects stay in view that long
+KITTI0000_FRAMES = 153          # example/vdo_slam.cc:95-96
+
+
+def bench_events(warmup, steps):
+    """Where the 8d events fall: SURVEY's frames (mask dropped at 30 and 31, object 2 leaves at 60, object 5 enters at 80) for a
+    KITTI-0000-length run, pulled inside the timed window [warmup, warmup+steps) whatever `steps` is."""
+    drop_at = min(30, warmup + 3)
+    leave_at = min(60, warmup + max(2, (2 * steps) // 5))
+    enter_at = min(80, warmup + max(4, (3 * steps) // 5))
+    return {drop_at: {1}, drop_at + 1: {1}}, leave_at, enter_at
+
+
+def bench_spec(warmup, steps, seed=0):
+    """Everything that defines the bench sequence of a (warmup, steps) run: a plain dict (picklable, hashable through repr)."""
+    drop, leave_at, enter_at = bench_events(warmup, steps)
+    return dict(n_seq=min(warmup + steps, BENCH_MAX_FRAMES), drop_masks={k: sorted(v) for k, v in drop.items()}, leave_at=leave_at, enter_at=enter_at, seed=int(seed))
+
+
+def bench_objects(spec):
+    return survey_objects(leave_at=spec["leave_at"], enter_at=spec["enter_at"], box_depth=BENCH_BOX_DEPTH)
+
+
+def render_bench_frame(spec, k):
+    Ts = camera_poses(spec["n_seq"])
+    return render_frame(k, Ts, bench_objects(spec), flow_sigma=BENCH_FLOW_SIGMA, seed=spec["seed"], invalid_depth=BENCH_INVALID_DEPTH, zero_flow=BENCH_ZERO_FLOW,
+                        drop_masks={k_: set(v) for k_, v in spec["drop_masks"].items()})
+
+
+FRAME_KEYS = ("gray", "depth_raw", "flow", "mask", "Tcw", "Tcw_next")
+
+
+def _render_worker(spec_json, out_dir, k0, stride, n=None):
+    """child process: frames k0, k0 + stride, ... (below n) of the sequence into out_dir/f{k}.npz (numpy only)"""
+    import json
+    import os
+    spec = json.loads(spec_json)
+    spec["drop_masks"] = {int(k): v for k, v in spec["drop_masks"].items()}
+    for k in range(int(k0), min(spec["n_seq"], int(n)) if n else spec["n_seq"], int(stride)):
+        fr = render_bench_frame(spec, k)
+        tmp = os.path.join(out_dir, f".f{k}.tmp.npz")
+        np.savez(tmp, **{q: fr[q] for q in FRAME_KEYS})
+        os.replace(tmp, os.path.join(out_dir, f"f{k}.npz"))
+
+
+def load_bench_frame(out_dir, k):
+    import os
+    z = np.load(os.path.join(out_dir, f"f{k}.npz"))
+    return {q: z[q] for q in FRAME_KEYS}
+
+
+def render_bench_sequence(spec, out_dir, workers=None, timeout_s=900, n=None):
+    """All frames of the sequence as files out_dir/f{k}.npz, rendered by `workers` numpy-only child processes started with their own command line
+    (a frame is ~1 s of numpy on one core; no fork of a process that holds the HIP runtime, no re-import of the caller's __main__).  Returns the
+    frames as a list of dicts."""
+    import json
+    import os
+    import subprocess
+    import sys
+    n = spec["n_seq"] if n is None else min(int(n), spec["n_seq"])      # (n: only the first n frames of the sequence)
+    if workers is None:
+        workers = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+            if q != "max":
+                workers = min(workers, max(1, int(int(q) / int(per))))
+        except (OSError, ValueError):
+            pass
+    workers = max(1, min(int(workers), 16, n))
+    os.makedirs(out_dir, exist_ok=True)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sj = json.dumps(spec)
+    code = "import sys; sys.path.insert(0, sys.argv[1]); from vdo_slam_amd.synth_seq import _render_worker; _render_worker(sys.argv[2], sys.argv[3], sys.argv[4], sys.argv[5], sys.argv[6])"
+    env = dict(os.environ, OMP_NUM_THREADS="1", OPENBLAS_NUM_THREADS="1", MKL_NUM_THREADS="1")
+    procs = [subprocess.Popen([sys.executable, "-c", code, root, sj, out_dir, str(w), str(workers), str(n)], env=env, stdout=subprocess.DEVNULL) for w in range(workers)]
+    try:
+        for pr in procs:
+            if pr.wait(timeout=timeout_s) != 0:
+                raise RuntimeError("render_bench_sequence: a render worker failed")
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return [load_bench_frame(out_dir, k) for k in range(n)]

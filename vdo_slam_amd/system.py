@@ -96,6 +96,33 @@ class System:
         m = self._L.host_system_refined_poses(self._h, n, _ptr(rf))
         return rf[:min(m, n)].reshape(-1, 4, 4)
 
+    def tracks(self, dynamic=False):
+        """(off, frame, feat, obj): tracklet t = pairs [off[t], off[t+1]) of (frame, feature index); obj = object id per dynamic tracklet"""
+        L = self._L
+        L.host_system_tracks.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int64), K.c_int32_p, K.c_int32_p, K.c_int32_p, K.c_int32_p]
+        sz = (C.c_int64 * 2)()
+        if L.host_system_tracks(self._h, int(dynamic), sz, None, None, None, None) != 0:
+            raise K.VdoError("System.tracks failed")
+        nt, npairs = int(sz[0]), int(sz[1])
+        off = np.zeros(nt + 1, np.int32); fr = np.zeros(max(npairs, 1), np.int32); ft = np.zeros(max(npairs, 1), np.int32); ob = np.zeros(max(nt, 1), np.int32)
+        ip = lambda a: a.ctypes.data_as(K.c_int32_p)
+        if L.host_system_tracks(self._h, int(dynamic), sz, ip(off), ip(fr), ip(ft), ip(ob)) != 0:
+            raise K.VdoError("System.tracks failed")
+        return off, fr[:npairs], ft[:npairs], (ob[:nt] if dynamic else None)
+
+    def frame_state(self, what, rows):
+        """Tracking::SyncFrameState() + a flat copy (host_system_frame_state): what = 0 static set [10][n], 1 object set [12][n], 2 per object [n][19],
+        3 samples [8][n], 4 scalars [17]; returns (n, flat float32 array)"""
+        L = self._L
+        L.host_system_frame_state.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int]
+        n = L.host_system_frame_state(self._h, what, None, 0)
+        if n < 0:
+            raise K.VdoError("System.frame_state failed")
+        buf = np.zeros(max(rows * n, 1), np.float32)
+        if L.host_system_frame_state(self._h, what, _ptr(buf), buf.size) != n:
+            raise K.VdoError("System.frame_state failed")
+        return n, buf[:rows * n]
+
     def save(self, path):
         self._L.host_system_save(self._h, str(path).encode())
 
