@@ -416,6 +416,23 @@ int vdo_ref_system_tracks(void* sp, int which, int64_t* sizes2, int32_t* off, in
   return 0;
 }
 
+// flat copy of the Map the batch optimisers read and write (include/Map.h:35-84): what = 0 vmCameraPose [F][16], 1 vmCameraPose_RF, 2 vmRigidMotion (all frames, all entries)
+// [n][16], 3 vmRigidMotion_RF, 4 vnRMLabel [n] (as floats), 5 vp3DPointSta [n][3], 6 vp3DPointDyn [n][3], 7 entries of vmRigidMotion per frame [F-1].  Returns the number of floats
+// (out filled only when cap allows), -1 on a bad `what`.
+long vdo_ref_system_map_export(void* sp, int what, float* out, long cap) {
+  VDO_SLAM::Map* m = ((System*)sp)->mpMap;
+  long n = 0;
+  auto put = [&](float v) { if (out && n < cap) out[n] = v; ++n; };
+  auto put_mat = [&](const cv::Mat& M) { for (int i = 0; i < M.rows; ++i) for (int j = 0; j < M.cols; ++j) put(M.at<float>(i, j)); };
+  if (what == 0 || what == 1) { for (const cv::Mat& T : (what ? m->vmCameraPose_RF : m->vmCameraPose)) put_mat(T); }
+  else if (what == 2 || what == 3) { for (const auto& fr : (what == 3 ? m->vmRigidMotion_RF : m->vmRigidMotion)) for (const cv::Mat& T : fr) put_mat(T); }
+  else if (what == 4) { for (const auto& fr : m->vnRMLabel) for (int l : fr) put((float)l); }
+  else if (what == 5 || what == 6) { for (const auto& fr : (what == 6 ? m->vp3DPointDyn : m->vp3DPointSta)) for (const cv::Mat& X : fr) put_mat(X); }
+  else if (what == 7) { for (const auto& fr : m->vmRigidMotion) put((float)fr.size()); }
+  else return -1;
+  return n;
+}
+
 // the five clock() brackets of the frame (all_timing, src/Tracking.cc:230-243, 685-703, 868-1010, 1016-1026, 1370-1603), milliseconds
 void vdo_ref_system_timing(void* sp, float* ms5) {
   Tracking* T = ((System*)sp)->mpTracker;

@@ -146,6 +146,9 @@ def _bind_ref_system(L):
     L.vdo_ref_system_tracks.argtypes = [vp, C.c_int, vp, vp, vp, vp, vp]
     L.vdo_ref_system_timing.argtypes = [vp, vp]
     L.vdo_ref_set_time.argtypes = [C.c_long]
+    if hasattr(L, "vdo_ref_system_map_export"):
+        L.vdo_ref_system_map_export.restype = C.c_long
+        L.vdo_ref_system_map_export.argtypes = [vp, C.c_int, vp, C.c_long]
 
 
 def load_ref_full():

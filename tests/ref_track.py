@@ -104,6 +104,14 @@ class RefSystem:
         self.L.vdo_ref_system_tracks(self.h, int(dynamic), _p(sz), _p(off), _p(fr), _p(ft), _p(ob))
         return off, fr[:npairs], ft[:npairs], (ob[:nt] if dynamic else None)
 
+    def map_export(self, what):
+        """flat copy of the Map (vdo_ref_system_map_export): 0 vmCameraPose, 1 vmCameraPose_RF, 2 vmRigidMotion, 3 vmRigidMotion_RF, 4 vnRMLabel, 5 vp3DPointSta, 6 vp3DPointDyn, 7 motions per frame"""
+        n = self.L.vdo_ref_system_map_export(self.h, what, None, 0)
+        assert n >= 0
+        buf = np.zeros(max(n, 1), np.float32)
+        assert self.L.vdo_ref_system_map_export(self.h, what, _p(buf), n) == n
+        return buf[:n]
+
     def timing_ms(self):
         t = np.zeros(5, np.float32)
         self.L.vdo_ref_system_timing(self.h, _p(t))
@@ -182,7 +190,10 @@ def _digest(a):
     return np.frombuffer(hashlib.sha1(np.ascontiguousarray(a).tobytes()).digest(), np.uint8).copy()
 
 
-def dir_worker_main(settings, frames_dir, n, out_npz, n_images, labels, full=True, keep_images=False):
+MAP_PARTS = ("cam_pose", "cam_pose_rf", "rigid_motion", "rigid_motion_rf", "rm_label", "points_sta", "points_dyn", "rm_count")
+
+
+def dir_worker_main(settings, frames_dir, n, out_npz, n_images, labels, full=True, keep_images=False, export_map=False):
     from vdo_slam_amd.synth_seq import load_bench_frame
     rs = RefSystem(settings, full=full)
     out = {"n": n}
@@ -200,6 +211,9 @@ def dir_worker_main(settings, frames_dir, n, out_npz, n_images, labels, full=Tru
         c = rs.counts()
         out[f"counts_{k}"] = np.array([c[q] for q in RefSystem.COUNTS], np.int32)
     out["seconds"] = time.perf_counter() - t0
+    if export_map:                                   # what the windowed / final batch optimisation left in the Map
+        for what, name in enumerate(MAP_PARTS):
+            out["map_" + name] = rs.map_export(what)
     for which, name in ((0, "sta"), (1, "dyn")):
         off, fr_, ft_, ob_ = rs.tracks(bool(which))
         out[f"tr_{name}_off"] = off; out[f"tr_{name}_frame"] = fr_; out[f"tr_{name}_feat"] = ft_
@@ -211,13 +225,13 @@ def dir_worker_main(settings, frames_dir, n, out_npz, n_images, labels, full=Tru
     os.replace(tmp, out_npz)
 
 
-def start_sequence_from_dir(settings, frames_dir, n, out_npz, n_images=1 << 30, labels=(1, 2, 3, 4, 5), full=True, keep_images=False):
+def start_sequence_from_dir(settings, frames_dir, n, out_npz, n_images=1 << 30, labels=(1, 2, 3, 4, 5), full=True, keep_images=False, export_map=False):
     """The reference (child process, CPU) over the n frames of frames_dir; returns the Popen - the caller overlaps it with GPU work and then calls finish_sequence."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     code = (f"import sys; sys.path.insert(0, {root!r}); from tests.ref_track import dir_worker_main; "
-            f"dir_worker_main({str(settings)!r}, {str(frames_dir)!r}, {int(n)}, {str(out_npz)!r}, {int(n_images)}, {tuple(labels)!r}, {bool(full)!r}, {bool(keep_images)!r})")
+            f"dir_worker_main({str(settings)!r}, {str(frames_dir)!r}, {int(n)}, {str(out_npz)!r}, {int(n_images)}, {tuple(labels)!r}, {bool(full)!r}, {bool(keep_images)!r}, {bool(export_map)!r})")
     return subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.DEVNULL, cwd=root, env=dict(os.environ, OMP_NUM_THREADS="1"))
 
 

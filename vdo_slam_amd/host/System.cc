@@ -425,6 +425,23 @@ int host_system_refined_poses(VDO_SLAM::System* s, int cap, float* Twc16) {
   return (int)P.size();
 }
 void host_system_save(VDO_SLAM::System* s, const char* path) { s->SaveResults(path); }
+// flat copy of the Map (reference format, include/Map.h:35-84) after System::map() has brought it up to date - the layout of oracle/ref's vdo_ref_system_map_export: what = 0
+// vmCameraPose [F][16], 1 vmCameraPose_RF, 2 vmRigidMotion [n][16], 3 vmRigidMotion_RF, 4 vnRMLabel [n], 5 vp3DPointSta [n][3], 6 vp3DPointDyn [n][3], 7 motions per frame [F-1]
+long host_system_map_export(VDO_SLAM::System* s, int what, float* out, long cap) {
+  try {
+    VDO_SLAM::Map* m = s->map();
+    long n = 0;
+    auto put = [&](float v) { if (out && n < cap) out[n] = v; ++n; };
+    auto put_mat = [&](const cv::Mat& M) { const float* p = (const float*)M.data; for (int i = 0; i < M.rows * M.cols; ++i) put(p[i]); };
+    if (what == 0 || what == 1) { for (const cv::Mat& T : (what ? m->vmCameraPose_RF : m->vmCameraPose)) put_mat(T); }
+    else if (what == 2 || what == 3) { for (const auto& fr : (what == 3 ? m->vmRigidMotion_RF : m->vmRigidMotion)) for (const cv::Mat& T : fr) put_mat(T); }
+    else if (what == 4) { for (const auto& fr : m->vnRMLabel) for (int l : fr) put((float)l); }
+    else if (what == 5 || what == 6) { for (const auto& fr : (what == 6 ? m->vp3DPointDyn : m->vp3DPointSta)) for (const cv::Mat& X : fr) put_mat(X); }
+    else if (what == 7) { for (const auto& fr : m->vmRigidMotion) put((float)fr.size()); }
+    else return -1;
+    return n;
+  } catch (const std::exception& e) { std::fprintf(stderr, "host_system_map_export: %s\n", e.what()); return -1; }
+}
 // the tracklets Track() has built so far (GetStaticTrack / GetDynamicTrackNew, src/Tracking.cc:2201-2421): which = 0 static, 1 dynamic; off == NULL -> sizes only
 int host_pipeline_tracks(VDO_SLAM::FramePipeline* fp, int which, int64_t* sizes2, int32_t* off, int32_t* frame, int32_t* feat, int32_t* obj);
 int host_system_tracks(VDO_SLAM::System* s, int which, int64_t* sizes2, int32_t* off, int32_t* frame, int32_t* feat, int32_t* obj) {

@@ -123,6 +123,20 @@ class System:
             raise K.VdoError("System.frame_state failed")
         return n, buf[:rows * n]
 
+    def map_export(self, what):
+        """flat copy of the Map in the reference's format (host_system_map_export): 0 vmCameraPose [F][16], 1 vmCameraPose_RF, 2 vmRigidMotion [n][16], 3 vmRigidMotion_RF,
+        4 vnRMLabel [n], 5 vp3DPointSta [n][3], 6 vp3DPointDyn [n][3], 7 motions per frame [F-1]"""
+        L = self._L
+        L.host_system_map_export.restype = C.c_long
+        L.host_system_map_export.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_long]
+        n = L.host_system_map_export(self._h, what, None, 0)
+        if n < 0:
+            raise K.VdoError("System.map_export failed")
+        buf = np.zeros(max(n, 1), np.float32)
+        if L.host_system_map_export(self._h, what, _ptr(buf), n) != n:
+            raise K.VdoError("System.map_export failed")
+        return buf[:n]
+
     def save(self, path):
         self._L.host_system_save(self._h, str(path).encode())
 
