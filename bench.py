@@ -72,21 +72,22 @@ def _pmc_traffic_bytes(graph, dims):
 _PMC_EXTRA = {}        # SQ counters of the sweep kernel per launch (the third pass of _pmc_traffic_live)
 
 
-def _pmc_traffic_live(n_static, graph, dims, timeout_s=150):
-    """HBM bytes per k_sweep_tile launch MEASURED DURING THIS BENCH RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE - each in its own run, as
-    MI355X_MICROARCH.md prescribes, no trace domains beside them) over tools/sweep_only.py on the same graph, in child processes; 2*FETCH + WRITE with
+def _pmc_traffic_live(n_static, graph, dims, timeout_s=150, script="sweep_only.py", kernel_like="%k_sweep_tile<true%", sq=True, extra=None):
+    """HBM bytes per launch of one kernel MEASURED DURING THIS BENCH RUN: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE - each in its own run, as
+    MI355X_MICROARCH.md prescribes, no trace domains beside them) over tools/<script> on the same graph, in child processes; 2*FETCH + WRITE with
     the guide's gfx950 correction.  None when rocprofv3 is not there, a pass fails or the child's graph / tile layout is not this one (the committed
-    counter file, then the byte model, take over)."""
+    counter file, then the byte model, take over).  sq: a third pass with the SQ counters (VALU issue, LDS pipe) into `extra`."""
     import re, shutil, sqlite3, subprocess, tempfile
     if not shutil.which("rocprofv3"):
         return None
     here = os.path.dirname(os.path.abspath(__file__))
+    extra = _PMC_EXTRA if extra is None else extra
     tot = {}
     tmp = tempfile.mkdtemp(prefix="vdo_pmc_", dir="/tmp")
     try:
         for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
             out = os.path.join(tmp, ctr)
-            r = subprocess.run(["rocprofv3", "--pmc", ctr, "-d", out, "--", sys.executable, os.path.join(here, "tools", "sweep_only.py"), str(n_static)],
+            r = subprocess.run(["rocprofv3", "--pmc", ctr, "-d", out, "--", sys.executable, os.path.join(here, "tools", script), str(n_static)],
                                cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, text=True)
             m = re.search(r"n_eb (\d+) n_et (\d+) n_point (\d+) tiles (\d+) eb_entries (\d+)", r.stdout or "")
             if r.returncode != 0 or not m or tuple(int(v) for v in m.groups()) != (graph.n_eb, graph.n_et, graph.n_point, dims["tiles"], dims["eb_entries"]):
@@ -94,25 +95,26 @@ def _pmc_traffic_live(n_static, graph, dims, timeout_s=150):
             dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
             if not dbs:
                 return None
-            row = sqlite3.connect(dbs[0]).execute("select avg(value), count(*) from counters_collection where kernel_name like '%k_sweep_tile<true%' and counter_name = ?", (ctr,)).fetchone()
+            row = sqlite3.connect(dbs[0]).execute("select avg(value), count(*) from counters_collection where kernel_name like ? and counter_name = ?", (kernel_like, ctr)).fetchone()
             if not row or not row[1]:
                 return None
             tot[ctr] = float(row[0]) * 1024.0                    # (the counters are in KB)
-        _PMC_EXTRA.clear()
-        try:                                                     # a third pass: what the SQ saw (VALU issue, LDS pipe) - reported beside the HBM fraction, never instead of it
-            out = os.path.join(tmp, "SQ")
-            ctrs = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT"]
-            r = subprocess.run(["rocprofv3", "--pmc"] + ctrs + ["-d", out, "--", sys.executable, os.path.join(here, "tools", "sweep_only.py"), str(n_static)],
-                               cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, text=True)
-            dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
-            if r.returncode == 0 and dbs:
-                con = sqlite3.connect(dbs[0])
-                for c in ctrs:
-                    row = con.execute("select avg(value), count(*) from counters_collection where kernel_name like '%k_sweep_tile<true%' and counter_name = ?", (c,)).fetchone()
-                    if row and row[1]:
-                        _PMC_EXTRA[c] = float(row[0])
-        except Exception:                                        # noqa: BLE001
-            pass
+        extra.clear()
+        if sq:
+            try:                                                 # a third pass: what the SQ saw (VALU issue, LDS pipe) - reported beside the HBM fraction, never instead of it
+                out = os.path.join(tmp, "SQ")
+                ctrs = ["SQ_INSTS_VALU", "SQ_ACTIVE_INST_LDS", "SQ_LDS_BANK_CONFLICT"]
+                r = subprocess.run(["rocprofv3", "--pmc"] + ctrs + ["-d", out, "--", sys.executable, os.path.join(here, "tools", script), str(n_static)],
+                                   cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=timeout_s, text=True)
+                dbs = [os.path.join(dp, f) for dp, _, fs in os.walk(out) for f in fs if f.endswith(".db")]
+                if r.returncode == 0 and dbs:
+                    con = sqlite3.connect(dbs[0])
+                    for c in ctrs:
+                        row = con.execute("select avg(value), count(*) from counters_collection where kernel_name like ? and counter_name = ?", (kernel_like, c)).fetchone()
+                        if row and row[1]:
+                            extra[c] = float(row[0])
+            except Exception:                                    # noqa: BLE001
+                pass
         return 2.0 * tot["FETCH_SIZE"] + tot["WRITE_SIZE"]       # (gfx950 tallies 128-B read requests at 64 B: FETCH_SIZE doubled)
     except Exception:
         return None
@@ -807,6 +809,40 @@ def main():
             if _PMC_EXTRA.get("SQ_ACTIVE_INST_LDS"):
                 out["roofline"]["lds"] = {"active_quad_cycles_per_launch": _PMC_EXTRA["SQ_ACTIVE_INST_LDS"], "bank_conflict_cycles_per_launch": _PMC_EXTRA.get("SQ_LDS_BANK_CONFLICT"),
                                           "busy_frac": _PMC_EXTRA["SQ_ACTIVE_INST_LDS"] * 4.0 / 256.0 / cyc, "note": "SQ_ACTIVE_INST_LDS x 4 / (256 CUs x clock x kernel time)"}
+        # ---- the solver side of the same graph: the Schur mat-vec of a CG iteration (k_schur_tile<0>), the largest consumer of an LM iteration - the work the
+        # matrix-free sweep moved out of the linearisation (it stores 8 B per edge instead of the 144-B pose-landmark block; every mat-vec recomputes the block)
+        try:
+            from vdo_slam_amd.ba import schur_byte_model
+            st_r = bar.optimize(max_iterations=1, gain_threshold=-1.0)
+            bar.profile_schur(100)                                                      # untimed warm-up
+            schur_ms = bar.profile_schur(100)
+            smodel = schur_byte_model(gr, dims, args.roofline_static)
+            sx = {}
+            s_traffic = _pmc_traffic_live(args.roofline_static, gr, dims, script="schur_only.py", kernel_like="%k_schur_tile<0>%", sq=True, extra=sx) \
+                if (rank == 0 and world == 1 and not args.no_live_pmc) else None
+            s_used = s_traffic if s_traffic is not None else float(smodel["matvec"])
+            out["roofline_solver"] = {
+                "bound": "hbm", "kernel": "k_schur_tile<0>", "achieved": s_used / (schur_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": s_used / (schur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": s_traffic,
+                "frac_basis": "counters (2*FETCH_SIZE + WRITE_SIZE, live passes over tools/schur_only.py)" if s_traffic is not None else "model_bytes (no live counter pass)",
+                "model_bytes": smodel, "frac_model": smodel["matvec"] / (schur_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "avg_launch_ms": schur_ms,
+                "survey_8d_matvec_bytes": smodel["stored_hpl"], "survey_8d_matvec_rate": smodel["stored_hpl"] / (schur_ms * 1e-3) / 1e9,
+                "launches_per_lm_iteration": "one per CG iteration (+ one each of the <1> and <2> instantiations per trial)",
+                "timed_launches": 100, "lm_iteration_before": [int(st_r.iterations), int(st_r.total_trials)],
+                "note": "`frac` = HBM bytes one Schur mat-vec launch moves (counters of this run when available, else the byte model of vdo_slam_amd/ba.py schur_byte_model) / its mean "
+                        "duration (hipEvents on the context's stream, vdo_ba_profile_schur) / 8 TB/s.  `survey_8d_matvec_rate` divides what a design with STORED 6x3 pose-landmark blocks "
+                        "would move (SURVEY 8d: 144 B per EdgeSE3PointXYZ + 360 B per ternary edge) by the same time - a comparison, not a bandwidth: this design moves 12 B per incidence "
+                        "and recomputes the block (two cross products) from the point and the slot's pose in LDS"}
+            if sx.get("SQ_INSTS_VALU"):
+                prop = torch.cuda.get_device_properties(local)
+                clk = float(getattr(prop, "clock_rate", 0) or 2.4e6) * 1e3
+                cyc = clk * schur_ms * 1e-3
+                out["roofline_solver"]["valu"] = {"insts_per_launch": sx["SQ_INSTS_VALU"], "issue_frac": sx["SQ_INSTS_VALU"] * 4.0 / 1024.0 / cyc}
+                if sx.get("SQ_ACTIVE_INST_LDS"):
+                    out["roofline_solver"]["lds"] = {"active_quad_cycles_per_launch": sx["SQ_ACTIVE_INST_LDS"], "bank_conflict_cycles_per_launch": sx.get("SQ_LDS_BANK_CONFLICT"),
+                                                     "busy_frac": sx["SQ_ACTIVE_INST_LDS"] * 4.0 / 256.0 / cyc}
+        except Exception as e:                                   # noqa: BLE001 - the sweep's roofline above stays valid
+            out["roofline_solver"] = {"error": repr(e)[:300]}
         bar.close()
         if rank == 0 and world == 1 and not args.no_cpu_baseline:
             cb_ms, cb_sweep, cb_its = cpu_baseline_batch(g)

@@ -158,6 +158,9 @@ int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep);
  *   [6] EdgeSE3PointXYZ ENTRIES of the tiles' edge blocks (>= the graph's edges: every tile holds its edges as a padded block of
  *       256 x (edges per thread) entries, thread-transposed, so that every load of a tile kernel is one contiguous row), [7] reserved (0). */
 int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int64_t dims[8]);
+/* new (measurement): mean milliseconds of ONE Schur mat-vec launch (k_schur_tile<0>, the product B Hll^-1 B^T p of a CG iteration of the reduced-camera solve that
+   replaces g2o's BlockSolver::solve / LinearSolverCSparse, g2o/core/block_solver.hpp:143-295), timed alone with events on the context's stream.  Call after vdo_ba_optimize. */
+int vdo_ba_profile_schur(vdo_ba* ba, int repeat, float* ms);
 /* One self-consistent linearisation in block form (BlockSolver::buildSystem) AT THE CURRENT ESTIMATE: the blocks of the last
  * vdo_ba_linearize when nothing moved the estimate since, else (after vdo_ba_optimize / vdo_ba_set_estimates) a fresh linearisation is
  * run first - collective on a sharded handle. */

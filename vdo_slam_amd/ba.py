@@ -82,6 +82,14 @@ class BatchBA:
         K.check(K.lib().vdo_ba_linearize(self._h, repeat, C.byref(ms) if timed else None))
         return ms.value if timed else None
 
+    def profile_schur(self, repeat=100):
+        """mean ms of one Schur mat-vec launch (k_schur_tile<0>) - vdo_ba_profile_schur; call after optimize()."""
+        L = K.lib()
+        ms = C.c_float()
+        L.vdo_ba_profile_schur.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float)]
+        K.check(L.vdo_ba_profile_schur(self._h, repeat, C.byref(ms)))
+        return float(ms.value)
+
     def profile_linearize(self, repeat: int = 10):
         """(ms of the sweep kernel alone, ms of a whole linearisation, layout dims) - vdo_ba_profile_linearize."""
         ms = (C.c_float * 2)(); dims = (C.c_int64 * 8)()
@@ -142,3 +150,16 @@ def linearize_byte_model(graph, dims):
     sweep_w = 8 * (graph.n_eb + graph.n_et) + 72 * graph.n_et + 32 * graph.n_point + row * dims["slots"]
     fin = row * dims["slots"] + 336 * graph.n_pose
     return dict(sweep_read=int(sweep_r), sweep_write=int(sweep_w), sweep=int(sweep_r + sweep_w), finalize=int(fin), linearize=int(sweep_r + sweep_w + fin))
+
+
+def schur_byte_model(graph, dims, n_static):
+    """HBM bytes ONE Schur mat-vec launch (k_schur_tile<0>: part_q = B Hll^-1 B^T p, csrc/ba_solve.hip) has to move with the matrix-free design: per incidence of the
+    tiles' padded edge blocks and per ternary incidence the slot key + the scalar `we` the sweep stored (12 B - the 6x3 block is RECOMPUTED from the point and the slot's
+    pose); per point its linearisation point + landmark scalar + chain range (40 B), per point of a dynamic track its two 3x3 chain factors (144 B); per (tile, pose-slot)
+    pair pose id, row id, the pose (96 B) and the two direction vectors (96 B); 48 B of descriptor per tile (reads); one row of 8 doubles per pair (write).
+    `stored_hpl`: what SURVEY 8d's formula prices - a design that keeps the 6x3 pose-landmark blocks: 144 B per EdgeSE3PointXYZ, 360 B per ternary edge."""
+    entries = dims.get("eb_entries") or graph.n_eb
+    n_dyn = max(0, graph.n_point - int(n_static))
+    rd = 12 * (entries + 2 * graph.n_et) + 40 * graph.n_point + 144 * n_dyn + 48 * dims["tiles"] + 200 * dims["slots"]
+    wr = 64 * dims["slots"]
+    return dict(read=int(rd), write=int(wr), matvec=int(rd + wr), stored_hpl=int(144 * graph.n_eb + 360 * graph.n_et))

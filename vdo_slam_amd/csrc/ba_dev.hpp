@@ -139,6 +139,7 @@ enum Scal { S_CHI2 = 0, S_RCHI2, S_MAXDIAG, S_RZ, S_PQ, S_RZ0, S_SCALE, S_RZNEW,
 
 // ---- ba_sweep.hip
 void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R);      // chi2 of estimate[which] -> scal
+void launch_schur_matvec_only(const BADev& d, hipStream_t s);                     // k_schur_tile<0> alone (vdo_ba_profile_schur)
 void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R);              // build system at estimate[0] (+chi2)
 void launch_sweep_only(const BADev& d, hipStream_t s);             // just the K18 tile sweep kernel (bench)
 // ---- ba_solve.hip

@@ -1948,6 +1948,11 @@ void launch_pcg_iter(const BADev& d, double lambda, double tol2, int parity, hip
   hipLaunchKernelGGL(k_pcg_chain<0>, dim3(d.n_pchains), dim3(64 * d.pc_nwave), pc_strip_bytes(d), s, d, tol2, parity, nq);
 }
 
+// (profiling: the Schur mat-vec of one CG iteration alone, on whatever direction the last solve left in zp / pp; the caller clears flags[1])
+void launch_schur_matvec_only(const BADev& d, hipStream_t s) {
+  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<0>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<0>, schur_lds(d)), s, d, (const double*)d.zp, (const double*)d.pp);
+}
+
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s) {
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<2>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<2>, schur_lds(d)), s, d, (const double*)d.xp, (const double*)nullptr);
   const int nb = red_blocks(d);

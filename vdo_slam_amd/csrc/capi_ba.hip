@@ -694,6 +694,29 @@ extern "C" int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int
   return sync_check(ba, "vdo_ba_profile_linearize");
 }
 
+// Mean duration of the Schur mat-vec of one CG iteration (k_schur_tile<0>: part_q = B Hll^-1 B^T p over every tile) - the largest consumer of an LM
+// iteration - timed alone with events on the context's stream.  Call after an optimisation (vdo_ba_optimize) of this handle: the landmark factors of its
+// last trial and the direction of its last solve are what the launches read.  ms: mean milliseconds per launch.
+extern "C" int vdo_ba_profile_schur(vdo_ba* ba, int repeat, float* ms) {
+  if (!ba || !ms) return set_error(VDO_ERR_INVALID, "vdo_ba_profile_schur: null argument");
+  int rc = ctx_bind(ba->ctx);
+  if (rc != VDO_OK) return rc;
+  hipStream_t s = ba->ctx->stream;
+  if (repeat < 1) repeat = 1;
+  const BADev& d = ba->d;
+  if (!d.n_tiles) { *ms = 0.f; return VDO_OK; }
+  hipMemsetAsync(d.flags, 0, 4 * sizeof(int32_t), s);          // (flags[1] = "PCG converged" turns the queued mat-vecs into no-ops)
+  launch_schur_matvec_only(d, s);                              // warm-up
+  hipEventRecord(ba->ev0, s);
+  for (int i = 0; i < repeat; ++i) launch_schur_matvec_only(d, s);
+  hipEventRecord(ba->ev1, s);
+  hipEventSynchronize(ba->ev1);
+  float t = 0;
+  hipEventElapsedTime(&t, ba->ev0, ba->ev1);
+  *ms = t / repeat;
+  return sync_check(ba, "vdo_ba_profile_schur");
+}
+
 extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
   if (!ba || !out) return set_error(VDO_ERR_INVALID, "null argument");
   int rc = ctx_bind(ba->ctx);
