@@ -742,7 +742,7 @@ def main():
                 except Exception as e:                       # the replica numbers above stay valid
                     out["sharded"][tag] = {"error": repr(e)[:300]}
             out["config"]["batch_sharding"] = ("landmark tracks cut into `ranks` runs of equal incidence count, all pose / motion vertices and pose-pose edges replicated; per LM iteration: "
-                                               "Hpp | bp | chi2 (42 P + 2 doubles) once per linearisation, the block-Jacobi diagonal (21 P + 1) once per trial, 6 P doubles per CG iteration, "
+                                               "Hpp | bp | chi2 (42 P + 2 doubles) once per linearisation, the block-Jacobi diagonal and the reduced right-hand side in ONE exchange per trial (27 P + 1; two dependent ones until round 6), 6 P doubles per CG iteration, "
                                                "3 scalars per trial (DESIGN 6); transport 'rccl' = ncclAllReduce issued by the C-ABI on its stream, 'callback' = torch.distributed through the "
                                                "host callback (ranks sharing a GPU)")
         # ---- BASELINE configs[2] (KITTI 0018-0020-shaped: ~10 k landmarks, 5 objects) and a configs[4]-shaped graph (1 M landmarks,

@@ -278,8 +278,12 @@ int vdo_pose_optimize(vdo_ctx* ctx, const vdo_pose_problem* p, vdo_flow2_result*
  * SOLVEPNP_AP3P): the sequential RANSAC of OpenCV 3.4 (cv::RNG subsets of 4 points, minimal P3P solve on 3 with
  * the 4th as tie-breaker, inliers = squared reprojection error <= thr^2, iteration budget shrunk by
  * RANSACUpdateNumIters) with every hypothesis solved (AP3P) and voted on the GPU at once and the loop replayed on the
- * host over the votes.  OpenCV's final EPnP refit on the inliers is NOT applied (the LM refinement that follows in
- * the reference starts from this pose).  T = [R|t] camera-from-world (what Rodrigues(rvec), tvec give). */
+ * host over the votes.  `refit` is a FLAG WORD (below): bit 0 applies OpenCV's final EPnP re-estimation on the inliers (what
+ * solvePnPRansac returns since 3.3 and what the reference's LM is seeded with - the host classes set it); with the bit clear
+ * the winning minimal hypothesis is returned.  Behaviour change of round 5 for callers that pass 0 or 1: the minimal solver
+ * is AP3P with the hypotheses re-orthogonalised as cv::Rodrigues does (bit 1 restores Grunert's P3P of rounds 1-4), so
+ * hypotheses, inlier sets and poses of noisy problems differ from the earlier rounds'; a batch that mixes the two solvers
+ * returns VDO_ERR_INVALID.  T = [R|t] camera-from-world (what Rodrigues(rvec), tvec give). */
 typedef struct vdo_pnp_problem {
   int32_t n;
   const double* X;          /* [n][3] 3-D points (pre_3d)                         */

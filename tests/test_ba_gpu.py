@@ -16,6 +16,13 @@ pytestmark = pytest.mark.gpu
 # (same iterations, same trials per iteration, chi2 trace to 1e-6, estimates to 1e-4 - test_lm_matches_oracle, test_bench_scale_graphs_match_the_oracle).
 # chi2 itself keeps 1e-12.
 BLOCK_TOL = 1e-10
+#  only the RIGHT-HAND SIDES suffer that amplification: the Hessian blocks - products of Jacobians and weights, no residual in them - keep the old bar
+HESS_TOL = 1e-12
+HESS_BLOCKS = ("Hpp", "Hll", "Hpl_eb", "Hll_et", "Hlp1_et", "Hlp2_et", "Hpp_ep")
+
+
+def block_tol(name):
+    return HESS_TOL if name in HESS_BLOCKS else BLOCK_TOL
 
 
 def _scale(name, R):
@@ -61,7 +68,7 @@ def test_sweep_blocks_match_oracle(ctx, oracle, shape):
         a, b = getattr(S, name), getattr(R, name)
         if b.size == 0:
             continue
-        assert np.abs(a - b).max() <= BLOCK_TOL * _scale(name, R) + 1e-300, name
+        assert np.abs(a - b).max() <= block_tol(name) * _scale(name, R) + 1e-300, (name, np.abs(a - b).max() / max(_scale(name, R), 1e-300))
     assert abs(S.chi2 - R.chi2) <= 1e-12 * abs(R.chi2)
     assert abs(S.robust_chi2 - R.robust_chi2) <= 1e-12 * abs(R.robust_chi2)
     ba.close()
@@ -86,7 +93,7 @@ def test_general_edge_inputs_match_oracle(ctx, oracle):
         for name in BLOCKS:
             a, b = getattr(S, name), getattr(R, name)
             if b.size:
-                assert np.abs(a - b).max() <= BLOCK_TOL * _scale(name, R) + 1e-300, name
+                assert np.abs(a - b).max() <= block_tol(name) * _scale(name, R) + 1e-300, (name, np.abs(a - b).max() / max(_scale(name, R), 1e-300))
         assert abs(S.robust_chi2 - R.robust_chi2) <= 1e-12 * abs(R.robust_chi2)
         ba.close()
 
@@ -148,7 +155,7 @@ def test_bench_scale_graphs_match_the_oracle(ctx, oracle, shape, seed):
     for name in BLOCKS:
         a, b = getattr(S, name), getattr(R, name)
         if b.size:
-            assert np.abs(a - b).max() <= BLOCK_TOL * _scale(name, R) + 1e-300, name
+            assert np.abs(a - b).max() <= block_tol(name) * _scale(name, R) + 1e-300, (name, np.abs(a - b).max() / max(_scale(name, R), 1e-300))
     assert abs(S.robust_chi2 - R.robust_chi2) <= 1e-12 * abs(R.robust_chi2)
     gc, keep = K.graph_to_c(g)
     opt = K.LMOptionsC(5, 1e-4, 0, 0, 0.0, 0)
@@ -197,7 +204,7 @@ def test_wide_partial_rows_match_oracle(ctx, oracle, shape, mode, monkeypatch):
     for name in BLOCKS:
         a, b = getattr(S, name), getattr(R, name)
         if b.size:
-            assert np.abs(a - b).max() <= BLOCK_TOL * _scale(name, R) + 1e-300, name
+            assert np.abs(a - b).max() <= block_tol(name) * _scale(name, R) + 1e-300, (name, np.abs(a - b).max() / max(_scale(name, R), 1e-300))
     assert abs(S.chi2 - R.chi2) <= 1e-12 * abs(R.chi2) and abs(S.robust_chi2 - R.robust_chi2) <= 1e-12 * abs(R.robust_chi2)
     gc, keep = K.graph_to_c(g)
     opt = K.LMOptionsC(6, 1e-4, 0, 0, 0.0, 0)
@@ -235,7 +242,7 @@ def test_every_tile_size_gives_the_oracles_blocks_and_trajectory(ctx, oracle, ep
     for name in BLOCKS:
         a, b = getattr(S, name), getattr(R, name)
         if b.size:
-            assert np.abs(a - b).max() <= BLOCK_TOL * _scale(name, R) + 1e-300, name
+            assert np.abs(a - b).max() <= block_tol(name) * _scale(name, R) + 1e-300, (name, np.abs(a - b).max() / max(_scale(name, R), 1e-300))
     assert abs(S.chi2 - R.chi2) <= 1e-12 * abs(R.chi2) and abs(S.robust_chi2 - R.robust_chi2) <= 1e-12 * abs(R.robust_chi2)
     gc, keep = K.graph_to_c(g)
     opt = K.LMOptionsC(5, 1e-4, 0, 0, 0.0, 0)
@@ -270,7 +277,7 @@ def test_graph_without_binary_edges_linearises_like_the_oracle(ctx, oracle):
         for name in BLOCKS:
             a, b = getattr(S, name), getattr(R, name)
             if b.size:
-                assert np.abs(a - b).max() <= BLOCK_TOL * _scale(name, R) + 1e-300, name
+                assert np.abs(a - b).max() <= block_tol(name) * _scale(name, R) + 1e-300, (name, np.abs(a - b).max() / max(_scale(name, R), 1e-300))
         assert abs(S.chi2 - R.chi2) <= 1e-12 * abs(R.chi2) + 1e-300
         st = ba.optimize(max_iterations=2, gain_threshold=-1.0)      # (the solver's tile kernels on the same tiles: must run through; without observations the system is rank deficient - only that it returns is checked)
         assert st.iterations >= 1
@@ -458,7 +465,8 @@ def test_config4_sized_graph_blocks_match_the_oracle_and_properties(ctx, oracle,
     R = _oracle_system(oracle, g)
     for name in BLOCKS:
         a, b = getattr(S1, name), getattr(R, name)
-        assert b.size and np.abs(a - b).max() <= BLOCK_TOL * np.abs(b).max(), name
+        # (the maximum over 9.1 M Hll entries / 5.8 M edge blocks is a tail statistic: 1.07e-12 seen on Hll, where the small graphs above stay under 1e-12)
+        assert b.size and np.abs(a - b).max() <= 4 * block_tol(name) * np.abs(b).max(), (name, np.abs(a - b).max() / np.abs(b).max())
     # (the two scalars are sums of 5.8 M terms: the oracle adds them one after the other - up to n * eps = 6e-10 of rounding, 5e-12 seen -,
     #  the kernels in a tree; the blocks above are short sums and hold 1e-12)
     assert abs(S1.chi2 - R.chi2) <= 1e-10 * abs(R.chi2) and abs(S1.robust_chi2 - R.robust_chi2) <= 1e-10 * abs(R.robust_chi2)
@@ -568,7 +576,7 @@ def test_static_landmarks_seen_in_every_frame_of_a_kitti_length_sequence(ctx, or
     for name in BLOCKS:
         a, b = getattr(S, name), getattr(R_, name)
         if b.size:
-            assert np.abs(a - b).max() <= BLOCK_TOL * _scale(name, R_) + 1e-300, name
+            assert np.abs(a - b).max() <= block_tol(name) * _scale(name, R_) + 1e-300, (name, np.abs(a - b).max() / max(_scale(name, R_), 1e-300))
     assert abs(S.chi2 - R_.chi2) <= 1e-12 * abs(R_.chi2)
     st = ba.optimize(max_iterations=4, gain_threshold=-1.0)
     gc, keep = K.graph_to_c(g)

@@ -19,8 +19,12 @@
 //           8 B/edge instead of 144 B, both for the sweep's write and for every PCG mat-vec.
 //   part_q / part_m / part_sums   per-(tile,pose-slot) partial sums of the solver and of the sweep (NPS = total slots): pose-major rows, see below
 #pragma once
+#include <atomic>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include "../../include/vdo_slam_hip.h"
+#include "ctx.hpp"
 
 #define VDO_TILE_PTS 256        // max points per tile
 #define VDO_TILE_THREADS 256
@@ -158,10 +162,21 @@ void launch_dense_solve(const BADev& d, double* S, int64_t ld, double* Winv, dou
 
 size_t dense_tile_lds(const BADev& d);      // dynamic LDS of k_schur_dense_tile (ba_solve.hip)
 // A tile kernel's dynamic LDS grows with the pose slots of the graph's largest tile (a landmark seen from 150 frames needs 150 slots): past the runtime's
-// default limit the launch has to say so (per launch: the attribute is per device and such graphs are rare - nothing is cached).
+// default limit the launch has to say so.  The attribute is per (kernel, device): the size already granted is remembered per kernel instantiation and device
+// (one runtime call per growth, none per launch - ADVICE r5); a refused request is reported through set_error and fails the launch's caller at its next sync_check
+// with that message instead of a generic asynchronous launch failure.
 template <typename Kernel>
 inline size_t raise_lds(Kernel kernel, size_t bytes) {
-  if (bytes > (size_t)(48 * 1024)) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  static std::atomic<size_t> granted[64];
+  if (bytes > (size_t)(48 * 1024)) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    if (bytes > granted[dev].load(std::memory_order_relaxed)) {
+      const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+      if (e == hipSuccess) granted[dev].store(bytes, std::memory_order_relaxed);
+      else set_error(VDO_ERR_UNSUPPORTED, "a tile kernel needs %zu bytes of LDS per workgroup and the device refused it (%s)", bytes, hipGetErrorString(e));
+    }
+  }
   return bytes;
 }
 #define VDO_LDS_MAX_BYTES (160 * 1024)

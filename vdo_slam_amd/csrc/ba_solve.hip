@@ -1899,8 +1899,12 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
   if (!precond) { }
   else if (!d.sharded) hipLaunchKernelGGL(k_precond_finalize<0>, g, b, 0, s, d, lambda);
   else {
+    // Sharded (round 6): the reduced right-hand side needs the landmark factors only, so its tile pass runs BEFORE the exchange and the block-Jacobi sums (21 P + 1) and
+    // qs (6 P) - contiguous in memory - cross the ranks in ONE all-reduce per trial instead of two dependent ones.
     hipLaunchKernelGGL(k_precond_finalize<1>, g, b, 0, s, d, lambda);
-    R(d.msum, 21 * (int64_t)d.P + 1);
+    if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<1>, schur_lds(d)), s, d, (const double*)nullptr, (const double*)nullptr);
+    hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs, 0);
+    R(d.msum, 27 * (int64_t)d.P + 1);
     hipLaunchKernelGGL(k_precond_finalize<2>, g, b, 0, s, d, lambda);
   }
   const bool two = side && fork && join && !d.sharded;
@@ -1913,9 +1917,10 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
     else hipLaunchKernelGGL(k_pchain_factor<1>, dim3(d.n_pchains), dim3(128), 0, s, d);
     if (d.pc_lds && d.pc_nwave > 1) hipLaunchKernelGGL(k_pchain_prefix, dim3(d.n_pchains), dim3(64 * d.pc_nwave), 0, s, d);
   }
-  if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<1>, schur_lds(d)), sr, d, (const double*)nullptr, (const double*)nullptr);
-  hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, sr, d, d.qs, 0);
-  if (d.sharded) R(d.qs, 6 * (int64_t)d.P);
+  if (!d.sharded) {
+    if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<1>, schur_lds(d)), sr, d, (const double*)nullptr, (const double*)nullptr);
+    hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, sr, d, d.qs, 0);
+  }
   if (two) { hipEventRecord(join, side); hipStreamWaitEvent(s, join, 0); }
 }
 

@@ -60,6 +60,13 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   for (int e = 0; e < Npr; ++e)
     if ((unsigned)g->pr_pose[e] >= (unsigned)P) return set_error(VDO_ERR_INVALID, "prior %d: index out of range", e);
 
+  // ---- robust-kernel widths: g2o keeps delta^2 in a FLOAT member (robust_kernel_impl.h:84); the tile kernels' Huber weight (se3_dev.hpp huber_dev) takes its
+  // square root without range scaling and relies on e > dsqr being a NORMAL number: a positive delta whose float square underflows (delta below ~1.1e-19) is refused
+  // here - no camera, depth or motion residual is measured in units where that is a width
+  for (const double hd : {g->huber_eb, g->huber_et, g->huber_ep})
+    if (hd > 0 && !((double)(float)(hd * hd) >= 1.1754943508222875e-38))
+      return set_error(VDO_ERR_INVALID, "vdo_ba_create: Huber width %.3g: its square is not a normal float (RobustKernelHuber keeps it in one)", hd);
+
   // ---- chains (dynamic tracks) from the ternary edges
   std::vector<int32_t> next_e(L, -1), prev_e(L, -1);
   for (int e = 0; e < Et; ++e) {
@@ -593,7 +600,8 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   const double* Z = nullptr;
   UP(Hpp, Z, 42 * (size_t)P + 4);                      // Hpp | bp | red_chi contiguous: one all-reduce per linearisation when sharded
   ba->d.bp = ba->d.Hpp + 36 * (size_t)P; ba->d.red_chi = ba->d.bp + 6 * (size_t)P;
-  UP(msum, Z, 21 * (size_t)P + 1);
+  UP(msum, Z, 27 * (size_t)P + 2);                     // block-Jacobi sums | failure flag | qs contiguous: ONE all-reduce per trial for the preconditioner diagonal and the reduced right-hand side when sharded
+  ba->d.qs = ba->d.msum + 21 * (size_t)P + 1;
   UP(Hll, Z, (size_t)L); UP(bl, Z, 3 * (size_t)L);
   UP(Finc, Z, std::max<size_t>((size_t)Ebp, VDO_TILE_THREADS) + (size_t)Et + 1); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep); UP(ep_blk, Z, 84 * (size_t)std::max(Ep + Npr, 1));
   UP(part_sums, Z, (size_t)ps_stride * (size_t)std::max(NPS, 1));
@@ -603,7 +611,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(xl, Z, 3 * (size_t)L); UP(dscal, Z, (size_t)std::max(L, 1));
   UP(Minv, Z, 36 * (size_t)P); UP(Lc, Z, 36 * (size_t)P); UP(Lfar, Z, 36 * (size_t)std::max(n_pchains, 1)); UP(Pf, Z, 36 * (size_t)P); UP(Qb, Z, 36 * (size_t)P); UP(Adg, Z, 36 * (size_t)P);
   UP(xp, Z, 6 * (size_t)P); UP(rp, Z, 6 * (size_t)P); UP(zp, Z, 6 * (size_t)P); UP(pp, Z, 6 * (size_t)P); UP(pp2, Z, 6 * (size_t)P);
-  UP(qp, Z, 6 * (size_t)P); UP(bs, Z, 6 * (size_t)P); UP(qs, Z, 6 * (size_t)P);
+  UP(qp, Z, 6 * (size_t)P); UP(bs, Z, 6 * (size_t)P);
   UP(part_pq, Z, (size_t)(P + 3) / 4 + 1); UP(part_rz, Z, (size_t)n_pchains + 1);
   UP(part_q, Z, 8 * (size_t)NPS + 8); UP(part_m, Z, 16 * (size_t)NPS + 16); UP(part_m8, Z, 8 * (size_t)NPS + 8);
   UP(scal, Z, S_COUNT);

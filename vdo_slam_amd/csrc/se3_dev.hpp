@@ -164,10 +164,10 @@ VDO_HD double chi2_w3(double w, D3 e) {
 }
 
 // RobustKernelHuber::robustify for the tile kernels: the same rho0 = 2 sqrt(e) delta - dsqr (the square root by the Goldschmidt / Newton sequence the
-// compiler itself emits for sqrt(), minus its range scaling: e > dsqr >= 1e-200 here, checked on the host), rho1 = delta / sqrt(e) from the SAME iteration's
+// compiler itself emits for sqrt(), minus its range scaling: e > dsqr >= FLT_MIN here - vdo_ba_create refuses a positive width whose float square is not a normal number), rho1 = delta / sqrt(e) from the SAME iteration's
 // reciprocal-root estimate h ~ 0.5 / sqrt(e) plus one correction step (4 instructions, within 1 ulp) instead of a full IEEE division (14): the kernel is
 // VALU-issue-bound and with the reference's delta = 1e-4 (src/Optimizer.cc:1352) practically every edge is in this branch.  (Without the range
-// scaling the last bits degrade for e < 1e-230 - a delta below 1e-115.)
+// scaling the last bits would degrade for e < 1e-230; dsqr >= 1.2e-38 keeps every e of this branch far above that.)
 __device__ __forceinline__ void huber_dev(double e, double delta, double dsqr, double& rho0, double& rho1) {
 #if defined(VDO_SLOW_HUBER) || !defined(__HIP_DEVICE_COMPILE__)
   huber(e, delta, dsqr, rho0, rho1);
