@@ -158,6 +158,7 @@ void launch_expand_binc(const BADev& d, hipStream_t s);            // Finc -> ex
 void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R);   // explicit reduced-camera matrix
 void launch_dense_rhs(const BADev& d, double* rhs, int64_t ld, hipStream_t s);
 // ---- ba_dense.hip
+void launch_publish_scalars(const BADev& d, double* h_block_dev, hipStream_t s);      // ba_solve.hip
 void launch_dense_solve(const BADev& d, double* S, int64_t ld, double* Winv, double* rhs, hipStream_t s);    // MFMA Cholesky + substitutions -> xp
 
 size_t dense_tile_lds(const BADev& d);      // dynamic LDS of k_schur_dense_tile (ba_solve.hip)

@@ -12,8 +12,9 @@ struct vdo_ba {
   std::vector<void*> allocs;
   vdo::Reducer red;               // cross-rank sum/max hook (vdo_ba_set_allreduce); unset = single GPU
   int oplus_calls = 0;            // VertexSE3::_numOplusCalls (same value on every vertex)
-  double* h_scal = nullptr;       // pinned
-  int32_t* h_flags = nullptr;     // pinned
+  double* h_scal = nullptr;       // pinned, device-mapped: [S_COUNT doubles][4 int32 flags] in ONE block; a one-workgroup kernel publishes the device scalars and
+  int32_t* h_flags = nullptr;     // flags into it (ba_lm.hip fetch: two D2H copies of 13 us each on the stream before round 6); h_flags points behind the scalars
+  double* d_hscal = nullptr;      // the device-side address of that block
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   hipStream_t side = nullptr;     // second stream of a solve: the reduced right-hand side beside the pose-chain factorisation (ba_solve.hip)
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;

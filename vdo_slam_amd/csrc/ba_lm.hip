@@ -26,11 +26,10 @@ double now_ms() {
 
 namespace {
 
-// read back device scalars + flags (one sync)
+// read back device scalars + flags (one sync): a one-wave kernel writes them into the mapped pinned block - the two D2H copies this replaces were 13 us
+// of blit kernel each, 2-3 times per LM iteration (profiles/r05_ba_large_kernel_stats.txt: __amd_rocclr_copyBuffer 6 % of the stream)
 int fetch(vdo_ba* ba) {
-  hipStream_t s = ba->ctx->stream;
-  hipMemcpyAsync(ba->h_scal, ba->d.scal, sizeof(double) * S_COUNT, hipMemcpyDeviceToHost, s);
-  hipMemcpyAsync(ba->h_flags, ba->d.flags, sizeof(int32_t) * 4, hipMemcpyDeviceToHost, s);
+  launch_publish_scalars(ba->d, ba->d_hscal, ba->ctx->stream);
   return sync_check(ba, "LM scalar readback");
 }
 

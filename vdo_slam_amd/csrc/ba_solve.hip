@@ -1958,6 +1958,17 @@ void launch_schur_matvec_only(const BADev& d, hipStream_t s) {
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<0>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<0>, schur_lds(d)), s, d, (const double*)d.zp, (const double*)d.pp);
 }
 
+// the LM scalars and flags -> the handle's mapped pinned block [S_COUNT doubles][4 int32] (visible to the host once the stream has been waited for)
+__global__ __launch_bounds__(64) void k_publish_scalars(const double* __restrict__ scal, const int32_t* __restrict__ flags, double* __restrict__ h_block) {
+  const int t = threadIdx.x;
+  if (t < S_COUNT) h_block[t] = scal[t];
+  if (t < 4) ((int32_t*)(h_block + S_COUNT))[t] = flags[t];
+}
+void launch_publish_scalars(const BADev& d, double* h_block_dev, hipStream_t s) {
+  static_assert(S_COUNT <= 64, "one wave publishes the scalars");
+  hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, s, (const double*)d.scal, (const int32_t*)d.flags, h_block_dev);
+}
+
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s) {
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<2>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<2>, schur_lds(d)), s, d, (const double*)d.xp, (const double*)nullptr);
   const int nb = red_blocks(d);

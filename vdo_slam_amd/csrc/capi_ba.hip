@@ -617,10 +617,16 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(scal, Z, S_COUNT);
   const int32_t* ZI = nullptr;
   UP(flags, ZI, 4);
-  if (hipHostMalloc((void**)&ba->h_scal, S_COUNT * sizeof(double)) != hipSuccess ||
-      hipHostMalloc((void**)&ba->h_flags, 4 * sizeof(int32_t)) != hipSuccess) {
-    vdo_ba_destroy(ba);
-    return set_error(VDO_ERR_OOM, "hipHostMalloc failed");
+  {
+    void* dp = nullptr;
+    if (hipHostMalloc((void**)&ba->h_scal, S_COUNT * sizeof(double) + 4 * sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
+        hipHostGetDevicePointer(&dp, ba->h_scal, 0) != hipSuccess || !dp) {
+      vdo_ba_destroy(ba);
+      return set_error(VDO_ERR_OOM, "hipHostMalloc failed");
+    }
+    std::memset(ba->h_scal, 0, S_COUNT * sizeof(double) + 4 * sizeof(int32_t));
+    ba->h_flags = (int32_t*)(ba->h_scal + S_COUNT);
+    ba->d_hscal = (double*)dp;
   }
   hipEventCreate(&ba->ev0); hipEventCreate(&ba->ev1);
   if (!std::getenv("VDO_BA_ONE_STREAM") && hipStreamCreateWithFlags(&ba->side, hipStreamNonBlocking) == hipSuccess) {
@@ -635,8 +641,7 @@ extern "C" int vdo_ba_destroy(vdo_ba* ba) {
   if (!ba) return VDO_OK;
   if (ba->ctx) ctx_bind(ba->ctx);
   for (void* p : ba->allocs) hipFree(p);
-  if (ba->h_scal) hipHostFree(ba->h_scal);
-  if (ba->h_flags) hipHostFree(ba->h_flags);
+  if (ba->h_scal) hipHostFree(ba->h_scal);      // (h_flags lives in the same block)
   if (ba->ev0) hipEventDestroy(ba->ev0);
   if (ba->ev1) hipEventDestroy(ba->ev1);
   if (ba->ev_fork) hipEventDestroy(ba->ev_fork);
