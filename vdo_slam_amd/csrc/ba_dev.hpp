@@ -144,13 +144,14 @@ enum Scal { S_CHI2 = 0, S_RCHI2, S_MAXDIAG, S_RZ, S_PQ, S_RZ0, S_SCALE, S_RZNEW,
 // ---- ba_sweep.hip
 void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R);      // chi2 of estimate[which] -> scal
 void launch_schur_matvec_only(const BADev& d, hipStream_t s);                     // k_schur_tile<0> alone (vdo_ba_profile_schur)
-void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R);              // build system at estimate[0] (+chi2)
+void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R, bool defer_exchange = false);      // build system at estimate[0] (+chi2)
+void launch_linearize_finish(const BADev& d, hipStream_t s);                                               // the chi2 of a linearisation whose exchange was deferred
 void launch_sweep_only(const BADev& d, hipStream_t s);             // just the K18 tile sweep kernel (bench)
 // ---- ba_solve.hip
 void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R);
 // landmark-chain LDL^T + inverse blocks + block-Jacobi + pose-chain factorisation, and the reduced right-hand side qs (beside it on `side` if given)
 void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const Reducer& R, hipStream_t side, hipEvent_t fork, hipEvent_t join,
-                           bool precond = true);   // precond = false: without the PCG's preconditioner (block-Jacobi sums, pose-chain factorisation) - the dense solver's trials
+                           bool precond = true, bool lin_pending = false);   // precond = false: without the PCG's preconditioner (block-Jacobi sums, pose-chain factorisation) - the dense solver's trials
 void launch_pcg_init(const BADev& d, hipStream_t s);
 void launch_pcg_iter(const BADev& d, double lambda, double tol2, int parity, hipStream_t s, const Reducer& R);   // parity: 0, 1, 0, ... from the first iteration after launch_pcg_init
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s);

@@ -76,7 +76,8 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
   // (dense_tiles_ok: the dense assembly's workgroup fits - padded incidences per thread, LDS at the graph's largest tile; capi_ba.hip)
   if (dense && !ba->dense_tiles_ok) return set_error(VDO_ERR_UNSUPPORTED, "dense solver: a tile of this graph does not fit the dense assembly (more than %d pose slots of LDS); use the PCG solver", 200);
   if (dense && !small && opt->solver == 3) return set_error(VDO_ERR_UNSUPPORTED, "dense solver: %lld unknowns exceed %lld", 6LL * d.P, (long long)kDenseMaxUnknowns);
-  launch_factor_and_rhs(d, lambda, s, ba->red, ba->side, ba->ev_fork, ba->ev_join, !dense);
+  launch_factor_and_rhs(d, lambda, s, ba->red, ba->side, ba->ev_fork, ba->ev_join, !dense, ba->lin_exchange_pending);
+  ba->lin_exchange_pending = false;
   if (dense) {
     int rc = dense_prepare(ba);
     if (rc != VDO_OK) return rc;
@@ -143,6 +144,7 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
   if (!st) st = &local;
   std::memset(st, 0, sizeof(*st));
   ba->lin_current = false;        // (the accepted steps move estimate[0] away from the last linearisation)
+  ba->lin_exchange_pending = false;
   ba->pcg_last = 0;
   BADev& d = ba->d;
   hipStream_t s = ba->ctx->stream;
@@ -159,7 +161,12 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
   int it = 0;
   for (; it < opt->max_iterations && !forceStop && ok; ++it) {
     double t0 = now_ms();
-    launch_linearize(d, s, ba->red);                 // errors + buildSystem in one sweep (same estimate); its chi2 stays in S_LIN_RCHI2
+    static const bool sync_each = std::getenv("VDO_BA_LM_SYNC_EACH") != nullptr;      // (A/B: a host round trip after the linearisation and after the PCG batch, as before)
+    // sharded, lambda known (every iteration but the first): the linearisation's all-reduce is left to the first trial's, which follows at once (one exchange instead of two)
+    static const bool merge_off = std::getenv("VDO_BA_NO_EXCHANGE_MERGE") != nullptr;    // (A/B switch)
+    const bool defer = d.sharded && it > 0 && !sync_each && !merge_off;
+    launch_linearize(d, s, ba->red, defer);          // errors + buildSystem in one sweep (same estimate); its chi2 stays in S_LIN_RCHI2
+    ba->lin_exchange_pending = defer;
     // The chi2 of the linearisation is first NEEDED when the first trial is judged: it is read back with that trial's scalars (one host round
     // trip less per iteration).  Only the first iteration needs something before its first trial: the largest diagonal entry (lambda).
     bool have_lin = false;
@@ -171,7 +178,6 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
       last_err_chi = currentChi = tempChi = iniChi = ba->h_scal[S_LIN_RCHI2];
       have_lin = true;
     }
-    static const bool sync_each = std::getenv("VDO_BA_LM_SYNC_EACH") != nullptr;      // (A/B: a host round trip after the linearisation and after the PCG batch, as before)
     if (sync_each && !have_lin) { CK(fetch(ba)); last_err_chi = currentChi = tempChi = iniChi = ba->h_scal[S_LIN_RCHI2]; have_lin = true; }
     st->ms_linearize += now_ms() - t0;
     double rho = 0;

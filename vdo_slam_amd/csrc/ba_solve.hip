@@ -1885,7 +1885,7 @@ void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R) {
 // factorisation is a recurrence over the chain (a few workgroups, 0.7 us per step): on one GPU the reduced right-hand side (k_schur_tile<1>,
 // k_gather_q: every CU) runs beside it on the stream `side`, forked / joined with the two events.  Sharded solves keep one stream: the
 // exchanges of the all-reduce hook are ordered on it.
-void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const Reducer& R, hipStream_t side, hipEvent_t fork, hipEvent_t join, bool precond) {
+void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const Reducer& R, hipStream_t side, hipEvent_t fork, hipEvent_t join, bool precond, bool lin_pending) {
   hipMemsetAsync(d.flags, 0, 4 * sizeof(int32_t), s);
   if (d.n_chains) hipLaunchKernelGGL(k_factor_chains, dim3((d.n_chains + 127) / 128), dim3(128), 0, s, d, lambda);
   precond = precond || d.sharded;          // (the dense solver needs the landmark factors and the reduced right-hand side only; a sharded run keeps its exchanges as they are)
@@ -1904,7 +1904,10 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
     hipLaunchKernelGGL(k_precond_finalize<1>, g, b, 0, s, d, lambda);
     if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<1>, schur_lds(d)), s, d, (const double*)nullptr, (const double*)nullptr);
     hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs, 0);
-    R(d.msum, 27 * (int64_t)d.P + 1);
+    // lin_pending: the linearisation in front of this trial left its exchange to us - Hpp | bp | chi2 (42 P + 4) lie right in front of msum | qs: one all-reduce of
+    // 69 P + 5 doubles for the first trial of an LM iteration instead of two dependent ones
+    if (lin_pending) { R(d.Hpp, 69 * (int64_t)d.P + 5); launch_linearize_finish(d, s); }
+    else R(d.msum, 27 * (int64_t)d.P + 1);
     hipLaunchKernelGGL(k_precond_finalize<2>, g, b, 0, s, d, lambda);
   }
   const bool two = side && fork && join && !d.sharded;

@@ -528,6 +528,9 @@ void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R) {
   hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, which == 1 ? 3 : 2);
 }
 
+// the chi2 of a linearisation whose exchange was deferred (launch_linearize), behind that exchange
+void launch_linearize_finish(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 2 + 8); }
+
 void launch_sweep_only(const BADev& d, hipStream_t s) {
   const size_t lds = sweep_lds_doubles(d.max_slots, true, d.ps_stride) * sizeof(double);
   if (!d.n_tiles) return;
@@ -535,7 +538,9 @@ void launch_sweep_only(const BADev& d, hipStream_t s) {
   else hipLaunchKernelGGL((k_sweep_tile<true, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<true, false>, lds), s, d, 0);
 }
 
-void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R) {
+// defer_exchange (sharded solves): leave the partial Hpp | bp | chi2 of this rank where they are - the caller's launch_factor_and_rhs, which follows at once, sends them
+// with the block-Jacobi sums and the reduced right-hand side in ONE all-reduce (its tile passes read nothing of the pose blocks) and finishes the chi2 behind it.
+void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R, bool defer_exchange) {
   launch_posepose(d, 0, true, ep_chi_buf(d), s);           // per-edge blocks -> ep_blk (independent of the sweep)
   launch_sweep_only(d, s);
   // pose blocks = landmark-side sums + pose-pose blocks.  Shards: the (replicated) pose-pose terms are added by rank 0 only, the
@@ -544,6 +549,7 @@ void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R) {
   const int nb = d.P;                                      // one workgroup per pose
   if (!d.sharded) { hipLaunchKernelGGL(k_finalize_pose, dim3(nb + 1), dim3(VDO_FIN_THREADS), 0, s, d, add_pp, 8); return; }   // (+ the chi2 reduction in the last workgroup)
   hipLaunchKernelGGL(k_finalize_pose, dim3(nb + 1), dim3(VDO_FIN_THREADS), 0, s, d, add_pp, 1);
+  if (defer_exchange) return;
   R(d.Hpp, 42 * (int64_t)d.P + 2);
   hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 2 + 8);
 }

@@ -598,9 +598,12 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(pc_off, pc_off.data(), pc_off.size()); UP(pc_pose, pc_pose.data(), P); UP(pc_edge, pc_edge.data(), P);
   UP(pc_far_pos, pc_far_pos.data(), pc_far_pos.size()); UP(pc_far_edge, pc_far_edge.data(), pc_far_edge.size());
   const double* Z = nullptr;
-  UP(Hpp, Z, 42 * (size_t)P + 4);                      // Hpp | bp | red_chi contiguous: one all-reduce per linearisation when sharded
+  // ONE block: Hpp | bp | red_chi [4] | block-Jacobi sums msum [21 P] | failure flag | qs [6 P].  Sharded solves send Hpp .. red_chi[1] per linearisation, msum .. qs per trial -
+  // and the whole block at once for the first trial of an LM iteration (launch_linearize(defer_exchange) + launch_factor_and_rhs(lin_pending): red_chi[2..3], the scale partial
+  // of the last update, ride along; k_update rewrites them before they are read again)
+  UP(Hpp, Z, 69 * (size_t)P + 6);
   ba->d.bp = ba->d.Hpp + 36 * (size_t)P; ba->d.red_chi = ba->d.bp + 6 * (size_t)P;
-  UP(msum, Z, 27 * (size_t)P + 2);                     // block-Jacobi sums | failure flag | qs contiguous: ONE all-reduce per trial for the preconditioner diagonal and the reduced right-hand side when sharded
+  ba->d.msum = ba->d.red_chi + 4;
   ba->d.qs = ba->d.msum + 21 * (size_t)P + 1;
   UP(Hll, Z, (size_t)L); UP(bl, Z, 3 * (size_t)L);
   UP(Finc, Z, std::max<size_t>((size_t)Ebp, VDO_TILE_THREADS) + (size_t)Et + 1); UP(Oll, Z, 9 * (size_t)Et); UP(Hpp_ep, Z, 36 * (size_t)Ep); UP(ep_blk, Z, 84 * (size_t)std::max(Ep + Npr, 1));
