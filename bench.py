@@ -315,6 +315,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch", action="store_true", help="skip the batch-BA / roofline legs")
     ap.add_argument("--no-host-inputs", action="store_true", help="skip the System::TrackRGBD (host buffers in) leg")
+    ap.add_argument("--no-windowed-ba", action="store_true", help="skip the value_with_windowed_ba leg (the KITTI-0000-length run with PartialBatchOptimization inside the timed frames)")
     ap.add_argument("--replicas-per-gpu", type=int, default=1, help="R independent sequences (FramePipelines) on every GPU; value = all of them")
     ap.add_argument("--replica-sweep", type=str, default="", help="e.g. 1,2,4,8: also report frames/s for these numbers of sequences per GPU")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not run the two rocprofv3 --pmc passes of the roofline leg (the committed counter file, then the byte model, take over)")
@@ -409,7 +410,7 @@ def main():
 
     class Replica:
         """One sequence on this GPU: a FramePipeline with its own HIP streams (4 contexts), host helper thread and Map."""
-        def __init__(self, cpus_here, first=False, dev_frames=None):
+        def __init__(self, cpus_here, first=False, dev_frames=None, window=(0, 0), with_map=False):
             self.dev = dev if dev_frames is None else dev_frames
             # host threads per replica: main + 1 helper of FramePipeline (polls) + the quadtree helpers of ORB (sleep when idle);
             # with fewer than ~5 CPUs per replica the helpers would only steal time from each other
@@ -422,8 +423,10 @@ def main():
             # + ORB of the frame on a third host thread (its own context / stream) when there are CPUs for it
             self.ctx_orb = Context(local) if (self.ctx_w is not None and not os.environ.get("VDO_BENCH_NO_ORB_THREAD") and cpus_here >= 6) else None
             self.pipe = FramePipeline(self.ctx, self.ctx_lm, kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ,
-                                                                         build_lm=1, defer_objects=defer_now()), self.ctx_obj, self.ctx_w, self.ctx_orb)
-            if not os.environ.get("VDO_BENCH_NO_MAP"):
+                                                                         build_lm=1, defer_objects=defer_now(), window_size=window[0], overlap_size=window[1]), self.ctx_obj, self.ctx_w, self.ctx_orb)
+            if with_map:
+                self.pipe.attach_map()                            # (the untimed window-sample pass: the Map is what tests/map_builder_ref.py turns into the oracle's graph)
+            elif not os.environ.get("VDO_BENCH_NO_MAP"):
                 self.pipe.keep_graph()                            # "Save Graph Structure" (Tracking.cc:1031-1159): every frame is appended to the flat GraphStore the batch optimisers read
             self.agg = {q: 0 for q in AGG}
             self.step_ms = []
@@ -459,12 +462,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def run_sequences(R, dev_frames=None, warmup=None, steps=None):
+    def run_sequences(R, dev_frames=None, warmup=None, steps=None, window=(0, 0), with_map=False):
         """R independent sequences on this GPU (own pipelines, streams, host threads), each through warm-up + the timed steps;
         returns (seconds for the timed steps - max over ranks, replicas)."""
         warmup = args.warmup if warmup is None else warmup
         steps = args.steps if steps is None else steps
-        reps = [Replica(cpus / R, first=(k == 0), dev_frames=dev_frames) for k in range(R)]
+        reps = [Replica(cpus / R, first=(k == 0), dev_frames=dev_frames, window=window, with_map=with_map) for k in range(R)]
         torch.cuda.synchronize()
 
         def all_run(i0, n, timed):
@@ -548,7 +551,8 @@ def main():
         "ms_per_step": dt * 1e3 / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64 (LM, RANSAC) / u8,i32,f32 (front-end, tracking)", "data": "synthetic",
         "config": {"workload": "KITTI-0000-shaped TrackRGBD per frame = the per-frame path of Track() (C++ FramePipeline over the C-ABI, incl. \"Save Graph Structure\": every frame appended to the GraphStore of the batch optimisers; "
-                               "the windowed PartialBatchOptimization Track() fires every 16 frames, src/Tracking.cc:1168-1181, is NOT inside the timed frames on either side - it is reported separately as ms_per_lm_iter*): K15 UpdateMask, K1 depth, K11 propagation, "
+                               "the windowed PartialBatchOptimization Track() fires every 16 frames, src/Tracking.cc:1168-1181, is NOT inside the timed frames of `value` / `value_full_sequence` on either side - "
+                               "it is timed inside the frames under its own key, `value_with_windowed_ba` (+ cpu_baseline.with_windowed_ba), and per iteration as ms_per_lm_iter*): K15 UpdateMask, K1 depth, K11 propagation, "
                                "RANSAC (AP3P) + EPnP + motion-model initialisers, ORB 2500 feats/8 levels (pyramid, FAST, quadtree, angle, blur), K9 static filter, K10 object sampling, "
                                "joint pose+flow LM for the camera (<=1200 matches) and every tracked object (ref_quirks=1) built from the frame's own correspondences, "
                                "K13 scene flow + DynObjTracking, K14/K12 RenewFrameInfo (static 1200, objects 800 each), tracklets, graph store; "
@@ -598,6 +602,7 @@ def main():
     out.update(out_parity)
     # ---- the KITTI-0000-length run (5 warm-up + 148 timed frames of the 153-frame sequence, SURVEY's event frames), whatever --steps the caller passed: the same
     # Step with the reference's return semantics (everything of a frame done when its call returns); the driver's `value` window is shorter and carries no capped object LM
+    window_map = None
     if frames_full is not None and R == 1 and not os.environ.get("VDO_BENCH_SYNC_OBJECTS"):
         dev_full = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames_full]
         defer_saved = defer
@@ -615,7 +620,38 @@ def main():
                                                 f"{float(np.abs(Tf[:3, 3] - gt_full[:3, 3]).max()):.3f} m; this is the sequence `parity_full_sequence` compares with the reference")
         for r in rs_full:
             r.close()
-        del dev_full, rs_full
+        del rs_full
+        # ---- the same run with the windowed optimisation Track() contains INSIDE the timed frames (src/Tracking.cc:1165-1183: PartialBatchOptimization over the last
+        # WINDOW_SIZE = 20 frames every 16 frames, example/kitti-0000-0013.yaml): a key of its own, never `value`
+        if not args.no_windowed_ba:
+            defer = 0
+            dt_w, rs_w = run_sequences(1, dev_full, FULL_WARMUP, steps_full, window=(20, 4))
+            n_pb = rs_w[0].pipe.partial_batches()
+            sm_w = rs_w[0].step_ms
+            out["value_with_windowed_ba"] = world * steps_full / dt_w
+            out["config"]["value_with_windowed_ba"] = (f"value_full_sequence's run with window 20 / overlap 4: {n_pb} PartialBatchOptimization calls (C++ graph builder from the GraphStore, "
+                                                       f"Levenberg on the GPU, at most 100 iterations, gain 1e-3) inside the {steps_full} timed frames + warm-up; step ms p50 / p90 / max "
+                                                       f"{np.percentile(sm_w, 50):.3f} / {np.percentile(sm_w, 90):.3f} / {max(sm_w):.3f}")
+            out["config"]["windowed_ba_calls"] = int(n_pb)
+            for r in rs_w:
+                r.close()
+            del rs_w
+            # the CPU side needs a window of THIS sequence as a graph: the SECOND window (frames 16 .. 35: like every window but the first it has no gauge prior,
+            # src/Optimizer.cc:227-236, and takes ~27 Levenberg iterations where the first takes 2) through an untimed pass with a Map attached, exported and turned
+            # into the graph the reference's builder makes of it (tests/map_builder_ref.py: test-side code, used by the cpu_baseline leg only)
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                try:
+                    _, rs_m = run_sequences(1, dev_full, 0, 36, with_map=True)
+                    rs_m[0].pipe.finalize_map()
+                    window_map = rs_m[0].pipe.export_map(synth.KITTI_K)
+                    for r in rs_m:
+                        r.close()
+                    del rs_m
+                except Exception as e:                            # noqa: BLE001 - the product's number above stays valid
+                    window_map = None
+                    out["config"]["windowed_ba_cpu_sample_error"] = repr(e)[:200]
+            defer = defer_saved
+        del dev_full
     elif frames_full is None and args.steps + args.warmup == KITTI0000_FRAMES and "value_sync" in out:
         out["value_full_sequence"] = out["value"]
         out["config"]["value_full_sequence"] = "= value: this run IS the KITTI-0000-length run"
@@ -863,6 +899,29 @@ def main():
             cfps_f, cn_f, _, _, _ = cpu_baseline_frames(frames_full, budget_s=12.0)
             out["cpu_baseline"]["full_sequence"] = {"value": cfps_f, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"the first {cn_f} frames of the {KITTI0000_FRAMES}-frame sequence (oracle, 1 thread)"}
             out["speedup_vs_cpu_baseline"]["value_full_sequence"] = out["value_full_sequence"] / cfps_f
+            if window_map is not None and "value_with_windowed_ba" in out:
+                # the CPU path with the same windows: the oracle's Levenberg (1 thread, sparse Cholesky) on the first window of this sequence, once; every window has that shape
+                try:
+                    from tests import map_builder_ref as SM
+                    from tests import oracle_lib
+                    from vdo_slam_amd import _capi as K
+                    gw, _info = SM.map_to_graph(window_map, partial_window=20)
+                    gcw, keepw = K.graph_to_c(gw)
+                    optw = K.LMOptionsC(100, 1e-3, 0, 0, 0.0, 0)
+                    stw = K.LMStatsC()
+                    pw = np.zeros_like(gw.pose); qw = np.zeros_like(gw.point)
+                    t0w = time.perf_counter()
+                    oracle_lib.load().vdo_oracle_ba_optimize(C.byref(gcw), C.byref(optw), K._dp(pw), K._dp(qw), C.byref(stw))
+                    t_win = time.perf_counter() - t0w
+                    n_pb = out["config"]["windowed_ba_calls"]
+                    cfps_w = KITTI0000_FRAMES / (KITTI0000_FRAMES / cfps_f + n_pb * t_win)
+                    out["cpu_baseline"]["with_windowed_ba"] = {"value": cfps_w, "unit": "frames/s", "cores": 1, "kind": "port",
+                                                               "sample": (f"full_sequence's frame rate + {n_pb} windows at the cost of ONE measured here: the oracle's Levenberg on the second window (frames 16 .. 35, no "
+                                                                          f"windowed refinement before it) of this sequence ({gw.n_pose} poses, {gw.n_point} points, {gw.n_eb} + {gw.n_ep} edges; {stw.iterations} iterations, "
+                                                                          f"{t_win * 1e3:.0f} ms; the first window - the only one with a gauge prior - stops after 2)")}
+                    out["speedup_vs_cpu_baseline"]["value_with_windowed_ba"] = out["value_with_windowed_ba"] / cfps_w
+                except Exception as e:                            # noqa: BLE001
+                    out["cpu_baseline"]["with_windowed_ba_error"] = repr(e)[:200]
         elif "value_full_sequence" in out:
             out["speedup_vs_cpu_baseline"]["value_full_sequence"] = out["value_full_sequence"] / cfps
         # ---- the reference's own five clock() brackets (all_timing[0..4]: mask update, camera estimate, object tracking, object estimate per object,

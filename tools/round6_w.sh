@@ -1,0 +1,11 @@
+#!/bin/bash
+O=gpurun_out/r06w; mkdir -p $O
+timeout 1200 python -m pytest tests/test_windowed_ba_gpu.py tests/test_track_to_batch_gpu.py tests/test_host_classes_gpu.py tests/test_ba_gpu.py tests/test_g2o_replay_gpu.py tests/test_edge_cases_gpu.py tests/test_omd_gpu.py tests/test_dist.py tests/test_dense_check_gpu.py -q -x 2>&1 | tail -4 | tee $O/tests.log
+VDO_BATCH_TRACE=1 timeout 1200 python bench.py --steps 20 --warmup 5 --no-batch --no-host-inputs --no-parity > $O/bench.json 2> $O/bench.err
+grep "batch\]" $O/bench.err | head -8
+python - <<PY
+import json
+d=json.loads(open("$O/bench.json").read().strip().splitlines()[-1])
+for k in ("value","value_full_sequence","value_with_windowed_ba"): print(k, d.get(k))
+print(d["speedup_vs_cpu_baseline"])
+PY

@@ -10,6 +10,7 @@ struct vdo_ba {
   vdo_ctx* ctx = nullptr;
   vdo::BADev d;
   std::vector<void*> allocs;
+  bool pooled = false;            // device arrays (as far as they fit), pinned block, side stream and events belong to the context's pool (ctx.hpp), not to this handle
   vdo::Reducer red;               // cross-rank sum/max hook (vdo_ba_set_allreduce); unset = single GPU
   int oplus_calls = 0;            // VertexSE3::_numOplusCalls (same value on every vertex)
   double* h_scal = nullptr;       // pinned, device-mapped: [S_COUNT doubles][4 int32 flags] in ONE block; a one-workgroup kernel publishes the device scalars and
@@ -39,6 +40,7 @@ struct vdo_ba {
 };
 
 namespace vdo {
+void* ba_device_alloc(vdo_ba* ba, size_t bytes);      // capi_ba.hip: from the context's slab (pooled handles) or hipMalloc; released by vdo_ba_destroy
 inline int sync_check(vdo_ba* ba, const char* what) {
   hipError_t e = hipStreamSynchronize(ba->ctx->stream);
   if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "%s: %s", what, hipGetErrorString(e));

@@ -42,21 +42,18 @@ int robust_chi2(vdo_ba* ba, int which, double* out) {
   return VDO_OK;
 }
 
+constexpr int kPcgSlowTiny = 12;                 // ... on a reduced system of at most kDenseTinyUnknowns unknowns
+constexpr int64_t kDenseTinyUnknowns = 384;
 constexpr int kPcgSlow = 60;                     // PCG iterations per solve above which auto mode switches to the dense solver
 constexpr int64_t kDenseMaxUnknowns = 8192;     // 6P above this: S no longer "small" (512 MB at 8192) - PCG only
 
 int dense_prepare(vdo_ba* ba) {
   if (ba->dense_S) return VDO_OK;
   const int64_t ld = (6 * (int64_t)ba->d.P + 63) / 64 * 64;
-  void *pS = nullptr, *pW = nullptr, *pr = nullptr;
-  if (hipMalloc(&pS, sizeof(double) * (size_t)ld * (size_t)ld) != hipSuccess || hipMalloc(&pW, sizeof(double) * (size_t)ld * 64) != hipSuccess ||
-      hipMalloc(&pr, sizeof(double) * 2 * (size_t)ld) != hipSuccess) {
-    if (pS) hipFree(pS);
-    if (pW) hipFree(pW);
+  void *pS = ba_device_alloc(ba, sizeof(double) * (size_t)ld * (size_t)ld), *pW = ba_device_alloc(ba, sizeof(double) * (size_t)ld * 64), *pr = ba_device_alloc(ba, sizeof(double) * 2 * (size_t)ld);
+  if (!pS || !pW || !pr)      // (whatever was allocated is released with the handle)
     return set_error(VDO_ERR_OOM, "dense reduced-camera solver: hipMalloc(%lld x %lld doubles) failed", (long long)ld, (long long)ld);
-  }
   ba->dense_S = (double*)pS; ba->dense_W = (double*)pW; ba->dense_rhs = (double*)pr; ba->dense_ld = ld;
-  ba->allocs.push_back(pS); ba->allocs.push_back(pW); ba->allocs.push_back(pr);
   return VDO_OK;
 }
 
@@ -102,7 +99,9 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
   // The chain preconditioner converges in a handful of iterations and the count drifts slowly from trial to trial (3, 3, 4, 4, 5 on the bench's
   // graph): the first batch is what the previous solve needed + 1, at most 6 - an iteration that finds the convergence flag set still costs its
   // three (empty) launches, ~13 us.  (6 for the first solve of a run; a batch that turns out too short takes the second-look path of the caller.)
-  const int batch = std::min(std::min(6, maxit), ba->pcg_last > 0 ? std::max(2, ba->pcg_last + 1) : 6);
+  // (round 6: no cap of 6 any more - the gauge-free windows of PartialBatchOptimization need 7 .. 35 iterations per solve, rising by one or two from trial to trial, and
+  //  EVERY trial of theirs took the second-look path: a host round trip, a batch of 12, the update and the error evaluation twice.  The margin grows with the count.)
+  const int batch = std::min(std::min(64, maxit), ba->pcg_last > 0 ? std::max(2, ba->pcg_last + 1 + ba->pcg_last / 6) : 6);
   for (int k = 0; k < batch; ++k, ba->pcg_parity ^= 1) launch_pcg_iter(d, lambda, tol2, ba->pcg_parity, s, ba->red);
   ba->pcg_it = batch;
   *pending = true;
@@ -130,7 +129,10 @@ int solve_trial_finish(vdo_ba* ba, double lambda, const vdo_lm_options* opt, boo
   *pcg_iters = ba->h_flags[2];
   ba->pcg_last = *ok ? *pcg_iters : 0;
   const bool small = 6 * (int64_t)d.P <= kDenseMaxUnknowns;
-  if (opt->solver == 0 && small && *ok && *pcg_iters > kPcgSlow) ba->last_solver = 3;      // the next trials go to the dense solver
+  // the next trials go to the dense solver: a slow PCG - or a TINY reduced system (a 20-frame window: 120 unknowns, two MFMA panels) on which a dozen mat-vec
+  // round trips already cost more than assembling and factoring it
+  const bool tiny = 6 * (int64_t)d.P <= kDenseTinyUnknowns;
+  if (opt->solver == 0 && small && *ok && (*pcg_iters > kPcgSlow || (tiny && ba->dense_tiles_ok && *pcg_iters > kPcgSlowTiny))) ba->last_solver = 3;
   return VDO_OK;
 }
 

@@ -11,14 +11,34 @@
 
 #include "ba_host.hpp"
 
+namespace vdo {
+constexpr size_t kBaSlabBytes = (size_t)48 << 20;      // the context's slab for small batch handles (a 20-frame window of KITTI takes ~6 MB)
+
+// device memory of a handle: from the context's slab while the handle owns the pool and the block fits, else hipMalloc (freed by vdo_ba_destroy)
+void* ba_device_alloc(vdo_ba* ba, size_t bytes) {
+  vdo_ctx* c = ba->ctx;
+  const size_t need = (bytes + 255) & ~(size_t)255;
+  if (ba->pooled && c->ba_slab && c->ba_slab_used + need <= c->ba_slab_cap) {
+    void* p = c->ba_slab + c->ba_slab_used;
+    c->ba_slab_used += need;
+    return p;
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, bytes) != hipSuccess) return nullptr;
+  ba->allocs.push_back(p);
+  return p;
+}
+}  // namespace vdo
+
 using namespace vdo;
 
 namespace {
 
 template <class T>
-int upload(T** dst, const T* src, size_t n, hipStream_t s) {
+int upload(vdo_ba* ba, T** dst, const T* src, size_t n, hipStream_t s) {
   if (n == 0) { *dst = nullptr; return VDO_OK; }
-  if (hipMalloc((void**)dst, n * sizeof(T)) != hipSuccess) return set_error(VDO_ERR_OOM, "hipMalloc(%zu) failed", n * sizeof(T));
+  *dst = (T*)ba_device_alloc(ba, n * sizeof(T));
+  if (!*dst) return set_error(VDO_ERR_OOM, "hipMalloc(%zu) failed", n * sizeof(T));
   if (src) {
     if (hipMemcpyAsync(*dst, src, n * sizeof(T), hipMemcpyHostToDevice, s) != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "H2D copy failed");
   } else {
@@ -35,9 +55,8 @@ constexpr int kHardSlots = 256;    // a single long track may use up to this man
 
 #define UP(field, src, n)                                                          \
   do {                                                                             \
-    int rc_ = upload(&ba->d.field, src, (size_t)(n), s);                           \
+    int rc_ = upload(ba, &ba->d.field, src, (size_t)(n), s);                       \
     if (rc_ != VDO_OK) { vdo_ba_destroy(ba); return rc_; }                          \
-    if (ba->d.field) ba->allocs.push_back((void*)ba->d.field);                     \
   } while (0)
 
 extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) {
@@ -108,6 +127,13 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   // ---- greedy tiling
   vdo_ba* ba = new vdo_ba();
   ba->ctx = ctx;
+  // a small graph takes the context's pool if nobody holds it (VDO_BA_NO_POOL: A/B switch); the slab itself is allocated on the first such graph
+  static const bool pool_off = std::getenv("VDO_BA_NO_POOL") != nullptr;
+  if (!pool_off && !ctx->ba_pool_busy && (int64_t)L + Eb + Et < 200000) {
+    if (!ctx->ba_slab && hipMalloc((void**)&ctx->ba_slab, kBaSlabBytes) == hipSuccess) ctx->ba_slab_cap = kBaSlabBytes;
+    if (ctx->ba_slab) { ctx->ba_pool_busy = true; ctx->ba_slab_used = 0; ba->pooled = true; }
+    else (void)hipGetLastError();
+  }
   std::vector<Tile> tiles;
   std::vector<int32_t> tile_pose;                  // per slot: global pose id
   std::vector<int32_t> chain_off{0};
@@ -620,21 +646,29 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(scal, Z, S_COUNT);
   const int32_t* ZI = nullptr;
   UP(flags, ZI, 4);
-  {
+  static const bool one_stream = std::getenv("VDO_BA_ONE_STREAM") != nullptr;
+  if (ba->pooled && ctx->ba_hscal) {                     // the pinned block, the side stream and the events of the last pooled handle
+    ba->h_scal = ctx->ba_hscal; ba->d_hscal = ctx->ba_hscal_dev;
+    ba->ev0 = ctx->ba_ev[0]; ba->ev1 = ctx->ba_ev[1]; ba->ev_fork = ctx->ba_ev[2]; ba->ev_join = ctx->ba_ev[3]; ba->side = ctx->ba_side;
+  } else {
     void* dp = nullptr;
     if (hipHostMalloc((void**)&ba->h_scal, S_COUNT * sizeof(double) + 4 * sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(&dp, ba->h_scal, 0) != hipSuccess || !dp) {
       vdo_ba_destroy(ba);
       return set_error(VDO_ERR_OOM, "hipHostMalloc failed");
     }
-    std::memset(ba->h_scal, 0, S_COUNT * sizeof(double) + 4 * sizeof(int32_t));
-    ba->h_flags = (int32_t*)(ba->h_scal + S_COUNT);
     ba->d_hscal = (double*)dp;
+    hipEventCreate(&ba->ev0); hipEventCreate(&ba->ev1);
+    if (!one_stream && hipStreamCreateWithFlags(&ba->side, hipStreamNonBlocking) == hipSuccess) {
+      hipEventCreateWithFlags(&ba->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&ba->ev_join, hipEventDisableTiming);
+    } else ba->side = nullptr;
+    if (ba->pooled) {                                    // first pooled handle of this context: they stay with the context from here on
+      ctx->ba_hscal = ba->h_scal; ctx->ba_hscal_dev = ba->d_hscal;
+      ctx->ba_ev[0] = ba->ev0; ctx->ba_ev[1] = ba->ev1; ctx->ba_ev[2] = ba->ev_fork; ctx->ba_ev[3] = ba->ev_join; ctx->ba_side = ba->side;
+    }
   }
-  hipEventCreate(&ba->ev0); hipEventCreate(&ba->ev1);
-  if (!std::getenv("VDO_BA_ONE_STREAM") && hipStreamCreateWithFlags(&ba->side, hipStreamNonBlocking) == hipSuccess) {
-    hipEventCreateWithFlags(&ba->ev_fork, hipEventDisableTiming); hipEventCreateWithFlags(&ba->ev_join, hipEventDisableTiming);
-  } else ba->side = nullptr;
+  std::memset(ba->h_scal, 0, S_COUNT * sizeof(double) + 4 * sizeof(int32_t));
+  ba->h_flags = (int32_t*)(ba->h_scal + S_COUNT);
   if (hipStreamSynchronize(s) != hipSuccess) { vdo_ba_destroy(ba); return set_error(VDO_ERR_NO_DEVICE, "upload failed: %s", hipGetErrorString(hipGetLastError())); }
   *out = ba;
   return VDO_OK;
@@ -643,6 +677,21 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
 extern "C" int vdo_ba_destroy(vdo_ba* ba) {
   if (!ba) return VDO_OK;
   if (ba->ctx) ctx_bind(ba->ctx);
+  if (ba->pooled) {
+    // the slab, the pinned block, the side stream and the events go back to the context - once nothing in flight uses them (hipFree below waits by itself)
+    if (ba->ctx->stream) hipStreamSynchronize(ba->ctx->stream);
+    if (ba->side) hipStreamSynchronize(ba->side);
+    ba->ctx->ba_slab_used = 0; ba->ctx->ba_pool_busy = false;
+    const bool kept = ba->ctx->ba_hscal == ba->h_scal;       // (false: the handle failed before its pinned block was handed to the context)
+    for (void* p : ba->allocs) hipFree(p);
+    if (!kept) {
+      if (ba->h_scal) hipHostFree(ba->h_scal);
+      for (hipEvent_t e : {ba->ev0, ba->ev1, ba->ev_fork, ba->ev_join}) if (e) hipEventDestroy(e);
+      if (ba->side) hipStreamDestroy(ba->side);
+    }
+    delete ba;
+    return VDO_OK;
+  }
   for (void* p : ba->allocs) hipFree(p);
   if (ba->h_scal) hipHostFree(ba->h_scal);      // (h_flags lives in the same block)
   if (ba->ev0) hipEventDestroy(ba->ev0);

@@ -54,6 +54,10 @@ extern "C" int vdo_ctx_destroy(vdo_ctx* ctx) {
   hipSetDevice(ctx->device);
   if (ctx->d_arena) hipFree(ctx->d_arena);
   if (ctx->h_arena) hipHostFree(ctx->h_arena);
+  if (ctx->ba_slab) hipFree(ctx->ba_slab);
+  if (ctx->ba_hscal) hipHostFree(ctx->ba_hscal);
+  if (ctx->ba_side) hipStreamDestroy(ctx->ba_side);
+  for (hipEvent_t e : ctx->ba_ev) if (e) hipEventDestroy(e);
   if (ctx->d_stage) hipFree(ctx->d_stage);
   if (ctx->h_stage) hipHostFree(ctx->h_stage);
   if (ctx->owns_stream && ctx->stream) hipStreamDestroy(ctx->stream);

@@ -4,6 +4,8 @@
 // C-ABI instead of allocating g2o vertices/edges; optimisation and gating run in libvdo_hip.
 #include "Optimizer.h"
 
+#include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -116,12 +118,22 @@ struct GraphBuilder {
     g.pr_pose = pr_pose.data(); g.pr_z = pr_z.data(); g.pr_info = pr_info.data();
     g.huber_eb = g.huber_et = g.huber_ep = huber;
     vdo_ba* ba = nullptr;
+    static const bool trace = std::getenv("VDO_BATCH_TRACE") != nullptr;      // (debug: where a batch optimisation spends its time)
+    const auto t0 = std::chrono::steady_clock::now();
     if (vdo_ba_create(HostContext(), &g, &ba) != VDO_OK) die("vdo_ba_create");
-    vdo_lm_options o{max_it, gain, std::getenv("VDO_VERBOSE") ? 1 : 0, 0, 0.0, 0};
+    const auto t1 = std::chrono::steady_clock::now();
+    vdo_lm_options o{max_it, gain, std::getenv("VDO_VERBOSE") ? std::max(1, std::atoi(std::getenv("VDO_VERBOSE"))) : 0, 0, 0.0, 0};      // (VDO_VERBOSE=2: every trial with its PCG iterations)
     if (vdo_ba_optimize(ba, &o, st) != VDO_OK) die("vdo_ba_optimize");
+    const auto t2 = std::chrono::steady_clock::now();
     pose_out.resize(pose.size()); point_out.resize(point.size());
     if (vdo_ba_get_estimates(ba, pose_out.data(), point_out.data()) != VDO_OK) die("vdo_ba_get_estimates");
+    const auto t3 = std::chrono::steady_clock::now();
     vdo_ba_destroy(ba);
+    if (trace) {
+      auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+      std::fprintf(stderr, "[batch] P %d L %d Eb %d Et %d: create %.2f ms, optimize %.2f ms (%d its, %d trials), estimates %.2f ms, destroy %.2f ms\n", g.n_pose, g.n_point, Eb, Et,
+                   ms(t0, t1), ms(t1, t2), st ? st->iterations : -1, st ? st->total_trials : -1, ms(t2, t3), ms(t3, std::chrono::steady_clock::now()));
+    }
   }
 };
 
@@ -372,6 +384,7 @@ void Optimizer::FullBatchOptimization(GraphStore& S, const TrackList& StaTracks,
 void Optimizer::PartialBatchOptimization(GraphStore& S, const TrackList& StaTracks, const float K4[4], const int WINDOW_SIZE) {
   const int N = S.frames();
   if (N < WINDOW_SIZE || WINDOW_SIZE <= 0) return;
+  const auto t_begin = std::chrono::steady_clock::now();
   std::vector<int32_t> labS, posS;
   label_tracks(StaTracks, S.sta, labS, posS);
   std::vector<int32_t> mkS(labS.size(), -1);
@@ -403,7 +416,11 @@ void Optimizer::PartialBatchOptimization(GraphStore& S, const TrackList& StaTrac
     PreFrame = cam;
   }
   std::vector<double> pose, point;
+  const auto t_built = std::chrono::steady_clock::now();
   G.optimize((double)deltaHuber, 100, 1e-3, pose, point, &last_batch_stats);                        // optimize(100), gain 1e-3 (:182,:807)
+  if (std::getenv("VDO_BATCH_TRACE"))
+    std::fprintf(stderr, "[partial batch] frames %d: graph built in %.2f ms, optimised in %.2f ms\n", N, std::chrono::duration<double, std::milli>(t_built - t_begin).count(),
+                 std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_built).count());
   for (int i = Start; i < N; ++i) {                                                                 // :1055-1068
     iso12_to_f16(&pose[12 * (size_t)camID[i]], &S.cam[16 * (size_t)i]);
     if (i > Start) {                                                                                // vmRigidMotion[i-1][0] = toInvMatrix(pose[i-1]) * pose[i]  (fp32)
