@@ -233,6 +233,23 @@ def cpu_baseline_frames_multi(frames, nproc, budget_s=8.0, max_frames=40):
     return sum(o["frames"] / o["seconds"] for o in outs), [o["frames"] for o in outs]
 
 
+def cpu_baseline_window(window_map):
+    """The CPU side of value_with_windowed_ba: the oracle's Levenberg (1 thread, sparse Cholesky; at most 100 iterations, gain 1e-3 - Optimizer::PartialBatchOptimization's
+    settings) on the last 20 frames of a Map the product exported, as the graph the reference's builder makes of it (tests/map_builder_ref.py).  Returns (seconds,
+    iterations, (poses, points, EdgeSE3PointXYZ, EdgeSE3))."""
+    from tests import map_builder_ref as SM
+    from tests import oracle_lib
+    from vdo_slam_amd import _capi as K
+    gw, _info = SM.map_to_graph(window_map, partial_window=20)
+    gcw, keepw = K.graph_to_c(gw)
+    optw = K.LMOptionsC(100, 1e-3, 0, 0, 0.0, 0)
+    stw = K.LMStatsC()
+    pw = np.zeros_like(gw.pose); qw = np.zeros_like(gw.point)
+    t0w = time.perf_counter()
+    oracle_lib.load().vdo_oracle_ba_optimize(C.byref(gcw), C.byref(optw), K._dp(pw), K._dp(qw), C.byref(stw))
+    return time.perf_counter() - t0w, int(stw.iterations), (gw.n_pose, gw.n_point, gw.n_eb, gw.n_ep)
+
+
 def cpu_baseline_batch(graph, its=2):
     from tests import oracle_lib
     from vdo_slam_amd import _capi as K
@@ -902,22 +919,12 @@ def main():
             if window_map is not None and "value_with_windowed_ba" in out:
                 # the CPU path with the same windows: the oracle's Levenberg (1 thread, sparse Cholesky) on the first window of this sequence, once; every window has that shape
                 try:
-                    from tests import map_builder_ref as SM
-                    from tests import oracle_lib
-                    from vdo_slam_amd import _capi as K
-                    gw, _info = SM.map_to_graph(window_map, partial_window=20)
-                    gcw, keepw = K.graph_to_c(gw)
-                    optw = K.LMOptionsC(100, 1e-3, 0, 0, 0.0, 0)
-                    stw = K.LMStatsC()
-                    pw = np.zeros_like(gw.pose); qw = np.zeros_like(gw.point)
-                    t0w = time.perf_counter()
-                    oracle_lib.load().vdo_oracle_ba_optimize(C.byref(gcw), C.byref(optw), K._dp(pw), K._dp(qw), C.byref(stw))
-                    t_win = time.perf_counter() - t0w
+                    t_win, its_w, dims_w = cpu_baseline_window(window_map)
                     n_pb = out["config"]["windowed_ba_calls"]
                     cfps_w = KITTI0000_FRAMES / (KITTI0000_FRAMES / cfps_f + n_pb * t_win)
                     out["cpu_baseline"]["with_windowed_ba"] = {"value": cfps_w, "unit": "frames/s", "cores": 1, "kind": "port",
                                                                "sample": (f"full_sequence's frame rate + {n_pb} windows at the cost of ONE measured here: the oracle's Levenberg on the second window (frames 16 .. 35, no "
-                                                                          f"windowed refinement before it) of this sequence ({gw.n_pose} poses, {gw.n_point} points, {gw.n_eb} + {gw.n_ep} edges; {stw.iterations} iterations, "
+                                                                          f"windowed refinement before it) of this sequence ({dims_w[0]} poses, {dims_w[1]} points, {dims_w[2]} + {dims_w[3]} edges; {its_w} iterations, "
                                                                           f"{t_win * 1e3:.0f} ms; the first window - the only one with a gauge prior - stops after 2)")}
                     out["speedup_vs_cpu_baseline"]["value_with_windowed_ba"] = out["value_with_windowed_ba"] / cfps_w
                 except Exception as e:                            # noqa: BLE001
