@@ -13,7 +13,7 @@
 // by zero), for the three beta systems (cvSolve(CV_SVD): singular values under 2 eps sum(w) dropped) and for the absolute orientation
 // (R = U V^T of sum (pc - pc0)(pw - pw0)^T, THIRD ROW negated when det R < 0 - on near-planar noisy sets that is not the nearest rotation,
 // and it is what the reference receives).  Rounds 2-4 used normal equations, Horn's quaternion and "coplanar: keep the hypothesis" there and
-// differed from the oracle by up to 1.5 in the pose on near-planar inlier sets.  What stays the product's own: M^T M by
+// differed from the oracle by up to 1.5 in the pose on near-planar inlier sets (profiles/HISTORY.md 7.2).  What stays the product's own: M^T M by
 // running sums, its eigenvectors by tridiagonalisation + QL, the sums shared by the three candidates, Householder QR for the Gauss-Newton.
 // The CPU oracle (oracle/epnp_oracle.hpp) is a separately written restatement (dense M, SVD of M^T M, Givens QR); the two
 // are compared to 1e-9 / 1e-6 on near-planar sets (tests/test_epnp_independent.py on the CPU, tests/test_ransac_gpu.py through the C-ABI).
