@@ -96,7 +96,7 @@ struct BADev {
   double *Hll = nullptr, *bl = nullptr;              // [L] (the landmark diagonal block is Hll[l] * I3, see ba_sweep.hip),  [L][3]
   double* Finc = nullptr;                            // [Eb+Et] factored pose-landmark blocks: we (c is recomputed, ba_solve.hip make_f)
   double* Binc = nullptr;                            // [18][Ninc] explicit 6x3 blocks — only materialised for vdo_ba_download_system
-  double* Oll = nullptr;                             // [9][Et]  p1 x p2 blocks
+  double* Oll = nullptr;                             // [Et][9]  p1 x p2 blocks, one record per edge (round 6; [9][Et] planes before: a chain step fetched nine cache lines for 72 bytes)
   double* Hpp_ep = nullptr;                          // [Ep][36]
   double* ep_blk = nullptr;                          // [Ep+Npr][84] per pose-pose edge: Hii | Hjj | bi | bj (added to the pose blocks by k_finalize_pose)
   int32_t *pr_off = nullptr, *pr_idx = nullptr;      // pose -> priors CSR

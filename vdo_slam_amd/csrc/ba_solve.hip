@@ -56,7 +56,6 @@ __global__ __launch_bounds__(128) void k_factor_chains(BADev d, double lambda) {
   }
   double prev[9];
   bool ok = true;
-  const int64_t Et = d.Et;
   // The inputs of a step (Hll of the point, the O block through the pt_prev_edge -> Oll pointer chase) do not depend on the recursion, and a step is ~500 cycles of
   // arithmetic against ~2 500 of memory latency: with the next step's inputs requested one step ahead (rounds 2-4) the walk ran at one memory latency per step.
   // Round 5: chunks of FC steps - the next chunk's Hll and O blocks and the edge indices of the chunk after it are requested while this chunk computes (unconditional
@@ -75,7 +74,7 @@ __global__ __launch_bounds__(128) void k_factor_chains(BADev d, double lambda) {
 #pragma unroll
     for (int j = 0; j < FC; ++j)
 #pragma unroll
-      for (int i = 0; i < 9; ++i) O[j][i] = d.Oll[i * Et + e0[j]];
+      for (int i = 0; i < 9; ++i) O[j][i] = d.Oll[9 * e0[j] + i];
   }
   for (int64_t l0 = p0; l0 < p1; l0 += FC) {
     double hln[FC], On[FC][9];
@@ -84,7 +83,7 @@ __global__ __launch_bounds__(128) void k_factor_chains(BADev d, double lambda) {
     for (int j = 0; j < FC; ++j) {
       hln[j] = d.Hll[cl_h(l0 + FC + j)];
 #pragma unroll
-      for (int i = 0; i < 9; ++i) On[j][i] = d.Oll[i * Et + en[j]];
+      for (int i = 0; i < 9; ++i) On[j][i] = d.Oll[9 * en[j] + i];
     }
 #pragma unroll
     for (int j = 0; j < FC; ++j) enn[j] = d.pt_prev_edge[cl_e(l0 + 2 * FC + j)];

@@ -317,9 +317,9 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_sweep_tile(BADev d, int
           chi += c2; rchi += rho0;
           if (BUILD) {
             const double we = w * rho1;
-            double* O = d.Oll + e;               // O = we * J1^T J2 = -we * Hi.r (p1 x p2)
+            double* O = d.Oll + 9 * (int64_t)e;  // O = we * J1^T J2 = -we * Hi.r (p1 x p2); one 72-byte record per edge: the chain kernels read a block per step
 #pragma unroll
-            for (int i = 0; i < 9; ++i) O[i * Et] = -we * Hi[i];
+            for (int i = 0; i < 9; ++i) O[i] = -we * Hi[i];
             // (H,p1): we * [I ; [v]x]   and   (H,p2): -we * [I ; [v]x] * Hi.r   -> both from (we, v)
             d.Finc[Eb + e] = we;
             // p1: Hll += we*I, b += -we*e ; p2: Hll += we*R_H R_H^T = we*I, b += we * R_H e

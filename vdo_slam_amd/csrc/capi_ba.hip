@@ -817,7 +817,7 @@ extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
   if (out->Hll) for (int l = 0; l < d.L; ++l) { double* o = out->Hll + 9 * (size_t)ba->pt_old_of_new[l]; for (int i = 0; i < 9; ++i) o[i] = (i % 4 == 0) ? hll[(size_t)l] : 0.0; }
   if (out->bl) for (int l = 0; l < d.L; ++l) std::memcpy(out->bl + 3 * (size_t)ba->pt_old_of_new[l], bl.data() + 3 * (size_t)l, 24);
   if (out->Hll_et)
-    for (size_t e = 0; e < Et; ++e) for (int i = 0; i < 9; ++i) out->Hll_et[i * Et + ba->et_old_of_new[e]] = oll[i * Et + e];
+    for (size_t e = 0; e < Et; ++e) for (int i = 0; i < 9; ++i) out->Hll_et[i * Et + ba->et_old_of_new[e]] = oll[9 * e + i];
   if (out->Hpl_eb)
     for (size_t e = 0; e < Ebp; ++e) { if (ba->eb_old_of_new[e] < 0) continue; for (int i = 0; i < 18; ++i) out->Hpl_eb[i * Eb + ba->eb_old_of_new[e]] = binc[i * N + ba->inc_of_eb[e]]; }
   for (int rep = 0; rep < 2; ++rep) {
