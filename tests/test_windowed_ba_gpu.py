@@ -14,10 +14,12 @@ from tests import oracle_lib
 from vdo_slam_amd import synth_seq as SQ
 
 pytestmark = pytest.mark.gpu
-N = 24
 
 
-def test_trackrgbd_with_windowed_and_final_batch_equals_the_whole_reference(tmp_path):
+# 24 frames: the first window (f_id 19: the only one with a gauge prior, two Levenberg iterations) + the final batch.  40 frames (round 6): also the second window (f_id 35) -
+# no gauge prior (src/Optimizer.cc:227-236), ~27 iterations, the path on which the product's PCG gives way to its dense MFMA solver (ba_lm.hip kDenseTinyUnknowns).
+@pytest.mark.parametrize("N", [24, 40])
+def test_trackrgbd_with_windowed_and_final_batch_equals_the_whole_reference(tmp_path, N):
     from tests.ref_track import MAP_PARTS, _digest, finish_sequence, start_sequence_from_dir
     from vdo_slam_amd.system import System
     L = oracle_lib.load_ref_full()
