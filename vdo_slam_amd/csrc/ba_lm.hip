@@ -70,6 +70,10 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
   hipStream_t s = ba->ctx->stream;
   const bool small = 6 * (int64_t)d.P <= kDenseMaxUnknowns;
   bool dense = opt->solver == 3 || (opt->solver == 0 && small && ba->dense_tiles_ok && (!ba->pose_graph_is_paths || ba->last_solver == 3));
+  // a TINY reduced system (<= 384 unknowns: the 20-frame windows of PartialBatchOptimization) is assembled and factored (two MFMA panels) in less time than the handful of
+  // mat-vec round trips a PCG solve takes: 0.24 against 0.30 ms per LM iteration on such a window (VDO_BA_TINY_PCG: A/B switch back to the PCG-first rule)
+  static const bool tiny_pcg = std::getenv("VDO_BA_TINY_PCG") != nullptr;
+  if (!tiny_pcg && opt->solver == 0 && ba->dense_tiles_ok && 6 * (int64_t)d.P <= kDenseTinyUnknowns) dense = true;
   // (dense_tiles_ok: the dense assembly's workgroup fits - padded incidences per thread, LDS at the graph's largest tile; capi_ba.hip)
   if (dense && !ba->dense_tiles_ok) return set_error(VDO_ERR_UNSUPPORTED, "dense solver: a tile of this graph does not fit the dense assembly (more than %d pose slots of LDS); use the PCG solver", 200);
   if (dense && !small && opt->solver == 3) return set_error(VDO_ERR_UNSUPPORTED, "dense solver: %lld unknowns exceed %lld", 6LL * d.P, (long long)kDenseMaxUnknowns);
@@ -81,12 +85,14 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
     launch_dense_assemble(d, ba->dense_S, ba->dense_ld, lambda, s, ba->red);
     launch_dense_rhs(d, ba->dense_rhs, ba->dense_ld, s);
     launch_dense_solve(d, ba->dense_S, ba->dense_ld, ba->dense_W, ba->dense_rhs, s);
-    rc = fetch(ba);
-    if (rc != VDO_OK) return rc;
-    *ok = ba->h_flags[0] == 0;
+    // (no read-back here: like the PCG batch, the factorisation's failure flag comes back with the trial's scalars - the caller enqueues the update and the error
+    //  evaluation behind the solve and reads everything with ONE synchronisation; solve_trial_finish looks at the flag.  A failed factorisation leaves garbage in x:
+    //  the trial is then rejected whatever its errors are, as after a read-back in between.)
+    *ok = true;
     *pcg_iters = 0;
-    *pending = false;
+    *pending = true;
     ba->last_solver = 3;
+    ba->dense_pending = true;
     return VDO_OK;
   }
   ba->last_solver = 2;
@@ -114,6 +120,12 @@ int solve_trial_finish(vdo_ba* ba, double lambda, const vdo_lm_options* opt, boo
   const BADev& d = ba->d;
   hipStream_t s = ba->ctx->stream;
   *again = false;
+  if (ba->dense_pending) {                 // the trial was solved by the dense factorisation: only its failure flag is of interest
+    ba->dense_pending = false;
+    *ok = ba->h_flags[0] == 0;
+    *pcg_iters = 0;
+    return VDO_OK;
+  }
   for (;;) {
     if (ba->h_flags[0]) { *ok = false; break; }
     if (ba->h_flags[1] == 1) break;
@@ -147,6 +159,7 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
   std::memset(st, 0, sizeof(*st));
   ba->lin_current = false;        // (the accepted steps move estimate[0] away from the last linearisation)
   ba->lin_exchange_pending = false;
+  ba->dense_pending = false;
   ba->pcg_last = 0;
   BADev& d = ba->d;
   hipStream_t s = ba->ctx->stream;
