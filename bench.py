@@ -620,6 +620,40 @@ def main():
     # ---- the KITTI-0000-length run (5 warm-up + 148 timed frames of the 153-frame sequence, SURVEY's event frames), whatever --steps the caller passed: the same
     # Step with the reference's return semantics (everything of a frame done when its call returns); the driver's `value` window is shorter and carries no capped object LM
     window_map = None
+    def windowed_leg(dev_frames_w, warm_w, steps_w):
+        nonlocal defer, window_map
+        defer_saved = defer
+        # ---- the same run with the windowed optimisation Track() contains INSIDE the timed frames (src/Tracking.cc:1165-1183: PartialBatchOptimization over the last
+        # WINDOW_SIZE = 20 frames every 16 frames, example/kitti-0000-0013.yaml): a key of its own, never `value` (VERDICT r5 #8)
+        if not args.no_windowed_ba:
+            defer = 0
+            dt_w, rs_w = run_sequences(1, dev_frames_w, warm_w, steps_w, window=(20, 4))
+            n_pb = rs_w[0].pipe.partial_batches()
+            sm_w = rs_w[0].step_ms
+            out["value_with_windowed_ba"] = world * steps_w / dt_w
+            out["config"]["value_with_windowed_ba"] = (f"value_full_sequence's run with window 20 / overlap 4: {n_pb} PartialBatchOptimization calls (C++ graph builder from the GraphStore, "
+                                                       f"Levenberg on the GPU, at most 100 iterations, gain 1e-3) inside the {steps_w} timed frames + warm-up; step ms p50 / p90 / max "
+                                                       f"{np.percentile(sm_w, 50):.3f} / {np.percentile(sm_w, 90):.3f} / {max(sm_w):.3f}")
+            out["config"]["windowed_ba_calls"] = int(n_pb)
+            for r in rs_w:
+                r.close()
+            del rs_w
+            # the CPU side needs a window of THIS sequence as a graph: the SECOND window (frames 16 .. 35: like every window but the first it has no gauge prior,
+            # src/Optimizer.cc:227-236, and takes ~27 Levenberg iterations where the first takes 2) through an untimed pass with a Map attached, exported and turned
+            # into the graph the reference's builder makes of it (tests/map_builder_ref.py: test-side code, used by the cpu_baseline leg only)
+            if rank == 0 and world == 1 and not args.no_cpu_baseline:
+                try:
+                    _, rs_m = run_sequences(1, dev_frames_w, 0, 36, with_map=True)
+                    rs_m[0].pipe.finalize_map()
+                    window_map = rs_m[0].pipe.export_map(synth.KITTI_K)
+                    for r in rs_m:
+                        r.close()
+                    del rs_m
+                except Exception as e:                            # noqa: BLE001 - the product's number above stays valid
+                    window_map = None
+                    out["config"]["windowed_ba_cpu_sample_error"] = repr(e)[:200]
+            defer = defer_saved
+
     if frames_full is not None and R == 1 and not os.environ.get("VDO_BENCH_SYNC_OBJECTS"):
         dev_full = [{q: torch.from_numpy(np.ascontiguousarray(f[q])).cuda() for q in ("gray", "depth_raw", "flow", "mask")} for f in frames_full]
         defer_saved = defer
@@ -638,40 +672,13 @@ def main():
         for r in rs_full:
             r.close()
         del rs_full
-        # ---- the same run with the windowed optimisation Track() contains INSIDE the timed frames (src/Tracking.cc:1165-1183: PartialBatchOptimization over the last
-        # WINDOW_SIZE = 20 frames every 16 frames, example/kitti-0000-0013.yaml): a key of its own, never `value` (VERDICT r5 #8)
-        if not args.no_windowed_ba:
-            defer = 0
-            dt_w, rs_w = run_sequences(1, dev_full, FULL_WARMUP, steps_full, window=(20, 4))
-            n_pb = rs_w[0].pipe.partial_batches()
-            sm_w = rs_w[0].step_ms
-            out["value_with_windowed_ba"] = world * steps_full / dt_w
-            out["config"]["value_with_windowed_ba"] = (f"value_full_sequence's run with window 20 / overlap 4: {n_pb} PartialBatchOptimization calls (C++ graph builder from the GraphStore, "
-                                                       f"Levenberg on the GPU, at most 100 iterations, gain 1e-3) inside the {steps_full} timed frames + warm-up; step ms p50 / p90 / max "
-                                                       f"{np.percentile(sm_w, 50):.3f} / {np.percentile(sm_w, 90):.3f} / {max(sm_w):.3f}")
-            out["config"]["windowed_ba_calls"] = int(n_pb)
-            for r in rs_w:
-                r.close()
-            del rs_w
-            # the CPU side needs a window of THIS sequence as a graph: the SECOND window (frames 16 .. 35: like every window but the first it has no gauge prior,
-            # src/Optimizer.cc:227-236, and takes ~27 Levenberg iterations where the first takes 2) through an untimed pass with a Map attached, exported and turned
-            # into the graph the reference's builder makes of it (tests/map_builder_ref.py: test-side code, used by the cpu_baseline leg only)
-            if rank == 0 and world == 1 and not args.no_cpu_baseline:
-                try:
-                    _, rs_m = run_sequences(1, dev_full, 0, 36, with_map=True)
-                    rs_m[0].pipe.finalize_map()
-                    window_map = rs_m[0].pipe.export_map(synth.KITTI_K)
-                    for r in rs_m:
-                        r.close()
-                    del rs_m
-                except Exception as e:                            # noqa: BLE001 - the product's number above stays valid
-                    window_map = None
-                    out["config"]["windowed_ba_cpu_sample_error"] = repr(e)[:200]
-            defer = defer_saved
+        windowed_leg(dev_full, FULL_WARMUP, steps_full)
         del dev_full
     elif frames_full is None and args.steps + args.warmup == KITTI0000_FRAMES and "value_sync" in out:
         out["value_full_sequence"] = out["value"]
         out["config"]["value_full_sequence"] = "= value: this run IS the KITTI-0000-length run"
+        if R == 1 and not os.environ.get("VDO_BENCH_SYNC_OBJECTS"):
+            windowed_leg(None, args.warmup, args.steps)
         if "parity" in out:
             out["parity_full_sequence"] = out["parity"]
     # ---- R-sweep: aggregate frames/s for several numbers of independent sequences per GPU (the per-frame path keeps <= ~10 of the
@@ -916,21 +923,25 @@ def main():
             cfps_f, cn_f, _, _, _ = cpu_baseline_frames(frames_full, budget_s=12.0)
             out["cpu_baseline"]["full_sequence"] = {"value": cfps_f, "unit": "frames/s", "cores": 1, "kind": "port", "sample": f"the first {cn_f} frames of the {KITTI0000_FRAMES}-frame sequence (oracle, 1 thread)"}
             out["speedup_vs_cpu_baseline"]["value_full_sequence"] = out["value_full_sequence"] / cfps_f
-            if window_map is not None and "value_with_windowed_ba" in out:
-                # the CPU path with the same windows: the oracle's Levenberg (1 thread, sparse Cholesky) on the first window of this sequence, once; every window has that shape
-                try:
-                    t_win, its_w, dims_w = cpu_baseline_window(window_map)
-                    n_pb = out["config"]["windowed_ba_calls"]
-                    cfps_w = KITTI0000_FRAMES / (KITTI0000_FRAMES / cfps_f + n_pb * t_win)
-                    out["cpu_baseline"]["with_windowed_ba"] = {"value": cfps_w, "unit": "frames/s", "cores": 1, "kind": "port",
-                                                               "sample": (f"full_sequence's frame rate + {n_pb} windows at the cost of ONE measured here: the oracle's Levenberg on the second window (frames 16 .. 35, no "
-                                                                          f"windowed refinement before it) of this sequence ({dims_w[0]} poses, {dims_w[1]} points, {dims_w[2]} + {dims_w[3]} edges; {its_w} iterations, "
-                                                                          f"{t_win * 1e3:.0f} ms; the first window - the only one with a gauge prior - stops after 2)")}
-                    out["speedup_vs_cpu_baseline"]["value_with_windowed_ba"] = out["value_with_windowed_ba"] / cfps_w
-                except Exception as e:                            # noqa: BLE001
-                    out["cpu_baseline"]["with_windowed_ba_error"] = repr(e)[:200]
+            cfps_full = cfps_f
         elif "value_full_sequence" in out:
             out["speedup_vs_cpu_baseline"]["value_full_sequence"] = out["value_full_sequence"] / cfps
+            cfps_full = cfps
+        else:
+            cfps_full = cfps
+        if window_map is not None and "value_with_windowed_ba" in out:
+            # the CPU path with the same windows: the oracle's Levenberg (1 thread, sparse Cholesky) on the first window of this sequence, once; every window has that shape
+            try:
+                t_win, its_w, dims_w = cpu_baseline_window(window_map)
+                n_pb = out["config"]["windowed_ba_calls"]
+                cfps_w = KITTI0000_FRAMES / (KITTI0000_FRAMES / cfps_full + n_pb * t_win)
+                out["cpu_baseline"]["with_windowed_ba"] = {"value": cfps_w, "unit": "frames/s", "cores": 1, "kind": "port",
+                                                           "sample": (f"full_sequence's frame rate + {n_pb} windows at the cost of ONE measured here: the oracle's Levenberg on the second window (frames 16 .. 35, no "
+                                                                      f"windowed refinement before it) of this sequence ({dims_w[0]} poses, {dims_w[1]} points, {dims_w[2]} + {dims_w[3]} edges; {its_w} iterations, "
+                                                                      f"{t_win * 1e3:.0f} ms; the first window - the only one with a gauge prior - stops after 2)")}
+                out["speedup_vs_cpu_baseline"]["value_with_windowed_ba"] = out["value_with_windowed_ba"] / cfps_w
+            except Exception as e:                            # noqa: BLE001
+                out["cpu_baseline"]["with_windowed_ba_error"] = repr(e)[:200]
         # ---- the reference's own five clock() brackets (all_timing[0..4]: mask update, camera estimate, object tracking, object estimate per object,
         # map update = RenewFrameInfo; src/Tracking.cc:230-243, 685-703, 1366-1603, 868-1010, 1016-1020), side by side, ms per frame
         pf = out["config"]["host_ms_per_section"]; n_obj_mean = max(out["config"]["per_frame_mean"]["n_objects"], 1e-9)
