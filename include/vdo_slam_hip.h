@@ -135,12 +135,13 @@ typedef struct vdo_lm_stats {
 
 typedef struct vdo_ba vdo_ba;
 /* Uploads the graph to HBM (SoA, resident until destroy) and builds the chain structure.
- * Limits (g2o has none; VDO_ERR_UNSUPPORTED names the offending track): a landmark track - one static point, or a chain of dynamic
- * points linked by LandmarkMotionTernaryEdges - is processed by ONE workgroup and must fit its tile: <= 256 points, <= 1536 edge
- * incidences, <= 256 distinct pose vertices (cameras + motions), and sum over those poses of ceil(observations / 6) <= 256.  A static
- * point may therefore be observed from up to 256 frames (every frame of the 153-frame KITTI-0000 sequence), a dynamic chain may run over
- * up to 128 frames (its points bring a camera and a motion vertex each); a graph that holds such a track pays with fewer resident
- * workgroups per CU (the tile kernels' LDS grows with the pose slots of the largest tile) and has no dense solver beyond ~200 slots. */
+ * Limits (g2o has none; VDO_ERR_UNSUPPORTED names the offending track): a DYNAMIC landmark track - a chain of points linked by
+ * LandmarkMotionTernaryEdges - is processed by ONE workgroup and must fit its tile: <= 256 points, <= 1536 edge incidences, <= 256 distinct
+ * pose vertices (cameras + motions), and sum over those poses of ceil(observations / 6) <= 256: it may run over up to 128 frames (its
+ * points bring a camera and a motion vertex each).  A STATIC point has no such limit since round 6: up to those figures it lives in a tile
+ * (a graph that holds such a track pays with fewer resident workgroups per CU - the tile kernels' LDS grows with the pose slots of the
+ * largest tile - and has no dense solver beyond ~200 slots); beyond them it becomes a hub landmark with a workgroup of its own
+ * (csrc/ba_hub.hip; such graphs are solved by the PCG, the dense solver refuses them). */
 int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out);
 int vdo_ba_destroy(vdo_ba* ba);
 /* K18: `repeat` back-to-back linearisation sweeps (errors + Jacobians + Huber + block
@@ -156,7 +157,7 @@ int vdo_ba_linearize(vdo_ba* ba, int repeat, float* ms_sweep);
  *   dims[0] tiles, [1] (tile, pose-slot) pairs, [2] running sums per partial row (16 / 32), [3] max slots of a tile,
  *   [4] bytes read per EdgeSE3PointXYZ entry (key + measurement [+ weight]), [5] bytes read per ternary edge,
  *   [6] EdgeSE3PointXYZ ENTRIES of the tiles' edge blocks (>= the graph's edges: every tile holds its edges as a padded block of
- *       256 x (edges per thread) entries, thread-transposed, so that every load of a tile kernel is one contiguous row), [7] reserved (0). */
+ *       256 x (edges per thread) entries, thread-transposed, so that every load of a tile kernel is one contiguous row), [7] hub landmarks (static points whose observations do not fit a tile: a workgroup of its own each). */
 int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int64_t dims[8]);
 /* new (measurement): mean milliseconds of ONE Schur mat-vec launch (k_schur_tile<0>, the product B Hll^-1 B^T p of a CG iteration of the reduced-camera solve that
    replaces g2o's BlockSolver::solve / LinearSolverCSparse, g2o/core/block_solver.hpp:143-295), timed alone with events on the context's stream.  Call after vdo_ba_optimize. */

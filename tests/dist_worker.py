@@ -81,9 +81,15 @@ def gpu_lm(rank, world, out_path, backend):
              dict(n_frames=30, n_static=3000, n_objects=3, dyn_tracks_per_object=100, seed=4))
     if world > 2:
         cases = cases[1:]                                  # (many ranks on one GPU: one graph with enough tracks for every rank)
+    else:
+        cases = cases + (dict(n_frames=300, n_static=700, n_objects=1, dyn_tracks_per_object=30, seed=6, hubs=4),)      # round 6: 4 static points seen from all 300 cameras - hub landmarks (ba_hub.hip) on whichever rank owns them
     for transport in transports:
         for kw in cases:
+            kw = dict(kw)
+            n_hub = kw.pop("hubs", 0)
             g = synth.make_ba_graph(**kw)
+            if n_hub:
+                g = synth.with_hub_points(g, n_hub, seed=1)
             sh = D.ShardedBatchBA(ctx, g, transport=transport)
             st = sh.optimize(max_iterations=6, gain_threshold=-1.0)
             pose, point = sh.estimates()

@@ -541,7 +541,7 @@ def test_lm_reuses_the_accepted_trials_errors(ctx, monkeypatch):
     assert out[0][2] >= 3
 
 
-@pytest.mark.parametrize("frames", [153, 230])
+@pytest.mark.parametrize("frames", [153, 230, 420, 836])
 def test_static_landmarks_seen_in_every_frame_of_a_kitti_length_sequence(ctx, oracle, frames):
     """g2o has no limit on how many poses observe a landmark; rounds 1-4 refused a track touching more than 100 pose vertices
     (kHardSlots) - a static point seen in all 153 frames of KITTI-0000 failed vdo_ba_create.  The limit is 256 now (one thread per pose slot stages
@@ -549,7 +549,8 @@ def test_static_landmarks_seen_in_every_frame_of_a_kitti_length_sequence(ctx, or
     linearises like the oracle and takes the oracle's Levenberg trajectory."""
     import dataclasses
     from vdo_slam_amd.ba import BatchBA
-    g0 = synth.make_ba_graph(frames, 1500, 1, 40, seed=3)
+    its = 4 if frames < 800 else 2                      # (the oracle's sparse Cholesky over 836 camera poses is what this test waits for)
+    g0 = synth.make_ba_graph(frames, 1500 if frames < 800 else 500, 1, 40, seed=3)
     rng = np.random.default_rng(8)
     cams = np.arange(g0.n_cam)
     # 25 static points (never an end of a ternary edge): one more observation from every camera that does not see them yet
@@ -569,7 +570,11 @@ def test_static_landmarks_seen_in_every_frame_of_a_kitti_length_sequence(ctx, or
     per_point = np.bincount(g.eb_point, minlength=g.n_point)
     assert per_point[pick].min() >= frames
     ba = BatchBA(ctx, g)
-    assert ba.dims()["max_slots"] >= frames
+    if frames <= 256:
+        assert ba.dims()["max_slots"] >= frames and ba.dims()["hubs"] == 0
+    else:
+        # round 6: beyond 256 pose vertices a static point is a HUB landmark - out of the tiles, a workgroup of its own (ba_hub.hip); g2o has no limit
+        assert ba.dims()["hubs"] == len(pick) and ba.dims()["max_slots"] <= 256
     ba.linearize()
     S = ba.system()
     R_ = _oracle_system(oracle, g)
@@ -578,9 +583,9 @@ def test_static_landmarks_seen_in_every_frame_of_a_kitti_length_sequence(ctx, or
         if b.size:
             assert np.abs(a - b).max() <= block_tol(name) * _scale(name, R_) + 1e-300, (name, np.abs(a - b).max() / max(_scale(name, R_), 1e-300))
     assert abs(S.chi2 - R_.chi2) <= 1e-12 * abs(R_.chi2)
-    st = ba.optimize(max_iterations=4, gain_threshold=-1.0)
+    st = ba.optimize(max_iterations=its, gain_threshold=-1.0)
     gc, keep = K.graph_to_c(g)
-    opt = K.LMOptionsC(4, -1.0, 0, 0, 0.0, 0)
+    opt = K.LMOptionsC(its, -1.0, 0, 0, 0.0, 0)
     so = K.LMStatsC(); po = np.zeros_like(g.pose); qo = np.zeros_like(g.point)
     assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(po), K._dp(qo), C.byref(so)) == 0
     assert st.iterations == so.iterations and st.total_trials == so.total_trials
@@ -588,3 +593,18 @@ def test_static_landmarks_seen_in_every_frame_of_a_kitti_length_sequence(ctx, or
     pose, pt = ba.estimates()
     np.testing.assert_allclose(pose, po, rtol=0, atol=1e-4 * max(1.0, np.abs(po).max()))
     ba.close()
+
+
+def test_hub_landmarks_can_be_switched_off_and_the_dense_solver_refuses_them(ctx, monkeypatch):
+    """A static point seen from 300 cameras: a hub landmark (ba_hub.hip) by default; VDO_BA_NO_HUBS=1 brings the refusal of rounds 1-5 back, with its message;
+    the dense solver (whose assembly walks tiles only) says so when it is asked for explicitly."""
+    from vdo_slam_amd.ba import BatchBA
+    g = synth.with_hub_points(synth.make_ba_graph(300, 400, 0, 0, seed=5), 1, seed=2)
+    ba = BatchBA(ctx, g)
+    assert ba.dims()["hubs"] == 1
+    with pytest.raises(K.VdoError, match="dense"):
+        ba.optimize(max_iterations=1, gain_threshold=-1.0, solver=3)
+    ba.close()
+    monkeypatch.setenv("VDO_BA_NO_HUBS", "1")
+    with pytest.raises(K.VdoError, match="distinct pose vertices"):
+        BatchBA(ctx, g)

@@ -96,7 +96,7 @@ class BatchBA:
         L = K.lib()
         L.vdo_ba_profile_linearize.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_int64)]
         K.check(L.vdo_ba_profile_linearize(self._h, repeat, ms, dims))
-        return float(ms[0]), float(ms[1]), dict(zip(("tiles", "slots", "partial_row", "max_slots", "read_bytes_eb", "read_bytes_et", "eb_entries"), (int(v) for v in dims)))
+        return float(ms[0]), float(ms[1]), dict(zip(("tiles", "slots", "partial_row", "max_slots", "read_bytes_eb", "read_bytes_et", "eb_entries", "hubs"), (int(v) for v in dims)))
 
     def dims(self) -> dict:
         """Layout facts of the tiled graph (tests): tiles, (tile, slot) pairs, ps_stride (= partial_row), max_slots, bytes read per edge."""

@@ -127,6 +127,18 @@ struct BADev {
   // multi-GPU shards: poses replicated, points + their edges owned by one rank.
   // Hpp | bp | red_chi are ONE allocation so that a linearisation needs a single all-reduce.
   int sharded = 0, shard_rank = 0;
+  // HUB landmarks (round 6, ba_hub.hip): a STATIC point whose observations do not fit one tile (more than 256 distinct pose vertices / 256 per-pose pieces / 1 536 edges - a
+  // point seen in 300+ frames) belongs to no tile.  One workgroup per hub walks its edges; every hub edge owns one pose-major partial row (its own "slot": tile_pose /
+  // slot_dst / ps_off count it), so the pose side reaches k_finalize_pose, k_gather_q / k_pcg_q and k_precond_finalize like the rows of a (tile, slot) pair.
+  int n_hubs = 0, n_hub_edges = 0;
+  int32_t* hub_off = nullptr;            // [n_hubs + 1] edge ranges
+  int32_t* hub_point = nullptr;          // [n_hubs] device point id (hubs come after every tile's points; each is a chain of its own)
+  int32_t* hub_pose = nullptr;           // [n_hub_edges] pose vertex
+  int32_t* hub_row = nullptr;            // [n_hub_edges] pose-major row of the edge's partials (part_sums / part_q / part_m)
+  double* hub_z = nullptr;               // [3][n_hub_edges] measurements
+  double* hub_w = nullptr;               // [n_hub_edges] information scalars
+  double* hub_we = nullptr;              // [n_hub_edges] Huber-weighted information of the last linearisation (the Finc of these edges)
+  double* hub_chi = nullptr;             // [2][n_hubs] chi2 / robust chi2 partials
   double* red_chi = nullptr;                         // [4] chi2, robust chi2, scale partials (follows bp)
   double* msum = nullptr;                            // [P][21] block-Jacobi partials awaiting the all-reduce
 };
@@ -159,6 +171,11 @@ void launch_expand_binc(const BADev& d, hipStream_t s);            // Finc -> ex
 void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R);   // explicit reduced-camera matrix
 void launch_dense_rhs(const BADev& d, double* rhs, int64_t ld, hipStream_t s);
 // ---- ba_dense.hip
+// ba_hub.hip: the hub landmarks' share of the tile kernels' work (no-ops without hubs)
+void launch_hub_sweep(const BADev& d, int which, bool build, hipStream_t s);
+void launch_hub_precond(const BADev& d, hipStream_t s);
+void launch_hub_schur(const BADev& d, int mode, const double* v, const double* v2, hipStream_t s);
+void launch_hub_expand_binc(const BADev& d, double* binc18, hipStream_t s);      // [n_hub_edges][18] explicit 6x3 blocks (vdo_ba_download_system)
 void launch_publish_scalars(const BADev& d, double* h_block_dev, hipStream_t s);      // ba_solve.hip
 void launch_dense_solve(const BADev& d, double* S, int64_t ld, double* Winv, double* rhs, hipStream_t s);    // MFMA Cholesky + substitutions -> xp
 

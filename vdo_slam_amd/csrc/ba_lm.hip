@@ -75,7 +75,9 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
   static const bool tiny_pcg = std::getenv("VDO_BA_TINY_PCG") != nullptr;
   if (!tiny_pcg && opt->solver == 0 && ba->dense_tiles_ok && 6 * (int64_t)d.P <= kDenseTinyUnknowns) dense = true;
   // (dense_tiles_ok: the dense assembly's workgroup fits - padded incidences per thread, LDS at the graph's largest tile; capi_ba.hip)
-  if (dense && !ba->dense_tiles_ok) return set_error(VDO_ERR_UNSUPPORTED, "dense solver: a tile of this graph does not fit the dense assembly (more than %d pose slots of LDS); use the PCG solver", 200);
+  if (dense && !ba->dense_tiles_ok)
+    return set_error(VDO_ERR_UNSUPPORTED, d.n_hubs ? "dense solver: this graph has %d hub landmark(s) (static points beyond a tile's capacity, ba_hub.hip) - the dense assembly walks tiles only; use the PCG solver"
+                                                   : "dense solver: a tile of this graph does not fit the dense assembly (more than %d pose slots of LDS); use the PCG solver", d.n_hubs ? d.n_hubs : 200);
   if (dense && !small && opt->solver == 3) return set_error(VDO_ERR_UNSUPPORTED, "dense solver: %lld unknowns exceed %lld", 6LL * d.P, (long long)kDenseMaxUnknowns);
   launch_factor_and_rhs(d, lambda, s, ba->red, ba->side, ba->ev_fork, ba->ev_join, !dense, ba->lin_exchange_pending);
   ba->lin_exchange_pending = false;

@@ -1893,6 +1893,7 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
     const int nd = d.n_tiles < 1024 ? d.n_tiles : std::min(d.n_dyn_tiles, d.n_tiles);       // tiles with dynamic tracks come first in the launch order (a graph of few tiles: one launch - a second one costs more than the registers)
     if (nd > 0) hipLaunchKernelGGL(k_precond_tile<true>, dim3(nd), dim3(VDO_TILE_THREADS), raise_lds(k_precond_tile<true>, lds), s, d, 0);
     if (d.n_tiles > nd) hipLaunchKernelGGL(k_precond_tile<false>, dim3(d.n_tiles - nd), dim3(VDO_TILE_THREADS), raise_lds(k_precond_tile<false>, lds), s, d, nd);
+    launch_hub_precond(d, s);
   }
   const dim3 g((d.P + 3) / 4), b(256);
   if (!precond) { }
@@ -1902,6 +1903,7 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
     // qs (6 P) - contiguous in memory - cross the ranks in ONE all-reduce per trial instead of two dependent ones.
     hipLaunchKernelGGL(k_precond_finalize<1>, g, b, 0, s, d, lambda);
     if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<1>, schur_lds(d)), s, d, (const double*)nullptr, (const double*)nullptr);
+    launch_hub_schur(d, 1, nullptr, nullptr, s);
     hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, s, d, d.qs, 0);
     // lin_pending: the linearisation in front of this trial left its exchange to us - Hpp | bp | chi2 (42 P + 4) lie right in front of msum | qs: one all-reduce of
     // 69 P + 5 doubles for the first trial of an LM iteration instead of two dependent ones
@@ -1921,6 +1923,7 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
   }
   if (!d.sharded) {
     if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<1>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<1>, schur_lds(d)), sr, d, (const double*)nullptr, (const double*)nullptr);
+    launch_hub_schur(d, 1, nullptr, nullptr, sr);
     hipLaunchKernelGGL(k_gather_q, dim3((d.P + 3) / 4), dim3(256), 0, sr, d, d.qs, 0);
   }
   if (two) { hipEventRecord(join, side); hipStreamWaitEvent(s, join, 0); }
@@ -1946,6 +1949,7 @@ void launch_pcg_init(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_pcg_c
 
 void launch_pcg_iter(const BADev& d, double lambda, double tol2, int parity, hipStream_t s, const Reducer& R) {
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<0>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<0>, schur_lds(d)), s, d, (const double*)d.zp, (const double*)(parity ? d.pp2 : d.pp));
+  launch_hub_schur(d, 0, d.zp, parity ? d.pp2 : d.pp, s);
   const int nq = (d.P + 3) / 4;
   if (d.sharded) {
     hipLaunchKernelGGL(k_gather_q, dim3(nq), dim3(256), 0, s, d, d.qs, 1);
@@ -1973,6 +1977,7 @@ void launch_publish_scalars(const BADev& d, double* h_block_dev, hipStream_t s) 
 
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s) {
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_tile<2>, dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_schur_tile<2>, schur_lds(d)), s, d, (const double*)d.xp, (const double*)nullptr);
+  launch_hub_schur(d, 2, d.xp, nullptr, s);
   const int nb = red_blocks(d);
   hipLaunchKernelGGL(k_update, dim3(nb), dim3(1024), 0, s, d, lambda, ortho ? 1 : 0);
   hipLaunchKernelGGL(k_reduce_part, dim3(1), dim3(256), 0, s, d, nb, 0);

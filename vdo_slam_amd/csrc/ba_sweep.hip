@@ -490,8 +490,10 @@ __device__ void reduce_chi_body(const BADev& d, int mode_lin, double* lds) {
   // linearisation and of an error evaluation at the same estimate are the SAME BITS - ba_lm.hip skips the re-evaluation after an accepted trial on that
   // (ADVICE r4).  The waves beyond the fourth add zeros, in wave order.
   if (threadIdx.x < 256) {
-    if (mode <= 1)
+    if (mode <= 1) {
       for (int i = threadIdx.x; i < nt; i += 256) { a0 += d.part_chi[i]; a1 += d.part_chi[nt + i]; }
+      for (int i = threadIdx.x; i < d.n_hubs; i += 256) { a0 += d.hub_chi[i]; a1 += d.hub_chi[d.n_hubs + i]; }      // (hub landmarks, ba_hub.hip: rank-local like the tiles)
+    }
     if (mode != 1)
       for (int i = threadIdx.x; i < n2; i += 256) { a0 += ep_chi[i]; a1 += ep_chi[n2 + i]; }
   }
@@ -521,6 +523,7 @@ void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R) {
     if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<false, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<false, true>, lds), s, d, which);
     else hipLaunchKernelGGL((k_sweep_tile<false, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<false, false>, lds), s, d, which);
   }
+  launch_hub_sweep(d, which, false, s);
   launch_posepose(d, which, false, ep_chi_buf(d), s);
   if (!d.sharded) { hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 0); return; }
   hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 1);
@@ -533,6 +536,7 @@ void launch_linearize_finish(const BADev& d, hipStream_t s) { hipLaunchKernelGGL
 
 void launch_sweep_only(const BADev& d, hipStream_t s) {
   const size_t lds = sweep_lds_doubles(d.max_slots, true, d.ps_stride) * sizeof(double);
+  launch_hub_sweep(d, 0, true, s);
   if (!d.n_tiles) return;
   if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<true, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<true, true>, lds), s, d, 0);
   else hipLaunchKernelGGL((k_sweep_tile<true, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<true, false>, lds), s, d, 0);

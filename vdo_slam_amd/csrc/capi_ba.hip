@@ -317,7 +317,20 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     if (std::getenv("VDO_BA_TILE_EPT")) soft_inc = VDO_TILE_THREADS * std::min(std::max(ept, 1), VDO_TILE_EPT);
   }
   std::vector<int32_t> cposes;
+  // HUB landmarks (ba_hub.hip): a STATIC point (no LandmarkMotionTernaryEdge) whose observations do not fit a tile - more than kHardSlots distinct pose vertices, more than 256
+  // per-pose pieces or more than VDO_TILE_INC edges - stays out of the tiles; a workgroup of its own walks its edges.  (A dynamic track beyond the envelope is still refused.)
+  std::vector<int32_t> hubs;
+  const bool hubs_off = std::getenv("VDO_BA_NO_HUBS") != nullptr;             // (the refusal of rounds 1-5, for the tests of the envelope's messages)
   for (const ChainInfo& ci : chains) {
+    if (!hubs_off && ci.npts == 1 && next_e[ci.head] == -1 && ci.nb == ci.ninc) {
+      chain_poses(ci, cposes);
+      std::vector<int32_t> u(cposes);
+      std::sort(u.begin(), u.end());
+      int pieces = 0;
+      for (size_t j = 0; j < u.size();) { size_t k = j; while (k < u.size() && u[k] == u[j]) ++k; pieces += (int)((k - j + VDO_TILE_EPT - 1) / VDO_TILE_EPT); j = k; }
+      const int distinct = (int)(std::unique(u.begin(), u.end()) - u.begin());
+      if (distinct > kHardSlots || pieces > VDO_TILE_THREADS || ci.ninc > VDO_TILE_INC) { hubs.push_back(ci.head); continue; }
+    }
     if (ci.npts > VDO_TILE_PTS || ci.ninc > VDO_TILE_INC) {
       delete ba;
       return set_error(VDO_ERR_UNSUPPORTED, "landmark track with %d points / %d incidences exceeds the tile capacity (%d / %d)",
@@ -402,6 +415,20 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   }
   close_tile();
   if (thr_overflow) { delete ba; return set_error(VDO_ERR_UNSUPPORTED, "a tile has more pose-slot pieces than threads"); }
+  // ---- hub landmarks: device points behind every tile's (each a chain of its own), one pose-major partial row ("slot") per edge behind every tile's slots
+  const int NPS_tiles = (int)tile_pose.size();
+  std::vector<int32_t> hub_off{0}, hub_point, hub_pose, hub_eb_old;
+  for (int32_t c : hubs) {
+    pt_new_of_old[c] = (int32_t)pt_old_of_new.size();
+    hub_point.push_back((int32_t)pt_old_of_new.size());
+    pt_old_of_new.push_back(c);
+    pt_prev_edge_new.push_back(-1);
+    chain_off.push_back((int32_t)pt_old_of_new.size());
+    for (int k = pb_off[c]; k < pb_off[c + 1]; ++k) { const int o = pb_idx[k]; hub_eb_old.push_back(o); hub_pose.push_back(g->eb_pose[o]); tile_pose.push_back(g->eb_pose[o]); }
+    hub_off.push_back((int32_t)hub_pose.size());
+  }
+  const int n_hubs = (int)hubs.size(), n_hub_edges = (int)hub_pose.size();
+  if (n_hubs) dense_tiles_ok = false;      // (the dense assembly walks tiles only: graphs with hubs are solved by the PCG)
   if (std::getenv("VDO_BA_TILE_STATS") && place_groups)
     std::fprintf(stderr, "vdo_ba_create: %zu tiles, busiest LDS bank of a 16-lane group-row of EdgeSE3PointXYZ edges: %.3f addresses on average (placement %d)\n",
                  tiles.size(), (double)place_ways / (double)place_groups, place_mode);
@@ -607,6 +634,22 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   UP(pr_pose, g->pr_pose, Npr); UP(pr_z, g->pr_z, 12 * (size_t)Npr); UP(pr_info, g->pr_info, 36 * (size_t)Npr);
   UP(ps_off, ps_off.data(), P + 1); UP(ps_idx, ps_idx.data(), NPS);
   UP(slot_dst, slot_dst.data(), slot_dst.size()); UP(pose_kind, pose_kind.data(), std::max(P, 1));
+  d.n_hubs = n_hubs; d.n_hub_edges = n_hub_edges;
+  std::vector<int32_t> hub_row(std::max(n_hub_edges, 1), 0);
+  std::vector<double> hub_z(3 * (size_t)std::max(n_hub_edges, 1), 0.0), hub_w(std::max(n_hub_edges, 1), 0.0);
+  if (n_hubs) {
+    for (int e = 0; e < n_hub_edges; ++e) {
+      hub_row[e] = slot_dst[(size_t)NPS_tiles + e];
+      const int o = hub_eb_old[e];
+      for (int k = 0; k < 3; ++k) hub_z[(size_t)k * n_hub_edges + e] = g->eb_z[(size_t)k * Eb + o];
+      hub_w[e] = g->eb_w[o];
+    }
+    UP(hub_off, hub_off.data(), hub_off.size()); UP(hub_point, hub_point.data(), hub_point.size()); UP(hub_pose, hub_pose.data(), hub_pose.size());
+    UP(hub_row, hub_row.data(), (size_t)n_hub_edges); UP(hub_z, hub_z.data(), 3 * (size_t)n_hub_edges); UP(hub_w, hub_w.data(), (size_t)n_hub_edges);
+    const double* Zh = nullptr;
+    UP(hub_we, Zh, (size_t)n_hub_edges); UP(hub_chi, Zh, 2 * (size_t)n_hubs);
+    ba->hub_eb_old = hub_eb_old;
+  }
   d.ps_stride = ps_stride;
   UP(pe_off, pe_off.data(), P + 1); UP(pe_idx, pe_idx.data(), pe_idx.size());
   UP(pr_off, pr_off.data(), P + 1); UP(pr_idx, pr_idx.data(), pr_idx.size());
@@ -753,7 +796,7 @@ extern "C" int vdo_ba_profile_linearize(vdo_ba* ba, int repeat, float ms[2], int
     dims[0] = d.n_tiles; dims[1] = d.NPS; dims[2] = d.ps_stride; dims[3] = d.max_slots;
     dims[4] = 4 + (d.eb_zf ? 12 : 24) + (d.eb_w ? 8 : 0);
     dims[5] = 8 + (d.et_z ? 24 : 0) + (d.et_w ? 8 : 0);
-    dims[6] = d.Eb; dims[7] = 0;
+    dims[6] = d.Eb; dims[7] = d.n_hubs;
   }
   ba->lin_current = true;
   return sync_check(ba, "vdo_ba_profile_linearize");
@@ -793,7 +836,7 @@ extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
   // vdo_ba_set_estimates the stored Hpp / bp / Hll / Finc belong to an older estimate and the expansion would mix the two: re-linearise
   // first, so that what comes back is always one self-consistent system at the current estimate.
   if (!ba->lin_current) { launch_linearize(ba->d, s, ba->red); ba->lin_current = true; }
-  std::vector<double> hll, bl, oll, binc;
+  std::vector<double> hll, bl, oll, binc, hub_binc;
   D2H(out->Hpp, d.Hpp, sizeof(double) * 36 * (size_t)d.P);
   D2H(out->bp, d.bp, sizeof(double) * 6 * (size_t)d.P);
   D2H(out->Hpp_ep, d.Hpp_ep, sizeof(double) * 36 * (size_t)d.Ep);
@@ -807,6 +850,13 @@ extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
       ba->allocs.push_back((void*)ba->d.Binc);
     }
     launch_expand_binc(ba->d, s);
+    if (d.n_hub_edges && out->Hpl_eb) {                    // the hub landmarks' edges (ba_hub.hip)
+      double* hb = (double*)ba_device_alloc(ba, sizeof(double) * 18 * (size_t)d.n_hub_edges);
+      if (!hb) return set_error(VDO_ERR_OOM, "hipMalloc(hub blocks) failed");
+      launch_hub_expand_binc(ba->d, hb, s);
+      hub_binc.resize(18 * (size_t)d.n_hub_edges);
+      D2H(hub_binc.data(), hb, sizeof(double) * hub_binc.size());
+    }
     binc.resize(18 * (size_t)d.Ninc);
     D2H(binc.data(), ba->d.Binc, sizeof(double) * binc.size());
   }
@@ -818,8 +868,10 @@ extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
   if (out->bl) for (int l = 0; l < d.L; ++l) std::memcpy(out->bl + 3 * (size_t)ba->pt_old_of_new[l], bl.data() + 3 * (size_t)l, 24);
   if (out->Hll_et)
     for (size_t e = 0; e < Et; ++e) for (int i = 0; i < 9; ++i) out->Hll_et[i * Et + ba->et_old_of_new[e]] = oll[9 * e + i];
-  if (out->Hpl_eb)
+  if (out->Hpl_eb) {
     for (size_t e = 0; e < Ebp; ++e) { if (ba->eb_old_of_new[e] < 0) continue; for (int i = 0; i < 18; ++i) out->Hpl_eb[i * Eb + ba->eb_old_of_new[e]] = binc[i * N + ba->inc_of_eb[e]]; }
+    for (size_t e = 0; e < ba->hub_eb_old.size(); ++e) for (int i = 0; i < 18; ++i) out->Hpl_eb[i * Eb + ba->hub_eb_old[e]] = hub_binc[18 * e + i];      // (hub landmarks, ba_hub.hip)
+  }
   for (int rep = 0; rep < 2; ++rep) {
     double* dst = rep == 0 ? out->Hlp1_et : out->Hlp2_et;
     if (!dst) continue;

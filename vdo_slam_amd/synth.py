@@ -346,3 +346,24 @@ def make_flow2_problem(n: int = 1200, seed: int = 1, is_object: bool = False, ou
     return Flow2Problem(obs=obs, flow=f32(flow), depth=depth, K=KITTI_K, Twl=Twl, T0=f32(T0),
                         info_prior=0.5 if is_object else 0.3, max_iterations=200 if is_object else 100,
                         T_true=T_true)
+
+
+def with_hub_points(g: "BAGraph", n_hubs: int, seed: int = 0, sigma: float = 0.05) -> "BAGraph":
+    """g with `n_hubs` of its static points (never an end of a ternary edge) observed from EVERY camera: one more EdgeSE3PointXYZ from each camera that does not
+    see them yet (fp32-representable measurements, like the graphs the reference builds).  Beyond 256 cameras such a point no longer fits a tile of the batch
+    solver: a hub landmark (csrc/ba_hub.hip)."""
+    import dataclasses
+    rng = np.random.default_rng(seed)
+    dyn = np.zeros(g.n_point, bool); dyn[g.et_p1] = True; dyn[g.et_p2] = True
+    sta = np.nonzero(~dyn)[0]
+    pick = sta[:: max(1, len(sta) // n_hubs)][:n_hubs]
+    seen = set(zip(g.eb_pose.tolist(), g.eb_point.tolist()))
+    ep, el, ez = [], [], []
+    for l in pick:
+        for c in range(g.n_cam):
+            if (int(c), int(l)) in seen:
+                continue
+            R = g.pose[c, :9].reshape(3, 3); t = g.pose[c, 9:]
+            ep.append(c); el.append(l); ez.append(np.float32(R.T @ (g.point[l] - t) + rng.normal(0, sigma, 3)).astype(np.float64))
+    return dataclasses.replace(g, eb_pose=np.concatenate([g.eb_pose, np.array(ep, np.int32)]), eb_point=np.concatenate([g.eb_point, np.array(el, np.int32)]),
+                               eb_z=np.ascontiguousarray(np.concatenate([g.eb_z, np.array(ez).T], 1)), eb_w=np.concatenate([g.eb_w, np.full(len(ep), g.eb_w[0])]))
