@@ -611,3 +611,32 @@ def test_hub_landmarks_can_be_switched_off_and_the_dense_solver_refuses_them(ctx
     monkeypatch.setenv("VDO_BA_NO_HUBS", "1")
     with pytest.raises(K.VdoError, match="distinct pose vertices"):
         BatchBA(ctx, g)
+
+
+def test_hub_landmarks_with_wide_partial_rows_and_dynamic_tracks(ctx, oracle, monkeypatch):
+    """Hub landmarks next to dynamic tracks, with the 32-sums-per-row form of the partials forced (VDO_BA_WIDE_PARTIALS=1: a hub edge's row then has a ternary half of
+    zeros): every block of the linearisation and the Levenberg trajectory of the oracle, on a 300-frame graph with three points seen from every camera."""
+    from vdo_slam_amd.ba import BatchBA
+    monkeypatch.setenv("VDO_BA_WIDE_PARTIALS", "1")
+    g = synth.with_hub_points(synth.make_ba_graph(300, 900, 2, 40, seed=21), 3, seed=4)
+    ba = BatchBA(ctx, g)
+    assert ba.dims()["hubs"] == 3 and ba.dims()["ps_stride"] == 32
+    ba.linearize()
+    S = ba.system()
+    R = _oracle_system(oracle, g)
+    for name in BLOCKS:
+        a, b = getattr(S, name), getattr(R, name)
+        if b.size:
+            assert np.abs(a - b).max() <= block_tol(name) * _scale(name, R) + 1e-300, (name, np.abs(a - b).max() / max(_scale(name, R), 1e-300))
+    assert abs(S.chi2 - R.chi2) <= 1e-12 * abs(R.chi2) and abs(S.robust_chi2 - R.robust_chi2) <= 1e-12 * abs(R.robust_chi2)
+    gc, keep = K.graph_to_c(g)
+    opt = K.LMOptionsC(4, -1.0, 0, 0, 0.0, 0)
+    so = K.LMStatsC(); po = np.zeros_like(g.pose); qo = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(po), K._dp(qo), C.byref(so)) == 0
+    st = ba.optimize(max_iterations=4, gain_threshold=-1.0)
+    assert (st.iterations, st.total_trials) == (so.iterations, so.total_trials)
+    assert abs(st.final_chi2 - so.final_chi2) <= 1e-6 * so.final_chi2
+    pose, pt = ba.estimates()
+    np.testing.assert_allclose(pose, po, rtol=0, atol=1e-4 * max(1.0, np.abs(po).max()))
+    np.testing.assert_allclose(pt, qo, rtol=0, atol=1e-4 * max(1.0, np.abs(qo).max()))
+    ba.close()
