@@ -21,6 +21,7 @@ struct vdo_ba {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   // permutations between the caller's numbering and the tile-major device numbering
   std::vector<int32_t> pt_old_of_new, pt_new_of_old;
+  double* hub_binc = nullptr;                               // [n_hub_edges][18] explicit blocks of the hub edges (vdo_ba_download_system), allocated on first use
   std::vector<int32_t> hub_eb_old;                          // original EdgeSE3PointXYZ id of every hub edge (ba_hub.hip)
   std::vector<int32_t> eb_old_of_new, et_old_of_new;        // (eb: by padded device entry, -1 where a block entry holds no edge)
   int n_eb = 0;                                             // EdgeSE3PointXYZ edges of the graph (the device's d.Eb counts padded block entries)

@@ -851,7 +851,8 @@ extern "C" int vdo_ba_download_system(vdo_ba* ba, vdo_ba_system* out) {
     }
     launch_expand_binc(ba->d, s);
     if (d.n_hub_edges && out->Hpl_eb) {                    // the hub landmarks' edges (ba_hub.hip)
-      double* hb = (double*)ba_device_alloc(ba, sizeof(double) * 18 * (size_t)d.n_hub_edges);
+      if (!ba->hub_binc) ba->hub_binc = (double*)ba_device_alloc(ba, sizeof(double) * 18 * (size_t)d.n_hub_edges);      // (kept with the handle, like Binc)
+      double* hb = ba->hub_binc;
       if (!hb) return set_error(VDO_ERR_OOM, "hipMalloc(hub blocks) failed");
       launch_hub_expand_binc(ba->d, hb, s);
       hub_binc.resize(18 * (size_t)d.n_hub_edges);
