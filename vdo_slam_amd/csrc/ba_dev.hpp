@@ -126,6 +126,10 @@ struct BADev {
   int32_t* flags = nullptr;                          // [0] factor failure [1] pcg state [2] pcg iterations [3] arrival counter of k_pcg_chain
   // multi-GPU shards: poses replicated, points + their edges owned by one rank.
   // Hpp | bp | red_chi are ONE allocation so that a linearisation needs a single all-reduce.
+  // SECOND SET of everything a linearisation writes (round 6, ba_lm.hip): the error evaluation of a Levenberg trial is a full linearisation at the trial estimate into this set -
+  // an accepted trial swaps the sets (lin_swap) and the next iteration has its system already; a rejected one leaves the current set alone.  NULL: not allocated (sharded handles).
+  double *Finc_alt = nullptr, *Hll_alt = nullptr, *bl_alt = nullptr, *Oll_alt = nullptr, *part_sums_alt = nullptr, *ep_blk_alt = nullptr, *Hpp_ep_alt = nullptr, *hub_we_alt = nullptr;
+  double* Hpp_alt = nullptr;             // the whole block Hpp | bp | red_chi | msum | qs of the second set
   int sharded = 0, shard_rank = 0;
   // HUB landmarks (round 6, ba_hub.hip): a STATIC point whose observations do not fit one tile (more than 256 distinct pose vertices / 256 per-pose pieces / 1 536 edges - a
   // point seen in 300+ frames) belongs to no tile.  One workgroup per hub walks its edges; every hub edge owns one pose-major partial row (its own "slot": tile_pose /
@@ -156,9 +160,18 @@ enum Scal { S_CHI2 = 0, S_RCHI2, S_MAXDIAG, S_RZ, S_PQ, S_RZ0, S_SCALE, S_RZNEW,
 // ---- ba_sweep.hip
 void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R);      // chi2 of estimate[which] -> scal
 void launch_schur_matvec_only(const BADev& d, hipStream_t s);                     // k_schur_tile<0> alone (vdo_ba_profile_schur)
-void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R, bool defer_exchange = false);      // build system at estimate[0] (+chi2)
+void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R, bool defer_exchange = false, int which = 0);      // build system at estimate[which] (+chi2)
+// the two sets of linearisation outputs change places (host copy of the descriptor: the kernels take it by value)
+inline void lin_swap(BADev& d) {
+  auto sw = [](double*& a, double*& b) { double* t = a; a = b; b = t; };
+  sw(d.Finc, d.Finc_alt); sw(d.Hll, d.Hll_alt); sw(d.bl, d.bl_alt); sw(d.Oll, d.Oll_alt); sw(d.part_sums, d.part_sums_alt); sw(d.ep_blk, d.ep_blk_alt); sw(d.Hpp_ep, d.Hpp_ep_alt);
+  sw(d.hub_we, d.hub_we_alt);
+  const int64_t P = d.P;
+  sw(d.Hpp, d.Hpp_alt);
+  d.bp = d.Hpp + 36 * P; d.red_chi = d.bp + 6 * P; d.msum = d.red_chi + 4; d.qs = d.msum + 21 * P + 1;
+}
 void launch_linearize_finish(const BADev& d, hipStream_t s);                                               // the chi2 of a linearisation whose exchange was deferred
-void launch_sweep_only(const BADev& d, hipStream_t s);             // just the K18 tile sweep kernel (bench)
+void launch_sweep_only(const BADev& d, hipStream_t s, int which = 0);             // just the K18 tile sweep kernel (bench)
 // ---- ba_solve.hip
 void launch_max_diag(const BADev& d, hipStream_t s, const Reducer& R);
 // landmark-chain LDL^T + inverse blocks + block-Jacobi + pose-chain factorisation, and the reduced right-hand side qs (beside it on `side` if given)

@@ -35,6 +35,7 @@ struct vdo_ba {
   int last_solver = 0;            // 2 PCG, 3 dense: what the last trial used
   int pcg_it = 0, pcg_parity = 0, pcg_maxit = 0, pcg_last = 0;      // (pcg_last: iterations the previous solve of this run needed)      // state of the PCG solve of the trial in flight (ba_lm.hip solve_trial / solve_trial_finish)
   double pcg_tol2 = 0;
+  bool alt_failed = false;             // the second set of linearisation buffers could not be allocated (ba_lm.hip ensure_alt)
   bool dense_pending = false;          // the trial in flight was solved by the dense factorisation (solve_trial_finish reads its failure flag)
   bool lin_exchange_pending = false;   // sharded: the linearisation in front of the next trial deferred its all-reduce to that trial's launch_factor_and_rhs
   bool lin_current = false;       // the blocks on the device (Hpp, bp, Hll, bl, Finc) are the linearisation AT estimate[0]: set by vdo_ba_linearize,

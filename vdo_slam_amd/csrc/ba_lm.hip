@@ -33,6 +33,32 @@ int fetch(vdo_ba* ba) {
   return sync_check(ba, "LM scalar readback");
 }
 
+// the second set of linearisation outputs (ba_dev.hpp lin_swap), allocated on the first single-GPU optimisation of the handle; false: no memory for it (the caller keeps the
+// error-evaluation pass of rounds 1-5)
+bool ensure_alt(vdo_ba* ba) {
+  BADev& d = ba->d;
+  if (d.Hpp_alt) return true;
+  if (ba->alt_failed) return false;
+  hipStream_t s = ba->ctx->stream;
+  auto get = [&](double*& p, size_t n) {
+    if (n == 0) { p = nullptr; return true; }
+    p = (double*)ba_device_alloc(ba, n * sizeof(double));
+    if (!p) return false;
+    hipMemsetAsync(p, 0, n * sizeof(double), s);
+    return true;
+  };
+  const size_t P = (size_t)d.P, L = (size_t)d.L, Et = (size_t)d.Et;
+  const bool ok = get(d.Finc_alt, std::max<size_t>((size_t)d.Eb, VDO_TILE_THREADS) + Et + 1) && get(d.Hll_alt, L) && get(d.bl_alt, 3 * L) && get(d.Oll_alt, 9 * Et) &&
+                  get(d.part_sums_alt, (size_t)d.ps_stride * (size_t)std::max(d.NPS, 1)) && get(d.ep_blk_alt, 84 * (size_t)std::max(d.Ep + d.Npr, 1)) && get(d.Hpp_ep_alt, 36 * (size_t)d.Ep) &&
+                  get(d.hub_we_alt, (size_t)d.n_hub_edges) && get(d.Hpp_alt, 69 * P + 6);
+  if (!ok) {
+    (void)hipGetLastError();
+    d.Finc_alt = d.Hll_alt = d.bl_alt = d.Oll_alt = d.part_sums_alt = d.ep_blk_alt = d.Hpp_ep_alt = d.hub_we_alt = d.Hpp_alt = nullptr;      // (what was allocated goes with the handle)
+    ba->alt_failed = true;
+  }
+  return ok;
+}
+
 // computeActiveErrors + activeRobustChi2 at estimate[which]
 int robust_chi2(vdo_ba* ba, int which, double* out) {
   launch_errors(ba->d, which, ba->ctx->stream, ba->red);
@@ -175,6 +201,9 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
 #define CK(x) do { rc = (x); if (rc != VDO_OK) return rc; } while (0)
   CK(robust_chi2(ba, 0, &last_err_chi));
   st->initial_chi2 = last_err_chi;
+  static const bool spec_off = std::getenv("VDO_BA_NO_SPEC_LIN") != nullptr;      // (A/B switch: the error-evaluation pass of rounds 1-5)
+  const bool use_spec = !d.sharded && !spec_off && ensure_alt(ba);
+  bool spec_lin = false;          // the system at estimate[0] is already on the device (left there by the accepted trial of the last iteration)
   int it = 0;
   for (; it < opt->max_iterations && !forceStop && ok; ++it) {
     double t0 = now_ms();
@@ -182,12 +211,14 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
     // sharded, lambda known (every iteration but the first): the linearisation's all-reduce is left to the first trial's, which follows at once (one exchange instead of two)
     static const bool merge_off = std::getenv("VDO_BA_NO_EXCHANGE_MERGE") != nullptr;    // (A/B switch)
     const bool defer = d.sharded && it > 0 && !sync_each && !merge_off;
-    launch_linearize(d, s, ba->red, defer);          // errors + buildSystem in one sweep (same estimate); its chi2 stays in S_LIN_RCHI2
-    ba->lin_exchange_pending = defer;
+    // (spec_lin: the accepted trial of the last iteration was evaluated by a LINEARISATION at its estimate into the second set, and the sets changed places: the system is there)
+    if (!spec_lin) launch_linearize(d, s, ba->red, defer);          // errors + buildSystem in one sweep (same estimate); its chi2 stays in S_LIN_RCHI2
+    ba->lin_exchange_pending = defer && !spec_lin;
     // The chi2 of the linearisation is first NEEDED when the first trial is judged: it is read back with that trial's scalars (one host round
     // trip less per iteration).  Only the first iteration needs something before its first trial: the largest diagonal entry (lambda).
     bool have_lin = false;
     double currentChi = 0, tempChi = 0, iniChi = 0;
+    if (spec_lin) { currentChi = tempChi = iniChi = last_err_chi; have_lin = true; spec_lin = false; }      // (the chi2 of that linearisation = the accepted trial's, same kernels on the same estimate)
     if (it == 0) {
       launch_max_diag(d, s, ba->red);
       CK(fetch(ba));
@@ -209,14 +240,23 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
       const bool ortho = (++ba->oplus_calls > 1000);
       if (ortho) ba->oplus_calls = 0;
       launch_backsub_update(d, lambda, ortho, s);      // update() into the trial buffers (push/pop = keep [0])
-      launch_errors(d, 1, s, ba->red);
+      // The trial's errors.  Single GPU (round 6): by a full linearisation AT THE TRIAL ESTIMATE into the second set of buffers - its chi2 is the error evaluation's, bit for
+      // bit (same kernels, same estimate), and an accepted trial - the rule on these graphs - has the next iteration's system already: the separate error pass (a sweep over
+      // every edge + the pose-pose edges + a reduction per trial) is gone from every accepted iteration; a rejected trial paid a linearisation for an error evaluation.
+      // (not in the last iteration the caller asked for: nothing would read that system)
+      const bool spec_now = use_spec && it + 1 < opt->max_iterations;
+      auto evaluate_trial = [&]() {
+        if (spec_now) { BADev da = d; lin_swap(da); launch_linearize(da, s, ba->red, false, 1); }
+        else launch_errors(d, 1, s, ba->red);
+      };
+      evaluate_trial();
       CK(fetch(ba));
       if (!have_lin) { currentChi = iniChi = ba->h_scal[S_LIN_RCHI2]; have_lin = true; }
       if (pending) {
         CK(solve_trial_finish(ba, lambda, opt, &ok2, &pcg_it, &again));
         if (again) {                                   // (the first batch of PCG iterations had not converged: update and errors once more, from the converged x)
           launch_backsub_update(d, lambda, ortho, s);
-          launch_errors(d, 1, s, ba->red);
+          evaluate_trial();
           CK(fetch(ba));
         }
       }
@@ -235,10 +275,12 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
         lambda *= sf; ni = 2; currentChi = tempChi;
         std::swap(d.pose[0], d.pose[1]);               // discardTop(): accept the trial
         std::swap(d.point[0], d.point[1]);
+        if (spec_now) { lin_swap(d); spec_lin = true; }   // ... and its linearisation becomes the current one
         accepted = true;
       } else {
         lambda *= ni; ni *= 2;                          // pop(): estimate[0] untouched
         accepted = false;
+        spec_lin = false;
       }
       ++qmax;
       ++st->total_trials;

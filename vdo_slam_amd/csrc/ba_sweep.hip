@@ -534,19 +534,19 @@ void launch_errors(const BADev& d, int which, hipStream_t s, const Reducer& R) {
 // the chi2 of a linearisation whose exchange was deferred (launch_linearize), behind that exchange
 void launch_linearize_finish(const BADev& d, hipStream_t s) { hipLaunchKernelGGL(k_reduce_chi, dim3(1), dim3(256), 0, s, d, 2 + 8); }
 
-void launch_sweep_only(const BADev& d, hipStream_t s) {
+void launch_sweep_only(const BADev& d, hipStream_t s, int which) {
   const size_t lds = sweep_lds_doubles(d.max_slots, true, d.ps_stride) * sizeof(double);
-  launch_hub_sweep(d, 0, true, s);
+  launch_hub_sweep(d, which, true, s);
   if (!d.n_tiles) return;
-  if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<true, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<true, true>, lds), s, d, 0);
-  else hipLaunchKernelGGL((k_sweep_tile<true, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<true, false>, lds), s, d, 0);
+  if (d.eb_zf && !d.eb_w) hipLaunchKernelGGL((k_sweep_tile<true, true>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<true, true>, lds), s, d, which);
+  else hipLaunchKernelGGL((k_sweep_tile<true, false>), dim3(d.n_tiles), dim3(VDO_TILE_THREADS), raise_lds(k_sweep_tile<true, false>, lds), s, d, which);
 }
 
 // defer_exchange (sharded solves): leave the partial Hpp | bp | chi2 of this rank where they are - the caller's launch_factor_and_rhs, which follows at once, sends them
 // with the block-Jacobi sums and the reduced right-hand side in ONE all-reduce (its tile passes read nothing of the pose blocks) and finishes the chi2 behind it.
-void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R, bool defer_exchange) {
-  launch_posepose(d, 0, true, ep_chi_buf(d), s);           // per-edge blocks -> ep_blk (independent of the sweep)
-  launch_sweep_only(d, s);
+void launch_linearize(const BADev& d, hipStream_t s, const Reducer& R, bool defer_exchange, int which) {
+  launch_posepose(d, which, true, ep_chi_buf(d), s);       // per-edge blocks -> ep_blk (independent of the sweep)
+  launch_sweep_only(d, s, which);
   // pose blocks = landmark-side sums + pose-pose blocks.  Shards: the (replicated) pose-pose terms are added by rank 0 only, the
   // all-reduce of Hpp | bp | chi2 then hands every rank the same bits.
   const int add_pp = (!d.sharded || d.shard_rank == 0) ? 1 : 0;
