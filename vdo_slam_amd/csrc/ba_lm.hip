@@ -199,8 +199,11 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
   bool forceStop = false, ok = true;
   double action_lastChi = 0, chi2_check = 0, last_err_chi = 0;
 #define CK(x) do { rc = (x); if (rc != VDO_OK) return rc; } while (0)
-  CK(robust_chi2(ba, 0, &last_err_chi));
-  st->initial_chi2 = last_err_chi;
+  // The chi2 of the start estimate is the chi2 of the first linearisation (the same kernels on the same estimate: the same bits, what the loop relies on for its accepted
+  // trials): it is read with the first iteration's scalars instead of by an error evaluation + host round trip of its own (round 6; VDO_BA_LM_RECHECK=1: as before).
+  static const bool chi_passes = std::getenv("VDO_BA_LM_RECHECK") != nullptr;
+  if (chi_passes || opt->max_iterations <= 0) { CK(robust_chi2(ba, 0, &last_err_chi)); st->initial_chi2 = last_err_chi; }
+  bool last_accepted = false;      // the last trial that ran was accepted: estimate[0] is its estimate, last_err_chi its robust chi2
   static const bool spec_off = std::getenv("VDO_BA_NO_SPEC_LIN") != nullptr;      // (A/B switch: the error-evaluation pass of rounds 1-5)
   const bool use_spec = !d.sharded && !spec_off && ensure_alt(ba);
   bool spec_lin = false;          // the system at estimate[0] is already on the device (left there by the accepted trial of the last iteration)
@@ -224,6 +227,7 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
       CK(fetch(ba));
       lambda = tau * ba->h_scal[S_MAXDIAG]; ni = 2; nBad = 0;
       last_err_chi = currentChi = tempChi = iniChi = ba->h_scal[S_LIN_RCHI2];
+      if (!(chi_passes || opt->max_iterations <= 0)) st->initial_chi2 = last_err_chi;
       have_lin = true;
     }
     if (sync_each && !have_lin) { CK(fetch(ba)); last_err_chi = currentChi = tempChi = iniChi = ba->h_scal[S_LIN_RCHI2]; have_lin = true; }
@@ -300,7 +304,8 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
     // holds them) - so the pass and its host round trip are spent only after an iteration whose last trial was rejected
     // (VDO_BA_LM_RECHECK=1: always, as before).
     const bool recheck = std::getenv("VDO_BA_LM_RECHECK") != nullptr;
-    if ((opt->verbose || opt->gain_threshold >= 0) && (recheck || !accepted)) CK(robust_chi2(ba, 0, &last_err_chi));
+    if ((opt->verbose || opt->gain_threshold >= 0) && (recheck || !accepted)) { CK(robust_chi2(ba, 0, &last_err_chi)); last_accepted = true; }      // (last_err_chi is estimate[0]'s again)
+    else last_accepted = accepted;
     if (opt->verbose)
       std::fprintf(stderr, "iteration= %d\t chi2= %.6f\t lambda= %.6g\t levenbergIter= %d\n", it, last_err_chi, lambda, qmax);
     if (it < VDO_LM_MAX_TRACE) { st->chi2_trace[it] = last_err_chi; st->trials_trace[it] = qmax; }
@@ -315,7 +320,9 @@ extern "C" int vdo_ba_optimize(vdo_ba* ba, const vdo_lm_options* opt, vdo_lm_sta
   }
   st->iterations = it;
   st->final_lambda = lambda;
-  CK(robust_chi2(ba, 0, &st->final_chi2));
+  // ... and the chi2 of the final estimate is the last accepted trial's, when the run ended on one
+  if (last_accepted && it > 0 && !chi_passes) st->final_chi2 = last_err_chi;
+  else CK(robust_chi2(ba, 0, &st->final_chi2));
   st->ms_total = now_ms() - t_begin;
 #undef CK
   return VDO_OK;
