@@ -136,9 +136,9 @@ typedef struct vdo_lm_stats {
 typedef struct vdo_ba vdo_ba;
 /* Uploads the graph to HBM (SoA, resident until destroy) and builds the chain structure.
  * Limits (g2o has none; VDO_ERR_UNSUPPORTED names the offending track): a DYNAMIC landmark track - a chain of points linked by
- * LandmarkMotionTernaryEdges - is processed by ONE workgroup and must fit its tile: <= 256 points, <= 1536 edge incidences, <= 256 distinct
- * pose vertices (cameras + motions), and sum over those poses of ceil(observations / 6) <= 256: it may run over up to 128 frames (its
- * points bring a camera and a motion vertex each).  A STATIC point has no such limit since round 6: up to those figures it lives in a tile
+ * LandmarkMotionTernaryEdges - is processed by ONE workgroup and must fit its tile: <= 256 points, <= 1536 edge incidences, <= 512 distinct
+ * pose vertices (cameras + motions), and sum over those poses of ceil(observations / 6) <= 256: it may run over up to 256 frames (its
+ * points bring a camera and a motion vertex each; 128 until round 6).  A STATIC point has no such limit since round 6: up to 256 pose vertices it lives in a tile
  * (a graph that holds such a track pays with fewer resident workgroups per CU - the tile kernels' LDS grows with the pose slots of the
  * largest tile - and has no dense solver beyond ~200 slots); beyond them it becomes a hub landmark with a workgroup of its own
  * (csrc/ba_hub.hip; such graphs are solved by the PCG, the dense solver refuses them). */

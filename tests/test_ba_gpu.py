@@ -644,3 +644,33 @@ def test_hub_landmarks_with_wide_partial_rows_and_dynamic_tracks(ctx, oracle, mo
     np.testing.assert_allclose(pose, po, rtol=0, atol=1e-4 * max(1.0, np.abs(po).max()))
     np.testing.assert_allclose(pt, qo, rtol=0, atol=1e-4 * max(1.0, np.abs(qo).max()))
     ba.close()
+
+
+@pytest.mark.parametrize("frames", [160, 250])
+def test_dynamic_tracks_over_more_than_128_frames(ctx, oracle, frames):
+    """Round 6: an object point followed through 160 / 250 frames - a chain of that many points linked by LandmarkMotionTernaryEdges touches 2 n - 1 pose vertices (its
+    cameras and its motions): more than the 256 slots a tile held until round 5 (n <= 128).  The tile kernels stage slots in rounds of 256 now (kHardSlots 512: chains of up
+    to 256 points): every block of the linearisation and the Levenberg trajectory of the oracle."""
+    from vdo_slam_amd.ba import BatchBA
+    g = synth.make_ba_graph(frames, 600, 2, 12, seed=31, long_dyn_tracks=3)
+    ba = BatchBA(ctx, g)
+    assert ba.dims()["max_slots"] >= 2 * frames - 1 and ba.dims()["hubs"] == 0
+    ba.linearize()
+    S = ba.system()
+    R = _oracle_system(oracle, g)
+    for name in BLOCKS:
+        a, b = getattr(S, name), getattr(R, name)
+        if b.size:
+            assert np.abs(a - b).max() <= block_tol(name) * _scale(name, R) + 1e-300, (name, np.abs(a - b).max() / max(_scale(name, R), 1e-300))
+    assert abs(S.chi2 - R.chi2) <= 1e-12 * abs(R.chi2) and abs(S.robust_chi2 - R.robust_chi2) <= 1e-12 * abs(R.robust_chi2)
+    gc, keep = K.graph_to_c(g)
+    opt = K.LMOptionsC(4, -1.0, 0, 0, 0.0, 0)
+    so = K.LMStatsC(); po = np.zeros_like(g.pose); qo = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(po), K._dp(qo), C.byref(so)) == 0
+    st = ba.optimize(max_iterations=4, gain_threshold=-1.0)
+    assert (st.iterations, st.total_trials) == (so.iterations, so.total_trials)
+    assert abs(st.final_chi2 - so.final_chi2) <= 1e-6 * so.final_chi2
+    pose, pt = ba.estimates()
+    np.testing.assert_allclose(pose, po, rtol=0, atol=1e-4 * max(1.0, np.abs(po).max()))
+    np.testing.assert_allclose(pt, qo, rtol=0, atol=1e-4 * max(1.0, np.abs(qo).max()))
+    ba.close()

@@ -307,7 +307,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_precond_tile(BADev d, int 
   };
   asm volatile("" : "+v"(my_pose));         // (keeps the request where it was made: the compiler would sink it into the branch, behind a wait for every other request)
   if (tid < nslot) stage_slot(tid, my_pose);
-  for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
+  for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) { stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]); sdst[sidx] = d.slot_dst[T.slot_begin + sidx]; }      // (a tile of more than 256 slots: one long dynamic track)
   sdst[my_slot] = my_dst;
   // what hangs on the keys: is the point a chain of its own, and its scalar factor
   unsigned char sgl[VDO_TILE_EPT];
@@ -1117,7 +1117,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS, 4) void k_schur_tile(BADev d, con
   };
   asm volatile("" : "+v"(my_pose));         // (keeps the request where it was made: the compiler would sink it into the branch, behind a wait for every other request)
   if (tid < nslot) stage_slot(tid, my_pose);
-  for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]);
+  for (int sidx = tid + VDO_TILE_THREADS; sidx < nslot; sidx += VDO_TILE_THREADS) { stage_slot(sidx, d.tile_pose[T.slot_begin + sidx]); if (MODE != 2) sdst[sidx] = d.slot_dst[T.slot_begin + sidx]; }
   if (MODE != 2) sdst[my_slot] = my_dst;
   const double cg = d.dscal[cp0];                          // (meaningful for a chain of one point)
   D3 cbl{0.0, 0.0, 0.0};

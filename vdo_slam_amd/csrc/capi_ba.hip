@@ -48,8 +48,9 @@ int upload(vdo_ba* ba, T** dst, const T* src, size_t n, hipStream_t s) {
 }
 
 constexpr int kSoftSlots = 64;     // normal tiles stay below this many pose slots
-constexpr int kHardSlots = 256;    // a single long track may use up to this many: one thread per slot stages its pose, and 256 slots are 75 KB of the sweep's LDS (two workgroups per
-                                   // CU instead of four - paid only by graphs that hold such a track).  Rounds 1-4: 100 - a static landmark seen in all 153 frames of KITTI-0000 was refused.
+constexpr int kHardSlots = 512;    // a single long DYNAMIC track may use up to this many (a chain of n points touches n cameras + n - 1 motion vertices: n <= 256 = VDO_TILE_PTS): the tile kernels
+                                   // stage slots in rounds of 256, and 511 slots are ~140 KB of LDS (ONE workgroup per CU - paid only by graphs that hold such a track).  Rounds 1-4: 100; round 5: 256.
+constexpr int kStaticSlots = 256;  // a STATIC point beyond this many pose vertices is a hub landmark (ba_hub.hip: no LDS at all) instead of a tile of its own
 
 }  // namespace
 
@@ -317,7 +318,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     if (std::getenv("VDO_BA_TILE_EPT")) soft_inc = VDO_TILE_THREADS * std::min(std::max(ept, 1), VDO_TILE_EPT);
   }
   std::vector<int32_t> cposes;
-  // HUB landmarks (ba_hub.hip): a STATIC point (no LandmarkMotionTernaryEdge) whose observations do not fit a tile - more than kHardSlots distinct pose vertices, more than 256
+  // HUB landmarks (ba_hub.hip): a STATIC point (no LandmarkMotionTernaryEdge) whose observations do not fit a tile - more than kStaticSlots distinct pose vertices, more than 256
   // per-pose pieces or more than VDO_TILE_INC edges - stays out of the tiles; a workgroup of its own walks its edges.  (A dynamic track beyond the envelope is still refused.)
   std::vector<int32_t> hubs;
   const bool hubs_off = std::getenv("VDO_BA_NO_HUBS") != nullptr;             // (the refusal of rounds 1-5, for the tests of the envelope's messages)
@@ -329,7 +330,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       int pieces = 0;
       for (size_t j = 0; j < u.size();) { size_t k = j; while (k < u.size() && u[k] == u[j]) ++k; pieces += (int)((k - j + VDO_TILE_EPT - 1) / VDO_TILE_EPT); j = k; }
       const int distinct = (int)(std::unique(u.begin(), u.end()) - u.begin());
-      if (distinct > kHardSlots || pieces > VDO_TILE_THREADS || ci.ninc > VDO_TILE_INC) { hubs.push_back(ci.head); continue; }
+      if (distinct > kStaticSlots || pieces > VDO_TILE_THREADS || ci.ninc > VDO_TILE_INC) { hubs.push_back(ci.head); continue; }
     }
     if (ci.npts > VDO_TILE_PTS || ci.ninc > VDO_TILE_INC) {
       delete ba;
@@ -343,10 +344,11 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       std::vector<int32_t> u(cposes);
       std::sort(u.begin(), u.end());
       const int distinct = (int)(std::unique(u.begin(), u.end()) - u.begin());
-      if (distinct > kHardSlots) {
+      const int slot_limit = (ci.npts == 1 && next_e[ci.head] == -1) ? kStaticSlots : kHardSlots;      // (a static point gets here only with VDO_BA_NO_HUBS)
+      if (distinct > slot_limit) {
         delete ba;
         return set_error(VDO_ERR_UNSUPPORTED, "landmark track of %d point(s) / %d incidences touches %d distinct pose vertices (limit %d per track)",
-                         ci.npts, ci.ninc, distinct, kHardSlots);
+                         ci.npts, ci.ninc, distinct, slot_limit);
       }
       chain_eb_poses.clear();
       for (int c = ci.head;;) {

@@ -130,8 +130,9 @@ def _track_lengths(rng, n, mean_extra=3.0, min_len=3):
 def make_ba_graph(n_frames: int = 40, n_static: int = 2000, n_objects: int = 3,
                   dyn_tracks_per_object: int = 150, seed: int = 1,
                   outlier_frac: float = 0.05, meas_sigma: float = 0.05,
-                  init_sigma_t: float = 0.02, init_sigma_r: float = 0.005) -> BAGraph:
-    """KITTI-shaped synthetic dynamic-SLAM factor graph (SURVEY.md §8d "Batch graphs")."""
+                  init_sigma_t: float = 0.02, init_sigma_r: float = 0.005, long_dyn_tracks: int = 0) -> BAGraph:
+    """KITTI-shaped synthetic dynamic-SLAM factor graph (SURVEY.md §8d "Batch graphs").  long_dyn_tracks: that many dynamic tracks run over ALL frames
+    (an object point followed through the whole sequence: the longest chain the batch solver's tiles have to hold)."""
     rng = np.random.default_rng(seed)
     F = n_frames
     # ---- cameras: forward 0.8 m/frame, sinusoidal yaw <= 0.01 rad/frame
@@ -201,6 +202,8 @@ def make_ba_graph(n_frames: int = 40, n_static: int = 2000, n_objects: int = 3,
     d_obj = np.repeat(np.arange(K), dyn_tracks_per_object)
     d_len = np.minimum(_track_lengths(rng, Td), F)
     d_start = rng.integers(0, np.maximum(F - d_len + 1, 1))
+    if long_dyn_tracks:
+        d_len[:long_dyn_tracks] = F; d_start[:long_dyn_tracks] = 0
     body = np.stack([rng.uniform(-1, 1, Td), rng.uniform(-0.8, 0.8, Td), rng.uniform(-2, 2, Td)], -1)
     reps = d_len
     tr_idx = np.repeat(np.arange(Td), reps)
