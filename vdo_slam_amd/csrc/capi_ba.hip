@@ -126,7 +126,15 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     chains.push_back(ci);
   }
   if (visited != L) return set_error(VDO_ERR_UNSUPPORTED, "ternary edges form a cycle");
-  std::stable_sort(chains.begin(), chains.end(), [](const ChainInfo& a, const ChainInfo& b) { return a.key < b.key; });
+  // Order of the tracks = order of the tiles' contents: by first observing frame; round 6: the DYNAMIC tracks (chains of several points) first, among themselves by first frame, then
+  // the static points.  A dynamic track of n points brings 2 n - 1 pose vertices (its cameras and its motions) - more than the 64 slots a tile is closed at - and its neighbours in
+  // time on the same object share nearly all of them; interleaved with the static points (rounds 1-5) every such track closed its tile behind itself and sat there alone: one lane
+  // of 256 walking its chain in the solver's kernels, 70 points of 256 (the OMD-shaped graph: 11 k tiles of one track each).  VDO_BA_MIXED_ORDER=1: the old order (A/B).
+  static const bool mixed_order = std::getenv("VDO_BA_MIXED_ORDER") != nullptr;
+  std::stable_sort(chains.begin(), chains.end(), [](const ChainInfo& a, const ChainInfo& b) {
+    if (!mixed_order) { const bool da = a.npts > 1, db = b.npts > 1; if (da != db) return da; }
+    return a.key < b.key;
+  });
 
   // ---- greedy tiling
   vdo_ba* ba = new vdo_ba();
@@ -321,6 +329,17 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     if (std::getenv("VDO_BA_TILE_EPT")) soft_inc = VDO_TILE_THREADS * std::min(std::max(ept, 1), VDO_TILE_EPT);
   }
   std::vector<int32_t> cposes;
+  bool cur_dyn_only = true;                        // the open tile holds dynamic tracks only
+  int dyn_slot_cap = 0;                            // distinct pose vertices of the graph's largest dynamic track
+  if (!mixed_order)
+    for (const ChainInfo& ci : chains) {
+      if (ci.npts <= 1) break;                     // (dynamic tracks come first)
+      chain_poses(ci, cposes);
+      std::sort(cposes.begin(), cposes.end());
+      dyn_slot_cap = std::max(dyn_slot_cap, (int)(std::unique(cposes.begin(), cposes.end()) - cposes.begin()));
+    }
+  // (packing beyond the largest track's slot count - 125 / 150 / 200 % probed in round 6 - gains nothing on the OMD-shaped graph and costs the sweep of the roofline graph 6 %:
+  //  every tile kernel's LDS follows the largest tile)
   // HUB landmarks (ba_hub.hip): a STATIC point (no LandmarkMotionTernaryEdge) whose observations do not fit a tile - more than kStaticSlots distinct pose vertices, more than 256
   // per-pose pieces or more than VDO_TILE_INC edges - stays out of the tiles; a workgroup of its own walks its edges.  (A dynamic track beyond the envelope is still refused.)
   std::vector<int32_t> hubs;
@@ -390,9 +409,15 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       else for (int32_t p : chain_eb_poses) --pose_cnt[p];
       return need;
     };
+    // slots a tile is closed at: kSoftSlots - but dynamic tracks are packed together up to the slot count the graph's largest track forces on every tile kernel's LDS anyway
+    // (dyn_slot_cap: the tile kernels' LDS is sized by the largest tile, so packing up to it costs no occupancy; a tile that holds a static point keeps the soft limit)
+    const bool dyn_chain = ci.npts > 1;
+    const int slot_cap = (!mixed_order && dyn_chain && cur_dyn_only) ? std::max(kSoftSlots, dyn_slot_cap) : kSoftSlots;
     if (cur_npts > 0 && (cur_npts + ci.npts > VDO_TILE_PTS || cur_ninc + ci.ninc > soft_inc ||
-                         (int)cur_poses.size() + newp > kSoftSlots || pieces_with_chain(false) > VDO_TILE_THREADS))
+                         (int)cur_poses.size() + newp > slot_cap || pieces_with_chain(false) > VDO_TILE_THREADS))
       close_tile();
+    if (cur_npts == 0) cur_dyn_only = true;
+    cur_dyn_only = cur_dyn_only && dyn_chain;
     if (cur_npts == 0) {
       cur = Tile{};
       cur.pt_begin = (int32_t)pt_old_of_new.size();
