@@ -431,6 +431,34 @@ def test_static_only_graph_without_pose_pose_edges(ctx, oracle):
     ba.close()
 
 
+@pytest.mark.parametrize("shape", [(3, 120, 0, 0), (6, 200, 0, 0), (8, 300, 1, 12), (11, 400, 1, 20), (20, 2200, 0, 0), (21, 1500, 0, 0), (22, 1500, 0, 0)])
+@pytest.mark.parametrize("gauge", [True, False])
+def test_small_reduced_systems_are_solved_by_one_workgroup(ctx, oracle, shape, gauge):
+    """(round 6) 6P <= 128 unknowns - the 20-frame windows of PartialBatchOptimization: k_dense_small (ba_dense.hip) adds the pose side, appends the right-hand side as a
+    row of the matrix, factorises and substitutes inside ONE workgroup.  Orders that are and are not multiples of 16 (18, 36, 90, 120, 126 unknowns), with and without
+    dynamic tracks, with and without the gauge prior (the windows after the first have none), and 22 frames = 132 unknowns, which stays with the blocked solver:
+    same iterations, trials, chi2 and estimates as the oracle's direct solve."""
+    import dataclasses
+    from vdo_slam_amd.ba import BatchBA
+    g = synth.make_ba_graph(*shape, seed=31)
+    if not gauge and g.n_prior:
+        z = np.zeros(0, np.int32)
+        g = dataclasses.replace(g, pr_pose=z, pr_z=np.zeros((0, 12)), pr_info=np.zeros((0, 36)))
+    gc, keep = K.graph_to_c(g)
+    opt = K.LMOptionsC(12, -1.0, 0, 0, 0.0, 0)
+    st_o = K.LMStatsC()
+    pose_o = np.zeros_like(g.pose); point_o = np.zeros_like(g.point)
+    assert oracle.vdo_oracle_ba_optimize(C.byref(gc), C.byref(opt), K._dp(pose_o), K._dp(point_o), C.byref(st_o)) == 0
+    ba = BatchBA(ctx, g)
+    st = ba.optimize(max_iterations=12, gain_threshold=-1.0)
+    pose, point = ba.estimates()
+    assert st.iterations == st_o.iterations and st.total_trials == st_o.total_trials, (st.iterations, st.total_trials, st_o.iterations, st_o.total_trials)
+    assert abs(st.final_chi2 - st_o.final_chi2) <= 1e-6 * st_o.final_chi2
+    assert np.abs(pose - pose_o).max() <= 1e-4 * max(1.0, np.abs(pose_o).max())
+    assert np.abs(point - point_o).max() <= 1e-4 * np.abs(point_o).max()
+    ba.close()
+
+
 @pytest.mark.parametrize("n_frames", [12, 16, 17, 20, 40, 150, 239])
 def test_pose_chain_solver_is_the_same_operator_however_it_is_partitioned(ctx, oracle, n_frames, monkeypatch):
     """The chain preconditioner (block LDL^T along the pose chains) is applied with the chain cut into segments, one wave each

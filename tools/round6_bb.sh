@@ -1,0 +1,10 @@
+#!/bin/bash
+cd /root/repo; O=gpurun_out/r06bb; mkdir -p $O
+timeout 900 python -m pytest tests/test_ba_gpu.py -x -q -m gpu -k "small_reduced or dense_mfma or static_only" > $O/t1.log 2>&1; tail -8 $O/t1.log
+timeout 900 python -m pytest tests/test_windowed_ba_gpu.py tests/test_track_to_batch_gpu.py tests/test_host_classes_gpu.py -x -q -m gpu > $O/t2.log 2>&1; tail -5 $O/t2.log
+VDO_BATCH_TRACE=1 timeout 600 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-batch --no-host-inputs --no-parity > $O/bench.json 2> $O/bench.err
+grep "^\[batch\]" $O/bench.err | tail -4
+python - <<PY
+import json
+d=json.loads([l for l in open("$O/bench.json") if l.startswith("{")][-1]); print(d["value"], d.get("value_full_sequence"), d.get("value_with_windowed_ba"))
+PY

@@ -755,6 +755,119 @@ __global__ void k_copy_xp(BADev d, const double* __restrict__ x) {
   if (i < 6 * (int64_t)d.P) d.xp[i] = x[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------- small systems
+// The reduced system of a 20-frame window of PartialBatchOptimization has 120 unknowns: eight launches (k_dense_init, k_dense_rhs, k_potrf64_v2, k_chol_step,
+// k_fwd_last, two k_trsv_back_v2, k_copy_xp) of 4 .. 34 us each - 95 us of a 235-us Levenberg trial - for a matrix that fits the LDS of ONE workgroup.
+// k_dense_small does all of it for 6P <= 128: stages the lower triangle of S (what k_schur_dense_tile left: - sum B Hll^-1 B^T), adds blockdiag(Hpp + lambda I) and the
+// EdgeSE3 blocks there, appends the right-hand side bp - qs as ROW 128 of the matrix (the factorisation then leaves y = L^-1 b in that row: no forward substitution),
+// factorises by 16-column panels - EVERY wave repeats the 16x16 diagonal factor in lanes 0 .. 15 (so the pivots and the columns of L are wave-wide broadcasts, no barrier
+// inside a panel) and carries 48 rows of the sub-panel in lanes 16 .. 63 -, trailing update on v_mfma_f64_16x16x4_f64 tiles, then x = L^-T y by 16-row blocks -> d.xp.
+constexpr int SN = 128;                 // padded order (identity on the padding)
+constexpr int SLD = SN + 1;             // leading dimension in LDS: consecutive rows land one bank pair apart
+size_t dense_small_lds() { return ((size_t)(SN + 1) * SLD + 2 * SN) * sizeof(double); }
+
+__global__ __launch_bounds__(256) void k_dense_small(BADev d, const double* __restrict__ S, int64_t ld, double lambda) {
+  extern __shared__ __attribute__((aligned(16))) double sm_small[];
+  double* A = sm_small;                 // [SN + 1][SLD]
+  double* dinv = A + (SN + 1) * SLD;    // [SN]  1 / L_jj
+  double* xs = dinv + SN;               // [SN]  the solution
+  __shared__ int s_bad;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int n = 6 * d.P, np = (n + 15) / 16, npad = 16 * np;
+  if (tid == 0) s_bad = 0;
+#pragma unroll 8
+  for (int i = tid; i < SN * SN; i += 256) {
+    const int r = i >> 7, c = i & (SN - 1);
+    double v = (r == c && r >= n) ? 1.0 : 0.0;
+    if (c <= r && r < n) v = S[(int64_t)r * ld + c];
+    A[r * SLD + c] = v;
+  }
+  for (int c = tid; c < SN; c += 256) A[SN * SLD + c] = c < n ? d.bp[c] - d.qs[c] : 0.0;
+  __syncthreads();
+  for (int i = tid; i < 36 * d.P; i += 256) {
+    const int p = i / 36, a = (i % 36) / 6, b = i % 6;
+    if (b <= a) A[(6 * p + a) * SLD + 6 * p + b] += d.Hpp[i] + (a == b ? lambda : 0.0);
+  }
+  for (int i = tid; i < 36 * d.Ep; i += 256) {          // block (ep_i, ep_j) and its transpose: whichever lies below the diagonal
+    const int e = i / 36, a = (i % 36) / 6, b = i % 6;
+    const double v = d.Hpp_ep[i];
+    const int r = 6 * d.ep_i[e] + a, c = 6 * d.ep_j[e] + b;
+    atomicAdd(A + (r > c ? r * SLD + c : c * SLD + r), v);
+  }
+  __syncthreads();
+  bool bad = false;
+  for (int o = 0; o < npad; o += 16) {
+    // rows of this lane: lanes 0..15 the diagonal block (every wave its own copy), lanes 16..63 row sub = 48 wv + lane - 16 of the sub-panel; the last one is the right-hand side
+    const int nsub = npad - o - 16;                       // matrix rows below the diagonal block
+    const int sub = 48 * wv + lane - 16;
+    const bool diag = lane < 16, act = diag ? wv == 0 : sub <= nsub;
+    const int row = diag ? o + lane : (sub < nsub ? o + 16 + sub : SN);
+    double a[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) a[c] = A[row * SLD + o + c];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      double p = bcast(a[j], j);
+      if (!(p > 0.0)) { bad = true; p = 1.0; }
+      const double inv = rsqrt_nr(p);
+      const double l = (lane == j) ? p * inv : a[j] * inv;
+      a[j] = l;
+      if (tid == j) dinv[o + j] = inv;
+#pragma unroll
+      for (int c = j + 1; c < 16; ++c) a[c] = __builtin_fma(-l, bcast(l, c), a[c]);
+    }
+    if (act) {
+#pragma unroll
+      for (int c = 0; c < 16; ++c) A[row * SLD + o + c] = (diag && c > lane) ? 0.0 : a[c];
+    }
+    __syncthreads();
+    if (tid < nsub) {                                    // the right-hand side's row: b_c -= sum_k X_b[k] X_c[k]
+      const int c = o + 16 + tid;
+      double acc = A[SN * SLD + c];
+#pragma unroll
+      for (int k = 0; k < 16; ++k) acc = __builtin_fma(-A[SN * SLD + o + k], A[c * SLD + o + k], acc);
+      A[SN * SLD + c] = acc;
+    }
+    const int nrt = nsub / 16, ntile = nrt * (nrt + 1) / 2;
+    for (int q = wv; q < ntile; q += 4) {
+      int tj = q, ti = 0;
+      while (tj > ti) { tj -= ti + 1; ++ti; }
+      const int R0 = o + 16 + 16 * ti, C0 = o + 16 + 16 * tj;
+      const d4 u = mma16(A + R0 * SLD + o, SLD, 1, A + C0 * SLD + o, SLD, 1, 16);
+      for_acc([&](int rr, int cc, int qq) { A[(R0 + rr) * SLD + C0 + cc] -= u[qq]; });
+    }
+    __syncthreads();
+  }
+  if (bad && lane == 0) s_bad = 1;                        // (the pivots are wave-uniform)
+  // x = L^-T y, y = row SN: 16-row blocks from the end; wave 0 solves the block, everybody takes it out of the rows above
+  for (int ob = npad - 16; ob >= 0; ob -= 16) {
+    if (wv == 0) {
+      double yv = A[SN * SLD + ob + (lane & 15)], xv = 0.0;
+#pragma unroll
+      for (int j = 15; j >= 0; --j) {
+        const double xj = bcast(yv, j) * dinv[ob + j];
+        if (lane == j) xv = xj;
+        if (lane < j) yv = __builtin_fma(-A[(ob + j) * SLD + ob + lane], xj, yv);
+      }
+      if (lane < 16) xs[ob + lane] = xv;
+    }
+    __syncthreads();
+    if (tid < ob) {
+      double acc = A[SN * SLD + tid];
+#pragma unroll
+      for (int c = 0; c < 16; ++c) acc = __builtin_fma(-A[(ob + c) * SLD + tid], xs[ob + c], acc);
+      A[SN * SLD + tid] = acc;
+    }
+    __syncthreads();
+  }
+  if (tid < n) d.xp[tid] = xs[tid];
+  if (tid == 0 && s_bad) atomicOr(d.flags, 1);
+}
+
+void launch_dense_small(const BADev& d, const double* S, int64_t ld, double lambda, hipStream_t s) {
+  hipLaunchKernelGGL(k_dense_small, dim3(1), dim3(256), raise_lds(k_dense_small, dense_small_lds()), s, d, S, ld, lambda);
+}
+
 // VDO_BA_DENSE selects: 1 = the round-2 launch sequence (potrf + panel + syrk per step, two substitution sweeps); 2 = one launch per step
 // (above), potrf64_lds on the diagonal blocks; 3 = the same with potrf64_lds_v3; 4 = 3 + three block rows per launch of the backward
 // substitution; 5 = 2 + the same.

@@ -1841,7 +1841,7 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
 size_t dense_tile_lds(const BADev& d) { return (39 * VDO_TILE_PTS + 48 * (size_t)d.max_slots) * sizeof(double) + (3 * VDO_TILE_PTS + VDO_TILE_PTS / 2 + 4 + (size_t)d.max_slots) * sizeof(int); }
 
 // S <- reduced-camera matrix at this lambda (launch_factor must have run: it leaves the landmark chain factors of Hll + lambda I)
-void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R) {
+void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R, bool init) {
   hipMemsetAsync(S, 0, sizeof(double) * (size_t)ld * (size_t)ld, s);
   // A tile's columns (one per pose slot: up to max_slots sequential passes with five barriers each, and a dynamic track's chain solves walk
   // its points on 6 threads per chain) are independent of each other: they go in runs of `chunk` to the workgroups (tile, 0 .. max_slots / chunk) -
@@ -1850,6 +1850,7 @@ void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda,
   const int chunk = std::getenv("VDO_BA_DENSE_CHUNK") ? std::max(1, std::atoi(std::getenv("VDO_BA_DENSE_CHUNK"))) : VDO_BA_DENSE_CHUNK_DEFAULT;
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_dense_tile, dim3(d.n_tiles, (d.max_slots + chunk - 1) / chunk), dim3(VDO_TILE_THREADS), raise_lds(k_schur_dense_tile, dense_tile_lds(d)), s, d, S, ld, chunk);
   if (d.sharded) R(S, ld * ld);                     // landmark-side contributions of every rank (all-reduce of S)
+  if (!init) return;                                // (k_dense_small adds the pose side itself)
   const int64_t n = 36 * (int64_t)(d.P + d.Ep) + (ld - 6 * (int64_t)d.P);
   hipLaunchKernelGGL(k_dense_init, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, S, ld, lambda);
 }
