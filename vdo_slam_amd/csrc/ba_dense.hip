@@ -766,7 +766,7 @@ constexpr int SN = 128;                 // padded order (identity on the padding
 constexpr int SLD = SN + 1;             // leading dimension in LDS: consecutive rows land one bank pair apart
 size_t dense_small_lds() { return ((size_t)(SN + 1) * SLD + 2 * SN) * sizeof(double); }
 
-__global__ __launch_bounds__(256) void k_dense_small(BADev d, const double* __restrict__ S, int64_t ld, double lambda) {
+__global__ __launch_bounds__(256) void k_dense_small(BADev d, double* __restrict__ S, int64_t ld, double lambda) {
   extern __shared__ __attribute__((aligned(16))) double sm_small[];
   double* A = sm_small;                 // [SN + 1][SLD]
   double* dinv = A + (SN + 1) * SLD;    // [SN]  1 / L_jj
@@ -775,15 +775,28 @@ __global__ __launch_bounds__(256) void k_dense_small(BADev d, const double* __re
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = 6 * d.P, np = (n + 15) / 16, npad = 16 * np;
   if (tid == 0) s_bad = 0;
-#pragma unroll 8
-  for (int i = tid; i < SN * SN; i += 256) {
-    const int r = i >> 7, c = i & (SN - 1);
-    double v = (r == c && r >= n) ? 1.0 : 0.0;
-    if (c <= r && r < n) v = S[(int64_t)r * ld + c];
-    A[r * SLD + c] = v;
+  // the lower triangle, rows r and SN - 1 - r folded into one line of SN + 1 entries (r + 1 of the one, SN - r of the other): 64 x 129 entries, every load
+  // unconditional (clamped: the padding is never read from memory) and 8 in flight per thread; S is zeroed behind the read for the next assembly
+  constexpr int FOLD = (SN / 2) * (SN + 1);
+#pragma unroll 1
+  for (int i0 = tid; i0 < FOLD; i0 += 8 * 256) {
+    double v[8];
+    int rr[8], cc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int i = min(i0 + 256 * q, FOLD - 1), pr = i / (SN + 1), k = i - pr * (SN + 1);
+      rr[q] = k <= pr ? pr : SN - 1 - pr;
+      cc[q] = k <= pr ? k : k - pr - 1;
+      v[q] = S[(int64_t)min(rr[q], n - 1) * ld + min(cc[q], n - 1)];
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      if (i0 + 256 * q < FOLD) A[rr[q] * SLD + cc[q]] = rr[q] < n ? v[q] : (rr[q] == cc[q] ? 1.0 : 0.0);
+    }
   }
   for (int c = tid; c < SN; c += 256) A[SN * SLD + c] = c < n ? d.bp[c] - d.qs[c] : 0.0;
   __syncthreads();
+  for (int i = tid; i < n * n; i += 256) { const int r = i / n, c = i - r * n; S[(int64_t)r * ld + c] = 0.0; }
   for (int i = tid; i < 36 * d.P; i += 256) {
     const int p = i / 36, a = (i % 36) / 6, b = i % 6;
     if (b <= a) A[(6 * p + a) * SLD + 6 * p + b] += d.Hpp[i] + (a == b ? lambda : 0.0);
@@ -839,15 +852,21 @@ __global__ __launch_bounds__(256) void k_dense_small(BADev d, const double* __re
     __syncthreads();
   }
   if (bad && lane == 0) s_bad = 1;                        // (the pivots are wave-uniform)
-  // x = L^-T y, y = row SN: 16-row blocks from the end; wave 0 solves the block, everybody takes it out of the rows above
+  // x = L^-T y, y = row SN: 16-row blocks from the end; wave 0 solves the block in registers (column j of the block's L^T is row ob + j of L: requested before the
+  // recurrence starts), everybody takes the block out of the rows above
   for (int ob = npad - 16; ob >= 0; ob -= 16) {
     if (wv == 0) {
-      double yv = A[SN * SLD + ob + (lane & 15)], xv = 0.0;
+      const int l15 = lane & 15;
+      double yv = A[SN * SLD + ob + l15], xv = 0.0;
+      const double dv = dinv[ob + l15];
+      double Lc[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) Lc[j] = A[(ob + j) * SLD + ob + l15];
 #pragma unroll
       for (int j = 15; j >= 0; --j) {
-        const double xj = bcast(yv, j) * dinv[ob + j];
+        const double xj = bcast(yv * dv, j);
         if (lane == j) xv = xj;
-        if (lane < j) yv = __builtin_fma(-A[(ob + j) * SLD + ob + lane], xj, yv);
+        yv = lane < j ? __builtin_fma(-Lc[j], xj, yv) : yv;
       }
       if (lane < 16) xs[ob + lane] = xv;
     }
@@ -864,7 +883,7 @@ __global__ __launch_bounds__(256) void k_dense_small(BADev d, const double* __re
   if (tid == 0 && s_bad) atomicOr(d.flags, 1);
 }
 
-void launch_dense_small(const BADev& d, const double* S, int64_t ld, double lambda, hipStream_t s) {
+void launch_dense_small(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s) {
   hipLaunchKernelGGL(k_dense_small, dim3(1), dim3(256), raise_lds(k_dense_small, dense_small_lds()), s, d, S, ld, lambda);
 }
 

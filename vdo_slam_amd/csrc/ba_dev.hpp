@@ -181,8 +181,8 @@ void launch_pcg_init(const BADev& d, hipStream_t s);
 void launch_pcg_iter(const BADev& d, double lambda, double tol2, int parity, hipStream_t s, const Reducer& R);   // parity: 0, 1, 0, ... from the first iteration after launch_pcg_init
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s);
 void launch_expand_binc(const BADev& d, hipStream_t s);            // Finc -> explicit Binc (download/debug only)
-void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R, bool init = true);   // explicit reduced-camera matrix (init = false: only - sum B Hll^-1 B^T)
-void launch_dense_small(const BADev& d, const double* S, int64_t ld, double lambda, hipStream_t s);      // 6P <= 128: Hpp + lambda, right-hand side, Cholesky and both substitutions in ONE workgroup -> xp (ba_dense.hip)
+void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R, bool init = true, bool clean = false);   // explicit reduced-camera matrix (init = false: only - sum B Hll^-1 B^T; clean: S is zero already)
+void launch_dense_small(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s);      // 6P <= 128: Hpp + lambda, right-hand side, Cholesky and both substitutions in ONE workgroup -> xp (ba_dense.hip)
 void launch_dense_rhs(const BADev& d, double* rhs, int64_t ld, hipStream_t s);
 // ---- ba_dense.hip
 // ba_hub.hip: the hub landmarks' share of the tile kernels' work (no-ops without hubs)

@@ -30,6 +30,7 @@ struct vdo_ba {
   // dense reduced-camera solver (ba_dense.hip), allocated on first use: S [ld][ld], W [ld/64][64][64], rhs [ld]
   double *dense_S = nullptr, *dense_W = nullptr, *dense_rhs = nullptr;
   int64_t dense_ld = 0;
+  bool dense_S_clean = false;        // k_dense_small zeroes what it read of S: the next assembly needs no memset
   bool dense_tiles_ok = true;        // every tile's padded incidence count (256 * ept + 2 * ternary edges) fits VDO_TILE_INC: what k_schur_dense_tile holds per thread
   bool pose_graph_is_paths = true;   // every EdgeSE3 lies on a simple path (the chain preconditioner covers them all)
   int last_solver = 0;            // 2 PCG, 3 dense: what the last trial used

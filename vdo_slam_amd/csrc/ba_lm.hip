@@ -113,8 +113,8 @@ int solve_trial(vdo_ba* ba, double lambda, const vdo_lm_options* opt, bool* ok, 
     // (round 6) a reduced system of at most 128 unknowns - the 20-frame windows - is finished by ONE workgroup in LDS (k_dense_small: 8 launches less per trial)
     static const bool no_small = std::getenv("VDO_BA_NO_DENSE_SMALL") != nullptr;
     const bool one_wg = !no_small && 6 * (int64_t)d.P <= 128;
-    launch_dense_assemble(d, ba->dense_S, ba->dense_ld, lambda, s, ba->red, !one_wg);
-    if (one_wg) launch_dense_small(d, ba->dense_S, ba->dense_ld, lambda, s);
+    launch_dense_assemble(d, ba->dense_S, ba->dense_ld, lambda, s, ba->red, !one_wg, one_wg && ba->dense_S_clean);
+    if (one_wg) { launch_dense_small(d, ba->dense_S, ba->dense_ld, lambda, s); ba->dense_S_clean = true; }
     else {
       launch_dense_rhs(d, ba->dense_rhs, ba->dense_ld, s);
       launch_dense_solve(d, ba->dense_S, ba->dense_ld, ba->dense_W, ba->dense_rhs, s);

@@ -1841,8 +1841,8 @@ __global__ __launch_bounds__(VDO_TILE_THREADS) void k_schur_dense_tile(BADev d, 
 size_t dense_tile_lds(const BADev& d) { return (39 * VDO_TILE_PTS + 48 * (size_t)d.max_slots) * sizeof(double) + (3 * VDO_TILE_PTS + VDO_TILE_PTS / 2 + 4 + (size_t)d.max_slots) * sizeof(int); }
 
 // S <- reduced-camera matrix at this lambda (launch_factor must have run: it leaves the landmark chain factors of Hll + lambda I)
-void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R, bool init) {
-  hipMemsetAsync(S, 0, sizeof(double) * (size_t)ld * (size_t)ld, s);
+void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s, const Reducer& R, bool init, bool clean) {
+  if (!clean) hipMemsetAsync(S, 0, sizeof(double) * (size_t)ld * (size_t)ld, s);       // (clean: k_dense_small left S zeroed behind itself)
   // A tile's columns (one per pose slot: up to max_slots sequential passes with five barriers each, and a dynamic track's chain solves walk
   // its points on 6 threads per chain) are independent of each other: they go in runs of `chunk` to the workgroups (tile, 0 .. max_slots / chunk) -
   // most tiles of the bench graph carry a dozen slots, the ones with the long dynamic tracks 81: one workgroup per tile left the device waiting
@@ -1912,7 +1912,7 @@ void launch_factor_and_rhs(const BADev& d, double lambda, hipStream_t s, const R
     else R(d.msum, 27 * (int64_t)d.P + 1);
     hipLaunchKernelGGL(k_precond_finalize<2>, g, b, 0, s, d, lambda);
   }
-  const bool two = side && fork && join && !d.sharded;
+  const bool two = side && fork && join && !d.sharded && precond;      // (without the pose-chain factorisation nothing runs beside the reduced right-hand side: no fork / join - two cross-stream waits of ~10 us on a window-sized graph)
   hipStream_t sr = two ? side : s;
   if (two) { hipEventRecord(fork, s); hipStreamWaitEvent(side, fork, 0); }
   if (precond) {
