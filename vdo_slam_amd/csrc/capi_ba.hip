@@ -69,6 +69,9 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   int rc = ctx_bind(ctx);
   if (rc != VDO_OK) return rc;
   const auto t_create0 = std::chrono::steady_clock::now();
+  static const bool trace_create = std::getenv("VDO_BATCH_TRACE") != nullptr;
+  double t_mark[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  auto mark_t = [&](int k) { if (trace_create) t_mark[k] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_create0).count(); };
   const int P = g->n_pose, L = g->n_point, Eb = g->n_eb, Et = g->n_et, Ep = g->n_ep, Npr = g->n_prior;
   // ---- validate indices
   for (int e = 0; e < Eb; ++e)
@@ -90,6 +93,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     if (hd > 0 && !((double)(float)(hd * hd) >= 1.1754943508222875e-38))
       return set_error(VDO_ERR_INVALID, "vdo_ba_create: Huber width %.3g: its square is not a normal float (RobustKernelHuber keeps it in one)", hd);
 
+  mark_t(0);
   // ---- chains (dynamic tracks) from the ternary edges
   std::vector<int32_t> next_e(L, -1), prev_e(L, -1);
   for (int e = 0; e < Et; ++e) {
@@ -136,6 +140,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     return a.key < b.key;
   });
 
+  mark_t(1);
   // ---- greedy tiling
   vdo_ba* ba = new vdo_ba();
   ba->ctx = ctx;
@@ -178,7 +183,10 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   };
   int inc_total = 0;
   // VDO_BA_PLACE=0: the edges of a slot's run in pose-sorted order (round 4) instead of the bank-aware placement below (A/B, tools/)
-  const int place_mode = std::getenv("VDO_BA_PLACE") ? std::atoi(std::getenv("VDO_BA_PLACE")) : 1;
+  // (round 6: a graph of a few tiles - the 20-frame windows: 8 k edges - is launch-bound whatever its bank conflicts are, and the placement was half of its 0.9 ms of tile building:
+  //  below kPlaceMinInc incidences the edges keep their pose-sorted order)
+  constexpr int64_t kPlaceMinInc = 32768;
+  const int place_mode = std::getenv("VDO_BA_PLACE") ? std::atoi(std::getenv("VDO_BA_PLACE")) : ((int64_t)Eb + 2 * (int64_t)Et >= kPlaceMinInc ? 1 : 0);
   long long place_ways = 0, place_groups = 0;
   bool dense_tiles_ok = true;
   auto close_tile = [&]() {
@@ -243,7 +251,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
             for (int r = 0; r < 32; ++r) {
               if (bucket[r].empty()) continue;
               const int cost = place_mode ? 2 * occ16[w][i][g16][r & 15] + occ32[w][i][h][r] : 0;
-              if (cost < best_cost) { best_cost = cost; best = r; }
+              if (cost < best_cost) { best_cost = cost; best = r; if (cost == 0) break; }
             }
             const int e = bucket[best].back(); bucket[best].pop_back();
             ++occ16[w][i][g16][best & 15]; ++occ32[w][i][h][best];
@@ -345,7 +353,9 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   std::vector<int32_t> hubs;
   const bool hubs_off = std::getenv("VDO_BA_NO_HUBS") != nullptr;             // (the refusal of rounds 1-5, for the tests of the envelope's messages)
   for (const ChainInfo& ci : chains) {
-    if (!hubs_off && ci.npts == 1 && next_e[ci.head] == -1 && ci.nb == ci.ninc) {
+    // (a static point of at most min(kStaticSlots, 256 threads) observations - nearly every point of every graph - passes all of the checks below by its count alone)
+    const bool plain_static = ci.npts == 1 && next_e[ci.head] == -1 && ci.nb == ci.ninc && ci.ninc <= std::min(kStaticSlots, VDO_TILE_THREADS);
+    if (!plain_static && !hubs_off && ci.npts == 1 && next_e[ci.head] == -1 && ci.nb == ci.ninc) {
       chain_poses(ci, cposes);
       std::vector<int32_t> u(cposes);
       std::sort(u.begin(), u.end());
@@ -360,7 +370,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
                        ci.npts, ci.ninc, VDO_TILE_PTS, VDO_TILE_INC);
     }
     chain_poses(ci, cposes);
-    {   // the track on its own must fit a tile (checked here, before anything is built, with a message that names the track):
+    if (!plain_static) {   // the track on its own must fit a tile (checked here, before anything is built, with a message that names the track):
         // distinct pose vertices <= kHardSlots (LDS slots), and its EdgeSE3PointXYZ edges cut per pose into pieces of <= VDO_TILE_EPT must fit
         // the 256 threads of the sweep
       std::vector<int32_t> u(cposes);
@@ -445,6 +455,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   }
   close_tile();
   if (thr_overflow) { delete ba; return set_error(VDO_ERR_UNSUPPORTED, "a tile has more pose-slot pieces than threads"); }
+  mark_t(2);
   // ---- hub landmarks: device points behind every tile's (each a chain of its own), one pose-major partial row ("slot") per edge behind every tile's slots
   const int NPS_tiles = (int)tile_pose.size();
   std::vector<int32_t> hub_off{0}, hub_point, hub_pose, hub_eb_old;
@@ -465,6 +476,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   for (auto& pe : pt_prev_edge_new) if (pe >= 0) pe = et_new_of_old[pe];
   const int n_tiles = (int)tiles.size(), NPS = (int)tile_pose.size(), n_chains = (int)chain_off.size() - 1;
 
+  mark_t(3);
   // ---- permuted edge / vertex data
   // (Ebp: entries of the padded edge blocks = the device's edge index space; entries without an edge keep zeros)
   const int Ebp = (int)eb_old_of_new.size();
@@ -515,6 +527,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     std::vector<int32_t> fill(pr_off.begin(), pr_off.end() - 1);
     for (int q = 0; q < Npr; ++q) pr_idx[fill[g->pr_pose[q]]++] = q;
   }
+  mark_t(4);
   // ---- pose chains for the block-tridiagonal preconditioner: connected components of the pose-pose
   // (EdgeSE3) graph that are simple paths - the odometry chain of the cameras, the smoothness chain of
   // every object's motions (src/Optimizer.cc:1590-1612, 1743-1766) - in path order; every other pose
@@ -745,7 +758,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   ba->h_flags = (int32_t*)(ba->h_scal + S_COUNT);
   if (hipStreamSynchronize(s) != hipSuccess) { vdo_ba_destroy(ba); return set_error(VDO_ERR_NO_DEVICE, "upload failed: %s", hipGetErrorString(hipGetLastError())); }
   if (std::getenv("VDO_BATCH_TRACE"))
-    std::fprintf(stderr, "[vdo_ba_create] tiles built in %.2f ms, uploaded in %.2f ms (%s)\n", std::chrono::duration<double, std::milli>(t_built - t_create0).count(),
+    std::fprintf(stderr, "[vdo_ba_create] validated %.2f, chains %.2f, tiles %.2f, hubs %.2f, permuted data %.2f ms (cumulative); tiles built in %.2f ms, uploaded in %.2f ms (%s)\n", t_mark[0], t_mark[1], t_mark[2], t_mark[3], t_mark[4], std::chrono::duration<double, std::milli>(t_built - t_create0).count(),
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_built).count(), ba->pooled ? "pooled" : "own allocations");
   *out = ba;
   return VDO_OK;
