@@ -15,6 +15,9 @@
 
 using namespace vdo;
 
+// (raise_lds reports a refused LDS size through the library's error slot: the stand-alone build has none)
+namespace vdo { int set_error(int code, const char* fmt, ...) { fprintf(stderr, "set_error(%d): %s\n", code, fmt); return code; } }
+
 static uint64_t rng_state = 0x9E3779B97F4A7C15ull;
 static double urand() {   // xorshift64*, (-1, 1)
   rng_state ^= rng_state >> 12; rng_state ^= rng_state << 25; rng_state ^= rng_state >> 27;
@@ -74,6 +77,7 @@ int main(int argc, char** argv) {
   const int reps_big = argc > 1 ? atoi(argv[1]) : 5;
   const int only_ver = argc > 2 ? atoi(argv[2]) : 0;      // (for a kernel trace of one launch sequence)
   for (const auto& sz : sizes) {
+    if (argc > 3) break;                                  // (a third argument: the k_dense_small section only)
     const int n = sz[0], n0 = sz[1];
     for (int indef = 0; indef < 2; ++indef) {
       if (indef && n != 320) continue;
@@ -127,6 +131,85 @@ int main(int argc, char** argv) {
         hipEventDestroy(e0); hipEventDestroy(e1);
       }
       hipFree(dS); hipFree(dW); hipFree(dr); hipFree(dx); hipFree(dflags);
+    }
+  }
+  // ---- k_dense_small (<= 128 unknowns in one workgroup): S + blockdiag(Hpp + lambda I), right-hand side bp - qs, against the long-double Cholesky
+  for (int n0 : {18, 36, 90, 120, 126}) {
+    for (int indef = 0; indef < 2; ++indef) {
+      if (indef && n0 != 120) continue;
+      const int n = 128, P = n0 / 6;
+      std::vector<double> A, b, xref;
+      make_system(n, n0, A, b, indef != 0);
+      // split: S = A - blockdiag(H), Hpp = H - lambda I with H the 6x6 diagonal blocks of 0.5 A; bp = 2 b, qs = b
+      const double lambda = 0.37;
+      std::vector<double> S(A), Hpp(36 * (size_t)P), bp(n0), qs(n0);
+      for (int p = 0; p < P; ++p)
+        for (int a = 0; a < 6; ++a)
+          for (int c = 0; c < 6; ++c) {
+            const double h = 0.5 * A[(size_t)(6 * p + a) * n + 6 * p + c];
+            S[(size_t)(6 * p + a) * n + 6 * p + c] -= h;
+            Hpp[36 * (size_t)p + 6 * a + c] = h - (a == c ? lambda : 0.0);
+          }
+      for (int i = 0; i < n0; ++i) { bp[i] = 2.0 * b[i]; qs[i] = b[i]; }
+      const bool spd = host_solve(n, A, b, xref);
+      double *dS, *dH, *dbp, *dqs, *dx;
+      int32_t* dflags;
+      hipMalloc(&dS, sizeof(double) * (size_t)n * n); hipMalloc(&dH, sizeof(double) * 36 * P); hipMalloc(&dbp, sizeof(double) * n0); hipMalloc(&dqs, sizeof(double) * n0);
+      hipMalloc(&dx, sizeof(double) * n); hipMalloc(&dflags, 16);
+      hipMemcpy(dH, Hpp.data(), sizeof(double) * 36 * P, hipMemcpyHostToDevice);
+      hipMemcpy(dbp, bp.data(), sizeof(double) * n0, hipMemcpyHostToDevice); hipMemcpy(dqs, qs.data(), sizeof(double) * n0, hipMemcpyHostToDevice);
+      BADev d;
+      memset(&d, 0, sizeof d);
+      d.P = P; d.Ep = 0; d.Hpp = dH; d.bp = dbp; d.qs = dqs; d.xp = dx; d.flags = dflags;
+      hipEvent_t e0, e1;
+      hipEventCreate(&e0); hipEventCreate(&e1);
+      float ms = 0.f, best = 1e9f;
+      for (int rep = 0; rep < 20; ++rep) {
+        hipMemcpy(dS, S.data(), sizeof(double) * (size_t)n * n, hipMemcpyHostToDevice);
+        hipMemset(dflags, 0, 16); hipMemset(dx, 0, sizeof(double) * n);
+        hipDeviceSynchronize();
+        hipEventRecord(e0, 0);
+        launch_dense_small(d, dS, n, lambda, 0);
+        hipEventRecord(e1, 0);
+        if (hipDeviceSynchronize() != hipSuccess) { printf("k_dense_small n0=%d: device error %s\n", n0, hipGetErrorString(hipGetLastError())); return 100; }
+        hipEventElapsedTime(&ms, e0, e1);
+        best = std::fmin(best, ms);
+      }
+      std::vector<double> x(n, 0.0), Sback((size_t)n * n);
+      int32_t flag = 0;
+      hipMemcpy(x.data(), dx, sizeof(double) * n0, hipMemcpyDeviceToHost);
+      hipMemcpy(&flag, dflags, 4, hipMemcpyDeviceToHost);
+      hipMemcpy(Sback.data(), dS, sizeof(double) * (size_t)n * n, hipMemcpyDeviceToHost);
+      bool zeroed = true;
+      for (int i = 0; i < n0; ++i) for (int j = 0; j < n0; ++j) zeroed = zeroed && Sback[(size_t)i * n + j] == 0.0;
+      bool ok;
+      double relerr = 0.0, resid = 0.0;
+      if (!spd) ok = flag != 0;
+      else {
+        double num = 0.0, den = 0.0;
+        for (int i = 0; i < n0; ++i) { num = std::fmax(num, std::fabs(x[i] - xref[i])); den = std::fmax(den, std::fabs(xref[i])); }
+        relerr = num / den;
+        for (int i = 0; i < n0; ++i) { double s2 = -b[i], a = std::fabs(b[i]); for (int j = 0; j < n0; ++j) { s2 += A[(size_t)i * n + j] * x[j]; a += std::fabs(A[(size_t)i * n + j] * x[j]); } resid = std::fmax(resid, std::fabs(s2) / a); }
+        ok = flag == 0 && relerr < 1e-10 && resid < 1e-12 && std::isfinite(relerr);
+      }
+      ok = ok && zeroed;
+      printf("k_dense_small n0=%d %s: relerr %.3e resid %.3e us %.1f (best of 20) flag %d S zeroed %d %s\n", n0, spd ? "spd" : "indefinite", relerr, resid, best * 1e3, flag, (int)zeroed, ok ? "ok" : "BAD");
+      if (!ok) ++nbad;
+#ifdef DENSE_PROF
+      {
+        static long long h[64][16];
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(g_dense_prof), sizeof(h));
+        const char* nm[7] = {"stage + pose side", "panel: load rows", "panel: 16 pivots + store", "barrier", "rhs row + MFMA tiles", "barrier", "back-substitution"};
+        long long tot = 0;
+        for (int i = 0; i < 8; ++i) tot += h[63][i];
+        printf("   k_dense_small phases (shader cycles, thread 0):");
+        for (int i = 0; i < 7; ++i) printf(" %s %lld,", nm[i], h[63][i]);
+        printf(" (rhs row alone %lld)", h[63][7]);
+        printf(" total %lld\n", tot);
+      }
+#endif
+      hipEventDestroy(e0); hipEventDestroy(e1);
+      hipFree(dS); hipFree(dH); hipFree(dbp); hipFree(dqs); hipFree(dx); hipFree(dflags);
     }
   }
 #ifdef DENSE_PROF

@@ -763,77 +763,116 @@ __global__ void k_copy_xp(BADev d, const double* __restrict__ x) {
 // factorises by 16-column panels - EVERY wave repeats the 16x16 diagonal factor in lanes 0 .. 15 (so the pivots and the columns of L are wave-wide broadcasts, no barrier
 // inside a panel) and carries 48 rows of the sub-panel in lanes 16 .. 63 -, trailing update on v_mfma_f64_16x16x4_f64 tiles, then x = L^-T y by 16-row blocks -> d.xp.
 constexpr int SN = 128;                 // padded order (identity on the padding)
-constexpr int SLD = SN + 1;             // leading dimension in LDS: consecutive rows land one bank pair apart
-size_t dense_small_lds() { return ((size_t)(SN + 1) * SLD + 2 * SN) * sizeof(double); }
+constexpr int SLD = SN + 2;             // leading dimension in LDS: consecutive rows two doubles apart in bank space - the MFMA operand reads (16 rows x 2 consecutive k per half-wave) are conflict-free (as LDS_LD above; with SN + 1 they were 4-way: 1 050 cycles per 16x16x16 tile)
+size_t dense_small_lds() { return ((size_t)(SN + 1) * SLD + SN) * sizeof(double); }
 
 __global__ __launch_bounds__(256) void k_dense_small(BADev d, double* __restrict__ S, int64_t ld, double lambda) {
   extern __shared__ __attribute__((aligned(16))) double sm_small[];
   double* A = sm_small;                 // [SN + 1][SLD]
-  double* dinv = A + (SN + 1) * SLD;    // [SN]  1 / L_jj
-  double* xs = dinv + SN;               // [SN]  the solution
+  double* xs = A + (SN + 1) * SLD;      // [SN]  the solution
   __shared__ int s_bad;
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int n = 6 * d.P, np = (n + 15) / 16, npad = 16 * np;
   if (tid == 0) s_bad = 0;
+#ifdef DENSE_PROF
+  DProf pr; pr.prev = clock64();
+  for (int i = 0; i < 16; ++i) pr.t[i] = 0;
+#endif
   // the lower triangle, rows r and SN - 1 - r folded into one line of SN + 1 entries (r + 1 of the one, SN - r of the other): 64 x 129 entries, every load
   // unconditional (clamped: the padding is never read from memory) and 8 in flight per thread; S is zeroed behind the read for the next assembly
-  constexpr int FOLD = (SN / 2) * (SN + 1);
-#pragma unroll 1
-  for (int i0 = tid; i0 < FOLD; i0 += 8 * 256) {
-    double v[8];
-    int rr[8], cc[8];
+  constexpr int FOLD = (SN / 2) * (SN + 1), NLD = (FOLD + 255) / 256;      // 33 entries per thread: requested together, ONE round trip (five rounds of 8 cost 13 us of the kernel's 55)
+  {
+    double v[NLD];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int i = min(i0 + 256 * q, FOLD - 1), pr = i / (SN + 1), k = i - pr * (SN + 1);
-      rr[q] = k <= pr ? pr : SN - 1 - pr;
-      cc[q] = k <= pr ? k : k - pr - 1;
-      v[q] = S[(int64_t)min(rr[q], n - 1) * ld + min(cc[q], n - 1)];
+    for (int q = 0; q < NLD; ++q) {
+      const int i = min(tid + 256 * q, FOLD - 1), pr = i / (SN + 1), k = i - pr * (SN + 1);
+      const int r = k <= pr ? pr : SN - 1 - pr, c = k <= pr ? k : k - pr - 1;
+      v[q] = S[(int64_t)min(r, n - 1) * ld + min(c, n - 1)];
+    }
+    // the pose side and the right-hand side travel with them (clamped: every thread asks)
+    double hp[3], rb = 0.0, rq = 0.0;
+#pragma unroll
+    for (int q = 0; q < 3; ++q) hp[q] = d.Hpp[min(tid + 256 * q, 36 * d.P - 1)];
+    if (tid < SN) { rb = d.bp[min(tid, n - 1)]; rq = d.qs[min(tid, n - 1)]; }
+    double he[3];
+    int er[3], ec[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {                        // EdgeSE3 blocks (ep_i, ep_j): three entries per thread cover 21 edges - a window's 19
+      const int i = min(tid + 256 * q, max(36 * d.Ep - 1, 0)), e = i / 36;
+      he[q] = d.Ep ? d.Hpp_ep[i] : 0.0;
+      er[q] = d.Ep ? d.ep_i[e] : 0; ec[q] = d.Ep ? d.ep_j[e] : 0;
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      if (i0 + 256 * q < FOLD) A[rr[q] * SLD + cc[q]] = rr[q] < n ? v[q] : (rr[q] == cc[q] ? 1.0 : 0.0);
+    for (int q = 0; q < NLD; ++q) {
+      const int i = tid + 256 * q, pr = i / (SN + 1), k = i - pr * (SN + 1);
+      const int r = k <= pr ? pr : SN - 1 - pr, c = k <= pr ? k : k - pr - 1;
+      if (i < FOLD) A[r * SLD + c] = r < n ? v[q] : (r == c ? 1.0 : 0.0);
+    }
+    if (tid < SN) A[SN * SLD + tid] = tid < n ? rb - rq : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      const int i = tid + 256 * q;
+      if (i < 36 * d.P) {
+        const int p = i / 36, a = (i % 36) / 6, b = i % 6;
+        if (b <= a) A[(6 * p + a) * SLD + 6 * p + b] += hp[q] + (a == b ? lambda : 0.0);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {                        // the block or its transpose: whichever lies below the diagonal
+      const int i = tid + 256 * q;
+      if (i < 36 * d.Ep) {
+        const int r = 6 * er[q] + (i % 36) / 6, c = 6 * ec[q] + i % 6;
+        atomicAdd(A + (r > c ? r * SLD + c : c * SLD + r), he[q]);
+      }
     }
   }
-  for (int c = tid; c < SN; c += 256) A[SN * SLD + c] = c < n ? d.bp[c] - d.qs[c] : 0.0;
-  __syncthreads();
-  for (int i = tid; i < n * n; i += 256) { const int r = i / n, c = i - r * n; S[(int64_t)r * ld + c] = 0.0; }
-  for (int i = tid; i < 36 * d.P; i += 256) {
+  for (int i = tid + 768; i < 36 * d.P; i += 256) {       // (more than 21 poses' worth: never at <= 128 unknowns, kept for the bound's sake)
     const int p = i / 36, a = (i % 36) / 6, b = i % 6;
     if (b <= a) A[(6 * p + a) * SLD + 6 * p + b] += d.Hpp[i] + (a == b ? lambda : 0.0);
   }
-  for (int i = tid; i < 36 * d.Ep; i += 256) {          // block (ep_i, ep_j) and its transpose: whichever lies below the diagonal
+  for (int i = tid + 768; i < 36 * d.Ep; i += 256) {    // (more than 21 edges)
     const int e = i / 36, a = (i % 36) / 6, b = i % 6;
     const double v = d.Hpp_ep[i];
     const int r = 6 * d.ep_i[e] + a, c = 6 * d.ep_j[e] + b;
     atomicAdd(A + (r > c ? r * SLD + c : c * SLD + r), v);
   }
   __syncthreads();
-  bool bad = false;
+  DP_TICK(0);
   for (int o = 0; o < npad; o += 16) {
     // rows of this lane: lanes 0..15 the diagonal block (every wave its own copy), lanes 16..63 row sub = 48 wv + lane - 16 of the sub-panel; the last one is the right-hand side
     const int nsub = npad - o - 16;                       // matrix rows below the diagonal block
-    const int sub = 48 * wv + lane - 16;
-    const bool diag = lane < 16, act = diag ? wv == 0 : sub <= nsub;
-    const int row = diag ? o + lane : (sub < nsub ? o + 16 + sub : SN);
-    double a[16];
+    if (wv == 0 || 48 * wv <= nsub) {                     // (wave-uniform: this wave carries rows of the panel)
+      const int sub = 48 * wv + lane - 16;
+      const bool diag = lane < 16, act = diag ? wv == 0 : sub <= nsub;
+      const int row = diag ? o + lane : (sub < nsub ? o + 16 + sub : SN);
+      double a[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) a[c] = A[row * SLD + o + c];
+      for (int c = 0; c < 16; ++c) a[c] = A[row * SLD + o + c];
+      // No test of the pivot inside the recurrence: a pivot that is not positive turns its column into NaN (v_rsq_f64 of a negative number, 0 * inf) and the NaN spreads
+      // over everything behind it - the diagonal of L is looked at once, by the back-substitution.  The diagonal lane's own entry is the pivot: l = a_j / sqrt(p) for all.
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      double p = bcast(a[j], j);
-      if (!(p > 0.0)) { bad = true; p = 1.0; }
-      const double inv = rsqrt_nr(p);
-      const double l = (lane == j) ? p * inv : a[j] * inv;
-      a[j] = l;
-      if (tid == j) dinv[o + j] = inv;
+      for (int j = 0; j < 16; ++j) {
+        const double inv = rsqrt_nr(bcast(a[j], j));
+        const double l = a[j] * inv;
+        a[j] = l;
 #pragma unroll
-      for (int c = j + 1; c < 16; ++c) a[c] = __builtin_fma(-l, bcast(l, c), a[c]);
+        for (int c = j + 1; c < 16; ++c) a[c] = __builtin_fma(-l, bcast(l, c), a[c]);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (act) {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) A[row * SLD + o + c] = a[c];      // (the diagonal block's upper part receives garbage: nothing reads it)
+      }
+    } else if (wv == 3) {
+      // wave 3 never carries rows of a panel (<= 113 of them, 48 per wave): it zeroes S for the next assembly meanwhile, 16 rows per panel - 16-byte stores, a row per
+      // step (n = 6P is even, rows are 1 KB apart)
+      for (int r = o; r < min(o + 16, n); ++r)
+        for (int c2 = 2 * lane; c2 < n; c2 += 128) *reinterpret_cast<double2*>(S + (int64_t)r * ld + c2) = double2{0.0, 0.0};
     }
-    if (act) {
-#pragma unroll
-      for (int c = 0; c < 16; ++c) A[row * SLD + o + c] = (diag && c > lane) ? 0.0 : a[c];
-    }
+    DP_TICK(2);
     __syncthreads();
+    DP_TICK(3);
     if (tid < nsub) {                                    // the right-hand side's row: b_c -= sum_k X_b[k] X_c[k]
       const int c = o + 16 + tid;
       double acc = A[SN * SLD + c];
@@ -841,34 +880,69 @@ __global__ __launch_bounds__(256) void k_dense_small(BADev d, double* __restrict
       for (int k = 0; k < 16; ++k) acc = __builtin_fma(-A[SN * SLD + o + k], A[c * SLD + o + k], acc);
       A[SN * SLD + c] = acc;
     }
+    DP_TICK(7);
+    // trailing update, 16x16 tiles (ti, tj), tj <= ti, round-robin over the waves: C -= X_ti X_tj^T as ONE accumulation chain D = (-X_ti) X_tj^T + C.  The eight operand
+    // values and the four C values of a lane are requested together (mma16's loop paid an LDS round trip per MFMA: 1 050 cycles per tile), two tiles per trip.
     const int nrt = nsub / 16, ntile = nrt * (nrt + 1) / 2;
-    for (int q = wv; q < ntile; q += 4) {
-      int tj = q, ti = 0;
-      while (tj > ti) { tj -= ti + 1; ++ti; }
-      const int R0 = o + 16 + 16 * ti, C0 = o + 16 + 16 * tj;
-      const d4 u = mma16(A + R0 * SLD + o, SLD, 1, A + C0 * SLD + o, SLD, 1, 16);
-      for_acc([&](int rr, int cc, int qq) { A[(R0 + rr) * SLD + C0 + cc] -= u[qq]; });
+    {
+      const int i16 = lane & 15, kq = lane >> 4;
+      for (int q0 = wv; q0 < ntile; q0 += 8) {
+        int R0[2], C0[2];
+        bool on[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int q = q0 + 4 * h;
+          on[h] = q < ntile;
+          int tj = on[h] ? q : 0, ti = 0;
+          while (tj > ti) { tj -= ti + 1; ++ti; }
+          R0[h] = o + 16 + 16 * ti; C0[h] = o + 16 + 16 * tj;
+        }
+        double av[2][4], bv[2][4];
+        d4 acc[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { av[h][k] = A[(R0[h] + i16) * SLD + o + 4 * k + kq]; bv[h][k] = A[(C0[h] + i16) * SLD + o + 4 * k + kq]; }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[h][r] = A[(R0[h] + kq + 4 * r) * SLD + C0[h] + i16];
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+#pragma unroll
+          for (int k = 0; k < 4; ++k) acc[h] = __builtin_amdgcn_mfma_f64_16x16x4f64(-av[h][k], bv[h][k], acc[h], 0, 0, 0);
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (on[h]) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) A[(R0[h] + kq + 4 * r) * SLD + C0[h] + i16] = acc[h][r];
+          }
+        }
+      }
     }
+    DP_TICK(4);
     __syncthreads();
+    DP_TICK(5);
   }
-  if (bad && lane == 0) s_bad = 1;                        // (the pivots are wave-uniform)
   // x = L^-T y, y = row SN: 16-row blocks from the end; wave 0 solves the block in registers (column j of the block's L^T is row ob + j of L: requested before the
-  // recurrence starts), everybody takes the block out of the rows above
+  // recurrence starts; a lane's y is final when its own step comes: x = y / L_jj afterwards), everybody takes the block out of the rows above.  The factorisation failed
+  // (g2o: "Cholesky failure") when an entry of L's diagonal is not a positive finite number.
   for (int ob = npad - 16; ob >= 0; ob -= 16) {
     if (wv == 0) {
       const int l15 = lane & 15;
-      double yv = A[SN * SLD + ob + l15], xv = 0.0;
-      const double dv = dinv[ob + l15];
+      double yv = A[SN * SLD + ob + l15];
+      const double ljj = A[(ob + l15) * SLD + ob + l15];
       double Lc[16];
 #pragma unroll
       for (int j = 0; j < 16; ++j) Lc[j] = A[(ob + j) * SLD + ob + l15];
+      const double dv = 1.0 / ljj;
+      if (__ballot(!(ljj > 0.0 && ljj < __builtin_inf())) != 0ull && lane == 0) s_bad = 1;
 #pragma unroll
-      for (int j = 15; j >= 0; --j) {
+      for (int j = 15; j >= 1; --j) {
         const double xj = bcast(yv * dv, j);
-        if (lane == j) xv = xj;
         yv = lane < j ? __builtin_fma(-Lc[j], xj, yv) : yv;
       }
-      if (lane < 16) xs[ob + lane] = xv;
+      if (lane < 16) xs[ob + lane] = yv * dv;
     }
     __syncthreads();
     if (tid < ob) {
@@ -879,8 +953,12 @@ __global__ __launch_bounds__(256) void k_dense_small(BADev d, double* __restrict
     }
     __syncthreads();
   }
+  DP_TICK(6);
   if (tid < n) d.xp[tid] = xs[tid];
   if (tid == 0 && s_bad) atomicOr(d.flags, 1);
+#ifdef DENSE_PROF
+  if (tid == 0) for (int i = 0; i < 8; ++i) g_dense_prof[63][i] = pr.t[i];
+#endif
 }
 
 void launch_dense_small(const BADev& d, double* S, int64_t ld, double lambda, hipStream_t s) {
