@@ -1847,7 +1847,11 @@ void launch_dense_assemble(const BADev& d, double* S, int64_t ld, double lambda,
   // its points on 6 threads per chain) are independent of each other: they go in runs of `chunk` to the workgroups (tile, 0 .. max_slots / chunk) -
   // most tiles of the bench graph carry a dozen slots, the ones with the long dynamic tracks 81: one workgroup per tile left the device waiting
   // for those (1.82 ms).  VDO_BA_DENSE_CHUNK overrides.
-  const int chunk = std::getenv("VDO_BA_DENSE_CHUNK") ? std::max(1, std::atoi(std::getenv("VDO_BA_DENSE_CHUNK"))) : VDO_BA_DENSE_CHUNK_DEFAULT;
+  // (round 6) a graph of a few tiles - a 20-frame window: ~30 tiles x 20 slots - leaves most of the device idle at 4 slots per workgroup: one slot per workgroup there
+  // (k_schur_dense_tile 34 -> 13 us per Levenberg trial, profiles/r06_window_lm_trial_timeline.txt), two up to 8 k (tile, slot) pairs
+  const int64_t pairs = (int64_t)d.n_tiles * d.max_slots;
+  const int chunk_auto = pairs <= 2048 ? 1 : pairs <= 8192 ? 2 : VDO_BA_DENSE_CHUNK_DEFAULT;
+  const int chunk = std::getenv("VDO_BA_DENSE_CHUNK") ? std::max(1, std::atoi(std::getenv("VDO_BA_DENSE_CHUNK"))) : chunk_auto;
   if (d.n_tiles) hipLaunchKernelGGL(k_schur_dense_tile, dim3(d.n_tiles, (d.max_slots + chunk - 1) / chunk), dim3(VDO_TILE_THREADS), raise_lds(k_schur_dense_tile, dense_tile_lds(d)), s, d, S, ld, chunk);
   if (d.sharded) R(S, ld * ld);                     // landmark-side contributions of every rank (all-reduce of S)
   if (!init) return;                                // (k_dense_small adds the pose side itself)
