@@ -190,7 +190,7 @@ void launch_hub_sweep(const BADev& d, int which, bool build, hipStream_t s);
 void launch_hub_precond(const BADev& d, hipStream_t s);
 void launch_hub_schur(const BADev& d, int mode, const double* v, const double* v2, hipStream_t s);
 void launch_hub_expand_binc(const BADev& d, double* binc18, hipStream_t s);      // [n_hub_edges][18] explicit 6x3 blocks (vdo_ba_download_system)
-void launch_publish_scalars(const BADev& d, double* h_block_dev, hipStream_t s);      // ba_solve.hip
+void launch_publish_scalars(const BADev& d, double* h_block_dev, hipStream_t s, uint32_t ticket = 0);      // ba_solve.hip (ticket != 0: written behind the data, system-scope fence in between)
 void launch_dense_solve(const BADev& d, double* S, int64_t ld, double* Winv, double* rhs, hipStream_t s);    // MFMA Cholesky + substitutions -> xp
 
 size_t dense_tile_lds(const BADev& d);      // dynamic LDS of k_schur_dense_tile (ba_solve.hip)

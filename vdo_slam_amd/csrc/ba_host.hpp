@@ -14,6 +14,7 @@ struct vdo_ba {
   vdo::Reducer red;               // cross-rank sum/max hook (vdo_ba_set_allreduce); unset = single GPU
   int oplus_calls = 0;            // VertexSE3::_numOplusCalls (same value on every vertex)
   double* h_scal = nullptr;       // pinned, device-mapped: [S_COUNT doubles][4 int32 flags] in ONE block; a one-workgroup kernel publishes the device scalars and
+  uint32_t ticket = 0;            // read-backs so far: k_publish_scalars writes it behind the scalars (word 4 of the flags' row) and fetch() polls it instead of waiting for the stream
   int32_t* h_flags = nullptr;     // flags into it (ba_lm.hip fetch: two D2H copies of 13 us each on the stream before round 6); h_flags points behind the scalars
   double* d_hscal = nullptr;      // the device-side address of that block
   hipEvent_t ev0 = nullptr, ev1 = nullptr;

@@ -6,6 +6,7 @@
 // All heavy work is HIP kernels (ba_sweep.hip, ba_solve.hip); the host only sequences
 // launches and reads back a handful of scalars per Levenberg trial.
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -28,9 +29,27 @@ namespace {
 
 // read back device scalars + flags (one sync): a one-wave kernel writes them into the mapped pinned block - the two D2H copies this replaces were 13 us
 // of blit kernel each, 2-3 times per LM iteration (profiles/r05_ba_large_kernel_stats.txt: __amd_rocclr_copyBuffer 6 % of the stream)
+// (round 6) the kernel's last act is a ticket in the same pinned block and the host POLLS it: hipStreamSynchronize returns ~5 us after the kernel's end (completion signal,
+// barrier packet; tools/sync_latency_probe.hip: launch -> host knows 11.7 us, 7.0 with the ticket) - once per Levenberg trial.  The data is fenced system-wide before the ticket;
+// a ticket that does not come within 50 ms (a faulted kernel never writes it; a trial of the largest graphs takes ~1 ms) falls back to the stream wait, which reports the error.
 int fetch(vdo_ba* ba) {
-  launch_publish_scalars(ba->d, ba->d_hscal, ba->ctx->stream);
-  return sync_check(ba, "LM scalar readback");
+  static const bool no_poll = std::getenv("VDO_BA_NO_TICKET") != nullptr;
+  if (no_poll || ba->d.sharded) {                        // (sharded: the exchanges of the all-reduce hook may run on the host's side of the stream)
+    launch_publish_scalars(ba->d, ba->d_hscal, ba->ctx->stream);
+    return sync_check(ba, "LM scalar readback");
+  }
+  const uint32_t want = ++ba->ticket ? ba->ticket : ++ba->ticket;      // (never 0)
+  launch_publish_scalars(ba->d, ba->d_hscal, ba->ctx->stream, want);
+  volatile uint32_t* word = reinterpret_cast<volatile uint32_t*>(ba->h_flags) + 4;
+  const double t0 = now_ms();
+  for (uint32_t spins = 0; *word != want; ++spins) {
+    if ((spins & 1023u) == 1023u && now_ms() - t0 > 50.0) return sync_check(ba, "LM scalar readback");
+    __builtin_ia32_pause();
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_error(VDO_ERR_NO_DEVICE, "LM scalar readback: %s", hipGetErrorString(e));
+  return VDO_OK;
 }
 
 // the second set of linearisation outputs (ba_dev.hpp lin_swap), allocated on the first single-GPU optimisation of the handle; false: no memory for it (the caller keeps the

@@ -1970,14 +1970,18 @@ void launch_schur_matvec_only(const BADev& d, hipStream_t s) {
 }
 
 // the LM scalars and flags -> the handle's mapped pinned block [S_COUNT doubles][4 int32] (visible to the host once the stream has been waited for)
-__global__ __launch_bounds__(64) void k_publish_scalars(const double* __restrict__ scal, const int32_t* __restrict__ flags, double* __restrict__ h_block) {
+__global__ __launch_bounds__(64) void k_publish_scalars(const double* __restrict__ scal, const int32_t* __restrict__ flags, double* __restrict__ h_block, uint32_t ticket) {
   const int t = threadIdx.x;
   if (t < S_COUNT) h_block[t] = scal[t];
   if (t < 4) ((int32_t*)(h_block + S_COUNT))[t] = flags[t];
+  if (ticket) {                                          // the host polls this word (ba_lm.hip fetch): the data above is visible system-wide before it
+    __threadfence_system();
+    if (t == 0) ((volatile uint32_t*)(h_block + S_COUNT))[4] = ticket;
+  }
 }
-void launch_publish_scalars(const BADev& d, double* h_block_dev, hipStream_t s) {
+void launch_publish_scalars(const BADev& d, double* h_block_dev, hipStream_t s, uint32_t ticket) {
   static_assert(S_COUNT <= 64, "one wave publishes the scalars");
-  hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, s, (const double*)d.scal, (const int32_t*)d.flags, h_block_dev);
+  hipLaunchKernelGGL(k_publish_scalars, dim3(1), dim3(64), 0, s, (const double*)d.scal, (const int32_t*)d.flags, h_block_dev, ticket);
 }
 
 void launch_backsub_update(const BADev& d, double lambda, bool ortho, hipStream_t s) {

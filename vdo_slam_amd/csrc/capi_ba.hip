@@ -739,7 +739,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     ba->ev0 = ctx->ba_ev[0]; ba->ev1 = ctx->ba_ev[1]; ba->ev_fork = ctx->ba_ev[2]; ba->ev_join = ctx->ba_ev[3]; ba->side = ctx->ba_side;
   } else {
     void* dp = nullptr;
-    if (hipHostMalloc((void**)&ba->h_scal, S_COUNT * sizeof(double) + 4 * sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
+    if (hipHostMalloc((void**)&ba->h_scal, S_COUNT * sizeof(double) + 8 * sizeof(int32_t), hipHostMallocMapped) != hipSuccess ||
         hipHostGetDevicePointer(&dp, ba->h_scal, 0) != hipSuccess || !dp) {
       vdo_ba_destroy(ba);
       return set_error(VDO_ERR_OOM, "hipHostMalloc failed");
@@ -754,7 +754,8 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
       ctx->ba_ev[0] = ba->ev0; ctx->ba_ev[1] = ba->ev1; ctx->ba_ev[2] = ba->ev_fork; ctx->ba_ev[3] = ba->ev_join; ctx->ba_side = ba->side;
     }
   }
-  std::memset(ba->h_scal, 0, S_COUNT * sizeof(double) + 4 * sizeof(int32_t));
+  std::memset(ba->h_scal, 0, S_COUNT * sizeof(double) + 8 * sizeof(int32_t));      // (scalars, flags, the read-back ticket: ba_lm.hip fetch)
+  ba->ticket = 0;
   ba->h_flags = (int32_t*)(ba->h_scal + S_COUNT);
   if (hipStreamSynchronize(s) != hipSuccess) { vdo_ba_destroy(ba); return set_error(VDO_ERR_NO_DEVICE, "upload failed: %s", hipGetErrorString(hipGetLastError())); }
   if (std::getenv("VDO_BATCH_TRACE"))
