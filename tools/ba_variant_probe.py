@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vdo_slam_amd import synth
 from vdo_slam_amd.ba import BatchBA, Context
 ctx = Context(0)
-shapes = {"bench": (60, 30000, 10, 400), "config3": (60, 12000, 10, 200), "large": (240, 960000, 10, 500), "roof": (200, 2200000, 10, 1500)}
+shapes = {"bench": (60, 30000, 10, 400), "config3": (60, 12000, 10, 200), "large": (240, 960000, 10, 500), "roof": (200, 2200000, 10, 1500), "omd": (300, 150000, 4, 40000)}
 for name in (sys.argv[1:] or ["bench", "large", "roof"]):
     g = synth.make_ba_graph(*shapes[name], seed=7)
     ba = BatchBA(ctx, g)

@@ -44,6 +44,15 @@ __device__ __forceinline__ bool spd3_inv(const double* a, double* o) {
 // Per landmark chain: block LDL^T (Delta_k = D_k + lambda I - O^T Delta_{k-1}^-1 O) and the
 // diagonal / first off-diagonal blocks of Hll^-1 needed by the exact block-Jacobi preconditioner:
 //   G_kk = Delta_k^-1 + Gl_{k+1} G_{k+1,k+1} Gl_{k+1}^T ,  G_{k,k+1} = -Gl_{k+1} G_{k+1,k+1}
+// steps of the forward / backward walk whose inputs are requested together.  Round 6 (profiles/r06_landmark_chain_walk_ab.txt): 8 / 2 instead of 4 / 2 - ms per LM iteration
+// 1.27 -> 1.24 on the OMD-shaped graph, 0.79 -> 0.775 on the 1 M-point one; 8 / 4, 6 / 3, 12 / 4 no better.  Dealing the tracks to more, smaller workgroups (the 11 k tracks of the
+// OMD-shaped graph fill only 86 workgroups of 128) makes it SLOWER (16 per workgroup: equal; 8: +11 %; 1: +85 %): the walk is bound by its instruction stream, not by the CUs' address paths.
+#ifndef VDO_FC
+#define VDO_FC 8
+#endif
+#ifndef VDO_BC
+#define VDO_BC 2
+#endif
 __global__ __launch_bounds__(128) void k_factor_chains(BADev d, double lambda) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= d.n_chains) return;
@@ -60,7 +69,7 @@ __global__ __launch_bounds__(128) void k_factor_chains(BADev d, double lambda) {
   // arithmetic against ~2 500 of memory latency: with the next step's inputs requested one step ahead (rounds 2-4) the walk ran at one memory latency per step.
   // Round 5: chunks of FC steps - the next chunk's Hll and O blocks and the edge indices of the chunk after it are requested while this chunk computes (unconditional
   // loads from clamped positions: a load under a branch is waited for at its end).
-  constexpr int FC = 4;
+  constexpr int FC = VDO_FC;
   auto cl_h = [&](int64_t l) -> int64_t { return l < p1 ? l : p1 - 1; };
   auto cl_e = [&](int64_t l) -> int64_t { return l < p1 ? (l > p0 ? l : p0 + 1) : p1 - 1; };      // (p1 - p0 >= 2 here: positions p0 + 1 .. p1 - 1 have a previous edge)
   double hl[FC], O[FC][9];
@@ -119,7 +128,7 @@ __global__ __launch_bounds__(128) void k_factor_chains(BADev d, double lambda) {
   double Gn[9];
 #pragma unroll
   for (int i = 0; i < 9; ++i) { Gn[i] = prev[i]; d.Gdiag[9 * (p1 - 1) + i] = prev[i]; }
-  constexpr int BC = 2;
+  constexpr int BC = VDO_BC;
   auto cl_b = [&](int64_t l) -> int64_t { return l > p0 ? l : p0; };
   double Gx[BC][9], Dx[BC][9];                          // step l = lb - j reads Gl[l + 1], Dinv[l]
 #pragma unroll
