@@ -150,6 +150,23 @@ void label_tracks(const TrackList& T, const FeatureBlock& F, std::vector<int32_t
   }
 }
 
+// The same for a WINDOW of frames [first, ...): only their features are labelled, at index g - F.off[first]; a track whose last observation (a track's frames ascend)
+// lies before the window is skipped whole.  What PartialBatchOptimization pays per window then follows the window, not the length of the sequence so far
+// (label_tracks + the marker array over ALL features: 0.2 ms at frame 20, 0.6 ms at frame 148 of the bench sequence, ~3 ms at KITTI-0020's 837).
+void label_tracks_window(const TrackList& T, const FeatureBlock& F, int first, std::vector<int32_t>& lab, std::vector<int32_t>& pos) {
+  const int64_t base = F.off[first];
+  lab.assign((size_t)(F.off.back() - base), -1); pos.assign((size_t)(F.off.back() - base), -1);
+  for (int t = 0; t < T.size(); ++t) {
+    if (T.off[t + 1] - T.off[t] < 3) continue;
+    if (T.frame[T.off[t + 1] - 1] < first) continue;
+    for (int q = T.off[t]; q < T.off[t + 1]; ++q) {
+      if (T.frame[q] < first) continue;
+      const int64_t g = F.off[T.frame[q]] + T.feat[q] - base;
+      lab[(size_t)g] = t; pos[(size_t)g] = q - T.off[t];
+    }
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------------------- per frame
@@ -385,12 +402,13 @@ void Optimizer::PartialBatchOptimization(GraphStore& S, const TrackList& StaTrac
   const int N = S.frames();
   if (N < WINDOW_SIZE || WINDOW_SIZE <= 0) return;
   const auto t_begin = std::chrono::steady_clock::now();
+  const int Start = N - WINDOW_SIZE;
+  const int64_t base = S.sta.off[Start];                         // labels / markers of the window's features only (index g - base)
   std::vector<int32_t> labS, posS;
-  label_tracks(StaTracks, S.sta, labS, posS);
+  label_tracks_window(StaTracks, S.sta, Start, labS, posS);
   std::vector<int32_t> mkS(labS.size(), -1);
   const float sigma2_cam = 0.0001f, sigma2_3d_sta = 16;          // :190-195 (STATIC_ONLY = true, :211)
   const float deltaHuber = 0.0001f;
-  const int Start = N - WINDOW_SIZE;
   std::vector<int> camID(N, -1);
   GraphBuilder G;
   int PreFrame = -1;
@@ -400,18 +418,18 @@ void Optimizer::PartialBatchOptimization(GraphStore& S, const TrackList& StaTrac
     camID[i] = cam;
     if (i != Start) G.add_ep(PreFrame, cam, &S.rm[16 * (size_t)S.rm_off[i - 1]], 1.0 / sigma2_cam);
     for (int64_t g = S.sta.off[i]; g < S.sta.off[i + 1]; ++g) {
-      if (labS[(size_t)g] == -1) continue;
-      const int tr = labS[(size_t)g], ps = posS[(size_t)g];
+      if (labS[(size_t)(g - base)] == -1) continue;
+      const int tr = labS[(size_t)(g - base)], ps = posS[(size_t)(g - base)];
       int pt;
       if (ps == 0) pt = G.add_point(&S.sta.xyz[3 * (size_t)g]);
       else {
         const int q = StaTracks.off[tr] + ps - 1;
         const int pf = StaTracks.frame[q];
-        pt = pf >= Start ? mkS[(size_t)(S.sta.off[pf] + StaTracks.feat[q])] : -1;   // tracks that started before the window are skipped (:341-344)
+        pt = pf >= Start ? mkS[(size_t)(S.sta.off[pf] + StaTracks.feat[q] - base)] : -1;   // tracks that started before the window are skipped (:341-344)
       }
       if (pt < 0) continue;
       G.add_eb(cam, pt, S.sta.u[(size_t)g], S.sta.v[(size_t)g], S.sta.d[(size_t)g], K4, 1.0 / sigma2_3d_sta);
-      mkS[(size_t)g] = pt;
+      mkS[(size_t)(g - base)] = pt;
     }
     PreFrame = cam;
   }
@@ -429,7 +447,7 @@ void Optimizer::PartialBatchOptimization(GraphStore& S, const TrackList& StaTrac
       std::memcpy(&S.rm[16 * (size_t)S.rm_off[i - 1]], M.data, 64);
     }
   }
-  for (size_t g = 0; g < mkS.size(); ++g) if (mkS[g] != -1) for (int k = 0; k < 3; ++k) S.sta.xyz[3 * g + k] = (float)point[3 * (size_t)mkS[g] + k];
+  for (size_t g = 0; g < mkS.size(); ++g) if (mkS[g] != -1) for (int k = 0; k < 3; ++k) S.sta.xyz[3 * (g + (size_t)base) + k] = (float)point[3 * (size_t)mkS[g] + k];
 }
 
 // ---- the reference's signatures: the Map is read into a store, optimised, and receives the results (same builder)
