@@ -21,7 +21,9 @@ os.environ.setdefault("VDO_ORB_THREADS", "5")
 import gc
 gc.collect(); gc.freeze(); gc.disable()
 for defer in (1, 0, 1, 0):
-    ctxs = [Context(0) for _ in range(5)]
+    ctxs = [Context(0) for _ in range(4)]
+    # VDO_ORB_ON_LM_STREAM=1: the ORB context on the camera LM's STREAM (two contexts, one stream): the two alternate in time anyway, and four streams get a hardware queue each
+    ctxs.append(Context(0, stream=ctxs[1].stream_ptr) if os.environ.get("VDO_ORB_ON_LM_STREAM") else Context(0))
     pipe = FramePipeline(ctxs[0], ctxs[1], kitti_params(W, H, synth.KITTI_K, SF.BF, SF.DEPTH_MAP_FACTOR, SF.TH_DEPTH_BG, SF.TH_DEPTH_OBJ, build_lm=1, defer_objects=defer), ctxs[2], ctxs[3], ctxs[4])
     pipe.keep_graph()
     for i in range(warm):
