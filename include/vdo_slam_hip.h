@@ -118,7 +118,7 @@ typedef struct vdo_lm_options {
                                *    units (6 n_pose <= 8192) - what g2o's LinearSolverDense / CSparse do on the reduced system;
                                * 0: auto = 3 when the EdgeSE3 graph is not a set of simple paths (loop closures, branches) or a
                                *    PCG solve needed more than 60 iterations, else 2                                      */
-  double pcg_tolerance;       /* relative residual ||r||_M / ||b||_M; <=0 -> 1e-10          */
+  double pcg_tolerance;       /* relative residual ||r||_M / ||b||_M; <=0 -> 1e-8 (1e-10 until round 6; g2o's own PCG: 1e-6) */
   int32_t pcg_max_iterations; /* <=0 -> 24 n_pose + 200, capped at 20000                   */
 } vdo_lm_options;
 

@@ -18,5 +18,5 @@ for name in (sys.argv[1:] or ["bench", "large", "roof"]):
         ctx.synchronize(); t = time.perf_counter()
         st = ba.optimize(max_iterations=5)
         ctx.synchronize(); ts.append((time.perf_counter() - t) * 1e3 / max(1, st.iterations))
-    print(name, "edges", g.n_eb, "tiles", dims["tiles"], "max_slots", dims["max_slots"], "sweep %.4f lin %.4f" % (sw, lin), "ms/LM it %.3f" % min(ts), "its", st.iterations)
+    print(name, "edges", g.n_eb, "tiles", dims["tiles"], "max_slots", dims["max_slots"], "sweep %.4f lin %.4f" % (sw, lin), "ms/LM it %.3f" % min(ts), "its", st.iterations, "trials", st.total_trials, "chi2 %.12g" % st.final_chi2)
     ba.close()
