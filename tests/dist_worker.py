@@ -82,6 +82,7 @@ def gpu_lm(rank, world, out_path, backend):
     if world > 2:
         cases = cases[1:]                                  # (many ranks on one GPU: one graph with enough tracks for every rank)
     else:
+        cases = cases + (dict(n_frames=16, n_static=1200, n_objects=0, dyn_tracks_per_object=0, seed=8),)      # round 6: 96 unknowns - the reduced matrix is all-reduced and solved by ONE workgroup on every rank (k_dense_small, ba_dense.hip)
         cases = cases + (dict(n_frames=300, n_static=700, n_objects=1, dyn_tracks_per_object=30, seed=6, hubs=4),)      # round 6: 4 static points seen from all 300 cameras - hub landmarks (ba_hub.hip) on whichever rank owns them
     for transport in transports:
         for kw in cases:
