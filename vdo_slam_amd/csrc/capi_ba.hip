@@ -190,8 +190,10 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   const int place_mode = std::getenv("VDO_BA_PLACE") ? std::atoi(std::getenv("VDO_BA_PLACE")) : ((int64_t)Eb + 2 * (int64_t)Et >= kPlaceMinInc ? 1 : 0);
   long long place_ways = 0, place_groups = 0;
   bool dense_tiles_ok = true;
+  double t_close_ms = 0.0;
   auto close_tile = [&]() {
     if (cur_npts == 0) return;
+    const auto t_close0 = std::chrono::steady_clock::now();
     // slots: sorted distinct poses
     std::sort(cur_poses.begin(), cur_poses.end());
     cur.slot_begin = (int32_t)tile_pose.size();
@@ -343,6 +345,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
     ++cur_tile_id;
     cur_npts = 0; cur_ninc = 0; cur_nb = 0; cur_need = 0;
     cur_poses.clear(); tile_eb.clear(); tile_et.clear();
+    if (trace_create) t_close_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_close0).count();
   };
   // Incidences a tile is CLOSED at (soft; a single track may still take up to VDO_TILE_INC): VDO_TILE_EPT per thread spreads what a tile costs
   // apart from its edges over more edges - right for graphs of many tiles; a small graph (the 60-frame window: 0.25 M incidences) would be left
@@ -778,7 +781,7 @@ extern "C" int vdo_ba_create(vdo_ctx* ctx, const vdo_ba_graph* g, vdo_ba** out) 
   ba->h_flags = (int32_t*)(ba->h_scal + S_COUNT);
   if (hipStreamSynchronize(s) != hipSuccess) { vdo_ba_destroy(ba); return set_error(VDO_ERR_NO_DEVICE, "upload failed: %s", hipGetErrorString(hipGetLastError())); }
   if (std::getenv("VDO_BATCH_TRACE"))
-    std::fprintf(stderr, "[vdo_ba_create] validated %.2f, chains %.2f, tiles %.2f, hubs %.2f, permuted data %.2f ms (cumulative); tiles built in %.2f ms, uploaded in %.2f ms (%s)\n", t_mark[0], t_mark[1], t_mark[2], t_mark[3], t_mark[4], std::chrono::duration<double, std::milli>(t_built - t_create0).count(),
+    std::fprintf(stderr, "[vdo_ba_create] validated %.2f, chains %.2f, tiles %.2f (of which closing tiles %.2f), hubs %.2f, permuted data %.2f ms (cumulative); tiles built in %.2f ms, uploaded in %.2f ms (%s)\n", t_mark[0], t_mark[1], t_mark[2], t_close_ms, t_mark[3], t_mark[4], std::chrono::duration<double, std::milli>(t_built - t_create0).count(),
                  std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_built).count(), ba->pooled ? "pooled" : "own allocations");
   *out = ba;
   return VDO_OK;
