@@ -535,6 +535,9 @@ int vdo_tracks_destroy(vdo_tracks* t);
 int vdo_tracks_add_frame(vdo_tracks* t, int n, const int32_t* asso /* index in the previous frame or -1 */, const int32_t* feat_label);
 int vdo_tracks_size(vdo_tracks* t, int* n_tracks, int64_t* n_pairs);
 int vdo_tracks_get(vdo_tracks* t, int32_t* track_off, int32_t* pair_frame, int32_t* pair_feat, int32_t* obj_id);
+/* Only the tracks still observed in frame >= first_frame, whole and in creation order (buffers sized as for vdo_tracks_get; *n_tracks / *n_pairs = what was written):
+ * what the windowed optimisation reads (Optimizer::PartialBatchOptimization, reference src/Optimizer.cc:42-1230, walks mpMap->TrackletSta of the window's frames). */
+int vdo_tracks_get_since(vdo_tracks* t, int first_frame, int* n_tracks, int64_t* n_pairs, int32_t* track_off, int32_t* pair_frame, int32_t* pair_feat, int32_t* obj_id);
 
 #ifdef __cplusplus
 }

@@ -830,6 +830,24 @@ extern "C" int vdo_tracks_size(vdo_tracks* t, int* n_tracks, int64_t* n_pairs) {
   return VDO_OK;
 }
 
+// The tracks that are still observed in frame `first_frame` or later, whole (every pair since their start) and in creation order: what a WINDOW of the sequence needs
+// (PartialBatchOptimization: labels of the window's features, position inside the track, the observation before) without walking the chains of all the tracks that ended
+// before it - the cost follows the window, not the length of the sequence.  Buffers sized as for vdo_tracks_get; the counts actually written come back.
+extern "C" int vdo_tracks_get_since(vdo_tracks* t, int first_frame, int* n_tracks, int64_t* n_pairs, int32_t* track_off, int32_t* pair_frame, int32_t* pair_feat, int32_t* obj_id) {
+  if (!t || !n_tracks || !n_pairs || !track_off || !pair_frame || !pair_feat) return set_error(VDO_ERR_INVALID, "null argument");
+  int off = 0, nt = 0;
+  track_off[0] = 0;
+  for (size_t k = 0; k < t->trk.size(); ++k) {
+    const vdo_tracks::Track& tk = t->trk[k];
+    if (tk.last < 0 || t->pool[tk.last].frame < first_frame) continue;
+    for (int q = tk.first; q >= 0; q = t->pool[q].next) { pair_frame[off] = t->pool[q].frame; pair_feat[off] = t->pool[q].feat; ++off; }
+    if (obj_id && t->with_label) obj_id[nt] = t->obj_id[k];
+    track_off[++nt] = off;
+  }
+  *n_tracks = nt; *n_pairs = off;
+  return VDO_OK;
+}
+
 extern "C" int vdo_tracks_get(vdo_tracks* t, int32_t* track_off, int32_t* pair_frame, int32_t* pair_feat, int32_t* obj_id) {
   if (!t || !track_off || !pair_frame || !pair_feat) return set_error(VDO_ERR_INVALID, "null argument");
   int off = 0;

@@ -802,7 +802,10 @@ int FramePipeline::FinishObjectsTail(FrameCounts* fcp) {
     // ---- partial batch optimisation on the last window (local optimisation)      Tracking.cc:1165-1183
     const int Wn = p_.window_size, Ov = p_.overlap_size;
     if (Wn > 0 && Wn > Ov && (f_id_obj_ - Ov + 1) % (Wn - Ov) == 0 && f_id_obj_ >= Wn - 1 && store_.sta.frames() == f_id_obj_ + 1) {
-      if (GetTracks(&tl_sta_, nullptr) != 0) return -1;
+      const auto t_gt0 = std::chrono::steady_clock::now();
+      if (GetTracks(&tl_sta_, nullptr, f_id_obj_ + 1 - Wn) != 0) return -1;      // (the window's first frame: PartialBatchOptimization reads nothing of a track that ended before it)
+      static const bool trace_batch = std::getenv("VDO_BATCH_TRACE") != nullptr;
+      if (trace_batch) std::fprintf(stderr, "[partial batch] static tracklets flattened in %.2f ms (%zu tracks, %zu entries)\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_gt0).count(), tl_sta_.off.size() - 1, tl_sta_.frame.size());
       try { Optimizer::PartialBatchOptimization(store_, tl_sta_, p_.K4, Wn); }
       catch (const std::exception& e) { std::fprintf(stderr, "FramePipeline: %s\n", e.what()); return -1; }
       ++n_partial_batches_;
@@ -854,7 +857,7 @@ int FramePipeline::FullBatchOptimization() {
 }
 
 // the tracklets kept incrementally (vdo_tracks_*) as flat lists
-int FramePipeline::GetTracks(TrackList* sta, TrackList* dyn) {
+int FramePipeline::GetTracks(TrackList* sta, TrackList* dyn, int first_frame) {
   for (int which = 0; which < 2; ++which) {
     TrackList* L = which ? dyn : sta;
     if (!L) continue;
@@ -862,7 +865,12 @@ int FramePipeline::GetTracks(TrackList* sta, TrackList* dyn) {
     int nt = 0; int64_t np = 0;
     VDO_TRY(vdo_tracks_size(t, &nt, &np));
     L->off.assign((size_t)nt + 1, 0); L->frame.resize((size_t)std::max<int64_t>(np, 1)); L->feat.resize((size_t)std::max<int64_t>(np, 1)); L->obj.assign((size_t)std::max(nt, 1), 0);
-    VDO_TRY(vdo_tracks_get(t, L->off.data(), L->frame.data(), L->feat.data(), which ? L->obj.data() : nullptr));
+    if (first_frame >= 0) {
+      int64_t np2 = 0;
+      VDO_TRY(vdo_tracks_get_since(t, first_frame, &nt, &np2, L->off.data(), L->frame.data(), L->feat.data(), which ? L->obj.data() : nullptr));
+      np = np2;
+      L->off.resize((size_t)nt + 1);
+    } else VDO_TRY(vdo_tracks_get(t, L->off.data(), L->frame.data(), L->feat.data(), which ? L->obj.data() : nullptr));
     L->frame.resize((size_t)np); L->feat.resize((size_t)np); L->obj.resize((size_t)nt);
   }
   return 0;

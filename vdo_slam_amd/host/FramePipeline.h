@@ -99,7 +99,7 @@ class FramePipeline {
   // Ends a pending object stage (deferred mode); fc (optional) receives its n_object_tracked / n_dynamic_tracks.
   int Flush(FrameCounts* fc = nullptr) { return FinishObjects(fc); }
   // the tracklets kept incrementally (GetStaticTrack / GetDynamicTrackNew) as flat lists; either pointer may be NULL
-  int GetTracks(TrackList* sta, TrackList* dyn);
+  int GetTracks(TrackList* sta, TrackList* dyn, int first_frame = -1);      // first_frame >= 0: only the tracks still observed in that frame or later (vdo_tracks_get_since)
   bool ok() const { return ok_; }
   // deferred object stage on / off between frames (a pending stage is consumed by the next Step or by Flush either way)
   void SetDeferObjects(bool on) { p_.defer_objects = on ? 1 : 0; }
